@@ -1,0 +1,186 @@
+"""Seeded synthetic workloads for the solve + Kalman-logp hot path (host side, numpy).
+
+These generate the *inputs* of the path (Jacobian blocks A,B,C,D per parameter draw,
+shock/measurement covariances, design matrix and one shared data panel); they contain
+no solver.  Shapes and recipes are the ones fixed in SURVEY.md §8(d):
+
+* ``rbc_linearized_jacobians``: closed-form A,B,C,D of the reference's
+  ``tests/_resources/test_gcns/rbc_linearized.gcn`` (8 linear equations :22-49, steady
+  state :6-20, calibration :56-65), variable order ``[A, C, I, K, L, R, W, Y]``.
+* ``sw_shaped_system`` / ``sw_shaped_batch``: Smets-Wouters-*shaped* systems
+  (n=40, 18 states, 12 forward-looking variables, 7 shocks, 7 observables).  The reference
+  ships no Smets-Wouters model; the generator builds systems whose
+  unique stable solution ``T*`` is known by construction.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RBC_VARIABLES = ("A", "C", "I", "K", "L", "R", "W", "Y")
+RBC_CALIBRATION = dict(sigma=2.0, phi=1.5, alpha=0.35, beta=0.985, delta=0.025, rho_A=0.95, sigma_A=0.01)
+
+SW_SHAPE = dict(n=40, n_state=18, n_lead=12, k=7, p=7, T_len=200)
+SW_SEED0 = 20260630
+
+
+def rbc_steady_state(sigma, phi, alpha, beta, delta):
+    """rbc_linearized.gcn:6-20."""
+    R = 1.0 / beta - (1.0 - delta)
+    W = (1 - alpha) ** (1 / (1 - alpha)) * (alpha / R) ** (alpha / (1 - alpha))
+    Y = (R / (R - delta * alpha)) ** (sigma / (sigma + phi)) * ((1 - alpha) ** (-phi) * W ** (1 + phi)) ** (
+        1 / (sigma + phi)
+    )
+    K = alpha * Y / R
+    I = delta * K  # noqa: E741
+    C = Y - I
+    L = (1 - alpha) * Y / W
+    return dict(A=1.0, R=R, W=W, Y=Y, K=K, I=I, C=C, L=L)
+
+
+def rbc_linearized_jacobians(sigma, phi, alpha, beta, delta, rho_A, sigma_A=None):
+    """A = dF/dy_{t-1}, B = dF/dy_t, C = dF/dy_{t+1}, D = dF/de for F = LHS - RHS of
+    rbc_linearized.gcn:22-49.  Arguments may be scalars or equal-length 1-D arrays (a
+    batch of draws); returns arrays with a leading batch axis in the latter case."""
+    del sigma_A
+    th = np.broadcast_arrays(*(np.asarray(x, dtype=np.float64) for x in (sigma, phi, alpha, beta, delta, rho_A)))
+    scalar = th[0].ndim == 0
+    sigma, phi, alpha, beta, delta, rho_A = (np.atleast_1d(x) for x in th)
+    nb = sigma.shape[0]
+    ss = rbc_steady_state(sigma, phi, alpha, beta, delta)
+    iA, iC, iI, iK, iL, iR, iW, iY = range(8)
+    A = np.zeros((nb, 8, 8))
+    B = np.zeros((nb, 8, 8))
+    C = np.zeros((nb, 8, 8))
+    D = np.zeros((nb, 8, 1))
+    # 1. W = sigma C + phi L
+    B[:, 0, iW] = 1.0
+    B[:, 0, iC] = -sigma
+    B[:, 0, iL] = -phi
+    # 2. sigma/beta (C[1] - C) = R_ss R[1]
+    C[:, 1, iC] = sigma / beta
+    B[:, 1, iC] = -sigma / beta
+    C[:, 1, iR] = -ss["R"]
+    # 3. K = (1-delta) K[-1] + delta I
+    B[:, 2, iK] = 1.0
+    A[:, 2, iK] = -(1.0 - delta)
+    B[:, 2, iI] = -delta
+    # 4. Y = A + alpha K[-1] + (1-alpha) L
+    B[:, 3, iY] = 1.0
+    B[:, 3, iA] = -1.0
+    A[:, 3, iK] = -alpha
+    B[:, 3, iL] = -(1.0 - alpha)
+    # 5. R = Y - K[-1]
+    B[:, 4, iR] = 1.0
+    B[:, 4, iY] = -1.0
+    A[:, 4, iK] = 1.0
+    # 6. W = Y - L
+    B[:, 5, iW] = 1.0
+    B[:, 5, iY] = -1.0
+    B[:, 5, iL] = 1.0
+    # 7. Y_ss Y = C_ss C + I_ss I
+    B[:, 6, iY] = ss["Y"]
+    B[:, 6, iC] = -ss["C"]
+    B[:, 6, iI] = -ss["I"]
+    # 8. A = rho_A A[-1] + eps
+    B[:, 7, iA] = 1.0
+    A[:, 7, iA] = -rho_A
+    D[:, 7, 0] = -1.0
+    if scalar:
+        return A[0], B[0], C[0], D[0]
+    return A, B, C, D
+
+
+def rbc_prior_draws(batch, seed=1):
+    """Seeded parameter draws approximating the GCN priors (rbc_linearized.gcn:56-65;
+    the ``maxent`` Gamma priors need ``preliz``, absent here, so their [lower, upper]
+    mass intervals are sampled uniformly)."""
+    rng = np.random.default_rng(seed)
+    return dict(
+        sigma=rng.uniform(1.5, 3.0, batch),
+        phi=rng.uniform(1.0, 5.0, batch),
+        alpha=rng.beta(5, 9, batch),
+        beta=np.clip(rng.beta(10, 1, batch), 0.5, 0.9995),
+        delta=np.clip(rng.beta(1, 10, batch), 1e-3, 0.5),
+        rho_A=np.clip(rng.beta(1, 5, batch), 0.0, 0.995),
+        sigma_A=rng.uniform(0.001, 0.1, batch),
+    )
+
+
+def _rescale_spectral_radius(M, target):
+    rho = np.max(np.abs(np.linalg.eigvals(M)))
+    return M * (target / rho)
+
+
+def sw_shaped_system(seed, n=40, n_state=18, n_lead=12, k=7):
+    """One SW-shaped system.  Returns A,B,C,D,T_star with
+    ``A + B T* + C T*^2 = 0`` exactly in real arithmetic, ``rho(T*) < 1`` and exactly
+    ``n_lead`` unstable pencil roots (the reciprocals of eig(G))."""
+    rng = np.random.default_rng(seed)
+    S = _rescale_spectral_radius(rng.standard_normal((n_state, n_state)), 0.95 * rng.uniform(0.5, 1.0))
+    T_star = np.zeros((n, n))
+    T_star[:n_state, :n_state] = S
+    T_star[n_state:, :n_state] = 0.3 * rng.standard_normal((n - n_state, n_state))
+    G = np.zeros((n, n))
+    G[:, n - n_lead :] = rng.standard_normal((n, n_lead))
+    G = _rescale_spectral_radius(G, rng.uniform(0.3, 0.8))
+    M = np.eye(n) + 0.2 * rng.standard_normal((n, n))
+    C = M @ G
+    B = M - C @ T_star
+    A = -M @ T_star
+    E = np.zeros((n, k))
+    E[:k, :k] = -np.eye(k)
+    D = M @ E
+    return A, B, C, D, T_star
+
+
+def sw_shaped_batch(batch, first_draw=0, seed0=SW_SEED0, **shape):
+    """``batch`` systems, draw i seeded ``default_rng(seed0 + i)`` (bit-exact draw
+    indexing: draw i is the same system on every rank/shard).  Also returns per-draw
+    shock standard deviations sigma ~ U(0.005, 0.02) (k per draw)."""
+    sh = dict(SW_SHAPE)
+    sh.update(shape)
+    n, k = sh["n"], sh["k"]
+    A = np.empty((batch, n, n))
+    B = np.empty((batch, n, n))
+    C = np.empty((batch, n, n))
+    D = np.empty((batch, n, k))
+    Tst = np.empty((batch, n, n))
+    sig = np.empty((batch, k))
+    for b in range(batch):
+        i = first_draw + b
+        A[b], B[b], C[b], D[b], Tst[b] = sw_shaped_system(seed0 + i, n, sh["n_state"], sh["n_lead"], k)
+        sig[b] = np.random.default_rng((seed0 + i, 1)).uniform(0.005, 0.02, k)
+    return dict(A=A, B=B, C=C, D=D, T_star=Tst, sigma=sig)
+
+
+def sw_shaped_observation_model(seed0=SW_SEED0, **shape):
+    """Shared pieces: Z selects variables 0..p-1, H = diag(1e-4), and one data panel
+    ``y`` (T_len x p) simulated from draw 0's solution ``x_t = T* x_{t-1} + R e_t``
+    (R = [I_k; 0] by construction) plus measurement noise."""
+    sh = dict(SW_SHAPE)
+    sh.update(shape)
+    n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
+    d0 = sw_shaped_batch(1, 0, seed0, **shape)
+    T_star = d0["T_star"][0]
+    sig = d0["sigma"][0]
+    rng = np.random.default_rng((seed0, 2))
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    Hdiag = np.full(p, 1e-4)
+    x = np.zeros(n)
+    y = np.empty((T_len, p))
+    for t in range(T_len):
+        e = rng.standard_normal(k) * sig
+        x = T_star @ x
+        x[:k] += e
+        y[t] = Z @ x + rng.standard_normal(p) * np.sqrt(Hdiag)
+    return dict(Z=Z, Hdiag=Hdiag, y=y)
+
+
+def shard_bounds(batch, world_size, rank):
+    """Contiguous draw shard of ``rank``: ``[lo, hi)`` with the ragged tail on the last
+    rank."""
+    per = batch // world_size
+    lo = rank * per
+    hi = batch if rank == world_size - 1 else lo + per
+    return lo, hi

@@ -1,0 +1,164 @@
+"""Oracle restatement of the state-space assembly + Kalman log-likelihood
+(TEST INFRASTRUCTURE ONLY).  *** PARITY UNPINNED for everything in this file. ***
+
+Reference call sites (gEconpy):
+  * ``P0 = solve_discrete_lyapunov(T_aug, R Q R', method="bilinear")`` statespace.py:814-815
+  * ``a0 = 0`` statespace.py:812;  ``Q = diag(sigma^2)`` statespace.py:240-258
+  * ``H = diag(error_sigma^2)`` statespace.py:800-810; pure-selector Z statespace.py:282-296
+  * filter: ``PyMCStateSpace.build_statespace_graph`` statespace.py:1151-1157 with
+    ``missing_fill_value`` / ``cov_jitter=JITTER_DEFAULT`` (:1143-1144), default
+    ``filter_type="standard"`` (gEconpy/model/build.py:577).
+
+The recursion itself lives in third-party ``pymc_extras>=0.12.0``
+(``pymc_extras/statespace/filters/kalman_filter.py``: ``BaseFilter.kalman_step``,
+``handle_missing_values``, ``predict``, ``StandardFilter.update``) and the Lyapunov solve
+in ``pytensor>=3.0.4``; neither is vendored under /root/reference nor installed in this
+image (pyproject.toml:43-45).  What follows restates their published algorithm:
+
+    per step:  mask rows of Z/H and entries of y that are missing (NaN or == fill value)
+               v = y - (d + Z a);  F = Z P Z' + H + jitter I
+               K = P Z' F^-1;  a+ = a + K v
+               P+ = sym((I-KZ) P (I-KZ)') + sym(K H K') + jitter I      (Joseph form)
+               ll_t = 0 if every entry is missing else -1/2 (p ln 2pi + ln det F + v' F^-1 v)
+               a = T a+ + c;  P = sym(T P+ T') + sym(R Q R')
+    with sym(X) = (X + X')/2 and jitter = 1e-8 in float64.
+
+Note that ``d`` is *not* masked and ``p`` is the full observation dimension even when
+some entries are missing (a masked entry contributes ``ln(jitter) + d_i^2/jitter``);
+both mirror upstream and are exercised by the tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+JITTER_DEFAULT = 1e-8  # pymc_extras.statespace.utils.constants.JITTER_DEFAULT, float64
+MISSING_FILL = -9999.0  # pymc_extras.statespace.utils.constants.MISSING_FILL
+_LN2PI = np.log(2.0 * np.pi)
+
+
+def solve_discrete_lyapunov(T, RQR, method="bilinear"):
+    """X = T X T' + RQR (statespace.py:814-815; ``"bilinear"`` default, ``"direct"`` if
+    ``use_direct_lyapunov``)."""
+    return sla.solve_discrete_lyapunov(T, RQR, method=method)
+
+
+def _sym_quad(A, B):
+    out = A @ B @ A.T
+    return 0.5 * (out + out.T)
+
+
+def kalman_filter_logp(
+    y,
+    T,
+    R,
+    Q,
+    Z,
+    H=None,
+    d=None,
+    c=None,
+    a0=None,
+    P0=None,
+    jitter=JITTER_DEFAULT,
+    missing_fill_value=MISSING_FILL,
+    return_per_step=False,
+):
+    """Standard Kalman filter log-likelihood, ``sum_t ll_t``.
+
+    y : (T_len, p) data (NaN or ``missing_fill_value`` marks a missing entry);
+    T : (m, m); R : (m, k); Q : (k, k); Z : (p, m); H : (p, p) or None (= 0);
+    d : (p,) or None; c : (m,) or None; a0 : (m,) or None (= 0); P0 : (m, m) or None
+    (= stationary covariance).
+    """
+    y = np.atleast_2d(np.asarray(y, dtype=np.float64))
+    m = T.shape[0]
+    p = Z.shape[0]
+    H = np.zeros((p, p)) if H is None else np.asarray(H, dtype=np.float64)
+    d = np.zeros(p) if d is None else np.asarray(d, dtype=np.float64)
+    c = np.zeros(m) if c is None else np.asarray(c, dtype=np.float64)
+    a = np.zeros(m) if a0 is None else np.asarray(a0, dtype=np.float64).copy()
+    RQR = R @ Q @ R.T
+    P = solve_discrete_lyapunov(T, RQR) if P0 is None else np.asarray(P0, dtype=np.float64).copy()
+    RQR_sym = 0.5 * (RQR + RQR.T)
+    eye_m = np.eye(m)
+    eye_p = np.eye(p)
+
+    ll = np.zeros(y.shape[0])
+    for t in range(y.shape[0]):
+        yt = y[t]
+        miss = np.isnan(yt) | (yt == missing_fill_value)
+        W = np.diag((~miss).astype(np.float64))
+        Zm = W @ Z
+        Hm = W @ H
+        ym = np.where(miss, 0.0, yt)
+
+        v = ym - (d + Zm @ a)
+        PZt = P @ Zm.T
+        F = Zm @ PZt + Hm + jitter * eye_p
+        K = np.linalg.solve(F.T, PZt.T).T
+        IKZ = eye_m - K @ Zm
+        a_f = a + K @ v
+        P_f = _sym_quad(IKZ, P) + _sym_quad(K, Hm) + jitter * eye_m
+        if miss.all():
+            ll[t] = 0.0
+        else:
+            inner = v @ np.linalg.solve(F, v)
+            ll[t] = -0.5 * (p * _LN2PI + np.log(np.linalg.det(F)) + inner)
+        a = T @ a_f + c
+        P = _sym_quad(T, P_f) + RQR_sym
+    total = float(ll.sum())
+    return (total, ll) if return_per_step else total
+
+
+def solve_kalman_logp(
+    A,
+    B,
+    C,
+    D,
+    Q,
+    Z,
+    y,
+    H=None,
+    d=None,
+    solver="cycle_reduction",
+    tol=1e-8,
+    max_iter=1000,
+    jitter=JITTER_DEFAULT,
+    missing_fill_value=MISSING_FILL,
+    inv_var_order=None,
+):
+    """One full evaluation: A,B,C,D -> T,R -> P0 -> logp (SURVEY.md §3 A hot loop).
+
+    Mirrors ``DSGEStateSpace._setup_policy_matrices`` (statespace.py:197-222) followed by
+    ``make_symbolic_graph`` (:781-820) without augmentation, then the filter.  A failed
+    solve gives ``logp = -inf`` (what the Potentials at :1206-1215 do to the model logp).
+    Returns dict(logp, T, R, resid, success, n_iter, P0).
+    """
+    from .cycle_reduction import cycle_reduction_core
+    from .gensys_qz import gensys_T_success
+    from .shared import compute_selection_matrix, policy_residual
+
+    n_iter = 0
+    if solver == "gensys":
+        Tm, ok, _eu = gensys_T_success(A, B, C, D, tol)
+    elif solver == "cycle_reduction":
+        Tm, ok, n_iter = cycle_reduction_core(A, B, C, max_iter, tol)
+    elif solver == "backward_direct":
+        Tm, ok = np.linalg.solve(-B, A), True
+    else:
+        raise ValueError(solver)
+    out = {"T": Tm, "success": bool(ok), "n_iter": n_iter}
+    if not ok:
+        out.update(logp=-np.inf, R=np.zeros_like(D), resid=np.inf, P0=None)
+        return out
+    Rm = compute_selection_matrix(B, C, D, Tm)
+    out["resid"] = policy_residual(A, B, C, Tm)
+    if inv_var_order is not None:  # statespace.py:217-220
+        Tm = Tm[inv_var_order][:, inv_var_order]
+        Rm = Rm[inv_var_order]
+    P0 = solve_discrete_lyapunov(Tm, Rm @ Q @ Rm.T)
+    out["logp"] = kalman_filter_logp(
+        y, Tm, Rm, Q, Z, H=H, d=d, P0=P0, jitter=jitter, missing_fill_value=missing_fill_value
+    )
+    out.update(T=Tm, R=Rm, P0=P0)
+    return out

@@ -1,0 +1,161 @@
+"""CPU: the oracle restatement vs the reference's own outputs (golden fixtures).
+
+Mirrors the reference's solver tests:
+  tests/model/test_perturbation.py:163-206 (gensys == cycle reduction, T structure),
+  tests/model/test_model.py:501-529 (failure codes), tests/model/test_model.py:405-421
+  (golden A,B,C,D are the inputs).
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from geconpy_amd import workloads as wl
+
+KEYS = ["one_block", "rbc_2_block", "full_nk"]
+
+
+def _abcd(g, key):
+    return tuple(g[f"{key}_{x}"] for x in "ABCD")
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_gensys_matches_reference(ref_goldens, key):
+    A, B, C, D = _abcd(ref_goldens, key)
+    G1, Cc, impact, fmat, fwt, ywt, gev, eu, loose = oracle.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
+    n = A.shape[0]
+    assert list(eu) == list(ref_goldens[f"{key}_ref_gensys_eu"])
+    assert_allclose(G1, ref_goldens[f"{key}_ref_gensys_G1"], atol=1e-11, rtol=0)
+    assert_allclose(G1[:n, :n], ref_goldens[f"{key}_ref_gensys_T"], atol=1e-11, rtol=0)
+    assert_allclose(impact[:n], ref_goldens[f"{key}_ref_gensys_R"], atol=1e-11, rtol=0)
+    # generalized eigenvalue moduli agree as multisets
+    lam = np.sort(np.abs(gev[:, 1]) / np.maximum(np.abs(gev[:, 0]), 1e-300))
+    gr = ref_goldens[f"{key}_ref_gensys_gev"]
+    lam_r = np.sort(np.abs(gr[:, 1]) / np.maximum(np.abs(gr[:, 0]), 1e-300))
+    finite = lam_r < 1e6
+    assert_allclose(lam[finite], lam_r[finite], rtol=1e-6)
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_cycle_reduction_matches_reference(ref_goldens, key):
+    A, B, C, D = _abcd(ref_goldens, key)
+    T, R, msg, _ = oracle.solve_policy_function_with_cycle_reduction(A, B, C, D, max_iter=1000, tol=1e-8)
+    assert msg == "Optimization successful"
+    assert_allclose(T, ref_goldens[f"{key}_ref_cr_T"], atol=1e-13, rtol=0)
+    assert_allclose(R, ref_goldens[f"{key}_ref_cr_R"], atol=1e-12, rtol=0)
+    for tol, it_ref in zip(ref_goldens["cr_tols"], ref_goldens[f"{key}_ref_cr_iters"]):
+        Tc, conv, it = oracle.cycle_reduction_core(A, B, C, 1000, float(tol))
+        assert conv and it == it_ref
+    assert oracle.policy_residual(A, B, C, T) < 1e-20
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_gensys_equals_cycle_reduction(ref_goldens, key):
+    # reference tests/model/test_perturbation.py:163-206, atol = rtol = 1e-8
+    A, B, C, D = _abcd(ref_goldens, key)
+    Tg, ok, eu = oracle.gensys_T_success(A, B, C, D)
+    Tc, conv, _ = oracle.cycle_reduction_core(A, B, C, 1000, 1e-8)
+    assert ok and conv
+    assert_allclose(Tg, Tc, atol=1e-8, rtol=1e-8)
+    Rg = oracle.compute_selection_matrix(B, C, D, Tg)
+    Rc = oracle.compute_selection_matrix(B, C, D, Tc)
+    assert_allclose(Rg, Rc, atol=1e-8, rtol=1e-8)
+    # jumper columns of T are zero, state columns are not
+    state = np.abs(A).sum(axis=0) > 0
+    assert np.abs(Tg[:, ~state]).max() < 1e-8
+    assert np.all(np.abs(Tg[:, state]).sum(axis=0) > 1e-8)
+
+
+def test_scan_cycle_reduction(ref_goldens):
+    A, B, C, D = _abcd(ref_goldens, "full_nk")
+    T, n_steps = oracle.scan_cycle_reduction(A, B, C, max_iter=50, tol=1e-7)
+    assert_allclose(T, ref_goldens["full_nk_ref_cr_T"], atol=1e-9)
+    assert 5 < n_steps < 20
+
+
+def test_rbc_closed_form(rbc_golden):
+    g = rbc_golden
+    A, B, C, D = wl.rbc_linearized_jacobians(**wl.RBC_CALIBRATION)
+    for x, M in zip("ABCD", (A, B, C, D)):
+        assert_allclose(M, g[f"cal_{x}"], atol=0)
+    Tg, ok, eu = oracle.gensys_T_success(A, B, C, D)
+    assert ok and list(eu) == [1, 1, 0]
+    assert_allclose(Tg, g["cal_ref_gensys_T"], atol=1e-12)
+    # economic sanity: technology is AR(1) with rho_A, capital is the only other state
+    assert_allclose(Tg[0, 0], wl.RBC_CALIBRATION["rho_A"], atol=1e-12)
+    assert np.abs(Tg[:, [1, 2, 4, 5, 6, 7]]).max() < 1e-12
+
+
+def test_rbc_draws(rbc_golden):
+    g = rbc_golden
+    th = {k[6:]: g[k] for k in g.files if k.startswith("theta_")}
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    for i in range(A.shape[0]):
+        Tg, ok, eu = oracle.gensys_T_success(A[i], B[i], C[i], D[i])
+        assert ok
+        assert_allclose(Tg, g["ref_gensys_T"][i], atol=1e-11)
+        Tc, conv, it = oracle.cycle_reduction_core(A[i], B[i], C[i], 1000, 1e-8)
+        assert conv and it == g["ref_cr_iters"][i]
+        assert_allclose(Tc, g["ref_cr_T"][i], atol=1e-12)
+
+
+def test_sw_shaped(sw_golden):
+    g = sw_golden
+    nb = int(g["n_draws"])
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    chk = np.array([np.abs(b[x]).sum() for x in "ABCD"] + [np.abs(om["y"]).sum()])
+    assert_allclose(chk, g["input_checksum"], rtol=1e-13)  # RNG stream has not drifted
+    for i in range(nb):
+        A, B, C, D = (b[x][i] for x in "ABCD")
+        Tg, ok, eu = oracle.gensys_T_success(A, B, C, D)
+        assert ok and list(eu) == list(g["ref_gensys_eu"][i])
+        assert_allclose(Tg, g["ref_gensys_T"][i], atol=1e-11)
+        assert_allclose(Tg, b["T_star"][i], atol=1e-11)
+        Tc, conv, it = oracle.cycle_reduction_core(A, B, C, 1000, 1e-8)
+        assert conv and it == g["ref_cr_iters"][i]
+        assert_allclose(Tc, g["ref_cr_T"][i], atol=1e-12)
+
+
+@pytest.mark.parametrize(
+    "name,eu_expected", [("ok", [1, 1, 0]), ("nonunique", None), ("noexist", None), ("coincident", [-2, -2, 0])]
+)
+def test_failure_codes(failure_golden, name, eu_expected):
+    g = failure_golden
+    A, B, C, D = (g[f"{name}_{x}"] for x in "ABCD")
+    Tg, ok, eu = oracle.gensys_T_success(A, B, C, D)
+    assert list(eu) == list(g[f"{name}_ref_gensys_eu"])
+    if eu_expected is not None:
+        assert list(eu) == eu_expected
+    assert ok == (name == "ok")
+    if name == "nonunique":  # the class pinned at tests/model/test_model.py:514-529 (eu = [1, 0, k>0])
+        assert eu[0] == 1 and eu[1] == 0 and eu[2] > 0
+    if name == "noexist":
+        assert eu[0] == 0
+    if name == "coincident":
+        assert np.all(Tg == 0)
+        out = oracle.solve_policy_function_with_gensys(A, B, C, D)
+        assert out[0] is None and out[7] == [-2, -2, 0]
+    Tc, conv, _ = oracle.cycle_reduction_core(A, B, C, 1000, 1e-8)
+    assert conv == bool(g[f"{name}_ref_cr_converged"][0])
+    if not conv:
+        assert np.all(Tc == 0)
+        if name == "coincident":
+            # exactly singular A1: np.linalg.solve raises, as it does in the reference's
+            # numpy variant (cycle_reduction.py:88)
+            with pytest.raises(np.linalg.LinAlgError):
+                oracle.cycle_reduction_numpy(A, B, C, 100, 1e-8)
+        else:
+            X, res, msg, _ = oracle.cycle_reduction_numpy(A, B, C, 100, 1e-8)
+            assert X is None and msg != "Optimization successful"
+
+
+def test_backward_direct():
+    rng = np.random.default_rng(3)
+    n, k = 6, 2
+    B = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    A = 0.3 * rng.standard_normal((n, n))
+    D = rng.standard_normal((n, k))
+    T, R = oracle.solve_policy_function_with_backward_direct(A, B, np.zeros((n, n)), D)
+    assert_allclose(A + B @ T, 0, atol=1e-13)
+    assert_allclose(B @ R + D, 0, atol=1e-13)
