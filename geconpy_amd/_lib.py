@@ -1,0 +1,96 @@
+"""ctypes binding of libdsge_hip.so (C ABI declared in include/dsge_hip.h).
+
+The library is the product path; there is NO fallback.  ``load()`` raises when the shared
+object is missing and every compute call raises ``DsgeHipError`` when no gfx950 device is
+present (the library itself refuses with DSGE_ERR_HIP).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
+
+ABI_VERSION = 1
+MAX_N = 64
+MAX_N_CR = 48
+MAX_P = 16
+
+ST_OK = 0
+ST_NOT_CONVERGED = 1
+ST_NAN = 2
+ST_LYAP_FAIL = 4
+ST_FILTER_NONFINITE = 8
+
+Q_DIAG_SHARED, Q_DIAG_BATCHED, Q_FULL_SHARED, Q_FULL_BATCHED = 0, 1, 2, 3
+SOLVER_CYCLE_REDUCTION, SOLVER_GENSYS, SOLVER_BACKWARD_DIRECT = 0, 1, 2
+SOLVER_CODES = {
+    "cycle_reduction": SOLVER_CYCLE_REDUCTION,
+    "gensys": SOLVER_GENSYS,
+    "backward_direct": SOLVER_BACKWARD_DIRECT,
+}
+
+
+class DsgeHipError(RuntimeError):
+    pass
+
+
+_dp = C.c_void_p  # double* / int32* / stream: passed as raw addresses (host or device)
+_i = C.c_int
+_f = C.c_double
+
+# name -> argtypes; every symbol include/dsge_hip.h declares must appear here
+PROTOTYPES = {
+    "dsge_abi_version": [],
+    "dsge_last_error": [],
+    "dsge_device_count": [],
+    "dsge_set_device": [_i],
+    "dsge_stream_synchronize": [_dp],
+    "dsge_cycle_reduction_batched": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp, _dp],
+    "dsge_cycle_reduction_batched_host": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp],
+    "dsge_selection_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
+    "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
+    "dsge_backward_direct_batched": [_dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
+    "dsge_backward_direct_batched_host": [_dp, _dp, _dp, _i, _i, _i, _dp, _dp],
+    "dsge_lyapunov_batched": [_dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp, _dp],
+    "dsge_lyapunov_batched_host": [_dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp],
+    "dsge_kalman_logp_batched": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _dp, _dp, _dp],
+    "dsge_kalman_logp_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _dp, _dp],
+    "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_profile_pipeline": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _dp, _dp, _i, _dp, _dp],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Loading does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsgeHipError(
+            f"{LIB_PATH} is missing: build it with `python -m geconpy_amd.build` "
+            "(there is no CPU fallback for the HIP engine)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "dsge_last_error" else C.c_int
+    if lib.dsge_abi_version() != ABI_VERSION:
+        raise DsgeHipError("libdsge_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().dsge_last_error()
+        raise DsgeHipError(f"libdsge_hip call failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def device_count():
+    return load().dsge_device_count()

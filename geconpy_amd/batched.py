@@ -1,0 +1,205 @@
+"""Batched numpy front-end of the HIP engine (host arrays in, host arrays out).
+
+Every function takes arrays with a leading draw axis, calls ONE C-ABI entry point of
+libdsge_hip.so (the ``*_host`` twins, which stage through device memory) and returns fresh
+numpy arrays.  Layout/dtype coercion mirrors the reference
+(``np.ascontiguousarray(..., float64)``, gEconpy/solvers/gensys.py:625-628).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import DsgeHipError  # noqa: F401
+
+JITTER_DEFAULT = 1e-8  # float64 cov_jitter default (gEconpy/model/statespace.py:22,1144)
+MISSING_FILL = -9999.0  # default missing_fill_value (gEconpy/model/statespace.py:1143)
+
+
+def _f64(x, ndim=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError(f"expected a {ndim}-d array, got shape {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _check_abc(A, B, C):
+    A, B, C = _f64(A, 3), _f64(B, 3), _f64(C, 3)
+    if not (A.shape == B.shape == C.shape and A.shape[1] == A.shape[2]):
+        raise ValueError(f"A, B, C must be (batch, n, n); got {A.shape}, {B.shape}, {C.shape}")
+    return A, B, C
+
+
+def cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9):
+    """T, status, n_iter for a batch of systems (``_cycle_reduction_core`` semantics,
+    gEconpy/solvers/cycle_reduction.py:127-183; Op defaults :190)."""
+    A, B, C = _check_abc(A, B, C)
+    nb, n, _ = A.shape
+    T = np.empty_like(A)
+    status = np.empty(nb, dtype=np.int32)
+    n_iter = np.empty(nb, dtype=np.int32)
+    _lib.check(
+        _lib.load().dsge_cycle_reduction_batched_host(
+            _ptr(A), _ptr(B), _ptr(C), nb, n, int(max_iter), float(tol), _ptr(T), _ptr(status), _ptr(n_iter)
+        )
+    )
+    return T, status, n_iter
+
+
+def selection_batched(B, C, D, T, A=None):
+    """R = -(C T + B)^-1 D (gEconpy/solvers/shared.py:74-75); with ``A`` also the residual
+    ``sum((A + B T + C T T)^2)`` (gEconpy/model/statespace.py:213)."""
+    B, C, T = _check_abc(B, C, T)
+    D = _f64(D, 3)
+    nb, n, _ = B.shape
+    k = D.shape[2]
+    if D.shape[:2] != (nb, n):
+        raise ValueError("D must be (batch, n, k)")
+    R = np.empty((nb, n, k))
+    resid = None
+    if A is not None:
+        A = _f64(A, 3)
+        resid = np.empty(nb)
+    _lib.check(
+        _lib.load().dsge_selection_batched_host(_ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(T), nb, n, k, _ptr(R), _ptr(resid))
+    )
+    return (R, resid) if A is not None else R
+
+
+def backward_direct_batched(A, B, D):
+    """T = (-B)^-1 A, R = -B^-1 D (gEconpy/solvers/backward_looking.py:102-134)."""
+    A, B = _f64(A, 3), _f64(B, 3)
+    D = _f64(D, 3)
+    nb, n, _ = A.shape
+    k = D.shape[2]
+    T = np.empty_like(A)
+    R = np.empty((nb, n, k))
+    _lib.check(_lib.load().dsge_backward_direct_batched_host(_ptr(A), _ptr(B), _ptr(D), nb, n, k, _ptr(T), _ptr(R)))
+    return T, R
+
+
+def _q_mode(Q, nb, k):
+    """Infer the covariance layout from the shape (ambiguous only when batch == k)."""
+    Q = _f64(Q)
+    if Q.shape == (k,):
+        return Q, _lib.Q_DIAG_SHARED
+    if Q.shape == (nb, k, k):
+        return Q, _lib.Q_FULL_BATCHED
+    if Q.ndim == 2 and nb != k:
+        if Q.shape == (nb, k):
+            return Q, _lib.Q_DIAG_BATCHED
+        if Q.shape == (k, k):
+            return Q, _lib.Q_FULL_SHARED
+    raise ValueError(f"cannot infer the layout of Q with shape {Q.shape} (batch={nb}, k={k}); pass q_mode")
+
+
+def _resolve_q(Q, q_mode, nb, k):
+    if q_mode is None:
+        return _q_mode(Q, nb, k)
+    modes = {"diag": _lib.Q_DIAG_SHARED, "diag_batched": _lib.Q_DIAG_BATCHED, "full": _lib.Q_FULL_SHARED,
+             "full_batched": _lib.Q_FULL_BATCHED}
+    code = modes[q_mode] if isinstance(q_mode, str) else int(q_mode)
+    Q = _f64(Q)
+    want = {0: (k,), 1: (nb, k), 2: (k, k), 3: (nb, k, k)}[code]
+    if Q.shape != want:
+        raise ValueError(f"Q has shape {Q.shape}, q_mode needs {want}")
+    return Q, code
+
+
+def lyapunov_batched(T, R, Q, q_mode=None):
+    """P0 = solve_discrete_lyapunov(T, R Q R') (gEconpy/model/statespace.py:814-815) ->
+    (P0, RQR, status)."""
+    T, R = _f64(T, 3), _f64(R, 3)
+    nb, m, _ = T.shape
+    k = R.shape[2]
+    Q, code = _resolve_q(Q, q_mode, nb, k)
+    P0 = np.empty_like(T)
+    RQR = np.empty_like(T)
+    status = np.empty(nb, dtype=np.int32)
+    _lib.check(_lib.load().dsge_lyapunov_batched_host(_ptr(T), _ptr(R), _ptr(Q), code, nb, m, k, _ptr(P0), _ptr(RQR), _ptr(status)))
+    return P0, RQR, status
+
+
+def _obs_args(Z, d, Hdiag, nb, p, m):
+    Z = _f64(Z)
+    if Z.shape == (p, m):
+        zb = 0
+    elif Z.shape == (nb, p, m):
+        zb = 1
+    else:
+        raise ValueError(f"Z must be (p, m) or (batch, p, m); got {Z.shape}")
+
+    def vec(x, name):
+        if x is None:
+            return None, 0
+        x = _f64(x)
+        if x.shape == (p,):
+            return x, 0
+        if x.shape == (nb, p):
+            return x, 1
+        raise ValueError(f"{name} must be (p,) or (batch, p); got {x.shape}")
+
+    d, db = vec(d, "d")
+    Hdiag, hb = vec(Hdiag, "Hdiag")
+    return Z, zb, d, db, Hdiag, hb
+
+
+def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None,
+                        jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL):
+    """Per-draw Kalman log-likelihood (the filter DSGEStateSpace hands to PyMC,
+    gEconpy/model/statespace.py:1151-1157) -> (logp, status)."""
+    T, R = _f64(T, 3), _f64(R, 3)
+    y = _f64(y, 2)
+    nb, m, _ = T.shape
+    k = R.shape[2]
+    T_len, p = y.shape
+    Q, code = _resolve_q(Q, q_mode, nb, k)
+    Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, m)
+    st = np.zeros(nb, dtype=np.int32) if status is None else np.ascontiguousarray(status, dtype=np.int32).copy()
+    logp = np.empty(nb)
+    _lib.check(
+        _lib.load().dsge_kalman_logp_batched_host(
+            _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len,
+            float(jitter), float(missing_fill_value), _ptr(logp), _ptr(st)
+        )
+    )
+    return logp, st
+
+
+def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
+                              tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
+                              return_policy=False):
+    """One fused evaluation per draw: A,B,C,D -> T,R -> P0 -> logp.  ``tol``/``max_iter``
+    default to what ``DSGEStateSpace.configure`` passes (statespace.py:835-836).
+    Returns dict(logp, status[, T, R, resid, n_iter])."""
+    A, B, C = _check_abc(A, B, C)
+    D = _f64(D, 3)
+    y = _f64(y, 2)
+    nb, n, _ = A.shape
+    k = D.shape[2]
+    T_len, p = y.shape
+    Q, code = _resolve_q(Q, q_mode, nb, k)
+    Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, n)
+    logp = np.empty(nb)
+    status = np.empty(nb, dtype=np.int32)
+    T = R = resid = n_iter = None
+    if return_policy:
+        T = np.empty_like(A)
+        R = np.empty((nb, n, k))
+        resid = np.empty(nb)
+        n_iter = np.empty(nb, dtype=np.int32)
+    _lib.check(
+        _lib.load().dsge_solve_kalman_logp_batched_host(
+            _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb,
+            n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter),
+            float(missing_fill_value), _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
+        )
+    )
+    out = dict(logp=logp, status=status)
+    if return_policy:
+        out.update(T=T, R=R, resid=resid, n_iter=n_iter)
+    return out

@@ -1,0 +1,625 @@
+// C ABI of libdsge_hip.so (declared in include/dsge_hip.h): argument checking, kernel
+// dispatch on the tile size BS = ceil(n/8), library-owned scratch, host staging twins.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dsge_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      (void)hipGetLastError(); /* clear the sticky error so later calls are not poisoned */        \
+      return fail(DSGE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+    }                                                                                              \
+  } while (0)
+
+bool g_device_checked = false;
+int g_device_ok = 0;
+std::mutex g_mutex;
+
+// Lazy device check (fork-aware: nothing touches HIP before the first call).
+int ensure_device() {
+  std::lock_guard<std::mutex> lk(g_mutex);
+  if (g_device_checked) return g_device_ok ? DSGE_SUCCESS : fail(DSGE_ERR_HIP, "no gfx950 device available");
+  g_device_checked = true;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    (void)hipGetLastError();
+    return fail(DSGE_ERR_HIP, "no HIP device visible: libdsge_hip has no CPU fallback");
+  }
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(DSGE_ERR_HIP, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  g_device_ok = 1;
+  return DSGE_SUCCESS;
+}
+
+// ---- library-owned device scratch (grown on demand, one arena per device) ----------------
+struct Arena {
+  void* ptr = nullptr;
+  size_t cap = 0;
+};
+constexpr int MAX_DEV = 16;
+Arena g_scratch[MAX_DEV];  // pipeline intermediates
+Arena g_stage[MAX_DEV];    // host-twin staging
+
+int arena_reserve(Arena* arenas, size_t bytes, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEV) return fail(DSGE_ERR_INVALID, "device index out of range");
+  Arena& a = arenas[dev];
+  if (a.cap < bytes) {
+    if (a.ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a.ptr));
+      a.ptr = nullptr;
+      a.cap = 0;
+    }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&a.ptr, cap));
+    a.cap = cap;
+  }
+  *out = a.ptr;
+  return DSGE_SUCCESS;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = (T*)(base + off);
+    off += align256(count * sizeof(T));
+    return p;
+  }
+};
+
+inline int tile_bs(int n) {
+  int bs = (n + 7) / 8;
+  if (bs == 7) bs = 8;
+  return bs < 1 ? 1 : bs;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return DSGE_SUCCESS;
+}
+
+#define DISPATCH_BS(bs, MAXBS, ...)                                                  \
+  switch (bs) {                                                                      \
+    case 1: { constexpr int BS = 1; __VA_ARGS__; } break;                            \
+    case 2: { constexpr int BS = 2; __VA_ARGS__; } break;                            \
+    case 3: { constexpr int BS = 3; __VA_ARGS__; } break;                            \
+    case 4: { constexpr int BS = 4; __VA_ARGS__; } break;                            \
+    case 5: { constexpr int BS = 5; __VA_ARGS__; } break;                            \
+    case 6: { constexpr int BS = 6; __VA_ARGS__; } break;                            \
+    case 8: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 8 : 6); __VA_ARGS__; } break; \
+    default: break;                                                                  \
+  }
+
+int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
+              double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 6, {
+    rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
+                         max_iter, tol, T_out, status, n_iter);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
+                   double* R_out, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 6, {
+    rc = set_lds(dsge::bdirect_kernel<BS>, dsge::BdSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::bdirect_kernel<BS>, dim3(batch), dim3(64), dsge::BdSmem<BS>::bytes, st, A, B, D, batch,
+                         n, k, T_out, R_out);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
+                    const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
+                    double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
+                    hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::assemble_kernel<BS>, dsge::AsmSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::assemble_kernel<BS>, dim3(batch), dim3(64), dsge::AsmSmem<BS>::bytes, st, A, B, C, D, T,
+                         R_in, Q, q_mode, batch, n, k, R_out, resid_out, RQR_out, P0_out, status, do_sel, do_lyap);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
+                  const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                  int m, int p, int T_len, double jitter, double missing_fill, double* logp, int32_t* status,
+                  hipStream_t st) {
+  const int bs = tile_bs(m);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    const size_t lds = dsge::KfSmem<BS>::bytes(p);
+    rc = set_lds(dsge::kalman_kernel<BS>, lds);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
+                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int check_common(int batch, int n, int n_max) {
+  if (batch < 0) return fail(DSGE_ERR_INVALID, "batch < 0");
+  if (n < 1 || n > n_max) return fail(DSGE_ERR_INVALID, "n out of range (1.." + std::to_string(n_max) + ")");
+  return DSGE_SUCCESS;
+}
+
+size_t q_elems(int q_mode, int batch, int k) {
+  switch (q_mode) {
+    case DSGE_Q_DIAG_SHARED: return (size_t)k;
+    case DSGE_Q_DIAG_BATCHED: return (size_t)batch * k;
+    case DSGE_Q_FULL_SHARED: return (size_t)k * k;
+    case DSGE_Q_FULL_BATCHED: return (size_t)batch * k * k;
+    default: return 0;
+  }
+}
+
+// host staging helpers ---------------------------------------------------------------------
+struct Stage {
+  Carver carver;
+  std::vector<std::pair<void*, std::pair<const void*, size_t>>> ups;
+  explicit Stage(void* base) : carver(base) {}
+};
+
+}  // namespace
+
+extern "C" {
+
+int dsge_abi_version(void) { return DSGE_ABI_VERSION; }
+const char* dsge_last_error(void) { return g_last_error.c_str(); }
+
+int dsge_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int ok = 0;
+  for (int i = 0; i < count; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+int dsge_set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return DSGE_SUCCESS;
+}
+
+int dsge_stream_synchronize(void* stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return DSGE_SUCCESS;
+}
+
+int dsge_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n, int max_iter,
+                                 double tol, double* T_out, int32_t* status, int32_t* n_iter, void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if (max_iter < 0) return fail(DSGE_ERR_INVALID, "max_iter < 0");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_cr(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, (hipStream_t)stream);
+}
+
+int dsge_selection_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
+                           int batch, int n, int k, double* R_out, double* resid_out, void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!B || !C || !D || !T || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if (resid_out && !A) return fail(DSGE_ERR_INVALID, "resid_out requires A");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_assemble(A, B, C, D, T, nullptr, nullptr, 0, batch, n, k, R_out, resid_out, nullptr, nullptr, nullptr,
+                         1, 0, (hipStream_t)stream);
+}
+
+int dsge_backward_direct_batched(const double* A, const double* B, const double* D, int batch, int n, int k,
+                                 double* T_out, double* R_out, void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!A || !B || !D || !T_out || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_bdirect(A, B, D, batch, n, k, T_out, R_out, (hipStream_t)stream);
+}
+
+int dsge_lyapunov_batched(const double* T, const double* R, const double* Q, int q_mode, int batch, int m, int k,
+                          double* P0_out, double* RQR_out, int32_t* status, void* stream) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!T || !R || !Q || !P0_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, (hipStream_t)stream));
+  return launch_assemble(nullptr, nullptr, nullptr, nullptr, T, R, Q, q_mode, batch, m, k, nullptr, nullptr, RQR_out,
+                         P0_out, status, 0, 1, (hipStream_t)stream);
+}
+
+int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                             int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                             const double* y, int batch, int m, int k, int p, int T_len, double jitter,
+                             double missing_fill, double* logp_out, int32_t* status_io, void* stream) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!T || !R || !Q || !Z || !y || !logp_out || !status_io) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  void* base = nullptr;
+  const size_t mm = (size_t)batch * m * m;
+  if ((rc = arena_reserve(g_scratch, 2 * align256(mm * sizeof(double)) + 4096, &base))) return rc;
+  Carver cv(base);
+  double* RQR = cv.take<double>(mm);
+  double* P0 = cv.take<double>(mm);
+  if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T, R, Q, q_mode, batch, m, k, nullptr, nullptr, RQR, P0,
+                            status_io, 0, 1, st)))
+    return rc;
+  return launch_kalman(T, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter,
+                       missing_fill, logp_out, status_io, st);
+}
+
+static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
+                    const double* Z, int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                    const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                    double jitter, double missing_fill, double* logp_out, int32_t* status_out, double* T_out,
+                    double* R_out, double* resid_out, int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out) {
+  int rc = check_common(batch, n, solver == DSGE_SOLVER_CYCLE_REDUCTION ? DSGE_MAX_N_CR : DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_BACKWARD_DIRECT)
+    return fail(DSGE_ERR_INVALID, "solver not available in this build (cycle_reduction, backward_direct)");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_scratch, 3 * align256(nn * 8) + align256(nk * 8) + 4096, &base))) return rc;
+  Carver cv(base);
+  double* Tw = T_out ? T_out : cv.take<double>(nn);
+  double* Rw = R_out ? R_out : cv.take<double>(nk);
+  double* RQR = cv.take<double>(nn);
+  double* P0 = cv.take<double>(nn);
+
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float acc_ms[3] = {0.f, 0.f, 0.f};
+  if (ms_out)
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  const int n_rep = ms_out ? reps : 1;
+  for (int rep = 0; rep < n_rep; ++rep) {
+    if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
+    if (solver == DSGE_SOLVER_CYCLE_REDUCTION) {
+      rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, n_iter_out, st);
+    } else {
+      HIP_TRY(hipMemsetAsync(status_out, 0, sizeof(int32_t) * batch, st));
+      if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
+      rc = launch_bdirect(A, B, D, batch, n, k, Tw, Rw, st);
+    }
+    if (rc) return rc;
+    if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
+    // backward_direct already produced R; the assemble kernel recomputes it from the same
+    // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
+    if ((rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, RQR, P0, status_out, 1, 1,
+                              st)))
+      return rc;
+    if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
+    if ((rc = launch_kalman(Tw, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
+                            missing_fill, logp_out, status_out, st)))
+      return rc;
+    if (ms_out) {
+      HIP_TRY(hipEventRecord(ev[3], st));
+      HIP_TRY(hipEventSynchronize(ev[3]));
+      for (int i = 0; i < 3; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        acc_ms[i] += ms;
+      }
+    }
+  }
+  if (ms_out) {
+    for (int i = 0; i < 3; ++i) ms_out[i] = acc_ms[i] / (float)n_rep;
+    for (auto& e : ev) HIP_TRY(hipEventDestroy(e));
+  }
+  return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_batched(const double* A, const double* B, const double* C, const double* D, const double* Q,
+                                   int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
+                                   const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
+                                   int T_len, int solver, double tol, int max_iter, double jitter, double missing_fill,
+                                   double* logp_out, int32_t* status_out, double* T_out, double* R_out,
+                                   double* resid_out, int32_t* n_iter_out, void* stream) {
+  return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
+                  tol, max_iter, jitter, missing_fill, logp_out, status_out, T_out, R_out, resid_out, n_iter_out,
+                  (hipStream_t)stream, 1, nullptr);
+}
+
+int dsge_profile_pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q,
+                          int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
+                          const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
+                          int T_len, int solver, double tol, int max_iter, double jitter, double missing_fill,
+                          double* logp_out, int32_t* status_out, int reps, float* ms_out, void* stream) {
+  if (!ms_out || reps < 1) return fail(DSGE_ERR_INVALID, "ms_out null or reps < 1");
+  return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
+                  tol, max_iter, jitter, missing_fill, logp_out, status_out, nullptr, nullptr, nullptr, nullptr,
+                  (hipStream_t)stream, reps, ms_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Host twins: stage through library-owned device buffers on the default stream.
+// ------------------------------------------------------------------------------------------
+#define UP(dst, src, count, type)                                                                   \
+  type* dst = nullptr;                                                                              \
+  if (src) {                                                                                        \
+    dst = cv.take<type>(count);                                                                     \
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(type) * (count), hipMemcpyHostToDevice, nullptr));      \
+  }
+#define OUTBUF(dst, host, count, type) type* dst = (host) ? cv.take<type>(count) : nullptr;
+#define DOWN(host, dev, count, type)                                                                \
+  if (host) HIP_TRY(hipMemcpyAsync(host, dev, sizeof(type) * (count), hipMemcpyDeviceToHost, nullptr));
+
+int dsge_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
+                                      int max_iter, double tol, double* T_out, int32_t* status, int32_t* n_iter) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256((size_t)batch * 4) + 4096, &base))) return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  OUTBUF(dT, T_out, nn, double);
+  OUTBUF(dS, status, batch, int32_t);
+  OUTBUF(dI, n_iter, batch, int32_t);
+  if ((rc = dsge_cycle_reduction_batched(dA, dB, dC, batch, n, max_iter, tol, dT, dS, dI, nullptr))) return rc;
+  DOWN(T_out, dT, nn, double);
+  DOWN(status, dS, batch, int32_t);
+  DOWN(n_iter, dI, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_selection_batched_host(const double* A, const double* B, const double* C, const double* D, const double* T,
+                                int batch, int n, int k, double* R_out, double* resid_out) {
+  int rc = check_common(batch, n, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!B || !C || !D || !T || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256(nk * 8) + align256((size_t)batch * 8) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dT, T, nn, double);
+  OUTBUF(dR, R_out, nk, double);
+  OUTBUF(dRes, resid_out, batch, double);
+  if ((rc = dsge_selection_batched(dA, dB, dC, dD, dT, batch, n, k, dR, dRes, nullptr))) return rc;
+  DOWN(R_out, dR, nk, double);
+  DOWN(resid_out, dRes, batch, double);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_backward_direct_batched_host(const double* A, const double* B, const double* D, int batch, int n, int k,
+                                      double* T_out, double* R_out) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!A || !B || !D || !T_out || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 3 * align256(nn * 8) + 2 * align256(nk * 8) + 4096, &base))) return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dD, D, nk, double);
+  OUTBUF(dT, T_out, nn, double);
+  OUTBUF(dR, R_out, nk, double);
+  if ((rc = dsge_backward_direct_batched(dA, dB, dD, batch, n, k, dT, dR, nullptr))) return rc;
+  DOWN(T_out, dT, nn, double);
+  DOWN(R_out, dR, nk, double);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q, int q_mode, int batch, int m, int k,
+                               double* P0_out, double* RQR_out, int32_t* status) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!T || !R || !Q || !P0_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 3 * align256(mm * 8) + align256(mk * 8) + align256(nq * 8) +
+                                       align256((size_t)batch * 4) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dT, T, mm, double);
+  UP(dR, R, mk, double);
+  UP(dQ, Q, nq, double);
+  OUTBUF(dP, P0_out, mm, double);
+  OUTBUF(dX, RQR_out, mm, double);
+  OUTBUF(dS, status, batch, int32_t);
+  if ((rc = dsge_lyapunov_batched(dT, dR, dQ, q_mode, batch, m, k, dP, dX, dS, nullptr))) return rc;
+  DOWN(P0_out, dP, mm, double);
+  DOWN(RQR_out, dX, mm, double);
+  DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_kalman_logp_batched_host(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                  int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                  const double* y, int batch, int m, int k, int p, int T_len, double jitter,
+                                  double missing_fill, double* logp_out, int32_t* status_io) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!T || !R || !Q || !Z || !y || !logp_out || !status_io) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
+  const size_t nz = (size_t)(z_batched ? batch : 1) * p * m, nd = (size_t)(d_batched ? batch : 1) * p,
+               nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage,
+                          align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(nz * 8) +
+                              align256(nd * 8) + align256(nh * 8) + align256(ny * 8) + align256((size_t)batch * 8) +
+                              align256((size_t)batch * 4) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dT, T, mm, double);
+  UP(dR, R, mk, double);
+  UP(dQ, Q, nq, double);
+  UP(dZ, Z, nz, double);
+  UP(dd, d, nd, double);
+  UP(dH, Hdiag, nh, double);
+  UP(dy, y, ny, double);
+  UP(dS, status_io, batch, int32_t);
+  OUTBUF(dL, logp_out, batch, double);
+  if ((rc = dsge_kalman_logp_batched(dT, dR, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy, batch, m, k,
+                                     p, T_len, jitter, missing_fill, dL, dS, nullptr)))
+    return rc;
+  DOWN(logp_out, dL, batch, double);
+  DOWN(status_io, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                        const double* Q, int q_mode, const double* Z, int z_batched, const double* d,
+                                        int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                                        int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                                        double jitter, double missing_fill, double* logp_out, int32_t* status_out,
+                                        double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out) {
+  int rc = check_common(batch, n, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = q_elems(q_mode, batch, k);
+  const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
+               nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage,
+                          4 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+                              align256(nd * 8) + align256(nh * 8) + align256(ny * 8) + 2 * align256((size_t)batch * 8) +
+                              2 * align256((size_t)batch * 4) + 8192,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dQ, Q, nq, double);
+  UP(dZ, Z, nz, double);
+  UP(dd, d, nd, double);
+  UP(dH, Hdiag, nh, double);
+  UP(dy, y, ny, double);
+  OUTBUF(dL, logp_out, batch, double);
+  OUTBUF(dS, status_out, batch, int32_t);
+  OUTBUF(dT, T_out, nn, double);
+  OUTBUF(dR, R_out, nk, double);
+  OUTBUF(dRes, resid_out, batch, double);
+  OUTBUF(dI, n_iter_out, batch, int32_t);
+  if ((rc = dsge_solve_kalman_logp_batched(dA, dB, dC, dD, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy,
+                                           batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill, dL, dS,
+                                           dT, dR, dRes, dI, nullptr)))
+    return rc;
+  DOWN(logp_out, dL, batch, double);
+  DOWN(status_out, dS, batch, int32_t);
+  DOWN(T_out, dT, nn, double);
+  DOWN(R_out, dR, nk, double);
+  DOWN(resid_out, dRes, batch, double);
+  DOWN(n_iter_out, dI, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+}  // extern "C"

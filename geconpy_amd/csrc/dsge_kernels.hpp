@@ -1,0 +1,580 @@
+// Kernels of the solve + Kalman-logp pipeline; one wavefront per draw (see dsge_device.hpp).
+//   cr_kernel        : cycle reduction           A,B,C -> T, status, n_iter
+//   bdirect_kernel   : backward-direct           A,B,D -> T, R
+//   assemble_kernel  : R, resid, sym(RQR'), P0   (selection matrix + doubling Lyapunov)
+//   kalman_kernel    : standard Kalman filter    T,RQR,P0,Z,d,H,y -> logp
+#pragma once
+#include "dsge_device.hpp"
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge {
+
+// ---------------------------------------------------------------------------------------
+// Cycle reduction (Bini-Latouche-Meini), njit-variant semantics of
+// gEconpy/solvers/cycle_reduction.py:127-183.
+//   LDS: A0s, A2s (left operands of the four products) and the augmented system
+//   W = [A1 | A0 | A2] that Gauss-Jordan turns into [. | A1^-1 A0 | A1^-1 A2].
+//   A1 and A1_hat never serve as product operands, so they live in the lanes' register blocks.
+// ---------------------------------------------------------------------------------------
+template <int BS>
+struct CrSmem {
+  static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 3 * NP + 1;
+  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW);
+};
+
+template <int BS>
+__global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                 const double* __restrict__ C, int batch, int n, int max_iter,
+                                                 double tol, double* __restrict__ T_out,
+                                                 int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out) {
+  constexpr int NP = CrSmem<BS>::NP, LD = CrSmem<BS>::LD, LDW = CrSmem<BS>::LDW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* A0s = smem;
+  double* A2s = A0s + NP * LD;
+  double* W = A2s + NP * LD;
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    wave_sync();
+    lds_load_matrix(A0s, LD, NP, NP, A + off, n, n, lane);
+    lds_load_matrix(A2s, LD, NP, NP, C + off, n, n, lane);
+    for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+    double A1[BS][BS], Ah[BS][BS];
+    blk_load_global<BS>(A1, B + off, n, n, n, lr, lc);
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Ah[i][j] = A1[i][j];
+    wave_sync();
+
+    bool converged = false, saw_nan = false;
+    int it = 0;
+    for (; it < max_iter;) {
+      // W = [A1 | A0 | A2]
+      blk_store_lds<BS>(A1, W, LDW, lr, lc);
+      {
+        double t[BS][BS];
+        blk_load_lds<BS>(t, A0s, LD, lr, lc);
+        blk_store_lds<BS>(t, W + NP, LDW, lr, lc);
+        blk_load_lds<BS>(t, A2s, LD, lr, lc);
+        blk_store_lds<BS>(t, W + 2 * NP, LDW, lr, lc);
+      }
+      gauss_jordan_lds(W, LDW, n, 3 * NP, lane);  // syncs on entry and exit
+      const double* X0 = W + NP;
+      const double* X2 = W + 2 * NP;
+      double acc[BS][BS];
+      blk_zero<BS>(acc);
+      mm_acc<BS, false>(acc, A0s, LD, X2, LDW, n, lr, lc);  // m02
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) A1[i][j] -= acc[i][j];
+      blk_zero<BS>(acc);
+      mm_acc<BS, false>(acc, A2s, LD, X0, LDW, n, lr, lc);  // m20
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          A1[i][j] -= acc[i][j];
+          Ah[i][j] -= acc[i][j];
+        }
+      double m00[BS][BS], m22[BS][BS];
+      blk_zero<BS>(m00);
+      blk_zero<BS>(m22);
+      mm_acc<BS, false>(m00, A0s, LD, X0, LDW, n, lr, lc);
+      mm_acc<BS, false>(m22, A2s, LD, X2, LDW, n, lr, lc);
+      wave_sync();  // every lane is done reading A0s/A2s
+      blk_store_lds<BS>(m00, A0s, LD, lr, lc, -1.0);
+      blk_store_lds<BS>(m22, A2s, LD, lr, lc, -1.0);
+      ++it;
+      const double nrm0 = blk_norm1<BS>(m00);
+      if (nrm0 < tol) {
+        const double nrm2 = blk_norm1<BS>(m22);
+        if (nrm2 < tol) {
+          converged = true;
+          break;
+        }
+      } else if (nrm0 != nrm0) {
+        saw_nan = true;
+        break;
+      }
+      wave_sync();
+    }
+
+    double Tb[BS][BS];
+    blk_zero<BS>(Tb);
+    if (converged) {
+      // T = -A1_hat^-1 A0_initial   (cycle_reduction.py:181)
+      wave_sync();
+      blk_store_lds<BS>(Ah, W, LDW, lr, lc);
+      {
+        double t[BS][BS];
+        blk_load_global<BS>(t, A + off, n, n, n, lr, lc);
+        blk_store_lds<BS>(t, W + NP, LDW, lr, lc);
+      }
+      gauss_jordan_lds(W, LDW, n, 2 * NP, lane);
+      blk_load_lds<BS>(Tb, W + NP, LDW, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Tb[i][j] = -Tb[i][j];
+    }
+    blk_store_global<BS>(Tb, T_out + off, n, n, n, lr, lc);
+    if (lane == 0) {
+      status[draw] = converged ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
+      if (n_iter_out) n_iter_out[draw] = it;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward-direct (gEconpy/solvers/backward_looking.py:8-24,46-78): T = (-B)^-1 A, R = -B^-1 D
+// ---------------------------------------------------------------------------------------
+template <int BS>
+struct BdSmem {
+  static constexpr int NP = Tile<BS>::NP, LDW = 3 * NP + 1;
+  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW);
+};
+
+template <int BS>
+__global__ __launch_bounds__(64) void bdirect_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                      const double* __restrict__ D, int batch, int n, int k,
+                                                      double* __restrict__ T_out, double* __restrict__ R_out) {
+  constexpr int NP = BdSmem<BS>::NP, LDW = BdSmem<BS>::LDW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* W = smem;
+  const int lane = threadIdx.x;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    wave_sync();
+    for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+    wave_sync();
+    const double* Bg = B + (size_t)draw * n * n;
+    const double* Ag = A + (size_t)draw * n * n;
+    const double* Dg = D + (size_t)draw * n * k;
+    for (int idx = lane; idx < n * n; idx += 64) {
+      const int r = idx / n, c = idx - r * n;
+      W[r * LDW + c] = Bg[idx];
+      W[r * LDW + NP + c] = Ag[idx];
+    }
+    for (int idx = lane; idx < n * k; idx += 64) {
+      const int r = idx / k, c = idx - r * k;
+      W[r * LDW + 2 * NP + c] = Dg[idx];
+    }
+    gauss_jordan_lds(W, LDW, n, 2 * NP + k, lane);
+    for (int idx = lane; idx < n * n; idx += 64) {
+      const int r = idx / n, c = idx - r * n;
+      T_out[(size_t)draw * n * n + idx] = -W[r * LDW + NP + c];
+    }
+    for (int idx = lane; idx < n * k; idx += 64) {
+      const int r = idx / k, c = idx - r * k;
+      R_out[(size_t)draw * n * k + idx] = -W[r * LDW + 2 * NP + c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Assemble: R = -(C T + B)^-1 D (shared.py:74-75), resid = sum((A + (B + C T) T)^2)
+// (statespace.py:213), RQR = sym(R Q R'), P0 = dlyap(T, RQR) by doubling:
+//   P <- P + A_k P A_k',  A_{k+1} = A_k^2,  A_0 = T   (P = sum_j T^j RQR T'^j)
+// ---------------------------------------------------------------------------------------
+template <int BS>
+struct AsmSmem {
+  static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 2 * NP + 1;
+  // M1, M2 (NP x LD each), W (NP x LDW)
+  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW);
+};
+
+constexpr int LYAP_MAX_DOUBLINGS = 64;
+
+template <int BS>
+__global__ __launch_bounds__(64) void assemble_kernel(
+    const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ C,
+    const double* __restrict__ D, const double* __restrict__ T, const double* __restrict__ R_in,
+    const double* __restrict__ Q, int q_mode, int batch, int n, int k, double* __restrict__ R_out,
+    double* __restrict__ resid_out, double* __restrict__ RQR_out, double* __restrict__ P0_out,
+    int32_t* __restrict__ status, int do_selection, int do_lyapunov) {
+  constexpr int NP = AsmSmem<BS>::NP, LD = AsmSmem<BS>::LD, LDW = AsmSmem<BS>::LDW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* M1 = smem;            // T, later A_k
+  double* M2 = M1 + NP * LD;    // C, then (B + C T), later P
+  double* W = M2 + NP * LD;     // [B + C T | D] -> [. | X];  later R | RQ, then scratch W1 (ld = LDW)
+  double* RQs = W + NP;         // R Q staging lives in the right half of W (ld = LDW)
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    const size_t offk = (size_t)draw * n * k;
+    if (status && status[draw] != 0) {
+      // failed solve: nothing to assemble; outputs zero-filled so downstream stays finite
+      double z[BS][BS];
+      blk_zero<BS>(z);
+      if (do_selection && R_out) blk_store_global<BS>(z, R_out + offk, n, k, k, lr, lc);
+      if (do_selection && resid_out && lane == 0) resid_out[draw] = INFINITY;
+      if (do_lyapunov) {
+        if (RQR_out) blk_store_global<BS>(z, RQR_out + off, n, n, n, lr, lc);
+        blk_store_global<BS>(z, P0_out + off, n, n, n, lr, lc);
+      }
+      continue;
+    }
+    wave_sync();
+    lds_load_matrix(M1, LD, NP, NP, T + off, n, n, lane);
+    for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+    wave_sync();
+
+    double Rb[BS][BS];  // R in register blocks (rows lr*BS.., cols lc*BS.. < k)
+    if (do_selection) {
+      lds_load_matrix(M2, LD, NP, NP, C + off, n, n, lane);
+      wave_sync();
+      double Mb[BS][BS];
+      blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
+      mm_acc<BS, false>(Mb, M2, LD, M1, LD, n, lr, lc);  // B + C T
+      wave_sync();
+      blk_store_lds<BS>(Mb, W, LDW, lr, lc);
+      blk_store_lds<BS>(Mb, M2, LD, lr, lc);  // keep a copy for the residual
+      {
+        double Db[BS][BS];
+        blk_load_global<BS>(Db, D + offk, n, k, k, lr, lc);
+        blk_store_lds<BS>(Db, W + NP, LDW, lr, lc);
+      }
+      gauss_jordan_lds(W, LDW, n, NP + k, lane);
+      blk_load_lds<BS>(Rb, W + NP, LDW, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Rb[i][j] = -Rb[i][j];
+      if (R_out) blk_store_global<BS>(Rb, R_out + offk, n, k, k, lr, lc);
+      if (resid_out) {
+        double Eb[BS][BS];
+        blk_load_global<BS>(Eb, A + off, n, n, n, lr, lc);
+        mm_acc<BS, false>(Eb, M2, LD, M1, LD, n, lr, lc);  // A + (B + C T) T
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) s = fma(Eb[i][j], Eb[i][j], s);
+        s = wave_sum(s);
+        if (lane == 0) resid_out[draw] = s;
+      }
+    } else {
+      blk_load_global<BS>(Rb, R_in + offk, n, k, k, lr, lc);
+    }
+    if (!do_lyapunov) continue;
+
+    // ---- R -> left half of W (the transposed operand), R Q -> right half of W
+    wave_sync();
+    blk_store_lds<BS>(Rb, W, LDW, lr, lc);
+    if (q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED) {
+      const double* q = Q + (q_mode == DSGE_Q_DIAG_BATCHED ? (size_t)draw * k : 0);
+      double RQ[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int c = lc * BS + j;
+          RQ[i][j] = (c < k) ? Rb[i][j] * q[c] : 0.0;
+        }
+      blk_store_lds<BS>(RQ, RQs, LDW, lr, lc);
+      wave_sync();
+    } else {
+      const double* q = Q + (q_mode == DSGE_Q_FULL_BATCHED ? (size_t)draw * k * k : 0);
+      lds_load_matrix(M2, LD, NP, NP, q, k, k, lane);  // M2 is free here
+      wave_sync();
+      double RQ[BS][BS];
+      blk_zero<BS>(RQ);
+      mm_acc<BS, false>(RQ, W, LDW, M2, LD, k, lr, lc);
+      blk_store_lds<BS>(RQ, RQs, LDW, lr, lc);
+      wave_sync();
+    }
+    double Pb[BS][BS];
+    blk_zero<BS>(Pb);
+    mm_acc<BS, true>(Pb, RQs, LDW, W, LDW, k, lr, lc);  // (R Q) R'
+    // symmetrise through M2
+    wave_sync();
+    blk_store_lds<BS>(Pb, M2, LD, lr, lc);
+    wave_sync();
+    {
+      double Pt[BS][BS];
+      blk_load_lds_t<BS>(Pt, M2, LD, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Pb[i][j] = 0.5 * (Pb[i][j] + Pt[i][j]);
+    }
+    if (RQR_out) blk_store_global<BS>(Pb, RQR_out + off, n, n, n, lr, lc);
+    wave_sync();
+    blk_store_lds<BS>(Pb, M2, LD, lr, lc);  // P_0 = RQR
+    wave_sync();
+
+    // ---- doubling iteration; M1 = A_k, M2 = P_k, W = scratch
+    bool lyap_ok = false;
+    for (int itl = 0; itl < LYAP_MAX_DOUBLINGS; ++itl) {
+      double W1[BS][BS];
+      blk_zero<BS>(W1);
+      mm_acc<BS, true>(W1, M2, LD, M1, LD, n, lr, lc);  // P A_k'
+      wave_sync();
+      blk_store_lds<BS>(W1, W, LDW, lr, lc);
+      wave_sync();
+      double Db[BS][BS], A2b[BS][BS];
+      blk_zero<BS>(Db);
+      blk_zero<BS>(A2b);
+      mm_acc<BS, false>(Db, M1, LD, W, LDW, n, lr, lc);    // A_k P A_k'
+      mm_acc<BS, false>(A2b, M1, LD, M1, LD, n, lr, lc);   // A_k^2
+      wave_sync();
+      blk_store_lds<BS>(Db, W, LDW, lr, lc);
+      blk_store_lds<BS>(A2b, M1, LD, lr, lc);
+      wave_sync();
+      {
+        double Dt[BS][BS];
+        blk_load_lds_t<BS>(Dt, W, LDW, lr, lc);
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            Db[i][j] = 0.5 * (Db[i][j] + Dt[i][j]);
+            Pb[i][j] += Db[i][j];
+          }
+      }
+      const double dmax = blk_maxabs<BS>(Db);
+      const double pmax = blk_maxabs<BS>(Pb);
+      wave_sync();
+      blk_store_lds<BS>(Pb, M2, LD, lr, lc);
+      wave_sync();
+      if (!(dmax == dmax) || !(pmax < 1e300)) break;  // NaN / overflow: rho(T) >= 1
+      if (dmax <= 1e-17 * pmax) {
+        lyap_ok = true;
+        break;
+      }
+    }
+    blk_store_global<BS>(Pb, P0_out + off, n, n, n, lr, lc);
+    if (!lyap_ok && status && lane == 0) status[draw] |= DSGE_ST_LYAP_FAIL;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Kalman filter log-likelihood, "standard" filter (reference call
+// site gEconpy/model/statespace.py:1151-1157, a0 = 0 :812).
+//
+// Update in square-root-free downdate form.  With F = L L' (Cholesky), G = P Zm' L^-T and
+// K = G L^-1 = P Zm' F^-1, the Joseph-form covariance of the reference recursion
+//     P+ = sym((I-KZm) P (I-KZm)') + sym(K Hm K') + jitter I
+// equals, exactly in real arithmetic (F = Zm P Zm' + Hm + jitter I),
+//     P+ = P - G G' - jitter K K' + jitter I
+// which costs O(m^2 p) instead of O(m^3).  Verified against the Joseph form of the oracle to
+// ~1e-15 relative on logp (tests/test_device_algorithm_model.py).
+// Prediction:  a = T a+,  P = sym(T P+ T') + sym(RQR).
+// ---------------------------------------------------------------------------------------
+template <int BS>
+struct KfSmem {
+  static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD;
+  // Ts, Ps, Ws (NP x LD), Zs (p x LD), PZt, G, K (NP x pld), F (p x pld), vectors; pld = p|1
+  __host__ __device__ static constexpr size_t doubles(int p) {
+    return (size_t)3 * NP * LD + (size_t)p * LD + (size_t)3 * NP * (p | 1) + (size_t)p * (p | 1) + 2 * NP +
+           6 * DSGE_MAX_P;
+  }
+  static size_t bytes(int p) { return sizeof(double) * doubles(p); }
+};
+
+template <int BS>
+__global__ __launch_bounds__(64) void kalman_kernel(
+    const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
+    const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
+    const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m, int p,
+    int T_len, double jitter, double missing_fill, double* __restrict__ logp_out,
+    int32_t* __restrict__ status) {
+  constexpr int NP = KfSmem<BS>::NP, LD = KfSmem<BS>::LD, PMAX = DSGE_MAX_P;
+  const int PLD = p | 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ts = smem;
+  double* Ps = Ts + NP * LD;
+  double* Ws = Ps + NP * LD;
+  double* Zs = Ws + NP * LD;
+  double* PZt = Zs + p * LD;
+  double* Gs = PZt + NP * PLD;
+  double* Ks = Gs + NP * PLD;
+  double* Fs = Ks + NP * PLD;
+  double* av = Fs + p * PLD;  // predicted state a (NP)
+  double* af = av + NP;          // filtered state a+ (NP)
+  double* vv = af + NP;          // innovation v (PMAX)
+  double* wv = vv + PMAX;        // L^-1 v
+  double* ww = wv + PMAX;        // 1/0 observation weights
+  double* ds = ww + PMAX;        // obs intercept
+  double* hs = ds + PMAX;        // diag(H)
+  double* ys = hs + PMAX;        // masked y_t
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+  const double LN2PI = 1.8378770664093453;
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    if (status && status[draw] != 0) {
+      if (lane == 0) logp_out[draw] = -INFINITY;
+      continue;
+    }
+    const size_t off = (size_t)draw * m * m;
+    wave_sync();
+    for (int idx = lane; idx < (int)KfSmem<BS>::doubles(p); idx += 64) smem[idx] = 0.0;
+    wave_sync();
+    lds_load_matrix(Ts, LD, NP, NP, T + off, m, m, lane);
+    lds_load_matrix(Ps, LD, NP, NP, P0 + off, m, m, lane);
+    lds_load_matrix(Zs, LD, p, NP, Z + (z_batched ? (size_t)draw * p * m : 0), p, m, lane);
+    if (lane < PMAX) {
+      ds[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+      hs[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+    }
+    for (int i = lane; i < NP; i += 64) av[i] = 0.0;
+    double Qb[BS][BS], Pb[BS][BS];
+    blk_load_global<BS>(Qb, RQR + off, m, m, m, lr, lc);
+    blk_load_global<BS>(Pb, P0 + off, m, m, m, lr, lc);
+    wave_sync();
+
+    double ll_sum = 0.0, ll_comp = 0.0;  // Kahan-compensated sum of ll_t
+    for (int t = 0; t < T_len; ++t) {
+      // ---- missing-data mask (handle_missing_values): weights, masked y
+      int n_obs = 0;
+      if (lane < PMAX) {
+        double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
+        const bool miss = (lane >= p) || (yt != yt) || (yt == missing_fill);
+        ww[lane] = miss ? 0.0 : 1.0;
+        ys[lane] = miss ? 0.0 : yt;
+      }
+      {
+        double yt = (lane < p) ? y[(size_t)t * p + lane] : missing_fill;
+        const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
+        n_obs = __popcll(__ballot(obs));
+      }
+      wave_sync();
+      // ---- PZt[i][o] = w_o sum_k P[i][k] Z[o][k];  v_o = y_o - (d_o + w_o Z[o] a)
+      for (int idx = lane; idx < m * p; idx += 64) {
+        const int i = idx / p, o = idx - i * p;
+        double s = 0.0;
+        for (int kk = 0; kk < m; ++kk) s = fma(Ps[i * LD + kk], Zs[o * LD + kk], s);
+        PZt[i * PLD + o] = ww[o] * s;
+      }
+      if (lane < p) {
+        double s = 0.0;
+        for (int kk = 0; kk < m; ++kk) s = fma(Zs[lane * LD + kk], av[kk], s);
+        vv[lane] = ys[lane] - (ds[lane] + ww[lane] * s);
+      }
+      wave_sync();
+      // ---- F = Zm PZt + Hm + jitter I
+      for (int idx = lane; idx < p * p; idx += 64) {
+        const int o = idx / p, q = idx - o * p;
+        double s = 0.0;
+        for (int kk = 0; kk < m; ++kk) s = fma(Zs[o * LD + kk], PZt[kk * PLD + q], s);
+        s *= ww[o];
+        if (o == q) s += ww[o] * hs[o] + jitter;
+        Fs[o * PLD + q] = s;
+      }
+      wave_sync();
+      // ---- Cholesky F = L L' (lower, in place), column by column
+      for (int j = 0; j < p; ++j) {
+        if (lane == 0) {
+          double s = Fs[j * PLD + j];
+          for (int q = 0; q < j; ++q) s = fma(-Fs[j * PLD + q], Fs[j * PLD + q], s);
+          Fs[j * PLD + j] = sqrt(s);
+        }
+        wave_sync();
+        const int i = j + 1 + lane;
+        if (i < p) {
+          double s = Fs[i * PLD + j];
+          for (int q = 0; q < j; ++q) s = fma(-Fs[i * PLD + q], Fs[j * PLD + q], s);
+          Fs[i * PLD + j] = s / Fs[j * PLD + j];
+        }
+        wave_sync();
+      }
+      // ---- w = L^-1 v (lane 0), G = PZt L^-T and K = G L^-1 (one row per lane)
+      if (lane == 0) {
+        for (int o = 0; o < p; ++o) {
+          double s = vv[o];
+          for (int q = 0; q < o; ++q) s = fma(-Fs[o * PLD + q], wv[q], s);
+          wv[o] = s / Fs[o * PLD + o];
+        }
+      }
+      for (int i = lane; i < m; i += 64) {
+        // forward substitution: L g = PZt[i,:]'
+        for (int o = 0; o < p; ++o) {
+          double s = PZt[i * PLD + o];
+          for (int q = 0; q < o; ++q) s = fma(-Fs[o * PLD + q], Gs[i * PLD + q], s);
+          Gs[i * PLD + o] = s / Fs[o * PLD + o];
+        }
+        // back substitution: L' k = g
+        for (int o = p - 1; o >= 0; --o) {
+          double s = Gs[i * PLD + o];
+          for (int q = o + 1; q < p; ++q) s = fma(-Fs[q * PLD + o], Ks[i * PLD + q], s);
+          Ks[i * PLD + o] = s / Fs[o * PLD + o];
+        }
+      }
+      wave_sync();
+      // ---- log-likelihood of the step
+      {
+        double logdet = 0.0, inner = 0.0;
+        for (int o = 0; o < p; ++o) {
+          logdet += log(Fs[o * PLD + o]);
+          inner = fma(wv[o], wv[o], inner);
+        }
+        const double ll = (n_obs == 0) ? 0.0 : -0.5 * ((double)p * LN2PI + 2.0 * logdet + inner);
+        const double yk = ll - ll_comp;
+        const double tk = ll_sum + yk;
+        ll_comp = (tk - ll_sum) - yk;
+        ll_sum = tk;
+      }
+      // ---- a+ = a + G w
+      for (int i = lane; i < m; i += 64) {
+        double s = av[i];
+        for (int o = 0; o < p; ++o) s = fma(Gs[i * PLD + o], wv[o], s);
+        af[i] = s;
+      }
+      // ---- P+ = P - G G' - jitter K K' + jitter I   (register blocks)
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int r = lr * BS + i, c = lc * BS + j;
+          double gg = 0.0, kk2 = 0.0;
+          for (int o = 0; o < p; ++o) {
+            gg = fma(Gs[r * PLD + o], Gs[c * PLD + o], gg);
+            kk2 = fma(Ks[r * PLD + o], Ks[c * PLD + o], kk2);
+          }
+          double v = Pb[i][j] - gg - jitter * kk2;
+          if (r == c && r < m) v += jitter;
+          Pb[i][j] = v;
+        }
+      wave_sync();
+      blk_store_lds<BS>(Pb, Ps, LD, lr, lc);  // P+ as the operand of the prediction
+      wave_sync();
+      // ---- predict: a = T a+;  W = P+ T';  X = T W;  P = sym(X) + RQR
+      for (int i = lane; i < m; i += 64) {
+        double s = 0.0;
+        for (int kk = 0; kk < m; ++kk) s = fma(Ts[i * LD + kk], af[kk], s);
+        av[i] = s;
+      }
+      double Wb[BS][BS];
+      blk_zero<BS>(Wb);
+      mm_acc<BS, true>(Wb, Ps, LD, Ts, LD, m, lr, lc);
+      blk_store_lds<BS>(Wb, Ws, LD, lr, lc);
+      wave_sync();
+      blk_zero<BS>(Pb);
+      mm_acc<BS, false>(Pb, Ts, LD, Ws, LD, m, lr, lc);
+      blk_store_lds<BS>(Pb, Ps, LD, lr, lc);  // X (P+ no longer needed)
+      wave_sync();
+      {
+        double Xt[BS][BS];
+        blk_load_lds_t<BS>(Xt, Ps, LD, lr, lc);
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) Pb[i][j] = 0.5 * (Pb[i][j] + Xt[i][j]) + Qb[i][j];
+      }
+      wave_sync();
+      blk_store_lds<BS>(Pb, Ps, LD, lr, lc);
+      // the wave_sync at the top of the next step orders this store before its readers
+    }
+    if (lane == 0) {
+      const bool finite = (ll_sum == ll_sum) && (fabs(ll_sum) < 1.797e308);
+      logp_out[draw] = ll_sum;
+      if (!finite && status) status[draw] |= DSGE_ST_FILTER_NONFINITE;
+    }
+  }
+}
+
+}  // namespace dsge

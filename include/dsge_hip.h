@@ -1,0 +1,192 @@
+/*
+ * dsge_hip.h -- C ABI of libdsge_hip.so, the MI355X (gfx950) batched engine for gEconpy's
+ * estimation hot path: first-order perturbation solve + Kalman-filter log-likelihood,
+ * evaluated for a batch of parameter draws per call.
+ *
+ * Conventions (reference conventions cited per entry point):
+ *   - every matrix is float64, row-major, contiguous: [batch][rows][cols];
+ *     the reference coerces with np.ascontiguousarray(..., float64)
+ *     (gEconpy/solvers/gensys.py:505-509,625-628) and asserts C order
+ *     (gEconpy/model/model.py:2000);
+ *   - A,B,C,D arrive in solver order and T,R are returned in that order; the library
+ *     applies no variable permutation (the caller un-permutes exactly as
+ *     gEconpy/model/statespace.py:217-220 does);
+ *   - the caller owns every input and output buffer; inputs are never written
+ *     (gEconpy/solvers/cycle_reduction.py:134-136); scratch is library-owned;
+ *   - numerical failure of a draw is a VALUE, never an error return: per-draw status
+ *     words / eu codes, zero-filled T, logp = -inf (gensys.py:255-265,
+ *     cycle_reduction.py:181, statespace.py:1206-1215).  The int return value is non-zero
+ *     only when the CALL is malformed or HIP fails; dsge_last_error() describes it;
+ *   - entry points without suffix take DEVICE pointers and a hipStream_t (passed as
+ *     void*, NULL = default stream) and only enqueue work; the *_host twins take HOST
+ *     pointers, stage through library-owned device buffers and return after completion.
+ *
+ * The library refuses to run (DSGE_ERR_HIP) when no gfx950 device is present; there is no
+ * CPU fallback.
+ */
+#ifndef DSGE_HIP_H
+#define DSGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSGE_ABI_VERSION 1
+
+/* limits of this build */
+#define DSGE_MAX_N 64      /* model variables n == Kalman states m (cycle reduction: 48) */
+#define DSGE_MAX_N_CR 48
+#define DSGE_MAX_P 16      /* observed series */
+
+/* call-level return codes */
+#define DSGE_SUCCESS 0
+#define DSGE_ERR_INVALID 1     /* bad size / null pointer / unsupported option */
+#define DSGE_ERR_HIP 2         /* HIP runtime error or no usable device */
+
+/* per-draw status bits (int32) */
+#define DSGE_ST_OK 0
+#define DSGE_ST_NOT_CONVERGED 1   /* cycle reduction hit max_iter / gensys eu != [1,1]      */
+#define DSGE_ST_NAN 2             /* NaN met in the solver (cycle_reduction.py:176-177)      */
+#define DSGE_ST_LYAP_FAIL 4       /* doubling iteration for P0 did not converge (rho(T)>=1)  */
+#define DSGE_ST_FILTER_NONFINITE 8 /* non-finite log-likelihood (F not positive definite...) */
+
+/* covariance layouts for the Q argument */
+#define DSGE_Q_DIAG_SHARED 0    /* Q = diag(q), q: [k]            */
+#define DSGE_Q_DIAG_BATCHED 1   /* q: [batch][k]  (statespace.py:240-258, sigma_i^2)          */
+#define DSGE_Q_FULL_SHARED 2    /* Q: [k][k]                                                  */
+#define DSGE_Q_FULL_BATCHED 3   /* Q: [batch][k][k] (full_covariance, statespace.py:247-251)  */
+
+/* solver selector of the fused entry point (statespace.py:197-207) */
+#define DSGE_SOLVER_CYCLE_REDUCTION 0
+#define DSGE_SOLVER_GENSYS 1
+#define DSGE_SOLVER_BACKWARD_DIRECT 2
+
+int dsge_abi_version(void);
+const char* dsge_last_error(void);
+/* number of visible gfx950 devices (0 if none); never throws */
+int dsge_device_count(void);
+int dsge_set_device(int device);
+/* blocks until all work enqueued on `stream` has finished */
+int dsge_stream_synchronize(void* stream);
+
+/*
+ * Cycle reduction, batched.  Replaces _cycle_reduction_core / CycleReductionWrapper.perform
+ * (gEconpy/solvers/cycle_reduction.py:127-183, :206-210): solves A + B T + C T^2 = 0.
+ *   A,B,C : [batch][n][n]      T_out : [batch][n][n] (zeros where not converged, :181)
+ *   status: [batch] DSGE_ST_*  n_iter: [batch] iterations used (may be NULL)
+ * Stopping rule of the njit variant (:171-177): ||A0||_1 < tol and ||A2||_1 < tol.
+ */
+int dsge_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n,
+                                 int max_iter, double tol, double* T_out, int32_t* status,
+                                 int32_t* n_iter, void* stream);
+int dsge_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
+                                      int max_iter, double tol, double* T_out, int32_t* status,
+                                      int32_t* n_iter);
+
+/*
+ * Shock-impact matrix and policy residual.  Replaces pt_compute_selection_matrix
+ * (gEconpy/solvers/shared.py:74-75; numpy twin cycle_reduction.py:395-396) and the residual
+ * of DSGEStateSpace._setup_policy_matrices (gEconpy/model/statespace.py:213):
+ *   R = -(C T + B)^-1 D            R_out    : [batch][n][k]
+ *   resid = sum((A + B T + C T T)^2)  resid_out: [batch] (NULL to skip; then A may be NULL)
+ */
+int dsge_selection_batched(const double* A, const double* B, const double* C, const double* D,
+                           const double* T, int batch, int n, int k, double* R_out, double* resid_out,
+                           void* stream);
+int dsge_selection_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                const double* T, int batch, int n, int k, double* R_out,
+                                double* resid_out);
+
+/*
+ * Backward-looking direct solve.  Replaces solve_policy_function_with_backward_direct
+ * (gEconpy/solvers/backward_looking.py:102-134): T = (-B)^-1 A, R = -B^-1 D.
+ */
+int dsge_backward_direct_batched(const double* A, const double* B, const double* D, int batch, int n,
+                                 int k, double* T_out, double* R_out, void* stream);
+int dsge_backward_direct_batched_host(const double* A, const double* B, const double* D, int batch,
+                                      int n, int k, double* T_out, double* R_out);
+
+/*
+ * Stationary state covariance.  Replaces
+ *   P0 = solve_discrete_lyapunov(T, R Q R^T)        (gEconpy/model/statespace.py:814-815)
+ * by the doubling (Smith) iteration; also returns sym(R Q R^T).
+ *   T : [batch][m][m]  R : [batch][m][k]  Q per q_mode
+ *   P0_out, RQR_out : [batch][m][m] (RQR_out may be NULL)   status |= DSGE_ST_LYAP_FAIL
+ */
+int dsge_lyapunov_batched(const double* T, const double* R, const double* Q, int q_mode, int batch,
+                          int m, int k, double* P0_out, double* RQR_out, int32_t* status, void* stream);
+int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q, int q_mode, int batch,
+                               int m, int k, double* P0_out, double* RQR_out, int32_t* status);
+
+/*
+ * Kalman-filter log-likelihood, batched over draws, "standard" filter.  Replaces the scan
+ * that PyMCStateSpace.build_statespace_graph builds for DSGEStateSpace
+ * (gEconpy/model/statespace.py:1151-1157; recursion restated in SURVEY.md Appendix B.4)
+ * with a0 = 0 (statespace.py:812), state intercept c = 0 and P0 = dlyap(T, R Q R^T).
+ *   T : [batch][m][m]   R : [batch][m][k]   Q per q_mode
+ *   Z : [p][m] (z_batched=0) or [batch][p][m]     (statespace.py:260-332)
+ *   d : NULL (=0), [p] or [batch][p]              (statespace.py:334-388)
+ *   Hdiag : NULL (=0), [p] or [batch][p]          (statespace.py:800-810)
+ *   y : [T_len][p] shared by all draws; NaN or == missing_fill marks a missing entry
+ *       (statespace.py:1143)
+ *   status_io : [batch] in/out.  A draw whose incoming status is non-zero is skipped and
+ *       gets logp = -inf (the -inf Potentials of statespace.py:1206-1215).
+ *   logp_out  : [batch]
+ */
+int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, int q_mode,
+                             const double* Z, int z_batched, const double* d, int d_batched,
+                             const double* Hdiag, int h_batched, const double* y, int batch, int m,
+                             int k, int p, int T_len, double jitter, double missing_fill,
+                             double* logp_out, int32_t* status_io, void* stream);
+int dsge_kalman_logp_batched_host(const double* T, const double* R, const double* Q, int q_mode,
+                                  const double* Z, int z_batched, const double* d, int d_batched,
+                                  const double* Hdiag, int h_batched, const double* y, int batch,
+                                  int m, int k, int p, int T_len, double jitter, double missing_fill,
+                                  double* logp_out, int32_t* status_io);
+
+/*
+ * Fused evaluation A,B,C,D -> T,R -> P0 -> logp: one call per MCMC step for the whole draw
+ * batch (the per-evaluation hot loop of SURVEY.md section 3A; what
+ * DSGEStateSpace._setup_policy_matrices + make_symbolic_graph + the filter compute,
+ * statespace.py:197-222,725-820,1151-1157).  Intermediate T,R,P0 stay in library scratch
+ * unless the optional outputs are given.
+ *   solver : DSGE_SOLVER_*; tol/max_iter as configure(...) passes them (statespace.py:835-836)
+ *   T_out [batch][n][n], R_out [batch][n][k], resid_out [batch], n_iter_out [batch]: optional
+ *   status_out : [batch] (required)    logp_out : [batch] (required)
+ */
+int dsge_solve_kalman_logp_batched(const double* A, const double* B, const double* C, const double* D,
+                                   const double* Q, int q_mode, const double* Z, int z_batched,
+                                   const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                   const double* y, int batch, int n, int k, int p, int T_len,
+                                   int solver, double tol, int max_iter, double jitter,
+                                   double missing_fill, double* logp_out, int32_t* status_out,
+                                   double* T_out, double* R_out, double* resid_out,
+                                   int32_t* n_iter_out, void* stream);
+int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const double* C,
+                                        const double* D, const double* Q, int q_mode, const double* Z,
+                                        int z_batched, const double* d, int d_batched,
+                                        const double* Hdiag, int h_batched, const double* y, int batch,
+                                        int n, int k, int p, int T_len, int solver, double tol,
+                                        int max_iter, double jitter, double missing_fill,
+                                        double* logp_out, int32_t* status_out, double* T_out,
+                                        double* R_out, double* resid_out, int32_t* n_iter_out);
+
+/*
+ * Timing hook for bench.py: runs `reps` back-to-back launches of the fused pipeline's
+ * kernels on `stream` bracketed by hipEvents and reports the average duration of each
+ * kernel in milliseconds: ms_out[0] = solver, [1] = selection+Lyapunov, [2] = Kalman.
+ * Same arguments as dsge_solve_kalman_logp_batched (device pointers).
+ */
+int dsge_profile_pipeline(const double* A, const double* B, const double* C, const double* D,
+                          const double* Q, int q_mode, const double* Z, int z_batched, const double* d,
+                          int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                          int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                          double jitter, double missing_fill, double* logp_out, int32_t* status_out,
+                          int reps, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSGE_HIP_H */
