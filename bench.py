@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark: solve + Kalman-logp evaluations per second on Smets-Wouters-shaped systems.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the fused pipeline (cycle reduction -> selection/Lyapunov -> Kalman
+filter) over the rank's shard of parameter draws, inputs already resident in HBM, followed
+(N > 1) by the RCCL all-gather of per-draw logp/status.  Per-GPU shard is fixed (weak scaling):
+4096 draws of the SW-shaped workload (n = 40 variables, 7 shocks, 7 observables, T = 200;
+BASELINE.json configs[2]).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector == FP64 matrix peak (AMD datasheet)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_flops(n, k, p, T_len, cr_iters=7.0, lyap_doublings=12):
+    """SURVEY.md section 8(d) formulas (the reference formulation), per evaluation."""
+    m = n
+    kalman = T_len * (8 * m**3 + 6 * m**2 * p + 6 * m * p**2 + p**3 / 3.0)
+    lyap = lyap_doublings * 6 * m**3
+    sel = (2 + 2.0 / 3.0) * n**3 + 2 * n**2 * k + 4 * n**3
+    cr = 12.7 * n**3 * cr_iters + 2.7 * n**3
+    return dict(kalman=kalman, lyapunov=lyap, selection=sel, solver=cr, total=kalman + lyap + sel + cr)
+
+
+def executed_kalman_flops(m, p, T_len):
+    """What kalman_kernel actually executes per draw (downdate form instead of Joseph):
+    predict 4 m^3 + 2 m^2, P Z' 2 m^2 p, F 2 m p^2, G/K 2 m p^2, downdate 4 m^2 p, misc."""
+    return T_len * (4 * m**3 + 2 * m**2 + 2 * m**2 * p + 2 * m * p**2 + 2 * m * p**2 + 4 * m**2 * p + p**3 / 3.0)
+
+
+def algorithmic_bytes(n, k, p):
+    """Compulsory HBM bytes per evaluation: inputs A,B,C,D + q + outputs."""
+    return (3 * n * n + n * k + k + p) * 8 + 12
+
+
+def _cpu_worker(args):
+    import oracle
+
+    A, B, C, D, q, Z, y, Hd = args
+    r = oracle.solve_kalman_logp(A, B, C, D, np.diag(q), Z, y, H=np.diag(Hd), solver="cycle_reduction", tol=1e-8,
+                                 max_iter=1000)
+    return r["logp"]
+
+
+def cpu_baseline(batch, om, n_sample, cores):
+    """Time the CPU oracle (numpy/scipy port of the reference path) on a bounded sample of the
+    same workload, one process per host core with single-threaded BLAS."""
+    import multiprocessing as mp
+
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    os.environ["MKL_NUM_THREADS"] = "1"
+    jobs = [
+        (batch["A"][i], batch["B"][i], batch["C"][i], batch["D"][i], batch["sigma"][i] ** 2, om["Z"], om["y"],
+         om["Hdiag"])
+        for i in range(n_sample)
+    ]
+    ctx = mp.get_context("spawn")  # never fork a process that has initialised the GPU
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, jobs[: min(cores, n_sample)])  # warm-up: imports, page-in
+        t0 = time.perf_counter()
+        logp = pool.map(_cpu_worker, jobs, chunksize=max(1, n_sample // (4 * cores)))
+        dt = time.perf_counter() - t0
+    return np.array(logp), n_sample / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=192, help="evaluations timed on the host cores (0 = skip)")
+    ap.add_argument("--profile-reps", type=int, default=3)
+    ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--max-iter", type=int, default=1000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    # CPU baseline first (rank 0, N = 1 only), in spawned workers, before this process touches the GPU
+    from geconpy_amd import workloads as wl
+
+    sh = wl.SW_SHAPE
+    n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
+    per_gpu = args.batch_per_gpu
+    global_batch = per_gpu * world
+    lo, hi = wl.shard_bounds(global_batch, world, rank)
+    om = wl.sw_shaped_observation_model()
+    shard = wl.sw_shaped_batch(hi - lo, first_draw=lo)
+
+    cpu = None
+    cpu_logp = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cores = os.cpu_count() or 1
+        n_sample = min(max(args.cpu_sample, 4 * cores), hi - lo)
+        cpu_logp, cpu_rate, cpu_dt = cpu_baseline(shard, om, n_sample, cores)
+        cpu = {
+            "value": round(cpu_rate, 3),
+            "unit": "evals/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"first {n_sample} draws of the same SW-shaped batch, numpy/scipy oracle "
+                      f"(cycle reduction + bilinear Lyapunov + Joseph-form Kalman), {cores} worker processes x 1 BLAS "
+                      f"thread, {cpu_dt:.1f} s wall",
+        }
+
+    import torch
+    import torch.distributed as dist
+
+    from geconpy_amd.engine import LogpEngine, ShardedLogpEvaluator
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    eng = LogpEngine(device)
+    dA, dB, dC, dD = (eng.to_device(shard[x]) for x in "ABCD")
+    dq = eng.to_device(shard["sigma"] ** 2)
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
+    nloc = hi - lo
+    logp_buf = torch.empty(nloc, dtype=torch.float64, device=device)
+    stat_buf = torch.empty(nloc, dtype=torch.int32, device=device)
+
+    def local_eval(lo_, hi_):
+        return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
+                                     max_iter=args.max_iter, logp=logp_buf, status=stat_buf)
+
+    ev = ShardedLogpEvaluator(global_batch, local_eval, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ev.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logp_all, stat_all = ev.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    logp_host = logp_all.cpu().numpy()
+    stat_host = stat_all.cpu().numpy()
+    n_fail = int((stat_host != 0).sum())
+
+    # per-kernel durations, HIP events on the launch stream (rank 0's shard)
+    kms = eng.profile_kernels(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter,
+                              reps=args.profile_reps)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        flops = algorithmic_flops(n, k, p, T_len)
+        kal_s = kms["kalman"] * 1e-3
+        achieved = flops["kalman"] * nloc / kal_s / 1e12
+        exec_tf = executed_kalman_flops(n, p, T_len) * nloc / kal_s / 1e12
+        total_kernel_s = (kms["solver"] + kms["assemble"] + kms["kalman"]) * 1e-3
+        b_eval = algorithmic_bytes(n, k, p)
+        value = global_batch * args.steps / dt
+        out = {
+            "metric": "solve+Kalman-logp evals/sec, Smets-Wouters n~40 T=200",
+            "value": round(value, 2),
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"sw_shaped synthetic (SURVEY 8d): n=m={n}, n_state=18, n_lead=12, k={k}, p={p}, "
+                            f"T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[2])",
+                "global_batch": global_batch,
+                "solver": "cycle_reduction",
+                "tol": args.tol,
+                "parallelism": f"draw-sharded x{world}, all_gather(logp,status)" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "dsge::kalman_kernel<5>",
+                "bound": "mfma",
+                "pipe": "fp64 VALU FMA (same peak rate as v_mfma_f64 on gfx950)",
+                "achieved": round(achieved, 4),
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / FP64_PEAK_TFLOPS, 5),
+                "traffic": None,
+                "algorithmic_flops_per_eval": flops["kalman"],
+                "executed_tflops": round(exec_tf, 4),
+                "executed_frac": round(exec_tf / FP64_PEAK_TFLOPS, 5),
+                "kernel_ms": {k_: round(v, 4) for k_, v in kms.items()},
+                "whole_eval_algorithmic_tflops": round(flops["total"] * nloc / total_kernel_s / 1e12, 4),
+                "hbm": {
+                    "algorithmic_bytes_per_eval": b_eval,
+                    "achieved_GBs": round(b_eval * nloc / total_kernel_s / 1e9, 3),
+                    "peak_GBs": HBM_PEAK_GBS,
+                    "frac": round(b_eval * nloc / total_kernel_s / 1e9 / HBM_PEAK_GBS, 7),
+                },
+            },
+            "failed_draws": n_fail,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            ns = len(cpu_logp)
+            rel = np.abs(logp_host[:ns] - cpu_logp) / np.abs(cpu_logp)
+            out["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel.max()), "n_checked": ns}
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

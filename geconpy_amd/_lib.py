@@ -75,6 +75,15 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m geconpy_amd.build` "
             "(there is no CPU fallback for the HIP engine)"
         )
+    # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64 (soname
+    # libamdhip64.so.7, but linked by the name "libamdhip64.so").  If this library were loaded
+    # first it would pull /opt/rocm's copy and a later `import torch` would load a SECOND
+    # runtime, after which one of the two sees no device.  Importing torch first makes our
+    # NEEDED libamdhip64.so.7 resolve to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
