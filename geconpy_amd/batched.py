@@ -148,8 +148,25 @@ def _obs_args(Z, d, Hdiag, nb, p, m):
     return Z, zb, d, db, Hdiag, hb
 
 
+def state_hint(M):
+    """Performance hint: number of columns of ``M`` (A or T, any leading batch axes) that are
+    non-zero in at least one draw -- the model's state variables."""
+    M = np.asarray(M)
+    return int(np.count_nonzero(np.any(M != 0, axis=tuple(range(M.ndim - 1)))))
+
+
+def selector_hint(Z):
+    """Performance hint: 1 if every row of Z has exactly one non-zero entry, in distinct columns."""
+    Z2 = np.asarray(Z).reshape(-1, Z.shape[-2], Z.shape[-1])
+    nz = Z2 != 0
+    one_per_row = np.all(nz.sum(axis=2) == 1)
+    distinct = np.all(nz.sum(axis=1) <= 1)
+    return int(bool(one_per_row and distinct))
+
+
 def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None,
-                        jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL):
+                        jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
+                        z_selector_hint=None):
     """Per-draw Kalman log-likelihood (the filter DSGEStateSpace hands to PyMC,
     gEconpy/model/statespace.py:1151-1157) -> (logp, status)."""
     T, R = _f64(T, 3), _f64(R, 3)
@@ -161,10 +178,12 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
     Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, m)
     st = np.zeros(nb, dtype=np.int32) if status is None else np.ascontiguousarray(status, dtype=np.int32).copy()
     logp = np.empty(nb)
+    ns = state_hint(T) if n_state_hint is None else int(n_state_hint)
+    zs = selector_hint(Z) if z_selector_hint is None else int(z_selector_hint)
     _lib.check(
         _lib.load().dsge_kalman_logp_batched_host(
             _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len,
-            float(jitter), float(missing_fill_value), _ptr(logp), _ptr(st)
+            float(jitter), float(missing_fill_value), ns, zs, _ptr(logp), _ptr(st)
         )
     )
     return logp, st
@@ -172,7 +191,7 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
 
 def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                               tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
-                              return_policy=False):
+                              return_policy=False, n_state_hint=None, z_selector_hint=None):
     """One fused evaluation per draw: A,B,C,D -> T,R -> P0 -> logp.  ``tol``/``max_iter``
     default to what ``DSGEStateSpace.configure`` passes (statespace.py:835-836).
     Returns dict(logp, status[, T, R, resid, n_iter])."""
@@ -192,11 +211,13 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
         R = np.empty((nb, n, k))
         resid = np.empty(nb)
         n_iter = np.empty(nb, dtype=np.int32)
+    ns = state_hint(A) if n_state_hint is None else int(n_state_hint)
+    zs = selector_hint(Z) if z_selector_hint is None else int(z_selector_hint)
     _lib.check(
         _lib.load().dsge_solve_kalman_logp_batched_host(
             _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb,
             n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter),
-            float(missing_fill_value), _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
+            float(missing_fill_value), ns, zs, _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
         )
     )
     out = dict(logp=logp, status=status)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "dsge_kernels.hpp"
+#include "dsge_kalman2.hpp"
 
 namespace {
 
@@ -169,16 +170,37 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
 
 int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
-                  int m, int p, int T_len, double jitter, double missing_fill, double* logp, int32_t* status,
-                  hipStream_t st) {
+                  int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
+                  double* logp, int32_t* status, hipStream_t st) {
   const int bs = tile_bs(m);
   int rc = DSGE_ERR_INVALID;
+  // Fast path: selector Z, p <= 8, compact state block of at most s_cap columns.  Draws that
+  // violate a hint come back flagged and are re-run by the general kernel below.
+  const bool fast = z_selector_hint && p <= 8;
+  if (fast) {
+    DISPATCH_BS(bs, 8, {
+      constexpr int NP = 8 * BS;
+      int s_cap = (n_state_hint > 0 && n_state_hint < NP) ? ((n_state_hint + BS - 1) / BS) * BS : NP;
+      if (s_cap > NP) s_cap = NP;
+      const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap);
+      rc = set_lds(dsge::kalman_sel_kernel<BS>, lds);
+      if (rc == DSGE_SUCCESS) {
+        hipLaunchKernelGGL(dsge::kalman_sel_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
+                           d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter, missing_fill, logp,
+                           status);
+        HIP_TRY(hipGetLastError());
+      }
+    });
+    if (rc) return rc;
+  }
+  rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 8, {
     const size_t lds = dsge::KfSmem<BS>::bytes(p);
     rc = set_lds(dsge::kalman_kernel<BS>, lds);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
-                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status);
+                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status,
+                         fast ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
   });
@@ -291,7 +313,8 @@ int dsge_lyapunov_batched(const double* T, const double* R, const double* Q, int
 int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
                              int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
                              const double* y, int batch, int m, int k, int p, int T_len, double jitter,
-                             double missing_fill, double* logp_out, int32_t* status_io, void* stream) {
+                             double missing_fill, int n_state_hint, int z_selector_hint, double* logp_out,
+                             int32_t* status_io, void* stream) {
   int rc = check_common(batch, m, DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
@@ -312,14 +335,15 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
                             status_io, 0, 1, st)))
     return rc;
   return launch_kalman(T, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter,
-                       missing_fill, logp_out, status_io, st);
+                       missing_fill, n_state_hint, z_selector_hint, logp_out, status_io, st);
 }
 
 static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
                     const double* Z, int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
                     const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
-                    double jitter, double missing_fill, double* logp_out, int32_t* status_out, double* T_out,
-                    double* R_out, double* resid_out, int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out) {
+                    double jitter, double missing_fill, int n_state_hint, int z_selector_hint, double* logp_out,
+                    int32_t* status_out, double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out,
+                    hipStream_t st, int reps, float* ms_out) {
   int rc = check_common(batch, n, solver == DSGE_SOLVER_CYCLE_REDUCTION ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
@@ -364,7 +388,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
       return rc;
     if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
     if ((rc = launch_kalman(Tw, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
-                            missing_fill, logp_out, status_out, st)))
+                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st)))
       return rc;
     if (ms_out) {
       HIP_TRY(hipEventRecord(ev[3], st));
@@ -387,22 +411,24 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                                    int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
                                    const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
                                    int T_len, int solver, double tol, int max_iter, double jitter, double missing_fill,
-                                   double* logp_out, int32_t* status_out, double* T_out, double* R_out,
-                                   double* resid_out, int32_t* n_iter_out, void* stream) {
+                                   int n_state_hint, int z_selector_hint, double* logp_out, int32_t* status_out,
+                                   double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out,
+                                   void* stream) {
   return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
-                  tol, max_iter, jitter, missing_fill, logp_out, status_out, T_out, R_out, resid_out, n_iter_out,
-                  (hipStream_t)stream, 1, nullptr);
+                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, T_out,
+                  R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
 }
 
 int dsge_profile_pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q,
                           int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
                           const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
                           int T_len, int solver, double tol, int max_iter, double jitter, double missing_fill,
-                          double* logp_out, int32_t* status_out, int reps, float* ms_out, void* stream) {
+                          int n_state_hint, int z_selector_hint, double* logp_out, int32_t* status_out, int reps,
+                          float* ms_out, void* stream) {
   if (!ms_out || reps < 1) return fail(DSGE_ERR_INVALID, "ms_out null or reps < 1");
   return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
-                  tol, max_iter, jitter, missing_fill, logp_out, status_out, nullptr, nullptr, nullptr, nullptr,
-                  (hipStream_t)stream, reps, ms_out);
+                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, nullptr,
+                  nullptr, nullptr, nullptr, (hipStream_t)stream, reps, ms_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -528,7 +554,8 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
 int dsge_kalman_logp_batched_host(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
                                   int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
                                   const double* y, int batch, int m, int k, int p, int T_len, double jitter,
-                                  double missing_fill, double* logp_out, int32_t* status_io) {
+                                  double missing_fill, int n_state_hint, int z_selector_hint, double* logp_out,
+                                  int32_t* status_io) {
   int rc = check_common(batch, m, DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
@@ -559,7 +586,7 @@ int dsge_kalman_logp_batched_host(const double* T, const double* R, const double
   UP(dS, status_io, batch, int32_t);
   OUTBUF(dL, logp_out, batch, double);
   if ((rc = dsge_kalman_logp_batched(dT, dR, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy, batch, m, k,
-                                     p, T_len, jitter, missing_fill, dL, dS, nullptr)))
+                                     p, T_len, jitter, missing_fill, n_state_hint, z_selector_hint, dL, dS, nullptr)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_io, dS, batch, int32_t);
@@ -571,8 +598,9 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         const double* Q, int q_mode, const double* Z, int z_batched, const double* d,
                                         int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                                         int n, int k, int p, int T_len, int solver, double tol, int max_iter,
-                                        double jitter, double missing_fill, double* logp_out, int32_t* status_out,
-                                        double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out) {
+                                        double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
+                                        double* logp_out, int32_t* status_out, double* T_out, double* R_out,
+                                        double* resid_out, int32_t* n_iter_out) {
   int rc = check_common(batch, n, DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
@@ -609,8 +637,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   OUTBUF(dRes, resid_out, batch, double);
   OUTBUF(dI, n_iter_out, batch, int32_t);
   if ((rc = dsge_solve_kalman_logp_batched(dA, dB, dC, dD, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy,
-                                           batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill, dL, dS,
-                                           dT, dR, dRes, dI, nullptr)))
+                                           batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
+                                           n_state_hint, z_selector_hint, dL, dS, dT, dR, dRes, dI, nullptr)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_out, dS, batch, int32_t);

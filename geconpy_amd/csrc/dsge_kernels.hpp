@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64) void kalman_kernel(
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m, int p,
     int T_len, double jitter, double missing_fill, double* __restrict__ logp_out,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, int rerun_only) {
   constexpr int NP = KfSmem<BS>::NP, LD = KfSmem<BS>::LD, PMAX = DSGE_MAX_P;
   const int PLD = p | 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -406,7 +406,12 @@ __global__ __launch_bounds__(64) void kalman_kernel(
   const double LN2PI = 1.8378770664093453;
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    if (status && status[draw] != 0) {
+    if (rerun_only) {
+      // second pass after kalman_sel_kernel: only the draws it could not handle
+      if (status[draw] != (1 << 30)) continue;
+      wave_sync();
+      if (lane == 0) status[draw] = 0;
+    } else if (status && status[draw] != 0) {
       if (lane == 0) logp_out[draw] = -INFINITY;
       continue;
     }

@@ -82,10 +82,19 @@ class LogpEngine:
         hb = int(Hdiag is not None and self._chk(Hdiag).dim() == 2)
         return nb, n, k, p, T_len, int(q_mode), zb, db, hb
 
+    def structure_hints(self, A, Z):
+        """(n_state_hint, z_selector_hint) from device tensors: one small reduction + host sync;
+        the structure is a property of the model, so call this once, not per step."""
+        torch = self.torch
+        n_state = int(torch.count_nonzero((A != 0).reshape(-1, A.shape[-1]).any(dim=0)).item())
+        nz = (Z != 0).reshape(-1, Z.shape[-2], Z.shape[-1])
+        sel = bool(((nz.sum(dim=2) == 1).all() & (nz.sum(dim=1) <= 1).all()).item())
+        return n_state, int(sel)
+
     # -- product entry points --------------------------------------------------------------
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
-                          logp=None, status=None):
+                          logp=None, status=None, n_state_hint=0, z_selector_hint=0):
         """Enqueue one fused evaluation of the whole batch; returns (logp, status) tensors
         (asynchronous: synchronize the stream before reading them on the host)."""
         torch = self.torch
@@ -98,14 +107,15 @@ class LogpEngine:
             self.lib.dsge_solve_kalman_logp_batched(
                 self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol),
-                int(max_iter), float(jitter), float(missing_fill_value), self._p(logp), status.data_ptr(), None, None,
-                None, None, self._stream(),
+                int(max_iter), float(jitter), float(missing_fill_value), int(n_state_hint), int(z_selector_hint),
+                self._p(logp), status.data_ptr(), None, None, None, None, self._stream(),
             )
         )
         return logp, status
 
     def profile_kernels(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
-                        tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, reps=5):
+                        tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, reps=5,
+                        n_state_hint=0, z_selector_hint=0):
         """Average per-kernel durations (ms) measured with HIP events on the launch stream:
         dict(solver=, assemble=, kalman=)."""
         import ctypes
@@ -119,8 +129,8 @@ class LogpEngine:
             self.lib.dsge_profile_pipeline(
                 self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol),
-                int(max_iter), float(jitter), float(missing_fill_value), self._p(logp), status.data_ptr(), int(reps),
-                ctypes.addressof(ms), self._stream(),
+                int(max_iter), float(jitter), float(missing_fill_value), int(n_state_hint), int(z_selector_hint),
+                self._p(logp), status.data_ptr(), int(reps), ctypes.addressof(ms), self._stream(),
             )
         )
         return dict(solver=float(ms[0]), assemble=float(ms[1]), kalman=float(ms[2]))

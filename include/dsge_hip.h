@@ -134,17 +134,25 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
  *   status_io : [batch] in/out.  A draw whose incoming status is non-zero is skipped and
  *       gets logp = -inf (the -inf Potentials of statespace.py:1206-1215).
  *   logp_out  : [batch]
+ * Performance hints (never affect results; each is verified per draw on the device and a draw
+ * that violates one is re-run by the general kernel):
+ *   n_state_hint    : upper bound on the number of non-zero columns of T (the model's state
+ *                     variables, i.e. non-zero columns of A); 0 = unknown
+ *   z_selector_hint : non-zero if every row of Z has exactly one non-zero entry, in distinct
+ *                     columns (the pure-selector design of statespace.py:282-296)
  */
 int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, int q_mode,
                              const double* Z, int z_batched, const double* d, int d_batched,
                              const double* Hdiag, int h_batched, const double* y, int batch, int m,
                              int k, int p, int T_len, double jitter, double missing_fill,
-                             double* logp_out, int32_t* status_io, void* stream);
+                             int n_state_hint, int z_selector_hint, double* logp_out,
+                             int32_t* status_io, void* stream);
 int dsge_kalman_logp_batched_host(const double* T, const double* R, const double* Q, int q_mode,
                                   const double* Z, int z_batched, const double* d, int d_batched,
                                   const double* Hdiag, int h_batched, const double* y, int batch,
                                   int m, int k, int p, int T_len, double jitter, double missing_fill,
-                                  double* logp_out, int32_t* status_io);
+                                  int n_state_hint, int z_selector_hint, double* logp_out,
+                                  int32_t* status_io);
 
 /*
  * Fused evaluation A,B,C,D -> T,R -> P0 -> logp: one call per MCMC step for the whole draw
@@ -161,7 +169,8 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                                    const double* d, int d_batched, const double* Hdiag, int h_batched,
                                    const double* y, int batch, int n, int k, int p, int T_len,
                                    int solver, double tol, int max_iter, double jitter,
-                                   double missing_fill, double* logp_out, int32_t* status_out,
+                                   double missing_fill, int n_state_hint, int z_selector_hint,
+                                   double* logp_out, int32_t* status_out,
                                    double* T_out, double* R_out, double* resid_out,
                                    int32_t* n_iter_out, void* stream);
 int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const double* C,
@@ -170,7 +179,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         const double* Hdiag, int h_batched, const double* y, int batch,
                                         int n, int k, int p, int T_len, int solver, double tol,
                                         int max_iter, double jitter, double missing_fill,
-                                        double* logp_out, int32_t* status_out, double* T_out,
+                                        int n_state_hint, int z_selector_hint, double* logp_out,
+                                        int32_t* status_out, double* T_out,
                                         double* R_out, double* resid_out, int32_t* n_iter_out);
 
 /*
@@ -183,8 +193,8 @@ int dsge_profile_pipeline(const double* A, const double* B, const double* C, con
                           const double* Q, int q_mode, const double* Z, int z_batched, const double* d,
                           int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                           int n, int k, int p, int T_len, int solver, double tol, int max_iter,
-                          double jitter, double missing_fill, double* logp_out, int32_t* status_out,
-                          int reps, float* ms_out, void* stream);
+                          double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
+                          double* logp_out, int32_t* status_out, int reps, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -222,3 +222,71 @@ def test_draw_indexing_bit_exact_and_deterministic():
     for j in range(32):
         vals = l1[idx == j]
         assert np.all(vals == vals[0])
+
+
+def _kalman_inputs(nb, m, k, p, T_len, n_state, seed, selector=True):
+    rng = np.random.default_rng(seed)
+    T = np.zeros((nb, m, m))
+    cols = np.sort(rng.choice(m, n_state, replace=False))
+    for i in range(nb):
+        M = rng.standard_normal((m, n_state))
+        S = M[cols]
+        M *= rng.uniform(0.3, 0.95) / np.max(np.abs(np.linalg.eigvals(S)))
+        T[i][:, cols] = M
+    R = rng.standard_normal((nb, m, k))
+    q = rng.uniform(0.5, 1.5, (nb, k))
+    Z = np.zeros((p, m))
+    if selector:
+        Z[np.arange(p), rng.choice(m, p, replace=False)] = rng.choice([1.0, 0.25, -2.0], p)
+    else:
+        Z[:] = rng.standard_normal((p, m))
+    d = rng.standard_normal(p)
+    H = rng.uniform(0.05, 0.5, p)
+    y = rng.standard_normal((T_len, p))
+    y[2, 0] = np.nan
+    y[5, :] = np.nan
+    if p > 2:
+        y[9, 1:3] = oracle.MISSING_FILL
+    return T, R, q, Z, d, H, y
+
+
+@pytest.mark.parametrize("m,k,p,ns", [(8, 1, 1, 2), (12, 2, 3, 5), (24, 4, 4, 9), (40, 7, 7, 18), (40, 7, 8, 40),
+                                      (37, 3, 5, 11), (64, 6, 8, 23)])
+def test_kalman_selector_fast_path(m, k, p, ns):
+    """kalman_sel_kernel (compact state block + selector Z) vs the oracle, and vs the general
+    kernel (hints off)."""
+    nb, T_len = 6, 30
+    T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=m + p)
+    logp, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+    assert np.all(st == 0)
+    logp_gen, st2 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched", n_state_hint=0,
+                                                z_selector_hint=0)
+    assert np.all(st2 == 0)
+    for i in range(nb):
+        ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
+        assert_allclose(logp[i], ref, rtol=LOGP_RTOL)
+        assert_allclose(logp_gen[i], ref, rtol=LOGP_RTOL)
+
+
+def test_kalman_wrong_hints_are_harmless():
+    """Hints are verified on the device: a too-small state hint or a false selector claim must
+    not change any result (the flagged draws are re-run by the general kernel)."""
+    nb, m, k, p, T_len = 6, 24, 3, 4, 20
+    T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, 9, seed=5)
+    good, _ = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+    too_small, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched", n_state_hint=3)
+    assert np.all(st == 0)
+    assert_allclose(too_small, good, rtol=1e-12)
+    Tg, Rg, qg, Zg, dg, Hg, yg = _kalman_inputs(nb, m, k, p, T_len, 9, seed=5, selector=False)
+    lied, st = batched.kalman_logp_batched(Tg, Rg, qg, Zg, yg, d=dg, Hdiag=Hg, q_mode="diag_batched", z_selector_hint=1)
+    honest, _ = batched.kalman_logp_batched(Tg, Rg, qg, Zg, yg, d=dg, Hdiag=Hg, q_mode="diag_batched")
+    assert np.all(st == 0)
+    assert np.array_equal(lied, honest)
+    # mixed batch: one draw with a dense T among compact ones
+    T2 = T.copy()
+    T2[2] = 0.1 * np.random.default_rng(0).standard_normal((m, m))
+    mixed, st = batched.kalman_logp_batched(T2, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched", n_state_hint=9)
+    assert np.all(st == 0)
+    for i in range(nb):
+        ref = oracle.kalman_filter_logp(y, T2[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
+        assert_allclose(mixed[i], ref, rtol=LOGP_RTOL)
