@@ -199,3 +199,210 @@ __device__ __forceinline__ void gauss_jordan_lds(double* W, int ldw, int n, int 
 }
 
 }  // namespace dsge
+
+// ===========================================================================================
+// Blocked Gauss-Jordan with partial pivoting inside each BS-column panel.
+//
+// Same elimination as gauss_jordan_lds (identical pivot sequence: the panel is eliminated column
+// by column on a copy, exactly as the unblocked sweep would update those columns), but the
+// O(n^2 ncols) work is done as rank-BS updates on BSxBS register blocks, and the O(n BS^2) panel
+// work runs in registers with one matrix row per lane, pivot search by a DPP wave reduction and
+// pivot-row broadcast by v_readlane.  Rows are never swapped: row r that served as pivot for
+// column j ends up holding solution row j; `prow[j] = r` records it and gj_unpermute() restores
+// the natural order of the right-hand-side columns.
+//
+// Block step for panel columns J (width bw), pivot rows Rk = (r_0..r_{bw-1}), M = W[Rk, J]:
+//   Lhat[i,:] = W[i,J] M^-1 (i not in Rk),  Lhat[r_a,:] = e_a - M^-1[a,:]
+//   Y = M^-1 W[Rk,:]                         W[i,:] -= Lhat[i,:] W[Rk,:]  (all rows)
+// Lhat and M^-1 come out of the augmented panel elimination [W[:,J] | 0 or e_a].
+// ===========================================================================================
+namespace dsge {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long v) {
+  int lo = (int)(v & 0xffffffffull), hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
+// max over the 64 lanes of an unsigned 64-bit key (identity 0); result is wave-uniform
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  unsigned long long t;
+  t = dpp_move_u64<0x111, 0xf>(v);  // row_shr:1
+  v = t > v ? t : v;
+  t = dpp_move_u64<0x112, 0xf>(v);  // row_shr:2
+  v = t > v ? t : v;
+  t = dpp_move_u64<0x114, 0xf>(v);  // row_shr:4
+  v = t > v ? t : v;
+  t = dpp_move_u64<0x118, 0xf>(v);  // row_shr:8
+  v = t > v ? t : v;
+  t = dpp_move_u64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = t > v ? t : v;
+  t = dpp_move_u64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  v = t > v ? t : v;
+  int lo = (int)(v & 0xffffffffull), hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_readlane(lo, 63);
+  hi = __builtin_amdgcn_readlane(hi, 63);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
+// reference implementation with plain shuffles (self-test of the DPP encodings)
+__device__ __forceinline__ unsigned long long wave_max_u64_shfl(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned long long t = __shfl_xor(v, m, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ double readlane_dyn_f64(double v, int src_lane_uniform) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane_uniform);
+  hi = __builtin_amdgcn_readlane(hi, src_lane_uniform);
+  return __hiloint2double(hi, lo);
+}
+
+// W: n rows x (ngroups*NP) columns, row stride ldw, matrix in columns [0,n).  Scratch in LDS:
+// Lbuf (NP*BS doubles), Ybuf (BS * ngroups*NP doubles), prow (NP ints).
+template <int BS>
+__device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,
+                                                     int* prow, int lane) {
+  constexpr int NP = 8 * BS;
+  const int lr = lane >> 3, lc = lane & 7;
+  const int wcols = ngroups * NP;
+  unsigned long long used = 0ull;
+  const int nsteps = (n + BS - 1) / BS;
+  for (int kb = 0; kb < nsteps; ++kb) {
+    const int j0 = kb * BS;
+    const int bw = (n - j0 < BS) ? (n - j0) : BS;
+    wave_sync();
+    // ---- panel: one matrix row per lane, augmented with the identity slots ------------
+    double pw[BS], id[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      pw[c] = (lane < n && c < bw) ? W[lane * ldw + j0 + c] : 0.0;
+      id[c] = 0.0;
+    }
+    int rsel[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      rsel[c] = 0;
+      if (c < bw) {
+        const bool cand = (lane < n) && !((used >> lane) & 1ull);
+        unsigned long long key = 0ull;
+        if (cand) key = ((unsigned long long)__double_as_longlong(fabs(pw[c])) & ~63ull) | (unsigned long long)(63 - lane);
+        key = wave_max_u64(key);
+        const int r = __builtin_amdgcn_readfirstlane(63 - (int)(key & 63ull));
+        rsel[c] = r;
+        used |= 1ull << r;
+        if (lane == r) id[c] = 1.0;
+        // broadcast the pivot lane's row, scale it, eliminate everywhere else
+        const double inv = 1.0 / readlane_dyn_f64(pw[c], r);
+        double prw[BS], pri[BS];
+#pragma unroll
+        for (int c2 = 0; c2 < BS; ++c2) {
+          prw[c2] = (c2 > c) ? readlane_dyn_f64(pw[c2], r) * inv : 0.0;
+          pri[c2] = (c2 <= c) ? readlane_dyn_f64(id[c2], r) * inv : 0.0;
+        }
+        const double f = pw[c];
+        if (lane == r) {
+#pragma unroll
+          for (int c2 = 0; c2 < BS; ++c2) {
+            if (c2 > c) pw[c2] = prw[c2];
+            if (c2 <= c) id[c2] = pri[c2];
+          }
+          pw[c] = 1.0;
+        } else {
+#pragma unroll
+          for (int c2 = 0; c2 < BS; ++c2) {
+            if (c2 > c) pw[c2] = fma(-f, prw[c2], pw[c2]);
+            if (c2 <= c) id[c2] = fma(-f, pri[c2], id[c2]);
+          }
+          pw[c] = 0.0;
+        }
+      }
+    }
+    // Lhat row of this lane: -id for ordinary rows; pivot lane r_a holds id = Minv[a,:] and
+    // needs e_a - Minv[a,:]
+    if (lane < NP) {
+      double lh[BS];
+#pragma unroll
+      for (int b = 0; b < BS; ++b) lh[b] = -id[b];
+#pragma unroll
+      for (int a = 0; a < BS; ++a)
+        if (a < bw && lane == rsel[a]) lh[a] += 1.0;
+#pragma unroll
+      for (int b = 0; b < BS; ++b) Lbuf[lane * BS + b] = (lane < n) ? lh[b] : 0.0;
+    }
+    // pivot rows of W (original values) -> Ybuf, one column per lane
+    for (int c = lane; c < wcols; c += 64) {
+#pragma unroll
+      for (int b = 0; b < BS; ++b) Ybuf[b * wcols + c] = (b < bw) ? W[rsel[b] * ldw + c] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < BS; ++a)
+      if (a < bw && lane == 0) prow[j0 + a] = rsel[a];
+    wave_sync();
+    // ---- trailing update on register blocks: W[i,:] -= Lhat[i,:] Wpiv ---------------------
+    double lh[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) lh[i][b] = Lbuf[(lr * BS + i) * BS + b];
+    for (int g = 0; g < ngroups; ++g) {
+      // block columns at or left of the panel inside the matrix part are dead (never read again)
+      if (g == 0 && lc <= kb) continue;
+      const int c0 = g * NP + lc * BS;
+      double wb[BS][BS], yb[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) wb[i][j] = W[(lr * BS + i) * ldw + c0 + j];
+#pragma unroll
+      for (int b = 0; b < BS; ++b)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) yb[b][j] = Ybuf[b * wcols + c0 + j];
+#pragma unroll
+      for (int b = 0; b < BS; ++b)
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) wb[i][j] = fma(-lh[i][b], yb[b][j], wb[i][j]);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) W[(lr * BS + i) * ldw + c0 + j] = wb[i][j];
+    }
+  }
+  wave_sync();
+}
+
+// Restore natural row order of the right-hand-side column groups [g_first, ngroups): row j of the
+// solution sits in row prow[j] of W.  Rows >= n are left untouched.
+template <int BS>
+__device__ __forceinline__ void gj_unpermute(double* W, int ldw, int n, int g_first, int ngroups, const int* prow,
+                                             int lane) {
+  constexpr int NP = 8 * BS;
+  const int lr = lane >> 3, lc = lane & 7;
+  for (int g = g_first; g < ngroups; ++g) {
+    const int c0 = g * NP + lc * BS;
+    double t[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      const int r = lr * BS + i;
+      const int src = (r < n) ? prow[r] : r;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) t[i][j] = W[src * ldw + c0 + j];
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) W[(lr * BS + i) * ldw + c0 + j] = t[i][j];
+    wave_sync();
+  }
+}
+
+}  // namespace dsge

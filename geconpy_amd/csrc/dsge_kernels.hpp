@@ -20,7 +20,8 @@ namespace dsge {
 template <int BS>
 struct CrSmem {
   static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 3 * NP + 1;
-  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW);
+  // A0s, A2s, W, then the blocked Gauss-Jordan scratch: Lbuf NP*BS, Ybuf BS*3NP, prow NP ints
+  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW + NP * BS + BS * 3 * NP + NP / 2);
 };
 
 template <int BS>
@@ -33,6 +34,9 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
   double* A0s = smem;
   double* A2s = A0s + NP * LD;
   double* W = A2s + NP * LD;
+  double* Lbuf = W + NP * LDW;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 3 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
@@ -61,7 +65,8 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
         blk_load_lds<BS>(t, A2s, LD, lr, lc);
         blk_store_lds<BS>(t, W + 2 * NP, LDW, lr, lc);
       }
-      gauss_jordan_lds(W, LDW, n, 3 * NP, lane);  // syncs on entry and exit
+      gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);  // syncs on entry and exit
+      gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
       const double* X0 = W + NP;
       const double* X2 = W + 2 * NP;
       double acc[BS][BS];
@@ -114,7 +119,8 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
         blk_load_global<BS>(t, A + off, n, n, n, lr, lc);
         blk_store_lds<BS>(t, W + NP, LDW, lr, lc);
       }
-      gauss_jordan_lds(W, LDW, n, 2 * NP, lane);
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
       blk_load_lds<BS>(Tb, W + NP, LDW, lr, lc);
 #pragma unroll
       for (int i = 0; i < BS; ++i)
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
 template <int BS>
 struct BdSmem {
   static constexpr int NP = Tile<BS>::NP, LDW = 3 * NP + 1;
-  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW);
+  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + NP * BS + BS * 3 * NP + NP / 2);
 };
 
 template <int BS>
@@ -145,6 +151,9 @@ __global__ __launch_bounds__(64) void bdirect_kernel(const double* __restrict__ 
   constexpr int NP = BdSmem<BS>::NP, LDW = BdSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
+  double* Lbuf = W + NP * LDW;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 3 * NP);
   const int lane = threadIdx.x;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     wave_sync();
@@ -162,7 +171,8 @@ __global__ __launch_bounds__(64) void bdirect_kernel(const double* __restrict__ 
       const int r = idx / k, c = idx - r * k;
       W[r * LDW + 2 * NP + c] = Dg[idx];
     }
-    gauss_jordan_lds(W, LDW, n, 2 * NP + k, lane);
+    gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);
+    gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
     for (int idx = lane; idx < n * n; idx += 64) {
       const int r = idx / n, c = idx - r * n;
       T_out[(size_t)draw * n * n + idx] = -W[r * LDW + NP + c];
@@ -182,8 +192,8 @@ __global__ __launch_bounds__(64) void bdirect_kernel(const double* __restrict__ 
 template <int BS>
 struct AsmSmem {
   static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 2 * NP + 1;
-  // M1, M2 (NP x LD each), W (NP x LDW)
-  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW);
+  // M1, M2 (NP x LD each), W (NP x LDW), blocked Gauss-Jordan scratch (Lbuf, Ybuf, prow)
+  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW + NP * BS + BS * 2 * NP + NP / 2);
 };
 
 constexpr int LYAP_MAX_DOUBLINGS = 64;
@@ -201,6 +211,9 @@ __global__ __launch_bounds__(64) void assemble_kernel(
   double* M2 = M1 + NP * LD;    // C, then (B + C T), later P
   double* W = M2 + NP * LD;     // [B + C T | D] -> [. | X];  later R | RQ, then scratch W1 (ld = LDW)
   double* RQs = W + NP;         // R Q staging lives in the right half of W (ld = LDW)
+  double* Lbuf = W + NP * LDW;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 2 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
@@ -238,7 +251,8 @@ __global__ __launch_bounds__(64) void assemble_kernel(
         blk_load_global<BS>(Db, D + offk, n, k, k, lr, lc);
         blk_store_lds<BS>(Db, W + NP, LDW, lr, lc);
       }
-      gauss_jordan_lds(W, LDW, n, NP + k, lane);
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
       blk_load_lds<BS>(Rb, W + NP, LDW, lr, lc);
 #pragma unroll
       for (int i = 0; i < BS; ++i)
