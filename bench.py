@@ -38,10 +38,16 @@ def algorithmic_flops(n, k, p, T_len, cr_iters=7.0, lyap_doublings=12):
     return dict(kalman=kalman, lyapunov=lyap, selection=sel, solver=cr, total=kalman + lyap + sel + cr)
 
 
-def executed_kalman_flops(m, p, T_len):
-    """What kalman_kernel actually executes per draw (downdate form instead of Joseph):
-    predict 4 m^3 + 2 m^2, P Z' 2 m^2 p, F 2 m p^2, G/K 2 m p^2, downdate 4 m^2 p, misc."""
-    return T_len * (4 * m**3 + 2 * m**2 + 2 * m**2 * p + 2 * m * p**2 + 2 * m * p**2 + 4 * m**2 * p + p**3 / 3.0)
+def executed_kalman_flops(m, p, T_len, s=None, selector=True):
+    """FLOPs the Kalman kernel actually executes per draw.  Fast path (kalman_sel_kernel): the
+    prediction touches only the s non-zero (state) columns of T -- 2 s^2 m + 2 m^2 s + 2 m s -- the
+    gain costs 2 m 8^2, the downdate 16 m^2 (p padded to 8), the in-register 8x8 inverse ~2*8^3.
+    General path (kalman_kernel): 4 m^3 prediction, Cholesky-based update."""
+    if selector and s is not None:
+        per_step = 2 * s * s * m + 2 * m * m * s + 2 * m * s + 2 * m * 64 + 16 * m * m + 2 * 512 + 4 * m
+    else:
+        per_step = 4 * m**3 + 2 * m**2 + 2 * m**2 * p + 4 * m * p**2 + 4 * m**2 * p + p**3 / 3.0
+    return T_len * per_step
 
 
 def algorithmic_bytes(n, k, p):
@@ -191,7 +197,7 @@ def main():
         flops = algorithmic_flops(n, k, p, T_len)
         kal_s = kms["kalman"] * 1e-3
         achieved = flops["kalman"] * nloc / kal_s / 1e12
-        exec_tf = executed_kalman_flops(n, p, T_len) * nloc / kal_s / 1e12
+        exec_tf = executed_kalman_flops(n, p, T_len, s=hints[0] or n, selector=bool(hints[1])) * nloc / kal_s / 1e12
         total_kernel_s = (kms["solver"] + kms["assemble"] + kms["kalman"]) * 1e-3
         b_eval = algorithmic_bytes(n, k, p)
         value = global_batch * args.steps / dt

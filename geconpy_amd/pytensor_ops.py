@@ -1,0 +1,212 @@
+"""pytensor Ops backed by libdsge_hip.so -- the drop-in surface for gEconpy's solver Ops.
+
+Mirrors, for the cycle-reduction path, the interface of
+``gEconpy/solvers/cycle_reduction.py``: ``CycleReductionWrapper`` (``__props__ = ("max_iter",
+"tol")``, ``gufunc_signature = "(n,n),(n,n),(n,n)->(n,n)"``, ``make_node`` / ``infer_shape`` /
+``perform`` / ``pullback`` contract, :186-213) and ``cycle_reduction_pt`` (:216-219), plus
+``pt_compute_selection_matrix`` (``gEconpy/solvers/shared.py:74-75``).  On top of that it adds
+what the reference does not have: explicitly batched Ops (leading draw axis, ONE kernel launch
+per batch) and the fused ``A,B,C,D -> logp`` Op, and it registers a vectorisation rule so that
+``pytensor.graph.replace.vectorize_graph`` / ``Blockwise`` turn the per-draw Op into the batched
+one instead of a Python loop over draws (the hook of ``statespace.py:1217-1303``).
+
+pytensor is imported lazily: this module can be imported without it (``available()`` tells),
+and the engine is fully usable through ``geconpy_amd.batched`` / ``geconpy_amd.engine`` alone.
+Registration happens by import side effect, the same pattern as ``gEconpy/__init__.py:33-35``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import batched
+
+try:  # pragma: no cover - exercised only where pytensor is installed
+    import pytensor.tensor as pt
+    from pytensor.graph.basic import Apply
+    from pytensor.graph.op import Op
+
+    _HAVE_PYTENSOR = True
+except Exception:  # noqa: BLE001  (ImportError or a broken install)
+    pt = None
+    Apply = None
+    Op = object
+    _HAVE_PYTENSOR = False
+
+
+def available() -> bool:
+    return _HAVE_PYTENSOR
+
+
+def _require():
+    if not _HAVE_PYTENSOR:
+        raise ImportError("pytensor is not installed; use geconpy_amd.batched / geconpy_amd.engine directly")
+
+
+def _as3(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return x[None] if x.ndim == 2 else x
+
+
+class HipCycleReduction(Op):
+    """Drop-in for ``CycleReductionWrapper``: ``T = Op(A, B, C)`` with (n, n) inputs.
+
+    ``perform`` calls ``dsge_cycle_reduction_batched_host`` with batch = 1.  Like the reference's
+    numpy ``perform`` it has no convergence output; unlike it (which stores ``None``) a failed solve
+    yields the zero matrix, i.e. the njit semantics of cycle_reduction.py:181.
+    """
+
+    __props__ = ("max_iter", "tol")
+    gufunc_signature = "(n,n),(n,n),(n,n)->(n,n)"
+
+    def __init__(self, max_iter=1000, tol=1e-9):
+        self.max_iter = int(max_iter)
+        self.tol = tol
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C)]
+        outputs = [pt.tensor("T", dtype="float64", shape=inputs[0].type.shape)]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        n = input_shapes[0][0]
+        return [(n, n)]
+
+    def perform(self, node, inputs, outputs):
+        A, B, C = (_as3(x) for x in inputs)
+        T, _status, _n_iter = batched.cycle_reduction_batched(A, B, C, max_iter=self.max_iter, tol=self.tol)
+        outputs[0][0] = T[0]
+
+    def pullback(self, inputs, outputs, cotangents):
+        # Reverse mode goes through the reference's own adjoint (shared.py:12-71); the device
+        # adjoint kernel is a "next" row.
+        from gEconpy.solvers.shared import o1_policy_function_adjoints  # noqa: PLC0415
+
+        A, B, C = inputs
+        return o1_policy_function_adjoints(A, B, C, outputs[0], cotangents[0])
+
+
+class HipCycleReductionBatched(Op):
+    """``T, status = Op(A, B, C)`` with (batch, n, n) inputs: one launch for all draws."""
+
+    __props__ = ("max_iter", "tol")
+
+    def __init__(self, max_iter=1000, tol=1e-9):
+        self.max_iter = int(max_iter)
+        self.tol = tol
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C)]
+        outputs = [
+            pt.tensor("T", dtype="float64", shape=inputs[0].type.shape),
+            pt.tensor("status", dtype="int32", shape=inputs[0].type.shape[:1]),
+        ]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        b, n, _ = input_shapes[0]
+        return [(b, n, n), (b,)]
+
+    def perform(self, node, inputs, outputs):
+        T, status, _n_iter = batched.cycle_reduction_batched(*inputs, max_iter=self.max_iter, tol=self.tol)
+        outputs[0][0] = T
+        outputs[1][0] = status
+
+
+class HipSelection(Op):
+    """``R = -(C T + B)^-1 D`` for (n, n)/(n, k) or batched inputs (shared.py:74-75)."""
+
+    __props__ = ()
+    gufunc_signature = "(n,n),(n,n),(n,k),(n,n)->(n,k)"
+
+    def make_node(self, B, C, D, T):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (B, C, D, T)]
+        outputs = [pt.tensor("R", dtype="float64", shape=inputs[2].type.shape)]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        return [input_shapes[2]]
+
+    def perform(self, node, inputs, outputs):
+        squeeze = np.ndim(inputs[0]) == 2
+        B, C, D, T = (_as3(x) for x in inputs)
+        R = batched.selection_batched(B, C, D, T)
+        outputs[0][0] = R[0] if squeeze else R
+
+
+class HipSolveKalmanLogp(Op):
+    """Fused per-draw log-likelihood: ``logp, status = Op(A, B, C, D, q, Z, y, d, Hdiag)``.
+
+    A,B,C: (batch, n, n); D: (batch, n, k); q: (batch, k) shock variances (the diagonal of
+    ``state_cov``, statespace.py:240-258); Z: (p, n); y: (T_len, p); d, Hdiag: (p,).  Evaluates
+    what ``_setup_policy_matrices`` + ``make_symbolic_graph`` + the Kalman scan compute
+    (statespace.py:197-222, 725-820, 1151-1157) for all draws in one call; failed draws give -inf.
+    """
+
+    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value")
+
+    def __init__(self, solver="cycle_reduction", tol=1e-6, max_iter=50, jitter=batched.JITTER_DEFAULT,
+                 missing_fill_value=batched.MISSING_FILL):
+        self.solver = solver
+        self.tol = tol
+        self.max_iter = int(max_iter)
+        self.jitter = jitter
+        self.missing_fill_value = missing_fill_value
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C, D, q, Z, y, d, Hdiag):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C, D, q, Z, y, d, Hdiag)]
+        b = inputs[0].type.shape[:1]
+        outputs = [pt.tensor("logp", dtype="float64", shape=b), pt.tensor("status", dtype="int32", shape=b)]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        b = input_shapes[0][0]
+        return [(b,), (b,)]
+
+    def perform(self, node, inputs, outputs):
+        A, B, C, D, q, Z, y, d, Hdiag = inputs
+        out = batched.solve_kalman_logp_batched(
+            A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, q_mode="diag_batched", solver=self.solver, tol=self.tol,
+            max_iter=self.max_iter, jitter=self.jitter, missing_fill_value=self.missing_fill_value,
+        )
+        outputs[0][0] = out["logp"]
+        outputs[1][0] = out["status"]
+
+
+def cycle_reduction_pt(A, B, C, D, max_iter=1000, tol=1e-9):
+    """Same signature and return as ``gEconpy.solvers.cycle_reduction.cycle_reduction_pt``
+    (:216-219): ``(T, R)``."""
+    T = HipCycleReduction(max_iter=max_iter, tol=tol)(A, B, C)
+    R = HipSelection()(B, C, D, T)
+    return T, R
+
+
+def _register_vectorize():
+    """Teach pytensor to vectorise HipCycleReduction into ONE batched launch."""
+    try:
+        from pytensor.graph.replace import _vectorize_node  # noqa: PLC0415
+    except Exception:  # noqa: BLE001
+        return False
+
+    @_vectorize_node.register(HipCycleReduction)
+    def _vectorize_hip_cr(op, node, A, B, C):
+        if A.type.ndim == 3 and B.type.ndim == 3 and C.type.ndim == 3:
+            return HipCycleReductionBatched(max_iter=op.max_iter, tol=op.tol).make_node(A, B, C)
+        from pytensor.tensor.blockwise import Blockwise  # noqa: PLC0415
+
+        return Blockwise(op).make_node(A, B, C)
+
+    return True
+
+
+if _HAVE_PYTENSOR:  # registration by import side effect
+    _register_vectorize()
