@@ -1,0 +1,399 @@
+"""Executable model (plain numpy, scalar loops) of the DEVICE algorithm for gensys.
+
+This is NOT the oracle (the oracle calls LAPACK's zgges/ztgsen through scipy exactly as the
+reference does, oracle/gensys_qz.py).  It restates, step for step, what `gensys_kernel` in
+geconpy_amd/csrc/dsge_gensys.hpp executes on one wavefront, so that the algorithm can be
+validated on the CPU against the oracle and the golden vectors before/independently of the HIP
+port, and so that a kernel bug can be told apart from an algorithm bug:
+
+  1. pencil (G0, G1), X = Pi, Ztop = I[:n]             gensys.py:568-614 (index arithmetic only)
+  2. G1 -> upper triangular by Givens rotations on rows (left transforms also hit G0 and X)
+  3. G0 -> upper Hessenberg keeping G1 triangular (row + column Givens pairs)
+  4. complex single-shift QZ with the LAPACK zhgeqz deflation logic (small sub-diagonal of H,
+     negligible diagonal of T incl. "chase the zero" procedures, Wilkinson / exceptional shifts)
+  5. reorder: stable roots (gensys.py:246 criterion, `realsmall` thresholds) to the top by adjacent
+     1x1 swaps (ztgex2 for complex triangular pencils)
+  6. gensys post-processing in the partitioned basis (gensys.py:267-343): Jacobi SVDs of Q2 Pi and
+     Q1 Pi, existence / uniqueness codes, Phi, and  T = Re(Ztop[:, :ns] A11^-1 [B11, B12 - Phi B22] Ztop^H)
+     -- G_0 of gensys.py:322-330 is upper triangular in this basis, so its LU is a back-substitution.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SAFMIN = np.finfo(np.float64).tiny
+ULP = np.finfo(np.float64).eps  # dlamch('E') * dlamch('B')
+
+
+def lartg(f, g):
+    """c (real), s, r with  [c s; -conj(s) c] [f; g] = [r; 0]."""
+    if g == 0:
+        return 1.0, 0j, f
+    if f == 0:
+        ag = abs(g)
+        return 0.0, np.conj(g) / ag, ag + 0j
+    af, ag = abs(f), abs(g)
+    d = np.hypot(af, ag)
+    ph = f / af
+    return af / d, ph * np.conj(g) / d, ph * d
+
+
+def rot(x, y, c, s):
+    """x' = c x + s y ; y' = c y - conj(s) x   (vectors, in place)."""
+    tx = c * x + s * y
+    y[:] = c * y - np.conj(s) * x
+    x[:] = tx
+
+
+class Pencil:
+    """H (from G0), T (from G1), X = (left transform) Pi, Z = top n rows of the right transform."""
+
+    def __init__(self, G0, G1, n):
+        N = G0.shape[0]
+        self.N, self.n = N, n
+        self.H = G0.astype(np.complex128).copy()
+        self.T = G1.astype(np.complex128).copy()
+        ell = N - n
+        self.X = np.zeros((N, ell), np.complex128)
+        self.X[n:, :] = np.eye(ell)
+        self.Z = np.eye(N, dtype=np.complex128)[:n].copy()
+        self.n_rot = 0
+
+    def rot_rows(self, i, k, c, s):
+        """rows i (x) and k (y) of H, T, X."""
+        for M in (self.H, self.T, self.X):
+            rot(M[i], M[k], c, s)
+        self.n_rot += 1
+
+    def rot_cols(self, i, k, c, s):
+        """columns i (x) and k (y) of H, T, Z."""
+        for M in (self.H, self.T, self.Z):
+            rot(M[:, i], M[:, k], c, s)
+        self.n_rot += 1
+
+
+def hessenberg_triangular(P):
+    N, H, T = P.N, P.H, P.T
+    # T -> upper triangular
+    for j in range(N - 1):
+        for i in range(N - 1, j, -1):
+            if T[i, j] == 0:
+                continue
+            c, s, r = lartg(T[i - 1, j], T[i, j])
+            P.rot_rows(i - 1, i, c, s)
+            T[i - 1, j] = r
+            T[i, j] = 0
+    # H -> upper Hessenberg, T stays triangular
+    for j in range(N - 2):
+        for i in range(N - 1, j + 1, -1):
+            if H[i, j] == 0:
+                continue
+            c, s, r = lartg(H[i - 1, j], H[i, j])
+            P.rot_rows(i - 1, i, c, s)
+            H[i - 1, j] = r
+            H[i, j] = 0
+            if T[i, i - 1] != 0:
+                c, s, r = lartg(T[i, i], T[i, i - 1])
+                P.rot_cols(i, i - 1, c, s)
+                T[i, i] = r
+                T[i, i - 1] = 0
+
+
+def abs1(z):
+    return abs(z.real) + abs(z.imag)
+
+
+def qz_iterate(P, max_it_factor=30):
+    """LAPACK zhgeqz (JOB='S'), ilo = 0, ihi = N-1.  Returns True on convergence."""
+    N, H, T = P.N, P.H, P.T
+    if N == 1:
+        return True
+    anorm = np.linalg.norm(H)
+    bnorm = np.linalg.norm(T)
+    atol = max(SAFMIN, ULP * anorm)
+    btol = max(SAFMIN, ULP * bnorm)
+    ascale = 1.0 / max(SAFMIN, anorm)
+    bscale = 1.0 / max(SAFMIN, bnorm)
+    ilo, ilast = 0, N - 1
+    iiter = 0
+    eshift = 0j
+    maxit = max_it_factor * N
+    for _jiter in range(maxit):
+        # ---- deflation tests ------------------------------------------------------------
+        action = None  # "split60" | "zeroT50" | ("qz", ifirst)
+        if ilast == ilo:
+            action = "split60"
+        elif abs1(H[ilast, ilast - 1]) <= max(SAFMIN, ULP * (abs1(H[ilast, ilast]) + abs1(H[ilast - 1, ilast - 1]))):
+            H[ilast, ilast - 1] = 0
+            action = "split60"
+        elif abs(T[ilast, ilast]) <= btol:
+            T[ilast, ilast] = 0
+            action = "zeroT50"
+        else:
+            for j in range(ilast - 1, ilo - 1, -1):
+                if j == ilo:
+                    ilazro = True
+                elif abs1(H[j, j - 1]) <= max(SAFMIN, ULP * (abs1(H[j, j]) + abs1(H[j - 1, j - 1]))):
+                    H[j, j - 1] = 0
+                    ilazro = True
+                else:
+                    ilazro = False
+                if abs(T[j, j]) < btol:
+                    T[j, j] = 0
+                    ilazr2 = False
+                    if not ilazro:
+                        if abs1(H[j, j - 1]) * (ascale * abs1(H[j + 1, j])) <= abs1(H[j, j]) * (ascale * atol):
+                            ilazr2 = True
+                    if ilazro or ilazr2:
+                        # chase the zero of T down; each step splits off / moves the zero
+                        for jch in range(j, ilast):
+                            c, s, r = lartg(H[jch, jch], H[jch + 1, jch])
+                            P.rot_rows(jch, jch + 1, c, s)
+                            H[jch, jch] = r
+                            H[jch + 1, jch] = 0
+                            if ilazr2:
+                                H[jch, jch - 1] = H[jch, jch - 1] * c
+                            ilazr2 = False
+                            if abs1(T[jch + 1, jch + 1]) >= btol:
+                                if jch + 1 >= ilast:
+                                    action = "split60"
+                                else:
+                                    action = ("qz", jch + 1)
+                                break
+                            T[jch + 1, jch + 1] = 0
+                        else:
+                            action = "zeroT50"
+                        break
+                    # only the T test passed: chase the zero to T[ilast, ilast]
+                    for jch in range(j, ilast):
+                        c, s, r = lartg(T[jch, jch + 1], T[jch + 1, jch + 1])
+                        P.rot_rows(jch, jch + 1, c, s)
+                        T[jch, jch + 1] = r
+                        T[jch + 1, jch + 1] = 0
+                        c, s, r = lartg(H[jch + 1, jch], H[jch + 1, jch - 1])
+                        P.rot_cols(jch, jch - 1, c, s)
+                        H[jch + 1, jch] = r
+                        H[jch + 1, jch - 1] = 0
+                    action = "zeroT50"
+                    break
+                if ilazro:
+                    action = ("qz", j)
+                    break
+            if action is None:
+                return False  # cannot happen (j == ilo always sets ilazro)
+        if action == "zeroT50":
+            c, s, r = lartg(H[ilast, ilast], H[ilast, ilast - 1])
+            P.rot_cols(ilast, ilast - 1, c, s)
+            H[ilast, ilast] = r
+            H[ilast, ilast - 1] = 0
+            action = "split60"
+        if action == "split60":
+            ilast -= 1
+            if ilast < ilo:
+                return True
+            iiter = 0
+            eshift = 0j
+            continue
+        # ---- one single-shift QZ sweep on ifirst..ilast ------------------------------------
+        ifirst = action[1]
+        iiter += 1
+        if iiter % 10 != 0:
+            u12 = (bscale * T[ilast - 1, ilast]) / (bscale * T[ilast, ilast])
+            ad11 = (ascale * H[ilast - 1, ilast - 1]) / (bscale * T[ilast - 1, ilast - 1])
+            ad21 = (ascale * H[ilast, ilast - 1]) / (bscale * T[ilast - 1, ilast - 1])
+            ad12 = (ascale * H[ilast - 1, ilast]) / (bscale * T[ilast, ilast])
+            ad22 = (ascale * H[ilast, ilast]) / (bscale * T[ilast, ilast])
+            abi22 = ad22 - u12 * ad21
+            t1 = 0.5 * (ad11 + abi22)
+            rtdisc = np.sqrt(t1 * t1 + ad12 * ad21 - ad11 * ad22 + 0j)
+            temp = (t1 - abi22).real * rtdisc.real + (t1 - abi22).imag * rtdisc.imag
+            shift = t1 + rtdisc if temp <= 0 else t1 - rtdisc
+        else:
+            eshift = eshift + (ascale * H[ilast, ilast - 1]) / (bscale * T[ilast - 1, ilast - 1])
+            shift = eshift
+        istart = ifirst
+        ctemp = ascale * H[ifirst, ifirst] - shift * (bscale * T[ifirst, ifirst])
+        for j in range(ilast - 1, ifirst, -1):
+            ct = ascale * H[j, j] - shift * (bscale * T[j, j])
+            temp = abs1(ct)
+            temp2 = ascale * abs1(H[j + 1, j])
+            tempr = max(temp, temp2)
+            if tempr < 1.0 and tempr != 0.0:
+                temp /= tempr
+                temp2 /= tempr
+            if abs1(H[j, j - 1]) * temp2 <= temp * atol:
+                istart = j
+                ctemp = ct
+                break
+        ctemp2 = ascale * H[istart + 1, istart]
+        c, s, _ = lartg(ctemp, ctemp2)
+        for j in range(istart, ilast):
+            if j > istart:
+                c, s, r = lartg(H[j, j - 1], H[j + 1, j - 1])
+                P.rot_rows(j, j + 1, c, s)
+                H[j, j - 1] = r
+                H[j + 1, j - 1] = 0
+            else:
+                P.rot_rows(j, j + 1, c, s)
+            c, s, r = lartg(T[j + 1, j + 1], T[j + 1, j])
+            P.rot_cols(j + 1, j, c, s)
+            T[j + 1, j + 1] = r
+            T[j + 1, j] = 0
+    return False
+
+
+def swap_adjacent(P, k):
+    """Exchange the 1x1 blocks k and k+1 of the triangular pencil (LAPACK ztgex2)."""
+    H, T = P.H, P.T
+    f = H[k + 1, k + 1] * T[k, k] - T[k + 1, k + 1] * H[k, k]
+    g = H[k + 1, k + 1] * T[k, k + 1] - T[k + 1, k + 1] * H[k, k + 1]
+    sa = abs(H[k + 1, k + 1])
+    sb = abs(T[k + 1, k + 1])
+    c0, s0, _ = lartg(g, f)
+    P.rot_cols(k, k + 1, c0, -np.conj(s0))
+    if sa >= sb:
+        c, s, _ = lartg(H[k, k], H[k + 1, k])
+    else:
+        c, s, _ = lartg(T[k, k], T[k + 1, k])
+    P.rot_rows(k, k + 1, c, s)
+    H[k + 1, k] = 0
+    T[k + 1, k] = 0
+
+
+def is_stable(a, b, rs):
+    """gensys.py:246 on (alpha, beta) = (H_ii, T_ii)."""
+    aa, ab = abs(a), abs(b)
+    return (ab < rs and aa >= rs) or (ab >= rs and aa > ab)
+
+
+def reorder_stable_first(P, rs):
+    N, H, T = P.N, P.H, P.T
+    ns = 0
+    for i in range(N):
+        if is_stable(H[i, i], T[i, i], rs):
+            for k in range(i - 1, ns - 1, -1):
+                swap_adjacent(P, k)
+            ns += 1
+    return ns
+
+
+def jacobi_svd(M, max_sweeps=60):
+    """One-sided (Hestenes) Jacobi on the columns of M (r x c): returns G = M V (columns sigma_j u_j),
+    V (c x c) and sigma (c,).  No sorting."""
+    G = M.astype(np.complex128).copy()
+    c = G.shape[1]
+    V = np.eye(c, dtype=np.complex128)
+    for _ in range(max_sweeps):
+        rotated = False
+        for p in range(c - 1):
+            for q in range(p + 1, c):
+                alpha = np.vdot(G[:, p], G[:, p]).real
+                beta = np.vdot(G[:, q], G[:, q]).real
+                gamma = np.vdot(G[:, p], G[:, q])
+                ag = abs(gamma)
+                if ag < 1e-290 or ag <= 1e-15 * np.sqrt(alpha) * np.sqrt(beta):
+                    continue
+                rotated = True
+                ph = gamma / ag
+                zeta = (beta - alpha) / (2.0 * ag)
+                t = (1.0 if zeta >= 0 else -1.0) / (abs(zeta) + np.sqrt(1.0 + zeta * zeta))
+                cs = 1.0 / np.sqrt(1.0 + t * t)
+                sn = cs * t
+                for Mx in (G, V):
+                    gp = Mx[:, p].copy()
+                    gq = Mx[:, q] * np.conj(ph)
+                    Mx[:, p] = cs * gp - sn * gq
+                    Mx[:, q] = sn * gp + cs * gq
+        if not rotated:
+            break
+    sigma = np.sqrt(np.maximum(0.0, np.einsum("ij,ij->j", G.conj(), G).real))
+    return G, V, sigma
+
+
+def gensys_post(P, ns, rs):
+    """gensys.py:267-343 in the partitioned Schur basis -> (T (n x n real), eu)."""
+    N, n, H, T, X, Z = P.N, P.n, P.H, P.T, P.X, P.Z
+    nu = N - ns
+    ell = N - n
+    eu = np.zeros(3, dtype=np.int64)
+    # coincident zeros (gensys.py:243-244)
+    for i in range(N):
+        if abs(H[i, i]) < rs and abs(T[i, i]) < rs:
+            eu[0] = eu[1] = -2
+            return np.zeros((n, n)), eu
+    eta2 = X[ns:, :]
+    eta1 = X[:ns, :]
+    # SVD of eta2 (nu x ell): keep sigma > rs
+    if nu > 0:
+        G2, V2, s2 = jacobi_svd(eta2)
+        keep2 = s2 > rs
+    else:
+        G2 = np.zeros((0, ell), np.complex128)
+        V2 = np.eye(ell, dtype=np.complex128)
+        s2 = np.zeros(ell)
+        keep2 = np.zeros(ell, bool)
+    r2 = int(keep2.sum())
+    if r2 >= nu:
+        eu[0] = 1
+    if ns > 0:
+        G1, V1, s1 = jacobi_svd(eta1)
+        keep1 = s1 > rs
+    else:
+        G1 = np.zeros((0, ell), np.complex128)
+        V1 = np.eye(ell, dtype=np.complex128)
+        s1 = np.zeros(ell)
+        keep1 = np.zeros(ell, bool)
+    r1 = int(keep1.sum())
+    V2k = V2[:, keep2]
+    V1k = V1[:, keep1]
+    if r1 == 0:
+        unique = True
+    else:
+        loose = V1k - V2k @ (V2k.conj().T @ V1k)
+        _, _, sl = jacobi_svd(loose)
+        n_loose = int((sl > rs * N).sum())
+        eu[2] = n_loose
+        unique = n_loose == 0
+    if unique:
+        eu[1] = 1
+    # Phi = eta1_k pinv_k(eta2):  eta1_k = G1k V1k^H,  pinv_k(eta2) = V2k diag(1/s2k^2) G2k^H
+    eta1k = G1[:, keep1] @ V1k.conj().T
+    pinv2 = (V2k / (s2[keep2] ** 2)[None, :]) @ G2[:, keep2].conj().T
+    Phi = eta1k @ pinv2  # ns x nu
+    A11 = H[:ns, :ns]
+    rhs = np.hstack((T[:ns, :ns], T[:ns, ns:] - Phi @ T[ns:, ns:]))  # ns x N
+    # back-substitution with the upper-triangular A11
+    Y = np.zeros((ns, N), np.complex128)
+    for i in range(ns - 1, -1, -1):
+        Y[i] = (rhs[i] - A11[i, i + 1 :] @ Y[i + 1 :]) / A11[i, i]
+    Tm = (Z[:, :ns] @ Y @ Z.conj().T).real
+    return Tm, eu
+
+
+def gensys_device_model(A, B, C, D, tol=1e-8):
+    """(T, eu, info) for one system; mirrors the kernel's control flow."""
+    A, B, C = (np.asarray(x, dtype=np.float64) for x in (A, B, C))
+    n = A.shape[0]
+    lead = np.flatnonzero(np.abs(C).sum(axis=0) > tol)
+    ell = lead.size
+    N = n + ell
+    G0 = np.zeros((N, N))
+    G0[:n, :n] = -B
+    G0[:n, n:] = -C[:, lead]
+    G0[n + np.arange(ell), lead] = 1.0
+    G1 = np.zeros((N, N))
+    G1[:n, :n] = A
+    G1[n:, n:] = np.eye(ell)
+    rs = tol if tol > 0 else np.spacing(1.0)
+    P = Pencil(G0, G1, n)
+    hessenberg_triangular(P)
+    rot_ht = P.n_rot
+    ok = qz_iterate(P)
+    rot_qz = P.n_rot - rot_ht
+    if not ok:
+        return np.zeros((n, n)), np.array([-3, -3, 0]), dict(converged=False)
+    ns = reorder_stable_first(P, rs)
+    Tm, eu = gensys_post(P, ns, rs)
+    info = dict(converged=True, N=N, ns=ns, rot_ht=rot_ht, rot_qz=rot_qz, rot_reorder=P.n_rot - rot_ht - rot_qz,
+                alpha=np.diag(P.H).copy(), beta=np.diag(P.T).copy())
+    return Tm, eu, info

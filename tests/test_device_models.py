@@ -1,0 +1,116 @@
+"""CPU: executable models of the DEVICE algorithms vs the oracle.
+
+The device kernels do not run the reference's LAPACK calls; they run (a) a complex single-shift
+QZ + adjacent-swap reordering + Jacobi SVDs for gensys and (b) a downdate-form Kalman update.
+These models restate exactly that arithmetic in numpy so that the algorithms themselves are
+validated here, on the CPU, against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from geconpy_amd import workloads as wl
+from tests.device_models.gensys_qz_model import gensys_device_model, jacobi_svd, lartg
+from tests.device_models.kalman_model import kalman_downdate_logp
+
+
+def test_lartg():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        f, g = rng.standard_normal(2) + 1j * rng.standard_normal(2)
+        if rng.random() < 0.2:
+            f = 0j
+        if rng.random() < 0.2:
+            g = 0j
+        c, s, r = lartg(f, g)
+        assert_allclose(c * f + s * g, r, atol=1e-14)
+        assert_allclose(-np.conj(s) * f + c * g, 0, atol=1e-14)
+        assert_allclose(c * c + abs(s) ** 2, 1.0, atol=1e-14)
+
+
+def test_jacobi_svd():
+    rng = np.random.default_rng(1)
+    for r, c in [(12, 12), (40, 12), (6, 12), (3, 1)]:
+        M = rng.standard_normal((r, c)) + 1j * rng.standard_normal((r, c))
+        if r == 12:
+            M[:, 3] = M[:, 2]  # rank deficient
+        G, V, s = jacobi_svd(M)
+        assert_allclose(G @ V.conj().T, M, atol=1e-12)
+        assert_allclose(V.conj().T @ V, np.eye(c), atol=1e-12)
+        assert_allclose(np.sort(s)[::-1][: min(r, c)], np.linalg.svd(M, compute_uv=False), atol=1e-10)
+
+
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
+def test_gensys_model_reference_goldens(ref_goldens, key):
+    g = ref_goldens
+    A, B, C, D = (g[f"{key}_{x}"] for x in "ABCD")
+    T, eu, info = gensys_device_model(A, B, C, D, 1e-8)
+    assert list(eu) == list(g[f"{key}_ref_gensys_eu"])
+    assert_allclose(T, g[f"{key}_ref_gensys_T"], atol=1e-10, rtol=0)
+    # same generalized eigenvalue moduli as LAPACK
+    lam = np.sort(np.abs(info["beta"]) / np.maximum(np.abs(info["alpha"]), 1e-300))
+    gr = g[f"{key}_ref_gensys_gev"]
+    lam_r = np.sort(np.abs(gr[:, 1]) / np.maximum(np.abs(gr[:, 0]), 1e-300))
+    fin = lam_r < 1e6
+    assert_allclose(lam[fin], lam_r[fin], rtol=1e-6, atol=1e-9)
+
+
+def test_gensys_model_rbc_and_sw(rbc_golden, sw_golden):
+    th = {k[6:]: rbc_golden[k] for k in rbc_golden.files if k.startswith("theta_")}
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    for i in range(0, 64, 4):
+        T, eu, _ = gensys_device_model(A[i], B[i], C[i], D[i], 1e-8)
+        assert list(eu) == [1, 1, 0]
+        assert_allclose(T, rbc_golden["ref_gensys_T"][i], atol=1e-10)
+    b = wl.sw_shaped_batch(4)
+    for i in range(4):
+        T, eu, _ = gensys_device_model(b["A"][i], b["B"][i], b["C"][i], b["D"][i], 1e-8)
+        assert list(eu) == list(sw_golden["ref_gensys_eu"][i])
+        assert_allclose(T, sw_golden["ref_gensys_T"][i], atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["ok", "nonunique", "noexist", "coincident"])
+def test_gensys_model_failure_codes(failure_golden, name):
+    g = failure_golden
+    A, B, C, D = (g[f"{name}_{x}"] for x in "ABCD")
+    T, eu, _ = gensys_device_model(A, B, C, D, 1e-8)
+    assert list(eu) == list(g[f"{name}_ref_gensys_eu"])
+    if name in ("ok", "noexist"):
+        assert_allclose(T, g[f"{name}_ref_gensys_T"], atol=1e-9)
+    if name == "coincident":
+        assert np.all(T == 0)
+
+
+def test_gensys_model_random_structures():
+    """Small random systems with singular A / C blocks (zero and infinite roots, repeated roots)."""
+    rng = np.random.default_rng(5)
+    n_checked = 0
+    for trial in range(40):
+        n = int(rng.integers(3, 9))
+        ns = int(rng.integers(1, n))
+        nl = int(rng.integers(1, n))
+        A, B, C, D, Tst = wl.sw_shaped_system(1000 + trial, n=n, n_state=ns, n_lead=nl, k=1)
+        if trial % 3 == 0:  # static equation: a row that involves only time-t variables
+            A[0] = 0
+            C[0] = 0
+        To, ok, euo = oracle.gensys_T_success(A, B, C, D, 1e-8)
+        T, eu, _ = gensys_device_model(A, B, C, D, 1e-8)
+        assert list(eu) == list(euo), (trial, eu, euo)
+        if ok:
+            assert_allclose(T, To, atol=1e-8)
+            n_checked += 1
+    assert n_checked > 10
+
+
+def test_kalman_downdate_model_equals_joseph_oracle():
+    b = wl.sw_shaped_batch(3)
+    om = wl.sw_shaped_observation_model()
+    y = om["y"].copy()
+    y[5, 2] = np.nan
+    y[17, :] = np.nan
+    y[40, 0] = oracle.MISSING_FILL
+    for i in range(3):
+        Q = np.diag(b["sigma"][i] ** 2)
+        r = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], Q, om["Z"], y, H=np.diag(om["Hdiag"]))
+        lp = kalman_downdate_logp(y, r["T"], r["R"], Q, om["Z"], om["Hdiag"], np.zeros(7), r["P0"])
+        assert_allclose(lp, r["logp"], rtol=1e-12)
