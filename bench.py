@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--max-iter", type=int, default=1000)
+    ap.add_argument("--solver", default="cycle_reduction", choices=["cycle_reduction", "gensys"])
     ap.add_argument("--no-hints", action="store_true", help="disable the structure hints (general kernels only)")
     args = ap.parse_args()
 
@@ -155,11 +156,14 @@ def main():
 
     # structure hints (verified on the device per draw; they never change results)
     hints = eng.structure_hints(dA, dZ) if not args.no_hints else (0, 0)
+    from geconpy_amd.batched import lead_hint
+
+    n_lead = lead_hint(shard["C"], args.tol) if args.solver == "gensys" else 0
 
     def local_eval(lo_, hi_):
         return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
-                                     max_iter=args.max_iter, logp=logp_buf, status=stat_buf,
-                                     n_state_hint=hints[0], z_selector_hint=hints[1])
+                                     max_iter=args.max_iter, logp=logp_buf, status=stat_buf, solver=args.solver,
+                                     n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead)
 
     ev = ShardedLogpEvaluator(global_batch, local_eval, device)
 
@@ -190,7 +194,8 @@ def main():
 
     # per-kernel durations, HIP events on the launch stream (rank 0's shard)
     kms = eng.profile_kernels(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter,
-                              reps=args.profile_reps, n_state_hint=hints[0], z_selector_hint=hints[1])
+                              reps=args.profile_reps, n_state_hint=hints[0], z_selector_hint=hints[1],
+                              solver=args.solver, n_lead_hint=n_lead)
     torch.cuda.synchronize()
 
     if rank == 0:
@@ -218,7 +223,7 @@ def main():
                 "workload": f"sw_shaped synthetic (SURVEY 8d): n=m={n}, n_state=18, n_lead=12, k={k}, p={p}, "
                             f"T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[2])",
                 "global_batch": global_batch,
-                "solver": "cycle_reduction",
+                "solver": args.solver,
                 "tol": args.tol,
                 "parallelism": f"draw-sharded x{world}, all_gather(logp,status)" if world > 1 else "single GPU",
             },

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 ABI_VERSION = 1
 MAX_N = 64
 MAX_N_CR = 48
+MAX_N_GENSYS = 64
 MAX_P = 16
 
 ST_OK = 0
@@ -22,6 +23,8 @@ ST_NOT_CONVERGED = 1
 ST_NAN = 2
 ST_LYAP_FAIL = 4
 ST_FILTER_NONFINITE = 8
+ST_GENSYS_QZ_FAIL = 16
+ST_GENSYS_TOO_BIG = 32
 
 Q_DIAG_SHARED, Q_DIAG_BATCHED, Q_FULL_SHARED, Q_FULL_BATCHED = 0, 1, 2, 3
 SOLVER_CYCLE_REDUCTION, SOLVER_GENSYS, SOLVER_BACKWARD_DIRECT = 0, 1, 2
@@ -49,6 +52,8 @@ PROTOTYPES = {
     "dsge_stream_synchronize": [_dp],
     "dsge_cycle_reduction_batched": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp, _dp],
     "dsge_cycle_reduction_batched_host": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp],
+    "dsge_gensys_batched": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp, _dp],
+    "dsge_gensys_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_selection_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
     "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_backward_direct_batched": [_dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
@@ -57,9 +62,9 @@ PROTOTYPES = {
     "dsge_lyapunov_batched_host": [_dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp],
     "dsge_kalman_logp_batched": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp, _dp],
     "dsge_kalman_logp_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp],
-    "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
-    "dsge_solve_kalman_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
-    "dsge_profile_pipeline": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _i, _dp, _dp],
+    "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_profile_pipeline": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _i, _dp, _dp],
 }
 
 _lib = None

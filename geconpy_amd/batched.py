@@ -50,6 +50,39 @@ def cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9):
     return T, status, n_iter
 
 
+def lead_hint(C, tol=0.0):
+    """Performance hint: number of columns of ``C`` (any leading batch axes) whose absolute column
+    sum exceeds ``tol`` in at least one draw -- the forward-looking variables (gensys.py:580-589)."""
+    C = np.asarray(C)
+    cs = np.abs(C).sum(axis=-2)
+    return int(np.count_nonzero(np.any(cs.reshape(-1, C.shape[-1]) > tol, axis=0)))
+
+
+def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None):
+    """Batched ``GensysWrapper`` / ``gensys_pt`` (gEconpy/solvers/gensys.py:634-683):
+    returns dict(T, success, eu, status[, R])."""
+    A, B, C = _check_abc(A, B, C)
+    nb, n, _ = A.shape
+    T = np.empty_like(A)
+    eu = np.empty((nb, 3), dtype=np.int32)
+    status = np.empty(nb, dtype=np.int32)
+    R = None
+    k = 1
+    if D is not None:
+        D = _f64(D, 3)
+        k = D.shape[2]
+        R = np.empty((nb, n, k))
+    nl = lead_hint(C, tol) if n_lead_hint is None else int(n_lead_hint)
+    _lib.check(
+        _lib.load().dsge_gensys_batched_host(_ptr(A), _ptr(B), _ptr(C), _ptr(D), nb, n, k, float(tol), nl, _ptr(T),
+                                             _ptr(R), _ptr(eu), _ptr(status))
+    )
+    out = dict(T=T, success=status == 0, eu=eu, status=status)
+    if R is not None:
+        out["R"] = R
+    return out
+
+
 def selection_batched(B, C, D, T, A=None):
     """R = -(C T + B)^-1 D (gEconpy/solvers/shared.py:74-75); with ``A`` also the residual
     ``sum((A + B T + C T T)^2)`` (gEconpy/model/statespace.py:213)."""
@@ -191,7 +224,7 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
 
 def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                               tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
-                              return_policy=False, n_state_hint=None, z_selector_hint=None):
+                              return_policy=False, n_state_hint=None, z_selector_hint=None, n_lead_hint=None):
     """One fused evaluation per draw: A,B,C,D -> T,R -> P0 -> logp.  ``tol``/``max_iter``
     default to what ``DSGEStateSpace.configure`` passes (statespace.py:835-836).
     Returns dict(logp, status[, T, R, resid, n_iter])."""
@@ -213,11 +246,12 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
         n_iter = np.empty(nb, dtype=np.int32)
     ns = state_hint(A) if n_state_hint is None else int(n_state_hint)
     zs = selector_hint(Z) if z_selector_hint is None else int(z_selector_hint)
+    nl = (lead_hint(C, tol) if solver == "gensys" else 0) if n_lead_hint is None else int(n_lead_hint)
     _lib.check(
         _lib.load().dsge_solve_kalman_logp_batched_host(
             _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb,
             n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter),
-            float(missing_fill_value), ns, zs, _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
+            float(missing_fill_value), ns, zs, nl, _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
         )
     )
     out = dict(logp=logp, status=status)

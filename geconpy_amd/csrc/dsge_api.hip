@@ -11,6 +11,7 @@
 
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
+#include "dsge_gensys.hpp"
 
 namespace {
 
@@ -207,6 +208,36 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
   return rc;
 }
 
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+// choose the on-chip pencil capacity (n_cap = n + l_cap) for gensys
+int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {
+  int l = (n_lead_hint > 0) ? n_lead_hint : n;
+  if (l > n) l = n;
+  if (n + l > DSGE_MAX_N_GENSYS) l = DSGE_MAX_N_GENSYS - n;
+  while (l >= 1 && dsge::gensys_smem_bytes(n, n + l, l) > LDS_LIMIT) {
+    if (n_lead_hint > 0) return fail(DSGE_ERR_INVALID, "gensys: n + n_lead_hint does not fit the 160 KB LDS");
+    --l;
+  }
+  if (l < 1) return fail(DSGE_ERR_INVALID, "gensys: model too large for the on-chip pencil");
+  *l_cap = l;
+  *n_cap = n + l;
+  return DSGE_SUCCESS;
+}
+
+int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
+                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st) {
+  int n_cap = 0, l_cap = 0;
+  int rc = gensys_caps(n, n_lead_hint, &n_cap, &l_cap);
+  if (rc) return rc;
+  const size_t lds = dsge::gensys_smem_bytes(n, n_cap, l_cap);
+  if ((rc = set_lds(dsge::gensys_kernel, lds))) return rc;
+  hipLaunchKernelGGL(dsge::gensys_kernel, dim3(batch), dim3(64), lds, st, A, B, C, batch, n, n_cap, l_cap, tol, T_out,
+                     eu_out, status);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
 int check_common(int batch, int n, int n_max) {
   if (batch < 0) return fail(DSGE_ERR_INVALID, "batch < 0");
   if (n < 1 || n > n_max) return fail(DSGE_ERR_INVALID, "n out of range (1.." + std::to_string(n_max) + ")");
@@ -270,6 +301,22 @@ int dsge_cycle_reduction_batched(const double* A, const double* B, const double*
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
   return launch_cr(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, (hipStream_t)stream);
+}
+
+int dsge_gensys_batched(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
+                        double tol, int n_lead_hint, double* T_out, double* R_out, int32_t* eu_out, int32_t* status,
+                        void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  if (rc) return rc;
+  if (!A || !B || !C || !T_out || !eu_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "R_out requires D and 1 <= k <= n");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  if ((rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, T_out, eu_out, status, (hipStream_t)stream))) return rc;
+  if (R_out)  // gensys_pt: R = -(C T + B)^-1 D  (gensys.py:681); computed for every draw, as the graph does
+    return launch_assemble(nullptr, B, C, D, T_out, nullptr, nullptr, 0, batch, n, k, R_out, nullptr, nullptr, nullptr,
+                           nullptr, 1, 0, (hipStream_t)stream);
+  return DSGE_SUCCESS;
 }
 
 int dsge_selection_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
@@ -341,9 +388,9 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
 static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
                     const double* Z, int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
                     const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
-                    double jitter, double missing_fill, int n_state_hint, int z_selector_hint, double* logp_out,
-                    int32_t* status_out, double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out,
-                    hipStream_t st, int reps, float* ms_out) {
+                    double jitter, double missing_fill, int n_state_hint, int z_selector_hint, int n_lead_hint,
+                    double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* resid_out,
+                    int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out) {
   int rc = check_common(batch, n, solver == DSGE_SOLVER_CYCLE_REDUCTION ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
@@ -351,19 +398,22 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
-  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_BACKWARD_DIRECT)
-    return fail(DSGE_ERR_INVALID, "solver not available in this build (cycle_reduction, backward_direct)");
+  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_BACKWARD_DIRECT && solver != DSGE_SOLVER_GENSYS)
+    return fail(DSGE_ERR_INVALID, "unknown solver code");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
 
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_scratch, 3 * align256(nn * 8) + align256(nk * 8) + 4096, &base))) return rc;
+  if ((rc = arena_reserve(g_scratch, 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 4096,
+                          &base)))
+    return rc;
   Carver cv(base);
   double* Tw = T_out ? T_out : cv.take<double>(nn);
   double* Rw = R_out ? R_out : cv.take<double>(nk);
   double* RQR = cv.take<double>(nn);
   double* P0 = cv.take<double>(nn);
+  int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float acc_ms[3] = {0.f, 0.f, 0.f};
@@ -374,6 +424,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
     if (solver == DSGE_SOLVER_CYCLE_REDUCTION) {
       rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, n_iter_out, st);
+    } else if (solver == DSGE_SOLVER_GENSYS) {
+      if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
+      rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st);
     } else {
       HIP_TRY(hipMemsetAsync(status_out, 0, sizeof(int32_t) * batch, st));
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
@@ -411,24 +464,24 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                                    int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
                                    const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
                                    int T_len, int solver, double tol, int max_iter, double jitter, double missing_fill,
-                                   int n_state_hint, int z_selector_hint, double* logp_out, int32_t* status_out,
-                                   double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out,
-                                   void* stream) {
+                                   int n_state_hint, int z_selector_hint, int n_lead_hint, double* logp_out,
+                                   int32_t* status_out, double* T_out, double* R_out, double* resid_out,
+                                   int32_t* n_iter_out, void* stream) {
   return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
-                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, T_out,
-                  R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
+                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, n_lead_hint, logp_out, status_out,
+                  T_out, R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
 }
 
 int dsge_profile_pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q,
                           int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
                           const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
                           int T_len, int solver, double tol, int max_iter, double jitter, double missing_fill,
-                          int n_state_hint, int z_selector_hint, double* logp_out, int32_t* status_out, int reps,
-                          float* ms_out, void* stream) {
+                          int n_state_hint, int z_selector_hint, int n_lead_hint, double* logp_out,
+                          int32_t* status_out, int reps, float* ms_out, void* stream) {
   if (!ms_out || reps < 1) return fail(DSGE_ERR_INVALID, "ms_out null or reps < 1");
   return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
-                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, nullptr,
-                  nullptr, nullptr, nullptr, (hipStream_t)stream, reps, ms_out);
+                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, n_lead_hint, logp_out, status_out,
+                  nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, reps, ms_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -465,6 +518,42 @@ int dsge_cycle_reduction_batched_host(const double* A, const double* B, const do
   DOWN(T_out, dT, nn, double);
   DOWN(status, dS, batch, int32_t);
   DOWN(n_iter, dI, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_gensys_batched_host(const double* A, const double* B, const double* C, const double* D, int batch, int n,
+                             int k, double tol, int n_lead_hint, double* T_out, double* R_out, int32_t* eu_out,
+                             int32_t* status) {
+  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  if (rc) return rc;
+  if (!A || !B || !C || !T_out || !eu_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "R_out requires D and 1 <= k <= n");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * (R_out ? k : 0);
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256(nk * 8) + 2 * align256((size_t)batch * 12) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  const double* dDp = nullptr;
+  if (R_out) {
+    UP(dD, D, nk, double);
+    dDp = dD;
+  }
+  OUTBUF(dT, T_out, nn, double);
+  OUTBUF(dR, R_out, nk, double);
+  OUTBUF(dE, eu_out, (size_t)batch * 3, int32_t);
+  OUTBUF(dS, status, batch, int32_t);
+  if ((rc = dsge_gensys_batched(dA, dB, dC, dDp, batch, n, k, tol, n_lead_hint, dT, dR, dE, dS, nullptr))) return rc;
+  DOWN(T_out, dT, nn, double);
+  DOWN(R_out, dR, nk, double);
+  DOWN(eu_out, dE, (size_t)batch * 3, int32_t);
+  DOWN(status, dS, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }
@@ -599,8 +688,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                                         int n, int k, int p, int T_len, int solver, double tol, int max_iter,
                                         double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                                        double* logp_out, int32_t* status_out, double* T_out, double* R_out,
-                                        double* resid_out, int32_t* n_iter_out) {
+                                        int n_lead_hint, double* logp_out, int32_t* status_out, double* T_out,
+                                        double* R_out, double* resid_out, int32_t* n_iter_out) {
   int rc = check_common(batch, n, DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
@@ -638,7 +727,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   OUTBUF(dI, n_iter_out, batch, int32_t);
   if ((rc = dsge_solve_kalman_logp_batched(dA, dB, dC, dD, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy,
                                            batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
-                                           n_state_hint, z_selector_hint, dL, dS, dT, dR, dRes, dI, nullptr)))
+                                           n_state_hint, z_selector_hint, n_lead_hint, dL, dS, dT, dR, dRes, dI,
+                                           nullptr)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_out, dS, batch, int32_t);

@@ -1,0 +1,712 @@
+// gensys on one wavefront: ordered complex generalized Schur decomposition + Sims' existence /
+// uniqueness algebra.  Replaces _gensys_setup + _gensys_core as GensysWrapper uses them
+// (gEconpy/solvers/gensys.py:568-614, :190-395, :657-666): outputs T = G1[:n,:n] and eu[3].
+//
+// The reference calls LAPACK zgges + ztgsen (complex QZ of the real pencil), two gesdd SVDs, one
+// complex LU.  The same mathematics is executed here with wavefront-level Givens rotations:
+//   1. pencil (G0, G1) by index arithmetic, X = Pi (tracks Q Pi), Ztop = I[:n] (tracks Z[:n,:])
+//   2. G1 -> upper triangular, G0 -> upper Hessenberg (row / column Givens pairs)
+//   3. complex single-shift QZ, LAPACK zhgeqz deflation logic (negligible sub-diagonal of H,
+//      negligible diagonal of T incl. the two "chase the zero" procedures; Wilkinson shift,
+//      exceptional shift every 10th iteration)
+//   4. stable roots first (gensys.py:246 criterion) by adjacent 1x1 swaps (ztgex2)
+//   5. post-processing in the partitioned basis: one-sided Jacobi SVDs of Q2 Pi, Q1 Pi and of the
+//      uniqueness matrix, Phi, and T = Re(Ztop[:, :ns] A11^-1 [B11, B12 - Phi B22] Ztop^H).
+//      In this basis G_0 of gensys.py:322-330 is upper triangular, so the reference's LU is a
+//      back-substitution.
+// The arithmetic is restated statement by statement in tests/device_models/gensys_qz_model.py,
+// which is validated on the CPU against the oracle (LAPACK) and the golden vectors.
+//
+// One rotation touches two rows (or columns) of H, T and X (or Ztop): lanes own columns (rows),
+// so a rotation is two 16-byte LDS loads, a complex 2x2 rotation and two stores per lane and
+// matrix.  Everything stays in LDS: H, T (N x N complex), X (N x l), Ztop (n x N).
+#pragma once
+#include "dsge_device.hpp"
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge {
+
+struct cx {
+  double re, im;
+};
+__device__ __forceinline__ cx mk(double r, double i) { return cx{r, i}; }
+__device__ __forceinline__ cx operator+(cx a, cx b) { return cx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cx operator-(cx a, cx b) { return cx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cx operator*(cx a, cx b) {
+  return cx{fma(a.re, b.re, -a.im * b.im), fma(a.re, b.im, a.im * b.re)};
+}
+__device__ __forceinline__ cx operator*(double s, cx a) { return cx{s * a.re, s * a.im}; }
+__device__ __forceinline__ cx conj(cx a) { return cx{a.re, -a.im}; }
+__device__ __forceinline__ cx neg(cx a) { return cx{-a.re, -a.im}; }
+__device__ __forceinline__ double cabs_(cx a) { return hypot(a.re, a.im); }
+__device__ __forceinline__ double abs1(cx a) { return fabs(a.re) + fabs(a.im); }
+__device__ __forceinline__ bool is0(cx a) { return a.re == 0.0 && a.im == 0.0; }
+__device__ __forceinline__ cx cdiv(cx a, cx b) {
+  // Smith's algorithm
+  if (fabs(b.re) >= fabs(b.im)) {
+    const double r = b.im / b.re, d = b.re + b.im * r;
+    return cx{(a.re + a.im * r) / d, (a.im - a.re * r) / d};
+  }
+  const double r = b.re / b.im, d = b.re * r + b.im;
+  return cx{(a.re * r + a.im) / d, (a.im * r - a.re) / d};
+}
+__device__ __forceinline__ cx csqrt_(cx a) {
+  const double m = hypot(a.re, a.im);
+  if (m == 0.0) return cx{0.0, 0.0};
+  double re = sqrt(0.5 * (m + fabs(a.re)));
+  double im = 0.5 * a.im / re;
+  if (a.re < 0.0) {
+    const double t = re;
+    re = fabs(im);
+    im = (a.im >= 0.0) ? t : -t;
+  }
+  return cx{re, im};
+}
+// make a value that is identical in every lane provably uniform for the compiler
+__device__ __forceinline__ double uni(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cx uni(cx v) { return cx{uni(v.re), uni(v.im)}; }
+
+// c (real), s, r with [c s; -conj(s) c] [f; g] = [r; 0]
+__device__ __forceinline__ void lartg(cx f, cx g, double& c, cx& s, cx& r) {
+  if (is0(g)) {
+    c = 1.0;
+    s = mk(0, 0);
+    r = f;
+    return;
+  }
+  if (is0(f)) {
+    const double ag = cabs_(g);
+    c = 0.0;
+    s = (1.0 / ag) * conj(g);
+    r = mk(ag, 0);
+    return;
+  }
+  const double af = cabs_(f), ag = cabs_(g), d = hypot(af, ag);
+  const cx ph = (1.0 / af) * f;
+  c = af / d;
+  s = (1.0 / d) * (ph * conj(g));
+  r = d * ph;
+}
+
+struct GsLayout {
+  int N, n, ell, ldh, ldx, ldz;  // complex leading dimensions (odd)
+  cx *H, *T, *X, *Z, *V1, *V2, *S3;
+  double *s1, *s2;
+  int* lead;
+};
+
+__host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap) {
+  const int ldh = n_cap | 1, ldx = l_cap | 1;
+  const size_t cplx = (size_t)2 * n_cap * ldh + (size_t)n_cap * ldx + (size_t)n * ldh + (size_t)3 * l_cap * ldx;
+  return cplx * 16 + (size_t)2 * 64 * 8 + 64 * 4 + 64;
+}
+
+#define GH(i, j) L.H[(i)*L.ldh + (j)]
+#define GT(i, j) L.T[(i)*L.ldh + (j)]
+#define GX(i, j) L.X[(i)*L.ldx + (j)]
+#define GZ(i, j) L.Z[(i)*L.ldz + (j)]
+
+__device__ __forceinline__ void rot2(cx& x, cx& y, double c, cx s) {
+  const cx tx = c * x + s * y;
+  y = c * y - conj(s) * x;
+  x = tx;
+}
+
+// rows i (x) and k (y) of H, T (columns c0..N-1) and X
+__device__ __forceinline__ void rot_rows(const GsLayout& L, int i, int k, double c, cx s, int c0, int lane) {
+  for (int col = c0 + lane; col < L.N; col += 64) {
+    cx x = GH(i, col), y = GH(k, col);
+    rot2(x, y, c, s);
+    GH(i, col) = x;
+    GH(k, col) = y;
+    x = GT(i, col);
+    y = GT(k, col);
+    rot2(x, y, c, s);
+    GT(i, col) = x;
+    GT(k, col) = y;
+  }
+  if (lane < L.ell) {
+    cx x = GX(i, lane), y = GX(k, lane);
+    rot2(x, y, c, s);
+    GX(i, lane) = x;
+    GX(k, lane) = y;
+  }
+  wave_sync();
+}
+
+// columns i (x) and k (y) of H, T (rows 0..r1) and Ztop
+__device__ __forceinline__ void rot_cols(const GsLayout& L, int i, int k, double c, cx s, int r1, int lane) {
+  for (int row = lane; row <= r1; row += 64) {
+    cx x = GH(row, i), y = GH(row, k);
+    rot2(x, y, c, s);
+    GH(row, i) = x;
+    GH(row, k) = y;
+    x = GT(row, i);
+    y = GT(row, k);
+    rot2(x, y, c, s);
+    GT(row, i) = x;
+    GT(row, k) = y;
+  }
+  if (lane < L.n) {
+    cx x = GZ(lane, i), y = GZ(lane, k);
+    rot2(x, y, c, s);
+    GZ(lane, i) = x;
+    GZ(lane, k) = y;
+  }
+  wave_sync();
+}
+
+__device__ __forceinline__ void set_elem(cx* p, cx v, int lane) {
+  if (lane == 0) *p = v;
+}
+
+// ---- step 2: Hessenberg-triangular reduction ---------------------------------------------------
+__device__ __forceinline__ void hess_tri(const GsLayout& L, int lane) {
+  const int N = L.N;
+  double c;
+  cx s, r;
+  // T = [[A, 0], [0, I]]: only the leading n x n block can have sub-diagonal entries, and row
+  // rotations inside that block leave the identity block alone
+  for (int j = 0; j < L.n - 1; ++j)
+    for (int i = L.n - 1; i > j; --i) {
+      const cx g = uni(GT(i, j));
+      if (is0(g)) continue;
+      lartg(uni(GT(i - 1, j)), g, c, s, r);
+      rot_rows(L, i - 1, i, c, s, 0, lane);
+      set_elem(&GT(i - 1, j), r, lane);
+      set_elem(&GT(i, j), mk(0, 0), lane);
+      wave_sync();
+    }
+  for (int j = 0; j < N - 2; ++j)
+    for (int i = N - 1; i > j + 1; --i) {
+      const cx g = uni(GH(i, j));
+      if (is0(g)) continue;
+      lartg(uni(GH(i - 1, j)), g, c, s, r);
+      rot_rows(L, i - 1, i, c, s, 0, lane);
+      set_elem(&GH(i - 1, j), r, lane);
+      set_elem(&GH(i, j), mk(0, 0), lane);
+      wave_sync();
+      const cx g2 = uni(GT(i, i - 1));
+      if (!is0(g2)) {
+        lartg(uni(GT(i, i)), g2, c, s, r);
+        rot_cols(L, i, i - 1, c, s, N - 1, lane);
+        set_elem(&GT(i, i), r, lane);
+        set_elem(&GT(i, i - 1), mk(0, 0), lane);
+        wave_sync();
+      }
+    }
+}
+
+__device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane) {
+  double acc = 0.0;
+  for (int idx = lane; idx < N * N; idx += 64) {
+    const int i = idx / N, j = idx - i * N;
+    const cx v = M[i * ld + j];
+    acc = fma(v.re, v.re, acc);
+    acc = fma(v.im, v.im, acc);
+  }
+  return sqrt(uni(wave_sum(acc)));
+}
+
+// ---- step 3: complex single-shift QZ (zhgeqz, JOB='S') -------------------------------------------
+__device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
+  const int N = L.N;
+  if (N <= 1) return true;
+  const double SAFMIN = 2.2250738585072014e-308, ULP = 2.220446049250313e-16;
+  const double anorm = frob_norm(L.H, L.ldh, N, lane), bnorm = frob_norm(L.T, L.ldh, N, lane);
+  const double atol = fmax(SAFMIN, ULP * anorm), btol = fmax(SAFMIN, ULP * bnorm);
+  const double ascale = 1.0 / fmax(SAFMIN, anorm), bscale = 1.0 / fmax(SAFMIN, bnorm);
+  const int ilo = 0;
+  int ilast = N - 1, iiter = 0;
+  cx eshift = mk(0, 0);
+  const int maxit = 30 * N;
+  double c;
+  cx s, r;
+  for (int jiter = 0; jiter < maxit; ++jiter) {
+    // action: 0 = none, 1 = split (label 60), 2 = zero T (label 50), 3 = QZ sweep from ifirst
+    int action = 0, ifirst = 0;
+    if (ilast == ilo) {
+      action = 1;
+    } else if (abs1(uni(GH(ilast, ilast - 1))) <=
+               fmax(SAFMIN, ULP * (abs1(uni(GH(ilast, ilast))) + abs1(uni(GH(ilast - 1, ilast - 1)))))) {
+      set_elem(&GH(ilast, ilast - 1), mk(0, 0), lane);
+      wave_sync();
+      action = 1;
+    } else if (cabs_(uni(GT(ilast, ilast))) <= btol) {
+      set_elem(&GT(ilast, ilast), mk(0, 0), lane);
+      wave_sync();
+      action = 2;
+    } else {
+      for (int j = ilast - 1; j >= ilo && action == 0; --j) {
+        bool ilazro;
+        if (j == ilo) {
+          ilazro = true;
+        } else if (abs1(uni(GH(j, j - 1))) <=
+                   fmax(SAFMIN, ULP * (abs1(uni(GH(j, j))) + abs1(uni(GH(j - 1, j - 1)))))) {
+          set_elem(&GH(j, j - 1), mk(0, 0), lane);
+          wave_sync();
+          ilazro = true;
+        } else {
+          ilazro = false;
+        }
+        if (cabs_(uni(GT(j, j))) < btol) {
+          set_elem(&GT(j, j), mk(0, 0), lane);
+          wave_sync();
+          bool ilazr2 = false;
+          if (!ilazro) {
+            if (abs1(uni(GH(j, j - 1))) * (ascale * abs1(uni(GH(j + 1, j)))) <=
+                abs1(uni(GH(j, j))) * (ascale * atol))
+              ilazr2 = true;
+          }
+          if (ilazro || ilazr2) {
+            action = 2;  // if the loop below runs to completion
+            for (int jch = j; jch < ilast; ++jch) {
+              lartg(uni(GH(jch, jch)), uni(GH(jch + 1, jch)), c, s, r);
+              rot_rows(L, jch, jch + 1, c, s, 0, lane);
+              set_elem(&GH(jch, jch), r, lane);
+              set_elem(&GH(jch + 1, jch), mk(0, 0), lane);
+              if (ilazr2) set_elem(&GH(jch, jch - 1), c * uni(GH(jch, jch - 1)), lane);
+              wave_sync();
+              ilazr2 = false;
+              if (abs1(uni(GT(jch + 1, jch + 1))) >= btol) {
+                if (jch + 1 >= ilast) {
+                  action = 1;
+                } else {
+                  action = 3;
+                  ifirst = jch + 1;
+                }
+                break;
+              }
+              set_elem(&GT(jch + 1, jch + 1), mk(0, 0), lane);
+              wave_sync();
+            }
+          } else {
+            for (int jch = j; jch < ilast; ++jch) {
+              lartg(uni(GT(jch, jch + 1)), uni(GT(jch + 1, jch + 1)), c, s, r);
+              rot_rows(L, jch, jch + 1, c, s, 0, lane);
+              set_elem(&GT(jch, jch + 1), r, lane);
+              set_elem(&GT(jch + 1, jch + 1), mk(0, 0), lane);
+              wave_sync();
+              lartg(uni(GH(jch + 1, jch)), uni(GH(jch + 1, jch - 1)), c, s, r);
+              rot_cols(L, jch, jch - 1, c, s, N - 1, lane);
+              set_elem(&GH(jch + 1, jch), r, lane);
+              set_elem(&GH(jch + 1, jch - 1), mk(0, 0), lane);
+              wave_sync();
+            }
+            action = 2;
+          }
+        } else if (ilazro) {
+          action = 3;
+          ifirst = j;
+        }
+      }
+      if (action == 0) return false;
+    }
+    if (action == 2) {
+      lartg(uni(GH(ilast, ilast)), uni(GH(ilast, ilast - 1)), c, s, r);
+      rot_cols(L, ilast, ilast - 1, c, s, N - 1, lane);
+      set_elem(&GH(ilast, ilast), r, lane);
+      set_elem(&GH(ilast, ilast - 1), mk(0, 0), lane);
+      wave_sync();
+      action = 1;
+    }
+    if (action == 1) {
+      --ilast;
+      if (ilast < ilo) return true;
+      iiter = 0;
+      eshift = mk(0, 0);
+      continue;
+    }
+    // ---- one QZ sweep on ifirst..ilast
+    ++iiter;
+    cx shift;
+    if (iiter % 10 != 0) {
+      const cx t_ll = bscale * uni(GT(ilast, ilast)), t_mm = bscale * uni(GT(ilast - 1, ilast - 1));
+      const cx u12 = cdiv(bscale * uni(GT(ilast - 1, ilast)), t_ll);
+      const cx ad11 = cdiv(ascale * uni(GH(ilast - 1, ilast - 1)), t_mm);
+      const cx ad21 = cdiv(ascale * uni(GH(ilast, ilast - 1)), t_mm);
+      const cx ad12 = cdiv(ascale * uni(GH(ilast - 1, ilast)), t_ll);
+      const cx ad22 = cdiv(ascale * uni(GH(ilast, ilast)), t_ll);
+      const cx abi22 = ad22 - u12 * ad21;
+      const cx t1 = 0.5 * (ad11 + abi22);
+      const cx rtdisc = csqrt_(t1 * t1 + ad12 * ad21 - ad11 * ad22);
+      const cx dd = t1 - abi22;
+      const double temp = dd.re * rtdisc.re + dd.im * rtdisc.im;
+      shift = (temp <= 0.0) ? (t1 + rtdisc) : (t1 - rtdisc);
+    } else {
+      eshift = eshift + cdiv(ascale * uni(GH(ilast, ilast - 1)), bscale * uni(GT(ilast - 1, ilast - 1)));
+      shift = eshift;
+    }
+    int istart = ifirst;
+    cx ctemp = ascale * uni(GH(ifirst, ifirst)) - shift * (bscale * uni(GT(ifirst, ifirst)));
+    for (int j = ilast - 1; j > ifirst; --j) {
+      const cx ct = ascale * uni(GH(j, j)) - shift * (bscale * uni(GT(j, j)));
+      double temp = abs1(ct), temp2 = ascale * abs1(uni(GH(j + 1, j)));
+      const double tempr = fmax(temp, temp2);
+      if (tempr < 1.0 && tempr != 0.0) {
+        temp /= tempr;
+        temp2 /= tempr;
+      }
+      if (abs1(uni(GH(j, j - 1))) * temp2 <= temp * atol) {
+        istart = j;
+        ctemp = ct;
+        break;
+      }
+    }
+    lartg(ctemp, ascale * uni(GH(istart + 1, istart)), c, s, r);
+    for (int j = istart; j < ilast; ++j) {
+      if (j > istart) {
+        lartg(uni(GH(j, j - 1)), uni(GH(j + 1, j - 1)), c, s, r);
+        rot_rows(L, j, j + 1, c, s, 0, lane);
+        set_elem(&GH(j, j - 1), r, lane);
+        set_elem(&GH(j + 1, j - 1), mk(0, 0), lane);
+        wave_sync();
+      } else {
+        rot_rows(L, j, j + 1, c, s, 0, lane);
+      }
+      lartg(uni(GT(j + 1, j + 1)), uni(GT(j + 1, j)), c, s, r);
+      rot_cols(L, j + 1, j, c, s, N - 1, lane);
+      set_elem(&GT(j + 1, j + 1), r, lane);
+      set_elem(&GT(j + 1, j), mk(0, 0), lane);
+      wave_sync();
+    }
+  }
+  return false;
+}
+
+// ---- step 4: reordering --------------------------------------------------------------------------
+__device__ __forceinline__ bool root_is_stable(cx a, cx b, double rs) {
+  const double aa = cabs_(a), ab = cabs_(b);
+  return (ab < rs && aa >= rs) || (ab >= rs && aa > ab);
+}
+
+__device__ __forceinline__ void swap_adjacent(const GsLayout& L, int k, int lane) {
+  const cx h00 = uni(GH(k, k)), h01 = uni(GH(k, k + 1)), h11 = uni(GH(k + 1, k + 1));
+  const cx t00 = uni(GT(k, k)), t01 = uni(GT(k, k + 1)), t11 = uni(GT(k + 1, k + 1));
+  const cx f = h11 * t00 - t11 * h00;
+  const cx g = h11 * t01 - t11 * h01;
+  const double sa = cabs_(h11), sb = cabs_(t11);
+  double c;
+  cx s, r;
+  lartg(g, f, c, s, r);
+  rot_cols(L, k, k + 1, c, neg(conj(s)), L.N - 1, lane);
+  if (sa >= sb)
+    lartg(uni(GH(k, k)), uni(GH(k + 1, k)), c, s, r);
+  else
+    lartg(uni(GT(k, k)), uni(GT(k + 1, k)), c, s, r);
+  rot_rows(L, k, k + 1, c, s, 0, lane);
+  set_elem(&GH(k + 1, k), mk(0, 0), lane);
+  set_elem(&GT(k + 1, k), mk(0, 0), lane);
+  wave_sync();
+}
+
+__device__ __forceinline__ int reorder_stable_first(const GsLayout& L, double rs, int lane) {
+  int ns = 0;
+  for (int i = 0; i < L.N; ++i) {
+    if (root_is_stable(uni(GH(i, i)), uni(GT(i, i)), rs)) {
+      for (int k = i - 1; k >= ns; --k) swap_adjacent(L, k, lane);
+      ++ns;
+    }
+  }
+  return ns;
+}
+
+// ---- step 5 helpers: one-sided Jacobi SVD on the columns of G (rows r0..r0+nr-1 of a row-major
+// complex array with leading dimension ldg, nc columns).  V (nc x nc, ld ldv) accumulates the right
+// transformation when V != nullptr.  On exit sig[j] = ||column j||.  Lanes own rows.
+__device__ __forceinline__ void jacobi_svd(cx* G, int ldg, int nr, int nc, cx* V, int ldv, double* sig, int lane) {
+  if (V) {
+    for (int idx = lane; idx < nc * nc; idx += 64) {
+      const int i = idx / nc, j = idx - i * nc;
+      V[i * ldv + j] = mk(i == j ? 1.0 : 0.0, 0.0);
+    }
+  }
+  wave_sync();
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < nc - 1; ++p)
+      for (int q = p + 1; q < nc; ++q) {
+        double al = 0.0, be = 0.0, gr = 0.0, gi = 0.0;
+        for (int row = lane; row < nr; row += 64) {
+          const cx gp = G[row * ldg + p], gq = G[row * ldg + q];
+          al += gp.re * gp.re + gp.im * gp.im;
+          be += gq.re * gq.re + gq.im * gq.im;
+          // conj(gp) * gq
+          gr += gp.re * gq.re + gp.im * gq.im;
+          gi += gp.re * gq.im - gp.im * gq.re;
+        }
+        al = uni(wave_sum(al));
+        be = uni(wave_sum(be));
+        gr = uni(wave_sum(gr));
+        gi = uni(wave_sum(gi));
+        const double ag = hypot(gr, gi);
+        if (ag < 1e-290 || ag <= 1e-15 * sqrt(al) * sqrt(be)) continue;
+        rotated = true;
+        const cx phc = mk(gr / ag, -gi / ag);  // conj(phase)
+        const double zeta = (be - al) / (2.0 * ag);
+        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + hypot(1.0, zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        for (int row = lane; row < nr; row += 64) {
+          const cx gp = G[row * ldg + p], gq = G[row * ldg + q] * phc;
+          G[row * ldg + p] = cs * gp - sn * gq;
+          G[row * ldg + q] = sn * gp + cs * gq;
+        }
+        if (V) {
+          for (int row = lane; row < nc; row += 64) {
+            const cx gp = V[row * ldv + p], gq = V[row * ldv + q] * phc;
+            V[row * ldv + p] = cs * gp - sn * gq;
+            V[row * ldv + q] = sn * gp + cs * gq;
+          }
+        }
+        wave_sync();
+      }
+    if (!rotated) break;
+  }
+  for (int j = 0; j < nc; ++j) {
+    double al = 0.0;
+    for (int row = lane; row < nr; row += 64) {
+      const cx gp = G[row * ldg + j];
+      al += gp.re * gp.re + gp.im * gp.im;
+    }
+    al = uni(wave_sum(al));
+    if (lane == 0) sig[j] = sqrt(al);
+  }
+  wave_sync();
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                     const double* __restrict__ C, int batch, int n, int n_cap,
+                                                     int l_cap, double tol, double* __restrict__ T_out,
+                                                     int32_t* __restrict__ eu_out, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  GsLayout L;
+  L.n = n;
+  L.ldh = n_cap | 1;
+  L.ldx = l_cap | 1;
+  L.ldz = L.ldh;
+  L.H = reinterpret_cast<cx*>(smem);
+  L.T = L.H + n_cap * L.ldh;
+  L.X = L.T + n_cap * L.ldh;
+  L.Z = L.X + n_cap * L.ldx;
+  L.V1 = L.Z + n * L.ldh;
+  L.V2 = L.V1 + l_cap * L.ldx;
+  L.S3 = L.V2 + l_cap * L.ldx;
+  L.s1 = reinterpret_cast<double*>(L.S3 + l_cap * L.ldx);
+  L.s2 = L.s1 + 64;
+  L.lead = reinterpret_cast<int*>(L.s2 + 64);
+  const double rs = (tol > 0.0) ? tol : 2.220446049250313e-16;
+  const size_t total_cx = (size_t)2 * n_cap * L.ldh + (size_t)n_cap * L.ldx + (size_t)n * L.ldh + (size_t)3 * l_cap * L.ldx;
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    const double* Ag = A + off;
+    const double* Bg = B + off;
+    const double* Cg = C + off;
+    wave_sync();
+    for (size_t idx = lane; idx < total_cx; idx += 64) L.H[idx] = mk(0, 0);
+    // ---- lead columns (gensys.py:580-589) and pencil (gensys.py:591-614), index arithmetic only
+    int ell = 0;
+    unsigned long long a_colmask = 0ull;  // columns of A with any non-zero entry (the state variables)
+    {
+      double cs = 0.0;
+      bool anz = false;
+      if (lane < n)
+        for (int i = 0; i < n; ++i) {
+          cs += fabs(Cg[(size_t)i * n + lane]);
+          anz = anz || (Ag[(size_t)i * n + lane] != 0.0);
+        }
+      a_colmask = __ballot(anz);
+      const unsigned long long lm = __ballot(lane < n && cs > tol);
+      ell = __popcll(lm);
+      if (lane < n && ((lm >> lane) & 1ull)) L.lead[__popcll(lm & ((1ull << lane) - 1ull))] = lane;
+    }
+    const int N = n + ell;
+    if (N > n_cap || ell > l_cap) {
+      for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+      if (lane == 0) {
+        eu_out[3 * draw] = eu_out[3 * draw + 1] = -3;
+        eu_out[3 * draw + 2] = 0;
+        status[draw] = DSGE_ST_NOT_CONVERGED | DSGE_ST_GENSYS_TOO_BIG;
+      }
+      continue;
+    }
+    L.N = N;
+    L.ell = ell;
+    wave_sync();
+    for (int idx = lane; idx < n * n; idx += 64) {
+      const int i = idx / n, j = idx - i * n;
+      GH(i, j) = mk(-Bg[idx], 0.0);
+      GT(i, j) = mk(Ag[idx], 0.0);
+    }
+    for (int idx = lane; idx < n * ell; idx += 64) {
+      const int i = idx / ell, a = idx - i * ell;
+      GH(i, n + a) = mk(-Cg[(size_t)i * n + L.lead[a]], 0.0);
+    }
+    if (lane < ell) {
+      GH(n + lane, L.lead[lane]) = mk(1.0, 0.0);
+      GT(n + lane, n + lane) = mk(1.0, 0.0);
+      GX(n + lane, lane) = mk(1.0, 0.0);
+    }
+    if (lane < n) GZ(lane, lane) = mk(1.0, 0.0);
+    wave_sync();
+
+    hess_tri(L, lane);
+    const bool converged = qz_iterate(L, lane);
+    int eu0 = 0, eu1 = 0, eu2 = 0;
+    bool have_T = false;
+    if (!converged) {
+      eu0 = eu1 = -3;
+    } else {
+      const int ns = reorder_stable_first(L, rs, lane);
+      const int nu = N - ns;
+      // coincident zeros (gensys.py:243-244)
+      bool zxz = false;
+      for (int i = 0; i < N; ++i)
+        if (cabs_(uni(GH(i, i))) < rs && cabs_(uni(GT(i, i))) < rs) zxz = true;
+      if (zxz) {
+        eu0 = eu1 = -2;
+      } else {
+        // SVDs of eta2 = X[ns:], eta1 = X[:ns] in place (G = eta V)
+        int r2 = 0, r1 = 0;
+        if (nu > 0) {
+          jacobi_svd(&GX(ns, 0), L.ldx, nu, ell, L.V2, L.ldx, L.s2, lane);
+          for (int j = 0; j < ell; ++j) r2 += (L.s2[j] > rs) ? 1 : 0;
+        } else {
+          if (lane < ell) L.s2[lane] = 0.0;
+          wave_sync();
+        }
+        if (r2 >= nu) eu0 = 1;
+        if (ns > 0) {
+          jacobi_svd(&GX(0, 0), L.ldx, ns, ell, L.V1, L.ldx, L.s1, lane);
+          for (int j = 0; j < ell; ++j) r1 += (L.s1[j] > rs) ? 1 : 0;
+        } else {
+          if (lane < ell) L.s1[lane] = 0.0;
+          wave_sync();
+        }
+        // uniqueness: rank of V1k - V2k V2k^H V1k  (gensys.py:301-310); columns of S3 = kept cols of V1
+        bool unique = true;
+        if (r1 > 0) {
+          // S3[:, jj] for kept j: v1_j - sum_{kept c} v2_c (v2_c^H v1_j)
+          int jj = 0;
+          for (int j = 0; j < ell; ++j) {
+            if (!(L.s1[j] > rs)) continue;
+            cx acc = mk(0, 0);
+            if (lane < ell) acc = L.V1[lane * L.ldx + j];
+            for (int cc = 0; cc < ell; ++cc) {
+              if (!(L.s2[cc] > rs)) continue;
+              // dot = v2_c^H v1_j
+              cx part = mk(0, 0);
+              if (lane < ell) part = conj(L.V2[lane * L.ldx + cc]) * L.V1[lane * L.ldx + j];
+              const double dr = uni(wave_sum(part.re)), di = uni(wave_sum(part.im));
+              if (lane < ell) acc = acc - L.V2[lane * L.ldx + cc] * mk(dr, di);
+            }
+            if (lane < ell) L.S3[lane * L.ldx + jj] = acc;
+            ++jj;
+          }
+          wave_sync();
+          double* s3 = L.s1 + 32;  // scratch for the singular values of the uniqueness matrix
+          jacobi_svd(L.S3, L.ldx, ell, r1, nullptr, 0, s3, lane);
+          int n_loose = 0;
+          for (int j = 0; j < r1; ++j) n_loose += (s3[j] > rs * (double)N) ? 1 : 0;
+          eu2 = n_loose;
+          unique = (n_loose == 0);
+        }
+        if (unique) eu1 = 1;
+
+        // ---- Phi = (G1k V1k^H)(V2k D2k^-2 G2k^H)  (ns x nu), stored transposed-free in the unused
+        // lower-left block of H:  Phi[i][j] at H[ns + j][i]
+        // M12 = V1k^H V2k D2k^-2   (ell x ell, rows = columns j of V1 (kept), cols = columns c of V2 (kept))
+        for (int idx = lane; idx < ell * ell; idx += 64) {
+          const int j = idx / ell, cc = idx - j * ell;
+          cx acc = mk(0, 0);
+          if (L.s1[j] > rs && L.s2[cc] > rs) {
+            for (int q = 0; q < ell; ++q) acc = acc + conj(L.V1[q * L.ldx + j]) * L.V2[q * L.ldx + cc];
+            const double w = 1.0 / (L.s2[cc] * L.s2[cc]);
+            acc = w * acc;
+          }
+          L.S3[j * L.ldx + cc] = acc;
+        }
+        wave_sync();
+        // Phi[i][u] = sum_j G1[i][j] (sum_c M12[j][c] conj(G2[u][c]))
+        for (int idx = lane; idx < ns * nu; idx += 64) {
+          const int i = idx / nu, u = idx - i * nu;
+          cx acc = mk(0, 0);
+          for (int j = 0; j < ell; ++j) {
+            if (!(L.s1[j] > rs)) continue;
+            cx inner = mk(0, 0);
+            for (int cc = 0; cc < ell; ++cc) inner = inner + L.S3[j * L.ldx + cc] * conj(GX(ns + u, cc));
+            acc = acc + GX(i, j) * inner;
+          }
+          GH(ns + u, i) = acc;
+        }
+        wave_sync();
+        // rhs = [B11, B12 - Phi B22] in place in T[:ns, :]
+        for (int idx = lane; idx < ns * nu; idx += 64) {
+          const int i = idx / nu, cc = idx - i * nu;
+          cx acc = GT(i, ns + cc);
+          for (int u = 0; u <= cc; ++u) acc = acc - GH(ns + u, i) * GT(ns + u, ns + cc);
+          GT(i, ns + cc) = acc;
+        }
+        wave_sync();
+        // Y = A11^-1 rhs by back-substitution, one column per lane, in place in T[:ns, :]
+        for (int col = lane; col < N; col += 64) {
+          for (int i = ns - 1; i >= 0; --i) {
+            cx acc = GT(i, col);
+            for (int k2 = i + 1; k2 < ns; ++k2) acc = acc - GH(i, k2) * GT(k2, col);
+            GT(i, col) = cdiv(acc, GH(i, i));
+          }
+        }
+        wave_sync();
+        // W = Y Ztop^H (ns x n) into H[:ns, :n] (A11 no longer needed); one column per lane
+        for (int col = lane; col < n; col += 64) {
+          for (int i = 0; i < ns; ++i) {
+            cx acc = mk(0, 0);
+            for (int k2 = 0; k2 < N; ++k2) acc = acc + GT(i, k2) * conj(GZ(col, k2));
+            GH(i, col) = acc;
+          }
+        }
+        wave_sync();
+        // T = Re(Ztop[:, :ns] W).  Structural zeros: T = -(B + C T)^-1 A, so a column of T whose
+        // column of A is exactly zero is exactly zero in exact arithmetic; QZ returns ~1e-16 noise
+        // there (the reference asserts only |.| < tol, tests/model/test_perturbation.py:201-203).
+        // It is written as 0.0, which is what cycle reduction produces and what lets the Kalman
+        // kernel drop those columns.
+        for (int col = lane; col < n; col += 64) {
+          const bool structural_zero = !((a_colmask >> col) & 1ull);
+          for (int row = 0; row < n; ++row) {
+            double acc = 0.0;
+            for (int i = 0; i < ns; ++i) {
+              const cx z = GZ(row, i), w = GH(i, col);
+              acc += z.re * w.re - z.im * w.im;
+            }
+            T_out[off + (size_t)row * n + col] = structural_zero ? 0.0 : acc;
+          }
+        }
+        have_T = true;
+      }
+    }
+    if (!have_T)
+      for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+    if (lane == 0) {
+      eu_out[3 * draw] = eu0;
+      eu_out[3 * draw + 1] = eu1;
+      eu_out[3 * draw + 2] = eu2;
+      status[draw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK
+                                            : (DSGE_ST_NOT_CONVERGED | (converged ? 0 : DSGE_ST_GENSYS_QZ_FAIL));
+    }
+  }
+}
+
+#undef GH
+#undef GT
+#undef GX
+#undef GZ
+
+}  // namespace dsge

@@ -94,7 +94,7 @@ class LogpEngine:
     # -- product entry points --------------------------------------------------------------
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
-                          logp=None, status=None, n_state_hint=0, z_selector_hint=0):
+                          logp=None, status=None, n_state_hint=0, z_selector_hint=0, n_lead_hint=0):
         """Enqueue one fused evaluation of the whole batch; returns (logp, status) tensors
         (asynchronous: synchronize the stream before reading them on the host)."""
         torch = self.torch
@@ -108,14 +108,14 @@ class LogpEngine:
                 self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol),
                 int(max_iter), float(jitter), float(missing_fill_value), int(n_state_hint), int(z_selector_hint),
-                self._p(logp), status.data_ptr(), None, None, None, None, self._stream(),
+                int(n_lead_hint), self._p(logp), status.data_ptr(), None, None, None, None, self._stream(),
             )
         )
         return logp, status
 
     def profile_kernels(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                         tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, reps=5,
-                        n_state_hint=0, z_selector_hint=0):
+                        n_state_hint=0, z_selector_hint=0, n_lead_hint=0):
         """Average per-kernel durations (ms) measured with HIP events on the launch stream:
         dict(solver=, assemble=, kalman=)."""
         import ctypes
@@ -130,7 +130,7 @@ class LogpEngine:
                 self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol),
                 int(max_iter), float(jitter), float(missing_fill_value), int(n_state_hint), int(z_selector_hint),
-                self._p(logp), status.data_ptr(), int(reps), ctypes.addressof(ms), self._stream(),
+                int(n_lead_hint), self._p(logp), status.data_ptr(), int(reps), ctypes.addressof(ms), self._stream(),
             )
         )
         return dict(solver=float(ms[0]), assemble=float(ms[1]), kalman=float(ms[2]))

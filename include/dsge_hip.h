@@ -38,6 +38,7 @@ extern "C" {
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m (cycle reduction: 48) */
 #define DSGE_MAX_N_CR 48
+#define DSGE_MAX_N_GENSYS 64   /* pencil dimension n + #lead columns (further limited by 160 KB LDS) */
 #define DSGE_MAX_P 16      /* observed series */
 
 /* call-level return codes */
@@ -51,6 +52,8 @@ extern "C" {
 #define DSGE_ST_NAN 2             /* NaN met in the solver (cycle_reduction.py:176-177)      */
 #define DSGE_ST_LYAP_FAIL 4       /* doubling iteration for P0 did not converge (rho(T)>=1)  */
 #define DSGE_ST_FILTER_NONFINITE 8 /* non-finite log-likelihood (F not positive definite...) */
+#define DSGE_ST_GENSYS_QZ_FAIL 16  /* QZ iteration did not converge                           */
+#define DSGE_ST_GENSYS_TOO_BIG 32  /* n + #lead exceeds the on-chip capacity of the launch     */
 
 /* covariance layouts for the Q argument */
 #define DSGE_Q_DIAG_SHARED 0    /* Q = diag(q), q: [k]            */
@@ -84,6 +87,27 @@ int dsge_cycle_reduction_batched(const double* A, const double* B, const double*
 int dsge_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
                                       int max_iter, double tol, double* T_out, int32_t* status,
                                       int32_t* n_iter);
+
+/*
+ * gensys, batched.  Replaces _gensys_setup + _gensys_core as GensysWrapper / gensys_pt use them
+ * (gEconpy/solvers/gensys.py:568-614, :190-395, :657-666, :679-683): ordered complex QZ of the
+ * (n + #lead)-dimensional pencil, existence / uniqueness codes, T = G1[:n,:n].
+ *   A,B,C : [batch][n][n]   D : [batch][n][k] (may be NULL when R_out is NULL)
+ *   tol   : lead-column threshold and `realsmall` (gensys.py:223,587)
+ *   T_out : [batch][n][n] (zeros on coincident zeros, gensys.py:255-265)
+ *   R_out : [batch][n][k] or NULL; R = -(C T + B)^-1 D as gensys_pt computes it (:681)
+ *   eu_out: [batch][3] int32  {1,1,0} unique stable solution; {-2,-2,0} coincident zeros;
+ *           eu[2] = number of loose endogenous variables; {-3,-3,0} = QZ failed / model too large
+ *   status: [batch] 0 iff eu[0] == 1 && eu[1] == 1 (the Op's `success`, gensys.py:663)
+ *   n_lead_hint : upper bound on the number of lead columns of C (0 = unknown); sizes the
+ *           on-chip pencil.  n + #lead <= DSGE_MAX_N_GENSYS.
+ */
+int dsge_gensys_batched(const double* A, const double* B, const double* C, const double* D, int batch, int n,
+                        int k, double tol, int n_lead_hint, double* T_out, double* R_out, int32_t* eu_out,
+                        int32_t* status, void* stream);
+int dsge_gensys_batched_host(const double* A, const double* B, const double* C, const double* D, int batch,
+                             int n, int k, double tol, int n_lead_hint, double* T_out, double* R_out,
+                             int32_t* eu_out, int32_t* status);
 
 /*
  * Shock-impact matrix and policy residual.  Replaces pt_compute_selection_matrix
@@ -170,7 +194,7 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                                    const double* y, int batch, int n, int k, int p, int T_len,
                                    int solver, double tol, int max_iter, double jitter,
                                    double missing_fill, int n_state_hint, int z_selector_hint,
-                                   double* logp_out, int32_t* status_out,
+                                   int n_lead_hint, double* logp_out, int32_t* status_out,
                                    double* T_out, double* R_out, double* resid_out,
                                    int32_t* n_iter_out, void* stream);
 int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const double* C,
@@ -179,8 +203,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         const double* Hdiag, int h_batched, const double* y, int batch,
                                         int n, int k, int p, int T_len, int solver, double tol,
                                         int max_iter, double jitter, double missing_fill,
-                                        int n_state_hint, int z_selector_hint, double* logp_out,
-                                        int32_t* status_out, double* T_out,
+                                        int n_state_hint, int z_selector_hint, int n_lead_hint,
+                                        double* logp_out, int32_t* status_out, double* T_out,
                                         double* R_out, double* resid_out, int32_t* n_iter_out);
 
 /*
@@ -194,7 +218,8 @@ int dsge_profile_pipeline(const double* A, const double* B, const double* C, con
                           int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                           int n, int k, int p, int T_len, int solver, double tol, int max_iter,
                           double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                          double* logp_out, int32_t* status_out, int reps, float* ms_out, void* stream);
+                          int n_lead_hint, double* logp_out, int32_t* status_out, int reps, float* ms_out,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -319,3 +319,79 @@ def test_pivoting_is_exercised():
     Tb, Rb = batched.backward_direct_batched(Am, Bm, Dm)
     assert_allclose(Tb[0], np.linalg.solve(-Bm[0], Am[0]), atol=1e-13)
     assert_allclose(Rb[0], -np.linalg.solve(Bm[0], Dm[0]), atol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------------
+# gensys on the device (complex QZ + reordering + Jacobi SVDs)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
+def test_gensys_reference_goldens(ref_goldens, key):
+    g = ref_goldens
+    A, B, C, D = (g[f"{key}_{x}"][None] for x in "ABCD")
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    assert list(out["eu"][0]) == list(g[f"{key}_ref_gensys_eu"]) and out["success"][0]
+    assert_allclose(out["T"][0], g[f"{key}_ref_gensys_T"], atol=1e-9, rtol=0)
+    assert_allclose(out["T"][0], g[f"{key}_ref_cr_T"], atol=1e-8, rtol=1e-8)  # tests/model/test_perturbation.py:205-206
+    assert_allclose(out["R"][0], g[f"{key}_ref_gensys_R"], atol=1e-8, rtol=1e-8)
+
+
+def test_gensys_rbc_and_sw(rbc_golden, sw_golden):
+    th = {k[6:]: rbc_golden[k] for k in rbc_golden.files if k.startswith("theta_")}
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    assert np.all(out["success"]) and np.all(out["eu"] == np.array([1, 1, 0]))
+    assert_allclose(out["T"], rbc_golden["ref_gensys_T"], atol=1e-9)
+    assert_allclose(out["R"], rbc_golden["ref_gensys_R"], atol=1e-8, rtol=1e-8)
+    nb = int(sw_golden["n_draws"])
+    b = wl.sw_shaped_batch(nb)
+    out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8)
+    assert np.all(out["success"])
+    assert np.array_equal(out["eu"], sw_golden["ref_gensys_eu"].astype(np.int32))
+    assert_allclose(out["T"], sw_golden["ref_gensys_T"], atol=1e-9)
+    assert_allclose(out["T"], b["T_star"], atol=1e-9)
+
+
+def test_gensys_failure_codes(failure_golden):
+    g = failure_golden
+    names = ["ok", "nonunique", "noexist", "coincident"]
+    A, B, C, D = _stack(g, names)
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    for i, name in enumerate(names):
+        assert list(out["eu"][i]) == list(g[f"{name}_ref_gensys_eu"]), name
+        assert out["success"][i] == (name == "ok")
+    assert_allclose(out["T"][0], g["ok_ref_gensys_T"], atol=1e-9)
+    assert_allclose(out["T"][2], g["noexist_ref_gensys_T"], atol=1e-8)  # the reference still returns G1 there
+    assert np.all(out["T"][3] == 0)  # coincident zeros: zero-filled (gensys.py:255-265)
+    # fused path with solver="gensys"
+    om = wl.sw_shaped_observation_model()
+    q = np.full(7, 1e-4)
+    f = batched.solve_kalman_logp_batched(A, B, C, D, q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8)
+    assert np.isfinite(f["logp"][0]) and np.all(f["logp"][1:] == -np.inf)
+    ref = oracle.solve_kalman_logp(A[0], B[0], C[0], D[0], np.diag(q), om["Z"], om["y"], H=np.diag(om["Hdiag"]), solver="gensys")
+    assert_allclose(f["logp"][0], ref["logp"], rtol=1e-8)  # north_star tolerance; gensys T differs from CR T at 1e-13
+
+
+def test_gensys_random_structures_vs_oracle():
+    rng = np.random.default_rng(5)
+    systems, expect = [], []
+    for trial in range(40):
+        n = int(rng.integers(3, 9))
+        ns_ = int(rng.integers(1, n))
+        nl = int(rng.integers(1, n))
+        A, B, C, D, _ = wl.sw_shaped_system(1000 + trial, n=n, n_state=ns_, n_lead=nl, k=1)
+        if trial % 3 == 0:
+            A[0] = 0
+            C[0] = 0
+        To, ok, euo = oracle.gensys_T_success(A, B, C, D, 1e-8)
+        out = batched.gensys_batched(A[None], B[None], C[None], D[None], tol=1e-8)
+        assert list(out["eu"][0]) == list(euo), (trial, out["eu"][0], euo)
+        if ok:
+            assert_allclose(out["T"][0], To, atol=1e-8)
+
+
+def test_gensys_capacity_flag():
+    """A draw whose pencil exceeds the capacity implied by a (too small) lead hint is flagged, not
+    silently wrong."""
+    b = wl.sw_shaped_batch(2)
+    out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5)
+    assert np.all(out["status"] & _lib.ST_GENSYS_TOO_BIG) and np.all(out["eu"][:, 0] == -3) and np.all(out["T"] == 0)
