@@ -17,7 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdsge_hip.so")
 SOURCES = ["dsge_api.hip"]
-HEADERS = ["dsge_device.hpp", "dsge_kernels.hpp", os.path.join("..", "..", "include", "dsge_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "dsge_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
