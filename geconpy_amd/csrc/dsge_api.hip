@@ -226,14 +226,14 @@ int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {
 }
 
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
-                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st) {
+                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr) {
   int n_cap = 0, l_cap = 0;
   int rc = gensys_caps(n, n_lead_hint, &n_cap, &l_cap);
   if (rc) return rc;
   const size_t lds = dsge::gensys_smem_bytes(n, n_cap, l_cap);
   if ((rc = set_lds(dsge::gensys_kernel, lds))) return rc;
   hipLaunchKernelGGL(dsge::gensys_kernel, dim3(batch), dim3(64), lds, st, A, B, C, batch, n, n_cap, l_cap, tol, T_out,
-                     eu_out, status);
+                     eu_out, status, dbg);
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
 }
@@ -520,6 +520,26 @@ int dsge_cycle_reduction_batched_host(const double* A, const double* B, const do
   DOWN(n_iter, dI, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
+}
+
+// Debug hook (not part of the drop-in surface): shader-clock stamps of draw 0 at the phase
+// boundaries of gensys_kernel: [start, after Hessenberg-triangular, after QZ, after reordering,
+// after SVDs / eu codes, end].  Device pointers; cycles_out is a HOST array of 6 int64.
+int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, int batch, int n, double tol,
+                             int n_lead_hint, double* T_out, int32_t* eu_out, int32_t* status, long long* cycles_out) {
+  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  if (rc) return rc;
+  if ((rc = ensure_device())) return rc;
+  long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 6 * sizeof(long long)));
+  HIP_TRY(hipMemset(d, 0, 6 * sizeof(long long)));
+  rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, T_out, eu_out, status, nullptr, d);
+  if (!rc) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_out, d, 6 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d);
+  return rc;
 }
 
 int dsge_gensys_batched_host(const double* A, const double* B, const double* C, const double* D, int batch, int n,

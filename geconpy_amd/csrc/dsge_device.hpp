@@ -247,6 +247,37 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes (wave-uniform result): DPP row shifts + row broadcasts, no LDS traffic.
+// Lanes that receive nothing get +0.0 (identity).  Summation order differs from wave_sum().
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_move_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_move_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_move_f64<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_move_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v += dpp_move_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) for x in a safe range: hardware estimate + two Newton steps (~1 ulp)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
 // reference implementation with plain shuffles (self-test of the DPP encodings)
 __device__ __forceinline__ unsigned long long wave_max_u64_shfl(unsigned long long v) {
 #pragma unroll

@@ -73,17 +73,28 @@ __device__ __forceinline__ cx uni(cx v) { return cx{uni(v.re), uni(v.im)}; }
 
 // c (real), s, r with [c s; -conj(s) c] [f; g] = [r; 0]
 __device__ __forceinline__ void lartg(cx f, cx g, double& c, cx& s, cx& r) {
-  if (is0(g)) {
+  const double f2 = fma(f.re, f.re, f.im * f.im), g2 = fma(g.re, g.re, g.im * g.im);
+  if (g2 == 0.0 && is0(g)) {
     c = 1.0;
     s = mk(0, 0);
     r = f;
     return;
   }
-  if (is0(f)) {
+  if (f2 == 0.0 && is0(f)) {
     const double ag = cabs_(g);
     c = 0.0;
     s = (1.0 / ag) * conj(g);
     r = mk(ag, 0);
+    return;
+  }
+  const double d2 = f2 + g2;
+  if (f2 > 1e-280 && g2 > 1e-280 && d2 < 1e280) {
+    // squares are safely representable: two square roots and two divisions
+    const double inv_d = fast_rsqrt(d2), inv_af = fast_rsqrt(f2);
+    const cx ph = inv_af * f;
+    c = (f2 * inv_af) * inv_d;
+    s = inv_d * (ph * conj(g));
+    r = (d2 * inv_d) * ph;
     return;
   }
   const double af = cabs_(f), ag = cabs_(g), d = hypot(af, ag);
@@ -161,45 +172,128 @@ __device__ __forceinline__ void rot_cols(const GsLayout& L, int i, int k, double
   wave_sync();
 }
 
+// Register-returning variants (N <= 64: one lane per column / row).  The rotated values stay in the
+// owner lane's registers so that the NEXT pivot pair is fetched with v_readlane instead of an LDS
+// write -> fence -> broadcast read.  `fixm` (1 = H, 2 = T) names the matrix whose element pair in
+// column/row `fixi` is the annihilated one: it is stored as exactly (r, 0).
+struct Rot4 {
+  cx hx, hy, tx, ty;
+};
+__device__ __forceinline__ cx bc(cx v, int src) { return cx{readlane_dyn_f64(v.re, src), readlane_dyn_f64(v.im, src)}; }
+
+__device__ __forceinline__ Rot4 rot_rows_r(const GsLayout& L, int i, int k, double c, cx s, int fixm, int fixi, cx r,
+                                           int lane) {
+  Rot4 o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
+  if (lane < L.N) {
+    cx x = GH(i, lane), y = GH(k, lane);
+    cx u = GT(i, lane), v = GT(k, lane);
+    rot2(x, y, c, s);
+    rot2(u, v, c, s);
+    if (lane == fixi) {
+      if (fixm == 1) {
+        x = r;
+        y = mk(0, 0);
+      } else if (fixm == 2) {
+        u = r;
+        v = mk(0, 0);
+      }
+    }
+    GH(i, lane) = x;
+    GH(k, lane) = y;
+    GT(i, lane) = u;
+    GT(k, lane) = v;
+    o = Rot4{x, y, u, v};
+  }
+  if (lane < L.ell) {
+    cx x = GX(i, lane), y = GX(k, lane);
+    rot2(x, y, c, s);
+    GX(i, lane) = x;
+    GX(k, lane) = y;
+  }
+  wave_sync();
+  return o;
+}
+
+__device__ __forceinline__ Rot4 rot_cols_r(const GsLayout& L, int i, int k, double c, cx s, int fixm, int fixi, cx r,
+                                           int lane) {
+  Rot4 o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
+  if (lane < L.N) {
+    cx x = GH(lane, i), y = GH(lane, k);
+    cx u = GT(lane, i), v = GT(lane, k);
+    rot2(x, y, c, s);
+    rot2(u, v, c, s);
+    if (lane == fixi) {
+      if (fixm == 1) {
+        x = r;
+        y = mk(0, 0);
+      } else if (fixm == 2) {
+        u = r;
+        v = mk(0, 0);
+      }
+    }
+    GH(lane, i) = x;
+    GH(lane, k) = y;
+    GT(lane, i) = u;
+    GT(lane, k) = v;
+    o = Rot4{x, y, u, v};
+  }
+  if (lane < L.n) {
+    cx x = GZ(lane, i), y = GZ(lane, k);
+    rot2(x, y, c, s);
+    GZ(lane, i) = x;
+    GZ(lane, k) = y;
+  }
+  wave_sync();
+  return o;
+}
+
 __device__ __forceinline__ void set_elem(cx* p, cx v, int lane) {
   if (lane == 0) *p = v;
 }
 
 // ---- step 2: Hessenberg-triangular reduction ---------------------------------------------------
+// Column j is prefetched with one row per lane; within the column sweep the only element that
+// changes is the running pivot, which comes back from the rotation in the column owner's registers.
 __device__ __forceinline__ void hess_tri(const GsLayout& L, int lane) {
   const int N = L.N;
   double c;
   cx s, r;
   // T = [[A, 0], [0, I]]: only the leading n x n block can have sub-diagonal entries, and row
   // rotations inside that block leave the identity block alone
-  for (int j = 0; j < L.n - 1; ++j)
+  for (int j = 0; j < L.n - 1; ++j) {
+    const cx colv = (lane < N) ? GT(lane, j) : mk(0, 0);
+    cx g = bc(colv, L.n - 1);
     for (int i = L.n - 1; i > j; --i) {
-      const cx g = uni(GT(i, j));
-      if (is0(g)) continue;
-      lartg(uni(GT(i - 1, j)), g, c, s, r);
-      rot_rows(L, i - 1, i, c, s, 0, lane);
-      set_elem(&GT(i - 1, j), r, lane);
-      set_elem(&GT(i, j), mk(0, 0), lane);
-      wave_sync();
+      const cx f = bc(colv, i - 1);
+      if (is0(g)) {
+        g = f;
+        continue;
+      }
+      lartg(f, g, c, s, r);
+      rot_rows_r(L, i - 1, i, c, s, 2, j, r, lane);
+      g = r;
     }
-  for (int j = 0; j < N - 2; ++j)
+  }
+  for (int j = 0; j < N - 2; ++j) {
+    const cx colv = (lane < N) ? GH(lane, j) : mk(0, 0);
+    cx g = bc(colv, N - 1);
     for (int i = N - 1; i > j + 1; --i) {
-      const cx g = uni(GH(i, j));
-      if (is0(g)) continue;
-      lartg(uni(GH(i - 1, j)), g, c, s, r);
-      rot_rows(L, i - 1, i, c, s, 0, lane);
-      set_elem(&GH(i - 1, j), r, lane);
-      set_elem(&GH(i, j), mk(0, 0), lane);
-      wave_sync();
-      const cx g2 = uni(GT(i, i - 1));
-      if (!is0(g2)) {
-        lartg(uni(GT(i, i)), g2, c, s, r);
-        rot_cols(L, i, i - 1, c, s, N - 1, lane);
-        set_elem(&GT(i, i), r, lane);
-        set_elem(&GT(i, i - 1), mk(0, 0), lane);
-        wave_sync();
+      const cx f = bc(colv, i - 1);
+      if (is0(g)) {
+        g = f;
+        continue;
+      }
+      lartg(f, g, c, s, r);
+      const Rot4 rr = rot_rows_r(L, i - 1, i, c, s, 1, j, r, lane);
+      g = r;
+      const cx tii = bc(rr.ty, i), tim = bc(rr.ty, i - 1);  // T[i][i], T[i][i-1] after the row rotation
+      if (!is0(tim)) {
+        cx r2;
+        lartg(tii, tim, c, s, r2);
+        rot_cols_r(L, i, i - 1, c, s, 2, i, r2, lane);
       }
     }
+  }
 }
 
 __device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane) {
@@ -210,7 +304,7 @@ __device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane
     acc = fma(v.re, v.re, acc);
     acc = fma(v.im, v.im, acc);
   }
-  return sqrt(uni(wave_sum(acc)));
+  return sqrt(wave_sum_dpp(acc));
 }
 
 // ---- step 3: complex single-shift QZ (zhgeqz, JOB='S') -------------------------------------------
@@ -228,91 +322,100 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
   double c;
   cx s, r;
   for (int jiter = 0; jiter < maxit; ++jiter) {
-    // action: 0 = none, 1 = split (label 60), 2 = zero T (label 50), 3 = QZ sweep from ifirst
+    // ---- per-iteration prefetch: lane j holds the three diagonals of H and two of T around (j,j).
+    // Every scalar the deflation logic and the shift need is then a v_readlane away.
+    const bool act = lane < N;
+    const cx hjj = act ? GH(lane, lane) : mk(0, 0);
+    const cx tjj = act ? GT(lane, lane) : mk(0, 0);
+    const cx hsub = (act && lane > 0) ? GH(lane, lane - 1) : mk(0, 0);    // H[j][j-1]
+    const cx hsup = (act && lane > 0) ? GH(lane - 1, lane) : mk(0, 0);    // H[j-1][j]
+    const cx tsup = (act && lane > 0) ? GT(lane - 1, lane) : mk(0, 0);    // T[j-1][j]
+    const double a_jj = abs1(hjj);
+    const double a_prev = __shfl_up(a_jj, 1, 64);                           // |H[j-1][j-1]|_1
+    const bool smallsub = act && (lane == ilo || abs1(hsub) <= fmax(SAFMIN, ULP * (a_jj + a_prev)));
+    const double t_abs = cabs_(tjj);
+    const unsigned long long msub = __ballot(smallsub);
+    const unsigned long long mtz = __ballot(act && t_abs < btol);
+
+    // action: 1 = split (label 60), 2 = zero T (label 50), 3 = QZ sweep from ifirst
     int action = 0, ifirst = 0;
     if (ilast == ilo) {
       action = 1;
-    } else if (abs1(uni(GH(ilast, ilast - 1))) <=
-               fmax(SAFMIN, ULP * (abs1(uni(GH(ilast, ilast))) + abs1(uni(GH(ilast - 1, ilast - 1)))))) {
+    } else if ((msub >> ilast) & 1ull) {
       set_elem(&GH(ilast, ilast - 1), mk(0, 0), lane);
       wave_sync();
       action = 1;
-    } else if (cabs_(uni(GT(ilast, ilast))) <= btol) {
+    } else if (readlane_dyn_f64(t_abs, ilast) <= btol) {
       set_elem(&GT(ilast, ilast), mk(0, 0), lane);
       wave_sync();
       action = 2;
     } else {
-      for (int j = ilast - 1; j >= ilo && action == 0; --j) {
-        bool ilazro;
-        if (j == ilo) {
-          ilazro = true;
-        } else if (abs1(uni(GH(j, j - 1))) <=
-                   fmax(SAFMIN, ULP * (abs1(uni(GH(j, j))) + abs1(uni(GH(j - 1, j - 1)))))) {
-          set_elem(&GH(j, j - 1), mk(0, 0), lane);
-          wave_sync();
-          ilazro = true;
-        } else {
-          ilazro = false;
-        }
-        if (cabs_(uni(GT(j, j))) < btol) {
-          set_elem(&GT(j, j), mk(0, 0), lane);
-          wave_sync();
-          bool ilazr2 = false;
-          if (!ilazro) {
-            if (abs1(uni(GH(j, j - 1))) * (ascale * abs1(uni(GH(j + 1, j)))) <=
-                abs1(uni(GH(j, j))) * (ascale * atol))
-              ilazr2 = true;
-          }
-          if (ilazro || ilazr2) {
-            action = 2;  // if the loop below runs to completion
-            for (int jch = j; jch < ilast; ++jch) {
-              lartg(uni(GH(jch, jch)), uni(GH(jch + 1, jch)), c, s, r);
-              rot_rows(L, jch, jch + 1, c, s, 0, lane);
-              set_elem(&GH(jch, jch), r, lane);
-              set_elem(&GH(jch + 1, jch), mk(0, 0), lane);
-              if (ilazr2) set_elem(&GH(jch, jch - 1), c * uni(GH(jch, jch - 1)), lane);
-              wave_sync();
-              ilazr2 = false;
-              if (abs1(uni(GT(jch + 1, jch + 1))) >= btol) {
-                if (jch + 1 >= ilast) {
-                  action = 1;
-                } else {
-                  action = 3;
-                  ifirst = jch + 1;
-                }
-                break;
-              }
-              set_elem(&GT(jch + 1, jch + 1), mk(0, 0), lane);
-              wave_sync();
-            }
-          } else {
-            for (int jch = j; jch < ilast; ++jch) {
-              lartg(uni(GT(jch, jch + 1)), uni(GT(jch + 1, jch + 1)), c, s, r);
-              rot_rows(L, jch, jch + 1, c, s, 0, lane);
-              set_elem(&GT(jch, jch + 1), r, lane);
-              set_elem(&GT(jch + 1, jch + 1), mk(0, 0), lane);
-              wave_sync();
-              lartg(uni(GH(jch + 1, jch)), uni(GH(jch + 1, jch - 1)), c, s, r);
-              rot_cols(L, jch, jch - 1, c, s, N - 1, lane);
-              set_elem(&GH(jch + 1, jch), r, lane);
-              set_elem(&GH(jch + 1, jch - 1), mk(0, 0), lane);
-              wave_sync();
-            }
-            action = 2;
-          }
-        } else if (ilazro) {
-          action = 3;
-          ifirst = j;
-        }
+      // highest j in [ilo, ilast-1] with a negligible sub-diagonal or a negligible T diagonal
+      const unsigned long long range = (ilast >= 64 ? ~0ull : ((1ull << ilast) - 1ull));
+      const unsigned long long hit = (msub | mtz) & range;
+      if (hit == 0ull) return false;  // cannot happen: bit ilo of msub is always set
+      const int j = 63 - __clzll((long long)hit);
+      // negligible sub-diagonals met on the way down (j' > j cannot be flagged) and at j are zeroed
+      if (((msub >> j) & 1ull) && j > ilo) {
+        set_elem(&GH(j, j - 1), mk(0, 0), lane);
+        wave_sync();
       }
-      if (action == 0) return false;
+      const bool ilazro = (msub >> j) & 1ull;
+      if ((mtz >> j) & 1ull) {
+        set_elem(&GT(j, j), mk(0, 0), lane);
+        wave_sync();
+        bool ilazr2 = false;
+        if (!ilazro) {
+          const double hs_j = abs1(bc(hsub, j)), hs_j1 = abs1(bc(hsub, j + 1)), hd_j = abs1(bc(hjj, j));
+          if (hs_j * (ascale * hs_j1) <= hd_j * (ascale * atol)) ilazr2 = true;
+        }
+        if (ilazro || ilazr2) {
+          action = 2;  // if the loop below runs to completion
+          cx hdiag = bc(hjj, j);  // H[jch][jch] (running), H[jch+1][jch] comes from the prefetch
+          for (int jch = j; jch < ilast; ++jch) {
+            lartg(hdiag, bc(hsub, jch + 1), c, s, r);
+            const Rot4 rr = rot_rows_r(L, jch, jch + 1, c, s, 1, jch, r, lane);
+            if (ilazr2) {
+              set_elem(&GH(jch, jch - 1), c * uni(GH(jch, jch - 1)), lane);
+              wave_sync();
+            }
+            ilazr2 = false;
+            if (abs1(bc(rr.ty, jch + 1)) >= btol) {  // T[jch+1][jch+1] after the rotation
+              if (jch + 1 >= ilast) {
+                action = 1;
+              } else {
+                action = 3;
+                ifirst = jch + 1;
+              }
+              break;
+            }
+            set_elem(&GT(jch + 1, jch + 1), mk(0, 0), lane);
+            wave_sync();
+            hdiag = bc(rr.hy, jch + 1);  // H[jch+1][jch+1] after the rotation
+          }
+        } else {
+          for (int jch = j; jch < ilast; ++jch) {
+            lartg(uni(GT(jch, jch + 1)), uni(GT(jch + 1, jch + 1)), c, s, r);
+            rot_rows(L, jch, jch + 1, c, s, 0, lane);
+            set_elem(&GT(jch, jch + 1), r, lane);
+            set_elem(&GT(jch + 1, jch + 1), mk(0, 0), lane);
+            wave_sync();
+            lartg(uni(GH(jch + 1, jch)), uni(GH(jch + 1, jch - 1)), c, s, r);
+            rot_cols(L, jch, jch - 1, c, s, N - 1, lane);
+            set_elem(&GH(jch + 1, jch), r, lane);
+            set_elem(&GH(jch + 1, jch - 1), mk(0, 0), lane);
+            wave_sync();
+          }
+          action = 2;
+        }
+      } else {
+        action = 3;
+        ifirst = j;
+      }
     }
     if (action == 2) {
       lartg(uni(GH(ilast, ilast)), uni(GH(ilast, ilast - 1)), c, s, r);
-      rot_cols(L, ilast, ilast - 1, c, s, N - 1, lane);
-      set_elem(&GH(ilast, ilast), r, lane);
-      set_elem(&GH(ilast, ilast - 1), mk(0, 0), lane);
-      wave_sync();
+      rot_cols_r(L, ilast, ilast - 1, c, s, 1, ilast, r, lane);
       action = 1;
     }
     if (action == 1) {
@@ -322,16 +425,16 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
       eshift = mk(0, 0);
       continue;
     }
-    // ---- one QZ sweep on ifirst..ilast
+    // ---- one QZ sweep on ifirst..ilast (prefetched values are still current: nothing was modified)
     ++iiter;
     cx shift;
     if (iiter % 10 != 0) {
-      const cx t_ll = bscale * uni(GT(ilast, ilast)), t_mm = bscale * uni(GT(ilast - 1, ilast - 1));
-      const cx u12 = cdiv(bscale * uni(GT(ilast - 1, ilast)), t_ll);
-      const cx ad11 = cdiv(ascale * uni(GH(ilast - 1, ilast - 1)), t_mm);
-      const cx ad21 = cdiv(ascale * uni(GH(ilast, ilast - 1)), t_mm);
-      const cx ad12 = cdiv(ascale * uni(GH(ilast - 1, ilast)), t_ll);
-      const cx ad22 = cdiv(ascale * uni(GH(ilast, ilast)), t_ll);
+      const cx t_ll = bscale * bc(tjj, ilast), t_mm = bscale * bc(tjj, ilast - 1);
+      const cx u12 = cdiv(bscale * bc(tsup, ilast), t_ll);
+      const cx ad11 = cdiv(ascale * bc(hjj, ilast - 1), t_mm);
+      const cx ad21 = cdiv(ascale * bc(hsub, ilast), t_mm);
+      const cx ad12 = cdiv(ascale * bc(hsup, ilast), t_ll);
+      const cx ad22 = cdiv(ascale * bc(hjj, ilast), t_ll);
       const cx abi22 = ad22 - u12 * ad21;
       const cx t1 = 0.5 * (ad11 + abi22);
       const cx rtdisc = csqrt_(t1 * t1 + ad12 * ad21 - ad11 * ad22);
@@ -339,41 +442,44 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
       const double temp = dd.re * rtdisc.re + dd.im * rtdisc.im;
       shift = (temp <= 0.0) ? (t1 + rtdisc) : (t1 - rtdisc);
     } else {
-      eshift = eshift + cdiv(ascale * uni(GH(ilast, ilast - 1)), bscale * uni(GT(ilast - 1, ilast - 1)));
+      eshift = eshift + cdiv(ascale * bc(hsub, ilast), bscale * bc(tjj, ilast - 1));
       shift = eshift;
     }
+    // start of the sweep: highest j in (ifirst, ilast-1] whose sub-diagonal is negligible relative
+    // to the shifted column, evaluated by every lane for its own j
+    const cx ct_own = ascale * hjj - shift * (bscale * tjj);
     int istart = ifirst;
-    cx ctemp = ascale * uni(GH(ifirst, ifirst)) - shift * (bscale * uni(GT(ifirst, ifirst)));
-    for (int j = ilast - 1; j > ifirst; --j) {
-      const cx ct = ascale * uni(GH(j, j)) - shift * (bscale * uni(GT(j, j)));
-      double temp = abs1(ct), temp2 = ascale * abs1(uni(GH(j + 1, j)));
+    {
+      double temp = abs1(ct_own);
+      const cx hsub_next = cx{__shfl_down(hsub.re, 1, 64), __shfl_down(hsub.im, 1, 64)};  // H[j+1][j]
+      double temp2 = ascale * abs1(hsub_next);
       const double tempr = fmax(temp, temp2);
       if (tempr < 1.0 && tempr != 0.0) {
         temp /= tempr;
         temp2 /= tempr;
       }
-      if (abs1(uni(GH(j, j - 1))) * temp2 <= temp * atol) {
-        istart = j;
-        ctemp = ct;
-        break;
-      }
+      const bool cand = act && lane > ifirst && lane <= ilast - 1 && (abs1(hsub) * temp2 <= temp * atol);
+      const unsigned long long mc = __ballot(cand);
+      if (mc) istart = 63 - __clzll((long long)mc);
     }
-    lartg(ctemp, ascale * uni(GH(istart + 1, istart)), c, s, r);
-    for (int j = istart; j < ilast; ++j) {
-      if (j > istart) {
-        lartg(uni(GH(j, j - 1)), uni(GH(j + 1, j - 1)), c, s, r);
-        rot_rows(L, j, j + 1, c, s, 0, lane);
-        set_elem(&GH(j, j - 1), r, lane);
-        set_elem(&GH(j + 1, j - 1), mk(0, 0), lane);
-        wave_sync();
-      } else {
-        rot_rows(L, j, j + 1, c, s, 0, lane);
+    const cx ctemp = bc(ct_own, istart);
+    lartg(ctemp, ascale * bc(hsub, istart + 1), c, s, r);
+    {
+      // the sweep: pivots travel through registers (Rot4 + v_readlane), one LDS fence per rotation
+      Rot4 cr{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
+      for (int j = istart; j < ilast; ++j) {
+        Rot4 rr;
+        if (j > istart) {
+          // bulge: H[j][j-1] (row j), H[j+1][j-1] (row j+1) = "y" outputs of the last column rotation
+          lartg(bc(cr.hy, j), bc(cr.hy, j + 1), c, s, r);
+          rr = rot_rows_r(L, j, j + 1, c, s, 1, j - 1, r, lane);
+        } else {
+          rr = rot_rows_r(L, j, j + 1, c, s, 0, 0, r, lane);
+        }
+        cx r2;
+        lartg(bc(rr.ty, j + 1), bc(rr.ty, j), c, s, r2);  // T[j+1][j+1], T[j+1][j]
+        cr = rot_cols_r(L, j + 1, j, c, s, 2, j + 1, r2, lane);
       }
-      lartg(uni(GT(j + 1, j + 1)), uni(GT(j + 1, j)), c, s, r);
-      rot_cols(L, j + 1, j, c, s, N - 1, lane);
-      set_elem(&GT(j + 1, j + 1), r, lane);
-      set_elem(&GT(j + 1, j), mk(0, 0), lane);
-      wave_sync();
     }
   }
   return false;
@@ -386,22 +492,29 @@ __device__ __forceinline__ bool root_is_stable(cx a, cx b, double rs) {
 }
 
 __device__ __forceinline__ void swap_adjacent(const GsLayout& L, int k, int lane) {
-  const cx h00 = uni(GH(k, k)), h01 = uni(GH(k, k + 1)), h11 = uni(GH(k + 1, k + 1));
-  const cx t00 = uni(GT(k, k)), t01 = uni(GT(k, k + 1)), t11 = uni(GT(k + 1, k + 1));
+  // rows k, k+1 restricted to columns k, k+1: fetched with one row-owner load each
+  const cx hk = (lane < L.N) ? GH(k, lane) : mk(0, 0), hk1 = (lane < L.N) ? GH(k + 1, lane) : mk(0, 0);
+  const cx tk = (lane < L.N) ? GT(k, lane) : mk(0, 0), tk1 = (lane < L.N) ? GT(k + 1, lane) : mk(0, 0);
+  const cx h00 = bc(hk, k), h01 = bc(hk, k + 1), h11 = bc(hk1, k + 1);
+  const cx t00 = bc(tk, k), t01 = bc(tk, k + 1), t11 = bc(tk1, k + 1);
   const cx f = h11 * t00 - t11 * h00;
   const cx g = h11 * t01 - t11 * h01;
   const double sa = cabs_(h11), sb = cabs_(t11);
   double c;
   cx s, r;
   lartg(g, f, c, s, r);
-  rot_cols(L, k, k + 1, c, neg(conj(s)), L.N - 1, lane);
+  const Rot4 cr = rot_cols_r(L, k, k + 1, c, neg(conj(s)), 0, 0, r, lane);
+  // after the column rotation: column k of rows k, k+1 ("x" outputs of lanes k, k+1)
   if (sa >= sb)
-    lartg(uni(GH(k, k)), uni(GH(k + 1, k)), c, s, r);
+    lartg(bc(cr.hx, k), bc(cr.hx, k + 1), c, s, r);
   else
-    lartg(uni(GT(k, k)), uni(GT(k + 1, k)), c, s, r);
-  rot_rows(L, k, k + 1, c, s, 0, lane);
-  set_elem(&GH(k + 1, k), mk(0, 0), lane);
-  set_elem(&GT(k + 1, k), mk(0, 0), lane);
+    lartg(bc(cr.tx, k), bc(cr.tx, k + 1), c, s, r);
+  rot_rows_r(L, k, k + 1, c, s, 0, 0, r, lane);
+  // both (k+1, k) entries are annihilated up to rounding: store exact zeros
+  if (lane == 0) {
+    GH(k + 1, k) = mk(0, 0);
+    GT(k + 1, k) = mk(0, 0);
+  }
   wave_sync();
 }
 
@@ -440,10 +553,10 @@ __device__ __forceinline__ void jacobi_svd(cx* G, int ldg, int nr, int nc, cx* V
           gr += gp.re * gq.re + gp.im * gq.im;
           gi += gp.re * gq.im - gp.im * gq.re;
         }
-        al = uni(wave_sum(al));
-        be = uni(wave_sum(be));
-        gr = uni(wave_sum(gr));
-        gi = uni(wave_sum(gi));
+        al = wave_sum_dpp(al);
+        be = wave_sum_dpp(be);
+        gr = wave_sum_dpp(gr);
+        gi = wave_sum_dpp(gi);
         const double ag = hypot(gr, gi);
         if (ag < 1e-290 || ag <= 1e-15 * sqrt(al) * sqrt(be)) continue;
         rotated = true;
@@ -473,7 +586,7 @@ __device__ __forceinline__ void jacobi_svd(cx* G, int ldg, int nr, int nc, cx* V
       const cx gp = G[row * ldg + j];
       al += gp.re * gp.re + gp.im * gp.im;
     }
-    al = uni(wave_sum(al));
+    al = wave_sum_dpp(al);
     if (lane == 0) sig[j] = sqrt(al);
   }
   wave_sync();
@@ -483,7 +596,12 @@ __device__ __forceinline__ void jacobi_svd(cx* G, int ldg, int nr, int nc, cx* V
 __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                      const double* __restrict__ C, int batch, int n, int n_cap,
                                                      int l_cap, double tol, double* __restrict__ T_out,
-                                                     int32_t* __restrict__ eu_out, int32_t* __restrict__ status) {
+                                                     int32_t* __restrict__ eu_out, int32_t* __restrict__ status,
+                                                     long long* __restrict__ dbg) {
+#define DBG_T(k)                                                         \
+  do {                                                                   \
+    if (dbg && blockIdx.x == 0 && lane == 0) dbg[k] = (long long)clock64(); \
+  } while (0)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   GsLayout L;
@@ -557,8 +675,11 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
     if (lane < n) GZ(lane, lane) = mk(1.0, 0.0);
     wave_sync();
 
+    DBG_T(0);
     hess_tri(L, lane);
+    DBG_T(1);
     const bool converged = qz_iterate(L, lane);
+    DBG_T(2);
     int eu0 = 0, eu1 = 0, eu2 = 0;
     bool have_T = false;
     if (!converged) {
@@ -566,6 +687,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
     } else {
       const int ns = reorder_stable_first(L, rs, lane);
       const int nu = N - ns;
+      DBG_T(3);
       // coincident zeros (gensys.py:243-244)
       bool zxz = false;
       for (int i = 0; i < N; ++i)
@@ -604,7 +726,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
               // dot = v2_c^H v1_j
               cx part = mk(0, 0);
               if (lane < ell) part = conj(L.V2[lane * L.ldx + cc]) * L.V1[lane * L.ldx + j];
-              const double dr = uni(wave_sum(part.re)), di = uni(wave_sum(part.im));
+              const double dr = wave_sum_dpp(part.re), di = wave_sum_dpp(part.im);
               if (lane < ell) acc = acc - L.V2[lane * L.ldx + cc] * mk(dr, di);
             }
             if (lane < ell) L.S3[lane * L.ldx + jj] = acc;
@@ -619,6 +741,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
           unique = (n_loose == 0);
         }
         if (unique) eu1 = 1;
+        DBG_T(4);
 
         // ---- Phi = (G1k V1k^H)(V2k D2k^-2 G2k^H)  (ns x nu), stored transposed-free in the unused
         // lower-left block of H:  Phi[i][j] at H[ns + j][i]
@@ -690,6 +813,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
           }
         }
         have_T = true;
+        DBG_T(5);
       }
     }
     if (!have_T)
@@ -704,6 +828,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
   }
 }
 
+#undef DBG_T
 #undef GH
 #undef GT
 #undef GX

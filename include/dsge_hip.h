@@ -109,6 +109,12 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
                              int n, int k, double tol, int n_lead_hint, double* T_out, double* R_out,
                              int32_t* eu_out, int32_t* status);
 
+/* Debug hook: shader-clock stamps of draw 0 at the phase boundaries of the gensys kernel (start,
+ * Hessenberg-triangular, QZ, reordering, SVDs/eu, end).  Device pointers; cycles_out: host int64[6]. */
+int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, int batch, int n, double tol,
+                             int n_lead_hint, double* T_out, int32_t* eu_out, int32_t* status,
+                             long long* cycles_out);
+
 /*
  * Shock-impact matrix and policy residual.  Replaces pt_compute_selection_matrix
  * (gEconpy/solvers/shared.py:74-75; numpy twin cycle_reduction.py:395-396) and the residual
