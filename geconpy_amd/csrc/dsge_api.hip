@@ -169,6 +169,8 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
   return rc;
 }
 
+long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
+
 int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
@@ -188,7 +190,7 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
       if (rc == DSGE_SUCCESS) {
         hipLaunchKernelGGL(dsge::kalman_sel_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
                            d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter, missing_fill, logp,
-                           status);
+                           status, g_kalman_dbg);
         HIP_TRY(hipGetLastError());
       }
     });
@@ -519,6 +521,26 @@ int dsge_cycle_reduction_batched_host(const double* A, const double* B, const do
   DOWN(status, dS, batch, int32_t);
   DOWN(n_iter, dI, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+// Debug hook: when enabled, kalman_sel_kernel accumulates the shader cycles draw 0 spends in each
+// of its five per-step phases; dsge_debug_kalman_phases(0/1 enable, out[5]) reads them back.
+int dsge_debug_kalman_phases(int enable, long long* cycles_out) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (enable && !g_kalman_dbg) {
+    HIP_TRY(hipMalloc((void**)&g_kalman_dbg, 8 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_kalman_dbg, 0, 8 * sizeof(long long)));
+  }
+  if (cycles_out && g_kalman_dbg) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_out, g_kalman_dbg, 5 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && g_kalman_dbg) {
+    (void)hipFree(g_kalman_dbg);
+    g_kalman_dbg = nullptr;
+  }
   return DSGE_SUCCESS;
 }
 

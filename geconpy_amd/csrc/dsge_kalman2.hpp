@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m, int p,
     int T_len, int s_cap, double jitter, double missing_fill, double* __restrict__ logp_out,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, long long* __restrict__ dbg) {
   constexpr int NP = Kf2Smem<BS>::NP, LDM = Kf2Smem<BS>::LDM;
   const int LDT = Kf2Smem<BS>::ldt(s_cap);
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
     long long ld_exp = 0;
     long long n_ll_steps = 0;
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
     for (int t = 0; t < T_len; ++t) {
+      long long tk0 = dbg ? clock64() : 0;
       // ---- (a) missing-data mask ------------------------------------------------------
       const double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
       const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
@@ -215,6 +217,11 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       }
       Fi[lane] = f;
       wave_sync();  // #1
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[0] += tk1 - tk0;
+        tk0 = tk1;
+      }
       // ---- log-likelihood pieces ------------------------------------------------------
       {
         double qp = f * vv[fo] * vv[fq];
@@ -253,6 +260,11 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         if (ri >= 0) afc[ri] = afi;
       }
       wave_sync();  // #2
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[1] += tk1 - tk0;
+        tk0 = tk1;
+      }
       // ---- (e) P+ = P - K V' + jitter I (register blocks), compact copy to LDS -----------
 #pragma unroll
       for (int o2 = 0; o2 < 4; ++o2) {
@@ -280,6 +292,11 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         for (int j = 0; j < BS; ++j)
           if (rr[i] >= 0 && rc[j] >= 0) Pc[rr[i] * LDT + rc[j]] = Pb[i][j];
       wave_sync();  // #3
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[2] += tk1 - tk0;
+        tk0 = tk1;
+      }
       // ---- (f) predict: a = Tc a+[S];  W = Pc Tc';  X = Tc W;  P = sym(X) + RQR ---------
       for (int i = lane; i < m; i += 64) {
         double sacc = 0.0;
@@ -293,6 +310,11 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         blk_store_lds<BS>(Wb, Wc, LDM, lr, lc);
       }
       wave_sync();  // #4
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[3] += tk1 - tk0;
+        tk0 = tk1;
+      }
       {
         double Xb[BS][BS];
         blk_zero<BS>(Xb);
@@ -314,7 +336,14 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
           for (int i = 0; i < BS; ++i) PZt[(lr * BS + i) * 8 + ocol[j]] = zcol[j] * Pb[i][j];
         }
       wave_sync();  // #5
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[4] += tk1 - tk0;
+        tk0 = tk1;
+      }
     }
+    if (dbg && draw == 0 && lane == 0)
+      for (int k = 0; k < 5; ++k) dbg[k] = ph[k];
     if (lane == 0) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
       const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_sum);

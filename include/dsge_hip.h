@@ -109,6 +109,10 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
                              int n, int k, double tol, int n_lead_hint, double* T_out, double* R_out,
                              int32_t* eu_out, int32_t* status);
 
+/* Debug hook: enable != 0 makes the selector-path Kalman kernel record the shader cycles draw 0 spends
+ * in each of its five per-step phases; cycles_out (host int64[5], may be NULL) reads them back. */
+int dsge_debug_kalman_phases(int enable, long long* cycles_out);
+
 /* Debug hook: shader-clock stamps of draw 0 at the phase boundaries of the gensys kernel (start,
  * Hessenberg-triangular, QZ, reordering, SVDs/eu, end).  Device pointers; cycles_out: host int64[6]. */
 int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, int batch, int n, double tol,
