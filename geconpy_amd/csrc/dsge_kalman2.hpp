@@ -36,12 +36,10 @@ constexpr int32_t DSGE_ST_INTERNAL_RERUN = 1 << 30;
 template <int BS>
 struct Kf2Smem {
   static constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD;
-  __host__ __device__ static constexpr int ldt(int s_cap) { return s_cap | 1; }
-  // doubles: Tc NP*LDT, Pc s_cap*LDT, Wc s_cap*LDM, PZt/K/V NP*8 each, Fi 64, av NP, afc NP,
-  // vv/dd/hh/zv 8 each; ints: zidx 8 (4 doubles)
+  // doubles: PZt/K/V NP*8 each, Fi 64, Tc NP*LDM, Pc s_cap*LDM, Wc s_cap*LDM, av NP, af NP,
+  // vv/dd/hh/zv 8 each, trash 64; ints: perm NP, zpos 8
   __host__ __device__ static constexpr size_t doubles(int s_cap) {
-    return (size_t)NP * ldt(s_cap) + (size_t)s_cap * ldt(s_cap) + (size_t)s_cap * LDM + 3 * (size_t)NP * 8 + 64 +
-           2 * NP + 32 + 4;
+    return 3 * (size_t)NP * 8 + 64 + (size_t)NP * LDM + 2 * (size_t)s_cap * LDM + 2 * NP + 32 + 64 + NP / 2 + 4;
   }
   static size_t bytes(int s_cap) { return sizeof(double) * doubles(s_cap); }
 };
@@ -53,6 +51,53 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/x for x in a safe range: hardware estimate + two Newton steps
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * fma(-x, y, 2.0);
+  y = y * fma(-x, y, 2.0);
+  return y;
+}
+
+// Register-blocked product with compile-time strides, software-pipelined by hand: two operand
+// register sets ping-pong, the LDS loads of step k+1 are issued BEFORE the 25 FMAs of step k and
+// scheduling barriers keep hipcc from sinking them below the FMAs (it otherwise does, exposing the
+// full LDS latency every step).
+template <int BS, bool TB, int LDA, int LDB>
+__device__ __forceinline__ void mm_acc_p(double (&acc)[BS][BS], const double* A, const double* B, int K, int lr,
+                                         int lc) {
+  const double* a0p = A + lr * BS * LDA;
+  const double* b0p = TB ? (B + lc * BS * LDB) : (B + lc * BS);
+  double a0[BS], b0[BS], a1[BS], b1[BS];
+#define MM_LOAD(a, b, k)                                                              \
+  do {                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i) a[i] = a0p[i * LDA + (k)];         \
+    _Pragma("unroll") for (int j = 0; j < BS; ++j) b[j] = TB ? b0p[j * LDB + (k)] : b0p[(k)*LDB + j]; \
+  } while (0)
+#define MM_FMA(a, b)                                                                  \
+  do {                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i)                                    \
+      _Pragma("unroll") for (int j = 0; j < BS; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]); \
+  } while (0)
+  if (K <= 0) return;
+  MM_LOAD(a0, b0, 0);
+  int k = 0;
+  for (; k + 2 <= K; k += 2) {
+    MM_LOAD(a1, b1, k + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    MM_FMA(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int kn = (k + 2 < K) ? k + 2 : K - 1;
+    MM_LOAD(a0, b0, kn);
+    __builtin_amdgcn_sched_barrier(0);
+    MM_FMA(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (k < K) MM_FMA(a0, b0);
+#undef MM_LOAD
+#undef MM_FMA
+}
+
 template <int BS>
 __global__ __launch_bounds__(64) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
@@ -61,22 +106,23 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     int T_len, int s_cap, double jitter, double missing_fill, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg) {
   constexpr int NP = Kf2Smem<BS>::NP, LDM = Kf2Smem<BS>::LDM;
-  const int LDT = Kf2Smem<BS>::ldt(s_cap);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* PZt = smem;                // NP x 8     P Z'   (unmasked)     [16-byte aligned block first]
   double* Ks = PZt + NP * 8;         // NP x 8     K = P Zm' Finv
   double* Vs = Ks + NP * 8;          // NP x 8     P Zm' + jitter K
   double* Fi = Vs + NP * 8;          // 8 x 8      Finv
-  double* Tc = Fi + 64;              // NP x LDT   compact transition  T[:, S]
-  double* Pc = Tc + NP * LDT;        // s_cap x LDT compact P+[S,S]
-  double* Wc = Pc + s_cap * LDT;     // s_cap x LDM W = Pc Tc'
+  double* Tc = Fi + 64;              // NP x LDM   transition in the states-first ordering (columns < s)
+  double* Pc = Tc + NP * LDM;        // s_cap x LDM  P+ restricted to the state block
+  double* Wc = Pc + s_cap * LDM;     // s_cap x LDM  W = Pc Tc'
   double* av = Wc + s_cap * LDM;     // NP         predicted state
-  double* afc = av + NP;             // NP         filtered state, compacted to S
-  double* vv = afc + NP;             // 8 innovation
+  double* af = av + NP;              // NP         filtered state
+  double* vv = af + NP;              // 8 innovation
   double* dd = vv + 8;               // 8 obs intercept
   double* hh = dd + 8;               // 8 diag(H)
   double* zv = hh + 8;               // 8 selector values
-  int* zidx = (int*)(zv + 8);        // 8 selector columns
+  double* trash = zv + 8;            // 64: sink for the stores of lanes that own no observed column
+  int* perm = (int*)(trash + 64);    // NP: position -> original state index (states first)
+  int* zpos = perm + NP;             // 8: position of the state each observation selects
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   const int fo = lane >> 3, fq = lane & 7;  // owner of F[fo][fq]
   const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
@@ -90,9 +136,9 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     wave_sync();
     for (int idx = lane; idx < (int)Kf2Smem<BS>::doubles(s_cap); idx += 64) smem[idx] = 0.0;
 
-    // ---- structure of T: non-zero columns S, rank map ---------------------------------
+    // ---- structure of T: non-zero columns S ------------------------------------------------
     double Pb[BS][BS];
-    blk_load_global<BS>(Pb, T + off, m, m, m, lr, lc);  // T blocks (reused register file)
+    blk_load_global<BS>(Pb, T + off, m, m, m, lr, lc);
     unsigned long long colmask = 0ull;
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
@@ -112,15 +158,20 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     // ---- selector structure of Z ---------------------------------------------------------
     const double* Zg = Z + (z_batched ? (size_t)draw * p * m : 0);
     unsigned long long used = 0ull;
+    int my_pos = 0;  // position of original index `lane` in the states-first ordering
+    if (lane < m) {
+      const int rk = __popcll(colmask & ((1ull << lane) - 1ull));
+      my_pos = ((colmask >> lane) & 1ull) ? rk : s + (lane - rk);
+      perm[my_pos] = lane;
+    }
     for (int o = 0; o < p; ++o) {
       const double zl = (lane < m) ? Zg[(size_t)o * m + lane] : 0.0;
       const unsigned long long b = __ballot(zl != 0.0);
       if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
       used |= b;
-      const int idx = b ? (__ffsll((long long)b) - 1) : 0;
-      if (lane == 0) {
-        zidx[o] = idx;
-        zv[o] = Zg[(size_t)o * m + idx];
+      if (zl != 0.0) {  // the single owner lane of this observation
+        zpos[o] = my_pos;
+        zv[o] = zl;
       }
     }
     if (!ok) {
@@ -128,51 +179,62 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       continue;
     }
     wave_sync();
-    // per-lane constant maps: rank of my rows / columns in S, observation attached to my columns
-    int rr[BS], rc[BS], ocol[BS];
+    // ---- load everything in the states-first ordering (a consistent permutation of the state
+    // vector leaves the likelihood unchanged): element (r,c) <- original (perm[r], perm[c])
+    int pr[BS], pcx[BS], ocol[BS];
     double zcol[BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i) {
       const int r = lr * BS + i, c = lc * BS + i;
-      rr[i] = ((colmask >> r) & 1ull) ? __popcll(colmask & ((1ull << r) - 1ull)) : -1;
-      rc[i] = ((colmask >> c) & 1ull) ? __popcll(colmask & ((1ull << c) - 1ull)) : -1;
+      pr[i] = (r < m) ? perm[r] : -1;
+      pcx[i] = (c < m) ? perm[c] : -1;
       ocol[i] = -1;
       zcol[i] = 0.0;
       for (int o = 0; o < p; ++o)
-        if (zidx[o] == c) {
+        if (zpos[o] == c) {
           ocol[i] = o;
           zcol[i] = zv[o];
         }
     }
-    // Tc = T[:, S]
+    double Qb[BS][BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
-      for (int j = 0; j < BS; ++j)
-        if (rc[j] >= 0) Tc[(lr * BS + i) * LDT + rc[j]] = Pb[i][j];
+      for (int j = 0; j < BS; ++j) {
+        const bool in = pr[i] >= 0 && pcx[j] >= 0;
+        const size_t g = in ? (size_t)pr[i] * m + pcx[j] : 0;
+        const double tv = in ? T[off + g] : 0.0;
+        Qb[i][j] = in ? RQR[off + g] : 0.0;
+        Pb[i][j] = in ? P0[off + g] : 0.0;
+        Tc[(lr * BS + i) * LDM + lc * BS + j] = tv;  // columns >= s are exactly zero
+      }
     if (lane < 8) {
       dd[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
       hh[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
     }
-    double Qb[BS][BS];
-    blk_load_global<BS>(Qb, RQR + off, m, m, m, lr, lc);
-    blk_load_global<BS>(Pb, P0 + off, m, m, m, lr, lc);
-    // P Z' for the first step
+    // destination of my P Z' contributions: PZt[row][obs] for observed columns, a private sink else
+    int pz_dst[BS];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) pz_dst[j] = ocol[j];
+    const bool in_state_block = (lr * BS < s) && (lc * BS < s);
 #pragma unroll
     for (int j = 0; j < BS; ++j)
-      if (ocol[j] >= 0) {
 #pragma unroll
-        for (int i = 0; i < BS; ++i) PZt[(lr * BS + i) * 8 + ocol[j]] = zcol[j] * Pb[i][j];
+      for (int i = 0; i < BS; ++i) {
+        double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * 8 + pz_dst[j]] : &trash[lane];
+        *dst = zcol[j] * Pb[i][j];
       }
-    const int my_zidx = (fo < p) ? zidx[fo] : 0;
+    const int my_zpos = (fo < p) ? zpos[fo] : 0;
     const double my_zv = (fo < p) ? zv[fo] : 0.0;
+    const int v_zpos = (lane < p) ? zpos[lane] : 0;
+    const double v_zv = (lane < p) ? zv[lane] : 0.0, v_dd = (lane < 8) ? dd[lane & 7] : 0.0;
     wave_sync();
 
     double quad_sum = 0.0, quad_comp = 0.0;  // Kahan sum of v' Finv v over observed steps
     double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
     long long ld_exp = 0;
     long long n_ll_steps = 0;
-    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    long long ph[5] = {0, 0, 0, 0, 0};
     for (int t = 0; t < T_len; ++t) {
       long long tk0 = dbg ? clock64() : 0;
       // ---- (a) missing-data mask ------------------------------------------------------
@@ -184,16 +246,14 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       // ---- (b) F[fo][fq] and the innovation -------------------------------------------
       double f;
       if (fo < p && fq < p) {
-        f = wo * wq * my_zv * PZt[my_zidx * 8 + fq];
+        f = wo * wq * my_zv * PZt[my_zpos * 8 + fq];
         if (fo == fq) f += wo * hh[fo] + jitter;
       } else {
         f = (fo == fq) ? 1.0 : 0.0;
       }
-      if (lane < 8) {
-        const double wl = (double)((omask >> lane) & 1ull);
-        const double ym = obs ? yt : 0.0;
-        vv[lane] = (lane < p) ? ym - (dd[lane] + wl * zv[lane] * av[zidx[lane]]) : 0.0;
-      }
+      double v_own = 0.0;
+      if (lane < p) v_own = (obs ? yt : 0.0) - (v_dd + (obs ? 1.0 : 0.0) * v_zv * av[v_zpos]);
+      if (lane < 8) vv[lane] = v_own;
       // ---- (c) Finv by in-register Gauss-Jordan (SPD: no pivoting) ----------------------
       double step_mant = 1.0;
       int step_exp = 0;
@@ -203,7 +263,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
           const double piv = readlane_f64(f, j * 9);
           const double rowj = __shfl(f, (j << 3) | fq, 64);
           const double colj = __shfl(f, (fo << 3) | j, 64);
-          const double inv = 1.0 / piv;
+          const double inv = fast_rcp(piv);
           const double ci = colj * inv;
           double nf = fma(-ci, rowj, f);
           nf = (fo == j) ? rowj * inv : nf;
@@ -216,16 +276,10 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         }
       }
       Fi[lane] = f;
-      wave_sync();  // #1
-      if (dbg) {
-        const long long tk1 = clock64();
-        ph[0] += tk1 - tk0;
-        tk0 = tk1;
-      }
-      // ---- log-likelihood pieces ------------------------------------------------------
+      // v' Finv v: the innovation entries come from lanes 0..7 by shuffle
       {
-        double qp = f * vv[fo] * vv[fq];
-        qp = wave_sum(qp);
+        const double vo = __shfl(v_own, fo, 64), vq = __shfl(v_own, fq, 64);
+        const double qp = wave_sum_dpp(f * vo * vq);
         if (n_obs > 0) {
           const double yk = qp - quad_comp;
           const double tk = quad_sum + yk;
@@ -237,27 +291,42 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
           ++n_ll_steps;
         }
       }
+      wave_sync();  // #1
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[0] += tk1 - tk0;
+        tk0 = tk1;
+      }
       // ---- (d) K = (P Zm') Finv, V = P Zm' + jitter K, a+ = a + K v (one state per lane) -
-      for (int i = lane; i < m; i += 64) {
+      if (lane < m) {
+        const int i = lane;
         double pz[8], kr[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          pz[q] = ((omask >> q) & 1ull) ? PZt[i * 8 + q] : 0.0;
-          kr[q] = 0.0;
+        for (int q2 = 0; q2 < 4; ++q2) {
+          const double2 t2 = *reinterpret_cast<const double2*>(&PZt[i * 8 + 2 * q2]);
+          pz[2 * q2] = ((omask >> (2 * q2)) & 1ull) ? t2.x : 0.0;
+          pz[2 * q2 + 1] = ((omask >> (2 * q2 + 1)) & 1ull) ? t2.y : 0.0;
+          kr[2 * q2] = 0.0;
+          kr[2 * q2 + 1] = 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
-          for (int o = 0; o < 8; ++o) kr[o] = fma(pz[q], Fi[q * 8 + o], kr[o]);
+          for (int o2 = 0; o2 < 4; ++o2) {
+            const double2 fi2 = *reinterpret_cast<const double2*>(&Fi[q * 8 + 2 * o2]);
+            kr[2 * o2] = fma(pz[q], fi2.x, kr[2 * o2]);
+            kr[2 * o2 + 1] = fma(pz[q], fi2.y, kr[2 * o2 + 1]);
+          }
         double afi = av[i];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          Ks[i * 8 + o] = kr[o];
-          Vs[i * 8 + o] = fma(jitter, kr[o], pz[o]);
-          afi = fma(kr[o], vv[o], afi);
+        for (int o2 = 0; o2 < 4; ++o2) {
+          *reinterpret_cast<double2*>(&Ks[i * 8 + 2 * o2]) = double2{kr[2 * o2], kr[2 * o2 + 1]};
+          *reinterpret_cast<double2*>(&Vs[i * 8 + 2 * o2]) =
+              double2{fma(jitter, kr[2 * o2], pz[2 * o2]), fma(jitter, kr[2 * o2 + 1], pz[2 * o2 + 1])};
+          afi = fma(kr[2 * o2], vv[2 * o2], afi);
+          afi = fma(kr[2 * o2 + 1], vv[2 * o2 + 1], afi);
         }
-        const int ri = ((colmask >> i) & 1ull) ? __popcll(colmask & ((1ull << i) - 1ull)) : -1;
-        if (ri >= 0) afc[ri] = afi;
+        af[i] = afi;
       }
       wave_sync();  // #2
       if (dbg) {
@@ -265,48 +334,64 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         ph[1] += tk1 - tk0;
         tk0 = tk1;
       }
-      // ---- (e) P+ = P - K V' + jitter I (register blocks), compact copy to LDS -----------
+      // ---- (e) P+ = P - K V' + jitter I (register blocks); state block -> LDS -------------
+      {
+        // two-stage software pipeline over the four observation pairs
+        double2 ka[BS], vb[BS], kan[BS], vbn[BS];
 #pragma unroll
-      for (int o2 = 0; o2 < 4; ++o2) {
-        double2 ka[BS], vb[BS];
+        for (int i = 0; i < BS; ++i) ka[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * 8]);
 #pragma unroll
-        for (int i = 0; i < BS; ++i) ka[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * 8 + 2 * o2]);
+        for (int j = 0; j < BS; ++j) vb[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * 8]);
 #pragma unroll
-        for (int j = 0; j < BS; ++j) vb[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * 8 + 2 * o2]);
+        for (int o2 = 0; o2 < 4; ++o2) {
+          if (o2 < 3) {
 #pragma unroll
-        for (int i = 0; i < BS; ++i)
+            for (int i = 0; i < BS; ++i)
+              kan[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * 8 + 2 * (o2 + 1)]);
 #pragma unroll
-          for (int j = 0; j < BS; ++j) {
-            Pb[i][j] = fma(-ka[i].x, vb[j].x, Pb[i][j]);
-            Pb[i][j] = fma(-ka[i].y, vb[j].y, Pb[i][j]);
+            for (int j = 0; j < BS; ++j)
+              vbn[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * 8 + 2 * (o2 + 1)]);
           }
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+              Pb[i][j] = fma(-ka[i].x, vb[j].x, Pb[i][j]);
+              Pb[i][j] = fma(-ka[i].y, vb[j].y, Pb[i][j]);
+            }
+#pragma unroll
+          for (int i = 0; i < BS; ++i) ka[i] = kan[i];
+#pragma unroll
+          for (int j = 0; j < BS; ++j) vb[j] = vbn[j];
+        }
       }
       if (lr == lc) {
 #pragma unroll
         for (int i = 0; i < BS; ++i)
           if (lr * BS + i < m) Pb[i][i] += jitter;
       }
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j)
-          if (rr[i] >= 0 && rc[j] >= 0) Pc[rr[i] * LDT + rc[j]] = Pb[i][j];
+      if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDM, lr, lc);
       wave_sync();  // #3
       if (dbg) {
         const long long tk1 = clock64();
         ph[2] += tk1 - tk0;
         tk0 = tk1;
       }
-      // ---- (f) predict: a = Tc a+[S];  W = Pc Tc';  X = Tc W;  P = sym(X) + RQR ---------
-      for (int i = lane; i < m; i += 64) {
-        double sacc = 0.0;
-        for (int kk = 0; kk < s; ++kk) sacc = fma(Tc[i * LDT + kk], afc[kk], sacc);
-        av[i] = sacc;
+      // ---- (f) predict: a = Tc a+[:s];  W = Pc Tc';  X = Tc W;  P = sym(X) + RQR ---------
+      if (lane < m) {
+        double s0 = 0.0, s1 = 0.0;
+        int kk = 0;
+        for (; kk + 1 < s; kk += 2) {
+          s0 = fma(Tc[lane * LDM + kk], af[kk], s0);
+          s1 = fma(Tc[lane * LDM + kk + 1], af[kk + 1], s1);
+        }
+        if (kk < s) s0 = fma(Tc[lane * LDM + kk], af[kk], s0);
+        av[lane] = s0 + s1;
       }
       if (lr * BS < s) {
         double Wb[BS][BS];
         blk_zero<BS>(Wb);
-        mm_acc<BS, true>(Wb, Pc, LDT, Tc, LDT, s, lr, lc);
+        mm_acc_p<BS, true, LDM, LDM>(Wb, Pc, Tc, s, lr, lc);
         blk_store_lds<BS>(Wb, Wc, LDM, lr, lc);
       }
       wave_sync();  // #4
@@ -318,7 +403,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       {
         double Xb[BS][BS];
         blk_zero<BS>(Xb);
-        mm_acc<BS, false>(Xb, Tc, LDT, Wc, LDM, s, lr, lc);
+        mm_acc_p<BS, false, LDM, LDM>(Xb, Tc, Wc, s, lr, lc);
         const int src = (lc << 3) | lr;  // lane holding the transposed block
 #pragma unroll
         for (int i = 0; i < BS; ++i)
@@ -328,12 +413,13 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
             Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
           }
       }
-      // ---- P Z' for the next step ---------------------------------------------------------
+      // ---- P Z' for the next step (branch-free: unobserved columns go to the sink) -----------
 #pragma unroll
       for (int j = 0; j < BS; ++j)
-        if (ocol[j] >= 0) {
 #pragma unroll
-          for (int i = 0; i < BS; ++i) PZt[(lr * BS + i) * 8 + ocol[j]] = zcol[j] * Pb[i][j];
+        for (int i = 0; i < BS; ++i) {
+          double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * 8 + pz_dst[j]] : &trash[lane];
+          *dst = zcol[j] * Pb[i][j];
         }
       wave_sync();  // #5
       if (dbg) {
