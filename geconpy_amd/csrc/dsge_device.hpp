@@ -115,20 +115,38 @@ __device__ __forceinline__ void lds_load_matrix(double* s, int ld, int np_rows, 
 template <int BS, bool TB>
 __device__ __forceinline__ void mm_acc(double (&acc)[BS][BS], const double* A, int lda, const double* B,
                                        int ldb, int K, int lr, int lc) {
-  const double* a0 = A + lr * BS * lda;
-  const double* b0 = TB ? (B + lc * BS * ldb) : (B + lc * BS);
-#pragma unroll 2
-  for (int k = 0; k < K; ++k) {
-    double a[BS], b[BS];
-#pragma unroll
-    for (int i = 0; i < BS; ++i) a[i] = a0[i * lda + k];
-#pragma unroll
-    for (int j = 0; j < BS; ++j) b[j] = TB ? b0[j * ldb + k] : b0[k * ldb + j];
-#pragma unroll
-    for (int i = 0; i < BS; ++i)
-#pragma unroll
-      for (int j = 0; j < BS; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  // Software-pipelined by hand: two operand register sets ping-pong; the LDS loads of step k+1 are
+  // issued before the FMAs of step k, and scheduling barriers keep hipcc from sinking them.
+  const double* a0p = A + lr * BS * lda;
+  const double* b0p = TB ? (B + lc * BS * ldb) : (B + lc * BS);
+  double a0[BS], b0[BS], a1[BS], b1[BS];
+#define MM_LOAD(a, b, k)                                                              \
+  do {                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i) a[i] = a0p[i * lda + (k)];         \
+    _Pragma("unroll") for (int j = 0; j < BS; ++j) b[j] = TB ? b0p[j * ldb + (k)] : b0p[(k)*ldb + j]; \
+  } while (0)
+#define MM_FMA(a, b)                                                                  \
+  do {                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i)                                    \
+      _Pragma("unroll") for (int j = 0; j < BS; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]); \
+  } while (0)
+  if (K <= 0) return;
+  MM_LOAD(a0, b0, 0);
+  int k = 0;
+  for (; k + 2 <= K; k += 2) {
+    MM_LOAD(a1, b1, k + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    MM_FMA(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int kn = (k + 2 < K) ? k + 2 : K - 1;
+    MM_LOAD(a0, b0, kn);
+    __builtin_amdgcn_sched_barrier(0);
+    MM_FMA(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (k < K) MM_FMA(a0, b0);
+#undef MM_LOAD
+#undef MM_FMA
 }
 
 // induced 1-norm (max absolute column sum, NaN-propagating) of a register-block matrix
