@@ -39,7 +39,7 @@ struct Kf2Smem {
   // doubles: PZt/K/V NP*8 each, Fi 64, Tc NP*LDM, Pc s_cap*LDM, Wc s_cap*LDM, av NP, af NP,
   // vv/dd/hh/zv 8 each, trash 64; ints: perm NP, zpos 8
   __host__ __device__ static constexpr size_t doubles(int s_cap) {
-    return 3 * (size_t)NP * 8 + 64 + (size_t)NP * LDM + 2 * (size_t)s_cap * LDM + 2 * NP + 32 + 64 + NP / 2 + 4;
+    return 3 * (size_t)NP * 10 + 64 + (size_t)NP * LDM + 2 * (size_t)s_cap * LDM + 2 * NP + 32 + 64 + NP / 2 + 4;
   }
   static size_t bytes(int s_cap) { return sizeof(double) * doubles(s_cap); }
 };
@@ -106,11 +106,12 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     int T_len, int s_cap, double jitter, double missing_fill, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg) {
   constexpr int NP = Kf2Smem<BS>::NP, LDM = Kf2Smem<BS>::LDM;
+  constexpr int PS = 10;  // row stride of the NP x 8 panels: 80 B keeps 16-byte alignment and spreads rows over all banks
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* PZt = smem;                // NP x 8     P Z'   (unmasked)     [16-byte aligned block first]
-  double* Ks = PZt + NP * 8;         // NP x 8     K = P Zm' Finv
-  double* Vs = Ks + NP * 8;          // NP x 8     P Zm' + jitter K
-  double* Fi = Vs + NP * 8;          // 8 x 8      Finv
+  double* Ks = PZt + NP * PS;        // NP x 8     K = P Zm' Finv
+  double* Vs = Ks + NP * PS;         // NP x 8     P Zm' + jitter K
+  double* Fi = Vs + NP * PS;         // 8 x 8      Finv
   double* Tc = Fi + 64;              // NP x LDM   transition in the states-first ordering (columns < s)
   double* Pc = Tc + NP * LDM;        // s_cap x LDM  P+ restricted to the state block
   double* Wc = Pc + s_cap * LDM;     // s_cap x LDM  W = Pc Tc'
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     for (int j = 0; j < BS; ++j)
 #pragma unroll
       for (int i = 0; i < BS; ++i) {
-        double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * 8 + pz_dst[j]] : &trash[lane];
+        double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * PS + pz_dst[j]] : &trash[lane];
         *dst = zcol[j] * Pb[i][j];
       }
     const int my_zpos = (fo < p) ? zpos[fo] : 0;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       // ---- (b) F[fo][fq] and the innovation -------------------------------------------
       double f;
       if (fo < p && fq < p) {
-        f = wo * wq * my_zv * PZt[my_zpos * 8 + fq];
+        f = wo * wq * my_zv * PZt[my_zpos * PS + fq];
         if (fo == fq) f += wo * hh[fo] + jitter;
       } else {
         f = (fo == fq) ? 1.0 : 0.0;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         double pz[8], kr[8];
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
-          const double2 t2 = *reinterpret_cast<const double2*>(&PZt[i * 8 + 2 * q2]);
+          const double2 t2 = *reinterpret_cast<const double2*>(&PZt[i * PS + 2 * q2]);
           pz[2 * q2] = ((omask >> (2 * q2)) & 1ull) ? t2.x : 0.0;
           pz[2 * q2 + 1] = ((omask >> (2 * q2 + 1)) & 1ull) ? t2.y : 0.0;
           kr[2 * q2] = 0.0;
@@ -320,8 +321,8 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         double afi = av[i];
 #pragma unroll
         for (int o2 = 0; o2 < 4; ++o2) {
-          *reinterpret_cast<double2*>(&Ks[i * 8 + 2 * o2]) = double2{kr[2 * o2], kr[2 * o2 + 1]};
-          *reinterpret_cast<double2*>(&Vs[i * 8 + 2 * o2]) =
+          *reinterpret_cast<double2*>(&Ks[i * PS + 2 * o2]) = double2{kr[2 * o2], kr[2 * o2 + 1]};
+          *reinterpret_cast<double2*>(&Vs[i * PS + 2 * o2]) =
               double2{fma(jitter, kr[2 * o2], pz[2 * o2]), fma(jitter, kr[2 * o2 + 1], pz[2 * o2 + 1])};
           afi = fma(kr[2 * o2], vv[2 * o2], afi);
           afi = fma(kr[2 * o2 + 1], vv[2 * o2 + 1], afi);
@@ -339,18 +340,18 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         // two-stage software pipeline over the four observation pairs
         double2 ka[BS], vb[BS], kan[BS], vbn[BS];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) ka[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * 8]);
+        for (int i = 0; i < BS; ++i) ka[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * PS]);
 #pragma unroll
-        for (int j = 0; j < BS; ++j) vb[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * 8]);
+        for (int j = 0; j < BS; ++j) vb[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * PS]);
 #pragma unroll
         for (int o2 = 0; o2 < 4; ++o2) {
           if (o2 < 3) {
 #pragma unroll
             for (int i = 0; i < BS; ++i)
-              kan[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * 8 + 2 * (o2 + 1)]);
+              kan[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * PS + 2 * (o2 + 1)]);
 #pragma unroll
             for (int j = 0; j < BS; ++j)
-              vbn[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * 8 + 2 * (o2 + 1)]);
+              vbn[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * PS + 2 * (o2 + 1)]);
           }
 #pragma unroll
           for (int i = 0; i < BS; ++i)
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       for (int j = 0; j < BS; ++j)
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
-          double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * 8 + pz_dst[j]] : &trash[lane];
+          double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * PS + pz_dst[j]] : &trash[lane];
           *dst = zcol[j] * Pb[i][j];
         }
       wave_sync();  // #5
