@@ -296,6 +296,14 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return y;
 }
 
+// 1/x for x in a safe range: hardware estimate + two Newton steps
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * fma(-x, y, 2.0);
+  y = y * fma(-x, y, 2.0);
+  return y;
+}
+
 // reference implementation with plain shuffles (self-test of the DPP encodings)
 __device__ __forceinline__ unsigned long long wave_max_u64_shfl(unsigned long long v) {
 #pragma unroll

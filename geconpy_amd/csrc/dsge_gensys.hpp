@@ -123,9 +123,48 @@ __host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap)
 #define GZ(i, j) L.Z[(i)*L.ldz + (j)]
 
 __device__ __forceinline__ void rot2(cx& x, cx& y, double c, cx s) {
-  const cx tx = c * x + s * y;
-  y = c * y - conj(s) * x;
+  // x' = c x + s y ; y' = c y - conj(s) x, 12 FMAs/MULs
+  cx tx, ty;
+  tx.re = fma(c, x.re, fma(s.re, y.re, -s.im * y.im));
+  tx.im = fma(c, x.im, fma(s.re, y.im, s.im * y.re));
+  ty.re = fma(c, y.re, -fma(s.re, x.re, s.im * x.im));
+  ty.im = fma(c, y.im, -fma(s.re, x.im, -s.im * x.re));
   x = tx;
+  y = ty;
+}
+// real rotation of the real parts only (the pencil is real until the first complex shift)
+__device__ __forceinline__ void rot2_real(cx& x, cx& y, double c, double s) {
+  const double tx = fma(c, x.re, s * y.re);
+  y.re = fma(c, y.re, -s * x.re);
+  x.re = tx;
+}
+// real Givens: c, s, r with [c s; -s c] [f; g] = [r; 0], c >= 0
+__device__ __forceinline__ void lartg_real(double f, double g, double& c, double& s, double& r) {
+  if (g == 0.0) {
+    c = 1.0;
+    s = 0.0;
+    r = f;
+    return;
+  }
+  if (f == 0.0) {
+    c = 0.0;
+    s = (g > 0.0) ? 1.0 : -1.0;
+    r = fabs(g);
+    return;
+  }
+  const double d2 = fma(f, f, g * g);
+  double inv_d, d;
+  if (d2 > 1e-280 && d2 < 1e280) {
+    inv_d = fast_rsqrt(d2);
+    d = d2 * inv_d;
+  } else {
+    d = hypot(f, g);
+    inv_d = 1.0 / d;
+  }
+  const double sg = (f > 0.0) ? 1.0 : -1.0;  // same convention as the complex lartg: c = |f|/d, r = sign(f) d
+  c = fabs(f) * inv_d;
+  s = sg * g * inv_d;
+  r = sg * d;
 }
 
 // rows i (x) and k (y) of H, T (columns c0..N-1) and X
@@ -180,6 +219,151 @@ struct Rot4 {
   cx hx, hy, tx, ty;
 };
 __device__ __forceinline__ cx bc(cx v, int src) { return cx{readlane_dyn_f64(v.re, src), readlane_dyn_f64(v.im, src)}; }
+
+// Split form for the hot loops: *_begin fences the previous rotation's stores and ISSUES the six
+// 16-byte loads; the caller then computes the rotation (readlane + lartg, ~200 cycles) while they are
+// in flight; *_finish rotates, applies the exact (r, 0) fix-up and stores WITHOUT a trailing fence
+// (the next *_begin, or an explicit wave_sync() before any plain LDS read, provides it).
+struct RotLd {
+  cx hx, hy, tx, ty, ax, ay;
+};
+__device__ __forceinline__ RotLd rows_begin(const GsLayout& L, int i, int k, int lane) {
+  wave_sync();
+  RotLd o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
+  if (lane < L.N) {
+    o.hx = GH(i, lane);
+    o.hy = GH(k, lane);
+    o.tx = GT(i, lane);
+    o.ty = GT(k, lane);
+  }
+  if (lane < L.ell) {
+    o.ax = GX(i, lane);
+    o.ay = GX(k, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  return o;
+}
+__device__ __forceinline__ Rot4 rows_finish(const GsLayout& L, int i, int k, RotLd d, double c, cx s, int fixm,
+                                            int fixi, cx r, int lane) {
+  rot2(d.hx, d.hy, c, s);
+  rot2(d.tx, d.ty, c, s);
+  rot2(d.ax, d.ay, c, s);
+  if (lane == fixi) {
+    if (fixm == 1) {
+      d.hx = r;
+      d.hy = mk(0, 0);
+    } else if (fixm == 2) {
+      d.tx = r;
+      d.ty = mk(0, 0);
+    }
+  }
+  if (lane < L.N) {
+    GH(i, lane) = d.hx;
+    GH(k, lane) = d.hy;
+    GT(i, lane) = d.tx;
+    GT(k, lane) = d.ty;
+  }
+  if (lane < L.ell) {
+    GX(i, lane) = d.ax;
+    GX(k, lane) = d.ay;
+  }
+  return Rot4{d.hx, d.hy, d.tx, d.ty};
+}
+__device__ __forceinline__ Rot4 rows_finish_real(const GsLayout& L, int i, int k, RotLd d, double c, double s,
+                                                 int fixm, int fixi, double r, int lane) {
+  rot2_real(d.hx, d.hy, c, s);
+  rot2_real(d.tx, d.ty, c, s);
+  rot2_real(d.ax, d.ay, c, s);
+  if (lane == fixi) {
+    if (fixm == 1) {
+      d.hx.re = r;
+      d.hy.re = 0.0;
+    } else if (fixm == 2) {
+      d.tx.re = r;
+      d.ty.re = 0.0;
+    }
+  }
+  if (lane < L.N) {
+    GH(i, lane) = d.hx;
+    GH(k, lane) = d.hy;
+    GT(i, lane) = d.tx;
+    GT(k, lane) = d.ty;
+  }
+  if (lane < L.ell) {
+    GX(i, lane) = d.ax;
+    GX(k, lane) = d.ay;
+  }
+  return Rot4{d.hx, d.hy, d.tx, d.ty};
+}
+__device__ __forceinline__ RotLd cols_begin(const GsLayout& L, int i, int k, int lane) {
+  wave_sync();
+  RotLd o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
+  if (lane < L.N) {
+    o.hx = GH(lane, i);
+    o.hy = GH(lane, k);
+    o.tx = GT(lane, i);
+    o.ty = GT(lane, k);
+  }
+  if (lane < L.n) {
+    o.ax = GZ(lane, i);
+    o.ay = GZ(lane, k);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  return o;
+}
+__device__ __forceinline__ Rot4 cols_finish(const GsLayout& L, int i, int k, RotLd d, double c, cx s, int fixm,
+                                            int fixi, cx r, int lane) {
+  rot2(d.hx, d.hy, c, s);
+  rot2(d.tx, d.ty, c, s);
+  rot2(d.ax, d.ay, c, s);
+  if (lane == fixi) {
+    if (fixm == 1) {
+      d.hx = r;
+      d.hy = mk(0, 0);
+    } else if (fixm == 2) {
+      d.tx = r;
+      d.ty = mk(0, 0);
+    }
+  }
+  if (lane < L.N) {
+    GH(lane, i) = d.hx;
+    GH(lane, k) = d.hy;
+    GT(lane, i) = d.tx;
+    GT(lane, k) = d.ty;
+  }
+  if (lane < L.n) {
+    GZ(lane, i) = d.ax;
+    GZ(lane, k) = d.ay;
+  }
+  return Rot4{d.hx, d.hy, d.tx, d.ty};
+}
+
+__device__ __forceinline__ Rot4 cols_finish_real(const GsLayout& L, int i, int k, RotLd d, double c, double s,
+                                                 int fixm, int fixi, double r, int lane) {
+  rot2_real(d.hx, d.hy, c, s);
+  rot2_real(d.tx, d.ty, c, s);
+  rot2_real(d.ax, d.ay, c, s);
+  if (lane == fixi) {
+    if (fixm == 1) {
+      d.hx.re = r;
+      d.hy.re = 0.0;
+    } else if (fixm == 2) {
+      d.tx.re = r;
+      d.ty.re = 0.0;
+    }
+  }
+  if (lane < L.N) {
+    GH(lane, i) = d.hx;
+    GH(lane, k) = d.hy;
+    GT(lane, i) = d.tx;
+    GT(lane, k) = d.ty;
+  }
+  if (lane < L.n) {
+    GZ(lane, i) = d.ax;
+    GZ(lane, k) = d.ay;
+  }
+  return Rot4{d.hx, d.hy, d.tx, d.ty};
+}
 
 __device__ __forceinline__ Rot4 rot_rows_r(const GsLayout& L, int i, int k, double c, cx s, int fixm, int fixi, cx r,
                                            int lane) {
@@ -252,48 +436,55 @@ __device__ __forceinline__ void set_elem(cx* p, cx v, int lane) {
 }
 
 // ---- step 2: Hessenberg-triangular reduction ---------------------------------------------------
-// Column j is prefetched with one row per lane; within the column sweep the only element that
-// changes is the running pivot, which comes back from the rotation in the column owner's registers.
+// The pencil is still REAL here (complex numbers enter with the first QZ shift), so this phase runs
+// real Givens rotations on the real parts only.  Column j is prefetched with one row per lane; within
+// the column sweep the only element that changes is the running pivot, which comes back from the
+// rotation in the column owner's registers.
 __device__ __forceinline__ void hess_tri(const GsLayout& L, int lane) {
   const int N = L.N;
-  double c;
-  cx s, r;
+  double c, s, r;
   // T = [[A, 0], [0, I]]: only the leading n x n block can have sub-diagonal entries, and row
   // rotations inside that block leave the identity block alone
   for (int j = 0; j < L.n - 1; ++j) {
-    const cx colv = (lane < N) ? GT(lane, j) : mk(0, 0);
-    cx g = bc(colv, L.n - 1);
+    wave_sync();
+    const double colv = (lane < N) ? GT(lane, j).re : 0.0;
+    double g = readlane_dyn_f64(colv, L.n - 1);
     for (int i = L.n - 1; i > j; --i) {
-      const cx f = bc(colv, i - 1);
-      if (is0(g)) {
+      const double f = readlane_dyn_f64(colv, i - 1);
+      if (g == 0.0) {
         g = f;
         continue;
       }
-      lartg(f, g, c, s, r);
-      rot_rows_r(L, i - 1, i, c, s, 2, j, r, lane);
+      const RotLd ld = rows_begin(L, i - 1, i, lane);
+      lartg_real(f, g, c, s, r);
+      rows_finish_real(L, i - 1, i, ld, c, s, 2, j, r, lane);
       g = r;
     }
   }
   for (int j = 0; j < N - 2; ++j) {
-    const cx colv = (lane < N) ? GH(lane, j) : mk(0, 0);
-    cx g = bc(colv, N - 1);
+    wave_sync();
+    const double colv = (lane < N) ? GH(lane, j).re : 0.0;
+    double g = readlane_dyn_f64(colv, N - 1);
     for (int i = N - 1; i > j + 1; --i) {
-      const cx f = bc(colv, i - 1);
-      if (is0(g)) {
+      const double f = readlane_dyn_f64(colv, i - 1);
+      if (g == 0.0) {
         g = f;
         continue;
       }
-      lartg(f, g, c, s, r);
-      const Rot4 rr = rot_rows_r(L, i - 1, i, c, s, 1, j, r, lane);
+      const RotLd ld = rows_begin(L, i - 1, i, lane);
+      lartg_real(f, g, c, s, r);
+      const Rot4 rr = rows_finish_real(L, i - 1, i, ld, c, s, 1, j, r, lane);
       g = r;
-      const cx tii = bc(rr.ty, i), tim = bc(rr.ty, i - 1);  // T[i][i], T[i][i-1] after the row rotation
-      if (!is0(tim)) {
-        cx r2;
-        lartg(tii, tim, c, s, r2);
-        rot_cols_r(L, i, i - 1, c, s, 2, i, r2, lane);
+      const double tii = readlane_dyn_f64(rr.ty.re, i), tim = readlane_dyn_f64(rr.ty.re, i - 1);
+      if (tim != 0.0) {
+        const RotLd lc2 = cols_begin(L, i, i - 1, lane);
+        double r2;
+        lartg_real(tii, tim, c, s, r2);
+        cols_finish_real(L, i, i - 1, lc2, c, s, 2, i, r2, lane);
       }
     }
   }
+  wave_sync();
 }
 
 __device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane) {
@@ -469,17 +660,20 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
       Rot4 cr{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
       for (int j = istart; j < ilast; ++j) {
         Rot4 rr;
+        const RotLd ld = rows_begin(L, j, j + 1, lane);
         if (j > istart) {
           // bulge: H[j][j-1] (row j), H[j+1][j-1] (row j+1) = "y" outputs of the last column rotation
           lartg(bc(cr.hy, j), bc(cr.hy, j + 1), c, s, r);
-          rr = rot_rows_r(L, j, j + 1, c, s, 1, j - 1, r, lane);
+          rr = rows_finish(L, j, j + 1, ld, c, s, 1, j - 1, r, lane);
         } else {
-          rr = rot_rows_r(L, j, j + 1, c, s, 0, 0, r, lane);
+          rr = rows_finish(L, j, j + 1, ld, c, s, 0, 0, r, lane);
         }
+        const RotLd lc2 = cols_begin(L, j + 1, j, lane);
         cx r2;
         lartg(bc(rr.ty, j + 1), bc(rr.ty, j), c, s, r2);  // T[j+1][j+1], T[j+1][j]
-        cr = rot_cols_r(L, j + 1, j, c, s, 2, j + 1, r2, lane);
+        cr = cols_finish(L, j + 1, j, lc2, c, s, 2, j + 1, r2, lane);
       }
+      wave_sync();
     }
   }
   return false;
@@ -502,14 +696,17 @@ __device__ __forceinline__ void swap_adjacent(const GsLayout& L, int k, int lane
   const double sa = cabs_(h11), sb = cabs_(t11);
   double c;
   cx s, r;
+  const RotLd lc2 = cols_begin(L, k, k + 1, lane);
   lartg(g, f, c, s, r);
-  const Rot4 cr = rot_cols_r(L, k, k + 1, c, neg(conj(s)), 0, 0, r, lane);
+  const Rot4 cr = cols_finish(L, k, k + 1, lc2, c, neg(conj(s)), 0, 0, r, lane);
+  const RotLd ld = rows_begin(L, k, k + 1, lane);
   // after the column rotation: column k of rows k, k+1 ("x" outputs of lanes k, k+1)
   if (sa >= sb)
     lartg(bc(cr.hx, k), bc(cr.hx, k + 1), c, s, r);
   else
     lartg(bc(cr.tx, k), bc(cr.tx, k + 1), c, s, r);
-  rot_rows_r(L, k, k + 1, c, s, 0, 0, r, lane);
+  rows_finish(L, k, k + 1, ld, c, s, 0, 0, r, lane);
+  wave_sync();
   // both (k+1, k) entries are annihilated up to rounding: store exact zeros
   if (lane == 0) {
     GH(k + 1, k) = mk(0, 0);
@@ -557,13 +754,22 @@ __device__ __forceinline__ void jacobi_svd(cx* G, int ldg, int nr, int nc, cx* V
         be = wave_sum_dpp(be);
         gr = wave_sum_dpp(gr);
         gi = wave_sum_dpp(gi);
-        const double ag = hypot(gr, gi);
-        if (ag < 1e-290 || ag <= 1e-15 * sqrt(al) * sqrt(be)) continue;
+        const double ag2 = fma(gr, gr, gi * gi);
+        // |gamma| <= 1e-15 sqrt(alpha beta)  <=>  |gamma|^2 <= 1e-30 alpha beta (no square roots)
+        if (ag2 < 1e-290 || ag2 <= 1e-30 * al * be) continue;
         rotated = true;
-        const cx phc = mk(gr / ag, -gi / ag);  // conj(phase)
-        const double zeta = (be - al) / (2.0 * ag);
-        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + hypot(1.0, zeta));
-        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        const double inv_ag = fast_rsqrt(ag2);
+        const cx phc = mk(gr * inv_ag, -gi * inv_ag);  // conj(phase)
+        const double zeta = 0.5 * (be - al) * inv_ag;
+        const double z2 = fma(zeta, zeta, 1.0);
+        double t;
+        if (z2 < 1e280) {
+          const double root = z2 * fast_rsqrt(z2);  // sqrt(1 + zeta^2)
+          t = ((zeta >= 0.0) ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + root);
+        } else {
+          t = 0.5 / zeta;  // |zeta| huge: tan(phi) ~ 1/(2 zeta)
+        }
+        const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
         for (int row = lane; row < nr; row += 64) {
           const cx gp = G[row * ldg + p], gq = G[row * ldg + q] * phc;
           G[row * ldg + p] = cs * gp - sn * gq;

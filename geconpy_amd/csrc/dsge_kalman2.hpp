@@ -51,14 +51,6 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/x for x in a safe range: hardware estimate + two Newton steps
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * fma(-x, y, 2.0);
-  y = y * fma(-x, y, 2.0);
-  return y;
-}
-
 // Register-blocked product with compile-time strides, software-pipelined by hand: two operand
 // register sets ping-pong, the LDS loads of step k+1 are issued BEFORE the 25 FMAs of step k and
 // scheduling barriers keep hipcc from sinking them below the FMAs (it otherwise does, exposing the
