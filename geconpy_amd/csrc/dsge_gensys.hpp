@@ -435,33 +435,65 @@ __device__ __forceinline__ void set_elem(cx* p, cx v, int lane) {
   if (lane == 0) *p = v;
 }
 
-// ---- step 2: Hessenberg-triangular reduction ---------------------------------------------------
-// The pencil is still REAL here (complex numbers enter with the first QZ shift), so this phase runs
-// real Givens rotations on the real parts only.  Column j is prefetched with one row per lane; within
-// the column sweep the only element that changes is the running pivot, which comes back from the
-// rotation in the column owner's registers.
-__device__ __forceinline__ void hess_tri(const GsLayout& L, int lane) {
+// ---- real Householder reflector from column j of M (rows j..N-1), applied from the left to rows
+// j..N-1 of H, T and X (the pencil is real at this stage; only the real parts are touched).
+//   x = M[j:, j]; beta = -sign(x0) ||x||; tau = (beta - x0)/beta; v = x/(x0 - beta), v0 = 1   (dlarfg)
+//   rows <- rows - tau v (v' rows);  M[j][j] = beta, M[j+1:, j] = 0 exactly.
+// One matrix row per lane for building v (norm by DPP wave sum, v_r broadcast by v_readlane); one
+// matrix column per lane for applying it.
+__device__ __forceinline__ void householder_left(const GsLayout& L, cx* M, int j, int lane) {
+  const int N = L.N;
+  wave_sync();
+  const double x = (lane >= j && lane < N) ? M[lane * L.ldh + j].re : 0.0;
+  const double xnorm2 = wave_sum_dpp((lane > j) ? x * x : 0.0);
+  if (xnorm2 == 0.0) return;  // already zero below the diagonal (tau = 0)
+  const double alpha = readlane_dyn_f64(x, j);
+  const double nrm = sqrt(fma(alpha, alpha, xnorm2));
+  const double beta = (alpha >= 0.0) ? -nrm : nrm;
+  const double tau = (beta - alpha) / beta;
+  const double scal = 1.0 / (alpha - beta);
+  const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
+  // pass 1: w_c = sum_r v_r M[r][c] for the lane's column of H, T and X
+  double wh = 0.0, wt = 0.0, wx = 0.0;
+  const bool colact = lane < N, xact = lane < L.ell;
+  for (int r = j; r < N; ++r) {
+    const double vr = readlane_dyn_f64(v, r);
+    if (colact) {
+      wh = fma(vr, L.H[r * L.ldh + lane].re, wh);
+      wt = fma(vr, L.T[r * L.ldh + lane].re, wt);
+    }
+    if (xact) wx = fma(vr, L.X[r * L.ldx + lane].re, wx);
+  }
+  wh *= tau;
+  wt *= tau;
+  wx *= tau;
+  // pass 2: M[r][c] -= v_r (tau w_c)
+  for (int r = j; r < N; ++r) {
+    const double vr = readlane_dyn_f64(v, r);
+    if (colact) {
+      L.H[r * L.ldh + lane].re = fma(-vr, wh, L.H[r * L.ldh + lane].re);
+      L.T[r * L.ldh + lane].re = fma(-vr, wt, L.T[r * L.ldh + lane].re);
+    }
+    if (xact) L.X[r * L.ldx + lane].re = fma(-vr, wx, L.X[r * L.ldx + lane].re);
+  }
+  wave_sync();
+  if (lane >= j && lane < N) M[lane * L.ldh + j].re = (lane == j) ? beta : 0.0;
+  wave_sync();
+}
+
+// ---- step 2: structural deflation + Hessenberg-triangular reduction -----------------------------
+// Columns 0..z-1 of T are exactly zero (non-state variables, permuted to the front): a QR of
+// H[:, :z] deflates z roots (alpha = R0_ii, beta = 0) before any QZ work.  Then T[z:, z:] is made
+// upper triangular by reflectors on rows >= z, and H[z:, z:] upper Hessenberg by Givens pairs.
+// Everything is real here (complex numbers enter with the first QZ shift).  In the Givens phase
+// column j is prefetched with one row per lane; within the column sweep the only element that
+// changes is the running pivot, which comes back from the rotation in the column owner's registers.
+__device__ __forceinline__ void hess_tri(const GsLayout& L, int z, int lane) {
   const int N = L.N;
   double c, s, r;
-  // T = [[A, 0], [0, I]]: only the leading n x n block can have sub-diagonal entries, and row
-  // rotations inside that block leave the identity block alone
-  for (int j = 0; j < L.n - 1; ++j) {
-    wave_sync();
-    const double colv = (lane < N) ? GT(lane, j).re : 0.0;
-    double g = readlane_dyn_f64(colv, L.n - 1);
-    for (int i = L.n - 1; i > j; --i) {
-      const double f = readlane_dyn_f64(colv, i - 1);
-      if (g == 0.0) {
-        g = f;
-        continue;
-      }
-      const RotLd ld = rows_begin(L, i - 1, i, lane);
-      lartg_real(f, g, c, s, r);
-      rows_finish_real(L, i - 1, i, ld, c, s, 2, j, r, lane);
-      g = r;
-    }
-  }
-  for (int j = 0; j < N - 2; ++j) {
+  for (int j = 0; j < z; ++j) householder_left(L, L.H, j, lane);
+  for (int j = z; j < N - 1; ++j) householder_left(L, L.T, j, lane);
+  for (int j = z; j < N - 2; ++j) {
     wave_sync();
     const double colv = (lane < N) ? GH(lane, j).re : 0.0;
     double g = readlane_dyn_f64(colv, N - 1);
@@ -499,17 +531,18 @@ __device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane
 }
 
 // ---- step 3: complex single-shift QZ (zhgeqz, JOB='S') -------------------------------------------
-__device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
+__device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane) {
   const int N = L.N;
-  if (N <= 1) return true;
+  if (N - ilo <= 1) return true;
   const double SAFMIN = 2.2250738585072014e-308, ULP = 2.220446049250313e-16;
-  const double anorm = frob_norm(L.H, L.ldh, N, lane), bnorm = frob_norm(L.T, L.ldh, N, lane);
+  // norms of the active block (zhgeqz: zlanhs of H(ilo:ihi, ilo:ihi))
+  const double anorm = frob_norm(L.H + ilo * L.ldh + ilo, L.ldh, N - ilo, lane),
+               bnorm = frob_norm(L.T + ilo * L.ldh + ilo, L.ldh, N - ilo, lane);
   const double atol = fmax(SAFMIN, ULP * anorm), btol = fmax(SAFMIN, ULP * bnorm);
   const double ascale = 1.0 / fmax(SAFMIN, anorm), bscale = 1.0 / fmax(SAFMIN, bnorm);
-  const int ilo = 0;
   int ilast = N - 1, iiter = 0;
   cx eshift = mk(0, 0);
-  const int maxit = 30 * N;
+  const int maxit = 30 * (N - ilo);
   double c;
   cx s, r;
   for (int jiter = 0; jiter < maxit; ++jiter) {
@@ -542,7 +575,7 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int lane) {
       action = 2;
     } else {
       // highest j in [ilo, ilast-1] with a negligible sub-diagonal or a negligible T diagonal
-      const unsigned long long range = (ilast >= 64 ? ~0ull : ((1ull << ilast) - 1ull));
+      const unsigned long long range = (ilast >= 64 ? ~0ull : ((1ull << ilast) - 1ull)) & ~((1ull << ilo) - 1ull);
       const unsigned long long hit = (msub | mtz) & range;
       if (hit == 0ull) return false;  // cannot happen: bit ilo of msub is always set
       const int j = 63 - __clzll((long long)hit);
@@ -864,27 +897,37 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
     L.N = N;
     L.ell = ell;
     wave_sync();
+    // column permutation: exactly-zero columns of G1 (= zero columns of A, the non-state variables)
+    // first.  colpos(c) = position of original column c.
+    const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long zmask = ~a_colmask & nmask;  // zero columns of A
+    const int z = __popcll(zmask);
+#define COLPOS(c) ((((c) < n) && ((zmask >> (c)) & 1ull)) ? __popcll(zmask & ((1ull << (c)) - 1ull)) \
+                                                         : (z + (c) - __popcll(zmask & (((c) >= 64) ? ~0ull : ((1ull << (c)) - 1ull)))))
     for (int idx = lane; idx < n * n; idx += 64) {
       const int i = idx / n, j = idx - i * n;
-      GH(i, j) = mk(-Bg[idx], 0.0);
-      GT(i, j) = mk(Ag[idx], 0.0);
+      const int pj = COLPOS(j);
+      GH(i, pj) = mk(-Bg[idx], 0.0);
+      GT(i, pj) = mk(Ag[idx], 0.0);
     }
     for (int idx = lane; idx < n * ell; idx += 64) {
       const int i = idx / ell, a = idx - i * ell;
-      GH(i, n + a) = mk(-Cg[(size_t)i * n + L.lead[a]], 0.0);
+      GH(i, n + a) = mk(-Cg[(size_t)i * n + L.lead[a]], 0.0);  // columns >= n keep their place
     }
     if (lane < ell) {
-      GH(n + lane, L.lead[lane]) = mk(1.0, 0.0);
+      const int lc0 = L.lead[lane];
+      GH(n + lane, COLPOS(lc0)) = mk(1.0, 0.0);
       GT(n + lane, n + lane) = mk(1.0, 0.0);
       GX(n + lane, lane) = mk(1.0, 0.0);
     }
-    if (lane < n) GZ(lane, lane) = mk(1.0, 0.0);
+    if (lane < n) GZ(lane, COLPOS(lane)) = mk(1.0, 0.0);
+#undef COLPOS
     wave_sync();
 
     DBG_T(0);
-    hess_tri(L, lane);
+    hess_tri(L, z, lane);
     DBG_T(1);
-    const bool converged = qz_iterate(L, lane);
+    const bool converged = qz_iterate(L, z, lane);
     DBG_T(2);
     int eu0 = 0, eu1 = 0, eu2 = 0;
     bool have_T = false;
@@ -908,72 +951,75 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
           for (int j = 0; j < ell; ++j) r2 += (L.s2[j] > rs) ? 1 : 0;
         } else {
           if (lane < ell) L.s2[lane] = 0.0;
+          for (int idx = lane; idx < ell * ell; idx += 64) {
+            const int i = idx / ell, j = idx - i * ell;
+            L.V2[i * L.ldx + j] = mk(i == j ? 1.0 : 0.0, 0.0);
+          }
           wave_sync();
         }
         if (r2 >= nu) eu0 = 1;
-        if (ns > 0) {
-          jacobi_svd(&GX(0, 0), L.ldx, ns, ell, L.V1, L.ldx, L.s1, lane);
-          for (int j = 0; j < ell; ++j) r1 += (L.s1[j] > rs) ? 1 : 0;
-        } else {
-          if (lane < ell) L.s1[lane] = 0.0;
-          wave_sync();
+        // eta = [eta1; eta2] = Q Pi has orthonormal columns, so eta1^H eta1 + eta2^H eta2 = I (CS
+        // decomposition): eta1 shares the right singular vectors V2 of eta2 and the columns of
+        // eta1 V2 are orthogonal with norms sqrt(1 - s2^2).  The reference's second gesdd
+        // (gensys.py:291-296) therefore reduces to the column norms of eta1 V2, with V1 := V2.
+        for (int j = 0; j < ell; ++j) {
+          cx g = mk(0, 0);
+          if (lane < ns)
+            for (int cc = 0; cc < ell; ++cc) g = g + GX(lane, cc) * L.V2[cc * L.ldx + j];
+          const double sq = wave_sum_dpp(fma(g.re, g.re, g.im * g.im));
+          if (lane == 0) L.s1[j] = sqrt(sq);
         }
-        // uniqueness: rank of V1k - V2k V2k^H V1k  (gensys.py:301-310); columns of S3 = kept cols of V1
+        wave_sync();
+        // uniqueness (gensys.py:301-310): V1k - V2k V2k^H V1k keeps exactly the columns v_j with
+        // s1_j > rs and s2_j <= rs; they are orthonormal, so the rank is their count
+        int n_loose = 0;
+        for (int j = 0; j < ell; ++j) {
+          const bool k1 = L.s1[j] > rs, k2 = L.s2[j] > rs;
+          r1 += k1 ? 1 : 0;
+          n_loose += (k1 && !k2) ? 1 : 0;
+        }
         bool unique = true;
         if (r1 > 0) {
-          // S3[:, jj] for kept j: v1_j - sum_{kept c} v2_c (v2_c^H v1_j)
-          int jj = 0;
-          for (int j = 0; j < ell; ++j) {
-            if (!(L.s1[j] > rs)) continue;
-            cx acc = mk(0, 0);
-            if (lane < ell) acc = L.V1[lane * L.ldx + j];
-            for (int cc = 0; cc < ell; ++cc) {
-              if (!(L.s2[cc] > rs)) continue;
-              // dot = v2_c^H v1_j
-              cx part = mk(0, 0);
-              if (lane < ell) part = conj(L.V2[lane * L.ldx + cc]) * L.V1[lane * L.ldx + j];
-              const double dr = wave_sum_dpp(part.re), di = wave_sum_dpp(part.im);
-              if (lane < ell) acc = acc - L.V2[lane * L.ldx + cc] * mk(dr, di);
-            }
-            if (lane < ell) L.S3[lane * L.ldx + jj] = acc;
-            ++jj;
-          }
-          wave_sync();
-          double* s3 = L.s1 + 32;  // scratch for the singular values of the uniqueness matrix
-          jacobi_svd(L.S3, L.ldx, ell, r1, nullptr, 0, s3, lane);
-          int n_loose = 0;
-          for (int j = 0; j < r1; ++j) n_loose += (s3[j] > rs * (double)N) ? 1 : 0;
           eu2 = n_loose;
           unique = (n_loose == 0);
         }
         if (unique) eu1 = 1;
         DBG_T(4);
 
-        // ---- Phi = (G1k V1k^H)(V2k D2k^-2 G2k^H)  (ns x nu), stored transposed-free in the unused
-        // lower-left block of H:  Phi[i][j] at H[ns + j][i]
-        // M12 = V1k^H V2k D2k^-2   (ell x ell, rows = columns j of V1 (kept), cols = columns c of V2 (kept))
-        for (int idx = lane; idx < ell * ell; idx += 64) {
-          const int j = idx / ell, cc = idx - j * ell;
-          cx acc = mk(0, 0);
-          if (L.s1[j] > rs && L.s2[cc] > rs) {
-            for (int q = 0; q < ell; ++q) acc = acc + conj(L.V1[q * L.ldx + j]) * L.V2[q * L.ldx + cc];
-            const double w = 1.0 / (L.s2[cc] * L.s2[cc]);
-            acc = w * acc;
+        // ---- Phi = eta1_k pinv_k(eta2) = sum_j w_j (eta1 v_j)(G2_j)^H,  w_j = [s1_j > rs][s2_j > rs]/s2_j^2
+        // (ns x nu), stored in the unused lower-left block of H:  Phi[i][u] at H[ns + u][i]
+        if (nu <= ell) {
+          // Bm[c][u] = sum_j V2[c][j] w_j conj(G2[u][j])   (ell x nu) in the V1 scratch
+          for (int idx = lane; idx < ell * nu; idx += 64) {
+            const int cc = idx / nu, u = idx - cc * nu;
+            cx acc = mk(0, 0);
+            for (int j = 0; j < ell; ++j) {
+              if (!(L.s1[j] > rs && L.s2[j] > rs)) continue;
+              const double w = 1.0 / (L.s2[j] * L.s2[j]);
+              acc = acc + L.V2[cc * L.ldx + j] * (w * conj(GX(ns + u, j)));
+            }
+            L.V1[cc * L.ldx + u] = acc;
           }
-          L.S3[j * L.ldx + cc] = acc;
-        }
-        wave_sync();
-        // Phi[i][u] = sum_j G1[i][j] (sum_c M12[j][c] conj(G2[u][c]))
-        for (int idx = lane; idx < ns * nu; idx += 64) {
-          const int i = idx / nu, u = idx - i * nu;
-          cx acc = mk(0, 0);
-          for (int j = 0; j < ell; ++j) {
-            if (!(L.s1[j] > rs)) continue;
-            cx inner = mk(0, 0);
-            for (int cc = 0; cc < ell; ++cc) inner = inner + L.S3[j * L.ldx + cc] * conj(GX(ns + u, cc));
-            acc = acc + GX(i, j) * inner;
+          wave_sync();
+          for (int idx = lane; idx < ns * nu; idx += 64) {
+            const int i = idx / nu, u = idx - i * nu;
+            cx acc = mk(0, 0);
+            for (int cc = 0; cc < ell; ++cc) acc = acc + GX(i, cc) * L.V1[cc * L.ldx + u];
+            GH(ns + u, i) = acc;
           }
-          GH(ns + u, i) = acc;
+        } else {
+          for (int idx = lane; idx < ns * nu; idx += 64) {
+            const int i = idx / nu, u = idx - i * nu;
+            cx acc = mk(0, 0);
+            for (int j = 0; j < ell; ++j) {
+              if (!(L.s1[j] > rs && L.s2[j] > rs)) continue;
+              cx g1 = mk(0, 0);
+              for (int cc = 0; cc < ell; ++cc) g1 = g1 + GX(i, cc) * L.V2[cc * L.ldx + j];
+              const double w = 1.0 / (L.s2[j] * L.s2[j]);
+              acc = acc + g1 * (w * conj(GX(ns + u, j)));
+            }
+            GH(ns + u, i) = acc;
+          }
         }
         wave_sync();
         // rhs = [B11, B12 - Phi B22] in place in T[:ns, :]

@@ -58,6 +58,7 @@ class Pencil:
         self.X[n:, :] = np.eye(ell)
         self.Z = np.eye(N, dtype=np.complex128)[:n].copy()
         self.n_rot = 0
+        self.n_refl = 0
 
     def rot_rows(self, i, k, c, s):
         """rows i (x) and k (y) of H, T, X."""
@@ -72,19 +73,52 @@ class Pencil:
         self.n_rot += 1
 
 
-def hessenberg_triangular(P):
+def _householder(x):
+    """Real reflector H = I - tau v v' with H x = beta e1 (LAPACK dlarfg); v[0] = 1."""
+    alpha = x[0]
+    xnorm = np.linalg.norm(x[1:])
+    if xnorm == 0.0:
+        return np.zeros_like(x), 0.0, alpha
+    beta = -np.copysign(np.hypot(alpha, xnorm), alpha)
+    tau = (beta - alpha) / beta
+    v = x / (alpha - beta)
+    v[0] = 1.0
+    return v, tau, beta
+
+
+def _apply_left(P, j0, v, tau):
+    """rows j0.. of H, T, X  <-  (I - tau v v') rows   (real data at this stage)."""
+    if tau == 0.0:
+        return
+    for M in (P.H, P.T, P.X):
+        w = v @ M[j0:, :]
+        M[j0:, :] -= tau * np.outer(v, w)
+    P.n_refl += 1
+
+
+def deflate_zero_columns(P, z):
+    """The first z columns of T are exactly zero (non-state variables, moved to the front by the
+    column permutation).  A QR of H[:, :z] turns the pencil into  [[R0, *], [0, H']] , [[0, *], [0, T']]:
+    z roots (alpha = R0_ii, beta = 0) are deflated before any QZ work, exactly, and (H', T') has
+    dimension N - z."""
+    H = P.H
+    for j in range(z):
+        v, tau, beta = _householder(H[j:, j].real.copy())
+        _apply_left(P, j, v, tau)
+        H[j, j] = beta
+        H[j + 1 :, j] = 0
+
+
+def hessenberg_triangular(P, ilo=0):
     N, H, T = P.N, P.H, P.T
-    # T -> upper triangular
-    for j in range(N - 1):
-        for i in range(N - 1, j, -1):
-            if T[i, j] == 0:
-                continue
-            c, s, r = lartg(T[i - 1, j], T[i, j])
-            P.rot_rows(i - 1, i, c, s)
-            T[i - 1, j] = r
-            T[i, j] = 0
-    # H -> upper Hessenberg, T stays triangular
-    for j in range(N - 2):
+    # T[ilo:, ilo:] -> upper triangular by Householder reflectors on rows >= ilo
+    for j in range(ilo, N - 1):
+        v, tau, beta = _householder(T[j:, j].real.copy())
+        _apply_left(P, j, v, tau)
+        T[j, j] = beta
+        T[j + 1 :, j] = 0
+    # H[ilo:, ilo:] -> upper Hessenberg, T stays triangular
+    for j in range(ilo, N - 2):
         for i in range(N - 1, j + 1, -1):
             if H[i, j] == 0:
                 continue
@@ -103,21 +137,22 @@ def abs1(z):
     return abs(z.real) + abs(z.imag)
 
 
-def qz_iterate(P, max_it_factor=30):
-    """LAPACK zhgeqz (JOB='S'), ilo = 0, ihi = N-1.  Returns True on convergence."""
+def qz_iterate(P, ilo=0, max_it_factor=30):
+    """LAPACK zhgeqz (JOB='S') on the active block ilo..N-1 (rows/columns < ilo are already
+    triangular).  Returns True on convergence."""
     N, H, T = P.N, P.H, P.T
-    if N == 1:
+    if N - ilo <= 1:
         return True
-    anorm = np.linalg.norm(H)
-    bnorm = np.linalg.norm(T)
+    anorm = np.linalg.norm(H[ilo:, ilo:])
+    bnorm = np.linalg.norm(T[ilo:, ilo:])
     atol = max(SAFMIN, ULP * anorm)
     btol = max(SAFMIN, ULP * bnorm)
     ascale = 1.0 / max(SAFMIN, anorm)
     bscale = 1.0 / max(SAFMIN, bnorm)
-    ilo, ilast = 0, N - 1
+    ilast = N - 1
     iiter = 0
     eshift = 0j
-    maxit = max_it_factor * N
+    maxit = max_it_factor * (N - ilo)
     for _jiter in range(maxit):
         # ---- deflation tests ------------------------------------------------------------
         action = None  # "split60" | "zeroT50" | ("qz", ifirst)
@@ -335,31 +370,27 @@ def gensys_post(P, ns, rs):
     r2 = int(keep2.sum())
     if r2 >= nu:
         eu[0] = 1
-    if ns > 0:
-        G1, V1, s1 = jacobi_svd(eta1)
-        keep1 = s1 > rs
-    else:
-        G1 = np.zeros((0, ell), np.complex128)
-        V1 = np.eye(ell, dtype=np.complex128)
-        s1 = np.zeros(ell)
-        keep1 = np.zeros(ell, bool)
+    # eta = [eta1; eta2] = Q Pi has orthonormal columns, so eta1^H eta1 + eta2^H eta2 = I (CS
+    # decomposition): the right singular vectors of eta1 are those of eta2 and G1 = eta1 V2 has
+    # orthogonal columns with norms sqrt(1 - s2^2).  The reference runs a second gesdd on eta1
+    # (gensys.py:291-296); here its singular values are the column norms of eta1 V2 and V1 := V2.
+    G1 = eta1 @ V2
+    s1 = np.sqrt(np.einsum("ij,ij->j", G1.conj(), G1).real) if ns > 0 else np.zeros(ell)
+    keep1 = s1 > rs
     r1 = int(keep1.sum())
-    V2k = V2[:, keep2]
-    V1k = V1[:, keep1]
+    # uniqueness (gensys.py:301-310): V1k - V2k V2k^H V1k keeps exactly the columns v_j with keep1_j and
+    # not keep2_j, which are orthonormal, so its rank is their count (each has norm 1 > rs N).
     if r1 == 0:
         unique = True
     else:
-        loose = V1k - V2k @ (V2k.conj().T @ V1k)
-        _, _, sl = jacobi_svd(loose)
-        n_loose = int((sl > rs * N).sum())
+        n_loose = int((keep1 & ~keep2).sum())
         eu[2] = n_loose
         unique = n_loose == 0
     if unique:
         eu[1] = 1
-    # Phi = eta1_k pinv_k(eta2):  eta1_k = G1k V1k^H,  pinv_k(eta2) = V2k diag(1/s2k^2) G2k^H
-    eta1k = G1[:, keep1] @ V1k.conj().T
-    pinv2 = (V2k / (s2[keep2] ** 2)[None, :]) @ G2[:, keep2].conj().T
-    Phi = eta1k @ pinv2  # ns x nu
+    # Phi = eta1_k pinv_k(eta2) = sum_j [keep1_j keep2_j / s2_j^2] (eta1 v_j)(G2_j)^H
+    w = np.where(keep1 & keep2, 1.0 / np.maximum(s2, 1e-300) ** 2, 0.0)
+    Phi = (G1 * w[None, :]) @ G2.conj().T  # ns x nu
     A11 = H[:ns, :ns]
     rhs = np.hstack((T[:ns, :ns], T[:ns, ns:] - Phi @ T[ns:, ns:]))  # ns x N
     # back-substitution with the upper-triangular A11
@@ -370,7 +401,7 @@ def gensys_post(P, ns, rs):
     return Tm, eu
 
 
-def gensys_device_model(A, B, C, D, tol=1e-8):
+def gensys_device_model(A, B, C, D, tol=1e-8, deflate=True):
     """(T, eu, info) for one system; mirrors the kernel's control flow."""
     A, B, C = (np.asarray(x, dtype=np.float64) for x in (A, B, C))
     n = A.shape[0]
@@ -385,15 +416,25 @@ def gensys_device_model(A, B, C, D, tol=1e-8):
     G1[:n, :n] = A
     G1[n:, n:] = np.eye(ell)
     rs = tol if tol > 0 else np.spacing(1.0)
+    # structural deflation: columns of G1 that are exactly zero (non-state variables) go first
+    zero_cols = [j for j in range(n) if not np.any(A[:, j] != 0.0)]
+    z = len(zero_cols) if deflate else 0
+    if z:
+        colperm = np.array(zero_cols + [j for j in range(N) if j not in set(zero_cols)])
+        G0 = G0[:, colperm]
+        G1 = G1[:, colperm]
     P = Pencil(G0, G1, n)
-    hessenberg_triangular(P)
+    if z:
+        P.Z = np.eye(N, dtype=np.complex128)[:n][:, colperm].copy()
+        deflate_zero_columns(P, z)
+    hessenberg_triangular(P, ilo=z)
     rot_ht = P.n_rot
-    ok = qz_iterate(P)
+    ok = qz_iterate(P, ilo=z)
     rot_qz = P.n_rot - rot_ht
     if not ok:
         return np.zeros((n, n)), np.array([-3, -3, 0]), dict(converged=False)
     ns = reorder_stable_first(P, rs)
     Tm, eu = gensys_post(P, ns, rs)
-    info = dict(converged=True, N=N, ns=ns, rot_ht=rot_ht, rot_qz=rot_qz, rot_reorder=P.n_rot - rot_ht - rot_qz,
+    info = dict(converged=True, N=N, ns=ns, z=z, n_refl=P.n_refl, rot_ht=rot_ht, rot_qz=rot_qz, rot_reorder=P.n_rot - rot_ht - rot_qz,
                 alpha=np.diag(P.H).copy(), beta=np.diag(P.T).copy())
     return Tm, eu, info
