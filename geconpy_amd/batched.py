@@ -103,6 +103,23 @@ def selection_batched(B, C, D, T, A=None):
     return (R, resid) if A is not None else R
 
 
+def policy_norms_batched(A, B, C, D, T, R, state_mask):
+    """``deterministic_norm`` and ``stochastic_norm`` of gEconpy/model/statespace.py:1181-1204 for a
+    batch of draws; ``state_mask`` is the boolean vector ``tm1_idx & t_idx`` (:1186-1193)."""
+    A, B, C = _check_abc(A, B, C)
+    T, R, D = _f64(T, 3), _f64(R, 3), _f64(D, 3)
+    nb, n, _ = A.shape
+    k = D.shape[2]
+    mask = np.ascontiguousarray(np.asarray(state_mask) != 0, dtype=np.int32)
+    if mask.shape != (n,):
+        raise ValueError("state_mask must have one entry per variable")
+    det = np.empty(nb)
+    sto = np.empty(nb)
+    _lib.check(_lib.load().dsge_policy_norms_batched_host(_ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(T), _ptr(R),
+                                                          _ptr(mask), nb, n, k, _ptr(det), _ptr(sto)))
+    return det, sto
+
+
 def backward_direct_batched(A, B, D):
     """T = (-B)^-1 A, R = -B^-1 D (gEconpy/solvers/backward_looking.py:102-134)."""
     A, B = _f64(A, 3), _f64(B, 3)

@@ -169,6 +169,21 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
   return rc;
 }
 
+int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
+                 const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::norms_kernel<BS>, dsge::NormSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::norms_kernel<BS>, dim3(batch), dim3(64), dsge::NormSmem<BS>::bytes, st, A, B, C, D, T, R,
+                         mask, batch, n, k, det, sto);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
 
 int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
@@ -332,6 +347,19 @@ int dsge_selection_batched(const double* A, const double* B, const double* C, co
   if (batch == 0) return DSGE_SUCCESS;
   return launch_assemble(A, B, C, D, T, nullptr, nullptr, 0, batch, n, k, R_out, resid_out, nullptr, nullptr, nullptr,
                          1, 0, (hipStream_t)stream);
+}
+
+int dsge_policy_norms_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
+                              const double* R, const int32_t* state_mask, int batch, int n, int k,
+                              double* det_norm_out, double* stoch_norm_out, void* stream) {
+  int rc = check_common(batch, n, 56);  // five n x n matrices in LDS: n <= 56
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!A || !B || !C || !D || !T || !R || !state_mask || !det_norm_out || !stoch_norm_out)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_norms(A, B, C, D, T, R, state_mask, batch, n, k, det_norm_out, stoch_norm_out, (hipStream_t)stream);
 }
 
 int dsge_backward_direct_batched(const double* A, const double* B, const double* D, int batch, int n, int k,
@@ -624,6 +652,39 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
   if ((rc = dsge_selection_batched(dA, dB, dC, dD, dT, batch, n, k, dR, dRes, nullptr))) return rc;
   DOWN(R_out, dR, nk, double);
   DOWN(resid_out, dRes, batch, double);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_policy_norms_batched_host(const double* A, const double* B, const double* C, const double* D, const double* T,
+                                   const double* R, const int32_t* state_mask, int batch, int n, int k,
+                                   double* det_norm_out, double* stoch_norm_out) {
+  int rc = check_common(batch, n, 56);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!A || !B || !C || !D || !T || !R || !state_mask || !det_norm_out || !stoch_norm_out)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256(nk * 8) + 2 * align256((size_t)batch * 8) +
+                                       align256((size_t)n * 4) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dT, T, nn, double);
+  UP(dR, R, nk, double);
+  UP(dM, state_mask, (size_t)n, int32_t);
+  OUTBUF(d1, det_norm_out, batch, double);
+  OUTBUF(d2, stoch_norm_out, batch, double);
+  if ((rc = dsge_policy_norms_batched(dA, dB, dC, dD, dT, dR, dM, batch, n, k, d1, d2, nullptr))) return rc;
+  DOWN(det_norm_out, d1, batch, double);
+  DOWN(stoch_norm_out, d2, batch, double);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }

@@ -367,6 +367,90 @@ __global__ __launch_bounds__(64) void assemble_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// gEcon recursion residual norms (diagnostics of DSGEStateSpace.build_statespace_graph,
+// gEconpy/model/statespace.py:1181-1204).  With the state mask s (variables that appear at t-1 and at
+// t), M = diag(s):
+//   deterministic_norm = || (A + B T + C T M T)[:, s] ||_F     (A' + B R' + C R' P)
+//   stochastic_norm    = || B R + C T M R + D ||_F              (B S' + C R' Q + D)
+// ---------------------------------------------------------------------------------------
+template <int BS>
+struct NormSmem {
+  static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD;
+  static constexpr size_t bytes = sizeof(double) * (size_t)(5 * NP * LD);
+};
+
+template <int BS>
+__global__ __launch_bounds__(64) void norms_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                    const double* __restrict__ C, const double* __restrict__ D,
+                                                    const double* __restrict__ T, const double* __restrict__ R,
+                                                    const int32_t* __restrict__ state_mask, int batch, int n, int k,
+                                                    double* __restrict__ det_out, double* __restrict__ sto_out) {
+  constexpr int NP = NormSmem<BS>::NP, LD = NormSmem<BS>::LD;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ts = smem;
+  double* TMs = Ts + NP * LD;   // T with the non-state columns zeroed
+  double* Ws = TMs + NP * LD;   // T M T, then T M R
+  double* Ls = Ws + NP * LD;    // left operand (B, then C)
+  double* Rs = Ls + NP * LD;    // R padded to NP columns
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+  bool colmask[BS];
+#pragma unroll
+  for (int j = 0; j < BS; ++j) {
+    const int c = lc * BS + j;
+    colmask[j] = (c < n) && (state_mask[c] != 0);
+  }
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
+    wave_sync();
+    lds_load_matrix(Ts, LD, NP, NP, T + off, n, n, lane);
+    lds_load_matrix(Rs, LD, NP, NP, R + offk, n, k, lane);
+    lds_load_matrix(Ls, LD, NP, NP, B + off, n, n, lane);
+    {
+      double t[BS][BS];
+      blk_load_global<BS>(t, T + off, n, n, n, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) t[i][j] = colmask[j] ? t[i][j] : 0.0;
+      blk_store_lds<BS>(t, TMs, LD, lr, lc);
+    }
+    wave_sync();
+    double W1[BS][BS], W2[BS][BS], E1[BS][BS], E2[BS][BS];
+    blk_zero<BS>(W1);
+    blk_zero<BS>(W2);
+    mm_acc<BS, false>(W1, TMs, LD, Ts, LD, n, lr, lc);  // T M T
+    mm_acc<BS, false>(W2, TMs, LD, Rs, LD, n, lr, lc);  // T M R
+    blk_load_global<BS>(E1, A + off, n, n, n, lr, lc);
+    blk_load_global<BS>(E2, D + offk, n, k, k, lr, lc);
+    mm_acc<BS, false>(E1, Ls, LD, Ts, LD, n, lr, lc);   // + B T
+    mm_acc<BS, false>(E2, Ls, LD, Rs, LD, n, lr, lc);   // + B R
+    wave_sync();
+    lds_load_matrix(Ls, LD, NP, NP, C + off, n, n, lane);
+    blk_store_lds<BS>(W1, Ws, LD, lr, lc);
+    wave_sync();
+    mm_acc<BS, false>(E1, Ls, LD, Ws, LD, n, lr, lc);   // + C T M T
+    wave_sync();
+    blk_store_lds<BS>(W2, Ws, LD, lr, lc);
+    wave_sync();
+    mm_acc<BS, false>(E2, Ls, LD, Ws, LD, n, lr, lc);   // + C T M R
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        if (colmask[j]) s1 = fma(E1[i][j], E1[i][j], s1);
+        s2 = fma(E2[i][j], E2[i][j], s2);
+      }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      det_out[draw] = sqrt(s1);
+      sto_out[draw] = sqrt(s2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Kalman filter log-likelihood, "standard" filter (reference call
 // site gEconpy/model/statespace.py:1151-1157, a0 = 0 :812).
 //

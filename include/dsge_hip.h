@@ -134,6 +134,21 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
                                 double* resid_out);
 
 /*
+ * gEcon recursion residual norms, the `deterministic_norm` / `stochastic_norm` Deterministics of
+ * DSGEStateSpace.build_statespace_graph (gEconpy/model/statespace.py:1181-1204).  With the state mask
+ * s (variables that appear at t-1 and at t in some equation, :1186-1193):
+ *   deterministic_norm = ||A[:,s] + B T[:,s] + C T[:,s] T[s][:,s]||_F
+ *   stochastic_norm    = ||B R + C T[:,s] R[s] + D||_F
+ *   state_mask : [n] int32 (non-zero = state), shared by all draws;  outputs: [batch] each.  n <= 56.
+ */
+int dsge_policy_norms_batched(const double* A, const double* B, const double* C, const double* D,
+                              const double* T, const double* R, const int32_t* state_mask, int batch, int n,
+                              int k, double* det_norm_out, double* stoch_norm_out, void* stream);
+int dsge_policy_norms_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                   const double* T, const double* R, const int32_t* state_mask, int batch,
+                                   int n, int k, double* det_norm_out, double* stoch_norm_out);
+
+/*
  * Backward-looking direct solve.  Replaces solve_policy_function_with_backward_direct
  * (gEconpy/solvers/backward_looking.py:102-134): T = (-B)^-1 A, R = -B^-1 D.
  */

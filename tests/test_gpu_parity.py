@@ -395,3 +395,27 @@ def test_gensys_capacity_flag():
     b = wl.sw_shaped_batch(2)
     out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5)
     assert np.all(out["status"] & _lib.ST_GENSYS_TOO_BIG) and np.all(out["eu"][:, 0] == -3) and np.all(out["T"] == 0)
+
+
+@pytest.mark.parametrize("n,k", [(9, 2), (24, 4), (40, 7)])
+def test_policy_norms(n, k):
+    """deterministic_norm / stochastic_norm diagnostics (gEconpy/model/statespace.py:1181-1204)."""
+    nb = 5
+    ns = max(1, n // 2)
+    sysm = [wl.sw_shaped_system(300 + i, n=n, n_state=ns, n_lead=max(1, n // 3), k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s[j] for s in sysm]) for j in range(5))
+    rng = np.random.default_rng(n)
+    T = Tst + 1e-3 * rng.standard_normal(Tst.shape)  # a perturbed policy so that the norms are not ~0
+    R = np.stack([oracle.compute_selection_matrix(B[i], C[i], D[i], Tst[i]) for i in range(nb)])
+    mask = np.zeros(n, dtype=bool)
+    mask[:ns] = True
+    mask[rng.integers(ns, n)] = True
+    det, sto = batched.policy_norms_batched(A, B, C, D, T, R, mask)
+    for i in range(nb):
+        P = T[i][mask][:, mask]
+        Q = R[i][mask]
+        Rp = T[i][:, mask]
+        det_ref = np.linalg.norm(A[i][:, mask] + B[i] @ Rp + C[i] @ Rp @ P)
+        sto_ref = np.linalg.norm(B[i] @ R[i] + C[i] @ Rp @ Q + D[i])
+        assert_allclose(det[i], det_ref, rtol=1e-10)
+        assert_allclose(sto[i], sto_ref, rtol=1e-10, atol=1e-13)
