@@ -84,6 +84,8 @@ int arena_reserve(Arena* arenas, size_t bytes, void** out) {
   return DSGE_SUCCESS;
 }
 
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Carver {
@@ -194,19 +196,40 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
   int rc = DSGE_ERR_INVALID;
   // Fast path: selector Z, p <= 8, compact state block of at most s_cap columns.  Draws that
   // violate a hint come back flagged and are re-run by the general kernel below.
-  const bool fast = z_selector_hint && p <= 8;
+  // Fast path (p <= 8): compact state block of at most s_cap columns; selector Z (gathers) or dense
+  // Z (one extra product per step).  Draws that violate a hint come back flagged and are re-run by
+  // the general kernel below.
+  const bool fast = p <= 8;
+  bool launched_fast = false;
   if (fast) {
     DISPATCH_BS(bs, 8, {
       constexpr int NP = 8 * BS;
       int s_cap = (n_state_hint > 0 && n_state_hint < NP) ? ((n_state_hint + BS - 1) / BS) * BS : NP;
       if (s_cap > NP) s_cap = NP;
-      const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap);
-      rc = set_lds(dsge::kalman_sel_kernel<BS>, lds);
-      if (rc == DSGE_SUCCESS) {
-        hipLaunchKernelGGL(dsge::kalman_sel_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
-                           d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter, missing_fill, logp,
-                           status, g_kalman_dbg);
-        HIP_TRY(hipGetLastError());
+      if (z_selector_hint) {
+        const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
+        rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
+        if (rc == DSGE_SUCCESS) {
+          hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, P0, Z,
+                             z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
+                             missing_fill, logp, status, g_kalman_dbg);
+          HIP_TRY(hipGetLastError());
+          launched_fast = true;
+        }
+      } else {
+        const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, true);
+        if (lds > LDS_LIMIT) {
+          rc = DSGE_SUCCESS;  // does not fit: the general kernel handles everything
+        } else {
+          rc = set_lds(dsge::kalman_sel_kernel<BS, false>, lds);
+          if (rc == DSGE_SUCCESS) {
+            hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, P0, Z,
+                               z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
+                               missing_fill, logp, status, g_kalman_dbg);
+            HIP_TRY(hipGetLastError());
+            launched_fast = true;
+          }
+        }
       }
     });
     if (rc) return rc;
@@ -218,14 +241,12 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
                          d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status,
-                         fast ? 1 : 0);
+                         launched_fast ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
   });
   return rc;
 }
-
-constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // choose the on-chip pencil capacity (n_cap = n + l_cap) for gensys
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {

@@ -38,10 +38,11 @@ struct Kf2Smem {
   static constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD;
   // doubles: PZt/K/V NP*8 each, Fi 64, Tc NP*LDM, Pc s_cap*LDM, Wc s_cap*LDM, av NP, af NP,
   // vv/dd/hh/zv 8 each, trash 64; ints: perm NP, zpos 8
-  __host__ __device__ static constexpr size_t doubles(int s_cap) {
-    return 3 * (size_t)NP * 10 + 64 + (size_t)NP * LDM + 2 * (size_t)s_cap * LDM + 2 * NP + 32 + 64 + NP / 2 + 4;
+  __host__ __device__ static constexpr size_t doubles(int s_cap, bool dense_z = false) {
+    return 3 * (size_t)NP * 10 + 64 + (size_t)NP * LDM + 2 * (size_t)s_cap * LDM + 2 * NP + 32 + 64 + NP / 2 + 4 +
+           (dense_z ? (size_t)NP * LDM + 8 * (size_t)LDM : 0);  // dense Z: full P and Z (8 x LDM) in LDS
   }
-  static size_t bytes(int s_cap) { return sizeof(double) * doubles(s_cap); }
+  static size_t bytes(int s_cap, bool dense_z = false) { return sizeof(double) * doubles(s_cap, dense_z); }
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
@@ -90,7 +91,9 @@ __device__ __forceinline__ void mm_acc_p(double (&acc)[BS][BS], const double* A,
 #undef MM_FMA
 }
 
-template <int BS>
+// SEL = true : selector design matrix (P Z' and F are gathers)
+// SEL = false: dense Z (p <= 8): P Z' is a register-block product against the full P kept in LDS
+template <int BS, bool SEL>
 __global__ __launch_bounds__(64) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
@@ -116,6 +119,8 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
   double* trash = zv + 8;            // 64: sink for the stores of lanes that own no observed column
   int* perm = (int*)(trash + 64);    // NP: position -> original state index (states first)
   int* zpos = perm + NP;             // 8: position of the state each observation selects
+  double* Pf = (double*)(zpos + 8);  // dense Z only: NP x LDM full P (operand of P Z')
+  double* Zs = Pf + NP * LDM;        // dense Z only: 8 x LDM design matrix in the states-first ordering
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   const int fo = lane >> 3, fq = lane & 7;  // owner of F[fo][fq]
   const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     }
     const size_t off = (size_t)draw * m * m;
     wave_sync();
-    for (int idx = lane; idx < (int)Kf2Smem<BS>::doubles(s_cap); idx += 64) smem[idx] = 0.0;
+    for (int idx = lane; idx < (int)Kf2Smem<BS>::doubles(s_cap, !SEL); idx += 64) smem[idx] = 0.0;
 
     // ---- structure of T: non-zero columns S ------------------------------------------------
     double Pb[BS][BS];
@@ -159,12 +164,16 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     }
     for (int o = 0; o < p; ++o) {
       const double zl = (lane < m) ? Zg[(size_t)o * m + lane] : 0.0;
-      const unsigned long long b = __ballot(zl != 0.0);
-      if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
-      used |= b;
-      if (zl != 0.0) {  // the single owner lane of this observation
-        zpos[o] = my_pos;
-        zv[o] = zl;
+      if (SEL) {
+        const unsigned long long b = __ballot(zl != 0.0);
+        if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
+        used |= b;
+        if (zl != 0.0) {  // the single owner lane of this observation
+          zpos[o] = my_pos;
+          zv[o] = zl;
+        }
+      } else if (lane < m) {
+        Zs[o * LDM + my_pos] = zl;  // design matrix in the states-first ordering
       }
     }
     if (!ok) {
@@ -210,13 +219,30 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
 #pragma unroll
     for (int j = 0; j < BS; ++j) pz_dst[j] = ocol[j];
     const bool in_state_block = (lr * BS < s) && (lc * BS < s);
-#pragma unroll
-    for (int j = 0; j < BS; ++j)
-#pragma unroll
-      for (int i = 0; i < BS; ++i) {
-        double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * PS + pz_dst[j]] : &trash[lane];
-        *dst = zcol[j] * Pb[i][j];
-      }
+    // P Z' for the coming step: a column gather (selector) or a product against the full P (dense Z)
+#define STORE_PZT()                                                                                   \
+  do {                                                                                                \
+    if (SEL) {                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < BS; ++j) _Pragma("unroll") for (int i = 0; i < BS; ++i) { \
+        double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * PS + pz_dst[j]] : &trash[lane];          \
+        *dst = zcol[j] * Pb[i][j];                                                                    \
+      }                                                                                               \
+    } else {                                                                                          \
+      blk_store_lds<BS>(Pb, Pf, LDM, lr, lc);                                                         \
+      wave_sync();                                                                                    \
+      if (lc < p) {                                                                                   \
+        double pacc[BS];                                                                              \
+        _Pragma("unroll") for (int i = 0; i < BS; ++i) pacc[i] = 0.0;                                 \
+        for (int jj = 0; jj < m; ++jj) {                                                              \
+          const double zz = Zs[lc * LDM + jj];                                                        \
+          _Pragma("unroll") for (int i = 0; i < BS; ++i)                                              \
+              pacc[i] = fma(Pf[(lr * BS + i) * LDM + jj], zz, pacc[i]);                               \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < BS; ++i) PZt[(lr * BS + i) * PS + lc] = pacc[i];        \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
+    STORE_PZT();
     const int my_zpos = (fo < p) ? zpos[fo] : 0;
     const double my_zv = (fo < p) ? zv[fo] : 0.0;
     const int v_zpos = (lane < p) ? zpos[lane] : 0;
@@ -239,13 +265,33 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
       // ---- (b) F[fo][fq] and the innovation -------------------------------------------
       double f;
       if (fo < p && fq < p) {
-        f = wo * wq * my_zv * PZt[my_zpos * PS + fq];
+        if (SEL) {
+          f = wo * wq * my_zv * PZt[my_zpos * PS + fq];
+        } else {
+          double fa = 0.0, fb = 0.0;  // F = Z (P Z'): two chains over the state index
+          int jj = 0;
+          for (; jj + 1 < m; jj += 2) {
+            fa = fma(Zs[fo * LDM + jj], PZt[jj * PS + fq], fa);
+            fb = fma(Zs[fo * LDM + jj + 1], PZt[(jj + 1) * PS + fq], fb);
+          }
+          if (jj < m) fa = fma(Zs[fo * LDM + jj], PZt[jj * PS + fq], fa);
+          f = wo * wq * (fa + fb);
+        }
         if (fo == fq) f += wo * hh[fo] + jitter;
       } else {
         f = (fo == fq) ? 1.0 : 0.0;
       }
       double v_own = 0.0;
-      if (lane < p) v_own = (obs ? yt : 0.0) - (v_dd + (obs ? 1.0 : 0.0) * v_zv * av[v_zpos]);
+      if (lane < p) {
+        double za;
+        if (SEL) {
+          za = v_zv * av[v_zpos];
+        } else {
+          za = 0.0;
+          for (int jj = 0; jj < m; ++jj) za = fma(Zs[lane * LDM + jj], av[jj], za);
+        }
+        v_own = (obs ? yt : 0.0) - (v_dd + (obs ? 1.0 : 0.0) * za);
+      }
       if (lane < 8) vv[lane] = v_own;
       // ---- (c) Finv by in-register Gauss-Jordan (SPD: no pivoting) ----------------------
       double step_mant = 1.0;
@@ -406,14 +452,8 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
             Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
           }
       }
-      // ---- P Z' for the next step (branch-free: unobserved columns go to the sink) -----------
-#pragma unroll
-      for (int j = 0; j < BS; ++j)
-#pragma unroll
-        for (int i = 0; i < BS; ++i) {
-          double* dst = (pz_dst[j] >= 0) ? &PZt[(lr * BS + i) * PS + pz_dst[j]] : &trash[lane];
-          *dst = zcol[j] * Pb[i][j];
-        }
+      // ---- P Z' for the next step -------------------------------------------------------------
+      STORE_PZT();
       wave_sync();  // #5
       if (dbg) {
         const long long tk1 = clock64();
@@ -421,6 +461,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         tk0 = tk1;
       }
     }
+#undef STORE_PZT
     if (dbg && draw == 0 && lane == 0)
       for (int k = 0; k < 5; ++k) dbg[k] = ph[k];
     if (lane == 0) {

@@ -281,7 +281,10 @@ def test_kalman_wrong_hints_are_harmless():
     lied, st = batched.kalman_logp_batched(Tg, Rg, qg, Zg, yg, d=dg, Hdiag=Hg, q_mode="diag_batched", z_selector_hint=1)
     honest, _ = batched.kalman_logp_batched(Tg, Rg, qg, Zg, yg, d=dg, Hdiag=Hg, q_mode="diag_batched")
     assert np.all(st == 0)
-    assert np.array_equal(lied, honest)
+    assert_allclose(lied, honest, rtol=1e-11)  # general kernel (re-run) vs dense-Z fast path: same filter
+    for i in range(nb):
+        ref = oracle.kalman_filter_logp(yg, Tg[i], Rg[i], np.diag(qg[i]), Zg, H=np.diag(Hg), d=dg)
+        assert_allclose(lied[i], ref, rtol=LOGP_RTOL)
     # mixed batch: one draw with a dense T among compact ones
     T2 = T.copy()
     T2[2] = 0.1 * np.random.default_rng(0).standard_normal((m, m))
@@ -419,3 +422,20 @@ def test_policy_norms(n, k):
         sto_ref = np.linalg.norm(B[i] @ R[i] + C[i] @ Rp @ Q + D[i])
         assert_allclose(det[i], det_ref, rtol=1e-10)
         assert_allclose(sto[i], sto_ref, rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("m,k,p,ns", [(12, 2, 3, 5), (24, 4, 4, 9), (40, 7, 7, 18), (40, 7, 8, 40), (64, 6, 5, 23)])
+def test_kalman_dense_z_fast_path(m, k, p, ns):
+    """Dense design matrix (observation equations, statespace.py:297-332) on the compact-state fast path."""
+    nb, T_len = 6, 30
+    T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=100 + m + p, selector=False)
+    logp, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+    assert np.all(st == 0)
+    Zb = np.stack([Z * (1.0 + 0.1 * i) for i in range(nb)])  # per-draw design matrices
+    logp_b, st_b = batched.kalman_logp_batched(T, R, q, Zb, y, d=d, Hdiag=H, q_mode="diag_batched")
+    assert np.all(st_b == 0)
+    for i in range(nb):
+        ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
+        assert_allclose(logp[i], ref, rtol=LOGP_RTOL)
+        ref_b = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Zb[i], H=np.diag(H), d=d)
+        assert_allclose(logp_b[i], ref_b, rtol=LOGP_RTOL)
