@@ -199,6 +199,16 @@ def main():
     torch.cuda.synchronize()
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2 +
+        # WRITE_SIZE, profiles/r1_final/pmc_traffic.json); only valid for the default workload/batch
+        kalman_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_final", "pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if per_gpu == 4096 and hints[1]:
+                kalman_traffic = round(pmc["kernels"]["kalman_sel_kernel<5,true>"]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         flops = algorithmic_flops(n, k, p, T_len)
         kal_s = kms["kalman"] * 1e-3
         achieved = flops["kalman"] * nloc / kal_s / 1e12
@@ -228,7 +238,7 @@ def main():
                 "parallelism": f"draw-sharded x{world}, all_gather(logp,status)" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "dsge::kalman_sel_kernel<5>" if hints[1] else "dsge::kalman_kernel<5>",
+                "kernel": "dsge::kalman_sel_kernel<5,true>" if hints[1] else "dsge::kalman_sel_kernel<5,false>",
                 "structure_hints": {"n_state": hints[0], "z_selector": hints[1]},
                 "bound": "mfma",
                 "pipe": "fp64 VALU FMA (same peak rate as v_mfma_f64 on gfx950)",
@@ -236,7 +246,7 @@ def main():
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP64_PEAK_TFLOPS, 5),
-                "traffic": None,
+                "traffic": kalman_traffic,
                 "algorithmic_flops_per_eval": flops["kalman"],
                 "executed_tflops": round(exec_tf, 4),
                 "executed_frac": round(exec_tf / FP64_PEAK_TFLOPS, 5),
