@@ -439,3 +439,106 @@ def test_kalman_dense_z_fast_path(m, k, p, ns):
         assert_allclose(logp[i], ref, rtol=LOGP_RTOL)
         ref_b = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Zb[i], H=np.diag(H), d=d)
         assert_allclose(logp_b[i], ref_b, rtol=LOGP_RTOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases (empty / degenerate / maximum sizes), the way the reference's tests probe its boundaries
+# ------------------------------------------------------------------------------------------------
+def test_empty_batch_and_empty_series():
+    z3 = np.zeros((0, 5, 5))
+    T, status, n_iter = batched.cycle_reduction_batched(z3, z3, z3)
+    assert T.shape == (0, 5, 5) and status.shape == (0,)
+    out = batched.gensys_batched(z3, z3, z3, np.zeros((0, 5, 1)))
+    assert out["T"].shape == (0, 5, 5)
+    # T_len = 0: the log-likelihood of no data is 0
+    b = wl.sw_shaped_batch(2)
+    om = wl.sw_shaped_observation_model()
+    r = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], np.zeros((0, 7)),
+                                          Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+    assert np.all(r["logp"] == 0.0) and np.all(r["status"] == 0)
+
+
+def test_scalar_model_n1():
+    # a y_{t-1} + b y_t + c E y_{t+1} + d e = 0  ->  c T^2 + b T + a = 0, stable root
+    a, bb, c, dd = -0.5, 1.0, -0.2, -1.0
+    A, B, C, D = (np.full((3, 1, 1), v) for v in (a, bb, c, dd))
+    root = (-bb + np.sqrt(bb * bb - 4 * a * c)) / (2 * c)
+    root2 = (-bb - np.sqrt(bb * bb - 4 * a * c)) / (2 * c)
+    stable = root if abs(root) < 1 else root2
+    T, status, _ = batched.cycle_reduction_batched(A, B, C, max_iter=200, tol=1e-12)
+    assert np.all(status == 0)
+    assert_allclose(T[:, 0, 0], stable, atol=1e-12)
+    g = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    assert np.all(g["success"])
+    assert_allclose(g["T"][:, 0, 0], stable, atol=1e-12)
+    y = np.random.default_rng(0).standard_normal((12, 1))
+    out = batched.solve_kalman_logp_batched(A, B, C, D, np.array([0.3]), np.ones((1, 1)), y, Hdiag=np.array([0.1]),
+                                            tol=1e-12, max_iter=200, return_policy=True)
+    ref = oracle.solve_kalman_logp(A[0], B[0], C[0], D[0], np.array([[0.3]]), np.ones((1, 1)), y, H=np.array([[0.1]]),
+                                   tol=1e-12, max_iter=200)
+    assert_allclose(out["logp"], ref["logp"], rtol=LOGP_RTOL)
+
+
+def test_all_missing_and_missing_column():
+    b = wl.sw_shaped_batch(3)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y_all = np.full((20, 7), np.nan)
+    r = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y_all, Hdiag=om["Hdiag"], tol=1e-8,
+                                          max_iter=1000)
+    assert np.all(r["logp"] == 0.0)  # every step fully missing -> every ll_t = 0
+    y_col = om["y"][:40].copy()
+    y_col[:, 3] = oracle.MISSING_FILL  # one series never observed
+    r = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y_col, Hdiag=om["Hdiag"], tol=1e-8,
+                                          max_iter=1000)
+    for i in range(3):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], y_col,
+                                       H=np.diag(om["Hdiag"]))
+        assert_allclose(r["logp"][i], ref["logp"], rtol=LOGP_RTOL)
+
+
+def test_explosive_transition_is_flagged():
+    """rho(T) > 1: the stationary covariance does not exist; the draw must be flagged, not crash/hang."""
+    rng = np.random.default_rng(1)
+    m, k, p = 10, 2, 2
+    T = rng.standard_normal((2, m, m))
+    T[0] *= 0.6 / np.max(np.abs(np.linalg.eigvals(T[0])))
+    T[1] *= 1.3 / np.max(np.abs(np.linalg.eigvals(T[1])))
+    R = rng.standard_normal((2, m, k))
+    Z = np.zeros((p, m))
+    Z[0, 0] = Z[1, 3] = 1.0
+    y = rng.standard_normal((15, p))
+    logp, st = batched.kalman_logp_batched(T, R, np.ones(k), Z, y, Hdiag=np.full(p, 0.1))
+    assert st[0] == 0 and np.isfinite(logp[0])
+    assert st[1] & _lib.ST_LYAP_FAIL and logp[1] == -np.inf
+
+
+def test_full_size_batches_properties():
+    """BASELINE sizes: 4096 SW-shaped draws (configs[2]) and 65536 RBC draws -- checked through
+    size-independent properties (a sample against the oracle, status all-clear, repeatability)."""
+    nb = 4096
+    base = wl.sw_shaped_batch(64)
+    rep = nb // 64
+    A, B, C, D = (np.tile(base[x], (rep, 1, 1)) for x in "ABCD")
+    q = np.tile(base["sigma"] ** 2, (rep, 1))
+    om = wl.sw_shaped_observation_model()
+    r = batched.solve_kalman_logp_batched(A, B, C, D, q, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+    assert np.all(r["status"] == 0)
+    assert np.array_equal(r["logp"][:64], r["logp"][-64:])  # same draw, same bits, wherever it sits
+    for i in (0, 17, 63):
+        ref = oracle.solve_kalman_logp(base["A"][i], base["B"][i], base["C"][i], base["D"][i], np.diag(q[i]), om["Z"],
+                                       om["y"], H=np.diag(om["Hdiag"]))
+        assert_allclose(r["logp"][i], ref["logp"], rtol=LOGP_RTOL)
+    # RBC, 65536 draws (the multi-GPU config's total, on one device)
+    nb = 65536
+    th = wl.rbc_prior_draws(nb, seed=2)
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    Z = np.zeros((1, 8))
+    Z[0, 7] = 1.0
+    y = np.random.default_rng(0).normal(0, 0.05, (200, 1))
+    r = batched.solve_kalman_logp_batched(A, B, C, D, (th["sigma_A"] ** 2)[:, None], Z, y, tol=1e-8, max_iter=1000,
+                                          q_mode="diag_batched")
+    assert np.all(r["status"] == 0) and np.all(np.isfinite(r["logp"]))
+    for i in (0, 12345, 65535):
+        ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.array([[th["sigma_A"][i] ** 2]]), Z, y)
+        assert_allclose(r["logp"][i], ref["logp"], rtol=LOGP_RTOL)
