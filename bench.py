@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--max-iter", type=int, default=1000)
+    ap.add_argument("--workload", default="sw_shaped", choices=["sw_shaped", "rbc"])
     ap.add_argument("--solver", default="cycle_reduction", choices=["cycle_reduction", "gensys"])
     ap.add_argument("--no-hints", action="store_true", help="disable the structure hints (general kernels only)")
     args = ap.parse_args()
@@ -113,13 +114,17 @@ def main():
     # CPU baseline first (rank 0, N = 1 only), in spawned workers, before this process touches the GPU
     from geconpy_amd import workloads as wl
 
-    sh = wl.SW_SHAPE
-    n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
     per_gpu = args.batch_per_gpu
     global_batch = per_gpu * world
     lo, hi = wl.shard_bounds(global_batch, world, rank)
-    om = wl.sw_shaped_observation_model()
-    shard = wl.sw_shaped_batch(hi - lo, first_draw=lo)
+    if args.workload == "rbc":  # BASELINE configs[1] (informational; the metric is quoted on sw_shaped)
+        n, k, p, T_len = 8, 1, 1, 200
+        shard, om = wl.rbc_batch(hi - lo, first_draw=lo)
+    else:
+        sh = wl.SW_SHAPE
+        n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
+        om = wl.sw_shaped_observation_model()
+        shard = wl.sw_shaped_batch(hi - lo, first_draw=lo)
 
     cpu = None
     cpu_logp = None
@@ -205,7 +210,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r1_final", "pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            if per_gpu == 4096 and hints[1]:
+            if per_gpu == 4096 and hints[1] and args.workload == "sw_shaped":
                 kalman_traffic = round(pmc["kernels"]["kalman_sel_kernel<5,true>"]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
@@ -230,15 +235,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"sw_shaped synthetic (SURVEY 8d): n=m={n}, n_state=18, n_lead=12, k={k}, p={p}, "
-                            f"T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[2])",
+                "workload": (f"sw_shaped synthetic (SURVEY 8d): n=m={n}, n_state=18, n_lead=12, k={k}, p={p}, "
+                             f"T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[2])") if args.workload == "sw_shaped"
+                else f"rbc_linearized closed form: n={n}, k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[1])",
                 "global_batch": global_batch,
                 "solver": args.solver,
                 "tol": args.tol,
                 "parallelism": f"draw-sharded x{world}, all_gather(logp,status)" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "dsge::kalman_sel_kernel<5,true>" if hints[1] else "dsge::kalman_sel_kernel<5,false>",
+                "kernel": f"dsge::kalman_sel_kernel<{(n + 7) // 8},{'true' if hints[1] else 'false'}>",
                 "structure_hints": {"n_state": hints[0], "z_selector": hints[1]},
                 "bound": "mfma",
                 "pipe": "fp64 VALU FMA (same peak rate as v_mfma_f64 on gfx950)",

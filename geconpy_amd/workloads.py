@@ -184,3 +184,16 @@ def shard_bounds(batch, world_size, rank):
     lo = rank * per
     hi = batch if rank == world_size - 1 else lo + per
     return lo, hi
+
+
+def rbc_batch(batch, first_draw=0, seed=1, T_len=200):
+    """BASELINE.json configs[1]: the RBC model at ``batch`` seeded prior draws (closed-form Jacobians),
+    observed series Y, T_len periods of data default_rng(0).normal(0, 0.05).  Same dict layout as
+    ``sw_shaped_batch`` + observation model; draw i is the same system whichever shard asks for it."""
+    th = rbc_prior_draws(first_draw + batch, seed=seed)
+    th = {k_: v[first_draw:] for k_, v in th.items()}
+    A, B, C, D = rbc_linearized_jacobians(**th)
+    Z = np.zeros((1, 8))
+    Z[0, RBC_VARIABLES.index("Y")] = 1.0
+    y = np.random.default_rng(0).normal(0, 0.05, (T_len, 1))
+    return dict(A=A, B=B, C=C, D=D, sigma=th["sigma_A"][:, None]), dict(Z=Z, Hdiag=np.zeros(1), y=y)
