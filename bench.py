@@ -271,7 +271,9 @@ def main():
             out["cpu_baseline"] = cpu
             ns = len(cpu_logp)
             rel = np.abs(logp_host[:ns] - cpu_logp) / np.abs(cpu_logp)
-            out["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel.max()), "n_checked": ns}
+            out["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel.max()),
+                             "median_rel_logp_err_vs_cpu_oracle": float(np.median(rel)),
+                             "n_above_1e-12": int((rel > 1e-12).sum()), "n_checked": ns}
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
