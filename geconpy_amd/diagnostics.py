@@ -1,0 +1,87 @@
+"""Batched counterpart of the per-draw pipeline behind ``solvability_check``
+(gEconpy/model/statistics/perturbation_diagnostics.py:105-161, :362-490).
+
+The reference loops over draws (serially or in a fork pool whose ``imap_unordered`` scrambles the
+order, :484-489); per draw it solves the steady state and linearises on the host, then
+``_solve_perturbation`` -> Blanchard-Kahn check -> gEcon residual norms.  Here the part after the
+linearisation runs for ALL draws in three launches and the result arrays are in input order.
+
+The steady-state / linearisation stages stay with the caller: pass a boolean ``upstream_failed``
+(or ``None``) to have those draws labelled ``"steady_state"`` as the reference would.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import batched
+
+
+def _gecon_partition(T, R, tol):
+    """statespace_to_gEcon_representation (gEconpy/model/perturbation.py:322-382): state variables =
+    columns of T with an entry >= tol; entries below tol are flushed to zero."""
+    PP = np.where(np.abs(T) < tol, 0.0, T)
+    QQ = np.where(np.abs(R) < tol, 0.0, R)
+    mask = np.abs(T).max(axis=1) >= tol  # (batch, n): column-wise max over rows
+    return PP, QQ, mask
+
+
+def solvability_check_batched(A, B, C, D, solver="cycle_reduction", tol=1e-8, max_iter=1000, norm_tol=1e-8,
+                              backward_looking=False, upstream_failed=None):
+    """Returns dict(failure_step (object array: None or the name of the failing stage),
+    norm_deterministic, norm_stochastic, T, R) for a batch of linearised systems.
+
+    Stages and labels as in ``_check_one_draw`` (:105-161): "perturbation" (solver failure),
+    "blanchard-kahn" (root count: taken from the gensys existence/uniqueness codes, eu[0] = 0 too many
+    unstable roots, eu[1] = 0 too few), "deterministic_norm", "stochastic_norm"; norms are NaN where not
+    reached.
+    """
+    A, B, C = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, B, C))
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    nb, n, _ = A.shape
+    failure = np.full(nb, None, dtype=object)
+    det = np.full(nb, np.nan)
+    sto = np.full(nb, np.nan)
+    if upstream_failed is not None:
+        failure[np.asarray(upstream_failed, dtype=bool)] = "steady_state"
+
+    eff = "backward_direct" if backward_looking else solver
+    if eff == "cycle_reduction":
+        T, status, _ = batched.cycle_reduction_batched(A, B, C, max_iter=max_iter, tol=tol)
+        ok = status == 0
+        R = batched.selection_batched(B, C, D, T)
+    elif eff == "gensys":
+        g = batched.gensys_batched(A, B, C, D, tol=tol)
+        T, R, ok = g["T"], g["R"], g["success"]
+    elif eff == "backward_direct":
+        T, R = batched.backward_direct_batched(A, B, D)
+        ok = np.isfinite(T).all(axis=(1, 2))
+    else:
+        raise ValueError(f"Unknown solver {solver!r}")
+    reached = failure == None  # noqa: E711
+    failure[reached & ~ok] = "perturbation"
+
+    # Blanchard-Kahn: root counting by the device QZ (skipped when gensys already decided it)
+    reached = failure == None  # noqa: E711
+    if eff == "cycle_reduction" and reached.any():
+        eu = batched.gensys_batched(A, B, C, None, tol=tol)["eu"]
+        bk_ok = (eu[:, 0] == 1) & (eu[:, 1] == 1)
+        failure[reached & ~bk_ok] = "blanchard-kahn"
+
+    reached = failure == None  # noqa: E711
+    if reached.any():
+        PP, QQ, mask = _gecon_partition(T, R, tol)
+        # draws that share a state mask go through one launch (the mask is structural: normally one group)
+        keys = {}
+        for i in np.flatnonzero(reached):
+            keys.setdefault(mask[i].tobytes(), []).append(i)
+        for key, idx in keys.items():
+            idx = np.asarray(idx)
+            m = np.frombuffer(key, dtype=bool)
+            d_, s_ = batched.policy_norms_batched(A[idx], B[idx], C[idx], D[idx], PP[idx], QQ[idx], m)
+            det[idx] = d_
+            sto[idx] = s_
+        bad_det = reached & ~(det <= norm_tol)
+        failure[bad_det] = "deterministic_norm"
+        bad_sto = reached & ~bad_det & ~(sto <= norm_tol)
+        failure[bad_sto] = "stochastic_norm"
+    return dict(failure_step=failure, norm_deterministic=det, norm_stochastic=sto, T=T, R=R)

@@ -542,3 +542,35 @@ def test_full_size_batches_properties():
     for i in (0, 12345, 65535):
         ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.array([[th["sigma_A"][i] ** 2]]), Z, y)
         assert_allclose(r["logp"][i], ref["logp"], rtol=LOGP_RTOL)
+
+
+def test_solvability_check_batched(failure_golden):
+    """The draw-batch driver (perturbation_diagnostics.py:105-161): labels and norms, in input order."""
+    from geconpy_amd.diagnostics import solvability_check_batched
+
+    g = failure_golden
+    names = ["ok", "nonunique", "noexist", "coincident"]
+    A, B, C, D = _stack(g, names)
+    good = wl.sw_shaped_batch(3)
+    A = np.concatenate([good["A"], A]); B = np.concatenate([good["B"], B])
+    C = np.concatenate([good["C"], C]); D = np.concatenate([good["D"], D])
+    for solver in ("cycle_reduction", "gensys"):
+        out = solvability_check_batched(A, B, C, D, solver=solver, tol=1e-8)
+        assert list(out["failure_step"][:4]) == [None] * 4
+        assert all(f == "perturbation" for f in out["failure_step"][4:])
+        assert np.all(out["norm_deterministic"][:4] < 1e-8) and np.all(out["norm_stochastic"][:4] < 1e-8)
+        assert np.all(np.isnan(out["norm_deterministic"][4:]))
+        # the reference's own formulas on the reference's partition
+        for i in range(4):
+            T, R = out["T"][i], out["R"][i]
+            mask = np.abs(T).max(axis=0) >= 1e-8
+            PP = np.where(np.abs(T) < 1e-8, 0, T); QQ = np.where(np.abs(R) < 1e-8, 0, R)
+            det_ref = np.linalg.norm(A[i][:, mask] + B[i] @ PP[:, mask] + C[i] @ PP[:, mask] @ PP[mask][:, mask])
+            sto_ref = np.linalg.norm(B[i] @ QQ + C[i] @ PP[:, mask] @ QQ[mask] + D[i])
+            assert_allclose(out["norm_deterministic"][i], det_ref, atol=1e-13)
+            assert_allclose(out["norm_stochastic"][i], sto_ref, atol=1e-13)
+    # a wrong policy is caught by the norm gate
+    out = solvability_check_batched(A[:2], B[:2], C[:2], D[:2], norm_tol=1e-30)
+    assert all(f in ("deterministic_norm", "stochastic_norm") for f in out["failure_step"])
+    up = solvability_check_batched(A[:2], B[:2], C[:2], D[:2], upstream_failed=[True, False])
+    assert up["failure_step"][0] == "steady_state" and up["failure_step"][1] is None
