@@ -58,6 +58,8 @@ PROTOTYPES = {
     "dsge_debug_gensys_phases": [_dp, _dp, _dp, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_selection_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
     "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
+    "dsge_policy_adjoints_batched": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp, _dp],
+    "dsge_policy_adjoints_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp],
     "dsge_policy_norms_batched": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
     "dsge_policy_norms_batched_host": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_backward_direct_batched": [_dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],

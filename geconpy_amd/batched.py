@@ -103,6 +103,19 @@ def selection_batched(B, C, D, T, A=None):
     return (R, resid) if A is not None else R
 
 
+def policy_adjoints_batched(B, C, T, T_bar):
+    """``(A_bar, B_bar, C_bar, status)``: the reverse-mode sensitivities of
+    ``o1_policy_function_adjoints`` (gEconpy/solvers/shared.py:12-71) for a batch of draws."""
+    B, C, T = _check_abc(B, C, T)
+    T_bar = _f64(T_bar, 3)
+    nb, n, _ = B.shape
+    Ab, Bb, Cb = np.empty_like(B), np.empty_like(B), np.empty_like(B)
+    status = np.empty(nb, dtype=np.int32)
+    _lib.check(_lib.load().dsge_policy_adjoints_batched_host(_ptr(B), _ptr(C), _ptr(T), _ptr(T_bar), nb, n, _ptr(Ab),
+                                                             _ptr(Bb), _ptr(Cb), _ptr(status)))
+    return Ab, Bb, Cb, status
+
+
 def policy_norms_batched(A, B, C, D, T, R, state_mask):
     """``deterministic_norm`` and ``stochastic_norm`` of gEconpy/model/statespace.py:1181-1204 for a
     batch of draws; ``state_mask`` is the boolean vector ``tm1_idx & t_idx`` (:1186-1193)."""

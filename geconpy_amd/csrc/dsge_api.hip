@@ -171,6 +171,21 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
   return rc;
 }
 
+int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 6, {
+    rc = set_lds(dsge::adjoint_kernel<BS>, dsge::AdjSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::adjoint_kernel<BS>, dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
+                         batch, n, Ab, Bb, Cb, status);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
 int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
                  const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st) {
   const int bs = tile_bs(n);
@@ -368,6 +383,16 @@ int dsge_selection_batched(const double* A, const double* B, const double* C, co
   if (batch == 0) return DSGE_SUCCESS;
   return launch_assemble(A, B, C, D, T, nullptr, nullptr, 0, batch, n, k, R_out, resid_out, nullptr, nullptr, nullptr,
                          1, 0, (hipStream_t)stream);
+}
+
+int dsge_policy_adjoints_batched(const double* B, const double* C, const double* T, const double* T_bar, int batch,
+                                 int n, double* A_bar, double* B_bar, double* C_bar, int32_t* status, void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_adjoint(B, C, T, T_bar, batch, n, A_bar, B_bar, C_bar, status, (hipStream_t)stream);
 }
 
 int dsge_policy_norms_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
@@ -673,6 +698,34 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
   if ((rc = dsge_selection_batched(dA, dB, dC, dD, dT, batch, n, k, dR, dRes, nullptr))) return rc;
   DOWN(R_out, dR, nk, double);
   DOWN(resid_out, dRes, batch, double);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_policy_adjoints_batched_host(const double* B, const double* C, const double* T, const double* T_bar,
+                                      int batch, int n, double* A_bar, double* B_bar, double* C_bar, int32_t* status) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 7 * align256(nn * 8) + align256((size_t)batch * 4) + 4096, &base))) return rc;
+  Carver cv(base);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dT, T, nn, double);
+  UP(dTb, T_bar, nn, double);
+  OUTBUF(dAb, A_bar, nn, double);
+  OUTBUF(dBb, B_bar, nn, double);
+  OUTBUF(dCb, C_bar, nn, double);
+  OUTBUF(dS, status, batch, int32_t);
+  if ((rc = dsge_policy_adjoints_batched(dB, dC, dT, dTb, batch, n, dAb, dBb, dCb, dS, nullptr))) return rc;
+  DOWN(A_bar, dAb, nn, double);
+  DOWN(B_bar, dBb, nn, double);
+  DOWN(C_bar, dCb, nn, double);
+  DOWN(status, dS, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }

@@ -80,12 +80,35 @@ class HipCycleReduction(Op):
         outputs[0][0] = T[0]
 
     def pullback(self, inputs, outputs, cotangents):
-        # Reverse mode goes through the reference's own adjoint (shared.py:12-71); the device
-        # adjoint kernel is a "next" row.
-        from gEconpy.solvers.shared import o1_policy_function_adjoints  # noqa: PLC0415
+        # Same contract as _linear_policy_jvp (cycle_reduction.py:117-124): cotangents of (A, B, C)
+        # from the cotangent of T, computed on the device (doubling solve of the adjoint Stein
+        # equation) instead of the reference's n^2 x n^2 Kronecker solve (shared.py:53-71).
+        _A, B, C = inputs
+        return list(HipPolicyAdjoint()(B, C, outputs[0], cotangents[0]))
 
-        A, B, C = inputs
-        return o1_policy_function_adjoints(A, B, C, outputs[0], cotangents[0])
+
+class HipPolicyAdjoint(Op):
+    """``A_bar, B_bar, C_bar = Op(B, C, T, T_bar)`` -- ``o1_policy_function_adjoints``
+    (gEconpy/solvers/shared.py:12-71) for (n, n) or (batch, n, n) inputs."""
+
+    __props__ = ()
+    gufunc_signature = "(n,n),(n,n),(n,n),(n,n)->(n,n),(n,n),(n,n)"
+
+    def make_node(self, B, C, T, T_bar):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (B, C, T, T_bar)]
+        outputs = [pt.tensor(name, dtype="float64", shape=inputs[0].type.shape) for name in ("A_bar", "B_bar", "C_bar")]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        return [input_shapes[0]] * 3
+
+    def perform(self, node, inputs, outputs):
+        squeeze = np.ndim(inputs[0]) == 2
+        B, C, T, T_bar = (_as3(x) for x in inputs)
+        Ab, Bb, Cb, _status = batched.policy_adjoints_batched(B, C, T, T_bar)
+        for cell, val in zip(outputs, (Ab, Bb, Cb)):
+            cell[0] = val[0] if squeeze else val
 
 
 class HipCycleReductionBatched(Op):

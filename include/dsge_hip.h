@@ -134,6 +134,22 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
                                 double* resid_out);
 
 /*
+ * Adjoints of the policy function.  Replaces o1_policy_function_adjoints (gEconpy/solvers/shared.py:12-71),
+ * the pullback of GensysWrapper / CycleReductionWrapper (gensys.py:668-676, cycle_reduction.py:117-124):
+ * given the cotangent T_bar of T it returns A_bar = S, B_bar = S T', C_bar = S T' T' where S solves
+ *   (kron(T, C') + kron(I, T'C') + kron(I, B')) vec(S) = -vec(T_bar)   <=>   (B + C T)' S + C' S T' = -T_bar.
+ * The reference factorises the n^2 x n^2 Kronecker matrix; here the equivalent Stein equation is solved
+ * by a doubling iteration (valid for a determinate solution: rho(T) < 1 and stable-inverse roots).
+ *   B, C, T, T_bar, A_bar, B_bar, C_bar : [batch][n][n];  status : [batch] (non-zero = not converged)
+ */
+int dsge_policy_adjoints_batched(const double* B, const double* C, const double* T, const double* T_bar,
+                                 int batch, int n, double* A_bar, double* B_bar, double* C_bar,
+                                 int32_t* status, void* stream);
+int dsge_policy_adjoints_batched_host(const double* B, const double* C, const double* T, const double* T_bar,
+                                      int batch, int n, double* A_bar, double* B_bar, double* C_bar,
+                                      int32_t* status);
+
+/*
  * gEcon recursion residual norms, the `deterministic_norm` / `stochastic_norm` Deterministics of
  * DSGEStateSpace.build_statespace_graph (gEconpy/model/statespace.py:1181-1204).  With the state mask
  * s (variables that appear at t-1 and at t in some equation, :1186-1193):

@@ -38,6 +38,7 @@ from .gensys_qz import (  # noqa: F401
 )
 from .shared import (  # noqa: F401
     compute_selection_matrix,
+    policy_function_adjoints,
     policy_residual,
     solve_policy_function_with_backward_direct,
 )

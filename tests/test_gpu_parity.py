@@ -574,3 +574,36 @@ def test_solvability_check_batched(failure_golden):
     assert all(f in ("deterministic_norm", "stochastic_norm") for f in out["failure_step"])
     up = solvability_check_batched(A[:2], B[:2], C[:2], D[:2], upstream_failed=[True, False])
     assert up["failure_step"][0] == "steady_state" and up["failure_step"][1] is None
+
+
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
+def test_policy_adjoints_vs_kronecker_oracle(ref_goldens, key):
+    """Device doubling solve of the adjoint Stein equation vs the reference's n^2 x n^2 Kronecker solve
+    (gEconpy/solvers/shared.py:53-71, restated in oracle/shared.py)."""
+    g = ref_goldens
+    A, B, C, D = (g[f"{key}_{x}"] for x in "ABCD")
+    T = g[f"{key}_ref_cr_T"]
+    rng = np.random.default_rng(1)
+    nb = 3
+    Tbar = rng.standard_normal((nb,) + T.shape)
+    Ab, Bb, Cb, st = batched.policy_adjoints_batched(np.tile(B, (nb, 1, 1)), np.tile(C, (nb, 1, 1)), np.tile(T, (nb, 1, 1)), Tbar)
+    assert np.all(st == 0)
+    for i in range(nb):
+        Ar, Br, Cr = oracle.policy_function_adjoints(A, B, C, T, Tbar[i])
+        scale = np.abs(Ar).max()
+        assert_allclose(Ab[i], Ar, atol=1e-9 * scale)
+        assert_allclose(Bb[i], Br, atol=1e-9 * scale)
+        assert_allclose(Cb[i], Cr, atol=1e-9 * scale)
+
+
+def test_policy_adjoints_sw_shaped():
+    b = wl.sw_shaped_batch(4)
+    rng = np.random.default_rng(2)
+    Tbar = rng.standard_normal(b["A"].shape)
+    Ab, Bb, Cb, st = batched.policy_adjoints_batched(b["B"], b["C"], b["T_star"], Tbar)
+    assert np.all(st == 0)
+    for i in range(4):
+        Ar, Br, Cr = oracle.policy_function_adjoints(b["A"][i], b["B"][i], b["C"][i], b["T_star"][i], Tbar[i])
+        scale = np.abs(Ar).max()
+        assert_allclose(Ab[i], Ar, atol=1e-9 * scale)
+        assert_allclose(Cb[i], Cr, atol=1e-9 * scale)

@@ -159,3 +159,27 @@ def test_backward_direct():
     T, R = oracle.solve_policy_function_with_backward_direct(A, B, np.zeros((n, n)), D)
     assert_allclose(A + B @ T, 0, atol=1e-13)
     assert_allclose(B @ R + D, 0, atol=1e-13)
+
+
+def test_policy_adjoints_match_finite_differences(ref_goldens):
+    """Analogue of the reference's verify_grad on the solver adjoints
+    (tests/model/test_perturbation.py:209-276): <T_bar, dT> == <A_bar,dA> + <B_bar,dB> + <C_bar,dC>."""
+    A, B, C, D = _abcd(ref_goldens, "one_block")
+    rng = np.random.default_rng(0)
+    T0, conv, _ = oracle.cycle_reduction_core(A, B, C, 1000, 1e-14)
+    assert conv
+    T_bar = rng.standard_normal(T0.shape)
+    A_bar, B_bar, C_bar = oracle.policy_function_adjoints(A, B, C, T0, T_bar)
+    for M, M_bar, which in ((A, A_bar, 0), (B, B_bar, 1), (C, C_bar, 2)):
+        # directional derivative along a random direction supported on the non-zero pattern
+        dM = rng.standard_normal(M.shape) * (M != 0)
+        eps = 1e-6
+        args_p = [A, B, C]
+        args_m = [A, B, C]
+        args_p[which] = M + eps * dM
+        args_m[which] = M - eps * dM
+        Tp, cp, _ = oracle.cycle_reduction_core(*args_p, 1000, 1e-14)
+        Tm, cm, _ = oracle.cycle_reduction_core(*args_m, 1000, 1e-14)
+        assert cp and cm
+        fd = np.sum(T_bar * (Tp - Tm)) / (2 * eps)
+        assert_allclose(np.sum(M_bar * dM), fd, rtol=1e-5, atol=1e-8)
