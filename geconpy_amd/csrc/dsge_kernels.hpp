@@ -20,8 +20,10 @@ namespace dsge {
 template <int BS>
 struct CrSmem {
   static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 3 * NP + 1;
-  // A0s, A2s, W, then the blocked Gauss-Jordan scratch: Lbuf NP*BS, Ybuf BS*3NP, prow NP ints
-  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW + NP * BS + BS * 3 * NP + NP / 2);
+  // W, then the blocked Gauss-Jordan scratch: Lbuf NP*BS, Ybuf BS*3NP, prow NP ints.  A0, A1, A2 and
+  // A1_hat live in register blocks; the left operands of the four products are staged one after the
+  // other in the dead first column group of W, which keeps the footprint at 45 KB (3 draws per CU)
+  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + NP * BS + BS * 3 * NP + NP / 2);
 };
 
 template <int BS>
@@ -31,22 +33,21 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
                                                  int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out) {
   constexpr int NP = CrSmem<BS>::NP, LD = CrSmem<BS>::LD, LDW = CrSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* A0s = smem;
-  double* A2s = A0s + NP * LD;
-  double* W = A2s + NP * LD;
+  double* W = smem;
   double* Lbuf = W + NP * LDW;
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 3 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+  (void)LD;
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     wave_sync();
-    lds_load_matrix(A0s, LD, NP, NP, A + off, n, n, lane);
-    lds_load_matrix(A2s, LD, NP, NP, C + off, n, n, lane);
     for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
-    double A1[BS][BS], Ah[BS][BS];
+    double A0[BS][BS], A1[BS][BS], A2[BS][BS], Ah[BS][BS];
+    blk_load_global<BS>(A0, A + off, n, n, n, lr, lc);
     blk_load_global<BS>(A1, B + off, n, n, n, lr, lc);
+    blk_load_global<BS>(A2, C + off, n, n, n, lr, lc);
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -58,41 +59,41 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
     for (; it < max_iter;) {
       // W = [A1 | A0 | A2]
       blk_store_lds<BS>(A1, W, LDW, lr, lc);
-      {
-        double t[BS][BS];
-        blk_load_lds<BS>(t, A0s, LD, lr, lc);
-        blk_store_lds<BS>(t, W + NP, LDW, lr, lc);
-        blk_load_lds<BS>(t, A2s, LD, lr, lc);
-        blk_store_lds<BS>(t, W + 2 * NP, LDW, lr, lc);
-      }
+      blk_store_lds<BS>(A0, W + NP, LDW, lr, lc);
+      blk_store_lds<BS>(A2, W + 2 * NP, LDW, lr, lc);
       gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);  // syncs on entry and exit
       gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
       const double* X0 = W + NP;
       const double* X2 = W + 2 * NP;
-      double acc[BS][BS];
+      // left operand A0 -> dead column group 0
+      blk_store_lds<BS>(A0, W, LDW, lr, lc);
+      wave_sync();
+      double acc[BS][BS], m00[BS][BS];
       blk_zero<BS>(acc);
-      mm_acc<BS, false>(acc, A0s, LD, X2, LDW, n, lr, lc);  // m02
+      blk_zero<BS>(m00);
+      mm_acc<BS, false>(acc, W, LDW, X2, LDW, n, lr, lc);  // m02 = A0 X2
+      mm_acc<BS, false>(m00, W, LDW, X0, LDW, n, lr, lc);  // m00 = A0 X0
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
         for (int j = 0; j < BS; ++j) A1[i][j] -= acc[i][j];
+      wave_sync();
+      blk_store_lds<BS>(A2, W, LDW, lr, lc);  // left operand A2
+      wave_sync();
+      double m22[BS][BS];
       blk_zero<BS>(acc);
-      mm_acc<BS, false>(acc, A2s, LD, X0, LDW, n, lr, lc);  // m20
+      blk_zero<BS>(m22);
+      mm_acc<BS, false>(acc, W, LDW, X0, LDW, n, lr, lc);  // m20 = A2 X0
+      mm_acc<BS, false>(m22, W, LDW, X2, LDW, n, lr, lc);  // m22 = A2 X2
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
         for (int j = 0; j < BS; ++j) {
           A1[i][j] -= acc[i][j];
           Ah[i][j] -= acc[i][j];
+          A0[i][j] = -m00[i][j];
+          A2[i][j] = -m22[i][j];
         }
-      double m00[BS][BS], m22[BS][BS];
-      blk_zero<BS>(m00);
-      blk_zero<BS>(m22);
-      mm_acc<BS, false>(m00, A0s, LD, X0, LDW, n, lr, lc);
-      mm_acc<BS, false>(m22, A2s, LD, X2, LDW, n, lr, lc);
-      wave_sync();  // every lane is done reading A0s/A2s
-      blk_store_lds<BS>(m00, A0s, LD, lr, lc, -1.0);
-      blk_store_lds<BS>(m22, A2s, LD, lr, lc, -1.0);
       ++it;
       const double nrm0 = blk_norm1<BS>(m00);
       if (nrm0 < tol) {
