@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64) void bdirect_kernel(const double* __restrict__ 
 template <int BS>
 struct AsmSmem {
   static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 2 * NP + 1;
-  // M1, M2 (NP x LD each), W (NP x LDW), blocked Gauss-Jordan scratch (Lbuf, Ybuf, prow)
-  static constexpr size_t bytes = sizeof(double) * (size_t)(2 * NP * LD + NP * LDW + NP * BS + BS * 2 * NP + NP / 2);
+  // M1 (NP x LD), W (NP x LDW: two column groups G0 | G1), blocked Gauss-Jordan scratch (Lbuf, Ybuf, prow)
+  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LD + NP * LDW + NP * BS + BS * 2 * NP + NP / 2);
 };
 
 constexpr int LYAP_MAX_DOUBLINGS = 64;
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(64) void assemble_kernel(
   constexpr int NP = AsmSmem<BS>::NP, LD = AsmSmem<BS>::LD, LDW = AsmSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* M1 = smem;            // T, later A_k
-  double* M2 = M1 + NP * LD;    // C, then (B + C T), later P
-  double* W = M2 + NP * LD;     // [B + C T | D] -> [. | X];  later R | RQ, then scratch W1 (ld = LDW)
-  double* RQs = W + NP;         // R Q staging lives in the right half of W (ld = LDW)
+  double* W = M1 + NP * LD;     // two column groups (ld = LDW)
+  double* G0 = W;               //   C-stage: B + C T, then [M | .] of the solve; later R, W1 / transposes
+  double* G1 = W + NP;          //   C, then D -> X; later R Q, then P_k
   double* Lbuf = W + NP * LDW;
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 2 * NP);
@@ -239,31 +239,27 @@ __global__ __launch_bounds__(64) void assemble_kernel(
 
     double Rb[BS][BS];  // R in register blocks (rows lr*BS.., cols lc*BS.. < k)
     if (do_selection) {
-      lds_load_matrix(M2, LD, NP, NP, C + off, n, n, lane);
+      {
+        double Cb[BS][BS];
+        blk_load_global<BS>(Cb, C + off, n, n, n, lr, lc);
+        blk_store_lds<BS>(Cb, G1, LDW, lr, lc);
+      }
       wave_sync();
       double Mb[BS][BS];
       blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
-      mm_acc<BS, false>(Mb, M2, LD, M1, LD, n, lr, lc);  // B + C T
+      mm_acc<BS, false>(Mb, G1, LDW, M1, LD, n, lr, lc);  // M = B + C T
       wave_sync();
-      blk_store_lds<BS>(Mb, W, LDW, lr, lc);
-      blk_store_lds<BS>(Mb, M2, LD, lr, lc);  // keep a copy for the residual
+      blk_store_lds<BS>(Mb, G0, LDW, lr, lc);
       {
         double Db[BS][BS];
         blk_load_global<BS>(Db, D + offk, n, k, k, lr, lc);
-        blk_store_lds<BS>(Db, W + NP, LDW, lr, lc);
+        blk_store_lds<BS>(Db, G1, LDW, lr, lc);  // k < NP columns, the rest zero
       }
-      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
-      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
-      blk_load_lds<BS>(Rb, W + NP, LDW, lr, lc);
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) Rb[i][j] = -Rb[i][j];
-      if (R_out) blk_store_global<BS>(Rb, R_out + offk, n, k, k, lr, lc);
-      if (resid_out) {
+      wave_sync();
+      if (resid_out) {  // before the solve destroys M:  A + (B + C T) T
         double Eb[BS][BS];
         blk_load_global<BS>(Eb, A + off, n, n, n, lr, lc);
-        mm_acc<BS, false>(Eb, M2, LD, M1, LD, n, lr, lc);  // A + (B + C T) T
+        mm_acc<BS, false>(Eb, G0, LDW, M1, LD, n, lr, lc);
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < BS; ++i)
@@ -272,14 +268,22 @@ __global__ __launch_bounds__(64) void assemble_kernel(
         s = wave_sum(s);
         if (lane == 0) resid_out[draw] = s;
       }
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+      blk_load_lds<BS>(Rb, G1, LDW, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Rb[i][j] = -Rb[i][j];
+      if (R_out) blk_store_global<BS>(Rb, R_out + offk, n, k, k, lr, lc);
     } else {
       blk_load_global<BS>(Rb, R_in + offk, n, k, k, lr, lc);
     }
     if (!do_lyapunov) continue;
 
-    // ---- R -> left half of W (the transposed operand), R Q -> right half of W
+    // ---- R -> G0 (the transposed operand), R Q -> G1
     wave_sync();
-    blk_store_lds<BS>(Rb, W, LDW, lr, lc);
+    blk_store_lds<BS>(Rb, G0, LDW, lr, lc);
     if (q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED) {
       const double* q = Q + (q_mode == DSGE_Q_DIAG_BATCHED ? (size_t)draw * k : 0);
       double RQ[BS][BS];
@@ -290,28 +294,33 @@ __global__ __launch_bounds__(64) void assemble_kernel(
           const int c = lc * BS + j;
           RQ[i][j] = (c < k) ? Rb[i][j] * q[c] : 0.0;
         }
-      blk_store_lds<BS>(RQ, RQs, LDW, lr, lc);
+      blk_store_lds<BS>(RQ, G1, LDW, lr, lc);
       wave_sync();
     } else {
       const double* q = Q + (q_mode == DSGE_Q_FULL_BATCHED ? (size_t)draw * k * k : 0);
-      lds_load_matrix(M2, LD, NP, NP, q, k, k, lane);  // M2 is free here
+      {
+        double Qb[BS][BS];
+        blk_load_global<BS>(Qb, q, k, k, k, lr, lc);
+        blk_store_lds<BS>(Qb, G1, LDW, lr, lc);
+      }
       wave_sync();
       double RQ[BS][BS];
       blk_zero<BS>(RQ);
-      mm_acc<BS, false>(RQ, W, LDW, M2, LD, k, lr, lc);
-      blk_store_lds<BS>(RQ, RQs, LDW, lr, lc);
+      mm_acc<BS, false>(RQ, G0, LDW, G1, LDW, k, lr, lc);
+      wave_sync();
+      blk_store_lds<BS>(RQ, G1, LDW, lr, lc);
       wave_sync();
     }
     double Pb[BS][BS];
     blk_zero<BS>(Pb);
-    mm_acc<BS, true>(Pb, RQs, LDW, W, LDW, k, lr, lc);  // (R Q) R'
-    // symmetrise through M2
+    mm_acc<BS, true>(Pb, G1, LDW, G0, LDW, k, lr, lc);  // (R Q) R'
+    // symmetrise through G0
     wave_sync();
-    blk_store_lds<BS>(Pb, M2, LD, lr, lc);
+    blk_store_lds<BS>(Pb, G0, LDW, lr, lc);
     wave_sync();
     {
       double Pt[BS][BS];
-      blk_load_lds_t<BS>(Pt, M2, LD, lr, lc);
+      blk_load_lds_t<BS>(Pt, G0, LDW, lr, lc);
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -319,30 +328,30 @@ __global__ __launch_bounds__(64) void assemble_kernel(
     }
     if (RQR_out) blk_store_global<BS>(Pb, RQR_out + off, n, n, n, lr, lc);
     wave_sync();
-    blk_store_lds<BS>(Pb, M2, LD, lr, lc);  // P_0 = RQR
+    blk_store_lds<BS>(Pb, G1, LDW, lr, lc);  // P_0 = RQR
     wave_sync();
 
-    // ---- doubling iteration; M1 = A_k, M2 = P_k, W = scratch
+    // ---- doubling iteration; M1 = A_k, G1 = P_k, G0 = scratch
     bool lyap_ok = false;
     for (int itl = 0; itl < LYAP_MAX_DOUBLINGS; ++itl) {
       double W1[BS][BS];
       blk_zero<BS>(W1);
-      mm_acc<BS, true>(W1, M2, LD, M1, LD, n, lr, lc);  // P A_k'
+      mm_acc<BS, true>(W1, G1, LDW, M1, LD, n, lr, lc);  // P A_k'
       wave_sync();
-      blk_store_lds<BS>(W1, W, LDW, lr, lc);
+      blk_store_lds<BS>(W1, G0, LDW, lr, lc);
       wave_sync();
       double Db[BS][BS], A2b[BS][BS];
       blk_zero<BS>(Db);
       blk_zero<BS>(A2b);
-      mm_acc<BS, false>(Db, M1, LD, W, LDW, n, lr, lc);    // A_k P A_k'
+      mm_acc<BS, false>(Db, M1, LD, G0, LDW, n, lr, lc);   // A_k P A_k'
       mm_acc<BS, false>(A2b, M1, LD, M1, LD, n, lr, lc);   // A_k^2
       wave_sync();
-      blk_store_lds<BS>(Db, W, LDW, lr, lc);
+      blk_store_lds<BS>(Db, G0, LDW, lr, lc);
       blk_store_lds<BS>(A2b, M1, LD, lr, lc);
       wave_sync();
       {
         double Dt[BS][BS];
-        blk_load_lds_t<BS>(Dt, W, LDW, lr, lc);
+        blk_load_lds_t<BS>(Dt, G0, LDW, lr, lc);
 #pragma unroll
         for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(
       const double dmax = blk_maxabs<BS>(Db);
       const double pmax = blk_maxabs<BS>(Pb);
       wave_sync();
-      blk_store_lds<BS>(Pb, M2, LD, lr, lc);
+      blk_store_lds<BS>(Pb, G1, LDW, lr, lc);
       wave_sync();
       if (!(dmax == dmax) || !(pmax < 1e300)) break;  // NaN / overflow: rho(T) >= 1
       if (dmax <= 1e-17 * pmax) {
