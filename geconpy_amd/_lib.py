@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
 ABI_VERSION = 1
 MAX_N = 64
-MAX_N_CR = 48
+MAX_N_CR = 64
 MAX_N_GENSYS = 64
 MAX_P = 16
 

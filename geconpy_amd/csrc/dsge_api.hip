@@ -128,7 +128,7 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 6, {
+  DISPATCH_BS(bs, 8, {
     rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
@@ -143,7 +143,7 @@ int launch_bdirect(const double* A, const double* B, const double* D, int batch,
                    double* R_out, hipStream_t st) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 6, {
+  DISPATCH_BS(bs, 8, {
     rc = set_lds(dsge::bdirect_kernel<BS>, dsge::BdSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::bdirect_kernel<BS>, dim3(batch), dim3(64), dsge::BdSmem<BS>::bytes, st, A, B, D, batch,
@@ -387,7 +387,7 @@ int dsge_selection_batched(const double* A, const double* B, const double* C, co
 
 int dsge_policy_adjoints_batched(const double* B, const double* C, const double* T, const double* T_bar, int batch,
                                  int n, double* A_bar, double* B_bar, double* C_bar, int32_t* status, void* stream) {
-  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  int rc = check_common(batch, n, 48);  // [M' | T_bar | C'] + two operands in LDS: n <= 48
   if (rc) return rc;
   if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
@@ -704,7 +704,7 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
 
 int dsge_policy_adjoints_batched_host(const double* B, const double* C, const double* T, const double* T_bar,
                                       int batch, int n, double* A_bar, double* B_bar, double* C_bar, int32_t* status) {
-  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  int rc = check_common(batch, n, 48);
   if (rc) return rc;
   if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;

@@ -36,8 +36,8 @@ extern "C" {
 #define DSGE_ABI_VERSION 1
 
 /* limits of this build */
-#define DSGE_MAX_N 64      /* model variables n == Kalman states m (cycle reduction: 48) */
-#define DSGE_MAX_N_CR 48
+#define DSGE_MAX_N 64      /* model variables n == Kalman states m */
+#define DSGE_MAX_N_CR 64
 #define DSGE_MAX_N_GENSYS 64   /* pencil dimension n + #lead columns (further limited by 160 KB LDS) */
 #define DSGE_MAX_P 16      /* observed series */
 
@@ -140,7 +140,7 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
  *   (kron(T, C') + kron(I, T'C') + kron(I, B')) vec(S) = -vec(T_bar)   <=>   (B + C T)' S + C' S T' = -T_bar.
  * The reference factorises the n^2 x n^2 Kronecker matrix; here the equivalent Stein equation is solved
  * by a doubling iteration (valid for a determinate solution: rho(T) < 1 and stable-inverse roots).
- *   B, C, T, T_bar, A_bar, B_bar, C_bar : [batch][n][n];  status : [batch] (non-zero = not converged)
+ *   B, C, T, T_bar, A_bar, B_bar, C_bar : [batch][n][n], n <= 48;  status : [batch] (non-zero = not converged)
  */
 int dsge_policy_adjoints_batched(const double* B, const double* C, const double* T, const double* T_bar,
                                  int batch, int n, double* A_bar, double* B_bar, double* C_bar,

@@ -68,7 +68,7 @@ def test_malformed_calls_are_rejected_before_touching_the_gpu():
     st = np.zeros(1, dtype=np.int32)
     p = lambda x: x.ctypes.data  # noqa: E731
     assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), 1, 0, 10, 1e-8, p(a), p(st), None) == 1
-    assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), 1, 49, 10, 1e-8, p(a), p(st), None) == 1
+    assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), 1, 65, 10, 1e-8, p(a), p(st), None) == 1
     assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), -1, 4, 10, 1e-8, p(a), p(st), None) == 1
     assert b"range" in lib.dsge_last_error() or b"batch" in lib.dsge_last_error()
     assert lib.dsge_selection_batched_host(p(a), p(a), p(a), p(a), p(a), 1, 4, 5, p(a), None) == 1  # k > n
