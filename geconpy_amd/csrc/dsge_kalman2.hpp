@@ -97,9 +97,9 @@ template <int BS, bool SEL>
 __global__ __launch_bounds__(64) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
-    const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m, int p,
+    const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
     int T_len, int s_cap, double jitter, double missing_fill, double* __restrict__ logp_out,
-    int32_t* __restrict__ status, long long* __restrict__ dbg) {
+    int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only) {
   constexpr int NP = Kf2Smem<BS>::NP, LDM = Kf2Smem<BS>::LDM;
   constexpr int PS = 10;  // row stride of the NP x 8 panels: 80 B keeps 16-byte alignment and spreads rows over all banks
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -126,60 +126,66 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
   const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    if (status[draw] != 0) {
+    const int32_t st_in = status[draw];
+    if (rerun_only) {
+      // later pass of the tile-size cascade: only the draws an earlier (smaller) instance flagged
+      if (st_in != DSGE_ST_INTERNAL_RERUN) continue;
+    } else if (st_in != 0) {
       if (lane == 0) logp_out[draw] = -INFINITY;
       continue;
     }
-    const size_t off = (size_t)draw * m * m;
+    const size_t off = (size_t)draw * m_full * m_full;
     wave_sync();
     for (int idx = lane; idx < (int)Kf2Smem<BS>::doubles(s_cap, !SEL); idx += 64) smem[idx] = 0.0;
 
-    // ---- structure of T: non-zero columns S ------------------------------------------------
-    double Pb[BS][BS];
-    blk_load_global<BS>(Pb, T + off, m, m, m, lr, lc);
-    unsigned long long colmask = 0ull;
-#pragma unroll
-    for (int j = 0; j < BS; ++j) {
-      bool nz = false;
-#pragma unroll
-      for (int i = 0; i < BS; ++i) nz = nz || (Pb[i][j] != 0.0);
-      unsigned long long b = __ballot(nz);
-      b |= b >> 32;
-      b |= b >> 16;
-      b |= b >> 8;
-#pragma unroll
-      for (int g = 0; g < 8; ++g)
-        if ((b >> g) & 1ull) colmask |= 1ull << (g * BS + j);
+    // ---- exact state-space reduction.  S = variables with a non-zero column in T (the states),
+    // O = variables some observation loads on.  A variable outside U = S u O neither feeds back into
+    // the recursion (its column of T is exactly zero) nor is observed, so dropping it changes nothing
+    // in the retained entries of a, P, F, K: the filter runs on the u = |U| retained variables, ordered
+    // states first, then the observed non-states.  (One lane per original variable, m_full <= 64.)
+    const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
+    bool is_state = false;
+    if (lane < m_full)
+      for (int r = 0; r < m_full; ++r) is_state = is_state || (T[off + (size_t)r * m_full + lane] != 0.0);
+    const unsigned long long colmask = __ballot(is_state);
+    unsigned long long obsmask = 0ull, used = 0ull;
+    bool ok = true;
+    for (int o = 0; o < p; ++o) {
+      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
+      const unsigned long long b = __ballot(zl != 0.0);
+      if (SEL && (__popcll(b) != 1 || ((used & b) != 0ull))) ok = false;
+      used |= b;
+      obsmask |= b;
     }
+    const unsigned long long extra = obsmask & ~colmask;  // observed non-states
     const int s = __popcll(colmask);
-    bool ok = (s <= s_cap);
-    // ---- selector structure of Z ---------------------------------------------------------
-    const double* Zg = Z + (z_batched ? (size_t)draw * p * m : 0);
-    unsigned long long used = 0ull;
-    int my_pos = 0;  // position of original index `lane` in the states-first ordering
-    if (lane < m) {
-      const int rk = __popcll(colmask & ((1ull << lane) - 1ull));
-      my_pos = ((colmask >> lane) & 1ull) ? rk : s + (lane - rk);
-      perm[my_pos] = lane;
+    const int m = s + __popcll(extra);  // dimension of the reduced filter
+    ok = ok && (s <= s_cap) && (m <= NP);
+    int my_pos = -1;  // position of original variable `lane` in the reduced ordering (-1 = dropped)
+    if (lane < m_full) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if ((colmask >> lane) & 1ull)
+        my_pos = __popcll(colmask & below);
+      else if ((extra >> lane) & 1ull)
+        my_pos = s + __popcll(extra & below);
+      if (my_pos >= 0 && my_pos < NP) perm[my_pos] = lane;
     }
     for (int o = 0; o < p; ++o) {
-      const double zl = (lane < m) ? Zg[(size_t)o * m + lane] : 0.0;
+      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
       if (SEL) {
-        const unsigned long long b = __ballot(zl != 0.0);
-        if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
-        used |= b;
         if (zl != 0.0) {  // the single owner lane of this observation
-          zpos[o] = my_pos;
+          zpos[o] = (my_pos >= 0 && my_pos < NP) ? my_pos : 0;
           zv[o] = zl;
         }
-      } else if (lane < m) {
-        Zs[o * LDM + my_pos] = zl;  // design matrix in the states-first ordering
+      } else if (my_pos >= 0 && my_pos < NP) {
+        Zs[o * LDM + my_pos] = zl;  // design matrix restricted to the retained variables
       }
     }
     if (!ok) {
       if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
       continue;
     }
+    if (rerun_only && lane == 0) status[draw] = 0;
     wave_sync();
     // ---- load everything in the states-first ordering (a consistent permutation of the state
     // vector leaves the likelihood unchanged): element (r,c) <- original (perm[r], perm[c])
@@ -198,13 +204,13 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
           zcol[i] = zv[o];
         }
     }
-    double Qb[BS][BS];
+    double Qb[BS][BS], Pb[BS][BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         const bool in = pr[i] >= 0 && pcx[j] >= 0;
-        const size_t g = in ? (size_t)pr[i] * m + pcx[j] : 0;
+        const size_t g = in ? (size_t)pr[i] * m_full + pcx[j] : 0;
         const double tv = in ? T[off + g] : 0.0;
         Qb[i][j] = in ? RQR[off + g] : 0.0;
         Pb[i][j] = in ? P0[off + g] : 0.0;
