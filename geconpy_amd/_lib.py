@@ -54,6 +54,9 @@ PROTOTYPES = {
     "dsge_cycle_reduction_batched_host": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp],
     "dsge_gensys_batched": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_gensys_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
+    "dsge_set_kalman_steady_tol": [_f],
+    "dsge_get_kalman_steady_tol": [],
+    "dsge_debug_kalman_steady_steps": [_dp],
     "dsge_debug_kalman_phases": [_i, _dp],
     "dsge_debug_gensys_phases": [_dp, _dp, _dp, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_selection_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
@@ -99,7 +102,7 @@ def load():
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "dsge_last_error" else C.c_int
+        fn.restype = {"dsge_last_error": C.c_char_p, "dsge_get_kalman_steady_tol": C.c_double}.get(name, C.c_int)
     if lib.dsge_abi_version() != ABI_VERSION:
         raise DsgeHipError("libdsge_hip ABI version mismatch")
     _lib = lib

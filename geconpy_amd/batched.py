@@ -227,6 +227,17 @@ def selector_hint(Z):
     return int(bool(one_per_row and distinct))
 
 
+def set_kalman_steady_tol(tol):
+    """Steady-state switch of the fast Kalman kernel (include/dsge_hip.h): relative change of the
+    predicted covariance below which F^-1, K and det F are frozen.  0 = step-for-step recursion;
+    default 1e-14 (rounding level).  Process-wide."""
+    _lib.check(_lib.load().dsge_set_kalman_steady_tol(float(tol)))
+
+
+def get_kalman_steady_tol():
+    return float(_lib.load().dsge_get_kalman_steady_tol())
+
+
 def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None,
                         jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
                         z_selector_hint=None):

@@ -9,27 +9,25 @@
 #include <string>
 #include <vector>
 
-#include "dsge_kernels.hpp"
-#include "dsge_kalman2.hpp"
-#include "dsge_gensys.hpp"
+#include "dsge_host.hpp"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
+namespace dsge_host {
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+}  // namespace dsge_host
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) {                                                                        \
-      (void)hipGetLastError(); /* clear the sticky error so later calls are not poisoned */        \
-      return fail(DSGE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
-    }                                                                                              \
-  } while (0)
+using namespace dsge_host;
+
+namespace {
+
+
+
 
 bool g_device_checked = false;
 int g_device_ok = 0;
@@ -84,7 +82,6 @@ int arena_reserve(Arena* arenas, size_t bytes, void** out) {
   return DSGE_SUCCESS;
 }
 
-constexpr size_t LDS_LIMIT = 160 * 1024;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -99,216 +96,6 @@ struct Carver {
     return p;
   }
 };
-
-inline int tile_bs(int n) {
-  int bs = (n + 7) / 8;
-  if (bs == 7) bs = 8;
-  return bs < 1 ? 1 : bs;
-}
-
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return DSGE_SUCCESS;
-}
-
-#define DISPATCH_BS(bs, MAXBS, ...)                                                  \
-  switch (bs) {                                                                      \
-    case 1: { constexpr int BS = 1; __VA_ARGS__; } break;                            \
-    case 2: { constexpr int BS = 2; __VA_ARGS__; } break;                            \
-    case 3: { constexpr int BS = 3; __VA_ARGS__; } break;                            \
-    case 4: { constexpr int BS = 4; __VA_ARGS__; } break;                            \
-    case 5: { constexpr int BS = 5; __VA_ARGS__; } break;                            \
-    case 6: { constexpr int BS = 6; __VA_ARGS__; } break;                            \
-    case 8: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 8 : 6); __VA_ARGS__; } break; \
-    default: break;                                                                  \
-  }
-
-int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
-              double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
-  const int bs = tile_bs(n);
-  int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 8, {
-    rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
-                         max_iter, tol, T_out, status, n_iter);
-      HIP_TRY(hipGetLastError());
-    }
-  });
-  return rc;
-}
-
-int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
-                   double* R_out, hipStream_t st) {
-  const int bs = tile_bs(n);
-  int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 8, {
-    rc = set_lds(dsge::bdirect_kernel<BS>, dsge::BdSmem<BS>::bytes);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::bdirect_kernel<BS>, dim3(batch), dim3(64), dsge::BdSmem<BS>::bytes, st, A, B, D, batch,
-                         n, k, T_out, R_out);
-      HIP_TRY(hipGetLastError());
-    }
-  });
-  return rc;
-}
-
-int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
-                    const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
-                    double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
-                    hipStream_t st) {
-  const int bs = tile_bs(n);
-  int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 8, {
-    rc = set_lds(dsge::assemble_kernel<BS>, dsge::AsmSmem<BS>::bytes);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::assemble_kernel<BS>, dim3(batch), dim3(64), dsge::AsmSmem<BS>::bytes, st, A, B, C, D, T,
-                         R_in, Q, q_mode, batch, n, k, R_out, resid_out, RQR_out, P0_out, status, do_sel, do_lyap);
-      HIP_TRY(hipGetLastError());
-    }
-  });
-  return rc;
-}
-
-int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
-                   double* Bb, double* Cb, int32_t* status, hipStream_t st) {
-  const int bs = tile_bs(n);
-  int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 6, {
-    rc = set_lds(dsge::adjoint_kernel<BS>, dsge::AdjSmem<BS>::bytes);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::adjoint_kernel<BS>, dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
-                         batch, n, Ab, Bb, Cb, status);
-      HIP_TRY(hipGetLastError());
-    }
-  });
-  return rc;
-}
-
-int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
-                 const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st) {
-  const int bs = tile_bs(n);
-  int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 8, {
-    rc = set_lds(dsge::norms_kernel<BS>, dsge::NormSmem<BS>::bytes);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::norms_kernel<BS>, dim3(batch), dim3(64), dsge::NormSmem<BS>::bytes, st, A, B, C, D, T, R,
-                         mask, batch, n, k, det, sto);
-      HIP_TRY(hipGetLastError());
-    }
-  });
-  return rc;
-}
-
-long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
-
-int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
-                  const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
-                  int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                  double* logp, int32_t* status, hipStream_t st) {
-  const int bs = tile_bs(m);
-  int rc = DSGE_ERR_INVALID;
-  // Fast path: selector Z, p <= 8, compact state block of at most s_cap columns.  Draws that
-  // violate a hint come back flagged and are re-run by the general kernel below.
-  // Fast path (p <= 8): compact state block of at most s_cap columns; selector Z (gathers) or dense
-  // Z (one extra product per step).  Draws that violate a hint come back flagged and are re-run by
-  // the general kernel below.
-  const bool fast = p <= 8;
-  bool launched_fast = false;
-  if (fast) {
-    // The fast kernel filters only the variables that matter (states + observed non-states), so its
-    // tile size follows that reduced dimension u, not m.  u is only known per draw on the device
-    // (n_state_hint <= u <= n_state_hint + p for a selector), so the instances are tried smallest
-    // first: each one flags the draws that do not fit it, the next one picks up exactly those.
-    // A dense Z may load on every variable: no reduction is assumed for it.
-    int tiles[2];
-    int n_tiles = 0;
-    if (z_selector_hint && n_state_hint > 0 && n_state_hint < m) {
-      tiles[n_tiles++] = tile_bs(n_state_hint);
-      const int hi = tile_bs(n_state_hint + p < m ? n_state_hint + p : m);
-      if (hi != tiles[0]) tiles[n_tiles++] = hi;
-    } else {
-      tiles[n_tiles++] = tile_bs(m);
-    }
-    for (int it = 0; it < n_tiles; ++it) {
-      const int bs_fast = tiles[it];
-      const int rerun = launched_fast ? 1 : 0;
-      rc = DSGE_ERR_INVALID;
-      DISPATCH_BS(bs_fast, 8, {
-        constexpr int NP = 8 * BS;
-        int s_cap = (n_state_hint > 0 && n_state_hint < NP) ? ((n_state_hint + BS - 1) / BS) * BS : NP;
-        if (s_cap > NP) s_cap = NP;
-        if (z_selector_hint) {
-          const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
-          rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
-          if (rc == DSGE_SUCCESS) {
-            hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, P0, Z,
-                               z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
-                               missing_fill, logp, status, g_kalman_dbg, rerun);
-            HIP_TRY(hipGetLastError());
-            launched_fast = true;
-          }
-        } else {
-          const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, true);
-          if (lds > LDS_LIMIT) {
-            rc = DSGE_SUCCESS;  // does not fit: the general kernel handles everything
-          } else {
-            rc = set_lds(dsge::kalman_sel_kernel<BS, false>, lds);
-            if (rc == DSGE_SUCCESS) {
-              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, P0,
-                                 Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
-                                 jitter, missing_fill, logp, status, g_kalman_dbg, rerun);
-              HIP_TRY(hipGetLastError());
-              launched_fast = true;
-            }
-          }
-        }
-      });
-      if (rc) return rc;
-    }
-  }
-  rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 8, {
-    const size_t lds = dsge::KfSmem<BS>::bytes(p);
-    rc = set_lds(dsge::kalman_kernel<BS>, lds);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
-                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status,
-                         launched_fast ? 1 : 0);
-      HIP_TRY(hipGetLastError());
-    }
-  });
-  return rc;
-}
-
-// choose the on-chip pencil capacity (n_cap = n + l_cap) for gensys
-int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {
-  int l = (n_lead_hint > 0) ? n_lead_hint : n;
-  if (l > n) l = n;
-  if (n + l > DSGE_MAX_N_GENSYS) l = DSGE_MAX_N_GENSYS - n;
-  while (l >= 1 && dsge::gensys_smem_bytes(n, n + l, l) > LDS_LIMIT) {
-    if (n_lead_hint > 0) return fail(DSGE_ERR_INVALID, "gensys: n + n_lead_hint does not fit the 160 KB LDS");
-    --l;
-  }
-  if (l < 1) return fail(DSGE_ERR_INVALID, "gensys: model too large for the on-chip pencil");
-  *l_cap = l;
-  *n_cap = n + l;
-  return DSGE_SUCCESS;
-}
-
-int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
-                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr) {
-  int n_cap = 0, l_cap = 0;
-  int rc = gensys_caps(n, n_lead_hint, &n_cap, &l_cap);
-  if (rc) return rc;
-  const size_t lds = dsge::gensys_smem_bytes(n, n_cap, l_cap);
-  if ((rc = set_lds(dsge::gensys_kernel, lds))) return rc;
-  hipLaunchKernelGGL(dsge::gensys_kernel, dim3(batch), dim3(64), lds, st, A, B, C, batch, n, n_cap, l_cap, tol, T_out,
-                     eu_out, status, dbg);
-  HIP_TRY(hipGetLastError());
-  return DSGE_SUCCESS;
-}
 
 int check_common(int batch, int n, int n_max) {
   if (batch < 0) return fail(DSGE_ERR_INVALID, "batch < 0");
@@ -339,6 +126,17 @@ extern "C" {
 
 int dsge_abi_version(void) { return DSGE_ABI_VERSION; }
 const char* dsge_last_error(void) { return g_last_error.c_str(); }
+
+int dsge_set_kalman_steady_tol(double tol) {
+  if (!(tol >= 0.0) || tol > 1e-6) return fail(DSGE_ERR_INVALID, "steady-state tolerance must be in [0, 1e-6]");
+  g_kalman_steady_tol = tol;
+  return DSGE_SUCCESS;
+}
+double dsge_get_kalman_steady_tol(void) { return g_kalman_steady_tol; }
+int dsge_debug_kalman_steady_steps(int32_t* steady_at_device) {
+  g_kalman_steady_at = steady_at_device;
+  return DSGE_SUCCESS;
+}
 
 int dsge_device_count(void) {
   int count = 0;
@@ -618,7 +416,8 @@ int dsge_cycle_reduction_batched_host(const double* A, const double* B, const do
 }
 
 // Debug hook: when enabled, kalman_sel_kernel accumulates the shader cycles draw 0 spends in each
-// of its five per-step phases; dsge_debug_kalman_phases(0/1 enable, out[5]) reads them back.
+// of its five per-step phases, [5] = cycles in steady-state steps, [6] = number of steady-state steps,
+// [7] = total; dsge_debug_kalman_phases(0/1 enable, out[8]) reads them back.
 int dsge_debug_kalman_phases(int enable, long long* cycles_out) {
   int rc = ensure_device();
   if (rc) return rc;
@@ -628,7 +427,7 @@ int dsge_debug_kalman_phases(int enable, long long* cycles_out) {
   }
   if (cycles_out && g_kalman_dbg) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(cycles_out, g_kalman_dbg, 5 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cycles_out, g_kalman_dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost));
   }
   if (!enable && g_kalman_dbg) {
     (void)hipFree(g_kalman_dbg);

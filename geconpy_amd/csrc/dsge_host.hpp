@@ -1,0 +1,77 @@
+// Host-side plumbing shared by the translation units of libdsge_hip.so: error reporting, the tile-size
+// dispatch and the prototypes of the kernel launchers.  Each launch_*.hip file instantiates only its
+// own kernels, so the library builds as independent (parallel) hipcc jobs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge_host {
+
+int fail(int code, const std::string& msg);  // records the message for dsge_last_error(), returns code
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      (void)hipGetLastError(); /* clear the sticky error so later calls are not poisoned */        \
+      return dsge_host::fail(DSGE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+    }                                                                                              \
+  } while (0)
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+inline int tile_bs(int n) {
+  int bs = (n + 7) / 8;
+  if (bs == 7) bs = 8;
+  return bs < 1 ? 1 : bs;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return DSGE_SUCCESS;
+}
+
+#define DISPATCH_BS(bs, MAXBS, ...)                                                  \
+  switch (bs) {                                                                      \
+    case 1: { constexpr int BS = 1; __VA_ARGS__; } break;                            \
+    case 2: { constexpr int BS = 2; __VA_ARGS__; } break;                            \
+    case 3: { constexpr int BS = 3; __VA_ARGS__; } break;                            \
+    case 4: { constexpr int BS = 4; __VA_ARGS__; } break;                            \
+    case 5: { constexpr int BS = 5; __VA_ARGS__; } break;                            \
+    case 6: { constexpr int BS = 6; __VA_ARGS__; } break;                            \
+    case 8: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 8 : 6); __VA_ARGS__; } break; \
+    default: break;                                                                  \
+  }
+
+// ---- launchers (launch_solvers.hip, launch_assemble.hip, launch_kalman.hip, launch_gensys.hip) ----
+int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
+              double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st);
+int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
+                   double* R_out, hipStream_t st);
+int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
+                    const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
+                    double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
+                    hipStream_t st);
+int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st);
+int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
+                 const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st);
+int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
+                  const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                  int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
+                  double* logp, int32_t* status, hipStream_t st);
+int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
+int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
+                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr);
+
+// process-wide settings of the fast Kalman kernel (launch_kalman.hip)
+extern long long* g_kalman_dbg;       // debug: device buffer for per-phase cycles of draw 0
+extern double g_kalman_steady_tol;    // steady-state switch (0 = never switch)
+extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first steady step per draw (-1 = never)
+
+}  // namespace dsge_host

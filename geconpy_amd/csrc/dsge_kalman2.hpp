@@ -94,12 +94,12 @@ __device__ __forceinline__ void mm_acc_p(double (&acc)[BS][BS], const double* A,
 // SEL = true : selector design matrix (P Z' and F are gathers)
 // SEL = false: dense Z (p <= 8): P Z' is a register-block product against the full P kept in LDS
 template <int BS, bool SEL>
-__global__ __launch_bounds__(64) void kalman_sel_kernel(
+__global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
-    int T_len, int s_cap, double jitter, double missing_fill, double* __restrict__ logp_out,
-    int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only) {
+    int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
+    int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at) {
   constexpr int NP = Kf2Smem<BS>::NP, LDM = Kf2Smem<BS>::LDM;
   constexpr int PS = 10;  // row stride of the NP x 8 panels: 80 B keeps 16-byte alignment and spreads rows over all banks
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -259,14 +259,34 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
     double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
     long long ld_exp = 0;
     long long n_ll_steps = 0;
-    long long ph[5] = {0, 0, 0, 0, 0};
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk_start = dbg ? clock64() : 0;
+    // ---- steady-state switch.  The covariance recursion P_{t+1|t} = f(P_{t|t-1}; mask_t) does not
+    // depend on the data; once it has reached its fixed point for the current missing-data mask
+    // (max|P_{t+1|t} - P_{t|t-1}| <= steady_tol * max|P|, i.e. rounding level for the default 1e-14),
+    // F^-1, K and det F of the last full step are reused and only the O(m p + m s) mean recursion
+    // runs.  A step whose mask differs falls back to the full update from the current P.
+    double kr_ss[8], av_reg = 0.0;
+    int steady_step = -1;
+    // selector Z and a small tile: the steady-state steps run out of registers only
+    constexpr bool REG_SS = SEL && (BS <= 4);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) kr_ss[o] = 0.0;
+    double yt_next = (lane < p && T_len > 0) ? y[lane] : 0.0;
     for (int t = 0; t < T_len; ++t) {
       long long tk0 = dbg ? clock64() : 0;
       // ---- (a) missing-data mask ------------------------------------------------------
-      const double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
+      const double yt = yt_next;  // fetched one step ahead: the global-load latency is off the chain
+      yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
       const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
       const unsigned long long omask = __ballot(obs);
       const int n_obs = __popcll(omask);
+      bool steady = false;
+      double Pprev[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Pprev[i][j] = Pb[i][j];
       const double wo = (double)((omask >> fo) & 1ull), wq = (double)((omask >> fq) & 1ull);
       // ---- (b) F[fo][fq] and the innovation -------------------------------------------
       double f;
@@ -372,6 +392,8 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
           afi = fma(kr[2 * o2 + 1], vv[2 * o2 + 1], afi);
         }
         af[i] = afi;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) kr_ss[o] = kr[o];
       }
       wave_sync();  // #2
       if (dbg) {
@@ -432,6 +454,7 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         }
         if (kk < s) s0 = fma(Tc[lane * LDM + kk], af[kk], s0);
         av[lane] = s0 + s1;
+        av_reg = s0 + s1;
       }
       if (lr * BS < s) {
         double Wb[BS][BS];
@@ -450,13 +473,23 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         blk_zero<BS>(Xb);
         mm_acc_p<BS, false, LDM, LDM>(Xb, Tc, Wc, s, lr, lc);
         const int src = (lc << 3) | lr;  // lane holding the transposed block
+        double dmax = 0.0, pmax = 0.0;
+        steady = false;
 #pragma unroll
         for (int i = 0; i < BS; ++i)
 #pragma unroll
           for (int j = 0; j < BS; ++j) {
             const double xt = __shfl(Xb[j][i], src, 64);
             Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
+            dmax = nanmax(dmax, fabs(Pb[i][j] - Pprev[i][j]));
+            pmax = nanmax(pmax, fabs(Pb[i][j]));
           }
+        if (steady_tol > 0.0) {
+          // non-negative doubles order like their bit patterns; a NaN compares above everything
+          const double dm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(dmax)));
+          const double pm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(pmax)));
+          steady = (dm <= steady_tol * pm);
+        }
       }
       // ---- P Z' for the next step -------------------------------------------------------------
       STORE_PZT();
@@ -466,14 +499,126 @@ __global__ __launch_bounds__(64) void kalman_sel_kernel(
         ph[4] += tk1 - tk0;
         tk0 = tk1;
       }
+      if (!steady) continue;
+      // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same ====
+      if (steady_step < 0) steady_step = t + 1;
+      if constexpr (REG_SS) {
+        // register-only: this lane's row of Tc, rows of F^-1 in lanes 0..7, no LDS memory traffic
+        double trow[NP], finv_row[8];
+#pragma unroll
+        for (int kk = 0; kk < NP; ++kk) trow[kk] = (lane < NP) ? Tc[lane * LDM + kk] : 0.0;  // columns >= s are zero
+#pragma unroll
+        for (int q = 0; q < 8; ++q) finv_row[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
+        while (t + 1 < T_len) {
+          const double yt_s = yt_next;
+          const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);
+          if (__ballot(obs_s) != omask) break;
+          ++t;
+          yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+          const double av_sel = __shfl(av_reg, v_zpos, 64);
+          double v_s = 0.0;
+          if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
+          double vsc[8];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
+          double w0 = 0.0, w1 = 0.0, a0 = av_reg, a1 = 0.0;
+#pragma unroll
+          for (int o = 0; o < 8; o += 2) {
+            w0 = fma(finv_row[o], vsc[o], w0);
+            w1 = fma(finv_row[o + 1], vsc[o + 1], w1);
+            a0 = fma(kr_ss[o], vsc[o], a0);
+            a1 = fma(kr_ss[o + 1], vsc[o + 1], a1);
+          }
+          double part = v_s * (w0 + w1);  // lanes >= 8 hold finv_row = 0
+          part += dpp_move_f64<0x111, 0xf>(part);
+          part += dpp_move_f64<0x112, 0xf>(part);
+          part += dpp_move_f64<0x114, 0xf>(part);
+          const double qp = readlane_f64(part, 7);
+          if (n_obs > 0) {
+            const double yk = qp - quad_comp;
+            const double tk = quad_sum + yk;
+            quad_comp = (tk - quad_sum) - yk;
+            quad_sum = tk;
+            int e;
+            ld_mant = frexp(ld_mant * step_mant, &e);
+            ld_exp += (long long)e + step_exp;
+            ++n_ll_steps;
+          }
+          const double afi = a0 + a1;
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < NP; kk += 2) {
+            s0 = fma(trow[kk], readlane_f64(afi, kk), s0);
+            s1 = fma(trow[kk + 1], readlane_f64(afi, kk + 1), s1);
+          }
+          av_reg = (lane < m) ? s0 + s1 : 0.0;
+          if (dbg) ++ph[6];
+        }
+        if (lane < m) av[lane] = av_reg;  // hand the predicted state back to the LDS copy
+        wave_sync();
+      } else {
+        while (t + 1 < T_len) {
+          const double yt_s = yt_next;
+          const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);
+          if (__ballot(obs_s) != omask) break;
+          ++t;
+          yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+          double v_s = 0.0;
+          if (lane < p) {
+            double za;
+            if (SEL) {
+              za = v_zv * av[v_zpos];
+            } else {
+              za = 0.0;
+              for (int jj = 0; jj < m; ++jj) za = fma(Zs[lane * LDM + jj], av[jj], za);
+            }
+            v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * za);
+          }
+          const double vo = __shfl(v_s, fo, 64), vq = __shfl(v_s, fq, 64);
+          const double qp = wave_sum_dpp(f * vo * vq);
+          if (n_obs > 0) {
+            const double yk = qp - quad_comp;
+            const double tk = quad_sum + yk;
+            quad_comp = (tk - quad_sum) - yk;
+            quad_sum = tk;
+            int e;
+            ld_mant = frexp(ld_mant * step_mant, &e);
+            ld_exp += (long long)e + step_exp;
+            ++n_ll_steps;
+          }
+          double afi = (lane < m) ? av[lane] : 0.0;
+#pragma unroll
+          for (int o = 0; o < 8; ++o) afi = fma(kr_ss[o], readlane_f64(v_s, o), afi);
+          if (lane < m) af[lane] = afi;
+          wave_sync();
+          if (lane < m) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int kk = 0;
+            for (; kk + 3 < s; kk += 4) {
+              s0 = fma(Tc[lane * LDM + kk], af[kk], s0);
+              s1 = fma(Tc[lane * LDM + kk + 1], af[kk + 1], s1);
+              s2 = fma(Tc[lane * LDM + kk + 2], af[kk + 2], s2);
+              s3 = fma(Tc[lane * LDM + kk + 3], af[kk + 3], s3);
+            }
+            for (; kk < s; ++kk) s0 = fma(Tc[lane * LDM + kk], af[kk], s0);
+            av[lane] = (s0 + s1) + (s2 + s3);
+          }
+          wave_sync();
+          if (dbg) ++ph[6];
+        }
+      }
+      if (dbg) ph[5] += clock64() - tk0;
     }
 #undef STORE_PZT
-    if (dbg && draw == 0 && lane == 0)
-      for (int k = 0; k < 5; ++k) dbg[k] = ph[k];
+    if (dbg && draw == 0 && lane == 0) {
+      ph[7] = clock64() - tk_start;
+      for (int k = 0; k < 8; ++k) dbg[k] = ph[k];
+    }
     if (lane == 0) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
       const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_sum);
       logp_out[draw] = ll;
+      if (steady_at) steady_at[draw] = steady_step;
       if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
     }
   }

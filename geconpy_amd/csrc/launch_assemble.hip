@@ -1,0 +1,54 @@
+// Launchers of the assembly kernels: selection matrix / residual / Lyapunov, policy adjoints, gEcon norms.
+#include "dsge_host.hpp"
+#include "dsge_kernels.hpp"
+
+namespace dsge_host {
+
+int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
+                    const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
+                    double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
+                    hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::assemble_kernel<BS>, dsge::AsmSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::assemble_kernel<BS>, dim3(batch), dim3(64), dsge::AsmSmem<BS>::bytes, st, A, B, C, D, T,
+                         R_in, Q, q_mode, batch, n, k, R_out, resid_out, RQR_out, P0_out, status, do_sel, do_lyap);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 6, {
+    rc = set_lds(dsge::adjoint_kernel<BS>, dsge::AdjSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::adjoint_kernel<BS>, dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
+                         batch, n, Ab, Bb, Cb, status);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
+                 const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::norms_kernel<BS>, dsge::NormSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::norms_kernel<BS>, dim3(batch), dim3(64), dsge::NormSmem<BS>::bytes, st, A, B, C, D, T, R,
+                         mask, batch, n, k, det, sto);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+}  // namespace dsge_host

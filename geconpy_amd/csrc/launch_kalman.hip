@@ -1,0 +1,93 @@
+// Launcher of the Kalman log-likelihood kernels (fast-path tile cascade + general kernel).
+#include "dsge_host.hpp"
+#include "dsge_kernels.hpp"
+#include "dsge_kalman2.hpp"
+
+namespace dsge_host {
+
+long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
+double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
+int32_t* g_kalman_steady_at = nullptr;  // debug: device buffer [batch], first steady step per draw (-1 = never)
+
+int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
+                  const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                  int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
+                  double* logp, int32_t* status, hipStream_t st) {
+  const int bs = tile_bs(m);
+  int rc = DSGE_ERR_INVALID;
+  // Fast path: selector Z, p <= 8, compact state block of at most s_cap columns.  Draws that
+  // violate a hint come back flagged and are re-run by the general kernel below.
+  // Fast path (p <= 8): compact state block of at most s_cap columns; selector Z (gathers) or dense
+  // Z (one extra product per step).  Draws that violate a hint come back flagged and are re-run by
+  // the general kernel below.
+  const bool fast = p <= 8;
+  bool launched_fast = false;
+  if (fast) {
+    // The fast kernel filters only the variables that matter (states + observed non-states), so its
+    // tile size follows that reduced dimension u, not m.  u is only known per draw on the device
+    // (n_state_hint <= u <= n_state_hint + p for a selector), so the instances are tried smallest
+    // first: each one flags the draws that do not fit it, the next one picks up exactly those.
+    // A dense Z may load on every variable: no reduction is assumed for it.
+    int tiles[2];
+    int n_tiles = 0;
+    if (z_selector_hint && n_state_hint > 0 && n_state_hint < m) {
+      tiles[n_tiles++] = tile_bs(n_state_hint);
+      const int hi = tile_bs(n_state_hint + p < m ? n_state_hint + p : m);
+      if (hi != tiles[0]) tiles[n_tiles++] = hi;
+    } else {
+      tiles[n_tiles++] = tile_bs(m);
+    }
+    for (int it = 0; it < n_tiles; ++it) {
+      const int bs_fast = tiles[it];
+      const int rerun = launched_fast ? 1 : 0;
+      rc = DSGE_ERR_INVALID;
+      DISPATCH_BS(bs_fast, 8, {
+        constexpr int NP = 8 * BS;
+        int s_cap = (n_state_hint > 0 && n_state_hint < NP) ? ((n_state_hint + BS - 1) / BS) * BS : NP;
+        if (s_cap > NP) s_cap = NP;
+        if (z_selector_hint) {
+          const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
+          rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
+          if (rc == DSGE_SUCCESS) {
+            hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, P0, Z,
+                               z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
+                               missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                               g_kalman_steady_at);
+            HIP_TRY(hipGetLastError());
+            launched_fast = true;
+          }
+        } else {
+          const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, true);
+          if (lds > LDS_LIMIT) {
+            rc = DSGE_SUCCESS;  // does not fit: the general kernel handles everything
+          } else {
+            rc = set_lds(dsge::kalman_sel_kernel<BS, false>, lds);
+            if (rc == DSGE_SUCCESS) {
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, P0,
+                                 Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
+                                 jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 g_kalman_steady_at);
+              HIP_TRY(hipGetLastError());
+              launched_fast = true;
+            }
+          }
+        }
+      });
+      if (rc) return rc;
+    }
+  }
+  rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    const size_t lds = dsge::KfSmem<BS>::bytes(p);
+    rc = set_lds(dsge::kalman_kernel<BS>, lds);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
+                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status,
+                         launched_fast ? 1 : 0);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+}  // namespace dsge_host

@@ -1,0 +1,37 @@
+// Launchers of the solver kernels: cycle reduction and the backward-looking direct solve.
+#include "dsge_host.hpp"
+#include "dsge_kernels.hpp"
+
+namespace dsge_host {
+
+int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
+              double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
+                         max_iter, tol, T_out, status, n_iter);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
+                   double* R_out, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::bdirect_kernel<BS>, dsge::BdSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::bdirect_kernel<BS>, dim3(batch), dim3(64), dsge::BdSmem<BS>::bytes, st, A, B, D, batch,
+                         n, k, T_out, R_out);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+}  // namespace dsge_host

@@ -91,6 +91,13 @@ class LogpEngine:
         sel = bool(((nz.sum(dim=2) == 1).all() & (nz.sum(dim=1) <= 1).all()).item())
         return n_state, int(sel)
 
+    def record_steady_steps(self, buf):
+        """Debug: ``buf`` (int32 CUDA tensor [batch]) receives, from the fast-path Kalman launches that
+        follow, the first time step each draw ran in steady-state mode (-1 = never); ``None`` stops."""
+        if buf is not None and not (buf.is_cuda and buf.dtype == self.torch.int32 and buf.is_contiguous()):
+            raise ValueError("expected a contiguous int32 CUDA tensor")
+        _lib.check(self.lib.dsge_debug_kalman_steady_steps(None if buf is None else buf.data_ptr()))
+
     # -- product entry points --------------------------------------------------------------
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,

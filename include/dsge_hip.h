@@ -109,8 +109,23 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
                              int n, int k, double tol, int n_lead_hint, double* T_out, double* R_out,
                              int32_t* eu_out, int32_t* status);
 
+/*
+ * Steady-state switch of the fast Kalman kernel.  The covariance recursion of a time-invariant model
+ * does not depend on the data; once max|P_{t+1|t} - P_{t|t-1}| <= tol * max|P| (and while the
+ * missing-data mask stays the same) the kernel reuses F^-1, K and det F and runs only the mean
+ * recursion; a step with a different mask resumes the full update.  tol = 0 never switches (the
+ * recursion of pymc_extras' "standard" filter step for step); the default 1e-14 is rounding level:
+ * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  Process-wide setting.  tol in [0, 1e-6].
+ */
+int dsge_set_kalman_steady_tol(double tol);
+double dsge_get_kalman_steady_tol(void);
+/* Debug hook: device int32[batch] that later fast-path Kalman launches fill with the first time step
+ * that ran in steady-state mode (-1 = never); NULL stops recording. */
+int dsge_debug_kalman_steady_steps(int32_t* steady_at_device);
+
 /* Debug hook: enable != 0 makes the selector-path Kalman kernel record the shader cycles draw 0 spends
- * in each of its five per-step phases; cycles_out (host int64[5], may be NULL) reads them back. */
+ * in each of its five per-step phases, [5] the cycles spent in steady-state steps, [6] their number and
+ * [7] the kernel total; cycles_out (host int64[8], may be NULL) reads them back. */
 int dsge_debug_kalman_phases(int enable, long long* cycles_out);
 
 /* Debug hook: shader-clock stamps of draw 0 at the phase boundaries of the gensys kernel (start,

@@ -600,3 +600,81 @@ def test_policy_adjoints_sw_shaped():
         scale = np.abs(Ar).max()
         assert_allclose(Ab[i], Ar, atol=1e-9 * scale)
         assert_allclose(Cb[i], Cr, atol=1e-9 * scale)
+
+
+def _steady_steps(fn, nb):
+    """Run fn() with the steady-step recorder armed; returns (fn's result, int32[nb] first steady step)."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    eng = LogpEngine(0)
+    buf = torch.full((nb,), -7, dtype=torch.int32, device=eng.device)
+    eng.record_steady_steps(buf)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        eng.record_steady_steps(None)
+    return out, buf.cpu().numpy()
+
+
+def test_kalman_steady_state_switch_matches_full_recursion():
+    """The steady-state switch (default tol 1e-14) must actually engage on the SW-shaped workload and
+    leave logp unchanged at the 1e-12 level relative to the step-for-step recursion (tol = 0) and
+    within LOGP_RTOL of the oracle, which never switches."""
+    nb = 64
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+
+    def run():
+        return batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"],
+                                                 Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+
+    assert batched.get_kalman_steady_tol() == 1e-14
+    r_ss, at = _steady_steps(run, nb)
+    assert np.all(r_ss["status"] == 0)
+    assert np.all(at > 0) and np.all(at < 150), at  # every draw reaches its fixed point well before T_len
+    batched.set_kalman_steady_tol(0.0)
+    try:
+        r_full, at0 = _steady_steps(run, nb)
+    finally:
+        batched.set_kalman_steady_tol(1e-14)
+    assert np.all(at0 == -1)
+    assert_allclose(r_ss["logp"], r_full["logp"], rtol=1e-12)
+    for i in (0, 10, 63):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], om["y"],
+                                       H=np.diag(om["Hdiag"]))
+        assert_allclose(r_ss["logp"][i], ref["logp"], rtol=LOGP_RTOL)
+
+
+@pytest.mark.parametrize("selector", [True, False])
+def test_kalman_steady_state_resumes_on_mask_change(selector):
+    """Missing entries AFTER the switch: the step with a different mask must leave steady mode, run the
+    full update from the current covariance, and (the mask being constant again) re-enter it."""
+    nb, m, k, p, T_len, ns = 5, 24, 4, 4, 160, 9
+    T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=77, selector=selector)
+    T *= 0.5  # spectral radius <= 0.475: the covariance recursion settles within a few dozen steps
+    y[90, 1] = np.nan
+    y[91, 1] = np.nan
+    y[120, :] = oracle.MISSING_FILL
+    y[140:, 2] = np.nan  # a series that stops being observed: second fixed point with another mask
+
+    def run():
+        return batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+
+    (logp, st), at = _steady_steps(run, nb)
+    assert np.all(st == 0)
+    assert np.all((at > 9) & (at < 90)), at
+    for i in range(nb):
+        ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
+        assert_allclose(logp[i], ref, rtol=LOGP_RTOL)
+
+
+def test_kalman_steady_tol_validation():
+    with pytest.raises(_lib.DsgeHipError):
+        batched.set_kalman_steady_tol(-1.0)
+    with pytest.raises(_lib.DsgeHipError):
+        batched.set_kalman_steady_tol(1e-3)
+    assert batched.get_kalman_steady_tol() == 1e-14
