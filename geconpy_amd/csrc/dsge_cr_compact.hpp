@@ -1,0 +1,222 @@
+// Cycle reduction on the column-compact form of the quadratic matrix equation A + B T + C T^2 = 0.
+//
+// In a DSGE model A = dF/dy_{t-1} has non-zero columns only for the state variables S (|S| = s) and
+// C = dF/dy_{t+1} only for the forward-looking variables L (|L| = l); gEconpy's own tests rely on the
+// first fact (tests/model/test_perturbation.py:201-203).  Cycle reduction preserves both supports:
+//   X0 = A1^-1 A0 and A0' = -A0 X0 vanish outside the columns S,  X2 = A1^-1 A2 and A2' = -A2 X2 outside L.
+// So the iteration (gEconpy/solvers/cycle_reduction.py:127-183) runs on R = [A0[:,S] | A2[:,L]], n x (s+l):
+//   X  = A1^-1 R                                   (blocked Gauss-Jordan on [A1 | R], 2 column groups)
+//   P1 = A0[:,S] X[S,:] = [m00 | m02],  P2 = A2[:,L] X[L,:] = [m20 | m22]       (K = s and K = l)
+//   A1 -= scatter(m02 -> columns L) ; A1 -= scatter(m20 -> columns S) ; A1_hat -= scatter(m20)
+//   R  = [-m00 | -m22]
+// Dropping the exactly-zero columns only removes additions of +0.0, so T is bit-identical to the dense
+// kernel's (tests/test_gpu_parity.py::test_cycle_reduction_compact_equals_dense) at
+//   Gauss-Jordan 2/3 of the work, products (s^2 + 2 s l + l^2)/(4 n^2) of it  (SW-shaped: 900/6400).
+// A draw with s + l > 8*BS does not fit the compact tile; it is flagged DSGE_ST_INTERNAL_RERUN and the
+// dense cr_kernel picks it up.
+#pragma once
+#include "dsge_device.hpp"
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge {
+
+template <int BS>
+struct CrcSmem {
+  static constexpr int NP = Tile<BS>::NP, LDW = 2 * NP + 1;
+  // W = [A1 | R], Gauss-Jordan scratch (Lbuf NP*BS, Ybuf BS*2NP), ints: prow, cmap, posS, posL, rsrc
+  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + NP * BS + BS * 2 * NP) + sizeof(int) * 5 * NP;
+};
+
+// non-zero column mask of a register-block matrix (bit v = column v has a non-zero or NaN entry)
+template <int BS>
+__device__ __forceinline__ unsigned long long blk_colmask(const double (&x)[BS][BS]) {
+  unsigned long long mask = 0ull;
+#pragma unroll
+  for (int j = 0; j < BS; ++j) {
+    bool nz = false;
+#pragma unroll
+    for (int i = 0; i < BS; ++i) nz = nz || (x[i][j] != 0.0);
+    unsigned long long b = __ballot(nz);  // bit lr*8+lc
+    b |= b >> 32;
+    b |= b >> 16;
+    b |= b >> 8;
+    b &= 0xffull;  // bit lc: some row block has a non-zero in its column lc*BS+j
+    while (b) {
+      const int lcb = __ffsll((long long)b) - 1;
+      b &= b - 1;
+      const int col = lcb * BS + j;
+      if (col < 64) mask |= 1ull << col;
+    }
+  }
+  return mask;
+}
+
+template <int BS>
+__global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                         const double* __restrict__ C, int batch, int n, int max_iter,
+                                                         double tol, double* __restrict__ T_out,
+                                                         int32_t* __restrict__ status,
+                                                         int32_t* __restrict__ n_iter_out) {
+  constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* W = smem;
+  double* G1 = W + NP;
+  double* Lbuf = W + NP * LDW;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 2 * NP);
+  int* cmap = prow + NP;   // compact column -> variable (S first, then L)
+  int* posS = cmap + NP;   // variable -> compact column of R if it is a state, else -1
+  int* posL = posS + NP;   // variable -> compact column of R if it is a lead variable, else -1
+  int* rsrc = posL + NP;   // compact row r of X sits in row rsrc[r] of W after the elimination
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    wave_sync();
+    for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+    double A1[BS][BS], Ah[BS][BS], Rb[BS][BS];
+    unsigned long long maskS, maskL;
+    {
+      double t[BS][BS];
+      blk_load_global<BS>(t, A + off, n, n, n, lr, lc);
+      maskS = blk_colmask<BS>(t);
+      blk_load_global<BS>(t, C + off, n, n, n, lr, lc);
+      maskL = blk_colmask<BS>(t);
+    }
+    const int s = __popcll(maskS), l = __popcll(maskL), wr = s + l;
+    if (wr > NP) {  // does not fit the compact tile: the dense kernel handles this draw
+      if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
+      continue;
+    }
+    if (lane < NP) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const bool isS = (maskS >> lane) & 1ull, isL = (maskL >> lane) & 1ull;
+      const int ps = __popcll(maskS & below), pl = s + __popcll(maskL & below);
+      posS[lane] = isS ? ps : -1;
+      posL[lane] = isL ? pl : -1;
+      if (isS) cmap[ps] = lane;
+      if (isL) cmap[pl] = lane;
+    }
+    wave_sync();
+    // R = [A[:,S] | C[:,L]] (column gather), A1 = B
+    int ccol[BS];   // source variable of my compact columns (-1 = padding)
+    int vS[BS], vL[BS];  // compact positions of my variable columns
+#pragma unroll
+    for (int j = 0; j < BS; ++j) {
+      const int c = lc * BS + j;
+      ccol[j] = (c < wr) ? cmap[c] : -1;
+      vS[j] = posS[c];
+      vL[j] = posL[c];
+    }
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int r = lr * BS + i, c = lc * BS + j;
+        double v = 0.0;
+        if (r < n && ccol[j] >= 0) v = (c < s) ? A[off + (size_t)r * n + ccol[j]] : C[off + (size_t)r * n + ccol[j]];
+        Rb[i][j] = v;
+      }
+    blk_load_global<BS>(A1, B + off, n, n, n, lr, lc);
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Ah[i][j] = A1[i][j];
+
+    bool converged = false, saw_nan = false;
+    int it = 0;
+    for (; it < max_iter;) {
+      // W = [A1 | R] -> [. | A1^-1 R] (rows in pivot order)
+      blk_store_lds<BS>(A1, W, LDW, lr, lc);
+      blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);  // syncs on entry and exit
+      // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
+      if (lane < NP) rsrc[lane] = (lane < wr) ? prow[cmap[lane]] : 0;
+      wave_sync();
+      {
+        double t[BS][BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+          const int src = rsrc[lr * BS + i];
+#pragma unroll
+          for (int j = 0; j < BS; ++j) t[i][j] = G1[src * LDW + lc * BS + j];
+        }
+        wave_sync();
+        blk_store_lds<BS>(t, G1, LDW, lr, lc);
+      }
+      blk_store_lds<BS>(Rb, W, LDW, lr, lc);  // left operands [A0c | A2c] -> dead column group 0
+      wave_sync();
+      double acc1[BS][BS], acc2[BS][BS];
+      blk_zero<BS>(acc1);
+      blk_zero<BS>(acc2);
+      mm_acc<BS, false>(acc1, W, LDW, G1, LDW, s, lr, lc);                    // [m00 | m02] = A0c X[S,:]
+      mm_acc<BS, false>(acc2, W + s, LDW, G1 + s * LDW, LDW, l, lr, lc);      // [m20 | m22] = A2c X[L,:]
+      wave_sync();
+      blk_store_lds<BS>(acc1, W, LDW, lr, lc);
+      blk_store_lds<BS>(acc2, G1, LDW, lr, lc);
+      wave_sync();
+      double t0[BS][BS], t2[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int row = lr * BS + i, c = lc * BS + j;
+          const double d02 = (vL[j] >= 0) ? W[row * LDW + vL[j]] : 0.0;   // m02[:, posL(v)]
+          const double d20 = (vS[j] >= 0) ? G1[row * LDW + vS[j]] : 0.0;  // m20[:, posS(v)]
+          A1[i][j] -= d02;
+          A1[i][j] -= d20;
+          Ah[i][j] -= d20;
+          t0[i][j] = (c < s) ? acc1[i][j] : 0.0;
+          t2[i][j] = (c >= s && c < wr) ? acc2[i][j] : 0.0;
+          Rb[i][j] = -(t0[i][j] + t2[i][j]);
+        }
+      ++it;
+      const double nrm0 = blk_norm1<BS>(t0);
+      if (nrm0 < tol) {
+        const double nrm2 = blk_norm1<BS>(t2);
+        if (nrm2 < tol) {
+          converged = true;
+          break;
+        }
+      } else if (nrm0 != nrm0) {
+        saw_nan = true;
+        break;
+      }
+      wave_sync();
+    }
+
+    double Tb[BS][BS];
+    blk_zero<BS>(Tb);
+    if (converged) {
+      // T[:,S] = -A1_hat^-1 A[:,S]   (cycle_reduction.py:181); every other column is exactly zero
+      wave_sync();
+      blk_store_lds<BS>(Ah, W, LDW, lr, lc);
+      {
+        double t[BS][BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const int r = lr * BS + i, c = lc * BS + j;
+            t[i][j] = (r < n && c < s) ? A[off + (size_t)r * n + ccol[j]] : 0.0;
+          }
+        blk_store_lds<BS>(t, G1, LDW, lr, lc);
+      }
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j)
+          Tb[i][j] = (vS[j] >= 0) ? -G1[(lr * BS + i) * LDW + vS[j]] : 0.0;
+    }
+    blk_store_global<BS>(Tb, T_out + off, n, n, n, lr, lc);
+    if (lane == 0) {
+      status[draw] = converged ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
+      if (n_iter_out) n_iter_out[draw] = it;
+    }
+  }
+}
+
+}  // namespace dsge

@@ -24,6 +24,10 @@ struct Tile {
   static constexpr int LD = NP | 1;
 };
 
+// internal per-draw status value: "a structure-exploiting kernel could not take this draw; the general
+// kernel must".  Never returned to the caller.
+constexpr int32_t DSGE_ST_INTERNAL_RERUN = 1 << 30;
+
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
 // NaN-propagating max (np.max semantics, used by the induced 1-norm)

@@ -31,8 +31,6 @@
 
 namespace dsge {
 
-constexpr int32_t DSGE_ST_INTERNAL_RERUN = 1 << 30;
-
 template <int BS>
 struct Kf2Smem {
   static constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD;

@@ -30,7 +30,8 @@ template <int BS>
 __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                  const double* __restrict__ C, int batch, int n, int max_iter,
                                                  double tol, double* __restrict__ T_out,
-                                                 int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out) {
+                                                 int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
+                                                 int rerun_only) {
   constexpr int NP = CrSmem<BS>::NP, LD = CrSmem<BS>::LD, LDW = CrSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
@@ -41,6 +42,8 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
   (void)LD;
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    // second pass of the cascade: only the draws the column-compact kernel could not take
+    if (rerun_only && status[draw] != DSGE_ST_INTERNAL_RERUN) continue;
     const size_t off = (size_t)draw * n * n;
     wave_sync();
     for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;

@@ -1,18 +1,36 @@
 // Launchers of the solver kernels: cycle reduction and the backward-looking direct solve.
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
+#include "dsge_cr_compact.hpp"
 
 namespace dsge_host {
+
+int g_cr_compact = 1;  // 0 = dense kernel only (tests compare the two paths)
 
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
+  // Column-compact kernel first (zero columns of A and C dropped); it flags the draws whose
+  // s + l exceeds the tile, and the dense kernel then runs on exactly those.
+  const bool compact = g_cr_compact && bs <= 6;
+  if (compact) {
+    DISPATCH_BS(bs, 6, {
+      rc = set_lds(dsge::cr_compact_kernel<BS>, dsge::CrcSmem<BS>::bytes);
+      if (rc == DSGE_SUCCESS) {
+        hipLaunchKernelGGL(dsge::cr_compact_kernel<BS>, dim3(batch), dim3(64), dsge::CrcSmem<BS>::bytes, st, A, B, C,
+                           batch, n, max_iter, tol, T_out, status, n_iter);
+        HIP_TRY(hipGetLastError());
+      }
+    });
+    if (rc) return rc;
+  }
+  rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 8, {
     rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
-                         max_iter, tol, T_out, status, n_iter);
+                         max_iter, tol, T_out, status, n_iter, compact ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
   });

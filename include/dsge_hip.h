@@ -87,6 +87,11 @@ int dsge_cycle_reduction_batched(const double* A, const double* B, const double*
 int dsge_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
                                       int max_iter, double tol, double* T_out, int32_t* status,
                                       int32_t* n_iter);
+/* Cycle reduction runs on the column-compact form [A[:,S] | C[:,L]] (S, L = non-zero columns of A and C,
+ * detected per draw on the device; zero columns only ever contribute +0.0, so T is bit-identical) whenever
+ * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every
+ * draw (used by the tests to compare the two).  Process-wide; default 1. */
+int dsge_set_cr_compact(int enable);
 
 /*
  * gensys, batched.  Replaces _gensys_setup + _gensys_core as GensysWrapper / gensys_pt use them

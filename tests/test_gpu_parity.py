@@ -678,3 +678,40 @@ def test_kalman_steady_tol_validation():
     with pytest.raises(_lib.DsgeHipError):
         batched.set_kalman_steady_tol(1e-3)
     assert batched.get_kalman_steady_tol() == 1e-14
+
+
+def test_cycle_reduction_compact_equals_dense(sw_golden, ref_goldens, rbc_golden):
+    """The column-compact kernel drops only exactly-zero columns of A and C: T, status and iteration
+    counts must be IDENTICAL (bit for bit) to the dense kernel's, on the SW-shaped systems, the
+    reference goldens and the RBC draws; a system with dense A and C must fall through to the dense
+    kernel and still be solved."""
+    lib = _lib.load()
+    b = wl.sw_shaped_batch(int(sw_golden["n_draws"]))
+    th = {k[6:]: rbc_golden[k] for k in rbc_golden.files if k.startswith("theta_")}
+    sets = [tuple(b[x] for x in "ABC"), wl.rbc_linearized_jacobians(**th)[:3]]
+    for key in ("one_block", "rbc_2_block", "full_nk"):
+        sets.append(tuple(ref_goldens[f"{key}_{x}"][None] for x in "ABC"))
+    for A, B, C in sets:
+        assert (np.abs(A).sum(axis=-2) == 0).sum() > 0  # the structure the compact kernel exploits is there
+        T1, st1, it1 = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9)
+        _lib.check(lib.dsge_set_cr_compact(0))
+        try:
+            T0, st0, it0 = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9)
+        finally:
+            _lib.check(lib.dsge_set_cr_compact(1))
+        assert np.array_equal(st0, st1) and np.array_equal(it0, it1) and np.all(st1 == 0)
+        assert np.array_equal(T0, T1)
+    # dense A and C: |S| + |L| = 2n > 8*ceil(n/8) -> dense kernel
+    rng = np.random.default_rng(5)
+    n = 12
+    Tstar = rng.standard_normal((3, n, n))
+    Tstar *= 0.5 / np.abs(np.linalg.eigvals(Tstar)).max(axis=1)[:, None, None]
+    G = rng.standard_normal((3, n, n))
+    G *= 0.4 / np.abs(np.linalg.eigvals(G)).max(axis=1)[:, None, None]
+    M = np.eye(n) + 0.2 * rng.standard_normal((3, n, n))
+    C = M @ G
+    B = M - C @ Tstar
+    A = -M @ Tstar
+    T, st, _ = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-12)
+    assert np.all(st == 0)
+    assert_allclose(T, Tstar, atol=1e-9)
