@@ -276,9 +276,9 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
   double* RQR = cv.take<double>(mm);
   double* P0 = cv.take<double>(mm);
   if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T, R, Q, q_mode, batch, m, k, nullptr, nullptr, RQR, P0,
-                            status_io, 0, 1, st)))
+                            status_io, 0, 2, st)))
     return rc;
-  return launch_kalman(T, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter,
+  return launch_kalman(T, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter,
                        missing_fill, n_state_hint, z_selector_hint, logp_out, status_io, st);
 }
 
@@ -333,11 +333,11 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
     // backward_direct already produced R; the assemble kernel recomputes it from the same
     // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
-    if ((rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, RQR, P0, status_out, 1, 1,
+    if ((rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, RQR, P0, status_out, 1, 2,
                               st)))
       return rc;
     if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
-    if ((rc = launch_kalman(Tw, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
+    if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
                             missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st)))
       return rc;
     if (ms_out) {

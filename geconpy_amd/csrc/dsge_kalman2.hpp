@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
           zcol[i] = zv[o];
         }
     }
-    double Qb[BS][BS], Pb[BS][BS];
+    double Qb[BS][BS], Pb[BS][BS], Tb0[BS][BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -211,9 +211,70 @@ __global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
         const size_t g = in ? (size_t)pr[i] * m_full + pcx[j] : 0;
         const double tv = in ? T[off + g] : 0.0;
         Qb[i][j] = in ? RQR[off + g] : 0.0;
-        Pb[i][j] = in ? P0[off + g] : 0.0;
+        Pb[i][j] = (in && P0) ? P0[off + g] : 0.0;
+        Tb0[i][j] = tv;
         Tc[(lr * BS + i) * LDM + lc * BS + j] = tv;  // columns >= s are exactly zero
       }
+    const bool in_state_block = (lr * BS < s) && (lc * BS < s);
+    if (!P0) {
+      // ---- stationary covariance of the REDUCED model, P0 = dlyap(T, RQR')[U,U], by doubling:
+      //   P <- P + A_k[:,S] P[S,S] A_k[:,S]',  A_{k+1} = A_k[:,S] A_k[S,:],  A_0 = T[U,:]
+      // (statespace.py:814-815; the recursion closes on U because the columns of T outside S vanish:
+      // (T M T')[U,U] = T[U,S] M[S,S] T[U,S]').  Same products as the prediction step below.
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Pb[i][j] = Qb[i][j];
+      bool lyap_ok = false;
+      for (int itl = 0; itl < 64; ++itl) {
+        wave_sync();
+        if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDM, lr, lc);
+        wave_sync();
+        if (lr * BS < s) {
+          double Wb[BS][BS];
+          blk_zero<BS>(Wb);
+          mm_acc_p<BS, true, LDM, LDM>(Wb, Pc, Tc, s, lr, lc);  // P[S,S] A_k'
+          blk_store_lds<BS>(Wb, Wc, LDM, lr, lc);
+        }
+        double Ab[BS][BS];
+        blk_zero<BS>(Ab);
+        mm_acc_p<BS, false, LDM, LDM>(Ab, Tc, Tc, s, lr, lc);  // A_k[:,S] A_k[S,:] (states come first)
+        wave_sync();
+        double Xb[BS][BS];
+        blk_zero<BS>(Xb);
+        mm_acc_p<BS, false, LDM, LDM>(Xb, Tc, Wc, s, lr, lc);
+        wave_sync();
+        blk_store_lds<BS>(Ab, Tc, LDM, lr, lc);
+        const int src = (lc << 3) | lr;
+        double dmax = 0.0, pmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const double xt = __shfl(Xb[j][i], src, 64);
+            const double dlt = 0.5 * (Xb[i][j] + xt);
+            Pb[i][j] += dlt;
+            dmax = nanmax(dmax, fabs(dlt));
+            pmax = nanmax(pmax, fabs(Pb[i][j]));
+          }
+        dmax = wave_nanmax(dmax);
+        pmax = wave_nanmax(pmax);
+        if (!(dmax == dmax) || !(pmax < 1e300)) break;  // NaN / overflow: rho(T) >= 1
+        if (dmax <= 1e-17 * pmax) {
+          lyap_ok = true;
+          break;
+        }
+      }
+      wave_sync();
+      blk_store_lds<BS>(Tb0, Tc, LDM, lr, lc);  // the transition itself again
+      if (!lyap_ok) {
+        if (lane == 0) {
+          status[draw] |= DSGE_ST_LYAP_FAIL;
+          logp_out[draw] = -INFINITY;
+        }
+        continue;
+      }
+    }
     if (lane < 8) {
       dd[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
       hh[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
@@ -222,7 +283,6 @@ __global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
     int pz_dst[BS];
 #pragma unroll
     for (int j = 0; j < BS; ++j) pz_dst[j] = ocol[j];
-    const bool in_state_block = (lr * BS < s) && (lc * BS < s);
     // P Z' for the coming step: a column gather (selector) or a product against the full P (dense Z)
 #define STORE_PZT()                                                                                   \
   do {                                                                                                \

@@ -220,19 +220,24 @@ __global__ __launch_bounds__(64) void assemble_kernel(
   int* prow = (int*)(Ybuf + BS * 2 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
 
+  // do_lyapunov: 0 none | 1 RQR' and P0 from R, Q | 2 RQR' only | 3 P0 from RQR_out (read) for the draws
+  // flagged DSGE_ST_INTERNAL_RERUN only | 4 P0 from RQR_out (read) for every healthy draw
+  const bool lyap_from_rqr = (do_lyapunov == 3 || do_lyapunov == 4);
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     const size_t offk = (size_t)draw * n * k;
-    if (status && status[draw] != 0) {
+    if (do_lyapunov == 3) {
+      if (status[draw] != DSGE_ST_INTERNAL_RERUN) continue;
+    } else if (status && status[draw] != 0) {
       // failed solve: nothing to assemble; outputs zero-filled so downstream stays finite
       double z[BS][BS];
       blk_zero<BS>(z);
       if (do_selection && R_out) blk_store_global<BS>(z, R_out + offk, n, k, k, lr, lc);
       if (do_selection && resid_out && lane == 0) resid_out[draw] = INFINITY;
-      if (do_lyapunov) {
+      if (do_lyapunov == 1 || do_lyapunov == 2) {
         if (RQR_out) blk_store_global<BS>(z, RQR_out + off, n, n, n, lr, lc);
-        blk_store_global<BS>(z, P0_out + off, n, n, n, lr, lc);
       }
+      if ((do_lyapunov == 1 || do_lyapunov == 4) && P0_out) blk_store_global<BS>(z, P0_out + off, n, n, n, lr, lc);
       continue;
     }
     wave_sync();
@@ -279,11 +284,13 @@ __global__ __launch_bounds__(64) void assemble_kernel(
 #pragma unroll
         for (int j = 0; j < BS; ++j) Rb[i][j] = -Rb[i][j];
       if (R_out) blk_store_global<BS>(Rb, R_out + offk, n, k, k, lr, lc);
-    } else {
+    } else if (!lyap_from_rqr) {
       blk_load_global<BS>(Rb, R_in + offk, n, k, k, lr, lc);
     }
     if (!do_lyapunov) continue;
 
+    double Pb[BS][BS];
+    if (!lyap_from_rqr) {
     // ---- R -> G0 (the transposed operand), R Q -> G1
     wave_sync();
     blk_store_lds<BS>(Rb, G0, LDW, lr, lc);
@@ -314,7 +321,6 @@ __global__ __launch_bounds__(64) void assemble_kernel(
       blk_store_lds<BS>(RQ, G1, LDW, lr, lc);
       wave_sync();
     }
-    double Pb[BS][BS];
     blk_zero<BS>(Pb);
     mm_acc<BS, true>(Pb, G1, LDW, G0, LDW, k, lr, lc);  // (R Q) R'
     // symmetrise through G0
@@ -330,6 +336,10 @@ __global__ __launch_bounds__(64) void assemble_kernel(
         for (int j = 0; j < BS; ++j) Pb[i][j] = 0.5 * (Pb[i][j] + Pt[i][j]);
     }
     if (RQR_out) blk_store_global<BS>(Pb, RQR_out + off, n, n, n, lr, lc);
+    if (do_lyapunov == 2) continue;
+    } else {
+      blk_load_global<BS>(Pb, RQR_out + off, n, n, n, lr, lc);  // sym(R Q R') computed by an earlier launch
+    }
     wave_sync();
     blk_store_lds<BS>(Pb, G1, LDW, lr, lc);  // P_0 = RQR
     wave_sync();
@@ -641,9 +651,14 @@ __global__ __launch_bounds__(64) void kalman_kernel(
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     if (rerun_only) {
       // second pass after kalman_sel_kernel: only the draws it could not handle
-      if (status[draw] != (1 << 30)) continue;
+      const int32_t st_in = status[draw];
+      if (!(st_in & DSGE_ST_INTERNAL_RERUN)) continue;
       wave_sync();
-      if (lane == 0) status[draw] = 0;
+      if (lane == 0) status[draw] = st_in & ~DSGE_ST_INTERNAL_RERUN;
+      if (st_in != DSGE_ST_INTERNAL_RERUN) {  // a failure was recorded on the way here (e.g. Lyapunov)
+        if (lane == 0) logp_out[draw] = -INFINITY;
+        continue;
+      }
     } else if (status && status[draw] != 0) {
       if (lane == 0) logp_out[draw] = -INFINITY;
       continue;

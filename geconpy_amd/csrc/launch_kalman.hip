@@ -9,7 +9,10 @@ long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles
 double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
 int32_t* g_kalman_steady_at = nullptr;  // debug: device buffer [batch], first steady step per draw (-1 = never)
 
-int launch_kalman(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched,
+// p0_valid = 0: P0 is an uninitialised scratch buffer.  The fast kernels then compute the stationary
+// covariance themselves (on the reduced model); only the draws that end up in the general kernel get
+// their full-size P0 from the assemble kernel's Lyapunov pass (from RQR, which must be valid).
+int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st) {
@@ -49,8 +52,8 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
           const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
           rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
           if (rc == DSGE_SUCCESS) {
-            hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, P0, Z,
-                               z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
+            hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+                               p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
                                missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                g_kalman_steady_at);
             HIP_TRY(hipGetLastError());
@@ -63,8 +66,8 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
           } else {
             rc = set_lds(dsge::kalman_sel_kernel<BS, false>, lds);
             if (rc == DSGE_SUCCESS) {
-              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, P0,
-                                 Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR,
+                                 p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
                                  jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at);
               HIP_TRY(hipGetLastError());
@@ -75,6 +78,12 @@ int launch_kalman(const double* T, const double* RQR, const double* P0, const do
       });
       if (rc) return rc;
     }
+  }
+  if (!p0_valid) {
+    // full-size P0 for the general kernel: flagged draws only when a fast kernel ran, else every draw
+    if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, batch, m, 1, nullptr, nullptr,
+                              RQR, P0, status, 0, launched_fast ? 3 : 4, st)))
+      return rc;
   }
   rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 8, {
