@@ -340,11 +340,15 @@ __global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
       const unsigned long long omask = __ballot(obs);
       const int n_obs = __popcll(omask);
       bool steady = false;
-      double Pprev[BS][BS];
+      // scale of the steady-state test: max |P_{t|t-1}| (the filtered block P+[S,S] that is compared can be
+      // orders of magnitude smaller than P when the observations are precise; its rounding noise is not)
+      double pscale = 0.0;
+      if (steady_tol > 0.0) {
 #pragma unroll
-      for (int i = 0; i < BS; ++i)
+        for (int i = 0; i < BS; ++i)
 #pragma unroll
-        for (int j = 0; j < BS; ++j) Pprev[i][j] = Pb[i][j];
+          for (int j = 0; j < BS; ++j) pscale = nanmax(pscale, fabs(Pb[i][j]));
+      }
       const double wo = (double)((omask >> fo) & 1ull), wq = (double)((omask >> fq) & 1ull);
       // ---- (b) F[fo][fq] and the innovation -------------------------------------------
       double f;
@@ -495,6 +499,23 @@ __global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
         for (int i = 0; i < BS; ++i)
           if (lr * BS + i < m) Pb[i][i] += jitter;
       }
+      // steady-state test on the filtered state block: P_{t+1|t} depends on P+ only through P+[S,S], so the
+      // covariance recursion has reached its fixed point once that block stops moving.  The previous
+      // step's block is still in LDS (Pc): compare before overwriting it.
+      if (steady_tol > 0.0) {
+        double dmax = 0.0;
+        if (in_state_block) {
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j)
+              dmax = nanmax(dmax, fabs(Pb[i][j] - Pc[(lr * BS + i) * LDM + lc * BS + j]));
+        }
+        // non-negative doubles order like their bit patterns; a NaN compares above everything
+        const double dm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(dmax)));
+        const double pm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(pscale)));
+        steady = (t > 0) && (dm <= steady_tol * pm);
+      }
       if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDM, lr, lc);
       wave_sync();  // #3
       if (dbg) {
@@ -531,23 +552,13 @@ __global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
         blk_zero<BS>(Xb);
         mm_acc_p<BS, false, LDM, LDM>(Xb, Tc, Wc, s, lr, lc);
         const int src = (lc << 3) | lr;  // lane holding the transposed block
-        double dmax = 0.0, pmax = 0.0;
-        steady = false;
 #pragma unroll
         for (int i = 0; i < BS; ++i)
 #pragma unroll
           for (int j = 0; j < BS; ++j) {
             const double xt = __shfl(Xb[j][i], src, 64);
             Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
-            dmax = nanmax(dmax, fabs(Pb[i][j] - Pprev[i][j]));
-            pmax = nanmax(pmax, fabs(Pb[i][j]));
           }
-        if (steady_tol > 0.0) {
-          // non-negative doubles order like their bit patterns; a NaN compares above everything
-          const double dm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(dmax)));
-          const double pm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(pmax)));
-          steady = (dm <= steady_tol * pm);
-        }
       }
       // ---- P Z' for the next step -------------------------------------------------------------
       STORE_PZT();
