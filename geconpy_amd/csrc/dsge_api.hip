@@ -127,6 +127,23 @@ extern "C" {
 int dsge_abi_version(void) { return DSGE_ABI_VERSION; }
 const char* dsge_last_error(void) { return g_last_error.c_str(); }
 
+int dsge_debug_cr_phases(int enable, long long* cycles_out) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (enable && !g_cr_dbg) {
+    HIP_TRY(hipMalloc((void**)&g_cr_dbg, 8 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_cr_dbg, 0, 8 * sizeof(long long)));
+  }
+  if (cycles_out && g_cr_dbg) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_out, g_cr_dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && g_cr_dbg) {
+    (void)hipFree(g_cr_dbg);
+    g_cr_dbg = nullptr;
+  }
+  return DSGE_SUCCESS;
+}
 int dsge_set_cr_compact(int enable) {
   g_cr_compact = enable ? 1 : 0;
   return DSGE_SUCCESS;

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
                                                          const double* __restrict__ C, int batch, int n, int max_iter,
                                                          double tol, double* __restrict__ T_out,
                                                          int32_t* __restrict__ status,
-                                                         int32_t* __restrict__ n_iter_out) {
+                                                         int32_t* __restrict__ n_iter_out,
+                                                         long long* __restrict__ dbg) {
   constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
@@ -126,11 +127,16 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
 
     bool converged = false, saw_nan = false;
     int it = 0;
+    // debug stamps (draw 0): [0] GJ panels, [1] GJ trailing updates, [2] row gather + staging, [3] products,
+    // [4] scatter/update/norms, [5] final solve, [6] total
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk_start = dbg ? clock64() : 0;
     for (; it < max_iter;) {
       // W = [A1 | R] -> [. | A1^-1 R] (rows in pivot order)
       blk_store_lds<BS>(A1, W, LDW, lr, lc);
       blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
-      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);  // syncs on entry and exit
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, dbg ? ph : nullptr);  // syncs on entry and exit
+      long long tk0 = dbg ? clock64() : 0;
       // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
       if (lane < NP) rsrc[lane] = (lane < wr) ? prow[cmap[lane]] : 0;
       wave_sync();
@@ -147,12 +153,22 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
       }
       blk_store_lds<BS>(Rb, W, LDW, lr, lc);  // left operands [A0c | A2c] -> dead column group 0
       wave_sync();
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[2] += tk1 - tk0;
+        tk0 = tk1;
+      }
       double acc1[BS][BS], acc2[BS][BS];
       blk_zero<BS>(acc1);
       blk_zero<BS>(acc2);
       mm_acc<BS, false>(acc1, W, LDW, G1, LDW, s, lr, lc);                    // [m00 | m02] = A0c X[S,:]
       mm_acc<BS, false>(acc2, W + s, LDW, G1 + s * LDW, LDW, l, lr, lc);      // [m20 | m22] = A2c X[L,:]
       wave_sync();
+      if (dbg) {
+        const long long tk1 = clock64();
+        ph[3] += tk1 - tk0;
+        tk0 = tk1;
+      }
       blk_store_lds<BS>(acc1, W, LDW, lr, lc);
       blk_store_lds<BS>(acc2, G1, LDW, lr, lc);
       wave_sync();
@@ -173,8 +189,9 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
         }
       ++it;
       const double nrm0 = blk_norm1<BS>(t0);
+      const double nrm2 = blk_norm1<BS>(t2);
+      if (dbg) ph[4] += clock64() - tk0;
       if (nrm0 < tol) {
-        const double nrm2 = blk_norm1<BS>(t2);
         if (nrm2 < tol) {
           converged = true;
           break;
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
       }
       wave_sync();
     }
+    const long long tk_fin = dbg ? clock64() : 0;
 
     double Tb[BS][BS];
     blk_zero<BS>(Tb);
@@ -215,6 +233,13 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
     if (lane == 0) {
       status[draw] = converged ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
       if (n_iter_out) n_iter_out[draw] = it;
+      if (dbg && draw == 0) {
+        const long long tk_end = clock64();
+        ph[5] = tk_end - tk_fin;
+        ph[6] = tk_end - tk_start;
+        ph[7] = it;
+        for (int q = 0; q < 8; ++q) dbg[q] = ph[q];
+      }
     }
   }
 }

@@ -269,6 +269,24 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
 }
 
+// max over the 64 lanes of an unsigned 32-bit key (identity 0); wave-uniform result.  One v_max_u32 with a
+// DPP operand per step.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define DSGE_DPP_MAX(CTRL, ROWS)                                                                   \
+  do {                                                                                             \
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false);   \
+    v = t > v ? t : v;                                                                             \
+  } while (0)
+  DSGE_DPP_MAX(0x111, 0xf);  // row_shr:1
+  DSGE_DPP_MAX(0x112, 0xf);  // row_shr:2
+  DSGE_DPP_MAX(0x114, 0xf);  // row_shr:4
+  DSGE_DPP_MAX(0x118, 0xf);  // row_shr:8
+  DSGE_DPP_MAX(0x142, 0xa);  // row_bcast:15 -> rows 1,3
+  DSGE_DPP_MAX(0x143, 0xc);  // row_bcast:31 -> rows 2,3
+#undef DSGE_DPP_MAX
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_move_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -329,7 +347,7 @@ __device__ __forceinline__ double readlane_dyn_f64(double v, int src_lane_unifor
 // Lbuf (NP*BS doubles), Ybuf (BS * ngroups*NP doubles), prow (NP ints).
 template <int BS>
 __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,
-                                                     int* prow, int lane) {
+                                                     int* prow, int lane, long long* ph = nullptr) {
   constexpr int NP = 8 * BS;
   const int lr = lane >> 3, lc = lane & 7;
   const int wcols = ngroups * NP;
@@ -339,6 +357,7 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
     const int j0 = kb * BS;
     const int bw = (n - j0 < BS) ? (n - j0) : BS;
     wave_sync();
+    const long long tk_p = ph ? clock64() : 0;
     // ---- panel: one matrix row per lane, augmented with the identity slots ------------
     double pw[BS], id[BS];
 #pragma unroll
@@ -351,16 +370,19 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
     for (int c = 0; c < BS; ++c) {
       rsel[c] = 0;
       if (c < bw) {
+        // pivot = largest |entry| among the unused rows, compared on the high 32 bits of the double (sign
+        // cleared; exponent + 20 mantissa bits; low 6 bits carry 63 - lane so that ties go to the first row):
+        // within 2^-14 of the true maximum, which is all partial pivoting needs, at one v_max_u32 per DPP step
         const bool cand = (lane < n) && !((used >> lane) & 1ull);
-        unsigned long long key = 0ull;
-        if (cand) key = ((unsigned long long)__double_as_longlong(fabs(pw[c])) & ~63ull) | (unsigned long long)(63 - lane);
-        key = wave_max_u64(key);
-        const int r = __builtin_amdgcn_readfirstlane(63 - (int)(key & 63ull));
+        unsigned key = 0u;
+        if (cand) key = (((unsigned)__double2hiint(pw[c]) & 0x7fffffffu) & ~63u) | (unsigned)(63 - lane);
+        key = wave_max_u32(key);
+        const int r = 63 - (int)(key & 63u);
         rsel[c] = r;
         used |= 1ull << r;
         if (lane == r) id[c] = 1.0;
         // broadcast the pivot lane's row, scale it, eliminate everywhere else
-        const double inv = 1.0 / readlane_dyn_f64(pw[c], r);
+        const double inv = fast_rcp(readlane_dyn_f64(pw[c], r));
         double prw[BS], pri[BS];
 #pragma unroll
         for (int c2 = 0; c2 < BS; ++c2) {
@@ -406,6 +428,8 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
     for (int a = 0; a < BS; ++a)
       if (a < bw && lane == 0) prow[j0 + a] = rsel[a];
     wave_sync();
+    const long long tk_t = ph ? clock64() : 0;
+    if (ph) ph[0] += tk_t - tk_p;
     // ---- trailing update on register blocks: W[i,:] -= Lhat[i,:] Wpiv ---------------------
     double lh[BS][BS];
 #pragma unroll
@@ -436,6 +460,7 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
 #pragma unroll
         for (int j = 0; j < BS; ++j) W[(lr * BS + i) * ldw + c0 + j] = wb[i][j];
     }
+    if (ph) ph[1] += clock64() - tk_t;
   }
   wave_sync();
 }

@@ -6,6 +6,7 @@
 namespace dsge_host {
 
 int g_cr_compact = 1;  // 0 = dense kernel only (tests compare the two paths)
+long long* g_cr_dbg = nullptr;  // debug: device int64[8], phase cycles of draw 0 of the compact kernel
 
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
@@ -19,7 +20,7 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
       rc = set_lds(dsge::cr_compact_kernel<BS>, dsge::CrcSmem<BS>::bytes);
       if (rc == DSGE_SUCCESS) {
         hipLaunchKernelGGL(dsge::cr_compact_kernel<BS>, dim3(batch), dim3(64), dsge::CrcSmem<BS>::bytes, st, A, B, C,
-                           batch, n, max_iter, tol, T_out, status, n_iter);
+                           batch, n, max_iter, tol, T_out, status, n_iter, g_cr_dbg);
         HIP_TRY(hipGetLastError());
       }
     });

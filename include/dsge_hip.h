@@ -92,6 +92,10 @@ int dsge_cycle_reduction_batched_host(const double* A, const double* B, const do
  * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every
  * draw (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_cr_compact(int enable);
+/* Debug hook: enable != 0 makes the compact cycle-reduction kernel record the shader cycles draw 0 spends in
+ * [0] Gauss-Jordan panels, [1] trailing updates, [2] row gather + staging, [3] products, [4] scatter/updates/
+ * norms, [5] the final solve, [6] total, [7] = iterations; cycles_out (host int64[8], may be NULL). */
+int dsge_debug_cr_phases(int enable, long long* cycles_out);
 
 /*
  * gensys, batched.  Replaces _gensys_setup + _gensys_core as GensysWrapper / gensys_pt use them
