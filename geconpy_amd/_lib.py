@@ -27,11 +27,12 @@ ST_GENSYS_QZ_FAIL = 16
 ST_GENSYS_TOO_BIG = 32
 
 Q_DIAG_SHARED, Q_DIAG_BATCHED, Q_FULL_SHARED, Q_FULL_BATCHED = 0, 1, 2, 3
-SOLVER_CYCLE_REDUCTION, SOLVER_GENSYS, SOLVER_BACKWARD_DIRECT = 0, 1, 2
+SOLVER_CYCLE_REDUCTION, SOLVER_GENSYS, SOLVER_BACKWARD_DIRECT, SOLVER_SCAN_CYCLE_REDUCTION = 0, 1, 2, 3
 SOLVER_CODES = {
     "cycle_reduction": SOLVER_CYCLE_REDUCTION,
     "gensys": SOLVER_GENSYS,
     "backward_direct": SOLVER_BACKWARD_DIRECT,
+    "scan_cycle_reduction": SOLVER_SCAN_CYCLE_REDUCTION,
 }
 
 
@@ -52,6 +53,8 @@ PROTOTYPES = {
     "dsge_stream_synchronize": [_dp],
     "dsge_cycle_reduction_batched": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp, _dp],
     "dsge_cycle_reduction_batched_host": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp],
+    "dsge_scan_cycle_reduction_batched": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp, _dp],
+    "dsge_scan_cycle_reduction_batched_host": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp],
     "dsge_gensys_batched": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_gensys_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_set_cr_compact": [_i],

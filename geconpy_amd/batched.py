@@ -50,6 +50,21 @@ def cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9):
     return T, status, n_iter
 
 
+def scan_cycle_reduction_batched(A, B, C, max_iter=50, tol=1e-7):
+    """Batched ``scan_cycle_reduction`` (gEconpy/solvers/cycle_reduction.py:246-325) -> (T, status, n_steps):
+    A0-norm-only stopping rule, fixed trip count, 1e-16 diagonal jitter in every solve."""
+    A, B, C = _check_abc(A, B, C)
+    nb, n, _ = A.shape
+    T = np.empty_like(A)
+    status = np.empty(nb, dtype=np.int32)
+    n_steps = np.empty(nb, dtype=np.int32)
+    _lib.check(
+        _lib.load().dsge_scan_cycle_reduction_batched_host(_ptr(A), _ptr(B), _ptr(C), nb, n, int(max_iter), float(tol),
+                                                           _ptr(T), _ptr(status), _ptr(n_steps))
+    )
+    return T, status, n_steps
+
+
 def lead_hint(C, tol=0.0):
     """Performance hint: number of columns of ``C`` (any leading batch axes) whose absolute column
     sum exceeds ``tol`` in at least one draw -- the forward-looking variables (gensys.py:580-589)."""

@@ -183,15 +183,26 @@ int dsge_stream_synchronize(void* stream) {
   return DSGE_SUCCESS;
 }
 
-int dsge_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n, int max_iter,
-                                 double tol, double* T_out, int32_t* status, int32_t* n_iter, void* stream) {
+static int cr_entry(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
+                    double* T_out, int32_t* status, int32_t* n_iter, void* stream, int scan_mode) {
   int rc = check_common(batch, n, DSGE_MAX_N_CR);
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if (max_iter < 0) return fail(DSGE_ERR_INVALID, "max_iter < 0");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
-  return launch_cr(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, (hipStream_t)stream);
+  return launch_cr(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, (hipStream_t)stream, scan_mode);
+}
+
+int dsge_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n, int max_iter,
+                                 double tol, double* T_out, int32_t* status, int32_t* n_iter, void* stream) {
+  return cr_entry(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, stream, 0);
+}
+
+int dsge_scan_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n,
+                                      int max_iter, double tol, double* T_out, int32_t* status, int32_t* n_steps,
+                                      void* stream) {
+  return cr_entry(A, B, C, batch, n, max_iter, tol, T_out, status, n_steps, stream, 1);
 }
 
 int dsge_gensys_batched(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
@@ -305,14 +316,16 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
                     double jitter, double missing_fill, int n_state_hint, int z_selector_hint, int n_lead_hint,
                     double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* resid_out,
                     int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out) {
-  int rc = check_common(batch, n, solver == DSGE_SOLVER_CYCLE_REDUCTION ? DSGE_MAX_N_CR : DSGE_MAX_N);
+  const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
+  int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
   if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
-  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_BACKWARD_DIRECT && solver != DSGE_SOLVER_GENSYS)
+  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_BACKWARD_DIRECT && solver != DSGE_SOLVER_GENSYS &&
+      solver != DSGE_SOLVER_SCAN_CYCLE_REDUCTION)
     return fail(DSGE_ERR_INVALID, "unknown solver code");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
@@ -336,8 +349,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   const int n_rep = ms_out ? reps : 1;
   for (int rep = 0; rep < n_rep; ++rep) {
     if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
-    if (solver == DSGE_SOLVER_CYCLE_REDUCTION) {
-      rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, n_iter_out, st);
+    if (is_cr) {
+      rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, n_iter_out, st,
+                     solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0);
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
       rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st);
@@ -411,8 +425,22 @@ int dsge_profile_pipeline(const double* A, const double* B, const double* C, con
 #define DOWN(host, dev, count, type)                                                                \
   if (host) HIP_TRY(hipMemcpyAsync(host, dev, sizeof(type) * (count), hipMemcpyDeviceToHost, nullptr));
 
+static int cr_host(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
+                   double* T_out, int32_t* status, int32_t* n_iter, int scan_mode);
+
 int dsge_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
                                       int max_iter, double tol, double* T_out, int32_t* status, int32_t* n_iter) {
+  return cr_host(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, 0);
+}
+
+int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
+                                           int max_iter, double tol, double* T_out, int32_t* status,
+                                           int32_t* n_steps) {
+  return cr_host(A, B, C, batch, n, max_iter, tol, T_out, status, n_steps, 1);
+}
+
+static int cr_host(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
+                   double* T_out, int32_t* status, int32_t* n_iter, int scan_mode) {
   int rc = check_common(batch, n, DSGE_MAX_N_CR);
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
@@ -428,7 +456,7 @@ int dsge_cycle_reduction_batched_host(const double* A, const double* B, const do
   OUTBUF(dT, T_out, nn, double);
   OUTBUF(dS, status, batch, int32_t);
   OUTBUF(dI, n_iter, batch, int32_t);
-  if ((rc = dsge_cycle_reduction_batched(dA, dB, dC, batch, n, max_iter, tol, dT, dS, dI, nullptr))) return rc;
+  if ((rc = cr_entry(dA, dB, dC, batch, n, max_iter, tol, dT, dS, dI, nullptr, scan_mode))) return rc;
   DOWN(T_out, dT, nn, double);
   DOWN(status, dS, batch, int32_t);
   DOWN(n_iter, dI, batch, int32_t);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
                                                          double tol, double* __restrict__ T_out,
                                                          int32_t* __restrict__ status,
                                                          int32_t* __restrict__ n_iter_out,
-                                                         long long* __restrict__ dbg) {
+                                                         long long* __restrict__ dbg, int scan_mode) {
   constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
@@ -134,6 +134,10 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
     for (; it < max_iter;) {
       // W = [A1 | R] -> [. | A1^-1 R] (rows in pivot order)
       blk_store_lds<BS>(A1, W, LDW, lr, lc);
+      if (scan_mode && lr == lc) {  // stabilize(A1): 1e-16 on the diagonal of the solve only (shared.py:6-9)
+#pragma unroll
+        for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
+      }
       blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
       gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, dbg ? ph : nullptr);  // syncs on entry and exit
       long long tk0 = dbg ? clock64() : 0;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
       const double nrm2 = blk_norm1<BS>(t2);
       if (dbg) ph[4] += clock64() - tk0;
       if (nrm0 < tol) {
-        if (nrm2 < tol) {
+        if (nrm2 < tol || scan_mode) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
           converged = true;
           break;
         }
@@ -206,10 +210,16 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
 
     double Tb[BS][BS];
     blk_zero<BS>(Tb);
-    if (converged) {
+    // scan variant: T is formed from whatever A1_hat the fixed trip count reached (:292), NaN excepted
+    const bool solve_T = converged || (scan_mode && !saw_nan);
+    if (solve_T) {
       // T[:,S] = -A1_hat^-1 A[:,S]   (cycle_reduction.py:181); every other column is exactly zero
       wave_sync();
       blk_store_lds<BS>(Ah, W, LDW, lr, lc);
+      if (scan_mode && lr == lc) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = Ah[i][i] + 1e-16;
+      }
       {
         double t[BS][BS];
 #pragma unroll
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
     }
     blk_store_global<BS>(Tb, T_out + off, n, n, n, lr, lc);
     if (lane == 0) {
-      status[draw] = converged ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
+      status[draw] = solve_T ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
       if (n_iter_out) n_iter_out[draw] = it;
       if (dbg && draw == 0) {
         const long long tk_end = clock64();

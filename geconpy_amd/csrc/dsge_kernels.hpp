@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
                                                  const double* __restrict__ C, int batch, int n, int max_iter,
                                                  double tol, double* __restrict__ T_out,
                                                  int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
-                                                 int rerun_only) {
+                                                 int rerun_only, int scan_mode) {
   constexpr int NP = CrSmem<BS>::NP, LD = CrSmem<BS>::LD, LDW = CrSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
@@ -62,6 +62,10 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
     for (; it < max_iter;) {
       // W = [A1 | A0 | A2]
       blk_store_lds<BS>(A1, W, LDW, lr, lc);
+      if (scan_mode && lr == lc) {  // stabilize(A1): 1e-16 on the diagonal of the solve only (shared.py:6-9)
+#pragma unroll
+        for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
+      }
       blk_store_lds<BS>(A0, W + NP, LDW, lr, lc);
       blk_store_lds<BS>(A2, W + 2 * NP, LDW, lr, lc);
       gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);  // syncs on entry and exit
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
       const double nrm0 = blk_norm1<BS>(m00);
       if (nrm0 < tol) {
         const double nrm2 = blk_norm1<BS>(m22);
-        if (nrm2 < tol) {
+        if (nrm2 < tol || scan_mode) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
           converged = true;
           break;
         }
@@ -114,10 +118,15 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
 
     double Tb[BS][BS];
     blk_zero<BS>(Tb);
-    if (converged) {
+    const bool solve_T = converged || (scan_mode && !saw_nan);
+    if (solve_T) {
       // T = -A1_hat^-1 A0_initial   (cycle_reduction.py:181)
       wave_sync();
       blk_store_lds<BS>(Ah, W, LDW, lr, lc);
+      if (scan_mode && lr == lc) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = Ah[i][i] + 1e-16;
+      }
       {
         double t[BS][BS];
         blk_load_global<BS>(t, A + off, n, n, n, lr, lc);
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
     }
     blk_store_global<BS>(Tb, T_out + off, n, n, n, lr, lc);
     if (lane == 0) {
-      status[draw] = converged ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
+      status[draw] = solve_T ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
       if (n_iter_out) n_iter_out[draw] = it;
     }
   }

@@ -205,6 +205,97 @@ class HipSolveKalmanLogp(Op):
         outputs[1][0] = out["status"]
 
 
+class HipGensys(Op):
+    """Drop-in for ``GensysWrapper`` (gEconpy/solvers/gensys.py:634-676): ``T, success = Op(A, B, C, D)``
+    with ``__props__ = ("tol",)``, the same ``gufunc_signature``, ``T`` (n, n) float64 and a boolean
+    scalar ``success = (eu[0] == 1 and eu[1] == 1)`` (:663).  Batched (leading draw axis) inputs give
+    (batch, n, n) and (batch,) outputs from ONE launch.  ``pullback`` returns the adjoints of
+    (A, B, C) from the cotangent of T on the device and a zero cotangent for D (:668-676)."""
+
+    __props__ = ("tol",)
+    gufunc_signature = "(n,n),(n,n),(n,n),(n,k)->(n,n),()"
+
+    def __init__(self, tol=1e-8):
+        self.tol = tol
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C, D):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C, D)]
+        shp = inputs[0].type.shape
+        outputs = [pt.tensor("T", dtype="float64", shape=shp), pt.tensor("success", dtype="bool", shape=shp[:-2])]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        return [input_shapes[0], input_shapes[0][:-2]]
+
+    def perform(self, node, inputs, outputs):
+        squeeze = np.ndim(inputs[0]) == 2
+        A, B, C, D = (_as3(x) for x in inputs)
+        out = batched.gensys_batched(A, B, C, None, tol=self.tol)
+        outputs[0][0] = out["T"][0] if squeeze else out["T"]
+        outputs[1][0] = np.asarray(out["success"][0] if squeeze else out["success"], dtype=bool)
+
+    def pullback(self, inputs, outputs, cotangents):
+        _A, B, C, D = inputs
+        A_bar, B_bar, C_bar = HipPolicyAdjoint()(B, C, outputs[0], cotangents[0])
+        return [A_bar, B_bar, C_bar, pt.zeros_like(D)]
+
+
+def gensys_pt(A, B, C, D, tol=1e-8):
+    """Same signature and return as ``gEconpy.solvers.gensys.gensys_pt`` (:679-683): ``(T, R, success)``."""
+    T, success = HipGensys(tol=tol)(A, B, C, D)
+    R = HipSelection()(B, C, D, T)
+    return T, R, success
+
+
+class HipScanCycleReduction(Op):
+    """``T, n_steps = Op(A, B, C)`` with the semantics of ``_scan_cycle_reduction``
+    (gEconpy/solvers/cycle_reduction.py:246-294): fixed trip count, A0-norm-only stopping rule, 1e-16
+    diagonal jitter.  (n, n) or (batch, n, n) inputs."""
+
+    __props__ = ("max_iter", "tol")
+    gufunc_signature = "(n,n),(n,n),(n,n)->(n,n),()"
+
+    def __init__(self, max_iter=50, tol=1e-7):
+        self.max_iter = int(max_iter)
+        self.tol = tol
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C)]
+        shp = inputs[0].type.shape
+        outputs = [pt.tensor("T", dtype="float64", shape=shp), pt.tensor("n_steps", dtype="int32", shape=shp[:-2])]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        return [input_shapes[0], input_shapes[0][:-2]]
+
+    def perform(self, node, inputs, outputs):
+        squeeze = np.ndim(inputs[0]) == 2
+        A, B, C = (_as3(x) for x in inputs)
+        T, _status, n_steps = batched.scan_cycle_reduction_batched(A, B, C, max_iter=self.max_iter, tol=self.tol)
+        outputs[0][0] = T[0] if squeeze else T
+        outputs[1][0] = np.asarray(n_steps[0] if squeeze else n_steps, dtype=np.int32)
+
+    def pullback(self, inputs, outputs, cotangents):
+        _A, B, C = inputs
+        return list(HipPolicyAdjoint()(B, C, outputs[0], cotangents[0]))
+
+
+def scan_cycle_reduction(A, B, C, D, max_iter=50, tol=1e-7, mode=None, use_adjoint_gradients=True):
+    """Same signature and return as ``gEconpy.solvers.cycle_reduction.scan_cycle_reduction`` (:297-325):
+    ``(T, R, n_steps)``.  ``mode`` is accepted for signature compatibility (there is no scan to compile);
+    gradients always use the adjoint solve."""
+    del mode, use_adjoint_gradients
+    T, n_steps = HipScanCycleReduction(max_iter=max_iter, tol=tol)(A, B, C)
+    R = HipSelection()(B, C, D, T)
+    return T, R, n_steps
+
+
 def cycle_reduction_pt(A, B, C, D, max_iter=1000, tol=1e-9):
     """Same signature and return as ``gEconpy.solvers.cycle_reduction.cycle_reduction_pt``
     (:216-219): ``(T, R)``."""

@@ -3,6 +3,7 @@ executing on the HIP engine (batch of one or many).
 
   solve_policy_function_with_cycle_reduction  <- gEconpy/solvers/cycle_reduction.py:328-398
   solve_policy_function_with_backward_direct  <- gEconpy/solvers/backward_looking.py:102-134
+  solve_policy_function_with_gensys / gensys  <- gEconpy/solvers/gensys.py:617-631, :398-521
   cycle_reduction_numpy-like batched driver    <- the per-draw loop of
       gEconpy/model/statistics/perturbation_diagnostics.py:453-490 (one launch instead of a pool)
 """
@@ -46,6 +47,38 @@ def solve_policy_function_with_backward_direct(A, B, C, D):
     return T[0], R[0]
 
 
+def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=True):
+    """Reference signature (gEconpy/solvers/gensys.py:617-631).  The estimation and ``solve_model`` call
+    sites consume ``G_1[:n, :n]``, ``impact[:n]`` and ``eu`` only (gensys.py:657-666,
+    gEconpy/model/model.py:1696-1708); the device produces exactly those, so
+
+      * ``return_all_matrices=False`` -> ``(G_1, eu)`` with ``G_1`` the n x n policy block ``T``;
+      * ``return_all_matrices=True``  -> the 9-tuple ``(G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose)``
+        with ``G_1 = T`` (n x n), ``constant = 0`` (c = 0, gensys.py:598), ``impact = R = -(C T + B)^-1 D``
+        (what ``gensys_pt`` uses, :679-683; it equals ``impact[:n]`` of the QZ formula to ~1e-12) and
+        ``None`` for ``f_mat, f_wt, y_wt, gev, loose`` -- the five outputs no caller of the hot path reads;
+        on coincident zeros (``eu = [-2, -2, 0]``) the seven matrices are ``None`` as at :515-516.
+    Slicing ``G_1[:n, :n]`` / ``impact[:n, :]`` as the callers do is a no-op on these shapes."""
+    A3, B3, C3, D3 = (np.ascontiguousarray(x, dtype=np.float64)[None] for x in (A, B, C, D))
+    out = batched.gensys_batched(A3, B3, C3, D3, tol=tol)
+    eu = [int(v) for v in out["eu"][0]]
+    if eu[0] == -2 and eu[1] == -2:
+        return (None, eu) if not return_all_matrices else (None,) * 7 + (eu, None)
+    G_1 = np.ascontiguousarray(out["T"][0])
+    if not return_all_matrices:
+        return G_1, eu
+    n = G_1.shape[0]
+    return G_1, np.zeros((n, 1)), out["R"][0], None, None, None, None, eu, None
+
+
+def gensys(g0, g1, c, psi, pi, div=None, tol=1e-8, return_all_matrices=True):
+    """The raw-pencil entry point (gEconpy/solvers/gensys.py:398-521) is host-side bookkeeping around
+    ``_gensys_core`` for an ARBITRARY pencil; the device kernel takes the structural form A, B, C
+    (it never materialises the pencil).  Not provided: use
+    ``solve_policy_function_with_gensys(A, B, C, D)``."""
+    raise NotImplementedError(gensys.__doc__)
+
+
 def solve_policy_functions_batched(A, B, C, D, solver="cycle_reduction", max_iter=100, tol=1e-8):
     """Many draws, one launch: dict(T, R, resid, success, n_iter).  ``success[i]`` is what
     ``_solve_perturbation`` decides per draw in the reference's ``solvability_check`` loop
@@ -59,6 +92,20 @@ def solve_policy_functions_batched(A, B, C, D, solver="cycle_reduction", max_ite
         ok = status == _lib.ST_OK
         R[~ok] = 0.0
         resid[~ok] = np.inf
+    elif solver == "scan_cycle_reduction":
+        T, status, n_iter = batched.scan_cycle_reduction_batched(A, B, C, max_iter=max_iter, tol=tol)
+        R, resid = batched.selection_batched(B, C, D, T, A=A)
+        ok = status == _lib.ST_OK
+        R[~ok] = 0.0
+        resid[~ok] = np.inf
+    elif solver == "gensys":
+        out = batched.gensys_batched(A, B, C, D, tol=tol)
+        T, R, ok = out["T"], out["R"], out["success"]
+        _R2, resid = batched.selection_batched(B, C, D, T, A=A)
+        R[~ok] = 0.0
+        resid[~ok] = np.inf
+        n_iter = np.zeros(A.shape[0], dtype=np.int32)
+        return dict(T=T, R=R, resid=resid, success=ok, n_iter=n_iter, eu=out["eu"])
     elif solver == "backward_direct":
         T, R = batched.backward_direct_batched(A, B, D)
         resid = np.square(A + B @ T).sum(axis=(1, 2))

@@ -65,6 +65,7 @@ extern "C" {
 #define DSGE_SOLVER_CYCLE_REDUCTION 0
 #define DSGE_SOLVER_GENSYS 1
 #define DSGE_SOLVER_BACKWARD_DIRECT 2
+#define DSGE_SOLVER_SCAN_CYCLE_REDUCTION 3
 
 int dsge_abi_version(void);
 const char* dsge_last_error(void);
@@ -87,6 +88,22 @@ int dsge_cycle_reduction_batched(const double* A, const double* B, const double*
 int dsge_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
                                       int max_iter, double tol, double* T_out, int32_t* status,
                                       int32_t* n_iter);
+/*
+ * Cycle reduction with the semantics of the pure-pytensor scan variant.  Replaces _scan_cycle_reduction /
+ * scan_cycle_reduction (gEconpy/solvers/cycle_reduction.py:246-325): at most max_iter steps, a step is
+ * skipped once ||A0||_1 < tol (the A0 norm ONLY, :269-277), 1e-16 is added to the diagonal of A1 / A1_hat
+ * in every solve (stabilize, gEconpy/solvers/shared.py:6-9), and T = -(A1_hat + 1e-16 I)^-1 A is formed from
+ * whatever iterate the trip count reached (:292) -- there is no convergence flag in the reference.
+ *   n_steps : [batch] steps actually taken (the third output of scan_cycle_reduction), may be NULL
+ *   status  : 0 unless a NaN appeared (then DSGE_ST_NOT_CONVERGED | DSGE_ST_NAN and T = 0: the reference
+ *             would return a NaN matrix; this library never hands NaN policies downstream)
+ */
+int dsge_scan_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n,
+                                      int max_iter, double tol, double* T_out, int32_t* status, int32_t* n_steps,
+                                      void* stream);
+int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
+                                           int max_iter, double tol, double* T_out, int32_t* status,
+                                           int32_t* n_steps);
 /* Cycle reduction runs on the column-compact form [A[:,S] | C[:,L]] (S, L = non-zero columns of A and C,
  * detected per draw on the device; zero columns only ever contribute +0.0, so T is bit-identical) whenever
  * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every

@@ -143,6 +143,11 @@ def solve_kalman_logp(
         Tm, ok, _eu = gensys_T_success(A, B, C, D, tol)
     elif solver == "cycle_reduction":
         Tm, ok, n_iter = cycle_reduction_core(A, B, C, max_iter, tol)
+    elif solver == "scan_cycle_reduction":  # statespace.py:205-207: no success flag, T from the last iterate
+        from .cycle_reduction import scan_cycle_reduction
+
+        Tm, n_iter = scan_cycle_reduction(A, B, C, max_iter, tol)
+        ok = bool(np.all(np.isfinite(Tm)))
     elif solver == "backward_direct":
         Tm, ok = np.linalg.solve(-B, A), True
     else:

@@ -715,3 +715,78 @@ def test_cycle_reduction_compact_equals_dense(sw_golden, ref_goldens, rbc_golden
     T, st, _ = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-12)
     assert np.all(st == 0)
     assert_allclose(T, Tstar, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# scan_cycle_reduction semantics and the gensys numpy wrappers
+# ------------------------------------------------------------------------------------------------
+def test_scan_cycle_reduction_semantics(ref_goldens, sw_golden):
+    """_scan_cycle_reduction (cycle_reduction.py:246-294): A0-norm-only stopping rule, fixed trip count,
+    T from whatever iterate was reached.  Steps taken must equal the oracle's exactly."""
+    b = wl.sw_shaped_batch(int(sw_golden["n_draws"]))
+    sets = [tuple(b[x] for x in "ABC")]
+    for key in ("one_block", "rbc_2_block", "full_nk"):
+        sets.append(tuple(ref_goldens[f"{key}_{x}"][None] for x in "ABC"))
+    for A, B, C in sets:
+        for max_iter, tol in ((50, 1e-7), (3, 1e-7), (50, 1e-2)):  # converged / trip count exhausted / loose
+            T, st, n_steps = batched.scan_cycle_reduction_batched(A, B, C, max_iter=max_iter, tol=tol)
+            assert np.all(st == 0)
+            for i in range(A.shape[0]):
+                T_ref, n_ref = oracle.scan_cycle_reduction(A[i], B[i], C[i], max_iter=max_iter, tol=tol)
+                assert n_steps[i] == n_ref
+                assert_allclose(T[i], T_ref, atol=1e-9 * max(1.0, np.abs(T_ref).max()), rtol=0)
+    # the njit variant needs ||A2|| < tol as well: on these systems it takes at least as many steps
+    A, B, C = sets[0]
+    _, _, it_njit = batched.cycle_reduction_batched(A, B, C, max_iter=50, tol=1e-7)
+    _, _, it_scan = batched.scan_cycle_reduction_batched(A, B, C, max_iter=50, tol=1e-7)
+    assert np.all(it_scan <= it_njit)
+    # NaN input: flagged, zero T, no hang
+    An = A[:2].copy()
+    An[0, 0, 0] = np.nan
+    T, st, _ = batched.scan_cycle_reduction_batched(An, B[:2], C[:2], max_iter=50, tol=1e-7)
+    assert st[0] & _lib.ST_NAN and np.all(T[0] == 0) and st[1] == 0
+
+
+def test_fused_pipeline_with_scan_cycle_reduction():
+    b = wl.sw_shaped_batch(6)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    r = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"][:60], Hdiag=om["Hdiag"],
+                                          solver="scan_cycle_reduction", tol=1e-7, max_iter=50, return_policy=True)
+    assert np.all(r["status"] == 0)
+    for i in range(6):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], om["y"][:60],
+                                       H=np.diag(om["Hdiag"]), solver="scan_cycle_reduction", tol=1e-7, max_iter=50)
+        assert r["n_iter"][i] == ref["n_iter"]
+        assert_allclose(r["logp"][i], ref["logp"], rtol=LOGP_RTOL)
+
+
+def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
+    """solve_policy_function_with_gensys (gensys.py:617-631) as model.py:1696-1708 consumes it."""
+    from geconpy_amd import solvers
+
+    g = ref_goldens
+    for key in ("one_block", "rbc_2_block", "full_nk"):
+        A, B, C, D = (g[f"{key}_{x}"] for x in "ABCD")
+        n = A.shape[0]
+        G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
+        assert eu == [1, 1, 0] and constant.shape == (n, 1) and f_mat is None and loose is None
+        assert_allclose(G_1[:n, :n], g[f"{key}_ref_gensys_T"], atol=1e-9)
+        assert_allclose(impact[:n, :], g[f"{key}_ref_gensys_R"], atol=1e-8)
+        G_1s, eu_s = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8, return_all_matrices=False)
+        assert eu_s == eu and np.array_equal(G_1s, G_1)
+    f = failure_golden
+    A, B, C, D = (f[f"coincident_{x}"] for x in "ABCD")
+    out = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
+    assert out[7] == [-2, -2, 0] and all(m is None for m in out[:7])
+    with pytest.raises(NotImplementedError):
+        solvers.gensys(None, None, None, None, None)
+    # batched driver, all four solvers give the same policy on a healthy system
+    b = wl.sw_shaped_batch(4)
+    outs = {s: solvers.solve_policy_functions_batched(b["A"], b["B"], b["C"], b["D"], solver=s, tol=1e-9)
+            for s in ("cycle_reduction", "scan_cycle_reduction", "gensys")}
+    for s, o in outs.items():
+        assert np.all(o["success"]), s
+        assert_allclose(o["T"], b["T_star"], atol=1e-9)
+        assert np.all(o["resid"] < 1e-16)
+    assert np.array_equal(outs["gensys"]["eu"], np.tile([1, 1, 0], (4, 1)))
