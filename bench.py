@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--max-iter", type=int, default=1000)
     ap.add_argument("--workload", default="sw_shaped", choices=["sw_shaped", "rbc"])
     ap.add_argument("--solver", default="cycle_reduction", choices=["cycle_reduction", "gensys"])
+    ap.add_argument("--from-theta", action="store_true",
+                    help="rbc workload only: start each step from the parameter draws (generated Jacobian kernel on the "
+                         "device, SURVEY 8 f1) instead of from resident A,B,C,D")
     ap.add_argument("--no-hints", action="store_true", help="disable the structure hints (general kernels only)")
     args = ap.parse_args()
 
@@ -167,7 +170,23 @@ def main():
 
     n_lead = lead_hint(shard["C"], args.tol) if args.solver == "gensys" else 0
 
+    prog = d_theta = jac_out = None
+    if args.from_theta:
+        if args.workload != "rbc":
+            ap.error("--from-theta needs --workload rbc (the SW-shaped systems have no parameterisation)")
+        from geconpy_amd.jacobian_codegen import rbc_linearized_program
+
+        prog = rbc_linearized_program()
+        th = wl.rbc_prior_draws(hi, seed=1)
+        d_theta = eng.to_device(np.stack([th[k_][lo:hi] for k_ in ("sigma", "phi", "alpha", "beta", "delta", "rho_A",
+                                                                  "sigma_A")], axis=1))
+        jac_out = (dA, dB, dC, dD, dq)
+
     def local_eval(lo_, hi_):
+        if prog is not None:
+            return eng.logp_from_theta(prog, d_theta, dZ, dy, Hdiag=dH, jac_out=jac_out, tol=args.tol,
+                                       max_iter=args.max_iter, logp=logp_buf, status=stat_buf, solver=args.solver,
+                                       n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead)
         return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
                                      max_iter=args.max_iter, logp=logp_buf, status=stat_buf, solver=args.solver,
                                      n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead)
@@ -292,6 +311,7 @@ def main():
                 else f"rbc_linearized closed form: n={n}, k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[1])",
                 "global_batch": global_batch,
                 "solver": args.solver,
+                "inputs": "theta (generated Jacobian kernel inside the step)" if args.from_theta else "A,B,C,D resident in HBM",
                 "tol": args.tol,
                 "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
                 "parallelism": f"draw-sharded x{world}, all_gather(logp,status)" if world > 1 else "single GPU",

@@ -98,6 +98,34 @@ class LogpEngine:
             raise ValueError("expected a contiguous int32 CUDA tensor")
         _lib.check(self.lib.dsge_debug_kalman_steady_steps(None if buf is None else buf.data_ptr()))
 
+    # -- on-device Jacobians ---------------------------------------------------
+    def jacobians_from_theta(self, program, theta, out=None):
+        """``theta`` (float64 CUDA tensor [batch][npar]) -> (A, B, C, D, q) resident in HBM, evaluated by
+        the generated kernel of ``program`` (geconpy_amd.jacobian_codegen.JacobianProgram) on the current
+        stream; ``q`` is None when the program carries no shock variances.  ``out`` may hold preallocated
+        tensors (A, B, C, D, q) to reuse across MCMC steps."""
+        torch = self.torch
+        self._chk(theta)
+        nb, npar = theta.shape
+        if npar != len(program.params):
+            raise ValueError(f"theta has {npar} columns, the program has {len(program.params)} parameters")
+        n, k = program.n, program.k
+        if out is None:
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.device)  # noqa: E731
+            out = (mk(nb, n, n), mk(nb, n, n), mk(nb, n, n), mk(nb, n, k), mk(nb, k) if program.q is not None else None)
+        A, B, C, D, q = out
+        program.launch(theta.data_ptr(), nb, A.data_ptr(), B.data_ptr(), C.data_ptr(), D.data_ptr(),
+                       None if q is None else q.data_ptr(), self._stream())
+        return A, B, C, D, q
+
+    def logp_from_theta(self, program, theta, Z, y, d=None, Hdiag=None, jac_out=None, **kw):
+        """theta -> A,B,C,D,q -> T,R -> P0 -> logp without the matrices ever leaving the device: the generated
+        Jacobian kernel followed by the fused pipeline on the same stream.  Returns (logp, status)."""
+        A, B, C, D, q = self.jacobians_from_theta(program, theta, out=jac_out)
+        if q is None:
+            raise ValueError("the program has no shock variances; call jacobians_from_theta + solve_kalman_logp")
+        return self.solve_kalman_logp(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, q_mode=1, **kw)
+
     # -- product entry points --------------------------------------------------------------
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
