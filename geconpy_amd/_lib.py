@@ -74,6 +74,8 @@ PROTOTYPES = {
     "dsge_backward_direct_batched_host": [_dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_lyapunov_batched": [_dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp, _dp],
     "dsge_lyapunov_batched_host": [_dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp],
+    "dsge_autocorrelation_batched": [_dp, _dp, _dp, _i, _dp, _dp, _i, _i, _i, _i, _i, _i, _i, _dp, _dp, _dp, _dp],
+    "dsge_autocorrelation_batched_host": [_dp, _dp, _dp, _i, _dp, _dp, _i, _i, _i, _i, _i, _i, _i, _dp, _dp, _dp],
     "dsge_kalman_logp_batched": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp, _dp],
     "dsge_kalman_logp_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp],
     "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],

@@ -202,6 +202,36 @@ def lyapunov_batched(T, R, Q, q_mode=None):
     return P0, RQR, status
 
 
+def autocorrelation_matrices_batched(T, R, Q, n_lags=10, lag_step=1, Z=None, Hdiag=None, correlation=True, q_mode=None,
+                                     return_sigma=False):
+    """Per-draw autocorrelation (or autocovariance) matrices at lags 0..n_lags -- the batch version of
+    ``_compute_autocovariance_matrix`` (gEconpy/model/statistics/covariance.py:133-161; note that one returns lags
+    0..n_lags-1) and of the graph ``sample_autocorrelation_matrices`` evaluates per posterior draw
+    (gEconpy/model/statespace.py:1262-1300; ``observed=True`` <=> ``Z`` given, measurement-error variances
+    ``Hdiag`` enter the lag-0 matrix).  Returns ``acf[batch, n_lags+1, dim, dim]`` (+ status [, Sigma])."""
+    T, R = _f64(T, 3), _f64(R, 3)
+    nb, m, _ = T.shape
+    k = R.shape[2]
+    Q, code = _resolve_q(Q, q_mode, nb, k)
+    p = 0
+    if Z is not None:
+        Z = _f64(Z, 2)
+        p = Z.shape[0]
+        if Z.shape[1] != m:
+            raise ValueError("Z must be (p, m)")
+        Hdiag = None if Hdiag is None else _f64(Hdiag, 1)
+    dim = p if Z is not None else m
+    out = np.empty((nb, n_lags + 1, dim, dim))
+    sigma = np.empty((nb, m, m)) if return_sigma else None
+    status = np.empty(nb, dtype=np.int32)
+    _lib.check(
+        _lib.load().dsge_autocorrelation_batched_host(_ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), _ptr(Hdiag), nb, m, k, p,
+                                                      int(n_lags), int(lag_step), int(bool(correlation)), _ptr(out),
+                                                      _ptr(sigma), _ptr(status))
+    )
+    return (out, status, sigma) if return_sigma else (out, status)
+
+
 def _obs_args(Z, d, Hdiag, nb, p, m):
     Z = _f64(Z)
     if Z.shape == (p, m):

@@ -282,6 +282,32 @@ int dsge_lyapunov_batched(const double* T, const double* R, const double* Q, int
                          P0_out, status, 0, 1, (hipStream_t)stream);
 }
 
+int dsge_autocorrelation_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                 const double* Hdiag, int batch, int m, int k, int p, int n_lags, int lag_step,
+                                 int correlation, double* acf_out, double* Sigma_out, int32_t* status, void* stream) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (n_lags < 0 || lag_step < 1) return fail(DSGE_ERR_INVALID, "n_lags >= 0 and lag_step >= 1 required");
+  if (Z && (p < 1 || p > DSGE_MAX_P)) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (!T || !R || !Q || !acf_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  double* Sigma = Sigma_out;
+  if (!Sigma) {
+    void* base = nullptr;
+    if ((rc = arena_reserve(g_scratch, align256((size_t)batch * m * m * sizeof(double)) + 4096, &base))) return rc;
+    Sigma = (double*)base;
+  }
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, st));
+  if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T, R, Q, q_mode, batch, m, k, nullptr, nullptr, nullptr,
+                            Sigma, status, 0, 1, st)))
+    return rc;
+  return launch_acf(T, Sigma, Z, Hdiag, batch, m, p, n_lags, lag_step, correlation, acf_out, status, st);
+}
+
 int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
                              int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
                              const double* y, int batch, int m, int k, int p, int T_len, double jitter,
@@ -679,6 +705,46 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
   if ((rc = dsge_lyapunov_batched(dT, dR, dQ, q_mode, batch, m, k, dP, dX, dS, nullptr))) return rc;
   DOWN(P0_out, dP, mm, double);
   DOWN(RQR_out, dX, mm, double);
+  DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_autocorrelation_batched_host(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                      const double* Hdiag, int batch, int m, int k, int p, int n_lags, int lag_step,
+                                      int correlation, double* acf_out, double* Sigma_out, int32_t* status) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (n_lags < 0 || lag_step < 1) return fail(DSGE_ERR_INVALID, "n_lags >= 0 and lag_step >= 1 required");
+  if (Z && (p < 1 || p > DSGE_MAX_P)) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (!T || !R || !Q || !acf_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const int dim = Z ? p : m;
+  const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
+  const size_t no = (size_t)batch * (n_lags + 1) * dim * dim;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 2 * align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(no * 8) +
+                                       align256((size_t)p * m * 8) + align256((size_t)p * 8) +
+                                       align256((size_t)batch * 4) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dT, T, mm, double);
+  UP(dR, R, mk, double);
+  UP(dQ, Q, nq, double);
+  UP(dZ, Z, (size_t)p * m, double);
+  UP(dH, Hdiag, (size_t)p, double);
+  double* dSig = cv.take<double>(mm);
+  OUTBUF(dO, acf_out, no, double);
+  OUTBUF(dS, status, batch, int32_t);
+  if ((rc = dsge_autocorrelation_batched(dT, dR, dQ, q_mode, dZ, dH, batch, m, k, p, n_lags, lag_step, correlation, dO,
+                                         dSig, dS, nullptr)))
+    return rc;
+  DOWN(acf_out, dO, no, double);
+  DOWN(Sigma_out, dSig, mm, double);
   DOWN(status, dS, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;

@@ -1,6 +1,7 @@
 // Launchers of the assembly kernels: selection matrix / residual / Lyapunov, policy adjoints, gEcon norms.
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
+#include "dsge_acf.hpp"
 
 namespace dsge_host {
 
@@ -45,6 +46,21 @@ int launch_norms(const double* A, const double* B, const double* C, const double
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::norms_kernel<BS>, dim3(batch), dim3(64), dsge::NormSmem<BS>::bytes, st, A, B, C, D, T, R,
                          mask, batch, n, k, det, sto);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  return rc;
+}
+
+int launch_acf(const double* T, const double* Sigma, const double* Z, const double* Hdiag, int batch, int m, int p,
+               int n_lags, int lag_step, int correlation, double* out, const int32_t* status, hipStream_t st) {
+  const int bs = tile_bs(m);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::acf_kernel<BS>, dsge::AcfSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::acf_kernel<BS>, dim3(batch), dim3(64), dsge::AcfSmem<BS>::bytes, st, T, Sigma, Z, Hdiag,
+                         batch, m, p, n_lags, lag_step, correlation, out, status);
       HIP_TRY(hipGetLastError());
     }
   });

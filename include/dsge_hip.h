@@ -227,6 +227,25 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
                                int m, int k, double* P0_out, double* RQR_out, int32_t* status);
 
 /*
+ * Model-implied autocovariance / autocorrelation matrices.  Replaces _compute_autocovariance_matrix
+ * (gEconpy/model/statistics/covariance.py:133-161) and the per-draw graph of
+ * DSGEStateSpace.sample_autocorrelation_matrices (gEconpy/model/statespace.py:1262-1300):
+ *   Sigma = dlyap(T, R Q R'),  T_step = T^lag_step,  G_k = T_step^k Sigma  (k = 0..n_lags)
+ *   Z == NULL : out[draw][k] = G_k                      (m x m, latent states)
+ *   Z != NULL : out[draw][k] = Z G_k Z', lag 0 + diag(Hdiag)   (p x p, observed series; Z [p][m] shared)
+ *   correlation != 0 : every matrix divided by std std', std = sqrt(diag(out[draw][0]))
+ *   acf_out   : [batch][n_lags+1][dim][dim], dim = Z ? p : m
+ *   Sigma_out : [batch][m][m] or NULL (device variant: NULL uses library scratch)
+ *   status    : [batch] out; DSGE_ST_LYAP_FAIL (rho(T) >= 1) fills that draw's matrices with NaN
+ */
+int dsge_autocorrelation_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                 const double* Hdiag, int batch, int m, int k, int p, int n_lags, int lag_step,
+                                 int correlation, double* acf_out, double* Sigma_out, int32_t* status, void* stream);
+int dsge_autocorrelation_batched_host(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                      const double* Hdiag, int batch, int m, int k, int p, int n_lags, int lag_step,
+                                      int correlation, double* acf_out, double* Sigma_out, int32_t* status);
+
+/*
  * Kalman-filter log-likelihood, batched over draws, "standard" filter.  Replaces the scan
  * that PyMCStateSpace.build_statespace_graph builds for DSGEStateSpace
  * (gEconpy/model/statespace.py:1151-1157; recursion restated in SURVEY.md Appendix B.4)

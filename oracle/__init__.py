@@ -45,6 +45,7 @@ from .shared import (  # noqa: F401
 from .statespace import (  # noqa: F401
     JITTER_DEFAULT,
     MISSING_FILL,
+    autocorrelation_matrices,
     kalman_filter_logp,
     solve_discrete_lyapunov,
     solve_kalman_logp,

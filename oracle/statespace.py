@@ -167,3 +167,27 @@ def solve_kalman_logp(
     )
     out.update(T=Tm, R=Rm, P0=P0)
     return out
+
+
+def autocorrelation_matrices(T, R, Q, n_lags=10, lag_step=1, Z=None, H=None, correlation=True):
+    """Lags 0..n_lags of the model-implied autocorrelation, following the graph of
+    ``DSGEStateSpace.sample_autocorrelation_matrices`` (statespace.py:1262-1300): ``Sigma = dlyap(T, R Q R')``,
+    ``T_step = T^lag_step``, ``G_k = T_step^k Sigma`` (observed: ``Z G_k Z'``, lag 0 ``+ H``), normalised by
+    ``std = sqrt(diag(G_0))``.  With ``lag_step=1, Z=None`` the first ``n_lags`` matrices are exactly
+    ``_compute_autocovariance_matrix(T, Sigma, n_lags, correlation)`` (covariance.py:133-161)."""
+    Sigma = solve_discrete_lyapunov(T, R @ Q @ R.T)
+    T_step = np.linalg.matrix_power(T, lag_step)
+    powers = [np.eye(T.shape[0])]
+    for _ in range(n_lags):
+        powers.append(powers[-1] @ T_step)  # statespace.py:1279-1286: prev @ mat
+    T_powers = np.stack(powers)
+    if Z is not None:
+        autocov = (Z @ (T_powers @ Sigma)) @ Z.T
+        autocov[0] = Z @ Sigma @ Z.T + (0.0 if H is None else H)
+    else:
+        autocov = T_powers @ Sigma
+        autocov[0] = Sigma
+    if correlation:
+        std = np.sqrt(np.diag(autocov[0]))
+        autocov = autocov / np.outer(std, std)[None]
+    return autocov

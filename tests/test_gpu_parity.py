@@ -790,3 +790,32 @@ def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
         assert_allclose(o["T"], b["T_star"], atol=1e-9)
         assert np.all(o["resid"] < 1e-16)
     assert np.array_equal(outs["gensys"]["eu"], np.tile([1, 1, 0], (4, 1)))
+
+
+@pytest.mark.parametrize("m,k,p", [(9, 2, 3), (24, 4, 4), (40, 7, 7)])
+def test_autocorrelation_matrices(m, k, p):
+    """sample_autocorrelation_matrices (statespace.py:1262-1300) / _compute_autocovariance_matrix
+    (covariance.py:133-161) for a batch of draws in one launch."""
+    nb = 5
+    T, R, q, Z, _d, H, _y = _kalman_inputs(nb, m, k, p, 10, max(2, m // 2), seed=100 + m)
+    for kw in (dict(n_lags=6, lag_step=1, correlation=True), dict(n_lags=3, lag_step=4, correlation=True),
+               dict(n_lags=5, lag_step=1, correlation=False)):
+        acf, st, sig = batched.autocorrelation_matrices_batched(T, R, q, q_mode="diag_batched", return_sigma=True, **kw)
+        assert np.all(st == 0) and acf.shape == (nb, kw["n_lags"] + 1, m, m)
+        obs, st2 = batched.autocorrelation_matrices_batched(T, R, q, q_mode="diag_batched", Z=Z, Hdiag=H, **kw)
+        assert np.all(st2 == 0) and obs.shape == (nb, kw["n_lags"] + 1, p, p)
+        for i in range(nb):
+            ref = oracle.autocorrelation_matrices(T[i], R[i], np.diag(q[i]), **kw)
+            scale = np.abs(ref).max()
+            assert_allclose(acf[i], ref, atol=1e-11 * scale, rtol=1e-9)
+            assert_allclose(sig[i], oracle.solve_discrete_lyapunov(T[i], R[i] @ np.diag(q[i]) @ R[i].T), rtol=1e-10,
+                            atol=1e-12 * np.abs(sig[i]).max())
+            ref_o = oracle.autocorrelation_matrices(T[i], R[i], np.diag(q[i]), Z=Z, H=np.diag(H), **kw)
+            assert_allclose(obs[i], ref_o, atol=1e-11 * np.abs(ref_o).max(), rtol=1e-9)
+            if kw["correlation"]:
+                assert_allclose(np.diag(acf[i, 0]), 1.0, rtol=1e-13)
+    # no stationary distribution: flagged, NaN-filled
+    Tx = T[:2].copy()
+    Tx[1] *= 1.5 / np.max(np.abs(np.linalg.eigvals(Tx[1])))
+    acf, st = batched.autocorrelation_matrices_batched(Tx, R[:2], q[:2], n_lags=2, q_mode="diag_batched")
+    assert st[0] == 0 and np.all(np.isfinite(acf[0])) and (st[1] & _lib.ST_LYAP_FAIL) and np.all(np.isnan(acf[1]))
