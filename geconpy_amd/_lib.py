@@ -25,6 +25,7 @@ ST_LYAP_FAIL = 4
 ST_FILTER_NONFINITE = 8
 ST_GENSYS_QZ_FAIL = 16
 ST_GENSYS_TOO_BIG = 32
+ST_GRAD_UNSUPPORTED = 64
 
 Q_DIAG_SHARED, Q_DIAG_BATCHED, Q_FULL_SHARED, Q_FULL_BATCHED = 0, 1, 2, 3
 SOLVER_CYCLE_REDUCTION, SOLVER_GENSYS, SOLVER_BACKWARD_DIRECT, SOLVER_SCAN_CYCLE_REDUCTION = 0, 1, 2, 3
@@ -80,6 +81,10 @@ PROTOTYPES = {
     "dsge_kalman_logp_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp],
     "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_grad_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i,
+                                            _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_grad_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
+                                                 _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_profile_pipeline": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _i, _dp, _dp],
 }
 

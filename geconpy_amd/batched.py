@@ -344,3 +344,40 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
     if return_policy:
         out.update(T=T, R=R, resid=resid, n_iter=n_iter)
     return out
+
+
+def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
+                                   jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
+                                   n_lead_hint=None):
+    """logp and its reverse-mode gradient per draw (include/dsge_hip.h: dsge_solve_kalman_logp_grad_batched): what
+    pytensor autodiff computes for the reference's logp graph, on the device.  ``q``: (k,) or (batch, k) diagonal shock
+    variances; ``Z``: selector design matrix (p, n), p <= 8; n <= 48.
+    Returns dict(logp, status, A_bar, B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar])."""
+    A, B, C = _check_abc(A, B, C)
+    D = _f64(D, 3)
+    y = _f64(y, 2)
+    nb, n, _ = A.shape
+    k = D.shape[2]
+    T_len, p = y.shape
+    q = _f64(q)
+    if q.shape not in ((k,), (nb, k)):
+        raise ValueError("q must be (k,) or (batch, k) (diagonal shock covariance)")
+    qb = int(q.ndim == 2)
+    Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, n)
+    ns = state_hint(A) if n_state_hint is None else int(n_state_hint)
+    nl = (lead_hint(C, tol) if solver == "gensys" else 0) if n_lead_hint is None else int(n_lead_hint)
+    out = dict(logp=np.empty(nb), status=np.empty(nb, dtype=np.int32), A_bar=np.empty_like(A), B_bar=np.empty_like(A),
+               C_bar=np.empty_like(A), D_bar=np.empty_like(D), q_bar=np.empty((nb, k)))
+    if d is not None:
+        out["d_bar"] = np.empty((nb, p))
+    if Hdiag is not None:
+        out["h_bar"] = np.empty((nb, p))
+    _lib.check(
+        _lib.load().dsge_solve_kalman_logp_grad_batched_host(
+            _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(q), qb, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, n, k, p,
+            T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter), float(missing_fill_value), ns, nl,
+            _ptr(out["logp"]), _ptr(out["status"]), _ptr(out["A_bar"]), _ptr(out["B_bar"]), _ptr(out["C_bar"]),
+            _ptr(out["D_bar"]), _ptr(out["q_bar"]), _ptr(out.get("d_bar")), _ptr(out.get("h_bar"))
+        )
+    )
+    return out

@@ -426,6 +426,75 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                   T_out, R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
 }
 
+int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const double* C, const double* D, const double* q,
+                                        int q_batched, const double* Z, int z_batched, const double* d, int d_batched,
+                                        const double* Hdiag, int h_batched, const double* y, int batch, int n, int k,
+                                        int p, int T_len, int solver, double tol, int max_iter, double jitter,
+                                        double missing_fill, int n_state_hint, int n_lead_hint, double* logp_out,
+                                        int32_t* status_out, double* A_bar, double* B_bar, double* C_bar, double* D_bar,
+                                        double* q_bar, double* d_bar, double* h_bar, void* stream) {
+  int rc = check_common(batch, n, 48);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (p < 1 || p > 8) return fail(DSGE_ERR_INVALID, "gradient path: p out of range (1..8)");
+  if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
+  if (!A || !B || !C || !D || !q || !Z || !y || !logp_out || !status_out || !A_bar || !B_bar || !C_bar || !D_bar || !q_bar)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_GENSYS && solver != DSGE_SOLVER_SCAN_CYCLE_REDUCTION)
+    return fail(DSGE_ERR_INVALID, "gradient path: solver must be cycle_reduction, scan_cycle_reduction or gensys");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  const int u_hint = (n_state_hint > 0) ? n_state_hint + p : 0;
+  // the reverse sweep re-reads every predicted (a_t, P_t): chunk the batch so that the store stays <= 2 GiB
+  const size_t per_draw = kalman_grad_store_doubles_per_draw(u_hint, n, T_len) * sizeof(double);
+  size_t chunk = per_draw ? ((size_t)2 << 30) / per_draw : (size_t)batch;
+  if (chunk < 1) chunk = 1;
+  if (chunk > (size_t)batch) chunk = (size_t)batch;
+  const size_t nn = chunk * n * n, nk = chunk * n * k;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_scratch, 4 * align256(nn * 8) + align256(nk * 8) + align256(chunk * 12) +
+                                         align256(chunk * per_draw + 8) + 8192,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  double* Tw = cv.take<double>(nn);
+  double* Rw = cv.take<double>(nk);
+  double* RQR = cv.take<double>(nn);
+  double* Tbar = cv.take<double>(nn);
+  double* Gbar = cv.take<double>(nn);
+  int32_t* eu_w = cv.take<int32_t>(chunk * 3);
+  double* store = cv.take<double>(chunk * per_draw / sizeof(double) + 1);
+  for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
+    const int nb = (int)(((size_t)batch - c0 < chunk) ? (size_t)batch - c0 : chunk);
+    const double *Ac = A + c0 * n * n, *Bc = B + c0 * n * n, *Cc = C + c0 * n * n, *Dc = D + c0 * n * k;
+    const double* qc = q + (q_batched ? c0 * k : 0);
+    const double* Zc = Z + (z_batched ? c0 * p * n : 0);
+    const double* dc = d ? d + (d_batched ? c0 * p : 0) : nullptr;
+    const double* hc = Hdiag ? Hdiag + (h_batched ? c0 * p : 0) : nullptr;
+    int32_t* stc = status_out + c0;
+    if (solver == DSGE_SOLVER_GENSYS)
+      rc = launch_gensys(Ac, Bc, Cc, nb, n, tol, n_lead_hint, Tw, eu_w, stc, st);
+    else
+      rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, nullptr, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
+    if (rc) return rc;
+    if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
+                              Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))
+      return rc;
+    if ((rc = launch_kalman_grad(Tw, RQR, Zc, z_batched, dc, d_batched, hc, h_batched, y, nb, n, p, T_len, jitter,
+                                 missing_fill, u_hint, store, logp_out + c0, stc, Tbar, Gbar,
+                                 d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st)))
+      return rc;
+    if ((rc = launch_grad_assemble(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, nb, n, k, stc, Tbar, B_bar + c0 * n * n,
+                                   C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * k, st)))
+      return rc;
+    if ((rc = launch_adjoint(Bc, Cc, Tw, Tbar, nb, n, A_bar + c0 * n * n, B_bar + c0 * n * n, C_bar + c0 * n * n, stc, st,
+                             1)))
+      return rc;
+  }
+  return DSGE_SUCCESS;
+}
+
 int dsge_profile_pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q,
                           int q_mode, const double* Z, int z_batched, const double* d, int d_batched,
                           const double* Hdiag, int h_batched, const double* y, int batch, int n, int k, int p,
@@ -706,6 +775,67 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
   DOWN(P0_out, dP, mm, double);
   DOWN(RQR_out, dX, mm, double);
   DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                             const double* q, int q_batched, const double* Z, int z_batched,
+                                             const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                             const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                             double tol, int max_iter, double jitter, double missing_fill,
+                                             int n_state_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                             double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                                             double* d_bar, double* h_bar) {
+  int rc = check_common(batch, n, 48);
+  if (rc) return rc;
+  if (k < 1 || k > n || p < 1 || p > 8 || T_len < 0) return fail(DSGE_ERR_INVALID, "bad sizes");
+  if (!A || !B || !C || !D || !q || !Z || !y || !logp_out || !status_out || !A_bar || !B_bar || !C_bar || !D_bar || !q_bar)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = (size_t)(q_batched ? batch : 1) * k;
+  const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
+               nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p, bp = (size_t)batch * p;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 6 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+                                       align256(nd * 8) + align256(nh * 8) + align256(ny * 8 + 8) +
+                                       2 * align256(bp * 8) + align256((size_t)batch * k * 8) +
+                                       2 * align256((size_t)batch * 8) + 8192,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dq, q, nq, double);
+  UP(dZ, Z, nz, double);
+  UP(dd, d, nd, double);
+  UP(dH, Hdiag, nh, double);
+  UP(dy, y, ny, double);
+  OUTBUF(dL, logp_out, batch, double);
+  OUTBUF(dS, status_out, batch, int32_t);
+  OUTBUF(gA, A_bar, nn, double);
+  OUTBUF(gB, B_bar, nn, double);
+  OUTBUF(gC, C_bar, nn, double);
+  OUTBUF(gD, D_bar, nk, double);
+  OUTBUF(gq, q_bar, (size_t)batch * k, double);
+  OUTBUF(gd, d_bar, bp, double);
+  OUTBUF(gh, h_bar, bp, double);
+  if ((rc = dsge_solve_kalman_logp_grad_batched(dA, dB, dC, dD, dq, q_batched, dZ, z_batched, dd, d_batched, dH, h_batched,
+                                                dy, batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
+                                                n_state_hint, n_lead_hint, dL, dS, gA, gB, gC, gD, gq, gd, gh, nullptr)))
+    return rc;
+  DOWN(logp_out, dL, batch, double);
+  DOWN(status_out, dS, batch, int32_t);
+  DOWN(A_bar, gA, nn, double);
+  DOWN(B_bar, gB, nn, double);
+  DOWN(C_bar, gC, nn, double);
+  DOWN(D_bar, gD, nk, double);
+  DOWN(q_bar, gq, (size_t)batch * k, double);
+  DOWN(d_bar, gd, bp, double);
+  DOWN(h_bar, gh, bp, double);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }

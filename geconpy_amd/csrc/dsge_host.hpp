@@ -58,7 +58,7 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
                     hipStream_t st);
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
-                   double* Bb, double* Cb, int32_t* status, hipStream_t st);
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate = 0);
 int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
                  const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st);
 int launch_acf(const double* T, const double* Sigma, const double* Z, const double* Hdiag, int batch, int m, int p,
@@ -67,6 +67,15 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st);
+// launch_grad.hip: reverse sweep of the Kalman filter + reverse of the assembly (dsge_kalman_grad.hpp)
+int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
+                       const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
+                       double jitter, double missing_fill, int u_hint, double* store, double* logp, int32_t* status,
+                       double* Tbar, double* Gbar, double* dbar, double* hbar, hipStream_t st);
+size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len);
+int launch_grad_assemble(const double* B, const double* C, const double* T, const double* R, const double* q,
+                         int q_batched, const double* Gbar, int batch, int n, int k, const int32_t* status, double* Tbar,
+                         double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st);
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr);

@@ -1,0 +1,639 @@
+// Reverse-mode gradient of the Kalman-filter log-likelihood (second half).
+//
+// The reference obtains d logp / d theta by pytensor autodiff through solve_discrete_lyapunov and the
+// pymc_extras filter scan (gEconpy/model/statespace.py:814-815, 1151-1157).  This kernel is that reverse
+// sweep written out by hand for ONE draw per wavefront, on the exactly reduced model of kalman_sel_kernel
+// (U = states + observed variables, states first; selector design matrix, p <= 8):
+//
+//   forward  (t = 0..T_len-1), storing the predicted (a_t, P_t) of every step in a global scratch:
+//     M = P Zm',  F = Zm M + Hm + jit I,  K = M F^-1,  v = ym - d - Zm a,  a+ = a + K v,
+//     P+ = P - K (M + jit K)' + jit I,  ll_t = -1/2 (p ln 2pi + ln det F + v' F^-1 v),
+//     a' = T a+,  P' = sym(T P+ T') + G                                  
+//   reverse  (t = T_len-1..0), cotangents (abar, Pbar) of the predicted moments of step t+1:
+//     Tbar += abar a+' + 2 Pbar T P+,   Gbar += Pbar,   a+bar = T' abar,   P+bar = T' Pbar T
+//     vbar  = -lam F^-1 v + K' a+bar
+//     Y     = P+bar K
+//     Kbar  = a+bar v' - 2 Y (F + jit I)
+//     Mbar  = Kbar F^-1
+//     Fbar  = -lam/2 (F^-1 - F^-1 v v' F^-1) - K' Y - K' Mbar
+//     Mbar += Zm' Fbar,   hbar += w o diag(Fbar)
+//     Pbar  = sym(P+bar + Mbar Zm),   abar = a+bar - Zm' vbar,   dbar -= vbar
+//   (lam = 1 unless every entry of y_t is missing), then the stationary initial covariance
+//   P0 = dlyap(T, G):   S = dlyap(T', Pbar_0) by doubling,   Gbar += S,   Tbar += 2 S T P0.
+// Outputs: logp, Tbar (cotangent of T; rows U, columns S -- the columns of T outside S are structurally
+// zero functions of the parameters), Gbar (cotangent of sym(R Q R'), block [U,U]), dbar, hbar.
+// Zbar is not produced (the selector design matrix is a constant of the model, statespace.py:282-296).
+//
+// Written for clarity, not speed: every matrix lives in LDS, products go through mm_acc register blocks.
+#pragma once
+#include "dsge_device.hpp"
+#include "dsge_kalman2.hpp"
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge {
+
+template <int BS>
+struct KgSmem {
+  static constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD, PS = 9;
+  // 9 NP x LDM matrices (Tc, Tt, P, Pb, Tb, Gb, X1, X2, X3), 5 NP x PS panels (M, K, Kb, Mb, Y),
+  // 4 8x8 (F, Fi, Fb, tmp), 6 NP vectors, 10 8-vectors, ints perm NP + zpos 8
+  __host__ __device__ static constexpr size_t doubles() {
+    return 9 * (size_t)NP * LDM + 5 * (size_t)NP * PS + 4 * 64 + 6 * NP + 10 * 8 + NP / 2 + 4;
+  }
+  static constexpr size_t bytes = sizeof(double) * doubles();
+};
+
+// dst (LDS, NP x LDM) = or += alpha * A B   (TB: A B').  dst must not alias A or B; caller fences.
+template <int BS, bool TB>
+__device__ __forceinline__ void kg_mm(double* dst, const double* A, const double* B, int K, double alpha, bool accumulate,
+                                      int lr, int lc) {
+  constexpr int LDM = Tile<BS>::LD;
+  double acc[BS][BS];
+  blk_zero<BS>(acc);
+  mm_acc<BS, TB>(acc, A, LDM, B, LDM, K, lr, lc);
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) {
+      double* d = &dst[(lr * BS + i) * LDM + lc * BS + j];
+      *d = accumulate ? fma(alpha, acc[i][j], *d) : alpha * acc[i][j];
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(64) void kalman_grad_kernel(
+    const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ Z, int z_batched,
+    const double* __restrict__ dvec, int d_batched, const double* __restrict__ Hdiag, int h_batched,
+    const double* __restrict__ y, int batch, int m_full, int p, int T_len, double jitter, double missing_fill,
+    double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
+    double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
+    double* __restrict__ hbar_out) {
+  constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
+  constexpr size_t STEP = (size_t)NP * NP + NP;  // doubles stored per time step: P (NP x NP, dense) then a
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Tc = smem;              // transition, states-first ordering (columns >= s are zero)
+  double* Tt = Tc + NP * LDM;     // its transpose
+  double* Ps = Tt + NP * LDM;     // predicted covariance of the current step
+  double* Pb = Ps + NP * LDM;     // cotangent of the predicted covariance
+  double* Tb = Pb + NP * LDM;     // cotangent of T (accumulated)
+  double* Gb = Tb + NP * LDM;     // cotangent of G = sym(R Q R') (accumulated)
+  double* X1 = Gb + NP * LDM;     // P+ / scratch
+  double* X2 = X1 + NP * LDM;
+  double* X3 = X2 + NP * LDM;
+  double* Mp = X3 + NP * LDM;     // M = P Zm'          NP x PS panels
+  double* Kp = Mp + NP * PS;      // K
+  double* Kb = Kp + NP * PS;      // Kbar
+  double* Mb = Kb + NP * PS;      // Mbar
+  double* Yp = Mb + NP * PS;      // Y = P+bar K
+  double* Fs = Yp + NP * PS;      // F
+  double* Fi = Fs + 64;           // F^-1
+  double* Fb = Fi + 64;           // Fbar
+  double* Ft = Fb + 64;           // scratch
+  double* av = Ft + 64;           // a (predicted)
+  double* ap = av + NP;           // a+
+  double* ab = ap + NP;           // abar
+  double* apb = ab + NP;          // a+bar
+  double* t1 = apb + NP;
+  double* t2 = t1 + NP;
+  double* vv = t2 + NP;           // v
+  double* vb = vv + 8;            // vbar
+  double* fiv = vb + 8;           // F^-1 v
+  double* dd = fiv + 8;
+  double* hh = dd + 8;
+  double* zv = hh + 8;
+  double* ww = zv + 8;            // observation weights of the step
+  double* db = ww + 8;            // dbar (accumulated)
+  double* hb = db + 8;            // hbar (accumulated)
+  double* sp = hb + 8;            // spare
+  int* perm = (int*)(sp + 8);
+  int* zpos = perm + NP;
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+  const int fo = lane >> 3, fq = lane & 7;
+  const double LN2PI = 1.8378770664093453;
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * m_full * m_full;
+    double* Tbo = Tbar_out + off;
+    double* Gbo = Gbar_out + off;
+    for (int idx = lane; idx < m_full * m_full; idx += 64) {
+      Tbo[idx] = 0.0;
+      Gbo[idx] = 0.0;
+    }
+    if (lane < p) {
+      if (dbar_out) dbar_out[(size_t)draw * p + lane] = 0.0;
+      if (hbar_out) hbar_out[(size_t)draw * p + lane] = 0.0;
+    }
+    if (status[draw] != 0) {
+      if (lane == 0) logp_out[draw] = -INFINITY;
+      continue;
+    }
+    wave_sync();
+    for (int idx = lane; idx < (int)KgSmem<BS>::doubles(); idx += 64) smem[idx] = 0.0;
+    // ---- reduction to U = S u O, states first (same construction as kalman_sel_kernel) -------------
+    const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
+    bool is_state = false;
+    if (lane < m_full)
+      for (int r = 0; r < m_full; ++r) is_state = is_state || (T[off + (size_t)r * m_full + lane] != 0.0);
+    const unsigned long long colmask = __ballot(is_state);
+    unsigned long long obsmask = 0ull, used = 0ull;
+    bool ok = p <= 8;
+    for (int o = 0; o < p; ++o) {
+      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
+      const unsigned long long b = __ballot(zl != 0.0);
+      if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
+      used |= b;
+      obsmask |= b;
+    }
+    const unsigned long long extra = obsmask & ~colmask;
+    const int s = __popcll(colmask);
+    const int u = s + __popcll(extra);
+    ok = ok && (u <= NP);
+    if (!ok) {  // dense design matrix or model too large for this tile: gradient not available here
+      if (lane == 0) {
+        status[draw] |= DSGE_ST_GRAD_UNSUPPORTED;
+        logp_out[draw] = __longlong_as_double(0x7ff8000000000000ll);
+      }
+      continue;
+    }
+    int my_pos = -1;
+    if (lane < m_full) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if ((colmask >> lane) & 1ull)
+        my_pos = __popcll(colmask & below);
+      else if ((extra >> lane) & 1ull)
+        my_pos = s + __popcll(extra & below);
+      if (my_pos >= 0) perm[my_pos] = lane;
+    }
+    for (int o = 0; o < p; ++o) {
+      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
+      if (zl != 0.0) {
+        zpos[o] = my_pos;
+        zv[o] = zl;
+      }
+    }
+    if (lane < 8) {
+      dd[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+      hh[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+    }
+    wave_sync();
+    // Tc, Tt <- T[U,U];  Gs (kept in X3 during the forward sweep) <- G[U,U]
+    for (int idx = lane; idx < u * u; idx += 64) {
+      const int i = idx / u, j = idx - i * u;
+      const size_t g = (size_t)perm[i] * m_full + perm[j];
+      const double tv = T[off + g];
+      Tc[i * LDM + j] = tv;
+      Tt[j * LDM + i] = tv;
+      X3[i * LDM + j] = RQR[off + g];
+    }
+    wave_sync();
+    // ---- P0 = dlyap(Tu, G) by doubling: P <- P + A P A', A <- A A  (A in X1) ---------------------
+    for (int idx = lane; idx < NP * LDM; idx += 64) {
+      Ps[idx] = X3[idx];
+      X1[idx] = Tc[idx];
+    }
+    wave_sync();
+    bool lyap_ok = false;
+    for (int itl = 0; itl < 64; ++itl) {
+      kg_mm<BS, true>(X2, Ps, X1, u, 1.0, false, lr, lc);   // P A'
+      wave_sync();
+      double inc[BS][BS], a2[BS][BS];
+      blk_zero<BS>(inc);
+      blk_zero<BS>(a2);
+      mm_acc<BS, false>(inc, X1, LDM, X2, LDM, u, lr, lc);  // A P A'
+      mm_acc<BS, false>(a2, X1, LDM, X1, LDM, u, lr, lc);   // A A
+      wave_sync();
+      double dmax = 0.0, pmax = 0.0;
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          double* pp = &Ps[(lr * BS + i) * LDM + lc * BS + j];
+          *pp += inc[i][j];
+          dmax = nanmax(dmax, fabs(inc[i][j]));
+          pmax = nanmax(pmax, fabs(*pp));
+          X1[(lr * BS + i) * LDM + lc * BS + j] = a2[i][j];
+        }
+      dmax = wave_nanmax(dmax);
+      pmax = wave_nanmax(pmax);
+      wave_sync();
+      if (!(dmax == dmax) || !(pmax < 1e300)) break;
+      if (dmax <= 1e-17 * pmax) {
+        lyap_ok = true;
+        break;
+      }
+    }
+    if (!lyap_ok) {
+      if (lane == 0) {
+        status[draw] |= DSGE_ST_LYAP_FAIL;
+        logp_out[draw] = -INFINITY;
+      }
+      continue;
+    }
+    // symmetrise P0 (the doubling keeps it symmetric up to rounding)
+    {
+      double a[BS][BS], b[BS][BS];
+      blk_load_lds<BS>(a, Ps, LDM, lr, lc);
+      blk_load_lds_t<BS>(b, Ps, LDM, lr, lc);
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Ps[(lr * BS + i) * LDM + lc * BS + j] = 0.5 * (a[i][j] + b[i][j]);
+    }
+    wave_sync();
+
+    double* st = store + (size_t)draw * T_len * STEP;
+    // The measurement update of one step from (av, Ps): fills ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+.
+    // Returns lam * (ln det F + v' F^-1 v) through `quad_logdet` (lam = 0 when every entry is missing).
+    auto update = [&](int t, double& ll_term, double& lam) {
+      const double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
+      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
+      const unsigned long long omask = __ballot(obs);
+      lam = (omask != 0ull) ? 1.0 : 0.0;
+      if (lane < 8) ww[lane] = (lane < p && obs) ? 1.0 : 0.0;
+      if (lane < p) vv[lane] = (obs ? yt : 0.0) - (dd[lane] + (obs ? 1.0 : 0.0) * zv[lane] * av[zpos[lane]]);
+      if (lane >= p && lane < 8) vv[lane] = 0.0;
+      wave_sync();
+      for (int idx = lane; idx < u * 8; idx += 64) {
+        const int i = idx >> 3, o = idx & 7;
+        Mp[i * PS + o] = (o < p) ? ww[o] * zv[o] * Ps[i * LDM + zpos[o]] : 0.0;
+      }
+      wave_sync();
+      double f;
+      if (fo < p && fq < p) {
+        f = ww[fo] * zv[fo] * Mp[zpos[fo] * PS + fq];
+        if (fo == fq) f += ww[fo] * hh[fo] + jitter;
+      } else {
+        f = (fo == fq) ? 1.0 : 0.0;
+      }
+      Fs[lane] = f;
+      double logdet = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < p) {
+          const double piv = readlane_f64(f, j * 9);
+          const double rowj = __shfl(f, (j << 3) | fq, 64);
+          const double colj = __shfl(f, (fo << 3) | j, 64);
+          const double inv = 1.0 / piv;
+          const double ci = colj * inv;
+          double nf = fma(-ci, rowj, f);
+          nf = (fo == j) ? rowj * inv : nf;
+          nf = (fq == j) ? -ci : nf;
+          nf = (fo == j && fq == j) ? inv : nf;
+          f = nf;
+          logdet += log(piv);
+        }
+      }
+      Fi[lane] = f;
+      wave_sync();
+      if (lane < 8) {
+        double sfv = 0.0;
+        for (int q = 0; q < 8; ++q) sfv = fma(Fi[lane * 8 + q], vv[q], sfv);
+        fiv[lane] = (lane < p) ? sfv : 0.0;
+      }
+      for (int idx = lane; idx < u * 8; idx += 64) {
+        const int i = idx >> 3, o = idx & 7;
+        double sk = 0.0;
+        for (int q = 0; q < 8; ++q) sk = fma(Mp[i * PS + q], Fi[q * 8 + o], sk);
+        Kp[i * PS + o] = (o < p) ? sk : 0.0;
+      }
+      wave_sync();
+      double quad = 0.0;
+      for (int q = 0; q < 8; ++q) quad = fma(vv[q], fiv[q], quad);
+      ll_term = lam * (logdet + quad);
+      if (lane < u) {
+        double sa = av[lane];
+        for (int o = 0; o < 8; ++o) sa = fma(Kp[lane * PS + o], vv[o], sa);
+        ap[lane] = sa;
+      }
+      // P+ = P - K (M + jit K)' + jit I
+      for (int idx = lane; idx < u * u; idx += 64) {
+        const int i = idx / u, j = idx - i * u;
+        double sp2 = Ps[i * LDM + j];
+        for (int o = 0; o < 8; ++o) sp2 = fma(-Kp[i * PS + o], fma(jitter, Kp[j * PS + o], Mp[j * PS + o]), sp2);
+        X1[i * LDM + j] = sp2 + ((i == j) ? jitter : 0.0);
+      }
+      wave_sync();
+    };
+
+    // ---- forward sweep ----------------------------------------------------------------------------
+    double ll_acc = 0.0;
+    long long n_ll = 0;
+    for (int t = 0; t < T_len; ++t) {
+      double* sg = st + (size_t)t * STEP;
+      for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
+      if (lane < NP) sg[NP * NP + lane] = av[lane];
+      double ll_term, lam;
+      update(t, ll_term, lam);
+      ll_acc += ll_term;
+      n_ll += (lam != 0.0);
+      // predict: a = T a+,  P = sym(T P+ T') + G
+      if (lane < u) {
+        double sa = 0.0;
+        for (int k2 = 0; k2 < u; ++k2) sa = fma(Tc[lane * LDM + k2], ap[k2], sa);
+        t1[lane] = sa;
+      }
+      kg_mm<BS, true>(X2, X1, Tc, u, 1.0, false, lr, lc);  // P+ T'
+      wave_sync();
+      if (lane < NP) av[lane] = (lane < u) ? t1[lane] : 0.0;
+      {
+        double xb[BS][BS], xt[BS][BS];
+        blk_zero<BS>(xb);
+        mm_acc<BS, false>(xb, Tc, LDM, X2, LDM, u, lr, lc);  // T P+ T'
+        const int src = (lc << 3) | lr;
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) xt[i][j] = __shfl(xb[j][i], src, 64);
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j)
+            Ps[(lr * BS + i) * LDM + lc * BS + j] = 0.5 * (xb[i][j] + xt[i][j]) + X3[(lr * BS + i) * LDM + lc * BS + j];
+      }
+      wave_sync();
+    }
+    const double logp = -0.5 * ((double)n_ll * (double)p * LN2PI + ll_acc);
+    if (lane == 0) {
+      logp_out[draw] = logp;
+      if (!((logp == logp) && (fabs(logp) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
+    }
+
+    // ---- reverse sweep ------------------------------------------------------------------------------
+    for (int idx = lane; idx < NP * LDM; idx += 64) {
+      Pb[idx] = 0.0;
+      Tb[idx] = 0.0;
+      Gb[idx] = 0.0;
+    }
+    if (lane < NP) ab[lane] = 0.0;
+    if (lane < 8) {
+      db[lane] = 0.0;
+      hb[lane] = 0.0;
+    }
+    wave_sync();
+    for (int t = T_len - 1; t >= 0; --t) {
+      const double* sg = st + (size_t)t * STEP;
+      for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = sg[idx];
+      if (lane < NP) av[lane] = sg[NP * NP + lane];
+      wave_sync();
+      double ll_term, lam;
+      update(t, ll_term, lam);  // ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+
+      // -- predict, reversed.  (abar, Pb) are the cotangents of (a_{t+1}, P_{t+1}).
+      kg_mm<BS, false>(X2, Tc, X1, u, 1.0, false, lr, lc);   // T P+
+      if (lane < u) {
+        double sa = 0.0;
+        for (int i = 0; i < u; ++i) sa = fma(Tc[i * LDM + lane], ab[i], sa);
+        apb[lane] = sa;  // a+bar = T' abar
+      }
+      for (int idx = lane; idx < NP * LDM; idx += 64) Gb[idx] += Pb[idx];  // Gbar += Pbar
+      wave_sync();
+      kg_mm<BS, false>(Tb, Pb, X2, u, 2.0, true, lr, lc);    // Tbar += 2 Pbar T P+
+      kg_mm<BS, false>(X3, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
+      wave_sync();
+      for (int idx = lane; idx < u * u; idx += 64) {
+        const int i = idx / u, j = idx - i * u;
+        Tb[i * LDM + j] = fma(ab[i], ap[j], Tb[i * LDM + j]);  // Tbar += abar a+'
+      }
+      kg_mm<BS, false>(X2, Tt, X3, u, 1.0, false, lr, lc);   // P+bar = T' Pbar T
+      wave_sync();
+      // -- update, reversed (P+bar in X2)
+      for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
+        const int i = idx >> 3, o = idx & 7;
+        double sy = 0.0;
+        for (int j = 0; j < u; ++j) sy = fma(X2[i * LDM + j], Kp[j * PS + o], sy);
+        Yp[i * PS + o] = sy;
+      }
+      if (lane < 8) {  // vbar = -lam F^-1 v + K' a+bar
+        double sv = -lam * fiv[lane];
+        for (int i = 0; i < u; ++i) sv = fma(Kp[i * PS + lane], apb[i], sv);
+        vb[lane] = (lane < p) ? sv : 0.0;
+      }
+      wave_sync();
+      for (int idx = lane; idx < u * 8; idx += 64) {  // Kbar = a+bar v' - 2 Y (F + jit I)
+        const int i = idx >> 3, o = idx & 7;
+        double sk = apb[i] * vv[o];
+        for (int q = 0; q < 8; ++q) sk = fma(-2.0 * Yp[i * PS + q], Fs[q * 8 + o] + ((q == o) ? jitter : 0.0), sk);
+        Kb[i * PS + o] = (o < p) ? sk : 0.0;
+      }
+      wave_sync();
+      for (int idx = lane; idx < u * 8; idx += 64) {  // Mbar = Kbar F^-1
+        const int i = idx >> 3, o = idx & 7;
+        double sm = 0.0;
+        for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], Fi[q * 8 + o], sm);
+        Mb[i * PS + o] = (o < p) ? sm : 0.0;
+      }
+      wave_sync();
+      {  // Fbar = -lam/2 (F^-1 - fiv fiv') - K' Y - K' Mbar      (lane = fo*8 + fq)
+        double sf = 0.0;
+        if (fo < p && fq < p) {
+          sf = -0.5 * lam * (Fi[lane] - fiv[fo] * fiv[fq]);
+          for (int i = 0; i < u; ++i) sf = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], sf);
+        }
+        Fb[lane] = sf;
+      }
+      wave_sync();
+      if (lane < 8 && lane < p) hb[lane] = fma(ww[lane], Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)
+      if (fo < p && fq < p) {  // Mbar += Zm' Fbar: row zpos[fo] (distinct per fo) gets w zv Fbar[fo,:]
+        Mb[zpos[fo] * PS + fq] = fma(ww[fo] * zv[fo], Fb[lane], Mb[zpos[fo] * PS + fq]);
+      }
+      wave_sync();
+      // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]
+      for (int idx = lane; idx < u * 8; idx += 64) {
+        const int i = idx >> 3, o = idx & 7;
+        if (o < p) X2[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], X2[i * LDM + zpos[o]]);
+      }
+      if (lane < u) t1[lane] = apb[lane];
+      wave_sync();
+      if (lane < p) {  // abar = a+bar - Zm' vbar;  dbar -= vbar
+        t1[zpos[lane]] = fma(-ww[lane] * zv[lane], vb[lane], t1[zpos[lane]]);
+        db[lane] -= vb[lane];
+      }
+      for (int idx = lane; idx < u * u; idx += 64) {
+        const int i = idx / u, j = idx - i * u;
+        Pb[i * LDM + j] = 0.5 * (X2[i * LDM + j] + X2[j * LDM + i]);
+      }
+      wave_sync();
+      if (lane < NP) ab[lane] = (lane < u) ? t1[lane] : 0.0;
+      wave_sync();
+    }
+    // ---- initial covariance: S = dlyap(T', Pbar_0) by doubling; Gbar += S; Tbar += 2 S T P0 ---------
+    // S in Pb, A = T^(2^k) in X1, A' in X3
+    for (int idx = lane; idx < NP * LDM; idx += 64) {
+      X1[idx] = Tc[idx];
+      X3[idx] = Tt[idx];
+    }
+    wave_sync();
+    for (int itl = 0; itl < 64; ++itl) {
+      kg_mm<BS, false>(X2, Pb, X1, u, 1.0, false, lr, lc);  // S A
+      wave_sync();
+      double inc[BS][BS], a2[BS][BS], at2[BS][BS];
+      blk_zero<BS>(inc);
+      blk_zero<BS>(a2);
+      blk_zero<BS>(at2);
+      mm_acc<BS, false>(inc, X3, LDM, X2, LDM, u, lr, lc);  // A' S A
+      mm_acc<BS, false>(a2, X1, LDM, X1, LDM, u, lr, lc);
+      mm_acc<BS, false>(at2, X3, LDM, X3, LDM, u, lr, lc);
+      wave_sync();
+      double dmax = 0.0, smax = 0.0;
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int e = (lr * BS + i) * LDM + lc * BS + j;
+          Pb[e] += inc[i][j];
+          dmax = nanmax(dmax, fabs(inc[i][j]));
+          smax = nanmax(smax, fabs(Pb[e]));
+          X1[e] = a2[i][j];
+          X3[e] = at2[i][j];
+        }
+      dmax = wave_nanmax(dmax);
+      smax = wave_nanmax(smax);
+      wave_sync();
+      if (!(dmax == dmax) || dmax <= 1e-17 * smax || smax == 0.0) break;
+    }
+    for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = st[idx];  // P0
+    for (int idx = lane; idx < NP * LDM; idx += 64) Gb[idx] += Pb[idx];
+    wave_sync();
+    kg_mm<BS, false>(X2, Tc, Ps, u, 1.0, false, lr, lc);  // T P0
+    wave_sync();
+    kg_mm<BS, false>(Tb, Pb, X2, u, 2.0, true, lr, lc);   // Tbar += 2 S T P0
+    wave_sync();
+    // ---- scatter to the caller's variable order -----------------------------------------------------
+    for (int idx = lane; idx < u * u; idx += 64) {
+      const int i = idx / u, j = idx - i * u;
+      const size_t g = (size_t)perm[i] * m_full + perm[j];
+      if (j < s) Tbo[g] = Tb[i * LDM + j];
+      Gbo[g] = Gb[i * LDM + j];
+    }
+    if (lane < p) {
+      if (dbar_out) dbar_out[(size_t)draw * p + lane] = db[lane];
+      if (hbar_out) hbar_out[(size_t)draw * p + lane] = hb[lane];
+    }
+  }
+}
+
+}  // namespace dsge
+
+namespace dsge {
+
+// -------------------------------------------------------------------------------------------------------
+// Reverse of the state-space assembly (full model size n), between the Kalman reverse sweep and the
+// policy-function adjoints:
+//   G = sym(R Q R'), Q = diag(q):   Rbar = 2 Gbar R Q,   qbar_j = (R' Gbar R)_jj
+//   R = -M^-1 D,  M = B + C T  (gEconpy/solvers/shared.py:74-75):
+//       X = M^-T Rbar,   Dbar = -X,   Mbar = -X R',   Bbar = Mbar,   Cbar = Mbar T',   Tbar += C' Mbar
+// Tbar then goes through adjoint_kernel (shared.py:12-71), which ADDS its B, C cotangents to these.
+// -------------------------------------------------------------------------------------------------------
+template <int BS>
+struct GaSmem {
+  static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 2 * NP + 1;
+  // Ts, Cs, Ms, Rs (NP x LD), W (NP x LDW), GJ scratch
+  static constexpr size_t bytes = sizeof(double) * (size_t)(4 * NP * LD + NP * LDW + NP * BS + BS * 2 * NP + NP / 2);
+};
+
+template <int BS>
+__global__ __launch_bounds__(64) void grad_assemble_kernel(
+    const double* __restrict__ B, const double* __restrict__ C, const double* __restrict__ T,
+    const double* __restrict__ R, const double* __restrict__ q, int q_batched, const double* __restrict__ Gbar,
+    int batch, int n, int k, const int32_t* __restrict__ status, double* __restrict__ Tbar,
+    double* __restrict__ B_bar, double* __restrict__ C_bar, double* __restrict__ D_bar, double* __restrict__ q_bar) {
+  constexpr int NP = GaSmem<BS>::NP, LD = GaSmem<BS>::LD, LDW = GaSmem<BS>::LDW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ts = smem;
+  double* Cs = Ts + NP * LD;   // C, later C'
+  double* Ms = Cs + NP * LD;   // Gbar, later Mbar
+  double* Rs = Ms + NP * LD;   // R (n x k, zero padded), later X
+  double* W = Rs + NP * LD;    // [M' | Rbar]
+  double* Lbuf = W + NP * LDW;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 2 * NP);
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
+    if (status[draw] != 0) {  // failed draw: zero cotangents
+      double z[BS][BS];
+      blk_zero<BS>(z);
+      blk_store_global<BS>(z, B_bar + off, n, n, n, lr, lc);
+      blk_store_global<BS>(z, C_bar + off, n, n, n, lr, lc);
+      blk_store_global<BS>(z, D_bar + offk, n, k, k, lr, lc);
+      if (lane < k) q_bar[(size_t)draw * k + lane] = 0.0;
+      continue;
+    }
+    wave_sync();
+    for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+    lds_load_matrix(Ts, LD, NP, NP, T + off, n, n, lane);
+    lds_load_matrix(Cs, LD, NP, NP, C + off, n, n, lane);
+    lds_load_matrix(Ms, LD, NP, NP, Gbar + off, n, n, lane);
+    lds_load_matrix(Rs, LD, NP, NP, R + offk, n, k, lane);
+    wave_sync();
+    const double* qd = q + (q_batched ? (size_t)draw * k : 0);
+    // GR = Gbar R  (n x k);  Rbar = 2 GR Q;  qbar_j = sum_i R_ij GR_ij
+    double GR[BS][BS], Rb[BS][BS];
+    blk_zero<BS>(GR);
+    mm_acc<BS, false>(GR, Ms, LD, Rs, LD, n, lr, lc);
+    blk_load_lds<BS>(Rb, Rs, LD, lr, lc);
+    double Rbar[BS][BS];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) {
+      const int c = lc * BS + j;
+      const double qj = (c < k) ? qd[c] : 0.0;
+      double colsum = 0.0;
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
+        Rbar[i][j] = 2.0 * GR[i][j] * qj;
+        colsum = fma(Rb[i][j], GR[i][j], colsum);
+      }
+      colsum += shfl_xor_f64(colsum, 8);
+      colsum += shfl_xor_f64(colsum, 16);
+      colsum += shfl_xor_f64(colsum, 32);
+      if (lr == 0 && c < k) q_bar[(size_t)draw * k + c] = colsum;
+    }
+    // M = B + C T; W = [M' | Rbar]
+    {
+      double Mb[BS][BS];
+      blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
+      mm_acc<BS, false>(Mb, Cs, LD, Ts, LD, n, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) W[(lc * BS + j) * LDW + lr * BS + i] = Mb[i][j];
+      blk_store_lds<BS>(Rbar, W + NP, LDW, lr, lc);
+    }
+    gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+    gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+    double Xb[BS][BS];
+    blk_load_lds<BS>(Xb, W + NP, LDW, lr, lc);  // X = M^-T Rbar  (columns >= k are zero)
+    blk_store_global<BS>(Xb, D_bar + offk, n, k, k, lr, lc, -1.0);
+    // Mbar = -X R'
+    wave_sync();
+    blk_store_lds<BS>(Xb, W, LDW, lr, lc);  // X -> dead group 0
+    {
+      double Ct[BS][BS];
+      blk_load_lds_t<BS>(Ct, Cs, LD, lr, lc);
+      wave_sync();
+      blk_store_lds<BS>(Ct, Cs, LD, lr, lc);  // Cs <- C'
+    }
+    wave_sync();
+    double Mbar[BS][BS];
+    blk_zero<BS>(Mbar);
+    mm_acc<BS, true>(Mbar, W, LDW, Rs, LD, k, lr, lc);  // X R'
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Mbar[i][j] = -Mbar[i][j];
+    blk_store_global<BS>(Mbar, B_bar + off, n, n, n, lr, lc);
+    wave_sync();
+    blk_store_lds<BS>(Mbar, Ms, LD, lr, lc);
+    wave_sync();
+    double Cb[BS][BS], Tb[BS][BS];
+    blk_zero<BS>(Cb);
+    mm_acc<BS, true>(Cb, Ms, LD, Ts, LD, n, lr, lc);  // Mbar T'
+    blk_store_global<BS>(Cb, C_bar + off, n, n, n, lr, lc);
+    blk_load_global<BS>(Tb, Tbar + off, n, n, n, lr, lc);
+    mm_acc<BS, false>(Tb, Cs, LD, Ms, LD, n, lr, lc);  // Tbar += C' Mbar
+    blk_store_global<BS>(Tb, Tbar + off, n, n, n, lr, lc);
+  }
+}
+
+}  // namespace dsge

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
                                                       const double* __restrict__ T, const double* __restrict__ T_bar,
                                                       int batch, int n, double* __restrict__ A_bar,
                                                       double* __restrict__ B_bar, double* __restrict__ C_bar,
-                                                      int32_t* __restrict__ status) {
+                                                      int32_t* __restrict__ status, int accumulate) {
   constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;             // [M' | T_bar | C'] -> [. | M^-T T_bar | M^-T C'];  later [W1 | S | G_k]
@@ -508,15 +508,37 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       double Bb[BS][BS], Cb[BS][BS];
       blk_zero<BS>(Bb);
       mm_acc<BS, true>(Bb, W + NP, LDW, Ts, LD, n, lr, lc);  // S T'
-      blk_store_global<BS>(Bb, B_bar + off, n, n, n, lr, lc);
+      if (accumulate) {  // gradient pipeline: B_bar, C_bar already hold the cotangents that came through R
+        double t0[BS][BS];
+        blk_load_global<BS>(t0, B_bar + off, n, n, n, lr, lc);
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) t0[i][j] += Bb[i][j];
+        blk_store_global<BS>(t0, B_bar + off, n, n, n, lr, lc);
+      } else {
+        blk_store_global<BS>(Bb, B_bar + off, n, n, n, lr, lc);
+      }
       wave_sync();
       blk_store_lds<BS>(Bb, W, LDW, lr, lc);
       wave_sync();
       blk_zero<BS>(Cb);
       mm_acc<BS, true>(Cb, W, LDW, Ts, LD, n, lr, lc);       // S T' T'
+      if (accumulate) {
+        double t0[BS][BS];
+        blk_load_global<BS>(t0, C_bar + off, n, n, n, lr, lc);
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) Cb[i][j] += t0[i][j];
+      }
       blk_store_global<BS>(Cb, C_bar + off, n, n, n, lr, lc);
     }
-    if (lane == 0) status[draw] = ok ? DSGE_ST_OK : DSGE_ST_NOT_CONVERGED;
+    if (accumulate) {
+      if (lane == 0 && !ok) status[draw] |= DSGE_ST_NOT_CONVERGED;
+    } else if (lane == 0) {
+      status[draw] = ok ? DSGE_ST_OK : DSGE_ST_NOT_CONVERGED;
+    }
   }
 }
 

@@ -23,14 +23,14 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
 }
 
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
-                   double* Bb, double* Cb, int32_t* status, hipStream_t st) {
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 6, {
     rc = set_lds(dsge::adjoint_kernel<BS>, dsge::AdjSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::adjoint_kernel<BS>, dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
-                         batch, n, Ab, Bb, Cb, status);
+                         batch, n, Ab, Bb, Cb, status, accumulate);
       HIP_TRY(hipGetLastError());
     }
   });

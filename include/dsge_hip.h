@@ -54,6 +54,7 @@ extern "C" {
 #define DSGE_ST_FILTER_NONFINITE 8 /* non-finite log-likelihood (F not positive definite...) */
 #define DSGE_ST_GENSYS_QZ_FAIL 16  /* QZ iteration did not converge                           */
 #define DSGE_ST_GENSYS_TOO_BIG 32  /* n + #lead exceeds the on-chip capacity of the launch     */
+#define DSGE_ST_GRAD_UNSUPPORTED 64 /* gradient path: dense design matrix / reduced model exceeds the tile */
 
 /* covariance layouts for the Q argument */
 #define DSGE_Q_DIAG_SHARED 0    /* Q = diag(q), q: [k]            */
@@ -307,6 +308,41 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         int n_state_hint, int z_selector_hint, int n_lead_hint,
                                         double* logp_out, int32_t* status_out, double* T_out,
                                         double* R_out, double* resid_out, int32_t* n_iter_out);
+
+/*
+ * Fused evaluation WITH reverse-mode gradient: logp and its cotangents with respect to A, B, C, D, the shock
+ * variances q, the observation intercept d and the measurement-error variances Hdiag, per draw.  This is what
+ * pytensor autodiff produces for the reference's logp graph (solver pullback gensys.py:668-676 /
+ * cycle_reduction.py:117-124 = o1_policy_function_adjoints shared.py:12-71; R = -(C T + B)^-1 D shared.py:74-75;
+ * P0 = solve_discrete_lyapunov statespace.py:814-815; the filter scan statespace.py:1151-1157), written as four
+ * kernels: Kalman reverse sweep on the reduced model (stores every predicted (a_t, P_t) in library scratch, the
+ * batch is processed in chunks of <= 2 GiB), reverse of the assembly, policy-function adjoints.
+ *   q : [k] (q_batched=0) or [batch][k] diagonal shock covariance;  Z : selector design matrix (one non-zero per
+ *       row, distinct columns), [p][n] or [batch][p][n];  p <= 8;  n <= 48
+ *   A_bar,B_bar,C_bar : [batch][n][n];  D_bar : [batch][n][k];  q_bar : [batch][k] (also for a shared q: sum over
+ *       the batch for a joint logp);  d_bar, h_bar : [batch][p] or NULL
+ *   Contract: the columns of A that are exactly zero (non-state variables) are treated as structurally zero -- T has
+ *   exactly-zero columns there for every parameter value, so A_bar is meaningful on the non-zero columns of A only
+ *   (the others multiply dA = 0 in any chain rule through the model's Jacobians).  No cotangent is produced for Z, y.
+ *   A draw whose design matrix is not a selector or whose reduced model exceeds the tile gets
+ *   DSGE_ST_GRAD_UNSUPPORTED, logp = NaN and zero cotangents.
+ */
+int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const double* C, const double* D,
+                                        const double* q, int q_batched, const double* Z, int z_batched,
+                                        const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                        const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                        double tol, int max_iter, double jitter, double missing_fill, int n_state_hint,
+                                        int n_lead_hint, double* logp_out, int32_t* status_out, double* A_bar,
+                                        double* B_bar, double* C_bar, double* D_bar, double* q_bar, double* d_bar,
+                                        double* h_bar, void* stream);
+int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                             const double* q, int q_batched, const double* Z, int z_batched,
+                                             const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                             const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                             double tol, int max_iter, double jitter, double missing_fill,
+                                             int n_state_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                             double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                                             double* d_bar, double* h_bar);
 
 /*
  * Timing hook for bench.py: runs `reps` back-to-back launches of the fused pipeline's
