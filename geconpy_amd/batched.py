@@ -347,7 +347,7 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
 
 
 def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
-                                   jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
+                                   jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=None,
                                    n_lead_hint=None):
     """logp and its reverse-mode gradient per draw (include/dsge_hip.h: dsge_solve_kalman_logp_grad_batched): what
     pytensor autodiff computes for the reference's logp graph, on the device.  ``q``: (k,) or (batch, k) diagonal shock
@@ -364,7 +364,10 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
         raise ValueError("q must be (k,) or (batch, k) (diagonal shock covariance)")
     qb = int(q.ndim == 2)
     Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, n)
-    ns = state_hint(A) if n_state_hint is None else int(n_state_hint)
+    if n_filter_hint is None:  # |S u O|: non-zero columns of A (in any draw) or of Z
+        ns = int(np.count_nonzero(np.any(A.reshape(-1, n) != 0, axis=0) | np.any(Z.reshape(-1, n) != 0, axis=0)))
+    else:
+        ns = int(n_filter_hint)
     nl = (lead_hint(C, tol) if solver == "gensys" else 0) if n_lead_hint is None else int(n_lead_hint)
     out = dict(logp=np.empty(nb), status=np.empty(nb, dtype=np.int32), A_bar=np.empty_like(A), B_bar=np.empty_like(A),
                C_bar=np.empty_like(A), D_bar=np.empty_like(D), q_bar=np.empty((nb, k)))

@@ -430,7 +430,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
                                         int q_batched, const double* Z, int z_batched, const double* d, int d_batched,
                                         const double* Hdiag, int h_batched, const double* y, int batch, int n, int k,
                                         int p, int T_len, int solver, double tol, int max_iter, double jitter,
-                                        double missing_fill, int n_state_hint, int n_lead_hint, double* logp_out,
+                                        double missing_fill, int n_filter_hint, int n_lead_hint, double* logp_out,
                                         int32_t* status_out, double* A_bar, double* B_bar, double* C_bar, double* D_bar,
                                         double* q_bar, double* d_bar, double* h_bar, void* stream) {
   int rc = check_common(batch, n, 48);
@@ -445,7 +445,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
-  const int u_hint = (n_state_hint > 0) ? n_state_hint + p : 0;
+  const int u_hint = n_filter_hint;
   // the reverse sweep re-reads every predicted (a_t, P_t): chunk the batch so that the store stays <= 2 GiB
   const size_t per_draw = kalman_grad_store_doubles_per_draw(u_hint, n, T_len) * sizeof(double);
   size_t chunk = per_draw ? ((size_t)2 << 30) / per_draw : (size_t)batch;
@@ -784,7 +784,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
                                              const double* d, int d_batched, const double* Hdiag, int h_batched,
                                              const double* y, int batch, int n, int k, int p, int T_len, int solver,
                                              double tol, int max_iter, double jitter, double missing_fill,
-                                             int n_state_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                             int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
                                              double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
                                              double* d_bar, double* h_bar) {
   int rc = check_common(batch, n, 48);
@@ -825,7 +825,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   OUTBUF(gh, h_bar, bp, double);
   if ((rc = dsge_solve_kalman_logp_grad_batched(dA, dB, dC, dD, dq, q_batched, dZ, z_batched, dd, d_batched, dH, h_batched,
                                                 dy, batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
-                                                n_state_hint, n_lead_hint, dL, dS, gA, gB, gC, gD, gq, gd, gh, nullptr)))
+                                                n_filter_hint, n_lead_hint, dL, dS, gA, gB, gC, gD, gq, gd, gh, nullptr)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_out, dS, batch, int32_t);

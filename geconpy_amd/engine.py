@@ -126,6 +126,24 @@ class LogpEngine:
             raise ValueError("the program has no shock variances; call jacobians_from_theta + solve_kalman_logp")
         return self.solve_kalman_logp(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, q_mode=1, **kw)
 
+    def logp_and_grad_from_theta(self, program, theta, Z, y, d=None, Hdiag=None, jac_out=None, grad_out=None,
+                                 theta_bar=None, **kw):
+        """theta -> (logp, status, d logp / d theta) entirely on the device: generated Jacobian kernel, the fused
+        logp + reverse-mode pipeline, and the generated pullback kernel theta_bar = J' (A_bar, B_bar, C_bar, D_bar,
+        q_bar) -- the interface a gradient-based sampler (NUTS) needs.  Cotangents of d / Hdiag stay available in the
+        returned dict (``grad``)."""
+        torch = self.torch
+        A, B, C, D, q = self.jacobians_from_theta(program, theta, out=jac_out)
+        if q is None:
+            raise ValueError("the program has no shock variances")
+        g = self.solve_kalman_logp_grad(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, out=grad_out, **kw)
+        if theta_bar is None:
+            theta_bar = torch.empty_like(theta)
+        program.launch_vjp(theta.data_ptr(), theta.shape[0], g["A_bar"].data_ptr(), g["B_bar"].data_ptr(),
+                           g["C_bar"].data_ptr(), g["D_bar"].data_ptr(), g["q_bar"].data_ptr(), theta_bar.data_ptr(),
+                           self._stream())
+        return g["logp"], g["status"], theta_bar, g
+
     # -- product entry points --------------------------------------------------------------
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
@@ -147,6 +165,47 @@ class LogpEngine:
             )
         )
         return logp, status
+
+    def solve_kalman_logp_grad(self, A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
+                               jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=0, n_lead_hint=0,
+                               out=None):
+        """logp and its reverse-mode gradient for the whole batch, device-resident (dsge_solve_kalman_logp_grad_batched).
+        ``q``: (k,) or (batch, k) diagonal shock variances.  Returns a dict of tensors: logp, status, A_bar, B_bar, C_bar,
+        D_bar, q_bar[, d_bar][, h_bar] (asynchronous).  ``out`` may carry the same dict from an earlier call to reuse
+        the buffers."""
+        torch = self.torch
+        nb, n, _ = A.shape
+        k = D.shape[2]
+        T_len, p = y.shape
+        for t in (A, B, C):
+            self._chk(t, (nb, n, n))
+        self._chk(D, (nb, n, k))
+        self._chk(y, (T_len, p))
+        self._chk(q)
+        if tuple(q.shape) not in ((k,), (nb, k)):
+            raise ValueError("q must be (k,) or (batch, k)")
+        zb = int(self._chk(Z).dim() == 3)
+        db = int(d is not None and self._chk(d).dim() == 2)
+        hb = int(Hdiag is not None and self._chk(Hdiag).dim() == 2)
+        if out is None:
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.device)  # noqa: E731
+            out = dict(logp=mk(nb), status=torch.empty(nb, dtype=torch.int32, device=self.device), A_bar=mk(nb, n, n),
+                       B_bar=mk(nb, n, n), C_bar=mk(nb, n, n), D_bar=mk(nb, n, k), q_bar=mk(nb, k))
+            if d is not None:
+                out["d_bar"] = mk(nb, p)
+            if Hdiag is not None:
+                out["h_bar"] = mk(nb, p)
+        _lib.check(
+            self.lib.dsge_solve_kalman_logp_grad_batched(
+                self._p(A), self._p(B), self._p(C), self._p(D), self._p(q), int(q.dim() == 2), self._p(Z), zb, self._p(d), db,
+                self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter),
+                float(jitter), float(missing_fill_value), int(n_filter_hint), int(n_lead_hint), self._p(out["logp"]),
+                out["status"].data_ptr(), self._p(out["A_bar"]), self._p(out["B_bar"]), self._p(out["C_bar"]),
+                self._p(out["D_bar"]), self._p(out["q_bar"]), self._p(out.get("d_bar")), self._p(out.get("h_bar")),
+                self._stream(),
+            )
+        )
+        return out
 
     def profile_kernels(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                         tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, reps=5,

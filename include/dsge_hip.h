@@ -324,6 +324,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
  *   Contract: the columns of A that are exactly zero (non-state variables) are treated as structurally zero -- T has
  *   exactly-zero columns there for every parameter value, so A_bar is meaningful on the non-zero columns of A only
  *   (the others multiply dA = 0 in any chain rule through the model's Jacobians).  No cotangent is produced for Z, y.
+ *   n_filter_hint : upper bound on the number of variables the filter keeps, |S u O| = non-zero columns of A plus
+ *       observed non-states (0 = unknown: tile sized for n); it only sizes the tile, a draw that exceeds it is flagged.
  *   A draw whose design matrix is not a selector or whose reduced model exceeds the tile gets
  *   DSGE_ST_GRAD_UNSUPPORTED, logp = NaN and zero cotangents.
  */
@@ -331,7 +333,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
                                         const double* q, int q_batched, const double* Z, int z_batched,
                                         const double* d, int d_batched, const double* Hdiag, int h_batched,
                                         const double* y, int batch, int n, int k, int p, int T_len, int solver,
-                                        double tol, int max_iter, double jitter, double missing_fill, int n_state_hint,
+                                        double tol, int max_iter, double jitter, double missing_fill, int n_filter_hint,
                                         int n_lead_hint, double* logp_out, int32_t* status_out, double* A_bar,
                                         double* B_bar, double* C_bar, double* D_bar, double* q_bar, double* d_bar,
                                         double* h_bar, void* stream);
@@ -340,7 +342,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
                                              const double* d, int d_batched, const double* Hdiag, int h_batched,
                                              const double* y, int batch, int n, int k, int p, int T_len, int solver,
                                              double tol, int max_iter, double jitter, double missing_fill,
-                                             int n_state_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                             int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
                                              double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
                                              double* d_bar, double* h_bar);
 

@@ -1,0 +1,18 @@
+"""GPU box: rate of logp + gradient evaluations (dsge_solve_kalman_logp_grad_batched) on the SW-shaped workload."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from geconpy_amd import workloads as wl
+from geconpy_amd.engine import LogpEngine
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+b = wl.sw_shaped_batch(min(nb, 64)); om = wl.sw_shaped_observation_model(); rep = (nb + 63) // 64
+eng = LogpEngine(0)
+A, B, C, D = (eng.to_device(np.tile(b[x], (rep, 1, 1))[:nb]) for x in "ABCD")
+q = eng.to_device(np.tile(b["sigma"] ** 2, (rep, 1))[:nb]); Z = eng.to_device(om["Z"]); y = eng.to_device(om["y"]); H = eng.to_device(om["Hdiag"])
+out = None
+for it in range(4):
+    if it == 1:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+print(f"{nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {int((out['status'] != 0).sum())}")
