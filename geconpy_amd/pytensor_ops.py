@@ -204,6 +204,64 @@ class HipSolveKalmanLogp(Op):
         outputs[0][0] = out["logp"]
         outputs[1][0] = out["status"]
 
+    def pullback(self, inputs, outputs, cotangents):
+        """Reverse mode through the whole fused evaluation on the device (dsge_solve_kalman_logp_grad_batched):
+        cotangents of A, B, C, D, q, d, Hdiag; Z and y are treated as constants of the model (no cotangent --
+        gEconpy's selector design matrix and the data)."""
+        from pytensor.gradient import disconnected_type  # noqa: PLC0415
+
+        A, B, C, D, q, Z, y, d, Hdiag = inputs
+        g_logp = cotangents[0]
+        grads = HipSolveKalmanLogpGrad(solver=self.solver, tol=self.tol, max_iter=self.max_iter, jitter=self.jitter,
+                                       missing_fill_value=self.missing_fill_value)(A, B, C, D, q, Z, y, d, Hdiag)
+        A_bar, B_bar, C_bar, D_bar, q_bar, d_bar, h_bar = grads
+        w3, w2 = g_logp[:, None, None], g_logp[:, None]
+        # d / Hdiag are shared across draws: (p,) inputs receive the sum over the batch
+        d_g = (w2 * d_bar).sum(axis=0) if d.type.ndim == 1 else w2 * d_bar
+        h_g = (w2 * h_bar).sum(axis=0) if Hdiag.type.ndim == 1 else w2 * h_bar
+        return [w3 * A_bar, w3 * B_bar, w3 * C_bar, w3 * D_bar, w2 * q_bar, disconnected_type(), disconnected_type(), d_g, h_g]
+
+
+class HipSolveKalmanLogpGrad(Op):
+    """Cotangents of the fused logp Op: ``A_bar, B_bar, C_bar, D_bar, q_bar, d_bar, h_bar = Op(A, B, C, D, q, Z, y, d,
+    Hdiag)`` per draw (for a unit cotangent of logp), computed by the device's reverse sweep."""
+
+    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value")
+
+    def __init__(self, solver="cycle_reduction", tol=1e-6, max_iter=50, jitter=batched.JITTER_DEFAULT,
+                 missing_fill_value=batched.MISSING_FILL):
+        self.solver = solver
+        self.tol = tol
+        self.max_iter = int(max_iter)
+        self.jitter = jitter
+        self.missing_fill_value = missing_fill_value
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C, D, q, Z, y, d, Hdiag):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C, D, q, Z, y, d, Hdiag)]
+        A_, D_, q_ = inputs[0], inputs[3], inputs[4]
+        b = A_.type.shape[:1]
+        p = inputs[6].type.shape[-1:]
+        outputs = [pt.tensor("A_bar", dtype="float64", shape=A_.type.shape), pt.tensor("B_bar", dtype="float64", shape=A_.type.shape),
+                   pt.tensor("C_bar", dtype="float64", shape=A_.type.shape), pt.tensor("D_bar", dtype="float64", shape=D_.type.shape),
+                   pt.tensor("q_bar", dtype="float64", shape=q_.type.shape), pt.tensor("d_bar", dtype="float64", shape=b + p),
+                   pt.tensor("h_bar", dtype="float64", shape=b + p)]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        sA, _sB, _sC, sD, sq, _sZ, sy, _sd, _sh = input_shapes
+        return [sA, sA, sA, sD, sq, (sA[0], sy[1]), (sA[0], sy[1])]
+
+    def perform(self, node, inputs, outputs):
+        A, B, C, D, q, Z, y, d, Hdiag = inputs
+        out = batched.solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, solver=self.solver,
+                                                     tol=self.tol, max_iter=self.max_iter, jitter=self.jitter,
+                                                     missing_fill_value=self.missing_fill_value)
+        for cell, key in zip(outputs, ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar")):
+            cell[0] = out[key]
+
 
 class HipGensys(Op):
     """Drop-in for ``GensysWrapper`` (gEconpy/solvers/gensys.py:634-676): ``T, success = Op(A, B, C, D)``
