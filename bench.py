@@ -314,7 +314,7 @@ def main():
                 "inputs": "theta (generated Jacobian kernel inside the step)" if args.from_theta else "A,B,C,D resident in HBM",
                 "tol": args.tol,
                 "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
-                "parallelism": f"draw-sharded x{world}, all_gather(logp,status)" if world > 1 else "single GPU",
+                "parallelism": f"draw-sharded x{world}, one all_gather of packed (logp,status) records" if world > 1 else "single GPU",
             },
             "roofline": {
                 "kernel": kern[dom]["kernel"],

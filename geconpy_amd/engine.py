@@ -259,10 +259,14 @@ class ShardedLogpEvaluator:
         self.bounds = [shard_bounds(self.global_batch, self.world, r) for r in range(self.world)]
         self.lo, self.hi = self.bounds[self.rank]
         self.max_shard = max(hi - lo for lo, hi in self.bounds)
-        self._g_logp = torch.empty(self.world * self.max_shard, dtype=torch.float64, device=device)
-        self._g_stat = torch.empty(self.world * self.max_shard, dtype=torch.int32, device=device)
-        self._l_logp = torch.full((self.max_shard,), float("nan"), dtype=torch.float64, device=device)
-        self._l_stat = torch.zeros(self.max_shard, dtype=torch.int32, device=device)
+        # ONE collective per step: each rank contributes one byte record [logp f64 x m | status i32 x m | pad]
+        m = self.max_shard
+        self._rec = 8 * m + 4 * m + (-(12 * m) % 8)
+        self._l_buf = torch.zeros(self._rec, dtype=torch.uint8, device=device)
+        self._g_buf = torch.empty(self.world * self._rec, dtype=torch.uint8, device=device)
+        self._l_logp = self._l_buf[: 8 * m].view(torch.float64)
+        self._l_stat = self._l_buf[8 * m : 12 * m].view(torch.int32)
+        self._l_logp.fill_(float("nan"))
 
     def step(self):
         """Evaluate the local shard and gather; returns (logp, status) for ALL draws."""
@@ -272,11 +276,14 @@ class ShardedLogpEvaluator:
             return logp, status
         self._l_logp[:n_loc].copy_(logp)
         self._l_stat[:n_loc].copy_(status)
-        self.dist.all_gather_into_tensor(self._g_logp, self._l_logp, group=self.group)
-        self.dist.all_gather_into_tensor(self._g_stat, self._l_stat, group=self.group)
-        if all(hi - lo == self.max_shard for lo, hi in self.bounds):
-            return self._g_logp, self._g_stat
+        self.dist.all_gather_into_tensor(self._g_buf, self._l_buf, group=self.group)
         torch = self.torch
-        parts_l = [self._g_logp[r * self.max_shard : r * self.max_shard + (hi - lo)] for r, (lo, hi) in enumerate(self.bounds)]
-        parts_s = [self._g_stat[r * self.max_shard : r * self.max_shard + (hi - lo)] for r, (lo, hi) in enumerate(self.bounds)]
+        m = self.max_shard
+        recs = self._g_buf.view(self.world, self._rec)
+        g_logp = recs[:, : 8 * m].view(torch.float64)        # (world, m) strided views of the gathered records
+        g_stat = recs[:, 8 * m : 12 * m].view(torch.int32)
+        if all(hi - lo == m for lo, hi in self.bounds):
+            return g_logp.reshape(-1), g_stat.reshape(-1)
+        parts_l = [g_logp[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)]
+        parts_s = [g_stat[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)]
         return torch.cat(parts_l), torch.cat(parts_s)
