@@ -81,6 +81,12 @@ PROTOTYPES = {
     "dsge_kalman_logp_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp],
     "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_augmented_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
+                                                 _i, _f, _i, _f, _f, _i, _dp, _i, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp,
+                                                 _dp, _dp],
+    "dsge_solve_kalman_logp_augmented_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i,
+                                                      _i, _i, _i, _f, _i, _f, _f, _i, _dp, _i, _dp, _dp, _i, _i, _i, _dp,
+                                                      _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_grad_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i,
                                             _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_grad_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,

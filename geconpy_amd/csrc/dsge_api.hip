@@ -426,6 +426,65 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                   T_out, R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
 }
 
+int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, const double* C, const double* D,
+                                             const double* Q, int q_mode, const double* Z, int z_batched,
+                                             const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                             const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                             double tol, int max_iter, double jitter, double missing_fill, int m,
+                                             const int32_t* inv_var_order, int n_links, const int32_t* link_rows,
+                                             const int32_t* link_cols, int n_state_hint, int z_selector_hint,
+                                             int n_lead_hint, double* logp_out, int32_t* status_out, double* T_aug_out,
+                                             double* R_aug_out, double* resid_out, void* stream) {
+  const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
+  int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
+  if (rc) return rc;
+  if (m < n || m > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "augmented state dimension m out of range (n..DSGE_MAX_N)");
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (T_len < 0 || n_links < 0) return fail(DSGE_ERR_INVALID, "T_len < 0 or n_links < 0");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out || (n_links > 0 && (!link_rows || !link_cols)))
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if (!is_cr && solver != DSGE_SOLVER_BACKWARD_DIRECT && solver != DSGE_SOLVER_GENSYS)
+    return fail(DSGE_ERR_INVALID, "unknown solver code");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, mm = (size_t)batch * m * m, mk = (size_t)batch * m * k;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_scratch, align256(nn * 8) + align256(nk * 8) + 3 * align256(mm * 8) + align256(mk * 8) +
+                                         align256((size_t)batch * 12) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  double* Tw = cv.take<double>(nn);
+  double* Rw = cv.take<double>(nk);
+  double* Ta = T_aug_out ? T_aug_out : cv.take<double>(mm);
+  double* Ra = R_aug_out ? R_aug_out : cv.take<double>(mk);
+  double* RQR = cv.take<double>(mm);
+  double* P0 = cv.take<double>(mm);
+  int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
+  if (is_cr) {
+    rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, nullptr, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
+  } else if (solver == DSGE_SOLVER_GENSYS) {
+    rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st);
+  } else {
+    HIP_TRY(hipMemsetAsync(status_out, 0, sizeof(int32_t) * batch, st));
+    rc = launch_bdirect(A, B, D, batch, n, k, Tw, Rw, st);
+  }
+  if (rc) return rc;
+  // R and the policy residual in SOLVER order (statespace.py:213), then un-permute + augment
+  if ((rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, nullptr, nullptr, status_out, 1,
+                            0, st)))
+    return rc;
+  if ((rc = launch_augment(Tw, Rw, batch, n, k, m, inv_var_order, n_links, link_rows, link_cols, Ta, Ra, st))) return rc;
+  if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, Ta, Ra, Q, q_mode, batch, m, k, nullptr, nullptr, RQR, P0,
+                            status_out, 0, 2, st)))
+    return rc;
+  return launch_kalman(Ta, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter,
+                       missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st);
+}
+
 int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const double* C, const double* D, const double* q,
                                         int q_batched, const double* Z, int z_batched, const double* d, int d_batched,
                                         const double* Hdiag, int h_batched, const double* y, int batch, int n, int k,
@@ -775,6 +834,66 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
   DOWN(P0_out, dP, mm, double);
   DOWN(RQR_out, dX, mm, double);
   DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                                  const double* Q, int q_mode, const double* Z, int z_batched,
+                                                  const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                                  const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                                  double tol, int max_iter, double jitter, double missing_fill, int m,
+                                                  const int32_t* inv_var_order, int n_links, const int32_t* link_rows,
+                                                  const int32_t* link_cols, int n_state_hint, int z_selector_hint,
+                                                  int n_lead_hint, double* logp_out, int32_t* status_out,
+                                                  double* T_aug_out, double* R_aug_out, double* resid_out) {
+  int rc = check_common(batch, n, DSGE_MAX_N);
+  if (rc) return rc;
+  if (m < n || m > DSGE_MAX_N || k < 1 || k > n || p < 1 || p > DSGE_MAX_P || T_len < 0 || n_links < 0)
+    return fail(DSGE_ERR_INVALID, "bad sizes");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = q_elems(q_mode, batch, k);
+  const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k;
+  const size_t nz = (size_t)(z_batched ? batch : 1) * p * m, nd = (size_t)(d_batched ? batch : 1) * p,
+               nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 3 * align256(nn * 8) + align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+                                       align256(nd * 8) + align256(nh * 8) + align256(ny * 8 + 8) + align256(mm * 8) +
+                                       align256(mk * 8) + 3 * align256((size_t)batch * 8) +
+                                       align256((size_t)n * 4) + 2 * align256((size_t)n_links * 4 + 4) + 8192,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dQ, Q, nq, double);
+  UP(dZ, Z, nz, double);
+  UP(dd, d, nd, double);
+  UP(dH, Hdiag, nh, double);
+  UP(dy, y, ny, double);
+  UP(dinv, inv_var_order, (size_t)n, int32_t);
+  UP(dlr, link_rows, (size_t)n_links, int32_t);
+  UP(dlc, link_cols, (size_t)n_links, int32_t);
+  OUTBUF(dL, logp_out, batch, double);
+  OUTBUF(dS, status_out, batch, int32_t);
+  OUTBUF(dTa, T_aug_out, mm, double);
+  OUTBUF(dRa, R_aug_out, mk, double);
+  OUTBUF(dRes, resid_out, batch, double);
+  if ((rc = dsge_solve_kalman_logp_augmented_batched(dA, dB, dC, dD, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched,
+                                                     dy, batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
+                                                     m, dinv, n_links, dlr, dlc, n_state_hint, z_selector_hint, n_lead_hint,
+                                                     dL, dS, dTa, dRa, dRes, nullptr)))
+    return rc;
+  DOWN(logp_out, dL, batch, double);
+  DOWN(status_out, dS, batch, int32_t);
+  DOWN(T_aug_out, dTa, mm, double);
+  DOWN(R_aug_out, dRa, mk, double);
+  DOWN(resid_out, dRes, batch, double);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }

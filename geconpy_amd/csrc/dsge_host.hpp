@@ -61,6 +61,9 @@ int launch_adjoint(const double* B, const double* C, const double* T, const doub
                    double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate = 0);
 int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
                  const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st);
+int launch_augment(const double* T, const double* R, int batch, int n, int k, int m, const int32_t* inv_var_order,
+                   int n_links, const int32_t* link_rows, const int32_t* link_cols, double* T_aug, double* R_aug,
+                   hipStream_t st);
 int launch_acf(const double* T, const double* Sigma, const double* Z, const double* Hdiag, int batch, int m, int p,
                int n_lags, int lag_step, int correlation, double* out, const int32_t* status, hipStream_t st);
 int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const double* Z, int z_batched,

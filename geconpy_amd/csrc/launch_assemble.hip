@@ -2,6 +2,7 @@
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_acf.hpp"
+#include "dsge_augment.hpp"
 
 namespace dsge_host {
 
@@ -50,6 +51,15 @@ int launch_norms(const double* A, const double* B, const double* C, const double
     }
   });
   return rc;
+}
+
+int launch_augment(const double* T, const double* R, int batch, int n, int k, int m, const int32_t* inv_var_order,
+                   int n_links, const int32_t* link_rows, const int32_t* link_cols, double* T_aug, double* R_aug,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(dsge::augment_kernel, dim3(batch), dim3(256), 0, st, T, R, batch, n, k, m, inv_var_order, n_links,
+                     link_rows, link_cols, T_aug, R_aug);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
 }
 
 int launch_acf(const double* T, const double* Sigma, const double* Z, const double* Hdiag, int batch, int m, int p,

@@ -310,6 +310,39 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         double* R_out, double* resid_out, int32_t* n_iter_out);
 
 /*
+ * Fused evaluation with the un-permutation and state augmentation of DSGEStateSpace.make_symbolic_graph
+ * (gEconpy/model/statespace.py:781-820): A,B,C,D -> T,R (solver order) -> resid (:213) -> T = T[inv][:,inv],
+ * R = R[inv] (:217-220) -> T_aug = [[T,0],[F,C]], R_aug = [R;0] (_augment_transition :598-650,
+ * _append_obs_lag_block :652-694, _augment_selection :696-723) -> P0 = dlyap(T_aug, R_aug Q R_aug') (:814-815)
+ * -> Kalman logp with the m-dimensional design matrix of _make_design_matrix (:260-332).
+ *   m : augmented state dimension (n <= m <= DSGE_MAX_N);  Z : [p][m] or [batch][p][m]
+ *   inv_var_order : [n] int32 or NULL (identity)
+ *   link_rows/link_cols : [n_links] int32; T_aug[link_rows[i]][link_cols[i]] = 1.0 -- the unit entries of the
+ *       constant blocks F (model variable -> first slot of its cumulator / lag chain) and C (slot -> next slot);
+ *       rows in [n, m)
+ *   T_aug_out [batch][m][m], R_aug_out [batch][m][k], resid_out [batch] : optional
+ * n_state_hint / z_selector_hint refer to the AUGMENTED system (non-zero columns of T_aug, rows of Z).
+ */
+int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, const double* C, const double* D,
+                                             const double* Q, int q_mode, const double* Z, int z_batched,
+                                             const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                             const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                             double tol, int max_iter, double jitter, double missing_fill, int m,
+                                             const int32_t* inv_var_order, int n_links, const int32_t* link_rows,
+                                             const int32_t* link_cols, int n_state_hint, int z_selector_hint,
+                                             int n_lead_hint, double* logp_out, int32_t* status_out, double* T_aug_out,
+                                             double* R_aug_out, double* resid_out, void* stream);
+int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                                  const double* Q, int q_mode, const double* Z, int z_batched,
+                                                  const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                                  const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                                  double tol, int max_iter, double jitter, double missing_fill, int m,
+                                                  const int32_t* inv_var_order, int n_links, const int32_t* link_rows,
+                                                  const int32_t* link_cols, int n_state_hint, int z_selector_hint,
+                                                  int n_lead_hint, double* logp_out, int32_t* status_out,
+                                                  double* T_aug_out, double* R_aug_out, double* resid_out);
+
+/*
  * Fused evaluation WITH reverse-mode gradient: logp and its cotangents with respect to A, B, C, D, the shock
  * variances q, the observation intercept d and the measurement-error variances Hdiag, per draw.  This is what
  * pytensor autodiff produces for the reference's logp graph (solver pullback gensys.py:668-676 /
