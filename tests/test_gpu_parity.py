@@ -819,3 +819,88 @@ def test_autocorrelation_matrices(m, k, p):
     Tx[1] *= 1.5 / np.max(np.abs(np.linalg.eigvals(Tx[1])))
     acf, st = batched.autocorrelation_matrices_batched(Tx, R[:2], q[:2], n_lags=2, q_mode="diag_batched")
     assert st[0] == 0 and np.all(np.isfinite(acf[0])) and (st[1] & _lib.ST_LYAP_FAIL) and np.all(np.isnan(acf[1]))
+
+
+def _structured_system(rng, n, s_cols, l_cols, rho_t=0.9, rho_g=0.7):
+    """A + B T + C T^2 = 0 with a known stable solvent T* whose non-zero columns are ``s_cols`` and a C whose
+    non-zero columns are ``l_cols`` (SURVEY 8d recipe, arbitrary supports)."""
+    s, l = len(s_cols), len(l_cols)
+    Tstar = np.zeros((n, n))
+    if s:
+        M = rng.standard_normal((n, s))
+        M *= rho_t * rng.uniform(0.5, 1.0) / max(np.max(np.abs(np.linalg.eigvals(M[s_cols]))), 1e-12)
+        Tstar[:, s_cols] = M
+    G = np.zeros((n, n))
+    if l:
+        Gm = rng.standard_normal((n, l))
+        Gm *= rho_g * rng.uniform(0.4, 1.0) / max(np.max(np.abs(np.linalg.eigvals(Gm[l_cols]))), 1e-12)
+        G[:, l_cols] = Gm
+    Mx = np.eye(n) + 0.2 * rng.standard_normal((n, n))
+    C = Mx @ G
+    B = Mx - C @ Tstar
+    A = -Mx @ Tstar
+    return A, B, C, Tstar
+
+
+def test_cycle_reduction_structure_fuzz():
+    """Random sizes and column supports (overlapping, empty, too wide for the compact tile): the column-compact
+    kernel, the dense kernel and the oracle must agree; compact vs dense bit for bit."""
+    rng = np.random.default_rng(2026)
+    lib = _lib.load()
+    cases = []
+    for n in (5, 8, 13, 16, 17, 24, 31, 40, 48):
+        for _ in range(3):
+            s = int(rng.integers(0, n + 1))
+            l = int(rng.integers(0, n + 1))
+            cases.append((n, np.sort(rng.choice(n, s, replace=False)), np.sort(rng.choice(n, l, replace=False))))
+    cases.append((12, np.arange(12), np.arange(12)))      # dense A and C: s + l = 2n > tile -> dense kernel
+    cases.append((10, np.array([], dtype=int), np.arange(3)))  # purely forward-looking: T = 0
+    cases.append((10, np.arange(4), np.array([], dtype=int)))  # no leads: one step
+    for n, s_cols, l_cols in cases:
+        A, B, C, Tstar = _structured_system(rng, n, s_cols, l_cols)
+        A3, B3, C3 = A[None], B[None], C[None]
+        T1, st1, it1 = batched.cycle_reduction_batched(A3, B3, C3, max_iter=200, tol=1e-10)
+        _lib.check(lib.dsge_set_cr_compact(0))
+        try:
+            T0, st0, it0 = batched.cycle_reduction_batched(A3, B3, C3, max_iter=200, tol=1e-10)
+        finally:
+            _lib.check(lib.dsge_set_cr_compact(1))
+        assert st1[0] == 0 and st0[0] == 0, (n, len(s_cols), len(l_cols))
+        assert it1[0] == it0[0] and np.array_equal(T1, T0), (n, len(s_cols), len(l_cols))
+        T_or, ok, it_or = oracle.cycle_reduction_core(A, B, C, 200, 1e-10)
+        assert ok and it_or == it1[0]
+        assert_allclose(T1[0], Tstar, atol=1e-8)
+        assert_allclose(T1[0], T_or, atol=1e-9)
+        zero_cols = np.setdiff1d(np.arange(n), s_cols)
+        assert np.all(T1[0][:, zero_cols] == 0.0)  # exactly zero, as the Kalman fast path relies on
+
+
+def test_kalman_fuzz_against_oracle():
+    """Random sizes, state supports, selector positions (observed states and observed non-states), weights,
+    measurement errors (including none), intercepts and missing-data patterns, long enough for the steady-state
+    switch to engage: logp vs the oracle filter, fast path vs general kernel."""
+    rng = np.random.default_rng(77)
+    for trial in range(14):
+        m = int(rng.integers(3, 49))
+        k = int(rng.integers(1, min(m, 8) + 1))
+        p = int(rng.integers(1, min(k, 8) + 1))  # p <= k: no stochastic singularity without measurement error
+        ns = int(rng.integers(1, m + 1))
+        nb, T_len = 3, int(rng.integers(20, 120))
+        T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=1000 + trial)
+        T *= rng.uniform(0.3, 1.0)
+        if trial % 3 == 0:
+            H = None  # no measurement error: F = Z P Z' + jitter
+        if trial % 4 == 1:
+            y[rng.random(y.shape) < 0.15] = np.nan
+        if trial % 5 == 2:
+            y[T_len // 2:, 0] = oracle.MISSING_FILL
+        scale = 10.0 ** rng.uniform(-3, 1)
+        q = q * scale
+        logp, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+        logp_gen, st2 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched", n_state_hint=0,
+                                                    z_selector_hint=0)
+        assert np.all(st == 0) and np.all(st2 == 0), (trial, m, k, p, ns)
+        for i in range(nb):
+            ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=None if H is None else np.diag(H), d=d)
+            assert_allclose(logp[i], ref, rtol=LOGP_RTOL, err_msg=str((trial, m, k, p, ns)))
+            assert_allclose(logp_gen[i], ref, rtol=LOGP_RTOL, err_msg=str((trial, m, k, p, ns)))
