@@ -153,6 +153,26 @@ __device__ __forceinline__ void mm_acc(double (&acc)[BS][BS], const double* A, i
 #undef MM_FMA
 }
 
+// acc += A(:, rows lr*BS..)^T * B(:, cols lc*BS..)   i.e. (A' B) with A, B row-major in LDS: both operands are read
+// along rows (conflict-free with the odd leading dimension), no transposed copy of A needed.
+template <int BS>
+__device__ __forceinline__ void mm_acc_ta(double (&acc)[BS][BS], const double* A, int lda, const double* B, int ldb, int K,
+                                          int lr, int lc) {
+  const double* a0p = A + lr * BS;
+  const double* b0p = B + lc * BS;
+  for (int k = 0; k < K; ++k) {
+    double a[BS], b[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) a[i] = a0p[k * lda + i];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) b[j] = b0p[k * ldb + j];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+}
+
 // induced 1-norm (max absolute column sum, NaN-propagating) of a register-block matrix
 template <int BS>
 __device__ __forceinline__ double blk_norm1(const double (&x)[BS][BS]) {

@@ -36,10 +36,10 @@ namespace dsge {
 template <int BS>
 struct KgSmem {
   static constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD, PS = 9;
-  // 9 NP x LDM matrices (Tc, Tt, P, Pb, Tb, Gb, X1, X2, X3), 5 NP x PS panels (M, K, Kb, Mb, Y),
+  // 5 NP x LDM matrices (Tc, P, Pb, X1, X2), 5 NP x PS panels (M, K, Kb, Mb, Y),
   // 4 8x8 (F, Fi, Fb, tmp), 6 NP vectors, 10 8-vectors, ints perm NP + zpos 8
   __host__ __device__ static constexpr size_t doubles() {
-    return 9 * (size_t)NP * LDM + 5 * (size_t)NP * PS + 4 * 64 + 6 * NP + 10 * 8 + NP / 2 + 4;
+    return 5 * (size_t)NP * LDM + 5 * (size_t)NP * PS + 4 * 64 + 6 * NP + 10 * 8 + NP / 2 + 4;
   }
   static constexpr size_t bytes = sizeof(double) * doubles();
 };
@@ -73,15 +73,12 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
   constexpr size_t STEP = (size_t)NP * NP + NP;  // doubles stored per time step: P (NP x NP, dense) then a
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;              // transition, states-first ordering (columns >= s are zero)
-  double* Tt = Tc + NP * LDM;     // its transpose
-  double* Ps = Tt + NP * LDM;     // predicted covariance of the current step
+  double* Ps = Tc + NP * LDM;     // predicted covariance of the current step
   double* Pb = Ps + NP * LDM;     // cotangent of the predicted covariance
-  double* Tb = Pb + NP * LDM;     // cotangent of T (accumulated)
-  double* Gb = Tb + NP * LDM;     // cotangent of G = sym(R Q R') (accumulated)
-  double* X1 = Gb + NP * LDM;     // P+ / scratch
+  double* X1 = Pb + NP * LDM;     // P+ / scratch  (the cotangents of T and G accumulate in register blocks)
   double* X2 = X1 + NP * LDM;
-  double* X3 = X2 + NP * LDM;
-  double* Mp = X3 + NP * LDM;     // M = P Zm'          NP x PS panels
+  double* Mp = X2 + NP * LDM;     // M = P Zm'          NP x PS panels
+  double* Gs = Pb;                // forward sweep only: G[U,U] lives in the (not yet used) cotangent buffer
   double* Kp = Mp + NP * PS;      // K
   double* Kb = Kp + NP * PS;      // Kbar
   double* Mb = Kb + NP * PS;      // Mbar
@@ -177,19 +174,18 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       hh[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
     }
     wave_sync();
-    // Tc, Tt <- T[U,U];  Gs (kept in X3 during the forward sweep) <- G[U,U]
+    // Tc <- T[U,U];  Gs <- G[U,U]
     for (int idx = lane; idx < u * u; idx += 64) {
       const int i = idx / u, j = idx - i * u;
       const size_t g = (size_t)perm[i] * m_full + perm[j];
       const double tv = T[off + g];
       Tc[i * LDM + j] = tv;
-      Tt[j * LDM + i] = tv;
-      X3[i * LDM + j] = RQR[off + g];
+      Gs[i * LDM + j] = RQR[off + g];
     }
     wave_sync();
     // ---- P0 = dlyap(Tu, G) by doubling: P <- P + A P A', A <- A A  (A in X1) ---------------------
     for (int idx = lane; idx < NP * LDM; idx += 64) {
-      Ps[idx] = X3[idx];
+      Ps[idx] = Gs[idx];
       X1[idx] = Tc[idx];
     }
     wave_sync();
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     double* st = store + (size_t)draw * T_len * STEP;
     // The measurement update of one step from (av, Ps): fills ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+.
     // Returns lam * (ln det F + v' F^-1 v) through `quad_logdet` (lam = 0 when every entry is missing).
-    auto update = [&](int t, double& ll_term, double& lam) {
+    auto update = [&](int t, double& ll_term, double& lam, bool want_ll) {
       const double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
       const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
       const unsigned long long omask = __ballot(obs);
@@ -268,21 +264,24 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         f = (fo == fq) ? 1.0 : 0.0;
       }
       Fs[lane] = f;
-      double logdet = 0.0;
+      double det_m = 1.0;  // det F = det_m * 2^det_e (one logarithm per step instead of one per pivot)
+      int det_e = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j < p) {
           const double piv = readlane_f64(f, j * 9);
           const double rowj = __shfl(f, (j << 3) | fq, 64);
           const double colj = __shfl(f, (fo << 3) | j, 64);
-          const double inv = 1.0 / piv;
+          const double inv = fast_rcp(piv);
           const double ci = colj * inv;
           double nf = fma(-ci, rowj, f);
           nf = (fo == j) ? rowj * inv : nf;
           nf = (fq == j) ? -ci : nf;
           nf = (fo == j && fq == j) ? inv : nf;
           f = nf;
-          logdet += log(piv);
+          int e;
+          det_m *= frexp(piv, &e);
+          det_e += e;
         }
       }
       Fi[lane] = f;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
       double quad = 0.0;
       for (int q = 0; q < 8; ++q) quad = fma(vv[q], fiv[q], quad);
-      ll_term = lam * (logdet + quad);
+      ll_term = want_ll ? lam * (log(det_m) + (double)det_e * 0.6931471805599453 + quad) : 0.0;
       if (lane < u) {
         double sa = av[lane];
         for (int o = 0; o < 8; ++o) sa = fma(Kp[lane * PS + o], vv[o], sa);
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
       if (lane < NP) sg[NP * NP + lane] = av[lane];
       double ll_term, lam;
-      update(t, ll_term, lam);
+      update(t, ll_term, lam, true);
       ll_acc += ll_term;
       n_ll += (lam != 0.0);
       // predict: a = T a+,  P = sym(T P+ T') + G
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         for (int i = 0; i < BS; ++i)
 #pragma unroll
           for (int j = 0; j < BS; ++j)
-            Ps[(lr * BS + i) * LDM + lc * BS + j] = 0.5 * (xb[i][j] + xt[i][j]) + X3[(lr * BS + i) * LDM + lc * BS + j];
+            Ps[(lr * BS + i) * LDM + lc * BS + j] = 0.5 * (xb[i][j] + xt[i][j]) + Gs[(lr * BS + i) * LDM + lc * BS + j];
       }
       wave_sync();
     }
@@ -361,11 +360,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     }
 
     // ---- reverse sweep ------------------------------------------------------------------------------
-    for (int idx = lane; idx < NP * LDM; idx += 64) {
-      Pb[idx] = 0.0;
-      Tb[idx] = 0.0;
-      Gb[idx] = 0.0;
-    }
+    for (int idx = lane; idx < NP * LDM; idx += 64) Pb[idx] = 0.0;
+    double TbR[BS][BS], GbR[BS][BS];  // cotangents of T and G, accumulated in register blocks
+    blk_zero<BS>(TbR);
+    blk_zero<BS>(GbR);
     if (lane < NP) ab[lane] = 0.0;
     if (lane < 8) {
       db[lane] = 0.0;
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (lane < NP) av[lane] = sg[NP * NP + lane];
       wave_sync();
       double ll_term, lam;
-      update(t, ll_term, lam);  // ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+
+      update(t, ll_term, lam, false);  // ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+
       // -- predict, reversed.  (abar, Pb) are the cotangents of (a_{t+1}, P_{t+1}).
       kg_mm<BS, false>(X2, Tc, X1, u, 1.0, false, lr, lc);   // T P+
       if (lane < u) {
@@ -386,16 +384,28 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         for (int i = 0; i < u; ++i) sa = fma(Tc[i * LDM + lane], ab[i], sa);
         apb[lane] = sa;  // a+bar = T' abar
       }
-      for (int idx = lane; idx < NP * LDM; idx += 64) Gb[idx] += Pb[idx];  // Gbar += Pbar
       wave_sync();
-      kg_mm<BS, false>(Tb, Pb, X2, u, 2.0, true, lr, lc);    // Tbar += 2 Pbar T P+
-      kg_mm<BS, false>(X3, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
-      wave_sync();
-      for (int idx = lane; idx < u * u; idx += 64) {
-        const int i = idx / u, j = idx - i * u;
-        Tb[i * LDM + j] = fma(ab[i], ap[j], Tb[i * LDM + j]);  // Tbar += abar a+'
+      {
+        double pb[BS][BS], t2[BS][BS];
+        blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
+        blk_zero<BS>(t2);
+        mm_acc<BS, false>(t2, Pb, LDM, X2, LDM, u, lr, lc);  // Pbar (T P+)
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            GbR[i][j] += pb[i][j];                                                       // Gbar += Pbar
+            TbR[i][j] = fma(2.0, t2[i][j], fma(ab[lr * BS + i], ap[lc * BS + j], TbR[i][j]));  // Tbar += 2 Pbar T P+ + abar a+'
+          }
       }
-      kg_mm<BS, false>(X2, Tt, X3, u, 1.0, false, lr, lc);   // P+bar = T' Pbar T
+      kg_mm<BS, false>(X1, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T  (P+ in X1 is dead by now)
+      wave_sync();
+      {
+        double pp[BS][BS];
+        blk_zero<BS>(pp);
+        mm_acc_ta<BS>(pp, Tc, LDM, X1, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
+        blk_store_lds<BS>(pp, X2, LDM, lr, lc);
+      }
       wave_sync();
       // -- update, reversed (P+bar in X2)
       for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
@@ -458,22 +468,17 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
     }
     // ---- initial covariance: S = dlyap(T', Pbar_0) by doubling; Gbar += S; Tbar += 2 S T P0 ---------
-    // S in Pb, A = T^(2^k) in X1, A' in X3
-    for (int idx = lane; idx < NP * LDM; idx += 64) {
-      X1[idx] = Tc[idx];
-      X3[idx] = Tt[idx];
-    }
+    // S in Pb, A = T^(2^k) in X1
+    for (int idx = lane; idx < NP * LDM; idx += 64) X1[idx] = Tc[idx];
     wave_sync();
     for (int itl = 0; itl < 64; ++itl) {
       kg_mm<BS, false>(X2, Pb, X1, u, 1.0, false, lr, lc);  // S A
       wave_sync();
-      double inc[BS][BS], a2[BS][BS], at2[BS][BS];
+      double inc[BS][BS], a2[BS][BS];
       blk_zero<BS>(inc);
       blk_zero<BS>(a2);
-      blk_zero<BS>(at2);
-      mm_acc<BS, false>(inc, X3, LDM, X2, LDM, u, lr, lc);  // A' S A
+      mm_acc_ta<BS>(inc, X1, LDM, X2, LDM, u, lr, lc);      // A' S A
       mm_acc<BS, false>(a2, X1, LDM, X1, LDM, u, lr, lc);
-      mm_acc<BS, false>(at2, X3, LDM, X3, LDM, u, lr, lc);
       wave_sync();
       double dmax = 0.0, smax = 0.0;
 #pragma unroll
@@ -485,7 +490,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           dmax = nanmax(dmax, fabs(inc[i][j]));
           smax = nanmax(smax, fabs(Pb[e]));
           X1[e] = a2[i][j];
-          X3[e] = at2[i][j];
         }
       dmax = wave_nanmax(dmax);
       smax = wave_nanmax(smax);
@@ -493,18 +497,26 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (!(dmax == dmax) || dmax <= 1e-17 * smax || smax == 0.0) break;
     }
     for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = st[idx];  // P0
-    for (int idx = lane; idx < NP * LDM; idx += 64) Gb[idx] += Pb[idx];
     wave_sync();
     kg_mm<BS, false>(X2, Tc, Ps, u, 1.0, false, lr, lc);  // T P0
     wave_sync();
-    kg_mm<BS, false>(Tb, Pb, X2, u, 2.0, true, lr, lc);   // Tbar += 2 S T P0
-    wave_sync();
-    // ---- scatter to the caller's variable order -----------------------------------------------------
-    for (int idx = lane; idx < u * u; idx += 64) {
-      const int i = idx / u, j = idx - i * u;
-      const size_t g = (size_t)perm[i] * m_full + perm[j];
-      if (j < s) Tbo[g] = Tb[i * LDM + j];
-      Gbo[g] = Gb[i * LDM + j];
+    {
+      double sb[BS][BS], t2[BS][BS];
+      blk_load_lds<BS>(sb, Pb, LDM, lr, lc);
+      blk_zero<BS>(t2);
+      mm_acc<BS, false>(t2, Pb, LDM, X2, LDM, u, lr, lc);  // S T P0
+      // ---- scatter to the caller's variable order --------------------------------------------------
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int r = lr * BS + i, c = lc * BS + j;
+          if (r < u && c < u) {
+            const size_t g = (size_t)perm[r] * m_full + perm[c];
+            if (c < s) Tbo[g] = fma(2.0, t2[i][j], TbR[i][j]);  // Tbar += 2 S T P0
+            Gbo[g] = GbR[i][j] + sb[i][j];                      // Gbar += S
+          }
+        }
     }
     if (lane < p) {
       if (dbar_out) dbar_out[(size_t)draw * p + lane] = db[lane];
