@@ -61,16 +61,18 @@ __device__ __forceinline__ void kg_mm(double* dst, const double* A, const double
     }
 }
 
+__device__ __forceinline__ double yt_or_zero(double yt) { return (yt == yt) ? yt : 0.0; }
+
 template <int BS>
 __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ Z, int z_batched,
     const double* __restrict__ dvec, int d_batched, const double* __restrict__ Hdiag, int h_batched,
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, double jitter, double missing_fill,
-    double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
+    double steady_tol, double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
     double* __restrict__ hbar_out) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
-  constexpr size_t STEP = (size_t)NP * NP + NP;  // doubles stored per time step: P (NP x NP, dense) then a
+  constexpr size_t STEP = (size_t)NP * NP + NP + 1;  // doubles stored per time step: P (NP x NP, dense), a, source step
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;              // transition, states-first ordering (columns >= s are zero)
   double* Ps = Tc + NP * LDM;     // predicted covariance of the current step
@@ -240,17 +242,9 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     wave_sync();
 
     double* st = store + (size_t)draw * T_len * STEP;
-    // The measurement update of one step from (av, Ps): fills ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+.
-    // Returns lam * (ln det F + v' F^-1 v) through `quad_logdet` (lam = 0 when every entry is missing).
-    auto update = [&](int t, double& ll_term, double& lam, bool want_ll) {
-      const double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
-      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
-      const unsigned long long omask = __ballot(obs);
-      lam = (omask != 0ull) ? 1.0 : 0.0;
-      if (lane < 8) ww[lane] = (lane < p && obs) ? 1.0 : 0.0;
-      if (lane < p) vv[lane] = (obs ? yt : 0.0) - (dd[lane] + (obs ? 1.0 : 0.0) * zv[lane] * av[zpos[lane]]);
-      if (lane >= p && lane < 8) vv[lane] = 0.0;
-      wave_sync();
+    // ---- the measurement update, split in its data-independent and data-dependent halves --------------
+    // update_cov: from Ps and the mask weights ww -> Mp, Fs, Fi, Kp, X1 = P+; returns ln det F.
+    auto update_cov = [&]() -> double {
       for (int idx = lane; idx < u * 8; idx += 64) {
         const int i = idx >> 3, o = idx & 7;
         Mp[i * PS + o] = (o < p) ? ww[o] * zv[o] * Ps[i * LDM + zpos[o]] : 0.0;
@@ -264,7 +258,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         f = (fo == fq) ? 1.0 : 0.0;
       }
       Fs[lane] = f;
-      double det_m = 1.0;  // det F = det_m * 2^det_e (one logarithm per step instead of one per pivot)
+      double det_m = 1.0;  // det F = det_m * 2^det_e (one logarithm per update instead of one per pivot)
       int det_e = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -286,11 +280,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       }
       Fi[lane] = f;
       wave_sync();
-      if (lane < 8) {
-        double sfv = 0.0;
-        for (int q = 0; q < 8; ++q) sfv = fma(Fi[lane * 8 + q], vv[q], sfv);
-        fiv[lane] = (lane < p) ? sfv : 0.0;
-      }
       for (int idx = lane; idx < u * 8; idx += 64) {
         const int i = idx >> 3, o = idx & 7;
         double sk = 0.0;
@@ -298,14 +287,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         Kp[i * PS + o] = (o < p) ? sk : 0.0;
       }
       wave_sync();
-      double quad = 0.0;
-      for (int q = 0; q < 8; ++q) quad = fma(vv[q], fiv[q], quad);
-      ll_term = want_ll ? lam * (log(det_m) + (double)det_e * 0.6931471805599453 + quad) : 0.0;
-      if (lane < u) {
-        double sa = av[lane];
-        for (int o = 0; o < 8; ++o) sa = fma(Kp[lane * PS + o], vv[o], sa);
-        ap[lane] = sa;
-      }
       // P+ = P - K (M + jit K)' + jit I
       for (int idx = lane; idx < u * u; idx += 64) {
         const int i = idx / u, j = idx - i * u;
@@ -314,29 +295,74 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         X1[i * LDM + j] = sp2 + ((i == j) ? jitter : 0.0);
       }
       wave_sync();
+      return log(det_m) + (double)det_e * 0.6931471805599453;
+    };
+    // mask of step t -> ww; returns the ballot
+    auto load_mask = [&](int t, double& yt) -> unsigned long long {
+      yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
+      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
+      const unsigned long long omask = __ballot(obs);
+      if (lane < 8) ww[lane] = (lane < p && obs) ? 1.0 : 0.0;
+      return omask;
+    };
+    // update_mean: from av, y_t, ww, Kp, Fi -> vv, fiv, ap; returns v' F^-1 v.  (Fences on entry and exit.)
+    auto update_mean = [&](double yt) -> double {
+      wave_sync();
+      if (lane < p) vv[lane] = ww[lane] * yt_or_zero(yt) - (dd[lane] + ww[lane] * zv[lane] * av[zpos[lane]]);
+      if (lane >= p && lane < 8) vv[lane] = 0.0;
+      wave_sync();
+      if (lane < 8) {
+        double sfv = 0.0;
+        for (int q = 0; q < 8; ++q) sfv = fma(Fi[lane * 8 + q], vv[q], sfv);
+        fiv[lane] = (lane < p) ? sfv : 0.0;
+      }
+      if (lane < u) {
+        double sa = av[lane];
+        for (int o = 0; o < 8; ++o) sa = fma(Kp[lane * PS + o], vv[o], sa);
+        ap[lane] = sa;
+      }
+      wave_sync();
+      double quad = 0.0;
+      for (int q = 0; q < 8; ++q) quad = fma(vv[q], fiv[q], quad);
+      return quad;
     };
 
-    // ---- forward sweep ----------------------------------------------------------------------------
+    // ---- forward sweep.  Step t stores (P_t, a_t, src_t): src_t = t for a full step; once the predicted
+    // covariance has stopped moving (same rounding-level criterion as kalman_sel_kernel) and while the mask stays
+    // the same, the steps are "steady": only a_t is stored and src_t names the step whose covariance they share.
     double ll_acc = 0.0;
     long long n_ll = 0;
+    bool steady = false;
+    unsigned long long smask = 0ull;
+    int seg_src = -1;
+    double seg_logdet = 0.0;
     for (int t = 0; t < T_len; ++t) {
       double* sg = st + (size_t)t * STEP;
-      for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
+      double yt;
+      const unsigned long long omask = load_mask(t, yt);
+      const double lam = (omask != 0ull) ? 1.0 : 0.0;
+      const bool light = steady && (omask == smask);
       if (lane < NP) sg[NP * NP + lane] = av[lane];
-      double ll_term, lam;
-      update(t, ll_term, lam, true);
-      ll_acc += ll_term;
+      if (!light) {
+        steady = false;
+        seg_src = t;
+        for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
+        wave_sync();
+        seg_logdet = update_cov();
+      }
+      if (lane == 0) sg[NP * NP + NP] = (double)seg_src;
+      const double quad = update_mean(yt);
+      ll_acc += lam * (seg_logdet + quad);
       n_ll += (lam != 0.0);
-      // predict: a = T a+,  P = sym(T P+ T') + G
+      // predict: a = T a+
       if (lane < u) {
         double sa = 0.0;
         for (int k2 = 0; k2 < u; ++k2) sa = fma(Tc[lane * LDM + k2], ap[k2], sa);
         t1[lane] = sa;
       }
-      kg_mm<BS, true>(X2, X1, Tc, u, 1.0, false, lr, lc);  // P+ T'
-      wave_sync();
-      if (lane < NP) av[lane] = (lane < u) ? t1[lane] : 0.0;
-      {
+      if (!light) {  // P = sym(T P+ T') + G, with the steady-state test against the outgoing P_t
+        kg_mm<BS, true>(X2, X1, Tc, u, 1.0, false, lr, lc);  // P+ T'
+        wave_sync();
         double xb[BS][BS], xt[BS][BS];
         blk_zero<BS>(xb);
         mm_acc<BS, false>(xb, Tc, LDM, X2, LDM, u, lr, lc);  // T P+ T'
@@ -345,12 +371,26 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         for (int i = 0; i < BS; ++i)
 #pragma unroll
           for (int j = 0; j < BS; ++j) xt[i][j] = __shfl(xb[j][i], src, 64);
+        double dmax = 0.0, pmax = 0.0;
 #pragma unroll
         for (int i = 0; i < BS; ++i)
 #pragma unroll
-          for (int j = 0; j < BS; ++j)
-            Ps[(lr * BS + i) * LDM + lc * BS + j] = 0.5 * (xb[i][j] + xt[i][j]) + Gs[(lr * BS + i) * LDM + lc * BS + j];
+          for (int j = 0; j < BS; ++j) {
+            double* pp = &Ps[(lr * BS + i) * LDM + lc * BS + j];
+            const double nv = 0.5 * (xb[i][j] + xt[i][j]) + Gs[(lr * BS + i) * LDM + lc * BS + j];
+            dmax = nanmax(dmax, fabs(nv - *pp));
+            pmax = nanmax(pmax, fabs(nv));
+            *pp = nv;
+          }
+        dmax = wave_nanmax(dmax);
+        pmax = wave_nanmax(pmax);
+        if (steady_tol > 0.0 && dmax <= steady_tol * pmax) {  // P_{t+1} = P_t to rounding: later steps reuse step t's update
+          steady = true;
+          smask = omask;
+        }
       }
+      wave_sync();
+      if (lane < NP) av[lane] = (lane < u) ? t1[lane] : 0.0;
       wave_sync();
     }
     const double logp = -0.5 * ((double)n_ll * (double)p * LN2PI + ll_acc);
@@ -360,7 +400,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     }
 
     // ---- reverse sweep ------------------------------------------------------------------------------
-    for (int idx = lane; idx < NP * LDM; idx += 64) Pb[idx] = 0.0;
+    wave_sync();
+    for (int idx = lane; idx < NP * LDM; idx += 64) Pb[idx] = 0.0;  // (Gs aliases Pb: the forward sweep is over)
     double TbR[BS][BS], GbR[BS][BS];  // cotangents of T and G, accumulated in register blocks
     blk_zero<BS>(TbR);
     blk_zero<BS>(GbR);
@@ -370,15 +411,24 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       hb[lane] = 0.0;
     }
     wave_sync();
+    int cur_src = -1;  // step whose covariance-side quantities (Mp, Fs, Fi, Kp, X1 = P+) are in LDS
     for (int t = T_len - 1; t >= 0; --t) {
       const double* sg = st + (size_t)t * STEP;
-      for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = sg[idx];
+      const int src_t = (int)sg[NP * NP + NP];
       if (lane < NP) av[lane] = sg[NP * NP + lane];
-      wave_sync();
-      double ll_term, lam;
-      update(t, ll_term, lam, false);  // ww, Mp, Fs, Fi, Kp, vv, fiv, ap, X1 = P+
-      // -- predict, reversed.  (abar, Pb) are the cotangents of (a_{t+1}, P_{t+1}).
-      kg_mm<BS, false>(X2, Tc, X1, u, 1.0, false, lr, lc);   // T P+
+      double yt;
+      const unsigned long long omask = load_mask(t, yt);
+      const double lam = (omask != 0ull) ? 1.0 : 0.0;
+      if (src_t != cur_src) {  // a full step, or the first (last in time) step of a steady segment
+        const double* sp_ = st + (size_t)src_t * STEP;
+        for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = sp_[idx];
+        wave_sync();
+        (void)update_cov();
+        cur_src = src_t;
+      }
+      (void)update_mean(yt);
+      // -- predict, reversed.  (abar, Pb) are the cotangents of (a_{t+1}, P_{t+1}); X1 = P+ stays intact.
+      kg_mm<BS, false>(X2, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
       if (lane < u) {
         double sa = 0.0;
         for (int i = 0; i < u; ++i) sa = fma(Tc[i * LDM + lane], ab[i], sa);
@@ -386,32 +436,27 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       }
       wave_sync();
       {
-        double pb[BS][BS], t2[BS][BS];
+        double pb[BS][BS], t2[BS][BS], pp[BS][BS];
         blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
         blk_zero<BS>(t2);
-        mm_acc<BS, false>(t2, Pb, LDM, X2, LDM, u, lr, lc);  // Pbar (T P+)
+        blk_zero<BS>(pp);
+        mm_acc<BS, false>(t2, X2, LDM, X1, LDM, u, lr, lc);  // (Pbar T) P+
+        mm_acc_ta<BS>(pp, Tc, LDM, X2, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
 #pragma unroll
         for (int i = 0; i < BS; ++i)
 #pragma unroll
           for (int j = 0; j < BS; ++j) {
-            GbR[i][j] += pb[i][j];                                                       // Gbar += Pbar
+            GbR[i][j] += pb[i][j];                                                              // Gbar += Pbar
             TbR[i][j] = fma(2.0, t2[i][j], fma(ab[lr * BS + i], ap[lc * BS + j], TbR[i][j]));  // Tbar += 2 Pbar T P+ + abar a+'
           }
-      }
-      kg_mm<BS, false>(X1, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T  (P+ in X1 is dead by now)
-      wave_sync();
-      {
-        double pp[BS][BS];
-        blk_zero<BS>(pp);
-        mm_acc_ta<BS>(pp, Tc, LDM, X1, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
-        blk_store_lds<BS>(pp, X2, LDM, lr, lc);
+        blk_store_lds<BS>(pp, Ps, LDM, lr, lc);  // Ps now holds P+bar (P_t itself is no longer needed this step)
       }
       wave_sync();
-      // -- update, reversed (P+bar in X2)
+      // -- update, reversed (P+bar in Ps)
       for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
         const int i = idx >> 3, o = idx & 7;
         double sy = 0.0;
-        for (int j = 0; j < u; ++j) sy = fma(X2[i * LDM + j], Kp[j * PS + o], sy);
+        for (int j = 0; j < u; ++j) sy = fma(Ps[i * LDM + j], Kp[j * PS + o], sy);
         Yp[i * PS + o] = sy;
       }
       if (lane < 8) {  // vbar = -lam F^-1 v + K' a+bar
@@ -451,7 +496,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]
       for (int idx = lane; idx < u * 8; idx += 64) {
         const int i = idx >> 3, o = idx & 7;
-        if (o < p) X2[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], X2[i * LDM + zpos[o]]);
+        if (o < p) Ps[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], Ps[i * LDM + zpos[o]]);
       }
       if (lane < u) t1[lane] = apb[lane];
       wave_sync();
@@ -461,7 +506,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       }
       for (int idx = lane; idx < u * u; idx += 64) {
         const int i = idx / u, j = idx - i * u;
-        Pb[i * LDM + j] = 0.5 * (X2[i * LDM + j] + X2[j * LDM + i]);
+        Pb[i * LDM + j] = 0.5 * (Ps[i * LDM + j] + Ps[j * LDM + i]);
       }
       wave_sync();
       if (lane < NP) ab[lane] = (lane < u) ? t1[lane] : 0.0;

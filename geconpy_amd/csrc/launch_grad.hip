@@ -9,7 +9,7 @@ static int grad_tile(int u_hint, int m) { return tile_bs((u_hint > 0 && u_hint <
 
 size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len) {
   const size_t np = 8 * (size_t)grad_tile(u_hint, m);
-  return (size_t)T_len * (np * np + np);
+  return (size_t)T_len * (np * np + np + 1);
 }
 
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
@@ -24,7 +24,8 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
     rc = set_lds(dsge::kalman_grad_kernel<BS>, lds);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::kalman_grad_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, store, logp, status, Tbar, Gbar,
+                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, g_kalman_steady_tol, store, logp, status, Tbar,
+                         Gbar,
                          dbar, hbar);
       HIP_TRY(hipGetLastError());
     }

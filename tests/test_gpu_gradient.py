@@ -108,3 +108,33 @@ def test_gradient_failed_and_unsupported_draws():
     Zd = np.random.default_rng(2).standard_normal((7, 40))  # dense design matrix: not covered by the gradient path
     out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, Zd, om["y"][:20], tol=1e-10, max_iter=100)
     assert np.all(out["status"] & _lib.ST_GRAD_UNSUPPORTED) and np.all(np.isnan(out["logp"]))
+
+
+def test_gradient_with_steady_state_segments():
+    """Long sample: the gradient kernel's forward sweep switches to the steady-state recursion (only a_t stored), a
+    missing entry later forces a full step and a second steady segment; the reverse sweep must walk both segments.
+    Checked against finite differences of the oracle (which never switches) and against tol = 0."""
+    rng = np.random.default_rng(3)
+    nb = 2
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y = om["y"][:130].copy()
+    y[95, 1] = np.nan
+    y[96, :] = np.nan
+    d = rng.normal(0, 0.01, 7)
+    h = om["Hdiag"].copy()
+    kw = dict(d=d, Hdiag=h, tol=1e-13, max_iter=200)
+    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, **kw)
+    batched.set_kalman_steady_tol(0.0)
+    try:
+        out0 = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, **kw)
+    finally:
+        batched.set_kalman_steady_tol(1e-14)
+    assert np.all(out["status"] == 0) and np.all(out0["status"] == 0)
+    assert_allclose(out["logp"], out0["logp"], rtol=1e-12)
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
+        scale = np.abs(out0[key]).max()
+        assert_allclose(out[key], out0[key], atol=1e-8 * scale, rtol=1e-7, err_msg=key)
+    g = {k_: v[0] for k_, v in out.items() if k_.endswith("_bar")}
+    _directional_check(b["A"][0], b["B"][0], b["C"][0], b["D"][0], q[0], om["Z"], y, d, h, g, rng, n_dirs=1)
