@@ -505,9 +505,9 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   if (batch == 0) return DSGE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
   const int u_hint = n_filter_hint;
-  // the reverse sweep re-reads every predicted (a_t, P_t): chunk the batch so that the store stays <= 2 GiB
+  // the reverse sweep re-reads the stored (a_t, P_t): chunk the batch so that the store stays <= 16 GiB of the 288 GB
   const size_t per_draw = kalman_grad_store_doubles_per_draw(u_hint, n, T_len) * sizeof(double);
-  size_t chunk = per_draw ? ((size_t)2 << 30) / per_draw : (size_t)batch;
+  size_t chunk = per_draw ? ((size_t)16 << 30) / per_draw : (size_t)batch;
   if (chunk < 1) chunk = 1;
   if (chunk > (size_t)batch) chunk = (size_t)batch;
   const size_t nn = chunk * n * n, nk = chunk * n * k;

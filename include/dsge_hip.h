@@ -349,7 +349,7 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
  * cycle_reduction.py:117-124 = o1_policy_function_adjoints shared.py:12-71; R = -(C T + B)^-1 D shared.py:74-75;
  * P0 = solve_discrete_lyapunov statespace.py:814-815; the filter scan statespace.py:1151-1157), written as four
  * kernels: Kalman reverse sweep on the reduced model (stores every predicted (a_t, P_t) in library scratch, the
- * batch is processed in chunks of <= 2 GiB), reverse of the assembly, policy-function adjoints.
+ * batch is processed in chunks of <= 16 GiB of scratch), reverse of the assembly, policy-function adjoints.
  *   q : [k] (q_batched=0) or [batch][k] diagonal shock covariance;  Z : selector design matrix (one non-zero per
  *       row, distinct columns), [p][n] or [batch][p][n];  p <= 8;  n <= 48
  *   A_bar,B_bar,C_bar : [batch][n][n];  D_bar : [batch][n][k];  q_bar : [batch][k] (also for a shared q: sum over
