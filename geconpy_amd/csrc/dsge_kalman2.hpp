@@ -92,7 +92,7 @@ __device__ __forceinline__ void mm_acc_p(double (&acc)[BS][BS], const double* A,
 // SEL = true : selector design matrix (P Z' and F are gathers)
 // SEL = false: dense Z (p <= 8): P Z' is a register-block product against the full P kept in LDS
 template <int BS, bool SEL>
-__global__ __launch_bounds__(64, (BS <= 4 ? 2 : 1)) void kalman_sel_kernel(
+__global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
