@@ -148,6 +148,10 @@ int dsge_set_cr_compact(int enable) {
   g_cr_compact = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
+int dsge_set_kalman_tiny(int enable) {
+  g_kalman_tiny = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
 int dsge_set_kalman_steady_tol(double tol) {
   if (!(tol >= 0.0) || tol > 1e-6) return fail(DSGE_ERR_INVALID, "steady-state tolerance must be in [0, 1e-6]");
   g_kalman_steady_tol = tol;

@@ -2,12 +2,14 @@
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
+#include "dsge_kalman_tiny.hpp"
 
 namespace dsge_host {
 
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
 double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
-int32_t* g_kalman_steady_at = nullptr;  // debug: device buffer [batch], first steady step per draw (-1 = never)
+int32_t* g_kalman_steady_at = nullptr;
+int g_kalman_tiny = 1;  // 0 = never use the thread-per-draw kernel (tests compare the two paths)  // debug: device buffer [batch], first steady step per draw (-1 = never)
 
 // p0_valid = 0: P0 is an uninitialised scratch buffer.  The fast kernels then compute the stationary
 // covariance themselves (on the reduced model); only the draws that end up in the general kernel get
@@ -25,6 +27,22 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   // the general kernel below.
   const bool fast = p <= 8;
   bool launched_fast = false;
+  // Small models (reduced filter of at most 6 variables, p <= 3, selector Z): one thread per draw, all in
+  // registers.  Draws that do not fit are flagged and fall through to the wave-per-draw cascade below.
+  if (g_kalman_tiny && z_selector_hint && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) {
+    const int blocks = (batch + 63) / 64;
+    if (n_state_hint + p <= 4) {
+      hipLaunchKernelGGL((dsge::kalman_tiny_kernel<4, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
+                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, g_kalman_steady_tol, logp, status,
+                         g_kalman_steady_at);
+    } else {
+      hipLaunchKernelGGL((dsge::kalman_tiny_kernel<6, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
+                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, g_kalman_steady_tol, logp, status,
+                         g_kalman_steady_at);
+    }
+    HIP_TRY(hipGetLastError());
+    launched_fast = true;
+  }
   if (fast) {
     // The fast kernel filters only the variables that matter (states + observed non-states), so its
     // tile size follows that reduced dimension u, not m.  u is only known per draw on the device

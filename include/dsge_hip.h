@@ -145,6 +145,10 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
  * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  Process-wide setting.  tol in [0, 1e-6].
  */
 int dsge_set_kalman_steady_tol(double tol);
+/* Small models (selector Z, p <= 3, at most 6 filtered variables) are filtered by a thread-per-draw kernel that keeps
+ * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
+ * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
+int dsge_set_kalman_tiny(int enable);
 double dsge_get_kalman_steady_tol(void);
 /* Debug hook: device int32[batch] that later fast-path Kalman launches fill with the first time step
  * that ran in steady-state mode (-1 = never); NULL stops recording. */

@@ -904,3 +904,33 @@ def test_kalman_fuzz_against_oracle():
             ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=None if H is None else np.diag(H), d=d)
             assert_allclose(logp[i], ref, rtol=LOGP_RTOL, err_msg=str((trial, m, k, p, ns)))
             assert_allclose(logp_gen[i], ref, rtol=LOGP_RTOL, err_msg=str((trial, m, k, p, ns)))
+
+
+def test_kalman_tiny_kernel_matches_wave_kernels():
+    """Small models (reduced filter <= 6 variables, p <= 3) take the thread-per-draw kernel: same logp as the
+    wave-per-draw kernels (switch off -> on) and as the oracle; observed non-states, weights, missing data, d, H."""
+    lib = _lib.load()
+    rng = np.random.default_rng(314)
+    cases = [(8, 1, 1, 2), (8, 2, 2, 3), (9, 3, 3, 3), (12, 2, 2, 4), (6, 1, 1, 5), (16, 3, 2, 2)]
+    for m, k, p, ns in cases:
+        nb, T_len = 70, 90  # more than one 64-thread block
+        T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=500 + m + p)
+        T *= 0.7
+        y[40, 0] = np.nan
+        logp1, st1 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+        _lib.check(lib.dsge_set_kalman_tiny(0))
+        try:
+            logp0, st0 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+        finally:
+            _lib.check(lib.dsge_set_kalman_tiny(1))
+        assert np.all(st1 == 0) and np.all(st0 == 0), (m, k, p, ns)
+        assert_allclose(logp1, logp0, rtol=1e-11, err_msg=str((m, k, p, ns)))
+        for i in (0, 33, 69):
+            ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
+            assert_allclose(logp1[i], ref, rtol=LOGP_RTOL)
+    # explosive draw inside a tiny batch: flagged, not crashed
+    T, R, q, Z, d, H, y = _kalman_inputs(3, 8, 1, 1, 30, 2, seed=9)
+    cols = np.flatnonzero(np.abs(T[1]).sum(axis=0))
+    T[1] *= 1.4 / np.max(np.abs(np.linalg.eigvals(T[1][np.ix_(cols, cols)])))
+    logp, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+    assert st[0] == 0 and st[2] == 0 and (st[1] & _lib.ST_LYAP_FAIL) and logp[1] == -np.inf
