@@ -14,9 +14,9 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
   int rc = DSGE_ERR_INVALID;
   // Column-compact kernel first (zero columns of A and C dropped); it flags the draws whose
   // s + l exceeds the tile, and the dense kernel then runs on exactly those.
-  const bool compact = g_cr_compact && bs <= 6;
+  const bool compact = g_cr_compact != 0;
   if (compact) {
-    DISPATCH_BS(bs, 6, {
+    DISPATCH_BS(bs, 8, {
       rc = set_lds(dsge::cr_compact_kernel<BS>, dsge::CrcSmem<BS>::bytes);
       if (rc == DSGE_SUCCESS) {
         hipLaunchKernelGGL(dsge::cr_compact_kernel<BS>, dim3(batch), dim3(64), dsge::CrcSmem<BS>::bytes, st, A, B, C,
