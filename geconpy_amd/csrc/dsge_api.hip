@@ -60,6 +60,7 @@ struct Arena {
 };
 constexpr int MAX_DEV = 16;
 Arena g_scratch[MAX_DEV];  // pipeline intermediates
+Arena g_scratch2[MAX_DEV]; // second set: the chunked host path keeps two pipelines in flight
 Arena g_stage[MAX_DEV];    // host-twin staging
 
 int arena_reserve(Arena* arenas, size_t bytes, void** out) {
@@ -345,7 +346,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
                     const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
                     double jitter, double missing_fill, int n_state_hint, int z_selector_hint, int n_lead_hint,
                     double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* resid_out,
-                    int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out) {
+                    int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out, int arena_id = 0) {
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
   int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
@@ -362,8 +363,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
 
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_scratch, 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 4096,
-                          &base)))
+  if ((rc = arena_reserve(arena_id ? g_scratch2 : g_scratch,
+                          3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 4096, &base)))
     return rc;
   Carver cv(base);
   double* Tw = T_out ? T_out : cv.take<double>(nn);
@@ -1073,26 +1074,63 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                           &base)))
     return rc;
   Carver cv(base);
-  UP(dA, A, nn, double);
-  UP(dB, B, nn, double);
-  UP(dC, C, nn, double);
-  UP(dD, D, nk, double);
-  UP(dQ, Q, nq, double);
-  UP(dZ, Z, nz, double);
-  UP(dd, d, nd, double);
-  UP(dH, Hdiag, nh, double);
-  UP(dy, y, ny, double);
+  // Shared inputs first (default stream), then the batch in chunks on two streams: while the kernels of chunk c run,
+  // the host stages chunk c+1 (pageable memory: hipMemcpyAsync returns once the runtime has staged the buffer), so
+  // the PCIe transfer of the Jacobians overlaps the compute.  Outputs come back in one go at the end.
+  double *dA = cv.take<double>(nn), *dB = cv.take<double>(nn), *dC = cv.take<double>(nn), *dD = cv.take<double>(nk);
+  const bool q_b = (q_mode == DSGE_Q_DIAG_BATCHED || q_mode == DSGE_Q_FULL_BATCHED);
+  double* dQ = cv.take<double>(nq);
+  double* dZ = cv.take<double>(nz);
+  double* dd = d ? cv.take<double>(nd) : nullptr;
+  double* dH = Hdiag ? cv.take<double>(nh) : nullptr;
+  double* dy = cv.take<double>(ny);
   OUTBUF(dL, logp_out, batch, double);
   OUTBUF(dS, status_out, batch, int32_t);
   OUTBUF(dT, T_out, nn, double);
   OUTBUF(dR, R_out, nk, double);
   OUTBUF(dRes, resid_out, batch, double);
   OUTBUF(dI, n_iter_out, batch, int32_t);
-  if ((rc = dsge_solve_kalman_logp_batched(dA, dB, dC, dD, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy,
-                                           batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
-                                           n_state_hint, z_selector_hint, n_lead_hint, dL, dS, dT, dR, dRes, dI,
-                                           nullptr)))
-    return rc;
+  if (!q_b) HIP_TRY(hipMemcpyAsync(dQ, Q, nq * 8, hipMemcpyHostToDevice, nullptr));
+  if (!z_batched) HIP_TRY(hipMemcpyAsync(dZ, Z, nz * 8, hipMemcpyHostToDevice, nullptr));
+  if (d && !d_batched) HIP_TRY(hipMemcpyAsync(dd, d, nd * 8, hipMemcpyHostToDevice, nullptr));
+  if (Hdiag && !h_batched) HIP_TRY(hipMemcpyAsync(dH, Hdiag, nh * 8, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(dy, y, ny * 8, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  static thread_local hipStream_t s_str[2] = {nullptr, nullptr};
+  static thread_local int s_dev = -1;
+  int dev_now = 0;
+  HIP_TRY(hipGetDevice(&dev_now));
+  if (s_dev != dev_now) {  // (streams belong to a device; recreate after a device switch)
+    for (auto& x : s_str) HIP_TRY(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    s_dev = dev_now;
+  }
+  const int n_chunks = (batch >= 2048) ? 4 : (batch >= 512 ? 2 : 1);
+  const int per = (batch + n_chunks - 1) / n_chunks;
+  const size_t qk = (q_mode == DSGE_Q_FULL_BATCHED) ? (size_t)k * k : (size_t)k;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int c0 = c * per;
+    const int nb = (batch - c0 < per) ? batch - c0 : per;
+    if (nb <= 0) break;
+    hipStream_t st = s_str[c & 1];
+    const size_t o2 = (size_t)c0 * n * n, ok = (size_t)c0 * n * k;
+    HIP_TRY(hipMemcpyAsync(dA + o2, A + o2, (size_t)nb * n * n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dB + o2, B + o2, (size_t)nb * n * n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dC + o2, C + o2, (size_t)nb * n * n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dD + ok, D + ok, (size_t)nb * n * k * 8, hipMemcpyHostToDevice, st));
+    if (q_b) HIP_TRY(hipMemcpyAsync(dQ + c0 * qk, Q + c0 * qk, (size_t)nb * qk * 8, hipMemcpyHostToDevice, st));
+    if (z_batched)
+      HIP_TRY(hipMemcpyAsync(dZ + (size_t)c0 * p * n, Z + (size_t)c0 * p * n, (size_t)nb * p * n * 8, hipMemcpyHostToDevice, st));
+    if (d && d_batched) HIP_TRY(hipMemcpyAsync(dd + (size_t)c0 * p, d + (size_t)c0 * p, (size_t)nb * p * 8, hipMemcpyHostToDevice, st));
+    if (Hdiag && h_batched)
+      HIP_TRY(hipMemcpyAsync(dH + (size_t)c0 * p, Hdiag + (size_t)c0 * p, (size_t)nb * p * 8, hipMemcpyHostToDevice, st));
+    if ((rc = pipeline(dA + o2, dB + o2, dC + o2, dD + ok, q_b ? dQ + c0 * qk : dQ, q_mode, z_batched ? dZ + (size_t)c0 * p * n : dZ,
+                       z_batched, (dd && d_batched) ? dd + (size_t)c0 * p : dd, d_batched,
+                       (dH && h_batched) ? dH + (size_t)c0 * p : dH, h_batched, dy, nb, n, k, p, T_len, solver, tol, max_iter, jitter,
+                       missing_fill, n_state_hint, z_selector_hint, n_lead_hint, dL + c0, dS + c0, dT ? dT + o2 : nullptr,
+                       dR ? dR + ok : nullptr, dRes ? dRes + c0 : nullptr, dI ? dI + c0 : nullptr, st, 1, nullptr, c & 1)))
+      return rc;
+  }
+  for (auto& x : s_str) HIP_TRY(hipStreamSynchronize(x));
   DOWN(logp_out, dL, batch, double);
   DOWN(status_out, dS, batch, int32_t);
   DOWN(T_out, dT, nn, double);
