@@ -44,7 +44,8 @@ def executed_flops(n, k, p, T_len, s, l, u, cr_iters, n_full, n_doublings, selec
     n_full = time steps that ran the full covariance update (the rest ran the steady-state mean recursion)."""
     wr = s + l
     cr = cr_iters * (n**3 + 2 * n * n * wr + 2 * n * wr * wr) + n**3 + 2 * n * n * s
-    asm = 2 * n * n * l + n**3 + 2 * n * n * k + 2 * n**3 + 2 * n * n * k  # B + C T, GJ [M | D], resid, R Q R'
+    cr += 2 * n * n * k  # the final elimination also carries D: R = -A1_hat^-1 D (fused selection)
+    asm = 2 * n * n * k + n * n  # what is left for the assemble kernel: sym(R Q R')
     full = 2 * s * s * u + 2 * u * u * s + 2 * u * s + 2 * u * 64 + 16 * u * u + 2 * 512 + 4 * u
     steady = 2 * u * s + 2 * u * 8 + 2 * 64
     doubling = 2 * s * s * u + 2 * u * u * s + 2 * u * s * s
@@ -267,7 +268,11 @@ def main():
         cr_it = stats.get("cr_iters_mean", 7.0)
         flops = algorithmic_flops(n, k, p, T_len, cr_iters=cr_it)
         # contract flops by the kernel that does the work (the Lyapunov solve now runs inside the Kalman kernel)
-        contract = {"solver": flops["solver"], "assemble": flops["selection"], "kalman": flops["kalman"] + flops["lyapunov"]}
+        # (selection: R comes out of the cycle-reduction kernel's final elimination unless --solver gensys)
+        fused_sel = args.solver == "cycle_reduction"
+        contract = {"solver": flops["solver"] + (flops["selection"] if fused_sel else 0.0),
+                    "assemble": 2.0 * n * n * k if fused_sel else flops["selection"],
+                    "kalman": flops["kalman"] + flops["lyapunov"]}
         s_cols = hints[0] or n
         u_dim = min(n, s_cols + p) if not hints[1] else int(np.count_nonzero((shard["A"][0] != 0).any(axis=0)
                                                                              | (om["Z"] != 0).any(axis=0)))

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "dsge_gensys_batched": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_gensys_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_set_cr_compact": [_i],
+    "dsge_set_cr_fused_selection": [_i],
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_set_kalman_tiny": [_i],
     "dsge_set_kalman_steady_tol": [_f],

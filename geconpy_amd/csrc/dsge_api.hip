@@ -29,6 +29,7 @@ namespace {
 
 
 
+int g_cr_fuse_R = 1;  // fused pipeline: take R from the cycle-reduction kernel's final elimination
 bool g_device_checked = false;
 int g_device_ok = 0;
 std::mutex g_mutex;
@@ -143,6 +144,10 @@ int dsge_debug_cr_phases(int enable, long long* cycles_out) {
     (void)hipFree(g_cr_dbg);
     g_cr_dbg = nullptr;
   }
+  return DSGE_SUCCESS;
+}
+int dsge_set_cr_fused_selection(int enable) {
+  g_cr_fuse_R = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_cr_compact(int enable) {
@@ -380,9 +385,12 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   const int n_rep = ms_out ? reps : 1;
   for (int rep = 0; rep < n_rep; ++rep) {
     if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
+    // Cycle reduction (njit semantics) can hand back R from its final elimination (A1_hat = B + C T at convergence);
+    // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
+    const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && g_cr_fuse_R;
     if (is_cr) {
       rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, n_iter_out, st,
-                     solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0);
+                     solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0, fuse_R ? D : nullptr, k, fuse_R ? Rw : nullptr);
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
       rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st);
@@ -395,9 +403,12 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
     // backward_direct already produced R; the assemble kernel recomputes it from the same
     // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
-    if ((rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, RQR, P0, status_out, 1, 2,
-                              st)))
-      return rc;
+    if (fuse_R)
+      rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, Tw, Rw, Q, q_mode, batch, n, k, nullptr, nullptr, RQR, P0,
+                           status_out, 0, 2, st);
+    else
+      rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, RQR, P0, status_out, 1, 2, st);
+    if (rc) return rc;
     if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
     if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
                             missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st)))

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
                                                          double tol, double* __restrict__ T_out,
                                                          int32_t* __restrict__ status,
                                                          int32_t* __restrict__ n_iter_out,
-                                                         long long* __restrict__ dbg, int scan_mode) {
+                                                         long long* __restrict__ dbg, int scan_mode,
+                                                         const double* __restrict__ D, int k,
+                                                         double* __restrict__ R_out) {
   constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
@@ -213,7 +215,11 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
     // scan variant: T is formed from whatever A1_hat the fixed trip count reached (:292), NaN excepted
     const bool solve_T = converged || (scan_mode && !saw_nan);
     if (solve_T) {
-      // T[:,S] = -A1_hat^-1 A[:,S]   (cycle_reduction.py:181); every other column is exactly zero
+      // T[:,S] = -A1_hat^-1 A[:,S]   (cycle_reduction.py:181); every other column is exactly zero.
+      // With D given the same elimination also yields the shock-impact matrix: at convergence A1_hat = B + C T
+      // (to the square of the last iterate's norms), so R = -(C T + B)^-1 D (shared.py:74-75) = -A1_hat^-1 D.
+      const bool want_R = (R_out != nullptr) && !scan_mode;
+      const bool r_fits = want_R && (s + k <= NP);
       wave_sync();
       blk_store_lds<BS>(Ah, W, LDW, lr, lc);
       if (scan_mode && lr == lc) {
@@ -227,7 +233,10 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
 #pragma unroll
           for (int j = 0; j < BS; ++j) {
             const int r = lr * BS + i, c = lc * BS + j;
-            t[i][j] = (r < n && c < s) ? A[off + (size_t)r * n + ccol[j]] : 0.0;
+            double v = 0.0;
+            if (r < n && c < s) v = A[off + (size_t)r * n + ccol[j]];
+            else if (r_fits && r < n && c >= s && c < s + k) v = D[(size_t)draw * n * k + (size_t)r * k + (c - s)];
+            t[i][j] = v;
           }
         blk_store_lds<BS>(t, G1, LDW, lr, lc);
       }
@@ -238,7 +247,29 @@ __global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict
 #pragma unroll
         for (int j = 0; j < BS; ++j)
           Tb[i][j] = (vS[j] >= 0) ? -G1[(lr * BS + i) * LDW + vS[j]] : 0.0;
+      if (r_fits) {
+        for (int idx = lane; idx < n * k; idx += 64) {
+          const int r = idx / k, c = idx - r * k;
+          R_out[(size_t)draw * n * k + idx] = -G1[r * LDW + s + c];
+        }
+      } else if (want_R) {  // s + k does not fit next to A[:,S]: one more elimination for D alone
+        wave_sync();
+        blk_store_lds<BS>(Ah, W, LDW, lr, lc);
+        {
+          double t[BS][BS];
+          blk_load_global<BS>(t, D + (size_t)draw * n * k, n, k, k, lr, lc);
+          blk_store_lds<BS>(t, G1, LDW, lr, lc);
+        }
+        gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+        gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+        for (int idx = lane; idx < n * k; idx += 64) {
+          const int r = idx / k, c = idx - r * k;
+          R_out[(size_t)draw * n * k + idx] = -G1[r * LDW + c];
+        }
+      }
     }
+    if (R_out != nullptr && !scan_mode && !solve_T)
+      for (int idx = lane; idx < n * k; idx += 64) R_out[(size_t)draw * n * k + idx] = 0.0;
     blk_store_global<BS>(Tb, T_out + off, n, n, n, lr, lc);
     if (lane == 0) {
       status[draw] = solve_T ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));

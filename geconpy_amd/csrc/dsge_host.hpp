@@ -50,7 +50,8 @@ int set_lds(K kernel, size_t bytes) {
 
 // ---- launchers (launch_solvers.hip, launch_assemble.hip, launch_kalman.hip, launch_gensys.hip) ----
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
-              double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode = 0);
+              double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode = 0,
+              const double* D = nullptr, int k = 0, double* R_out = nullptr);  // D, R_out: also R = -A1_hat^-1 D
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
                    double* R_out, hipStream_t st);
 int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,

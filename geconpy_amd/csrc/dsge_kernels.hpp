@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
                                                  const double* __restrict__ C, int batch, int n, int max_iter,
                                                  double tol, double* __restrict__ T_out,
                                                  int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
-                                                 int rerun_only, int scan_mode) {
+                                                 int rerun_only, int scan_mode, const double* __restrict__ D, int k,
+                                                 double* __restrict__ R_out) {
   constexpr int NP = CrSmem<BS>::NP, LD = CrSmem<BS>::LD, LDW = CrSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
@@ -132,14 +133,28 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
         blk_load_global<BS>(t, A + off, n, n, n, lr, lc);
         blk_store_lds<BS>(t, W + NP, LDW, lr, lc);
       }
-      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
-      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+      // with D: the same elimination gives R = -A1_hat^-1 D (= -(C T + B)^-1 D at convergence, see dsge_cr_compact.hpp)
+      const bool want_R = (R_out != nullptr) && !scan_mode;
+      if (want_R) {
+        double t[BS][BS];
+        blk_load_global<BS>(t, D + (size_t)draw * n * k, n, k, k, lr, lc);
+        blk_store_lds<BS>(t, W + 2 * NP, LDW, lr, lc);
+      }
+      gauss_jordan_blocked<BS>(W, LDW, n, want_R ? 3 : 2, Lbuf, Ybuf, prow, lane);
+      gj_unpermute<BS>(W, LDW, n, 1, want_R ? 3 : 2, prow, lane);
       blk_load_lds<BS>(Tb, W + NP, LDW, lr, lc);
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
         for (int j = 0; j < BS; ++j) Tb[i][j] = -Tb[i][j];
+      if (want_R)
+        for (int idx = lane; idx < n * k; idx += 64) {
+          const int r = idx / k, c = idx - r * k;
+          R_out[(size_t)draw * n * k + idx] = -W[r * LDW + 2 * NP + c];
+        }
     }
+    if (R_out != nullptr && !scan_mode && !solve_T)
+      for (int idx = lane; idx < n * k; idx += 64) R_out[(size_t)draw * n * k + idx] = 0.0;
     blk_store_global<BS>(Tb, T_out + off, n, n, n, lr, lc);
     if (lane == 0) {
       status[draw] = solve_T ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));

@@ -110,6 +110,12 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
  * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every
  * draw (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_cr_compact(int enable);
+/* In the fused entry points with solver = cycle_reduction and no residual requested, R = -(C T + B)^-1 D is taken
+ * from the final elimination of cycle reduction: T = -A1_hat^-1 A and A1_hat -> B + C T (the difference is of the
+ * order of the product of the last iterate's norms, < tol^2), so R = -A1_hat^-1 D comes out of the same Gauss-Jordan
+ * sweep (agreement with the explicit formula ~1e-13 relative, tests/test_gpu_parity.py).  enable = 0 always uses the
+ * explicit formula in the assemble kernel.  Process-wide; default 1. */
+int dsge_set_cr_fused_selection(int enable);
 /* Debug hook: enable != 0 makes the compact cycle-reduction kernel record the shader cycles draw 0 spends in
  * [0] Gauss-Jordan panels, [1] trailing updates, [2] row gather + staging, [3] products, [4] scatter/updates/
  * norms, [5] the final solve, [6] total, [7] = iterations; cycles_out (host int64[8], may be NULL). */

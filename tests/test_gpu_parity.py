@@ -934,3 +934,37 @@ def test_kalman_tiny_kernel_matches_wave_kernels():
     T[1] *= 1.4 / np.max(np.abs(np.linalg.eigvals(T[1][np.ix_(cols, cols)])))
     logp, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
     assert st[0] == 0 and st[2] == 0 and (st[1] & _lib.ST_LYAP_FAIL) and logp[1] == -np.inf
+
+
+def test_cr_fused_selection_matches_explicit_formula():
+    """Fused pipeline, cycle reduction: R taken from the final elimination (-A1_hat^-1 D) vs the explicit
+    R = -(C T + B)^-1 D of the assemble kernel: same logp to 1e-11 on healthy draws, same statuses on failing ones,
+    including draws that take the dense fallback kernel."""
+    lib = _lib.load()
+    om = wl.sw_shaped_observation_model()
+    b = wl.sw_shaped_batch(24)
+    q = b["sigma"] ** 2
+    A = b["A"].copy()
+    A[5, 0, 0] = np.nan                                 # a failing draw
+    sets = [(A, b["B"], b["C"], b["D"], q, om["Z"], om["y"][:60], om["Hdiag"])]
+    rng = np.random.default_rng(12)
+    n = 12                                              # dense A and C: the compact kernel hands over to the dense one
+    sysd = [_structured_system(rng, n, np.arange(n), np.arange(n), rho_t=0.8, rho_g=0.5) for _ in range(4)]
+    Ad, Bd, Cd = (np.stack([s_[i] for s_ in sysd]) for i in range(3))
+    Dd = rng.standard_normal((4, n, 2))
+    Zd = np.zeros((2, n))
+    Zd[0, 1] = Zd[1, 4] = 1.0
+    sets.append((Ad, Bd, Cd, Dd, np.full((4, 2), 0.3), Zd, rng.standard_normal((40, 2)), np.array([0.1, 0.2])))
+    for A_, B_, C_, D_, q_, Z_, y_, H_ in sets:
+        kw = dict(Hdiag=H_, tol=1e-10, max_iter=200, q_mode="diag_batched")
+        r1 = batched.solve_kalman_logp_batched(A_, B_, C_, D_, q_, Z_, y_, **kw)
+        _lib.check(lib.dsge_set_cr_fused_selection(0))
+        try:
+            r0 = batched.solve_kalman_logp_batched(A_, B_, C_, D_, q_, Z_, y_, **kw)
+        finally:
+            _lib.check(lib.dsge_set_cr_fused_selection(1))
+        assert np.array_equal(r1["status"], r0["status"])
+        good = r0["status"] == 0
+        assert good.sum() >= len(good) - 1
+        assert_allclose(r1["logp"][good], r0["logp"][good], rtol=1e-11)
+        assert np.all(r1["logp"][~good] == -np.inf)
