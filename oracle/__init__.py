@@ -14,14 +14,16 @@ Pinning status
   extraction, ``tests/golden/_ref_extract.py``) on the reference's golden A,B,C,D
   fixtures (``tests/_resources/expected_matrices.py``); outputs frozen under
   ``tests/golden/*.npz`` by ``tests/golden/make_golden.py``.
-* Discrete Lyapunov ``P0`` and the Kalman filter log-likelihood: PARITY UNPINNED.  The
-  reference delegates both to third-party packages that are absent from
-  ``/root/reference`` and from this image (``pytensor>=3.0.4``
-  ``solve_discrete_lyapunov`` and ``pymc_extras>=0.12.0`` ``StandardFilter``;
-  ``pyproject.toml:43-45``).  ``oracle/statespace.py`` restates their published
-  algorithm; the reference's own tests assert only finiteness and one
-  self-consistency equality at this boundary (tests/model/test_statespace.py:100-115,
-  583-630), which ``tests/test_oracle_kalman.py`` reproduces.
+* Discrete Lyapunov ``P0`` and the Kalman filter log-likelihood: the RECURSION is pinned against
+  statsmodels 0.12.2 (independent compiled filter found in the build container's Anaconda tree;
+  ``tests/golden/make_statsmodels_golden.py`` -> ``tests/golden/statsmodels_kalman.npz``; with
+  ``jitter = 0`` and complete data the conventions coincide: 4e-11 relative from a common P0).
+  The pymc_extras CONVENTIONS layered on it stay restated and unpinned (jitter 1e-8 on F and P+,
+  fill value -9999, masked rows kept with the full ``p``, ``d`` unmasked): the reference delegates
+  the filter to ``pymc_extras>=0.12.0`` ``StandardFilter`` and the Lyapunov solve to
+  ``pytensor>=3.0.4`` (``pyproject.toml:43-45``), absent from ``/root/reference`` and from this
+  image; its own tests assert only finiteness and one self-consistency equality at this boundary
+  (tests/model/test_statespace.py:100-115, 583-630), which ``tests/test_oracle_kalman.py`` reproduces.
 """
 from .cycle_reduction import (  # noqa: F401
     cycle_reduction_core,

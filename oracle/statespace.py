@@ -1,5 +1,6 @@
 """Oracle restatement of the state-space assembly + Kalman log-likelihood
-(TEST INFRASTRUCTURE ONLY).  *** PARITY UNPINNED for everything in this file. ***
+(TEST INFRASTRUCTURE ONLY).  *** The recursion is pinned against statsmodels (jitter = 0, complete data:
+tests/golden/statsmodels_kalman.npz); the pymc_extras conventions below are restated and UNPINNED. ***
 
 Reference call sites (gEconpy):
   * ``P0 = solve_discrete_lyapunov(T_aug, R Q R', method="bilinear")`` statespace.py:814-815
