@@ -970,23 +970,25 @@ def test_cr_fused_selection_matches_explicit_formula():
         assert np.all(r1["logp"][~good] == -np.inf)
 
 
-def test_kalman_matches_statsmodels():
-    """Device filter (every kernel variant the hints select) with jitter = 0 against statsmodels' log-likelihood
-    (tests/golden/statsmodels_kalman.npz): pins the recursion, the stationary P0 and the likelihood formula against an
-    independent third-party implementation."""
+def test_kalman_matches_statsmodels_and_arbitrary_precision():
+    """Device filter (every kernel variant the hints select) against (i) statsmodels' log-likelihood at jitter = 0
+    (independent third-party implementation; itself only 1.2e-8 accurate on the ill-conditioned RBC case) and (ii) the
+    40-digit mpmath evaluation of the recursion at jitter 0 and 1e-8 (tests/golden/mp_kalman.npz)."""
     import os
 
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "statsmodels_kalman.npz"))
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "statsmodels_kalman.npz"))
+    mpg = np.load(os.path.join(gold, "mp_kalman.npz"))
     for name in g["names"]:
         c = {key: g[f"{name}_{key}"] for key in ("T", "R", "Q", "Z", "H", "d", "y")}
-        ref = float(g[f"{name}_loglike"])
         T3, R3 = c["T"][None], c["R"][None]
         for hints in (dict(), dict(n_state_hint=0, z_selector_hint=0)):
-            logp, st = batched.kalman_logp_batched(T3, R3, c["Q"], c["Z"], c["y"], d=c["d"], Hdiag=np.diag(c["H"]).copy(),
-                                                   q_mode="full", jitter=0.0, **hints)
-            assert st[0] == 0
-            # 1e-7: statsmodels' own stationary covariance is only that accurate on the near-unit-root RBC system
-            # (tests/test_oracle_kalman.py pins the recursion to 1e-9 from a common P0)
-            assert_allclose(logp[0], ref, rtol=1e-7, err_msg=f"{name} {hints}")
-            own = oracle.kalman_filter_logp(c["y"], c["T"], c["R"], c["Q"], c["Z"], H=c["H"], d=c["d"], jitter=0.0)
-            assert_allclose(logp[0], own, rtol=LOGP_RTOL, err_msg=f"{name} {hints}")
+            for label, jit in (("", 0.0), ("_jitter", 1e-8)):
+                logp, st = batched.kalman_logp_batched(T3, R3, c["Q"], c["Z"], c["y"], d=c["d"], Hdiag=np.diag(c["H"]).copy(),
+                                                       q_mode="full", jitter=jit, **hints)
+                assert st[0] == 0
+                if jit == 0.0:
+                    assert_allclose(logp[0], float(g[f"{name}_loglike"]), rtol=5e-8, err_msg=f"{name} {hints}")
+                key = f"{name}_loglike_mp{label}"
+                if key in mpg.files:
+                    assert_allclose(logp[0], float(mpg[key]), rtol=1e-10, err_msg=f"{name}{label} {hints}")
