@@ -62,6 +62,7 @@ PROTOTYPES = {
     "dsge_set_cr_fused_selection": [_i],
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_set_kalman_tiny": [_i],
+    "dsge_set_kalman_mfma": [_i],
     "dsge_set_kalman_steady_tol": [_f],
     "dsge_get_kalman_steady_tol": [],
     "dsge_debug_kalman_steady_steps": [_dp],

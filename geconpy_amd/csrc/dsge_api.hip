@@ -154,6 +154,10 @@ int dsge_set_cr_compact(int enable) {
   g_cr_compact = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
+int dsge_set_kalman_mfma(int enable) {
+  g_kalman_mfma = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
 int dsge_set_kalman_tiny(int enable) {
   g_kalman_tiny = enable ? 1 : 0;
   return DSGE_SUCCESS;

@@ -89,6 +89,7 @@ extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-red
 // process-wide settings of the fast Kalman kernel (launch_kalman.hip)
 extern long long* g_kalman_dbg;       // debug: device buffer for per-phase cycles of draw 0
 extern double g_kalman_steady_tol;    // steady-state switch (0 = never switch)
+extern int g_kalman_mfma;             // launch_kalman.hip: 0 = VALU products only
 extern int g_kalman_tiny;             // 0 = never use the thread-per-draw small-model kernel
 extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first steady step per draw (-1 = never)
 

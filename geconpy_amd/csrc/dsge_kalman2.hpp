@@ -89,9 +89,71 @@ __device__ __forceinline__ void mm_acc_p(double (&acc)[BS][BS], const double* A,
 #undef MM_FMA
 }
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// One 16 x 16 output tile of a product on the FP64 matrix core: K4/4 x v_mfma_f64_16x16x4_f64.
+//   TB = true : D = A[0:16, 0:K] B[0:16, 0:K]'      TB = false : D = A[0:16, 0:K] B[0:K, 0:16]
+// Fragment layout (probed on gfx950, tools/mfma_probe): lane l supplies A[l & 15][k0 + (l >> 4)] and
+// B[k0 + (l >> 4)][l & 15]; it receives D[(l >> 4) + 4 r][l & 15], r = 0..3.  Rows >= a_rows / b_rows and
+// k >= K are fed as zeros (the operands are read with predicates, nothing outside the buffers is touched).
+template <bool TB, int KMAX>
+__device__ __forceinline__ v4f64 mfma_tile_16(const double* A, int lda, int a_rows, const double* B, int ldb, int b_rows,
+                                              int K, int lane) {
+  const int r16 = lane & 15, kq = lane >> 4;
+  // every operand of the (at most KMAX / 4) steps is loaded up front from a clamped, always valid address and zeroed
+  // by a select afterwards (no exec-mask branches); two accumulators halve the dependent MFMA chain
+  const int ra = r16 < a_rows ? r16 : a_rows - 1, rb = r16 < b_rows ? r16 : b_rows - 1;
+  double a[KMAX / 4], b[KMAX / 4];
+#pragma unroll
+  for (int q = 0; q < KMAX / 4; ++q) {
+    const int k = 4 * q + kq, kc = k < K ? k : K - 1;
+    const double av = A[ra * lda + kc];
+    const double bv = TB ? B[rb * ldb + kc] : B[kc * ldb + r16];
+    a[q] = (k < K && r16 < a_rows) ? av : 0.0;
+    b[q] = (k < K && (!TB || r16 < b_rows)) ? bv : 0.0;
+  }
+  v4f64 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < KMAX / 4; q += 2) {
+    if (4 * q < K) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], c0, 0, 0, 0);
+    if (q + 1 < KMAX / 4 && 4 * (q + 1) < K) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q + 1], b[q + 1], c1, 0, 0, 0);
+  }
+  return c0 + c1;
+}
+
+// Elements of an (nr x nc) product outside the 16 x 16 core tile, on the VALU: rows >= 16 (all columns) and
+// rows < 16 with columns >= 16.  dst[i][j] = sum_{k<K} A[i][k] * (TB ? B[j][k] : B[k][j]).
+template <bool TB>
+__device__ __forceinline__ void product_fringe(double* dst, int ldd, const double* A, int lda, const double* B, int ldb,
+                                               int nr, int nc, int K, int lane) {
+  const int r_hi = nr > 16 ? nr - 16 : 0, c_hi = nc > 16 ? nc - 16 : 0, r_lo = nr < 16 ? nr : 16;
+  const int n1 = r_hi * nc, n2 = r_lo * c_hi;
+  for (int idx = lane; idx < n1 + n2; idx += 64) {
+    int i, j;
+    if (idx < n1) {
+      i = 16 + idx / nc;
+      j = idx - (i - 16) * nc;
+    } else {
+      const int e = idx - n1;
+      i = e / c_hi;
+      j = 16 + (e - i * c_hi);
+    }
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 1 < K; k += 2) {
+      s0 = fma(A[i * lda + k], TB ? B[j * ldb + k] : B[k * ldb + j], s0);
+      s1 = fma(A[i * lda + k + 1], TB ? B[j * ldb + k + 1] : B[(k + 1) * ldb + j], s1);
+    }
+    if (k < K) s0 = fma(A[i * lda + k], TB ? B[j * ldb + k] : B[k * ldb + j], s0);
+    dst[i * ldd + j] = s0 + s1;
+  }
+}
+
 // SEL = true : selector design matrix (P Z' and F are gathers)
 // SEL = false: dense Z (p <= 8): P Z' is a register-block product against the full P kept in LDS
-template <int BS, bool SEL>
+// MF = true : the two prediction products of every full step run on the FP64 matrix core (16 x 16 core tile by
+//             v_mfma_f64_16x16x4_f64, the <= 8 fringe rows/columns on the VALU); needs 16 <= NP <= 24 (BS = 2, 3)
+template <int BS, bool SEL, bool MF = false>
 __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
@@ -470,6 +532,10 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
         tk0 = tk1;
       }
       // ---- (e) P+ = P - K V' + jitter I (register blocks); state block -> LDS -------------
+      if constexpr (MF) {  // the MFMA path reuses the K / V panels as scratch in (f): keep this lane's row of K
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
+      }
       {
         // two-stage software pipeline over the four observation pairs
         double2 ka[BS], vb[BS], kan[BS], vbn[BS];
@@ -541,6 +607,63 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
         av[lane] = s0 + s1;
         av_reg = s0 + s1;
       }
+      if constexpr (MF) {
+        // W = Pc Tc' (s x m) -> Wc: core tile on the matrix core, fringe on the VALU
+        {
+          const v4f64 c = mfma_tile_16<true, NP>(Pc, LDM, s, Tc, LDM, m, s, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) + 4 * r;
+            if (row < s) Wc[row * LDM + (lane & 15)] = c[r];
+          }
+          product_fringe<true>(Wc, LDM, Pc, LDM, Tc, LDM, s, m, s, lane);
+        }
+        wave_sync();  // #4
+        if (dbg) {
+          const long long tk1 = clock64();
+          ph[3] += tk1 - tk0;
+          tk0 = tk1;
+        }
+        // X = Tc W (m x m) -> Xs, which reuses the dead P Z' / K / V panels
+        double* Xs = PZt;
+        {
+          const v4f64 c = mfma_tile_16<false, NP>(Tc, LDM, m, Wc, LDM, s, s, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) + 4 * r;
+            if (row < m) Xs[row * LDM + (lane & 15)] = c[r];
+          }
+          // fringe: only the rows >= 16 (all columns); X = T P+ T' is symmetric, so the entries (r < 16, c >= 16) are
+          // read from their mirror images below (sym() only averages rounding noise anyway)
+          product_fringe<false>(Xs, LDM, Tc, LDM, Wc, LDM, m, m < 16 ? m : 16, s, lane);
+          if (m > 16) {
+            const int nrest = (m - 16) * (m - 16);
+            for (int idx = lane; idx < nrest; idx += 64) {
+              const int i = 16 + idx / (m - 16), j = 16 + idx % (m - 16);
+              double s0 = 0.0;
+              for (int k = 0; k < s; ++k) s0 = fma(Tc[i * LDM + k], Wc[k * LDM + j], s0);
+              Xs[i * LDM + j] = s0;
+            }
+          }
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const int r = lr * BS + i, c = lc * BS + j;
+            const bool in = r < m && c < m;
+            // of a mixed pair (one index < 16, the other >= 16) only the element with the row >= 16 was computed:
+            // it stands for itself and for its mirror image
+            const bool mixed = (r < 16) != (c < 16);
+            const int r1 = mixed ? (r > c ? r : c) : r, c1 = mixed ? (r > c ? c : r) : c;
+            const double x = in ? Xs[r1 * LDM + c1] : 0.0, xt = in ? (mixed ? x : Xs[c1 * LDM + r1]) : 0.0;
+            Pb[i][j] = 0.5 * (x + xt) + Qb[i][j];
+          }
+        wave_sync();
+        for (int idx = lane; idx < 3 * NP * PS; idx += 64) PZt[idx] = 0.0;  // the panels again (P Z' needs its zeros)
+        wave_sync();
+      } else {
       if (lr * BS < s) {
         double Wb[BS][BS];
         blk_zero<BS>(Wb);
@@ -566,6 +689,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
             Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
           }
       }
+      }
       // ---- P Z' for the next step -------------------------------------------------------------
       STORE_PZT();
       wave_sync();  // #5
@@ -585,7 +709,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           finv_row[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
-          kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
+          if constexpr (!MF) kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
         }
         while (t + 1 < T_len) {
           const double yt_s = yt_next;
@@ -635,8 +759,10 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
         if (lane < m) av[lane] = av_reg;  // hand the predicted state back to the LDS copy
         wave_sync();
       } else {
+        if constexpr (!MF) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
+          for (int q = 0; q < 8; ++q) kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
+        }
         while (t + 1 < T_len) {
           const double yt_s = yt_next;
           const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);

@@ -9,6 +9,8 @@ namespace dsge_host {
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
 double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
 int32_t* g_kalman_steady_at = nullptr;
+int g_kalman_mfma = 0;  // 1 = prediction products of the BS = 2, 3 selector instances on the FP64 matrix core
+                       // (experimental: measured SLOWER than the VALU register blocks)
 int g_kalman_tiny = 1;  // 0 = never use the thread-per-draw kernel (tests compare the two paths)  // debug: device buffer [batch], first steady step per draw (-1 = never)
 
 // p0_valid = 0: P0 is an uninitialised scratch buffer.  The fast kernels then compute the stationary
@@ -68,14 +70,31 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
         if (s_cap > NP) s_cap = NP;
         if (z_selector_hint) {
           const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
-          rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
-          if (rc == DSGE_SUCCESS) {
-            hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR,
-                               p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap, jitter,
-                               missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                               g_kalman_steady_at);
-            HIP_TRY(hipGetLastError());
-            launched_fast = true;
+          bool done = false;
+          if constexpr (BS == 2 || BS == 3) {
+            if (g_kalman_mfma) {  // prediction products on the FP64 matrix core
+              rc = set_lds(dsge::kalman_sel_kernel<BS, true, true>, lds);
+              if (rc == DSGE_SUCCESS) {
+                hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+                                   p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p,
+                                   T_len, s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                   g_kalman_steady_at);
+                HIP_TRY(hipGetLastError());
+                launched_fast = true;
+              }
+              done = true;
+            }
+          }
+          if (!done) {
+            rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
+            if (rc == DSGE_SUCCESS) {
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+                                 p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
+                                 s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 g_kalman_steady_at);
+              HIP_TRY(hipGetLastError());
+              launched_fast = true;
+            }
           }
         } else {
           const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, true);

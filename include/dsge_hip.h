@@ -155,6 +155,13 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
+/* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
+ * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
+ * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
+ * per 4096-draw step) -- FP64 MFMA has the VALU's peak rate on gfx950, the 18-wide reduced model does not fill a
+ * 16 x 16 fragment, and the accumulator + operand registers push the 256-VGPR kernel into spills.
+ * enable = 1 switches it on (tests compare both).  Process-wide. */
+int dsge_set_kalman_mfma(int enable);
 double dsge_get_kalman_steady_tol(void);
 /* Debug hook: device int32[batch] that later fast-path Kalman launches fill with the first time step
  * that ran in steady-state mode (-1 = never); NULL stops recording. */

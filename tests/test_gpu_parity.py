@@ -992,3 +992,24 @@ def test_kalman_matches_statsmodels_and_arbitrary_precision():
                 key = f"{name}_loglike_mp{label}"
                 if key in mpg.files:
                     assert_allclose(logp[0], float(mpg[key]), rtol=1e-10, err_msg=f"{name}{label} {hints}")
+
+
+def test_kalman_mfma_products_match_valu():
+    """The FP64-MFMA prediction products (16 x 16 core tile + VALU fringe) against the VALU register-block products:
+    same logp to 1e-11 for reduced sizes below, at and above one tile (u = 9, 16, 18, 24), and within LOGP_RTOL of the
+    oracle."""
+    lib = _lib.load()
+    for m, k, p, ns in [(12, 2, 2, 9), (20, 4, 4, 16), (40, 7, 7, 18), (30, 6, 6, 24), (16, 3, 3, 10)]:
+        nb, T_len = 5, 60
+        T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=4000 + m)
+        logp0, st0 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+        _lib.check(lib.dsge_set_kalman_mfma(1))  # experimental path, off by default
+        try:
+            logp1, st1 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
+        finally:
+            _lib.check(lib.dsge_set_kalman_mfma(0))
+        assert np.all(st1 == 0) and np.all(st0 == 0), (m, ns)
+        assert_allclose(logp1, logp0, rtol=1e-11, err_msg=str((m, k, p, ns)))
+        for i in (0, 4):
+            ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
+            assert_allclose(logp1[i], ref, rtol=LOGP_RTOL)
