@@ -62,11 +62,13 @@ PROTOTYPES = {
     "dsge_set_cr_fused_selection": [_i],
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_set_kalman_tiny": [_i],
+    "dsge_set_gensys_split": [_i],
     "dsge_set_kalman_mfma": [_i],
     "dsge_set_kalman_steady_tol": [_f],
     "dsge_get_kalman_steady_tol": [],
     "dsge_debug_kalman_steady_steps": [_dp],
     "dsge_debug_kalman_phases": [_i, _dp],
+    "dsge_debug_gensys_window_phases": [_i, _dp],
     "dsge_debug_gensys_phases": [_dp, _dp, _dp, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_selection_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
     "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],

@@ -158,6 +158,10 @@ int dsge_set_kalman_mfma(int enable) {
   g_kalman_mfma = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
+int dsge_set_gensys_split(int enable) {
+  g_gensys_split = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
 int dsge_set_kalman_tiny(int enable) {
   g_kalman_tiny = enable ? 1 : 0;
   return DSGE_SUCCESS;
@@ -677,6 +681,26 @@ int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, 
   }
   (void)hipFree(d);
   return rc;
+}
+
+// Debug hook: enable = 1 allocates the stamp buffer of the window kernels (draw 0 of each launch: reduce [0..4], QZ [8..11],
+// post [16..23]); cycles_out (host int64[24], may be NULL) reads it back; enable = 0 frees it.
+int dsge_debug_gensys_window_phases(int enable, long long* cycles_out) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (enable && !g_gensys_win_dbg) {
+    HIP_TRY(hipMalloc((void**)&g_gensys_win_dbg, 24 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_gensys_win_dbg, 0, 24 * sizeof(long long)));
+  }
+  if (cycles_out && g_gensys_win_dbg) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_out, g_gensys_win_dbg, 24 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && g_gensys_win_dbg) {
+    (void)hipFree(g_gensys_win_dbg);
+    g_gensys_win_dbg = nullptr;
+  }
+  return DSGE_SUCCESS;
 }
 
 int dsge_gensys_batched_host(const double* A, const double* B, const double* C, const double* D, int batch, int n,

@@ -531,7 +531,7 @@ __device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane
 }
 
 // ---- step 3: complex single-shift QZ (zhgeqz, JOB='S') -------------------------------------------
-__device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane) {
+__device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane, long long* cnt = nullptr) {
   const int N = L.N;
   if (N - ilo <= 1) return true;
   const double SAFMIN = 2.2250738585072014e-308, ULP = 2.220446049250313e-16;
@@ -691,6 +691,10 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane)
     {
       // the sweep: pivots travel through registers (Rot4 + v_readlane), one LDS fence per rotation
       Rot4 cr{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
+      if (cnt && lane == 0) {
+        cnt[0] += ilast - istart;  // sweep steps (one row + one column rotation each)
+        cnt[1] += 1;               // sweeps
+      }
       for (int j = istart; j < ilast; ++j) {
         Rot4 rr;
         const RotLd ld = rows_begin(L, j, j + 1, lane);

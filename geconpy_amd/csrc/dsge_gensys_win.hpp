@@ -1,0 +1,803 @@
+// gensys in three launches on the ACTIVE WINDOW of the pencil (same mathematics as dsge_gensys.hpp, which stays as the
+// single-launch fallback): the monolithic kernel keeps H, T (N x N complex), Q Pi and Z[:n] in LDS -- 140 KB at N = 52,
+// one wavefront per CU.  Here
+//   * the z structurally deflated roots (zero columns of A, permuted to the front; a QR of those columns of G0) leave the
+//     chip after the reflector phase: rows < z of the pencil are never touched by a row rotation again, and the column
+//     rotations they would receive are applied once, at the end, through the accumulated right transformation M;
+//   * the reduction to Hessenberg-triangular form runs in REAL storage (the pencil is real until the first complex shift);
+//   * the complex QZ iteration + reordering work on the w x w window (w = N - z) only: H22, T22, M (accumulated Z22), X2;
+//   * the post-processing uses  Z[:n, :] = P diag(I_z, M)  (P = the column permutation), so that
+//       T[state rows]     = Re(M[:, :ns2] Yb Ms^H)[:s']                    (Ms = M[:s'], s' = n - z state variables)
+//       T[non-state rows] = R0^-1 (T12[:, :s'] - H12 Re(M1 Yb Ms^H) - X1 Re(Bm B22 Ms2^H))
+//     with Yb = A11w^-1 [B11w, B12w - Phi_b B22] the window part of the reference's G0^-1 [Tmat BB] (gensys.py:322-343);
+//     tests/device_models/gensys_window_model.py restates this algebra in numpy and checks it against the oracle.
+// LDS per draw at N = 52, z = 22: 48 KB (reduce), 51 KB (QZ), 70 KB (post) => 3 / 3 / 2 wavefronts per CU, each on its own
+// SIMD.  The launches hand the window over through a library-owned HBM workspace (88 KB per draw, read and written once).
+#pragma once
+#include "dsge_gensys.hpp"
+
+namespace dsge {
+
+struct GwCaps {
+  int n, lcap, wcap, zcap, scap;  // variables; max #lead; max window N - z; max z; max #state variables n - z
+};
+
+struct GwOffsets {  // per draw, in doubles
+  size_t meta, R0, H12, T12, X1, HR, TR, ZR, XR, HC, TC, MC, XC, total;
+};
+
+__host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
+  GwOffsets o;
+  size_t p = 0;
+  const size_t ww = (size_t)c.wcap * c.wcap, wl = (size_t)c.wcap * c.lcap;
+  o.meta = p, p += 8;
+  o.R0 = p, p += (size_t)c.zcap * c.zcap;
+  o.H12 = p, p += (size_t)c.zcap * c.wcap;
+  o.T12 = p, p += (size_t)c.zcap * c.scap;
+  o.X1 = p, p += (size_t)c.zcap * c.lcap;
+  o.HR = p, p += ww;
+  o.TR = p, p += ww;
+  o.ZR = p, p += ww;
+  o.XR = p, p += wl;
+  p = (p + 1) & ~(size_t)1;  // complex arrays: 16-byte aligned
+  o.HC = p, p += 2 * ww;
+  o.TC = p, p += 2 * ww;
+  o.MC = p, p += 2 * ww;
+  o.XC = p, p += 2 * wl;
+  o.total = (p + 1) & ~(size_t)1;
+  return o;
+}
+
+// meta (int32[16] at the head of a draw's workspace)
+enum { GW_N = 0, GW_ELL = 1, GW_Z = 2, GW_FLAG = 3, GW_CONV = 4, GW_NS2 = 5, GW_MASK_LO = 6, GW_MASK_HI = 7 };
+
+__host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
+  const int Ncap = c.n + c.lcap;
+  return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1) +
+          (size_t)c.wcap * (c.wcap | 1)) * 8 + 64 * 4;
+}
+__host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {
+  return ((size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
+}
+__host__ __device__ inline size_t gw_post_smem(const GwCaps& c) {
+  const size_t cplx = (size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1) + (size_t)c.lcap * (c.wcap | 1) +
+                      (size_t)c.lcap * (c.lcap | 1);
+  const size_t real = (size_t)(c.wcap + c.lcap) * (c.scap | 1) + (size_t)c.zcap * (c.scap | 1) + 128;
+  return cplx * 16 + real * 8;
+}
+
+#define GW_STAMP(k)                                                         \
+  do {                                                                     \
+    if (dbg && draw == 0 && lane == 0) dbg[k] = (long long)clock64();        \
+  } while (0)
+
+// ---- pre-pass: the shape of the batch (max #lead, max window, max / min z) ----------------------------------------
+__global__ __launch_bounds__(64) void gensys_shape_kernel(const double* __restrict__ A, const double* __restrict__ C,
+                                                           int batch, int n, double tol, int* __restrict__ out) {
+  const int lane = threadIdx.x;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    double cs = 0.0;
+    bool anz = false;
+    if (lane < n)
+      for (int i = 0; i < n; ++i) {
+        cs += fabs(C[off + (size_t)i * n + lane]);
+        anz = anz || (A[off + (size_t)i * n + lane] != 0.0);
+      }
+    const int ell = __popcll(__ballot(lane < n && cs > tol));
+    const int z = n - __popcll(__ballot(anz));
+    if (lane == 0) {
+      atomicMax(out + 0, ell);
+      atomicMax(out + 1, n - z + ell);
+      atomicMax(out + 2, z);
+      atomicMin(out + 3, z);
+    }
+  }
+}
+
+// ---- real Householder reflector built from column `col` of `src` (rows j..N-1, one row per lane) and applied from the
+// left to rows j..N-1 of H (columns h0..h0+nH-1), T (nT columns) and X (nX columns).  dlarfg conventions as in
+// householder_left (dsge_gensys.hpp).  The nH + nT + nX columns are dealt one per lane (in passes of 64); a lane walks
+// down its column with a private pointer and stride, four rows per trip and no divergent control flow, so the LDS loads
+// of a trip are in flight together (the first version -- one conditional load per matrix and row -- spent 300 cycles
+// per row).
+__device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH, double* Tr, int ldW, int nT, double* Xr,
+                                             int ldX, int nX, double* src, int ld_src, int col, int j, int N, int lane) {
+  wave_sync();
+  const double x = (lane >= j && lane < N) ? src[lane * ld_src + col] : 0.0;
+  const double xnorm2 = wave_sum_dpp((lane > j) ? x * x : 0.0);
+  if (xnorm2 == 0.0) return;
+  const double alpha = readlane_dyn_f64(x, j);
+  const double nrm = sqrt(fma(alpha, alpha, xnorm2));
+  const double beta = (alpha >= 0.0) ? -nrm : nrm;
+  const double tau = (beta - alpha) / beta;
+  const double scal = 1.0 / (alpha - beta);
+  const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
+  const int ncols = nH + nT + nX;
+  for (int c0 = 0; c0 < ncols; c0 += 64) {
+    const int c = c0 + lane;
+    const bool act = c < ncols;
+    double* base = Hr + h0;  // inactive lanes walk a valid column and store nothing
+    int ld = ldH;
+    if (act) {
+      if (c < nH) {
+        base = Hr + h0 + c;
+      } else if (c < nH + nT) {
+        base = Tr + (c - nH);
+        ld = ldW;
+      } else {
+        base = Xr + (c - nH - nT);
+        ld = ldX;
+      }
+    }
+    double* p = base + j * ld;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = j;
+    for (; r + 4 <= N; r += 4) {
+      const double m0 = p[0], m1 = p[ld], m2 = p[2 * ld], m3 = p[3 * ld];
+      a0 = fma(readlane_dyn_f64(v, r), m0, a0);
+      a1 = fma(readlane_dyn_f64(v, r + 1), m1, a1);
+      a2 = fma(readlane_dyn_f64(v, r + 2), m2, a2);
+      a3 = fma(readlane_dyn_f64(v, r + 3), m3, a3);
+      p += 4 * ld;
+    }
+    for (; r < N; ++r) {
+      a0 = fma(readlane_dyn_f64(v, r), p[0], a0);
+      p += ld;
+    }
+    const double wv = -tau * ((a0 + a1) + (a2 + a3));
+    p = base + j * ld;
+    for (r = j; r + 4 <= N; r += 4) {
+      double m0 = p[0], m1 = p[ld], m2 = p[2 * ld], m3 = p[3 * ld];
+      m0 = fma(readlane_dyn_f64(v, r), wv, m0);
+      m1 = fma(readlane_dyn_f64(v, r + 1), wv, m1);
+      m2 = fma(readlane_dyn_f64(v, r + 2), wv, m2);
+      m3 = fma(readlane_dyn_f64(v, r + 3), wv, m3);
+      if (act) {
+        p[0] = m0;
+        p[ld] = m1;
+        p[2 * ld] = m2;
+        p[3 * ld] = m3;
+      }
+      p += 4 * ld;
+    }
+    for (; r < N; ++r) {
+      const double m0 = fma(readlane_dyn_f64(v, r), wv, p[0]);
+      if (act) p[0] = m0;
+      p += ld;
+    }
+  }
+  wave_sync();
+  if (lane >= j && lane < N) src[lane * ld_src + col] = (lane == j) ? beta : 0.0;
+  wave_sync();
+}
+
+__device__ __forceinline__ void rot2r(double& x, double& y, double c, double s) {
+  const double tx = fma(c, x, s * y);
+  y = fma(c, y, -s * x);
+  x = tx;
+}
+
+// ---- launch 1: pencil, structural deflation, Hessenberg-triangular reduction of the window (all real) ------------------
+__global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                            const double* __restrict__ C, int batch, GwCaps cp,
+                                                            double tol, double* __restrict__ ws,
+                                                            long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int n = cp.n, Ncap = cp.n + cp.lcap;
+  const int ldH = Ncap | 1, ldW = cp.wcap | 1, ldX = cp.lcap | 1;
+  double* Hr = smem;
+  double* Tr = Hr + (size_t)Ncap * ldH;
+  double* Xr = Tr + (size_t)Ncap * ldW;
+  double* Zr = Xr + (size_t)Ncap * ldX;
+  int* lead = reinterpret_cast<int*>(Zr + (size_t)cp.wcap * ldW);
+  const size_t total = (size_t)Ncap * ldH + (size_t)Ncap * ldW + (size_t)Ncap * ldX + (size_t)cp.wcap * ldW;
+  const GwOffsets wo = gw_offsets(cp);
+
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    const double* Ag = A + off;
+    const double* Bg = B + off;
+    const double* Cg = C + off;
+    double* wd = ws + (size_t)draw * wo.total;
+    int* meta = reinterpret_cast<int*>(wd + wo.meta);
+    wave_sync();
+    for (size_t idx = lane; idx < total; idx += 64) smem[idx] = 0.0;
+    // lead columns (gensys.py:580-589) and the zero columns of A
+    int ell = 0;
+    unsigned long long a_colmask = 0ull;
+    {
+      double cs = 0.0;
+      bool anz = false;
+      if (lane < n)
+        for (int i = 0; i < n; ++i) {
+          cs += fabs(Cg[(size_t)i * n + lane]);
+          anz = anz || (Ag[(size_t)i * n + lane] != 0.0);
+        }
+      a_colmask = __ballot(anz);
+      const unsigned long long lm = __ballot(lane < n && cs > tol);
+      ell = __popcll(lm);
+      if (lane < n && ((lm >> lane) & 1ull)) lead[__popcll(lm & ((1ull << lane) - 1ull))] = lane;
+    }
+    const int N = n + ell;
+    const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long zmask = ~a_colmask & nmask;
+    const int z = __popcll(zmask);
+    const int w = N - z, sp = n - z;
+    const bool too_big = (ell > cp.lcap) || (w > cp.wcap) || (z > cp.zcap) || (sp > cp.scap) || (N > 64);
+    if (lane == 0) {
+      meta[GW_N] = N;
+      meta[GW_ELL] = ell;
+      meta[GW_Z] = z;
+      meta[GW_FLAG] = too_big ? 1 : 0;
+      meta[GW_CONV] = 0;
+      meta[GW_NS2] = 0;
+      meta[GW_MASK_LO] = (int)(unsigned)(a_colmask & 0xffffffffull);
+      meta[GW_MASK_HI] = (int)(unsigned)(a_colmask >> 32);
+    }
+    if (too_big) continue;
+    wave_sync();
+#define COLPOS(c) ((((c) < n) && ((zmask >> (c)) & 1ull)) ? __popcll(zmask & ((1ull << (c)) - 1ull)) \
+                                                         : (z + (c) - __popcll(zmask & (((c) >= 64) ? ~0ull : ((1ull << (c)) - 1ull)))))
+    // pencil (gensys.py:591-614) by index arithmetic; T holds columns >= z only (the others are exactly zero)
+    for (int idx = lane; idx < n * n; idx += 64) {
+      const int i = idx / n, j = idx - i * n;
+      const int pj = COLPOS(j);
+      Hr[i * ldH + pj] = -Bg[idx];
+      if (pj >= z) Tr[i * ldW + pj - z] = Ag[idx];
+    }
+    for (int idx = lane; idx < n * ell; idx += 64) {
+      const int i = idx / ell, a = idx - i * ell;
+      Hr[i * ldH + n + a] = -Cg[(size_t)i * n + lead[a]];
+    }
+    if (lane < ell) {
+      const int lc0 = lead[lane];
+      Hr[(n + lane) * ldH + COLPOS(lc0)] = 1.0;
+      Tr[(n + lane) * ldW + n + lane - z] = 1.0;
+      Xr[(n + lane) * ldX + lane] = 1.0;
+    }
+    if (lane < w) Zr[lane * ldW + lane] = 1.0;
+#undef COLPOS
+    wave_sync();
+
+    GW_STAMP(0);
+    // ---- structural deflation: QR of the z zero-columns-of-A columns of G0
+    for (int j = 0; j < z; ++j) hh_left_real(Hr, ldH, j, N - j, Tr, ldW, w, Xr, ldX, ell, Hr, ldH, j, j, N, lane);
+    // rows < z are final: R0, H12, T12[:, :s'], X1 leave the chip
+    for (int idx = lane; idx < z * z; idx += 64) {
+      const int i = idx / z, j = idx - i * z;
+      wd[wo.R0 + (size_t)i * cp.zcap + j] = Hr[i * ldH + j];
+    }
+    for (int idx = lane; idx < z * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      wd[wo.H12 + (size_t)i * cp.wcap + j] = Hr[i * ldH + z + j];
+    }
+    for (int idx = lane; idx < z * sp; idx += 64) {
+      const int i = idx / sp, j = idx - i * sp;
+      wd[wo.T12 + (size_t)i * cp.scap + j] = Tr[i * ldW + j];
+    }
+    for (int idx = lane; idx < z * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      wd[wo.X1 + (size_t)i * cp.lcap + j] = Xr[i * ldX + j];
+    }
+    GW_STAMP(1);
+    // ---- window: T22 -> upper triangular (reflectors on rows >= z)
+    for (int j = 0; j < w - 1; ++j) hh_left_real(Hr, ldH, z, w, Tr, ldW, w, Xr, ldX, ell, Tr, ldW, j, z + j, N, lane);
+    GW_STAMP(2);
+    // ---- window: H22 -> upper Hessenberg by Givens pairs (column j prefetched, pivots travel through registers)
+    double* hb = Hr + (size_t)z * ldH + z;
+    double* tb = Tr + (size_t)z * ldW;
+    double* xb = Xr + (size_t)z * ldX;
+    const bool wa = lane < w, xa = lane < ell;
+    for (int j = 0; j < w - 2; ++j) {
+      wave_sync();
+      const double colv = wa ? hb[lane * ldH + j] : 0.0;
+      double g = readlane_dyn_f64(colv, w - 1);
+      for (int i = w - 1; i > j + 1; --i) {
+        const double f = readlane_dyn_f64(colv, i - 1);
+        if (g == 0.0) {
+          g = f;
+          continue;
+        }
+        wave_sync();
+        double hx = 0.0, hy = 0.0, tx = 0.0, ty = 0.0, ax = 0.0, ay = 0.0;
+        if (wa) {
+          hx = hb[(i - 1) * ldH + lane];
+          hy = hb[i * ldH + lane];
+          tx = tb[(i - 1) * ldW + lane];
+          ty = tb[i * ldW + lane];
+        }
+        if (xa) {
+          ax = xb[(i - 1) * ldX + lane];
+          ay = xb[i * ldX + lane];
+        }
+        double c, s, r;
+        lartg_real(f, g, c, s, r);
+        rot2r(hx, hy, c, s);
+        rot2r(tx, ty, c, s);
+        rot2r(ax, ay, c, s);
+        if (lane == j) {
+          hx = r;
+          hy = 0.0;
+        }
+        if (wa) {
+          hb[(i - 1) * ldH + lane] = hx;
+          hb[i * ldH + lane] = hy;
+          tb[(i - 1) * ldW + lane] = tx;
+          tb[i * ldW + lane] = ty;
+        }
+        if (xa) {
+          xb[(i - 1) * ldX + lane] = ax;
+          xb[i * ldX + lane] = ay;
+        }
+        g = r;
+        const double tii = readlane_dyn_f64(ty, i), tim = readlane_dyn_f64(ty, i - 1);
+        if (tim != 0.0) {
+          wave_sync();
+          double qx = 0.0, qy = 0.0;
+          if (wa) {
+            hx = hb[lane * ldH + i];
+            hy = hb[lane * ldH + i - 1];
+            tx = tb[lane * ldW + i];
+            ty = tb[lane * ldW + i - 1];
+            qx = Zr[lane * ldW + i];
+            qy = Zr[lane * ldW + i - 1];
+          }
+          double r2;
+          lartg_real(tii, tim, c, s, r2);
+          rot2r(hx, hy, c, s);
+          rot2r(tx, ty, c, s);
+          rot2r(qx, qy, c, s);
+          if (lane == i) {
+            tx = r2;
+            ty = 0.0;
+          }
+          if (wa) {
+            hb[lane * ldH + i] = hx;
+            hb[lane * ldH + i - 1] = hy;
+            tb[lane * ldW + i] = tx;
+            tb[lane * ldW + i - 1] = ty;
+            Zr[lane * ldW + i] = qx;
+            Zr[lane * ldW + i - 1] = qy;
+          }
+        }
+      }
+    }
+    wave_sync();
+    GW_STAMP(3);
+    for (int idx = lane; idx < w * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      const size_t o = (size_t)i * cp.wcap + j;
+      wd[wo.HR + o] = hb[i * ldH + j];
+      wd[wo.TR + o] = tb[i * ldW + j];
+      wd[wo.ZR + o] = Zr[i * ldW + j];
+    }
+    for (int idx = lane; idx < w * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      wd[wo.XR + (size_t)i * cp.lcap + j] = xb[i * ldX + j];
+    }
+    GW_STAMP(4);
+  }
+}
+
+// ---- launch 2: complex single-shift QZ + reordering on the window (qz_iterate / reorder_stable_first of dsge_gensys.hpp
+// with N := w, ilo := 0; "Ztop" := the accumulated right transformation M, started from the real phase's Zr) -----------
+__global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, double tol, double* __restrict__ ws,
+                                                           long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  GsLayout L;
+  L.ldh = cp.wcap | 1;
+  L.ldx = cp.lcap | 1;
+  L.ldz = L.ldh;
+  L.H = reinterpret_cast<cx*>(smem);
+  L.T = L.H + (size_t)cp.wcap * L.ldh;
+  L.Z = L.T + (size_t)cp.wcap * L.ldh;
+  L.X = L.Z + (size_t)cp.wcap * L.ldh;
+  L.V1 = L.V2 = L.S3 = nullptr;
+  L.s1 = L.s2 = nullptr;
+  L.lead = nullptr;
+  const double rs = (tol > 0.0) ? tol : 2.220446049250313e-16;
+  const GwOffsets wo = gw_offsets(cp);
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    double* wd = ws + (size_t)draw * wo.total;
+    int* meta = reinterpret_cast<int*>(wd + wo.meta);
+    if (meta[GW_FLAG] != 0) continue;
+    const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
+    L.N = w;
+    L.n = w;
+    L.ell = ell;
+    wave_sync();
+    for (int idx = lane; idx < w * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      const size_t o = (size_t)i * cp.wcap + j;
+      L.H[i * L.ldh + j] = mk(wd[wo.HR + o], 0.0);
+      L.T[i * L.ldh + j] = mk(wd[wo.TR + o], 0.0);
+      L.Z[i * L.ldz + j] = mk(wd[wo.ZR + o], 0.0);
+    }
+    for (int idx = lane; idx < w * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      L.X[i * L.ldx + j] = mk(wd[wo.XR + (size_t)i * cp.lcap + j], 0.0);
+    }
+    wave_sync();
+    GW_STAMP(8);
+    const bool converged = qz_iterate(L, 0, lane, (dbg && draw == 0) ? dbg + 12 : nullptr);
+    GW_STAMP(9);
+    const int ns2 = converged ? reorder_stable_first(L, rs, lane) : 0;
+    wave_sync();
+    GW_STAMP(10);
+    cx* HC = reinterpret_cast<cx*>(wd + wo.HC);
+    cx* TC = reinterpret_cast<cx*>(wd + wo.TC);
+    cx* MC = reinterpret_cast<cx*>(wd + wo.MC);
+    cx* XC = reinterpret_cast<cx*>(wd + wo.XC);
+    for (int idx = lane; idx < w * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      const size_t o = (size_t)i * cp.wcap + j;
+      HC[o] = L.H[i * L.ldh + j];
+      TC[o] = L.T[i * L.ldh + j];
+      MC[o] = L.Z[i * L.ldz + j];
+    }
+    for (int idx = lane; idx < w * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      XC[(size_t)i * cp.lcap + j] = L.X[i * L.ldx + j];
+    }
+    if (lane == 0) {
+      meta[GW_CONV] = converged ? 1 : 0;
+      meta[GW_NS2] = ns2;
+    }
+    GW_STAMP(11);
+  }
+}
+
+// ---- one-sided Jacobi SVD with a round-robin (tournament) ordering: the nc/2 disjoint column pairs of a round are
+// rotated at the same time, `lpp` lanes per pair (each lane owns the rows sub, sub + lpp, ... of G and V), the three inner
+// products are reduced inside the lane group by DPP butterflies.  Same rotation formula, threshold and stopping rule as
+// jacobi_svd (dsge_gensys.hpp), which visits the pairs one after the other with four wave-wide sums each; the singular
+// values / vectors agree up to order and rounding.  G: nr x nc (row-major, ld ldg), V: nc x nc accumulates the right
+// transformation, sig[j] = ||column j|| on exit.
+template <int STEP>
+__device__ __forceinline__ double group_xor_sum(double v) {
+  if constexpr (STEP == 1) return v + dpp_move_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  if constexpr (STEP == 2) return v + dpp_move_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  if constexpr (STEP == 4) return v + dpp_move_f64<0x141, 0xf>(v);  // row_half_mirror (quads already uniform)
+  if constexpr (STEP == 8) return v + dpp_move_f64<0x140, 0xf>(v);  // row_mirror (halves already uniform)
+  return v + __shfl_xor(v, STEP, 64);
+}
+__device__ __forceinline__ double group_sum(double v, int lpp) {
+  if (lpp > 1) v = group_xor_sum<1>(v);
+  if (lpp > 2) v = group_xor_sum<2>(v);
+  if (lpp > 4) v = group_xor_sum<4>(v);
+  if (lpp > 8) v = group_xor_sum<8>(v);
+  if (lpp > 16) v = group_xor_sum<16>(v);
+  if (lpp > 32) v = group_xor_sum<32>(v);
+  return v;
+}
+
+__device__ __forceinline__ void jacobi_svd_rr(cx* G, int ldg, int nr, int nc, cx* V, int ldv, double* sig, int lane) {
+  for (int idx = lane; idx < nc * nc; idx += 64) {
+    const int i = idx / nc, j = idx - i * nc;
+    V[i * ldv + j] = mk(i == j ? 1.0 : 0.0, 0.0);
+  }
+  wave_sync();
+  const int ncp = nc + (nc & 1), npairs = ncp >> 1;
+  if (nc >= 2) {
+    int lpp = 1;
+    while (2 * lpp * npairs <= 64) lpp *= 2;
+    const int pid = lane / lpp, sub = lane - pid * lpp;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      bool rotated = false;
+      for (int t = 0; t < ncp - 1; ++t) {
+        // round t of the tournament: pair 0 = (ncp-1, t); pair k = ((t+k) mod (ncp-1), (t-k) mod (ncp-1))
+        int p = 0, q = 0;
+        bool act = pid < npairs;
+        if (act) {
+          if (pid == 0) {
+            p = t;
+            q = ncp - 1;
+          } else {
+            p = (t + pid) % (ncp - 1);
+            q = (t + (ncp - 1) - pid) % (ncp - 1);
+            if (p > q) {
+              const int tmp = p;
+              p = q;
+              q = tmp;
+            }
+          }
+          act = q < nc;  // the padding column of an odd nc sits out
+        }
+        double al = 0.0, be = 0.0, gr = 0.0, gi = 0.0;
+        if (act)
+          for (int row = sub; row < nr; row += lpp) {
+            const cx gp = G[row * ldg + p], gq = G[row * ldg + q];
+            al += gp.re * gp.re + gp.im * gp.im;
+            be += gq.re * gq.re + gq.im * gq.im;
+            gr += gp.re * gq.re + gp.im * gq.im;  // conj(gp) * gq
+            gi += gp.re * gq.im - gp.im * gq.re;
+          }
+        al = group_sum(al, lpp);
+        be = group_sum(be, lpp);
+        gr = group_sum(gr, lpp);
+        gi = group_sum(gi, lpp);
+        const double ag2 = fma(gr, gr, gi * gi);
+        const bool rot = act && !(ag2 < 1e-290 || ag2 <= 1e-30 * al * be);
+        if (__ballot(rot) != 0ull) rotated = true;
+        if (rot) {
+          const double inv_ag = fast_rsqrt(ag2);
+          const cx phc = mk(gr * inv_ag, -gi * inv_ag);  // conj(phase)
+          const double zeta = 0.5 * (be - al) * inv_ag;
+          const double z2 = fma(zeta, zeta, 1.0);
+          double tt;
+          if (z2 < 1e280) {
+            const double root = z2 * fast_rsqrt(z2);
+            tt = ((zeta >= 0.0) ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + root);
+          } else {
+            tt = 0.5 / zeta;
+          }
+          const double cs = fast_rsqrt(fma(tt, tt, 1.0)), sn = cs * tt;
+          for (int row = sub; row < nr; row += lpp) {
+            const cx gp = G[row * ldg + p], gq = G[row * ldg + q] * phc;
+            G[row * ldg + p] = cs * gp - sn * gq;
+            G[row * ldg + q] = sn * gp + cs * gq;
+          }
+          for (int row = sub; row < nc; row += lpp) {
+            const cx gp = V[row * ldv + p], gq = V[row * ldv + q] * phc;
+            V[row * ldv + p] = cs * gp - sn * gq;
+            V[row * ldv + q] = sn * gp + cs * gq;
+          }
+        }
+        wave_sync();
+      }
+      if (!rotated) break;
+    }
+  }
+  // column norms: one column per lane group would need another reduction tree; nc wave sums are cheap enough
+  for (int j = 0; j < nc; ++j) {
+    double al = 0.0;
+    for (int row = lane; row < nr; row += 64) {
+      const cx gp = G[row * ldg + j];
+      al += gp.re * gp.re + gp.im * gp.im;
+    }
+    al = wave_sum_dpp(al);
+    if (lane == 0) sig[j] = sqrt(al);
+  }
+  wave_sync();
+}
+
+// ---- launch 3: existence / uniqueness (gensys.py:267-310) and T in the window basis ---------------------------------------
+__global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
+                                                          double* __restrict__ T_out, int32_t* __restrict__ eu_out,
+                                                          int32_t* __restrict__ status, long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int n = cp.n;
+  const int ldh = cp.wcap | 1, ldx = cp.lcap | 1, lds_ = cp.scap | 1;
+  cx* Hc = reinterpret_cast<cx*>(smem);
+  cx* Tc = Hc + (size_t)cp.wcap * ldh;
+  cx* Mc = Tc + (size_t)cp.wcap * ldh;
+  cx* Xc = Mc + (size_t)cp.wcap * ldh;
+  cx* Bm = Xc + (size_t)cp.wcap * ldx;   // lcap x ldh
+  cx* V2 = Bm + (size_t)cp.lcap * ldh;   // lcap x ldx
+  double* RR = reinterpret_cast<double*>(V2 + (size_t)cp.lcap * ldx);  // (wcap + lcap) x lds_: [Re(M1 Yb Ms^H); Re(Bm B22 Ms2^H)]
+  double* E = RR + (size_t)(cp.wcap + cp.lcap) * lds_;                // zcap x lds_
+  double* s1 = E + (size_t)cp.zcap * lds_;
+  double* s2 = s1 + 64;
+  const double rs = (tol > 0.0) ? tol : 2.220446049250313e-16;
+  const GwOffsets wo = gw_offsets(cp);
+#define PH(i, j) Hc[(i)*ldh + (j)]
+#define PT(i, j) Tc[(i)*ldh + (j)]
+#define PM(i, j) Mc[(i)*ldh + (j)]
+#define PX(i, j) Xc[(i)*ldx + (j)]
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    const double* wd = ws + (size_t)draw * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    int eu0 = 0, eu1 = 0, eu2 = 0, st_extra = 0;
+    bool have_T = false;
+    wave_sync();
+    GW_STAMP(16);
+    if (meta[GW_FLAG] != 0) {
+      eu0 = eu1 = -3;
+      st_extra = DSGE_ST_GENSYS_TOO_BIG;
+    } else if (meta[GW_CONV] == 0) {
+      eu0 = eu1 = -3;
+      st_extra = DSGE_ST_GENSYS_QZ_FAIL;
+    } else {
+      const int N = meta[GW_N], ell = meta[GW_ELL], z = meta[GW_Z], ns2 = meta[GW_NS2];
+      const int w = N - z, sp = n - z, nu = w - ns2;
+      const unsigned long long a_colmask =
+          (unsigned long long)(unsigned)meta[GW_MASK_LO] | ((unsigned long long)(unsigned)meta[GW_MASK_HI] << 32);
+      const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+      const unsigned long long zmask = ~a_colmask & nmask;
+      const cx* HC = reinterpret_cast<const cx*>(wd + wo.HC);
+      const cx* TC = reinterpret_cast<const cx*>(wd + wo.TC);
+      const cx* MC = reinterpret_cast<const cx*>(wd + wo.MC);
+      const cx* XC = reinterpret_cast<const cx*>(wd + wo.XC);
+      const double* R0 = wd + wo.R0;
+      const double* H12 = wd + wo.H12;
+      const double* T12 = wd + wo.T12;
+      const double* X1 = wd + wo.X1;
+      for (int idx = lane; idx < w * w; idx += 64) {
+        const int i = idx / w, j = idx - i * w;
+        const size_t o = (size_t)i * cp.wcap + j;
+        PH(i, j) = HC[o];
+        PT(i, j) = TC[o];
+        PM(i, j) = MC[o];
+      }
+      for (int idx = lane; idx < w * ell; idx += 64) {
+        const int i = idx / ell, j = idx - i * ell;
+        PX(i, j) = XC[(size_t)i * cp.lcap + j];
+      }
+      wave_sync();
+      GW_STAMP(17);
+      // coincident zeros (gensys.py:243-244): deflated roots have beta = 0
+      const bool zz0 = (lane < z) && (fabs(R0[(size_t)lane * cp.zcap + lane]) < rs);
+      const bool zz1 = (lane < w) && (cabs_(PH(lane, lane)) < rs) && (cabs_(PT(lane, lane)) < rs);
+      if (__ballot(zz0 || zz1) != 0ull) {
+        eu0 = eu1 = -2;
+      } else {
+        int r2 = 0, r1 = 0;
+        if (nu > 0) {
+          jacobi_svd_rr(&PX(ns2, 0), ldx, nu, ell, V2, ldx, s2, lane);
+          for (int j = 0; j < ell; ++j) r2 += (s2[j] > rs) ? 1 : 0;
+        } else {
+          if (lane < ell) s2[lane] = 0.0;
+          for (int idx = lane; idx < ell * ell; idx += 64) {
+            const int i = idx / ell, j = idx - i * ell;
+            V2[i * ldx + j] = mk(i == j ? 1.0 : 0.0, 0.0);
+          }
+          wave_sync();
+        }
+        if (r2 >= nu) eu0 = 1;
+        GW_STAMP(18);
+        // s1_j = || eta1 v_j ||, eta1 = [X1; X2[:ns2]] (CS decomposition argument of dsge_gensys.hpp)
+        for (int j = 0; j < ell; ++j) {
+          cx g = mk(0, 0), g0 = mk(0, 0);
+          if (lane < ns2)
+            for (int cc = 0; cc < ell; ++cc) g = g + PX(lane, cc) * V2[cc * ldx + j];
+          if (lane < z)
+            for (int cc = 0; cc < ell; ++cc) g0 = g0 + X1[(size_t)lane * cp.lcap + cc] * V2[cc * ldx + j];
+          const double sq = wave_sum_dpp(fma(g.re, g.re, g.im * g.im) + fma(g0.re, g0.re, g0.im * g0.im));
+          if (lane == 0) s1[j] = sqrt(sq);
+        }
+        wave_sync();
+        int n_loose = 0;
+        for (int j = 0; j < ell; ++j) {
+          const bool k1 = s1[j] > rs, k2 = s2[j] > rs;
+          r1 += k1 ? 1 : 0;
+          n_loose += (k1 && !k2) ? 1 : 0;
+        }
+        bool unique = true;
+        if (r1 > 0) {
+          eu2 = n_loose;
+          unique = (n_loose == 0);
+        }
+        if (unique) eu1 = 1;
+
+        // Bm = V2 diag(w_j) G2^H (ell x nu), w_j = [s1_j > rs][s2_j > rs] / s2_j^2
+        for (int idx = lane; idx < ell * nu; idx += 64) {
+          const int cc = idx / nu, u = idx - cc * nu;
+          cx acc = mk(0, 0);
+          for (int j = 0; j < ell; ++j) {
+            if (!(s1[j] > rs && s2[j] > rs)) continue;
+            const double wj = 1.0 / (s2[j] * s2[j]);
+            acc = acc + V2[cc * ldx + j] * (wj * conj(PX(ns2 + u, j)));
+          }
+          Bm[cc * ldh + u] = acc;
+        }
+        wave_sync();
+        // Phi_b = X2[:ns2] Bm (ns2 x nu) in the free lower-left block of H: Phi_b[i][u] at H[ns2 + u][i]
+        for (int idx = lane; idx < ns2 * nu; idx += 64) {
+          const int i = idx / nu, u = idx - i * nu;
+          cx acc = mk(0, 0);
+          for (int cc = 0; cc < ell; ++cc) acc = acc + PX(i, cc) * Bm[cc * ldh + u];
+          PH(ns2 + u, i) = acc;
+        }
+        wave_sync();
+        // rhs = [B11, B12 - Phi_b B22] in place in T[:ns2, :]
+        for (int idx = lane; idx < ns2 * nu; idx += 64) {
+          const int i = idx / nu, cc = idx - i * nu;
+          cx acc = PT(i, ns2 + cc);
+          for (int u = 0; u <= cc; ++u) acc = acc - PH(ns2 + u, i) * PT(ns2 + u, ns2 + cc);
+          PT(i, ns2 + cc) = acc;
+        }
+        wave_sync();
+        GW_STAMP(19);
+        // Yb = A11w^-1 rhs by back-substitution, one column per lane
+        if (lane < w) {
+          for (int i = ns2 - 1; i >= 0; --i) {
+            cx acc = PT(i, lane);
+            for (int k2 = i + 1; k2 < ns2; ++k2) acc = acc - PH(i, k2) * PT(k2, lane);
+            PT(i, lane) = cdiv(acc, PH(i, i));
+          }
+        }
+        wave_sync();
+        GW_STAMP(20);
+        // Wb = Yb Ms^H (ns2 x s') into H[:ns2, :s'];  BB = B22 Ms2^H (nu x s') into H[ns2:, :s']
+        for (int idx = lane; idx < ns2 * sp; idx += 64) {
+          const int i = idx / sp, cc = idx - i * sp;
+          cx acc = mk(0, 0);
+          for (int k2 = 0; k2 < w; ++k2) acc = acc + PT(i, k2) * conj(PM(cc, k2));
+          PH(i, cc) = acc;
+        }
+        for (int idx = lane; idx < nu * sp; idx += 64) {
+          const int u = idx / sp, cc = idx - u * sp;
+          cx acc = mk(0, 0);
+          for (int v = u; v < nu; ++v) acc = acc + PT(ns2 + u, ns2 + v) * conj(PM(cc, ns2 + v));
+          PH(ns2 + u, cc) = acc;
+        }
+        wave_sync();
+        // RR = [Re(M[:, :ns2] Wb); Re(Bm BB)]  ((w + ell) x s', real)
+        for (int idx = lane; idx < w * sp; idx += 64) {
+          const int r = idx / sp, cc = idx - r * sp;
+          double acc = 0.0;
+          for (int i = 0; i < ns2; ++i) {
+            const cx a = PM(r, i), b = PH(i, cc);
+            acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
+          }
+          RR[r * lds_ + cc] = acc;
+        }
+        for (int idx = lane; idx < ell * sp; idx += 64) {
+          const int a0 = idx / sp, cc = idx - a0 * sp;
+          double acc = 0.0;
+          for (int u = 0; u < nu; ++u) {
+            const cx a = Bm[a0 * ldh + u], b = PH(ns2 + u, cc);
+            acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
+          }
+          RR[(w + a0) * lds_ + cc] = acc;
+        }
+        wave_sync();
+        GW_STAMP(21);
+        // non-state rows: E = T12[:, :s'] - [H12 | X1] RR, then R0^-1 E by back-substitution (one column per lane)
+        for (int idx = lane; idx < z * sp; idx += 64) {
+          const int p = idx / sp, cc = idx - p * sp;
+          double acc = T12[(size_t)p * cp.scap + cc];
+          for (int k2 = 0; k2 < w; ++k2) acc = fma(-H12[(size_t)p * cp.wcap + k2], RR[k2 * lds_ + cc], acc);
+          for (int a0 = 0; a0 < ell; ++a0) acc = fma(-X1[(size_t)p * cp.lcap + a0], RR[(w + a0) * lds_ + cc], acc);
+          E[p * lds_ + cc] = acc;
+        }
+        wave_sync();
+        if (lane < sp) {
+          for (int p = z - 1; p >= 0; --p) {
+            double acc = E[p * lds_ + lane];
+            for (int q = p + 1; q < z; ++q) acc = fma(-R0[(size_t)p * cp.zcap + q], E[q * lds_ + lane], acc);
+            E[p * lds_ + lane] = acc / R0[(size_t)p * cp.zcap + p];
+          }
+        }
+        wave_sync();
+        GW_STAMP(22);
+        // T in the caller's variable order; columns of non-state variables are exact zeros (see dsge_gensys.hpp)
+        for (int idx = lane; idx < n * n; idx += 64) {
+          const int v = idx / n, c = idx - v * n;
+          const unsigned long long bc_ = 1ull << c, bv = 1ull << v;
+          double val = 0.0;
+          if (!(zmask & bc_)) {
+            const int jc = c - __popcll(zmask & (bc_ - 1ull));  // index among the state variables
+            if (zmask & bv)
+              val = E[__popcll(zmask & (bv - 1ull)) * lds_ + jc];
+            else
+              val = RR[(v - __popcll(zmask & (bv - 1ull))) * lds_ + jc];
+          }
+          T_out[off + idx] = val;
+        }
+        have_T = true;
+        GW_STAMP(23);
+      }
+    }
+    if (!have_T)
+      for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+    if (lane == 0) {
+      eu_out[3 * draw] = eu0;
+      eu_out[3 * draw + 1] = eu1;
+      eu_out[3 * draw + 2] = eu2;
+      status[draw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | st_extra);
+    }
+  }
+#undef GW_STAMP
+#undef PH
+#undef PT
+#undef PM
+#undef PX
+}
+
+}  // namespace dsge

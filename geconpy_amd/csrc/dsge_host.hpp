@@ -90,6 +90,8 @@ extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-red
 extern long long* g_kalman_dbg;       // debug: device buffer for per-phase cycles of draw 0
 extern double g_kalman_steady_tol;    // steady-state switch (0 = never switch)
 extern int g_kalman_mfma;             // launch_kalman.hip: 0 = VALU products only
+extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[24])
+extern int g_gensys_split;           // launch_gensys.hip: 1 = window path (three launches), 0 = single-launch kernel
 extern int g_kalman_tiny;             // 0 = never use the thread-per-draw small-model kernel
 extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first steady step per draw (-1 = never)
 

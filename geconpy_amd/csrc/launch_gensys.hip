@@ -1,8 +1,88 @@
 // Launcher of the gensys (ordered QZ) kernel.
 #include "dsge_host.hpp"
 #include "dsge_gensys.hpp"
+#include "dsge_gensys_win.hpp"
 
 namespace dsge_host {
+
+long long* g_gensys_win_dbg = nullptr;  // debug: device int64[24], phase stamps of draw 0 of the window kernels
+int g_gensys_split = 1;  // 1 = three launches on the active window (dsge_gensys_win.hpp), 0 = the single-launch kernel
+
+namespace {
+struct GwArena {
+  void* ptr = nullptr;
+  size_t cap = 0;
+};
+GwArena g_gw_arena[16];
+constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
+
+int gw_reserve(size_t bytes, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
+  GwArena& a = g_gw_arena[dev];
+  if (a.cap < bytes) {
+    if (a.ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a.ptr));
+      a.ptr = nullptr;
+      a.cap = 0;
+    }
+    HIP_TRY(hipMalloc(&a.ptr, bytes));
+    a.cap = bytes;
+  }
+  *out = a.ptr;
+  return DSGE_SUCCESS;
+}
+
+// window path; *used = 0 when the batch does not fit it (the caller then takes the single-launch kernel)
+int launch_gensys_split(const double* A, const double* B, const double* C, int batch, int n, double tol, double* T_out,
+                        int32_t* eu_out, int32_t* status, hipStream_t st, int* used) {
+  *used = 0;
+  void* base = nullptr;
+  int rc = gw_reserve(256, &base);
+  if (rc) return rc;
+  int* shape_d = (int*)base;  // the first 256 bytes of the arena hold the shape record
+  int shape[4] = {0, 0, 0, n};
+  HIP_TRY(hipMemcpyAsync(shape_d, shape, sizeof(shape), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(dsge::gensys_shape_kernel, dim3(batch < 4096 ? batch : 4096), dim3(64), 0, st, A, C, batch, n, tol,
+                     shape_d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(shape, shape_d, sizeof(shape), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  dsge::GwCaps cp;
+  cp.n = n;
+  cp.lcap = shape[0] < 1 ? 1 : shape[0];
+  cp.wcap = shape[1] < 1 ? 1 : shape[1];
+  cp.zcap = shape[2] < 1 ? 1 : shape[2];
+  cp.scap = (n - shape[3]) < 1 ? 1 : (n - shape[3]);
+  if (n + cp.lcap > DSGE_MAX_N_GENSYS) return DSGE_SUCCESS;
+  const size_t lds1 = dsge::gw_reduce_smem(cp), lds2 = dsge::gw_qz_smem(cp), lds3 = dsge::gw_post_smem(cp);
+  if (lds1 > LDS_LIMIT || lds2 > LDS_LIMIT || lds3 > LDS_LIMIT) return DSGE_SUCCESS;
+  const dsge::GwOffsets wo = dsge::gw_offsets(cp);
+  const size_t per_draw = wo.total * sizeof(double);
+  size_t chunk = GW_WORKSPACE_LIMIT / per_draw;
+  if (chunk < 256) chunk = 256;
+  if (chunk > (size_t)batch) chunk = (size_t)batch;
+  if ((rc = gw_reserve(256 + chunk * per_draw, &base))) return rc;
+  double* wsp = (double*)((char*)base + 256);
+  if ((rc = set_lds(dsge::gensys_reduce_kernel, lds1))) return rc;
+  if ((rc = set_lds(dsge::gensys_qzwin_kernel, lds2))) return rc;
+  if ((rc = set_lds(dsge::gensys_post_kernel, lds3))) return rc;
+  const size_t nn = (size_t)n * n;
+  for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
+    const int nb = (int)((c0 + chunk <= (size_t)batch) ? chunk : (size_t)batch - c0);
+    hipLaunchKernelGGL(dsge::gensys_reduce_kernel, dim3(nb), dim3(64), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
+                       cp, tol, wsp, g_gensys_win_dbg);
+    hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg);
+    hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(64), lds3, st, nb, cp, tol, (const double*)wsp,
+                       T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg);
+    HIP_TRY(hipGetLastError());
+  }
+  *used = 1;
+  return DSGE_SUCCESS;
+}
+}  // namespace
 
 // choose the on-chip pencil capacity (n_cap = n + l_cap) for gensys
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {
@@ -21,8 +101,14 @@ int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {
 
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg) {
+  int rc;
+  if (g_gensys_split && !dbg) {
+    int used = 0;
+    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used))) return rc;
+    if (used) return DSGE_SUCCESS;
+  }
   int n_cap = 0, l_cap = 0;
-  int rc = gensys_caps(n, n_lead_hint, &n_cap, &l_cap);
+  rc = gensys_caps(n, n_lead_hint, &n_cap, &l_cap);
   if (rc) return rc;
   const size_t lds = dsge::gensys_smem_bytes(n, n_cap, l_cap);
   if ((rc = set_lds(dsge::gensys_kernel, lds))) return rc;

@@ -155,6 +155,10 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
+/* gensys runs as three launches on the active window of the pencil (real reduction, complex QZ + reordering on the
+ * (N - z) x (N - z) block left after the structural deflation, post-processing; 3 / 3 / 2 draws per CU instead of 1 at
+ * N = 52) when the batch fits; enable = 0 forces the single-launch kernel (tests compare both).  Process-wide. */
+int dsge_set_gensys_split(int enable);
 /* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
  * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
  * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
@@ -177,6 +181,10 @@ int dsge_debug_kalman_phases(int enable, long long* cycles_out);
 int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, int batch, int n, double tol,
                              int n_lead_hint, double* T_out, int32_t* eu_out, int32_t* status,
                              long long* cycles_out);
+/* Debug hook of the window path: enable = 1 arms the stamp buffer (draw 0 of each launch: reduce [0..4] = start, deflation,
+ * triangular T22, Hessenberg H22, stored; QZ [8..11] = start, QZ, reordering, stored; post [16..23] = start, loaded, SVD,
+ * eu + Phi + rhs, back-substitution, products, non-state rows, T written); cycles_out: host int64[24] or NULL. */
+int dsge_debug_gensys_window_phases(int enable, long long* cycles_out);
 
 /*
  * Shock-impact matrix and policy residual.  Replaces pt_compute_selection_matrix

@@ -114,3 +114,27 @@ def test_kalman_downdate_model_equals_joseph_oracle():
         r = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], Q, om["Z"], y, H=np.diag(om["Hdiag"]))
         lp = kalman_downdate_logp(y, r["T"], r["R"], Q, om["Z"], om["Hdiag"], np.zeros(7), r["P0"])
         assert_allclose(lp, r["logp"], rtol=1e-12)
+
+
+def test_window_gensys_algebra(ref_goldens, failure_golden):
+    """Post-processing identity of the three-launch gensys path (dsge_gensys_win.hpp) against the reference outputs:
+    goldens, SW-shaped draws, and the non-unique / no-solution systems (T is still G1[:n,:n] there)."""
+    from tests.device_models.gensys_window_model import window_gensys
+    from geconpy_amd import workloads as wl
+
+    for key in ("one_block", "rbc_2_block", "full_nk"):
+        A, B, C = (ref_goldens[f"{key}_{x}"] for x in "ABC")
+        T, eu = window_gensys(A, B, C)
+        assert eu == [1, 1, 0]
+        assert_allclose(T, ref_goldens[f"{key}_ref_gensys_T"], atol=1e-10)
+    for name in ("ok", "nonunique", "noexist"):
+        A, B, C = (failure_golden[f"{name}_{x}"] for x in "ABC")
+        T, eu = window_gensys(A, B, C)
+        assert eu == list(failure_golden[f"{name}_ref_gensys_eu"])
+        assert_allclose(T, failure_golden[f"{name}_ref_gensys_T"], atol=1e-10)
+    b = wl.sw_shaped_batch(3)
+    for i in range(3):
+        T, eu = window_gensys(b["A"][i], b["B"][i], b["C"][i])
+        T_ref, ok, _ = oracle.gensys_T_success(b["A"][i], b["B"][i], b["C"][i], b["D"][i], tol=1e-8)
+        assert ok and eu == [1, 1, 0]
+        assert_allclose(T, T_ref, atol=1e-11)

@@ -390,6 +390,13 @@ def test_gensys_capacity_flag():
     silently wrong."""
     b = wl.sw_shaped_batch(2)
     out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5)
+    assert np.all(out["status"] == 0)  # the window path measures the batch itself and ignores the hint
+    lib = _lib.load()
+    _lib.check(lib.dsge_set_gensys_split(0))
+    try:
+        out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5)
+    finally:
+        _lib.check(lib.dsge_set_gensys_split(1))
     assert np.all(out["status"] & _lib.ST_GENSYS_TOO_BIG) and np.all(out["eu"][:, 0] == -3) and np.all(out["T"] == 0)
 
 
@@ -1013,3 +1020,38 @@ def test_kalman_mfma_products_match_valu():
         for i in (0, 4):
             ref = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(H), d=d)
             assert_allclose(logp1[i], ref, rtol=LOGP_RTOL)
+
+
+def test_gensys_window_path_matches_single_launch(ref_goldens, failure_golden):
+    """gensys as three launches on the active window (dsge_gensys_win.hpp) vs the single-launch kernel: same eu and status
+    everywhere, T to 1e-10 on the goldens, the failure systems (non-unique / no solution / coincident zeros: the
+    reference still returns G1 there) and SW-shaped draws; both against the oracle."""
+    lib = _lib.load()
+    sets = []
+    for key in ("one_block", "rbc_2_block", "full_nk"):
+        sets.append(tuple(ref_goldens[f"{key}_{x}"][None] for x in "ABCD"))
+    names = ["ok", "nonunique", "noexist", "coincident"]
+    sets.append(tuple(np.stack([failure_golden[f"{nm}_{x}"] for nm in names]) for x in "ABCD"))
+    b = wl.sw_shaped_batch(96)
+    sets.append(tuple(b[x] for x in "ABCD"))
+    # a mixed batch: structures differ per draw (one draw with a dense A => z = 0 for the caps)
+    rng = np.random.default_rng(5)
+    A2, B2, C2, D2 = (b[x][:6].copy() for x in "ABCD")
+    A2[3] += 1e-3 * rng.standard_normal(A2[3].shape)
+    sets.append((A2, B2, C2, D2))
+    for A, B, C, D in sets:
+        out1 = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        _lib.check(lib.dsge_set_gensys_split(0))
+        try:
+            out0 = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        finally:
+            _lib.check(lib.dsge_set_gensys_split(1))
+        assert np.array_equal(out1["eu"], out0["eu"]), (out1["eu"], out0["eu"])
+        assert np.array_equal(out1["status"], out0["status"])
+        scale = max(1.0, np.abs(out0["T"]).max())
+        assert_allclose(out1["T"], out0["T"], atol=1e-10 * scale)
+        for i in range(min(A.shape[0], 4)):
+            T_ref, ok, _eu = oracle.gensys_T_success(A[i], B[i], C[i], D[i], tol=1e-8)
+            if out1["eu"][i][0] > -2:
+                assert_allclose(out1["T"][i], T_ref, atol=1e-8)
+            assert bool(ok) == bool(out1["status"][i] == 0)
