@@ -109,7 +109,20 @@ struct GsLayout {
   cx *H, *T, *X, *Z, *V1, *V2, *S3;
   double *s1, *s2;
   int* lead;
+  // Storage map of H and T.  Plain: two N x ldh arrays (hoff = 0, tsi = ldh, tsj = 1).  Packed (QZ window kernel only,
+  // where H is upper Hessenberg and T upper triangular from the start): ONE N x ldh array, ldh >= N + 4, holding
+  // H(i, j) at [i][j + 4] and T(i, j) transposed at [j][i] (T = H, hoff = 4, tsi = 1, tsj = ldh).  The bands the QZ
+  // iteration ever touches -- H: i <= j + 2 (sub-diagonal + bulge), T: i <= j + 1 (diagonal + fill-in) -- do not meet;
+  // every accessor below masks out-of-band elements (they are structural zeros: read as 0, never written).
+  int hoff, tsi, tsj;
+  bool packed;
 };
+__device__ __forceinline__ void gs_plain_map(GsLayout& L) {
+  L.hoff = 0;
+  L.tsi = L.ldh;
+  L.tsj = 1;
+  L.packed = false;
+}
 
 __host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap) {
   const int ldh = n_cap | 1, ldx = l_cap | 1;
@@ -117,10 +130,40 @@ __host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap)
   return cplx * 16 + (size_t)2 * 64 * 8 + 64 * 4 + 64;
 }
 
-#define GH(i, j) L.H[(i)*L.ldh + (j)]
-#define GT(i, j) L.T[(i)*L.ldh + (j)]
+#define GH(i, j) L.H[(i)*L.ldh + (j) + L.hoff]
+#define GT(i, j) L.T[(i)*L.tsi + (j)*L.tsj]
 #define GX(i, j) L.X[(i)*L.ldx + (j)]
 #define GZ(i, j) L.Z[(i)*L.ldz + (j)]
+
+// band-aware element access (see GsLayout)
+__device__ __forceinline__ bool h_in(const GsLayout& L, int i, int j) { return !L.packed || i <= j + 2; }
+__device__ __forceinline__ bool t_in(const GsLayout& L, int i, int j) { return !L.packed || i <= j + 1; }
+__device__ __forceinline__ cx hget(const GsLayout& L, int i, int j) { return h_in(L, i, j) ? GH(i, j) : cx{0.0, 0.0}; }
+__device__ __forceinline__ cx tget(const GsLayout& L, int i, int j) { return t_in(L, i, j) ? GT(i, j) : cx{0.0, 0.0}; }
+__device__ __forceinline__ void hput(const GsLayout& L, int i, int j, cx v) {
+  if (h_in(L, i, j)) GH(i, j) = v;
+}
+__device__ __forceinline__ void tput(const GsLayout& L, int i, int j, cx v) {
+  if (t_in(L, i, j)) GT(i, j) = v;
+}
+
+// Rotation-level masks (cheaper than one test per element).  Rows (i, k), |i - k| = 1: every context that rotates two
+// adjacent rows (QZ sweep, zero chasing, reordering) has H = 0 left of column min(i,k) - 1 and T = 0 left of column
+// min(i,k) in BOTH rows.  Columns (i, k): H = 0 below row max(i,k) + 1, T = 0 below row max(i,k), in both columns (the
+// bulge H(j+2, j) and the fill-in T(j+1, j) are inside).  Plain storage rotates everything (the Hessenberg-triangular
+// reduction of the single-launch kernel works on full matrices).
+__device__ __forceinline__ bool rowmask_h(const GsLayout& L, int i, int k, int lane) {
+  return lane < L.N && (!L.packed || lane >= (i < k ? i : k) - 1);
+}
+__device__ __forceinline__ bool rowmask_t(const GsLayout& L, int i, int k, int lane) {
+  return lane < L.N && (!L.packed || lane >= (i < k ? i : k));
+}
+__device__ __forceinline__ bool colmask_h(const GsLayout& L, int i, int k, int lane) {
+  return lane < L.N && (!L.packed || lane <= (i > k ? i : k) + 1);
+}
+__device__ __forceinline__ bool colmask_t(const GsLayout& L, int i, int k, int lane) {
+  return lane < L.N && (!L.packed || lane <= (i > k ? i : k));
+}
 
 __device__ __forceinline__ void rot2(cx& x, cx& y, double c, cx s) {
   // x' = c x + s y ; y' = c y - conj(s) x, 12 FMAs/MULs
@@ -170,15 +213,15 @@ __device__ __forceinline__ void lartg_real(double f, double g, double& c, double
 // rows i (x) and k (y) of H, T (columns c0..N-1) and X
 __device__ __forceinline__ void rot_rows(const GsLayout& L, int i, int k, double c, cx s, int c0, int lane) {
   for (int col = c0 + lane; col < L.N; col += 64) {
-    cx x = GH(i, col), y = GH(k, col);
+    cx x = hget(L, i, col), y = hget(L, k, col);
     rot2(x, y, c, s);
-    GH(i, col) = x;
-    GH(k, col) = y;
-    x = GT(i, col);
-    y = GT(k, col);
+    hput(L, i, col, x);
+    hput(L, k, col, y);
+    x = tget(L, i, col);
+    y = tget(L, k, col);
     rot2(x, y, c, s);
-    GT(i, col) = x;
-    GT(k, col) = y;
+    tput(L, i, col, x);
+    tput(L, k, col, y);
   }
   if (lane < L.ell) {
     cx x = GX(i, lane), y = GX(k, lane);
@@ -192,15 +235,15 @@ __device__ __forceinline__ void rot_rows(const GsLayout& L, int i, int k, double
 // columns i (x) and k (y) of H, T (rows 0..r1) and Ztop
 __device__ __forceinline__ void rot_cols(const GsLayout& L, int i, int k, double c, cx s, int r1, int lane) {
   for (int row = lane; row <= r1; row += 64) {
-    cx x = GH(row, i), y = GH(row, k);
+    cx x = hget(L, row, i), y = hget(L, row, k);
     rot2(x, y, c, s);
-    GH(row, i) = x;
-    GH(row, k) = y;
-    x = GT(row, i);
-    y = GT(row, k);
+    hput(L, row, i, x);
+    hput(L, row, k, y);
+    x = tget(L, row, i);
+    y = tget(L, row, k);
     rot2(x, y, c, s);
-    GT(row, i) = x;
-    GT(row, k) = y;
+    tput(L, row, i, x);
+    tput(L, row, k, y);
   }
   if (lane < L.n) {
     cx x = GZ(lane, i), y = GZ(lane, k);
@@ -230,9 +273,11 @@ struct RotLd {
 __device__ __forceinline__ RotLd rows_begin(const GsLayout& L, int i, int k, int lane) {
   wave_sync();
   RotLd o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
-  if (lane < L.N) {
+  if (rowmask_h(L, i, k, lane)) {
     o.hx = GH(i, lane);
     o.hy = GH(k, lane);
+  }
+  if (rowmask_t(L, i, k, lane)) {
     o.tx = GT(i, lane);
     o.ty = GT(k, lane);
   }
@@ -257,9 +302,11 @@ __device__ __forceinline__ Rot4 rows_finish(const GsLayout& L, int i, int k, Rot
       d.ty = mk(0, 0);
     }
   }
-  if (lane < L.N) {
+  if (rowmask_h(L, i, k, lane)) {
     GH(i, lane) = d.hx;
     GH(k, lane) = d.hy;
+  }
+  if (rowmask_t(L, i, k, lane)) {
     GT(i, lane) = d.tx;
     GT(k, lane) = d.ty;
   }
@@ -283,9 +330,11 @@ __device__ __forceinline__ Rot4 rows_finish_real(const GsLayout& L, int i, int k
       d.ty.re = 0.0;
     }
   }
-  if (lane < L.N) {
+  if (rowmask_h(L, i, k, lane)) {
     GH(i, lane) = d.hx;
     GH(k, lane) = d.hy;
+  }
+  if (rowmask_t(L, i, k, lane)) {
     GT(i, lane) = d.tx;
     GT(k, lane) = d.ty;
   }
@@ -298,9 +347,11 @@ __device__ __forceinline__ Rot4 rows_finish_real(const GsLayout& L, int i, int k
 __device__ __forceinline__ RotLd cols_begin(const GsLayout& L, int i, int k, int lane) {
   wave_sync();
   RotLd o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
-  if (lane < L.N) {
+  if (colmask_h(L, i, k, lane)) {
     o.hx = GH(lane, i);
     o.hy = GH(lane, k);
+  }
+  if (colmask_t(L, i, k, lane)) {
     o.tx = GT(lane, i);
     o.ty = GT(lane, k);
   }
@@ -325,9 +376,11 @@ __device__ __forceinline__ Rot4 cols_finish(const GsLayout& L, int i, int k, Rot
       d.ty = mk(0, 0);
     }
   }
-  if (lane < L.N) {
+  if (colmask_h(L, i, k, lane)) {
     GH(lane, i) = d.hx;
     GH(lane, k) = d.hy;
+  }
+  if (colmask_t(L, i, k, lane)) {
     GT(lane, i) = d.tx;
     GT(lane, k) = d.ty;
   }
@@ -352,9 +405,11 @@ __device__ __forceinline__ Rot4 cols_finish_real(const GsLayout& L, int i, int k
       d.ty.re = 0.0;
     }
   }
-  if (lane < L.N) {
+  if (colmask_h(L, i, k, lane)) {
     GH(lane, i) = d.hx;
     GH(lane, k) = d.hy;
+  }
+  if (colmask_t(L, i, k, lane)) {
     GT(lane, i) = d.tx;
     GT(lane, k) = d.ty;
   }
@@ -369,8 +424,8 @@ __device__ __forceinline__ Rot4 rot_rows_r(const GsLayout& L, int i, int k, doub
                                            int lane) {
   Rot4 o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
   if (lane < L.N) {
-    cx x = GH(i, lane), y = GH(k, lane);
-    cx u = GT(i, lane), v = GT(k, lane);
+    cx x = hget(L, i, lane), y = hget(L, k, lane);
+    cx u = tget(L, i, lane), v = tget(L, k, lane);
     rot2(x, y, c, s);
     rot2(u, v, c, s);
     if (lane == fixi) {
@@ -382,10 +437,10 @@ __device__ __forceinline__ Rot4 rot_rows_r(const GsLayout& L, int i, int k, doub
         v = mk(0, 0);
       }
     }
-    GH(i, lane) = x;
-    GH(k, lane) = y;
-    GT(i, lane) = u;
-    GT(k, lane) = v;
+    hput(L, i, lane, x);
+    hput(L, k, lane, y);
+    tput(L, i, lane, u);
+    tput(L, k, lane, v);
     o = Rot4{x, y, u, v};
   }
   if (lane < L.ell) {
@@ -402,8 +457,8 @@ __device__ __forceinline__ Rot4 rot_cols_r(const GsLayout& L, int i, int k, doub
                                            int lane) {
   Rot4 o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
   if (lane < L.N) {
-    cx x = GH(lane, i), y = GH(lane, k);
-    cx u = GT(lane, i), v = GT(lane, k);
+    cx x = hget(L, lane, i), y = hget(L, lane, k);
+    cx u = tget(L, lane, i), v = tget(L, lane, k);
     rot2(x, y, c, s);
     rot2(u, v, c, s);
     if (lane == fixi) {
@@ -415,10 +470,10 @@ __device__ __forceinline__ Rot4 rot_cols_r(const GsLayout& L, int i, int k, doub
         v = mk(0, 0);
       }
     }
-    GH(lane, i) = x;
-    GH(lane, k) = y;
-    GT(lane, i) = u;
-    GT(lane, k) = v;
+    hput(L, lane, i, x);
+    hput(L, lane, k, y);
+    tput(L, lane, i, u);
+    tput(L, lane, k, v);
     o = Rot4{x, y, u, v};
   }
   if (lane < L.n) {
@@ -519,11 +574,13 @@ __device__ __forceinline__ void hess_tri(const GsLayout& L, int z, int lane) {
   wave_sync();
 }
 
-__device__ __forceinline__ double frob_norm(const cx* M, int ld, int N, int lane) {
+// Frobenius norm of the block [ilo, N) x [ilo, N) of H (which = 0) or T (which = 1)
+__device__ __forceinline__ double frob_norm(const GsLayout& L, int which, int ilo, int lane) {
+  const int nb = L.N - ilo;
   double acc = 0.0;
-  for (int idx = lane; idx < N * N; idx += 64) {
-    const int i = idx / N, j = idx - i * N;
-    const cx v = M[i * ld + j];
+  for (int idx = lane; idx < nb * nb; idx += 64) {
+    const int i = ilo + idx / nb, j = ilo + idx % nb;
+    const cx v = which ? tget(L, i, j) : hget(L, i, j);
     acc = fma(v.re, v.re, acc);
     acc = fma(v.im, v.im, acc);
   }
@@ -536,8 +593,7 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
   if (N - ilo <= 1) return true;
   const double SAFMIN = 2.2250738585072014e-308, ULP = 2.220446049250313e-16;
   // norms of the active block (zhgeqz: zlanhs of H(ilo:ihi, ilo:ihi))
-  const double anorm = frob_norm(L.H + ilo * L.ldh + ilo, L.ldh, N - ilo, lane),
-               bnorm = frob_norm(L.T + ilo * L.ldh + ilo, L.ldh, N - ilo, lane);
+  const double anorm = frob_norm(L, 0, ilo, lane), bnorm = frob_norm(L, 1, ilo, lane);
   const double atol = fmax(SAFMIN, ULP * anorm), btol = fmax(SAFMIN, ULP * bnorm);
   const double ascale = 1.0 / fmax(SAFMIN, anorm), bscale = 1.0 / fmax(SAFMIN, bnorm);
   int ilast = N - 1, iiter = 0;
@@ -724,8 +780,8 @@ __device__ __forceinline__ bool root_is_stable(cx a, cx b, double rs) {
 
 __device__ __forceinline__ void swap_adjacent(const GsLayout& L, int k, int lane) {
   // rows k, k+1 restricted to columns k, k+1: fetched with one row-owner load each
-  const cx hk = (lane < L.N) ? GH(k, lane) : mk(0, 0), hk1 = (lane < L.N) ? GH(k + 1, lane) : mk(0, 0);
-  const cx tk = (lane < L.N) ? GT(k, lane) : mk(0, 0), tk1 = (lane < L.N) ? GT(k + 1, lane) : mk(0, 0);
+  const cx hk = (lane < L.N) ? hget(L, k, lane) : mk(0, 0), hk1 = (lane < L.N) ? hget(L, k + 1, lane) : mk(0, 0);
+  const cx tk = (lane < L.N) ? tget(L, k, lane) : mk(0, 0), tk1 = (lane < L.N) ? tget(L, k + 1, lane) : mk(0, 0);
   const cx h00 = bc(hk, k), h01 = bc(hk, k + 1), h11 = bc(hk1, k + 1);
   const cx t00 = bc(tk, k), t01 = bc(tk, k + 1), t11 = bc(tk1, k + 1);
   const cx f = h11 * t00 - t11 * h00;
@@ -852,6 +908,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
   L.ldh = n_cap | 1;
   L.ldx = l_cap | 1;
   L.ldz = L.ldh;
+  gs_plain_map(L);
   L.H = reinterpret_cast<cx*>(smem);
   L.T = L.H + n_cap * L.ldh;
   L.X = L.T + n_cap * L.ldh;

@@ -11,7 +11,7 @@
 //       T[non-state rows] = R0^-1 (T12[:, :s'] - H12 Re(M1 Yb Ms^H) - X1 Re(Bm B22 Ms2^H))
 //     with Yb = A11w^-1 [B11w, B12w - Phi_b B22] the window part of the reference's G0^-1 [Tmat BB] (gensys.py:322-343);
 //     tests/device_models/gensys_window_model.py restates this algebra in numpy and checks it against the oracle.
-// LDS per draw at N = 52, z = 22: 48 KB (reduce), 51 KB (QZ), 70 KB (post) => 3 / 3 / 2 wavefronts per CU, each on its own
+// LDS per draw at N = 52, z = 22: 48 KB (reduce), 38 KB (QZ; H and T share one array), 70 KB (post) => 3 / 4 / 2 wavefronts per CU, each on its own
 // SIMD.  The launches hand the window over through a library-owned HBM workspace (88 KB per draw, read and written once).
 #pragma once
 #include "dsge_gensys.hpp"
@@ -56,8 +56,8 @@ __host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
   return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1) +
           (size_t)c.wcap * (c.wcap | 1)) * 8 + 64 * 4;
 }
-__host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {
-  return ((size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
+__host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array (GsLayout, packed map)
+  return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
 }
 __host__ __device__ inline size_t gw_post_smem(const GwCaps& c) {
   const size_t cplx = (size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1) + (size_t)c.lcap * (c.wcap | 1) +
@@ -388,13 +388,17 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   GsLayout L;
-  L.ldh = cp.wcap | 1;
+  L.ldh = (cp.wcap + 4) | 1;
   L.ldx = cp.lcap | 1;
-  L.ldz = L.ldh;
+  L.ldz = cp.wcap | 1;
   L.H = reinterpret_cast<cx*>(smem);
-  L.T = L.H + (size_t)cp.wcap * L.ldh;
-  L.Z = L.T + (size_t)cp.wcap * L.ldh;
-  L.X = L.Z + (size_t)cp.wcap * L.ldh;
+  L.T = L.H;  // packed map: H(i, j) at [i][j + 4], T(i, j) at [j][i]
+  L.hoff = 4;
+  L.tsi = 1;
+  L.tsj = L.ldh;
+  L.packed = true;
+  L.Z = L.H + (size_t)cp.wcap * L.ldh;
+  L.X = L.Z + (size_t)cp.wcap * L.ldz;
   L.V1 = L.V2 = L.S3 = nullptr;
   L.s1 = L.s2 = nullptr;
   L.lead = nullptr;
@@ -409,11 +413,13 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
     L.n = w;
     L.ell = ell;
     wave_sync();
+    for (int idx = lane; idx < w * L.ldh; idx += 64) L.H[idx] = mk(0.0, 0.0);
+    wave_sync();
     for (int idx = lane; idx < w * w; idx += 64) {
       const int i = idx / w, j = idx - i * w;
       const size_t o = (size_t)i * cp.wcap + j;
-      L.H[i * L.ldh + j] = mk(wd[wo.HR + o], 0.0);
-      L.T[i * L.ldh + j] = mk(wd[wo.TR + o], 0.0);
+      hput(L, i, j, mk(wd[wo.HR + o], 0.0));  // out-of-band entries are exact zeros after the real reduction
+      tput(L, i, j, mk(wd[wo.TR + o], 0.0));
       L.Z[i * L.ldz + j] = mk(wd[wo.ZR + o], 0.0);
     }
     for (int idx = lane; idx < w * ell; idx += 64) {
@@ -434,8 +440,8 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
     for (int idx = lane; idx < w * w; idx += 64) {
       const int i = idx / w, j = idx - i * w;
       const size_t o = (size_t)i * cp.wcap + j;
-      HC[o] = L.H[i * L.ldh + j];
-      TC[o] = L.T[i * L.ldh + j];
+      HC[o] = hget(L, i, j);
+      TC[o] = tget(L, i, j);
       MC[o] = L.Z[i * L.ldz + j];
     }
     for (int idx = lane; idx < w * ell; idx += 64) {
