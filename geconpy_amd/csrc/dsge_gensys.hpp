@@ -116,12 +116,19 @@ struct GsLayout {
   // every accessor below masks out-of-band elements (they are structural zeros: read as 0, never written).
   int hoff, tsi, tsj;
   bool packed;
+  // zglobal: the accumulated right transformation is NOT in LDS.  Z then points to global memory and holds the matrix
+  // TRANSPOSED (element (row, col) at Z[col * ldz + row]: a column rotation reads / writes two contiguous runs, one
+  // row per lane).  Nothing in the iteration ever reads Z back, so the QZ sweep keeps the shared column of consecutive
+  // rotations in registers, prefetches the next one a step ahead and stores each finished column once (qz_iterate);
+  // the rare other column rotations (zero chasing, reordering) do a plain read-modify-write.
+  bool zglobal;
 };
 __device__ __forceinline__ void gs_plain_map(GsLayout& L) {
   L.hoff = 0;
   L.tsi = L.ldh;
   L.tsj = 1;
   L.packed = false;
+  L.zglobal = false;
 }
 
 __host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap) {
@@ -134,6 +141,13 @@ __host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap)
 #define GT(i, j) L.T[(i)*L.tsi + (j)*L.tsj]
 #define GX(i, j) L.X[(i)*L.ldx + (j)]
 #define GZ(i, j) L.Z[(i)*L.ldz + (j)]
+// element (row, col) of the accumulated right transformation in either storage (see GsLayout::zglobal)
+#define ZEL(row, col) L.Z[L.zglobal ? ((col)*L.ldz + (row)) : ((row)*L.ldz + (col))]
+// all outstanding global stores of this wavefront have completed (orders a later load of the same address)
+#define Z_FENCE()                                              \
+  do {                                                         \
+    if (L.zglobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+  } while (0)
 
 // band-aware element access (see GsLayout)
 __device__ __forceinline__ bool h_in(const GsLayout& L, int i, int j) { return !L.packed || i <= j + 2; }
@@ -246,10 +260,11 @@ __device__ __forceinline__ void rot_cols(const GsLayout& L, int i, int k, double
     tput(L, row, k, y);
   }
   if (lane < L.n) {
-    cx x = GZ(lane, i), y = GZ(lane, k);
+    Z_FENCE();
+    cx x = ZEL(lane, i), y = ZEL(lane, k);
     rot2(x, y, c, s);
-    GZ(lane, i) = x;
-    GZ(lane, k) = y;
+    ZEL(lane, i) = x;
+    ZEL(lane, k) = y;
   }
   wave_sync();
 }
@@ -344,7 +359,7 @@ __device__ __forceinline__ Rot4 rows_finish_real(const GsLayout& L, int i, int k
   }
   return Rot4{d.hx, d.hy, d.tx, d.ty};
 }
-__device__ __forceinline__ RotLd cols_begin(const GsLayout& L, int i, int k, int lane) {
+__device__ __forceinline__ RotLd cols_begin(const GsLayout& L, int i, int k, int lane, bool with_z = true) {
   wave_sync();
   RotLd o{mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0), mk(0, 0)};
   if (colmask_h(L, i, k, lane)) {
@@ -355,15 +370,16 @@ __device__ __forceinline__ RotLd cols_begin(const GsLayout& L, int i, int k, int
     o.tx = GT(lane, i);
     o.ty = GT(lane, k);
   }
-  if (lane < L.n) {
-    o.ax = GZ(lane, i);
-    o.ay = GZ(lane, k);
+  if (with_z && lane < L.n) {
+    Z_FENCE();
+    o.ax = ZEL(lane, i);
+    o.ay = ZEL(lane, k);
   }
   __builtin_amdgcn_sched_barrier(0);
   return o;
 }
 __device__ __forceinline__ Rot4 cols_finish(const GsLayout& L, int i, int k, RotLd d, double c, cx s, int fixm,
-                                            int fixi, cx r, int lane) {
+                                            int fixi, cx r, int lane, bool with_z = true) {
   rot2(d.hx, d.hy, c, s);
   rot2(d.tx, d.ty, c, s);
   rot2(d.ax, d.ay, c, s);
@@ -384,9 +400,9 @@ __device__ __forceinline__ Rot4 cols_finish(const GsLayout& L, int i, int k, Rot
     GT(lane, i) = d.tx;
     GT(lane, k) = d.ty;
   }
-  if (lane < L.n) {
-    GZ(lane, i) = d.ax;
-    GZ(lane, k) = d.ay;
+  if (with_z && lane < L.n) {
+    ZEL(lane, i) = d.ax;
+    ZEL(lane, k) = d.ay;
   }
   return Rot4{d.hx, d.hy, d.tx, d.ty};
 }
@@ -477,10 +493,11 @@ __device__ __forceinline__ Rot4 rot_cols_r(const GsLayout& L, int i, int k, doub
     o = Rot4{x, y, u, v};
   }
   if (lane < L.n) {
-    cx x = GZ(lane, i), y = GZ(lane, k);
+    Z_FENCE();
+    cx x = ZEL(lane, i), y = ZEL(lane, k);
     rot2(x, y, c, s);
-    GZ(lane, i) = x;
-    GZ(lane, k) = y;
+    ZEL(lane, i) = x;
+    ZEL(lane, k) = y;
   }
   wave_sync();
   return o;
@@ -751,6 +768,18 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
         cnt[0] += ilast - istart;  // sweep steps (one row + one column rotation each)
         cnt[1] += 1;               // sweeps
       }
+      // zglobal: columns istart, istart+1 (+ the prefetch of istart+2) of the accumulated transformation, one row per
+      // lane; the loads are in flight during the first row rotation
+      const bool zg = L.zglobal, zrow = lane < L.n;
+      cx m_y = mk(0, 0), m_x = mk(0, 0), m_n = mk(0, 0);
+      if (zg) {
+        Z_FENCE();
+        if (zrow) {
+          m_y = ZEL(lane, istart);
+          m_x = ZEL(lane, istart + 1);
+          if (istart + 2 <= ilast) m_n = ZEL(lane, istart + 2);
+        }
+      }
       for (int j = istart; j < ilast; ++j) {
         Rot4 rr;
         const RotLd ld = rows_begin(L, j, j + 1, lane);
@@ -761,11 +790,19 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
         } else {
           rr = rows_finish(L, j, j + 1, ld, c, s, 0, 0, r, lane);
         }
-        const RotLd lc2 = cols_begin(L, j + 1, j, lane);
+        const RotLd lc2 = cols_begin(L, j + 1, j, lane, !zg);
         cx r2;
         lartg(bc(rr.ty, j + 1), bc(rr.ty, j), c, s, r2);  // T[j+1][j+1], T[j+1][j]
-        cr = cols_finish(L, j + 1, j, lc2, c, s, 2, j + 1, r2, lane);
+        cr = cols_finish(L, j + 1, j, lc2, c, s, 2, j + 1, r2, lane, !zg);
+        if (zg) {
+          rot2(m_x, m_y, c, s);  // x = column j+1, y = column j (final for this sweep)
+          if (zrow) ZEL(lane, j) = m_y;
+          m_y = m_x;
+          m_x = m_n;
+          if (zrow && j + 3 <= ilast) m_n = ZEL(lane, j + 3);
+        }
       }
+      if (zg && zrow) ZEL(lane, ilast) = m_y;
       wave_sync();
     }
   }

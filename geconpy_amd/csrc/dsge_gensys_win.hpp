@@ -11,7 +11,7 @@
 //       T[non-state rows] = R0^-1 (T12[:, :s'] - H12 Re(M1 Yb Ms^H) - X1 Re(Bm B22 Ms2^H))
 //     with Yb = A11w^-1 [B11w, B12w - Phi_b B22] the window part of the reference's G0^-1 [Tmat BB] (gensys.py:322-343);
 //     tests/device_models/gensys_window_model.py restates this algebra in numpy and checks it against the oracle.
-// LDS per draw at N = 52, z = 22: 48 KB (reduce), 38 KB (QZ; H and T share one array), 70 KB (post) => 3 / 4 / 2 wavefronts per CU, each on its own
+// LDS per draw at N = 52, z = 22: 48 KB (reduce), 23 KB (QZ: H and T share one array, M stays in HBM / L2), 70 KB (post) => 3 / 6 / 2 wavefronts per CU, each on its own
 // SIMD.  The launches hand the window over through a library-owned HBM workspace (88 KB per draw, read and written once).
 #pragma once
 #include "dsge_gensys.hpp"
@@ -23,7 +23,7 @@ struct GwCaps {
 };
 
 struct GwOffsets {  // per draw, in doubles
-  size_t meta, R0, H12, T12, X1, HR, TR, ZR, XR, HC, TC, MC, XC, total;
+  size_t meta, R0, H12, T12, X1, HR, TR, XR, HC, TC, MC, XC, total;
 };
 
 __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
@@ -37,7 +37,6 @@ __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
   o.X1 = p, p += (size_t)c.zcap * c.lcap;
   o.HR = p, p += ww;
   o.TR = p, p += ww;
-  o.ZR = p, p += ww;
   o.XR = p, p += wl;
   p = (p + 1) & ~(size_t)1;  // complex arrays: 16-byte aligned
   o.HC = p, p += 2 * ww;
@@ -56,8 +55,8 @@ __host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
   return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1) +
           (size_t)c.wcap * (c.wcap | 1)) * 8 + 64 * 4;
 }
-__host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array (GsLayout, packed map)
-  return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
+__host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array; M stays in HBM / L2 (GsLayout)
+  return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
 }
 __host__ __device__ inline size_t gw_post_smem(const GwCaps& c) {
   const size_t cplx = (size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1) + (size_t)c.lcap * (c.wcap | 1) +
@@ -371,7 +370,13 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
       const size_t o = (size_t)i * cp.wcap + j;
       wd[wo.HR + o] = hb[i * ldH + j];
       wd[wo.TR + o] = tb[i * ldW + j];
-      wd[wo.ZR + o] = Zr[i * ldW + j];
+    }
+    {  // the right transformation so far, TRANSPOSED and complex: the QZ launch keeps accumulating it in place
+      cx* MC = reinterpret_cast<cx*>(wd + wo.MC);
+      for (int idx = lane; idx < w * w; idx += 64) {
+        const int col = idx / w, row = idx - col * w;
+        MC[(size_t)col * cp.wcap + row] = mk(Zr[row * ldW + col], 0.0);
+      }
     }
     for (int idx = lane; idx < w * ell; idx += 64) {
       const int i = idx / ell, j = idx - i * ell;
@@ -390,15 +395,16 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
   GsLayout L;
   L.ldh = (cp.wcap + 4) | 1;
   L.ldx = cp.lcap | 1;
-  L.ldz = cp.wcap | 1;
+  L.ldz = cp.wcap;
   L.H = reinterpret_cast<cx*>(smem);
   L.T = L.H;  // packed map: H(i, j) at [i][j + 4], T(i, j) at [j][i]
   L.hoff = 4;
   L.tsi = 1;
   L.tsj = L.ldh;
   L.packed = true;
-  L.Z = L.H + (size_t)cp.wcap * L.ldh;
-  L.X = L.Z + (size_t)cp.wcap * L.ldz;
+  L.zglobal = true;  // M: transposed, in the draw's workspace (set per draw)
+  L.Z = nullptr;
+  L.X = L.H + (size_t)cp.wcap * L.ldh;
   L.V1 = L.V2 = L.S3 = nullptr;
   L.s1 = L.s2 = nullptr;
   L.lead = nullptr;
@@ -412,6 +418,7 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
     L.N = w;
     L.n = w;
     L.ell = ell;
+    L.Z = reinterpret_cast<cx*>(wd + wo.MC);
     wave_sync();
     for (int idx = lane; idx < w * L.ldh; idx += 64) L.H[idx] = mk(0.0, 0.0);
     wave_sync();
@@ -420,7 +427,6 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
       const size_t o = (size_t)i * cp.wcap + j;
       hput(L, i, j, mk(wd[wo.HR + o], 0.0));  // out-of-band entries are exact zeros after the real reduction
       tput(L, i, j, mk(wd[wo.TR + o], 0.0));
-      L.Z[i * L.ldz + j] = mk(wd[wo.ZR + o], 0.0);
     }
     for (int idx = lane; idx < w * ell; idx += 64) {
       const int i = idx / ell, j = idx - i * ell;
@@ -435,14 +441,12 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
     GW_STAMP(10);
     cx* HC = reinterpret_cast<cx*>(wd + wo.HC);
     cx* TC = reinterpret_cast<cx*>(wd + wo.TC);
-    cx* MC = reinterpret_cast<cx*>(wd + wo.MC);
     cx* XC = reinterpret_cast<cx*>(wd + wo.XC);
     for (int idx = lane; idx < w * w; idx += 64) {
       const int i = idx / w, j = idx - i * w;
       const size_t o = (size_t)i * cp.wcap + j;
       HC[o] = hget(L, i, j);
       TC[o] = tget(L, i, j);
-      MC[o] = L.Z[i * L.ldz + j];
     }
     for (int idx = lane; idx < w * ell; idx += 64) {
       const int i = idx / ell, j = idx - i * ell;
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
         const size_t o = (size_t)i * cp.wcap + j;
         PH(i, j) = HC[o];
         PT(i, j) = TC[o];
-        PM(i, j) = MC[o];
+        PM(i, j) = MC[(size_t)j * cp.wcap + i];  // stored transposed
       }
       for (int idx = lane; idx < w * ell; idx += 64) {
         const int i = idx / ell, j = idx - i * ell;
