@@ -50,10 +50,17 @@ __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
 // meta (int32[16] at the head of a draw's workspace)
 enum { GW_N = 0, GW_ELL = 1, GW_Z = 2, GW_FLAG = 3, GW_CONV = 4, GW_NS2 = 5, GW_MASK_LO = 6, GW_MASK_HI = 7 };
 
+// The accumulated right transformation Zr of the reduce launch is only needed once rows < z of H are dead (they leave
+// the chip after the deflation phase): when EVERY draw of the batch has enough of them (zmin = n - scap rows of H hold
+// wcap x ldW doubles) Zr lives there and the launch needs 40 KB instead of 48 KB at N = 52 (4 draws per CU).
+__host__ __device__ inline bool gw_reduce_alias(const GwCaps& c) {
+  const int Ncap = c.n + c.lcap, zmin = c.n - c.scap;
+  return (size_t)zmin * (Ncap | 1) >= (size_t)c.wcap * (c.wcap | 1);
+}
 __host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
   const int Ncap = c.n + c.lcap;
   return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1) +
-          (size_t)c.wcap * (c.wcap | 1)) * 8 + 64 * 4;
+          (gw_reduce_alias(c) ? 0 : (size_t)c.wcap * (c.wcap | 1))) * 8 + 64 * 4;
 }
 __host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array; M stays in HBM / L2 (GsLayout)
   return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
@@ -77,14 +84,16 @@ __global__ __launch_bounds__(64) void gensys_shape_kernel(const double* __restri
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     double cs = 0.0;
-    bool anz = false;
-    if (lane < n)
-      for (int i = 0; i < n; ++i) {
+    int anz = 0;
+    if (lane < n) {
+#pragma unroll 8
+      for (int i = 0; i < n; ++i) {  // no short-circuit: the loads of a trip are independent
         cs += fabs(C[off + (size_t)i * n + lane]);
-        anz = anz || (A[off + (size_t)i * n + lane] != 0.0);
+        anz |= (A[off + (size_t)i * n + lane] != 0.0) ? 1 : 0;
       }
+    }
     const int ell = __popcll(__ballot(lane < n && cs > tol));
-    const int z = n - __popcll(__ballot(anz));
+    const int z = n - __popcll(__ballot(anz != 0));
     if (lane == 0) {
       atomicMax(out + 0, ell);
       atomicMax(out + 1, n - z + ell);
@@ -113,57 +122,92 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
   const double scal = 1.0 / (alpha - beta);
   const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
   const int ncols = nH + nT + nX;
-  for (int c0 = 0; c0 < ncols; c0 += 64) {
-    const int c = c0 + lane;
-    const bool act = c < ncols;
-    double* base = Hr + h0;  // inactive lanes walk a valid column and store nothing
-    int ld = ldH;
-    if (act) {
-      if (c < nH) {
-        base = Hr + h0 + c;
-      } else if (c < nH + nT) {
-        base = Tr + (c - nH);
-        ld = ldW;
-      } else {
-        base = Xr + (c - nH - nT);
-        ld = ldX;
-      }
+  // column c of the virtual matrix [H | T | X] -> base pointer and row stride (inactive lanes walk a valid column of H
+  // and store nothing)
+  auto column = [&](int c, double*& base, int& ld) -> bool {
+    base = Hr + h0;
+    ld = ldH;
+    if (c >= ncols) return false;
+    if (c < nH) {
+      base = Hr + h0 + c;
+    } else if (c < nH + nT) {
+      base = Tr + (c - nH);
+      ld = ldW;
+    } else {
+      base = Xr + (c - nH - nT);
+      ld = ldX;
     }
-    double* p = base + j * ld;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    return true;
+  };
+  for (int c0 = 0; c0 < ncols; c0 += 128) {  // two columns per lane and trip: eight loads in flight
+    double *bA, *bB;
+    int lA, lB;
+    const bool actA = column(c0 + lane, bA, lA), actB = column(c0 + 64 + lane, bB, lB);
+    double* pA = bA + j * lA;
+    double* pB = bB + j * lB;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     int r = j;
     for (; r + 4 <= N; r += 4) {
-      const double m0 = p[0], m1 = p[ld], m2 = p[2 * ld], m3 = p[3 * ld];
-      a0 = fma(readlane_dyn_f64(v, r), m0, a0);
-      a1 = fma(readlane_dyn_f64(v, r + 1), m1, a1);
-      a2 = fma(readlane_dyn_f64(v, r + 2), m2, a2);
-      a3 = fma(readlane_dyn_f64(v, r + 3), m3, a3);
-      p += 4 * ld;
+      const double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
+      const double q0 = pB[0], q1 = pB[lB], q2 = pB[2 * lB], q3 = pB[3 * lB];
+      const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
+                   v3 = readlane_dyn_f64(v, r + 3);
+      a0 = fma(v0, m0, a0);
+      a1 = fma(v1, m1, a1);
+      a2 = fma(v2, m2, a2);
+      a3 = fma(v3, m3, a3);
+      b0 = fma(v0, q0, b0);
+      b1 = fma(v1, q1, b1);
+      b2 = fma(v2, q2, b2);
+      b3 = fma(v3, q3, b3);
+      pA += 4 * lA;
+      pB += 4 * lB;
     }
     for (; r < N; ++r) {
-      a0 = fma(readlane_dyn_f64(v, r), p[0], a0);
-      p += ld;
+      const double vr = readlane_dyn_f64(v, r);
+      a0 = fma(vr, pA[0], a0);
+      b0 = fma(vr, pB[0], b0);
+      pA += lA;
+      pB += lB;
     }
-    const double wv = -tau * ((a0 + a1) + (a2 + a3));
-    p = base + j * ld;
+    const double wA = -tau * ((a0 + a1) + (a2 + a3)), wB = -tau * ((b0 + b1) + (b2 + b3));
+    pA = bA + j * lA;
+    pB = bB + j * lB;
     for (r = j; r + 4 <= N; r += 4) {
-      double m0 = p[0], m1 = p[ld], m2 = p[2 * ld], m3 = p[3 * ld];
-      m0 = fma(readlane_dyn_f64(v, r), wv, m0);
-      m1 = fma(readlane_dyn_f64(v, r + 1), wv, m1);
-      m2 = fma(readlane_dyn_f64(v, r + 2), wv, m2);
-      m3 = fma(readlane_dyn_f64(v, r + 3), wv, m3);
-      if (act) {
-        p[0] = m0;
-        p[ld] = m1;
-        p[2 * ld] = m2;
-        p[3 * ld] = m3;
+      double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
+      double q0 = pB[0], q1 = pB[lB], q2 = pB[2 * lB], q3 = pB[3 * lB];
+      const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
+                   v3 = readlane_dyn_f64(v, r + 3);
+      m0 = fma(v0, wA, m0);
+      m1 = fma(v1, wA, m1);
+      m2 = fma(v2, wA, m2);
+      m3 = fma(v3, wA, m3);
+      q0 = fma(v0, wB, q0);
+      q1 = fma(v1, wB, q1);
+      q2 = fma(v2, wB, q2);
+      q3 = fma(v3, wB, q3);
+      if (actA) {
+        pA[0] = m0;
+        pA[lA] = m1;
+        pA[2 * lA] = m2;
+        pA[3 * lA] = m3;
       }
-      p += 4 * ld;
+      if (actB) {
+        pB[0] = q0;
+        pB[lB] = q1;
+        pB[2 * lB] = q2;
+        pB[3 * lB] = q3;
+      }
+      pA += 4 * lA;
+      pB += 4 * lB;
     }
     for (; r < N; ++r) {
-      const double m0 = fma(readlane_dyn_f64(v, r), wv, p[0]);
-      if (act) p[0] = m0;
-      p += ld;
+      const double vr = readlane_dyn_f64(v, r);
+      const double m0 = fma(vr, wA, pA[0]), q0 = fma(vr, wB, pB[0]);
+      if (actA) pA[0] = m0;
+      if (actB) pB[0] = q0;
+      pA += lA;
+      pB += lB;
     }
   }
   wave_sync();
@@ -189,9 +233,11 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
   double* Hr = smem;
   double* Tr = Hr + (size_t)Ncap * ldH;
   double* Xr = Tr + (size_t)Ncap * ldW;
-  double* Zr = Xr + (size_t)Ncap * ldX;
-  int* lead = reinterpret_cast<int*>(Zr + (size_t)cp.wcap * ldW);
-  const size_t total = (size_t)Ncap * ldH + (size_t)Ncap * ldW + (size_t)Ncap * ldX + (size_t)cp.wcap * ldW;
+  const bool zr_alias = gw_reduce_alias(cp);
+  double* Zr = zr_alias ? Hr : Xr + (size_t)Ncap * ldX;  // aliased: rows < z of H, dead after the deflation phase
+  int* lead = reinterpret_cast<int*>(Xr + (size_t)Ncap * ldX + (zr_alias ? 0 : (size_t)cp.wcap * ldW));
+  const size_t total =
+      (size_t)Ncap * ldH + (size_t)Ncap * ldW + (size_t)Ncap * ldX + (zr_alias ? 0 : (size_t)cp.wcap * ldW);
   const GwOffsets wo = gw_offsets(cp);
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
@@ -208,13 +254,15 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
     unsigned long long a_colmask = 0ull;
     {
       double cs = 0.0;
-      bool anz = false;
-      if (lane < n)
+      int anz = 0;
+      if (lane < n) {
+#pragma unroll 8
         for (int i = 0; i < n; ++i) {
           cs += fabs(Cg[(size_t)i * n + lane]);
-          anz = anz || (Ag[(size_t)i * n + lane] != 0.0);
+          anz |= (Ag[(size_t)i * n + lane] != 0.0) ? 1 : 0;
         }
-      a_colmask = __ballot(anz);
+      }
+      a_colmask = __ballot(anz != 0);
       const unsigned long long lm = __ballot(lane < n && cs > tol);
       ell = __popcll(lm);
       if (lane < n && ((lm >> lane) & 1ull)) lead[__popcll(lm & ((1ull << lane) - 1ull))] = lane;
@@ -256,7 +304,6 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
       Tr[(n + lane) * ldW + n + lane - z] = 1.0;
       Xr[(n + lane) * ldX + lane] = 1.0;
     }
-    if (lane < w) Zr[lane * ldW + lane] = 1.0;
 #undef COLPOS
     wave_sync();
 
@@ -279,6 +326,11 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
     for (int idx = lane; idx < z * ell; idx += 64) {
       const int i = idx / ell, j = idx - i * ell;
       wd[wo.X1 + (size_t)i * cp.lcap + j] = Xr[i * ldX + j];
+    }
+    wave_sync();
+    for (int idx = lane; idx < w * ldW; idx += 64) {  // Zr = I (possibly in the rows of H that just left)
+      const int i = idx / ldW, j = idx - i * ldW;
+      Zr[idx] = (i == j) ? 1.0 : 0.0;
     }
     GW_STAMP(1);
     // ---- window: T22 -> upper triangular (reflectors on rows >= z)
