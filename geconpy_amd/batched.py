@@ -272,6 +272,24 @@ def selector_hint(Z):
     return int(bool(one_per_row and distinct))
 
 
+def bk_eigenvalues_batched(A, B, C, tol=1e-8):
+    """Batched ``compute_bk_eigenvalues`` (gEconpy/model/perturbation.py:412-445): generalized eigenvalues of the
+    Sims pencil sorted by ascending modulus, plus the two counts ``check_bk_condition`` (:448-565) compares.
+
+    Returns dict(real, imag (batch, 2n; the first ``n_eig[i]`` entries of a row are valid), n_eig, n_forward,
+    n_unstable, satisfied, status)."""
+    A, B, C = _check_abc(A, B, C)
+    nb, n, _ = A.shape
+    re = np.empty((nb, 2 * n))
+    im = np.empty((nb, 2 * n))
+    ne, nf, nu, st = (np.empty(nb, dtype=np.int32) for _ in range(4))
+    _lib.check(
+        _lib.load().dsge_bk_eigenvalues_batched_host(_ptr(A), _ptr(B), _ptr(C), nb, n, float(tol), _ptr(re), _ptr(im),
+                                                     _ptr(ne), _ptr(nf), _ptr(nu), _ptr(st))
+    )
+    return dict(real=re, imag=im, n_eig=ne, n_forward=nf, n_unstable=nu, satisfied=(st == 0) & (nf == nu), status=st)
+
+
 def set_kalman_steady_tol(tol):
     """Steady-state switch of the fast Kalman kernel (include/dsge_hip.h): relative change of the
     predicted covariance below which F^-1, K and det F are frozen.  0 = step-for-step recursion;

@@ -159,7 +159,7 @@ int dsge_set_kalman_mfma(int enable) {
   return DSGE_SUCCESS;
 }
 int dsge_set_gensys_split(int enable) {
-  g_gensys_split = enable ? 1 : 0;
+  g_gensys_split = (enable == 2) ? 2 : (enable ? 1 : 0);
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_tiny(int enable) {
@@ -237,6 +237,19 @@ int dsge_gensys_batched(const double* A, const double* B, const double* C, const
     return launch_assemble(nullptr, B, C, D, T_out, nullptr, nullptr, 0, batch, n, k, R_out, nullptr, nullptr, nullptr,
                            nullptr, 1, 0, (hipStream_t)stream);
   return DSGE_SUCCESS;
+}
+
+int dsge_bk_eigenvalues_batched(const double* A, const double* B, const double* C, int batch, int n, double tol,
+                                double* eig_re, double* eig_im, int32_t* n_eig, int32_t* n_forward,
+                                int32_t* n_unstable, int32_t* status, void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  if (rc) return rc;
+  if (!A || !B || !C || !eig_re || !eig_im || !n_eig || !n_forward || !n_unstable || !status)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_gensys_bk(A, B, C, batch, n, tol, eig_re, eig_im, n_eig, n_forward, n_unstable, status,
+                          (hipStream_t)stream);
 }
 
 int dsge_selection_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
@@ -734,6 +747,41 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
   DOWN(T_out, dT, nn, double);
   DOWN(R_out, dR, nk, double);
   DOWN(eu_out, dE, (size_t)batch * 3, int32_t);
+  DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const double* C, int batch, int n, double tol,
+                                     double* eig_re, double* eig_im, int32_t* n_eig, int32_t* n_forward,
+                                     int32_t* n_unstable, int32_t* status) {
+  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  if (rc) return rc;
+  if (!A || !B || !C || !eig_re || !eig_im || !n_eig || !n_forward || !n_unstable || !status)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, ne = (size_t)batch * 2 * n;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_stage, 3 * align256(nn * 8) + 2 * align256(ne * 8) + 4 * align256((size_t)batch * 4) + 4096,
+                          &base)))
+    return rc;
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  OUTBUF(dRe, eig_re, ne, double);
+  OUTBUF(dIm, eig_im, ne, double);
+  OUTBUF(dNe, n_eig, batch, int32_t);
+  OUTBUF(dNf, n_forward, batch, int32_t);
+  OUTBUF(dNu, n_unstable, batch, int32_t);
+  OUTBUF(dS, status, batch, int32_t);
+  if ((rc = dsge_bk_eigenvalues_batched(dA, dB, dC, batch, n, tol, dRe, dIm, dNe, dNf, dNu, dS, nullptr))) return rc;
+  DOWN(eig_re, dRe, ne, double);
+  DOWN(eig_im, dIm, ne, double);
+  DOWN(n_eig, dNe, batch, int32_t);
+  DOWN(n_forward, dNf, batch, int32_t);
+  DOWN(n_unstable, dNu, batch, int32_t);
   DOWN(status, dS, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;

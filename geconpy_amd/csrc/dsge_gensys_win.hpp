@@ -862,4 +862,73 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
 #undef PX
 }
 
+
+// ---- Blanchard-Kahn eigenvalues (compute_bk_eigenvalues, gEconpy/model/perturbation.py:412-445): after the reduce and QZ
+// launches the generalized eigenvalues are on the diagonals -- (R0_ii, 0) for the deflated roots, (H_ii, T_ii) for the
+// window.  The reference divides LAPACK's (alpha, beta) with beta real and non-negative (zgges normalisation):
+// lambda = beta / (alpha + tol); the pair is rotated to that convention here before tol is added.  Output per draw:
+// N = n + #lead eigenvalues sorted by ascending modulus (stride 2n), n_forward = #lead, n_unstable = #{|lambda| > 1}.
+__global__ __launch_bounds__(64) void gensys_bk_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
+                                                        double* __restrict__ eig_re, double* __restrict__ eig_im,
+                                                        int32_t* __restrict__ n_eig, int32_t* __restrict__ n_forward,
+                                                        int32_t* __restrict__ n_unstable, int32_t* __restrict__ status) {
+  const int lane = threadIdx.x;
+  const int n = cp.n;
+  const GwOffsets wo = gw_offsets(cp);
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const double* wd = ws + (size_t)draw * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    const size_t o = (size_t)draw * 2 * n;
+    const bool ok = meta[GW_FLAG] == 0 && meta[GW_CONV] != 0;
+    const int N = meta[GW_N], ell = meta[GW_ELL], z = meta[GW_Z];
+    for (int i = lane; i < 2 * n; i += 64) {
+      eig_re[o + i] = 0.0;
+      eig_im[o + i] = 0.0;
+    }
+    if (!ok) {
+      if (lane == 0) {
+        n_eig[draw] = 0;
+        n_forward[draw] = ell;
+        n_unstable[draw] = 0;
+        status[draw] = DSGE_ST_NOT_CONVERGED | (meta[GW_FLAG] ? DSGE_ST_GENSYS_TOO_BIG : DSGE_ST_GENSYS_QZ_FAIL);
+      }
+      continue;
+    }
+    cx al = mk(1.0, 0.0), be = mk(0.0, 0.0);
+    if (lane < z) {
+      al = mk(wd[wo.R0 + (size_t)lane * cp.zcap + lane], 0.0);
+    } else if (lane < N) {
+      const int i = lane - z;
+      al = reinterpret_cast<const cx*>(wd + wo.HC)[(size_t)i * cp.wcap + i];
+      be = reinterpret_cast<const cx*>(wd + wo.TC)[(size_t)i * cp.wcap + i];
+    }
+    const double ab = cabs_(be);
+    if (ab > 0.0) {  // rotate the pair so that beta is real and non-negative
+      const cx ph = (1.0 / ab) * conj(be);
+      al = al * ph;
+      be = mk(ab, 0.0);
+    }
+    // compute_bk_eigenvalues decomposes (-G0, G1) = (Gamma_0, Gamma_1) (perturbation.py:436-437): alpha changes sign
+    const cx lam = cdiv(be, mk(tol - al.re, -al.im));
+    const double mod = (lane < N) ? cabs_(lam) : 1e308;
+    // rank by (modulus, original position): N <= 64, one eigenvalue per lane
+    int rank = 0;
+    for (int j = 0; j < N; ++j) {
+      const double mj = readlane_dyn_f64(mod, j);
+      rank += (mj < mod || (mj == mod && j < lane)) ? 1 : 0;
+    }
+    if (lane < N) {
+      eig_re[o + rank] = lam.re;
+      eig_im[o + rank] = lam.im;
+    }
+    const int nun = __popcll(__ballot(lane < N && mod > 1.0));
+    if (lane == 0) {
+      n_eig[draw] = N;
+      n_forward[draw] = ell;
+      n_unstable[draw] = nun;
+      status[draw] = DSGE_ST_OK;
+    }
+  }
+}
+
 }  // namespace dsge

@@ -84,6 +84,10 @@ int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr);
 
+int launch_gensys_bk(const double* A, const double* B, const double* C, int batch, int n, double tol, double* eig_re,
+                     double* eig_im, int32_t* n_eig, int32_t* n_forward, int32_t* n_unstable, int32_t* status,
+                     hipStream_t st);
+
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
 extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-reduction kernel only
 // process-wide settings of the fast Kalman kernel (launch_kalman.hip)

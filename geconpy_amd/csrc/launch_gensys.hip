@@ -6,7 +6,7 @@
 namespace dsge_host {
 
 long long* g_gensys_win_dbg = nullptr;  // debug: device int64[24], phase stamps of draw 0 of the window kernels
-int g_gensys_split = 1;  // 1 = three launches on the active window (dsge_gensys_win.hpp), 0 = the single-launch kernel
+int g_gensys_split = 1;  // 0 = single-launch kernel, 1 = window path (dsge_gensys_win.hpp) unless the pencil is small, 2 = always
 
 namespace {
 struct GwArena {
@@ -36,8 +36,13 @@ int gw_reserve(size_t bytes, void** out) {
 }
 
 // window path; *used = 0 when the batch does not fit it (the caller then takes the single-launch kernel)
+// bk != nullptr: eigenvalue mode (reduce + QZ + gensys_bk_kernel instead of the post-processing)
+struct BkOut {
+  double *re, *im;
+  int32_t *n_eig, *n_forward, *n_unstable;
+};
 int launch_gensys_split(const double* A, const double* B, const double* C, int batch, int n, double tol, double* T_out,
-                        int32_t* eu_out, int32_t* status, hipStream_t st, int* used) {
+                        int32_t* eu_out, int32_t* status, hipStream_t st, int* used, const BkOut* bk = nullptr) {
   *used = 0;
   void* base = nullptr;
   int rc = gw_reserve(256, &base);
@@ -75,8 +80,13 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
     hipLaunchKernelGGL(dsge::gensys_reduce_kernel, dim3(nb), dim3(64), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
                        cp, tol, wsp, g_gensys_win_dbg);
     hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg);
-    hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(64), lds3, st, nb, cp, tol, (const double*)wsp,
-                       T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg);
+    if (bk)
+      hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,
+                         bk->re + c0 * 2 * n, bk->im + c0 * 2 * n, bk->n_eig + c0, bk->n_forward + c0,
+                         bk->n_unstable + c0, status + c0);
+    else
+      hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(64), lds3, st, nb, cp, tol, (const double*)wsp,
+                         T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg);
     HIP_TRY(hipGetLastError());
   }
   *used = 1;
@@ -99,10 +109,28 @@ int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap) {
   return DSGE_SUCCESS;
 }
 
+int launch_gensys_bk(const double* A, const double* B, const double* C, int batch, int n, double tol, double* eig_re,
+                     double* eig_im, int32_t* n_eig, int32_t* n_forward, int32_t* n_unstable, int32_t* status,
+                     hipStream_t st) {
+  BkOut bk{eig_re, eig_im, n_eig, n_forward, n_unstable};
+  int used = 0;
+  int rc = launch_gensys_split(A, B, C, batch, n, tol, nullptr, nullptr, status, st, &used, &bk);
+  if (rc) return rc;
+  if (!used) return fail(DSGE_ERR_INVALID, "bk eigenvalues: the pencil does not fit the on-chip window path");
+  return DSGE_SUCCESS;
+}
+
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg) {
   int rc;
-  if (g_gensys_split && !dbg) {
+  // Small pencils (<= 24 KB of LDS in the single-launch kernel, i.e. >= 6 draws per CU already) gain nothing from the
+  // window path and would pay for its three launches and the shape read-back: RBC-sized models stay on one launch.
+  bool small = false;
+  {
+    int nc = 0, lc = 0;
+    if (gensys_caps(n, n_lead_hint, &nc, &lc) == DSGE_SUCCESS) small = dsge::gensys_smem_bytes(n, nc, lc) <= 24 * 1024;
+  }
+  if (g_gensys_split && !dbg && (!small || g_gensys_split == 2)) {
     int used = 0;
     if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used))) return rc;
     if (used) return DSGE_SUCCESS;

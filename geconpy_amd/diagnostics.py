@@ -85,3 +85,27 @@ def solvability_check_batched(A, B, C, D, solver="cycle_reduction", tol=1e-8, ma
         bad_sto = reached & ~bad_det & ~(sto <= norm_tol)
         failure[bad_sto] = "stochastic_norm"
     return dict(failure_step=failure, norm_deterministic=det, norm_stochastic=sto, T=T, R=R)
+
+
+def check_bk_condition_batched(A, B, C, D=None, tol=1e-8, return_value="bool"):
+    """Batched ``check_bk_condition`` (gEconpy/model/perturbation.py:448-565): per draw, the number of eigenvalues of the
+    Sims pencil with modulus > 1 must equal the number of forward-looking variables.
+
+    ``return_value="bool"`` -> boolean array; ``"dataframe"`` -> list of per-draw pandas DataFrames with the reference's
+    columns ``Modulus``, ``Real``, ``Imaginary`` (ascending modulus); ``None`` -> nothing (the counts are in
+    ``batched.bk_eigenvalues_batched``).  ``D`` is accepted for signature parity and ignored, as in the reference."""
+    if return_value not in ("dataframe", "bool", None):
+        raise ValueError(f'Unknown return type "{return_value}"')
+    out = batched.bk_eigenvalues_batched(A, B, C, tol=tol)
+    if return_value is None:
+        return None
+    if return_value == "bool":
+        return out["satisfied"]
+    import pandas as pd
+
+    frames = []
+    for i in range(out["real"].shape[0]):
+        m = int(out["n_eig"][i])
+        re, im = out["real"][i, :m], out["imag"][i, :m]
+        frames.append(pd.DataFrame({"Modulus": np.hypot(re, im), "Real": re, "Imaginary": im}))
+    return frames

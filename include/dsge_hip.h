@@ -143,6 +143,25 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
                              int32_t* eu_out, int32_t* status);
 
 /*
+ * Blanchard-Kahn eigenvalues.  Replaces compute_bk_eigenvalues / check_bk_condition
+ * (gEconpy/model/perturbation.py:412-445, :448-565; the graph twin check_bk_condition_pt :586-625 computes the same
+ * counts from a dense eig of the regularised pencil): the generalized eigenvalues of the Sims pencil of _gensys_setup
+ * (gensys.py:568-614), lambda_i = beta_i / (alpha_i + tol) with LAPACK's normalisation (beta real, non-negative), sorted
+ * by ascending modulus, and the two counts the condition compares.  Runs the reduce + QZ launches of the window path.
+ *   eig_re, eig_im : [batch][2n]  the first n_eig[i] = n + n_forward[i] entries of a row are valid, the rest 0
+ *   n_forward      : [batch]      columns of C with an absolute column sum > tol
+ *   n_unstable     : [batch]      eigenvalues with modulus > 1 (an infinite root, alpha = 0, counts: beta / tol)
+ *   status         : [batch]      DSGE_ST_OK, or NOT_CONVERGED | GENSYS_QZ_FAIL (n_eig = 0)
+ * The condition holds for draw i iff n_forward[i] == n_unstable[i].
+ */
+int dsge_bk_eigenvalues_batched(const double* A, const double* B, const double* C, int batch, int n, double tol,
+                                double* eig_re, double* eig_im, int32_t* n_eig, int32_t* n_forward,
+                                int32_t* n_unstable, int32_t* status, void* stream);
+int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const double* C, int batch, int n, double tol,
+                                     double* eig_re, double* eig_im, int32_t* n_eig, int32_t* n_forward,
+                                     int32_t* n_unstable, int32_t* status);
+
+/*
  * Steady-state switch of the fast Kalman kernel.  The covariance recursion of a time-invariant model
  * does not depend on the data; once max|P_{t+1|t} - P_{t|t-1}| <= tol * max|P| (and while the
  * missing-data mask stays the same) the kernel reuses F^-1, K and det F and runs only the mean
@@ -155,9 +174,11 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
-/* gensys runs as three launches on the active window of the pencil (real reduction, complex QZ + reordering on the
- * (N - z) x (N - z) block left after the structural deflation, post-processing; 3 / 3 / 2 draws per CU instead of 1 at
- * N = 52) when the batch fits; enable = 0 forces the single-launch kernel (tests compare both).  Process-wide. */
+/* gensys runs as three launches on the active window of the pencil -- real reduction; complex QZ + reordering on the
+ * (N - z) x (N - z) block left after the structural deflation, with H and T sharing one LDS array and the accumulated
+ * right transformation kept in HBM/L2; post-processing -- 4 / 6-7 / 2 draws per CU instead of 1 at N = 52.  enable = 1
+ * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
+ * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide. */
 int dsge_set_gensys_split(int enable);
 /* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
  * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the

@@ -32,6 +32,8 @@ from .cycle_reduction import (  # noqa: F401
     solve_policy_function_with_cycle_reduction,
 )
 from .gensys_qz import (  # noqa: F401
+    check_bk_condition,
+    compute_bk_eigenvalues,
     gensys,
     gensys_core,
     gensys_setup,

@@ -214,3 +214,23 @@ def gensys_T_success(A, B, C, D, tol=1e-8):
     out = gensys_core(g0, g1, c, psi, pi, tol if tol > 0 else _EPS)
     eu = out[7]
     return np.ascontiguousarray(out[0][:n, :n]), bool(eu[0] == 1 and eu[1] == 1), eu
+
+
+def compute_bk_eigenvalues(A, B, C, D, tol=1e-8):
+    """``compute_bk_eigenvalues`` (gEconpy/model/perturbation.py:412-445): ordered QZ of ``(-G0, G1)`` from
+    ``gensys_setup`` (i.e. of Sims' (Gamma_0, Gamma_1)), ``lambda = diag(BB) / (diag(AA) + tol)``, sorted by ascending
+    modulus; returns (real, imag, n_forward)."""
+    G0, G1, *_ = gensys_setup(A, B, C, D, tol)
+    AA, BB, *_ = sla.ordqz(-G0, G1, sort="ouc", output="complex")
+    eig = np.diag(BB) / (np.diag(AA) + tol)
+    eig = eig[np.argsort(np.abs(eig))]
+    n_forward = int((np.abs(np.asarray(C)).sum(axis=0) > tol).sum())
+    return np.real(eig), np.imag(eig), n_forward
+
+
+def check_bk_condition(A, B, C, D, tol=1e-8):
+    """The boolean of ``check_bk_condition`` (perturbation.py:448-565): #{|lambda| > 1} == n_forward.
+    Returns (satisfied, n_forward, n_unstable)."""
+    re, im, n_forward = compute_bk_eigenvalues(A, B, C, D, tol)
+    n_unstable = int((np.sqrt(re**2 + im**2) > 1).sum())
+    return n_forward == n_unstable, n_forward, n_unstable

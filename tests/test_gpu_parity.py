@@ -1040,7 +1040,11 @@ def test_gensys_window_path_matches_single_launch(ref_goldens, failure_golden):
     A2[3] += 1e-3 * rng.standard_normal(A2[3].shape)
     sets.append((A2, B2, C2, D2))
     for A, B, C, D in sets:
-        out1 = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        _lib.check(lib.dsge_set_gensys_split(2))  # also for the small goldens (auto mode keeps them on one launch)
+        try:
+            out1 = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        finally:
+            _lib.check(lib.dsge_set_gensys_split(1))
         _lib.check(lib.dsge_set_gensys_split(0))
         try:
             out0 = batched.gensys_batched(A, B, C, D, tol=1e-8)
@@ -1055,3 +1059,45 @@ def test_gensys_window_path_matches_single_launch(ref_goldens, failure_golden):
             if out1["eu"][i][0] > -2:
                 assert_allclose(out1["T"][i], T_ref, atol=1e-8)
             assert bool(ok) == bool(out1["status"][i] == 0)
+
+
+def test_bk_eigenvalues_batched():
+    """dsge_bk_eigenvalues_batched (reduce + QZ launches of the window path) vs the reference's compute_bk_eigenvalues
+    (golden, tests/golden/make_bk_golden.py) and the oracle: moduli to 1e-7 relative (finite roots; the 1/tol-sized
+    'infinite' ones only in magnitude), counts exact, BK verdict = the eu verdict of gensys on the same systems."""
+    import os
+
+    from geconpy_amd.diagnostics import check_bk_condition_batched
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "bk_eigenvalues.npz"))
+    rg = np.load(os.path.join(here, "golden", "reference_goldens.npz"))
+    fg = np.load(os.path.join(here, "golden", "failure_cases.npz"))
+    groups = [[(k, tuple(rg[f"{k}_{x}"] for x in "ABCD"))] for k in ("one_block", "rbc_2_block", "full_nk")]
+    b = wl.sw_shaped_batch(2)
+    groups.append([(k, tuple(fg[f"{k}_{x}"] for x in "ABCD")) for k in ("ok", "nonunique", "noexist")]
+                  + [(f"sw{i}", tuple(b[x][i] for x in "ABCD")) for i in range(2)])
+    for grp in groups:
+        A, B, C, D = (np.stack([c[1][j] for c in grp]) for j in range(4))
+        out = batched.bk_eigenvalues_batched(A, B, C, tol=1e-8)
+        assert np.all(out["status"] == 0)
+        for i, (name, _) in enumerate(grp):
+            m = int(out["n_eig"][i])
+            ref_mod = np.hypot(g[f"{name}_real"], g[f"{name}_imag"])
+            assert m == ref_mod.size and int(out["n_forward"][i]) == int(g[f"{name}_n_forward"])
+            mod = np.hypot(out["real"][i, :m], out["imag"][i, :m])
+            assert np.all(np.diff(mod) >= 0)
+            finite = ref_mod < 1e4
+            assert_allclose(mod[finite], ref_mod[finite], rtol=1e-7, atol=1e-10)
+            # infinite roots (alpha = 0): beta / tol depends on the scaling of the Schur form, only the size is meaningful
+            assert np.all(mod[~finite] > 1e6)
+            assert int(out["n_unstable"][i]) == int((ref_mod > 1).sum())
+            # complex eigenvalues of a real pencil come in conjugate pairs: compare as multisets of (re, |im|)
+            ref_pairs = np.sort_complex(g[f"{name}_real"][finite] + 1j * np.abs(g[f"{name}_imag"][finite]))
+            dev_pairs = np.sort_complex(out["real"][i, :m][finite] + 1j * np.abs(out["imag"][i, :m][finite]))
+            assert_allclose(dev_pairs, ref_pairs, rtol=1e-6, atol=1e-8)
+        ok = check_bk_condition_batched(A, B, C, D, return_value="bool")
+        eu = batched.gensys_batched(A, B, C, D, tol=1e-8)["eu"]
+        assert np.array_equal(ok, (eu[:, 0] == 1) & (eu[:, 1] == 1))
+        frames = check_bk_condition_batched(A, B, C, D, return_value="dataframe")
+        assert list(frames[0].columns) == ["Modulus", "Real", "Imaginary"] and len(frames[0]) == int(out["n_eig"][0])

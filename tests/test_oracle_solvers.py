@@ -183,3 +183,36 @@ def test_policy_adjoints_match_finite_differences(ref_goldens):
         assert cp and cm
         fd = np.sum(T_bar * (Tp - Tm)) / (2 * eps)
         assert_allclose(np.sum(M_bar * dM), fd, rtol=1e-5, atol=1e-8)
+
+
+def _bk_cases():
+    import os
+
+    from geconpy_amd import workloads as wl
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "bk_eigenvalues.npz"))
+    rg = np.load(os.path.join(here, "golden", "reference_goldens.npz"))
+    fg = np.load(os.path.join(here, "golden", "failure_cases.npz"))
+    cases = {k: tuple(rg[f"{k}_{x}"] for x in "ABCD") for k in ("one_block", "rbc_2_block", "full_nk")}
+    cases.update({k: tuple(fg[f"{k}_{x}"] for x in "ABCD") for k in ("ok", "nonunique", "noexist")})
+    b = wl.sw_shaped_batch(2)
+    cases.update({f"sw{i}": tuple(b[x][i] for x in "ABCD") for i in range(2)})
+    return g, cases
+
+
+def test_bk_eigenvalues_match_extracted_reference():
+    """oracle.compute_bk_eigenvalues vs the reference's own compute_bk_eigenvalues (perturbation.py:412-445, executed by
+    AST extraction in tests/golden/make_bk_golden.py): same LAPACK call, so the values agree to rounding; the BK verdicts
+    agree with the eu codes of the same systems."""
+    g, cases = _bk_cases()
+    for name, (A, B, C, D) in cases.items():
+        re, im, nf = oracle.compute_bk_eigenvalues(A, B, C, D, 1e-8)
+        assert nf == int(g[f"{name}_n_forward"])
+        assert_allclose(np.hypot(re, im), np.hypot(g[f"{name}_real"], g[f"{name}_imag"]), rtol=1e-9, atol=1e-12)
+        ok, n_forward, n_unstable = oracle.check_bk_condition(A, B, C, D)
+        assert ok == (name not in ("nonunique", "noexist"))
+        if name == "nonunique":
+            assert n_unstable < n_forward
+        if name == "noexist":
+            assert n_unstable > n_forward
