@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--max-iter", type=int, default=1000)
-    ap.add_argument("--workload", default="sw_shaped", choices=["sw_shaped", "rbc"])
+    ap.add_argument("--workload", default="sw_shaped", choices=["sw_shaped", "rbc", "full_nk"])
     ap.add_argument("--solver", default="cycle_reduction", choices=["cycle_reduction", "gensys"])
     ap.add_argument("--from-theta", action="store_true",
                     help="rbc workload only: start each step from the parameter draws (generated Jacobian kernel on the "
@@ -126,6 +126,9 @@ def main():
     if args.workload == "rbc":  # BASELINE configs[1] (informational; the metric is quoted on sw_shaped)
         n, k, p, T_len = 8, 1, 1, 200
         shard, om = wl.rbc_batch(hi - lo, first_draw=lo)
+    elif args.workload == "full_nk":  # SURVEY 8d sanity configuration (informational)
+        n, k, p, T_len = 24, 4, 3, 200
+        shard, om = wl.full_nk_batch(hi - lo, first_draw=lo)
     else:
         sh = wl.SW_SHAPE
         n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
@@ -313,6 +316,8 @@ def main():
             "config": {
                 "workload": (f"sw_shaped synthetic (SURVEY 8d): n=m={n}, n_state=18, n_lead=12, k={k}, p={p}, "
                              f"T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[2])") if args.workload == "sw_shaped"
+                else (f"full_nk golden system with seeded 1e-3 relative perturbations (SURVEY 8d sanity configuration): n={n}, "
+                      f"k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU") if args.workload == "full_nk"
                 else f"rbc_linearized closed form: n={n}, k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[1])",
                 "global_batch": global_batch,
                 "solver": args.solver,

@@ -197,3 +197,35 @@ def rbc_batch(batch, first_draw=0, seed=1, T_len=200):
     Z[0, RBC_VARIABLES.index("Y")] = 1.0
     y = np.random.default_rng(0).normal(0, 0.05, (T_len, 1))
     return dict(A=A, B=B, C=C, D=D, sigma=th["sigma_A"][:, None]), dict(Z=Z, Hdiag=np.zeros(1), y=y)
+
+
+FULL_NK_SEED0 = 20260777
+
+
+def full_nk_batch(batch, first_draw=0, T_len=200, rel=1e-3):
+    """SURVEY 8d, non-synthetic sanity configuration: the reference's ``full_nk`` golden system (24 variables, 4 shocks,
+    14 forward-looking variables, pencil N = 38; tests/_resources/expected_matrices.py via tests/golden/reference_goldens.npz)
+    replicated with seeded relative perturbations of the non-zero entries of A, B, C (``default_rng(FULL_NK_SEED0 + i)``
+    for draw i).  Observed: the first three variables with measurement error 1e-4 (4 shocks, 3 series), ``T_len`` periods
+    of ``default_rng(0).normal(0, 0.01)`` data.  Same layout as ``rbc_batch``."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        "reference_goldens.npz")
+    g = np.load(path)
+    A0, B0, C0, D0 = (np.asarray(g[f"full_nk_{x}"], dtype=np.float64) for x in "ABCD")
+    n, k = D0.shape
+    A = np.empty((batch, n, n))
+    B = np.empty((batch, n, n))
+    C = np.empty((batch, n, n))
+    for j in range(batch):
+        rng = np.random.default_rng(FULL_NK_SEED0 + first_draw + j)
+        A[j] = A0 * (1.0 + rel * rng.standard_normal(A0.shape))
+        B[j] = B0 * (1.0 + rel * rng.standard_normal(B0.shape))
+        C[j] = C0 * (1.0 + rel * rng.standard_normal(C0.shape))
+    D = np.broadcast_to(D0, (batch, n, k)).copy()
+    p = 3
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(0).normal(0, 0.01, (T_len, p))
+    return dict(A=A, B=B, C=C, D=D, sigma=np.full((batch, k), 0.01)), dict(Z=Z, Hdiag=np.full(p, 1e-4), y=y)

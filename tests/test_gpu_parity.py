@@ -1101,3 +1101,24 @@ def test_bk_eigenvalues_batched():
         assert np.array_equal(ok, (eu[:, 0] == 1) & (eu[:, 1] == 1))
         frames = check_bk_condition_batched(A, B, C, D, return_value="dataframe")
         assert list(frames[0].columns) == ["Modulus", "Real", "Imaginary"] and len(frames[0]) == int(out["n_eig"][0])
+
+
+@pytest.mark.parametrize("solver", ["cycle_reduction", "gensys"])
+def test_full_nk_perturbed_workload(solver):
+    """SURVEY 8d sanity configuration: the reference's full_nk golden system (N = 38) under seeded 1e-3 relative
+    perturbations; fused device evaluation vs the oracle on every draw, both solvers."""
+    shard, om = wl.full_nk_batch(12, first_draw=5, T_len=80)
+    q = shard["sigma"] ** 2
+    out = batched.solve_kalman_logp_batched(shard["A"], shard["B"], shard["C"], shard["D"], q, om["Z"], om["y"],
+                                            Hdiag=om["Hdiag"], solver=solver, tol=1e-8, max_iter=1000)
+    n_ok = 0
+    for i in range(12):
+        r = oracle.solve_kalman_logp(shard["A"][i], shard["B"][i], shard["C"][i], shard["D"][i], np.diag(q[i]), om["Z"],
+                                     om["y"], H=np.diag(om["Hdiag"]), solver=solver, tol=1e-8, max_iter=1000)
+        assert bool(r["success"]) == bool(out["status"][i] == 0)
+        if r["success"]:
+            assert_allclose(out["logp"][i], r["logp"], rtol=LOGP_RTOL)
+            n_ok += 1
+        else:
+            assert out["logp"][i] == -np.inf
+    assert n_ok >= 10
