@@ -95,10 +95,12 @@ __global__ __launch_bounds__(64) void gensys_shape_kernel(const double* __restri
     const int ell = __popcll(__ballot(lane < n && cs > tol));
     const int z = n - __popcll(__ballot(anz != 0));
     if (lane == 0) {
-      atomicMax(out + 0, ell);
-      atomicMax(out + 1, n - z + ell);
-      atomicMax(out + 2, z);
-      atomicMin(out + 3, z);
+      // the four records are monotone: a (possibly stale) plain read filters out almost every atomic -- 16 k atomics on four
+      // addresses took 0.15 ms
+      if (ell > __atomic_load_n(out + 0, __ATOMIC_RELAXED)) atomicMax(out + 0, ell);
+      if (n - z + ell > __atomic_load_n(out + 1, __ATOMIC_RELAXED)) atomicMax(out + 1, n - z + ell);
+      if (z > __atomic_load_n(out + 2, __ATOMIC_RELAXED)) atomicMax(out + 2, z);
+      if (z < __atomic_load_n(out + 3, __ATOMIC_RELAXED)) atomicMin(out + 3, z);
     }
   }
 }

@@ -5,7 +5,7 @@ import numpy as np, torch
 from geconpy_amd import _lib, workloads as wl
 from geconpy_amd.batched import lead_hint
 lib = _lib.load(); dev = torch.device("cuda", 0); nb = 4096
-for n in (8, 16, 24, 32, 40, 44):
+for n in (8, 16, 24, 32, 40, 44, 48):
     ns, nl, k = max(2, int(0.45 * n)), max(1, int(0.3 * n)), min(7, n // 2)
     base = [wl.sw_shaped_system(2000 + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(16)]
     A, B, C = (torch.as_tensor(np.tile(np.stack([b[x] for b in base]), (nb // 16, 1, 1)), device=dev) for x in range(3))
@@ -16,4 +16,14 @@ for n in (8, 16, 24, 32, 40, 44):
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
-    print(f"n={n:2d} N={n + nlh:2d}: gensys {e0.elapsed_time(e1) / 2:.2f} ms per {nb} draws; ok {int((st == 0).sum())}")
+    t_auto = e0.elapsed_time(e1) / 2
+    _lib.check(lib.dsge_set_gensys_split(0))  # the single-launch kernel for comparison
+    try:
+        run(); torch.cuda.synchronize()
+        e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
+        t_single = e0.elapsed_time(e1) / 2
+    except _lib.DsgeHipError:
+        t_single = float("nan")  # does not fit the 160 KB of LDS
+    finally:
+        _lib.check(lib.dsge_set_gensys_split(1))
+    print(f"n={n:2d} N={n + nlh:2d}: gensys {t_auto:.2f} ms per {nb} draws (single-launch kernel {t_single:.2f} ms); ok {int((st == 0).sum())}")
