@@ -12,30 +12,49 @@ namespace {
 struct GwArena {
   void* ptr = nullptr;
   size_t cap = 0;
+  hipStream_t stream = nullptr;
+  bool used = false;
 };
-GwArena g_gw_arena[16];
+// One workspace per (device, stream): the chunked host path keeps two pipelines in flight on two streams, and a
+// workspace shared between them would be overwritten by the next chunk's reduce launch while the previous chunk's QZ /
+// post launches still read it.
+constexpr int GW_SLOTS = 4;
+GwArena g_gw_arena[16][GW_SLOTS];
 constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
 
-int gw_reserve(size_t bytes, void** out) {
+int gw_reserve(size_t bytes, hipStream_t st, void** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
-  GwArena& a = g_gw_arena[dev];
-  if (a.cap < bytes) {
-    if (a.ptr) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(a.ptr));
-      a.ptr = nullptr;
-      a.cap = 0;
-    }
-    HIP_TRY(hipMalloc(&a.ptr, bytes));
-    a.cap = bytes;
+  GwArena* a = nullptr;
+  for (auto& slot : g_gw_arena[dev])
+    if (slot.used && slot.stream == st) a = &slot;
+  if (!a)
+    for (auto& slot : g_gw_arena[dev])
+      if (!slot.used) {
+        a = &slot;
+        break;
+      }
+  if (!a) {  // more streams than slots: recycle the first one once everything in flight has finished
+    HIP_TRY(hipDeviceSynchronize());
+    a = &g_gw_arena[dev][0];
   }
-  *out = a.ptr;
+  a->used = true;
+  a->stream = st;
+  if (a->cap < bytes) {
+    if (a->ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a->ptr));
+      a->ptr = nullptr;
+      a->cap = 0;
+    }
+    HIP_TRY(hipMalloc(&a->ptr, bytes));
+    a->cap = bytes;
+  }
+  *out = a->ptr;
   return DSGE_SUCCESS;
 }
 
-// window path; *used = 0 when the batch does not fit it (the caller then takes the single-launch kernel)
 // bk != nullptr: eigenvalue mode (reduce + QZ + gensys_bk_kernel instead of the post-processing)
 struct BkOut {
   double *re, *im;
@@ -45,7 +64,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
                         int32_t* eu_out, int32_t* status, hipStream_t st, int* used, const BkOut* bk = nullptr) {
   *used = 0;
   void* base = nullptr;
-  int rc = gw_reserve(256, &base);
+  int rc = gw_reserve(256, st, &base);
   if (rc) return rc;
   int* shape_d = (int*)base;  // the first 256 bytes of the arena hold the shape record
   int shape[4] = {0, 0, 0, n};
@@ -69,7 +88,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   size_t chunk = GW_WORKSPACE_LIMIT / per_draw;
   if (chunk < 256) chunk = 256;
   if (chunk > (size_t)batch) chunk = (size_t)batch;
-  if ((rc = gw_reserve(256 + chunk * per_draw, &base))) return rc;
+  if ((rc = gw_reserve(256 + chunk * per_draw, st, &base))) return rc;
   double* wsp = (double*)((char*)base + 256);
   if ((rc = set_lds(dsge::gensys_reduce_kernel, lds1))) return rc;
   if ((rc = set_lds(dsge::gensys_qzwin_kernel, lds2))) return rc;

@@ -1122,3 +1122,21 @@ def test_full_nk_perturbed_workload(solver):
         else:
             assert out["logp"][i] == -np.inf
     assert n_ok >= 10
+
+
+def test_fused_host_path_gensys_chunks_on_two_streams():
+    """The host-pointer fused call stages the batch in chunks on two streams; with solver="gensys" each stream must own its
+    window workspace (a shared one would be overwritten by the next chunk's reduce launch).  1024 draws (2 chunks in
+    flight) must reproduce four independent 256-draw calls (one chunk each) bit for bit."""
+    om = wl.sw_shaped_observation_model()
+    b = wl.sw_shaped_batch(1024)
+    q = b["sigma"] ** 2
+    y = om["y"][:30]
+    kw = dict(Hdiag=om["Hdiag"], solver="gensys", tol=1e-8)
+    big = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, **kw)
+    for c in range(4):
+        sl = slice(256 * c, 256 * (c + 1))
+        part = batched.solve_kalman_logp_batched(b["A"][sl], b["B"][sl], b["C"][sl], b["D"][sl], q[sl], om["Z"], y, **kw)
+        assert np.array_equal(part["status"], big["status"][sl])
+        assert np.array_equal(part["logp"], big["logp"][sl])
+    assert np.all(big["status"] == 0)
