@@ -1140,3 +1140,50 @@ def test_fused_host_path_gensys_chunks_on_two_streams():
         assert np.array_equal(part["status"], big["status"][sl])
         assert np.array_equal(part["logp"], big["logp"][sl])
     assert np.all(big["status"] == 0)
+
+
+def test_gensys_window_path_fuzz():
+    """Window path over random sizes and structures (number of state variables, of forward-looking variables, of
+    non-state variables; state columns scattered instead of leading; explosive variants with too few / too many stable
+    roots): eu and the success flag exact against the oracle (LAPACK), T to 1e-8 wherever the reference defines it; the
+    single-launch kernel must agree where it fits."""
+    lib = _lib.load()
+    rng = np.random.default_rng(2026)
+    shapes = [(6, 2, 1), (9, 4, 3), (13, 5, 2), (20, 9, 7), (27, 12, 6), (33, 14, 11), (40, 18, 12), (47, 20, 14), (31, 31, 9)]
+    for n, ns, nl in shapes:
+        k = min(3, n // 2)
+        sysl = []
+        for j in range(4):
+            A, B, C, D, _ = wl.sw_shaped_system(7000 + 13 * n + j, n=n, n_state=ns, n_lead=nl, k=k)
+            if j == 1:  # scatter the variables: a random symmetric permutation of variables (rows stay equations)
+                perm = rng.permutation(n)
+                A, B, C = A[:, perm], B[:, perm], C[:, perm]
+            if j == 2:  # more unstable roots than forward-looking variables (no stable solution)
+                A = 2.5 * A
+            if j == 3:  # fewer unstable roots than forward-looking variables (indeterminacy: eu = [1, 0, k] on most sizes)
+                C = 6.0 * C
+            sysl.append((A, B, C, D))
+        A, B, C, D = (np.stack([s_[i] for s_ in sysl]) for i in range(4))
+        _lib.check(lib.dsge_set_gensys_split(2))
+        try:
+            out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        finally:
+            _lib.check(lib.dsge_set_gensys_split(1))
+        single = None
+        _lib.check(lib.dsge_set_gensys_split(0))
+        try:
+            single = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        except _lib.DsgeHipError:
+            single = None  # the single-launch kernel does not fit this pencil into 160 KB of LDS
+        finally:
+            _lib.check(lib.dsge_set_gensys_split(1))
+        for i in range(4):
+            T_ref, ok, eu_ref = oracle.gensys_T_success(A[i], B[i], C[i], D[i], tol=1e-8)
+            assert list(out["eu"][i]) == [int(x) for x in eu_ref], (n, ns, nl, i, out["eu"][i], eu_ref)
+            assert bool(out["status"][i] == 0) == bool(ok)
+            scale = max(1.0, np.abs(T_ref).max())
+            if eu_ref[0] > -2:
+                assert_allclose(out["T"][i], T_ref, atol=1e-8 * scale, err_msg=str((n, ns, nl, i)))
+            if single is not None:
+                assert np.array_equal(single["eu"][i], out["eu"][i])
+                assert_allclose(single["T"][i], out["T"][i], atol=1e-8 * scale)
