@@ -281,7 +281,8 @@ def main():
                                                                              | (om["Z"] != 0).any(axis=0)))
         ex = executed_flops(n, k, p, T_len, s_cols, stats.get("lead_columns", n), u_dim, cr_it,
                             stats.get("full_steps_mean", T_len), 8, selector=bool(hints[1]))
-        names = {"solver": f"dsge::cr_compact_kernel<{(n + 7) // 8}>" if args.solver == "cycle_reduction" else "dsge::gensys_kernel",
+        names = {"solver": f"dsge::cr_compact_kernel<{(n + 7) // 8}>" if args.solver == "cycle_reduction" else ("dsge::gensys_reduce_kernel + gensys_qzwin_kernel + gensys_post_kernel (window path, three launches)"
+                                if n > 16 else "dsge::gensys_kernel"),
                  "assemble": f"dsge::assemble_kernel<{(n + 7) // 8}>",
                  "kalman": f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>"}
         kern = {}

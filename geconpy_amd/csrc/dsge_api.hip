@@ -697,17 +697,17 @@ int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, 
 }
 
 // Debug hook: enable = 1 allocates the stamp buffer of the window kernels (draw 0 of each launch: reduce [0..4], QZ [8..11],
-// post [16..23]); cycles_out (host int64[24], may be NULL) reads it back; enable = 0 frees it.
+// eu [16..19], post [20..26]); cycles_out (host int64[32], may be NULL) reads it back; enable = 0 frees it.
 int dsge_debug_gensys_window_phases(int enable, long long* cycles_out) {
   int rc = ensure_device();
   if (rc) return rc;
   if (enable && !g_gensys_win_dbg) {
-    HIP_TRY(hipMalloc((void**)&g_gensys_win_dbg, 24 * sizeof(long long)));
-    HIP_TRY(hipMemset(g_gensys_win_dbg, 0, 24 * sizeof(long long)));
+    HIP_TRY(hipMalloc((void**)&g_gensys_win_dbg, 32 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_gensys_win_dbg, 0, 32 * sizeof(long long)));
   }
   if (cycles_out && g_gensys_win_dbg) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(cycles_out, g_gensys_win_dbg, 24 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cycles_out, g_gensys_win_dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
   }
   if (!enable && g_gensys_win_dbg) {
     (void)hipFree(g_gensys_win_dbg);

@@ -23,7 +23,7 @@ struct GwCaps {
 };
 
 struct GwOffsets {  // per draw, in doubles
-  size_t meta, R0, H12, T12, X1, HR, TR, XR, HC, TC, MC, XC, total;
+  size_t meta, R0, H12, T12, X1, HR, TR, XR, HC, TC, MC, XC, BM, PHI, total;
 };
 
 __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
@@ -43,12 +43,17 @@ __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
   o.TC = p, p += 2 * ww;
   o.MC = p, p += 2 * ww;
   o.XC = p, p += 2 * wl;
+  o.BM = p, p += 2 * wl;   // Bm (#lead x nu), leading dimension wcap
+  o.PHI = p, p += 2 * ww;  // Phi_b (ns2 x nu), leading dimension wcap
   o.total = (p + 1) & ~(size_t)1;
   return o;
 }
 
 // meta (int32[16] at the head of a draw's workspace)
-enum { GW_N = 0, GW_ELL = 1, GW_Z = 2, GW_FLAG = 3, GW_CONV = 4, GW_NS2 = 5, GW_MASK_LO = 6, GW_MASK_HI = 7 };
+enum {
+  GW_N = 0, GW_ELL = 1, GW_Z = 2, GW_FLAG = 3, GW_CONV = 4, GW_NS2 = 5, GW_MASK_LO = 6, GW_MASK_HI = 7,
+  GW_EU0 = 8, GW_EU1 = 9, GW_EU2 = 10, GW_HAVE_T = 11  // written by the eu launch, read by the post launch
+};
 
 // The accumulated right transformation Zr of the reduce launch is only needed once rows < z of H are dead (they leave
 // the chip after the deflation phase): when EVERY draw of the batch has enough of them (zmin = n - scap rows of H hold
@@ -65,10 +70,13 @@ __host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
 __host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array; M stays in HBM / L2 (GsLayout)
   return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
 }
+__host__ __device__ inline size_t gw_eu_smem(const GwCaps& c) {  // X2, V2, Bm + singular values
+  return ((size_t)c.wcap * (c.lcap | 1) + (size_t)c.lcap * (c.lcap | 1) + (size_t)c.lcap * (c.wcap | 1)) * 16 + 128 * 8;
+}
 __host__ __device__ inline size_t gw_post_smem(const GwCaps& c) {
-  const size_t cplx = (size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1) + (size_t)c.lcap * (c.wcap | 1) +
-                      (size_t)c.lcap * (c.lcap | 1);
-  const size_t real = (size_t)(c.wcap + c.lcap) * (c.scap | 1) + (size_t)c.zcap * (c.scap | 1) + 128;
+  const size_t cplx = (size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.lcap * (c.wcap | 1);
+  const size_t real = (size_t)(c.wcap + c.lcap) * (c.scap | 1) + (size_t)c.zcap * (c.scap | 1) +
+                      (size_t)c.zcap * (c.zcap | 1) + (size_t)c.zcap * ((c.wcap + c.lcap) | 1);
   return cplx * 16 + real * 8;
 }
 
@@ -628,66 +636,38 @@ __device__ __forceinline__ void jacobi_svd_rr(cx* G, int ldg, int nr, int nc, cx
   wave_sync();
 }
 
-// ---- launch 3: existence / uniqueness (gensys.py:267-310) and T in the window basis ---------------------------------------
-__global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
-                                                          double* __restrict__ T_out, int32_t* __restrict__ eu_out,
-                                                          int32_t* __restrict__ status, long long* __restrict__ dbg) {
+// ---- launch 3: existence / uniqueness (gensys.py:267-310): coincident zeros, SVD of Q2 Pi, the eu codes, Bm and Phi_b.
+// Needs only X2 (w x #lead), V2 and Bm on the chip (15 KB at N = 52 => 10 draws per CU): the Jacobi sweeps are a chain
+// of short dependent steps, so occupancy is what makes them cheap.
+__global__ __launch_bounds__(64) void gensys_eu_kernel(int batch, GwCaps cp, double tol, double* __restrict__ ws,
+                                                        long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
-  const int n = cp.n;
-  const int ldh = cp.wcap | 1, ldx = cp.lcap | 1, lds_ = cp.scap | 1;
-  cx* Hc = reinterpret_cast<cx*>(smem);
-  cx* Tc = Hc + (size_t)cp.wcap * ldh;
-  cx* Mc = Tc + (size_t)cp.wcap * ldh;
-  cx* Xc = Mc + (size_t)cp.wcap * ldh;
-  cx* Bm = Xc + (size_t)cp.wcap * ldx;   // lcap x ldh
-  cx* V2 = Bm + (size_t)cp.lcap * ldh;   // lcap x ldx
-  double* RR = reinterpret_cast<double*>(V2 + (size_t)cp.lcap * ldx);  // (wcap + lcap) x lds_: [Re(M1 Yb Ms^H); Re(Bm B22 Ms2^H)]
-  double* E = RR + (size_t)(cp.wcap + cp.lcap) * lds_;                // zcap x lds_
-  double* s1 = E + (size_t)cp.zcap * lds_;
+  const int ldx = cp.lcap | 1, ldb = cp.wcap | 1;
+  cx* Xc = reinterpret_cast<cx*>(smem);
+  cx* V2 = Xc + (size_t)cp.wcap * ldx;  // lcap x ldx
+  cx* Bm = V2 + (size_t)cp.lcap * ldx;  // lcap x ldb
+  double* s1 = reinterpret_cast<double*>(Bm + (size_t)cp.lcap * ldb);
   double* s2 = s1 + 64;
   const double rs = (tol > 0.0) ? tol : 2.220446049250313e-16;
   const GwOffsets wo = gw_offsets(cp);
-#define PH(i, j) Hc[(i)*ldh + (j)]
-#define PT(i, j) Tc[(i)*ldh + (j)]
-#define PM(i, j) Mc[(i)*ldh + (j)]
 #define PX(i, j) Xc[(i)*ldx + (j)]
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    const size_t off = (size_t)draw * n * n;
-    const double* wd = ws + (size_t)draw * wo.total;
-    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
-    int eu0 = 0, eu1 = 0, eu2 = 0, st_extra = 0;
-    bool have_T = false;
+    double* wd = ws + (size_t)draw * wo.total;
+    int* meta = reinterpret_cast<int*>(wd + wo.meta);
+    int eu0 = 0, eu1 = 0, eu2 = 0, have_T = 0;
     wave_sync();
     GW_STAMP(16);
-    if (meta[GW_FLAG] != 0) {
+    if (meta[GW_FLAG] != 0 || meta[GW_CONV] == 0) {
       eu0 = eu1 = -3;
-      st_extra = DSGE_ST_GENSYS_TOO_BIG;
-    } else if (meta[GW_CONV] == 0) {
-      eu0 = eu1 = -3;
-      st_extra = DSGE_ST_GENSYS_QZ_FAIL;
     } else {
       const int N = meta[GW_N], ell = meta[GW_ELL], z = meta[GW_Z], ns2 = meta[GW_NS2];
-      const int w = N - z, sp = n - z, nu = w - ns2;
-      const unsigned long long a_colmask =
-          (unsigned long long)(unsigned)meta[GW_MASK_LO] | ((unsigned long long)(unsigned)meta[GW_MASK_HI] << 32);
-      const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-      const unsigned long long zmask = ~a_colmask & nmask;
+      const int w = N - z, nu = w - ns2;
       const cx* HC = reinterpret_cast<const cx*>(wd + wo.HC);
       const cx* TC = reinterpret_cast<const cx*>(wd + wo.TC);
-      const cx* MC = reinterpret_cast<const cx*>(wd + wo.MC);
       const cx* XC = reinterpret_cast<const cx*>(wd + wo.XC);
       const double* R0 = wd + wo.R0;
-      const double* H12 = wd + wo.H12;
-      const double* T12 = wd + wo.T12;
       const double* X1 = wd + wo.X1;
-      for (int idx = lane; idx < w * w; idx += 64) {
-        const int i = idx / w, j = idx - i * w;
-        const size_t o = (size_t)i * cp.wcap + j;
-        PH(i, j) = HC[o];
-        PT(i, j) = TC[o];
-        PM(i, j) = MC[(size_t)j * cp.wcap + i];  // stored transposed
-      }
       for (int idx = lane; idx < w * ell; idx += 64) {
         const int i = idx / ell, j = idx - i * ell;
         PX(i, j) = XC[(size_t)i * cp.lcap + j];
@@ -696,7 +676,8 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       GW_STAMP(17);
       // coincident zeros (gensys.py:243-244): deflated roots have beta = 0
       const bool zz0 = (lane < z) && (fabs(R0[(size_t)lane * cp.zcap + lane]) < rs);
-      const bool zz1 = (lane < w) && (cabs_(PH(lane, lane)) < rs) && (cabs_(PT(lane, lane)) < rs);
+      const bool zz1 = (lane < w) && (cabs_(HC[(size_t)lane * cp.wcap + lane]) < rs) &&
+                       (cabs_(TC[(size_t)lane * cp.wcap + lane]) < rs);
       if (__ballot(zz0 || zz1) != 0ull) {
         eu0 = eu1 = -2;
       } else {
@@ -737,8 +718,8 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
           unique = (n_loose == 0);
         }
         if (unique) eu1 = 1;
-
         // Bm = V2 diag(w_j) G2^H (ell x nu), w_j = [s1_j > rs][s2_j > rs] / s2_j^2
+        cx* BMg = reinterpret_cast<cx*>(wd + wo.BM);
         for (int idx = lane; idx < ell * nu; idx += 64) {
           const int cc = idx / nu, u = idx - cc * nu;
           cx acc = mk(0, 0);
@@ -747,109 +728,203 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
             const double wj = 1.0 / (s2[j] * s2[j]);
             acc = acc + V2[cc * ldx + j] * (wj * conj(PX(ns2 + u, j)));
           }
-          Bm[cc * ldh + u] = acc;
+          Bm[cc * ldb + u] = acc;
+          BMg[(size_t)cc * cp.wcap + u] = acc;
         }
         wave_sync();
-        // Phi_b = X2[:ns2] Bm (ns2 x nu) in the free lower-left block of H: Phi_b[i][u] at H[ns2 + u][i]
+        // Phi_b = X2[:ns2] Bm (ns2 x nu)
+        cx* PHg = reinterpret_cast<cx*>(wd + wo.PHI);
         for (int idx = lane; idx < ns2 * nu; idx += 64) {
           const int i = idx / nu, u = idx - i * nu;
           cx acc = mk(0, 0);
-          for (int cc = 0; cc < ell; ++cc) acc = acc + PX(i, cc) * Bm[cc * ldh + u];
-          PH(ns2 + u, i) = acc;
+          for (int cc = 0; cc < ell; ++cc) acc = acc + PX(i, cc) * Bm[cc * ldb + u];
+          PHg[(size_t)i * cp.wcap + u] = acc;
         }
-        wave_sync();
-        // rhs = [B11, B12 - Phi_b B22] in place in T[:ns2, :]
-        for (int idx = lane; idx < ns2 * nu; idx += 64) {
-          const int i = idx / nu, cc = idx - i * nu;
-          cx acc = PT(i, ns2 + cc);
-          for (int u = 0; u <= cc; ++u) acc = acc - PH(ns2 + u, i) * PT(ns2 + u, ns2 + cc);
-          PT(i, ns2 + cc) = acc;
-        }
-        wave_sync();
-        GW_STAMP(19);
-        // Yb = A11w^-1 rhs by back-substitution, one column per lane
-        if (lane < w) {
-          for (int i = ns2 - 1; i >= 0; --i) {
-            cx acc = PT(i, lane);
-            for (int k2 = i + 1; k2 < ns2; ++k2) acc = acc - PH(i, k2) * PT(k2, lane);
-            PT(i, lane) = cdiv(acc, PH(i, i));
-          }
-        }
-        wave_sync();
-        GW_STAMP(20);
-        // Wb = Yb Ms^H (ns2 x s') into H[:ns2, :s'];  BB = B22 Ms2^H (nu x s') into H[ns2:, :s']
-        for (int idx = lane; idx < ns2 * sp; idx += 64) {
-          const int i = idx / sp, cc = idx - i * sp;
-          cx acc = mk(0, 0);
-          for (int k2 = 0; k2 < w; ++k2) acc = acc + PT(i, k2) * conj(PM(cc, k2));
-          PH(i, cc) = acc;
-        }
-        for (int idx = lane; idx < nu * sp; idx += 64) {
-          const int u = idx / sp, cc = idx - u * sp;
-          cx acc = mk(0, 0);
-          for (int v = u; v < nu; ++v) acc = acc + PT(ns2 + u, ns2 + v) * conj(PM(cc, ns2 + v));
-          PH(ns2 + u, cc) = acc;
-        }
-        wave_sync();
-        // RR = [Re(M[:, :ns2] Wb); Re(Bm BB)]  ((w + ell) x s', real)
-        for (int idx = lane; idx < w * sp; idx += 64) {
-          const int r = idx / sp, cc = idx - r * sp;
-          double acc = 0.0;
-          for (int i = 0; i < ns2; ++i) {
-            const cx a = PM(r, i), b = PH(i, cc);
-            acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
-          }
-          RR[r * lds_ + cc] = acc;
-        }
-        for (int idx = lane; idx < ell * sp; idx += 64) {
-          const int a0 = idx / sp, cc = idx - a0 * sp;
-          double acc = 0.0;
-          for (int u = 0; u < nu; ++u) {
-            const cx a = Bm[a0 * ldh + u], b = PH(ns2 + u, cc);
-            acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
-          }
-          RR[(w + a0) * lds_ + cc] = acc;
-        }
-        wave_sync();
-        GW_STAMP(21);
-        // non-state rows: E = T12[:, :s'] - [H12 | X1] RR, then R0^-1 E by back-substitution (one column per lane)
-        for (int idx = lane; idx < z * sp; idx += 64) {
-          const int p = idx / sp, cc = idx - p * sp;
-          double acc = T12[(size_t)p * cp.scap + cc];
-          for (int k2 = 0; k2 < w; ++k2) acc = fma(-H12[(size_t)p * cp.wcap + k2], RR[k2 * lds_ + cc], acc);
-          for (int a0 = 0; a0 < ell; ++a0) acc = fma(-X1[(size_t)p * cp.lcap + a0], RR[(w + a0) * lds_ + cc], acc);
-          E[p * lds_ + cc] = acc;
-        }
-        wave_sync();
-        if (lane < sp) {
-          for (int p = z - 1; p >= 0; --p) {
-            double acc = E[p * lds_ + lane];
-            for (int q = p + 1; q < z; ++q) acc = fma(-R0[(size_t)p * cp.zcap + q], E[q * lds_ + lane], acc);
-            E[p * lds_ + lane] = acc / R0[(size_t)p * cp.zcap + p];
-          }
-        }
-        wave_sync();
-        GW_STAMP(22);
-        // T in the caller's variable order; columns of non-state variables are exact zeros (see dsge_gensys.hpp)
-        for (int idx = lane; idx < n * n; idx += 64) {
-          const int v = idx / n, c = idx - v * n;
-          const unsigned long long bc_ = 1ull << c, bv = 1ull << v;
-          double val = 0.0;
-          if (!(zmask & bc_)) {
-            const int jc = c - __popcll(zmask & (bc_ - 1ull));  // index among the state variables
-            if (zmask & bv)
-              val = E[__popcll(zmask & (bv - 1ull)) * lds_ + jc];
-            else
-              val = RR[(v - __popcll(zmask & (bv - 1ull))) * lds_ + jc];
-          }
-          T_out[off + idx] = val;
-        }
-        have_T = true;
-        GW_STAMP(23);
+        have_T = 1;
       }
     }
-    if (!have_T)
+    if (lane == 0) {
+      meta[GW_EU0] = eu0;
+      meta[GW_EU1] = eu1;
+      meta[GW_EU2] = eu2;
+      meta[GW_HAVE_T] = have_T;
+    }
+    GW_STAMP(19);
+  }
+#undef PX
+}
+
+// ---- launch 4: T in the window basis (gensys.py:314-343) and the outputs ------------------------------------------------------
+__global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
+                                                          double* __restrict__ T_out, int32_t* __restrict__ eu_out,
+                                                          int32_t* __restrict__ status, long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int n = cp.n;
+  const int ldh = cp.wcap | 1, lds_ = cp.scap | 1;
+  cx* Hc = reinterpret_cast<cx*>(smem);
+  cx* Tc = Hc + (size_t)cp.wcap * ldh;
+  cx* Mc = Tc + (size_t)cp.wcap * ldh;
+  cx* Bm = Mc + (size_t)cp.wcap * ldh;   // lcap x ldh
+  double* RR = reinterpret_cast<double*>(Bm + (size_t)cp.lcap * ldh);  // (wcap + lcap) x lds_: [Re(M1 Yb Ms^H); Re(Bm B22 Ms2^H)]
+  double* E = RR + (size_t)(cp.wcap + cp.lcap) * lds_;                // zcap x lds_
+  const int ldr = cp.zcap | 1, ldq = (cp.wcap + cp.lcap) | 1;
+  double* R0s = E + (size_t)cp.zcap * lds_;                           // zcap x ldr   (R0)
+  double* HXs = R0s + (size_t)cp.zcap * ldr;                          // zcap x ldq   ([H12 | X1])
+  const GwOffsets wo = gw_offsets(cp);
+#define PH(i, j) Hc[(i)*ldh + (j)]
+#define PT(i, j) Tc[(i)*ldh + (j)]
+#define PM(i, j) Mc[(i)*ldh + (j)]
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    const double* wd = ws + (size_t)draw * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    const int eu0 = meta[GW_EU0], eu1 = meta[GW_EU1], eu2 = meta[GW_EU2];
+    int st_extra = 0;
+    if (meta[GW_FLAG] != 0)
+      st_extra = DSGE_ST_GENSYS_TOO_BIG;
+    else if (meta[GW_CONV] == 0)
+      st_extra = DSGE_ST_GENSYS_QZ_FAIL;
+    const bool have_T = meta[GW_HAVE_T] != 0;
+    wave_sync();
+    GW_STAMP(20);
+    if (have_T) {
+      const int N = meta[GW_N], ell = meta[GW_ELL], z = meta[GW_Z], ns2 = meta[GW_NS2];
+      const int w = N - z, sp = n - z, nu = w - ns2;
+      const unsigned long long a_colmask =
+          (unsigned long long)(unsigned)meta[GW_MASK_LO] | ((unsigned long long)(unsigned)meta[GW_MASK_HI] << 32);
+      const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+      const unsigned long long zmask = ~a_colmask & nmask;
+      const cx* HC = reinterpret_cast<const cx*>(wd + wo.HC);
+      const cx* TC = reinterpret_cast<const cx*>(wd + wo.TC);
+      const cx* MC = reinterpret_cast<const cx*>(wd + wo.MC);
+      const cx* BMg = reinterpret_cast<const cx*>(wd + wo.BM);
+      const cx* PHg = reinterpret_cast<const cx*>(wd + wo.PHI);
+      const double* R0 = wd + wo.R0;
+      const double* H12 = wd + wo.H12;
+      const double* T12 = wd + wo.T12;
+      const double* X1 = wd + wo.X1;
+      for (int idx = lane; idx < w * w; idx += 64) {
+        const int i = idx / w, j = idx - i * w;
+        const size_t o = (size_t)i * cp.wcap + j;
+        PH(i, j) = HC[o];
+        PT(i, j) = TC[o];
+        PM(i, j) = MC[(size_t)j * cp.wcap + i];  // stored transposed
+      }
+      for (int idx = lane; idx < ell * nu; idx += 64) {
+        const int cc = idx / nu, u = idx - cc * nu;
+        Bm[cc * ldh + u] = BMg[(size_t)cc * cp.wcap + u];
+      }
+      // the real tail's operands: R0 and [H12 | X1] (read once, coalesced; the products below broadcast them from LDS)
+      for (int idx = lane; idx < z * z; idx += 64) {
+        const int i = idx / z, j = idx - i * z;
+        R0s[i * ldr + j] = R0[(size_t)i * cp.zcap + j];
+      }
+      for (int idx = lane; idx < z * w; idx += 64) {
+        const int i = idx / w, j = idx - i * w;
+        HXs[i * ldq + j] = H12[(size_t)i * cp.wcap + j];
+      }
+      for (int idx = lane; idx < z * ell; idx += 64) {
+        const int i = idx / ell, j = idx - i * ell;
+        HXs[i * ldq + w + j] = X1[(size_t)i * cp.lcap + j];
+      }
+      wave_sync();
+      // Phi_b (ns2 x nu) into the free lower-left block of H: Phi_b[i][u] at H[ns2 + u][i]
+      for (int idx = lane; idx < ns2 * nu; idx += 64) {
+        const int i = idx / nu, u = idx - i * nu;
+        PH(ns2 + u, i) = PHg[(size_t)i * cp.wcap + u];
+      }
+      wave_sync();
+      GW_STAMP(21);
+      // rhs = [B11, B12 - Phi_b B22] in place in T[:ns2, :]
+      for (int idx = lane; idx < ns2 * nu; idx += 64) {
+        const int i = idx / nu, cc = idx - i * nu;
+        cx acc = PT(i, ns2 + cc);
+        for (int u = 0; u <= cc; ++u) acc = acc - PH(ns2 + u, i) * PT(ns2 + u, ns2 + cc);
+        PT(i, ns2 + cc) = acc;
+      }
+      wave_sync();
+      GW_STAMP(22);
+      // Yb = A11w^-1 rhs by back-substitution, one column per lane
+      if (lane < w) {
+        for (int i = ns2 - 1; i >= 0; --i) {
+          cx acc = PT(i, lane);
+          for (int k2 = i + 1; k2 < ns2; ++k2) acc = acc - PH(i, k2) * PT(k2, lane);
+          PT(i, lane) = cdiv(acc, PH(i, i));
+        }
+      }
+      wave_sync();
+      GW_STAMP(23);
+      // Wb = Yb Ms^H (ns2 x s') into H[:ns2, :s'];  BB = B22 Ms2^H (nu x s') into H[ns2:, :s']
+      for (int idx = lane; idx < ns2 * sp; idx += 64) {
+        const int i = idx / sp, cc = idx - i * sp;
+        cx acc = mk(0, 0);
+        for (int k2 = 0; k2 < w; ++k2) acc = acc + PT(i, k2) * conj(PM(cc, k2));
+        PH(i, cc) = acc;
+      }
+      for (int idx = lane; idx < nu * sp; idx += 64) {
+        const int u = idx / sp, cc = idx - u * sp;
+        cx acc = mk(0, 0);
+        for (int v = u; v < nu; ++v) acc = acc + PT(ns2 + u, ns2 + v) * conj(PM(cc, ns2 + v));
+        PH(ns2 + u, cc) = acc;
+      }
+      wave_sync();
+      // RR = [Re(M[:, :ns2] Wb); Re(Bm BB)]  ((w + ell) x s', real)
+      for (int idx = lane; idx < w * sp; idx += 64) {
+        const int r = idx / sp, cc = idx - r * sp;
+        double acc = 0.0;
+        for (int i = 0; i < ns2; ++i) {
+          const cx a = PM(r, i), b = PH(i, cc);
+          acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
+        }
+        RR[r * lds_ + cc] = acc;
+      }
+      for (int idx = lane; idx < ell * sp; idx += 64) {
+        const int a0 = idx / sp, cc = idx - a0 * sp;
+        double acc = 0.0;
+        for (int u = 0; u < nu; ++u) {
+          const cx a = Bm[a0 * ldh + u], b = PH(ns2 + u, cc);
+          acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
+        }
+        RR[(w + a0) * lds_ + cc] = acc;
+      }
+      wave_sync();
+      GW_STAMP(24);
+      // non-state rows: E = T12[:, :s'] - [H12 | X1] RR, then R0^-1 E by back-substitution (one column per lane)
+      for (int idx = lane; idx < z * sp; idx += 64) {
+        const int p = idx / sp, cc = idx - p * sp;
+        double acc = T12[(size_t)p * cp.scap + cc];
+        for (int k2 = 0; k2 < w + ell; ++k2) acc = fma(-HXs[p * ldq + k2], RR[k2 * lds_ + cc], acc);
+        E[p * lds_ + cc] = acc;
+      }
+      wave_sync();
+      if (lane < sp) {
+        for (int p = z - 1; p >= 0; --p) {
+          double acc = E[p * lds_ + lane];
+          for (int q = p + 1; q < z; ++q) acc = fma(-R0s[p * ldr + q], E[q * lds_ + lane], acc);
+          E[p * lds_ + lane] = acc / R0s[p * ldr + p];
+        }
+      }
+      wave_sync();
+      GW_STAMP(25);
+      // T in the caller's variable order; columns of non-state variables are exact zeros (see dsge_gensys.hpp)
+      for (int idx = lane; idx < n * n; idx += 64) {
+        const int v = idx / n, c = idx - v * n;
+        const unsigned long long bc_ = 1ull << c, bv = 1ull << v;
+        double val = 0.0;
+        if (!(zmask & bc_)) {
+          const int jc = c - __popcll(zmask & (bc_ - 1ull));  // index among the state variables
+          if (zmask & bv)
+            val = E[__popcll(zmask & (bv - 1ull)) * lds_ + jc];
+          else
+            val = RR[(v - __popcll(zmask & (bv - 1ull))) * lds_ + jc];
+        }
+        T_out[off + idx] = val;
+      }
+      GW_STAMP(26);
+    } else {
       for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+    }
     if (lane == 0) {
       eu_out[3 * draw] = eu0;
       eu_out[3 * draw + 1] = eu1;
@@ -861,7 +936,6 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
 #undef PH
 #undef PT
 #undef PM
-#undef PX
 }
 
 

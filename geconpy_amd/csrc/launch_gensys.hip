@@ -5,7 +5,7 @@
 
 namespace dsge_host {
 
-long long* g_gensys_win_dbg = nullptr;  // debug: device int64[24], phase stamps of draw 0 of the window kernels
+long long* g_gensys_win_dbg = nullptr;  // debug: device int64[32], phase stamps of draw 0 of the window kernels
 int g_gensys_split = 1;  // 0 = single-launch kernel, 1 = window path (dsge_gensys_win.hpp) unless the pencil is small, 2 = always
 
 namespace {
@@ -81,8 +81,9 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   cp.zcap = shape[2] < 1 ? 1 : shape[2];
   cp.scap = (n - shape[3]) < 1 ? 1 : (n - shape[3]);
   if (n + cp.lcap > DSGE_MAX_N_GENSYS) return DSGE_SUCCESS;
-  const size_t lds1 = dsge::gw_reduce_smem(cp), lds2 = dsge::gw_qz_smem(cp), lds3 = dsge::gw_post_smem(cp);
-  if (lds1 > LDS_LIMIT || lds2 > LDS_LIMIT || lds3 > LDS_LIMIT) return DSGE_SUCCESS;
+  const size_t lds1 = dsge::gw_reduce_smem(cp), lds2 = dsge::gw_qz_smem(cp), lds3 = dsge::gw_post_smem(cp),
+               lds_eu = dsge::gw_eu_smem(cp);
+  if (lds1 > LDS_LIMIT || lds2 > LDS_LIMIT || lds3 > LDS_LIMIT || lds_eu > LDS_LIMIT) return DSGE_SUCCESS;
   const dsge::GwOffsets wo = dsge::gw_offsets(cp);
   const size_t per_draw = wo.total * sizeof(double);
   size_t chunk = GW_WORKSPACE_LIMIT / per_draw;
@@ -93,6 +94,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   if ((rc = set_lds(dsge::gensys_reduce_kernel, lds1))) return rc;
   if ((rc = set_lds(dsge::gensys_qzwin_kernel, lds2))) return rc;
   if ((rc = set_lds(dsge::gensys_post_kernel, lds3))) return rc;
+  if ((rc = set_lds(dsge::gensys_eu_kernel, lds_eu))) return rc;
   const size_t nn = (size_t)n * n;
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)((c0 + chunk <= (size_t)batch) ? chunk : (size_t)batch - c0);
@@ -103,9 +105,11 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
       hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,
                          bk->re + c0 * 2 * n, bk->im + c0 * 2 * n, bk->n_eig + c0, bk->n_forward + c0,
                          bk->n_unstable + c0, status + c0);
-    else
+    else {
+      hipLaunchKernelGGL(dsge::gensys_eu_kernel, dim3(nb), dim3(64), lds_eu, st, nb, cp, tol, wsp, g_gensys_win_dbg);
       hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(64), lds3, st, nb, cp, tol, (const double*)wsp,
                          T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg);
+    }
     HIP_TRY(hipGetLastError());
   }
   *used = 1;

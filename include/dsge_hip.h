@@ -203,8 +203,9 @@ int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, 
                              int n_lead_hint, double* T_out, int32_t* eu_out, int32_t* status,
                              long long* cycles_out);
 /* Debug hook of the window path: enable = 1 arms the stamp buffer (draw 0 of each launch: reduce [0..4] = start, deflation,
- * triangular T22, Hessenberg H22, stored; QZ [8..11] = start, QZ, reordering, stored; post [16..23] = start, loaded, SVD,
- * eu + Phi + rhs, back-substitution, products, non-state rows, T written); cycles_out: host int64[24] or NULL. */
+ * triangular T22, Hessenberg H22, stored; QZ [8..11] = start, QZ, reordering, stored; eu [16..19] = start, loaded, SVD, end;
+ * post [20..26] = start, loaded, rhs, back-substitution, products, non-state rows, T written; [12], [13] = sweep steps and
+ * sweeps, accumulated); cycles_out: host int64[32] or NULL. */
 int dsge_debug_gensys_window_phases(int enable, long long* cycles_out);
 
 /*

@@ -1,4 +1,4 @@
-"""GPU box: per-phase shader cycles of the three window-path gensys kernels for draw 0 of an SW-shaped batch."""
+"""GPU box: per-phase shader cycles of the window-path gensys kernels for draw 0 of an SW-shaped batch."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,7 @@ A, B, C, D = (b[x] for x in "ABCD")
 _lib.check(lib.dsge_debug_gensys_window_phases(1, None))
 for _ in range(2):
     out = batched.gensys_batched(A, B, C, D, tol=1e-8)
-cyc = (ctypes.c_longlong * 24)()
+cyc = (ctypes.c_longlong * 32)()
 _lib.check(lib.dsge_debug_gensys_window_phases(0, ctypes.addressof(cyc)))
 c = np.array(list(cyc), dtype=np.int64)
 def split(names, base):
@@ -18,4 +18,5 @@ def split(names, base):
 print("reduce", split(["deflation(hh)", "T22 triangular(hh)", "Hessenberg(givens)", "store"], 0), "total", int(c[4] - c[0]))
 print("qz    ", split(["qz", "reorder", "store"], 8), "total", int(c[11] - c[8]))
 print("qz sweep steps", int(c[12]) // 2, "sweeps", int(c[13]) // 2, "(per call)")
-print("post  ", split(["load", "svd", "eu+Bm+Phi+rhs", "backsub", "Wb+BB+RR", "E+R0 solve", "T write"], 16), "total", int(c[23] - c[16]))
+print("eu    ", split(["load", "svd", "eu+Bm+Phi"], 16), "total", int(c[19] - c[16]))
+print("post  ", split(["load", "rhs", "backsub", "Wb+BB+RR", "E+R0 solve", "T write"], 20), "total", int(c[26] - c[20]))

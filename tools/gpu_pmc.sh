@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 i=0
 for GROUP in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$OUT/g$i" -o pmc -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 --profile-reps 1 > "$OUT/g$i.log" 2>&1
+  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$OUT/g$i" -o pmc -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 --profile-reps 1 ${PMC_BENCH_ARGS:-} > "$OUT/g$i.log" 2>&1
   python3 - "$OUT/g$i" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)
