@@ -1187,3 +1187,43 @@ def test_gensys_window_path_fuzz():
             if single is not None:
                 assert np.array_equal(single["eu"][i], out["eu"][i])
                 assert_allclose(single["T"][i], out["T"][i], atol=1e-8 * scale)
+
+
+@pytest.mark.parametrize("split", [2, 0])
+def test_gensys_nan_inf_inputs_are_flagged_not_hung(split):
+    """NaN / Inf entries in one draw's Jacobians: the draw is flagged (success False, logp = -inf in the fused call), the
+    launch terminates (every loop of the QZ / Jacobi kernels is bounded) and the neighbouring draws are untouched --
+    window path and single-launch kernel."""
+    lib = _lib.load()
+    b = wl.sw_shaped_batch(6)
+    A, B, C, D = (b[x].copy() for x in "ABCD")
+    A[1, 3, 2] = np.nan
+    B[3, 0, 0] = np.inf
+    C[4, 5, 39] = np.nan
+    clean = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8)
+    _lib.check(lib.dsge_set_gensys_split(split))
+    try:
+        out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+        om = wl.sw_shaped_observation_model()
+        fused = batched.solve_kalman_logp_batched(A, B, C, D, b["sigma"] ** 2, om["Z"], om["y"][:40], Hdiag=om["Hdiag"],
+                                                  solver="gensys", tol=1e-8)
+    finally:
+        _lib.check(lib.dsge_set_gensys_split(1))
+    for i in (1, 3):
+        assert out["status"][i] != 0 and not out["success"][i] and np.all(out["T"][i] == 0)
+    # a NaN in a column of C: |C|.sum(0) > tol is False for that column, so it is not a forward-looking variable for
+    # _gensys_setup (gensys.py:580-589) and never enters the pencil -- the reference solves the reduced system and so
+    # does the device (same eu, same T); the fused evaluation then fails at R = -(C T + B)^-1 D
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        T_ref, ok_ref, eu_ref = oracle.gensys_T_success(A[4], B[4], C[4], D[4], tol=1e-8)
+    assert list(out["eu"][4]) == [int(x) for x in eu_ref] and bool(out["success"][4]) == bool(ok_ref)
+    assert_allclose(out["T"][4], T_ref, atol=1e-8)
+    for i in (1, 3, 4):
+        assert fused["status"][i] != 0 and fused["logp"][i] == -np.inf
+    for i in (0, 2, 5):
+        assert out["status"][i] == 0
+        assert_allclose(out["T"][i], clean["T"][i], atol=1e-10)
+        assert np.isfinite(fused["logp"][i]) and fused["status"][i] == 0
