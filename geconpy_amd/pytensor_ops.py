@@ -308,6 +308,51 @@ def gensys_pt(A, B, C, D, tol=1e-8):
     return T, R, success
 
 
+class HipBKEigenvalues(Op):
+    """``real, imag, n_unstable = Op(A, B, C)``: the generalized eigenvalues of the Sims pencil sorted by modulus (what
+    ``compute_bk_eigenvalues_pt`` returns through ``real_eig``, gEconpy/model/perturbation.py:448-505) and the number of
+    them with modulus > 1, from ``dsge_bk_eigenvalues_batched``.  The reference's graph regularises Gamma_0 and takes a dense
+    ``eig``; the counts -- all the BK condition uses -- are the same.  Not differentiable: the reference detaches the
+    eigenvalues as well (``disconnected_grad``, :608-611)."""
+
+    __props__ = ("tol", "n_forward")
+
+    def __init__(self, n_forward, tol=1e-8):
+        self.tol = tol
+        self.n_forward = int(n_forward)
+        if _HAVE_PYTENSOR:
+            super().__init__()
+
+    def make_node(self, A, B, C):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (A, B, C)]
+        n = inputs[0].type.shape[-1]
+        N = None if n is None else n + self.n_forward
+        outputs = [pt.tensor("eig_real", dtype="float64", shape=(N,)), pt.tensor("eig_imag", dtype="float64", shape=(N,)),
+                   pt.tensor("n_unstable", dtype="int64", shape=())]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        N = input_shapes[0][-1] + self.n_forward
+        return [(N,), (N,), ()]
+
+    def perform(self, node, inputs, outputs):
+        A, B, C = (_as3(x) for x in inputs)
+        out = batched.bk_eigenvalues_batched(A, B, C, tol=self.tol)
+        m = int(out["n_eig"][0])
+        outputs[0][0] = out["real"][0, :m].copy()
+        outputs[1][0] = out["imag"][0, :m].copy()
+        outputs[2][0] = np.asarray(out["n_unstable"][0], dtype=np.int64)
+
+
+def check_bk_condition_pt(A, B, C, D, lead_var_idx, tol=1e-8):
+    """Same signature and return as ``gEconpy.model.perturbation.check_bk_condition_pt`` (:586-625):
+    ``(bk_satisfied, n_forward, n_unstable)``; ``D`` is unused there too."""
+    n_forward = len(np.asarray(lead_var_idx))
+    _re, _im, n_unstable = HipBKEigenvalues(n_forward, tol=tol)(A, B, C)
+    return pt.eq(n_forward, n_unstable), pt.constant(n_forward), n_unstable
+
+
 class HipScanCycleReduction(Op):
     """``T, n_steps = Op(A, B, C)`` with the semantics of ``_scan_cycle_reduction``
     (gEconpy/solvers/cycle_reduction.py:246-294): fixed trip count, A0-norm-only stopping rule, 1e-16
