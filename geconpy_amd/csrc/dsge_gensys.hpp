@@ -122,6 +122,9 @@ struct GsLayout {
   // rotations in registers, prefetches the next one a step ahead and stores each finished column once (qz_iterate);
   // the rare other column rotations (zero chasing, reordering) do a plain read-modify-write.
   bool zglobal;
+  // halfwave (packed + zglobal + N <= 32 only): inside a QZ sweep lanes 0..31 rotate H and lanes 32..63 rotate T with ONE
+  // complex rotation per lane (the full-wave code spends one on each matrix with half the lanes idle).
+  bool halfwave;
 };
 __device__ __forceinline__ void gs_plain_map(GsLayout& L) {
   L.hoff = 0;
@@ -129,6 +132,7 @@ __device__ __forceinline__ void gs_plain_map(GsLayout& L) {
   L.tsj = 1;
   L.packed = false;
   L.zglobal = false;
+  L.halfwave = false;
 }
 
 __host__ __device__ inline size_t gensys_smem_bytes(int n, int n_cap, int l_cap) {
@@ -780,6 +784,75 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
           if (istart + 2 <= ilast) m_n = ZEL(lane, istart + 2);
         }
       }
+      if (L.halfwave) {
+        // lanes 0..31: H, lanes 32..63: T (packed map: H(i, c) at [i][c + 4], T(i, c) at [c][i]).  Row phase, rows
+        // (j, j+1): element (j, idx) at a_r + j s_r, (j+1, idx) one s_r further; column phase, columns (j+1, j):
+        // element (idx, j) at a_c + j s_c, (idx, j+1) one s_c further.
+        const int half = lane >> 5, idx = lane & 31;
+        const bool hl = half == 0, inw = idx < L.N;
+        const int s_r = hl ? L.ldh : 1, a_r = hl ? idx + 4 : idx * L.ldh;
+        const int s_c = hl ? 1 : L.ldh, a_c = hl ? idx * L.ldh + 4 : idx;
+        const bool xrow = lane < L.ell;
+        cx cy = mk(0, 0);  // "y" output of the last column rotation: H(idx, j-1) on the H lanes
+        for (int j = istart; j < ilast; ++j) {
+          // ---- row rotation (j, j+1): H columns >= j-1, T columns >= j
+          wave_sync();
+          const bool rmask = inw && idx >= j - 1 + half;
+          cx* px = L.H + a_r + j * s_r;
+          cx x = mk(0, 0), y = mk(0, 0), ax = mk(0, 0), ay = mk(0, 0);
+          if (rmask) {
+            x = px[0];
+            y = px[s_r];
+          }
+          if (xrow) {
+            ax = GX(j, lane);
+            ay = GX(j + 1, lane);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (j > istart) lartg(bc(cy, j), bc(cy, j + 1), c, s, r);  // bulge: H[j][j-1], H[j+1][j-1]
+          rot2(x, y, c, s);
+          rot2(ax, ay, c, s);
+          if (j > istart && lane == j - 1) {
+            x = r;
+            y = mk(0, 0);
+          }
+          if (rmask) {
+            px[0] = x;
+            px[s_r] = y;
+          }
+          if (xrow) {
+            GX(j, lane) = ax;
+            GX(j + 1, lane) = ay;
+          }
+          // ---- column rotation (j+1, j): H rows <= j+2, T rows <= j+1
+          wave_sync();
+          const bool cmask = inw && idx <= j + 2 - half;
+          cx* py = L.H + a_c + j * s_c;
+          cx qx = mk(0, 0), qy = mk(0, 0);
+          if (cmask) {
+            qy = py[0];
+            qx = py[s_c];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          cx r2;
+          lartg(bc(y, 32 + j + 1), bc(y, 32 + j), c, s, r2);  // T[j+1][j+1], T[j+1][j]: row j+1 on the T lanes
+          rot2(qx, qy, c, s);
+          if (lane == 32 + j + 1) {
+            qx = r2;
+            qy = mk(0, 0);
+          }
+          if (cmask) {
+            py[0] = qy;
+            py[s_c] = qx;
+          }
+          cy = qy;
+          rot2(m_x, m_y, c, s);  // accumulated right transformation: x = column j+1, y = column j (final)
+          if (zrow) ZEL(lane, j) = m_y;
+          m_y = m_x;
+          m_x = m_n;
+          if (zrow && j + 3 <= ilast) m_n = ZEL(lane, j + 3);
+        }
+      } else {
       for (int j = istart; j < ilast; ++j) {
         Rot4 rr;
         const RotLd ld = rows_begin(L, j, j + 1, lane);
@@ -801,6 +874,7 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
           m_x = m_n;
           if (zrow && j + 3 <= ilast) m_n = ZEL(lane, j + 3);
         }
+      }
       }
       if (zg && zrow) ZEL(lane, ilast) = m_y;
       wave_sync();

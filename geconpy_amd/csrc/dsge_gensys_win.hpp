@@ -465,6 +465,7 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
   L.tsj = L.ldh;
   L.packed = true;
   L.zglobal = true;  // M: transposed, in the draw's workspace (set per draw)
+  L.halfwave = cp.wcap <= 32;
   L.Z = nullptr;
   L.X = L.H + (size_t)cp.wcap * L.ldh;
   L.V1 = L.V2 = L.S3 = nullptr;
