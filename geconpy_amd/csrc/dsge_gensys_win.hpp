@@ -55,17 +55,14 @@ enum {
   GW_EU0 = 8, GW_EU1 = 9, GW_EU2 = 10, GW_HAVE_T = 11  // written by the eu launch, read by the post launch
 };
 
-// The accumulated right transformation Zr of the reduce launch is only needed once rows < z of H are dead (they leave
-// the chip after the deflation phase): when EVERY draw of the batch has enough of them (zmin = n - scap rows of H hold
-// wcap x ldW doubles) Zr lives there and the launch needs 40 KB instead of 48 KB at N = 52 (4 draws per CU).
-__host__ __device__ inline bool gw_reduce_alias(const GwCaps& c) {
-  const int Ncap = c.n + c.lcap, zmin = c.n - c.scap;
-  return (size_t)zmin * (Ncap | 1) >= (size_t)c.wcap * (c.wcap | 1);
-}
+// reduce launch A (deflation): the full real pencil H (N x N), the non-zero columns of T (N x w), X (N x #lead);
+// reduce launch B (Hessenberg-triangular reduction of the window): H22, T22, Zr (w x w) and X2 (w x #lead).
 __host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
   const int Ncap = c.n + c.lcap;
-  return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1) +
-          (gw_reduce_alias(c) ? 0 : (size_t)c.wcap * (c.wcap | 1))) * 8 + 64 * 4;
+  return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1)) * 8 + 64 * 4;
+}
+__host__ __device__ inline size_t gw_reduce2_smem(const GwCaps& c) {
+  return ((size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1)) * 8;
 }
 __host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array; M stays in HBM / L2 (GsLayout)
   return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
@@ -231,7 +228,9 @@ __device__ __forceinline__ void rot2r(double& x, double& y, double c, double s) 
   x = tx;
 }
 
-// ---- launch 1: pencil, structural deflation, Hessenberg-triangular reduction of the window (all real) ------------------
+// ---- launch 1a: pencil and structural deflation (real).  Rows < z are final afterwards and leave the chip (R0, H12,
+// T12[:, :s'], X1); the window (rows / columns >= z of H and T, rows >= z of X) is handed to launch 1b, which needs a
+// third of this launch's LDS and therefore runs at a higher occupancy.
 __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                             const double* __restrict__ C, int batch, GwCaps cp,
                                                             double tol, double* __restrict__ ws,
@@ -243,11 +242,8 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
   double* Hr = smem;
   double* Tr = Hr + (size_t)Ncap * ldH;
   double* Xr = Tr + (size_t)Ncap * ldW;
-  const bool zr_alias = gw_reduce_alias(cp);
-  double* Zr = zr_alias ? Hr : Xr + (size_t)Ncap * ldX;  // aliased: rows < z of H, dead after the deflation phase
-  int* lead = reinterpret_cast<int*>(Xr + (size_t)Ncap * ldX + (zr_alias ? 0 : (size_t)cp.wcap * ldW));
-  const size_t total =
-      (size_t)Ncap * ldH + (size_t)Ncap * ldW + (size_t)Ncap * ldX + (zr_alias ? 0 : (size_t)cp.wcap * ldW);
+  int* lead = reinterpret_cast<int*>(Xr + (size_t)Ncap * ldX);
+  const size_t total = (size_t)Ncap * ldH + (size_t)Ncap * ldW + (size_t)Ncap * ldX;
   const GwOffsets wo = gw_offsets(cp);
 
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
@@ -337,19 +333,57 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
       const int i = idx / ell, j = idx - i * ell;
       wd[wo.X1 + (size_t)i * cp.lcap + j] = Xr[i * ldX + j];
     }
-    wave_sync();
-    for (int idx = lane; idx < w * ldW; idx += 64) {  // Zr = I (possibly in the rows of H that just left)
-      const int i = idx / ldW, j = idx - i * ldW;
-      Zr[idx] = (i == j) ? 1.0 : 0.0;
+    // the window, as it stands after the deflation
+    for (int idx = lane; idx < w * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      const size_t o = (size_t)i * cp.wcap + j;
+      wd[wo.HR + o] = Hr[(z + i) * ldH + z + j];
+      wd[wo.TR + o] = Tr[(z + i) * ldW + j];
+    }
+    for (int idx = lane; idx < w * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      wd[wo.XR + (size_t)i * cp.lcap + j] = Xr[(z + i) * ldX + j];
     }
     GW_STAMP(1);
-    // ---- window: T22 -> upper triangular (reflectors on rows >= z)
-    for (int j = 0; j < w - 1; ++j) hh_left_real(Hr, ldH, z, w, Tr, ldW, w, Xr, ldX, ell, Tr, ldW, j, z + j, N, lane);
+  }
+}
+
+// ---- launch 1b: Hessenberg-triangular reduction of the window (real): T22 -> upper triangular by reflectors, H22 -> upper
+// Hessenberg by Givens pairs; the right transformation Zr is accumulated and handed over transposed and complex.
+__global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp, double* __restrict__ ws,
+                                                             long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int ldW = cp.wcap | 1, ldX = cp.lcap | 1;
+  const int ldH = ldW;  // the window copy of H
+  double* hb = smem;
+  double* tb = hb + (size_t)cp.wcap * ldW;
+  double* Zr = tb + (size_t)cp.wcap * ldW;
+  double* xb = Zr + (size_t)cp.wcap * ldW;
+  const GwOffsets wo = gw_offsets(cp);
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    double* wd = ws + (size_t)draw * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    if (meta[GW_FLAG] != 0) continue;
+    const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
+    wave_sync();
+    GW_STAMP(5);
+    for (int idx = lane; idx < w * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      const size_t o = (size_t)i * cp.wcap + j;
+      hb[i * ldH + j] = wd[wo.HR + o];
+      tb[i * ldW + j] = wd[wo.TR + o];
+      Zr[i * ldW + j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int idx = lane; idx < w * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      xb[i * ldX + j] = wd[wo.XR + (size_t)i * cp.lcap + j];
+    }
+    wave_sync();
+    // ---- T22 -> upper triangular (reflectors)
+    for (int j = 0; j < w - 1; ++j) hh_left_real(hb, ldH, 0, w, tb, ldW, w, xb, ldX, ell, tb, ldW, j, j, w, lane);
     GW_STAMP(2);
     // ---- window: H22 -> upper Hessenberg by Givens pairs (column j prefetched, pivots travel through registers)
-    double* hb = Hr + (size_t)z * ldH + z;
-    double* tb = Tr + (size_t)z * ldW;
-    double* xb = Xr + (size_t)z * ldX;
     const bool wa = lane < w, xa = lane < ell;
     for (int j = 0; j < w - 2; ++j) {
       wave_sync();
@@ -447,6 +481,7 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
     GW_STAMP(4);
   }
 }
+
 
 // ---- launch 2: complex single-shift QZ + reordering on the window (qz_iterate / reorder_stable_first of dsge_gensys.hpp
 // with N := w, ilo := 0; "Ztop" := the accumulated right transformation M, started from the real phase's Zr) -----------
