@@ -1,4 +1,4 @@
-// gensys in four launches on the ACTIVE WINDOW of the pencil (same mathematics as dsge_gensys.hpp, which stays as the
+// gensys in five launches on the ACTIVE WINDOW of the pencil (same mathematics as dsge_gensys.hpp, which stays as the
 // single-launch fallback): the monolithic kernel keeps H, T (N x N complex), Q Pi and Z[:n] in LDS -- 140 KB at N = 52,
 // one wavefront per CU.  Here
 //   * the z structurally deflated roots (zero columns of A, permuted to the front; a QR of those columns of G0) leave the
@@ -11,7 +11,7 @@
 //       T[non-state rows] = R0^-1 (T12[:, :s'] - H12 Re(M1 Yb Ms^H) - X1 Re(Bm B22 Ms2^H))
 //     with Yb = A11w^-1 [B11w, B12w - Phi_b B22] the window part of the reference's G0^-1 [Tmat BB] (gensys.py:322-343);
 //     tests/device_models/gensys_window_model.py restates this algebra in numpy and checks it against the oracle.
-// LDS per draw at N = 52, z = 22: 40 KB (reduce), 23 KB (QZ: H and T share one array, M stays in HBM / L2), 15 KB (eu), 72 KB (post) => 4 / 6-7 / 10 / 2 wavefronts per CU, each on its own
+// LDS per draw at N = 52, z = 22: 40 KB (deflation), 25 KB (Hessenberg-triangular), 23 KB (QZ: H and T share one array, M stays in HBM / L2), 15 KB (eu), 72 KB (post) => 4 / 6 / 6-7 / 10 / 2 wavefronts per CU, each on its own
 // SIMD.  The launches hand the window over through a library-owned HBM workspace (88 KB per draw, read and written once).
 #pragma once
 #include "dsge_gensys.hpp"

@@ -174,10 +174,10 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
-/* gensys runs as four launches on the active window of the pencil -- real reduction; complex QZ + reordering on the
- * (N - z) x (N - z) block left after the structural deflation, with H and T sharing one LDS array and the accumulated
- * right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing -- 4 / 6-7 / 10 / 2 draws per
- * CU instead of 1 at N = 52.  enable = 1
+/* gensys runs as five launches on the active window of the pencil -- structural deflation; real Hessenberg-triangular
+ * reduction and complex QZ + reordering on the (N - z) x (N - z) block the deflation leaves, with H and T sharing one LDS
+ * array and the accumulated right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing --
+ * 4 / 6 / 6-7 / 10 / 2 draws per CU instead of 1 at N = 52.  enable = 1
  * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
  * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide. */
 int dsge_set_gensys_split(int enable);
