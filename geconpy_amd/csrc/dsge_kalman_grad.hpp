@@ -24,7 +24,10 @@
 // zero functions of the parameters), Gbar (cotangent of sym(R Q R'), block [U,U]), dbar, hbar.
 // Zbar is not produced (the selector design matrix is a constant of the model, statespace.py:282-296).
 //
-// Written for clarity, not speed: every matrix lives in LDS, products go through mm_acc register blocks.
+// Steady segments: the forward sweep freezes K, F^-1 and ln det F of the segment's source step, so the reverse sweep
+// collects the cotangents the segment's steps send to those shared quantities (Kacc, Qacc, nlam below) and runs the
+// covariance part of the step ONCE per segment, at the source step; a steady step costs two matrix-vector products.
+// Every matrix lives in LDS, products go through mm_acc register blocks.
 #pragma once
 #include "dsge_device.hpp"
 #include "dsge_kalman2.hpp"
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, double jitter, double missing_fill,
     double steady_tol, double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
-    double* __restrict__ hbar_out) {
+    double* __restrict__ hbar_out, long long* __restrict__ dbg) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
   constexpr size_t STEP = (size_t)NP * NP + NP + 1;  // doubles stored per time step: P (NP x NP, dense), a, source step
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -111,7 +114,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
   const int fo = lane >> 3, fq = lane & 7;
   const double LN2PI = 1.8378770664093453;
 
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug (draw 0): setup+P0, fwd full, fwd steady, rev full, rev steady, tail, #full, #steady
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const bool tm = dbg && draw == 0;
+    long long tk0 = tm ? clock64() : 0;
     const size_t off = (size_t)draw * m_full * m_full;
     double* Tbo = Tbar_out + off;
     double* Gbo = Gbar_out + off;
@@ -298,8 +304,9 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       return log(det_m) + (double)det_e * 0.6931471805599453;
     };
     // mask of step t -> ww; returns the ballot
-    auto load_mask = [&](int t, double& yt) -> unsigned long long {
-      yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
+    // (y_t, and in the reverse sweep a_t and the source index, are fetched ONE STEP AHEAD: a steady step is a few hundred
+    // cycles of arithmetic, a dependent global load is a few thousand)
+    auto load_mask = [&](double yt) -> unsigned long long {
       const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
       const unsigned long long omask = __ballot(obs);
       if (lane < 8) ww[lane] = (lane < p && obs) ? 1.0 : 0.0;
@@ -330,16 +337,23 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     // ---- forward sweep.  Step t stores (P_t, a_t, src_t): src_t = t for a full step; once the predicted
     // covariance has stopped moving (same rounding-level criterion as kalman_sel_kernel) and while the mask stays
     // the same, the steps are "steady": only a_t is stored and src_t names the step whose covariance they share.
+    if (tm) {
+      const long long tk1 = clock64();
+      ph[0] += tk1 - tk0;
+      tk0 = tk1;
+    }
     double ll_acc = 0.0;
     long long n_ll = 0;
     bool steady = false;
     unsigned long long smask = 0ull;
     int seg_src = -1;
     double seg_logdet = 0.0;
+    double yt_next = (lane < p && T_len > 0) ? y[lane] : 0.0;
     for (int t = 0; t < T_len; ++t) {
       double* sg = st + (size_t)t * STEP;
-      double yt;
-      const unsigned long long omask = load_mask(t, yt);
+      const double yt = yt_next;
+      yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+      const unsigned long long omask = load_mask(yt);
       const double lam = (omask != 0ull) ? 1.0 : 0.0;
       const bool light = steady && (omask == smask);
       if (lane < NP) sg[NP * NP + lane] = av[lane];
@@ -392,6 +406,12 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
       if (lane < NP) av[lane] = (lane < u) ? t1[lane] : 0.0;
       wave_sync();
+      if (tm) {
+        const long long tk1 = clock64();
+        ph[light ? 2 : 1] += tk1 - tk0;
+        ph[light ? 7 : 6] += 1;
+        tk0 = tk1;
+      }
     }
     const double logp = -0.5 * ((double)n_ll * (double)p * LN2PI + ll_acc);
     if (lane == 0) {
@@ -412,12 +432,34 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     }
     wave_sync();
     int cur_src = -1;  // step whose covariance-side quantities (Mp, Fs, Fi, Kp, X1 = P+) are in LDS
+    // Cotangents that the steps of one steady segment send to the quantities they SHARE (the forward sweep freezes K, F^-1
+    // and ln det F of the segment's source step, so this is the exact reverse of what was executed): they are collected in
+    // registers and pulled back through the covariance update once, at the source step.  A steady step therefore costs two
+    // matrix-vector products instead of the three u x u products of a full reverse step.
+    //   Kacc  = sum_t a+bar_t v_t'           (u x 8 panel: element (i, o) = idx = lane + 64 k -> register k)
+    //   Qacc  = sum_t lam_t (F^-1 v_t)(F^-1 v_t)'   (8 x 8: lane = fo * 8 + fq)
+    //   nlam  = sum_t lam_t                  (number of log-determinants the segment contributed)
+    double Kacc[BS], Qacc = 0.0, nlam = 0.0;
+#pragma unroll
+    for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
+    double src_next = 0.0, av_next = 0.0, yr_next = 0.0;
+    if (T_len > 0) {
+      const double* sg0 = st + (size_t)(T_len - 1) * STEP;
+      src_next = sg0[NP * NP + NP];
+      if (lane < NP) av_next = sg0[NP * NP + lane];
+      if (lane < p) yr_next = y[(size_t)(T_len - 1) * p + lane];
+    }
     for (int t = T_len - 1; t >= 0; --t) {
-      const double* sg = st + (size_t)t * STEP;
-      const int src_t = (int)sg[NP * NP + NP];
-      if (lane < NP) av[lane] = sg[NP * NP + lane];
-      double yt;
-      const unsigned long long omask = load_mask(t, yt);
+      const int src_t = (int)src_next;
+      if (lane < NP) av[lane] = av_next;
+      const double yt = yr_next;
+      if (t > 0) {
+        const double* sgp = st + (size_t)(t - 1) * STEP;
+        src_next = sgp[NP * NP + NP];
+        if (lane < NP) av_next = sgp[NP * NP + lane];
+        yr_next = (lane < p) ? y[(size_t)(t - 1) * p + lane] : 0.0;
+      }
+      const unsigned long long omask = load_mask(yt);
       const double lam = (omask != 0ull) ? 1.0 : 0.0;
       if (src_t != cur_src) {  // a full step, or the first (last in time) step of a steady segment
         const double* sp_ = st + (size_t)src_t * STEP;
@@ -425,92 +467,120 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         wave_sync();
         (void)update_cov();
         cur_src = src_t;
+#pragma unroll
+        for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
+        Qacc = 0.0;
+        nlam = 0.0;
       }
       (void)update_mean(yt);
-      // -- predict, reversed.  (abar, Pb) are the cotangents of (a_{t+1}, P_{t+1}); X1 = P+ stays intact.
-      kg_mm<BS, false>(X2, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
+      // ---- mean side (every step).  abar is the cotangent of a_{t+1}.
       if (lane < u) {
         double sa = 0.0;
         for (int i = 0; i < u; ++i) sa = fma(Tc[i * LDM + lane], ab[i], sa);
         apb[lane] = sa;  // a+bar = T' abar
       }
-      wave_sync();
-      {
-        double pb[BS][BS], t2[BS][BS], pp[BS][BS];
-        blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
-        blk_zero<BS>(t2);
-        blk_zero<BS>(pp);
-        mm_acc<BS, false>(t2, X2, LDM, X1, LDM, u, lr, lc);  // (Pbar T) P+
-        mm_acc_ta<BS>(pp, Tc, LDM, X2, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
 #pragma unroll
-        for (int i = 0; i < BS; ++i)
+      for (int i = 0; i < BS; ++i)
 #pragma unroll
-          for (int j = 0; j < BS; ++j) {
-            GbR[i][j] += pb[i][j];                                                              // Gbar += Pbar
-            TbR[i][j] = fma(2.0, t2[i][j], fma(ab[lr * BS + i], ap[lc * BS + j], TbR[i][j]));  // Tbar += 2 Pbar T P+ + abar a+'
-          }
-        blk_store_lds<BS>(pp, Ps, LDM, lr, lc);  // Ps now holds P+bar (P_t itself is no longer needed this step)
-      }
+        for (int j = 0; j < BS; ++j) TbR[i][j] = fma(ab[lr * BS + i], ap[lc * BS + j], TbR[i][j]);  // Tbar += abar a+'
       wave_sync();
-      // -- update, reversed (P+bar in Ps)
-      for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
-        const int i = idx >> 3, o = idx & 7;
-        double sy = 0.0;
-        for (int j = 0; j < u; ++j) sy = fma(Ps[i * LDM + j], Kp[j * PS + o], sy);
-        Yp[i * PS + o] = sy;
-      }
       if (lane < 8) {  // vbar = -lam F^-1 v + K' a+bar
         double sv = -lam * fiv[lane];
         for (int i = 0; i < u; ++i) sv = fma(Kp[i * PS + lane], apb[i], sv);
         vb[lane] = (lane < p) ? sv : 0.0;
       }
-      wave_sync();
-      for (int idx = lane; idx < u * 8; idx += 64) {  // Kbar = a+bar v' - 2 Y (F + jit I)
-        const int i = idx >> 3, o = idx & 7;
-        double sk = apb[i] * vv[o];
-        for (int q = 0; q < 8; ++q) sk = fma(-2.0 * Yp[i * PS + q], Fs[q * 8 + o] + ((q == o) ? jitter : 0.0), sk);
-        Kb[i * PS + o] = (o < p) ? sk : 0.0;
+#pragma unroll
+      for (int k2 = 0; k2 < BS; ++k2) {
+        const int idx = lane + 64 * k2, i = idx >> 3, o = idx & 7;
+        if (i < u) Kacc[k2] = fma(apb[i], vv[o], Kacc[k2]);
       }
-      wave_sync();
-      for (int idx = lane; idx < u * 8; idx += 64) {  // Mbar = Kbar F^-1
-        const int i = idx >> 3, o = idx & 7;
-        double sm = 0.0;
-        for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], Fi[q * 8 + o], sm);
-        Mb[i * PS + o] = (o < p) ? sm : 0.0;
-      }
-      wave_sync();
-      {  // Fbar = -lam/2 (F^-1 - fiv fiv') - K' Y - K' Mbar      (lane = fo*8 + fq)
-        double sf = 0.0;
-        if (fo < p && fq < p) {
-          sf = -0.5 * lam * (Fi[lane] - fiv[fo] * fiv[fq]);
-          for (int i = 0; i < u; ++i) sf = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], sf);
-        }
-        Fb[lane] = sf;
-      }
-      wave_sync();
-      if (lane < 8 && lane < p) hb[lane] = fma(ww[lane], Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)
-      if (fo < p && fq < p) {  // Mbar += Zm' Fbar: row zpos[fo] (distinct per fo) gets w zv Fbar[fo,:]
-        Mb[zpos[fo] * PS + fq] = fma(ww[fo] * zv[fo], Fb[lane], Mb[zpos[fo] * PS + fq]);
-      }
-      wave_sync();
-      // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]
-      for (int idx = lane; idx < u * 8; idx += 64) {
-        const int i = idx >> 3, o = idx & 7;
-        if (o < p) Ps[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], Ps[i * LDM + zpos[o]]);
-      }
+      Qacc = fma(lam * fiv[fo], fiv[fq], Qacc);
+      nlam += lam;
       if (lane < u) t1[lane] = apb[lane];
       wave_sync();
       if (lane < p) {  // abar = a+bar - Zm' vbar;  dbar -= vbar
         t1[zpos[lane]] = fma(-ww[lane] * zv[lane], vb[lane], t1[zpos[lane]]);
         db[lane] -= vb[lane];
       }
-      for (int idx = lane; idx < u * u; idx += 64) {
-        const int i = idx / u, j = idx - i * u;
-        Pb[i * LDM + j] = 0.5 * (Ps[i * LDM + j] + Ps[j * LDM + i]);
+      if (t == src_t) {
+        // ---- covariance side, once per segment: Pb is the cotangent of the predicted covariance P_{src+1}, which the
+        // steady steps after src never touched; X1 = P+ of the source step.
+        kg_mm<BS, false>(X2, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
+        wave_sync();
+        {
+          double pb[BS][BS], t2[BS][BS], pp[BS][BS];
+          blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
+          blk_zero<BS>(t2);
+          blk_zero<BS>(pp);
+          mm_acc<BS, false>(t2, X2, LDM, X1, LDM, u, lr, lc);  // (Pbar T) P+
+          mm_acc_ta<BS>(pp, Tc, LDM, X2, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+              GbR[i][j] += pb[i][j];                        // Gbar += Pbar
+              TbR[i][j] = fma(2.0, t2[i][j], TbR[i][j]);    // Tbar += 2 Pbar T P+
+            }
+          blk_store_lds<BS>(pp, Ps, LDM, lr, lc);  // Ps now holds P+bar (P_t itself is no longer needed)
+        }
+        wave_sync();
+        for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
+          const int i = idx >> 3, o = idx & 7;
+          double sy = 0.0;
+          for (int j = 0; j < u; ++j) sy = fma(Ps[i * LDM + j], Kp[j * PS + o], sy);
+          Yp[i * PS + o] = sy;
+        }
+        wave_sync();
+#pragma unroll
+        for (int k2 = 0; k2 < BS; ++k2) {  // Kbar = sum_t a+bar_t v_t' - 2 Y (F + jit I)
+          const int idx = lane + 64 * k2, i = idx >> 3, o = idx & 7;
+          if (i < u) {
+            double sk = Kacc[k2];
+            for (int q = 0; q < 8; ++q) sk = fma(-2.0 * Yp[i * PS + q], Fs[q * 8 + o] + ((q == o) ? jitter : 0.0), sk);
+            Kb[i * PS + o] = (o < p) ? sk : 0.0;
+          }
+        }
+        wave_sync();
+        for (int idx = lane; idx < u * 8; idx += 64) {  // Mbar = Kbar F^-1
+          const int i = idx >> 3, o = idx & 7;
+          double sm = 0.0;
+          for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], Fi[q * 8 + o], sm);
+          Mb[i * PS + o] = (o < p) ? sm : 0.0;
+        }
+        wave_sync();
+        {  // Fbar = -1/2 (nlam F^-1 - sum_t lam_t fiv_t fiv_t') - K' Y - K' Mbar      (lane = fo*8 + fq)
+          double sf = 0.0;
+          if (fo < p && fq < p) {
+            sf = -0.5 * (nlam * Fi[lane] - Qacc);
+            for (int i = 0; i < u; ++i) sf = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], sf);
+          }
+          Fb[lane] = sf;
+        }
+        wave_sync();
+        if (lane < 8 && lane < p) hb[lane] = fma(ww[lane], Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)
+        if (fo < p && fq < p) {  // Mbar += Zm' Fbar: row zpos[fo] (distinct per fo) gets w zv Fbar[fo,:]
+          Mb[zpos[fo] * PS + fq] = fma(ww[fo] * zv[fo], Fb[lane], Mb[zpos[fo] * PS + fq]);
+        }
+        wave_sync();
+        // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]
+        for (int idx = lane; idx < u * 8; idx += 64) {
+          const int i = idx >> 3, o = idx & 7;
+          if (o < p) Ps[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], Ps[i * LDM + zpos[o]]);
+        }
+        wave_sync();
+        for (int idx = lane; idx < u * u; idx += 64) {
+          const int i = idx / u, j = idx - i * u;
+          Pb[i * LDM + j] = 0.5 * (Ps[i * LDM + j] + Ps[j * LDM + i]);
+        }
       }
       wave_sync();
       if (lane < NP) ab[lane] = (lane < u) ? t1[lane] : 0.0;
       wave_sync();
+      if (tm) {
+        const long long tk1 = clock64();
+        ph[(t == src_t) ? 3 : 4] += tk1 - tk0;
+        tk0 = tk1;
+      }
     }
     // ---- initial covariance: S = dlyap(T', Pbar_0) by doubling; Gbar += S; Tbar += 2 S T P0 ---------
     // S in Pb, A = T^(2^k) in X1
@@ -566,6 +636,11 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     if (lane < p) {
       if (dbar_out) dbar_out[(size_t)draw * p + lane] = db[lane];
       if (hbar_out) hbar_out[(size_t)draw * p + lane] = hb[lane];
+    }
+    if (tm) {
+      ph[5] += clock64() - tk0;
+      if (lane == 0)
+        for (int k2 = 0; k2 < 8; ++k2) dbg[k2] = ph[k2];
     }
   }
 }
