@@ -356,6 +356,74 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       const unsigned long long omask = load_mask(yt);
       const double lam = (omask != 0ull) ? 1.0 : 0.0;
       const bool light = steady && (omask == smask);
+      if (light) {
+        // ==== steady steps in registers (as in kalman_sel_kernel): this lane's row of Tc and of K, rows of F^-1 in lanes
+        // 0..7, the state exchanged by v_readlane; per step one global store of a_t and no LDS traffic.  The loop runs
+        // until the missing-data mask changes; the reverse sweep recomputes v, F^-1 v and a+ of these steps from a_t.
+        double trow[NP], krow[8], firow[8];
+#pragma unroll
+        for (int kk = 0; kk < NP; ++kk) trow[kk] = (lane < u) ? Tc[lane * LDM + kk] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          krow[q] = (lane < u) ? Kp[lane * PS + q] : 0.0;
+          firow[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
+        }
+        double a_reg = (lane < NP) ? av[lane] : 0.0;
+        const double v_dd = (lane < p) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
+        const int v_zpos = (lane < p) ? zpos[lane] : 0;
+        const double w_l = (lane < p && ((smask >> lane) & 1ull)) ? 1.0 : 0.0;
+        double yc = yt;
+        long long n_ss = 0;
+        for (;;) {
+          double* sgs = st + (size_t)t * STEP;
+          if (lane < NP) sgs[NP * NP + lane] = a_reg;
+          if (lane == 0) sgs[NP * NP + NP] = (double)seg_src;
+          const double a_sel = __shfl(a_reg, v_zpos, 64);
+          const double v_s = (lane < p) ? w_l * yt_or_zero(yc) - (v_dd + w_l * v_zv * a_sel) : 0.0;
+          double vsc[8];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
+          double w0 = 0.0, w1 = 0.0, a0 = a_reg, a1 = 0.0;
+#pragma unroll
+          for (int o = 0; o < 8; o += 2) {
+            w0 = fma(firow[o], vsc[o], w0);
+            w1 = fma(firow[o + 1], vsc[o + 1], w1);
+            a0 = fma(krow[o], vsc[o], a0);
+            a1 = fma(krow[o + 1], vsc[o + 1], a1);
+          }
+          double part = v_s * (w0 + w1);  // lanes >= 8: firow = 0
+          part += dpp_move_f64<0x111, 0xf>(part);
+          part += dpp_move_f64<0x112, 0xf>(part);
+          part += dpp_move_f64<0x114, 0xf>(part);
+          const double quad_s = readlane_f64(part, 7);
+          ll_acc += lam * (seg_logdet + quad_s);
+          n_ll += (lam != 0.0);
+          const double apl = a0 + a1;
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < NP; kk += 2) {
+            s0 = fma(trow[kk], readlane_f64(apl, kk), s0);
+            s1 = fma(trow[kk + 1], readlane_f64(apl, kk + 1), s1);
+          }
+          a_reg = (lane < u) ? s0 + s1 : 0.0;
+          ++n_ss;
+          if (t + 1 >= T_len) break;
+          const bool obs_n = (lane < p) && (yt_next == yt_next) && (yt_next != missing_fill);
+          if (__ballot(obs_n) != smask) break;
+          ++t;
+          yc = yt_next;
+          yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+        }
+        if (lane < NP) av[lane] = a_reg;
+        wave_sync();
+        if (tm) {
+          const long long tk1 = clock64();
+          ph[2] += tk1 - tk0;
+          ph[7] += n_ss;
+          tk0 = tk1;
+        }
+        continue;
+      }
       if (lane < NP) sg[NP * NP + lane] = av[lane];
       if (!light) {
         steady = false;
@@ -450,9 +518,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (lane < p) yr_next = y[(size_t)(T_len - 1) * p + lane];
     }
     for (int t = T_len - 1; t >= 0; --t) {
-      const int src_t = (int)src_next;
-      if (lane < NP) av[lane] = av_next;
-      const double yt = yr_next;
+      int src_t = (int)src_next;
+      double a_cur = av_next;
+      if (lane < NP) av[lane] = a_cur;
+      double yt = yr_next;
       if (t > 0) {
         const double* sgp = st + (size_t)(t - 1) * STEP;
         src_next = sgp[NP * NP + NP];
@@ -471,6 +540,107 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
         Qacc = 0.0;
         nlam = 0.0;
+      }
+      if (t != src_t) {
+        // ==== steady steps of the segment in registers: column `lane` of Tc (a+bar = T' abar), row `lane` of K (a+), rows of
+        // F^-1 and columns of K in lanes 0..7 (F^-1 v, K' a+bar); vectors are exchanged by v_readlane / ds_bpermute, no fence.
+        double tcol[NP], krow[8], firow[8], kcol[NP];
+#pragma unroll
+        for (int kk = 0; kk < NP; ++kk) {
+          tcol[kk] = (lane < u && kk < u) ? Tc[kk * LDM + lane] : 0.0;
+          kcol[kk] = (lane < 8 && kk < u) ? Kp[kk * PS + lane] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          krow[q] = (lane < u) ? Kp[lane * PS + q] : 0.0;
+          firow[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
+        }
+        const double v_dd = (lane < p) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
+        const int v_zpos = (lane < p) ? zpos[lane] : 0;
+        const double w_l = (lane < p && ((omask >> lane) & 1ull)) ? 1.0 : 0.0;
+        int my_o = -1;  // the observation (if any) that selects this lane's variable
+        for (int o = 0; o < p; ++o)
+          if (zpos[o] == lane) my_o = o;
+        const double my_wz = (my_o >= 0) ? (((omask >> my_o) & 1ull) ? 1.0 : 0.0) * zv[my_o] : 0.0;
+        const int my_os = (my_o >= 0) ? my_o : 0;
+        double ab_reg = (lane < NP) ? ab[lane] : 0.0, db_reg = 0.0;
+        while (t != src_t) {
+          // v, F^-1 v, a+ of step t from the stored a_t
+          const double a_sel = __shfl(a_cur, v_zpos, 64);
+          const double v_s = (lane < p) ? w_l * yt_or_zero(yt) - (v_dd + w_l * v_zv * a_sel) : 0.0;
+          double vsc[8];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
+          double w0 = 0.0, w1 = 0.0, a0 = (lane < u) ? a_cur : 0.0, a1 = 0.0;
+#pragma unroll
+          for (int o = 0; o < 8; o += 2) {
+            w0 = fma(firow[o], vsc[o], w0);
+            w1 = fma(firow[o + 1], vsc[o + 1], w1);
+            a0 = fma(krow[o], vsc[o], a0);
+            a1 = fma(krow[o + 1], vsc[o + 1], a1);
+          }
+          const double fiv_l = (lane < p) ? w0 + w1 : 0.0;  // F^-1 v (lanes 0..7)
+          const double ap_l = a0 + a1;                       // a+ (lanes < u)
+          // a+bar = T' abar
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < NP; kk += 2) {
+            s0 = fma(tcol[kk], readlane_f64(ab_reg, kk), s0);
+            s1 = fma(tcol[kk + 1], readlane_f64(ab_reg, kk + 1), s1);
+          }
+          const double apb_l = (lane < u) ? s0 + s1 : 0.0;
+          // Tbar += abar a+'
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const double abi = __shfl(ab_reg, lr * BS + i, 64);
+#pragma unroll
+            for (int j = 0; j < BS; ++j) TbR[i][j] = fma(abi, __shfl(ap_l, lc * BS + j, 64), TbR[i][j]);
+          }
+          // vbar = -lam F^-1 v + K' a+bar (lanes 0..7)
+          double q0 = -lam * fiv_l, q1 = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < NP; kk += 2) {
+            q0 = fma(kcol[kk], readlane_f64(apb_l, kk), q0);
+            q1 = fma(kcol[kk + 1], readlane_f64(apb_l, kk + 1), q1);
+          }
+          const double vb_l = (lane < p) ? q0 + q1 : 0.0;
+          // shared-quantity cotangents
+          const double v_mine = __shfl(v_s, lane & 7, 64);
+#pragma unroll
+          for (int k2 = 0; k2 < BS; ++k2) {
+            const int i = (lane + 64 * k2) >> 3;
+            const double api = __shfl(apb_l, i & 63, 64);
+            if (i < u) Kacc[k2] = fma(api, v_mine, Kacc[k2]);
+          }
+          Qacc = fma(lam * __shfl(fiv_l, fo, 64), __shfl(fiv_l, fq, 64), Qacc);
+          nlam += lam;
+          // abar = a+bar - Zm' vbar;  dbar -= vbar
+          ab_reg = apb_l - my_wz * __shfl(vb_l, my_os, 64);
+          db_reg -= vb_l;
+          // next (earlier) step: data was fetched one step ahead
+          --t;
+          src_t = (int)src_next;
+          a_cur = av_next;
+          yt = yr_next;
+          if (t > 0) {
+            const double* sgp = st + (size_t)(t - 1) * STEP;
+            src_next = sgp[NP * NP + NP];
+            if (lane < NP) av_next = sgp[NP * NP + lane];
+            yr_next = (lane < p) ? y[(size_t)(t - 1) * p + lane] : 0.0;
+          }
+        }
+        // t == src_t now: hand the state back to LDS and run the source step with the generic code below
+        if (lane < NP) {
+          ab[lane] = ab_reg;
+          av[lane] = a_cur;
+        }
+        if (lane < 8) db[lane] += db_reg;
+        wave_sync();
+        if (tm) {
+          const long long tk1 = clock64();
+          ph[4] += tk1 - tk0;
+          tk0 = tk1;
+        }
       }
       (void)update_mean(yt);
       // ---- mean side (every step).  abar is the cotangent of a_{t+1}.
