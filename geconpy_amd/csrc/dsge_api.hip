@@ -29,6 +29,7 @@ namespace {
 
 
 
+int g_pipeline_chunks = 0;  // fused device call: chunks alternating over two internal streams (< 2 = one pass on the caller's stream)
 int g_cr_fuse_R = 1;  // fused pipeline: take R from the cycle-reduction kernel's final elimination
 bool g_device_checked = false;
 int g_device_ok = 0;
@@ -160,6 +161,19 @@ int dsge_set_kalman_mfma(int enable) {
 }
 int dsge_set_gensys_split(int enable) {
   g_gensys_split = (enable == 2) ? 2 : (enable ? 1 : 0);
+  return DSGE_SUCCESS;
+}
+int dsge_set_pipeline_chunks(int n_chunks) {
+  if (n_chunks < 0 || n_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline chunks must be in 0..64");
+  g_pipeline_chunks = n_chunks;
+  return DSGE_SUCCESS;
+}
+int dsge_set_kalman_order(int enable) {
+  g_kalman_order = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
+int dsge_set_kalman_block(int enable) {
+  g_kalman_block = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_tiny(int enable) {
@@ -367,12 +381,18 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
                        missing_fill, n_state_hint, z_selector_hint, logp_out, status_io, st);
 }
 
+inline size_t pipeline_scratch_bytes(int batch, int n, int k) {
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  return 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + align256((size_t)batch * 4) + 4096;
+}
+
 static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
                     const double* Z, int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
                     const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
                     double jitter, double missing_fill, int n_state_hint, int z_selector_hint, int n_lead_hint,
                     double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* resid_out,
-                    int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out, int arena_id = 0) {
+                    int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out, int arena_id = 0,
+                    void* scratch_slice = nullptr) {
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
   int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
@@ -388,9 +408,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   if (batch == 0) return DSGE_SUCCESS;
 
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
-  void* base = nullptr;
-  if ((rc = arena_reserve(arena_id ? g_scratch2 : g_scratch,
-                          3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 4096, &base)))
+  void* base = scratch_slice;  // (a slice of an arena the caller reserved: chunks in flight on several streams)
+  if (!base &&
+      (rc = arena_reserve(arena_id ? g_scratch2 : g_scratch, pipeline_scratch_bytes(batch, n, k), &base)))
     return rc;
   Carver cv(base);
   double* Tw = T_out ? T_out : cv.take<double>(nn);
@@ -398,6 +418,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   double* RQR = cv.take<double>(nn);
   double* P0 = cv.take<double>(nn);
   int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
+  int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);  // cycle-reduction iterations: the dispatch key
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float acc_ms[3] = {0.f, 0.f, 0.f};
@@ -410,7 +431,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
     const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && g_cr_fuse_R;
     if (is_cr) {
-      rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, n_iter_out, st,
+      rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st,
                      solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0, fuse_R ? D : nullptr, k, fuse_R ? Rw : nullptr);
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
@@ -432,7 +453,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (rc) return rc;
     if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
     if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
-                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st)))
+                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st, is_cr ? it_w : nullptr)))
       return rc;
     if (ms_out) {
       HIP_TRY(hipEventRecord(ev[3], st));
@@ -458,9 +479,55 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
                                    int n_state_hint, int z_selector_hint, int n_lead_hint, double* logp_out,
                                    int32_t* status_out, double* T_out, double* R_out, double* resid_out,
                                    int32_t* n_iter_out, void* stream) {
-  return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
-                  tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, n_lead_hint, logp_out, status_out,
-                  T_out, R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
+  // Large batches run as chunks alternating over two library-owned streams (fork / join by events on the caller's
+  // stream): a draw whose covariance recursion converges late -- or never, within the sample -- keeps ONE wavefront of the
+  // Kalman launch busy for up to 200 full steps (1.5 ms) while the rest of the GPU has long finished; with two chunk
+  // pipelines in flight that tail overlaps the cycle-reduction launch of the next chunk instead of being idle time.
+  if (g_pipeline_chunks < 2 || batch < 1024 || batch / g_pipeline_chunks < 256)
+    return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
+                    tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, n_lead_hint, logp_out, status_out,
+                    T_out, R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
+  int rc = ensure_device();
+  if (rc) return rc;
+  constexpr int MAXS = 8;
+  static thread_local hipStream_t s_str[MAXS] = {};
+  static thread_local hipEvent_t s_ev[MAXS + 1] = {};
+  static thread_local int s_dev = -1;
+  int dev_now = 0;
+  HIP_TRY(hipGetDevice(&dev_now));
+  if (s_dev != dev_now) {
+    for (auto& x : s_str) HIP_TRY(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    for (auto& e : s_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s_dev = dev_now;
+  }
+  hipStream_t caller = (hipStream_t)stream;
+  const int n_chunks = g_pipeline_chunks;
+  const int n_str = n_chunks < MAXS ? n_chunks : MAXS;
+  const int per = ((batch + n_chunks - 1) / n_chunks + 63) & ~63;
+  const size_t slice = (pipeline_scratch_bytes(per, n, k) + 255) & ~(size_t)255;
+  void* base = nullptr;
+  if ((rc = arena_reserve(g_scratch, slice * n_chunks, &base))) return rc;
+  HIP_TRY(hipEventRecord(s_ev[MAXS], caller));
+  for (int i = 0; i < n_str; ++i) HIP_TRY(hipStreamWaitEvent(s_str[i], s_ev[MAXS], 0));
+  const bool q_b = (q_mode == DSGE_Q_DIAG_BATCHED || q_mode == DSGE_Q_FULL_BATCHED);
+  const size_t qk = (q_mode == DSGE_Q_FULL_BATCHED) ? (size_t)k * k : (size_t)k;
+  for (int c = 0; c * per < batch; ++c) {
+    const int c0 = c * per;
+    const int nb = (batch - c0 < per) ? batch - c0 : per;
+    const size_t o2 = (size_t)c0 * n * n, ok = (size_t)c0 * n * k;
+    rc = pipeline(A + o2, B + o2, C + o2, D + ok, q_b ? Q + c0 * qk : Q, q_mode, z_batched ? Z + (size_t)c0 * p * n : Z,
+                  z_batched, (d && d_batched) ? d + (size_t)c0 * p : d, d_batched,
+                  (Hdiag && h_batched) ? Hdiag + (size_t)c0 * p : Hdiag, h_batched, y, nb, n, k, p, T_len, solver, tol,
+                  max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, n_lead_hint, logp_out + c0, status_out + c0,
+                  T_out ? T_out + o2 : nullptr, R_out ? R_out + ok : nullptr, resid_out ? resid_out + c0 : nullptr,
+                  n_iter_out ? n_iter_out + c0 : nullptr, s_str[c % n_str], 1, nullptr, 0, (char*)base + slice * c);
+    if (rc) break;
+  }
+  for (int i = 0; i < n_str; ++i) {
+    HIP_TRY(hipEventRecord(s_ev[i], s_str[i]));
+    HIP_TRY(hipStreamWaitEvent(caller, s_ev[i], 0));
+  }
+  return rc;
 }
 
 int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, const double* C, const double* D,

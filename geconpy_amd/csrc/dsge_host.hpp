@@ -70,7 +70,7 @@ int launch_acf(const double* T, const double* Sigma, const double* Z, const doub
 int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                  double* logp, int32_t* status, hipStream_t st);
+                  double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr);
 // launch_grad.hip: reverse sweep of the Kalman filter + reverse of the assembly (dsge_kalman_grad.hpp)
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
                        const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
@@ -93,6 +93,8 @@ extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-red
 // process-wide settings of the fast Kalman kernel (launch_kalman.hip)
 extern long long* g_kalman_dbg;       // debug: device buffer for per-phase cycles of draw 0
 extern double g_kalman_steady_tol;    // steady-state switch (0 = never switch)
+extern int g_kalman_order;            // launch_kalman.hip: 0 = index order
+extern int g_kalman_block;            // launch_kalman.hip: 0 = steady-state steps one by one
 extern int g_kalman_mfma;             // launch_kalman.hip: 0 = VALU products only
 extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[24])
 extern int g_gensys_split;           // launch_gensys.hip: 1 = window path (three launches), 0 = single-launch kernel

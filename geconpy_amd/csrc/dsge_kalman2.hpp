@@ -43,6 +43,17 @@ struct Kf2Smem {
   static size_t bytes(int s_cap, bool dense_z = false) { return sizeof(double) * doubles(s_cap, dense_z); }
 };
 
+// hand-off record of kalman_sel_kernel -> kalman_tail_kernel (doubles per draw)
+constexpr int KT_T = 0;              // 32 x 32   transition, states-first ordering
+constexpr int KT_K = KT_T + 1024;    // 32 x 8    gain
+constexpr int KT_FI = KT_K + 256;    // 8 x 8     F^-1
+constexpr int KT_A = KT_FI + 64;     // 32        predicted state of the next step
+constexpr int KT_ZV = KT_A + 32;     // 8         selector values
+constexpr int KT_DD = KT_ZV + 8;     // 8         observation intercept
+constexpr int KT_ZP = KT_DD + 8;     // 8         selected positions (as doubles)
+constexpr int KT_SC = KT_ZP + 8;     // 16        m, s, t, mask, n_obs, step_mant, step_exp, quad_sum, quad_comp, ld_mant, ld_exp, n_ll, steady_step
+constexpr int KT_REC = KT_SC + 16;
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, src_lane);
@@ -159,7 +170,9 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
     int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
-    int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at) {
+    int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
+    double* __restrict__ tail_rec, int32_t* __restrict__ tail_flag, const int32_t* __restrict__ tail_from,
+    const int32_t* __restrict__ order) {
   constexpr int NP = Kf2Smem<BS>::NP, LDM = Kf2Smem<BS>::LDM;
   constexpr int PS = 10;  // row stride of the NP x 8 panels: 80 B keeps 16-byte alignment and spreads rows over all banks
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -185,7 +198,11 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
   const int fo = lane >> 3, fq = lane & 7;  // owner of F[fo][fq]
   const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
 
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  // `order` (optional): workgroup b processes draw order[b] -- the launch's makespan is set by its slowest draws (late or
+  // no steady state: up to T_len full steps on one wavefront), so the caller dispatches the likely slow ones first
+  // (kalman_order_kernel).  Results do not depend on the order: every draw writes logp[draw], status[draw].
+  for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
+    const int draw = order ? order[bi] : bi;
     const int32_t st_in = status[draw];
     if (rerun_only) {
       // later pass of the tile-size cascade: only the draws an earlier (smaller) instance flagged
@@ -388,6 +405,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
     // runs.  A step whose mask differs falls back to the full update from the current P.
     double kr_ss[8], av_reg = 0.0;
     int steady_step = -1;
+    bool handed_off = false;  // the tail kernel finishes the draw and writes its logp
     // selector Z and a small tile: the steady-state steps run out of registers only
     constexpr bool REG_SS = SEL && (BS <= 4);
 #pragma unroll
@@ -701,6 +719,48 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
       if (!steady) continue;
       // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same ====
       if (steady_step < 0) steady_step = t + 1;
+      if constexpr (REG_SS && !MF) {
+        // ---- hand-off: once the covariance is frozen AND the missing-data mask no longer changes until the end of the
+        // sample (t >= *tail_from, found by kalman_mask_scan_kernel), the remaining steps are a linear recursion in the
+        // mean alone.  kalman_tail_kernel runs it two steps at a time as one matrix-vector product per pair -- in a launch of
+        // its own, because the rows it keeps in registers do not fit next to this kernel's 256 (dsge_kalman_tail.hpp).
+        // This kernel only writes the record and leaves the time loop.
+        if (tail_rec && t + 2 < T_len && t >= *tail_from) {
+          double* rec = tail_rec + (size_t)draw * KT_REC;
+          for (int idx = lane; idx < NP * NP; idx += 64) {
+            const int i = idx / NP, c = idx - i * NP;
+            rec[KT_T + i * 32 + c] = (c < s) ? Tc[i * LDM + c] : 0.0;
+          }
+          for (int idx = lane; idx < NP * 8; idx += 64) rec[KT_K + idx] = Ks[(idx >> 3) * PS + (idx & 7)];
+          rec[KT_FI + lane] = Fi[lane];
+          if (lane < NP) rec[KT_A + lane] = (lane < m) ? av_reg : 0.0;
+          if (lane < 8) {
+            rec[KT_ZV + lane] = (lane < p) ? zv[lane] : 0.0;
+            rec[KT_DD + lane] = (lane < p) ? dd[lane] : 0.0;
+            rec[KT_ZP + lane] = (lane < p) ? (double)zpos[lane] : 0.0;
+          }
+          if (lane == 0) {
+            double* sc = rec + KT_SC;
+            sc[0] = (double)m;
+            sc[1] = (double)s;
+            sc[2] = (double)t;
+            sc[3] = (double)omask;
+            sc[4] = (double)n_obs;
+            sc[5] = step_mant;
+            sc[6] = (double)step_exp;
+            sc[7] = quad_sum;
+            sc[8] = quad_comp;
+            sc[9] = ld_mant;
+            sc[10] = (double)ld_exp;
+            sc[11] = (double)n_ll_steps;
+            sc[12] = (double)steady_step;
+            tail_flag[draw] = 1;
+          }
+          handed_off = true;
+          if (dbg) ph[5] += clock64() - tk0;
+          break;
+        }
+      }
       if constexpr (REG_SS) {
         // register-only: this lane's row of Tc, rows of F^-1 in lanes 0..7, no LDS memory traffic
         double trow[NP], finv_row[8];
@@ -819,7 +879,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
       ph[7] = clock64() - tk_start;
       for (int k = 0; k < 8; ++k) dbg[k] = ph[k];
     }
-    if (lane == 0) {
+    if (lane == 0 && !handed_off) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
       const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_sum);
       logp_out[draw] = ll;

@@ -1,0 +1,280 @@
+// The tail of the Kalman log-likelihood once the covariance recursion is frozen AND the missing-data mask no longer
+// changes: a linear recursion in the mean alone,
+//   v_t = c_t - Zw a_t,   a_{t+1} = Phi a_t + Gam c_t      (c_t = w o y_t - d,  Gam = T K,  Phi = T - Gam Zw).
+// kalman_sel_kernel runs it step by step (1.1 k cycles per step: a chain of shuffles and reductions); here two steps are ONE
+// matrix-vector product
+//     [ R v_t ; R v_{t+1} ; a_{t+2} ] = [ -R Zw      |  R        |  0  ]   [ a_t     ]
+//                                       [ -R Zw Phi  | -R Zw Gam |  R  ]   [ c_t     ]
+//                                       [  Phi^2     |  Phi Gam  | Gam ]   [ c_{t+1} ]
+// with R'R = F^-1 (Cholesky), so that v' F^-1 v is a sum of squares each lane accumulates on its own.  Lane i < m owns row i
+// of the state block, lanes 32..47 the 16 innovation rows; a row (m + 16 coefficients) lives in registers, the input vector is
+// broadcast by v_readlane: about 140 VALU instructions per pair of steps and no LDS traffic.  The set-up (Gam, Phi, R, the
+// rows) is done once per draw.  It is a launch of its own because those rows do not fit next to the 256 registers of
+// kalman_sel_kernel (an in-kernel version spilled into the full-step loop and lost more than it won); the hand-off record
+// (transition, gain, F^-1, state, partial sums: 11 KB per draw) goes through HBM once.
+#pragma once
+#include "dsge_device.hpp"
+#include "dsge_kalman2.hpp"
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge {
+
+// first step from which the missing-data mask stays the same until the end of the sample (0 if it never changes);
+// y is shared by all draws, so one wavefront scans it once per call.  *out must be 0 on entry.
+__global__ __launch_bounds__(64) void kalman_mask_scan_kernel(const double* __restrict__ y, int p, int T_len,
+                                                               double missing_fill, int32_t* __restrict__ out) {
+  const int lane = threadIdx.x;
+  for (int t = lane; t + 1 < T_len; t += 64) {
+    unsigned m0 = 0u, m1 = 0u;
+    for (int o = 0; o < p; ++o) {
+      const double a = y[(size_t)t * p + o], b = y[(size_t)(t + 1) * p + o];
+      m0 |= ((a == a) && (a != missing_fill)) ? (1u << o) : 0u;
+      m1 |= ((b == b) && (b != missing_fill)) ? (1u << o) : 0u;
+    }
+    if (m0 != m1) atomicMax(out, t + 1);
+  }
+}
+
+// Dispatch order for the Kalman launch: draws sorted by DESCENDING key (counting sort, keys clamped to 0..63; the order inside
+// a bin is arbitrary).  The key is the number of cycle-reduction iterations of the draw: both grow with the persistence of
+// the model (roots close to the unit circle), and a persistent model is the one whose covariance recursion reaches its
+// fixed point late.  One workgroup.
+__global__ __launch_bounds__(256) void kalman_order_kernel(const int32_t* __restrict__ key, int batch,
+                                                            int32_t* __restrict__ order) {
+  __shared__ int hist[64], offs[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < batch; i += 256) {
+    int kq = key[i];
+    kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
+    atomicAdd(&hist[kq], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 63; b >= 0; --b) {
+      offs[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < batch; i += 256) {
+    int kq = key[i];
+    kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
+    order[atomicAdd(&offs[kq], 1)] = i;
+  }
+}
+
+__global__ __launch_bounds__(64) void kalman_tail_kernel(const double* __restrict__ rec_all,
+                                                          const int32_t* __restrict__ tail_flag,
+                                                          const double* __restrict__ y, int batch, int p, int T_len,
+                                                          double missing_fill, double* __restrict__ logp_out,
+                                                          int32_t* __restrict__ status, int32_t* __restrict__ steady_at) {
+  constexpr int NP = 32, LDM = 33, PS = 10;
+  __shared__ __attribute__((aligned(16))) double Tc[NP * LDM];  // transition
+  __shared__ __attribute__((aligned(16))) double Ph[NP * LDM];  // Phi = T - Gam Zw
+  __shared__ double Ks[NP * PS], Gm[NP * PS];                   // K, Gam = T K
+  __shared__ double Fi[64], Rs[64], Lm[8 * LDM];                // F^-1, its Cholesky factor, -R Zw
+  __shared__ double av[NP], af[NP], vv[8], zv[8], dd[8];
+  __shared__ int zpos[8];
+  const int lane = threadIdx.x, fo = lane >> 3, fq = lane & 7;
+  const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    if (tail_flag[draw] != 1) continue;
+    const double* rec = rec_all + (size_t)draw * KT_REC;
+    const double* sc = rec + KT_SC;
+    const int m = (int)sc[0], s = (int)sc[1];
+    int t = (int)sc[2];
+    const unsigned long long omask = (unsigned long long)sc[3];
+    const int n_obs = (int)sc[4];
+    const double step_mant = sc[5];
+    const int step_exp = (int)sc[6];
+    double quad_sum = sc[7], quad_comp = sc[8], ld_mant = sc[9];
+    long long ld_exp = (long long)sc[10], n_ll = (long long)sc[11];
+    wave_sync();
+    for (int idx = lane; idx < NP * NP; idx += 64) Tc[(idx >> 5) * LDM + (idx & 31)] = rec[KT_T + idx];
+    for (int idx = lane; idx < NP * 8; idx += 64) Ks[(idx >> 3) * PS + (idx & 7)] = rec[KT_K + idx];
+    Fi[lane] = rec[KT_FI + lane];
+    if (lane < NP) av[lane] = rec[KT_A + lane];
+    if (lane < 8) {
+      zv[lane] = rec[KT_ZV + lane];
+      dd[lane] = rec[KT_DD + lane];
+      zpos[lane] = (int)rec[KT_ZP + lane];
+    }
+    wave_sync();
+    double av_reg = (lane < NP) ? av[lane] : 0.0;
+    for (int idx = lane; idx < m * 8; idx += 64) {  // Gam = T K
+      const int i = idx >> 3, o = idx & 7;
+      double g = 0.0;
+      for (int k2 = 0; k2 < s; ++k2) g = fma(Tc[i * LDM + k2], Ks[k2 * PS + o], g);
+      Gm[i * PS + o] = g;
+    }
+    // R = upper Cholesky factor of F^-1, in the 8 x 8 lane grid (lane = fo * 8 + fq)
+    double rch = Fi[lane];
+    bool chol_ok = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double dj = readlane_f64(rch, j * 9);
+      if (!(dj > 0.0)) chol_ok = false;
+      const double rd = 1.0 / sqrt(dj);
+      const double rowq = __shfl(rch, (j << 3) | fq, 64), rowo = __shfl(rch, (j << 3) | fo, 64);
+      if (fo == j)
+        rch = rowq * rd;
+      else if (fo > j)
+        rch = fma(-rowo * (rd * rd), rowq, rch);
+    }
+    if (fq < fo) rch = 0.0;
+    Rs[lane] = rch;
+    wave_sync();
+    if (chol_ok && t + 2 < T_len) {
+      for (int idx = lane; idx < NP * LDM; idx += 64) Ph[idx] = 0.0;
+      wave_sync();
+      for (int idx = lane; idx < m * m; idx += 64) {  // Phi = T - Gam Zw
+        const int i = idx / m, c = idx - i * m;
+        double val = (c < s) ? Tc[i * LDM + c] : 0.0;
+        for (int o = 0; o < p; ++o)
+          if (zpos[o] == c && ((omask >> o) & 1ull)) val = fma(-zv[o], Gm[i * PS + o], val);
+        Ph[i * LDM + c] = val;
+      }
+      for (int idx = lane; idx < 8 * LDM; idx += 64) Lm[idx] = 0.0;
+      wave_sync();
+      if (lane < 8)
+        for (int q = lane; q < p; ++q)
+          if ((omask >> q) & 1ull) Lm[lane * LDM + zpos[q]] -= Rs[lane * 8 + q] * zv[q];  // row `lane` of -R Zw
+      wave_sync();
+      const bool vl = lane >= 32 && lane < 48;
+      const int vj = (lane - 32) >> 3, vo = lane & 7;
+      double coef[NP + 16];
+      {
+        double Lw[NP];
+#pragma unroll
+        for (int k2 = 0; k2 < NP; ++k2)
+          Lw[k2] = (k2 < m) ? ((lane < m) ? Ph[lane * LDM + k2] : (vl ? Lm[vo * LDM + k2] : 0.0)) : 0.0;
+#pragma unroll
+        for (int c = 0; c < NP + 16; ++c) coef[c] = 0.0;
+        for (int k2 = 0; k2 < m; ++k2) {  // (row of weights) x [Phi | Gam]
+          const double lw = (lane < m) ? Ph[lane * LDM + k2] : (vl ? Lm[vo * LDM + k2] : 0.0);
+#pragma unroll
+          for (int c = 0; c < NP; ++c) coef[c] = fma(lw, Ph[k2 * LDM + c], coef[c]);
+#pragma unroll
+          for (int o = 0; o < 8; ++o) coef[NP + o] = fma(lw, Gm[k2 * PS + o], coef[NP + o]);
+        }
+        if (lane < m) {
+#pragma unroll
+          for (int o = 0; o < 8; ++o) coef[NP + 8 + o] = Gm[lane * PS + o];
+        } else if (vl && vj == 1) {
+#pragma unroll
+          for (int o = 0; o < 8; ++o) coef[NP + 8 + o] = (o < p) ? Rs[vo * 8 + o] : 0.0;
+        } else if (vl) {  // first step of the pair: [-R Zw | R | 0]
+#pragma unroll
+          for (int c = 0; c < NP; ++c) coef[c] = Lw[c];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) {
+            coef[NP + o] = (o < p) ? Rs[vo * 8 + o] : 0.0;
+            coef[NP + 8 + o] = 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < NP + 16; ++c) coef[c] = 0.0;
+        }
+      }
+      // the pair loop: steps t+1, t+2 per trip; y of the NEXT trip is in flight during the current one
+      const double c_dd = (vl && vo < p) ? dd[vo] : 0.0;
+      const bool c_w = vl && vo < p && ((omask >> vo) & 1ull);
+      double yb = (vl && vo < p) ? y[(size_t)(t + 1 + vj) * p + vo] : 0.0;
+      double qacc = 0.0;
+      while (t + 2 < T_len) {
+        const double cval = vl ? ((c_w ? ((yb == yb) ? yb : 0.0) : 0.0) - c_dd) : 0.0;
+        yb = (vl && vo < p && t + 3 + vj < T_len) ? y[(size_t)(t + 3 + vj) * p + vo] : 0.0;
+        double o0 = 0.0, o1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NP; c += 2) {
+          if (c < m) {
+            o0 = fma(coef[c], readlane_f64(av_reg, c), o0);
+            o1 = fma(coef[c + 1], readlane_f64(av_reg, c + 1), o1);
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < 16; o += 2) {
+          o0 = fma(coef[NP + o], readlane_f64(cval, 32 + o), o0);
+          o1 = fma(coef[NP + o + 1], readlane_f64(cval, 33 + o), o1);
+        }
+        const double outv = o0 + o1;
+        if (lane < m) av_reg = outv;
+        if (vl && n_obs > 0) qacc = fma(outv, outv, qacc);
+        if (n_obs > 0) {
+          int e;
+          ld_mant = frexp(ld_mant * step_mant, &e);
+          ld_exp += (long long)e + step_exp;
+          ld_mant = frexp(ld_mant * step_mant, &e);
+          ld_exp += (long long)e + step_exp;
+          n_ll += 2;
+        }
+        t += 2;
+      }
+      const double qs = wave_sum_dpp(qacc);
+      const double yk = qs - quad_comp;
+      const double tk = quad_sum + yk;
+      quad_comp = (tk - quad_sum) - yk;
+      quad_sum = tk;
+    }
+    // ---- whatever is left (one step after an even number of pairs; everything if F^-1 lost positive definiteness to
+    // rounding): the plain recursion through LDS
+    wave_sync();
+    if (lane < NP) av[lane] = (lane < m) ? av_reg : 0.0;
+    wave_sync();
+    while (t + 1 < T_len) {
+      ++t;
+      if (lane < 8) {
+        double v = 0.0;
+        if (lane < p) {
+          const double yt = y[(size_t)t * p + lane];
+          const bool ob = (omask >> lane) & 1ull;
+          v = (ob ? ((yt == yt) ? yt : 0.0) : 0.0) - (dd[lane] + (ob ? 1.0 : 0.0) * zv[lane] * av[zpos[lane]]);
+        }
+        vv[lane] = v;
+      }
+      wave_sync();
+      double part = 0.0;
+      if (lane < 8) {
+        double w = 0.0;
+        for (int q = 0; q < 8; ++q) w = fma(Fi[lane * 8 + q], vv[q], w);
+        part = vv[lane] * w;
+      }
+      const double qp = wave_sum_dpp(part);
+      if (n_obs > 0) {
+        const double yk = qp - quad_comp;
+        const double tk = quad_sum + yk;
+        quad_comp = (tk - quad_sum) - yk;
+        quad_sum = tk;
+        int e;
+        ld_mant = frexp(ld_mant * step_mant, &e);
+        ld_exp += (long long)e + step_exp;
+        ++n_ll;
+      }
+      if (lane < m) {
+        double a = av[lane];
+        for (int o = 0; o < 8; ++o) a = fma(Ks[lane * PS + o], vv[o], a);
+        af[lane] = a;
+      }
+      wave_sync();
+      if (lane < m) {
+        double a = 0.0;
+        for (int k2 = 0; k2 < s; ++k2) a = fma(Tc[lane * LDM + k2], af[k2], a);
+        av[lane] = a;
+      }
+      wave_sync();
+    }
+    if (lane == 0) {
+      const double logdet = log(ld_mant) + (double)ld_exp * LN2;
+      const double ll = -0.5 * ((double)n_ll * (double)p * LN2PI + logdet + quad_sum);
+      logp_out[draw] = ll;
+      if (steady_at) steady_at[draw] = (int)sc[12];
+      if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
+    }
+  }
+}
+
+}  // namespace dsge

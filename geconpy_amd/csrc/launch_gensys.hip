@@ -18,7 +18,7 @@ struct GwArena {
 // One workspace per (device, stream): the chunked host path keeps two pipelines in flight on two streams, and a
 // workspace shared between them would be overwritten by the next chunk's reduce launch while the previous chunk's QZ /
 // post launches still read it.
-constexpr int GW_SLOTS = 4;
+constexpr int GW_SLOTS = 16;
 GwArena g_gw_arena[16][GW_SLOTS];
 constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
 

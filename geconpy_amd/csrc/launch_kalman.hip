@@ -2,16 +2,63 @@
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
+#include "dsge_kalman_tail.hpp"
 #include "dsge_kalman_tiny.hpp"
 
 namespace dsge_host {
 
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
+int g_kalman_order = 1;  // dispatch the Kalman workgroups in descending order of the caller's key (cycle-reduction iterations)
+int g_kalman_block = 0;  // 1 = hand the steady, constant-mask tail of the sample to kalman_tail_kernel (measured slower)
 double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
 int32_t* g_kalman_steady_at = nullptr;
 int g_kalman_mfma = 0;  // 1 = prediction products of the BS = 2, 3 selector instances on the FP64 matrix core
                        // (experimental: measured SLOWER than the VALU register blocks)
 int g_kalman_tiny = 1;  // 0 = never use the thread-per-draw kernel (tests compare the two paths)  // debug: device buffer [batch], first steady step per draw (-1 = never)
+
+namespace {
+// hand-off records of the fast kernel for kalman_tail_kernel: one buffer per (device, stream), grown on demand
+struct TailArena {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  bool used = false;
+};
+TailArena g_tail_arena[16][16];
+
+int tail_reserve(size_t bytes, hipStream_t st, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
+  TailArena* a = nullptr;
+  for (auto& slot : g_tail_arena[dev])
+    if (slot.used && slot.stream == st) a = &slot;
+  if (!a)
+    for (auto& slot : g_tail_arena[dev])
+      if (!slot.used) {
+        a = &slot;
+        break;
+      }
+  if (!a) {
+    HIP_TRY(hipDeviceSynchronize());
+    a = &g_tail_arena[dev][0];
+  }
+  a->used = true;
+  a->stream = st;
+  if (a->cap < bytes) {
+    if (a->ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a->ptr));
+      a->ptr = nullptr;
+      a->cap = 0;
+    }
+    HIP_TRY(hipMalloc(&a->ptr, bytes + bytes / 4));
+    a->cap = bytes + bytes / 4;
+  }
+  *out = a->ptr;
+  return DSGE_SUCCESS;
+}
+}  // namespace
 
 // p0_valid = 0: P0 is an uninitialised scratch buffer.  The fast kernels then compute the stationary
 // covariance themselves (on the reduced model); only the draws that end up in the general kernel get
@@ -19,7 +66,7 @@ int g_kalman_tiny = 1;  // 0 = never use the thread-per-draw kernel (tests compa
 int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                  double* logp, int32_t* status, hipStream_t st) {
+                  double* logp, int32_t* status, hipStream_t st, const int32_t* order_key) {
   const int bs = tile_bs(m);
   int rc = DSGE_ERR_INVALID;
   // Fast path: selector Z, p <= 8, compact state block of at most s_cap columns.  Draws that
@@ -44,6 +91,33 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     }
     HIP_TRY(hipGetLastError());
     launched_fast = true;
+  }
+  // Tail hand-off (selector Z, no hint violation needed: the kernels decide per draw): records, flags and the index from
+  // which the missing-data mask of the shared panel y no longer changes.
+  double* tail_rec = nullptr;
+  int32_t* tail_flag = nullptr;
+  int32_t* tail_from = nullptr;
+  int32_t* order = nullptr;
+  const bool want_tail = fast && z_selector_hint && g_kalman_block && T_len >= 8;
+  const bool want_order = fast && order_key && g_kalman_order && batch >= 512;
+  if (want_tail || want_order) {
+    void* base = nullptr;
+    const size_t rec_bytes = want_tail ? (size_t)batch * dsge::KT_REC * sizeof(double) : 0;
+    const size_t int_bytes = ((2 * (size_t)batch + 1) * sizeof(int32_t) + 255) & ~(size_t)255;
+    if ((rc = tail_reserve(rec_bytes + int_bytes, st, &base))) return rc;
+    int32_t* ints = (int32_t*)base;  // [batch] flags, [1] scan result, [batch] dispatch order
+    if (want_tail) {
+      tail_flag = ints;
+      tail_from = ints + batch;
+      tail_rec = (double*)((char*)base + int_bytes);
+      HIP_TRY(hipMemsetAsync(tail_flag, 0, ((size_t)batch + 1) * sizeof(int32_t), st));
+      hipLaunchKernelGGL(dsge::kalman_mask_scan_kernel, dim3(1), dim3(64), 0, st, y, p, T_len, missing_fill, tail_from);
+    }
+    if (want_order) {
+      order = ints + batch + 1;
+      hipLaunchKernelGGL(dsge::kalman_order_kernel, dim3(1), dim3(256), 0, st, order_key, batch, order);
+    }
+    HIP_TRY(hipGetLastError());
   }
   if (fast) {
     // The fast kernel filters only the variables that matter (states + observed non-states), so its
@@ -78,7 +152,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                 hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(batch), dim3(64), lds, st, T, RQR,
                                    p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p,
                                    T_len, s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at);
+                                   g_kalman_steady_at, nullptr, nullptr, nullptr, order);
                 HIP_TRY(hipGetLastError());
                 launched_fast = true;
               }
@@ -91,7 +165,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                  s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                 g_kalman_steady_at);
+                                 g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
             }
@@ -106,7 +180,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
                                  jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                 g_kalman_steady_at);
+                                 g_kalman_steady_at, nullptr, nullptr, nullptr, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
             }
@@ -115,6 +189,11 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
       });
       if (rc) return rc;
     }
+  }
+  if (tail_rec) {
+    hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, st, (const double*)tail_rec,
+                       (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at);
+    HIP_TRY(hipGetLastError());
   }
   if (!p0_valid) {
     // full-size P0 for the general kernel: flagged draws only when a fast kernel ran, else every draw

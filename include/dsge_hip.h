@@ -174,6 +174,27 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
+/* Fused evaluation with cycle reduction: the workgroups of the Kalman launch are dispatched in descending order of the
+ * draws' cycle-reduction iteration counts (a counting sort on the device).  The launch's makespan is set by its slowest
+ * draws -- a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for
+ * up to T_len full steps -- and both counts grow with the persistence, so the likely slow draws start first instead of
+ * wherever their index puts them (3.29 -> 2.8 ms per 4096 SW-shaped draws).  Results are unaffected: every draw writes
+ * its own logp / status.  enable = 0: index order.  Default on.  Process-wide. */
+int dsge_set_kalman_order(int enable);
+/* dsge_solve_kalman_logp_batched (device pointers) runs batches of >= 1024 draws as n_chunks chunks alternating over two
+ * library-owned streams, forked from and joined to the caller's stream by events, so that the straggler tail of one
+ * chunk's Kalman launch (a draw whose covariance recursion converges late keeps one wavefront busy for up to T_len full
+ * steps) overlaps the solver launch of the next chunk.  Results are identical (the kernels are per-draw).  n_chunks < 2:
+ * one pass on the caller's stream (the default: on MI355X the chunks' launches did not overlap enough to pay for the
+ * extra straggler tails).  Process-wide. */
+int dsge_set_pipeline_chunks(int n_chunks);
+/* Experimental, OFF by default: once the covariance is frozen and the missing-data mask of the shared panel no longer
+ * changes, the fast Kalman kernel hands the rest of the sample to kalman_tail_kernel, which runs the (then linear) mean
+ * recursion two steps at a time as one matrix-vector product [R v_t; R v_{t+1}; a_{t+2}] = M [a_t; c_t; c_{t+1}], R'R = F^-1,
+ * rows in registers.  It removes a quarter of the kernel's work but not its makespan, which is set by the draws that reach
+ * the steady state late or never -- measured 3.14 vs 2.85 ms per 4096 draws with the launch's extra 0.26 ms (DESIGN.md
+ * 4.3).  enable = 1 switches it on (tests compare both: same logp to 1e-12).  Process-wide. */
+int dsge_set_kalman_block(int enable);
 /* gensys runs as five launches on the active window of the pencil -- structural deflation; real Hessenberg-triangular
  * reduction and complex QZ + reordering on the (N - z) x (N - z) block the deflation leaves, with H and T sharing one LDS
  * array and the accumulated right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing --

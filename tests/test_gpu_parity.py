@@ -1227,3 +1227,81 @@ def test_gensys_nan_inf_inputs_are_flagged_not_hung(split):
         assert out["status"][i] == 0
         assert_allclose(out["T"][i], clean["T"][i], atol=1e-10)
         assert np.isfinite(fused["logp"][i]) and fused["status"][i] == 0
+
+
+def test_kalman_block_steady_matches_step_by_step():
+    """Tail hand-off (kalman_tail_kernel: steady-state steps two at a time, one matrix-vector product per pair, R'R = F^-1,
+    rows in registers; experimental, off by default) vs the step-by-step register loop: same status, logp to 1e-12; with missing-data patterns that interrupt the pairs (a mask
+    change at an odd and at an even offset, a fully missing step, a series that stops), an odd remaining step count, and
+    against the oracle."""
+    lib = _lib.load()
+    om = wl.sw_shaped_observation_model()
+    b = wl.sw_shaped_batch(24)
+    q = b["sigma"] ** 2
+    ys = []
+    y0 = om["y"].copy()
+    ys.append(y0)
+    y1 = om["y"][:151].copy()            # odd length
+    y1[90, 1] = np.nan                   # single missing entry at an even offset
+    y1[121, 3] = np.nan                  # ... and at an odd one
+    y1[130, :] = np.nan                  # fully missing step
+    ys.append(y1)
+    y2 = om["y"].copy()
+    y2[100:, 2] = np.nan                 # a series that stops: second steady segment with another mask
+    y2[60:64, 0] = oracle.MISSING_FILL   # fill-value run
+    ys.append(y2)
+    for y in ys:
+        out0 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, Hdiag=om["Hdiag"], tol=1e-8,
+                                                 max_iter=1000)
+        _lib.check(lib.dsge_set_kalman_block(1))
+        try:
+            out1 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, Hdiag=om["Hdiag"],
+                                                     tol=1e-8, max_iter=1000)
+        finally:
+            _lib.check(lib.dsge_set_kalman_block(0))
+        assert np.array_equal(out1["status"], out0["status"]) and np.all(out1["status"] == 0)
+        assert_allclose(out1["logp"], out0["logp"], rtol=1e-12)
+        for i in (0, 7, 23):
+            r = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], y,
+                                         H=np.diag(om["Hdiag"]), tol=1e-8, max_iter=1000)
+            assert_allclose(out1["logp"][i], r["logp"], rtol=LOGP_RTOL)
+
+
+def test_dispatch_order_and_chunks_do_not_change_results():
+    """Scheduling switches of the fused device call -- Kalman workgroups dispatched in descending order of the cycle-
+    reduction iteration counts (default on), chunks on several streams (default off) -- must leave logp / status of every
+    draw bit-identical (each draw writes its own outputs), including failed draws and a batch that is not a multiple of
+    the chunk size."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    lib = _lib.load()
+    nb = 1500
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    A = b["A"].copy()
+    A[77, 0, 0] = np.nan
+    eng = LogpEngine(torch.device("cuda", 0))
+    dA, dB, dC, dD = (eng.to_device(x) for x in (A, b["B"], b["C"], b["D"]))
+    dq = eng.to_device(b["sigma"] ** 2)
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:50]), eng.to_device(om["Hdiag"])
+    hints = eng.structure_hints(dA, dZ)
+
+    def run():
+        lp, st = eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000,
+                                       n_state_hint=hints[0], z_selector_hint=hints[1])
+        torch.cuda.synchronize()
+        return lp.cpu().numpy(), st.cpu().numpy()
+
+    ref_lp, ref_st = run()
+    assert ref_st[77] != 0 and ref_lp[77] == -np.inf and np.count_nonzero(ref_st) == 1
+    try:
+        for order, chunks in ((0, 0), (1, 3), (0, 4), (1, 2)):
+            _lib.check(lib.dsge_set_kalman_order(order))
+            _lib.check(lib.dsge_set_pipeline_chunks(chunks))
+            lp, st = run()
+            assert np.array_equal(st, ref_st) and np.array_equal(lp, ref_lp), (order, chunks)
+    finally:
+        _lib.check(lib.dsge_set_kalman_order(1))
+        _lib.check(lib.dsge_set_pipeline_chunks(0))
