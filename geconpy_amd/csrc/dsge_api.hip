@@ -616,7 +616,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   if (chunk > (size_t)batch) chunk = (size_t)batch;
   const size_t nn = chunk * n * n, nk = chunk * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_scratch, 4 * align256(nn * 8) + align256(nk * 8) + align256(chunk * 12) +
+  if ((rc = arena_reserve(g_scratch, 4 * align256(nn * 8) + align256(nk * 8) + align256(chunk * 12) + 2 * align256(chunk * 4) +
                                          align256(chunk * per_draw + 8) + 8192,
                           &base)))
     return rc;
@@ -627,6 +627,8 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   double* Tbar = cv.take<double>(nn);
   double* Gbar = cv.take<double>(nn);
   int32_t* eu_w = cv.take<int32_t>(chunk * 3);
+  int32_t* it_w = cv.take<int32_t>(chunk);   // cycle-reduction iterations = dispatch key of the reverse-sweep launch
+  int32_t* ord_w = cv.take<int32_t>(chunk);
   double* store = cv.take<double>(chunk * per_draw / sizeof(double) + 1);
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)(((size_t)batch - c0 < chunk) ? (size_t)batch - c0 : chunk);
@@ -639,14 +641,15 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
     if (solver == DSGE_SOLVER_GENSYS)
       rc = launch_gensys(Ac, Bc, Cc, nb, n, tol, n_lead_hint, Tw, eu_w, stc, st);
     else
-      rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, nullptr, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
+      rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, it_w, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
     if (rc) return rc;
     if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
                               Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))
       return rc;
     if ((rc = launch_kalman_grad(Tw, RQR, Zc, z_batched, dc, d_batched, hc, h_batched, y, nb, n, p, T_len, jitter,
                                  missing_fill, u_hint, store, logp_out + c0, stc, Tbar, Gbar,
-                                 d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st)))
+                                 d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st,
+                                 (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w, ord_w)))
       return rc;
     if ((rc = launch_grad_assemble(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, nb, n, k, stc, Tbar, B_bar + c0 * n * n,
                                    C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * k, st)))

@@ -511,4 +511,37 @@ __device__ __forceinline__ void gj_unpermute(double* W, int ldw, int n, int g_fi
   }
 }
 
+// Dispatch order for the Kalman launch: draws sorted by DESCENDING key (counting sort, keys clamped to 0..63; the order inside
+// a bin is arbitrary).  The key is the number of cycle-reduction iterations of the draw: both grow with the persistence of
+// the model (roots close to the unit circle), and a persistent model is the one whose covariance recursion reaches its
+// fixed point late.  One workgroup.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void kalman_order_kernel(const int32_t* __restrict__ key, int batch,
+                                                            int32_t* __restrict__ order) {
+  __shared__ int hist[64], offs[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < batch; i += BLOCK) {
+    int kq = key[i];
+    kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
+    atomicAdd(&hist[kq], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 63; b >= 0; --b) {
+      offs[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < batch; i += BLOCK) {
+    int kq = key[i];
+    kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
+    order[atomicAdd(&offs[kq], 1)] = i;
+  }
+}
+
+
 }  // namespace dsge

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, double jitter, double missing_fill,
     double steady_tol, double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
-    double* __restrict__ hbar_out, long long* __restrict__ dbg) {
+    double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
   constexpr size_t STEP = (size_t)NP * NP + NP + 1;  // doubles stored per time step: P (NP x NP, dense), a, source step
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
   const double LN2PI = 1.8378770664093453;
 
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug (draw 0): setup+P0, fwd full, fwd steady, rev full, rev steady, tail, #full, #steady
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
+    const int draw = order ? order[bi] : bi;  // likely slow draws first (kalman_order_kernel), see kalman_sel_kernel
     const bool tm = dbg && draw == 0;
     long long tk0 = tm ? clock64() : 0;
     const size_t off = (size_t)draw * m_full * m_full;

@@ -36,37 +36,6 @@ __global__ __launch_bounds__(64) void kalman_mask_scan_kernel(const double* __re
   }
 }
 
-// Dispatch order for the Kalman launch: draws sorted by DESCENDING key (counting sort, keys clamped to 0..63; the order inside
-// a bin is arbitrary).  The key is the number of cycle-reduction iterations of the draw: both grow with the persistence of
-// the model (roots close to the unit circle), and a persistent model is the one whose covariance recursion reaches its
-// fixed point late.  One workgroup.
-__global__ __launch_bounds__(256) void kalman_order_kernel(const int32_t* __restrict__ key, int batch,
-                                                            int32_t* __restrict__ order) {
-  __shared__ int hist[64], offs[64];
-  const int tid = threadIdx.x;
-  if (tid < 64) hist[tid] = 0;
-  __syncthreads();
-  for (int i = tid; i < batch; i += 256) {
-    int kq = key[i];
-    kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
-    atomicAdd(&hist[kq], 1);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int b = 63; b >= 0; --b) {
-      offs[b] = acc;
-      acc += hist[b];
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < batch; i += 256) {
-    int kq = key[i];
-    kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
-    order[atomicAdd(&offs[kq], 1)] = i;
-  }
-}
-
 __global__ __launch_bounds__(64) void kalman_tail_kernel(const double* __restrict__ rec_all,
                                                           const int32_t* __restrict__ tail_flag,
                                                           const double* __restrict__ y, int batch, int p, int T_len,

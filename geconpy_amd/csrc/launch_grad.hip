@@ -15,9 +15,16 @@ size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len) {
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
                        const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                        double jitter, double missing_fill, int u_hint, double* store, double* logp, int32_t* status,
-                       double* Tbar, double* Gbar, double* dbar, double* hbar, hipStream_t st) {
+                       double* Tbar, double* Gbar, double* dbar, double* hbar, hipStream_t st, const int32_t* order_key,
+                       int32_t* order_buf) {
   const int bs = grad_tile(u_hint, m);
   int rc = DSGE_ERR_INVALID;
+  const int32_t* order = nullptr;
+  if (order_key && order_buf && g_kalman_order && batch >= 512) {
+    hipLaunchKernelGGL(dsge::kalman_order_kernel<256>, dim3(1), dim3(256), 0, st, order_key, batch, order_buf);
+    HIP_TRY(hipGetLastError());
+    order = order_buf;
+  }
   DISPATCH_BS(bs, 8, {
     const size_t lds = dsge::KgSmem<BS>::bytes;
     if (lds > LDS_LIMIT) return fail(DSGE_ERR_INVALID, "gradient kernel: model too large for the 160 KB LDS");
@@ -26,7 +33,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
       hipLaunchKernelGGL(dsge::kalman_grad_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
                          Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, g_kalman_steady_tol, store, logp, status, Tbar,
                          Gbar,
-                         dbar, hbar, g_kalman_dbg);
+                         dbar, hbar, g_kalman_dbg, order);
       HIP_TRY(hipGetLastError());
     }
   });
