@@ -168,8 +168,9 @@ int dsge_set_pipeline_chunks(int n_chunks) {
   g_pipeline_chunks = n_chunks;
   return DSGE_SUCCESS;
 }
-int dsge_set_kalman_order(int enable) {
-  g_kalman_order = enable ? 1 : 0;
+int dsge_set_kalman_order(int mode) {
+  if (mode < 0 || mode > 2) return fail(DSGE_ERR_INVALID, "order mode must be 0, 1 or 2");
+  g_kalman_order = mode;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_block(int enable) {
@@ -383,7 +384,7 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
 
 inline size_t pipeline_scratch_bytes(int batch, int n, int k) {
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
-  return 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + align256((size_t)batch * 4) + 4096;
+  return 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 2 * align256((size_t)batch * 4) + 4096;
 }
 
 static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
@@ -418,7 +419,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   double* RQR = cv.take<double>(nn);
   double* P0 = cv.take<double>(nn);
   int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
-  int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);  // cycle-reduction iterations: the dispatch key
+  int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);  // cycle-reduction iterations
+  int32_t* key_w = cv.take<int32_t>((size_t)batch);                            // dispatch key of the Kalman launch
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float acc_ms[3] = {0.f, 0.f, 0.f};
@@ -452,8 +454,17 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
       rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, RQR, P0, status_out, 1, 2, st);
     if (rc) return rc;
     if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
+    const int32_t* okey = nullptr;
+    // dispatch key of the Kalman launch: the cycle-reduction iteration counts when there are any (free, and the better
+    // predictor on the bench workload), else a persistence key computed from T itself (gensys, backward-direct)
+    if (g_kalman_order == 1 && is_cr) {
+      okey = it_w;
+    } else if (g_kalman_order != 0 && batch >= 512 && n <= 64) {
+      if ((rc = launch_persistence_key(Tw, status_out, batch, n, key_w, st))) return rc;
+      okey = key_w;
+    }
     if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
-                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st, is_cr ? it_w : nullptr)))
+                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st, okey)))
       return rc;
     if (ms_out) {
       HIP_TRY(hipEventRecord(ev[3], st));
@@ -646,10 +657,17 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
     if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
                               Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))
       return rc;
+    const int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;
+    if (g_kalman_order == 0) {
+      gkey = nullptr;
+    } else if ((g_kalman_order == 2 || solver == DSGE_SOLVER_GENSYS) && nb >= 512) {
+      if ((rc = launch_persistence_key(Tw, stc, nb, n, it_w, st))) return rc;  // (the iteration counts are not needed again)
+      gkey = it_w;
+    }
     if ((rc = launch_kalman_grad(Tw, RQR, Zc, z_batched, dc, d_batched, hc, h_batched, y, nb, n, p, T_len, jitter,
                                  missing_fill, u_hint, store, logp_out + c0, stc, Tbar, Gbar,
                                  d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st,
-                                 (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w, ord_w)))
+                                 gkey, ord_w)))
       return rc;
     if ((rc = launch_grad_assemble(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, nb, n, k, stc, Tbar, B_bar + c0 * n * n,
                                    C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * k, st)))

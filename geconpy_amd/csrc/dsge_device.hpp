@@ -544,4 +544,50 @@ __global__ __launch_bounds__(BLOCK) void kalman_order_kernel(const int32_t* __re
 }
 
 
+
+// Persistence key of a draw for the dispatch order of the Kalman launches: a rough spectral-radius estimate of the
+// transition matrix, rho ~ (||T^k v|| / ||v||)^(1/k) after k = 24 power-iteration steps from v = 1 (one row of T per lane
+// in registers, the vector exchanged by v_readlane), mapped to key = 8 * -log2(1 - rho) clamped to 0..63 -- finer towards
+// the unit circle, where the covariance recursion of the filter converges slowly.  Failed draws (status != 0) get key 0.
+// One wavefront per draw, n <= 64; a few thousand cycles per draw.
+template <int NMAX>
+__global__ __launch_bounds__(64) void persistence_key_kernel(const double* __restrict__ T, const int32_t* __restrict__ status,
+                                                             int batch, int n, int32_t* __restrict__ key) {
+  const int lane = threadIdx.x;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    if (status && status[draw] != 0) {
+      if (lane == 0) key[draw] = 0;
+      continue;
+    }
+    const double* Tg = T + (size_t)draw * n * n;
+    double row[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) row[c] = (lane < n && c < n) ? Tg[(size_t)lane * n + c] : 0.0;
+    double v = (lane < n) ? 1.0 : 0.0, lg = 0.0;
+    for (int it = 0; it < 24; ++it) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NMAX; c += 2) {
+        if (c < n) {
+          a0 = fma(row[c], readlane_dyn_f64(v, c), a0);
+          a1 = fma(row[c + 1], readlane_dyn_f64(v, c + 1), a1);
+        }
+      }
+      v = a0 + a1;
+      if ((it & 3) == 3) {  // renormalise every fourth step
+        const double nrm = sqrt(wave_sum_dpp(v * v));
+        if (!(nrm > 0.0) || !(nrm < 1e300)) break;
+        lg += log2(nrm);
+        v *= 1.0 / nrm;
+      }
+    }
+    // ||v_0|| = sqrt(n): rho^24 ~ 2^lg / sqrt(n)
+    const double rho = exp2((lg - 0.5 * log2((double)n)) / 24.0);
+    double kq = (rho < 1.0) ? -8.0 * log2(1.0 - rho) : 63.0;
+    if (!(kq == kq)) kq = 0.0;
+    kq = kq < 0.0 ? 0.0 : (kq > 63.0 ? 63.0 : kq);
+    if (lane == 0) key[draw] = (int32_t)kq;
+  }
+}
+
 }  // namespace dsge

@@ -72,6 +72,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr);
 // launch_grad.hip: reverse sweep of the Kalman filter + reverse of the assembly (dsge_kalman_grad.hpp)
+int launch_persistence_key(const double* T, const int32_t* status, int batch, int n, int32_t* key, hipStream_t st);
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
                        const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                        double jitter, double missing_fill, int u_hint, double* store, double* logp, int32_t* status,

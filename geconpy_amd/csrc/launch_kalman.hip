@@ -8,7 +8,7 @@
 namespace dsge_host {
 
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
-int g_kalman_order = 1;  // dispatch the Kalman workgroups in descending order of the caller's key (cycle-reduction iterations)
+int g_kalman_order = 1;  // Kalman workgroups in descending order of a key: 1 = cycle-reduction iterations (persistence key of T for the other solvers), 2 = always the persistence key, 0 = index order
 int g_kalman_block = 0;  // 1 = hand the steady, constant-mask tail of the sample to kalman_tail_kernel (measured slower)
 double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
 int32_t* g_kalman_steady_at = nullptr;
@@ -59,6 +59,14 @@ int tail_reserve(size_t bytes, hipStream_t st, void** out) {
   return DSGE_SUCCESS;
 }
 }  // namespace
+
+// dispatch key from the transition matrices themselves (any solver): see persistence_key_kernel
+int launch_persistence_key(const double* T, const int32_t* status, int batch, int n, int32_t* key, hipStream_t st) {
+  if (n > 64) return fail(DSGE_ERR_INVALID, "persistence key: n > 64");
+  hipLaunchKernelGGL(dsge::persistence_key_kernel<64>, dim3(batch), dim3(64), 0, st, T, status, batch, n, key);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
 
 // p0_valid = 0: P0 is an uninitialised scratch buffer.  The fast kernels then compute the stationary
 // covariance themselves (on the reduced model); only the draws that end up in the general kernel get

@@ -174,13 +174,14 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
-/* Fused evaluation with cycle reduction: the workgroups of the Kalman launch are dispatched in descending order of the
- * draws' cycle-reduction iteration counts (a counting sort on the device).  The launch's makespan is set by its slowest
- * draws -- a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for
- * up to T_len full steps -- and both counts grow with the persistence, so the likely slow draws start first instead of
- * wherever their index puts them (3.29 -> 2.8 ms per 4096 SW-shaped draws).  Results are unaffected: every draw writes
- * its own logp / status.  enable = 0: index order.  Default on.  Process-wide. */
-int dsge_set_kalman_order(int enable);
+/* Fused evaluation: the workgroups of the Kalman launch (and of the gradient path's reverse-sweep launch) are dispatched in
+ * descending order of a per-draw key (a counting sort on the device).  The launch's makespan is set by its slowest draws --
+ * a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for up to T_len
+ * full steps -- so the likely slow draws start first instead of wherever their index puts them (3.29 -> 2.86 ms per 4096
+ * SW-shaped draws).  mode 1 (default): key = the draw's cycle-reduction iteration count (free; both grow with the persistence
+ * of the model), for the other solvers a spectral-radius estimate of T (24 power-iteration steps, persistence_key_kernel);
+ * mode 2: always the latter; mode 0: index order.  Results are unaffected: every draw writes its own logp / status. */
+int dsge_set_kalman_order(int mode);
 /* dsge_solve_kalman_logp_batched (device pointers) runs batches of >= 1024 draws as n_chunks chunks alternating over two
  * library-owned streams, forked from and joined to the caller's stream by events, so that the straggler tail of one
  * chunk's Kalman launch (a draw whose covariance recursion converges late keeps one wavefront busy for up to T_len full

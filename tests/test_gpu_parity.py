@@ -1297,7 +1297,7 @@ def test_dispatch_order_and_chunks_do_not_change_results():
     ref_lp, ref_st = run()
     assert ref_st[77] != 0 and ref_lp[77] == -np.inf and np.count_nonzero(ref_st) == 1
     try:
-        for order, chunks in ((0, 0), (1, 3), (0, 4), (1, 2)):
+        for order, chunks in ((0, 0), (1, 3), (0, 4), (2, 2), (2, 0)):
             _lib.check(lib.dsge_set_kalman_order(order))
             _lib.check(lib.dsge_set_pipeline_chunks(chunks))
             lp, st = run()

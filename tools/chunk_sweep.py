@@ -13,7 +13,7 @@ hints = eng.structure_hints(dA, dZ)
 def run():
     return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000, n_state_hint=hints[0], z_selector_hint=hints[1])
 ref = None
-for order, blk, ch in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (1, 0, 2), (1, 1, 2), (1, 0, 4)):
+for order, blk, ch in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 0, 2)):
     if True:
         _lib.check(lib.dsge_set_kalman_order(order)); _lib.check(lib.dsge_set_kalman_block(blk))
         _lib.check(lib.dsge_set_pipeline_chunks(ch))
