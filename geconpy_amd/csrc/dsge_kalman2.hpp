@@ -164,7 +164,9 @@ __device__ __forceinline__ void product_fringe(double* dst, int ldd, const doubl
 // SEL = false: dense Z (p <= 8): P Z' is a register-block product against the full P kept in LDS
 // MF = true : the two prediction products of every full step run on the FP64 matrix core (16 x 16 core tile by
 //             v_mfma_f64_16x16x4_f64, the <= 8 fringe rows/columns on the VALU); needs 16 <= NP <= 24 (BS = 2, 3)
-template <int BS, bool SEL, bool MF = false>
+// TAIL = true : the instance that can hand the steady, constant-mask tail of the sample to kalman_tail_kernel (its own
+//               instance because the hand-off code costs registers -- and spills -- in a kernel that sits at the 256 limit)
+template <int BS, bool SEL, bool MF = false, bool TAIL = false>
 __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_
       if (!steady) continue;
       // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same ====
       if (steady_step < 0) steady_step = t + 1;
-      if constexpr (REG_SS && !MF) {
+      if constexpr (REG_SS && !MF && TAIL) {
         // ---- hand-off: once the covariance is frozen AND the missing-data mask no longer changes until the end of the
         // sample (t >= *tail_from, found by kalman_mask_scan_kernel), the remaining steps are a linear recursion in the
         // mean alone.  kalman_tail_kernel runs it two steps at a time as one matrix-vector product per pair -- in a launch of

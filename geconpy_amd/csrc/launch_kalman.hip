@@ -167,13 +167,25 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               done = true;
             }
           }
+          if (!done && tail_rec) {
+            rc = set_lds(dsge::kalman_sel_kernel<BS, true, false, true>, lds);
+            if (rc == DSGE_SUCCESS) {
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, false, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+                                 p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
+                                 s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
+              HIP_TRY(hipGetLastError());
+              launched_fast = true;
+            }
+            done = true;
+          }
           if (!done) {
             rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                  s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                 g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
+                                 g_kalman_steady_at, nullptr, nullptr, nullptr, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
             }
