@@ -488,11 +488,22 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       blk_store_lds<BS>(Tb, Tk, LD, lr, lc);           // F_0' = T
       wave_sync();
     }
+    // T (and every power of it) has non-zero columns only for the state variables; when those end at column ks the two
+    // products that contract over the columns of T_k run over ks terms instead of n (18 instead of 40 on the SW-shaped
+    // systems, whose states lead; ks = n and nothing changes when a state sits in the last column)
+    int ks = n;
+    {
+      bool nz = false;
+      if (lane < n)
+        for (int r = 0; r < n; ++r) nz = nz | (Ts[r * LD + lane] != 0.0);
+      const unsigned long long cm = __ballot(nz);
+      ks = cm ? 64 - __clzll((long long)cm) : 0;
+    }
     bool ok = false;
     for (int it = 0; it < LYAP_MAX_DOUBLINGS; ++it) {
       double W1[BS][BS];
       blk_zero<BS>(W1);
-      mm_acc<BS, true>(W1, W + NP, LDW, Tk, LD, n, lr, lc);  // S F_k = S (T^(2^k))'
+      mm_acc<BS, true>(W1, W + NP, LDW, Tk, LD, ks, lr, lc);  // S F_k = S (T^(2^k))'
       blk_store_lds<BS>(W1, W, LDW, lr, lc);
       wave_sync();
       double Ib[BS][BS], G2[BS][BS], T2[BS][BS];
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       blk_zero<BS>(T2);
       mm_acc<BS, false>(Ib, W + 2 * NP, LDW, W, LDW, n, lr, lc);           // G_k S F_k
       mm_acc<BS, false>(G2, W + 2 * NP, LDW, W + 2 * NP, LDW, n, lr, lc);  // G_k^2
-      mm_acc<BS, false>(T2, Tk, LD, Tk, LD, n, lr, lc);                    // T_k^2
+      mm_acc<BS, false>(T2, Tk, LD, Tk, LD, ks, lr, lc);                   // T_k^2
       wave_sync();
 #pragma unroll
       for (int i = 0; i < BS; ++i)
