@@ -61,8 +61,6 @@ struct Arena {
   size_t cap = 0;
 };
 constexpr int MAX_DEV = 16;
-Arena g_scratch[MAX_DEV];  // pipeline intermediates
-Arena g_scratch2[MAX_DEV]; // second set: the chunked host path keeps two pipelines in flight
 Arena g_stage[MAX_DEV];    // host-twin staging
 
 int arena_reserve(Arena* arenas, size_t bytes, void** out) {
@@ -85,6 +83,52 @@ int arena_reserve(Arena* arenas, size_t bytes, void** out) {
   return DSGE_SUCCESS;
 }
 
+
+// Scratch of the device entry points: one arena per (device, stream) -- the library is re-entrant per stream:
+// two fused calls enqueued on two streams must not share intermediates.  16 slots per device; when more streams than slots
+// show up the first slot is recycled after a device-wide synchronisation.
+struct StreamArena {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  bool used = false;
+};
+StreamArena g_stream_scratch[MAX_DEV][16];
+
+int scratch_reserve(hipStream_t st, size_t bytes, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEV) return fail(DSGE_ERR_INVALID, "device index out of range");
+  std::lock_guard<std::mutex> lk(g_mutex);
+  StreamArena* a = nullptr;
+  for (auto& slot : g_stream_scratch[dev])
+    if (slot.used && slot.stream == st) a = &slot;
+  if (!a)
+    for (auto& slot : g_stream_scratch[dev])
+      if (!slot.used) {
+        a = &slot;
+        break;
+      }
+  if (!a) {
+    HIP_TRY(hipDeviceSynchronize());
+    a = &g_stream_scratch[dev][0];
+  }
+  a->used = true;
+  a->stream = st;
+  if (a->cap < bytes) {
+    if (a->ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a->ptr));
+      a->ptr = nullptr;
+      a->cap = 0;
+    }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&a->ptr, cap));
+    a->cap = cap;
+  }
+  *out = a->ptr;
+  return DSGE_SUCCESS;
+}
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -344,7 +388,7 @@ int dsge_autocorrelation_batched(const double* T, const double* R, const double*
   double* Sigma = Sigma_out;
   if (!Sigma) {
     void* base = nullptr;
-    if ((rc = arena_reserve(g_scratch, align256((size_t)batch * m * m * sizeof(double)) + 4096, &base))) return rc;
+    if ((rc = scratch_reserve(st, align256((size_t)batch * m * m * sizeof(double)) + 4096, &base))) return rc;
     Sigma = (double*)base;
   }
   HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * batch, st));
@@ -371,7 +415,7 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
   hipStream_t st = (hipStream_t)stream;
   void* base = nullptr;
   const size_t mm = (size_t)batch * m * m;
-  if ((rc = arena_reserve(g_scratch, 2 * align256(mm * sizeof(double)) + 4096, &base))) return rc;
+  if ((rc = scratch_reserve(st, 2 * align256(mm * sizeof(double)) + 4096, &base))) return rc;
   Carver cv(base);
   double* RQR = cv.take<double>(mm);
   double* P0 = cv.take<double>(mm);
@@ -394,6 +438,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
                     double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* resid_out,
                     int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out, int arena_id = 0,
                     void* scratch_slice = nullptr) {
+  (void)arena_id;  // (scratch is keyed by stream now; the chunked host path runs its chunks on two streams)
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
   int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
@@ -411,7 +456,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = scratch_slice;  // (a slice of an arena the caller reserved: chunks in flight on several streams)
   if (!base &&
-      (rc = arena_reserve(arena_id ? g_scratch2 : g_scratch, pipeline_scratch_bytes(batch, n, k), &base)))
+      (rc = scratch_reserve(st, pipeline_scratch_bytes(batch, n, k), &base)))
     return rc;
   Carver cv(base);
   double* Tw = T_out ? T_out : cv.take<double>(nn);
@@ -517,7 +562,7 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
   const int per = ((batch + n_chunks - 1) / n_chunks + 63) & ~63;
   const size_t slice = (pipeline_scratch_bytes(per, n, k) + 255) & ~(size_t)255;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_scratch, slice * n_chunks, &base))) return rc;
+  if ((rc = scratch_reserve(caller, slice * n_chunks, &base))) return rc;
   HIP_TRY(hipEventRecord(s_ev[MAXS], caller));
   for (int i = 0; i < n_str; ++i) HIP_TRY(hipStreamWaitEvent(s_str[i], s_ev[MAXS], 0));
   const bool q_b = (q_mode == DSGE_Q_DIAG_BATCHED || q_mode == DSGE_Q_FULL_BATCHED);
@@ -567,7 +612,7 @@ int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, c
   hipStream_t st = (hipStream_t)stream;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, mm = (size_t)batch * m * m, mk = (size_t)batch * m * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_scratch, align256(nn * 8) + align256(nk * 8) + 3 * align256(mm * 8) + align256(mk * 8) +
+  if ((rc = scratch_reserve(st, align256(nn * 8) + align256(nk * 8) + 3 * align256(mm * 8) + align256(mk * 8) +
                                          align256((size_t)batch * 12) + 4096,
                           &base)))
     return rc;
@@ -627,7 +672,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   if (chunk > (size_t)batch) chunk = (size_t)batch;
   const size_t nn = chunk * n * n, nk = chunk * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_scratch, 4 * align256(nn * 8) + align256(nk * 8) + align256(chunk * 12) + 2 * align256(chunk * 4) +
+  if ((rc = scratch_reserve(st, 4 * align256(nn * 8) + align256(nk * 8) + align256(chunk * 12) + 2 * align256(chunk * 4) +
                                          align256(chunk * per_draw + 8) + 8192,
                           &base)))
     return rc;

@@ -1305,3 +1305,42 @@ def test_dispatch_order_and_chunks_do_not_change_results():
     finally:
         _lib.check(lib.dsge_set_kalman_order(1))
         _lib.check(lib.dsge_set_pipeline_chunks(0))
+
+
+def test_fused_calls_on_two_streams_do_not_share_scratch():
+    """The library is re-entrant per stream: fused evaluations enqueued back to back on two torch streams --
+    different batches, cycle reduction on one and gensys on the other -- keep their intermediates (T, R, RQR, P0, the gensys
+    window workspace, the dispatch order) in per-stream arenas and reproduce the results of running them one after the other."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    om = wl.sw_shaped_observation_model()
+    eng = LogpEngine(torch.device("cuda", 0))
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:60]), eng.to_device(om["Hdiag"])
+    jobs = []
+    for first, nb, solver in ((0, 1536, "cycle_reduction"), (3000, 1024, "gensys"), (5000, 768, "cycle_reduction")):
+        b = wl.sw_shaped_batch(nb, first_draw=first)
+        t = tuple(eng.to_device(b[x]) for x in "ABCD") + (eng.to_device(b["sigma"] ** 2),)
+        jobs.append((t, solver))
+
+    def run(job):
+        (dA, dB, dC, dD, dq), solver = job
+        hints = eng.structure_hints(dA, dZ)
+        return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, solver=solver, tol=1e-8, max_iter=1000,
+                                     n_state_hint=hints[0], z_selector_hint=hints[1])
+
+    ref = []
+    for job in jobs:
+        lp, st = run(job)
+        torch.cuda.synchronize()
+        ref.append((lp.cpu().numpy().copy(), st.cpu().numpy().copy()))
+    streams = [torch.cuda.Stream() for _ in jobs]
+    outs = [None] * len(jobs)
+    for rep in range(3):  # enqueue everything before anything is waited for
+        for i, job in enumerate(jobs):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = run(job)
+    torch.cuda.synchronize()
+    for (lp, st), (rlp, rst) in zip(outs, ref):
+        assert np.array_equal(st.cpu().numpy(), rst) and np.array_equal(lp.cpu().numpy(), rlp)
