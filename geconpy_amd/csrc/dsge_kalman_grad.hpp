@@ -75,7 +75,11 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
     double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
-  constexpr size_t STEP = (size_t)NP * NP + NP + 1;  // doubles stored per time step: P (NP x NP, dense), a, source step
+  // doubles stored per time step: for a FULL step the results of its covariance update -- P+ (NP x NP), K (NP x 8), F^-1,
+  // F (8 x 8 each) -- so that the reverse sweep loads them instead of repeating the update; for every step a_t and the
+  // index of the step whose covariance it shares.  The initial covariance P_0 sits behind the last step.
+  constexpr size_t OFF_K = (size_t)NP * NP, OFF_FI = OFF_K + (size_t)NP * 8, OFF_F = OFF_FI + 64, OFF_A = OFF_F + 64,
+                   OFF_SRC = OFF_A + NP, STEP = OFF_SRC + 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;              // transition, states-first ordering (columns >= s are zero)
   double* Ps = Tc + NP * LDM;     // predicted covariance of the current step
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         long long n_ss = 0;
         for (;;) {
           double* sgs = st + (size_t)t * STEP;
-          if (lane < NP) sgs[NP * NP + lane] = a_reg;
-          if (lane == 0) sgs[NP * NP + NP] = (double)seg_src;
+          if (lane < NP) sgs[OFF_A + lane] = a_reg;
+          if (lane == 0) sgs[OFF_SRC] = (double)seg_src;
           const double a_sel = __shfl(a_reg, v_zpos, 64);
           const double v_s = (lane < p) ? w_l * yt_or_zero(yc) - (v_dd + w_l * v_zv * a_sel) : 0.0;
           double vsc[8];
@@ -425,15 +429,21 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         }
         continue;
       }
-      if (lane < NP) sg[NP * NP + lane] = av[lane];
+      if (lane < NP) sg[OFF_A + lane] = av[lane];
       if (!light) {
         steady = false;
         seg_src = t;
-        for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
-        wave_sync();
+        if (t == 0) {  // P_0, for the adjoint of the stationary initial covariance at the end of the reverse sweep
+          double* p0s = st + (size_t)T_len * STEP;
+          for (int idx = lane; idx < NP * NP; idx += 64) p0s[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
+        }
         seg_logdet = update_cov();
+        for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = X1[(idx / NP) * LDM + (idx % NP)];  // P+
+        for (int idx = lane; idx < NP * 8; idx += 64) sg[OFF_K + idx] = Kp[(idx >> 3) * PS + (idx & 7)];
+        sg[OFF_FI + lane] = Fi[lane];
+        sg[OFF_F + lane] = Fs[lane];
       }
-      if (lane == 0) sg[NP * NP + NP] = (double)seg_src;
+      if (lane == 0) sg[OFF_SRC] = (double)seg_src;
       const double quad = update_mean(yt);
       ll_acc += lam * (seg_logdet + quad);
       n_ll += (lam != 0.0);
@@ -514,8 +524,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     double src_next = 0.0, av_next = 0.0, yr_next = 0.0;
     if (T_len > 0) {
       const double* sg0 = st + (size_t)(T_len - 1) * STEP;
-      src_next = sg0[NP * NP + NP];
-      if (lane < NP) av_next = sg0[NP * NP + lane];
+      src_next = sg0[OFF_SRC];
+      if (lane < NP) av_next = sg0[OFF_A + lane];
       if (lane < p) yr_next = y[(size_t)(T_len - 1) * p + lane];
     }
     for (int t = T_len - 1; t >= 0; --t) {
@@ -525,17 +535,20 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       double yt = yr_next;
       if (t > 0) {
         const double* sgp = st + (size_t)(t - 1) * STEP;
-        src_next = sgp[NP * NP + NP];
-        if (lane < NP) av_next = sgp[NP * NP + lane];
+        src_next = sgp[OFF_SRC];
+        if (lane < NP) av_next = sgp[OFF_A + lane];
         yr_next = (lane < p) ? y[(size_t)(t - 1) * p + lane] : 0.0;
       }
       const unsigned long long omask = load_mask(yt);
       const double lam = (omask != 0ull) ? 1.0 : 0.0;
       if (src_t != cur_src) {  // a full step, or the first (last in time) step of a steady segment
-        const double* sp_ = st + (size_t)src_t * STEP;
-        for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = sp_[idx];
+        const double* sp_ = st + (size_t)src_t * STEP;  // the source step's covariance update, as the forward sweep left it
         wave_sync();
-        (void)update_cov();
+        for (int idx = lane; idx < NP * NP; idx += 64) X1[(idx / NP) * LDM + (idx % NP)] = sp_[idx];
+        for (int idx = lane; idx < NP * 8; idx += 64) Kp[(idx >> 3) * PS + (idx & 7)] = sp_[OFF_K + idx];
+        Fi[lane] = sp_[OFF_FI + lane];
+        Fs[lane] = sp_[OFF_F + lane];
+        wave_sync();
         cur_src = src_t;
 #pragma unroll
         for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
@@ -625,8 +638,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           yt = yr_next;
           if (t > 0) {
             const double* sgp = st + (size_t)(t - 1) * STEP;
-            src_next = sgp[NP * NP + NP];
-            if (lane < NP) av_next = sgp[NP * NP + lane];
+            src_next = sgp[OFF_SRC];
+            if (lane < NP) av_next = sgp[OFF_A + lane];
             yr_next = (lane < p) ? y[(size_t)(t - 1) * p + lane] : 0.0;
           }
         }
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
       if (!(dmax == dmax) || dmax <= 1e-17 * smax || smax == 0.0) break;
     }
-    for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = st[idx];  // P0
+    for (int idx = lane; idx < NP * NP; idx += 64) Ps[(idx / NP) * LDM + (idx % NP)] = st[(size_t)T_len * STEP + idx];  // P0
     wave_sync();
     kg_mm<BS, false>(X2, Tc, Ps, u, 1.0, false, lr, lc);  // T P0
     wave_sync();
