@@ -17,6 +17,8 @@ for n in (8, 16, 24, 32, 40, 48, 56, 64):
     dZ, dy, dH = eng.to_device(Z), eng.to_device(y), eng.to_device(np.full(p, 1e-4))
     hints = eng.structure_hints(A, dZ)
     try:
+        eng.profile_kernels(A, B, C, D, q, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, reps=1,
+                            n_state_hint=hints[0], z_selector_hint=hints[1])  # warm-up (code objects, arenas)
         ms = eng.profile_kernels(A, B, C, D, q, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, reps=2,
                                  n_state_hint=hints[0], z_selector_hint=hints[1])
         lp, st = eng.solve_kalman_logp(A, B, C, D, q, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000,
