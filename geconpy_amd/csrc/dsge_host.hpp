@@ -26,7 +26,6 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 
 inline int tile_bs(int n) {
   int bs = (n + 7) / 8;
-  if (bs == 7) bs = 8;
   return bs < 1 ? 1 : bs;
 }
 
@@ -44,6 +43,7 @@ int set_lds(K kernel, size_t bytes) {
     case 4: { constexpr int BS = 4; __VA_ARGS__; } break;                            \
     case 5: { constexpr int BS = 5; __VA_ARGS__; } break;                            \
     case 6: { constexpr int BS = 6; __VA_ARGS__; } break;                            \
+    case 7: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 7 : 6); __VA_ARGS__; } break; \
     case 8: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 8 : 6); __VA_ARGS__; } break; \
     default: break;                                                                  \
   }

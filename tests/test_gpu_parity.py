@@ -92,7 +92,7 @@ def test_nan_inputs_do_not_hang():
     assert np.all(status & _lib.ST_NAN)
 
 
-@pytest.mark.parametrize("n,k", [(3, 1), (8, 1), (9, 2), (17, 3), (24, 4), (33, 5), (40, 7), (48, 6), (64, 8)])
+@pytest.mark.parametrize("n,k", [(3, 1), (8, 1), (9, 2), (17, 3), (24, 4), (33, 5), (40, 7), (48, 6), (50, 5), (56, 7), (64, 8)])
 def test_sizes_cr_selection_lyapunov(n, k):
     nb = 5
     ns = max(1, n // 2)
@@ -1344,3 +1344,24 @@ def test_fused_calls_on_two_streams_do_not_share_scratch():
     torch.cuda.synchronize()
     for (lp, st), (rlp, rst) in zip(outs, ref):
         assert np.array_equal(st.cpu().numpy(), rst) and np.array_equal(lp.cpu().numpy(), rlp)
+
+
+@pytest.mark.parametrize("n,ns,nl", [(50, 22, 15), (56, 25, 16)])
+def test_fused_pipeline_seven_wide_tile(n, ns, nl):
+    """n = 49..56 runs on the 7 x 7 register-block instances (56-wide tile) of every kernel of the fused call instead of the
+    spilling 64-wide ones: logp against the oracle, T against the construction."""
+    k = p = 7
+    nb = 4
+    sysm = [wl.sw_shaped_system(4200 + 7 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    q = np.full((nb, k), 1e-4)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(n).normal(0, 0.02, (40, p))
+    H = np.full(p, 1e-4)
+    out = batched.solve_kalman_logp_batched(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-9, max_iter=1000, return_policy=True)
+    assert np.all(out["status"] == 0)
+    assert_allclose(out["T"], Tst, atol=1e-8)
+    for i in range(nb):
+        r = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(q[i]), Z, y, H=np.diag(H), tol=1e-9, max_iter=1000)
+        assert_allclose(out["logp"][i], r["logp"], rtol=LOGP_RTOL)

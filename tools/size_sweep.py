@@ -6,7 +6,7 @@ from geconpy_amd import workloads as wl
 from geconpy_amd.engine import LogpEngine
 eng = LogpEngine(0)
 nb = 4096
-for n in (8, 16, 24, 32, 40, 48, 56, 64):
+for n in (tuple(int(x) for x in sys.argv[1:]) if len(sys.argv) > 1 else (8, 16, 24, 32, 40, 48, 56, 64)):
     ns, nl, k, p = max(2, int(0.45 * n)), max(1, int(0.3 * n)), min(7, n // 2), min(7, n // 2)
     base = [wl.sw_shaped_system(1000 + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(16)]
     rep = nb // 16
