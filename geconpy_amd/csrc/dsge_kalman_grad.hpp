@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
   // F (8 x 8 each) -- so that the reverse sweep loads them instead of repeating the update; for every step a_t and the
   // index of the step whose covariance it shares.  The initial covariance P_0 sits behind the last step.
   constexpr size_t OFF_K = (size_t)NP * NP, OFF_FI = OFF_K + (size_t)NP * 8, OFF_F = OFF_FI + 64, OFF_A = OFF_F + 64,
-                   OFF_SRC = OFF_A + NP, STEP = OFF_SRC + 1;
+                   OFF_SRC = OFF_A + NP, OFF_PREV = OFF_SRC + 1, STEP = OFF_PREV + 1;  // OFF_PREV: source of the PREVIOUS segment
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;              // transition, states-first ordering (columns >= s are zero)
   double* Ps = Tc + NP * LDM;     // predicted covariance of the current step
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (lane < NP) sg[OFF_A + lane] = av[lane];
       if (!light) {
         steady = false;
+        if (lane == 0) sg[OFF_PREV] = (double)seg_src;  // (-1 for the first step) lets the reverse sweep fetch that record early
         seg_src = t;
         if (t == 0) {  // P_0, for the adjoint of the stationary initial covariance at the end of the reverse sweep
           double* p0s = st + (size_t)T_len * STEP;
@@ -521,6 +522,15 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     double Kacc[BS], Qacc = 0.0, nlam = 0.0;
 #pragma unroll
     for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
+    // the record of the NEXT segment's source step (P+, K, F^-1, F: NPF + NKF + 2 doubles per lane) is fetched while the
+    // current segment is processed: it was written ~1e5 cycles ago and comes from HBM
+    constexpr int NPF = (NP * NP + 63) / 64, NKF = (NP * 8 + 63) / 64;
+    double pf_p[NPF], pf_k[NKF], pf_fi = 0.0, pf_f = 0.0;
+    int pf_src = -2;
+#pragma unroll
+    for (int k2 = 0; k2 < NPF; ++k2) pf_p[k2] = 0.0;
+#pragma unroll
+    for (int k2 = 0; k2 < NKF; ++k2) pf_k[k2] = 0.0;
     double src_next = 0.0, av_next = 0.0, yr_next = 0.0;
     if (T_len > 0) {
       const double* sg0 = st + (size_t)(T_len - 1) * STEP;
@@ -544,10 +554,44 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (src_t != cur_src) {  // a full step, or the first (last in time) step of a steady segment
         const double* sp_ = st + (size_t)src_t * STEP;  // the source step's covariance update, as the forward sweep left it
         wave_sync();
-        for (int idx = lane; idx < NP * NP; idx += 64) X1[(idx / NP) * LDM + (idx % NP)] = sp_[idx];
-        for (int idx = lane; idx < NP * 8; idx += 64) Kp[(idx >> 3) * PS + (idx & 7)] = sp_[OFF_K + idx];
-        Fi[lane] = sp_[OFF_FI + lane];
-        Fs[lane] = sp_[OFF_F + lane];
+        if (pf_src == src_t) {
+#pragma unroll
+          for (int k2 = 0; k2 < NPF; ++k2) {
+            const int idx = lane + 64 * k2;
+            if (idx < NP * NP) X1[(idx / NP) * LDM + (idx % NP)] = pf_p[k2];
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < NKF; ++k2) {
+            const int idx = lane + 64 * k2;
+            if (idx < NP * 8) Kp[(idx >> 3) * PS + (idx & 7)] = pf_k[k2];
+          }
+          Fi[lane] = pf_fi;
+          Fs[lane] = pf_f;
+        } else {
+          for (int idx = lane; idx < NP * NP; idx += 64) X1[(idx / NP) * LDM + (idx % NP)] = sp_[idx];
+          for (int idx = lane; idx < NP * 8; idx += 64) Kp[(idx >> 3) * PS + (idx & 7)] = sp_[OFF_K + idx];
+          Fi[lane] = sp_[OFF_FI + lane];
+          Fs[lane] = sp_[OFF_F + lane];
+        }
+        {  // start fetching the record this sweep needs next
+          const int prev = (int)sp_[OFF_PREV];
+          pf_src = prev;
+          if (prev >= 0) {
+            const double* pp_ = st + (size_t)prev * STEP;
+#pragma unroll
+            for (int k2 = 0; k2 < NPF; ++k2) {
+              const int idx = lane + 64 * k2;
+              pf_p[k2] = (idx < NP * NP) ? pp_[idx] : 0.0;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < NKF; ++k2) {
+              const int idx = lane + 64 * k2;
+              pf_k[k2] = (idx < NP * 8) ? pp_[OFF_K + idx] : 0.0;
+            }
+            pf_fi = pp_[OFF_FI + lane];
+            pf_f = pp_[OFF_F + lane];
+          }
+        }
         wave_sync();
         cur_src = src_t;
 #pragma unroll
@@ -555,8 +599,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         Qacc = 0.0;
         nlam = 0.0;
       }
-      if (t != src_t) {
-        // ==== steady steps of the segment in registers: column `lane` of Tc (a+bar = T' abar), row `lane` of K (a+), rows of
+      {
+        // ==== the mean side of every step of the segment (its source step included) in registers: column `lane` of Tc (a+bar = T' abar), row `lane` of K (a+), rows of
         // F^-1 and columns of K in lanes 0..7 (F^-1 v, K' a+bar); vectors are exchanged by v_readlane / ds_bpermute, no fence.
         double tcol[NP], krow[8], firow[8], kcol[NP];
 #pragma unroll
@@ -578,7 +622,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         const double my_wz = (my_o >= 0) ? (((omask >> my_o) & 1ull) ? 1.0 : 0.0) * zv[my_o] : 0.0;
         const int my_os = (my_o >= 0) ? my_o : 0;
         double ab_reg = (lane < NP) ? ab[lane] : 0.0, db_reg = 0.0;
-        while (t != src_t) {
+        for (;;) {
           // v, F^-1 v, a+ of step t from the stored a_t
           const double a_sel = __shfl(a_cur, v_zpos, 64);
           const double v_s = (lane < p) ? w_l * yt_or_zero(yt) - (v_dd + w_l * v_zv * a_sel) : 0.0;
@@ -631,6 +675,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           // abar = a+bar - Zm' vbar;  dbar -= vbar
           ab_reg = apb_l - my_wz * __shfl(vb_l, my_os, 64);
           db_reg -= vb_l;
+          if (t == src_t) break;  // the source step: its covariance side follows below
           // next (earlier) step: data was fetched one step ahead
           --t;
           src_t = (int)src_next;
@@ -643,11 +688,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
             yr_next = (lane < p) ? y[(size_t)(t - 1) * p + lane] : 0.0;
           }
         }
-        // t == src_t now: hand the state back to LDS and run the source step with the generic code below
-        if (lane < NP) {
-          ab[lane] = ab_reg;
-          av[lane] = a_cur;
-        }
+        // t == src_t now: the cotangent of a_t goes back to LDS for the next segment (or the end of the sweep)
+        if (lane < NP) ab[lane] = ab_reg;
         if (lane < 8) db[lane] += db_reg;
         wave_sync();
         if (tm) {
@@ -655,36 +697,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           ph[4] += tk1 - tk0;
           tk0 = tk1;
         }
-      }
-      (void)update_mean(yt);
-      // ---- mean side (every step).  abar is the cotangent of a_{t+1}.
-      if (lane < u) {
-        double sa = 0.0;
-        for (int i = 0; i < u; ++i) sa = fma(Tc[i * LDM + lane], ab[i], sa);
-        apb[lane] = sa;  // a+bar = T' abar
-      }
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) TbR[i][j] = fma(ab[lr * BS + i], ap[lc * BS + j], TbR[i][j]);  // Tbar += abar a+'
-      wave_sync();
-      if (lane < 8) {  // vbar = -lam F^-1 v + K' a+bar
-        double sv = -lam * fiv[lane];
-        for (int i = 0; i < u; ++i) sv = fma(Kp[i * PS + lane], apb[i], sv);
-        vb[lane] = (lane < p) ? sv : 0.0;
-      }
-#pragma unroll
-      for (int k2 = 0; k2 < BS; ++k2) {
-        const int idx = lane + 64 * k2, i = idx >> 3, o = idx & 7;
-        if (i < u) Kacc[k2] = fma(apb[i], vv[o], Kacc[k2]);
-      }
-      Qacc = fma(lam * fiv[fo], fiv[fq], Qacc);
-      nlam += lam;
-      if (lane < u) t1[lane] = apb[lane];
-      wave_sync();
-      if (lane < p) {  // abar = a+bar - Zm' vbar;  dbar -= vbar
-        t1[zpos[lane]] = fma(-ww[lane] * zv[lane], vb[lane], t1[zpos[lane]]);
-        db[lane] -= vb[lane];
       }
       if (t == src_t) {
         // ---- covariance side, once per segment: Pb is the cotangent of the predicted covariance P_{src+1}, which the
@@ -758,11 +770,9 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         }
       }
       wave_sync();
-      if (lane < NP) ab[lane] = (lane < u) ? t1[lane] : 0.0;
-      wave_sync();
       if (tm) {
         const long long tk1 = clock64();
-        ph[(t == src_t) ? 3 : 4] += tk1 - tk0;
+        ph[3] += tk1 - tk0;
         tk0 = tk1;
       }
     }

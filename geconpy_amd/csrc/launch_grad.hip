@@ -9,7 +9,7 @@ static int grad_tile(int u_hint, int m) { return tile_bs((u_hint > 0 && u_hint <
 
 size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len) {
   const size_t np = 8 * (size_t)grad_tile(u_hint, m);
-  return (size_t)T_len * (np * np + np * 8 + 128 + np + 1) + np * np;  // per step: P+, K, F^-1, F, a_t, source index; + P_0
+  return (size_t)T_len * (np * np + np * 8 + 128 + np + 2) + np * np;  // per step: P+, K, F^-1, F, a_t, source index, previous source; + P_0
 }
 
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
