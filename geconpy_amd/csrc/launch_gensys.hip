@@ -1,4 +1,6 @@
 // Launcher of the gensys (ordered QZ) kernel.
+#include <mutex>
+
 #include "dsge_host.hpp"
 #include "dsge_gensys.hpp"
 #include "dsge_gensys_win.hpp"
@@ -22,7 +24,10 @@ constexpr int GW_SLOTS = 16;
 GwArena g_gw_arena[16][GW_SLOTS];
 constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
 
+std::mutex g_arena_mutex;  // host threads may call into the library concurrently (ctypes releases the GIL)
+
 int gw_reserve(size_t bytes, hipStream_t st, void** out) {
+  std::lock_guard<std::mutex> lk(g_arena_mutex);
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");

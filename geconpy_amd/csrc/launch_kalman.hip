@@ -1,4 +1,6 @@
 // Launcher of the Kalman log-likelihood kernels (fast-path tile cascade + general kernel).
+#include <mutex>
+
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
@@ -26,7 +28,10 @@ struct TailArena {
 };
 TailArena g_tail_arena[16][16];
 
+std::mutex g_arena_mutex;  // host threads may call into the library concurrently (ctypes releases the GIL)
+
 int tail_reserve(size_t bytes, hipStream_t st, void** out) {
+  std::lock_guard<std::mutex> lk(g_arena_mutex);
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
