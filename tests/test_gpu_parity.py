@@ -1365,3 +1365,34 @@ def test_fused_pipeline_seven_wide_tile(n, ns, nl):
     for i in range(nb):
         r = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(q[i]), Z, y, H=np.diag(H), tol=1e-9, max_iter=1000)
         assert_allclose(out["logp"][i], r["logp"], rtol=LOGP_RTOL)
+
+
+def test_fused_call_is_independent_of_batch_size():
+    """logp / status of a draw must not depend on how many other draws share the launch: batch sizes around the thresholds
+    of the dispatch order (512) and of the workgroup loops (1, 63, 64, 65), cut from one 600-draw set, against the
+    full-set call -- bit for bit, both solvers."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    nb = 600
+    b = wl.sw_shaped_batch(nb, first_draw=7000)
+    om = wl.sw_shaped_observation_model()
+    eng = LogpEngine(torch.device("cuda", 0))
+    dev = {x: eng.to_device(b[x]) for x in "ABCD"}
+    dq = eng.to_device(b["sigma"] ** 2)
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:48]), eng.to_device(om["Hdiag"])
+    hints = eng.structure_hints(dev["A"], dZ)
+    for solver in ("cycle_reduction", "gensys"):
+        def run(lo, hi):
+            lp, st = eng.solve_kalman_logp(dev["A"][lo:hi], dev["B"][lo:hi], dev["C"][lo:hi], dev["D"][lo:hi], dq[lo:hi], dZ, dy,
+                                           Hdiag=dH, solver=solver, tol=1e-8, max_iter=1000, n_state_hint=hints[0],
+                                           z_selector_hint=hints[1])
+            torch.cuda.synchronize()
+            return lp.cpu().numpy(), st.cpu().numpy()
+
+        full_lp, full_st = run(0, nb)
+        assert np.all(full_st == 0)
+        for lo, hi in ((0, 1), (5, 68), (100, 164), (17, 82), (0, 511), (40, 552), (87, 600)):
+            lp, st = run(lo, hi)
+            assert np.array_equal(st, full_st[lo:hi]) and np.array_equal(lp, full_lp[lo:hi]), (solver, lo, hi)
