@@ -164,10 +164,14 @@ __device__ __forceinline__ void product_fringe(double* dst, int ldd, const doubl
 // SEL = false: dense Z (p <= 8): P Z' is a register-block product against the full P kept in LDS
 // MF = true : the two prediction products of every full step run on the FP64 matrix core (16 x 16 core tile by
 //             v_mfma_f64_16x16x4_f64, the <= 8 fringe rows/columns on the VALU); needs 16 <= NP <= 24 (BS = 2, 3)
+// Two waves per SIMD (a 256-register budget) pay off up to the 24-wide tile; the 32-wide one spills 440 B at that budget and
+// is faster with one wave per SIMD (n = 56: 3.3 -> 2.7 ms per 4096 draws); for the 24-wide tile one wave per SIMD makes the
+// step only 8 % shorter and the launch 30 % longer.
+constexpr int KSEL_TWO_WAVES_MAX_BS = 3;
 // TAIL = true : the instance that can hand the steady, constant-mask tail of the sample to kalman_tail_kernel (its own
 //               instance because the hand-off code costs registers -- and spills -- in a kernel that sits at the 256 limit)
 template <int BS, bool SEL, bool MF = false, bool TAIL = false>
-__global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= 4 ? 2 : 1))) void kalman_sel_kernel(
+__global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2 : 1))) void kalman_sel_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
