@@ -64,6 +64,7 @@ PROTOTYPES = {
     "dsge_set_cr_fused_selection": [_i],
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_set_kalman_tiny": [_i],
+    "dsge_set_cr_deflation": [_i],
     "dsge_set_kalman_order": [_i],
     "dsge_set_pipeline_chunks": [_i],
     "dsge_set_kalman_block": [_i],

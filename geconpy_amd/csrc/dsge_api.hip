@@ -212,6 +212,11 @@ int dsge_set_pipeline_chunks(int n_chunks) {
   g_pipeline_chunks = n_chunks;
   return DSGE_SUCCESS;
 }
+int dsge_set_cr_deflation(int enable) {
+  g_cr_deflate = enable ? 1 : 0;
+  cr_deflation_reset();
+  return DSGE_SUCCESS;
+}
 int dsge_set_kalman_order(int mode) {
   if (mode < 0 || mode > 2) return fail(DSGE_ERR_INVALID, "order mode must be 0, 1 or 2");
   g_kalman_order = mode;
@@ -478,8 +483,14 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
     const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && g_cr_fuse_R;
     if (is_cr) {
-      rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st,
-                     solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0, fuse_R ? D : nullptr, k, fuse_R ? Rw : nullptr);
+      int deflated = 0;
+      // static variables deflated first (the iteration then runs on n - h variables); not when the caller asks for the
+      // iteration counts or the residual, whose contract is the full-size iteration
+      if (fuse_R && !n_iter_out && (rc = launch_cr_deflated(A, B, C, D, batch, n, k, max_iter, tol, Tw, Rw, status_out, it_w, st, &deflated)))
+        return rc;
+      if (!deflated)
+        rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st,
+                       solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0, fuse_R ? D : nullptr, k, fuse_R ? Rw : nullptr);
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
       rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st);

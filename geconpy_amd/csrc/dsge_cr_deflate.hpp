@@ -1,0 +1,392 @@
+// Static-variable deflation in front of cycle reduction.  A variable whose columns of A and C are both exactly zero (it
+// appears neither lagged nor led: a "static" variable in Dynare's partition) only enters through B.  A Householder QR of
+// those h columns of B, applied to the whole system,
+//     Q' [B_st | B_dy | A_dy | C_dy | D] = [ R_st  Btop  Atop  Ctop  Dtop ]     h rows
+//                                          [  0    Bred  Ared  Cred  Dred ]     n - h rows
+// leaves a quadratic matrix equation  Ared + Bred T_dy + Cred T_dy^2 = 0  in the n - h dynamic variables alone, and the
+// static rows follow by back-substitution:
+//     T_st = -R_st^-1 ((Btop + Ctop T_dy) T_dy + Atop),      R_st = -R_st^-1 ((Btop + Ctop T_dy) R_dy + Dtop).
+// The solution is the one cycle reduction finds on the full system (it is unique); the iteration works on (n - h)^3
+// instead of n^3 -- 30 instead of 40 variables on the SW-shaped systems (10 static), 20 of 24 on full_nk, 6 of 12 on the
+// two-block RBC golden.  tests/device_models/cr_deflation_model.py restates the algebra in numpy.
+// Three launches: cr_deflate_kernel (QR, one wavefront per draw), the existing cycle-reduction kernels on the reduced
+// system, cr_inflate_kernel (static rows, scatter to the caller's variable order).  Both kernels keep ONE COLUMN PER LANE
+// IN REGISTERS (the reflectors / the small left factors are broadcast from LDS), load it with all rows in flight and
+// store it coalesced: the first version -- the whole system in LDS, wave-wide reflectors on it -- took 0.44 + 0.13 ms
+// per 4096 SW-shaped draws, a third of what the smaller iteration saved.  `h` is a lower bound of the number of
+// static variables that the host passes in (measured once per model size, cr_static_scan_kernel); every draw verifies it and
+// a draw with fewer static variables is flagged and solved by the full-size kernels afterwards.
+#pragma once
+#include "dsge_device.hpp"
+
+#include "../../include/dsge_hip.h"
+
+namespace dsge {
+
+constexpr int CRD_HMAX = 16;  // static variables deflated at most (register-resident rows of B_st / of the solutions)
+
+// per-draw record of the top block: h x (h + 3 nd + k) doubles + 2 (selection mask)
+__host__ __device__ inline size_t crd_top_doubles(int n, int k, int h) {
+  return (size_t)h * (h + 3 * (n - h) + k) + 2;
+}
+// dynamic LDS: tile = 8 * BS of the full system (deflate) / of the reduced system (inflate)
+__host__ __device__ inline size_t crd_deflate_smem(int tile) {
+  return (size_t)(CRD_HMAX * tile + CRD_HMAX) * 8 + (64 + CRD_HMAX) * 4;
+}
+__host__ __device__ inline size_t crd_inflate_smem(int tile) {
+  return (size_t)(2 * CRD_HMAX * tile + CRD_HMAX * CRD_HMAX + CRD_HMAX) * 8 + (64 + CRD_HMAX) * 4;
+}
+
+// minimum over the batch of the number of static variables (*out must hold n on entry)
+__global__ __launch_bounds__(64) void cr_static_scan_kernel(const double* __restrict__ A, const double* __restrict__ C,
+                                                             int batch, int n, int32_t* __restrict__ out) {
+  const int lane = threadIdx.x;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n;
+    int nz = 0;
+    if (lane < n) {
+#pragma unroll 8
+      for (int i = 0; i < n; ++i)
+        nz |= ((A[off + (size_t)i * n + lane] != 0.0) | (C[off + (size_t)i * n + lane] != 0.0)) ? 1 : 0;
+    }
+    const int h = n - __popcll(__ballot(nz != 0));
+    if (lane == 0 && h < __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMin(out, h);
+  }
+}
+
+// index tables of a selection mask: sti[s] = s-th static variable, dyi[d] = d-th dynamic variable
+__device__ __forceinline__ void crd_index_tables(unsigned long long smask, int n, int lane, int* dyi, int* sti) {
+  wave_sync();
+  if (lane < n) {
+    const unsigned long long bj = 1ull << lane;
+    const int below = __popcll(smask & (bj - 1ull));
+    if (smask & bj)
+      sti[below] = lane;
+    else
+      dyi[lane - below] = lane;
+  }
+  wave_sync();
+}
+
+template <int BS>
+__global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                         const double* __restrict__ C, const double* __restrict__ D,
+                                                         int batch, int n, int k, int h, double* __restrict__ Ared,
+                                                         double* __restrict__ Bred, double* __restrict__ Cred,
+                                                         double* __restrict__ Dred, double* __restrict__ top,
+                                                         int32_t* __restrict__ flag) {
+  constexpr int NM = 8 * BS, HM = CRD_HMAX;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* V = smem;             // HM x NM: reflector j in row j (zero above its pivot and below row n)
+  double* tau_s = V + HM * NM;  // HM
+  int* dyi = (int*)(tau_s + HM);
+  int* sti = dyi + 64;
+  const int lane = threadIdx.x;
+  const int nd = n - h, nv = 3 * nd + k, ncols = h + nv;
+  const size_t top_stride = crd_top_doubles(n, k, h);
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
+    const size_t offr = (size_t)draw * nd * nd, offrk = (size_t)draw * nd * k;
+    // ---- which variables are static: lane j looks down column j of A and C (all rows in flight)
+    int nz = 0;
+    {
+      const double* ap = A + off + lane;
+      const double* cp = C + off + lane;
+      double av[NM], cv[NM];
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const bool in = (i < n) && (lane < n);
+        av[i] = in ? ap[(size_t)i * n] : 0.0;
+        cv[i] = in ? cp[(size_t)i * n] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < NM; ++i) nz |= ((av[i] != 0.0) | (cv[i] != 0.0)) ? 1 : 0;
+    }
+    const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    unsigned long long smask = ~__ballot(nz != 0) & nmask;
+    if (__popcll(smask) < h) {
+      // fewer static variables than assumed: hand the draw to the full-size kernels; the reduced system gets a harmless
+      // stand-in (B = I, A = C = D = 0) so that the cycle-reduction launch has something finite to chew on
+      for (int idx = lane; idx < nd * nd; idx += 64) {
+        Ared[offr + idx] = 0.0;
+        Cred[offr + idx] = 0.0;
+        Bred[offr + idx] = (idx / nd == idx % nd) ? 1.0 : 0.0;
+      }
+      for (int idx = lane; idx < nd * k; idx += 64) Dred[offrk + idx] = 0.0;
+      if (lane == 0) flag[draw] = 1;
+      continue;
+    }
+    {  // keep the first h of them (the others stay in the dynamic block with their zero columns)
+      unsigned long long keep = 0ull, rest = smask;
+      for (int c = 0; c < h; ++c) {
+        const unsigned long long low = rest & (~rest + 1ull);
+        keep |= low;
+        rest ^= low;
+      }
+      smask = keep;
+    }
+    crd_index_tables(smask, n, lane, dyi, sti);
+    double* tp = top + (size_t)draw * top_stride;
+    // ---- QR of B_st, one ROW per lane in registers; the reflectors go to LDS
+    {
+      double bst[HM];
+#pragma unroll
+      for (int s2 = 0; s2 < HM; ++s2) bst[s2] = (s2 < h && lane < n) ? B[off + (size_t)lane * n + sti[s2 < h ? s2 : 0]] : 0.0;
+#pragma unroll
+      for (int j = 0; j < HM; ++j) {
+        if (j < h) {
+          const double x = (lane >= j) ? bst[j] : 0.0;
+          const double xn2 = wave_sum_dpp((lane > j) ? x * x : 0.0);
+          const double alpha = readlane_dyn_f64(x, j);
+          double v = (lane == j) ? 1.0 : 0.0, tau = 0.0, beta = alpha;
+          if (xn2 != 0.0) {  // dlarfg
+            const double nrm = sqrt(fma(alpha, alpha, xn2));
+            beta = (alpha >= 0.0) ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            const double scal = 1.0 / (alpha - beta);
+            v = (lane == j) ? 1.0 : ((lane > j) ? x * scal : 0.0);
+          }
+#pragma unroll
+          for (int c = j + 1; c < HM; ++c) {
+            if (c < h) {
+              const double dot = wave_sum_dpp(v * bst[c]);
+              bst[c] = fma(-tau * dot, v, bst[c]);
+            }
+          }
+          bst[j] = (lane == j) ? beta : ((lane > j) ? 0.0 : bst[j]);
+          if (lane < NM) V[j * NM + lane] = v;
+          if (lane == 0) tau_s[j] = tau;
+        }
+      }
+      if (lane < h) {  // R_st
+#pragma unroll
+        for (int s2 = 0; s2 < HM; ++s2)
+          if (s2 < h) tp[(size_t)lane * ncols + s2] = bst[s2];
+      }
+    }
+    wave_sync();
+    // ---- Q' applied to [B_dy | A_dy | C_dy | D]: two columns per lane, in registers
+    for (int c0 = 0; c0 < nv; c0 += 128) {
+      const double *srcA, *srcB;
+      double *dstA, *dstB;
+      int ssA, ssB, dsA, dsB;
+      auto describe = [&](int c, const double*& src, int& ss, double*& dst, int& ds) -> bool {
+        src = B + off;
+        ss = n;
+        dst = Bred + offr;
+        ds = nd;
+        if (c >= nv) return false;
+        if (c >= 3 * nd) {
+          src = D + offk + (c - 3 * nd);
+          ss = k;
+          dst = Dred + offrk + (c - 3 * nd);
+          ds = k;
+          return true;
+        }
+        const int blk = (c >= nd) + (c >= 2 * nd);
+        const int d = c - blk * nd;
+        const int j0 = dyi[d];
+        src = (blk == 0 ? B : (blk == 1 ? A : C)) + off + j0;
+        dst = (blk == 0 ? Bred : (blk == 1 ? Ared : Cred)) + offr + d;
+        return true;
+      };
+      const int cA = c0 + lane, cB = c0 + 64 + lane;
+      const bool actA = describe(cA, srcA, ssA, dstA, dsA), actB = describe(cB, srcB, ssB, dstB, dsB);
+      double colA[NM], colB[NM];
+#pragma unroll
+      for (int r = 0; r < NM; ++r) {
+        colA[r] = (r < n && actA) ? srcA[(size_t)r * ssA] : 0.0;
+        colB[r] = (r < n && actB) ? srcB[(size_t)r * ssB] : 0.0;
+      }
+      for (int j = 0; j < h; ++j) {
+        double v[NM];
+        const double2* vj = reinterpret_cast<const double2*>(V + j * NM);
+#pragma unroll
+        for (int r2 = 0; r2 < NM / 2; ++r2) {
+          const double2 t = vj[r2];
+          v[2 * r2] = t.x;
+          v[2 * r2 + 1] = t.y;
+        }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < NM; r += 4) {
+          a0 = fma(v[r], colA[r], a0);
+          a1 = fma(v[r + 1], colA[r + 1], a1);
+          a2 = fma(v[r + 2], colA[r + 2], a2);
+          a3 = fma(v[r + 3], colA[r + 3], a3);
+          b0 = fma(v[r], colB[r], b0);
+          b1 = fma(v[r + 1], colB[r + 1], b1);
+          b2 = fma(v[r + 2], colB[r + 2], b2);
+          b3 = fma(v[r + 3], colB[r + 3], b3);
+        }
+        const double tj = tau_s[j];
+        const double wA = -tj * ((a0 + a1) + (a2 + a3)), wB = -tj * ((b0 + b1) + (b2 + b3));
+#pragma unroll
+        for (int r = 0; r < NM; ++r) {
+          colA[r] = fma(v[r], wA, colA[r]);
+          colB[r] = fma(v[r], wB, colB[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NM; ++r) {
+        if (r < h) {
+          if (actA) tp[(size_t)r * ncols + h + cA] = colA[r];
+          if (actB) tp[(size_t)r * ncols + h + cB] = colB[r];
+        } else if (r < n) {
+          if (actA) dstA[(size_t)(r - h) * dsA] = colA[r];
+          if (actB) dstB[(size_t)(r - h) * dsB] = colB[r];
+        }
+      }
+    }
+    if (lane == 0) {
+      tp[(size_t)h * ncols] = (double)(unsigned)(smask & 0xffffffffull);
+      tp[(size_t)h * ncols + 1] = (double)(unsigned)(smask >> 32);
+      flag[draw] = 0;
+    }
+    wave_sync();  // the tables and V are rewritten by the next draw
+  }
+}
+
+// BSD: tile of the REDUCED system (8 * BSD >= n - h)
+template <int BSD>
+__global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict__ Tdy, const double* __restrict__ Rdy,
+                                                         const double* __restrict__ top, const int32_t* __restrict__ flag,
+                                                         int batch, int n, int k, int h, int32_t* __restrict__ status,
+                                                         double* __restrict__ T_out, double* __restrict__ R_out) {
+  constexpr int NMD = 8 * BSD, HM = CRD_HMAX;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ct = smem;             // HM x NMD: Ctop, zero padded
+  double* G1s = Ct + HM * NMD;   // HM x NMD: Btop + Ctop T_dy, zero padded
+  double* Rs = G1s + HM * NMD;   // HM x HM: R_st, zero padded
+  double* rinv = Rs + HM * HM;   // HM: 1 / diag(R_st), zero padded
+  int* dyi = (int*)(rinv + HM);
+  int* sti = dyi + 64;
+  const int lane = threadIdx.x;
+  const int nd = n - h, ncols = h + 3 * nd + k, ntot = nd + k;
+  const size_t top_stride = crd_top_doubles(n, k, h);
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
+    const size_t offr = (size_t)draw * nd * nd, offrk = (size_t)draw * nd * k;
+    if (flag[draw] != 0) {  // not deflated: the full-size kernels solve it next
+      if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
+      continue;
+    }
+    if (status[draw] != 0) {  // the reduced cycle reduction failed: zero policy matrices, as the full-size kernels write
+      for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+      for (int idx = lane; idx < n * k; idx += 64) R_out[offk + idx] = 0.0;
+      continue;
+    }
+    const double* tp = top + (size_t)draw * top_stride;
+    const unsigned long long smask = (unsigned long long)(unsigned)tp[(size_t)h * ncols] |
+                                     ((unsigned long long)(unsigned)tp[(size_t)h * ncols + 1] << 32);
+    crd_index_tables(smask, n, lane, dyi, sti);
+#pragma unroll
+    for (int i = 0; i < HM; ++i) {
+      if (lane < NMD) Ct[i * NMD + lane] = (i < h && lane < nd) ? tp[(size_t)i * ncols + h + 2 * nd + lane] : 0.0;
+    }
+    for (int idx = lane; idx < HM * HM; idx += 64) {
+      const int i = idx / HM, q = idx % HM;
+      Rs[idx] = (i < h && q < h) ? tp[(size_t)i * ncols + q] : 0.0;
+    }
+    wave_sync();
+    bool bad = false;
+    if (lane < HM) {
+      const double dg = Rs[lane * HM + lane];
+      bad = (lane < h) && !(fabs(dg) > 1e-300);
+      rinv[lane] = (lane < h && !bad) ? 1.0 / dg : 0.0;
+    }
+    if (__ballot(bad) != 0ull) {  // a (numerically) singular R_st: leave the verdict to the full-size kernels
+      if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
+      wave_sync();
+      continue;
+    }
+    double y[NMD];
+    auto load_column = [&](int c) {
+      const double* src = (c < nd) ? (Tdy + offr + c) : (Rdy + offrk + (c - nd));
+      const int ss = (c < nd) ? nd : k;
+      const bool act = c < ntot;
+      if (!act) src = Tdy + offr;
+#pragma unroll
+      for (int q = 0; q < NMD; ++q) y[q] = (q < nd && act) ? src[(size_t)q * ss] : 0.0;
+    };
+    load_column(lane);
+    {  // G1 = Btop + Ctop T_dy, column `lane`
+      double g[HM];
+#pragma unroll
+      for (int i = 0; i < HM; ++i) g[i] = (i < h && lane < nd) ? tp[(size_t)i * ncols + h + lane] : 0.0;
+#pragma unroll
+      for (int i = 0; i < HM; ++i) {
+        if (i < h) {
+          const double2* cr = reinterpret_cast<const double2*>(Ct + i * NMD);
+          double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < NMD / 2; ++q2) {
+            const double2 t = cr[q2];
+            e0 = fma(t.x, y[2 * q2], e0);
+            e1 = fma(t.y, y[2 * q2 + 1], e1);
+          }
+          g[i] += e0 + e1;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HM; ++i)
+        if (lane < NMD) G1s[i * NMD + lane] = (lane < nd) ? g[i] : 0.0;
+    }
+    wave_sync();
+    // static columns of T are exact zeros
+    if (lane < n) {
+#pragma unroll
+      for (int s2 = 0; s2 < HM; ++s2)
+        if (s2 < h) T_out[off + (size_t)lane * n + sti[s2]] = 0.0;
+    }
+    for (int c0 = 0; c0 < ntot; c0 += 64) {
+      const int c = c0 + lane;
+      if (c0 > 0) load_column(c);
+      const bool act = c < ntot;
+      double x[HM];
+      {  // right-hand sides [G1 T_dy + Atop | G1 R_dy + Dtop], column c
+        const int tc = h + nd + c + ((c >= nd) ? nd : 0);
+#pragma unroll
+        for (int i = 0; i < HM; ++i) x[i] = (i < h && act) ? tp[(size_t)i * ncols + tc] : 0.0;
+#pragma unroll
+        for (int i = 0; i < HM; ++i) {
+          if (i < h) {
+            const double2* gr = reinterpret_cast<const double2*>(G1s + i * NMD);
+            double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+            for (int q2 = 0; q2 < NMD / 2; ++q2) {
+              const double2 t = gr[q2];
+              e0 = fma(t.x, y[2 * q2], e0);
+              e1 = fma(t.y, y[2 * q2 + 1], e1);
+            }
+            x[i] += e0 + e1;
+          }
+        }
+      }
+      // back-substitution with R_st (zero padded: rows >= h come out as zeros)
+#pragma unroll
+      for (int i = HM - 1; i >= 0; --i) {
+        if (i < h) {
+          double acc = x[i];
+#pragma unroll
+          for (int q = i + 1; q < HM; ++q) acc = fma(-Rs[i * HM + q], x[q], acc);
+          x[i] = acc * rinv[i];
+        }
+      }
+      // scatter to the caller's variable order
+      double* dcol = (c < nd) ? (T_out + off + dyi[act && c < nd ? c : 0]) : (R_out + offk + (c - nd));
+      const int ds = (c < nd) ? n : k;
+      if (act) {
+#pragma unroll
+        for (int s2 = 0; s2 < HM; ++s2)
+          if (s2 < h) dcol[(size_t)sti[s2] * ds] = -x[s2];
+#pragma unroll
+        for (int q = 0; q < NMD; ++q)
+          if (q < nd) dcol[(size_t)dyi[q] * ds] = y[q];
+      }
+    }
+    wave_sync();  // the LDS tables are rewritten by the next draw
+  }
+}
+
+}  // namespace dsge

@@ -15,6 +15,7 @@
 // SIMD.  The launches hand the window over through a library-owned HBM workspace (88 KB per draw, read and written once).
 #pragma once
 #include "dsge_gensys.hpp"
+#include "dsge_householder.hpp"
 
 namespace dsge {
 
@@ -108,118 +109,6 @@ __global__ __launch_bounds__(64) void gensys_shape_kernel(const double* __restri
       if (z < __atomic_load_n(out + 3, __ATOMIC_RELAXED)) atomicMin(out + 3, z);
     }
   }
-}
-
-// ---- real Householder reflector built from column `col` of `src` (rows j..N-1, one row per lane) and applied from the
-// left to rows j..N-1 of H (columns h0..h0+nH-1), T (nT columns) and X (nX columns).  dlarfg conventions as in
-// householder_left (dsge_gensys.hpp).  The nH + nT + nX columns are dealt one per lane (in passes of 64); a lane walks
-// down its column with a private pointer and stride, four rows per trip and no divergent control flow, so the LDS loads
-// of a trip are in flight together (the first version -- one conditional load per matrix and row -- spent 300 cycles
-// per row).
-__device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH, double* Tr, int ldW, int nT, double* Xr,
-                                             int ldX, int nX, double* src, int ld_src, int col, int j, int N, int lane) {
-  wave_sync();
-  const double x = (lane >= j && lane < N) ? src[lane * ld_src + col] : 0.0;
-  const double xnorm2 = wave_sum_dpp((lane > j) ? x * x : 0.0);
-  if (xnorm2 == 0.0) return;
-  const double alpha = readlane_dyn_f64(x, j);
-  const double nrm = sqrt(fma(alpha, alpha, xnorm2));
-  const double beta = (alpha >= 0.0) ? -nrm : nrm;
-  const double tau = (beta - alpha) / beta;
-  const double scal = 1.0 / (alpha - beta);
-  const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
-  const int ncols = nH + nT + nX;
-  // column c of the virtual matrix [H | T | X] -> base pointer and row stride (inactive lanes walk a valid column of H
-  // and store nothing)
-  auto column = [&](int c, double*& base, int& ld) -> bool {
-    base = Hr + h0;
-    ld = ldH;
-    if (c >= ncols) return false;
-    if (c < nH) {
-      base = Hr + h0 + c;
-    } else if (c < nH + nT) {
-      base = Tr + (c - nH);
-      ld = ldW;
-    } else {
-      base = Xr + (c - nH - nT);
-      ld = ldX;
-    }
-    return true;
-  };
-  for (int c0 = 0; c0 < ncols; c0 += 128) {  // two columns per lane and trip: eight loads in flight
-    double *bA, *bB;
-    int lA, lB;
-    const bool actA = column(c0 + lane, bA, lA), actB = column(c0 + 64 + lane, bB, lB);
-    double* pA = bA + j * lA;
-    double* pB = bB + j * lB;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    int r = j;
-    for (; r + 4 <= N; r += 4) {
-      const double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
-      const double q0 = pB[0], q1 = pB[lB], q2 = pB[2 * lB], q3 = pB[3 * lB];
-      const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
-                   v3 = readlane_dyn_f64(v, r + 3);
-      a0 = fma(v0, m0, a0);
-      a1 = fma(v1, m1, a1);
-      a2 = fma(v2, m2, a2);
-      a3 = fma(v3, m3, a3);
-      b0 = fma(v0, q0, b0);
-      b1 = fma(v1, q1, b1);
-      b2 = fma(v2, q2, b2);
-      b3 = fma(v3, q3, b3);
-      pA += 4 * lA;
-      pB += 4 * lB;
-    }
-    for (; r < N; ++r) {
-      const double vr = readlane_dyn_f64(v, r);
-      a0 = fma(vr, pA[0], a0);
-      b0 = fma(vr, pB[0], b0);
-      pA += lA;
-      pB += lB;
-    }
-    const double wA = -tau * ((a0 + a1) + (a2 + a3)), wB = -tau * ((b0 + b1) + (b2 + b3));
-    pA = bA + j * lA;
-    pB = bB + j * lB;
-    for (r = j; r + 4 <= N; r += 4) {
-      double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
-      double q0 = pB[0], q1 = pB[lB], q2 = pB[2 * lB], q3 = pB[3 * lB];
-      const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
-                   v3 = readlane_dyn_f64(v, r + 3);
-      m0 = fma(v0, wA, m0);
-      m1 = fma(v1, wA, m1);
-      m2 = fma(v2, wA, m2);
-      m3 = fma(v3, wA, m3);
-      q0 = fma(v0, wB, q0);
-      q1 = fma(v1, wB, q1);
-      q2 = fma(v2, wB, q2);
-      q3 = fma(v3, wB, q3);
-      if (actA) {
-        pA[0] = m0;
-        pA[lA] = m1;
-        pA[2 * lA] = m2;
-        pA[3 * lA] = m3;
-      }
-      if (actB) {
-        pB[0] = q0;
-        pB[lB] = q1;
-        pB[2 * lB] = q2;
-        pB[3 * lB] = q3;
-      }
-      pA += 4 * lA;
-      pB += 4 * lB;
-    }
-    for (; r < N; ++r) {
-      const double vr = readlane_dyn_f64(v, r);
-      const double m0 = fma(vr, wA, pA[0]), q0 = fma(vr, wB, pB[0]);
-      if (actA) pA[0] = m0;
-      if (actB) pB[0] = q0;
-      pA += lA;
-      pB += lB;
-    }
-  }
-  wave_sync();
-  if (lane >= j && lane < N) src[lane * ld_src + col] = (lane == j) ? beta : 0.0;
-  wave_sync();
 }
 
 __device__ __forceinline__ void rot2r(double& x, double& y, double c, double s) {

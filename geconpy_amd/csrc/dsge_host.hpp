@@ -52,6 +52,10 @@ int set_lds(K kernel, size_t bytes) {
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode = 0,
               const double* D = nullptr, int k = 0, double* R_out = nullptr);  // D, R_out: also R = -A1_hat^-1 D
+int launch_cr_deflated(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
+                       int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
+                       hipStream_t st, int* used);  // static-variable deflation + cycle reduction on the reduced system
+void cr_deflation_reset();
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
                    double* R_out, hipStream_t st);
 int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
@@ -91,6 +95,7 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
                      hipStream_t st);
 
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
+extern int g_cr_deflate;              // launch_solvers.hip: 0 = no static-variable deflation
 extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-reduction kernel only
 // process-wide settings of the fast Kalman kernel (launch_kalman.hip)
 extern long long* g_kalman_dbg;       // debug: device buffer for per-phase cycles of draw 0

@@ -2,6 +2,10 @@
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_cr_compact.hpp"
+#include "dsge_cr_deflate.hpp"
+
+#include <algorithm>
+#include <mutex>
 
 namespace dsge_host {
 
@@ -37,6 +41,139 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
     }
   });
   return rc;
+}
+
+// ---- cycle reduction behind the static-variable deflation (dsge_cr_deflate.hpp) -----------------------------------------
+int g_cr_deflate = 1;  // 0 = always the full-size system
+
+namespace {
+std::mutex g_defl_mutex;
+int g_static_hint[DSGE_MAX_N + 2];  // per model size n: lower bound of the number of static variables; 0 = not measured yet
+bool g_static_hint_init = false;    // (stored as h + 1)
+struct DeflArena {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  bool used = false;
+};
+DeflArena g_defl_arena[16][16];
+
+int defl_reserve(size_t bytes, hipStream_t st, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
+  DeflArena* a = nullptr;
+  for (auto& slot : g_defl_arena[dev])
+    if (slot.used && slot.stream == st) a = &slot;
+  if (!a)
+    for (auto& slot : g_defl_arena[dev])
+      if (!slot.used) {
+        a = &slot;
+        break;
+      }
+  if (!a) {
+    HIP_TRY(hipDeviceSynchronize());
+    a = &g_defl_arena[dev][0];
+  }
+  a->used = true;
+  a->stream = st;
+  if (a->cap < bytes) {
+    if (a->ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a->ptr));
+      a->ptr = nullptr;
+      a->cap = 0;
+    }
+    HIP_TRY(hipMalloc(&a->ptr, bytes + bytes / 4));
+    a->cap = bytes + bytes / 4;
+  }
+  *out = a->ptr;
+  return DSGE_SUCCESS;
+}
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+void cr_deflation_reset() {
+  std::lock_guard<std::mutex> lk(g_defl_mutex);
+  g_static_hint_init = false;
+}
+
+// *used = 0: nothing done (deflation off, too few static variables, ...): the caller runs launch_cr on the full system.
+int launch_cr_deflated(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
+                       int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
+                       hipStream_t st, int* used) {
+  *used = 0;
+  if (!g_cr_deflate || !D || !R_out || n < 8 || n > 64 || batch < 1) return DSGE_SUCCESS;
+  std::lock_guard<std::mutex> lk(g_defl_mutex);
+  if (!g_static_hint_init) {
+    for (auto& x : g_static_hint) x = 0;
+    g_static_hint_init = true;
+  }
+  int rc;
+  void* base = nullptr;
+  if (g_static_hint[n] == 0) {  // first batch of this model size: measure (one small launch and a 4-byte read-back)
+    if ((rc = defl_reserve(256, st, &base))) return rc;
+    int32_t hmin = n;
+    HIP_TRY(hipMemcpyAsync(base, &hmin, sizeof(hmin), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dsge::cr_static_scan_kernel, dim3(batch < 4096 ? batch : 4096), dim3(64), 0, st, A, C, batch, n,
+                       (int32_t*)base);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&hmin, base, sizeof(hmin), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    g_static_hint[n] = hmin + 1;
+  }
+  const int h = std::min(g_static_hint[n] - 1, (int)dsge::CRD_HMAX);
+  const int nd = n - h;
+  // worth it only when the reduced system drops to a smaller register-block tile or loses a fifth of its variables
+  if (h < 1 || nd < 4 || (tile_bs(nd) == tile_bs(n) && 5 * h < n)) return DSGE_SUCCESS;
+  const size_t lds1 = dsge::crd_deflate_smem(8 * tile_bs(n)), lds2 = dsge::crd_inflate_smem(8 * tile_bs(nd));
+  const size_t ndd = (size_t)batch * nd * nd, ndk = (size_t)batch * nd * k, tops = (size_t)batch * dsge::crd_top_doubles(n, k, h);
+  if ((rc = defl_reserve(4 * al256(ndd * 8) + 2 * al256(ndk * 8) + al256(tops * 8) + al256((size_t)batch * 4) + 4096, st,
+                         &base)))
+    return rc;
+  char* p = (char*)base;
+  double* Ared = (double*)p; p += al256(ndd * 8);
+  double* Bred = (double*)p; p += al256(ndd * 8);
+  double* Cred = (double*)p; p += al256(ndd * 8);
+  double* Tdy = (double*)p; p += al256(ndd * 8);
+  double* Dred = (double*)p; p += al256(ndk * 8);
+  double* Rdy = (double*)p; p += al256(ndk * 8);
+  double* top = (double*)p; p += al256(tops * 8);
+  int32_t* flag = (int32_t*)p;
+  rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(tile_bs(n), 8, {
+    rc = DSGE_SUCCESS;
+    hipLaunchKernelGGL(dsge::cr_deflate_kernel<BS>, dim3(batch), dim3(64), lds1, st, A, B, C, D, batch, n, k, h, Ared, Bred,
+                       Cred, Dred, top, flag);
+  });
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  if ((rc = launch_cr(Ared, Bred, Cred, batch, nd, max_iter, tol, Tdy, status, n_iter, st, 0, Dred, k, Rdy))) return rc;
+  rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(tile_bs(nd), 8, {
+    rc = DSGE_SUCCESS;
+    hipLaunchKernelGGL(dsge::cr_inflate_kernel<BS>, dim3(batch), dim3(64), lds2, st, (const double*)Tdy, (const double*)Rdy,
+                       (const double*)top, (const int32_t*)flag, batch, n, k, h, status, T_out, R_out);
+  });
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  // draws the deflation could not take (fewer static variables than the bound, singular R_st): full-size dense kernel on
+  // exactly those (status == DSGE_ST_INTERNAL_RERUN)
+  {
+    const int bs = tile_bs(n);
+    rc = DSGE_ERR_INVALID;
+    DISPATCH_BS(bs, 8, {
+      rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
+      if (rc == DSGE_SUCCESS) {
+        hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
+                           max_iter, tol, T_out, status, n_iter, 1, 0, D, k, R_out);
+        HIP_TRY(hipGetLastError());
+      }
+    });
+    if (rc) return rc;
+  }
+  *used = 1;
+  return DSGE_SUCCESS;
 }
 
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,

@@ -147,9 +147,11 @@ class LogpEngine:
     # -- product entry points --------------------------------------------------------------
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
-                          logp=None, status=None, n_state_hint=0, z_selector_hint=0, n_lead_hint=0):
+                          logp=None, status=None, n_state_hint=0, z_selector_hint=0, n_lead_hint=0, T_out=None,
+                          R_out=None):
         """Enqueue one fused evaluation of the whole batch; returns (logp, status) tensors
-        (asynchronous: synchronize the stream before reading them on the host)."""
+        (asynchronous: synchronize the stream before reading them on the host).  ``T_out`` [batch][n][n] /
+        ``R_out`` [batch][n][k]: optional float64 CUDA tensors that receive the policy matrices."""
         torch = self.torch
         nb, n, k, p, T_len, qm, zb, db, hb = self._pack(A, B, C, D, Q, Z, y, d, Hdiag, q_mode)
         if logp is None:
@@ -161,7 +163,8 @@ class LogpEngine:
                 self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol),
                 int(max_iter), float(jitter), float(missing_fill_value), int(n_state_hint), int(z_selector_hint),
-                int(n_lead_hint), self._p(logp), status.data_ptr(), None, None, None, None, self._stream(),
+                int(n_lead_hint), self._p(logp), status.data_ptr(), self._p(T_out), self._p(R_out), None, None,
+                self._stream(),
             )
         )
         return logp, status

@@ -174,6 +174,14 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
 int dsge_set_kalman_tiny(int enable);
+/* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
+ * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
+ * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by
+ * back-substitution (dsge_cr_deflate.hpp).  Same solution (it is unique), (n - h)^3 instead of n^3 work per iteration.
+ * h is measured once per model size (a small launch and a 4-byte read-back on the first call) and verified per draw; a
+ * draw with fewer static variables is solved by the full-size kernels.  Not used when the caller asks for the iteration
+ * counts or the policy residual.  enable = 0 switches it off and forgets the measured sizes.  Default on.  Process-wide. */
+int dsge_set_cr_deflation(int enable);
 /* Fused evaluation: the workgroups of the Kalman launch (and of the gradient path's reverse-sweep launch) are dispatched in
  * descending order of a per-draw key (a counting sort on the device).  The launch's makespan is set by its slowest draws --
  * a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for up to T_len

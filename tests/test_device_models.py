@@ -138,3 +138,28 @@ def test_window_gensys_algebra(ref_goldens, failure_golden):
         T_ref, ok, _ = oracle.gensys_T_success(b["A"][i], b["B"][i], b["C"][i], b["D"][i], tol=1e-8)
         assert ok and eu == [1, 1, 0]
         assert_allclose(T, T_ref, atol=1e-11)
+
+
+def test_cr_static_deflation_algebra(ref_goldens):
+    """Static-variable deflation in front of cycle reduction (dsge_cr_deflate.hpp): same T and R as the reference's
+    cycle reduction on the full system, on the goldens and on SW-shaped draws; also with fewer static variables
+    deflated than the system has (the device's lower-bound hint)."""
+    from tests.device_models.cr_deflation_model import deflated_cycle_reduction
+
+    for key, h_expect in (("one_block", 3), ("rbc_2_block", 6), ("full_nk", 4)):
+        A, B, C, D = (ref_goldens[f"{key}_{x}"] for x in "ABCD")
+        T_ref = ref_goldens[f"{key}_ref_cr_T"]
+        R_ref = oracle.compute_selection_matrix(B, C, D, T_ref)
+        for h in (None, 1):
+            T, R, h_used, _ = deflated_cycle_reduction(A, B, C, D, h=h)
+            assert h_used == (h_expect if h is None else h)
+            assert_allclose(T, T_ref, atol=1e-10)
+            assert_allclose(R, R_ref, atol=1e-10)
+    b = wl.sw_shaped_batch(3)
+    for i in range(3):
+        A, B, C, D = (b[x][i] for x in "ABCD")
+        T, R, h_used, it = deflated_cycle_reduction(A, B, C, D)
+        full = oracle.cycle_reduction_core(A, B, C, 1000, 1e-9)
+        assert h_used == 10 and it == full[2]
+        assert_allclose(T, b["T_star"][i], atol=1e-11)
+        assert_allclose(R, oracle.compute_selection_matrix(B, C, D, b["T_star"][i]), atol=1e-11)

@@ -1396,3 +1396,100 @@ def test_fused_call_is_independent_of_batch_size():
         for lo, hi in ((0, 1), (5, 68), (100, 164), (17, 82), (0, 511), (40, 552), (87, 600)):
             lp, st = run(lo, hi)
             assert np.array_equal(st, full_st[lo:hi]) and np.array_equal(lp, full_lp[lo:hi]), (solver, lo, hi)
+
+
+def _fused_policy(eng, dev, dq, dZ, dy, dH, hints, **kw):
+    import torch
+
+    nb, n = dev["A"].shape[:2]
+    T = torch.full((nb, n, n), np.nan, dtype=torch.float64, device=eng.device)
+    R = torch.full((nb, n, dev["D"].shape[2]), np.nan, dtype=torch.float64, device=eng.device)
+    lp, st = eng.solve_kalman_logp(dev["A"], dev["B"], dev["C"], dev["D"], dq, dZ, dy, Hdiag=dH, tol=1e-9, max_iter=1000,
+                                   n_state_hint=hints[0], z_selector_hint=hints[1], T_out=T, R_out=R, **kw)
+    torch.cuda.synchronize()
+    return lp.cpu().numpy(), st.cpu().numpy(), T.cpu().numpy(), R.cpu().numpy()
+
+
+def test_cr_static_deflation_matches_full_system():
+    """Cycle reduction behind the static-variable deflation (default on; 30 of 40 variables on the SW-shaped draws) against
+    the full-size iteration: T, R to 1e-10, logp to the parity tolerance, status identical -- with a failed draw (NaN), a
+    draw with FEWER static variables than the measured bound (a lag coefficient on a static variable: solved by the
+    full-size kernels) and one with more (an extra zero column: only the first h are deflated)."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    lib = _lib.load()
+    nb = 700
+    b = wl.sw_shaped_batch(nb, first_draw=9100)
+    om = wl.sw_shaped_observation_model()
+    A, B, C, D = (b[x].copy() for x in "ABCD")
+    static = np.where(~(A[0] != 0).any(0) & ~(C[0] != 0).any(0))[0]
+    assert len(static) == 10
+    A[5, 0, 0] = np.nan
+    A[9, 3, static[2]] = 1e-3   # static variable turned (weakly) predetermined
+    A[300, 7, static[-1]] = -2e-3
+    eng = LogpEngine(torch.device("cuda", 0))
+    dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
+    dq = eng.to_device(b["sigma"] ** 2)
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:40]), eng.to_device(om["Hdiag"])
+    hints = eng.structure_hints(dev["A"], dZ)
+    try:
+        _lib.check(lib.dsge_set_cr_deflation(0))
+        lp0, st0, T0, R0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+        _lib.check(lib.dsge_set_cr_deflation(1))
+        # the bound is measured on the first batch of a model size: give it the clean one, so that draws 9 and 300 of
+        # the second call are the violators
+        clean = {x: eng.to_device(b[x]) for x in "ABCD"}
+        _fused_policy(eng, clean, dq, dZ, dy, dH, hints)
+        lp1, st1, T1, R1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+        lp2, st2, T2, R2 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+    finally:
+        _lib.check(lib.dsge_set_cr_deflation(1))
+    assert np.array_equal(st0, st1) and st0[5] != 0 and np.count_nonzero(st0) == 1
+    ok = st0 == 0
+    assert_allclose(T1[ok], T0[ok], atol=1e-10)
+    assert_allclose(R1[ok], R0[ok], atol=1e-10)
+    assert_allclose(lp1[ok], lp0[ok], rtol=LOGP_RTOL)
+    assert lp1[5] == -np.inf
+    # the violators went through the full-size kernels: bit-identical to the run without deflation
+    for i in (9, 300):
+        assert np.array_equal(T1[i], T0[i]) and np.array_equal(R1[i], R0[i]) and lp1[i] == lp0[i]
+    assert np.array_equal(lp1, lp2) and np.array_equal(T1, T2)
+    # and against the oracle
+    for i in (0, 9, 300, 699):
+        r = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(b["sigma"][i] ** 2), om["Z"], om["y"][:40],
+                                     H=np.diag(om["Hdiag"]), tol=1e-9, max_iter=1000)
+        assert_allclose(lp1[i], r["logp"], rtol=LOGP_RTOL)
+        assert_allclose(T1[i], r["T"], atol=1e-9)
+
+
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
+def test_cr_static_deflation_on_reference_goldens(ref_goldens, key):
+    """The reference's own models (3 of 9, 6 of 12, 4 of 24 static variables): fused call with the deflation against the
+    reference's cycle-reduction T and the oracle's logp."""
+    A, B, C, D = (ref_goldens[f"{key}_{x}"] for x in "ABCD")
+    n, k = A.shape[0], D.shape[1]
+    nb = 3
+    rng = np.random.default_rng(11)
+    Ab, Bb, Cb, Db = (np.repeat(x[None], nb, 0).copy() for x in (A, B, C, D))
+    Bb[1:] *= 1.0 + 1e-3 * rng.standard_normal((nb - 1, 1, 1))
+    p = min(k, 2)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p) + 1] = 1.0
+    y = rng.normal(0, 0.05, (30, p))
+    q = np.full((nb, k), 0.01)
+    H = np.full(p, 1e-3)
+    lib = _lib.load()
+    outs = []
+    try:
+        for on in (0, 1):
+            _lib.check(lib.dsge_set_cr_deflation(on))
+            outs.append(batched.solve_kalman_logp_batched(Ab, Bb, Cb, Db, q, Z, y, Hdiag=H, tol=1e-10, max_iter=1000))
+    finally:
+        _lib.check(lib.dsge_set_cr_deflation(1))
+    assert np.all(outs[0]["status"] == 0) and np.all(outs[1]["status"] == 0)
+    assert_allclose(outs[1]["logp"], outs[0]["logp"], rtol=LOGP_RTOL)
+    for i in range(nb):
+        r = oracle.solve_kalman_logp(Ab[i], Bb[i], Cb[i], Db[i], np.diag(q[i]), Z, y, H=np.diag(H), tol=1e-10, max_iter=1000)
+        assert_allclose(outs[1]["logp"][i], r["logp"], rtol=LOGP_RTOL)
