@@ -707,8 +707,14 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
     int32_t* stc = status_out + c0;
     if (solver == DSGE_SOLVER_GENSYS)
       rc = launch_gensys(Ac, Bc, Cc, nb, n, tol, n_lead_hint, Tw, eu_w, stc, st);
-    else
-      rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, it_w, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
+    else {
+      int deflated = 0;  // static variables deflated first, as in the forward-only call (R is recomputed by the assemble)
+      if (solver == DSGE_SOLVER_CYCLE_REDUCTION &&
+          (rc = launch_cr_deflated(Ac, Bc, Cc, Dc, nb, n, k, max_iter, tol, Tw, Rw, stc, it_w, st, &deflated)))
+        return rc;
+      if (!deflated)
+        rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, it_w, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
+    }
     if (rc) return rc;
     if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
                               Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))

@@ -77,27 +77,32 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
                                                          int32_t* __restrict__ flag) {
   constexpr int NM = 8 * BS, HM = CRD_HMAX;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* V = smem;             // HM x NM: reflector j in row j (zero above its pivot and below row n)
-  double* tau_s = V + HM * NM;  // HM
+  double* V = smem;             // HM x NM: pivot column j (shifted: pivot in slot 0), for the second column chunk
+  double* tau_s = V + HM * NM;  // HM (unused)
   int* dyi = (int*)(tau_s + HM);
   int* sti = dyi + 64;
   const int lane = threadIdx.x;
   const int nd = n - h, nv = 3 * nd + k, ncols = h + nv;
   const size_t top_stride = crd_top_doubles(n, k, h);
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  {  // one draw per workgroup (grid = batch): a grid-stride loop here makes the compiler hoist every address and
+     // comparison of the unrolled row loops out of it, into scalar registers it then has to spill
+    const int draw = blockIdx.x;
+    if (draw >= batch) return;
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
     const size_t offr = (size_t)draw * nd * nd, offrk = (size_t)draw * nd * k;
     // ---- which variables are static: lane j looks down column j of A and C (all rows in flight)
     int nz = 0;
     {
-      const double* ap = A + off + lane;
-      const double* cp = C + off + lane;
+      // unconditional loads (clamped indices): conditional ones compile to one exec-masked block per load
+      const int cl = lane < n ? lane : n - 1;
+      const double* ap = A + off + cl;
+      const double* cp = C + off + cl;
       double av[NM], cv[NM];
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
-        const bool in = (i < n) && (lane < n);
-        av[i] = in ? ap[(size_t)i * n] : 0.0;
-        cv[i] = in ? cp[(size_t)i * n] : 0.0;
+        const int ri = i < n ? i : n - 1;
+        av[i] = ap[(size_t)ri * n];
+        cv[i] = cp[(size_t)ri * n];
       }
 #pragma unroll
       for (int i = 0; i < NM; ++i) nz |= ((av[i] != 0.0) | (cv[i] != 0.0)) ? 1 : 0;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
       }
       for (int idx = lane; idx < nd * k; idx += 64) Dred[offrk + idx] = 0.0;
       if (lane == 0) flag[draw] = 1;
-      continue;
+      return;
     }
     {  // keep the first h of them (the others stay in the dynamic block with their zero columns)
       unsigned long long keep = 0ull, rest = smask;
@@ -127,55 +132,30 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
     }
     crd_index_tables(smask, n, lane, dyi, sti);
     double* tp = top + (size_t)draw * top_stride;
-    // ---- QR of B_st, one ROW per lane in registers; the reflectors go to LDS
-    {
-      double bst[HM];
-#pragma unroll
-      for (int s2 = 0; s2 < HM; ++s2) bst[s2] = (s2 < h && lane < n) ? B[off + (size_t)lane * n + sti[s2 < h ? s2 : 0]] : 0.0;
-#pragma unroll
-      for (int j = 0; j < HM; ++j) {
-        if (j < h) {
-          const double x = (lane >= j) ? bst[j] : 0.0;
-          const double xn2 = wave_sum_dpp((lane > j) ? x * x : 0.0);
-          const double alpha = readlane_dyn_f64(x, j);
-          double v = (lane == j) ? 1.0 : 0.0, tau = 0.0, beta = alpha;
-          if (xn2 != 0.0) {  // dlarfg
-            const double nrm = sqrt(fma(alpha, alpha, xn2));
-            beta = (alpha >= 0.0) ? -nrm : nrm;
-            tau = (beta - alpha) / beta;
-            const double scal = 1.0 / (alpha - beta);
-            v = (lane == j) ? 1.0 : ((lane > j) ? x * scal : 0.0);
-          }
-#pragma unroll
-          for (int c = j + 1; c < HM; ++c) {
-            if (c < h) {
-              const double dot = wave_sum_dpp(v * bst[c]);
-              bst[c] = fma(-tau * dot, v, bst[c]);
-            }
-          }
-          bst[j] = (lane == j) ? beta : ((lane > j) ? 0.0 : bst[j]);
-          if (lane < NM) V[j * NM + lane] = v;
-          if (lane == 0) tau_s[j] = tau;
-        }
-      }
-      if (lane < h) {  // R_st
-#pragma unroll
-        for (int s2 = 0; s2 < HM; ++s2)
-          if (s2 < h) tp[(size_t)lane * ncols + s2] = bst[s2];
-      }
-    }
-    wave_sync();
-    // ---- Q' applied to [B_dy | A_dy | C_dy | D]: two columns per lane, in registers
-    for (int c0 = 0; c0 < nv; c0 += 128) {
+    // ---- Q' applied to [B_st | B_dy | A_dy | C_dy | D]: two columns per lane, in registers, all rows of a column loaded
+    // in flight.  The first h columns (lanes 0..h-1 of the first chunk) are B_st itself: reflector j is read off lane j
+    // with v_readlane (it is wave-uniform from there on), so the QR needs neither LDS nor wave reductions.  Only systems
+    // with more than 128 columns (n > 45 or so) take a second chunk, which reads the reflectors back from LDS.
+    const int ntotc = h + nv;
+    const bool multi = ntotc > 128;
+    for (int c0 = 0; c0 < ntotc; c0 += 128) {
       const double *srcA, *srcB;
       double *dstA, *dstB;
       int ssA, ssB, dsA, dsB;
-      auto describe = [&](int c, const double*& src, int& ss, double*& dst, int& ds) -> bool {
+      bool redA, redB;  // has rows in the reduced system (everything but B_st)
+      auto describe = [&](int cv, const double*& src, int& ss, double*& dst, int& ds, bool& red) -> bool {
         src = B + off;
         ss = n;
         dst = Bred + offr;
         ds = nd;
-        if (c >= nv) return false;
+        red = false;
+        if (cv >= ntotc) return false;
+        if (cv < h) {
+          src = B + off + sti[cv];
+          return true;
+        }
+        red = true;
+        const int c = cv - h;
         if (c >= 3 * nd) {
           src = D + offk + (c - 3 * nd);
           ss = k;
@@ -191,51 +171,104 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
         return true;
       };
       const int cA = c0 + lane, cB = c0 + 64 + lane;
-      const bool actA = describe(cA, srcA, ssA, dstA, dsA), actB = describe(cB, srcB, ssB, dstB, dsB);
+      const bool actA = describe(cA, srcA, ssA, dstA, dsA, redA), actB = describe(cB, srcB, ssB, dstB, dsB, redB);
       double colA[NM], colB[NM];
 #pragma unroll
-      for (int r = 0; r < NM; ++r) {
-        colA[r] = (r < n && actA) ? srcA[(size_t)r * ssA] : 0.0;
-        colB[r] = (r < n && actB) ? srcB[(size_t)r * ssB] : 0.0;
+      for (int r = 0; r < NM; ++r) {  // unconditional loads (inactive lanes walk a valid column, rows are clamped)
+        const int rr = r < n ? r : n - 1;
+        const double tA = srcA[(size_t)rr * ssA], tB = srcB[(size_t)rr * ssB];
+        colA[r] = (r < n && actA) ? tA : 0.0;
+        colB[r] = (r < n && actB) ? tB : 0.0;
       }
+      // Row j is final once reflector j has been applied: it goes straight to the top block and the columns are shifted
+      // up by one row, so that the pivot is always register row 0 (no index-dependent selects, which cost a scalar lane
+      // mask each) and what is left after h reflectors is the reduced system, rows 0..nd-1.
+      // The reflector is never materialised: with u = column j below the pivot (wave-uniform, read off lane j with
+      // v_readlane in the first chunk, from LDS in a later one), v = [1; scal u], so v'x = x_0 + scal u'x and the raw
+      // dots u'x ride along with the norm sweep; the second sweep updates and shifts.  Registers: the two columns only.
       for (int j = 0; j < h; ++j) {
-        double v[NM];
-        const double2* vj = reinterpret_cast<const double2*>(V + j * NM);
+        double xn2 = 0.0, alpha;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        if (c0 == 0) {
+          if (multi && lane == j) {
 #pragma unroll
-        for (int r2 = 0; r2 < NM / 2; ++r2) {
-          const double2 t = vj[r2];
-          v[2 * r2] = t.x;
-          v[2 * r2 + 1] = t.y;
-        }
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+            for (int r = 0; r < NM; ++r) V[j * NM + r] = colA[r];
+          }
+          alpha = readlane_dyn_f64(colA[0], j);
 #pragma unroll
-        for (int r = 0; r < NM; r += 4) {
-          a0 = fma(v[r], colA[r], a0);
-          a1 = fma(v[r + 1], colA[r + 1], a1);
-          a2 = fma(v[r + 2], colA[r + 2], a2);
-          a3 = fma(v[r + 3], colA[r + 3], a3);
-          b0 = fma(v[r], colB[r], b0);
-          b1 = fma(v[r + 1], colB[r + 1], b1);
-          b2 = fma(v[r + 2], colB[r + 2], b2);
-          b3 = fma(v[r + 3], colB[r + 3], b3);
-        }
-        const double tj = tau_s[j];
-        const double wA = -tj * ((a0 + a1) + (a2 + a3)), wB = -tj * ((b0 + b1) + (b2 + b3));
+          for (int r = 1; r < NM; r += 2) {
+            const double u0 = readlane_dyn_f64(colA[r], j);
+            xn2 = fma(u0, u0, xn2);
+            a0 = fma(u0, colA[r], a0);
+            b0 = fma(u0, colB[r], b0);
+            if (r + 1 < NM) {
+              const double u1 = readlane_dyn_f64(colA[r + 1], j);
+              xn2 = fma(u1, u1, xn2);
+              a1 = fma(u1, colA[r + 1], a1);
+              b1 = fma(u1, colB[r + 1], b1);
+            }
+          }
+        } else {
+          const double* vj = V + j * NM;
+          alpha = vj[0];
 #pragma unroll
-        for (int r = 0; r < NM; ++r) {
-          colA[r] = fma(v[r], wA, colA[r]);
-          colB[r] = fma(v[r], wB, colB[r]);
+          for (int r = 1; r < NM; r += 2) {
+            const double u0 = vj[r];
+            xn2 = fma(u0, u0, xn2);
+            a0 = fma(u0, colA[r], a0);
+            b0 = fma(u0, colB[r], b0);
+            if (r + 1 < NM) {
+              const double u1 = vj[r + 1];
+              xn2 = fma(u1, u1, xn2);
+              a1 = fma(u1, colA[r + 1], a1);
+              b1 = fma(u1, colB[r + 1], b1);
+            }
+          }
         }
+        double beta = alpha, scal = 0.0, tj = 0.0;
+        if (xn2 != 0.0) {  // dlarfg
+          const double nrm = sqrt(fma(alpha, alpha, xn2));
+          beta = (alpha >= 0.0) ? -nrm : nrm;
+          tj = (beta - alpha) / beta;
+          scal = 1.0 / (alpha - beta);
+        }
+        // w = -tau v'x; the pivot column (beta e_0 exactly) and the columns left of it (all zeros by now) are set directly
+        const bool left = (c0 == 0) && (lane <= j);
+        const double wA = left ? 0.0 : -tj * fma(scal, a0 + a1, colA[0]);
+        const double wB = -tj * fma(scal, b0 + b1, colB[0]);
+        const double topA = left ? ((lane == j) ? beta : 0.0) : colA[0] + wA, topB = colB[0] + wB;
+        if (actA) tp[(size_t)j * ncols + cA] = topA;
+        if (actB) tp[(size_t)j * ncols + cB] = topB;
+        const double wsA = wA * scal, wsB = wB * scal;
+        if (c0 == 0) {
+#pragma unroll
+          for (int r = 1; r < NM; ++r) {  // update and shift up by one row
+            const double u = readlane_dyn_f64(colA[r], j);
+            colA[r - 1] = left ? 0.0 : fma(u, wsA, colA[r]);
+            colB[r - 1] = fma(u, wsB, colB[r]);
+          }
+        } else {
+          const double* vj = V + j * NM;
+#pragma unroll
+          for (int r = 1; r < NM; ++r) {
+            const double u = vj[r];
+            colA[r - 1] = fma(u, wsA, colA[r]);
+            colB[r - 1] = fma(u, wsB, colB[r]);
+          }
+        }
+        colA[NM - 1] = 0.0;
+        colB[NM - 1] = 0.0;
       }
+      if (multi) wave_sync();
+      if (actA && redA) {
 #pragma unroll
-      for (int r = 0; r < NM; ++r) {
-        if (r < h) {
-          if (actA) tp[(size_t)r * ncols + h + cA] = colA[r];
-          if (actB) tp[(size_t)r * ncols + h + cB] = colB[r];
-        } else if (r < n) {
-          if (actA) dstA[(size_t)(r - h) * dsA] = colA[r];
-          if (actB) dstB[(size_t)(r - h) * dsB] = colB[r];
-        }
+        for (int r = 0; r < NM; ++r)
+          if (r < nd) dstA[(size_t)r * dsA] = colA[r];
+      }
+      if (actB && redB) {
+#pragma unroll
+        for (int r = 0; r < NM; ++r)
+          if (r < nd) dstB[(size_t)r * dsB] = colB[r];
       }
     }
     if (lane == 0) {
@@ -264,17 +297,20 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
   const int lane = threadIdx.x;
   const int nd = n - h, ncols = h + 3 * nd + k, ntot = nd + k;
   const size_t top_stride = crd_top_doubles(n, k, h);
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  {  // one draw per workgroup (grid = batch): a grid-stride loop here makes the compiler hoist every address and
+     // comparison of the unrolled row loops out of it, into scalar registers it then has to spill
+    const int draw = blockIdx.x;
+    if (draw >= batch) return;
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
     const size_t offr = (size_t)draw * nd * nd, offrk = (size_t)draw * nd * k;
     if (flag[draw] != 0) {  // not deflated: the full-size kernels solve it next
       if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
-      continue;
+      return;
     }
     if (status[draw] != 0) {  // the reduced cycle reduction failed: zero policy matrices, as the full-size kernels write
       for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
       for (int idx = lane; idx < n * k; idx += 64) R_out[offk + idx] = 0.0;
-      continue;
+      return;
     }
     const double* tp = top + (size_t)draw * top_stride;
     const unsigned long long smask = (unsigned long long)(unsigned)tp[(size_t)h * ncols] |
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
     if (__ballot(bad) != 0ull) {  // a (numerically) singular R_st: leave the verdict to the full-size kernels
       if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
       wave_sync();
-      continue;
+      return;
     }
     double y[NMD];
     auto load_column = [&](int c) {

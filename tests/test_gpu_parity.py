@@ -1493,3 +1493,41 @@ def test_cr_static_deflation_on_reference_goldens(ref_goldens, key):
     for i in range(nb):
         r = oracle.solve_kalman_logp(Ab[i], Bb[i], Cb[i], Db[i], np.diag(q[i]), Z, y, H=np.diag(H), tol=1e-10, max_iter=1000)
         assert_allclose(outs[1]["logp"][i], r["logp"], rtol=LOGP_RTOL)
+
+
+@pytest.mark.parametrize("n,ns,nl", [(16, 6, 5), (24, 10, 7), (50, 22, 15), (56, 25, 16), (64, 28, 20)])
+def test_cr_static_deflation_other_sizes(n, ns, nl):
+    """Deflation across tile sizes: systems with more than 128 columns in [B_st | B_dy | A_dy | C_dy | D] (n >= 46) take the
+    second column chunk of the deflation kernel (reflectors read back from LDS); n = 64 has 16 static variables, the cap."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    k = p = 7
+    nb = 6
+    sysm = [wl.sw_shaped_system(5200 + 7 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    q = np.full((nb, k), 1e-4)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(n).normal(0, 0.02, (30, p))
+    H = np.full(p, 1e-4)
+    lib = _lib.load()
+    eng = LogpEngine(torch.device("cuda", 0))
+    dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
+    dq, dZ, dy, dH = eng.to_device(q), eng.to_device(Z), eng.to_device(y), eng.to_device(H)
+    hints = eng.structure_hints(dev["A"], dZ)
+    try:
+        _lib.check(lib.dsge_set_cr_deflation(0))
+        lp0, st0, T0, R0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+        _lib.check(lib.dsge_set_cr_deflation(1))
+        lp1, st1, T1, R1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+    finally:
+        _lib.check(lib.dsge_set_cr_deflation(1))
+    assert np.all(st0 == 0) and np.all(st1 == 0)
+    assert_allclose(T1, Tst, atol=1e-8)
+    assert_allclose(T1, T0, atol=1e-9)
+    assert_allclose(R1, R0, atol=1e-9)
+    assert_allclose(lp1, lp0, rtol=LOGP_RTOL)
+    r = oracle.solve_kalman_logp(A[0], B[0], C[0], D[0], np.diag(q[0]), Z, y, H=np.diag(H), tol=1e-9, max_iter=1000)
+    assert_allclose(lp1[0], r["logp"], rtol=LOGP_RTOL)
