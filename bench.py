@@ -38,13 +38,27 @@ def algorithmic_flops(n, k, p, T_len, cr_iters=7.0, lyap_doublings=12):
     return dict(kalman=kalman, lyapunov=lyap, selection=sel, solver=cr, total=kalman + lyap + sel + cr)
 
 
-def executed_flops(n, k, p, T_len, s, l, u, cr_iters, n_full, n_doublings, selector=True):
-    """FLOPs the three kernels actually execute per draw (structure exploited).
+def deflated_static(n, A0, C0):
+    """Static variables the cycle-reduction launcher deflates (launch_cr_deflated's rule): 0 = full-size iteration."""
+    h = min(int(np.count_nonzero(~((A0 != 0).any(axis=0) | (C0 != 0).any(axis=0)))), 16)
+    nd = n - h
+    if n < 8 or h < 1 or nd < 4 or ((nd + 7) // 8 == (n + 7) // 8 and 5 * h < n):
+        return 0
+    return h
+
+
+def executed_flops(n, k, p, T_len, s, l, u, cr_iters, n_full, n_doublings, selector=True, h=0):
+    """FLOPs the kernels actually execute per draw (structure exploited).
     s = state columns of A, l = lead columns of C, u = variables the filter keeps (states + observed),
-    n_full = time steps that ran the full covariance update (the rest ran the steady-state mean recursion)."""
+    n_full = time steps that ran the full covariance update (the rest ran the steady-state mean recursion),
+    h = static variables deflated in front of the cycle reduction (the iteration then runs on n - h variables)."""
     wr = s + l
-    cr = cr_iters * (n**3 + 2 * n * n * wr + 2 * n * wr * wr) + n**3 + 2 * n * n * s
-    cr += 2 * n * n * k  # the final elimination also carries D: R = -A1_hat^-1 D (fused selection)
+    nd = n - h
+    cr = cr_iters * (nd**3 + 2 * nd * nd * wr + 2 * nd * wr * wr) + nd**3 + 2 * nd * nd * s
+    cr += 2 * nd * nd * k  # the final elimination also carries D: R = -A1_hat^-1 D (fused selection)
+    if h:
+        cr += 4 * n * h * (h + 3 * nd + k)  # h reflectors over [B_st | B_dy | A_dy | C_dy | D]
+        cr += 2 * h * nd * (2 * nd + k) + h * h * (nd + k)  # static rows: G1, right-hand sides, back-substitution
     asm = 2 * n * n * k + n * n  # what is left for the assemble kernel: sym(R Q R')
     full = 2 * s * s * u + 2 * u * u * s + 2 * u * s + 2 * u * 64 + 16 * u * u + 2 * 512 + 4 * u
     steady = 2 * u * s + 2 * u * 8 + 2 * 64
@@ -279,9 +293,13 @@ def main():
         s_cols = hints[0] or n
         u_dim = min(n, s_cols + p) if not hints[1] else int(np.count_nonzero((shard["A"][0] != 0).any(axis=0)
                                                                              | (om["Z"] != 0).any(axis=0)))
+        h_defl = deflated_static(n, shard["A"][0], shard["C"][0]) if args.solver == "cycle_reduction" else 0
         ex = executed_flops(n, k, p, T_len, s_cols, stats.get("lead_columns", n), u_dim, cr_it,
-                            stats.get("full_steps_mean", T_len), 8, selector=bool(hints[1]))
-        names = {"solver": f"dsge::cr_compact_kernel<{(n + 7) // 8}>" if args.solver == "cycle_reduction" else ("dsge::gensys_reduce_kernel + gensys_qzwin_kernel + gensys_post_kernel (window path, three launches)"
+                            stats.get("full_steps_mean", T_len), 8, selector=bool(hints[1]), h=h_defl)
+        bs_n, bs_d = (n + 7) // 8, (n - h_defl + 7) // 8
+        names = {"solver": (f"dsge::cr_deflate_kernel<{bs_n}> + cr_compact_kernel<{bs_d}> + cr_inflate_kernel<{bs_d}> (static-variable "
+                            f"deflation {n} -> {n - h_defl}, three launches)" if h_defl else f"dsge::cr_compact_kernel<{bs_n}>")
+                 if args.solver == "cycle_reduction" else ("dsge::gensys_reduce_kernel + gensys_qzwin_kernel + gensys_post_kernel (window path, three launches)"
                                 if n > 16 else "dsge::gensys_kernel"),
                  "assemble": f"dsge::assemble_kernel<{(n + 7) // 8}>",
                  "kalman": f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>"}
@@ -344,7 +362,8 @@ def main():
                          "not a utilisation figure -- executed_frac is"),
                 "executed_tflops": kern[dom]["executed_tflops"],
                 "executed_frac": round(kern[dom]["executed_tflops"] / FP64_PEAK_TFLOPS, 5),
-                "structure": {"n_state": hints[0], "z_selector": hints[1], "filtered_variables": u_dim, **stats},
+                "structure": {"n_state": hints[0], "z_selector": hints[1], "filtered_variables": u_dim,
+                              "static_variables_deflated": h_defl, **stats},
                 "kernel_ms": {k_: round(v, 4) for k_, v in kms.items()},
                 "kernels": kern,
                 "whole_eval_contract_tflops": round(flops["total"] * nloc / total_kernel_s / 1e12, 4),

@@ -104,6 +104,9 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
         av[i] = ap[(size_t)ri * n];
         cv[i] = cp[(size_t)ri * n];
       }
+      // (without the barrier the scheduler, short of registers, pairs every load with its compare: 40 serial round
+      // trips to HBM, 54k cycles)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NM; ++i) nz |= ((av[i] != 0.0) | (cv[i] != 0.0)) ? 1 : 0;
     }
@@ -133,9 +136,9 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
     crd_index_tables(smask, n, lane, dyi, sti);
     double* tp = top + (size_t)draw * top_stride;
     // ---- Q' applied to [B_st | B_dy | A_dy | C_dy | D]: two columns per lane, in registers, all rows of a column loaded
-    // in flight.  The first h columns (lanes 0..h-1 of the first chunk) are B_st itself: reflector j is read off lane j
-    // with v_readlane (it is wave-uniform from there on), so the QR needs neither LDS nor wave reductions.  Only systems
-    // with more than 128 columns (n > 45 or so) take a second chunk, which reads the reflectors back from LDS.
+    // in flight.  The first h columns (lanes 0..h-1 of the first chunk) are B_st itself: lane j publishes pivot column j
+    // to LDS, from where every lane (and a second chunk, for systems with more than 128 columns, n > 45 or so) reads it
+    // as a broadcast; no wave reductions anywhere.
     const int ntotc = h + nv;
     const bool multi = ntotc > 128;
     for (int c0 = 0; c0 < ntotc; c0 += 128) {
@@ -176,53 +179,49 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
 #pragma unroll
       for (int r = 0; r < NM; ++r) {  // unconditional loads (inactive lanes walk a valid column, rows are clamped)
         const int rr = r < n ? r : n - 1;
-        const double tA = srcA[(size_t)rr * ssA], tB = srcB[(size_t)rr * ssB];
-        colA[r] = (r < n && actA) ? tA : 0.0;
-        colB[r] = (r < n && actB) ? tB : 0.0;
+        colA[r] = srcA[(size_t)rr * ssA];
+        colB[r] = srcB[(size_t)rr * ssB];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // all 2 * NM loads in flight before the first select waits for one
+#pragma unroll
+      for (int r = 0; r < NM; ++r) {
+        colA[r] = (r < n && actA) ? colA[r] : 0.0;
+        colB[r] = (r < n && actB) ? colB[r] : 0.0;
       }
       // Row j is final once reflector j has been applied: it goes straight to the top block and the columns are shifted
       // up by one row, so that the pivot is always register row 0 (no index-dependent selects, which cost a scalar lane
       // mask each) and what is left after h reflectors is the reduced system, rows 0..nd-1.
-      // The reflector is never materialised: with u = column j below the pivot (wave-uniform, read off lane j with
-      // v_readlane in the first chunk, from LDS in a later one), v = [1; scal u], so v'x = x_0 + scal u'x and the raw
-      // dots u'x ride along with the norm sweep; the second sweep updates and shifts.  Registers: the two columns only.
+      // The reflector is never materialised: with u = column j below the pivot (published to LDS by lane j of the first
+      // chunk and read back as broadcasts -- 2 x NM v_readlane per sweep cost more than the whole arithmetic),
+      // v = [1; scal u], so v'x = x_0 + scal u'x and the raw dots u'x ride along with the norm sweep; the second sweep
+      // updates and shifts.  Registers: the two columns only.
       for (int j = 0; j < h; ++j) {
         double xn2 = 0.0, alpha;
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        if (c0 == 0) {
-          if (multi && lane == j) {
+        if (c0 == 0) {  // publish the pivot column (lane j of the first chunk)
+          if (lane == j) {
+            double2* vw = reinterpret_cast<double2*>(V + j * NM);
 #pragma unroll
-            for (int r = 0; r < NM; ++r) V[j * NM + r] = colA[r];
+            for (int r2 = 0; r2 < NM / 2; ++r2) vw[r2] = make_double2(colA[2 * r2], colA[2 * r2 + 1]);
           }
-          alpha = readlane_dyn_f64(colA[0], j);
+          wave_sync();
+        }
+        const double2* vj2 = reinterpret_cast<const double2*>(V + j * NM);
+        {
+          const double2 t0 = vj2[0];
+          alpha = t0.x;
+          xn2 = t0.y * t0.y;
+          a0 = t0.y * colA[1];
+          b0 = t0.y * colB[1];
 #pragma unroll
-          for (int r = 1; r < NM; r += 2) {
-            const double u0 = readlane_dyn_f64(colA[r], j);
-            xn2 = fma(u0, u0, xn2);
-            a0 = fma(u0, colA[r], a0);
-            b0 = fma(u0, colB[r], b0);
-            if (r + 1 < NM) {
-              const double u1 = readlane_dyn_f64(colA[r + 1], j);
-              xn2 = fma(u1, u1, xn2);
-              a1 = fma(u1, colA[r + 1], a1);
-              b1 = fma(u1, colB[r + 1], b1);
-            }
-          }
-        } else {
-          const double* vj = V + j * NM;
-          alpha = vj[0];
-#pragma unroll
-          for (int r = 1; r < NM; r += 2) {
-            const double u0 = vj[r];
-            xn2 = fma(u0, u0, xn2);
-            a0 = fma(u0, colA[r], a0);
-            b0 = fma(u0, colB[r], b0);
-            if (r + 1 < NM) {
-              const double u1 = vj[r + 1];
-              xn2 = fma(u1, u1, xn2);
-              a1 = fma(u1, colA[r + 1], a1);
-              b1 = fma(u1, colB[r + 1], b1);
-            }
+          for (int r2 = 1; r2 < NM / 2; ++r2) {
+            const double2 t = vj2[r2];
+            xn2 = fma(t.x, t.x, xn2);
+            a1 = fma(t.x, colA[2 * r2], a1);
+            b1 = fma(t.x, colB[2 * r2], b1);
+            xn2 = fma(t.y, t.y, xn2);
+            a0 = fma(t.y, colA[2 * r2 + 1], a0);
+            b0 = fma(t.y, colB[2 * r2 + 1], b0);
           }
         }
         double beta = alpha, scal = 0.0, tj = 0.0;
@@ -240,20 +239,17 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
         if (actA) tp[(size_t)j * ncols + cA] = topA;
         if (actB) tp[(size_t)j * ncols + cB] = topB;
         const double wsA = wA * scal, wsB = wB * scal;
-        if (c0 == 0) {
+        {  // update and shift up by one row
+          const double2 t0 = vj2[0];
+          colA[0] = left ? 0.0 : fma(t0.y, wsA, colA[1]);
+          colB[0] = fma(t0.y, wsB, colB[1]);
 #pragma unroll
-          for (int r = 1; r < NM; ++r) {  // update and shift up by one row
-            const double u = readlane_dyn_f64(colA[r], j);
-            colA[r - 1] = left ? 0.0 : fma(u, wsA, colA[r]);
-            colB[r - 1] = fma(u, wsB, colB[r]);
-          }
-        } else {
-          const double* vj = V + j * NM;
-#pragma unroll
-          for (int r = 1; r < NM; ++r) {
-            const double u = vj[r];
-            colA[r - 1] = fma(u, wsA, colA[r]);
-            colB[r - 1] = fma(u, wsB, colB[r]);
+          for (int r2 = 1; r2 < NM / 2; ++r2) {
+            const double2 t = vj2[r2];
+            colA[2 * r2 - 1] = left ? 0.0 : fma(t.x, wsA, colA[2 * r2]);
+            colB[2 * r2 - 1] = fma(t.x, wsB, colB[2 * r2]);
+            colA[2 * r2] = left ? 0.0 : fma(t.y, wsA, colA[2 * r2 + 1]);
+            colB[2 * r2] = fma(t.y, wsB, colB[2 * r2 + 1]);
           }
         }
         colA[NM - 1] = 0.0;

@@ -20,7 +20,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print("no counter csv for", c); continue
     for row in csv.DictReader(open(f[0])):
         name = row["Kernel_Name"]
-        key = "solver" if ("cr_compact_kernel" in name or "gensys_kernel" in name) else "assemble" if "assemble_kernel" in name \
+        key = "solver_deflate" if "cr_deflate_kernel" in name else "solver_inflate" if "cr_inflate_kernel" in name \
+            else "solver_iterate" if ("cr_compact_kernel" in name or "gensys_kernel" in name) else "assemble" if "assemble_kernel" in name \
             else "kalman" if "kalman_sel_kernel<3" in name else None
         if key and row["Counter_Name"] == c:
             acc[key][c].append(float(row["Counter_Value"]))
@@ -31,6 +32,9 @@ for k, d in acc.items():
     fs = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
     ws = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
     res["kernels"][k] = {"FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1), "hbm_bytes_per_launch": round((2 * fs + ws) * 1024, 1)}
+parts = [v for k, v in res["kernels"].items() if k.startswith("solver_")]
+if parts:  # the solver leg of the fused call: deflation + iteration + inflation (one launch each)
+    res["kernels"]["solver"] = {f: round(sum(v[f] for v in parts), 1) for f in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch")}
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
