@@ -58,12 +58,25 @@ __device__ __forceinline__ void blk_zero(double (&x)[BS][BS]) {
 template <int BS>
 __device__ __forceinline__ void blk_load_global(double (&x)[BS][BS], const double* __restrict__ g, int n,
                                                 int ncols, int ldg, int lr, int lc) {
+  // Unconditional loads from clamped (always valid) addresses, a scheduling barrier, then the selects: a conditional
+  // load compiles to its own exec-masked block, and the scheduler, when short of registers, pairs each load with its
+  // use -- BS * BS serial round trips to HBM instead of BS * BS loads in flight (32 of them opened the compact
+  // cycle-reduction kernel).
 #pragma unroll
   for (int i = 0; i < BS; ++i)
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
       const int r = lr * BS + i, c = lc * BS + j;
-      x[i][j] = (r < n && c < ncols) ? g[(size_t)r * ldg + c] : 0.0;
+      const int rc = r < n ? r : n - 1, cc = c < ncols ? c : ncols - 1;
+      x[i][j] = g[(size_t)rc * ldg + cc];
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) {
+      const int r = lr * BS + i, c = lc * BS + j;
+      x[i][j] = (r < n && c < ncols) ? x[i][j] : 0.0;
     }
 }
 
