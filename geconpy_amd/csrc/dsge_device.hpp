@@ -121,9 +121,26 @@ __device__ __forceinline__ void blk_load_lds_t(double (&x)[BS][BS], const double
 // LDS matrix (NP x LD) <- global [n][ncols] (coalesced), zero padding
 __device__ __forceinline__ void lds_load_matrix(double* s, int ld, int np_rows, int np_cols,
                                                 const double* __restrict__ g, int n, int ncols, int lane) {
-  for (int idx = lane; idx < np_rows * np_cols; idx += 64) {
-    const int r = idx / np_cols, c = idx - r * np_cols;
-    s[r * ld + c] = (r < n && c < ncols) ? g[(size_t)r * ncols + c] : 0.0;
+  // eight loads in flight per trip (clamped, unconditional addresses; the selects wait behind a scheduling barrier):
+  // the plain loop -- conditional load, store to LDS -- is one round trip to memory per 64 elements
+  const int total = np_rows * np_cols;
+  for (int base = 0; base < total; base += 8 * 64) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 64 + lane;
+      const int ic = idx < total ? idx : total - 1;
+      const int r = ic / np_cols, c = ic - r * np_cols;
+      const int rc = r < n ? r : n - 1, cc = c < ncols ? c : ncols - 1;
+      v[u] = g[(size_t)rc * ncols + cc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 64 + lane;
+      const int r = idx / np_cols, c = idx - r * np_cols;
+      if (idx < total) s[r * ld + c] = (r < n && c < ncols) ? v[u] : 0.0;
+    }
   }
 }
 

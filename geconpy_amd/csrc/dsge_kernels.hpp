@@ -265,7 +265,9 @@ __global__ __launch_bounds__(64) void assemble_kernel(
       continue;
     }
     wave_sync();
-    lds_load_matrix(M1, LD, NP, NP, T + off, n, n, lane);
+    // T is an operand of the selection (B + C T) and of the doubling iteration; sym(R Q R') alone (the fused call, where
+    // R comes from the solver and P0 is left to the Kalman kernel) does not touch it
+    if (do_selection || do_lyapunov != 2) lds_load_matrix(M1, LD, NP, NP, T + off, n, n, lane);
     for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
     wave_sync();
 
