@@ -228,8 +228,18 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     // states first, then the observed non-states.  (One lane per original variable, m_full <= 64.)
     const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
     bool is_state = false;
-    if (lane < m_full)
-      for (int r = 0; r < m_full; ++r) is_state = is_state || (T[off + (size_t)r * m_full + lane] != 0.0);
+    {  // eight unconditional loads in flight per trip (a short-circuit || here is one round trip per row)
+      const double* tcol = T + off + (lane < m_full ? lane : 0);
+      for (int r0 = 0; r0 < m_full; r0 += 8) {
+        double tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tv[u] = tcol[(size_t)(r0 + u < m_full ? r0 + u : m_full - 1) * m_full];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) is_state |= (tv[u] != 0.0);
+      }
+      is_state = is_state && (lane < m_full);
+    }
     const unsigned long long colmask = __ballot(is_state);
     unsigned long long obsmask = 0ull, used = 0ull;
     bool ok = true;
