@@ -49,6 +49,7 @@ int g_cr_deflate = 1;  // 0 = always the full-size system
 namespace {
 std::mutex g_defl_mutex;
 int g_static_hint[DSGE_MAX_N + 2];  // per model size n: lower bound of the number of static variables; 0 = not measured yet
+unsigned g_static_calls[DSGE_MAX_N + 2];
 bool g_static_hint_init = false;    // (stored as h + 1)
 struct DeflArena {
   void* ptr = nullptr;
@@ -107,11 +108,16 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
   std::lock_guard<std::mutex> lk(g_defl_mutex);
   if (!g_static_hint_init) {
     for (auto& x : g_static_hint) x = 0;
+    for (auto& x : g_static_calls) x = 0;
     g_static_hint_init = true;
   }
   int rc;
   void* base = nullptr;
-  if (g_static_hint[n] == 0) {  // first batch of this model size: measure (one small launch and a 4-byte read-back)
+  // first batch of this model size: measure (one small launch and a 4-byte read-back); every 256th call after that
+  // measures again and keeps the minimum, so that an unrepresentative first batch (more static variables than the later
+  // ones have: every later draw would be flagged and solved at full size) corrects itself
+  const bool remeasure = g_static_hint[n] != 0 && (++g_static_calls[n] & 255) == 0;
+  if (g_static_hint[n] == 0 || remeasure) {
     if ((rc = defl_reserve(256, st, &base))) return rc;
     int32_t hmin = n;
     HIP_TRY(hipMemcpyAsync(base, &hmin, sizeof(hmin), hipMemcpyHostToDevice, st));
@@ -120,7 +126,7 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&hmin, base, sizeof(hmin), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    g_static_hint[n] = hmin + 1;
+    g_static_hint[n] = (remeasure && g_static_hint[n] - 1 < hmin) ? g_static_hint[n] : hmin + 1;
   }
   const int h = std::min(g_static_hint[n] - 1, (int)dsge::CRD_HMAX);
   const int nd = n - h;

@@ -1531,3 +1531,42 @@ def test_cr_static_deflation_other_sizes(n, ns, nl):
     assert_allclose(lp1, lp0, rtol=LOGP_RTOL)
     r = oracle.solve_kalman_logp(A[0], B[0], C[0], D[0], np.diag(q[0]), Z, y, H=np.diag(H), tol=1e-9, max_iter=1000)
     assert_allclose(lp1[0], r["logp"], rtol=LOGP_RTOL)
+
+
+def test_cr_static_deflation_bound_corrects_itself():
+    """The bound h is measured on the first batch of a model size.  If later batches have FEWER static variables every draw
+    is flagged and solved at full size (bit-identical to the run without deflation); the launcher measures again every 256th
+    call and keeps the minimum, after which the later batches are deflated again (same T to 1e-10, no longer bit-identical)."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    lib = _lib.load()
+    nb = 64
+    b = wl.sw_shaped_batch(nb, first_draw=12000)
+    om = wl.sw_shaped_observation_model()
+    static = np.where(~(b["A"][0] != 0).any(0) & ~(b["C"][0] != 0).any(0))[0]
+    A2 = b["A"].copy()
+    A2[:, 4, static[0]] = 1e-3  # nine static variables in every draw
+    eng = LogpEngine(torch.device("cuda", 0))
+    clean = {x: eng.to_device(b[x]) for x in "ABCD"}
+    fewer = dict(clean, A=eng.to_device(A2))
+    dq = eng.to_device(b["sigma"] ** 2)
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:6]), eng.to_device(om["Hdiag"])
+    hints = eng.structure_hints(fewer["A"], dZ)
+    try:
+        _lib.check(lib.dsge_set_cr_deflation(0))
+        lp0, st0, T0, R0 = _fused_policy(eng, fewer, dq, dZ, dy, dH, hints)
+        _lib.check(lib.dsge_set_cr_deflation(1))
+        _fused_policy(eng, clean, dq, dZ, dy, dH, hints)  # h = 10
+        lp1, st1, T1, R1 = _fused_policy(eng, fewer, dq, dZ, dy, dH, hints)
+        assert np.all(st0 == 0) and np.array_equal(T1, T0) and np.array_equal(lp1, lp0)  # all flagged: full-size kernels
+        for _ in range(256):
+            eng.solve_kalman_logp(fewer["A"], fewer["B"], fewer["C"], fewer["D"], dq, dZ, dy, Hdiag=dH, tol=1e-9, max_iter=1000,
+                                  n_state_hint=hints[0], z_selector_hint=hints[1])
+        lp2, st2, T2, R2 = _fused_policy(eng, fewer, dq, dZ, dy, dH, hints)
+    finally:
+        _lib.check(lib.dsge_set_cr_deflation(1))
+    assert np.all(st2 == 0) and not np.array_equal(T2, T0)  # h = 9 now: deflated again
+    assert_allclose(T2, T0, atol=1e-10)
+    assert_allclose(lp2, lp0, rtol=LOGP_RTOL)
