@@ -1,4 +1,5 @@
-import sys, time; sys.path.insert(0, '.')
+"""GPU box: fused device evaluation (4096 SW-shaped draws) with the static-variable deflation off / on (argv: 0 1 ...)."""
+import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 from geconpy_amd import _lib, workloads as wl
 from geconpy_amd.engine import LogpEngine

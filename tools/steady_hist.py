@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0, '.')
+"""GPU box: distribution of the number of full covariance steps (first steady-state step) over the 4096 SW-shaped bench draws."""
+import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch
 from geconpy_amd import _lib, workloads as wl
 from geconpy_amd.engine import LogpEngine
