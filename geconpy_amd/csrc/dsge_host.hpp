@@ -29,6 +29,10 @@ inline int tile_bs(int n) {
   return bs < 1 ? 1 : bs;
 }
 
+// Grid of a second pass that only takes the draws an earlier kernel flagged (normally none): the workgroups loop over the
+// draws, so a quarter of the batch-sized grid costs a few microseconds less per empty pass and still fills the chip.
+inline int rerun_grid(int batch) { return batch < 1024 ? batch : 1024; }
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

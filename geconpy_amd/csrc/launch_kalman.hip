@@ -162,7 +162,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (g_kalman_mfma) {  // prediction products on the FP64 matrix core
               rc = set_lds(dsge::kalman_sel_kernel<BS, true, true>, lds);
               if (rc == DSGE_SUCCESS) {
-                hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+                hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                    p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p,
                                    T_len, s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                    g_kalman_steady_at, nullptr, nullptr, nullptr, order);
@@ -175,7 +175,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
           if (!done && tail_rec) {
             rc = set_lds(dsge::kalman_sel_kernel<BS, true, false, true>, lds);
             if (rc == DSGE_SUCCESS) {
-              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, false, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, false, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                  s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
@@ -187,7 +187,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
           if (!done) {
             rc = set_lds(dsge::kalman_sel_kernel<BS, true>, lds);
             if (rc == DSGE_SUCCESS) {
-              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR,
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                  s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, nullptr, nullptr, nullptr, order);
@@ -202,7 +202,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
           } else {
             rc = set_lds(dsge::kalman_sel_kernel<BS, false>, lds);
             if (rc == DSGE_SUCCESS) {
-              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR,
+              hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
                                  jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, nullptr, nullptr, nullptr, order);
@@ -231,7 +231,8 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     const size_t lds = dsge::KfSmem<BS>::bytes(p);
     rc = set_lds(dsge::kalman_kernel<BS>, lds);
     if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, P0, Z, z_batched, d,
+      hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(launched_fast ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR, P0, Z,
+                         z_batched, d,
                          d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status,
                          launched_fast ? 1 : 0);
       HIP_TRY(hipGetLastError());

@@ -35,8 +35,8 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
   DISPATCH_BS(bs, 8, {
     rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
-                         max_iter, tol, T_out, status, n_iter, compact ? 1 : 0, scan_mode, D, k, R_out);
+      hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(compact ? rerun_grid(batch) : batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A,
+                         B, C, batch, n, max_iter, tol, T_out, status, n_iter, compact ? 1 : 0, scan_mode, D, k, R_out);
       HIP_TRY(hipGetLastError());
     }
   });
@@ -171,8 +171,8 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
     DISPATCH_BS(bs, 8, {
       rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
       if (rc == DSGE_SUCCESS) {
-        hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(batch), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
-                           max_iter, tol, T_out, status, n_iter, 1, 0, D, k, R_out);
+        hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(rerun_grid(batch)), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch,
+                           n, max_iter, tol, T_out, status, n_iter, 1, 0, D, k, R_out);
         HIP_TRY(hipGetLastError());
       }
     });
