@@ -312,13 +312,50 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
     const unsigned long long smask = (unsigned long long)(unsigned)tp[(size_t)h * ncols] |
                                      ((unsigned long long)(unsigned)tp[(size_t)h * ncols + 1] << 32);
     crd_index_tables(smask, n, lane, dyi, sti);
+    // Every global load of the prologue is issued before the first one is waited for (unconditional loads from clamped
+    // addresses, selects behind a scheduling barrier): the kernel is 1.7 k vector instructions per draw and spent 69 % of
+    // its 63 k cycles waiting on one load at a time.
+    double y[NMD], g[HM], ctv[HM], rsv[(HM * HM + 63) / 64];
+    const int ln = lane < nd ? lane : nd - 1;  // column of T_dy / Btop / Ctop this lane looks at (clamped)
+    auto column_source = [&](int c, const double*& src, int& ss) -> bool {
+      const bool act = c < ntot;
+      src = (act && c >= nd) ? (Rdy + offrk + (c - nd)) : (Tdy + offr + (c < nd ? c : 0));
+      ss = (act && c >= nd) ? k : nd;
+      return act;
+    };
+    {
+      const double* src;
+      int ss;
+      column_source(lane, src, ss);
 #pragma unroll
-    for (int i = 0; i < HM; ++i) {
-      if (lane < NMD) Ct[i * NMD + lane] = (i < h && lane < nd) ? tp[(size_t)i * ncols + h + 2 * nd + lane] : 0.0;
+      for (int q = 0; q < NMD; ++q) y[q] = src[(size_t)(q < nd ? q : nd - 1) * ss];
+#pragma unroll
+      for (int i = 0; i < HM; ++i) {
+        const size_t row = (size_t)(i < h ? i : h - 1) * ncols;
+        g[i] = tp[row + h + ln];
+        ctv[i] = tp[row + h + 2 * nd + ln];
+      }
+#pragma unroll
+      for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
+        const int idx = u * 64 + lane, i = idx / HM, q = idx % HM;
+        rsv[u] = tp[(size_t)(i < h ? i : h - 1) * ncols + (q < h ? q : h - 1)];
+      }
     }
-    for (int idx = lane; idx < HM * HM; idx += 64) {
-      const int i = idx / HM, q = idx % HM;
-      Rs[idx] = (i < h && q < h) ? tp[(size_t)i * ncols + q] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const bool act = lane < ntot;
+#pragma unroll
+      for (int q = 0; q < NMD; ++q) y[q] = (q < nd && act) ? y[q] : 0.0;
+#pragma unroll
+      for (int i = 0; i < HM; ++i) {
+        g[i] = (i < h && lane < nd) ? g[i] : 0.0;
+        if (lane < NMD) Ct[i * NMD + lane] = (i < h && lane < nd) ? ctv[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
+        const int idx = u * 64 + lane, i = idx / HM, q = idx % HM;
+        if (idx < HM * HM) Rs[idx] = (i < h && q < h) ? rsv[u] : 0.0;
+      }
     }
     wave_sync();
     bool bad = false;
@@ -329,23 +366,9 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
     }
     if (__ballot(bad) != 0ull) {  // a (numerically) singular R_st: leave the verdict to the full-size kernels
       if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
-      wave_sync();
       return;
     }
-    double y[NMD];
-    auto load_column = [&](int c) {
-      const double* src = (c < nd) ? (Tdy + offr + c) : (Rdy + offrk + (c - nd));
-      const int ss = (c < nd) ? nd : k;
-      const bool act = c < ntot;
-      if (!act) src = Tdy + offr;
-#pragma unroll
-      for (int q = 0; q < NMD; ++q) y[q] = (q < nd && act) ? src[(size_t)q * ss] : 0.0;
-    };
-    load_column(lane);
     {  // G1 = Btop + Ctop T_dy, column `lane`
-      double g[HM];
-#pragma unroll
-      for (int i = 0; i < HM; ++i) g[i] = (i < h && lane < nd) ? tp[(size_t)i * ncols + h + lane] : 0.0;
 #pragma unroll
       for (int i = 0; i < HM; ++i) {
         if (i < h) {
@@ -373,13 +396,27 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
     }
     for (int c0 = 0; c0 < ntot; c0 += 64) {
       const int c = c0 + lane;
-      if (c0 > 0) load_column(c);
       const bool act = c < ntot;
       double x[HM];
       {  // right-hand sides [G1 T_dy + Atop | G1 R_dy + Dtop], column c
-        const int tc = h + nd + c + ((c >= nd) ? nd : 0);
+        const int cc = act ? c : 0;
+        const int tc = h + nd + cc + ((cc >= nd) ? nd : 0);
+        if (c0 > 0) {
+          const double* src;
+          int ss;
+          column_source(c, src, ss);
 #pragma unroll
-        for (int i = 0; i < HM; ++i) x[i] = (i < h && act) ? tp[(size_t)i * ncols + tc] : 0.0;
+          for (int q = 0; q < NMD; ++q) y[q] = src[(size_t)(q < nd ? q : nd - 1) * ss];
+        }
+#pragma unroll
+        for (int i = 0; i < HM; ++i) x[i] = tp[(size_t)(i < h ? i : h - 1) * ncols + tc];
+        __builtin_amdgcn_sched_barrier(0);
+        if (c0 > 0) {
+#pragma unroll
+          for (int q = 0; q < NMD; ++q) y[q] = (q < nd && act) ? y[q] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < HM; ++i) x[i] = (i < h && act) ? x[i] : 0.0;
 #pragma unroll
         for (int i = 0; i < HM; ++i) {
           if (i < h) {
