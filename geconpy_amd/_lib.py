@@ -65,6 +65,7 @@ PROTOTYPES = {
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_set_kalman_tiny": [_i],
     "dsge_set_cr_deflation": [_i],
+    "dsge_set_cr_two_waves": [_i],
     "dsge_set_kalman_order": [_i],
     "dsge_set_pipeline_chunks": [_i],
     "dsge_set_kalman_block": [_i],

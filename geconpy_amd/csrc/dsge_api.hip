@@ -212,6 +212,10 @@ int dsge_set_pipeline_chunks(int n_chunks) {
   g_pipeline_chunks = n_chunks;
   return DSGE_SUCCESS;
 }
+int dsge_set_cr_two_waves(int enable) {
+  g_cr_occ2 = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
 int dsge_set_cr_deflation(int enable) {
   g_cr_deflate = enable ? 1 : 0;
   cr_deflation_reset();

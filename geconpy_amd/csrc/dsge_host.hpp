@@ -99,6 +99,7 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
                      hipStream_t st);
 
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
+extern int g_cr_occ2;                 // launch_solvers.hip: 4 x 4-tile compact kernel at two waves per SIMD
 extern int g_cr_deflate;              // launch_solvers.hip: 0 = no static-variable deflation
 extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-reduction kernel only
 // process-wide settings of the fast Kalman kernel (launch_kalman.hip)

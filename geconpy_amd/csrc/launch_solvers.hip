@@ -12,6 +12,8 @@ namespace dsge_host {
 int g_cr_compact = 1;  // 0 = dense kernel only (tests compare the two paths)
 long long* g_cr_dbg = nullptr;  // debug: device int64[8], phase cycles of draw 0 of the compact kernel
 
+int g_cr_occ2 = 1;  // 4 x 4-tile compact kernel built for two waves per SIMD (dsge_set_cr_two_waves)
+
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode, const double* D, int k,
               double* R_out) {
@@ -22,11 +24,20 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
   const bool compact = g_cr_compact != 0;
   if (compact) {
     DISPATCH_BS(bs, 8, {
-      rc = set_lds(dsge::cr_compact_kernel<BS>, dsge::CrcSmem<BS>::bytes);
-      if (rc == DSGE_SUCCESS) {
-        hipLaunchKernelGGL(dsge::cr_compact_kernel<BS>, dim3(batch), dim3(64), dsge::CrcSmem<BS>::bytes, st, A, B, C,
-                           batch, n, max_iter, tol, T_out, status, n_iter, g_cr_dbg, scan_mode, D, k, R_out);
-        HIP_TRY(hipGetLastError());
+      if (BS == 4 && g_cr_occ2) {
+        rc = set_lds(dsge::cr_compact_kernel_occ2<4>, dsge::CrcSmem<4>::bytes);
+        if (rc == DSGE_SUCCESS) {
+          hipLaunchKernelGGL(dsge::cr_compact_kernel_occ2<4>, dim3(batch), dim3(64), dsge::CrcSmem<4>::bytes, st, A, B, C,
+                             batch, n, max_iter, tol, T_out, status, n_iter, g_cr_dbg, scan_mode, D, k, R_out);
+          HIP_TRY(hipGetLastError());
+        }
+      } else {
+        rc = set_lds(dsge::cr_compact_kernel<BS>, dsge::CrcSmem<BS>::bytes);
+        if (rc == DSGE_SUCCESS) {
+          hipLaunchKernelGGL(dsge::cr_compact_kernel<BS>, dim3(batch), dim3(64), dsge::CrcSmem<BS>::bytes, st, A, B, C,
+                             batch, n, max_iter, tol, T_out, status, n_iter, g_cr_dbg, scan_mode, D, k, R_out);
+          HIP_TRY(hipGetLastError());
+        }
       }
     });
     if (rc) return rc;

@@ -1570,3 +1570,33 @@ def test_cr_static_deflation_bound_corrects_itself():
     assert np.all(st2 == 0) and not np.array_equal(T2, T0)  # h = 9 now: deflated again
     assert_allclose(T2, T0, atol=1e-10)
     assert_allclose(lp2, lp0, rtol=LOGP_RTOL)
+
+
+def test_cr_two_wave_instance_is_bit_identical():
+    """The 32-wide compact cycle-reduction kernel built for two waves per SIMD (default) runs the same arithmetic as the
+    one-wave instance: T, R, logp bit for bit, on the deflated SW-shaped system (30 variables) and on a 32-variable one."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    lib = _lib.load()
+    eng = LogpEngine(torch.device("cuda", 0))
+    om = wl.sw_shaped_observation_model()
+    b = wl.sw_shaped_batch(300, first_draw=15000)
+    sysm = [wl.sw_shaped_system(6100 + i, n=32, n_state=14, n_lead=9, k=7) for i in range(40)]
+    b32 = {x: np.stack([s_[j] for s_ in sysm]) for j, x in enumerate("ABCD")}
+    for batch, Z, nb in ((b, om["Z"], 300), (b32, np.eye(7, 32), 40)):
+        dev = {x: eng.to_device(batch[x]) for x in "ABCD"}
+        dq = eng.to_device(np.full((nb, 7), 1e-4))
+        dZ, dy, dH = eng.to_device(Z), eng.to_device(om["y"][:30]), eng.to_device(om["Hdiag"])
+        hints = eng.structure_hints(dev["A"], dZ)
+        try:
+            _lib.check(lib.dsge_set_cr_two_waves(0))
+            r0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+            _lib.check(lib.dsge_set_cr_two_waves(1))
+            r1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+        finally:
+            _lib.check(lib.dsge_set_cr_two_waves(1))
+        assert np.all(r0[1] == 0)
+        for a0, a1 in zip(r0, r1):
+            assert np.array_equal(a0, a1)
