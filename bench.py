@@ -343,6 +343,8 @@ def main():
                 "inputs": "theta (generated Jacobian kernel inside the step)" if args.from_theta else "A,B,C,D resident in HBM",
                 "tol": args.tol,
                 "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
+                "cr_static_deflation": (f"{h_defl} static variables (zero columns of A and C) eliminated by a QR of their columns of B before the "
+                                        f"iteration, which runs on {n - h_defl} variables; verified per draw on the device") if h_defl else "none",
                 "kalman_dispatch": ("workgroups in descending order of the draws' cycle-reduction iteration counts" if args.solver == "cycle_reduction"
                                     else "workgroups in descending order of a persistence key of T (power iteration)") + " (slow draws first; outputs stay in draw order)",
                 "parallelism": f"draw-sharded x{world}, one all_gather of packed (logp,status) records" if world > 1 else "single GPU",
