@@ -183,16 +183,24 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
 #define COLPOS(c) ((((c) < n) && ((zmask >> (c)) & 1ull)) ? __popcll(zmask & ((1ull << (c)) - 1ull)) \
                                                          : (z + (c) - __popcll(zmask & (((c) >= 64) ? ~0ull : ((1ull << (c)) - 1ull)))))
     // pencil (gensys.py:591-614) by index arithmetic; T holds columns >= z only (the others are exactly zero)
-    for (int idx = lane; idx < n * n; idx += 64) {
-      const int i = idx / n, j = idx - i * n;
-      const int pj = COLPOS(j);
-      Hr[i * ldH + pj] = -Bg[idx];
-      if (pj >= z) Tr[i * ldW + pj - z] = Ag[idx];
-    }
-    for (int idx = lane; idx < n * ell; idx += 64) {
-      const int i = idx / ell, a = idx - i * ell;
-      Hr[i * ldH + n + a] = -Cg[(size_t)i * n + lead[a]];
-    }
+    lane_loop_batched<4>(
+        n * n, lane, [&](int idx) { return double2{Bg[idx], Ag[idx]}; },
+        [&](int idx, double2 v) {
+          const int i = idx / n, j = idx - i * n;
+          const int pj = COLPOS(j);
+          Hr[i * ldH + pj] = -v.x;
+          if (pj >= z) Tr[i * ldW + pj - z] = v.y;
+        });
+    lane_loop_batched<8>(
+        n * ell, lane,
+        [&](int idx) {
+          const int i = idx / ell, a = idx - i * ell;
+          return Cg[(size_t)i * n + lead[a]];
+        },
+        [&](int idx, double v) {
+          const int i = idx / ell, a = idx - i * ell;
+          Hr[i * ldH + n + a] = -v;
+        });
     if (lane < ell) {
       const int lc0 = lead[lane];
       Hr[(n + lane) * ldH + COLPOS(lc0)] = 1.0;
@@ -257,17 +265,29 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
     const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
     wave_sync();
     GW_STAMP(5);
-    for (int idx = lane; idx < w * w; idx += 64) {
-      const int i = idx / w, j = idx - i * w;
-      const size_t o = (size_t)i * cp.wcap + j;
-      hb[i * ldH + j] = wd[wo.HR + o];
-      tb[i * ldW + j] = wd[wo.TR + o];
-      Zr[i * ldW + j] = (i == j) ? 1.0 : 0.0;
-    }
-    for (int idx = lane; idx < w * ell; idx += 64) {
-      const int i = idx / ell, j = idx - i * ell;
-      xb[i * ldX + j] = wd[wo.XR + (size_t)i * cp.lcap + j];
-    }
+    lane_loop_batched<4>(
+        w * w, lane,
+        [&](int idx) {
+          const int i = idx / w, j = idx - i * w;
+          const size_t o = (size_t)i * cp.wcap + j;
+          return double2{wd[wo.HR + o], wd[wo.TR + o]};
+        },
+        [&](int idx, double2 v) {
+          const int i = idx / w, j = idx - i * w;
+          hb[i * ldH + j] = v.x;
+          tb[i * ldW + j] = v.y;
+          Zr[i * ldW + j] = (i == j) ? 1.0 : 0.0;
+        });
+    lane_loop_batched<8>(
+        w * ell, lane,
+        [&](int idx) {
+          const int i = idx / ell, j = idx - i * ell;
+          return wd[wo.XR + (size_t)i * cp.lcap + j];
+        },
+        [&](int idx, double v) {
+          const int i = idx / ell, j = idx - i * ell;
+          xb[i * ldX + j] = v;
+        });
     wave_sync();
     // ---- T22 -> upper triangular (reflectors)
     for (int j = 0; j < w - 1; ++j) hh_left_real(hb, ldH, 0, w, tb, ldW, w, xb, ldX, ell, tb, ldW, j, j, w, lane);
@@ -409,16 +429,28 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
     wave_sync();
     for (int idx = lane; idx < w * L.ldh; idx += 64) L.H[idx] = mk(0.0, 0.0);
     wave_sync();
-    for (int idx = lane; idx < w * w; idx += 64) {
-      const int i = idx / w, j = idx - i * w;
-      const size_t o = (size_t)i * cp.wcap + j;
-      hput(L, i, j, mk(wd[wo.HR + o], 0.0));  // out-of-band entries are exact zeros after the real reduction
-      tput(L, i, j, mk(wd[wo.TR + o], 0.0));
-    }
-    for (int idx = lane; idx < w * ell; idx += 64) {
-      const int i = idx / ell, j = idx - i * ell;
-      L.X[i * L.ldx + j] = mk(wd[wo.XR + (size_t)i * cp.lcap + j], 0.0);
-    }
+    lane_loop_batched<4>(
+        w * w, lane,
+        [&](int idx) {
+          const int i = idx / w, j = idx - i * w;
+          const size_t o = (size_t)i * cp.wcap + j;
+          return double2{wd[wo.HR + o], wd[wo.TR + o]};
+        },
+        [&](int idx, double2 v) {
+          const int i = idx / w, j = idx - i * w;
+          hput(L, i, j, mk(v.x, 0.0));  // out-of-band entries are exact zeros after the real reduction
+          tput(L, i, j, mk(v.y, 0.0));
+        });
+    lane_loop_batched<8>(
+        w * ell, lane,
+        [&](int idx) {
+          const int i = idx / ell, j = idx - i * ell;
+          return wd[wo.XR + (size_t)i * cp.lcap + j];
+        },
+        [&](int idx, double v) {
+          const int i = idx / ell, j = idx - i * ell;
+          L.X[i * L.ldx + j] = mk(v, 0.0);
+        });
     wave_sync();
     GW_STAMP(8);
     const bool converged = qz_iterate(L, 0, lane, (dbg && draw == 0) ? dbg + 12 : nullptr);
@@ -729,30 +761,63 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       const double* H12 = wd + wo.H12;
       const double* T12 = wd + wo.T12;
       const double* X1 = wd + wo.X1;
-      for (int idx = lane; idx < w * w; idx += 64) {
-        const int i = idx / w, j = idx - i * w;
-        const size_t o = (size_t)i * cp.wcap + j;
-        PH(i, j) = HC[o];
-        PT(i, j) = TC[o];
-        PM(i, j) = MC[(size_t)j * cp.wcap + i];  // stored transposed
-      }
-      for (int idx = lane; idx < ell * nu; idx += 64) {
-        const int cc = idx / nu, u = idx - cc * nu;
-        Bm[cc * ldh + u] = BMg[(size_t)cc * cp.wcap + u];
-      }
+      struct cx3 {
+        cx h, t, m;
+      };
+      lane_loop_batched<4>(
+          w * w, lane,
+          [&](int idx) {
+            const int i = idx / w, j = idx - i * w;
+            const size_t o = (size_t)i * cp.wcap + j;
+            return cx3{HC[o], TC[o], MC[(size_t)j * cp.wcap + i]};  // M is stored transposed
+          },
+          [&](int idx, cx3 v) {
+            const int i = idx / w, j = idx - i * w;
+            PH(i, j) = v.h;
+            PT(i, j) = v.t;
+            PM(i, j) = v.m;
+          });
+      lane_loop_batched<4>(
+          ell * nu, lane,
+          [&](int idx) {
+            const int cc = idx / nu, u = idx - cc * nu;
+            return BMg[(size_t)cc * cp.wcap + u];
+          },
+          [&](int idx, auto v) {
+            const int cc = idx / nu, u = idx - cc * nu;
+            Bm[cc * ldh + u] = v;
+          });
       // the real tail's operands: R0 and [H12 | X1] (read once, coalesced; the products below broadcast them from LDS)
-      for (int idx = lane; idx < z * z; idx += 64) {
-        const int i = idx / z, j = idx - i * z;
-        R0s[i * ldr + j] = R0[(size_t)i * cp.zcap + j];
-      }
-      for (int idx = lane; idx < z * w; idx += 64) {
-        const int i = idx / w, j = idx - i * w;
-        HXs[i * ldq + j] = H12[(size_t)i * cp.wcap + j];
-      }
-      for (int idx = lane; idx < z * ell; idx += 64) {
-        const int i = idx / ell, j = idx - i * ell;
-        HXs[i * ldq + w + j] = X1[(size_t)i * cp.lcap + j];
-      }
+      lane_loop_batched<8>(
+          z * z, lane,
+          [&](int idx) {
+            const int i = idx / z, j = idx - i * z;
+            return R0[(size_t)i * cp.zcap + j];
+          },
+          [&](int idx, double v) {
+            const int i = idx / z, j = idx - i * z;
+            R0s[i * ldr + j] = v;
+          });
+      lane_loop_batched<8>(
+          z * w, lane,
+          [&](int idx) {
+            const int i = idx / w, j = idx - i * w;
+            return H12[(size_t)i * cp.wcap + j];
+          },
+          [&](int idx, double v) {
+            const int i = idx / w, j = idx - i * w;
+            HXs[i * ldq + j] = v;
+          });
+      lane_loop_batched<8>(
+          z * ell, lane,
+          [&](int idx) {
+            const int i = idx / ell, j = idx - i * ell;
+            return X1[(size_t)i * cp.lcap + j];
+          },
+          [&](int idx, double v) {
+            const int i = idx / ell, j = idx - i * ell;
+            HXs[i * ldq + w + j] = v;
+          });
       wave_sync();
       // Phi_b (ns2 x nu) into the free lower-left block of H: Phi_b[i][u] at H[ns2 + u][i]
       for (int idx = lane; idx < ns2 * nu; idx += 64) {
