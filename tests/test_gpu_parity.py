@@ -1429,6 +1429,9 @@ def test_cr_static_deflation_matches_full_system():
     A[5, 0, 0] = np.nan
     A[9, 3, static[2]] = 1e-3   # static variable turned (weakly) predetermined
     A[300, 7, static[-1]] = -2e-3
+    states = np.where((A[0] != 0).any(0) & ~(C[0] != 0).any(0))[0]
+    A[11, :, states[0]] = 0.0   # one more static variable than the bound (a state that stops feeding back)
+    A[12, :, states[-1]] = 0.0
     eng = LogpEngine(torch.device("cuda", 0))
     dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
     dq = eng.to_device(b["sigma"] ** 2)
@@ -1446,8 +1449,9 @@ def test_cr_static_deflation_matches_full_system():
         lp2, st2, T2, R2 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
     finally:
         _lib.check(lib.dsge_set_cr_deflation(1))
-    assert np.array_equal(st0, st1) and st0[5] != 0 and np.count_nonzero(st0) == 1
+    assert np.array_equal(st0, st1) and st0[5] != 0 and np.count_nonzero(st0[[0, 9, 300, 699]]) == 0
     ok = st0 == 0
+    assert ok.sum() >= nb - 3
     assert_allclose(T1[ok], T0[ok], atol=1e-10)
     assert_allclose(R1[ok], R0[ok], atol=1e-10)
     assert_allclose(lp1[ok], lp0[ok], rtol=LOGP_RTOL)
