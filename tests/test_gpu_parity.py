@@ -1604,3 +1604,53 @@ def test_cr_two_wave_instance_is_bit_identical():
         assert np.all(r0[1] == 0)
         for a0, a1 in zip(r0, r1):
             assert np.array_equal(a0, a1)
+
+
+def test_cr_static_deflation_fuzz():
+    """Deflation on / off over random sizes, shock counts and variable orders (the static columns scattered by a random
+    permutation of the variables, so the index tables, the two-column chunks and the scatter of the inflate kernel see
+    arbitrary masks): T, R to 1e-9, logp to the parity tolerance, status identical."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    lib = _lib.load()
+    eng = LogpEngine(torch.device("cuda", 0))
+    rng = np.random.default_rng(2024)
+    tried = 0
+    for trial in range(28):
+        n = int(rng.integers(9, 49))
+        ns = max(2, int(0.4 * n) + int(rng.integers(-1, 2)))
+        nl = max(1, int(0.25 * n) + int(rng.integers(-1, 2)))
+        k = int(rng.choice([1, 2, 3, 7, min(n // 3, 10)]))
+        p = min(k, 4)
+        nb = 5
+        try:
+            sysm = [wl.sw_shaped_system(9000 + 31 * trial + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+        except Exception:
+            continue
+        perm = rng.permutation(n)
+        A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+        A, B, C = (np.ascontiguousarray(M[:, :, perm]) for M in (A, B, C))
+        n_static = int(np.count_nonzero(~((A[0] != 0).any(0) | (C[0] != 0).any(0))))
+        Z = np.zeros((p, n))
+        Z[np.arange(p), rng.choice(n, p, replace=False)] = 1.0
+        y = rng.normal(0, 0.02, (12, p))
+        dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
+        dq, dZ, dy, dH = eng.to_device(np.full((nb, k), 1e-4)), eng.to_device(Z), eng.to_device(y), eng.to_device(np.full(p, 1e-4))
+        hints = eng.structure_hints(dev["A"], dZ)
+        try:
+            _lib.check(lib.dsge_set_cr_deflation(0))
+            lp0, st0, T0, R0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+            _lib.check(lib.dsge_set_cr_deflation(1))
+            lp1, st1, T1, R1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+        finally:
+            _lib.check(lib.dsge_set_cr_deflation(1))
+        assert np.array_equal(st0, st1), (n, k, n_static)
+        ok = st0 == 0
+        assert ok.any(), (n, k, n_static)
+        assert_allclose(T1[ok], T0[ok], atol=1e-9, err_msg=str((n, k, n_static)))
+        assert_allclose(R1[ok], R0[ok], atol=1e-9, err_msg=str((n, k, n_static)))
+        assert_allclose(lp1[ok], lp0[ok], rtol=LOGP_RTOL, err_msg=str((n, k, n_static)))
+        tried += 1
+    assert tried >= 20
