@@ -301,7 +301,8 @@ def main():
                             f"deflation {n} -> {n - h_defl}, three launches)" if h_defl else f"dsge::cr_compact_kernel<{bs_n}>")
                  if args.solver == "cycle_reduction" else ("dsge::gensys_reduce_kernel + gensys_qzwin_kernel + gensys_post_kernel (window path, three launches)"
                                 if n > 16 else "dsge::gensys_kernel"),
-                 "assemble": f"dsge::assemble_kernel<{(n + 7) // 8}>",
+                 "assemble": ("dsge::rqr_kernel<16>" if (args.solver == "cycle_reduction" and k <= 16)
+                              else f"dsge::assemble_kernel<{(n + 7) // 8}>"),
                  "kalman": f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>"}
         kern = {}
         for key in ("solver", "assemble", "kalman"):

@@ -507,7 +507,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
     // backward_direct already produced R; the assemble kernel recomputes it from the same
     // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
-    if (fuse_R)
+    if (fuse_R && (q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED) && k <= 16 && n <= 64)
+      rc = launch_rqr(Rw, Q, q_mode == DSGE_Q_DIAG_BATCHED, batch, n, k, status_out, RQR, st);  // (RQR_KMAX = 16)
+    else if (fuse_R)
       rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, Tw, Rw, Q, q_mode, batch, n, k, nullptr, nullptr, RQR, P0,
                            status_out, 0, 2, st);
     else

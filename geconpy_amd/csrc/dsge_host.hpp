@@ -62,6 +62,8 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
 void cr_deflation_reset();
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
                    double* R_out, hipStream_t st);
+int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n, int k, const int32_t* status,
+               double* RQR_out, hipStream_t st);  // sym(R diag(q) R') alone, k <= RQR_KMAX (dsge_kernels.hpp)
 int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
                     const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,

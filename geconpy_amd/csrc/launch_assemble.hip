@@ -25,6 +25,14 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
   return rc;
 }
 
+int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n, int k, const int32_t* status,
+               double* RQR_out, hipStream_t st) {
+  const size_t lds = sizeof(double) * (size_t)n * ((k + 1) & ~1);
+  hipLaunchKernelGGL(dsge::rqr_kernel<dsge::RQR_KMAX>, dim3(batch), dim3(64), lds, st, R, q, q_batched, batch, n, k, status, RQR_out);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
                    double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate) {
   const int bs = tile_bs(n);

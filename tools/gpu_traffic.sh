@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for row in csv.DictReader(open(f[0])):
         name = row["Kernel_Name"]
         key = "solver_deflate" if "cr_deflate_kernel" in name else "solver_inflate" if "cr_inflate_kernel" in name \
-            else "solver_iterate" if ("cr_compact_kernel" in name or "gensys_kernel" in name) else "assemble" if "assemble_kernel" in name \
+            else "solver_iterate" if ("cr_compact_kernel" in name or "gensys_kernel" in name) else "assemble" if ("rqr_kernel" in name or "assemble_kernel" in name) \
             else "kalman" if "kalman_sel_kernel<3" in name else None
         if key and row["Counter_Name"] == c:
             acc[key][c].append(float(row["Counter_Value"]))
