@@ -1654,3 +1654,41 @@ def test_cr_static_deflation_fuzz():
         assert_allclose(lp1[ok], lp0[ok], rtol=LOGP_RTOL, err_msg=str((n, k, n_static)))
         tried += 1
     assert tried >= 20
+
+
+@pytest.mark.parametrize("n,ns,nl,k", [(40, 18, 12, 7), (24, 10, 7, 3), (12, 5, 3, 1), (50, 22, 15, 16)])
+def test_rqr_kernel_matches_assemble_kernel(n, ns, nl, k):
+    """Fused call with a diagonal Q (`rqr_kernel`: sym(R diag(q) R') with one result column per lane) against the same Q
+    handed over as full per-draw matrices (`assemble_kernel`): logp to 1e-12, status identical; a failed draw gives -inf
+    on both routes.  Shared and per-draw q."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    eng = LogpEngine(torch.device("cuda", 0))
+    rng = np.random.default_rng(n + k)
+    nb = 9
+    sysm = [wl.sw_shaped_system(7700 + 13 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    A[4, 0, 0] = np.nan
+    p = min(k, 5)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = rng.normal(0, 0.02, (25, p))
+    dev = [eng.to_device(x) for x in (A, B, C, D)]
+    dZ, dy, dH = eng.to_device(Z), eng.to_device(y), eng.to_device(np.full(p, 1e-4))
+    hints = eng.structure_hints(dev[0], dZ)
+    for q in (rng.uniform(0.5e-4, 2e-4, k), rng.uniform(0.5e-4, 2e-4, (nb, k))):
+        qb = np.broadcast_to(q, (nb, k))
+        Qfull = np.stack([np.diag(qb[i]) for i in range(nb)])
+        outs = []
+        for Q, mode in ((q, 0 if q.ndim == 1 else 1), (Qfull, 3)):
+            lp, st = eng.solve_kalman_logp(*dev, eng.to_device(np.ascontiguousarray(Q)), dZ, dy, Hdiag=dH, q_mode=mode, tol=1e-9,
+                                           max_iter=1000, n_state_hint=hints[0], z_selector_hint=hints[1])
+            torch.cuda.synchronize()
+            outs.append((lp.cpu().numpy(), st.cpu().numpy()))
+        (lp_d, st_d), (lp_f, st_f) = outs
+        assert np.array_equal(st_d, st_f) and st_d[4] != 0 and lp_d[4] == -np.inf and lp_f[4] == -np.inf
+        ok = st_d == 0
+        assert ok.sum() == nb - 1
+        assert_allclose(lp_d[ok], lp_f[ok], rtol=1e-12)
