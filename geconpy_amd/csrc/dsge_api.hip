@@ -713,16 +713,24 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
     int32_t* stc = status_out + c0;
     if (solver == DSGE_SOLVER_GENSYS)
       rc = launch_gensys(Ac, Bc, Cc, nb, n, tol, n_lead_hint, Tw, eu_w, stc, st);
-    else {
-      int deflated = 0;  // static variables deflated first, as in the forward-only call (R is recomputed by the assemble)
+    bool have_R = false;  // R from the solver's final elimination (as in the forward-only call): only sym(RQR') is left
+    if (solver != DSGE_SOLVER_GENSYS) {
+      int deflated = 0;  // static variables deflated first, as in the forward-only call
       if (solver == DSGE_SOLVER_CYCLE_REDUCTION &&
           (rc = launch_cr_deflated(Ac, Bc, Cc, Dc, nb, n, k, max_iter, tol, Tw, Rw, stc, it_w, st, &deflated)))
         return rc;
-      if (!deflated)
-        rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, it_w, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION);
+      have_R = deflated != 0;
+      if (!deflated) {
+        const bool fr = solver == DSGE_SOLVER_CYCLE_REDUCTION && g_cr_fuse_R;
+        rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, it_w, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION,
+                       fr ? Dc : nullptr, k, fr ? Rw : nullptr);
+        have_R = fr;
+      }
     }
     if (rc) return rc;
-    if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
+    if (have_R && k <= 16 && n <= 64) {
+      if ((rc = launch_rqr(Rw, qc, q_batched, nb, n, k, stc, RQR, st))) return rc;
+    } else if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
                               Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))
       return rc;
     const int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;
