@@ -487,7 +487,11 @@ __global__ __launch_bounds__(64) void assemble_kernel(
 template <int BS>
 struct AdjSmem {
   static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 3 * NP + 1;
-  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + 2 * NP * LD + NP * BS + BS * 3 * NP + NP / 2);
+  // W (three column groups) and one NP x LD matrix; T is kept in the third column group of W while it is free and read
+  // again from global memory for the final products, and the Gauss-Jordan scratch lives in the NP x LD matrix while that
+  // is free: 51.8 instead of 71.5 KB at n = 40, three draws per CU instead of two
+  static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + NP * LD);
+  static_assert(NP * BS + BS * 3 * NP + NP / 2 <= NP * LD, "Gauss-Jordan scratch must fit the NP x LD matrix");
 };
 
 template <int BS>
@@ -499,9 +503,9 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
   constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;             // [M' | T_bar | C'] -> [. | M^-T T_bar | M^-T C'];  later [W1 | S | G_k]
-  double* Tk = W + NP * LDW;    // C at first, then T^(2^k)
-  double* Ts = Tk + NP * LD;    // T
-  double* Lbuf = Ts + NP * LD;
+  double* Tk = W + NP * LDW;    // C at first, then the Gauss-Jordan scratch, then T^(2^k)
+  double* Ts = W + 2 * NP;      // T (row stride LDW): before W is filled, and again for the final products
+  double* Lbuf = Tk;
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 3 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
@@ -509,13 +513,26 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
     const size_t off = (size_t)draw * n * n;
     wave_sync();
     for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
-    lds_load_matrix(Ts, LD, NP, NP, T + off, n, n, lane);
+    wave_sync();
+    lds_load_matrix(Ts, LDW, NP, NP, T + off, n, n, lane);
     lds_load_matrix(Tk, LD, NP, NP, C + off, n, n, lane);
     wave_sync();
+    // T (and every power of it) has non-zero columns only for the state variables; when those end at column ks the two
+    // products that contract over the columns of T_k run over ks terms instead of n (18 instead of 40 on the SW-shaped
+    // systems, whose states lead; ks = n and nothing changes when a state sits in the last column)
+    int ks = n;
+    {
+      bool nz = false;
+      if (lane < n)
+        for (int r = 0; r < n; ++r) nz = nz | (Ts[r * LDW + lane] != 0.0);
+      const unsigned long long cm = __ballot(nz);
+      ks = cm ? 64 - __clzll((long long)cm) : 0;
+    }
     {
       double Mb[BS][BS], Cb[BS][BS], Hb[BS][BS];
       blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
-      mm_acc<BS, false>(Mb, Tk, LD, Ts, LD, n, lr, lc);  // M = B + C T
+      mm_acc<BS, false>(Mb, Tk, LD, Ts, LDW, n, lr, lc);  // M = B + C T
+      wave_sync();  // T (third column group of W) and C (Tk) are dead from here: C' and the Gauss-Jordan scratch take over
       blk_load_global<BS>(Cb, C + off, n, n, n, lr, lc);
       blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);
 #pragma unroll
@@ -536,7 +553,7 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       blk_load_lds<BS>(Gb, W + 2 * NP, LDW, lr, lc);
       wave_sync();
       double Tb[BS][BS];
-      blk_load_lds<BS>(Tb, Ts, LD, lr, lc);
+      blk_load_global<BS>(Tb, T + off, n, n, n, lr, lc);
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -548,17 +565,6 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       blk_store_lds<BS>(Gb, W + 2 * NP, LDW, lr, lc);  // G_0
       blk_store_lds<BS>(Tb, Tk, LD, lr, lc);           // F_0' = T
       wave_sync();
-    }
-    // T (and every power of it) has non-zero columns only for the state variables; when those end at column ks the two
-    // products that contract over the columns of T_k run over ks terms instead of n (18 instead of 40 on the SW-shaped
-    // systems, whose states lead; ks = n and nothing changes when a state sits in the last column)
-    int ks = n;
-    {
-      bool nz = false;
-      if (lane < n)
-        for (int r = 0; r < n; ++r) nz = nz | (Ts[r * LD + lane] != 0.0);
-      const unsigned long long cm = __ballot(nz);
-      ks = cm ? 64 - __clzll((long long)cm) : 0;
     }
     bool ok = false;
     for (int it = 0; it < LYAP_MAX_DOUBLINGS; ++it) {
@@ -591,10 +597,13 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       }
     }
     blk_store_global<BS>(Sb, A_bar + off, n, n, n, lr, lc);
+    wave_sync();
+    lds_load_matrix(Ts, LDW, NP, NP, T + off, n, n, lane);  // T again, over the dead G_k
+    wave_sync();
     {
       double Bb[BS][BS], Cb[BS][BS];
       blk_zero<BS>(Bb);
-      mm_acc<BS, true>(Bb, W + NP, LDW, Ts, LD, n, lr, lc);  // S T'
+      mm_acc<BS, true>(Bb, W + NP, LDW, Ts, LDW, n, lr, lc);  // S T'
       if (accumulate) {  // gradient pipeline: B_bar, C_bar already hold the cotangents that came through R
         double t0[BS][BS];
         blk_load_global<BS>(t0, B_bar + off, n, n, n, lr, lc);
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ 
       blk_store_lds<BS>(Bb, W, LDW, lr, lc);
       wave_sync();
       blk_zero<BS>(Cb);
-      mm_acc<BS, true>(Cb, W, LDW, Ts, LD, n, lr, lc);       // S T' T'
+      mm_acc<BS, true>(Cb, W, LDW, Ts, LDW, n, lr, lc);      // S T' T'
       if (accumulate) {
         double t0[BS][BS];
         blk_load_global<BS>(t0, C_bar + off, n, n, n, lr, lc);
