@@ -864,8 +864,10 @@ namespace dsge {
 template <int BS>
 struct GaSmem {
   static constexpr int NP = Tile<BS>::NP, LD = Tile<BS>::LD, LDW = 2 * NP + 1;
-  // Ts, Cs, Ms, Rs (NP x LD), W (NP x LDW), GJ scratch
-  static constexpr size_t bytes = sizeof(double) * (size_t)(4 * NP * LD + NP * LDW + NP * BS + BS * 2 * NP + NP / 2);
+  // Ts, Cs, Ms, Rs (NP x LD), W (NP x LDW); the Gauss-Jordan scratch lives in Ms, which is dead between the product
+  // Gbar R and the store of Mbar: 78.4 instead of 83.4 KB at n = 40 -- two draws per CU instead of ONE
+  static constexpr size_t bytes = sizeof(double) * (size_t)(4 * NP * LD + NP * LDW);
+  static_assert(NP * BS + BS * 2 * NP + NP / 2 <= NP * LD, "Gauss-Jordan scratch must fit an NP x LD matrix");
 };
 
 template <int BS>
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
   double* Ms = Cs + NP * LD;   // Gbar, later Mbar
   double* Rs = Ms + NP * LD;   // R (n x k, zero padded), later X
   double* W = Rs + NP * LD;    // [M' | Rbar]
-  double* Lbuf = W + NP * LDW;
+  double* Lbuf = Ms;           // (Gauss-Jordan scratch: Ms is dead while the solve runs)
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 2 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
@@ -936,6 +938,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
         for (int j = 0; j < BS; ++j) W[(lc * BS + j) * LDW + lr * BS + i] = Mb[i][j];
       blk_store_lds<BS>(Rbar, W + NP, LDW, lr, lc);
     }
+    wave_sync();  // (Gbar in Ms has been consumed by every lane)
     gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
     gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
     double Xb[BS][BS];
