@@ -298,7 +298,11 @@ __global__ __launch_bounds__(64) void assemble_kernel(
   double* W = rqr_only ? smem : M1 + NP * LD;     // two column groups (ld = LDW)
   double* G0 = W;               //   C-stage: B + C T, then [M | .] of the solve; later R, W1 / transposes
   double* G1 = W + NP;          //   C, then D -> X; later R Q, then P_k
-  double* Lbuf = W + NP * LDW;
+  // Gauss-Jordan scratch: behind W -- or, when no doubling iteration follows (T in M1 is dead once the solve starts), in
+  // M1 itself, and the launcher allocates M1 + W only (39 instead of 44 KB at n = 40: four draws per CU instead of three)
+  const bool scratch_in_m1 = do_selection && (do_lyapunov == 0 || do_lyapunov == 2);
+  static_assert(NP * BS + BS * 2 * NP + NP / 2 <= NP * LD, "Gauss-Jordan scratch must fit M1");
+  double* Lbuf = scratch_in_m1 ? M1 : W + NP * LDW;
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 2 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(
         s = wave_sum(s);
         if (lane == 0) resid_out[draw] = s;
       }
+      wave_sync();  // (every lane is done with T in M1, which may hold the scratch from here)
       gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
       gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
       blk_load_lds<BS>(Rb, G1, LDW, lr, lc);

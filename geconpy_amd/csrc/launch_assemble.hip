@@ -15,8 +15,11 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
   DISPATCH_BS(bs, 8, {
     rc = set_lds(dsge::assemble_kernel<BS>, dsge::AsmSmem<BS>::bytes);
     // sym(R Q R') alone needs the two column groups of W only (see the kernel)
+    // ... and the selection without a doubling iteration M1 + W (the Gauss-Jordan scratch moves into M1)
     const size_t lds = (!do_sel && do_lyap == 2) ? sizeof(double) * dsge::AsmSmem<BS>::NP * dsge::AsmSmem<BS>::LDW
-                                                  : dsge::AsmSmem<BS>::bytes;
+                       : (do_sel && (do_lyap == 0 || do_lyap == 2))
+                           ? sizeof(double) * dsge::AsmSmem<BS>::NP * (dsge::AsmSmem<BS>::LD + dsge::AsmSmem<BS>::LDW)
+                           : dsge::AsmSmem<BS>::bytes;
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::assemble_kernel<BS>, dim3(do_lyap == 3 ? rerun_grid(batch) : batch), dim3(64), lds, st, A, B, C, D, T, R_in, Q, q_mode, batch, n, k, R_out, resid_out, RQR_out, P0_out, status, do_sel, do_lyap);
       HIP_TRY(hipGetLastError());
