@@ -102,6 +102,48 @@ def cpu_baseline(batch, om, n_sample, cores):
         dt = time.perf_counter() - t0
     return np.array(logp), n_sample / dt, dt
 
+def spawn_ranks(n_ranks, argv, shared_gpu=False, timeout=None):
+    """Start ``n_ranks`` fresh ``python bench.py`` processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment, 127.0.0.1 rendezvous), wait for them and return the worst exit code.  Rank 0 prints the JSON
+    line on the inherited stdout.  A rank that dies takes the others down (exact PIDs, never a pattern)."""
+    import socket
+    import subprocess
+
+    import torch  # device_count() does not initialise the GPU on this image; the launcher stays off it
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < n_ranks and not shared_gpu:
+        print(f"bench.py: --gpus {n_ranks} but only {n_dev} device(s) visible (pass --allow-shared-gpu to put several "
+              f"ranks on one device over gloo: a functional check, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    t_end = None if timeout is None else time.time() + timeout
+    worst = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                for q in alive:  # a dead rank leaves the others blocked in a collective
+                    q.terminate()
+        if t_end is not None and time.time() > t_end:
+            for q in alive:
+                q.kill()
+            worst = worst or 124
+    return worst
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -119,17 +161,22 @@ def main():
                     help="rbc workload only: start each step from the parameter draws (generated Jacobian kernel on the "
                          "device, SURVEY 8 f1) instead of from resident A,B,C,D")
     ap.add_argument("--no-hints", action="store_true", help="disable the structure hints (general kernels only)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="functional check on a box with fewer devices than ranks: rank r uses device r %% device_count "
+                         "and the gather runs over gloo (the JSON line says so; not a measurement)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of its N rank processes.  It never
+        # touches the GPU (no torch.cuda call, no HIP call) and never re-execs itself; the ranks are fresh children.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], shared_gpu=args.allow_shared_gpu))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
 
     # CPU baseline first (rank 0, N = 1 only), in spawned workers, before this process touches the GPU
     from geconpy_amd import workloads as wl
@@ -170,10 +217,21 @@ def main():
 
     from geconpy_amd.engine import LogpEngine, ShardedLogpEvaluator
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    shared = world > 1 and n_dev < world
+    if shared and not args.allow_shared_gpu:
+        print(f"bench.py: rank {rank}: {world} ranks but {n_dev} device(s)", file=sys.stderr)
+        sys.exit(2)
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm); RCCL refuses two ranks on one device, so the
+        # functional shared-device check gathers over gloo instead (ShardedLogpEvaluator stages through the host)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     eng = LogpEngine(device)
     dA, dB, dC, dD = (eng.to_device(shard[x]) for x in "ABCD")
     dq = eng.to_device(shard["sigma"] ** 2)
@@ -325,6 +383,8 @@ def main():
             "value": round(value, 2),
             "unit": "evals/s",
             "n_gpus": world,
+            **({"shared_device": f"{world} ranks on {n_dev} device(s), gloo gather: functional check, not a measurement"}
+               if shared else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

@@ -265,8 +265,13 @@ class ShardedLogpEvaluator:
         # ONE collective per step: each rank contributes one byte record [logp f64 x m | status i32 x m | pad]
         m = self.max_shard
         self._rec = 8 * m + 4 * m + (-(12 * m) % 8)
-        self._l_buf = torch.zeros(self._rec, dtype=torch.uint8, device=device)
-        self._g_buf = torch.empty(self.world * self._rec, dtype=torch.uint8, device=device)
+        # RCCL gathers device buffers in place over xGMI; a gloo group (CPU tests, several ranks sharing one device)
+        # stages the 12-byte-per-draw records through the host
+        self.host_staged = bool(self.distributed and dist.get_backend(group) != "nccl" and
+                                torch.device(device).type != "cpu")
+        buf_dev = "cpu" if self.host_staged else device
+        self._l_buf = torch.zeros(self._rec, dtype=torch.uint8, device=buf_dev)
+        self._g_buf = torch.empty(self.world * self._rec, dtype=torch.uint8, device=buf_dev)
         self._l_logp = self._l_buf[: 8 * m].view(torch.float64)
         self._l_stat = self._l_buf[8 * m : 12 * m].view(torch.int32)
         self._l_logp.fill_(float("nan"))
@@ -286,7 +291,7 @@ class ShardedLogpEvaluator:
         g_logp = recs[:, : 8 * m].view(torch.float64)        # (world, m) strided views of the gathered records
         g_stat = recs[:, 8 * m : 12 * m].view(torch.int32)
         if all(hi - lo == m for lo, hi in self.bounds):
-            return g_logp.reshape(-1), g_stat.reshape(-1)
+            return g_logp.reshape(-1).to(self.device), g_stat.reshape(-1).to(self.device)
         parts_l = [g_logp[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)]
         parts_s = [g_stat[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)]
-        return torch.cat(parts_l), torch.cat(parts_s)
+        return torch.cat(parts_l).to(self.device), torch.cat(parts_s).to(self.device)

@@ -1,0 +1,94 @@
+"""Wide parity fixtures (run ONLY in the build container; reads /root/reference through _ref_extract.py).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py
+
+``sw_shaped_wide.npz``: 512 DISTINCT draws of BASELINE configs[2]'s SW-shaped workload -- draws 0..495 plus 16 picked from
+the rest of the 4096-draw bench batch, among them the two ill-conditioned ones the round-1 worst-case search found (752:
+largest device-vs-oracle difference; 2950: nine cycle-reduction iterations, a near-unit root).  The inputs are regenerated
+from the draw index (``workloads.sw_shaped_batch(first_draw=i)``, seed 20260630 + i; ``input_checksum`` pins them); the
+expected outputs are
+
+    ref_cr_logp      logp of the oracle filter on T from the REFERENCE's _cycle_reduction_core (tol 1e-8) and
+                     R = -(C T + B)^-1 D (shared.py:74-75)
+    ref_gensys_logp  the same on T from the reference's _gensys_setup + _gensys_core (tol 1e-8)
+    ref_cr_iters     the reference's iteration count
+
+``rbc_wide.npz``: BASELINE configs[1] (RBC, 4096 prior draws, observed Y, T_len = 200): 64 draws spread over the batch,
+same three arrays.
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+EXTRA_SW = (752, 2950, 1023, 1024, 2047, 2048, 3071, 3333, 3500, 3750, 3900, 4000, 4050, 4093, 4094, 4095)
+TOL = 1e-8
+
+
+def _logps(A, B, C, D, Q, Z, y, H):
+    from make_golden import REF, ref_cr_iters, ref_gensys
+
+    import oracle
+
+    out = []
+    Tcr, conv = REF["_cycle_reduction_core"](A, B, C, 1000, TOL)
+    assert conv
+    rg = ref_gensys(A, B, C, D, TOL)
+    assert list(rg["eu"][:2]) == [1, 1]
+    for T in (Tcr, rg["T"]):
+        R = -np.linalg.solve(C @ T + B, D)
+        out.append(oracle.kalman_filter_logp(y, T, R, Q, Z, H=H))
+    return out[0], out[1], ref_cr_iters(A, B, C, TOL)
+
+
+def _sw_one(i):
+    from geconpy_amd import workloads as wl
+
+    b = wl.sw_shaped_batch(1, first_draw=i)
+    om = wl.sw_shaped_observation_model()
+    return _logps(b["A"][0], b["B"][0], b["C"][0], b["D"][0], np.diag(b["sigma"][0] ** 2), om["Z"], om["y"],
+                  np.diag(om["Hdiag"]))
+
+
+def _rbc_one(i):
+    from geconpy_amd import workloads as wl
+
+    b, om = wl.rbc_batch(1, first_draw=i)
+    return _logps(b["A"][0], b["B"][0], b["C"][0], b["D"][0], np.diag(b["sigma"][0] ** 2), om["Z"], om["y"],
+                  np.diag(om["Hdiag"]))
+
+
+def main():
+    from geconpy_amd import workloads as wl
+
+    os.environ["OMP_NUM_THREADS"] = "1"
+    sw_idx = np.array(list(range(496)) + list(EXTRA_SW))
+    rbc_idx = np.arange(0, 4096, 64) + (np.arange(64) % 7)
+    with mp.get_context("spawn").Pool(os.cpu_count()) as pool:
+        sw = pool.map(_sw_one, sw_idx.tolist(), chunksize=4)
+        rbc = pool.map(_rbc_one, rbc_idx.tolist(), chunksize=4)
+    b = wl.sw_shaped_batch(8)
+    chk = np.array([np.abs(b[x]).sum() for x in "ABCD"])
+    np.savez_compressed(os.path.join(HERE, "sw_shaped_wide.npz"), draw_idx=sw_idx, input_checksum_first8=chk,
+                        ref_cr_logp=np.array([r[0] for r in sw]), ref_gensys_logp=np.array([r[1] for r in sw]),
+                        ref_cr_iters=np.array([r[2] for r in sw]))
+    br, _ = wl.rbc_batch(8)
+    np.savez_compressed(os.path.join(HERE, "rbc_wide.npz"), draw_idx=rbc_idx,
+                        input_checksum_first8=np.array([np.abs(br[x]).sum() for x in "ABCD"]),
+                        ref_cr_logp=np.array([r[0] for r in rbc]), ref_gensys_logp=np.array([r[1] for r in rbc]),
+                        ref_cr_iters=np.array([r[2] for r in rbc]))
+    a = np.array([r[:2] for r in sw])
+    print("sw: cr vs gensys max rel", np.max(np.abs(a[:, 0] - a[:, 1]) / np.abs(a[:, 0])), "iters", np.unique([r[2] for r in sw]))
+    a = np.array([r[:2] for r in rbc])
+    print("rbc: cr vs gensys max rel", np.max(np.abs(a[:, 0] - a[:, 1]) / np.abs(a[:, 0])), "iters", np.unique([r[2] for r in rbc]))
+
+
+if __name__ == "__main__":
+    main()
