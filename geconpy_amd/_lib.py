@@ -12,7 +12,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_N = 64
 MAX_N_CR = 64
 MAX_N_GENSYS = 64
@@ -103,8 +103,84 @@ PROTOTYPES = {
                                             _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_grad_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
                                                  _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_options_init": [_dp],
+    "dsge_options_push": [_dp],
+    "dsge_options_pop": [],
+    "dsge_solve_kalman_logp_batched_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_batched_host_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_grad_batched_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i,
+                                                _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_grad_batched_host_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
+                                                     _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_profile_pipeline": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _i, _dp, _dp],
 }
+
+
+
+class Options(C.Structure):
+    """``dsge_options`` of include/dsge_hip.h: the kernel-variant switches of ONE call (per call / per host thread;
+    the ``dsge_set_*`` functions only edit the process-wide defaults this struct is initialised from)."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("cr_compact", C.c_int32),
+        ("cr_fused_selection", C.c_int32),
+        ("cr_deflation", C.c_int32),
+        ("cr_two_waves", C.c_int32),
+        ("n_static_hint", C.c_int32),
+        ("kalman_order", C.c_int32),
+        ("kalman_tiny", C.c_int32),
+        ("kalman_block", C.c_int32),
+        ("kalman_mfma", C.c_int32),
+        ("pipeline_chunks", C.c_int32),
+        ("gensys_split", C.c_int32),
+        ("kalman_steady_tol", C.c_double),
+    ]
+
+
+def make_options(options=None, **fields):
+    """A ``dsge_options`` holding the process-wide defaults with ``fields`` (or the dict ``options``) applied;
+    an ``Options`` instance is passed through."""
+    if isinstance(options, Options) and not fields:
+        return options
+    o = Options()
+    check(load().dsge_options_init(C.addressof(o)))
+    if isinstance(options, Options):
+        C.memmove(C.addressof(o), C.addressof(options), C.sizeof(Options))
+    elif options:
+        fields = {**options, **fields}
+    for name, value in fields.items():
+        if name not in {f[0] for f in Options._fields_} or name == "struct_size":
+            raise ValueError(f"unknown option {name!r}")
+        setattr(o, name, value)
+    return o
+
+
+def opt_ptr(options):
+    """(address or None, keep-alive object) for the ``*_opt`` entry points."""
+    if options is None:
+        return None, None
+    o = make_options(options)
+    return C.addressof(o), o
+
+
+class options_scope:
+    """``with options_scope(opts): ...`` -- every library call this THREAD makes inside uses ``opts``
+    (dsge_options_push / dsge_options_pop); ``None`` is a no-op."""
+
+    def __init__(self, options):
+        self.options = None if options is None else make_options(options)
+
+    def __enter__(self):
+        if self.options is not None:
+            check(load().dsge_options_push(C.addressof(self.options)))
+        return self.options
+
+    def __exit__(self, *exc):
+        if self.options is not None:
+            check(load().dsge_options_pop())
+        return False
+
 
 _lib = None
 

@@ -34,7 +34,7 @@ def _check_abc(A, B, C):
     return A, B, C
 
 
-def cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9):
+def cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9, options=None):
     """T, status, n_iter for a batch of systems (``_cycle_reduction_core`` semantics,
     gEconpy/solvers/cycle_reduction.py:127-183; Op defaults :190)."""
     A, B, C = _check_abc(A, B, C)
@@ -42,11 +42,12 @@ def cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9):
     T = np.empty_like(A)
     status = np.empty(nb, dtype=np.int32)
     n_iter = np.empty(nb, dtype=np.int32)
-    _lib.check(
-        _lib.load().dsge_cycle_reduction_batched_host(
-            _ptr(A), _ptr(B), _ptr(C), nb, n, int(max_iter), float(tol), _ptr(T), _ptr(status), _ptr(n_iter)
+    with _lib.options_scope(options):
+        _lib.check(
+            _lib.load().dsge_cycle_reduction_batched_host(
+                _ptr(A), _ptr(B), _ptr(C), nb, n, int(max_iter), float(tol), _ptr(T), _ptr(status), _ptr(n_iter)
+            )
         )
-    )
     return T, status, n_iter
 
 
@@ -73,7 +74,7 @@ def lead_hint(C, tol=0.0):
     return int(np.count_nonzero(np.any(cs.reshape(-1, C.shape[-1]) > tol, axis=0)))
 
 
-def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None):
+def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None, options=None):
     """Batched ``GensysWrapper`` / ``gensys_pt`` (gEconpy/solvers/gensys.py:634-683):
     returns dict(T, success, eu, status[, R])."""
     A, B, C = _check_abc(A, B, C)
@@ -88,10 +89,11 @@ def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None):
         k = D.shape[2]
         R = np.empty((nb, n, k))
     nl = lead_hint(C, tol) if n_lead_hint is None else int(n_lead_hint)
-    _lib.check(
-        _lib.load().dsge_gensys_batched_host(_ptr(A), _ptr(B), _ptr(C), _ptr(D), nb, n, k, float(tol), nl, _ptr(T),
-                                             _ptr(R), _ptr(eu), _ptr(status))
-    )
+    with _lib.options_scope(options):
+        _lib.check(
+            _lib.load().dsge_gensys_batched_host(_ptr(A), _ptr(B), _ptr(C), _ptr(D), nb, n, k, float(tol), nl, _ptr(T),
+                                                 _ptr(R), _ptr(eu), _ptr(status))
+        )
     out = dict(T=T, success=status == 0, eu=eu, status=status)
     if R is not None:
         out["R"] = R
@@ -263,6 +265,14 @@ def state_hint(M):
     return int(np.count_nonzero(np.any(M != 0, axis=tuple(range(M.ndim - 1)))))
 
 
+def static_hint(A, C):
+    """Performance hint (``dsge_options.n_static_hint``): number of variables whose columns of ``A`` AND ``C`` are
+    exactly zero in every draw -- the static variables the cycle-reduction launcher deflates."""
+    A, C = np.asarray(A), np.asarray(C)
+    n = A.shape[-1]
+    return int(np.count_nonzero(~(np.any(A.reshape(-1, n) != 0, axis=0) | np.any(C.reshape(-1, n) != 0, axis=0))))
+
+
 def selector_hint(Z):
     """Performance hint: 1 if every row of Z has exactly one non-zero entry, in distinct columns."""
     Z2 = np.asarray(Z).reshape(-1, Z.shape[-2], Z.shape[-1])
@@ -303,7 +313,7 @@ def get_kalman_steady_tol():
 
 def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None,
                         jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
-                        z_selector_hint=None):
+                        z_selector_hint=None, options=None):
     """Per-draw Kalman log-likelihood (the filter DSGEStateSpace hands to PyMC,
     gEconpy/model/statespace.py:1151-1157) -> (logp, status)."""
     T, R = _f64(T, 3), _f64(R, 3)
@@ -317,20 +327,23 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
     logp = np.empty(nb)
     ns = state_hint(T) if n_state_hint is None else int(n_state_hint)
     zs = selector_hint(Z) if z_selector_hint is None else int(z_selector_hint)
-    _lib.check(
-        _lib.load().dsge_kalman_logp_batched_host(
-            _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len,
-            float(jitter), float(missing_fill_value), ns, zs, _ptr(logp), _ptr(st)
+    with _lib.options_scope(options):
+        _lib.check(
+            _lib.load().dsge_kalman_logp_batched_host(
+                _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len,
+                float(jitter), float(missing_fill_value), ns, zs, _ptr(logp), _ptr(st)
+            )
         )
-    )
     return logp, st
 
 
 def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                               tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
-                              return_policy=False, n_state_hint=None, z_selector_hint=None, n_lead_hint=None):
+                              return_policy=False, n_state_hint=None, z_selector_hint=None, n_lead_hint=None,
+                              options=None):
     """One fused evaluation per draw: A,B,C,D -> T,R -> P0 -> logp.  ``tol``/``max_iter``
     default to what ``DSGEStateSpace.configure`` passes (statespace.py:835-836).
+    ``options``: per-call kernel-variant switches (dict of ``dsge_options`` fields or ``_lib.Options``).
     Returns dict(logp, status[, T, R, resid, n_iter])."""
     A, B, C = _check_abc(A, B, C)
     D = _f64(D, 3)
@@ -351,9 +364,10 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
     ns = state_hint(A) if n_state_hint is None else int(n_state_hint)
     zs = selector_hint(Z) if z_selector_hint is None else int(z_selector_hint)
     nl = (lead_hint(C, tol) if solver == "gensys" else 0) if n_lead_hint is None else int(n_lead_hint)
+    op, _keep = _lib.opt_ptr(options)
     _lib.check(
-        _lib.load().dsge_solve_kalman_logp_batched_host(
-            _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb,
+        _lib.load().dsge_solve_kalman_logp_batched_host_opt(
+            op, _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb,
             n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter),
             float(missing_fill_value), ns, zs, nl, _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
         )
@@ -366,7 +380,7 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
 
 def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
                                    jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=None,
-                                   n_lead_hint=None):
+                                   n_lead_hint=None, options=None):
     """logp and its reverse-mode gradient per draw (include/dsge_hip.h: dsge_solve_kalman_logp_grad_batched): what
     pytensor autodiff computes for the reference's logp graph, on the device.  ``q``: (k,) or (batch, k) diagonal shock
     variances; ``Z``: selector design matrix (p, n), p <= 8; n <= 48.
@@ -393,9 +407,10 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
         out["d_bar"] = np.empty((nb, p))
     if Hdiag is not None:
         out["h_bar"] = np.empty((nb, p))
+    op, _keep = _lib.opt_ptr(options)
     _lib.check(
-        _lib.load().dsge_solve_kalman_logp_grad_batched_host(
-            _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(q), qb, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, n, k, p,
+        _lib.load().dsge_solve_kalman_logp_grad_batched_host_opt(
+            op, _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(q), qb, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, n, k, p,
             T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter), float(missing_fill_value), ns, nl,
             _ptr(out["logp"]), _ptr(out["status"]), _ptr(out["A_bar"]), _ptr(out["B_bar"]), _ptr(out["C_bar"]),
             _ptr(out["D_bar"]), _ptr(out["q_bar"]), _ptr(out.get("d_bar")), _ptr(out.get("h_bar"))

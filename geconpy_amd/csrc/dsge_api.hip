@@ -20,6 +20,8 @@ int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+Options g_defaults;                                   // process-wide defaults (dsge_set_*)
+thread_local const Options* t_call_options = nullptr;  // options of the call running on this thread
 }  // namespace dsge_host
 
 using namespace dsge_host;
@@ -29,8 +31,6 @@ namespace {
 
 
 
-int g_pipeline_chunks = 0;  // fused device call: chunks alternating over two internal streams (< 2 = one pass on the caller's stream)
-int g_cr_fuse_R = 1;  // fused pipeline: take R from the cycle-reduction kernel's final elimination
 bool g_device_checked = false;
 int g_device_ok = 0;
 std::mutex g_mutex;
@@ -59,30 +59,92 @@ int ensure_device() {
 struct Arena {
   void* ptr = nullptr;
   size_t cap = 0;
+  int dev = -1;
+  bool leased = false;
 };
 constexpr int MAX_DEV = 16;
-Arena g_stage[MAX_DEV];    // host-twin staging
 
-int arena_reserve(Arena* arenas, size_t bytes, void** out) {
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= MAX_DEV) return fail(DSGE_ERR_INVALID, "device index out of range");
-  Arena& a = arenas[dev];
-  if (a.cap < bytes) {
-    if (a.ptr) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(a.ptr));
-      a.ptr = nullptr;
-      a.cap = 0;
+// Host-twin staging.  Host threads call the twins concurrently (ctypes releases the GIL: PyMC / nutpie chains in threads,
+// two pytensor Ops), so a twin LEASES a staging arena for the duration of its call from a pool that grows to the number of
+// concurrent callers; arenas are never shared between two calls in flight and never freed while leased.
+std::mutex g_stage_mutex;
+std::vector<Arena*> g_stage_pool;
+
+struct StageLease {
+  Arena* a = nullptr;
+  ~StageLease() {
+    if (a) {
+      std::lock_guard<std::mutex> lk(g_stage_mutex);
+      a->leased = false;
     }
-    size_t cap = bytes + bytes / 4 + 4096;
-    HIP_TRY(hipMalloc(&a.ptr, cap));
-    a.cap = cap;
   }
-  *out = a.ptr;
+  int reserve(size_t bytes, void** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) return fail(DSGE_ERR_INVALID, "device index out of range");
+    {
+      std::lock_guard<std::mutex> lk(g_stage_mutex);
+      for (Arena* c : g_stage_pool)  // the largest free arena of this device
+        if (!c->leased && c->dev == dev && (!a || c->cap > a->cap)) a = c;
+      if (!a) {
+        a = new Arena();
+        a->dev = dev;
+        g_stage_pool.push_back(a);
+      }
+      a->leased = true;
+    }
+    if (a->cap < bytes) {  // only this call holds the arena: nothing of it is in flight
+      if (a->ptr) {
+        HIP_TRY(hipFree(a->ptr));
+        a->ptr = nullptr;
+        a->cap = 0;
+      }
+      const size_t cap = bytes + bytes / 4 + 4096;
+      HIP_TRY(hipMalloc(&a->ptr, cap));
+      a->cap = cap;
+    }
+    *out = a->ptr;
+    return DSGE_SUCCESS;
+  }
+};
+#define STAGE_RESERVE(bytes, out) \
+  StageLease stage_lease_;        \
+  if ((rc = stage_lease_.reserve((bytes), (out)))) return rc
+
+// Installs the options of one call on the calling thread (see dsge_host.hpp); nests.
+struct OptionsGuard {
+  Options local;
+  const Options* prev;
+  explicit OptionsGuard(const dsge_options* o) : prev(t_call_options) {
+    if (!o) return;
+    local.cr_compact = o->cr_compact;
+    local.cr_fused_selection = o->cr_fused_selection;
+    local.cr_deflation = o->cr_deflation;
+    local.cr_two_waves = o->cr_two_waves;
+    local.n_static_hint = o->n_static_hint;
+    local.kalman_order = o->kalman_order;
+    local.kalman_tiny = o->kalman_tiny;
+    local.kalman_block = o->kalman_block;
+    local.kalman_mfma = o->kalman_mfma;
+    local.pipeline_chunks = o->pipeline_chunks;
+    local.gensys_split = o->gensys_split;
+    local.kalman_steady_tol = o->kalman_steady_tol;
+    t_call_options = &local;
+  }
+  ~OptionsGuard() { t_call_options = prev; }
+};
+
+int check_options(const dsge_options* o) {
+  if (!o) return DSGE_SUCCESS;
+  if (o->struct_size != sizeof(dsge_options)) return fail(DSGE_ERR_INVALID, "dsge_options.struct_size mismatch (call dsge_options_init)");
+  if (!(o->kalman_steady_tol >= 0.0) || o->kalman_steady_tol > 1e-6)
+    return fail(DSGE_ERR_INVALID, "kalman_steady_tol must be in [0, 1e-6]");
+  if (o->kalman_order < 0 || o->kalman_order > 2) return fail(DSGE_ERR_INVALID, "kalman_order must be 0, 1 or 2");
+  if (o->pipeline_chunks < 0 || o->pipeline_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline_chunks must be in 0..64");
+  if (o->gensys_split < 0 || o->gensys_split > 2) return fail(DSGE_ERR_INVALID, "gensys_split must be 0, 1 or 2");
+  if (o->n_static_hint < -1 || o->n_static_hint > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "n_static_hint out of range");
   return DSGE_SUCCESS;
 }
-
 
 // Scratch of the device entry points: one arena per (device, stream) -- the library is re-entrant per stream:
 // two fused calls enqueued on two streams must not share intermediates.  16 slots per device; when more streams than slots
@@ -192,54 +254,54 @@ int dsge_debug_cr_phases(int enable, long long* cycles_out) {
   return DSGE_SUCCESS;
 }
 int dsge_set_cr_fused_selection(int enable) {
-  g_cr_fuse_R = enable ? 1 : 0;
+  g_defaults.cr_fused_selection = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_cr_compact(int enable) {
-  g_cr_compact = enable ? 1 : 0;
+  g_defaults.cr_compact = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_mfma(int enable) {
-  g_kalman_mfma = enable ? 1 : 0;
+  g_defaults.kalman_mfma = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_gensys_split(int enable) {
-  g_gensys_split = (enable == 2) ? 2 : (enable ? 1 : 0);
+  g_defaults.gensys_split = (enable == 2) ? 2 : (enable ? 1 : 0);
   return DSGE_SUCCESS;
 }
 int dsge_set_pipeline_chunks(int n_chunks) {
   if (n_chunks < 0 || n_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline chunks must be in 0..64");
-  g_pipeline_chunks = n_chunks;
+  g_defaults.pipeline_chunks = n_chunks;
   return DSGE_SUCCESS;
 }
 int dsge_set_cr_two_waves(int enable) {
-  g_cr_occ2 = enable ? 1 : 0;
+  g_defaults.cr_two_waves = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_cr_deflation(int enable) {
-  g_cr_deflate = enable ? 1 : 0;
+  g_defaults.cr_deflation = enable ? 1 : 0;
   cr_deflation_reset();
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_order(int mode) {
   if (mode < 0 || mode > 2) return fail(DSGE_ERR_INVALID, "order mode must be 0, 1 or 2");
-  g_kalman_order = mode;
+  g_defaults.kalman_order = mode;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_block(int enable) {
-  g_kalman_block = enable ? 1 : 0;
+  g_defaults.kalman_block = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_tiny(int enable) {
-  g_kalman_tiny = enable ? 1 : 0;
+  g_defaults.kalman_tiny = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_steady_tol(double tol) {
   if (!(tol >= 0.0) || tol > 1e-6) return fail(DSGE_ERR_INVALID, "steady-state tolerance must be in [0, 1e-6]");
-  g_kalman_steady_tol = tol;
+  g_defaults.kalman_steady_tol = tol;
   return DSGE_SUCCESS;
 }
-double dsge_get_kalman_steady_tol(void) { return g_kalman_steady_tol; }
+double dsge_get_kalman_steady_tol(void) { return g_defaults.kalman_steady_tol; }
 int dsge_debug_kalman_steady_steps(int32_t* steady_at_device) {
   g_kalman_steady_at = steady_at_device;
   return DSGE_SUCCESS;
@@ -485,7 +547,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
     // Cycle reduction (njit semantics) can hand back R from its final elimination (A1_hat = B + C T at convergence);
     // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
-    const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && g_cr_fuse_R;
+    const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && opt().cr_fused_selection;
     if (is_cr) {
       int deflated = 0;
       // static variables deflated first (the iteration then runs on n - h variables); not when the caller asks for the
@@ -519,9 +581,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     const int32_t* okey = nullptr;
     // dispatch key of the Kalman launch: the cycle-reduction iteration counts when there are any (free, and the better
     // predictor on the bench workload), else a persistence key computed from T itself (gensys, backward-direct)
-    if (g_kalman_order == 1 && is_cr) {
+    if (opt().kalman_order == 1 && is_cr) {
       okey = it_w;
-    } else if (g_kalman_order != 0 && batch >= 512 && n <= 64) {
+    } else if (opt().kalman_order != 0 && batch >= 512 && n <= 64) {
       if ((rc = launch_persistence_key(Tw, status_out, batch, n, key_w, st))) return rc;
       okey = key_w;
     }
@@ -556,7 +618,7 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
   // stream): a draw whose covariance recursion converges late -- or never, within the sample -- keeps ONE wavefront of the
   // Kalman launch busy for up to 200 full steps (1.5 ms) while the rest of the GPU has long finished; with two chunk
   // pipelines in flight that tail overlaps the cycle-reduction launch of the next chunk instead of being idle time.
-  if (g_pipeline_chunks < 2 || batch < 1024 || batch / g_pipeline_chunks < 256)
+  if (opt().pipeline_chunks < 2 || batch < 1024 || batch / opt().pipeline_chunks < 256)
     return pipeline(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
                     tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint, n_lead_hint, logp_out, status_out,
                     T_out, R_out, resid_out, n_iter_out, (hipStream_t)stream, 1, nullptr);
@@ -574,7 +636,7 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
     s_dev = dev_now;
   }
   hipStream_t caller = (hipStream_t)stream;
-  const int n_chunks = g_pipeline_chunks;
+  const int n_chunks = opt().pipeline_chunks;
   const int n_str = n_chunks < MAXS ? n_chunks : MAXS;
   const int per = ((batch + n_chunks - 1) / n_chunks + 63) & ~63;
   const size_t slice = (pipeline_scratch_bytes(per, n, k) + 255) & ~(size_t)255;
@@ -721,7 +783,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
         return rc;
       have_R = deflated != 0;
       if (!deflated) {
-        const bool fr = solver == DSGE_SOLVER_CYCLE_REDUCTION && g_cr_fuse_R;
+        const bool fr = solver == DSGE_SOLVER_CYCLE_REDUCTION && opt().cr_fused_selection;
         rc = launch_cr(Ac, Bc, Cc, nb, n, max_iter, tol, Tw, stc, it_w, st, solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION,
                        fr ? Dc : nullptr, k, fr ? Rw : nullptr);
         have_R = fr;
@@ -734,9 +796,9 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
                               Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))
       return rc;
     const int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;
-    if (g_kalman_order == 0) {
+    if (opt().kalman_order == 0) {
       gkey = nullptr;
-    } else if ((g_kalman_order == 2 || solver == DSGE_SOLVER_GENSYS) && nb >= 512) {
+    } else if ((opt().kalman_order == 2 || solver == DSGE_SOLVER_GENSYS) && nb >= 512) {
       if ((rc = launch_persistence_key(Tw, stc, nb, n, it_w, st))) return rc;  // (the iteration counts are not needed again)
       gkey = it_w;
     }
@@ -803,7 +865,7 @@ static int cr_host(const double* A, const double* B, const double* C, int batch,
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256((size_t)batch * 4) + 4096, &base))) return rc;
+  STAGE_RESERVE(4 * align256(nn * 8) + 2 * align256((size_t)batch * 4) + 4096, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -891,9 +953,7 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * (R_out ? k : 0);
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256(nk * 8) + 2 * align256((size_t)batch * 12) + 4096,
-                          &base)))
-    return rc;
+  STAGE_RESERVE(4 * align256(nn * 8) + 2 * align256(nk * 8) + 2 * align256((size_t)batch * 12) + 4096, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -927,9 +987,7 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, ne = (size_t)batch * 2 * n;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 3 * align256(nn * 8) + 2 * align256(ne * 8) + 4 * align256((size_t)batch * 4) + 4096,
-                          &base)))
-    return rc;
+  STAGE_RESERVE(3 * align256(nn * 8) + 2 * align256(ne * 8) + 4 * align256((size_t)batch * 4) + 4096, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -961,9 +1019,7 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256(nk * 8) + align256((size_t)batch * 8) + 4096,
-                          &base)))
-    return rc;
+  STAGE_RESERVE(4 * align256(nn * 8) + 2 * align256(nk * 8) + align256((size_t)batch * 8) + 4096, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -988,7 +1044,7 @@ int dsge_policy_adjoints_batched_host(const double* B, const double* C, const do
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 7 * align256(nn * 8) + align256((size_t)batch * 4) + 4096, &base))) return rc;
+  STAGE_RESERVE(7 * align256(nn * 8) + align256((size_t)batch * 4) + 4096, &base);
   Carver cv(base);
   UP(dB, B, nn, double);
   UP(dC, C, nn, double);
@@ -1019,10 +1075,8 @@ int dsge_policy_norms_batched_host(const double* A, const double* B, const doubl
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 4 * align256(nn * 8) + 2 * align256(nk * 8) + 2 * align256((size_t)batch * 8) +
-                                       align256((size_t)n * 4) + 4096,
-                          &base)))
-    return rc;
+  STAGE_RESERVE(4 * align256(nn * 8) + 2 * align256(nk * 8) + 2 * align256((size_t)batch * 8) +
+                                       align256((size_t)n * 4) + 4096, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -1050,7 +1104,7 @@ int dsge_backward_direct_batched_host(const double* A, const double* B, const do
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 3 * align256(nn * 8) + 2 * align256(nk * 8) + 4096, &base))) return rc;
+  STAGE_RESERVE(3 * align256(nn * 8) + 2 * align256(nk * 8) + 4096, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -1075,10 +1129,8 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
   if (batch == 0) return DSGE_SUCCESS;
   const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 3 * align256(mm * 8) + align256(mk * 8) + align256(nq * 8) +
-                                       align256((size_t)batch * 4) + 4096,
-                          &base)))
-    return rc;
+  STAGE_RESERVE(3 * align256(mm * 8) + align256(mk * 8) + align256(nq * 8) +
+                                       align256((size_t)batch * 4) + 4096, &base);
   Carver cv(base);
   UP(dT, T, mm, double);
   UP(dR, R, mk, double);
@@ -1116,12 +1168,10 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * m, nd = (size_t)(d_batched ? batch : 1) * p,
                nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 3 * align256(nn * 8) + align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+  STAGE_RESERVE(3 * align256(nn * 8) + align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
                                        align256(nd * 8) + align256(nh * 8) + align256(ny * 8 + 8) + align256(mm * 8) +
                                        align256(mk * 8) + 3 * align256((size_t)batch * 8) +
-                                       align256((size_t)n * 4) + 2 * align256((size_t)n_links * 4 + 4) + 8192,
-                          &base)))
-    return rc;
+                                       align256((size_t)n * 4) + 2 * align256((size_t)n_links * 4 + 4) + 8192, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -1173,12 +1223,10 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
                nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p, bp = (size_t)batch * p;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 6 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+  STAGE_RESERVE(6 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
                                        align256(nd * 8) + align256(nh * 8) + align256(ny * 8 + 8) +
                                        2 * align256(bp * 8) + align256((size_t)batch * k * 8) +
-                                       2 * align256((size_t)batch * 8) + 8192,
-                          &base)))
-    return rc;
+                                       2 * align256((size_t)batch * 8) + 8192, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
   UP(dB, B, nn, double);
@@ -1231,11 +1279,9 @@ int dsge_autocorrelation_batched_host(const double* T, const double* R, const do
   const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
   const size_t no = (size_t)batch * (n_lags + 1) * dim * dim;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage, 2 * align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(no * 8) +
+  STAGE_RESERVE(2 * align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(no * 8) +
                                        align256((size_t)p * m * 8) + align256((size_t)p * 8) +
-                                       align256((size_t)batch * 4) + 4096,
-                          &base)))
-    return rc;
+                                       align256((size_t)batch * 4) + 4096, &base);
   Carver cv(base);
   UP(dT, T, mm, double);
   UP(dR, R, mk, double);
@@ -1273,12 +1319,9 @@ int dsge_kalman_logp_batched_host(const double* T, const double* R, const double
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * m, nd = (size_t)(d_batched ? batch : 1) * p,
                nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage,
-                          align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(nz * 8) +
+  STAGE_RESERVE(align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(nz * 8) +
                               align256(nd * 8) + align256(nh * 8) + align256(ny * 8) + align256((size_t)batch * 8) +
-                              align256((size_t)batch * 4) + 4096,
-                          &base)))
-    return rc;
+                              align256((size_t)batch * 4) + 4096, &base);
   Carver cv(base);
   UP(dT, T, mm, double);
   UP(dR, R, mk, double);
@@ -1318,12 +1361,9 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
                nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p;
   void* base = nullptr;
-  if ((rc = arena_reserve(g_stage,
-                          4 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+  STAGE_RESERVE(4 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
                               align256(nd * 8) + align256(nh * 8) + align256(ny * 8) + 2 * align256((size_t)batch * 8) +
-                              2 * align256((size_t)batch * 4) + 8192,
-                          &base)))
-    return rc;
+                              2 * align256((size_t)batch * 4) + 8192, &base);
   Carver cv(base);
   // Shared inputs first (default stream), then the batch in chunks on two streams: while the kernels of chunk c run,
   // the host stages chunk c+1 (pageable memory: hipMemcpyAsync returns once the runtime has staged the buffer), so
@@ -1390,6 +1430,111 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   DOWN(n_iter_out, dI, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
+}
+
+// ---- per-call options (include/dsge_hip.h: dsge_options) --------------------------------------------------------------
+int dsge_options_init(dsge_options* o) {
+  if (!o) return fail(DSGE_ERR_INVALID, "null pointer");
+  const Options& d = g_defaults;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = (uint32_t)sizeof(dsge_options);
+  o->cr_compact = d.cr_compact;
+  o->cr_fused_selection = d.cr_fused_selection;
+  o->cr_deflation = d.cr_deflation;
+  o->cr_two_waves = d.cr_two_waves;
+  o->n_static_hint = d.n_static_hint;
+  o->kalman_order = d.kalman_order;
+  o->kalman_tiny = d.kalman_tiny;
+  o->kalman_block = d.kalman_block;
+  o->kalman_mfma = d.kalman_mfma;
+  o->pipeline_chunks = d.pipeline_chunks;
+  o->gensys_split = d.gensys_split;
+  o->kalman_steady_tol = d.kalman_steady_tol;
+  return DSGE_SUCCESS;
+}
+
+namespace {
+thread_local std::vector<OptionsGuard*> t_scope;  // dsge_options_push / dsge_options_pop of this thread
+}
+
+int dsge_options_push(const dsge_options* o) {
+  if (!o) return fail(DSGE_ERR_INVALID, "null pointer");
+  int rc = check_options(o);
+  if (rc) return rc;
+  t_scope.push_back(new OptionsGuard(o));
+  return DSGE_SUCCESS;
+}
+
+int dsge_options_pop(void) {
+  if (t_scope.empty()) return fail(DSGE_ERR_INVALID, "dsge_options_pop without a matching push on this thread");
+  delete t_scope.back();
+  t_scope.pop_back();
+  return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_batched_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                       const double* D, const double* Q, int q_mode, const double* Z, int z_batched,
+                                       const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y,
+                                       int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                                       double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
+                                       int n_lead_hint, double* logp_out, int32_t* status_out, double* T_out, double* R_out,
+                                       double* resid_out, int32_t* n_iter_out, void* stream) {
+  int rc = check_options(opt);
+  if (rc) return rc;
+  OptionsGuard guard(opt);
+  return dsge_solve_kalman_logp_batched(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p,
+                                        T_len, solver, tol, max_iter, jitter, missing_fill, n_state_hint, z_selector_hint,
+                                        n_lead_hint, logp_out, status_out, T_out, R_out, resid_out, n_iter_out, stream);
+}
+
+int dsge_solve_kalman_logp_batched_host_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                            const double* D, const double* Q, int q_mode, const double* Z, int z_batched,
+                                            const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                            const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol,
+                                            int max_iter, double jitter, double missing_fill, int n_state_hint,
+                                            int z_selector_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                            double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out) {
+  int rc = check_options(opt);
+  if (rc) return rc;
+  OptionsGuard guard(opt);
+  return dsge_solve_kalman_logp_batched_host(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n,
+                                             k, p, T_len, solver, tol, max_iter, jitter, missing_fill, n_state_hint,
+                                             z_selector_hint, n_lead_hint, logp_out, status_out, T_out, R_out, resid_out,
+                                             n_iter_out);
+}
+
+int dsge_solve_kalman_logp_grad_batched_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                            const double* D, const double* q, int q_batched, const double* Z, int z_batched,
+                                            const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                            const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol,
+                                            int max_iter, double jitter, double missing_fill, int n_filter_hint,
+                                            int n_lead_hint, double* logp_out, int32_t* status_out, double* A_bar,
+                                            double* B_bar, double* C_bar, double* D_bar, double* q_bar, double* d_bar,
+                                            double* h_bar, void* stream) {
+  int rc = check_options(opt);
+  if (rc) return rc;
+  OptionsGuard guard(opt);
+  return dsge_solve_kalman_logp_grad_batched(A, B, C, D, q, q_batched, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n,
+                                             k, p, T_len, solver, tol, max_iter, jitter, missing_fill, n_filter_hint,
+                                             n_lead_hint, logp_out, status_out, A_bar, B_bar, C_bar, D_bar, q_bar, d_bar, h_bar,
+                                             stream);
+}
+
+int dsge_solve_kalman_logp_grad_batched_host_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                                 const double* D, const double* q, int q_batched, const double* Z,
+                                                 int z_batched, const double* d, int d_batched, const double* Hdiag,
+                                                 int h_batched, const double* y, int batch, int n, int k, int p, int T_len,
+                                                 int solver, double tol, int max_iter, double jitter, double missing_fill,
+                                                 int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                                 double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                                                 double* d_bar, double* h_bar) {
+  int rc = check_options(opt);
+  if (rc) return rc;
+  OptionsGuard guard(opt);
+  return dsge_solve_kalman_logp_grad_batched_host(A, B, C, D, q, q_batched, Z, z_batched, d, d_batched, Hdiag, h_batched, y,
+                                                  batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
+                                                  n_filter_hint, n_lead_hint, logp_out, status_out, A_bar, B_bar, C_bar, D_bar,
+                                                  q_bar, d_bar, h_bar);
 }
 
 }  // extern "C"

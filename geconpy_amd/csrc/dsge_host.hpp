@@ -101,18 +101,30 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
                      hipStream_t st);
 
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
-extern int g_cr_occ2;                 // launch_solvers.hip: 4 x 4-tile compact kernel at two waves per SIMD
-extern int g_cr_deflate;              // launch_solvers.hip: 0 = no static-variable deflation
-extern int g_cr_compact;              // launch_solvers.hip: 0 = dense cycle-reduction kernel only
-// process-wide settings of the fast Kalman kernel (launch_kalman.hip)
-extern long long* g_kalman_dbg;       // debug: device buffer for per-phase cycles of draw 0
-extern double g_kalman_steady_tol;    // steady-state switch (0 = never switch)
-extern int g_kalman_order;            // launch_kalman.hip: 0 = index order
-extern int g_kalman_block;            // launch_kalman.hip: 0 = steady-state steps one by one
-extern int g_kalman_mfma;             // launch_kalman.hip: 0 = VALU products only
-extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[24])
-extern int g_gensys_split;           // launch_gensys.hip: 1 = window path (three launches), 0 = single-launch kernel
-extern int g_kalman_tiny;             // 0 = never use the thread-per-draw small-model kernel
+extern long long* g_kalman_dbg;       // launch_kalman.hip: debug buffer for per-phase cycles of draw 0
+extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[32])
 extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first steady step per draw (-1 = never)
+
+// Kernel-variant switches.  They are PER CALL: the *_opt entry points carry a dsge_options, which an RAII guard installs
+// for the duration of the call on the calling thread (launching is synchronous on the host, every kernel argument is
+// passed by value at launch), so two host threads -- two PyMC chains, two streams -- never see each other's settings.
+// The dsge_set_* functions only edit the process-wide DEFAULTS that calls without options use.
+struct Options {
+  int cr_compact = 1;          // 0 = dense cycle-reduction kernel only
+  int cr_fused_selection = 1;  // fused pipeline: R from the cycle-reduction kernel's final elimination
+  int cr_deflation = 1;        // static-variable deflation in front of cycle reduction
+  int cr_two_waves = 1;        // 4 x 4-tile compact kernel built for two waves per SIMD
+  int n_static_hint = -1;      // static variables (zero columns of A and C): -1 = measure on the device, >= 0 caller's bound
+  int kalman_order = 1;        // Kalman workgroups slow-draws-first (1 = CR iteration count / persistence key, 2 = key, 0 = index)
+  int kalman_tiny = 1;         // thread-per-draw kernel for small models
+  int kalman_block = 0;        // steady tail handed to kalman_tail_kernel
+  int kalman_mfma = 0;         // prediction products on the FP64 matrix core
+  int pipeline_chunks = 0;     // fused device call in chunks over library-owned streams
+  int gensys_split = 1;        // 0 = single-launch gensys kernel, 1 = window path unless small, 2 = always
+  double kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never)
+};
+extern Options g_defaults;
+extern thread_local const Options* t_call_options;
+inline const Options& opt() { return t_call_options ? *t_call_options : g_defaults; }
 
 }  // namespace dsge_host

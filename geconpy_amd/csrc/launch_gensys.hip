@@ -8,7 +8,6 @@
 namespace dsge_host {
 
 long long* g_gensys_win_dbg = nullptr;  // debug: device int64[32], phase stamps of draw 0 of the window kernels
-int g_gensys_split = 1;  // 0 = single-launch kernel, 1 = window path (dsge_gensys_win.hpp) unless the pencil is small, 2 = always
 
 namespace {
 struct GwArena {
@@ -161,7 +160,7 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
     int nc = 0, lc = 0;
     if (gensys_caps(n, n_lead_hint, &nc, &lc) == DSGE_SUCCESS) small = dsge::gensys_smem_bytes(n, nc, lc) <= 24 * 1024;
   }
-  if (g_gensys_split && !dbg && (!small || g_gensys_split == 2)) {
+  if (opt().gensys_split && !dbg && (!small || opt().gensys_split == 2)) {
     int used = 0;
     if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used))) return rc;
     if (used) return DSGE_SUCCESS;

@@ -10,13 +10,8 @@
 namespace dsge_host {
 
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
-int g_kalman_order = 1;  // Kalman workgroups in descending order of a key: 1 = cycle-reduction iterations (persistence key of T for the other solvers), 2 = always the persistence key, 0 = index order
-int g_kalman_block = 0;  // 1 = hand the steady, constant-mask tail of the sample to kalman_tail_kernel (measured slower)
-double g_kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never switch)
 int32_t* g_kalman_steady_at = nullptr;
-int g_kalman_mfma = 0;  // 1 = prediction products of the BS = 2, 3 selector instances on the FP64 matrix core
                        // (experimental: measured SLOWER than the VALU register blocks)
-int g_kalman_tiny = 1;  // 0 = never use the thread-per-draw kernel (tests compare the two paths)  // debug: device buffer [batch], first steady step per draw (-1 = never)
 
 namespace {
 // hand-off records of the fast kernel for kalman_tail_kernel: one buffer per (device, stream), grown on demand
@@ -91,15 +86,15 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   bool launched_fast = false;
   // Small models (reduced filter of at most 6 variables, p <= 3, selector Z): one thread per draw, all in
   // registers.  Draws that do not fit are flagged and fall through to the wave-per-draw cascade below.
-  if (g_kalman_tiny && z_selector_hint && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) {
+  if (opt().kalman_tiny && z_selector_hint && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) {
     const int blocks = (batch + 63) / 64;
     if (n_state_hint + p <= 4) {
       hipLaunchKernelGGL((dsge::kalman_tiny_kernel<4, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, g_kalman_steady_tol, logp, status,
+                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, opt().kalman_steady_tol, logp, status,
                          g_kalman_steady_at);
     } else {
       hipLaunchKernelGGL((dsge::kalman_tiny_kernel<6, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, g_kalman_steady_tol, logp, status,
+                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, opt().kalman_steady_tol, logp, status,
                          g_kalman_steady_at);
     }
     HIP_TRY(hipGetLastError());
@@ -111,8 +106,8 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   int32_t* tail_flag = nullptr;
   int32_t* tail_from = nullptr;
   int32_t* order = nullptr;
-  const bool want_tail = fast && z_selector_hint && g_kalman_block && T_len >= 8;
-  const bool want_order = fast && order_key && g_kalman_order && batch >= 512;
+  const bool want_tail = fast && z_selector_hint && opt().kalman_block && T_len >= 8;
+  const bool want_order = fast && order_key && opt().kalman_order && batch >= 512;
   if (want_tail || want_order) {
     void* base = nullptr;
     const size_t rec_bytes = want_tail ? (size_t)batch * dsge::KT_REC * sizeof(double) : 0;
@@ -159,12 +154,12 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
           const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
           bool done = false;
           if constexpr (BS == 2 || BS == 3) {
-            if (g_kalman_mfma) {  // prediction products on the FP64 matrix core
+            if (opt().kalman_mfma) {  // prediction products on the FP64 matrix core
               rc = set_lds(dsge::kalman_sel_kernel<BS, true, true>, lds);
               if (rc == DSGE_SUCCESS) {
                 hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                    p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p,
-                                   T_len, s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                   T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                    g_kalman_steady_at, nullptr, nullptr, nullptr, order);
                 HIP_TRY(hipGetLastError());
                 launched_fast = true;
@@ -177,7 +172,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, false, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
-                                 s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
@@ -189,7 +184,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
-                                 s_cap, jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, nullptr, nullptr, nullptr, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
@@ -204,7 +199,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
-                                 jitter, missing_fill, g_kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, nullptr, nullptr, nullptr, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;

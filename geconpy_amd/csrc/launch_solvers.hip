@@ -9,10 +9,8 @@
 
 namespace dsge_host {
 
-int g_cr_compact = 1;  // 0 = dense kernel only (tests compare the two paths)
 long long* g_cr_dbg = nullptr;  // debug: device int64[8], phase cycles of draw 0 of the compact kernel
 
-int g_cr_occ2 = 1;  // 4 x 4-tile compact kernel built for two waves per SIMD (dsge_set_cr_two_waves)
 
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode, const double* D, int k,
@@ -21,10 +19,10 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
   int rc = DSGE_ERR_INVALID;
   // Column-compact kernel first (zero columns of A and C dropped); it flags the draws whose
   // s + l exceeds the tile, and the dense kernel then runs on exactly those.
-  const bool compact = g_cr_compact != 0;
+  const bool compact = opt().cr_compact != 0;
   if (compact) {
     DISPATCH_BS(bs, 8, {
-      if (BS == 4 && g_cr_occ2) {
+      if (BS == 4 && opt().cr_two_waves) {
         rc = set_lds(dsge::cr_compact_kernel_occ2<4>, dsge::CrcSmem<4>::bytes);
         if (rc == DSGE_SUCCESS) {
           hipLaunchKernelGGL(dsge::cr_compact_kernel_occ2<4>, dim3(batch), dim3(64), dsge::CrcSmem<4>::bytes, st, A, B, C,
@@ -55,7 +53,6 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
 }
 
 // ---- cycle reduction behind the static-variable deflation (dsge_cr_deflate.hpp) -----------------------------------------
-int g_cr_deflate = 1;  // 0 = always the full-size system
 
 namespace {
 std::mutex g_defl_mutex;
@@ -70,7 +67,9 @@ struct DeflArena {
 };
 DeflArena g_defl_arena[16][16];
 
+std::mutex g_defl_arena_mutex;
 int defl_reserve(size_t bytes, hipStream_t st, void** out) {
+  std::lock_guard<std::mutex> lk(g_defl_arena_mutex);
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
@@ -115,31 +114,38 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
                        int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
                        hipStream_t st, int* used) {
   *used = 0;
-  if (!g_cr_deflate || !D || !R_out || n < 8 || n > 64 || batch < 1) return DSGE_SUCCESS;
-  std::lock_guard<std::mutex> lk(g_defl_mutex);
-  if (!g_static_hint_init) {
-    for (auto& x : g_static_hint) x = 0;
-    for (auto& x : g_static_calls) x = 0;
-    g_static_hint_init = true;
-  }
+  if (!opt().cr_deflation || !D || !R_out || n < 8 || n > 64 || batch < 1) return DSGE_SUCCESS;
   int rc;
   void* base = nullptr;
-  // first batch of this model size: measure (one small launch and a 4-byte read-back); every 256th call after that
-  // measures again and keeps the minimum, so that an unrepresentative first batch (more static variables than the later
-  // ones have: every later draw would be flagged and solved at full size) corrects itself
-  const bool remeasure = g_static_hint[n] != 0 && (++g_static_calls[n] & 255) == 0;
-  if (g_static_hint[n] == 0 || remeasure) {
-    if ((rc = defl_reserve(256, st, &base))) return rc;
-    int32_t hmin = n;
-    HIP_TRY(hipMemcpyAsync(base, &hmin, sizeof(hmin), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(dsge::cr_static_scan_kernel, dim3(batch < 4096 ? batch : 4096), dim3(64), 0, st, A, C, batch, n,
-                       (int32_t*)base);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&hmin, base, sizeof(hmin), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    g_static_hint[n] = (remeasure && g_static_hint[n] - 1 < hmin) ? g_static_hint[n] : hmin + 1;
+  int h;
+  if (opt().n_static_hint >= 0) {
+    // the caller's bound (a property of the model, computed once on the host like n_state_hint): nothing is measured, no
+    // read-back, no synchronisation -- the call only enqueues; a draw with fewer static variables is caught on the device
+    h = std::min(opt().n_static_hint, (int)dsge::CRD_HMAX);
+  } else {
+    std::lock_guard<std::mutex> lk(g_defl_mutex);
+    if (!g_static_hint_init) {
+      for (auto& x : g_static_hint) x = 0;
+      for (auto& x : g_static_calls) x = 0;
+      g_static_hint_init = true;
+    }
+    // n_static_hint = -1: first batch of this model size measures (one small launch and a 4-byte read-back, which
+    // synchronises the stream); every 256th call after that measures again and keeps the minimum, so that an
+    // unrepresentative first batch corrects itself.  Callers that need a pure enqueue pass the hint.
+    const bool remeasure = g_static_hint[n] != 0 && (++g_static_calls[n] & 255) == 0;
+    if (g_static_hint[n] == 0 || remeasure) {
+      if ((rc = defl_reserve(256, st, &base))) return rc;
+      int32_t hmin = n;
+      HIP_TRY(hipMemcpyAsync(base, &hmin, sizeof(hmin), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(dsge::cr_static_scan_kernel, dim3(batch < 4096 ? batch : 4096), dim3(64), 0, st, A, C, batch, n,
+                         (int32_t*)base);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&hmin, base, sizeof(hmin), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      g_static_hint[n] = (remeasure && g_static_hint[n] - 1 < hmin) ? g_static_hint[n] : hmin + 1;
+    }
+    h = std::min(g_static_hint[n] - 1, (int)dsge::CRD_HMAX);
   }
-  const int h = std::min(g_static_hint[n] - 1, (int)dsge::CRD_HMAX);
   const int nd = n - h;
   // worth it only when the reduced system drops to a smaller register-block tile or loses a fifth of its variables
   if (h < 1 || nd < 4 || (tile_bs(nd) == tile_bs(n) && 5 * h < n)) return DSGE_SUCCESS;

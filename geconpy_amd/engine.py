@@ -91,6 +91,15 @@ class LogpEngine:
         sel = bool(((nz.sum(dim=2) == 1).all() & (nz.sum(dim=1) <= 1).all()).item())
         return n_state, int(sel)
 
+    def static_hint(self, A, C):
+        """``dsge_options.n_static_hint`` from device tensors: variables whose columns of A and C are exactly zero in
+        every draw (one reduction + host sync; a property of the model: call once).  With it the fused call is a pure
+        enqueue -- no measuring launch, no read-back inside the library."""
+        torch = self.torch
+        n = A.shape[-1]
+        nz = (A != 0).reshape(-1, n).any(dim=0) | (C != 0).reshape(-1, n).any(dim=0)
+        return int(n - torch.count_nonzero(nz).item())
+
     def record_steady_steps(self, buf):
         """Debug: ``buf`` (int32 CUDA tensor [batch]) receives, from the fast-path Kalman launches that
         follow, the first time step each draw ran in steady-state mode (-1 = never); ``None`` stops."""
@@ -148,7 +157,7 @@ class LogpEngine:
     def solve_kalman_logp(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                           tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
                           logp=None, status=None, n_state_hint=0, z_selector_hint=0, n_lead_hint=0, T_out=None,
-                          R_out=None):
+                          R_out=None, options=None):
         """Enqueue one fused evaluation of the whole batch; returns (logp, status) tensors
         (asynchronous: synchronize the stream before reading them on the host).  ``T_out`` [batch][n][n] /
         ``R_out`` [batch][n][k]: optional float64 CUDA tensors that receive the policy matrices."""
@@ -158,9 +167,10 @@ class LogpEngine:
             logp = torch.empty(nb, dtype=torch.float64, device=self.device)
         if status is None:
             status = torch.empty(nb, dtype=torch.int32, device=self.device)
+        op, _keep = _lib.opt_ptr(options)
         _lib.check(
-            self.lib.dsge_solve_kalman_logp_batched(
-                self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
+            self.lib.dsge_solve_kalman_logp_batched_opt(
+                op, self._p(A), self._p(B), self._p(C), self._p(D), self._p(Q), qm, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol),
                 int(max_iter), float(jitter), float(missing_fill_value), int(n_state_hint), int(z_selector_hint),
                 int(n_lead_hint), self._p(logp), status.data_ptr(), self._p(T_out), self._p(R_out), None, None,
@@ -171,7 +181,7 @@ class LogpEngine:
 
     def solve_kalman_logp_grad(self, A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
                                jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=0, n_lead_hint=0,
-                               out=None):
+                               out=None, options=None):
         """logp and its reverse-mode gradient for the whole batch, device-resident (dsge_solve_kalman_logp_grad_batched).
         ``q``: (k,) or (batch, k) diagonal shock variances.  Returns a dict of tensors: logp, status, A_bar, B_bar, C_bar,
         D_bar, q_bar[, d_bar][, h_bar] (asynchronous).  ``out`` may carry the same dict from an earlier call to reuse
@@ -198,9 +208,10 @@ class LogpEngine:
                 out["d_bar"] = mk(nb, p)
             if Hdiag is not None:
                 out["h_bar"] = mk(nb, p)
+        op, _keep = _lib.opt_ptr(options)
         _lib.check(
-            self.lib.dsge_solve_kalman_logp_grad_batched(
-                self._p(A), self._p(B), self._p(C), self._p(D), self._p(q), int(q.dim() == 2), self._p(Z), zb, self._p(d), db,
+            self.lib.dsge_solve_kalman_logp_grad_batched_opt(
+                op, self._p(A), self._p(B), self._p(C), self._p(D), self._p(q), int(q.dim() == 2), self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter),
                 float(jitter), float(missing_fill_value), int(n_filter_hint), int(n_lead_hint), self._p(out["logp"]),
                 out["status"].data_ptr(), self._p(out["A_bar"]), self._p(out["B_bar"]), self._p(out["C_bar"]),

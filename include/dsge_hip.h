@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 2
+#define DSGE_ABI_VERSION 3
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
@@ -105,16 +105,54 @@ int dsge_scan_cycle_reduction_batched(const double* A, const double* B, const do
 int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, const double* C, int batch, int n,
                                            int max_iter, double tol, double* T_out, int32_t* status,
                                            int32_t* n_steps);
+/*
+ * Per-call options ("re-entrant per stream").  Every kernel-variant switch of the library is a field
+ * of this struct.  Calls that carry a dsge_options -- the *_opt twins of the fused entry points, or any entry point
+ * called between dsge_options_push() and dsge_options_pop() on the same host thread -- use exactly those settings:
+ * they are installed for the duration of the call on the calling thread only, so two host threads (two PyMC / nutpie
+ * chains, two pytensor Ops, two streams) never see each other's settings.  The dsge_set_* functions below only edit
+ * the process-wide DEFAULTS that calls without options use (configure-once; dsge_options_init() copies them).
+ *   struct_size        : sizeof(dsge_options) of the caller's build (set by dsge_options_init; checked)
+ *   cr_compact         : see dsge_set_cr_compact            cr_fused_selection : see dsge_set_cr_fused_selection
+ *   cr_deflation       : see dsge_set_cr_deflation          cr_two_waves       : see dsge_set_cr_two_waves
+ *   n_static_hint      : number of static variables of the model (columns of A and C both exactly zero), a property of
+ *                        the model like n_state_hint, verified per draw on the device; with a value >= 0 the fused call
+ *                        is a pure enqueue (stream-capturable); -1 (default) measures it on the device on the first
+ *                        call of a model size: one small launch, a 4-byte read-back and a stream synchronisation
+ *   kalman_order, kalman_tiny, kalman_block, kalman_mfma, pipeline_chunks, gensys_split, kalman_steady_tol :
+ *                        see the dsge_set_* function of the same name
+ */
+typedef struct dsge_options {
+  uint32_t struct_size;
+  int32_t cr_compact;
+  int32_t cr_fused_selection;
+  int32_t cr_deflation;
+  int32_t cr_two_waves;
+  int32_t n_static_hint;
+  int32_t kalman_order;
+  int32_t kalman_tiny;
+  int32_t kalman_block;
+  int32_t kalman_mfma;
+  int32_t pipeline_chunks;
+  int32_t gensys_split;
+  double kalman_steady_tol;
+} dsge_options;
+/* fills *opt with the current process-wide defaults */
+int dsge_options_init(dsge_options* opt);
+/* install / remove *opt for the calls THIS host thread makes in between (nests; copied, the caller may free it) */
+int dsge_options_push(const dsge_options* opt);
+int dsge_options_pop(void);
+
 /* Cycle reduction runs on the column-compact form [A[:,S] | C[:,L]] (S, L = non-zero columns of A and C,
  * detected per draw on the device; zero columns only ever contribute +0.0, so T is bit-identical) whenever
  * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every
- * draw (used by the tests to compare the two).  Process-wide; default 1. */
+ * draw (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
 int dsge_set_cr_compact(int enable);
 /* In the fused entry points with solver = cycle_reduction and no residual requested, R = -(C T + B)^-1 D is taken
  * from the final elimination of cycle reduction: T = -A1_hat^-1 A and A1_hat -> B + C T (the difference is of the
  * order of the product of the last iterate's norms, < tol^2), so R = -A1_hat^-1 D comes out of the same Gauss-Jordan
  * sweep (agreement with the explicit formula ~1e-13 relative, tests/test_gpu_parity.py).  enable = 0 always uses the
- * explicit formula in the assemble kernel.  Process-wide; default 1. */
+ * explicit formula in the assemble kernel.  Process-wide DEFAULT (per call: dsge_options); default 1. */
 int dsge_set_cr_fused_selection(int enable);
 /* Debug hook: enable != 0 makes the compact cycle-reduction kernel record the shader cycles draw 0 spends in
  * [0] Gauss-Jordan panels, [1] trailing updates, [2] row gather + staging, [3] products, [4] scatter/updates/
@@ -167,12 +205,12 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
  * missing-data mask stays the same) the kernel reuses F^-1, K and det F and runs only the mean
  * recursion; a step with a different mask resumes the full update.  tol = 0 never switches (the
  * recursion of pymc_extras' "standard" filter step for step); the default 1e-14 is rounding level:
- * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  Process-wide setting.  tol in [0, 1e-6].
+ * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  Process-wide DEFAULT (per call: dsge_options).  tol in [0, 1e-6].
  */
 int dsge_set_kalman_steady_tol(double tol);
 /* Small models (selector Z, p <= 3, at most 6 filtered variables) are filtered by a thread-per-draw kernel that keeps
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
- * wave-per-draw kernels (used by the tests to compare the two).  Process-wide; default 1. */
+ * wave-per-draw kernels (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
 int dsge_set_kalman_tiny(int enable);
 /* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
  * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
@@ -180,11 +218,11 @@ int dsge_set_kalman_tiny(int enable);
  * back-substitution (dsge_cr_deflate.hpp).  Same solution (it is unique), (n - h)^3 instead of n^3 work per iteration.
  * h is measured once per model size (a small launch and a 4-byte read-back on the first call) and verified per draw; a
  * draw with fewer static variables is solved by the full-size kernels.  Not used when the caller asks for the iteration
- * counts or the policy residual.  enable = 0 switches it off and forgets the measured sizes.  Default on.  Process-wide. */
+ * counts or the policy residual.  enable = 0 switches it off and forgets the measured sizes.  Default on.  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_cr_deflation(int enable);
 /* Column-compact cycle reduction on the 32-wide tile (n or n - h in 25..32): the kernel instance built for two waves per SIMD
  * (256 registers + 528 B of scratch instead of 369 registers): same arithmetic, bit-identical results, 10 % faster.
- * enable = 0 launches the one-wave instance.  Default on.  Process-wide. */
+ * enable = 0 launches the one-wave instance.  Default on.  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_cr_two_waves(int enable);
 /* Fused evaluation: the workgroups of the Kalman launch (and of the gradient path's reverse-sweep launch) are dispatched in
  * descending order of a per-draw key (a counting sort on the device).  The launch's makespan is set by its slowest draws --
@@ -199,28 +237,28 @@ int dsge_set_kalman_order(int mode);
  * chunk's Kalman launch (a draw whose covariance recursion converges late keeps one wavefront busy for up to T_len full
  * steps) overlaps the solver launch of the next chunk.  Results are identical (the kernels are per-draw).  n_chunks < 2:
  * one pass on the caller's stream (the default: on MI355X the chunks' launches did not overlap enough to pay for the
- * extra straggler tails).  Process-wide. */
+ * extra straggler tails).  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_pipeline_chunks(int n_chunks);
 /* Experimental, OFF by default: once the covariance is frozen and the missing-data mask of the shared panel no longer
  * changes, the fast Kalman kernel hands the rest of the sample to kalman_tail_kernel, which runs the (then linear) mean
  * recursion two steps at a time as one matrix-vector product [R v_t; R v_{t+1}; a_{t+2}] = M [a_t; c_t; c_{t+1}], R'R = F^-1,
  * rows in registers.  It removes a quarter of the kernel's work but not its makespan, which is set by the draws that reach
  * the steady state late or never -- measured 3.14 vs 2.85 ms per 4096 draws with the launch's extra 0.26 ms (DESIGN.md
- * 4.3).  enable = 1 switches it on (tests compare both: same logp to 1e-12).  Process-wide. */
+ * 4.3).  enable = 1 switches it on (tests compare both: same logp to 1e-12).  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_kalman_block(int enable);
 /* gensys runs as five launches on the active window of the pencil -- structural deflation; real Hessenberg-triangular
  * reduction and complex QZ + reordering on the (N - z) x (N - z) block the deflation leaves, with H and T sharing one LDS
  * array and the accumulated right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing --
  * 4 / 6 / 6-7 / 10 / 2 draws per CU instead of 1 at N = 52.  enable = 1
  * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
- * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide. */
+ * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_gensys_split(int enable);
 /* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
  * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
  * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
  * per 4096-draw step) -- FP64 MFMA has the VALU's peak rate on gfx950, the 18-wide reduced model does not fill a
  * 16 x 16 fragment, and the accumulator + operand registers push the 256-VGPR kernel into spills.
- * enable = 1 switches it on (tests compare both).  Process-wide. */
+ * enable = 1 switches it on (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_kalman_mfma(int enable);
 double dsge_get_kalman_steady_tol(void);
 /* Debug hook: device int32[batch] that later fast-path Kalman launches fill with the first time step
@@ -460,6 +498,44 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
                                              int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
                                              double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
                                              double* d_bar, double* h_bar);
+
+/*
+ * The fused entry points with per-call options (opt == NULL: the process-wide defaults); otherwise identical to the
+ * functions of the same name without the suffix.
+ */
+int dsge_solve_kalman_logp_batched_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                       const double* D, const double* Q, int q_mode, const double* Z, int z_batched,
+                                       const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                       const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                       double tol, int max_iter, double jitter, double missing_fill, int n_state_hint,
+                                       int z_selector_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                       double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out,
+                                       void* stream);
+int dsge_solve_kalman_logp_batched_host_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                            const double* D, const double* Q, int q_mode, const double* Z,
+                                            int z_batched, const double* d, int d_batched, const double* Hdiag,
+                                            int h_batched, const double* y, int batch, int n, int k, int p, int T_len,
+                                            int solver, double tol, int max_iter, double jitter, double missing_fill,
+                                            int n_state_hint, int z_selector_hint, int n_lead_hint, double* logp_out,
+                                            int32_t* status_out, double* T_out, double* R_out, double* resid_out,
+                                            int32_t* n_iter_out);
+int dsge_solve_kalman_logp_grad_batched_opt(const dsge_options* opt, const double* A, const double* B, const double* C,
+                                            const double* D, const double* q, int q_batched, const double* Z,
+                                            int z_batched, const double* d, int d_batched, const double* Hdiag,
+                                            int h_batched, const double* y, int batch, int n, int k, int p, int T_len,
+                                            int solver, double tol, int max_iter, double jitter, double missing_fill,
+                                            int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                            double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                                            double* d_bar, double* h_bar, void* stream);
+int dsge_solve_kalman_logp_grad_batched_host_opt(const dsge_options* opt, const double* A, const double* B,
+                                                 const double* C, const double* D, const double* q, int q_batched,
+                                                 const double* Z, int z_batched, const double* d, int d_batched,
+                                                 const double* Hdiag, int h_batched, const double* y, int batch, int n,
+                                                 int k, int p, int T_len, int solver, double tol, int max_iter,
+                                                 double jitter, double missing_fill, int n_filter_hint, int n_lead_hint,
+                                                 double* logp_out, int32_t* status_out, double* A_bar, double* B_bar,
+                                                 double* C_bar, double* D_bar, double* q_bar, double* d_bar,
+                                                 double* h_bar);
 
 /*
  * Timing hook for bench.py: runs `reps` back-to-back launches of the fused pipeline's

@@ -115,3 +115,37 @@ def test_draw_seeding_is_shard_independent():
     for x in "ABCD":
         assert np.array_equal(full[x][3:], part[x])
     assert np.array_equal(full["sigma"][3:], part["sigma"])
+
+
+def test_options_struct_defaults_and_scope():
+    """dsge_options (per-call switches): init copies the process-wide defaults, unknown fields are refused, the
+    push/pop scope is balanced per thread -- no GPU needed."""
+    import ctypes
+
+    lib = _lib.load()
+    o = _lib.make_options()
+    assert o.struct_size == ctypes.sizeof(_lib.Options)
+    assert (o.cr_compact, o.cr_fused_selection, o.cr_deflation, o.cr_two_waves) == (1, 1, 1, 1)
+    assert (o.kalman_order, o.kalman_tiny, o.kalman_block, o.kalman_mfma, o.pipeline_chunks, o.gensys_split) == (1, 1, 0, 0, 0, 1)
+    assert o.n_static_hint == -1 and o.kalman_steady_tol == 1e-14
+    o2 = _lib.make_options({"kalman_steady_tol": 0.0}, n_static_hint=10)
+    assert o2.kalman_steady_tol == 0.0 and o2.n_static_hint == 10 and o2.cr_compact == 1
+    with pytest.raises(ValueError):
+        _lib.make_options(no_such_switch=1)
+    assert lib.dsge_options_pop() != 0  # nothing pushed on this thread
+    with _lib.options_scope({"cr_compact": 0}):
+        with _lib.options_scope({"kalman_order": 2}):
+            pass
+    assert lib.dsge_options_pop() != 0
+    bad = _lib.make_options()
+    bad.kalman_steady_tol = 1.0
+    assert lib.dsge_options_push(ctypes.addressof(bad)) != 0
+    bad.kalman_steady_tol = 1e-14
+    bad.struct_size = 8
+    assert lib.dsge_options_push(ctypes.addressof(bad)) != 0
+    # the setters edit the defaults new option structs start from
+    lib.dsge_set_kalman_steady_tol(1e-12)
+    try:
+        assert _lib.make_options().kalman_steady_tol == 1e-12
+    finally:
+        lib.dsge_set_kalman_steady_tol(1e-14)

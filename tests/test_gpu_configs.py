@@ -22,13 +22,17 @@ import pytest
 from numpy.testing import assert_allclose
 
 import oracle
-from conftest import load_golden
 from geconpy_amd import batched
 from geconpy_amd import workloads as wl
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name))
+
 LOGP_RTOL = 1e-8
 
 
