@@ -189,7 +189,7 @@ def shard_bounds(batch, world_size, rank):
 def rbc_batch(batch, first_draw=0, seed=1, T_len=200):
     """BASELINE.json configs[1]: the RBC model at ``batch`` seeded prior draws (closed-form Jacobians),
     observed series Y, T_len periods of data default_rng(0).normal(0, 0.05).  Same dict layout as
-    ``sw_shaped_batch`` + observation model; draw i is the same system whichever shard asks for it."""
+    ``sw_shaped_batch`` + observation model; draw i of the GLOBAL batch `first_draw + batch` (the prior draws of a batch depend on its total size)."""
     th = rbc_prior_draws(first_draw + batch, seed=seed)
     th = {k_: v[first_draw:] for k_, v in th.items()}
     A, B, C, D = rbc_linearized_jacobians(**th)

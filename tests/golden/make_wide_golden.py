@@ -60,8 +60,8 @@ def _sw_one(i):
 def _rbc_one(i):
     from geconpy_amd import workloads as wl
 
-    b, om = wl.rbc_batch(1, first_draw=i)
-    return _logps(b["A"][0], b["B"][0], b["C"][0], b["D"][0], np.diag(b["sigma"][0] ** 2), om["Z"], om["y"],
+    b, om = wl.rbc_batch(4096)  # (the prior draws of the batch depend on its size: index into THE 4096-draw batch)
+    return _logps(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(b["sigma"][i] ** 2), om["Z"], om["y"],
                   np.diag(om["Hdiag"]))
 
 
@@ -72,22 +72,24 @@ def main():
     sw_idx = np.array(list(range(496)) + list(EXTRA_SW))
     rbc_idx = np.arange(0, 4096, 64) + (np.arange(64) % 7)
     with mp.get_context("spawn").Pool(os.cpu_count()) as pool:
-        sw = pool.map(_sw_one, sw_idx.tolist(), chunksize=4)
+        sw = pool.map(_sw_one, sw_idx.tolist(), chunksize=4) if "--rbc-only" not in sys.argv else None
         rbc = pool.map(_rbc_one, rbc_idx.tolist(), chunksize=4)
+    br, _ = wl.rbc_batch(4096)
+    np.savez_compressed(os.path.join(HERE, "rbc_wide.npz"), draw_idx=rbc_idx,
+                        input_checksum_first8=np.array([np.abs(br[x][:8]).sum() for x in "ABCD"]),
+                        ref_cr_logp=np.array([r[0] for r in rbc]), ref_gensys_logp=np.array([r[1] for r in rbc]),
+                        ref_cr_iters=np.array([r[2] for r in rbc]))
+    a = np.array([r[:2] for r in rbc])
+    print("rbc: cr vs gensys max rel", np.max(np.abs(a[:, 0] - a[:, 1]) / np.abs(a[:, 0])), "iters", np.unique([r[2] for r in rbc]))
+    if sw is None:
+        return
     b = wl.sw_shaped_batch(8)
     chk = np.array([np.abs(b[x]).sum() for x in "ABCD"])
     np.savez_compressed(os.path.join(HERE, "sw_shaped_wide.npz"), draw_idx=sw_idx, input_checksum_first8=chk,
                         ref_cr_logp=np.array([r[0] for r in sw]), ref_gensys_logp=np.array([r[1] for r in sw]),
                         ref_cr_iters=np.array([r[2] for r in sw]))
-    br, _ = wl.rbc_batch(8)
-    np.savez_compressed(os.path.join(HERE, "rbc_wide.npz"), draw_idx=rbc_idx,
-                        input_checksum_first8=np.array([np.abs(br[x]).sum() for x in "ABCD"]),
-                        ref_cr_logp=np.array([r[0] for r in rbc]), ref_gensys_logp=np.array([r[1] for r in rbc]),
-                        ref_cr_iters=np.array([r[2] for r in rbc]))
     a = np.array([r[:2] for r in sw])
     print("sw: cr vs gensys max rel", np.max(np.abs(a[:, 0] - a[:, 1]) / np.abs(a[:, 0])), "iters", np.unique([r[2] for r in sw]))
-    a = np.array([r[:2] for r in rbc])
-    print("rbc: cr vs gensys max rel", np.max(np.abs(a[:, 0] - a[:, 1]) / np.abs(a[:, 0])), "iters", np.unique([r[2] for r in rbc]))
 
 
 if __name__ == "__main__":
