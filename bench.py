@@ -102,6 +102,90 @@ def cpu_baseline(batch, om, n_sample, cores):
         dt = time.perf_counter() - t0
     return np.array(logp), n_sample / dt, dt
 
+PMC_LEGS = {  # kernels of one fused step, by leg (substring of the rocprofv3 kernel name)
+    "solver": ("cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel", "cr_solve_kernel"),
+    "assemble": ("rqr_kernel",),
+    "kalman": ("kalman_sel_kernel", "kalman_seq_kernel"),
+}
+
+
+def load_pmc():
+    """Newest profiles/r*/pmc_counters.json (tools/pmc_collect.py) -> ({leg: {flops, hbm_bytes, kernels}}, path)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters.json")))
+    if not files:
+        return {}, None
+    try:
+        with open(files[-1]) as fh:
+            kernels = json.load(fh)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return {}, None
+    legs = {}
+    for leg, pats in PMC_LEGS.items():
+        chosen = []
+        for pat in pats:  # several instantiations can match (second passes, the statistics pass): keep the one that
+            cands = [(v.get("calls_in_trace", v.get("dispatches", 0)) * v.get("avg_ns", 0.0), nm, v)  # carries the time
+                     for nm, v in kernels.items() if pat in nm]
+            if cands:
+                chosen.append(max(cands)[1:])
+        if chosen:
+            legs[leg] = {"kernels": [nm for nm, _ in chosen],
+                         "fp64_flops": sum(v.get("fp64_flops", 0.0) for _, v in chosen),
+                         "hbm_bytes": sum(v.get("hbm_bytes", 0.0) for _, v in chosen),
+                         "lds_conflict_share": max((v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
+                                                    for _, v in chosen), default=0.0)}
+    return legs, os.path.relpath(files[-1], ROOT)
+
+
+def roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_eval, hints, u_dim, h_defl, stats):
+    """The roofline object of the JSON line, for the kernel with the longest launch.  `achieved` / `frac` are EXECUTED
+    FP64 flops (hardware instruction counters x 64 lanes when profiles/ holds them for this configuration, otherwise the
+    analytic model of executed_flops) over the launch duration measured in this run -- a utilisation figure.  The SURVEY
+    8(d) contract count of the reference formulation is reported under contract_* (it can exceed the peak: the kernels reach
+    the same logp with far fewer flops)."""
+    k = kern[dom]
+    counted = k["counted_tflops"] is not None
+    achieved = k["counted_tflops"] if counted else k["model_tflops"]
+    total_counted = sum(v["counted_mflop_per_eval"] for v in kern.values()) if counted else None
+    return {
+        "kernel": k["kernel"],
+        "bound": "valu-latency",
+        "pipe": ("fp64 VALU (v_fma_f64; no MFMA issued: SQ_INSTS_VALU_MFMA_F64 = 0).  Neither HBM- nor MFMA-bound: a dependent "
+                 "chain per draw at 1-2 waves per SIMD"),
+        "achieved": achieved,
+        "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / FP64_PEAK_TFLOPS, 5),
+        "flops_source": (f"{pmc_src}: rocprofv3 --pmc SQ_INSTS_VALU_{{FMA,ADD,MUL,TRANS}}_F64 x 64 lanes of the same bench "
+                         f"command (tools/pmc_collect.py; committed counters, not collected in this run); duration measured in "
+                         f"this run with HIP events") if counted else "analytic model bench.py::executed_flops (no counters "
+                                                                     "committed for this configuration)",
+        "traffic": k["hbm_bytes_per_launch"],
+        "traffic_source": (f"{pmc_src}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, separate --pmc passes; committed "
+                           f"counters, not collected in this run") if counted else None,
+        "algorithmic_bytes_per_launch": b_eval * nloc,
+        "contract_tflops": k["contract_tflops"],
+        "contract_frac": round(k["contract_tflops"] / FP64_PEAK_TFLOPS, 5),
+        "contract_note": ("SURVEY 8(d) flop count of the REFERENCE formulation (dense m=40 filter, 200 full covariance "
+                          "updates) over the measured duration; not a utilisation figure"),
+        "structure": {"n_state": hints[0], "z_selector": hints[1], "filtered_variables": u_dim,
+                      "static_variables_deflated": h_defl, **stats},
+        "kernel_ms": {k_: round(v, 4) for k_, v in kms.items()},
+        "kernels": kern,
+        "whole_eval_contract_tflops": round(flops["total"] * nloc / total_kernel_s / 1e12, 4),
+        "whole_eval_model_tflops": round(sum(ex.values()) * nloc / total_kernel_s / 1e12, 4),
+        "whole_eval_counted_tflops": round(total_counted * 1e6 * nloc / total_kernel_s / 1e12, 4) if counted else None,
+        "hbm": {
+            "algorithmic_bytes_per_eval": b_eval,
+            "achieved_GBs": round(b_eval * nloc / total_kernel_s / 1e9, 3),
+            "peak_GBs": HBM_PEAK_GBS,
+            "frac": round(b_eval * nloc / total_kernel_s / 1e9 / HBM_PEAK_GBS, 7),
+            "measured_bytes_per_step": (sum(v["hbm_bytes_per_launch"] for v in kern.values()) if counted else None),
+        },
+    }
+
+
 def spawn_ranks(n_ranks, argv, shared_gpu=False, timeout=None):
     """Start ``n_ranks`` fresh ``python bench.py`` processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
     environment, 127.0.0.1 rendezvous), wait for them and return the worst exit code.  Rank 0 prints the JSON
@@ -330,16 +414,14 @@ def main():
         del T_buf
 
     if rank == 0:
-        # HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
-        # profiles/r1_s5/pmc_traffic.json); only valid for the default workload/batch
-        traffic = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_s5", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if per_gpu == 4096 and hints[1] and args.workload == "sw_shaped" and args.solver == "cycle_reduction":
-                traffic = {k_: round(v["hbm_bytes_per_launch"]) for k_, v in pmc["kernels"].items()}
-        except (OSError, KeyError, ValueError):
-            pass
+        # hardware counters of the same command, collected by tools/pmc_collect.py on an MI355X and committed under
+        # profiles/ (rocprofv3 cannot profile the process it runs in): FP64 VALU instruction counts and HBM bytes per
+        # launch.  Only valid for the default workload / batch / solver; the JSON line names the file.
+        pmc, pmc_src = {}, None
+        default_cfg = (per_gpu == 4096 and hints[1] and args.workload == "sw_shaped" and args.solver == "cycle_reduction"
+                       and not args.no_hints)
+        if default_cfg:
+            pmc, pmc_src = load_pmc()
         cr_it = stats.get("cr_iters_mean", 7.0)
         flops = algorithmic_flops(n, k, p, T_len, cr_iters=cr_it)
         # contract flops by the kernel that does the work (the Lyapunov solve now runs inside the Kalman kernel)
@@ -365,14 +447,18 @@ def main():
         kern = {}
         for key in ("solver", "assemble", "kalman"):
             sec = kms[key] * 1e-3
+            leg = pmc.get(key, {})
             kern[key] = {
                 "kernel": names[key],
                 "ms": round(kms[key], 4),
                 "contract_mflop_per_eval": round(contract[key] / 1e6, 3),
                 "contract_tflops": round(contract[key] * nloc / sec / 1e12, 3),
-                "executed_mflop_per_eval": round(ex[key] / 1e6, 3),
-                "executed_tflops": round(ex[key] * nloc / sec / 1e12, 3),
-                "hbm_bytes_per_launch": traffic.get(key),
+                "model_mflop_per_eval": round(ex[key] / 1e6, 3),
+                "model_tflops": round(ex[key] * nloc / sec / 1e12, 3),
+                "counted_mflop_per_eval": round(leg["fp64_flops"] / nloc / 1e6, 3) if leg else None,
+                "counted_tflops": round(leg["fp64_flops"] / sec / 1e12, 3) if leg else None,
+                "hbm_bytes_per_launch": round(leg["hbm_bytes"]) if leg else None,
+                "lds_conflict_share": round(leg["lds_conflict_share"], 3) if leg else None,
             }
         dom = max(kern, key=lambda k_: kern[k_]["ms"])
         total_kernel_s = sum(kms.values()) * 1e-3
@@ -410,34 +496,8 @@ def main():
                                     else "workgroups in descending order of a persistence key of T (power iteration)") + " (slow draws first; outputs stay in draw order)",
                 "parallelism": f"draw-sharded x{world}, one all_gather of packed (logp,status) records" if world > 1 else "single GPU",
             },
-            "roofline": {
-                "kernel": kern[dom]["kernel"],
-                "bound": "mfma",
-                "pipe": "fp64 VALU FMA (same peak rate as v_mfma_f64 on gfx950); the path is FP64/latency bound, not HBM bound",
-                "achieved": kern[dom]["contract_tflops"],
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(kern[dom]["contract_tflops"] / FP64_PEAK_TFLOPS, 5),
-                "traffic": kern[dom]["hbm_bytes_per_launch"],
-                "note": ("achieved/frac use the SURVEY 8(d) contract flop count of the REFERENCE formulation (dense m=40 "
-                         "filter, 200 full covariance updates); the kernel reaches the same logp with far fewer flops "
-                         "(exact column-structure reduction 40->18, steady-state switch), so frac can exceed 1 and is "
-                         "not a utilisation figure -- executed_frac is"),
-                "executed_tflops": kern[dom]["executed_tflops"],
-                "executed_frac": round(kern[dom]["executed_tflops"] / FP64_PEAK_TFLOPS, 5),
-                "structure": {"n_state": hints[0], "z_selector": hints[1], "filtered_variables": u_dim,
-                              "static_variables_deflated": h_defl, **stats},
-                "kernel_ms": {k_: round(v, 4) for k_, v in kms.items()},
-                "kernels": kern,
-                "whole_eval_contract_tflops": round(flops["total"] * nloc / total_kernel_s / 1e12, 4),
-                "whole_eval_executed_tflops": round(sum(ex.values()) * nloc / total_kernel_s / 1e12, 4),
-                "hbm": {
-                    "algorithmic_bytes_per_eval": b_eval,
-                    "achieved_GBs": round(b_eval * nloc / total_kernel_s / 1e9, 3),
-                    "peak_GBs": HBM_PEAK_GBS,
-                    "frac": round(b_eval * nloc / total_kernel_s / 1e9 / HBM_PEAK_GBS, 7),
-                },
-            },
+            "roofline": roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_eval, hints, u_dim, h_defl,
+                                       stats),
             "failed_draws": n_fail,
         }
         if cpu is not None:

@@ -81,6 +81,8 @@ PROTOTYPES = {
     "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_policy_adjoints_batched": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_policy_adjoints_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp],
+    "dsge_selection_adjoints_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp],
+    "dsge_selection_adjoints_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp],
     "dsge_policy_norms_batched": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
     "dsge_policy_norms_batched_host": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_backward_direct_batched": [_dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],

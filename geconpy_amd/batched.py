@@ -120,6 +120,22 @@ def selection_batched(B, C, D, T, A=None):
     return (R, resid) if A is not None else R
 
 
+def selection_adjoints_batched(B, C, T, R, R_bar):
+    """Pullback of ``R = -(C T + B)^-1 D`` (gEconpy/solvers/shared.py:74-75) -> ``(B_bar, C_bar, D_bar, T_bar)``:
+    ``G = -(C T + B)^-T R_bar``, ``D_bar = G``, ``B_bar = G R'``, ``C_bar = G R' T'``, ``T_bar = C' G R'``."""
+    B, C, T = _check_abc(B, C, T)
+    R, R_bar = _f64(R, 3), _f64(R_bar, 3)
+    nb, n, _ = B.shape
+    k = R.shape[2]
+    if R.shape != (nb, n, k) or R_bar.shape != (nb, n, k):
+        raise ValueError("R and R_bar must be (batch, n, k)")
+    Bb, Cb, Tb = np.empty_like(B), np.empty_like(B), np.empty_like(B)
+    Db = np.empty_like(R)
+    _lib.check(_lib.load().dsge_selection_adjoints_batched_host(_ptr(B), _ptr(C), _ptr(T), _ptr(R), _ptr(R_bar), nb, n, k,
+                                                                _ptr(Bb), _ptr(Cb), _ptr(Db), _ptr(Tb)))
+    return Bb, Cb, Db, Tb
+
+
 def policy_adjoints_batched(B, C, T, T_bar):
     """``(A_bar, B_bar, C_bar, status)``: the reverse-mode sensitivities of
     ``o1_policy_function_adjoints`` (gEconpy/solvers/shared.py:12-71) for a batch of draws."""

@@ -405,6 +405,19 @@ int dsge_policy_adjoints_batched(const double* B, const double* C, const double*
   return launch_adjoint(B, C, T, T_bar, batch, n, A_bar, B_bar, C_bar, status, (hipStream_t)stream);
 }
 
+int dsge_selection_adjoints_batched(const double* B, const double* C, const double* T, const double* R, const double* R_bar,
+                                    int batch, int n, int k, double* B_bar, double* C_bar, double* D_bar, double* T_bar,
+                                    void* stream) {
+  int rc = check_common(batch, n, 48);  // (the tile cascade of grad_assemble_kernel stops at 48)
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!B || !C || !T || !R || !R_bar || !B_bar || !C_bar || !D_bar || !T_bar) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_grad_assemble(B, C, T, R, nullptr, 0, nullptr, batch, n, k, nullptr, T_bar, B_bar, C_bar, D_bar, nullptr,
+                              (hipStream_t)stream, R_bar);
+}
+
 int dsge_policy_norms_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
                               const double* R, const int32_t* state_mask, int batch, int n, int k,
                               double* det_norm_out, double* stoch_norm_out, void* stream) {
@@ -1031,6 +1044,37 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
   if ((rc = dsge_selection_batched(dA, dB, dC, dD, dT, batch, n, k, dR, dRes, nullptr))) return rc;
   DOWN(R_out, dR, nk, double);
   DOWN(resid_out, dRes, batch, double);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_selection_adjoints_batched_host(const double* B, const double* C, const double* T, const double* R,
+                                         const double* R_bar, int batch, int n, int k, double* B_bar, double* C_bar,
+                                         double* D_bar, double* T_bar) {
+  int rc = check_common(batch, n, 48);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (!B || !C || !T || !R || !R_bar || !B_bar || !C_bar || !D_bar || !T_bar) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = nullptr;
+  STAGE_RESERVE(6 * align256(nn * 8) + 3 * align256(nk * 8) + 4096, &base);
+  Carver cv(base);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dT, T, nn, double);
+  UP(dR, R, nk, double);
+  UP(dRb, R_bar, nk, double);
+  OUTBUF(dBb, B_bar, nn, double);
+  OUTBUF(dCb, C_bar, nn, double);
+  OUTBUF(dDb, D_bar, nk, double);
+  OUTBUF(dTb, T_bar, nn, double);
+  if ((rc = dsge_selection_adjoints_batched(dB, dC, dT, dR, dRb, batch, n, k, dBb, dCb, dDb, dTb, nullptr))) return rc;
+  DOWN(B_bar, dBb, nn, double);
+  DOWN(C_bar, dCb, nn, double);
+  DOWN(D_bar, dDb, nk, double);
+  DOWN(T_bar, dTb, nn, double);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }

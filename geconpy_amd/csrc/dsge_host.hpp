@@ -91,7 +91,8 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
 size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len);
 int launch_grad_assemble(const double* B, const double* C, const double* T, const double* R, const double* q,
                          int q_batched, const double* Gbar, int batch, int n, int k, const int32_t* status, double* Tbar,
-                         double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st);
+                         double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st,
+                         const double* Rbar_in = nullptr);  // Rbar_in: pullback of R = -(C T + B)^-1 D alone (Tbar written)
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr);

@@ -875,7 +875,10 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     const double* __restrict__ B, const double* __restrict__ C, const double* __restrict__ T,
     const double* __restrict__ R, const double* __restrict__ q, int q_batched, const double* __restrict__ Gbar,
     int batch, int n, int k, const int32_t* __restrict__ status, double* __restrict__ Tbar,
-    double* __restrict__ B_bar, double* __restrict__ C_bar, double* __restrict__ D_bar, double* __restrict__ q_bar) {
+    double* __restrict__ B_bar, double* __restrict__ C_bar, double* __restrict__ D_bar, double* __restrict__ q_bar,
+    const double* __restrict__ Rbar_in = nullptr) {
+  // Rbar_in != nullptr: the pullback of R = -(C T + B)^-1 D ALONE (pt_compute_selection_matrix, shared.py:74-75) --
+  // the cotangent of R arrives directly, nothing is known about Q, and Tbar is WRITTEN (= C' Mbar) instead of accumulated.
   constexpr int NP = GaSmem<BS>::NP, LD = GaSmem<BS>::LD, LDW = GaSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ts = smem;
@@ -889,29 +892,33 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
-    if (status[draw] != 0) {  // failed draw: zero cotangents
+    if (status && status[draw] != 0) {  // failed draw: zero cotangents
       double z[BS][BS];
       blk_zero<BS>(z);
       blk_store_global<BS>(z, B_bar + off, n, n, n, lr, lc);
       blk_store_global<BS>(z, C_bar + off, n, n, n, lr, lc);
       blk_store_global<BS>(z, D_bar + offk, n, k, k, lr, lc);
-      if (lane < k) q_bar[(size_t)draw * k + lane] = 0.0;
+      if (q_bar && lane < k) q_bar[(size_t)draw * k + lane] = 0.0;
+      if (Rbar_in) blk_store_global<BS>(z, Tbar + off, n, n, n, lr, lc);
       continue;
     }
     wave_sync();
     for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
     lds_load_matrix(Ts, LD, NP, NP, T + off, n, n, lane);
     lds_load_matrix(Cs, LD, NP, NP, C + off, n, n, lane);
-    lds_load_matrix(Ms, LD, NP, NP, Gbar + off, n, n, lane);
+    if (!Rbar_in) lds_load_matrix(Ms, LD, NP, NP, Gbar + off, n, n, lane);
     lds_load_matrix(Rs, LD, NP, NP, R + offk, n, k, lane);
     wave_sync();
-    const double* qd = q + (q_batched ? (size_t)draw * k : 0);
+    const double* qd = Rbar_in ? nullptr : q + (q_batched ? (size_t)draw * k : 0);
     // GR = Gbar R  (n x k);  Rbar = 2 GR Q;  qbar_j = sum_i R_ij GR_ij
     double GR[BS][BS], Rb[BS][BS];
     blk_zero<BS>(GR);
+    double Rbar[BS][BS];
+    if (Rbar_in) {
+      blk_load_global<BS>(Rbar, Rbar_in + offk, n, k, k, lr, lc);
+    } else {
     mm_acc<BS, false>(GR, Ms, LD, Rs, LD, n, lr, lc);
     blk_load_lds<BS>(Rb, Rs, LD, lr, lc);
-    double Rbar[BS][BS];
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
       const int c = lc * BS + j;
@@ -926,6 +933,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
       colsum += shfl_xor_f64(colsum, 16);
       colsum += shfl_xor_f64(colsum, 32);
       if (lr == 0 && c < k) q_bar[(size_t)draw * k + c] = colsum;
+    }
     }
     // M = B + C T; W = [M' | Rbar]
     {
@@ -969,7 +977,10 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     blk_zero<BS>(Cb);
     mm_acc<BS, true>(Cb, Ms, LD, Ts, LD, n, lr, lc);  // Mbar T'
     blk_store_global<BS>(Cb, C_bar + off, n, n, n, lr, lc);
-    blk_load_global<BS>(Tb, Tbar + off, n, n, n, lr, lc);
+    if (Rbar_in)
+      blk_zero<BS>(Tb);
+    else
+      blk_load_global<BS>(Tb, Tbar + off, n, n, n, lr, lc);
     mm_acc<BS, false>(Tb, Cs, LD, Ms, LD, n, lr, lc);  // Tbar += C' Mbar
     blk_store_global<BS>(Tb, Tbar + off, n, n, n, lr, lc);
   }

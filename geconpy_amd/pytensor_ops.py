@@ -29,8 +29,12 @@ try:  # pragma: no cover - exercised only where pytensor is installed
 except Exception:  # noqa: BLE001  (ImportError or a broken install)
     pt = None
     Apply = None
-    Op = object
     _HAVE_PYTENSOR = False
+
+    class Op:  # minimal base so that the classes exist (perform() is callable) without pytensor
+        def __call__(self, *inputs):
+            node = self.make_node(*inputs)  # raises ImportError through _require() unless a tensor module is bound
+            return node.outputs[0] if len(node.outputs) == 1 else list(node.outputs)
 
 
 def available() -> bool:
@@ -45,6 +49,19 @@ def _require():
 def _as3(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     return x[None] if x.ndim == 2 else x
+
+
+def _out_dtype(*dtypes):
+    """Output dtype of a solver Op: pytensor's ``linalg_output_dtype`` (what ``CycleReductionWrapper.make_node`` uses,
+    cycle_reduction.py:197) when this pytensor has it; otherwise its rule restated -- float32 only if every input is
+    float32 (or narrower), float64 else.  The kernels always compute in float64; ``perform`` casts the result
+    (``np.asarray(T, dtype=node.outputs[0].type.dtype)``, cycle_reduction.py:210)."""
+    try:
+        from pytensor.tensor.linalg.dtype_utils import linalg_output_dtype  # noqa: PLC0415
+
+        return linalg_output_dtype(*dtypes)
+    except Exception:  # noqa: BLE001
+        return "float32" if dtypes and all(np.dtype(d).itemsize <= 4 and np.dtype(d).kind == "f" for d in dtypes) else "float64"
 
 
 class HipCycleReduction(Op):
@@ -67,7 +84,8 @@ class HipCycleReduction(Op):
     def make_node(self, A, B, C):
         _require()
         inputs = [pt.as_tensor(x) for x in (A, B, C)]
-        outputs = [pt.tensor("T", dtype="float64", shape=inputs[0].type.shape)]
+        o_dtype = _out_dtype(*(inp.type.dtype for inp in inputs))
+        outputs = [pt.tensor("T", dtype=o_dtype, shape=inputs[0].type.shape)]
         return Apply(self, inputs, outputs)
 
     def infer_shape(self, fgraph, node, input_shapes):
@@ -77,7 +95,8 @@ class HipCycleReduction(Op):
     def perform(self, node, inputs, outputs):
         A, B, C = (_as3(x) for x in inputs)
         T, _status, _n_iter = batched.cycle_reduction_batched(A, B, C, max_iter=self.max_iter, tol=self.tol)
-        outputs[0][0] = T[0]
+        o_dtype = node.outputs[0].type.dtype if node is not None else "float64"
+        outputs[0][0] = np.asarray(T[0], dtype=o_dtype)
 
     def pullback(self, inputs, outputs, cotangents):
         # Same contract as _linear_policy_jvp (cycle_reduction.py:117-124): cotangents of (A, B, C)
@@ -161,6 +180,40 @@ class HipSelection(Op):
         B, C, D, T = (_as3(x) for x in inputs)
         R = batched.selection_batched(B, C, D, T)
         outputs[0][0] = R[0] if squeeze else R
+
+    def pullback(self, inputs, outputs, cotangents):
+        # The reference's R is plain differentiable pytensor (-pt.linalg.solve(C @ T + B, D), shared.py:74-75), so
+        # pytensor.grad flows through it into B, C, D and T; same rule here, as one launch:
+        # G = -(C T + B)^-T R_bar, B_bar = G R', C_bar = G R' T', D_bar = G, T_bar = C' G R'.
+        B, C, _D, T = inputs
+        B_bar, C_bar, D_bar, T_bar = HipSelectionAdjoint()(B, C, T, outputs[0], cotangents[0])
+        return [B_bar, C_bar, D_bar, T_bar]
+
+
+class HipSelectionAdjoint(Op):
+    """``B_bar, C_bar, D_bar, T_bar = Op(B, C, T, R, R_bar)``: reverse mode of ``R = -(C T + B)^-1 D``
+    (``dsge_selection_adjoints_batched``), for (n, n)/(n, k) or batched inputs."""
+
+    __props__ = ()
+    gufunc_signature = "(n,n),(n,n),(n,n),(n,k),(n,k)->(n,n),(n,n),(n,k),(n,n)"
+
+    def make_node(self, B, C, T, R, R_bar):
+        _require()
+        inputs = [pt.as_tensor(x) for x in (B, C, T, R, R_bar)]
+        sq, sk = inputs[0].type.shape, inputs[3].type.shape
+        outputs = [pt.tensor("B_bar", dtype="float64", shape=sq), pt.tensor("C_bar", dtype="float64", shape=sq),
+                   pt.tensor("D_bar", dtype="float64", shape=sk), pt.tensor("T_bar", dtype="float64", shape=sq)]
+        return Apply(self, inputs, outputs)
+
+    def infer_shape(self, fgraph, node, input_shapes):
+        return [input_shapes[0], input_shapes[0], input_shapes[3], input_shapes[0]]
+
+    def perform(self, node, inputs, outputs):
+        squeeze = np.ndim(inputs[0]) == 2
+        B, C, T, R, R_bar = (_as3(x) for x in inputs)
+        res = batched.selection_adjoints_batched(B, C, T, R, R_bar)
+        for cell, val in zip(outputs, res):
+            cell[0] = val[0] if squeeze else val
 
 
 class HipSolveKalmanLogp(Op):
@@ -291,6 +344,9 @@ class HipGensys(Op):
     def perform(self, node, inputs, outputs):
         squeeze = np.ndim(inputs[0]) == 2
         A, B, C, D = (_as3(x) for x in inputs)
+        if D.shape[:2] != A.shape[:2]:
+            raise ValueError(f"D must be (n, k) with n = {A.shape[1]}; got {D.shape[1:]}")
+        # T = G1[:n,:n] and eu do not depend on D (psi only enters `impact`, gensys.py:359-365): it is not shipped to the device
         out = batched.gensys_batched(A, B, C, None, tol=self.tol)
         outputs[0][0] = out["T"][0] if squeeze else out["T"]
         outputs[1][0] = np.asarray(out["success"][0] if squeeze else out["success"], dtype=bool)
@@ -408,7 +464,7 @@ def cycle_reduction_pt(A, B, C, D, max_iter=1000, tol=1e-9):
 
 
 def _register_vectorize():
-    """Teach pytensor to vectorise HipCycleReduction into ONE batched launch."""
+    """Teach pytensor to vectorise the per-draw Ops into ONE batched launch instead of a Blockwise loop over draws."""
     try:
         from pytensor.graph.replace import _vectorize_node  # noqa: PLC0415
     except Exception:  # noqa: BLE001
@@ -422,8 +478,123 @@ def _register_vectorize():
 
         return Blockwise(op).make_node(A, B, C)
 
+    def _native(op_cls):  # Ops whose perform already takes a leading draw axis on every input
+        @_vectorize_node.register(op_cls)
+        def _vec(op, node, *batched_inputs):
+            nd = {x.type.ndim for x in batched_inputs}
+            if nd == {3}:
+                return op.make_node(*batched_inputs)
+            from pytensor.tensor.blockwise import Blockwise  # noqa: PLC0415
+
+            return Blockwise(op).make_node(*batched_inputs)
+
+    for cls in (HipGensys, HipSelection, HipSelectionAdjoint, HipPolicyAdjoint, HipScanCycleReduction):
+        _native(cls)
+    return True
+
+
+# ---- backend dispatch: numba and JAX (gensys.py:686-713, cycle_reduction.py:222-243, real_eig.py:100-137) ------------------
+def make_numba_cycle_reduction(njit, cr_host, max_iter, tol, out_dtype=np.float64):
+    """The njit-compiled twin of ``HipCycleReduction.perform``: numba calls the SAME C entry point
+    (``dsge_cycle_reduction_batched_host``, batch = 1) through its ctypes binding, so the numba backend neither falls
+    back to object mode nor to a CPU solver.  ``njit`` is the decorator (pytensor's ``numba_njit`` or ``numba.njit``);
+    ``cr_host`` the ctypes function.  A malformed call / missing device gives a NaN matrix (numba code cannot raise
+    the library's error message)."""
+    max_iter = int(max_iter)
+    tol = float(tol)
+
+    @njit
+    def cycle_reduction(A, B, C):
+        n = A.shape[0]
+        A64 = np.ascontiguousarray(A).astype(np.float64)
+        B64 = np.ascontiguousarray(B).astype(np.float64)
+        C64 = np.ascontiguousarray(C).astype(np.float64)
+        T = np.zeros((n, n), dtype=np.float64)
+        status = np.zeros(1, dtype=np.int32)
+        n_iter = np.zeros(1, dtype=np.int32)
+        rc = cr_host(A64.ctypes, B64.ctypes, C64.ctypes, 1, n, max_iter, tol, T.ctypes, status.ctypes, n_iter.ctypes)
+        if rc != 0:
+            T[:, :] = np.nan
+        return T.astype(out_dtype)
+
+    return cycle_reduction
+
+
+def make_numba_gensys(njit, gensys_host, tol):
+    """njit twin of ``HipGensys.perform`` -> ``(T, success)`` through ``dsge_gensys_batched_host`` (batch = 1)."""
+    tol = float(tol)
+
+    @njit
+    def gensys_wrapper(A, B, C, D):
+        n = A.shape[0]
+        A64 = np.ascontiguousarray(A).astype(np.float64)
+        B64 = np.ascontiguousarray(B).astype(np.float64)
+        C64 = np.ascontiguousarray(C).astype(np.float64)
+        T = np.zeros((n, n), dtype=np.float64)
+        eu = np.zeros(3, dtype=np.int32)
+        status = np.ones(1, dtype=np.int32)
+        rc = gensys_host(A64.ctypes, B64.ctypes, C64.ctypes, 0, 1, n, 1, tol, 0, T.ctypes, 0, eu.ctypes, status.ctypes)
+        success = (rc == 0) and (eu[0] == 1) and (eu[1] == 1)
+        return T, success
+
+    return gensys_wrapper
+
+
+def _register_numba():
+    try:
+        from pytensor.link.numba.dispatch import basic as numba_basic  # noqa: PLC0415
+        from pytensor.link.numba.dispatch.basic import register_funcify_default_op_cache_key  # noqa: PLC0415
+    except Exception:  # noqa: BLE001
+        return False
+    from . import _lib  # noqa: PLC0415
+
+    @register_funcify_default_op_cache_key(HipCycleReduction)
+    def numba_funcify_HipCycleReduction(op, node, **kwargs):  # noqa: ARG001
+        fn = make_numba_cycle_reduction(numba_basic.numba_njit, _lib.load().dsge_cycle_reduction_batched_host, op.max_iter,
+                                        op.tol, node.outputs[0].type.numpy_dtype)
+        cache_version = 1
+        return fn, cache_version
+
+    @register_funcify_default_op_cache_key(HipGensys)
+    def numba_funcify_HipGensys(op, node, **kwargs):  # noqa: ARG001
+        fn = make_numba_gensys(numba_basic.numba_njit, _lib.load().dsge_gensys_batched_host, op.tol)
+        cache_version = 1
+        return fn, cache_version
+
+    return True
+
+
+def _register_jax():
+    """JAX backend: the Ops run as host callbacks (``jax.pure_callback``) into the same ``perform`` -- the library owns
+    its own device buffers, JAX only sees numpy in / numpy out with the shapes ``infer_shape`` gives."""
+    try:
+        import jax  # noqa: PLC0415
+        from pytensor.link.jax.dispatch.basic import jax_funcify  # noqa: PLC0415
+    except Exception:  # noqa: BLE001
+        return False
+
+    def _callback(op, node):
+        def fn(*inputs):
+            shapes = [jax.ShapeDtypeStruct(tuple(int(d) for d in s), np.dtype(o.type.dtype))
+                      for s, o in zip(op.infer_shape(None, node, [tuple(x.shape) for x in inputs]), node.outputs)]
+
+            def host(*arrays):
+                cells = [[None] for _ in node.outputs]
+                op.perform(node, [np.asarray(a) for a in arrays], cells)
+                return tuple(np.asarray(c[0], dtype=sd.dtype).reshape(sd.shape) for c, sd in zip(cells, shapes))
+
+            res = jax.pure_callback(host, tuple(shapes), *inputs)
+            return res[0] if len(res) == 1 else res
+
+        return fn
+
+    for cls in (HipCycleReduction, HipGensys, HipSelection, HipSelectionAdjoint, HipPolicyAdjoint, HipScanCycleReduction,
+                HipCycleReductionBatched, HipSolveKalmanLogp, HipSolveKalmanLogpGrad, HipBKEigenvalues):
+        jax_funcify.register(cls)(lambda op, node, **kwargs: _callback(op, node))  # noqa: ARG005
     return True
 
 
 if _HAVE_PYTENSOR:  # registration by import side effect
     _register_vectorize()
+    _register_numba()
+    _register_jax()

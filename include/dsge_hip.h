@@ -312,6 +312,22 @@ int dsge_policy_adjoints_batched_host(const double* B, const double* C, const do
                                       int32_t* status);
 
 /*
+ * Pullback of the shock-impact matrix.  The reference's R = -solve(C @ T + B, D) is plain differentiable pytensor
+ * (pt_compute_selection_matrix, gEconpy/solvers/shared.py:74-75), so pytensor.grad flows through it into B, C, D and T;
+ * this is that reverse-mode rule as one launch.  With M = C T + B and the cotangent R_bar of R:
+ *   G = -M^-T R_bar,   D_bar = G,   B_bar = G R',   C_bar = G R' T',   T_bar = C' G R'
+ *   B, C, T, B_bar, C_bar, T_bar : [batch][n][n]   R, R_bar, D_bar : [batch][n][k]   n <= 48
+ * T_bar is the contribution of R only: the caller adds the direct cotangent of T and passes the sum on to
+ * dsge_policy_adjoints_batched.
+ */
+int dsge_selection_adjoints_batched(const double* B, const double* C, const double* T, const double* R,
+                                    const double* R_bar, int batch, int n, int k, double* B_bar, double* C_bar,
+                                    double* D_bar, double* T_bar, void* stream);
+int dsge_selection_adjoints_batched_host(const double* B, const double* C, const double* T, const double* R,
+                                         const double* R_bar, int batch, int n, int k, double* B_bar, double* C_bar,
+                                         double* D_bar, double* T_bar);
+
+/*
  * gEcon recursion residual norms, the `deterministic_norm` / `stochastic_norm` Deterministics of
  * DSGEStateSpace.build_statespace_graph (gEconpy/model/statespace.py:1181-1204).  With the state mask
  * s (variables that appear at t-1 and at t in some equation, :1186-1193):

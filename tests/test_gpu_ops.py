@@ -1,0 +1,148 @@
+"""Every Op of geconpy_amd.pytensor_ops executed on the device through its ``perform()`` (needs no pytensor: the storage
+cell protocol ``outputs[i][0] = array`` is all it uses), against the reference-extracted goldens and the oracle; plus the
+new pullback of the shock-impact matrix against finite differences of the oracle formula (shared.py:74-75)."""
+import types
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from geconpy_amd import batched
+from geconpy_amd import pytensor_ops as ops
+from geconpy_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _perform(op, inputs, n_out, node=None):
+    cells = [[None] for _ in range(n_out)]
+    op.perform(node, list(inputs), cells)
+    return [c[0] for c in cells]
+
+
+def _node(dtype):
+    return types.SimpleNamespace(outputs=[types.SimpleNamespace(type=types.SimpleNamespace(dtype=dtype))])
+
+
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
+def test_solver_ops_perform_on_reference_goldens(ref_goldens, key):
+    g = ref_goldens
+    A, B, C, D = (g[f"{key}_{x}"] for x in "ABCD")
+    (T,) = _perform(ops.HipCycleReduction(max_iter=1000, tol=1e-8), (A, B, C), 1)
+    assert T.shape == A.shape and T.dtype == np.float64
+    assert_allclose(T, g[f"{key}_ref_cr_T"], atol=1e-10)
+    (T32,) = _perform(ops.HipCycleReduction(max_iter=1000, tol=1e-8), (A.astype(np.float32),) * 1 + (B.astype(np.float32),
+                      C.astype(np.float32)), 1, node=_node("float32"))
+    assert T32.dtype == np.float32 and np.abs(T32 - g[f"{key}_ref_cr_T"]).max() < 1e-4
+    T_g, success = _perform(ops.HipGensys(tol=1e-8), (A, B, C, D), 2)
+    assert success.dtype == bool and success.shape == () and bool(success)
+    assert_allclose(T_g, g[f"{key}_ref_gensys_T"], atol=1e-9)
+    (R,) = _perform(ops.HipSelection(), (B, C, D, T_g), 1)
+    assert R.shape == D.shape
+    assert_allclose(R, g[f"{key}_ref_gensys_R"], atol=1e-8)
+    T_s, n_steps = _perform(ops.HipScanCycleReduction(max_iter=50, tol=1e-7), (A, B, C), 2)
+    To, _Ro, ns_o = oracle.scan_cycle_reduction(A, B, C, D, max_iter=50, tol=1e-7)
+    assert n_steps.shape == () and int(n_steps) == int(ns_o)
+    assert_allclose(T_s, To, atol=1e-10)
+    # batched: one launch, leading axis on every output
+    Ab, Bb, Cb, Db = (np.stack([x, x]) for x in (A, B, C, D))
+    Tb, sb = _perform(ops.HipGensys(tol=1e-8), (Ab, Bb, Cb, Db), 2)
+    assert Tb.shape == (2,) + A.shape and sb.shape == (2,) and sb.all() and np.array_equal(Tb[0], Tb[1])
+    Tcb, stb = _perform(ops.HipCycleReductionBatched(max_iter=1000, tol=1e-8), (Ab, Bb, Cb), 2)
+    assert stb.dtype == np.int32 and not stb.any() and np.array_equal(Tcb[0], T)
+
+
+def test_failed_solves_through_the_ops(failure_golden):
+    g = failure_golden
+    for name in ("nonunique", "noexist", "coincident"):
+        A, B, C, D = (g[f"{name}_{x}"] for x in "ABCD")
+        T, success = _perform(ops.HipGensys(tol=1e-8), (A, B, C, D), 2)
+        assert not bool(success), name  # eu != [1, 1] (gensys.py:663)
+    A, B, C, D = (g[f"nonunique_{x}"] for x in "ABCD")
+    (T,) = _perform(ops.HipCycleReduction(max_iter=50, tol=1e-8), (A, B, C), 1)
+    if not bool(g["nonunique_ref_cr_converged"][1]):
+        assert np.all(T == 0.0)  # njit semantics, cycle_reduction.py:181
+
+
+def test_policy_adjoint_op_perform(ref_goldens):
+    g = ref_goldens
+    A, B, C = (g[f"full_nk_{x}"] for x in "ABC")
+    T = g["full_nk_ref_cr_T"]
+    T_bar = np.random.default_rng(0).standard_normal(T.shape)
+    Ab, Bb, Cb = _perform(ops.HipPolicyAdjoint(), (B, C, T, T_bar), 3)
+    ref = oracle.policy_function_adjoints(A, B, C, T, T_bar)
+    for got, want in zip((Ab, Bb, Cb), ref):
+        assert_allclose(got, want, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("key", ["rbc_2_block", "full_nk", "sw"])
+def test_selection_pullback_vs_finite_differences(ref_goldens, key):
+    """HipSelection.pullback / dsge_selection_adjoints_batched: for a random cotangent R_bar the directional derivative
+    <R_bar, dR> of R = -(C T + B)^-1 D along random directions of B, C, D, T (central differences of the oracle formula)
+    equals <B_bar, dB> + <C_bar, dC> + <D_bar, dD> + <T_bar, dT>."""
+    if key == "sw":
+        b = wl.sw_shaped_batch(1)
+        B, C, D, T = b["B"][0], b["C"][0], b["D"][0], b["T_star"][0]
+    else:
+        B, C, D = (ref_goldens[f"{key}_{x}"] for x in "BCD")
+        T = ref_goldens[f"{key}_ref_cr_T"]
+    rng = np.random.default_rng(5)
+    R = oracle.compute_selection_matrix(B, C, D, T)
+    R_bar = rng.standard_normal(R.shape)
+    B_bar, C_bar, D_bar, T_bar = _perform(ops.HipSelectionAdjoint(), (B, C, T, R, R_bar), 4)
+    # closed form (ADVICE): G = -(C T + B)^-T R_bar
+    G = -np.linalg.solve((C @ T + B).T, R_bar)
+    assert_allclose(D_bar, G, rtol=1e-9, atol=1e-11)
+    assert_allclose(B_bar, G @ R.T, rtol=1e-9, atol=1e-11)
+    assert_allclose(C_bar, G @ R.T @ T.T, rtol=1e-9, atol=1e-11)
+    assert_allclose(T_bar, C.T @ G @ R.T, rtol=1e-9, atol=1e-11)
+    for _ in range(3):
+        dB, dC, dD, dT = (rng.standard_normal(x.shape) for x in (B, C, D, T))
+        h = 1e-6
+        Rp = oracle.compute_selection_matrix(B + h * dB, C + h * dC, D + h * dD, T + h * dT)
+        Rm = oracle.compute_selection_matrix(B - h * dB, C - h * dC, D - h * dD, T - h * dT)
+        fd = np.sum(R_bar * (Rp - Rm)) / (2 * h)
+        an = np.sum(B_bar * dB) + np.sum(C_bar * dC) + np.sum(D_bar * dD) + np.sum(T_bar * dT)
+        assert abs(fd - an) <= 2e-6 * max(abs(fd), abs(an), 1.0)
+    # batched inputs give the batch of the same numbers
+    res = batched.selection_adjoints_batched(np.stack([B, B]), np.stack([C, C]), np.stack([T, T]), np.stack([R, R]),
+                                             np.stack([R_bar, 2 * R_bar]))
+    assert_allclose(res[0][0], B_bar, rtol=1e-13, atol=0) and assert_allclose(res[3][1], 2 * T_bar, rtol=1e-12, atol=1e-14)
+
+
+def test_fused_logp_ops_perform():
+    nb = 24
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    d = np.zeros(7)
+    args = (b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"], d, om["Hdiag"])
+    logp, status = _perform(ops.HipSolveKalmanLogp(solver="cycle_reduction", tol=1e-8, max_iter=1000), args, 2)
+    assert logp.shape == (nb,) and status.dtype == np.int32 and not status.any()
+    for i in (0, 11, 23):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], om["y"],
+                                       H=np.diag(om["Hdiag"]), tol=1e-8, max_iter=1000)
+        assert abs(logp[i] - ref["logp"]) <= 1e-8 * abs(ref["logp"])
+    grads = _perform(ops.HipSolveKalmanLogpGrad(solver="cycle_reduction", tol=1e-8, max_iter=1000), args, 7)
+    assert [x.shape for x in grads] == [(nb, 40, 40)] * 3 + [(nb, 40, 7), (nb, 7), (nb, 7), (nb, 7)]
+    assert all(np.isfinite(x).all() for x in grads)
+    # d logp / d q_0 against a central difference of the fused Op itself
+    h = 1e-7 * q[:, 0]
+    qp, qm = q.copy(), q.copy()
+    qp[:, 0] += h
+    qm[:, 0] -= h
+    lp = _perform(ops.HipSolveKalmanLogp(tol=1e-8, max_iter=1000), args[:4] + (qp,) + args[5:], 2)[0]
+    lm = _perform(ops.HipSolveKalmanLogp(tol=1e-8, max_iter=1000), args[:4] + (qm,) + args[5:], 2)[0]
+    assert_allclose(grads[4][:, 0], (lp - lm) / (2 * h), rtol=2e-4)
+
+
+def test_bk_eigenvalues_op_perform(ref_goldens):
+    g = ref_goldens
+    A, B, C = (g[f"full_nk_{x}"] for x in "ABC")
+    n_forward = int(np.count_nonzero(np.abs(C).sum(axis=0) > 1e-8))
+    re, im, n_unstable = _perform(ops.HipBKEigenvalues(n_forward, tol=1e-8), (A, B, C), 3)
+    assert re.shape == im.shape == (A.shape[0] + n_forward,) and n_unstable.dtype == np.int64
+    assert int(n_unstable) == n_forward  # the golden model satisfies Blanchard-Kahn
+    mod = np.hypot(re, im)
+    assert np.all(np.diff(mod[np.isfinite(mod)]) >= -1e-9)
