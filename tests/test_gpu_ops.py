@@ -42,7 +42,7 @@ def test_solver_ops_perform_on_reference_goldens(ref_goldens, key):
     assert R.shape == D.shape
     assert_allclose(R, g[f"{key}_ref_gensys_R"], atol=1e-8)
     T_s, n_steps = _perform(ops.HipScanCycleReduction(max_iter=50, tol=1e-7), (A, B, C), 2)
-    To, _Ro, ns_o = oracle.scan_cycle_reduction(A, B, C, D, max_iter=50, tol=1e-7)
+    To, ns_o = oracle.scan_cycle_reduction(A, B, C, max_iter=50, tol=1e-7)
     assert n_steps.shape == () and int(n_steps) == int(ns_o)
     assert_allclose(T_s, To, atol=1e-10)
     # batched: one launch, leading axis on every output
@@ -108,7 +108,8 @@ def test_selection_pullback_vs_finite_differences(ref_goldens, key):
     # batched inputs give the batch of the same numbers
     res = batched.selection_adjoints_batched(np.stack([B, B]), np.stack([C, C]), np.stack([T, T]), np.stack([R, R]),
                                              np.stack([R_bar, 2 * R_bar]))
-    assert_allclose(res[0][0], B_bar, rtol=1e-13, atol=0) and assert_allclose(res[3][1], 2 * T_bar, rtol=1e-12, atol=1e-14)
+    assert_allclose(res[0][0], B_bar, rtol=1e-13, atol=0)
+    assert_allclose(res[3][1], 2 * T_bar, rtol=1e-12, atol=1e-14)
 
 
 def test_fused_logp_ops_perform():
