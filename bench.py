@@ -105,7 +105,7 @@ def cpu_baseline(batch, om, n_sample, cores):
 PMC_LEGS = {  # kernels of one fused step, by leg (substring of the rocprofv3 kernel name)
     "solver": ("cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel", "cr_solve_kernel"),
     "assemble": ("rqr_kernel",),
-    "kalman": ("kalman_sel_kernel", "kalman_seq_kernel"),
+    "kalman": ("kalman_sel_kernel", "kalman_nt_kernel"),
 }
 
 

@@ -129,6 +129,7 @@ struct OptionsGuard {
     local.pipeline_chunks = o->pipeline_chunks;
     local.gensys_split = o->gensys_split;
     local.kalman_steady_tol = o->kalman_steady_tol;
+    local.kalman_nt_products = o->kalman_nt_products;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -290,6 +291,10 @@ int dsge_set_kalman_order(int mode) {
 }
 int dsge_set_kalman_block(int enable) {
   g_defaults.kalman_block = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
+int dsge_set_kalman_nt_products(int enable) {
+  g_defaults.kalman_nt_products = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_kalman_tiny(int enable) {
@@ -1494,6 +1499,7 @@ int dsge_options_init(dsge_options* o) {
   o->pipeline_chunks = d.pipeline_chunks;
   o->gensys_split = d.gensys_split;
   o->kalman_steady_tol = d.kalman_steady_tol;
+  o->kalman_nt_products = d.kalman_nt_products;
   return DSGE_SUCCESS;
 }
 

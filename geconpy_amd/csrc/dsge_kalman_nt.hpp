@@ -1,0 +1,654 @@
+// Kalman filter log-likelihood, selector design matrix: "kalman_nt_kernel" -- the fast path of round 2.
+//
+// Same algorithm, step for step, as kalman_sel_kernel<BS, true> (dsge_kalman2.hpp: exact reduction to the retained
+// variables in a states-first ordering, stationary initial covariance by doubling, p x p inverse by in-register
+// Gauss-Jordan, P+ = P - K (P Zm' + jitter K)' + jitter I, steady-state switch with a register-resident mean recursion;
+// the recursion is the one restated in SURVEY.md Appendix B.4 for statespace.py:1151-1157).  What changed is how the two
+// prediction products of a full step -- W = P+[S,S] Tc' and X = Tc W, 7.5 k of the 15.2 k cycles of a full step on the
+// 18-variable bench model -- reach their operands:
+//
+//   * "NT" form.  W is stored TRANSPOSED, so both products contract over the second index of two row-major operands:
+//       W[i][j] = sum_k P+[i][k] Tc[j][k],        X[r][c] = sum_k Tc[r][k] Wt[c][k].
+//   * an EVEN leading dimension (NP + 2) makes every row 16-byte aligned: one ds_read_b128 feeds two k-steps (the odd
+//     stride of round 1 allowed only ds_read_b64, one per operand element and k-step);
+//   * a stage covers four k-steps (12 loads, 36 FMAs for 3 x 3 blocks) and two stages are in flight; the round-1 loop
+//     had 6 loads / 9 FMAs per stage, which did not cover the LDS latency.
+//   Measured (tools/kalman_phases.py, draw 0, two waves per SIMD): products 7.5 k -> 5.4 k cycles including the mean
+//   prediction and the P Z' panel, full step 15.2 k -> 12.6 k, launch 1.28 -> 1.09 ms per 4096 draws.
+//
+// Two reformulations of the measurement update were built and measured on the way and are NOT used:
+// observation-at-a-time updates on the register blocks (exact for a diagonal H + jitter I; 12 ds_bpermute per observation,
+// 8.4 k + 6.4 k cycles with the jitter K K' correction) and a Gauss-Jordan recursion on the u x p panel with one row per
+// lane (p^2 v_readlane pairs: 11 k cycles).  Both reproduce the oracle to 3e-16 in numpy; neither beats the joint
+// p x p inverse (3.4 k) + gain (1.3 k) + downdate (2.5 k) on this hardware.
+#pragma once
+#include <type_traits>
+
+#include "dsge_kalman2.hpp"
+
+namespace dsge {
+
+template <int BS>
+struct KntSmem {
+  static constexpr int NP = Tile<BS>::NP, LDK = NP + 2, PS = 10;
+  static constexpr int WT = (NP * LDK > NP * PS) ? NP * LDK : NP * PS;  // W' buffer; the V panel aliases it
+  // doubles: Tc NP*LDK, Wt WT, Pc s_cap*LDK, PZt, Ks NP*PS each, Fi 64, av NP, af NP, vv/dd/hh/zv 8 each; ints perm NP, zpos 8
+  __host__ __device__ static constexpr size_t doubles(int s_cap) {
+    return (size_t)NP * LDK + WT + (size_t)s_cap * LDK + 2 * (size_t)NP * PS + 64 + 2 * NP + 32 + NP / 2 + 4;
+  }
+  static size_t bytes(int s_cap) { return sizeof(double) * doubles(s_cap); }
+};
+
+// acc += A[rows lr*BS.., :K] * B[rows lc*BS.., :K]'  -- both operands row-major along k with the even stride LD
+// (16-byte aligned rows): one ds_read_b128 per row and k-pair, stages of four k-steps, two stages in flight.
+// K is rounded up to a multiple of four: the callers keep the padding columns zero / finite.
+template <int BS, int LD>
+__device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, const double* B, int K, int lr, int lc) {
+  const double2* ap = reinterpret_cast<const double2*>(A + lr * BS * LD);
+  const double2* bp = reinterpret_cast<const double2*>(B + lc * BS * LD);
+  constexpr int RS = LD / 2;  // row stride in double2
+  double2 a0[BS][2], b0[BS][2], a1[BS][2], b1[BS][2];
+#define NT_LOAD(a, b, q)                                                     \
+  do {                                                                       \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i) {                         \
+      a[i][0] = ap[i * RS + 2 * (q)];                                        \
+      a[i][1] = ap[i * RS + 2 * (q) + 1];                                    \
+    }                                                                        \
+    _Pragma("unroll") for (int j = 0; j < BS; ++j) {                         \
+      b[j][0] = bp[j * RS + 2 * (q)];                                        \
+      b[j][1] = bp[j * RS + 2 * (q) + 1];                                    \
+    }                                                                        \
+  } while (0)
+#define NT_FMA(a, b)                                                         \
+  do {                                                                       \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i)                           \
+      _Pragma("unroll") for (int j = 0; j < BS; ++j) {                       \
+        acc[i][j] = fma(a[i][0].x, b[j][0].x, acc[i][j]);                    \
+        acc[i][j] = fma(a[i][0].y, b[j][0].y, acc[i][j]);                    \
+        acc[i][j] = fma(a[i][1].x, b[j][1].x, acc[i][j]);                    \
+        acc[i][j] = fma(a[i][1].y, b[j][1].y, acc[i][j]);                    \
+      }                                                                      \
+  } while (0)
+  const int nq = (K + 3) >> 2;
+  if (nq <= 0) return;
+  NT_LOAD(a0, b0, 0);
+  int q = 0;
+  for (; q + 2 <= nq; q += 2) {
+    NT_LOAD(a1, b1, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    NT_FMA(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int qn = (q + 2 < nq) ? q + 2 : nq - 1;
+    NT_LOAD(a0, b0, qn);
+    __builtin_amdgcn_sched_barrier(0);
+    NT_FMA(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (q < nq) NT_FMA(a0, b0);
+#undef NT_LOAD
+#undef NT_FMA
+}
+
+// Calls f(integral_constant<J>) for the wave-uniform j in [0, BS): a chain of scalar branches, so that the column index
+// of a register block is a compile-time constant inside f.  (A select chain over the block's registers is pattern-
+// matched by LLVM into a dynamically indexed array -- the whole covariance block then lives in scratch memory: measured
+// 3.5 k cycles per observation instead of 0.3 k.)
+template <int BS, int J = 0, typename F>
+__device__ __forceinline__ void dispatch_col(int j, F&& f) {
+  if constexpr (J + 1 < BS) {
+    if (j == J)
+      f(std::integral_constant<int, J>{});
+    else
+      dispatch_col<BS, J + 1>(j, f);
+  } else {
+    f(std::integral_constant<int, J>{});
+  }
+}
+
+// One scalar measurement update: observation with selector value zvo on state z = lz * BS + JZ, noise variance hto
+// (= h + jitter), residual constant yd = y_o - d_o.
+template <int BS, int JZ>
+__device__ __forceinline__ void seq_update_obs(double (&Pb)[BS][BS], double (&arow)[BS], int lane, int lc, int lz,
+                                               double zvo, double hto, double yd, double& step_quad, double& step_mant,
+                                               int& step_exp) {
+  double grow[BS], gcol[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) grow[i] = zvo * __shfl(Pb[i][JZ], (lane & 56) | lz, 64);  // zv P[lr*BS+i][z]
+#pragma unroll
+  for (int j = 0; j < BS; ++j) gcol[j] = zvo * __shfl(Pb[j][JZ], (lc << 3) | lz, 64);     // zv P[lc*BS+j][z] (P symmetric)
+  const double gz = readlane_f64(grow[JZ], lz << 3);                                      // zv P[z][z]
+  const double az = readlane_f64(arow[JZ], lz << 3);                                      // a[z]
+  const double f = fma(zvo, gz, hto);
+  const double finv = fast_rcp(f);
+  const double v = yd - zvo * az;
+  const double w = v * finv;
+  step_quad = fma(v, w, step_quad);
+  int e;
+  step_mant *= frexp(f, &e);
+  step_exp += e;
+#pragma unroll
+  for (int i = 0; i < BS; ++i) arow[i] = fma(grow[i], w, arow[i]);
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) Pb[i][j] = fma(-(grow[i] * gcol[j]), finv, Pb[i][j]);
+}
+
+// Db += kap * c c',  c = column z = lz * BS + JZ of the (filtered) covariance block
+template <int BS, int JZ>
+__device__ __forceinline__ void seq_gain_term(const double (&Pb)[BS][BS], double (&Db)[BS][BS], int lane, int lc, int lz,
+                                              double kap) {
+  double crow[BS], ccol[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) crow[i] = kap * __shfl(Pb[i][JZ], (lane & 56) | lz, 64);
+#pragma unroll
+  for (int j = 0; j < BS; ++j) ccol[j] = __shfl(Pb[j][JZ], (lc << 3) | lz, 64);
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) Db[i][j] = fma(crow[i], ccol[j], Db[i][j]);
+}
+
+// DBG = true: the instance tools/kalman_phases.py launches (phase stamps of draw 0 in `dbg`); the product instance carries
+// neither the stamps nor their registers.
+template <int BS, bool DBG = false>
+__global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2 : 1))) void kalman_nt_kernel(
+    const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
+    const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
+    const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
+    int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
+    int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
+    const int32_t* __restrict__ order) {
+  constexpr int NP = KntSmem<BS>::NP, LDK = KntSmem<BS>::LDK, PS = KntSmem<BS>::PS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Tc = smem;                 // NP x LDK    transition, states-first ordering (columns >= s exactly zero)
+  double* Wt = Tc + NP * LDK;        // WT doubles  W' : Wt[j][k] = (P+[S,S] Tc')[k][j]            (phase f)
+  double* Vs = Wt;                   //   alias: NP x PS  V = P Zm' + jitter K                    (phases d, e)
+  double* Pc = Wt + KntSmem<BS>::WT; // s_cap x LDK P+ restricted to the state block
+  double* PZt = Pc + s_cap * LDK;    // NP x PS     (predicted P) Z', unmasked
+  double* Ks = PZt + NP * PS;        // NP x PS     K = P Zm' Finv  (kept through the prediction: the steady loop reads it)
+  double* Fi = Ks + NP * PS;         // 8 x 8       Finv
+  double* av = Fi + 64;              // NP          predicted state
+  double* af = av + NP;              // NP          filtered state
+  double* vv = af + NP;              // 8 innovation
+  double* dd = vv + 8;               // 8 obs intercept
+  double* hh = dd + 8;               // 8 diag(H)
+  double* zv = hh + 8;               // 8 selector values
+  int* perm = (int*)(zv + 8);        // NP: position -> original variable (states first)
+  int* zpos = perm + NP;             // 8: position of the state each observation selects
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
+  const int fo = lane >> 3, fq = lane & 7;  // owner of F[fo][fq] at the switch
+  const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
+
+  for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
+    const int draw = order ? order[bi] : bi;
+    const int32_t st_in = status[draw];
+    if (rerun_only) {
+      if (st_in != DSGE_ST_INTERNAL_RERUN) continue;
+    } else if (st_in != 0) {
+      if (lane == 0) logp_out[draw] = -INFINITY;
+      continue;
+    }
+    const size_t off = (size_t)draw * m_full * m_full;
+    wave_sync();
+    for (int idx = lane; idx < (int)KntSmem<BS>::doubles(s_cap); idx += 64) smem[idx] = 0.0;
+
+    // ---- exact state-space reduction to U = S u O, states first (as kalman_sel_kernel) ----------------------------
+    const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
+    bool is_state = false;
+    {
+      const double* tcol = T + off + (lane < m_full ? lane : 0);
+      for (int r0 = 0; r0 < m_full; r0 += 8) {
+        double tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tv[u] = tcol[(size_t)(r0 + u < m_full ? r0 + u : m_full - 1) * m_full];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) is_state |= (tv[u] != 0.0);
+      }
+      is_state = is_state && (lane < m_full);
+    }
+    const unsigned long long colmask = __ballot(is_state);
+    unsigned long long obsmask = 0ull, used = 0ull;
+    bool ok = true;
+    for (int o = 0; o < p; ++o) {
+      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
+      const unsigned long long b = __ballot(zl != 0.0);
+      if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
+      used |= b;
+      obsmask |= b;
+    }
+    const unsigned long long extra = obsmask & ~colmask;  // observed non-states
+    const int s = __popcll(colmask);
+    const int m = s + __popcll(extra);
+    ok = ok && (s <= s_cap) && (m <= NP);
+    int my_pos = -1;
+    if (lane < m_full) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if ((colmask >> lane) & 1ull)
+        my_pos = __popcll(colmask & below);
+      else if ((extra >> lane) & 1ull)
+        my_pos = s + __popcll(extra & below);
+      if (my_pos >= 0 && my_pos < NP) perm[my_pos] = lane;
+    }
+    for (int o = 0; o < p; ++o) {
+      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
+      if (zl != 0.0) {
+        zpos[o] = (my_pos >= 0 && my_pos < NP) ? my_pos : 0;
+        zv[o] = zl;
+      }
+    }
+    if (!ok) {
+      if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
+      continue;
+    }
+    if (rerun_only && lane == 0) status[draw] = 0;
+    wave_sync();
+    int pr[BS], pcx[BS], ocol[BS];
+    double zcol[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      const int r = lr * BS + i, c = lc * BS + i;
+      pr[i] = (r < m) ? perm[r] : -1;
+      pcx[i] = (c < m) ? perm[c] : -1;
+      ocol[i] = -1;
+      zcol[i] = 0.0;
+      for (int o = 0; o < p; ++o)
+        if (zpos[o] == c) {
+          ocol[i] = o;
+          zcol[i] = zv[o];
+        }
+    }
+    double Qb[BS][BS], Pb[BS][BS], Tb0[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const bool in = pr[i] >= 0 && pcx[j] >= 0;
+        const size_t g = in ? (size_t)pr[i] * m_full + pcx[j] : 0;
+        const double tv = in ? T[off + g] : 0.0;
+        Qb[i][j] = in ? RQR[off + g] : 0.0;
+        Pb[i][j] = (in && P0) ? P0[off + g] : 0.0;
+        Tb0[i][j] = tv;
+        Tc[(lr * BS + i) * LDK + lc * BS + j] = tv;
+      }
+    const bool in_state_block = (lr * BS < s) && (lc * BS < s);
+    const bool w_rows = lr * BS < s;  // this lane's rows of W = P+[S,S] Tc' exist
+    if (!P0) {
+      // ---- P0 = dlyap(T, RQR)[U,U] by doubling on the reduced model (statespace.py:814-815) ---------------------
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Pb[i][j] = Qb[i][j];
+      bool lyap_ok = false;
+      for (int itl = 0; itl < 64; ++itl) {
+        wave_sync();
+        if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDK, lr, lc);
+        wave_sync();
+        if (w_rows) {
+          double Wb[BS][BS];
+          blk_zero<BS>(Wb);
+          mm_nt<BS, LDK>(Wb, Pc, Tc, s, lr, lc);  // P[S,S] A_k'
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) Wt[(lc * BS + j) * LDK + lr * BS + i] = Wb[i][j];
+        }
+        double Ab[BS][BS];
+        blk_zero<BS>(Ab);
+        mm_acc_p<BS, false, LDK, LDK>(Ab, Tc, Tc, s, lr, lc);  // A_k[:,S] A_k[S,:]
+        wave_sync();
+        double Xb[BS][BS];
+        blk_zero<BS>(Xb);
+        mm_nt<BS, LDK>(Xb, Tc, Wt, s, lr, lc);
+        wave_sync();
+        blk_store_lds<BS>(Ab, Tc, LDK, lr, lc);
+        const int src = (lc << 3) | lr;
+        double dmax = 0.0, pmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const double xt = __shfl(Xb[j][i], src, 64);
+            const double dlt = 0.5 * (Xb[i][j] + xt);
+            Pb[i][j] += dlt;
+            dmax = nanmax(dmax, fabs(dlt));
+            pmax = nanmax(pmax, fabs(Pb[i][j]));
+          }
+        dmax = wave_nanmax(dmax);
+        pmax = wave_nanmax(pmax);
+        if (!(dmax == dmax) || !(pmax < 1e300)) break;
+        if (dmax <= 1e-17 * pmax) {
+          lyap_ok = true;
+          break;
+        }
+      }
+      wave_sync();
+      blk_store_lds<BS>(Tb0, Tc, LDK, lr, lc);
+      for (int idx = lane; idx < KntSmem<BS>::WT; idx += 64) Wt[idx] = 0.0;  // (the filter relies on zero padding)
+      if (!lyap_ok) {
+        if (lane == 0) {
+          status[draw] |= DSGE_ST_LYAP_FAIL;
+          logp_out[draw] = -INFINITY;
+        }
+        continue;
+      }
+    }
+    if (lane < 8) {
+      dd[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+      hh[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+    }
+    // P Z' panel of the predicted covariance (unmasked): written by the lanes that own an observed column
+#define STORE_PZT()                                                                              \
+  do {                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < BS; ++j) if (ocol[j] >= 0) {                           \
+      _Pragma("unroll") for (int i = 0; i < BS; ++i) PZt[(lr * BS + i) * PS + ocol[j]] = zcol[j] * Pb[i][j]; \
+    }                                                                                            \
+  } while (0)
+    STORE_PZT();
+    const int my_zpos = (fo < p) ? zpos[fo] : 0;
+    const double my_zv = (fo < p) ? zv[fo] : 0.0;
+    const int v_zpos = (lane < p) ? zpos[lane] : 0;
+    const double v_zv = (lane < p) ? zv[lane] : 0.0, v_dd = (lane < 8) ? dd[lane & 7] : 0.0;
+    wave_sync();
+
+    double quad_sum = 0.0, quad_comp = 0.0;  // Kahan sum of v' Finv v over observed steps
+    double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
+    int ld_exp = 0;
+    int n_ll_steps = 0;
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk_start = DBG ? clock64() : 0;
+    double av_reg = 0.0;  // predicted state a_{t|t-1}, one entry per lane
+    int steady_step = -1;
+    double yt_next = (lane < p && T_len > 0) ? y[lane] : 0.0;
+    for (int t = 0; t < T_len; ++t) {
+      long long tk0 = DBG ? clock64() : 0;
+      // ---- (a) missing-data mask ------------------------------------------------------
+      const double yt = yt_next;
+      yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
+      const unsigned long long omask = __ballot(obs);
+      const int n_obs = __popcll(omask);
+      bool steady = false;
+      double pscale = 0.0;
+      if (steady_tol > 0.0) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) pscale = nanmax(pscale, fabs(Pb[i][j]));
+      }
+      // ---- (b) the innovation (selector: one entry of the predicted state per observation) -----------------------
+      const double av_sel0 = __shfl(av_reg, v_zpos, 64);
+      double v_own = 0.0;
+      if (lane < p) v_own = (obs ? yt : 0.0) - (v_dd + (obs ? 1.0 : 0.0) * (v_zv * av_sel0));
+      if (lane < 8) vv[lane] = v_own;
+      // ---- (b') F[fo][fq]: lane (fo,fq) of the 8 x 8 grid ---------------------------------------
+      double step_mant = 1.0;
+      int step_exp = 0;
+      double f;
+      {
+        const double wo = (double)((omask >> fo) & 1ull), wq = (double)((omask >> fq) & 1ull);
+        if (fo < p && fq < p) {
+          f = wo * wq * my_zv * PZt[my_zpos * PS + fq];
+          if (fo == fq) f += wo * hh[fo] + jitter;
+        } else {
+          f = (fo == fq) ? 1.0 : 0.0;
+        }
+      }
+      // ---- (c) Finv by in-register Gauss-Jordan (SPD: no pivoting) ----
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < p) {
+          const double piv = readlane_f64(f, j * 9);
+          const double rowj = __shfl(f, (j << 3) | fq, 64);
+          const double colj = __shfl(f, (fo << 3) | j, 64);
+          const double inv = fast_rcp(piv);
+          const double ci = colj * inv;
+          double nf = fma(-ci, rowj, f);
+          nf = (fo == j) ? rowj * inv : nf;
+          nf = (fq == j) ? -ci : nf;
+          nf = (fo == j && fq == j) ? inv : nf;
+          f = nf;
+          int e;
+          step_mant *= frexp(piv, &e);
+          step_exp += e;
+        }
+      }
+      Fi[lane] = f;
+      const double qp = wave_sum_dpp(f * __shfl(v_own, fo, 64) * __shfl(v_own, fq, 64));
+      if (n_obs > 0) {
+        const double yk = qp - quad_comp;
+        const double tk = quad_sum + yk;
+        quad_comp = (tk - quad_sum) - yk;
+        quad_sum = tk;
+        int e;
+        ld_mant = frexp(ld_mant * step_mant, &e);
+        ld_exp += e + step_exp;
+        ++n_ll_steps;
+      }
+      wave_sync();  // #1
+      if constexpr (DBG) {
+        const long long tk1 = clock64();
+        ph[0] += tk1 - tk0;
+        tk0 = tk1;
+      }
+      // ---- (d) K = (P Zm') Finv, V = P Zm' + jitter K, a+ = a + K v -----------------------------
+      {
+        const int o2 = lane & 3, i16 = lane >> 2;
+        double2 fi2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fi2[q] = *reinterpret_cast<const double2*>(&Fi[q * 8 + 2 * o2]);
+        const double2 vp = *reinterpret_cast<const double2*>(&vv[2 * o2]);
+        const bool on0 = (omask >> (2 * o2)) & 1ull, on1 = (omask >> (2 * o2 + 1)) & 1ull;
+#pragma unroll
+        for (int pass = 0; pass < (NP + 15) / 16; ++pass) {
+          const int i = i16 + 16 * pass;
+          const bool row_ok = i < m;
+          const int ir = row_ok ? i : 0;
+          double k0 = 0.0, k1 = 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < 4; ++q2) {
+            const double2 t2 = *reinterpret_cast<const double2*>(&PZt[ir * PS + 2 * q2]);
+            const double pa = ((omask >> (2 * q2)) & 1ull) ? t2.x : 0.0;
+            const double pb2 = ((omask >> (2 * q2 + 1)) & 1ull) ? t2.y : 0.0;
+            k0 = fma(pa, fi2[2 * q2].x, k0);
+            k1 = fma(pa, fi2[2 * q2].y, k1);
+            k0 = fma(pb2, fi2[2 * q2 + 1].x, k0);
+            k1 = fma(pb2, fi2[2 * q2 + 1].y, k1);
+          }
+          const double2 pzp = *reinterpret_cast<const double2*>(&PZt[ir * PS + 2 * o2]);
+          double part = fma(k0, vp.x, k1 * vp.y);
+          part += dpp_move_f64<0xB1, 0xf>(part);  // quad_perm [1,0,3,2]
+          part += dpp_move_f64<0x4E, 0xf>(part);  // quad_perm [2,3,0,1]
+          if (row_ok) {
+            *reinterpret_cast<double2*>(&Ks[i * PS + 2 * o2]) = double2{k0, k1};
+            *reinterpret_cast<double2*>(&Vs[i * PS + 2 * o2]) =
+                double2{fma(jitter, k0, on0 ? pzp.x : 0.0), fma(jitter, k1, on1 ? pzp.y : 0.0)};
+            if (o2 == 0) af[i] = av[i] + part;
+          }
+        }
+      }
+      wave_sync();  // #2
+      if constexpr (DBG) {
+        const long long tk1 = clock64();
+        ph[1] += tk1 - tk0;
+        tk0 = tk1;
+      }
+      // ---- (e) P+ = P - K V' + jitter I (register blocks); state block -> LDS -------------
+      {
+        double2 ka[BS], vb[BS], kan[BS], vbn[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) ka[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * PS]);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) vb[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * PS]);
+#pragma unroll
+        for (int o2 = 0; o2 < 4; ++o2) {
+          if (o2 < 3) {
+#pragma unroll
+            for (int i = 0; i < BS; ++i) kan[i] = *reinterpret_cast<const double2*>(&Ks[(lr * BS + i) * PS + 2 * (o2 + 1)]);
+#pragma unroll
+            for (int j = 0; j < BS; ++j) vbn[j] = *reinterpret_cast<const double2*>(&Vs[(lc * BS + j) * PS + 2 * (o2 + 1)]);
+          }
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+              Pb[i][j] = fma(-ka[i].x, vb[j].x, Pb[i][j]);
+              Pb[i][j] = fma(-ka[i].y, vb[j].y, Pb[i][j]);
+            }
+#pragma unroll
+          for (int i = 0; i < BS; ++i) ka[i] = kan[i];
+#pragma unroll
+          for (int j = 0; j < BS; ++j) vb[j] = vbn[j];
+        }
+      }
+      if (lr == lc) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+          if (lr * BS + i < m) Pb[i][i] += jitter;
+      }
+      if (steady_tol > 0.0) {
+        double dmax = 0.0;
+        if (in_state_block) {
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) dmax = nanmax(dmax, fabs(Pb[i][j] - Pc[(lr * BS + i) * LDK + lc * BS + j]));
+        }
+        const double dm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(dmax)));
+        const double pm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(pscale)));
+        steady = (t > 0) && (dm <= steady_tol * pm);
+      }
+      if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDK, lr, lc);
+      wave_sync();  // #3
+      if constexpr (DBG) {
+        const long long tk1 = clock64();
+        ph[2] += tk1 - tk0;
+        tk0 = tk1;
+      }
+      // ---- (f) predict: a = Tc a+[:s];  W = P+[S,S] Tc' (stored transposed);  X = Tc W;  P = sym(X) + RQR -------------
+      if (lane < m) {
+        const double2* trow2 = reinterpret_cast<const double2*>(Tc + lane * LDK);
+        const double2* af2 = reinterpret_cast<const double2*>(af);
+        double s0 = 0.0, s1 = 0.0;
+        for (int kk = 0; 2 * kk < s; ++kk) {  // (columns >= s of Tc are zero: an odd s reads one harmless extra term)
+          const double2 tv2 = trow2[kk], fv = af2[kk];
+          s0 = fma(tv2.x, fv.x, s0);
+          s1 = fma(tv2.y, fv.y, s1);
+        }
+        av_reg = s0 + s1;
+        av[lane] = av_reg;
+      }
+      if (w_rows) {
+        double Wb[BS][BS];
+        blk_zero<BS>(Wb);
+        mm_nt<BS, LDK>(Wb, Pc, Tc, s, lr, lc);
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) Wt[(lc * BS + j) * LDK + lr * BS + i] = Wb[i][j];
+      }
+      wave_sync();  // #4
+      if constexpr (DBG) {
+        const long long tk1 = clock64();
+        ph[3] += tk1 - tk0;
+        tk0 = tk1;
+      }
+      {
+        double Xb[BS][BS];
+        blk_zero<BS>(Xb);
+        mm_nt<BS, LDK>(Xb, Tc, Wt, s, lr, lc);
+        const int src = (lc << 3) | lr;  // lane holding the transposed block
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const double xt = __shfl(Xb[j][i], src, 64);
+            Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
+          }
+      }
+      STORE_PZT();
+      wave_sync();  // #5
+      if constexpr (DBG) {
+        const long long tk1 = clock64();
+        ph[4] += tk1 - tk0;
+        tk0 = tk1;
+      }
+      if (!steady) continue;
+      // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same (register-only) ====
+      if (steady_step < 0) steady_step = t + 1;
+      {
+        double trow[NP], finv_row[8], kr_ss[8];
+#pragma unroll
+        for (int kk = 0; kk < NP; ++kk) trow[kk] = (lane < NP) ? Tc[lane * LDK + kk] : 0.0;  // columns >= s are zero
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          finv_row[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
+          kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
+        }
+        while (t + 1 < T_len) {
+          const double yt_s = yt_next;
+          const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);
+          if (__ballot(obs_s) != omask) break;
+          ++t;
+          yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+          const double av_sel = __shfl(av_reg, v_zpos, 64);
+          double v_s = 0.0;
+          if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
+          double vsc[8];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
+          double w0 = 0.0, w1 = 0.0, a0 = av_reg, a1 = 0.0;
+#pragma unroll
+          for (int o = 0; o < 8; o += 2) {
+            w0 = fma(finv_row[o], vsc[o], w0);
+            w1 = fma(finv_row[o + 1], vsc[o + 1], w1);
+            a0 = fma(kr_ss[o], vsc[o], a0);
+            a1 = fma(kr_ss[o + 1], vsc[o + 1], a1);
+          }
+          double part = v_s * (w0 + w1);  // lanes >= 8 hold finv_row = 0
+          part += dpp_move_f64<0x111, 0xf>(part);
+          part += dpp_move_f64<0x112, 0xf>(part);
+          part += dpp_move_f64<0x114, 0xf>(part);
+          const double qp_s = readlane_f64(part, 7);
+          if (n_obs > 0) {
+            const double yk = qp_s - quad_comp;
+            const double tk = quad_sum + yk;
+            quad_comp = (tk - quad_sum) - yk;
+            quad_sum = tk;
+            int e;
+            ld_mant = frexp(ld_mant * step_mant, &e);
+            ld_exp += e + step_exp;
+            ++n_ll_steps;
+          }
+          const double afi = a0 + a1;
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < NP; kk += 2) {
+            s0 = fma(trow[kk], readlane_f64(afi, kk), s0);
+            s1 = fma(trow[kk + 1], readlane_f64(afi, kk + 1), s1);
+          }
+          av_reg = (lane < m) ? s0 + s1 : 0.0;
+          if constexpr (DBG) ++ph[6];
+        }
+        if (lane < m) av[lane] = av_reg;  // hand the predicted state back to the LDS copy
+      }
+      wave_sync();
+      if constexpr (DBG) ph[5] += clock64() - tk0;
+    }
+#undef STORE_PZT
+    if (DBG && dbg && draw == 0 && lane == 0) {
+      ph[7] = clock64() - tk_start;
+      for (int k = 0; k < 8; ++k) dbg[k] = ph[k];
+    }
+    if (lane == 0) {
+      const double logdet = log(ld_mant) + (double)ld_exp * LN2;
+      const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_sum);
+      logp_out[draw] = ll;
+      if (steady_at) steady_at[draw] = steady_step;
+      if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
+    }
+  }
+}
+
+}  // namespace dsge

@@ -4,6 +4,7 @@
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
+#include "dsge_kalman_nt.hpp"
 #include "dsge_kalman_tail.hpp"
 #include "dsge_kalman_tiny.hpp"
 
@@ -174,6 +175,30 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                  s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
+              HIP_TRY(hipGetLastError());
+              launched_fast = true;
+            }
+            done = true;
+          }
+          if (!done && opt().kalman_nt_products) {
+            // round-2 fast path: NT prediction products on 16-byte aligned rows (dsge_kalman_nt.hpp)
+            const size_t lds_q = dsge::KntSmem<BS>::bytes(s_cap);
+            if (g_kalman_dbg) {  // tools/kalman_phases.py: the instance with the phase stamps
+              rc = set_lds(dsge::kalman_nt_kernel<BS, true>, lds_q);
+              if (rc == DSGE_SUCCESS)
+                hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T,
+                                   RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
+                                   s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                   g_kalman_steady_at, order);
+            } else {
+              rc = set_lds(dsge::kalman_nt_kernel<BS>, lds_q);
+              if (rc == DSGE_SUCCESS)
+                hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T, RQR,
+                                   p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
+                                   s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                   g_kalman_steady_at, order);
+            }
+            if (rc == DSGE_SUCCESS) {
               HIP_TRY(hipGetLastError());
               launched_fast = true;
             }

@@ -119,6 +119,7 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
  *                        the model like n_state_hint, verified per draw on the device; with a value >= 0 the fused call
  *                        is a pure enqueue (stream-capturable); -1 (default) measures it on the device on the first
  *                        call of a model size: one small launch, a 4-byte read-back and a stream synchronisation
+ *   kalman_nt_products  : see dsge_set_kalman_nt_products
  *   kalman_order, kalman_tiny, kalman_block, kalman_mfma, pipeline_chunks, gensys_split, kalman_steady_tol :
  *                        see the dsge_set_* function of the same name
  */
@@ -136,6 +137,8 @@ typedef struct dsge_options {
   int32_t pipeline_chunks;
   int32_t gensys_split;
   double kalman_steady_tol;
+  int32_t kalman_nt_products;
+  int32_t reserved_;
 } dsge_options;
 /* fills *opt with the current process-wide defaults */
 int dsge_options_init(dsge_options* opt);
@@ -212,6 +215,12 @@ int dsge_set_kalman_steady_tol(double tol);
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
 int dsge_set_kalman_tiny(int enable);
+/* Selector design matrix, p <= 8: the two prediction products of a full filter step run in "NT" form on 16-byte aligned
+ * rows (W stored transposed, even leading dimension, one ds_read_b128 per two k-steps, stages of four k-steps double-
+ * buffered; dsge_kalman_nt.hpp): 15.2 k -> 12.6 k cycles per full step on the 18-variable bench model.  enable = 0 keeps
+ * the round-1 kernel (kalman_sel_kernel); same arithmetic up to the summation order of the products (tests compare them).
+ * Process-wide DEFAULT (per call: dsge_options); default 1. */
+int dsge_set_kalman_nt_products(int enable);
 /* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
  * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
  * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by
