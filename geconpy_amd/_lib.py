@@ -58,6 +58,8 @@ PROTOTYPES = {
     "dsge_scan_cycle_reduction_batched_host": [_dp, _dp, _dp, _i, _i, _i, _f, _dp, _dp, _dp],
     "dsge_gensys_batched": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_gensys_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
+    "dsge_gensys_pencil_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_gensys_pencil_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_bk_eigenvalues_batched": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_bk_eigenvalues_batched_host": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_set_cr_compact": [_i],

@@ -100,6 +100,30 @@ def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None, options=None):
     return out
 
 
+def gensys_pencil_batched(g0, g1, psi, pi, c=None, tol=1e-8):
+    """Batched ``gensys(g0, g1, c, psi, pi)`` (gEconpy/solvers/gensys.py:398-521) on caller-supplied pencils:
+    returns dict(G1, C, impact, gev (batch, N, 2) complex (alpha, beta), eu, status, success)."""
+    g0, g1 = _f64(g0, 3), _f64(g1, 3)
+    psi, pi = _f64(psi, 3), _f64(pi, 3)
+    nb, N, _ = g0.shape
+    if g1.shape != (nb, N, N) or psi.shape[:2] != (nb, N) or pi.shape[:2] != (nb, N):
+        raise ValueError("g0, g1: (batch, N, N); psi: (batch, N, k); pi: (batch, N, n_eta)")
+    k, ne = psi.shape[2], pi.shape[2]
+    if c is not None:
+        c = _f64(c).reshape(nb, N)
+    G1 = np.empty_like(g0)
+    Cc = np.empty((nb, N))
+    impact = np.empty((nb, N, k))
+    gev = np.empty((nb, N, 4))
+    eu = np.empty((nb, 3), dtype=np.int32)
+    status = np.empty(nb, dtype=np.int32)
+    _lib.check(_lib.load().dsge_gensys_pencil_batched_host(_ptr(g0), _ptr(g1), _ptr(c), _ptr(psi), _ptr(pi), nb, N, k, ne,
+                                                           float(tol), _ptr(G1), _ptr(Cc), _ptr(impact), _ptr(gev), _ptr(eu),
+                                                           _ptr(status)))
+    gev_c = np.stack([gev[..., 0] + 1j * gev[..., 1], gev[..., 2] + 1j * gev[..., 3]], axis=-1)
+    return dict(G1=G1, C=Cc, impact=impact, gev=gev_c, eu=eu, status=status, success=status == 0)
+
+
 def selection_batched(B, C, D, T, A=None):
     """R = -(C T + B)^-1 D (gEconpy/solvers/shared.py:74-75); with ``A`` also the residual
     ``sum((A + B T + C T T)^2)`` (gEconpy/model/statespace.py:213)."""

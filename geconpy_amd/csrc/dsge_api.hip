@@ -374,6 +374,20 @@ int dsge_gensys_batched(const double* A, const double* B, const double* C, const
   return DSGE_SUCCESS;
 }
 
+int dsge_gensys_pencil_batched(const double* g0, const double* g1, const double* c, const double* psi, const double* pi,
+                               int batch, int N, int k, int n_eta, double tol, double* G1_out, double* C_out,
+                               double* impact_out, double* gev_out, int32_t* eu_out, int32_t* status, void* stream) {
+  int rc = check_common(batch, N, DSGE_MAX_N_GENSYS);
+  if (rc) return rc;
+  if (k < 1 || n_eta < 0 || n_eta + k + 1 > 64) return fail(DSGE_ERR_INVALID, "need k >= 1, n_eta >= 0, n_eta + k + 1 <= 64");
+  if (!g0 || !g1 || !psi || (n_eta > 0 && !pi) || !G1_out || !C_out || !impact_out || !gev_out || !eu_out || !status)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  return launch_gensys_pencil(g0, g1, c, psi, pi, batch, N, k, n_eta, tol, G1_out, C_out, impact_out, gev_out, eu_out, status,
+                              (hipStream_t)stream);
+}
+
 int dsge_bk_eigenvalues_batched(const double* A, const double* B, const double* C, int batch, int n, double tol,
                                 double* eig_re, double* eig_im, int32_t* n_eig, int32_t* n_forward,
                                 int32_t* n_unstable, int32_t* status, void* stream) {
@@ -988,6 +1002,45 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
   if ((rc = dsge_gensys_batched(dA, dB, dC, dDp, batch, n, k, tol, n_lead_hint, dT, dR, dE, dS, nullptr))) return rc;
   DOWN(T_out, dT, nn, double);
   DOWN(R_out, dR, nk, double);
+  DOWN(eu_out, dE, (size_t)batch * 3, int32_t);
+  DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const double* c, const double* psi, const double* pi,
+                                    int batch, int N, int k, int n_eta, double tol, double* G1_out, double* C_out,
+                                    double* impact_out, double* gev_out, int32_t* eu_out, int32_t* status) {
+  int rc = check_common(batch, N, DSGE_MAX_N_GENSYS);
+  if (rc) return rc;
+  if (k < 1 || n_eta < 0 || n_eta + k + 1 > 64) return fail(DSGE_ERR_INVALID, "need k >= 1, n_eta >= 0, n_eta + k + 1 <= 64");
+  if (!g0 || !g1 || !psi || (n_eta > 0 && !pi) || !G1_out || !C_out || !impact_out || !gev_out || !eu_out || !status)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * N * N, nk = (size_t)batch * N * k, ne = (size_t)batch * N * (n_eta > 0 ? n_eta : 1),
+               nv = (size_t)batch * N;
+  void* base = nullptr;
+  STAGE_RESERVE(3 * align256(nn * 8) + 2 * align256(nk * 8) + align256(ne * 8) + 2 * align256(nv * 8) + align256(nv * 32) +
+                    2 * align256((size_t)batch * 12) + 4096,
+                &base);
+  Carver cv(base);
+  UP(d0, g0, nn, double);
+  UP(d1, g1, nn, double);
+  UP(dc, c, nv, double);
+  UP(dps, psi, nk, double);
+  UP(dpi, pi, (size_t)batch * N * n_eta, double);
+  OUTBUF(dG, G1_out, nn, double);
+  OUTBUF(dC, C_out, nv, double);
+  OUTBUF(dI, impact_out, nk, double);
+  OUTBUF(dV, gev_out, nv * 4, double);
+  OUTBUF(dE, eu_out, (size_t)batch * 3, int32_t);
+  OUTBUF(dS, status, batch, int32_t);
+  if ((rc = dsge_gensys_pencil_batched(d0, d1, dc, dps, dpi, batch, N, k, n_eta, tol, dG, dC, dI, dV, dE, dS, nullptr))) return rc;
+  DOWN(G1_out, dG, nn, double);
+  DOWN(C_out, dC, nv, double);
+  DOWN(impact_out, dI, nk, double);
+  DOWN(gev_out, dV, nv * 4, double);
   DOWN(eu_out, dE, (size_t)batch * 3, int32_t);
   DOWN(status, dS, batch, int32_t);
   HIP_TRY(hipStreamSynchronize(nullptr));

@@ -107,6 +107,7 @@ __device__ __forceinline__ void lartg(cx f, cx g, double& c, cx& s, cx& r) {
 
 struct GsLayout {
   int N, n, ell, ldh, ldx, ldz;  // complex leading dimensions (odd)
+  int xw;  // columns of X the left transformations act on (= ell, or ell + k + 1 when X = [Pi | Psi | c])
   cx *H, *T, *X, *Z, *V1, *V2, *S3;
   double *s1, *s2;
   int* lead;
@@ -242,7 +243,7 @@ __device__ __forceinline__ void rot_rows(const GsLayout& L, int i, int k, double
     tput(L, i, col, x);
     tput(L, k, col, y);
   }
-  if (lane < L.ell) {
+  if (lane < L.xw) {
     cx x = GX(i, lane), y = GX(k, lane);
     rot2(x, y, c, s);
     GX(i, lane) = x;
@@ -301,7 +302,7 @@ __device__ __forceinline__ RotLd rows_begin(const GsLayout& L, int i, int k, int
     o.tx = GT(i, lane);
     o.ty = GT(k, lane);
   }
-  if (lane < L.ell) {
+  if (lane < L.xw) {
     o.ax = GX(i, lane);
     o.ay = GX(k, lane);
   }
@@ -330,7 +331,7 @@ __device__ __forceinline__ Rot4 rows_finish(const GsLayout& L, int i, int k, Rot
     GT(i, lane) = d.tx;
     GT(k, lane) = d.ty;
   }
-  if (lane < L.ell) {
+  if (lane < L.xw) {
     GX(i, lane) = d.ax;
     GX(k, lane) = d.ay;
   }
@@ -358,7 +359,7 @@ __device__ __forceinline__ Rot4 rows_finish_real(const GsLayout& L, int i, int k
     GT(i, lane) = d.tx;
     GT(k, lane) = d.ty;
   }
-  if (lane < L.ell) {
+  if (lane < L.xw) {
     GX(i, lane) = d.ax;
     GX(k, lane) = d.ay;
   }
@@ -464,7 +465,7 @@ __device__ __forceinline__ Rot4 rot_rows_r(const GsLayout& L, int i, int k, doub
     tput(L, k, lane, v);
     o = Rot4{x, y, u, v};
   }
-  if (lane < L.ell) {
+  if (lane < L.xw) {
     cx x = GX(i, lane), y = GX(k, lane);
     rot2(x, y, c, s);
     GX(i, lane) = x;
@@ -532,7 +533,7 @@ __device__ __forceinline__ void householder_left(const GsLayout& L, cx* M, int j
   const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
   // pass 1: w_c = sum_r v_r M[r][c] for the lane's column of H, T and X
   double wh = 0.0, wt = 0.0, wx = 0.0;
-  const bool colact = lane < N, xact = lane < L.ell;
+  const bool colact = lane < N, xact = lane < L.xw;
   for (int r = j; r < N; ++r) {
     const double vr = readlane_dyn_f64(v, r);
     if (colact) {
@@ -793,7 +794,7 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
         const bool hl = half == 0, inw = idx < L.N;
         const int s_r = hl ? L.ldh : 1, a_r = hl ? idx + 4 : idx * L.ldh;
         const int s_c = hl ? 1 : L.ldh, a_c = hl ? idx * L.ldh + 4 : idx;
-        const bool xrow = lane < L.ell;
+        const bool xrow = lane < L.xw;
         cx cy = mk(0, 0);  // "y" output of the last column rotation: H(idx, j-1) on the H lanes
         for (int j = istart; j < ilast; ++j) {
           // ---- row rotation (j, j+1): H columns >= j-1, T columns >= j
@@ -1069,6 +1070,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
     }
     L.N = N;
     L.ell = ell;
+    L.xw = ell;
     wave_sync();
     // column permutation: exactly-zero columns of G1 (= zero columns of A, the non-state variables)
     // first.  colpos(c) = position of original column c.
@@ -1243,6 +1245,263 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
     }
     if (!have_T)
       for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+    if (lane == 0) {
+      eu_out[3 * draw] = eu0;
+      eu_out[3 * draw + 1] = eu1;
+      eu_out[3 * draw + 2] = eu2;
+      status[draw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK
+                                            : (DSGE_ST_NOT_CONVERGED | (converged ? 0 : DSGE_ST_GENSYS_QZ_FAIL));
+    }
+  }
+}
+
+
+// ---- gensys on a caller-supplied pencil (gensys(g0, g1, c, psi, pi), gEconpy/solvers/gensys.py:398-521 -> _gensys_core
+// :190-395): the interactive numpy path, not the hot loop.  Same QZ / reordering / existence-uniqueness code as
+// gensys_kernel on a general N x N pencil (no structural deflation, the whole right transformation Z in LDS) and the
+// outputs the reference's 9-tuple carries besides T: G1 (N x N), C (N x 1), impact (N x k), gev (alpha, beta), eu.
+//   X = [Pi | Psi | c]: the left transformation Q is applied to all of it (Q Pi for the existence / uniqueness SVDs,
+//   Q Psi for `impact` :359-365, Q c for `C` :345-357).
+//   Pi is first replaced by an orthonormal basis of its column space (one-sided Jacobi, columns with a zero norm dropped):
+//   G1, C, impact and eu depend on Pi only through that space, and orthonormal columns make eta = Q Pi orthonormal,
+//   which the CS-decomposition shortcut below relies on (the reference runs two gesdd, :270-296).
+__host__ __device__ inline size_t gensys_pencil_smem_bytes(int N, int ell, int xw) {
+  const int ldh = N | 1, ldx = xw | 1;
+  const size_t cplx = (size_t)3 * N * ldh + (size_t)N * ldx + (size_t)3 * ell * ldx;
+  return cplx * 16 + (size_t)2 * 64 * 8 + 64 * 4 + 64;
+}
+
+__global__ __launch_bounds__(64) void gensys_pencil_kernel(const double* __restrict__ g0, const double* __restrict__ g1,
+                                                            const double* __restrict__ cvec, const double* __restrict__ psi,
+                                                            const double* __restrict__ pi, int batch, int N, int k, int ell,
+                                                            double tol, double* __restrict__ G1_out,
+                                                            double* __restrict__ C_out, double* __restrict__ impact_out,
+                                                            double* __restrict__ gev_out, int32_t* __restrict__ eu_out,
+                                                            int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int xw = ell + k + 1;
+  GsLayout L;
+  L.n = N;  // all N rows of Z are kept
+  L.N = N;
+  L.ell = ell;
+  L.xw = xw;
+  L.ldh = N | 1;
+  L.ldx = xw | 1;
+  L.ldz = L.ldh;
+  gs_plain_map(L);
+  L.H = reinterpret_cast<cx*>(smem);
+  L.T = L.H + N * L.ldh;
+  L.Z = L.T + N * L.ldh;
+  L.X = L.Z + N * L.ldh;
+  L.V1 = L.X + N * L.ldx;
+  L.V2 = L.V1 + ell * L.ldx;
+  L.S3 = L.V2 + ell * L.ldx;
+  L.s1 = reinterpret_cast<double*>(L.S3 + ell * L.ldx);
+  L.s2 = L.s1 + 64;
+  L.lead = reinterpret_cast<int*>(L.s2 + 64);
+  const double rs = (tol > 0.0) ? tol : 2.220446049250313e-16;
+  const size_t total_cx = (size_t)3 * N * L.ldh + (size_t)N * L.ldx + (size_t)3 * ell * L.ldx;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t oNN = (size_t)draw * N * N;
+    wave_sync();
+    for (size_t idx = lane; idx < total_cx; idx += 64) L.H[idx] = mk(0, 0);
+    wave_sync();
+    for (int idx = lane; idx < N * N; idx += 64) {
+      const int i = idx / N, j = idx - i * N;
+      GH(i, j) = mk(g0[oNN + idx], 0.0);
+      GT(i, j) = mk(g1[oNN + idx], 0.0);
+      GZ(i, j) = mk(i == j ? 1.0 : 0.0, 0.0);
+    }
+    for (int idx = lane; idx < N * ell; idx += 64) GX(idx / ell, idx % ell) = mk(pi[(size_t)draw * N * ell + idx], 0.0);
+    for (int idx = lane; idx < N * k; idx += 64) GX(idx / k, ell + idx % k) = mk(psi[(size_t)draw * N * k + idx], 0.0);
+    if (cvec)
+      for (int idx = lane; idx < N; idx += 64) GX(idx, ell + k) = mk(cvec[(size_t)draw * N + idx], 0.0);
+    wave_sync();
+    // orthonormal basis of span(Pi)
+    if (ell > 0) {
+      jacobi_svd(&GX(0, 0), L.ldx, N, ell, nullptr, 0, L.s1, lane);
+      double smax = 0.0;
+      for (int j = 0; j < ell; ++j) smax = fmax(smax, L.s1[j]);
+      for (int idx = lane; idx < N * ell; idx += 64) {
+        const int i = idx / ell, j = idx - i * ell;
+        const double sj = L.s1[j];
+        GX(i, j) = (sj > 1e-13 * smax && sj > 0.0) ? (1.0 / sj) * GX(i, j) : mk(0, 0);
+      }
+      wave_sync();
+    }
+    hess_tri(L, 0, lane);
+    const bool converged = qz_iterate(L, 0, lane);
+    int eu0 = 0, eu1 = 0, eu2 = 0;
+    bool have = false;
+    if (!converged) {
+      eu0 = eu1 = -3;
+    } else {
+      const int ns = reorder_stable_first(L, rs, lane);
+      const int nu = N - ns;
+      // generalized eigenvalues, LAPACK's normalisation (beta real, non-negative): gev[i] = (alpha_i, beta_i)
+      if (lane < N) {
+        const cx a = GH(lane, lane), b = GT(lane, lane);
+        const double ab = cabs_(b);
+        const cx ph = (ab > 0.0) ? (1.0 / ab) * conj(b) : mk(1.0, 0.0);
+        const cx a2 = a * ph;
+        double* gv = gev_out + ((size_t)draw * N + lane) * 4;
+        gv[0] = a2.re;
+        gv[1] = a2.im;
+        gv[2] = ab;
+        gv[3] = 0.0;
+      }
+      bool zxz = false;
+      for (int i = 0; i < N; ++i)
+        if (cabs_(uni(GH(i, i))) < rs && cabs_(uni(GT(i, i))) < rs) zxz = true;
+      if (zxz) {
+        eu0 = eu1 = -2;
+      } else {
+        int r2 = 0, r1 = 0;
+        if (nu > 0 && ell > 0) {
+          jacobi_svd(&GX(ns, 0), L.ldx, nu, ell, L.V2, L.ldx, L.s2, lane);
+          for (int j = 0; j < ell; ++j) r2 += (L.s2[j] > rs) ? 1 : 0;
+        } else {
+          if (lane < ell) L.s2[lane] = 0.0;
+          for (int idx = lane; idx < ell * ell; idx += 64) {
+            const int i = idx / ell, j = idx - i * ell;
+            L.V2[i * L.ldx + j] = mk(i == j ? 1.0 : 0.0, 0.0);
+          }
+          wave_sync();
+        }
+        if (r2 >= nu) eu0 = 1;
+        for (int j = 0; j < ell; ++j) {  // column norms of eta1 V2 (CS decomposition, see gensys_kernel)
+          cx g = mk(0, 0);
+          if (lane < ns)
+            for (int cc = 0; cc < ell; ++cc) g = g + GX(lane, cc) * L.V2[cc * L.ldx + j];
+          const double sq = wave_sum_dpp(fma(g.re, g.re, g.im * g.im));
+          if (lane == 0) L.s1[j] = sqrt(sq);
+        }
+        wave_sync();
+        int n_loose = 0;
+        for (int j = 0; j < ell; ++j) {
+          const bool k1 = L.s1[j] > rs, k2 = L.s2[j] > rs;
+          r1 += k1 ? 1 : 0;
+          n_loose += (k1 && !k2) ? 1 : 0;
+        }
+        bool unique = true;
+        if (r1 > 0) {
+          eu2 = n_loose;
+          unique = (n_loose == 0);
+        }
+        if (unique) eu1 = 1;
+        // Phi (ns x nu) = sum_j w_j (eta1 v_j)(G2_j)^H, stored at H[ns + u][i]
+        for (int idx = lane; idx < ns * nu; idx += 64) {
+          const int i = idx / nu, u = idx - i * nu;
+          cx acc = mk(0, 0);
+          for (int j = 0; j < ell; ++j) {
+            if (!(L.s1[j] > rs && L.s2[j] > rs)) continue;
+            cx g1v = mk(0, 0);
+            for (int cc = 0; cc < ell; ++cc) g1v = g1v + GX(i, cc) * L.V2[cc * L.ldx + j];
+            const double w = 1.0 / (L.s2[j] * L.s2[j]);
+            acc = acc + g1v * (w * conj(GX(ns + u, j)));
+          }
+          GH(ns + u, i) = acc;
+        }
+        wave_sync();
+        // right-hand sides: [B11, B12 - Phi B22] in T[:ns, :],  T_mat Q [Psi | c] in X[:ns, ell:]
+        for (int idx = lane; idx < ns * nu; idx += 64) {
+          const int i = idx / nu, cc = idx - i * nu;
+          cx acc = GT(i, ns + cc);
+          for (int u = 0; u <= cc; ++u) acc = acc - GH(ns + u, i) * GT(ns + u, ns + cc);
+          GT(i, ns + cc) = acc;
+        }
+        for (int idx = lane; idx < ns * (k + 1); idx += 64) {
+          const int i = idx / (k + 1), cc = ell + idx % (k + 1);
+          cx acc = GX(i, cc);
+          for (int u = 0; u < nu; ++u) acc = acc - GH(ns + u, i) * GX(ns + u, cc);
+          GX(i, cc) = acc;
+        }
+        wave_sync();
+        // C tail: (A22 - B22)^-1 (Q c)[ns:]   (upper triangular, :350-356), one lane
+        if (lane == 0 && cvec) {
+          for (int i = N - 1; i >= ns; --i) {
+            cx acc = GX(i, ell + k);
+            for (int k2 = i + 1; k2 < N; ++k2) acc = acc - (GH(i, k2) - GT(i, k2)) * GX(k2, ell + k);
+            GX(i, ell + k) = cdiv(acc, GH(i, i) - GT(i, i));
+          }
+        }
+        wave_sync();
+        // C = Z G0^-1 [T_mat Q c; tail] with G0 = [[A11, A12 - Phi A22], [0, I]] (Sims' gensys.m).  The reference drops the
+        // G0^-1 on this one output (gensys.py:356: C_complex = [T_mat Q c; C_tail]), which makes its C for c != 0 depend on
+        // the particular ordered Schur basis LAPACK returns (Z1 V U x instead of the invariant Z1 A11^-1 x); for c = 0, the
+        // only case gEconpy produces (:598), both are zero.  Here: top <- top - (A12 - Phi A22) tail, then the common solve.
+        if (cvec) {
+          for (int i = lane; i < ns; i += 64) {
+            cx acc = GX(i, ell + k);
+            for (int cc = 0; cc < nu; ++cc) {
+              cx a12 = GH(i, ns + cc);
+              for (int u = 0; u <= cc; ++u) a12 = a12 - GH(ns + u, i) * GH(ns + u, ns + cc);
+              acc = acc - a12 * GX(ns + cc, ell + k);
+            }
+            GX(i, ell + k) = acc;
+          }
+        }
+        wave_sync();
+        // Y = A11^-1 rhs (G1), A11^-1 T_mat Q Psi (impact) and the top of C by back-substitution, one column per lane
+        for (int col = lane; col < N + k + 1; col += 64) {
+          for (int i = ns - 1; i >= 0; --i) {
+            cx acc = (col < N) ? GT(i, col) : GX(i, ell + col - N);
+            for (int k2 = i + 1; k2 < ns; ++k2) acc = acc - GH(i, k2) * ((col < N) ? GT(k2, col) : GX(k2, ell + col - N));
+            const cx v = cdiv(acc, GH(i, i));
+            if (col < N)
+              GT(i, col) = v;
+            else
+              GX(i, ell + col - N) = v;
+          }
+        }
+        wave_sync();
+        // W = Y Z^H (ns x N) into H[:ns, :] (A11 no longer needed)
+        for (int col = lane; col < N; col += 64) {
+          for (int i = 0; i < ns; ++i) {
+            cx acc = mk(0, 0);
+            for (int k2 = 0; k2 < N; ++k2) acc = acc + GT(i, k2) * conj(GZ(col, k2));
+            GH(i, col) = acc;
+          }
+        }
+        wave_sync();
+        for (int col = lane; col < N; col += 64)
+          for (int row = 0; row < N; ++row) {
+            double acc = 0.0;
+            for (int i = 0; i < ns; ++i) {
+              const cx z = GZ(row, i), w = GH(i, col);
+              acc += z.re * w.re - z.im * w.im;
+            }
+            G1_out[oNN + (size_t)row * N + col] = acc;
+          }
+        for (int idx = lane; idx < N * k; idx += 64) {
+          const int row = idx / k, j = idx - row * k;
+          double acc = 0.0;
+          for (int i = 0; i < ns; ++i) {
+            const cx z = GZ(row, i), w = GX(i, ell + j);
+            acc += z.re * w.re - z.im * w.im;
+          }
+          impact_out[(size_t)draw * N * k + idx] = acc;
+        }
+        for (int row = lane; row < N; row += 64) {
+          double acc = 0.0;
+          if (cvec)
+            for (int i = 0; i < N; ++i) {
+              const cx z = GZ(row, i), w = GX(i, ell + k);
+              acc += z.re * w.re - z.im * w.im;
+            }
+          C_out[(size_t)draw * N + row] = acc;
+        }
+        have = true;
+      }
+    }
+    if (!have) {
+      for (int idx = lane; idx < N * N; idx += 64) G1_out[oNN + idx] = 0.0;
+      for (int idx = lane; idx < N * k; idx += 64) impact_out[(size_t)draw * N * k + idx] = 0.0;
+      for (int idx = lane; idx < N; idx += 64) C_out[(size_t)draw * N + idx] = 0.0;
+      if (!converged)
+        for (int idx = lane; idx < N * 4; idx += 64) gev_out[(size_t)draw * N * 4 + idx] = 0.0;
+    }
     if (lane == 0) {
       eu_out[3 * draw] = eu0;
       eu_out[3 * draw + 1] = eu1;

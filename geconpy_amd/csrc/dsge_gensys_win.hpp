@@ -425,6 +425,7 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
     L.N = w;
     L.n = w;
     L.ell = ell;
+    L.xw = ell;
     L.Z = reinterpret_cast<cx*>(wd + wo.MC);
     wave_sync();
     for (int idx = lane; idx < w * L.ldh; idx += 64) L.H[idx] = mk(0.0, 0.0);

@@ -176,4 +176,20 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
   return DSGE_SUCCESS;
 }
 
+// gensys on a caller-supplied pencil (dsge_gensys_pencil_batched): single-launch kernel, everything in LDS
+int launch_gensys_pencil(const double* g0, const double* g1, const double* c, const double* psi, const double* pi, int batch,
+                         int N, int k, int ell, double tol, double* G1_out, double* C_out, double* impact_out,
+                         double* gev_out, int32_t* eu_out, int32_t* status, hipStream_t st) {
+  const size_t lds = dsge::gensys_pencil_smem_bytes(N, ell, ell + k + 1);
+  if (lds > LDS_LIMIT)
+    return fail(DSGE_ERR_INVALID, "gensys pencil: H, T, Z (N x N complex each) and Q [Pi | Psi | c] do not fit the 160 KB LDS "
+                                  "(N <= ~52)");
+  int rc;
+  if ((rc = set_lds(dsge::gensys_pencil_kernel, lds))) return rc;
+  hipLaunchKernelGGL(dsge::gensys_pencil_kernel, dim3(batch), dim3(64), lds, st, g0, g1, c, psi, pi, batch, N, k, ell, tol,
+                     G1_out, C_out, impact_out, gev_out, eu_out, status);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
 }  // namespace dsge_host

@@ -47,36 +47,67 @@ def solve_policy_function_with_backward_direct(A, B, C, D):
     return T[0], R[0]
 
 
-def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=True):
-    """Reference signature (gEconpy/solvers/gensys.py:617-631).  The estimation and ``solve_model`` call
-    sites consume ``G_1[:n, :n]``, ``impact[:n]`` and ``eu`` only (gensys.py:657-666,
-    gEconpy/model/model.py:1696-1708); the device produces exactly those, so
+def gensys_setup(A, B, C, D, tol=1e-8):
+    """The Sims pencil of ``_gensys_setup`` (gEconpy/solvers/gensys.py:568-614), by index arithmetic (host bookkeeping, no
+    floating-point work): with ``lead`` = columns of C whose absolute column sum exceeds ``tol`` and ``w_t = [y_t; E_t y_{t+1}[lead]]``
 
-      * ``return_all_matrices=False`` -> ``(G_1, eu)`` with ``G_1`` the n x n policy block ``T``;
-      * ``return_all_matrices=True``  -> the 9-tuple ``(G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose)``
-        with ``G_1 = T`` (n x n), ``constant = 0`` (c = 0, gensys.py:598), ``impact = R = -(C T + B)^-1 D``
-        (what ``gensys_pt`` uses, :679-683; it equals ``impact[:n]`` of the QZ formula to ~1e-12) and
-        ``None`` for ``f_mat, f_wt, y_wt, gev, loose`` -- the five outputs no caller of the hot path reads;
-        on coincident zeros (``eu = [-2, -2, 0]``) the seven matrices are ``None`` as at :515-516.
-    Slicing ``G_1[:n, :n]`` / ``impact[:n, :]`` as the callers do is a no-op on these shapes."""
-    A3, B3, C3, D3 = (np.ascontiguousarray(x, dtype=np.float64)[None] for x in (A, B, C, D))
-    out = batched.gensys_batched(A3, B3, C3, D3, tol=tol)
-    eu = [int(v) for v in out["eu"][0]]
-    if eu[0] == -2 and eu[1] == -2:
-        return (None, eu) if not return_all_matrices else (None,) * 7 + (eu, None)
-    G_1 = np.ascontiguousarray(out["T"][0])
-    if not return_all_matrices:
-        return G_1, eu
-    n = G_1.shape[0]
-    return G_1, np.zeros((n, 1)), out["R"][0], None, None, None, None, eu, None
+        G0 = [[-B, -C[:, lead]], [E, 0]]   G1 = [[A, 0], [0, I]]   c = 0   Psi = [D; 0]   Pi = [0; I]
+
+    -> ``(g0, g1, c, psi, pi)`` of dimension N = n + #lead."""
+    A, B, C, D = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, B, C, D))
+    n, k = D.shape
+    lead = np.flatnonzero(np.abs(C).sum(axis=0) > tol)
+    nl = lead.size
+    N = n + nl
+    g0 = np.zeros((N, N))
+    g0[:n, :n] = -B
+    g0[:n, n:] = -C[:, lead]
+    g0[n + np.arange(nl), lead] = 1.0
+    g1 = np.zeros((N, N))
+    g1[:n, :n] = A
+    g1[n + np.arange(nl), n + np.arange(nl)] = 1.0
+    psi = np.zeros((N, k))
+    psi[:n] = D
+    pi = np.zeros((N, nl))
+    pi[n + np.arange(nl), np.arange(nl)] = 1.0
+    return g0, g1, np.zeros((N, 1)), psi, pi
 
 
 def gensys(g0, g1, c, psi, pi, div=None, tol=1e-8, return_all_matrices=True):
-    """The raw-pencil entry point (gEconpy/solvers/gensys.py:398-521) is host-side bookkeeping around
-    ``_gensys_core`` for an ARBITRARY pencil; the device kernel takes the structural form A, B, C
-    (it never materialises the pencil).  Not provided: use
-    ``solve_policy_function_with_gensys(A, B, C, D)``."""
-    raise NotImplementedError(gensys.__doc__)
+    """Reference signature and return (gEconpy/solvers/gensys.py:398-521) for an arbitrary pencil
+    ``g0 y_t = g1 y_{t-1} + c + psi z_t + pi eta_t``, solved on the device by ``dsge_gensys_pencil_batched`` (ordered
+    complex QZ, existence / uniqueness SVDs, one triangular solve; N <= ~52, everything resident in LDS):
+
+      * ``return_all_matrices=False`` -> ``(G_1, eu)``;
+      * ``return_all_matrices=True``  -> ``(G_1, C, impact, f_mat, f_wt, y_wt, gev, eu, loose)`` with ``G_1`` (N, N),
+        ``C`` (N, 1), ``impact`` (N, k) from the QZ formulas (:336-365), ``gev`` (N, 2) complex ``[alpha, beta]`` (:253)
+        and ``None`` for ``f_mat, f_wt, y_wt, loose`` (:367-393) -- nothing on the estimation path reads them and the
+        device does not form them;
+      * coincident zeros (``eu = [-2, -2, 0]``): every matrix is ``None`` (:515-516).
+    ``div`` is accepted and ignored, as in the reference (:502)."""
+    del div
+    tol_eff = tol if tol is not None and tol > 0 else float(np.spacing(1))
+    g0, g1, psi, pi = (np.ascontiguousarray(x, dtype=np.float64) for x in (g0, g1, psi, pi))
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(g0.shape[0], -1)
+    if c.shape[1] != 1:
+        raise ValueError("c must have one column")
+    out = batched.gensys_pencil_batched(g0[None], g1[None], psi[None], pi[None], c=c[None, :, 0], tol=tol_eff)
+    eu = [int(v) for v in out["eu"][0]]
+    if eu[0] == -2 and eu[1] == -2:
+        return None, None, None, None, None, None, None, eu, None
+    G_1 = out["G1"][0]
+    if not return_all_matrices:
+        return G_1, eu
+    return G_1, out["C"][0][:, None], out["impact"][0], None, None, None, out["gev"][0], eu, None
+
+
+def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=True):
+    """Reference signature and return (gEconpy/solvers/gensys.py:617-631): the pencil of ``_gensys_setup`` handed to
+    ``gensys``.  ``G_1`` is (N, N) with N = n + #lead and ``impact`` (N, k); callers slice ``G_1[:n, :n]``,
+    ``impact[:n, :]`` (gensys.py:657-666, gEconpy/model/model.py:1696-1708).  The batched estimation path does not go
+    through here: it uses the structure-exploiting kernels behind ``batched.gensys_batched`` (T and eu only)."""
+    g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
+    return gensys(g0, g1, c, psi, pi, tol=tol, return_all_matrices=return_all_matrices)
 
 
 def solve_policy_functions_batched(A, B, C, D, solver="cycle_reduction", max_iter=100, tol=1e-8):

@@ -184,6 +184,31 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
                              int32_t* eu_out, int32_t* status);
 
 /*
+ * gensys on a caller-supplied pencil.  Replaces gensys(g0, g1, c, psi, pi, div, tol) (gEconpy/solvers/gensys.py:398-521 ->
+ * _gensys_core :190-395), the interactive numpy entry point: Gamma0 y_t = Gamma1 y_{t-1} + c + Psi z_t + Pi eta_t.
+ *   g0, g1 : [batch][N][N]   c : [batch][N] or NULL (= 0)   psi : [batch][N][k]   pi : [batch][N][n_eta]
+ *   G1_out : [batch][N][N]  (:336-343)
+ *   C_out : [batch][N] = Z G0^-1 [T_mat Q c; (A22 - B22)^-1 Q2 c] as in Sims' gensys.m.  The reference omits the G0^-1 on
+ *           this output (:345-357: the stable block is not solved), which makes its C for c != 0 depend on the ordered
+ *           Schur basis LAPACK happens to return; with c = 0 -- all gEconpy ever passes (:598) -- both are zero.
+ *   impact_out : [batch][N][k]  (:359-365, 392)
+ *   gev_out : [batch][N][4] = (Re alpha, Im alpha, Re beta, Im beta) per generalized eigenvalue, stable roots first,
+ *             LAPACK's normalisation beta real >= 0 (:253; the order within each group is not defined, as in LAPACK)
+ *   eu_out : [batch][3], status : [batch] as dsge_gensys_batched
+ * fmat, fwt, ywt and loose of the reference's 9-tuple (:367-393) are not produced: no caller on the estimation path reads
+ * them (the Python wrapper returns None for them).  Only the column space of Pi matters for the outputs above, so Pi is
+ * replaced on the device by an orthonormal basis of it (the existence / uniqueness SVDs then share their right singular
+ * vectors).  Everything is resident in LDS: N x N complex H, T, Z and N x (n_eta + k + 1) Q [Pi | Psi | c] -- N <= ~52.
+ */
+int dsge_gensys_pencil_batched(const double* g0, const double* g1, const double* c, const double* psi, const double* pi,
+                               int batch, int N, int k, int n_eta, double tol, double* G1_out, double* C_out,
+                               double* impact_out, double* gev_out, int32_t* eu_out, int32_t* status, void* stream);
+int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const double* c, const double* psi,
+                                    const double* pi, int batch, int N, int k, int n_eta, double tol, double* G1_out,
+                                    double* C_out, double* impact_out, double* gev_out, int32_t* eu_out,
+                                    int32_t* status);
+
+/*
  * Blanchard-Kahn eigenvalues.  Replaces compute_bk_eigenvalues / check_bk_condition
  * (gEconpy/model/perturbation.py:412-445, :448-565; the graph twin check_bk_condition_pt :586-625 computes the same
  * counts from a dense eig of the regularised pencil): the generalized eigenvalues of the Sims pencil of _gensys_setup

@@ -769,7 +769,9 @@ def test_fused_pipeline_with_scan_cycle_reduction():
 
 
 def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
-    """solve_policy_function_with_gensys (gensys.py:617-631) as model.py:1696-1708 consumes it."""
+    """solve_policy_function_with_gensys (gensys.py:617-631) and the raw-pencil gensys() (:398-521) against the outputs of
+    the reference's own _gensys_setup + _gensys_core (tests/golden/reference_goldens.npz): full-size G_1, impact from the
+    QZ formula, generalized eigenvalues, eu."""
     from geconpy_amd import solvers
 
     g = ref_goldens
@@ -777,17 +779,73 @@ def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
         A, B, C, D = (g[f"{key}_{x}"] for x in "ABCD")
         n = A.shape[0]
         G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
-        assert eu == [1, 1, 0] and constant.shape == (n, 1) and f_mat is None and loose is None
+        N = g[f"{key}_ref_gensys_G1"].shape[0]
+        assert eu == [1, 1, 0] and G_1.shape == (N, N) and impact.shape == (N, D.shape[1]) and constant.shape == (N, 1)
+        assert f_mat is None and f_wt is None and y_wt is None and loose is None
+        assert_allclose(G_1, g[f"{key}_ref_gensys_G1"], atol=1e-9)
         assert_allclose(G_1[:n, :n], g[f"{key}_ref_gensys_T"], atol=1e-9)
-        assert_allclose(impact[:n, :], g[f"{key}_ref_gensys_R"], atol=1e-8)
+        assert_allclose(impact[:n, :], g[f"{key}_ref_gensys_R"], atol=1e-9)
+        assert np.all(constant == 0.0)
+        # generalized eigenvalues: same multiset of beta / alpha moduli (the order inside the stable / unstable groups is
+        # LAPACK's business), stable group first
+        ref_gev = g[f"{key}_ref_gensys_gev"]
+        assert gev.shape == ref_gev.shape == (N, 2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mod = np.abs(gev[:, 1]) / np.abs(gev[:, 0])
+            mod_ref = np.abs(ref_gev[:, 1]) / np.abs(ref_gev[:, 0])
+        fin, fin_ref = (mod > 1e-6) & (mod < 1e6), (mod_ref > 1e-6) & (mod_ref < 1e6)  # zero / infinite roots: counted
+        assert_allclose(np.sort(mod[fin]), np.sort(mod_ref[fin_ref]), rtol=1e-7)
+        assert np.sum(mod <= 1e-6) == np.sum(mod_ref <= 1e-6) and np.sum(~(mod < 1e6)) == np.sum(~(mod_ref < 1e6))
+        ns = int(np.sum(mod_ref < 1.0))
+        assert np.all(mod[:ns] < 1.0) and np.all(~(mod[ns:] < 1.0))
+        assert np.all(gev[:, 1].imag == 0.0) and np.all(gev[:, 1].real >= 0.0)  # LAPACK's normalisation of beta
         G_1s, eu_s = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8, return_all_matrices=False)
         assert eu_s == eu and np.array_equal(G_1s, G_1)
     f = failure_golden
     A, B, C, D = (f[f"coincident_{x}"] for x in "ABCD")
     out = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
     assert out[7] == [-2, -2, 0] and all(m is None for m in out[:7])
-    with pytest.raises(NotImplementedError):
-        solvers.gensys(None, None, None, None, None)
+    for name in ("nonunique", "noexist"):
+        A, B, C, D = (f[f"{name}_{x}"] for x in "ABCD")
+        out = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
+        assert out[7] == [int(v) for v in f[f"{name}_ref_gensys_eu"]]
+        assert_allclose(out[0][:40, :40], f[f"{name}_ref_gensys_T"], atol=1e-8)  # the reference still returns G1 there
+
+
+def test_raw_pencil_gensys_arbitrary_inputs(ref_goldens):
+    """gensys(g0, g1, c, psi, pi) on pencils that do NOT come from _gensys_setup, against the oracle's restatement of
+    _gensys_core: a non-zero constant, a Pi whose columns are neither orthogonal nor normalised (only its column space
+    matters), a row-scaled / row-mixed pencil."""
+    from geconpy_amd import solvers
+
+    g = ref_goldens
+    rng = np.random.default_rng(11)
+    for key in ("one_block", "rbc_2_block", "full_nk"):
+        A, B, C, D = (g[f"{key}_{x}"] for x in "ABCD")
+        g0, g1, c, psi, pi = oracle.gensys_setup(A, B, C, D, 1e-8)
+        s0, s1, s2, s3, s4 = solvers.gensys_setup(A, B, C, D, 1e-8)
+        for u, v in zip((g0, g1, c, psi, pi), (s0, s1, s2, s3, s4)):
+            assert np.array_equal(u, v)  # index arithmetic: bit-identical pencil
+        N = g0.shape[0]
+        M = np.eye(N) + 0.3 * rng.standard_normal((N, N))  # mixes the equations: same solution
+        Rm = np.eye(pi.shape[1]) + 0.5 * rng.standard_normal((pi.shape[1], pi.shape[1]))
+        c2 = 0.1 * rng.standard_normal((N, 1))
+        args = (M @ g0, M @ g1, M @ c2, M @ psi, M @ pi @ Rm)
+        ref = oracle.gensys(*args, tol=1e-8)
+        out = solvers.gensys(*args, tol=1e-8)
+        assert out[7] == [int(v) for v in ref[7]] == [1, 1, 0]
+        assert_allclose(out[0], ref[0], atol=1e-8)
+        assert_allclose(out[2], ref[2], atol=1e-8)
+        assert_allclose(out[0], g[f"{key}_ref_gensys_G1"], atol=1e-8)  # and unchanged by the mixing
+        # the constant: Sims' formula (the reference's omits G0^-1 on the stable block and is basis dependent for c != 0,
+        # include/dsge_hip.h).  Its defining property: the fixed point y* = (I - G1)^-1 C of y_t = G1 y_{t-1} + C solves
+        # the original system without shocks and expectational errors, (g0 - g1) y* = c.
+        g0m, g1m, cm = args[0], args[1], args[2]
+        ystar = np.linalg.solve(np.eye(N) - out[0], out[1])
+        assert_allclose((g0m - g1m) @ ystar, cm, atol=1e-7 * max(1.0, np.abs(ystar).max()))
+        assert np.all(solvers.gensys(args[0], args[1], 0 * cm, args[3], args[4])[1] == 0.0)
+
+
     # batched driver, all four solvers give the same policy on a healthy system
     b = wl.sw_shaped_batch(4)
     outs = {s: solvers.solve_policy_functions_batched(b["A"], b["B"], b["C"], b["D"], solver=s, tol=1e-9)
