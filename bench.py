@@ -278,7 +278,12 @@ def main():
         sh = wl.SW_SHAPE
         n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
         om = wl.sw_shaped_observation_model()
-        shard = wl.sw_shaped_batch(hi - lo, first_draw=lo)
+        if args.from_theta:  # the 37-parameter affine family around draw 0; the host twin feeds the CPU checker only
+            sw_theta = wl.sw_theta_draws(hi - lo, first_draw=lo)
+            tA, tB, tC, tD, tq = wl.sw_theta_jacobians(sw_theta)
+            shard = dict(A=tA, B=tB, C=tC, D=tD, sigma=np.sqrt(tq))
+        else:
+            shard = wl.sw_shaped_batch(hi - lo, first_draw=lo)
 
     cpu = None
     cpu_logp = None
@@ -332,15 +337,26 @@ def main():
 
     prog = d_theta = jac_out = None
     if args.from_theta:
-        if args.workload != "rbc":
-            ap.error("--from-theta needs --workload rbc (the SW-shaped systems have no parameterisation)")
-        from geconpy_amd.jacobian_codegen import rbc_linearized_program
+        if args.workload == "rbc":
+            from geconpy_amd.jacobian_codegen import rbc_linearized_program
 
-        prog = rbc_linearized_program()
-        th = wl.rbc_prior_draws(hi, seed=1)
-        d_theta = eng.to_device(np.stack([th[k_][lo:hi] for k_ in ("sigma", "phi", "alpha", "beta", "delta", "rho_A",
-                                                                  "sigma_A")], axis=1))
+            prog = rbc_linearized_program()
+            th = wl.rbc_prior_draws(hi, seed=1)
+            d_theta = eng.to_device(np.stack([th[k_][lo:hi] for k_ in ("sigma", "phi", "alpha", "beta", "delta", "rho_A",
+                                                                      "sigma_A")], axis=1))
+        elif args.workload == "sw_shaped":
+            # the 37-parameter affine family around draw 0 (jacobian_codegen.sw_shaped_program): every step starts from
+            # 296 B of parameters per draw; A, B, C, D (40 KB per draw) are produced in HBM by the generated kernel
+            from geconpy_amd.jacobian_codegen import sw_shaped_program
+
+            prog = sw_shaped_program()
+            d_theta = eng.to_device(sw_theta)
+        else:
+            ap.error("--from-theta needs --workload rbc or sw_shaped")
         jac_out = (dA, dB, dC, dD, dq)
+        eng.jacobians_from_theta(prog, d_theta, out=jac_out)  # the hints below describe THIS family's structure
+        torch.cuda.synchronize()
+        hints = eng.structure_hints(dA, dZ) if not args.no_hints else (0, 0)
 
     def local_eval(lo_, hi_):
         if prog is not None:
@@ -487,7 +503,8 @@ def main():
                 else f"rbc_linearized closed form: n={n}, k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[1])",
                 "global_batch": global_batch,
                 "solver": args.solver,
-                "inputs": "theta (generated Jacobian kernel inside the step)" if args.from_theta else "A,B,C,D resident in HBM",
+                "inputs": (f"theta resident in HBM ({d_theta.shape[1]} parameters = {8 * d_theta.shape[1]} B per draw); A,B,C,D are produced "
+                           f"by the generated Jacobian kernel inside every timed step") if args.from_theta else "A,B,C,D resident in HBM",
                 "tol": args.tol,
                 "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
                 "cr_static_deflation": (f"{h_defl} static variables (zero columns of A and C) eliminated by a QR of their columns of B before the "

@@ -53,8 +53,27 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+STAMP = LIB + ".sha256"  # travels with the library (git-ignored, not gpurun-ignored)
+
+
+def sources_digest():
+    """Content hash of every source the library is built from (csrc/*.hip, csrc/*.hpp, include/dsge_hip.h) and of the
+    compiler flags: what `libdsge_hip.so` is checked against, so that a prebuilt library travelling with a snapshot can
+    never be older than the sources next to it, whatever the file times say."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(CFLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES + HEADERS])
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    with open(STAMP) as fh:
+        return fh.read().strip() != sources_digest()
 
 
 def build_library(force=False, verbose=True):
@@ -79,6 +98,8 @@ def build_library(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(STAMP, "w") as fh:
+        fh.write(sources_digest())
     return LIB
 
 

@@ -75,6 +75,7 @@ class JacobianProgram:
         if unknown:
             raise ValueError(f"expressions use symbols that are not parameters: {sorted(map(str, unknown))}")
         self._lib = None
+        self._source = None
 
     # -- code generation -------------------------------------------------------------------
     def nonzero_entries(self):
@@ -91,6 +92,11 @@ class JacobianProgram:
         return out
 
     def source(self):
+        if self._source is None:
+            self._source = self._generate()
+        return self._source
+
+    def _generate(self):
         import sympy as sp
         from sympy.printing.c import C99CodePrinter
 
@@ -273,3 +279,53 @@ def rbc_linearized_program():
     B[6, iY], B[6, iC], B[6, iI] = Y, -Cs, -I                             # Y_ss Y = C_ss C + I_ss I
     B[7, iA], A[7, iA], D[7, 0] = 1, -rho_A, -1                           # A = rho_A A[-1] + eps
     return JacobianProgram("rbc_linearized", params, A, B, Cm, D, q=[sigma_A**2])
+
+
+SW_THETA_SCALE = 0.02
+
+
+def sw_shaped_program(seed=None):
+    """A parameterisation of the SW-shaped workload (BASELINE configs[2]; the reference ships no Smets-Wouters model, so
+    there is no economic theta behind those systems): the base system is draw 0 of ``workloads.sw_shaped_batch`` and
+
+        A[:, S_j] = A0[:, S_j] (1 + 0.02 a_j)   (18 state columns)      B = B0      D = D0
+        C[:, L_j] = C0[:, L_j] (1 + 0.02 c_j)   (12 forward-looking columns)         q_j = sigma_j^2   (7 shocks)
+
+    theta = (a_0..a_17, c_0..c_11, sigma_0..sigma_6): 37 parameters, every entry affine in theta, the zero-column
+    structure (states / leads / static variables) that of the base system for every theta.  Goes through the same
+    shared-CSE code generator as the RBC model: 2 600 non-zero entries, one thread per draw.  ``workloads.sw_theta_draws``
+    draws a, c ~ U(-1, 1) and sigma ~ U(0.005, 0.02); within that box the systems keep a unique stable solution."""
+    import numpy as np
+    import sympy as sp
+
+    from . import workloads as wl
+
+    A0, B0, C0, D0, _ = wl.sw_shaped_system(wl.SW_SEED0 if seed is None else seed)
+    n, k = D0.shape
+    S = np.flatnonzero((A0 != 0).any(axis=0))
+    Lc = np.flatnonzero((C0 != 0).any(axis=0))
+    a = sp.symbols(f"a0:{len(S)}", real=True)
+    c = sp.symbols(f"c0:{len(Lc)}", real=True)
+    sg = sp.symbols(f"sigma0:{k}", positive=True)
+    sc = sp.Float(SW_THETA_SCALE)
+
+    def flt(x):
+        return sp.Float(repr(float(x)), 17)
+
+    A, B, Cm, D = sp.zeros(n, n), sp.zeros(n, n), sp.zeros(n, n), sp.zeros(n, k)
+    for j, col in enumerate(S):
+        for r in range(n):
+            if A0[r, col] != 0:
+                A[r, col] = flt(A0[r, col]) * (1 + sc * a[j])
+    for j, col in enumerate(Lc):
+        for r in range(n):
+            if C0[r, col] != 0:
+                Cm[r, col] = flt(C0[r, col]) * (1 + sc * c[j])
+    for r in range(n):
+        for col in range(n):
+            if B0[r, col] != 0:
+                B[r, col] = flt(B0[r, col])
+        for col in range(k):
+            if D0[r, col] != 0:
+                D[r, col] = flt(D0[r, col])
+    return JacobianProgram("sw_shaped_theta", list(a) + list(c) + list(sg), A, B, Cm, D, q=[s_ ** 2 for s_ in sg])

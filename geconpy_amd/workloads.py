@@ -229,3 +229,34 @@ def full_nk_batch(batch, first_draw=0, T_len=200, rel=1e-3):
     Z[np.arange(p), np.arange(p)] = 1.0
     y = np.random.default_rng(0).normal(0, 0.01, (T_len, p))
     return dict(A=A, B=B, C=C, D=D, sigma=np.full((batch, k), 0.01)), dict(Z=Z, Hdiag=np.full(p, 1e-4), y=y)
+
+
+def sw_theta_draws(batch, first_draw=0, seed0=SW_SEED0, n_state=18, n_lead=12, k=7):
+    """Parameter draws of ``jacobian_codegen.sw_shaped_program`` as a (batch, 37) array: column scalings a, c ~ U(-1, 1),
+    shock standard deviations sigma ~ U(0.005, 0.02); draw i is seeded ``default_rng((seed0 + i, 3))`` whichever shard
+    generates it."""
+    th = np.empty((batch, n_state + n_lead + k))
+    for b in range(batch):
+        rng = np.random.default_rng((seed0 + first_draw + b, 3))
+        th[b, : n_state + n_lead] = rng.uniform(-1.0, 1.0, n_state + n_lead)
+        th[b, n_state + n_lead :] = rng.uniform(0.005, 0.02, k)
+    return th
+
+
+def sw_theta_jacobians(theta, seed=None):
+    """Host (numpy) twin of ``sw_shaped_program``: the same affine map theta -> A, B, C, D, q -- the inputs of the path for
+    the checker, no solver in it."""
+    from .jacobian_codegen import SW_THETA_SCALE
+
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    A0, B0, C0, D0, _ = sw_shaped_system(SW_SEED0 if seed is None else seed)
+    S = np.flatnonzero((A0 != 0).any(axis=0))
+    Lc = np.flatnonzero((C0 != 0).any(axis=0))
+    nb = theta.shape[0]
+    A = np.repeat(A0[None], nb, axis=0)
+    C = np.repeat(C0[None], nb, axis=0)
+    A[:, :, S] = A0[None][:, :, S] * (1.0 + SW_THETA_SCALE * theta[:, None, : len(S)])
+    C[:, :, Lc] = C0[None][:, :, Lc] * (1.0 + SW_THETA_SCALE * theta[:, None, len(S) : len(S) + len(Lc)])
+    B = np.repeat(B0[None], nb, axis=0)
+    D = np.repeat(D0[None], nb, axis=0)
+    return A, B, C, D, theta[:, len(S) + len(Lc) :] ** 2

@@ -136,3 +136,59 @@ def test_theta_gradient_end_to_end():
             tm[j] -= e
             fd = (f(tp) - f(tm)) / (2 * e)
             assert_allclose(theta_bar[i, j], fd, rtol=5e-5, atol=1e-5 * max(1.0, np.abs(theta_bar[i]).max()))
+
+
+@pytest.mark.gpu
+def test_sw_shaped_theta_program_on_device():
+    """The 37-parameter affine family of the SW-shaped workload (bench.py --from-theta on BASELINE configs[2]): the generated
+    kernel reproduces the host twin bit for bit on the entries it writes (one multiply-add each), keeps the zero-column
+    structure of the base system, and theta -> logp through the fused call matches the oracle on the host twin."""
+    import torch
+
+    import oracle
+    from geconpy_amd import workloads as wl
+    from geconpy_amd.engine import LogpEngine
+    from geconpy_amd.jacobian_codegen import sw_shaped_program
+
+    prog = sw_shaped_program()
+    assert (prog.n, prog.k, len(prog.params)) == (40, 7, 37)
+    nb = 96
+    th = wl.sw_theta_draws(nb)
+    A, B, C, D, q = wl.sw_theta_jacobians(th)
+    eng = LogpEngine(0)
+    d_th = eng.to_device(th)
+    dA, dB, dC, dD, dq = eng.jacobians_from_theta(prog, d_th)
+    torch.cuda.synchronize()
+    for got, want in ((dA, A), (dB, B), (dC, C), (dD, D), (dq, q)):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=4e-16, atol=0)
+    assert np.array_equal(dA.cpu().numpy() != 0, A != 0) and np.array_equal(dC.cpu().numpy() != 0, C != 0)
+    om = wl.sw_shaped_observation_model()
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
+    ns, zs = eng.structure_hints(dA, dZ)
+    assert (ns, zs, eng.static_hint(dA, dC)) == (18, 1, 10)
+    logp, status = eng.logp_from_theta(prog, d_th, dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000, n_state_hint=ns, z_selector_hint=zs,
+                                       options={"n_static_hint": 10})
+    torch.cuda.synchronize()
+    logp, status = logp.cpu().numpy(), status.cpu().numpy()
+    assert not status.any()
+    for i in (0, 31, 95):
+        ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(q[i]), om["Z"], om["y"], H=np.diag(om["Hdiag"]), tol=1e-8,
+                                       max_iter=1000)
+        assert abs(logp[i] - ref["logp"]) <= 1e-8 * abs(ref["logp"])
+    # d logp / d theta through the generated pullback kernel against central differences of the fused call
+    lp, st, tb, _g = eng.logp_and_grad_from_theta(prog, d_th, dZ, dy, Hdiag=dH, tol=1e-10, max_iter=1000)
+    torch.cuda.synchronize()
+    assert not st.cpu().numpy().any()
+    tb = tb.cpu().numpy()
+    for j in (0, 17, 20, 33):
+        h = 1e-5 if j < 30 else 1e-7
+        tp, tm = th.copy(), th.copy()
+        tp[:, j] += h
+        tm[:, j] -= h
+        lps = []
+        for tt in (tp, tm):
+            l_, _s = eng.logp_from_theta(prog, eng.to_device(tt), dZ, dy, Hdiag=dH, tol=1e-10, max_iter=1000)
+            torch.cuda.synchronize()
+            lps.append(l_.cpu().numpy())
+        fd = (lps[0] - lps[1]) / (2 * h)
+        np.testing.assert_allclose(tb[:, j], fd, rtol=5e-4, atol=1e-3)
