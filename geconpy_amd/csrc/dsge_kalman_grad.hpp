@@ -262,7 +262,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     }
     wave_sync();
 
-    double* st = store + (size_t)draw * T_len * STEP;
+    // per-draw record: T_len step records + P_0 (NP x NP) behind them -- kalman_grad_store_doubles_per_draw() on the host.
+    // (Round 1 strode by T_len * STEP only: the P_0 of draw d sat on the step-0 record of draw d + 1, a cross-workgroup
+    // race that made the cotangent of T non-repeatable for batches of ~100 draws and more.)
+    double* st = store + (size_t)draw * ((size_t)T_len * STEP + (size_t)NP * NP);
     // ---- the measurement update, split in its data-independent and data-dependent halves --------------
     // update_cov: from Ps and the mask weights ww -> Mp, Fs, Fi, Kp, X1 = P+; returns ln det F.
     auto update_cov = [&]() -> double {

@@ -138,3 +138,33 @@ def test_gradient_with_steady_state_segments():
         assert_allclose(out[key], out0[key], atol=1e-8 * scale, rtol=1e-7, err_msg=key)
     g = {k_: v[0] for k_, v in out.items() if k_.endswith("_bar")}
     _directional_check(b["A"][0], b["B"][0], b["C"][0], b["D"][0], q[0], om["Z"], y, d, h, g, rng, n_dirs=1)
+
+
+def test_gradient_is_repeatable_and_independent_of_the_batch_size():
+    """Regression (round 2): the per-draw record of the reverse sweep is T_len step records + P_0; round 1 strode the
+    store by the step records alone, so the P_0 of draw d sat on the step-0 record of draw d + 1 -- a cross-workgroup race
+    that made the cotangents of A, B, C non-repeatable (and wrong by tens of percent) for batches of ~100 draws and more
+    while logp, q_bar and D_bar stayed exact.  A draw's gradient must not depend on the batch it travels in."""
+    om = wl.sw_shaped_observation_model()
+    nb = 256
+    b = wl.sw_shaped_batch(nb)
+    q = b["sigma"] ** 2
+    kw = dict(Hdiag=om["Hdiag"], tol=1e-10, max_iter=1000)
+    g1 = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"], **kw)
+    g2 = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"], **kw)
+    assert not g1["status"].any()
+    for key in ("logp", "A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "h_bar"):
+        assert np.array_equal(g1[key], g2[key]), key
+    sub = batched.solve_kalman_logp_grad_batched(b["A"][:40], b["B"][:40], b["C"][:40], b["D"][:40], q[:40], om["Z"], om["y"], **kw)
+    for key in ("logp", "A_bar", "B_bar", "C_bar", "D_bar", "q_bar"):
+        assert np.array_equal(g1[key][:40], sub[key]), key
+    # every draw of the batch against a central difference of the device's own logp along one random direction of A, C
+    rng = np.random.default_rng(0)
+    dA = rng.standard_normal(b["A"].shape) * (b["A"] != 0)
+    dC = rng.standard_normal(b["C"].shape) * (b["C"] != 0)
+    h = 1e-6
+    lp = batched.solve_kalman_logp_batched(b["A"] + h * dA, b["B"], b["C"] + h * dC, b["D"], q, om["Z"], om["y"], **kw)["logp"]
+    lm = batched.solve_kalman_logp_batched(b["A"] - h * dA, b["B"], b["C"] - h * dC, b["D"], q, om["Z"], om["y"], **kw)["logp"]
+    fd = (lp - lm) / (2 * h)
+    an = np.einsum("bij,bij->b", g1["A_bar"], dA) + np.einsum("bij,bij->b", g1["C_bar"], dC)
+    assert np.max(np.abs(fd - an) / np.maximum(np.abs(fd), 1.0)) < 1e-4

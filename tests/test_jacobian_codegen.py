@@ -181,7 +181,7 @@ def test_sw_shaped_theta_program_on_device():
     assert not st.cpu().numpy().any()
     tb = tb.cpu().numpy()
     for j in (0, 17, 20, 33):
-        h = 1e-5 if j < 30 else 1e-7
+        h = 1e-2 if j < 30 else 1e-6  # (a column scaling moves by 0.02 h; sigma ~ 1e-2)
         tp, tm = th.copy(), th.copy()
         tp[:, j] += h
         tm[:, j] -= h
@@ -191,4 +191,4 @@ def test_sw_shaped_theta_program_on_device():
             torch.cuda.synchronize()
             lps.append(l_.cpu().numpy())
         fd = (lps[0] - lps[1]) / (2 * h)
-        np.testing.assert_allclose(tb[:, j], fd, rtol=5e-4, atol=1e-3)
+        np.testing.assert_allclose(tb[:, j], fd, rtol=2e-3, atol=2e-3 * np.abs(fd).max())
