@@ -167,4 +167,4 @@ def test_gradient_is_repeatable_and_independent_of_the_batch_size():
     lm = batched.solve_kalman_logp_batched(b["A"] - h * dA, b["B"], b["C"] - h * dC, b["D"], q, om["Z"], om["y"], **kw)["logp"]
     fd = (lp - lm) / (2 * h)
     an = np.einsum("bij,bij->b", g1["A_bar"], dA) + np.einsum("bij,bij->b", g1["C_bar"], dC)
-    assert np.max(np.abs(fd - an) / np.maximum(np.abs(fd), 1.0)) < 1e-4
+    assert np.max(np.abs(fd - an) / np.maximum(np.abs(fd), 1.0)) < 1e-3  # (central differences, h = 1e-6; the race gave tens of percent)
