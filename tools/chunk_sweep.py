@@ -1,29 +1,26 @@
-"""GPU box: fused device evaluation (4096 SW-shaped draws) vs the number of pipeline chunks and the tail hand-off."""
-import sys, os
+"""GPU box: fused step time of the bench workload with the batch split into chunks on library-owned streams
+(dsge_options.pipeline_chunks): does a chunk's Kalman straggler tail overlap the next chunk's solver?"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from geconpy_amd import _lib, workloads as wl
+from geconpy_amd import workloads as wl
 from geconpy_amd.engine import LogpEngine
-nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+nb = 4096
 b = wl.sw_shaped_batch(nb); om = wl.sw_shaped_observation_model()
-eng = LogpEngine(torch.device("cuda", 0)); lib = _lib.load()
-dA, dB, dC, dD = (eng.to_device(b[x]) for x in "ABCD"); dq = eng.to_device(b["sigma"] ** 2)
+eng = LogpEngine(0)
+dev = [eng.to_device(b[x]) for x in "ABCD"]; dq = eng.to_device(b["sigma"] ** 2)
 dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
-hints = eng.structure_hints(dA, dZ)
-def run():
-    return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000, n_state_hint=hints[0], z_selector_hint=hints[1])
+ns, zs = eng.structure_hints(dev[0], dZ); nst = eng.static_hint(dev[0], dev[2])
 ref = None
-for order, blk, ch in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 0, 2)):
-    if True:
-        _lib.check(lib.dsge_set_kalman_order(order)); _lib.check(lib.dsge_set_kalman_block(blk))
-        _lib.check(lib.dsge_set_pipeline_chunks(ch))
-        out = run(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10): out = run()
-        e1.record(); torch.cuda.synchronize()
-        lp = out[0].cpu().numpy()
-        if ref is None: ref = lp
-        ok = np.isfinite(ref)
-        print(f"order {order} tail hand-off {blk} chunks {ch:2d}: {e0.elapsed_time(e1)/10:.3f} ms/step, max rel diff {np.max(np.abs(lp[ok]-ref[ok])/np.abs(ref[ok])):.1e}")
-_lib.check(lib.dsge_set_kalman_block(1)); _lib.check(lib.dsge_set_pipeline_chunks(0)); _lib.check(lib.dsge_set_kalman_order(1))
+for chunks in (0, 2, 3, 4):
+    opts = {"pipeline_chunks": chunks, "n_static_hint": nst}
+    kw = dict(Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, n_state_hint=ns, z_selector_hint=zs, options=opts)
+    for _ in range(3):
+        lp, st = eng.solve_kalman_logp(*dev, dq, dZ, dy, **kw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        lp, st = eng.solve_kalman_logp(*dev, dq, dZ, dy, **kw)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    l = lp.cpu().numpy()
+    if ref is None: ref = l
+    print(f"chunks {chunks}: {dt*1e3:.3f} ms per step, {nb/dt/1e6:.3f} M evals/s, identical results: {np.array_equal(l, ref)}")
