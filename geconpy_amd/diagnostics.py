@@ -109,3 +109,89 @@ def check_bk_condition_batched(A, B, C, D=None, tol=1e-8, return_value="bool"):
         re, im = out["real"][i, :m], out["imag"][i, :m]
         frames.append(pd.DataFrame({"Modulus": np.hypot(re, im), "Real": re, "Imaginary": im}))
     return frames
+
+
+def sample_parameters(priors, n_samples, seed=None, method="lhs", hdi_prob=0.99):
+    """Parameter draws for ``prior_solvability_check_batched`` -> (names, array (n_samples, len(priors))).
+
+    ``priors``: dict name -> frozen ``scipy.stats`` distribution (anything with ``rvs`` / ``ppf``; the reference's priors
+    are preliz distributions, which expose the same two methods) or a ``(low, high)`` pair.  ``method`` as in
+    ``prior_solvability_check`` (gEconpy/model/statistics/perturbation_diagnostics.py:526-579): ``"random"`` -- Monte
+    Carlo through ``rvs``; ``"lhs" | "sobol" | "halton"`` -- uniform quasi-Monte-Carlo over the central ``hdi_prob``
+    interval of every prior (the reference uses the HDI; for the unimodal priors of DSGE models the two coincide up to
+    skewness); ``"sobol_ppf" | "halton_ppf" | "lhs_ppf"`` -- quasi-Monte-Carlo through the inverse CDF."""
+    from scipy.stats import qmc
+
+    names = list(priors)
+    d = len(names)
+    rng = np.random.default_rng(seed)
+    if method == "random":
+        cols = []
+        for nm in names:
+            pr = priors[nm]
+            cols.append(rng.uniform(pr[0], pr[1], n_samples) if isinstance(pr, tuple) else
+                        np.asarray(pr.rvs(n_samples, random_state=rng), dtype=np.float64))
+        return names, np.stack(cols, axis=1)
+    base = method.removesuffix("_ppf")
+    engines = {"lhs": qmc.LatinHypercube, "sobol": qmc.Sobol, "halton": qmc.Halton}
+    if base not in engines:
+        raise ValueError(f"unknown sampling method {method!r}")
+    u = engines[base](d=d, seed=rng).random(n_samples)
+    out = np.empty_like(u)
+    tail = 0.5 * (1.0 - hdi_prob)
+    for j, nm in enumerate(names):
+        pr = priors[nm]
+        if isinstance(pr, tuple):
+            out[:, j] = pr[0] + (pr[1] - pr[0]) * u[:, j]
+        elif method.endswith("_ppf"):
+            out[:, j] = pr.ppf(np.clip(u[:, j], 1e-12, 1.0 - 1e-12))
+        else:
+            lo, hi = pr.ppf(tail), pr.ppf(1.0 - tail)
+            out[:, j] = lo + (hi - lo) * u[:, j]
+    return names, out
+
+
+def prior_solvability_check_batched(program, n_samples, priors, *, seed=None, method="lhs", hdi_prob=0.99, defaults=None,
+                                    device=0, **kwargs):
+    """Batched ``prior_solvability_check`` (gEconpy/model/statistics/perturbation_diagnostics.py:526-579) for a model
+    given as a ``JacobianProgram`` (the generated theta -> A, B, C, D kernel): sample ``n_samples`` parameter
+    vectors from ``priors`` (``sample_parameters``), evaluate ALL Jacobians in one launch on the device, and push the batch
+    through ``solvability_check_batched``.  Parameters without a prior take ``defaults[name]``.  A draw whose Jacobians
+    are not finite is labelled ``"steady_state"`` -- in a generated program the steady state is part of the same closed
+    form, so that is where a draw outside the model's domain fails (the reference labels the host stage that raises,
+    :126-133).  Returns a pandas DataFrame like the reference's: one row per draw, the sampled parameters followed by
+    ``failure_step``, ``norm_deterministic``, ``norm_stochastic`` -- in input order (the reference's pool returns
+    completion order, :484-489).  ``**kwargs`` go to ``solvability_check_batched`` (solver, tol, max_iter, norm_tol)."""
+    import pandas as pd
+
+    from .engine import LogpEngine
+
+    pnames = [str(p) for p in program.params]
+    unknown = set(priors) - set(pnames)
+    if unknown:
+        raise ValueError(f"priors for names that are not parameters of the program: {sorted(unknown)}")
+    if not priors:
+        raise ValueError("no priors given (use solvability_check_batched with a hand-made sample instead)")
+    names, draws = sample_parameters(priors, n_samples, seed=seed, method=method, hdi_prob=hdi_prob)
+    defaults = defaults or {}
+    missing = [p for p in pnames if p not in priors and p not in defaults]
+    if missing:
+        raise ValueError(f"no prior and no default for {missing}")
+    theta = np.empty((n_samples, len(pnames)))
+    for j, p in enumerate(pnames):
+        theta[:, j] = draws[:, names.index(p)] if p in priors else float(defaults[p])
+    eng = LogpEngine(device)
+    A, B, C, D, _q = eng.jacobians_from_theta(program, eng.to_device(theta))
+    eng.torch.cuda.synchronize()
+    A, B, C, D = (x.cpu().numpy() for x in (A, B, C, D))
+    bad = ~(np.isfinite(A).all(axis=(1, 2)) & np.isfinite(B).all(axis=(1, 2)) & np.isfinite(C).all(axis=(1, 2)) &
+            np.isfinite(D).all(axis=(1, 2)))
+    for M in (A, B, C, D):  # the kernels never see NaN / Inf inputs from a draw that is already labelled
+        M[bad] = 0.0
+    A[bad] = B[bad] = np.eye(A.shape[1])
+    res = solvability_check_batched(A, B, C, D, upstream_failed=bad, **kwargs)
+    df = pd.DataFrame(draws, columns=names)
+    df["failure_step"] = res["failure_step"]
+    df["norm_deterministic"] = res["norm_deterministic"]
+    df["norm_stochastic"] = res["norm_stochastic"]
+    return df

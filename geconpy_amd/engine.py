@@ -127,12 +127,35 @@ class LogpEngine:
                        None if q is None else q.data_ptr(), self._stream())
         return A, B, C, D, q
 
+    def observation_from_theta(self, program, theta, out=None):
+        """``theta`` -> (Z [batch][p][n] or None, d [batch][p] or None): the parameter-dependent observation equation of a
+        program built with ``Z=`` / ``d=`` (statespace.py:298-388), by its second generated kernel."""
+        torch = self.torch
+        self._chk(theta)
+        nb = theta.shape[0]
+        if program.Z is None and program.d is None:
+            return None, None
+        if out is None:
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.device)  # noqa: E731
+            out = (mk(nb, program.p, program.n) if program.Z is not None else None,
+                   mk(nb, program.p) if program.d is not None else None)
+        Zb, db = out
+        program.launch_obs(theta.data_ptr(), nb, self._p(Zb), self._p(db), self._stream())
+        return Zb, db
+
     def logp_from_theta(self, program, theta, Z, y, d=None, Hdiag=None, jac_out=None, **kw):
         """theta -> A,B,C,D,q -> T,R -> P0 -> logp without the matrices ever leaving the device: the generated
-        Jacobian kernel followed by the fused pipeline on the same stream.  Returns (logp, status)."""
+        Jacobian kernel followed by the fused pipeline on the same stream.  Returns (logp, status).  ``Z`` / ``d`` = None
+        take the program's own parameter-dependent observation equation (``observation_from_theta``)."""
         A, B, C, D, q = self.jacobians_from_theta(program, theta, out=jac_out)
         if q is None:
             raise ValueError("the program has no shock variances; call jacobians_from_theta + solve_kalman_logp")
+        if Z is None or (d is None and getattr(program, "d", None) is not None):
+            Zg, dg = self.observation_from_theta(program, theta)
+            Z = Zg if Z is None else Z
+            d = dg if d is None else d
+            if Z is None:
+                raise ValueError("no design matrix: pass Z or build the program with Z=")
         return self.solve_kalman_logp(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, q_mode=1, **kw)
 
     def logp_and_grad_from_theta(self, program, theta, Z, y, d=None, Hdiag=None, jac_out=None, grad_out=None,

@@ -54,7 +54,10 @@ class JacobianProgram:
     A, B, C : sympy (n, n) matrices;  D : (n, k);  q : optional length-k sequence of shock variances
     """
 
-    def __init__(self, name, params, A, B, C_, D, q=None):
+    def __init__(self, name, params, A, B, C_, D, q=None, Z=None, d=None):
+        """``Z`` (p, n) / ``d`` (p,): optional parameter-dependent observation equation -- the linearised design rows of
+        ``_make_design_matrix`` (gEconpy/model/statespace.py:298-332) and the steady-state intercept of
+        ``_make_obs_intercept`` (:334-388) -- evaluated by a second generated kernel (``launch_obs``)."""
         import sympy as sp
 
         self.name = str(name)
@@ -68,9 +71,20 @@ class JacobianProgram:
         self.q = None if q is None else [sp.sympify(x) for x in q]
         if self.q is not None and len(self.q) != self.k:
             raise ValueError("q must have one entry per shock")
+        self.Z = None if Z is None else sp.Matrix(Z)
+        self.d = None if d is None else [sp.sympify(x) for x in d]
+        if self.Z is not None and self.Z.shape[1] != self.n:
+            raise ValueError("Z must have one column per model variable")
+        self.p = self.Z.shape[0] if self.Z is not None else (len(self.d) if self.d is not None else 0)
+        if self.Z is not None and self.d is not None and len(self.d) != self.p:
+            raise ValueError("d must have one entry per row of Z")
         free = set().union(*(M.free_symbols for M in self.mats))
         if self.q is not None:
             free |= set().union(*(x.free_symbols for x in self.q))
+        if self.Z is not None:
+            free |= self.Z.free_symbols
+        if self.d is not None:
+            free |= set().union(*(sp.sympify(x).free_symbols for x in self.d))
         unknown = free - set(self.params)
         if unknown:
             raise ValueError(f"expressions use symbols that are not parameters: {sorted(map(str, unknown))}")
@@ -162,9 +176,58 @@ class JacobianProgram:
         lines.append("  double* tb = theta_bar + (size_t)draw * JAC_NPAR;")
         for i, expr in enumerate(reduced2):
             lines.append(f"  tb[{i}] = {pr.doprint(expr)};")
+        lines += ["}", ""]
+        has_obs = self.Z is not None or self.d is not None
+        if has_obs:
+            # ---- observation equation: Z [batch][p][n] (zero-filled by the launcher), d [batch][p], and the pullback of d
+            zent = []
+            if self.Z is not None:
+                for r in range(self.p):
+                    for c_ in range(n):
+                        if self.Z[r, c_] != 0:
+                            zent.append((0, r * n + c_, self.Z[r, c_]))
+            dent = [(1, j, e) for j, e in enumerate(self.d)] if self.d is not None else []
+            oent = zent + dent
+            repl3, red3 = sp.cse([e for _, _, e in oent], symbols=sp.numbered_symbols("w"), optimizations="basic")
+            lines += [
+                f"#define JAC_P {self.p}",
+                "__global__ __launch_bounds__(256) void jac_obs_kernel(const double* __restrict__ theta, int batch,",
+                "    double* __restrict__ Z, double* __restrict__ d) {",
+                "  const int draw = blockIdx.x * 256 + threadIdx.x;",
+                "  if (draw >= batch) return;",
+                "  const double* th = theta + (size_t)draw * JAC_NPAR;",
+            ]
+            for i, p_ in enumerate(self.params):
+                lines.append(f"  const double {pr.doprint(p_)} = th[{i}];")
+            for sym, expr in repl3:
+                lines.append(f"  const double {pr.doprint(sym)} = {pr.doprint(expr)};")
+            for (mi, flat, _), expr in zip(oent, red3):
+                tgt = f"Z[(size_t)draw * JAC_P * JAC_N + {flat}]" if mi == 0 else f"d[(size_t)draw * JAC_P + {flat}]"
+                lines.append(f"  {tgt} = {pr.doprint(expr)};")
+            lines += ["}", ""]
+            if self.d is not None:
+                gs = [sp.Symbol(f"gd_{j}") for j in range(self.p)]
+                dv = [sp.Add(*[g * sp.diff(e, th_) for g, e in zip(gs, self.d)]) for th_ in self.params]
+                repl4, red4 = sp.cse(dv, symbols=sp.numbered_symbols("v"), optimizations="basic")
+                lines += [
+                    "// theta_bar += (d d / d theta)' d_bar",
+                    "__global__ __launch_bounds__(256) void jac_obs_vjp_kernel(const double* __restrict__ theta, int batch,",
+                    "    const double* __restrict__ d_bar, double* __restrict__ theta_bar) {",
+                    "  const int draw = blockIdx.x * 256 + threadIdx.x;",
+                    "  if (draw >= batch) return;",
+                    "  const double* th = theta + (size_t)draw * JAC_NPAR;",
+                ]
+                for i, p_ in enumerate(self.params):
+                    lines.append(f"  const double {pr.doprint(p_)} = th[{i}];")
+                for j, g in enumerate(gs):
+                    lines.append(f"  const double {g} = d_bar[(size_t)draw * JAC_P + {j}];")
+                for sym, expr in repl4:
+                    lines.append(f"  const double {pr.doprint(sym)} = {pr.doprint(expr)};")
+                lines.append("  double* tb = theta_bar + (size_t)draw * JAC_NPAR;")
+                for i, expr in enumerate(red4):
+                    lines.append(f"  tb[{i}] += {pr.doprint(expr)};")
+                lines += ["}", ""]
         lines += [
-            "}",
-            "",
             'extern "C" {',
             "int dsge_jac_dims(int* n, int* k, int* npar, int* has_q) {",
             f"  *n = JAC_N; *k = JAC_K; *npar = JAC_NPAR; *has_q = {0 if self.q is None else 1};",
@@ -196,9 +259,34 @@ class JacobianProgram:
             "                     A_bar, B_bar, C_bar, D_bar, q_bar, theta_bar);",
             "  return hipGetLastError() == hipSuccess ? 0 : 2;",
             "}",
-            "}",
-            "",
         ]
+        if has_obs:
+            lines += [
+                "// observation equation: Z [batch][p][n] (NULL if the program has none), d [batch][p] (NULL if none); 0 = success",
+                "int dsge_jac_obs_dims(int* p, int* has_Z, int* has_d) {",
+                f"  *p = JAC_P; *has_Z = {0 if self.Z is None else 1}; *has_d = {0 if self.d is None else 1};",
+                "  return 0;",
+                "}",
+                "int dsge_jac_obs_launch(const double* theta, int batch, double* Z, double* d, void* stream) {",
+                "  hipStream_t st = (hipStream_t)stream;",
+                f"  if (batch < 0 || !theta || ({0 if self.Z is None else 1} && !Z) || ({0 if self.d is None else 1} && !d)) return 1;",
+                "  if (batch == 0) return 0;",
+                "  if (Z && hipMemsetAsync(Z, 0, (size_t)batch * JAC_P * JAC_N * sizeof(double), st) != hipSuccess) return 2;",
+                "  hipLaunchKernelGGL(jac_obs_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, theta, batch, Z, d);",
+                "  return hipGetLastError() == hipSuccess ? 0 : 2;",
+                "}",
+            ]
+            if self.d is not None:
+                lines += [
+                    "int dsge_jac_obs_vjp_launch(const double* theta, int batch, const double* d_bar, double* theta_bar, void* stream) {",
+                    "  if (batch < 0 || !theta || !d_bar || !theta_bar) return 1;",
+                    "  if (batch == 0) return 0;",
+                    "  hipLaunchKernelGGL(jac_obs_vjp_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, batch,",
+                    "                     d_bar, theta_bar);",
+                    "  return hipGetLastError() == hipSuccess ? 0 : 2;",
+                    "}",
+                ]
+        lines += ["}", ""]
         return "\n".join(lines)
 
     # -- build / load ----------------------------------------------------------------------
@@ -234,6 +322,10 @@ class JacobianProgram:
             lib.dsge_jac_dims.argtypes = [C.POINTER(C.c_int)] * 4
             lib.dsge_jac_launch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
             lib.dsge_jac_vjp_launch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+            if self.Z is not None or self.d is not None:
+                lib.dsge_jac_obs_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                if self.d is not None:
+                    lib.dsge_jac_obs_vjp_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
             dims = [C.c_int() for _ in range(4)]
             lib.dsge_jac_dims(*[C.byref(d) for d in dims])
             if (dims[0].value, dims[1].value, dims[2].value) != (self.n, self.k, len(self.params)):
@@ -246,6 +338,18 @@ class JacobianProgram:
         if rc != 0:
             raise RuntimeError(f"dsge_jac_launch failed with code {rc}")
 
+
+    def launch_obs(self, theta_ptr, batch, Z_ptr, d_ptr, stream):
+        """theta -> Z [batch][p][n], d [batch][p] (device pointers; the one the program lacks may be None)."""
+        rc = self.load().dsge_jac_obs_launch(theta_ptr, int(batch), Z_ptr, d_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"dsge_jac_obs_launch failed with code {rc}")
+
+    def launch_obs_vjp(self, theta_ptr, batch, d_bar, theta_bar, stream):
+        """theta_bar += (d d / d theta)' d_bar."""
+        rc = self.load().dsge_jac_obs_vjp_launch(theta_ptr, int(batch), d_bar, theta_bar, stream)
+        if rc != 0:
+            raise RuntimeError(f"dsge_jac_obs_vjp_launch failed with code {rc}")
 
     def launch_vjp(self, theta_ptr, batch, A_bar, B_bar, C_bar, D_bar, q_bar, theta_bar, stream):
         rc = self.load().dsge_jac_vjp_launch(theta_ptr, int(batch), A_bar, B_bar, C_bar, D_bar, q_bar, theta_bar, stream)

@@ -192,3 +192,107 @@ def test_sw_shaped_theta_program_on_device():
             lps.append(l_.cpu().numpy())
         fd = (lps[0] - lps[1]) / (2 * h)
         np.testing.assert_allclose(tb[:, j], fd, rtol=2e-3, atol=2e-3 * np.abs(fd).max())
+
+
+def test_sample_parameters_methods():
+    from scipy import stats
+
+    from geconpy_amd.diagnostics import sample_parameters
+
+    priors = {"beta": stats.beta(10, 1), "sigma": stats.gamma(4, scale=0.5), "rho": (0.0, 0.99)}
+    for method in ("random", "lhs", "sobol", "halton", "sobol_ppf", "lhs_ppf"):
+        names, x = sample_parameters(priors, 128, seed=3, method=method)
+        assert names == ["beta", "sigma", "rho"] and x.shape == (128, 3) and np.isfinite(x).all()
+        assert (x[:, 0] > 0).all() and (x[:, 0] <= 1).all() and (x[:, 2] >= 0).all() and (x[:, 2] <= 0.99).all()
+        names2, x2 = sample_parameters(priors, 128, seed=3, method=method)
+        assert np.array_equal(x, x2)  # seeded
+    _n, x = sample_parameters(priors, 256, seed=0, method="lhs", hdi_prob=0.9)
+    lo, hi = stats.gamma(4, scale=0.5).ppf([0.05, 0.95])
+    assert x[:, 1].min() >= lo and x[:, 1].max() <= hi
+    with pytest.raises(ValueError):
+        sample_parameters(priors, 8, method="nope")
+
+
+@pytest.mark.gpu
+def test_prior_solvability_check_batched_rbc():
+    """prior_solvability_check (perturbation_diagnostics.py:526-579) on the generated RBC kernel: draws inside the priors'
+    bulk all solve; widening delta / rho_A far outside produces labelled failures, in input order."""
+    from scipy import stats
+
+    from geconpy_amd.diagnostics import prior_solvability_check_batched
+
+    prog = rbc_linearized_program()
+    priors = {"sigma": stats.gamma(8, scale=0.25), "phi": stats.gamma(9, scale=1 / 3), "alpha": stats.beta(5, 9),
+              "beta": stats.beta(40, 1), "delta": stats.beta(2, 40), "rho_A": stats.beta(3, 2)}
+    df = prior_solvability_check_batched(prog, 512, priors, seed=1, method="sobol", defaults={"sigma_A": 0.01}, tol=1e-8,
+                                         max_iter=1000)
+    assert list(df.columns) == list(priors) + ["failure_step", "norm_deterministic", "norm_stochastic"] and len(df) == 512
+    assert df["failure_step"].isna().all() or (df["failure_step"].isna().mean() > 0.98)
+    ok = df["failure_step"].isna()
+    assert (df.loc[ok, "norm_deterministic"] < 1e-8).all() and (df.loc[ok, "norm_stochastic"] < 1e-8).all()
+    wild = dict(priors, rho_A=(0.5, 1.5), alpha=(-0.2, 0.9))
+    dfw = prior_solvability_check_batched(prog, 512, wild, seed=1, method="lhs", defaults={"sigma_A": 0.01}, tol=1e-8,
+                                          max_iter=200)
+    labels = set(dfw["failure_step"].dropna())
+    assert labels and labels <= {"steady_state", "perturbation", "blanchard-kahn", "deterministic_norm", "stochastic_norm"}
+    explosive = dfw["rho_A"] > 1.0
+    assert dfw.loc[explosive & (dfw["alpha"] > 0.05), "failure_step"].notna().all()  # an explosive shock process never passes
+    assert dfw.loc[dfw["alpha"] < 0, "failure_step"].eq("steady_state").all()        # (alpha / R)^(...) of a negative number
+
+
+def _rbc_obs_program():
+    """RBC with a parameter-dependent observation equation: log-level output and consumption,
+    y_obs = ln X_ss(theta) + x_hat  (Z rows select Y and C with unit loadings scaled by a parameter-dependent factor to
+    exercise Z(theta) as well: the second row loads 1 / sigma on C)."""
+    import sympy as sp
+
+    base = rbc_linearized_program()
+    sigma, phi, alpha, beta, delta, rho_A, sigma_A = base.params
+    R = 1 / beta - (1 - delta)
+    W = (1 - alpha) ** (1 / (1 - alpha)) * (alpha / R) ** (alpha / (1 - alpha))
+    Y = (R / (R - delta * alpha)) ** (sigma / (sigma + phi)) * ((1 - alpha) ** (-phi) * W ** (1 + phi)) ** (1 / (sigma + phi))
+    Cs = Y - delta * alpha * Y / R
+    Z = sp.zeros(2, 8)
+    Z[0, 7] = 1
+    Z[1, 1] = 1 / sigma
+    return JacobianProgram("rbc_obs", base.params, *base.mats, q=base.q, Z=Z, d=[sp.log(Y), sp.log(Cs)])
+
+
+def test_observation_equation_codegen_source():
+    prog = _rbc_obs_program()
+    src = prog.source()
+    assert "jac_obs_kernel" in src and "dsge_jac_obs_launch" in src and "dsge_jac_obs_vjp_launch" in src and prog.p == 2
+    assert "jac_obs_kernel" not in rbc_linearized_program().source()  # programs without Z / d are unchanged
+
+
+@pytest.mark.gpu
+def test_observation_equation_from_theta_on_device():
+    """Z(theta), d(theta) generated on the device (statespace.py:298-388) and used by the fused call as batched design
+    matrix / intercept: values against the numpy closed form, logp against the oracle with that draw's Z and d."""
+    import torch
+
+    import oracle
+    from geconpy_amd.engine import LogpEngine
+
+    prog = _rbc_obs_program()
+    nb = 48
+    th, theta = _theta(nb)
+    eng = LogpEngine(0)
+    d_th = eng.to_device(theta)
+    Zb, db = eng.observation_from_theta(prog, d_th)
+    torch.cuda.synchronize()
+    ss = wl.rbc_steady_state(th["sigma"], th["phi"], th["alpha"], th["beta"], th["delta"])
+    assert_allclose(db.cpu().numpy(), np.stack([np.log(ss["Y"]), np.log(ss["C"])], axis=1), rtol=1e-13)
+    Zh = Zb.cpu().numpy()
+    assert_allclose(Zh[:, 1, 1], 1.0 / th["sigma"], rtol=1e-15)
+    assert np.all(Zh[:, 0, 7] == 1.0) and np.count_nonzero(Zh) == 2 * nb
+    y = np.stack([np.log(ss["Y"][0]), np.log(ss["C"][0])]) + np.random.default_rng(0).normal(0, 0.02, (60, 2))
+    dy, dH = eng.to_device(y), eng.to_device(np.array([1e-4, 1e-4]))
+    logp, status = eng.logp_from_theta(prog, d_th, None, dy, Hdiag=dH, tol=1e-10, max_iter=1000)
+    torch.cuda.synchronize()
+    assert not status.cpu().numpy().any()
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    for i in (0, 20, 47):
+        ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.array([[th["sigma_A"][i] ** 2]]), Zh[i], y,
+                                       H=np.diag([1e-4, 1e-4]), d=db.cpu().numpy()[i], tol=1e-10, max_iter=1000)
+        assert abs(logp[i].item() - ref["logp"]) <= 1e-8 * abs(ref["logp"])
