@@ -288,8 +288,13 @@ def main():
     cpu = None
     cpu_logp = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        cores = os.cpu_count() or 1
-        n_sample = min(max(args.cpu_sample, 16 * cores), hi - lo)  # a few seconds of wall on every core
+        try:  # one worker per PHYSICAL core: with SMT siblings as workers the per-core rate halves and says nothing more
+            import psutil
+
+            cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+        except ImportError:
+            cores = os.cpu_count() or 1
+        n_sample = min(max(args.cpu_sample, 24 * cores), hi - lo)  # ~10 s of CPU work per core, a few seconds of wall
         cpu_logp, cpu_rate, cpu_dt = cpu_baseline(shard, om, n_sample, cores)
         cpu = {
             "value": round(cpu_rate, 3),
@@ -297,8 +302,8 @@ def main():
             "cores": cores,
             "kind": "port",
             "sample": f"first {n_sample} draws of the same SW-shaped batch, numpy/scipy oracle "
-                      f"(cycle reduction + bilinear Lyapunov + Joseph-form Kalman), {cores} worker processes x 1 BLAS "
-                      f"thread, {cpu_dt:.1f} s wall",
+                      f"(cycle reduction + bilinear Lyapunov + Joseph-form Kalman), {cores} worker processes (one per physical "
+                      f"core) x 1 BLAS thread, {cpu_dt:.1f} s wall",
         }
 
     import torch
@@ -459,7 +464,8 @@ def main():
                                 if n > 16 else "dsge::gensys_kernel"),
                  "assemble": ("dsge::rqr_kernel<16>" if (args.solver == "cycle_reduction" and k <= 16)
                               else f"dsge::assemble_kernel<{(n + 7) // 8}>"),
-                 "kalman": f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>"}
+                 "kalman": (f"dsge::kalman_nt_kernel<{(u_dim + 7) // 8}>" if hints[1] and p <= 8
+                            else f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>")}
         kern = {}
         for key in ("solver", "assemble", "kalman"):
             sec = kms[key] * 1e-3
