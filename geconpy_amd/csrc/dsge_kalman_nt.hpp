@@ -346,11 +346,14 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     }                                                                                            \
   } while (0)
     STORE_PZT();
-    const int my_zpos = (fo < p) ? zpos[fo] : 0;
-    const double my_zv = (fo < p) ? zv[fo] : 0.0;
     const int v_zpos = (lane < p) ? zpos[lane] : 0;
     const double v_zv = (lane < p) ? zv[lane] : 0.0, v_dd = (lane < 8) ? dd[lane & 7] : 0.0;
     wave_sync();
+
+    const int r8 = lane & 7, g8 = lane >> 3;  // the update runs on 8 replicas of an 8-lane group: lane -> row r8 of F
+    const int r_zpos = (r8 < p) ? zpos[r8] : 0;
+    const double r_zv = (r8 < p) ? zv[r8] : 0.0, r_dd = dd[r8], r_hh = hh[r8];
+    const bool fold_a = m < NP;  // a spare padding column: the mean prediction rides along in the X product
 
     double quad_sum = 0.0, quad_comp = 0.0;  // Kahan sum of v' Finv v over observed steps
     double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
@@ -358,115 +361,130 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     int n_ll_steps = 0;
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = DBG ? clock64() : 0;
-    double av_reg = 0.0;  // predicted state a_{t|t-1}, one entry per lane
     int steady_step = -1;
-    double yt_next = (lane < p && T_len > 0) ? y[lane] : 0.0;
+    double yt_next = (r8 < p && T_len > 0) ? y[r8] : 0.0;
     for (int t = 0; t < T_len; ++t) {
       long long tk0 = DBG ? clock64() : 0;
-      // ---- (a) missing-data mask ------------------------------------------------------
+      // ---- (a) missing-data mask; every LDS operand of the update is requested up front ------------------------------
       const double yt = yt_next;
-      yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
-      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
-      const unsigned long long omask = __ballot(obs);
+      yt_next = (r8 < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + r8] : 0.0;
+      const bool obs = (r8 < p) && (yt == yt) && (yt != missing_fill);
+      const unsigned long long omask = __ballot(obs) & 0xffull;
       const int n_obs = __popcll(omask);
+      double2 fr2[4], pz2[BS][4];
+      double pzo[BS], avi[BS];
+#pragma unroll
+      for (int q2 = 0; q2 < 4; ++q2) fr2[q2] = *reinterpret_cast<const double2*>(&PZt[r_zpos * PS + 2 * q2]);
+      const double a_sel = av[r_zpos];
+#pragma unroll
+      for (int ps = 0; ps < BS; ++ps) {
+        const int i = g8 + 8 * ps;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) pz2[ps][q2] = *reinterpret_cast<const double2*>(&PZt[i * PS + 2 * q2]);
+        pzo[ps] = PZt[i * PS + r8];
+        avi[ps] = av[i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       bool steady = false;
-      double pscale = 0.0;
+      double pm = 0.0;  // max |P_{t|t-1}| (wave-uniform), reduced while the loads are in flight.  P is positive
+                        // semi-definite: its largest entry is on the diagonal, which the lanes lr == lc hold
       if (steady_tol > 0.0) {
+        double pscale = 0.0;
 #pragma unroll
-        for (int i = 0; i < BS; ++i)
-#pragma unroll
-          for (int j = 0; j < BS; ++j) pscale = nanmax(pscale, fabs(Pb[i][j]));
+        for (int i = 0; i < BS; ++i) pscale = fmax(pscale, fabs(Pb[i][i]));
+        if (lr != lc) pscale = 0.0;
+        // exact max of non-negative doubles: high words first, then the low words of the lanes that attain it
+        const unsigned hi = (unsigned)__double2hiint(pscale), lo = (unsigned)__double2loint(pscale);
+        const unsigned mhi = wave_max_u32(hi);
+        const unsigned mlo = wave_max_u32(hi == mhi ? lo : 0u);
+        pm = __hiloint2double((int)mhi, (int)mlo);
       }
-      // ---- (b) the innovation (selector: one entry of the predicted state per observation) -----------------------
-      const double av_sel0 = __shfl(av_reg, v_zpos, 64);
-      double v_own = 0.0;
-      if (lane < p) v_own = (obs ? yt : 0.0) - (v_dd + (obs ? 1.0 : 0.0) * (v_zv * av_sel0));
-      if (lane < 8) vv[lane] = v_own;
-      // ---- (b') F[fo][fq]: lane (fo,fq) of the 8 x 8 grid ---------------------------------------
-      double step_mant = 1.0;
+      // ---- (b) innovation v[r8] and row r8 of F = Zm P Zm' + Hm + jitter I, replicated over the eight 8-lane groups
+      //      (identity rows / columns for missing observations and for r8 >= p) ---------------------------------------
+      const double c_r = obs ? r_zv : 0.0;
+      const double v_r = (obs ? yt : 0.0) - (r_dd + c_r * a_sel);
+      const double dg = (r8 < p) ? ((obs ? r_hh : 0.0) + jitter) : 1.0;
+      if (lane < 8) vv[lane] = v_r;  // broadcast of v for the quadratic form: through LDS, behind the elimination
+      asm volatile("" ::: "memory");  // (the double2 reads below must not be hoisted above this store)
+      double fr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double tq = (q & 1) ? fr2[q >> 1].y : fr2[q >> 1].x;
+        const double wq = ((omask >> q) & 1ull) ? 1.0 : 0.0;  // wave-uniform
+        const double f = (c_r * tq) * wq;
+        fr[q] = (q == r8) ? f + dg : f;
+      }
+      // ---- (c) Finv by Gauss-Jordan, one row per lane (SPD: no pivoting); the pivot row arrives through SGPRs.  The
+      //      rows are left unscaled during the elimination (row j keeps its pivot: one fma per entry and lane, no
+      //      per-entry select); Finv[r][:] = inv_own * fr[:] afterwards -------------------------------------------------
+      double step_mant = 1.0, inv_own = 1.0;
       int step_exp = 0;
-      double f;
-      {
-        const double wo = (double)((omask >> fo) & 1ull), wq = (double)((omask >> fq) & 1ull);
-        if (fo < p && fq < p) {
-          f = wo * wq * my_zv * PZt[my_zpos * PS + fq];
-          if (fo == fq) f += wo * hh[fo] + jitter;
-        } else {
-          f = (fo == fq) ? 1.0 : 0.0;
-        }
-      }
-      // ---- (c) Finv by in-register Gauss-Jordan (SPD: no pivoting) ----
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j < p) {
-          const double piv = readlane_f64(f, j * 9);
-          const double rowj = __shfl(f, (j << 3) | fq, 64);
-          const double colj = __shfl(f, (fo << 3) | j, 64);
-          const double inv = fast_rcp(piv);
-          const double ci = colj * inv;
-          double nf = fma(-ci, rowj, f);
-          nf = (fo == j) ? rowj * inv : nf;
-          nf = (fq == j) ? -ci : nf;
-          nf = (fo == j && fq == j) ? inv : nf;
-          f = nf;
+          double rowj[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rowj[q] = readlane_f64(fr[q], j);
+          const double inv = fast_rcp(rowj[j]);
+          const bool is_j = (r8 == j);
+          const double ci = is_j ? 0.0 : fr[j] * inv;  // row j itself is left alone
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q != j) fr[q] = fma(-ci, rowj[q], fr[q]);
+          fr[j] = is_j ? 1.0 : -ci;  // column j of the identity block, stored in place
+          inv_own = is_j ? inv : inv_own;
           int e;
-          step_mant *= frexp(piv, &e);
+          step_mant *= frexp(rowj[j], &e);
           step_exp += e;
         }
       }
-      Fi[lane] = f;
-      const double qp = wave_sum_dpp(f * __shfl(v_own, fo, 64) * __shfl(v_own, fq, 64));
-      if (n_obs > 0) {
-        const double yk = qp - quad_comp;
-        const double tk = quad_sum + yk;
-        quad_comp = (tk - quad_sum) - yk;
-        quad_sum = tk;
-        int e;
-        ld_mant = frexp(ld_mant * step_mant, &e);
-        ld_exp += e + step_exp;
-        ++n_ll_steps;
+      {
+        const double2* vv2 = reinterpret_cast<const double2*>(vv);
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+          const double2 vq = vv2[q2];
+          w0 = fma(fr[2 * q2], vq.x, w0);
+          w1 = fma(fr[2 * q2 + 1], vq.y, w1);
+        }
+        if (n_obs > 0) {
+          // lane r < 8 keeps its own share v_r (Finv v)_r of the quadratic forms (Kahan); the lanes are added up once
+          const double yk = ((lane < 8) ? (v_r * inv_own) * (w0 + w1) : 0.0) - quad_comp;
+          const double tk = quad_sum + yk;
+          quad_comp = (tk - quad_sum) - yk;
+          quad_sum = tk;
+          int e;
+          ld_mant = frexp(ld_mant * step_mant, &e);
+          ld_exp += e + step_exp;
+          ++n_ll_steps;
+        }
       }
-      wave_sync();  // #1
       if constexpr (DBG) {
         const long long tk1 = clock64();
         ph[0] += tk1 - tk0;
         tk0 = tk1;
       }
-      // ---- (d) K = (P Zm') Finv, V = P Zm' + jitter K, a+ = a + K v -----------------------------
-      {
-        const int o2 = lane & 3, i16 = lane >> 2;
-        double2 fi2[8];
+      // ---- (d) K = (P Zm') Finv (Finv symmetric: lane (i, o) contracts row i of P Zm' with ITS row o of Finv),
+      //          V = P Zm' + jitter K, a+ = a + K v ---------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < 8; ++q) fi2[q] = *reinterpret_cast<const double2*>(&Fi[q * 8 + 2 * o2]);
-        const double2 vp = *reinterpret_cast<const double2*>(&vv[2 * o2]);
-        const bool on0 = (omask >> (2 * o2)) & 1ull, on1 = (omask >> (2 * o2 + 1)) & 1ull;
+      for (int ps = 0; ps < BS; ++ps) {
+        const int i = g8 + 8 * ps;
+        double k0 = 0.0, k1 = 0.0;
 #pragma unroll
-        for (int pass = 0; pass < (NP + 15) / 16; ++pass) {
-          const int i = i16 + 16 * pass;
-          const bool row_ok = i < m;
-          const int ir = row_ok ? i : 0;
-          double k0 = 0.0, k1 = 0.0;
-#pragma unroll
-          for (int q2 = 0; q2 < 4; ++q2) {
-            const double2 t2 = *reinterpret_cast<const double2*>(&PZt[ir * PS + 2 * q2]);
-            const double pa = ((omask >> (2 * q2)) & 1ull) ? t2.x : 0.0;
-            const double pb2 = ((omask >> (2 * q2 + 1)) & 1ull) ? t2.y : 0.0;
-            k0 = fma(pa, fi2[2 * q2].x, k0);
-            k1 = fma(pa, fi2[2 * q2].y, k1);
-            k0 = fma(pb2, fi2[2 * q2 + 1].x, k0);
-            k1 = fma(pb2, fi2[2 * q2 + 1].y, k1);
-          }
-          const double2 pzp = *reinterpret_cast<const double2*>(&PZt[ir * PS + 2 * o2]);
-          double part = fma(k0, vp.x, k1 * vp.y);
-          part += dpp_move_f64<0xB1, 0xf>(part);  // quad_perm [1,0,3,2]
-          part += dpp_move_f64<0x4E, 0xf>(part);  // quad_perm [2,3,0,1]
-          if (row_ok) {
-            *reinterpret_cast<double2*>(&Ks[i * PS + 2 * o2]) = double2{k0, k1};
-            *reinterpret_cast<double2*>(&Vs[i * PS + 2 * o2]) =
-                double2{fma(jitter, k0, on0 ? pzp.x : 0.0), fma(jitter, k1, on1 ? pzp.y : 0.0)};
-            if (o2 == 0) af[i] = av[i] + part;
-          }
+        for (int q2 = 0; q2 < 4; ++q2) {
+          const double pa = ((omask >> (2 * q2)) & 1ull) ? pz2[ps][q2].x : 0.0;
+          const double pb2 = ((omask >> (2 * q2 + 1)) & 1ull) ? pz2[ps][q2].y : 0.0;
+          k0 = fma(pa, fr[2 * q2], k0);
+          k1 = fma(pb2, fr[2 * q2 + 1], k1);
         }
+        const double kk = (k0 + k1) * inv_own;
+        Ks[i * PS + r8] = kk;
+        Vs[i * PS + r8] = fma(jitter, kk, obs ? pzo[ps] : 0.0);
+        double part = kk * v_r;
+        part += dpp_move_f64<0xB1, 0xf>(part);   // quad_perm [1,0,3,2]
+        part += dpp_move_f64<0x4E, 0xf>(part);   // quad_perm [2,3,0,1]
+        part += dpp_move_f64<0x141, 0xf>(part);  // row_half_mirror: the other quad of the 8-lane group
+        if (r8 == 0) af[i] = avi[ps] + part;
       }
       wave_sync();  // #2
       if constexpr (DBG) {
@@ -515,9 +533,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
 #pragma unroll
             for (int j = 0; j < BS; ++j) dmax = nanmax(dmax, fabs(Pb[i][j] - Pc[(lr * BS + i) * LDK + lc * BS + j]));
         }
-        const double dm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(dmax)));
-        const double pm = __longlong_as_double((long long)wave_max_u64((unsigned long long)__double_as_longlong(pscale)));
-        steady = (t > 0) && (dm <= steady_tol * pm);
+        // max|dP+[S,S]| <= tol * max|P|  <=>  no lane violates it (NaN on either side counts as a violation)
+        steady = (t > 0) && (__ballot(!(dmax <= steady_tol * pm)) == 0ull);
       }
       if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDK, lr, lc);
       wave_sync();  // #3
@@ -526,8 +543,12 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         ph[2] += tk1 - tk0;
         tk0 = tk1;
       }
-      // ---- (f) predict: a = Tc a+[:s];  W = P+[S,S] Tc' (stored transposed);  X = Tc W;  P = sym(X) + RQR -------------
-      if (lane < m) {
+      // ---- (f) predict: W = P+[S,S] Tc' (stored transposed);  X = Tc W;  P = sym(X) + RQR.  The mean a = Tc a+[:s] is
+      //      the last column of X when the tile has a spare padding column (a+ rides along as row NP-1 of W'): no extra flops ------
+      double af_l = 0.0;
+      if (fold_a) {
+        af_l = af[lane < NP ? lane : 0];
+      } else if (lane < m) {
         const double2* trow2 = reinterpret_cast<const double2*>(Tc + lane * LDK);
         const double2* af2 = reinterpret_cast<const double2*>(af);
         double s0 = 0.0, s1 = 0.0;
@@ -536,8 +557,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           s0 = fma(tv2.x, fv.x, s0);
           s1 = fma(tv2.y, fv.y, s1);
         }
-        av_reg = s0 + s1;
-        av[lane] = av_reg;
+        av[lane] = s0 + s1;
       }
       if (w_rows) {
         double Wb[BS][BS];
@@ -548,6 +568,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
 #pragma unroll
           for (int j = 0; j < BS; ++j) Wt[(lc * BS + j) * LDK + lr * BS + i] = Wb[i][j];
       }
+      if (fold_a && lane < NP) Wt[(NP - 1) * LDK + lane] = af_l;  // after the W stores (same wave: LDS keeps program order)
       wave_sync();  // #4
       if constexpr (DBG) {
         const long long tk1 = clock64();
@@ -558,6 +579,13 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         double Xb[BS][BS];
         blk_zero<BS>(Xb);
         mm_nt<BS, LDK>(Xb, Tc, Wt, s, lr, lc);
+        if (fold_a && lc == 7) {  // column NP-1 of X = Tc a+: hand it to the LDS copy of the mean, restore the padding
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            av[lr * BS + i] = Xb[i][BS - 1];
+            Xb[i][BS - 1] = 0.0;
+          }
+        }
         const int src = (lc << 3) | lr;  // lane holding the transposed block
 #pragma unroll
         for (int i = 0; i < BS; ++i)
@@ -579,11 +607,12 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       if (steady_step < 0) steady_step = t + 1;
       {
         double trow[NP], finv_row[8], kr_ss[8];
+        double av_reg = (lane < m) ? av[lane] : 0.0;
 #pragma unroll
         for (int kk = 0; kk < NP; ++kk) trow[kk] = (lane < NP) ? Tc[lane * LDK + kk] : 0.0;  // columns >= s are zero
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          finv_row[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
+          finv_row[q] = (lane < 8) ? fr[q] * inv_own : 0.0;  // lane r < 8 still holds row r of Finv (unscaled)
           kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
         }
         while (t + 1 < T_len) {
@@ -591,7 +620,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);
           if (__ballot(obs_s) != omask) break;
           ++t;
-          yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
+          yt_next = (r8 < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + r8] : 0.0;
           const double av_sel = __shfl(av_reg, v_zpos, 64);
           double v_s = 0.0;
           if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
@@ -606,13 +635,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
             a0 = fma(kr_ss[o], vsc[o], a0);
             a1 = fma(kr_ss[o + 1], vsc[o + 1], a1);
           }
-          double part = v_s * (w0 + w1);  // lanes >= 8 hold finv_row = 0
-          part += dpp_move_f64<0x111, 0xf>(part);
-          part += dpp_move_f64<0x112, 0xf>(part);
-          part += dpp_move_f64<0x114, 0xf>(part);
-          const double qp_s = readlane_f64(part, 7);
           if (n_obs > 0) {
-            const double yk = qp_s - quad_comp;
+            const double yk = v_s * (w0 + w1) - quad_comp;  // lanes >= 8 hold finv_row = 0
             const double tk = quad_sum + yk;
             quad_comp = (tk - quad_sum) - yk;
             quad_sum = tk;
@@ -641,9 +665,10 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       ph[7] = clock64() - tk_start;
       for (int k = 0; k < 8; ++k) dbg[k] = ph[k];
     }
+    const double quad_total = wave_sum_dpp(quad_sum - quad_comp);  // lanes 0..7 hold the shares, the others zero
     if (lane == 0) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
-      const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_sum);
+      const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_total);
       logp_out[draw] = ll;
       if (steady_at) steady_at[draw] = steady_step;
       if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
