@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;                 // NP x LDK    transition, states-first ordering (columns >= s exactly zero)
   double* Wt = Tc + NP * LDK;        // WT doubles  W' : Wt[j][k] = (P+[S,S] Tc')[k][j]            (phase f)
-  double* Vs = Wt;                   //   alias: NP x PS  V = P Zm' + jitter K                    (phases d, e)
+  double* Vs = Wt;                   //   alias: NP x PS  -V = -(P Zm' + jitter K)                 (phases d, e)
   double* Pc = Wt + KntSmem<BS>::WT; // s_cap x LDK P+ restricted to the state block
   double* PZt = Pc + s_cap * LDK;    // NP x PS     (predicted P) Z', unmasked
   double* Ks = PZt + NP * PS;        // NP x PS     K = P Zm' Finv  (kept through the prediction: the steady loop reads it)
@@ -353,6 +353,9 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     const int r8 = lane & 7, g8 = lane >> 3;  // the update runs on 8 replicas of an 8-lane group: lane -> row r8 of F
     const int r_zpos = (r8 < p) ? zpos[r8] : 0;
     const double r_zv = (r8 < p) ? zv[r8] : 0.0, r_dd = dd[r8], r_hh = hh[r8];
+    double jit_d[BS];  // jitter on the diagonal of P+ (rows < m of the diagonal lanes)
+#pragma unroll
+    for (int i = 0; i < BS; ++i) jit_d[i] = (lr == lc && lr * BS + i < m) ? jitter : 0.0;
     const bool fold_a = m < NP;  // a spare padding column: the mean prediction rides along in the X product
 
     double quad_sum = 0.0, quad_comp = 0.0;  // Kahan sum of v' Finv v over observed steps
@@ -469,17 +472,17 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
 #pragma unroll
       for (int ps = 0; ps < BS; ++ps) {
         const int i = g8 + 8 * ps;
+        // F is block diagonal (observed block, identity for the rest) and so is Finv, exactly: masking the result for a
+        // missing observation o = r8 is all the masking the gain needs
         double k0 = 0.0, k1 = 0.0;
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
-          const double pa = ((omask >> (2 * q2)) & 1ull) ? pz2[ps][q2].x : 0.0;
-          const double pb2 = ((omask >> (2 * q2 + 1)) & 1ull) ? pz2[ps][q2].y : 0.0;
-          k0 = fma(pa, fr[2 * q2], k0);
-          k1 = fma(pb2, fr[2 * q2 + 1], k1);
+          k0 = fma(pz2[ps][q2].x, fr[2 * q2], k0);
+          k1 = fma(pz2[ps][q2].y, fr[2 * q2 + 1], k1);
         }
-        const double kk = (k0 + k1) * inv_own;
+        const double kk = obs ? (k0 + k1) * inv_own : 0.0;
         Ks[i * PS + r8] = kk;
-        Vs[i * PS + r8] = fma(jitter, kk, obs ? pzo[ps] : 0.0);
+        Vs[i * PS + r8] = -fma(jitter, kk, obs ? pzo[ps] : 0.0);  // stored negated: the downdate is a plain fma chain
         double part = kk * v_r;
         part += dpp_move_f64<0xB1, 0xf>(part);   // quad_perm [1,0,3,2]
         part += dpp_move_f64<0x4E, 0xf>(part);   // quad_perm [2,3,0,1]
@@ -511,8 +514,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           for (int i = 0; i < BS; ++i)
 #pragma unroll
             for (int j = 0; j < BS; ++j) {
-              Pb[i][j] = fma(-ka[i].x, vb[j].x, Pb[i][j]);
-              Pb[i][j] = fma(-ka[i].y, vb[j].y, Pb[i][j]);
+              Pb[i][j] = fma(ka[i].x, vb[j].x, Pb[i][j]);
+              Pb[i][j] = fma(ka[i].y, vb[j].y, Pb[i][j]);
             }
 #pragma unroll
           for (int i = 0; i < BS; ++i) ka[i] = kan[i];
@@ -520,20 +523,17 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           for (int j = 0; j < BS; ++j) vb[j] = vbn[j];
         }
       }
-      if (lr == lc) {
 #pragma unroll
-        for (int i = 0; i < BS; ++i)
-          if (lr * BS + i < m) Pb[i][i] += jitter;
-      }
+      for (int i = 0; i < BS; ++i) Pb[i][i] += jit_d[i];
       if (steady_tol > 0.0) {
         double dmax = 0.0;
         if (in_state_block) {
 #pragma unroll
           for (int i = 0; i < BS; ++i)
 #pragma unroll
-            for (int j = 0; j < BS; ++j) dmax = nanmax(dmax, fabs(Pb[i][j] - Pc[(lr * BS + i) * LDK + lc * BS + j]));
+            for (int j = 0; j < BS; ++j) dmax = fmax(dmax, fabs(Pb[i][j] - Pc[(lr * BS + i) * LDK + lc * BS + j]));
         }
-        // max|dP+[S,S]| <= tol * max|P|  <=>  no lane violates it (NaN on either side counts as a violation)
+        // max|dP+[S,S]| <= tol * max|P|  <=>  no lane violates it (a NaN in P ends in a non-finite logp either way)
         steady = (t > 0) && (__ballot(!(dmax <= steady_tol * pm)) == 0ull);
       }
       if (in_state_block) blk_store_lds<BS>(Pb, Pc, LDK, lr, lc);
