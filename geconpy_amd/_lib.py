@@ -67,6 +67,7 @@ PROTOTYPES = {
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_set_kalman_tiny": [_i],
     "dsge_set_kalman_nt_products": [_i],
+    "dsge_set_cr_fused_deflation": [_i],
     "dsge_set_cr_deflation": [_i],
     "dsge_set_cr_two_waves": [_i],
     "dsge_set_kalman_order": [_i],
@@ -141,7 +142,7 @@ class Options(C.Structure):
         ("gensys_split", C.c_int32),
         ("kalman_steady_tol", C.c_double),
         ("kalman_nt_products", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("cr_fused_deflation", C.c_int32),
     ]
 
 
@@ -157,7 +158,7 @@ def make_options(options=None, **fields):
     elif options:
         fields = {**options, **fields}
     for name, value in fields.items():
-        if name not in {f[0] for f in Options._fields_} or name in ("struct_size", "reserved_"):
+        if name not in {f[0] for f in Options._fields_} or name == "struct_size":
             raise ValueError(f"unknown option {name!r}")
         setattr(o, name, value)
     return o

@@ -131,6 +131,7 @@ struct OptionsGuard {
     local.gensys_split = o->gensys_split;
     local.kalman_steady_tol = o->kalman_steady_tol;
     local.kalman_nt_products = o->kalman_nt_products;
+    local.cr_fused_deflation = o->cr_fused_deflation;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -294,6 +295,11 @@ int dsge_set_kalman_block(int enable) {
   g_defaults.kalman_block = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
+int dsge_set_cr_fused_deflation(int enable) {
+  g_defaults.cr_fused_deflation = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
+
 int dsge_set_kalman_nt_products(int enable) {
   g_defaults.kalman_nt_products = enable ? 1 : 0;
   return DSGE_SUCCESS;
@@ -1554,6 +1560,7 @@ int dsge_options_init(dsge_options* o) {
   o->gensys_split = d.gensys_split;
   o->kalman_steady_tol = d.kalman_steady_tol;
   o->kalman_nt_products = d.kalman_nt_products;
+  o->cr_fused_deflation = d.cr_fused_deflation;
   return DSGE_SUCCESS;
 }
 

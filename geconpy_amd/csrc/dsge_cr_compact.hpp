@@ -52,6 +52,98 @@ __device__ __forceinline__ unsigned long long blk_colmask(const double (&x)[BS][
   return mask;
 }
 
+// The cycle-reduction iteration on the compact form (register blocks A1, A1_hat, R = [A0c | A2c]; W = [A1 | R] in LDS).
+// ph (nullable): debug stamps [0] GJ panels, [1] GJ trailing updates, [2] row gather + staging, [3] products,
+// [4] scatter/update/norms.
+template <int BS>
+__device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[BS][BS], double (&Rb)[BS][BS], double* W,
+                                            double* Lbuf, double* Ybuf, int* prow, const int* cmap, int* rsrc,
+                                            const int (&vS)[BS], const int (&vL)[BS], int n, int s, int l, int max_iter,
+                                            double tol, int scan_mode, int lane, long long* ph, int& it, bool& converged,
+                                            bool& saw_nan) {
+  constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
+  double* G1 = W + NP;
+  const int lr = lane >> 3, lc = lane & 7, wr = s + l;
+  converged = false;
+  saw_nan = false;
+  it = 0;
+  for (; it < max_iter;) {
+    // W = [A1 | R] -> [. | A1^-1 R] (rows in pivot order)
+    blk_store_lds<BS>(A1, W, LDW, lr, lc);
+    if (scan_mode && lr == lc) {  // stabilize(A1): 1e-16 on the diagonal of the solve only (shared.py:6-9)
+#pragma unroll
+      for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
+    }
+    blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
+    gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, ph);  // syncs on entry and exit
+    long long tk0 = ph ? clock64() : 0;
+    // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
+    if (lane < NP) rsrc[lane] = (lane < wr) ? prow[cmap[lane]] : 0;
+    wave_sync();
+    {
+      double t[BS][BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
+        const int src = rsrc[lr * BS + i];
+#pragma unroll
+        for (int j = 0; j < BS; ++j) t[i][j] = G1[src * LDW + lc * BS + j];
+      }
+      wave_sync();
+      blk_store_lds<BS>(t, G1, LDW, lr, lc);
+    }
+    blk_store_lds<BS>(Rb, W, LDW, lr, lc);  // left operands [A0c | A2c] -> dead column group 0
+    wave_sync();
+    if (ph) {
+      const long long tk1 = clock64();
+      ph[2] += tk1 - tk0;
+      tk0 = tk1;
+    }
+    double acc1[BS][BS], acc2[BS][BS];
+    blk_zero<BS>(acc1);
+    blk_zero<BS>(acc2);
+    mm_acc<BS, false>(acc1, W, LDW, G1, LDW, s, lr, lc);                    // [m00 | m02] = A0c X[S,:]
+    mm_acc<BS, false>(acc2, W + s, LDW, G1 + s * LDW, LDW, l, lr, lc);      // [m20 | m22] = A2c X[L,:]
+    wave_sync();
+    if (ph) {
+      const long long tk1 = clock64();
+      ph[3] += tk1 - tk0;
+      tk0 = tk1;
+    }
+    blk_store_lds<BS>(acc1, W, LDW, lr, lc);
+    blk_store_lds<BS>(acc2, G1, LDW, lr, lc);
+    wave_sync();
+    double t0[BS][BS], t2[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int row = lr * BS + i, c = lc * BS + j;
+        const double d02 = (vL[j] >= 0) ? W[row * LDW + vL[j]] : 0.0;   // m02[:, posL(v)]
+        const double d20 = (vS[j] >= 0) ? G1[row * LDW + vS[j]] : 0.0;  // m20[:, posS(v)]
+        A1[i][j] -= d02;
+        A1[i][j] -= d20;
+        Ah[i][j] -= d20;
+        t0[i][j] = (c < s) ? acc1[i][j] : 0.0;
+        t2[i][j] = (c >= s && c < wr) ? acc2[i][j] : 0.0;
+        Rb[i][j] = -(t0[i][j] + t2[i][j]);
+      }
+    ++it;
+    const double nrm0 = blk_norm1<BS>(t0);
+    const double nrm2 = blk_norm1<BS>(t2);
+    if (ph) ph[4] += clock64() - tk0;
+    if (nrm0 < tol) {
+      if (nrm2 < tol || scan_mode) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
+        converged = true;
+        break;
+      }
+    } else if (nrm0 != nrm0) {
+      saw_nan = true;
+      break;
+    }
+    wave_sync();
+  }
+}
+
 template <int BS>
 __device__ __forceinline__ void cr_compact_body(const double* __restrict__ A, const double* __restrict__ B,
                                                 const double* __restrict__ C, int batch, int n, int max_iter,
@@ -127,87 +219,14 @@ __device__ __forceinline__ void cr_compact_body(const double* __restrict__ A, co
 #pragma unroll
       for (int j = 0; j < BS; ++j) Ah[i][j] = A1[i][j];
 
-    bool converged = false, saw_nan = false;
-    int it = 0;
+    bool converged, saw_nan;
+    int it;
     // debug stamps (draw 0): [0] GJ panels, [1] GJ trailing updates, [2] row gather + staging, [3] products,
     // [4] scatter/update/norms, [5] final solve, [6] total
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = dbg ? clock64() : 0;
-    for (; it < max_iter;) {
-      // W = [A1 | R] -> [. | A1^-1 R] (rows in pivot order)
-      blk_store_lds<BS>(A1, W, LDW, lr, lc);
-      if (scan_mode && lr == lc) {  // stabilize(A1): 1e-16 on the diagonal of the solve only (shared.py:6-9)
-#pragma unroll
-        for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
-      }
-      blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
-      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, dbg ? ph : nullptr);  // syncs on entry and exit
-      long long tk0 = dbg ? clock64() : 0;
-      // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
-      if (lane < NP) rsrc[lane] = (lane < wr) ? prow[cmap[lane]] : 0;
-      wave_sync();
-      {
-        double t[BS][BS];
-#pragma unroll
-        for (int i = 0; i < BS; ++i) {
-          const int src = rsrc[lr * BS + i];
-#pragma unroll
-          for (int j = 0; j < BS; ++j) t[i][j] = G1[src * LDW + lc * BS + j];
-        }
-        wave_sync();
-        blk_store_lds<BS>(t, G1, LDW, lr, lc);
-      }
-      blk_store_lds<BS>(Rb, W, LDW, lr, lc);  // left operands [A0c | A2c] -> dead column group 0
-      wave_sync();
-      if (dbg) {
-        const long long tk1 = clock64();
-        ph[2] += tk1 - tk0;
-        tk0 = tk1;
-      }
-      double acc1[BS][BS], acc2[BS][BS];
-      blk_zero<BS>(acc1);
-      blk_zero<BS>(acc2);
-      mm_acc<BS, false>(acc1, W, LDW, G1, LDW, s, lr, lc);                    // [m00 | m02] = A0c X[S,:]
-      mm_acc<BS, false>(acc2, W + s, LDW, G1 + s * LDW, LDW, l, lr, lc);      // [m20 | m22] = A2c X[L,:]
-      wave_sync();
-      if (dbg) {
-        const long long tk1 = clock64();
-        ph[3] += tk1 - tk0;
-        tk0 = tk1;
-      }
-      blk_store_lds<BS>(acc1, W, LDW, lr, lc);
-      blk_store_lds<BS>(acc2, G1, LDW, lr, lc);
-      wave_sync();
-      double t0[BS][BS], t2[BS][BS];
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) {
-          const int row = lr * BS + i, c = lc * BS + j;
-          const double d02 = (vL[j] >= 0) ? W[row * LDW + vL[j]] : 0.0;   // m02[:, posL(v)]
-          const double d20 = (vS[j] >= 0) ? G1[row * LDW + vS[j]] : 0.0;  // m20[:, posS(v)]
-          A1[i][j] -= d02;
-          A1[i][j] -= d20;
-          Ah[i][j] -= d20;
-          t0[i][j] = (c < s) ? acc1[i][j] : 0.0;
-          t2[i][j] = (c >= s && c < wr) ? acc2[i][j] : 0.0;
-          Rb[i][j] = -(t0[i][j] + t2[i][j]);
-        }
-      ++it;
-      const double nrm0 = blk_norm1<BS>(t0);
-      const double nrm2 = blk_norm1<BS>(t2);
-      if (dbg) ph[4] += clock64() - tk0;
-      if (nrm0 < tol) {
-        if (nrm2 < tol || scan_mode) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
-          converged = true;
-          break;
-        }
-      } else if (nrm0 != nrm0) {
-        saw_nan = true;
-        break;
-      }
-      wave_sync();
-    }
+    crc_iterate<BS>(A1, Ah, Rb, W, Lbuf, Ybuf, prow, cmap, rsrc, vS, vL, n, s, l, max_iter, tol, scan_mode, lane,
+                    dbg ? ph : nullptr, it, converged, saw_nan);
     const long long tk_fin = dbg ? clock64() : 0;
 
     double Tb[BS][BS];

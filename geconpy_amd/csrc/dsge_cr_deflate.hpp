@@ -68,6 +68,167 @@ __device__ __forceinline__ void crd_index_tables(unsigned long long smask, int n
   wave_sync();
 }
 
+// which variables are static: lane j looks down column j of A and C (all rows in flight); bit j of the result
+template <int NM>
+__device__ __forceinline__ unsigned long long crd_static_mask(const double* __restrict__ A, const double* __restrict__ C,
+                                                              size_t off, int n, int lane) {
+  int nz = 0;
+  {
+    // unconditional loads (clamped indices): conditional ones compile to one exec-masked block per load
+    const int cl = lane < n ? lane : n - 1;
+    const double* ap = A + off + cl;
+    const double* cp = C + off + cl;
+    double av[NM], cv[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int ri = i < n ? i : n - 1;
+      av[i] = ap[(size_t)ri * n];
+      cv[i] = cp[(size_t)ri * n];
+    }
+    // (without the barrier the scheduler, short of registers, pairs every load with its compare: 40 serial round
+    // trips to HBM, 54k cycles)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) nz |= ((av[i] != 0.0) | (cv[i] != 0.0)) ? 1 : 0;
+  }
+  const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+  return ~__ballot(nz != 0) & nmask;
+}
+
+// the first h set bits of a mask
+__device__ __forceinline__ unsigned long long crd_first_bits(unsigned long long mask, int h) {
+  unsigned long long keep = 0ull, rest = mask;
+  for (int c = 0; c < h; ++c) {
+    const unsigned long long low = rest & (~rest + 1ull);
+    keep |= low;
+    rest ^= low;
+  }
+  return keep;
+}
+
+// source of column cv of [B_st | B_dy | A_dy | C_dy | D] (h + 3 nd + k columns): pointer to its first row and row stride;
+// false for cv beyond the last column (the pointer then walks a valid column)
+__device__ __forceinline__ bool crd_col_source(int cv, const double* __restrict__ A, const double* __restrict__ B,
+                                               const double* __restrict__ C, const double* __restrict__ D, size_t off,
+                                               size_t offk, int n, int k, int h, const int* dyi, const int* sti,
+                                               const double*& src, int& ss) {
+  const int nd = n - h;
+  src = B + off;
+  ss = n;
+  if (cv >= h + 3 * nd + k) return false;
+  if (cv < h) {
+    src = B + off + sti[cv];
+    return true;
+  }
+  const int c = cv - h;
+  if (c >= 3 * nd) {
+    src = D + offk + (c - 3 * nd);
+    ss = k;
+    return true;
+  }
+  const int blk = (c >= nd) + (c >= 2 * nd);
+  src = (blk == 0 ? B : (blk == 1 ? A : C)) + off + dyi[c - blk * nd];
+  return true;
+}
+
+// Q' applied to the 128 columns c0 .. c0+127 of [B_st | B_dy | A_dy | C_dy | D]: two columns per lane, in registers, all
+// rows of a column loaded in flight.  The first h columns (lanes 0..h-1 of the first chunk) are B_st itself: lane j
+// publishes pivot column j to LDS (V), from where every lane (and a second chunk, for systems with more than 128 columns)
+// reads it as a broadcast; no wave reductions anywhere.  Rows 0..h-1 of Q'[...] go to `tp` (h x ncols, row-major); on
+// return colA / colB hold the rows of the REDUCED system (rows 0..nd-1, zeros below).
+template <int NM>
+__device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const double* __restrict__ B,
+                                             const double* __restrict__ C, const double* __restrict__ D, size_t off,
+                                             size_t offk, int n, int k, int h, int c0, const int* dyi, const int* sti,
+                                             double* V, double* __restrict__ tp, int lane, double (&colA)[NM],
+                                             double (&colB)[NM], bool& actA, bool& actB) {
+  const int ncols = h + 3 * (n - h) + k;
+  const double *srcA, *srcB;
+  int ssA, ssB;
+  const int cA = c0 + lane, cB = c0 + 64 + lane;
+  actA = crd_col_source(cA, A, B, C, D, off, offk, n, k, h, dyi, sti, srcA, ssA);
+  actB = crd_col_source(cB, A, B, C, D, off, offk, n, k, h, dyi, sti, srcB, ssB);
+#pragma unroll
+  for (int r = 0; r < NM; ++r) {  // unconditional loads (inactive lanes walk a valid column, rows are clamped)
+    const int rr = r < n ? r : n - 1;
+    colA[r] = srcA[(size_t)rr * ssA];
+    colB[r] = srcB[(size_t)rr * ssB];
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all 2 * NM loads in flight before the first select waits for one
+#pragma unroll
+  for (int r = 0; r < NM; ++r) {
+    colA[r] = (r < n && actA) ? colA[r] : 0.0;
+    colB[r] = (r < n && actB) ? colB[r] : 0.0;
+  }
+  // Row j is final once reflector j has been applied: it goes straight to the top block and the columns are shifted
+  // up by one row, so that the pivot is always register row 0 (no index-dependent selects, which cost a scalar lane
+  // mask each) and what is left after h reflectors is the reduced system, rows 0..nd-1.
+  // The reflector is never materialised: with u = column j below the pivot (published to LDS by lane j of the first
+  // chunk and read back as broadcasts -- 2 x NM v_readlane per sweep cost more than the whole arithmetic),
+  // v = [1; scal u], so v'x = x_0 + scal u'x and the raw dots u'x ride along with the norm sweep; the second sweep
+  // updates and shifts.  Registers: the two columns only.
+  for (int j = 0; j < h; ++j) {
+    double xn2 = 0.0, alpha;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (c0 == 0) {  // publish the pivot column (lane j of the first chunk)
+      if (lane == j) {
+        double2* vw = reinterpret_cast<double2*>(V + j * NM);
+#pragma unroll
+        for (int r2 = 0; r2 < NM / 2; ++r2) vw[r2] = make_double2(colA[2 * r2], colA[2 * r2 + 1]);
+      }
+      wave_sync();
+    }
+    const double2* vj2 = reinterpret_cast<const double2*>(V + j * NM);
+    {
+      const double2 t0 = vj2[0];
+      alpha = t0.x;
+      xn2 = t0.y * t0.y;
+      a0 = t0.y * colA[1];
+      b0 = t0.y * colB[1];
+#pragma unroll
+      for (int r2 = 1; r2 < NM / 2; ++r2) {
+        const double2 t = vj2[r2];
+        xn2 = fma(t.x, t.x, xn2);
+        a1 = fma(t.x, colA[2 * r2], a1);
+        b1 = fma(t.x, colB[2 * r2], b1);
+        xn2 = fma(t.y, t.y, xn2);
+        a0 = fma(t.y, colA[2 * r2 + 1], a0);
+        b0 = fma(t.y, colB[2 * r2 + 1], b0);
+      }
+    }
+    double beta = alpha, scal = 0.0, tj = 0.0;
+    if (xn2 != 0.0) {  // dlarfg
+      const double nrm = sqrt(fma(alpha, alpha, xn2));
+      beta = (alpha >= 0.0) ? -nrm : nrm;
+      tj = (beta - alpha) / beta;
+      scal = 1.0 / (alpha - beta);
+    }
+    // w = -tau v'x; the pivot column (beta e_0 exactly) and the columns left of it (all zeros by now) are set directly
+    const bool left = (c0 == 0) && (lane <= j);
+    const double wA = left ? 0.0 : -tj * fma(scal, a0 + a1, colA[0]);
+    const double wB = -tj * fma(scal, b0 + b1, colB[0]);
+    const double topA = left ? ((lane == j) ? beta : 0.0) : colA[0] + wA, topB = colB[0] + wB;
+    if (actA) tp[(size_t)j * ncols + cA] = topA;
+    if (actB) tp[(size_t)j * ncols + cB] = topB;
+    const double wsA = wA * scal, wsB = wB * scal;
+    {  // update and shift up by one row
+      const double2 t0 = vj2[0];
+      colA[0] = left ? 0.0 : fma(t0.y, wsA, colA[1]);
+      colB[0] = fma(t0.y, wsB, colB[1]);
+#pragma unroll
+      for (int r2 = 1; r2 < NM / 2; ++r2) {
+        const double2 t = vj2[r2];
+        colA[2 * r2 - 1] = left ? 0.0 : fma(t.x, wsA, colA[2 * r2]);
+        colB[2 * r2 - 1] = fma(t.x, wsB, colB[2 * r2]);
+        colA[2 * r2] = left ? 0.0 : fma(t.y, wsA, colA[2 * r2 + 1]);
+        colB[2 * r2] = fma(t.y, wsB, colB[2 * r2 + 1]);
+      }
+    }
+    colA[NM - 1] = 0.0;
+    colB[NM - 1] = 0.0;
+  }
+}
+
 template <int BS>
 __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                          const double* __restrict__ C, const double* __restrict__ D,
@@ -90,28 +251,7 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
     if (draw >= batch) return;
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
     const size_t offr = (size_t)draw * nd * nd, offrk = (size_t)draw * nd * k;
-    // ---- which variables are static: lane j looks down column j of A and C (all rows in flight)
-    int nz = 0;
-    {
-      // unconditional loads (clamped indices): conditional ones compile to one exec-masked block per load
-      const int cl = lane < n ? lane : n - 1;
-      const double* ap = A + off + cl;
-      const double* cp = C + off + cl;
-      double av[NM], cv[NM];
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const int ri = i < n ? i : n - 1;
-        av[i] = ap[(size_t)ri * n];
-        cv[i] = cp[(size_t)ri * n];
-      }
-      // (without the barrier the scheduler, short of registers, pairs every load with its compare: 40 serial round
-      // trips to HBM, 54k cycles)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) nz |= ((av[i] != 0.0) | (cv[i] != 0.0)) ? 1 : 0;
-    }
-    const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    unsigned long long smask = ~__ballot(nz != 0) & nmask;
+    unsigned long long smask = crd_static_mask<NM>(A, C, off, n, lane);
     if (__popcll(smask) < h) {
       // fewer static variables than assumed: hand the draw to the full-size kernels; the reduced system gets a harmless
       // stand-in (B = I, A = C = D = 0) so that the cycle-reduction launch has something finite to chew on
@@ -124,144 +264,40 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
       if (lane == 0) flag[draw] = 1;
       return;
     }
-    {  // keep the first h of them (the others stay in the dynamic block with their zero columns)
-      unsigned long long keep = 0ull, rest = smask;
-      for (int c = 0; c < h; ++c) {
-        const unsigned long long low = rest & (~rest + 1ull);
-        keep |= low;
-        rest ^= low;
-      }
-      smask = keep;
-    }
+    smask = crd_first_bits(smask, h);  // (the others stay in the dynamic block with their zero columns)
     crd_index_tables(smask, n, lane, dyi, sti);
     double* tp = top + (size_t)draw * top_stride;
-    // ---- Q' applied to [B_st | B_dy | A_dy | C_dy | D]: two columns per lane, in registers, all rows of a column loaded
-    // in flight.  The first h columns (lanes 0..h-1 of the first chunk) are B_st itself: lane j publishes pivot column j
-    // to LDS, from where every lane (and a second chunk, for systems with more than 128 columns, n > 45 or so) reads it
-    // as a broadcast; no wave reductions anywhere.
     const int ntotc = h + nv;
     const bool multi = ntotc > 128;
     for (int c0 = 0; c0 < ntotc; c0 += 128) {
-      const double *srcA, *srcB;
-      double *dstA, *dstB;
-      int ssA, ssB, dsA, dsB;
-      bool redA, redB;  // has rows in the reduced system (everything but B_st)
-      auto describe = [&](int cv, const double*& src, int& ss, double*& dst, int& ds, bool& red) -> bool {
-        src = B + off;
-        ss = n;
+      double colA[NM], colB[NM];
+      bool actA, actB;
+      crd_qr_chunk<NM>(A, B, C, D, off, offk, n, k, h, c0, dyi, sti, V, tp, lane, colA, colB, actA, actB);
+      if (multi) wave_sync();
+      // everything but B_st has rows in the reduced system
+      auto destination = [&](int cv, double*& dst, int& ds) -> bool {
         dst = Bred + offr;
         ds = nd;
-        red = false;
-        if (cv >= ntotc) return false;
-        if (cv < h) {
-          src = B + off + sti[cv];
-          return true;
-        }
-        red = true;
+        if (cv < h || cv >= ntotc) return false;
         const int c = cv - h;
         if (c >= 3 * nd) {
-          src = D + offk + (c - 3 * nd);
-          ss = k;
           dst = Dred + offrk + (c - 3 * nd);
           ds = k;
           return true;
         }
         const int blk = (c >= nd) + (c >= 2 * nd);
-        const int d = c - blk * nd;
-        const int j0 = dyi[d];
-        src = (blk == 0 ? B : (blk == 1 ? A : C)) + off + j0;
-        dst = (blk == 0 ? Bred : (blk == 1 ? Ared : Cred)) + offr + d;
+        dst = (blk == 0 ? Bred : (blk == 1 ? Ared : Cred)) + offr + (c - blk * nd);
         return true;
       };
-      const int cA = c0 + lane, cB = c0 + 64 + lane;
-      const bool actA = describe(cA, srcA, ssA, dstA, dsA, redA), actB = describe(cB, srcB, ssB, dstB, dsB, redB);
-      double colA[NM], colB[NM];
-#pragma unroll
-      for (int r = 0; r < NM; ++r) {  // unconditional loads (inactive lanes walk a valid column, rows are clamped)
-        const int rr = r < n ? r : n - 1;
-        colA[r] = srcA[(size_t)rr * ssA];
-        colB[r] = srcB[(size_t)rr * ssB];
-      }
-      __builtin_amdgcn_sched_barrier(0);  // all 2 * NM loads in flight before the first select waits for one
-#pragma unroll
-      for (int r = 0; r < NM; ++r) {
-        colA[r] = (r < n && actA) ? colA[r] : 0.0;
-        colB[r] = (r < n && actB) ? colB[r] : 0.0;
-      }
-      // Row j is final once reflector j has been applied: it goes straight to the top block and the columns are shifted
-      // up by one row, so that the pivot is always register row 0 (no index-dependent selects, which cost a scalar lane
-      // mask each) and what is left after h reflectors is the reduced system, rows 0..nd-1.
-      // The reflector is never materialised: with u = column j below the pivot (published to LDS by lane j of the first
-      // chunk and read back as broadcasts -- 2 x NM v_readlane per sweep cost more than the whole arithmetic),
-      // v = [1; scal u], so v'x = x_0 + scal u'x and the raw dots u'x ride along with the norm sweep; the second sweep
-      // updates and shifts.  Registers: the two columns only.
-      for (int j = 0; j < h; ++j) {
-        double xn2 = 0.0, alpha;
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        if (c0 == 0) {  // publish the pivot column (lane j of the first chunk)
-          if (lane == j) {
-            double2* vw = reinterpret_cast<double2*>(V + j * NM);
-#pragma unroll
-            for (int r2 = 0; r2 < NM / 2; ++r2) vw[r2] = make_double2(colA[2 * r2], colA[2 * r2 + 1]);
-          }
-          wave_sync();
-        }
-        const double2* vj2 = reinterpret_cast<const double2*>(V + j * NM);
-        {
-          const double2 t0 = vj2[0];
-          alpha = t0.x;
-          xn2 = t0.y * t0.y;
-          a0 = t0.y * colA[1];
-          b0 = t0.y * colB[1];
-#pragma unroll
-          for (int r2 = 1; r2 < NM / 2; ++r2) {
-            const double2 t = vj2[r2];
-            xn2 = fma(t.x, t.x, xn2);
-            a1 = fma(t.x, colA[2 * r2], a1);
-            b1 = fma(t.x, colB[2 * r2], b1);
-            xn2 = fma(t.y, t.y, xn2);
-            a0 = fma(t.y, colA[2 * r2 + 1], a0);
-            b0 = fma(t.y, colB[2 * r2 + 1], b0);
-          }
-        }
-        double beta = alpha, scal = 0.0, tj = 0.0;
-        if (xn2 != 0.0) {  // dlarfg
-          const double nrm = sqrt(fma(alpha, alpha, xn2));
-          beta = (alpha >= 0.0) ? -nrm : nrm;
-          tj = (beta - alpha) / beta;
-          scal = 1.0 / (alpha - beta);
-        }
-        // w = -tau v'x; the pivot column (beta e_0 exactly) and the columns left of it (all zeros by now) are set directly
-        const bool left = (c0 == 0) && (lane <= j);
-        const double wA = left ? 0.0 : -tj * fma(scal, a0 + a1, colA[0]);
-        const double wB = -tj * fma(scal, b0 + b1, colB[0]);
-        const double topA = left ? ((lane == j) ? beta : 0.0) : colA[0] + wA, topB = colB[0] + wB;
-        if (actA) tp[(size_t)j * ncols + cA] = topA;
-        if (actB) tp[(size_t)j * ncols + cB] = topB;
-        const double wsA = wA * scal, wsB = wB * scal;
-        {  // update and shift up by one row
-          const double2 t0 = vj2[0];
-          colA[0] = left ? 0.0 : fma(t0.y, wsA, colA[1]);
-          colB[0] = fma(t0.y, wsB, colB[1]);
-#pragma unroll
-          for (int r2 = 1; r2 < NM / 2; ++r2) {
-            const double2 t = vj2[r2];
-            colA[2 * r2 - 1] = left ? 0.0 : fma(t.x, wsA, colA[2 * r2]);
-            colB[2 * r2 - 1] = fma(t.x, wsB, colB[2 * r2]);
-            colA[2 * r2] = left ? 0.0 : fma(t.y, wsA, colA[2 * r2 + 1]);
-            colB[2 * r2] = fma(t.y, wsB, colB[2 * r2 + 1]);
-          }
-        }
-        colA[NM - 1] = 0.0;
-        colB[NM - 1] = 0.0;
-      }
-      if (multi) wave_sync();
-      if (actA && redA) {
+      double *dstA, *dstB;
+      int dsA, dsB;
+      const bool redA = destination(c0 + lane, dstA, dsA), redB = destination(c0 + 64 + lane, dstB, dsB);
+      if (redA) {
 #pragma unroll
         for (int r = 0; r < NM; ++r)
           if (r < nd) dstA[(size_t)r * dsA] = colA[r];
       }
-      if (actB && redB) {
+      if (redB) {
 #pragma unroll
         for (int r = 0; r < NM; ++r)
           if (r < nd) dstB[(size_t)r * dsB] = colB[r];
@@ -276,6 +312,139 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
   }
 }
 
+// ---- back-substitution of the static rows (the "inflation"), shared by cr_inflate_kernel and the fused kernel ------------
+// LDS arrays (zero padded): Ct (HM x NMD) = Ctop, G1s (HM x NMD) = Btop + Ctop T_dy, Rs (HM x HM) = R_st, rinv (HM) = 1 / diag.
+template <int NMD>
+struct CrdInflateLds {
+  static constexpr int HM = CRD_HMAX;
+  static constexpr size_t doubles = (size_t)(2 * HM * NMD + HM * HM + HM);
+  double *Ct, *G1s, *Rs, *rinv;
+  __device__ __forceinline__ explicit CrdInflateLds(double* base)
+      : Ct(base), G1s(base + HM * NMD), Rs(base + 2 * HM * NMD), rinv(base + 2 * HM * NMD + HM * HM) {}
+};
+
+// y = column `lane` of [T_dy | R_dy] as loaded (rows >= nd and inactive lanes, y_act = false, are cleared here, behind the
+// scheduling barrier, so that the caller's loads and the ones below are all in flight together).  Loads the top block,
+// builds the LDS arrays; false if R_st is numerically singular (the verdict is then left to the full-size kernels).
+template <int NMD>
+__device__ __forceinline__ bool crd_inflate_prepare(double (&y)[NMD], bool y_act, const double* __restrict__ tp, int n, int k,
+                                                    int h, int lane, const CrdInflateLds<NMD>& L) {
+  constexpr int HM = CRD_HMAX;
+  const int nd = n - h, ncols = h + 3 * nd + k;
+  double g[HM], ctv[HM], rsv[(HM * HM + 63) / 64];
+  const int ln = lane < nd ? lane : nd - 1;  // column of T_dy / Btop / Ctop this lane looks at (clamped)
+#pragma unroll
+  for (int i = 0; i < HM; ++i) {
+    const size_t row = (size_t)(i < h ? i : h - 1) * ncols;
+    g[i] = tp[row + h + ln];
+    ctv[i] = tp[row + h + 2 * nd + ln];
+  }
+#pragma unroll
+  for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
+    const int idx = u * 64 + lane, i = idx / HM, q = idx % HM;
+    rsv[u] = tp[(size_t)(i < h ? i : h - 1) * ncols + (q < h ? q : h - 1)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < NMD; ++q) y[q] = (q < nd && y_act) ? y[q] : 0.0;
+#pragma unroll
+  for (int i = 0; i < HM; ++i) {
+    g[i] = (i < h && lane < nd) ? g[i] : 0.0;
+    if (lane < NMD) L.Ct[i * NMD + lane] = (i < h && lane < nd) ? ctv[i] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
+    const int idx = u * 64 + lane, i = idx / HM, q = idx % HM;
+    if (idx < HM * HM) L.Rs[idx] = (i < h && q < h) ? rsv[u] : 0.0;
+  }
+  wave_sync();
+  bool bad = false;
+  if (lane < HM) {
+    const double dg = L.Rs[lane * HM + lane];
+    bad = (lane < h) && !(fabs(dg) > 1e-300);
+    L.rinv[lane] = (lane < h && !bad) ? 1.0 / dg : 0.0;
+  }
+  if (__ballot(bad) != 0ull) return false;
+  {  // G1 = Btop + Ctop T_dy, column `lane`
+#pragma unroll
+    for (int i = 0; i < HM; ++i) {
+      if (i < h) {
+        const double2* cr = reinterpret_cast<const double2*>(L.Ct + i * NMD);
+        double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < NMD / 2; ++q2) {
+          const double2 t = cr[q2];
+          e0 = fma(t.x, y[2 * q2], e0);
+          e1 = fma(t.y, y[2 * q2 + 1], e1);
+        }
+        g[i] += e0 + e1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HM; ++i)
+      if (lane < NMD) L.G1s[i * NMD + lane] = (lane < nd) ? g[i] : 0.0;
+  }
+  wave_sync();
+  return true;
+}
+
+// Column c = c0 + lane of [T_dy | R_dy] (y: its rows 0..nd-1) -> the static rows by back-substitution, and the whole column
+// scattered to the caller's variable order.
+template <int NMD>
+__device__ __forceinline__ void crd_inflate_chunk(int c0, const double (&y)[NMD], const double* __restrict__ tp, int n, int k,
+                                                  int h, int lane, const CrdInflateLds<NMD>& L, const int* dyi, const int* sti,
+                                                  double* __restrict__ Tg, double* __restrict__ Rg) {
+  constexpr int HM = CRD_HMAX;
+  const int nd = n - h, ncols = h + 3 * nd + k, ntot = nd + k;
+  const int c = c0 + lane;
+  const bool act = c < ntot;
+  double x[HM];
+  {  // right-hand sides [G1 T_dy + Atop | G1 R_dy + Dtop], column c
+    const int cc = act ? c : 0;
+    const int tc = h + nd + cc + ((cc >= nd) ? nd : 0);
+#pragma unroll
+    for (int i = 0; i < HM; ++i) x[i] = tp[(size_t)(i < h ? i : h - 1) * ncols + tc];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HM; ++i) x[i] = (i < h && act) ? x[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < HM; ++i) {
+      if (i < h) {
+        const double2* gr = reinterpret_cast<const double2*>(L.G1s + i * NMD);
+        double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < NMD / 2; ++q2) {
+          const double2 t = gr[q2];
+          e0 = fma(t.x, y[2 * q2], e0);
+          e1 = fma(t.y, y[2 * q2 + 1], e1);
+        }
+        x[i] += e0 + e1;
+      }
+    }
+  }
+  // back-substitution with R_st (zero padded: rows >= h come out as zeros)
+#pragma unroll
+  for (int i = HM - 1; i >= 0; --i) {
+    if (i < h) {
+      double acc = x[i];
+#pragma unroll
+      for (int q = i + 1; q < HM; ++q) acc = fma(-L.Rs[i * HM + q], x[q], acc);
+      x[i] = acc * L.rinv[i];
+    }
+  }
+  // scatter to the caller's variable order
+  double* dcol = (c < nd) ? (Tg + dyi[act && c < nd ? c : 0]) : (Rg + (c - nd));
+  const int ds = (c < nd) ? n : k;
+  if (act) {
+#pragma unroll
+    for (int s2 = 0; s2 < HM; ++s2)
+      if (s2 < h) dcol[(size_t)sti[s2] * ds] = -x[s2];
+#pragma unroll
+    for (int q = 0; q < NMD; ++q)
+      if (q < nd) dcol[(size_t)dyi[q] * ds] = y[q];
+  }
+}
+
 // BSD: tile of the REDUCED system (8 * BSD >= n - h)
 template <int BSD>
 __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict__ Tdy, const double* __restrict__ Rdy,
@@ -284,11 +453,8 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
                                                          double* __restrict__ T_out, double* __restrict__ R_out) {
   constexpr int NMD = 8 * BSD, HM = CRD_HMAX;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Ct = smem;             // HM x NMD: Ctop, zero padded
-  double* G1s = Ct + HM * NMD;   // HM x NMD: Btop + Ctop T_dy, zero padded
-  double* Rs = G1s + HM * NMD;   // HM x HM: R_st, zero padded
-  double* rinv = Rs + HM * HM;   // HM: 1 / diag(R_st), zero padded
-  int* dyi = (int*)(rinv + HM);
+  const CrdInflateLds<NMD> L(smem);
+  int* dyi = (int*)(smem + CrdInflateLds<NMD>::doubles);
   int* sti = dyi + 64;
   const int lane = threadIdx.x;
   const int nd = n - h, ncols = h + 3 * nd + k, ntot = nd + k;
@@ -315,79 +481,19 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
     // Every global load of the prologue is issued before the first one is waited for (unconditional loads from clamped
     // addresses, selects behind a scheduling barrier): the kernel is 1.7 k vector instructions per draw and spent 69 % of
     // its 63 k cycles waiting on one load at a time.
-    double y[NMD], g[HM], ctv[HM], rsv[(HM * HM + 63) / 64];
-    const int ln = lane < nd ? lane : nd - 1;  // column of T_dy / Btop / Ctop this lane looks at (clamped)
-    auto column_source = [&](int c, const double*& src, int& ss) -> bool {
+    double y[NMD];
+    auto load_column = [&](int c) {  // raw (unconditional loads from clamped addresses)
       const bool act = c < ntot;
-      src = (act && c >= nd) ? (Rdy + offrk + (c - nd)) : (Tdy + offr + (c < nd ? c : 0));
-      ss = (act && c >= nd) ? k : nd;
-      return act;
-    };
-    {
-      const double* src;
-      int ss;
-      column_source(lane, src, ss);
+      const double* src = (act && c >= nd) ? (Rdy + offrk + (c - nd)) : (Tdy + offr + (c < nd ? c : 0));
+      const int ss = (act && c >= nd) ? k : nd;
 #pragma unroll
       for (int q = 0; q < NMD; ++q) y[q] = src[(size_t)(q < nd ? q : nd - 1) * ss];
-#pragma unroll
-      for (int i = 0; i < HM; ++i) {
-        const size_t row = (size_t)(i < h ? i : h - 1) * ncols;
-        g[i] = tp[row + h + ln];
-        ctv[i] = tp[row + h + 2 * nd + ln];
-      }
-#pragma unroll
-      for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
-        const int idx = u * 64 + lane, i = idx / HM, q = idx % HM;
-        rsv[u] = tp[(size_t)(i < h ? i : h - 1) * ncols + (q < h ? q : h - 1)];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const bool act = lane < ntot;
-#pragma unroll
-      for (int q = 0; q < NMD; ++q) y[q] = (q < nd && act) ? y[q] : 0.0;
-#pragma unroll
-      for (int i = 0; i < HM; ++i) {
-        g[i] = (i < h && lane < nd) ? g[i] : 0.0;
-        if (lane < NMD) Ct[i * NMD + lane] = (i < h && lane < nd) ? ctv[i] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
-        const int idx = u * 64 + lane, i = idx / HM, q = idx % HM;
-        if (idx < HM * HM) Rs[idx] = (i < h && q < h) ? rsv[u] : 0.0;
-      }
-    }
-    wave_sync();
-    bool bad = false;
-    if (lane < HM) {
-      const double dg = Rs[lane * HM + lane];
-      bad = (lane < h) && !(fabs(dg) > 1e-300);
-      rinv[lane] = (lane < h && !bad) ? 1.0 / dg : 0.0;
-    }
-    if (__ballot(bad) != 0ull) {  // a (numerically) singular R_st: leave the verdict to the full-size kernels
+    };
+    load_column(lane);
+    if (!crd_inflate_prepare<NMD>(y, lane < ntot, tp, n, k, h, lane, L)) {
       if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
       return;
     }
-    {  // G1 = Btop + Ctop T_dy, column `lane`
-#pragma unroll
-      for (int i = 0; i < HM; ++i) {
-        if (i < h) {
-          const double2* cr = reinterpret_cast<const double2*>(Ct + i * NMD);
-          double e0 = 0.0, e1 = 0.0;
-#pragma unroll
-          for (int q2 = 0; q2 < NMD / 2; ++q2) {
-            const double2 t = cr[q2];
-            e0 = fma(t.x, y[2 * q2], e0);
-            e1 = fma(t.y, y[2 * q2 + 1], e1);
-          }
-          g[i] += e0 + e1;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < HM; ++i)
-        if (lane < NMD) G1s[i * NMD + lane] = (lane < nd) ? g[i] : 0.0;
-    }
-    wave_sync();
     // static columns of T are exact zeros
     if (lane < n) {
 #pragma unroll
@@ -395,64 +501,13 @@ __global__ __launch_bounds__(64) void cr_inflate_kernel(const double* __restrict
         if (s2 < h) T_out[off + (size_t)lane * n + sti[s2]] = 0.0;
     }
     for (int c0 = 0; c0 < ntot; c0 += 64) {
-      const int c = c0 + lane;
-      const bool act = c < ntot;
-      double x[HM];
-      {  // right-hand sides [G1 T_dy + Atop | G1 R_dy + Dtop], column c
-        const int cc = act ? c : 0;
-        const int tc = h + nd + cc + ((cc >= nd) ? nd : 0);
-        if (c0 > 0) {
-          const double* src;
-          int ss;
-          column_source(c, src, ss);
-#pragma unroll
-          for (int q = 0; q < NMD; ++q) y[q] = src[(size_t)(q < nd ? q : nd - 1) * ss];
-        }
-#pragma unroll
-        for (int i = 0; i < HM; ++i) x[i] = tp[(size_t)(i < h ? i : h - 1) * ncols + tc];
+      if (c0 > 0) {
+        load_column(c0 + lane);
         __builtin_amdgcn_sched_barrier(0);
-        if (c0 > 0) {
 #pragma unroll
-          for (int q = 0; q < NMD; ++q) y[q] = (q < nd && act) ? y[q] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < HM; ++i) x[i] = (i < h && act) ? x[i] : 0.0;
-#pragma unroll
-        for (int i = 0; i < HM; ++i) {
-          if (i < h) {
-            const double2* gr = reinterpret_cast<const double2*>(G1s + i * NMD);
-            double e0 = 0.0, e1 = 0.0;
-#pragma unroll
-            for (int q2 = 0; q2 < NMD / 2; ++q2) {
-              const double2 t = gr[q2];
-              e0 = fma(t.x, y[2 * q2], e0);
-              e1 = fma(t.y, y[2 * q2 + 1], e1);
-            }
-            x[i] += e0 + e1;
-          }
-        }
+        for (int q = 0; q < NMD; ++q) y[q] = (q < nd && c0 + lane < ntot) ? y[q] : 0.0;
       }
-      // back-substitution with R_st (zero padded: rows >= h come out as zeros)
-#pragma unroll
-      for (int i = HM - 1; i >= 0; --i) {
-        if (i < h) {
-          double acc = x[i];
-#pragma unroll
-          for (int q = i + 1; q < HM; ++q) acc = fma(-Rs[i * HM + q], x[q], acc);
-          x[i] = acc * rinv[i];
-        }
-      }
-      // scatter to the caller's variable order
-      double* dcol = (c < nd) ? (T_out + off + dyi[act && c < nd ? c : 0]) : (R_out + offk + (c - nd));
-      const int ds = (c < nd) ? n : k;
-      if (act) {
-#pragma unroll
-        for (int s2 = 0; s2 < HM; ++s2)
-          if (s2 < h) dcol[(size_t)sti[s2] * ds] = -x[s2];
-#pragma unroll
-        for (int q = 0; q < NMD; ++q)
-          if (q < nd) dcol[(size_t)dyi[q] * ds] = y[q];
-      }
+      crd_inflate_chunk<NMD>(c0, y, tp, n, k, h, lane, L, dyi, sti, T_out + off, R_out + offk);
     }
     wave_sync();  // the LDS tables are rewritten by the next draw
   }

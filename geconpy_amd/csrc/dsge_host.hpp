@@ -124,6 +124,7 @@ struct Options {
   int kalman_tiny = 1;         // thread-per-draw kernel for small models
   int kalman_block = 0;        // steady tail handed to kalman_tail_kernel
   int kalman_mfma = 0;         // prediction products on the FP64 matrix core
+  int cr_fused_deflation = 1;  // deflation + cycle reduction + inflation in one launch (dsge_cr_fused.hpp)
   int kalman_nt_products = 1;  // selector fast path: kalman_nt_kernel (NT prediction products, 16-byte LDS loads); 0 = kalman_sel_kernel
   int pipeline_chunks = 0;     // fused device call in chunks over library-owned streams
   int gensys_split = 1;        // 0 = single-launch gensys kernel, 1 = window path unless small, 2 = always

@@ -3,6 +3,7 @@
 #include "dsge_kernels.hpp"
 #include "dsge_cr_compact.hpp"
 #include "dsge_cr_deflate.hpp"
+#include "dsge_cr_fused.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -109,6 +110,70 @@ void cr_deflation_reset() {
   g_static_hint_init = false;
 }
 
+// deflation + cycle reduction + inflation in one launch; *done = 0 if no kernel instance covers (n, n - h)
+namespace {
+template <int BSF, int BSD>
+int launch_cr_fused_inst(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, int h,
+                         int max_iter, double tol, double* top, double* rhs, double* T_out, double* R_out, int32_t* status,
+                         int32_t* n_iter, hipStream_t st) {
+  using SM = dsge::CrfSmem<BSF, BSD>;
+  int rc;
+  if (BSD == 4 && opt().cr_two_waves) {
+    if ((rc = set_lds(dsge::cr_fused_kernel_occ2<BSF, BSD>, SM::bytes))) return rc;
+    hipLaunchKernelGGL((dsge::cr_fused_kernel_occ2<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
+                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter);
+  } else {
+    if ((rc = set_lds(dsge::cr_fused_kernel<BSF, BSD>, SM::bytes))) return rc;
+    hipLaunchKernelGGL((dsge::cr_fused_kernel<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
+                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter);
+  }
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+}  // namespace
+
+int launch_cr_fused(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, int h,
+                    int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter, hipStream_t st,
+                    int* done) {
+  *done = 0;
+  const int nd = n - h, bsf = tile_bs(n), bsd = tile_bs(nd);
+  const bool have = (bsf == 3 && (bsd == 2 || bsd == 3)) || (bsf == 4 && (bsd == 3 || bsd == 4)) ||
+                    (bsf == 5 && bsd == 4) || (bsf == 6 && (bsd == 4 || bsd == 5));
+  if (!have) return DSGE_SUCCESS;
+  int rc;
+  void* base = nullptr;
+  const size_t tops = (size_t)batch * dsge::crd_top_doubles(n, k, h), rhss = (size_t)batch * dsge::crf_rhs_doubles(nd, 8 * bsd);
+  if ((rc = defl_reserve(al256(tops * 8) + al256(rhss * 8) + 4096, st, &base))) return rc;
+  double* top = (double*)base;
+  double* rhs = (double*)((char*)base + al256(tops * 8));
+#define FUSED_CASE(F, D_)                                                                                              \
+  if (bsf == F && bsd == D_)                                                                                           \
+    rc = launch_cr_fused_inst<F, D_>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter, st)
+  rc = DSGE_ERR_INVALID;
+  FUSED_CASE(3, 2);
+  FUSED_CASE(3, 3);
+  FUSED_CASE(4, 3);
+  FUSED_CASE(4, 4);
+  FUSED_CASE(5, 4);
+  FUSED_CASE(6, 4);
+  FUSED_CASE(6, 5);
+#undef FUSED_CASE
+  if (rc) return rc;
+  // draws the fused kernel could not take (status == DSGE_ST_INTERNAL_RERUN): full-size dense kernel on exactly those
+  rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bsf, 8, {
+    rc = set_lds(dsge::cr_kernel<BS>, dsge::CrSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      hipLaunchKernelGGL(dsge::cr_kernel<BS>, dim3(rerun_grid(batch)), dim3(64), dsge::CrSmem<BS>::bytes, st, A, B, C, batch, n,
+                         max_iter, tol, T_out, status, n_iter, 1, 0, D, k, R_out);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  if (rc) return rc;
+  *done = 1;
+  return DSGE_SUCCESS;
+}
+
 // *used = 0: nothing done (deflation off, too few static variables, ...): the caller runs launch_cr on the full system.
 int launch_cr_deflated(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
                        int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
@@ -149,6 +214,16 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
   const int nd = n - h;
   // worth it only when the reduced system drops to a smaller register-block tile or loses a fifth of its variables
   if (h < 1 || nd < 4 || (tile_bs(nd) == tile_bs(n) && 5 * h < n)) return DSGE_SUCCESS;
+  if (opt().cr_fused_deflation && h + 3 * nd + k <= 128 && nd + k <= 64) {
+    // one launch (dsge_cr_fused.hpp); the (full tile, reduced tile) pairs built are the ones the deflation test above lets
+    // through for n <= 48
+    int done = 0;
+    if ((rc = launch_cr_fused(A, B, C, D, batch, n, k, h, max_iter, tol, T_out, R_out, status, n_iter, st, &done))) return rc;
+    if (done) {
+      *used = 1;
+      return DSGE_SUCCESS;
+    }
+  }
   const size_t lds1 = dsge::crd_deflate_smem(8 * tile_bs(n)), lds2 = dsge::crd_inflate_smem(8 * tile_bs(nd));
   const size_t ndd = (size_t)batch * nd * nd, ndk = (size_t)batch * nd * k, tops = (size_t)batch * dsge::crd_top_doubles(n, k, h);
   if ((rc = defl_reserve(4 * al256(ndd * 8) + 2 * al256(ndk * 8) + al256(tops * 8) + al256((size_t)batch * 4) + 4096, st,

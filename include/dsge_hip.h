@@ -119,7 +119,7 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
  *                        the model like n_state_hint, verified per draw on the device; with a value >= 0 the fused call
  *                        is a pure enqueue (stream-capturable); -1 (default) measures it on the device on the first
  *                        call of a model size: one small launch, a 4-byte read-back and a stream synchronisation
- *   kalman_nt_products  : see dsge_set_kalman_nt_products
+ *   kalman_nt_products  : see dsge_set_kalman_nt_products       cr_fused_deflation : see dsge_set_cr_fused_deflation
  *   kalman_order, kalman_tiny, kalman_block, kalman_mfma, pipeline_chunks, gensys_split, kalman_steady_tol :
  *                        see the dsge_set_* function of the same name
  */
@@ -138,7 +138,7 @@ typedef struct dsge_options {
   int32_t gensys_split;
   double kalman_steady_tol;
   int32_t kalman_nt_products;
-  int32_t reserved_;
+  int32_t cr_fused_deflation;
 } dsge_options;
 /* fills *opt with the current process-wide defaults */
 int dsge_options_init(dsge_options* opt);
@@ -246,6 +246,12 @@ int dsge_set_kalman_tiny(int enable);
  * the round-1 kernel (kalman_sel_kernel); same arithmetic up to the summation order of the products (tests compare them).
  * Process-wide DEFAULT (per call: dsge_options); default 1. */
 int dsge_set_kalman_nt_products(int enable);
+/* Static-variable deflation (dsge_set_cr_deflation) as ONE launch: QR of the static columns, cycle reduction on the reduced
+ * system and the back-substitution of the static rows in a single kernel, the reduced system handed over through LDS
+ * (dsge_cr_fused.hpp) instead of three launches with the reduced A, B, C, D, T, R in global memory.  Taken when
+ * h + 3 (n - h) + k <= 128 and (n - h) + k <= 64; otherwise, and with enable = 0, the three launches run.  Same results
+ * (the arithmetic is the same code).  Process-wide DEFAULT (per call: dsge_options); default 1. */
+int dsge_set_cr_fused_deflation(int enable);
 /* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
  * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
  * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by

@@ -1526,6 +1526,49 @@ def test_cr_static_deflation_matches_full_system():
         assert_allclose(T1[i], r["T"], atol=1e-9)
 
 
+@pytest.mark.parametrize("n,ns,nl", [(40, 18, 12), (24, 10, 7), (32, 14, 10), (44, 20, 13)])
+def test_cr_fused_deflation_equals_three_launches(n, ns, nl):
+    """The one-launch form of the deflated cycle reduction (default; dsge_cr_fused.hpp: the reduced system goes from the QR
+    to the iteration to the back-substitution through LDS) runs the arithmetic of the three launches: T, R, logp, status
+    bit for bit -- SW-shaped systems of 40 -> 30 variables (tiles 5 / 4), 24 -> 17 (3 / 3), 32 -> 24 (4 / 3) and 44 -> 33
+    (6 / 5), each batch with a NaN draw and a draw with fewer static variables than the bound."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    k = p = 7
+    nb = 200
+    sysm = [wl.sw_shaped_system(8800 + 11 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    static = np.where(~(A[0] != 0).any(0) & ~(C[0] != 0).any(0))[0]
+    assert len(static) == n - ns - nl
+    A[7, 0, 0] = np.nan
+    A[21, 2, static[1]] = 1e-3  # one static variable less than the bound: handed to the full-size kernel
+    q = np.full((nb, k), 1e-4)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(n).normal(0, 0.02, (30, p))
+    H = np.full(p, 1e-4)
+    eng = LogpEngine(torch.device("cuda", 0))
+    dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
+    dq, dZ, dy, dH = eng.to_device(q), eng.to_device(Z), eng.to_device(y), eng.to_device(H)
+    hints = eng.structure_hints(dev["A"], dZ)
+    res = {}
+    for fused in (0, 1):
+        with _lib.options_scope({"cr_fused_deflation": fused, "n_static_hint": len(static)}):
+            res[fused] = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+    for a, c in zip(res[0], res[1]):
+        assert np.array_equal(a, c, equal_nan=True)
+    lp, st, T, R = res[1]
+    assert st[7] != 0 and np.count_nonzero(st) == 1
+    ok = st == 0
+    ok[21] = False  # (its A was changed: the generator's T is no longer the solution)
+    assert_allclose(T[ok], Tst[ok], atol=1e-8)
+    r = oracle.solve_kalman_logp(A[3], B[3], C[3], D[3], np.diag(q[3]), Z, y, H=np.diag(H), tol=1e-9, max_iter=1000)
+    assert_allclose(lp[3], r["logp"], rtol=LOGP_RTOL)
+    assert_allclose(T[3], r["T"], atol=1e-9)
+
+
 @pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
 def test_cr_static_deflation_on_reference_goldens(ref_goldens, key):
     """The reference's own models (3 of 9, 6 of 12, 4 of 24 static variables): fused call with the deflation against the
