@@ -103,7 +103,7 @@ def cpu_baseline(batch, om, n_sample, cores):
     return np.array(logp), n_sample / dt, dt
 
 PMC_LEGS = {  # kernels of one fused step, by leg (substring of the rocprofv3 kernel name)
-    "solver": ("cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel", "cr_solve_kernel"),
+    "solver": ("cr_fused_kernel", "cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel", "cr_solve_kernel"),
     "assemble": ("rqr_kernel",),
     "kalman": ("kalman_sel_kernel", "kalman_nt_kernel"),
 }
@@ -458,8 +458,13 @@ def main():
         ex = executed_flops(n, k, p, T_len, s_cols, stats.get("lead_columns", n), u_dim, cr_it,
                             stats.get("full_steps_mean", T_len), 8, selector=bool(hints[1]), h=h_defl)
         bs_n, bs_d = (n + 7) // 8, (n - h_defl + 7) // 8
-        names = {"solver": (f"dsge::cr_deflate_kernel<{bs_n}> + cr_compact_kernel<{bs_d}> + cr_inflate_kernel<{bs_d}> (static-variable "
-                            f"deflation {n} -> {n - h_defl}, three launches)" if h_defl else f"dsge::cr_compact_kernel<{bs_n}>")
+        nd_ = n - h_defl
+        one_launch = (h_defl and h_defl + 3 * nd_ + k <= 128 and nd_ + k <= 64
+                      and (bs_n, bs_d) in {(3, 2), (3, 3), (4, 3), (4, 4), (5, 4), (6, 4), (6, 5)})  # launch_cr_fused
+        names = {"solver": ((f"dsge::cr_fused_kernel{'_occ2' if bs_d == 4 else ''}<{bs_n},{bs_d}> (static-variable deflation {n} -> {nd_}: "
+                             "QR of the static columns + cycle reduction + back-substitution, one launch)") if one_launch else
+                            (f"dsge::cr_deflate_kernel<{bs_n}> + cr_compact_kernel<{bs_d}> + cr_inflate_kernel<{bs_d}> (static-variable "
+                             f"deflation {n} -> {nd_}, three launches)") if h_defl else f"dsge::cr_compact_kernel<{bs_n}>")
                  if args.solver == "cycle_reduction" else ("dsge::gensys_reduce_kernel + gensys_qzwin_kernel + gensys_post_kernel (window path, three launches)"
                                 if n > 16 else "dsge::gensys_kernel"),
                  "assemble": ("dsge::rqr_kernel<16>" if (args.solver == "cycle_reduction" and k <= 16)

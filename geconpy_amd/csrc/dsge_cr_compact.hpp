@@ -21,6 +21,15 @@
 
 namespace dsge {
 
+// Bank conflicts of the even (BS = 4) tile, measured 39 % of its LDS cycles.  ds_read_b128 is served in four groups of 16
+// lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- i.e., in the 8 x 8 lane grid, block rows 0..3 with
+// the column halves (low, high, high, low).  In 16-byte slots a block row's access is a run of four same-parity slots:
+// slot = lr (4 sigma + kappa) + i sigma + 2 lc (mod 16), sigma = LDW / 2, kappa = a skew per block row.  Four runs need the
+// 16 slots exactly; with delta = 4 sigma + kappa odd the runs of block rows 0 and 2 are both even and would have to be
+// complementary (2 delta + 8 = 8 mod 16, i.e. delta = 0 or 8: a contradiction), with delta even all four are even: a
+// linear skew is 2-way at best (LDW = 66: 4-way on two slots).  The XOR swizzle chunk ^= [0, 1, 8, 9][lr & 3] is conflict-free
+// for block accesses but costs an XOR per k-step in mm_acc (operand columns at arbitrary offsets) and in the row-per-lane
+// panel reads; LDS is active 10 % of the kernel's cycles, so it was not built.
 template <int BS>
 struct CrcSmem {
   static constexpr int NP = Tile<BS>::NP, LDW = 2 * NP + (BS % 2 == 0 ? 2 : 1);  // even tiles: rows of a register block are 16-byte aligned (b128 LDS accesses; half the conflict cycles of the odd stride on the 4 x 4 tile: 0.90 -> 0.84 ms)

@@ -437,6 +437,7 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
       id[c] = 0.0;
     }
     int rsel[BS];
+    double inv_own = 1.0;  // pivot lanes: 1 / pivot of their row (the row is scaled once, after the panel)
 #pragma unroll
     for (int c = 0; c < BS; ++c) {
       rsel[c] = 0;
@@ -451,33 +452,23 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
         const int r = 63 - (int)(key & 63u);
         rsel[c] = r;
         used |= 1ull << r;
-        if (lane == r) id[c] = 1.0;
-        // broadcast the pivot lane's row, scale it, eliminate everywhere else
+        const bool is_r = (lane == r);
+        if (is_r) id[c] = 1.0;
+        // broadcast the pivot lane's row scaled by 1 / pivot and eliminate everywhere else.  The pivot lane itself is
+        // left alone (multiplier 0: no divergent branch) and scaled after the panel -- later columns only ever read
+        // a row through its own elimination multiplier, which is consistent with the unscaled row.
         const double inv = fast_rcp(readlane_dyn_f64(pw[c], r));
-        double prw[BS], pri[BS];
+        const double f = is_r ? 0.0 : pw[c];
+        inv_own = is_r ? inv : inv_own;
 #pragma unroll
         for (int c2 = 0; c2 < BS; ++c2) {
-          prw[c2] = (c2 > c) ? readlane_dyn_f64(pw[c2], r) * inv : 0.0;
-          pri[c2] = (c2 <= c) ? readlane_dyn_f64(id[c2], r) * inv : 0.0;
-        }
-        const double f = pw[c];
-        if (lane == r) {
-#pragma unroll
-          for (int c2 = 0; c2 < BS; ++c2) {
-            if (c2 > c) pw[c2] = prw[c2];
-            if (c2 <= c) id[c2] = pri[c2];
-          }
-          pw[c] = 1.0;
-        } else {
-#pragma unroll
-          for (int c2 = 0; c2 < BS; ++c2) {
-            if (c2 > c) pw[c2] = fma(-f, prw[c2], pw[c2]);
-            if (c2 <= c) id[c2] = fma(-f, pri[c2], id[c2]);
-          }
-          pw[c] = 0.0;
+          if (c2 > c) pw[c2] = fma(-f, readlane_dyn_f64(pw[c2], r) * inv, pw[c2]);
+          if (c2 <= c) id[c2] = fma(-f, readlane_dyn_f64(id[c2], r) * inv, id[c2]);
         }
       }
     }
+#pragma unroll
+    for (int c = 0; c < BS; ++c) id[c] *= inv_own;  // (pw is dead from here on)
     // Lhat row of this lane: -id for ordinary rows; pivot lane r_a holds id = Minv[a,:] and
     // needs e_a - Minv[a,:]
     if (lane < NP) {

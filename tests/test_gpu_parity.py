@@ -113,7 +113,10 @@ def test_sizes_cr_selection_lyapunov(n, k):
         assert_allclose(T[i], Tc, atol=T_ATOL)
         Rc = oracle.compute_selection_matrix(B[i], C[i], D[i], Tc)
         assert_allclose(R[i], Rc, atol=1e-9, rtol=1e-9)
-        assert_allclose(resid[i], oracle.policy_residual(A[i], B[i], C[i], Tc), atol=1e-18)
+        # the residual arithmetic itself, from the device's own T (a sum of squares of cancelled terms: 1e-5 relative);
+        # its size depends on how ill-conditioned the intermediate A1 of the draw are (1e-27 .. 1e-18 here)
+        assert_allclose(resid[i], oracle.policy_residual(A[i], B[i], C[i], T[i]), rtol=1e-5, atol=1e-26)
+        assert resid[i] < 1e-16
         RQRo = R[i] @ np.diag(q[i]) @ R[i].T  # the assembly arithmetic itself, from the device's own R and T
         assert_allclose(RQR[i], RQRo, atol=1e-12 * np.abs(RQRo).max())
         P0o = oracle.solve_discrete_lyapunov(T[i], RQRo)
