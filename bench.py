@@ -458,6 +458,10 @@ def main():
         ex = executed_flops(n, k, p, T_len, s_cols, stats.get("lead_columns", n), u_dim, cr_it,
                             stats.get("full_steps_mean", T_len), 8, selector=bool(hints[1]), h=h_defl)
         bs_n, bs_d = (n + 7) // 8, (n - h_defl + 7) // 8
+        np_lo = 8 * (((hints[0] if 0 < (hints[0] or 0) < n else n) + 7) // 8)  # launch_kalman.hip::kalman_folds_rqr
+        folds_rqr = bool(args.solver == "cycle_reduction" and hints[1] and p <= 8 and 1 <= k <= 16
+                         and not (p <= 3 and 0 < (hints[0] or 0) and (hints[0] or 0) + p <= 6)
+                         and n * ((k + 1) & ~1) <= np_lo * (np_lo + 2))
         nd_ = n - h_defl
         one_launch = (h_defl and h_defl + 3 * nd_ + k <= 128 and nd_ + k <= 64
                       and (bs_n, bs_d) in {(3, 2), (3, 3), (4, 3), (4, 4), (5, 4), (6, 4), (6, 5)})  # launch_cr_fused
@@ -467,7 +471,9 @@ def main():
                              f"deflation {n} -> {nd_}, three launches)") if h_defl else f"dsge::cr_compact_kernel<{bs_n}>")
                  if args.solver == "cycle_reduction" else ("dsge::gensys_reduce_kernel + gensys_qzwin_kernel + gensys_post_kernel (window path, three launches)"
                                 if n > 16 else "dsge::gensys_kernel"),
-                 "assemble": ("dsge::rqr_kernel<16>" if (args.solver == "cycle_reduction" and k <= 16)
+                 "assemble": (("none: sym(R Q R')[U,U] is formed in the prologue of the Kalman kernel (rqr_kernel<16> only for "
+                               "draws handed on to the general filter)") if folds_rqr else
+                              "dsge::rqr_kernel<16>" if (args.solver == "cycle_reduction" and k <= 16)
                               else f"dsge::assemble_kernel<{(n + 7) // 8}>"),
                  "kalman": (f"dsge::kalman_nt_kernel<{(u_dim + 7) // 8}>" if hints[1] and p <= 8
                             else f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>")}

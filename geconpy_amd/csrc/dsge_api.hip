@@ -608,7 +608,12 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
     // backward_direct already produced R; the assemble kernel recomputes it from the same
     // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
-    if (fuse_R && (q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED) && k <= 16 && n <= 64)
+    const bool q_diag = q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED;
+    // sym(R Q R') inside the filter kernel (its retained block only) when the fast selector kernel takes the draws
+    const bool fold_rqr = fuse_R && q_diag && n <= 64 && kalman_folds_rqr(n, p, k, n_state_hint, z_selector_hint);
+    if (fold_rqr)
+      rc = DSGE_SUCCESS;
+    else if (fuse_R && q_diag && k <= 16 && n <= 64)
       rc = launch_rqr(Rw, Q, q_mode == DSGE_Q_DIAG_BATCHED, batch, n, k, status_out, RQR, st);  // (RQR_KMAX = 16)
     else if (fuse_R)
       rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, Tw, Rw, Q, q_mode, batch, n, k, nullptr, nullptr, RQR, P0,
@@ -627,7 +632,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
       okey = key_w;
     }
     if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
-                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st, okey)))
+                            missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st, okey,
+                            fold_rqr ? Rw : nullptr, fold_rqr ? Q : nullptr, q_mode == DSGE_Q_DIAG_BATCHED, k)))
       return rc;
     if (ms_out) {
       HIP_TRY(hipEventRecord(ev[3], st));

@@ -5,7 +5,7 @@
 //   phase 1  Householder QR of the static columns of B applied to [B_st | B_dy | A_dy | C_dy | D], one column per lane in
 //            registers (crd_qr_chunk).  The h top rows go to a per-draw scratch record in global memory (8.5 KB at
 //            n = 40, h = 10; read back in phase 3 by the same workgroup, i.e. from L2); the columns of the REDUCED system are
-//            written straight into the compact kernel's LDS layout W = [B_dy | A_dy[:,S] A... C_dy[:,L]] -- the zero columns
+//            written straight into the compact kernel's LDS layout W = [B_dy | A_dy[:,S] C_dy[:,L]] -- the zero columns
 //            of A_dy and C_dy are found by a ballot over the column registers, not by a pass over global memory.
 //   phase 2  crc_iterate (the loop of cr_compact_kernel, unchanged) and the final solve  [T_dy[:,S] | R_dy] =
 //            -A1_hat^-1 [A_dy[:,S] | D_red]; the right-hand side of that solve is the one thing that has to survive the

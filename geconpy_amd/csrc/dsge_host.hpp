@@ -63,7 +63,8 @@ void cr_deflation_reset();
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
                    double* R_out, hipStream_t st);
 int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n, int k, const int32_t* status,
-               double* RQR_out, hipStream_t st);  // sym(R diag(q) R') alone, k <= RQR_KMAX (dsge_kernels.hpp)
+               double* RQR_out, hipStream_t st, int rerun_only = 0);  // sym(R diag(q) R') alone, k <= RQR_KMAX (dsge_kernels.hpp);
+                                                                      // rerun_only: draws flagged DSGE_ST_INTERNAL_RERUN
 int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
                     const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
@@ -80,7 +81,11 @@ int launch_acf(const double* T, const double* Sigma, const double* Z, const doub
 int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                  double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr);
+                  double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr,
+                  const double* Rsel = nullptr, const double* qdiag = nullptr, int q_batched = 0, int k_shocks = 0);
+// true if launch_kalman, given the selection matrix R and a diagonal Q (Rsel, qdiag), forms sym(R Q R')[U,U] inside the
+// fast filter kernel: the caller then skips the full-size product (RQR is filled for handed-on draws only)
+bool kalman_folds_rqr(int m, int p, int k, int n_state_hint, int z_selector_hint);
 // launch_grad.hip: reverse sweep of the Kalman filter + reverse of the assembly (dsge_kalman_grad.hpp)
 int launch_persistence_key(const double* T, const int32_t* status, int batch, int n, int32_t* key, hipStream_t st);
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
     int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
-    const int32_t* __restrict__ order) {
+    const int32_t* __restrict__ order, const double* __restrict__ Rsel, const double* __restrict__ qdiag, int q_batched,
+    int k_shocks) {
   constexpr int NP = KntSmem<BS>::NP, LDK = KntSmem<BS>::LDK, PS = KntSmem<BS>::PS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;                 // NP x LDK    transition, states-first ordering (columns >= s exactly zero)
@@ -260,6 +261,36 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         }
     }
     double Qb[BS][BS], Pb[BS][BS], Tb0[BS][BS];
+    if (Rsel) {
+      // sym(R diag(q) R')[U,U] from the selection matrix itself (m_full x k_shocks, staged in the W' buffer: the launcher
+      // checked that it fits): the 40 x 40 product launch and its 51 MB round trip through HBM are gone for the draws
+      // this kernel takes.  Same expression and summation order as rqr_kernel, so the block is bit-identical to it.
+      const int kp = (k_shocks + 1) & ~1;
+      const double* Rg = Rsel + (size_t)draw * m_full * k_shocks;
+      for (int idx = lane; idx < m_full * k_shocks; idx += 64) {
+        const int i = idx / k_shocks, c = idx - i * k_shocks;
+        Wt[i * kp + c] = Rg[idx];
+      }
+      const double* qd = qdiag + (q_batched ? (size_t)draw * k_shocks : 0);
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const bool in = pr[i] >= 0 && pcx[j] >= 0;
+          const double2* ri = reinterpret_cast<const double2*>(Wt + (in ? pr[i] : 0) * kp);
+          const double2* rj = reinterpret_cast<const double2*>(Wt + (in ? pcx[j] : 0) * kp);
+          double a0 = 0.0, a1 = 0.0;
+          for (int c2 = 0; 2 * c2 < kp; ++c2) {
+            const double2 ti = ri[c2], tj = rj[c2];
+            a0 = fma(ti.x * tj.x, qd[2 * c2], a0);
+            a1 = fma(ti.y * tj.y, (2 * c2 + 1 < k_shocks) ? qd[2 * c2 + 1] : 0.0, a1);
+          }
+          Qb[i][j] = in ? a0 + a1 : 0.0;
+        }
+      wave_sync();
+      for (int idx = lane; idx < m_full * kp; idx += 64) Wt[idx] = 0.0;  // (the filter relies on zero padding)
+    }
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -267,7 +298,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         const bool in = pr[i] >= 0 && pcx[j] >= 0;
         const size_t g = in ? (size_t)pr[i] * m_full + pcx[j] : 0;
         const double tv = in ? T[off + g] : 0.0;
-        Qb[i][j] = in ? RQR[off + g] : 0.0;
+        if (!Rsel) Qb[i][j] = in ? RQR[off + g] : 0.0;
         Pb[i][j] = (in && P0) ? P0[off + g] : 0.0;
         Tb0[i][j] = tv;
         Tc[(lr * BS + i) * LDK + lc * BS + j] = tv;

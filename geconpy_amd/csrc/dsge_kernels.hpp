@@ -233,13 +233,15 @@ constexpr int RQR_KMAX = 16;
 template <int KMAX>  // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(64) void rqr_kernel(const double* __restrict__ R, const double* __restrict__ q, int q_batched,
                                                   int batch, int n, int k, const int32_t* __restrict__ status,
-                                                  double* __restrict__ RQR_out) {
+                                                  double* __restrict__ RQR_out, int rerun_only) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int kp = (k + 1) & ~1;  // LDS row stride (even: b128 reads)
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
-    if (status && status[draw] != 0) {  // failed solve: zeros, so that downstream stays finite
+    if (rerun_only) {  // only the draws a structure-exploiting kernel handed on (it formed its own block of the product)
+      if (status[draw] != DSGE_ST_INTERNAL_RERUN) continue;
+    } else if (status && status[draw] != 0) {  // failed solve: zeros, so that downstream stays finite
       for (int idx = lane; idx < n * n; idx += 64) RQR_out[off + idx] = 0.0;
       continue;
     }

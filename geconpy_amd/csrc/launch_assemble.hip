@@ -29,9 +29,10 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
 }
 
 int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n, int k, const int32_t* status,
-               double* RQR_out, hipStream_t st) {
+               double* RQR_out, hipStream_t st, int rerun_only) {
   const size_t lds = sizeof(double) * (size_t)n * ((k + 1) & ~1);
-  hipLaunchKernelGGL(dsge::rqr_kernel<dsge::RQR_KMAX>, dim3(batch), dim3(64), lds, st, R, q, q_batched, batch, n, k, status, RQR_out);
+  hipLaunchKernelGGL(dsge::rqr_kernel<dsge::RQR_KMAX>, dim3(rerun_only ? rerun_grid(batch) : batch), dim3(64), lds, st, R, q,
+                     q_batched, batch, n, k, status, RQR_out, rerun_only);
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
 }

@@ -72,11 +72,26 @@ int launch_persistence_key(const double* T, const int32_t* status, int batch, in
 // p0_valid = 0: P0 is an uninitialised scratch buffer.  The fast kernels then compute the stationary
 // covariance themselves (on the reduced model); only the draws that end up in the general kernel get
 // their full-size P0 from the assemble kernel's Lyapunov pass (from RQR, which must be valid).
+bool kalman_folds_rqr(int m, int p, int k, int n_state_hint, int z_selector_hint) {
+  // mirrors the dispatch below: the NT fast kernel takes every draw first (no tiny / tail / MFMA variant in front of it)
+  if (!(p <= 8 && z_selector_hint && opt().kalman_nt_products) || opt().kalman_mfma || k < 1 || k > dsge::RQR_KMAX) return false;
+  if (opt().kalman_tiny && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) return false;
+  if (opt().kalman_block) return false;
+  const int kp = (k + 1) & ~1;
+  const int lo = (n_state_hint > 0 && n_state_hint < m) ? tile_bs(n_state_hint) : tile_bs(m);
+  if (lo < 1 || lo > 8) return false;
+  const int np = 8 * lo;  // staging area = the W' buffer of the smallest tile tried: NP x (NP + 2) doubles
+  return (size_t)m * kp <= (size_t)np * (np + 2);
+}
+
 int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const double* Z, int z_batched,
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
-                  double* logp, int32_t* status, hipStream_t st, const int32_t* order_key) {
+                  double* logp, int32_t* status, hipStream_t st, const int32_t* order_key, const double* Rsel,
+                  const double* qdiag, int q_batched, int k_shocks) {
   const int bs = tile_bs(m);
+  const bool fold = Rsel && qdiag && kalman_folds_rqr(m, p, k_shocks, n_state_hint, z_selector_hint);
+  if (Rsel && !fold) return fail(DSGE_ERR_INVALID, "launch_kalman: R given but the filter kernel cannot form R Q R' itself");
   int rc = DSGE_ERR_INVALID;
   // Fast path: selector Z, p <= 8, compact state block of at most s_cap columns.  Draws that
   // violate a hint come back flagged and are re-run by the general kernel below.
@@ -189,14 +204,14 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                 hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T,
                                    RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                    s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at, order);
+                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks);
             } else {
               rc = set_lds(dsge::kalman_nt_kernel<BS>, lds_q);
               if (rc == DSGE_SUCCESS)
                 hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T, RQR,
                                    p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                    s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at, order);
+                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks);
             }
             if (rc == DSGE_SUCCESS) {
               HIP_TRY(hipGetLastError());
@@ -239,6 +254,9 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, st, (const double*)tail_rec,
                        (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at);
     HIP_TRY(hipGetLastError());
+  }
+  if (fold) {  // the general kernel's inputs for the draws the fast kernel handed on: their sym(R Q R') after all
+    if ((rc = launch_rqr(Rsel, qdiag, q_batched, batch, m, k_shocks, status, RQR, st, 1))) return rc;
   }
   if (!p0_valid) {
     // full-size P0 for the general kernel: flagged draws only when a fast kernel ran, else every draw
