@@ -64,9 +64,9 @@ __device__ __forceinline__ unsigned long long blk_colmask(const double (&x)[BS][
 // The cycle-reduction iteration on the compact form (register blocks A1, A1_hat, R = [A0c | A2c]; W = [A1 | R] in LDS).
 // ph (nullable): debug stamps [0] GJ panels, [1] GJ trailing updates, [2] row gather + staging, [3] products,
 // [4] scatter/update/norms.
-template <int BS>
+template <int BS, typename IT>
 __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[BS][BS], double (&Rb)[BS][BS], double* W,
-                                            double* Lbuf, double* Ybuf, int* prow, const int* cmap, int* rsrc,
+                                            double* Lbuf, double* Ybuf, int* prow, const IT* cmap, IT* rsrc,
                                             const int (&vS)[BS], const int (&vL)[BS], int n, int s, int l, int max_iter,
                                             double tol, int scan_mode, int lane, long long* ph, int& it, bool& converged,
                                             bool& saw_nan) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
     gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, ph);  // syncs on entry and exit
     long long tk0 = ph ? clock64() : 0;
     // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
-    if (lane < NP) rsrc[lane] = (lane < wr) ? prow[cmap[lane]] : 0;
+    if (lane < NP) rsrc[lane] = (IT)((lane < wr) ? prow[cmap[lane]] : 0);
     wave_sync();
     {
       double t[BS][BS];

@@ -55,15 +55,16 @@ __global__ __launch_bounds__(64) void cr_static_scan_kernel(const double* __rest
 }
 
 // index tables of a selection mask: sti[s] = s-th static variable, dyi[d] = d-th dynamic variable
-__device__ __forceinline__ void crd_index_tables(unsigned long long smask, int n, int lane, int* dyi, int* sti) {
+template <typename IT>
+__device__ __forceinline__ void crd_index_tables(unsigned long long smask, int n, int lane, IT* dyi, IT* sti) {
   wave_sync();
   if (lane < n) {
     const unsigned long long bj = 1ull << lane;
     const int below = __popcll(smask & (bj - 1ull));
     if (smask & bj)
-      sti[below] = lane;
+      sti[below] = (IT)lane;
     else
-      dyi[lane - below] = lane;
+      dyi[lane - below] = (IT)lane;
   }
   wave_sync();
 }
@@ -108,9 +109,10 @@ __device__ __forceinline__ unsigned long long crd_first_bits(unsigned long long 
 
 // source of column cv of [B_st | B_dy | A_dy | C_dy | D] (h + 3 nd + k columns): pointer to its first row and row stride;
 // false for cv beyond the last column (the pointer then walks a valid column)
+template <typename IT>
 __device__ __forceinline__ bool crd_col_source(int cv, const double* __restrict__ A, const double* __restrict__ B,
                                                const double* __restrict__ C, const double* __restrict__ D, size_t off,
-                                               size_t offk, int n, int k, int h, const int* dyi, const int* sti,
+                                               size_t offk, int n, int k, int h, const IT* dyi, const IT* sti,
                                                const double*& src, int& ss) {
   const int nd = n - h;
   src = B + off;
@@ -136,10 +138,10 @@ __device__ __forceinline__ bool crd_col_source(int cv, const double* __restrict_
 // publishes pivot column j to LDS (V), from where every lane (and a second chunk, for systems with more than 128 columns)
 // reads it as a broadcast; no wave reductions anywhere.  Rows 0..h-1 of Q'[...] go to `tp` (h x ncols, row-major); on
 // return colA / colB hold the rows of the REDUCED system (rows 0..nd-1, zeros below).
-template <int NM>
+template <int NM, typename IT>
 __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const double* __restrict__ B,
                                              const double* __restrict__ C, const double* __restrict__ D, size_t off,
-                                             size_t offk, int n, int k, int h, int c0, const int* dyi, const int* sti,
+                                             size_t offk, int n, int k, int h, int c0, const IT* dyi, const IT* sti,
                                              double* V, double* __restrict__ tp, int lane, double (&colA)[NM],
                                              double (&colB)[NM], bool& actA, bool& actB) {
   const int ncols = h + 3 * (n - h) + k;
@@ -390,9 +392,9 @@ __device__ __forceinline__ bool crd_inflate_prepare(double (&y)[NMD], bool y_act
 
 // Column c = c0 + lane of [T_dy | R_dy] (y: its rows 0..nd-1) -> the static rows by back-substitution, and the whole column
 // scattered to the caller's variable order.
-template <int NMD>
+template <int NMD, typename IT>
 __device__ __forceinline__ void crd_inflate_chunk(int c0, const double (&y)[NMD], const double* __restrict__ tp, int n, int k,
-                                                  int h, int lane, const CrdInflateLds<NMD>& L, const int* dyi, const int* sti,
+                                                  int h, int lane, const CrdInflateLds<NMD>& L, const IT* dyi, const IT* sti,
                                                   double* __restrict__ Tg, double* __restrict__ Rg) {
   constexpr int HM = CRD_HMAX;
   const int nd = n - h, ncols = h + 3 * nd + k, ntot = nd + k;

@@ -33,8 +33,10 @@ struct CrfSmem {
   static constexpr size_t dbl_inflate = CrdInflateLds<NPD>::doubles;
   static constexpr size_t dbl =
       dbl_compact > dbl_qr ? (dbl_compact > dbl_inflate ? dbl_compact : dbl_inflate) : (dbl_qr > dbl_inflate ? dbl_qr : dbl_inflate);
-  // ints: prow, cmap, posS, posL, rsrc (NPD each), dyi (64), sti (HM)
-  static constexpr size_t bytes = sizeof(double) * dbl + sizeof(int) * (5 * NPD + 64 + HM);
+  // index tables: prow (NPD ints, shared with gauss_jordan_blocked); cmap, posS, posL, rsrc (NPD), dyi (64), sti (HM) as
+  // bytes (all values < 64): with 32-bit tables the (5, 4) instance needs 20.9 KB -- 7 draws per CU instead of 8
+  typedef signed char idx_t;
+  static constexpr size_t bytes = sizeof(double) * dbl + sizeof(int) * NPD + ((4 * NPD + 64 + HM + 15) & ~(size_t)15);
 };
 
 // per-draw global scratch: top block (crd_top_doubles) and the right-hand side of the final solve, nd x NPD (row-major,
@@ -60,13 +62,14 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   double* G1 = W + NPD;
   double* Lbuf = W + NPD * LDW;
   double* Ybuf = Lbuf + NPD * BSD;
+  typedef typename SM::idx_t idx_t;
   int* prow = (int*)(smem + SM::dbl);
-  int* cmap = prow + NPD;
-  int* posS = cmap + NPD;
-  int* posL = posS + NPD;
-  int* rsrc = posL + NPD;
-  int* dyi = rsrc + NPD;
-  int* sti = dyi + 64;
+  idx_t* cmap = (idx_t*)(prow + NPD);
+  idx_t* posS = cmap + NPD;
+  idx_t* posL = posS + NPD;
+  idx_t* rsrc = posL + NPD;
+  idx_t* dyi = rsrc + NPD;
+  idx_t* sti = dyi + 64;
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   const int nd = n - h;
   const int draw = blockIdx.x;  // one draw per workgroup (see cr_deflate_kernel)
@@ -121,10 +124,10 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
       const unsigned long long below = (1ull << lane) - 1ull;
       const bool isS = (maskS >> lane) & 1ull, isL = (maskL >> lane) & 1ull;
       const int ps = __popcll(maskS & below), pl = s + __popcll(maskL & below);
-      posS[lane] = isS ? ps : -1;
-      posL[lane] = isL ? pl : -1;
-      if (isS) cmap[ps] = lane;
-      if (isL) cmap[pl] = lane;
+      posS[lane] = (idx_t)(isS ? ps : -1);
+      posL[lane] = (idx_t)(isL ? pl : -1);
+      if (isS) cmap[ps] = (idx_t)lane;
+      if (isL) cmap[pl] = (idx_t)lane;
     }
     wave_sync();
     // the columns of the reduced system -> W = [B_dy | A_dy[:,S] C_dy[:,L]] (LDS); [A_dy[:,S] | D_red] -> global scratch
