@@ -138,10 +138,10 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
       }
     ++it;
     const double nrm0 = blk_norm1<BS>(t0);
-    const double nrm2 = blk_norm1<BS>(t2);
     if (ph) ph[4] += clock64() - tk0;
     if (nrm0 < tol) {
-      if (nrm2 < tol || scan_mode) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
+      // (the A2 norm is only looked at once the A0 norm has passed: 15 cross-lane exchanges saved per iteration before)
+      if (scan_mode || blk_norm1<BS>(t2) < tol) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
         converged = true;
         break;
       }

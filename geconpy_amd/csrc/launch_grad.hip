@@ -21,7 +21,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
   int rc = DSGE_ERR_INVALID;
   const int32_t* order = nullptr;
   if (order_key && order_buf && batch >= 512) {
-    hipLaunchKernelGGL(dsge::kalman_order_kernel<256>, dim3(1), dim3(256), 0, st, order_key, batch, order_buf);
+    hipLaunchKernelGGL(dsge::kalman_order_kernel<1024>, dim3(1), dim3(1024), 0, st, order_key, batch, order_buf);
     HIP_TRY(hipGetLastError());
     order = order_buf;
   }

@@ -139,7 +139,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     }
     if (want_order) {
       order = ints + batch + 1;
-      hipLaunchKernelGGL(dsge::kalman_order_kernel<256>, dim3(1), dim3(256), 0, st, order_key, batch, order);
+      hipLaunchKernelGGL(dsge::kalman_order_kernel<1024>, dim3(1), dim3(1024), 0, st, order_key, batch, order);
     }
     HIP_TRY(hipGetLastError());
   }
