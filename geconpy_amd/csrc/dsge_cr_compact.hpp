@@ -313,8 +313,10 @@ __device__ __forceinline__ void cr_compact_body(const double* __restrict__ A, co
   }
 }
 
+// (BS <= 3: the body sits at the 256-register boundary of two waves per SIMD -- 258 without the bound, i.e. ONE wave and
+// 1.5x the time on the 24-variable full_nk system)
 template <int BS>
-__global__ __launch_bounds__(64) void cr_compact_kernel(const double* __restrict__ A, const double* __restrict__ B,
+__global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void cr_compact_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                          const double* __restrict__ C, int batch, int n, int max_iter,
                                                          double tol, double* __restrict__ T_out,
                                                          int32_t* __restrict__ status,

@@ -30,6 +30,21 @@ constexpr int32_t DSGE_ST_INTERNAL_RERUN = 1 << 30;
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
+// Second passes of the kernel cascades visit only the draws an earlier kernel flagged DSGE_ST_INTERNAL_RERUN -- normally
+// none.  True if none of the draws this workgroup would visit (indices blockIdx.x + i gridDim.x, through `order` if
+// given) carries the flag: ONE parallel load per 64 draws instead of a dependent load per draw, so that an empty pass
+// costs its launch and little else.
+__device__ __forceinline__ bool rerun_pass_is_empty(const int32_t* __restrict__ status, int batch,
+                                                    const int32_t* __restrict__ order = nullptr) {
+  const int lane = threadIdx.x & 63;
+  bool any = false;
+  for (int b0 = blockIdx.x; b0 < batch; b0 += 64 * gridDim.x) {
+    const int bi = b0 + lane * gridDim.x;
+    if (bi < batch) any = any || ((status[order ? order[bi] : bi] & DSGE_ST_INTERNAL_RERUN) != 0);
+  }
+  return __ballot(any) == 0ull;
+}
+
 // NaN-propagating max (np.max semantics, used by the induced 1-norm)
 __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
 

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
   // `order` (optional): workgroup b processes draw order[b] -- the launch's makespan is set by its slowest draws (late or
   // no steady state: up to T_len full steps on one wavefront), so the caller dispatches the likely slow ones first
   // (kalman_order_kernel).  Results do not depend on the order: every draw writes logp[draw], status[draw].
+  if (rerun_only && rerun_pass_is_empty(status, batch, order)) return;
   for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
     const int draw = order ? order[bi] : bi;
     const int32_t st_in = status[draw];

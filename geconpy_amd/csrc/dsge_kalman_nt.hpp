@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
   const int fo = lane >> 3, fq = lane & 7;  // owner of F[fo][fq] at the switch
   const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
 
+  if (rerun_only && rerun_pass_is_empty(status, batch, order)) return;
   for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
     const int draw = order ? order[bi] : bi;
     const int32_t st_in = status[draw];

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   (void)LD;
 
+  if (rerun_only && rerun_pass_is_empty(status, batch)) return;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     // second pass of the cascade: only the draws the column-compact kernel could not take
     if (rerun_only && status[draw] != DSGE_ST_INTERNAL_RERUN) continue;
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(64) void rqr_kernel(const double* __restrict__ R, c
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int kp = (k + 1) & ~1;  // LDS row stride (even: b128 reads)
+  if (rerun_only && rerun_pass_is_empty(status, batch)) return;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
     if (rerun_only) {  // only the draws a structure-exploiting kernel handed on (it formed its own block of the product)
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(
   // do_lyapunov: 0 none | 1 RQR' and P0 from R, Q | 2 RQR' only | 3 P0 from RQR_out (read) for the draws
   // flagged DSGE_ST_INTERNAL_RERUN only | 4 P0 from RQR_out (read) for every healthy draw
   const bool lyap_from_rqr = (do_lyapunov == 3 || do_lyapunov == 4);
+  if (do_lyapunov == 3 && rerun_pass_is_empty(status, batch)) return;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     const size_t offk = (size_t)draw * n * k;
@@ -502,7 +505,8 @@ struct AdjSmem {
 };
 
 template <int BS>
-__global__ __launch_bounds__(64) void adjoint_kernel(const double* __restrict__ B, const double* __restrict__ C,
+__global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS = 3: 258 registers without the bound)
+    const double* __restrict__ B, const double* __restrict__ C,
                                                       const double* __restrict__ T, const double* __restrict__ T_bar,
                                                       int batch, int n, double* __restrict__ A_bar,
                                                       double* __restrict__ B_bar, double* __restrict__ C_bar,
@@ -782,6 +786,7 @@ __global__ __launch_bounds__(64) void kalman_kernel(
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   const double LN2PI = 1.8378770664093453;
 
+  if (rerun_only && rerun_pass_is_empty(status, batch)) return;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     if (rerun_only) {
       // second pass after kalman_sel_kernel: only the draws it could not handle
