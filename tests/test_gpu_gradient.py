@@ -71,6 +71,53 @@ def test_gradient_rbc():
         _directional_check(A[i], B[i], C[i], D[i], q[i], Z, y, d, h, g, rng)
 
 
+def test_gradient_rbc_against_extrapolated_differences():
+    """A check of the reverse sweep three orders tighter than the 2e-5 of the plain central differences: the directional
+    derivative of the oracle by Richardson extrapolation of central differences (steps h, h/2, h/4 -> error O(h^6); with
+    the oracle's own noise of ~1e-13 relative in logp the extrapolated value is good to ~1e-9 relative), on the RBC model
+    with missing observations, every input block moving at once."""
+    rng = np.random.default_rng(5)
+    nb = 3
+    th = wl.rbc_prior_draws(nb, seed=9)
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    q = (th["sigma_A"] ** 2)[:, None]
+    Z = np.zeros((2, 8))
+    Z[0, wl.RBC_VARIABLES.index("Y")] = 1.0
+    Z[1, wl.RBC_VARIABLES.index("C")] = 0.5
+    y = rng.normal(0, 0.05, (40, 2))
+    y[5, 1] = np.nan
+    d = np.array([0.01, -0.02])
+    h = np.array([1e-4, 2e-4])
+    out = batched.solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=d, Hdiag=h, tol=1e-14, max_iter=200)
+    assert np.all(out["status"] == 0)
+
+    def central(f, step):
+        return (f(step) - f(-step)) / (2.0 * step)
+
+    for i in range(nb):
+        g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+        maskA = (A[i] != 0).any(axis=0)[None, :] * np.ones_like(A[i])
+        for _ in range(2):
+            dA = rng.standard_normal(A[i].shape) * maskA * 0.1
+            dB, dC, dD = (rng.standard_normal(M.shape) * 0.1 for M in (B[i], C[i], D[i]))
+            dq = rng.standard_normal(q[i].shape) * q[i] * 0.3
+            dd = rng.standard_normal(d.shape) * 0.1
+            dh = rng.standard_normal(h.shape) * h * 0.3
+            analytic = ((g["A_bar"] * dA).sum() + (g["B_bar"] * dB).sum() + (g["C_bar"] * dC).sum() + (g["D_bar"] * dD).sum()
+                        + (g["q_bar"] * dq).sum() + (g["d_bar"] * dd).sum() + (g["h_bar"] * dh).sum())
+
+            def f(e):
+                return oracle.solve_kalman_logp(A[i] + e * dA, B[i] + e * dB, C[i] + e * dC, D[i] + e * dD, np.diag(q[i] + e * dq),
+                                                Z, y, H=np.diag(h + e * dh), d=d + e * dd, tol=1e-15, max_iter=300)["logp"]
+
+            h0 = 8e-3
+            d1 = [central(f, h0 / 2 ** j) for j in range(3)]
+            d2 = [(4.0 * d1[j + 1] - d1[j]) / 3.0 for j in range(2)]
+            d3 = (16.0 * d2[1] - d2[0]) / 15.0
+            assert abs(d3 - d2[1]) <= 1e-6 * abs(d3)  # the extrapolation has converged (else the step is too large)
+            assert_allclose(analytic, d3, rtol=2e-8, atol=1e-9 * max(1.0, abs(d3)))
+
+
 def test_gradient_sw_shaped():
     rng = np.random.default_rng(1)
     nb = 3
@@ -92,6 +139,44 @@ def test_gradient_sw_shaped():
         assert_allclose(out["logp"][i], _oracle_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h),
                         rtol=1e-9)
         _directional_check(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h, g, rng, n_dirs=2)
+
+
+def test_gradient_sw_shaped_against_extrapolated_differences():
+    """The same extrapolated-difference check on the 40-variable SW-shaped system (deflated solve, reduced filter with
+    steady-state segments, 60 periods with a missing observation): 1e-7 relative."""
+    rng = np.random.default_rng(8)
+    b = wl.sw_shaped_batch(2, first_draw=300)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y = om["y"][:60].copy()
+    y[9, 2] = np.nan
+    d = rng.normal(0, 0.01, 7)
+    h = om["Hdiag"].copy()
+    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, d=d, Hdiag=h, tol=1e-14,
+                                                 max_iter=200)
+    assert np.all(out["status"] == 0)
+    i = 1
+    A, B, C, D = (b[x][i] for x in "ABCD")
+    g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+    maskA = (A != 0).any(axis=0)[None, :] * np.ones_like(A)
+    dA = rng.standard_normal(A.shape) * maskA * 0.1
+    dB, dC, dD = (rng.standard_normal(M.shape) * 0.1 for M in (B, C, D))
+    dq = rng.standard_normal(q[i].shape) * q[i] * 0.3
+    dd = rng.standard_normal(d.shape) * 0.1
+    dh = rng.standard_normal(h.shape) * h * 0.3
+    analytic = ((g["A_bar"] * dA).sum() + (g["B_bar"] * dB).sum() + (g["C_bar"] * dC).sum() + (g["D_bar"] * dD).sum()
+                + (g["q_bar"] * dq).sum() + (g["d_bar"] * dd).sum() + (g["h_bar"] * dh).sum())
+
+    def f(e):
+        return oracle.solve_kalman_logp(A + e * dA, B + e * dB, C + e * dC, D + e * dD, np.diag(q[i] + e * dq), om["Z"], y,
+                                        H=np.diag(h + e * dh), d=d + e * dd, tol=1e-15, max_iter=300)["logp"]
+
+    h0 = 2e-3
+    d1 = [(f(h0 / 2 ** j) - f(-h0 / 2 ** j)) / (2.0 * h0 / 2 ** j) for j in range(3)]
+    d2 = [(4.0 * d1[j + 1] - d1[j]) / 3.0 for j in range(2)]
+    d3 = (16.0 * d2[1] - d2[0]) / 15.0
+    assert abs(d3 - d2[1]) <= 1e-5 * abs(d3)
+    assert_allclose(analytic, d3, rtol=1e-7, atol=1e-8 * max(1.0, abs(d3)))
 
 
 def test_gradient_failed_and_unsupported_draws():
