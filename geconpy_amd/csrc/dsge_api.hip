@@ -538,7 +538,8 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
 
 inline size_t pipeline_scratch_bytes(int batch, int n, int k) {
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
-  return 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 2 * align256((size_t)batch * 4) + 4096;
+  return 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 2 * align256((size_t)batch * 4) +
+         align256((size_t)batch * 8) + 4096;
 }
 
 static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
@@ -576,6 +577,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
   int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);  // cycle-reduction iterations
   int32_t* key_w = cv.take<int32_t>((size_t)batch);                            // dispatch key of the Kalman launch
+  unsigned long long* cm_w = cv.take<unsigned long long>((size_t)batch);       // non-zero columns of T, from the solver
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float acc_ms[3] = {0.f, 0.f, 0.f};
@@ -587,12 +589,15 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     // Cycle reduction (njit semantics) can hand back R from its final elimination (A1_hat = B + C T at convergence);
     // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
     const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && opt().cr_fused_selection;
+    bool have_colmask = false;
     if (is_cr) {
       int deflated = 0;
       // static variables deflated first (the iteration then runs on n - h variables); not when the caller asks for the
       // iteration counts or the residual, whose contract is the full-size iteration
-      if (fuse_R && !n_iter_out && (rc = launch_cr_deflated(A, B, C, D, batch, n, k, max_iter, tol, Tw, Rw, status_out, it_w, st, &deflated)))
+      if (fuse_R && !n_iter_out &&
+          (rc = launch_cr_deflated(A, B, C, D, batch, n, k, max_iter, tol, Tw, Rw, status_out, it_w, st, &deflated, cm_w)))
         return rc;
+      have_colmask = deflated == 2;
       if (!deflated)
         rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st,
                        solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0, fuse_R ? D : nullptr, k, fuse_R ? Rw : nullptr);
@@ -633,7 +638,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     }
     if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,
                             missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st, okey,
-                            fold_rqr ? Rw : nullptr, fold_rqr ? Q : nullptr, q_mode == DSGE_Q_DIAG_BATCHED, k)))
+                            fold_rqr ? Rw : nullptr, fold_rqr ? Q : nullptr, q_mode == DSGE_Q_DIAG_BATCHED, k,
+                            have_colmask ? cm_w : nullptr)))
       return rc;
     if (ms_out) {
       HIP_TRY(hipEventRecord(ev[3], st));

@@ -54,7 +54,8 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
                                               int k, int h, int max_iter, double tol, double* __restrict__ top,
                                               double* __restrict__ rhs, double* __restrict__ T_out,
                                               double* __restrict__ R_out, int32_t* __restrict__ status,
-                                              int32_t* __restrict__ n_iter_out) {
+                                              int32_t* __restrict__ n_iter_out,
+                                              unsigned long long* __restrict__ colmask_out) {
   using SM = CrfSmem<BSF, BSD>;
   constexpr int NMF = SM::NMF, NPD = SM::NPD, LDW = SM::LDW, HM = CRD_HMAX;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -76,8 +77,12 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   if (draw >= batch) return;
   const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
   auto hand_over = [&]() {  // the full-size kernel solves this draw
-    if (lane == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
+    if (lane == 0) {
+      status[draw] = DSGE_ST_INTERNAL_RERUN;
+      if (colmask_out) colmask_out[draw] = ~0ull;
+    }
   };
+  if (colmask_out && lane == 0) colmask_out[draw] = ~0ull;  // "not known" until the solve has succeeded
 
   // ---- phase 1: deflation ----------------------------------------------------------------------------------------------
   unsigned long long smask = crd_static_mask<NMF>(A, C, off, n, lane);
@@ -87,6 +92,7 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   double* tp = top + (size_t)draw * crd_top_doubles(n, k, h);
   double* rh = rhs + (size_t)draw * crf_rhs_doubles(nd, NPD);
   int s, l;
+  unsigned long long state_cols = 0ull;
   {
     double colA[NMF], colB[NMF];
     bool actA, actB;
@@ -118,6 +124,12 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
     s = __popcll(maskS);
     l = __popcll(maskL);
     if (s + l > NPD || s + k > NPD) return hand_over();
+    {  // the non-zero columns of T, in the caller's variable numbering: bit v <=> v is dynamic and a state
+      const unsigned long long below = (lane < 64) ? ((1ull << lane) - 1ull) : 0ull;
+      const bool dyn = (lane < n) && !((smask >> lane) & 1ull);
+      const int dred = lane - __popcll(smask & below);
+      state_cols = __ballot(dyn && ((maskS >> (dred & 63)) & 1ull));
+    }
     wave_sync();  // every lane is done with V
     for (int idx = lane; idx < NPD * LDW; idx += 64) W[idx] = 0.0;
     if (lane < NPD) {
@@ -230,6 +242,8 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
       if (s2 < h) T_out[off + (size_t)lane * n + sti[s2]] = 0.0;
   }
   crd_inflate_chunk<NPD>(0, y, tp, n, k, h, lane, L, dyi, sti, T_out + off, R_out + offk);
+  // every other column of T is exactly zero (written so): the filter kernel need not look for them
+  if (colmask_out && lane == 0) colmask_out[draw] = state_cols;
 }
 
 template <int BSF, int BSD>
@@ -238,8 +252,9 @@ __global__ __launch_bounds__(64) void cr_fused_kernel(const double* __restrict__
                                                        int n, int k, int h, int max_iter, double tol,
                                                        double* __restrict__ top, double* __restrict__ rhs,
                                                        double* __restrict__ T_out, double* __restrict__ R_out,
-                                                       int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out) {
-  cr_fused_body<BSF, BSD>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out);
+                                                       int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
+                                                       unsigned long long* __restrict__ colmask_out) {
+  cr_fused_body<BSF, BSD>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out, colmask_out);
 }
 
 // the register budget of two waves per SIMD for the 4 x 4 reduced tile (see cr_compact_kernel_occ2)
@@ -247,8 +262,9 @@ template <int BSF, int BSD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cr_fused_kernel_occ2(
     const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ C, const double* __restrict__ D,
     int batch, int n, int k, int h, int max_iter, double tol, double* __restrict__ top, double* __restrict__ rhs,
-    double* __restrict__ T_out, double* __restrict__ R_out, int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out) {
-  cr_fused_body<BSF, BSD>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out);
+    double* __restrict__ T_out, double* __restrict__ R_out, int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
+    unsigned long long* __restrict__ colmask_out) {
+  cr_fused_body<BSF, BSD>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out, colmask_out);
 }
 
 }  // namespace dsge

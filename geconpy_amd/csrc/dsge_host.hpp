@@ -58,7 +58,8 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
               const double* D = nullptr, int k = 0, double* R_out = nullptr);  // D, R_out: also R = -A1_hat^-1 D
 int launch_cr_deflated(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
                        int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
-                       hipStream_t st, int* used);  // static-variable deflation + cycle reduction on the reduced system
+                       hipStream_t st, int* used, unsigned long long* colmask = nullptr);
+// (*used = 2: the one-launch kernel ran and colmask[draw] holds the non-zero columns of T_out[draw], ~0 = not known)  // static-variable deflation + cycle reduction on the reduced system
 void cr_deflation_reset();
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
                    double* R_out, hipStream_t st);
@@ -82,7 +83,8 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr,
-                  const double* Rsel = nullptr, const double* qdiag = nullptr, int q_batched = 0, int k_shocks = 0);
+                  const double* Rsel = nullptr, const double* qdiag = nullptr, int q_batched = 0, int k_shocks = 0,
+                  const unsigned long long* colmask = nullptr);
 // true if launch_kalman, given the selection matrix R and a diagonal Q (Rsel, qdiag), forms sym(R Q R')[U,U] inside the
 // fast filter kernel: the caller then skips the full-size product (RQR is filled for handed-on draws only)
 bool kalman_folds_rqr(int m, int p, int k, int n_state_hint, int z_selector_hint);

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
     const int32_t* __restrict__ order, const double* __restrict__ Rsel, const double* __restrict__ qdiag, int q_batched,
-    int k_shocks) {
+    int k_shocks, const unsigned long long* __restrict__ colmask_in) {
   constexpr int NP = KntSmem<BS>::NP, LDK = KntSmem<BS>::LDK, PS = KntSmem<BS>::PS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;                 // NP x LDK    transition, states-first ordering (columns >= s exactly zero)
@@ -198,7 +198,11 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     // ---- exact state-space reduction to U = S u O, states first (as kalman_sel_kernel) ----------------------------
     const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
     bool is_state = false;
-    {
+    // the solver may hand over which columns of T are non-zero (it wrote the others as exact zeros): no pass over T then
+    const unsigned long long cm_in = colmask_in ? colmask_in[draw] : ~0ull;
+    if (cm_in != ~0ull) {
+      is_state = (lane < m_full) && ((cm_in >> lane) & 1ull);
+    } else {
       const double* tcol = T + off + (lane < m_full ? lane : 0);
       for (int r0 = 0; r0 < m_full; r0 += 8) {
         double tv[8];

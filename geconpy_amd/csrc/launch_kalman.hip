@@ -88,7 +88,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key, const double* Rsel,
-                  const double* qdiag, int q_batched, int k_shocks) {
+                  const double* qdiag, int q_batched, int k_shocks, const unsigned long long* colmask) {
   const int bs = tile_bs(m);
   const bool fold = Rsel && qdiag && kalman_folds_rqr(m, p, k_shocks, n_state_hint, z_selector_hint);
   if (Rsel && !fold) return fail(DSGE_ERR_INVALID, "launch_kalman: R given but the filter kernel cannot form R Q R' itself");
@@ -204,14 +204,14 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                 hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T,
                                    RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                    s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks);
+                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
             } else {
               rc = set_lds(dsge::kalman_nt_kernel<BS>, lds_q);
               if (rc == DSGE_SUCCESS)
                 hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T, RQR,
                                    p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
                                    s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks);
+                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
             }
             if (rc == DSGE_SUCCESS) {
               HIP_TRY(hipGetLastError());

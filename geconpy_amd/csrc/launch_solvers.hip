@@ -115,17 +115,17 @@ namespace {
 template <int BSF, int BSD>
 int launch_cr_fused_inst(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, int h,
                          int max_iter, double tol, double* top, double* rhs, double* T_out, double* R_out, int32_t* status,
-                         int32_t* n_iter, hipStream_t st) {
+                         int32_t* n_iter, hipStream_t st, unsigned long long* colmask) {
   using SM = dsge::CrfSmem<BSF, BSD>;
   int rc;
   if (BSD == 4 && opt().cr_two_waves) {
     if ((rc = set_lds(dsge::cr_fused_kernel_occ2<BSF, BSD>, SM::bytes))) return rc;
     hipLaunchKernelGGL((dsge::cr_fused_kernel_occ2<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
-                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter);
+                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter, colmask);
   } else {
     if ((rc = set_lds(dsge::cr_fused_kernel<BSF, BSD>, SM::bytes))) return rc;
     hipLaunchKernelGGL((dsge::cr_fused_kernel<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
-                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter);
+                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter, colmask);
   }
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
@@ -134,7 +134,7 @@ int launch_cr_fused_inst(const double* A, const double* B, const double* C, cons
 
 int launch_cr_fused(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, int h,
                     int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter, hipStream_t st,
-                    int* done) {
+                    int* done, unsigned long long* colmask) {
   *done = 0;
   const int nd = n - h, bsf = tile_bs(n), bsd = tile_bs(nd);
   const bool have = (bsf == 3 && (bsd == 2 || bsd == 3)) || (bsf == 4 && (bsd == 3 || bsd == 4)) ||
@@ -148,7 +148,7 @@ int launch_cr_fused(const double* A, const double* B, const double* C, const dou
   double* rhs = (double*)((char*)base + al256(tops * 8));
 #define FUSED_CASE(F, D_)                                                                                              \
   if (bsf == F && bsd == D_)                                                                                           \
-    rc = launch_cr_fused_inst<F, D_>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter, st)
+    rc = launch_cr_fused_inst<F, D_>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter, st, colmask)
   rc = DSGE_ERR_INVALID;
   FUSED_CASE(3, 2);
   FUSED_CASE(3, 3);
@@ -177,7 +177,7 @@ int launch_cr_fused(const double* A, const double* B, const double* C, const dou
 // *used = 0: nothing done (deflation off, too few static variables, ...): the caller runs launch_cr on the full system.
 int launch_cr_deflated(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
                        int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
-                       hipStream_t st, int* used) {
+                       hipStream_t st, int* used, unsigned long long* colmask) {
   *used = 0;
   if (!opt().cr_deflation || !D || !R_out || n < 8 || n > 64 || batch < 1) return DSGE_SUCCESS;
   int rc;
@@ -218,9 +218,10 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
     // one launch (dsge_cr_fused.hpp); the (full tile, reduced tile) pairs built are the ones the deflation test above lets
     // through for n <= 48
     int done = 0;
-    if ((rc = launch_cr_fused(A, B, C, D, batch, n, k, h, max_iter, tol, T_out, R_out, status, n_iter, st, &done))) return rc;
+    if ((rc = launch_cr_fused(A, B, C, D, batch, n, k, h, max_iter, tol, T_out, R_out, status, n_iter, st, &done, colmask)))
+      return rc;
     if (done) {
-      *used = 1;
+      *used = colmask ? 2 : 1;  // 2: colmask[draw] holds the non-zero columns of T (or ~0: not known)
       return DSGE_SUCCESS;
     }
   }

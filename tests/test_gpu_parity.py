@@ -1572,6 +1572,39 @@ def test_cr_fused_deflation_equals_three_launches(n, ns, nl):
     assert_allclose(T[3], r["T"], atol=1e-9)
 
 
+def test_cr_fused_deflation_hands_over_what_does_not_fit():
+    """16 shocks on the 40-variable system: the right-hand side [A_dy[:,S] | D_red] of the final solve (18 + 16 columns) does
+    not fit the 32-wide reduced tile, so the one-launch kernel flags every draw and the full-size dense kernel solves them --
+    same T, R, logp as the three-launch path (which eliminates D separately) to 1e-10, status clear."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    n, ns, nl, k, p, nb = 40, 18, 12, 16, 7, 24
+    sysm = [wl.sw_shaped_system(9900 + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    q = np.full((nb, k), 1e-4)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(3).normal(0, 0.02, (30, p))
+    H = np.full(p, 1e-4)
+    eng = LogpEngine(torch.device("cuda", 0))
+    dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
+    dq, dZ, dy, dH = eng.to_device(q), eng.to_device(Z), eng.to_device(y), eng.to_device(H)
+    hints = eng.structure_hints(dev["A"], dZ)
+    res = {}
+    for fused in (0, 1):
+        with _lib.options_scope({"cr_fused_deflation": fused, "n_static_hint": n - ns - nl}):
+            res[fused] = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+    lp0, st0, T0, R0 = res[0]
+    lp1, st1, T1, R1 = res[1]
+    assert np.all(st0 == 0) and np.all(st1 == 0)
+    assert_allclose(T1, Tst, atol=1e-8)
+    assert_allclose(T1, T0, atol=1e-10)
+    assert_allclose(R1, R0, atol=1e-10)
+    assert_allclose(lp1, lp0, rtol=LOGP_RTOL)
+
+
 @pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
 def test_cr_static_deflation_on_reference_goldens(ref_goldens, key):
     """The reference's own models (3 of 9, 6 of 12, 4 of 24 static variables): fused call with the deflation against the
