@@ -143,7 +143,7 @@ __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const
                                              const double* __restrict__ C, const double* __restrict__ D, size_t off,
                                              size_t offk, int n, int k, int h, int c0, const IT* dyi, const IT* sti,
                                              double* V, double* __restrict__ tp, int lane, double (&colA)[NM],
-                                             double (&colB)[NM], bool& actA, bool& actB) {
+                                             double (&colB)[NM], bool& actA, bool& actB, bool skip_zero_ac = false) {
   const int ncols = h + 3 * (n - h) + k;
   const double *srcA, *srcB;
   int ssA, ssB;
@@ -161,6 +161,21 @@ __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const
   for (int r = 0; r < NM; ++r) {
     colA[r] = (r < n && actA) ? colA[r] : 0.0;
     colB[r] = (r < n && actB) ? colB[r] : 0.0;
+  }
+  // skip_zero_ac: an all-zero column of A_dy or C_dy stays all-zero under the reflectors; its h top entries are not
+  // written (the reader masks them: crd_inflate_* with the column masks) -- 30 of the 107 columns on the SW-shaped system
+  bool wrA = actA, wrB = actB;
+  if (skip_zero_ac) {
+    bool nzA = false, nzB = false;
+#pragma unroll
+    for (int r = 0; r < NM; ++r) {
+      nzA = nzA || (colA[r] != 0.0);
+      nzB = nzB || (colB[r] != 0.0);
+    }
+    const int nd_ = n - h;
+    const bool acA = cA >= h + nd_ && cA < h + 3 * nd_, acB = cB >= h + nd_ && cB < h + 3 * nd_;
+    wrA = actA && (nzA || !acA);
+    wrB = actB && (nzB || !acB);
   }
   // Row j is final once reflector j has been applied: it goes straight to the top block and the columns are shifted
   // up by one row, so that the pivot is always register row 0 (no index-dependent selects, which cost a scalar lane
@@ -210,8 +225,8 @@ __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const
     const double wA = left ? 0.0 : -tj * fma(scal, a0 + a1, colA[0]);
     const double wB = -tj * fma(scal, b0 + b1, colB[0]);
     const double topA = left ? ((lane == j) ? beta : 0.0) : colA[0] + wA, topB = colB[0] + wB;
-    if (actA) tp[(size_t)j * ncols + cA] = topA;
-    if (actB) tp[(size_t)j * ncols + cB] = topB;
+    if (wrA) tp[(size_t)j * ncols + cA] = topA;
+    if (wrB) tp[(size_t)j * ncols + cB] = topB;
     const double wsA = wA * scal, wsB = wB * scal;
     {  // update and shift up by one row
       const double2 t0 = vj2[0];
@@ -330,7 +345,8 @@ struct CrdInflateLds {
 // builds the LDS arrays; false if R_st is numerically singular (the verdict is then left to the full-size kernels).
 template <int NMD>
 __device__ __forceinline__ bool crd_inflate_prepare(double (&y)[NMD], bool y_act, const double* __restrict__ tp, int n, int k,
-                                                    int h, int lane, const CrdInflateLds<NMD>& L) {
+                                                    int h, int lane, const CrdInflateLds<NMD>& L,
+                                                    unsigned long long cmask = ~0ull) {  // bit d: column d of Ctop was stored
   constexpr int HM = CRD_HMAX;
   const int nd = n - h, ncols = h + 3 * nd + k;
   double g[HM], ctv[HM], rsv[(HM * HM + 63) / 64];
@@ -352,7 +368,7 @@ __device__ __forceinline__ bool crd_inflate_prepare(double (&y)[NMD], bool y_act
 #pragma unroll
   for (int i = 0; i < HM; ++i) {
     g[i] = (i < h && lane < nd) ? g[i] : 0.0;
-    if (lane < NMD) L.Ct[i * NMD + lane] = (i < h && lane < nd) ? ctv[i] : 0.0;
+    if (lane < NMD) L.Ct[i * NMD + lane] = (i < h && lane < nd && ((cmask >> (lane & 63)) & 1ull)) ? ctv[i] : 0.0;
   }
 #pragma unroll
   for (int u = 0; u < (HM * HM + 63) / 64; ++u) {
@@ -395,7 +411,8 @@ __device__ __forceinline__ bool crd_inflate_prepare(double (&y)[NMD], bool y_act
 template <int NMD, typename IT>
 __device__ __forceinline__ void crd_inflate_chunk(int c0, const double (&y)[NMD], const double* __restrict__ tp, int n, int k,
                                                   int h, int lane, const CrdInflateLds<NMD>& L, const IT* dyi, const IT* sti,
-                                                  double* __restrict__ Tg, double* __restrict__ Rg) {
+                                                  double* __restrict__ Tg, double* __restrict__ Rg,
+                                                  unsigned long long amask = ~0ull) {  // bit d: column d of Atop was stored
   constexpr int HM = CRD_HMAX;
   const int nd = n - h, ncols = h + 3 * nd + k, ntot = nd + k;
   const int c = c0 + lane;
@@ -407,8 +424,9 @@ __device__ __forceinline__ void crd_inflate_chunk(int c0, const double (&y)[NMD]
 #pragma unroll
     for (int i = 0; i < HM; ++i) x[i] = tp[(size_t)(i < h ? i : h - 1) * ncols + tc];
     __builtin_amdgcn_sched_barrier(0);
+    const bool stored = act && (c >= nd || ((amask >> (c & 63)) & 1ull));
 #pragma unroll
-    for (int i = 0; i < HM; ++i) x[i] = (i < h && act) ? x[i] : 0.0;
+    for (int i = 0; i < HM; ++i) x[i] = (i < h && stored) ? x[i] : 0.0;
 #pragma unroll
     for (int i = 0; i < HM; ++i) {
       if (i < h) {

@@ -39,8 +39,8 @@ struct CrfSmem {
   static constexpr size_t bytes = sizeof(double) * dbl + sizeof(int) * NPD + ((4 * NPD + 64 + HM + 15) & ~(size_t)15);
 };
 
-// per-draw global scratch: top block (crd_top_doubles) and the right-hand side of the final solve, nd x NPD (row-major,
-// columns [A_dy[:,S] | D_red], s + k <= NPD of them)
+// per-draw global scratch: top block (crd_top_doubles) and the right-hand side of the final solve, NPD columns of nd
+// doubles (column-major; columns [A_dy[:,S] | D_red], s + k <= NPD of them are written)
 __host__ __device__ inline size_t crf_rhs_doubles(int nd, int npd) { return (size_t)nd * npd; }
 
 // bit (lane + shift) of the result = bit lane of b, for any shift in (-64, 64)
@@ -92,11 +92,12 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   double* tp = top + (size_t)draw * crd_top_doubles(n, k, h);
   double* rh = rhs + (size_t)draw * crf_rhs_doubles(nd, NPD);
   int s, l;
-  unsigned long long state_cols = 0ull;
+  unsigned long long state_cols = 0ull, maskS_red = 0ull, maskL_red = 0ull;  // (red: over the reduced variables)
   {
     double colA[NMF], colB[NMF];
     bool actA, actB;
-    crd_qr_chunk<NMF>(A, B, C, D, off, offk, n, k, h, 0, dyi, sti, /*V=*/smem, tp, lane, colA, colB, actA, actB);
+    crd_qr_chunk<NMF>(A, B, C, D, off, offk, n, k, h, 0, dyi, sti, /*V=*/smem, tp, lane, colA, colB, actA, actB,
+                      /*skip_zero_ac=*/true);
     // block (0 B, 1 A, 2 C, 3 D, -1 none) and column inside the block of this lane's two columns
     auto classify = [&](int cv, bool act, int& blk, int& d) {
       const int c = cv - h;
@@ -123,6 +124,8 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
                                       crf_place(__ballot(blkB == 2 && nzB), 64 - (h + 2 * nd))) & ndmask;
     s = __popcll(maskS);
     l = __popcll(maskL);
+    maskS_red = maskS;
+    maskL_red = maskL;
     if (s + l > NPD || s + k > NPD) return hand_over();
     {  // the non-zero columns of T, in the caller's variable numbering: bit v <=> v is dynamic and a state
       const unsigned long long below = (lane < 64) ? ((1ull << lane) - 1ull) : 0ull;
@@ -164,11 +167,11 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
         for (int r = 0; r < NMF; ++r)
           if (r < nd) dst[r * LDW] = col[r];
       }
-      if (gcol >= 0) {
-        double* dst = rh + gcol;
+      if (gcol >= 0) {  // (column-major: a lane writes its column contiguously, unused columns are never touched)
+        double* dst = rh + (size_t)gcol * nd;
 #pragma unroll
         for (int r = 0; r < NMF; ++r)
-          if (r < nd) dst[(size_t)r * NPD] = col[r];
+          if (r < nd) dst[r] = col[r];
       }
     };
     deposit(colA, blkA, dA);
@@ -214,7 +217,7 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
 #pragma unroll
       for (int j = 0; j < BSD; ++j) {
         const int r = lr * BSD + i, c = lc * BSD + j;
-        t[i][j] = (r < nd && c < s + k) ? rh[(size_t)r * NPD + c] : 0.0;
+        t[i][j] = (r < nd && c < s + k) ? rh[(size_t)c * nd + r] : 0.0;
       }
     blk_store_lds<BSD>(t, G1, LDW, lr, lc);
   }
@@ -235,13 +238,13 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   }
   wave_sync();  // the solution is in registers: W becomes the work space of the back-substitution
   const CrdInflateLds<NPD> L(smem);
-  if (!crd_inflate_prepare<NPD>(y, lane < nd + k, tp, n, k, h, lane, L)) return hand_over();
+  if (!crd_inflate_prepare<NPD>(y, lane < nd + k, tp, n, k, h, lane, L, maskL_red)) return hand_over();
   if (lane < n) {  // static columns of T are exact zeros
 #pragma unroll
     for (int s2 = 0; s2 < HM; ++s2)
       if (s2 < h) T_out[off + (size_t)lane * n + sti[s2]] = 0.0;
   }
-  crd_inflate_chunk<NPD>(0, y, tp, n, k, h, lane, L, dyi, sti, T_out + off, R_out + offk);
+  crd_inflate_chunk<NPD>(0, y, tp, n, k, h, lane, L, dyi, sti, T_out + off, R_out + offk, maskS_red);
   // every other column of T is exactly zero (written so): the filter kernel need not look for them
   if (colmask_out && lane == 0) colmask_out[draw] = state_cols;
 }

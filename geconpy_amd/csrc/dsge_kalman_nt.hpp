@@ -183,8 +183,10 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
 
   if (rerun_only && rerun_pass_is_empty(status, batch, order)) return;
   for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
-    const int draw = order ? order[bi] : bi;
-    const int32_t st_in = status[draw];
+    // (readfirstlane: the draw index is wave-uniform, and everything derived from it -- base addresses of a dozen
+    // arrays -- then lives in scalar registers instead of being spilled around the time loop)
+    const int draw = __builtin_amdgcn_readfirstlane(order ? order[bi] : bi);
+    const int32_t st_in = __builtin_amdgcn_readfirstlane(status[draw]);
     if (rerun_only) {
       if (st_in != DSGE_ST_INTERNAL_RERUN) continue;
     } else if (st_in != 0) {
