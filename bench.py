@@ -102,15 +102,18 @@ def cpu_baseline(batch, om, n_sample, cores):
         dt = time.perf_counter() - t0
     return np.array(logp), n_sample / dt, dt
 
-PMC_LEGS = {  # kernels of one fused step, by leg (substring of the rocprofv3 kernel name)
-    "solver": ("cr_fused_kernel", "cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel", "cr_solve_kernel"),
-    "assemble": ("rqr_kernel",),
-    "kalman": ("kalman_sel_kernel", "kalman_nt_kernel"),
+PMC_LEGS = {  # kernels of one fused step, by leg: alternative GROUPS of rocprofv3 kernel-name substrings, first match wins
+    "solver": (("cr_fused_kernel",), ("cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel"), ("cr_compact_kernel",),
+               ("cr_solve_kernel",)),
+    "assemble": (("rqr_kernel",),),
+    "kalman": (("kalman_nt_kernel",), ("kalman_sel_kernel",)),
 }
 
 
 def load_pmc():
-    """Newest profiles/r*/pmc_counters.json (tools/pmc_collect.py) -> ({leg: {flops, hbm_bytes, kernels}}, path)."""
+    """Newest profiles/r*/pmc_counters.json (tools/pmc_collect.py) -> ({leg: {flops, hbm_bytes, kernels}}, path).  Only
+    kernels dispatched once per profiled step or more count (the collection run also launches one-off statistics
+    kernels, e.g. the full-size cycle reduction that bench.py uses for the iteration counts)."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters.json")))
@@ -121,20 +124,24 @@ def load_pmc():
             kernels = json.load(fh)["kernels"]
     except (OSError, KeyError, ValueError):
         return {}, None
+    steps = max((v.get("dispatches", 0) for v in kernels.values()), default=0)
+    per_step = {nm: v for nm, v in kernels.items() if steps and v.get("dispatches", 0) >= max(2, steps - 1)}
     legs = {}
-    for leg, pats in PMC_LEGS.items():
-        chosen = []
-        for pat in pats:  # several instantiations can match (second passes, the statistics pass): keep the one that
-            cands = [(v.get("calls_in_trace", v.get("dispatches", 0)) * v.get("avg_ns", 0.0), nm, v)  # carries the time
-                     for nm, v in kernels.items() if pat in nm]
-            if cands:
-                chosen.append(max(cands)[1:])
-        if chosen:
-            legs[leg] = {"kernels": [nm for nm, _ in chosen],
-                         "fp64_flops": sum(v.get("fp64_flops", 0.0) for _, v in chosen),
-                         "hbm_bytes": sum(v.get("hbm_bytes", 0.0) for _, v in chosen),
-                         "lds_conflict_share": max((v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
-                                                    for _, v in chosen), default=0.0)}
+    for leg, groups in PMC_LEGS.items():
+        for pats in groups:
+            chosen = []
+            for pat in pats:  # several instantiations can match (second passes): keep the one that carries the time
+                cands = [(v.get("calls_in_trace", v.get("dispatches", 0)) * v.get("avg_ns", 0.0), nm, v)
+                         for nm, v in per_step.items() if pat in nm]
+                if cands:
+                    chosen.append(max(cands)[1:])
+            if len(chosen) == len(pats):
+                legs[leg] = {"kernels": [nm for nm, _ in chosen],
+                             "fp64_flops": sum(v.get("fp64_flops", 0.0) for _, v in chosen),
+                             "hbm_bytes": sum(v.get("hbm_bytes", 0.0) for _, v in chosen),
+                             "lds_conflict_share": max((v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
+                                                        for _, v in chosen), default=0.0)}
+                break
     return legs, os.path.relpath(files[-1], ROOT)
 
 
