@@ -1,29 +1,26 @@
 // Kalman filter log-likelihood, selector design matrix: "kalman_nt_kernel" -- the fast path of round 2.
 //
-// Same algorithm, step for step, as kalman_sel_kernel<BS, true> (dsge_kalman2.hpp: exact reduction to the retained
-// variables in a states-first ordering, stationary initial covariance by doubling, p x p inverse by in-register
-// Gauss-Jordan, P+ = P - K (P Zm' + jitter K)' + jitter I, steady-state switch with a register-resident mean recursion;
-// the recursion is the one restated in SURVEY.md Appendix B.4 for statespace.py:1151-1157).  What changed is how the two
-// prediction products of a full step -- W = P+[S,S] Tc' and X = Tc W, 7.5 k of the 15.2 k cycles of a full step on the
-// 18-variable bench model -- reach their operands:
+// Same algorithm as kalman_sel_kernel<BS, true> (dsge_kalman2.hpp: exact reduction to the retained variables in a
+// states-first ordering, stationary initial covariance by doubling, p x p inverse by Gauss-Jordan, P+ = P - K (P Zm' +
+// jitter K)' + jitter I, steady-state switch with a register-resident mean recursion; the recursion is the one restated in
+// SURVEY.md Appendix B.4 for statespace.py:1151-1157), rebuilt twice in round 2:
 //
-//   * "NT" form.  W is stored TRANSPOSED, so both products contract over the second index of two row-major operands:
-//       W[i][j] = sum_k P+[i][k] Tc[j][k],        X[r][c] = sum_k Tc[r][k] Wt[c][k].
-//   * an EVEN leading dimension (NP + 2) makes every row 16-byte aligned: one ds_read_b128 feeds two k-steps (the odd
-//     stride of round 1 allowed only ds_read_b64, one per operand element and k-step);
-//   * a stage covers four k-steps (12 loads, 36 FMAs for 3 x 3 blocks) and two stages are in flight; the round-1 loop
-//     had 6 loads / 9 FMAs per stage, which did not cover the LDS latency.
-//   Measured (tools/kalman_phases.py, draw 0, two waves per SIMD): products 7.5 k -> 5.4 k cycles including the mean
-//   prediction and the P Z' panel, full step 15.2 k -> 12.6 k, launch 1.28 -> 1.09 ms per 4096 draws.
+// (1) the two prediction products of a full step -- W = P+[S,S] Tc' and X = Tc W -- in "NT" form: W is stored TRANSPOSED,
+//     so both products contract over the second index of two row-major operands,
+//       W[i][j] = sum_k P+[i][k] Tc[j][k],        X[r][c] = sum_k Tc[r][k] Wt[c][k],
+//     on an EVEN leading dimension (NP + 2: 16-byte aligned rows, one ds_read_b128 per two k-steps), stages of four k-steps
+//     (12 loads, 36 FMAs for 3 x 3 blocks), two stages in flight: full step 15.2 k -> 12.6 k cycles.
+// (2) the measurement update as the latency chain of a lone wave (tools/latency_probe): lane l works on row l & 7 of F in
+//     eight replicated 8-lane groups -- row-per-lane Gauss-Jordan with the pivot row through SGPRs and unscaled rows, the
+//     gain K = (P Zm') Finv from registers (Finv symmetric: no round trip through LDS, one fence less), the steady test
+//     by ballot, the mean prediction as the spare padding column of the X product, per-lane Kahan shares of the quadratic
+//     form, sym(R Q R')[U,U] formed in the prologue from R and q: 12.6 k -> 8.9 k cycles per full step for a lone wave
+//     (tools/kalman_phases.py 1), launch 1.10 -> 0.85 ms per 4096 draws.
 //
-// Two reformulations of the measurement update were built and measured on the way and are NOT used:
-// observation-at-a-time updates on the register blocks (exact for a diagonal H + jitter I; 12 ds_bpermute per observation,
-// 8.4 k + 6.4 k cycles with the jitter K K' correction) and a Gauss-Jordan recursion on the u x p panel with one row per
-// lane (p^2 v_readlane pairs: 11 k cycles).  Both reproduce the oracle to 3e-16 in numpy; neither beats the joint
-// p x p inverse (3.4 k) + gain (1.3 k) + downdate (2.5 k) on this hardware.
+// Measured on the way and NOT used: observation-at-a-time updates, a panel recursion with one row
+// per lane, a per-lane Cholesky of F, the predicted-form recursion, raised wave priority for the slowest draws, a two-wave
+// build of the 32-wide tile.
 #pragma once
-#include <type_traits>
-
 #include "dsge_kalman2.hpp"
 
 namespace dsge {
@@ -32,9 +29,9 @@ template <int BS>
 struct KntSmem {
   static constexpr int NP = Tile<BS>::NP, LDK = NP + 2, PS = 10;
   static constexpr int WT = (NP * LDK > NP * PS) ? NP * LDK : NP * PS;  // W' buffer; the V panel aliases it
-  // doubles: Tc NP*LDK, Wt WT, Pc s_cap*LDK, PZt, Ks NP*PS each, Fi 64, av NP, af NP, vv/dd/hh/zv 8 each; ints perm NP, zpos 8
+  // doubles: Tc NP*LDK, Wt WT, Pc s_cap*LDK, PZt, Ks NP*PS each, av NP, af NP, vv/dd/hh/zv 8 each; ints perm NP, zpos 8
   __host__ __device__ static constexpr size_t doubles(int s_cap) {
-    return (size_t)NP * LDK + WT + (size_t)s_cap * LDK + 2 * (size_t)NP * PS + 64 + 2 * NP + 32 + NP / 2 + 4;
+    return (size_t)NP * LDK + WT + (size_t)s_cap * LDK + 2 * (size_t)NP * PS + 2 * NP + 32 + NP / 2 + 4;
   }
   static size_t bytes(int s_cap) { return sizeof(double) * doubles(s_cap); }
 };
@@ -89,66 +86,6 @@ __device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, co
 #undef NT_FMA
 }
 
-// Calls f(integral_constant<J>) for the wave-uniform j in [0, BS): a chain of scalar branches, so that the column index
-// of a register block is a compile-time constant inside f.  (A select chain over the block's registers is pattern-
-// matched by LLVM into a dynamically indexed array -- the whole covariance block then lives in scratch memory: measured
-// 3.5 k cycles per observation instead of 0.3 k.)
-template <int BS, int J = 0, typename F>
-__device__ __forceinline__ void dispatch_col(int j, F&& f) {
-  if constexpr (J + 1 < BS) {
-    if (j == J)
-      f(std::integral_constant<int, J>{});
-    else
-      dispatch_col<BS, J + 1>(j, f);
-  } else {
-    f(std::integral_constant<int, J>{});
-  }
-}
-
-// One scalar measurement update: observation with selector value zvo on state z = lz * BS + JZ, noise variance hto
-// (= h + jitter), residual constant yd = y_o - d_o.
-template <int BS, int JZ>
-__device__ __forceinline__ void seq_update_obs(double (&Pb)[BS][BS], double (&arow)[BS], int lane, int lc, int lz,
-                                               double zvo, double hto, double yd, double& step_quad, double& step_mant,
-                                               int& step_exp) {
-  double grow[BS], gcol[BS];
-#pragma unroll
-  for (int i = 0; i < BS; ++i) grow[i] = zvo * __shfl(Pb[i][JZ], (lane & 56) | lz, 64);  // zv P[lr*BS+i][z]
-#pragma unroll
-  for (int j = 0; j < BS; ++j) gcol[j] = zvo * __shfl(Pb[j][JZ], (lc << 3) | lz, 64);     // zv P[lc*BS+j][z] (P symmetric)
-  const double gz = readlane_f64(grow[JZ], lz << 3);                                      // zv P[z][z]
-  const double az = readlane_f64(arow[JZ], lz << 3);                                      // a[z]
-  const double f = fma(zvo, gz, hto);
-  const double finv = fast_rcp(f);
-  const double v = yd - zvo * az;
-  const double w = v * finv;
-  step_quad = fma(v, w, step_quad);
-  int e;
-  step_mant *= frexp(f, &e);
-  step_exp += e;
-#pragma unroll
-  for (int i = 0; i < BS; ++i) arow[i] = fma(grow[i], w, arow[i]);
-#pragma unroll
-  for (int i = 0; i < BS; ++i)
-#pragma unroll
-    for (int j = 0; j < BS; ++j) Pb[i][j] = fma(-(grow[i] * gcol[j]), finv, Pb[i][j]);
-}
-
-// Db += kap * c c',  c = column z = lz * BS + JZ of the (filtered) covariance block
-template <int BS, int JZ>
-__device__ __forceinline__ void seq_gain_term(const double (&Pb)[BS][BS], double (&Db)[BS][BS], int lane, int lc, int lz,
-                                              double kap) {
-  double crow[BS], ccol[BS];
-#pragma unroll
-  for (int i = 0; i < BS; ++i) crow[i] = kap * __shfl(Pb[i][JZ], (lane & 56) | lz, 64);
-#pragma unroll
-  for (int j = 0; j < BS; ++j) ccol[j] = __shfl(Pb[j][JZ], (lc << 3) | lz, 64);
-#pragma unroll
-  for (int i = 0; i < BS; ++i)
-#pragma unroll
-    for (int j = 0; j < BS; ++j) Db[i][j] = fma(crow[i], ccol[j], Db[i][j]);
-}
-
 // DBG = true: the instance tools/kalman_phases.py launches (phase stamps of draw 0 in `dbg`); the product instance carries
 // neither the stamps nor their registers.
 template <int BS, bool DBG = false>
@@ -168,8 +105,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
   double* Pc = Wt + KntSmem<BS>::WT; // s_cap x LDK P+ restricted to the state block
   double* PZt = Pc + s_cap * LDK;    // NP x PS     (predicted P) Z', unmasked
   double* Ks = PZt + NP * PS;        // NP x PS     K = P Zm' Finv  (kept through the prediction: the steady loop reads it)
-  double* Fi = Ks + NP * PS;         // 8 x 8       Finv
-  double* av = Fi + 64;              // NP          predicted state
+  double* av = Ks + NP * PS;         // NP          predicted state
   double* af = av + NP;              // NP          filtered state
   double* vv = af + NP;              // 8 innovation
   double* dd = vv + 8;               // 8 obs intercept
