@@ -423,7 +423,7 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
                                    n_lead_hint=None, options=None):
     """logp and its reverse-mode gradient per draw (include/dsge_hip.h: dsge_solve_kalman_logp_grad_batched): what
     pytensor autodiff computes for the reference's logp graph, on the device.  ``q``: (k,) or (batch, k) diagonal shock
-    variances; ``Z``: selector design matrix (p, n), p <= 8; n <= 48.
+    variances; ``Z``: selector design matrix (p, n), p <= 8; n <= 56.
     Returns dict(logp, status, A_bar, B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar])."""
     A, B, C = _check_abc(A, B, C)
     D = _f64(D, 3)

@@ -423,7 +423,7 @@ int dsge_selection_batched(const double* A, const double* B, const double* C, co
 
 int dsge_policy_adjoints_batched(const double* B, const double* C, const double* T, const double* T_bar, int batch,
                                  int n, double* A_bar, double* B_bar, double* C_bar, int32_t* status, void* stream) {
-  int rc = check_common(batch, n, 48);  // [M' | T_bar | C'] + two operands in LDS: n <= 48
+  int rc = check_common(batch, n, 56);  // [M' | T_bar | C'] + two operands in LDS: n <= 56 (132 KB at the 64-wide tile, not built)
   if (rc) return rc;
   if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
@@ -434,7 +434,7 @@ int dsge_policy_adjoints_batched(const double* B, const double* C, const double*
 int dsge_selection_adjoints_batched(const double* B, const double* C, const double* T, const double* R, const double* R_bar,
                                     int batch, int n, int k, double* B_bar, double* C_bar, double* D_bar, double* T_bar,
                                     void* stream) {
-  int rc = check_common(batch, n, 48);  // (the tile cascade of grad_assemble_kernel stops at 48)
+  int rc = check_common(batch, n, 56);  // (grad_assemble_kernel: 153 KB of LDS at the 56-wide tile, 199 KB at 64)
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!B || !C || !T || !R || !R_bar || !B_bar || !C_bar || !D_bar || !T_bar) return fail(DSGE_ERR_INVALID, "null pointer");
@@ -782,7 +782,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
                                         double missing_fill, int n_filter_hint, int n_lead_hint, double* logp_out,
                                         int32_t* status_out, double* A_bar, double* B_bar, double* C_bar, double* D_bar,
                                         double* q_bar, double* d_bar, double* h_bar, void* stream) {
-  int rc = check_common(batch, n, 48);
+  int rc = check_common(batch, n, 56);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > 8) return fail(DSGE_ERR_INVALID, "gradient path: p out of range (1..8)");
@@ -1128,7 +1128,7 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
 int dsge_selection_adjoints_batched_host(const double* B, const double* C, const double* T, const double* R,
                                          const double* R_bar, int batch, int n, int k, double* B_bar, double* C_bar,
                                          double* D_bar, double* T_bar) {
-  int rc = check_common(batch, n, 48);
+  int rc = check_common(batch, n, 56);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!B || !C || !T || !R || !R_bar || !B_bar || !C_bar || !D_bar || !T_bar) return fail(DSGE_ERR_INVALID, "null pointer");
@@ -1158,7 +1158,7 @@ int dsge_selection_adjoints_batched_host(const double* B, const double* C, const
 
 int dsge_policy_adjoints_batched_host(const double* B, const double* C, const double* T, const double* T_bar,
                                       int batch, int n, double* A_bar, double* B_bar, double* C_bar, int32_t* status) {
-  int rc = check_common(batch, n, 48);
+  int rc = check_common(batch, n, 56);
   if (rc) return rc;
   if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
@@ -1333,7 +1333,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
                                              int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
                                              double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
                                              double* d_bar, double* h_bar) {
-  int rc = check_common(batch, n, 48);
+  int rc = check_common(batch, n, 56);
   if (rc) return rc;
   if (k < 1 || k > n || p < 1 || p > 8 || T_len < 0) return fail(DSGE_ERR_INVALID, "bad sizes");
   if (!A || !B || !C || !D || !q || !Z || !y || !logp_out || !status_out || !A_bar || !B_bar || !C_bar || !D_bar || !q_bar)

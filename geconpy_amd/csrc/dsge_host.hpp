@@ -47,7 +47,7 @@ int set_lds(K kernel, size_t bytes) {
     case 4: { constexpr int BS = 4; __VA_ARGS__; } break;                            \
     case 5: { constexpr int BS = 5; __VA_ARGS__; } break;                            \
     case 6: { constexpr int BS = 6; __VA_ARGS__; } break;                            \
-    case 7: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 7 : 6); __VA_ARGS__; } break; \
+    case 7: if (MAXBS >= 7) { constexpr int BS = (MAXBS >= 7 ? 7 : 6); __VA_ARGS__; } break; \
     case 8: if (MAXBS >= 8) { constexpr int BS = (MAXBS >= 8 ? 8 : 6); __VA_ARGS__; } break; \
     default: break;                                                                  \
   }

@@ -41,7 +41,7 @@ int launch_adjoint(const double* B, const double* C, const double* T, const doub
                    double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 6, {
+  DISPATCH_BS(bs, 7, {
     rc = set_lds(dsge::adjoint_kernel<BS>, dsge::AdjSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::adjoint_kernel<BS>, dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,

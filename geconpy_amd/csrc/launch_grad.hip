@@ -45,7 +45,7 @@ int launch_grad_assemble(const double* B, const double* C, const double* T, cons
                          double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st, const double* Rbar_in) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
-  DISPATCH_BS(bs, 6, {
+  DISPATCH_BS(bs, 7, {
     rc = set_lds(dsge::grad_assemble_kernel<BS>, dsge::GaSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::grad_assemble_kernel<BS>, dim3(batch), dim3(64), dsge::GaSmem<BS>::bytes, st, B, C, T, R, q,

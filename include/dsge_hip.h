@@ -342,7 +342,7 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
  *   (kron(T, C') + kron(I, T'C') + kron(I, B')) vec(S) = -vec(T_bar)   <=>   (B + C T)' S + C' S T' = -T_bar.
  * The reference factorises the n^2 x n^2 Kronecker matrix; here the equivalent Stein equation is solved
  * by a doubling iteration (valid for a determinate solution: rho(T) < 1 and stable-inverse roots).
- *   B, C, T, T_bar, A_bar, B_bar, C_bar : [batch][n][n], n <= 48;  status : [batch] (non-zero = not converged)
+ *   B, C, T, T_bar, A_bar, B_bar, C_bar : [batch][n][n], n <= 56;  status : [batch] (non-zero = not converged)
  */
 int dsge_policy_adjoints_batched(const double* B, const double* C, const double* T, const double* T_bar,
                                  int batch, int n, double* A_bar, double* B_bar, double* C_bar,
@@ -356,7 +356,7 @@ int dsge_policy_adjoints_batched_host(const double* B, const double* C, const do
  * (pt_compute_selection_matrix, gEconpy/solvers/shared.py:74-75), so pytensor.grad flows through it into B, C, D and T;
  * this is that reverse-mode rule as one launch.  With M = C T + B and the cotangent R_bar of R:
  *   G = -M^-T R_bar,   D_bar = G,   B_bar = G R',   C_bar = G R' T',   T_bar = C' G R'
- *   B, C, T, B_bar, C_bar, T_bar : [batch][n][n]   R, R_bar, D_bar : [batch][n][k]   n <= 48
+ *   B, C, T, B_bar, C_bar, T_bar : [batch][n][n]   R, R_bar, D_bar : [batch][n][k]   n <= 56
  * T_bar is the contribution of R only: the caller adds the direct cotangent of T and passes the sum on to
  * dsge_policy_adjoints_batched.
  */
@@ -527,7 +527,7 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
  * kernels: Kalman reverse sweep on the reduced model (stores every predicted (a_t, P_t) in library scratch, the
  * batch is processed in chunks of <= 16 GiB of scratch), reverse of the assembly, policy-function adjoints.
  *   q : [k] (q_batched=0) or [batch][k] diagonal shock covariance;  Z : selector design matrix (one non-zero per
- *       row, distinct columns), [p][n] or [batch][p][n];  p <= 8;  n <= 48
+ *       row, distinct columns), [p][n] or [batch][p][n];  p <= 8;  n <= 56
  *   A_bar,B_bar,C_bar : [batch][n][n];  D_bar : [batch][n][k];  q_bar : [batch][k] (also for a shared q: sum over
  *       the batch for a joint logp);  d_bar, h_bar : [batch][p] or NULL
  *   Contract: the columns of A that are exactly zero (non-state variables) are treated as structurally zero -- T has

@@ -179,6 +179,30 @@ def test_gradient_sw_shaped_against_extrapolated_differences():
     assert_allclose(analytic, d3, rtol=1e-7, atol=1e-8 * max(1.0, abs(d3)))
 
 
+@pytest.mark.parametrize("n,ns,nl", [(52, 23, 15), (56, 25, 16)])
+def test_gradient_on_the_56_wide_tile(n, ns, nl):
+    """Systems of 49..56 variables (round 2: the 7 x 7-block instances of adjoint_kernel and grad_assemble_kernel, 101 and
+    153 KB of LDS): logp against the oracle, directional derivatives against central differences of the oracle."""
+    rng = np.random.default_rng(n)
+    k = p = 7
+    nb = 2
+    sysm = [wl.sw_shaped_system(6100 + 3 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    q = np.full((nb, k), 1e-4) * rng.uniform(0.5, 2.0, (nb, k))
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = rng.normal(0, 0.02, (30, p))
+    y[4, 1] = np.nan
+    d = rng.normal(0, 0.01, p)
+    h = np.full(p, 1e-4)
+    out = batched.solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=d, Hdiag=h, tol=1e-13, max_iter=200)
+    assert np.all(out["status"] == 0)
+    for i in range(nb):
+        g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+        assert_allclose(out["logp"][i], _oracle_logp(A[i], B[i], C[i], D[i], q[i], Z, y, d, h), rtol=1e-9)
+        _directional_check(A[i], B[i], C[i], D[i], q[i], Z, y, d, h, g, rng, n_dirs=1)
+
+
 def test_gradient_failed_and_unsupported_draws():
     b = wl.sw_shaped_batch(3)
     om = wl.sw_shaped_observation_model()
