@@ -470,9 +470,11 @@ def main():
                          and not (p <= 3 and 0 < (hints[0] or 0) and (hints[0] or 0) + p <= 6)
                          and n * ((k + 1) & ~1) <= np_lo * (np_lo + 2))
         nd_ = n - h_defl
-        one_launch = (h_defl and h_defl + 3 * nd_ + k <= 128 and nd_ + k <= 64
-                      and (bs_n, bs_d) in {(3, 2), (3, 3), (4, 3), (4, 4), (5, 4), (6, 4), (6, 5)})  # launch_cr_fused
-        names = {"solver": ((f"dsge::cr_fused_kernel{'_occ2' if bs_d == 4 else ''}<{bs_n},{bs_d}> (static-variable deflation {n} -> {nd_}: "
+        ncol_ = h_defl + 3 * nd_ + k  # launch_cr_fused: two columns of the QR per lane up to 128, three up to 192
+        one_launch = (h_defl and nd_ + k <= 64 and
+                      ((ncol_ <= 128 and (bs_n, bs_d) in {(3, 2), (3, 3), (4, 3), (4, 4), (5, 4), (6, 4), (6, 5)}) or
+                       (128 < ncol_ <= 192 and (bs_n, bs_d) in {(6, 5), (7, 5), (7, 6), (8, 6)})))
+        names = {"solver": ((f"dsge::cr_fused_kernel{'_occ2' if bs_d == 4 and ncol_ <= 128 else ''}<{bs_n},{bs_d}> (static-variable deflation {n} -> {nd_}: "
                              "QR of the static columns + cycle reduction + back-substitution, one launch)") if one_launch else
                             (f"dsge::cr_deflate_kernel<{bs_n}> + cr_compact_kernel<{bs_d}> + cr_inflate_kernel<{bs_d}> (static-variable "
                              f"deflation {n} -> {nd_}, three launches)") if h_defl else f"dsge::cr_compact_kernel<{bs_n}>")

@@ -133,49 +133,51 @@ __device__ __forceinline__ bool crd_col_source(int cv, const double* __restrict_
   return true;
 }
 
-// Q' applied to the 128 columns c0 .. c0+127 of [B_st | B_dy | A_dy | C_dy | D]: two columns per lane, in registers, all
-// rows of a column loaded in flight.  The first h columns (lanes 0..h-1 of the first chunk) are B_st itself: lane j
-// publishes pivot column j to LDS (V), from where every lane (and a second chunk, for systems with more than 128 columns)
-// reads it as a broadcast; no wave reductions anywhere.  Rows 0..h-1 of Q'[...] go to `tp` (h x ncols, row-major); on
-// return colA / colB hold the rows of the REDUCED system (rows 0..nd-1, zeros below).
-template <int NM, typename IT>
+// Q' applied to the 64 NC columns c0 .. c0 + 64 NC - 1 of [B_st | B_dy | A_dy | C_dy | D]: NC columns per lane (column
+// c0 + 64 q + lane in col[q]), in registers, all rows of a column loaded in flight.  The first h columns (lanes 0..h-1 of
+// the first chunk) are B_st itself: lane j publishes pivot column j to LDS (V), from where every lane (and a later chunk,
+// for systems with more columns than one pass holds) reads it as a broadcast; no wave reductions anywhere.  Rows 0..h-1 of
+// Q'[...] go to `tp` (h x ncols, row-major); on return col[q] holds the rows of the REDUCED system (rows 0..nd-1, zeros
+// below).
+template <int NM, int NC, typename IT>
 __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const double* __restrict__ B,
                                              const double* __restrict__ C, const double* __restrict__ D, size_t off,
                                              size_t offk, int n, int k, int h, int c0, const IT* dyi, const IT* sti,
-                                             double* V, double* __restrict__ tp, int lane, double (&colA)[NM],
-                                             double (&colB)[NM], bool& actA, bool& actB, bool skip_zero_ac = false) {
+                                             double* V, double* __restrict__ tp, int lane, double (&col)[NC][NM],
+                                             bool (&act)[NC], bool skip_zero_ac = false) {
   const int ncols = h + 3 * (n - h) + k;
-  const double *srcA, *srcB;
-  int ssA, ssB;
-  const int cA = c0 + lane, cB = c0 + 64 + lane;
-  actA = crd_col_source(cA, A, B, C, D, off, offk, n, k, h, dyi, sti, srcA, ssA);
-  actB = crd_col_source(cB, A, B, C, D, off, offk, n, k, h, dyi, sti, srcB, ssB);
+  const double* src[NC];
+  int ss[NC], cv[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    cv[q] = c0 + 64 * q + lane;
+    act[q] = crd_col_source(cv[q], A, B, C, D, off, offk, n, k, h, dyi, sti, src[q], ss[q]);
+  }
 #pragma unroll
   for (int r = 0; r < NM; ++r) {  // unconditional loads (inactive lanes walk a valid column, rows are clamped)
     const int rr = r < n ? r : n - 1;
-    colA[r] = srcA[(size_t)rr * ssA];
-    colB[r] = srcB[(size_t)rr * ssB];
-  }
-  __builtin_amdgcn_sched_barrier(0);  // all 2 * NM loads in flight before the first select waits for one
 #pragma unroll
-  for (int r = 0; r < NM; ++r) {
-    colA[r] = (r < n && actA) ? colA[r] : 0.0;
-    colB[r] = (r < n && actB) ? colB[r] : 0.0;
+    for (int q = 0; q < NC; ++q) col[q][r] = src[q][(size_t)rr * ss[q]];
   }
+  __builtin_amdgcn_sched_barrier(0);  // all NC * NM loads in flight before the first select waits for one
+#pragma unroll
+  for (int r = 0; r < NM; ++r)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) col[q][r] = (r < n && act[q]) ? col[q][r] : 0.0;
   // skip_zero_ac: an all-zero column of A_dy or C_dy stays all-zero under the reflectors; its h top entries are not
   // written (the reader masks them: crd_inflate_* with the column masks) -- 30 of the 107 columns on the SW-shaped system
-  bool wrA = actA, wrB = actB;
-  if (skip_zero_ac) {
-    bool nzA = false, nzB = false;
+  bool wr[NC];
 #pragma unroll
-    for (int r = 0; r < NM; ++r) {
-      nzA = nzA || (colA[r] != 0.0);
-      nzB = nzB || (colB[r] != 0.0);
+  for (int q = 0; q < NC; ++q) {
+    wr[q] = act[q];
+    if (skip_zero_ac) {
+      bool nz = false;
+#pragma unroll
+      for (int r = 0; r < NM; ++r) nz = nz || (col[q][r] != 0.0);
+      const int nd_ = n - h;
+      const bool ac = cv[q] >= h + nd_ && cv[q] < h + 3 * nd_;
+      wr[q] = act[q] && (nz || !ac);
     }
-    const int nd_ = n - h;
-    const bool acA = cA >= h + nd_ && cA < h + 3 * nd_, acB = cB >= h + nd_ && cB < h + 3 * nd_;
-    wrA = actA && (nzA || !acA);
-    wrB = actB && (nzB || !acB);
   }
   // Row j is final once reflector j has been applied: it goes straight to the top block and the columns are shifted
   // up by one row, so that the pivot is always register row 0 (no index-dependent selects, which cost a scalar lane
@@ -183,15 +185,15 @@ __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const
   // The reflector is never materialised: with u = column j below the pivot (published to LDS by lane j of the first
   // chunk and read back as broadcasts -- 2 x NM v_readlane per sweep cost more than the whole arithmetic),
   // v = [1; scal u], so v'x = x_0 + scal u'x and the raw dots u'x ride along with the norm sweep; the second sweep
-  // updates and shifts.  Registers: the two columns only.
+  // updates and shifts.  Registers: the columns only.
   for (int j = 0; j < h; ++j) {
     double xn2 = 0.0, alpha;
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    double d0[NC], d1[NC];
     if (c0 == 0) {  // publish the pivot column (lane j of the first chunk)
       if (lane == j) {
         double2* vw = reinterpret_cast<double2*>(V + j * NM);
 #pragma unroll
-        for (int r2 = 0; r2 < NM / 2; ++r2) vw[r2] = make_double2(colA[2 * r2], colA[2 * r2 + 1]);
+        for (int r2 = 0; r2 < NM / 2; ++r2) vw[r2] = make_double2(col[0][2 * r2], col[0][2 * r2 + 1]);
       }
       wave_sync();
     }
@@ -200,17 +202,20 @@ __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const
       const double2 t0 = vj2[0];
       alpha = t0.x;
       xn2 = t0.y * t0.y;
-      a0 = t0.y * colA[1];
-      b0 = t0.y * colB[1];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        d0[q] = t0.y * col[q][1];
+        d1[q] = 0.0;
+      }
 #pragma unroll
       for (int r2 = 1; r2 < NM / 2; ++r2) {
         const double2 t = vj2[r2];
         xn2 = fma(t.x, t.x, xn2);
-        a1 = fma(t.x, colA[2 * r2], a1);
-        b1 = fma(t.x, colB[2 * r2], b1);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) d1[q] = fma(t.x, col[q][2 * r2], d1[q]);
         xn2 = fma(t.y, t.y, xn2);
-        a0 = fma(t.y, colA[2 * r2 + 1], a0);
-        b0 = fma(t.y, colB[2 * r2 + 1], b0);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) d0[q] = fma(t.y, col[q][2 * r2 + 1], d0[q]);
       }
     }
     double beta = alpha, scal = 0.0, tj = 0.0;
@@ -222,27 +227,24 @@ __device__ __forceinline__ void crd_qr_chunk(const double* __restrict__ A, const
     }
     // w = -tau v'x; the pivot column (beta e_0 exactly) and the columns left of it (all zeros by now) are set directly
     const bool left = (c0 == 0) && (lane <= j);
-    const double wA = left ? 0.0 : -tj * fma(scal, a0 + a1, colA[0]);
-    const double wB = -tj * fma(scal, b0 + b1, colB[0]);
-    const double topA = left ? ((lane == j) ? beta : 0.0) : colA[0] + wA, topB = colB[0] + wB;
-    if (wrA) tp[(size_t)j * ncols + cA] = topA;
-    if (wrB) tp[(size_t)j * ncols + cB] = topB;
-    const double wsA = wA * scal, wsB = wB * scal;
-    {  // update and shift up by one row
-      const double2 t0 = vj2[0];
-      colA[0] = left ? 0.0 : fma(t0.y, wsA, colA[1]);
-      colB[0] = fma(t0.y, wsB, colB[1]);
+    const double2 t0 = vj2[0];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const bool lf = (q == 0) && left;
+      const double w = lf ? 0.0 : -tj * fma(scal, d0[q] + d1[q], col[q][0]);
+      const double topv = lf ? ((lane == j) ? beta : 0.0) : col[q][0] + w;
+      if (wr[q]) tp[(size_t)j * ncols + cv[q]] = topv;
+      const double ws = w * scal;
+      // update and shift up by one row
+      col[q][0] = lf ? 0.0 : fma(t0.y, ws, col[q][1]);
 #pragma unroll
       for (int r2 = 1; r2 < NM / 2; ++r2) {
         const double2 t = vj2[r2];
-        colA[2 * r2 - 1] = left ? 0.0 : fma(t.x, wsA, colA[2 * r2]);
-        colB[2 * r2 - 1] = fma(t.x, wsB, colB[2 * r2]);
-        colA[2 * r2] = left ? 0.0 : fma(t.y, wsA, colA[2 * r2 + 1]);
-        colB[2 * r2] = fma(t.y, wsB, colB[2 * r2 + 1]);
+        col[q][2 * r2 - 1] = lf ? 0.0 : fma(t.x, ws, col[q][2 * r2]);
+        col[q][2 * r2] = lf ? 0.0 : fma(t.y, ws, col[q][2 * r2 + 1]);
       }
+      col[q][NM - 1] = 0.0;
     }
-    colA[NM - 1] = 0.0;
-    colB[NM - 1] = 0.0;
   }
 }
 
@@ -287,9 +289,9 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
     const int ntotc = h + nv;
     const bool multi = ntotc > 128;
     for (int c0 = 0; c0 < ntotc; c0 += 128) {
-      double colA[NM], colB[NM];
-      bool actA, actB;
-      crd_qr_chunk<NM>(A, B, C, D, off, offk, n, k, h, c0, dyi, sti, V, tp, lane, colA, colB, actA, actB);
+      double col[2][NM];
+      bool act[2];
+      crd_qr_chunk<NM, 2>(A, B, C, D, off, offk, n, k, h, c0, dyi, sti, V, tp, lane, col, act);
       if (multi) wave_sync();
       // everything but B_st has rows in the reduced system
       auto destination = [&](int cv, double*& dst, int& ds) -> bool {
@@ -306,18 +308,15 @@ __global__ __launch_bounds__(64) void cr_deflate_kernel(const double* __restrict
         dst = (blk == 0 ? Bred : (blk == 1 ? Ared : Cred)) + offr + (c - blk * nd);
         return true;
       };
-      double *dstA, *dstB;
-      int dsA, dsB;
-      const bool redA = destination(c0 + lane, dstA, dsA), redB = destination(c0 + 64 + lane, dstB, dsB);
-      if (redA) {
 #pragma unroll
-        for (int r = 0; r < NM; ++r)
-          if (r < nd) dstA[(size_t)r * dsA] = colA[r];
-      }
-      if (redB) {
+      for (int q = 0; q < 2; ++q) {
+        double* dst;
+        int ds;
+        if (destination(c0 + 64 * q + lane, dst, ds)) {
 #pragma unroll
-        for (int r = 0; r < NM; ++r)
-          if (r < nd) dstB[(size_t)r * dsB] = colB[r];
+          for (int r = 0; r < NM; ++r)
+            if (r < nd) dst[(size_t)r * ds] = col[q][r];
+        }
       }
     }
     if (lane == 0) {

@@ -17,7 +17,8 @@
 // (131 MB written and read back twice), two launches and their tails less.  Draws the fused kernel cannot take -- fewer
 // static variables than the bound h, s + l or s + k beyond the reduced tile, a numerically singular R_st -- are flagged
 // DSGE_ST_INTERNAL_RERUN and solved by the full-size dense kernel afterwards, exactly as on the three-launch path.
-// Limits checked by the launcher: h + 3 nd + k <= 128 (one column chunk), nd + k <= 64.
+// Limits checked by the launcher: h + 3 nd + k <= 128 with two columns per lane, <= 192 with three (n = 46 .. 64), and
+// nd + k <= 64.
 #pragma once
 #include "dsge_cr_compact.hpp"
 #include "dsge_cr_deflate.hpp"
@@ -48,7 +49,8 @@ __device__ __forceinline__ unsigned long long crf_place(unsigned long long b, in
   return shift >= 0 ? (shift < 64 ? b << shift : 0ull) : (-shift < 64 ? b >> (-shift) : 0ull);
 }
 
-template <int BSF, int BSD>
+// NC = columns of [B_st | B_dy | A_dy | C_dy | D] per lane: 2 for h + 3 nd + k <= 128, 3 up to 192 (n = 46 .. 64)
+template <int BSF, int BSD, int NC>
 __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, const double* __restrict__ B,
                                               const double* __restrict__ C, const double* __restrict__ D, int batch, int n,
                                               int k, int h, int max_iter, double tol, double* __restrict__ top,
@@ -94,41 +96,37 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   int s, l;
   unsigned long long state_cols = 0ull, maskS_red = 0ull, maskL_red = 0ull;  // (red: over the reduced variables)
   {
-    double colA[NMF], colB[NMF];
-    bool actA, actB;
-    crd_qr_chunk<NMF>(A, B, C, D, off, offk, n, k, h, 0, dyi, sti, /*V=*/smem, tp, lane, colA, colB, actA, actB,
-                      /*skip_zero_ac=*/true);
-    // block (0 B, 1 A, 2 C, 3 D, -1 none) and column inside the block of this lane's two columns
-    auto classify = [&](int cv, bool act, int& blk, int& d) {
-      const int c = cv - h;
-      blk = -1;
-      d = 0;
-      if (!act || c < 0) return;
-      blk = (c >= nd) + (c >= 2 * nd) + (c >= 3 * nd);
-      d = c - blk * nd;
-    };
-    int blkA, dA, blkB, dB;
-    classify(lane, actA, blkA, dA);
-    classify(64 + lane, actB, blkB, dB);
-    bool nzA = false, nzB = false;  // (rows >= nd of a column are zeros by now)
+    double col[NC][NMF];
+    bool act[NC];
+    crd_qr_chunk<NMF, NC>(A, B, C, D, off, offk, n, k, h, 0, dyi, sti, /*V=*/smem, tp, lane, col, act,
+                          /*skip_zero_ac=*/true);
+    // block (0 B, 1 A, 2 C, 3 D, -1 none) and column inside the block of this lane's columns 64 q + lane
+    int blk[NC], dcol[NC];
+    unsigned long long bS = 0ull, bL = 0ull;  // non-zero columns of A_dy (states) / C_dy (leads), over the reduced variables
 #pragma unroll
-    for (int r = 0; r < NMF; ++r) {
-      nzA = nzA || (colA[r] != 0.0);
-      nzB = nzB || (colB[r] != 0.0);
+    for (int q = 0; q < NC; ++q) {
+      const int c = 64 * q + lane - h;
+      blk[q] = -1;
+      dcol[q] = 0;
+      if (act[q] && c >= 0) {
+        blk[q] = (c >= nd) + (c >= 2 * nd) + (c >= 3 * nd);
+        dcol[q] = c - blk[q] * nd;
+      }
+      bool nz = false;  // (rows >= nd of a column are zeros by now)
+#pragma unroll
+      for (int r = 0; r < NMF; ++r) nz = nz || (col[q][r] != 0.0);
+      bS |= crf_place(__ballot(blk[q] == 1 && nz), 64 * q - (h + nd));
+      bL |= crf_place(__ballot(blk[q] == 2 && nz), 64 * q - (h + 2 * nd));
     }
-    // non-zero columns of A_dy (states) and C_dy (leads), as bit masks over the reduced variables
     const unsigned long long ndmask = (nd >= 64) ? ~0ull : ((1ull << nd) - 1ull);
-    const unsigned long long maskS = (crf_place(__ballot(blkA == 1 && nzA), -(h + nd)) |
-                                      crf_place(__ballot(blkB == 1 && nzB), 64 - (h + nd))) & ndmask;
-    const unsigned long long maskL = (crf_place(__ballot(blkA == 2 && nzA), -(h + 2 * nd)) |
-                                      crf_place(__ballot(blkB == 2 && nzB), 64 - (h + 2 * nd))) & ndmask;
+    const unsigned long long maskS = bS & ndmask, maskL = bL & ndmask;
     s = __popcll(maskS);
     l = __popcll(maskL);
     maskS_red = maskS;
     maskL_red = maskL;
     if (s + l > NPD || s + k > NPD) return hand_over();
     {  // the non-zero columns of T, in the caller's variable numbering: bit v <=> v is dynamic and a state
-      const unsigned long long below = (lane < 64) ? ((1ull << lane) - 1ull) : 0ull;
+      const unsigned long long below = (1ull << lane) - 1ull;
       const bool dyn = (lane < n) && !((smask >> lane) & 1ull);
       const int dred = lane - __popcll(smask & below);
       state_cols = __ballot(dyn && ((maskS >> (dred & 63)) & 1ull));
@@ -146,36 +144,36 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
     }
     wave_sync();
     // the columns of the reduced system -> W = [B_dy | A_dy[:,S] C_dy[:,L]] (LDS); [A_dy[:,S] | D_red] -> global scratch
-    auto deposit = [&](const double (&col)[NMF], int blk, int d) {
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const int d = dcol[q];
       const unsigned long long below = (1ull << d) - 1ull;
       int lcol = -1, gcol = -1;  // column of W / of the scratch record
-      if (blk == 0) {
+      if (blk[q] == 0) {
         lcol = d;
-      } else if (blk == 1) {
+      } else if (blk[q] == 1) {
         if ((maskS >> d) & 1ull) {
           gcol = __popcll(maskS & below);
           lcol = NPD + gcol;
         }
-      } else if (blk == 2) {
+      } else if (blk[q] == 2) {
         if ((maskL >> d) & 1ull) lcol = NPD + s + __popcll(maskL & below);
-      } else if (blk == 3) {
+      } else if (blk[q] == 3) {
         gcol = s + d;
       }
       if (lcol >= 0) {
         double* dst = W + lcol;
 #pragma unroll
         for (int r = 0; r < NMF; ++r)
-          if (r < nd) dst[r * LDW] = col[r];
+          if (r < nd) dst[r * LDW] = col[q][r];
       }
       if (gcol >= 0) {  // (column-major: a lane writes its column contiguously, unused columns are never touched)
         double* dst = rh + (size_t)gcol * nd;
 #pragma unroll
         for (int r = 0; r < NMF; ++r)
-          if (r < nd) dst[r] = col[r];
+          if (r < nd) dst[r] = col[q][r];
       }
-    };
-    deposit(colA, blkA, dA);
-    deposit(colB, blkB, dB);
+    }
   }
   wave_sync();
 
@@ -249,7 +247,7 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   if (colmask_out && lane == 0) colmask_out[draw] = state_cols;
 }
 
-template <int BSF, int BSD>
+template <int BSF, int BSD, int NC = 2>
 __global__ __launch_bounds__(64) void cr_fused_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                        const double* __restrict__ C, const double* __restrict__ D, int batch,
                                                        int n, int k, int h, int max_iter, double tol,
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(64) void cr_fused_kernel(const double* __restrict__
                                                        double* __restrict__ T_out, double* __restrict__ R_out,
                                                        int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
                                                        unsigned long long* __restrict__ colmask_out) {
-  cr_fused_body<BSF, BSD>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out, colmask_out);
+  cr_fused_body<BSF, BSD, NC>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out, colmask_out);
 }
 
 // the register budget of two waves per SIMD for the 4 x 4 reduced tile (see cr_compact_kernel_occ2)
@@ -267,7 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int batch, int n, int k, int h, int max_iter, double tol, double* __restrict__ top, double* __restrict__ rhs,
     double* __restrict__ T_out, double* __restrict__ R_out, int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
     unsigned long long* __restrict__ colmask_out) {
-  cr_fused_body<BSF, BSD>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out, colmask_out);
+  cr_fused_body<BSF, BSD, 2>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter_out, colmask_out);
 }
 
 }  // namespace dsge

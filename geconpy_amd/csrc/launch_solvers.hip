@@ -112,21 +112,24 @@ void cr_deflation_reset() {
 
 // deflation + cycle reduction + inflation in one launch; *done = 0 if no kernel instance covers (n, n - h)
 namespace {
-template <int BSF, int BSD>
+template <int BSF, int BSD, int NC>
 int launch_cr_fused_inst(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, int h,
                          int max_iter, double tol, double* top, double* rhs, double* T_out, double* R_out, int32_t* status,
                          int32_t* n_iter, hipStream_t st, unsigned long long* colmask) {
   using SM = dsge::CrfSmem<BSF, BSD>;
   int rc;
-  if (BSD == 4 && opt().cr_two_waves) {
-    if ((rc = set_lds(dsge::cr_fused_kernel_occ2<BSF, BSD>, SM::bytes))) return rc;
-    hipLaunchKernelGGL((dsge::cr_fused_kernel_occ2<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
-                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter, colmask);
-  } else {
-    if ((rc = set_lds(dsge::cr_fused_kernel<BSF, BSD>, SM::bytes))) return rc;
-    hipLaunchKernelGGL((dsge::cr_fused_kernel<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
-                       max_iter, tol, top, rhs, T_out, R_out, status, n_iter, colmask);
+  if constexpr (BSD == 4 && NC == 2) {
+    if (opt().cr_two_waves) {
+      if ((rc = set_lds(dsge::cr_fused_kernel_occ2<BSF, BSD>, SM::bytes))) return rc;
+      hipLaunchKernelGGL((dsge::cr_fused_kernel_occ2<BSF, BSD>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
+                         max_iter, tol, top, rhs, T_out, R_out, status, n_iter, colmask);
+      HIP_TRY(hipGetLastError());
+      return DSGE_SUCCESS;
+    }
   }
+  if ((rc = set_lds(dsge::cr_fused_kernel<BSF, BSD, NC>, SM::bytes))) return rc;
+  hipLaunchKernelGGL((dsge::cr_fused_kernel<BSF, BSD, NC>), dim3(batch), dim3(64), SM::bytes, st, A, B, C, D, batch, n, k, h,
+                     max_iter, tol, top, rhs, T_out, R_out, status, n_iter, colmask);
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
 }
@@ -137,8 +140,12 @@ int launch_cr_fused(const double* A, const double* B, const double* C, const dou
                     int* done, unsigned long long* colmask) {
   *done = 0;
   const int nd = n - h, bsf = tile_bs(n), bsd = tile_bs(nd);
-  const bool have = (bsf == 3 && (bsd == 2 || bsd == 3)) || (bsf == 4 && (bsd == 3 || bsd == 4)) ||
-                    (bsf == 5 && bsd == 4) || (bsf == 6 && (bsd == 4 || bsd == 5));
+  const int ncol = h + 3 * nd + k, nc = ncol <= 128 ? 2 : 3;  // columns of [B_st | B_dy | A_dy | C_dy | D] per lane
+  if (ncol > 192 || nd + k > 64) return DSGE_SUCCESS;
+  // instances built: (full tile, reduced tile) x columns per lane
+  const bool have = nc == 2 ? ((bsf == 3 && (bsd == 2 || bsd == 3)) || (bsf == 4 && (bsd == 3 || bsd == 4)) ||
+                               (bsf == 5 && bsd == 4) || (bsf == 6 && (bsd == 4 || bsd == 5)))
+                            : ((bsf == 6 && bsd == 5) || (bsf == 7 && (bsd == 5 || bsd == 6)) || (bsf == 8 && bsd == 6));
   if (!have) return DSGE_SUCCESS;
   int rc;
   void* base = nullptr;
@@ -146,17 +153,22 @@ int launch_cr_fused(const double* A, const double* B, const double* C, const dou
   if ((rc = defl_reserve(al256(tops * 8) + al256(rhss * 8) + 4096, st, &base))) return rc;
   double* top = (double*)base;
   double* rhs = (double*)((char*)base + al256(tops * 8));
-#define FUSED_CASE(F, D_)                                                                                              \
-  if (bsf == F && bsd == D_)                                                                                           \
-    rc = launch_cr_fused_inst<F, D_>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter, st, colmask)
+#define FUSED_CASE(F, D_, N_)                                                                                          \
+  if (bsf == F && bsd == D_ && nc == N_)                                                                               \
+    rc = launch_cr_fused_inst<F, D_, N_>(A, B, C, D, batch, n, k, h, max_iter, tol, top, rhs, T_out, R_out, status, n_iter, st, \
+                                         colmask)
   rc = DSGE_ERR_INVALID;
-  FUSED_CASE(3, 2);
-  FUSED_CASE(3, 3);
-  FUSED_CASE(4, 3);
-  FUSED_CASE(4, 4);
-  FUSED_CASE(5, 4);
-  FUSED_CASE(6, 4);
-  FUSED_CASE(6, 5);
+  FUSED_CASE(3, 2, 2);
+  FUSED_CASE(3, 3, 2);
+  FUSED_CASE(4, 3, 2);
+  FUSED_CASE(4, 4, 2);
+  FUSED_CASE(5, 4, 2);
+  FUSED_CASE(6, 4, 2);
+  FUSED_CASE(6, 5, 2);
+  FUSED_CASE(6, 5, 3);
+  FUSED_CASE(7, 5, 3);
+  FUSED_CASE(7, 6, 3);
+  FUSED_CASE(8, 6, 3);
 #undef FUSED_CASE
   if (rc) return rc;
   // draws the fused kernel could not take (status == DSGE_ST_INTERNAL_RERUN): full-size dense kernel on exactly those
@@ -214,7 +226,7 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
   const int nd = n - h;
   // worth it only when the reduced system drops to a smaller register-block tile or loses a fifth of its variables
   if (h < 1 || nd < 4 || (tile_bs(nd) == tile_bs(n) && 5 * h < n)) return DSGE_SUCCESS;
-  if (opt().cr_fused_deflation && h + 3 * nd + k <= 128 && nd + k <= 64) {
+  if (opt().cr_fused_deflation) {  // (launch_cr_fused checks the sizes: h + 3 nd + k <= 192, nd + k <= 64)
     // one launch (dsge_cr_fused.hpp); the (full tile, reduced tile) pairs built are the ones the deflation test above lets
     // through for n <= 48
     int done = 0;

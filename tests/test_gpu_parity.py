@@ -1529,13 +1529,14 @@ def test_cr_static_deflation_matches_full_system():
         assert_allclose(T1[i], r["T"], atol=1e-9)
 
 
-@pytest.mark.parametrize("n,ns,nl", [(40, 18, 12), (24, 10, 7), (32, 14, 10), (44, 20, 13), (24, 8, 6), (32, 16, 9), (44, 16, 12)])
+@pytest.mark.parametrize("n,ns,nl", [(40, 18, 12), (24, 10, 7), (32, 14, 10), (44, 20, 13), (24, 8, 6), (32, 16, 9), (44, 16, 12),
+                                     (48, 23, 15), (50, 22, 15), (56, 25, 16), (64, 28, 20)])
 def test_cr_fused_deflation_equals_three_launches(n, ns, nl):
     """The one-launch form of the deflated cycle reduction (default; dsge_cr_fused.hpp: the reduced system goes from the QR
     to the iteration to the back-substitution through LDS) runs the arithmetic of the three launches: T, R, logp, status
     bit for bit -- SW-shaped systems of 40 -> 30 variables (tiles 5 / 4), 24 -> 17 (3 / 3), 32 -> 24 (4 / 3), 44 -> 33
-    (6 / 5), 24 -> 14 (3 / 2), 32 -> 25 (4 / 4) and 44 -> 28 (6 / 4, the cap of 16 deflated variables): every instance of the
-    kernel, each batch with a NaN draw and a draw with fewer static variables than the bound."""
+    (6 / 5), 24 -> 14 (3 / 2), 32 -> 25 (4 / 4) and 44 -> 28 (6 / 4, the cap of 16 deflated variables), and with three columns per lane in the QR 48 -> 38 (6 / 5),
+    50 -> 37 (7 / 5), 56 -> 41 (7 / 6), 64 -> 48 (8 / 6): every instance of the kernel, each batch with a NaN draw and a draw with fewer static variables than the bound."""
     import torch
 
     from geconpy_amd.engine import LogpEngine
