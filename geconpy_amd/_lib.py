@@ -12,7 +12,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_N = 64
 MAX_N_CR = 64
 MAX_N_GENSYS = 64
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "dsge_set_kalman_tiny": [_i],
     "dsge_set_kalman_nt_products": [_i],
     "dsge_set_cr_fused_deflation": [_i],
+    "dsge_set_cr_four_waves": [_i],
     "dsge_set_cr_deflation": [_i],
     "dsge_set_cr_two_waves": [_i],
     "dsge_set_kalman_order": [_i],
@@ -143,6 +144,8 @@ class Options(C.Structure):
         ("kalman_steady_tol", C.c_double),
         ("kalman_nt_products", C.c_int32),
         ("cr_fused_deflation", C.c_int32),
+        ("cr_four_waves", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -158,7 +161,7 @@ def make_options(options=None, **fields):
     elif options:
         fields = {**options, **fields}
     for name, value in fields.items():
-        if name not in {f[0] for f in Options._fields_} or name == "struct_size":
+        if name not in {f[0] for f in Options._fields_} or name in ("struct_size", "reserved_"):
             raise ValueError(f"unknown option {name!r}")
         setattr(o, name, value)
     return o

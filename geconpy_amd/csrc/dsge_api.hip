@@ -132,6 +132,7 @@ struct OptionsGuard {
     local.kalman_steady_tol = o->kalman_steady_tol;
     local.kalman_nt_products = o->kalman_nt_products;
     local.cr_fused_deflation = o->cr_fused_deflation;
+    local.cr_four_waves = o->cr_four_waves;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -295,6 +296,11 @@ int dsge_set_kalman_block(int enable) {
   g_defaults.kalman_block = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
+int dsge_set_cr_four_waves(int enable) {
+  g_defaults.cr_four_waves = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
+
 int dsge_set_cr_fused_deflation(int enable) {
   g_defaults.cr_fused_deflation = enable ? 1 : 0;
   return DSGE_SUCCESS;
@@ -1573,6 +1579,7 @@ int dsge_options_init(dsge_options* o) {
   o->kalman_steady_tol = d.kalman_steady_tol;
   o->kalman_nt_products = d.kalman_nt_products;
   o->cr_fused_deflation = d.cr_fused_deflation;
+  o->cr_four_waves = d.cr_four_waves;
   return DSGE_SUCCESS;
 }
 

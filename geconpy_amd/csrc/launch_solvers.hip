@@ -4,6 +4,7 @@
 #include "dsge_cr_compact.hpp"
 #include "dsge_cr_deflate.hpp"
 #include "dsge_cr_fused.hpp"
+#include "dsge_cr_wide.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -21,7 +22,13 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
   // Column-compact kernel first (zero columns of A and C dropped); it flags the draws whose
   // s + l exceeds the tile, and the dense kernel then runs on exactly those.
   const bool compact = opt().cr_compact != 0;
-  if (compact) {
+  if (compact && n > 48 && opt().cr_four_waves) {
+    // 49..64 variables: four wavefronts per draw (dsge_cr_wide.hpp); it flags what it cannot take like the compact kernel
+    if ((rc = set_lds(dsge::cr_wide_kernel, dsge::CrwSmem::bytes))) return rc;
+    hipLaunchKernelGGL(dsge::cr_wide_kernel, dim3(batch), dim3(256), dsge::CrwSmem::bytes, st, A, B, C, batch, n, max_iter, tol,
+                       T_out, status, n_iter, scan_mode, D, k, R_out);
+    HIP_TRY(hipGetLastError());
+  } else if (compact) {
     DISPATCH_BS(bs, 8, {
       if (BS == 4 && opt().cr_two_waves) {
         rc = set_lds(dsge::cr_compact_kernel_occ2<4>, dsge::CrcSmem<4>::bytes);

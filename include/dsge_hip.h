@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 3
+#define DSGE_ABI_VERSION 4
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
@@ -120,6 +120,7 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
  *                        is a pure enqueue (stream-capturable); -1 (default) measures it on the device on the first
  *                        call of a model size: one small launch, a 4-byte read-back and a stream synchronisation
  *   kalman_nt_products  : see dsge_set_kalman_nt_products       cr_fused_deflation : see dsge_set_cr_fused_deflation
+ *   cr_four_waves       : see dsge_set_cr_four_waves
  *   kalman_order, kalman_tiny, kalman_block, kalman_mfma, pipeline_chunks, gensys_split, kalman_steady_tol :
  *                        see the dsge_set_* function of the same name
  */
@@ -139,6 +140,8 @@ typedef struct dsge_options {
   double kalman_steady_tol;
   int32_t kalman_nt_products;
   int32_t cr_fused_deflation;
+  int32_t cr_four_waves;
+  int32_t reserved_;
 } dsge_options;
 /* fills *opt with the current process-wide defaults */
 int dsge_options_init(dsge_options* opt);
@@ -252,6 +255,12 @@ int dsge_set_kalman_nt_products(int enable);
  * h + 3 (n - h) + k <= 128 and (n - h) + k <= 64; otherwise, and with enable = 0, the three launches run.  Same results
  * (the arithmetic is the same code).  Process-wide DEFAULT (per call: dsge_options); default 1. */
 int dsge_set_cr_fused_deflation(int enable);
+/* Cycle reduction on systems of 49..64 variables (after the deflation, if any) runs on FOUR wavefronts per draw
+ * (cr_wide_kernel, dsge_cr_wide.hpp: 16 x 16 threads with 4 x 4 register blocks, the panel factorisation on one of the
+ * wavefronts) instead of one wavefront with 7 x 7 / 8 x 8 blocks that spill.  enable = 0 keeps the one-wavefront kernels
+ * (same algorithm; the norms of the stopping rule are summed in a different order).  Process-wide DEFAULT (per call:
+ * dsge_options); default 1. */
+int dsge_set_cr_four_waves(int enable);
 /* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
  * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
  * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by

@@ -1715,6 +1715,48 @@ def test_cr_static_deflation_bound_corrects_itself():
     assert_allclose(lp2, lp0, rtol=LOGP_RTOL)
 
 
+@pytest.mark.parametrize("n,ns,nl", [(50, 22, 15), (56, 25, 16), (64, 28, 20)])
+def test_cr_four_wave_kernel_matches_one_wave_kernel(n, ns, nl):
+    """49..64 variables: cycle reduction on four wavefronts per draw (cr_wide_kernel, default) against the one-wavefront
+    compact kernel: same iteration counts and status, T and R to 1e-11 (the norms of the stopping rule are summed in a
+    different order; the rest is the same arithmetic), logp to the parity tolerance -- with a NaN draw, without the
+    deflation (which would shrink the systems below 49 variables)."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    k = p = 7
+    nb = 40
+    sysm = [wl.sw_shaped_system(4300 + 13 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    A[6, 1, 1] = np.nan
+    T4, st4, it4 = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9, options={"cr_four_waves": 1})
+    T1, st1, it1 = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9, options={"cr_four_waves": 0})
+    assert np.array_equal(st4, st1) and st4[6] != 0 and np.count_nonzero(st4) == 1
+    ok = st4 == 0
+    assert np.array_equal(it4[ok], it1[ok])
+    assert_allclose(T4[ok], T1[ok], atol=1e-11)
+    assert_allclose(T4[ok], Tst[ok], atol=1e-8)
+    q = np.full((nb, k), 1e-4)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(n).normal(0, 0.02, (30, p))
+    H = np.full(p, 1e-4)
+    eng = LogpEngine(torch.device("cuda", 0))
+    dev = {x: eng.to_device(v) for x, v in zip("ABCD", (A, B, C, D))}
+    dq, dZ, dy, dH = eng.to_device(q), eng.to_device(Z), eng.to_device(y), eng.to_device(H)
+    hints = eng.structure_hints(dev["A"], dZ)
+    res = {}
+    for four in (0, 1):
+        with _lib.options_scope({"cr_four_waves": four, "cr_deflation": 0}):
+            res[four] = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
+    assert np.array_equal(res[0][1], res[1][1])
+    assert_allclose(res[1][0][ok], res[0][0][ok], rtol=LOGP_RTOL)
+    assert_allclose(res[1][3][ok], res[0][3][ok], atol=1e-10)  # R out of the final elimination
+    r = oracle.solve_kalman_logp(A[3], B[3], C[3], D[3], np.diag(q[3]), Z, y, H=np.diag(H), tol=1e-9, max_iter=1000)
+    assert_allclose(res[1][0][3], r["logp"], rtol=LOGP_RTOL)
+
+
 def test_cr_two_wave_instance_is_bit_identical():
     """The 32-wide compact cycle-reduction kernel built for two waves per SIMD (default) runs the same arithmetic as the
     one-wave instance: T, R, logp bit for bit, on the deflated SW-shaped system (30 variables) and on a 32-variable one."""
