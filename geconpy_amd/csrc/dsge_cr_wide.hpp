@@ -35,6 +35,7 @@ __device__ __forceinline__ void gauss_jordan_wide(double* W, int n, double* Lbuf
     __syncthreads();
     if (wv == 0) {
       // ---- panel: one matrix row per lane, augmented with the identity slots ------------
+      __builtin_amdgcn_s_setprio(3);  // (the chain everybody waits for: ahead of the other workgroup's wave on this SIMD)
       double pw[BS], id[BS];
 #pragma unroll
       for (int c = 0; c < BS; ++c) {
@@ -85,6 +86,7 @@ __device__ __forceinline__ void gauss_jordan_wide(double* W, int n, double* Lbuf
 #pragma unroll
       for (int a = 0; a < BS; ++a)
         if (a < bw && lane == 0) prow[j0 + a] = rsel[a];
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     // ---- trailing update on register blocks: W[i,:] -= Lhat[i,:] Wpiv (16 x 16 thread grid) ----------
