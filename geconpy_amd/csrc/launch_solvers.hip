@@ -233,6 +233,9 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
   const int nd = n - h;
   // worth it only when the reduced system drops to a smaller register-block tile or loses a fifth of its variables
   if (h < 1 || nd < 4 || (tile_bs(nd) == tile_bs(n) && 5 * h < n)) return DSGE_SUCCESS;
+  // D_red (nd x k) rides through the reduced cycle reduction as ONE column group of its tile: more shocks than the reduced
+  // tile is wide (possible only when most variables are static) do not fit -- full-size solve then
+  if (k > 8 * tile_bs(nd)) return DSGE_SUCCESS;
   if (opt().cr_fused_deflation) {  // (launch_cr_fused checks the sizes: h + 3 nd + k <= 192, nd + k <= 64)
     // one launch (dsge_cr_fused.hpp); the (full tile, reduced tile) pairs built are the ones the deflation test above lets
     // through for n <= 48

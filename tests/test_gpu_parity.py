@@ -1607,6 +1607,26 @@ def test_cr_fused_deflation_hands_over_what_does_not_fit():
     assert_allclose(lp1, lp0, rtol=LOGP_RTOL)
 
 
+@pytest.mark.parametrize("n,ns,nl,k,p", [(15, 1, 3, 11, 8), (14, 4, 2, 10, 5), (24, 3, 2, 17, 4)])
+def test_more_shocks_than_the_reduced_tile_is_wide(n, ns, nl, k, p):
+    """Mostly static systems with many shocks (found by tools/fuzz_fused.py): the deflation would leave fewer dynamic
+    variables than there are shocks, and D_red no longer fits one column group of the reduced tile -- the launcher must
+    fall back to the full-size solve (round 1 silently dropped the columns of D beyond the tile: wrong R, wrong logp)."""
+    nb = 3
+    sysm = [wl.sw_shaped_system(3100 + 7 * n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D, Tst = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    q = np.full((nb, k), 1e-4)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), np.arange(p)] = 1.0
+    y = np.random.default_rng(n).normal(0, 0.02, (12, p))
+    H = np.full(p, 1e-4)
+    out = batched.solve_kalman_logp_batched(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-10, max_iter=1000, q_mode="diag_batched")
+    assert np.all(out["status"] == 0)
+    for i in range(nb):
+        r = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(q[i]), Z, y, H=np.diag(H), tol=1e-10, max_iter=1000)
+        assert_allclose(out["logp"][i], r["logp"], rtol=LOGP_RTOL)
+
+
 @pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
 def test_cr_static_deflation_on_reference_goldens(ref_goldens, key):
     """The reference's own models (3 of 9, 6 of 12, 4 of 24 static variables): fused call with the deflation against the
