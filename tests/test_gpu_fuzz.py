@@ -17,3 +17,12 @@ def test_fused_evaluation_fuzz(seed):
     import fuzz_fused
 
     assert fuzz_fused.run(seed, 60, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_gradient_fuzz(seed):
+    """Directional derivatives of the device gradient against extrapolated central differences of the oracle over random
+    configurations (6..56 variables, selector Z, batches of 1 / 2 / 5): 1e-6 relative (observed: <= 1e-9)."""
+    import fuzz_grad
+
+    assert fuzz_grad.run(seed, 40, verbose=False, rtol=1e-6) == 0

@@ -1,0 +1,66 @@
+"""GPU box: randomized configurations of the logp gradient against central differences of the oracle."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from geconpy_amd import batched, workloads as wl
+import oracle
+
+
+def run(seed, trials, verbose=True, rtol=5e-5):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for trial in range(trials):
+        n = int(rng.integers(6, 57))
+        ns = int(rng.integers(1, max(2, n // 2)))
+        nl = int(rng.integers(1, max(2, n // 3)))
+        k = int(rng.integers(1, min(n, 10) + 1))
+        p = int(rng.integers(1, min(k, 8) + 1))
+        T_len = int(rng.choice([1, 3, 12, 60]))
+        nb = int(rng.choice([1, 2, 5]))
+        try:
+            sysm = [wl.sw_shaped_system(int(rng.integers(1 << 30)), n=n, n_state=ns, n_lead=nl, k=k) for _ in range(nb)]
+        except Exception:
+            continue
+        A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+        q = rng.uniform(0.5, 2.0, (nb, k)) * 1e-4
+        Z = np.zeros((p, n)); Z[np.arange(p), rng.choice(n, p, replace=False)] = rng.uniform(0.5, 1.5, p)
+        y = rng.normal(0, 0.02, (T_len, p))
+        if T_len > 2: y[1, 0] = np.nan
+        H = rng.uniform(0.5, 2.0, p) * 1e-4
+        d = rng.normal(0, 0.01, p)
+        out = batched.solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=d, Hdiag=H, tol=1e-13, max_iter=300)
+        i = int(rng.integers(nb))
+        if out["status"][i] != 0:
+            if verbose: print("status", out["status"][i], dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len))
+            continue
+        maskA = (A[i] != 0).any(axis=0)[None, :] * np.ones_like(A[i])
+        dA = rng.standard_normal(A[i].shape) * maskA * 0.1
+        dB, dC, dD = (rng.standard_normal(M.shape) * 0.1 for M in (B[i], C[i], D[i]))
+        dq = rng.standard_normal(k) * q[i] * 0.3
+        dd = rng.standard_normal(p) * 0.1
+        dh = rng.standard_normal(p) * H * 0.3
+        g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+        analytic = ((g["A_bar"] * dA).sum() + (g["B_bar"] * dB).sum() + (g["C_bar"] * dC).sum() + (g["D_bar"] * dD).sum()
+                    + (g["q_bar"] * dq).sum() + (g["d_bar"] * dd).sum() + (g["h_bar"] * dh).sum())
+
+        def f(e):
+            return oracle.solve_kalman_logp(A[i] + e * dA, B[i] + e * dB, C[i] + e * dC, D[i] + e * dD, np.diag(q[i] + e * dq), Z, y,
+                                            H=np.diag(H + e * dh), d=d + e * dd, tol=1e-14, max_iter=300)["logp"]
+
+        e = 1e-5
+        d1 = (f(e) - f(-e)) / (2 * e)
+        d2 = (f(e / 2) - f(-e / 2)) / e
+        fd = (4 * d2 - d1) / 3
+        if verbose:
+            print("rel", f"{abs(analytic - fd) / max(abs(fd), 1.0):.2e}", "fd-noise", f"{abs(d1 - d2) / max(abs(fd), 1.0):.2e}", dict(n=n, k=k, p=p, T_len=T_len))
+        if not abs(analytic - fd) <= rtol * max(abs(fd), 1.0) + 20 * abs(d1 - d2):
+            bad += 1
+            if verbose:
+                print("MISMATCH", dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len, nb=nb, draw=i), analytic, fd, abs(d1 - d2))
+    if verbose:
+        print("trials done, mismatches:", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40)
