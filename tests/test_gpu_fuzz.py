@@ -26,3 +26,12 @@ def test_gradient_fuzz(seed):
     import fuzz_grad
 
     assert fuzz_grad.run(seed, 40, verbose=False, rtol=1e-6) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_cycle_reduction_fuzz(seed):
+    """Cycle reduction alone, 3..64 variables, three tolerances, default kernels / one wavefront for 49..64 / dense kernel:
+    status and ITERATION COUNTS equal to the oracle's, T within 1e-7."""
+    import fuzz_cr
+
+    assert fuzz_cr.run(seed, 60, verbose=False) == 0

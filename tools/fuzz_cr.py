@@ -1,0 +1,41 @@
+"""GPU box: cycle reduction alone at random sizes against the oracle: T, status, iteration counts, for the default kernels
+and with the structure-exploiting ones switched off."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from geconpy_amd import batched, workloads as wl
+import oracle
+
+
+def run(seed, trials, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for trial in range(trials):
+        n = int(rng.integers(3, 65))
+        ns = int(rng.integers(1, max(2, n // 2)))
+        nl = int(rng.integers(1, max(2, n // 3)))
+        nb = 4
+        try:
+            sysm = [wl.sw_shaped_system(int(rng.integers(1 << 30)), n=n, n_state=ns, n_lead=nl, k=1) for _ in range(nb)]
+        except Exception:
+            continue
+        A, B, C = (np.stack([s_[j] for s_ in sysm]) for j in range(3))
+        tol = float(rng.choice([1e-6, 1e-9, 1e-12]))
+        ref = [oracle.cycle_reduction_core(A[i], B[i], C[i], 200, tol) for i in range(nb)]
+        for opts in ({}, {"cr_four_waves": 0}, {"cr_compact": 0}):
+            T, st, it = batched.cycle_reduction_batched(A, B, C, max_iter=200, tol=tol, options=opts)
+            for i in range(nb):
+                Tc, conv, itc = ref[i]
+                ok = (st[i] == 0) == bool(conv) and (not conv or (it[i] == itc and np.abs(T[i] - Tc).max() <= 1e-7))  # (1e-8 happens on ill-conditioned intermediates)
+                if not ok:
+                    bad += 1
+                    if verbose:
+                        print("MISMATCH", opts, dict(n=n, ns=ns, nl=nl, tol=tol, draw=i), st[i], it[i], itc,
+                              np.abs(T[i] - Tc).max() if conv else None)
+    if verbose:
+        print("trials done, mismatches:", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 60)
