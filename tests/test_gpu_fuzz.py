@@ -35,3 +35,12 @@ def test_cycle_reduction_fuzz(seed):
     import fuzz_cr
 
     assert fuzz_cr.run(seed, 60, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_standalone_filter_fuzz(seed):
+    """dsge_kalman_logp_batched (T, R, Q given) at random sizes up to 64 states / 16 observables: column-sparse and dense
+    transitions, selector / dense / batched design matrices, diagonal and full Q, missing data."""
+    import fuzz_kalman
+
+    assert fuzz_kalman.run(seed, 50, verbose=False) == 0
