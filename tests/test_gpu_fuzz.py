@@ -44,3 +44,12 @@ def test_standalone_filter_fuzz(seed):
     import fuzz_kalman
 
     assert fuzz_kalman.run(seed, 50, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_mixed_structure_batches_fuzz(seed):
+    """Batches in which a quarter of the draws violate the structure hints (more states, fewer static variables): every
+    second pass of the kernel cascades runs, every sampled draw matches the oracle."""
+    import fuzz_mixed
+
+    assert fuzz_mixed.run(seed, 20, verbose=False) == 0

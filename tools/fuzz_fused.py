@@ -46,6 +46,13 @@ def run(seed, trials, verbose=True):
       elif variant == 5 and T_len > 4:  # a whole period missing, and a different mask later
           y[2, :] = np.nan
           y[T_len - 1, p - 1] = np.nan
+      if rng.random() < 0.5:  # a random combination of the kernel-variant switches: every one must give the same answer
+          kw["options"] = {name: int(rng.integers(0, 2)) for name in
+                           ("cr_compact", "cr_fused_selection", "cr_deflation", "cr_two_waves", "cr_fused_deflation",
+                            "cr_four_waves", "kalman_tiny", "kalman_nt_products") if rng.random() < 0.5}
+          kw["options"]["kalman_order"] = int(rng.integers(0, 3))
+          if rng.random() < 0.3:
+              kw["options"]["kalman_steady_tol"] = 0.0
       try:
           out = batched.solve_kalman_logp_batched(A, B, C, D, q, Z, y, d=d, Hdiag=H, tol=1e-10, max_iter=1000, **kw)
       except Exception as e:
@@ -58,7 +65,7 @@ def run(seed, trials, verbose=True):
           ok_d = out["status"][i] == 0
           if ok_o != ok_d or (ok_o and abs(out["logp"][i] - r["logp"]) > 1e-8 * max(1.0, abs(r["logp"]))):
               bad += 1
-              print("MISMATCH", "variant", variant, dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len, draw=i), out["status"][i], out["logp"][i], r["logp"])
+              print("MISMATCH", "variant", variant, kw.get("options"), dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len, draw=i), out["status"][i], out["logp"][i], r["logp"])
   if verbose:
     print("trials done, mismatches:", bad)
   return bad
