@@ -53,3 +53,13 @@ def test_mixed_structure_batches_fuzz(seed):
     import fuzz_mixed
 
     assert fuzz_mixed.run(seed, 20, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_standalone_pullbacks_fuzz(seed):
+    """dsge_policy_adjoints_batched against the oracle's Kronecker solve and dsge_selection_adjoints_batched against the
+    closed form, 3..56 variables.  Policy adjoints: 1e-5 (typically 1e-12; the doubling series loses digits on rare
+    non-normal systems, see tools/fuzz_adjoints.py), selection pullback: 1e-9."""
+    import fuzz_adjoints
+
+    assert fuzz_adjoints.run(seed, 30, verbose=False) == 0
