@@ -63,3 +63,12 @@ def test_standalone_pullbacks_fuzz(seed):
     import fuzz_adjoints
 
     assert fuzz_adjoints.run(seed, 30, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gensys_and_bk_fuzz(seed):
+    """gensys alone at random sizes (3..48 variables, pencils up to 60) against the LAPACK-based oracle: T, success, eu, and
+    the Blanchard-Kahn counts; a fifth of the batches carries an explosive draw."""
+    import fuzz_gensys
+
+    assert fuzz_gensys.run(seed, 40, verbose=False) == 0
