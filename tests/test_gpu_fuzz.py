@@ -72,3 +72,12 @@ def test_gensys_and_bk_fuzz(seed):
     import fuzz_gensys
 
     assert fuzz_gensys.run(seed, 40, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_raw_pencil_gensys_fuzz(seed):
+    """dsge_gensys_pencil_batched on the pencils of random models, plain and under a random equivalence transformation
+    (dense pencils, same solution): G1, impact, eu against the oracle's gensys."""
+    import fuzz_pencil
+
+    assert fuzz_pencil.run(seed, 30, verbose=False) == 0
