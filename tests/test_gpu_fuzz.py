@@ -81,3 +81,12 @@ def test_raw_pencil_gensys_fuzz(seed):
     import fuzz_pencil
 
     assert fuzz_pencil.run(seed, 30, verbose=False) == 0
+
+
+def test_chunked_host_path_fuzz():
+    """The `*_host` twin of the fused evaluation (two chunks from 512 draws, four from 2048, on two streams with leased
+    arenas) against the device-resident single pipeline at random sizes: same status, logp bit-identical (1e-10 where the
+    structure hints select another gensys kernel)."""
+    import fuzz_hostpath
+
+    assert fuzz_hostpath.run(3, 8, verbose=False) == 0
