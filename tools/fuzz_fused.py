@@ -12,8 +12,8 @@ def run(seed, trials, verbose=True):
       n = int(rng.integers(6, 65))
       ns = int(rng.integers(1, max(2, n // 2)))
       nl = int(rng.integers(1, max(2, n // 3)))
-      k = int(rng.integers(1, min(n, 12) + 1))
-      p = int(rng.integers(1, min(k, 8) + 1))
+      k = int(rng.integers(1, min(n, 24 if rng.random() < 0.2 else 12) + 1))
+      p = int(rng.integers(1, min(n, 8) + 1)) if rng.random() < 0.3 else int(rng.integers(1, min(k, 8) + 1))  # (p > k: H > 0 keeps F regular)
       T_len = int(rng.choice([1, 2, 7, 40]))
       nb = 3
       try:
