@@ -370,14 +370,18 @@ def main():
         torch.cuda.synchronize()
         hints = eng.structure_hints(dA, dZ) if not args.no_hints else (0, 0)
 
+    # the number of static variables is a property of the model like the other two hints: with it the fused call is a
+    # pure enqueue (no measuring launch, no read-back inside the library)
+    opts = {"n_static_hint": eng.static_hint(dA, dC)} if (args.solver == "cycle_reduction" and not args.no_hints) else None
+
     def local_eval(lo_, hi_):
         if prog is not None:
             return eng.logp_from_theta(prog, d_theta, dZ, dy, Hdiag=dH, jac_out=jac_out, tol=args.tol,
                                        max_iter=args.max_iter, logp=logp_buf, status=stat_buf, solver=args.solver,
-                                       n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead)
+                                       n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead, options=opts)
         return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
                                      max_iter=args.max_iter, logp=logp_buf, status=stat_buf, solver=args.solver,
-                                     n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead)
+                                     n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead, options=opts)
 
     ev = ShardedLogpEvaluator(global_batch, local_eval, device)
 
