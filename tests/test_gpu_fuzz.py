@@ -90,3 +90,11 @@ def test_chunked_host_path_fuzz():
     import fuzz_hostpath
 
     assert fuzz_hostpath.run(3, 8, verbose=False) == 0
+
+
+def test_autocorrelation_and_lyapunov_fuzz():
+    """dsge_autocorrelation_batched (latent and observed, correlation and covariance, lag steps) and dsge_lyapunov_batched at
+    random sizes up to 64 states against the oracle: 1e-9."""
+    import fuzz_acf
+
+    assert fuzz_acf.run(1, 40, verbose=False) == 0
