@@ -99,7 +99,8 @@ def main():
     for name, k in res["kernels"].items():
         print(f"{name:60s} n={k['dispatches']:3d} flops={k.get('fp64_flops', 0):.4g} hbm={k.get('hbm_bytes', 0):.4g} "
               f"avg_us={k.get('avg_ns', 0) / 1e3:.1f} conflict/active="
-              f"{k.get('SQ_LDS_BANK_CONFLICT', 0) / max(k.get('SQ_LDS_IDX_ACTIVE', 1), 1):.2f}")
+              f"{k.get('SQ_LDS_BANK_CONFLICT', 0) / max(k.get('SQ_LDS_IDX_ACTIVE', 1), 1):.2f} "
+              f"valu_busy={k.get('SQ_ACTIVE_INST_VALU', 0) / max(k.get('SQ_WAVE_CYCLES', 1), 1):.3f}")
 
 
 if __name__ == "__main__":
