@@ -114,9 +114,18 @@ class JacobianProgram:
         import sympy as sp
         from sympy.printing.c import C99CodePrinter
 
-        entries = self.nonzero_entries()
+        # The parameters are printed as par0, par1, ...: a model parameter may be called theta, A, q, draw, x0 or carry
+        # characters that are not valid in a C identifier, and none of that may meet the kernel's own names.
+        ren = {p_: sp.Symbol(f"par{i}", **p_.assumptions0) for i, p_ in enumerate(self.params)}
+        params = [ren[p_] for p_ in self.params]
+        entries = [(mi, flat, e.xreplace(ren)) for mi, flat, e in self.nonzero_entries()]
         repl, reduced = sp.cse([e for _, _, e in entries], symbols=sp.numbered_symbols("x"), optimizations="basic")
-        pr = C99CodePrinter()
+        class _Printer(C99CodePrinter):
+            def _print_Integer(self, expr):  # an integer beyond 32 bits is written as a double literal (found by tools/fuzz_theta.py:
+                v = int(expr)                # sympy folds rational coefficients into integers clang cannot represent)
+                return f"{v}.0" if abs(v) >= 2 ** 31 else super()._print_Integer(expr)
+
+        pr = _Printer()
         npar, n, k = len(self.params), self.n, self.k
         lines = [
             "// generated by geconpy_amd/jacobian_codegen.py -- do not edit",
@@ -134,7 +143,7 @@ class JacobianProgram:
             "  if (draw >= batch) return;",
             "  const double* th = theta + (size_t)draw * JAC_NPAR;",
         ]
-        for i, p in enumerate(self.params):
+        for i, p in enumerate(params):
             lines.append(f"  const double {pr.doprint(p)} = th[{i}];")
         for sym, expr in repl:
             lines.append(f"  const double {pr.doprint(sym)} = {pr.doprint(expr)};")
@@ -149,7 +158,7 @@ class JacobianProgram:
         lines += ["}", ""]
         # ---- pullback kernel: theta_bar_i = sum_e bar_e * d expr_e / d theta_i (one shared CSE pass again)
         bar_syms = [sp.Symbol(f"g{mi}_{flat}") for mi, flat, _ in entries]
-        vjp_exprs = [sp.Add(*[g * sp.diff(e, th_) for g, (_, _, e) in zip(bar_syms, entries)]) for th_ in self.params]
+        vjp_exprs = [sp.Add(*[g * sp.diff(e, th_) for g, (_, _, e) in zip(bar_syms, entries)]) for th_ in params]
         used_bars = sorted(set().union(*(v.free_symbols for v in vjp_exprs)) & set(bar_syms), key=lambda x_: bar_syms.index(x_))
         repl2, reduced2 = sp.cse(vjp_exprs, symbols=sp.numbered_symbols("z"), optimizations="basic")
         bar_names = ["Ab", "Bb", "Cb", "Db", "qb"]
@@ -161,7 +170,7 @@ class JacobianProgram:
             "  if (draw >= batch) return;",
             "  const double* th = theta + (size_t)draw * JAC_NPAR;",
         ]
-        for i, p_ in enumerate(self.params):
+        for i, p_ in enumerate(params):
             lines.append(f"  const double {pr.doprint(p_)} = th[{i}];")
         bar_bases = ["A_bar + (size_t)draw * JAC_N * JAC_N", "B_bar + (size_t)draw * JAC_N * JAC_N",
                      "C_bar + (size_t)draw * JAC_N * JAC_N", "D_bar + (size_t)draw * JAC_N * JAC_K", "q_bar + (size_t)draw * JAC_K"]
@@ -185,8 +194,8 @@ class JacobianProgram:
                 for r in range(self.p):
                     for c_ in range(n):
                         if self.Z[r, c_] != 0:
-                            zent.append((0, r * n + c_, self.Z[r, c_]))
-            dent = [(1, j, e) for j, e in enumerate(self.d)] if self.d is not None else []
+                            zent.append((0, r * n + c_, self.Z[r, c_].xreplace(ren)))
+            dent = [(1, j, e.xreplace(ren)) for j, e in enumerate(self.d)] if self.d is not None else []
             oent = zent + dent
             repl3, red3 = sp.cse([e for _, _, e in oent], symbols=sp.numbered_symbols("w"), optimizations="basic")
             lines += [
@@ -197,7 +206,7 @@ class JacobianProgram:
                 "  if (draw >= batch) return;",
                 "  const double* th = theta + (size_t)draw * JAC_NPAR;",
             ]
-            for i, p_ in enumerate(self.params):
+            for i, p_ in enumerate(params):
                 lines.append(f"  const double {pr.doprint(p_)} = th[{i}];")
             for sym, expr in repl3:
                 lines.append(f"  const double {pr.doprint(sym)} = {pr.doprint(expr)};")
@@ -207,7 +216,7 @@ class JacobianProgram:
             lines += ["}", ""]
             if self.d is not None:
                 gs = [sp.Symbol(f"gd_{j}") for j in range(self.p)]
-                dv = [sp.Add(*[g * sp.diff(e, th_) for g, e in zip(gs, self.d)]) for th_ in self.params]
+                dv = [sp.Add(*[g * sp.diff(e.xreplace(ren), th_) for g, e in zip(gs, self.d)]) for th_ in params]
                 repl4, red4 = sp.cse(dv, symbols=sp.numbered_symbols("v"), optimizations="basic")
                 lines += [
                     "// theta_bar += (d d / d theta)' d_bar",
@@ -217,7 +226,7 @@ class JacobianProgram:
                     "  if (draw >= batch) return;",
                     "  const double* th = theta + (size_t)draw * JAC_NPAR;",
                 ]
-                for i, p_ in enumerate(self.params):
+                for i, p_ in enumerate(params):
                     lines.append(f"  const double {pr.doprint(p_)} = th[{i}];")
                 for j, g in enumerate(gs):
                     lines.append(f"  const double {g} = d_bar[(size_t)draw * JAC_P + {j}];")
@@ -292,7 +301,8 @@ class JacobianProgram:
     # -- build / load ----------------------------------------------------------------------
     def lib_path(self):
         h = hashlib.sha256(self.source().encode()).hexdigest()[:16]
-        return os.path.join(JIT_DIR, f"libjac_{self.name}_{h}.so")
+        safe = "".join(ch if (ch.isalnum() and ch.isascii()) or ch == "_" else "_" for ch in self.name)  # model names are free text
+        return os.path.join(JIT_DIR, f"libjac_{safe}_{h}.so")
 
     def build(self, force=False, verbose=False):
         """Compile for gfx950 (cross-compiles without a GPU); returns the path of the shared library."""

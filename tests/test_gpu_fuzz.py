@@ -98,3 +98,13 @@ def test_autocorrelation_and_lyapunov_fuzz():
     import fuzz_acf
 
     assert fuzz_acf.run(1, 40, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_generated_theta_kernels_fuzz(seed):
+    """Random parameter programs (jacobian_codegen): theta -> A, B, C, D, q / Z, d and both pullbacks against sympy's
+    lambdify of the same expressions and derivatives; the parameter names include the generated kernel's own identifiers
+    (theta, A, q, draw, x0 ...) and names that are no C identifiers (rho^A, sigma.e)."""
+    import fuzz_theta
+
+    assert fuzz_theta.run(seed, 6, verbose=False) == 0

@@ -2,6 +2,7 @@
 generated source, and that the cross-compiled library exports its C ABI.  GPU: the kernel's matrices
 against the numpy closed form and the theta -> logp path against the matrix-fed pipeline."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -296,3 +297,38 @@ def test_observation_equation_from_theta_on_device():
         ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.array([[th["sigma_A"][i] ** 2]]), Zh[i], y,
                                        H=np.diag([1e-4, 1e-4]), d=db.cpu().numpy()[i], tol=1e-10, max_iter=1000)
         assert abs(logp[i].item() - ref["logp"]) <= 1e-8 * abs(ref["logp"])
+
+
+def test_parameter_names_never_meet_the_kernel_identifiers():
+    """A parameter called theta / A / q / draw / x0, or one that is no C identifier, is printed as par<i>."""
+    import sympy as sp
+
+    from geconpy_amd.jacobian_codegen import JacobianProgram
+
+    names = ["theta", "A", "q", "draw", "x0", "rho^A", "sigma.e", "par1"]
+    ps = [sp.Symbol(nm, positive=True) for nm in names]
+    A, B, C, D = sp.zeros(2, 2), sp.zeros(2, 2), sp.zeros(2, 2), sp.zeros(2, 1)
+    A[0, 0] = ps[0] * ps[1] + sp.exp(ps[4])
+    B[1, 1] = ps[2] ** sp.Rational(1, 3) / ps[3]
+    C[1, 0] = ps[5] * ps[6] / ps[7]
+    D[0, 0] = ps[2]
+    prog = JacobianProgram("hostile_names", ps, A, B, C, D, q=[ps[2] ** 2], Z=sp.Matrix([[ps[0], 0]]), d=[sp.log(ps[1])])
+    src = prog.source()
+    for i in range(len(names)):
+        assert f"const double par{i} = th[{i}];" in src
+    assert "const double theta =" not in src and "const double A =" not in src and "rho^A" not in src
+    assert os.path.exists(prog.build())  # hipcc accepts it (cross-compiles without a GPU)
+
+
+def test_integers_beyond_32_bits_are_double_literals():
+    """sympy folds rational coefficients into integers of any size; clang rejects a literal beyond 64 bits (found by
+    tools/fuzz_theta.py).  Small integers stay integers (pow(x, 2) keeps its integer exponent)."""
+    import sympy as sp
+
+    from geconpy_amd.jacobian_codegen import JacobianProgram
+
+    a = sp.Symbol("a", positive=True)
+    M = sp.Matrix([[339799298607853600768 * a / (68719476736 * a + 424010647921) ** 2 + sp.exp(a) ** 2]])
+    src = JacobianProgram("bigint", [a], M, M, M, M).source()
+    assert "339799298607853600768.0" in src and "68719476736.0" in src and "424010647921.0" in src
+    assert ", 2)" in src and ", 2.0)" not in src
