@@ -241,3 +241,46 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["failed_draws"] == 0
     assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("solver", ["cycle_reduction", "gensys"])
+def test_a_draw_gives_the_same_bits_in_a_batch_of_any_size(solver):
+    """The batch size only changes the dispatch (ordering kernel, grid sizes, second passes): the first nb draws of a
+    4097-draw batch evaluated as a batch of nb = 1, 63, 65, 1023, 1025, 2049 draws give bit-identical logp, with and
+    without the structure hints; the gradient path likewise (cycle reduction)."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    eng = LogpEngine(0)
+    b = wl.sw_shaped_batch(130)
+    om = wl.sw_shaped_observation_model()
+    total = 4097
+    rep = (total + 129) // 130
+    dev = [eng.to_device(np.tile(b[x], (rep, 1, 1))[:total]) for x in "ABCD"]
+    dq = eng.to_device(np.tile(b["sigma"] ** 2, (rep, 1))[:total])
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
+    ns, zs = eng.structure_hints(dev[0][:64], dZ)
+    for hinted in (True, False):
+        kw = dict(Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, solver=solver)
+        if hinted:
+            kw.update(n_state_hint=ns, z_selector_hint=zs)
+        full, st = eng.solve_kalman_logp(*dev, dq, dZ, dy, **kw)
+        torch.cuda.synchronize()
+        full = full.cpu().numpy().copy()
+        assert int((st != 0).sum()) == 0
+        for nb in (1, 63, 65, 1023, 1025, 2049):
+            lp, st2 = eng.solve_kalman_logp(*(x[:nb] for x in dev), dq[:nb], dZ, dy, **kw)
+            torch.cuda.synchronize()
+            assert int((st2 != 0).sum()) == 0
+            assert np.array_equal(lp.cpu().numpy(), full[:nb]), (solver, hinted, nb)
+    if solver == "cycle_reduction":
+        g_full = eng.solve_kalman_logp_grad(*dev, dq, dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000)
+        torch.cuda.synchronize()
+        g_full = {k_: v.cpu().numpy().copy() for k_, v in g_full.items() if hasattr(v, "cpu")}
+        for nb in (1, 65, 1025):
+            g = eng.solve_kalman_logp_grad(*(x[:nb] for x in dev), dq[:nb], dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000)
+            torch.cuda.synchronize()
+            for k_, v in g.items():
+                if hasattr(v, "cpu"):
+                    assert np.array_equal(v.cpu().numpy(), g_full[k_][:nb]), (k_, nb)
