@@ -635,14 +635,15 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         const double my_wz = (my_o >= 0) ? (((omask >> my_o) & 1ull) ? 1.0 : 0.0) * zv[my_o] : 0.0;
         const int my_os = (my_o >= 0) ? my_o : 0;
         double ab_reg = (lane < NP) ? ab[lane] : 0.0, db_reg = 0.0;
-        for (;;) {
+        // one steady step of the reverse sweep from the stored a_t (a_in) and y_t (y_in)
+        auto steady_step = [&](const double a_in, const double y_in) __attribute__((always_inline)) {
           // v, F^-1 v, a+ of step t from the stored a_t
-          const double a_sel = __shfl(a_cur, v_zpos, 64);
-          const double v_s = (lane < p) ? w_l * yt_or_zero(yt) - (v_dd + w_l * v_zv * a_sel) : 0.0;
+          const double a_sel = __shfl(a_in, v_zpos, 64);
+          const double v_s = (lane < p) ? w_l * yt_or_zero(y_in) - (v_dd + w_l * v_zv * a_sel) : 0.0;
           double vsc[8];
 #pragma unroll
           for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
-          double w0 = 0.0, w1 = 0.0, a0 = (lane < u) ? a_cur : 0.0, a1 = 0.0;
+          double w0 = 0.0, w1 = 0.0, a0 = (lane < u) ? a_in : 0.0, a1 = 0.0;
 #pragma unroll
           for (int o = 0; o < 8; o += 2) {
             w0 = fma(firow[o], vsc[o], w0);
@@ -688,19 +689,42 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           // abar = a+bar - Zm' vbar;  dbar -= vbar
           ab_reg = apb_l - my_wz * __shfl(vb_l, my_os, 64);
           db_reg -= vb_l;
+        };
+        // The steps' records (a_t, y_t, source index) come from HBM, ~2.5 k cycles away, and are fetched one step ahead.
+        // Two register sets take turns (current / being fetched) so that NO copy joins them at the loop's back edge: with
+        // one set and `cur = next; next = load` the compiler loaded into a temporary, copied it into the loop-carried
+        // register right away and had to wait for the load it had just issued (s_waitcnt vmcnt(0) in every step: 4.6 k
+        // cycles per step, of which 2.6 k were this latency).
+        const int lane_a = (lane < NP) ? lane : NP - 1, lane_y = (lane < p) ? lane : (p > 0 ? p - 1 : 0);
+        // set 0: (a_cur, yt) = step t;  set 1: (av_next, yr_next) = step t - 1.  Every step of a steady segment carries the
+        // SAME source index (the forward sweep wrote seg_src into all of them), so the loop ends at t == src_t without
+        // reading the steps' own copies; the step before the source step belongs to the previous segment, whose source
+        // the source record names (OFF_PREV, in pf_src since the segment's first step).
+        // The loads are unconditional and branch-free (clamped indices; lanes >= NP / >= p are never read): a load under a
+        // condition leaves the number of loads in flight unknown to the compiler, which then waits for all of them.
+        for (;;) {
+          steady_step(a_cur, yt);
           if (t == src_t) break;  // the source step: its covariance side follows below
-          // next (earlier) step: data was fetched one step ahead
           --t;
-          src_t = (int)src_next;
-          a_cur = av_next;
-          yt = yr_next;
-          if (t > 0) {
-            const double* sgp = st + (size_t)(t - 1) * STEP;
-            src_next = sgp[OFF_SRC];
-            if (lane < NP) av_next = sgp[OFF_A + lane];
-            yr_next = (lane < p) ? y[(size_t)(t - 1) * p + lane] : 0.0;
+          {  // set 1 is the current step now; step t - 1 goes to set 0
+            const int tp = (t > 0) ? t - 1 : 0;
+            a_cur = st[(size_t)tp * STEP + OFF_A + lane_a];
+            yt = y[(size_t)tp * p + lane_y];
+          }
+          steady_step(av_next, yr_next);
+          if (t == src_t) {  // leave with the prefetched step in (av_next, yr_next), as the outer loop expects it
+            av_next = a_cur;
+            yr_next = yt;
+            break;
+          }
+          --t;
+          {  // back to set 0; step t - 1 goes to set 1
+            const int tp = (t > 0) ? t - 1 : 0;
+            av_next = st[(size_t)tp * STEP + OFF_A + lane_a];
+            yr_next = y[(size_t)tp * p + lane_y];
           }
         }
+        src_next = (double)pf_src;
         // t == src_t now: the cotangent of a_t goes back to LDS for the next segment (or the end of the sweep)
         if (lane < NP) ab[lane] = ab_reg;
         if (lane < 8) db[lane] += db_reg;

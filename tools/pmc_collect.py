@@ -5,6 +5,7 @@ pass for the durations.  Writes <out>/pmc_counters.json, the file bench.py's roo
 (profiles/<round>/pmc_counters.json once copied there).
 
     python3 tools/pmc_collect.py gpurun_out/r2_pmc [-- extra bench.py args]
+    python3 tools/pmc_collect.py gpurun_out/r2_pmc_grad --script tools/grad_rate.py
 
 Per kernel (template instance, averaged over its dispatches):
     fp64_flops   = (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64) x 64 lanes + 512 MFMA_MOPS_F64   (wave-level instruction
@@ -45,6 +46,8 @@ def main():
     env = dict(os.environ, TMPDIR="/tmp")
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
              "--profile-reps", "1", *extra]
+    if "--script" in sys.argv:  # counters of another driver, e.g. --script tools/grad_rate.py (the gradient pipeline)
+        bench = ["python3", os.path.join(ROOT, sys.argv[sys.argv.index("--script") + 1])]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for tag, counters in GROUPS.items():
         d = os.path.join(out, tag)
@@ -75,8 +78,8 @@ def main():
             if "dsge" in row["Name"]:
                 stats[short(row["Name"])] = dict(calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]))
     subprocess.run(["rm", "-rf", d])
-    res = {"source": "tools/pmc_collect.py: rocprofv3 --pmc (one pass per group) + --kernel-trace --stats over `bench.py "
-                     "--steps 2 --warmup 1 --cpu-sample 0 --profile-reps 1" + (" " + " ".join(extra) if extra else "") + "`, MI355X",
+    what = " ".join(bench[1:]).replace(ROOT + "/", "")
+    res = {"source": "tools/pmc_collect.py: rocprofv3 --pmc (one pass per group) + --kernel-trace --stats over `" + what + "`, MI355X",
            "groups": GROUPS,
            "corrections": "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; fp64_flops = (2 FMA + ADD + MUL + TRANS) x 64 "
                           "+ 512 MFMA_MOPS; SQ_*_CYCLES are quad-cycles",
