@@ -690,35 +690,65 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           ab_reg = apb_l - my_wz * __shfl(vb_l, my_os, 64);
           db_reg -= vb_l;
         };
-        // The steps' records (a_t, y_t, source index) come from HBM, ~2.5 k cycles away, and are fetched one step ahead.
-        // Two register sets take turns (current / being fetched) so that NO copy joins them at the loop's back edge: with
-        // one set and `cur = next; next = load` the compiler loaded into a temporary, copied it into the loop-carried
-        // register right away and had to wait for the load it had just issued (s_waitcnt vmcnt(0) in every step: 4.6 k
-        // cycles per step, of which 2.6 k were this latency).
+        // The steps' records (a_t, y_t) come from HBM.  Fetching them one step ahead into registers (`cur = next; next =
+        // load`) does not work: the compiler loads into a temporary, copies it into the loop-carried register right away and
+        // waits for the load it has just issued (s_waitcnt vmcnt(0) in every step); two or three register sets taking
+        // turns end in the same copies at the back edge.  So a steady segment stages CH steps at a time through LDS (X2 is
+        // scratch, dead here): the NEXT chunk is in flight during the CH steps of the current one, its registers are
+        // defined and consumed in the same trip of the chunk loop, and a step reads its a_t / y_t from LDS -- no global
+        // load and no vmcnt wait inside the step loop (measured: 4.6 k -> 3.9 k cycles per step; the rest is the step's own
+        // 112 v_readlane + 28 ds_bpermute + ~90 FP64 instructions in one dependent chain).  Every step of a segment
+        // carries the SAME source index (the forward sweep wrote seg_src into all of them), so the loop ends at
+        // t == src_t; the step before the source step belongs to the previous segment, whose source the source record
+        // names (OFF_PREV, in pf_src since the segment's first step).  Loads are unconditional and branch-free (clamped
+        // indices; unused lanes are never read): a load under a condition leaves the number of loads in flight unknown to
+        // the compiler, which then waits for all of them.
         const int lane_a = (lane < NP) ? lane : NP - 1, lane_y = (lane < p) ? lane : (p > 0 ? p - 1 : 0);
-        // set 0: (a_cur, yt) = step t;  set 1: (av_next, yr_next) = step t - 1.  Every step of a steady segment carries the
-        // SAME source index (the forward sweep wrote seg_src into all of them), so the loop ends at t == src_t without
-        // reading the steps' own copies; the step before the source step belongs to the previous segment, whose source
-        // the source record names (OFF_PREV, in pf_src since the segment's first step).
-        // The loads are unconditional and branch-free (clamped indices; lanes >= NP / >= p are never read): a load under a
-        // condition leaves the number of loads in flight unknown to the compiler, which then waits for all of them.
-        for (;;) {
-          steady_step(a_cur, yt);
-          if (t == src_t) break;  // the source step: its covariance side follows below
-          --t;
-          {  // set 1 is the current step now; step t - 1 goes to set 0
-            const int tp = (t > 0) ? t - 1 : 0;
-            a_cur = st[(size_t)tp * STEP + OFF_A + lane_a];
-            yt = y[(size_t)tp * p + lane_y];
+        {
+          const bool single = (t == src_t);  // a full step: its record came with the outer loop's own fetch; (av_next, yr_next) stay valid
+          constexpr int CH = (BS == 1) ? 4 : 8, NCA = (CH * NP + 63) / 64;
+          double* SA = X2;            // [CH][NP]
+          double* SY = X2 + CH * NP;  // [CH][8]
+          double ra[NCA], ry;
+          auto chunk_load = [&](int t_hi) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k2 = 0; k2 < NCA; ++k2) {
+              const int idx = (lane + 64 * k2 < CH * NP) ? lane + 64 * k2 : CH * NP - 1;
+              const int jj = idx / NP, el = idx - jj * NP;
+              const int tt = (t_hi - jj > 0) ? t_hi - jj : 0;
+              ra[k2] = st[(size_t)tt * STEP + OFF_A + el];
+            }
+            const int jy = ((lane >> 3) < CH) ? (lane >> 3) : CH - 1, oy = ((lane & 7) < p) ? (lane & 7) : (p > 0 ? p - 1 : 0);
+            const int ty = (t_hi - jy > 0) ? t_hi - jy : 0;
+            ry = y[(size_t)ty * p + oy];
+          };
+          auto chunk_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int k2 = 0; k2 < NCA; ++k2)
+              if (lane + 64 * k2 < CH * NP) SA[lane + 64 * k2] = ra[k2];
+            if (lane < CH * 8) SY[lane] = ry;
+          };
+          if (!single) {
+            chunk_load(t);
+            chunk_store();
           }
-          steady_step(av_next, yr_next);
-          if (t == src_t) {  // leave with the prefetched step in (av_next, yr_next), as the outer loop expects it
-            av_next = a_cur;
-            yr_next = yt;
-            break;
+          for (;;) {
+            if (!single) chunk_load(t - CH);
+            bool done = false;
+#pragma unroll 1
+            for (int j = 0; j < CH; ++j) {
+              const double a_in = single ? a_cur : SA[j * NP + lane_a], y_in = single ? yt : SY[j * 8 + (lane & 7)];
+              steady_step(a_in, y_in);
+              if (t == src_t) {
+                done = true;
+                break;
+              }
+              --t;
+            }
+            if (done) break;
+            chunk_store();
           }
-          --t;
-          {  // back to set 0; step t - 1 goes to set 1
+          if (!single) {  // the step before the source step, for the outer loop
             const int tp = (t > 0) ? t - 1 : 0;
             av_next = st[(size_t)tp * STEP + OFF_A + lane_a];
             yr_next = y[(size_t)tp * p + lane_y];
