@@ -339,12 +339,16 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = DBG ? clock64() : 0;
     int steady_step = -1;
-    double yt_next = (r8 < p && T_len > 0) ? y[r8] : 0.0;
+    // y_t is fetched one step ahead by an UNCONDITIONAL, branch-free load (clamped indices; lanes with r8 >= p and the value
+    // past the last step are never used -- every use is guarded by `obs`): under a condition the compiler sank the load to
+    // the top of the step that needs it and waited for it there (s_waitcnt vmcnt(0) right behind the load, every step)
+    const int r8c = (r8 < p) ? r8 : (p > 0 ? p - 1 : 0);
+    double yt_next = (T_len > 0) ? y[r8c] : 0.0;
     for (int t = 0; t < T_len; ++t) {
       long long tk0 = DBG ? clock64() : 0;
       // ---- (a) missing-data mask; every LDS operand of the update is requested up front ------------------------------
       const double yt = yt_next;
-      yt_next = (r8 < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + r8] : 0.0;
+      yt_next = y[(size_t)((t + 1 < T_len) ? t + 1 : t) * p + r8c];
       const bool obs = (r8 < p) && (yt == yt) && (yt != missing_fill);
       const unsigned long long omask = __ballot(obs) & 0xffull;
       const int n_obs = __popcll(omask);
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);
           if (__ballot(obs_s) != omask) break;
           ++t;
-          yt_next = (r8 < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + r8] : 0.0;
+          yt_next = y[(size_t)((t + 1 < T_len) ? t + 1 : t) * p + r8c];
           const double av_sel = __shfl(av_reg, v_zpos, 64);
           double v_s = 0.0;
           if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
