@@ -84,7 +84,43 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
       for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
     }
     blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
-    gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, ph);  // syncs on entry and exit
+    double inv_lo = 1e300, inv_hi = 0.0;
+    gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, ph, inv_lo, inv_hi);  // syncs on entry and exit
+    // One step of iterative refinement, X += A1^-1 (R - A1 X), when the pivots of one of the first two iterations span more
+    // than CR_REFINE_PIVOT_RATIO: the iteration's A1 has its worst condition there (A1 = B in the first), the blocked
+    // Gauss-Jordan loses ~1e-13 x cond where the reference's LAPACK LU keeps 1e-10, and one refinement step in these two
+    // iterations restores LAPACK's level (tools/blocked_elimination_model.py: 3e-7 -> 1.2e-10 on the flagged draw).  About one
+    // draw in several thousand takes the branch; the others are untouched (bit-identical).
+    if (it < 2 && __builtin_amdgcn_readfirstlane((int)(inv_hi > CR_REFINE_PIVOT_RATIO * inv_lo))) {
+      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);  // X in natural row order (syncs inside)
+      double xh[BS][BS], rr[BS][BS];
+      blk_load_lds<BS>(xh, G1, LDW, lr, lc);
+      blk_store_lds<BS>(A1, W, LDW, lr, lc);
+      if (scan_mode && lr == lc) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
+      }
+      wave_sync();
+      blk_zero<BS>(rr);
+      mm_acc<BS, false>(rr, W, LDW, G1, LDW, n, lr, lc);  // A1 X
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) rr[i][j] = Rb[i][j] - rr[i][j];
+      blk_store_lds<BS>(rr, G1, LDW, lr, lc);
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);  // [A1 | R - A1 X] -> the correction (syncs on entry and exit)
+      gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+      blk_load_lds<BS>(rr, G1, LDW, lr, lc);
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) xh[i][j] += rr[i][j];
+      blk_store_lds<BS>(xh, G1, LDW, lr, lc);
+      if (lane < NP) prow[lane] = lane;  // the solution sits in natural row order now
+      wave_sync();
+    }
     long long tk0 = ph ? clock64() : 0;
     // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
     if (lane < NP) rsrc[lane] = (IT)((lane < wr) ? prow[cmap[lane]] : 0);

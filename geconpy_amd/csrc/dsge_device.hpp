@@ -431,9 +431,13 @@ __device__ __forceinline__ double readlane_dyn_f64(double v, int src_lane_unifor
 
 // W: n rows x (ngroups*NP) columns, row stride ldw, matrix in columns [0,n).  Scratch in LDS:
 // Lbuf (NP*BS doubles), Ybuf (BS * ngroups*NP doubles), prow (NP ints).
+constexpr double CR_REFINE_PIVOT_RATIO = 1e4;  // largest / smallest |pivot| of a solve beyond which it is refined once: the ratio sits ~1e3 below cond(A1) (flagged draws: 2e4 and 1.5e5 at cond 5e6 and 1.2e8; SW-shaped draws: median 8, 99th percentile 650..1600)
+
 template <int BS>
 __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,
-                                                     int* prow, int lane, long long* ph = nullptr) {
+                                                     int* prow, int lane, long long* ph, double& inv_min, double& inv_max) {
+  // inv_min / inv_max: smallest and largest |1 / pivot| met (wave-uniform): their ratio is a free lower estimate of the
+  // condition number, which crc_iterate uses to decide on a step of iterative refinement
   constexpr int NP = 8 * BS;
   const int lr = lane >> 3, lc = lane & 7;
   const int wcols = ngroups * NP;
@@ -473,6 +477,8 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
         // left alone (multiplier 0: no divergent branch) and scaled after the panel -- later columns only ever read
         // a row through its own elimination multiplier, which is consistent with the unscaled row.
         const double inv = fast_rcp(readlane_dyn_f64(pw[c], r));
+        inv_min = fmin(inv_min, fabs(inv));
+        inv_max = fmax(inv_max, fabs(inv));
         const double f = is_r ? 0.0 : pw[c];
         inv_own = is_r ? inv : inv_own;
 #pragma unroll
@@ -540,6 +546,13 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
     if (ph) ph[1] += clock64() - tk_t;
   }
   wave_sync();
+}
+
+template <int BS>
+__device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,
+                                                     int* prow, int lane, long long* ph = nullptr) {
+  double lo = 1e300, hi = 0.0;
+  gauss_jordan_blocked<BS>(W, ldw, n, ngroups, Lbuf, Ybuf, prow, lane, ph, lo, hi);
 }
 
 // Restore natural row order of the right-hand-side column groups [g_first, ngroups): row j of the

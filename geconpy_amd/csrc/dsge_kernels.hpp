@@ -70,8 +70,51 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
       }
       blk_store_lds<BS>(A0, W + NP, LDW, lr, lc);
       blk_store_lds<BS>(A2, W + 2 * NP, LDW, lr, lc);
-      gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);  // syncs on entry and exit
+      double inv_lo = 1e300, inv_hi = 0.0;
+      gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane, nullptr, inv_lo, inv_hi);  // syncs on entry and exit
       gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
+      // the same single step of iterative refinement as crc_iterate (dsge_cr_compact.hpp), with the same test and the same
+      // arithmetic per column: the column-compact kernels stay bit-identical to this one
+      if (it < 2 && __builtin_amdgcn_readfirstlane((int)(inv_hi > CR_REFINE_PIVOT_RATIO * inv_lo))) {
+        double x0h[BS][BS], x2h[BS][BS], r0[BS][BS], r2[BS][BS];
+        blk_load_lds<BS>(x0h, W + NP, LDW, lr, lc);
+        blk_load_lds<BS>(x2h, W + 2 * NP, LDW, lr, lc);
+        blk_store_lds<BS>(A1, W, LDW, lr, lc);
+        if (scan_mode && lr == lc) {
+#pragma unroll
+          for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
+        }
+        wave_sync();
+        blk_zero<BS>(r0);
+        blk_zero<BS>(r2);
+        mm_acc<BS, false>(r0, W, LDW, W + NP, LDW, n, lr, lc);      // A1 X0
+        mm_acc<BS, false>(r2, W, LDW, W + 2 * NP, LDW, n, lr, lc);  // A1 X2
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            r0[i][j] = A0[i][j] - r0[i][j];
+            r2[i][j] = A2[i][j] - r2[i][j];
+          }
+        blk_store_lds<BS>(r0, W + NP, LDW, lr, lc);
+        blk_store_lds<BS>(r2, W + 2 * NP, LDW, lr, lc);
+        gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);
+        gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
+        blk_load_lds<BS>(r0, W + NP, LDW, lr, lc);
+        blk_load_lds<BS>(r2, W + 2 * NP, LDW, lr, lc);
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            x0h[i][j] += r0[i][j];
+            x2h[i][j] += r2[i][j];
+          }
+        blk_store_lds<BS>(x0h, W + NP, LDW, lr, lc);
+        blk_store_lds<BS>(x2h, W + 2 * NP, LDW, lr, lc);
+        wave_sync();
+      }
       const double* X0 = W + NP;
       const double* X2 = W + 2 * NP;
       // left operand A0 -> dead column group 0
