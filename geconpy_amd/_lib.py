@@ -12,7 +12,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_N = 64
 MAX_N_CR = 64
 MAX_N_GENSYS = 64
@@ -86,6 +86,7 @@ PROTOTYPES = {
     "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_policy_adjoints_batched": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_policy_adjoints_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp],
+    "dsge_debug_adjoint_refine": [_i],
     "dsge_selection_adjoints_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_selection_adjoints_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp],
     "dsge_policy_norms_batched": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
@@ -119,6 +120,10 @@ PROTOTYPES = {
                                                 _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_grad_batched_host_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
                                                      _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_second_order_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _i, _i, _f,
+                                       _i, _f, _f, _dp, _i, _dp, _i, _dp, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_second_order_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _i, _i,
+                                            _f, _i, _f, _f, _dp, _i, _dp, _i, _dp, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_profile_pipeline": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _i, _dp, _dp],
 }
 

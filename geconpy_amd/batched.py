@@ -457,3 +457,66 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
         )
     )
     return out
+
+
+def second_order_structure(A, C, Z):
+    """Model structure the second-order path takes as index lists (int32): the state variables S (non-zero columns of A in
+    any draw), the forward-looking variables L (non-zero columns of C) and the variables the pruned filter retains, U = S
+    followed by the observed non-states (non-zero columns of Z)."""
+    A = np.asarray(A)
+    C = np.asarray(C)
+    n = A.shape[-1]
+    S = np.flatnonzero(np.any(A.reshape(-1, n) != 0, axis=0))
+    Lc = np.flatnonzero(np.any(C.reshape(-1, n) != 0, axis=0))
+    obs = np.flatnonzero(np.any(np.asarray(Z).reshape(-1, n) != 0, axis=0))
+    U = np.concatenate([S, np.setdiff1d(obs, S)])
+    return S.astype(np.int32), Lc.astype(np.int32), U.astype(np.int32)
+
+
+def second_order_logp_batched(A, B, C, D, hess_idx, hess_val, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-8,
+                              max_iter=1000, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, return_solution=False,
+                              structure=None, options=None):
+    """Second-order perturbation + pruned-state-space quasi-likelihood per draw (include/dsge_hip.h:
+    ``dsge_second_order_logp_batched``; BASELINE configs[4]).  The reference raises ``NotImplementedError`` for ``order != 1``
+    (gEconpy/model/perturbation.py:97-98); this is what replaces the raise.
+    ``hess_idx``: (nnz, 3) int32 (equation, z_a <= z_b) sorted by equation, z = [y-; y; y+; u]; ``hess_val``: (batch, nnz);
+    ``q``: (k,) or (batch, k) shock variances; ``Z``: (p, n), p <= 8.
+    Returns dict(logp, status[, T, R, g_yy (batch, n, s, s), g_yu (batch, n, s, k), g_uu (batch, n, k, k), g_ss (batch, n), S])."""
+    A, B, C = _check_abc(A, B, C)
+    D = _f64(D, 3)
+    y = _f64(y, 2)
+    nb, n, _ = A.shape
+    k = D.shape[2]
+    T_len, p = y.shape
+    hess_idx = np.ascontiguousarray(hess_idx, dtype=np.int32).reshape(-1, 3)
+    nnz = hess_idx.shape[0]
+    hess_val = _f64(hess_val, 2)
+    if hess_val.shape != (nb, nnz):
+        raise ValueError("hess_val must be (batch, nnz)")
+    q = _f64(q)
+    if q.shape not in ((k,), (nb, k)):
+        raise ValueError("q must be (k,) or (batch, k) (diagonal shock covariance)")
+    Z = _f64(Z, 2)
+    if Z.shape != (p, n):
+        raise ValueError("Z must be (p, n)")
+    d = None if d is None else _f64(d, 1)
+    Hdiag = None if Hdiag is None else _f64(Hdiag, 1)
+    S, Lc, U = second_order_structure(A, C, Z) if structure is None else (np.ascontiguousarray(x, dtype=np.int32) for x in structure)
+    s = len(S)
+    out = dict(logp=np.empty(nb), status=np.empty(nb, dtype=np.int32))
+    T = R = gyy = gyu = guu = gss = None
+    if return_solution:
+        T, R = np.empty_like(A), np.empty((nb, n, k))
+        gyy, gyu, guu, gss = np.empty((nb, n, s, s)), np.empty((nb, n, s, k)), np.empty((nb, n, k, k)), np.empty((nb, n))
+    with _lib.options_scope(options):
+        _lib.check(
+            _lib.load().dsge_second_order_logp_batched_host(
+                _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(hess_idx), nnz, _ptr(hess_val), _ptr(q), int(q.ndim == 2), _ptr(Z),
+                _ptr(d), _ptr(Hdiag), _ptr(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter),
+                float(jitter), float(missing_fill_value), _ptr(S), s, _ptr(Lc), len(Lc), _ptr(U), len(U), _ptr(out["logp"]),
+                _ptr(out["status"]), _ptr(T), _ptr(R), _ptr(gyy), _ptr(gyu), _ptr(guu), _ptr(gss)
+            )
+        )
+    if return_solution:
+        out.update(T=T, R=R, g_yy=gyy, g_yu=gyu, g_uu=guu, g_ss=gss, S=S)
+    return out

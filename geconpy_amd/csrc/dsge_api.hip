@@ -257,6 +257,11 @@ int dsge_debug_cr_phases(int enable, long long* cycles_out) {
   }
   return DSGE_SUCCESS;
 }
+int dsge_debug_adjoint_refine(int mode) {
+  if (mode < 0 || mode > 2) return fail(DSGE_ERR_INVALID, "mode out of range (0..2)");
+  g_adj_refine_mode = mode;
+  return DSGE_SUCCESS;
+}
 int dsge_set_cr_fused_selection(int enable) {
   g_defaults.cr_fused_selection = enable ? 1 : 0;
   return DSGE_SUCCESS;
@@ -720,6 +725,72 @@ int dsge_solve_kalman_logp_batched(const double* A, const double* B, const doubl
     HIP_TRY(hipStreamWaitEvent(caller, s_ev[i], 0));
   }
   return rc;
+}
+
+int dsge_second_order_logp_batched(const double* A, const double* B, const double* C, const double* D,
+                                   const int32_t* hess_idx, int nnz, const double* hess_val, const double* q, int q_batched,
+                                   const double* Z, const double* d, const double* Hdiag, const double* y, int batch, int n,
+                                   int k, int p, int T_len, int solver, double tol, int max_iter, double jitter,
+                                   double missing_fill, const int32_t* state_idx, int n_state, const int32_t* lead_idx,
+                                   int n_lead, const int32_t* ret_idx, int n_ret, double* logp_out, int32_t* status_out,
+                                   double* T_out, double* R_out, double* gyy_out, double* gyu_out, double* guu_out,
+                                   double* gss_out, float* stage_ms, void* stream) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
+  if (p < 1 || p > 8) return fail(DSGE_ERR_INVALID, "second order: p out of range (1..8)");
+  if (T_len < 0 || nnz < 0) return fail(DSGE_ERR_INVALID, "T_len < 0 or nnz < 0");
+  if (!A || !B || !C || !D || (nnz > 0 && (!hess_idx || !hess_val)) || !q || !Z || !y || !logp_out || !status_out ||
+      !state_idx || !ret_idx || (n_lead > 0 && !lead_idx))
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_GENSYS)
+    return fail(DSGE_ERR_INVALID, "second order: solver must be cycle reduction or gensys");
+  for (int i = 0; i < n_state; ++i)
+    if (state_idx[i] < 0 || state_idx[i] >= n) return fail(DSGE_ERR_INVALID, "state_idx out of range");
+  for (int i = 0; i < n_lead; ++i)
+    if (lead_idx[i] < 0 || lead_idx[i] >= n) return fail(DSGE_ERR_INVALID, "lead_idx out of range");
+  for (int i = 0; i < n_ret; ++i)
+    if (ret_idx[i] < 0 || ret_idx[i] >= n) return fail(DSGE_ERR_INVALID, "ret_idx out of range");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = nullptr;
+  if ((rc = scratch_reserve(st, align256(nn * 8) + align256(nk * 8) + 2 * align256((size_t)batch * 12) + 4096, &base)))
+    return rc;
+  Carver cv(base);
+  double* Tw = T_out ? T_out : cv.take<double>(nn);
+  double* Rw = R_out ? R_out : cv.take<double>(nk);
+  int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
+  int32_t* it_w = cv.take<int32_t>((size_t)batch);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (stage_ms) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+  }
+  if (solver == DSGE_SOLVER_CYCLE_REDUCTION) {
+    int deflated = 0;
+    if ((rc = launch_cr_deflated(A, B, C, D, batch, n, k, max_iter, tol, Tw, Rw, status_out, it_w, st, &deflated))) return rc;
+    if (!deflated && (rc = launch_cr(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st, 0, D, k, Rw))) return rc;
+  } else {
+    if ((rc = launch_gensys(A, B, C, batch, n, tol, n_lead, Tw, eu_w, status_out, st))) return rc;
+    if ((rc = launch_assemble(A, B, C, D, Tw, nullptr, q, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, batch, n, k,
+                              Rw, nullptr, nullptr, nullptr, status_out, 1, 0, st)))
+      return rc;
+  }
+  if (stage_ms) HIP_TRY(hipEventRecord(e1, st));
+  rc = launch_second_order(B, C, Tw, Rw, hess_idx, nnz, hess_val, q, q_batched, Z, d, Hdiag, y, batch, n, k, p, T_len, jitter,
+                           missing_fill, state_idx, n_state, lead_idx, n_lead, ret_idx, n_ret, logp_out, status_out, gyy_out,
+                           gyu_out, guu_out, gss_out, nullptr, nullptr, st, stage_ms ? stage_ms + 1 : nullptr);
+  if (rc) return rc;
+  if (stage_ms) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&stage_ms[0], e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  return DSGE_SUCCESS;
 }
 
 int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, const double* C, const double* D,
@@ -1186,6 +1257,66 @@ int dsge_policy_adjoints_batched_host(const double* B, const double* C, const do
   DOWN(B_bar, dBb, nn, double);
   DOWN(C_bar, dCb, nn, double);
   DOWN(status, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return DSGE_SUCCESS;
+}
+
+int dsge_second_order_logp_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                        const int32_t* hess_idx, int nnz, const double* hess_val, const double* q,
+                                        int q_batched, const double* Z, const double* d, const double* Hdiag, const double* y,
+                                        int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                                        double jitter, double missing_fill, const int32_t* state_idx, int n_state,
+                                        const int32_t* lead_idx, int n_lead, const int32_t* ret_idx, int n_ret,
+                                        double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* gyy_out,
+                                        double* gyu_out, double* guu_out, double* gss_out) {
+  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  if (rc) return rc;
+  if (k < 1 || k > n || p < 1 || p > 8 || T_len < 0 || nnz < 0 || n_state < 1 || n_state > 24)
+    return fail(DSGE_ERR_INVALID, "second order: size out of range");
+  if (!A || !B || !C || !D || (nnz > 0 && (!hess_idx || !hess_val)) || !q || !Z || !y || !logp_out || !status_out)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nv = (size_t)batch * nnz, ss = (size_t)n_state * n_state;
+  void* base = nullptr;
+  STAGE_RESERVE(5 * align256(nn * 8) + 4 * align256(nk * 8) + align256(nv * 8) + align256((size_t)nnz * 12) +
+                    align256((size_t)batch * k * 8) + align256(nn / n * ss * 8 + 64) + align256(nk * n_state * 8 + 64) +
+                    align256((size_t)batch * n * k * k * 8 + 64) + align256((size_t)batch * n * 8) +
+                    align256((size_t)p * n * 8) + 2 * align256((size_t)p * 8) + align256((size_t)T_len * p * 8 + 8) +
+                    2 * align256((size_t)batch * 8) + 16384,
+                &base);
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dHi, hess_idx, (size_t)nnz * 3, int32_t);
+  UP(dHv, hess_val, nv, double);
+  UP(dq, q, q_batched ? (size_t)batch * k : (size_t)k, double);
+  UP(dZ, Z, (size_t)p * n, double);
+  UP(dd, d, p, double);
+  UP(dH, Hdiag, p, double);
+  UP(dy, y, (size_t)T_len * p, double);
+  OUTBUF(dlp, logp_out, batch, double);
+  OUTBUF(dst, status_out, batch, int32_t);
+  OUTBUF(dT, T_out, nn, double);
+  OUTBUF(dR, R_out, nk, double);
+  OUTBUF(dgyy, gyy_out, (size_t)batch * n * ss, double);
+  OUTBUF(dgyu, gyu_out, (size_t)batch * n * n_state * k, double);
+  OUTBUF(dguu, guu_out, (size_t)batch * n * k * k, double);
+  OUTBUF(dgss, gss_out, (size_t)batch * n, double);
+  if ((rc = dsge_second_order_logp_batched(dA, dB, dC, dD, dHi, nnz, dHv, dq, q_batched, dZ, dd, dH, dy, batch, n, k, p, T_len,
+                                           solver, tol, max_iter, jitter, missing_fill, state_idx, n_state, lead_idx, n_lead,
+                                           ret_idx, n_ret, dlp, dst, dT, dR, dgyy, dgyu, dguu, dgss, nullptr, nullptr)))
+    return rc;
+  DOWN(logp_out, dlp, batch, double);
+  DOWN(status_out, dst, batch, int32_t);
+  DOWN(T_out, dT, nn, double);
+  DOWN(R_out, dR, nk, double);
+  DOWN(gyy_out, dgyy, (size_t)batch * n * ss, double);
+  DOWN(gyu_out, dgyu, (size_t)batch * n * n_state * k, double);
+  DOWN(guu_out, dguu, (size_t)batch * n * k * k, double);
+  DOWN(gss_out, dgss, (size_t)batch * n, double);
   HIP_TRY(hipStreamSynchronize(nullptr));
   return DSGE_SUCCESS;
 }

@@ -86,12 +86,13 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
     blk_store_lds<BS>(Rb, G1, LDW, lr, lc);
     double inv_lo = 1e300, inv_hi = 0.0;
     gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, ph, inv_lo, inv_hi);  // syncs on entry and exit
-    // One step of iterative refinement, X += A1^-1 (R - A1 X), when the pivots of one of the first two iterations span more
-    // than CR_REFINE_PIVOT_RATIO: the iteration's A1 has its worst condition there (A1 = B in the first), the blocked
-    // Gauss-Jordan loses ~1e-13 x cond where the reference's LAPACK LU keeps 1e-10, and one refinement step in these two
-    // iterations restores LAPACK's level (tools/blocked_elimination_model.py: 3e-7 -> 1.2e-10 on the flagged draw).  About one
-    // draw in several thousand takes the branch; the others are untouched (bit-identical).
-    if (it < 2 && __builtin_amdgcn_readfirstlane((int)(inv_hi > CR_REFINE_PIVOT_RATIO * inv_lo))) {
+    // One step of iterative refinement, X += A1^-1 (R - A1 X), in every iteration whose pivots span more than
+    // CR_REFINE_PIVOT_RATIO: the blocked Gauss-Jordan loses ~1e-15 x cond(A1) where the reference's LAPACK LU
+    // (cycle_reduction.py:150-160) keeps 1e-10, and the worst A1 of a draw may come as late as the third or fourth iteration
+    // (round 2 only looked at the first two: fuzz seed 23 found draws with a pivot ratio of 2.5e6 / 9e5 in iteration 2, 4..7e-9
+    // off in T; with the step they are at 6e-12 / 1e-10, tools/cr_refine_model.py).  About one draw in three hundred takes
+    // the branch in some iteration; the others are untouched (bit-identical).
+    if (__builtin_amdgcn_readfirstlane((int)(inv_hi > CR_REFINE_PIVOT_RATIO * inv_lo))) {
       gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);  // X in natural row order (syncs inside)
       double xh[BS][BS], rr[BS][BS];
       blk_load_lds<BS>(xh, G1, LDW, lr, lc);

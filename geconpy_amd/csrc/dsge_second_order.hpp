@@ -1,0 +1,1063 @@
+// Second-order perturbation + pruned-state-space quasi-likelihood (BASELINE.json configs[4]).
+//
+// The reference has NO second-order solver: it raises NotImplementedError at gEconpy/model/perturbation.py:97-98 and
+// gEconpy/model/model.py:1433-1434, 1614-1615.  What is built here is the published algorithm (Schmitt-Grohe & Uribe 2004 for
+// the coefficients; Kim, Kim, Schaumburg & Sims 2008 / Andreasen, Fernandez-Villaverde & Rubio-Ramirez 2018 for the pruned
+// system) in the reduced formulation of oracle/second_order.py (`second_order_solution_reduced`,
+// `pruned_state_space_reduced`, `pruned_kalman_logp`), which is what the kernels are checked against -- parity unpinned
+// against the reference by construction.
+//
+// Notation (gEconpy/model/perturbation.py:42-46): F(y-, y, y+, u) = 0, Jacobians A, B, C, D, first order y = T y- + R u.
+//   S = state variables (non-zero columns of A / T), s = |S|;  L = forward-looking variables (non-zero columns of C);
+//   U = S followed by the observed non-states, u = |U|;  z = [y-; y; y+; u] indexes the Hessian, given as COO entries
+//   (equation, z_a <= z_b) sorted by equation -- pattern shared by the draws, one value vector per draw.
+//   M = B + C T,  G = M^-1 C (non-zero columns: L),  Ts = T[S, S],  Rs = R[S].
+//
+// Three kernels, one workgroup per draw, hand-overs through a per-draw workspace in HBM (SoLayout):
+//   so_setup_kernel  (256 threads, VALU)   g_yy, g_yu, g_uu, g_ss: M^-1 by Gauss-Jordan, the Hessian contractions, the
+//                                          generalised Sylvester equation X + G X (Ts (x) Ts) = M^-1 rhs by DOUBLING on the
+//                                          state block (X_i as s x s matrices: X (Ts (x) Ts) is Ts' X_i Ts, only the rows L of
+//                                          it are needed), then the pruned system Az', c, the factors of Qz, the stationary
+//                                          mean
+//   so_lyap_kernel   (512 threads, MFMA)   Qz = Y' L (one product), P0 = dlyap(Az, Qz) by doubling (three products per step)
+//   so_filter_kernel (512 threads, MFMA)   the "standard" filter of oracle/statespace.py on the m = 2u + s(s+1)/2 dimensional
+//                                          pruned state (207 on the SW-shaped workload): rank-p update on the VALU, the
+//                                          prediction Az P+ Az' + Qz as two products on the FP64 matrix core
+//                                          (dsge_so_gemm.hpp), steady-state switch as in the first-order kernels
+#pragma once
+#include "dsge_device.hpp"
+#include "dsge_so_gemm.hpp"
+
+namespace dsge {
+
+constexpr int SO_MAX_S = 24, SO_MAX_K = 12, SO_MAX_P = 8;
+constexpr int32_t DSGE_ST_SO_UNSUPPORTED = 128;  // (mirrors DSGE_ST_SECOND_ORDER_UNSUPPORTED of dsge_hip.h)
+
+// Per-draw workspace (doubles).  Everything the three kernels hand to each other.
+struct SoLayout {
+  int n, k, s, u, l, p, q, m, MP, KQ, KQP;
+  size_t gyy, gyu, guu, gss, x0, azt, az, cvec, a0, lt, yt, qz, p0, wt, xb, ak, akt, ak2, akt2, pp, total;
+  __host__ __device__ static int pad8(int x) { return (x + 7) & ~7; }
+  // mt: tiles of 16 per side of the kernel instance that will run (>= ceil(m / 16))
+  __host__ __device__ void init(int n_, int k_, int s_, int u_, int l_, int p_, int mt) {
+    n = n_; k = k_; s = s_; u = u_; l = l_; p = p_;
+    q = s * (s + 1) / 2;
+    m = 2 * u + q;
+    MP = 16 * mt;
+    KQ = k + s * k + k * (k + 1) / 2;
+    KQP = pad8(KQ);
+    size_t o = 0;
+    auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 1) & ~(size_t)1; return r; };
+    gyy = take((size_t)n * s * s);
+    gyu = take((size_t)n * s * k);
+    guu = take((size_t)n * k * k);
+    gss = take(n);
+    x0 = take((size_t)n * s * s);
+    const size_t mm = (size_t)MP * MP;
+    azt = take(mm);   // Az' (row k = column k of Az): the k-major operand of Az X
+    az = take(mm);    // Az
+    cvec = take(MP);
+    a0 = take(MP);
+    lt = take((size_t)KQP * MP);
+    yt = take((size_t)KQP * MP);
+    qz = take(mm);
+    p0 = take(mm);
+    wt = take(mm);
+    xb = take(mm);
+    ak = take(mm);
+    akt = take(mm);
+    ak2 = take(mm);
+    akt2 = take(mm);
+    pp = take(mm);
+    total = o;
+  }
+};
+
+// ---- small dense helpers for a workgroup of NT threads on LDS / L2-resident arrays ------------------------------------------
+
+// In-place Gauss-Jordan with partial pivoting on the n x w array Aug (row stride ld, LDS): the leading n x n block becomes the
+// identity, the remaining columns X with A X = rhs.  colbuf: n doubles, red: 2 ints (LDS).  Returns false on a zero / NaN pivot.
+template <int NT>
+__device__ __forceinline__ bool so_gauss_jordan(double* Aug, int ld, int n, int w, double* colbuf, int* red) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  bool ok = true;
+  for (int c = 0; c < n; ++c) {
+    __syncthreads();
+    if (tid < 64) {  // pivot: largest |entry| of column c among rows >= c
+      double best = -1.0;
+      int bi = c;
+      for (int r = c + lane; r < n; r += 64) {
+        const double v = fabs(Aug[r * ld + c]);
+        if (v > best || v != v) { best = v; bi = r; }
+      }
+      for (int mk = 32; mk >= 1; mk >>= 1) {
+        const double ob = __shfl_xor(best, mk, 64);
+        const int oi = __shfl_xor(bi, mk, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) {
+        red[0] = bi;
+        red[1] = (best > 0.0 && best < 1e300) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    const int pr = red[0];
+    if (!red[1]) ok = false;
+    if (pr != c)
+      for (int j = tid; j < w; j += NT) {
+        const double t = Aug[c * ld + j];
+        Aug[c * ld + j] = Aug[pr * ld + j];
+        Aug[pr * ld + j] = t;
+      }
+    __syncthreads();
+    const double inv = 1.0 / Aug[c * ld + c];
+    for (int r = tid; r < n; r += NT) colbuf[r] = Aug[r * ld + c];
+    __syncthreads();
+    for (int j = tid; j < w; j += NT) Aug[c * ld + j] *= inv;
+    __syncthreads();
+    for (int idx = tid; idx < n * w; idx += NT) {
+      const int r = idx / w, j = idx - r * w;
+      if (r != c) Aug[r * ld + j] = fma(-colbuf[r], Aug[c * ld + j], Aug[r * ld + j]);
+    }
+  }
+  __syncthreads();
+  return ok;
+}
+
+// workgroup maximum of a per-thread value (NaN-propagating); red: NT / 64 doubles of LDS
+template <int NT>
+__device__ __forceinline__ double so_wg_max(double v, double* red) {
+  v = wave_nanmax(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r = nanmax(r, red[w]);
+  return r;
+}
+
+struct SoIdx {  // the model's index sets, passed by value in the kernel arguments
+  uint8_t S[SO_MAX_S];   // state variables (non-zero columns of A), ascending
+  uint8_t U[40];         // retained variables: S, then the observed non-states
+  uint8_t L[64];         // forward-looking variables (non-zero columns of C)
+};
+
+struct SoSetupArgs {
+  const double* B;
+  const double* C;
+  const double* T;
+  const double* R;
+  const int32_t* hess_ptr;   // [n + 1] offsets into the entry list, by equation (so_hessptr_kernel)
+  const int32_t* hess_idx;   // [nnz][3] (equation, z_a <= z_b), sorted by equation
+  const double* hess_val;    // [batch][nnz]
+  const double* q;           // shock variances, [k] or [batch][k]
+  SoIdx ix;
+  const int32_t* flags;      // [2] device flags of the structure kernels (non-zero = unsupported input)
+  double* work;              // [batch][layout.total]
+  int32_t* status;           // [batch] in/out
+  double* gyy_out;           // optional caller copies of the coefficients: [batch][n][s][s], [n][s][k], [n][k][k], [n]
+  double* gyu_out;
+  double* guu_out;
+  double* gss_out;
+  int batch, nnz, q_batched;
+};
+
+constexpr int SO_SETUP_THREADS = 256;
+
+// LDS of the setup kernel (doubles): see the carve in the kernel
+__host__ __device__ inline size_t so_setup_lds_doubles(const SoLayout& L) {
+  const int n = L.n, k = L.k, s = L.s, l = L.l, mz = 3 * n + k;
+  size_t o = 0;
+  o += (size_t)n * (2 * n + 1);          // Maug = [M | I] -> [I | M^-1], one spare column
+  o += (size_t)n * s + (size_t)n * k;    // Tc = T[:, S], Rm = R
+  o += (size_t)mz * s + (size_t)mz * k;  // Zy, Zu
+  o += (size_t)n * l;                    // GL = (M^-1 C)[:, L]
+  o += (size_t)n * l;                    // Gk
+  o += 2 * (size_t)l * s * s;            // Y1, Y2
+  o += 3 * (size_t)s * s;                // Ts, Tk, Tk2
+  o += (size_t)s * s;                    // Pf
+  o += (size_t)l * l;                    // GLL scratch
+  o += (size_t)n + 64;                   // colbuf, reductions
+  o += (size_t)l * s * (s > k ? s : k);  // V / W
+  o += 192;                              // three short vectors
+  o += 96;                               // index lists
+  return o + 64;
+}
+
+__global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs a, SoLayout lay) {
+  constexpr int NT = SO_SETUP_THREADS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, draw = blockIdx.x;
+  if (draw >= a.batch) return;
+  if (a.status[draw] != 0) return;  // failed first-order solve: nothing to do (logp = -inf downstream)
+  const int n = lay.n, k = lay.k, s = lay.s, u = lay.u, l = lay.l, mz = 3 * n + k, ss = s * s;
+  double* wk = a.work + (size_t)draw * lay.total;
+  const double* Bg = a.B + (size_t)draw * n * n;
+  const double* Cg = a.C + (size_t)draw * n * n;
+  const double* Tg = a.T + (size_t)draw * n * n;
+  const double* Rg = a.R + (size_t)draw * n * k;
+  const double* hv = a.hess_val + (size_t)draw * a.nnz;
+  const double* qv = a.q + (a.q_batched ? (size_t)draw * k : 0);
+  // ---- carve LDS ---------------------------------------------------------------------------------------------------------
+  double* p_ = smem;
+  auto carve = [&](size_t cnt) { double* r = p_; p_ += cnt; return r; };
+  const int ldm = 2 * n + 1;
+  double* Maug = carve((size_t)n * ldm);
+  double* Tc = carve((size_t)n * s);
+  double* Rm = carve((size_t)n * k);
+  double* Zy = carve((size_t)mz * s);
+  double* Zu = carve((size_t)mz * k);
+  double* GL = carve((size_t)n * l);
+  double* Gk = carve((size_t)n * l);
+  double* Y1 = carve((size_t)l * ss);
+  double* Y2 = carve((size_t)l * ss);
+  double* Ts = carve(ss);
+  double* Tk = carve(ss);
+  double* Tk2 = carve(ss);
+  double* Pf = carve(ss);
+  double* GLL = carve((size_t)l * l);
+  double* colbuf = carve(n);
+  double* red = carve(32);
+  int* ired = (int*)carve(32);
+  double* VW = carve((size_t)l * s * (s > k ? s : k));
+  double* vec3 = carve(192);
+  int* Si = (int*)carve(96);  // S (24), U (40), L (64) as ints
+  int* Ui = Si + 24;
+  int* Li = Ui + 40;
+  if (tid < 24) Si[tid] = a.ix.S[tid];
+  if (tid < 40) Ui[tid] = a.ix.U[tid];
+  if (tid < 64) Li[tid] = a.ix.L[tid];
+  __syncthreads();
+  if (a.flags[0] | a.flags[1]) {
+    if (tid == 0) a.status[draw] |= DSGE_ST_SO_UNSUPPORTED;
+    return;
+  }
+  // ---- 1. T[:, S], R; structure check: T must vanish outside the columns S ------------------------------------------------
+  bool bad = false;
+  for (int idx = tid; idx < n * n; idx += NT) {
+    const int j = idx % n;
+    bool in_s = false;
+    for (int c = 0; c < s; ++c) in_s = in_s || (Si[c] == j);
+    if (!in_s && Tg[idx] != 0.0) bad = true;
+  }
+  for (int idx = tid; idx < n * s; idx += NT) Tc[idx] = Tg[(size_t)(idx / s) * n + Si[idx % s]];
+  for (int idx = tid; idx < n * k; idx += NT) Rm[idx] = Rg[idx];
+  __syncthreads();
+  for (int idx = tid; idx < ss; idx += NT) Ts[idx] = Tc[Si[idx / s] * s + idx % s];
+  // ---- 2. M = B + C T (only the columns S of C T are non-zero) -> Maug = [M | I] ------------------------------------------
+  for (int idx = tid; idx < n * n; idx += NT) {
+    const int i = idx / n, j = idx - i * n;
+    Maug[i * ldm + j] = Bg[idx];
+    Maug[i * ldm + n + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * s; idx += NT) {
+    const int i = idx / s, c = idx - i * s;
+    double acc = 0.0;
+    for (int jj = 0; jj < l; ++jj) acc = fma(Cg[(size_t)i * n + Li[jj]], Tc[Li[jj] * s + c], acc);
+    Maug[i * ldm + Si[c]] += acc;
+  }
+  // columns of C outside L must vanish (the caller's L is a model property)
+  for (int idx = tid; idx < n * n; idx += NT) {
+    const int j = idx % n;
+    bool in_l = false;
+    for (int c = 0; c < l; ++c) in_l = in_l || (Li[c] == j);
+    if (!in_l && Cg[idx] != 0.0) bad = true;
+  }
+  if (__syncthreads_or(bad ? 1 : 0)) {
+    if (tid == 0) a.status[draw] |= DSGE_ST_SO_UNSUPPORTED;
+    return;
+  }
+  // M + C (for g_ss) is needed after M is gone: park it in the workspace's x0 block is too small -> use Az block (free until step 13)
+  double* MpC = wk + lay.az;
+  for (int idx = tid; idx < n * n; idx += NT) {
+    const int i = idx / n, j = idx - i * n;
+    MpC[idx] = Maug[i * ldm + j] + Cg[idx];
+  }
+  bool okm = so_gauss_jordan<NT>(Maug, ldm, n, 2 * n, colbuf, ired);
+  const double* Mi = Maug + n;  // M^-1, row stride ldm
+  // ---- 4. GL = (M^-1 C)[:, L];  5. Zy = [e_S; T[:, S]; (T T)[:, S]; 0],  Zu = [0; R; T R; I] ------------------------------
+  for (int idx = tid; idx < n * l; idx += NT) {
+    const int i = idx / l, jj = idx - i * l;
+    double acc = 0.0;
+    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], Cg[(size_t)r * n + Li[jj]], acc);
+    GL[idx] = acc;
+  }
+  for (int idx = tid; idx < mz * s; idx += NT) {
+    const int r = idx / s, c = idx - r * s;
+    double v = 0.0;
+    if (r < n) v = (Si[c] == r) ? 1.0 : 0.0;
+    else if (r < 2 * n) v = Tc[(r - n) * s + c];
+    else if (r < 3 * n) {
+      const int i = r - 2 * n;
+      for (int b = 0; b < s; ++b) v = fma(Tc[i * s + b], Ts[b * s + c], v);  // (T T)[:, S] = T[:, S] Ts
+    }
+    Zy[idx] = v;
+  }
+  for (int idx = tid; idx < mz * k; idx += NT) {
+    const int r = idx / k, j = idx - r * k;
+    double v = 0.0;
+    if (r >= n && r < 2 * n) v = Rm[(r - n) * k + j];
+    else if (r >= 2 * n && r < 3 * n) {
+      const int i = r - 2 * n;
+      for (int b = 0; b < s; ++b) v = fma(Tc[i * s + b], Rm[Si[b] * k + j], v);  // T R = T[:, S] R[S]
+    } else if (r >= 3 * n) v = (r - 3 * n == j) ? 1.0 : 0.0;
+    Zu[idx] = v;
+  }
+  __syncthreads();
+  // ---- 6. rhs_yy = -H (Zy (x) Zy) -> x0 (global);  7. X = M^-1 rhs -> gyy block (global) ---------------------------------
+  double* X0 = wk + lay.x0;
+  double* X = wk + lay.gyy;
+  for (int idx = tid; idx < n * ss; idx += NT) {
+    const int i = idx / ss, cd = idx - i * ss, c = cd / s, d = cd - c * s;
+    double acc = 0.0;
+    for (int e = a.hess_ptr[i]; e < a.hess_ptr[i + 1]; ++e) {
+      const int za = a.hess_idx[3 * e + 1], zb = a.hess_idx[3 * e + 2];
+      const double v = hv[e];
+      acc = fma(v, Zy[za * s + c] * Zy[zb * s + d], acc);
+      if (za != zb) acc = fma(v, Zy[zb * s + c] * Zy[za * s + d], acc);
+    }
+    X0[idx] = -acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * ss; idx += NT) {
+    const int i = idx / ss, cd = idx - i * ss;
+    double acc = 0.0;
+    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], X0[(size_t)r * ss + cd], acc);
+    X[idx] = acc;
+  }
+  // ---- 8. doubling: X <- X - G_k (X (T_k (x) T_k)),  sign: X + G X (Ts (x) Ts) = X0  =>  X = sum_j (-G)^j X0 (Ts (x) Ts)^j ------
+  for (int idx = tid; idx < n * l; idx += NT) Gk[idx] = -GL[idx];
+  for (int idx = tid; idx < ss; idx += NT) Tk[idx] = Ts[idx];
+  __syncthreads();
+  bool conv = false;
+  for (int it = 0; it < 40 && !conv; ++it) {
+    // Y1[j] = X[L_j] T_k,  Y2[j] = T_k' Y1[j]
+    for (int idx = tid; idx < l * ss; idx += NT) {
+      const int jj = idx / ss, ad = idx - jj * ss, a_ = ad / s, d = ad - a_ * s;
+      const double* xr = X + (size_t)Li[jj] * ss + a_ * s;
+      double acc = 0.0;
+      for (int b = 0; b < s; ++b) acc = fma(xr[b], Tk[b * s + d], acc);
+      Y1[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < l * ss; idx += NT) {
+      const int jj = idx / ss, cd = idx - jj * ss, c = cd / s, d = cd - c * s;
+      double acc = 0.0;
+      for (int a_ = 0; a_ < s; ++a_) acc = fma(Tk[a_ * s + c], Y1[jj * ss + a_ * s + d], acc);
+      Y2[idx] = acc;
+    }
+    __syncthreads();
+    double dmax = 0.0, xmax = 0.0;
+    for (int idx = tid; idx < n * ss; idx += NT) {
+      const int i = idx / ss, cd = idx - i * ss;
+      double acc = 0.0;
+      for (int jj = 0; jj < l; ++jj) acc = fma(Gk[i * l + jj], Y2[jj * ss + cd], acc);
+      const double xn = X[idx] + acc;
+      X[idx] = xn;
+      dmax = nanmax(dmax, fabs(acc));
+      xmax = nanmax(xmax, fabs(xn));
+    }
+    // G_{k+1}[:, L] = G_k[:, L] G_k[L, L],  T_{k+1} = T_k T_k
+    for (int idx = tid; idx < l * l; idx += NT) GLL[idx] = Gk[Li[idx / l] * l + idx % l];
+    for (int idx = tid; idx < ss; idx += NT) {
+      const int r = idx / s, c = idx - r * s;
+      double acc = 0.0;
+      for (int b = 0; b < s; ++b) acc = fma(Tk[r * s + b], Tk[b * s + c], acc);
+      Tk2[idx] = acc;
+    }
+    dmax = so_wg_max<NT>(dmax, red);
+    xmax = so_wg_max<NT>(xmax, red);  // (barriers inside: GLL, Tk2 and X are complete)
+    double* Gn = GL;  // (GL is dead after step 8 starts: next G_k goes there, then swapped back)
+    for (int idx = tid; idx < n * l; idx += NT) {
+      const int i = idx / l, c = idx - i * l;
+      double acc = 0.0;
+      for (int b = 0; b < l; ++b) acc = fma(Gk[i * l + b], GLL[b * l + c], acc);
+      Gn[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * l; idx += NT) Gk[idx] = Gn[idx];
+    for (int idx = tid; idx < ss; idx += NT) Tk[idx] = Tk2[idx];
+    __syncthreads();
+    if (!(dmax == dmax) || !(xmax < 1e300)) {
+      okm = false;
+      break;
+    }
+    conv = dmax <= 1e-17 * xmax;
+  }
+  if (!conv) okm = false;
+  // GL was overwritten: recompute GL = (M^-1 C)[:, L] is not needed below (only M^-1 and C are)
+  // ---- 9. g_yu = -M^-1 [H (Zy (x) Zu) + C g_yy (T (x) R)] -----------------------------------------------------------------
+  // V[j][c][q] = sum_{a,b} X[L_j][a][b] Ts[a][c] Rs[b][q]
+  for (int idx = tid; idx < l * s * k; idx += NT) {  // Y1[j][a][q] = sum_b X[L_j][a][b] Rs[b][q]
+    const int jj = idx / (s * k), aq = idx - jj * s * k, a_ = aq / k, qq = aq - a_ * k;
+    const double* xr = X + (size_t)Li[jj] * ss + a_ * s;
+    double acc = 0.0;
+    for (int b = 0; b < s; ++b) acc = fma(xr[b], Rm[Si[b] * k + qq], acc);
+    Y1[idx] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < l * s * k; idx += NT) {
+    const int jj = idx / (s * k), cq = idx - jj * s * k, c = cq / k, qq = cq - c * k;
+    double acc = 0.0;
+    for (int a_ = 0; a_ < s; ++a_) acc = fma(Ts[a_ * s + c], Y1[jj * s * k + a_ * k + qq], acc);
+    VW[idx] = acc;
+  }
+  __syncthreads();
+  double* Gyu = wk + lay.gyu;
+  for (int idx = tid; idx < n * s * k; idx += NT) {
+    const int i = idx / (s * k), cq = idx - i * s * k, c = cq / k, qq = cq - c * k;
+    double acc = 0.0;
+    for (int e = a.hess_ptr[i]; e < a.hess_ptr[i + 1]; ++e) {
+      const int za = a.hess_idx[3 * e + 1], zb = a.hess_idx[3 * e + 2];
+      const double v = hv[e];
+      acc = fma(v, Zy[za * s + c] * Zu[zb * k + qq], acc);
+      if (za != zb) acc = fma(v, Zy[zb * s + c] * Zu[za * k + qq], acc);
+    }
+    for (int jj = 0; jj < l; ++jj) acc = fma(Cg[(size_t)i * n + Li[jj]], VW[jj * s * k + cq], acc);
+    X0[idx] = acc;  // (x0 block reused: n s k <= n s s is not guaranteed -> sized n s s with s >= k checked by the launcher)
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * s * k; idx += NT) {
+    const int i = idx / (s * k), cq = idx - i * s * k;
+    double acc = 0.0;
+    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], X0[(size_t)r * s * k + cq], acc);
+    Gyu[idx] = -acc;
+  }
+  __syncthreads();
+  // ---- 10. g_uu = -M^-1 [H (Zu (x) Zu) + C g_yy (R (x) R)] ---------------------------------------------------------------
+  for (int idx = tid; idx < l * k * k; idx += NT) {  // W[j][p][q] = sum_a Rs[a][p] Y1[j][a][q]  (Y1 of step 9 is still valid)
+    const int jj = idx / (k * k), pq = idx - jj * k * k, pp = pq / k, qq = pq - pp * k;
+    double acc = 0.0;
+    for (int a_ = 0; a_ < s; ++a_) acc = fma(Rm[Si[a_] * k + pp], Y1[jj * s * k + a_ * k + qq], acc);
+    VW[idx] = acc;
+  }
+  __syncthreads();
+  double* Guu = wk + lay.guu;
+  for (int idx = tid; idx < n * k * k; idx += NT) {
+    const int i = idx / (k * k), pq = idx - i * k * k, pp = pq / k, qq = pq - pp * k;
+    double acc = 0.0;
+    for (int e = a.hess_ptr[i]; e < a.hess_ptr[i + 1]; ++e) {
+      const int za = a.hess_idx[3 * e + 1], zb = a.hess_idx[3 * e + 2];
+      const double v = hv[e];
+      acc = fma(v, Zu[za * k + pp] * Zu[zb * k + qq], acc);
+      if (za != zb) acc = fma(v, Zu[zb * k + pp] * Zu[za * k + qq], acc);
+    }
+    for (int jj = 0; jj < l; ++jj) acc = fma(Cg[(size_t)i * n + Li[jj]], VW[jj * k * k + pq], acc);
+    X0[idx] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * k * k; idx += NT) {
+    const int i = idx / (k * k), pq = idx - i * k * k;
+    double acc = 0.0;
+    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], X0[(size_t)r * k * k + pq], acc);
+    Guu[idx] = -acc;
+  }
+  __syncthreads();
+  // ---- 11. g_ss = -(M + C)^-1 [C g_uu + H (Zu' (x) Zu')] vec(Sigma),  Zu' = [0; 0; R; 0],  Sigma = diag(q) ------------------
+  for (int i = tid; i < n; i += NT) {
+    double acc = 0.0;
+    for (int jj = 0; jj < l; ++jj) {
+      double t = 0.0;
+      for (int pp = 0; pp < k; ++pp) t = fma(Guu[(size_t)Li[jj] * k * k + pp * k + pp], qv[pp], t);
+      acc = fma(Cg[(size_t)i * n + Li[jj]], t, acc);
+    }
+    for (int e = a.hess_ptr[i]; e < a.hess_ptr[i + 1]; ++e) {
+      const int za = a.hess_idx[3 * e + 1], zb = a.hess_idx[3 * e + 2];
+      if (za >= 2 * n && za < 3 * n && zb >= 2 * n && zb < 3 * n) {
+        double t = 0.0;
+        for (int pp = 0; pp < k; ++pp) t = fma(Rm[(za - 2 * n) * k + pp] * Rm[(zb - 2 * n) * k + pp], qv[pp], t);
+        acc = fma(hv[e] * (za != zb ? 2.0 : 1.0), t, acc);
+      }
+    }
+    colbuf[i] = acc;
+  }
+  __syncthreads();
+  // Maug <- [M + C | rhs]: M^-1 is not needed any more
+  for (int idx = tid; idx < n * n; idx += NT) Maug[(idx / n) * ldm + idx % n] = MpC[idx];
+  for (int i = tid; i < n; i += NT) Maug[i * ldm + n] = colbuf[i];
+  okm = so_gauss_jordan<NT>(Maug, ldm, n, n + 1, colbuf, ired) && okm;
+  double* Gss = wk + lay.gss;
+  for (int i = tid; i < n; i += NT) Gss[i] = -Maug[i * ldm + n];
+  __syncthreads();
+  // =========================================================================================================================
+  // The pruned system on z = [x_f[U]; x_s[U]; w], w_(a<=b) = x_f[S_a] x_f[S_b] (row-major upper triangle)
+  // =========================================================================================================================
+  const int q_ = lay.q, m = lay.m, MP = lay.MP, KQP = lay.KQP;
+  double* AzT = wk + lay.azt;
+  double* Az = wk + lay.az;
+  double* cvec = wk + lay.cvec;
+  double* a0 = wk + lay.a0;
+  double* Lt = wk + lay.lt;
+  double* Yt = wk + lay.yt;
+  for (size_t idx = tid; idx < (size_t)MP * MP; idx += NT) {
+    AzT[idx] = 0.0;
+    Az[idx] = 0.0;
+  }
+  for (size_t idx = tid; idx < (size_t)KQP * MP; idx += NT) {
+    Lt[idx] = 0.0;
+    Yt[idx] = 0.0;
+  }
+  for (int idx = tid; idx < MP; idx += NT) {
+    cvec[idx] = 0.0;
+    a0[idx] = 0.0;
+  }
+  // pair tables (a <= b) in LDS (ints over the dead Zy block)
+  int* pa = (int*)Zy;
+  int* pb = pa + q_;
+  __syncthreads();
+  for (int a_ = tid; a_ < s; a_ += NT) {
+    int base = a_ * s - a_ * (a_ - 1) / 2;  // number of pairs before row a_
+    for (int b = a_; b < s; ++b) {
+      pa[base + b - a_] = a_;
+      pb[base + b - a_] = b;
+    }
+  }
+  // ---- 12. Pf = dlyap(Ts, Rs Sigma Rs') by doubling --------------------------------------------------------------------
+  for (int idx = tid; idx < ss; idx += NT) {
+    const int r = idx / s, c = idx - r * s;
+    double acc = 0.0;
+    for (int pp = 0; pp < k; ++pp) acc = fma(Rm[Si[r] * k + pp] * Rm[Si[c] * k + pp], qv[pp], acc);
+    Pf[idx] = acc;
+    Y2[idx] = acc;  // Rs Sigma Rs' kept for c_w
+    Tk[idx] = Ts[idx];
+  }
+  __syncthreads();
+  bool pconv = false;
+  for (int it = 0; it < 40 && !pconv; ++it) {
+    for (int idx = tid; idx < ss; idx += NT) {  // Y1 = T_k Pf
+      const int r = idx / s, c = idx - r * s;
+      double acc = 0.0;
+      for (int b = 0; b < s; ++b) acc = fma(Tk[r * s + b], Pf[b * s + c], acc);
+      Y1[idx] = acc;
+    }
+    __syncthreads();
+    double dmax = 0.0, pmax = 0.0;
+    for (int idx = tid; idx < ss; idx += NT) {
+      const int r = idx / s, c = idx - r * s;
+      double acc = 0.0, acct = 0.0;
+      for (int b = 0; b < s; ++b) {
+        acc = fma(Y1[r * s + b], Tk[c * s + b], acc);   // (T_k Pf T_k')[r][c]
+        acct = fma(Y1[c * s + b], Tk[r * s + b], acct);  // its transpose entry: symmetrised increment
+      }
+      const double inc = 0.5 * (acc + acct);
+      Tk2[idx] = inc;
+      dmax = nanmax(dmax, fabs(inc));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ss; idx += NT) {
+      Pf[idx] += Tk2[idx];
+      pmax = nanmax(pmax, fabs(Pf[idx]));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ss; idx += NT) {
+      const int r = idx / s, c = idx - r * s;
+      double acc = 0.0;
+      for (int b = 0; b < s; ++b) acc = fma(Tk[r * s + b], Tk[b * s + c], acc);
+      Tk2[idx] = acc;
+    }
+    dmax = so_wg_max<NT>(dmax, red);
+    pmax = so_wg_max<NT>(pmax, red);
+    for (int idx = tid; idx < ss; idx += NT) Tk[idx] = Tk2[idx];
+    __syncthreads();
+    if (!(dmax == dmax) || !(pmax < 1e300)) break;
+    pconv = dmax <= 1e-17 * pmax;
+  }
+  if (!pconv) okm = false;
+  // ---- 13. Az and Az' ------------------------------------------------------------------------------------------------------
+  for (int idx = tid; idx < u * s; idx += NT) {  // T[U, S] in the x_f and x_s blocks
+    const int i = idx / s, c = idx - i * s;
+    const double v = Tc[Ui[i] * s + c];
+    Az[(size_t)i * MP + c] = v;
+    AzT[(size_t)c * MP + i] = v;
+    Az[(size_t)(u + i) * MP + u + c] = v;
+    AzT[(size_t)(u + c) * MP + u + i] = v;
+  }
+  for (int idx = tid; idx < u * q_; idx += NT) {  // 1/2 g_yy on the symmetric half
+    const int i = idx / q_, j = idx - i * q_, c = pa[j], d = pb[j];
+    const double* g = X + (size_t)Ui[i] * ss;
+    const double v = (c == d) ? 0.5 * g[c * s + c] : 0.5 * (g[c * s + d] + g[d * s + c]);
+    Az[(size_t)(u + i) * MP + 2 * u + j] = v;
+    AzT[(size_t)(2 * u + j) * MP + u + i] = v;
+  }
+  for (int idx = tid; idx < q_ * q_; idx += NT) {  // Elim (Ts (x) Ts) Dup
+    const int i = idx / q_, j = idx - i * q_, a_ = pa[i], b_ = pb[i], c = pa[j], d = pb[j];
+    double v = Ts[a_ * s + c] * Ts[b_ * s + d];
+    if (c != d) v = fma(Ts[a_ * s + d], Ts[b_ * s + c], v);
+    Az[(size_t)(2 * u + i) * MP + 2 * u + j] = v;
+    AzT[(size_t)(2 * u + j) * MP + 2 * u + i] = v;
+  }
+  // ---- 14. c;  15. the stationary mean a0 ----------------------------------------------------------------------------------
+  for (int i = tid; i < u; i += NT) {
+    double acc = Gss[Ui[i]];
+    for (int pp = 0; pp < k; ++pp) acc = fma(Guu[(size_t)Ui[i] * k * k + pp * k + pp], qv[pp], acc);
+    cvec[u + i] = 0.5 * acc;
+  }
+  for (int j = tid; j < q_; j += NT) {
+    cvec[2 * u + j] = Y2[pa[j] * s + pb[j]];
+    a0[2 * u + j] = Pf[pa[j] * s + pb[j]];
+  }
+  __syncthreads();
+  // b = Gh mean_w + c_xs (u entries);  x_S = (I - Ts)^-1 b_S by the product (I + T)(I + T^2)(I + T^4)... applied to b_S
+  double* bv = vec3;
+  double* xv = vec3 + 64;
+  double* xn = vec3 + 128;
+  for (int i = tid; i < u; i += NT) {
+    double acc = cvec[u + i];
+    for (int j = 0; j < q_; ++j) acc = fma(Az[(size_t)(u + i) * MP + 2 * u + j], a0[2 * u + j], acc);
+    bv[i] = acc;
+    if (i < s) xv[i] = acc;
+  }
+  for (int idx = tid; idx < ss; idx += NT) Tk[idx] = Ts[idx];
+  __syncthreads();
+  for (int it = 0; it < 40; ++it) {
+    double dm = 0.0, xm = 0.0;
+    for (int i = tid; i < s; i += NT) {
+      double acc = 0.0;
+      for (int b = 0; b < s; ++b) acc = fma(Tk[i * s + b], xv[b], acc);
+      xn[i] = xv[i] + acc;
+      dm = nanmax(dm, fabs(acc));
+      xm = nanmax(xm, fabs(xn[i]));
+    }
+    for (int idx = tid; idx < ss; idx += NT) {
+      const int r = idx / s, c = idx - r * s;
+      double acc = 0.0;
+      for (int b = 0; b < s; ++b) acc = fma(Tk[r * s + b], Tk[b * s + c], acc);
+      Tk2[idx] = acc;
+    }
+    dm = so_wg_max<NT>(dm, red);
+    xm = so_wg_max<NT>(xm, red);
+    for (int i = tid; i < s; i += NT) xv[i] = xn[i];
+    for (int idx = tid; idx < ss; idx += NT) Tk[idx] = Tk2[idx];
+    __syncthreads();
+    if (!(dm == dm) || !(xm < 1e300)) {
+      okm = false;
+      break;
+    }
+    if (dm <= 1e-18 * xm) break;
+  }
+  for (int i = tid; i < u; i += NT) {
+    double acc = bv[i];
+    for (int c = 0; c < s; ++c) acc = fma(Tc[Ui[i] * s + c], xv[c], acc);
+    a0[u + i] = acc;
+  }
+  // ---- 16. the factors of Qz = sum_r Yt[r][.]' Lt[r][.] ---------------------------------------------------------------------
+  //   rows [0, k):            L1 e:              L = [R[U]; 0; 0],                                   Y = q_j L
+  //   rows k + a k + j:       L2 (x_f[S_a] e_j): L = [0; g_yu[U, a, j]; Ts[a_, a] Rs[b_, j] + Ts[b_, a] Rs[a_, j]],  Y = q_j sum_b L_(b, j) Pf[b][a]
+  //   rows k + s k + (i<=j):  L3 (e_i e_j - .):  L = [0; 1/2 (g_uu[U, i, j] + [i != j] g_uu[U, j, i]); Rs[a_, i] Rs[b_, j] + [i != j] Rs[a_, j] Rs[b_, i]],
+  //                                              Y = (i == j ? 2 q_i^2 : q_i q_j) L
+  for (int idx = tid; idx < k * u; idx += NT) {
+    const int j = idx / u, i = idx - j * u;
+    const double v = Rm[Ui[i] * k + j];
+    Lt[(size_t)j * MP + i] = v;
+    Yt[(size_t)j * MP + i] = qv[j] * v;
+  }
+  for (int idx = tid; idx < s * k * (u + q_); idx += NT) {
+    const int row = idx / (u + q_), col = idx - row * (u + q_), a_ = row / k, j = row - a_ * k;
+    double v;
+    int mcol;
+    if (col < u) {
+      v = Gyu[(size_t)Ui[col] * s * k + a_ * k + j];
+      mcol = u + col;
+    } else {
+      const int pi = col - u, x_ = pa[pi], y_ = pb[pi];
+      v = Ts[x_ * s + a_] * Rm[Si[y_] * k + j] + Ts[y_ * s + a_] * Rm[Si[x_] * k + j];
+      mcol = 2 * u + pi;
+    }
+    Lt[(size_t)(k + row) * MP + mcol] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < s * k * (u + q_); idx += NT) {
+    const int row = idx / (u + q_), col = idx - row * (u + q_), a_ = row / k, j = row - a_ * k;
+    const int mcol = col < u ? u + col : 2 * u + (col - u);
+    double acc = 0.0;
+    for (int b = 0; b < s; ++b) acc = fma(Lt[(size_t)(k + b * k + j) * MP + mcol], Pf[b * s + a_], acc);
+    Yt[(size_t)(k + row) * MP + mcol] = qv[j] * acc;
+  }
+  {
+    const int r0 = k + s * k;
+    for (int idx = tid; idx < (k * (k + 1) / 2) * (u + q_); idx += NT) {
+      const int t = idx / (u + q_), col = idx - t * (u + q_);
+      int i = 0, rem = t;  // pair t -> (i <= j) of shocks, row-major upper triangle
+      while (rem >= k - i) {
+        rem -= k - i;
+        ++i;
+      }
+      const int j = i + rem;
+      double v;
+      int mcol;
+      if (col < u) {
+        const double* g = Guu + (size_t)Ui[col] * k * k;
+        v = (i == j) ? 0.5 * g[i * k + i] : 0.5 * (g[i * k + j] + g[j * k + i]);
+        mcol = u + col;
+      } else {
+        const int pi = col - u, x_ = pa[pi], y_ = pb[pi];
+        v = Rm[Si[x_] * k + i] * Rm[Si[y_] * k + j];
+        if (i != j) v = fma(Rm[Si[x_] * k + j], Rm[Si[y_] * k + i], v);
+        mcol = 2 * u + pi;
+      }
+      Lt[(size_t)(r0 + t) * MP + mcol] = v;
+      Yt[(size_t)(r0 + t) * MP + mcol] = ((i == j) ? 2.0 * qv[i] * qv[i] : qv[i] * qv[j]) * v;
+    }
+  }
+  (void)m;
+  if (a.gyy_out)
+    for (int idx = tid; idx < n * ss; idx += NT) a.gyy_out[(size_t)draw * n * ss + idx] = X[idx];
+  if (a.gyu_out)
+    for (int idx = tid; idx < n * s * k; idx += NT) a.gyu_out[(size_t)draw * n * s * k + idx] = Gyu[idx];
+  if (a.guu_out)
+    for (int idx = tid; idx < n * k * k; idx += NT) a.guu_out[(size_t)draw * n * k * k + idx] = Guu[idx];
+  if (a.gss_out)
+    for (int idx = tid; idx < n; idx += NT) a.gss_out[(size_t)draw * n + idx] = Gss[idx];
+  if (!okm && tid == 0) a.status[draw] |= DSGE_ST_NOT_CONVERGED;
+}
+
+// ---- structure kernels (one small workgroup each, once per call) -------------------------------------------------------------
+// offsets of the Hessian entries by equation; flag[0] != 0: entries unsorted / out of range / z_a > z_b
+__global__ void so_hessptr_kernel(const int32_t* __restrict__ idx, int nnz, int n, int k, int32_t* __restrict__ ptr,
+                                  int32_t* __restrict__ flag) {
+  __shared__ int cnt[DSGE_MAX_N + 1];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid <= n) cnt[tid] = 0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  const int mz = 3 * n + k;
+  for (int e = tid; e < nnz; e += blockDim.x) {
+    const int i = idx[3 * e], za = idx[3 * e + 1], zb = idx[3 * e + 2];
+    if (i < 0 || i >= n || za < 0 || zb >= mz || za > zb || (e > 0 && idx[3 * (e - 1)] > i)) bad = 1;
+    else atomicAdd(&cnt[i], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < n; ++i) {
+      ptr[i] = acc;
+      acc += cnt[i];
+    }
+    ptr[n] = acc;
+    flag[0] = bad;
+  }
+}
+
+// Zu = Z[:, U]; flag[1] != 0: Z has a non-zero (or NaN) entry outside the columns U
+__global__ void so_design_kernel(const double* __restrict__ Z, int p, int n, SoIdx ix, int u, double* __restrict__ Zu,
+                                 int32_t* __restrict__ flag) {
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int idx = tid; idx < p * n; idx += blockDim.x) {
+    const int j = idx % n;
+    bool in_u = false;
+    for (int c = 0; c < u; ++c) in_u = in_u || (ix.U[c] == j);
+    if (!in_u && Z[idx] != 0.0) bad = 1;
+  }
+  for (int idx = tid; idx < p * u; idx += blockDim.x) Zu[idx] = Z[(size_t)(idx / u) * n + ix.U[idx % u]];
+  __syncthreads();
+  if (tid == 0) flag[1] = bad;
+}
+
+
+// =============================================================================================================================
+// Qz and the stationary covariance P0 = dlyap(Az, Qz) (512 threads, products on the matrix core)
+// =============================================================================================================================
+struct SoFilterArgs {
+  double* work;             // [batch][layout.total]
+  const double* Zu;         // [p][u]  design matrix restricted to the retained variables (Z[:, U])
+  const double* d;          // [p] or nullptr
+  const double* Hdiag;      // [p] or nullptr
+  const double* y;          // [T_len][p]
+  double* logp;             // [batch]
+  int32_t* status;          // [batch] in/out
+  int32_t* steady_at;       // [batch] or nullptr (debug: first steady step)
+  int32_t* n_doublings;     // [batch] or nullptr (debug)
+  int batch, T_len;
+  double jitter, missing_fill, steady_tol;
+};
+
+template <int MT>
+struct SoFilterSmem {
+  static constexpr int MP = 16 * MT;
+  // GEMM staging + vectors: a, ap (MP each), K, PZ (MP x 8 each), F, Lc (64 each), v, w, dvec, hvec (8 each), reductions
+  static constexpr size_t doubles = SoGemmCfg<MT>::LDS_DOUBLES + 2 * MP + 2 * MP * 8 + 2 * 64 + 4 * 8 + 64;
+  static constexpr size_t bytes = doubles * sizeof(double);
+};
+
+// sym + add pass shared by the doubling and the prediction: P_new = 1/2 (X + X') + base (+ P_old if ACC); returns max |P_new -
+// P_old| and max |P_new| in dmax / pmax (workgroup-uniform)
+template <int NT, bool ACC>
+__device__ __forceinline__ void so_sym_update(double* P, const double* Xb, const double* base, int MP, int m, double* red,
+                                              double& dmax, double& pmax) {
+  double dm = 0.0, pm = 0.0;
+  for (int idx = threadIdx.x; idx < m * m; idx += NT) {
+    const int i = idx / m, j = idx - i * m;
+    const double xs = 0.5 * (Xb[(size_t)i * MP + j] + Xb[(size_t)j * MP + i]);
+    const double po = P[(size_t)i * MP + j];
+    const double pn = ACC ? po + xs : xs + base[(size_t)i * MP + j];
+    P[(size_t)i * MP + j] = pn;
+    dm = nanmax(dm, fabs(pn - po));
+    pm = nanmax(pm, fabs(pn));
+  }
+  dmax = so_wg_max<NT>(dm, red);
+  pmax = so_wg_max<NT>(pm, red);
+}
+
+template <int MT>
+__global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoLayout lay) {
+  constexpr int NT = SO_THREADS, MP = 16 * MT;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* lds = smem;
+  double* red = smem + SoGemmCfg<MT>::LDS_DOUBLES;
+  const int tid = threadIdx.x, draw = blockIdx.x;
+  if (draw >= a.batch) return;
+  if (a.status[draw] != 0) return;
+  double* wk = a.work + (size_t)draw * lay.total;
+  const int m = lay.m;
+  double* Qz = wk + lay.qz;
+  double* P = wk + lay.p0;
+  double* Wt = wk + lay.wt;
+  double* Xb = wk + lay.xb;
+  double* Ak = wk + lay.ak;
+  double* AkT = wk + lay.akt;
+  double* Ak2 = wk + lay.ak2;
+  double* AkT2 = wk + lay.akt2;
+  // Qz = sym(Y' L)
+  so_gemm<MT>(wk + lay.yt, MP, wk + lay.lt, MP, lay.KQP, lds, [&](int r, int c, double v) { Xb[(size_t)r * MP + c] = v; });
+  __syncthreads();
+  for (int idx = tid; idx < MP * MP; idx += NT) {
+    const int i = idx / MP, j = idx - i * MP;
+    const double v = (i < m && j < m) ? 0.5 * (Xb[(size_t)i * MP + j] + Xb[(size_t)j * MP + i]) : 0.0;
+    Qz[idx] = v;
+    P[idx] = v;
+    Ak[idx] = wk[lay.az + idx];
+    AkT[idx] = wk[lay.azt + idx];
+  }
+  bool conv = false;
+  int it = 0;
+  for (; it < 48 && !conv; ++it) {
+    // W = A_k P (stored transposed),  X = W A_k',  A_{k+1} = A_k A_k (both layouts)
+    so_gemm<MT>(AkT, MP, P, MP, MP, lds, [&](int r, int c, double v) { Wt[(size_t)c * MP + r] = v; });
+    so_gemm<MT>(Wt, MP, AkT, MP, MP, lds, [&](int r, int c, double v) { Xb[(size_t)r * MP + c] = v; });
+    so_gemm<MT>(AkT, MP, Ak, MP, MP, lds, [&](int r, int c, double v) {
+      Ak2[(size_t)r * MP + c] = v;
+      AkT2[(size_t)c * MP + r] = v;
+    });
+    __syncthreads();
+    double dmax, pmax;
+    so_sym_update<NT, true>(P, Xb, nullptr, MP, m, red, dmax, pmax);
+    double* t = Ak; Ak = Ak2; Ak2 = t;
+    t = AkT; AkT = AkT2; AkT2 = t;
+    if (!(dmax == dmax) || !(pmax < 1e300)) break;
+    conv = dmax <= 1e-17 * pmax;
+  }
+  if (tid == 0) {
+    if (!conv) a.status[draw] |= DSGE_ST_LYAP_FAIL;
+    if (a.n_doublings) a.n_doublings[draw] = it;
+  }
+}
+
+// =============================================================================================================================
+// The filter (oracle/statespace.py kalman_filter_logp on the pruned system: a0 = stationary mean, P0 = stationary covariance,
+// state intercept c, design [Zu, Zu, 0]).  Update in the rank-p form of the first-order kernels:
+//     P+ = P - sym(K (P Z' + jitter K)') + jitter I
+// =============================================================================================================================
+template <int MT>
+__global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, SoLayout lay) {
+  constexpr int NT = SO_THREADS, MP = 16 * MT, PM = SO_MAX_P;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* lds = smem;
+  double* pl = smem + SoGemmCfg<MT>::LDS_DOUBLES;
+  double* av = pl; pl += MP;        // predicted mean
+  double* ap = pl; pl += MP;        // filtered mean
+  double* Kg = pl; pl += MP * PM;   // gain [m][PM]
+  double* PZ = pl; pl += MP * PM;   // P Z' [m][PM]
+  double* Fm = pl; pl += 64;        // F, then its Cholesky factor (lower)
+  double* Lc = pl; pl += 64;
+  double* vv = pl; pl += 8;         // innovation
+  pl += 8;
+  double* dv = pl; pl += 8;
+  double* hv = pl; pl += 8;
+  double* red = pl; pl += 32;
+  int* imask = (int*)pl;            // [0] = current mask, [1] = steady flag, [2] = finite flag
+  const int tid = threadIdx.x, draw = blockIdx.x;
+  if (draw >= a.batch) return;
+  if (a.status[draw] != 0) {
+    if (tid == 0) a.logp[draw] = -INFINITY;
+    return;
+  }
+  double* wk = a.work + (size_t)draw * lay.total;
+  const int m = lay.m, u = lay.u, p = lay.p;
+  const double* AzT = wk + lay.azt;
+  const double* Qz = wk + lay.qz;
+  const double* cvec = wk + lay.cvec;
+  double* P = wk + lay.p0;
+  double* Pp = wk + lay.pp;
+  double* Wt = wk + lay.wt;
+  double* Xb = wk + lay.xb;
+  const double* Zu = a.Zu;
+  for (int i = tid; i < MP; i += NT) av[i] = wk[lay.a0 + i];
+  if (tid < 8) {
+    dv[tid] = (a.d && tid < p) ? a.d[tid] : 0.0;
+    hv[tid] = (a.Hdiag && tid < p) ? a.Hdiag[tid] : 0.0;
+  }
+  for (size_t idx = tid; idx < (size_t)MP * MP; idx += NT) Pp[idx] = 0.0;  // (padding of P+ stays zero)
+  __syncthreads();
+  const double LN2PI = 1.8378770664093453;
+  double ll_sum = 0.0, logdet = 0.0;  // (thread 0)
+  bool steady = false, finite = true;
+  int steady_mask = -1, steady_at = -1;
+  for (int t = 0; t < a.T_len; ++t) {
+    // ---- missing-data mask of this step (bit o set = observed) -----------------------------------------------------------
+    if (tid == 0) {
+      int mk = 0;
+      for (int o = 0; o < p; ++o) {
+        const double yo = a.y[(size_t)t * p + o];
+        if (!(yo != yo) && yo != a.missing_fill) mk |= 1 << o;
+      }
+      imask[0] = mk;
+    }
+    __syncthreads();
+    const int mask = imask[0];
+    if (steady && mask != steady_mask) steady = false;  // (workgroup-uniform)
+    // ---- innovation v = ym - d - Zm a -------------------------------------------------------------------------------------
+    if (tid < p) {
+      const int o = tid;
+      double za = 0.0;
+      if ((mask >> o) & 1)
+        for (int c = 0; c < u; ++c) za = fma(Zu[o * u + c], av[c] + av[u + c], za);
+      const double yo = ((mask >> o) & 1) ? a.y[(size_t)t * p + o] : 0.0;
+      vv[o] = yo - dv[o] - za;
+    }
+    if (!steady) {
+      // ---- P Z' (m x p), F = Zm P Zm' + Hm + jitter I ---------------------------------------------------------------------
+      for (int idx = tid; idx < m * p; idx += NT) {
+        const int i = idx / p, o = idx - i * p;
+        double acc = 0.0;
+        if ((mask >> o) & 1) {
+          const double* pr = P + (size_t)i * MP;
+          for (int c = 0; c < u; ++c) acc = fma(pr[c] + pr[u + c], Zu[o * u + c], acc);
+        }
+        PZ[i * PM + o] = acc;
+      }
+      __syncthreads();
+      if (tid < p * p) {
+        const int o = tid / p, o2 = tid - o * p;
+        double acc = 0.0;
+        if ((mask >> o) & 1)
+          for (int c = 0; c < u; ++c) acc = fma(Zu[o * u + c], PZ[c * PM + o2] + PZ[(u + c) * PM + o2], acc);
+        if (o == o2) acc += (((mask >> o) & 1) ? hv[o] : 0.0) + a.jitter;
+        Fm[o * 8 + o2] = acc;
+      }
+      __syncthreads();
+      // ---- Cholesky F = Lc Lc' (thread 0; p <= 8), log det F ----------------------------------------------------------------
+      if (tid == 0) {
+        double ld = 0.0;
+        bool okc = true;
+        for (int j = 0; j < p; ++j) {
+          double dsum = 0.5 * (Fm[j * 8 + j] + Fm[j * 8 + j]);
+          for (int r = 0; r < j; ++r) dsum -= Lc[j * 8 + r] * Lc[j * 8 + r];
+          if (!(dsum > 0.0)) okc = false;
+          const double dj = sqrt(dsum);
+          Lc[j * 8 + j] = dj;
+          ld += 2.0 * log(dj);
+          for (int i = j + 1; i < p; ++i) {
+            double sv = 0.5 * (Fm[i * 8 + j] + Fm[j * 8 + i]);
+            for (int r = 0; r < j; ++r) sv -= Lc[i * 8 + r] * Lc[j * 8 + r];
+            Lc[i * 8 + j] = sv / dj;
+          }
+        }
+        logdet = ld;
+        if (!okc) finite = false;
+        imask[2] = okc ? 1 : 0;
+      }
+      __syncthreads();
+      // ---- gain K = P Z' F^-1 (one row per thread: two triangular solves) ---------------------------------------------------
+      for (int i = tid; i < m; i += NT) {
+        double x[PM];
+#pragma unroll
+        for (int o = 0; o < PM; ++o) x[o] = (o < p) ? PZ[i * PM + o] : 0.0;
+        for (int o = 0; o < p; ++o) {  // Lc z = pz
+          double sv = x[o];
+          for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
+          x[o] = sv / Lc[o * 8 + o];
+        }
+        for (int o = p - 1; o >= 0; --o) {  // Lc' k = z
+          double sv = x[o];
+          for (int r = o + 1; r < p; ++r) sv -= Lc[r * 8 + o] * x[r];
+          x[o] = sv / Lc[o * 8 + o];
+        }
+#pragma unroll
+        for (int o = 0; o < PM; ++o) Kg[i * PM + o] = x[o];
+      }
+      __syncthreads();
+    }
+    // ---- F^-1 v, log-likelihood contribution, filtered mean ---------------------------------------------------------------
+    if (tid == 0) {
+      double x[PM];
+      for (int o = 0; o < p; ++o) {
+        double sv = vv[o];
+        for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
+        x[o] = sv / Lc[o * 8 + o];
+      }
+      double quad = 0.0;
+      for (int o = 0; o < p; ++o) quad = fma(x[o], x[o], quad);
+      if (mask != 0) ll_sum += -0.5 * (p * LN2PI + logdet + quad);
+      if (!(quad == quad)) finite = false;
+    }
+    for (int i = tid; i < m; i += NT) {
+      double acc = av[i];
+      for (int o = 0; o < p; ++o) acc = fma(Kg[i * PM + o], vv[o], acc);
+      ap[i] = acc;
+    }
+    __syncthreads();
+    // ---- predicted mean a = Az a+ + c --------------------------------------------------------------------------------------
+    for (int i = tid; i < m; i += NT) {
+      double acc0 = cvec[i], acc1 = 0.0;
+      int kx = 0;
+      for (; kx + 1 < m; kx += 2) {
+        acc0 = fma(AzT[(size_t)kx * MP + i], ap[kx], acc0);
+        acc1 = fma(AzT[(size_t)(kx + 1) * MP + i], ap[kx + 1], acc1);
+      }
+      if (kx < m) acc0 = fma(AzT[(size_t)kx * MP + i], ap[kx], acc0);
+      av[i] = acc0 + acc1;
+    }
+    if (steady) {
+      __syncthreads();
+      continue;
+    }
+    // ---- P+ = P - sym(K (P Z' + jitter K)') + jitter I --------------------------------------------------------------------
+    for (int idx = tid; idx < m * m; idx += NT) {
+      const int i = idx / m, j = idx - i * m;
+      double acc = 0.0;
+#pragma unroll
+      for (int o = 0; o < PM; ++o) {
+        const double ki = Kg[i * PM + o], kj = Kg[j * PM + o];
+        acc = fma(ki, fma(a.jitter, kj, PZ[j * PM + o]), acc);
+        acc = fma(kj, fma(a.jitter, ki, PZ[i * PM + o]), acc);
+      }
+      Pp[(size_t)i * MP + j] = P[(size_t)i * MP + j] - 0.5 * acc + (i == j ? a.jitter : 0.0);
+    }
+    // ---- P = sym(Az P+ Az') + Qz: two products on the matrix core -------------------------------------------------------------
+    so_gemm<MT>(AzT, MP, Pp, MP, MP, lds, [&](int r, int c, double v) { Wt[(size_t)c * MP + r] = v; });
+    so_gemm<MT>(Wt, MP, AzT, MP, MP, lds, [&](int r, int c, double v) { Xb[(size_t)r * MP + c] = v; });
+    __syncthreads();
+    double dmax, pmax;
+    so_sym_update<NT, false>(P, Xb, Qz, MP, m, red, dmax, pmax);
+    if (!(pmax < 1e300)) finite = false;  // (uniform; thread 0 keeps the flag that matters)
+    if (a.steady_tol > 0.0 && dmax <= a.steady_tol * pmax) {
+      steady = true;
+      steady_mask = mask;
+      if (steady_at < 0) steady_at = t + 1;
+    }
+  }
+  if (tid == 0) {
+    const bool okf = finite && (ll_sum == ll_sum) && fabs(ll_sum) < 1e300;
+    a.logp[draw] = okf ? ll_sum : -INFINITY;
+    if (!okf) a.status[draw] |= DSGE_ST_FILTER_NONFINITE;
+    if (a.steady_at) a.steady_at[draw] = steady_at;
+  }
+}
+
+}  // namespace dsge

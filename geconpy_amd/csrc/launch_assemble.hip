@@ -37,15 +37,22 @@ int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n
   return DSGE_SUCCESS;
 }
 
+int g_adj_refine_mode = 0;
+
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
                    double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 7, {
-    rc = set_lds(dsge::adjoint_kernel<BS>, dsge::AdjSmem<BS>::bytes);
+    rc = set_lds(dsge::adjoint_kernel<BS, false>, dsge::AdjSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) rc = set_lds(dsge::adjoint_kernel<BS, true>, dsge::AdjSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::adjoint_kernel<BS>, dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
-                         batch, n, Ab, Bb, Cb, status, accumulate);
+      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, false>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
+                         batch, n, Ab, Bb, Cb, status, accumulate, g_adj_refine_mode);
+      HIP_TRY(hipGetLastError());
+      // second pass: one step of iterative refinement for the draws whose Stein residual the first pass flagged (normally none)
+      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, true>), dim3(rerun_grid(batch)), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C,
+                         T, Tbar, batch, n, Ab, Bb, Cb, status, 1, 0);
       HIP_TRY(hipGetLastError());
     }
   });

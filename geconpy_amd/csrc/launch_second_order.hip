@@ -1,0 +1,192 @@
+// Launcher of the second-order path (dsge_second_order.hpp): structure kernels, coefficient / pruned-system set-up,
+// stationary covariance and the filter on the FP64 matrix core.
+#include "dsge_host.hpp"
+#include "dsge_second_order.hpp"
+
+#include <algorithm>
+#include <mutex>
+
+namespace dsge_host {
+
+namespace {
+struct SoArena {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  bool used = false;
+};
+SoArena g_so_arena[16][8];
+std::mutex g_so_mutex;
+int so_reserve(size_t bytes, hipStream_t st, void** out) {
+  std::lock_guard<std::mutex> lk(g_so_mutex);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
+  SoArena* a = nullptr;
+  for (auto& slot : g_so_arena[dev])
+    if (slot.used && slot.stream == st) a = &slot;
+  if (!a)
+    for (auto& slot : g_so_arena[dev])
+      if (!slot.used) {
+        a = &slot;
+        break;
+      }
+  if (!a) {
+    HIP_TRY(hipDeviceSynchronize());
+    a = &g_so_arena[dev][0];
+  }
+  a->used = true;
+  a->stream = st;
+  if (a->cap < bytes) {
+    if (a->ptr) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(a->ptr));
+      a->ptr = nullptr;
+      a->cap = 0;
+    }
+    HIP_TRY(hipMalloc(&a->ptr, bytes + 4096));
+    a->cap = bytes + 4096;
+  }
+  *out = a->ptr;
+  return DSGE_SUCCESS;
+}
+
+template <int MT>
+int launch_so_mt(const dsge::SoFilterArgs& fa, const dsge::SoLayout& lay, int nb, hipStream_t st, float* ms) {
+  int rc;
+  const size_t lds = dsge::SoFilterSmem<MT>::bytes;
+  if ((rc = set_lds(dsge::so_lyap_kernel<MT>, lds))) return rc;
+  if ((rc = set_lds(dsge::so_filter_kernel<MT>, lds))) return rc;
+  hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+  if (ms)
+    for (auto& x : e) HIP_TRY(hipEventCreate(&x));
+  if (ms) HIP_TRY(hipEventRecord(e[0], st));
+  hipLaunchKernelGGL(dsge::so_lyap_kernel<MT>, dim3(nb), dim3(dsge::SO_THREADS), lds, st, fa, lay);
+  HIP_TRY(hipGetLastError());
+  if (ms) HIP_TRY(hipEventRecord(e[1], st));
+  hipLaunchKernelGGL(dsge::so_filter_kernel<MT>, dim3(nb), dim3(dsge::SO_THREADS), lds, st, fa, lay);
+  HIP_TRY(hipGetLastError());
+  if (ms) {
+    HIP_TRY(hipEventRecord(e[2], st));
+    HIP_TRY(hipEventSynchronize(e[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], e[1], e[2]));
+    for (auto& x : e) (void)hipEventDestroy(x);
+  }
+  return DSGE_SUCCESS;
+}
+}  // namespace
+
+int so_tiles(int m) {  // kernel instances built: 2, 4, 7, 10, 13 tiles of 16 per side
+  const int need = (m + 15) / 16;
+  for (int mt : {2, 4, 7, 10, 13})
+    if (need <= mt) return mt;
+  return 0;
+}
+
+// T, R: first-order solution (device, [batch][n][n], [batch][n][k]); status_io: draws with a non-zero status are skipped
+// (logp = -inf).  ms (nullable): durations of the three stages of the LAST chunk in milliseconds (synchronises).
+int launch_second_order(const double* B, const double* C, const double* T, const double* R, const int32_t* hess_idx, int nnz,
+                        const double* hess_val, const double* q, int q_batched, const double* Z, const double* d,
+                        const double* Hdiag, const double* y, int batch, int n, int k, int p, int T_len, double jitter,
+                        double missing_fill, const int32_t* S, int s, const int32_t* L, int l, const int32_t* U, int u,
+                        double* logp, int32_t* status_io, double* gyy_out, double* gyu_out, double* guu_out, double* gss_out,
+                        int32_t* steady_at, int32_t* n_doublings, hipStream_t st, float* ms) {
+  if (s < 1 || s > dsge::SO_MAX_S || u < s || u > 40 || l < 0 || l > 64 || k > dsge::SO_MAX_K || k > s || p > dsge::SO_MAX_P)
+    return fail(DSGE_ERR_INVALID, "second order: sizes out of range (1 <= s <= 24, s <= u <= 40, k <= min(s, 12), p <= 8)");
+  const int q_ = s * (s + 1) / 2, m = 2 * u + q_, mt = so_tiles(m);
+  if (mt == 0) return fail(DSGE_ERR_INVALID, "second order: pruned state 2 u + s (s + 1) / 2 exceeds 208");
+  dsge::SoLayout lay;
+  lay.init(n, k, s, u, l, p, mt);
+  const size_t lds_setup = dsge::so_setup_lds_doubles(lay) * sizeof(double);
+  if (lds_setup > LDS_LIMIT) return fail(DSGE_ERR_INVALID, "second order: model too large for the set-up kernel's LDS");
+  dsge::SoIdx ix{};
+  for (int i = 0; i < s; ++i) ix.S[i] = (uint8_t)S[i];
+  for (int i = 0; i < u; ++i) ix.U[i] = (uint8_t)U[i];
+  for (int i = 0; i < l; ++i) ix.L[i] = (uint8_t)L[i];
+  for (int i = 0; i < s; ++i)
+    if (U[i] != S[i]) return fail(DSGE_ERR_INVALID, "second order: the retained variables must list the states first");
+  // workspace: chunks of draws so that it stays below ~6 GiB
+  const size_t per_draw = lay.total * sizeof(double);
+  int chunk = (int)std::min<size_t>((size_t)batch, std::max<size_t>(1, ((size_t)6 << 30) / per_draw));
+  int rc;
+  void* base = nullptr;
+  const size_t head = 4096 + sizeof(double) * 8 * 40;
+  if ((rc = so_reserve(head + per_draw * chunk, st, &base))) return rc;
+  int32_t* hptr = (int32_t*)base;                      // [n + 1]
+  int32_t* flags = hptr + 128;                         // [2]
+  double* Zu = (double*)((char*)base + 4096);          // [p][u]
+  double* work = (double*)((char*)base + head);
+  HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(dsge::so_hessptr_kernel, dim3(1), dim3(256), 0, st, hess_idx, nnz, n, k, hptr, flags);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(dsge::so_design_kernel, dim3(1), dim3(256), 0, st, Z, p, n, ix, u, Zu, flags);
+  HIP_TRY(hipGetLastError());
+  if ((rc = set_lds(dsge::so_setup_kernel, lds_setup))) return rc;
+  for (int c0 = 0; c0 < batch; c0 += chunk) {
+    const int nb = std::min(chunk, batch - c0);
+    dsge::SoSetupArgs sa{};
+    sa.B = B + (size_t)c0 * n * n;
+    sa.C = C + (size_t)c0 * n * n;
+    sa.T = T + (size_t)c0 * n * n;
+    sa.R = R + (size_t)c0 * n * k;
+    sa.hess_ptr = hptr;
+    sa.hess_idx = hess_idx;
+    sa.hess_val = hess_val + (size_t)c0 * nnz;
+    sa.q = q + (q_batched ? (size_t)c0 * k : 0);
+    sa.ix = ix;
+    sa.flags = flags;
+    sa.work = work;
+    sa.status = status_io + c0;
+    sa.gyy_out = gyy_out ? gyy_out + (size_t)c0 * n * s * s : nullptr;
+    sa.gyu_out = gyu_out ? gyu_out + (size_t)c0 * n * s * k : nullptr;
+    sa.guu_out = guu_out ? guu_out + (size_t)c0 * n * k * k : nullptr;
+    sa.gss_out = gss_out ? gss_out + (size_t)c0 * n : nullptr;
+    sa.batch = nb;
+    sa.nnz = nnz;
+    sa.q_batched = q_batched;
+    const bool time_it = ms && c0 + chunk >= batch;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (time_it) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(dsge::so_setup_kernel, dim3(nb), dim3(dsge::SO_SETUP_THREADS), lds_setup, st, sa, lay);
+    HIP_TRY(hipGetLastError());
+    if (time_it) HIP_TRY(hipEventRecord(e1, st));
+    dsge::SoFilterArgs fa{};
+    fa.work = work;
+    fa.Zu = Zu;
+    fa.d = d;
+    fa.Hdiag = Hdiag;
+    fa.y = y;
+    fa.logp = logp + c0;
+    fa.status = status_io + c0;
+    fa.steady_at = steady_at ? steady_at + c0 : nullptr;
+    fa.n_doublings = n_doublings ? n_doublings + c0 : nullptr;
+    fa.batch = nb;
+    fa.T_len = T_len;
+    fa.jitter = jitter;
+    fa.missing_fill = missing_fill;
+    fa.steady_tol = opt().kalman_steady_tol;
+    float* msl = time_it ? ms : nullptr;
+    switch (mt) {
+      case 2: rc = launch_so_mt<2>(fa, lay, nb, st, msl); break;
+      case 4: rc = launch_so_mt<4>(fa, lay, nb, st, msl); break;
+      case 7: rc = launch_so_mt<7>(fa, lay, nb, st, msl); break;
+      case 10: rc = launch_so_mt<10>(fa, lay, nb, st, msl); break;
+      case 13: rc = launch_so_mt<13>(fa, lay, nb, st, msl); break;
+      default: rc = fail(DSGE_ERR_INVALID, "second order: no kernel instance");
+    }
+    if (rc) return rc;
+    if (time_it) {
+      HIP_TRY(hipEventElapsedTime(&ms[0], e0, e1));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  }
+  return DSGE_SUCCESS;
+}
+
+}  // namespace dsge_host

@@ -260,3 +260,44 @@ def sw_theta_jacobians(theta, seed=None):
     B = np.repeat(B0[None], nb, axis=0)
     D = np.repeat(D0[None], nb, axis=0)
     return A, B, C, D, theta[:, len(S) + len(Lc) :] ** 2
+
+
+# ---- BASELINE.json configs[4]: second-order perturbation + pruned-state-space filter on the SW-shaped systems -------------
+
+SW2_SEED = 20260931
+SW2_NNZ_PER_EQUATION = 12
+
+
+def second_order_hessian_pattern(A0, C0, k, nnz_per_eq=SW2_NNZ_PER_EQUATION, seed=SW2_SEED):
+    """Sparsity pattern of the model Hessian d2F_i / dz_a dz_b, z = [y-; y; y+; u], as the device takes it: an int32 (nnz, 3)
+    array of (equation, z_a, z_b) with z_a <= z_b, sorted by equation, shared by every draw of a model.  The reference builds
+    no second derivatives (gEconpy/model/perturbation.py:97-98), so the pattern is synthetic: ``nnz_per_eq`` seeded pairs per
+    equation among the z entries the equation can depend on -- y- only through the state variables (non-zero columns of A),
+    y+ only through the forward-looking ones (non-zero columns of C)."""
+    n = A0.shape[0]
+    S = np.flatnonzero((A0 != 0).any(axis=0))
+    L = np.flatnonzero((C0 != 0).any(axis=0))
+    allowed = np.concatenate([S, n + np.arange(n), 2 * n + L, 3 * n + np.arange(k)])
+    rng = np.random.default_rng(seed)
+    idx = []
+    for i in range(n):
+        seen = set()
+        while len(seen) < nnz_per_eq:
+            a, b = sorted(int(x) for x in rng.choice(allowed, 2))
+            seen.add((a, b))
+        idx += [(i, a, b) for a, b in sorted(seen)]
+    return np.asarray(idx, dtype=np.int32)
+
+
+def sw_second_order_batch(batch, first_draw=0, seed0=SW_SEED0, **shape):
+    """``sw_shaped_batch`` + per-draw Hessian values on the shared pattern of ``second_order_hessian_pattern`` (draw i seeded
+    ``default_rng((seed0 + i, 4))``): entries ~ N(0, 1).  -> the dict of ``sw_shaped_batch`` with ``hess_idx`` (nnz, 3) int32
+    and ``hess_val`` (batch, nnz)."""
+    b = sw_shaped_batch(batch, first_draw, seed0, **shape)
+    idx = second_order_hessian_pattern(b["A"][0] if batch else None, b["C"][0], b["D"].shape[2])
+    val = np.empty((batch, len(idx)))
+    for j in range(batch):
+        val[j] = np.random.default_rng((seed0 + first_draw + j, 4)).standard_normal(len(idx))
+    b["hess_idx"] = idx
+    b["hess_val"] = val
+    return b

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 4
+#define DSGE_ABI_VERSION 5
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
@@ -55,6 +55,7 @@ extern "C" {
 #define DSGE_ST_GENSYS_QZ_FAIL 16  /* QZ iteration did not converge                           */
 #define DSGE_ST_GENSYS_TOO_BIG 32  /* n + #lead exceeds the on-chip capacity of the launch     */
 #define DSGE_ST_GRAD_UNSUPPORTED 64 /* gradient path: dense design matrix / reduced model exceeds the tile */
+#define DSGE_ST_SECOND_ORDER_UNSUPPORTED 128 /* second-order path: input violates the declared model structure */
 
 /* covariance layouts for the Q argument */
 #define DSGE_Q_DIAG_SHARED 0    /* Q = diag(q), q: [k]            */
@@ -359,6 +360,11 @@ int dsge_policy_adjoints_batched(const double* B, const double* C, const double*
 int dsge_policy_adjoints_batched_host(const double* B, const double* C, const double* T, const double* T_bar,
                                       int batch, int n, double* A_bar, double* B_bar, double* C_bar,
                                       int32_t* status);
+/* The doubling iteration of the Stein solve loses digits when the powers of G = -(B + C T)^-T C' grow before they decay; the
+ * kernel tracks max_k max|G^(2^k)| of every draw and a second pass refines the draws above 100 once (S += solve(residual),
+ * residual = T_bar + M' S + C' S T'): the level of the reference's Kronecker LU (shared.py:53-71).  Debug hook for the tests:
+ * mode 0 = that rule (default), 1 = refine every draw, 2 = never refine.  Process-wide. */
+int dsge_debug_adjoint_refine(int mode);
 
 /*
  * Pullback of the shock-impact matrix.  The reference's R = -solve(C @ T + B, D) is plain differentiable pytensor
@@ -601,6 +607,47 @@ int dsge_solve_kalman_logp_grad_batched_host_opt(const dsge_options* opt, const 
                                                  double* logp_out, int32_t* status_out, double* A_bar, double* B_bar,
                                                  double* C_bar, double* D_bar, double* q_bar, double* d_bar,
                                                  double* h_bar);
+
+/*
+ * Second-order perturbation + pruned-state-space quasi-likelihood, batched over draws (BASELINE.json configs[4]).
+ * The reference has NO such solver -- it raises NotImplementedError for order != 1 (gEconpy/model/perturbation.py:97-98,
+ * gEconpy/model/model.py:1433-1434, 1614-1615) -- so this entry point replaces that raise; its results are defined by
+ * oracle/second_order.py (Schmitt-Grohe & Uribe 2004; pruning after Kim, Kim, Schaumburg & Sims 2008 / Andreasen,
+ * Fernandez-Villaverde & Rubio-Ramirez 2018) and are parity-unpinned against the reference by construction.
+ *   A,B,C,D -> T,R by the first-order solver (solver: DSGE_SOLVER_CYCLE_REDUCTION or DSGE_SOLVER_GENSYS), then
+ *   y_t = T y- + R u + 1/2 [g_yy (y- (x) y-) + 2 g_yu (y- (x) u) + g_uu (u (x) u) + g_ss]  from the model Hessian, then the
+ *   Gaussian ("standard" filter) likelihood of the pruned system on z = [x_f[U]; x_s[U]; vech(x_f[S] x_f[S]')], started
+ *   from its stationary mean and covariance, observation y = Z (x_f + x_s) + d.
+ *   hess_idx : [nnz][3] int32 DEVICE, (equation, z_a, z_b) with z_a <= z_b over z = [y-; y; y+; u] (3 n + k entries), sorted
+ *              by equation: the sparsity pattern of d2F_i / dz_a dz_b, shared by all draws
+ *   hess_val : [batch][nnz] the values per draw
+ *   q        : shock variances (diagonal Sigma), [k] (q_batched = 0) or [batch][k]
+ *   Z [p][n], d [p] or NULL, Hdiag [p] or NULL, y [T_len][p]: shared by the draws; p <= 8
+ *   state_idx / lead_idx / ret_idx : HOST int32 arrays (model structure, read during the call): the non-zero columns of A
+ *              (n_state <= 24), the non-zero columns of C, and the variables the filter retains = the states followed by the
+ *              observed non-states (n_ret <= 40); 2 n_ret + n_state (n_state + 1) / 2 <= 208, k <= min(n_state, 12).
+ *              A draw that violates the structure gets DSGE_ST_SECOND_ORDER_UNSUPPORTED and logp = -inf.
+ *   T_out, R_out, gyy_out [batch][n][n_state][n_state], gyu_out [batch][n][n_state][k], guu_out [batch][n][k][k],
+ *   gss_out [batch][n] : optional
+ *   stage_ms : HOST float[4] or NULL; non-NULL makes the call synchronise and report the durations (ms) of the first-order
+ *              solve, the coefficient / pruned-system set-up, the stationary covariance and the filter (last chunk)
+ */
+int dsge_second_order_logp_batched(const double* A, const double* B, const double* C, const double* D,
+                                   const int32_t* hess_idx, int nnz, const double* hess_val, const double* q, int q_batched,
+                                   const double* Z, const double* d, const double* Hdiag, const double* y, int batch, int n,
+                                   int k, int p, int T_len, int solver, double tol, int max_iter, double jitter,
+                                   double missing_fill, const int32_t* state_idx, int n_state, const int32_t* lead_idx,
+                                   int n_lead, const int32_t* ret_idx, int n_ret, double* logp_out, int32_t* status_out,
+                                   double* T_out, double* R_out, double* gyy_out, double* gyu_out, double* guu_out,
+                                   double* gss_out, float* stage_ms, void* stream);
+int dsge_second_order_logp_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                        const int32_t* hess_idx, int nnz, const double* hess_val, const double* q,
+                                        int q_batched, const double* Z, const double* d, const double* Hdiag, const double* y,
+                                        int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                                        double jitter, double missing_fill, const int32_t* state_idx, int n_state,
+                                        const int32_t* lead_idx, int n_lead, const int32_t* ret_idx, int n_ret,
+                                        double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* gyy_out,
+                                        double* gyu_out, double* guu_out, double* gss_out);
 
 /*
  * Timing hook for bench.py: runs `reps` back-to-back launches of the fused pipeline's

@@ -277,3 +277,33 @@ def test_gradient_is_repeatable_and_independent_of_the_batch_size():
     fd = (lp - lm) / (2 * h)
     an = np.einsum("bij,bij->b", g1["A_bar"], dA) + np.einsum("bij,bij->b", g1["C_bar"], dC)
     assert np.max(np.abs(fd - an) / np.maximum(np.abs(fd), 1.0)) < 1e-3  # (central differences, h = 1e-6; the race gave tens of percent)
+
+
+@pytest.mark.parametrize("n,ns,nl", [(12, 5, 3), (30, 13, 8), (40, 18, 12), (47, 14, 8), (48, 23, 4), (53, 20, 16)])
+def test_policy_adjoint_refinement_pass(n, ns, nl):
+    """adjoint_kernel<BS, true>, the out-of-line refinement pass of the Stein solve (one step of iterative refinement for draws
+    whose residual T_bar + M' S + C' S T' shows lost digits): forced on every draw (debug mode 1) it must reproduce the
+    oracle's Kronecker LU (shared.py:53-71) to 1e-10 or as well as the unrefined solve (mode 2), and the default rule (mode 0)
+    must be inside 1e-9 on every draw."""
+    from geconpy_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    nb = 6
+    sysm = [wl.sw_shaped_system(4100 + 17 * n + i, n=n, n_state=ns, n_lead=nl, k=3) for i in range(nb)]
+    A, B, C, D, T = (np.stack([s_[j] for s_ in sysm]) for j in range(5))
+    T_bar = rng.standard_normal(T.shape) * (T != 0).any(axis=1)[:, None, :]
+    ref = [oracle.policy_function_adjoints(A[i], B[i], C[i], T[i], T_bar[i]) for i in range(nb)]
+    errs = {}
+    try:
+        for mode in (2, 1, 0):
+            _lib.check(lib.dsge_debug_adjoint_refine(mode))
+            Ab, Bb, Cb, st = batched.policy_adjoints_batched(B, C, T, T_bar)
+            assert (st == 0).all(), (mode, st)
+            errs[mode] = np.array([max(np.abs(x[i] - r_).max() for x, r_ in zip((Ab, Bb, Cb), ref[i])) /
+                                   max(1.0, np.abs(ref[i][0]).max()) for i in range(nb)])
+    finally:
+        _lib.check(lib.dsge_debug_adjoint_refine(0))
+    # (in working precision a refinement step cannot go below ~cond x u: it may move a 1e-12 solution to 1e-11)
+    assert (errs[1] <= np.maximum(errs[2], 1e-10)).all(), errs
+    assert (errs[0] <= 1e-9).all() and (errs[1] <= 1e-9).all(), errs

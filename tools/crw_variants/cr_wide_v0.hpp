@@ -24,14 +24,10 @@ struct CrwSmem {
 
 // Blocked Gauss-Jordan with partial pivoting on W (n rows, two column groups of 64), 256 threads: see
 // gauss_jordan_blocked<4> for the panel (run by wavefront 0 here) and the trailing update (all four).
-// piv (nullable, LDS): piv[0], piv[1] receive the smallest and largest |1 / pivot| of the elimination (the free condition
-// estimate of gauss_jordan_blocked, same arithmetic), valid for every thread after the call.
-__device__ __forceinline__ void gauss_jordan_wide(double* W, int n, double* Lbuf, double* Ybuf, int* prow, int tid,
-                                                  double* piv = nullptr) {
+__device__ __forceinline__ void gauss_jordan_wide(double* W, int n, double* Lbuf, double* Ybuf, int* prow, int tid) {
   constexpr int NP = CrwSmem::NP, BS = CrwSmem::BS, LDW = CrwSmem::LDW, wcols = 2 * NP;
   const int lane = tid & 63, wv = tid >> 6, tr = tid >> 4, tc = tid & 15;
   unsigned long long used = 0ull;  // (wavefront 0 only)
-  double inv_lo = 1e300, inv_hi = 0.0;  // (wavefront 0 only, wave-uniform)
   const int nsteps = (n + BS - 1) / BS;
   for (int kb = 0; kb < nsteps; ++kb) {
     const int j0 = kb * BS;
@@ -62,8 +58,6 @@ __device__ __forceinline__ void gauss_jordan_wide(double* W, int n, double* Lbuf
           const bool is_r = (lane == r);
           if (is_r) id[c] = 1.0;
           const double inv = fast_rcp(readlane_dyn_f64(pw[c], r));
-          inv_lo = fmin(inv_lo, fabs(inv));
-          inv_hi = fmax(inv_hi, fabs(inv));
           const double f = is_r ? 0.0 : pw[c];
           inv_own = is_r ? inv : inv_own;
 #pragma unroll
@@ -75,10 +69,6 @@ __device__ __forceinline__ void gauss_jordan_wide(double* W, int n, double* Lbuf
       }
 #pragma unroll
       for (int c = 0; c < BS; ++c) id[c] *= inv_own;
-      if (piv && kb == nsteps - 1 && lane == 0) {
-        piv[0] = inv_lo;
-        piv[1] = inv_hi;
-      }
       {
         double lh[BS];
 #pragma unroll
@@ -177,21 +167,14 @@ __device__ __forceinline__ double norm1_wide(const double (&x)[4][4], double* pa
   return red[0];
 }
 
-// One draw on the workgroup.  REFINE = true (what the kernel runs): when the pivots of the elimination of an iteration span
-// more than CR_REFINE_PIVOT_RATIO (an ill-conditioned A1: the blocked Gauss-Jordan then loses ~1e-15 x cond
-// where the reference's LAPACK LU, cycle_reduction.py:150-160, keeps 1e-10) the solve gets the one step of iterative
-// refinement X += A1^-1 (R - A1 X) of crc_iterate (dsge_cr_compact.hpp; same test, same arithmetic).  REFINE = false leaves
-// at that point and returns true (kept for the experiment below).  Measured at n = 56, 4096 systems without static variables
-// (tools/crw_variants, profiles/r3/crw_variants.txt): no test 3.85 ms; test + leave 3.97; test + refinement inlined (this)
-// 3.95; test + the refined instance behind a device function call 4.09 -- the call's ABI registers cost the common loop more
-// scalar spills than the inlined block costs in code size.
-template <bool REFINE>
-__device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict__ A, const double* __restrict__ B,
-                                       const double* __restrict__ C, int draw, int n, int max_iter, double tol,
-                                       double* __restrict__ T_out, int32_t* __restrict__ status,
-                                       int32_t* __restrict__ n_iter_out, int scan_mode, const double* __restrict__ D, int k,
-                                       double* __restrict__ R_out) {
+__global__ __launch_bounds__(256, 2) void cr_wide_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                       const double* __restrict__ C, int batch, int n, int max_iter,
+                                                       double tol, double* __restrict__ T_out,
+                                                       int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
+                                                       int scan_mode, const double* __restrict__ D, int k,
+                                                       double* __restrict__ R_out) {
   constexpr int NP = CrwSmem::NP, BS = CrwSmem::BS, LDW = CrwSmem::LDW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;
   double* G1 = W + NP;
   double* Lbuf = W + NP * LDW;
@@ -205,6 +188,8 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
   int* rsrc = posL + NP;
   int* misc = rsrc + NP;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tr = tid >> 4, tc = tid & 15;
+  const int draw = blockIdx.x;  // one draw per workgroup
+  if (draw >= batch) return;
   const size_t off = (size_t)draw * n * n;
   for (int idx = tid; idx < NP * LDW; idx += 256) W[idx] = 0.0;
   // non-zero columns of A (states) and C (leads): lane j of wavefront 0 looks down column j, all rows in flight
@@ -242,7 +227,7 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
   const int s = __popcll(maskS), l = __popcll(maskL), wr = s + l;
   if (wr > NP) {  // does not fit the compact tile: the dense kernel handles this draw
     if (tid == 0) status[draw] = DSGE_ST_INTERNAL_RERUN;
-    return false;
+    return;
   }
   if (tid < NP) {
     const unsigned long long below = (1ull << tid) - 1ull;
@@ -292,41 +277,7 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
       for (int i = 0; i < BS; ++i) W[(tr * BS + i) * LDW + tc * BS + i] = A1[i][i] + 1e-16;
     }
     blk_store_lds<BS>(Rb, G1, LDW, tr, tc);
-    gauss_jordan_wide(W, n, Lbuf, Ybuf, prow, tid, red + 2);  // barriers on entry and exit
-    if (red[3] > CR_REFINE_PIVOT_RATIO * red[2]) {  // (workgroup-uniform: LDS values behind a barrier)
-      if constexpr (!REFINE) {
-        return true;
-      } else {
-        gj_unpermute_wide(W, n, prow, tid);  // X in natural row order (barriers inside)
-        double xh[BS][BS], rr[BS][BS];
-        blk_load_lds<BS>(xh, G1, LDW, tr, tc);
-        blk_store_lds<BS>(A1, W, LDW, tr, tc);
-        if (scan_mode && tr == tc) {
-#pragma unroll
-          for (int i = 0; i < BS; ++i) W[(tr * BS + i) * LDW + tc * BS + i] = A1[i][i] + 1e-16;
-        }
-        __syncthreads();
-        blk_zero<BS>(rr);
-        mm_acc<BS, false>(rr, W, LDW, G1, LDW, n, tr, tc);  // A1 X
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < BS; ++i)
-#pragma unroll
-          for (int j = 0; j < BS; ++j) rr[i][j] = Rb[i][j] - rr[i][j];
-        blk_store_lds<BS>(rr, G1, LDW, tr, tc);
-        gauss_jordan_wide(W, n, Lbuf, Ybuf, prow, tid);  // [A1 | R - A1 X] -> the correction
-        gj_unpermute_wide(W, n, prow, tid);
-        blk_load_lds<BS>(rr, G1, LDW, tr, tc);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < BS; ++i)
-#pragma unroll
-          for (int j = 0; j < BS; ++j) xh[i][j] += rr[i][j];
-        blk_store_lds<BS>(xh, G1, LDW, tr, tc);
-        if (tid < NP) prow[tid] = tid;  // the solution sits in natural row order now
-        __syncthreads();
-      }
-    }
+    gauss_jordan_wide(W, n, Lbuf, Ybuf, prow, tid);  // barriers on entry and exit
     // gather the rows S then L of the solution into compact order: XC[r] = X[cmap[r]]
     if (tid < NP) rsrc[tid] = (tid < wr) ? prow[cmap[tid]] : 0;
     __syncthreads();
@@ -442,19 +393,6 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
     status[draw] = solve_T ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
     if (n_iter_out) n_iter_out[draw] = it;
   }
-  return false;
-}
-
-__global__ __launch_bounds__(256, 2) void cr_wide_kernel(const double* __restrict__ A, const double* __restrict__ B,
-                                                       const double* __restrict__ C, int batch, int n, int max_iter,
-                                                       double tol, double* __restrict__ T_out,
-                                                       int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
-                                                       int scan_mode, const double* __restrict__ D, int k,
-                                                       double* __restrict__ R_out) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int draw = blockIdx.x;  // one draw per workgroup
-  if (draw >= batch) return;
-  crw_solve<true>(smem, A, B, C, draw, n, max_iter, tol, T_out, status, n_iter_out, scan_mode, D, k, R_out);
 }
 
 }  // namespace dsge

@@ -18,9 +18,26 @@ struct CrwSmem {
   static constexpr int NP = 64, BS = 4, LDW = 2 * NP + 2;
   // W (NP x LDW), Lbuf (NP x BS), Ybuf (BS x 2 NP), column-sum partials (4 x NP), reduction slots (8)
   static constexpr size_t dbl = (size_t)NP * LDW + NP * BS + BS * 2 * NP + 4 * NP + 8;
-  // ints: prow, cmap, posS, posL, rsrc (NP each), misc (8)
-  static constexpr size_t bytes = sizeof(double) * dbl + sizeof(int) * (5 * NP + 8);
+  // ints: prow, cmap, posS, posL, rsrc (NP each), misc (8); then the argument record of the out-of-line refined solve
+  static constexpr size_t args_offset = sizeof(double) * dbl + sizeof(int) * (5 * NP + 8);
+  static constexpr size_t bytes = args_offset + 128;
 };
+
+// Arguments of crw_solve_refined, parked in LDS at kernel start: were they passed by value the 26 scalar registers they
+// occupy would stay live across the whole common path for the sake of a call one draw in a hundred makes.
+struct CrwArgs {
+  const double* A;
+  const double* B;
+  const double* C;
+  const double* D;
+  double* T_out;
+  double* R_out;
+  int32_t* status;
+  int32_t* n_iter;
+  double tol;
+  int draw, n, max_iter, scan_mode, k;
+};
+static_assert(sizeof(CrwArgs) <= 128, "argument record");
 
 // Blocked Gauss-Jordan with partial pivoting on W (n rows, two column groups of 64), 256 threads: see
 // gauss_jordan_blocked<4> for the panel (run by wavefront 0 here) and the trailing update (all four).
@@ -177,14 +194,14 @@ __device__ __forceinline__ double norm1_wide(const double (&x)[4][4], double* pa
   return red[0];
 }
 
-// One draw on the workgroup.  REFINE = true (what the kernel runs): when the pivots of the elimination of an iteration span
-// more than CR_REFINE_PIVOT_RATIO (an ill-conditioned A1: the blocked Gauss-Jordan then loses ~1e-15 x cond
-// where the reference's LAPACK LU, cycle_reduction.py:150-160, keeps 1e-10) the solve gets the one step of iterative
-// refinement X += A1^-1 (R - A1 X) of crc_iterate (dsge_cr_compact.hpp; same test, same arithmetic).  REFINE = false leaves
-// at that point and returns true (kept for the experiment below).  Measured at n = 56, 4096 systems without static variables
-// (tools/crw_variants, profiles/r3/crw_variants.txt): no test 3.85 ms; test + leave 3.97; test + refinement inlined (this)
-// 3.95; test + the refined instance behind a device function call 4.09 -- the call's ABI registers cost the common loop more
-// scalar spills than the inlined block costs in code size.
+// One draw on the workgroup.  REFINE = false is the common path: when the pivots of the elimination of one of the first two
+// iterations span more than CR_REFINE_PIVOT_RATIO (an ill-conditioned A1: the blocked Gauss-Jordan then loses ~1e-13 x cond
+// where the reference's LAPACK LU, cycle_reduction.py:150-160, keeps 1e-10) it gives up at once and returns true; the kernel
+// then calls the REFINE = true instance, which applies the one step of iterative refinement X += A1^-1 (R - A1 X) of
+// crc_iterate (dsge_cr_compact.hpp; same test, same arithmetic) to those eliminations.  The refined instance is OUT OF LINE
+// (crw_solve_refined, noinline): its two extra eliminations per iteration cost every draw 8 % when they were inlined into
+// the common loop (code size); as a separate function they are never fetched unless a draw is flagged (about one in
+// several thousand), and the common instance stays the kernel body itself (no call, no callee-saved registers).
 template <bool REFINE>
 __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict__ A, const double* __restrict__ B,
                                        const double* __restrict__ C, int draw, int n, int max_iter, double tol,
@@ -293,7 +310,7 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
     }
     blk_store_lds<BS>(Rb, G1, LDW, tr, tc);
     gauss_jordan_wide(W, n, Lbuf, Ybuf, prow, tid, red + 2);  // barriers on entry and exit
-    if (red[3] > CR_REFINE_PIVOT_RATIO * red[2]) {  // (workgroup-uniform: LDS values behind a barrier)
+    if (it < 2 && red[3] > CR_REFINE_PIVOT_RATIO * red[2]) {  // (workgroup-uniform: LDS values behind a barrier)
       if constexpr (!REFINE) {
         return true;
       } else {
@@ -445,6 +462,12 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
   return false;
 }
 
+__device__ __noinline__ void crw_solve_refined(double* smem) {
+  const CrwArgs a = *(const CrwArgs*)((const char*)smem + CrwSmem::args_offset);
+  crw_solve<true>(smem, a.A, a.B, a.C, a.draw, a.n, a.max_iter, a.tol, a.T_out, a.status, a.n_iter, a.scan_mode, a.D, a.k,
+                  a.R_out);
+}
+
 __global__ __launch_bounds__(256, 2) void cr_wide_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                        const double* __restrict__ C, int batch, int n, int max_iter,
                                                        double tol, double* __restrict__ T_out,
@@ -454,7 +477,15 @@ __global__ __launch_bounds__(256, 2) void cr_wide_kernel(const double* __restric
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int draw = blockIdx.x;  // one draw per workgroup
   if (draw >= batch) return;
-  crw_solve<true>(smem, A, B, C, draw, n, max_iter, tol, T_out, status, n_iter_out, scan_mode, D, k, R_out);
+  if (threadIdx.x == 0) {
+    CrwArgs* a = (CrwArgs*)((char*)smem + CrwSmem::args_offset);
+    a->A = A; a->B = B; a->C = C; a->D = D; a->T_out = T_out; a->R_out = R_out; a->status = status; a->n_iter = n_iter_out;
+    a->tol = tol; a->draw = draw; a->n = n; a->max_iter = max_iter; a->scan_mode = scan_mode; a->k = k;
+  }
+  if (crw_solve<false>(smem, A, B, C, draw, n, max_iter, tol, T_out, status, n_iter_out, scan_mode, D, k, R_out)) {
+    __syncthreads();  // (everybody has left the common instance: its LDS contents are dead)
+    crw_solve_refined(smem);
+  }
 }
 
 }  // namespace dsge

@@ -35,14 +35,13 @@ def run(seed, trials, verbose=True):
             GR = G @ R[i].T
             ref = (GR, GR @ T[i].T, G, C[i].T @ GR)
             e2 = max(np.abs(x - r_).max() / max(1.0, np.abs(r_).max()) for x, r_ in zip((Bs[i], Cs[i], Ds[i], Ts[i]), ref))
-            # The device sums the series S = sum_k G^k H (T')^k by doubling; when the powers of G = -(B + C T)^-T C' grow before
-            # they decay (a non-normal G) it loses digits: 1 of ~160 random systems came out at 6e-7 (residual of the Stein
-            # equation 1e-6, the reference's Kronecker LU: 1e-12).  One step of iterative refinement inside the kernel fixes
-            # it but costs 1.1-1.6 KB of scratch on the 40-wide tile (gradient 7.3 -> 8.1 ms): not built; 1e-5 is asserted.
-            if st[i] == 0 and e1 > 1e-8 and verbose:
+            # The device sums the series S = sum_k G^k H (T')^k by doubling; a draw whose Stein residual shows lost digits (a
+            # non-normal G = -(B + C T)^-T C') gets one step of iterative refinement in a second pass (adjoint_kernel<BS, true>):
+            # the reference's Kronecker LU level, 1e-9 asserted.
+            if st[i] == 0 and e1 > 1e-10 and verbose:
                 res = lambda S_: np.abs(M.T @ S_ + C[i].T @ S_ @ T[i].T + T_bar[i]).max() / max(1.0, np.abs(T_bar[i]).max())
                 print("  policy adjoints differ by", f"{e1:.1e}", "residual device", f"{res(Ab[i]):.1e}", "oracle", f"{res(S):.1e}", dict(n=n, ns=ns, nl=nl))
-            if st[i] != 0 or not (e1 <= 1e-5 and e2 <= 1e-9):
+            if st[i] != 0 or not (e1 <= 1e-9 and e2 <= 1e-9):
                 bad += 1
                 if verbose:
                     print("MISMATCH", dict(n=n, ns=ns, nl=nl, k=k, draw=i), st[i], e1, e2)

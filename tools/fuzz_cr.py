@@ -5,7 +5,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from geconpy_amd import batched, workloads as wl
 import oracle
-from oracle.cycle_reduction import _cr_step
+
+
+def cycle_reduction_exact(A, B, C, tol, digits=40):
+    """40-digit cycle reduction with the reference's stopping rule (cycle_reduction.py:171-177) -> (T as float64, iterations)."""
+    from mpmath import mp, matrix, mpf
+
+    mp.dps = digits
+    M = lambda a: matrix(a.tolist())
+    norm1 = lambda X: max(sum(abs(X[i, j]) for i in range(X.rows)) for j in range(X.cols))
+    A0, A1, A2, Ah = M(A), M(B), M(C), M(B)
+    for it in range(1000):
+        A1i = A1 ** -1
+        X0, X2 = A1i * A0, A1i * A2
+        m00, m02, m20, m22 = A0 * X0, A0 * X2, A2 * X0, A2 * X2
+        A1, Ah, A0, A2 = A1 - m02 - m20, Ah - m20, -m00, -m22
+        if norm1(A0) < mpf(tol) and norm1(A2) < mpf(tol):
+            return np.array((-(Ah ** -1) * M(A)).tolist(), dtype=float), it + 1
+    raise RuntimeError("no convergence")
 
 
 def run(seed, trials, verbose=True):
@@ -23,24 +40,25 @@ def run(seed, trials, verbose=True):
         A, B, C = (np.stack([s_[j] for s_ in sysm]) for j in range(3))
         tol = float(rng.choice([1e-6, 1e-9, 1e-12]))
         ref = [oracle.cycle_reduction_core(A[i], B[i], C[i], 200, tol) for i in range(nb)]
+        exact = {}
         for opts in ({}, {"cr_four_waves": 0}, {"cr_compact": 0}):
             T, st, it = batched.cycle_reduction_batched(A, B, C, max_iter=200, tol=tol, options=opts)
             for i in range(nb):
                 Tc, conv, itc = ref[i]
-                ok = (st[i] == 0) == bool(conv) and (not conv or (it[i] == itc and np.abs(T[i] - Tc).max() <= 1e-7))  # (1e-8 happens on ill-conditioned intermediates)
+                # fixed bars: status and iteration count exact, |T - T_oracle| <= 1e-9 (ill-conditioned intermediates are
+                # refined on the device: CR_REFINE_PIVOT_RATIO, dsge_cr_compact.hpp / dsge_cr_wide.hpp)
+                ok = (st[i] == 0) == bool(conv) and (not conv or (it[i] == itc and np.abs(T[i] - Tc).max() <= 1e-9))
                 if not ok and conv and st[i] == 0 and it[i] == itc:
-                    # T differs by more than 1e-7: accepted only if the iteration's own matrices explain it.  The solves
-                    # X = A1^-1 [A0 A2] run on matrices of condition up to 1e8 in the first iterations of some draws;
-                    # Gauss-Jordan with partial pivoting is forward stable (error ~ cond x u), LAPACK's LU is backward
-                    # stable and often better than that bound (seed 11, n = 62: cond 1.2e8, device 1.5e-7, numpy 1e-10).
-                    a0, a1, a2, a1h, worst = A[i], B[i], C[i], B[i], 0.0
-                    for _ in range(int(itc)):
-                        worst = max(worst, np.linalg.cond(a1))
-                        a0, a1, a2, a1h = _cr_step(a0, a1, a2, a1h)
-                    if np.abs(T[i] - Tc).max() <= 2e-14 * worst:
+                    # The float64 oracle (the reference's LAPACK path) is itself uncertain at this level on some draws (seed 11,
+                    # n = 27: 6.4e-9 from a 40-digit evaluation).  Adjudicate against exact arithmetic: the device must be within
+                    # 1e-9 of the exact T, or at least as close to it as the reference's own float64 result.
+                    Tx, itx = exact.setdefault(i, cycle_reduction_exact(A[i], B[i], C[i], tol))
+                    e_dev, e_orc = np.abs(T[i] - Tx).max(), np.abs(Tc - Tx).max()
+                    if itx == itc and e_dev <= max(1e-9, e_orc):
                         ok = True
                         if verbose:
-                            print("conditioning outlier", opts, dict(n=n, tol=tol, draw=i), f"|dT| = {np.abs(T[i] - Tc).max():.2e}, worst cond(A1) = {worst:.2e}")
+                            print("adjudicated against 40-digit arithmetic", opts, dict(n=n, tol=tol, draw=i),
+                                  f"|T_dev - T_exact| = {e_dev:.2e}, |T_oracle - T_exact| = {e_orc:.2e}")
                 if not ok:
                     bad += 1
                     if verbose:

@@ -1,0 +1,62 @@
+// Experiment / self-test (not product): the workgroup MFMA product of dsge_so_gemm.hpp against the host, and its rate.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "../../geconpy_amd/csrc/dsge_so_gemm.hpp"
+#ifndef MT_
+#define MT_ 13
+#endif
+using Cfg = dsge::SoGemmCfg<MT_>;
+__global__ __launch_bounds__(512) void k(const double* A, const double* B, double* C, double* Ct, int K, int reps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int MP = Cfg::MP;
+  const size_t off = (size_t)blockIdx.x * MP * MP;
+  for (int r = 0; r < reps; ++r)
+    dsge::so_gemm<MT_>(A + off, MP, B + off, MP, K, lds, [&](int row, int col, double v) {
+      C[off + (size_t)row * MP + col] = v;
+      Ct[off + (size_t)col * MP + row] = v;
+    });
+}
+int main(int argc, char** argv) {
+  constexpr int MP = Cfg::MP;
+  const int nb = argc > 1 ? atoi(argv[1]) : 1024, reps = argc > 2 ? atoi(argv[2]) : 10, K = MP;
+  const size_t mat = (size_t)MP * MP;
+  std::vector<double> hA(mat * 2), hB(mat * 2), hC(mat * 2), hCt(mat * 2);
+  srand(1);
+  for (auto& x : hA) x = rand() / (double)RAND_MAX - 0.5;
+  for (auto& x : hB) x = rand() / (double)RAND_MAX - 0.3;
+  double *A, *B, *C, *Ct;
+  hipMalloc(&A, nb * mat * 8); hipMalloc(&B, nb * mat * 8); hipMalloc(&C, nb * mat * 8); hipMalloc(&Ct, nb * mat * 8);
+  for (int i = 0; i < nb; ++i) {
+    hipMemcpy(A + i * mat, hA.data() + (i & 1) * mat, mat * 8, hipMemcpyHostToDevice);
+    hipMemcpy(B + i * mat, hB.data() + (i & 1) * mat, mat * 8, hipMemcpyHostToDevice);
+  }
+  const size_t lds = Cfg::LDS_DOUBLES * 8;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(nb), dim3(512), lds, 0, A, B, C, Ct, K, 1);
+  hipDeviceSynchronize();
+  double err = 0, errt = 0;
+  for (int d : {0, 1, nb - 1}) {
+    hipMemcpy(hC.data(), C + d * mat, mat * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hCt.data(), Ct + d * mat, mat * 8, hipMemcpyDeviceToHost);
+    const double* a = hA.data() + (d & 1) * mat; const double* b = hB.data() + (d & 1) * mat;
+    for (int i = 0; i < MP; i += 3) for (int j = 0; j < MP; ++j) {
+      double s = 0; for (int kk = 0; kk < K; ++kk) s += a[kk * MP + i] * b[kk * MP + j];
+      err = fmax(err, fabs(s - hC[i * MP + j])); errt = fmax(errt, fabs(s - hCt[j * MP + i]));
+    }
+  }
+  printf("MT=%d MP=%d lds=%zu B: max abs err %.3e (transposed store %.3e)\n", MT_, MP, lds, err, errt);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k, dim3(nb), dim3(512), lds, 0, A, B, C, Ct, K, reps);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double fl = 2.0 * MP * MP * K * (double)nb * reps;
+    printf("  %d draws x %d products: %.3f ms = %.2f TFLOP/s (padded flops), %.1f us per product per CU-slot\n", nb, reps, ms,
+           fl / ms / 1e9, ms * 1e3 / reps / ((nb + 255) / 256));
+  }
+  return err < 1e-10 && errt < 1e-10 ? 0 : 1;
+}
