@@ -179,7 +179,6 @@ __host__ __device__ inline size_t so_setup_lds_doubles(const SoLayout& L) {
   o += (size_t)s * s;                    // Pf
   o += (size_t)l * l;                    // GLL scratch
   o += (size_t)n + 64;                   // colbuf, reductions
-  o += (size_t)l * s * (s > k ? s : k);  // V / W
   o += 192;                              // three short vectors
   o += 96;                               // index lists
   return o + 64;
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
   double* colbuf = carve(n);
   double* red = carve(32);
   int* ired = (int*)carve(32);
-  double* VW = carve((size_t)l * s * (s > k ? s : k));
+  double* VW = Y2;  // V / W of steps 9 and 10 (l s k doubles, k <= s): Y2 is free between the doubling and step 12
   double* vec3 = carve(192);
   int* Si = (int*)carve(96);  // S (24), U (40), L (64) as ints
   int* Ui = Si + 24;
@@ -930,6 +929,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       const double yo = ((mask >> o) & 1) ? a.y[(size_t)t * p + o] : 0.0;
       vv[o] = yo - dv[o] - za;
     }
+    __syncthreads();  // (the innovation is read by every wavefront below, also on the steady path)
     if (!steady) {
       // ---- P Z' (m x p), F = Zm P Zm' + Hm + jitter I ---------------------------------------------------------------------
       for (int idx = tid; idx < m * p; idx += NT) {

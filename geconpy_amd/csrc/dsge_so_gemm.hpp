@@ -114,7 +114,7 @@ template <int MT, class Epi>
 __device__ __forceinline__ void so_gemm(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb, int K,
                                         double* lds, Epi epi) {
   constexpr int RB = SoGemmCfg<MT>::RB;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: block offsets and the half are wave-uniform)
   const int pair = wave >> 1, rbk = pair >> 1, cbk = pair & 1;
   const int rt0 = rbk ? RB : 0, nrt = rbk ? MT - RB : RB, ct0 = cbk ? RB : 0, nct = cbk ? MT - RB : RB;
   if (wave & 1)

@@ -168,12 +168,25 @@ class LogpEngine:
         A, B, C, D, q = self.jacobians_from_theta(program, theta, out=jac_out)
         if q is None:
             raise ValueError("the program has no shock variances")
+        # the observation equation: the same resolution as logp_from_theta, so that the pair (logp, gradient) belongs to the
+        # SAME function of theta -- a program built with d= filters with its parameter-dependent intercept and the cotangent
+        # of d flows back through the generated pullback; a parameter-dependent Z has no cotangent on the device
+        if getattr(program, "Z", None) is not None and Z is None:
+            raise NotImplementedError("gradient through a parameter-dependent design matrix Z(theta) is not built "
+                                      "(DSGE_ST_GRAD_UNSUPPORTED: no Z cotangent); pass a constant selector Z")
+        d_from_program = d is None and getattr(program, "d", None) is not None
+        if d_from_program:
+            _, d = self.observation_from_theta(program, theta)
+        if Z is None:
+            raise ValueError("no design matrix: pass Z")
         g = self.solve_kalman_logp_grad(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, out=grad_out, **kw)
         if theta_bar is None:
             theta_bar = torch.empty_like(theta)
         program.launch_vjp(theta.data_ptr(), theta.shape[0], g["A_bar"].data_ptr(), g["B_bar"].data_ptr(),
                            g["C_bar"].data_ptr(), g["D_bar"].data_ptr(), g["q_bar"].data_ptr(), theta_bar.data_ptr(),
                            self._stream())
+        if d_from_program:  # theta_bar += (d d / d theta)' d_bar
+            program.launch_obs_vjp(theta.data_ptr(), theta.shape[0], g["d_bar"].data_ptr(), theta_bar.data_ptr(), self._stream())
         return g["logp"], g["status"], theta_bar, g
 
     # -- product entry points --------------------------------------------------------------
@@ -243,6 +256,56 @@ class LogpEngine:
             )
         )
         return out
+
+    def second_order_structure(self, A, C, Z):
+        """(S, L, U) int32 numpy index lists of ``batched.second_order_structure`` from device tensors (a property of the
+        model: one reduction + host sync, call once)."""
+        n = A.shape[-1]
+        nzA = (A != 0).reshape(-1, n).any(dim=0).cpu().numpy()
+        nzC = (C != 0).reshape(-1, n).any(dim=0).cpu().numpy()
+        nzZ = (Z != 0).reshape(-1, n).any(dim=0).cpu().numpy()
+        S = np.flatnonzero(nzA)
+        U = np.concatenate([S, np.setdiff1d(np.flatnonzero(nzZ), S)])
+        return S.astype(np.int32), np.flatnonzero(nzC).astype(np.int32), U.astype(np.int32)
+
+    def second_order_logp(self, A, B, C, D, hess_idx, hess_val, q, Z, y, structure, d=None, Hdiag=None,
+                          solver="cycle_reduction", tol=1e-8, max_iter=1000, jitter=JITTER_DEFAULT,
+                          missing_fill_value=MISSING_FILL, logp=None, status=None, stage_ms=None, options=None):
+        """Second-order perturbation + pruned-state-space quasi-likelihood of the whole batch, device-resident
+        (include/dsge_hip.h: ``dsge_second_order_logp_batched``; BASELINE configs[4]).  ``hess_idx``: int32 CUDA tensor
+        (nnz, 3); ``hess_val``: float64 (batch, nnz); ``q``: (k,) or (batch, k); ``structure`` = ``second_order_structure``.
+        ``stage_ms``: a ctypes float[4] that receives the stage durations (synchronises).  Returns (logp, status)."""
+        torch = self.torch
+        nb, n, _ = A.shape
+        k = D.shape[2]
+        T_len, p = y.shape
+        for t in (A, B, C):
+            self._chk(t, (nb, n, n))
+        self._chk(D, (nb, n, k))
+        self._chk(y, (T_len, p))
+        self._chk(Z, (p, n))
+        self._chk(q)
+        if not (hess_idx.is_cuda and hess_idx.dtype == torch.int32 and hess_idx.is_contiguous() and hess_idx.shape[1] == 3):
+            raise ValueError("hess_idx must be a contiguous int32 CUDA tensor (nnz, 3)")
+        nnz = hess_idx.shape[0]
+        self._chk(hess_val, (nb, nnz))
+        S, Lc, U = (np.ascontiguousarray(x, dtype=np.int32) for x in structure)
+        if logp is None:
+            logp = torch.empty(nb, dtype=torch.float64, device=self.device)
+        if status is None:
+            status = torch.empty(nb, dtype=torch.int32, device=self.device)
+        with _lib.options_scope(options):
+            _lib.check(
+                self.lib.dsge_second_order_logp_batched(
+                    self._p(A), self._p(B), self._p(C), self._p(D), hess_idx.data_ptr(), nnz, self._p(hess_val), self._p(q),
+                    int(q.dim() == 2), self._p(Z), self._p(d), self._p(Hdiag), self._p(y), nb, n, k, p, T_len,
+                    _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter), float(missing_fill_value),
+                    S.ctypes.data, len(S), Lc.ctypes.data, len(Lc), U.ctypes.data, len(U), self._p(logp), status.data_ptr(),
+                    None, None, None, None, None, None, None if stage_ms is None else __import__("ctypes").addressof(stage_ms),
+                    self._stream(),
+                )
+            )
+        return logp, status
 
     def profile_kernels(self, A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                         tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, reps=5,

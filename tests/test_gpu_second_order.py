@@ -22,19 +22,22 @@ def _small_batch(n, ns, nl, k, nb, seed, nnz_per_eq=6):
     return A, B, C, D, idx, val
 
 
-@pytest.mark.parametrize("n,ns,nl,k,obs", [(6, 3, 2, 2, (0, 4, 5)), (8, 2, 3, 1, (0, 1)), (12, 5, 4, 3, (0, 1, 2, 7)),
-                                           (20, 9, 6, 4, (0, 1, 2, 3))])
-def test_second_order_small_models(n, ns, nl, k, obs):
-    """Coefficients g_yy, g_yu, g_uu, g_ss and the pruned likelihood on small random systems (some with observed
-    non-states, i.e. u > s) against the reduced oracle; every tile-count instance up to 7 is exercised."""
-    nb = 5
+@pytest.mark.parametrize("n,ns,nl,k,obs,T_len", [(6, 3, 2, 2, (0, 4, 5), 40), (8, 2, 3, 1, (0, 1), 40), (12, 5, 4, 3, (0, 1, 2, 7), 40),
+                                                 (20, 9, 6, 4, (0, 1, 2, 3), 40), (26, 12, 8, 5, (0, 1, 20), 150),
+                                                 (32, 15, 9, 6, (0, 1, 2, 3, 4), 60)])
+def test_second_order_small_models(n, ns, nl, k, obs, T_len):
+    """Coefficients g_yy, g_yu, g_uu, g_ss and the pruned likelihood on random systems (some with observed non-states,
+    i.e. u > s) against the reduced oracle; pruned states of 16, 9, 27, 63, 104 and 150 dimensions, i.e. the 2-, 4-, 7- and
+    10-tile kernel instances (the 13-tile one runs the SW-shaped test); missing observations; the longer samples reach the
+    steady-state switch."""
+    nb = 5 if n <= 20 else 3
     A, B, C, D, idx, val = _small_batch(n, ns, nl, k, nb, 3100 + n)
     rng = np.random.default_rng(n)
     q = rng.uniform(0.5e-4, 4e-4, (nb, k))
     p = len(obs)
     Z = np.zeros((p, n))
     Z[np.arange(p), list(obs)] = 1.0
-    y = rng.normal(0, 0.02, (40, p))
+    y = rng.normal(0, 0.02, (T_len, p))
     y[7, 0] = np.nan
     y[20] = np.nan
     H = np.full(p, 1e-5)
@@ -54,6 +57,9 @@ def test_second_order_small_models(n, ns, nl, k, obs):
 def test_second_order_brock_mirman_closed_form():
     """The closed-form Brock-Mirman policy (tests/test_oracle_second_order.py): the device's second derivatives against the
     exact ones."""
+    import os, sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_oracle_second_order import _brock_mirman
 
     A, B, C, D, H, T, R, G2 = _brock_mirman()
