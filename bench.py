@@ -241,12 +241,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="draws per GPU; default: 4096 at --gpus 1 (BASELINE configs[2]), 8192 at --gpus N > 1 (configs[3]: "
+                         "65 536 draws over 8 GPUs), 1024 for --workload sw_second_order (configs[4])")
     ap.add_argument("--cpu-sample", type=int, default=192, help="evaluations timed on the host cores (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--max-iter", type=int, default=1000)
-    ap.add_argument("--workload", default="sw_shaped", choices=["sw_shaped", "rbc", "full_nk"])
+    ap.add_argument("--workload", default="sw_shaped", choices=["sw_shaped", "rbc", "full_nk", "sw_second_order"])
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two extra legs of the default line (full recursion: kalman_steady_tol = 0; solver = gensys)")
     ap.add_argument("--solver", default="cycle_reduction", choices=["cycle_reduction", "gensys"])
     ap.add_argument("--from-theta", action="store_true",
                     help="rbc workload only: start each step from the parameter draws (generated Jacobian kernel on the "
@@ -272,7 +276,9 @@ def main():
     # CPU baseline first (rank 0, N = 1 only), in spawned workers, before this process touches the GPU
     from geconpy_amd import workloads as wl
 
-    per_gpu = args.batch_per_gpu
+    if args.workload == "sw_second_order":
+        return main_second_order(args, world, rank, local_rank)
+    per_gpu = args.batch_per_gpu if args.batch_per_gpu else (4096 if world == 1 else 8192)
     global_batch = per_gpu * world
     lo, hi = wl.shard_bounds(global_batch, world, rank)
     if args.workload == "rbc":  # BASELINE configs[1] (informational; the metric is quoted on sw_shaped)
@@ -294,7 +300,7 @@ def main():
 
     cpu = None
     cpu_logp = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and args.cpu_sample > 0:  # (also at N > 1: rank 0's shard; the other ranks wait in the rendezvous)
         try:  # one worker per PHYSICAL core: with SMT siblings as workers the per-core rate halves and says nothing more
             import psutil
 
@@ -308,7 +314,7 @@ def main():
             "unit": "evals/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"first {n_sample} draws of the same SW-shaped batch, numpy/scipy oracle "
+            "sample": f"first {n_sample} draws of {'rank 0 shard of ' if world > 1 else ''}the same SW-shaped batch, numpy/scipy oracle "
                       f"(cycle reduction + bilinear Lyapunov + Joseph-form Kalman), {cores} worker processes (one per physical "
                       f"core) x 1 BLAS thread, {cpu_dt:.1f} s wall",
         }
@@ -409,6 +415,46 @@ def main():
     logp_host = logp_all.cpu().numpy()
     stat_host = stat_all.cpu().numpy()
     n_fail = int((stat_host != 0).sum())
+
+    # Two more legs of the same loop, outside the headline timer (N = 1): the full recursion (kalman_steady_tol = 0 per call:
+    # what data with changing missing-data masks costs, statespace.py:1432-1505) and the reference's default estimation solver
+    # (configure(..., solver="gensys"), statespace.py:832).
+    extras = {}
+    if world == 1 and not args.no_extras and prog is None and args.workload == "sw_shaped" and args.solver == "cycle_reduction":
+        def timed(fn, steps):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / steps
+
+        opts_full = dict(opts or {}, kalman_steady_tol=0.0)
+        lp_full = torch.empty_like(logp_buf)
+        dt_full = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
+                                                      max_iter=args.max_iter, logp=lp_full, status=stat_buf, solver=args.solver,
+                                                      n_state_hint=hints[0], z_selector_hint=hints[1], options=opts_full),
+                        max(3, args.steps // 2))
+        extras["full_recursion"] = {"value": round(nloc / dt_full, 2), "ms_per_step": round(dt_full * 1e3, 4), "unit": "evals/s",
+                                    "note": "same step with kalman_steady_tol = 0 (per call): every one of the T_len filter steps "
+                                            "updates the covariance, as pymc_extras' standard filter does",
+                                    "max_rel_logp_diff_vs_headline": float((torch.abs(lp_full - logp_all[lo:hi]) /
+                                                                            torch.abs(lp_full)).max().item())}
+        nl_g = lead_hint(shard["C"], args.tol)
+        lp_g = torch.empty_like(logp_buf)
+        st_g = torch.empty_like(stat_buf)
+        dt_g = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
+                                                   max_iter=args.max_iter, logp=lp_g, status=st_g, solver="gensys",
+                                                   n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g),
+                     max(3, args.steps // 2))
+        extras["gensys"] = {"value": round(nloc / dt_g, 2), "ms_per_step": round(dt_g * 1e3, 4), "unit": "evals/s",
+                            "note": "same step with solver = gensys (ordered QZ), the reference's default estimation solver",
+                            "failed_draws": int((st_g != 0).sum().item()),
+                            "max_rel_logp_diff_vs_headline": float((torch.abs(lp_g - logp_all[lo:hi]) / torch.abs(lp_g)).max().item())}
+        local_eval(0, nloc)  # (leave the buffers as the headline loop left them)
+        torch.cuda.synchronize()
 
     # per-kernel durations, HIP events on the launch stream (rank 0's shard)
     kms = eng.profile_kernels(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter,
@@ -527,7 +573,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": (f"sw_shaped synthetic (SURVEY 8d): n=m={n}, n_state=18, n_lead=12, k={k}, p={p}, "
-                             f"T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[2])") if args.workload == "sw_shaped"
+                             f"T_len={T_len}, {per_gpu} draws per GPU " +
+                             ("(BASELINE configs[2])" if world == 1 else
+                              f"x {world} GPUs = {global_batch} draws (BASELINE configs[3]: 65 536 draws sharded over 8 GPUs, "
+                              f"8192 per GPU)")) if args.workload == "sw_shaped"
                 else (f"full_nk golden system with seeded 1e-3 relative perturbations (SURVEY 8d sanity configuration): n={n}, "
                       f"k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU") if args.workload == "full_nk"
                 else f"rbc_linearized closed form: n={n}, k={k}, p={p}, T_len={T_len}, {per_gpu} draws per GPU (BASELINE configs[1])",
@@ -546,6 +595,7 @@ def main():
             "roofline": roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_eval, hints, u_dim, h_defl,
                                        stats),
             "failed_draws": n_fail,
+            **extras,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -554,6 +604,180 @@ def main():
             out["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel.max()),
                              "median_rel_logp_err_vs_cpu_oracle": float(np.median(rel)),
                              "n_above_1e-12": int((rel > 1e-12).sum()), "n_checked": ns}
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _cpu_worker_so(args):
+    from oracle import second_order as so
+
+    A, B, C, D, idx, val, q, Z, y, Hd = args
+    return so.solve_second_order_logp(A, B, C, D, idx, val, np.diag(q), Z, y, H=np.diag(Hd), tol=1e-8)["logp"]
+
+
+def main_second_order(args, world, rank, local_rank):
+    """BASELINE configs[4]: second-order perturbation (generalised Sylvester) + pruned-state-space Kalman filter on the
+    SW-shaped systems, 1024 draws per GPU.  One step = first-order solve -> second-order coefficients -> pruned system ->
+    stationary covariance -> 207-dimensional filter, inputs (A, B, C, D, Hessian values) resident in HBM."""
+    import ctypes
+    import multiprocessing as mp
+
+    from geconpy_amd import workloads as wl
+
+    per_gpu = args.batch_per_gpu if args.batch_per_gpu else 1024
+    global_batch = per_gpu * world
+    lo, hi = wl.shard_bounds(global_batch, world, rank)
+    nloc = hi - lo
+    sh = wl.SW_SHAPE
+    n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
+    shard = wl.sw_second_order_batch(nloc, first_draw=lo)
+    om = wl.sw_shaped_observation_model()
+    cpu = None
+    cpu_logp = None
+    if rank == 0 and args.cpu_sample > 0:
+        try:
+            import psutil
+
+            cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+        except ImportError:
+            cores = os.cpu_count() or 1
+        os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+        n_sample = min(max(16, 2 * cores), nloc)  # ~3 s of CPU work per draw
+        jobs = [(shard["A"][i], shard["B"][i], shard["C"][i], shard["D"][i], shard["hess_idx"], shard["hess_val"][i],
+                 shard["sigma"][i] ** 2, om["Z"], om["y"], om["Hdiag"]) for i in range(n_sample)]
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_cpu_worker_so, jobs[: min(cores, n_sample)])
+            t0 = time.perf_counter()
+            cpu_logp = np.array(pool.map(_cpu_worker_so, jobs, chunksize=1))
+            cpu_dt = time.perf_counter() - t0
+        cpu = {"value": round(n_sample / cpu_dt, 3), "unit": "evals/s", "cores": cores, "kind": "port",
+               "sample": f"first {n_sample} draws of the same batch, numpy/scipy oracle (oracle/second_order.py: cycle reduction, "
+                         f"Sylvester by a Schur back-substitution, 207-dimensional Joseph-form filter), {cores} worker processes x 1 "
+                         f"BLAS thread, {cpu_dt:.1f} s wall"}
+
+    import torch
+    import torch.distributed as dist
+
+    from geconpy_amd import _lib
+    from geconpy_amd.engine import LogpEngine, ShardedLogpEvaluator
+
+    n_dev = torch.cuda.device_count()
+    shared = world > 1 and n_dev < world
+    if shared and not args.allow_shared_gpu:
+        print(f"bench.py: rank {rank}: {world} ranks but {n_dev} device(s)", file=sys.stderr)
+        sys.exit(2)
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        dist.init_process_group("gloo") if shared else dist.init_process_group("nccl", device_id=device)
+    eng = LogpEngine(device)
+    dA, dB, dC, dD = (eng.to_device(shard[x]) for x in "ABCD")
+    dq = eng.to_device(shard["sigma"] ** 2)
+    dhv = eng.to_device(shard["hess_val"])
+    dhi = torch.as_tensor(shard["hess_idx"], dtype=torch.int32, device=device).contiguous()
+    dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
+    structure = eng.second_order_structure(dA, dC, dZ)
+    S, Lc, U = structure
+    s, u = len(S), len(U)
+    m = 2 * u + s * (s + 1) // 2
+    logp_buf = torch.empty(nloc, dtype=torch.float64, device=device)
+    stat_buf = torch.empty(nloc, dtype=torch.int32, device=device)
+
+    def local_eval(lo_, hi_, stage_ms=None, options=None):
+        return eng.second_order_logp(dA, dB, dC, dD, dhi, dhv, dq, dZ, dy, structure, Hdiag=dH, tol=args.tol,
+                                     max_iter=args.max_iter, logp=logp_buf, status=stat_buf, stage_ms=stage_ms, options=options)
+
+    ev = ShardedLogpEvaluator(global_batch, local_eval, device)
+    for _ in range(args.warmup):
+        ev.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logp_all, stat_all = ev.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    logp_host = logp_all.cpu().numpy()
+    n_fail = int((stat_all != 0).sum().item())
+    # stage durations (HIP events on the launch stream inside the library) and the number of full filter steps per draw
+    ms = (ctypes.c_float * 4)()
+    at = torch.full((nloc,), -1, dtype=torch.int32, device=device)
+    eng.record_steady_steps(at)
+    local_eval(0, nloc, stage_ms=ms)
+    torch.cuda.synchronize()
+    eng.record_steady_steps(None)
+    at_h = at.cpu().numpy()
+    n_full = np.where(at_h < 0, T_len, at_h).astype(np.float64)
+    full = None
+    if world == 1 and not args.no_extras:
+        ms_f = (ctypes.c_float * 4)()
+        lp_h = logp_buf.clone()
+        local_eval(0, nloc, stage_ms=ms_f, options={"kalman_steady_tol": 0.0})
+        torch.cuda.synchronize()
+        full = {"value": round(nloc / (sum(ms_f) * 1e-3), 2), "ms_per_step": round(float(sum(ms_f)), 3), "unit": "evals/s",
+                "note": "kalman_steady_tol = 0: all T_len steps update the covariance",
+                "max_rel_logp_diff_vs_headline": float((torch.abs(logp_buf - lp_h) / torch.abs(lp_h)).max().item())}
+        local_eval(0, nloc)
+        torch.cuda.synchronize()
+    if rank == 0:
+        mp16 = 16 * ((m + 15) // 16)
+        kq = k + s * k + k * (k + 1) // 2
+        gemm_useful = 2.0 * m ** 3  # one product of the prediction step (unpadded)
+        flops_filter = float(n_full.sum()) * 2 * gemm_useful
+        filt_s = ms[3] * 1e-3
+        value = global_batch * args.steps / dt
+        out = {
+            "metric": "second-order solve + pruned-state-space Kalman-logp evals/sec, Smets-Wouters-shaped n=40 T=200",
+            "value": round(value, 2), "unit": "evals/s", "n_gpus": world,
+            **({"shared_device": f"{world} ranks on {n_dev} device(s), gloo gather: functional check, not a measurement"} if shared else {}),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": (f"sw_second_order (BASELINE configs[4]): SW-shaped systems n={n}, n_state={s}, n_lead={len(Lc)}, k={k}, p={p}, "
+                             f"T_len={T_len}, synthetic sparse model Hessian ({shard['hess_idx'].shape[0]} entries), pruned state "
+                             f"2u + s(s+1)/2 = {m}; {per_gpu} draws per GPU"),
+                "global_batch": global_batch, "solver": "cycle_reduction", "tol": args.tol,
+                "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
+                "inputs": "A,B,C,D and the Hessian values resident in HBM",
+                "parity_note": "the reference has no second-order solver (perturbation.py:97-98 raises): checked against "
+                               "oracle/second_order.py, parity unpinned by construction",
+                "parallelism": f"draw-sharded x{world}, one all_gather of packed (logp,status) records" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": f"dsge::so_filter_kernel<{mp16 // 16}> (512 threads per draw; v_mfma_f64_16x16x4_f64 on {mp16 // 16} x {mp16 // 16} tiles)",
+                "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                "achieved": round(flops_filter / filt_s / 1e12, 3),
+                "frac": round(flops_filter / filt_s / 1e12 / FP64_PEAK_TFLOPS, 5),
+                "flops_source": f"2 products x 2 m^3 (m = {m}, unpadded) per full filter step x the measured number of full steps per "
+                                f"draw (mean {n_full.mean():.1f} of {T_len}); duration: HIP events around the kernel in this run",
+                "traffic": None,
+                "stage_ms": {"first_order_solver": round(ms[0], 3), "second_order_setup": round(ms[1], 3),
+                             "stationary_covariance": round(ms[2], 3), "filter": round(ms[3], 3)},
+                "full_steps_mean": float(n_full.mean()), "never_steady": int((at_h < 0).sum()),
+                "qz_product_K": kq,
+            },
+            "failed_draws": n_fail,
+        }
+        if full is not None:
+            out["full_recursion"] = full
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            ns = len(cpu_logp)
+            rel = np.abs(logp_host[:ns] - cpu_logp) / np.abs(cpu_logp)
+            out["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel.max()), "median_rel_logp_err_vs_cpu_oracle": float(np.median(rel)),
+                             "n_checked": ns}
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:

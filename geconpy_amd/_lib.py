@@ -87,6 +87,7 @@ PROTOTYPES = {
     "dsge_policy_adjoints_batched": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_policy_adjoints_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp],
     "dsge_debug_adjoint_refine": [_i],
+    "dsge_debug_second_order_phases": [_i, _dp],
     "dsge_selection_adjoints_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp],
     "dsge_selection_adjoints_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp],
     "dsge_policy_norms_batched": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],

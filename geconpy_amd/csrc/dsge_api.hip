@@ -257,6 +257,23 @@ int dsge_debug_cr_phases(int enable, long long* cycles_out) {
   }
   return DSGE_SUCCESS;
 }
+int dsge_debug_second_order_phases(int enable, long long* cycles_out) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (enable && !g_so_dbg) {
+    HIP_TRY(hipMalloc((void**)&g_so_dbg, 8 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_so_dbg, 0, 8 * sizeof(long long)));
+  }
+  if (cycles_out && g_so_dbg) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_out, g_so_dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && g_so_dbg) {
+    (void)hipFree(g_so_dbg);
+    g_so_dbg = nullptr;
+  }
+  return DSGE_SUCCESS;
+}
 int dsge_debug_adjoint_refine(int mode) {
   if (mode < 0 || mode > 2) return fail(DSGE_ERR_INVALID, "mode out of range (0..2)");
   g_adj_refine_mode = mode;
@@ -782,7 +799,8 @@ int dsge_second_order_logp_batched(const double* A, const double* B, const doubl
   if (stage_ms) HIP_TRY(hipEventRecord(e1, st));
   rc = launch_second_order(B, C, Tw, Rw, hess_idx, nnz, hess_val, q, q_batched, Z, d, Hdiag, y, batch, n, k, p, T_len, jitter,
                            missing_fill, state_idx, n_state, lead_idx, n_lead, ret_idx, n_ret, logp_out, status_out, gyy_out,
-                           gyu_out, guu_out, gss_out, nullptr, nullptr, st, stage_ms ? stage_ms + 1 : nullptr);
+                           gyu_out, guu_out, gss_out, g_kalman_steady_at, nullptr, st, stage_ms ? stage_ms + 1 : nullptr,
+                           solver == DSGE_SOLVER_CYCLE_REDUCTION ? it_w : nullptr);
   if (rc) return rc;
   if (stage_ms) {
     HIP_TRY(hipStreamSynchronize(st));

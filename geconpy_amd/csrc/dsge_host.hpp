@@ -118,9 +118,10 @@ int launch_second_order(const double* B, const double* C, const double* T, const
                         const double* Hdiag, const double* y, int batch, int n, int k, int p, int T_len, double jitter,
                         double missing_fill, const int32_t* S, int s, const int32_t* L, int l, const int32_t* U, int u,
                         double* logp, int32_t* status_io, double* gyy_out, double* gyu_out, double* guu_out, double* gss_out,
-                        int32_t* steady_at, int32_t* n_doublings, hipStream_t st, float* ms);
+                        int32_t* steady_at, int32_t* n_doublings, hipStream_t st, float* ms, const int32_t* order_key = nullptr);
 
 extern int g_adj_refine_mode;          // launch_assemble.hip: 0 = residual rule, 1 = refine every draw, 2 = never (debug)
+extern long long* g_so_dbg;            // launch_second_order.hip: debug phase counters of the second-order filter kernel
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
 extern long long* g_kalman_dbg;       // launch_kalman.hip: debug buffer for per-phase cycles of draw 0
 extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[32])

@@ -36,7 +36,7 @@ constexpr int32_t DSGE_ST_SO_UNSUPPORTED = 128;  // (mirrors DSGE_ST_SECOND_ORDE
 // Per-draw workspace (doubles).  Everything the three kernels hand to each other.
 struct SoLayout {
   int n, k, s, u, l, p, q, m, MP, KQ, KQP;
-  size_t gyy, gyu, guu, gss, x0, azt, az, cvec, a0, lt, yt, qz, p0, wt, xb, ak, akt, ak2, akt2, pp, total;
+  size_t gyy, gyu, guu, gss, x0, azt, az, cvec, a0, lt, yt, qz, p0, wt, xb, ak, akt, ak2, akt2, pp, qzj, total;
   __host__ __device__ static int pad8(int x) { return (x + 7) & ~7; }
   // mt: tiles of 16 per side of the kernel instance that will run (>= ceil(m / 16))
   __host__ __device__ void init(int n_, int k_, int s_, int u_, int l_, int p_, int mt) {
@@ -69,6 +69,7 @@ struct SoLayout {
     ak2 = take(mm);
     akt2 = take(mm);
     pp = take(mm);
+    qzj = take(mm);   // Qz + jitter Az Az'
     total = o;
   }
 };
@@ -770,8 +771,11 @@ struct SoFilterArgs {
   const double* y;          // [T_len][p]
   double* logp;             // [batch]
   int32_t* status;          // [batch] in/out
+  const int32_t* order;     // [batch] or nullptr: workgroup b filters draw order[b] (slow draws first, kalman_order_kernel)
   int32_t* steady_at;       // [batch] or nullptr (debug: first steady step)
   int32_t* n_doublings;     // [batch] or nullptr (debug)
+  long long* phases;        // device int64[8] or nullptr (debug): shader cycles draw 0 spends in [0] P Z', F, gain; [1] the pass
+                            // over Az'; [2] first product; [3] second product; [4] steady steps; [5] full steps; [6] steady steps (count); [7] total
   int batch, T_len;
   double jitter, missing_fill, steady_tol;
 };
@@ -780,7 +784,8 @@ template <int MT>
 struct SoFilterSmem {
   static constexpr int MP = 16 * MT;
   // GEMM staging + vectors: a, ap (MP each), K, PZ (MP x 8 each), F, Lc (64 each), v, w, dvec, hvec (8 each), reductions
-  static constexpr size_t doubles = SoGemmCfg<MT>::LDS_DOUBLES + 2 * MP + 2 * MP * 8 + 2 * 64 + 4 * 8 + 64;
+  // ... + Az K, Az V (MP x 8 each) and the partial sums of the mean prediction (2 MP)
+  static constexpr size_t doubles = SoGemmCfg<MT>::LDS_DOUBLES + 2 * MP + 4 * MP * 8 + 2 * MP + 2 * 64 + 4 * 8 + 64;
   static constexpr size_t bytes = doubles * sizeof(double);
 };
 
@@ -823,7 +828,10 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
   double* Ak2 = wk + lay.ak2;
   double* AkT2 = wk + lay.akt2;
   // Qz = sym(Y' L)
-  so_gemm<MT>(wk + lay.yt, MP, wk + lay.lt, MP, lay.KQP, lds, [&](int r, int c, double v) { Xb[(size_t)r * MP + c] = v; });
+  so_gemm<MT>(wk + lay.yt, MP, wk + lay.lt, MP, lay.KQP, lds, [&](int r, int c, so_v4f64 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Xb[(size_t)(r + 4 * e) * MP + c] = v[e];
+  });
   __syncthreads();
   for (int idx = tid; idx < MP * MP; idx += NT) {
     const int i = idx / MP, j = idx - i * MP;
@@ -834,14 +842,25 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
     AkT[idx] = wk[lay.azt + idx];
   }
   bool conv = false;
-  int it = 0;
-  for (; it < 48 && !conv; ++it) {
-    // W = A_k P (stored transposed),  X = W A_k',  A_{k+1} = A_k A_k (both layouts)
-    so_gemm<MT>(AkT, MP, P, MP, MP, lds, [&](int r, int c, double v) { Wt[(size_t)c * MP + r] = v; });
-    so_gemm<MT>(Wt, MP, AkT, MP, MP, lds, [&](int r, int c, double v) { Xb[(size_t)r * MP + c] = v; });
-    so_gemm<MT>(AkT, MP, Ak, MP, MP, lds, [&](int r, int c, double v) {
-      Ak2[(size_t)r * MP + c] = v;
-      AkT2[(size_t)c * MP + r] = v;
+  int it = 0, extra = 0;
+  // (one more doubling after the increment has dropped below 1e-17 max |P|: the blocks of P differ by orders of magnitude and
+  // the test only sees the largest; the error of the doubling squares with every step)
+  for (; it < 48 && extra < 2; ++it) {
+    // W' = P A_k' (= (A_k P)': P is symmetric; natural stores),  X = W A_k',  A_{k+1} = A_k A_k (both layouts)
+    so_gemm<MT>(P, MP, AkT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {  // (P symmetric: P A_k' = (A_k P)', natural stores)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Wt[(size_t)(r + 4 * e) * MP + c] = v[e];
+    });
+    so_gemm<MT>(Wt, MP, AkT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Xb[(size_t)(r + 4 * e) * MP + c] = v[e];
+    });
+    so_gemm<MT>(AkT, MP, Ak, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Ak2[(size_t)(r + 4 * e) * MP + c] = v[e];
+        AkT2[(size_t)c * MP + r + 4 * e] = v[e];
+      }
     });
     __syncthreads();
     double dmax, pmax;
@@ -849,12 +868,47 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
     double* t = Ak; Ak = Ak2; Ak2 = t;
     t = AkT; AkT = AkT2; AkT2 = t;
     if (!(dmax == dmax) || !(pmax < 1e300)) break;
-    conv = dmax <= 1e-17 * pmax;
+    conv = conv || dmax <= 1e-17 * pmax;
+    extra += conv ? 1 : 0;
+  }
+  // Qz + jitter Az Az' for the filter's prediction step (the jitter of P+ = ... + jitter I, carried through Az . Az')
+  {
+    const double* AzT = wk + lay.azt;
+    double* Qzj = wk + lay.qzj;
+    const double jit = a.jitter;
+    so_gemm<MT>(AzT, MP, AzT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Qzj[(size_t)(r + 4 * e) * MP + c] = fma(jit, v[e], Qz[(size_t)(r + 4 * e) * MP + c]);
+    });
   }
   if (tid == 0) {
     if (!conv) a.status[draw] |= DSGE_ST_LYAP_FAIL;
     if (a.n_doublings) a.n_doublings[draw] = it;
   }
+}
+
+// a = Az a+ + c by all the threads: two halves of the sum over k per output, eight loads of Az' in flight per thread
+template <int NT>
+__device__ __forceinline__ void so_mean_predict(const double* __restrict__ AzT, const double* ap, const double* __restrict__ cvec,
+                                                double* av, double* part, int MP, int m) {
+  const int tid = threadIdx.x, half = tid >= NT / 2 ? 1 : 0, i = tid - half * (NT / 2);
+  const int kh = (m + 1) / 2, k0 = half * kh, k1 = half ? m : kh;
+  if (i < m) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int kx = k0;
+    for (; kx + 8 <= k1; kx += 8) {
+      double z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = AzT[(size_t)(kx + e) * MP + i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e & 3] = fma(z[e], ap[kx + e], acc[e & 3]);
+    }
+    for (; kx < k1; ++kx) acc[0] = fma(AzT[(size_t)kx * MP + i], ap[kx], acc[0]);
+    part[half * MP + i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+  __syncthreads();
+  if (tid < m) av[tid] = cvec[tid] + part[tid] + part[MP + tid];
+  __syncthreads();
 }
 
 // =============================================================================================================================
@@ -870,8 +924,11 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   double* pl = smem + SoGemmCfg<MT>::LDS_DOUBLES;
   double* av = pl; pl += MP;        // predicted mean
   double* ap = pl; pl += MP;        // filtered mean
-  double* Kg = pl; pl += MP * PM;   // gain [m][PM]
-  double* PZ = pl; pl += MP * PM;   // P Z' [m][PM]
+  double* Kg = pl; pl += MP * PM;   // gain, o-major: Kg[o MP + i] = K[i][o] (the operand transform below reads two adjacent i at once)
+  double* PZ = pl; pl += MP * PM;   // P Z', then V = P Z' + jitter K, same layout
+  double* AK = pl; pl += MP * PM;   // Az K and Az V of the current full step, o-major like Kg
+  double* AV = pl; pl += MP * PM;
+  double* part = pl; pl += 2 * MP;  // partial sums of the mean prediction
   double* Fm = pl; pl += 64;        // F, then its Cholesky factor (lower)
   double* Lc = pl; pl += 64;
   double* vv = pl; pl += 8;         // innovation
@@ -880,8 +937,11 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   double* hv = pl; pl += 8;
   double* red = pl; pl += 32;
   int* imask = (int*)pl;            // [0] = current mask, [1] = steady flag, [2] = finite flag
-  const int tid = threadIdx.x, draw = blockIdx.x;
-  if (draw >= a.batch) return;
+  // The launch's makespan is set by the draws whose covariance recursion reaches its fixed point late (up to T_len full
+  // steps against ~60 on average): like the first-order filter, the workgroups take the draws in the caller's order
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.batch) return;
+  const int draw = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   if (a.status[draw] != 0) {
     if (tid == 0) a.logp[draw] = -INFINITY;
     return;
@@ -889,25 +949,31 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   double* wk = a.work + (size_t)draw * lay.total;
   const int m = lay.m, u = lay.u, p = lay.p;
   const double* AzT = wk + lay.azt;
-  const double* Qz = wk + lay.qz;
+  const double* Qzj = wk + lay.qzj;
   const double* cvec = wk + lay.cvec;
-  double* P = wk + lay.p0;
-  double* Pp = wk + lay.pp;
+  double* Pc = wk + lay.p0;  // current predicted covariance
+  double* Pn = wk + lay.pp;  // the other buffer: written by the prediction, then swapped
   double* Wt = wk + lay.wt;
-  double* Xb = wk + lay.xb;
   const double* Zu = a.Zu;
   for (int i = tid; i < MP; i += NT) av[i] = wk[lay.a0 + i];
   if (tid < 8) {
     dv[tid] = (a.d && tid < p) ? a.d[tid] : 0.0;
     hv[tid] = (a.Hdiag && tid < p) ? a.Hdiag[tid] : 0.0;
   }
-  for (size_t idx = tid; idx < (size_t)MP * MP; idx += NT) Pp[idx] = 0.0;  // (padding of P+ stays zero)
+  for (int idx = tid; idx < MP * PM; idx += NT) {  // (rows beyond m stay zero: the padding of P+ is the padding of P)
+    Kg[idx] = 0.0;
+    PZ[idx] = 0.0;
+  }
   __syncthreads();
   const double LN2PI = 1.8378770664093453;
   double ll_sum = 0.0, logdet = 0.0;  // (thread 0)
   bool steady = false, finite = true;
   int steady_mask = -1, steady_at = -1;
+  const bool stamp = a.phases != nullptr && draw == 0 && tid == 0;
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = stamp ? clock64() : 0;
   for (int t = 0; t < a.T_len; ++t) {
+    long long tk = stamp ? clock64() : 0;
     // ---- missing-data mask of this step (bit o set = observed) -----------------------------------------------------------
     if (tid == 0) {
       int mk = 0;
@@ -932,21 +998,36 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     __syncthreads();  // (the innovation is read by every wavefront below, also on the steady path)
     if (!steady) {
       // ---- P Z' (m x p), F = Zm P Zm' + Hm + jitter I ---------------------------------------------------------------------
-      for (int idx = tid; idx < m * p; idx += NT) {
-        const int i = idx / p, o = idx - i * p;
-        double acc = 0.0;
-        if ((mask >> o) & 1) {
-          const double* pr = P + (size_t)i * MP;
-          for (int c = 0; c < u; ++c) acc = fma(pr[c] + pr[u + c], Zu[o * u + c], acc);
+      for (int i = tid; i < m; i += NT) {  // (P is symmetric: column i is read as row entries P[c][i], coalesced over i)
+        double acc[PM];
+#pragma unroll
+        for (int o = 0; o < PM; ++o) acc[o] = 0.0;
+        for (int c0 = 0; c0 < u; c0 += 8) {  // (sixteen loads in flight)
+          double pv[16];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e < u ? c0 + e : u - 1;
+            pv[e] = Pc[(size_t)c * MP + i];
+            pv[8 + e] = Pc[(size_t)(u + c) * MP + i];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const double pc = (c0 + e < u) ? pv[e] + pv[8 + e] : 0.0;
+            const int c = c0 + e < u ? c0 + e : u - 1;
+#pragma unroll
+            for (int o = 0; o < PM; ++o)
+              if (o < p) acc[o] = fma(pc, Zu[o * u + c], acc[o]);
+          }
         }
-        PZ[i * PM + o] = acc;
+#pragma unroll
+        for (int o = 0; o < PM; ++o) PZ[o * MP + i] = (o < p && ((mask >> o) & 1)) ? acc[o] : 0.0;
       }
       __syncthreads();
       if (tid < p * p) {
         const int o = tid / p, o2 = tid - o * p;
         double acc = 0.0;
         if ((mask >> o) & 1)
-          for (int c = 0; c < u; ++c) acc = fma(Zu[o * u + c], PZ[c * PM + o2] + PZ[(u + c) * PM + o2], acc);
+          for (int c = 0; c < u; ++c) acc = fma(Zu[o * u + c], PZ[o2 * MP + c] + PZ[o2 * MP + u + c], acc);
         if (o == o2) acc += (((mask >> o) & 1) ? hv[o] : 0.0) + a.jitter;
         Fm[o * 8 + o2] = acc;
       }
@@ -977,7 +1058,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       for (int i = tid; i < m; i += NT) {
         double x[PM];
 #pragma unroll
-        for (int o = 0; o < PM; ++o) x[o] = (o < p) ? PZ[i * PM + o] : 0.0;
+        for (int o = 0; o < PM; ++o) x[o] = (o < p) ? PZ[o * MP + i] : 0.0;
         for (int o = 0; o < p; ++o) {  // Lc z = pz
           double sv = x[o];
           for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
@@ -989,7 +1070,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
           x[o] = sv / Lc[o * 8 + o];
         }
 #pragma unroll
-        for (int o = 0; o < PM; ++o) Kg[i * PM + o] = x[o];
+        for (int o = 0; o < PM; ++o) Kg[o * MP + i] = x[o];
       }
       __syncthreads();
     }
@@ -1008,45 +1089,133 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     }
     for (int i = tid; i < m; i += NT) {
       double acc = av[i];
-      for (int o = 0; o < p; ++o) acc = fma(Kg[i * PM + o], vv[o], acc);
+      for (int o = 0; o < p; ++o) acc = fma(Kg[o * MP + i], vv[o], acc);
       ap[i] = acc;
     }
     __syncthreads();
-    // ---- predicted mean a = Az a+ + c --------------------------------------------------------------------------------------
-    for (int i = tid; i < m; i += NT) {
-      double acc0 = cvec[i], acc1 = 0.0;
-      int kx = 0;
-      for (; kx + 1 < m; kx += 2) {
-        acc0 = fma(AzT[(size_t)kx * MP + i], ap[kx], acc0);
-        acc1 = fma(AzT[(size_t)(kx + 1) * MP + i], ap[kx + 1], acc1);
-      }
-      if (kx < m) acc0 = fma(AzT[(size_t)kx * MP + i], ap[kx], acc0);
-      av[i] = acc0 + acc1;
-    }
+    // ---- predicted mean a = Az a+ + c ----------------------------------------------------------------------------------------
+    so_mean_predict<NT>(AzT, ap, cvec, av, part, MP, m);
     if (steady) {
-      __syncthreads();
+      if (stamp) {
+        ph[4] += clock64() - tk;
+        ph[6] += 1;
+      }
       continue;
     }
-    // ---- P+ = P - sym(K (P Z' + jitter K)') + jitter I --------------------------------------------------------------------
-    for (int idx = tid; idx < m * m; idx += NT) {
-      const int i = idx / m, j = idx - i * m;
-      double acc = 0.0;
+    if (stamp) {
+      const long long tn = clock64();
+      ph[0] += tn - tk;
+      tk = tn;
+    }
+    // ---- P = Az P+ Az' + Qz, P+ = P - 1/2 (K V' + V K') + jitter I with V = P Z' + jitter K.  P+ is never formed:
+    //        Az P+ Az' = Az P Az' - 1/2 (AK AV' + AV AK') + jitter Az Az',   AK = Az K,  AV = Az V,
+    // so the two products on the matrix core are the plain W' = P Az' (P symmetric: natural stores) and X = W Az'; AK and AV
+    // need no pass over Az either: Az P Z' is a combination of 2u rows of W', AK = (Az P Z') F^-1, AV = Az P Z' + jitter AK;
+    // the rank-2p term, Qz + jitter Az Az' (a constant, from so_lyap_kernel) and the steady-state test sit in the second
+    // product's epilogue, which writes the other P buffer.
+    so_gemm<MT>(Pc, MP, AzT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Wt[(size_t)(r + 4 * e) * MP + c] = v[e];
+    });
+    __syncthreads();
+    if (stamp) {
+      const long long tn = clock64();
+      ph[2] += tn - tk;
+      tk = tn;
+    }
+    for (int i = tid; i < MP; i += NT) {
+      double x[PM];
+#pragma unroll
+      for (int o = 0; o < PM; ++o) x[o] = 0.0;
+      if (i < m) {
+        for (int c0 = 0; c0 < u; c0 += 8) {
+          double wv[16];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e < u ? c0 + e : u - 1;
+            wv[e] = Wt[(size_t)c * MP + i];
+            wv[8 + e] = Wt[(size_t)(u + c) * MP + i];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const double wc = (c0 + e < u) ? wv[e] + wv[8 + e] : 0.0;
+            const int c = c0 + e < u ? c0 + e : u - 1;
+#pragma unroll
+            for (int o = 0; o < PM; ++o)
+              if (o < p) x[o] = fma(wc, Zu[o * u + c], x[o]);
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < PM; ++o) x[o] = (o < p && ((mask >> o) & 1)) ? x[o] : 0.0;
+      }
+      double apz[PM];
+#pragma unroll
+      for (int o = 0; o < PM; ++o) apz[o] = x[o];
+      for (int o = 0; o < p; ++o) {  // (Az P Z') F^-1 row by row: Lc z = ., Lc' k = z
+        double sv = x[o];
+        for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
+        x[o] = sv / Lc[o * 8 + o];
+      }
+      for (int o = p - 1; o >= 0; --o) {
+        double sv = x[o];
+        for (int r = o + 1; r < p; ++r) sv -= Lc[r * 8 + o] * x[r];
+        x[o] = sv / Lc[o * 8 + o];
+      }
 #pragma unroll
       for (int o = 0; o < PM; ++o) {
-        const double ki = Kg[i * PM + o], kj = Kg[j * PM + o];
-        acc = fma(ki, fma(a.jitter, kj, PZ[j * PM + o]), acc);
-        acc = fma(kj, fma(a.jitter, ki, PZ[i * PM + o]), acc);
+        AK[o * MP + i] = x[o];
+        AV[o * MP + i] = fma(a.jitter, x[o], apz[o]);
       }
-      Pp[(size_t)i * MP + j] = P[(size_t)i * MP + j] - 0.5 * acc + (i == j ? a.jitter : 0.0);
     }
-    // ---- P = sym(Az P+ Az') + Qz: two products on the matrix core -------------------------------------------------------------
-    so_gemm<MT>(AzT, MP, Pp, MP, MP, lds, [&](int r, int c, double v) { Wt[(size_t)c * MP + r] = v; });
-    so_gemm<MT>(Wt, MP, AzT, MP, MP, lds, [&](int r, int c, double v) { Xb[(size_t)r * MP + c] = v; });
     __syncthreads();
-    double dmax, pmax;
-    so_sym_update<NT, false>(P, Xb, Qz, MP, m, red, dmax, pmax);
-    if (!(pmax < 1e300)) finite = false;  // (uniform; thread 0 keeps the flag that matters)
-    if (a.steady_tol > 0.0 && dmax <= a.steady_tol * pmax) {
+    if (stamp) {
+      const long long tn = clock64();
+      ph[1] += tn - tk;
+      tk = tn;
+    }
+    so_gemm<MT>(Wt, MP, AzT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Pn[(size_t)(r + 4 * e) * MP + c] = v[e];
+    });
+    for (int i = tid; i < MP; i += NT) part[i] = (i < m) ? Pc[(size_t)i * MP + i] : 1.0;  // diagonal of the previous P
+    __syncthreads();
+    // fix-up pass (coalesced, two entries per thread and trip): P_new = X + Qz + jitter Az Az' - 1/2 (AK AV' + AV AK'), and the
+    // steady-state test, scale-free: (dP_ij)^2 <= tol^2 P_ii P_jj for every entry -- the blocks of the pruned state differ by
+    // orders of magnitude (x_f ~ 1e-4, the products ~ 1e-8), a test against max |P| would only see the largest block (and a
+    // component without second-order dynamics has variance exactly 0 in P0: no division)
+    double dm = 0.0, pm = 0.0;
+    const double tol2 = a.steady_tol * a.steady_tol;
+    for (int idx = tid; idx < MP * MP / 2; idx += NT) {
+      const int i = idx / (MP / 2), j = 2 * (idx - i * (MP / 2));
+      double2 x = ((const double2*)Pn)[idx];
+      const double2 qz = ((const double2*)Qzj)[idx], po = ((const double2*)Pc)[idx];
+      double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+      for (int o = 0; o < PM; ++o) {
+        const double aki = AK[o * MP + i], avi = AV[o * MP + i];
+        const double2 akj = *(const double2*)(AK + o * MP + j), avj = *(const double2*)(AV + o * MP + j);
+        c0 = fma(aki, avj.x, fma(avi, akj.x, c0));
+        c1 = fma(aki, avj.y, fma(avi, akj.y, c1));
+      }
+      x.x = fma(-0.5, c0, x.x) + qz.x;
+      x.y = fma(-0.5, c1, x.y) + qz.y;
+      ((double2*)Pn)[idx] = x;
+      const double di = part[i], d0 = x.x - po.x, d1 = x.y - po.y;
+      dm = fmax(dm, (d0 * d0 > tol2 * di * part[j] || d1 * d1 > tol2 * di * part[j + 1]) ? 1.0 : 0.0);  // 1 = still moving
+      pm = nanmax(pm, nanmax(fabs(x.x), fabs(x.y)));
+    }
+    {
+      double* t = Pc;
+      Pc = Pn;
+      Pn = t;
+    }
+    if (stamp) {
+      ph[3] += clock64() - tk;
+      ph[5] += 1;
+    }
+    const double dmax = so_wg_max<NT>(dm, red), pmax = so_wg_max<NT>(pm, red);
+    if (!(pmax < 1e300)) finite = false;  // (uniform; thread 0 keeps the flag that matters; NaN / overflow of P ends here)
+    if (a.steady_tol > 0.0 && dmax == 0.0 && pmax < 1e300) {
       steady = true;
       steady_mask = mask;
       if (steady_at < 0) steady_at = t + 1;
@@ -1057,6 +1226,10 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     a.logp[draw] = okf ? ll_sum : -INFINITY;
     if (!okf) a.status[draw] |= DSGE_ST_FILTER_NONFINITE;
     if (a.steady_at) a.steady_at[draw] = steady_at;
+    if (stamp) {
+      ph[7] = clock64() - t_begin;
+      for (int e = 0; e < 8; ++e) a.phases[e] = ph[e];
+    }
   }
 }
 

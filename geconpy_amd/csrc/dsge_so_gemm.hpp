@@ -27,61 +27,63 @@ constexpr int SO_THREADS = 512;
 template <int MT>
 struct SoGemmCfg {
   static constexpr int MP = 16 * MT;                         // padded matrix dimension
-  static constexpr int LDSROW = MP + ((MT & 1) ? 0 : 16);    // == 16 (mod 32)
+  static constexpr int LDSROW = MP;                          // linear image of the chunk (direct-to-LDS loads write lane-linear);
+                                                             // == 16 (mod 32) for odd MT, two-way conflicts on the small even ones
   static constexpr int KC = 8;                               // rows of Aop / Bop per stage
   static constexpr int RB = (MT + 1) / 2;                    // tiles per block side (the larger block)
   static constexpr int NT0 = (RB * RB + 1) / 2;              // tiles of a block the first wavefront of the pair takes
   static constexpr int STAGE = 2 * KC * LDSROW;              // doubles per stage: [A chunk | B chunk]
   static constexpr int LDS_DOUBLES = 2 * STAGE + 32;         // two stages + slack for the (discarded) out-of-range tile reads
-  static constexpr int UNITS = KC * MP / 2;                  // double2 units per operand chunk
-  static constexpr int NLD = (UNITS + SO_THREADS - 1) / SO_THREADS;  // loads per thread and operand
+  static constexpr int PIECES = KC * MP * 8 / 1024;          // 1 KiB wave-instructions per operand chunk (KC MP 8 bytes = MT KiB)
+  static_assert(KC * MP * 8 % 1024 == 0, "operand chunk is a whole number of 1 KiB pieces");
 };
 
 // One wavefront's share of C = Aop' Bop: tiles [HALF NT0, ...) of block (rt0, ct0).  K a multiple of KC (rows beyond the
 // data must be zero).  lds: SoGemmCfg<MT>::LDS_DOUBLES doubles, 16-byte aligned.  All 512 threads run it; barriers inside.
-template <int MT, int HALF, class Epi>
+struct SoZeroInit {
+  __device__ __forceinline__ so_v4f64 operator()(int, int) const { return so_v4f64{0.0, 0.0, 0.0, 0.0}; }
+};
+
+// init(row0, col): the starting value of a tile fragment (C = init + Aop' Bop): an epilogue that needs a matrix from global
+// memory per element pays one memory latency per fragment -- 25 in a row per wavefront -- whereas the fragments' starting
+// values are all requested at once, before the first chunk is multiplied.
+template <int MT, int HALF, class Epi, class Init>
 __device__ __forceinline__ void so_gemm_half(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb,
-                                             int K, double* lds, int rt0, int nrt, int ct0, int nct, Epi epi) {
+                                             int K, double* lds, int rt0, int nrt, int ct0, int nct, Epi epi, Init init) {
   using Cfg = SoGemmCfg<MT>;
-  constexpr int MP = Cfg::MP, LDSROW = Cfg::LDSROW, KC = Cfg::KC, RB = Cfg::RB, STAGE = Cfg::STAGE, UNITS = Cfg::UNITS,
-                NLD = Cfg::NLD, T0 = HALF ? Cfg::NT0 : 0, NT = HALF ? RB * RB - Cfg::NT0 : Cfg::NT0;
+  constexpr int MP = Cfg::MP, LDSROW = Cfg::LDSROW, KC = Cfg::KC, RB = Cfg::RB, STAGE = Cfg::STAGE, PIECES = Cfg::PIECES,
+                T0 = HALF ? Cfg::NT0 : 0, NT = HALF ? RB * RB - Cfg::NT0 : Cfg::NT0;
   constexpr int I0 = T0 / RB, I1 = (T0 + NT - 1) / RB;  // block rows this half touches
   const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   so_v4f64 acc[NT > 0 ? NT : 1];  // (NT = 0: a one-tile block's second wavefront only helps with the staging)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = so_v4f64{0.0, 0.0, 0.0, 0.0};
-  double2 ra[NLD], rb[NLD];
-  auto load_regs = [&](int k0) {
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      int idx = tid + SO_THREADS * u;
-      idx = idx < UNITS ? idx : UNITS - 1;  // (clamped: unconditional loads)
-      const int r = idx / (MP / 2), c2 = idx - r * (MP / 2);
-      ra[u] = *(const double2*)(Aop + (size_t)(k0 + r) * lda + 2 * c2);
-      rb[u] = *(const double2*)(Bop + (size_t)(k0 + r) * ldb + 2 * c2);
-    }
-  };
-  auto store_lds = [&](int stage) {
-    double* sa = lds + stage * STAGE;
-    double* sb = sa + KC * LDSROW;
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int idx = tid + SO_THREADS * u;
-      if (idx < UNITS) {
-        const int r = idx / (MP / 2), c2 = idx - r * (MP / 2);
-        *(double2*)(sa + r * LDSROW + 2 * c2) = ra[u];
-        *(double2*)(sb + r * LDSROW + 2 * c2) = rb[u];
-      }
+  for (int t = 0; t < NT; ++t) {
+    const int i = (T0 + t) / RB, j = (T0 + t) % RB;
+    acc[t] = (i < nrt && j < nct) ? init(16 * (rt0 + i) + (lane >> 4), 16 * (ct0 + j) + (lane & 15)) : so_v4f64{0.0, 0.0, 0.0, 0.0};
+  }
+  // Staging: rows [k0, k0 + KC) of both operands straight into LDS (global_load_lds_dwordx4: 16 bytes per lane, 1 KiB per
+  // wave-instruction, destination = wave-uniform base + 16 lane; no staging registers -- with 200 accumulator registers per
+  // wavefront the register-staged version spilled its prefetch to scratch right behind the loads and exposed the whole memory
+  // latency in every chunk).  The operand rows are contiguous in memory (lda = ldb = MP), so a chunk is one linear image of
+  // 2 PIECES KiB; the eight wavefronts take the pieces round-robin.
+  auto stage_chunk = [&](int stage, int k0) {
+    const char* ga = (const char*)(Aop + (size_t)k0 * MP);
+    const char* gb = (const char*)(Bop + (size_t)k0 * MP);
+    char* ls = (char*)(lds + stage * STAGE);
+    for (int t = wave; t < 2 * PIECES; t += SO_THREADS / 64) {
+      const char* src = (t < PIECES ? ga + (size_t)t * 1024 : gb + (size_t)(t - PIECES) * 1024) + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(ls + (size_t)t * 1024), 16, 0, 0);
     }
   };
   const int nchunks = K / KC;
   const int foff = (lane >> 4) * LDSROW + (lane & 15);
   __syncthreads();  // (the previous user of the staging buffers is done; global results of the previous phase are visible)
-  load_regs(0);
-  store_lds(0);
-  __syncthreads();
+  stage_chunk(0, 0);
+  __syncthreads();  // (carries the vmcnt(0) that lands chunk 0)
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) load_regs((c + 1) * KC);
+    if (c + 1 < nchunks) stage_chunk((c + 1) & 1, (c + 1) * KC);  // in flight while chunk c is multiplied
     const double* sa = lds + (c & 1) * STAGE + foff;
     const double* sb = sa + KC * LDSROW;
 #pragma unroll
@@ -95,32 +97,29 @@ __device__ __forceinline__ void so_gemm_half(const double* __restrict__ Aop, int
       for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(T0 + t) / RB], b[(T0 + t) % RB], acc[t], 0, 0, 0);
     }
-    if (c + 1 < nchunks) store_lds((c + 1) & 1);
-    __syncthreads();
+    __syncthreads();  // (everybody is done with stage c & 1; the loads of chunk c + 1 have landed: vmcnt(0) before the barrier)
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int i = (T0 + t) / RB, j = (T0 + t) % RB;
-    if (i < nrt && j < nct) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) epi(16 * (rt0 + i) + (lane >> 4) + 4 * r, 16 * (ct0 + j) + (lane & 15), acc[t][r]);
-    }
+    if (i < nrt && j < nct) epi(16 * (rt0 + i) + (lane >> 4), 16 * (ct0 + j) + (lane & 15), acc[t]);
   }
 }
 
-// C = Aop' Bop handed to `epi(row, col, value)` element by element (rows / columns < 16 MT): lane l holds, for tile (ti, tj)
-// and r = 0..3, the element (16 ti + (l >> 4) + 4 r, 16 tj + (l & 15)).  Every element is delivered exactly once.
-template <int MT, class Epi>
+// C = Aop' Bop handed to `epi(row0, col, v)` one tile fragment at a time (rows / columns < 16 MT): v[r], r = 0..3, is the element
+// (row0 + 4 r, col) -- lane l of tile (ti, tj) has row0 = 16 ti + (l >> 4), col = 16 tj + (l & 15).  Every element is delivered
+// exactly once.  (Per fragment, so that an epilogue that also READS can issue its four loads before its four stores.)
+template <int MT, class Epi, class Init = SoZeroInit>
 __device__ __forceinline__ void so_gemm(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb, int K,
-                                        double* lds, Epi epi) {
+                                        double* lds, Epi epi, Init init = Init()) {
   constexpr int RB = SoGemmCfg<MT>::RB;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: block offsets and the half are wave-uniform)
   const int pair = wave >> 1, rbk = pair >> 1, cbk = pair & 1;
   const int rt0 = rbk ? RB : 0, nrt = rbk ? MT - RB : RB, ct0 = cbk ? RB : 0, nct = cbk ? MT - RB : RB;
   if (wave & 1)
-    so_gemm_half<MT, 1>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi);
+    so_gemm_half<MT, 1>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi, init);
   else
-    so_gemm_half<MT, 0>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi);
+    so_gemm_half<MT, 0>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi, init);
 }
 
 }  // namespace dsge

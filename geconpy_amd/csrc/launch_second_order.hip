@@ -8,6 +8,8 @@
 
 namespace dsge_host {
 
+long long* g_so_dbg = nullptr;  // debug: device int64[8], phase cycles of draw 0 of the filter kernel
+
 namespace {
 struct SoArena {
   void* ptr = nullptr;
@@ -91,7 +93,7 @@ int launch_second_order(const double* B, const double* C, const double* T, const
                         const double* Hdiag, const double* y, int batch, int n, int k, int p, int T_len, double jitter,
                         double missing_fill, const int32_t* S, int s, const int32_t* L, int l, const int32_t* U, int u,
                         double* logp, int32_t* status_io, double* gyy_out, double* gyu_out, double* guu_out, double* gss_out,
-                        int32_t* steady_at, int32_t* n_doublings, hipStream_t st, float* ms) {
+                        int32_t* steady_at, int32_t* n_doublings, hipStream_t st, float* ms, const int32_t* order_key) {
   if (s < 1 || s > dsge::SO_MAX_S || u < s || u > 40 || l < 0 || l > 64 || k > dsge::SO_MAX_K || k > s || p > dsge::SO_MAX_P)
     return fail(DSGE_ERR_INVALID, "second order: sizes out of range (1 <= s <= 24, s <= u <= 40, k <= min(s, 12), p <= 8)");
   const int q_ = s * (s + 1) / 2, m = 2 * u + q_, mt = so_tiles(m);
@@ -112,11 +114,12 @@ int launch_second_order(const double* B, const double* C, const double* T, const
   int rc;
   void* base = nullptr;
   const size_t head = 4096 + sizeof(double) * 8 * 40;
-  if ((rc = so_reserve(head + per_draw * chunk, st, &base))) return rc;
+  if ((rc = so_reserve(head + per_draw * chunk + sizeof(int32_t) * (size_t)chunk + 256, st, &base))) return rc;
   int32_t* hptr = (int32_t*)base;                      // [n + 1]
   int32_t* flags = hptr + 128;                         // [2]
   double* Zu = (double*)((char*)base + 4096);          // [p][u]
   double* work = (double*)((char*)base + head);
+  int32_t* order = (int32_t*)((char*)base + head + per_draw * chunk);
   HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st));
   hipLaunchKernelGGL(dsge::so_hessptr_kernel, dim3(1), dim3(256), 0, st, hess_idx, nnz, n, k, hptr, flags);
   HIP_TRY(hipGetLastError());
@@ -163,8 +166,15 @@ int launch_second_order(const double* B, const double* C, const double* T, const
     fa.y = y;
     fa.logp = logp + c0;
     fa.status = status_io + c0;
+    fa.order = nullptr;
+    if (order_key && opt().kalman_order && nb >= 512) {  // slow draws first (descending key: cycle-reduction iterations)
+      hipLaunchKernelGGL(dsge::kalman_order_kernel<1024>, dim3(1), dim3(1024), 0, st, order_key + c0, nb, order);
+      HIP_TRY(hipGetLastError());
+      fa.order = order;
+    }
     fa.steady_at = steady_at ? steady_at + c0 : nullptr;
     fa.n_doublings = n_doublings ? n_doublings + c0 : nullptr;
+    fa.phases = (c0 == 0) ? g_so_dbg : nullptr;
     fa.batch = nb;
     fa.T_len = T_len;
     fa.jitter = jitter;

@@ -311,8 +311,8 @@ int dsge_set_gensys_split(int enable);
  * enable = 1 switches it on (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_kalman_mfma(int enable);
 double dsge_get_kalman_steady_tol(void);
-/* Debug hook: device int32[batch] that later fast-path Kalman launches fill with the first time step
- * that ran in steady-state mode (-1 = never); NULL stops recording. */
+/* Debug hook: device int32[batch] that later fast-path Kalman launches (and the second-order filter) fill with the first
+ * time step that ran in steady-state mode (-1 = never); NULL stops recording. */
 int dsge_debug_kalman_steady_steps(int32_t* steady_at_device);
 
 /* Debug hook: enable != 0 makes the selector-path Kalman kernel record the shader cycles draw 0 spends
@@ -648,6 +648,11 @@ int dsge_second_order_logp_batched_host(const double* A, const double* B, const 
                                         const int32_t* lead_idx, int n_lead, const int32_t* ret_idx, int n_ret,
                                         double* logp_out, int32_t* status_out, double* T_out, double* R_out, double* gyy_out,
                                         double* gyu_out, double* guu_out, double* gss_out);
+
+/* Debug hook: enable != 0 makes the second-order filter kernel record the shader cycles draw 0 spends in [0] P Z', F, the gain;
+ * [1] the pass over Az' (predicted mean, Az K, Az V); [2] the first product; [3] the second product + epilogue; [4] steady
+ * steps; [5] = number of full steps, [6] = number of steady steps, [7] = kernel total; cycles_out: host int64[8] or NULL. */
+int dsge_debug_second_order_phases(int enable, long long* cycles_out);
 
 /*
  * Timing hook for bench.py: runs `reps` back-to-back launches of the fused pipeline's

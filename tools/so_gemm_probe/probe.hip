@@ -16,10 +16,12 @@ __global__ __launch_bounds__(512) void k(const double* A, const double* B, doubl
   const size_t off = (size_t)blockIdx.x * MP * MP;
   const long long t0 = clock64();
   for (int r = 0; r < reps; ++r)
-    dsge::so_gemm<MT_>(A + off, MP, B + off, MP, K, lds, [&](int row, int col, double v) {
-      if (EPI & 1) C[off + (size_t)row * MP + col] = v;
-      if (EPI & 2) Ct[off + (size_t)col * MP + row] = v;
-      if (EPI == 0 && v == 1.2345e300) C[off] = v;
+    dsge::so_gemm<MT_>(A + off, MP, B + off, MP, K, lds, [&](int row0, int col, dsge::so_v4f64 v) {
+      for (int q = 0; q < 4; ++q) {
+        if (EPI & 1) C[off + (size_t)(row0 + 4 * q) * MP + col] = v[q];
+        if (EPI & 2) Ct[off + (size_t)col * MP + row0 + 4 * q] = v[q];
+        if (EPI == 0 && v[q] == 1.2345e300) C[off] = v[q];
+      }
     });
   if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = clock64() - t0;
 }
