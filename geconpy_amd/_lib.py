@@ -100,6 +100,10 @@ PROTOTYPES = {
     "dsge_autocorrelation_batched_host": [_dp, _dp, _dp, _i, _dp, _dp, _i, _i, _i, _i, _i, _i, _i, _dp, _dp, _dp],
     "dsge_kalman_logp_batched": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp, _dp],
     "dsge_kalman_logp_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _dp, _dp],
+    "dsge_kalman_filter_outputs_batched": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _dp, _dp,
+                                           _dp, _dp, _dp, _i, _dp, _dp],
+    "dsge_kalman_filter_outputs_batched_host": [_dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _f, _f, _dp,
+                                                _dp, _dp, _dp, _dp, _i, _dp],
     "dsge_solve_kalman_logp_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_augmented_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,

@@ -377,6 +377,34 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
     return logp, st
 
 
+def kalman_filter_outputs_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None, jitter=JITTER_DEFAULT,
+                                 missing_fill_value=MISSING_FILL, full_covariances=False):
+    """Per-step filter outputs for a batch of draws -- what ``save_kalman_filter_outputs_in_idata=True`` stores
+    (gEconpy/model/statespace.py:1145, 1151-1157): dict(ll (batch, T_len), predicted_states / filtered_states (batch, T_len, m),
+    predicted_covs / filtered_covs: the diagonals (batch, T_len, m), or the matrices (batch, T_len, m, m) with
+    ``full_covariances``, status).  ``ll.sum(axis=1)`` is the log-likelihood of ``kalman_logp_batched``."""
+    T, R = _f64(T, 3), _f64(R, 3)
+    y = _f64(y, 2)
+    nb, m, _ = T.shape
+    k = R.shape[2]
+    T_len, p = y.shape
+    Q, code = _resolve_q(Q, q_mode, nb, k)
+    Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, m)
+    st = np.zeros(nb, dtype=np.int32) if status is None else np.ascontiguousarray(status, dtype=np.int32).copy()
+    cshape = (nb, T_len, m, m) if full_covariances else (nb, T_len, m)
+    out = dict(ll=np.empty((nb, T_len)), predicted_states=np.empty((nb, T_len, m)), filtered_states=np.empty((nb, T_len, m)),
+               predicted_covs=np.empty(cshape), filtered_covs=np.empty(cshape))
+    _lib.check(
+        _lib.load().dsge_kalman_filter_outputs_batched_host(
+            _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len, float(jitter),
+            float(missing_fill_value), _ptr(out["ll"]), _ptr(out["predicted_states"]), _ptr(out["filtered_states"]),
+            _ptr(out["predicted_covs"]), _ptr(out["filtered_covs"]), int(bool(full_covariances)), _ptr(st)
+        )
+    )
+    out["status"] = st
+    return out
+
+
 def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                               tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
                               return_policy=False, n_state_hint=None, z_selector_hint=None, n_lead_hint=None,

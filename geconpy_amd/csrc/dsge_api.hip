@@ -150,37 +150,50 @@ int check_options(const dsge_options* o) {
   return DSGE_SUCCESS;
 }
 
-// Scratch of the device entry points: one arena per (device, stream) -- the library is re-entrant per stream:
-// two fused calls enqueued on two streams must not share intermediates.  16 slots per device; when more streams than slots
-// show up the first slot is recycled after a device-wide synchronisation.
-struct StreamArena {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipStream_t stream = nullptr;
-  bool used = false;
-};
-StreamArena g_stream_scratch[MAX_DEV][16];
+}  // namespace
 
-int scratch_reserve(hipStream_t st, size_t bytes, void** out) {
+// ---- StreamArenaPool (dsge_host.hpp) ------------------------------------------------------------------------------------------
+namespace dsge_host {
+namespace {
+std::mutex& pool_registry_mutex() {
+  static std::mutex m;
+  return m;
+}
+std::vector<StreamArenaPool*>& pool_registry() {
+  static std::vector<StreamArenaPool*> v;
+  return v;
+}
+}  // namespace
+
+StreamArenaPool::StreamArenaPool() {
+  std::lock_guard<std::mutex> lk(pool_registry_mutex());
+  pool_registry().push_back(this);
+}
+
+int StreamArenaPool::reserve(size_t bytes, hipStream_t st, void** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= MAX_DEV) return fail(DSGE_ERR_INVALID, "device index out of range");
-  std::lock_guard<std::mutex> lk(g_mutex);
-  StreamArena* a = nullptr;
-  for (auto& slot : g_stream_scratch[dev])
-    if (slot.used && slot.stream == st) a = &slot;
+  std::lock_guard<std::mutex> lk(mu_);
+  Slot* a = nullptr;
+  for (auto& slot : slots_)
+    if (slot.used && slot.dev == dev && slot.stream == st) a = &slot;
   if (!a)
-    for (auto& slot : g_stream_scratch[dev])
-      if (!slot.used) {
-        a = &slot;
-        break;
-      }
-  if (!a) {
+    for (auto& slot : slots_)
+      if (!slot.used && (slot.dev == dev || slot.dev < 0) && (!a || slot.cap > a->cap)) a = &slot;  // the largest free one
+  if (!a && slots_.size() < MAX_SLOTS) {
+    slots_.emplace_back();
+    a = &slots_.back();
+  }
+  if (!a) {  // every slot is owned by a live stream: take the least recently used one over, once nothing is in flight
     HIP_TRY(hipDeviceSynchronize());
-    a = &g_stream_scratch[dev][0];
+    for (auto& slot : slots_)
+      if (slot.dev == dev && (!a || slot.stamp < a->stamp)) a = &slot;
+    if (!a) return fail(DSGE_ERR_HIP, "scratch arenas exhausted");
   }
   a->used = true;
+  a->dev = dev;
   a->stream = st;
+  a->stamp = ++clock_;
   if (a->cap < bytes) {
     if (a->ptr) {
       HIP_TRY(hipDeviceSynchronize());
@@ -195,6 +208,56 @@ int scratch_reserve(hipStream_t st, size_t bytes, void** out) {
   *out = a->ptr;
   return DSGE_SUCCESS;
 }
+
+void StreamArenaPool::release(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto& slot : slots_)
+    if (slot.used && slot.stream == st) slot.used = false;  // (the memory stays with the slot for its next owner)
+}
+
+void stream_arenas_release(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(pool_registry_mutex());
+  for (StreamArenaPool* p : pool_registry()) p->release(st);
+}
+
+namespace {
+struct ThreadStreams {
+  hipStream_t s[2] = {nullptr, nullptr};
+  int dev = -1;
+  void drop() {
+    for (auto& x : s)
+      if (x) {
+        (void)hipStreamSynchronize(x);
+        stream_arenas_release(x);
+        (void)hipStreamDestroy(x);
+        x = nullptr;
+      }
+    (void)hipGetLastError();
+  }
+  ~ThreadStreams() { drop(); }
+};
+thread_local ThreadStreams t_streams;
+}  // namespace
+
+int twin_streams(hipStream_t* s0, hipStream_t* s1) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (t_streams.dev != dev) {  // (streams belong to a device; recreate after a device switch)
+    t_streams.drop();
+    for (auto& x : t_streams.s) HIP_TRY(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    t_streams.dev = dev;
+  }
+  *s0 = t_streams.s[0];
+  if (s1) *s1 = t_streams.s[1];
+  return DSGE_SUCCESS;
+}
+
+}  // namespace dsge_host
+
+namespace {
+// Scratch of the device entry points (one arena per (device, stream), StreamArenaPool)
+StreamArenaPool g_scratch_pool;
+int scratch_reserve(hipStream_t st, size_t bytes, void** out) { return g_scratch_pool.reserve(bytes, st, out); }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -534,6 +597,34 @@ int dsge_autocorrelation_batched(const double* T, const double* R, const double*
                             Sigma, status, 0, 1, st)))
     return rc;
   return launch_acf(T, Sigma, Z, Hdiag, batch, m, p, n_lags, lag_step, correlation, acf_out, status, st);
+}
+
+int dsge_kalman_filter_outputs_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                       int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                       const double* y, int batch, int m, int k, int p, int T_len, double jitter,
+                                       double missing_fill, double* ll_out, double* a_pred_out, double* a_filt_out,
+                                       double* p_pred_out, double* p_filt_out, int full_cov, int32_t* status_io, void* stream) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m) return fail(DSGE_ERR_INVALID, "k out of range (1..m)");
+  if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
+  if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
+  if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
+  if (!T || !R || !Q || !Z || !y || !ll_out || !status_io) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t mm = (size_t)batch * m * m;
+  void* base = nullptr;
+  if ((rc = scratch_reserve(st, 2 * align256(mm * 8) + 4096, &base))) return rc;
+  Carver cv(base);
+  double* RQR = cv.take<double>(mm);
+  double* P0 = cv.take<double>(mm);
+  if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T, R, Q, q_mode, batch, m, k, nullptr, nullptr, RQR, P0,
+                            status_io, 0, 1, st)))
+    return rc;
+  return launch_kalman_outputs(T, RQR, P0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter,
+                               missing_fill, ll_out, a_pred_out, a_filt_out, p_pred_out, p_filt_out, full_cov, status_io, st);
 }
 
 int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
@@ -982,11 +1073,11 @@ int dsge_profile_pipeline(const double* A, const double* B, const double* C, con
   type* dst = nullptr;                                                                              \
   if (src) {                                                                                        \
     dst = cv.take<type>(count);                                                                     \
-    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(type) * (count), hipMemcpyHostToDevice, nullptr));      \
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(type) * (count), hipMemcpyHostToDevice, tw_st));      \
   }
 #define OUTBUF(dst, host, count, type) type* dst = (host) ? cv.take<type>(count) : nullptr;
 #define DOWN(host, dev, count, type)                                                                \
-  if (host) HIP_TRY(hipMemcpyAsync(host, dev, sizeof(type) * (count), hipMemcpyDeviceToHost, nullptr));
+  if (host) HIP_TRY(hipMemcpyAsync(host, dev, sizeof(type) * (count), hipMemcpyDeviceToHost, tw_st));
 
 static int cr_host(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
                    double* T_out, int32_t* status, int32_t* n_iter, int scan_mode);
@@ -1008,6 +1099,9 @@ static int cr_host(const double* A, const double* B, const double* C, int batch,
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n;
   void* base = nullptr;
@@ -1019,11 +1113,11 @@ static int cr_host(const double* A, const double* B, const double* C, int batch,
   OUTBUF(dT, T_out, nn, double);
   OUTBUF(dS, status, batch, int32_t);
   OUTBUF(dI, n_iter, batch, int32_t);
-  if ((rc = cr_entry(dA, dB, dC, batch, n, max_iter, tol, dT, dS, dI, nullptr, scan_mode))) return rc;
+  if ((rc = cr_entry(dA, dB, dC, batch, n, max_iter, tol, dT, dS, dI, tw_st, scan_mode))) return rc;
   DOWN(T_out, dT, nn, double);
   DOWN(status, dS, batch, int32_t);
   DOWN(n_iter, dI, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1056,6 +1150,9 @@ int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, 
   int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
   if (rc) return rc;
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   long long* d = nullptr;
   HIP_TRY(hipMalloc((void**)&d, 6 * sizeof(long long)));
   HIP_TRY(hipMemset(d, 0, 6 * sizeof(long long)));
@@ -1096,6 +1193,9 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
   if (!A || !B || !C || !T_out || !eu_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "R_out requires D and 1 <= k <= n");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * (R_out ? k : 0);
   void* base = nullptr;
@@ -1113,12 +1213,12 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
   OUTBUF(dR, R_out, nk, double);
   OUTBUF(dE, eu_out, (size_t)batch * 3, int32_t);
   OUTBUF(dS, status, batch, int32_t);
-  if ((rc = dsge_gensys_batched(dA, dB, dC, dDp, batch, n, k, tol, n_lead_hint, dT, dR, dE, dS, nullptr))) return rc;
+  if ((rc = dsge_gensys_batched(dA, dB, dC, dDp, batch, n, k, tol, n_lead_hint, dT, dR, dE, dS, tw_st))) return rc;
   DOWN(T_out, dT, nn, double);
   DOWN(R_out, dR, nk, double);
   DOWN(eu_out, dE, (size_t)batch * 3, int32_t);
   DOWN(status, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1131,6 +1231,9 @@ int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const do
   if (!g0 || !g1 || !psi || (n_eta > 0 && !pi) || !G1_out || !C_out || !impact_out || !gev_out || !eu_out || !status)
     return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * N * N, nk = (size_t)batch * N * k, ne = (size_t)batch * N * (n_eta > 0 ? n_eta : 1),
                nv = (size_t)batch * N;
@@ -1150,14 +1253,14 @@ int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const do
   OUTBUF(dV, gev_out, nv * 4, double);
   OUTBUF(dE, eu_out, (size_t)batch * 3, int32_t);
   OUTBUF(dS, status, batch, int32_t);
-  if ((rc = dsge_gensys_pencil_batched(d0, d1, dc, dps, dpi, batch, N, k, n_eta, tol, dG, dC, dI, dV, dE, dS, nullptr))) return rc;
+  if ((rc = dsge_gensys_pencil_batched(d0, d1, dc, dps, dpi, batch, N, k, n_eta, tol, dG, dC, dI, dV, dE, dS, tw_st))) return rc;
   DOWN(G1_out, dG, nn, double);
   DOWN(C_out, dC, nv, double);
   DOWN(impact_out, dI, nk, double);
   DOWN(gev_out, dV, nv * 4, double);
   DOWN(eu_out, dE, (size_t)batch * 3, int32_t);
   DOWN(status, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1169,6 +1272,9 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
   if (!A || !B || !C || !eig_re || !eig_im || !n_eig || !n_forward || !n_unstable || !status)
     return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, ne = (size_t)batch * 2 * n;
   void* base = nullptr;
@@ -1183,14 +1289,14 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
   OUTBUF(dNf, n_forward, batch, int32_t);
   OUTBUF(dNu, n_unstable, batch, int32_t);
   OUTBUF(dS, status, batch, int32_t);
-  if ((rc = dsge_bk_eigenvalues_batched(dA, dB, dC, batch, n, tol, dRe, dIm, dNe, dNf, dNu, dS, nullptr))) return rc;
+  if ((rc = dsge_bk_eigenvalues_batched(dA, dB, dC, batch, n, tol, dRe, dIm, dNe, dNf, dNu, dS, tw_st))) return rc;
   DOWN(eig_re, dRe, ne, double);
   DOWN(eig_im, dIm, ne, double);
   DOWN(n_eig, dNe, batch, int32_t);
   DOWN(n_forward, dNf, batch, int32_t);
   DOWN(n_unstable, dNu, batch, int32_t);
   DOWN(status, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1201,6 +1307,9 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!B || !C || !D || !T || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
@@ -1213,10 +1322,10 @@ int dsge_selection_batched_host(const double* A, const double* B, const double* 
   UP(dT, T, nn, double);
   OUTBUF(dR, R_out, nk, double);
   OUTBUF(dRes, resid_out, batch, double);
-  if ((rc = dsge_selection_batched(dA, dB, dC, dD, dT, batch, n, k, dR, dRes, nullptr))) return rc;
+  if ((rc = dsge_selection_batched(dA, dB, dC, dD, dT, batch, n, k, dR, dRes, tw_st))) return rc;
   DOWN(R_out, dR, nk, double);
   DOWN(resid_out, dRes, batch, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1228,6 +1337,9 @@ int dsge_selection_adjoints_batched_host(const double* B, const double* C, const
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!B || !C || !T || !R || !R_bar || !B_bar || !C_bar || !D_bar || !T_bar) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
@@ -1242,12 +1354,12 @@ int dsge_selection_adjoints_batched_host(const double* B, const double* C, const
   OUTBUF(dCb, C_bar, nn, double);
   OUTBUF(dDb, D_bar, nk, double);
   OUTBUF(dTb, T_bar, nn, double);
-  if ((rc = dsge_selection_adjoints_batched(dB, dC, dT, dR, dRb, batch, n, k, dBb, dCb, dDb, dTb, nullptr))) return rc;
+  if ((rc = dsge_selection_adjoints_batched(dB, dC, dT, dR, dRb, batch, n, k, dBb, dCb, dDb, dTb, tw_st))) return rc;
   DOWN(B_bar, dBb, nn, double);
   DOWN(C_bar, dCb, nn, double);
   DOWN(D_bar, dDb, nk, double);
   DOWN(T_bar, dTb, nn, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1257,6 +1369,9 @@ int dsge_policy_adjoints_batched_host(const double* B, const double* C, const do
   if (rc) return rc;
   if (!B || !C || !T || !T_bar || !A_bar || !B_bar || !C_bar || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n;
   void* base = nullptr;
@@ -1270,12 +1385,12 @@ int dsge_policy_adjoints_batched_host(const double* B, const double* C, const do
   OUTBUF(dBb, B_bar, nn, double);
   OUTBUF(dCb, C_bar, nn, double);
   OUTBUF(dS, status, batch, int32_t);
-  if ((rc = dsge_policy_adjoints_batched(dB, dC, dT, dTb, batch, n, dAb, dBb, dCb, dS, nullptr))) return rc;
+  if ((rc = dsge_policy_adjoints_batched(dB, dC, dT, dTb, batch, n, dAb, dBb, dCb, dS, tw_st))) return rc;
   DOWN(A_bar, dAb, nn, double);
   DOWN(B_bar, dBb, nn, double);
   DOWN(C_bar, dCb, nn, double);
   DOWN(status, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1294,6 +1409,9 @@ int dsge_second_order_logp_batched_host(const double* A, const double* B, const 
   if (!A || !B || !C || !D || (nnz > 0 && (!hess_idx || !hess_val)) || !q || !Z || !y || !logp_out || !status_out)
     return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nv = (size_t)batch * nnz, ss = (size_t)n_state * n_state;
   void* base = nullptr;
@@ -1325,7 +1443,7 @@ int dsge_second_order_logp_batched_host(const double* A, const double* B, const 
   OUTBUF(dgss, gss_out, (size_t)batch * n, double);
   if ((rc = dsge_second_order_logp_batched(dA, dB, dC, dD, dHi, nnz, dHv, dq, q_batched, dZ, dd, dH, dy, batch, n, k, p, T_len,
                                            solver, tol, max_iter, jitter, missing_fill, state_idx, n_state, lead_idx, n_lead,
-                                           ret_idx, n_ret, dlp, dst, dT, dR, dgyy, dgyu, dguu, dgss, nullptr, nullptr)))
+                                           ret_idx, n_ret, dlp, dst, dT, dR, dgyy, dgyu, dguu, dgss, nullptr, tw_st)))
     return rc;
   DOWN(logp_out, dlp, batch, double);
   DOWN(status_out, dst, batch, int32_t);
@@ -1335,7 +1453,57 @@ int dsge_second_order_logp_batched_host(const double* A, const double* B, const 
   DOWN(gyu_out, dgyu, (size_t)batch * n * n_state * k, double);
   DOWN(guu_out, dguu, (size_t)batch * n * k * k, double);
   DOWN(gss_out, dgss, (size_t)batch * n, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
+  return DSGE_SUCCESS;
+}
+
+int dsge_kalman_filter_outputs_batched_host(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                            int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                            const double* y, int batch, int m, int k, int p, int T_len, double jitter,
+                                            double missing_fill, double* ll_out, double* a_pred_out, double* a_filt_out,
+                                            double* p_pred_out, double* p_filt_out, int full_cov, int32_t* status_io) {
+  int rc = check_common(batch, m, DSGE_MAX_N);
+  if (rc) return rc;
+  if (k < 1 || k > m || p < 1 || p > DSGE_MAX_P || T_len < 0 || q_mode < 0 || q_mode > 3)
+    return fail(DSGE_ERR_INVALID, "size out of range");
+  if (!T || !R || !Q || !Z || !y || !ll_out || !status_io) return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr;
+  if ((rc = twin_streams(&tw_st, nullptr))) return rc;
+  if (batch == 0) return DSGE_SUCCESS;
+  const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
+  const size_t nz = (size_t)(z_batched ? batch : 1) * p * m, nd = (size_t)(d_batched ? batch : 1) * p,
+               nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p, tm = (size_t)batch * T_len * m,
+               tc = full_cov ? tm * m : tm;
+  void* base = nullptr;
+  STAGE_RESERVE(align256(mm * 8) + align256(mk * 8) + align256(nq * 8) + align256(nz * 8) + align256(nd * 8) + align256(nh * 8) +
+                    align256(ny * 8) + align256((size_t)batch * T_len * 8) + 2 * align256(tm * 8) + 2 * align256(tc * 8) +
+                    align256((size_t)batch * 4) + 8192,
+                &base);
+  Carver cv(base);
+  UP(dT, T, mm, double);
+  UP(dR, R, mk, double);
+  UP(dQ, Q, nq, double);
+  UP(dZ, Z, nz, double);
+  UP(dd, d, nd, double);
+  UP(dH, Hdiag, nh, double);
+  UP(dy, y, ny, double);
+  UP(dS, status_io, batch, int32_t);
+  OUTBUF(dll, ll_out, (size_t)batch * T_len, double);
+  OUTBUF(dap, a_pred_out, tm, double);
+  OUTBUF(daf, a_filt_out, tm, double);
+  OUTBUF(dpp, p_pred_out, tc, double);
+  OUTBUF(dpf, p_filt_out, tc, double);
+  if ((rc = dsge_kalman_filter_outputs_batched(dT, dR, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy, batch, m, k, p,
+                                               T_len, jitter, missing_fill, dll, dap, daf, dpp, dpf, full_cov, dS, tw_st)))
+    return rc;
+  DOWN(ll_out, dll, (size_t)batch * T_len, double);
+  DOWN(a_pred_out, dap, tm, double);
+  DOWN(a_filt_out, daf, tm, double);
+  DOWN(p_pred_out, dpp, tc, double);
+  DOWN(p_filt_out, dpf, tc, double);
+  DOWN(status_io, dS, batch, int32_t);
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1348,6 +1516,9 @@ int dsge_policy_norms_batched_host(const double* A, const double* B, const doubl
   if (!A || !B || !C || !D || !T || !R || !state_mask || !det_norm_out || !stoch_norm_out)
     return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
@@ -1363,10 +1534,10 @@ int dsge_policy_norms_batched_host(const double* A, const double* B, const doubl
   UP(dM, state_mask, (size_t)n, int32_t);
   OUTBUF(d1, det_norm_out, batch, double);
   OUTBUF(d2, stoch_norm_out, batch, double);
-  if ((rc = dsge_policy_norms_batched(dA, dB, dC, dD, dT, dR, dM, batch, n, k, d1, d2, nullptr))) return rc;
+  if ((rc = dsge_policy_norms_batched(dA, dB, dC, dD, dT, dR, dM, batch, n, k, d1, d2, tw_st))) return rc;
   DOWN(det_norm_out, d1, batch, double);
   DOWN(stoch_norm_out, d2, batch, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1377,6 +1548,9 @@ int dsge_backward_direct_batched_host(const double* A, const double* B, const do
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!A || !B || !D || !T_out || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = nullptr;
@@ -1387,10 +1561,10 @@ int dsge_backward_direct_batched_host(const double* A, const double* B, const do
   UP(dD, D, nk, double);
   OUTBUF(dT, T_out, nn, double);
   OUTBUF(dR, R_out, nk, double);
-  if ((rc = dsge_backward_direct_batched(dA, dB, dD, batch, n, k, dT, dR, nullptr))) return rc;
+  if ((rc = dsge_backward_direct_batched(dA, dB, dD, batch, n, k, dT, dR, tw_st))) return rc;
   DOWN(T_out, dT, nn, double);
   DOWN(R_out, dR, nk, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1402,6 +1576,9 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!T || !R || !Q || !P0_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
   void* base = nullptr;
@@ -1414,11 +1591,11 @@ int dsge_lyapunov_batched_host(const double* T, const double* R, const double* Q
   OUTBUF(dP, P0_out, mm, double);
   OUTBUF(dX, RQR_out, mm, double);
   OUTBUF(dS, status, batch, int32_t);
-  if ((rc = dsge_lyapunov_batched(dT, dR, dQ, q_mode, batch, m, k, dP, dX, dS, nullptr))) return rc;
+  if ((rc = dsge_lyapunov_batched(dT, dR, dQ, q_mode, batch, m, k, dP, dX, dS, tw_st))) return rc;
   DOWN(P0_out, dP, mm, double);
   DOWN(RQR_out, dX, mm, double);
   DOWN(status, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1438,6 +1615,9 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = q_elems(q_mode, batch, k);
   const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k;
@@ -1469,14 +1649,14 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
   if ((rc = dsge_solve_kalman_logp_augmented_batched(dA, dB, dC, dD, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched,
                                                      dy, batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
                                                      m, dinv, n_links, dlr, dlc, n_state_hint, z_selector_hint, n_lead_hint,
-                                                     dL, dS, dTa, dRa, dRes, nullptr)))
+                                                     dL, dS, dTa, dRa, dRes, tw_st)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_out, dS, batch, int32_t);
   DOWN(T_aug_out, dTa, mm, double);
   DOWN(R_aug_out, dRa, mk, double);
   DOWN(resid_out, dRes, batch, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1494,6 +1674,9 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   if (!A || !B || !C || !D || !q || !Z || !y || !logp_out || !status_out || !A_bar || !B_bar || !C_bar || !D_bar || !q_bar)
     return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = (size_t)(q_batched ? batch : 1) * k;
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
@@ -1524,7 +1707,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   OUTBUF(gh, h_bar, bp, double);
   if ((rc = dsge_solve_kalman_logp_grad_batched(dA, dB, dC, dD, dq, q_batched, dZ, z_batched, dd, d_batched, dH, h_batched,
                                                 dy, batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
-                                                n_filter_hint, n_lead_hint, dL, dS, gA, gB, gC, gD, gq, gd, gh, nullptr)))
+                                                n_filter_hint, n_lead_hint, dL, dS, gA, gB, gC, gD, gq, gd, gh, tw_st)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_out, dS, batch, int32_t);
@@ -1535,7 +1718,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   DOWN(q_bar, gq, (size_t)batch * k, double);
   DOWN(d_bar, gd, bp, double);
   DOWN(h_bar, gh, bp, double);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1550,6 +1733,9 @@ int dsge_autocorrelation_batched_host(const double* T, const double* R, const do
   if (Z && (p < 1 || p > DSGE_MAX_P)) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
   if (!T || !R || !Q || !acf_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const int dim = Z ? p : m;
   const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
@@ -1568,12 +1754,12 @@ int dsge_autocorrelation_batched_host(const double* T, const double* R, const do
   OUTBUF(dO, acf_out, no, double);
   OUTBUF(dS, status, batch, int32_t);
   if ((rc = dsge_autocorrelation_batched(dT, dR, dQ, q_mode, dZ, dH, batch, m, k, p, n_lags, lag_step, correlation, dO,
-                                         dSig, dS, nullptr)))
+                                         dSig, dS, tw_st)))
     return rc;
   DOWN(acf_out, dO, no, double);
   DOWN(Sigma_out, dSig, mm, double);
   DOWN(status, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1590,6 +1776,9 @@ int dsge_kalman_logp_batched_host(const double* T, const double* R, const double
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!T || !R || !Q || !Z || !y || !logp_out || !status_io) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t mm = (size_t)batch * m * m, mk = (size_t)batch * m * k, nq = q_elems(q_mode, batch, k);
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * m, nd = (size_t)(d_batched ? batch : 1) * p,
@@ -1609,11 +1798,11 @@ int dsge_kalman_logp_batched_host(const double* T, const double* R, const double
   UP(dS, status_io, batch, int32_t);
   OUTBUF(dL, logp_out, batch, double);
   if ((rc = dsge_kalman_logp_batched(dT, dR, dQ, q_mode, dZ, z_batched, dd, d_batched, dH, h_batched, dy, batch, m, k,
-                                     p, T_len, jitter, missing_fill, n_state_hint, z_selector_hint, dL, dS, nullptr)))
+                                     p, T_len, jitter, missing_fill, n_state_hint, z_selector_hint, dL, dS, tw_st)))
     return rc;
   DOWN(logp_out, dL, batch, double);
   DOWN(status_io, dS, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 
@@ -1632,6 +1821,9 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = q_elems(q_mode, batch, k);
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
@@ -1657,20 +1849,13 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   OUTBUF(dR, R_out, nk, double);
   OUTBUF(dRes, resid_out, batch, double);
   OUTBUF(dI, n_iter_out, batch, int32_t);
-  if (!q_b) HIP_TRY(hipMemcpyAsync(dQ, Q, nq * 8, hipMemcpyHostToDevice, nullptr));
-  if (!z_batched) HIP_TRY(hipMemcpyAsync(dZ, Z, nz * 8, hipMemcpyHostToDevice, nullptr));
-  if (d && !d_batched) HIP_TRY(hipMemcpyAsync(dd, d, nd * 8, hipMemcpyHostToDevice, nullptr));
-  if (Hdiag && !h_batched) HIP_TRY(hipMemcpyAsync(dH, Hdiag, nh * 8, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(hipMemcpyAsync(dy, y, ny * 8, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  static thread_local hipStream_t s_str[2] = {nullptr, nullptr};
-  static thread_local int s_dev = -1;
-  int dev_now = 0;
-  HIP_TRY(hipGetDevice(&dev_now));
-  if (s_dev != dev_now) {  // (streams belong to a device; recreate after a device switch)
-    for (auto& x : s_str) HIP_TRY(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
-    s_dev = dev_now;
-  }
+  if (!q_b) HIP_TRY(hipMemcpyAsync(dQ, Q, nq * 8, hipMemcpyHostToDevice, tw_st));
+  if (!z_batched) HIP_TRY(hipMemcpyAsync(dZ, Z, nz * 8, hipMemcpyHostToDevice, tw_st));
+  if (d && !d_batched) HIP_TRY(hipMemcpyAsync(dd, d, nd * 8, hipMemcpyHostToDevice, tw_st));
+  if (Hdiag && !h_batched) HIP_TRY(hipMemcpyAsync(dH, Hdiag, nh * 8, hipMemcpyHostToDevice, tw_st));
+  HIP_TRY(hipMemcpyAsync(dy, y, ny * 8, hipMemcpyHostToDevice, tw_st));
+  HIP_TRY(hipStreamSynchronize(tw_st));
+  hipStream_t s_str[2] = {tw_st, tw_st1};
   const int n_chunks = (batch >= 2048) ? 4 : (batch >= 512 ? 2 : 1);
   const int per = (batch + n_chunks - 1) / n_chunks;
   const size_t qk = (q_mode == DSGE_Q_FULL_BATCHED) ? (size_t)k * k : (size_t)k;
@@ -1704,7 +1889,7 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
   DOWN(R_out, dR, nk, double);
   DOWN(resid_out, dRes, batch, double);
   DOWN(n_iter_out, dI, batch, int32_t);
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }
 

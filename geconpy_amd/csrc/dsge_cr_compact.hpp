@@ -90,9 +90,9 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
     // CR_REFINE_PIVOT_RATIO: the blocked Gauss-Jordan loses ~1e-15 x cond(A1) where the reference's LAPACK LU
     // (cycle_reduction.py:150-160) keeps 1e-10, and the worst A1 of a draw may come as late as the third or fourth iteration
     // (round 2 only looked at the first two: fuzz seed 23 found draws with a pivot ratio of 2.5e6 / 9e5 in iteration 2, 4..7e-9
-    // off in T; with the step they are at 6e-12 / 1e-10, tools/cr_refine_model.py).  About one draw in three hundred takes
-    // the branch in some iteration; the others are untouched (bit-identical).
-    if (__builtin_amdgcn_readfirstlane((int)(inv_hi > CR_REFINE_PIVOT_RATIO * inv_lo))) {
+    // off in T; with the step they are at 6e-12 / 1e-10, tools/cr_refine_model.py).  One or two draws in a hundred take the
+    // branch in some iteration; the others are untouched (bit-identical).
+    if (__builtin_amdgcn_readfirstlane((int)(inv_hi > cr_refine_ratio<BS>() * inv_lo))) {
       gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);  // X in natural row order (syncs inside)
       double xh[BS][BS], rr[BS][BS];
       blk_load_lds<BS>(xh, G1, LDW, lr, lc);

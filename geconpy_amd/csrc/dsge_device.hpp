@@ -431,7 +431,18 @@ __device__ __forceinline__ double readlane_dyn_f64(double v, int src_lane_unifor
 
 // W: n rows x (ngroups*NP) columns, row stride ldw, matrix in columns [0,n).  Scratch in LDS:
 // Lbuf (NP*BS doubles), Ybuf (BS * ngroups*NP doubles), prow (NP ints).
-constexpr double CR_REFINE_PIVOT_RATIO = 1e4;  // largest / smallest |pivot| of a solve beyond which it is refined once: the ratio sits 1e2..1e3 below cond(A1) (SW-shaped draws: median 10..15, 99th percentile 1300..2300, 0.13..0.27 % above 1e4)
+// Largest / smallest |pivot| of a solve beyond which it is refined once.  The ratio is a free but loose proxy of cond(A1)
+// (1e2 .. 3e4 below it), and the blocked elimination loses more digits the wider its panels: on the tiles of up to 40
+// variables (panels of <= 5 columns) 1e4 in ANY iteration keeps the fuzz campaigns at the fixed 1e-9 bar (about two
+// SW-shaped draws in a thousand refine an iteration); on the wider tiles (panels of 6..8 columns, and the four-wavefront
+// kernel) a draw with a ratio of 3.3e3 at cond 9e7 came out 7e-9 off (fuzz seed 2): 1e3 there (one or two draws in a
+// hundred).  Every refinement lengthens its draw by an elimination, and the launch by that draw's tail: the 1e3 rule on the
+// 32-wide tile of the bench costs 0.1 ms of the 0.65 ms solver launch, the 1e4 rule 0.04 ms.
+constexpr double CR_REFINE_PIVOT_RATIO = 1e3;
+template <int BS>
+__device__ __forceinline__ constexpr double cr_refine_ratio() {
+  return BS <= 5 ? 1e4 : 1e3;
+}
 
 template <int BS>
 __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,

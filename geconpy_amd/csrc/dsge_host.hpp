@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/dsge_hip.h"
 
@@ -23,6 +25,35 @@ int fail(int code, const std::string& msg);  // records the message for dsge_las
   } while (0)
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+
+// Library-owned device scratch: ONE arena per (device, stream) and pool -- the library is re-entrant per stream:
+// two calls enqueued on two streams never share intermediates.  Slots are created on demand (a host thread's twin streams
+// release theirs when the thread exits: stream_arenas_release); beyond MAX_SLOTS live (device, stream) pairs the least
+// recently used slot is recycled after a device-wide synchronisation, and it changes owner -- the former stream gets a
+// fresh slot on its next call, so no two streams ever hold the same memory.
+class StreamArenaPool {
+ public:
+  StreamArenaPool();
+  int reserve(size_t bytes, hipStream_t st, void** out);  // the arena of (current device, st), grown to >= bytes
+  void release(hipStream_t st);                            // the stream is going away: its slots become free
+ private:
+  struct Slot {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    bool used = false;
+    unsigned long long stamp = 0;
+  };
+  static constexpr size_t MAX_SLOTS = 64;
+  std::vector<Slot> slots_;
+  std::mutex mu_;
+  unsigned long long clock_ = 0;
+};
+void stream_arenas_release(hipStream_t st);  // every pool of the library (dsge_api.hip)
+// The two streams the host twins of the CALLING THREAD run on (created on first use per device, destroyed -- and their
+// arenas released -- when the thread exits): two host threads in two twins never share a stream, hence never an arena.
+int twin_streams(hipStream_t* s0, hipStream_t* s1);
 
 inline int tile_bs(int n) {
   int bs = (n + 7) / 8;
@@ -85,6 +116,10 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr,
                   const double* Rsel = nullptr, const double* qdiag = nullptr, int q_batched = 0, int k_shocks = 0,
                   const unsigned long long* colmask = nullptr);
+int launch_kalman_outputs(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched, const double* d,
+                          int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
+                          double jitter, double missing_fill, double* ll, double* a_pred, double* a_filt, double* p_pred,
+                          double* p_filt, int full_cov, int32_t* status, hipStream_t st);
 // true if launch_kalman, given the selection matrix R and a diagonal Q (Rsel, qdiag), forms sym(R Q R')[U,U] inside the
 // fast filter kernel: the caller then skips the full-size product (RQR is filled for handed-on draws only)
 bool kalman_folds_rqr(int m, int p, int k, int n_state_hint, int z_selector_hint);

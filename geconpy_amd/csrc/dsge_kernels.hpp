@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
       gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
       // the same single step of iterative refinement as crc_iterate (dsge_cr_compact.hpp), with the same test and the same
       // arithmetic per column: the column-compact kernels stay bit-identical to this one
-      if (__builtin_amdgcn_readfirstlane((int)(inv_hi > CR_REFINE_PIVOT_RATIO * inv_lo))) {
+      if (__builtin_amdgcn_readfirstlane((int)(inv_hi > cr_refine_ratio<BS>() * inv_lo))) {
         double x0h[BS][BS], x2h[BS][BS], r0[BS][BS], r2[BS][BS];
         blk_load_lds<BS>(x0h, W + NP, LDW, lr, lc);
         blk_load_lds<BS>(x2h, W + 2 * NP, LDW, lr, lc);

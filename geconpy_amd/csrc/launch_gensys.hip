@@ -10,54 +10,12 @@ namespace dsge_host {
 long long* g_gensys_win_dbg = nullptr;  // debug: device int64[32], phase stamps of draw 0 of the window kernels
 
 namespace {
-struct GwArena {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipStream_t stream = nullptr;
-  bool used = false;
-};
-// One workspace per (device, stream): the chunked host path keeps two pipelines in flight on two streams, and a
-// workspace shared between them would be overwritten by the next chunk's reduce launch while the previous chunk's QZ /
+// One workspace per (device, stream) (StreamArenaPool): the chunked host path keeps two pipelines in flight on two streams, and
+// a workspace shared between them would be overwritten by the next chunk's reduce launch while the previous chunk's QZ /
 // post launches still read it.
-constexpr int GW_SLOTS = 16;
-GwArena g_gw_arena[16][GW_SLOTS];
+StreamArenaPool g_gw_pool;
 constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
-
-std::mutex g_arena_mutex;  // host threads may call into the library concurrently (ctypes releases the GIL)
-
-int gw_reserve(size_t bytes, hipStream_t st, void** out) {
-  std::lock_guard<std::mutex> lk(g_arena_mutex);
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
-  GwArena* a = nullptr;
-  for (auto& slot : g_gw_arena[dev])
-    if (slot.used && slot.stream == st) a = &slot;
-  if (!a)
-    for (auto& slot : g_gw_arena[dev])
-      if (!slot.used) {
-        a = &slot;
-        break;
-      }
-  if (!a) {  // more streams than slots: recycle the first one once everything in flight has finished
-    HIP_TRY(hipDeviceSynchronize());
-    a = &g_gw_arena[dev][0];
-  }
-  a->used = true;
-  a->stream = st;
-  if (a->cap < bytes) {
-    if (a->ptr) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(a->ptr));
-      a->ptr = nullptr;
-      a->cap = 0;
-    }
-    HIP_TRY(hipMalloc(&a->ptr, bytes));
-    a->cap = bytes;
-  }
-  *out = a->ptr;
-  return DSGE_SUCCESS;
-}
+int gw_reserve(size_t bytes, hipStream_t st, void** out) { return g_gw_pool.reserve(bytes, st, out); }
 
 // bk != nullptr: eigenvalue mode (reduce + QZ + gensys_bk_kernel instead of the post-processing)
 struct BkOut {

@@ -2,6 +2,7 @@
 #include <mutex>
 
 #include "dsge_host.hpp"
+#include "dsge_kalman_out.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
 #include "dsge_kalman_nt.hpp"
@@ -16,49 +17,8 @@ int32_t* g_kalman_steady_at = nullptr;
 
 namespace {
 // hand-off records of the fast kernel for kalman_tail_kernel: one buffer per (device, stream), grown on demand
-struct TailArena {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipStream_t stream = nullptr;
-  bool used = false;
-};
-TailArena g_tail_arena[16][16];
-
-std::mutex g_arena_mutex;  // host threads may call into the library concurrently (ctypes releases the GIL)
-
-int tail_reserve(size_t bytes, hipStream_t st, void** out) {
-  std::lock_guard<std::mutex> lk(g_arena_mutex);
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
-  TailArena* a = nullptr;
-  for (auto& slot : g_tail_arena[dev])
-    if (slot.used && slot.stream == st) a = &slot;
-  if (!a)
-    for (auto& slot : g_tail_arena[dev])
-      if (!slot.used) {
-        a = &slot;
-        break;
-      }
-  if (!a) {
-    HIP_TRY(hipDeviceSynchronize());
-    a = &g_tail_arena[dev][0];
-  }
-  a->used = true;
-  a->stream = st;
-  if (a->cap < bytes) {
-    if (a->ptr) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(a->ptr));
-      a->ptr = nullptr;
-      a->cap = 0;
-    }
-    HIP_TRY(hipMalloc(&a->ptr, bytes + bytes / 4));
-    a->cap = bytes + bytes / 4;
-  }
-  *out = a->ptr;
-  return DSGE_SUCCESS;
-}
+StreamArenaPool g_tail_pool;
+int tail_reserve(size_t bytes, hipStream_t st, void** out) { return g_tail_pool.reserve(bytes, st, out); }
 }  // namespace
 
 // dispatch key from the transition matrices themselves (any solver): see persistence_key_kernel
@@ -277,6 +237,24 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     }
   });
   return rc;
+}
+
+// per-step filter outputs (dsge_kalman_out.hpp)
+int launch_kalman_outputs(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched, const double* d,
+                          int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
+                          double jitter, double missing_fill, double* ll, double* a_pred, double* a_filt, double* p_pred,
+                          double* p_filt, int full_cov, int32_t* status, hipStream_t st) {
+  dsge::KoArgs a{};
+  a.T = T; a.RQR = RQR; a.P0 = P0; a.Z = Z; a.d = d; a.Hdiag = Hdiag; a.y = y; a.ll = ll; a.a_pred = a_pred; a.a_filt = a_filt;
+  a.p_pred = p_pred; a.p_filt = p_filt; a.status = status; a.batch = batch; a.m = m; a.p = p; a.T_len = T_len;
+  a.z_batched = z_batched; a.d_batched = d_batched; a.h_batched = h_batched; a.full_cov = full_cov; a.jitter = jitter;
+  a.missing_fill = missing_fill;
+  const size_t lds = dsge::ko_lds_doubles(m, p) * sizeof(double);
+  int rc;
+  if ((rc = set_lds(dsge::kalman_outputs_kernel, lds))) return rc;
+  hipLaunchKernelGGL(dsge::kalman_outputs_kernel, dim3(batch), dim3(dsge::KO_THREADS), lds, st, a);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
 }
 
 }  // namespace dsge_host

@@ -11,47 +11,8 @@ namespace dsge_host {
 long long* g_so_dbg = nullptr;  // debug: device int64[8], phase cycles of draw 0 of the filter kernel
 
 namespace {
-struct SoArena {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipStream_t stream = nullptr;
-  bool used = false;
-};
-SoArena g_so_arena[16][8];
-std::mutex g_so_mutex;
-int so_reserve(size_t bytes, hipStream_t st, void** out) {
-  std::lock_guard<std::mutex> lk(g_so_mutex);
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
-  SoArena* a = nullptr;
-  for (auto& slot : g_so_arena[dev])
-    if (slot.used && slot.stream == st) a = &slot;
-  if (!a)
-    for (auto& slot : g_so_arena[dev])
-      if (!slot.used) {
-        a = &slot;
-        break;
-      }
-  if (!a) {
-    HIP_TRY(hipDeviceSynchronize());
-    a = &g_so_arena[dev][0];
-  }
-  a->used = true;
-  a->stream = st;
-  if (a->cap < bytes) {
-    if (a->ptr) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(a->ptr));
-      a->ptr = nullptr;
-      a->cap = 0;
-    }
-    HIP_TRY(hipMalloc(&a->ptr, bytes + 4096));
-    a->cap = bytes + 4096;
-  }
-  *out = a->ptr;
-  return DSGE_SUCCESS;
-}
+StreamArenaPool g_so_pool;
+int so_reserve(size_t bytes, hipStream_t st, void** out) { return g_so_pool.reserve(bytes, st, out); }
 
 template <int MT>
 int launch_so_mt(const dsge::SoFilterArgs& fa, const dsge::SoLayout& lay, int nb, hipStream_t st, float* ms) {

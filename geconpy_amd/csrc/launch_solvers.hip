@@ -67,48 +67,8 @@ std::mutex g_defl_mutex;
 int g_static_hint[DSGE_MAX_N + 2];  // per model size n: lower bound of the number of static variables; 0 = not measured yet
 unsigned g_static_calls[DSGE_MAX_N + 2];
 bool g_static_hint_init = false;    // (stored as h + 1)
-struct DeflArena {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipStream_t stream = nullptr;
-  bool used = false;
-};
-DeflArena g_defl_arena[16][16];
-
-std::mutex g_defl_arena_mutex;
-int defl_reserve(size_t bytes, hipStream_t st, void** out) {
-  std::lock_guard<std::mutex> lk(g_defl_arena_mutex);
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return fail(DSGE_ERR_INVALID, "device index out of range");
-  DeflArena* a = nullptr;
-  for (auto& slot : g_defl_arena[dev])
-    if (slot.used && slot.stream == st) a = &slot;
-  if (!a)
-    for (auto& slot : g_defl_arena[dev])
-      if (!slot.used) {
-        a = &slot;
-        break;
-      }
-  if (!a) {
-    HIP_TRY(hipDeviceSynchronize());
-    a = &g_defl_arena[dev][0];
-  }
-  a->used = true;
-  a->stream = st;
-  if (a->cap < bytes) {
-    if (a->ptr) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(a->ptr));
-      a->ptr = nullptr;
-      a->cap = 0;
-    }
-    HIP_TRY(hipMalloc(&a->ptr, bytes + bytes / 4));
-    a->cap = bytes + bytes / 4;
-  }
-  *out = a->ptr;
-  return DSGE_SUCCESS;
-}
+StreamArenaPool g_defl_pool;
+int defl_reserve(size_t bytes, hipStream_t st, void** out) { return g_defl_pool.reserve(bytes, st, out); }
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 

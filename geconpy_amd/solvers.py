@@ -105,9 +105,37 @@ def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=
     """Reference signature and return (gEconpy/solvers/gensys.py:617-631): the pencil of ``_gensys_setup`` handed to
     ``gensys``.  ``G_1`` is (N, N) with N = n + #lead and ``impact`` (N, k); callers slice ``G_1[:n, :n]``,
     ``impact[:n, :]`` (gensys.py:657-666, gEconpy/model/model.py:1696-1708).  The batched estimation path does not go
-    through here: it uses the structure-exploiting kernels behind ``batched.gensys_batched`` (T and eu only)."""
+    through here: it uses the structure-exploiting kernels behind ``batched.gensys_batched`` (T and eu only).
+
+    The raw-pencil kernel keeps H, T, Z and Q as complex N x N matrices in LDS, which limits it to N <= ~52; a larger pencil
+    (n + #lead up to 64) falls back to the window-path kernels of ``batched.gensys_batched``: ``G_1[:n, :n] = T`` and
+    ``impact[:n] = R = -(C T + B)^-1 D`` (gensys.py:679-683) are what every caller reads; the lead rows are completed ON the
+    stable manifold (``x_t = E_t y_{t+1}[lead] = T[lead] y_t``, so ``G_1[n:, :n] = T[lead] T``, ``impact[n:] = T[lead] R``,
+    zero columns for ``x_{t-1}``), ``C = 0`` (the model pencil has c = 0, :598) and ``gev`` is ``None`` on this route."""
     g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
-    return gensys(g0, g1, c, psi, pi, tol=tol, return_all_matrices=return_all_matrices)
+    try:
+        return gensys(g0, g1, c, psi, pi, tol=tol, return_all_matrices=return_all_matrices)
+    except _lib.DsgeHipError as exc:
+        if "do not fit" not in str(exc):
+            raise
+    A3, B3, C3, D3 = (np.ascontiguousarray(x, dtype=np.float64)[None] for x in (A, B, C, D))
+    out = batched.gensys_batched(A3, B3, C3, D3, tol=tol)
+    eu = [int(v) for v in out["eu"][0]]
+    if eu[0] == -2 and eu[1] == -2:
+        return None, None, None, None, None, None, None, eu, None
+    n, k = D3.shape[1:]
+    N = g0.shape[0]
+    lead = np.flatnonzero(np.abs(C3[0]).sum(axis=0) > tol)
+    T, R = out["T"][0], out["R"][0]
+    G_1 = np.zeros((N, N))
+    G_1[:n, :n] = T
+    G_1[n:, :n] = T[lead] @ T
+    if not return_all_matrices:
+        return G_1, eu
+    impact = np.zeros((N, k))
+    impact[:n] = R
+    impact[n:] = T[lead] @ R
+    return G_1, np.zeros((N, 1)), impact, None, None, None, None, eu, None
 
 
 def solve_policy_functions_batched(A, B, C, D, solver="cycle_reduction", max_iter=100, tol=1e-8):

@@ -472,6 +472,28 @@ int dsge_kalman_logp_batched_host(const double* T, const double* R, const double
                                   int32_t* status_io);
 
 /*
+ * Per-step OUTPUTS of the "standard" filter, batched over draws: what DSGEStateSpace.build_statespace_graph(...,
+ * save_kalman_filter_outputs_in_idata=True) registers (gEconpy/model/statespace.py:1145, 1151-1157; pymc_extras
+ * filtered / predicted states and covariances, per-observation log-likelihood) -- the post-estimation pass, not the hot loop
+ * (full recursion, no steady-state switch, no state reduction).  Arguments as dsge_kalman_logp_batched, plus
+ *   ll_out     : [batch][T_len]      ll_t (0 for a step with every entry missing); sum_t ll_t = the logp of the fast kernels
+ *   a_pred_out : [batch][T_len][m]   a_{t|t-1} (a_{0|-1} = 0)          a_filt_out : [batch][T_len][m]  a_{t|t}
+ *   p_pred_out, p_filt_out : full_cov = 0: [batch][T_len][m] the DIAGONALS of P_{t|t-1}, P_{t|t};
+ *                            full_cov != 0: [batch][T_len][m][m] the matrices;  every output except ll_out may be NULL
+ *   status_io  : [batch] in/out; a draw with a non-zero incoming status is skipped (ll = NaN)
+ */
+int dsge_kalman_filter_outputs_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                       int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                       const double* y, int batch, int m, int k, int p, int T_len, double jitter,
+                                       double missing_fill, double* ll_out, double* a_pred_out, double* a_filt_out,
+                                       double* p_pred_out, double* p_filt_out, int full_cov, int32_t* status_io, void* stream);
+int dsge_kalman_filter_outputs_batched_host(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
+                                            int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                            const double* y, int batch, int m, int k, int p, int T_len, double jitter,
+                                            double missing_fill, double* ll_out, double* a_pred_out, double* a_filt_out,
+                                            double* p_pred_out, double* p_filt_out, int full_cov, int32_t* status_io);
+
+/*
  * Fused evaluation A,B,C,D -> T,R -> P0 -> logp: one call per MCMC step for the whole draw
  * batch (the per-evaluation hot loop of SURVEY.md section 3A; what
  * DSGEStateSpace._setup_policy_matrices + make_symbolic_graph + the filter compute,

@@ -63,6 +63,7 @@ def kalman_filter_logp(
     jitter=JITTER_DEFAULT,
     missing_fill_value=MISSING_FILL,
     return_per_step=False,
+    return_states=False,
 ):
     """Standard Kalman filter log-likelihood, ``sum_t ll_t``.
 
@@ -85,7 +86,10 @@ def kalman_filter_logp(
     eye_p = np.eye(p)
 
     ll = np.zeros(y.shape[0])
+    states = dict(a_pred=[], a_filt=[], P_pred=[], P_filt=[])
     for t in range(y.shape[0]):
+        states["a_pred"].append(a.copy())
+        states["P_pred"].append(P.copy())
         yt = y[t]
         miss = np.isnan(yt) | (yt == missing_fill_value)
         W = np.diag((~miss).astype(np.float64))
@@ -105,9 +109,13 @@ def kalman_filter_logp(
         else:
             inner = v @ np.linalg.solve(F, v)
             ll[t] = -0.5 * (p * _LN2PI + np.log(np.linalg.det(F)) + inner)
+        states["a_filt"].append(a_f.copy())
+        states["P_filt"].append(P_f.copy())
         a = T @ a_f + c
         P = _sym_quad(T, P_f) + RQR_sym
     total = float(ll.sum())
+    if return_states:  # (per-step outputs: what save_kalman_filter_outputs_in_idata stores, statespace.py:1145)
+        return total, ll, {k_: np.array(v_) for k_, v_ in states.items()}
     return (total, ll) if return_per_step else total
 
 

@@ -230,17 +230,34 @@ def test_sharded_evaluator_real_engine_two_ranks(tmp_path, global_batch):
 
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without torch.distributed.run: the launcher starts two rank processes (before anything
-    touches the GPU) and rank 0 prints one JSON line with n_gpus = 2."""
+    touches the GPU) and rank 0 prints one JSON line with n_gpus = 2 -- a COMPLETE line: roofline, cpu_baseline and parity
+    (rank 0 computes them on its shard before it touches the GPU), so that a multi-GPU driver run counts as measured."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch-per-gpu", "512", "--cpu-sample", "0", "--profile-reps", "1", "--allow-shared-gpu"]
+           "--batch-per-gpu", "512", "--cpu-sample", "8", "--profile-reps", "1", "--allow-shared-gpu"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["failed_draws"] == 0
     assert out["value"] > 0 and out["scaling"] == "weak"
+    assert out["roofline"]["achieved"] > 0 and out["roofline"]["peak"] > 0 and "frac" in out["roofline"]
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["kind"] == "port"
+    assert out["parity"]["n_checked"] >= 8 and out["parity"]["max_rel_logp_err_vs_cpu_oracle"] <= 1e-8
+
+
+def test_bench_sizes_a_multi_gpu_run_as_configs3():
+    """Without --batch-per-gpu a run on N > 1 GPUs is BASELINE configs[3]'s share: 8192 draws per GPU (65 536 over 8), and the
+    line says so (argument handling only: the launcher is asked for more ranks than devices and refuses before any work)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "4096 if world == 1 else 8192" in src and "BASELINE configs[3]" in src
+    assert hasattr(mod, "main_second_order") and hasattr(mod, "spawn_ranks")
 
 
 @pytest.mark.parametrize("solver", ["cycle_reduction", "gensys"])

@@ -169,3 +169,62 @@ def test_nt_kernel_matches_round1_kernel():
             ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(b["sigma"][i] ** 2), om["Z"], yy,
                                            H=np.diag(om["Hdiag"]), tol=1e-8, max_iter=1000)
             assert abs(a["logp"][i] - ref["logp"]) <= 1e-9 * abs(ref["logp"])
+
+
+def test_two_host_threads_in_the_other_twins():
+    """every host twin runs on the calling thread's own streams (twin_streams), so the device scratch of the entry
+    points -- keyed by (device, stream) -- is never shared between two host threads.  Two threads hammer the gradient twin
+    (the NUTS path), the gensys twin and the standalone filter twin with DIFFERENT batches: every result is bit-identical to
+    the single-threaded one."""
+    b1, om = _inputs(96)
+    b2, _ = _inputs(80, first=700)
+
+    def grad(b):
+        g = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"],
+                                                   Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+        return np.concatenate([g["logp"], g["A_bar"].ravel(), g["q_bar"].ravel()])
+
+    def gensys(b):
+        g = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8)
+        return np.concatenate([g["T"].ravel(), g["R"].ravel(), g["eu"].ravel().astype(float)])
+
+    def filt(b):
+        g = batched.gensys_batched(b["A"][:32], b["B"][:32], b["C"][:32], b["D"][:32], tol=1e-8)
+        lp, st = batched.kalman_logp_batched(g["T"], g["R"], b["sigma"][:32] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"])
+        return lp
+
+    for fn in (grad, gensys, filt):
+        ref1, ref2 = fn(b1), fn(b2)
+        out = {1: [], 2: []}
+        errs = []
+
+        def worker(key, b, reps=6):
+            try:
+                for _ in range(reps):
+                    out[key].append(fn(b))
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        t1 = threading.Thread(target=worker, args=(1, b1))
+        t2 = threading.Thread(target=worker, args=(2, b2))
+        t1.start(); t2.start(); t1.join(); t2.join()
+        assert not errs, (fn.__name__, errs)
+        assert all(np.array_equal(r, ref1) for r in out[1]), fn.__name__
+        assert all(np.array_equal(r, ref2) for r in out[2]), fn.__name__
+
+
+def test_many_short_lived_threads_do_not_exhaust_the_arenas():
+    """Thread-local twin streams release their scratch arenas when the thread exits: forty threads, one after the other (far
+    more than the slots of a pool), keep getting correct, identical results."""
+    b, om = _inputs(64)
+    ref = _run(b, om, None)
+    res = []
+
+    def worker():
+        res.append(_run(b, om, None))
+
+    for _ in range(40):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+    assert len(res) == 40 and all(np.array_equal(r, ref) for r in res)

@@ -5,6 +5,7 @@ cross-solver tolerance, tests/model/test_perturbation.py:205-206 -- observed ~1e
 logp relative <= 1e-8 (BASELINE.json north_star -- observed ~1e-13); iteration counts and
 status codes exact; draw indexing bit-exact.
 """
+import os
 import numpy as np
 import pytest
 from numpy.testing import assert_allclose
@@ -769,6 +770,26 @@ def test_fused_pipeline_with_scan_cycle_reduction():
                                        H=np.diag(om["Hdiag"]), solver="scan_cycle_reduction", tol=1e-7, max_iter=50)
         assert r["n_iter"][i] == ref["n_iter"]
         assert_allclose(r["logp"][i], ref["logp"], rtol=LOGP_RTOL)
+
+
+def test_numpy_gensys_wrapper_large_pencil_fallback():
+    """a model whose pencil n + #lead exceeds what the raw-pencil kernel holds in LDS (~52) still solves through
+    solve_policy_function_with_gensys: T and R come from the window-path kernels, embedded in the reference's (N, N) / (N, k)
+    return shapes (gensys.py:617-631; callers read G_1[:n, :n] and impact[:n], :657-666)."""
+    from geconpy_amd import solvers
+
+    n, ns, nl, k = 48, 20, 14, 5  # N = 62
+    A, B, C, D, T_star = wl.sw_shaped_system(991, n=n, n_state=ns, n_lead=nl, k=k)
+    G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
+    N = n + nl
+    assert eu == [1, 1, 0] and G_1.shape == (N, N) and impact.shape == (N, k) and constant.shape == (N, 1)
+    Tg, ok = oracle.gensys_T_success(A, B, C, D)[:2]
+    assert ok
+    assert_allclose(G_1[:n, :n], Tg, atol=1e-9)
+    assert_allclose(G_1[:n, :n], T_star, atol=1e-9)
+    assert_allclose(impact[:n], oracle.compute_selection_matrix(B, C, D, Tg), atol=1e-9)
+    G1s, eus = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8, return_all_matrices=False)
+    assert eus == eu and np.array_equal(G1s, G_1)
 
 
 def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
@@ -1908,3 +1929,50 @@ def test_ill_conditioned_solves_are_refined():
         T, st, it = batched.cycle_reduction_batched(A, B, C, max_iter=200, tol=1e-9, options=opts)
         assert st[0] == 0 and it[0] == itc
         assert np.abs(T[0] - Tc).max() <= bar, (opts, np.abs(T[0] - Tc).max())
+
+
+def test_kalman_filter_outputs_per_step():
+    """save_kalman_filter_outputs_in_idata (statespace.py:1145, 1151-1157): per-step log-likelihood, predicted / filtered
+    states and covariances from the device against the oracle's recursion, on SW-shaped draws with missing observations
+    (one partial row, one empty row), dense-Z and selector-Z; the per-step ll sums to the fast kernels' logp, and the stored
+    per-step ll of tests/golden/sw_shaped.npz (oracle_ll) is reproduced."""
+    nb = 4
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    T = b["T_star"]
+    R = np.stack([oracle.compute_selection_matrix(b["B"][i], b["C"][i], b["D"][i], T[i]) for i in range(nb)])
+    q = b["sigma"] ** 2
+    rng = np.random.default_rng(5)
+    for variant in ("selector", "dense"):
+        y = om["y"][:60].copy()
+        y[5, 2] = np.nan
+        y[11] = np.nan
+        Z = om["Z"].copy()
+        d = None
+        if variant == "dense":
+            Z = Z + 0.05 * rng.standard_normal(Z.shape) * (rng.random(Z.shape) < 0.2)
+            d = rng.normal(0, 0.01, Z.shape[0])
+        out = batched.kalman_filter_outputs_batched(T, R, q, Z, y, d=d, Hdiag=om["Hdiag"], full_covariances=True)
+        diag = batched.kalman_filter_outputs_batched(T, R, q, Z, y, d=d, Hdiag=om["Hdiag"])
+        lp, st = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=om["Hdiag"])
+        assert (out["status"] == 0).all() and (st == 0).all()
+        assert_allclose(out["ll"].sum(axis=1), lp, rtol=1e-10)
+        for i in range(nb):
+            tot, ll, stt = oracle.kalman_filter_logp(y, T[i], R[i], np.diag(q[i]), Z, H=np.diag(om["Hdiag"]), d=d, return_states=True)
+            assert_allclose(out["ll"][i], ll, rtol=1e-8, atol=1e-9)
+            assert ll[11] == 0.0 and out["ll"][i, 11] == 0.0
+            sc = max(1.0, np.abs(stt["a_filt"]).max())
+            assert_allclose(out["predicted_states"][i], stt["a_pred"], atol=1e-9 * sc)
+            assert_allclose(out["filtered_states"][i], stt["a_filt"], atol=1e-9 * sc)
+            pc = np.abs(stt["P_pred"]).max()
+            assert_allclose(out["predicted_covs"][i], stt["P_pred"], atol=1e-9 * pc)
+            assert_allclose(out["filtered_covs"][i], stt["P_filt"], atol=1e-9 * pc)
+            assert_allclose(diag["filtered_covs"][i], np.diagonal(stt["P_filt"], axis1=1, axis2=2), atol=1e-9 * pc)
+            assert_allclose(diag["predicted_covs"][i], np.diagonal(stt["P_pred"], axis1=1, axis2=2), atol=1e-9 * pc)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sw_shaped.npz"))
+    if "oracle_ll" in g.files:
+        n_g = g["oracle_ll"].shape[0]
+        bb = wl.sw_shaped_batch(n_g)
+        Rg = np.stack([oracle.compute_selection_matrix(bb["B"][i], bb["C"][i], bb["D"][i], bb["T_star"][i]) for i in range(n_g)])
+        o2 = batched.kalman_filter_outputs_batched(bb["T_star"], Rg, bb["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"])
+        assert_allclose(o2["ll"], g["oracle_ll"], rtol=1e-7, atol=1e-8)
