@@ -140,7 +140,11 @@ int launch_second_order(const double* B, const double* C, const double* T, const
     fa.T_len = T_len;
     fa.jitter = jitter;
     fa.missing_fill = missing_fill;
-    fa.steady_tol = opt().kalman_steady_tol;
+    // The scale-free test of the second-order filter ((dP_ij)^2 <= tol^2 P_ii P_jj for EVERY entry of a 207 x 207 matrix whose
+    // entries are sums of 207 products) meets its own rounding noise at ~1e-14: with the option's default the covariance of
+    // one draw in twenty never "stops" (profiles/r3/so_steady_tol_sweep.txt).  100 x the option value (1e-12 by default) moves
+    // logp by 3.6e-14 relative against the full recursion -- the level the first-order kernels' max-norm test has at 1e-14.
+    fa.steady_tol = 100.0 * opt().kalman_steady_tol;
     float* msl = time_it ? ms : nullptr;
     switch (mt) {
       case 2: rc = launch_so_mt<2>(fa, lay, nb, st, msl); break;

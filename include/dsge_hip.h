@@ -651,6 +651,8 @@ int dsge_solve_kalman_logp_grad_batched_host_opt(const dsge_options* opt, const 
  *              A draw that violates the structure gets DSGE_ST_SECOND_ORDER_UNSUPPORTED and logp = -inf.
  *   T_out, R_out, gyy_out [batch][n][n_state][n_state], gyu_out [batch][n][n_state][k], guu_out [batch][n][k][k],
  *   gss_out [batch][n] : optional
+ * The steady-state switch (dsge_options.kalman_steady_tol) applies with a scale-free test, (dP_ij)^2 <= (100 tol)^2 P_ii P_jj
+ * for every entry; tol = 0 runs the full recursion.
  *   stage_ms : HOST float[4] or NULL; non-NULL makes the call synchronise and report the durations (ms) of the first-order
  *              solve, the coefficient / pruned-system set-up, the stationary covariance and the filter (last chunk)
  */

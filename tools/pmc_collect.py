@@ -30,7 +30,7 @@ GROUPS = {
              "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_WAVES",
     "sq1": "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU "
            "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS",
-    "sq2": "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_SCA",
+    "sq2": "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES",
 }
 
 
