@@ -658,7 +658,7 @@ __device__ __forceinline__ bool adj_stein_solve(double* W, double* Tk, const dou
 // S += solve(rho), added to all three outputs.  Inlined into the first pass the second solve cost every draw 1.1-1.6 KB of
 // scratch (round 2); behind a device function call the kernel loses the 256 accumulation registers its 40-wide instance
 // spills into; measuring the residual in the first pass cost it 30 % (1.05 -> 1.37 ms per 4096 draws).
-constexpr double ADJ_REFINE_GROWTH = 100.0;
+constexpr double ADJ_REFINE_GROWTH = 150.0;  // (error <~ 5e-14 x growth^2: 1e-9 at ~140; 3..6 % of the SW-shaped draws are above 100)
 
 template <int BS, bool REFINE>
 __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS = 3: 258 registers without the bound)
@@ -673,9 +673,6 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
   double* Tk = W + NP * LDW;    // C at first, then the Gauss-Jordan scratch, then T^(2^k)
   double* Ts = W + 2 * NP;      // T (row stride LDW): before W is filled, and again for the final products
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
-  if constexpr (REFINE) {
-    if (rerun_pass_is_empty(status, batch)) return;
-  }
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     double Sb[BS][BS];

@@ -51,7 +51,8 @@ int launch_adjoint(const double* B, const double* C, const double* T, const doub
                          batch, n, Ab, Bb, Cb, status, accumulate, g_adj_refine_mode);
       HIP_TRY(hipGetLastError());
       // second pass: one step of iterative refinement for the draws whose Stein residual the first pass flagged (normally none)
-      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, true>), dim3(rerun_grid(batch)), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C,
+      // (one workgroup per draw: a flagged draw costs a whole solve, two of them behind each other in one workgroup twice that)
+      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, true>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C,
                          T, Tbar, batch, n, Ab, Bb, Cb, status, 1, 0);
       HIP_TRY(hipGetLastError());
     }

@@ -5,7 +5,8 @@ import numpy as np, torch
 from geconpy_amd import workloads as wl
 from geconpy_amd.engine import LogpEngine
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-b = wl.sw_shaped_batch(min(nb, 64)); om = wl.sw_shaped_observation_model(); rep = (nb + 63) // 64
+nd = min(nb, 4096)  # distinct draws (a tiled small set clusters the draws that take second passes)
+b = wl.sw_shaped_batch(nd); om = wl.sw_shaped_observation_model(); rep = (nb + nd - 1) // nd
 eng = LogpEngine(0)
 A, B, C, D = (eng.to_device(np.tile(b[x], (rep, 1, 1))[:nb]) for x in "ABCD")
 q = eng.to_device(np.tile(b["sigma"] ** 2, (rep, 1))[:nb]); Z = eng.to_device(om["Z"]); y = eng.to_device(om["y"]); H = eng.to_device(om["Hdiag"])
