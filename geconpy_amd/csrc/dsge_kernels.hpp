@@ -647,6 +647,102 @@ __device__ __forceinline__ bool adj_stein_solve(double* W, double* Tk, const dou
   return ok;
 }
 
+// The fall-back of the second pass: X <- -M^-T (T_bar + C' X T') with an ELIMINATION per sweep instead of powers of an explicit
+// G = -M^-T C'.  When M = B + C T is nearly singular (SW-shaped draw 752: cond 3e8, max|G| = 2e7) G is only known to
+// cond x eps x |G| ~ 0.6 in absolute terms: its computed powers explode (true |G^16| = 1.7e5, float64 1e25) and even the plain
+// fixed point with the explicit G stalls at 3 % -- the eigenvalues of G are the reciprocals of the unstable roots, well
+// conditioned as functions of (M, C) but not as functions of the entries of G.  A backward-stable solve per sweep is a sweep
+// with a slightly perturbed M: it contracts at rho(G) rho(T) (0.53 per sweep on that draw, 30 sweeps) down to the level of the
+// reference's Kronecker LU (5e-9 of exact against 1.5e-8, tools/adjoint_fixed_point_model.py).  Starts from the first
+// pass's S (zero when that pass failed) and returns the CORRECTION X - S in Sb and in the second column group of W.
+constexpr int ADJ_FP_MAX_SWEEPS = 200;
+constexpr double ADJ_FP_RESIDUAL = 1e-4;  // relative Stein residual of the first pass above which the second pass eliminates
+template <int BS>
+__device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, const double* __restrict__ B,
+                                                      const double* __restrict__ C, const double* __restrict__ T,
+                                                      const double* __restrict__ T_bar, const double* __restrict__ S0, size_t off,
+                                                      int n, double (&Sb)[BS][BS], int lane) {
+  constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
+  double* Ts = W + 2 * NP;
+  double* Lbuf = Tk;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 3 * NP);
+  const int lr = lane >> 3, lc = lane & 7;
+  wave_sync();
+  lds_load_matrix(W + NP, LDW, NP, NP, S0 + off, n, n, lane);  // X_0
+  lds_load_matrix(Ts, LDW, NP, NP, T + off, n, n, lane);
+  wave_sync();
+  bool ok = false;
+  double best = 1e300;
+  int since = 0;  // sweeps since the step last shrank by 10 % (the steps of a complex pair of modes are not monotone)
+  for (int sweep = 0; sweep < ADJ_FP_MAX_SWEEPS; ++sweep) {
+    {
+      double P1[BS][BS];
+      blk_zero<BS>(P1);
+      mm_acc<BS, true>(P1, W + NP, LDW, Ts, LDW, n, lr, lc);  // X T'
+      wave_sync();
+      blk_store_lds<BS>(P1, W, LDW, lr, lc);
+    }
+    lds_load_matrix(Tk, LD, NP, NP, C + off, n, n, lane);  // the elimination's scratch lives here: C comes back every sweep
+    wave_sync();
+    double Xo[BS][BS];
+    blk_load_lds<BS>(Xo, W + NP, LDW, lr, lc);
+    {
+      double Rr[BS][BS], Mb[BS][BS];
+      blk_load_global<BS>(Rr, T_bar + off, n, n, n, lr, lc);
+      mm_acc_ta<BS>(Rr, Tk, LD, W, LDW, n, lr, lc);  // T_bar + C' X T'
+      blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
+      mm_acc<BS, false>(Mb, Tk, LD, Ts, LDW, n, lr, lc);  // M = B + C T
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) W[(lc * BS + j) * LDW + lr * BS + i] = Mb[i][j];  // M'
+      blk_store_lds<BS>(Rr, W + NP, LDW, lr, lc);
+    }
+    gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
+    gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+    double Xn[BS][BS], Df[BS][BS];
+    blk_load_lds<BS>(Xn, W + NP, LDW, lr, lc);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        Xn[i][j] = -Xn[i][j];
+        Df[i][j] = Xn[i][j] - Xo[i][j];
+      }
+    blk_store_lds<BS>(Xn, W + NP, LDW, lr, lc);
+    const double dmax = blk_maxabs<BS>(Df), xmax = blk_maxabs<BS>(Xn);
+    wave_sync();
+    if (!(dmax == dmax) || !(xmax < 1e300)) break;
+    if (dmax < 0.9 * best) {
+      best = dmax;
+      since = 0;
+    } else {
+      ++since;
+    }
+    // converged, or at the noise floor of an ill-conditioned M (the step is small and has stopped shrinking)
+    if (dmax <= 1e-15 * xmax || (dmax <= 1e-6 * xmax && since >= 8)) {
+      ok = true;
+      break;
+    }
+  }
+  {
+    double t0[BS][BS];
+    blk_load_global<BS>(t0, S0 + off, n, n, n, lr, lc);
+    blk_load_lds<BS>(Sb, W + NP, LDW, lr, lc);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Sb[i][j] -= t0[i][j];
+    blk_store_lds<BS>(Sb, W + NP, LDW, lr, lc);
+    wave_sync();
+  }
+  return ok;
+}
+
 // REFINE = false: the solve and the outputs.  The doubling sums S = sum_k G^k H F^k; when the powers of G = -(B + C T)^-T C'
 // grow before they decay (a non-normal G) it loses digits -- 6e-7 relative on 1 of ~160 random systems where the reference's
 // Kronecker LU (shared.py:53-71) keeps 1e-12.  The loss follows max_k max|G^(2^k)| closely (numpy emulation of the iteration
@@ -709,12 +805,31 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
       }
       wave_sync();
       mm_acc_ta<BS>(Rr, Tk, LD, W, LDW, n, lr, lc);       // + C' P1
-      ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Rr, Sb, lane, gmax);  // the correction dS (also in W's second group)
+      double tmax;
+      {
+        double t0[BS][BS];
+        blk_load_global<BS>(t0, T_bar + off, n, n, n, lr, lc);
+        tmax = blk_maxabs<BS>(t0);
+      }
+      const double rmax = blk_maxabs<BS>(Rr);
+      if (rmax <= ADJ_FP_RESIDUAL * tmax)
+        ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Rr, Sb, lane, gmax);  // the correction dS (also in W's second group)
+      else  // the first pass broke down or is far off: no power of G can be trusted
+        ok = adj_stein_fixed_point<BS>(W, Tk, B, C, T, T_bar, A_bar, off, n, Sb, lane);
     } else {
       double Hb[BS][BS];
       blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);
       ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax);
-      flag = ok && (refine_mode ? refine_mode == 1 : gmax > ADJ_REFINE_GROWTH);  // (debug hook: every draw / none)
+      // (debug hook: refine_mode 1 = every draw, 2 = none).  A solve that broke down -- the computed powers of G exploded --
+      // leaves zeros and goes to the second pass as well, which then takes its elimination-based fall-back
+      flag = refine_mode ? refine_mode == 1 : (!ok || gmax > ADJ_REFINE_GROWTH);
+      if (!ok && flag) {
+        blk_zero<BS>(Sb);
+        wave_sync();
+        blk_store_lds<BS>(Sb, W + NP, LDW, lr, lc);
+        wave_sync();
+        ok = true;
+      }
     }
     const bool acc_out = REFINE || accumulate;
     if constexpr (REFINE) {

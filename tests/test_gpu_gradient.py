@@ -307,3 +307,45 @@ def test_policy_adjoint_refinement_pass(n, ns, nl):
     # (in working precision a refinement step cannot go below ~cond x u: it may move a 1e-12 solution to 1e-11)
     assert (errs[1] <= np.maximum(errs[2], 1e-10)).all(), errs
     assert (errs[0] <= 1e-9).all() and (errs[1] <= 1e-9).all(), errs
+
+
+def test_policy_adjoints_of_a_nearly_singular_draw():
+    """SW-shaped draw 752: M = B + C T has cond 3e8 and G = -M^-T C' entries of 2e7, so G is known to ~0.6 in absolute terms,
+    its float64 powers explode (true |G^16| = 1.7e5, computed 1e25) and the doubling of the first pass breaks down.  The
+    second pass then falls back to X <- -M^-T (T_bar + C' X T') with an elimination per sweep (adj_stein_fixed_point;
+    tools/adjoint_fixed_point_model.py is its CPU model).  Adjudicated in 50-digit arithmetic: the reference's Kronecker LU
+    (shared.py:53-71) is 1.5e-8 from the exact S on this draw; the device has to be within 5e-8 of the exact S, T-side
+    products included, and the gradient entry point must return a clear status and finite cotangents for the draw."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from adjoint_fixed_point_model import exact_stein
+
+    b = wl.sw_shaped_batch(760)
+    om = wl.sw_shaped_observation_model()
+    sl_ = slice(748, 756)
+    A, B, C, D = (b[x][sl_] for x in "ABCD")
+    T, st, _ = batched.cycle_reduction_batched(A, B, C, tol=1e-8, max_iter=1000)
+    assert (st == 0).all()
+    T_bar = np.random.default_rng(1).standard_normal(T.shape)
+    Ab, Bb, Cb, st = batched.policy_adjoints_batched(B, C, T, T_bar)
+    assert (st == 0).all(), st
+    i = 4  # draw 752
+    Sx = exact_stein(B[i], C[i], T[i], T_bar[i], terms=90)
+    ref = oracle.policy_function_adjoints(A[i], B[i], C[i], T[i], T_bar[i])
+    sc = np.abs(Sx).max()
+    err_ref = np.abs(ref[0] - Sx).max() / sc
+    err_dev = np.abs(Ab[i] - Sx).max() / sc
+    assert err_ref <= 5e-8 and err_dev <= 5e-8, (err_ref, err_dev)
+    assert np.abs(Bb[i] - Sx @ T[i].T).max() <= 5e-8 * np.abs(Sx @ T[i].T).max()
+    assert np.abs(Cb[i] - Sx @ T[i].T @ T[i].T).max() <= 5e-8 * np.abs(Sx @ T[i].T @ T[i].T).max()
+    # the neighbours are ordinary draws: 1e-9 against the reference
+    for j in (0, 3, 5):
+        r = oracle.policy_function_adjoints(A[j], B[j], C[j], T[j], T_bar[j])
+        assert np.abs(Ab[j] - r[0]).max() <= 1e-9 * max(1.0, np.abs(r[0]).max())
+    g = batched.solve_kalman_logp_grad_batched(A, B, C, D, b["sigma"][sl_] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8,
+                                               max_iter=1000)
+    assert (g["status"] == 0).all(), g["status"]
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar"):
+        assert np.isfinite(g[key]).all(), key

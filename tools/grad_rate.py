@@ -16,4 +16,7 @@ for it in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
     out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-print(f"{nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {int((out['status'] != 0).sum())}")
+st = out["status"].cpu().numpy() if hasattr(out["status"], "cpu") else np.asarray(out["status"])
+bad = np.flatnonzero(st != 0)
+print(f"{nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {len(bad)}"
+      + (f" (draws {bad[:8].tolist()}, status words {st[bad[:8]].tolist()})" if len(bad) else ""))
