@@ -75,6 +75,7 @@ PROTOTYPES = {
     "dsge_set_pipeline_chunks": [_i],
     "dsge_set_kalman_block": [_i],
     "dsge_set_gensys_split": [_i],
+    "dsge_set_gensys_real_stage": [_i],
     "dsge_set_kalman_mfma": [_i],
     "dsge_set_kalman_steady_tol": [_f],
     "dsge_get_kalman_steady_tol": [],
@@ -155,7 +156,7 @@ class Options(C.Structure):
         ("kalman_nt_products", C.c_int32),
         ("cr_fused_deflation", C.c_int32),
         ("cr_four_waves", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("gensys_real_stage", C.c_int32),
     ]
 
 

@@ -133,6 +133,7 @@ struct OptionsGuard {
     local.kalman_nt_products = o->kalman_nt_products;
     local.cr_fused_deflation = o->cr_fused_deflation;
     local.cr_four_waves = o->cr_four_waves;
+    local.gensys_real_stage = o->gensys_real_stage;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -352,6 +353,10 @@ int dsge_set_cr_compact(int enable) {
 }
 int dsge_set_kalman_mfma(int enable) {
   g_defaults.kalman_mfma = enable ? 1 : 0;
+  return DSGE_SUCCESS;
+}
+int dsge_set_gensys_real_stage(int enable) {
+  g_defaults.gensys_real_stage = enable ? 1 : 0;
   return DSGE_SUCCESS;
 }
 int dsge_set_gensys_split(int enable) {
@@ -1910,6 +1915,7 @@ int dsge_options_init(dsge_options* o) {
   o->kalman_mfma = d.kalman_mfma;
   o->pipeline_chunks = d.pipeline_chunks;
   o->gensys_split = d.gensys_split;
+  o->gensys_real_stage = d.gensys_real_stage;
   o->kalman_steady_tol = d.kalman_steady_tol;
   o->kalman_nt_products = d.kalman_nt_products;
   o->cr_fused_deflation = d.cr_fused_deflation;

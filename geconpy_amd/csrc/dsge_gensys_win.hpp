@@ -245,6 +245,52 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
   }
 }
 
+// ---- real double-shift accelerator (round 3; model: tests/device_models/gensys_qz_model.py::real_double_shift_stage) ------
+// Implicit double-shift QZ sweeps in REAL arithmetic (Moler & Stewart; Golub & Van Loan, Algorithm 7.7.2) on the real
+// Hessenberg-triangular window while it is still in this launch's LDS, until every sub-diagonal block has shrunk to 1 x 1 or
+// 2 x 2 -- or until anything unusual turns up (a negligible diagonal entry of T inside the active block, 30 sweeps without a
+// deflation): the stage then simply stops.  Every transformation is an orthogonal equivalence that keeps the
+// Hessenberg-triangular form, so whatever it leaves is a valid input of the complex single-shift iteration of the next launch,
+// which owns all of zhgeqz's deflation logic and only has to split the remaining 2 x 2 blocks (12 sweep steps instead of
+// 1284 on the SW-shaped window).  A real step is a 3-row reflector from the left and a 3- and a 2-column reflector from the
+// right -- about half the FP64 operations of a complex step's two rotations -- and advances two shifts: ~780 steps.
+// A launch of its own (gensys_realqz_kernel) between the reduction and the complex iteration: the step is a latency chain
+// (two LDS round trips, three reflector generations), so it lives on occupancy, and it needs less LDS than either neighbour:
+// [H | X] (w x (w + #lead)) and T only -- 18 KB on the SW-shaped window, 9 draws per CU.  The accumulated right transformation
+// M is NOT on the chip: lane = row of M, consecutive steps work on columns k..k+2 and k+1..k+3, so two columns are carried in
+// registers, the finished column is stored and the next one prefetched a step ahead (M lives transposed in the draw's HBM
+// workspace, as for the complex iteration: a column is one run, one row per lane).
+// Mapping: left transformations with one column of [H | X] per lane (42 lanes busy) and one column of T per lane; right
+// transformations with one row of H and one row of T per lane; the vectors that define the reflectors travel through
+// registers (v_readlane).  Entries outside the bands are exact zeros and stay exact zeros under the reflectors: no masks.
+struct GwHouse {
+  double v1, v2, tau, beta;
+};
+// (I - tau v v') [x y z]' = [beta 0 0]', v = [1 v1 v2]; tau = 0 when y = z = 0.  The chain is what a sweep step waits for, three
+// times: 1/||.|| from v_rsq_f64 + two Newton steps, ONE reciprocal (1/(x - beta), v_rcp_f64 + two Newton steps) and
+// tau = (beta - x)/beta = (|x| + ||.||)/||.|| as a product -- ~150 dependent cycles instead of ~350 with sqrt() and two divisions.
+__device__ __forceinline__ GwHouse gw_house3(double x, double y, double z) {
+  // branch-free (a branch would split the sweep step into basic blocks the scheduler cannot interleave) and with ONE select:
+  // a vector with y = z = 0, or below 1e-140 in norm, gets tau = 0 (v stays finite, the reflector is the identity; the
+  // caller zeroes the targeted entries explicitly anyway).
+  GwHouse h;
+  const double xn2 = fma(y, y, z * z);
+  const double s2 = fma(x, x, xn2);
+  const bool ok = xn2 > 0.0 && s2 > 1e-280;
+  const double s2c = ok ? s2 : 1.0;
+  double rn = __builtin_amdgcn_rsq(s2c);
+  rn = rn * fma(-0.5 * s2c * rn, rn, 1.5);
+  rn = rn * fma(-0.5 * s2c * rn, rn, 1.5);
+  const double nrm = s2c * rn;
+  const double d = fabs(x) + nrm;                    // |x - beta|
+  const double inv = copysign(fast_rcp(d), x);       // 1 / (x - beta)
+  h.beta = ok ? -copysign(nrm, x) : x;
+  h.v1 = y * inv;
+  h.v2 = z * inv;
+  h.tau = ok ? d * rn : 0.0;
+  return h;
+}
+
 // ---- launch 1b: Hessenberg-triangular reduction of the window (real): T22 -> upper triangular by reflectors, H22 -> upper
 // Hessenberg by Givens pairs; the right transformation Zr is accumulated and handed over transposed and complex.
 __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp, double* __restrict__ ws,
@@ -388,6 +434,312 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
       wd[wo.XR + (size_t)i * cp.lcap + j] = xb[i * ldX + j];
     }
     GW_STAMP(4);
+  }
+}
+
+
+// ---- launch 1c: real double-shift QZ sweeps on the window (see gw_house3 above) --------------------------------------------
+__host__ __device__ inline size_t gw_realqz_smem(const GwCaps& c) {
+  return ((size_t)c.wcap * ((c.wcap + c.lcap) | 1) + (size_t)c.wcap * (c.wcap | 1)) * 8;
+}
+
+__global__ __launch_bounds__(64) void gensys_realqz_kernel(int batch, GwCaps cp, double* __restrict__ ws,
+                                                            long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
+  double* hb = smem;                          // [H | X]: X(i, j) at column wcap + j
+  double* tb = hb + (size_t)cp.wcap * ldH;
+  const GwOffsets wo = gw_offsets(cp);
+  constexpr double ULPD = 2.220446049250313e-16, SAFMIN = 2.2250738585072014e-308;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    double* wd = ws + (size_t)draw * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    if (meta[GW_FLAG] != 0) continue;
+    const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
+    if (w < 3 || w + ell > 64) continue;  // nothing to gain / the packed lane map does not fit: the complex iteration does it all
+    wave_sync();
+    GW_STAMP(6);
+    lane_loop_batched<4>(
+        w * w, lane,
+        [&](int idx) {
+          const int i = idx / w, j = idx - i * w;
+          const size_t o = (size_t)i * cp.wcap + j;
+          return double2{wd[wo.HR + o], wd[wo.TR + o]};
+        },
+        [&](int idx, double2 v) {
+          const int i = idx / w, j = idx - i * w;
+          hb[i * ldH + j] = v.x;
+          tb[i * ldW + j] = v.y;
+        });
+    lane_loop_batched<8>(
+        w * ell, lane,
+        [&](int idx) {
+          const int i = idx / ell, j = idx - i * ell;
+          return wd[wo.XR + (size_t)i * cp.lcap + j];
+        },
+        [&](int idx, double v) {
+          const int i = idx / ell, j = idx - i * ell;
+          hb[i * ldH + cp.wcap + j] = v;
+        });
+    wave_sync();
+    // M transposed and complex (real content): element (row, col) at MR[2 * (col * wcap + row)]
+    double* MR = wd + wo.MC;
+    const size_t mcol = 2 * (size_t)cp.wcap;
+    const bool wa = lane < w, la = lane < w + ell;
+    const int cw = min(lane, w - 1);                                        // column of T / row of H, T, M (loads)
+    const int ca = lane < w ? lane : (la ? cp.wcap + lane - w : 0);          // column of [H | X]
+    double btol;
+    {
+      double ss = 0.0;
+      if (wa)
+        for (int i = 0; i <= lane; ++i) {
+          const double t = tb[i * ldW + lane];
+          ss = fma(t, t, ss);
+        }
+      btol = fmax(SAFMIN, ULPD * sqrt(wave_sum(ss)));
+    }
+    int ilast = w - 1, it = 0;
+    long long steps = 0, sweeps = 0;
+    const int max_total = 40 * w;
+    for (int guard = 0; guard < max_total && ilast >= 2; ++guard) {
+      wave_sync();
+      // ---- deflation tests: one sub-diagonal entry per lane
+      double hjj = 0.0, hmm = 0.0, hsub = 0.0, tjj = 1.0;
+      if (wa) {
+        hjj = hb[lane * ldH + lane];
+        tjj = tb[lane * ldW + lane];
+        if (lane > 0) {
+          hsub = hb[lane * ldH + lane - 1];
+          hmm = hb[(lane - 1) * ldH + lane - 1];
+        }
+      }
+      const bool sm = wa && lane > 0 && fabs(hsub) <= fmax(SAFMIN, ULPD * (fabs(hjj) + fabs(hmm)));
+      const unsigned long long small = __ballot(sm);
+      const unsigned long long tzero = __ballot(wa && fabs(tjj) <= btol);
+      if ((small >> ilast) & 1ull) {
+        if (lane == 0) hb[ilast * ldH + ilast - 1] = 0.0;
+        ilast -= 1;
+        it = 0;
+        continue;
+      }
+      if ((small >> (ilast - 1)) & 1ull) {
+        if (lane == 0) hb[(ilast - 1) * ldH + ilast - 2] = 0.0;
+        ilast -= 2;  // a 2 x 2 block: the complex iteration splits it
+        it = 0;
+        continue;
+      }
+      int ifirst = 0;
+      {
+        const unsigned long long below = small & ((1ull << (ilast - 1)) - 1ull);  // bits 1 .. ilast-2
+        if (below) {
+          ifirst = 63 - __clzll((long long)below);
+          if (lane == 0) hb[ifirst * ldH + ifirst - 1] = 0.0;
+        }
+      }
+      {
+        const unsigned long long act = ((ilast >= 63) ? ~0ull : ((1ull << (ilast + 1)) - 1ull)) & ~((1ull << ifirst) - 1ull);
+        if (tzero & act) break;  // an infinite root inside the active block: zhgeqz's zero chasing lives in the next launch
+      }
+      if (++it > 30) break;
+      wave_sync();
+      // the first three columns of M for this sweep (in flight during the shift arithmetic)
+      double m0 = MR[(size_t)ifirst * mcol + 2 * cw], m1 = MR[(size_t)(ifirst + 1) * mcol + 2 * cw],
+             m2 = MR[(size_t)(ifirst + 2) * mcol + 2 * cw];
+      // ---- the first column of (M - s1)(M - s2), M = H T^-1 on the active block, shifts = roots of the trailing 2 x 2 pencil
+      double x, y, z;
+      {
+        const int m = ilast;
+        const double p_ = hb[(m - 1) * ldH + m - 1], q_ = hb[(m - 1) * ldH + m], r_ = hb[m * ldH + m - 1], s_ = hb[m * ldH + m];
+        const double e_ = tb[(m - 1) * ldW + m - 1], f_ = tb[(m - 1) * ldW + m], g_ = tb[m * ldW + m];
+        double tr, det;
+        if (it % 10 == 0) {  // exceptional shifts
+          const double w_ = 1.5 * (fabs(r_ / e_) + fabs(hb[(m - 1) * ldH + m - 2] / tb[(m - 2) * ldW + m - 2]));
+          tr = w_;
+          det = w_ * w_;
+        } else {
+          tr = p_ / e_ + (s_ - r_ * f_ / e_) / g_;
+          det = (p_ * s_ - q_ * r_) / (e_ * g_);
+        }
+        const int k = ifirst;
+        const double a11 = hb[k * ldH + k], a12 = hb[k * ldH + k + 1], a21 = hb[(k + 1) * ldH + k],
+                     a22 = hb[(k + 1) * ldH + k + 1], a32 = hb[(k + 2) * ldH + k + 1];
+        const double b11 = tb[k * ldW + k], b12 = tb[k * ldW + k + 1], b22 = tb[(k + 1) * ldW + k + 1];
+        const double m11 = a11 / b11, m21 = a21 / b11;
+        const double y2 = m21 / b22;
+        const double y1 = (m11 - b12 * y2) / b11;
+        x = a11 * y1 + a12 * y2 - tr * m11 + det;
+        y = a21 * y1 + a22 * y2 - tr * m21;
+        z = a32 * y2;
+      }
+      if (!(fabs(x) + fabs(y) + fabs(z) < 1e300)) break;  // NaN / overflow in the shift arithmetic: leave it to zhgeqz's logic
+      ++sweeps;
+      for (int k = ifirst; k <= ilast - 2; ++k) {
+        // the column of M the NEXT step brings in (consumed at the end of this one)
+        const double m3 = MR[(size_t)min(k + 3, w - 1) * mcol + 2 * cw];
+        // ---- left: rows k .. k+2; lane = column of [H | X] and column of T.  Loads unmasked, stores under one mask each.
+        double h0 = hb[k * ldH + ca], h1 = hb[(k + 1) * ldH + ca], h2 = hb[(k + 2) * ldH + ca];
+        double t0 = tb[k * ldW + cw], t1 = tb[(k + 1) * ldW + cw], t2 = tb[(k + 2) * ldW + cw];
+        const GwHouse q = gw_house3(x, y, z);
+        {
+          const double sh = q.tau * fma(q.v2, h2, fma(q.v1, h1, h0));
+          h0 -= sh;
+          h1 = fma(-sh, q.v1, h1);
+          h2 = fma(-sh, q.v2, h2);
+          const double st = q.tau * fma(q.v2, t2, fma(q.v1, t1, t0));
+          t0 -= st;
+          t1 = fma(-st, q.v1, t1);
+          t2 = fma(-st, q.v2, t2);
+        }
+        if (k > ifirst && lane == k - 1) {
+          h0 = q.beta;
+          h1 = 0.0;
+          h2 = 0.0;
+        }
+        if (la) {
+          hb[k * ldH + ca] = h0;
+          hb[(k + 1) * ldH + ca] = h1;
+          hb[(k + 2) * ldH + ca] = h2;
+        }
+        if (wa) {
+          tb[k * ldW + cw] = t0;
+          tb[(k + 1) * ldW + cw] = t1;
+          tb[(k + 2) * ldW + cw] = t2;
+        }
+        // row k+2 of T, columns k .. k+2: defines the 3-column reflector  [b0 b1 b2] Z1 = [0 0 *]
+        const double b0 = readlane_dyn_f64(t2, k), b1 = readlane_dyn_f64(t2, k + 1), b2 = readlane_dyn_f64(t2, k + 2);
+        wave_sync();
+        // ---- right: columns k .. k+2; lane = row of H, of T and of M
+        double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1], r2 = hb[cw * ldH + k + 2];
+        double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1], u2 = tb[cw * ldW + k + 2];
+        {
+          const GwHouse g1 = gw_house3(b2, b1, b0);  // reversed: v = [v2 v1 1] on columns k, k+1, k+2
+          const double sh = g1.tau * fma(g1.v2, r0, fma(g1.v1, r1, r2));
+          r0 = fma(-sh, g1.v2, r0);
+          r1 = fma(-sh, g1.v1, r1);
+          r2 -= sh;
+          const double st = g1.tau * fma(g1.v2, u0, fma(g1.v1, u1, u2));
+          u0 = fma(-st, g1.v2, u0);
+          u1 = fma(-st, g1.v1, u1);
+          u2 -= st;
+          const double sz = g1.tau * fma(g1.v2, m0, fma(g1.v1, m1, m2));
+          m0 = fma(-sz, g1.v2, m0);
+          m1 = fma(-sz, g1.v1, m1);
+          m2 -= sz;
+          if (lane == k + 2) {
+            u0 = 0.0;
+            u1 = 0.0;
+            u2 = g1.beta;
+          }
+        }
+        {
+          const double c0 = readlane_dyn_f64(u0, k + 1), c1 = readlane_dyn_f64(u1, k + 1);  // T[k+1][k], T[k+1][k+1] after Z1
+          const GwHouse g2 = gw_house3(c1, c0, 0.0);  // v = [v1 1] on columns k, k+1
+          const double sh = g2.tau * fma(g2.v1, r0, r1);
+          r0 = fma(-sh, g2.v1, r0);
+          r1 -= sh;
+          const double st = g2.tau * fma(g2.v1, u0, u1);
+          u0 = fma(-st, g2.v1, u0);
+          u1 -= st;
+          const double sz = g2.tau * fma(g2.v1, m0, m1);
+          m0 = fma(-sz, g2.v1, m0);
+          m1 -= sz;
+          if (lane == k + 1) {
+            u0 = 0.0;
+            u1 = g2.beta;
+          }
+        }
+        if (wa) {
+          hb[cw * ldH + k] = r0;
+          hb[cw * ldH + k + 1] = r1;
+          hb[cw * ldH + k + 2] = r2;
+          tb[cw * ldW + k] = u0;
+          tb[cw * ldW + k + 1] = u1;
+          tb[cw * ldW + k + 2] = u2;
+          MR[(size_t)k * mcol + 2 * cw] = m0;  // column k of M is final for this sweep
+        }
+        x = readlane_dyn_f64(r0, k + 1);
+        y = readlane_dyn_f64(r0, k + 2);
+        {
+          const double z3 = readlane_dyn_f64(r0, min(k + 3, 63));
+          z = (k + 3 <= ilast) ? z3 : 0.0;
+        }
+        m0 = m1;
+        m1 = m2;
+        m2 = m3;
+        wave_sync();
+        ++steps;
+      }
+      {  // ---- the last step of the sweep: two rows, two columns (m0, m1 = columns ilast-1, ilast of M)
+        const int k = ilast - 1;
+        double h0 = hb[k * ldH + ca], h1 = hb[(k + 1) * ldH + ca];
+        double t0 = tb[k * ldW + cw], t1 = tb[(k + 1) * ldW + cw];
+        const GwHouse q = gw_house3(x, y, 0.0);
+        {
+          const double sh = q.tau * fma(q.v1, h1, h0);
+          h0 -= sh;
+          h1 = fma(-sh, q.v1, h1);
+          const double st = q.tau * fma(q.v1, t1, t0);
+          t0 -= st;
+          t1 = fma(-st, q.v1, t1);
+        }
+        if (lane == k - 1) {
+          h0 = q.beta;
+          h1 = 0.0;
+        }
+        if (la) {
+          hb[k * ldH + ca] = h0;
+          hb[(k + 1) * ldH + ca] = h1;
+        }
+        if (wa) {
+          tb[k * ldW + cw] = t0;
+          tb[(k + 1) * ldW + cw] = t1;
+        }
+        const double c0 = readlane_dyn_f64(t1, k), c1 = readlane_dyn_f64(t1, k + 1);
+        wave_sync();
+        double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1];
+        double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1];
+        const GwHouse g2 = gw_house3(c1, c0, 0.0);
+        const double sh = g2.tau * fma(g2.v1, r0, r1);
+        r0 = fma(-sh, g2.v1, r0);
+        r1 -= sh;
+        const double st = g2.tau * fma(g2.v1, u0, u1);
+        u0 = fma(-st, g2.v1, u0);
+        u1 -= st;
+        const double sz = g2.tau * fma(g2.v1, m0, m1);
+        m0 = fma(-sz, g2.v1, m0);
+        m1 -= sz;
+        if (lane == k + 1) {
+          u0 = 0.0;
+          u1 = g2.beta;
+        }
+        if (wa) {
+          hb[cw * ldH + k] = r0;
+          hb[cw * ldH + k + 1] = r1;
+          tb[cw * ldW + k] = u0;
+          tb[cw * ldW + k + 1] = u1;
+          MR[(size_t)k * mcol + 2 * cw] = m0;
+          MR[(size_t)(k + 1) * mcol + 2 * cw] = m1;
+        }
+        ++steps;
+      }
+    }
+    wave_sync();
+    GW_STAMP(7);
+    for (int idx = lane; idx < w * w; idx += 64) {
+      const int i = idx / w, j = idx - i * w;
+      const size_t o = (size_t)i * cp.wcap + j;
+      wd[wo.HR + o] = hb[i * ldH + j];
+      wd[wo.TR + o] = tb[i * ldW + j];
+    }
+    for (int idx = lane; idx < w * ell; idx += 64) {
+      const int i = idx / ell, j = idx - i * ell;
+      wd[wo.XR + (size_t)i * cp.lcap + j] = hb[i * ldH + cp.wcap + j];
+    }
+    if (dbg && draw == 0 && lane == 0) {
+      dbg[27] = steps;
+      dbg[28] = sweeps;
+    }
   }
 }
 

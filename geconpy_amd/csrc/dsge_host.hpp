@@ -181,6 +181,7 @@ struct Options {
   int kalman_nt_products = 1;  // selector fast path: kalman_nt_kernel (NT prediction products, 16-byte LDS loads); 0 = kalman_sel_kernel
   int pipeline_chunks = 0;     // fused device call in chunks over library-owned streams
   int gensys_split = 1;        // 0 = single-launch gensys kernel, 1 = window path unless small, 2 = always
+  int gensys_real_stage = 1;   // window path: real double-shift sweeps in front of the complex single-shift iteration
   double kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never)
 };
 extern Options g_defaults;

@@ -121,7 +121,7 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
  *                        is a pure enqueue (stream-capturable); -1 (default) measures it on the device on the first
  *                        call of a model size: one small launch, a 4-byte read-back and a stream synchronisation
  *   kalman_nt_products  : see dsge_set_kalman_nt_products       cr_fused_deflation : see dsge_set_cr_fused_deflation
- *   cr_four_waves       : see dsge_set_cr_four_waves
+ *   cr_four_waves       : see dsge_set_cr_four_waves       gensys_real_stage  : see dsge_set_gensys_real_stage
  *   kalman_order, kalman_tiny, kalman_block, kalman_mfma, pipeline_chunks, gensys_split, kalman_steady_tol :
  *                        see the dsge_set_* function of the same name
  */
@@ -142,7 +142,7 @@ typedef struct dsge_options {
   int32_t kalman_nt_products;
   int32_t cr_fused_deflation;
   int32_t cr_four_waves;
-  int32_t reserved_;
+  int32_t gensys_real_stage; /* (the slot was reserved_ up to ABI 4 builds: same size, same offsets) */
 } dsge_options;
 /* fills *opt with the current process-wide defaults */
 int dsge_options_init(dsge_options* opt);
@@ -303,6 +303,12 @@ int dsge_set_kalman_block(int enable);
  * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
  * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
 int dsge_set_gensys_split(int enable);
+/* Window path of gensys: implicit double-shift QZ sweeps in REAL arithmetic (Moler-Stewart) at the end of the
+ * Hessenberg-triangular launch, in front of the complex single-shift iteration that reproduces zhgeqz's logic (which then only
+ * splits the remaining 2 x 2 blocks).  An accelerator: every step is an orthogonal equivalence, T and eu are the same to
+ * rounding (test_gensys_real_stage_matches_complex_only).  enable = 0: complex iteration only (round 1-2 behaviour).
+ * Process-wide DEFAULT (per call: dsge_options.gensys_real_stage); default 1. */
+int dsge_set_gensys_real_stage(int enable);
 /* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
  * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
  * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms

@@ -277,6 +277,122 @@ def qz_iterate(P, ilo=0, max_it_factor=30):
     return False
 
 
+def _house3(x):
+    """Reflector I - tau v v' (v[0] = 1) with (I - tau v v') x = beta e1, any length; tau = 0 when x[1:] = 0."""
+    alpha = x[0]
+    xn = np.sqrt(np.sum(x[1:] ** 2))
+    if xn == 0.0:
+        return np.zeros_like(x), 0.0
+    beta = -np.copysign(np.hypot(alpha, xn), alpha)
+    v = x / (alpha - beta)
+    v[0] = 1.0
+    return v, (beta - alpha) / beta
+
+
+def real_double_shift_stage(P, ilo=0, max_it=30):
+    """ACCELERATOR in front of qz_iterate (round 3): implicit double-shift QZ sweeps in REAL arithmetic (Moler & Stewart 1973;
+    Golub & Van Loan, Algorithm 7.7.2) on the real Hessenberg-triangular pencil the reduction hands over, until every
+    sub-diagonal block has shrunk to 1 x 1 or 2 x 2 -- or until anything unusual turns up (a negligible diagonal entry of T,
+    i.e. an infinite root inside the active block; 30 sweeps without a deflation): the stage then simply stops.  Every
+    transformation is an orthogonal equivalence that keeps the Hessenberg-triangular form, so whatever state it leaves is a
+    valid input for the complex single-shift iteration (qz_iterate), which owns all the deflation logic of zhgeqz and only has
+    to split the remaining 2 x 2 blocks.  A real sweep step costs two 3-row reflectors in real arithmetic and advances two
+    shifts; a complex single-shift step costs two complex rotations and advances one.
+    Returns (number of sweep steps, number of sweeps)."""
+    N = P.N
+    H, T, X, Z = P.H, P.T, P.X, P.Z  # complex storage, real content at this stage
+    if N - ilo <= 2:
+        return 0, 0
+    bnorm = np.linalg.norm(T[ilo:, ilo:].real)
+    btol = max(SAFMIN, ULP * bnorm)
+
+    def small(j):  # negligible H[j, j-1] (zhgeqz's test)
+        return abs(H[j, j - 1].real) <= max(SAFMIN, ULP * (abs(H[j, j].real) + abs(H[j - 1, j - 1].real)))
+
+    def left(k, nrow, x, c0):  # reflector from x on rows k..k+nrow-1, columns c0.. of H, from k of T, all of X
+        v, tau = _house3(np.array(x, dtype=float))
+        if tau == 0.0:
+            return
+        for M, cs in ((H, c0), (T, k), (X, 0)):
+            blk = M[k:k + nrow, cs:].real
+            M[k:k + nrow, cs:] = blk - tau * np.outer(v, v @ blk)
+
+    def right(k, ncol, rowvec, rmaxH, rmaxT):  # [rowvec] Zr = [0 .. 0 *] on columns k..k+ncol-1
+        v, tau = _house3(np.array(rowvec[::-1], dtype=float))
+        if tau == 0.0:
+            return
+        v = v[::-1]
+        for M, r1 in ((H, rmaxH), (T, rmaxT), (Z, Z.shape[0])):
+            blk = M[:r1, k:k + ncol].real
+            M[:r1, k:k + ncol] = blk - tau * np.outer(blk @ v, v)
+
+    ilast = N - 1
+    it = 0
+    steps = sweeps = 0
+    while ilast - ilo >= 2:
+        if small(ilast):
+            H[ilast, ilast - 1] = 0
+            ilast -= 1
+            it = 0
+            continue
+        if small(ilast - 1):
+            H[ilast - 1, ilast - 2] = 0
+            ilast -= 2  # a 2 x 2 block: the complex iteration splits it
+            it = 0
+            continue
+        ifirst = ilo
+        for j in range(ilast - 2, ilo, -1):
+            if small(j):
+                H[j, j - 1] = 0
+                ifirst = j
+                break
+        if np.any(np.abs(np.diag(T)[ifirst:ilast + 1].real) <= btol):
+            break
+        it += 1
+        if it > max_it:
+            break
+        m = ilast
+        p_, q_, r_, s_ = H[m - 1, m - 1].real, H[m - 1, m].real, H[m, m - 1].real, H[m, m].real
+        e_, f_, g_ = T[m - 1, m - 1].real, T[m - 1, m].real, T[m, m].real
+        if it % 10 == 0:  # exceptional shifts
+            w_ = 1.5 * (abs(r_ / e_) + abs(H[m - 1, m - 2].real / T[m - 2, m - 2].real))
+            tr, det = w_, w_ * w_
+        else:
+            tr = p_ / e_ + (s_ - r_ * f_ / e_) / g_
+            det = (p_ * s_ - q_ * r_) / (e_ * g_)
+        k = ifirst
+        a11, a12, a21, a22, a32 = H[k, k].real, H[k, k + 1].real, H[k + 1, k].real, H[k + 1, k + 1].real, H[k + 2, k + 1].real
+        b11, b12, b22 = T[k, k].real, T[k, k + 1].real, T[k + 1, k + 1].real
+        m11, m21 = a11 / b11, a21 / b11
+        y2 = m21 / b22
+        y1 = (m11 - b12 * y2) / b11
+        x = a11 * y1 + a12 * y2 - tr * m11 + det
+        y = a21 * y1 + a22 * y2 - tr * m21
+        z = a32 * y2
+        sweeps += 1
+        for k in range(ifirst, ilast - 1):
+            left(k, 3, [x, y, z], max(k - 1, ifirst) if k > ifirst else k)
+            if k > ifirst:
+                H[k + 1, k - 1] = 0
+                H[k + 2, k - 1] = 0
+            right(k, 3, [T[k + 2, k].real, T[k + 2, k + 1].real, T[k + 2, k + 2].real], min(k + 4, ilast + 1), k + 3)
+            T[k + 2, k] = 0
+            T[k + 2, k + 1] = 0
+            right(k, 2, [T[k + 1, k].real, T[k + 1, k + 1].real], min(k + 4, ilast + 1), k + 2)
+            T[k + 1, k] = 0
+            x, y = H[k + 1, k].real, H[k + 2, k].real
+            if k < ilast - 2:
+                z = H[k + 3, k].real
+            steps += 1
+        k = ilast - 1
+        left(k, 2, [x, y], k - 1)
+        H[k + 1, k - 1] = 0
+        right(k, 2, [T[k + 1, k].real, T[k + 1, k + 1].real], ilast + 1, k + 2)
+        T[k + 1, k] = 0
+        steps += 1
+    return steps, sweeps
+
+
 def swap_adjacent(P, k):
     """Exchange the 1x1 blocks k and k+1 of the triangular pencil (LAPACK ztgex2)."""
     H, T = P.H, P.T
@@ -401,7 +517,7 @@ def gensys_post(P, ns, rs):
     return Tm, eu
 
 
-def gensys_device_model(A, B, C, D, tol=1e-8, deflate=True):
+def gensys_device_model(A, B, C, D, tol=1e-8, deflate=True, real_stage=True):
     """(T, eu, info) for one system; mirrors the kernel's control flow."""
     A, B, C = (np.asarray(x, dtype=np.float64) for x in (A, B, C))
     n = A.shape[0]
@@ -429,12 +545,13 @@ def gensys_device_model(A, B, C, D, tol=1e-8, deflate=True):
         deflate_zero_columns(P, z)
     hessenberg_triangular(P, ilo=z)
     rot_ht = P.n_rot
+    real_steps = real_double_shift_stage(P, ilo=z) if real_stage else (0, 0)
     ok = qz_iterate(P, ilo=z)
     rot_qz = P.n_rot - rot_ht
     if not ok:
         return np.zeros((n, n)), np.array([-3, -3, 0]), dict(converged=False)
     ns = reorder_stable_first(P, rs)
     Tm, eu = gensys_post(P, ns, rs)
-    info = dict(converged=True, N=N, ns=ns, z=z, n_refl=P.n_refl, rot_ht=rot_ht, rot_qz=rot_qz, rot_reorder=P.n_rot - rot_ht - rot_qz,
+    info = dict(converged=True, N=N, ns=ns, z=z, real_steps=real_steps, n_refl=P.n_refl, rot_ht=rot_ht, rot_qz=rot_qz, rot_reorder=P.n_rot - rot_ht - rot_qz,
                 alpha=np.diag(P.H).copy(), beta=np.diag(P.T).copy())
     return Tm, eu, info

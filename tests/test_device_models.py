@@ -163,3 +163,22 @@ def test_cr_static_deflation_algebra(ref_goldens):
         assert h_used == 10 and it == full[2]
         assert_allclose(T, b["T_star"][i], atol=1e-11)
         assert_allclose(R, oracle.compute_selection_matrix(B, C, D, b["T_star"][i]), atol=1e-11)
+
+
+def test_gensys_model_real_double_shift_stage():
+    """Device-algorithm model of round 3's real double-shift accelerator (gensys_qz_model.real_double_shift_stage, the model of
+    gensys_realqz_kernel): with and without it the model returns the same eu and T (1e-10), both equal to the oracle's
+    LAPACK-based gensys, and the complex single-shift iteration is left with a handful of rotations."""
+    from geconpy_amd import workloads as wl
+
+    b = wl.sw_shaped_batch(3)
+    for i in range(3):
+        A, B, C, D = (b[x][i] for x in "ABCD")
+        T0, eu0, i0 = gensys_device_model(A, B, C, D, real_stage=False)
+        T1, eu1, i1 = gensys_device_model(A, B, C, D, real_stage=True)
+        assert list(eu0) == list(eu1) == [1, 1, 0]
+        assert np.abs(T0 - T1).max() <= 1e-10
+        Tref, ok, _ = oracle.gensys_T_success(A, B, C, D, tol=1e-8)
+        assert ok and np.abs(T1 - Tref).max() <= 1e-10
+        steps, sweeps = i1["real_steps"]
+        assert steps > 0 and i1["rot_qz"] < 0.05 * i0["rot_qz"], (steps, i1["rot_qz"], i0["rot_qz"])

@@ -1976,3 +1976,31 @@ def test_kalman_filter_outputs_per_step():
         Rg = np.stack([oracle.compute_selection_matrix(bb["B"][i], bb["C"][i], bb["D"][i], bb["T_star"][i]) for i in range(n_g)])
         o2 = batched.kalman_filter_outputs_batched(bb["T_star"], Rg, bb["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"])
         assert_allclose(o2["ll"], g["oracle_ll"], rtol=1e-7, atol=1e-8)
+
+
+def test_gensys_real_stage_matches_complex_only():
+    """gensys window path: the real double-shift sweeps in front of the complex single-shift iteration (dsge_options.
+    gensys_real_stage, default on; device model: tests/device_models/gensys_qz_model.py::real_double_shift_stage) are an
+    accelerator -- same eu, same status, T equal to 1e-10 with the stage off -- on SW-shaped draws, the reference's golden
+    systems (under perturbation) and systems without a unique stable solution."""
+    b = wl.sw_shaped_batch(96)
+    cases = [(b["A"], b["B"], b["C"], b["D"])]
+    fk = wl.full_nk_batch(48)[0]
+    cases.append((fk["A"], fk["B"], fk["C"], fk["D"]))
+    # explosive / indeterminate variants: scale the lead block (more / fewer unstable roots than forward-looking variables)
+    cases.append((b["A"][:32], b["B"][:32], 3.0 * b["C"][:32], b["D"][:32]))
+    cases.append((b["A"][:32] * 1.6, b["B"][:32], b["C"][:32] * 0.2, b["D"][:32]))
+    for A, B, C, D in cases:
+        on = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_real_stage": 1})
+        off = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_real_stage": 0})
+        assert np.array_equal(on["eu"], off["eu"])
+        assert np.array_equal(on["status"], off["status"]) if "status" in on else True
+        good = (off["eu"][:, 0] == 1) & (off["eu"][:, 1] == 1)
+        sc = np.maximum(1.0, np.abs(off["T"]).max(axis=(1, 2)))
+        err = np.abs(on["T"] - off["T"]).max(axis=(1, 2)) / sc
+        assert (err[good] <= 1e-10).all(), err[good].max()
+    # and against the oracle (LAPACK's ordered QZ) on the first draws
+    on = batched.gensys_batched(b["A"][:8], b["B"][:8], b["C"][:8], b["D"][:8], tol=1e-8, options={"gensys_split": 2})
+    for i in range(8):
+        Tref, ok = oracle.gensys_T_success(b["A"][i], b["B"][i], b["C"][i], b["D"][i], tol=1e-8)[:2]
+        assert ok and np.abs(on["T"][i] - Tref).max() <= 1e-9
