@@ -161,6 +161,8 @@ struct SoSetupArgs {
   double* gyu_out;
   double* guu_out;
   double* gss_out;
+  int32_t* order_key;        // optional [batch] dispatch key of the filter launch (see launch_second_order): bumped here for
+                             // nearly singular M = B + C T, whose covariance recursion never leaves its rounding noise
   int batch, nnz, q_batched;
 };
 
@@ -275,8 +277,17 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
     const int i = idx / n, j = idx - i * n;
     MpC[idx] = Maug[i * ldm + j] + Cg[idx];
   }
+  double mmax = 0.0;
+  for (int idx = tid; idx < n * n; idx += NT) mmax = fmax(mmax, fabs(Maug[(idx / n) * ldm + idx % n]));
+  mmax = so_wg_max<NT>(mmax, red);
   bool okm = so_gauss_jordan<NT>(Maug, ldm, n, 2 * n, colbuf, ired);
   const double* Mi = Maug + n;  // M^-1, row stride ldm
+  if (a.order_key) {  // max|M| max|M^-1| > 1e6: dispatch it with the slowest draws
+    double imax = 0.0;
+    for (int idx = tid; idx < n * n; idx += NT) imax = fmax(imax, fabs(Mi[(idx / n) * ldm + idx % n]));
+    imax = so_wg_max<NT>(imax, red);
+    if (tid == 0 && !(mmax * imax <= 1e6)) a.order_key[draw] = 63;
+  }
   // ---- 4. GL = (M^-1 C)[:, L];  5. Zy = [e_S; T[:, S]; (T T)[:, S]; 0],  Zu = [0; R; T R; I] ------------------------------
   for (int idx = tid; idx < n * l; idx += NT) {
     const int i = idx / l, jj = idx - i * l;

@@ -75,12 +75,20 @@ int launch_second_order(const double* B, const double* C, const double* T, const
   int rc;
   void* base = nullptr;
   const size_t head = 4096 + sizeof(double) * 8 * 40;
-  if ((rc = so_reserve(head + per_draw * chunk + sizeof(int32_t) * (size_t)chunk + 256, st, &base))) return rc;
+  if ((rc = so_reserve(head + per_draw * chunk + 2 * sizeof(int32_t) * (size_t)chunk + 256, st, &base))) return rc;
   int32_t* hptr = (int32_t*)base;                      // [n + 1]
   int32_t* flags = hptr + 128;                         // [2]
   double* Zu = (double*)((char*)base + 4096);          // [p][u]
   double* work = (double*)((char*)base + head);
   int32_t* order = (int32_t*)((char*)base + head + per_draw * chunk);
+  int32_t* key = order + chunk;
+  // Dispatch order of the filter launch (slow draws first; a never-steady draw is 200 full steps = 68 ms of one CU, the
+  // average draw 17 ms, four draws per CU at 1024 draws): the number of full steps follows the spectral radius of T (rank
+  // correlation 0.99 on the SW-shaped draws, tools/so_order_potential.py; the cycle-reduction iteration count of the
+  // first-order kernels: 0.76), so the key is persistence_key_kernel's power-iteration estimate; the set-up kernel raises it
+  // to the top for nearly singular M = B + C T, whose covariance never leaves its rounding noise.
+  const bool use_key = opt().kalman_order && n <= 64;
+  (void)order_key;
   HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st));
   hipLaunchKernelGGL(dsge::so_hessptr_kernel, dim3(1), dim3(256), 0, st, hess_idx, nnz, n, k, hptr, flags);
   HIP_TRY(hipGetLastError());
@@ -109,6 +117,11 @@ int launch_second_order(const double* B, const double* C, const double* T, const
     sa.batch = nb;
     sa.nnz = nnz;
     sa.q_batched = q_batched;
+    sa.order_key = nullptr;
+    if (use_key && nb >= 512) {
+      if ((rc = launch_persistence_key(T + (size_t)c0 * n * n, status_io + c0, nb, n, key, st))) return rc;
+      sa.order_key = key;
+    }
     const bool time_it = ms && c0 + chunk >= batch;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (time_it) {
@@ -128,8 +141,8 @@ int launch_second_order(const double* B, const double* C, const double* T, const
     fa.logp = logp + c0;
     fa.status = status_io + c0;
     fa.order = nullptr;
-    if (order_key && opt().kalman_order && nb >= 512) {  // slow draws first (descending key: cycle-reduction iterations)
-      hipLaunchKernelGGL(dsge::kalman_order_kernel<1024>, dim3(1), dim3(1024), 0, st, order_key + c0, nb, order);
+    if (sa.order_key) {  // slow draws first (descending key)
+      hipLaunchKernelGGL(dsge::kalman_order_kernel<1024>, dim3(1), dim3(1024), 0, st, key, nb, order);
       HIP_TRY(hipGetLastError());
       fa.order = order;
     }
