@@ -448,21 +448,31 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
 
 def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
                                    jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=None,
-                                   n_lead_hint=None, options=None):
+                                   n_lead_hint=None, options=None, Q=None):
     """logp and its reverse-mode gradient per draw (include/dsge_hip.h: dsge_solve_kalman_logp_grad_batched): what
     pytensor autodiff computes for the reference's logp graph, on the device.  ``q``: (k,) or (batch, k) diagonal shock
-    variances; ``Z``: selector design matrix (p, n), p <= 8; n <= 56.
-    Returns dict(logp, status, A_bar, B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar])."""
+    variances, or ``q=None, Q=`` a full symmetric shock covariance (k, k) / (batch, k, k) (``full_covariance``,
+    statespace.py:247-251); ``Z``: selector design matrix (p, n), p <= 8; n <= 56.
+    Returns dict(logp, status, A_bar, B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar]); with ``Q=`` the key is ``Q_bar``
+    (batch, k, k): the cotangent of all k x k entries taken as independent (symmetric)."""
     A, B, C = _check_abc(A, B, C)
     D = _f64(D, 3)
     y = _f64(y, 2)
     nb, n, _ = A.shape
     k = D.shape[2]
     T_len, p = y.shape
-    q = _f64(q)
-    if q.shape not in ((k,), (nb, k)):
-        raise ValueError("q must be (k,) or (batch, k) (diagonal shock covariance)")
-    qb = int(q.ndim == 2)
+    if Q is not None:
+        if q is not None:
+            raise ValueError("pass either q (diagonal variances) or Q (full covariance)")
+        q = _f64(Q)
+        if q.shape not in ((k, k), (nb, k, k)):
+            raise ValueError("Q must be (k, k) or (batch, k, k)")
+        qb = 2 + int(q.ndim == 3)
+    else:
+        q = _f64(q)
+        if q.shape not in ((k,), (nb, k)):
+            raise ValueError("q must be (k,) or (batch, k) (diagonal shock covariance)")
+        qb = int(q.ndim == 2)
     Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, n)
     if n_filter_hint is None:  # |S u O|: non-zero columns of A (in any draw) or of Z
         ns = int(np.count_nonzero(np.any(A.reshape(-1, n) != 0, axis=0) | np.any(Z.reshape(-1, n) != 0, axis=0)))
@@ -470,7 +480,7 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
         ns = int(n_filter_hint)
     nl = (lead_hint(C, tol) if solver == "gensys" else 0) if n_lead_hint is None else int(n_lead_hint)
     out = dict(logp=np.empty(nb), status=np.empty(nb, dtype=np.int32), A_bar=np.empty_like(A), B_bar=np.empty_like(A),
-               C_bar=np.empty_like(A), D_bar=np.empty_like(D), q_bar=np.empty((nb, k)))
+               C_bar=np.empty_like(A), D_bar=np.empty_like(D), q_bar=np.empty((nb, k, k) if qb >= 2 else (nb, k)))
     if d is not None:
         out["d_bar"] = np.empty((nb, p))
     if Hdiag is not None:
@@ -484,6 +494,8 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
             _ptr(out["D_bar"]), _ptr(out["q_bar"]), _ptr(out.get("d_bar")), _ptr(out.get("h_bar"))
         )
     )
+    if qb >= 2:
+        out["Q_bar"] = out.pop("q_bar")
     return out
 
 

@@ -982,10 +982,13 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
     return fail(DSGE_ERR_INVALID, "null pointer");
   if (solver != DSGE_SOLVER_CYCLE_REDUCTION && solver != DSGE_SOLVER_GENSYS && solver != DSGE_SOLVER_SCAN_CYCLE_REDUCTION)
     return fail(DSGE_ERR_INVALID, "gradient path: solver must be cycle_reduction, scan_cycle_reduction or gensys");
+  if (q_batched < 0 || q_batched > 3) return fail(DSGE_ERR_INVALID, "gradient path: q_batched is a DSGE_Q_* mode (0..3)");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
   const int u_hint = n_filter_hint;
+  const bool qfull = q_batched >= 2;                       // DSGE_Q_FULL_*: Q and q_bar are k x k
+  const size_t qstride = qfull ? (size_t)k * k : (size_t)k;
   // the reverse sweep re-reads the stored (a_t, P_t): chunk the batch so that the store stays <= 16 GiB of the 288 GB
   const size_t per_draw = kalman_grad_store_doubles_per_draw(u_hint, n, T_len) * sizeof(double);
   size_t chunk = per_draw ? ((size_t)16 << 30) / per_draw : (size_t)batch;
@@ -1010,7 +1013,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)(((size_t)batch - c0 < chunk) ? (size_t)batch - c0 : chunk);
     const double *Ac = A + c0 * n * n, *Bc = B + c0 * n * n, *Cc = C + c0 * n * n, *Dc = D + c0 * n * k;
-    const double* qc = q + (q_batched ? c0 * k : 0);
+    const double* qc = q + ((q_batched & 1) ? c0 * qstride : 0);
     const double* Zc = Z + (z_batched ? c0 * p * n : 0);
     const double* dc = d ? d + (d_batched ? c0 * p : 0) : nullptr;
     const double* hc = Hdiag ? Hdiag + (h_batched ? c0 * p : 0) : nullptr;
@@ -1032,10 +1035,10 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
       }
     }
     if (rc) return rc;
-    if (have_R && k <= 16 && n <= 64) {
+    if (have_R && k <= 16 && n <= 64 && !qfull) {
       if ((rc = launch_rqr(Rw, qc, q_batched, nb, n, k, stc, RQR, st))) return rc;
-    } else if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched ? DSGE_Q_DIAG_BATCHED : DSGE_Q_DIAG_SHARED, nb, n, k,
-                              Rw, nullptr, RQR, nullptr, stc, 1, 2, st)))
+    } else if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched, nb, n, k, Rw, nullptr, RQR, nullptr, stc, 1, 2,
+                                     st)))
       return rc;
     const int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;
     if (opt().kalman_order == 0) {
@@ -1050,7 +1053,7 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
                                  gkey, ord_w)))
       return rc;
     if ((rc = launch_grad_assemble(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, nb, n, k, stc, Tbar, B_bar + c0 * n * n,
-                                   C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * k, st)))
+                                   C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * qstride, st)))
       return rc;
     if ((rc = launch_adjoint(Bc, Cc, Tw, Tbar, nb, n, A_bar + c0 * n * n, B_bar + c0 * n * n, C_bar + c0 * n * n, stc, st,
                              1)))
@@ -1683,13 +1686,15 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
   (void)tw_st1;
   if (batch == 0) return DSGE_SUCCESS;
-  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = (size_t)(q_batched ? batch : 1) * k;
+  if (q_batched < 0 || q_batched > 3) return fail(DSGE_ERR_INVALID, "gradient path: q_batched is a DSGE_Q_* mode (0..3)");
+  const size_t qstride = (q_batched >= 2) ? (size_t)k * k : (size_t)k;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = (size_t)((q_batched & 1) ? batch : 1) * qstride;
   const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
                nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p, bp = (size_t)batch * p;
   void* base = nullptr;
   STAGE_RESERVE(6 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
                                        align256(nd * 8) + align256(nh * 8) + align256(ny * 8 + 8) +
-                                       2 * align256(bp * 8) + align256((size_t)batch * k * 8) +
+                                       2 * align256(bp * 8) + align256((size_t)batch * qstride * 8) +
                                        2 * align256((size_t)batch * 8) + 8192, &base);
   Carver cv(base);
   UP(dA, A, nn, double);
@@ -1707,7 +1712,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   OUTBUF(gB, B_bar, nn, double);
   OUTBUF(gC, C_bar, nn, double);
   OUTBUF(gD, D_bar, nk, double);
-  OUTBUF(gq, q_bar, (size_t)batch * k, double);
+  OUTBUF(gq, q_bar, (size_t)batch * qstride, double);
   OUTBUF(gd, d_bar, bp, double);
   OUTBUF(gh, h_bar, bp, double);
   if ((rc = dsge_solve_kalman_logp_grad_batched(dA, dB, dC, dD, dq, q_batched, dZ, z_batched, dd, d_batched, dH, h_batched,
@@ -1720,7 +1725,7 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   DOWN(B_bar, gB, nn, double);
   DOWN(C_bar, gC, nn, double);
   DOWN(D_bar, gD, nk, double);
-  DOWN(q_bar, gq, (size_t)batch * k, double);
+  DOWN(q_bar, gq, (size_t)batch * qstride, double);
   DOWN(d_bar, gd, bp, double);
   DOWN(h_bar, gh, bp, double);
   HIP_TRY(hipStreamSynchronize(tw_st));

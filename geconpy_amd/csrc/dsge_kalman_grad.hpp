@@ -913,7 +913,7 @@ namespace dsge {
 // -------------------------------------------------------------------------------------------------------
 // Reverse of the state-space assembly (full model size n), between the Kalman reverse sweep and the
 // policy-function adjoints:
-//   G = sym(R Q R'), Q = diag(q):   Rbar = 2 Gbar R Q,   qbar_j = (R' Gbar R)_jj
+//   G = sym(R Q R'), Q = diag(q):   Rbar = 2 Gbar R Q,   qbar_j = (R' Gbar R)_jj;   full Q:  Qbar = R' Gbar R  (k x k)
 //   R = -M^-1 D,  M = B + C T  (gEconpy/solvers/shared.py:74-75):
 //       X = M^-T Rbar,   Dbar = -X,   Mbar = -X R',   Bbar = Mbar,   Cbar = Mbar T',   Tbar += C' Mbar
 // Tbar then goes through adjoint_kernel (shared.py:12-71), which ADDS its B, C cotangents to these.
@@ -955,7 +955,11 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
       blk_store_global<BS>(z, B_bar + off, n, n, n, lr, lc);
       blk_store_global<BS>(z, C_bar + off, n, n, n, lr, lc);
       blk_store_global<BS>(z, D_bar + offk, n, k, k, lr, lc);
-      if (q_bar && lane < k) q_bar[(size_t)draw * k + lane] = 0.0;
+      if (q_bar && q_batched >= 2 && !Rbar_in) {
+        for (int idx = lane; idx < k * k; idx += 64) q_bar[(size_t)draw * k * k + idx] = 0.0;
+      } else if (q_bar && lane < k) {
+        q_bar[(size_t)draw * k + lane] = 0.0;
+      }
       if (Rbar_in) blk_store_global<BS>(z, Tbar + off, n, n, n, lr, lc);
       continue;
     }
@@ -966,7 +970,10 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     if (!Rbar_in) lds_load_matrix(Ms, LD, NP, NP, Gbar + off, n, n, lane);
     lds_load_matrix(Rs, LD, NP, NP, R + offk, n, k, lane);
     wave_sync();
-    const double* qd = Rbar_in ? nullptr : q + (q_batched ? (size_t)draw * k : 0);
+    // q_batched is the q_mode of include/dsge_hip.h: 0 / 1 = diag(q) shared / per draw, 2 / 3 = full k x k Q shared / per draw
+    const bool qfull = !Rbar_in && q_batched >= 2;
+    const double* qd = Rbar_in ? nullptr
+                               : (qfull ? q + (q_batched == 3 ? (size_t)draw * k * k : 0) : q + (q_batched ? (size_t)draw * k : 0));
     // GR = Gbar R  (n x k);  Rbar = 2 GR Q;  qbar_j = sum_i R_ij GR_ij
     double GR[BS][BS], Rb[BS][BS];
     blk_zero<BS>(GR);
@@ -975,6 +982,27 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
       blk_load_global<BS>(Rbar, Rbar_in + offk, n, k, k, lr, lc);
     } else {
     mm_acc<BS, false>(GR, Ms, LD, Rs, LD, n, lr, lc);
+    if (qfull) {
+      // full shock covariance (full_covariance, statespace.py:247-251): G = R Q R', Q symmetric ->
+      //   Rbar = 2 (Gbar R) Q,   Qbar = R' (Gbar R)   (k x k, symmetric because Gbar is)
+      // GR and Q go through the two (still unused) column groups of W
+      blk_store_lds<BS>(GR, W, LDW, lr, lc);
+      lds_load_matrix(W + NP, LDW, NP, NP, qd, k, k, lane);
+      wave_sync();
+      blk_zero<BS>(Rbar);
+      mm_acc<BS, false>(Rbar, W, LDW, W + NP, LDW, k, lr, lc);
+      double Qb[BS][BS];
+      blk_zero<BS>(Qb);
+      mm_acc_ta<BS>(Qb, Rs, LD, W, LDW, n, lr, lc);
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Rbar[i][j] *= 2.0;
+      blk_store_global<BS>(Qb, q_bar + (size_t)draw * k * k, k, k, k, lr, lc);
+      wave_sync();
+      for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+      wave_sync();
+    } else {
     blk_load_lds<BS>(Rb, Rs, LD, lr, lc);
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
@@ -990,6 +1018,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
       colsum += shfl_xor_f64(colsum, 16);
       colsum += shfl_xor_f64(colsum, 32);
       if (lr == 0 && c < k) q_bar[(size_t)draw * k + c] = colsum;
+    }
     }
     }
     // M = B + C T; W = [M' | Rbar]

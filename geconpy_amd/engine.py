@@ -217,11 +217,12 @@ class LogpEngine:
 
     def solve_kalman_logp_grad(self, A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
                                jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=0, n_lead_hint=0,
-                               out=None, options=None):
+                               out=None, options=None, full_covariance=False):
         """logp and its reverse-mode gradient for the whole batch, device-resident (dsge_solve_kalman_logp_grad_batched).
-        ``q``: (k,) or (batch, k) diagonal shock variances.  Returns a dict of tensors: logp, status, A_bar, B_bar, C_bar,
-        D_bar, q_bar[, d_bar][, h_bar] (asynchronous).  ``out`` may carry the same dict from an earlier call to reuse
-        the buffers."""
+        ``q``: (k,) or (batch, k) diagonal shock variances; with ``full_covariance=True`` a full symmetric Q, (k, k) or
+        (batch, k, k) (statespace.py:247-251), and ``q_bar`` is (batch, k, k).  Returns a dict of tensors: logp, status, A_bar,
+        B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar] (asynchronous).  ``out`` may carry the same dict from an earlier call to
+        reuse the buffers."""
         torch = self.torch
         nb, n, _ = A.shape
         k = D.shape[2]
@@ -231,15 +232,22 @@ class LogpEngine:
         self._chk(D, (nb, n, k))
         self._chk(y, (T_len, p))
         self._chk(q)
-        if tuple(q.shape) not in ((k,), (nb, k)):
-            raise ValueError("q must be (k,) or (batch, k)")
+        if full_covariance:
+            if tuple(q.shape) not in ((k, k), (nb, k, k)):
+                raise ValueError("Q must be (k, k) or (batch, k, k)")
+            q_mode = 2 + int(q.dim() == 3)
+        else:
+            if tuple(q.shape) not in ((k,), (nb, k)):
+                raise ValueError("q must be (k,) or (batch, k)")
+            q_mode = int(q.dim() == 2)
         zb = int(self._chk(Z).dim() == 3)
         db = int(d is not None and self._chk(d).dim() == 2)
         hb = int(Hdiag is not None and self._chk(Hdiag).dim() == 2)
         if out is None:
             mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.device)  # noqa: E731
             out = dict(logp=mk(nb), status=torch.empty(nb, dtype=torch.int32, device=self.device), A_bar=mk(nb, n, n),
-                       B_bar=mk(nb, n, n), C_bar=mk(nb, n, n), D_bar=mk(nb, n, k), q_bar=mk(nb, k))
+                       B_bar=mk(nb, n, n), C_bar=mk(nb, n, n), D_bar=mk(nb, n, k),
+                       q_bar=mk(nb, k, k) if full_covariance else mk(nb, k))
             if d is not None:
                 out["d_bar"] = mk(nb, p)
             if Hdiag is not None:
@@ -247,7 +255,7 @@ class LogpEngine:
         op, _keep = _lib.opt_ptr(options)
         _lib.check(
             self.lib.dsge_solve_kalman_logp_grad_batched_opt(
-                op, self._p(A), self._p(B), self._p(C), self._p(D), self._p(q), int(q.dim() == 2), self._p(Z), zb, self._p(d), db,
+                op, self._p(A), self._p(B), self._p(C), self._p(D), self._p(q), q_mode, self._p(Z), zb, self._p(d), db,
                 self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter),
                 float(jitter), float(missing_fill_value), int(n_filter_hint), int(n_lead_hint), self._p(out["logp"]),
                 out["status"].data_ptr(), self._p(out["A_bar"]), self._p(out["B_bar"]), self._p(out["C_bar"]),

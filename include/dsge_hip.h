@@ -569,10 +569,12 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
  * P0 = solve_discrete_lyapunov statespace.py:814-815; the filter scan statespace.py:1151-1157), written as four
  * kernels: Kalman reverse sweep on the reduced model (stores every predicted (a_t, P_t) in library scratch, the
  * batch is processed in chunks of <= 16 GiB of scratch), reverse of the assembly, policy-function adjoints.
- *   q : [k] (q_batched=0) or [batch][k] diagonal shock covariance;  Z : selector design matrix (one non-zero per
- *       row, distinct columns), [p][n] or [batch][p][n];  p <= 8;  n <= 56
+ *   q, q_batched : q_batched is a DSGE_Q_* mode (the name is historical): 0 / 1 = diagonal variances [k] / [batch][k]
+ *       (sigma_i^2, statespace.py:252-258), 2 / 3 = full symmetric Q [k][k] / [batch][k][k] (full_covariance, :247-251)
+ *   Z : selector design matrix (one non-zero per row, distinct columns), [p][n] or [batch][p][n];  p <= 8;  n <= 56
  *   A_bar,B_bar,C_bar : [batch][n][n];  D_bar : [batch][n][k];  q_bar : [batch][k] (also for a shared q: sum over
- *       the batch for a joint logp);  d_bar, h_bar : [batch][p] or NULL
+ *       the batch for a joint logp); for a full Q [batch][k][k] = R' Gbar R, the cotangent of ALL k x k entries taken as
+ *       independent (symmetric; chain it through the caller's parametrisation of Q);  d_bar, h_bar : [batch][p] or NULL
  *   Contract: the columns of A that are exactly zero (non-state variables) are treated as structurally zero -- T has
  *   exactly-zero columns there for every parameter value, so A_bar is meaningful on the non-zero columns of A only
  *   (the others multiply dA = 0 in any chain rule through the model's Jacobians).  No cotangent is produced for Z, y.

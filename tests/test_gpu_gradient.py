@@ -349,3 +349,64 @@ def test_policy_adjoints_of_a_nearly_singular_draw():
     assert (g["status"] == 0).all(), g["status"]
     for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar"):
         assert np.isfinite(g[key]).all(), key
+
+
+@pytest.mark.parametrize("batched_q", [False, True])
+def test_gradient_with_a_full_shock_covariance(batched_q):
+    """full_covariance (statespace.py:247-251: ``state_cov`` is a full k x k matrix): Q (k, k) or (batch, k, k) instead of the
+    diagonal variances.  logp equals the oracle's with that Q; Q_bar = R' Gbar R is checked -- together with every other input
+    block, which now flows through 2 (Gbar R) Q -- against Richardson-extrapolated central differences of the oracle along
+    random SYMMETRIC directions dQ (1e-7 relative, SW-shaped 40-variable system), and it is symmetric; with a diagonal Q the
+    diagonal of Q_bar and every other cotangent equal the diagonal path's bit for bit."""
+    rng = np.random.default_rng(21)
+    nb = 3
+    b = wl.sw_shaped_batch(nb, first_draw=40)
+    om = wl.sw_shaped_observation_model()
+    k = b["D"].shape[2]
+    y = om["y"][:50].copy()
+    y[7, 1] = np.nan
+    h = om["Hdiag"].copy()
+    Ls = [np.diag(b["sigma"][i]) + 0.25 * np.tril(rng.standard_normal((k, k)), -1) * b["sigma"][i].mean() for i in range(nb)]
+    Q = np.stack([L_ @ L_.T for L_ in Ls])
+    Qarg = Q if batched_q else Q[0]
+    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], None, om["Z"], y, Hdiag=h, tol=1e-14, max_iter=200,
+                                                 Q=Qarg)
+    assert np.all(out["status"] == 0) and out["Q_bar"].shape == (nb, k, k)
+    assert np.abs(out["Q_bar"] - out["Q_bar"].transpose(0, 2, 1)).max() <= 1e-9 * np.abs(out["Q_bar"]).max()
+    i = 1
+    Qi = Q[i] if batched_q else Q[0]
+    A, B, C, D = (b[x][i] for x in "ABCD")
+    ref = oracle.solve_kalman_logp(A, B, C, D, Qi, om["Z"], y, H=np.diag(h), tol=1e-15, max_iter=300)["logp"]
+    assert abs(out["logp"][i] - ref) <= 1e-9 * abs(ref)
+    g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+    maskA = (A != 0).any(axis=0)[None, :] * np.ones_like(A)
+    dA = rng.standard_normal(A.shape) * maskA * 0.1
+    dB, dC, dD = (rng.standard_normal(M.shape) * 0.1 for M in (B, C, D))
+    dQ = rng.standard_normal((k, k)) * np.abs(Qi).max() * 0.2
+    dQ = 0.5 * (dQ + dQ.T)
+    analytic = ((g["A_bar"] * dA).sum() + (g["B_bar"] * dB).sum() + (g["C_bar"] * dC).sum() + (g["D_bar"] * dD).sum()
+                + (g["Q_bar"] * dQ).sum())
+
+    def f(e):
+        return oracle.solve_kalman_logp(A + e * dA, B + e * dB, C + e * dC, D + e * dD, Qi + e * dQ, om["Z"], y, H=np.diag(h),
+                                        tol=1e-15, max_iter=300)["logp"]
+
+    def central(step):
+        return (f(step) - f(-step)) / (2.0 * step)
+
+    h0 = 2e-3
+    d1, d2, d3 = central(h0), central(h0 / 2), central(h0 / 4)
+    r1, r2 = (4 * d2 - d1) / 3, (4 * d3 - d2) / 3
+    fd = (16 * r2 - r1) / 15
+    assert abs(analytic - fd) <= 1e-7 * max(1.0, abs(fd)), (analytic, fd)
+    # a diagonal Q through the full-Q path against the diagonal path
+    qd = b["sigma"] ** 2
+    diag_path = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], qd, om["Z"], y, Hdiag=h, tol=1e-14, max_iter=200)
+    full_path = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], None, om["Z"], y, Hdiag=h, tol=1e-14,
+                                                       max_iter=200, Q=np.stack([np.diag(v) for v in qd]))
+    assert np.allclose(full_path["logp"], diag_path["logp"], rtol=1e-12)
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar"):
+        sc = np.abs(diag_path[key]).max()
+        assert np.abs(full_path[key] - diag_path[key]).max() <= 1e-9 * sc, key
+    dq = np.diagonal(full_path["Q_bar"], axis1=1, axis2=2)
+    assert np.abs(dq - diag_path["q_bar"]).max() <= 1e-9 * np.abs(diag_path["q_bar"]).max()
