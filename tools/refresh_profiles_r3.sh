@@ -29,6 +29,9 @@ python3 tools/so_rate.py 1024 > "$OUT/so_steady_tol_sweep.txt" 2>&1
 python3 tools/wide_rate.py > "$OUT/wide_rate.txt" 2>&1
 python3 tools/grad_rate.py > "$OUT/grad_rate.txt" 2>&1
 python3 tools/kalman_phases.py > "$OUT/kalman_phases.txt" 2>&1
+python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
+python3 tools/so_order_potential.py > "$OUT/so_order_potential.txt" 2>&1
+python3 tools/two_streams.py > "$OUT/two_streams.txt" 2>&1
 tools/so_gemm_probe/probe13 1024 10 > "$OUT/so_gemm_probe.txt" 2>&1
 python3 -m pytest tests -m gpu -q > "$OUT/tests_gpu.log" 2>&1
 tail -3 "$OUT/tests_gpu.log"
