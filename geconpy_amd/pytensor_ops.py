@@ -46,6 +46,17 @@ def _require():
         raise ImportError("pytensor is not installed; use geconpy_amd.batched / geconpy_amd.engine directly")
 
 
+def _floatx():
+    """``pytensor.config.floatX``: the dtype ``pt.tensor("T", shape=...)`` gets in ``GensysWrapper.make_node`` (gensys.py:646),
+    which declares no dtype; float64 where pytensor is not importable."""
+    try:
+        import pytensor  # noqa: PLC0415
+
+        return str(pytensor.config.floatX)
+    except Exception:  # noqa: BLE001
+        return "float64"
+
+
 def _as3(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     return x[None] if x.ndim == 2 else x
@@ -318,7 +329,7 @@ class HipSolveKalmanLogpGrad(Op):
 
 class HipGensys(Op):
     """Drop-in for ``GensysWrapper`` (gEconpy/solvers/gensys.py:634-676): ``T, success = Op(A, B, C, D)``
-    with ``__props__ = ("tol",)``, the same ``gufunc_signature``, ``T`` (n, n) float64 and a boolean
+    with ``__props__ = ("tol",)``, the same ``gufunc_signature``, ``T`` (n, n) of dtype floatX (as upstream) and a boolean
     scalar ``success = (eu[0] == 1 and eu[1] == 1)`` (:663).  Batched (leading draw axis) inputs give
     (batch, n, n) and (batch,) outputs from ONE launch.  ``pullback`` returns the adjoints of
     (A, B, C) from the cotangent of T on the device and a zero cotangent for D (:668-676)."""
@@ -335,7 +346,9 @@ class HipGensys(Op):
         _require()
         inputs = [pt.as_tensor(x) for x in (A, B, C, D)]
         shp = inputs[0].type.shape
-        outputs = [pt.tensor("T", dtype="float64", shape=shp), pt.tensor("success", dtype="bool", shape=shp[:-2])]
+        # the reference declares T without a dtype, i.e. floatX (gensys.py:646); the kernels compute in float64 and
+        # perform() casts to the declared type
+        outputs = [pt.tensor("T", dtype=_floatx(), shape=shp), pt.tensor("success", dtype="bool", shape=shp[:-2])]
         return Apply(self, inputs, outputs)
 
     def infer_shape(self, fgraph, node, input_shapes):
@@ -348,7 +361,9 @@ class HipGensys(Op):
             raise ValueError(f"D must be (n, k) with n = {A.shape[1]}; got {D.shape[1:]}")
         # T = G1[:n,:n] and eu do not depend on D (psi only enters `impact`, gensys.py:359-365): it is not shipped to the device
         out = batched.gensys_batched(A, B, C, None, tol=self.tol)
-        outputs[0][0] = out["T"][0] if squeeze else out["T"]
+        T = out["T"][0] if squeeze else out["T"]
+        dt = getattr(getattr(node.outputs[0], "type", None), "dtype", "float64") if node is not None else "float64"
+        outputs[0][0] = np.asarray(T, dtype=dt)
         outputs[1][0] = np.asarray(out["success"][0] if squeeze else out["success"], dtype=bool)
 
     def pullback(self, inputs, outputs, cotangents):

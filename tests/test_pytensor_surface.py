@@ -169,3 +169,14 @@ def test_numba_wrappers_are_plain_python_when_handed_an_identity_decorator():
     g = ops.make_numba_gensys(lambda fn: fn, fake_gs, 1e-8)
     T, success = g(np.eye(4), np.eye(4), np.eye(4), np.ones((4, 1)))
     assert calls[-1] == (1, 4, 1, 1e-8, 0, 0, 0) and T.shape == (4, 4) and not success  # eu stayed [0,0,0]
+
+
+def test_gensys_output_dtype_follows_floatx(surface, monkeypatch):
+    """GensysWrapper.make_node declares ``pt.tensor("T", shape=...)`` without a dtype, i.e. config.floatX (gensys.py:646);
+    HipGensys does the same (float64 when pytensor is absent) and perform() casts the float64 result to the declared dtype."""
+    op = surface.HipGensys()
+    node = op.make_node(_m(5), _m(5), _m(5), _m(5, 2))
+    assert node.outputs[0].type.dtype == "float64" and node.outputs[1].type.dtype == "bool"
+    monkeypatch.setattr(surface, "_floatx", lambda: "float32")
+    node32 = op.make_node(_m(5), _m(5), _m(5), _m(5, 2))
+    assert node32.outputs[0].type.dtype == "float32"
