@@ -29,6 +29,7 @@ ST_GRAD_UNSUPPORTED = 64
 
 Q_DIAG_SHARED, Q_DIAG_BATCHED, Q_FULL_SHARED, Q_FULL_BATCHED = 0, 1, 2, 3
 SOLVER_CYCLE_REDUCTION, SOLVER_GENSYS, SOLVER_BACKWARD_DIRECT, SOLVER_SCAN_CYCLE_REDUCTION = 0, 1, 2, 3
+SOLVER_FLAG_ZERO_T_ON_FAILURE = 0x100  # include/dsge_hip.h: DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE
 SOLVER_CODES = {
     "cycle_reduction": SOLVER_CYCLE_REDUCTION,
     "gensys": SOLVER_GENSYS,

@@ -408,9 +408,12 @@ def kalman_filter_outputs_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None
 def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                               tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
                               return_policy=False, n_state_hint=None, z_selector_hint=None, n_lead_hint=None,
-                              options=None):
+                              options=None, add_solver_success_check=True):
     """One fused evaluation per draw: A,B,C,D -> T,R -> P0 -> logp.  ``tol``/``max_iter``
     default to what ``DSGEStateSpace.configure`` passes (statespace.py:835-836).
+    ``add_solver_success_check=False`` (the reference's default, statespace.py:1148): a draw whose cycle reduction fails carries
+    ``T = 0`` on and gets the finite log-likelihood of that system (``DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE``); the default here
+    is the safe one, ``-inf``.
     ``options``: per-call kernel-variant switches (dict of ``dsge_options`` fields or ``_lib.Options``).
     Returns dict(logp, status[, T, R, resid, n_iter])."""
     A, B, C = _check_abc(A, B, C)
@@ -436,7 +439,8 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
     _lib.check(
         _lib.load().dsge_solve_kalman_logp_batched_host_opt(
             op, _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb,
-            n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter),
+            n, k, p, T_len, _lib.SOLVER_CODES[solver] | (0 if add_solver_success_check else _lib.SOLVER_FLAG_ZERO_T_ON_FAILURE),
+            float(tol), int(max_iter), float(jitter),
             float(missing_fill_value), ns, zs, nl, _ptr(logp), _ptr(status), _ptr(T), _ptr(R), _ptr(resid), _ptr(n_iter)
         )
     )

@@ -674,7 +674,10 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
                     int32_t* n_iter_out, hipStream_t st, int reps, float* ms_out, int arena_id = 0,
                     void* scratch_slice = nullptr) {
   (void)arena_id;  // (scratch is keyed by stream now; the chunked host path runs its chunks on two streams)
+  const bool zero_T_on_failure = (solver & DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE) != 0;
+  solver &= ~DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE;
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
+  const bool park_failures = zero_T_on_failure && is_cr;
   int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
@@ -712,7 +715,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
     // Cycle reduction (njit semantics) can hand back R from its final elimination (A1_hat = B + C T at convergence);
     // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
-    const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && opt().cr_fused_selection;
+    const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && opt().cr_fused_selection && !park_failures;
     bool have_colmask = false;
     if (is_cr) {
       int deflated = 0;
@@ -734,6 +737,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
       rc = launch_bdirect(A, B, D, batch, n, k, Tw, Rw, st);
     }
     if (rc) return rc;
+    if (park_failures) {  // failed draws carry T = 0 on as ordinary draws (the column-mask buffer is free: no deflated solve in this mode)
+      if ((rc = launch_status_park(status_out, (int32_t*)cm_w, batch, 0, st))) return rc;
+    }
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
     // backward_direct already produced R; the assemble kernel recomputes it from the same
     // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
@@ -765,6 +771,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
                             fold_rqr ? Rw : nullptr, fold_rqr ? Q : nullptr, q_mode == DSGE_Q_DIAG_BATCHED, k,
                             have_colmask ? cm_w : nullptr)))
       return rc;
+    if (park_failures) {
+      if ((rc = launch_status_park(status_out, (int32_t*)cm_w, batch, 1, st))) return rc;
+    }
     if (ms_out) {
       HIP_TRY(hipEventRecord(ev[3], st));
       HIP_TRY(hipEventSynchronize(ev[3]));

@@ -101,6 +101,7 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
                     const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
                     hipStream_t st);
+int launch_status_park(int32_t* status, int32_t* park, int batch, int restore, hipStream_t st);
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
                    double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate = 0);
 int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,

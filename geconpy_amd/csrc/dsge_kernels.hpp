@@ -1206,4 +1206,19 @@ __global__ __launch_bounds__(64) void kalman_kernel(
   }
 }
 
+// DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE: park the solver's failure bits of a draw (it carries T = 0) so that the assembly and the
+// filter treat it as an ordinary draw; `restore` = 1 ORs them back into the status after the filter.
+template <int BLOCK>  // (a template only so that the header can be included by several translation units)
+__global__ __launch_bounds__(BLOCK) void status_park_kernel(int32_t* __restrict__ status, int32_t* __restrict__ park, int batch, int restore) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  if (restore) {
+    status[i] |= park[i];
+  } else {
+    const int32_t s = status[i], f = s & (DSGE_ST_NOT_CONVERGED | DSGE_ST_NAN);
+    park[i] = f;
+    if (f && (s & ~f) == 0) status[i] = 0;
+  }
+}
+
 }  // namespace dsge

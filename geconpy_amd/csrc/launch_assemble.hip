@@ -99,4 +99,10 @@ int launch_acf(const double* T, const double* Sigma, const double* Z, const doub
   return rc;
 }
 
+int launch_status_park(int32_t* status, int32_t* park, int batch, int restore, hipStream_t st) {
+  hipLaunchKernelGGL(dsge::status_park_kernel<256>, dim3((batch + 255) / 256), dim3(256), 0, st, status, park, batch, restore);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
 }  // namespace dsge_host

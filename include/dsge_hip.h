@@ -68,6 +68,13 @@ extern "C" {
 #define DSGE_SOLVER_GENSYS 1
 #define DSGE_SOLVER_BACKWARD_DIRECT 2
 #define DSGE_SOLVER_SCAN_CYCLE_REDUCTION 3
+/* Flag, OR-ed into the solver code of dsge_solve_kalman_logp_batched (+ _opt / _host twins) with a cycle-reduction solver: what
+ * the reference's graph computes when add_solver_success_check is left at its default False (statespace.py:1148, 1210-1215) -- a
+ * draw whose cycle reduction did not converge carries T = 0 on (cycle_reduction.py:181), R = -B^-1 D, P0 = R Q R', and gets
+ * the FINITE log-likelihood of that system instead of -inf.  status[i] still reports the failure.  Without the flag (default)
+ * a failed draw gives logp = -inf, i.e. add_solver_success_check = True.  The flag turns off the shortcuts that take R from
+ * the solver's final elimination (R is recomputed from T for every draw) and is ignored by the other solvers. */
+#define DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE 0x100
 
 int dsge_abi_version(void);
 const char* dsge_last_error(void);

@@ -135,6 +135,7 @@ def solve_kalman_logp(
     jitter=JITTER_DEFAULT,
     missing_fill_value=MISSING_FILL,
     inv_var_order=None,
+    add_solver_success_check=True,
 ):
     """One full evaluation: A,B,C,D -> T,R -> P0 -> logp (SURVEY.md §3 A hot loop).
 
@@ -142,6 +143,9 @@ def solve_kalman_logp(
     ``make_symbolic_graph`` (:781-820) without augmentation, then the filter.  A failed
     solve gives ``logp = -inf`` (what the Potentials at :1206-1215 do to the model logp).
     Returns dict(logp, T, R, resid, success, n_iter, P0).
+    ``add_solver_success_check=False`` is the reference's DEFAULT graph (statespace.py:1148, 1210-1215: no Potential on the
+    policy residual): a failed cycle reduction hands on ``T = 0`` (cycle_reduction.py:181) and the log-likelihood of that
+    system -- finite -- is what the model sees.
     """
     from .cycle_reduction import cycle_reduction_core
     from .gensys_qz import gensys_T_success
@@ -162,7 +166,7 @@ def solve_kalman_logp(
     else:
         raise ValueError(solver)
     out = {"T": Tm, "success": bool(ok), "n_iter": n_iter}
-    if not ok:
+    if not ok and not (solver == "cycle_reduction" and not add_solver_success_check):
         out.update(logp=-np.inf, R=np.zeros_like(D), resid=np.inf, P0=None)
         return out
     Rm = compute_selection_matrix(B, C, D, Tm)

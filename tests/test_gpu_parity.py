@@ -2004,3 +2004,35 @@ def test_gensys_real_stage_matches_complex_only():
     for i in range(8):
         Tref, ok = oracle.gensys_T_success(b["A"][i], b["B"][i], b["C"][i], b["D"][i], tol=1e-8)[:2]
         assert ok and np.abs(on["T"][i] - Tref).max() <= 1e-9
+
+
+def test_zero_T_on_solver_failure_matches_the_reference_default_graph():
+    """add_solver_success_check=False is the reference's default (statespace.py:1148, 1210-1215): a failed cycle reduction hands
+    on T = 0 (cycle_reduction.py:181) and the model sees the FINITE log-likelihood of that system.  With
+    DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE the fused call does the same (status still reports the failure); without it (default)
+    the draw gets -inf.  Converged draws are unaffected by the flag (1e-10: R comes from the explicit solve instead of the
+    solver's final elimination)."""
+    nb = 12
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y = om["y"][:80]
+    kw = dict(Hdiag=om["Hdiag"], tol=1e-8, q_mode=1)
+    # max_iter = 6: some of these draws need 7..9 iterations
+    strict = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, max_iter=6, return_policy=True, **kw)
+    loose = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, max_iter=6, return_policy=True,
+                                              add_solver_success_check=False, **kw)
+    failed = strict["status"] != 0
+    assert failed.any() and (~failed).any()
+    assert np.array_equal(loose["status"], strict["status"])
+    assert np.all(strict["logp"][failed] == -np.inf) and np.all(np.isfinite(loose["logp"][failed]))
+    assert np.all(loose["T"][failed] == 0.0)
+    ok = ~failed
+    assert np.abs(loose["logp"][ok] - strict["logp"][ok]).max() <= 1e-10 * np.abs(strict["logp"][ok]).max()
+    for i in range(nb):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], y, H=np.diag(om["Hdiag"]),
+                                       tol=1e-8, max_iter=6, add_solver_success_check=False)
+        assert ref["success"] == (not failed[i])
+        assert abs(loose["logp"][i] - ref["logp"]) <= 1e-8 * abs(ref["logp"]), (i, loose["logp"][i], ref["logp"])
+        if failed[i]:
+            assert np.abs(loose["R"][i] - ref["R"]).max() <= 1e-9 * max(1.0, np.abs(ref["R"]).max())
