@@ -545,10 +545,14 @@ def make_numba_gensys(njit, gensys_host, tol):
         A64 = np.ascontiguousarray(A).astype(np.float64)
         B64 = np.ascontiguousarray(B).astype(np.float64)
         C64 = np.ascontiguousarray(C).astype(np.float64)
+        D64 = np.ascontiguousarray(D).astype(np.float64)
+        k = D64.shape[1]
         T = np.zeros((n, n), dtype=np.float64)
+        R = np.zeros((n, k), dtype=np.float64)  # (real buffers for D and R: numba may refuse to type an integer 0 as a pointer)
         eu = np.zeros(3, dtype=np.int32)
         status = np.ones(1, dtype=np.int32)
-        rc = gensys_host(A64.ctypes, B64.ctypes, C64.ctypes, 0, 1, n, 1, tol, 0, T.ctypes, 0, eu.ctypes, status.ctypes)
+        rc = gensys_host(A64.ctypes, B64.ctypes, C64.ctypes, D64.ctypes, 1, n, k, tol, 0, T.ctypes, R.ctypes, eu.ctypes,
+                         status.ctypes)
         success = (rc == 0) and (eu[0] == 1) and (eu[1] == 1)
         return T, success
 
@@ -567,14 +571,14 @@ def _register_numba():
     def numba_funcify_HipCycleReduction(op, node, **kwargs):  # noqa: ARG001
         fn = make_numba_cycle_reduction(numba_basic.numba_njit, _lib.load().dsge_cycle_reduction_batched_host, op.max_iter,
                                         op.tol, node.outputs[0].type.numpy_dtype)
-        cache_version = 1
-        return fn, cache_version
+        # no cache key: the compiled function holds the ADDRESS of a ctypes function of this process's library; an on-disk
+        # cache entry would outlive it
+        return fn, None
 
     @register_funcify_default_op_cache_key(HipGensys)
     def numba_funcify_HipGensys(op, node, **kwargs):  # noqa: ARG001
         fn = make_numba_gensys(numba_basic.numba_njit, _lib.load().dsge_gensys_batched_host, op.tol)
-        cache_version = 1
-        return fn, cache_version
+        return fn, None
 
     return True
 
@@ -598,7 +602,10 @@ def _register_jax():
                 op.perform(node, [np.asarray(a) for a in arrays], cells)
                 return tuple(np.asarray(c[0], dtype=sd.dtype).reshape(sd.shape) for c, sd in zip(cells, shapes))
 
-            res = jax.pure_callback(host, tuple(shapes), *inputs)
+            try:  # batched by running the callback once per element (the library call is itself batched where it matters)
+                res = jax.pure_callback(host, tuple(shapes), *inputs, vmap_method="sequential")
+            except TypeError:  # older jax: no vmap_method keyword
+                res = jax.pure_callback(host, tuple(shapes), *inputs)
             return res[0] if len(res) == 1 else res
 
         return fn

@@ -163,12 +163,13 @@ def test_numba_wrappers_are_plain_python_when_handed_an_identity_decorator():
     assert calls == [(1, 3, 77, 1e-5)] and T.dtype == np.float32 and np.isnan(T).all()
 
     def fake_gs(a, b, c, d, batch, n, k, tol, nl, t, r, eu, status):
-        calls.append((batch, n, k, tol, nl, d, r))
+        calls.append((batch, n, k, tol, nl, type(d).__name__, type(r).__name__))
         return 0
 
     g = ops.make_numba_gensys(lambda fn: fn, fake_gs, 1e-8)
-    T, success = g(np.eye(4), np.eye(4), np.eye(4), np.ones((4, 1)))
-    assert calls[-1] == (1, 4, 1, 1e-8, 0, 0, 0) and T.shape == (4, 4) and not success  # eu stayed [0,0,0]
+    T, success = g(np.eye(4), np.eye(4), np.eye(4), np.ones((4, 2)))
+    # D and R are real buffers (numba may refuse to type an integer 0 as a pointer argument)
+    assert calls[-1] == (1, 4, 2, 1e-8, 0, "_ctypes", "_ctypes") and T.shape == (4, 4) and not success  # eu stayed [0,0,0]
 
 
 def test_gensys_output_dtype_follows_floatx(surface, monkeypatch):
