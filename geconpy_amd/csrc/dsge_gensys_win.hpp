@@ -62,8 +62,8 @@ __host__ __device__ inline size_t gw_reduce_smem(const GwCaps& c) {
   const int Ncap = c.n + c.lcap;
   return ((size_t)Ncap * (Ncap | 1) + (size_t)Ncap * (c.wcap | 1) + (size_t)Ncap * (c.lcap | 1)) * 8 + 64 * 4;
 }
-__host__ __device__ inline size_t gw_reduce2_smem(const GwCaps& c) {
-  return ((size_t)3 * c.wcap * (c.wcap | 1) + (size_t)c.wcap * (c.lcap | 1)) * 8;
+__host__ __device__ inline size_t gw_reduce2_smem(const GwCaps& c) {  // [H | X] and T; M stays in the HBM workspace
+  return ((size_t)c.wcap * ((c.wcap + c.lcap) | 1) + (size_t)c.wcap * (c.wcap | 1)) * 8;
 }
 __host__ __device__ inline size_t gw_qz_smem(const GwCaps& c) {  // H and T share one array; M stays in HBM / L2 (GsLayout)
   return ((size_t)c.wcap * ((c.wcap + 4) | 1) + (size_t)c.wcap * (c.lcap | 1)) * 16;
@@ -291,415 +291,163 @@ __device__ __forceinline__ GwHouse gw_house3(double x, double y, double z) {
   return h;
 }
 
-// ---- launch 1b: Hessenberg-triangular reduction of the window (real): T22 -> upper triangular by reflectors, H22 -> upper
-// Hessenberg by Givens pairs; the right transformation Zr is accumulated and handed over transposed and complex.
-__global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp, double* __restrict__ ws,
-                                                             long long* __restrict__ dbg) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
-  const int ldW = cp.wcap | 1, ldX = cp.lcap | 1;
-  const int ldH = ldW;  // the window copy of H
-  double* hb = smem;
-  double* tb = hb + (size_t)cp.wcap * ldW;
-  double* Zr = tb + (size_t)cp.wcap * ldW;
-  double* xb = Zr + (size_t)cp.wcap * ldW;
-  const GwOffsets wo = gw_offsets(cp);
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    double* wd = ws + (size_t)draw * wo.total;
-    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
-    if (meta[GW_FLAG] != 0) continue;
-    const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
-    wave_sync();
-    GW_STAMP(5);
-    lane_loop_batched<4>(
-        w * w, lane,
-        [&](int idx) {
-          const int i = idx / w, j = idx - i * w;
-          const size_t o = (size_t)i * cp.wcap + j;
-          return double2{wd[wo.HR + o], wd[wo.TR + o]};
-        },
-        [&](int idx, double2 v) {
-          const int i = idx / w, j = idx - i * w;
-          hb[i * ldH + j] = v.x;
-          tb[i * ldW + j] = v.y;
-          Zr[i * ldW + j] = (i == j) ? 1.0 : 0.0;
-        });
-    lane_loop_batched<8>(
-        w * ell, lane,
-        [&](int idx) {
-          const int i = idx / ell, j = idx - i * ell;
-          return wd[wo.XR + (size_t)i * cp.lcap + j];
-        },
-        [&](int idx, double v) {
-          const int i = idx / ell, j = idx - i * ell;
-          xb[i * ldX + j] = v;
-        });
-    wave_sync();
-    // ---- T22 -> upper triangular (reflectors)
-    for (int j = 0; j < w - 1; ++j) hh_left_real(hb, ldH, 0, w, tb, ldW, w, xb, ldX, ell, tb, ldW, j, j, w, lane);
-    GW_STAMP(2);
-    // ---- window: H22 -> upper Hessenberg by Givens pairs (column j prefetched, pivots travel through registers)
-    const bool wa = lane < w, xa = lane < ell;
-    for (int j = 0; j < w - 2; ++j) {
-      wave_sync();
-      const double colv = wa ? hb[lane * ldH + j] : 0.0;
-      double g = readlane_dyn_f64(colv, w - 1);
-      for (int i = w - 1; i > j + 1; --i) {
-        const double f = readlane_dyn_f64(colv, i - 1);
-        if (g == 0.0) {
-          g = f;
-          continue;
-        }
-        wave_sync();
-        double hx = 0.0, hy = 0.0, tx = 0.0, ty = 0.0, ax = 0.0, ay = 0.0;
-        if (wa) {
-          hx = hb[(i - 1) * ldH + lane];
-          hy = hb[i * ldH + lane];
-          tx = tb[(i - 1) * ldW + lane];
-          ty = tb[i * ldW + lane];
-        }
-        if (xa) {
-          ax = xb[(i - 1) * ldX + lane];
-          ay = xb[i * ldX + lane];
-        }
-        double c, s, r;
-        lartg_real(f, g, c, s, r);
-        rot2r(hx, hy, c, s);
-        rot2r(tx, ty, c, s);
-        rot2r(ax, ay, c, s);
-        if (lane == j) {
-          hx = r;
-          hy = 0.0;
-        }
-        if (wa) {
-          hb[(i - 1) * ldH + lane] = hx;
-          hb[i * ldH + lane] = hy;
-          tb[(i - 1) * ldW + lane] = tx;
-          tb[i * ldW + lane] = ty;
-        }
-        if (xa) {
-          xb[(i - 1) * ldX + lane] = ax;
-          xb[i * ldX + lane] = ay;
-        }
-        g = r;
-        const double tii = readlane_dyn_f64(ty, i), tim = readlane_dyn_f64(ty, i - 1);
-        if (tim != 0.0) {
-          wave_sync();
-          double qx = 0.0, qy = 0.0;
-          if (wa) {
-            hx = hb[lane * ldH + i];
-            hy = hb[lane * ldH + i - 1];
-            tx = tb[lane * ldW + i];
-            ty = tb[lane * ldW + i - 1];
-            qx = Zr[lane * ldW + i];
-            qy = Zr[lane * ldW + i - 1];
-          }
-          double r2;
-          lartg_real(tii, tim, c, s, r2);
-          rot2r(hx, hy, c, s);
-          rot2r(tx, ty, c, s);
-          rot2r(qx, qy, c, s);
-          if (lane == i) {
-            tx = r2;
-            ty = 0.0;
-          }
-          if (wa) {
-            hb[lane * ldH + i] = hx;
-            hb[lane * ldH + i - 1] = hy;
-            tb[lane * ldW + i] = tx;
-            tb[lane * ldW + i - 1] = ty;
-            Zr[lane * ldW + i] = qx;
-            Zr[lane * ldW + i - 1] = qy;
-          }
-        }
-      }
-    }
-    wave_sync();
-    GW_STAMP(3);
-    for (int idx = lane; idx < w * w; idx += 64) {
-      const int i = idx / w, j = idx - i * w;
-      const size_t o = (size_t)i * cp.wcap + j;
-      wd[wo.HR + o] = hb[i * ldH + j];
-      wd[wo.TR + o] = tb[i * ldW + j];
-    }
-    {  // the right transformation so far, TRANSPOSED and complex: the QZ launch keeps accumulating it in place
-      cx* MC = reinterpret_cast<cx*>(wd + wo.MC);
-      for (int idx = lane; idx < w * w; idx += 64) {
-        const int col = idx / w, row = idx - col * w;
-        MC[(size_t)col * cp.wcap + row] = mk(Zr[row * ldW + col], 0.0);
-      }
-    }
-    for (int idx = lane; idx < w * ell; idx += 64) {
-      const int i = idx / ell, j = idx - i * ell;
-      wd[wo.XR + (size_t)i * cp.lcap + j] = xb[i * ldX + j];
-    }
-    GW_STAMP(4);
-  }
-}
-
-
-// ---- launch 1c: real double-shift QZ sweeps on the window (see gw_house3 above) --------------------------------------------
-__host__ __device__ inline size_t gw_realqz_smem(const GwCaps& c) {
-  return ((size_t)c.wcap * ((c.wcap + c.lcap) | 1) + (size_t)c.wcap * (c.wcap | 1)) * 8;
-}
-
-__global__ __launch_bounds__(64) void gensys_realqz_kernel(int batch, GwCaps cp, double* __restrict__ ws,
-                                                            long long* __restrict__ dbg) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
-  const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
-  double* hb = smem;                          // [H | X]: X(i, j) at column wcap + j
-  double* tb = hb + (size_t)cp.wcap * ldH;
-  const GwOffsets wo = gw_offsets(cp);
+// The sweeps: [H | X] in hb (X(i, j) at column wcap + j, row stride ldH), T in tb (row stride ldW), M transposed and complex
+// (real content) in the draw's workspace: element (row, col) at MR[col * mcol + 2 * row].
+__device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb, int ldW, double* MR, size_t mcol, int wcap, int w,
+                                                 int ell, int lane, long long* cnt) {
+  if (w < 3 || w + ell > 64) return;  // nothing to gain / the packed lane map does not fit: the complex iteration does it all
   constexpr double ULPD = 2.220446049250313e-16, SAFMIN = 2.2250738585072014e-308;
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    double* wd = ws + (size_t)draw * wo.total;
-    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
-    if (meta[GW_FLAG] != 0) continue;
-    const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
-    if (w < 3 || w + ell > 64) continue;  // nothing to gain / the packed lane map does not fit: the complex iteration does it all
+  wave_sync();
+  // M transposed and complex (real content): element (row, col) at MR[2 * (col * wcap + row)]
+  const bool wa = lane < w, la = lane < w + ell;
+  const int cw = min(lane, w - 1);                                        // column of T / row of H, T, M (loads)
+  const int ca = lane < w ? lane : (la ? wcap + lane - w : 0);          // column of [H | X]
+  double btol;
+  {
+    double ss = 0.0;
+    if (wa)
+      for (int i = 0; i <= lane; ++i) {
+        const double t = tb[i * ldW + lane];
+        ss = fma(t, t, ss);
+      }
+    btol = fmax(SAFMIN, ULPD * sqrt(wave_sum(ss)));
+  }
+  int ilast = w - 1, it = 0;
+  long long steps = 0, sweeps = 0;
+  const int max_total = 40 * w;
+  for (int guard = 0; guard < max_total && ilast >= 2; ++guard) {
     wave_sync();
-    GW_STAMP(6);
-    lane_loop_batched<4>(
-        w * w, lane,
-        [&](int idx) {
-          const int i = idx / w, j = idx - i * w;
-          const size_t o = (size_t)i * cp.wcap + j;
-          return double2{wd[wo.HR + o], wd[wo.TR + o]};
-        },
-        [&](int idx, double2 v) {
-          const int i = idx / w, j = idx - i * w;
-          hb[i * ldH + j] = v.x;
-          tb[i * ldW + j] = v.y;
-        });
-    lane_loop_batched<8>(
-        w * ell, lane,
-        [&](int idx) {
-          const int i = idx / ell, j = idx - i * ell;
-          return wd[wo.XR + (size_t)i * cp.lcap + j];
-        },
-        [&](int idx, double v) {
-          const int i = idx / ell, j = idx - i * ell;
-          hb[i * ldH + cp.wcap + j] = v;
-        });
-    wave_sync();
-    // M transposed and complex (real content): element (row, col) at MR[2 * (col * wcap + row)]
-    double* MR = wd + wo.MC;
-    const size_t mcol = 2 * (size_t)cp.wcap;
-    const bool wa = lane < w, la = lane < w + ell;
-    const int cw = min(lane, w - 1);                                        // column of T / row of H, T, M (loads)
-    const int ca = lane < w ? lane : (la ? cp.wcap + lane - w : 0);          // column of [H | X]
-    double btol;
-    {
-      double ss = 0.0;
-      if (wa)
-        for (int i = 0; i <= lane; ++i) {
-          const double t = tb[i * ldW + lane];
-          ss = fma(t, t, ss);
-        }
-      btol = fmax(SAFMIN, ULPD * sqrt(wave_sum(ss)));
+    // ---- deflation tests: one sub-diagonal entry per lane
+    double hjj = 0.0, hmm = 0.0, hsub = 0.0, tjj = 1.0;
+    if (wa) {
+      hjj = hb[lane * ldH + lane];
+      tjj = tb[lane * ldW + lane];
+      if (lane > 0) {
+        hsub = hb[lane * ldH + lane - 1];
+        hmm = hb[(lane - 1) * ldH + lane - 1];
+      }
     }
-    int ilast = w - 1, it = 0;
-    long long steps = 0, sweeps = 0;
-    const int max_total = 40 * w;
-    for (int guard = 0; guard < max_total && ilast >= 2; ++guard) {
-      wave_sync();
-      // ---- deflation tests: one sub-diagonal entry per lane
-      double hjj = 0.0, hmm = 0.0, hsub = 0.0, tjj = 1.0;
+    const bool sm = wa && lane > 0 && fabs(hsub) <= fmax(SAFMIN, ULPD * (fabs(hjj) + fabs(hmm)));
+    const unsigned long long small = __ballot(sm);
+    const unsigned long long tzero = __ballot(wa && fabs(tjj) <= btol);
+    if ((small >> ilast) & 1ull) {
+      if (lane == 0) hb[ilast * ldH + ilast - 1] = 0.0;
+      ilast -= 1;
+      it = 0;
+      continue;
+    }
+    if ((small >> (ilast - 1)) & 1ull) {
+      if (lane == 0) hb[(ilast - 1) * ldH + ilast - 2] = 0.0;
+      ilast -= 2;  // a 2 x 2 block: the complex iteration splits it
+      it = 0;
+      continue;
+    }
+    int ifirst = 0;
+    {
+      const unsigned long long below = small & ((1ull << (ilast - 1)) - 1ull);  // bits 1 .. ilast-2
+      if (below) {
+        ifirst = 63 - __clzll((long long)below);
+        if (lane == 0) hb[ifirst * ldH + ifirst - 1] = 0.0;
+      }
+    }
+    {
+      const unsigned long long act = ((ilast >= 63) ? ~0ull : ((1ull << (ilast + 1)) - 1ull)) & ~((1ull << ifirst) - 1ull);
+      if (tzero & act) break;  // an infinite root inside the active block: zhgeqz's zero chasing lives in the next launch
+    }
+    if (++it > 30) break;
+    wave_sync();
+    // the first three columns of M for this sweep (in flight during the shift arithmetic)
+    double m0 = MR[(size_t)ifirst * mcol + 2 * cw], m1 = MR[(size_t)(ifirst + 1) * mcol + 2 * cw],
+           m2 = MR[(size_t)(ifirst + 2) * mcol + 2 * cw];
+    // ---- the first column of (M - s1)(M - s2), M = H T^-1 on the active block, shifts = roots of the trailing 2 x 2 pencil
+    double x, y, z;
+    {
+      const int m = ilast;
+      const double p_ = hb[(m - 1) * ldH + m - 1], q_ = hb[(m - 1) * ldH + m], r_ = hb[m * ldH + m - 1], s_ = hb[m * ldH + m];
+      const double e_ = tb[(m - 1) * ldW + m - 1], f_ = tb[(m - 1) * ldW + m], g_ = tb[m * ldW + m];
+      double tr, det;
+      if (it % 10 == 0) {  // exceptional shifts
+        const double w_ = 1.5 * (fabs(r_ / e_) + fabs(hb[(m - 1) * ldH + m - 2] / tb[(m - 2) * ldW + m - 2]));
+        tr = w_;
+        det = w_ * w_;
+      } else {
+        tr = p_ / e_ + (s_ - r_ * f_ / e_) / g_;
+        det = (p_ * s_ - q_ * r_) / (e_ * g_);
+      }
+      const int k = ifirst;
+      const double a11 = hb[k * ldH + k], a12 = hb[k * ldH + k + 1], a21 = hb[(k + 1) * ldH + k],
+                   a22 = hb[(k + 1) * ldH + k + 1], a32 = hb[(k + 2) * ldH + k + 1];
+      const double b11 = tb[k * ldW + k], b12 = tb[k * ldW + k + 1], b22 = tb[(k + 1) * ldW + k + 1];
+      const double m11 = a11 / b11, m21 = a21 / b11;
+      const double y2 = m21 / b22;
+      const double y1 = (m11 - b12 * y2) / b11;
+      x = a11 * y1 + a12 * y2 - tr * m11 + det;
+      y = a21 * y1 + a22 * y2 - tr * m21;
+      z = a32 * y2;
+    }
+    if (!(fabs(x) + fabs(y) + fabs(z) < 1e300)) break;  // NaN / overflow in the shift arithmetic: leave it to zhgeqz's logic
+    ++sweeps;
+    for (int k = ifirst; k <= ilast - 2; ++k) {
+      // the column of M the NEXT step brings in (consumed at the end of this one)
+      const double m3 = MR[(size_t)min(k + 3, w - 1) * mcol + 2 * cw];
+      // ---- left: rows k .. k+2; lane = column of [H | X] and column of T.  Loads unmasked, stores under one mask each.
+      double h0 = hb[k * ldH + ca], h1 = hb[(k + 1) * ldH + ca], h2 = hb[(k + 2) * ldH + ca];
+      double t0 = tb[k * ldW + cw], t1 = tb[(k + 1) * ldW + cw], t2 = tb[(k + 2) * ldW + cw];
+      const GwHouse q = gw_house3(x, y, z);
+      {
+        const double sh = q.tau * fma(q.v2, h2, fma(q.v1, h1, h0));
+        h0 -= sh;
+        h1 = fma(-sh, q.v1, h1);
+        h2 = fma(-sh, q.v2, h2);
+        const double st = q.tau * fma(q.v2, t2, fma(q.v1, t1, t0));
+        t0 -= st;
+        t1 = fma(-st, q.v1, t1);
+        t2 = fma(-st, q.v2, t2);
+      }
+      if (k > ifirst && lane == k - 1) {
+        h0 = q.beta;
+        h1 = 0.0;
+        h2 = 0.0;
+      }
+      if (la) {
+        hb[k * ldH + ca] = h0;
+        hb[(k + 1) * ldH + ca] = h1;
+        hb[(k + 2) * ldH + ca] = h2;
+      }
       if (wa) {
-        hjj = hb[lane * ldH + lane];
-        tjj = tb[lane * ldW + lane];
-        if (lane > 0) {
-          hsub = hb[lane * ldH + lane - 1];
-          hmm = hb[(lane - 1) * ldH + lane - 1];
-        }
+        tb[k * ldW + cw] = t0;
+        tb[(k + 1) * ldW + cw] = t1;
+        tb[(k + 2) * ldW + cw] = t2;
       }
-      const bool sm = wa && lane > 0 && fabs(hsub) <= fmax(SAFMIN, ULPD * (fabs(hjj) + fabs(hmm)));
-      const unsigned long long small = __ballot(sm);
-      const unsigned long long tzero = __ballot(wa && fabs(tjj) <= btol);
-      if ((small >> ilast) & 1ull) {
-        if (lane == 0) hb[ilast * ldH + ilast - 1] = 0.0;
-        ilast -= 1;
-        it = 0;
-        continue;
-      }
-      if ((small >> (ilast - 1)) & 1ull) {
-        if (lane == 0) hb[(ilast - 1) * ldH + ilast - 2] = 0.0;
-        ilast -= 2;  // a 2 x 2 block: the complex iteration splits it
-        it = 0;
-        continue;
-      }
-      int ifirst = 0;
-      {
-        const unsigned long long below = small & ((1ull << (ilast - 1)) - 1ull);  // bits 1 .. ilast-2
-        if (below) {
-          ifirst = 63 - __clzll((long long)below);
-          if (lane == 0) hb[ifirst * ldH + ifirst - 1] = 0.0;
-        }
-      }
-      {
-        const unsigned long long act = ((ilast >= 63) ? ~0ull : ((1ull << (ilast + 1)) - 1ull)) & ~((1ull << ifirst) - 1ull);
-        if (tzero & act) break;  // an infinite root inside the active block: zhgeqz's zero chasing lives in the next launch
-      }
-      if (++it > 30) break;
+      // row k+2 of T, columns k .. k+2: defines the 3-column reflector  [b0 b1 b2] Z1 = [0 0 *]
+      const double b0 = readlane_dyn_f64(t2, k), b1 = readlane_dyn_f64(t2, k + 1), b2 = readlane_dyn_f64(t2, k + 2);
       wave_sync();
-      // the first three columns of M for this sweep (in flight during the shift arithmetic)
-      double m0 = MR[(size_t)ifirst * mcol + 2 * cw], m1 = MR[(size_t)(ifirst + 1) * mcol + 2 * cw],
-             m2 = MR[(size_t)(ifirst + 2) * mcol + 2 * cw];
-      // ---- the first column of (M - s1)(M - s2), M = H T^-1 on the active block, shifts = roots of the trailing 2 x 2 pencil
-      double x, y, z;
+      // ---- right: columns k .. k+2; lane = row of H, of T and of M
+      double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1], r2 = hb[cw * ldH + k + 2];
+      double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1], u2 = tb[cw * ldW + k + 2];
       {
-        const int m = ilast;
-        const double p_ = hb[(m - 1) * ldH + m - 1], q_ = hb[(m - 1) * ldH + m], r_ = hb[m * ldH + m - 1], s_ = hb[m * ldH + m];
-        const double e_ = tb[(m - 1) * ldW + m - 1], f_ = tb[(m - 1) * ldW + m], g_ = tb[m * ldW + m];
-        double tr, det;
-        if (it % 10 == 0) {  // exceptional shifts
-          const double w_ = 1.5 * (fabs(r_ / e_) + fabs(hb[(m - 1) * ldH + m - 2] / tb[(m - 2) * ldW + m - 2]));
-          tr = w_;
-          det = w_ * w_;
-        } else {
-          tr = p_ / e_ + (s_ - r_ * f_ / e_) / g_;
-          det = (p_ * s_ - q_ * r_) / (e_ * g_);
+        const GwHouse g1 = gw_house3(b2, b1, b0);  // reversed: v = [v2 v1 1] on columns k, k+1, k+2
+        const double sh = g1.tau * fma(g1.v2, r0, fma(g1.v1, r1, r2));
+        r0 = fma(-sh, g1.v2, r0);
+        r1 = fma(-sh, g1.v1, r1);
+        r2 -= sh;
+        const double st = g1.tau * fma(g1.v2, u0, fma(g1.v1, u1, u2));
+        u0 = fma(-st, g1.v2, u0);
+        u1 = fma(-st, g1.v1, u1);
+        u2 -= st;
+        const double sz = g1.tau * fma(g1.v2, m0, fma(g1.v1, m1, m2));
+        m0 = fma(-sz, g1.v2, m0);
+        m1 = fma(-sz, g1.v1, m1);
+        m2 -= sz;
+        if (lane == k + 2) {
+          u0 = 0.0;
+          u1 = 0.0;
+          u2 = g1.beta;
         }
-        const int k = ifirst;
-        const double a11 = hb[k * ldH + k], a12 = hb[k * ldH + k + 1], a21 = hb[(k + 1) * ldH + k],
-                     a22 = hb[(k + 1) * ldH + k + 1], a32 = hb[(k + 2) * ldH + k + 1];
-        const double b11 = tb[k * ldW + k], b12 = tb[k * ldW + k + 1], b22 = tb[(k + 1) * ldW + k + 1];
-        const double m11 = a11 / b11, m21 = a21 / b11;
-        const double y2 = m21 / b22;
-        const double y1 = (m11 - b12 * y2) / b11;
-        x = a11 * y1 + a12 * y2 - tr * m11 + det;
-        y = a21 * y1 + a22 * y2 - tr * m21;
-        z = a32 * y2;
       }
-      if (!(fabs(x) + fabs(y) + fabs(z) < 1e300)) break;  // NaN / overflow in the shift arithmetic: leave it to zhgeqz's logic
-      ++sweeps;
-      for (int k = ifirst; k <= ilast - 2; ++k) {
-        // the column of M the NEXT step brings in (consumed at the end of this one)
-        const double m3 = MR[(size_t)min(k + 3, w - 1) * mcol + 2 * cw];
-        // ---- left: rows k .. k+2; lane = column of [H | X] and column of T.  Loads unmasked, stores under one mask each.
-        double h0 = hb[k * ldH + ca], h1 = hb[(k + 1) * ldH + ca], h2 = hb[(k + 2) * ldH + ca];
-        double t0 = tb[k * ldW + cw], t1 = tb[(k + 1) * ldW + cw], t2 = tb[(k + 2) * ldW + cw];
-        const GwHouse q = gw_house3(x, y, z);
-        {
-          const double sh = q.tau * fma(q.v2, h2, fma(q.v1, h1, h0));
-          h0 -= sh;
-          h1 = fma(-sh, q.v1, h1);
-          h2 = fma(-sh, q.v2, h2);
-          const double st = q.tau * fma(q.v2, t2, fma(q.v1, t1, t0));
-          t0 -= st;
-          t1 = fma(-st, q.v1, t1);
-          t2 = fma(-st, q.v2, t2);
-        }
-        if (k > ifirst && lane == k - 1) {
-          h0 = q.beta;
-          h1 = 0.0;
-          h2 = 0.0;
-        }
-        if (la) {
-          hb[k * ldH + ca] = h0;
-          hb[(k + 1) * ldH + ca] = h1;
-          hb[(k + 2) * ldH + ca] = h2;
-        }
-        if (wa) {
-          tb[k * ldW + cw] = t0;
-          tb[(k + 1) * ldW + cw] = t1;
-          tb[(k + 2) * ldW + cw] = t2;
-        }
-        // row k+2 of T, columns k .. k+2: defines the 3-column reflector  [b0 b1 b2] Z1 = [0 0 *]
-        const double b0 = readlane_dyn_f64(t2, k), b1 = readlane_dyn_f64(t2, k + 1), b2 = readlane_dyn_f64(t2, k + 2);
-        wave_sync();
-        // ---- right: columns k .. k+2; lane = row of H, of T and of M
-        double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1], r2 = hb[cw * ldH + k + 2];
-        double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1], u2 = tb[cw * ldW + k + 2];
-        {
-          const GwHouse g1 = gw_house3(b2, b1, b0);  // reversed: v = [v2 v1 1] on columns k, k+1, k+2
-          const double sh = g1.tau * fma(g1.v2, r0, fma(g1.v1, r1, r2));
-          r0 = fma(-sh, g1.v2, r0);
-          r1 = fma(-sh, g1.v1, r1);
-          r2 -= sh;
-          const double st = g1.tau * fma(g1.v2, u0, fma(g1.v1, u1, u2));
-          u0 = fma(-st, g1.v2, u0);
-          u1 = fma(-st, g1.v1, u1);
-          u2 -= st;
-          const double sz = g1.tau * fma(g1.v2, m0, fma(g1.v1, m1, m2));
-          m0 = fma(-sz, g1.v2, m0);
-          m1 = fma(-sz, g1.v1, m1);
-          m2 -= sz;
-          if (lane == k + 2) {
-            u0 = 0.0;
-            u1 = 0.0;
-            u2 = g1.beta;
-          }
-        }
-        {
-          const double c0 = readlane_dyn_f64(u0, k + 1), c1 = readlane_dyn_f64(u1, k + 1);  // T[k+1][k], T[k+1][k+1] after Z1
-          const GwHouse g2 = gw_house3(c1, c0, 0.0);  // v = [v1 1] on columns k, k+1
-          const double sh = g2.tau * fma(g2.v1, r0, r1);
-          r0 = fma(-sh, g2.v1, r0);
-          r1 -= sh;
-          const double st = g2.tau * fma(g2.v1, u0, u1);
-          u0 = fma(-st, g2.v1, u0);
-          u1 -= st;
-          const double sz = g2.tau * fma(g2.v1, m0, m1);
-          m0 = fma(-sz, g2.v1, m0);
-          m1 -= sz;
-          if (lane == k + 1) {
-            u0 = 0.0;
-            u1 = g2.beta;
-          }
-        }
-        if (wa) {
-          hb[cw * ldH + k] = r0;
-          hb[cw * ldH + k + 1] = r1;
-          hb[cw * ldH + k + 2] = r2;
-          tb[cw * ldW + k] = u0;
-          tb[cw * ldW + k + 1] = u1;
-          tb[cw * ldW + k + 2] = u2;
-          MR[(size_t)k * mcol + 2 * cw] = m0;  // column k of M is final for this sweep
-        }
-        x = readlane_dyn_f64(r0, k + 1);
-        y = readlane_dyn_f64(r0, k + 2);
-        {
-          const double z3 = readlane_dyn_f64(r0, min(k + 3, 63));
-          z = (k + 3 <= ilast) ? z3 : 0.0;
-        }
-        m0 = m1;
-        m1 = m2;
-        m2 = m3;
-        wave_sync();
-        ++steps;
-      }
-      {  // ---- the last step of the sweep: two rows, two columns (m0, m1 = columns ilast-1, ilast of M)
-        const int k = ilast - 1;
-        double h0 = hb[k * ldH + ca], h1 = hb[(k + 1) * ldH + ca];
-        double t0 = tb[k * ldW + cw], t1 = tb[(k + 1) * ldW + cw];
-        const GwHouse q = gw_house3(x, y, 0.0);
-        {
-          const double sh = q.tau * fma(q.v1, h1, h0);
-          h0 -= sh;
-          h1 = fma(-sh, q.v1, h1);
-          const double st = q.tau * fma(q.v1, t1, t0);
-          t0 -= st;
-          t1 = fma(-st, q.v1, t1);
-        }
-        if (lane == k - 1) {
-          h0 = q.beta;
-          h1 = 0.0;
-        }
-        if (la) {
-          hb[k * ldH + ca] = h0;
-          hb[(k + 1) * ldH + ca] = h1;
-        }
-        if (wa) {
-          tb[k * ldW + cw] = t0;
-          tb[(k + 1) * ldW + cw] = t1;
-        }
-        const double c0 = readlane_dyn_f64(t1, k), c1 = readlane_dyn_f64(t1, k + 1);
-        wave_sync();
-        double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1];
-        double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1];
-        const GwHouse g2 = gw_house3(c1, c0, 0.0);
+      {
+        const double c0 = readlane_dyn_f64(u0, k + 1), c1 = readlane_dyn_f64(u1, k + 1);  // T[k+1][k], T[k+1][k+1] after Z1
+        const GwHouse g2 = gw_house3(c1, c0, 0.0);  // v = [v1 1] on columns k, k+1
         const double sh = g2.tau * fma(g2.v1, r0, r1);
         r0 = fma(-sh, g2.v1, r0);
         r1 -= sh;
@@ -713,19 +461,228 @@ __global__ __launch_bounds__(64) void gensys_realqz_kernel(int batch, GwCaps cp,
           u0 = 0.0;
           u1 = g2.beta;
         }
-        if (wa) {
-          hb[cw * ldH + k] = r0;
-          hb[cw * ldH + k + 1] = r1;
-          tb[cw * ldW + k] = u0;
-          tb[cw * ldW + k + 1] = u1;
-          MR[(size_t)k * mcol + 2 * cw] = m0;
-          MR[(size_t)(k + 1) * mcol + 2 * cw] = m1;
-        }
-        ++steps;
       }
+      if (wa) {
+        hb[cw * ldH + k] = r0;
+        hb[cw * ldH + k + 1] = r1;
+        hb[cw * ldH + k + 2] = r2;
+        tb[cw * ldW + k] = u0;
+        tb[cw * ldW + k + 1] = u1;
+        tb[cw * ldW + k + 2] = u2;
+        MR[(size_t)k * mcol + 2 * cw] = m0;  // column k of M is final for this sweep
+      }
+      x = readlane_dyn_f64(r0, k + 1);
+      y = readlane_dyn_f64(r0, k + 2);
+      {
+        const double z3 = readlane_dyn_f64(r0, min(k + 3, 63));
+        z = (k + 3 <= ilast) ? z3 : 0.0;
+      }
+      m0 = m1;
+      m1 = m2;
+      m2 = m3;
+      wave_sync();
+      ++steps;
+    }
+    {  // ---- the last step of the sweep: two rows, two columns (m0, m1 = columns ilast-1, ilast of M)
+      const int k = ilast - 1;
+      double h0 = hb[k * ldH + ca], h1 = hb[(k + 1) * ldH + ca];
+      double t0 = tb[k * ldW + cw], t1 = tb[(k + 1) * ldW + cw];
+      const GwHouse q = gw_house3(x, y, 0.0);
+      {
+        const double sh = q.tau * fma(q.v1, h1, h0);
+        h0 -= sh;
+        h1 = fma(-sh, q.v1, h1);
+        const double st = q.tau * fma(q.v1, t1, t0);
+        t0 -= st;
+        t1 = fma(-st, q.v1, t1);
+      }
+      if (lane == k - 1) {
+        h0 = q.beta;
+        h1 = 0.0;
+      }
+      if (la) {
+        hb[k * ldH + ca] = h0;
+        hb[(k + 1) * ldH + ca] = h1;
+      }
+      if (wa) {
+        tb[k * ldW + cw] = t0;
+        tb[(k + 1) * ldW + cw] = t1;
+      }
+      const double c0 = readlane_dyn_f64(t1, k), c1 = readlane_dyn_f64(t1, k + 1);
+      wave_sync();
+      double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1];
+      double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1];
+      const GwHouse g2 = gw_house3(c1, c0, 0.0);
+      const double sh = g2.tau * fma(g2.v1, r0, r1);
+      r0 = fma(-sh, g2.v1, r0);
+      r1 -= sh;
+      const double st = g2.tau * fma(g2.v1, u0, u1);
+      u0 = fma(-st, g2.v1, u0);
+      u1 -= st;
+      const double sz = g2.tau * fma(g2.v1, m0, m1);
+      m0 = fma(-sz, g2.v1, m0);
+      m1 -= sz;
+      if (lane == k + 1) {
+        u0 = 0.0;
+        u1 = g2.beta;
+      }
+      if (wa) {
+        hb[cw * ldH + k] = r0;
+        hb[cw * ldH + k + 1] = r1;
+        tb[cw * ldW + k] = u0;
+        tb[cw * ldW + k + 1] = u1;
+        MR[(size_t)k * mcol + 2 * cw] = m0;
+        MR[(size_t)(k + 1) * mcol + 2 * cw] = m1;
+      }
+      ++steps;
+    }
+  }
+  wave_sync();
+  if (cnt && lane == 0) {
+    cnt[0] = steps;
+    cnt[1] = sweeps;
+  }
+}
+
+// ---- launch 1b: Hessenberg-triangular reduction of the window (real): T22 -> upper triangular by reflectors, H22 -> upper
+// Hessenberg by Givens pairs, then (real_stage) the real double-shift sweeps above.  On the chip: [H | X] and T only (18 KB on
+// the SW-shaped window: 8 draws per CU).  The accumulated right transformation M lives transposed and complex in the draw's
+// HBM workspace (as the complex iteration wants it): lane = row of M, the column shared by two consecutive column rotations
+// is carried in a register, the next one is prefetched a rotation ahead, each finished column is stored once.
+__global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp, double* __restrict__ ws,
+                                                             long long* __restrict__ dbg, int real_stage) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
+  double* hb = smem;                          // [H | X]: X(i, j) at column wcap + j
+  double* tb = hb + (size_t)cp.wcap * ldH;
+  double* xb = hb + cp.wcap;
+  const int ldX = ldH;
+  const GwOffsets wo = gw_offsets(cp);
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    double* wd = ws + (size_t)draw * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    if (meta[GW_FLAG] != 0) continue;
+    const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
+    double* MR = wd + wo.MC;
+    const size_t mcol = 2 * (size_t)cp.wcap;
+    wave_sync();
+    GW_STAMP(5);
+    lane_loop_batched<4>(
+        w * w, lane,
+        [&](int idx) {
+          const int i = idx / w, j = idx - i * w;
+          const size_t o = (size_t)i * cp.wcap + j;
+          return double2{wd[wo.HR + o], wd[wo.TR + o]};
+        },
+        [&](int idx, double2 v) {
+          const int i = idx / w, j = idx - i * w;
+          hb[i * ldH + j] = v.x;
+          tb[i * ldW + j] = v.y;
+        });
+    lane_loop_batched<8>(
+        w * ell, lane,
+        [&](int idx) {
+          const int i = idx / ell, j = idx - i * ell;
+          return wd[wo.XR + (size_t)i * cp.lcap + j];
+        },
+        [&](int idx, double v) {
+          const int i = idx / ell, j = idx - i * ell;
+          xb[i * ldX + j] = v;
+        });
+    if (lane < w) {  // M = I, every lane writing the row it will keep reading and writing (no cross-lane traffic through HBM)
+      cx* MC = reinterpret_cast<cx*>(MR);
+      for (int col = 0; col < w; ++col) MC[(size_t)col * cp.wcap + lane] = mk(lane == col ? 1.0 : 0.0, 0.0);
     }
     wave_sync();
-    GW_STAMP(7);
+    // ---- T22 -> upper triangular (reflectors)
+    for (int j = 0; j < w - 1; ++j) hh_left_real(hb, ldH, 0, w, tb, ldW, w, xb, ldX, ell, tb, ldW, j, j, w, lane);
+    GW_STAMP(2);
+    // ---- window: H22 -> upper Hessenberg by Givens pairs (column j prefetched, pivots travelling through registers).
+    // Row rotations with one column of [H | X] and one column of T per lane, column rotations with one row of H, T and M per
+    // lane; loads with clamped indices, stores under one mask.
+    const bool wa = lane < w, la = lane < w + ell || lane < w;
+    const int cw = min(lane, w - 1);
+    const bool packed = w + ell <= 64;
+    const int ca = lane < w ? lane : ((packed && lane < w + ell) ? cp.wcap + lane - w : 0);
+    const bool laa = packed ? (lane < w + ell) : wa;
+    (void)la;
+    for (int j = 0; j < w - 2; ++j) {
+      wave_sync();
+      const double colv = hb[cw * ldH + j];
+      double g = readlane_dyn_f64(colv, w - 1);
+      double m_hi = MR[(size_t)(w - 1) * mcol + 2 * cw];  // column w-1 of M, this lane's row
+      double m_nx = MR[(size_t)(w - 2) * mcol + 2 * cw];  // (the partner column of the NEXT rotation is always in flight)
+      for (int i = w - 1; i > j + 1; --i) {
+        const double m_lo_in = m_nx;
+        m_nx = MR[(size_t)max(i - 2, 0) * mcol + 2 * cw];
+        const double f = readlane_dyn_f64(colv, i - 1);
+        if (g == 0.0) {  // nothing to annihilate: the column pair of M moves on unrotated
+          if (wa) MR[(size_t)i * mcol + 2 * cw] = m_hi;
+          m_hi = m_lo_in;
+          g = f;
+          continue;
+        }
+        wave_sync();
+        double hx = hb[(i - 1) * ldH + ca], hy = hb[i * ldH + ca];
+        double tx = tb[(i - 1) * ldW + cw], ty = tb[i * ldW + cw];
+        double c, s, r;
+        lartg_real(f, g, c, s, r);
+        rot2r(hx, hy, c, s);
+        rot2r(tx, ty, c, s);
+        if (lane == j) {
+          hx = r;
+          hy = 0.0;
+        }
+        if (laa) {
+          hb[(i - 1) * ldH + ca] = hx;
+          hb[i * ldH + ca] = hy;
+        }
+        if (wa) {
+          tb[(i - 1) * ldW + cw] = tx;
+          tb[i * ldW + cw] = ty;
+        }
+        if (!packed) {  // (window + #lead > 64: X in a pass of its own)
+          for (int c0 = lane; c0 < ell; c0 += 64) {
+            double ax = xb[(i - 1) * ldX + c0], ay = xb[i * ldX + c0];
+            rot2r(ax, ay, c, s);
+            xb[(i - 1) * ldX + c0] = ax;
+            xb[i * ldX + c0] = ay;
+          }
+        }
+        g = r;
+        const double tii = readlane_dyn_f64(ty, i), tim = readlane_dyn_f64(ty, i - 1);
+        double m_lo = m_lo_in;
+        if (tim != 0.0) {
+          wave_sync();
+          double hx2 = hb[cw * ldH + i], hy2 = hb[cw * ldH + i - 1];
+          double tx2 = tb[cw * ldW + i], ty2 = tb[cw * ldW + i - 1];
+          double r2;
+          lartg_real(tii, tim, c, s, r2);
+          rot2r(hx2, hy2, c, s);
+          rot2r(tx2, ty2, c, s);
+          rot2r(m_hi, m_lo, c, s);
+          if (lane == i) {
+            tx2 = r2;
+            ty2 = 0.0;
+          }
+          if (wa) {
+            hb[cw * ldH + i] = hx2;
+            hb[cw * ldH + i - 1] = hy2;
+            tb[cw * ldW + i] = tx2;
+            tb[cw * ldW + i - 1] = ty2;
+          }
+        }
+        if (wa) MR[(size_t)i * mcol + 2 * cw] = m_hi;  // column i of M is final for this j
+        m_hi = m_lo;
+      }
+      if (wa) MR[(size_t)(j + 1) * mcol + 2 * cw] = m_hi;
+    }
+    wave_sync();
+    GW_STAMP(3);
+    if (real_stage) gw_realqz_sweeps(hb, ldH, tb, ldW, MR, mcol, cp.wcap, w, ell, lane, (dbg && draw == 0) ? dbg + 27 : nullptr);
+    wave_sync();
+    GW_STAMP(6);
     for (int idx = lane; idx < w * w; idx += 64) {
       const int i = idx / w, j = idx - i * w;
       const size_t o = (size_t)i * cp.wcap + j;
@@ -734,12 +691,9 @@ __global__ __launch_bounds__(64) void gensys_realqz_kernel(int batch, GwCaps cp,
     }
     for (int idx = lane; idx < w * ell; idx += 64) {
       const int i = idx / ell, j = idx - i * ell;
-      wd[wo.XR + (size_t)i * cp.lcap + j] = hb[i * ldH + cp.wcap + j];
+      wd[wo.XR + (size_t)i * cp.lcap + j] = xb[i * ldX + j];
     }
-    if (dbg && draw == 0 && lane == 0) {
-      dbg[27] = steps;
-      dbg[28] = sweeps;
-    }
+    GW_STAMP(4);
   }
 }
 

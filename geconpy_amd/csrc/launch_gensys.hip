@@ -44,7 +44,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   cp.scap = (n - shape[3]) < 1 ? 1 : (n - shape[3]);
   if (n + cp.lcap > DSGE_MAX_N_GENSYS) return DSGE_SUCCESS;
   const size_t lds1 = dsge::gw_reduce_smem(cp), lds2 = dsge::gw_qz_smem(cp), lds3 = dsge::gw_post_smem(cp),
-               lds_eu = dsge::gw_eu_smem(cp), lds1b = dsge::gw_reduce2_smem(cp), lds1c = dsge::gw_realqz_smem(cp);
+               lds_eu = dsge::gw_eu_smem(cp), lds1b = dsge::gw_reduce2_smem(cp);
   if (lds1 > LDS_LIMIT || lds2 > LDS_LIMIT || lds3 > LDS_LIMIT || lds_eu > LDS_LIMIT || lds1b > LDS_LIMIT)
     return DSGE_SUCCESS;
   const dsge::GwOffsets wo = dsge::gw_offsets(cp);
@@ -56,7 +56,6 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   double* wsp = (double*)((char*)base + 256);
   if ((rc = set_lds(dsge::gensys_reduce_kernel, lds1))) return rc;
   if ((rc = set_lds(dsge::gensys_hesstri_kernel, lds1b))) return rc;
-  if ((rc = set_lds(dsge::gensys_realqz_kernel, lds1c))) return rc;
   if ((rc = set_lds(dsge::gensys_qzwin_kernel, lds2))) return rc;
   if ((rc = set_lds(dsge::gensys_post_kernel, lds3))) return rc;
   if ((rc = set_lds(dsge::gensys_eu_kernel, lds_eu))) return rc;
@@ -65,9 +64,8 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
     const int nb = (int)((c0 + chunk <= (size_t)batch) ? chunk : (size_t)batch - c0);
     hipLaunchKernelGGL(dsge::gensys_reduce_kernel, dim3(nb), dim3(64), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
                        cp, tol, wsp, g_gensys_win_dbg);
-    hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg);
-    if (opt().gensys_real_stage)
-      hipLaunchKernelGGL(dsge::gensys_realqz_kernel, dim3(nb), dim3(64), lds1c, st, nb, cp, wsp, g_gensys_win_dbg);
+    hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg,
+                       opt().gensys_real_stage);
     hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg);
     if (bk)
       hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,
