@@ -254,12 +254,12 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
 // which owns all of zhgeqz's deflation logic and only has to split the remaining 2 x 2 blocks (12 sweep steps instead of
 // 1284 on the SW-shaped window).  A real step is a 3-row reflector from the left and a 3- and a 2-column reflector from the
 // right -- about half the FP64 operations of a complex step's two rotations -- and advances two shifts: ~780 steps.
-// A launch of its own (gensys_realqz_kernel) between the reduction and the complex iteration: the step is a latency chain
-// (two LDS round trips, three reflector generations), so it lives on occupancy, and it needs less LDS than either neighbour:
-// [H | X] (w x (w + #lead)) and T only -- 18 KB on the SW-shaped window, 9 draws per CU.  The accumulated right transformation
-// M is NOT on the chip: lane = row of M, consecutive steps work on columns k..k+2 and k+1..k+3, so two columns are carried in
-// registers, the finished column is stored and the next one prefetched a step ahead (M lives transposed in the draw's HBM
-// workspace, as for the complex iteration: a column is one run, one row per lane).
+// It runs at the end of the reduction launch (gensys_hesstri_kernel), on that launch's LDS image: [H | X] (w x (w + #lead)) and
+// T only -- 18 KB on the SW-shaped window, 8 draws per CU; the step is a chain (two LDS round trips, three reflector
+// generations) and VALU-issue bound across the chip, so it lives on occupancy and on its instruction count.  The accumulated
+// right transformation M is NOT on the chip: lane = row of M, consecutive steps work on columns k..k+2 and k+1..k+3, so two
+// columns are carried in registers, the finished column is stored and the next one prefetched a step ahead (M lives
+// transposed in the draw's HBM workspace, as for the complex iteration: a column is one run, one row per lane).
 // Mapping: left transformations with one column of [H | X] per lane (42 lanes busy) and one column of T per lane; right
 // transformations with one row of H and one row of T per lane; the vectors that define the reflectors travel through
 // registers (v_readlane).  Entries outside the bands are exact zeros and stay exact zeros under the reflectors: no masks.

@@ -167,7 +167,7 @@ def test_cr_static_deflation_algebra(ref_goldens):
 
 def test_gensys_model_real_double_shift_stage():
     """Device-algorithm model of round 3's real double-shift accelerator (gensys_qz_model.real_double_shift_stage, the model of
-    gensys_realqz_kernel): with and without it the model returns the same eu and T (1e-10), both equal to the oracle's
+    gw_realqz_sweeps in gensys_hesstri_kernel): with and without it the model returns the same eu and T (1e-10), both equal to the oracle's
     LAPACK-based gensys, and the complex single-shift iteration is left with a handful of rotations."""
     from geconpy_amd import workloads as wl
 
