@@ -108,3 +108,13 @@ def test_generated_theta_kernels_fuzz(seed):
     import fuzz_theta
 
     assert fuzz_theta.run(seed, 6, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_second_order_fuzz(seed):
+    """The second-order path at random sizes / structures (tools/fuzz_second_order.py: 4..34 variables, pruned states up to
+    208, observed non-states, missing observations, samples that reach the steady-state switch): coefficients to 1e-9 and the
+    pruned quasi-likelihood to 1e-8 against oracle/second_order.py (parity unpinned against the reference, which raises)."""
+    import fuzz_second_order
+
+    assert fuzz_second_order.run(seed, 10, verbose=False) == 0
