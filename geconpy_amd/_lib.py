@@ -118,6 +118,12 @@ PROTOTYPES = {
                                             _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_grad_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
                                                  _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_solve_kalman_logp_grad_dense_z_batched": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i,
+                                                    _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                                    _dp],
+    "dsge_solve_kalman_logp_grad_dense_z_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i,
+                                                         _i, _i, _i, _f, _i, _f, _f, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                                         _dp, _dp, _dp],
     "dsge_options_init": [_dp],
     "dsge_options_push": [_dp],
     "dsge_options_pop": [],

@@ -452,13 +452,16 @@ def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=No
 
 def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
                                    jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=None,
-                                   n_lead_hint=None, options=None, Q=None):
+                                   n_lead_hint=None, options=None, Q=None, dense_z=None, return_Z_bar=False):
     """logp and its reverse-mode gradient per draw (include/dsge_hip.h: dsge_solve_kalman_logp_grad_batched): what
     pytensor autodiff computes for the reference's logp graph, on the device.  ``q``: (k,) or (batch, k) diagonal shock
     variances, or ``q=None, Q=`` a full symmetric shock covariance (k, k) / (batch, k, k) (``full_covariance``,
     statespace.py:247-251); ``Z``: selector design matrix (p, n), p <= 8; n <= 56.
     Returns dict(logp, status, A_bar, B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar]); with ``Q=`` the key is ``Q_bar``
-    (batch, k, k): the cotangent of all k x k entries taken as independent (symmetric)."""
+    (batch, k, k): the cotangent of all k x k entries taken as independent (symmetric).
+    A design matrix that is not a selector (observation equations, statespace.py:298-332) takes the dense-Z entry point
+    (``dsge_solve_kalman_logp_grad_dense_z_batched``: the observed combinations become p extra variables, n + p <= 56) --
+    automatically, or forced with ``dense_z=True``; ``return_Z_bar=True`` adds ``Z_bar`` (batch, p, n), the cotangent of Z."""
     A, B, C = _check_abc(A, B, C)
     D = _f64(D, 3)
     y = _f64(y, 2)
@@ -478,10 +481,14 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
             raise ValueError("q must be (k,) or (batch, k) (diagonal shock covariance)")
         qb = int(q.ndim == 2)
     Z, zb, d, db, Hdiag, hb = _obs_args(Z, d, Hdiag, nb, p, n)
-    if n_filter_hint is None:  # |S u O|: non-zero columns of A (in any draw) or of Z
-        ns = int(np.count_nonzero(np.any(A.reshape(-1, n) != 0, axis=0) | np.any(Z.reshape(-1, n) != 0, axis=0)))
-    else:
+    if dense_z is None:
+        dense_z = bool(return_Z_bar) or not selector_hint(Z)
+    if n_filter_hint is not None:
         ns = int(n_filter_hint)
+    elif dense_z:  # the dense entry point wants the number of STATE variables (non-zero columns of A in any draw)
+        ns = int(np.count_nonzero(np.any(A.reshape(-1, n) != 0, axis=0)))
+    else:  # |S u O|: non-zero columns of A (in any draw) or of Z
+        ns = int(np.count_nonzero(np.any(A.reshape(-1, n) != 0, axis=0) | np.any(Z.reshape(-1, n) != 0, axis=0)))
     nl = (lead_hint(C, tol) if solver == "gensys" else 0) if n_lead_hint is None else int(n_lead_hint)
     out = dict(logp=np.empty(nb), status=np.empty(nb, dtype=np.int32), A_bar=np.empty_like(A), B_bar=np.empty_like(A),
                C_bar=np.empty_like(A), D_bar=np.empty_like(D), q_bar=np.empty((nb, k, k) if qb >= 2 else (nb, k)))
@@ -489,15 +496,28 @@ def solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=None, Hdiag=None, solv
         out["d_bar"] = np.empty((nb, p))
     if Hdiag is not None:
         out["h_bar"] = np.empty((nb, p))
-    op, _keep = _lib.opt_ptr(options)
-    _lib.check(
-        _lib.load().dsge_solve_kalman_logp_grad_batched_host_opt(
-            op, _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(q), qb, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, n, k, p,
-            T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter), float(missing_fill_value), ns, nl,
-            _ptr(out["logp"]), _ptr(out["status"]), _ptr(out["A_bar"]), _ptr(out["B_bar"]), _ptr(out["C_bar"]),
-            _ptr(out["D_bar"]), _ptr(out["q_bar"]), _ptr(out.get("d_bar")), _ptr(out.get("h_bar"))
+    if dense_z:
+        if return_Z_bar:
+            out["Z_bar"] = np.empty((nb, p, n))
+        with _lib.options_scope(options):
+            _lib.check(
+                _lib.load().dsge_solve_kalman_logp_grad_dense_z_batched_host(
+                    _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(q), qb, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, n, k,
+                    p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter), float(missing_fill_value), ns,
+                    nl, _ptr(out["logp"]), _ptr(out["status"]), _ptr(out["A_bar"]), _ptr(out["B_bar"]), _ptr(out["C_bar"]),
+                    _ptr(out["D_bar"]), _ptr(out["q_bar"]), _ptr(out.get("d_bar")), _ptr(out.get("h_bar")), _ptr(out.get("Z_bar"))
+                )
+            )
+    else:
+        op, _keep = _lib.opt_ptr(options)
+        _lib.check(
+            _lib.load().dsge_solve_kalman_logp_grad_batched_host_opt(
+                op, _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(q), qb, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, n, k,
+                p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter), float(jitter), float(missing_fill_value), ns, nl,
+                _ptr(out["logp"]), _ptr(out["status"]), _ptr(out["A_bar"]), _ptr(out["B_bar"]), _ptr(out["C_bar"]),
+                _ptr(out["D_bar"]), _ptr(out["q_bar"]), _ptr(out.get("d_bar")), _ptr(out.get("h_bar"))
+            )
         )
-    )
     if qb >= 2:
         out["Q_bar"] = out.pop("q_bar")
     return out

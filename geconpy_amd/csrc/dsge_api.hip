@@ -975,15 +975,18 @@ int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, c
                        missing_fill, n_state_hint, z_selector_hint, logp_out, status_out, st);
 }
 
-int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const double* C, const double* D, const double* q,
-                                        int q_batched, const double* Z, int z_batched, const double* d, int d_batched,
-                                        const double* Hdiag, int h_batched, const double* y, int batch, int n, int k,
-                                        int p, int T_len, int solver, double tol, int max_iter, double jitter,
-                                        double missing_fill, int n_filter_hint, int n_lead_hint, double* logp_out,
-                                        int32_t* status_out, double* A_bar, double* B_bar, double* C_bar, double* D_bar,
-                                        double* q_bar, double* d_bar, double* h_bar, void* stream) {
+// dense_z = 0: the selector path.  dense_z = 1: any design matrix, by carrying the observed combinations as p extra variables
+// (dsge_augment.hpp: dense_z_augment_kernel): the reverse sweep runs on the augmented model of n + p variables, the assembly
+// reverse and the policy adjoints on the original n; n_filter_hint then counts the STATE variables (non-zero columns of A).
+static int grad_pipeline(const double* A, const double* B, const double* C, const double* D, const double* q, int q_batched,
+                         const double* Z, int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                         const double* y, int batch, int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                         double jitter, double missing_fill, int n_filter_hint, int n_lead_hint, double* logp_out,
+                         int32_t* status_out, double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                         double* d_bar, double* h_bar, int dense_z, double* Z_bar, void* stream) {
   int rc = check_common(batch, n, 56);
   if (rc) return rc;
+  if (dense_z && n + p > 56) return fail(DSGE_ERR_INVALID, "gradient path with a dense design matrix: n + p must not exceed 56");
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > 8) return fail(DSGE_ERR_INVALID, "gradient path: p out of range (1..8)");
   if (T_len < 0) return fail(DSGE_ERR_INVALID, "T_len < 0");
@@ -995,18 +998,21 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
-  const int u_hint = n_filter_hint;
+  const int m = dense_z ? n + p : n;                                   // size of the model the reverse sweep runs on
+  const int u_hint = dense_z ? (n_filter_hint > 0 ? n_filter_hint + p : 0) : n_filter_hint;
   const bool qfull = q_batched >= 2;                       // DSGE_Q_FULL_*: Q and q_bar are k x k
   const size_t qstride = qfull ? (size_t)k * k : (size_t)k;
   // the reverse sweep re-reads the stored (a_t, P_t): chunk the batch so that the store stays <= 16 GiB of the 288 GB
-  const size_t per_draw = kalman_grad_store_doubles_per_draw(u_hint, n, T_len) * sizeof(double);
+  const size_t per_draw = kalman_grad_store_doubles_per_draw(u_hint, m, T_len) * sizeof(double);
   size_t chunk = per_draw ? ((size_t)16 << 30) / per_draw : (size_t)batch;
   if (chunk < 1) chunk = 1;
   if (chunk > (size_t)batch) chunk = (size_t)batch;
   const size_t nn = chunk * n * n, nk = chunk * n * k;
   void* base = nullptr;
+  const size_t mm = chunk * (size_t)m * m, mk = chunk * (size_t)m * k;
   if ((rc = scratch_reserve(st, 4 * align256(nn * 8) + align256(nk * 8) + align256(chunk * 12) + 2 * align256(chunk * 4) +
-                                         align256(chunk * per_draw + 8) + 8192,
+                                         align256(chunk * per_draw + 8) + 8192 +
+                                         (dense_z ? 4 * align256(mm * 8) + align256(mk * 8) + align256((size_t)p * m * 8) : 0),
                           &base)))
     return rc;
   Carver cv(base);
@@ -1019,6 +1025,15 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
   int32_t* it_w = cv.take<int32_t>(chunk);   // cycle-reduction iterations = dispatch key of the reverse-sweep launch
   int32_t* ord_w = cv.take<int32_t>(chunk);
   double* store = cv.take<double>(chunk * per_draw / sizeof(double) + 1);
+  double *Ta = nullptr, *Ra = nullptr, *RQRa = nullptr, *Tbar_a = nullptr, *Gbar_a = nullptr, *Zaug = nullptr;
+  if (dense_z) {
+    Ta = cv.take<double>(mm);
+    Ra = cv.take<double>(mk);
+    RQRa = cv.take<double>(mm);
+    Tbar_a = cv.take<double>(mm);
+    Gbar_a = cv.take<double>(mm);
+    Zaug = cv.take<double>((size_t)p * m);
+  }
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)(((size_t)batch - c0 < chunk) ? (size_t)batch - c0 : chunk);
     const double *Ac = A + c0 * n * n, *Bc = B + c0 * n * n, *Cc = C + c0 * n * n, *Dc = D + c0 * n * k;
@@ -1045,10 +1060,16 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
     }
     if (rc) return rc;
     if (have_R && k <= 16 && n <= 64 && !qfull) {
-      if ((rc = launch_rqr(Rw, qc, q_batched, nb, n, k, stc, RQR, st))) return rc;
+      if (!dense_z && (rc = launch_rqr(Rw, qc, q_batched, nb, n, k, stc, RQR, st))) return rc;
     } else if ((rc = launch_assemble(Ac, Bc, Cc, Dc, Tw, nullptr, qc, q_batched, nb, n, k, Rw, nullptr, RQR, nullptr, stc, 1, 2,
                                      st)))
       return rc;
+    if (dense_z) {  // the augmented model and its sym(R Q R')
+      if ((rc = launch_dense_z_augment(Tw, Rw, Zc, z_batched, nb, n, k, p, Ta, Ra, Zaug, st))) return rc;
+      if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, Ta, Ra, qc, q_batched, nb, m, k, nullptr, nullptr, RQRa, nullptr,
+                                stc, 0, 2, st)))
+        return rc;
+    }
     const int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;
     if (opt().kalman_order == 0) {
       gkey = nullptr;
@@ -1056,10 +1077,17 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
       if ((rc = launch_persistence_key(Tw, stc, nb, n, it_w, st))) return rc;  // (the iteration counts are not needed again)
       gkey = it_w;
     }
-    if ((rc = launch_kalman_grad(Tw, RQR, Zc, z_batched, dc, d_batched, hc, h_batched, y, nb, n, p, T_len, jitter,
-                                 missing_fill, u_hint, store, logp_out + c0, stc, Tbar, Gbar,
-                                 d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st,
-                                 gkey, ord_w)))
+    if (dense_z) {
+      if ((rc = launch_kalman_grad(Ta, RQRa, Zaug, 0, dc, d_batched, hc, h_batched, y, nb, m, p, T_len, jitter, missing_fill,
+                                   u_hint, store, logp_out + c0, stc, Tbar_a, Gbar_a, d_bar ? d_bar + c0 * p : nullptr,
+                                   h_bar ? h_bar + c0 * p : nullptr, st, gkey, ord_w)))
+        return rc;
+      if ((rc = launch_dense_z_deaugment(Tbar_a, Gbar_a, Tw, RQRa, Zc, z_batched, stc, nb, n, p, Tbar, Gbar,
+                                         Z_bar ? Z_bar + c0 * p * n : nullptr, st)))
+        return rc;
+    } else if ((rc = launch_kalman_grad(Tw, RQR, Zc, z_batched, dc, d_batched, hc, h_batched, y, nb, n, p, T_len, jitter,
+                                        missing_fill, u_hint, store, logp_out + c0, stc, Tbar, Gbar,
+                                        d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st, gkey, ord_w)))
       return rc;
     if ((rc = launch_grad_assemble(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, nb, n, k, stc, Tbar, B_bar + c0 * n * n,
                                    C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * qstride, st)))
@@ -1069,6 +1097,31 @@ int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const 
       return rc;
   }
   return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_grad_batched(const double* A, const double* B, const double* C, const double* D, const double* q,
+                                        int q_batched, const double* Z, int z_batched, const double* d, int d_batched,
+                                        const double* Hdiag, int h_batched, const double* y, int batch, int n, int k,
+                                        int p, int T_len, int solver, double tol, int max_iter, double jitter,
+                                        double missing_fill, int n_filter_hint, int n_lead_hint, double* logp_out,
+                                        int32_t* status_out, double* A_bar, double* B_bar, double* C_bar, double* D_bar,
+                                        double* q_bar, double* d_bar, double* h_bar, void* stream) {
+  return grad_pipeline(A, B, C, D, q, q_batched, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
+                       tol, max_iter, jitter, missing_fill, n_filter_hint, n_lead_hint, logp_out, status_out, A_bar, B_bar, C_bar,
+                       D_bar, q_bar, d_bar, h_bar, 0, nullptr, stream);
+}
+
+int dsge_solve_kalman_logp_grad_dense_z_batched(const double* A, const double* B, const double* C, const double* D,
+                                                const double* q, int q_batched, const double* Z, int z_batched, const double* d,
+                                                int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                                                int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                                                double jitter, double missing_fill, int n_state_hint, int n_lead_hint,
+                                                double* logp_out, int32_t* status_out, double* A_bar, double* B_bar,
+                                                double* C_bar, double* D_bar, double* q_bar, double* d_bar, double* h_bar,
+                                                double* Z_bar, void* stream) {
+  return grad_pipeline(A, B, C, D, q, q_batched, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
+                       tol, max_iter, jitter, missing_fill, n_state_hint, n_lead_hint, logp_out, status_out, A_bar, B_bar, C_bar,
+                       D_bar, q_bar, d_bar, h_bar, 1, Z_bar, stream);
 }
 
 int dsge_profile_pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q,
@@ -1737,6 +1790,73 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
   DOWN(q_bar, gq, (size_t)batch * qstride, double);
   DOWN(d_bar, gd, bp, double);
   DOWN(h_bar, gh, bp, double);
+  HIP_TRY(hipStreamSynchronize(tw_st));
+  return DSGE_SUCCESS;
+}
+
+int dsge_solve_kalman_logp_grad_dense_z_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                             const double* q, int q_batched, const double* Z, int z_batched,
+                                             const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                             const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                             double tol, int max_iter, double jitter, double missing_fill,
+                                             int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                             double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                                             double* d_bar, double* h_bar, double* Z_bar) {
+  int rc = check_common(batch, n, 56);
+  if (rc) return rc;
+  if (n + p > 56) return fail(DSGE_ERR_INVALID, "gradient path with a dense design matrix: n + p must not exceed 56");
+  if (k < 1 || k > n || p < 1 || p > 8 || T_len < 0) return fail(DSGE_ERR_INVALID, "bad sizes");
+  if (!A || !B || !C || !D || !q || !Z || !y || !logp_out || !status_out || !A_bar || !B_bar || !C_bar || !D_bar || !q_bar)
+    return fail(DSGE_ERR_INVALID, "null pointer");
+  if ((rc = ensure_device())) return rc;
+  hipStream_t tw_st = nullptr, tw_st1 = nullptr;
+  if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;
+  (void)tw_st1;
+  if (batch == 0) return DSGE_SUCCESS;
+  if (q_batched < 0 || q_batched > 3) return fail(DSGE_ERR_INVALID, "gradient path: q_batched is a DSGE_Q_* mode (0..3)");
+  const size_t qstride = (q_batched >= 2) ? (size_t)k * k : (size_t)k;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k, nq = (size_t)((q_batched & 1) ? batch : 1) * qstride;
+  const size_t nz = (size_t)(z_batched ? batch : 1) * p * n, nd = (size_t)(d_batched ? batch : 1) * p,
+               nh = (size_t)(h_batched ? batch : 1) * p, ny = (size_t)T_len * p, bp = (size_t)batch * p;
+  void* base = nullptr;
+  STAGE_RESERVE(6 * align256(nn * 8) + 2 * align256(nk * 8) + align256(nq * 8) + align256(nz * 8) +
+                                       align256(nd * 8) + align256(nh * 8) + align256(ny * 8 + 8) +
+                                       2 * align256(bp * 8) + align256((size_t)batch * qstride * 8) + align256((size_t)batch * p * n * 8) +
+                                       2 * align256((size_t)batch * 8) + 8192, &base);
+  Carver cv(base);
+  UP(dA, A, nn, double);
+  UP(dB, B, nn, double);
+  UP(dC, C, nn, double);
+  UP(dD, D, nk, double);
+  UP(dq, q, nq, double);
+  UP(dZ, Z, nz, double);
+  UP(dd, d, nd, double);
+  UP(dH, Hdiag, nh, double);
+  UP(dy, y, ny, double);
+  OUTBUF(dL, logp_out, batch, double);
+  OUTBUF(dS, status_out, batch, int32_t);
+  OUTBUF(gA, A_bar, nn, double);
+  OUTBUF(gB, B_bar, nn, double);
+  OUTBUF(gC, C_bar, nn, double);
+  OUTBUF(gD, D_bar, nk, double);
+  OUTBUF(gq, q_bar, (size_t)batch * qstride, double);
+  OUTBUF(gd, d_bar, bp, double);
+  OUTBUF(gh, h_bar, bp, double);
+  OUTBUF(gZ, Z_bar, (size_t)batch * p * n, double);
+  if ((rc = dsge_solve_kalman_logp_grad_dense_z_batched(dA, dB, dC, dD, dq, q_batched, dZ, z_batched, dd, d_batched, dH, h_batched,
+                                                dy, batch, n, k, p, T_len, solver, tol, max_iter, jitter, missing_fill,
+                                                n_filter_hint, n_lead_hint, dL, dS, gA, gB, gC, gD, gq, gd, gh, gZ, tw_st)))
+    return rc;
+  DOWN(logp_out, dL, batch, double);
+  DOWN(status_out, dS, batch, int32_t);
+  DOWN(A_bar, gA, nn, double);
+  DOWN(B_bar, gB, nn, double);
+  DOWN(C_bar, gC, nn, double);
+  DOWN(D_bar, gD, nk, double);
+  DOWN(q_bar, gq, (size_t)batch * qstride, double);
+  DOWN(d_bar, gd, bp, double);
+  DOWN(h_bar, gh, bp, double);
+  DOWN(Z_bar, gZ, (size_t)batch * p * n, double);
   HIP_TRY(hipStreamSynchronize(tw_st));
   return DSGE_SUCCESS;
 }

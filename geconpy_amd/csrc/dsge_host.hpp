@@ -101,6 +101,11 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
                     const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
                     hipStream_t st);
+int launch_dense_z_augment(const double* T, const double* R, const double* Z, int z_batched, int batch, int n, int k, int p,
+                           double* T_aug, double* R_aug, double* Z_aug, hipStream_t st);
+int launch_dense_z_deaugment(const double* Tbar_a, const double* Gbar_a, const double* T, const double* G_aug, const double* Z,
+                             int z_batched, const int32_t* status, int batch, int n, int p, double* Tbar, double* Gbar,
+                             double* Z_bar, hipStream_t st);
 int launch_status_park(int32_t* status, int32_t* park, int batch, int restore, hipStream_t st);
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
                    double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate = 0);

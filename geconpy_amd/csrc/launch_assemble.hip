@@ -99,6 +99,24 @@ int launch_acf(const double* T, const double* Sigma, const double* Z, const doub
   return rc;
 }
 
+int launch_dense_z_augment(const double* T, const double* R, const double* Z, int z_batched, int batch, int n, int k, int p,
+                           double* T_aug, double* R_aug, double* Z_aug, hipStream_t st) {
+  hipLaunchKernelGGL(dsge::dense_z_augment_kernel, dim3(batch), dim3(256), 0, st, T, R, Z, z_batched, batch, n, k, p, T_aug, R_aug);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(dsge::dense_z_selector_kernel, dim3(1), dim3(256), 0, st, Z_aug, n, p);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
+int launch_dense_z_deaugment(const double* Tbar_a, const double* Gbar_a, const double* T, const double* G_aug, const double* Z,
+                             int z_batched, const int32_t* status, int batch, int n, int p, double* Tbar, double* Gbar,
+                             double* Z_bar, hipStream_t st) {
+  hipLaunchKernelGGL(dsge::dense_z_deaugment_kernel, dim3(batch), dim3(256), sizeof(double) * (size_t)p * n, st, Tbar_a, Gbar_a, T,
+                     G_aug, Z, z_batched, status, batch, n, p, Tbar, Gbar, Z_bar);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
 int launch_status_park(int32_t* status, int32_t* park, int batch, int restore, hipStream_t st) {
   hipLaunchKernelGGL(dsge::status_park_kernel<256>, dim3((batch + 255) / 256), dim3(256), 0, st, status, park, batch, restore);
   HIP_TRY(hipGetLastError());

@@ -170,15 +170,20 @@ class LogpEngine:
             raise ValueError("the program has no shock variances")
         # the observation equation: the same resolution as logp_from_theta, so that the pair (logp, gradient) belongs to the
         # SAME function of theta -- a program built with d= filters with its parameter-dependent intercept and the cotangent
-        # of d flows back through the generated pullback; a parameter-dependent Z has no cotangent on the device
-        if getattr(program, "Z", None) is not None and Z is None:
-            raise NotImplementedError("gradient through a parameter-dependent design matrix Z(theta) is not built "
-                                      "(DSGE_ST_GRAD_UNSUPPORTED: no Z cotangent); pass a constant selector Z")
+        # of d flows back through the generated pullback; a parameter-dependent Z(theta) takes the dense-Z gradient entry
+        # point, whose Z_bar goes through the generated pullback of Z
+        z_from_program = Z is None and getattr(program, "Z", None) is not None
         d_from_program = d is None and getattr(program, "d", None) is not None
-        if d_from_program:
-            _, d = self.observation_from_theta(program, theta)
+        if z_from_program or d_from_program:
+            Zp, dp = self.observation_from_theta(program, theta)
+            if z_from_program:
+                Z = Zp
+            if d_from_program:
+                d = dp
         if Z is None:
             raise ValueError("no design matrix: pass Z")
+        if z_from_program:
+            kw = dict(kw, dense_z=True)
         g = self.solve_kalman_logp_grad(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, out=grad_out, **kw)
         if theta_bar is None:
             theta_bar = torch.empty_like(theta)
@@ -187,6 +192,8 @@ class LogpEngine:
                            self._stream())
         if d_from_program:  # theta_bar += (d d / d theta)' d_bar
             program.launch_obs_vjp(theta.data_ptr(), theta.shape[0], g["d_bar"].data_ptr(), theta_bar.data_ptr(), self._stream())
+        if z_from_program:  # theta_bar += (d Z / d theta)' Z_bar
+            program.launch_obs_z_vjp(theta.data_ptr(), theta.shape[0], g["Z_bar"].data_ptr(), theta_bar.data_ptr(), self._stream())
         return g["logp"], g["status"], theta_bar, g
 
     # -- product entry points --------------------------------------------------------------
@@ -217,12 +224,14 @@ class LogpEngine:
 
     def solve_kalman_logp_grad(self, A, B, C, D, q, Z, y, d=None, Hdiag=None, solver="cycle_reduction", tol=1e-6, max_iter=50,
                                jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_filter_hint=0, n_lead_hint=0,
-                               out=None, options=None, full_covariance=False):
+                               out=None, options=None, full_covariance=False, dense_z=False):
         """logp and its reverse-mode gradient for the whole batch, device-resident (dsge_solve_kalman_logp_grad_batched).
         ``q``: (k,) or (batch, k) diagonal shock variances; with ``full_covariance=True`` a full symmetric Q, (k, k) or
         (batch, k, k) (statespace.py:247-251), and ``q_bar`` is (batch, k, k).  Returns a dict of tensors: logp, status, A_bar,
         B_bar, C_bar, D_bar, q_bar[, d_bar][, h_bar] (asynchronous).  ``out`` may carry the same dict from an earlier call to
-        reuse the buffers."""
+        reuse the buffers.  ``dense_z=True``: any design matrix (observation equations), through
+        ``dsge_solve_kalman_logp_grad_dense_z_batched`` (n + p <= 56); the dict then also holds ``Z_bar`` (batch, p, n) and
+        ``n_filter_hint`` counts the state variables (non-zero columns of A)."""
         torch = self.torch
         nb, n, _ = A.shape
         k = D.shape[2]
@@ -252,6 +261,21 @@ class LogpEngine:
                 out["d_bar"] = mk(nb, p)
             if Hdiag is not None:
                 out["h_bar"] = mk(nb, p)
+            if dense_z:
+                out["Z_bar"] = mk(nb, p, n)
+        if dense_z:
+            with _lib.options_scope(options):
+                _lib.check(
+                    self.lib.dsge_solve_kalman_logp_grad_dense_z_batched(
+                        self._p(A), self._p(B), self._p(C), self._p(D), self._p(q), q_mode, self._p(Z), zb, self._p(d), db,
+                        self._p(Hdiag), hb, self._p(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver], float(tol), int(max_iter),
+                        float(jitter), float(missing_fill_value), int(n_filter_hint), int(n_lead_hint), self._p(out["logp"]),
+                        out["status"].data_ptr(), self._p(out["A_bar"]), self._p(out["B_bar"]), self._p(out["C_bar"]),
+                        self._p(out["D_bar"]), self._p(out["q_bar"]), self._p(out.get("d_bar")), self._p(out.get("h_bar")),
+                        self._p(out.get("Z_bar")), self._stream(),
+                    )
+                )
+            return out
         op, _keep = _lib.opt_ptr(options)
         _lib.check(
             self.lib.dsge_solve_kalman_logp_grad_batched_opt(

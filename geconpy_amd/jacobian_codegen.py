@@ -236,6 +236,31 @@ class JacobianProgram:
                 for i, expr in enumerate(red4):
                     lines.append(f"  tb[{i}] += {pr.doprint(expr)};")
                 lines += ["}", ""]
+            if zent:
+                gz = [sp.Symbol(f"gz_{flat}") for _, flat, _ in zent]
+                zv_ = [sp.Add(*[g * sp.diff(e, th_) for g, (_, _, e) in zip(gz, zent)]) for th_ in params]
+                repl5, red5 = sp.cse(zv_, symbols=sp.numbered_symbols("u"), optimizations="basic")
+                used_gz = sorted(set().union(*(v.free_symbols for v in zv_)) & set(gz), key=lambda x_: gz.index(x_))
+                lines += [
+                    "// theta_bar += (d Z / d theta)' Z_bar   (Z_bar: [batch][p][n], the cotangent of every entry of Z)",
+                    "__global__ __launch_bounds__(256) void jac_obs_z_vjp_kernel(const double* __restrict__ theta, int batch,",
+                    "    const double* __restrict__ Z_bar, double* __restrict__ theta_bar) {",
+                    "  const int draw = blockIdx.x * 256 + threadIdx.x;",
+                    "  if (draw >= batch) return;",
+                    "  const double* th = theta + (size_t)draw * JAC_NPAR;",
+                ]
+                for i, p_ in enumerate(params):
+                    lines.append(f"  const double {pr.doprint(p_)} = th[{i}];")
+                for g in used_gz:
+                    flat = zent[gz.index(g)][1]
+                    lines.append(f"  const double {g} = Z_bar[(size_t)draw * JAC_P * JAC_N + {flat}];")
+                for sym, expr in repl5:
+                    lines.append(f"  const double {pr.doprint(sym)} = {pr.doprint(expr)};")
+                lines.append("  double* tb = theta_bar + (size_t)draw * JAC_NPAR;")
+                for i, expr in enumerate(red5):
+                    if expr != 0:
+                        lines.append(f"  tb[{i}] += {pr.doprint(expr)};")
+                lines += ["}", ""]
         lines += [
             'extern "C" {',
             "int dsge_jac_dims(int* n, int* k, int* npar, int* has_q) {",
@@ -295,6 +320,16 @@ class JacobianProgram:
                     "  return hipGetLastError() == hipSuccess ? 0 : 2;",
                     "}",
                 ]
+        if has_obs and self.Z is not None:
+            lines += [
+                "int dsge_jac_obs_z_vjp_launch(const double* theta, int batch, const double* Z_bar, double* theta_bar, void* stream) {",
+                "  if (batch < 0 || !theta || !Z_bar || !theta_bar) return 1;",
+                "  if (batch == 0) return 0;",
+                "  hipLaunchKernelGGL(jac_obs_z_vjp_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, batch,",
+                "                     Z_bar, theta_bar);",
+                "  return hipGetLastError() == hipSuccess ? 0 : 2;",
+                "}",
+            ]
         lines += ["}", ""]
         return "\n".join(lines)
 
@@ -360,6 +395,14 @@ class JacobianProgram:
         rc = self.load().dsge_jac_obs_vjp_launch(theta_ptr, int(batch), d_bar, theta_bar, stream)
         if rc != 0:
             raise RuntimeError(f"dsge_jac_obs_vjp_launch failed with code {rc}")
+
+    def launch_obs_z_vjp(self, theta_ptr, batch, Z_bar, theta_bar, stream):
+        """theta_bar += (d Z / d theta)' Z_bar  (programs built with ``Z=``)."""
+        lib = self.load()
+        lib.dsge_jac_obs_z_vjp_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = lib.dsge_jac_obs_z_vjp_launch(theta_ptr, int(batch), Z_bar, theta_bar, stream)
+        if rc != 0:
+            raise RuntimeError(f"dsge_jac_obs_z_vjp_launch failed with code {rc}")
 
     def launch_vjp(self, theta_ptr, batch, A_bar, B_bar, C_bar, D_bar, q_bar, theta_bar, stream):
         rc = self.load().dsge_jac_vjp_launch(theta_ptr, int(batch), A_bar, B_bar, C_bar, D_bar, q_bar, theta_bar, stream)

@@ -606,6 +606,32 @@ int dsge_solve_kalman_logp_grad_batched_host(const double* A, const double* B, c
                                              int n_filter_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
                                              double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
                                              double* d_bar, double* h_bar);
+/*
+ * The same with ANY design matrix (observation equations: rows of Z that are linear combinations of the variables,
+ * _make_design_matrix, gEconpy/model/statespace.py:298-332, which pytensor differentiates through), and with the cotangent of Z
+ * itself for a parameter-dependent design matrix.  The observed combinations o_t = Z x_t are carried as p extra variables
+ * (T_aug = [[T, 0], [Z T, 0]], R_aug = [R; Z R], selector on the new variables: the same likelihood function), the reverse sweep
+ * runs on that model of n + p <= 56 variables and the cotangents are mapped back (csrc/dsge_augment.hpp).
+ *   n_state_hint : number of STATE variables (non-zero columns of A), 0 = unknown; it sizes the filter tile (states + p)
+ *   Z_bar        : [batch][p][n] or NULL -- cotangent of every entry of Z (also for a shared Z: sum over the batch for a joint
+ *                  logp); everything else as dsge_solve_kalman_logp_grad_batched.  A selector Z is a valid input (slower here).
+ */
+int dsge_solve_kalman_logp_grad_dense_z_batched(const double* A, const double* B, const double* C, const double* D,
+                                                const double* q, int q_batched, const double* Z, int z_batched, const double* d,
+                                                int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
+                                                int n, int k, int p, int T_len, int solver, double tol, int max_iter,
+                                                double jitter, double missing_fill, int n_state_hint, int n_lead_hint,
+                                                double* logp_out, int32_t* status_out, double* A_bar, double* B_bar,
+                                                double* C_bar, double* D_bar, double* q_bar, double* d_bar, double* h_bar,
+                                                double* Z_bar, void* stream);
+int dsge_solve_kalman_logp_grad_dense_z_batched_host(const double* A, const double* B, const double* C, const double* D,
+                                                     const double* q, int q_batched, const double* Z, int z_batched,
+                                                     const double* d, int d_batched, const double* Hdiag, int h_batched,
+                                                     const double* y, int batch, int n, int k, int p, int T_len, int solver,
+                                                     double tol, int max_iter, double jitter, double missing_fill,
+                                                     int n_state_hint, int n_lead_hint, double* logp_out, int32_t* status_out,
+                                                     double* A_bar, double* B_bar, double* C_bar, double* D_bar, double* q_bar,
+                                                     double* d_bar, double* h_bar, double* Z_bar);
 
 /*
  * The fused entry points with per-call options (opt == NULL: the process-wide defaults); otherwise identical to the

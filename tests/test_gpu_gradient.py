@@ -410,3 +410,69 @@ def test_gradient_with_a_full_shock_covariance(batched_q):
         assert np.abs(full_path[key] - diag_path[key]).max() <= 1e-9 * sc, key
     dq = np.diagonal(full_path["Q_bar"], axis1=1, axis2=2)
     assert np.abs(dq - diag_path["q_bar"]).max() <= 1e-9 * np.abs(diag_path["q_bar"]).max()
+
+
+@pytest.mark.parametrize("batched_z", [False, True])
+def test_gradient_with_a_dense_design_matrix(batched_z):
+    """Observation equations (statespace.py:298-332): rows of Z that are linear combinations of variables.  The dense-Z entry
+    point carries o_t = Z x_t as p extra variables (T_aug = [[T, 0], [Z T, 0]], R_aug = [R; Z R]) and maps the cotangents back;
+    logp equals the oracle's dense-Z filter (1e-9), every cotangent -- A, B, C, D, q, d, H and Z itself -- is checked against
+    Richardson-extrapolated central differences of the oracle (1e-7 relative, 40-variable SW-shaped system with missing
+    observations), and on a selector Z the dense route reproduces the selector route (1e-9)."""
+    rng = np.random.default_rng(33)
+    nb = 3
+    b = wl.sw_shaped_batch(nb, first_draw=80)
+    om = wl.sw_shaped_observation_model()
+    n = b["A"].shape[1]
+    p = om["Z"].shape[0]
+    q = b["sigma"] ** 2
+    y = om["y"][:50].copy()
+    y[7, 1] = np.nan
+    y[13] = np.nan
+    h = om["Hdiag"].copy()
+    d = rng.normal(0, 0.01, p)
+    Zs = np.stack([om["Z"] + 0.15 * rng.standard_normal(om["Z"].shape) * (rng.random(om["Z"].shape) < 0.15) for _ in range(nb)])
+    Zarg = Zs if batched_z else Zs[0]
+    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, Zarg, y, d=d, Hdiag=h, tol=1e-14, max_iter=200,
+                                                 return_Z_bar=True)
+    assert np.all(out["status"] == 0) and out["Z_bar"].shape == (nb, p, n)
+    i = 1
+    Zi = Zs[i] if batched_z else Zs[0]
+    A, B, C, D = (b[x][i] for x in "ABCD")
+    ref = oracle.solve_kalman_logp(A, B, C, D, np.diag(q[i]), Zi, y, H=np.diag(h), d=d, tol=1e-15, max_iter=300)["logp"]
+    assert abs(out["logp"][i] - ref) <= 1e-9 * abs(ref), (out["logp"][i], ref)
+    g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+    maskA = (A != 0).any(axis=0)[None, :] * np.ones_like(A)
+    dA = rng.standard_normal(A.shape) * maskA * 0.1
+    dB, dC, dD = (rng.standard_normal(M.shape) * 0.1 for M in (B, C, D))
+    dq = rng.standard_normal(q[i].shape) * q[i] * 0.3
+    dd = rng.standard_normal(d.shape) * 0.1
+    dh = rng.standard_normal(h.shape) * h * 0.3
+    dZ = rng.standard_normal(Zi.shape) * 0.1
+    analytic = ((g["A_bar"] * dA).sum() + (g["B_bar"] * dB).sum() + (g["C_bar"] * dC).sum() + (g["D_bar"] * dD).sum()
+                + (g["q_bar"] * dq).sum() + (g["d_bar"] * dd).sum() + (g["h_bar"] * dh).sum() + (g["Z_bar"] * dZ).sum())
+    only_Z = (g["Z_bar"] * dZ).sum()
+
+    def f(e, z_only=False):
+        if z_only:
+            return oracle.solve_kalman_logp(A, B, C, D, np.diag(q[i]), Zi + e * dZ, y, H=np.diag(h), d=d, tol=1e-15, max_iter=300)["logp"]
+        return oracle.solve_kalman_logp(A + e * dA, B + e * dB, C + e * dC, D + e * dD, np.diag(q[i] + e * dq), Zi + e * dZ, y,
+                                        H=np.diag(h + e * dh), d=d + e * dd, tol=1e-15, max_iter=300)["logp"]
+
+    def extrapolated(z_only):
+        h0 = 2e-3
+        d1 = [(f(h0 / 2 ** j, z_only) - f(-h0 / 2 ** j, z_only)) / (2.0 * h0 / 2 ** j) for j in range(3)]
+        d2 = [(4.0 * d1[j + 1] - d1[j]) / 3.0 for j in range(2)]
+        return (16.0 * d2[1] - d2[0]) / 15.0
+
+    fd_all, fd_z = extrapolated(False), extrapolated(True)
+    assert abs(analytic - fd_all) <= 1e-7 * max(1.0, abs(fd_all)), (analytic, fd_all)
+    assert abs(only_Z - fd_z) <= 1e-7 * max(1.0, abs(fd_z)), (only_Z, fd_z)
+    # a selector through the dense route = the selector route
+    sel = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, d=d, Hdiag=h, tol=1e-14, max_iter=200)
+    den = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, d=d, Hdiag=h, tol=1e-14, max_iter=200,
+                                                 dense_z=True)
+    assert np.all(den["status"] == 0)
+    assert np.abs(den["logp"] - sel["logp"]).max() <= 1e-10 * np.abs(sel["logp"]).max()
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
+        assert np.abs(den[key] - sel[key]).max() <= 1e-8 * np.abs(sel[key]).max(), key

@@ -299,6 +299,53 @@ def test_observation_equation_from_theta_on_device():
         assert abs(logp[i].item() - ref["logp"]) <= 1e-8 * abs(ref["logp"])
 
 
+@pytest.mark.gpu
+def test_theta_gradient_through_a_parameter_dependent_observation_equation():
+    """d logp / d theta when BOTH the design matrix and the intercept depend on theta (statespace.py:298-388: observation
+    equations are differentiated by pytensor upstream): generated Z(theta), d(theta) kernels -> dense-Z gradient entry point
+    (Z_bar) -> generated pullbacks of Z and d, against central finite differences of the oracle in theta."""
+    import torch
+
+    import oracle
+    from geconpy_amd.engine import LogpEngine
+
+    prog = _rbc_obs_program()
+    assert "dsge_jac_obs_z_vjp_launch" in prog.source()
+    nb = 4
+    th, theta = _theta(nb, seed=11)
+    names = ["sigma", "phi", "alpha", "beta", "delta", "rho_A", "sigma_A"]
+    ss0 = wl.rbc_steady_state(th["sigma"], th["phi"], th["alpha"], th["beta"], th["delta"])
+    y = np.stack([np.log(ss0["Y"][0]), np.log(ss0["C"][0])]) + np.random.default_rng(2).normal(0, 0.02, (50, 2))
+    h = np.array([1e-4, 2e-4])
+    eng = LogpEngine(0)
+    logp, st, theta_bar, g = eng.logp_and_grad_from_theta(prog, eng.to_device(theta), None, eng.to_device(y), Hdiag=eng.to_device(h),
+                                                          tol=1e-13, max_iter=300, n_filter_hint=2)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0 and "Z_bar" in g
+    theta_bar = theta_bar.cpu().numpy()
+
+    def f(row):
+        kw = dict(zip(names, row))
+        A, B, C, D = wl.rbc_linearized_jacobians(**kw)
+        ss = wl.rbc_steady_state(kw["sigma"], kw["phi"], kw["alpha"], kw["beta"], kw["delta"])
+        Z = np.zeros((2, 8))
+        Z[0, 7] = 1.0
+        Z[1, 1] = 1.0 / kw["sigma"]
+        d = np.array([np.log(ss["Y"]), np.log(ss["C"])]).reshape(2)
+        return oracle.solve_kalman_logp(A, B, C, D, np.array([[kw["sigma_A"] ** 2]]), Z, y, H=np.diag(h), d=d, tol=1e-13,
+                                        max_iter=300)["logp"]
+
+    for i in range(nb):
+        assert_allclose(logp[i].item(), f(theta[i]), rtol=1e-9)
+        for j in range(7):
+            e = 1e-6 * max(abs(theta[i, j]), 1e-2)
+            tp, tm = theta[i].copy(), theta[i].copy()
+            tp[j] += e
+            tm[j] -= e
+            fd = (f(tp) - f(tm)) / (2 * e)
+            assert_allclose(theta_bar[i, j], fd, rtol=5e-5, atol=1e-5 * max(1.0, np.abs(theta_bar[i]).max()))
+
+
 def test_parameter_names_never_meet_the_kernel_identifiers():
     """A parameter called theta / A / q / draw / x0, or one that is no C identifier, is printed as par<i>."""
     import sympy as sp
