@@ -325,8 +325,13 @@ class JacobianProgram:
                 "int dsge_jac_obs_z_vjp_launch(const double* theta, int batch, const double* Z_bar, double* theta_bar, void* stream) {",
                 "  if (batch < 0 || !theta || !Z_bar || !theta_bar) return 1;",
                 "  if (batch == 0) return 0;",
-                "  hipLaunchKernelGGL(jac_obs_z_vjp_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, batch,",
-                "                     Z_bar, theta_bar);",
+            ]
+            if zent:  # (a design matrix without a non-zero entry has no pullback kernel: nothing to add)
+                lines += [
+                    "  hipLaunchKernelGGL(jac_obs_z_vjp_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, batch,",
+                    "                     Z_bar, theta_bar);",
+                ]
+            lines += [
                 "  return hipGetLastError() == hipSuccess ? 0 : 2;",
                 "}",
             ]

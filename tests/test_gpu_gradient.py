@@ -214,9 +214,18 @@ def test_gradient_failed_and_unsupported_draws():
     assert out["status"][0] == 0 and out["status"][2] == 0 and out["status"][1] != 0
     assert out["logp"][1] == -np.inf and np.all(out["D_bar"][1] == 0) and np.all(out["q_bar"][1] == 0)
     assert np.all(np.isfinite(out["A_bar"][[0, 2]]))
-    Zd = np.random.default_rng(2).standard_normal((7, 40))  # dense design matrix: not covered by the gradient path
-    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, Zd, om["y"][:20], tol=1e-10, max_iter=100)
+    # a dense design matrix handed to the SELECTOR entry point is flagged, never mis-evaluated (the Python wrapper routes it to
+    # the dense-Z entry point by itself: dense_z=False forces the selector one)
+    Zd = np.random.default_rng(2).standard_normal((7, 40))
+    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, Zd, om["y"][:20], tol=1e-10, max_iter=100,
+                                                 dense_z=False)
     assert np.all(out["status"] & _lib.ST_GRAD_UNSUPPORTED) and np.all(np.isnan(out["logp"]))
+    # ... and through the dense-Z entry point it is an ordinary evaluation; a failed draw there gives -inf and zero cotangents
+    out = batched.solve_kalman_logp_grad_batched(A, b["B"], b["C"], b["D"], q, Zd, om["y"][:20], Hdiag=om["Hdiag"], tol=1e-10,
+                                                 max_iter=100, return_Z_bar=True)
+    assert out["status"][0] == 0 and out["status"][2] == 0 and out["status"][1] != 0
+    assert out["logp"][1] == -np.inf and np.all(out["D_bar"][1] == 0) and np.all(out["Z_bar"][1] == 0)
+    assert np.all(np.isfinite(out["A_bar"][[0, 2]])) and np.all(np.isfinite(out["Z_bar"][[0, 2]]))
 
 
 def test_gradient_with_steady_state_segments():
