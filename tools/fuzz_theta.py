@@ -115,6 +115,21 @@ def run(seed, trials, verbose=True):
                 for e_i, e in enumerate(list(Z)):
                     ref = np.broadcast_to(np.asarray(sp.lambdify(ps, e, "numpy")(*cols), dtype=float), (nb,))
                     errs.append(float(np.max(np.abs(g[:, e_i] - ref) / (1.0 + np.abs(ref)))) if e != 0 else float(np.any(g[:, e_i] != 0)))
+            if with_Z:  # the pullback of Z (round 3: dsge_jac_obs_z_vjp_launch) ACCUMULATES into theta_bar
+                zbar = rng.normal(size=(nb, p_obs, n))
+                tb3 = torch.full((nb, npar), -0.25, dtype=torch.float64, device=eng.device)
+                prog.launch_obs_z_vjp(d_theta.data_ptr(), nb, eng.to_device(zbar).data_ptr(), tb3.data_ptr(), eng._stream())
+                torch.cuda.synchronize()
+                ref3 = np.full((nb, npar), -0.25)
+                zflat = zbar.reshape(nb, -1)
+                for e_i, e in enumerate(list(Z)):
+                    if e == 0:
+                        continue
+                    for pi, p_ in enumerate(ps):
+                        de = sp.diff(e, p_)
+                        if de != 0:
+                            ref3[:, pi] += zflat[:, e_i] * np.broadcast_to(np.asarray(sp.lambdify(ps, de, "numpy")(*cols), dtype=float), (nb,))
+                errs.append(float(np.max(np.abs(tb3.cpu().numpy() - ref3)) / np.max(np.abs(ref3))) * 1e-2)
             if with_d:
                 g = dg.cpu().numpy()
                 for e_i, e in enumerate(d):
