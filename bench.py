@@ -145,6 +145,37 @@ def load_pmc():
     return legs, os.path.relpath(files[-1], ROOT)
 
 
+def so_counters(kernel, nloc):
+    """traffic (HBM bytes per launch, 2 x FETCH + WRITE as the guide prescribes) and the matrix-core busy fraction of the
+    second-order filter kernel from the newest committed profiles/r*/pmc_counters_sw_second_order.json -- only when it was
+    collected at this batch size (the counters scale with the batch)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters_sw_second_order.json")))
+    none = {"traffic": None, "traffic_source": None}
+    if not files or nloc != 1024:
+        return none
+    try:
+        with open(files[-1]) as fh:
+            kern = json.load(fh)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return none
+    hit = [v for nm, v in kern.items() if kernel in nm]
+    if not hit:
+        return none
+    v = hit[0]
+    src = os.path.relpath(files[-1], ROOT)
+    out = {"traffic": int(v.get("hbm_bytes", 0)),
+           "traffic_source": f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same bench command (committed counters, not "
+                             "collected in this run)"}
+    if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and v.get("avg_ns"):
+        # busy cycles are summed over the SIMDs; 1024 SIMDs x launch duration x 2.4 GHz is the denominator
+        out["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["avg_ns"] * 2.4), 4)
+        out["mfma_busy_source"] = f"{src}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x committed launch duration x 2.4 GHz)"
+        out["counted_tflops"] = round(v.get("fp64_flops", 0.0) / v["avg_ns"] / 1e3, 2)
+    return out
+
+
 def roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_eval, hints, u_dim, h_defl, stats):
     """The roofline object of the JSON line, for the kernel with the longest launch.  `achieved` / `frac` are EXECUTED
     FP64 flops (hardware instruction counters x 64 lanes when profiles/ holds them for this configuration, otherwise the
@@ -781,7 +812,7 @@ def main_second_order(args, world, rank, local_rank):
                 "frac": round(flops_filter / filt_s / 1e12 / FP64_PEAK_TFLOPS, 5),
                 "flops_source": f"2 products x 2 m^3 (m = {m}, unpadded) per full filter step x the measured number of full steps per "
                                 f"draw (mean {n_full.mean():.1f} of {T_len}); duration: HIP events around the kernel in this run",
-                "traffic": None,
+                **so_counters(f"so_filter_kernel<{mp16 // 16}>", nloc),
                 "stage_ms": {"first_order_solver": round(ms[0], 3), "second_order_setup": round(ms[1], 3),
                              "stationary_covariance": round(ms[2], 3), "filter": round(ms[3], 3)},
                 "full_steps_mean": float(n_full.mean()), "never_steady": int((at_h < 0).sum()),
