@@ -46,3 +46,26 @@ for nb in (1, 8, 64):
     ms_c = median_ms(lambda: perform(crb_op, args[:3], 2), 50)
     print(f"batch {nb:3d}: HipSolveKalmanLogp.perform {ms_l:.3f} ms ({ms_l / nb:.3f} per draw; CPU oracle {cpu_ms:.0f} ms per draw = x{cpu_ms * nb / ms_l:.0f}), "
           f"HipSolveKalmanLogpGrad.perform {ms_g:.3f} ms, HipCycleReductionBatched.perform {ms_c:.3f} ms")
+
+# where the batch-1 call goes: HIP-event durations of the launch groups (device-resident inputs) against the wall time of the
+# device-resident call and of the host twin
+import torch
+from geconpy_amd.engine import LogpEngine
+
+eng = LogpEngine(0)
+dev = [eng.to_device(b[x][:1]) for x in "ABCD"]
+dq, dZ, dy, dH = eng.to_device(q[:1]), eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
+ns, zs = eng.structure_hints(dev[0], dZ)
+kms = eng.profile_kernels(*dev, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, reps=20, n_state_hint=ns, z_selector_hint=zs)
+
+
+def dev_call():
+    eng.solve_kalman_logp(*dev, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, n_state_hint=ns, z_selector_hint=zs)
+    torch.cuda.synchronize()
+
+
+ms_dev = median_ms(dev_call, 50)
+print(f"batch 1, device-resident inputs: {ms_dev:.3f} ms per call + synchronize; launch groups by HIP events: solver "
+      f"{kms['solver']:.3f} ms, assembly {kms['assemble']:.3f} ms, filter {kms['kalman']:.3f} ms (sum {sum(kms.values()):.3f} ms): "
+      f"a single draw is ONE wavefront's dependent chain (7 cycle-reduction iterations, ~30 full + ~170 steady filter steps); "
+      f"launch and staging overhead is the difference")
