@@ -12,7 +12,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_N = 64
 MAX_N_CR = 64
 MAX_N_GENSYS = 64

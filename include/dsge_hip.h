@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 5
+#define DSGE_ABI_VERSION 6
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
