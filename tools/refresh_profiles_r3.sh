@@ -32,6 +32,7 @@ python3 tools/kalman_phases.py > "$OUT/kalman_phases.txt" 2>&1
 python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
 python3 tools/so_order_potential.py > "$OUT/so_order_potential.txt" 2>&1
 python3 tools/two_streams.py > "$OUT/two_streams.txt" 2>&1
+[ -x tools/so_gemm_probe/probe13 ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -o tools/so_gemm_probe/probe13 tools/so_gemm_probe/probe.hip
 tools/so_gemm_probe/probe13 1024 10 > "$OUT/so_gemm_probe.txt" 2>&1
 python3 -m pytest tests -m gpu -q > "$OUT/tests_gpu.log" 2>&1
 tail -3 "$OUT/tests_gpu.log"

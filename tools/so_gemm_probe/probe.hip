@@ -1,4 +1,5 @@
 // Experiment / self-test (not product): the workgroup MFMA product of dsge_so_gemm.hpp against the host, and its rate.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -o tools/so_gemm_probe/probe13 tools/so_gemm_probe/probe.hip   (from the repo root)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
