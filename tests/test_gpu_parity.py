@@ -2036,3 +2036,37 @@ def test_zero_T_on_solver_failure_matches_the_reference_default_graph():
         assert abs(loose["logp"][i] - ref["logp"]) <= 1e-8 * abs(ref["logp"]), (i, loose["logp"][i], ref["logp"])
         if failed[i]:
             assert np.abs(loose["R"][i] - ref["R"]).max() <= 1e-9 * max(1.0, np.abs(ref["R"]).max())
+
+
+def test_round3_entry_points_reject_malformed_calls_and_accept_empty_batches():
+    """Call-level errors of the entry points added in round 3 are return codes with a message (never a crash, never a wrong
+    number): the dense-Z gradient beyond n + p = 56, a full covariance of the wrong shape, second order with p > 8 or a
+    retained set that does not list the states first, filter outputs with p > DSGE_MAX_P; an empty batch is a no-op."""
+    b = wl.sw_shaped_batch(2)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y = om["y"][:20]
+    # n + p > 56 on the dense-Z gradient route
+    sysm = [wl.sw_shaped_system(9100 + i, n=52, n_state=20, n_lead=14, k=7) for i in range(2)]
+    A52, B52, C52, D52 = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    Zd = np.random.default_rng(0).standard_normal((7, 52))
+    with pytest.raises(_lib.DsgeHipError, match="n \\+ p"):
+        batched.solve_kalman_logp_grad_batched(A52, B52, C52, D52, np.full((2, 7), 1e-4), Zd, y, dense_z=True)
+    with pytest.raises(ValueError):
+        batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], None, om["Z"], y, Q=np.eye(3))
+    with pytest.raises(ValueError):
+        batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, Q=np.eye(7))
+    # second order: retained variables must list the states first
+    s2 = wl.sw_second_order_batch(2)
+    S, Lc, U = batched.second_order_structure(s2["A"], s2["C"], om["Z"])
+    bad_U = np.ascontiguousarray(U[::-1])
+    with pytest.raises(_lib.DsgeHipError, match="states first"):
+        batched.second_order_logp_batched(s2["A"], s2["B"], s2["C"], s2["D"], s2["hess_idx"], s2["hess_val"], s2["sigma"] ** 2,
+                                          om["Z"], y, Hdiag=om["Hdiag"], structure=(S, Lc, bad_U))
+    # empty batches
+    e3 = np.empty((0, 40, 40))
+    out = batched.solve_kalman_logp_grad_batched(e3, e3, e3, np.empty((0, 40, 7)), np.empty((0, 7)), om["Z"], y, dense_z=True,
+                                                 return_Z_bar=True)
+    assert out["logp"].shape == (0,) and out["Z_bar"].shape == (0, 7, 40)
+    out = batched.kalman_filter_outputs_batched(np.empty((0, 40, 40)), np.empty((0, 40, 7)), np.empty((0, 7)), om["Z"], y)
+    assert out["ll"].shape == (0, 20)
