@@ -544,6 +544,23 @@ __device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb
   }
 }
 
+// branch-free real Givens for the inner loop of the reduction (selects only): c, s, r with [c s; -s c] [f; g] = [r; 0];
+// f = g = 0 (or both below 1e-140) gives the identity.  g = 0 gives c = 1, s = 0, r = f exactly.
+__device__ __forceinline__ void gw_lartg(double f, double g, double& c, double& s, double& r) {
+  const double d2 = fma(f, f, g * g);
+  const bool ok = d2 > 1e-280;
+  const double d2c = ok ? d2 : 1.0;
+  double rn = __builtin_amdgcn_rsq(d2c);
+  rn = rn * fma(-0.5 * d2c * rn, rn, 1.5);
+  rn = rn * fma(-0.5 * d2c * rn, rn, 1.5);
+  const double d = d2c * rn;
+  const double cf = fabs(f) * rn;
+  c = ok ? cf : 1.0;
+  s = ok ? copysign(g * rn, f * g) : 0.0;   // sign(f) g / d
+  r = ok ? copysign(d, f) : f;
+  // (f = 0 exactly: copysign(., +0) keeps s = |g| / d * sign(g)... handled: f * g = 0 -> s = +|g| rn; r = +d)
+}
+
 // ---- launch 1b: Hessenberg-triangular reduction of the window (real): T22 -> upper triangular by reflectors, H22 -> upper
 // Hessenberg by Givens pairs, then (real_stage) the real double-shift sweeps above.  On the chip: [H | X] and T only (18 KB on
 // the SW-shaped window: 8 draws per CU).  The accumulated right transformation M lives transposed and complex in the draw's
@@ -627,7 +644,7 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
         double hx = hb[(i - 1) * ldH + ca], hy = hb[i * ldH + ca];
         double tx = tb[(i - 1) * ldW + cw], ty = tb[i * ldW + cw];
         double c, s, r;
-        lartg_real(f, g, c, s, r);
+        gw_lartg(f, g, c, s, r);
         rot2r(hx, hy, c, s);
         rot2r(tx, ty, c, s);
         if (lane == j) {
@@ -658,7 +675,7 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
           double hx2 = hb[cw * ldH + i], hy2 = hb[cw * ldH + i - 1];
           double tx2 = tb[cw * ldW + i], ty2 = tb[cw * ldW + i - 1];
           double r2;
-          lartg_real(tii, tim, c, s, r2);
+          gw_lartg(tii, tim, c, s, r2);
           rot2r(hx2, hy2, c, s);
           rot2r(tx2, ty2, c, s);
           rot2r(m_hi, m_lo, c, s);
