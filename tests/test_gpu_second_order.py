@@ -147,3 +147,30 @@ def test_second_order_large_batch_is_chunked_and_ordered():
     lp = big["logp"].reshape(rep, nd)
     assert np.array_equal(lp, np.broadcast_to(lp[0], lp.shape))
     assert np.array_equal(lp[0], small["logp"])
+
+
+def test_second_order_on_top_of_gensys():
+    """solver="gensys": the first-order T, R come from the ordered QZ instead of cycle reduction; coefficients and the pruned
+    likelihood agree with the cycle-reduction route to the accuracy of T (1e-9), and an explosive draw (no stable solution:
+    eu != [1, 1]) is flagged, not evaluated."""
+    nb = 6
+    b = wl.sw_second_order_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y = om["y"][:60]
+    kw = dict(Hdiag=om["Hdiag"], tol=1e-10, return_solution=True)
+    cr = batched.second_order_logp_batched(b["A"], b["B"], b["C"], b["D"], b["hess_idx"], b["hess_val"], q, om["Z"], y,
+                                           solver="cycle_reduction", **kw)
+    gs = batched.second_order_logp_batched(b["A"], b["B"], b["C"], b["D"], b["hess_idx"], b["hess_val"], q, om["Z"], y,
+                                           solver="gensys", **kw)
+    assert (cr["status"] == 0).all() and (gs["status"] == 0).all()
+    assert np.abs(gs["logp"] - cr["logp"]).max() <= 1e-8 * np.abs(cr["logp"]).max()
+    for key in ("g_yy", "g_yu", "g_uu", "g_ss"):
+        assert np.abs(gs[key] - cr[key]).max() <= 1e-8 * max(1.0, np.abs(cr[key]).max()), key
+    C = b["C"].copy()
+    C[2] *= 25.0  # far too much weight on the expectations of draw 2
+    bad = batched.second_order_logp_batched(b["A"], b["B"], C, b["D"], b["hess_idx"], b["hess_val"], q, om["Z"], y, solver="gensys",
+                                            Hdiag=om["Hdiag"], tol=1e-10)
+    assert bad["status"][2] != 0 and bad["logp"][2] == -np.inf
+    ok = np.arange(nb) != 2
+    assert (bad["status"][ok] == 0).all() and np.array_equal(bad["logp"][ok], gs["logp"][ok])
