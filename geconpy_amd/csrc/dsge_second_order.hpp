@@ -862,7 +862,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
 #pragma unroll
       for (int e = 0; e < 4; ++e) Wt[(size_t)(r + 4 * e) * MP + c] = v[e];
     });
-    so_gemm<MT>(Wt, MP, AkT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+    so_gemm_sym<MT>(Wt, AkT, MP, lds, [&](int r, int c, so_v4f64 v) {  // (A_k P A_k': symmetric, upper tiles + mirror)
 #pragma unroll
       for (int e = 0; e < 4; ++e) Xb[(size_t)(r + 4 * e) * MP + c] = v[e];
     });
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
     const double* AzT = wk + lay.azt;
     double* Qzj = wk + lay.qzj;
     const double jit = a.jitter;
-    so_gemm<MT>(AzT, MP, AzT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+    so_gemm_sym<MT>(AzT, AzT, MP, lds, [&](int r, int c, so_v4f64 v) {  // (Az Az': a Gram matrix)
 #pragma unroll
       for (int e = 0; e < 4; ++e) Qzj[(size_t)(r + 4 * e) * MP + c] = fma(jit, v[e], Qz[(size_t)(r + 4 * e) * MP + c]);
     });
@@ -1184,7 +1184,8 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       ph[1] += tn - tk;
       tk = tn;
     }
-    so_gemm<MT>(Wt, MP, AzT, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+    // (X = W Az' = Az P Az' is symmetric: only the tiles on and above the diagonal are multiplied, the others are mirrored)
+    so_gemm_sym<MT>(Wt, AzT, MP, lds, [&](int r, int c, so_v4f64 v) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) Pn[(size_t)(r + 4 * e) * MP + c] = v[e];
     });
