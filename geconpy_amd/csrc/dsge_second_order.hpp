@@ -791,6 +791,29 @@ struct SoFilterArgs {
   double jitter, missing_fill, steady_tol;
 };
 
+// x <- (Lc Lc')^-1 x (FWD_ONLY: x <- Lc^-1 x) for the p x p Cholesky factor of F, IDENTITY-PADDED to 8 x 8 with the reciprocals of
+// its diagonal in Li: compile-time loop bounds, so x stays in registers.  (With loops bounded by the run-time p the register
+// array x was addressed dynamically, i.e. lived in scratch memory: every one of the ~50 dependent accesses of a row's two
+// triangular solves was a memory round trip -- most of the 120 k cycles of the update phase and of the 60 k of Az K, Az V.)
+template <bool FWD_ONLY>
+__device__ __forceinline__ void so_chol_solve8(double (&x)[8], const double* __restrict__ Lc, const double* __restrict__ Li) {
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {  // Lc z = x
+    double sv = x[o];
+#pragma unroll
+    for (int r = 0; r < o; ++r) sv = fma(-Lc[o * 8 + r], x[r], sv);
+    x[o] = sv * Li[o];
+  }
+  if (FWD_ONLY) return;
+#pragma unroll
+  for (int o = 7; o >= 0; --o) {  // Lc' k = z
+    double sv = x[o];
+#pragma unroll
+    for (int r = o + 1; r < 8; ++r) sv = fma(-Lc[r * 8 + o], x[r], sv);
+    x[o] = sv * Li[o];
+  }
+}
+
 template <int MT>
 struct SoFilterSmem {
   static constexpr int MP = 16 * MT;
@@ -943,7 +966,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   double* Fm = pl; pl += 64;        // F, then its Cholesky factor (lower)
   double* Lc = pl; pl += 64;
   double* vv = pl; pl += 8;         // innovation
-  pl += 8;
+  double* Li = pl; pl += 8;         // reciprocals of the diagonal of Lc (1 beyond p)
   double* dv = pl; pl += 8;
   double* hv = pl; pl += 8;
   double* red = pl; pl += 32;
@@ -1043,23 +1066,40 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
         Fm[o * 8 + o2] = acc;
       }
       __syncthreads();
-      // ---- Cholesky F = Lc Lc' (thread 0; p <= 8), log det F ----------------------------------------------------------------
+      // ---- Cholesky F = Lc Lc' (thread 0; p <= 8), log det F.  In registers with compile-time bounds on the identity-padded
+      //      8 x 8 matrix (sym(F) in the leading p x p block): the version that worked on the LDS copy with loops bounded by p
+      //      was a chain of ~150 dependent LDS round trips ---------------------------------------------------------------
       if (tid == 0) {
+        double L[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j)
+            L[i][j] = (i < p && j < p) ? 0.5 * (Fm[i * 8 + j] + Fm[j * 8 + i]) : ((i == j) ? 1.0 : 0.0);
         double ld = 0.0;
         bool okc = true;
-        for (int j = 0; j < p; ++j) {
-          double dsum = 0.5 * (Fm[j * 8 + j] + Fm[j * 8 + j]);
-          for (int r = 0; r < j; ++r) dsum -= Lc[j * 8 + r] * Lc[j * 8 + r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          double dsum = L[j][j];
+#pragma unroll
+          for (int r = 0; r < j; ++r) dsum = fma(-L[j][r], L[j][r], dsum);
           if (!(dsum > 0.0)) okc = false;
-          const double dj = sqrt(dsum);
-          Lc[j * 8 + j] = dj;
-          ld += 2.0 * log(dj);
-          for (int i = j + 1; i < p; ++i) {
-            double sv = 0.5 * (Fm[i * 8 + j] + Fm[j * 8 + i]);
-            for (int r = 0; r < j; ++r) sv -= Lc[i * 8 + r] * Lc[j * 8 + r];
-            Lc[i * 8 + j] = sv / dj;
+          const double dj = sqrt(dsum), rj = 1.0 / dj;
+          L[j][j] = dj;
+          Li[j] = rj;
+          if (j < p) ld += 2.0 * log(dj);
+#pragma unroll
+          for (int i = j + 1; i < 8; ++i) {
+            double sv = L[i][j];
+#pragma unroll
+            for (int r = 0; r < j; ++r) sv = fma(-L[i][r], L[j][r], sv);
+            L[i][j] = sv * rj;
           }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) Lc[i * 8 + j] = (j <= i) ? L[i][j] : 0.0;
         logdet = ld;
         if (!okc) finite = false;
         imask[2] = okc ? 1 : 0;
@@ -1070,16 +1110,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
         double x[PM];
 #pragma unroll
         for (int o = 0; o < PM; ++o) x[o] = (o < p) ? PZ[o * MP + i] : 0.0;
-        for (int o = 0; o < p; ++o) {  // Lc z = pz
-          double sv = x[o];
-          for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
-          x[o] = sv / Lc[o * 8 + o];
-        }
-        for (int o = p - 1; o >= 0; --o) {  // Lc' k = z
-          double sv = x[o];
-          for (int r = o + 1; r < p; ++r) sv -= Lc[r * 8 + o] * x[r];
-          x[o] = sv / Lc[o * 8 + o];
-        }
+        so_chol_solve8<false>(x, Lc, Li);
 #pragma unroll
         for (int o = 0; o < PM; ++o) Kg[o * MP + i] = x[o];
       }
@@ -1088,13 +1119,12 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     // ---- F^-1 v, log-likelihood contribution, filtered mean ---------------------------------------------------------------
     if (tid == 0) {
       double x[PM];
-      for (int o = 0; o < p; ++o) {
-        double sv = vv[o];
-        for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
-        x[o] = sv / Lc[o * 8 + o];
-      }
+#pragma unroll
+      for (int o = 0; o < PM; ++o) x[o] = (o < p) ? vv[o] : 0.0;
+      so_chol_solve8<true>(x, Lc, Li);
       double quad = 0.0;
-      for (int o = 0; o < p; ++o) quad = fma(x[o], x[o], quad);
+#pragma unroll
+      for (int o = 0; o < PM; ++o) quad = fma(x[o], x[o], quad);
       if (mask != 0) ll_sum += -0.5 * (p * LN2PI + logdet + quad);
       if (!(quad == quad)) finite = false;
     }
@@ -1162,16 +1192,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       double apz[PM];
 #pragma unroll
       for (int o = 0; o < PM; ++o) apz[o] = x[o];
-      for (int o = 0; o < p; ++o) {  // (Az P Z') F^-1 row by row: Lc z = ., Lc' k = z
-        double sv = x[o];
-        for (int r = 0; r < o; ++r) sv -= Lc[o * 8 + r] * x[r];
-        x[o] = sv / Lc[o * 8 + o];
-      }
-      for (int o = p - 1; o >= 0; --o) {
-        double sv = x[o];
-        for (int r = o + 1; r < p; ++r) sv -= Lc[r * 8 + o] * x[r];
-        x[o] = sv / Lc[o * 8 + o];
-      }
+      so_chol_solve8<false>(x, Lc, Li);  // (Az P Z') F^-1 row by row
 #pragma unroll
       for (int o = 0; o < PM; ++o) {
         AK[o * MP + i] = x[o];
