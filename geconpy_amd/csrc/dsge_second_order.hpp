@@ -1218,24 +1218,40 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     // component without second-order dynamics has variance exactly 0 in P0: no division)
     double dm = 0.0, pm = 0.0;
     const double tol2 = a.steady_tol * a.steady_tol;
-    for (int idx = tid; idx < MP * MP / 2; idx += NT) {
-      const int i = idx / (MP / 2), j = 2 * (idx - i * (MP / 2));
-      double2 x = ((const double2*)Pn)[idx];
-      const double2 qz = ((const double2*)Qzj)[idx], po = ((const double2*)Pc)[idx];
-      double c0 = 0.0, c1 = 0.0;
+    // (three pairs per trip, their nine global loads requested before any of them is used: the pass is a chain of load
+    //  latencies otherwise -- 42 dependent trips per thread)
+    constexpr int FX = 3;
+    for (int idx0 = tid; idx0 < MP * MP / 2; idx0 += FX * NT) {
+      double2 x[FX], qz[FX], po[FX];
 #pragma unroll
-      for (int o = 0; o < PM; ++o) {
-        const double aki = AK[o * MP + i], avi = AV[o * MP + i];
-        const double2 akj = *(const double2*)(AK + o * MP + j), avj = *(const double2*)(AV + o * MP + j);
-        c0 = fma(aki, avj.x, fma(avi, akj.x, c0));
-        c1 = fma(aki, avj.y, fma(avi, akj.y, c1));
+      for (int f = 0; f < FX; ++f) {
+        const int idx = idx0 + f * NT < MP * MP / 2 ? idx0 + f * NT : idx0;
+        x[f] = ((const double2*)Pn)[idx];
+        qz[f] = ((const double2*)Qzj)[idx];
+        po[f] = ((const double2*)Pc)[idx];
       }
-      x.x = fma(-0.5, c0, x.x) + qz.x;
-      x.y = fma(-0.5, c1, x.y) + qz.y;
-      ((double2*)Pn)[idx] = x;
-      const double di = part[i], d0 = x.x - po.x, d1 = x.y - po.y;
-      dm = fmax(dm, (d0 * d0 > tol2 * di * part[j] || d1 * d1 > tol2 * di * part[j + 1]) ? 1.0 : 0.0);  // 1 = still moving
-      pm = nanmax(pm, nanmax(fabs(x.x), fabs(x.y)));
+#pragma unroll
+      for (int f = 0; f < FX; ++f) {
+        const int idx = idx0 + f * NT;
+        if (idx < MP * MP / 2) {
+          const int i = idx / (MP / 2), j = 2 * (idx - i * (MP / 2));
+          double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+          for (int o = 0; o < PM; ++o) {
+            const double aki = AK[o * MP + i], avi = AV[o * MP + i];
+            const double2 akj = *(const double2*)(AK + o * MP + j), avj = *(const double2*)(AV + o * MP + j);
+            c0 = fma(aki, avj.x, fma(avi, akj.x, c0));
+            c1 = fma(aki, avj.y, fma(avi, akj.y, c1));
+          }
+          double2 xn;
+          xn.x = fma(-0.5, c0, x[f].x) + qz[f].x;
+          xn.y = fma(-0.5, c1, x[f].y) + qz[f].y;
+          ((double2*)Pn)[idx] = xn;
+          const double di = part[i], d0 = xn.x - po[f].x, d1 = xn.y - po[f].y;
+          dm = fmax(dm, (d0 * d0 > tol2 * di * part[j] || d1 * d1 > tol2 * di * part[j + 1]) ? 1.0 : 0.0);  // 1 = still moving
+          pm = nanmax(pm, nanmax(fabs(xn.x), fabs(xn.y)));
+        }
+      }
     }
     {
       double* t = Pc;
