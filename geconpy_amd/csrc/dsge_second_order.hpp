@@ -823,20 +823,37 @@ struct SoFilterSmem {
   static constexpr size_t bytes = doubles * sizeof(double);
 };
 
-// sym + add pass shared by the doubling and the prediction: P_new = 1/2 (X + X') + base (+ P_old if ACC); returns max |P_new -
+// add pass of the doubling: P_new = X + base (+ P_old if ACC) for an exactly symmetric X; returns max |P_new -
 // P_old| and max |P_new| in dmax / pmax (workgroup-uniform)
 template <int NT, bool ACC>
 __device__ __forceinline__ void so_sym_update(double* P, const double* Xb, const double* base, int MP, int m, double* red,
                                               double& dmax, double& pmax) {
   double dm = 0.0, pm = 0.0;
-  for (int idx = threadIdx.x; idx < m * m; idx += NT) {
-    const int i = idx / m, j = idx - i * m;
-    const double xs = 0.5 * (Xb[(size_t)i * MP + j] + Xb[(size_t)j * MP + i]);
-    const double po = P[(size_t)i * MP + j];
-    const double pn = ACC ? po + xs : xs + base[(size_t)i * MP + j];
-    P[(size_t)i * MP + j] = pn;
-    dm = nanmax(dm, fabs(pn - po));
-    pm = nanmax(pm, fabs(pn));
+  // Xb comes from so_gemm_sym: exactly symmetric, so the (uncoalesced) average with its transpose is gone; four rows of pairs
+  // per trip with their loads requested together (padding rows / columns of Xb, P and base are zero and stay zero)
+  constexpr int FX = 4;
+  const int npairs = m * (MP / 2);
+  for (int idx0 = threadIdx.x; idx0 < npairs; idx0 += FX * NT) {
+    double2 x[FX], po[FX], bs[FX];
+#pragma unroll
+    for (int f = 0; f < FX; ++f) {
+      const int idx = idx0 + f * NT < npairs ? idx0 + f * NT : idx0;
+      x[f] = ((const double2*)Xb)[idx];
+      po[f] = ((const double2*)P)[idx];
+      if (!ACC) bs[f] = ((const double2*)base)[idx];
+    }
+#pragma unroll
+    for (int f = 0; f < FX; ++f) {
+      const int idx = idx0 + f * NT;
+      if (idx < npairs) {
+        double2 pn;
+        pn.x = ACC ? po[f].x + x[f].x : x[f].x + bs[f].x;
+        pn.y = ACC ? po[f].y + x[f].y : x[f].y + bs[f].y;
+        ((double2*)P)[idx] = pn;
+        dm = nanmax(dm, nanmax(fabs(pn.x - po[f].x), fabs(pn.y - po[f].y)));
+        pm = nanmax(pm, nanmax(fabs(pn.x), fabs(pn.y)));
+      }
+    }
   }
   dmax = so_wg_max<NT>(dm, red);
   pmax = so_wg_max<NT>(pm, red);
@@ -889,13 +906,17 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
 #pragma unroll
       for (int e = 0; e < 4; ++e) Xb[(size_t)(r + 4 * e) * MP + c] = v[e];
     });
-    so_gemm<MT>(AkT, MP, Ak, MP, MP, lds, [&](int r, int c, so_v4f64 v) {
+    so_gemm<MT>(
+        AkT, MP, Ak, MP, MP, lds,
+        [&](int r, int c, so_v4f64 v) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Ak2[(size_t)(r + 4 * e) * MP + c] = v[e];
-        AkT2[(size_t)c * MP + r + 4 * e] = v[e];
-      }
-    });
+          for (int e = 0; e < 4; ++e) Ak2[(size_t)(r + 4 * e) * MP + c] = v[e];
+        },
+        SoZeroInit(),
+        [&](int r, int c, so_v4f64 v) {  // (the transposed tiles, with natural store addresses)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) AkT2[(size_t)(r + 4 * e) * MP + c] = v[e];
+        });
     __syncthreads();
     double dmax, pmax;
     so_sym_update<NT, true>(P, Xb, nullptr, MP, m, red, dmax, pmax);

@@ -49,9 +49,12 @@ struct SoZeroInit {
 // init(row0, col): the starting value of a tile fragment (C = init + Aop' Bop): an epilogue that needs a matrix from global
 // memory per element pays one memory latency per fragment -- 25 in a row per wavefront -- whereas the fragments' starting
 // values are all requested at once, before the first chunk is multiplied.
-template <int MT, int HALF, class Epi, class Init>
+struct SoNoTranspose {};
+
+template <int MT, int HALF, class Epi, class Init, class EpiT = SoNoTranspose>
 __device__ __forceinline__ void so_gemm_half(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb,
-                                             int K, double* lds, int rt0, int nrt, int ct0, int nct, Epi epi, Init init) {
+                                             int K, double* lds, int rt0, int nrt, int ct0, int nct, Epi epi, Init init,
+                                             EpiT epit = EpiT()) {
   using Cfg = SoGemmCfg<MT>;
   constexpr int MP = Cfg::MP, LDSROW = Cfg::LDSROW, KC = Cfg::KC, RB = Cfg::RB, STAGE = Cfg::STAGE, PIECES = Cfg::PIECES,
                 T0 = HALF ? Cfg::NT0 : 0, NT = HALF ? RB * RB - Cfg::NT0 : Cfg::NT0;
@@ -106,22 +109,47 @@ __device__ __forceinline__ void so_gemm_half(const double* __restrict__ Aop, int
     const int i = (T0 + t) / RB, j = (T0 + t) % RB;
     if (i < nrt && j < nct) epi(16 * (rt0 + i) + (lane >> 4), 16 * (ct0 + j) + (lane & 15), acc[t]);
   }
+  if constexpr (!__is_same(EpiT, SoNoTranspose)) {
+    // C' as well (A_k^2 in both layouts): every tile once more, transposed through this wavefront's 16 x 17 doubles of the idle
+    // staging LDS and handed to `epit` with the coordinates of the transposed tile -- the store then coalesces like the natural
+    // one (a store with transposed addresses cost +50 us per product)
+    double* tr = lds + wave * (16 * 17);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int i = (T0 + t) / RB, j = (T0 + t) % RB;
+      if (i < nrt && j < nct) {
+        int lq = lane >> 4, lm = lane & 15;
+        asm volatile("" : "+v"(lq), "+v"(lm));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[(lq + 4 * r) * 17 + lm] = acc[t][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        so_v4f64 vt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vt[r] = tr[lm * 17 + lq + 4 * r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        epit(16 * (ct0 + j) + lq, 16 * (rt0 + i) + lm, vt);
+      }
+    }
+  }
 }
 
 // C = Aop' Bop handed to `epi(row0, col, v)` one tile fragment at a time (rows / columns < 16 MT): v[r], r = 0..3, is the element
 // (row0 + 4 r, col) -- lane l of tile (ti, tj) has row0 = 16 ti + (l >> 4), col = 16 tj + (l & 15).  Every element is delivered
 // exactly once.  (Per fragment, so that an epilogue that also READS can issue its four loads before its four stores.)
-template <int MT, class Epi, class Init = SoZeroInit>
+template <int MT, class Epi, class Init = SoZeroInit, class EpiT = SoNoTranspose>
 __device__ __forceinline__ void so_gemm(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb, int K,
-                                        double* lds, Epi epi, Init init = Init()) {
+                                        double* lds, Epi epi, Init init = Init(), EpiT epit = EpiT()) {
   constexpr int RB = SoGemmCfg<MT>::RB;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: block offsets and the half are wave-uniform)
   const int pair = wave >> 1, rbk = pair >> 1, cbk = pair & 1;
   const int rt0 = rbk ? RB : 0, nrt = rbk ? MT - RB : RB, ct0 = cbk ? RB : 0, nct = cbk ? MT - RB : RB;
   if (wave & 1)
-    so_gemm_half<MT, 1>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi, init);
+    so_gemm_half<MT, 1>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi, init, epit);
   else
-    so_gemm_half<MT, 0>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi, init);
+    so_gemm_half<MT, 0>(Aop, lda, Bop, ldb, K, lds, rt0, nrt, ct0, nct, epi, init, epit);
 }
 
 // ---- symmetric product: C = Aop' Bop is KNOWN to be symmetric (X = W Az' = Az P Az', A_k P A_k', Az Az') --------------------------
