@@ -1053,29 +1053,42 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     __syncthreads();  // (the innovation is read by every wavefront below, also on the steady path)
     if (!steady) {
       // ---- P Z' (m x p), F = Zm P Zm' + Hm + jitter I ---------------------------------------------------------------------
-      for (int i = tid; i < m; i += NT) {  // (P is symmetric: column i is read as row entries P[c][i], coalesced over i)
+      // (P is symmetric: column i is read as row entries P[c][i], coalesced over i.  Two groups of 256 threads share the 2u rows:
+      //  the pass is a chain of load latencies -- ~10 k cycles each under the launch's own HBM traffic --, not of arithmetic)
+      {
+        static_assert(NT == 512, "two groups of 256 threads");
+        const int g = tid >> 8, i = tid & 255, uh = (u + 1) / 2, cb = g * uh, ce = (cb + uh < u) ? cb + uh : u;
         double acc[PM];
 #pragma unroll
         for (int o = 0; o < PM; ++o) acc[o] = 0.0;
-        for (int c0 = 0; c0 < u; c0 += 8) {  // (sixteen loads in flight)
-          double pv[16];
+        if (i < m) {
+          for (int c0 = cb; c0 < ce; c0 += 12) {  // (24 loads in flight)
+            double pv[24];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e < u ? c0 + e : u - 1;
-            pv[e] = Pc[(size_t)c * MP + i];
-            pv[8 + e] = Pc[(size_t)(u + c) * MP + i];
+            for (int e = 0; e < 12; ++e) {
+              const int c = c0 + e < ce ? c0 + e : cb;
+              pv[e] = Pc[(size_t)c * MP + i];
+              pv[12 + e] = Pc[(size_t)(u + c) * MP + i];
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+              const double pc = (c0 + e < ce) ? pv[e] + pv[12 + e] : 0.0;
+              const int c = c0 + e < ce ? c0 + e : cb;
+#pragma unroll
+              for (int o = 0; o < PM; ++o)
+                if (o < p) acc[o] = fma(pc, Zu[o * u + c], acc[o]);
+            }
           }
+          if (g == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const double pc = (c0 + e < u) ? pv[e] + pv[8 + e] : 0.0;
-            const int c = c0 + e < u ? c0 + e : u - 1;
-#pragma unroll
-            for (int o = 0; o < PM; ++o)
-              if (o < p) acc[o] = fma(pc, Zu[o * u + c], acc[o]);
+            for (int o = 0; o < PM; ++o) AV[o * MP + i] = acc[o];  // (AV is free until the second half of the step)
           }
         }
+        __syncthreads();
+        if (g == 0 && i < m) {
 #pragma unroll
-        for (int o = 0; o < PM; ++o) PZ[o * MP + i] = (o < p && ((mask >> o) & 1)) ? acc[o] : 0.0;
+          for (int o = 0; o < PM; ++o) PZ[o * MP + i] = (o < p && ((mask >> o) & 1)) ? acc[o] + AV[o * MP + i] : 0.0;
+        }
       }
       __syncthreads();
       if (tid < p * p) {
@@ -1185,39 +1198,49 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       ph[2] += tn - tk;
       tk = tn;
     }
-    for (int i = tid; i < MP; i += NT) {
+    {  // (two groups of 256 threads share the 2u rows of W', as above; PZ is free by now and takes the second group's sums)
+      const int g = tid >> 8, i = tid & 255, uh = (u + 1) / 2, cb = g * uh, ce = (cb + uh < u) ? cb + uh : u;
       double x[PM];
 #pragma unroll
       for (int o = 0; o < PM; ++o) x[o] = 0.0;
       if (i < m) {
-        for (int c0 = 0; c0 < u; c0 += 8) {
-          double wv[16];
+        for (int c0 = cb; c0 < ce; c0 += 12) {
+          double wv[24];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e < u ? c0 + e : u - 1;
+          for (int e = 0; e < 12; ++e) {
+            const int c = c0 + e < ce ? c0 + e : cb;
             wv[e] = Wt[(size_t)c * MP + i];
-            wv[8 + e] = Wt[(size_t)(u + c) * MP + i];
+            wv[12 + e] = Wt[(size_t)(u + c) * MP + i];
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const double wc = (c0 + e < u) ? wv[e] + wv[8 + e] : 0.0;
-            const int c = c0 + e < u ? c0 + e : u - 1;
+          for (int e = 0; e < 12; ++e) {
+            const double wc = (c0 + e < ce) ? wv[e] + wv[12 + e] : 0.0;
+            const int c = c0 + e < ce ? c0 + e : cb;
 #pragma unroll
             for (int o = 0; o < PM; ++o)
               if (o < p) x[o] = fma(wc, Zu[o * u + c], x[o]);
           }
         }
+        if (g == 1) {
 #pragma unroll
-        for (int o = 0; o < PM; ++o) x[o] = (o < p && ((mask >> o) & 1)) ? x[o] : 0.0;
+          for (int o = 0; o < PM; ++o) PZ[o * MP + i] = x[o];
+        }
       }
-      double apz[PM];
+      __syncthreads();
+      if (g == 0 && i < MP) {
+        if (i < m) {
 #pragma unroll
-      for (int o = 0; o < PM; ++o) apz[o] = x[o];
-      so_chol_solve8<false>(x, Lc, Li);  // (Az P Z') F^-1 row by row
+          for (int o = 0; o < PM; ++o) x[o] = (o < p && ((mask >> o) & 1)) ? x[o] + PZ[o * MP + i] : 0.0;
+        }
+        double apz[PM];
 #pragma unroll
-      for (int o = 0; o < PM; ++o) {
-        AK[o * MP + i] = x[o];
-        AV[o * MP + i] = fma(a.jitter, x[o], apz[o]);
+        for (int o = 0; o < PM; ++o) apz[o] = x[o];
+        so_chol_solve8<false>(x, Lc, Li);  // (Az P Z') F^-1 row by row
+#pragma unroll
+        for (int o = 0; o < PM; ++o) {
+          AK[o * MP + i] = x[o];
+          AV[o * MP + i] = fma(a.jitter, x[o], apz[o]);
+        }
       }
     }
     __syncthreads();
