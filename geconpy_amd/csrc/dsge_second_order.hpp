@@ -819,7 +819,8 @@ struct SoFilterSmem {
   static constexpr int MP = 16 * MT;
   // GEMM staging + vectors: a, ap (MP each), K, PZ (MP x 8 each), F, Lc (64 each), v, w, dvec, hvec (8 each), reductions
   // ... + Az K, Az V (MP x 8 each) and the partial sums of the mean prediction (2 MP)
-  static constexpr size_t doubles = SoGemmCfg<MT>::LDS_DOUBLES + 2 * MP + 4 * MP * 8 + 2 * MP + 2 * 64 + 4 * 8 + 64;
+  static constexpr size_t doubles = SoGemmCfg<MT>::LDS_DOUBLES + 2 * MP + 4 * MP * 8 + 2 * MP + 2 * 64 + 4 * 8 + 64 +
+                                    3 * SO_MAX_S * SO_MAX_S;  // + Ts, unvech(w), Ts unvech(w) of the structured mean prediction
   static constexpr size_t bytes = doubles * sizeof(double);
 };
 
@@ -951,6 +952,15 @@ __device__ __forceinline__ void so_mean_predict(const double* __restrict__ AzT, 
   if (i < m) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     int kx = k0;
+#pragma unroll 1
+    for (; kx + 16 <= k1; kx += 16) {  // (sixteen loads in flight)
+      double z[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) z[e] = AzT[(size_t)(kx + e) * MP + i];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e & 3] = fma(z[e], ap[kx + e], acc[e & 3]);
+    }
+#pragma unroll 1
     for (; kx + 8 <= k1; kx += 8) {
       double z[8];
 #pragma unroll
@@ -963,6 +973,77 @@ __device__ __forceinline__ void so_mean_predict(const double* __restrict__ AzT, 
   }
   __syncthreads();
   if (tid < m) av[tid] = cvec[tid] + part[tid] + part[MP + tid];
+  __syncthreads();
+}
+
+// The same prediction through the STRUCTURE of Az (so_setup_kernel, step 13):
+//     x_f' = T[U, S] x_f[S],    x_s' = T[U, S] x_s[S] + 1/2 g_yy[U] w,    w' = vech(Ts unvech(w) Ts') + (constants in c)
+// -- 36 x 18 + 36 x 189 entries of Az' and Ts instead of all 207 x 207 (59 KB instead of 343 KB per step: a steady step is
+// this prediction and nothing else, and 256 workgroups reading their Az' every 30 k cycles are 6 TB/s of Infinity-Cache
+// traffic, i.e. the steady steps were bandwidth-bound).  The w block is two s x s products: Y = Ts X, X' = Y Ts' (X = unvech(w)).
+// Ts: LDS copy of T[S, S] (s x s), Xs, Ys: s x s scratch, pr: pr_cap doubles of scratch (the Az K buffer is free here).
+template <int NT>
+__device__ __forceinline__ void so_mean_predict_structured(const double* __restrict__ AzT, const double* ap,
+                                                           const double* __restrict__ cvec, double* av, const double* Ts,
+                                                           double* Xs, double* Ys, double* pr, int pr_cap, int MP, int u, int s,
+                                                           int q_) {
+  const int tid = threadIdx.x;
+  const int G = (NT / u < pr_cap / (2 * u)) ? NT / u : pr_cap / (2 * u);  // k-groups: as many as threads and scratch allow
+  const int kg = tid / u, io = tid - kg * u, nk = s + q_;
+  // ---- phase A: unvech(w), and the partial sums of the x_f and x_s outputs over this thread's share of the state
+  for (int idx = tid; idx < s * s; idx += NT) {
+    const int c = idx / s, d = idx - c * s, a_ = c < d ? c : d, b_ = c < d ? d : c;
+    Xs[idx] = ap[2 * u + a_ * s - (a_ * (a_ - 1)) / 2 + (b_ - a_)];
+  }
+  if (kg < G) {
+    double sf = 0.0, ss0 = 0.0, ss1 = 0.0;
+    for (int kf = kg; kf < s; kf += G) sf = fma(AzT[(size_t)kf * MP + io], ap[kf], sf);  // x_f'[io] <- T[U_io, S_k] x_f[S_k]
+    for (int k0 = kg; k0 < nk; k0 += 8 * G) {              // x_s'[io]: up to eight loads in flight
+      double z[8], xk[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kk = k0 + e * G, kc = kk < nk ? kk : kg;
+        const int row = kc < s ? u + kc : 2 * u + (kc - s);
+        z[e] = AzT[(size_t)row * MP + u + io];
+        xk[e] = kk < nk ? ap[row] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        ss0 = fma(z[e], xk[e], ss0);
+        ss1 = fma(z[e + 1], xk[e + 1], ss1);
+      }
+    }
+    pr[kg * 2 * u + io] = sf;
+    pr[kg * 2 * u + u + io] = ss0 + ss1;
+  }
+  __syncthreads();
+  // ---- phase B: Y = Ts X; the x_f, x_s outputs
+  for (int idx = tid; idx < s * s; idx += NT) {
+    const int a_ = idx / s, d = idx - a_ * s;
+    double acc = 0.0;
+    for (int c = 0; c < s; ++c) acc = fma(Ts[a_ * s + c], Xs[c * s + d], acc);
+    Ys[idx] = acc;
+  }
+  if (tid >= NT - 2 * u) {  // (the last 2u threads: the first s^2 are busy with Y)
+    const int i = tid - (NT - 2 * u);
+    double acc = cvec[i];
+    for (int g = 0; g < G; ++g) acc += pr[g * 2 * u + i];
+    av[i] = acc;
+  }
+  __syncthreads();
+  // ---- phase C: w' = vech(Y Ts') + c
+  for (int j = tid; j < q_; j += NT) {
+    // pair j -> (a, b), a <= b, row-major upper triangle
+    int a_ = 0, base = 0;
+    while (base + (s - a_) <= j) {
+      base += s - a_;
+      ++a_;
+    }
+    const int b_ = a_ + (j - base);
+    double acc = 0.0;
+    for (int d = 0; d < s; ++d) acc = fma(Ys[a_ * s + d], Ts[b_ * s + d], acc);
+    av[2 * u + j] = cvec[2 * u + j] + acc;
+  }
   __syncthreads();
 }
 
@@ -991,7 +1072,10 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   double* dv = pl; pl += 8;
   double* hv = pl; pl += 8;
   double* red = pl; pl += 32;
-  int* imask = (int*)pl;            // [0] = current mask, [1] = steady flag, [2] = finite flag
+  int* imask = (int*)pl; pl += 8;   // [0] = current mask, [1] = steady flag, [2] = finite flag
+  double* Tss = pl; pl += SO_MAX_S * SO_MAX_S;  // T[S, S] (the x_f block of Az) for the structured mean prediction
+  double* Xss = pl; pl += SO_MAX_S * SO_MAX_S;
+  double* Yss = pl; pl += SO_MAX_S * SO_MAX_S;
   // The launch's makespan is set by the draws whose covariance recursion reaches its fixed point late (up to T_len full
   // steps against ~60 on average): like the first-order filter, the workgroups take the draws in the caller's order
   const int tid = threadIdx.x;
@@ -1011,6 +1095,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   double* Wt = wk + lay.wt;
   const double* Zu = a.Zu;
   for (int i = tid; i < MP; i += NT) av[i] = wk[lay.a0 + i];
+  for (int idx = tid; idx < lay.s * lay.s; idx += NT) Tss[idx] = AzT[(size_t)(idx % lay.s) * MP + idx / lay.s];  // Ts[a][c] = Az[a][c]
   if (tid < 8) {
     dv[tid] = (a.d && tid < p) ? a.d[tid] : 0.0;
     hv[tid] = (a.Hdiag && tid < p) ? a.Hdiag[tid] : 0.0;
@@ -1169,7 +1254,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
     }
     __syncthreads();
     // ---- predicted mean a = Az a+ + c ----------------------------------------------------------------------------------------
-    so_mean_predict<NT>(AzT, ap, cvec, av, part, MP, m);
+    so_mean_predict_structured<NT>(AzT, ap, cvec, av, Tss, Xss, Yss, AK, MP * PM, MP, u, lay.s, lay.q);
     if (steady) {
       if (stamp) {
         ph[4] += clock64() - tk;
