@@ -1112,16 +1112,15 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   const bool stamp = a.phases != nullptr && draw == 0 && tid == 0;
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = stamp ? clock64() : 0;
+  double y_next = (tid < p && a.T_len > 0) ? a.y[tid] : 0.0;  // (this thread's entry of the next observation row)
   for (int t = 0; t < a.T_len; ++t) {
     long long tk = stamp ? clock64() : 0;
-    // ---- missing-data mask of this step (bit o set = observed) -----------------------------------------------------------
-    if (tid == 0) {
-      int mk = 0;
-      for (int o = 0; o < p; ++o) {
-        const double yo = a.y[(size_t)t * p + o];
-        if (!(yo != yo) && yo != a.missing_fill) mk |= 1 << o;
-      }
-      imask[0] = mk;
+    // ---- missing-data mask of this step (bit o set = observed); the observation row was requested one step ahead --------------
+    const double y_now = y_next;
+    if (tid < p && t + 1 < a.T_len) y_next = a.y[(size_t)(t + 1) * p + tid];
+    if (tid < 64) {
+      const unsigned long long ob = __ballot(tid < p && !(y_now != y_now) && y_now != a.missing_fill);
+      if (tid == 0) imask[0] = (int)(ob & 0xffull);
     }
     __syncthreads();
     const int mask = imask[0];
@@ -1132,7 +1131,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       double za = 0.0;
       if ((mask >> o) & 1)
         for (int c = 0; c < u; ++c) za = fma(Zu[o * u + c], av[c] + av[u + c], za);
-      const double yo = ((mask >> o) & 1) ? a.y[(size_t)t * p + o] : 0.0;
+      const double yo = ((mask >> o) & 1) ? y_now : 0.0;
       vv[o] = yo - dv[o] - za;
     }
     __syncthreads();  // (the innovation is read by every wavefront below, also on the steady path)
