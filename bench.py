@@ -784,8 +784,10 @@ def main_second_order(args, world, rank, local_rank):
     if rank == 0:
         mp16 = 16 * ((m + 15) // 16)
         kq = k + s * k + k * (k + 1) // 2
-        gemm_useful = 2.0 * m ** 3  # one product of the prediction step (unpadded)
-        flops_filter = float(n_full.sum()) * 2 * gemm_useful
+        # the prediction step's two products (unpadded): W' = P Az' in full, X = W Az' on and above the diagonal only (it is
+        # symmetric: so_gemm_sym multiplies m (m + 1) / 2 of its m^2 entries)
+        flops_step = 2.0 * m ** 3 + 2.0 * m * (m * (m + 1) / 2)
+        flops_filter = float(n_full.sum()) * flops_step
         filt_s = ms[3] * 1e-3
         value = global_batch * args.steps / dt
         out = {
@@ -810,8 +812,9 @@ def main_second_order(args, world, rank, local_rank):
                 "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
                 "achieved": round(flops_filter / filt_s / 1e12, 3),
                 "frac": round(flops_filter / filt_s / 1e12 / FP64_PEAK_TFLOPS, 5),
-                "flops_source": f"2 products x 2 m^3 (m = {m}, unpadded) per full filter step x the measured number of full steps per "
-                                f"draw (mean {n_full.mean():.1f} of {T_len}); duration: HIP events around the kernel in this run",
+                "flops_source": f"2 m^3 (W' = P Az') + m^2 (m + 1) (the symmetric X = W Az', upper half only) with m = {m}, unpadded, per "
+                                f"full filter step x the measured number of full steps per draw (mean {n_full.mean():.1f} of {T_len}); "
+                                "duration: HIP events around the kernel in this run",
                 **so_counters(f"so_filter_kernel<{mp16 // 16}>", nloc),
                 "stage_ms": {"first_order_solver": round(ms[0], 3), "second_order_setup": round(ms[1], 3),
                              "stationary_covariance": round(ms[2], 3), "filter": round(ms[3], 3)},
