@@ -144,6 +144,24 @@ struct SoIdx {  // the model's index sets, passed by value in the kernel argumen
   uint8_t L[64];         // forward-looking variables (non-zero columns of C)
 };
 
+// sum_k a[k sa] b[k sb], k < K, on four independent accumulators with the eight loads of a trip requested together: the set-up
+// kernel's inner loops are bounded by run-time sizes (s, l, n), which the compiler does not unroll -- one accumulator and one
+// dependent load pair per term made every term cost a full LDS (or global) latency.
+__device__ __forceinline__ double so_dot4(const double* a, int sa, const double* b, int sb, int K) {
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    const double a0 = a[(size_t)k * sa], a1 = a[(size_t)(k + 1) * sa], a2 = a[(size_t)(k + 2) * sa], a3 = a[(size_t)(k + 3) * sa];
+    const double b0 = b[(size_t)k * sb], b1 = b[(size_t)(k + 1) * sb], b2 = b[(size_t)(k + 2) * sb], b3 = b[(size_t)(k + 3) * sb];
+    c0 = fma(a0, b0, c0);
+    c1 = fma(a1, b1, c1);
+    c2 = fma(a2, b2, c2);
+    c3 = fma(a3, b3, c3);
+  }
+  for (; k < K; ++k) c0 = fma(a[(size_t)k * sa], b[(size_t)k * sb], c0);
+  return (c0 + c1) + (c2 + c3);
+}
+
 struct SoSetupArgs {
   const double* B;
   const double* C;
@@ -334,9 +352,7 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
   __syncthreads();
   for (int idx = tid; idx < n * ss; idx += NT) {
     const int i = idx / ss, cd = idx - i * ss;
-    double acc = 0.0;
-    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], X0[(size_t)r * ss + cd], acc);
-    X[idx] = acc;
+    X[idx] = so_dot4(Mi + i * ldm, 1, X0 + cd, ss, n);
   }
   // ---- 8. doubling: X <- X - G_k (X (T_k (x) T_k)),  sign: X + G X (Ts (x) Ts) = X0  =>  X = sum_j (-G)^j X0 (Ts (x) Ts)^j ------
   for (int idx = tid; idx < n * l; idx += NT) Gk[idx] = -GL[idx];
@@ -348,24 +364,20 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
     for (int idx = tid; idx < l * ss; idx += NT) {
       const int jj = idx / ss, ad = idx - jj * ss, a_ = ad / s, d = ad - a_ * s;
       const double* xr = X + (size_t)Li[jj] * ss + a_ * s;
-      double acc = 0.0;
-      for (int b = 0; b < s; ++b) acc = fma(xr[b], Tk[b * s + d], acc);
-      Y1[idx] = acc;
+      Y1[idx] = so_dot4(xr, 1, Tk + d, s, s);
     }
     __syncthreads();
     for (int idx = tid; idx < l * ss; idx += NT) {
       const int jj = idx / ss, cd = idx - jj * ss, c = cd / s, d = cd - c * s;
-      double acc = 0.0;
-      for (int a_ = 0; a_ < s; ++a_) acc = fma(Tk[a_ * s + c], Y1[jj * ss + a_ * s + d], acc);
-      Y2[idx] = acc;
+      Y2[idx] = so_dot4(Tk + c, s, Y1 + jj * ss + d, s, s);
     }
     __syncthreads();
     double dmax = 0.0, xmax = 0.0;
     for (int idx = tid; idx < n * ss; idx += NT) {
       const int i = idx / ss, cd = idx - i * ss;
-      double acc = 0.0;
-      for (int jj = 0; jj < l; ++jj) acc = fma(Gk[i * l + jj], Y2[jj * ss + cd], acc);
-      const double xn = X[idx] + acc;
+      const double xold = X[idx];
+      const double acc = so_dot4(Gk + i * l, 1, Y2 + cd, ss, l);
+      const double xn = xold + acc;
       X[idx] = xn;
       dmax = nanmax(dmax, fabs(acc));
       xmax = nanmax(xmax, fabs(xn));
@@ -374,18 +386,14 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
     for (int idx = tid; idx < l * l; idx += NT) GLL[idx] = Gk[Li[idx / l] * l + idx % l];
     for (int idx = tid; idx < ss; idx += NT) {
       const int r = idx / s, c = idx - r * s;
-      double acc = 0.0;
-      for (int b = 0; b < s; ++b) acc = fma(Tk[r * s + b], Tk[b * s + c], acc);
-      Tk2[idx] = acc;
+      Tk2[idx] = so_dot4(Tk + r * s, 1, Tk + c, s, s);
     }
     dmax = so_wg_max<NT>(dmax, red);
     xmax = so_wg_max<NT>(xmax, red);  // (barriers inside: GLL, Tk2 and X are complete)
     double* Gn = GL;  // (GL is dead after step 8 starts: next G_k goes there, then swapped back)
     for (int idx = tid; idx < n * l; idx += NT) {
       const int i = idx / l, c = idx - i * l;
-      double acc = 0.0;
-      for (int b = 0; b < l; ++b) acc = fma(Gk[i * l + b], GLL[b * l + c], acc);
-      Gn[idx] = acc;
+      Gn[idx] = so_dot4(Gk + i * l, 1, GLL + c, l, l);
     }
     __syncthreads();
     for (int idx = tid; idx < n * l; idx += NT) Gk[idx] = Gn[idx];
@@ -411,9 +419,7 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
   __syncthreads();
   for (int idx = tid; idx < l * s * k; idx += NT) {
     const int jj = idx / (s * k), cq = idx - jj * s * k, c = cq / k, qq = cq - c * k;
-    double acc = 0.0;
-    for (int a_ = 0; a_ < s; ++a_) acc = fma(Ts[a_ * s + c], Y1[jj * s * k + a_ * k + qq], acc);
-    VW[idx] = acc;
+    VW[idx] = so_dot4(Ts + c, s, Y1 + jj * s * k + qq, k, s);
   }
   __syncthreads();
   double* Gyu = wk + lay.gyu;
@@ -432,9 +438,7 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
   __syncthreads();
   for (int idx = tid; idx < n * s * k; idx += NT) {
     const int i = idx / (s * k), cq = idx - i * s * k;
-    double acc = 0.0;
-    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], X0[(size_t)r * s * k + cq], acc);
-    Gyu[idx] = -acc;
+    Gyu[idx] = -so_dot4(Mi + i * ldm, 1, X0 + cq, s * k, n);
   }
   __syncthreads();
   // ---- 10. g_uu = -M^-1 [H (Zu (x) Zu) + C g_yy (R (x) R)] ---------------------------------------------------------------
@@ -461,9 +465,7 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
   __syncthreads();
   for (int idx = tid; idx < n * k * k; idx += NT) {
     const int i = idx / (k * k), pq = idx - i * k * k;
-    double acc = 0.0;
-    for (int r = 0; r < n; ++r) acc = fma(Mi[i * ldm + r], X0[(size_t)r * k * k + pq], acc);
-    Guu[idx] = -acc;
+    Guu[idx] = -so_dot4(Mi + i * ldm, 1, X0 + pq, k * k, n);
   }
   __syncthreads();
   // ---- 11. g_ss = -(M + C)^-1 [C g_uu + H (Zu' (x) Zu')] vec(Sigma),  Zu' = [0; 0; R; 0],  Sigma = diag(q) ------------------
@@ -682,9 +684,7 @@ __global__ __launch_bounds__(SO_SETUP_THREADS) void so_setup_kernel(SoSetupArgs 
   for (int idx = tid; idx < s * k * (u + q_); idx += NT) {
     const int row = idx / (u + q_), col = idx - row * (u + q_), a_ = row / k, j = row - a_ * k;
     const int mcol = col < u ? u + col : 2 * u + (col - u);
-    double acc = 0.0;
-    for (int b = 0; b < s; ++b) acc = fma(Lt[(size_t)(k + b * k + j) * MP + mcol], Pf[b * s + a_], acc);
-    Yt[(size_t)(k + row) * MP + mcol] = qv[j] * acc;
+    Yt[(size_t)(k + row) * MP + mcol] = qv[j] * so_dot4(Lt + (size_t)(k + j) * MP + mcol, k * MP, Pf + a_, s, s);
   }
   {
     const int r0 = k + s * k;
