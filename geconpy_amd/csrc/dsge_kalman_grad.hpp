@@ -36,6 +36,23 @@
 
 namespace dsge {
 
+// sum_k a[k sa] b[k sb] on four accumulators, the loads of a trip requested together: a loop bounded by the run-time u is not
+// unrolled, and with one accumulator every term waited for its own pair of LDS loads.
+__device__ __forceinline__ double kg_dot4(const double* a, int sa, const double* b, int sb, int K) {
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    const double a0 = a[k * sa], a1 = a[(k + 1) * sa], a2 = a[(k + 2) * sa], a3 = a[(k + 3) * sa];
+    const double b0 = b[k * sb], b1 = b[(k + 1) * sb], b2 = b[(k + 2) * sb], b3 = b[(k + 3) * sb];
+    c0 = fma(a0, b0, c0);
+    c1 = fma(a1, b1, c1);
+    c2 = fma(a2, b2, c2);
+    c3 = fma(a3, b3, c3);
+  }
+  for (; k < K; ++k) c0 = fma(a[k * sa], b[k * sb], c0);
+  return (c0 + c1) + (c2 + c3);
+}
+
 template <int BS>
 struct KgSmem {
   static constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD, PS = 9;
@@ -463,9 +480,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       n_ll += (lam != 0.0);
       // predict: a = T a+
       if (lane < u) {
-        double sa = 0.0;
-        for (int k2 = 0; k2 < u; ++k2) sa = fma(Tc[lane * LDM + k2], ap[k2], sa);
-        t1[lane] = sa;
+        t1[lane] = kg_dot4(Tc + lane * LDM, 1, ap, 1, u);
       }
       if (!light) {  // P = sym(T P+ T') + G, with the steady-state test against the outgoing P_t
         kg_mm<BS, true>(X2, X1, Tc, u, 1.0, false, lr, lc);  // P+ T'
@@ -789,9 +804,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         wave_sync();
         for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
           const int i = idx >> 3, o = idx & 7;
-          double sy = 0.0;
-          for (int j = 0; j < u; ++j) sy = fma(Ps[i * LDM + j], Kp[j * PS + o], sy);
-          Yp[i * PS + o] = sy;
+          Yp[i * PS + o] = kg_dot4(Ps + i * LDM, 1, Kp + o, PS, u);
         }
         wave_sync();
 #pragma unroll
