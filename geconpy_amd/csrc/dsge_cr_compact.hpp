@@ -91,7 +91,9 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
     // (cycle_reduction.py:150-160) keeps 1e-10, and the worst A1 of a draw may come as late as the third or fourth iteration
     // (round 2 only looked at the first two: fuzz seed 23 found draws with a pivot ratio of 2.5e6 / 9e5 in iteration 2, 4..7e-9
     // off in T; with the step they are at 6e-12 / 1e-10, tools/cr_refine_model.py).  One or two draws in a hundred take the
-    // branch in some iteration; the others are untouched (bit-identical).
+    // branch in some iteration; the others are untouched (bit-identical).  The residual is formed in twice the working
+    // precision (mm_residual_dot2): the corrected X is then better than the reference's own LU on the systems where float64
+    // algorithms cannot agree to 1e-9 (cond(A1) ~ 1e6: tools/cr_accuracy_study.py, tests/golden/cr_ill_conditioned_54.npz).
     if (__builtin_amdgcn_readfirstlane((int)(inv_hi > cr_refine_ratio<BS>() * inv_lo))) {
       gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);  // X in natural row order (syncs inside)
       double xh[BS][BS], rr[BS][BS];
@@ -102,13 +104,8 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
         for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
       }
       wave_sync();
-      blk_zero<BS>(rr);
-      mm_acc<BS, false>(rr, W, LDW, G1, LDW, n, lr, lc);  // A1 X
+      mm_residual_dot2<BS>(rr, Rb, W, LDW, G1, LDW, n, lr, lc);  // R - A1 X, inner products in twice the working precision
       wave_sync();
-#pragma unroll
-      for (int i = 0; i < BS; ++i)
-#pragma unroll
-        for (int j = 0; j < BS; ++j) rr[i][j] = Rb[i][j] - rr[i][j];
       blk_store_lds<BS>(rr, G1, LDW, lr, lc);
       gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);  // [A1 | R - A1 X] -> the correction (syncs on entry and exit)
       gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);

@@ -306,13 +306,8 @@ __device__ __forceinline__ bool crw_solve(double* smem, const double* __restrict
           for (int i = 0; i < BS; ++i) W[(tr * BS + i) * LDW + tc * BS + i] = A1[i][i] + 1e-16;
         }
         __syncthreads();
-        blk_zero<BS>(rr);
-        mm_acc<BS, false>(rr, W, LDW, G1, LDW, n, tr, tc);  // A1 X
+        mm_residual_dot2<BS>(rr, Rb, W, LDW, G1, LDW, n, tr, tc);  // R - A1 X, inner products in twice the working precision
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < BS; ++i)
-#pragma unroll
-          for (int j = 0; j < BS; ++j) rr[i][j] = Rb[i][j] - rr[i][j];
         blk_store_lds<BS>(rr, G1, LDW, tr, tc);
         gauss_jordan_wide(W, n, Lbuf, Ybuf, prow, tid);  // [A1 | R - A1 X] -> the correction
         gj_unpermute_wide(W, n, prow, tid);

@@ -219,6 +219,52 @@ __device__ __forceinline__ void mm_acc(double (&acc)[BS][BS], const double* A, i
 #undef MM_FMA
 }
 
+// out = R - A(rows lr*BS.., :K) * B(:K, cols lc*BS..) with the inner products in twice the working precision (Dot2 of Ogita,
+// Rump & Oishi 2005: every product split exactly by an FMA, every addition by TwoSum, the error terms summed on the side): the
+// residual of the refinement step of the cycle-reduction solves.  A residual formed in plain float64 limits one step of
+// iterative refinement to the accuracy of a backward-stable solver -- |dX| ~ cond(A1) eps |X|, what LAPACK's LU gives the
+// reference --; with this one the corrected X is good to working precision as long as cond(A1) eps << 1, i.e. BETTER than
+// the reference's on exactly the draws where two float64 algorithms cannot agree to 1e-9 anyway (tools/cr_accuracy_study.py:
+// a 54-variable system with cond(A1) = 2..5e6 and |C| = 3e5, reference 0.8..4.5e-8 from the 40-digit T).  Ten operations per
+// term instead of one FMA; only the refined iterations of the flagged draws run it (+0.04 ms on the 0.71 ms solver launch of
+// the bench: a refined iteration of the 32-wide tile is two eliminations + 19 k cycles of this).  Tried: a plain first step and
+// this one only when the first correction exceeds 1e-11 |X| (the level at which the error reaches 1e-9 in T) -- the refined
+// draws of the bench are above that level too and then pay a third elimination: slower.  Contraction is switched off: the
+// error-free transformations need p = fl(a b) and t = fl(s + p) as written.
+template <int BS>
+__device__ __forceinline__ void mm_residual_dot2(double (&out)[BS][BS], const double (&R)[BS][BS], const double* A, int lda,
+                                                 const double* B, int ldb, int K, int lr, int lc) {
+#pragma clang fp contract(off)
+  const double* ap = A + lr * BS * lda;
+  const double* bp = B + lc * BS;
+  double s[BS][BS], c[BS][BS];
+  blk_zero<BS>(s);
+  blk_zero<BS>(c);
+  for (int k = 0; k < K; ++k) {
+    double a[BS], b[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) a[i] = ap[i * lda + k];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) b[j] = bp[k * ldb + j];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const double p = a[i] * b[j];
+        const double e = __builtin_fma(a[i], b[j], -p);  // a b = p + e exactly
+        const double t = s[i][j] + p;
+        const double z = t - s[i][j];
+        const double err = (s[i][j] - (t - z)) + (p - z);  // s + p = t + err exactly
+        s[i][j] = t;
+        c[i][j] += e + err;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) out[i][j] = (R[i][j] - s[i][j]) - c[i][j];
+}
+
 // acc += A(:, rows lr*BS..)^T * B(:, cols lc*BS..)   i.e. (A' B) with A, B row-major in LDS: both operands are read
 // along rows (conflict-free with the odd leading dimension), no transposed copy of A needed.
 template <int BS>

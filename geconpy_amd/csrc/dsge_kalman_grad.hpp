@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     double* st = store + (size_t)draw * ((size_t)T_len * STEP + (size_t)NP * NP);
     // ---- the measurement update, split in its data-independent and data-dependent halves --------------
     // update_cov: from Ps and the mask weights ww -> Mp, Fs, Fi, Kp, X1 = P+; returns ln det F.
-    auto update_cov = [&]() -> double {
+    auto update_cov = [&](double* rec) -> double {
       for (int idx = lane; idx < u * 8; idx += 64) {
         const int i = idx >> 3, o = idx & 7;
         Mp[i * PS + o] = (o < p) ? ww[o] * zv[o] * Ps[i * LDM + zpos[o]] : 0.0;
@@ -328,12 +328,45 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         Kp[i * PS + o] = (o < p) ? sk : 0.0;
       }
       wave_sync();
-      // P+ = P - K (M + jit K)' + jit I
-      for (int idx = lane; idx < u * u; idx += 64) {
-        const int i = idx / u, j = idx - i * u;
-        double sp2 = Ps[i * LDM + j];
-        for (int o = 0; o < 8; ++o) sp2 = fma(-Kp[i * PS + o], fma(jitter, Kp[j * PS + o], Mp[j * PS + o]), sp2);
-        X1[i * LDM + j] = sp2 + ((i == j) ? jitter : 0.0);
+      // P+ = P - K (M + jit K)' + jit I on this lane's BS x BS block (rows of K, rows of M + jit K in registers: a rank-8
+      // update of nine entries; the entry-per-lane loop it replaces -- kept for the tiles whose register blocks leave no
+      // room for 32 BS more registers -- ran six trips of 24 dependent LDS reads and an integer division each).  The block
+      // goes to X1 for the prediction products and -- `rec` = the step's record -- straight from the registers to HBM in
+      // lane-major order (entry (i, j) of lane l at rec[(i BS + j) 64 + l]: BS^2 coalesced stores, no staging pass through
+      // LDS); the reverse sweep reads it back in the same order.
+      if constexpr (BS <= 4) {
+        double kr[BS][8], mk[BS][8];
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int o = 0; o < 8; ++o) {
+            kr[i][o] = Kp[(lr * BS + i) * PS + o];
+            mk[i][o] = fma(jitter, Kp[(lc * BS + i) * PS + o], Mp[(lc * BS + i) * PS + o]);
+          }
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const int r = lr * BS + i, c = lc * BS + j;
+            double sp2 = Ps[r * LDM + c];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) sp2 = fma(-kr[i][o], mk[j][o], sp2);
+            sp2 += (r == c && r < u) ? jitter : 0.0;
+            X1[r * LDM + c] = sp2;
+            rec[(i * BS + j) * 64 + lane] = sp2;
+          }
+      } else {
+        for (int idx = lane; idx < u * u; idx += 64) {
+          const int i = idx / u, j = idx - i * u;
+          double sp2 = Ps[i * LDM + j];
+          for (int o = 0; o < 8; ++o) sp2 = fma(-Kp[i * PS + o], fma(jitter, Kp[j * PS + o], Mp[j * PS + o]), sp2);
+          X1[i * LDM + j] = sp2 + ((i == j) ? jitter : 0.0);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) rec[(i * BS + j) * 64 + lane] = X1[(lr * BS + i) * LDM + lc * BS + j];
       }
       wave_sync();
       return log(det_m) + (double)det_e * 0.6931471805599453;
@@ -468,8 +501,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           double* p0s = st + (size_t)T_len * STEP;
           for (int idx = lane; idx < NP * NP; idx += 64) p0s[idx] = Ps[(idx / NP) * LDM + (idx % NP)];
         }
-        seg_logdet = update_cov();
-        for (int idx = lane; idx < NP * NP; idx += 64) sg[idx] = X1[(idx / NP) * LDM + (idx % NP)];  // P+
+        seg_logdet = update_cov(sg);  // (stores P+ into the record)
         for (int idx = lane; idx < NP * 8; idx += 64) sg[OFF_K + idx] = Kp[(idx >> 3) * PS + (idx & 7)];
         sg[OFF_FI + lane] = Fi[lane];
         sg[OFF_F + lane] = Fs[lane];
@@ -584,10 +616,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         wave_sync();
         if (pf_src == src_t) {
 #pragma unroll
-          for (int k2 = 0; k2 < NPF; ++k2) {
-            const int idx = lane + 64 * k2;
-            if (idx < NP * NP) X1[(idx / NP) * LDM + (idx % NP)] = pf_p[k2];
-          }
+          for (int k2 = 0; k2 < NPF; ++k2)  // (lane-major record: entry (k2 / BS, k2 % BS) of this lane's block)
+            X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = pf_p[k2];
 #pragma unroll
           for (int k2 = 0; k2 < NKF; ++k2) {
             const int idx = lane + 64 * k2;
@@ -596,7 +626,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           Fi[lane] = pf_fi;
           Fs[lane] = pf_f;
         } else {
-          for (int idx = lane; idx < NP * NP; idx += 64) X1[(idx / NP) * LDM + (idx % NP)] = sp_[idx];
+#pragma unroll
+          for (int k2 = 0; k2 < NPF; ++k2) X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = sp_[lane + 64 * k2];
           for (int idx = lane; idx < NP * 8; idx += 64) Kp[(idx >> 3) * PS + (idx & 7)] = sp_[OFF_K + idx];
           Fi[lane] = sp_[OFF_FI + lane];
           Fs[lane] = sp_[OFF_F + lane];
@@ -827,8 +858,18 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         {  // Fbar = -1/2 (nlam F^-1 - sum_t lam_t fiv_t fiv_t') - K' Y - K' Mbar      (lane = fo*8 + fq)
           double sf = 0.0;
           if (fo < p && fq < p) {
-            sf = -0.5 * (nlam * Fi[lane] - Qacc);
-            for (int i = 0; i < u; ++i) sf = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], sf);
+            // (over all NP rows with a compile-time bound: rows >= u of K are zero, of Y and Mbar zero or stale but finite;
+            // four accumulators, the 72 LDS reads requested together -- the loop over u waited for three reads per term)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            constexpr int FB_UNROLL = BS <= 4 ? NP / 4 : 2;
+#pragma unroll FB_UNROLL
+            for (int i = 0; i < NP; i += 4) {
+              s0 = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], s0);
+              s1 = fma(-Kp[(i + 1) * PS + fo], Yp[(i + 1) * PS + fq] + Mb[(i + 1) * PS + fq], s1);
+              s2 = fma(-Kp[(i + 2) * PS + fo], Yp[(i + 2) * PS + fq] + Mb[(i + 2) * PS + fq], s2);
+              s3 = fma(-Kp[(i + 3) * PS + fo], Yp[(i + 3) * PS + fq] + Mb[(i + 3) * PS + fq], s3);
+            }
+            sf = -0.5 * (nlam * Fi[lane] - Qacc) + ((s0 + s1) + (s2 + s3));
           }
           Fb[lane] = sf;
         }
@@ -844,9 +885,17 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           if (o < p) Ps[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], Ps[i * LDM + zpos[o]]);
         }
         wave_sync();
-        for (int idx = lane; idx < u * u; idx += 64) {
-          const int i = idx / u, j = idx - i * u;
-          Pb[i * LDM + j] = 0.5 * (Ps[i * LDM + j] + Ps[j * LDM + i]);
+        {  // (register blocks: the entry-per-lane loop divided by u and read two dependent entries per trip)
+          double a[BS][BS], b[BS][BS];
+          blk_load_lds<BS>(a, Ps, LDM, lr, lc);
+          blk_load_lds_t<BS>(b, Ps, LDM, lr, lc);
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+              const int r = lr * BS + i, c = lc * BS + j;
+              if (r < u && c < u) Pb[r * LDM + c] = 0.5 * (a[i][j] + b[i][j]);
+            }
         }
       }
       wave_sync();

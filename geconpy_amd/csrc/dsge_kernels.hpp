@@ -85,18 +85,9 @@ __global__ __launch_bounds__(64) void cr_kernel(const double* __restrict__ A, co
           for (int i = 0; i < BS; ++i) W[(lr * BS + i) * LDW + lc * BS + i] = A1[i][i] + 1e-16;
         }
         wave_sync();
-        blk_zero<BS>(r0);
-        blk_zero<BS>(r2);
-        mm_acc<BS, false>(r0, W, LDW, W + NP, LDW, n, lr, lc);      // A1 X0
-        mm_acc<BS, false>(r2, W, LDW, W + 2 * NP, LDW, n, lr, lc);  // A1 X2
+        mm_residual_dot2<BS>(r0, A0, W, LDW, W + NP, LDW, n, lr, lc);      // A0 - A1 X0
+        mm_residual_dot2<BS>(r2, A2, W, LDW, W + 2 * NP, LDW, n, lr, lc);  // A2 - A1 X2
         wave_sync();
-#pragma unroll
-        for (int i = 0; i < BS; ++i)
-#pragma unroll
-          for (int j = 0; j < BS; ++j) {
-            r0[i][j] = A0[i][j] - r0[i][j];
-            r2[i][j] = A2[i][j] - r2[i][j];
-          }
         blk_store_lds<BS>(r0, W + NP, LDW, lr, lc);
         blk_store_lds<BS>(r2, W + 2 * NP, LDW, lr, lc);
         gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);

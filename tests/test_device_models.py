@@ -182,3 +182,43 @@ def test_gensys_model_real_double_shift_stage():
         assert ok and np.abs(T1 - Tref).max() <= 1e-10
         steps, sweeps = i1["real_steps"]
         assert steps > 0 and i1["rot_qz"] < 0.05 * i0["rot_qz"], (steps, i1["rot_qz"], i0["rot_qz"])
+
+
+def test_refinement_with_an_extended_residual_on_the_ill_conditioned_fixture():
+    """tests/golden/cr_ill_conditioned_54.npz: the stored oracle T is what the oracle computes, it is ~2e-8 from the stored
+    40-digit T, and cycle reduction whose solves take ONE step of iterative refinement with the residual in extended
+    precision (numpy longdouble standing in for the device's Dot2 residual, mm_residual_dot2 in dsge_device.hpp) ends several
+    times closer to the exact T -- while a float64 residual, one step or two, stays at the reference's level."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cr_ill_conditioned_54.npz"))
+    A, B, C, Tx, tol = g["A"], g["B"], g["C"], g["T_exact"], float(g["tol"])
+    Tc, conv, itc = oracle.cycle_reduction_core(A, B, C, 200, tol)
+    assert conv and np.abs(Tc - g["T_oracle"]).max() <= 1e-12
+    e_ref = np.abs(Tc - Tx).max()
+    assert 5e-9 < e_ref < 1e-7
+    n = A.shape[0]
+
+    def cr(extended):
+        A0, A1, A2, Ah = A.copy(), B.copy(), C.copy(), B.copy()
+        for it in range(50):
+            R = np.hstack([A0, A2])
+            X = np.linalg.solve(A1, R)
+            if extended:
+                r = (R.astype(np.longdouble) - A1.astype(np.longdouble) @ X.astype(np.longdouble)).astype(np.float64)
+            else:
+                r = R - A1 @ X
+            X = X + np.linalg.solve(A1, r)
+            X0, X2 = X[:, :n], X[:, n:]
+            m00, m02, m20, m22 = A0 @ X0, A0 @ X2, A2 @ X0, A2 @ X2
+            A1, Ah, A0, A2 = A1 - m02 - m20, Ah - m20, -m00, -m22
+            if np.abs(A0).sum(0).max() < tol and np.abs(A2).sum(0).max() < tol:
+                break
+        return -np.linalg.solve(Ah, A), it + 1
+
+    T_ext, it_ext = cr(True)
+    T_f64, it_f64 = cr(False)
+    assert it_ext == itc and it_f64 == itc
+    if np.finfo(np.longdouble).eps < 1e-18:  # (platforms whose longdouble is float64 have nothing to show here)
+        assert np.abs(T_ext - Tx).max() <= 0.3 * e_ref
+    assert np.abs(T_f64 - Tx).max() >= 0.3 * e_ref

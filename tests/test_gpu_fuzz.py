@@ -28,6 +28,15 @@ def test_gradient_fuzz(seed):
     assert fuzz_grad.run(seed, 40, verbose=False, rtol=1e-6) == 0
 
 
+@pytest.mark.parametrize("seed", [17, 18])
+def test_gradient_fuzz_full_covariance_and_dense_design(seed):
+    """The same with the shock covariance (diagonal / full symmetric: Q_bar) and the design matrix (selector / dense
+    observation equations through the state augmentation: Z_bar) drawn at random per trial (statespace.py:247-251, 298-332)."""
+    import fuzz_grad
+
+    assert fuzz_grad.run(seed, 40, verbose=False, rtol=1e-6, modes=True) == 0
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_cycle_reduction_fuzz(seed):
     """Cycle reduction alone, 3..64 variables, three tolerances, default kernels / one wavefront for 49..64 / dense kernel:

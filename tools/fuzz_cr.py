@@ -64,6 +64,13 @@ def run(seed, trials, verbose=True):
                     if verbose:
                         print("MISMATCH", opts, dict(n=n, ns=ns, nl=nl, tol=tol, draw=i), st[i], it[i], itc,
                               np.abs(T[i] - Tc).max() if conv else None)
+                        if i in exact:
+                            Tx, itx = exact[i]
+                            print("   against 40-digit arithmetic: iterations", itx, f"|T_dev - T_exact| = {np.abs(T[i] - Tx).max():.2e},",
+                                  f"|T_oracle - T_exact| = {np.abs(Tc - Tx).max():.2e}, max|T| = {np.abs(Tx).max():.2e},",
+                                  f"cond(B + C T) = {np.linalg.cond(B[i] + C[i] @ Tx):.2e}")
+                            if os.environ.get("FUZZ_CR_DUMP"):
+                                np.savez(os.environ["FUZZ_CR_DUMP"], A=A[i], B=B[i], C=C[i], tol=tol, T_dev=T[i], T_oracle=Tc, T_exact=Tx)
     if verbose:
         print("trials done, mismatches:", bad)
     return bad

@@ -1,4 +1,5 @@
-"""GPU box: randomized configurations of the logp gradient against central differences of the oracle."""
+"""GPU box: randomized configurations of the logp gradient against central differences of the oracle.  `modes=True` also draws
+the shock covariance (diagonal / full symmetric, `Q_bar`) and the design matrix (selector / dense with `Z_bar`) at random."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,11 +7,13 @@ from geconpy_amd import batched, workloads as wl
 import oracle
 
 
-def run(seed, trials, verbose=True, rtol=5e-5):
+def run(seed, trials, verbose=True, rtol=5e-5, modes=False):
     rng = np.random.default_rng(seed)
     bad = 0
     for trial in range(trials):
-        n = int(rng.integers(6, 57))
+        full_q = bool(modes and rng.integers(2))
+        dense = bool(modes and rng.integers(3) > 0)
+        n = int(rng.integers(6, 57 - (8 if dense else 0)))  # the dense route carries p <= 8 extra variables
         ns = int(rng.integers(1, max(2, n // 2)))
         nl = int(rng.integers(1, max(2, n // 3)))
         k = int(rng.integers(1, min(n, 10) + 1))
@@ -24,14 +27,20 @@ def run(seed, trials, verbose=True, rtol=5e-5):
         A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
         q = rng.uniform(0.5, 2.0, (nb, k)) * 1e-4
         Z = np.zeros((p, n)); Z[np.arange(p), rng.choice(n, p, replace=False)] = rng.uniform(0.5, 1.5, p)
+        if dense:  # observation equations: every observable loads on a few more variables
+            Z += (rng.random((p, n)) < 0.2) * rng.normal(0, 0.5, (p, n))
+        if full_q:
+            Lq = rng.normal(0, 1, (nb, k, k)) * 0.3 + np.eye(k)
+            Qf = 1e-4 * Lq @ Lq.transpose(0, 2, 1)
         y = rng.normal(0, 0.02, (T_len, p))
         if T_len > 2: y[1, 0] = np.nan
         H = rng.uniform(0.5, 2.0, p) * 1e-4
         d = rng.normal(0, 0.01, p)
-        out = batched.solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=d, Hdiag=H, tol=1e-13, max_iter=300)
+        out = batched.solve_kalman_logp_grad_batched(A, B, C, D, None if full_q else q, Z, y, d=d, Hdiag=H, tol=1e-13, max_iter=300,
+                                                     Q=Qf if full_q else None, dense_z=dense, return_Z_bar=dense)
         i = int(rng.integers(nb))
         if out["status"][i] != 0:
-            if verbose: print("status", out["status"][i], dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len))
+            if verbose: print("status", out["status"][i], dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len, full_q=full_q, dense=dense))
             continue
         maskA = (A[i] != 0).any(axis=0)[None, :] * np.ones_like(A[i])
         dA = rng.standard_normal(A[i].shape) * maskA * 0.1
@@ -41,10 +50,21 @@ def run(seed, trials, verbose=True, rtol=5e-5):
         dh = rng.standard_normal(p) * H * 0.3
         g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
         analytic = ((g["A_bar"] * dA).sum() + (g["B_bar"] * dB).sum() + (g["C_bar"] * dC).sum() + (g["D_bar"] * dD).sum()
-                    + (g["q_bar"] * dq).sum() + (g["d_bar"] * dd).sum() + (g["h_bar"] * dh).sum())
+                    + (g["d_bar"] * dd).sum() + (g["h_bar"] * dh).sum())
+        if full_q:
+            dQ = rng.standard_normal((k, k)) * 0.3
+            dQ = 1e-4 * (dQ + dQ.T)
+            analytic += (g["Q_bar"] * dQ).sum()
+        else:
+            analytic += (g["q_bar"] * dq).sum()
+        dZ = np.zeros_like(Z)
+        if dense:
+            dZ = rng.standard_normal(Z.shape) * 0.1
+            analytic += (g["Z_bar"] * dZ).sum()
 
         def f(e):
-            return oracle.solve_kalman_logp(A[i] + e * dA, B[i] + e * dB, C[i] + e * dC, D[i] + e * dD, np.diag(q[i] + e * dq), Z, y,
+            Qe = Qf[i] + e * dQ if full_q else np.diag(q[i] + e * dq)
+            return oracle.solve_kalman_logp(A[i] + e * dA, B[i] + e * dB, C[i] + e * dC, D[i] + e * dD, Qe, Z + e * dZ, y,
                                             H=np.diag(H + e * dh), d=d + e * dd, tol=1e-14, max_iter=300)["logp"]
 
         # a draw can sit so close to the edge of the determinacy region that the oracle has no solution at +-1e-5 along the
@@ -59,15 +79,16 @@ def run(seed, trials, verbose=True, rtol=5e-5):
             if verbose: print("no finite difference available", dict(n=n, k=k, p=p, T_len=T_len))
             continue
         if verbose:
-            print("rel", f"{abs(analytic - fd) / max(abs(fd), 1.0):.2e}", "fd-noise", f"{abs(d1 - d2) / max(abs(fd), 1.0):.2e}", dict(n=n, k=k, p=p, T_len=T_len))
+            print("rel", f"{abs(analytic - fd) / max(abs(fd), 1.0):.2e}", "fd-noise", f"{abs(d1 - d2) / max(abs(fd), 1.0):.2e}", dict(n=n, k=k, p=p, T_len=T_len, full_q=full_q, dense=dense))
         if not abs(analytic - fd) <= rtol * max(abs(fd), 1.0) + 20 * abs(d1 - d2):
             bad += 1
             if verbose:
-                print("MISMATCH", dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len, nb=nb, draw=i), analytic, fd, abs(d1 - d2))
+                print("MISMATCH", dict(n=n, ns=ns, nl=nl, k=k, p=p, T_len=T_len, nb=nb, draw=i, full_q=full_q, dense=dense), analytic, fd, abs(d1 - d2))
     if verbose:
         print("trials done, mismatches:", bad)
     return bad
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40,
+        modes=len(sys.argv) > 3 and sys.argv[3] == "modes")

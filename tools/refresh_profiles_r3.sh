@@ -6,8 +6,6 @@ TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python3 bench.py --workload sw_second_order > "$OUT/bench_sw_second_order.json" 2> "$OUT/bench_sw_second_order.err"
 python3 bench.py --solver gensys --cpu-sample 0 > "$OUT/bench_gensys.json" 2>/dev/null
 python3 bench.py --from-theta --cpu-sample 0 > "$OUT/bench_sw_from_theta.json" 2>/dev/null
 python3 bench.py --workload rbc --cpu-sample 0 > "$OUT/bench_rbc.json" 2>/dev/null
@@ -24,10 +22,18 @@ python3 tools/pmc_collect.py "$OUT/pmc_default" -- --no-extras > "$OUT/pmc_defau
 python3 tools/pmc_collect.py "$OUT/pmc_gensys" -- --solver gensys > "$OUT/pmc_gensys.txt" 2>&1 && cp "$OUT/pmc_gensys/pmc_counters.json" "$OUT/pmc_counters_gensys.json"
 python3 tools/pmc_collect.py "$OUT/pmc_so" -- --workload sw_second_order --no-extras > "$OUT/pmc_so.txt" 2>&1 && cp "$OUT/pmc_so/pmc_counters.json" "$OUT/pmc_counters_sw_second_order.json"
 rm -rf "$OUT/pmc_default" "$OUT/pmc_gensys" "$OUT/pmc_so"
+# the f4 line quotes traffic / matrix-core busy from the counters committed under profiles/: take it after they are refreshed
+cp "$OUT/pmc_counters_sw_second_order.json" profiles/r3/ 2>/dev/null; cp "$OUT/pmc_counters.json" profiles/r3/ 2>/dev/null
+python3 bench.py --workload sw_second_order > "$OUT/bench_sw_second_order.json" 2> "$OUT/bench_sw_second_order.err"
+python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 tools/op_latency.py > "$OUT/op_latency.txt" 2>&1
 python3 tools/so_rate.py 1024 > "$OUT/so_steady_tol_sweep.txt" 2>&1
 python3 tools/wide_rate.py > "$OUT/wide_rate.txt" 2>&1
 python3 tools/grad_rate.py > "$OUT/grad_rate.txt" 2>&1
+rm -rf "$OUT/kt_grad"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_grad" -o kt -- python3 tools/grad_rate.py > /dev/null 2>&1
+find "$OUT/kt_grad" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_gradient.csv" \;
+rm -rf "$OUT/kt_grad"
 python3 tools/kalman_phases.py > "$OUT/kalman_phases.txt" 2>&1
 python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
 python3 tools/so_order_potential.py > "$OUT/so_order_potential.txt" 2>&1
