@@ -14,6 +14,23 @@ from ._lib import DsgeHipError  # noqa: F401
 
 JITTER_DEFAULT = 1e-8  # float64 cov_jitter default (gEconpy/model/statespace.py:22,1144)
 MISSING_FILL = -9999.0  # default missing_fill_value (gEconpy/model/statespace.py:1143)
+FILTER_TYPES_UPSTREAM = ("standard", "univariate", "steady_state", "single", "cholesky")
+
+
+def check_filter_type(filter_type):
+    """``filter_type`` of ``statespace_from_gcn`` / ``DSGEStateSpace`` (gEconpy/model/build.py:577, 608-609; statespace.py:69, 187:
+    handed to PyMCStateSpace).  The device computes the log-likelihood of the "standard" filter -- the default, and the only one
+    the oracle restates.  The other variants are different algorithms with their own jitter and missing-data conventions
+    (univariate: observation-at-a-time updates; steady_state: a constant gain from the first step; single / cholesky: other
+    factorisations of F); silently running the standard recursion under their name would return a number that differs from the
+    reference's, so anything but "standard" raises."""
+    if filter_type == "standard":
+        return
+    if filter_type in FILTER_TYPES_UPSTREAM:
+        raise NotImplementedError(
+            f"filter_type={filter_type!r}: only the 'standard' Kalman filter is built on the device "
+            "(DESIGN.md section 7); evaluate this model with the reference's CPU filter")
+    raise ValueError(f"unknown filter_type {filter_type!r}; upstream knows {FILTER_TYPES_UPSTREAM}")
 
 
 def _f64(x, ndim=None):
@@ -353,9 +370,10 @@ def get_kalman_steady_tol():
 
 def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None,
                         jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
-                        z_selector_hint=None, options=None):
+                        z_selector_hint=None, options=None, filter_type="standard"):
     """Per-draw Kalman log-likelihood (the filter DSGEStateSpace hands to PyMC,
-    gEconpy/model/statespace.py:1151-1157) -> (logp, status)."""
+    gEconpy/model/statespace.py:1151-1157) -> (logp, status).  ``filter_type``: see ``check_filter_type``."""
+    check_filter_type(filter_type)
     T, R = _f64(T, 3), _f64(R, 3)
     y = _f64(y, 2)
     nb, m, _ = T.shape
@@ -408,14 +426,16 @@ def kalman_filter_outputs_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None
 def solve_kalman_logp_batched(A, B, C, D, Q, Z, y, d=None, Hdiag=None, q_mode=None, solver="cycle_reduction",
                               tol=1e-6, max_iter=50, jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL,
                               return_policy=False, n_state_hint=None, z_selector_hint=None, n_lead_hint=None,
-                              options=None, add_solver_success_check=True):
+                              options=None, add_solver_success_check=True, filter_type="standard"):
     """One fused evaluation per draw: A,B,C,D -> T,R -> P0 -> logp.  ``tol``/``max_iter``
     default to what ``DSGEStateSpace.configure`` passes (statespace.py:835-836).
+    ``filter_type`` (build.py:577): only "standard" is built, the others raise (``check_filter_type``).
     ``add_solver_success_check=False`` (the reference's default, statespace.py:1148): a draw whose cycle reduction fails carries
     ``T = 0`` on and gets the finite log-likelihood of that system (``DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE``); the default here
     is the safe one, ``-inf``.
     ``options``: per-call kernel-variant switches (dict of ``dsge_options`` fields or ``_lib.Options``).
     Returns dict(logp, status[, T, R, resid, n_iter])."""
+    check_filter_type(filter_type)
     A, B, C = _check_abc(A, B, C)
     D = _f64(D, 3)
     y = _f64(y, 2)

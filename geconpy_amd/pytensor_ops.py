@@ -236,15 +236,17 @@ class HipSolveKalmanLogp(Op):
     (statespace.py:197-222, 725-820, 1151-1157) for all draws in one call; failed draws give -inf.
     """
 
-    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value")
+    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value", "filter_type")
 
     def __init__(self, solver="cycle_reduction", tol=1e-6, max_iter=50, jitter=batched.JITTER_DEFAULT,
-                 missing_fill_value=batched.MISSING_FILL):
+                 missing_fill_value=batched.MISSING_FILL, filter_type="standard"):
+        batched.check_filter_type(filter_type)  # (build.py:577: only the default filter is built; the others raise here)
         self.solver = solver
         self.tol = tol
         self.max_iter = int(max_iter)
         self.jitter = jitter
         self.missing_fill_value = missing_fill_value
+        self.filter_type = filter_type
         if _HAVE_PYTENSOR:
             super().__init__()
 

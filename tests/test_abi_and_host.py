@@ -86,6 +86,24 @@ def test_shape_checks_in_numpy_front_end():
     assert batched._q_mode(np.ones((2, 2)), 5, 2)[1] == _lib.Q_FULL_SHARED
 
 
+def test_filter_type_other_than_standard_is_refused_loudly():
+    """build.py:577 / statespace.py:69 hand ``filter_type`` to the Kalman filter: the device computes the "standard" one, and a
+    request for another variant must not silently get it (no GPU needed: the check runs before anything is staged)."""
+    from geconpy_amd import pytensor_ops
+
+    A = np.zeros((1, 3, 3))
+    for ft in ("univariate", "steady_state", "single", "cholesky"):
+        with pytest.raises(NotImplementedError):
+            batched.solve_kalman_logp_batched(A, A, A, np.zeros((1, 3, 1)), np.ones(1), np.zeros((1, 3)), np.zeros((4, 1)), filter_type=ft)
+        with pytest.raises(NotImplementedError):
+            batched.kalman_logp_batched(A, np.zeros((1, 3, 1)), np.ones(1), np.zeros((1, 3)), np.zeros((4, 1)), filter_type=ft)
+        with pytest.raises(NotImplementedError):
+            pytensor_ops.HipSolveKalmanLogp(filter_type=ft)
+    with pytest.raises(ValueError):
+        batched.check_filter_type("kalman")
+    assert pytensor_ops.HipSolveKalmanLogp().filter_type == "standard"
+
+
 def test_structure_hints():
     b = wl.sw_shaped_batch(3)
     om = wl.sw_shaped_observation_model()
