@@ -419,48 +419,33 @@ __device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb
         tb[(k + 1) * ldW + cw] = t1;
         tb[(k + 2) * ldW + cw] = t2;
       }
-      // row k+2 of T, columns k .. k+2: defines the 3-column reflector  [b0 b1 b2] Z1 = [0 0 *]
+      // Rows k+1 and k+2 of T, columns k .. k+2: ONE right reflector per step, as in LAPACK's dhgeqz -- its first column is
+      // the null vector of these two rows, i.e. their cross product, so that column k of T is zero below the diagonal; the
+      // entry (k+2, k+1) stays and is part of the next step's 3 x 3 block (the last step of the sweep clears the last one).
+      // (Round 3 first chased the bulge with two reflectors, 3 and 2 columns wide: one Householder generation, fifteen
+      // FP64 operations and one dependent readlane round more per step.)
+      const double a0 = readlane_dyn_f64(t1, k), a1 = readlane_dyn_f64(t1, k + 1), a2 = readlane_dyn_f64(t1, k + 2);
       const double b0 = readlane_dyn_f64(t2, k), b1 = readlane_dyn_f64(t2, k + 1), b2 = readlane_dyn_f64(t2, k + 2);
       wave_sync();
       // ---- right: columns k .. k+2; lane = row of H, of T and of M
       double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1], r2 = hb[cw * ldH + k + 2];
       double u0 = tb[cw * ldW + k], u1 = tb[cw * ldW + k + 1], u2 = tb[cw * ldW + k + 2];
       {
-        const GwHouse g1 = gw_house3(b2, b1, b0);  // reversed: v = [v2 v1 1] on columns k, k+1, k+2
-        const double sh = g1.tau * fma(g1.v2, r0, fma(g1.v1, r1, r2));
-        r0 = fma(-sh, g1.v2, r0);
+        const double w0 = fma(a1, b2, -(a2 * b1)), w1 = fma(a2, b0, -(a0 * b2)), w2 = fma(a0, b1, -(a1 * b0));
+        const GwHouse g1 = gw_house3(w0, w1, w2);  // v = [1 v1 v2] on columns k, k+1, k+2: (I - tau v v') e1 = w / beta
+        const double sh = g1.tau * fma(g1.v2, r2, fma(g1.v1, r1, r0));
+        r0 -= sh;
         r1 = fma(-sh, g1.v1, r1);
-        r2 -= sh;
-        const double st = g1.tau * fma(g1.v2, u0, fma(g1.v1, u1, u2));
-        u0 = fma(-st, g1.v2, u0);
+        r2 = fma(-sh, g1.v2, r2);
+        const double st = g1.tau * fma(g1.v2, u2, fma(g1.v1, u1, u0));
+        u0 -= st;
         u1 = fma(-st, g1.v1, u1);
-        u2 -= st;
-        const double sz = g1.tau * fma(g1.v2, m0, fma(g1.v1, m1, m2));
-        m0 = fma(-sz, g1.v2, m0);
+        u2 = fma(-st, g1.v2, u2);
+        const double sz = g1.tau * fma(g1.v2, m2, fma(g1.v1, m1, m0));
+        m0 -= sz;
         m1 = fma(-sz, g1.v1, m1);
-        m2 -= sz;
-        if (lane == k + 2) {
-          u0 = 0.0;
-          u1 = 0.0;
-          u2 = g1.beta;
-        }
-      }
-      {
-        const double c0 = readlane_dyn_f64(u0, k + 1), c1 = readlane_dyn_f64(u1, k + 1);  // T[k+1][k], T[k+1][k+1] after Z1
-        const GwHouse g2 = gw_house3(c1, c0, 0.0);  // v = [v1 1] on columns k, k+1
-        const double sh = g2.tau * fma(g2.v1, r0, r1);
-        r0 = fma(-sh, g2.v1, r0);
-        r1 -= sh;
-        const double st = g2.tau * fma(g2.v1, u0, u1);
-        u0 = fma(-st, g2.v1, u0);
-        u1 -= st;
-        const double sz = g2.tau * fma(g2.v1, m0, m1);
-        m0 = fma(-sz, g2.v1, m0);
-        m1 -= sz;
-        if (lane == k + 1) {
-          u0 = 0.0;
-          u1 = g2.beta;
-        }
+        m2 = fma(-sz, g1.v2, m2);
+        if (lane == k + 1 || lane == k + 2) u0 = 0.0;
       }
       if (wa) {
         hb[cw * ldH + k] = r0;

@@ -296,7 +296,7 @@ def real_double_shift_stage(P, ilo=0, max_it=30):
     i.e. an infinite root inside the active block; 30 sweeps without a deflation): the stage then simply stops.  Every
     transformation is an orthogonal equivalence that keeps the Hessenberg-triangular form, so whatever state it leaves is a
     valid input for the complex single-shift iteration (qz_iterate), which owns all the deflation logic of zhgeqz and only has
-    to split the remaining 2 x 2 blocks.  A real sweep step costs two 3-row reflectors in real arithmetic and advances two
+    to split the remaining 2 x 2 blocks.  A real sweep step costs two 3-wide reflectors in real arithmetic (rows, then columns) and advances two
     shifts; a complex single-shift step costs two complex rotations and advances one.
     Returns (number of sweep steps, number of sweeps)."""
     N = P.N
@@ -325,6 +325,14 @@ def real_double_shift_stage(P, ilo=0, max_it=30):
         for M, r1 in ((H, rmaxH), (T, rmaxT), (Z, Z.shape[0])):
             blk = M[:r1, k:k + ncol].real
             M[:r1, k:k + ncol] = blk - tau * np.outer(blk @ v, v)
+
+    def right_first(k, w, rmaxH, rmaxT):  # (I - tau v v') e1 = w / beta on columns k..k+2: column k of [.] Zr is [.] w / beta
+        v, tau = _house3(np.array(w, dtype=float))
+        if tau == 0.0:
+            return
+        for M, r1 in ((H, rmaxH), (T, rmaxT), (Z, Z.shape[0])):
+            blk = M[:r1, k:k + 3].real
+            M[:r1, k:k + 3] = blk - tau * np.outer(blk @ v, v)
 
     ilast = N - 1
     it = 0
@@ -375,11 +383,12 @@ def real_double_shift_stage(P, ilo=0, max_it=30):
             if k > ifirst:
                 H[k + 1, k - 1] = 0
                 H[k + 2, k - 1] = 0
-            right(k, 3, [T[k + 2, k].real, T[k + 2, k + 1].real, T[k + 2, k + 2].real], min(k + 4, ilast + 1), k + 3)
-            T[k + 2, k] = 0
-            T[k + 2, k + 1] = 0
-            right(k, 2, [T[k + 1, k].real, T[k + 1, k + 1].real], min(k + 4, ilast + 1), k + 2)
+            # ONE right reflector per step (LAPACK dhgeqz): its first column is the null vector of rows k+1, k+2 of the
+            # 3 x 3 block of T -- their cross product --, which clears column k below the diagonal; T[k+2, k+1] stays for
+            # the next step's block
+            right_first(k, np.cross(T[k + 1, k:k + 3].real, T[k + 2, k:k + 3].real), min(k + 4, ilast + 1), k + 3)
             T[k + 1, k] = 0
+            T[k + 2, k] = 0
             x, y = H[k + 1, k].real, H[k + 2, k].real
             if k < ilast - 2:
                 z = H[k + 3, k].real
