@@ -14,6 +14,8 @@ from geconpy_amd.engine import LogpEngine
 
 eng = LogpEngine(0)
 om = wl.sw_shaped_observation_model()
+SOLVER = sys.argv[1] if len(sys.argv) > 1 else "cycle_reduction"  # (or "gensys": five launches at 2..10 draws per CU each)
+print("solver", SOLVER)
 for NB in (4096, 8192):
     b = wl.sw_shaped_batch(NB)
     A, B, C, D = (eng.to_device(b[x]) for x in "ABCD")
@@ -27,7 +29,7 @@ for NB in (4096, 8192):
         st = torch.empty(NB, dtype=torch.int32, device="cuda")
 
         def call():
-            eng.solve_kalman_logp(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, n_state_hint=hints[0],
+            eng.solve_kalman_logp(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, solver=SOLVER, n_state_hint=hints[0],
                                   z_selector_hint=hints[1], logp=lp, status=st, options=opts)
 
         for _ in range(3):
