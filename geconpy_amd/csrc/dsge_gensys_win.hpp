@@ -902,6 +902,37 @@ __device__ __forceinline__ void jacobi_svd_rr(cx* G, int ldg, int nr, int nc, cx
   wave_sync();
 }
 
+// sum_{k = lo}^{hi-1} term(k) on FOUR accumulators, the operands of a trip requested together: the run-time-bounded inner
+// products of the tail kernels waited for their own pair of LDS loads in every term (one accumulator, no unrolling).
+template <class F>
+__device__ __forceinline__ cx gw_csum4(int lo, int hi, F term) {
+  cx s0 = mk(0, 0), s1 = s0, s2 = s0, s3 = s0;
+  int k = lo;
+  for (; k + 4 <= hi; k += 4) {
+    const cx t0 = term(k), t1 = term(k + 1), t2 = term(k + 2), t3 = term(k + 3);
+    s0 = s0 + t0;
+    s1 = s1 + t1;
+    s2 = s2 + t2;
+    s3 = s3 + t3;
+  }
+  for (; k < hi; ++k) s0 = s0 + term(k);
+  return (s0 + s1) + (s2 + s3);
+}
+template <class F>
+__device__ __forceinline__ double gw_sum4(int lo, int hi, F term) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = lo;
+  for (; k + 4 <= hi; k += 4) {
+    const double t0 = term(k), t1 = term(k + 1), t2 = term(k + 2), t3 = term(k + 3);
+    s0 += t0;
+    s1 += t1;
+    s2 += t2;
+    s3 += t3;
+  }
+  for (; k < hi; ++k) s0 += term(k);
+  return (s0 + s1) + (s2 + s3);
+}
+
 // ---- launch 3: existence / uniqueness (gensys.py:267-310): coincident zeros, SVD of Q2 Pi, the eu codes, Bm and Phi_b.
 // Needs only X2 (w x #lead), V2 and Bm on the chip (15 KB at N = 52 => 10 draws per CU): the Jacobi sweeps are a chain
 // of short dependent steps, so occupancy is what makes them cheap.
@@ -964,10 +995,8 @@ __global__ __launch_bounds__(64) void gensys_eu_kernel(int batch, GwCaps cp, dou
         // s1_j = || eta1 v_j ||, eta1 = [X1; X2[:ns2]] (CS decomposition argument of dsge_gensys.hpp)
         for (int j = 0; j < ell; ++j) {
           cx g = mk(0, 0), g0 = mk(0, 0);
-          if (lane < ns2)
-            for (int cc = 0; cc < ell; ++cc) g = g + PX(lane, cc) * V2[cc * ldx + j];
-          if (lane < z)
-            for (int cc = 0; cc < ell; ++cc) g0 = g0 + X1[(size_t)lane * cp.lcap + cc] * V2[cc * ldx + j];
+          if (lane < ns2) g = gw_csum4(0, ell, [&](int cc) { return PX(lane, cc) * V2[cc * ldx + j]; });
+          if (lane < z) g0 = gw_csum4(0, ell, [&](int cc) { return X1[(size_t)lane * cp.lcap + cc] * V2[cc * ldx + j]; });
           const double sq = wave_sum_dpp(fma(g.re, g.re, g.im * g.im) + fma(g0.re, g0.re, g0.im * g0.im));
           if (lane == 0) s1[j] = sqrt(sq);
         }
@@ -1002,9 +1031,7 @@ __global__ __launch_bounds__(64) void gensys_eu_kernel(int batch, GwCaps cp, dou
         cx* PHg = reinterpret_cast<cx*>(wd + wo.PHI);
         for (int idx = lane; idx < ns2 * nu; idx += 64) {
           const int i = idx / nu, u = idx - i * nu;
-          cx acc = mk(0, 0);
-          for (int cc = 0; cc < ell; ++cc) acc = acc + PX(i, cc) * Bm[cc * ldb + u];
-          PHg[(size_t)i * cp.wcap + u] = acc;
+          PHg[(size_t)i * cp.wcap + u] = gw_csum4(0, ell, [&](int cc) { return PX(i, cc) * Bm[cc * ldb + u]; });
         }
         have_T = 1;
       }
@@ -1138,17 +1165,14 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       // rhs = [B11, B12 - Phi_b B22] in place in T[:ns2, :]
       for (int idx = lane; idx < ns2 * nu; idx += 64) {
         const int i = idx / nu, cc = idx - i * nu;
-        cx acc = PT(i, ns2 + cc);
-        for (int u = 0; u <= cc; ++u) acc = acc - PH(ns2 + u, i) * PT(ns2 + u, ns2 + cc);
-        PT(i, ns2 + cc) = acc;
+        PT(i, ns2 + cc) = PT(i, ns2 + cc) - gw_csum4(0, cc + 1, [&](int u) { return PH(ns2 + u, i) * PT(ns2 + u, ns2 + cc); });
       }
       wave_sync();
       GW_STAMP(22);
       // Yb = A11w^-1 rhs by back-substitution, one column per lane
       if (lane < w) {
         for (int i = ns2 - 1; i >= 0; --i) {
-          cx acc = PT(i, lane);
-          for (int k2 = i + 1; k2 < ns2; ++k2) acc = acc - PH(i, k2) * PT(k2, lane);
+          const cx acc = PT(i, lane) - gw_csum4(i + 1, ns2, [&](int k2) { return PH(i, k2) * PT(k2, lane); });
           PT(i, lane) = cdiv(acc, PH(i, i));
         }
       }
@@ -1157,50 +1181,39 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       // Wb = Yb Ms^H (ns2 x s') into H[:ns2, :s'];  BB = B22 Ms2^H (nu x s') into H[ns2:, :s']
       for (int idx = lane; idx < ns2 * sp; idx += 64) {
         const int i = idx / sp, cc = idx - i * sp;
-        cx acc = mk(0, 0);
-        for (int k2 = 0; k2 < w; ++k2) acc = acc + PT(i, k2) * conj(PM(cc, k2));
-        PH(i, cc) = acc;
+        PH(i, cc) = gw_csum4(0, w, [&](int k2) { return PT(i, k2) * conj(PM(cc, k2)); });
       }
       for (int idx = lane; idx < nu * sp; idx += 64) {
         const int u = idx / sp, cc = idx - u * sp;
-        cx acc = mk(0, 0);
-        for (int v = u; v < nu; ++v) acc = acc + PT(ns2 + u, ns2 + v) * conj(PM(cc, ns2 + v));
-        PH(ns2 + u, cc) = acc;
+        PH(ns2 + u, cc) = gw_csum4(u, nu, [&](int v) { return PT(ns2 + u, ns2 + v) * conj(PM(cc, ns2 + v)); });
       }
       wave_sync();
       // RR = [Re(M[:, :ns2] Wb); Re(Bm BB)]  ((w + ell) x s', real)
       for (int idx = lane; idx < w * sp; idx += 64) {
         const int r = idx / sp, cc = idx - r * sp;
-        double acc = 0.0;
-        for (int i = 0; i < ns2; ++i) {
+        RR[r * lds_ + cc] = gw_sum4(0, ns2, [&](int i) {
           const cx a = PM(r, i), b = PH(i, cc);
-          acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
-        }
-        RR[r * lds_ + cc] = acc;
+          return fma(a.re, b.re, -(a.im * b.im));
+        });
       }
       for (int idx = lane; idx < ell * sp; idx += 64) {
         const int a0 = idx / sp, cc = idx - a0 * sp;
-        double acc = 0.0;
-        for (int u = 0; u < nu; ++u) {
+        RR[(w + a0) * lds_ + cc] = gw_sum4(0, nu, [&](int u) {
           const cx a = Bm[a0 * ldh + u], b = PH(ns2 + u, cc);
-          acc = fma(a.re, b.re, fma(-a.im, b.im, acc));
-        }
-        RR[(w + a0) * lds_ + cc] = acc;
+          return fma(a.re, b.re, -(a.im * b.im));
+        });
       }
       wave_sync();
       GW_STAMP(24);
       // non-state rows: E = T12[:, :s'] - [H12 | X1] RR, then R0^-1 E by back-substitution (one column per lane)
       for (int idx = lane; idx < z * sp; idx += 64) {
         const int p = idx / sp, cc = idx - p * sp;
-        double acc = T12[(size_t)p * cp.scap + cc];
-        for (int k2 = 0; k2 < w + ell; ++k2) acc = fma(-HXs[p * ldq + k2], RR[k2 * lds_ + cc], acc);
-        E[p * lds_ + cc] = acc;
+        E[p * lds_ + cc] = T12[(size_t)p * cp.scap + cc] - gw_sum4(0, w + ell, [&](int k2) { return HXs[p * ldq + k2] * RR[k2 * lds_ + cc]; });
       }
       wave_sync();
       if (lane < sp) {
         for (int p = z - 1; p >= 0; --p) {
-          double acc = E[p * lds_ + lane];
-          for (int q = p + 1; q < z; ++q) acc = fma(-R0s[p * ldr + q], E[q * lds_ + lane], acc);
+          const double acc = E[p * lds_ + lane] - gw_sum4(p + 1, z, [&](int q) { return R0s[p * ldr + q] * E[q * lds_ + lane]; });
           E[p * lds_ + lane] = acc / R0s[p * ldr + p];
         }
       }
