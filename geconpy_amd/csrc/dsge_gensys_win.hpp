@@ -404,21 +404,20 @@ __device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb
         t1 = fma(-st, q.v1, t1);
         t2 = fma(-st, q.v2, t2);
       }
-      if (k > ifirst && lane == k - 1) {
+      if (k > ifirst && ca == k - 1) {
         h0 = q.beta;
         h1 = 0.0;
         h2 = 0.0;
       }
-      if (la) {
-        hb[k * ldH + ca] = h0;
-        hb[(k + 1) * ldH + ca] = h1;
-        hb[(k + 2) * ldH + ca] = h2;
-      }
-      if (wa) {
-        tb[k * ldW + cw] = t0;
-        tb[(k + 1) * ldW + cw] = t1;
-        tb[(k + 2) * ldW + cw] = t2;
-      }
+      // (no store masks: a lane without a column of its own walks a clamped one -- ca = 0, cw = w - 1 -- computes bit for bit
+      // what that column's owner computes and stores the same values to the same addresses; the special cases therefore test
+      // the COLUMN / ROW index, not the lane.  Three exec-mask branches less per step.)
+      hb[k * ldH + ca] = h0;
+      hb[(k + 1) * ldH + ca] = h1;
+      hb[(k + 2) * ldH + ca] = h2;
+      tb[k * ldW + cw] = t0;
+      tb[(k + 1) * ldW + cw] = t1;
+      tb[(k + 2) * ldW + cw] = t2;
       // Rows k+1 and k+2 of T, columns k .. k+2: ONE right reflector per step, as in LAPACK's dhgeqz -- its first column is
       // the null vector of these two rows, i.e. their cross product, so that column k of T is zero below the diagonal; the
       // entry (k+2, k+1) stays and is part of the next step's 3 x 3 block (the last step of the sweep clears the last one).
@@ -445,17 +444,15 @@ __device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb
         m0 -= sz;
         m1 = fma(-sz, g1.v1, m1);
         m2 = fma(-sz, g1.v2, m2);
-        if (lane == k + 1 || lane == k + 2) u0 = 0.0;
+        if (cw == k + 1 || cw == k + 2) u0 = 0.0;
       }
-      if (wa) {
-        hb[cw * ldH + k] = r0;
-        hb[cw * ldH + k + 1] = r1;
-        hb[cw * ldH + k + 2] = r2;
-        tb[cw * ldW + k] = u0;
-        tb[cw * ldW + k + 1] = u1;
-        tb[cw * ldW + k + 2] = u2;
-        MR[(size_t)k * mcol + 2 * cw] = m0;  // column k of M is final for this sweep
-      }
+      hb[cw * ldH + k] = r0;
+      hb[cw * ldH + k + 1] = r1;
+      hb[cw * ldH + k + 2] = r2;
+      tb[cw * ldW + k] = u0;
+      tb[cw * ldW + k + 1] = u1;
+      tb[cw * ldW + k + 2] = u2;
+      MR[(size_t)k * mcol + 2 * cw] = m0;  // column k of M is final for this sweep
       x = readlane_dyn_f64(r0, k + 1);
       y = readlane_dyn_f64(r0, k + 2);
       {
@@ -481,18 +478,14 @@ __device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb
         t0 -= st;
         t1 = fma(-st, q.v1, t1);
       }
-      if (lane == k - 1) {
+      if (ca == k - 1) {
         h0 = q.beta;
         h1 = 0.0;
       }
-      if (la) {
-        hb[k * ldH + ca] = h0;
-        hb[(k + 1) * ldH + ca] = h1;
-      }
-      if (wa) {
-        tb[k * ldW + cw] = t0;
-        tb[(k + 1) * ldW + cw] = t1;
-      }
+      hb[k * ldH + ca] = h0;
+      hb[(k + 1) * ldH + ca] = h1;
+      tb[k * ldW + cw] = t0;
+      tb[(k + 1) * ldW + cw] = t1;
       const double c0 = readlane_dyn_f64(t1, k), c1 = readlane_dyn_f64(t1, k + 1);
       wave_sync();
       double r0 = hb[cw * ldH + k], r1 = hb[cw * ldH + k + 1];
@@ -507,18 +500,16 @@ __device__ __forceinline__ void gw_realqz_sweeps(double* hb, int ldH, double* tb
       const double sz = g2.tau * fma(g2.v1, m0, m1);
       m0 = fma(-sz, g2.v1, m0);
       m1 -= sz;
-      if (lane == k + 1) {
+      if (cw == k + 1) {
         u0 = 0.0;
         u1 = g2.beta;
       }
-      if (wa) {
-        hb[cw * ldH + k] = r0;
-        hb[cw * ldH + k + 1] = r1;
-        tb[cw * ldW + k] = u0;
-        tb[cw * ldW + k + 1] = u1;
-        MR[(size_t)k * mcol + 2 * cw] = m0;
-        MR[(size_t)(k + 1) * mcol + 2 * cw] = m1;
-      }
+      hb[cw * ldH + k] = r0;
+      hb[cw * ldH + k + 1] = r1;
+      tb[cw * ldW + k] = u0;
+      tb[cw * ldW + k + 1] = u1;
+      MR[(size_t)k * mcol + 2 * cw] = m0;
+      MR[(size_t)(k + 1) * mcol + 2 * cw] = m1;
       ++steps;
     }
   }
@@ -602,13 +593,10 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
     GW_STAMP(2);
     // ---- window: H22 -> upper Hessenberg by Givens pairs (column j prefetched, pivots travelling through registers).
     // Row rotations with one column of [H | X] and one column of T per lane, column rotations with one row of H, T and M per
-    // lane; loads with clamped indices, stores under one mask.
-    const bool wa = lane < w, la = lane < w + ell || lane < w;
+    // lane; loads with clamped indices, stores unmasked (a lane without a column / row of its own duplicates the clamped one).
     const int cw = min(lane, w - 1);
     const bool packed = w + ell <= 64;
     const int ca = lane < w ? lane : ((packed && lane < w + ell) ? cp.wcap + lane - w : 0);
-    const bool laa = packed ? (lane < w + ell) : wa;
-    (void)la;
     for (int j = 0; j < w - 2; ++j) {
       wave_sync();
       const double colv = hb[cw * ldH + j];
@@ -620,7 +608,7 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
         m_nx = MR[(size_t)max(i - 2, 0) * mcol + 2 * cw];
         const double f = readlane_dyn_f64(colv, i - 1);
         if (g == 0.0) {  // nothing to annihilate: the column pair of M moves on unrotated
-          if (wa) MR[(size_t)i * mcol + 2 * cw] = m_hi;
+          MR[(size_t)i * mcol + 2 * cw] = m_hi;
           m_hi = m_lo_in;
           g = f;
           continue;
@@ -632,18 +620,15 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
         gw_lartg(f, g, c, s, r);
         rot2r(hx, hy, c, s);
         rot2r(tx, ty, c, s);
-        if (lane == j) {
+        if (ca == j) {
           hx = r;
           hy = 0.0;
         }
-        if (laa) {
-          hb[(i - 1) * ldH + ca] = hx;
-          hb[i * ldH + ca] = hy;
-        }
-        if (wa) {
-          tb[(i - 1) * ldW + cw] = tx;
-          tb[i * ldW + cw] = ty;
-        }
+        // (no store masks, as in the sweeps: lanes without a column / row of their own duplicate the clamped one bit for bit)
+        hb[(i - 1) * ldH + ca] = hx;
+        hb[i * ldH + ca] = hy;
+        tb[(i - 1) * ldW + cw] = tx;
+        tb[i * ldW + cw] = ty;
         if (!packed) {  // (window + #lead > 64: X in a pass of its own)
           for (int c0 = lane; c0 < ell; c0 += 64) {
             double ax = xb[(i - 1) * ldX + c0], ay = xb[i * ldX + c0];
@@ -664,21 +649,19 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
           rot2r(hx2, hy2, c, s);
           rot2r(tx2, ty2, c, s);
           rot2r(m_hi, m_lo, c, s);
-          if (lane == i) {
+          if (cw == i) {
             tx2 = r2;
             ty2 = 0.0;
           }
-          if (wa) {
-            hb[cw * ldH + i] = hx2;
-            hb[cw * ldH + i - 1] = hy2;
-            tb[cw * ldW + i] = tx2;
-            tb[cw * ldW + i - 1] = ty2;
-          }
+          hb[cw * ldH + i] = hx2;
+          hb[cw * ldH + i - 1] = hy2;
+          tb[cw * ldW + i] = tx2;
+          tb[cw * ldW + i - 1] = ty2;
         }
-        if (wa) MR[(size_t)i * mcol + 2 * cw] = m_hi;  // column i of M is final for this j
+        MR[(size_t)i * mcol + 2 * cw] = m_hi;  // column i of M is final for this j
         m_hi = m_lo;
       }
-      if (wa) MR[(size_t)(j + 1) * mcol + 2 * cw] = m_hi;
+      MR[(size_t)(j + 1) * mcol + 2 * cw] = m_hi;
     }
     wave_sync();
     GW_STAMP(3);

@@ -44,7 +44,8 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
   for (int c0 = 0; c0 < ncols; c0 += 128) {  // two columns per lane and trip: eight loads in flight
     double *bA, *bB;
     int lA, lB;
-    const bool actA = column(c0 + lane, bA, lA), actB = column(c0 + 64 + lane, bB, lB);
+    column(c0 + lane, bA, lA);
+    column(c0 + 64 + lane, bB, lB);
     double* pA = bA + j * lA;
     double* pB = bB + j * lB;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
@@ -88,26 +89,24 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
       q1 = fma(v1, wB, q1);
       q2 = fma(v2, wB, q2);
       q3 = fma(v3, wB, q3);
-      if (actA) {
-        pA[0] = m0;
-        pA[lA] = m1;
-        pA[2 * lA] = m2;
-        pA[3 * lA] = m3;
-      }
-      if (actB) {
-        pB[0] = q0;
-        pB[lB] = q1;
-        pB[2 * lB] = q2;
-        pB[3 * lB] = q3;
-      }
+      // (no store masks: a lane beyond the last column walks column 0 of H, computes what that column's owner computes and
+      // stores the same values to the same addresses -- an exec-mask branch less per trip, see gw_realqz_sweeps)
+      pA[0] = m0;
+      pA[lA] = m1;
+      pA[2 * lA] = m2;
+      pA[3 * lA] = m3;
+      pB[0] = q0;
+      pB[lB] = q1;
+      pB[2 * lB] = q2;
+      pB[3 * lB] = q3;
       pA += 4 * lA;
       pB += 4 * lB;
     }
     for (; r < N; ++r) {
       const double vr = readlane_dyn_f64(v, r);
       const double m0 = fma(vr, wA, pA[0]), q0 = fma(vr, wB, pB[0]);
-      if (actA) pA[0] = m0;
-      if (actB) pB[0] = q0;
+      pA[0] = m0;
+      pB[0] = q0;
       pA += lA;
       pB += lB;
     }
