@@ -263,6 +263,10 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
 // Mapping: left transformations with one column of [H | X] per lane (42 lanes busy) and one column of T per lane; right
 // transformations with one row of H and one row of T per lane; the vectors that define the reflectors travel through
 // registers (v_readlane).  Entries outside the bands are exact zeros and stay exact zeros under the reflectors: no masks.
+// experiment switch: 1 = skip the rotations whose entry is already zero (two wave-uniform branches per pair), 0 = branch-free
+#ifndef GW_HESS_SKIP
+#define GW_HESS_SKIP 0
+#endif
 struct GwHouse {
   double v1, v2, tau, beta;
 };
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
         const double m_lo_in = m_nx;
         m_nx = MR[(size_t)max(i - 2, 0) * mcol + 2 * cw];
         const double f = readlane_dyn_f64(colv, i - 1);
-        if (g == 0.0) {  // nothing to annihilate: the column pair of M moves on unrotated
+        if (GW_HESS_SKIP && g == 0.0) {  // nothing to annihilate: the column pair of M moves on unrotated
           MR[(size_t)i * mcol + 2 * cw] = m_hi;
           m_hi = m_lo_in;
           g = f;
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
         g = r;
         const double tii = readlane_dyn_f64(ty, i), tim = readlane_dyn_f64(ty, i - 1);
         double m_lo = m_lo_in;
-        if (tim != 0.0) {
+        if (!GW_HESS_SKIP || tim != 0.0) {
           wave_sync();
           double hx2 = hb[cw * ldH + i], hy2 = hb[cw * ldH + i - 1];
           double tx2 = tb[cw * ldW + i], ty2 = tb[cw * ldW + i - 1];
