@@ -12,7 +12,8 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
+ERR_INVALID, ERR_HIP, ERR_TOO_LARGE = 1, 2, 3
 MAX_N = 64
 MAX_N_CR = 64
 MAX_N_GENSYS = 64
@@ -39,7 +40,18 @@ SOLVER_CODES = {
 
 
 class DsgeHipError(RuntimeError):
-    pass
+    code = None  # the library's return code (DSGE_ERR_*), when the error came from a call
+
+
+class DsgeTooLargeError(DsgeHipError):
+    """DSGE_ERR_TOO_LARGE: a well-formed call whose problem exceeds the entry point's on-chip capacity."""
+
+
+class GensysForward(C.Structure):
+    """``dsge_gensys_forward`` of include/dsge_hip.h (addresses; 0 = not wanted)."""
+
+    _fields_ = [("f_mat", C.c_void_p), ("f_wt", C.c_void_p), ("y_wt", C.c_void_p), ("loose", C.c_void_p),
+                ("n_unstable", C.c_void_p), ("pi_raw", C.c_int32)]
 
 
 _dp = C.c_void_p  # double* / int32* / stream: passed as raw addresses (host or device)
@@ -61,6 +73,8 @@ PROTOTYPES = {
     "dsge_gensys_batched_host": [_dp, _dp, _dp, _dp, _i, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_gensys_pencil_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_gensys_pencil_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_gensys_pencil_full_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "dsge_gensys_pencil_full_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_bk_eigenvalues_batched": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_bk_eigenvalues_batched_host": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_set_cr_compact": [_i],
@@ -247,7 +261,10 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().dsge_last_error()
-        raise DsgeHipError(f"libdsge_hip call failed (code {rc}): {msg.decode() if msg else '?'}")
+        cls = DsgeTooLargeError if rc == ERR_TOO_LARGE else DsgeHipError
+        err = cls(f"libdsge_hip call failed (code {rc}): {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err
 
 
 def device_count():

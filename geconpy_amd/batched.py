@@ -7,6 +7,8 @@ numpy arrays.  Layout/dtype coercion mirrors the reference
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 
 from . import _lib
@@ -117,9 +119,15 @@ def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None, options=None):
     return out
 
 
-def gensys_pencil_batched(g0, g1, psi, pi, c=None, tol=1e-8):
+def gensys_pencil_batched(g0, g1, psi, pi, c=None, tol=1e-8, forward=False):
     """Batched ``gensys(g0, g1, c, psi, pi)`` (gEconpy/solvers/gensys.py:398-521) on caller-supplied pencils:
-    returns dict(G1, C, impact, gev (batch, N, 2) complex (alpha, beta), eu, status, success)."""
+    returns dict(G1, C, impact, gev (batch, N, 2) complex (alpha, beta), eu, status, success).
+
+    ``forward=True`` adds the forward-solution part of the reference's 9-tuple (:367-393), formed on the device by
+    ``dsge_gensys_pencil_full_batched``: ``n_unstable`` (batch,) and, full-size with the valid block leading (slice with
+    ``n_unstable[i]``), ``f_mat`` (batch, N, N) complex, ``f_wt`` (batch, N, k) complex, ``y_wt`` (batch, N, N) complex and
+    ``loose`` (batch, N, n_eta).  When the columns of some ``pi[i]`` are not orthonormal two launches run (matrices from Pi as
+    given, existence / uniqueness codes from an orthonormal basis of its column space; see the comment below)."""
     g0, g1 = _f64(g0, 3), _f64(g1, 3)
     psi, pi = _f64(psi, 3), _f64(pi, 3)
     nb, N, _ = g0.shape
@@ -134,11 +142,42 @@ def gensys_pencil_batched(g0, g1, psi, pi, c=None, tol=1e-8):
     gev = np.empty((nb, N, 4))
     eu = np.empty((nb, 3), dtype=np.int32)
     status = np.empty(nb, dtype=np.int32)
-    _lib.check(_lib.load().dsge_gensys_pencil_batched_host(_ptr(g0), _ptr(g1), _ptr(c), _ptr(psi), _ptr(pi), nb, N, k, ne,
-                                                           float(tol), _ptr(G1), _ptr(Cc), _ptr(impact), _ptr(gev), _ptr(eu),
-                                                           _ptr(status)))
+    lib = _lib.load()
+
+    def call(fw):
+        _lib.check(lib.dsge_gensys_pencil_full_batched_host(_ptr(g0), _ptr(g1), _ptr(c), _ptr(psi), _ptr(pi), nb, N, k, ne,
+                                                            float(tol), _ptr(G1), _ptr(Cc), _ptr(impact), _ptr(gev),
+                                                            _ptr(eu), _ptr(status),
+                                                            None if fw is None else ctypes.addressof(fw)))
+
+    # Pi with orthonormal columns (every gEconpy pencil: [0; I], gensys.py:606-611): one launch, Pi as given.  Any other Pi: the
+    # matrices come from a launch on Pi AS GIVEN (for a non-unique solution G1, impact and loose depend on Pi itself, not only on
+    # its column space: Phi = (Q1 Pi)(Q2 Pi)^+), the existence / uniqueness codes from a launch on an orthonormal basis of its
+    # column space (they are rank decisions, which the device takes with orthonormal columns; include/dsge_hip.h).
+    gram = np.einsum("bij,bik->bjk", pi, pi)
+    orthonormal = ne == 0 or bool(np.abs(gram - np.eye(ne)).max() <= 1e-14)
+    out = {}
+    fw = None
+    if forward:
+        f_mat, y_wt = np.zeros((nb, N, N, 2)), np.zeros((nb, N, N, 2))
+        f_wt = np.zeros((nb, N, k, 2))
+        loose = np.zeros((nb, N, max(ne, 1)))
+        n_unst = np.zeros(nb, dtype=np.int32)
+        fw = _lib.GensysForward(_ptr(f_mat), _ptr(f_wt), _ptr(y_wt), _ptr(loose) if ne > 0 else None, _ptr(n_unst), 1)
+    elif not orthonormal:
+        fw = _lib.GensysForward(None, None, None, None, None, 1)
+    call(fw)
+    if forward:
+        out = dict(f_mat=f_mat[..., 0] + 1j * f_mat[..., 1], f_wt=f_wt[..., 0] + 1j * f_wt[..., 1],
+                   y_wt=y_wt[..., 0] + 1j * y_wt[..., 1], loose=loose[:, :, :ne], n_unstable=n_unst)
+    if not orthonormal:
+        keep = [x.copy() for x in (G1, Cc, impact, gev)]
+        call(None)  # eu / status of the orthonormalised launch stay; the matrices of the launch on Pi itself come back
+        for dst, src in zip((G1, Cc, impact, gev), keep):
+            dst[...] = src
     gev_c = np.stack([gev[..., 0] + 1j * gev[..., 1], gev[..., 2] + 1j * gev[..., 3]], axis=-1)
-    return dict(G1=G1, C=Cc, impact=impact, gev=gev_c, eu=eu, status=status, success=status == 0)
+    out.update(G1=G1, C=Cc, impact=impact, gev=gev_c, eu=eu, status=status, success=status == 0)
+    return out
 
 
 def selection_batched(B, C, D, T, A=None):

@@ -480,6 +480,14 @@ int dsge_gensys_batched(const double* A, const double* B, const double* C, const
 int dsge_gensys_pencil_batched(const double* g0, const double* g1, const double* c, const double* psi, const double* pi,
                                int batch, int N, int k, int n_eta, double tol, double* G1_out, double* C_out,
                                double* impact_out, double* gev_out, int32_t* eu_out, int32_t* status, void* stream) {
+  return dsge_gensys_pencil_full_batched(g0, g1, c, psi, pi, batch, N, k, n_eta, tol, G1_out, C_out, impact_out, gev_out,
+                                         eu_out, status, nullptr, stream);
+}
+
+int dsge_gensys_pencil_full_batched(const double* g0, const double* g1, const double* c, const double* psi,
+                                    const double* pi, int batch, int N, int k, int n_eta, double tol, double* G1_out,
+                                    double* C_out, double* impact_out, double* gev_out, int32_t* eu_out, int32_t* status,
+                                    const dsge_gensys_forward* forward, void* stream) {
   int rc = check_common(batch, N, DSGE_MAX_N_GENSYS);
   if (rc) return rc;
   if (k < 1 || n_eta < 0 || n_eta + k + 1 > 64) return fail(DSGE_ERR_INVALID, "need k >= 1, n_eta >= 0, n_eta + k + 1 <= 64");
@@ -487,8 +495,9 @@ int dsge_gensys_pencil_batched(const double* g0, const double* g1, const double*
     return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
+  if (forward && forward->loose && n_eta < 1) return fail(DSGE_ERR_INVALID, "loose needs n_eta >= 1");
   return launch_gensys_pencil(g0, g1, c, psi, pi, batch, N, k, n_eta, tol, G1_out, C_out, impact_out, gev_out, eu_out, status,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, forward);
 }
 
 int dsge_bk_eigenvalues_batched(const double* A, const double* B, const double* C, int batch, int n, double tol,
@@ -1295,6 +1304,14 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
 int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const double* c, const double* psi, const double* pi,
                                     int batch, int N, int k, int n_eta, double tol, double* G1_out, double* C_out,
                                     double* impact_out, double* gev_out, int32_t* eu_out, int32_t* status) {
+  return dsge_gensys_pencil_full_batched_host(g0, g1, c, psi, pi, batch, N, k, n_eta, tol, G1_out, C_out, impact_out, gev_out,
+                                              eu_out, status, nullptr);
+}
+
+int dsge_gensys_pencil_full_batched_host(const double* g0, const double* g1, const double* c, const double* psi,
+                                         const double* pi, int batch, int N, int k, int n_eta, double tol, double* G1_out,
+                                         double* C_out, double* impact_out, double* gev_out, int32_t* eu_out,
+                                         int32_t* status, const dsge_gensys_forward* forward) {
   int rc = check_common(batch, N, DSGE_MAX_N_GENSYS);
   if (rc) return rc;
   if (k < 1 || n_eta < 0 || n_eta + k + 1 > 64) return fail(DSGE_ERR_INVALID, "need k >= 1, n_eta >= 0, n_eta + k + 1 <= 64");
@@ -1308,8 +1325,10 @@ int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const do
   const size_t nn = (size_t)batch * N * N, nk = (size_t)batch * N * k, ne = (size_t)batch * N * (n_eta > 0 ? n_eta : 1),
                nv = (size_t)batch * N;
   void* base = nullptr;
+  const dsge_gensys_forward fh = forward ? *forward : dsge_gensys_forward{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   STAGE_RESERVE(3 * align256(nn * 8) + 2 * align256(nk * 8) + align256(ne * 8) + 2 * align256(nv * 8) + align256(nv * 32) +
-                    2 * align256((size_t)batch * 12) + 4096,
+                    2 * align256((size_t)batch * 12) + (fh.f_mat ? align256(nn * 16) : 0) + (fh.y_wt ? align256(nn * 16) : 0) +
+                    (fh.f_wt ? align256(nk * 16) : 0) + (fh.loose ? align256(ne * 8) : 0) + align256((size_t)batch * 4) + 8192,
                 &base);
   Carver cv(base);
   UP(d0, g0, nn, double);
@@ -1323,7 +1342,20 @@ int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const do
   OUTBUF(dV, gev_out, nv * 4, double);
   OUTBUF(dE, eu_out, (size_t)batch * 3, int32_t);
   OUTBUF(dS, status, batch, int32_t);
-  if ((rc = dsge_gensys_pencil_batched(d0, d1, dc, dps, dpi, batch, N, k, n_eta, tol, dG, dC, dI, dV, dE, dS, tw_st))) return rc;
+  OUTBUF(dFm, fh.f_mat, nn * 2, double);
+  OUTBUF(dFw, fh.f_wt, nk * 2, double);
+  OUTBUF(dYw, fh.y_wt, nn * 2, double);
+  OUTBUF(dLo, fh.loose, ne, double);
+  OUTBUF(dNu, fh.n_unstable, batch, int32_t);
+  const dsge_gensys_forward fd{dFm, dFw, dYw, dLo, dNu, fh.pi_raw};
+  if ((rc = dsge_gensys_pencil_full_batched(d0, d1, dc, dps, dpi, batch, N, k, n_eta, tol, dG, dC, dI, dV, dE, dS,
+                                            forward ? &fd : nullptr, tw_st)))
+    return rc;
+  DOWN(fh.f_mat, dFm, nn * 2, double);
+  DOWN(fh.f_wt, dFw, nk * 2, double);
+  DOWN(fh.y_wt, dYw, nn * 2, double);
+  DOWN(fh.loose, dLo, ne, double);
+  DOWN(fh.n_unstable, dNu, batch, int32_t);
   DOWN(G1_out, dG, nn, double);
   DOWN(C_out, dC, nv, double);
   DOWN(impact_out, dI, nk, double);

@@ -1265,6 +1265,23 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
 //   Pi is first replaced by an orthonormal basis of its column space (one-sided Jacobi, columns with a zero norm dropped):
 //   G1, C, impact and eu depend on Pi only through that space, and orthonormal columns make eta = Q Pi orthonormal,
 //   which the CS-decomposition shortcut below relies on (the reference runs two gesdd, :270-296).
+// The forward-solution part of the reference's 9-tuple (gensys.py:367-393), all optional (NULL = not wanted):
+//   f_mat [batch][N][N][2]  = B22^-1 A22 (upper triangular solve, :371), rows / columns < nu valid, row stride N
+//   f_wt  [batch][N][k][2]  = -B22^-1 Q2 Psi (:372), rows < nu valid
+//   y_wt  [batch][N][N][2]  = Z G0^-1[:, ns:] = Z2 - Z1 A11^-1 (A12 - Phi A22) (:374-379), columns < nu valid, row stride N
+//   loose [batch][N][n_eta] = Re(Z1 A11^-1 Q1 Pi (I - V V^H)), V = right singular vectors of Q2 Pi with sigma > realsmall
+//                             (:383-393).  Needs the caller's Pi itself, not a basis of its column space: pi_raw != 0 skips
+//                             the orthonormalisation (the existence / uniqueness shortcut then assumes orthonormal columns,
+//                             which the caller has checked -- or it reads only `loose` from that launch)
+//   n_unstable [batch]      = nu
+// f_mat, f_wt and y_wt are complex and defined up to the unitary basis of the unstable block that the ordered Schur form
+// happens to produce (LAPACK's differs from any other implementation's); y_wt f_mat^s f_wt is invariant.
+struct GensysFwdOut {
+  double *f_mat, *f_wt, *y_wt, *loose;
+  int32_t* n_unstable;
+  int pi_raw;
+};
+
 __host__ __device__ inline size_t gensys_pencil_smem_bytes(int N, int ell, int xw) {
   const int ldh = N | 1, ldx = xw | 1;
   const size_t cplx = (size_t)3 * N * ldh + (size_t)N * ldx + (size_t)3 * ell * ldx;
@@ -1277,7 +1294,7 @@ __global__ __launch_bounds__(64) void gensys_pencil_kernel(const double* __restr
                                                             double tol, double* __restrict__ G1_out,
                                                             double* __restrict__ C_out, double* __restrict__ impact_out,
                                                             double* __restrict__ gev_out, int32_t* __restrict__ eu_out,
-                                                            int32_t* __restrict__ status) {
+                                                            int32_t* __restrict__ status, GensysFwdOut fw) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int xw = ell + k + 1;
@@ -1319,7 +1336,7 @@ __global__ __launch_bounds__(64) void gensys_pencil_kernel(const double* __restr
       for (int idx = lane; idx < N; idx += 64) GX(idx, ell + k) = mk(cvec[(size_t)draw * N + idx], 0.0);
     wave_sync();
     // orthonormal basis of span(Pi)
-    if (ell > 0) {
+    if (ell > 0 && !fw.pi_raw) {
       jacobi_svd(&GX(0, 0), L.ldx, N, ell, nullptr, 0, L.s1, lane);
       double smax = 0.0;
       for (int j = 0; j < ell; ++j) smax = fmax(smax, L.s1[j]);
@@ -1418,6 +1435,46 @@ __global__ __launch_bounds__(64) void gensys_pencil_kernel(const double* __restr
           GX(i, cc) = acc;
         }
         wave_sync();
+        // A12 <- A12 - Phi A22 in place (the (1,2) block of G0, :322-330): read by the C path below and, solved with A11, y_wt
+        for (int idx = lane; idx < ns * nu; idx += 64) {
+          const int i = idx / nu, cc = idx - i * nu;
+          cx acc = GH(i, ns + cc);
+          for (int u = 0; u <= cc; ++u) acc = acc - GH(ns + u, i) * GH(ns + u, ns + cc);
+          GH(i, ns + cc) = acc;   // (row i only reads Phi[i, :] and A22: no entry another lane writes)
+        }
+        // loose: Q1 Pi (I - V V^H) in place in X[:ns, :ell] (Q1 Pi is not needed again), one row per lane, one kept singular
+        // vector after the other (they are orthogonal: subtracting the component along v_j leaves the others' untouched)
+        if (fw.loose) {
+          for (int i = lane; i < ns; i += 64)
+            for (int j = 0; j < ell; ++j) {
+              if (!(L.s2[j] > rs)) continue;
+              cx g = mk(0, 0);
+              for (int cc = 0; cc < ell; ++cc) g = g + GX(i, cc) * L.V2[cc * L.ldx + j];
+              for (int cc = 0; cc < ell; ++cc) GX(i, cc) = GX(i, cc) - g * conj(L.V2[cc * L.ldx + j]);
+            }
+        }
+        // f_mat = B22^-1 A22, f_wt = -B22^-1 Q2 Psi: upper triangular solves on blocks nothing below overwrites, one column per lane
+        if (fw.f_mat || fw.f_wt) {
+          for (int col = lane; col < nu + k; col += 64) {
+            const bool isf = col < nu;
+            if ((isf && !fw.f_mat) || (!isf && !fw.f_wt)) continue;
+            double* dst = isf ? fw.f_mat + ((size_t)draw * N * N + col) * 2 : fw.f_wt + ((size_t)draw * N * k + (col - nu)) * 2;
+            const int ldd = isf ? N : k;
+            // back-substitution with the solution kept in the output buffer (read back by this lane only)
+            for (int i = nu - 1; i >= 0; --i) {
+              cx acc = isf ? GH(ns + i, ns + col) : neg(GX(ns + i, ell + col - nu));
+              for (int k2 = i + 1; k2 < nu; ++k2) {
+                const cx xk = mk(dst[(size_t)k2 * ldd * 2], dst[(size_t)k2 * ldd * 2 + 1]);
+                acc = acc - GT(ns + i, ns + k2) * xk;
+              }
+              const cx v = cdiv(acc, GT(ns + i, ns + i));
+              dst[(size_t)i * ldd * 2] = v.re;
+              dst[(size_t)i * ldd * 2 + 1] = v.im;
+            }
+          }
+        }
+        if (fw.n_unstable && lane == 0) fw.n_unstable[draw] = nu;
+        wave_sync();
         // C tail: (A22 - B22)^-1 (Q c)[ns:]   (upper triangular, :350-356), one lane
         if (lane == 0 && cvec) {
           for (int i = N - 1; i >= ns; --i) {
@@ -1434,27 +1491,60 @@ __global__ __launch_bounds__(64) void gensys_pencil_kernel(const double* __restr
         if (cvec) {
           for (int i = lane; i < ns; i += 64) {
             cx acc = GX(i, ell + k);
-            for (int cc = 0; cc < nu; ++cc) {
-              cx a12 = GH(i, ns + cc);
-              for (int u = 0; u <= cc; ++u) a12 = a12 - GH(ns + u, i) * GH(ns + u, ns + cc);
-              acc = acc - a12 * GX(ns + cc, ell + k);
-            }
+            for (int cc = 0; cc < nu; ++cc) acc = acc - GH(i, ns + cc) * GX(ns + cc, ell + k);  // (A12 - Phi A22: formed above)
             GX(i, ell + k) = acc;
           }
         }
         wave_sync();
         // Y = A11^-1 rhs (G1), A11^-1 T_mat Q Psi (impact) and the top of C by back-substitution, one column per lane
-        for (int col = lane; col < N + k + 1; col += 64) {
-          for (int i = ns - 1; i >= 0; --i) {
-            cx acc = (col < N) ? GT(i, col) : GX(i, ell + col - N);
-            for (int k2 = i + 1; k2 < ns; ++k2) acc = acc - GH(i, k2) * ((col < N) ? GT(k2, col) : GX(k2, ell + col - N));
-            const cx v = cdiv(acc, GH(i, i));
-            if (col < N)
-              GT(i, col) = v;
-            else
-              GX(i, ell + col - N) = v;
+        // (+ with the forward outputs: A11^-1 (A12 - Phi A22) in H[:ns, ns:] for y_wt and A11^-1 Q1 Pi (I - V V^H) in X[:ns, :ell])
+        {
+          const int c1 = N + k + 1, c2 = c1 + (fw.y_wt ? nu : 0), c3 = c2 + (fw.loose ? ell : 0);
+          for (int col = lane; col < c3; col += 64) {
+            cx* base;
+            int ld;
+            if (col < N) {
+              base = &GT(0, col);
+              ld = (int)(&GT(1, col) - &GT(0, col));
+            } else if (col < c1) {
+              base = &GX(0, ell + col - N);
+              ld = L.ldx;
+            } else if (col < c2) {
+              base = &GH(0, ns + col - c1);
+              ld = (int)(&GH(1, 0) - &GH(0, 0));
+            } else {
+              base = &GX(0, col - c2);
+              ld = L.ldx;
+            }
+            for (int i = ns - 1; i >= 0; --i) {
+              cx acc = base[i * ld];
+              for (int k2 = i + 1; k2 < ns; ++k2) acc = acc - GH(i, k2) * base[k2 * ld];
+              base[i * ld] = cdiv(acc, GH(i, i));
+            }
           }
         }
+        wave_sync();
+        // y_wt = Z2 - Z1 [A11^-1 (A12 - Phi A22)] (N x nu, complex) and loose = Re(Z1 [A11^-1 Q1 Pi (I - V V^H)]) (N x ell), before
+        // W overwrites H[:ns, :]
+        if (fw.y_wt)
+          for (int idx = lane; idx < N * nu; idx += 64) {
+            const int row = idx / nu, u = idx - row * nu;
+            cx acc = GZ(row, ns + u);
+            for (int i = 0; i < ns; ++i) acc = acc - GZ(row, i) * GH(i, ns + u);
+            double* dst = fw.y_wt + ((size_t)draw * N * N + (size_t)row * N + u) * 2;
+            dst[0] = acc.re;
+            dst[1] = acc.im;
+          }
+        if (fw.loose)
+          for (int idx = lane; idx < N * ell; idx += 64) {
+            const int row = idx / ell, cc = idx - row * ell;
+            double acc = 0.0;
+            for (int i = 0; i < ns; ++i) {
+              const cx z = GZ(row, i), w = GX(i, cc);
+              acc += z.re * w.re - z.im * w.im;
+            }
+            fw.loose[(size_t)draw * N * ell + idx] = acc;
+          }
         wave_sync();
         // W = Y Z^H (ns x N) into H[:ns, :] (A11 no longer needed)
         for (int col = lane; col < N; col += 64) {
@@ -1494,6 +1584,15 @@ __global__ __launch_bounds__(64) void gensys_pencil_kernel(const double* __restr
         }
         have = true;
       }
+    }
+    // forward outputs: entries outside the valid nu x nu / nu x k / N x nu blocks are zero; everything is zero without a solution
+    // (gensys.py:258-264) -- the valid blocks were written above
+    if (!have) {
+      if (fw.n_unstable && lane == 0) fw.n_unstable[draw] = 0;
+      if (fw.f_mat) for (int idx = lane; idx < 2 * N * N; idx += 64) fw.f_mat[oNN * 2 + idx] = 0.0;
+      if (fw.y_wt) for (int idx = lane; idx < 2 * N * N; idx += 64) fw.y_wt[oNN * 2 + idx] = 0.0;
+      if (fw.f_wt) for (int idx = lane; idx < 2 * N * k; idx += 64) fw.f_wt[(size_t)draw * N * k * 2 + idx] = 0.0;
+      if (fw.loose) for (int idx = lane; idx < N * ell; idx += 64) fw.loose[(size_t)draw * N * ell + idx] = 0.0;
     }
     if (!have) {
       for (int idx = lane; idx < N * N; idx += 64) G1_out[oNN + idx] = 0.0;

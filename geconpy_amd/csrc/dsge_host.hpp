@@ -147,7 +147,8 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
 
 int launch_gensys_pencil(const double* g0, const double* g1, const double* c, const double* psi, const double* pi, int batch,
                          int N, int k, int ell, double tol, double* G1_out, double* C_out, double* impact_out,
-                         double* gev_out, int32_t* eu_out, int32_t* status, hipStream_t st);
+                         double* gev_out, int32_t* eu_out, int32_t* status, hipStream_t st,
+                         const dsge_gensys_forward* fw = nullptr);
 
 int launch_gensys_bk(const double* A, const double* B, const double* C, int batch, int n, double tol, double* eig_re,
                      double* eig_im, int32_t* n_eig, int32_t* n_forward, int32_t* n_unstable, int32_t* status,

@@ -138,15 +138,18 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
 // gensys on a caller-supplied pencil (dsge_gensys_pencil_batched): single-launch kernel, everything in LDS
 int launch_gensys_pencil(const double* g0, const double* g1, const double* c, const double* psi, const double* pi, int batch,
                          int N, int k, int ell, double tol, double* G1_out, double* C_out, double* impact_out,
-                         double* gev_out, int32_t* eu_out, int32_t* status, hipStream_t st) {
+                         double* gev_out, int32_t* eu_out, int32_t* status, hipStream_t st,
+                         const dsge_gensys_forward* fw) {
   const size_t lds = dsge::gensys_pencil_smem_bytes(N, ell, ell + k + 1);
   if (lds > LDS_LIMIT)
-    return fail(DSGE_ERR_INVALID, "gensys pencil: H, T, Z (N x N complex each) and Q [Pi | Psi | c] do not fit the 160 KB LDS "
-                                  "(N <= ~52)");
+    return fail(DSGE_ERR_TOO_LARGE, "gensys pencil: H, T, Z (N x N complex each) and Q [Pi | Psi | c] do not fit the 160 KB LDS "
+                                    "(N <= ~52)");
   int rc;
   if ((rc = set_lds(dsge::gensys_pencil_kernel, lds))) return rc;
+  dsge::GensysFwdOut fo{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (fw) fo = dsge::GensysFwdOut{fw->f_mat, fw->f_wt, fw->y_wt, fw->loose, fw->n_unstable, fw->pi_raw};
   hipLaunchKernelGGL(dsge::gensys_pencil_kernel, dim3(batch), dim3(64), lds, st, g0, g1, c, psi, pi, batch, N, k, ell, tol,
-                     G1_out, C_out, impact_out, gev_out, eu_out, status);
+                     G1_out, C_out, impact_out, gev_out, eu_out, status, fo);
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
 }

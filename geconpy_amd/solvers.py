@@ -75,30 +75,37 @@ def gensys_setup(A, B, C, D, tol=1e-8):
 
 def gensys(g0, g1, c, psi, pi, div=None, tol=1e-8, return_all_matrices=True):
     """Reference signature and return (gEconpy/solvers/gensys.py:398-521) for an arbitrary pencil
-    ``g0 y_t = g1 y_{t-1} + c + psi z_t + pi eta_t``, solved on the device by ``dsge_gensys_pencil_batched`` (ordered
+    ``g0 y_t = g1 y_{t-1} + c + psi z_t + pi eta_t``, solved on the device by ``dsge_gensys_pencil_full_batched`` (ordered
     complex QZ, existence / uniqueness SVDs, one triangular solve; N <= ~52, everything resident in LDS):
 
       * ``return_all_matrices=False`` -> ``(G_1, eu)``;
       * ``return_all_matrices=True``  -> ``(G_1, C, impact, f_mat, f_wt, y_wt, gev, eu, loose)`` with ``G_1`` (N, N),
-        ``C`` (N, 1), ``impact`` (N, k) from the QZ formulas (:336-365), ``gev`` (N, 2) complex ``[alpha, beta]`` (:253)
-        and ``None`` for ``f_mat, f_wt, y_wt, loose`` (:367-393) -- nothing on the estimation path reads them and the
-        device does not form them;
+        ``C`` (N, 1), ``impact`` (N, k) from the QZ formulas (:336-365), ``gev`` (N, 2) complex ``[alpha, beta]`` (:253),
+        ``f_mat`` (nu, nu), ``f_wt`` (nu, k), ``y_wt`` (N, nu) complex and ``loose`` (N, n_eta) real (:367-393), all formed on
+        the device.  ``f_mat, f_wt, y_wt`` are defined up to the unitary basis of the unstable block of the ordered Schur
+        form (LAPACK's choice in the reference, this library's here); ``y_wt @ f_mat**s @ f_wt`` and ``eig(f_mat)`` agree;
       * coincident zeros (``eu = [-2, -2, 0]``): every matrix is ``None`` (:515-516).
-    ``div`` is accepted and ignored, as in the reference (:502)."""
+    ``div`` is accepted and ignored, as in the reference (:502).  A pencil beyond the kernel's LDS raises
+    ``_lib.DsgeTooLargeError`` (return code DSGE_ERR_TOO_LARGE)."""
     del div
     tol_eff = tol if tol is not None and tol > 0 else float(np.spacing(1))
     g0, g1, psi, pi = (np.ascontiguousarray(x, dtype=np.float64) for x in (g0, g1, psi, pi))
     c = np.ascontiguousarray(c, dtype=np.float64).reshape(g0.shape[0], -1)
     if c.shape[1] != 1:
         raise ValueError("c must have one column")
-    out = batched.gensys_pencil_batched(g0[None], g1[None], psi[None], pi[None], c=c[None, :, 0], tol=tol_eff)
+    out = batched.gensys_pencil_batched(g0[None], g1[None], psi[None], pi[None], c=c[None, :, 0], tol=tol_eff,
+                                        forward=bool(return_all_matrices))
     eu = [int(v) for v in out["eu"][0]]
     if eu[0] == -2 and eu[1] == -2:
         return None, None, None, None, None, None, None, eu, None
     G_1 = out["G1"][0]
     if not return_all_matrices:
         return G_1, eu
-    return G_1, out["C"][0][:, None], out["impact"][0], None, None, None, out["gev"][0], eu, None
+    nu = int(out["n_unstable"][0])
+    f_mat = np.ascontiguousarray(out["f_mat"][0][:nu, :nu])
+    f_wt = np.ascontiguousarray(out["f_wt"][0][:nu])
+    y_wt = np.ascontiguousarray(out["y_wt"][0][:, :nu])
+    return G_1, out["C"][0][:, None], out["impact"][0], f_mat, f_wt, y_wt, out["gev"][0], eu, out["loose"][0]
 
 
 def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=True):
@@ -107,21 +114,26 @@ def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=
     ``impact[:n, :]`` (gensys.py:657-666, gEconpy/model/model.py:1696-1708).  The batched estimation path does not go
     through here: it uses the structure-exploiting kernels behind ``batched.gensys_batched`` (T and eu only).
 
-    The raw-pencil kernel keeps H, T, Z and Q as complex N x N matrices in LDS, which limits it to N <= ~52; a larger pencil
-    (n + #lead up to 64) falls back to the window-path kernels of ``batched.gensys_batched``: ``G_1[:n, :n] = T`` and
+    The raw-pencil kernel keeps H, T, Z and Q as complex N x N matrices in LDS, which limits it to N <= ~52.  A larger pencil
+    (n + #lead up to 64; the library answers DSGE_ERR_TOO_LARGE, a return CODE -- the route is never chosen from message text)
+    is solved by the window-path kernels of ``batched.gensys_batched``: ``G_1[:n, :n] = T`` and
     ``impact[:n] = R = -(C T + B)^-1 D`` (gensys.py:679-683) are what every caller reads; the lead rows are completed ON the
     stable manifold (``x_t = E_t y_{t+1}[lead] = T[lead] y_t``, so ``G_1[n:, :n] = T[lead] T``, ``impact[n:] = T[lead] R``,
-    zero columns for ``x_{t-1}``), ``C = 0`` (the model pencil has c = 0, :598) and ``gev`` is ``None`` on this route."""
+    zero columns for ``x_{t-1}``) and ``C = 0`` (the model pencil has c = 0, :598).  That route keeps the ordered Schur form
+    of the active window only, so ``gev, f_mat, f_wt, y_wt, loose`` are ``None`` there, and a draw WITHOUT a unique stable
+    solution (``eu != [1, 1]``) returns ``None`` for every matrix -- the reference would still hand back the QZ quantities of
+    the failed solve; nothing downstream reads them (model.py:1696-1702 raises first)."""
     g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
     try:
         return gensys(g0, g1, c, psi, pi, tol=tol, return_all_matrices=return_all_matrices)
-    except _lib.DsgeHipError as exc:
-        if "do not fit" not in str(exc):
-            raise
+    except _lib.DsgeTooLargeError:
+        pass
     A3, B3, C3, D3 = (np.ascontiguousarray(x, dtype=np.float64)[None] for x in (A, B, C, D))
     out = batched.gensys_batched(A3, B3, C3, D3, tol=tol)
     eu = [int(v) for v in out["eu"][0]]
-    if eu[0] == -2 and eu[1] == -2:
+    if not (eu[0] == 1 and eu[1] == 1):
+        if not return_all_matrices:
+            return None, eu
         return None, None, None, None, None, None, None, eu, None
     n, k = D3.shape[1:]
     N = g0.shape[0]

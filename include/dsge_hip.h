@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 6
+#define DSGE_ABI_VERSION 7
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
@@ -45,6 +45,10 @@ extern "C" {
 #define DSGE_SUCCESS 0
 #define DSGE_ERR_INVALID 1     /* bad size / null pointer / unsupported option */
 #define DSGE_ERR_HIP 2         /* HIP runtime error or no usable device */
+#define DSGE_ERR_TOO_LARGE 3   /* well-formed call whose problem exceeds this entry point's on-chip capacity (the 160 KB of
+                                  LDS); nothing was enqueued.  Callers with a second route (the Python wrapper of
+                                  solve_policy_function_with_gensys: window-path kernels) branch on this code, never on the
+                                  message text */
 
 /* per-draw status bits (int32) */
 #define DSGE_ST_OK 0
@@ -206,10 +210,10 @@ int dsge_gensys_batched_host(const double* A, const double* B, const double* C, 
  *   gev_out : [batch][N][4] = (Re alpha, Im alpha, Re beta, Im beta) per generalized eigenvalue, stable roots first,
  *             LAPACK's normalisation beta real >= 0 (:253; the order within each group is not defined, as in LAPACK)
  *   eu_out : [batch][3], status : [batch] as dsge_gensys_batched
- * fmat, fwt, ywt and loose of the reference's 9-tuple (:367-393) are not produced: no caller on the estimation path reads
- * them (the Python wrapper returns None for them).  Only the column space of Pi matters for the outputs above, so Pi is
- * replaced on the device by an orthonormal basis of it (the existence / uniqueness SVDs then share their right singular
- * vectors).  Everything is resident in LDS: N x N complex H, T, Z and N x (n_eta + k + 1) Q [Pi | Psi | c] -- N <= ~52.
+ * fmat, fwt, ywt and loose of the reference's 9-tuple (:367-393): dsge_gensys_pencil_full_batched below.  Only the column
+ * space of Pi matters for the outputs above, so Pi is replaced on the device by an orthonormal basis of it (the existence /
+ * uniqueness SVDs then share their right singular vectors).  Everything is resident in LDS: N x N complex H, T, Z and
+ * N x (n_eta + k + 1) Q [Pi | Psi | c] -- N <= ~52; a larger pencil returns DSGE_ERR_TOO_LARGE.
  */
 int dsge_gensys_pencil_batched(const double* g0, const double* g1, const double* c, const double* psi, const double* pi,
                                int batch, int N, int k, int n_eta, double tol, double* G1_out, double* C_out,
@@ -218,6 +222,45 @@ int dsge_gensys_pencil_batched_host(const double* g0, const double* g1, const do
                                     const double* pi, int batch, int N, int k, int n_eta, double tol, double* G1_out,
                                     double* C_out, double* impact_out, double* gev_out, int32_t* eu_out,
                                     int32_t* status);
+
+/*
+ * The forward-solution part of gensys' 9-tuple (gEconpy/solvers/gensys.py:367-393), formed on the device in the same
+ * launch as G1 / C / impact / gev.  Every pointer may be NULL (= not wanted).  Complex arrays are interleaved (re, im).
+ *   f_mat      : [batch][N][N][2]  B22^-1 A22 (:371); the leading nu x nu block is valid (row stride N)
+ *   f_wt       : [batch][N][k][2]  -B22^-1 Q2 Psi (:372); rows < nu valid
+ *   y_wt       : [batch][N][N][2]  Z G0^-1[:, n_stable:] (:374-379); columns < nu valid (row stride N)
+ *   loose      : [batch][N][n_eta] Re(Z G0^-1 [Q1 Pi (I - V V^H); 0]) (:383-393), V = right singular vectors of Q2 Pi with
+ *                sigma > realsmall
+ *   n_unstable : [batch]           nu (0 when there is no solution: every array above is zero-filled then, :258-264)
+ *   pi_raw     : 0 = Pi is replaced by an orthonormal basis of its column space (the default of the plain entry point);
+ *                1 = Pi is used as given.  With a UNIQUE solution every output depends on Pi only through its column space and
+ *                the two agree.  Without one (eu[1] = 0) G1, impact and loose depend on Pi itself -- Phi = (Q1 Pi)(Q2 Pi)^+ --
+ *                and only pi_raw = 1 returns the reference's values.  The existence / uniqueness codes are rank decisions
+ *                that the device takes with orthonormal columns: exact for pi_raw = 0, and for pi_raw = 1 when Pi has
+ *                orthonormal columns (the [0; I] of every gEconpy pencil, gensys.py:606-611).  For any other Pi run two
+ *                launches -- matrices from pi_raw = 1, eu / status from pi_raw = 0 (geconpy_amd.batched.gensys_pencil_batched
+ *                does; tests/test_gpu_parity.py::test_gensys_forward_outputs_vs_reference[arbitrary_nonunique]).
+ * f_mat, f_wt and y_wt are complex and only defined up to the unitary basis of the unstable block that an ordered Schur
+ * form happens to produce (LAPACK's differs from this library's: the reference's own values change with the LAPACK build);
+ * the products y_wt f_mat^s f_wt -- all the forward solution ever uses -- and the spectrum of f_mat are invariant and are
+ * what tests/test_gpu_parity.py compares with the reference's outputs.
+ */
+typedef struct dsge_gensys_forward {
+  double* f_mat;
+  double* f_wt;
+  double* y_wt;
+  double* loose;
+  int32_t* n_unstable;
+  int32_t pi_raw;
+} dsge_gensys_forward;
+int dsge_gensys_pencil_full_batched(const double* g0, const double* g1, const double* c, const double* psi,
+                                    const double* pi, int batch, int N, int k, int n_eta, double tol, double* G1_out,
+                                    double* C_out, double* impact_out, double* gev_out, int32_t* eu_out,
+                                    int32_t* status, const dsge_gensys_forward* forward, void* stream);
+int dsge_gensys_pencil_full_batched_host(const double* g0, const double* g1, const double* c, const double* psi,
+                                         const double* pi, int batch, int N, int k, int n_eta, double tol,
+                                         double* G1_out, double* C_out, double* impact_out, double* gev_out,
+                                         int32_t* eu_out, int32_t* status, const dsge_gensys_forward* forward);
 
 /*
  * Blanchard-Kahn eigenvalues.  Replaces compute_bk_eigenvalues / check_bk_condition

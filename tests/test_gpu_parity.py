@@ -805,7 +805,9 @@ def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
         G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
         N = g[f"{key}_ref_gensys_G1"].shape[0]
         assert eu == [1, 1, 0] and G_1.shape == (N, N) and impact.shape == (N, D.shape[1]) and constant.shape == (N, 1)
-        assert f_mat is None and f_wt is None and y_wt is None and loose is None
+        nu_ref = int(np.sum(~(np.abs(g[f"{key}_ref_gensys_gev"][:, 1]) < np.abs(g[f"{key}_ref_gensys_gev"][:, 0]))))
+        assert f_mat.shape == (nu_ref, nu_ref) and f_wt.shape == (nu_ref, D.shape[1]) and y_wt.shape == (N, nu_ref)
+        assert loose.shape == (N, N - n) and np.iscomplexobj(f_mat) and np.iscomplexobj(y_wt) and not np.iscomplexobj(loose)
         assert_allclose(G_1, g[f"{key}_ref_gensys_G1"], atol=1e-9)
         assert_allclose(G_1[:n, :n], g[f"{key}_ref_gensys_T"], atol=1e-9)
         assert_allclose(impact[:n, :], g[f"{key}_ref_gensys_R"], atol=1e-9)
@@ -834,6 +836,42 @@ def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
         out = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8)
         assert out[7] == [int(v) for v in f[f"{name}_ref_gensys_eu"]]
         assert_allclose(out[0][:40, :40], f[f"{name}_ref_gensys_T"], atol=1e-8)  # the reference still returns G1 there
+
+
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk", "nonunique", "arbitrary", "arbitrary_nonunique"])
+def test_gensys_forward_outputs_vs_reference(key):
+    """f_mat, f_wt, y_wt, loose of gensys' 9-tuple (gensys.py:367-393), formed on the device, against the outputs of the
+    reference's own _gensys_core (tests/golden/gensys_forward.npz, make_gensys_forward_golden.py).  The three complex
+    matrices are defined up to the unitary basis of the unstable block of the ordered Schur form, so the comparison is on what
+    the forward solution uses: the Markov parameters y_wt f_mat^s f_wt, the spectrum of f_mat, the column space of y_wt --
+    plus the defining equations  B22 f_mat = A22  in invariant form (f_mat similar to the reference's) and loose itself (real
+    and basis independent; non-zero only for the non-unique systems, incl. one with a Pi that is not orthonormal)."""
+    from geconpy_amd import solvers
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gensys_forward.npz"))
+    g0, g1, c, psi, pi = (g[f"{key}_{x}"] for x in ("g0", "g1", "c", "psi", "pi"))
+    G_1, constant, impact, f_mat, f_wt, y_wt, gev, eu, loose = solvers.gensys(g0, g1, c, psi, pi, tol=float(g[f"{key}_tol"]))
+    N, nu = g0.shape[0], g[f"{key}_ref_fmat"].shape[0]
+    assert eu == [int(v) for v in g[f"{key}_ref_eu"]]
+    assert f_mat.shape == (nu, nu) and f_wt.shape == (nu, psi.shape[1]) and y_wt.shape == (N, nu) and loose.shape == pi.shape
+    assert_allclose(G_1, g[f"{key}_ref_G1"], atol=1e-8)
+    assert_allclose(impact, g[f"{key}_ref_impact"], atol=1e-8)
+    scale = max(1.0, float(np.abs(g[f"{key}_ref_markov"]).max()))
+    P = f_wt
+    for s_ in range(4):
+        assert_allclose(y_wt @ P, g[f"{key}_ref_markov"][s_], atol=1e-8 * scale)
+        P = f_mat @ P
+    ev = np.linalg.eigvals(f_mat)
+    ev = ev[np.lexsort((ev.imag, ev.real))]
+    ref_ev = g[f"{key}_ref_fmat_eig"]
+    # (infinite roots give a multiple, defective zero eigenvalue of f_mat: that one moves by eps^(1/multiplicity))
+    assert_allclose(np.sort(np.abs(ev)), np.sort(np.abs(ref_ev)), rtol=1e-7, atol=1e-5)
+    # every eigenvalue of f_mat = B22^-1 A22 is the reciprocal of an UNSTABLE root beta / alpha: modulus <= 1 (+ rounding)
+    assert np.all(np.abs(ev) <= 1.0 + 1e-8)
+    assert_allclose(y_wt @ np.linalg.pinv(y_wt), g[f"{key}_ref_ywt_proj"], atol=1e-7)
+    assert_allclose(loose, g[f"{key}_ref_loose"], atol=1e-8 * max(1.0, float(np.abs(g[f"{key}_ref_loose"]).max())))
+    if key.endswith("nonunique"):
+        assert np.abs(loose).max() > 0.1  # the case the output exists for
 
 
 def test_raw_pencil_gensys_arbitrary_inputs(ref_goldens):
