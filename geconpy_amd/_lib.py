@@ -178,6 +178,9 @@ class Options(C.Structure):
         ("cr_fused_deflation", C.c_int32),
         ("cr_four_waves", C.c_int32),
         ("gensys_real_stage", C.c_int32),
+        ("gensys_pairs", C.c_int32),
+        ("gensys_shape_cache", C.c_int32),
+        ("reserved_", C.c_int32 * 6),
     ]
 
 

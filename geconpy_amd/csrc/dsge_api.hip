@@ -134,6 +134,8 @@ struct OptionsGuard {
     local.cr_fused_deflation = o->cr_fused_deflation;
     local.cr_four_waves = o->cr_four_waves;
     local.gensys_real_stage = o->gensys_real_stage;
+    local.gensys_pairs = o->gensys_pairs;
+    local.gensys_shape_cache = o->gensys_shape_cache;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -2086,6 +2088,8 @@ int dsge_options_init(dsge_options* o) {
   o->kalman_nt_products = d.kalman_nt_products;
   o->cr_fused_deflation = d.cr_fused_deflation;
   o->cr_four_waves = d.cr_four_waves;
+  o->gensys_pairs = d.gensys_pairs;
+  o->gensys_shape_cache = d.gensys_shape_cache;
   return DSGE_SUCCESS;
 }
 

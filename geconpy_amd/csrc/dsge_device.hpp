@@ -162,19 +162,19 @@ __device__ __forceinline__ void lds_load_matrix(double* s, int ld, int np_rows, 
 // Lane-strided loop `for (idx = lane; idx < total; idx += 64) store(idx, load(idx))` with U loads in flight per trip: the
 // loads of a trip are issued (from clamped, always valid indices) before the first store waits for one.  The plain loop is
 // one round trip to memory per 64 elements.  load: int -> V (any trivially copyable value), store: (int, V) -> void.
-template <int U = 8, class LoadF, class StoreF>
+template <int U = 8, int NT = 64, class LoadF, class StoreF>
 __device__ __forceinline__ void lane_loop_batched(int total, int lane, LoadF load, StoreF store) {
-  for (int base = 0; base < total; base += U * 64) {
+  for (int base = 0; base < total; base += U * NT) {
     decltype(load(0)) v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int idx = base + u * 64 + lane;
+      const int idx = base + u * NT + lane;
       v[u] = load(idx < total ? idx : total - 1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int idx = base + u * 64 + lane;
+      const int idx = base + u * NT + lane;
       if (idx < total) store(idx, v[u]);
     }
   }

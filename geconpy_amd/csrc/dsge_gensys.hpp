@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
                                                      const double* __restrict__ C, int batch, int n, int n_cap,
                                                      int l_cap, double tol, double* __restrict__ T_out,
                                                      int32_t* __restrict__ eu_out, int32_t* __restrict__ status,
-                                                     long long* __restrict__ dbg) {
+                                                     long long* __restrict__ dbg, int rerun_only) {
 #define DBG_T(k)                                                         \
   do {                                                                   \
     if (dbg && blockIdx.x == 0 && lane == 0) dbg[k] = (long long)clock64(); \
@@ -1035,7 +1035,11 @@ __global__ __launch_bounds__(64) void gensys_kernel(const double* __restrict__ A
   const double rs = (tol > 0.0) ? tol : 2.220446049250313e-16;
   const size_t total_cx = (size_t)2 * n_cap * L.ldh + (size_t)n_cap * L.ldx + (size_t)n * L.ldh + (size_t)3 * l_cap * L.ldx;
 
+  // rerun_only: the rescue pass behind the window path -- only the draws it flagged DSGE_ST_INTERNAL_RERUN (their shape
+  // exceeded the cached capacity record); normally none: one parallel look at the status words and out
+  if (rerun_only && rerun_pass_is_empty(status, batch)) return;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    if (rerun_only && !(status[draw] & DSGE_ST_INTERNAL_RERUN)) continue;
     const size_t off = (size_t)draw * n * n;
     const double* Ag = A + off;
     const double* Bg = B + off;

@@ -1,0 +1,370 @@
+// gensys window path, real double-shift QZ sweeps with TWO draws per wavefront (round 4).
+//
+// Why: gw_realqz_sweeps (dsge_gensys_win.hpp) is VALU-issue bound -- profiles/r4/batch_scaling.txt: 1024 draws (one wavefront per
+// SIMD) take 0.885 ms, 2048 draws (two per SIMD) 1.47 ms, i.e. a second wavefront buys 21 % -- and it issues every instruction
+// for 64 lanes while the 30 x 30 window of the SW-shaped pencil fills 30 (T, H rows) to 42 ([H | X] columns) of them.  Here a
+// wavefront chases the bulges of two draws at once: lanes 0..31 own draw 2p, lanes 32..63 draw 2p + 1 (window <= 32, #lead <= 32;
+// the launcher keeps the one-draw kernel for anything larger).  A sweep step then costs SIX 32-lane passes per PAIR (H, T, X
+// columns from the left; H, T, M rows from the right) instead of five 64-lane passes per draw, and the reflector generation,
+// the shift arithmetic and the loop control are shared by two draws.
+//
+// The two draws deflate at different times, so every half carries its own sweep state (ifirst, ilast, k, iteration count) in
+// lane-uniform-per-half registers and the loop body is a two-stage state machine:
+//   stage A (wave-uniform branch, entered when a half is between sweeps): zhgeqz-style deflation tests of that half, the
+//           double-shift vector of a new sweep;
+//   stage B: one bulge-chase step at each half's own k.  The last step of a sweep (two rows / two columns) is the general step
+//           with the third row and column switched off (z = 0 and b = e3 make v2 = 0 in both reflectors).
+// What a one-draw step hands from lane to lane through v_readlane (wave-uniform lane index) goes through LDS here: the six
+// entries of T that define the right reflector and the three entries of H that start the next step are read back after the
+// stores of the pass that produced them, in the same round trip as the operands of the next pass.
+//
+// LDS: H and T of a draw share ONE array of w x ((w + 6) | 1) doubles -- H(i, j) at [i][j + 6] (band i <= j + 3: Hessenberg +
+// bulge), T(i, j) transposed at [j][i] (band i <= j + 2) -- 8.9 KB at w = 30; X (rows of Q' Pi) and the accumulated right
+// transformation M stay in the draw's workspace (L2), one row / column carried in registers and the next prefetched a step
+// ahead, as gw_realqz_sweeps does for M.  17.8 KB per wavefront: nine wavefronts = 18 draws per CU, 4096 draws resident at once.
+// The arithmetic of a step is that of gw_realqz_sweeps (same reflectors, same shifts, same deflation rules); the pairing changes
+// which lane computes what, not what is computed.
+#pragma once
+#include "dsge_gensys_win.hpp"
+
+namespace dsge {
+
+// LD: compile-time row stride of the packed array (odd, >= wcap + 7: six columns of offset for H, one zero pad column); the
+// array has wcap + 2 rows (zero pad rows).  The pad row / column make the third row and column of the LAST step of a sweep at
+// the window's edge readable (zeros, written back unchanged because v2 = 0 there) without clamped addresses.
+__host__ __device__ inline int gp_ld(const GwCaps& c) { return c.wcap <= 30 ? 37 : 39; }
+__host__ __device__ inline size_t gp_smem(const GwCaps& c) { return (size_t)2 * (c.wcap + 2) * gp_ld(c) * 8; }
+__host__ __device__ inline bool gp_fits(const GwCaps& c) { return c.wcap <= 32 && c.lcap <= 32 && c.wcap >= 3; }
+
+__device__ __forceinline__ double half_sum(double v) {  // sum over the 32 lanes of a half
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+  return v;
+}
+
+// Instruction budget (the kernel is VALU-issue bound: time = slots x VALU instructions per slot x 4 cycles x wavefronts per SIMD):
+//   * LD is a template constant, so every row / column offset inside a pass is an immediate of the ds instruction;
+//   * T(k, c) at [c][k] and H(c, k) at [c][k + 6] are six doubles apart, and so are T(c, k) / H(k, c): TWO per-lane pointers
+//     (pA = row c of the array + k, pB = row k + c) address all four 32-lane passes of a step, a third (pk, the diagonal) the six
+//     entries of T that define the right reflector and the three of H that start the next step;
+//   * lanes outside a pass's band are switched off by the exec mask (one compare) instead of walking clamped duplicates;
+//   * the exact zeros / beta a reflector leaves behind are stored by the one lane that owns them, after the pass;
+//   * M and X are addressed by 32-bit offsets from the (wave-uniform) workspace base.
+template <int LD>
+__global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCaps cp, double* __restrict__ ws,
+                                                                 long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr double ULPD = 2.220446049250313e-16, SAFMIN = 2.2250738585072014e-308;
+  const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
+  const int rows = cp.wcap + 2;  // two zero pad rows: row k+2 of a last step and the (unused) row k+3 read at the window's edge
+  double* P = smem + (size_t)h * rows * LD;
+#define PH(i, j) P[(i)*LD + (j) + 6]
+#define PT(i, j) P[(j)*LD + (i)]
+  const GwOffsets wo = gw_offsets(cp);
+  const int npairs = (batch + 1) >> 1;
+  const unsigned mcolB = 16u * (unsigned)cp.wcap, xrowB = 8u * (unsigned)cp.lcap;  // bytes: one column of M, one row of X
+  const char* wsb = reinterpret_cast<const char*>(ws);
+  char* wsw = reinterpret_cast<char*>(ws);
+#define GLD(off) (*reinterpret_cast<const double*>(wsb + (size_t)(unsigned)(off)))
+#define GST(off, v) (*reinterpret_cast<double*>(wsw + (size_t)(unsigned)(off)) = (v))
+  for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const int draw = 2 * pair + h;
+    const bool exists = draw < batch;
+    const size_t wdo = (size_t)(exists ? draw : 2 * pair) * wo.total;  // (odd batch: the idle half only ever reads its neighbour)
+    double* wd = ws + wdo;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    const bool valid = exists && meta[GW_FLAG] == 0;
+    const int w = valid ? meta[GW_N] - meta[GW_Z] : 0, ell = valid ? meta[GW_ELL] : 0;
+    if (dbg && pair == 0 && lane == 0) dbg[3] = (long long)clock64();
+    wave_sync();
+    for (int idx = l; idx < rows * LD; idx += 32) P[idx] = 0.0;
+    wave_sync();
+    {  // the Hessenberg-triangular window: four (H, T) pairs in flight per trip
+      const int total = w * w;
+      const int wdiv = w > 0 ? w : 1;
+      for (int base = 0; base < cp.wcap * cp.wcap; base += 4 * 32) {
+        double hv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 32 + l;
+          const int ic = idx < total ? idx : 0;
+          const int i = ic / wdiv, j = ic - i * wdiv;
+          const size_t o = (size_t)i * cp.wcap + j;
+          hv[u] = wd[wo.HR + o];
+          tv[u] = wd[wo.TR + o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 32 + l;
+          if (idx < total) {
+            const int i = idx / wdiv, j = idx - i * wdiv;
+            if (i <= j + 1) PH(i, j) = hv[u];
+            if (i <= j) PT(i, j) = tv[u];
+          }
+        }
+      }
+    }
+    wave_sync();
+    const int cw = min(l, max(w - 1, 0));     // this lane's column of H / T and row of H / T / M (lanes >= w duplicate the last)
+    const int cx_ = min(l, max(ell - 1, 0));  // this lane's column of X
+    const unsigned offM0 = (unsigned)((wdo + wo.MC + 2 * (size_t)cw) * 8);  // M(cw, col) at offM0 + col * mcolB
+    const unsigned offX0 = (unsigned)((wdo + wo.XR + (size_t)cx_) * 8);     // X(row, cx_) at offX0 + row * xrowB
+    const unsigned offMmax = offM0 + (unsigned)max(w - 1, 0) * mcolB, offXmax = offX0 + (unsigned)max(w - 1, 0) * xrowB;
+    double* const rowc = P + cw * LD;  // array row cw: T(., cw) at rowc[.], H(cw, .) at rowc[. + 6]
+    const bool xst = ell > 0;
+    double btol;
+    {
+      double ss = 0.0;
+      if (l < w)
+        for (int i = 0; i <= l; ++i) {
+          const double t = PT(i, l);
+          ss = fma(t, t, ss);
+        }
+      btol = fmax(SAFMIN, ULPD * sqrt(half_sum(ss)));
+    }
+    // per-half sweep state (lane-uniform inside a half): k >= 0 chasing at k, -1 between sweeps, -2 finished
+    int ilast = w - 1, ifirst = 0, it = 0, guard = 0;
+    int k = (valid && w >= 3) ? -1 : -2;
+    const int max_total = 40 * w;
+    double x = 0.0, y = 0.0, z = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, xr0 = 0.0, xr1 = 0.0, xr2 = 0.0, x3 = 0.0;
+    double *pA = rowc, *pB = P + cw, *pk = P;  // pA = rowc + k, pB = P + k * LD + cw, pk = P + k * (LD + 1)
+    unsigned offM = offM0, offX = offX0;       // column k of M, row k of X
+    int steps = 0, sweeps = 0;
+    while (true) {
+      // ---------------- stage A: halves between sweeps -- deflation tests, shifts (repeated until none is left between sweeps)
+      while (true) {
+        if (k == -1 && guard >= max_total) k = -2;
+        if (__ballot(k == -1) == 0ull) break;
+        wave_sync();
+        const bool need = k == -1;
+        double hjj = 0.0, hmm = 0.0, hsub = 0.0, tjj = 1.0;
+        if (need && l < w) {
+          hjj = PH(l, l);
+          tjj = PT(l, l);
+          if (l > 0) {
+            hsub = PH(l, l - 1);
+            hmm = PH(l - 1, l - 1);
+          }
+        }
+        const bool sm = need && l < w && l > 0 && fabs(hsub) <= fmax(SAFMIN, ULPD * (fabs(hjj) + fabs(hmm)));
+        const unsigned small = (unsigned)(__ballot(sm) >> (32 * h));
+        const unsigned tzero = (unsigned)(__ballot(need && l < w && fabs(tjj) <= btol) >> (32 * h));
+        bool start = false;
+        if (need) {
+          ++guard;
+          if ((small >> ilast) & 1u) {
+            if (l == 0) PH(ilast, ilast - 1) = 0.0;
+            ilast -= 1;
+            it = 0;
+          } else if ((small >> (ilast - 1)) & 1u) {
+            if (l == 0) PH(ilast - 1, ilast - 2) = 0.0;
+            ilast -= 2;  // a 2 x 2 block: the complex iteration splits it
+            it = 0;
+          } else {
+            ifirst = 0;
+            const unsigned below = small & ((1u << (ilast - 1)) - 1u);  // bits 1 .. ilast-2
+            if (below) {
+              ifirst = 31 - __clz((int)below);
+              if (l == 0) PH(ifirst, ifirst - 1) = 0.0;
+            }
+            const unsigned act = ((ilast >= 31) ? ~0u : ((1u << (ilast + 1)) - 1u)) & ~((1u << ifirst) - 1u);
+            if (tzero & act)
+              k = -2;  // an infinite root inside the active block: zhgeqz's zero chasing lives in the next launch
+            else if (++it > 30)
+              k = -2;
+            else
+              start = true;
+          }
+          if (ilast < 2) k = -2;
+        }
+        if (__ballot(start) != 0ull) {
+          wave_sync();
+          if (start) {
+            // the first column of (M - s1)(M - s2), M = H T^-1 on the active block, shifts = roots of the trailing 2 x 2 pencil.
+            // Reciprocals from v_rcp_f64 + two Newton steps: the shifts steer the convergence, they do not enter the accuracy.
+            const int m = ilast;
+            const double p_ = PH(m - 1, m - 1), q_ = PH(m - 1, m), r_ = PH(m, m - 1), s_ = PH(m, m);
+            const double e_ = PT(m - 1, m - 1), f_ = PT(m - 1, m), g_ = PT(m, m);
+            const double ie = fast_rcp(e_), ig = fast_rcp(g_);
+            double tr, det;
+            if (it % 10 == 0) {  // exceptional shifts
+              const double w_ = 1.5 * (fabs(r_ * ie) + fabs(PH(m - 1, m - 2) / PT(m - 2, m - 2)));
+              tr = w_;
+              det = w_ * w_;
+            } else {
+              tr = p_ * ie + (s_ - r_ * f_ * ie) * ig;
+              det = (p_ * s_ - q_ * r_) * (ie * ig);
+            }
+            const int kf = ifirst;
+            double* pf = P + kf * (LD + 1);
+            const double a11 = pf[6], a12 = pf[7], a21 = pf[LD + 6], a22 = pf[LD + 7], a32 = pf[2 * LD + 7];
+            const double b11 = pf[0], b12 = pf[LD], b22 = pf[LD + 1];
+            const double i11 = fast_rcp(b11), i22 = fast_rcp(b22);
+            const double m11 = a11 * i11, m21 = a21 * i11;
+            const double y2 = m21 * i22;
+            const double y1 = (m11 - b12 * y2) * i11;
+            x = a11 * y1 + a12 * y2 - tr * m11 + det;
+            y = a21 * y1 + a22 * y2 - tr * m21;
+            z = a32 * y2;
+            if (!(fabs(x) + fabs(y) + fabs(z) < 1e300)) {
+              k = -2;  // NaN / overflow in the shift arithmetic: leave it to zhgeqz's logic
+            } else {
+              k = kf;
+              ++sweeps;
+              pk = pf;
+              pA = rowc + kf;
+              pB = P + kf * LD + cw;
+              offM = offM0 + (unsigned)kf * mcolB;
+              offX = offX0 + (unsigned)kf * xrowB;
+              m0 = GLD(offM);
+              m1 = GLD(offM + mcolB);
+              m2 = GLD(offM + 2 * mcolB);
+              xr0 = GLD(offX);
+              xr1 = GLD(offX + xrowB);
+              xr2 = GLD(offX + 2 * xrowB);
+              m3 = GLD(min(offM + 3 * mcolB, offMmax));
+              x3 = GLD(min(offX + 3 * xrowB, offXmax));
+            }
+          }
+        }
+      }
+      // ---------------- stage B: chase steps, one per half and trip, until a half finishes its sweep
+      if (__ballot(k >= 0) == 0ull) break;  // (no half is between sweeps after stage A: every half has finished)
+      do {
+        // Straight-line step: no branch around the arithmetic.  A half that is between sweeps (or finished) runs the same
+        // instructions on whatever its frozen pointers address and stores nothing (its band masks are empty: kl, kr), so no
+        // value is defined under a divergent branch -- the compiler turned every such definition into a copy at the join, with
+        // a wait for the prefetched column in front of it.  The workgroup is one wavefront, whose LDS instructions execute in
+        // program order (what lane A stores, a later load of lane B sees): no barrier inside the step.
+        const bool act = k >= 0;
+        const int ai = act ? 1 : 0;
+        const int kl = act ? k : 4096, kr = act ? k : -4096;
+        const bool last = k == ilast - 1;
+        const double nl = last ? 0.0 : 1.0;  // switches the third row / column off in the last step of a sweep
+        // ---- left: rows k .. k+2 of [H | T | X], one column per lane
+        double h0 = pB[6], h1 = pB[LD + 6], h2 = pB[2 * LD + 6];
+        double t0 = pA[0], t1 = pA[1], t2 = pA[2];
+        const GwHouse q = gw_house3(x, y, z * nl);
+        {
+          const double sh = q.tau * fma(q.v2, h2, fma(q.v1, h1, h0));
+          h0 -= sh;
+          h1 = fma(-sh, q.v1, h1);
+          h2 = fma(-sh, q.v2, h2);
+          const double st = q.tau * fma(q.v2, t2, fma(q.v1, t1, t0));
+          t0 -= st;
+          t1 = fma(-st, q.v1, t1);
+          t2 = fma(-st, q.v2, t2);
+          const double sx = q.tau * fma(q.v2, xr2, fma(q.v1, xr1, xr0));
+          xr0 -= sx;
+          xr1 = fma(-sx, q.v1, xr1);
+          xr2 = fma(-sx, q.v2, xr2);
+        }
+        if (cw >= kl) {  // columns k .. of H and T (the others hold exact zeros in these rows)
+          pB[2 * LD + 6] = h2;
+          pB[LD + 6] = h1;
+          pB[6] = h0;
+          pA[2] = t2;
+          pA[1] = t1;
+          pA[0] = t0;
+        }
+        if (cw == kl - 1 && kl > ifirst) {  // column k-1 of H: the reflector's target
+          pB[6] = q.beta;
+          pB[LD + 6] = 0.0;
+          pB[2 * LD + 6] = 0.0;
+        }
+        // ---- right: columns k .. k+2, one row of H, T, M per lane.  ONE reflector: its first column is the null vector of rows
+        // k+1, k+2 of T (their cross product); last step: rows k+1 and e3, i.e. the 2-column reflector of row k+1
+        const double a0 = pk[1], a1 = pk[LD + 1], a2 = pk[2 * LD + 1];
+        const double b0 = pk[2] * nl, b1 = pk[LD + 2] * nl, b2 = fma(pk[2 * LD + 2], nl, 1.0 - nl);
+        double r0 = pA[6], r1 = pA[7], r2 = pA[8];
+        double u0 = pB[0], u1 = pB[LD], u2 = pB[2 * LD];
+        const double w0 = fma(a1, b2, -(a2 * b1)), w1 = fma(a2, b0, -(a0 * b2)), w2 = fma(a0, b1, -(a1 * b0));
+        const GwHouse g1 = gw_house3(w0, w1, w2);
+        {
+          const double sh = g1.tau * fma(g1.v2, r2, fma(g1.v1, r1, r0));
+          r0 -= sh;
+          r1 = fma(-sh, g1.v1, r1);
+          r2 = fma(-sh, g1.v2, r2);
+          const double st = g1.tau * fma(g1.v2, u2, fma(g1.v1, u1, u0));
+          u0 -= st;
+          u1 = fma(-st, g1.v1, u1);
+          u2 = fma(-st, g1.v2, u2);
+          const double sz = g1.tau * fma(g1.v2, m2, fma(g1.v1, m1, m0));
+          m0 -= sz;
+          m1 = fma(-sz, g1.v1, m1);
+          m2 = fma(-sz, g1.v2, m2);
+        }
+        if (cw <= kr + 3) {  // rows .. k+3 of H (Hessenberg + bulge)
+          pA[8] = r2;
+          pA[7] = r1;
+          pA[6] = r0;
+        }
+        if (cw <= kr + 2) {  // rows .. k+2 of T
+          pB[2 * LD] = u2;
+          pB[LD] = u1;
+          pB[0] = (cw > kr) ? 0.0 : u0;  // T(k+1, k), T(k+2, k): the reflector's targets
+        }
+        // the next step's vector (dead after the last step of the sweep: read anyway)
+        x = pk[LD + 6];
+        y = pk[2 * LD + 6];
+        const double z3 = pk[3 * LD + 6];
+        z = (k + 3 <= ilast) ? z3 : 0.0;
+        // ---- M and X.  Order matters for the memory counter (vmcnt counts loads and stores together and a mix of both can
+        // only be waited for as a whole): FIRST take over the column / row prefetched one step ago -- the only thing outstanding
+        // besides it are the previous step's stores, a full step old --, THEN store, THEN prefetch for the next step.
+        const double m2n = m3, x2n = x3;
+        __builtin_amdgcn_sched_barrier(0);
+        if (act) {
+          GST(offM, m0);  // column k of M and row k of X are final for this sweep
+          if (xst) GST(offX, xr0);
+          if (last) {
+            GST(offM + mcolB, m1);
+            if (xst) GST(offX + xrowB, xr1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        m3 = GLD(min(offM + 4 * mcolB, offMmax));  // (clamped at the window's edge: only ever multiplied by v2 = 0 there)
+        x3 = GLD(min(offX + 4 * xrowB, offXmax));
+        m0 = m1;
+        m1 = m2;
+        m2 = m2n;
+        xr0 = xr1;
+        xr1 = xr2;
+        xr2 = x2n;
+        k = (act && last) ? -1 : k + ai;
+        pk += ai * (LD + 1);
+        pA += ai;
+        pB += ai * LD;
+        offM += (unsigned)ai * mcolB;
+        offX += (unsigned)ai * xrowB;
+        steps += ai;
+      } while (__ballot(k == -1) == 0ull);
+    }
+    wave_sync();
+    if (dbg && pair == 0 && lane == 0) {
+      dbg[6] = (long long)clock64();
+      dbg[27] = steps;
+      dbg[28] = sweeps;
+    }
+    {  // the window goes back as it came: full w x w, exact zeros outside the bands
+      const int total = w * w;
+      const int wdiv = w > 0 ? w : 1;
+      for (int idx = l; idx < cp.wcap * cp.wcap; idx += 32) {
+        if (idx < total) {
+          const int i = idx / wdiv, j = idx - i * wdiv;
+          const size_t o = (size_t)i * cp.wcap + j;
+          wd[wo.HR + o] = (i <= j + 3) ? PH(i, j) : 0.0;
+          wd[wo.TR + o] = (i <= j + 2) ? PT(i, j) : 0.0;
+        }
+      }
+    }
+    if (dbg && pair == 0 && lane == 0) dbg[4] = (long long)clock64();
+  }
+#undef PH
+#undef PT
+#undef GLD
+#undef GST
+}
+
+}  // namespace dsge

@@ -123,7 +123,7 @@ __device__ __forceinline__ void rot2r(double& x, double& y, double c, double s) 
 __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                             const double* __restrict__ C, int batch, GwCaps cp,
                                                             double tol, double* __restrict__ ws,
-                                                            long long* __restrict__ dbg) {
+                                                            long long* __restrict__ dbg, int* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int n = cp.n, Ncap = cp.n + cp.lcap;
@@ -178,7 +178,12 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
       meta[GW_MASK_LO] = (int)(unsigned)(a_colmask & 0xffffffffull);
       meta[GW_MASK_HI] = (int)(unsigned)(a_colmask >> 32);
     }
-    if (too_big) continue;
+    if (too_big) {
+      // the capacity record the launcher cached for this model size is too small for this draw (gensys_shape_cache): tell
+      // the next call (rare: no atomic traffic on the normal path)
+      if (obs && lane == 0) obs[0] = 1;
+      continue;
+    }
     wave_sync();
 #define COLPOS(c) ((((c) < n) && ((zmask >> (c)) & 1ull)) ? __popcll(zmask & ((1ull << (c)) - 1ull)) \
                                                          : (z + (c) - __popcll(zmask & (((c) >= 64) ? ~0ull : ((1ull << (c)) - 1ull)))))
@@ -1035,11 +1040,16 @@ __global__ __launch_bounds__(64) void gensys_eu_kernel(int batch, GwCaps cp, dou
 }
 
 // ---- launch 4: T in the window basis (gensys.py:314-343) and the outputs ------------------------------------------------------
-__global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
+// Four wavefronts per draw (round 4): 72 KB of LDS allow two draws per CU, and at one wavefront each the launch was eight rounds
+// of a 140 k-cycle chain; the products, loads and the output write are spread over 256 threads, the two back-substitutions
+// (one column per lane) stay on the first wavefront.
+constexpr int GW_POST_THREADS = 256;
+__global__ __launch_bounds__(GW_POST_THREADS) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
                                                           double* __restrict__ T_out, int32_t* __restrict__ eu_out,
-                                                          int32_t* __restrict__ status, long long* __restrict__ dbg) {
+                                                          int32_t* __restrict__ status, long long* __restrict__ dbg,
+                                                          int rescue) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;  // 0 .. GW_POST_THREADS-1
   const int n = cp.n;
   const int ldh = cp.wcap | 1, lds_ = cp.scap | 1;
   cx* Hc = reinterpret_cast<cx*>(smem);
@@ -1087,7 +1097,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       struct cx3 {
         cx h, t, m;
       };
-      lane_loop_batched<4>(
+      lane_loop_batched<4, GW_POST_THREADS>(
           w * w, lane,
           [&](int idx) {
             const int i = idx / w, j = idx - i * w;
@@ -1100,7 +1110,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
             PT(i, j) = v.t;
             PM(i, j) = v.m;
           });
-      lane_loop_batched<4>(
+      lane_loop_batched<4, GW_POST_THREADS>(
           ell * nu, lane,
           [&](int idx) {
             const int cc = idx / nu, u = idx - cc * nu;
@@ -1111,7 +1121,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
             Bm[cc * ldh + u] = v;
           });
       // the real tail's operands: R0 and [H12 | X1] (read once, coalesced; the products below broadcast them from LDS)
-      lane_loop_batched<8>(
+      lane_loop_batched<8, GW_POST_THREADS>(
           z * z, lane,
           [&](int idx) {
             const int i = idx / z, j = idx - i * z;
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
             const int i = idx / z, j = idx - i * z;
             R0s[i * ldr + j] = v;
           });
-      lane_loop_batched<8>(
+      lane_loop_batched<8, GW_POST_THREADS>(
           z * w, lane,
           [&](int idx) {
             const int i = idx / w, j = idx - i * w;
@@ -1131,7 +1141,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
             const int i = idx / w, j = idx - i * w;
             HXs[i * ldq + j] = v;
           });
-      lane_loop_batched<8>(
+      lane_loop_batched<8, GW_POST_THREADS>(
           z * ell, lane,
           [&](int idx) {
             const int i = idx / ell, j = idx - i * ell;
@@ -1143,14 +1153,14 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
           });
       wave_sync();
       // Phi_b (ns2 x nu) into the free lower-left block of H: Phi_b[i][u] at H[ns2 + u][i]
-      for (int idx = lane; idx < ns2 * nu; idx += 64) {
+      for (int idx = lane; idx < ns2 * nu; idx += GW_POST_THREADS) {
         const int i = idx / nu, u = idx - i * nu;
         PH(ns2 + u, i) = PHg[(size_t)i * cp.wcap + u];
       }
       wave_sync();
       GW_STAMP(21);
       // rhs = [B11, B12 - Phi_b B22] in place in T[:ns2, :]
-      for (int idx = lane; idx < ns2 * nu; idx += 64) {
+      for (int idx = lane; idx < ns2 * nu; idx += GW_POST_THREADS) {
         const int i = idx / nu, cc = idx - i * nu;
         PT(i, ns2 + cc) = PT(i, ns2 + cc) - gw_csum4(0, cc + 1, [&](int u) { return PH(ns2 + u, i) * PT(ns2 + u, ns2 + cc); });
       }
@@ -1166,24 +1176,24 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       wave_sync();
       GW_STAMP(23);
       // Wb = Yb Ms^H (ns2 x s') into H[:ns2, :s'];  BB = B22 Ms2^H (nu x s') into H[ns2:, :s']
-      for (int idx = lane; idx < ns2 * sp; idx += 64) {
+      for (int idx = lane; idx < ns2 * sp; idx += GW_POST_THREADS) {
         const int i = idx / sp, cc = idx - i * sp;
         PH(i, cc) = gw_csum4(0, w, [&](int k2) { return PT(i, k2) * conj(PM(cc, k2)); });
       }
-      for (int idx = lane; idx < nu * sp; idx += 64) {
+      for (int idx = lane; idx < nu * sp; idx += GW_POST_THREADS) {
         const int u = idx / sp, cc = idx - u * sp;
         PH(ns2 + u, cc) = gw_csum4(u, nu, [&](int v) { return PT(ns2 + u, ns2 + v) * conj(PM(cc, ns2 + v)); });
       }
       wave_sync();
       // RR = [Re(M[:, :ns2] Wb); Re(Bm BB)]  ((w + ell) x s', real)
-      for (int idx = lane; idx < w * sp; idx += 64) {
+      for (int idx = lane; idx < w * sp; idx += GW_POST_THREADS) {
         const int r = idx / sp, cc = idx - r * sp;
         RR[r * lds_ + cc] = gw_sum4(0, ns2, [&](int i) {
           const cx a = PM(r, i), b = PH(i, cc);
           return fma(a.re, b.re, -(a.im * b.im));
         });
       }
-      for (int idx = lane; idx < ell * sp; idx += 64) {
+      for (int idx = lane; idx < ell * sp; idx += GW_POST_THREADS) {
         const int a0 = idx / sp, cc = idx - a0 * sp;
         RR[(w + a0) * lds_ + cc] = gw_sum4(0, nu, [&](int u) {
           const cx a = Bm[a0 * ldh + u], b = PH(ns2 + u, cc);
@@ -1193,7 +1203,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       wave_sync();
       GW_STAMP(24);
       // non-state rows: E = T12[:, :s'] - [H12 | X1] RR, then R0^-1 E by back-substitution (one column per lane)
-      for (int idx = lane; idx < z * sp; idx += 64) {
+      for (int idx = lane; idx < z * sp; idx += GW_POST_THREADS) {
         const int p = idx / sp, cc = idx - p * sp;
         E[p * lds_ + cc] = T12[(size_t)p * cp.scap + cc] - gw_sum4(0, w + ell, [&](int k2) { return HXs[p * ldq + k2] * RR[k2 * lds_ + cc]; });
       }
@@ -1207,7 +1217,7 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       wave_sync();
       GW_STAMP(25);
       // T in the caller's variable order; columns of non-state variables are exact zeros (see dsge_gensys.hpp)
-      for (int idx = lane; idx < n * n; idx += 64) {
+      for (int idx = lane; idx < n * n; idx += GW_POST_THREADS) {
         const int v = idx / n, c = idx - v * n;
         const unsigned long long bc_ = 1ull << c, bv = 1ull << v;
         double val = 0.0;
@@ -1222,13 +1232,15 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
       }
       GW_STAMP(26);
     } else {
-      for (int idx = lane; idx < n * n; idx += 64) T_out[off + idx] = 0.0;
+      for (int idx = lane; idx < n * n; idx += GW_POST_THREADS) T_out[off + idx] = 0.0;
     }
     if (lane == 0) {
       eu_out[3 * draw] = eu0;
       eu_out[3 * draw + 1] = eu1;
       eu_out[3 * draw + 2] = eu2;
-      status[draw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | st_extra);
+      // rescue: a rescue pass follows (the capacity record came from a cache): it takes the draws that did not fit
+      status[draw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK
+                     : ((rescue && st_extra == DSGE_ST_GENSYS_TOO_BIG) ? DSGE_ST_INTERNAL_RERUN : (DSGE_ST_NOT_CONVERGED | st_extra));
     }
   }
 #undef GW_STAMP
@@ -1237,6 +1249,18 @@ __global__ __launch_bounds__(64) void gensys_post_kernel(int batch, GwCaps cp, d
 #undef PM
 }
 
+
+// after the rescue pass of the cached-capacity route: a draw that is still flagged fits neither the cached window launches nor
+// the single-launch kernel
+__global__ __launch_bounds__(256) void gensys_rescue_close_kernel(int batch, int32_t* __restrict__ status,
+                                                                   int32_t* __restrict__ eu_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch && (status[i] & DSGE_ST_INTERNAL_RERUN)) {
+    status[i] = DSGE_ST_NOT_CONVERGED | DSGE_ST_GENSYS_TOO_BIG;
+    eu_out[3 * i] = eu_out[3 * i + 1] = -3;
+    eu_out[3 * i + 2] = 0;
+  }
+}
 
 // ---- Blanchard-Kahn eigenvalues (compute_bk_eigenvalues, gEconpy/model/perturbation.py:412-445): after the reduce and QZ
 // launches the generalized eigenvalues are on the diagonals -- (R0_ii, 0) for the deflated roots, (H_ii, T_ii) for the

@@ -190,6 +190,8 @@ struct Options {
   int gensys_split = 1;        // 0 = single-launch gensys kernel, 1 = window path unless small, 2 = always
   int gensys_real_stage = 1;   // window path: real double-shift sweeps in front of the complex single-shift iteration
   double kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never)
+  int gensys_pairs = 1;        // window path: two draws per wavefront in the real double-shift sweeps (dsge_gensys_pair.hpp)
+  int gensys_shape_cache = 1;  // window path: capacity record measured once per model size
 };
 extern Options g_defaults;
 extern thread_local const Options* t_call_options;

@@ -1,11 +1,16 @@
 // Launcher of the gensys (ordered QZ) kernel.
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "dsge_host.hpp"
 #include "dsge_gensys.hpp"
 #include "dsge_gensys_win.hpp"
+#include "dsge_gensys_pair.hpp"
 
 namespace dsge_host {
+
+int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 
 long long* g_gensys_win_dbg = nullptr;  // debug: device int64[32], phase stamps of draw 0 of the window kernels
 
@@ -17,25 +22,85 @@ StreamArenaPool g_gw_pool;
 constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
 int gw_reserve(size_t bytes, hipStream_t st, void** out) { return g_gw_pool.reserve(bytes, st, out); }
 
+// Capacity record of the window path per (device, n, n_lead_hint): {max #lead, max window, max z, min z} of the batch it was measured on
+// (dsge_options.gensys_shape_cache).  gensys_shape_kernel measures it on the first call of a model size (a launch, a 16-byte
+// read-back and a stream synchronisation); later calls launch with the cached record as pure enqueues.  A draw that exceeds
+// the record is flagged by the reduce launch, solved in the same call by the rescue pass (the single-launch kernel on its
+// full-size pencil; the cache is not used for models that kernel cannot hold), and reported through `obs`, which every cached
+// call copies to pinned host memory behind its launches without waiting: the next call that sees it drops the record and
+// measures again.  The record is also measured afresh every 256 calls, so that it can shrink.
+struct ShapeRecord {
+  int shape[4] = {0, 0, 0, 0};
+  int* d_obs = nullptr;  // device: {flag}: a reduce launch met a draw beyond the record
+  int* h_obs = nullptr;  // pinned host mirror of d_obs
+  int age = 0;
+  bool valid = false;
+};
+std::mutex g_shape_mu;
+std::map<std::pair<int, int>, ShapeRecord> g_shape_cache;
+
 // bk != nullptr: eigenvalue mode (reduce + QZ + gensys_bk_kernel instead of the post-processing)
 struct BkOut {
   double *re, *im;
   int32_t *n_eig, *n_forward, *n_unstable;
 };
 int launch_gensys_split(const double* A, const double* B, const double* C, int batch, int n, double tol, double* T_out,
-                        int32_t* eu_out, int32_t* status, hipStream_t st, int* used, const BkOut* bk = nullptr) {
+                        int32_t* eu_out, int32_t* status, hipStream_t st, int* used, const BkOut* bk = nullptr,
+                        int n_lead_hint = 0) {
   *used = 0;
   void* base = nullptr;
   int rc = gw_reserve(256, st, &base);
   if (rc) return rc;
-  int* shape_d = (int*)base;  // the first 256 bytes of the arena hold the shape record
   int shape[4] = {0, 0, 0, n};
-  HIP_TRY(hipMemcpyAsync(shape_d, shape, sizeof(shape), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(dsge::gensys_shape_kernel, dim3(batch < 4096 ? batch : 4096), dim3(64), 0, st, A, C, batch, n, tol,
-                     shape_d);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(shape, shape_d, sizeof(shape), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  int* obs_d = nullptr;
+  int* obs_h = nullptr;
+  bool cached = false;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  int rescue_ncap = 0, rescue_lcap = 0;
+  // Cached only under a caller-supplied bound on the number of lead columns (n_lead_hint > 0; a draw beyond the caller's own
+  // bound is flagged with or without the cache, include/dsge_hip.h) and when the rescue pass -- the single-launch kernel sized
+  // for that bound -- exists: whatever else a later batch brings (fewer zero columns of A: a larger window) it solves in the
+  // same call.  Not in eigenvalue mode.
+  bool cacheable = opt().gensys_shape_cache && !bk && n_lead_hint > 0;
+  if (cacheable) cacheable = gensys_caps(n, n_lead_hint, &rescue_ncap, &rescue_lcap) == DSGE_SUCCESS;
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_shape_mu);
+    auto it = g_shape_cache.find({dev, n * 128 + n_lead_hint});
+    if (it != g_shape_cache.end() && it->second.valid) {
+      ShapeRecord& r = it->second;
+      if (r.h_obs[0] != 0 || ++r.age >= 256) {
+        r.valid = false;  // an earlier call met a draw beyond the record (or the record is old): measure again
+      } else {
+        for (int i = 0; i < 4; ++i) shape[i] = r.shape[i];
+        obs_d = r.d_obs;
+        obs_h = r.h_obs;
+        cached = true;
+      }
+    }
+  }
+  if (!cached) {
+    int* shape_d = (int*)base;  // the first 256 bytes of the arena hold the shape record
+    HIP_TRY(hipMemcpyAsync(shape_d, shape, sizeof(shape), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dsge::gensys_shape_kernel, dim3(batch < 4096 ? batch : 4096), dim3(64), 0, st, A, C, batch, n, tol,
+                       shape_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(shape, shape_d, sizeof(shape), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (cacheable) {
+      std::lock_guard<std::mutex> lk(g_shape_mu);
+      ShapeRecord& r = g_shape_cache[{dev, n * 128 + n_lead_hint}];
+      if (!r.d_obs) {
+        HIP_TRY(hipMalloc((void**)&r.d_obs, 4 * sizeof(int)));
+        HIP_TRY(hipHostMalloc((void**)&r.h_obs, 4 * sizeof(int), hipHostMallocDefault));
+      }
+      // (other streams' cached calls of this size may still be in flight with the old record: they only ever raise the flag)
+      HIP_TRY(hipMemsetAsync(r.d_obs, 0, 4 * sizeof(int), st));
+      for (int i = 0; i < 4; ++i) r.shape[i] = shape[i], r.h_obs[i] = 0;
+      r.age = 0;
+      r.valid = true;
+    }
+  }
   dsge::GwCaps cp;
   cp.n = n;
   cp.lcap = shape[0] < 1 ? 1 : shape[0];
@@ -59,13 +124,27 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   if ((rc = set_lds(dsge::gensys_qzwin_kernel, lds2))) return rc;
   if ((rc = set_lds(dsge::gensys_post_kernel, lds3))) return rc;
   if ((rc = set_lds(dsge::gensys_eu_kernel, lds_eu))) return rc;
+  const bool pairs = opt().gensys_real_stage && opt().gensys_pairs && dsge::gp_fits(cp);
+  const size_t lds_pair = dsge::gp_smem(cp);
+  if (pairs && (rc = set_lds(dsge::gensys_sweeps_pair_kernel<37>, lds_pair))) return rc;
+  if (pairs && (rc = set_lds(dsge::gensys_sweeps_pair_kernel<39>, lds_pair))) return rc;
   const size_t nn = (size_t)n * n;
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)((c0 + chunk <= (size_t)batch) ? chunk : (size_t)batch - c0);
     hipLaunchKernelGGL(dsge::gensys_reduce_kernel, dim3(nb), dim3(64), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
-                       cp, tol, wsp, g_gensys_win_dbg);
-    hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg,
-                       opt().gensys_real_stage);
+                       cp, tol, wsp, g_gensys_win_dbg, obs_d);
+    if (pairs) {
+      hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0);
+      if (dsge::gp_ld(cp) == 37)
+        hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<37>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,
+                           g_gensys_win_dbg);
+      else
+        hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<39>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,
+                           g_gensys_win_dbg);
+    } else {
+      hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg,
+                         opt().gensys_real_stage);
+    }
     hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg);
     if (bk)
       hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,
@@ -73,9 +152,22 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
                          bk->n_unstable + c0, status + c0);
     else {
       hipLaunchKernelGGL(dsge::gensys_eu_kernel, dim3(nb), dim3(64), lds_eu, st, nb, cp, tol, wsp, g_gensys_win_dbg);
-      hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(64), lds3, st, nb, cp, tol, (const double*)wsp,
-                         T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg);
+      hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(dsge::GW_POST_THREADS), lds3, st, nb, cp, tol, (const double*)wsp,
+                         T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg, cached ? 1 : 0);
     }
+    HIP_TRY(hipGetLastError());
+  }
+  if (obs_d) HIP_TRY(hipMemcpyAsync(obs_h, obs_d, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (cached) {
+    // rescue pass: draws whose shape exceeds the cached record (flagged DSGE_ST_INTERNAL_RERUN by the post launch) go
+    // through the single-launch kernel with its full-size pencil; normally there is none and the launch returns at once
+    {
+      const size_t lds = dsge::gensys_smem_bytes(n, rescue_ncap, rescue_lcap);
+      if ((rc = set_lds(dsge::gensys_kernel, lds))) return rc;
+      hipLaunchKernelGGL(dsge::gensys_kernel, dim3(rerun_grid(batch)), dim3(64), lds, st, A, B, C, batch, n, rescue_ncap,
+                         rescue_lcap, tol, T_out, eu_out, status, (long long*)nullptr, 1);
+    }
+    hipLaunchKernelGGL(dsge::gensys_rescue_close_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, status, eu_out);
     HIP_TRY(hipGetLastError());
   }
   *used = 1;
@@ -121,7 +213,7 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
   }
   if (opt().gensys_split && !dbg && (!small || opt().gensys_split == 2)) {
     int used = 0;
-    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used))) return rc;
+    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used, nullptr, n_lead_hint))) return rc;
     if (used) return DSGE_SUCCESS;
   }
   int n_cap = 0, l_cap = 0;
@@ -130,7 +222,7 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
   const size_t lds = dsge::gensys_smem_bytes(n, n_cap, l_cap);
   if ((rc = set_lds(dsge::gensys_kernel, lds))) return rc;
   hipLaunchKernelGGL(dsge::gensys_kernel, dim3(batch), dim3(64), lds, st, A, B, C, batch, n, n_cap, l_cap, tol, T_out,
-                     eu_out, status, dbg);
+                     eu_out, status, dbg, 0);
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
 }

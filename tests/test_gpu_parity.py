@@ -2064,6 +2064,62 @@ def test_gensys_real_stage_matches_complex_only():
         assert ok and np.abs(on["T"][i] - Tref).max() <= 1e-9
 
 
+def test_gensys_two_draws_per_wavefront_match_one():
+    """gensys window path, round 4: the real double-shift sweeps with two draws per wavefront (dsge_options.gensys_pairs,
+    dsge_gensys_pair.hpp; default on when the window and #lead are <= 32) against the one-draw kernel -- same eu, same status,
+    T equal to 1e-10 -- on an ODD number of SW-shaped draws (the last wavefront has one idle half), on full_nk, on batches whose
+    halves finish their sweeps at very different times (a well-behaved draw next to one without a unique stable solution) and
+    with a shape of its own in every other draw (two window sizes inside one batch)."""
+    b = wl.sw_shaped_batch(67)
+    cases = [(b["A"], b["B"], b["C"], b["D"])]
+    fk = wl.full_nk_batch(33)[0]
+    cases.append((fk["A"], fk["B"], fk["C"], fk["D"]))
+    A, B, C, D = (b[x][:32].copy() for x in "ABCD")
+    C[1::2] *= 3.0  # odd draws: more unstable roots than forward-looking variables
+    A[2::4] *= 1.6
+    cases.append((A, B, C, D))
+    b2 = wl.sw_shaped_batch(16, n_state=14)  # window 26 next to window 30
+    mix = [np.stack([b[x][i] if i % 2 == 0 else b2[x][i] for i in range(16)]) for x in "ABCD"]
+    cases.append(tuple(mix))
+    for A, B, C, D in cases:
+        on = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_pairs": 1})
+        off = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_pairs": 0})
+        assert np.array_equal(on["eu"], off["eu"])
+        assert np.array_equal(on["status"], off["status"])
+        good = (off["eu"][:, 0] == 1) & (off["eu"][:, 1] == 1)
+        sc = np.maximum(1.0, np.abs(off["T"]).max(axis=(1, 2)))
+        err = np.abs(on["T"] - off["T"]).max(axis=(1, 2)) / sc
+        assert (err[good] <= 1e-10).all(), err[good].max()
+    on = batched.gensys_batched(b["A"][:8], b["B"][:8], b["C"][:8], b["D"][:8], tol=1e-8, options={"gensys_split": 2})
+    for i in range(8):
+        Tref, ok = oracle.gensys_T_success(b["A"][i], b["B"][i], b["C"][i], b["D"][i], tol=1e-8)[:2]
+        assert ok and np.abs(on["T"][i] - Tref).max() <= 1e-9
+
+
+def test_gensys_cached_capacity_record_is_rescued_and_renewed():
+    """dsge_options.gensys_shape_cache (default on): the window path measures its capacity record (max #lead, window, deflated
+    roots) on the first call of a (model size, lead hint) and launches later calls without the measuring launch and its stream
+    synchronisation.  A later batch with a LARGER window (fewer zero columns of A: more state variables) does not fit the cached
+    launches: its draws are solved in the same call by the rescue pass (single-launch kernel), and the call after that has a
+    fresh record.  All three calls must return what the uncached path returns."""
+    n, nl, k = 36, 10, 4
+    small = wl.sw_shaped_batch(24, n=n, n_state=12, n_lead=nl, k=k, seed0=91000)
+    large = wl.sw_shaped_batch(24, n=n, n_state=20, n_lead=nl, k=k, seed0=92000)  # window 30 instead of 22
+    ref_small = batched.gensys_batched(*(small[x] for x in "ABCD"), tol=1e-8, n_lead_hint=nl,
+                                       options={"gensys_split": 2, "gensys_shape_cache": 0})
+    ref_large = batched.gensys_batched(*(large[x] for x in "ABCD"), tol=1e-8, n_lead_hint=nl,
+                                       options={"gensys_split": 2, "gensys_shape_cache": 0})
+    assert ref_small["success"].all() and ref_large["success"].all()
+    opts = {"gensys_split": 2, "gensys_shape_cache": 1}
+    runs = [(small, ref_small), (small, ref_small), (large, ref_large), (large, ref_large), (small, ref_small), (large, ref_large)]
+    for bb, ref in runs:  # measure / cached / cached + rescue / measured again / cached (record larger than needed) / cached
+        out = batched.gensys_batched(*(bb[x] for x in "ABCD"), tol=1e-8, n_lead_hint=nl, options=opts)
+        assert np.array_equal(out["eu"], ref["eu"]) and np.array_equal(out["status"], ref["status"])
+        assert np.abs(out["T"] - ref["T"]).max() <= 1e-9
+        assert np.abs(out["T"] - bb["T_star"]).max() <= 1e-8
+        assert np.abs(out["R"] - ref["R"]).max() <= 1e-8
+
+
 def test_zero_T_on_solver_failure_matches_the_reference_default_graph():
     """add_solver_success_check=False is the reference's default (statespace.py:1148, 1210-1215): a failed cycle reduction hands
     on T = 0 (cycle_reduction.py:181) and the model sees the FINITE log-likelihood of that system.  With
