@@ -42,6 +42,39 @@ __device__ __forceinline__ double half_sum(double v) {  // sum over the 32 lanes
   return v;
 }
 
+// LDS loads issued by hand: the result register must not be read before an LDS_WAIT that names it.  (Mixing them with the
+// compiler's own ds instructions is safe: LDS operations of a wavefront complete in order, so a counted wait of the compiler can
+// only become stricter through the extra operations in flight.)  "memory": the compiler's LDS stores stay in front / behind.
+__device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(size_t)p; }
+template <int OFF>
+__device__ __forceinline__ double lds_ld(unsigned addr) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+#define LDS_WAIT6(n, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+#define LDS_WAIT3(n, a, b, c) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c))
+
+// gw_house3 with ONE select: x^2 + y^2 + z^2 + 1e-290 never vanishes, so the reciprocals are always taken of positive numbers;
+// y = z = 0 then gives v1 = v2 = 0 and tau = 2 -- the reflector diag(-1, 1, 1), as orthogonal as the identity gw_house3 returns
+// there -- and only a vector below 1e-140 in norm (tau = 0: identity) needs the select.
+__device__ __forceinline__ GwHouse gp_house3(double x, double y, double z) {
+  GwHouse h;
+  const double s2 = fma(x, x, fma(y, y, fma(z, z, 1e-290)));
+  double rn = __builtin_amdgcn_rsq(s2);
+  const double hs = -0.5 * s2;
+  rn = rn * fma(hs * rn, rn, 1.5);
+  rn = rn * fma(hs * rn, rn, 1.5);
+  const double nrm = s2 * rn;
+  const double d = fabs(x) + nrm;               // |x - beta|
+  const double inv = copysign(fast_rcp(d), x);  // 1 / (x - beta)
+  h.beta = -copysign(nrm, x);
+  h.v1 = y * inv;
+  h.v2 = z * inv;
+  h.tau = (s2 > 1e-280) ? d * rn : 0.0;
+  return h;
+}
+
 // Instruction budget (the kernel is VALU-issue bound: time = slots x VALU instructions per slot x 4 cycles x wavefronts per SIMD):
 //   * LD is a template constant, so every row / column offset inside a pass is an immediate of the ds instruction;
 //   * T(k, c) at [c][k] and H(c, k) at [c][k + 6] are six doubles apart, and so are T(c, k) / H(k, c): TWO per-lane pointers
@@ -112,7 +145,6 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
     const unsigned offX0 = (unsigned)((wdo + wo.XR + (size_t)cx_) * 8);     // X(row, cx_) at offX0 + row * xrowB
     const unsigned offMmax = offM0 + (unsigned)max(w - 1, 0) * mcolB, offXmax = offX0 + (unsigned)max(w - 1, 0) * xrowB;
     double* const rowc = P + cw * LD;  // array row cw: T(., cw) at rowc[.], H(cw, .) at rowc[. + 6]
-    const bool xst = ell > 0;
     double btol;
     {
       double ss = 0.0;
@@ -131,11 +163,14 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
     double *pA = rowc, *pB = P + cw, *pk = P;  // pA = rowc + k, pB = P + k * LD + cw, pk = P + k * (LD + 1)
     unsigned offM = offM0, offX = offX0;       // column k of M, row k of X
     int steps = 0, sweeps = 0;
+    long long slots = 0, a_entries = 0, a_cycles = 0;  // debug counters (pair 0)
     while (true) {
       // ---------------- stage A: halves between sweeps -- deflation tests, shifts (repeated until none is left between sweeps)
       while (true) {
         if (k == -1 && guard >= max_total) k = -2;
         if (__ballot(k == -1) == 0ull) break;
+        const long long ta0 = dbg ? (long long)clock64() : 0;
+        ++a_entries;
         wave_sync();
         const bool need = k == -1;
         double hjj = 0.0, hmm = 0.0, hsub = 0.0, tjj = 1.0;
@@ -228,6 +263,7 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
             }
           }
         }
+        if (dbg) a_cycles += (long long)clock64() - ta0;
       }
       // ---------------- stage B: chase steps, one per half and trip, until a half finishes its sweep
       if (__ballot(k >= 0) == 0ull) break;  // (no half is between sweeps after stage A: every half has finished)
@@ -242,10 +278,14 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
         const int kl = act ? k : 4096, kr = act ? k : -4096;
         const bool last = k == ilast - 1;
         const double nl = last ? 0.0 : 1.0;  // switches the third row / column off in the last step of a sweep
-        // ---- left: rows k .. k+2 of [H | T | X], one column per lane
-        double h0 = pB[6], h1 = pB[LD + 6], h2 = pB[2 * LD + 6];
-        double t0 = pA[0], t1 = pA[1], t2 = pA[2];
-        const GwHouse q = gw_house3(x, y, z * nl);
+        // ---- left: rows k .. k+2 of [H | T | X], one column per lane.  The LDS loads of a step are issued by hand (lds_ld) in
+        // front of the arithmetic that does not need them and waited for where it does (LDS_WAIT): left to the compiler they sink
+        // into the exec-masked store regions, behind the 150-cycle chain of gw_house3.
+        const unsigned aA = lds_addr(pA), aB = lds_addr(pB), aK = lds_addr(pk);
+        double h0 = lds_ld<6 * 8>(aB), h1 = lds_ld<(LD + 6) * 8>(aB), h2 = lds_ld<(2 * LD + 6) * 8>(aB);
+        double t0 = lds_ld<0>(aA), t1 = lds_ld<8>(aA), t2 = lds_ld<16>(aA);
+        const GwHouse q = gp_house3(x, y, z * nl);
+        LDS_WAIT6(0, h0, h1, h2, t0, t1, t2);
         {
           const double sh = q.tau * fma(q.v2, h2, fma(q.v1, h1, h0));
           h0 -= sh;
@@ -275,12 +315,17 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
         }
         // ---- right: columns k .. k+2, one row of H, T, M per lane.  ONE reflector: its first column is the null vector of rows
         // k+1, k+2 of T (their cross product); last step: rows k+1 and e3, i.e. the 2-column reflector of row k+1
-        const double a0 = pk[1], a1 = pk[LD + 1], a2 = pk[2 * LD + 1];
-        const double b0 = pk[2] * nl, b1 = pk[LD + 2] * nl, b2 = fma(pk[2 * LD + 2], nl, 1.0 - nl);
-        double r0 = pA[6], r1 = pA[7], r2 = pA[8];
-        double u0 = pB[0], u1 = pB[LD], u2 = pB[2 * LD];
+        double a0 = lds_ld<8>(aK), a1 = lds_ld<(LD + 1) * 8>(aK), a2 = lds_ld<(2 * LD + 1) * 8>(aK);
+        double b0 = lds_ld<16>(aK), b1 = lds_ld<(LD + 2) * 8>(aK), b2 = lds_ld<(2 * LD + 2) * 8>(aK);
+        double r0 = lds_ld<6 * 8>(aA), r1 = lds_ld<7 * 8>(aA), r2 = lds_ld<8 * 8>(aA);
+        double u0 = lds_ld<0>(aB), u1 = lds_ld<LD * 8>(aB), u2 = lds_ld<2 * LD * 8>(aB);
+        LDS_WAIT6(6, a0, a1, a2, b0, b1, b2);
+        b0 *= nl;
+        b1 *= nl;
+        b2 = fma(b2, nl, 1.0 - nl);
         const double w0 = fma(a1, b2, -(a2 * b1)), w1 = fma(a2, b0, -(a0 * b2)), w2 = fma(a0, b1, -(a1 * b0));
-        const GwHouse g1 = gw_house3(w0, w1, w2);
+        const GwHouse g1 = gp_house3(w0, w1, w2);
+        LDS_WAIT6(0, r0, r1, r2, u0, u1, u2);
         {
           const double sh = g1.tau * fma(g1.v2, r2, fma(g1.v1, r1, r0));
           r0 -= sh;
@@ -305,23 +350,23 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
           pB[LD] = u1;
           pB[0] = (cw > kr) ? 0.0 : u0;  // T(k+1, k), T(k+2, k): the reflector's targets
         }
-        // the next step's vector (dead after the last step of the sweep: read anyway)
-        x = pk[LD + 6];
-        y = pk[2 * LD + 6];
-        const double z3 = pk[3 * LD + 6];
-        z = (k + 3 <= ilast) ? z3 : 0.0;
+        // the next step's vector (dead after the last step of the sweep: read anyway), requested now and waited for at the bottom
+        double xn = lds_ld<(LD + 6) * 8>(aK), yn = lds_ld<(2 * LD + 6) * 8>(aK), z3 = lds_ld<(3 * LD + 6) * 8>(aK);
         // ---- M and X.  Order matters for the memory counter (vmcnt counts loads and stores together and a mix of both can
         // only be waited for as a whole): FIRST take over the column / row prefetched one step ago -- the only thing outstanding
         // besides it are the previous step's stores, a full step old --, THEN store, THEN prefetch for the next step.
-        const double m2n = m3, x2n = x3;
+        double m2n, x2n;  // (moves pinned here: left to itself the compiler copies m3 at the TOP of the step, i.e. waits for the
+                          // prefetch a hundred cycles after issuing it)
+        asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(m2n), "=&v"(x2n) : "v"(m3), "v"(x3));
         __builtin_amdgcn_sched_barrier(0);
         if (act) {
-          GST(offM, m0);  // column k of M and row k of X are final for this sweep
-          if (xst) GST(offX, xr0);
-          if (last) {
-            GST(offM + mcolB, m1);
-            if (xst) GST(offX + xrowB, xr1);
-          }
+          // column k of M and row k of X are final for this sweep; column / row k+1 is final after the LAST step only -- stored
+          // in every step (the next step overwrites it) rather than under a branch of its own; with #lead = 0 the X stores go
+          // to the unused first column of the draw's X block
+          GST(offM, m0);
+          GST(offX, xr0);
+          GST(offM + mcolB, m1);
+          GST(offX + xrowB, xr1);
         }
         __builtin_amdgcn_sched_barrier(0);
         m3 = GLD(min(offM + 4 * mcolB, offMmax));  // (clamped at the window's edge: only ever multiplied by v2 = 0 there)
@@ -332,13 +377,22 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
         xr0 = xr1;
         xr1 = xr2;
         xr2 = x2n;
+        const int kz = k;
         k = (act && last) ? -1 : k + ai;
-        pk += ai * (LD + 1);
-        pA += ai;
-        pB += ai * LD;
-        offM += (unsigned)ai * mcolB;
-        offX += (unsigned)ai * xrowB;
+        {  // the step's pointers follow k (a half between sweeps keeps valid ones: k clamped at 0)
+          const int kc = max(k, 0);
+          pk = P + kc * (LD + 1);
+          pA = rowc + kc;
+          pB = P + kc * LD + cw;
+          offM = offM0 + (unsigned)kc * mcolB;
+          offX = offX0 + (unsigned)kc * xrowB;
+        }
         steps += ai;
+        ++slots;
+        LDS_WAIT3(0, xn, yn, z3);
+        x = xn;
+        y = yn;
+        z = (kz + 3 <= ilast) ? z3 : 0.0;
       } while (__ballot(k == -1) == 0ull);
     }
     wave_sync();
@@ -346,6 +400,11 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
       dbg[6] = (long long)clock64();
       dbg[27] = steps;
       dbg[28] = sweeps;
+      dbg[31] = a_cycles;
+    }
+    if (dbg && lane == 0) {  // debug: the sum and the maximum of the pairs' step counts (the launch ends with the slowest pair)
+      atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 29), (unsigned long long)slots);
+      atomicMax(reinterpret_cast<unsigned long long*>(dbg + 30), (unsigned long long)slots);
     }
     {  // the window goes back as it came: full w x w, exact zeros outside the bands
       const int total = w * w;

@@ -120,12 +120,17 @@ __device__ __forceinline__ void rot2r(double& x, double& y, double c, double s) 
 // ---- launch 1a: pencil and structural deflation (real).  Rows < z are final afterwards and leave the chip (R0, H12,
 // T12[:, :s'], X1); the window (rows / columns >= z of H and T, rows >= z of X) is handed to launch 1b, which needs a
 // third of this launch's LDS and therefore runs at a higher occupancy.
-__global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restrict__ A, const double* __restrict__ B,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gensys_reduce_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                             const double* __restrict__ C, int batch, GwCaps cp,
                                                             double tol, double* __restrict__ ws,
                                                             long long* __restrict__ dbg, int* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
+  // NW wavefronts per draw (round 4: 40 KB of LDS allow four draws per CU, and with one wavefront each the launch was four
+  // rounds of a 230 k-cycle chain): loads and stores are spread over all threads, the lead / zero-column masks are computed by
+  // every wavefront for itself, the reflectors run on hh_left_real_mw
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = cp.n, Ncap = cp.n + cp.lcap;
   const int ldH = Ncap | 1, ldW = cp.wcap | 1, ldX = cp.lcap | 1;
   double* Hr = smem;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
     double* wd = ws + (size_t)draw * wo.total;
     int* meta = reinterpret_cast<int*>(wd + wo.meta);
     wave_sync();
-    for (size_t idx = lane; idx < total; idx += 64) smem[idx] = 0.0;
+    for (size_t idx = tid; idx < total; idx += NT) smem[idx] = 0.0;
     // lead columns (gensys.py:580-589) and the zero columns of A
     int ell = 0;
     unsigned long long a_colmask = 0ull;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
       a_colmask = __ballot(anz != 0);
       const unsigned long long lm = __ballot(lane < n && cs > tol);
       ell = __popcll(lm);
-      if (lane < n && ((lm >> lane) & 1ull)) lead[__popcll(lm & ((1ull << lane) - 1ull))] = lane;
+      if (wv == 0 && lane < n && ((lm >> lane) & 1ull)) lead[__popcll(lm & ((1ull << lane) - 1ull))] = lane;
     }
     const int N = n + ell;
     const unsigned long long nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
     const int z = __popcll(zmask);
     const int w = N - z, sp = n - z;
     const bool too_big = (ell > cp.lcap) || (w > cp.wcap) || (z > cp.zcap) || (sp > cp.scap) || (N > 64);
-    if (lane == 0) {
+    if (tid == 0) {
       meta[GW_N] = N;
       meta[GW_ELL] = ell;
       meta[GW_Z] = z;
@@ -181,23 +186,23 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
     if (too_big) {
       // the capacity record the launcher cached for this model size is too small for this draw (gensys_shape_cache): tell
       // the next call (rare: no atomic traffic on the normal path)
-      if (obs && lane == 0) obs[0] = 1;
+      if (obs && tid == 0) obs[0] = 1;
       continue;
     }
     wave_sync();
 #define COLPOS(c) ((((c) < n) && ((zmask >> (c)) & 1ull)) ? __popcll(zmask & ((1ull << (c)) - 1ull)) \
                                                          : (z + (c) - __popcll(zmask & (((c) >= 64) ? ~0ull : ((1ull << (c)) - 1ull)))))
     // pencil (gensys.py:591-614) by index arithmetic; T holds columns >= z only (the others are exactly zero)
-    lane_loop_batched<4>(
-        n * n, lane, [&](int idx) { return double2{Bg[idx], Ag[idx]}; },
+    lane_loop_batched<4, NT>(
+        n * n, tid, [&](int idx) { return double2{Bg[idx], Ag[idx]}; },
         [&](int idx, double2 v) {
           const int i = idx / n, j = idx - i * n;
           const int pj = COLPOS(j);
           Hr[i * ldH + pj] = -v.x;
           if (pj >= z) Tr[i * ldW + pj - z] = v.y;
         });
-    lane_loop_batched<8>(
-        n * ell, lane,
+    lane_loop_batched<8, NT>(
+        n * ell, tid,
         [&](int idx) {
           const int i = idx / ell, a = idx - i * ell;
           return Cg[(size_t)i * n + lead[a]];
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
           const int i = idx / ell, a = idx - i * ell;
           Hr[i * ldH + n + a] = -v;
         });
-    if (lane < ell) {
+    if (wv == 0 && lane < ell) {
       const int lc0 = lead[lane];
       Hr[(n + lane) * ldH + COLPOS(lc0)] = 1.0;
       Tr[(n + lane) * ldW + n + lane - z] = 1.0;
@@ -217,32 +222,33 @@ __global__ __launch_bounds__(64) void gensys_reduce_kernel(const double* __restr
 
     GW_STAMP(0);
     // ---- structural deflation: QR of the z zero-columns-of-A columns of G0
-    for (int j = 0; j < z; ++j) hh_left_real(Hr, ldH, j, N - j, Tr, ldW, w, Xr, ldX, ell, Hr, ldH, j, j, N, lane);
+    for (int j = 0; j < z; ++j) hh_left_real_mw<NW>(Hr, ldH, j, N - j, Tr, ldW, w, Xr, ldX, ell, Hr, ldH, j, j, N, 0, lane, wv);
+    wave_sync();
     // rows < z are final: R0, H12, T12[:, :s'], X1 leave the chip
-    for (int idx = lane; idx < z * z; idx += 64) {
+    for (int idx = tid; idx < z * z; idx += NT) {
       const int i = idx / z, j = idx - i * z;
       wd[wo.R0 + (size_t)i * cp.zcap + j] = Hr[i * ldH + j];
     }
-    for (int idx = lane; idx < z * w; idx += 64) {
+    for (int idx = tid; idx < z * w; idx += NT) {
       const int i = idx / w, j = idx - i * w;
       wd[wo.H12 + (size_t)i * cp.wcap + j] = Hr[i * ldH + z + j];
     }
-    for (int idx = lane; idx < z * sp; idx += 64) {
+    for (int idx = tid; idx < z * sp; idx += NT) {
       const int i = idx / sp, j = idx - i * sp;
       wd[wo.T12 + (size_t)i * cp.scap + j] = Tr[i * ldW + j];
     }
-    for (int idx = lane; idx < z * ell; idx += 64) {
+    for (int idx = tid; idx < z * ell; idx += NT) {
       const int i = idx / ell, j = idx - i * ell;
       wd[wo.X1 + (size_t)i * cp.lcap + j] = Xr[i * ldX + j];
     }
     // the window, as it stands after the deflation
-    for (int idx = lane; idx < w * w; idx += 64) {
+    for (int idx = tid; idx < w * w; idx += NT) {
       const int i = idx / w, j = idx - i * w;
       const size_t o = (size_t)i * cp.wcap + j;
       wd[wo.HR + o] = Hr[(z + i) * ldH + z + j];
       wd[wo.TR + o] = Tr[(z + i) * ldW + j];
     }
-    for (int idx = lane; idx < w * ell; idx += 64) {
+    for (int idx = tid; idx < w * ell; idx += NT) {
       const int i = idx / ell, j = idx - i * ell;
       wd[wo.XR + (size_t)i * cp.lcap + j] = Xr[(z + i) * ldX + j];
     }

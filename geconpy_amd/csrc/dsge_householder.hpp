@@ -116,4 +116,84 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
   wave_sync();
 }
 
+// ---- the same reflector on NW wavefronts of one workgroup (gensys_reduce_kernel, round 4): every wavefront builds the reflector
+// for itself from column `col` of `src` (one row per lane: identical arithmetic, no exchange), the nH + nT + nX columns are
+// dealt out in NW contiguous shares, one column per lane.  `skip` is the index of the source column inside [H | T | X] (or -1):
+// it is left alone by the sweep -- other wavefronts may still be reading it -- and set to (beta, 0, ..., 0) by wavefront 0
+// behind the barrier.  Two barriers per reflector.
+template <int NW>
+__device__ __forceinline__ void hh_left_real_mw(double* Hr, int ldH, int h0, int nH, double* Tr, int ldW, int nT, double* Xr,
+                                                int ldX, int nX, double* src, int ld_src, int col, int j, int N, int skip,
+                                                int lane, int wv) {
+  __syncthreads();
+  const double x = (lane >= j && lane < N) ? src[lane * ld_src + col] : 0.0;
+  const double xnorm2 = wave_sum_dpp((lane > j) ? x * x : 0.0);
+  if (xnorm2 == 0.0) return;  // (the same decision in every wavefront)
+  const double alpha = readlane_dyn_f64(x, j);
+  const double nrm = sqrt(fma(alpha, alpha, xnorm2));
+  const double beta = (alpha >= 0.0) ? -nrm : nrm;
+  const double tau = (beta - alpha) / beta;
+  const double scal = 1.0 / (alpha - beta);
+  const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
+  const int ncols = nH + nT + nX;
+  const int per = (ncols + NW - 1) / NW;
+  const int c = wv * per + lane;
+  const bool mine = lane < per && c < ncols && c != skip;
+  double* bA = Hr + h0;
+  int lA = ldH;
+  if (mine) {
+    if (c < nH) {
+      bA = Hr + h0 + c;
+    } else if (c < nH + nT) {
+      bA = Tr + (c - nH);
+      lA = ldW;
+    } else {
+      bA = Xr + (c - nH - nT);
+      lA = ldX;
+    }
+  }
+  double* pA = bA + j * lA;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int r = j;
+  for (; r + 4 <= N; r += 4) {
+    const double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
+    const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
+                 v3 = readlane_dyn_f64(v, r + 3);
+    a0 = fma(v0, m0, a0);
+    a1 = fma(v1, m1, a1);
+    a2 = fma(v2, m2, a2);
+    a3 = fma(v3, m3, a3);
+    pA += 4 * lA;
+  }
+  for (; r < N; ++r) {
+    a0 = fma(readlane_dyn_f64(v, r), pA[0], a0);
+    pA += lA;
+  }
+  const double wA = -tau * ((a0 + a1) + (a2 + a3));
+  pA = bA + j * lA;
+  for (r = j; r + 4 <= N; r += 4) {
+    double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
+    const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
+                 v3 = readlane_dyn_f64(v, r + 3);
+    m0 = fma(v0, wA, m0);
+    m1 = fma(v1, wA, m1);
+    m2 = fma(v2, wA, m2);
+    m3 = fma(v3, wA, m3);
+    if (mine) {
+      pA[0] = m0;
+      pA[lA] = m1;
+      pA[2 * lA] = m2;
+      pA[3 * lA] = m3;
+    }
+    pA += 4 * lA;
+  }
+  for (; r < N; ++r) {
+    const double m0 = fma(readlane_dyn_f64(v, r), wA, pA[0]);
+    if (mine) pA[0] = m0;
+    pA += lA;
+  }
+  __syncthreads();
+  if (wv == 0 && lane >= j && lane < N) src[lane * ld_src + col] = (lane == j) ? beta : 0.0;
+}
+
 }  // namespace dsge

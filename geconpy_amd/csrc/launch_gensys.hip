@@ -119,7 +119,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   if (chunk > (size_t)batch) chunk = (size_t)batch;
   if ((rc = gw_reserve(256 + chunk * per_draw, st, &base))) return rc;
   double* wsp = (double*)((char*)base + 256);
-  if ((rc = set_lds(dsge::gensys_reduce_kernel, lds1))) return rc;
+  if ((rc = set_lds(dsge::gensys_reduce_kernel<2>, lds1))) return rc;
   if ((rc = set_lds(dsge::gensys_hesstri_kernel, lds1b))) return rc;
   if ((rc = set_lds(dsge::gensys_qzwin_kernel, lds2))) return rc;
   if ((rc = set_lds(dsge::gensys_post_kernel, lds3))) return rc;
@@ -131,7 +131,9 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   const size_t nn = (size_t)n * n;
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)((c0 + chunk <= (size_t)batch) ? chunk : (size_t)batch - c0);
-    hipLaunchKernelGGL(dsge::gensys_reduce_kernel, dim3(nb), dim3(64), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
+    // two wavefronts per draw: the reflectors' columns in two shares (measured: 595 us per 4096 SW-shaped draws on one wavefront,
+    // 499 us on two, 548 us on four -- the chain is the walk down the rows, which more column shares do not shorten)
+    hipLaunchKernelGGL(dsge::gensys_reduce_kernel<2>, dim3(nb), dim3(128), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
                        cp, tol, wsp, g_gensys_win_dbg, obs_d);
     if (pairs) {
       hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0);

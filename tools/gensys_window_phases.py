@@ -18,6 +18,7 @@ def split(names, base):
 print("reduce ", {"pencil+deflation(hh)+store": int(c[1] - c[0])})
 print("hesstri", {"load": 0, "T22 triangular(hh) incl. load": int(c[2] - c[5]), "Hessenberg(givens)": int(c[3] - c[2]), "real double-shift sweeps": int(c[6] - c[3]), "store": int(c[4] - c[6])}, "total", int(c[4] - c[5]))
 print("real double-shift stage:", int(c[27]), "sweep steps in", int(c[28]), "sweeps")
+print("pair kernel (two draws per wavefront): steps of all pairs (sum over the calls since the debug buffer was reset)", int(c[29]), "slowest pair", int(c[30]), "stage-A cycles of pair 0", int(c[31]))
 print("qz    ", split(["qz", "reorder", "store"], 8), "total", int(c[11] - c[8]))
 print("qz sweep steps", int(c[12]) // 2, "sweeps", int(c[13]) // 2, "(per call)")
 print("eu    ", split(["load", "svd", "eu+Bm+Phi"], 16), "total", int(c[19] - c[16]))
