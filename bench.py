@@ -75,13 +75,12 @@ def algorithmic_bytes(n, k, p):
 def _cpu_worker(args):
     import oracle
 
-    A, B, C, D, q, Z, y, Hd = args
-    r = oracle.solve_kalman_logp(A, B, C, D, np.diag(q), Z, y, H=np.diag(Hd), solver="cycle_reduction", tol=1e-8,
-                                 max_iter=1000)
+    A, B, C, D, q, Z, y, Hd, solver = args
+    r = oracle.solve_kalman_logp(A, B, C, D, np.diag(q), Z, y, H=np.diag(Hd), solver=solver, tol=1e-8, max_iter=1000)
     return r["logp"]
 
 
-def cpu_baseline(batch, om, n_sample, cores):
+def cpu_baseline(batch, om, n_sample, cores, solver="cycle_reduction"):
     """Time the CPU oracle (numpy/scipy port of the reference path) on a bounded sample of the
     same workload, one process per host core with single-threaded BLAS."""
     import multiprocessing as mp
@@ -91,7 +90,7 @@ def cpu_baseline(batch, om, n_sample, cores):
     os.environ["MKL_NUM_THREADS"] = "1"
     jobs = [
         (batch["A"][i], batch["B"][i], batch["C"][i], batch["D"][i], batch["sigma"][i] ** 2, om["Z"], om["y"],
-         om["Hdiag"])
+         om["Hdiag"], solver)
         for i in range(n_sample)
     ]
     ctx = mp.get_context("spawn")  # never fork a process that has initialised the GPU
@@ -224,6 +223,96 @@ def roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_e
     }
 
 
+GENSYS_STAGES = ("gensys_reduce_kernel<2> (structural deflation)", "gensys_hesstri_kernel (Hessenberg-triangular reduction)",
+                 "gensys_sweeps_pair_kernel (real double-shift QZ sweeps, two draws per wavefront)",
+                 "gensys_qzwin_kernel (complex QZ + reordering)", "gensys_eu_kernel (existence / uniqueness SVDs)",
+                 "gensys_post_kernel (T in the window basis)")
+
+
+def gensys_roofline(eng, call, nloc, n, n_lead):
+    """The roofline object of the gensys leg: the launch durations of the window path measured live with HIP events on the launch
+    stream (dsge_debug_gensys_stage_ms), executed FP64 flops of the dominant launch from the newest committed
+    profiles/r*/pmc_counters_gensys.json (same batch size only), and the useful flops of the algorithm it runs."""
+    import ctypes
+    import glob
+
+    import torch
+
+    from geconpy_amd import _lib
+
+    lib = _lib.load()
+    ms = (ctypes.c_float * 8)()
+    call()
+    torch.cuda.synchronize()
+    acc = np.zeros(8)
+    reps = 3
+    for _ in range(reps):
+        _lib.check(lib.dsge_debug_gensys_stage_ms(1, None))
+        call()
+        torch.cuda.synchronize()
+        _lib.check(lib.dsge_debug_gensys_stage_ms(0, ctypes.addressof(ms)))
+        acc += np.array(list(ms))
+    acc /= reps
+    dom = int(np.argmax(acc[:6]))
+    N = n + n_lead
+    # SURVEY 8(d): real-QZ formulation 66 N^3 + 24 N^3 (reordering, worst case) + (2/3 + 2 + 4) N^3
+    contract = (66 + 24 + 2.0 / 3 + 6) * N ** 3
+    out = {"kernel": "dsge::" + GENSYS_STAGES[dom], "bound": "valu-latency",
+           "pipe": "fp64 VALU, one or two draws per wavefront, a dependent chain of 3-row reflectors per draw (no MFMA: the 30 x 30 "
+                   "window's transformations are rank-1 updates of three rows / columns)",
+           "launch_ms": {GENSYS_STAGES[i].split(" ")[0]: round(float(acc[i]), 4) for i in range(6)},
+           "gensys_ms": round(float(acc[6]), 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "contract_mflop_per_eval": round(contract / 1e6, 3),
+           "contract_tflops_whole_gensys": round(contract * nloc / (acc[6] * 1e-3) / 1e12, 3),
+           "contract_note": "SURVEY 8(d) real-QZ count on the FULL (n + #lead)-dimensional pencil over the measured duration of the "
+                            "gensys launches; the kernels deflate the zero columns of A first and iterate on the 30 x 30 window"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters_gensys.json")))
+    counted = None
+    if files and nloc == 4096:
+        try:
+            with open(files[-1]) as fh:
+                kern = json.load(fh)["kernels"]
+            key = GENSYS_STAGES[dom].split(" ")[0].split("<")[0]
+            hit = [v for nm, v in kern.items() if key in nm]
+            if hit:
+                counted = hit[0]
+        except (OSError, KeyError, ValueError):
+            counted = None
+    if counted:
+        out["achieved"] = round(counted.get("fp64_flops", 0.0) / (acc[dom] * 1e-3) / 1e12, 3)
+        out["frac"] = round(out["achieved"] / FP64_PEAK_TFLOPS, 5)
+        out["traffic"] = int(counted.get("hbm_bytes", 0))
+        out["flops_source"] = (f"{os.path.relpath(files[-1], ROOT)}: rocprofv3 --pmc SQ_INSTS_VALU_{{FMA,ADD,MUL,TRANS}}_F64 x 64 lanes "
+                               "(committed counters, not collected in this run); duration measured in this run with HIP events")
+    else:
+        out["achieved"] = out["frac"] = out["traffic"] = None
+        out["flops_source"] = "no committed counters for this configuration (profiles/r*/pmc_counters_gensys.json)"
+    return out
+
+
+def second_order_leg(timeout=900):
+    """BASELINE configs[4] as a leg of the default line: a CHILD process runs `bench.py --workload sw_second_order` (1024 draws)
+    before this process touches the GPU and its JSON line is embedded; None if it fails."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "sw_second_order", "--steps", "3", "--warmup", "1",
+           "--cpu-sample", "0", "--no-extras"]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, check=False)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not line:
+            return {"error": f"child exited with {res.returncode}: {res.stderr[-300:]}"}
+        full = json.loads(line[-1])
+        keep = ("value", "unit", "ms_per_step", "config", "roofline", "full_recursion", "failed_draws", "stage_ms")
+        leg = {k_: full[k_] for k_ in keep if k_ in full}
+        leg["note"] = ("second-order perturbation + pruned-state-space filter, 1024 SW-shaped draws, measured by a child process "
+                       "of this run; the reference has no second-order solver (perturbation.py:97-98 raises): parity UNPINNED "
+                       "against it, checked against oracle/second_order.py by tests/test_gpu_second_order.py")
+        return leg
+    except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
+        return {"error": str(exc)}
+
+
 def spawn_ranks(n_ranks, argv, shared_gpu=False, timeout=None):
     """Start ``n_ranks`` fresh ``python bench.py`` processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
     environment, 127.0.0.1 rendezvous), wait for them and return the worst exit code.  Rank 0 prints the JSON
@@ -350,6 +439,20 @@ def main():
                       f"core) x 1 BLAS thread, {cpu_dt:.1f} s wall",
         }
 
+    # checker samples of the extra legs (rank 0, N = 1, default line only): the oracle with solver = gensys, and with the
+    # observation model of the realistic-structure leg (seven observed JUMP variables) -- also before the GPU is touched
+    want_extras = (world == 1 and not args.no_extras and not args.from_theta and args.workload == "sw_shaped"
+                   and args.solver == "cycle_reduction")
+    cpu_gensys = cpu_jumps = om_j = None
+    if want_extras:
+        om_j = wl.sw_shaped_observation_model(observed=wl.SW_OBSERVED_JUMPS)
+    if want_extras and rank == 0 and args.cpu_sample > 0:
+        n_x = min(hi - lo, max(64, 2 * cores))
+        cpu_gensys = cpu_baseline(shard, om, n_x, cores, solver="gensys")
+        cpu_jumps = cpu_baseline(shard, om_j, n_x, cores)
+
+    so_leg = second_order_leg() if (want_extras and rank == 0) else None
+
     import torch
     import torch.distributed as dist
 
@@ -451,7 +554,7 @@ def main():
     # what data with changing missing-data masks costs, statespace.py:1432-1505) and the reference's default estimation solver
     # (configure(..., solver="gensys"), statespace.py:832).
     extras = {}
-    if world == 1 and not args.no_extras and prog is None and args.workload == "sw_shaped" and args.solver == "cycle_reduction":
+    if want_extras:
         def timed(fn, steps):
             for _ in range(2):
                 fn()
@@ -481,9 +584,41 @@ def main():
                                                    n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g),
                      max(3, args.steps // 2))
         extras["gensys"] = {"value": round(nloc / dt_g, 2), "ms_per_step": round(dt_g * 1e3, 4), "unit": "evals/s",
-                            "note": "same step with solver = gensys (ordered QZ), the reference's default estimation solver",
+                            "note": "same step with solver = gensys (ordered QZ), the reference's default estimation solver "
+                                    "(configure(..., solver='gensys'), statespace.py:832)",
                             "failed_draws": int((st_g != 0).sum().item()),
                             "max_rel_logp_diff_vs_headline": float((torch.abs(lp_g - logp_all[lo:hi]) / torch.abs(lp_g)).max().item())}
+        if cpu_gensys is not None:  # against the ORACLE's gensys (LAPACK's ordered QZ), not against the headline
+            ref_g = cpu_gensys[0]
+            rel_g = np.abs(lp_g[: len(ref_g)].cpu().numpy() - ref_g) / np.abs(ref_g)
+            extras["gensys"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle_gensys": float(rel_g.max()),
+                                          "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_g)),
+                                          "n_checked": int(len(ref_g)),
+                                          "cpu_oracle_gensys_evals_per_s": round(cpu_gensys[1], 2)}
+        extras["gensys"]["roofline"] = gensys_roofline(eng, lambda: eng.solve_kalman_logp(
+            dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter, logp=lp_g, status=st_g,
+            solver="gensys", n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g), nloc, n, nl_g)
+        # realistic observation structure: the seven observed series are JUMP variables (growth rates, inflation, hours in a
+        # Smets-Wouters data set; _make_design_matrix allows any, statespace.py:260-332), so the filter runs on the 18 state
+        # variables + 7 observed ones = 25 (32-wide tile) instead of the 18 of SURVEY 8(d)'s generator (24-wide tile)
+        dZj, dyj, dHj = eng.to_device(om_j["Z"]), eng.to_device(om_j["y"]), eng.to_device(om_j["Hdiag"])
+        hints_j = eng.structure_hints(dA, dZj) if not args.no_hints else (0, 0)
+        lp_j = torch.empty_like(logp_buf)
+        st_j = torch.empty_like(stat_buf)
+        dt_j = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZj, dyj, Hdiag=dHj, q_mode=1, tol=args.tol,
+                                                   max_iter=args.max_iter, logp=lp_j, status=st_j, solver=args.solver,
+                                                   n_state_hint=hints_j[0], z_selector_hint=hints_j[1], options=opts),
+                     max(3, args.steps // 2))
+        extras["observe_jumps"] = {"value": round(nloc / dt_j, 2), "ms_per_step": round(dt_j * 1e3, 4), "unit": "evals/s",
+                                   "note": f"same step, Z selects the non-state variables {list(wl.SW_OBSERVED_JUMPS)}: 25 filtered "
+                                           "variables (18 states + 7 observed jumps), the 32-wide filter tile",
+                                   "failed_draws": int((st_j != 0).sum().item())}
+        if cpu_jumps is not None:
+            ref_j = cpu_jumps[0]
+            rel_j = np.abs(lp_j[: len(ref_j)].cpu().numpy() - ref_j) / np.abs(ref_j)
+            extras["observe_jumps"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel_j.max()),
+                                                 "median_rel_logp_err_vs_cpu_oracle": float(np.median(rel_j)),
+                                                 "n_checked": int(len(ref_j))}
         # the same batch evaluated by TWO callers at once, each on its own stream (two PyMC chains sharing the GPU, or a sampler
         # that splits its particles): the library keeps its scratch per (device, stream); one sequence leaves most of the chip idle
         # while the Kalman launch waits for its never-steady draw, a second one fills that time.  Whole-GPU rate, never `value`.
@@ -503,6 +638,8 @@ def main():
                                  "note": "two independent callers, each evaluating the same batch on its own HIP stream, whole-GPU "
                                          "rate (2 x batch per round); the headline `value` is the ONE-stream figure",
                                  "bit_identical_to_headline": bool(all(torch.equal(x, logp_all[lo:hi]) for x in lp2))}
+        if so_leg is not None:
+            extras["second_order"] = so_leg
         local_eval(0, nloc)  # (leave the buffers as the headline loop left them)
         torch.cuda.synchronize()
 
@@ -790,6 +927,9 @@ def main_second_order(args, world, rank, local_rank):
         flops_filter = float(n_full.sum()) * flops_step
         filt_s = ms[3] * 1e-3
         value = global_batch * args.steps / dt
+        soc = so_counters(f"so_filter_kernel<{mp16 // 16}>", nloc)
+        mfma_frac = flops_filter / filt_s / 1e12 / FP64_PEAK_TFLOPS
+        hbm_frac = (soc["traffic"] / filt_s / 1e9 / HBM_PEAK_GBS) if soc.get("traffic") else None
         out = {
             "metric": "second-order solve + pruned-state-space Kalman-logp evals/sec, Smets-Wouters-shaped n=40 T=200",
             "value": round(value, 2), "unit": "evals/s", "n_gpus": world,
@@ -809,13 +949,17 @@ def main_second_order(args, world, rank, local_rank):
             },
             "roofline": {
                 "kernel": f"dsge::so_filter_kernel<{mp16 // 16}> (512 threads per draw; v_mfma_f64_16x16x4_f64 on {mp16 // 16} x {mp16 // 16} tiles)",
-                "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                # the bound is read off the counters: whichever of the two fractions is larger (committed HBM traffic over the
+                # duration measured here vs useful matrix-core flops over the same duration)
+                "bound": "hbm" if (hbm_frac is not None and hbm_frac > mfma_frac) else "mfma",
+                "hbm_frac": round(hbm_frac, 4) if hbm_frac is not None else None, "mfma_frac": round(mfma_frac, 4),
+                "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
                 "achieved": round(flops_filter / filt_s / 1e12, 3),
                 "frac": round(flops_filter / filt_s / 1e12 / FP64_PEAK_TFLOPS, 5),
                 "flops_source": f"2 m^3 (W' = P Az') + m^2 (m + 1) (the symmetric X = W Az', upper half only) with m = {m}, unpadded, per "
                                 f"full filter step x the measured number of full steps per draw (mean {n_full.mean():.1f} of {T_len}); "
                                 "duration: HIP events around the kernel in this run",
-                **so_counters(f"so_filter_kernel<{mp16 // 16}>", nloc),
+                **soc,
                 "stage_ms": {"first_order_solver": round(ms[0], 3), "second_order_setup": round(ms[1], 3),
                              "stationary_covariance": round(ms[2], 3), "filter": round(ms[3], 3)},
                 "full_steps_mean": float(n_full.mean()), "never_steady": int((at_h < 0).sum()),

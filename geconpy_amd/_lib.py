@@ -98,6 +98,7 @@ PROTOTYPES = {
     "dsge_debug_kalman_phases": [_i, _dp],
     "dsge_debug_gensys_window_phases": [_i, _dp],
     "dsge_debug_gensys_phases": [_dp, _dp, _dp, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
+    "dsge_debug_gensys_stage_ms": [_i, _dp],
     "dsge_selection_batched": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp],
     "dsge_selection_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp],
     "dsge_policy_adjoints_batched": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _dp, _dp],

@@ -896,10 +896,10 @@ int dsge_second_order_logp_batched(const double* A, const double* B, const doubl
   double* Rw = R_out ? R_out : cv.take<double>(nk);
   int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);
   int32_t* it_w = cv.take<int32_t>((size_t)batch);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  EventGuard e0, e1;  // (destroyed on every return path)
   if (stage_ms) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(e0.create());
+    HIP_TRY(e1.create());
     HIP_TRY(hipEventRecord(e0, st));
   }
   if (solver == DSGE_SOLVER_CYCLE_REDUCTION) {
@@ -921,8 +921,6 @@ int dsge_second_order_logp_batched(const double* A, const double* B, const doubl
   if (stage_ms) {
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipEventElapsedTime(&stage_ms[0], e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
   }
   return DSGE_SUCCESS;
 }
@@ -1248,6 +1246,19 @@ int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, 
 
 // Debug hook: enable = 1 allocates the stamp buffer of the window kernels (draw 0 of each launch: reduce [0..4], QZ [8..11],
 // eu [16..19], post [20..26]); cycles_out (host int64[32], may be NULL) reads it back; enable = 0 frees it.
+int dsge_debug_gensys_stage_ms(int enable, float* ms_out) {
+  static float stage[8];
+  if (ms_out)
+    for (int i = 0; i < 8; ++i) ms_out[i] = stage[i];
+  if (enable) {
+    for (float& x : stage) x = 0.f;
+    g_gensys_stage_ms = stage;
+  } else {
+    g_gensys_stage_ms = nullptr;
+  }
+  return DSGE_SUCCESS;
+}
+
 int dsge_debug_gensys_window_phases(int enable, long long* cycles_out) {
   int rc = ensure_device();
   if (rc) return rc;
@@ -1510,8 +1521,17 @@ int dsge_second_order_logp_batched_host(const double* A, const double* B, const 
   if (rc) return rc;
   if (k < 1 || k > n || p < 1 || p > 8 || T_len < 0 || nnz < 0 || n_state < 1 || n_state > 24)
     return fail(DSGE_ERR_INVALID, "second order: size out of range");
-  if (!A || !B || !C || !D || (nnz > 0 && (!hess_idx || !hess_val)) || !q || !Z || !y || !logp_out || !status_out)
+  if (!A || !B || !C || !D || (nnz > 0 && (!hess_idx || !hess_val)) || !q || !Z || !y || !logp_out || !status_out ||
+      !state_idx || !ret_idx || (n_lead > 0 && !lead_idx))
     return fail(DSGE_ERR_INVALID, "null pointer");
+  // the structure arguments are host arrays here as in the device entry point: validated BEFORE anything is staged
+  if (n_lead < 0 || n_lead > n || n_ret < n_state || n_ret > n) return fail(DSGE_ERR_INVALID, "second order: n_lead / n_ret out of range");
+  for (int i = 0; i < n_state; ++i)
+    if (state_idx[i] < 0 || state_idx[i] >= n) return fail(DSGE_ERR_INVALID, "state_idx out of range");
+  for (int i = 0; i < n_lead; ++i)
+    if (lead_idx[i] < 0 || lead_idx[i] >= n) return fail(DSGE_ERR_INVALID, "lead_idx out of range");
+  for (int i = 0; i < n_ret; ++i)
+    if (ret_idx[i] < 0 || ret_idx[i] >= n) return fail(DSGE_ERR_INVALID, "ret_idx out of range");
   if ((rc = ensure_device())) return rc;
   hipStream_t tw_st = nullptr, tw_st1 = nullptr;
   if ((rc = twin_streams(&tw_st, &tw_st1))) return rc;

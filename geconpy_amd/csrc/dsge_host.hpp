@@ -55,6 +55,19 @@ void stream_arenas_release(hipStream_t st);  // every pool of the library (dsge_
 // arenas released -- when the thread exits): two host threads in two twins never share a stream, hence never an arena.
 int twin_streams(hipStream_t* s0, hipStream_t* s1);
 
+// hipEvent_t that destroys itself: stage-timing events must not leak on the early returns of HIP_TRY
+struct EventGuard {
+  hipEvent_t e = nullptr;
+  EventGuard() = default;
+  EventGuard(const EventGuard&) = delete;
+  EventGuard& operator=(const EventGuard&) = delete;
+  ~EventGuard() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  hipError_t create() { return hipEventCreate(&e); }
+  operator hipEvent_t() const { return e; }
+};
+
 inline int tile_bs(int n) {
   int bs = (n + 7) / 8;
   return bs < 1 ? 1 : bs;
@@ -167,6 +180,7 @@ extern long long* g_so_dbg;            // launch_second_order.hip: debug phase c
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
 extern long long* g_kalman_dbg;       // launch_kalman.hip: debug buffer for per-phase cycles of draw 0
 extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[32])
+extern float* g_gensys_stage_ms;      // launch_gensys.hip: debug, host float[8]: launch durations of the window path (dsge_debug_gensys_stage_ms)
 extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first steady step per draw (-1 = never)
 
 // Kernel-variant switches.  They are PER CALL: the *_opt entry points carry a dsge_options, which an RAII guard installs

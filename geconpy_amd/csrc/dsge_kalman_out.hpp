@@ -44,8 +44,13 @@ __global__ __launch_bounds__(KO_THREADS) void kalman_outputs_kernel(KoArgs a) {
   const int tid = threadIdx.x, draw = blockIdx.x, m = a.m, p = a.p, mm = m * m;
   if (draw >= a.batch) return;
   double* ll_o = a.ll + (size_t)draw * a.T_len;
-  if (a.status[draw] != 0) {  // failed solve upstream: no filter (NaN outputs, like a -inf logp)
+  if (a.status[draw] != 0) {  // failed solve upstream: no filter -- EVERY requested output of the draw is NaN (like a -inf logp)
     for (int t = tid; t < a.T_len; t += NT) ll_o[t] = NAN;
+    const size_t nv = (size_t)a.T_len * m, nc = a.full_cov ? nv * m : nv;
+    if (a.a_pred) for (size_t i = tid; i < nv; i += NT) a.a_pred[(size_t)draw * nv + i] = NAN;
+    if (a.a_filt) for (size_t i = tid; i < nv; i += NT) a.a_filt[(size_t)draw * nv + i] = NAN;
+    if (a.p_pred) for (size_t i = tid; i < nc; i += NT) a.p_pred[(size_t)draw * nc + i] = NAN;
+    if (a.p_filt) for (size_t i = tid; i < nc; i += NT) a.p_filt[(size_t)draw * nc + i] = NAN;
     return;
   }
   double* pl = smem;

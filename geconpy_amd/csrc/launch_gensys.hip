@@ -12,7 +12,8 @@ namespace dsge_host {
 
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 
-long long* g_gensys_win_dbg = nullptr;  // debug: device int64[32], phase stamps of draw 0 of the window kernels
+long long* g_gensys_win_dbg = nullptr;
+float* g_gensys_stage_ms = nullptr;  // debug: host float[8]; when set, the window path times its launches with HIP events (synchronising)  // debug: device int64[32], phase stamps of draw 0 of the window kernels
 
 namespace {
 // One workspace per (device, stream) (StreamArenaPool): the chunked host path keeps two pipelines in flight on two streams, and
@@ -103,6 +104,10 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   }
   dsge::GwCaps cp;
   cp.n = n;
+  // n_lead_hint is a promise (include/dsge_hip.h: "upper bound on the number of lead columns"): a draw with more lead columns
+  // than the caller's bound is flagged DSGE_ST_GENSYS_TOO_BIG -- by the single-launch kernel, by the window path with a fresh
+  // record and by the window path with a cached one alike
+  if (n_lead_hint > 0 && shape[0] > n_lead_hint) shape[0] = n_lead_hint;
   cp.lcap = shape[0] < 1 ? 1 : shape[0];
   cp.wcap = shape[1] < 1 ? 1 : shape[1];
   cp.zcap = shape[2] < 1 ? 1 : shape[2];
@@ -129,14 +134,26 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   if (pairs && (rc = set_lds(dsge::gensys_sweeps_pair_kernel<37>, lds_pair))) return rc;
   if (pairs && (rc = set_lds(dsge::gensys_sweeps_pair_kernel<39>, lds_pair))) return rc;
   const size_t nn = (size_t)n * n;
+  // stage timing (dsge_debug_gensys_stage_ms): events between the launches of the FIRST chunk
+  float* const stage_ms = bk ? nullptr : g_gensys_stage_ms;
+  EventGuard ev[8];
+  if (stage_ms)
+    for (auto& e : ev) HIP_TRY(e.create());
+#define GW_EVENT(i)                                          \
+  do {                                                       \
+    if (stage_ms && c0 == 0) HIP_TRY(hipEventRecord(ev[i], st)); \
+  } while (0)
   for (size_t c0 = 0; c0 < (size_t)batch; c0 += chunk) {
     const int nb = (int)((c0 + chunk <= (size_t)batch) ? chunk : (size_t)batch - c0);
+    GW_EVENT(0);
     // two wavefronts per draw: the reflectors' columns in two shares (measured: 595 us per 4096 SW-shaped draws on one wavefront,
     // 499 us on two, 548 us on four -- the chain is the walk down the rows, which more column shares do not shorten)
     hipLaunchKernelGGL(dsge::gensys_reduce_kernel<2>, dim3(nb), dim3(128), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
                        cp, tol, wsp, g_gensys_win_dbg, obs_d);
+    GW_EVENT(1);
     if (pairs) {
       hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0);
+      GW_EVENT(2);
       if (dsge::gp_ld(cp) == 37)
         hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<37>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,
                            g_gensys_win_dbg);
@@ -147,17 +164,36 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
       hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg,
                          opt().gensys_real_stage);
     }
+    if (!pairs) GW_EVENT(2);
+    GW_EVENT(3);
     hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg);
+    GW_EVENT(4);
     if (bk)
       hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,
                          bk->re + c0 * 2 * n, bk->im + c0 * 2 * n, bk->n_eig + c0, bk->n_forward + c0,
                          bk->n_unstable + c0, status + c0);
     else {
       hipLaunchKernelGGL(dsge::gensys_eu_kernel, dim3(nb), dim3(64), lds_eu, st, nb, cp, tol, wsp, g_gensys_win_dbg);
+      GW_EVENT(5);
       hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(dsge::GW_POST_THREADS), lds3, st, nb, cp, tol, (const double*)wsp,
                          T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg, cached ? 1 : 0);
     }
+    GW_EVENT(6);
     HIP_TRY(hipGetLastError());
+  }
+#undef GW_EVENT
+  if (stage_ms) {  // [0] reduce, [1] Hessenberg-triangular, [2] real sweeps (pair launch; 0 without it), [3] complex QZ + reordering,
+                   // [4] eu (or bk), [5] post, [6] = sum, [7] = draws timed
+    HIP_TRY(hipEventSynchronize(ev[6]));
+    float tot = 0.f;
+    for (int i = 0; i < 6; ++i) {  // event i is recorded in front of stage i, event 6 behind the post launch
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      stage_ms[i] = t;
+      tot += t;
+    }
+    stage_ms[6] = tot;
+    stage_ms[7] = (float)(chunk < (size_t)batch ? chunk : (size_t)batch);
   }
   if (obs_d) HIP_TRY(hipMemcpyAsync(obs_h, obs_d, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   if (cached) {

@@ -20,9 +20,9 @@ int launch_so_mt(const dsge::SoFilterArgs& fa, const dsge::SoLayout& lay, int nb
   const size_t lds = dsge::SoFilterSmem<MT>::bytes;
   if ((rc = set_lds(dsge::so_lyap_kernel<MT>, lds))) return rc;
   if ((rc = set_lds(dsge::so_filter_kernel<MT>, lds))) return rc;
-  hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+  EventGuard e[3];
   if (ms)
-    for (auto& x : e) HIP_TRY(hipEventCreate(&x));
+    for (auto& x : e) HIP_TRY(x.create());
   if (ms) HIP_TRY(hipEventRecord(e[0], st));
   hipLaunchKernelGGL(dsge::so_lyap_kernel<MT>, dim3(nb), dim3(dsge::SO_THREADS), lds, st, fa, lay);
   HIP_TRY(hipGetLastError());
@@ -32,9 +32,11 @@ int launch_so_mt(const dsge::SoFilterArgs& fa, const dsge::SoLayout& lay, int nb
   if (ms) {
     HIP_TRY(hipEventRecord(e[2], st));
     HIP_TRY(hipEventSynchronize(e[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], e[0], e[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], e[1], e[2]));
-    for (auto& x : e) (void)hipEventDestroy(x);
+    float t1 = 0.f, t2 = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t1, e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(&t2, e[1], e[2]));
+    ms[1] += t1;  // accumulated over the chunks of a call (launch_second_order zeroes them)
+    ms[2] += t2;
   }
   return DSGE_SUCCESS;
 }
@@ -48,7 +50,8 @@ int so_tiles(int m) {  // kernel instances built: 2, 4, 7, 10, 13 tiles of 16 pe
 }
 
 // T, R: first-order solution (device, [batch][n][n], [batch][n][k]); status_io: draws with a non-zero status are skipped
-// (logp = -inf).  ms (nullable): durations of the three stages of the LAST chunk in milliseconds (synchronises).
+// (logp = -inf).  ms (nullable): durations of the three stages in milliseconds, summed over ALL workspace chunks of the call
+// (synchronises after every chunk).
 int launch_second_order(const double* B, const double* C, const double* T, const double* R, const int32_t* hess_idx, int nnz,
                         const double* hess_val, const double* q, int q_batched, const double* Z, const double* d,
                         const double* Hdiag, const double* y, int batch, int n, int k, int p, int T_len, double jitter,
@@ -95,6 +98,7 @@ int launch_second_order(const double* B, const double* C, const double* T, const
   hipLaunchKernelGGL(dsge::so_design_kernel, dim3(1), dim3(256), 0, st, Z, p, n, ix, u, Zu, flags);
   HIP_TRY(hipGetLastError());
   if ((rc = set_lds(dsge::so_setup_kernel, lds_setup))) return rc;
+  if (ms) ms[0] = ms[1] = ms[2] = 0.f;
   for (int c0 = 0; c0 < batch; c0 += chunk) {
     const int nb = std::min(chunk, batch - c0);
     dsge::SoSetupArgs sa{};
@@ -122,11 +126,11 @@ int launch_second_order(const double* B, const double* C, const double* T, const
       if ((rc = launch_persistence_key(T + (size_t)c0 * n * n, status_io + c0, nb, n, key, st))) return rc;
       sa.order_key = key;
     }
-    const bool time_it = ms && c0 + chunk >= batch;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool time_it = ms != nullptr;
+    EventGuard e0, e1;
     if (time_it) {
-      HIP_TRY(hipEventCreate(&e0));
-      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(e0.create());
+      HIP_TRY(e1.create());
       HIP_TRY(hipEventRecord(e0, st));
     }
     hipLaunchKernelGGL(dsge::so_setup_kernel, dim3(nb), dim3(dsge::SO_SETUP_THREADS), lds_setup, st, sa, lay);
@@ -169,9 +173,9 @@ int launch_second_order(const double* B, const double* C, const double* T, const
     }
     if (rc) return rc;
     if (time_it) {
-      HIP_TRY(hipEventElapsedTime(&ms[0], e0, e1));
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
+      float t0 = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t0, e0, e1));
+      ms[0] += t0;
     }
   }
   return DSGE_SUCCESS;

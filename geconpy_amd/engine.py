@@ -252,17 +252,18 @@ class LogpEngine:
         zb = int(self._chk(Z).dim() == 3)
         db = int(d is not None and self._chk(d).dim() == 2)
         hb = int(Hdiag is not None and self._chk(Hdiag).dim() == 2)
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.device)  # noqa: E731
         if out is None:
-            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.device)  # noqa: E731
             out = dict(logp=mk(nb), status=torch.empty(nb, dtype=torch.int32, device=self.device), A_bar=mk(nb, n, n),
                        B_bar=mk(nb, n, n), C_bar=mk(nb, n, n), D_bar=mk(nb, n, k),
                        q_bar=mk(nb, k, k) if full_covariance else mk(nb, k))
-            if d is not None:
-                out["d_bar"] = mk(nb, p)
-            if Hdiag is not None:
-                out["h_bar"] = mk(nb, p)
-            if dense_z:
-                out["Z_bar"] = mk(nb, p, n)
+        # buffers this call needs that a reused ``out`` (from a call with another observation model) does not carry yet
+        if d is not None and "d_bar" not in out:
+            out["d_bar"] = mk(nb, p)
+        if Hdiag is not None and "h_bar" not in out:
+            out["h_bar"] = mk(nb, p)
+        if dense_z and "Z_bar" not in out:
+            out["Z_bar"] = mk(nb, p, n)
         if dense_z:
             with _lib.options_scope(options):
                 _lib.check(

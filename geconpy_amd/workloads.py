@@ -153,19 +153,26 @@ def sw_shaped_batch(batch, first_draw=0, seed0=SW_SEED0, **shape):
     return dict(A=A, B=B, C=C, D=D, T_star=Tst, sigma=sig)
 
 
-def sw_shaped_observation_model(seed0=SW_SEED0, **shape):
-    """Shared pieces: Z selects variables 0..p-1, H = diag(1e-4), and one data panel
-    ``y`` (T_len x p) simulated from draw 0's solution ``x_t = T* x_{t-1} + R e_t``
-    (R = [I_k; 0] by construction) plus measurement noise."""
+SW_OBSERVED_JUMPS = (19, 22, 25, 27, 30, 33, 37)  # seven NON-state variables (18..39), four of them forward-looking (28..39)
+
+
+def sw_shaped_observation_model(seed0=SW_SEED0, observed=None, **shape):
+    """Shared pieces: Z selects variables 0..p-1 (``observed``: any other p variables, e.g. ``SW_OBSERVED_JUMPS`` --
+    a Smets-Wouters data set observes growth rates, inflation, hours: jump variables, ``_make_design_matrix`` allows any,
+    statespace.py:260-332), H = diag(1e-4), and one data panel ``y`` (T_len x p) simulated from draw 0's solution
+    ``x_t = T* x_{t-1} + R e_t`` (R = [I_k; 0] by construction) plus measurement noise."""
     sh = dict(SW_SHAPE)
     sh.update(shape)
     n, k, p, T_len = sh["n"], sh["k"], sh["p"], sh["T_len"]
+    obs = np.arange(p) if observed is None else np.asarray(observed, dtype=np.int64)
+    if obs.shape != (p,) or obs.min() < 0 or obs.max() >= n or len(set(obs.tolist())) != p:
+        raise ValueError(f"observed must name {p} distinct variables in 0..{n - 1}")
     d0 = sw_shaped_batch(1, 0, seed0, **shape)
     T_star = d0["T_star"][0]
     sig = d0["sigma"][0]
     rng = np.random.default_rng((seed0, 2))
     Z = np.zeros((p, n))
-    Z[np.arange(p), np.arange(p)] = 1.0
+    Z[np.arange(p), obs] = 1.0
     Hdiag = np.full(p, 1e-4)
     x = np.zeros(n)
     y = np.empty((T_len, p))
@@ -294,7 +301,9 @@ def sw_second_order_batch(batch, first_draw=0, seed0=SW_SEED0, **shape):
     ``default_rng((seed0 + i, 4))``): entries ~ N(0, 1).  -> the dict of ``sw_shaped_batch`` with ``hess_idx`` (nnz, 3) int32
     and ``hess_val`` (batch, nnz)."""
     b = sw_shaped_batch(batch, first_draw, seed0, **shape)
-    idx = second_order_hessian_pattern(b["A"][0] if batch else None, b["C"][0], b["D"].shape[2])
+    # (the pattern is a property of the model, not of a draw: an empty batch takes it from the first draw of the family)
+    pat = b if batch else sw_shaped_batch(1, first_draw, seed0, **shape)
+    idx = second_order_hessian_pattern(pat["A"][0], pat["C"][0], pat["D"].shape[2])
     val = np.empty((batch, len(idx)))
     for j in range(batch):
         val[j] = np.random.default_rng((seed0 + first_draw + j, 4)).standard_normal(len(idx))

@@ -35,6 +35,19 @@ extern "C" {
 
 #define DSGE_ABI_VERSION 7
 
+/* The process-wide dsge_set_* switches below are DEPRECATED since ABI 7: they edit defaults shared by every host thread and
+ * every stream of the process, which is exactly what a library called from several PyMC chains must not have.  Use the per-call
+ * dsge_options struct -- the *_opt entry points, or dsge_options_push / dsge_options_pop around any entry point on the calling thread --:
+ * every switch is a field of that struct, and new switches (gensys_pairs, gensys_shape_cache) exist ONLY there.  The setters
+ * stay exported for existing callers and will go away with the next ABI break; the library and its tests no longer call them
+ * (two exceptions in the tests: dsge_set_cr_deflation, whose side effect -- forgetting the measured number of static variables --
+ * has no per-call equivalent, and dsge_set_kalman_steady_tol's range check). */
+#if defined(__GNUC__) || defined(__clang__)
+#define DSGE_DEPRECATED __attribute__((deprecated("process-wide default: use the per-call dsge_options struct")))
+#else
+#define DSGE_DEPRECATED
+#endif
+
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
 #define DSGE_MAX_N_CR 64
@@ -173,13 +186,13 @@ int dsge_options_pop(void);
  * detected per draw on the device; zero columns only ever contribute +0.0, so T is bit-identical) whenever
  * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every
  * draw (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
-int dsge_set_cr_compact(int enable);
+DSGE_DEPRECATED int dsge_set_cr_compact(int enable);
 /* In the fused entry points with solver = cycle_reduction and no residual requested, R = -(C T + B)^-1 D is taken
  * from the final elimination of cycle reduction: T = -A1_hat^-1 A and A1_hat -> B + C T (the difference is of the
  * order of the product of the last iterate's norms, < tol^2), so R = -A1_hat^-1 D comes out of the same Gauss-Jordan
  * sweep (agreement with the explicit formula ~1e-13 relative, tests/test_gpu_parity.py).  enable = 0 always uses the
  * explicit formula in the assemble kernel.  Process-wide DEFAULT (per call: dsge_options); default 1. */
-int dsge_set_cr_fused_selection(int enable);
+DSGE_DEPRECATED int dsge_set_cr_fused_selection(int enable);
 /* Debug hook: enable != 0 makes the compact cycle-reduction kernel record the shader cycles draw 0 spends in
  * [0] Gauss-Jordan panels, [1] trailing updates, [2] row gather + staging, [3] products, [4] scatter/updates/
  * norms, [5] the final solve, [6] total, [7] = iterations; cycles_out (host int64[8], may be NULL). */
@@ -297,29 +310,29 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
  * recursion of pymc_extras' "standard" filter step for step); the default 1e-14 is rounding level:
  * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  Process-wide DEFAULT (per call: dsge_options).  tol in [0, 1e-6].
  */
-int dsge_set_kalman_steady_tol(double tol);
+DSGE_DEPRECATED int dsge_set_kalman_steady_tol(double tol);
 /* Small models (selector Z, p <= 3, at most 6 filtered variables) are filtered by a thread-per-draw kernel that keeps
  * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
  * wave-per-draw kernels (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
-int dsge_set_kalman_tiny(int enable);
+DSGE_DEPRECATED int dsge_set_kalman_tiny(int enable);
 /* Selector design matrix, p <= 8: the two prediction products of a full filter step run in "NT" form on 16-byte aligned
  * rows (W stored transposed, even leading dimension, one ds_read_b128 per two k-steps, stages of four k-steps double-
  * buffered; dsge_kalman_nt.hpp): 15.2 k -> 12.6 k cycles per full step on the 18-variable bench model.  enable = 0 keeps
  * the round-1 kernel (kalman_sel_kernel); same arithmetic up to the summation order of the products (tests compare them).
  * Process-wide DEFAULT (per call: dsge_options); default 1. */
-int dsge_set_kalman_nt_products(int enable);
+DSGE_DEPRECATED int dsge_set_kalman_nt_products(int enable);
 /* Static-variable deflation (dsge_set_cr_deflation) as ONE launch: QR of the static columns, cycle reduction on the reduced
  * system and the back-substitution of the static rows in a single kernel, the reduced system handed over through LDS
  * (dsge_cr_fused.hpp) instead of three launches with the reduced A, B, C, D, T, R in global memory.  Taken when
  * h + 3 (n - h) + k <= 128 and (n - h) + k <= 64; otherwise, and with enable = 0, the three launches run.  Same results
  * (the arithmetic is the same code).  Process-wide DEFAULT (per call: dsge_options); default 1. */
-int dsge_set_cr_fused_deflation(int enable);
+DSGE_DEPRECATED int dsge_set_cr_fused_deflation(int enable);
 /* Cycle reduction on systems of 49..64 variables (after the deflation, if any) runs on FOUR wavefronts per draw
  * (cr_wide_kernel, dsge_cr_wide.hpp: 16 x 16 threads with 4 x 4 register blocks, the panel factorisation on one of the
  * wavefronts) instead of one wavefront with 7 x 7 / 8 x 8 blocks that spill.  enable = 0 keeps the one-wavefront kernels
  * (same algorithm; the norms of the stopping rule are summed in a different order).  Process-wide DEFAULT (per call:
  * dsge_options); default 1. */
-int dsge_set_cr_four_waves(int enable);
+DSGE_DEPRECATED int dsge_set_cr_four_waves(int enable);
 /* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
  * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
  * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by
@@ -327,11 +340,11 @@ int dsge_set_cr_four_waves(int enable);
  * h is measured once per model size (a small launch and a 4-byte read-back on the first call) and verified per draw; a
  * draw with fewer static variables is solved by the full-size kernels.  Not used when the caller asks for the iteration
  * counts or the policy residual.  enable = 0 switches it off and forgets the measured sizes.  Default on.  Process-wide DEFAULT (per call: dsge_options). */
-int dsge_set_cr_deflation(int enable);
+DSGE_DEPRECATED int dsge_set_cr_deflation(int enable);
 /* Column-compact cycle reduction on the 32-wide tile (n or n - h in 25..32): the kernel instance built for two waves per SIMD
  * (256 registers + 528 B of scratch instead of 369 registers): same arithmetic, bit-identical results, 10 % faster.
  * enable = 0 launches the one-wave instance.  Default on.  Process-wide DEFAULT (per call: dsge_options). */
-int dsge_set_cr_two_waves(int enable);
+DSGE_DEPRECATED int dsge_set_cr_two_waves(int enable);
 /* Fused evaluation: the workgroups of the Kalman launch (and of the gradient path's reverse-sweep launch) are dispatched in
  * descending order of a per-draw key (a counting sort on the device).  The launch's makespan is set by its slowest draws --
  * a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for up to T_len
@@ -339,41 +352,41 @@ int dsge_set_cr_two_waves(int enable);
  * SW-shaped draws).  mode 1 (default): key = the draw's cycle-reduction iteration count (free; both grow with the persistence
  * of the model), for the other solvers a spectral-radius estimate of T (24 power-iteration steps, persistence_key_kernel);
  * mode 2: always the latter; mode 0: index order.  Results are unaffected: every draw writes its own logp / status. */
-int dsge_set_kalman_order(int mode);
+DSGE_DEPRECATED int dsge_set_kalman_order(int mode);
 /* dsge_solve_kalman_logp_batched (device pointers) runs batches of >= 1024 draws as n_chunks chunks alternating over two
  * library-owned streams, forked from and joined to the caller's stream by events, so that the straggler tail of one
  * chunk's Kalman launch (a draw whose covariance recursion converges late keeps one wavefront busy for up to T_len full
  * steps) overlaps the solver launch of the next chunk.  Results are identical (the kernels are per-draw).  n_chunks < 2:
  * one pass on the caller's stream (the default: on MI355X the chunks' launches did not overlap enough to pay for the
  * extra straggler tails).  Process-wide DEFAULT (per call: dsge_options). */
-int dsge_set_pipeline_chunks(int n_chunks);
+DSGE_DEPRECATED int dsge_set_pipeline_chunks(int n_chunks);
 /* Experimental, OFF by default: once the covariance is frozen and the missing-data mask of the shared panel no longer
  * changes, the fast Kalman kernel hands the rest of the sample to kalman_tail_kernel, which runs the (then linear) mean
  * recursion two steps at a time as one matrix-vector product [R v_t; R v_{t+1}; a_{t+2}] = M [a_t; c_t; c_{t+1}], R'R = F^-1,
  * rows in registers.  It removes a quarter of the kernel's work but not its makespan, which is set by the draws that reach
  * the steady state late or never -- measured 3.14 vs 2.85 ms per 4096 draws with the launch's extra 0.26 ms (DESIGN.md
  * 4.3).  enable = 1 switches it on (tests compare both: same logp to 1e-12).  Process-wide DEFAULT (per call: dsge_options). */
-int dsge_set_kalman_block(int enable);
+DSGE_DEPRECATED int dsge_set_kalman_block(int enable);
 /* gensys runs as five launches on the active window of the pencil -- structural deflation; real Hessenberg-triangular
  * reduction and complex QZ + reordering on the (N - z) x (N - z) block the deflation leaves, with H and T sharing one LDS
  * array and the accumulated right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing --
  * 4 / 6 / 6-7 / 10 / 2 draws per CU instead of 1 at N = 52.  enable = 1
  * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
  * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
-int dsge_set_gensys_split(int enable);
+DSGE_DEPRECATED int dsge_set_gensys_split(int enable);
 /* Window path of gensys: implicit double-shift QZ sweeps in REAL arithmetic (Moler-Stewart) at the end of the
  * Hessenberg-triangular launch, in front of the complex single-shift iteration that reproduces zhgeqz's logic (which then only
  * splits the remaining 2 x 2 blocks).  An accelerator: every step is an orthogonal equivalence, T and eu are the same to
  * rounding (test_gensys_real_stage_matches_complex_only).  enable = 0: complex iteration only (round 1-2 behaviour).
  * Process-wide DEFAULT (per call: dsge_options.gensys_real_stage); default 1. */
-int dsge_set_gensys_real_stage(int enable);
+DSGE_DEPRECATED int dsge_set_gensys_real_stage(int enable);
 /* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
  * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
  * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
  * per 4096-draw step) -- FP64 MFMA has the VALU's peak rate on gfx950, the 18-wide reduced model does not fill a
  * 16 x 16 fragment, and the accumulator + operand registers push the 256-VGPR kernel into spills.
  * enable = 1 switches it on (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
-int dsge_set_kalman_mfma(int enable);
+DSGE_DEPRECATED int dsge_set_kalman_mfma(int enable);
 double dsge_get_kalman_steady_tol(void);
 /* Debug hook: device int32[batch] that later fast-path Kalman launches (and the second-order filter) fill with the first
  * time step that ran in steady-state mode (-1 = never); NULL stops recording. */
@@ -394,6 +407,12 @@ int dsge_debug_gensys_phases(const double* A, const double* B, const double* C, 
  * post [20..26] = start, loaded, rhs, back-substitution, products, non-state rows, T written; [12], [13] = sweep steps and
  * sweeps, accumulated); cycles_out: host int64[32] or NULL. */
 int dsge_debug_gensys_window_phases(int enable, long long* cycles_out);
+/* Debug hook: enable != 0 makes every later window-path gensys call (of any host thread: debugging only) time its launches
+ * with HIP events on the caller's stream -- the call then synchronises -- into an internal record; ms_out (host float[8] or
+ * NULL) receives the record of the last such call BEFORE `enable` takes effect: [0] structural deflation (reduce),
+ * [1] Hessenberg-triangular reduction, [2] real double-shift sweeps (the two-draws-per-wavefront launch; ~0 when the sweeps run
+ * inside [1]), [3] complex QZ + reordering, [4] existence / uniqueness, [5] post-processing, [6] their sum, [7] draws timed. */
+int dsge_debug_gensys_stage_ms(int enable, float* ms_out);
 
 /*
  * Shock-impact matrix and policy residual.  Replaces pt_compute_selection_matrix
@@ -544,7 +563,9 @@ int dsge_kalman_logp_batched_host(const double* T, const double* R, const double
  *   a_pred_out : [batch][T_len][m]   a_{t|t-1} (a_{0|-1} = 0)          a_filt_out : [batch][T_len][m]  a_{t|t}
  *   p_pred_out, p_filt_out : full_cov = 0: [batch][T_len][m] the DIAGONALS of P_{t|t-1}, P_{t|t};
  *                            full_cov != 0: [batch][T_len][m][m] the matrices;  every output except ll_out may be NULL
- *   status_io  : [batch] in/out; a draw with a non-zero incoming status is skipped (ll = NaN)
+ *   status_io  : [batch] in/out; a draw with a non-zero incoming status is skipped: EVERY requested output of it is NaN (ll and
+ *                the states / covariances); a filter that goes non-finite sets DSGE_ST_FILTER_NONFINITE and leaves the values of
+ *                the steps up to that point
  */
 int dsge_kalman_filter_outputs_batched(const double* T, const double* R, const double* Q, int q_mode, const double* Z,
                                        int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,

@@ -47,6 +47,8 @@ from .shared import (  # noqa: F401
     solve_policy_function_with_backward_direct,
 )
 from .statespace import (  # noqa: F401
+    DEFAULT_CONVENTIONS,
+    FilterConventions,
     JITTER_DEFAULT,
     MISSING_FILL,
     autocorrelation_matrices,

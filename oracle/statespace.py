@@ -1,6 +1,8 @@
 """Oracle restatement of the state-space assembly + Kalman log-likelihood
 (TEST INFRASTRUCTURE ONLY).  *** The recursion is pinned against statsmodels (jitter = 0, complete data:
-tests/golden/statsmodels_kalman.npz); the pymc_extras conventions below are restated and UNPINNED. ***
+tests/golden/statsmodels_kalman.npz); the pymc_extras conventions below are restated and UNPINNED ("parity unpinned") until
+tests/golden/pymc_extras_kalman.npz exists: tests/golden/make_pymc_extras_golden.py produces it on any machine with
+pymc_extras, tests/test_oracle_kalman.py::test_pymc_extras_pin consumes it, ``FilterConventions`` holds the switches. ***
 
 Reference call sites (gEconpy):
   * ``P0 = solve_discrete_lyapunov(T_aug, R Q R', method="bilinear")`` statespace.py:814-815
@@ -38,6 +40,37 @@ MISSING_FILL = -9999.0  # pymc_extras.statespace.utils.constants.MISSING_FILL
 _LN2PI = np.log(2.0 * np.pi)
 
 
+class FilterConventions:
+    """The third-party conventions of the "standard" filter that this oracle RESTATES and cannot pin in this image
+    (pymc_extras is not installed).  Every field is a switch, so that the day a real install produces
+    tests/golden/pymc_extras_kalman.npz (tests/golden/make_pymc_extras_golden.py) a mismatch is a one-line change of
+    ``DEFAULT_CONVENTIONS`` here -- tests/test_oracle_kalman.py::test_pymc_extras_pin then names the combination that matches --
+    and of the constants it maps to in the kernels ("filter conventions": the ``p ln 2pi`` term is
+    ``ll_const`` in dsge_kalman_nt.hpp / dsge_kalman2.hpp / dsge_kalman_tiny.hpp / dsge_kernels.hpp, the jitter placement the two
+    ``jit`` additions of the measurement update).
+
+      ll_constant     "p": p ln 2pi with p the FULL observation dimension, also under missing entries (restated default);
+                      "observed": (#observed entries) ln 2pi;  "one": a single ln 2pi (older upstream ``StandardFilter.update``)
+      jitter_on_F     jitter I added to F = Z P Z' + H
+      jitter_on_P     jitter I added to the filtered covariance P+
+      mask_d          observation intercept zeroed on missing entries (default: d is NOT masked)
+      joseph          Joseph-form covariance update (default) instead of P+ = P - K F K'
+    """
+
+    def __init__(self, ll_constant="p", jitter_on_F=True, jitter_on_P=True, mask_d=False, joseph=True):
+        if ll_constant not in ("p", "observed", "one"):
+            raise ValueError(ll_constant)
+        self.ll_constant, self.jitter_on_F, self.jitter_on_P = ll_constant, bool(jitter_on_F), bool(jitter_on_P)
+        self.mask_d, self.joseph = bool(mask_d), bool(joseph)
+
+    def __repr__(self):
+        return (f"FilterConventions(ll_constant={self.ll_constant!r}, jitter_on_F={self.jitter_on_F}, "
+                f"jitter_on_P={self.jitter_on_P}, mask_d={self.mask_d}, joseph={self.joseph})")
+
+
+DEFAULT_CONVENTIONS = FilterConventions()
+
+
 def solve_discrete_lyapunov(T, RQR, method="bilinear"):
     """X = T X T' + RQR (statespace.py:814-815; ``"bilinear"`` default, ``"direct"`` if
     ``use_direct_lyapunov``)."""
@@ -64,8 +97,10 @@ def kalman_filter_logp(
     missing_fill_value=MISSING_FILL,
     return_per_step=False,
     return_states=False,
+    conventions=None,
 ):
-    """Standard Kalman filter log-likelihood, ``sum_t ll_t``.
+    """Standard Kalman filter log-likelihood, ``sum_t ll_t``.  ``conventions``: the third-party
+    switches (``FilterConventions``; ``None`` = ``DEFAULT_CONVENTIONS``, what the device kernels implement).
 
     y : (T_len, p) data (NaN or ``missing_fill_value`` marks a missing entry);
     T : (m, m); R : (m, k); Q : (k, k); Z : (p, m); H : (p, p) or None (= 0);
@@ -85,6 +120,9 @@ def kalman_filter_logp(
     eye_m = np.eye(m)
     eye_p = np.eye(p)
 
+    cv = DEFAULT_CONVENTIONS if conventions is None else conventions
+    jit_F = jitter if cv.jitter_on_F else 0.0
+    jit_P = jitter if cv.jitter_on_P else 0.0
     ll = np.zeros(y.shape[0])
     states = dict(a_pred=[], a_filt=[], P_pred=[], P_filt=[])
     for t in range(y.shape[0]):
@@ -97,18 +135,23 @@ def kalman_filter_logp(
         Hm = W @ H
         ym = np.where(miss, 0.0, yt)
 
-        v = ym - (d + Zm @ a)
+        v = ym - ((np.where(miss, 0.0, d) if cv.mask_d else d) + Zm @ a)
         PZt = P @ Zm.T
-        F = Zm @ PZt + Hm + jitter * eye_p
+        F = Zm @ PZt + Hm + jit_F * eye_p
         K = np.linalg.solve(F.T, PZt.T).T
         IKZ = eye_m - K @ Zm
         a_f = a + K @ v
-        P_f = _sym_quad(IKZ, P) + _sym_quad(K, Hm) + jitter * eye_m
+        if cv.joseph:
+            P_f = _sym_quad(IKZ, P) + _sym_quad(K, Hm) + jit_P * eye_m
+        else:
+            P_f = P - K @ F @ K.T
+            P_f = 0.5 * (P_f + P_f.T) + jit_P * eye_m
         if miss.all():
             ll[t] = 0.0
         else:
             inner = v @ np.linalg.solve(F, v)
-            ll[t] = -0.5 * (p * _LN2PI + np.log(np.linalg.det(F)) + inner)
+            n_const = {"p": p, "observed": int((~miss).sum()), "one": 1}[cv.ll_constant]
+            ll[t] = -0.5 * (n_const * _LN2PI + np.log(np.linalg.det(F)) + inner)
         states["a_filt"].append(a_f.copy())
         states["P_filt"].append(P_f.copy())
         a = T @ a_f + c

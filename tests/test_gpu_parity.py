@@ -16,6 +16,30 @@ from geconpy_amd import workloads as wl
 
 pytestmark = pytest.mark.gpu
 
+# Kernel-variant switches of a test go through dsge_options (per call / per host thread: dsge_options_push / _pop), not through
+# the deprecated process-wide dsge_set_* setters: _set_option replaces this thread's pushed record by one that carries every
+# override made so far (a test's `finally` sets its switch back to the default, so nothing leaks into the next test).
+_OPTION_OVERRIDES = {}
+_OPTION_PUSHED = [False]
+
+
+def _set_option(name, value):
+    import ctypes as _ct
+
+    lib = _lib.load()
+    _OPTION_OVERRIDES[name] = int(value)
+    if _OPTION_PUSHED[0]:
+        _lib.check(lib.dsge_options_pop())
+        _OPTION_PUSHED[0] = False
+    defaults = _lib.make_options()
+    for key in [k for k, v in _OPTION_OVERRIDES.items() if getattr(defaults, k) == v]:
+        del _OPTION_OVERRIDES[key]  # back at the default: no record stays pushed (a pushed record would also shadow the defaults
+        #                             that the two remaining dsge_set_* users of this file edit)
+    if _OPTION_OVERRIDES:
+        rec = _lib.make_options(dict(_OPTION_OVERRIDES))
+        _lib.check(lib.dsge_options_push(_ct.addressof(rec)))
+        _OPTION_PUSHED[0] = True
+
 T_ATOL = 1e-10
 LOGP_RTOL = 1e-9
 
@@ -393,15 +417,18 @@ def test_gensys_capacity_flag():
     """A draw whose pencil exceeds the capacity implied by a (too small) lead hint is flagged, not
     silently wrong."""
     b = wl.sw_shaped_batch(2)
-    out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5)
-    assert np.all(out["status"] == 0)  # the window path measures the batch itself and ignores the hint
-    lib = _lib.load()
-    _lib.check(lib.dsge_set_gensys_split(0))
-    try:
-        out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5)
-    finally:
-        _lib.check(lib.dsge_set_gensys_split(1))
-    assert np.all(out["status"] & _lib.ST_GENSYS_TOO_BIG) and np.all(out["eu"][:, 0] == -3) and np.all(out["T"] == 0)
+    # n_lead_hint is the caller's promise of an upper bound: the same answer from the window path with a fresh capacity record,
+    # with a cached one (second call) and from the single-launch kernel
+    for split, cache in ((1, 1), (1, 1), (1, 0), (0, 1)):
+        _set_option("gensys_split", split)
+        try:
+            out = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=5,
+                                         options={"gensys_split": split, "gensys_shape_cache": cache})
+        finally:
+            _set_option("gensys_split", 1)
+        assert np.all(out["status"] & _lib.ST_GENSYS_TOO_BIG) and np.all(out["eu"][:, 0] == -3) and np.all(out["T"] == 0)
+    ok = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, n_lead_hint=12)
+    assert np.all(ok["status"] == 0)
 
 
 @pytest.mark.parametrize("n,k", [(9, 2), (24, 4), (40, 7)])
@@ -705,11 +732,11 @@ def test_cycle_reduction_compact_equals_dense(sw_golden, ref_goldens, rbc_golden
     for A, B, C in sets:
         assert (np.abs(A).sum(axis=-2) == 0).sum() > 0  # the structure the compact kernel exploits is there
         T1, st1, it1 = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9)
-        _lib.check(lib.dsge_set_cr_compact(0))
+        _set_option("cr_compact", 0)
         try:
             T0, st0, it0 = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9)
         finally:
-            _lib.check(lib.dsge_set_cr_compact(1))
+            _set_option("cr_compact", 1)
         assert np.array_equal(st0, st1) and np.array_equal(it0, it1) and np.all(st1 == 0)
         assert np.array_equal(T0, T1)
     # dense A and C: |S| + |L| = 2n > 8*ceil(n/8) -> dense kernel
@@ -987,11 +1014,11 @@ def test_cycle_reduction_structure_fuzz():
         A, B, C, Tstar = _structured_system(rng, n, s_cols, l_cols)
         A3, B3, C3 = A[None], B[None], C[None]
         T1, st1, it1 = batched.cycle_reduction_batched(A3, B3, C3, max_iter=200, tol=1e-10)
-        _lib.check(lib.dsge_set_cr_compact(0))
+        _set_option("cr_compact", 0)
         try:
             T0, st0, it0 = batched.cycle_reduction_batched(A3, B3, C3, max_iter=200, tol=1e-10)
         finally:
-            _lib.check(lib.dsge_set_cr_compact(1))
+            _set_option("cr_compact", 1)
         assert st1[0] == 0 and st0[0] == 0, (n, len(s_cols), len(l_cols))
         assert it1[0] == it0[0] and np.array_equal(T1, T0), (n, len(s_cols), len(l_cols))
         T_or, ok, it_or = oracle.cycle_reduction_core(A, B, C, 200, 1e-10)
@@ -1045,11 +1072,11 @@ def test_kalman_tiny_kernel_matches_wave_kernels():
         T *= 0.7
         y[40, 0] = np.nan
         logp1, st1 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
-        _lib.check(lib.dsge_set_kalman_tiny(0))
+        _set_option("kalman_tiny", 0)
         try:
             logp0, st0 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
         finally:
-            _lib.check(lib.dsge_set_kalman_tiny(1))
+            _set_option("kalman_tiny", 1)
         assert np.all(st1 == 0) and np.all(st0 == 0), (m, k, p, ns)
         assert_allclose(logp1, logp0, rtol=1e-11, err_msg=str((m, k, p, ns)))
         for i in (0, 33, 69):
@@ -1085,11 +1112,11 @@ def test_cr_fused_selection_matches_explicit_formula():
     for A_, B_, C_, D_, q_, Z_, y_, H_ in sets:
         kw = dict(Hdiag=H_, tol=1e-10, max_iter=200, q_mode="diag_batched")
         r1 = batched.solve_kalman_logp_batched(A_, B_, C_, D_, q_, Z_, y_, **kw)
-        _lib.check(lib.dsge_set_cr_fused_selection(0))
+        _set_option("cr_fused_selection", 0)
         try:
             r0 = batched.solve_kalman_logp_batched(A_, B_, C_, D_, q_, Z_, y_, **kw)
         finally:
-            _lib.check(lib.dsge_set_cr_fused_selection(1))
+            _set_option("cr_fused_selection", 1)
         assert np.array_equal(r1["status"], r0["status"])
         good = r0["status"] == 0
         assert good.sum() >= len(good) - 1
@@ -1130,11 +1157,11 @@ def test_kalman_mfma_products_match_valu():
         nb, T_len = 5, 60
         T, R, q, Z, d, H, y = _kalman_inputs(nb, m, k, p, T_len, ns, seed=4000 + m)
         logp0, st0 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
-        _lib.check(lib.dsge_set_kalman_mfma(1))  # experimental path, off by default
+        _set_option("kalman_mfma", 1)  # experimental path, off by default
         try:
             logp1, st1 = batched.kalman_logp_batched(T, R, q, Z, y, d=d, Hdiag=H, q_mode="diag_batched")
         finally:
-            _lib.check(lib.dsge_set_kalman_mfma(0))
+            _set_option("kalman_mfma", 0)
         assert np.all(st1 == 0) and np.all(st0 == 0), (m, ns)
         assert_allclose(logp1, logp0, rtol=1e-11, err_msg=str((m, k, p, ns)))
         for i in (0, 4):
@@ -1160,16 +1187,16 @@ def test_gensys_window_path_matches_single_launch(ref_goldens, failure_golden):
     A2[3] += 1e-3 * rng.standard_normal(A2[3].shape)
     sets.append((A2, B2, C2, D2))
     for A, B, C, D in sets:
-        _lib.check(lib.dsge_set_gensys_split(2))  # also for the small goldens (auto mode keeps them on one launch)
+        _set_option("gensys_split", 2)  # also for the small goldens (auto mode keeps them on one launch)
         try:
             out1 = batched.gensys_batched(A, B, C, D, tol=1e-8)
         finally:
-            _lib.check(lib.dsge_set_gensys_split(1))
-        _lib.check(lib.dsge_set_gensys_split(0))
+            _set_option("gensys_split", 1)
+        _set_option("gensys_split", 0)
         try:
             out0 = batched.gensys_batched(A, B, C, D, tol=1e-8)
         finally:
-            _lib.check(lib.dsge_set_gensys_split(1))
+            _set_option("gensys_split", 1)
         assert np.array_equal(out1["eu"], out0["eu"]), (out1["eu"], out0["eu"])
         assert np.array_equal(out1["status"], out0["status"])
         scale = max(1.0, np.abs(out0["T"]).max())
@@ -1284,19 +1311,19 @@ def test_gensys_window_path_fuzz():
                 C = 6.0 * C
             sysl.append((A, B, C, D))
         A, B, C, D = (np.stack([s_[i] for s_ in sysl]) for i in range(4))
-        _lib.check(lib.dsge_set_gensys_split(2))
+        _set_option("gensys_split", 2)
         try:
             out = batched.gensys_batched(A, B, C, D, tol=1e-8)
         finally:
-            _lib.check(lib.dsge_set_gensys_split(1))
+            _set_option("gensys_split", 1)
         single = None
-        _lib.check(lib.dsge_set_gensys_split(0))
+        _set_option("gensys_split", 0)
         try:
             single = batched.gensys_batched(A, B, C, D, tol=1e-8)
         except _lib.DsgeHipError:
             single = None  # the single-launch kernel does not fit this pencil into 160 KB of LDS
         finally:
-            _lib.check(lib.dsge_set_gensys_split(1))
+            _set_option("gensys_split", 1)
         for i in range(4):
             T_ref, ok, eu_ref = oracle.gensys_T_success(A[i], B[i], C[i], D[i], tol=1e-8)
             assert list(out["eu"][i]) == [int(x) for x in eu_ref], (n, ns, nl, i, out["eu"][i], eu_ref)
@@ -1321,14 +1348,14 @@ def test_gensys_nan_inf_inputs_are_flagged_not_hung(split):
     B[3, 0, 0] = np.inf
     C[4, 5, 39] = np.nan
     clean = batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8)
-    _lib.check(lib.dsge_set_gensys_split(split))
+    _set_option("gensys_split", split)
     try:
         out = batched.gensys_batched(A, B, C, D, tol=1e-8)
         om = wl.sw_shaped_observation_model()
         fused = batched.solve_kalman_logp_batched(A, B, C, D, b["sigma"] ** 2, om["Z"], om["y"][:40], Hdiag=om["Hdiag"],
                                                   solver="gensys", tol=1e-8)
     finally:
-        _lib.check(lib.dsge_set_gensys_split(1))
+        _set_option("gensys_split", 1)
     for i in (1, 3):
         assert out["status"][i] != 0 and not out["success"][i] and np.all(out["T"][i] == 0)
     # a NaN in a column of C: |C|.sum(0) > tol is False for that column, so it is not a forward-looking variable for
@@ -1373,12 +1400,12 @@ def test_kalman_block_steady_matches_step_by_step():
     for y in ys:
         out0 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, Hdiag=om["Hdiag"], tol=1e-8,
                                                  max_iter=1000)
-        _lib.check(lib.dsge_set_kalman_block(1))
+        _set_option("kalman_block", 1)
         try:
             out1 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, Hdiag=om["Hdiag"],
                                                      tol=1e-8, max_iter=1000)
         finally:
-            _lib.check(lib.dsge_set_kalman_block(0))
+            _set_option("kalman_block", 0)
         assert np.array_equal(out1["status"], out0["status"]) and np.all(out1["status"] == 0)
         assert_allclose(out1["logp"], out0["logp"], rtol=1e-12)
         for i in (0, 7, 23):
@@ -1418,13 +1445,13 @@ def test_dispatch_order_and_chunks_do_not_change_results():
     assert ref_st[77] != 0 and ref_lp[77] == -np.inf and np.count_nonzero(ref_st) == 1
     try:
         for order, chunks in ((0, 0), (1, 3), (0, 4), (2, 2), (2, 0)):
-            _lib.check(lib.dsge_set_kalman_order(order))
-            _lib.check(lib.dsge_set_pipeline_chunks(chunks))
+            _set_option("kalman_order", order)
+            _set_option("pipeline_chunks", chunks)
             lp, st = run()
             assert np.array_equal(st, ref_st) and np.array_equal(lp, ref_lp), (order, chunks)
     finally:
-        _lib.check(lib.dsge_set_kalman_order(1))
-        _lib.check(lib.dsge_set_pipeline_chunks(0))
+        _set_option("kalman_order", 1)
+        _set_option("pipeline_chunks", 0)
 
 
 def test_fused_calls_on_two_streams_do_not_share_scratch():
@@ -1855,12 +1882,12 @@ def test_cr_two_wave_instance_is_bit_identical():
         dZ, dy, dH = eng.to_device(Z), eng.to_device(om["y"][:30]), eng.to_device(om["Hdiag"])
         hints = eng.structure_hints(dev["A"], dZ)
         try:
-            _lib.check(lib.dsge_set_cr_two_waves(0))
+            _set_option("cr_two_waves", 0)
             r0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
-            _lib.check(lib.dsge_set_cr_two_waves(1))
+            _set_option("cr_two_waves", 1)
             r1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
         finally:
-            _lib.check(lib.dsge_set_cr_two_waves(1))
+            _set_option("cr_two_waves", 1)
         assert np.all(r0[1] == 0)
         for a0, a1 in zip(r0, r1):
             assert np.array_equal(a0, a1)

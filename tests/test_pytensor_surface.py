@@ -181,3 +181,17 @@ def test_gensys_output_dtype_follows_floatx(surface, monkeypatch):
     monkeypatch.setattr(surface, "_floatx", lambda: "float32")
     node32 = op.make_node(_m(5), _m(5), _m(5), _m(5, 2))
     assert node32.outputs[0].type.dtype == "float32"
+
+
+def test_live_check_tool_self_skips_without_pytensor():
+    """tools/pytensor_live_check.py is the one-command proof of the Op layer under a REAL pytensor: where pytensor is
+    absent -- here -- it must say so and exit 77 without touching anything; where it exists, every step it can run must pass."""
+    import os
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pytensor_live_check.py")
+    res = subprocess.run([sys.executable, tool, "--cpu-graph-only"], capture_output=True, text=True, timeout=600, check=False)
+    assert res.returncode in (0, 77), res.stdout + res.stderr
+    if res.returncode == 77:
+        assert "not installed" in res.stdout
