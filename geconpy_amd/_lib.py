@@ -181,7 +181,8 @@ class Options(C.Structure):
         ("gensys_real_stage", C.c_int32),
         ("gensys_pairs", C.c_int32),
         ("gensys_shape_cache", C.c_int32),
-        ("reserved_", C.c_int32 * 6),
+        ("kalman_narrow", C.c_int32),
+        ("reserved_", C.c_int32 * 5),
     ]
 
 

@@ -136,6 +136,7 @@ struct OptionsGuard {
     local.gensys_real_stage = o->gensys_real_stage;
     local.gensys_pairs = o->gensys_pairs;
     local.gensys_shape_cache = o->gensys_shape_cache;
+    local.kalman_narrow = o->kalman_narrow;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -2110,6 +2111,7 @@ int dsge_options_init(dsge_options* o) {
   o->cr_four_waves = d.cr_four_waves;
   o->gensys_pairs = d.gensys_pairs;
   o->gensys_shape_cache = d.gensys_shape_cache;
+  o->kalman_narrow = d.kalman_narrow;
   return DSGE_SUCCESS;
 }
 

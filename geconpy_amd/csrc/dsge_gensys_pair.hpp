@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
 #define PT(i, j) P[(j)*LD + (i)]
   const GwOffsets wo = gw_offsets(cp);
   const int npairs = (batch + 1) >> 1;
-  const unsigned mcolB = 16u * (unsigned)cp.wcap, xrowB = 8u * (unsigned)cp.lcap;  // bytes: one column of M, one row of X
+  const unsigned mcolB = 8u * (unsigned)cp.wcap, xrowB = 8u * (unsigned)cp.lcap;  // bytes: one column of the REAL M (MRE), one row of X
   const char* wsb = reinterpret_cast<const char*>(ws);
   char* wsw = reinterpret_cast<char*>(ws);
 #define GLD(off) (*reinterpret_cast<const double*>(wsb + (size_t)(unsigned)(off)))
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
     wave_sync();
     const int cw = min(l, max(w - 1, 0));     // this lane's column of H / T and row of H / T / M (lanes >= w duplicate the last)
     const int cx_ = min(l, max(ell - 1, 0));  // this lane's column of X
-    const unsigned offM0 = (unsigned)((wdo + wo.MC + 2 * (size_t)cw) * 8);  // M(cw, col) at offM0 + col * mcolB
+    const unsigned offM0 = (unsigned)((wdo + wo.MRE + (size_t)cw) * 8);  // M(cw, col) at offM0 + col * mcolB
     const unsigned offX0 = (unsigned)((wdo + wo.XR + (size_t)cx_) * 8);     // X(row, cx_) at offX0 + row * xrowB
     const unsigned offMmax = offM0 + (unsigned)max(w - 1, 0) * mcolB, offXmax = offX0 + (unsigned)max(w - 1, 0) * xrowB;
     double* const rowc = P + cw * LD;  // array row cw: T(., cw) at rowc[.], H(cw, .) at rowc[. + 6]
@@ -360,13 +360,14 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
         asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(m2n), "=&v"(x2n) : "v"(m3), "v"(x3));
         __builtin_amdgcn_sched_barrier(0);
         if (act) {
-          // column k of M and row k of X are final for this sweep; column / row k+1 is final after the LAST step only -- stored
-          // in every step (the next step overwrites it) rather than under a branch of its own; with #lead = 0 the X stores go
-          // to the unused first column of the draw's X block
+          // column k of M and row k of X are final for this sweep, column / row k+1 after the LAST step only (with #lead = 0 the
+          // X stores go to the unused first column of the draw's X block)
           GST(offM, m0);
           GST(offX, xr0);
-          GST(offM + mcolB, m1);
-          GST(offX + xrowB, xr1);
+          if (last) {
+            GST(offM + mcolB, m1);
+            GST(offX + xrowB, xr1);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         m3 = GLD(min(offM + 4 * mcolB, offMmax));  // (clamped at the window's edge: only ever multiplied by v2 = 0 there)
@@ -406,15 +407,19 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
       atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 29), (unsigned long long)slots);
       atomicMax(reinterpret_cast<unsigned long long*>(dbg + 30), (unsigned long long)slots);
     }
-    {  // the window goes back as it came: full w x w, exact zeros outside the bands
+    __threadfence_block();  // (the M stores of the sweeps are read back below by other lanes of this wavefront)
+    {  // the window goes back as it came: full w x w, exact zeros outside the bands; M becomes complex for the next launch
       const int total = w * w;
       const int wdiv = w > 0 ? w : 1;
+      cx* MCx = reinterpret_cast<cx*>(wd + wo.MC);
+      const double* MRx = wd + wo.MRE;
       for (int idx = l; idx < cp.wcap * cp.wcap; idx += 32) {
         if (idx < total) {
           const int i = idx / wdiv, j = idx - i * wdiv;
           const size_t o = (size_t)i * cp.wcap + j;
           wd[wo.HR + o] = (i <= j + 3) ? PH(i, j) : 0.0;
           wd[wo.TR + o] = (i <= j + 2) ? PT(i, j) : 0.0;
+          MCx[o] = mk(MRx[o], 0.0);  // (same transposed indexing in both: [col * wcap + row])
         }
       }
     }

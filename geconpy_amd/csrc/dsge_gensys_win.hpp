@@ -24,7 +24,7 @@ struct GwCaps {
 };
 
 struct GwOffsets {  // per draw, in doubles
-  size_t meta, R0, H12, T12, X1, HR, TR, XR, HC, TC, MC, XC, BM, PHI, total;
+  size_t meta, R0, H12, T12, X1, HR, TR, XR, MRE, HC, TC, MC, XC, BM, PHI, total;
 };
 
 __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
@@ -39,6 +39,8 @@ __host__ __device__ inline GwOffsets gw_offsets(const GwCaps& c) {
   o.HR = p, p += ww;
   o.TR = p, p += ww;
   o.XR = p, p += wl;
+  o.MRE = p, p += ww;  // the accumulated right transformation while it is REAL (two-draws-per-wavefront route): transposed,
+                       // element (row, col) at [col * wcap + row] -- half the bytes per streamed column of the complex MC
   p = (p + 1) & ~(size_t)1;  // complex arrays: 16-byte aligned
   o.HC = p, p += 2 * ww;
   o.TC = p, p += 2 * ww;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(64 * NW) void gensys_reduce_kernel(const double* __
     double* wd = ws + (size_t)draw * wo.total;
     int* meta = reinterpret_cast<int*>(wd + wo.meta);
     wave_sync();
+    GW_STAMP(14);  // (debug: start of the draw)
     for (size_t idx = tid; idx < total; idx += NT) smem[idx] = 0.0;
     // lead columns (gensys.py:580-589) and the zero columns of A
     int ell = 0;
@@ -224,6 +227,7 @@ __global__ __launch_bounds__(64 * NW) void gensys_reduce_kernel(const double* __
     // ---- structural deflation: QR of the z zero-columns-of-A columns of G0
     for (int j = 0; j < z; ++j) hh_left_real_mw<NW>(Hr, ldH, j, N - j, Tr, ldW, w, Xr, ldX, ell, Hr, ldH, j, j, N, 0, lane, wv);
     wave_sync();
+    GW_STAMP(7);  // (debug: end of the reflectors)
     // rows < z are final: R0, H12, T12[:, :s'], X1 leave the chip
     for (int idx = tid; idx < z * z; idx += NT) {
       const int i = idx / z, j = idx - i * z;
@@ -558,7 +562,7 @@ __device__ __forceinline__ void gw_lartg(double f, double g, double& c, double& 
 // HBM workspace (as the complex iteration wants it): lane = row of M, the column shared by two consecutive column rotations
 // is carried in a register, the next one is prefetched a rotation ahead, each finished column is stored once.
 __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp, double* __restrict__ ws,
-                                                             long long* __restrict__ dbg, int real_stage) {
+                                                             long long* __restrict__ dbg, int real_stage, int m_real) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
@@ -572,8 +576,10 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
     const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
     if (meta[GW_FLAG] != 0) continue;
     const int ell = meta[GW_ELL], w = meta[GW_N] - meta[GW_Z];
-    double* MR = wd + wo.MC;
-    const size_t mcol = 2 * (size_t)cp.wcap;
+    // m_real: the pair launch follows and keeps M real (MRE, stride 1) until the complex iteration needs it
+    double* MR = wd + (m_real ? wo.MRE : wo.MC);
+    const size_t mcol = (m_real ? 1 : 2) * (size_t)cp.wcap;
+    const int ms = m_real ? 1 : 2;
     wave_sync();
     GW_STAMP(5);
     lane_loop_batched<4>(
@@ -599,8 +605,12 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
           xb[i * ldX + j] = v;
         });
     if (lane < w) {  // M = I, every lane writing the row it will keep reading and writing (no cross-lane traffic through HBM)
-      cx* MC = reinterpret_cast<cx*>(MR);
-      for (int col = 0; col < w; ++col) MC[(size_t)col * cp.wcap + lane] = mk(lane == col ? 1.0 : 0.0, 0.0);
+      if (m_real) {
+        for (int col = 0; col < w; ++col) MR[(size_t)col * mcol + lane] = (lane == col) ? 1.0 : 0.0;
+      } else {
+        cx* MC = reinterpret_cast<cx*>(MR);
+        for (int col = 0; col < w; ++col) MC[(size_t)col * cp.wcap + lane] = mk(lane == col ? 1.0 : 0.0, 0.0);
+      }
     }
     wave_sync();
     // ---- T22 -> upper triangular (reflectors)
@@ -616,14 +626,14 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
       wave_sync();
       const double colv = hb[cw * ldH + j];
       double g = readlane_dyn_f64(colv, w - 1);
-      double m_hi = MR[(size_t)(w - 1) * mcol + 2 * cw];  // column w-1 of M, this lane's row
-      double m_nx = MR[(size_t)(w - 2) * mcol + 2 * cw];  // (the partner column of the NEXT rotation is always in flight)
+      double m_hi = MR[(size_t)(w - 1) * mcol + ms * cw];  // column w-1 of M, this lane's row
+      double m_nx = MR[(size_t)(w - 2) * mcol + ms * cw];  // (the partner column of the NEXT rotation is always in flight)
       for (int i = w - 1; i > j + 1; --i) {
         const double m_lo_in = m_nx;
-        m_nx = MR[(size_t)max(i - 2, 0) * mcol + 2 * cw];
+        m_nx = MR[(size_t)max(i - 2, 0) * mcol + ms * cw];
         const double f = readlane_dyn_f64(colv, i - 1);
         if (GW_HESS_SKIP && g == 0.0) {  // nothing to annihilate: the column pair of M moves on unrotated
-          MR[(size_t)i * mcol + 2 * cw] = m_hi;
+          MR[(size_t)i * mcol + ms * cw] = m_hi;
           m_hi = m_lo_in;
           g = f;
           continue;
@@ -673,10 +683,10 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
           tb[cw * ldW + i] = tx2;
           tb[cw * ldW + i - 1] = ty2;
         }
-        MR[(size_t)i * mcol + 2 * cw] = m_hi;  // column i of M is final for this j
+        MR[(size_t)i * mcol + ms * cw] = m_hi;  // column i of M is final for this j
         m_hi = m_lo;
       }
-      MR[(size_t)(j + 1) * mcol + 2 * cw] = m_hi;
+      MR[(size_t)(j + 1) * mcol + ms * cw] = m_hi;
     }
     wave_sync();
     GW_STAMP(3);

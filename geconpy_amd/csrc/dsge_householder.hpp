@@ -22,7 +22,6 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
   const double beta = (alpha >= 0.0) ? -nrm : nrm;
   const double tau = (beta - alpha) / beta;
   const double scal = 1.0 / (alpha - beta);
-  const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
   const int ncols = nH + nT + nX;
   // column c of the virtual matrix [H | T | X] -> base pointer and row stride (inactive lanes walk a valid column of H
   // and store nothing)
@@ -41,20 +40,26 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
     }
     return true;
   };
-  for (int c0 = 0; c0 < ncols; c0 += 128) {  // two columns per lane and trip: eight loads in flight
+  // Round 4: v is not handed out by v_readlane (two VALU instructions per value and row) but read back from the source column
+  // in LDS, every lane the same address (a broadcast), unscaled:  v' m = m_j + scal sum_{r > j} x_r m_r,  m_r += x_r (scal w),
+  // m_j += w.  The source column is part of the sweep: its owner updates rows r .. r+3 in the trip that has just read them
+  // (LDS operations of a wavefront execute in program order), and it is overwritten with (beta, 0, ...) at the end anyway.
+  const double* const px0 = src + (size_t)(j + 1) * ld_src + col;
+  for (int c0 = 0; c0 < ncols; c0 += 128) {  // two columns per lane and trip: eight own loads + four broadcast loads in flight
     double *bA, *bB;
     int lA, lB;
     column(c0 + lane, bA, lA);
     column(c0 + 64 + lane, bB, lB);
-    double* pA = bA + j * lA;
-    double* pB = bB + j * lB;
+    const double mjA = bA[j * lA], mjB = bB[j * lB];
+    double* pA = bA + (j + 1) * lA;
+    double* pB = bB + (j + 1) * lB;
+    const double* px = px0;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    int r = j;
+    int r = j + 1;
     for (; r + 4 <= N; r += 4) {
       const double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
       const double q0 = pB[0], q1 = pB[lB], q2 = pB[2 * lB], q3 = pB[3 * lB];
-      const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
-                   v3 = readlane_dyn_f64(v, r + 3);
+      const double v0 = px[0], v1 = px[ld_src], v2 = px[2 * ld_src], v3 = px[3 * ld_src];
       a0 = fma(v0, m0, a0);
       a1 = fma(v1, m1, a1);
       a2 = fma(v2, m2, a2);
@@ -65,30 +70,33 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
       b3 = fma(v3, q3, b3);
       pA += 4 * lA;
       pB += 4 * lB;
+      px += 4 * ld_src;
     }
     for (; r < N; ++r) {
-      const double vr = readlane_dyn_f64(v, r);
+      const double vr = px[0];
       a0 = fma(vr, pA[0], a0);
       b0 = fma(vr, pB[0], b0);
       pA += lA;
       pB += lB;
+      px += ld_src;
     }
-    const double wA = -tau * ((a0 + a1) + (a2 + a3)), wB = -tau * ((b0 + b1) + (b2 + b3));
-    pA = bA + j * lA;
-    pB = bB + j * lB;
-    for (r = j; r + 4 <= N; r += 4) {
+    const double wA = -tau * fma(scal, (a0 + a1) + (a2 + a3), mjA), wB = -tau * fma(scal, (b0 + b1) + (b2 + b3), mjB);
+    const double wsA = scal * wA, wsB = scal * wB;
+    pA = bA + (j + 1) * lA;
+    pB = bB + (j + 1) * lB;
+    px = px0;
+    for (r = j + 1; r + 4 <= N; r += 4) {
       double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
       double q0 = pB[0], q1 = pB[lB], q2 = pB[2 * lB], q3 = pB[3 * lB];
-      const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
-                   v3 = readlane_dyn_f64(v, r + 3);
-      m0 = fma(v0, wA, m0);
-      m1 = fma(v1, wA, m1);
-      m2 = fma(v2, wA, m2);
-      m3 = fma(v3, wA, m3);
-      q0 = fma(v0, wB, q0);
-      q1 = fma(v1, wB, q1);
-      q2 = fma(v2, wB, q2);
-      q3 = fma(v3, wB, q3);
+      const double v0 = px[0], v1 = px[ld_src], v2 = px[2 * ld_src], v3 = px[3 * ld_src];
+      m0 = fma(v0, wsA, m0);
+      m1 = fma(v1, wsA, m1);
+      m2 = fma(v2, wsA, m2);
+      m3 = fma(v3, wsA, m3);
+      q0 = fma(v0, wsB, q0);
+      q1 = fma(v1, wsB, q1);
+      q2 = fma(v2, wsB, q2);
+      q3 = fma(v3, wsB, q3);
       // (no store masks: a lane beyond the last column walks column 0 of H, computes what that column's owner computes and
       // stores the same values to the same addresses -- an exec-mask branch less per trip, see gw_realqz_sweeps)
       pA[0] = m0;
@@ -101,15 +109,19 @@ __device__ __forceinline__ void hh_left_real(double* Hr, int ldH, int h0, int nH
       pB[3 * lB] = q3;
       pA += 4 * lA;
       pB += 4 * lB;
+      px += 4 * ld_src;
     }
     for (; r < N; ++r) {
-      const double vr = readlane_dyn_f64(v, r);
-      const double m0 = fma(vr, wA, pA[0]), q0 = fma(vr, wB, pB[0]);
+      const double vr = px[0];
+      const double m0 = fma(vr, wsA, pA[0]), q0 = fma(vr, wsB, pB[0]);
       pA[0] = m0;
       pB[0] = q0;
       pA += lA;
       pB += lB;
+      px += ld_src;
     }
+    bA[j * lA] = mjA + wA;  // row j last: when this lane's column IS the source column the rows below were read unscaled above
+    bB[j * lB] = mjB + wB;
   }
   wave_sync();
   if (lane >= j && lane < N) src[lane * ld_src + col] = (lane == j) ? beta : 0.0;
@@ -134,7 +146,6 @@ __device__ __forceinline__ void hh_left_real_mw(double* Hr, int ldH, int h0, int
   const double beta = (alpha >= 0.0) ? -nrm : nrm;
   const double tau = (beta - alpha) / beta;
   const double scal = 1.0 / (alpha - beta);
-  const double v = (lane == j) ? 1.0 : ((lane > j && lane < N) ? x * scal : 0.0);
   const int ncols = nH + nT + nX;
   const int per = (ncols + NW - 1) / NW;
   const int c = wv * per + lane;
@@ -152,45 +163,63 @@ __device__ __forceinline__ void hh_left_real_mw(double* Hr, int ldH, int h0, int
       lA = ldX;
     }
   }
-  double* pA = bA + j * lA;
+  // The walk down the rows, eight per trip.  v is NOT handed out by v_readlane (two VALU instructions per value and lane-step:
+  // they were most of this routine's instruction stream): the source column itself -- which the sweep leaves alone -- is read
+  // back from LDS, every lane the same address (a broadcast, conflict-free), unscaled:
+  //   v' m = m_j + scal * sum_{r > j} x_r m_r,      m_r += v_r w = m_r + x_r (scal w)  (r > j),   m_j += w.
+  const double* px = src + (size_t)(j + 1) * ld_src + col;
+  double* pA = bA + (j + 1) * lA;
+  const double mj = bA[j * lA];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int r = j;
-  for (; r + 4 <= N; r += 4) {
-    const double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
-    const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
-                 v3 = readlane_dyn_f64(v, r + 3);
-    a0 = fma(v0, m0, a0);
-    a1 = fma(v1, m1, a1);
-    a2 = fma(v2, m2, a2);
-    a3 = fma(v3, m3, a3);
-    pA += 4 * lA;
-  }
-  for (; r < N; ++r) {
-    a0 = fma(readlane_dyn_f64(v, r), pA[0], a0);
-    pA += lA;
-  }
-  const double wA = -tau * ((a0 + a1) + (a2 + a3));
-  pA = bA + j * lA;
-  for (r = j; r + 4 <= N; r += 4) {
-    double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
-    const double v0 = readlane_dyn_f64(v, r), v1 = readlane_dyn_f64(v, r + 1), v2 = readlane_dyn_f64(v, r + 2),
-                 v3 = readlane_dyn_f64(v, r + 3);
-    m0 = fma(v0, wA, m0);
-    m1 = fma(v1, wA, m1);
-    m2 = fma(v2, wA, m2);
-    m3 = fma(v3, wA, m3);
-    if (mine) {
-      pA[0] = m0;
-      pA[lA] = m1;
-      pA[2 * lA] = m2;
-      pA[3 * lA] = m3;
+  int r = j + 1;
+  for (; r + 8 <= N; r += 8) {
+    double mr[8], xr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      mr[u] = pA[u * lA];
+      xr[u] = px[u * ld_src];
     }
-    pA += 4 * lA;
+#pragma unroll
+    for (int u = 0; u < 8; u += 4) {
+      a0 = fma(xr[u], mr[u], a0);
+      a1 = fma(xr[u + 1], mr[u + 1], a1);
+      a2 = fma(xr[u + 2], mr[u + 2], a2);
+      a3 = fma(xr[u + 3], mr[u + 3], a3);
+    }
+    pA += 8 * lA;
+    px += 8 * ld_src;
   }
   for (; r < N; ++r) {
-    const double m0 = fma(readlane_dyn_f64(v, r), wA, pA[0]);
+    a0 = fma(px[0], pA[0], a0);
+    pA += lA;
+    px += ld_src;
+  }
+  const double wA = -tau * fma(scal, (a0 + a1) + (a2 + a3), mj);
+  const double ws = scal * wA;
+  if (mine) bA[j * lA] = mj + wA;
+  pA = bA + (j + 1) * lA;
+  px = src + (size_t)(j + 1) * ld_src + col;
+  for (r = j + 1; r + 8 <= N; r += 8) {
+    double mr[8], xr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      mr[u] = pA[u * lA];
+      xr[u] = px[u * ld_src];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mr[u] = fma(xr[u], ws, mr[u]);
+    if (mine) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pA[u * lA] = mr[u];
+    }
+    pA += 8 * lA;
+    px += 8 * ld_src;
+  }
+  for (; r < N; ++r) {
+    const double m0 = fma(px[0], ws, pA[0]);
     if (mine) pA[0] = m0;
     pA += lA;
+    px += ld_src;
   }
   __syncthreads();
   if (wv == 0 && lane >= j && lane < N) src[lane * ld_src + col] = (lane == j) ? beta : 0.0;

@@ -25,9 +25,15 @@
 
 namespace dsge {
 
-template <int BS>
+// SK: compile-time capacity of the state block (columns of Tc / W' / Pc that can be non-zero; a multiple of four, >= the
+// run-time s_cap rounded up to the tile's block size).  The rows of the three LDS matrices are SK + 2 doubles long instead of
+// NP + 2 -- the columns beyond the state block are structural zeros that nothing reads -- and the steady-state loop keeps SK
+// instead of NP entries of its row of T in registers.  SK = NP is the generic instance; SK = 20 (18 states, the SW-shaped
+// models) takes the 32-wide tile from 28 KB to exactly 20 KB of LDS: eight draws per CU instead of five (round 4).
+template <int BS, int SK = 8 * BS>
 struct KntSmem {
-  static constexpr int NP = Tile<BS>::NP, LDK = NP + 2, PS = 10;
+  static constexpr int NP = Tile<BS>::NP, LDK = SK + 2, PS = 10;
+  static_assert(SK % 4 == 0 && SK <= NP && SK >= 8, "SK: a multiple of four in 8..NP");
   static constexpr int WT = (NP * LDK > NP * PS) ? NP * LDK : NP * PS;  // W' buffer; the V panel aliases it
   // doubles: Tc NP*LDK, Wt WT, Pc s_cap*LDK, PZt, Ks NP*PS each, av NP, af NP, vv/dd/hh/zv 8 each; ints perm NP, zpos 8
   __host__ __device__ static constexpr size_t doubles(int s_cap) {
@@ -36,9 +42,55 @@ struct KntSmem {
   static size_t bytes(int s_cap) { return sizeof(double) * doubles(s_cap); }
 };
 
+// register block -> LDS, columns < CAP only (CAP = 0: all of them)
+template <int BS, int CAP>
+__device__ __forceinline__ void knt_store_cols(const double (&x)[BS][BS], double* s, int ld, int lr, int lc) {
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS; ++j)
+      if (CAP == 0 || lc * BS + j < CAP) s[(lr * BS + i) * ld + lc * BS + j] = x[i][j];
+}
+
 // acc += A[rows lr*BS.., :K] * B[rows lc*BS.., :K]'  -- both operands row-major along k with the even stride LD
 // (16-byte aligned rows): one ds_read_b128 per row and k-pair, stages of four k-steps, two stages in flight.
 // K is rounded up to a multiple of four: the callers keep the padding columns zero / finite.
+// SB (single buffer): stages of TWO k-steps, one stage in flight -- a quarter of the operand registers of the double-buffered
+// four-step stages (BS = 4: 32 instead of 128 VGPRs); the two-waves-per-SIMD build of the 32-wide tile needs them.
+template <int BS, int LD>
+__device__ __forceinline__ void mm_nt_sb(double (&acc)[BS][BS], const double* A, const double* B, int K, int lr, int lc) {
+  const double2* ap = reinterpret_cast<const double2*>(A + lr * BS * LD);
+  const double2* bp = reinterpret_cast<const double2*>(B + lc * BS * LD);
+  constexpr int RS = LD / 2;
+  const int nq = (K + 1) >> 1;  // pairs of k
+  if (nq <= 0) return;
+  double2 a[BS], b[BS], an[BS], bn[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) a[i] = ap[i * RS];
+#pragma unroll
+  for (int j = 0; j < BS; ++j) b[j] = bp[j * RS];
+  for (int q = 0; q < nq; ++q) {
+    const int qn = (q + 1 < nq) ? q + 1 : q;
+#pragma unroll
+    for (int i = 0; i < BS; ++i) an[i] = ap[i * RS + qn];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) bn[j] = bp[j * RS + qn];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        acc[i][j] = fma(a[i].x, b[j].x, acc[i][j]);
+        acc[i][j] = fma(a[i].y, b[j].y, acc[i][j]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < BS; ++i) a[i] = an[i];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) b[j] = bn[j];
+  }
+}
+
 template <int BS, int LD>
 __device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, const double* B, int K, int lr, int lc) {
   const double2* ap = reinterpret_cast<const double2*>(A + lr * BS * LD);
@@ -88,7 +140,7 @@ __device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, co
 
 // DBG = true: the instance tools/kalman_phases.py launches (phase stamps of draw 0 in `dbg`); the product instance carries
 // neither the stamps nor their registers.
-template <int BS, bool DBG = false>
+template <int BS, bool DBG = false, int SK = 8 * BS>
 __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2 : 1))) void kalman_nt_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
@@ -97,12 +149,26 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
     const int32_t* __restrict__ order, const double* __restrict__ Rsel, const double* __restrict__ qdiag, int q_batched,
     int k_shocks, const unsigned long long* __restrict__ colmask_in) {
-  constexpr int NP = KntSmem<BS>::NP, LDK = KntSmem<BS>::LDK, PS = KntSmem<BS>::PS;
+  using SM = KntSmem<BS, SK>;
+  constexpr int NP = SM::NP, LDK = SM::LDK, PS = SM::PS;
+  constexpr bool NARROW = SK < NP;  // rows of Tc / W' / Pc shorter than the tile: stores beyond column SK - 1 are skipped
+  // LEAN (single-buffered products, for a two-waves-per-SIMD build of the 32-wide tile) is OFF: measured in round 4 on the
+  // observe_jumps leg (25 filtered variables): 2.49 -> 2.79 ms per step.  The launch ends with the never-steady draw's 200 full
+  // steps on a lone wavefront, so the full step's latency sets it, not the occupancy; 304 B of spills and the shorter product
+  // stages make that step slower.
+  constexpr bool LEAN = false;
+#define KNT_MM(acc, A_, B_, K_)                            \
+  do {                                                     \
+    if constexpr (LEAN)                                    \
+      mm_nt_sb<BS, LDK>(acc, A_, B_, K_, lr, lc);          \
+    else                                                   \
+      mm_nt<BS, LDK>(acc, A_, B_, K_, lr, lc);             \
+  } while (0)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;                 // NP x LDK    transition, states-first ordering (columns >= s exactly zero)
   double* Wt = Tc + NP * LDK;        // WT doubles  W' : Wt[j][k] = (P+[S,S] Tc')[k][j]            (phase f)
   double* Vs = Wt;                   //   alias: NP x PS  -V = -(P Zm' + jitter K)                 (phases d, e)
-  double* Pc = Wt + KntSmem<BS>::WT; // s_cap x LDK P+ restricted to the state block
+  double* Pc = Wt + SM::WT;          // s_cap x LDK P+ restricted to the state block
   double* PZt = Pc + s_cap * LDK;    // NP x PS     (predicted P) Z', unmasked
   double* Ks = PZt + NP * PS;        // NP x PS     K = P Zm' Finv  (kept through the prediction: the steady loop reads it)
   double* av = Ks + NP * PS;         // NP          predicted state
@@ -131,7 +197,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     }
     const size_t off = (size_t)draw * m_full * m_full;
     wave_sync();
-    for (int idx = lane; idx < (int)KntSmem<BS>::doubles(s_cap); idx += 64) smem[idx] = 0.0;
+    for (int idx = lane; idx < (int)SM::doubles(s_cap); idx += 64) smem[idx] = 0.0;
 
     // ---- exact state-space reduction to U = S u O, states first (as kalman_sel_kernel) ----------------------------
     const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
@@ -244,7 +310,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         if (!Rsel) Qb[i][j] = in ? RQR[off + g] : 0.0;
         Pb[i][j] = (in && P0) ? P0[off + g] : 0.0;
         Tb0[i][j] = tv;
-        Tc[(lr * BS + i) * LDK + lc * BS + j] = tv;
+        if (!NARROW || lc * BS + j < SK) Tc[(lr * BS + i) * LDK + lc * BS + j] = tv;  // (columns >= s of T are exact zeros)
       }
     const bool in_state_block = (lr * BS < s) && (lc * BS < s);
     const bool w_rows = lr * BS < s;  // this lane's rows of W = P+[S,S] Tc' exist
@@ -262,7 +328,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         if (w_rows) {
           double Wb[BS][BS];
           blk_zero<BS>(Wb);
-          mm_nt<BS, LDK>(Wb, Pc, Tc, s, lr, lc);  // P[S,S] A_k'
+          KNT_MM(Wb, Pc, Tc, s);  // P[S,S] A_k'
 #pragma unroll
           for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -274,9 +340,9 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         wave_sync();
         double Xb[BS][BS];
         blk_zero<BS>(Xb);
-        mm_nt<BS, LDK>(Xb, Tc, Wt, s, lr, lc);
+        KNT_MM(Xb, Tc, Wt, s);
         wave_sync();
-        blk_store_lds<BS>(Ab, Tc, LDK, lr, lc);
+        knt_store_cols<BS, NARROW ? SK : 0>(Ab, Tc, LDK, lr, lc);
         const int src = (lc << 3) | lr;
         double dmax = 0.0, pmax = 0.0;
 #pragma unroll
@@ -298,8 +364,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         }
       }
       wave_sync();
-      blk_store_lds<BS>(Tb0, Tc, LDK, lr, lc);
-      for (int idx = lane; idx < KntSmem<BS>::WT; idx += 64) Wt[idx] = 0.0;  // (the filter relies on zero padding)
+      knt_store_cols<BS, NARROW ? SK : 0>(Tb0, Tc, LDK, lr, lc);
+      for (int idx = lane; idx < SM::WT; idx += 64) Wt[idx] = 0.0;  // (the filter relies on zero padding)
       if (!lyap_ok) {
         if (lane == 0) {
           status[draw] |= DSGE_ST_LYAP_FAIL;
@@ -540,13 +606,14 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       if (w_rows) {
         double Wb[BS][BS];
         blk_zero<BS>(Wb);
-        mm_nt<BS, LDK>(Wb, Pc, Tc, s, lr, lc);
+        KNT_MM(Wb, Pc, Tc, s);
 #pragma unroll
         for (int i = 0; i < BS; ++i)
 #pragma unroll
           for (int j = 0; j < BS; ++j) Wt[(lc * BS + j) * LDK + lr * BS + i] = Wb[i][j];
       }
-      if (fold_a && lane < NP) Wt[(NP - 1) * LDK + lane] = af_l;  // after the W stores (same wave: LDS keeps program order)
+      if (fold_a && lane < SK) Wt[(NP - 1) * LDK + lane] = af_l;  // after the W stores (same wave: LDS keeps program order);
+                                                                  // the X product contracts over k < s <= SK only
       wave_sync();  // #4
       if constexpr (DBG) {
         const long long tk1 = clock64();
@@ -556,7 +623,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       {
         double Xb[BS][BS];
         blk_zero<BS>(Xb);
-        mm_nt<BS, LDK>(Xb, Tc, Wt, s, lr, lc);
+        KNT_MM(Xb, Tc, Wt, s);
         if (fold_a && lc == 7) {  // column NP-1 of X = Tc a+: hand it to the LDS copy of the mean, restore the padding
 #pragma unroll
           for (int i = 0; i < BS; ++i) {
@@ -584,10 +651,10 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same (register-only) ====
       if (steady_step < 0) steady_step = t + 1;
       {
-        double trow[NP], finv_row[8], kr_ss[8];
+        double trow[SK], finv_row[8], kr_ss[8];
         double av_reg = (lane < m) ? av[lane] : 0.0;
 #pragma unroll
-        for (int kk = 0; kk < NP; ++kk) trow[kk] = (lane < NP) ? Tc[lane * LDK + kk] : 0.0;  // columns >= s are zero
+        for (int kk = 0; kk < SK; ++kk) trow[kk] = (lane < NP) ? Tc[lane * LDK + kk] : 0.0;  // columns >= s are zero
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           finv_row[q] = (lane < 8) ? fr[q] * inv_own : 0.0;  // lane r < 8 still holds row r of Finv (unscaled)
@@ -626,7 +693,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           const double afi = a0 + a1;
           double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int kk = 0; kk < NP; kk += 2) {
+          for (int kk = 0; kk < SK; kk += 2) {
             s0 = fma(trow[kk], readlane_f64(afi, kk), s0);
             s1 = fma(trow[kk + 1], readlane_f64(afi, kk + 1), s1);
           }
@@ -639,6 +706,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       if constexpr (DBG) ph[5] += clock64() - tk0;
     }
 #undef STORE_PZT
+#undef KNT_MM
     if (DBG && dbg && draw == 0 && lane == 0) {
       ph[7] = clock64() - tk_start;
       for (int k = 0; k < 8; ++k) dbg[k] = ph[k];

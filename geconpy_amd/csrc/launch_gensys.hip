@@ -152,7 +152,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
                        cp, tol, wsp, g_gensys_win_dbg, obs_d);
     GW_EVENT(1);
     if (pairs) {
-      hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0);
+      hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0, 1);
       GW_EVENT(2);
       if (dsge::gp_ld(cp) == 37)
         hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<37>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,
@@ -162,7 +162,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
                            g_gensys_win_dbg);
     } else {
       hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg,
-                         opt().gensys_real_stage);
+                         opt().gensys_real_stage, 0);
     }
     if (!pairs) GW_EVENT(2);
     GW_EVENT(3);

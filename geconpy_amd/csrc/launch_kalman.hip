@@ -1,6 +1,8 @@
 // Launcher of the Kalman log-likelihood kernels (fast-path tile cascade + general kernel).
 #include <mutex>
 
+#include <type_traits>
+
 #include "dsge_host.hpp"
 #include "dsge_kalman_out.hpp"
 #include "dsge_kernels.hpp"
@@ -157,22 +159,32 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
           }
           if (!done && opt().kalman_nt_products) {
             // round-2 fast path: NT prediction products on 16-byte aligned rows (dsge_kalman_nt.hpp)
-            const size_t lds_q = dsge::KntSmem<BS>::bytes(s_cap);
-            if (g_kalman_dbg) {  // tools/kalman_phases.py: the instance with the phase stamps
-              rc = set_lds(dsge::kalman_nt_kernel<BS, true>, lds_q);
-              if (rc == DSGE_SUCCESS)
-                hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T,
-                                   RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
-                                   s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
-            } else {
-              rc = set_lds(dsge::kalman_nt_kernel<BS>, lds_q);
-              if (rc == DSGE_SUCCESS)
-                hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q, st, T, RQR,
-                                   p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
-                                   s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
-                                   g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
-            }
+            // instance by the state-block capacity: SK = 20 (up to 18-20 state variables: rows of the LDS matrices 22 doubles
+            // long, the 32-wide tile at exactly 20 KB = eight draws per CU and two waves per SIMD) or the generic SK = NP
+            auto launch_nt = [&](auto sk_tag) {
+              constexpr int SKV = decltype(sk_tag)::value;
+              const size_t lds_q = dsge::KntSmem<BS, SKV>::bytes(s_cap);
+              if (g_kalman_dbg) {  // tools/kalman_phases.py: the instance with the phase stamps
+                rc = set_lds(dsge::kalman_nt_kernel<BS, true, SKV>, lds_q);
+                if (rc == DSGE_SUCCESS)
+                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true, SKV>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q,
+                                     st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
+                                     p, T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
+                                     rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
+              } else {
+                rc = set_lds(dsge::kalman_nt_kernel<BS, false, SKV>, lds_q);
+                if (rc == DSGE_SUCCESS)
+                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q,
+                                     st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
+                                     p, T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
+                                     rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
+              }
+            };
+            constexpr int SK_NARROW = (BS == 3 || BS == 4) ? 20 : 8 * BS;  // (not an `if constexpr`: this is no template)
+            if (SK_NARROW < 8 * BS && s_cap <= SK_NARROW && opt().kalman_narrow)
+              launch_nt(std::integral_constant<int, SK_NARROW>{});
+            else
+              launch_nt(std::integral_constant<int, 8 * BS>{});
             if (rc == DSGE_SUCCESS) {
               HIP_TRY(hipGetLastError());
               launched_fast = true;

@@ -15,7 +15,7 @@ _lib.check(lib.dsge_debug_gensys_window_phases(0, ctypes.addressof(cyc)))
 c = np.array(list(cyc), dtype=np.int64)
 def split(names, base):
     return {nm: int(c[base + i + 1] - c[base + i]) for i, nm in enumerate(names)}
-print("reduce ", {"pencil+deflation(hh)+store": int(c[1] - c[0])})
+print("reduce ", {"zero + pencil": int(c[0] - c[14]), "deflation (reflectors)": int(c[7] - c[0]), "store": int(c[1] - c[7])})
 print("hesstri", {"load": 0, "T22 triangular(hh) incl. load": int(c[2] - c[5]), "Hessenberg(givens)": int(c[3] - c[2]), "real double-shift sweeps": int(c[6] - c[3]), "store": int(c[4] - c[6])}, "total", int(c[4] - c[5]))
 print("real double-shift stage:", int(c[27]), "sweep steps in", int(c[28]), "sweeps")
 print("pair kernel (two draws per wavefront): steps of all pairs (sum over the calls since the debug buffer was reset)", int(c[29]), "slowest pair", int(c[30]), "stage-A cycles of pair 0", int(c[31]))
