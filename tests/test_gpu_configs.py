@@ -71,6 +71,30 @@ def test_config2_sw_shaped_512_distinct_draws(solver):
         assert np.all(st == 0) and np.array_equal(it, g["ref_cr_iters"])
 
 
+@pytest.mark.parametrize("narrow", [1, 0])
+def test_config2_observed_jump_variables_512_distinct_draws(narrow):
+    """The realistic observation structure (bench.py leg `observe_jumps`): Z selects seven NON-state variables
+    (`_make_design_matrix` allows any, statespace.py:260-332), so the filter keeps 18 states + 7 observed jumps = 25 variables and
+    runs on the 32-wide tile.  512 distinct draws against tests/golden/sw_shaped_wide_jumps.npz (reference cycle reduction +
+    oracle filter, make_jumps_golden.py), with the narrow-row instance of the filter (dsge_options.kalman_narrow, default) and
+    with the generic one: same logp to the bit."""
+    g = load_golden("sw_shaped_wide_jumps.npz")
+    idx = g["draw_idx"]
+    b = _sw_draws(idx)
+    om = wl.sw_shaped_observation_model(observed=tuple(int(v) for v in g["observed"]))
+    assert_allclose(np.abs(om["y"]).sum(), g["y_checksum"], rtol=1e-13)
+    r = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"],
+                                          Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000, options={"kalman_narrow": narrow})
+    assert np.all(r["status"] == 0)
+    rel = np.abs(r["logp"] - g["ref_cr_logp"]) / np.abs(g["ref_cr_logp"])
+    assert rel.max() <= LOGP_RTOL, (int(idx[rel.argmax()]), rel.max())
+    assert np.median(rel) < 1e-13
+    if narrow == 0:
+        r1 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"],
+                                               Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000, options={"kalman_narrow": 1})
+        assert np.array_equal(r1["logp"], r["logp"])
+
+
 @pytest.mark.parametrize("solver", ["gensys", "cycle_reduction"])
 def test_config1_rbc_4096_draws(solver):
     g = load_golden("rbc_wide.npz")
