@@ -431,4 +431,235 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
 #undef GST
 }
 
+// ---- Hessenberg-triangular reduction with two draws per wavefront (round 4) ----------------------------------------------------
+// The launch in front of the sweeps (gensys_hesstri_kernel: T22 -> upper triangular by reflectors, H22 -> upper Hessenberg by
+// Givens pairs) is VALU-bound at two waves per SIMD while a 30 x 30 window fills 30 .. 42 of its 64 lanes.  Both phases are
+// lockstep loops (bounds depend on the window size only), so two draws of the same shape share one instruction stream: lanes
+// 0..31 own draw 2p, lanes 32..63 draw 2p + 1; a pair of different shapes runs one half at a time (the other half masked).
+// What the one-draw kernel broadcasts with v_readlane is read back from LDS (same address in every lane of a half):
+// the reflector's source column, the pivots f, g of a Givens pair and the two entries of T that define the column rotation.
+// Per Givens pair SIX 32-lane passes serve two draws (rows: H, X, T columns; columns: H, T, M rows) instead of five 64-lane
+// passes per draw, and the rotation generators are shared.  LDS: [H | X] and T of both draws, 35.5 KB per wavefront at w = 30,
+// #lead = 12 (four wavefronts per CU, one per SIMD: the launch is two rounds of a latency-bound chain).  M is kept REAL in
+// the workspace (MRE), one row per lane, the shared column of consecutive rotations in a register, as in the one-draw kernel.
+// MEASURED AND NOT THE DEFAULT (dsge_options.gensys_pairs = 2 selects it; tools/hess_pair_check.py): 92 VALU instructions per
+// Givens pair for TWO draws against 104 per draw in gensys_hesstri_kernel -- 2.3 x fewer -- but 3.26 ms instead of 3.17 ms per
+// 4096-draw gensys call: with a full H and T per draw the LDS holds one wavefront per SIMD, every instruction's latency is
+// exposed (135 instructions x ~7 cycles per rotation) and the 2048 wavefronts need two rounds; the one-draw kernel runs nine
+// draws per CU.  It would need ~4 wavefronts per SIMD to turn the saved instructions into time (H in a packed layout does not
+// exist before it is Hessenberg).
+__host__ __device__ inline size_t gp_hess_smem(const GwCaps& c) { return 2 * gw_reduce2_smem(c); }
+
+__global__ __launch_bounds__(64) void gensys_hesstri_pair_kernel(int batch, GwCaps cp, double* __restrict__ ws,
+                                                                  long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
+  const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
+  const size_t per_half = (size_t)cp.wcap * ldH + (size_t)cp.wcap * ldW;
+  double* hb = smem + (size_t)h * per_half;  // [H | X]: X(i, j) at column wcap + j
+  double* tb = hb + (size_t)cp.wcap * ldH;
+  const GwOffsets wo = gw_offsets(cp);
+  const int npairs = (batch + 1) >> 1;
+  for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const int draw = 2 * pair + h;
+    const bool exists = draw < batch;
+    double* wd = ws + (size_t)(exists ? draw : 2 * pair) * wo.total;
+    const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
+    const bool valid = exists && meta[GW_FLAG] == 0;
+    const int w_own = valid ? meta[GW_N] - meta[GW_Z] : 0, ell_own = valid ? meta[GW_ELL] : 0;
+    double* MR = wd + wo.MRE;  // element (row, col) at MR[col * wcap + row]
+    if (dbg && pair == 0 && lane == 0) dbg[5] = (long long)clock64();
+    wave_sync();
+    {  // the window as the deflation left it
+      const int total = w_own * w_own, wdiv = w_own > 0 ? w_own : 1;
+      for (int base = 0; base < cp.wcap * cp.wcap; base += 4 * 32) {
+        double hv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 32 + l;
+          const int ic = idx < total ? idx : 0;
+          const int i = ic / wdiv, j = ic - i * wdiv;
+          const size_t o = (size_t)i * cp.wcap + j;
+          hv[u] = wd[wo.HR + o];
+          tv[u] = wd[wo.TR + o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 32 + l;
+          if (idx < total) {
+            const int i = idx / wdiv, j = idx - i * wdiv;
+            hb[i * ldH + j] = hv[u];
+            tb[i * ldW + j] = tv[u];
+          }
+        }
+      }
+      const int totx = w_own * ell_own, ediv = ell_own > 0 ? ell_own : 1;
+      for (int idx = l; idx < cp.wcap * cp.lcap; idx += 32)
+        if (idx < totx) {
+          const int i = idx / ediv, j = idx - i * ediv;
+          hb[i * ldH + cp.wcap + j] = wd[wo.XR + (size_t)i * cp.lcap + j];
+        }
+      if (l < w_own)  // M = I, every lane the row it keeps reading and writing
+        for (int col = 0; col < w_own; ++col) MR[(size_t)col * cp.wcap + l] = (l == col) ? 1.0 : 0.0;
+    }
+    wave_sync();
+    // the shapes of the two halves (wave-uniform through readlane)
+    const int wA = __builtin_amdgcn_readlane(w_own, 0), wB = __builtin_amdgcn_readlane(w_own, 32);
+    const int eA = __builtin_amdgcn_readlane(ell_own, 0), eB = __builtin_amdgcn_readlane(ell_own, 32);
+    const bool same = (wA == wB && eA == eB);
+    const int nrun = same ? 1 : 2;
+    for (int run = 0; run < nrun; ++run) {
+      const int w = same ? wA : (run == 0 ? wA : wB), ell = same ? eA : (run == 0 ? eA : eB);
+      const bool on = same ? (w_own == w && w >= 1) : (h == run && w >= 1);  // this half takes part in this run
+      if (w < 2) continue;
+      const int cw = min(l, w - 1);                  // column of H / T, row of H / T / M (lanes >= w duplicate the last)
+      const int cxl = cp.wcap + min(l, max(ell - 1, 0));  // column of X inside hb
+      // ---- T22 -> upper triangular (reflectors from the left on [H | X] and T) ------------------------------------------
+      for (int j = 0; j < w - 1; ++j) {
+        const double xv = (l >= j && l < w) ? tb[l * ldW + j] : 0.0;
+        const double xnorm2 = half_sum((l > j) ? xv * xv : 0.0);
+        if (__ballot(on && xnorm2 != 0.0) == 0ull) continue;
+        const double alpha = tb[j * ldW + j];
+        const bool live = xnorm2 != 0.0;
+        const double nrm = sqrt(fma(alpha, alpha, xnorm2));
+        const double beta = live ? ((alpha >= 0.0) ? -nrm : nrm) : alpha;
+        const double tau = live ? (beta - alpha) / beta : 0.0;
+        const double scal = live ? 1.0 / (alpha - beta) : 0.0;
+        const double* px0 = tb + (size_t)(j + 1) * ldW + j;  // the source column below the diagonal (broadcast reads)
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+          if (pass == 1 && ell == 0) continue;
+          double* bA = pass == 0 ? hb + cw : (pass == 1 ? hb + cxl : tb + cw);
+          const int lA = pass == 2 ? ldW : ldH;
+          const double mj = bA[j * lA];
+          double* pA = bA + (j + 1) * lA;
+          const double* px = px0;
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          int r = j + 1;
+          for (; r + 4 <= w; r += 4) {
+            const double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
+            const double v0 = px[0], v1 = px[ldW], v2 = px[2 * ldW], v3 = px[3 * ldW];
+            a0 = fma(v0, m0, a0);
+            a1 = fma(v1, m1, a1);
+            a2 = fma(v2, m2, a2);
+            a3 = fma(v3, m3, a3);
+            pA += 4 * lA;
+            px += 4 * ldW;
+          }
+          for (; r < w; ++r) {
+            a0 = fma(px[0], pA[0], a0);
+            pA += lA;
+            px += ldW;
+          }
+          const double wv = -tau * fma(scal, (a0 + a1) + (a2 + a3), mj);
+          const double wsc = scal * wv;
+          pA = bA + (j + 1) * lA;
+          px = px0;
+          for (r = j + 1; r + 4 <= w; r += 4) {
+            double m0 = pA[0], m1 = pA[lA], m2 = pA[2 * lA], m3 = pA[3 * lA];
+            const double v0 = px[0], v1 = px[ldW], v2 = px[2 * ldW], v3 = px[3 * ldW];
+            m0 = fma(v0, wsc, m0);
+            m1 = fma(v1, wsc, m1);
+            m2 = fma(v2, wsc, m2);
+            m3 = fma(v3, wsc, m3);
+            if (on) {
+              pA[0] = m0;
+              pA[lA] = m1;
+              pA[2 * lA] = m2;
+              pA[3 * lA] = m3;
+            }
+            pA += 4 * lA;
+            px += 4 * ldW;
+          }
+          for (; r < w; ++r) {
+            const double m0 = fma(px[0], wsc, pA[0]);
+            if (on) pA[0] = m0;
+            pA += lA;
+            px += ldW;
+          }
+          if (on) bA[j * lA] = mj + wv;  // row j last (the source column's rows below were read unscaled above)
+        }
+        if (on && l >= j && l < w) tb[l * ldW + j] = (l == j) ? beta : 0.0;
+      }
+      if (dbg && pair == 0 && lane == 0 && run == 0) dbg[2] = (long long)clock64();
+      // ---- H22 -> upper Hessenberg by Givens pairs ----------------------------------------------------------------------
+      for (int j = 0; j < w - 2; ++j) {
+        double g = hb[(w - 1) * ldH + j];
+        double m_hi = MR[(size_t)(w - 1) * cp.wcap + cw];
+        double m_nx = MR[(size_t)(w - 2) * cp.wcap + cw];
+        for (int i = w - 1; i > j + 1; --i) {
+          const double m_lo_in = m_nx;
+          m_nx = MR[(size_t)max(i - 2, 0) * cp.wcap + cw];
+          const double f = hb[(i - 1) * ldH + j];
+          double hx = hb[(i - 1) * ldH + cw], hy = hb[i * ldH + cw];
+          double ax = hb[(i - 1) * ldH + cxl], ay = hb[i * ldH + cxl];
+          double tx = tb[(i - 1) * ldW + cw], ty = tb[i * ldW + cw];
+          double c, s, r;
+          gw_lartg(f, g, c, s, r);
+          rot2r(hx, hy, c, s);
+          rot2r(ax, ay, c, s);
+          rot2r(tx, ty, c, s);
+          if (cw == j) {
+            hx = r;
+            hy = 0.0;
+          }
+          if (on) {
+            hb[(i - 1) * ldH + cw] = hx;
+            hb[i * ldH + cw] = hy;
+            tb[(i - 1) * ldW + cw] = tx;
+            tb[i * ldW + cw] = ty;
+            if (ell > 0) {
+              hb[(i - 1) * ldH + cxl] = ax;
+              hb[i * ldH + cxl] = ay;
+            }
+          }
+          g = r;
+          // the column rotation that restores T(i, i-1) = 0 (read back behind the stores: LDS keeps program order)
+          const double tii = tb[i * ldW + i], tim = tb[i * ldW + i - 1];
+          double hx2 = hb[cw * ldH + i], hy2 = hb[cw * ldH + i - 1];
+          double tx2 = tb[cw * ldW + i], ty2 = tb[cw * ldW + i - 1];
+          double r2, m_lo = m_lo_in;
+          gw_lartg(tii, tim, c, s, r2);
+          rot2r(hx2, hy2, c, s);
+          rot2r(tx2, ty2, c, s);
+          rot2r(m_hi, m_lo, c, s);
+          if (cw == i) {
+            tx2 = r2;
+            ty2 = 0.0;
+          }
+          if (on) {
+            hb[cw * ldH + i] = hx2;
+            hb[cw * ldH + i - 1] = hy2;
+            tb[cw * ldW + i] = tx2;
+            tb[cw * ldW + i - 1] = ty2;
+            MR[(size_t)i * cp.wcap + cw] = m_hi;  // column i of M is final for this j
+          }
+          m_hi = m_lo;
+        }
+        if (on) MR[(size_t)(j + 1) * cp.wcap + cw] = m_hi;
+      }
+    }
+    wave_sync();
+    if (dbg && pair == 0 && lane == 0) dbg[3] = (long long)clock64();
+    {  // hand the window on
+      const int total = w_own * w_own, wdiv = w_own > 0 ? w_own : 1;
+      for (int idx = l; idx < cp.wcap * cp.wcap; idx += 32)
+        if (idx < total) {
+          const int i = idx / wdiv, j = idx - i * wdiv;
+          const size_t o = (size_t)i * cp.wcap + j;
+          wd[wo.HR + o] = hb[i * ldH + j];
+          wd[wo.TR + o] = tb[i * ldW + j];
+        }
+      const int totx = w_own * ell_own, ediv = ell_own > 0 ? ell_own : 1;
+      for (int idx = l; idx < cp.wcap * cp.lcap; idx += 32)
+        if (idx < totx) {
+          const int i = idx / ediv, j = idx - i * ediv;
+          wd[wo.XR + (size_t)i * cp.lcap + j] = hb[i * ldH + cp.wcap + j];
+        }
+    }
+    if (dbg && pair == 0 && lane == 0) dbg[4] = (long long)clock64();
+  }
+}
+
 }  // namespace dsge

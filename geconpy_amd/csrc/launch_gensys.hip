@@ -130,7 +130,9 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   if ((rc = set_lds(dsge::gensys_post_kernel, lds3))) return rc;
   if ((rc = set_lds(dsge::gensys_eu_kernel, lds_eu))) return rc;
   const bool pairs = opt().gensys_real_stage && opt().gensys_pairs && dsge::gp_fits(cp);
-  const size_t lds_pair = dsge::gp_smem(cp);
+  const size_t lds_pair = dsge::gp_smem(cp), lds_hpair = dsge::gp_hess_smem(cp);
+  const bool hess_pairs = pairs && opt().gensys_pairs >= 2 && lds_hpair <= LDS_LIMIT;
+  if (hess_pairs && (rc = set_lds(dsge::gensys_hesstri_pair_kernel, lds_hpair))) return rc;
   if (pairs && (rc = set_lds(dsge::gensys_sweeps_pair_kernel<37>, lds_pair))) return rc;
   if (pairs && (rc = set_lds(dsge::gensys_sweeps_pair_kernel<39>, lds_pair))) return rc;
   const size_t nn = (size_t)n * n;
@@ -152,7 +154,11 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
                        cp, tol, wsp, g_gensys_win_dbg, obs_d);
     GW_EVENT(1);
     if (pairs) {
-      hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0, 1);
+      if (hess_pairs)
+        hipLaunchKernelGGL(dsge::gensys_hesstri_pair_kernel, dim3((nb + 1) / 2), dim3(64), lds_hpair, st, nb, cp, wsp,
+                           g_gensys_win_dbg);
+      else
+        hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0, 1);
       GW_EVENT(2);
       if (dsge::gp_ld(cp) == 37)
         hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<37>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,

@@ -169,7 +169,8 @@ typedef struct dsge_options {
   int32_t gensys_real_stage; /* (the slot was reserved_ up to ABI 4 builds: same size, same offsets) */
   /* ABI 7 (no dsge_set_* twin: per call only; dsge_options_init fills the defaults) */
   int32_t gensys_pairs;       /* 1 (default): window path, real double-shift sweeps with TWO draws per wavefront when the window
-                                 and #lead are <= 32 (dsge_gensys_pair.hpp); 0: one draw per wavefront (round 3) */
+                                 and #lead are <= 32 (dsge_gensys_pair.hpp); 0: one draw per wavefront (round 3); 2: also the
+                                 Hessenberg-triangular launch on two draws per wavefront (measured slower: experiment) */
   int32_t gensys_shape_cache; /* 1 (default): the capacity record of the window path (max #lead, window, deflated roots) is
                                  measured on the first call of a model size and reused -- later calls are pure enqueues; a
                                  draw that exceeds it is flagged DSGE_ST_GENSYS_TOO_BIG and the record grows for the next

@@ -2109,14 +2109,15 @@ def test_gensys_two_draws_per_wavefront_match_one():
     mix = [np.stack([b[x][i] if i % 2 == 0 else b2[x][i] for i in range(16)]) for x in "ABCD"]
     cases.append(tuple(mix))
     for A, B, C, D in cases:
-        on = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_pairs": 1})
         off = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_pairs": 0})
-        assert np.array_equal(on["eu"], off["eu"])
-        assert np.array_equal(on["status"], off["status"])
-        good = (off["eu"][:, 0] == 1) & (off["eu"][:, 1] == 1)
-        sc = np.maximum(1.0, np.abs(off["T"]).max(axis=(1, 2)))
-        err = np.abs(on["T"] - off["T"]).max(axis=(1, 2)) / sc
-        assert (err[good] <= 1e-10).all(), err[good].max()
+        for mode in (1, 2):  # 1: the sweeps on two draws per wavefront (default); 2: also the Hessenberg-triangular launch
+            on = batched.gensys_batched(A, B, C, D, tol=1e-8, options={"gensys_split": 2, "gensys_pairs": mode})
+            assert np.array_equal(on["eu"], off["eu"])
+            assert np.array_equal(on["status"], off["status"])
+            good = (off["eu"][:, 0] == 1) & (off["eu"][:, 1] == 1)
+            sc = np.maximum(1.0, np.abs(off["T"]).max(axis=(1, 2)))
+            err = np.abs(on["T"] - off["T"]).max(axis=(1, 2)) / sc
+            assert (err[good] <= 1e-10).all(), (mode, err[good].max())
     on = batched.gensys_batched(b["A"][:8], b["B"][:8], b["C"][:8], b["D"][:8], tol=1e-8, options={"gensys_split": 2})
     for i in range(8):
         Tref, ok = oracle.gensys_T_success(b["A"][i], b["B"][i], b["C"][i], b["D"][i], tol=1e-8)[:2]
