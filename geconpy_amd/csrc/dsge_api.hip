@@ -729,6 +729,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     // the explicit R = -(C T + B)^-1 D of the assemble kernel is kept whenever the caller wants the policy residual.
     const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && opt().cr_fused_selection && !park_failures;
     bool have_colmask = false;
+    int gensys_key = 0;  // 1: the gensys launches have written the Kalman dispatch key
     if (is_cr) {
       int deflated = 0;
       // static variables deflated first (the iteration then runs on n - h variables); not when the caller asks for the
@@ -742,7 +743,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
                        solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ? 1 : 0, fuse_R ? D : nullptr, k, fuse_R ? Rw : nullptr);
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
-      rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st);
+      rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st, nullptr,
+                         (opt().kalman_order != 0 && batch >= 512) ? key_w : nullptr, &gensys_key);
     } else {
       HIP_TRY(hipMemsetAsync(status_out, 0, sizeof(int32_t) * batch, st));
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
@@ -757,9 +759,13 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     // formula (C T + B = B when C == 0), which keeps a single code path for resid/RQR/P0.
     const bool q_diag = q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED;
     // sym(R Q R') inside the filter kernel (its retained block only) when the fast selector kernel takes the draws
-    const bool fold_rqr = fuse_R && q_diag && n <= 64 && kalman_folds_rqr(n, p, k, n_state_hint, z_selector_hint);
-    if (fold_rqr)
+    // (round 4: also behind the explicit selection of gensys / backward-direct / a requested residual -- the assemble launch then
+    // forms R (and the residual) only: no 40 x 40 product, no 51 MB of R Q R' through HBM per 4096 draws)
+    const bool fold_rqr = !park_failures && q_diag && n <= 64 && kalman_folds_rqr(n, p, k, n_state_hint, z_selector_hint);
+    if (fold_rqr && fuse_R)
       rc = DSGE_SUCCESS;
+    else if (fold_rqr)
+      rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, nullptr, nullptr, status_out, 1, 0, st);
     else if (fuse_R && q_diag && k <= 16 && n <= 64)
       rc = launch_rqr(Rw, Q, q_mode == DSGE_Q_DIAG_BATCHED, batch, n, k, status_out, RQR, st);  // (RQR_KMAX = 16)
     else if (fuse_R)
@@ -775,7 +781,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (opt().kalman_order == 1 && is_cr) {
       okey = it_w;
     } else if (opt().kalman_order != 0 && batch >= 512 && n <= 64) {
-      if ((rc = launch_persistence_key(Tw, status_out, batch, n, key_w, st))) return rc;
+      // gensys on the window path has written the key from its own spectrum (gensys_post_kernel)
+      if (!gensys_key && (rc = launch_persistence_key(Tw, status_out, batch, n, key_w, st))) return rc;
       okey = key_w;
     }
     if ((rc = launch_kalman(Tw, RQR, P0, 0, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, p, T_len, jitter,

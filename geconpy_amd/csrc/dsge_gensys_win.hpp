@@ -1064,7 +1064,7 @@ constexpr int GW_POST_THREADS = 256;
 __global__ __launch_bounds__(GW_POST_THREADS) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
                                                           double* __restrict__ T_out, int32_t* __restrict__ eu_out,
                                                           int32_t* __restrict__ status, long long* __restrict__ dbg,
-                                                          int rescue) {
+                                                          int rescue, int32_t* __restrict__ key_out) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;  // 0 .. GW_POST_THREADS-1
   const int n = cp.n;
@@ -1250,6 +1250,25 @@ __global__ __launch_bounds__(GW_POST_THREADS) void gensys_post_kernel(int batch,
       GW_STAMP(26);
     } else {
       for (int idx = lane; idx < n * n; idx += GW_POST_THREADS) T_out[off + idx] = 0.0;
+    }
+    if (key_out && lane < 64) {
+      // Dispatch key of the Kalman launch (persistence_key_kernel's scale: 8 * -log2(1 - rho), 0..63) from the spectrum the QZ
+      // iteration has just computed: rho = the largest modulus |beta / alpha| among the stable roots of the window (the deflated
+      // roots are zero) -- the spectral radius of T itself, where the power iteration only estimates it
+      double kq = 0.0;
+      if (have_T) {
+        const int w_ = meta[GW_N] - meta[GW_Z], ns2_ = meta[GW_NS2];
+        const cx* HCd = reinterpret_cast<const cx*>(wd + wo.HC);
+        const cx* TCd = reinterpret_cast<const cx*>(wd + wo.TC);
+        double mod = 0.0;
+        if (lane < ns2_ && lane < w_) mod = cabs_(TCd[(size_t)lane * cp.wcap + lane]) / cabs_(HCd[(size_t)lane * cp.wcap + lane]);
+        if (!(mod == mod)) mod = 0.0;
+        const double rho = wave_nanmax(mod);
+        kq = (rho < 1.0) ? -8.0 * log2(1.0 - rho) : 63.0;
+        if (!(kq == kq)) kq = 0.0;
+        kq = kq < 0.0 ? 0.0 : (kq > 63.0 ? 63.0 : kq);
+      }
+      if (lane == 0) key_out[draw] = (int32_t)kq;
     }
     if (lane == 0) {
       eu_out[3 * draw] = eu0;

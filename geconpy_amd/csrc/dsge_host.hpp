@@ -156,7 +156,9 @@ int launch_grad_assemble(const double* B, const double* C, const double* T, cons
                          const double* Rbar_in = nullptr);  // Rbar_in: pullback of R = -(C T + B)^-1 D alone (Tbar written)
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
-                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr);
+                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr,
+                  int32_t* key_out = nullptr, int* key_written = nullptr);  // key_out: Kalman dispatch key from the QZ spectrum
+                                                                            // (window path only: *key_written tells)
 
 int launch_gensys_pencil(const double* g0, const double* g1, const double* c, const double* psi, const double* pi, int batch,
                          int N, int k, int ell, double tol, double* G1_out, double* C_out, double* impact_out,

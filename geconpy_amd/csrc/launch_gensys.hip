@@ -47,7 +47,7 @@ struct BkOut {
 };
 int launch_gensys_split(const double* A, const double* B, const double* C, int batch, int n, double tol, double* T_out,
                         int32_t* eu_out, int32_t* status, hipStream_t st, int* used, const BkOut* bk = nullptr,
-                        int n_lead_hint = 0) {
+                        int n_lead_hint = 0, int32_t* key_out = nullptr) {
   *used = 0;
   void* base = nullptr;
   int rc = gw_reserve(256, st, &base);
@@ -182,7 +182,8 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
       hipLaunchKernelGGL(dsge::gensys_eu_kernel, dim3(nb), dim3(64), lds_eu, st, nb, cp, tol, wsp, g_gensys_win_dbg);
       GW_EVENT(5);
       hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(dsge::GW_POST_THREADS), lds3, st, nb, cp, tol, (const double*)wsp,
-                         T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg, cached ? 1 : 0);
+                         T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg, cached ? 1 : 0,
+                         key_out ? key_out + c0 : nullptr);
     }
     GW_EVENT(6);
     HIP_TRY(hipGetLastError());
@@ -246,7 +247,9 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
 }
 
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
-                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg) {
+                  double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg, int32_t* key_out,
+                  int* key_written) {
+  if (key_written) *key_written = 0;
   int rc;
   // Small pencils (<= 24 KB of LDS in the single-launch kernel, i.e. >= 6 draws per CU already) gain nothing from the
   // window path and would pay for its three launches and the shape read-back: RBC-sized models stay on one launch.
@@ -257,8 +260,12 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
   }
   if (opt().gensys_split && !dbg && (!small || opt().gensys_split == 2)) {
     int used = 0;
-    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used, nullptr, n_lead_hint))) return rc;
-    if (used) return DSGE_SUCCESS;
+    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used, nullptr, n_lead_hint, key_out)))
+      return rc;
+    if (used) {
+      if (key_written && key_out) *key_written = 1;
+      return DSGE_SUCCESS;
+    }
   }
   int n_cap = 0, l_cap = 0;
   rc = gensys_caps(n, n_lead_hint, &n_cap, &l_cap);

@@ -181,7 +181,9 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               }
             };
             constexpr int SK_NARROW = (BS == 3 || BS == 4) ? 20 : 8 * BS;  // (not an `if constexpr`: this is no template)
-            if (SK_NARROW < 8 * BS && s_cap <= SK_NARROW && opt().kalman_narrow)
+            // (with R folded in, the kernel stages the m x k selection matrix in its W' buffer, which is narrower too)
+            const bool stage_fits = !fold || (size_t)m * ((k_shocks + 1) & ~1) <= (size_t)(8 * BS) * (SK_NARROW + 2);
+            if (SK_NARROW < 8 * BS && s_cap <= SK_NARROW && opt().kalman_narrow && stage_fits)
               launch_nt(std::integral_constant<int, SK_NARROW>{});
             else
               launch_nt(std::integral_constant<int, 8 * BS>{});
