@@ -182,7 +182,8 @@ class Options(C.Structure):
         ("gensys_pairs", C.c_int32),
         ("gensys_shape_cache", C.c_int32),
         ("kalman_narrow", C.c_int32),
-        ("reserved_", C.c_int32 * 5),
+        ("gensys_direct_blocks", C.c_int32),
+        ("reserved_", C.c_int32 * 4),
     ]
 
 

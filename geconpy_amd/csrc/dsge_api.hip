@@ -137,6 +137,7 @@ struct OptionsGuard {
     local.gensys_pairs = o->gensys_pairs;
     local.gensys_shape_cache = o->gensys_shape_cache;
     local.kalman_narrow = o->kalman_narrow;
+    local.gensys_direct_blocks = o->gensys_direct_blocks;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -2119,6 +2120,7 @@ int dsge_options_init(dsge_options* o) {
   o->gensys_pairs = d.gensys_pairs;
   o->gensys_shape_cache = d.gensys_shape_cache;
   o->kalman_narrow = d.kalman_narrow;
+  o->gensys_direct_blocks = d.gensys_direct_blocks;
   return DSGE_SUCCESS;
 }
 

@@ -886,6 +886,96 @@ __device__ __forceinline__ bool qz_iterate(const GsLayout& L, int ilo, int lane,
 }
 
 // ---- step 4: reordering --------------------------------------------------------------------------
+// ---- direct standardisation of isolated 2 x 2 blocks (round 4) -----------------------------------------------------------------
+// After the real double-shift stage the Hessenberg-triangular window is quasi-triangular: every sub-diagonal entry is an exact
+// zero except inside isolated 2 x 2 blocks (complex pairs, or two real roots the real iteration had not separated yet).
+// zhgeqz's logic (qz_iterate) then spends one iteration of its general machinery per eigenvalue -- prefetch of five diagonals,
+// ballots, the split of every 1 x 1 block, two sweeps per 2 x 2 block: 133 k cycles on the 30 x 30 window for twelve sweep
+// steps.  A 2 x 2 pencil (A, B), B upper triangular, is triangularised in closed form instead: lambda = a root of
+// det(A - lambda B) = 0, z = the null vector of A - lambda B (the better conditioned of its two rows), the column rotation
+// whose first column is z / |z|, then the row rotation that annihilates (B z)_2 -- and with it (A z)_2 = lambda (B z)_2.  The
+// blocks do not interact (rotations of rows / columns i, i+1 leave every other diagonal block alone), so one pass handles all
+// of them.  Every result is checked (both annihilated entries at rounding level of the block) and set to an exact zero; a
+// block that fails, a negligible diagonal of B inside a block, or two adjacent non-zero sub-diagonals (the real stage stopped
+// early) leave the matrix to qz_iterate, which remains the owner of every special case.  Returns true when the window is
+// upper triangular afterwards.  Any unitary equivalence is a valid input of the reordering and of everything behind it: T and
+// eu do not depend on the Schur basis inside the stable / unstable groups.
+__device__ __forceinline__ bool qz_direct_blocks(const GsLayout& L, int lane) {
+  const int N = L.N;
+  if (N > 64 || N < 2) return false;
+  const double ULP = 2.220446049250313e-16;
+  wave_sync();
+  const bool act = lane < N && lane > 0;
+  const cx hs = act ? hget(L, lane, lane - 1) : mk(0, 0);
+  const cx ts = act ? tget(L, lane, lane - 1) : mk(0, 0);
+  const unsigned long long blocks = __ballot(act && !is0(hs));
+  if (__ballot(act && !is0(ts)) != 0ull) return false;      // T is not triangular: not the real stage's output
+  if ((blocks & (blocks >> 1)) != 0ull) return false;       // adjacent sub-diagonals: an unreduced block larger than 2 x 2
+  bool all_ok = true;
+  unsigned long long rem = blocks;
+  while (rem != 0ull) {
+    const int j = __builtin_ctzll(rem);  // block rows / columns i = j - 1, j
+    rem &= rem - 1ull;
+    const int i = j - 1;
+    const cx a11 = hget(L, i, i), a12 = hget(L, i, j), a21 = hget(L, j, i), a22 = hget(L, j, j);
+    const cx b11 = tget(L, i, i), b12 = tget(L, i, j), b22 = tget(L, j, j);
+    const double an = abs1(a11) + abs1(a12) + abs1(a21) + abs1(a22), bn = abs1(b11) + abs1(b12) + abs1(b22);
+    if (!(abs1(b11) > 1e-10 * bn) || !(abs1(b22) > 1e-10 * bn) || !(an < 1e300) || !(bn < 1e300)) {
+      all_ok = false;  // an (almost) infinite root inside the block: zhgeqz's zero chasing
+      continue;
+    }
+    // det(A - l B) = qa l^2 + qb l + qc
+    const cx qa = b11 * b22, qb = neg(a11 * b22 + a22 * b11 - a21 * b12), qc = a11 * a22 - a12 * a21;
+    const cx dsq = qb * qb - 4.0 * (qa * qc);
+    // Complex pairs only.  Two REAL roots that the real stage left together are close to each other -- that is why they had not
+    // separated -- i.e. nearly defective: their values move by sqrt(eps) under rounding, and the iteration (which rounds like
+    // LAPACK's) stays closer to the reference's numbers than a closed form does (the BK eigenvalue test compares them at 1e-7).
+    if (!(dsq.re < 0.0) || fabs(dsq.im) > 1e-8 * fabs(dsq.re)) {
+      all_ok = false;
+      continue;
+    }
+    const cx disc = csqrt_(dsq);
+    // the root from the larger of -qb +- disc (no cancellation): l = (-qb +- disc) / (2 qa)
+    const cx n1 = neg(qb) + disc, n2 = neg(qb) - disc;
+    const cx lam = cdiv(abs1(n1) >= abs1(n2) ? n1 : n2, 2.0 * qa);
+    // z: null vector of A - l B, from its row of larger norm
+    const cx m11 = a11 - lam * b11, m12 = a12 - lam * b12, m21 = a21, m22 = a22 - lam * b22;
+    cx z1, z2;
+    if (abs1(m11) + abs1(m12) >= abs1(m21) + abs1(m22)) {
+      z1 = m12;
+      z2 = neg(m11);
+    } else {
+      z1 = m22;
+      z2 = neg(m21);
+    }
+    if (!(abs1(z1) + abs1(z2) > 0.0)) {
+      all_ok = false;
+      continue;
+    }
+    double c;
+    cx sv, r;
+    lartg(z1, z2, c, sv, r);
+    rot_cols(L, i, j, c, conj(sv), j, lane);  // column i <- (col_i z1 + col_j z2) / |z| (up to a phase)
+    // the row rotation from B z (from A z when B z is the smaller of the two)
+    const cx bz1 = tget(L, i, i), bz2 = tget(L, j, i), az1 = hget(L, i, i), az2 = hget(L, j, i);
+    const bool use_b = abs1(bz1) + abs1(bz2) >= 1e-3 * (abs1(az1) + abs1(az2));
+    lartg(use_b ? bz1 : az1, use_b ? bz2 : az2, c, sv, r);
+    rot_rows(L, i, j, c, sv, i, lane);
+    const cx h21 = hget(L, j, i), t21 = tget(L, j, i);
+    const bool fine = abs1(h21) <= 64.0 * ULP * an && abs1(t21) <= 64.0 * ULP * bn;
+    if (fine) {
+      if (lane == 0) {
+        hput(L, j, i, mk(0, 0));
+        tput(L, j, i, mk(0, 0));
+      }
+      wave_sync();
+    } else {
+      all_ok = false;
+    }
+  }
+  return all_ok;
+}
+
 __device__ __forceinline__ bool root_is_stable(cx a, cx b, double rs) {
   const double aa = cabs_(a), ab = cabs_(b);
   return (ab < rs && aa >= rs) || (ab >= rs && aa > ab);

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
 // ---- launch 2: complex single-shift QZ + reordering on the window (qz_iterate / reorder_stable_first of dsge_gensys.hpp
 // with N := w, ilo := 0; "Ztop" := the accumulated right transformation M, started from the real phase's Zr) -----------
 __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, double tol, double* __restrict__ ws,
-                                                           long long* __restrict__ dbg) {
+                                                           long long* __restrict__ dbg, int direct_blocks) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   GsLayout L;
@@ -770,7 +770,10 @@ __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, 
         });
     wave_sync();
     GW_STAMP(8);
-    const bool converged = qz_iterate(L, 0, lane, (dbg && draw == 0) ? dbg + 12 : nullptr);
+    // round 4: the isolated 2 x 2 blocks the real stage leaves are triangularised in closed form; zhgeqz's iteration only
+    // runs when something is left for it
+    const bool direct = direct_blocks && qz_direct_blocks(L, lane);
+    const bool converged = direct ? true : qz_iterate(L, 0, lane, (dbg && draw == 0) ? dbg + 12 : nullptr);
     GW_STAMP(9);
     const int ns2 = converged ? reorder_stable_first(L, rs, lane) : 0;
     wave_sync();

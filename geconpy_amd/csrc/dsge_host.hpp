@@ -208,6 +208,7 @@ struct Options {
   double kalman_steady_tol = 1e-14;  // steady-state switch of the fast Kalman kernel (0 = never)
   int gensys_pairs = 1;        // window path: two draws per wavefront in the real double-shift sweeps (dsge_gensys_pair.hpp)
   int gensys_shape_cache = 1;  // window path: capacity record measured once per model size
+  int gensys_direct_blocks = 1;  // window path: isolated 2 x 2 blocks triangularised in closed form in front of the complex iteration
   int kalman_narrow = 1;       // fast filter: the SK = 20 instances of the 24- and 32-wide tiles when the state block fits
 };
 extern Options g_defaults;

@@ -172,7 +172,8 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
     }
     if (!pairs) GW_EVENT(2);
     GW_EVENT(3);
-    hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg);
+    hipLaunchKernelGGL(dsge::gensys_qzwin_kernel, dim3(nb), dim3(64), lds2, st, nb, cp, tol, wsp, g_gensys_win_dbg,
+                       (opt().gensys_real_stage && opt().gensys_direct_blocks) ? 1 : 0);
     GW_EVENT(4);
     if (bk)
       hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,

@@ -179,7 +179,11 @@ typedef struct dsge_options {
                                  columns instead of the tile width when the model has at most 20 state variables (the 32-wide
                                  tile then takes exactly 20 KB: eight draws per CU); same arithmetic, bit-identical results;
                                  0: generic instance */
-  int32_t reserved_[5];
+  int32_t gensys_direct_blocks; /* 1 (default): window path, behind the real double-shift stage: the isolated 2 x 2 blocks of the
+                                 quasi-triangular window are triangularised in closed form (a root of the 2 x 2 pencil, its null
+                                 vector, two rotations), checked, and zhgeqz's iteration runs only when something is left for
+                                 it; 0: the complex single-shift iteration splits them (round 3) */
+  int32_t reserved_[4];
 } dsge_options;
 /* fills *opt with the current process-wide defaults */
 int dsge_options_init(dsge_options* opt);
