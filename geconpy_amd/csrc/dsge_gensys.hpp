@@ -911,33 +911,41 @@ __device__ __forceinline__ bool qz_direct_blocks(const GsLayout& L, int lane) {
   const unsigned long long blocks = __ballot(act && !is0(hs));
   if (__ballot(act && !is0(ts)) != 0ull) return false;      // T is not triangular: not the real stage's output
   if ((blocks & (blocks >> 1)) != 0ull) return false;       // adjacent sub-diagonals: an unreduced block larger than 2 x 2
-  bool all_ok = true;
-  unsigned long long rem = blocks;
-  while (rem != 0ull) {
-    const int j = __builtin_ctzll(rem);  // block rows / columns i = j - 1, j
-    rem &= rem - 1ull;
-    const int i = j - 1;
+  if (blocks == 0ull) return true;
+  // Lane j owns block (i, j) = (j - 1, j): the scalar work of all blocks runs side by side, the rotations of a pass are applied
+  // block after block without a fence in between (they touch disjoint row / column pairs).  Two passes: the first leaves
+  // |h21| at rounding level OF THE BLOCK NORM, which for a non-normal block (|a12| >> |a11 - a22|) still moves the roots by
+  // much more than an ULP; the second pass, on the almost triangular block, takes the root next to a11 / b11 and brings the
+  // residual to the level the iteration's quadratic convergence reaches.
+  const bool own = ((blocks >> lane) & 1ull) != 0ull;
+  const int j = own ? lane : 1, i = j - 1;
+  bool ok = true;  // this lane's block is taken by the closed form
+  double an = 0.0, bn = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
     const cx a11 = hget(L, i, i), a12 = hget(L, i, j), a21 = hget(L, j, i), a22 = hget(L, j, j);
     const cx b11 = tget(L, i, i), b12 = tget(L, i, j), b22 = tget(L, j, j);
-    const double an = abs1(a11) + abs1(a12) + abs1(a21) + abs1(a22), bn = abs1(b11) + abs1(b12) + abs1(b22);
-    if (!(abs1(b11) > 1e-10 * bn) || !(abs1(b22) > 1e-10 * bn) || !(an < 1e300) || !(bn < 1e300)) {
-      all_ok = false;  // an (almost) infinite root inside the block: zhgeqz's zero chasing
-      continue;
+    if (pass == 0) {
+      an = abs1(a11) + abs1(a12) + abs1(a21) + abs1(a22);
+      bn = abs1(b11) + abs1(b12) + abs1(b22);
+      // an (almost) infinite root inside the block: zhgeqz's zero chasing
+      if (!(abs1(b11) > 1e-8 * bn) || !(abs1(b22) > 1e-8 * bn) || !(an < 1e300) || !(bn < 1e300)) ok = false;
     }
     // det(A - l B) = qa l^2 + qb l + qc
     const cx qa = b11 * b22, qb = neg(a11 * b22 + a22 * b11 - a21 * b12), qc = a11 * a22 - a12 * a21;
     const cx dsq = qb * qb - 4.0 * (qa * qc);
-    // Complex pairs only.  Two REAL roots that the real stage left together are close to each other -- that is why they had not
-    // separated -- i.e. nearly defective: their values move by sqrt(eps) under rounding, and the iteration (which rounds like
-    // LAPACK's) stays closer to the reference's numbers than a closed form does (the BK eigenvalue test compares them at 1e-7).
-    if (!(dsq.re < 0.0) || fabs(dsq.im) > 1e-8 * fabs(dsq.re)) {
-      all_ok = false;
-      continue;
-    }
+    // the discriminant of a real block is real (complex pair: < 0, two real roots the real stage had not separated: > 0)
+    if (pass == 0 && fabs(dsq.im) > 1e-8 * fabs(dsq.re)) ok = false;
     const cx disc = csqrt_(dsq);
-    // the root from the larger of -qb +- disc (no cancellation): l = (-qb +- disc) / (2 qa)
+    // the two roots without cancellation: l_a = nb / (2 qa) from the larger of -qb +- disc, l_b = 2 qc / nb (Vieta)
     const cx n1 = neg(qb) + disc, n2 = neg(qb) - disc;
-    const cx lam = cdiv(abs1(n1) >= abs1(n2) ? n1 : n2, 2.0 * qa);
+    const cx nb = abs1(n1) >= abs1(n2) ? n1 : n2;
+    const bool nb_ok = abs1(nb) > 0.0;
+    const cx la = cdiv(nb, 2.0 * qa);
+    cx lam = la;
+    if (pass == 1 && nb_ok) {
+      const cx lb = cdiv(2.0 * qc, nb);
+      if (abs1(lb * b11 - a11) < abs1(la * b11 - a11)) lam = lb;  // refinement: the root this block already has at (1, 1)
+    }
     // z: null vector of A - l B, from its row of larger norm
     const cx m11 = a11 - lam * b11, m12 = a12 - lam * b12, m21 = a21, m22 = a22 - lam * b22;
     cx z1, z2;
@@ -948,32 +956,103 @@ __device__ __forceinline__ bool qz_direct_blocks(const GsLayout& L, int lane) {
       z1 = m22;
       z2 = neg(m21);
     }
-    if (!(abs1(z1) + abs1(z2) > 0.0)) {
-      all_ok = false;
-      continue;
-    }
-    double c;
-    cx sv, r;
-    lartg(z1, z2, c, sv, r);
-    rot_cols(L, i, j, c, conj(sv), j, lane);  // column i <- (col_i z1 + col_j z2) / |z| (up to a phase)
-    // the row rotation from B z (from A z when B z is the smaller of the two)
-    const cx bz1 = tget(L, i, i), bz2 = tget(L, j, i), az1 = hget(L, i, i), az2 = hget(L, j, i);
-    const bool use_b = abs1(bz1) + abs1(bz2) >= 1e-3 * (abs1(az1) + abs1(az2));
-    lartg(use_b ? bz1 : az1, use_b ? bz2 : az2, c, sv, r);
-    rot_rows(L, i, j, c, sv, i, lane);
-    const cx h21 = hget(L, j, i), t21 = tget(L, j, i);
-    const bool fine = abs1(h21) <= 64.0 * ULP * an && abs1(t21) <= 64.0 * ULP * bn;
-    if (fine) {
-      if (lane == 0) {
-        hput(L, j, i, mk(0, 0));
-        tput(L, j, i, mk(0, 0));
+    if (!(abs1(z1) + abs1(z2) > 0.0)) ok = false;
+    const unsigned long long todo = __ballot(own && ok);
+    if (todo == 0ull) break;
+    double c = 1.0;
+    cx sv = mk(0, 0), r;
+    if (own && ok) lartg(z1, z2, c, sv, r);
+    // ---- column rotations: column i <- (col_i z1 + col_j z2) / |z| (up to a phase); lane = row (rows <= j of H and T, every
+    // row of the accumulated right transformation)
+    for (unsigned long long rem = todo; rem != 0ull; rem &= rem - 1ull) {
+      const int bj = __builtin_ctzll(rem), bi = bj - 1;
+      const double cc = readlane_dyn_f64(c, bj);
+      const cx ss = conj(bc(sv, bj));
+      if (lane <= bj) {
+        cx x = hget(L, lane, bi), y = hget(L, lane, bj);
+        rot2(x, y, cc, ss);
+        hput(L, lane, bi, x);
+        hput(L, lane, bj, y);
+        x = tget(L, lane, bi);
+        y = tget(L, lane, bj);
+        rot2(x, y, cc, ss);
+        tput(L, lane, bi, x);
+        tput(L, lane, bj, y);
       }
-      wave_sync();
+    }
+    if (lane < L.n) {
+      // the accumulated right transformation (global when zglobal): the loads of up to eight blocks are issued together
+      Z_FENCE();
+      unsigned long long rem = todo;
+      while (rem != 0ull) {
+        cx zx[8], zy[8];
+        int jj[8];
+        unsigned long long r2 = rem;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          jj[u] = r2 != 0ull ? __builtin_ctzll(r2) : -1;
+          r2 &= r2 - 1ull;  // 0 stays 0
+          if (jj[u] >= 0) {
+            zx[u] = ZEL(lane, jj[u] - 1);
+            zy[u] = ZEL(lane, jj[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (jj[u] >= 0) {
+            rot2(zx[u], zy[u], readlane_dyn_f64(c, jj[u]), conj(bc(sv, jj[u])));
+            ZEL(lane, jj[u] - 1) = zx[u];
+            ZEL(lane, jj[u]) = zy[u];
+          }
+        }
+        rem = r2;
+      }
+    }
+    wave_sync();
+    // ---- row rotations from B z (from A z when B z is the smaller of the two); lane = column (columns >= i, X)
+    {
+      const cx bz1 = tget(L, i, i), bz2 = tget(L, j, i), az1 = hget(L, i, i), az2 = hget(L, j, i);
+      const bool use_b = abs1(bz1) + abs1(bz2) >= 1e-3 * (abs1(az1) + abs1(az2));
+      c = 1.0;
+      sv = mk(0, 0);
+      if (own && ok) lartg(use_b ? bz1 : az1, use_b ? bz2 : az2, c, sv, r);
+    }
+    for (unsigned long long rem = todo; rem != 0ull; rem &= rem - 1ull) {
+      const int bj = __builtin_ctzll(rem), bi = bj - 1;
+      const double cc = readlane_dyn_f64(c, bj);
+      const cx ss = bc(sv, bj);
+      if (lane >= bi && lane < N) {
+        cx x = hget(L, bi, lane), y = hget(L, bj, lane);
+        rot2(x, y, cc, ss);
+        hput(L, bi, lane, x);
+        hput(L, bj, lane, y);
+        x = tget(L, bi, lane);
+        y = tget(L, bj, lane);
+        rot2(x, y, cc, ss);
+        tput(L, bi, lane, x);
+        tput(L, bj, lane, y);
+      }
+      if (lane < L.xw) {
+        cx x = GX(bi, lane), y = GX(bj, lane);
+        rot2(x, y, cc, ss);
+        GX(bi, lane) = x;
+        GX(bj, lane) = y;
+      }
+    }
+    wave_sync();
+  }
+  // every annihilated entry is checked (rounding level of the block) and set to an exact zero
+  if (own && ok) {
+    const cx h21 = hget(L, j, i), t21 = tget(L, j, i);
+    if (abs1(h21) <= 8.0 * ULP * an && abs1(t21) <= 8.0 * ULP * bn) {
+      hput(L, j, i, mk(0, 0));
+      tput(L, j, i, mk(0, 0));
     } else {
-      all_ok = false;
+      ok = false;
     }
   }
-  return all_ok;
+  wave_sync();
+  return __ballot(own && !ok) == 0ull;
 }
 
 __device__ __forceinline__ bool root_is_stable(cx a, cx b, double rs) {

@@ -2124,6 +2124,34 @@ def test_gensys_two_draws_per_wavefront_match_one():
         assert ok and np.abs(on["T"][i] - Tref).max() <= 1e-9
 
 
+def test_gensys_direct_blocks_match_iteration():
+    """gensys window path, round 4: the isolated 2 x 2 blocks the real double-shift stage leaves (complex pairs, well separated
+    real pairs) are triangularised in closed form before the zhgeqz-style iteration (dsge_options.gensys_direct_blocks, default
+    on; qz_direct_blocks in dsge_gensys.hpp).  With the option off every block goes through the iteration: same eu, same
+    status, T equal to 1e-10 -- on SW-shaped draws, on full_nk, on draws without a unique stable solution and with the
+    one-draw-per-wavefront sweeps as well."""
+    b = wl.sw_shaped_batch(96, seed0=4400)
+    cases = [(b["A"], b["B"], b["C"], b["D"])]
+    fk = wl.full_nk_batch(33)[0]
+    cases.append((fk["A"], fk["B"], fk["C"], fk["D"]))
+    A, B, C, D = (b[x][:32].copy() for x in "ABCD")
+    C[1::2] *= 3.0
+    A[2::4] *= 1.6
+    cases.append((A, B, C, D))
+    for A, B, C, D in cases:
+        for pairs in (1, 0):
+            off = batched.gensys_batched(A, B, C, D, tol=1e-8,
+                                         options={"gensys_split": 2, "gensys_pairs": pairs, "gensys_direct_blocks": 0})
+            on = batched.gensys_batched(A, B, C, D, tol=1e-8,
+                                        options={"gensys_split": 2, "gensys_pairs": pairs, "gensys_direct_blocks": 1})
+            assert np.array_equal(on["eu"], off["eu"])
+            assert np.array_equal(on["status"], off["status"])
+            good = (off["eu"][:, 0] == 1) & (off["eu"][:, 1] == 1)
+            sc = np.maximum(1.0, np.abs(off["T"]).max(axis=(1, 2)))
+            err = np.abs(on["T"] - off["T"]).max(axis=(1, 2)) / sc
+            assert (err[good] <= 1e-10).all(), (pairs, err[good].max())
+
+
 def test_gensys_cached_capacity_record_is_rescued_and_renewed():
     """dsge_options.gensys_shape_cache (default on): the window path measures its capacity record (max #lead, window, deflated
     roots) on the first call of a (model size, lead hint) and launches later calls without the measuring launch and its stream
