@@ -17,6 +17,7 @@ ERR_INVALID, ERR_HIP, ERR_TOO_LARGE = 1, 2, 3
 MAX_N = 64
 MAX_N_CR = 64
 MAX_N_GENSYS = 64
+MAX_N_BIG = 96  # cycle reduction, selection and the fused solve + Kalman logp with a cycle-reduction solver (csrc/dsge_big.hpp)
 MAX_P = 16
 
 ST_OK = 0

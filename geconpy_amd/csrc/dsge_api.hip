@@ -445,12 +445,15 @@ int dsge_stream_synchronize(void* stream) {
 
 static int cr_entry(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
                     double* T_out, int32_t* status, int32_t* n_iter, void* stream, int scan_mode) {
-  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  int rc = check_common(batch, n, DSGE_MAX_N_BIG);
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if (max_iter < 0) return fail(DSGE_ERR_INVALID, "max_iter < 0");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
+  if (big_size(n))  // 65 .. 96 variables: one workgroup per draw (dsge_big.hpp)
+    return launch_cr_big(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, (hipStream_t)stream, scan_mode, nullptr, 0,
+                         nullptr);
   return launch_cr(A, B, C, batch, n, max_iter, tol, T_out, status, n_iter, (hipStream_t)stream, scan_mode);
 }
 
@@ -519,13 +522,14 @@ int dsge_bk_eigenvalues_batched(const double* A, const double* B, const double* 
 
 int dsge_selection_batched(const double* A, const double* B, const double* C, const double* D, const double* T,
                            int batch, int n, int k, double* R_out, double* resid_out, void* stream) {
-  int rc = check_common(batch, n, DSGE_MAX_N);
+  int rc = check_common(batch, n, DSGE_MAX_N_BIG);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!B || !C || !D || !T || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
   if (resid_out && !A) return fail(DSGE_ERR_INVALID, "resid_out requires A");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
+  if (big_size(n)) return launch_selection_big(A, B, C, D, T, batch, n, k, R_out, resid_out, nullptr, (hipStream_t)stream);
   return launch_assemble(A, B, C, D, T, nullptr, nullptr, 0, batch, n, k, R_out, resid_out, nullptr, nullptr, nullptr,
                          1, 0, (hipStream_t)stream);
 }
@@ -675,8 +679,94 @@ int dsge_kalman_logp_batched(const double* T, const double* R, const double* Q, 
 
 inline size_t pipeline_scratch_bytes(int batch, int n, int k) {
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
-  return 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 2 * align256((size_t)batch * 4) +
-         align256((size_t)batch * 8) + 4096;
+  size_t b = 3 * align256(nn * 8) + align256(nk * 8) + align256((size_t)batch * 12) + 2 * align256((size_t)batch * 4) +
+             align256((size_t)batch * 8) + 4096;
+  if (n > 64)  // pipeline_big: the gathered model (T_r, R_r, Z_r at 64 filtered variables) next to the full-size T, R
+    b += align256((size_t)batch * 64 * 64 * 8) + align256((size_t)batch * 64 * k * 8) +
+         align256((size_t)batch * DSGE_MAX_P * 64 * 8) + 1024;
+  return b;
+}
+
+// ---- 65 .. 96 variables (dsge_big.hpp): cycle reduction with one workgroup per draw, then the EXISTING filter kernels on the
+// model restricted to F = {state variables} u {observed variables}: x_t[F] = T[F, F] x_{t-1}[F] + R[F, :] eps_t is exact because
+// every column of T outside the state variables is zero (T = -(B + C T)^-1 A inherits the zero columns of A), and y_t reads
+// x_t[F] only.  |F| <= 64 or DSGE_ERR_TOO_LARGE.  Measuring F synchronises the stream once per call.
+static int pipeline_big(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
+                        const double* Z, int z_batched, const double* d, int d_batched, const double* Hdiag, int h_batched,
+                        const double* y, int batch, int n, int k, int p, int T_len, int solver, bool park_failures, double tol,
+                        int max_iter, double jitter, double missing_fill, int z_selector_hint, double* logp_out,
+                        int32_t* status_out, double* T_out, double* R_out, double* resid_out, int32_t* n_iter_out, hipStream_t st,
+                        int reps, float* ms_out, void* scratch_slice) {
+  int rc;
+  const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
+  void* base = scratch_slice;
+  if (!base && (rc = scratch_reserve(st, pipeline_scratch_bytes(batch, n, k), &base))) return rc;
+  Carver cv(base);
+  double* Tw = T_out ? T_out : cv.take<double>(nn);
+  double* Rw = R_out ? R_out : cv.take<double>(nk);
+  double* T_r = cv.take<double>((size_t)batch * 64 * 64);
+  double* R_r = cv.take<double>((size_t)batch * 64 * k);
+  double* Z_r = cv.take<double>(z_batched ? (size_t)batch * p * 64 : (size_t)p * 64);
+  double* RQR = cv.take<double>((size_t)batch * 64 * 64);
+  double* P0 = cv.take<double>((size_t)batch * 64 * 64);
+  int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);
+  int32_t* park_w = cv.take<int32_t>((size_t)batch);
+  EventGuard ev[4];
+  float acc_ms[3] = {0.f, 0.f, 0.f};
+  if (ms_out)
+    for (auto& e : ev) HIP_TRY(e.create());
+  const int n_rep = ms_out ? reps : 1;
+  for (int rep = 0; rep < n_rep; ++rep) {
+    if (ms_out) HIP_TRY(hipEventRecord(ev[0], st));
+    const bool scan = solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
+    // R from the final elimination of the (njit-rule) iteration; the scan variant and a requested residual take the explicit
+    // selection R = -(C T + B)^-1 D
+    const bool fuse_R = !scan && !resid_out;
+    if ((rc = launch_cr_big(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st, scan ? 1 : 0, fuse_R ? D : nullptr, k,
+                            fuse_R ? Rw : nullptr)))
+      return rc;
+    if (park_failures && (rc = launch_status_park(status_out, park_w, batch, 0, st))) return rc;
+    if (!fuse_R && (rc = launch_selection_big(A, B, C, D, Tw, batch, n, k, Rw, resid_out, status_out, st))) return rc;
+    if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
+    unsigned char idx[64];
+    int u = 0, ns = 0;
+    if ((rc = big_filtered_variables(A, Z, z_batched, batch, n, p, st, idx, &u, &ns))) return rc;
+    if (u > 64)
+      return fail(DSGE_ERR_TOO_LARGE, "solve + Kalman with n > 64: " + std::to_string(u) +
+                                          " state and observed variables, the filter kernels take at most 64");
+    if (u < 1) return fail(DSGE_ERR_INVALID, "solve + Kalman with n > 64: no state and no observed variable");
+    if ((rc = launch_big_compress(Tw, Rw, Z, z_batched, batch, n, k, p, idx, u, T_r, R_r, Z_r, st))) return rc;
+    const int ns_hint = (ns > 0 && ns < u) ? ns : 0;
+    const bool q_diag = q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED;
+    const bool fold_rqr = !park_failures && q_diag && kalman_folds_rqr(u, p, k, ns_hint, z_selector_hint);
+    if (fold_rqr)
+      rc = DSGE_SUCCESS;
+    else if (q_diag && k <= 16)
+      rc = launch_rqr(R_r, Q, q_mode == DSGE_Q_DIAG_BATCHED, batch, u, k, status_out, RQR, st);
+    else
+      rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T_r, R_r, Q, q_mode, batch, u, k, nullptr, nullptr, RQR, P0,
+                           status_out, 0, 2, st);
+    if (rc) return rc;
+    if (ms_out) HIP_TRY(hipEventRecord(ev[2], st));
+    const int32_t* okey = (opt().kalman_order == 1) ? it_w : nullptr;
+    if ((rc = launch_kalman(T_r, RQR, P0, 0, Z_r, z_batched, d, d_batched, Hdiag, h_batched, y, batch, u, p, T_len, jitter,
+                            missing_fill, ns_hint, z_selector_hint, logp_out, status_out, st, okey, fold_rqr ? R_r : nullptr,
+                            fold_rqr ? Q : nullptr, q_mode == DSGE_Q_DIAG_BATCHED, k, nullptr)))
+      return rc;
+    if (park_failures && (rc = launch_status_park(status_out, park_w, batch, 1, st))) return rc;
+    if (ms_out) {
+      HIP_TRY(hipEventRecord(ev[3], st));
+      HIP_TRY(hipEventSynchronize(ev[3]));
+      for (int i = 0; i < 3; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        acc_ms[i] += ms;
+      }
+    }
+  }
+  if (ms_out)
+    for (int i = 0; i < 3; ++i) ms_out[i] = acc_ms[i] / (float)n_rep;
+  return DSGE_SUCCESS;
 }
 
 static int pipeline(const double* A, const double* B, const double* C, const double* D, const double* Q, int q_mode,
@@ -691,7 +781,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   solver &= ~DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE;
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
   const bool park_failures = zero_T_on_failure && is_cr;
-  int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
+  int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_BIG : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
@@ -703,6 +793,10 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     return fail(DSGE_ERR_INVALID, "unknown solver code");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
+  if (big_size(n))
+    return pipeline_big(A, B, C, D, Q, q_mode, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, n, k, p, T_len, solver,
+                        park_failures, tol, max_iter, jitter, missing_fill, z_selector_hint, logp_out, status_out, T_out, R_out,
+                        resid_out, n_iter_out, st, reps, ms_out, scratch_slice);
 
   const size_t nn = (size_t)batch * n * n, nk = (size_t)batch * n * k;
   void* base = scratch_slice;  // (a slice of an arena the caller reserved: chunks in flight on several streams)
@@ -1183,7 +1277,7 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
 
 static int cr_host(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
                    double* T_out, int32_t* status, int32_t* n_iter, int scan_mode) {
-  int rc = check_common(batch, n, DSGE_MAX_N_CR);
+  int rc = check_common(batch, n, DSGE_MAX_N_BIG);
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if ((rc = ensure_device())) return rc;
@@ -1426,7 +1520,7 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
 
 int dsge_selection_batched_host(const double* A, const double* B, const double* C, const double* D, const double* T,
                                 int batch, int n, int k, double* R_out, double* resid_out) {
-  int rc = check_common(batch, n, DSGE_MAX_N);
+  int rc = check_common(batch, n, DSGE_MAX_N_BIG);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (!B || !C || !D || !T || !R_out) return fail(DSGE_ERR_INVALID, "null pointer");
@@ -2015,7 +2109,10 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                                         int n_lead_hint, double* logp_out, int32_t* status_out, double* T_out,
                                         double* R_out, double* resid_out, int32_t* n_iter_out) {
-  int rc = check_common(batch, n, DSGE_MAX_N);
+  const int solver_code = solver & ~DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE;
+  int rc = check_common(batch, n, (solver_code == DSGE_SOLVER_CYCLE_REDUCTION || solver_code == DSGE_SOLVER_SCAN_CYCLE_REDUCTION)
+                                      ? DSGE_MAX_N_BIG
+                                      : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");

@@ -100,6 +100,16 @@ int set_lds(K kernel, size_t bytes) {
 int launch_cr(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol,
               double* T_out, int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode = 0,
               const double* D = nullptr, int k = 0, double* R_out = nullptr);  // D, R_out: also R = -A1_hat^-1 D
+// launch_big.hip (dsge_big.hpp): models with 65 .. DSGE_MAX_N_BIG variables, one workgroup per draw
+bool big_size(int n);
+int launch_cr_big(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol, double* T_out,
+                  int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode, const double* D, int k, double* R_out);
+int launch_selection_big(const double* A, const double* B, const double* C, const double* D, const double* T, int batch, int n,
+                         int k, double* R_out, double* resid_out, const int32_t* status, hipStream_t st);
+int big_filtered_variables(const double* A, const double* Z, int z_batched, int batch, int n, int p, hipStream_t st,
+                           unsigned char* idx_out, int* u_out, int* ns_out);
+int launch_big_compress(const double* T, const double* R, const double* Z, int z_batched, int batch, int n, int k, int p,
+                        const unsigned char* idx, int u, double* T_r, double* R_r, double* Z_r, hipStream_t st);
 int launch_cr_deflated(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
                        int max_iter, double tol, double* T_out, double* R_out, int32_t* status, int32_t* n_iter,
                        hipStream_t st, int* used, unsigned long long* colmask = nullptr);

@@ -1,0 +1,106 @@
+// Launchers of the 65 .. 96-variable kernels (dsge_big.hpp): cycle reduction, selection matrix, and the gather that hands the
+// model restricted to its filtered variables to the n <= 64 filter kernels.
+#include "dsge_big.hpp"
+#include "dsge_host.hpp"
+
+namespace dsge_host {
+
+namespace {
+StreamArenaPool g_big_pool;
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// one workgroup per CU is resident (150 KB of LDS at NP = 96); two grid-strides per CU keep the tail short
+constexpr int BIG_GRID_MAX = 512;
+using Cfg80 = dsge::BigCfg<80, 5, 2>;
+using Cfg96 = dsge::BigCfg<96, 6, 3>;
+}  // namespace
+
+bool big_size(int n) { return n > 64 && n <= DSGE_MAX_N_BIG; }
+
+int launch_cr_big(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol, double* T_out,
+                  int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode, const double* D, int k, double* R_out) {
+  if (!big_size(n)) return fail(DSGE_ERR_INVALID, "launch_cr_big: n out of range");
+  if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "launch_cr_big: R_out requires D and 1 <= k <= n");
+  const int grid = batch < BIG_GRID_MAX ? batch : BIG_GRID_MAX;
+  int rc;
+  void* base = nullptr;
+#define BIG_CR(CFG)                                                                                                          \
+  do {                                                                                                                       \
+    if ((rc = g_big_pool.reserve(al256((size_t)grid * CFG::ws_doubles * 8), st, &base))) return rc;                          \
+    if ((rc = set_lds(dsge::cr_big_kernel<CFG>, CFG::lds_bytes))) return rc;                                                 \
+    hipLaunchKernelGGL(dsge::cr_big_kernel<CFG>, dim3(grid), dim3(CFG::NT), CFG::lds_bytes, st, A, B, C, batch, n, max_iter, \
+                       tol, (double*)base, T_out, status, n_iter, scan_mode, D, k, R_out);                                   \
+  } while (0)
+  if (n <= 80)
+    BIG_CR(Cfg80);
+  else
+    BIG_CR(Cfg96);
+#undef BIG_CR
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
+int launch_selection_big(const double* A, const double* B, const double* C, const double* D, const double* T, int batch, int n,
+                         int k, double* R_out, double* resid_out, const int32_t* status, hipStream_t st) {
+  if (!big_size(n)) return fail(DSGE_ERR_INVALID, "launch_selection_big: n out of range");
+  if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "launch_selection_big: k out of range (1..n)");
+  const int grid = batch < BIG_GRID_MAX ? batch : BIG_GRID_MAX;
+  int rc;
+  void* base = nullptr;
+#define BIG_SEL(CFG)                                                                                                        \
+  do {                                                                                                                      \
+    if ((rc = g_big_pool.reserve(al256((size_t)grid * CFG::ws_doubles * 8), st, &base))) return rc;                         \
+    if ((rc = set_lds(dsge::selection_big_kernel<CFG>, CFG::lds_bytes))) return rc;                                         \
+    hipLaunchKernelGGL(dsge::selection_big_kernel<CFG>, dim3(grid), dim3(CFG::NT), CFG::lds_bytes, st, A, B, C, D, T, batch, \
+                       n, k, (double*)base, R_out, resid_out, status);                                                      \
+  } while (0)
+  if (n <= 80)
+    BIG_SEL(Cfg80);
+  else
+    BIG_SEL(Cfg96);
+#undef BIG_SEL
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
+// F = {state variables} u {observed variables} of the batch, measured on the device (one small launch and a 32-byte read-back:
+// the call synchronises the stream here).  *u_out = |F|, *ns_out = number of state variables; idx_out: the sorted members.
+int big_filtered_variables(const double* A, const double* Z, int z_batched, int batch, int n, int p, hipStream_t st,
+                           unsigned char* idx_out, int* u_out, int* ns_out) {
+  int rc;
+  void* base = nullptr;
+  // (the mask lives behind the solver workspace's first bytes: the solver launch that used them is ordered before this one)
+  if ((rc = g_big_pool.reserve(256, st, &base))) return rc;
+  unsigned long long h[4] = {0ull, 0ull, 0ull, 0ull};
+  HIP_TRY(hipMemsetAsync(base, 0, sizeof(h), st));
+  hipLaunchKernelGGL(dsge::big_mask_kernel, dim3(batch < 4096 ? batch : 4096), dim3(128), 0, st, A, Z, z_batched, batch, n, p,
+                     (unsigned long long*)base);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h, base, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int u = 0, ns = 0;
+  for (int j = 0; j < n; ++j) {
+    const bool s = (h[j >> 6] >> (j & 63)) & 1ull, o = (h[2 + (j >> 6)] >> (j & 63)) & 1ull;
+    if (s) ++ns;
+    if (s || o) {
+      if (u < 64) idx_out[u] = (unsigned char)j;
+      ++u;
+    }
+  }
+  *u_out = u;
+  *ns_out = ns;
+  return DSGE_SUCCESS;
+}
+
+int launch_big_compress(const double* T, const double* R, const double* Z, int z_batched, int batch, int n, int k, int p,
+                        const unsigned char* idx, int u, double* T_r, double* R_r, double* Z_r, hipStream_t st) {
+  if (u < 1 || u > 64) return fail(DSGE_ERR_INVALID, "launch_big_compress: u out of range");
+  dsge::BigIndex F;
+  for (int i = 0; i < 64; ++i) F.idx[i] = i < u ? idx[i] : 0;
+  F.u = u;
+  hipLaunchKernelGGL(dsge::big_compress_kernel, dim3(batch < 4096 ? batch : 4096), dim3(256), 0, st, T, R, Z, z_batched, batch, n,
+                     k, p, F, T_r, R_r, Z_r);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
+}  // namespace dsge_host

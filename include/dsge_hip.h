@@ -52,6 +52,11 @@ extern "C" {
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
 #define DSGE_MAX_N_CR 64
 #define DSGE_MAX_N_GENSYS 64   /* pencil dimension n + #lead columns (further limited by 160 KB LDS) */
+#define DSGE_MAX_N_BIG 96      /* cycle reduction (both variants), the selection matrix and the fused solve + Kalman log-likelihood
+                                  with a cycle-reduction solver also take 65 .. 96 variables (one workgroup per draw,
+                                  csrc/dsge_big.hpp).  The filter then runs on the model restricted to its state and observed
+                                  variables, of which there may be at most 64 (else DSGE_ERR_TOO_LARGE); every other entry point
+                                  keeps the limits above */
 #define DSGE_MAX_P 16      /* observed series */
 
 /* call-level return codes */

@@ -39,6 +39,7 @@ def test_header_constants_match_python():
     assert int(consts["DSGE_ABI_VERSION"]) == _lib.ABI_VERSION
     assert int(consts["DSGE_MAX_N"]) == _lib.MAX_N
     assert int(consts["DSGE_MAX_N_CR"]) == _lib.MAX_N_CR
+    assert int(consts["DSGE_MAX_N_BIG"]) == _lib.MAX_N_BIG
     assert int(consts["DSGE_MAX_P"]) == _lib.MAX_P
     for name in ("ST_NOT_CONVERGED", "ST_NAN", "ST_LYAP_FAIL", "ST_FILTER_NONFINITE", "Q_DIAG_SHARED", "Q_DIAG_BATCHED",
                  "Q_FULL_SHARED", "Q_FULL_BATCHED", "SOLVER_CYCLE_REDUCTION", "SOLVER_GENSYS",
@@ -68,7 +69,7 @@ def test_malformed_calls_are_rejected_before_touching_the_gpu():
     st = np.zeros(1, dtype=np.int32)
     p = lambda x: x.ctypes.data  # noqa: E731
     assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), 1, 0, 10, 1e-8, p(a), p(st), None) == 1
-    assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), 1, 65, 10, 1e-8, p(a), p(st), None) == 1
+    assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), 1, _lib.MAX_N_BIG + 1, 10, 1e-8, p(a), p(st), None) == 1
     assert lib.dsge_cycle_reduction_batched_host(p(a), p(a), p(a), -1, 4, 10, 1e-8, p(a), p(st), None) == 1
     assert b"range" in lib.dsge_last_error() or b"batch" in lib.dsge_last_error()
     assert lib.dsge_selection_batched_host(p(a), p(a), p(a), p(a), p(a), 1, 4, 5, p(a), None) == 1  # k > n

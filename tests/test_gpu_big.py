@@ -1,0 +1,131 @@
+"""Models with 65 .. 96 variables (round 4, csrc/dsge_big.hpp): cycle reduction with one workgroup per draw, the selection matrix,
+and the fused solve + Kalman log-likelihood whose filter runs on the model restricted to its state and observed variables.
+The reference has no size limit (gEconpy/model/statespace.py:822-839); its cycle reduction is
+gEconpy/solvers/cycle_reduction.py:127-183 (njit rule) / :246-294 (scan rule), restated in oracle/cycle_reduction.py."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from geconpy_amd import _lib, batched
+from geconpy_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {65: dict(n_state=28, n_lead=20, k=8), 72: dict(n_state=30, n_lead=20, k=8), 80: dict(n_state=36, n_lead=24, k=10),
+          81: dict(n_state=36, n_lead=26, k=10), 96: dict(n_state=44, n_lead=30, k=12)}
+
+
+def _systems(n, nb, seed0=7000):
+    sh = SHAPES[n]
+    sysm = [wl.sw_shaped_system(seed0 + i, n=n, n_state=sh["n_state"], n_lead=sh["n_lead"], k=sh["k"]) for i in range(nb)]
+    return tuple(np.stack([s[j] for s in sysm]) for j in range(5))
+
+
+@pytest.mark.parametrize("n", [65, 72, 80, 81, 96])
+def test_big_cycle_reduction_and_selection_vs_oracle(n):
+    """T, the iteration count and the status of `dsge_cycle_reduction_batched` against `oracle.cycle_reduction_core` (the njit
+    rule), R and the policy residual of `dsge_selection_batched` against the oracle's selection matrix."""
+    nb = 6
+    A, B, C, D, Tst = _systems(n, nb)
+    T, status, n_iter = batched.cycle_reduction_batched(A, B, C, max_iter=1000, tol=1e-9)
+    assert np.all(status == 0)
+    assert_allclose(T, Tst, atol=1e-8)
+    R, resid = batched.selection_batched(B, C, D, T, A=A)
+    for i in range(nb):
+        Tc, conv, it = oracle.cycle_reduction_core(A[i], B[i], C[i], 1000, 1e-9)
+        assert conv and it == n_iter[i]
+        assert_allclose(T[i], Tc, atol=1e-9 * max(1.0, np.abs(Tc).max()))
+        Rc = oracle.compute_selection_matrix(B[i], C[i], D[i], Tc)
+        assert_allclose(R[i], Rc, atol=1e-8 * max(1.0, np.abs(Rc).max()))
+        assert_allclose(resid[i], oracle.policy_residual(A[i], B[i], C[i], T[i]), rtol=1e-4, atol=1e-24)
+        assert resid[i] < 1e-14
+    # bit-identical repeats, and a draw's result does not depend on its place in the batch
+    T2, status2, n_iter2 = batched.cycle_reduction_batched(A[::-1].copy(), B[::-1].copy(), C[::-1].copy(), max_iter=1000, tol=1e-9)
+    assert np.array_equal(T2[::-1], T) and np.array_equal(n_iter2[::-1], n_iter)
+
+
+@pytest.mark.parametrize("n", [72, 96])
+def test_big_scan_cycle_reduction_vs_oracle(n):
+    A, B, C, D, Tst = _systems(n, 4, seed0=7100)
+    T, status, n_steps = batched.scan_cycle_reduction_batched(A, B, C, max_iter=50, tol=1e-8)
+    assert np.all(status == 0)
+    for i in range(4):
+        Tc, steps = oracle.scan_cycle_reduction(A[i], B[i], C[i], max_iter=50, tol=1e-8)
+        assert steps == n_steps[i]
+        assert_allclose(T[i], Tc, atol=1e-9 * max(1.0, np.abs(Tc).max()))
+
+
+def test_big_cycle_reduction_failure_codes():
+    """A draw that cannot converge within max_iter and a draw with a NaN: status as the n <= 64 kernels report it, T = 0
+    (cycle_reduction.py:176-181)."""
+    n = 80
+    A, B, C, D, _ = _systems(n, 3, seed0=7200)
+    A[2, 3, 5] = np.nan
+    T, status, n_iter = batched.cycle_reduction_batched(A, B, C, max_iter=2, tol=1e-12)
+    assert status[0] == _lib.ST_NOT_CONVERGED and status[1] == _lib.ST_NOT_CONVERGED and n_iter[0] == 2
+    assert status[2] == (_lib.ST_NOT_CONVERGED | _lib.ST_NAN) and n_iter[2] == 1
+    assert np.all(T == 0.0)
+
+
+@pytest.mark.parametrize("n,observed", [(72, None), (80, (40, 45, 50, 55, 60, 70, 79)), (96, (2, 50, 60, 70, 80, 90, 95))])
+def test_big_solve_kalman_logp_vs_oracle(n, observed):
+    """The fused evaluation A, B, C, D -> logp for n > 64 against `oracle.solve_kalman_logp` (full-size cycle reduction and
+    full-size filter): 1e-9 relative, the contract of the n <= 64 path; observed states and observed jump variables; T, R, the
+    residual and the iteration counts on request (explicit selection route) and not (R from the last elimination)."""
+    sh = SHAPES[n]
+    nb = 12
+    b = wl.sw_shaped_batch(nb, n=n, p=7, T_len=60, **sh)
+    om = wl.sw_shaped_observation_model(observed=observed, n=n, p=7, T_len=60, **sh)
+    q = b["sigma"] ** 2
+    r = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8,
+                                          max_iter=1000, q_mode="diag_batched")
+    rp = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8,
+                                           max_iter=1000, return_policy=True, q_mode="diag_batched")
+    assert np.all(r["status"] == 0) and np.all(rp["status"] == 0)
+    for i in range(nb):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), om["Z"], om["y"],
+                                       H=np.diag(om["Hdiag"]), tol=1e-8, max_iter=1000)
+        assert ref["success"]
+        assert abs(r["logp"][i] - ref["logp"]) <= 1e-9 * abs(ref["logp"]), (i, r["logp"][i], ref["logp"])
+        assert abs(rp["logp"][i] - ref["logp"]) <= 1e-9 * abs(ref["logp"])
+        assert_allclose(rp["T"][i], ref["T"], atol=1e-9 * max(1.0, np.abs(ref["T"]).max()))
+        assert_allclose(rp["R"][i], ref["R"], atol=1e-8 * max(1.0, np.abs(ref["R"]).max()))
+        assert rp["n_iter"][i] == ref["n_iter"]
+    # a dense design matrix (every observed series loads on three variables), a batched one, an intercept
+    rng = np.random.default_rng(n)
+    Zd = np.zeros((nb, 7, n))
+    for i in range(nb):
+        for s in range(7):
+            Zd[i, s, rng.choice(n // 2, 3, replace=False)] = rng.uniform(0.5, 1.5, 3)
+    dvec = rng.standard_normal(7) * 0.01
+    rd = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, Zd, om["y"], d=dvec, Hdiag=om["Hdiag"], tol=1e-8,
+                                           max_iter=1000, q_mode="diag_batched")
+    assert np.all(rd["status"] == 0)
+    for i in range(0, nb, 3):
+        ref = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(q[i]), Zd[i], om["y"],
+                                       H=np.diag(om["Hdiag"]), d=dvec, tol=1e-8, max_iter=1000)
+        assert abs(rd["logp"][i] - ref["logp"]) <= 1e-9 * abs(ref["logp"])
+
+
+def test_big_failed_draw_and_too_many_filtered_variables():
+    """A failed solve inside the fused call: logp = -inf and the solver's status for that draw only.  More than 64 state and
+    observed variables: DSGE_ERR_TOO_LARGE (a return code), nothing computed.  Solvers other than cycle reduction keep n <= 64."""
+    n = 80
+    sh = SHAPES[n]
+    b = wl.sw_shaped_batch(4, n=n, p=7, T_len=30, **sh)
+    om = wl.sw_shaped_observation_model(n=n, p=7, T_len=30, **sh)
+    A = b["A"].copy()
+    A[1, 0, 0] = np.nan
+    r = batched.solve_kalman_logp_batched(A, b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"],
+                                          tol=1e-8, max_iter=1000)
+    assert r["status"][1] & _lib.ST_NAN and r["logp"][1] == -np.inf
+    assert np.all(r["status"][[0, 2, 3]] == 0) and np.all(np.isfinite(r["logp"][[0, 2, 3]]))
+    wide = wl.sw_shaped_batch(2, n=n, n_state=70, n_lead=6, k=8, p=7, T_len=30)
+    omw = wl.sw_shaped_observation_model(n=n, n_state=70, n_lead=6, k=8, p=7, T_len=30)
+    with pytest.raises(_lib.DsgeTooLargeError):
+        batched.solve_kalman_logp_batched(wide["A"], wide["B"], wide["C"], wide["D"], wide["sigma"] ** 2, omw["Z"], omw["y"],
+                                          Hdiag=omw["Hdiag"], tol=1e-8, max_iter=1000)
+    with pytest.raises(_lib.DsgeHipError):
+        batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"],
+                                          tol=1e-8, solver="gensys")
