@@ -97,6 +97,7 @@ PROTOTYPES = {
     "dsge_get_kalman_steady_tol": [],
     "dsge_debug_kalman_steady_steps": [_dp],
     "dsge_debug_kalman_phases": [_i, _dp],
+    "dsge_debug_big_phases": [_i, _dp],
     "dsge_debug_gensys_window_phases": [_i, _dp],
     "dsge_debug_gensys_phases": [_dp, _dp, _dp, _i, _i, _f, _i, _dp, _dp, _dp, _dp],
     "dsge_debug_gensys_stage_ms": [_i, _dp],

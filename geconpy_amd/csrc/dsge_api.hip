@@ -1324,6 +1324,27 @@ int dsge_debug_kalman_phases(int enable, long long* cycles_out) {
   return DSGE_SUCCESS;
 }
 
+// Debug hook: cr_big_kernel (n > 64) accumulates the shader cycles workgroup 0 spends on its first draw: [0] register-block loads,
+// [1] eliminations, [2] row scatters, [3] the four products and norms, [4] iterations, [5] total (with the final solve);
+// [8..12] inside the eliminations (thread 0): candidates + column, first barrier, pivot row, second barrier, update.  16 values.
+int dsge_debug_big_phases(int enable, long long* cycles_out) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (enable && !g_big_dbg) {
+    HIP_TRY(hipMalloc((void**)&g_big_dbg, 16 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_big_dbg, 0, 16 * sizeof(long long)));
+  }
+  if (cycles_out && g_big_dbg) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_out, g_big_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && g_big_dbg) {
+    (void)hipFree(g_big_dbg);
+    g_big_dbg = nullptr;
+  }
+  return DSGE_SUCCESS;
+}
+
 // Debug hook (not part of the drop-in surface): shader-clock stamps of draw 0 at the phase
 // boundaries of gensys_kernel: [start, after Hessenberg-triangular, after QZ, after reordering,
 // after SVDs / eu codes, end].  Device pointers; cycles_out is a HOST array of 6 int64.

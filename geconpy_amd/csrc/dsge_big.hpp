@@ -38,14 +38,19 @@ struct BigCfg {
   static constexpr int GY = NP / TR, GX = NP / TC, NT = GY * GX, NW = NT / 64;
   static constexpr int LD = NP + 2, MT = NP / 16;
   static_assert(NP % 16 == 0 && NP % TR == 0 && NP % TC == 0 && NT % 64 == 0 && NT <= 1024 && NP <= 128, "tile grid");
-  // LDS (doubles): left panel, right panel (NP x LD each) | column-sum partials (MT x NP) | reduction scratch (64).  The
-  // elimination runs while no product is in flight: its broadcast buffers alias the left panel.
-  static constexpr int OFF_R = NP * LD, OFF_PART = 2 * NP * LD, OFF_RED = OFF_PART + MT * NP;
-  static constexpr size_t lds_bytes = (size_t)(OFF_RED + 64) * 8;
-  static constexpr size_t ws_doubles = 6 * (size_t)NP * NP;  // A0, A1, A2, A1_hat, X0, X2 per workgroup
-  // elimination buffers inside the left panel
-  static constexpr int E_COL = 0, E_ROW = 2 * NP, E_PIV = 5 * NP;  // col[2][NP] | row[3][NP] | int pivcol[NP]
-  static_assert(E_PIV + NP / 2 + 1 <= NP * LD, "elimination buffers fit the left panel");
+  // LDS (doubles): left panel, right panel (NP x LD each) | column-sum partials (MT x NP) | reduction scratch (64) | the
+  // elimination's broadcast buffers (the left panel is filled with -A0 BEFORE the elimination, from the register blocks).
+  static constexpr int TPW = (MT * MT + NW - 1) / NW;  // 16 x 16 product tiles per wavefront
+  // Workspace matrices have the row stride of the LDS panels (LD), so that a panel copy is LINEAR -- piece tid + q NT of the
+  // matrix goes to piece tid + q NT of the panel: one base register and immediate offsets, no index arithmetic to hoist and
+  // spill (the NP-stride version kept 70 loop-invariant addresses alive: 592 bytes of scratch per lane at NP = 96).
+  static constexpr int MAT = NP * LD;                              // doubles per workspace matrix
+  static constexpr int PF = (MAT / 2 + NT - 1) / NT;               // double2 per thread of one panel (prefetch registers)
+  static constexpr int OFF_R = NP * LD, OFF_PART = 2 * NP * LD, OFF_RED = OFF_PART + MT * NP, OFF_EL = OFF_RED + 64;
+  static constexpr size_t lds_bytes = (size_t)(OFF_EL + 6 * NP + 4) * 8;
+  static constexpr size_t ws_doubles = 6 * (size_t)MAT;  // A0, A1, A2, A1_hat, X0, X2 per workgroup
+  static constexpr int E_COL = OFF_EL, E_ROW = OFF_EL + 2 * NP, E_PIV = OFF_EL + 5 * NP,
+                       E_KEY = OFF_EL + 6 * NP;  // col[2][NP] | row[3][NP] | int pivcol[NP] | u64 key[2]
 };
 
 // ---- register blocks <-> the workgroup's padded NP x NP workspace matrices ---------------------------------------------------------
@@ -54,18 +59,15 @@ __device__ __forceinline__ void big_tile_load(double (&t)[Cfg::TR][Cfg::TC], con
 #pragma unroll
   for (int i = 0; i < Cfg::TR; ++i)
 #pragma unroll
-    for (int jc = 0; jc < Cfg::TC; ++jc) t[i][jc] = G[(size_t)(r0 + i) * Cfg::NP + c0 + jc];
+    for (int jc = 0; jc < Cfg::TC; ++jc) t[i][jc] = G[(r0 + i) * Cfg::LD + c0 + jc];
 }
 
-// NP x NP workspace matrix -> LDS panel (row stride LD), 16 bytes per thread and trip
+// workspace matrix -> LDS panel (same layout), 16 bytes per thread and trip
 template <class Cfg>
 __device__ __forceinline__ void big_panel_load(double* __restrict__ buf, const double* __restrict__ G, int tid) {
-  constexpr int NP = Cfg::NP, H = NP / 2;
-  for (int idx = tid; idx < NP * H; idx += Cfg::NT) {
-    const int r = idx / H, c2 = idx - r * H;
-    const double2 v = *reinterpret_cast<const double2*>(G + (size_t)r * NP + 2 * c2);
-    *reinterpret_cast<double2*>(buf + r * Cfg::LD + 2 * c2) = v;
-  }
+  const double2* g2 = reinterpret_cast<const double2*>(G);
+  double2* b2 = reinterpret_cast<double2*>(buf);
+  for (int idx = tid; idx < Cfg::MAT / 2; idx += Cfg::NT) b2[idx] = g2[idx];
 }
 
 // ---- Gauss-Jordan elimination of [t1 | t0 | t2] with implicit partial pivoting -----------------------------------------------------
@@ -75,61 +77,61 @@ __device__ __forceinline__ void big_panel_load(double* __restrict__ buf, const d
 template <class Cfg>
 __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], double (&t0)[Cfg::TR][Cfg::TC],
                                               double (&t2)[Cfg::TR][Cfg::TC], int n, double* __restrict__ lds, int r0, int c0,
-                                              int tid) {
+                                              int tid, long long* __restrict__ prof = nullptr) {
   constexpr int NP = Cfg::NP, TR = Cfg::TR, TC = Cfg::TC;
+  long long pt = prof ? clock64() : 0, pa[5] = {0, 0, 0, 0, 0};
+#define EL_STAMP(K)                    \
+  do {                                 \
+    if (prof) {                        \
+      const long long t_b = clock64(); \
+      pa[K] += t_b - pt;               \
+      pt = t_b;                        \
+    }                                  \
+  } while (0)
   double* rowb = lds + Cfg::E_ROW;
   int* pivcol = reinterpret_cast<int*>(lds + Cfg::E_PIV);
-  const int lane = tid & 63;
-  unsigned long long used_lo = 0ull, used_hi = 0ull;
-  __syncthreads();  // (the panel this aliases is no longer read)
+  // Pivot search without a search phase: the GY threads that own column j fold their candidates (rows not used yet) into one
+  // 64-bit LDS word with ds_max_u64 -- key = bit pattern of |x| (monotone as an unsigned integer for x >= 0; a NaN sorts above
+  // Inf and is taken, as it must) with its low 7 bits replaced by 127 - row (ties and near-ties: the smaller row) -- while they
+  // publish the column.  [First version: every wavefront ran a 6-step shuffle arg-max over the column after the barrier --
+  // 18 dependent ds_bpermute per pivot; 4.1 k cycles per pivot at n = 80.]
+  unsigned long long* keyw = reinterpret_cast<unsigned long long*>(lds + Cfg::E_KEY);
+  unsigned used_mine = 0u;  // bit i: row r0 + i has been a pivot row
+  __syncthreads();          // (the panel this aliases is no longer read)
+  if (tid == 0) {
+    keyw[0] = 0ull;
+    keyw[1] = 0ull;
+  }
+  __syncthreads();
   for (int j = 0; j < n; ++j) {
     double* colb = lds + Cfg::E_COL + (j & 1) * NP;
-    // column j of t1: the multipliers of this step and the pivot candidates
+    // column j of t1: the multipliers of this step and the pivot candidates.  (One region per block column; picking the column
+    // out of the block with selects first and building the keys once measured slower -- 890 instead of 720 cycles -- and cost
+    // registers.)
 #pragma unroll
     for (int jc = 0; jc < TC; ++jc)
       if (c0 + jc == j) {
+        unsigned long long best = 0ull;
 #pragma unroll
-        for (int i = 0; i < TR; ++i) colb[r0 + i] = t1[i][jc];
-      }
-    __syncthreads();
-    // pivot: largest |.| among the rows not used yet (every wavefront runs the same search; NaN counts as the largest)
-    int p;
-    {
-      const int i0 = lane, i1 = lane + 64;
-      double v0 = -1.0, v1 = -1.0;
-      if (i0 < n && !((used_lo >> i0) & 1ull)) {
-        const double x = colb[i0];
-        v0 = (x != x) ? INFINITY : fabs(x);
-      }
-      if (i1 < n && !((used_hi >> (i1 - 64)) & 1ull)) {
-        const double x = colb[i1];
-        v1 = (x != x) ? INFINITY : fabs(x);
-      }
-      double v = v0;
-      int bi = i0;
-      if (v1 > v0) {
-        v = v1;
-        bi = i1;
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > v || (ov == v && oi < bi)) {
-          v = ov;
-          bi = oi;
+        for (int i = 0; i < TR; ++i) {
+          const double x = t1[i][jc];
+          colb[r0 + i] = x;
+          const unsigned long long key =
+              ((unsigned long long)__double_as_longlong(fabs(x)) & ~127ull) | (unsigned long long)(127 - (r0 + i));
+          if (r0 + i < n && !((used_mine >> i) & 1u) && key > best) best = key;
         }
+        if (best != 0ull) atomicMax(&keyw[j & 1], best);
       }
-      p = __builtin_amdgcn_readfirstlane(bi);
-    }
-    if (p < 64)
-      used_lo |= 1ull << p;
-    else
-      used_hi |= 1ull << (p - 64);
+    EL_STAMP(0);
+    __syncthreads();
+    EL_STAMP(1);
+    const int p = 127 - (int)(keyw[j & 1] & 127ull);
+    const double dinv = 1.0 / colb[p];  // (started here: the division's latency runs while the pivot row is being published)
     // the pivot row of all three matrices
 #pragma unroll
     for (int i = 0; i < TR; ++i)
       if (r0 + i == p) {
+        used_mine |= 1u << i;
 #pragma unroll
         for (int jc = 0; jc < TC; ++jc) {
           rowb[c0 + jc] = t1[i][jc];
@@ -137,9 +139,13 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
           rowb[2 * NP + c0 + jc] = t2[i][jc];
         }
       }
-    if (tid == 0) pivcol[p] = j;
+    if (tid == 0) {
+      pivcol[p] = j;
+      keyw[(j + 1) & 1] = 0ull;  // (read for the last time before this step's first barrier, written next after its second)
+    }
+    EL_STAMP(2);
     __syncthreads();
-    const double dinv = 1.0 / colb[p];
+    EL_STAMP(3);
     double pr1[TC], pr0[TC], pr2[TC];
 #pragma unroll
     for (int jc = 0; jc < TC; ++jc) {
@@ -165,8 +171,12 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
         }
       }
     }
+    EL_STAMP(4);
   }
   __syncthreads();  // pivcol complete; the next step-1 writes of a following elimination cannot overtake this one's reads
+  if (prof && tid == 0)
+    for (int q = 0; q < 5; ++q) prof[q] += pa[q];
+#undef EL_STAMP
 }
 
 // solution rows back in order: physical row r -> row pivcol[r] of the NP x NP workspace matrix (rows >= n stay zero)
@@ -181,28 +191,55 @@ __device__ __forceinline__ void big_scatter_rows(const double (&t)[Cfg::TR][Cfg:
       int q = pivcol[r];
       q = q < 0 ? 0 : (q >= n ? n - 1 : q);  // (NaN input: the search may have left garbage; stay inside the matrix)
 #pragma unroll
-      for (int jc = 0; jc < Cfg::TC; ++jc) G[(size_t)q * Cfg::NP + c0 + jc] = t[i][jc];
+      for (int jc = 0; jc < Cfg::TC; ++jc) G[q * Cfg::LD + c0 + jc] = t[i][jc];
     }
   }
 }
 
 // ---- C = L R on the matrix core: L, R = the two LDS panels; epi(tile row, tile col, row0, col, acc): acc[e] is element
 // (row0 + 4 e, col) (layout of v_mfma_f64_16x16x4_f64 probed in tools/mfma_probe) ----------------------------------------------------
-template <class Cfg, class Epi>
-__device__ __forceinline__ void big_gemm(const double* __restrict__ bufL, const double* __restrict__ bufR, int tid, Epi epi) {
+template <class Cfg, class Init, class Epi>
+__device__ __forceinline__ void big_gemm(const double* __restrict__ bufL, const double* __restrict__ bufR, int tid, Init init,
+                                         Epi epi) {
   constexpr int MT = Cfg::MT, LD = Cfg::LD, NP = Cfg::NP;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int t = wave; t < MT * MT; t += Cfg::NW) {
-    const int ti = t / MT, tj = t - ti * MT;
-    big_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    const double* pa = bufL + (16 * ti + (lane & 15)) * LD + (lane >> 4);
-    const double* pb = bufR + (lane >> 4) * LD + 16 * tj + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < Cfg::TPW; ++s) {  // (slot s of this wavefront: tile wave + s NW)
+    const int t = wave + s * Cfg::NW;
+    if (t < MT * MT) {
+      const int ti = t / MT, tj = t - ti * MT;
+      big_v4f64 acc = init(s);
+      const double* pa = bufL + (16 * ti + (lane & 15)) * LD + (lane >> 4);
+      const double* pb = bufR + (lane >> 4) * LD + 16 * tj + (lane & 15);
 #pragma unroll 4
-    for (int k4 = 0; k4 < NP / 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * k4], pb[4 * k4 * LD], acc, 0, 0, 0);
-    epi(ti, tj, 16 * ti + (lane >> 4), 16 * tj + (lane & 15), acc);
+      for (int k4 = 0; k4 < NP / 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * k4], pb[4 * k4 * LD], acc, 0, 0, 0);
+      epi(s, ti, 16 * ti + (lane >> 4), 16 * tj + (lane & 15), acc);
+    }
   }
 }
+struct BigZero {
+  __device__ __forceinline__ big_v4f64 operator()(int) const { return big_v4f64{0.0, 0.0, 0.0, 0.0}; }
+};
+
+// a panel on its way from the workspace to LDS, parked in registers while a product runs
+template <class Cfg>
+struct BigPanelRegs {
+  double2 v[Cfg::PF];
+  __device__ __forceinline__ void fetch(const double* __restrict__ G, int tid) {
+    const double2* g2 = reinterpret_cast<const double2*>(G) + tid;
+#pragma unroll
+    for (int q = 0; q < Cfg::PF; ++q)
+      if ((q + 1) * Cfg::NT <= Cfg::MAT / 2 || tid + q * Cfg::NT < Cfg::MAT / 2) v[q] = g2[q * Cfg::NT];
+  }
+  __device__ __forceinline__ void store(double* __restrict__ buf, int tid, double sign) const {
+    double2* b2 = reinterpret_cast<double2*>(buf) + tid;
+#pragma unroll
+    for (int q = 0; q < Cfg::PF; ++q)
+      if ((q + 1) * Cfg::NT <= Cfg::MAT / 2 || tid + q * Cfg::NT < Cfg::MAT / 2)
+        b2[q * Cfg::NT] = double2{sign * v[q].x, sign * v[q].y};
+  }
+};
 
 // column sums of |tile| into the partial array (deterministic: one writer per (tile row, column))
 template <class Cfg>
@@ -258,27 +295,50 @@ __global__ __launch_bounds__(Cfg::NT) void cr_big_kernel(const double* __restric
                                                          double* __restrict__ ws, double* __restrict__ T_out,
                                                          int32_t* __restrict__ status, int32_t* __restrict__ n_iter_out,
                                                          int scan_mode, const double* __restrict__ D, int k,
-                                                         double* __restrict__ R_out) {
+                                                         double* __restrict__ R_out, long long* __restrict__ dbg) {
   constexpr int NP = Cfg::NP, TR = Cfg::TR, TC = Cfg::TC, NT = Cfg::NT;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* bufL = lds;
   double* bufR = lds + Cfg::OFF_R;
   double* part = lds + Cfg::OFF_PART;
+  // debug (dsge_debug_big_phases): shader cycles of workgroup 0's first draw in [0] tile loads, [1] eliminations, [2] scatters,
+  // [3] the four products; [4] iterations, [5] total
+  const bool prof = dbg != nullptr && blockIdx.x == 0;
+  long long t_a = 0, acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, t_begin = 0;
+#define BIG_STAMP(ACC)                  \
+  do {                                  \
+    if (prof) {                         \
+      const long long t_b = clock64();  \
+      ACC += t_b - t_a;                 \
+      t_a = t_b;                        \
+    }                                   \
+  } while (0)
   double* red = lds + Cfg::OFF_RED;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int ty = tid / Cfg::GX, tx = tid - ty * Cfg::GX, r0 = ty * TR, c0 = tx * TC;
+  // Thread coordinates are re-derived from an OPAQUE copy of the thread index at the head of every phase (BIG_COORDS): the
+  // compiler otherwise hoists every address that depends on them out of the iteration and the draw loops and keeps ~70 of them
+  // alive through the elimination, whose register blocks then spill (544 bytes of scratch per lane at NP = 96).
+  // (tx fastest.  ty fastest -- the GY owners of a block column in ONE wavefront, the pivot-candidate code skipped by all others --
+  //  measured slower: 310 k instead of 246 k cycles per elimination at n = 80)
+#define BIG_COORDS()                                                                              \
+  int tid = threadIdx.x;                                                                          \
+  asm volatile("" : "+v"(tid));                                                                   \
+  const int lane = tid & 63;                                                                      \
+  const int ty = tid / Cfg::GX, tx = tid - ty * Cfg::GX, r0 = ty * TR, c0 = tx * TC;             \
+  (void)lane;                                                                                     \
+  (void)r0;                                                                                       \
+  (void)c0
   double* W = ws + (size_t)blockIdx.x * Cfg::ws_doubles;
-  double *A0g = W, *A1g = W + NP * NP, *A2g = W + 2 * NP * NP, *Ahg = W + 3 * NP * NP, *X0g = W + 4 * NP * NP,
-         *X2g = W + 5 * NP * NP;
-  for (int idx = tid; idx < NP * NP; idx += NT) {  // (rows >= n of X0, X2 are never written again)
+  constexpr int LD = Cfg::LD, MAT = Cfg::MAT;
+  double *A0g = W, *A1g = W + MAT, *A2g = W + 2 * MAT, *Ahg = W + 3 * MAT, *X0g = W + 4 * MAT, *X2g = W + 5 * MAT;
+  for (int idx = threadIdx.x; idx < MAT; idx += NT) {  // (rows >= n of X0, X2 are never written again)
     X0g[idx] = 0.0;
     X2g[idx] = 0.0;
   }
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     __syncthreads();
-    for (int idx = tid; idx < NP * NP; idx += NT) {
-      const int r = idx / NP, c = idx - r * NP;
+    for (int idx = threadIdx.x; idx < MAT; idx += NT) {
+      const int r = idx / LD, c = idx - r * LD;
       const bool in = r < n && c < n;
       const size_t g = off + (size_t)r * n + c;
       const double b = in ? B[g] : 0.0;
@@ -287,11 +347,15 @@ __global__ __launch_bounds__(Cfg::NT) void cr_big_kernel(const double* __restric
       Ahg[idx] = b;
       A2g[idx] = in ? C[g] : 0.0;
     }
+    for (int idx = threadIdx.x; idx < NP * Cfg::LD; idx += NT) bufR[idx] = 0.0;  // (rows >= n of X0 in the panel are never written)
     __syncthreads();
     bool converged = false, saw_nan = false;
     int it = 0;
     double t1[TR][TC], t0[TR][TC], t2[TR][TC];
+    if (prof) t_begin = t_a = clock64();
     for (; it < max_iter;) {
+      {
+      BIG_COORDS();
       big_tile_load<Cfg>(t1, A1g, r0, c0);
       big_tile_load<Cfg>(t0, A0g, r0, c0);
       big_tile_load<Cfg>(t2, A2g, r0, c0);
@@ -302,49 +366,90 @@ __global__ __launch_bounds__(Cfg::NT) void cr_big_kernel(const double* __restric
           for (int jc = 0; jc < TC; ++jc)
             if (r0 + i == c0 + jc && r0 + i < n) t1[i][jc] += 1e-16;
       }
-      big_eliminate<Cfg>(t1, t0, t2, n, lds, r0, c0, tid);
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int jc = 0; jc < TC; ++jc) bufL[(r0 + i) * Cfg::LD + c0 + jc] = -t0[i][jc];  // the left panel of the first two products
+      BIG_STAMP(acc0);
+      big_eliminate<Cfg>(t1, t0, t2, n, lds, r0, c0, tid, (prof && draw == 0) ? dbg + 8 : nullptr);
+      BIG_STAMP(acc1);
       big_scatter_rows<Cfg>(t0, X0g, n, lds, r0, c0);
       big_scatter_rows<Cfg>(t2, X2g, n, lds, r0, c0);
-      __syncthreads();
-      // m00 = A0 X0 -> A0 := -m00
-      big_panel_load<Cfg>(bufL, A0g, tid);
-      big_panel_load<Cfg>(bufR, X0g, tid);
-      __syncthreads();
-      big_gemm<Cfg>(bufL, bufR, tid, [&](int ti, int, int row0, int col, big_v4f64 v) {
+      {  // X0 straight into the right panel as well (rows >= n of the panel: zero since the draw's set-up)
+        const int* pivcol = reinterpret_cast<const int*>(lds + Cfg::E_PIV);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) A0g[(size_t)(row0 + 4 * e) * NP + col] = -v[e];
+        for (int i = 0; i < TR; ++i)
+          if (r0 + i < n) {
+            int q = pivcol[r0 + i];
+            q = q < 0 ? 0 : (q >= n ? n - 1 : q);
+#pragma unroll
+            for (int jc = 0; jc < TC; ++jc) bufR[q * Cfg::LD + c0 + jc] = t0[i][jc];
+          }
+      }
+      __syncthreads();
+      BIG_STAMP(acc2);
+      }
+      BIG_COORDS();
+      // The four products.  The left panel holds -A0, then -A2, so that every product IS the updated matrix: A0 := (-A0) X0,
+      // A1 := A1 + (-A0) X2 + (-A2) X0, A2 := (-A2) X2, A1_hat := A1_hat + (-A2) X0.  A1 and A1_hat stay in this wavefront's
+      // accumulator tiles from iteration to iteration (no read-modify-write through the workspace); the next panel is fetched
+      // into registers while the current product runs.
+      BigPanelRegs<Cfg> pf;
+      pf.fetch(X2g, tid);
+      // A1 and A1_hat in product-tile layout (slot s of this wavefront: tile wave + s NW; element (row0 + 4 e, col)), requested
+      // now and first used two products later.  [Kept in registers from iteration to iteration they cost the elimination its
+      // registers: 592 bytes of scratch per lane at NP = 96 and an elimination twice as slow.]
+      big_v4f64 a1acc[Cfg::TPW], ahacc[Cfg::TPW];
+      {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int sl = 0; sl < Cfg::TPW; ++sl) {
+          const int t = wave + sl * Cfg::NW, ti = t / Cfg::MT, tj = t - ti * Cfg::MT;
+          if (t < Cfg::MT * Cfg::MT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int o = (16 * ti + (lane >> 4) + 4 * e) * LD + 16 * tj + (lane & 15);
+              a1acc[sl][e] = A1g[o];
+              ahacc[sl][e] = Ahg[o];
+            }
+          }
+        }
+      }
+      big_gemm<Cfg>(bufL, bufR, tid, BigZero(), [&](int, int ti, int row0, int col, big_v4f64 v) {  // A0 := -A0 X0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) A0g[(row0 + 4 * e) * LD + col] = v[e];
         big_colsum_part<Cfg>(part, ti, col, v, lane);
       });
       const double nrm0 = big_norm1<Cfg>(part, red, tid);
-      // m02 = A0 X2 -> A1 -= m02
-      big_panel_load<Cfg>(bufR, X2g, tid);
+      pf.store(bufR, tid, 1.0);  // X2
       __syncthreads();
-      big_gemm<Cfg>(bufL, bufR, tid, [&](int, int, int row0, int col, big_v4f64 v) {
+      pf.fetch(A2g, tid);
+      big_gemm<Cfg>(bufL, bufR, tid, [&](int sl) { return a1acc[sl]; },
+                    [&](int sl, int, int, int, big_v4f64 v) { a1acc[sl] = v; });  // A1 -= A0 X2
+      __syncthreads();
+      pf.store(bufL, tid, -1.0);  // -A2
+      __syncthreads();
+      pf.fetch(X0g, tid);
+      big_gemm<Cfg>(bufL, bufR, tid, BigZero(), [&](int, int ti, int row0, int col, big_v4f64 v) {  // A2 := -A2 X2
 #pragma unroll
-        for (int e = 0; e < 4; ++e) A1g[(size_t)(row0 + 4 * e) * NP + col] -= v[e];
-      });
-      __syncthreads();
-      // m22 = A2 X2 -> A2 := -m22
-      big_panel_load<Cfg>(bufL, A2g, tid);
-      __syncthreads();
-      big_gemm<Cfg>(bufL, bufR, tid, [&](int ti, int, int row0, int col, big_v4f64 v) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) A2g[(size_t)(row0 + 4 * e) * NP + col] = -v[e];
+        for (int e = 0; e < 4; ++e) A2g[(row0 + 4 * e) * LD + col] = v[e];
         big_colsum_part<Cfg>(part, ti, col, v, lane);
       });
       const double nrm2 = big_norm1<Cfg>(part, red, tid);
-      // m20 = A2 X0 -> A1 -= m20, A1_hat -= m20
-      big_panel_load<Cfg>(bufR, X0g, tid);
+      pf.store(bufR, tid, 1.0);  // X0
       __syncthreads();
-      big_gemm<Cfg>(bufL, bufR, tid, [&](int, int, int row0, int col, big_v4f64 v) {
+      big_gemm<Cfg>(bufL, bufR, tid, BigZero(), [&](int sl, int, int row0, int col, big_v4f64 v) {  // A1, A1_hat -= A2 X0
+        a1acc[sl] += v;
+        ahacc[sl] += v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const size_t o = (size_t)(row0 + 4 * e) * NP + col;
-          A1g[o] -= v[e];
-          Ahg[o] -= v[e];
+          const int o = (row0 + 4 * e) * LD + col;
+          A1g[o] = a1acc[sl][e];
+          Ahg[o] = ahacc[sl][e];
         }
       });
       __syncthreads();
+      BIG_STAMP(acc3);
       ++it;
       if (nrm0 < tol) {
         if (nrm2 < tol || scan_mode) {  // the scan variant tests the A0 norm only (cycle_reduction.py:269-277)
@@ -361,6 +466,7 @@ __global__ __launch_bounds__(Cfg::NT) void cr_big_kernel(const double* __restric
     const size_t offk = (size_t)draw * n * k;
     if (solve_T) {
       // T = -A1_hat^-1 A  (cycle_reduction.py:181); with D the same elimination gives R = -A1_hat^-1 D
+      BIG_COORDS();
       big_tile_load<Cfg>(t1, Ahg, r0, c0);
 #pragma unroll
       for (int i = 0; i < TR; ++i)
@@ -388,15 +494,25 @@ __global__ __launch_bounds__(Cfg::NT) void cr_big_kernel(const double* __restric
         }
       }
     } else {
-      for (int idx = tid; idx < n * n; idx += NT) T_out[off + idx] = 0.0;
+      for (int idx = threadIdx.x; idx < n * n; idx += NT) T_out[off + idx] = 0.0;
       if (R_out != nullptr && !scan_mode)
-        for (int idx = tid; idx < n * k; idx += NT) R_out[offk + idx] = 0.0;
+        for (int idx = threadIdx.x; idx < n * k; idx += NT) R_out[offk + idx] = 0.0;
     }
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
       status[draw] = solve_T ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
       if (n_iter_out) n_iter_out[draw] = it;
+      if (prof && draw == 0) {
+        dbg[0] = acc0;
+        dbg[1] = acc1;
+        dbg[2] = acc2;
+        dbg[3] = acc3;
+        dbg[4] = it;
+        dbg[5] = clock64() - t_begin;
+      }
     }
   }
+#undef BIG_STAMP
+#undef BIG_COORDS
 }
 
 // ---- selection matrix and policy residual for a given T (assemble_kernel's do_selection part, n > 64):
@@ -414,9 +530,12 @@ __global__ __launch_bounds__(Cfg::NT) void selection_big_kernel(const double* __
   double* bufR = lds + Cfg::OFF_R;
   double* red = lds + Cfg::OFF_RED;
   const int tid = threadIdx.x;
+  // (tx fastest.  ty fastest -- the GY owners of a block column in ONE wavefront, the pivot-candidate code skipped by all others --
+  //  measured slower: 310 k instead of 246 k cycles per elimination at n = 80)
   const int ty = tid / Cfg::GX, tx = tid - ty * Cfg::GX, r0 = ty * TR, c0 = tx * TC;
   double* W = ws + (size_t)blockIdx.x * Cfg::ws_doubles;
-  double *Cg = W, *Tg = W + NP * NP, *Mg = W + 2 * NP * NP;
+  constexpr int LD = Cfg::LD, MAT = Cfg::MAT;
+  double *Cg = W, *Tg = W + MAT, *Mg = W + 2 * MAT;
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
     if (status && status[draw] != 0) {
@@ -426,8 +545,8 @@ __global__ __launch_bounds__(Cfg::NT) void selection_big_kernel(const double* __
       continue;
     }
     __syncthreads();
-    for (int idx = tid; idx < NP * NP; idx += NT) {
-      const int r = idx / NP, c = idx - r * NP;
+    for (int idx = tid; idx < MAT; idx += NT) {
+      const int r = idx / LD, c = idx - r * LD;
       const bool in = r < n && c < n;
       const size_t g = off + (size_t)r * n + c;
       Cg[idx] = in ? C[g] : 0.0;
@@ -437,11 +556,11 @@ __global__ __launch_bounds__(Cfg::NT) void selection_big_kernel(const double* __
     big_panel_load<Cfg>(bufL, Cg, tid);
     big_panel_load<Cfg>(bufR, Tg, tid);
     __syncthreads();
-    big_gemm<Cfg>(bufL, bufR, tid, [&](int, int, int row0, int col, big_v4f64 v) {  // M = B + C T
+    big_gemm<Cfg>(bufL, bufR, tid, BigZero(), [&](int, int, int row0, int col, big_v4f64 v) {  // M = B + C T
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = row0 + 4 * e;
-        Mg[(size_t)r * NP + col] = (r < n && col < n) ? B[off + (size_t)r * n + col] + v[e] : 0.0;
+        Mg[r * LD + col] = (r < n && col < n) ? B[off + (size_t)r * n + col] + v[e] : 0.0;
       }
     });
     __syncthreads();
@@ -449,7 +568,7 @@ __global__ __launch_bounds__(Cfg::NT) void selection_big_kernel(const double* __
       big_panel_load<Cfg>(bufL, Mg, tid);
       __syncthreads();
       double s = 0.0;
-      big_gemm<Cfg>(bufL, bufR, tid, [&](int, int, int row0, int col, big_v4f64 v) {
+      big_gemm<Cfg>(bufL, bufR, tid, BigZero(), [&](int, int, int row0, int col, big_v4f64 v) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = row0 + 4 * e;

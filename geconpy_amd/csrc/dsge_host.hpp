@@ -190,6 +190,7 @@ int launch_second_order(const double* B, const double* C, const double* T, const
 extern int g_adj_refine_mode;          // launch_assemble.hip: 0 = residual rule, 1 = refine every draw, 2 = never (debug)
 extern long long* g_so_dbg;            // launch_second_order.hip: debug phase counters of the second-order filter kernel
 extern long long* g_cr_dbg;            // launch_solvers.hip: debug phase counters of the compact CR kernel
+extern long long* g_big_dbg;          // launch_big.hip: debug phase cycles of cr_big_kernel
 extern long long* g_kalman_dbg;       // launch_kalman.hip: debug buffer for per-phase cycles of draw 0
 extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[32])
 extern float* g_gensys_stage_ms;      // launch_gensys.hip: debug, host float[8]: launch durations of the window path (dsge_debug_gensys_stage_ms)

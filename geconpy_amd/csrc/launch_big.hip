@@ -5,11 +5,16 @@
 
 namespace dsge_host {
 
+long long* g_big_dbg = nullptr;  // debug: device int64[8], phase cycles of workgroup 0's first draw (dsge_debug_big_phases)
+
 namespace {
 StreamArenaPool g_big_pool;
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // one workgroup per CU is resident (150 KB of LDS at NP = 96); two grid-strides per CU keep the tail short
 constexpr int BIG_GRID_MAX = 512;
+// Threads per draw: the elimination is a chain of short dependent phases separated by barriers, so a step's duration is set by
+// instruction latency, not by arithmetic -- more wavefronts per SIMD hide it better.  Measured cycles per pivot step at
+// n = 80 / 96 (tools/big_phases.py): 256 threads 4.5 k / 5.3 k; 640 / 512 threads (below) see DESIGN.md.
 using Cfg80 = dsge::BigCfg<80, 5, 2>;
 using Cfg96 = dsge::BigCfg<96, 6, 3>;
 }  // namespace
@@ -28,7 +33,7 @@ int launch_cr_big(const double* A, const double* B, const double* C, int batch, 
     if ((rc = g_big_pool.reserve(al256((size_t)grid * CFG::ws_doubles * 8), st, &base))) return rc;                          \
     if ((rc = set_lds(dsge::cr_big_kernel<CFG>, CFG::lds_bytes))) return rc;                                                 \
     hipLaunchKernelGGL(dsge::cr_big_kernel<CFG>, dim3(grid), dim3(CFG::NT), CFG::lds_bytes, st, A, B, C, batch, n, max_iter, \
-                       tol, (double*)base, T_out, status, n_iter, scan_mode, D, k, R_out);                                   \
+                       tol, (double*)base, T_out, status, n_iter, scan_mode, D, k, R_out, g_big_dbg);                                   \
   } while (0)
   if (n <= 80)
     BIG_CR(Cfg80);

@@ -410,6 +410,8 @@ int dsge_debug_kalman_steady_steps(int32_t* steady_at_device);
  * in each of its five per-step phases, [5] the cycles spent in steady-state steps, [6] their number and
  * [7] the kernel total; cycles_out (host int64[8], may be NULL) reads them back. */
 int dsge_debug_kalman_phases(int enable, long long* cycles_out);
+/* cr_big_kernel (65 .. 96 variables), first draw of workgroup 0; cycles_out: 16 values.  [0] block loads, [1] eliminations, [2] scatters, [3] products, [4] iterations, [5] total, [8..12] inside the eliminations (see dsge_api.hip) */
+int dsge_debug_big_phases(int enable, long long* cycles_out);
 
 /* Debug hook: shader-clock stamps of draw 0 at the phase boundaries of the gensys kernel (start,
  * Hessenberg-triangular, QZ, reordering, SVDs/eu, end).  Device pointers; cycles_out: host int64[6]. */
