@@ -47,10 +47,13 @@ struct BigCfg {
   static constexpr int MAT = NP * LD;                              // doubles per workspace matrix
   static constexpr int PF = (MAT / 2 + NT - 1) / NT;               // double2 per thread of one panel (prefetch registers)
   static constexpr int OFF_R = NP * LD, OFF_PART = 2 * NP * LD, OFF_RED = OFF_PART + MT * NP, OFF_EL = OFF_RED + 64;
-  static constexpr size_t lds_bytes = (size_t)(OFF_EL + 6 * NP + 4) * 8;
+  static constexpr size_t lds_bytes = (size_t)(OFF_EL + NP / 2 + 2 + 8) * 8;
   static constexpr size_t ws_doubles = 6 * (size_t)MAT;  // A0, A1, A2, A1_hat, X0, X2 per workgroup
-  static constexpr int E_COL = OFF_EL, E_ROW = OFF_EL + 2 * NP, E_PIV = OFF_EL + 5 * NP,
-                       E_KEY = OFF_EL + 6 * NP;  // col[2][NP] | row[3][NP] | int pivcol[NP] | u64 key[2]
+  // elimination: pivcol int[NP] and the round's pivot rows int[TC] in the tail; panel [NP][TC], coefficients [NP][TC] and the
+  // round's pivot rows [TC][3 NP] alias the RIGHT panel (free during an elimination; the left one already holds -A0)
+  static constexpr int E_PIV = OFF_EL, E_PS = OFF_EL + NP / 2 + 2;
+  static constexpr int E_PANEL = OFF_R, E_CV = OFF_R + NP * TC, E_ROW = OFF_R + 2 * NP * TC;
+  static_assert(5 * NP * TC <= NP * LD && TC <= 8, "elimination buffers fit the right panel");
 };
 
 // ---- register blocks <-> the workgroup's padded NP x NP workspace matrices ---------------------------------------------------------
@@ -70,10 +73,51 @@ __device__ __forceinline__ void big_panel_load(double* __restrict__ buf, const d
   for (int idx = tid; idx < Cfg::MAT / 2; idx += Cfg::NT) b2[idx] = g2[idx];
 }
 
-// ---- Gauss-Jordan elimination of [t1 | t0 | t2] with implicit partial pivoting -----------------------------------------------------
+// ---- Gauss-Jordan elimination of [t1 | t0 | t2] with implicit partial pivoting, one block column (TC pivots) per round ----------------
 // On exit t1 is (a row permutation of) the identity and physical row r of t0, t2 holds row pivcol[r] of t1_in^-1 [t0_in | t2_in];
 // pivcol (int[NP], LDS) is valid after the closing barrier.  A zero pivot divides by zero: the NaN / Inf flows into the
 // stopping rule's norm like LAPACK's singular-matrix error does in the reference (cycle_reduction.py:176-177).
+//
+// [First version, one pivot per round: column j published + arg-max by LDS atomic, barrier, pivot row published, barrier, rank-1
+//  update -- 3.7 k cycles per pivot at n = 80 for 30 FMAs per thread, all of it barrier waits and the latency of short dependent
+//  phases on ten wavefronts.]  A round now takes the TC columns of one block column:
+//    1. their owners publish the n x TC panel;                                                                       barrier
+//    2. wavefront 0 alone -- two rows per lane, no barrier inside -- eliminates the panel: per pivot a DPP arg-max over the rows
+//       not used yet, the pivot row's panel entries by v_readlane, and for EVERY row i its coefficients over the round's pivot
+//       rows:   row_i(new) = delta_i row_i(old) + sum_t cv_i[t] row_{p_t}(old),   delta_i = 0 for the round's pivot rows
+//       (selecting p at step s: cv_p[s] += 1, cv_p *= 1 / pivot;  every other row: cv_i -= x_i[s] cv_p);            barrier
+//    3. the owners of the TC pivot rows publish them (old values, all three matrices);                              barrier
+//    4. every thread applies the rank-TC update to its register blocks.
+// Three barriers and one serial section per TC pivots instead of two barriers per pivot.
+__device__ __forceinline__ unsigned long long big_wave_max_u64(unsigned long long k) {
+  unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+#define BIG_DPP_STEP(CTRL)                                                                        \
+  do {                                                                                            \
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false); \
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false); \
+    const bool gt = ohi > hi || (ohi == hi && olo > lo);                                          \
+    lo = gt ? olo : lo;                                                                           \
+    hi = gt ? ohi : hi;                                                                           \
+  } while (0)
+  BIG_DPP_STEP(0xB1);   // quad_perm [1, 0, 3, 2]
+  BIG_DPP_STEP(0x4E);   // quad_perm [2, 3, 0, 1]
+  BIG_DPP_STEP(0x141);  // row_half_mirror
+  BIG_DPP_STEP(0x140);  // row_mirror: every lane of a row of 16 holds the row's maximum
+#undef BIG_DPP_STEP
+  unsigned long long m = 0ull;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned long long v = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 16 * r) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)lo, 16 * r);
+    m = v > m ? v : m;
+  }
+  return m;
+}
+__device__ __forceinline__ double big_readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 template <class Cfg>
 __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], double (&t0)[Cfg::TR][Cfg::TC],
                                               double (&t2)[Cfg::TR][Cfg::TC], int n, double* __restrict__ lds, int r0, int c0,
@@ -88,92 +132,142 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
       pt = t_b;                        \
     }                                  \
   } while (0)
-  double* rowb = lds + Cfg::E_ROW;
+  double* panel = lds + Cfg::E_PANEL;  // [NP][TC]
+  double* cvb = lds + Cfg::E_CV;       // [NP][TC]
+  double* rowb = lds + Cfg::E_ROW;     // [TC][3 NP]
   int* pivcol = reinterpret_cast<int*>(lds + Cfg::E_PIV);
-  // Pivot search without a search phase: the GY threads that own column j fold their candidates (rows not used yet) into one
-  // 64-bit LDS word with ds_max_u64 -- key = bit pattern of |x| (monotone as an unsigned integer for x >= 0; a NaN sorts above
-  // Inf and is taken, as it must) with its low 7 bits replaced by 127 - row (ties and near-ties: the smaller row) -- while they
-  // publish the column.  [First version: every wavefront ran a 6-step shuffle arg-max over the column after the barrier --
-  // 18 dependent ds_bpermute per pivot; 4.1 k cycles per pivot at n = 80.]
-  unsigned long long* keyw = reinterpret_cast<unsigned long long*>(lds + Cfg::E_KEY);
-  unsigned used_mine = 0u;  // bit i: row r0 + i has been a pivot row
-  __syncthreads();          // (the panel this aliases is no longer read)
-  if (tid == 0) {
-    keyw[0] = 0ull;
-    keyw[1] = 0ull;
-  }
-  __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    double* colb = lds + Cfg::E_COL + (j & 1) * NP;
-    // column j of t1: the multipliers of this step and the pivot candidates.  (One region per block column; picking the column
-    // out of the block with selects first and building the keys once measured slower -- 890 instead of 720 cycles -- and cost
-    // registers.)
+  int* psb = reinterpret_cast<int*>(lds + Cfg::E_PS);  // [TC] pivot rows of the round
+  const int lane = tid & 63;
+  const bool w0 = tid < 64;
+  bool used_a = false, used_b = false;  // wavefront 0: rows lane, lane + 64 have been pivot rows
+  __syncthreads();                      // (the right panel, which these buffers alias, is no longer read)
+  for (int j0 = 0; j0 < n; j0 += TC) {
+    const int bs = (n - j0) < TC ? (n - j0) : TC;
+    // 1. the panel
+    if (c0 == j0) {
 #pragma unroll
-    for (int jc = 0; jc < TC; ++jc)
-      if (c0 + jc == j) {
-        unsigned long long best = 0ull;
+      for (int i = 0; i < TR; ++i)
 #pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          const double x = t1[i][jc];
-          colb[r0 + i] = x;
-          const unsigned long long key =
-              ((unsigned long long)__double_as_longlong(fabs(x)) & ~127ull) | (unsigned long long)(127 - (r0 + i));
-          if (r0 + i < n && !((used_mine >> i) & 1u) && key > best) best = key;
-        }
-        if (best != 0ull) atomicMax(&keyw[j & 1], best);
-      }
+        for (int jc = 0; jc < TC; ++jc) panel[(r0 + i) * TC + jc] = t1[i][jc];
+    }
     EL_STAMP(0);
     __syncthreads();
     EL_STAMP(1);
-    const int p = 127 - (int)(keyw[j & 1] & 127ull);
-    const double dinv = 1.0 / colb[p];  // (started here: the division's latency runs while the pivot row is being published)
-    // the pivot row of all three matrices
+    // 2. wavefront 0 eliminates the panel
+    if (w0) {
+      const int ra = lane, rb = lane + 64;
+      double xa[TC], xb[TC], ca[TC], cb[TC];
 #pragma unroll
-    for (int i = 0; i < TR; ++i)
-      if (r0 + i == p) {
-        used_mine |= 1u << i;
+      for (int c = 0; c < TC; ++c) {
+        xa[c] = panel[ra * TC + c];  // (n > 64: every lane has a first row)
+        xb[c] = (rb < n) ? panel[rb * TC + c] : 0.0;
+        ca[c] = 0.0;
+        cb[c] = 0.0;
+      }
 #pragma unroll
-        for (int jc = 0; jc < TC; ++jc) {
-          rowb[c0 + jc] = t1[i][jc];
-          rowb[NP + c0 + jc] = t0[i][jc];
-          rowb[2 * NP + c0 + jc] = t2[i][jc];
+      for (int sidx = 0; sidx < TC; ++sidx) {
+        if (sidx < bs) {
+          const unsigned long long ka =
+              used_a ? 0ull : (((unsigned long long)__double_as_longlong(fabs(xa[sidx])) & ~127ull) | (unsigned long long)(127 - ra));
+          const unsigned long long kb = (used_b || rb >= n)
+                                            ? 0ull
+                                            : (((unsigned long long)__double_as_longlong(fabs(xb[sidx])) & ~127ull) |
+                                               (unsigned long long)(127 - rb));
+          const unsigned long long km = big_wave_max_u64(ka > kb ? ka : kb);
+          const int p = 127 - (int)(km & 127ull);
+          const int pl = p & 63;
+          const bool hislot = p >= 64;
+          double xr[TC], cr[TC];
+#pragma unroll
+          for (int c = 0; c < TC; ++c) {
+            xr[c] = big_readlane_f64(hislot ? xb[c] : xa[c], pl);
+            cr[c] = big_readlane_f64(hislot ? cb[c] : ca[c], pl);
+          }
+          const double dinv = 1.0 / xr[sidx];
+          cr[sidx] += 1.0;
+#pragma unroll
+          for (int c = 0; c < TC; ++c) {
+            xr[c] *= dinv;
+            cr[c] *= dinv;
+          }
+          const bool is_a = (ra == p), is_b = (rb == p);
+          const double fa = xa[sidx], fb = xb[sidx];
+#pragma unroll
+          for (int c = 0; c < TC; ++c) {
+            xa[c] = is_a ? xr[c] : fma(-fa, xr[c], xa[c]);
+            ca[c] = is_a ? cr[c] : fma(-fa, cr[c], ca[c]);
+            xb[c] = is_b ? xr[c] : fma(-fb, xr[c], xb[c]);
+            cb[c] = is_b ? cr[c] : fma(-fb, cr[c], cb[c]);
+          }
+          used_a = used_a || is_a;
+          used_b = used_b || is_b;
+          if (lane == 0) {
+            psb[sidx] = p;
+            pivcol[p] = j0 + sidx;
+          }
         }
       }
-    if (tid == 0) {
-      pivcol[p] = j;
-      keyw[(j + 1) & 1] = 0ull;  // (read for the last time before this step's first barrier, written next after its second)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) {
+        cvb[ra * TC + c] = ca[c];
+        if (rb < n) cvb[rb * TC + c] = cb[c];
+      }
     }
     EL_STAMP(2);
     __syncthreads();
     EL_STAMP(3);
-    double pr1[TC], pr0[TC], pr2[TC];
+    // 3. the round's pivot rows (old values)
+    int ps[TC];
 #pragma unroll
-    for (int jc = 0; jc < TC; ++jc) {
-      pr1[jc] = rowb[c0 + jc] * dinv;
-      pr0[jc] = rowb[NP + c0 + jc] * dinv;
-      pr2[jc] = rowb[2 * NP + c0 + jc] * dinv;
-    }
+    for (int t = 0; t < TC; ++t) ps[t] = (t < bs) ? psb[t] : -1;
+    unsigned keep = 0u;  // bit i: row r0 + i is not one of the round's pivot rows (delta = 1)
 #pragma unroll
     for (int i = 0; i < TR; ++i) {
-      const double f = colb[r0 + i];
+      bool piv = false;
 #pragma unroll
-      for (int jc = 0; jc < TC; ++jc) {
-        t1[i][jc] = fma(-f, pr1[jc], t1[i][jc]);
-        t0[i][jc] = fma(-f, pr0[jc], t0[i][jc]);
-        t2[i][jc] = fma(-f, pr2[jc], t2[i][jc]);
-      }
-      if (r0 + i == p) {  // the pivot row itself: scaled, not eliminated
+      for (int t = 0; t < TC; ++t)
+        if (r0 + i == ps[t]) {
+          piv = true;
+#pragma unroll
+          for (int jc = 0; jc < TC; ++jc) {
+            rowb[t * 3 * NP + c0 + jc] = t1[i][jc];
+            rowb[t * 3 * NP + NP + c0 + jc] = t0[i][jc];
+            rowb[t * 3 * NP + 2 * NP + c0 + jc] = t2[i][jc];
+          }
+        }
+      keep |= piv ? 0u : (1u << i);
+    }
+    __syncthreads();
+    // 4. rank-bs update, one matrix after the other (the pivot rows of one matrix in registers at a time)
+    double cv[TR][TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int t = 0; t < TC; ++t) cv[i][t] = (r0 + i < n && t < bs) ? cvb[(r0 + i) * TC + t] : 0.0;
+    auto update = [&](double (&tm)[TR][TC], int mofs) {
+      double q[TC][TC];
+#pragma unroll
+      for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int jc = 0; jc < TC; ++jc) q[t][jc] = (t < bs) ? rowb[t * 3 * NP + mofs + c0 + jc] : 0.0;  // (short last round: not published)
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const bool kp = (keep >> i) & 1u;
 #pragma unroll
         for (int jc = 0; jc < TC; ++jc) {
-          t1[i][jc] = pr1[jc];
-          t0[i][jc] = pr0[jc];
-          t2[i][jc] = pr2[jc];
+          double acc = kp ? tm[i][jc] : 0.0;
+#pragma unroll
+          for (int t = 0; t < TC; ++t) acc = fma(cv[i][t], q[t][jc], acc);
+          tm[i][jc] = acc;
         }
       }
-    }
+    };
+    update(t1, 0);
+    update(t0, NP);
+    update(t2, 2 * NP);
     EL_STAMP(4);
   }
-  __syncthreads();  // pivcol complete; the next step-1 writes of a following elimination cannot overtake this one's reads
+  __syncthreads();  // pivcol complete; the buffers may be reused
   if (prof && tid == 0)
     for (int q = 0; q < 5; ++q) prof[q] += pa[q];
 #undef EL_STAMP
