@@ -443,13 +443,17 @@ def main():
     # observation model of the realistic-structure leg (seven observed JUMP variables) -- also before the GPU is touched
     want_extras = (world == 1 and not args.no_extras and not args.from_theta and args.workload == "sw_shaped"
                    and args.solver == "cycle_reduction")
-    cpu_gensys = cpu_jumps = om_j = None
+    cpu_gensys = cpu_jumps = om_j = b80 = om80 = cpu_n80 = None
     if want_extras:
         om_j = wl.sw_shaped_observation_model(observed=wl.SW_OBSERVED_JUMPS)
+        shape80 = dict(n=80, n_state=36, n_lead=24, k=10, p=7, T_len=200)  # the `n80` leg: a model beyond 64 variables
+        b80 = wl.sw_shaped_batch(128, **shape80)
+        om80 = wl.sw_shaped_observation_model(**shape80)
     if want_extras and rank == 0 and args.cpu_sample > 0:
         n_x = min(hi - lo, max(64, 2 * cores))
         cpu_gensys = cpu_baseline(shard, om, n_x, cores, solver="gensys")
         cpu_jumps = cpu_baseline(shard, om_j, n_x, cores)
+        cpu_n80 = cpu_baseline(b80, om80, min(128, max(16, cores)), cores)
 
     so_leg = second_order_leg() if (want_extras and rank == 0) else None
 
@@ -640,6 +644,29 @@ def main():
                                  "bit_identical_to_headline": bool(all(torch.equal(x, logp_all[lo:hi]) for x in lp2))}
         if so_leg is not None:
             extras["second_order"] = so_leg
+        # a model beyond 64 variables (csrc/dsge_big.hpp: cycle reduction with one workgroup per draw, the filter on the model
+        # restricted to its state and observed variables): SW-shaped systems scaled to n = 80, 1024 draws (128 distinct)
+        try:
+            t8 = lambda x: eng.to_device(np.tile(x, (8,) + (1,) * (x.ndim - 1)))  # noqa: E731
+            A8, B8, C8, D8, q8 = t8(b80["A"]), t8(b80["B"]), t8(b80["C"]), t8(b80["D"]), t8(b80["sigma"] ** 2)
+            Z8, y8, H8 = eng.to_device(om80["Z"]), eng.to_device(om80["y"]), eng.to_device(om80["Hdiag"])
+            lp8 = torch.empty(1024, dtype=torch.float64, device=device)
+            st8 = torch.empty(1024, dtype=torch.int32, device=device)
+            dt8 = timed(lambda: eng.solve_kalman_logp(A8, B8, C8, D8, q8, Z8, y8, Hdiag=H8, q_mode=1, tol=args.tol,
+                                                      max_iter=args.max_iter, logp=lp8, status=st8, solver="cycle_reduction",
+                                                      z_selector_hint=1), 3)
+            extras["n80"] = {"value": round(1024 / dt8, 2), "ms_per_step": round(dt8 * 1e3, 4), "unit": "evals/s",
+                             "note": "SW-shaped systems scaled to n = 80 (36 states, 24 forward-looking, 10 shocks, 7 observed), "
+                                     "1024 draws (128 distinct), cycle reduction: the 65..96-variable path (csrc/dsge_big.hpp)",
+                             "failed_draws": int((st8 != 0).sum().item())}
+            if cpu_n80 is not None:
+                ref8 = cpu_n80[0]
+                rel8 = np.abs(lp8[: len(ref8)].cpu().numpy() - ref8) / np.abs(ref8)
+                extras["n80"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel8.max()),
+                                           "median_rel_logp_err_vs_cpu_oracle": float(np.median(rel8)),
+                                           "n_checked": int(len(ref8)), "cpu_oracle_evals_per_s": round(cpu_n80[1], 2)}
+        except Exception as exc:  # (never lose the headline line to an extra leg)
+            extras["n80"] = {"error": repr(exc)}
         local_eval(0, nloc)  # (leave the buffers as the headline loop left them)
         torch.cuda.synchronize()
 
