@@ -112,6 +112,7 @@ int dsge_stream_synchronize(void* stream);
  *   A,B,C : [batch][n][n]      T_out : [batch][n][n] (zeros where not converged, :181)
  *   status: [batch] DSGE_ST_*  n_iter: [batch] iterations used (may be NULL)
  * Stopping rule of the njit variant (:171-177): ||A0||_1 < tol and ||A2||_1 < tol.
+ * n <= DSGE_MAX_N_BIG (65 .. 96 variables: one workgroup per draw, csrc/dsge_big.hpp); so has the scan variant below.
  */
 int dsge_cycle_reduction_batched(const double* A, const double* B, const double* C, int batch, int n,
                                  int max_iter, double tol, double* T_out, int32_t* status,
@@ -436,6 +437,7 @@ int dsge_debug_gensys_stage_ms(int enable, float* ms_out);
  * of DSGEStateSpace._setup_policy_matrices (gEconpy/model/statespace.py:213):
  *   R = -(C T + B)^-1 D            R_out    : [batch][n][k]
  *   resid = sum((A + B T + C T T)^2)  resid_out: [batch] (NULL to skip; then A may be NULL)
+ * n <= DSGE_MAX_N_BIG.
  */
 int dsge_selection_batched(const double* A, const double* B, const double* C, const double* D,
                            const double* T, int batch, int n, int k, double* R_out, double* resid_out,
@@ -603,6 +605,10 @@ int dsge_kalman_filter_outputs_batched_host(const double* T, const double* R, co
  *   solver : DSGE_SOLVER_*; tol/max_iter as configure(...) passes them (statespace.py:835-836)
  *   T_out [batch][n][n], R_out [batch][n][k], resid_out [batch], n_iter_out [batch]: optional
  *   status_out : [batch] (required)    logp_out : [batch] (required)
+ * n <= DSGE_MAX_N (64); with a cycle-reduction solver n <= DSGE_MAX_N_BIG (96): the solver then runs with one workgroup per draw
+ * and the filter on the model restricted to F = {state variables} u {observed variables} -- exact, because every column of T
+ * outside the state variables is zero.  F is measured on the device (the call synchronises `stream` once; the hints are not
+ * used); more than 64 variables in F: DSGE_ERR_TOO_LARGE, nothing computed.
  */
 int dsge_solve_kalman_logp_batched(const double* A, const double* B, const double* C, const double* D,
                                    const double* Q, int q_mode, const double* Z, int z_batched,
