@@ -141,6 +141,32 @@ def test_gradient_sw_shaped():
         _directional_check(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h, g, rng, n_dirs=2)
 
 
+def test_gradient_with_the_gensys_solver():
+    """The reference's default estimation solver is gensys (`configure(..., solver="gensys")`, statespace.py:832) and its
+    gradient is the same implicit-function adjoint of A + B T + C T^2 = 0 whichever solver produced T
+    (`o1_policy_function_adjoints`, shared.py:12-71; gensys.py:668-676): logp + gradient through the gensys launches against the
+    cycle-reduction route (logp 1e-9, every cotangent 1e-7 of its scale) and against directional differences of the oracle."""
+    rng = np.random.default_rng(4)
+    nb = 6
+    b = wl.sw_shaped_batch(nb, first_draw=40)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    y = om["y"][:60].copy()
+    h = om["Hdiag"].copy()
+    d = rng.normal(0, 0.01, 7)
+    cr = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, d=d, Hdiag=h, tol=1e-13,
+                                                max_iter=200)
+    gs = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, d=d, Hdiag=h, tol=1e-8,
+                                                solver="gensys")
+    assert np.all(cr["status"] == 0) and np.all(gs["status"] == 0)
+    assert_allclose(gs["logp"], cr["logp"], rtol=1e-9)
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
+        sc = np.abs(cr[key]).reshape(nb, -1).max(axis=1).reshape((nb,) + (1,) * (cr[key].ndim - 1))
+        assert np.all(np.abs(gs[key] - cr[key]) <= 1e-7 * np.maximum(sc, 1e-300)), key
+    g = {k_: v[0] for k_, v in gs.items() if k_.endswith("_bar")}
+    _directional_check(b["A"][0], b["B"][0], b["C"][0], b["D"][0], q[0], om["Z"], y, d, h, g, rng, n_dirs=2)
+
+
 def test_gradient_sw_shaped_against_extrapolated_differences():
     """The same extrapolated-difference check on the 40-variable SW-shaped system (deflated solve, reduced filter with
     steady-state segments, 60 periods with a missing observation): 1e-7 relative."""

@@ -5,6 +5,7 @@ import numpy as np, torch
 from geconpy_amd import workloads as wl
 from geconpy_amd.engine import LogpEngine
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+SOLVER = sys.argv[2] if len(sys.argv) > 2 else "cycle_reduction"  # or "gensys", the reference's default estimation solver
 nd = min(nb, 4096)  # distinct draws (a tiled small set clusters the draws that take second passes)
 b = wl.sw_shaped_batch(nd); om = wl.sw_shaped_observation_model(); rep = (nb + nd - 1) // nd
 eng = LogpEngine(0)
@@ -15,7 +16,7 @@ def run(A, B, C, D, q):
     for it in range(4):
         if it == 1:
             torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out)
+        out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out, solver=SOLVER, n_lead_hint=12 if SOLVER == "gensys" else 0)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / 3, out
 
@@ -24,11 +25,11 @@ out = None
 for it in range(4):
     if it == 1:
         torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out)
+    out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out, solver=SOLVER, n_lead_hint=12 if SOLVER == "gensys" else 0)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 st = out["status"].cpu().numpy() if hasattr(out["status"], "cpu") else np.asarray(out["status"])
 bad = np.flatnonzero(st != 0)
-print(f"{nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {len(bad)}"
+print(f"solver {SOLVER}: {nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {len(bad)}"
       + (f" (draws {bad[:8].tolist()}, status words {st[bad[:8]].tolist()})" if len(bad) else ""))
 
 # The batch holds ONE draw (752: cond(B + C T) = 3e8) whose policy adjoints need the elimination-based fixed point of the second
