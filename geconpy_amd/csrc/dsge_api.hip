@@ -721,7 +721,9 @@ static int pipeline_big(const double* A, const double* B, const double* C, const
     const bool scan = solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
     // R from the final elimination of the (njit-rule) iteration; the scan variant and a requested residual take the explicit
     // selection R = -(C T + B)^-1 D
-    const bool fuse_R = !scan && !resid_out;
+    // (nor with the reference's default gating: a failed draw carries T = 0 on, and its R = -(C 0 + B)^-1 D comes from the
+    // explicit selection, which runs after the statuses have been parked)
+    const bool fuse_R = !scan && !resid_out && !park_failures;
     if ((rc = launch_cr_big(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st, scan ? 1 : 0, fuse_R ? D : nullptr, k,
                             fuse_R ? Rw : nullptr)))
       return rc;

@@ -129,3 +129,34 @@ def test_big_failed_draw_and_too_many_filtered_variables():
     with pytest.raises(_lib.DsgeHipError):
         batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"],
                                           tol=1e-8, solver="gensys")
+
+
+def test_big_host_chunks_and_reference_default_gating():
+    """The host twin stages a batch >= 512 in chunks over two streams (each chunk measures its own filtered variables): same
+    logp to the bit as the draws evaluated in a small batch.  `add_solver_success_check=False` (the reference's default graph,
+    statespace.py:1148): a failed cycle reduction carries T = 0 on and the draw gets the finite log-likelihood of that system,
+    as on the n <= 64 path."""
+    n = 72
+    sh = SHAPES[n]
+    nd = 40
+    b = wl.sw_shaped_batch(nd, n=n, p=7, T_len=40, **sh)
+    om = wl.sw_shaped_observation_model(n=n, p=7, T_len=40, **sh)
+    rep = 16
+    big = {x: np.tile(b[x], (rep, 1, 1)) for x in "ABCD"}
+    qb = np.tile(b["sigma"] ** 2, (rep, 1))
+    small = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"],
+                                              Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+    large = batched.solve_kalman_logp_batched(big["A"], big["B"], big["C"], big["D"], qb, om["Z"], om["y"], Hdiag=om["Hdiag"],
+                                              tol=1e-8, max_iter=1000)
+    assert np.all(small["status"] == 0) and np.all(large["status"] == 0)
+    assert np.array_equal(large["logp"], np.tile(small["logp"], rep))
+    # max_iter = 2: every solve fails; with the reference's default gating the filter runs on T = 0, R = 0
+    gated = batched.solve_kalman_logp_batched(b["A"][:4], b["B"][:4], b["C"][:4], b["D"][:4], b["sigma"][:4] ** 2, om["Z"], om["y"],
+                                              Hdiag=om["Hdiag"], tol=1e-12, max_iter=2)
+    assert np.all(gated["status"] == _lib.ST_NOT_CONVERGED) and np.all(gated["logp"] == -np.inf)
+    ungated = batched.solve_kalman_logp_batched(b["A"][:4], b["B"][:4], b["C"][:4], b["D"][:4], b["sigma"][:4] ** 2, om["Z"],
+                                                om["y"], Hdiag=om["Hdiag"], tol=1e-12, max_iter=2, add_solver_success_check=False)
+    assert np.all(ungated["status"] == _lib.ST_NOT_CONVERGED) and np.all(np.isfinite(ungated["logp"]))
+    ref = oracle.solve_kalman_logp(b["A"][0], b["B"][0], b["C"][0], b["D"][0], np.diag(b["sigma"][0] ** 2), om["Z"], om["y"],
+                                   H=np.diag(om["Hdiag"]), tol=1e-12, max_iter=2, add_solver_success_check=False)
+    assert abs(ungated["logp"][0] - ref["logp"]) <= 1e-9 * abs(ref["logp"])
