@@ -24,5 +24,5 @@ print(f"n = {n}: {it} iterations, total {int(out[5])} cycles")
 for i, nm in enumerate(names):
     print(f"  {nm:16s} {int(out[i]):9d} cycles = {int(out[i]) // max(it, 1):7d} per iteration")
 piv = it * n
-for i, nm in enumerate(["candidates+column", "barrier 1", "pivot row", "barrier 2", "update"]):
-    print(f"  elimination / {nm:18s} {int(out[8 + i]) // max(piv, 1):6d} cycles per pivot step")
+for i, nm in enumerate(["panel published", "barrier 1", "panel eliminated (wavefront 0)", "barrier 2", "pivot rows + barrier + update"]):
+    print(f"  elimination / {nm:32s} {int(out[8 + i]) // max(piv, 1):6d} cycles per pivot step")

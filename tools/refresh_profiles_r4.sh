@@ -31,6 +31,14 @@ python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
 python3 tools/kalman_phases.py > "$OUT/kalman_phases.txt" 2>&1
 python3 tools/two_streams.py > "$OUT/two_streams.txt" 2>&1
 python3 tools/grad_rate.py > "$OUT/grad_rate.txt" 2>&1
+python3 tools/grad_rate.py 4096 gensys >> "$OUT/grad_rate.txt" 2>&1
+# models with 65 .. 96 variables (csrc/dsge_big.hpp)
+{ for N in 72 80 96; do python3 tools/big_rate.py $N 1024; done; python3 tools/big_phases.py 80; python3 tools/big_phases.py 96; } > "$OUT/big_rate.txt" 2>&1
+{ python3 tools/fuzz_big.py 0 40; python3 tools/fuzz_big.py 1 40; } > "$OUT/fuzz_big.txt" 2>&1
+rm -rf "$OUT/kt_big"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_big" -o kt -- python3 tools/big_rate.py 80 1024 > "$OUT/kt_big.log" 2>&1
+find "$OUT/kt_big" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_big80.csv" \;
+rm -rf "$OUT/kt_big" "$OUT/kt_big.log"
 python3 tools/pipeline_chunks_rate.py gensys > "$OUT/pipeline_chunks_gensys.txt" 2>&1
 bash tools/batch_scaling.sh "$TAG/bscale" > /dev/null 2>&1; cp "$OUT/bscale/summary.txt" "$OUT/batch_scaling.txt" 2>/dev/null; rm -rf "$OUT/bscale"
 python3 -m pytest tests -m gpu -q > "$OUT/tests_gpu.log" 2>&1
