@@ -416,6 +416,23 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
     T, R = _f64(T, 3), _f64(R, 3)
     y = _f64(y, 2)
     nb, m, _ = T.shape
+    if m > _lib.MAX_N:
+        # More than 64 variables: the filter of the model restricted to F = {variables with a non-zero column of T in some
+        # draw} u {observed variables} is the same filter (x_t[F] depends on x_{t-1}[F] only, y_t on x_t[F] only), and the
+        # device kernels take |F| <= 64 -- the gather the fused entry point does on the device (csrc/dsge_big.hpp), here on
+        # the host because T and R arrive as host arrays.  Exact zeros only: a T whose non-state columns carry rounding noise
+        # keeps them, and the call fails loudly instead of dropping them.
+        Zf = _f64(Z)
+        keep = np.any(T != 0.0, axis=(0, 1)) | np.any(Zf.reshape(-1, m) != 0.0, axis=0)
+        idx = np.flatnonzero(keep)
+        if idx.size > _lib.MAX_N:
+            raise _lib.DsgeTooLargeError(f"kalman_logp_batched: {idx.size} state and observed variables, the filter kernels "
+                                         f"take at most {_lib.MAX_N}")
+        T = np.ascontiguousarray(T[:, idx][:, :, idx])
+        R = np.ascontiguousarray(R[:, idx])
+        Z = np.ascontiguousarray(Zf[..., idx])
+        m = idx.size
+        n_state_hint = None
     k = R.shape[2]
     T_len, p = y.shape
     Q, code = _resolve_q(Q, q_mode, nb, k)

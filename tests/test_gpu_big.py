@@ -160,3 +160,26 @@ def test_big_host_chunks_and_reference_default_gating():
     ref = oracle.solve_kalman_logp(b["A"][0], b["B"][0], b["C"][0], b["D"][0], np.diag(b["sigma"][0] ** 2), om["Z"], om["y"],
                                    H=np.diag(om["Hdiag"]), tol=1e-12, max_iter=2, add_solver_success_check=False)
     assert abs(ungated["logp"][0] - ref["logp"]) <= 1e-9 * abs(ref["logp"])
+
+
+def test_big_standalone_filter_on_the_restricted_model():
+    """`kalman_logp_batched` with more than 64 variables: the numpy front end restricts (T, R, Z) to the state and observed
+    variables (exact-zero columns of T only) and the device filters that model: same logp as the oracle's full-size filter."""
+    n = 80
+    sh = SHAPES[n]
+    nb = 4
+    b = wl.sw_shaped_batch(nb, n=n, p=7, T_len=50, **sh)
+    om = wl.sw_shaped_observation_model(observed=(1, 5, 40, 50, 60, 70, 79), n=n, p=7, T_len=50, **sh)
+    T, status, _ = batched.cycle_reduction_batched(b["A"], b["B"], b["C"], max_iter=1000, tol=1e-10)
+    assert np.all(status == 0)
+    assert np.count_nonzero(np.any(T != 0.0, axis=(0, 1))) == sh["n_state"]  # the solver writes exact zeros in the other columns
+    R = batched.selection_batched(b["B"], b["C"], b["D"], T)
+    q = b["sigma"] ** 2
+    logp, st = batched.kalman_logp_batched(T, R, q, om["Z"], om["y"], Hdiag=om["Hdiag"])
+    assert np.all(st == 0)
+    for i in range(nb):
+        ref = oracle.kalman_filter_logp(om["y"], T[i], R[i], np.diag(q[i]), om["Z"], H=np.diag(om["Hdiag"]))
+        assert abs(logp[i] - ref) <= 1e-9 * abs(ref)
+    noisy = T + 1e-18
+    with pytest.raises(_lib.DsgeTooLargeError):
+        batched.kalman_logp_batched(noisy, R, q, om["Z"], om["y"], Hdiag=om["Hdiag"])
