@@ -220,7 +220,7 @@ struct Options {
   int gensys_pairs = 1;        // window path: two draws per wavefront in the real double-shift sweeps (dsge_gensys_pair.hpp)
   int gensys_shape_cache = 1;  // window path: capacity record measured once per model size
   int gensys_direct_blocks = 1;  // window path: isolated 2 x 2 blocks triangularised in closed form in front of the complex iteration
-  int kalman_narrow = 1;       // fast filter: the SK = 20 instances of the 24- and 32-wide tiles when the state block fits
+  int kalman_narrow = 1;       // fast filter: the SK = 20 instance of the 32-wide tile when the state block fits
 };
 extern Options g_defaults;
 extern thread_local const Options* t_call_options;

@@ -180,7 +180,10 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                                      rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
               }
             };
-            constexpr int SK_NARROW = (BS == 3 || BS == 4) ? 20 : 8 * BS;  // (not an `if constexpr`: this is no template)
+            // (the 32-wide tile only: on the 24-wide one the 20-column instance measured 1.4 % SLOWER on the headline step --
+            //  1.588 against 1.566 ms per 4096 draws --, its rows are only four columns shorter.  Not an `if constexpr`: this
+            //  is no template)
+            constexpr int SK_NARROW = (BS == 4) ? 20 : 8 * BS;
             // (with R folded in, the kernel stages the m x k selection matrix in its W' buffer, which is narrower too)
             const bool stage_fits = !fold || (size_t)m * ((k_shocks + 1) & ~1) <= (size_t)(8 * BS) * (SK_NARROW + 2);
             if (SK_NARROW < 8 * BS && s_cap <= SK_NARROW && opt().kalman_narrow && stage_fits)

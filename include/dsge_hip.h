@@ -181,7 +181,7 @@ typedef struct dsge_options {
                                  measured on the first call of a model size and reused -- later calls are pure enqueues; a
                                  draw that exceeds it is flagged DSGE_ST_GENSYS_TOO_BIG and the record grows for the next
                                  call; 0: measured in every call (one small launch + a stream synchronisation) */
-  int32_t kalman_narrow;      /* 1 (default): fast filter, 24- and 32-wide tiles: the instance whose LDS rows hold 20 state
+  int32_t kalman_narrow;      /* 1 (default): fast filter, 32-wide tile: the instance whose LDS rows hold 20 state
                                  columns instead of the tile width when the model has at most 20 state variables (the 32-wide
                                  tile then takes exactly 20 KB: eight draws per CU); same arithmetic, bit-identical results;
                                  0: generic instance */
