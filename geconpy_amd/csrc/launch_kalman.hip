@@ -167,14 +167,14 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               if (g_kalman_dbg) {  // tools/kalman_phases.py: the instance with the phase stamps
                 rc = set_lds(dsge::kalman_nt_kernel<BS, true, SKV>, lds_q);
                 if (rc == DSGE_SUCCESS)
-                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true, SKV>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q,
+                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true, SKV>), dim3(batch), dim3(64), lds_q,
                                      st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
                                      p, T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
                                      rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
               } else {
                 rc = set_lds(dsge::kalman_nt_kernel<BS, false, SKV>, lds_q);
                 if (rc == DSGE_SUCCESS)
-                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds_q,
+                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(batch), dim3(64), lds_q,
                                      st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
                                      p, T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
                                      rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
