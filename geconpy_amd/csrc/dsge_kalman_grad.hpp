@@ -136,7 +136,9 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
   const double LN2PI = 1.8378770664093453;
 
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug (draw 0): setup+P0, fwd full, fwd steady, rev full, rev steady, tail, #full, #steady
-  for (int bi = blockIdx.x; bi < batch; bi += gridDim.x) {
+  // (one draw per workgroup, grid = batch: no grid-stride loop for the compiler to hoist loop invariants out of and spill
+  //  them around the time loops -- see kalman_nt_kernel)
+  for (int bi = blockIdx.x; bi < batch; bi = batch) {
     const int draw = order ? order[bi] : bi;  // likely slow draws first (kalman_order_kernel), see kalman_sel_kernel
     const bool tm = dbg && draw == 0;
     long long tk0 = tm ? clock64() : 0;
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 2 * NP);
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  for (int draw = blockIdx.x; draw < batch; draw = batch) {  // (one draw per workgroup, grid = batch)
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
     if (status && status[draw] != 0) {  // failed draw: zero cotangents
       double z[BS][BS];

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
   double* Tk = W + NP * LDW;    // C at first, then the Gauss-Jordan scratch, then T^(2^k)
   double* Ts = W + 2 * NP;      // T (row stride LDW): before W is filled, and again for the final products
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  for (int draw = blockIdx.x; draw < batch; draw = batch) {  // (one draw per workgroup, grid = batch: see kalman_nt_kernel)
     const size_t off = (size_t)draw * n * n;
     double Sb[BS][BS];
     bool ok = true, flag = false;
