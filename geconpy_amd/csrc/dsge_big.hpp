@@ -428,7 +428,9 @@ __global__ __launch_bounds__(Cfg::NT) void cr_big_kernel(const double* __restric
     X0g[idx] = 0.0;
     X2g[idx] = 0.0;
   }
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  // (one draw per workgroup -- the launcher cuts the batch into launches of at most BIG_GRID_MAX draws --: no grid-stride loop
+  //  for the compiler to hoist loop invariants out of and spill them; see kalman_nt_kernel)
+  for (int draw = blockIdx.x; draw < batch; draw = batch) {
     const size_t off = (size_t)draw * n * n;
     __syncthreads();
     for (int idx = threadIdx.x; idx < MAT; idx += NT) {

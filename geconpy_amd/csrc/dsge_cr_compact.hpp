@@ -209,7 +209,7 @@ __device__ __forceinline__ void cr_compact_body(const double* __restrict__ A, co
   int* rsrc = posL + NP;   // compact row r of X sits in row rsrc[r] of W after the elimination
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
 
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+  for (int draw = blockIdx.x; draw < batch; draw = batch) {  // (one draw per workgroup, grid = batch: see kalman_nt_kernel)
     const size_t off = (size_t)draw * n * n;
     wave_sync();
     for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;

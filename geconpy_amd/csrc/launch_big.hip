@@ -10,8 +10,8 @@ long long* g_big_dbg = nullptr;  // debug: device int64[8], phase cycles of work
 namespace {
 StreamArenaPool g_big_pool;
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-// one workgroup per CU is resident (150 KB of LDS at NP = 96); two grid-strides per CU keep the tail short
-constexpr int BIG_GRID_MAX = 512;
+// draws (one workgroup and one 300-440 KB workspace each) per launch of the solver
+constexpr int BIG_GRID_MAX = 2048;
 // Threads per draw: the elimination is a chain of short dependent phases separated by barriers, so a step's duration is set by
 // instruction latency, not by arithmetic -- more wavefronts per SIMD hide it better.  Measured cycles per pivot step at
 // n = 80 / 96 (tools/big_phases.py): 256 threads 4.5 k / 5.3 k; 640 / 512 threads (below) see DESIGN.md.
@@ -28,12 +28,18 @@ int launch_cr_big(const double* A, const double* B, const double* C, int batch, 
   const int grid = batch < BIG_GRID_MAX ? batch : BIG_GRID_MAX;
   int rc;
   void* base = nullptr;
-#define BIG_CR(CFG)                                                                                                          \
-  do {                                                                                                                       \
-    if ((rc = g_big_pool.reserve(al256((size_t)grid * CFG::ws_doubles * 8), st, &base))) return rc;                          \
-    if ((rc = set_lds(dsge::cr_big_kernel<CFG>, CFG::lds_bytes))) return rc;                                                 \
-    hipLaunchKernelGGL(dsge::cr_big_kernel<CFG>, dim3(grid), dim3(CFG::NT), CFG::lds_bytes, st, A, B, C, batch, n, max_iter, \
-                       tol, (double*)base, T_out, status, n_iter, scan_mode, D, k, R_out, g_big_dbg);                                   \
+  // one workgroup per draw, at most BIG_GRID_MAX draws (= workspaces) per launch
+#define BIG_CR(CFG)                                                                                                            \
+  do {                                                                                                                         \
+    if ((rc = g_big_pool.reserve(al256((size_t)grid * CFG::ws_doubles * 8), st, &base))) return rc;                            \
+    if ((rc = set_lds(dsge::cr_big_kernel<CFG>, CFG::lds_bytes))) return rc;                                                   \
+    for (int c0 = 0; c0 < batch; c0 += grid) {                                                                                 \
+      const int nb = batch - c0 < grid ? batch - c0 : grid;                                                                    \
+      const size_t o2 = (size_t)c0 * n * n, ok = (size_t)c0 * n * k;                                                           \
+      hipLaunchKernelGGL(dsge::cr_big_kernel<CFG>, dim3(nb), dim3(CFG::NT), CFG::lds_bytes, st, A + o2, B + o2, C + o2, nb, n,  \
+                         max_iter, tol, (double*)base, T_out + o2, status + c0, n_iter ? n_iter + c0 : nullptr, scan_mode,     \
+                         D ? D + ok : nullptr, k, R_out ? R_out + ok : nullptr, c0 == 0 ? g_big_dbg : nullptr);                \
+    }                                                                                                                          \
   } while (0)
   if (n <= 80)
     BIG_CR(Cfg80);
