@@ -68,15 +68,22 @@ template <int BS, typename IT>
 __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[BS][BS], double (&Rb)[BS][BS], double* W,
                                             double* Lbuf, double* Ybuf, int* prow, const IT* cmap, IT* rsrc,
                                             const int (&vS)[BS], const int (&vL)[BS], int n, int s, int l, int max_iter,
-                                            double tol, int scan_mode, int lane, long long* ph, int& it, bool& converged,
+                                            double tol, int scan_mode, int lane_in, long long* ph, int& it, bool& converged,
                                             bool& saw_nan) {
   constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
   double* G1 = W + NP;
-  const int lr = lane >> 3, lc = lane & 7, wr = s + l;
+  const int wr = s + l;
   converged = false;
   saw_nan = false;
   it = 0;
   for (; it < max_iter;) {
+    // The lane index is re-derived from an opaque copy in every iteration: everything computed from it (LDS addresses of the
+    // register blocks, of the scatter, ...) is loop-invariant, gets hoisted in front of the loop by the compiler and -- with
+    // 256 registers taken by the blocks -- spilled there and re-loaded from scratch inside (60 dwords per iteration in
+    // cr_fused_kernel_occ2<5, 4>); a few integer instructions per iteration are cheaper than that.
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int lr = lane >> 3, lc = lane & 7;
     // W = [A1 | R] -> [. | A1^-1 R] (rows in pivot order)
     blk_store_lds<BS>(A1, W, LDW, lr, lc);
     if (scan_mode && lr == lc) {  // stabilize(A1): 1e-16 on the diagonal of the solve only (shared.py:6-9)
