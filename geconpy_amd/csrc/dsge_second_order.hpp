@@ -1113,7 +1113,12 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = stamp ? clock64() : 0;
   double y_next = (tid < p && a.T_len > 0) ? a.y[tid] : 0.0;  // (this thread's entry of the next observation row)
+  const int tid_kernel = tid;
   for (int t = 0; t < a.T_len; ++t) {
+    // (thread index re-derived from an opaque copy per step: what is computed from it would otherwise be hoisted in front of the
+    //  time loop and spilled there -- see crc_iterate / kalman_nt_kernel)
+    int tid = tid_kernel;
+    asm volatile("" : "+v"(tid));
     long long tk = stamp ? clock64() : 0;
     // ---- missing-data mask of this step (bit o set = observed); the observation row was requested one step ahead --------------
     const double y_now = y_next;

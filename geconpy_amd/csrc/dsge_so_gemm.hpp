@@ -59,7 +59,9 @@ __device__ __forceinline__ void so_gemm_half(const double* __restrict__ Aop, int
   constexpr int MP = Cfg::MP, LDSROW = Cfg::LDSROW, KC = Cfg::KC, RB = Cfg::RB, STAGE = Cfg::STAGE, PIECES = Cfg::PIECES,
                 T0 = HALF ? Cfg::NT0 : 0, NT = HALF ? RB * RB - Cfg::NT0 : Cfg::NT0;
   constexpr int I0 = T0 / RB, I1 = (T0 + NT - 1) / RB;  // block rows this half touches
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (opaque: the fragment addresses are re-derived per product, not hoisted out of the caller's loops)
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   so_v4f64 acc[NT > 0 ? NT : 1];  // (NT = 0: a one-tile block's second wavefront only helps with the staging)
 #pragma unroll
