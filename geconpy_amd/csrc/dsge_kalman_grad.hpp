@@ -419,7 +419,14 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     int seg_src = -1;
     double seg_logdet = 0.0;
     double yt_next = (lane < p && T_len > 0) ? y[lane] : 0.0;
+    const int lane_kernel = lane;
     for (int t = 0; t < T_len; ++t) {
+      // (lane index re-derived from an opaque copy per step: the addresses computed from it are recomputed, not hoisted in front of
+      //  the time loop and kept -- or spilled -- across it; see kalman_nt_kernel / crc_iterate)
+      int lane = lane_kernel;
+      asm volatile("" : "+v"(lane));
+      const int lr = lane >> 3, lc = lane & 7, fo = lane >> 3, fq = lane & 7;
+      (void)lr; (void)lc; (void)fo; (void)fq;
       double* sg = st + (size_t)t * STEP;
       const double yt = yt_next;
       yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
@@ -601,6 +608,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (lane < p) yr_next = y[(size_t)(T_len - 1) * p + lane];
     }
     for (int t = T_len - 1; t >= 0; --t) {
+      int lane = lane_kernel;
+      asm volatile("" : "+v"(lane));
+      const int lr = lane >> 3, lc = lane & 7, fo = lane >> 3, fq = lane & 7;
+      (void)lr; (void)lc; (void)fo; (void)fq;
       int src_t = (int)src_next;
       double a_cur = av_next;
       if (lane < NP) av[lane] = a_cur;
