@@ -67,7 +67,7 @@ __device__ __forceinline__ unsigned long long blk_colmask(const double (&x)[BS][
 template <int BS, typename IT>
 __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[BS][BS], double (&Rb)[BS][BS], double* W,
                                             double* Lbuf, double* Ybuf, int* prow, const IT* cmap, IT* rsrc,
-                                            const int (&vS)[BS], const int (&vL)[BS], int n, int s, int l, int max_iter,
+                                            const IT* posS, const IT* posL, int n, int s, int l, int max_iter,
                                             double tol, int scan_mode, int lane_in, long long* ph, int& it, bool& converged,
                                             bool& saw_nan) {
   constexpr int NP = CrcSmem<BS>::NP, LDW = CrcSmem<BS>::LDW;
@@ -163,6 +163,14 @@ __device__ __forceinline__ void crc_iterate(double (&A1)[BS][BS], double (&Ah)[B
     blk_store_lds<BS>(acc2, G1, LDW, lr, lc);
     wave_sync();
     double t0[BS][BS], t2[BS][BS];
+    // compact positions of my variable columns: read from the LDS tables where they are used (kept in registers across the
+    // iteration they were spilled: 20 scratch re-loads per iteration in cr_fused_kernel_occ2<5, 4>)
+    int vS[BS], vL[BS];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) {
+      vS[j] = posS[lc * BS + j];
+      vL[j] = posL[lc * BS + j];
+    }
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -275,7 +283,7 @@ __device__ __forceinline__ void cr_compact_body(const double* __restrict__ A, co
     // [4] scatter/update/norms, [5] final solve, [6] total
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = dbg ? clock64() : 0;
-    crc_iterate<BS>(A1, Ah, Rb, W, Lbuf, Ybuf, prow, cmap, rsrc, vS, vL, n, s, l, max_iter, tol, scan_mode, lane,
+    crc_iterate<BS>(A1, Ah, Rb, W, Lbuf, Ybuf, prow, cmap, rsrc, posS, posL, n, s, l, max_iter, tol, scan_mode, lane,
                     dbg ? ph : nullptr, it, converged, saw_nan);
     const long long tk_fin = dbg ? clock64() : 0;
 

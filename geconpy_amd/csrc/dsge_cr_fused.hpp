@@ -194,7 +194,7 @@ __device__ __forceinline__ void cr_fused_body(const double* __restrict__ A, cons
   wave_sync();
   bool converged, saw_nan;
   int it;
-  crc_iterate<BSD>(A1, Ah, Rb, W, Lbuf, Ybuf, prow, cmap, rsrc, vS, vL, nd, s, l, max_iter, tol, 0, lane, nullptr, it,
+  crc_iterate<BSD>(A1, Ah, Rb, W, Lbuf, Ybuf, prow, cmap, rsrc, posS, posL, nd, s, l, max_iter, tol, 0, lane, nullptr, it,
                    converged, saw_nan);
   if (lane == 0) {
     status[draw] = converged ? DSGE_ST_OK : (DSGE_ST_NOT_CONVERGED | (saw_nan ? DSGE_ST_NAN : 0));
