@@ -141,7 +141,10 @@ __device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, co
 // DBG = true: the instance tools/kalman_phases.py launches (phase stamps of draw 0 in `dbg`); the product instance carries
 // neither the stamps nor their registers.
 template <int BS, bool DBG = false, int SK = 8 * BS>
-__global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2 : 1))) void kalman_nt_kernel(
+// (two wavefronts per SIMD up to the 24-wide tile, and on the 32-wide one for its 20-column instance -- 20 KB of LDS, eight draws
+//  per CU; with the 256-register cap it spills 332 bytes per lane, and is still faster: observe_jumps 1.96 -> 2.04 M evals/s.  The
+//  generic 32-wide instance (28 KB of LDS) measured SLOWER with the cap: 1.92 against 1.77 ms per 4096 draws at 25 states.)
+__global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS || (BS == 4 && SK <= 20)) ? 2 : 1))) void kalman_nt_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
