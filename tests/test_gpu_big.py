@@ -183,3 +183,34 @@ def test_big_standalone_filter_on_the_restricted_model():
     noisy = T + 1e-18
     with pytest.raises(_lib.DsgeTooLargeError):
         batched.kalman_logp_batched(noisy, R, q, om["Z"], om["y"], Hdiag=om["Hdiag"])
+
+
+def test_big_device_entry_chunks_and_stage_timing():
+    """The device-pointer entry with `pipeline_chunks` (chunks alternating over library-owned streams, each with its own slice
+    of the scratch arena and its own workspace) and the stage-timing entry (`LogpEngine.profile_kernels`) on a 72-variable
+    model: same logp to the bit as the plain call."""
+    import torch
+
+    from geconpy_amd.engine import LogpEngine
+
+    n = 72
+    sh = SHAPES[n]
+    nd = 48
+    b = wl.sw_shaped_batch(nd, n=n, p=7, T_len=30, **sh)
+    om = wl.sw_shaped_observation_model(n=n, p=7, T_len=30, **sh)
+    rep = 25  # 1200 draws
+    eng = LogpEngine(0)
+    A, B, C, D = (eng.to_device(np.tile(b[x], (rep, 1, 1))) for x in "ABCD")
+    q = eng.to_device(np.tile(b["sigma"] ** 2, (rep, 1)))
+    Z, y, H = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
+    lp0, st0 = eng.solve_kalman_logp(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, z_selector_hint=1)
+    lp1, st1 = eng.solve_kalman_logp(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, z_selector_hint=1,
+                                     options={"pipeline_chunks": 2})
+    torch.cuda.synchronize()
+    assert int((st0 != 0).sum()) == 0 and int((st1 != 0).sum()) == 0
+    assert torch.equal(lp0, lp1)
+    ref = batched.solve_kalman_logp_batched(b["A"][:4], b["B"][:4], b["C"][:4], b["D"][:4], b["sigma"][:4] ** 2, om["Z"], om["y"],
+                                            Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+    assert np.array_equal(lp0[:4].cpu().numpy(), ref["logp"])
+    ms = eng.profile_kernels(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, reps=1, z_selector_hint=1)
+    assert ms["solver"] > 0.0 and ms["kalman"] > 0.0
