@@ -214,3 +214,21 @@ def test_big_device_entry_chunks_and_stage_timing():
     assert np.array_equal(lp0[:4].cpu().numpy(), ref["logp"])
     ms = eng.profile_kernels(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, reps=1, z_selector_hint=1)
     assert ms["solver"] > 0.0 and ms["kalman"] > 0.0
+
+
+def test_big_numpy_entry_points_with_the_reference_names():
+    """`solve_policy_function_with_cycle_reduction` (cycle_reduction.py:328-398) and the batched solvability driver on an
+    80-variable system: the reference's return shapes and message, T and R against the oracle."""
+    from geconpy_amd import solvers
+
+    n = 80
+    A, B, C, D, _ = _systems(n, 3, seed0=7300)
+    T, R, msg, _log_norm = solvers.solve_policy_function_with_cycle_reduction(A[0], B[0], C[0], D[0], max_iter=1000, tol=1e-9,
+                                                                             verbose=False)
+    Tc, Rc, msg_c, _ = oracle.solve_policy_function_with_cycle_reduction(A[0], B[0], C[0], D[0], max_iter=1000, tol=1e-9)
+    assert msg == msg_c == solvers.MSG_OK
+    assert_allclose(T, Tc, atol=1e-9 * max(1.0, np.abs(Tc).max()))
+    assert_allclose(R, Rc, atol=1e-8 * max(1.0, np.abs(Rc).max()))
+    out = solvers.solve_policy_functions_batched(A, B, C, D, solver="cycle_reduction", max_iter=1000, tol=1e-9)
+    assert out["success"].all() and np.all(out["resid"] < 1e-14)
+    assert_allclose(out["T"][0], Tc, atol=1e-9 * max(1.0, np.abs(Tc).max()))
