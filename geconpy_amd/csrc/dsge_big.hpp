@@ -32,9 +32,9 @@ namespace dsge {
 
 typedef double big_v4f64 __attribute__((ext_vector_type(4)));
 
-template <int NP_, int TR_, int TC_>
+template <int NP_, int TR_, int TC_, int NBLK_ = 1>
 struct BigCfg {
-  static constexpr int NP = NP_, TR = TR_, TC = TC_;
+  static constexpr int NP = NP_, TR = TR_, TC = TC_, PB = NBLK_ * TC_;  // PB: pivots per elimination round
   static constexpr int GY = NP / TR, GX = NP / TC, NT = GY * GX, NW = NT / 64;
   static constexpr int LD = NP + 2, MT = NP / 16;
   static_assert(NP % 16 == 0 && NP % TR == 0 && NP % TC == 0 && NT % 64 == 0 && NT <= 1024 && NP <= 128, "tile grid");
@@ -52,8 +52,8 @@ struct BigCfg {
   // elimination: pivcol int[NP] and the round's pivot rows int[TC] in the tail; panel [NP][TC], coefficients [NP][TC] and the
   // round's pivot rows [TC][3 NP] alias the RIGHT panel (free during an elimination; the left one already holds -A0)
   static constexpr int E_PIV = OFF_EL, E_PS = OFF_EL + NP / 2 + 2;
-  static constexpr int E_PANEL = OFF_R, E_CV = OFF_R + NP * TC, E_ROW = OFF_R + 2 * NP * TC;
-  static_assert(5 * NP * TC <= NP * LD && TC <= 8, "elimination buffers fit the right panel");
+  static constexpr int E_PANEL = OFF_R, E_CV = OFF_R + NP * PB, E_ROW = OFF_R + 2 * NP * PB;
+  static_assert(5 * NP * PB <= NP * LD && PB <= 8 && NP % PB == 0, "elimination buffers fit the right panel");
 };
 
 // ---- register blocks <-> the workgroup's padded NP x NP workspace matrices ---------------------------------------------------------
@@ -132,23 +132,25 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
       pt = t_b;                        \
     }                                  \
   } while (0)
-  double* panel = lds + Cfg::E_PANEL;  // [NP][TC]
-  double* cvb = lds + Cfg::E_CV;       // [NP][TC]
-  double* rowb = lds + Cfg::E_ROW;     // [TC][3 NP]
+  constexpr int PB = Cfg::PB;          // pivots per round: NBLK block columns
+  double* panel = lds + Cfg::E_PANEL;  // [NP][PB]
+  double* cvb = lds + Cfg::E_CV;       // [NP][PB]
+  double* rowb = lds + Cfg::E_ROW;     // [PB][3 NP]
   int* pivcol = reinterpret_cast<int*>(lds + Cfg::E_PIV);
-  int* psb = reinterpret_cast<int*>(lds + Cfg::E_PS);  // [TC] pivot rows of the round
+  int* psb = reinterpret_cast<int*>(lds + Cfg::E_PS);  // [PB] pivot rows of the round
   const int lane = tid & 63;
   const bool w0 = tid < 64;
   bool used_a = false, used_b = false;  // wavefront 0: rows lane, lane + 64 have been pivot rows
   __syncthreads();                      // (the right panel, which these buffers alias, is no longer read)
-  for (int j0 = 0; j0 < n; j0 += TC) {
-    const int bs = (n - j0) < TC ? (n - j0) : TC;
+  for (int j0 = 0; j0 < n; j0 += PB) {
+    const int bs = (n - j0) < PB ? (n - j0) : PB;
     // 1. the panel
-    if (c0 == j0) {
+    if (c0 >= j0 && c0 < j0 + PB) {
+      const int pc = c0 - j0;
 #pragma unroll
       for (int i = 0; i < TR; ++i)
 #pragma unroll
-        for (int jc = 0; jc < TC; ++jc) panel[(r0 + i) * TC + jc] = t1[i][jc];
+        for (int jc = 0; jc < TC; ++jc) panel[(r0 + i) * PB + pc + jc] = t1[i][jc];
     }
     EL_STAMP(0);
     __syncthreads();
@@ -156,16 +158,16 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
     // 2. wavefront 0 eliminates the panel
     if (w0) {
       const int ra = lane, rb = lane + 64;
-      double xa[TC], xb[TC], ca[TC], cb[TC];
+      double xa[PB], xb[PB], ca[PB], cb[PB];
 #pragma unroll
-      for (int c = 0; c < TC; ++c) {
-        xa[c] = panel[ra * TC + c];  // (n > 64: every lane has a first row)
-        xb[c] = (rb < n) ? panel[rb * TC + c] : 0.0;
+      for (int c = 0; c < PB; ++c) {
+        xa[c] = panel[ra * PB + c];  // (n > 64: every lane has a first row)
+        xb[c] = (rb < n) ? panel[rb * PB + c] : 0.0;
         ca[c] = 0.0;
         cb[c] = 0.0;
       }
 #pragma unroll
-      for (int sidx = 0; sidx < TC; ++sidx) {
+      for (int sidx = 0; sidx < PB; ++sidx) {
         if (sidx < bs) {
           const unsigned long long ka =
               used_a ? 0ull : (((unsigned long long)__double_as_longlong(fabs(xa[sidx])) & ~127ull) | (unsigned long long)(127 - ra));
@@ -177,23 +179,23 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
           const int p = 127 - (int)(km & 127ull);
           const int pl = p & 63;
           const bool hislot = p >= 64;
-          double xr[TC], cr[TC];
+          double xr[PB], cr[PB];
 #pragma unroll
-          for (int c = 0; c < TC; ++c) {
+          for (int c = 0; c < PB; ++c) {
             xr[c] = big_readlane_f64(hislot ? xb[c] : xa[c], pl);
             cr[c] = big_readlane_f64(hislot ? cb[c] : ca[c], pl);
           }
           const double dinv = 1.0 / xr[sidx];
           cr[sidx] += 1.0;
 #pragma unroll
-          for (int c = 0; c < TC; ++c) {
+          for (int c = 0; c < PB; ++c) {
             xr[c] *= dinv;
             cr[c] *= dinv;
           }
           const bool is_a = (ra == p), is_b = (rb == p);
           const double fa = xa[sidx], fb = xb[sidx];
 #pragma unroll
-          for (int c = 0; c < TC; ++c) {
+          for (int c = 0; c < PB; ++c) {
             xa[c] = is_a ? xr[c] : fma(-fa, xr[c], xa[c]);
             ca[c] = is_a ? cr[c] : fma(-fa, cr[c], ca[c]);
             xb[c] = is_b ? xr[c] : fma(-fb, xr[c], xb[c]);
@@ -208,24 +210,24 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
         }
       }
 #pragma unroll
-      for (int c = 0; c < TC; ++c) {
-        cvb[ra * TC + c] = ca[c];
-        if (rb < n) cvb[rb * TC + c] = cb[c];
+      for (int c = 0; c < PB; ++c) {
+        cvb[ra * PB + c] = ca[c];
+        if (rb < n) cvb[rb * PB + c] = cb[c];
       }
     }
     EL_STAMP(2);
     __syncthreads();
     EL_STAMP(3);
     // 3. the round's pivot rows (old values)
-    int ps[TC];
+    int ps[PB];
 #pragma unroll
-    for (int t = 0; t < TC; ++t) ps[t] = (t < bs) ? psb[t] : -1;
+    for (int t = 0; t < PB; ++t) ps[t] = (t < bs) ? psb[t] : -1;
     unsigned keep = 0u;  // bit i: row r0 + i is not one of the round's pivot rows (delta = 1)
 #pragma unroll
     for (int i = 0; i < TR; ++i) {
       bool piv = false;
 #pragma unroll
-      for (int t = 0; t < TC; ++t)
+      for (int t = 0; t < PB; ++t)
         if (r0 + i == ps[t]) {
           piv = true;
 #pragma unroll
@@ -239,15 +241,15 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
     }
     __syncthreads();
     // 4. rank-bs update, one matrix after the other (the pivot rows of one matrix in registers at a time)
-    double cv[TR][TC];
+    double cv[TR][PB];
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int t = 0; t < TC; ++t) cv[i][t] = (r0 + i < n && t < bs) ? cvb[(r0 + i) * TC + t] : 0.0;
+      for (int t = 0; t < PB; ++t) cv[i][t] = (r0 + i < n && t < bs) ? cvb[(r0 + i) * PB + t] : 0.0;
     auto update = [&](double (&tm)[TR][TC], int mofs) {
-      double q[TC][TC];
+      double q[PB][TC];
 #pragma unroll
-      for (int t = 0; t < TC; ++t)
+      for (int t = 0; t < PB; ++t)
 #pragma unroll
         for (int jc = 0; jc < TC; ++jc) q[t][jc] = (t < bs) ? rowb[t * 3 * NP + mofs + c0 + jc] : 0.0;  // (short last round: not published)
 #pragma unroll
@@ -257,7 +259,7 @@ __device__ __forceinline__ void big_eliminate(double (&t1)[Cfg::TR][Cfg::TC], do
         for (int jc = 0; jc < TC; ++jc) {
           double acc = kp ? tm[i][jc] : 0.0;
 #pragma unroll
-          for (int t = 0; t < TC; ++t) acc = fma(cv[i][t], q[t][jc], acc);
+          for (int t = 0; t < PB; ++t) acc = fma(cv[i][t], q[t][jc], acc);
           tm[i][jc] = acc;
         }
       }

@@ -15,7 +15,8 @@ constexpr int BIG_GRID_MAX = 2048;
 // Threads per draw: the elimination is a chain of short dependent phases separated by barriers, so a step's duration is set by
 // instruction latency, not by arithmetic -- more wavefronts per SIMD hide it better.  Measured cycles per pivot step at
 // n = 80 / 96 (tools/big_phases.py): 256 threads 4.5 k / 5.3 k; 640 / 512 threads (below) see DESIGN.md.
-using Cfg80 = dsge::BigCfg<80, 5, 2>;
+using Cfg80 = dsge::BigCfg<80, 5, 2>;  // (two block columns = four pivots per round, BigCfg<80, 5, 2, 2>: 272 bytes of scratch at the
+                                        //  168-register cap of ten wavefronts, 260 k instead of 241 k cycles per elimination)
 using Cfg96 = dsge::BigCfg<96, 6, 3>;
 }  // namespace
 
