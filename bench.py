@@ -799,7 +799,7 @@ def main():
                 "inputs": (f"theta resident in HBM ({d_theta.shape[1]} parameters = {8 * d_theta.shape[1]} B per draw); A,B,C,D are produced "
                            f"by the generated Jacobian kernel inside every timed step") if args.from_theta else "A,B,C,D resident in HBM",
                 "tol": args.tol,
-                "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
+                "kalman_steady_tol": __import__('geconpy_amd._lib', fromlist=['make_options']).make_options().kalman_steady_tol,
                 "cr_static_deflation": (f"{h_defl} static variables (zero columns of A and C) eliminated by a QR of their columns of B before the "
                                         f"iteration, which runs on {n - h_defl} variables; verified per draw on the device") if h_defl else "none",
                 "kalman_dispatch": ("workgroups in descending order of the draws' cycle-reduction iteration counts" if args.solver == "cycle_reduction"
@@ -968,7 +968,7 @@ def main_second_order(args, world, rank, local_rank):
                              f"T_len={T_len}, synthetic sparse model Hessian ({shard['hess_idx'].shape[0]} entries), pruned state "
                              f"2u + s(s+1)/2 = {m}; {per_gpu} draws per GPU"),
                 "global_batch": global_batch, "solver": "cycle_reduction", "tol": args.tol,
-                "kalman_steady_tol": eng.lib.dsge_get_kalman_steady_tol(),
+                "kalman_steady_tol": __import__('geconpy_amd._lib', fromlist=['make_options']).make_options().kalman_steady_tol,
                 "inputs": "A,B,C,D and the Hessian values resident in HBM",
                 "parity_note": "the reference has no second-order solver (perturbation.py:97-98 raises): checked against "
                                "oracle/second_order.py, parity unpinned by construction",

@@ -12,7 +12,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 ERR_INVALID, ERR_HIP, ERR_TOO_LARGE = 1, 2, 3
 MAX_N = 64
 MAX_N_CR = 64
@@ -78,23 +78,7 @@ PROTOTYPES = {
     "dsge_gensys_pencil_full_batched_host": [_dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_bk_eigenvalues_batched": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_bk_eigenvalues_batched_host": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp],
-    "dsge_set_cr_compact": [_i],
-    "dsge_set_cr_fused_selection": [_i],
     "dsge_debug_cr_phases": [_i, _dp],
-    "dsge_set_kalman_tiny": [_i],
-    "dsge_set_kalman_nt_products": [_i],
-    "dsge_set_cr_fused_deflation": [_i],
-    "dsge_set_cr_four_waves": [_i],
-    "dsge_set_cr_deflation": [_i],
-    "dsge_set_cr_two_waves": [_i],
-    "dsge_set_kalman_order": [_i],
-    "dsge_set_pipeline_chunks": [_i],
-    "dsge_set_kalman_block": [_i],
-    "dsge_set_gensys_split": [_i],
-    "dsge_set_gensys_real_stage": [_i],
-    "dsge_set_kalman_mfma": [_i],
-    "dsge_set_kalman_steady_tol": [_f],
-    "dsge_get_kalman_steady_tol": [],
     "dsge_debug_kalman_steady_steps": [_dp],
     "dsge_debug_kalman_phases": [_i, _dp],
     "dsge_debug_big_phases": [_i, _dp],
@@ -144,6 +128,7 @@ PROTOTYPES = {
     "dsge_options_init": [_dp],
     "dsge_options_push": [_dp],
     "dsge_options_pop": [],
+    "dsge_forget_measured_shapes": [],
     "dsge_solve_kalman_logp_batched_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_batched_host_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_solve_kalman_logp_grad_batched_opt": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i, _i, _i, _i, _i,
@@ -160,8 +145,8 @@ PROTOTYPES = {
 
 
 class Options(C.Structure):
-    """``dsge_options`` of include/dsge_hip.h: the kernel-variant switches of ONE call (per call / per host thread;
-    the ``dsge_set_*`` functions only edit the process-wide defaults this struct is initialised from)."""
+    """``dsge_options`` of include/dsge_hip.h: the kernel-variant switches and the filter conventions of ONE call (per call /
+    per host thread; there is no process-wide mutable state since ABI 8)."""
 
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -185,13 +170,32 @@ class Options(C.Structure):
         ("gensys_shape_cache", C.c_int32),
         ("kalman_narrow", C.c_int32),
         ("gensys_direct_blocks", C.c_int32),
+        # ABI 8: conventions of the filter step (third party: pymc_extras)
+        ("ll_constant", C.c_int32),
+        ("mask_d", C.c_int32),
+        ("joseph", C.c_int32),
+        ("reserved0_", C.c_int32),
+        ("jitter_F", C.c_double),
+        ("jitter_P", C.c_double),
         ("reserved_", C.c_int32 * 4),
     ]
 
 
+LL_CONSTANT = {"p": 0, "observed": 1, "one": 2}  # DSGE_LL_CONST_* (include/dsge_hip.h)
+
+
+def filter_conventions(ll_constant="p", jitter_on_F=True, jitter_on_P=True, mask_d=False, joseph=True):
+    """``dsge_options`` fields for one combination of the third-party conventions of the "standard" filter step, named as
+    ``oracle.FilterConventions`` names them (so that the combination tests/test_oracle_kalman.py::test_pymc_extras_pin reports
+    for a real pymc_extras install is pasted here verbatim): ``options=filter_conventions(ll_constant="one")``.  A jitter that
+    is "on" is the call's ``jitter`` argument (``jitter_F = -1``), "off" is 0."""
+    return {"ll_constant": LL_CONSTANT[ll_constant], "jitter_F": -1.0 if jitter_on_F else 0.0,
+            "jitter_P": -1.0 if jitter_on_P else 0.0, "mask_d": int(bool(mask_d)), "joseph": int(bool(joseph))}
+
+
 def make_options(options=None, **fields):
-    """A ``dsge_options`` holding the process-wide defaults with ``fields`` (or the dict ``options``) applied;
-    an ``Options`` instance is passed through."""
+    """A ``dsge_options`` holding the compiled-in defaults with ``fields`` (or the dict ``options``) applied;
+    an ``Options`` instance is passed through.  ``ll_constant`` also takes the names "p" / "observed" / "one"."""
     if isinstance(options, Options) and not fields:
         return options
     o = Options()
@@ -201,8 +205,10 @@ def make_options(options=None, **fields):
     elif options:
         fields = {**options, **fields}
     for name, value in fields.items():
-        if name not in {f[0] for f in Options._fields_} or name in ("struct_size", "reserved_"):
+        if name not in {f[0] for f in Options._fields_} or name in ("struct_size", "reserved_", "reserved0_"):
             raise ValueError(f"unknown option {name!r}")
+        if name == "ll_constant" and isinstance(value, str):
+            value = LL_CONSTANT[value]
         setattr(o, name, value)
     return o
 
@@ -259,7 +265,7 @@ def load():
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = {"dsge_last_error": C.c_char_p, "dsge_get_kalman_steady_tol": C.c_double}.get(name, C.c_int)
+        fn.restype = {"dsge_last_error": C.c_char_p}.get(name, C.c_int)
     if lib.dsge_abi_version() != ABI_VERSION:
         raise DsgeHipError("libdsge_hip ABI version mismatch")
     _lib = lib

@@ -396,17 +396,6 @@ def bk_eigenvalues_batched(A, B, C, tol=1e-8):
     return dict(real=re, imag=im, n_eig=ne, n_forward=nf, n_unstable=nu, satisfied=(st == 0) & (nf == nu), status=st)
 
 
-def set_kalman_steady_tol(tol):
-    """Steady-state switch of the fast Kalman kernel (include/dsge_hip.h): relative change of the
-    predicted covariance below which F^-1, K and det F are frozen.  0 = step-for-step recursion;
-    default 1e-14 (rounding level).  Process-wide."""
-    _lib.check(_lib.load().dsge_set_kalman_steady_tol(float(tol)))
-
-
-def get_kalman_steady_tol():
-    return float(_lib.load().dsge_get_kalman_steady_tol())
-
-
 def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None,
                         jitter=JITTER_DEFAULT, missing_fill_value=MISSING_FILL, n_state_hint=None,
                         z_selector_hint=None, options=None, filter_type="standard"):
@@ -423,7 +412,11 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
         # the host because T and R arrive as host arrays.  Exact zeros only: a T whose non-state columns carry rounding noise
         # keeps them, and the call fails loudly instead of dropping them.
         Zf = _f64(Z)
-        keep = np.any(T != 0.0, axis=(0, 1)) | np.any(Zf.reshape(-1, m) != 0.0, axis=0)
+        # (a draw that arrives with a non-zero status is skipped by the filter anyway, and a failed solve may have left NaN in
+        #  its T -- NaN compares non-zero --: neither may widen F for the whole batch)
+        live = np.ones(nb, dtype=bool) if status is None else (np.asarray(status).reshape(-1) == 0)
+        Tl = T[live]
+        keep = np.any(np.isfinite(Tl) & (Tl != 0.0), axis=(0, 1)) | np.any(Zf.reshape(-1, m) != 0.0, axis=0)
         idx = np.flatnonzero(keep)
         if idx.size > _lib.MAX_N:
             raise _lib.DsgeTooLargeError(f"kalman_logp_batched: {idx.size} state and observed variables, the filter kernels "
@@ -452,7 +445,7 @@ def kalman_logp_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=N
 
 
 def kalman_filter_outputs_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None, status=None, jitter=JITTER_DEFAULT,
-                                 missing_fill_value=MISSING_FILL, full_covariances=False):
+                                 missing_fill_value=MISSING_FILL, full_covariances=False, options=None):
     """Per-step filter outputs for a batch of draws -- what ``save_kalman_filter_outputs_in_idata=True`` stores
     (gEconpy/model/statespace.py:1145, 1151-1157): dict(ll (batch, T_len), predicted_states / filtered_states (batch, T_len, m),
     predicted_covs / filtered_covs: the diagonals (batch, T_len, m), or the matrices (batch, T_len, m, m) with
@@ -468,13 +461,14 @@ def kalman_filter_outputs_batched(T, R, Q, Z, y, d=None, Hdiag=None, q_mode=None
     cshape = (nb, T_len, m, m) if full_covariances else (nb, T_len, m)
     out = dict(ll=np.empty((nb, T_len)), predicted_states=np.empty((nb, T_len, m)), filtered_states=np.empty((nb, T_len, m)),
                predicted_covs=np.empty(cshape), filtered_covs=np.empty(cshape))
-    _lib.check(
-        _lib.load().dsge_kalman_filter_outputs_batched_host(
-            _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len, float(jitter),
-            float(missing_fill_value), _ptr(out["ll"]), _ptr(out["predicted_states"]), _ptr(out["filtered_states"]),
-            _ptr(out["predicted_covs"]), _ptr(out["filtered_covs"]), int(bool(full_covariances)), _ptr(st)
+    with _lib.options_scope(options):  # (the filter conventions: _lib.filter_conventions)
+        _lib.check(
+            _lib.load().dsge_kalman_filter_outputs_batched_host(
+                _ptr(T), _ptr(R), _ptr(Q), code, _ptr(Z), zb, _ptr(d), db, _ptr(Hdiag), hb, _ptr(y), nb, m, k, p, T_len, float(jitter),
+                float(missing_fill_value), _ptr(out["ll"]), _ptr(out["predicted_states"]), _ptr(out["filtered_states"]),
+                _ptr(out["predicted_covs"]), _ptr(out["filtered_covs"]), int(bool(full_covariances)), _ptr(st)
+            )
         )
-    )
     out["status"] = st
     return out
 

@@ -21,7 +21,7 @@ int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-Options g_defaults;                                   // process-wide defaults (dsge_set_*)
+const Options g_defaults{};                           // compiled-in defaults (never written)
 thread_local const Options* t_call_options = nullptr;  // options of the call running on this thread
 }  // namespace dsge_host
 
@@ -138,6 +138,11 @@ struct OptionsGuard {
     local.gensys_shape_cache = o->gensys_shape_cache;
     local.kalman_narrow = o->kalman_narrow;
     local.gensys_direct_blocks = o->gensys_direct_blocks;
+    local.ll_constant = o->ll_constant;
+    local.mask_d = o->mask_d;
+    local.joseph = o->joseph;
+    local.jitter_F = o->jitter_F;
+    local.jitter_P = o->jitter_P;
     t_call_options = &local;
   }
   ~OptionsGuard() { t_call_options = prev; }
@@ -152,6 +157,9 @@ int check_options(const dsge_options* o) {
   if (o->pipeline_chunks < 0 || o->pipeline_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline_chunks must be in 0..64");
   if (o->gensys_split < 0 || o->gensys_split > 2) return fail(DSGE_ERR_INVALID, "gensys_split must be 0, 1 or 2");
   if (o->n_static_hint < -1 || o->n_static_hint > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "n_static_hint out of range");
+  if (o->ll_constant < DSGE_LL_CONST_P || o->ll_constant > DSGE_LL_CONST_ONE)
+    return fail(DSGE_ERR_INVALID, "ll_constant must be DSGE_LL_CONST_P, _OBSERVED or _ONE");
+  if (o->jitter_F != o->jitter_F || o->jitter_P != o->jitter_P) return fail(DSGE_ERR_INVALID, "jitter_F / jitter_P must not be NaN");
   return DSGE_SUCCESS;
 }
 
@@ -347,73 +355,11 @@ int dsge_debug_adjoint_refine(int mode) {
   g_adj_refine_mode = mode;
   return DSGE_SUCCESS;
 }
-int dsge_set_cr_fused_selection(int enable) {
-  g_defaults.cr_fused_selection = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_cr_compact(int enable) {
-  g_defaults.cr_compact = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_kalman_mfma(int enable) {
-  g_defaults.kalman_mfma = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_gensys_real_stage(int enable) {
-  g_defaults.gensys_real_stage = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_gensys_split(int enable) {
-  g_defaults.gensys_split = (enable == 2) ? 2 : (enable ? 1 : 0);
-  return DSGE_SUCCESS;
-}
-int dsge_set_pipeline_chunks(int n_chunks) {
-  if (n_chunks < 0 || n_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline chunks must be in 0..64");
-  g_defaults.pipeline_chunks = n_chunks;
-  return DSGE_SUCCESS;
-}
-int dsge_set_cr_two_waves(int enable) {
-  g_defaults.cr_two_waves = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_cr_deflation(int enable) {
-  g_defaults.cr_deflation = enable ? 1 : 0;
+int dsge_forget_measured_shapes(void) {
   cr_deflation_reset();
+  gensys_shape_reset();
   return DSGE_SUCCESS;
 }
-int dsge_set_kalman_order(int mode) {
-  if (mode < 0 || mode > 2) return fail(DSGE_ERR_INVALID, "order mode must be 0, 1 or 2");
-  g_defaults.kalman_order = mode;
-  return DSGE_SUCCESS;
-}
-int dsge_set_kalman_block(int enable) {
-  g_defaults.kalman_block = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_cr_four_waves(int enable) {
-  g_defaults.cr_four_waves = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-
-int dsge_set_cr_fused_deflation(int enable) {
-  g_defaults.cr_fused_deflation = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-
-int dsge_set_kalman_nt_products(int enable) {
-  g_defaults.kalman_nt_products = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_kalman_tiny(int enable) {
-  g_defaults.kalman_tiny = enable ? 1 : 0;
-  return DSGE_SUCCESS;
-}
-int dsge_set_kalman_steady_tol(double tol) {
-  if (!(tol >= 0.0) || tol > 1e-6) return fail(DSGE_ERR_INVALID, "steady-state tolerance must be in [0, 1e-6]");
-  g_defaults.kalman_steady_tol = tol;
-  return DSGE_SUCCESS;
-}
-double dsge_get_kalman_steady_tol(void) { return g_defaults.kalman_steady_tol; }
 int dsge_debug_kalman_steady_steps(int32_t* steady_at_device) {
   g_kalman_steady_at = steady_at_device;
   return DSGE_SUCCESS;
@@ -2241,6 +2187,11 @@ int dsge_options_init(dsge_options* o) {
   o->gensys_shape_cache = d.gensys_shape_cache;
   o->kalman_narrow = d.kalman_narrow;
   o->gensys_direct_blocks = d.gensys_direct_blocks;
+  o->ll_constant = d.ll_constant;
+  o->mask_d = d.mask_d;
+  o->joseph = d.joseph;
+  o->jitter_F = d.jitter_F;
+  o->jitter_P = d.jitter_P;
   return DSGE_SUCCESS;
 }
 

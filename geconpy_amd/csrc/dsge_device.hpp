@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dsge_filter_conv.hpp"
+
 namespace dsge {
 
 template <int BS>

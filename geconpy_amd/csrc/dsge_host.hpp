@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/dsge_hip.h"
+#include "dsge_filter_conv.hpp"
 
 namespace dsge_host {
 
@@ -115,6 +116,7 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
                        hipStream_t st, int* used, unsigned long long* colmask = nullptr);
 // (*used = 2: the one-launch kernel ran and colmask[draw] holds the non-zero columns of T_out[draw], ~0 = not known)  // static-variable deflation + cycle reduction on the reduced system
 void cr_deflation_reset();
+void gensys_shape_reset();  // launch_gensys.hip
 int launch_bdirect(const double* A, const double* B, const double* D, int batch, int n, int k, double* T_out,
                    double* R_out, hipStream_t st);
 int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n, int k, const int32_t* status,
@@ -199,7 +201,7 @@ extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first ste
 // Kernel-variant switches.  They are PER CALL: the *_opt entry points carry a dsge_options, which an RAII guard installs
 // for the duration of the call on the calling thread (launching is synchronous on the host, every kernel argument is
 // passed by value at launch), so two host threads -- two PyMC chains, two streams -- never see each other's settings.
-// The dsge_set_* functions only edit the process-wide DEFAULTS that calls without options use.
+// Calls without options use the compiled-in defaults (g_defaults is never written: ABI 8 removed the dsge_set_* setters).
 struct Options {
   int cr_compact = 1;          // 0 = dense cycle-reduction kernel only
   int cr_fused_selection = 1;  // fused pipeline: R from the cycle-reduction kernel's final elimination
@@ -221,9 +223,26 @@ struct Options {
   int gensys_shape_cache = 1;  // window path: capacity record measured once per model size
   int gensys_direct_blocks = 1;  // window path: isolated 2 x 2 blocks triangularised in closed form in front of the complex iteration
   int kalman_narrow = 1;       // fast filter: the SK = 20 instance of the 32-wide tile when the state block fits
+  // conventions of the filter step (third party: pymc_extras; include/dsge_hip.h "Filter conventions")
+  int ll_constant = DSGE_LL_CONST_P;
+  int mask_d = 0;
+  int joseph = 1;
+  double jitter_F = -1.0;      // < 0: the call's `jitter` argument
+  double jitter_P = -1.0;
 };
-extern Options g_defaults;
+extern const Options g_defaults;
 extern thread_local const Options* t_call_options;
 inline const Options& opt() { return t_call_options ? *t_call_options : g_defaults; }
+// the conventions of the filter step for a call whose `jitter` argument is given: what every filter kernel receives by value
+inline dsge::FilterConv filter_conv(double jitter) {
+  const Options& o = opt();
+  dsge::FilterConv cv;
+  cv.jit_F = (o.jitter_F >= 0.0) ? o.jitter_F : jitter;
+  cv.jit_P = (o.jitter_P >= 0.0) ? o.jitter_P : jitter;
+  cv.jit_V = o.joseph ? cv.jit_F : 0.0;
+  cv.ll_mode = o.ll_constant;
+  cv.mask_d = o.mask_d ? 1 : 0;
+  return cv;
+}
 
 }  // namespace dsge_host

@@ -11,10 +11,11 @@
 //       S = non-zero columns, s = |S|.  Dropping the zero columns removes only additions of
 //       +0.0 and is therefore bit-identical to the dense product;
 //   (2) with a selector Z, P Z' is a column gather of P and F = Z P Z' + H is a p x p gather.
-// The update uses, with Finv = F^-1 (F = Zm P Zm' + Hm + jitter I), K = P Zm' Finv:
-//     P+ = P - K (P Zm' + jitter K)' + jitter I
-// which equals the reference's Joseph form  sym((I-KZm) P (I-KZm)') + sym(K Hm K') + jitter I
-// exactly in real arithmetic (expand with F = Zm P Zm' + Hm + jitter I).
+// The update uses, with Finv = F^-1 (F = Zm P Zm' + Hm + jit_F I), K = P Zm' Finv:
+//     P+ = P - K (P Zm' + jit_V K)' + jit_P I
+// which, with jit_V = jit_F, equals the Joseph form  sym((I-KZm) P (I-KZm)') + sym(K Hm K') + jit_P I
+// exactly in real arithmetic (expand with K F = P Zm'), and with jit_V = 0 the plain form P - K F K' + jit_P I.
+// jit_F, jit_P, jit_V, the ln 2pi constant and the masking of d are run-time conventions (FilterConv, dsge_device.hpp).
 //
 // The hints (s_cap = LDS capacity for the compact state dimension; selector Z) are verified
 // per draw on the device.  A draw that violates them is left untouched and flagged with
@@ -51,7 +52,7 @@ constexpr int KT_A = KT_FI + 64;     // 32        predicted state of the next st
 constexpr int KT_ZV = KT_A + 32;     // 8         selector values
 constexpr int KT_DD = KT_ZV + 8;     // 8         observation intercept
 constexpr int KT_ZP = KT_DD + 8;     // 8         selected positions (as doubles)
-constexpr int KT_SC = KT_ZP + 8;     // 16        m, s, t, mask, n_obs, step_mant, step_exp, quad_sum, quad_comp, ld_mant, ld_exp, n_ll, steady_step
+constexpr int KT_SC = KT_ZP + 8;     // 16        m, s, t, mask, n_obs, step_mant, step_exp, quad_sum, quad_comp, ld_mant, ld_exp, n_ll, steady_step, n_obs_entries
 constexpr int KT_REC = KT_SC + 16;
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
-    int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
+    int T_len, int s_cap, FilterConv cv, double missing_fill, double steady_tol, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
     double* __restrict__ tail_rec, int32_t* __restrict__ tail_flag, const int32_t* __restrict__ tail_from,
     const int32_t* __restrict__ order) {
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     double quad_sum = 0.0, quad_comp = 0.0;  // Kahan sum of v' Finv v over observed steps
     double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
     long long ld_exp = 0;
-    long long n_ll_steps = 0;
+    long long n_ll_steps = 0, n_obs_entries = 0;  // (FilterConv::ll_terms)
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = dbg ? clock64() : 0;
     // ---- steady-state switch.  The covariance recursion P_{t+1|t} = f(P_{t|t-1}; mask_t) does not
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           za = 0.0;
           for (int jj = 0; jj < m; ++jj) za = fma(Zs[lane * LDM + jj], av[jj], za);
         }
-        v_own = (obs ? yt : 0.0) - (v_dd + (obs ? 1.0 : 0.0) * za);
+        v_own = (obs ? yt : 0.0) - (((obs || !cv.mask_d) ? v_dd : 0.0) + (obs ? 1.0 : 0.0) * za);
       }
       if (lane < 8) vv[lane] = v_own;
       // ---- (b') F[fo][fq]: lane (fo,fq) of the 8 x 8 grid ---------------------------------------
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
             if (jj < m) fa = fma(Zs[fo * LDM + jj], PZt[jj * PS + fq], fa);
             f = wo * wq * (fa + fb);
           }
-          if (fo == fq) f += wo * hh[fo] + jitter;
+          if (fo == fq) f += wo * hh[fo] + cv.jit_F;
         } else {
           f = (fo == fq) ? 1.0 : 0.0;
         }
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
         ld_mant = frexp(ld_mant * step_mant, &e);
         ld_exp += (long long)e + step_exp;
         ++n_ll_steps;
+        n_obs_entries += n_obs;
       }
       wave_sync();  // #1
       if (dbg) {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           if (row_ok) {
             *reinterpret_cast<double2*>(&Ks[i * PS + 2 * o2]) = double2{k0, k1};
             *reinterpret_cast<double2*>(&Vs[i * PS + 2 * o2]) =
-                double2{fma(jitter, k0, on0 ? pzp.x : 0.0), fma(jitter, k1, on1 ? pzp.y : 0.0)};
+                double2{fma(cv.jit_V, k0, on0 ? pzp.x : 0.0), fma(cv.jit_V, k1, on1 ? pzp.y : 0.0)};
             if (o2 == 0) af[i] = av[i] + part;
           }
         }
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
       if (lr == lc) {
 #pragma unroll
         for (int i = 0; i < BS; ++i)
-          if (lr * BS + i < m) Pb[i][i] += jitter;
+          if (lr * BS + i < m) Pb[i][i] += cv.jit_P;
       }
       // steady-state test on the filtered state block: P_{t+1|t} depends on P+ only through P+[S,S], so the
       // covariance recursion has reached its fixed point once that block stops moving.  The previous
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           if (lane < NP) rec[KT_A + lane] = (lane < m) ? av_reg : 0.0;
           if (lane < 8) {
             rec[KT_ZV + lane] = (lane < p) ? zv[lane] : 0.0;
-            rec[KT_DD + lane] = (lane < p) ? dd[lane] : 0.0;
+            rec[KT_DD + lane] = (lane < p && (((omask >> lane) & 1ull) || !cv.mask_d)) ? dd[lane] : 0.0;  // (constant mask from here on)
             rec[KT_ZP + lane] = (lane < p) ? (double)zpos[lane] : 0.0;
           }
           if (lane == 0) {
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
             sc[10] = (double)ld_exp;
             sc[11] = (double)n_ll_steps;
             sc[12] = (double)steady_step;
+            sc[13] = (double)n_obs_entries;
             tail_flag[draw] = 1;
           }
           handed_off = true;
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
           yt_next = (lane < p && t + 1 < T_len) ? y[(size_t)(t + 1) * p + lane] : 0.0;
           const double av_sel = __shfl(av_reg, v_zpos, 64);
           double v_s = 0.0;
-          if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
+          if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (((obs_s || !cv.mask_d) ? v_dd : 0.0) + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
           double vsc[8];
 #pragma unroll
           for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
@@ -822,6 +825,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
             ld_mant = frexp(ld_mant * step_mant, &e);
             ld_exp += (long long)e + step_exp;
             ++n_ll_steps;
+            n_obs_entries += n_obs;
           }
           const double afi = a0 + a1;
           double s0 = 0.0, s1 = 0.0;
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
               za = 0.0;
               for (int jj = 0; jj < m; ++jj) za = fma(Zs[lane * LDM + jj], av[jj], za);
             }
-            v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * za);
+            v_s = (obs_s ? yt_s : 0.0) - (((obs_s || !cv.mask_d) ? v_dd : 0.0) + (obs_s ? 1.0 : 0.0) * za);
           }
           const double qp_s = wave_sum_dpp(f * __shfl(v_s, fo, 64) * __shfl(v_s, fq, 64));
           if (n_obs > 0) {
@@ -867,6 +871,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
             ld_mant = frexp(ld_mant * step_mant, &e);
             ld_exp += (long long)e + step_exp;
             ++n_ll_steps;
+            n_obs_entries += n_obs;
           }
           double afi = (lane < m) ? av[lane] : 0.0;
 #pragma unroll
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : (BS <= KSEL_TWO_WAVES_MAX_BS ? 2
     }
     if (lane == 0 && !handed_off) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
-      const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_sum);
+      const double ll = -0.5 * (cv.ll_terms(n_ll_steps, n_obs_entries, p) * LN2PI + logdet + quad_sum);
       logp_out[draw] = ll;
       if (steady_at) steady_at[draw] = steady_step;
       if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;

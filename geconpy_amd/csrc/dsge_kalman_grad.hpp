@@ -6,14 +6,16 @@
 // (U = states + observed variables, states first; selector design matrix, p <= 8):
 //
 //   forward  (t = 0..T_len-1), storing the predicted (a_t, P_t) of every step in a global scratch:
-//     M = P Zm',  F = Zm M + Hm + jit I,  K = M F^-1,  v = ym - d - Zm a,  a+ = a + K v,
-//     P+ = P - K (M + jit K)' + jit I,  ll_t = -1/2 (p ln 2pi + ln det F + v' F^-1 v),
+//     M = P Zm',  F = Zm M + Hm + jit_F I,  K = M F^-1,  v = ym - d - Zm a,  a+ = a + K v,
+//     P+ = P - K (M + jit_V K)' + jit_P I,  ll_t = -1/2 (c ln 2pi + ln det F + v' F^-1 v),
+//     (jit_F, jit_P, jit_V, c and the masking of d are the run-time conventions of FilterConv, dsge_device.hpp: constants of
+//      the sweep -- of the formulas below only Kbar carries one, jit_V)
 //     a' = T a+,  P' = sym(T P+ T') + G                                  
 //   reverse  (t = T_len-1..0), cotangents (abar, Pbar) of the predicted moments of step t+1:
 //     Tbar += abar a+' + 2 Pbar T P+,   Gbar += Pbar,   a+bar = T' abar,   P+bar = T' Pbar T
 //     vbar  = -lam F^-1 v + K' a+bar
 //     Y     = P+bar K
-//     Kbar  = a+bar v' - 2 Y (F + jit I)
+//     Kbar  = a+bar v' - 2 Y (F + jit_V I)
 //     Mbar  = Kbar F^-1
 //     Fbar  = -lam/2 (F^-1 - F^-1 v v' F^-1) - K' Y - K' Mbar
 //     Mbar += Zm' Fbar,   hbar += w o diag(Fbar)
@@ -87,7 +89,7 @@ template <int BS>
 __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ Z, int z_batched,
     const double* __restrict__ dvec, int d_batched, const double* __restrict__ Hdiag, int h_batched,
-    const double* __restrict__ y, int batch, int m_full, int p, int T_len, double jitter, double missing_fill,
+    const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill,
     double steady_tol, double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
     double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order) {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       double f;
       if (fo < p && fq < p) {
         f = ww[fo] * zv[fo] * Mp[zpos[fo] * PS + fq];
-        if (fo == fq) f += ww[fo] * hh[fo] + jitter;
+        if (fo == fq) f += ww[fo] * hh[fo] + cv.jit_F;
       } else {
         f = (fo == fq) ? 1.0 : 0.0;
       }
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
 #pragma unroll
           for (int o = 0; o < 8; ++o) {
             kr[i][o] = Kp[(lr * BS + i) * PS + o];
-            mk[i][o] = fma(jitter, Kp[(lc * BS + i) * PS + o], Mp[(lc * BS + i) * PS + o]);
+            mk[i][o] = fma(cv.jit_V, Kp[(lc * BS + i) * PS + o], Mp[(lc * BS + i) * PS + o]);
           }
 #pragma unroll
         for (int i = 0; i < BS; ++i)
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
             double sp2 = Ps[r * LDM + c];
 #pragma unroll
             for (int o = 0; o < 8; ++o) sp2 = fma(-kr[i][o], mk[j][o], sp2);
-            sp2 += (r == c && r < u) ? jitter : 0.0;
+            sp2 += (r == c && r < u) ? cv.jit_P : 0.0;
             X1[r * LDM + c] = sp2;
             rec[(i * BS + j) * 64 + lane] = sp2;
           }
@@ -361,8 +363,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         for (int idx = lane; idx < u * u; idx += 64) {
           const int i = idx / u, j = idx - i * u;
           double sp2 = Ps[i * LDM + j];
-          for (int o = 0; o < 8; ++o) sp2 = fma(-Kp[i * PS + o], fma(jitter, Kp[j * PS + o], Mp[j * PS + o]), sp2);
-          X1[i * LDM + j] = sp2 + ((i == j) ? jitter : 0.0);
+          for (int o = 0; o < 8; ++o) sp2 = fma(-Kp[i * PS + o], fma(cv.jit_V, Kp[j * PS + o], Mp[j * PS + o]), sp2);
+          X1[i * LDM + j] = sp2 + ((i == j) ? cv.jit_P : 0.0);
         }
         wave_sync();
 #pragma unroll
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     // update_mean: from av, y_t, ww, Kp, Fi -> vv, fiv, ap; returns v' F^-1 v.  (Fences on entry and exit.)
     auto update_mean = [&](double yt) -> double {
       wave_sync();
-      if (lane < p) vv[lane] = ww[lane] * yt_or_zero(yt) - (dd[lane] + ww[lane] * zv[lane] * av[zpos[lane]]);
+      if (lane < p) vv[lane] = ww[lane] * yt_or_zero(yt) - (((ww[lane] != 0.0 || !cv.mask_d) ? dd[lane] : 0.0) + ww[lane] * zv[lane] * av[zpos[lane]]);
       if (lane >= p && lane < 8) vv[lane] = 0.0;
       wave_sync();
       if (lane < 8) {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       tk0 = tk1;
     }
     double ll_acc = 0.0;
-    long long n_ll = 0;
+    long long n_ll = 0, n_entries = 0;  // (FilterConv::ll_terms)
     bool steady = false;
     unsigned long long smask = 0ull;
     int seg_src = -1;
@@ -446,9 +448,9 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           firow[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
         }
         double a_reg = (lane < NP) ? av[lane] : 0.0;
-        const double v_dd = (lane < p) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
-        const int v_zpos = (lane < p) ? zpos[lane] : 0;
         const double w_l = (lane < p && ((smask >> lane) & 1ull)) ? 1.0 : 0.0;
+        const double v_dd = (lane < p && (w_l != 0.0 || !cv.mask_d)) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;  // (constant mask)
+        const int v_zpos = (lane < p) ? zpos[lane] : 0;
         double yc = yt;
         long long n_ss = 0;
         for (;;) {
@@ -475,6 +477,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           const double quad_s = readlane_f64(part, 7);
           ll_acc += lam * (seg_logdet + quad_s);
           n_ll += (lam != 0.0);
+          n_entries += __popcll(smask);
           const double apl = a0 + a1;
           double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       const double quad = update_mean(yt);
       ll_acc += lam * (seg_logdet + quad);
       n_ll += (lam != 0.0);
+      n_entries += __popcll(omask);
       // predict: a = T a+
       if (lane < u) {
         t1[lane] = kg_dot4(Tc + lane * LDM, 1, ap, 1, u);
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         tk0 = tk1;
       }
     }
-    const double logp = -0.5 * ((double)n_ll * (double)p * LN2PI + ll_acc);
+    const double logp = -0.5 * (cv.ll_terms(n_ll, n_entries, p) * LN2PI + ll_acc);
     if (lane == 0) {
       logp_out[draw] = logp;
       if (!((logp == logp) && (fabs(logp) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
@@ -685,9 +689,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           krow[q] = (lane < u) ? Kp[lane * PS + q] : 0.0;
           firow[q] = (lane < 8) ? Fi[lane * 8 + q] : 0.0;
         }
-        const double v_dd = (lane < p) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
-        const int v_zpos = (lane < p) ? zpos[lane] : 0;
         const double w_l = (lane < p && ((omask >> lane) & 1ull)) ? 1.0 : 0.0;
+        const bool d_live = (w_l != 0.0 || !cv.mask_d);  // d enters v on this entry (the mask is constant over the segment)
+        const double v_dd = (lane < p && d_live) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
+        const int v_zpos = (lane < p) ? zpos[lane] : 0;
         int my_o = -1;  // the observation (if any) that selects this lane's variable
         for (int o = 0; o < p; ++o)
           if (zpos[o] == lane) my_o = o;
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           nlam += lam;
           // abar = a+bar - Zm' vbar;  dbar -= vbar
           ab_reg = apb_l - my_wz * __shfl(vb_l, my_os, 64);
-          db_reg -= vb_l;
+          db_reg -= d_live ? vb_l : 0.0;
         };
         // The steps' records (a_t, y_t) come from HBM.  Fetching them one step ahead into registers (`cur = next; next =
         // load`) does not work: the compiler loads into a temporary, copies it into the loop-carried register right away and
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           const int idx = lane + 64 * k2, i = idx >> 3, o = idx & 7;
           if (i < u) {
             double sk = Kacc[k2];
-            for (int q = 0; q < 8; ++q) sk = fma(-2.0 * Yp[i * PS + q], Fs[q * 8 + o] + ((q == o) ? jitter : 0.0), sk);
+            for (int q = 0; q < 8; ++q) sk = fma(-2.0 * Yp[i * PS + q], Fs[q * 8 + o] + ((q == o) ? cv.jit_V : 0.0), sk);
             Kb[i * PS + o] = (o < p) ? sk : 0.0;
           }
         }

@@ -2,7 +2,7 @@
 //
 // Same algorithm as kalman_sel_kernel<BS, true> (dsge_kalman2.hpp: exact reduction to the retained variables in a
 // states-first ordering, stationary initial covariance by doubling, p x p inverse by Gauss-Jordan, P+ = P - K (P Zm' +
-// jitter K)' + jitter I, steady-state switch with a register-resident mean recursion; the recursion is the one restated in
+// jit_V K)' + jit_P I (FilterConv, dsge_device.hpp), steady-state switch with a register-resident mean recursion; the recursion is the one restated in
 // SURVEY.md Appendix B.4 for statespace.py:1151-1157), rebuilt twice in round 2:
 //
 // (1) the two prediction products of a full step -- W = P+[S,S] Tc' and X = Tc W -- in "NT" form: W is stored TRANSPOSED,
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m_full, int p,
-    int T_len, int s_cap, double jitter, double missing_fill, double steady_tol, double* __restrict__ logp_out,
+    int T_len, int s_cap, FilterConv cv, double missing_fill, double steady_tol, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
     const int32_t* __restrict__ order, const double* __restrict__ Rsel, const double* __restrict__ qdiag, int q_batched,
     int k_shocks, const unsigned long long* __restrict__ colmask_in) {
@@ -402,13 +402,13 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     const double r_zv = (r8 < p) ? zv[r8] : 0.0, r_dd = dd[r8], r_hh = hh[r8];
     double jit_d[BS];  // jitter on the diagonal of P+ (rows < m of the diagonal lanes)
 #pragma unroll
-    for (int i = 0; i < BS; ++i) jit_d[i] = (lr == lc && lr * BS + i < m) ? jitter : 0.0;
+    for (int i = 0; i < BS; ++i) jit_d[i] = (lr == lc && lr * BS + i < m) ? cv.jit_P : 0.0;
     const bool fold_a = m < NP;  // a spare padding column: the mean prediction rides along in the X product
 
     double quad_sum = 0.0, quad_comp = 0.0;  // Kahan sum of v' Finv v over observed steps
     double ld_mant = 1.0;                    // prod of pivots = mant * 2^exp
     int ld_exp = 0;
-    int n_ll_steps = 0;
+    int n_ll_steps = 0, n_obs_entries = 0;  // steps with >= 1 observed entry, and their observed entries (FilterConv::ll_terms)
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = DBG ? clock64() : 0;
     int steady_step = -1;
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       // ---- (b) innovation v[r8] and row r8 of F = Zm P Zm' + Hm + jitter I, replicated over the eight 8-lane groups
       //      (identity rows / columns for missing observations and for r8 >= p) ---------------------------------------
       const double c_r = obs ? r_zv : 0.0;
-      const double v_r = (obs ? yt : 0.0) - (r_dd + c_r * a_sel);
-      const double dg = (r8 < p) ? ((obs ? r_hh : 0.0) + jitter) : 1.0;
+      const double v_r = (obs ? yt : 0.0) - (((obs || !cv.mask_d) ? r_dd : 0.0) + c_r * a_sel);
+      const double dg = (r8 < p) ? ((obs ? r_hh : 0.0) + cv.jit_F) : 1.0;
       if (lane < 8) vv[lane] = v_r;  // broadcast of v for the quadratic form: through LDS, behind the elimination
       asm volatile("" ::: "memory");  // (the double2 reads below must not be hoisted above this store)
       double fr[8];
@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
           ld_mant = frexp(ld_mant * step_mant, &e);
           ld_exp += e + step_exp;
           ++n_ll_steps;
+          n_obs_entries += n_obs;
         }
       }
       if constexpr (DBG) {
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
         }
         const double kk = obs ? (k0 + k1) * inv_own : 0.0;
         Ks[i * PS + r8] = kk;
-        Vs[i * PS + r8] = -fma(jitter, kk, obs ? pzo[ps] : 0.0);  // stored negated: the downdate is a plain fma chain
+        Vs[i * PS + r8] = -fma(cv.jit_V, kk, obs ? pzo[ps] : 0.0);  // stored negated: the downdate is a plain fma chain
         double part = kk * v_r;
         part += dpp_move_f64<0xB1, 0xf>(part);   // quad_perm [1,0,3,2]
         part += dpp_move_f64<0x4E, 0xf>(part);   // quad_perm [2,3,0,1]
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
           yt_next = y[(size_t)((t + 1 < T_len) ? t + 1 : t) * p + r8c];
           const double av_sel = __shfl(av_reg, v_zpos, 64);
           double v_s = 0.0;
-          if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (v_dd + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
+          if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (((obs_s || !cv.mask_d) ? v_dd : 0.0) + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));
           double vsc[8];
 #pragma unroll
           for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
             ld_mant = frexp(ld_mant * step_mant, &e);
             ld_exp += e + step_exp;
             ++n_ll_steps;
+            n_obs_entries += n_obs;
           }
           const double afi = a0 + a1;
           double s0 = 0.0, s1 = 0.0;
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     const double quad_total = wave_sum_dpp(quad_sum - quad_comp);  // lanes 0..7 hold the shares, the others zero
     if (lane == 0) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
-      const double ll = -0.5 * ((double)n_ll_steps * (double)p * LN2PI + logdet + quad_total);
+      const double ll = -0.5 * (cv.ll_terms(n_ll_steps, n_obs_entries, p) * LN2PI + logdet + quad_total);
       logp_out[draw] = ll;
       if (steady_at) steady_at[draw] = steady_step;
       if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;

@@ -4,8 +4,9 @@
 // (dsge_kalman_nt.hpp, dsge_kalman2.hpp); this kernel serves the post-estimation pass and favours clarity: one workgroup of
 // 256 threads per draw, T, P in LDS, the full recursion of oracle/statespace.py (no steady-state switch, no state reduction),
 // same rank-p update algebra as the fast kernels:
-//     v = ym - d - Zm a;  F = Zm P Zm' + Hm + jitter I;  K = P Zm' F^-1;  a+ = a + K v
-//     P+ = P - sym(K (P Zm' + jitter K)') + jitter I;    ll_t = -1/2 (p ln 2 pi + ln det F + v' F^-1 v)  (0 if all missing)
+//     v = ym - d - Zm a;  F = Zm P Zm' + Hm + jit_F I;  K = P Zm' F^-1;  a+ = a + K v
+//     P+ = P - sym(K (P Zm' + jit_V K)') + jit_P I;    ll_t = -1/2 (c ln 2 pi + ln det F + v' F^-1 v)  (0 if all missing)
+//     (jit_F, jit_P, jit_V, c and the masking of d: the run-time conventions of FilterConv, dsge_device.hpp)
 //     a = T a+;  P = sym(T P+ T') + sym(R Q R')
 // Outputs per draw and step t: ll[t]; a_pred[t] = a_{t|t-1}, a_filt[t] = a_{t|t}; the diagonals of P_{t|t-1} and P_{t|t}
 // (or, on request, the full matrices).
@@ -31,7 +32,8 @@ struct KoArgs {
   double* p_filt;
   int32_t* status;       // [batch] in/out
   int batch, m, p, T_len, z_batched, d_batched, h_batched, full_cov;
-  double jitter, missing_fill;
+  FilterConv cv;         // third-party conventions of the step (dsge_device.hpp)
+  double missing_fill;
 };
 
 __host__ __device__ inline size_t ko_lds_doubles(int m, int p) {
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(KO_THREADS) void kalman_outputs_kernel(KoArgs a) {
       double za = 0.0;
       if ((mask >> o) & 1)
         for (int j = 0; j < m; ++j) za = fma(Zm[o * m + j], av[j], za);
-      vv[o] = (((mask >> o) & 1) ? a.y[(size_t)t * p + o] : 0.0) - dv[o] - za;
+      vv[o] = (((mask >> o) & 1) ? a.y[(size_t)t * p + o] : 0.0) - ((((mask >> o) & 1) || !a.cv.mask_d) ? dv[o] : 0.0) - za;
     }
     for (int idx = tid; idx < m * p; idx += NT) {
       const int i = idx / p, o = idx - i * p;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(KO_THREADS) void kalman_outputs_kernel(KoArgs a) {
       double acc = 0.0;
       if ((mask >> o) & 1)
         for (int j = 0; j < m; ++j) acc = fma(Zm[o * m + j], PZ[j * PM + o2], acc);
-      if (o == o2) acc += (((mask >> o) & 1) ? hv[o] : 0.0) + a.jitter;
+      if (o == o2) acc += (((mask >> o) & 1) ? hv[o] : 0.0) + a.cv.jit_F;
       Fm[o * PM + o2] = acc;
     }
     __syncthreads();
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(KO_THREADS) void kalman_outputs_kernel(KoArgs a) {
         wv[o] = sv / Lc[o * PM + o];
         quad = fma(wv[o], wv[o], quad);
       }
-      const double l = (mask != 0) ? -0.5 * (p * LN2PI + ld + quad) : 0.0;
+      const double l = (mask != 0) ? -0.5 * (a.cv.ll_terms_step(__popc(mask), p) * LN2PI + ld + quad) : 0.0;
       ll_o[t] = l;
       if (!okc || !(l == l)) finite = false;
     }
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(KO_THREADS) void kalman_outputs_kernel(KoArgs a) {
       double acc = 0.0;
       for (int o = 0; o < p; ++o) {
         const double ki = Kg[i * PM + o], kj = Kg[j * PM + o];
-        acc = fma(ki, fma(a.jitter, kj, PZ[j * PM + o]), acc);
-        acc = fma(kj, fma(a.jitter, ki, PZ[i * PM + o]), acc);
+        acc = fma(ki, fma(a.cv.jit_V, kj, PZ[j * PM + o]), acc);
+        acc = fma(kj, fma(a.cv.jit_V, ki, PZ[i * PM + o]), acc);
       }
-      W[idx] = P[idx] - 0.5 * acc + (i == j ? a.jitter : 0.0);
+      W[idx] = P[idx] - 0.5 * acc + (i == j ? a.cv.jit_P : 0.0);
     }
     __syncthreads();
     if (a.a_filt)

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(64) void kalman_tail_kernel(const double* __restric
                                                           const int32_t* __restrict__ tail_flag,
                                                           const double* __restrict__ y, int batch, int p, int T_len,
                                                           double missing_fill, double* __restrict__ logp_out,
-                                                          int32_t* __restrict__ status, int32_t* __restrict__ steady_at) {
+                                                          int32_t* __restrict__ status, int32_t* __restrict__ steady_at,
+                                                          FilterConv cv) {
   constexpr int NP = 32, LDM = 33, PS = 10;
   __shared__ __attribute__((aligned(16))) double Tc[NP * LDM];  // transition
   __shared__ __attribute__((aligned(16))) double Ph[NP * LDM];  // Phi = T - Gam Zw
@@ -238,7 +239,9 @@ __global__ __launch_bounds__(64) void kalman_tail_kernel(const double* __restric
     }
     if (lane == 0) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
-      const double ll = -0.5 * ((double)n_ll * (double)p * LN2PI + logdet + quad_sum);
+      // (the mask is constant over the tail: every step of it has n_obs observed entries; d arrives masked if cv.mask_d)
+      const long long n_entries = (long long)sc[13] + (n_ll - (long long)sc[11]) * n_obs;
+      const double ll = -0.5 * (cv.ll_terms(n_ll, n_entries, p) * LN2PI + logdet + quad_sum);
       logp_out[draw] = ll;
       if (steady_at) steady_at[draw] = (int)sc[12];
       if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;

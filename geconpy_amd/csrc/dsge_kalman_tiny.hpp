@@ -8,7 +8,7 @@
 //
 // Same mathematics as kalman_sel_kernel (dsge_kalman2.hpp): exact reduction to U (ordered OBSERVED variables
 // first, in observation order, so that the selector picks a compile-time position), stationary P0 by doubling
-// on the reduced model, reference update P+ = P - K (M + jit K)' + jit I, missing data as upstream, the
+// on the reduced model, reference update P+ = P - K (M + jit_V K)' + jit_P I (FilterConv), missing data as upstream, the
 // steady-state switch with the same tolerance.  Conditions: selector design matrix, p <= PM, u <= U; a draw
 // that violates them is flagged DSGE_ST_INTERNAL_RERUN and taken by the wave-per-draw kernels.
 #pragma once
@@ -22,7 +22,7 @@ template <int U, int PM>
 __global__ __launch_bounds__(64) void kalman_tiny_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ Z, int z_batched,
     const double* __restrict__ dvec, int d_batched, const double* __restrict__ Hdiag, int h_batched,
-    const double* __restrict__ y, int batch, int m_full, int p, int T_len, double jitter, double missing_fill,
+    const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill,
     double steady_tol, double* __restrict__ logp_out, int32_t* __restrict__ status, int32_t* __restrict__ steady_at) {
   const int draw = blockIdx.x * 64 + threadIdx.x;
   if (draw >= batch) return;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void kalman_tiny_kernel(
 #pragma unroll
   for (int i = 0; i < U; ++i) a[i] = 0.0;
   double quad_sum = 0.0, quad_comp = 0.0, ld_mant = 1.0;
-  long long ld_exp = 0, n_ll = 0;
+  long long ld_exp = 0, n_ll = 0, n_entries = 0;
   double K[U][PM], Fi[PM][PM];
   double step_mant = 1.0;
   int step_exp = 0;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void kalman_tiny_kernel(
     const bool any_obs = omask != 0u;
     double v[PM];
 #pragma unroll
-    for (int o = 0; o < PM; ++o) v[o] = (o < p) ? yv[o] - (dd[o] + w[o] * zval[o] * a[o]) : 0.0;
+    for (int o = 0; o < PM; ++o) v[o] = (o < p) ? yv[o] - (((w[o] != 0.0 || !cv.mask_d) ? dd[o] : 0.0) + w[o] * zval[o] * a[o]) : 0.0;
     if (!(steady && omask == steady_mask)) {
       steady = false;
       // M = P Zm' (columns 0..p-1 of P scaled), F = Zm M + Hm + jit I
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void kalman_tiny_kernel(
 #pragma unroll
         for (int q = 0; q < PM; ++q) {
           if (o < p && q < p)
-            F[o][q] = w[o] * zval[o] * M[o][q] + ((o == q) ? (w[o] * hh[o] + jitter) : 0.0);
+            F[o][q] = w[o] * zval[o] * M[o][q] + ((o == q) ? (w[o] * hh[o] + cv.jit_F) : 0.0);
           else
             F[o][q] = (o == q) ? 1.0 : 0.0;
         }
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(64) void kalman_tiny_kernel(
           pscale = nanmax(pscale, fabs(P[i][j]));
           double s0 = P[i][j];
 #pragma unroll
-          for (int o = 0; o < PM; ++o) s0 = fma(-K[i][o], fma(jitter, K[j][o], M[j][o]), s0);
-          s0 += (i == j && i < u) ? jitter : 0.0;
+          for (int o = 0; o < PM; ++o) s0 = fma(-K[i][o], fma(cv.jit_V, K[j][o], M[j][o]), s0);
+          s0 += (i == j && i < u) ? cv.jit_P : 0.0;
           dmax = nanmax(dmax, fabs(s0 - Pf_prev[i][j]));
           Pf_prev[i][j] = s0;
         }
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(64) void kalman_tiny_kernel(
       ld_mant = frexp(ld_mant * step_mant, &e);
       ld_exp += (long long)e + step_exp;
       ++n_ll;
+      n_entries += __popc(omask);
     }
     double ap[U];
 #pragma unroll
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(64) void kalman_tiny_kernel(
     }
   }
   const double logdet = log(ld_mant) + (double)ld_exp * LN2;
-  const double ll = -0.5 * ((double)n_ll * (double)p * LN2PI + logdet + quad_sum);
+  const double ll = -0.5 * (cv.ll_terms(n_ll, n_entries, p) * LN2PI + logdet + quad_sum);
   logp_out[draw] = ll;
   if (steady_at) steady_at[draw] = steady_step;
   if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] = DSGE_ST_FILTER_NONFINITE;

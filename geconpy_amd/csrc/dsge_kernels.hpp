@@ -967,9 +967,10 @@ __global__ __launch_bounds__(64) void norms_kernel(const double* __restrict__ A,
 //
 // Update in square-root-free downdate form.  With F = L L' (Cholesky), G = P Zm' L^-T and
 // K = G L^-1 = P Zm' F^-1, the Joseph-form covariance of the reference recursion
-//     P+ = sym((I-KZm) P (I-KZm)') + sym(K Hm K') + jitter I
-// equals, exactly in real arithmetic (F = Zm P Zm' + Hm + jitter I),
-//     P+ = P - G G' - jitter K K' + jitter I
+//     P+ = sym((I-KZm) P (I-KZm)') + sym(K Hm K') + jit_P I
+// equals, exactly in real arithmetic (F = Zm P Zm' + Hm + jit_F I),
+//     P+ = P - G G' - jit_V K K' + jit_P I          (jit_V = jit_F; jit_V = 0 is the plain form P - K F K' + jit_P I;
+// the jitters, the ln 2pi constant and the masking of d are run-time conventions: FilterConv, dsge_device.hpp)
 // which costs O(m^2 p) instead of O(m^3).  Verified against the Joseph form of the oracle to
 // ~1e-15 relative on logp (tests/test_device_algorithm_model.py).
 // Prediction:  a = T a+,  P = sym(T P+ T') + sym(RQR).
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(64) void kalman_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0,
     const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ Hdiag, int h_batched, const double* __restrict__ y, int batch, int m, int p,
-    int T_len, double jitter, double missing_fill, double* __restrict__ logp_out,
+    int T_len, FilterConv cv, double missing_fill, double* __restrict__ logp_out,
     int32_t* __restrict__ status, int rerun_only) {
   constexpr int NP = KfSmem<BS>::NP, LD = KfSmem<BS>::LD, PMAX = DSGE_MAX_P;
   const int PLD = p | 1;
@@ -1073,16 +1074,16 @@ __global__ __launch_bounds__(64) void kalman_kernel(
       if (lane < p) {
         double s = 0.0;
         for (int kk = 0; kk < m; ++kk) s = fma(Zs[lane * LD + kk], av[kk], s);
-        vv[lane] = ys[lane] - (ds[lane] + ww[lane] * s);
+        vv[lane] = ys[lane] - (((ww[lane] != 0.0 || !cv.mask_d) ? ds[lane] : 0.0) + ww[lane] * s);
       }
       wave_sync();
-      // ---- F = Zm PZt + Hm + jitter I
+      // ---- F = Zm PZt + Hm + jit_F I
       for (int idx = lane; idx < p * p; idx += 64) {
         const int o = idx / p, q = idx - o * p;
         double s = 0.0;
         for (int kk = 0; kk < m; ++kk) s = fma(Zs[o * LD + kk], PZt[kk * PLD + q], s);
         s *= ww[o];
-        if (o == q) s += ww[o] * hs[o] + jitter;
+        if (o == q) s += ww[o] * hs[o] + cv.jit_F;
         Fs[o * PLD + q] = s;
       }
       wave_sync();
@@ -1132,7 +1133,7 @@ __global__ __launch_bounds__(64) void kalman_kernel(
           logdet += log(Fs[o * PLD + o]);
           inner = fma(wv[o], wv[o], inner);
         }
-        const double ll = (n_obs == 0) ? 0.0 : -0.5 * ((double)p * LN2PI + 2.0 * logdet + inner);
+        const double ll = (n_obs == 0) ? 0.0 : -0.5 * (cv.ll_terms_step(n_obs, p) * LN2PI + 2.0 * logdet + inner);
         const double yk = ll - ll_comp;
         const double tk = ll_sum + yk;
         ll_comp = (tk - ll_sum) - yk;
@@ -1144,7 +1145,7 @@ __global__ __launch_bounds__(64) void kalman_kernel(
         for (int o = 0; o < p; ++o) s = fma(Gs[i * PLD + o], wv[o], s);
         af[i] = s;
       }
-      // ---- P+ = P - G G' - jitter K K' + jitter I   (register blocks)
+      // ---- P+ = P - G G' - jit_V K K' + jit_P I   (register blocks)
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -1155,8 +1156,8 @@ __global__ __launch_bounds__(64) void kalman_kernel(
             gg = fma(Gs[r * PLD + o], Gs[c * PLD + o], gg);
             kk2 = fma(Ks[r * PLD + o], Ks[c * PLD + o], kk2);
           }
-          double v = Pb[i][j] - gg - jitter * kk2;
-          if (r == c && r < m) v += jitter;
+          double v = Pb[i][j] - gg - cv.jit_V * kk2;
+          if (r == c && r < m) v += cv.jit_P;
           Pb[i][j] = v;
         }
       wave_sync();

@@ -788,7 +788,8 @@ struct SoFilterArgs {
   long long* phases;        // device int64[8] or nullptr (debug): shader cycles draw 0 spends in [0] P Z', F, gain; [1] the pass
                             // over Az'; [2] first product; [3] second product; [4] steady steps; [5] full steps; [6] steady steps (count); [7] total
   int batch, T_len;
-  double jitter, missing_fill, steady_tol;
+  FilterConv cv;            // third-party conventions of the filter step (dsge_device.hpp)
+  double missing_fill, steady_tol;
 };
 
 // x <- (Lc Lc')^-1 x (FWD_ONLY: x <- Lc^-1 x) for the p x p Cholesky factor of F, IDENTITY-PADDED to 8 x 8 with the reciprocals of
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_lyap_kernel(SoFilterArgs a, SoL
   {
     const double* AzT = wk + lay.azt;
     double* Qzj = wk + lay.qzj;
-    const double jit = a.jitter;
+    const double jit = a.cv.jit_P;
     so_gemm_sym<MT>(AzT, AzT, MP, lds, [&](int r, int c, so_v4f64 v) {  // (Az Az': a Gram matrix)
 #pragma unroll
       for (int e = 0; e < 4; ++e) Qzj[(size_t)(r + 4 * e) * MP + c] = fma(jit, v[e], Qz[(size_t)(r + 4 * e) * MP + c]);
@@ -1137,7 +1138,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       if ((mask >> o) & 1)
         for (int c = 0; c < u; ++c) za = fma(Zu[o * u + c], av[c] + av[u + c], za);
       const double yo = ((mask >> o) & 1) ? y_now : 0.0;
-      vv[o] = yo - dv[o] - za;
+      vv[o] = yo - ((((mask >> o) & 1) || !a.cv.mask_d) ? dv[o] : 0.0) - za;
     }
     __syncthreads();  // (the innovation is read by every wavefront below, also on the steady path)
     if (!steady) {
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
         double acc = 0.0;
         if ((mask >> o) & 1)
           for (int c = 0; c < u; ++c) acc = fma(Zu[o * u + c], PZ[o2 * MP + c] + PZ[o2 * MP + u + c], acc);
-        if (o == o2) acc += (((mask >> o) & 1) ? hv[o] : 0.0) + a.jitter;
+        if (o == o2) acc += (((mask >> o) & 1) ? hv[o] : 0.0) + a.cv.jit_F;
         Fm[o * 8 + o2] = acc;
       }
       __syncthreads();
@@ -1248,7 +1249,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
       double quad = 0.0;
 #pragma unroll
       for (int o = 0; o < PM; ++o) quad = fma(x[o], x[o], quad);
-      if (mask != 0) ll_sum += -0.5 * (p * LN2PI + logdet + quad);
+      if (mask != 0) ll_sum += -0.5 * (a.cv.ll_terms_step(__popc(mask), p) * LN2PI + logdet + quad);
       if (!(quad == quad)) finite = false;
     }
     for (int i = tid; i < m; i += NT) {
@@ -1328,7 +1329,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_filter_kernel(SoFilterArgs a, S
 #pragma unroll
         for (int o = 0; o < PM; ++o) {
           AK[o * MP + i] = x[o];
-          AV[o * MP + i] = fma(a.jitter, x[o], apz[o]);
+          AV[o * MP + i] = fma(a.cv.jit_V, x[o], apz[o]);
         }
       }
     }

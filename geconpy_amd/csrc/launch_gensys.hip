@@ -40,6 +40,14 @@ struct ShapeRecord {
 std::mutex g_shape_mu;
 std::map<std::pair<int, int>, ShapeRecord> g_shape_cache;
 
+}  // namespace
+// dsge_forget_measured_shapes(): the next call of every model size measures its capacity record again (buffers are kept)
+void gensys_shape_reset() {
+  std::lock_guard<std::mutex> lk(g_shape_mu);
+  for (auto& kv : g_shape_cache) kv.second.valid = false;
+}
+namespace {
+
 // bk != nullptr: eigenvalue mode (reduce + QZ + gensys_bk_kernel instead of the post-processing)
 struct BkOut {
   double *re, *im;
@@ -70,7 +78,10 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
     auto it = g_shape_cache.find({dev, n * 128 + n_lead_hint});
     if (it != g_shape_cache.end() && it->second.valid) {
       ShapeRecord& r = it->second;
-      if (r.h_obs[0] != 0 || ++r.age >= 256) {
+      // (the periodic renewal synchronises the stream: never while the caller is capturing it into a graph)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      const bool capturing = (hipStreamIsCapturing(st, &cap) == hipSuccess) && cap != hipStreamCaptureStatusNone;
+      if (r.h_obs[0] != 0 || (!capturing && ++r.age >= 256)) {
         r.valid = false;  // an earlier call met a draw beyond the record (or the record is old): measure again
       } else {
         for (int i = 0; i < 4; ++i) shape[i] = r.shape[i];
@@ -91,9 +102,18 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
     if (cacheable) {
       std::lock_guard<std::mutex> lk(g_shape_mu);
       ShapeRecord& r = g_shape_cache[{dev, n * 128 + n_lead_hint}];
-      if (!r.d_obs) {
-        HIP_TRY(hipMalloc((void**)&r.d_obs, 4 * sizeof(int)));
-        HIP_TRY(hipHostMalloc((void**)&r.h_obs, 4 * sizeof(int), hipHostMallocDefault));
+      if (!r.d_obs || !r.h_obs) {  // both or neither: a record is published only with its two buffers
+        int* d_new = nullptr;
+        int* h_new = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_new, 4 * sizeof(int)));
+        const hipError_t eh = hipHostMalloc((void**)&h_new, 4 * sizeof(int), hipHostMallocDefault);
+        if (eh != hipSuccess) {
+          (void)hipFree(d_new);
+          (void)hipGetLastError();
+          return fail(DSGE_ERR_HIP, std::string("hipHostMalloc(shape record): ") + hipGetErrorString(eh));
+        }
+        r.d_obs = d_new;
+        r.h_obs = h_new;
       }
       // (other streams' cached calls of this size may still be in flight with the old record: they only ever raise the flag)
       HIP_TRY(hipMemsetAsync(r.d_obs, 0, 4 * sizeof(int), st));

@@ -31,7 +31,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
     rc = set_lds(dsge::kalman_grad_kernel<BS>, lds);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::kalman_grad_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, opt().kalman_steady_tol, store, logp, status, Tbar,
+                         Hdiag, h_batched, y, batch, m, p, T_len, filter_conv(jitter), missing_fill, opt().kalman_steady_tol, store, logp, status, Tbar,
                          Gbar,
                          dbar, hbar, g_kalman_dbg, order);
       HIP_TRY(hipGetLastError());

@@ -52,6 +52,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key, const double* Rsel,
                   const double* qdiag, int q_batched, int k_shocks, const unsigned long long* colmask) {
   const int bs = tile_bs(m);
+  const dsge::FilterConv cv = filter_conv(jitter);  // the call's jitter + the conventions of dsge_options
   const bool fold = Rsel && qdiag && kalman_folds_rqr(m, p, k_shocks, n_state_hint, z_selector_hint);
   if (Rsel && !fold) return fail(DSGE_ERR_INVALID, "launch_kalman: R given but the filter kernel cannot form R Q R' itself");
   int rc = DSGE_ERR_INVALID;
@@ -68,11 +69,11 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     const int blocks = (batch + 63) / 64;
     if (n_state_hint + p <= 4) {
       hipLaunchKernelGGL((dsge::kalman_tiny_kernel<4, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, opt().kalman_steady_tol, logp, status,
+                         Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, opt().kalman_steady_tol, logp, status,
                          g_kalman_steady_at);
     } else {
       hipLaunchKernelGGL((dsge::kalman_tiny_kernel<6, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, opt().kalman_steady_tol, logp, status,
+                         Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, opt().kalman_steady_tol, logp, status,
                          g_kalman_steady_at);
     }
     HIP_TRY(hipGetLastError());
@@ -137,7 +138,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               if (rc == DSGE_SUCCESS) {
                 hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                    p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p,
-                                   T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                   T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                    g_kalman_steady_at, nullptr, nullptr, nullptr, order);
                 HIP_TRY(hipGetLastError());
                 launched_fast = true;
@@ -150,7 +151,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, false, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
-                                 s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, tail_rec, tail_flag, tail_from, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
@@ -169,14 +170,14 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                 if (rc == DSGE_SUCCESS)
                   hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, true, SKV>), dim3(batch), dim3(64), lds_q,
                                      st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
-                                     p, T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
+                                     p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
                                      rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
               } else {
                 rc = set_lds(dsge::kalman_nt_kernel<BS, false, SKV>, lds_q);
                 if (rc == DSGE_SUCCESS)
                   hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(batch), dim3(64), lds_q,
                                      st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
-                                     p, T_len, s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
+                                     p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
                                      rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
               }
             };
@@ -201,7 +202,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
-                                 s_cap, jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, nullptr, nullptr, nullptr, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
@@ -216,7 +217,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, false>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
                                  p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, s_cap,
-                                 jitter, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
+                                 cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, rerun,
                                  g_kalman_steady_at, nullptr, nullptr, nullptr, order);
               HIP_TRY(hipGetLastError());
               launched_fast = true;
@@ -229,7 +230,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   }
   if (tail_rec) {
     hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, st, (const double*)tail_rec,
-                       (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at);
+                       (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv);
     HIP_TRY(hipGetLastError());
   }
   if (fold) {  // the general kernel's inputs for the draws the fast kernel handed on: their sym(R Q R') after all
@@ -248,7 +249,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::kalman_kernel<BS>, dim3(launched_fast ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR, P0, Z,
                          z_batched, d,
-                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, jitter, missing_fill, logp, status,
+                         d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, logp, status,
                          launched_fast ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
@@ -264,7 +265,7 @@ int launch_kalman_outputs(const double* T, const double* RQR, const double* P0, 
   dsge::KoArgs a{};
   a.T = T; a.RQR = RQR; a.P0 = P0; a.Z = Z; a.d = d; a.Hdiag = Hdiag; a.y = y; a.ll = ll; a.a_pred = a_pred; a.a_filt = a_filt;
   a.p_pred = p_pred; a.p_filt = p_filt; a.status = status; a.batch = batch; a.m = m; a.p = p; a.T_len = T_len;
-  a.z_batched = z_batched; a.d_batched = d_batched; a.h_batched = h_batched; a.full_cov = full_cov; a.jitter = jitter;
+  a.z_batched = z_batched; a.d_batched = d_batched; a.h_batched = h_batched; a.full_cov = full_cov; a.cv = filter_conv(jitter);
   a.missing_fill = missing_fill;
   const size_t lds = dsge::ko_lds_doubles(m, p) * sizeof(double);
   int rc;

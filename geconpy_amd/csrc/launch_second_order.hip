@@ -155,7 +155,7 @@ int launch_second_order(const double* B, const double* C, const double* T, const
     fa.phases = (c0 == 0) ? g_so_dbg : nullptr;
     fa.batch = nb;
     fa.T_len = T_len;
-    fa.jitter = jitter;
+    fa.cv = filter_conv(jitter);
     fa.missing_fill = missing_fill;
     // The scale-free test of the second-order filter ((dP_ij)^2 <= tol^2 P_ii P_jj for EVERY entry of a 207 x 207 matrix whose
     // entries are sums of 207 products) meets its own rounding noise at ~1e-14: with the option's default the covariance of

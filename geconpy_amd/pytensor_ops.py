@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import batched
+from . import _lib, batched
 
 try:  # pragma: no cover - exercised only where pytensor is installed
     import pytensor.tensor as pt
@@ -227,6 +227,20 @@ class HipSelectionAdjoint(Op):
             cell[0] = val[0] if squeeze else val
 
 
+def _conventions_prop(conventions):
+    """Hashable form of the ``conventions`` prop of the logp Ops: None, or the sorted items of the keyword arguments of
+    ``_lib.filter_conventions`` (validated here, so that a misspelt switch fails when the Op is built)."""
+    if conventions is None:
+        return None
+    items = dict(conventions)
+    _lib.filter_conventions(**items)
+    return tuple(sorted(items.items()))
+
+
+def _conventions_options(prop):
+    return None if prop is None else _lib.filter_conventions(**dict(prop))
+
+
 class HipSolveKalmanLogp(Op):
     """Fused per-draw log-likelihood: ``logp, status = Op(A, B, C, D, q, Z, y, d, Hdiag)``.
 
@@ -236,11 +250,14 @@ class HipSolveKalmanLogp(Op):
     (statespace.py:197-222, 725-820, 1151-1157) for all draws in one call; failed draws give -inf.
     """
 
-    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value", "filter_type")
+    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value", "filter_type", "conventions")
 
     def __init__(self, solver="cycle_reduction", tol=1e-6, max_iter=50, jitter=batched.JITTER_DEFAULT,
-                 missing_fill_value=batched.MISSING_FILL, filter_type="standard"):
+                 missing_fill_value=batched.MISSING_FILL, filter_type="standard", conventions=None):
         batched.check_filter_type(filter_type)  # (build.py:577: only the default filter is built; the others raise here)
+        # third-party conventions of the filter step (pymc_extras; dsge_options, ABI 8): None = the library defaults, or the
+        # keyword arguments of _lib.filter_conventions (a dict; kept as a sorted tuple: Op props must hash)
+        self.conventions = _conventions_prop(conventions)
         self.solver = solver
         self.tol = tol
         self.max_iter = int(max_iter)
@@ -266,6 +283,7 @@ class HipSolveKalmanLogp(Op):
         out = batched.solve_kalman_logp_batched(
             A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, q_mode="diag_batched", solver=self.solver, tol=self.tol,
             max_iter=self.max_iter, jitter=self.jitter, missing_fill_value=self.missing_fill_value,
+            options=_conventions_options(self.conventions),
         )
         outputs[0][0] = out["logp"]
         outputs[1][0] = out["status"]
@@ -279,7 +297,8 @@ class HipSolveKalmanLogp(Op):
         A, B, C, D, q, Z, y, d, Hdiag = inputs
         g_logp = cotangents[0]
         grads = HipSolveKalmanLogpGrad(solver=self.solver, tol=self.tol, max_iter=self.max_iter, jitter=self.jitter,
-                                       missing_fill_value=self.missing_fill_value)(A, B, C, D, q, Z, y, d, Hdiag)
+                                       missing_fill_value=self.missing_fill_value,
+                                       conventions=self.conventions)(A, B, C, D, q, Z, y, d, Hdiag)
         A_bar, B_bar, C_bar, D_bar, q_bar, d_bar, h_bar = grads
         w3, w2 = g_logp[:, None, None], g_logp[:, None]
         # d / Hdiag are shared across draws: (p,) inputs receive the sum over the batch
@@ -292,10 +311,11 @@ class HipSolveKalmanLogpGrad(Op):
     """Cotangents of the fused logp Op: ``A_bar, B_bar, C_bar, D_bar, q_bar, d_bar, h_bar = Op(A, B, C, D, q, Z, y, d,
     Hdiag)`` per draw (for a unit cotangent of logp), computed by the device's reverse sweep."""
 
-    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value")
+    __props__ = ("solver", "tol", "max_iter", "jitter", "missing_fill_value", "conventions")
 
     def __init__(self, solver="cycle_reduction", tol=1e-6, max_iter=50, jitter=batched.JITTER_DEFAULT,
-                 missing_fill_value=batched.MISSING_FILL):
+                 missing_fill_value=batched.MISSING_FILL, conventions=None):
+        self.conventions = _conventions_prop(conventions)
         self.solver = solver
         self.tol = tol
         self.max_iter = int(max_iter)
@@ -324,7 +344,8 @@ class HipSolveKalmanLogpGrad(Op):
         A, B, C, D, q, Z, y, d, Hdiag = inputs
         out = batched.solve_kalman_logp_grad_batched(A, B, C, D, q, Z, y, d=d, Hdiag=Hdiag, solver=self.solver,
                                                      tol=self.tol, max_iter=self.max_iter, jitter=self.jitter,
-                                                     missing_fill_value=self.missing_fill_value)
+                                                     missing_fill_value=self.missing_fill_value,
+                                                     options=_conventions_options(self.conventions))
         for cell, key in zip(outputs, ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar")):
             cell[0] = out[key]
 

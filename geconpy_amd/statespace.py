@@ -113,7 +113,7 @@ def make_design_matrix(aug, observed_states, temporal_aggregation=None):
 
 def solve_kalman_logp_augmented_batched(A, B, C, D, Q, Z, y, aug, inv_var_order=None, d=None, Hdiag=None, q_mode=None,
                                         solver="cycle_reduction", tol=1e-6, max_iter=50, jitter=batched.JITTER_DEFAULT,
-                                        missing_fill_value=batched.MISSING_FILL, return_statespace=False):
+                                        missing_fill_value=batched.MISSING_FILL, return_statespace=False, options=None):
     """One fused evaluation per draw with the un-permutation and augmentation of
     ``DSGEStateSpace.make_symbolic_graph`` done on the device.  ``Z`` is (p, m) (``make_design_matrix``) or
     (batch, p, m); ``inv_var_order`` the (n,) permutation of statespace.py:217-220 (None = identity).
@@ -149,15 +149,16 @@ def solve_kalman_logp_augmented_batched(A, B, C, D, Q, Z, y, aug, inv_var_order=
     Ta = np.empty((nb, m, m)) if return_statespace else None
     Ra = np.empty((nb, m, k)) if return_statespace else None
     nl = batched.lead_hint(C, tol) if solver == "gensys" else 0
-    _lib.check(
-        _lib.load().dsge_solve_kalman_logp_augmented_batched_host(
-            batched._ptr(A), batched._ptr(B), batched._ptr(C), batched._ptr(D), batched._ptr(Q), code, batched._ptr(Z), zb,
-            batched._ptr(d), db, batched._ptr(Hdiag), hb, batched._ptr(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver],
-            float(tol), int(max_iter), float(jitter), float(missing_fill_value), m, batched._ptr(inv), len(lr),
-            batched._ptr(lr), batched._ptr(lc), n_state_hint, batched.selector_hint(Z), nl, batched._ptr(logp),
-            batched._ptr(status), batched._ptr(Ta), batched._ptr(Ra), batched._ptr(resid)
+    with _lib.options_scope(options):
+        _lib.check(
+            _lib.load().dsge_solve_kalman_logp_augmented_batched_host(
+                batched._ptr(A), batched._ptr(B), batched._ptr(C), batched._ptr(D), batched._ptr(Q), code, batched._ptr(Z), zb,
+                batched._ptr(d), db, batched._ptr(Hdiag), hb, batched._ptr(y), nb, n, k, p, T_len, _lib.SOLVER_CODES[solver],
+                float(tol), int(max_iter), float(jitter), float(missing_fill_value), m, batched._ptr(inv), len(lr),
+                batched._ptr(lr), batched._ptr(lc), n_state_hint, batched.selector_hint(Z), nl, batched._ptr(logp),
+                batched._ptr(status), batched._ptr(Ta), batched._ptr(Ra), batched._ptr(resid)
+            )
         )
-    )
     out = dict(logp=logp, status=status, resid=resid)
     if return_statespace:
         out.update(T_aug=Ta, R_aug=Ra)

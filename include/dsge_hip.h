@@ -33,20 +33,12 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 7
+#define DSGE_ABI_VERSION 8
 
-/* The process-wide dsge_set_* switches below are DEPRECATED since ABI 7: they edit defaults shared by every host thread and
- * every stream of the process, which is exactly what a library called from several PyMC chains must not have.  Use the per-call
- * dsge_options struct -- the *_opt entry points, or dsge_options_push / dsge_options_pop around any entry point on the calling thread --:
- * every switch is a field of that struct, and new switches (gensys_pairs, gensys_shape_cache) exist ONLY there.  The setters
- * stay exported for existing callers and will go away with the next ABI break; the library and its tests no longer call them
- * (two exceptions in the tests: dsge_set_cr_deflation, whose side effect -- forgetting the measured number of static variables --
- * has no per-call equivalent, and dsge_set_kalman_steady_tol's range check). */
-#if defined(__GNUC__) || defined(__clang__)
-#define DSGE_DEPRECATED __attribute__((deprecated("process-wide default: use the per-call dsge_options struct")))
-#else
-#define DSGE_DEPRECATED
-#endif
+/* ABI 8: the process-wide dsge_set_* switches (deprecated at ABI 7) are GONE -- they edited defaults shared by every host
+ * thread and stream of the process, which a library called from several PyMC chains must not have.  Every switch is a field
+ * of the per-call dsge_options struct (the *_opt entry points, or dsge_options_push / dsge_options_pop around any entry point
+ * on the calling thread); dsge_options_init() fills the compiled-in defaults. */
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
@@ -137,24 +129,40 @@ int dsge_scan_cycle_reduction_batched_host(const double* A, const double* B, con
                                            int max_iter, double tol, double* T_out, int32_t* status,
                                            int32_t* n_steps);
 /*
- * Per-call options ("re-entrant per stream").  Every kernel-variant switch of the library is a field
- * of this struct.  Calls that carry a dsge_options -- the *_opt twins of the fused entry points, or any entry point
- * called between dsge_options_push() and dsge_options_pop() on the same host thread -- use exactly those settings:
- * they are installed for the duration of the call on the calling thread only, so two host threads (two PyMC / nutpie
- * chains, two pytensor Ops, two streams) never see each other's settings.  The dsge_set_* functions below only edit
- * the process-wide DEFAULTS that calls without options use (configure-once; dsge_options_init() copies them).
- *   struct_size        : sizeof(dsge_options) of the caller's build (set by dsge_options_init; checked)
- *   cr_compact         : see dsge_set_cr_compact            cr_fused_selection : see dsge_set_cr_fused_selection
- *   cr_deflation       : see dsge_set_cr_deflation          cr_two_waves       : see dsge_set_cr_two_waves
- *   n_static_hint      : number of static variables of the model (columns of A and C both exactly zero), a property of
- *                        the model like n_state_hint, verified per draw on the device; with a value >= 0 the fused call
- *                        is a pure enqueue (stream-capturable); -1 (default) measures it on the device on the first
- *                        call of a model size: one small launch, a 4-byte read-back and a stream synchronisation
- *   kalman_nt_products  : see dsge_set_kalman_nt_products       cr_fused_deflation : see dsge_set_cr_fused_deflation
- *   cr_four_waves       : see dsge_set_cr_four_waves       gensys_real_stage  : see dsge_set_gensys_real_stage
- *   kalman_order, kalman_tiny, kalman_block, kalman_mfma, pipeline_chunks, gensys_split, kalman_steady_tol :
- *                        see the dsge_set_* function of the same name
+ * Per-call options ("re-entrant per stream").  Every kernel-variant switch of the library and every
+ * third-party CONVENTION of the filter step is a field of this struct.  Calls that carry a dsge_options -- the *_opt twins of
+ * the fused entry points, or any entry point called between dsge_options_push() and dsge_options_pop() on the same host
+ * thread -- use exactly those settings: they are installed for the duration of the call on the calling thread only, so two
+ * host threads (two PyMC / nutpie chains, two pytensor Ops, two streams) never see each other's settings.  Calls without
+ * options use the compiled-in defaults (what dsge_options_init() fills in); there is no process-wide mutable state.
+ *   struct_size : sizeof(dsge_options) of the caller's build (set by dsge_options_init; checked)
+ *   n_static_hint : number of static variables of the model (columns of A and C both exactly zero), a property of the model
+ *                   like n_state_hint, verified per draw on the device; with a value >= 0 the fused call is a pure enqueue
+ *                   (stream-capturable); -1 (default) measures it on the device on the first call of a model size: one small
+ *                   launch, a 4-byte read-back and a stream synchronisation (dsge_forget_measured_shapes() drops the record)
+ *   the kernel-variant switches are documented one by one below the struct.
+ *
+ * Filter conventions (ABI 8).  The "standard" filter step of the reference lives in third-party pymc_extras
+ * (PyMCStateSpace.build_statespace_graph, reached from gEconpy/model/statespace.py:1143-1157); its constants cannot be pinned
+ * in the build image, so NONE of them is compiled into a kernel: every filter kernel (fast, selector, tiny, tail, general,
+ * per-step outputs, gradient, second order) takes them as run-time values.  oracle.FilterConventions has the same switches,
+ * tests/test_gpu_conventions.py checks every combination against it, and tests/test_oracle_kalman.py::test_pymc_extras_pin
+ * names the combination a real install matches -- which is then set here, without touching a kernel:
+ *   ll_constant : DSGE_LL_CONST_P (default) ll_t = -1/2 (p ln 2pi + ln det F + v' F^-1 v) with p the FULL observation
+ *                 dimension, also when entries are missing; DSGE_LL_CONST_OBSERVED: (#observed entries of y_t) ln 2pi;
+ *                 DSGE_LL_CONST_ONE: a single ln 2pi per step (older upstream StandardFilter.update)
+ *   jitter_F    : added to the diagonal of F = Zm P Zm' + Hm; < 0 (default -1): the `jitter` argument of the call
+ *   jitter_P    : added to the diagonal of the filtered covariance P+;  < 0 (default -1): the `jitter` argument of the call
+ *                 (the reference passes ONE cov_jitter for both, statespace.py:1144; 0 switches an addition off)
+ *   mask_d      : 1: the observation intercept d is zeroed on missing entries; 0 (default): d is NOT masked, a missing entry
+ *                 contributes ln(jitter_F) + d_i^2 / jitter_F to ll_t
+ *   joseph      : 1 (default): Joseph form P+ = (I - K Zm) P (I - K Zm)' + K Hm K' (+ jitter_P I); 0: P+ = P - K F K'.  The
+ *                 two differ by jitter_F K K' (expand with K F = P Zm'): the kernels compute P+ = P - K (P Zm' + j K)' with
+ *                 j = jitter_F or 0
  */
+#define DSGE_LL_CONST_P 0
+#define DSGE_LL_CONST_OBSERVED 1
+#define DSGE_LL_CONST_ONE 2
 typedef struct dsge_options {
   uint32_t struct_size;
   int32_t cr_compact;
@@ -172,8 +180,7 @@ typedef struct dsge_options {
   int32_t kalman_nt_products;
   int32_t cr_fused_deflation;
   int32_t cr_four_waves;
-  int32_t gensys_real_stage; /* (the slot was reserved_ up to ABI 4 builds: same size, same offsets) */
-  /* ABI 7 (no dsge_set_* twin: per call only; dsge_options_init fills the defaults) */
+  int32_t gensys_real_stage;
   int32_t gensys_pairs;       /* 1 (default): window path, real double-shift sweeps with TWO draws per wavefront when the window
                                  and #lead are <= 32 (dsge_gensys_pair.hpp); 0: one draw per wavefront (round 3); 2: also the
                                  Hessenberg-triangular launch on two draws per wavefront (measured slower: experiment) */
@@ -189,25 +196,106 @@ typedef struct dsge_options {
                                  quasi-triangular window are triangularised in closed form (a root of the 2 x 2 pencil, its null
                                  vector, two rotations), checked, and zhgeqz's iteration runs only when something is left for
                                  it; 0: the complex single-shift iteration splits them (round 3) */
+  /* ABI 8: conventions of the filter step (see above) */
+  int32_t ll_constant;
+  int32_t mask_d;
+  int32_t joseph;
+  int32_t reserved0_;
+  double jitter_F;
+  double jitter_P;
   int32_t reserved_[4];
 } dsge_options;
-/* fills *opt with the current process-wide defaults */
+/* fills *opt with the compiled-in defaults */
 int dsge_options_init(dsge_options* opt);
 /* install / remove *opt for the calls THIS host thread makes in between (nests; copied, the caller may free it) */
 int dsge_options_push(const dsge_options* opt);
 int dsge_options_pop(void);
+/* Drops every record the library measured on the device and reuses across calls: the number of static variables per model size
+ * (dsge_options.n_static_hint = -1) and the capacity records of the gensys window path (dsge_options.gensys_shape_cache).  The
+ * next call of each model size measures again.  For callers that change the model behind a fixed size, and for the tests. */
+int dsge_forget_measured_shapes(void);
 
-/* Cycle reduction runs on the column-compact form [A[:,S] | C[:,L]] (S, L = non-zero columns of A and C,
+/* ---- the kernel-variant switches of dsge_options, one by one (none of them changes a result beyond rounding) ---- */
+/* dsge_options.cr_compact: Cycle reduction runs on the column-compact form [A[:,S] | C[:,L]] (S, L = non-zero columns of A and C,
  * detected per draw on the device; zero columns only ever contribute +0.0, so T is bit-identical) whenever
  * |S| + |L| <= 8*ceil(n/8); other draws take the dense kernel.  enable = 0 forces the dense kernel for every
- * draw (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
-DSGE_DEPRECATED int dsge_set_cr_compact(int enable);
-/* In the fused entry points with solver = cycle_reduction and no residual requested, R = -(C T + B)^-1 D is taken
+ * draw (used by the tests to compare the two). default 1. */
+/* dsge_options.cr_fused_selection: In the fused entry points with solver = cycle_reduction and no residual requested, R = -(C T + B)^-1 D is taken
  * from the final elimination of cycle reduction: T = -A1_hat^-1 A and A1_hat -> B + C T (the difference is of the
  * order of the product of the last iterate's norms, < tol^2), so R = -A1_hat^-1 D comes out of the same Gauss-Jordan
  * sweep (agreement with the explicit formula ~1e-13 relative, tests/test_gpu_parity.py).  enable = 0 always uses the
- * explicit formula in the assemble kernel.  Process-wide DEFAULT (per call: dsge_options); default 1. */
-DSGE_DEPRECATED int dsge_set_cr_fused_selection(int enable);
+ * explicit formula in the assemble kernel. default 1. */
+/* dsge_options.kalman_steady_tol:
+ * Steady-state switch of the fast Kalman kernel.  The covariance recursion of a time-invariant model
+ * does not depend on the data; once max|P_{t+1|t} - P_{t|t-1}| <= tol * max|P| (and while the
+ * missing-data mask stays the same) the kernel reuses F^-1, K and det F and runs only the mean
+ * recursion; a step with a different mask resumes the full update.  tol = 0 never switches (the
+ * recursion of pymc_extras' "standard" filter step for step); the default 1e-14 is rounding level:
+ * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  tol in [0, 1e-6]. */
+/* dsge_options.kalman_tiny: Small models (selector Z, p <= 3, at most 6 filtered variables) are filtered by a thread-per-draw kernel that keeps
+ * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
+ * wave-per-draw kernels (used by the tests to compare the two). default 1. */
+/* dsge_options.kalman_nt_products: Selector design matrix, p <= 8: the two prediction products of a full filter step run in "NT" form on 16-byte aligned
+ * rows (W stored transposed, even leading dimension, one ds_read_b128 per two k-steps, stages of four k-steps double-
+ * buffered; dsge_kalman_nt.hpp): 15.2 k -> 12.6 k cycles per full step on the 18-variable bench model.  enable = 0 keeps
+ * the round-1 kernel (kalman_sel_kernel); same arithmetic up to the summation order of the products (tests compare them).
+ * default 1. */
+/* dsge_options.cr_fused_deflation: Static-variable deflation (cr_deflation) as ONE launch: QR of the static columns, cycle reduction on the reduced
+ * system and the back-substitution of the static rows in a single kernel, the reduced system handed over through LDS
+ * (dsge_cr_fused.hpp) instead of three launches with the reduced A, B, C, D, T, R in global memory.  Taken when
+ * h + 3 (n - h) + k <= 128 and (n - h) + k <= 64; otherwise, and with enable = 0, the three launches run.  Same results
+ * (the arithmetic is the same code). default 1. */
+/* dsge_options.cr_four_waves: Cycle reduction on systems of 49..64 variables (after the deflation, if any) runs on FOUR wavefronts per draw
+ * (cr_wide_kernel, dsge_cr_wide.hpp: 16 x 16 threads with 4 x 4 register blocks, the panel factorisation on one of the
+ * wavefronts) instead of one wavefront with 7 x 7 / 8 x 8 blocks that spill.  enable = 0 keeps the one-wavefront kernels
+ * (same algorithm; the norms of the stopping rule are summed in a different order).  default 1. */
+/* dsge_options.cr_deflation: Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
+ * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
+ * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by
+ * back-substitution (dsge_cr_deflate.hpp).  Same solution (it is unique), (n - h)^3 instead of n^3 work per iteration.
+ * h is measured once per model size (a small launch and a 4-byte read-back on the first call) and verified per draw; a
+ * draw with fewer static variables is solved by the full-size kernels.  Not used when the caller asks for the iteration
+ * counts or the policy residual.  enable = 0 switches it off (dsge_forget_measured_shapes() drops the measured sizes).  Default on. */
+/* dsge_options.cr_two_waves: Column-compact cycle reduction on the 32-wide tile (n or n - h in 25..32): the kernel instance built for two waves per SIMD
+ * (256 registers + 528 B of scratch instead of 369 registers): same arithmetic, bit-identical results, 10 % faster.
+ * enable = 0 launches the one-wave instance.  Default on. */
+/* dsge_options.kalman_order: Fused evaluation: the workgroups of the Kalman launch (and of the gradient path's reverse-sweep launch) are dispatched in
+ * descending order of a per-draw key (a counting sort on the device).  The launch's makespan is set by its slowest draws --
+ * a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for up to T_len
+ * full steps -- so the likely slow draws start first instead of wherever their index puts them (3.29 -> 2.86 ms per 4096
+ * SW-shaped draws).  mode 1 (default): key = the draw's cycle-reduction iteration count (free; both grow with the persistence
+ * of the model), for the other solvers a spectral-radius estimate of T (24 power-iteration steps, persistence_key_kernel);
+ * mode 2: always the latter; mode 0: index order.  Results are unaffected: every draw writes its own logp / status. */
+/* dsge_options.pipeline_chunks: dsge_solve_kalman_logp_batched (device pointers) runs batches of >= 1024 draws as n_chunks chunks alternating over two
+ * library-owned streams, forked from and joined to the caller's stream by events, so that the straggler tail of one
+ * chunk's Kalman launch (a draw whose covariance recursion converges late keeps one wavefront busy for up to T_len full
+ * steps) overlaps the solver launch of the next chunk.  Results are identical (the kernels are per-draw).  n_chunks < 2:
+ * one pass on the caller's stream (the default: on MI355X the chunks' launches did not overlap enough to pay for the
+ * extra straggler tails). */
+/* dsge_options.kalman_block: Experimental, OFF by default: once the covariance is frozen and the missing-data mask of the shared panel no longer
+ * changes, the fast Kalman kernel hands the rest of the sample to kalman_tail_kernel, which runs the (then linear) mean
+ * recursion two steps at a time as one matrix-vector product [R v_t; R v_{t+1}; a_{t+2}] = M [a_t; c_t; c_{t+1}], R'R = F^-1,
+ * rows in registers.  It removes a quarter of the kernel's work but not its makespan, which is set by the draws that reach
+ * the steady state late or never -- measured 3.14 vs 2.85 ms per 4096 draws with the launch's extra 0.26 ms (DESIGN.md
+ * 4.3).  enable = 1 switches it on (tests compare both: same logp to 1e-12). */
+/* dsge_options.gensys_split: gensys runs as five launches on the active window of the pencil -- structural deflation; real Hessenberg-triangular
+ * reduction and complex QZ + reordering on the (N - z) x (N - z) block the deflation leaves, with H and T sharing one LDS
+ * array and the accumulated right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing --
+ * 4 / 6 / 6-7 / 10 / 2 draws per CU instead of 1 at N = 52.  enable = 1
+ * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
+ * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both). */
+/* dsge_options.gensys_real_stage: Window path of gensys: implicit double-shift QZ sweeps in REAL arithmetic (Moler-Stewart) at the end of the
+ * Hessenberg-triangular launch, in front of the complex single-shift iteration that reproduces zhgeqz's logic (which then only
+ * splits the remaining 2 x 2 blocks).  An accelerator: every step is an orthogonal equivalence, T and eu are the same to
+ * rounding (test_gensys_real_stage_matches_complex_only).  enable = 0: complex iteration only (round 1-2 behaviour).
+ * default 1. */
+/* dsge_options.kalman_mfma: The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
+ * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
+ * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
+ * per 4096-draw step) -- FP64 MFMA has the VALU's peak rate on gfx950, the 18-wide reduced model does not fill a
+ * 16 x 16 fragment, and the accumulator + operand registers push the 256-VGPR kernel into spills (DESIGN.md 4.3).
+ * enable = 1 switches it on (tests compare both). */
+
 /* Debug hook: enable != 0 makes the compact cycle-reduction kernel record the shader cycles draw 0 spends in
  * [0] Gauss-Jordan panels, [1] trailing updates, [2] row gather + staging, [3] products, [4] scatter/updates/
  * norms, [5] the final solve, [6] total, [7] = iterations; cycles_out (host int64[8], may be NULL). */
@@ -317,92 +405,6 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
                                      double* eig_re, double* eig_im, int32_t* n_eig, int32_t* n_forward,
                                      int32_t* n_unstable, int32_t* status);
 
-/*
- * Steady-state switch of the fast Kalman kernel.  The covariance recursion of a time-invariant model
- * does not depend on the data; once max|P_{t+1|t} - P_{t|t-1}| <= tol * max|P| (and while the
- * missing-data mask stays the same) the kernel reuses F^-1, K and det F and runs only the mean
- * recursion; a step with a different mask resumes the full update.  tol = 0 never switches (the
- * recursion of pymc_extras' "standard" filter step for step); the default 1e-14 is rounding level:
- * logp moves by < 1e-12 relative (tests/test_gpu_parity.py).  Process-wide DEFAULT (per call: dsge_options).  tol in [0, 1e-6].
- */
-DSGE_DEPRECATED int dsge_set_kalman_steady_tol(double tol);
-/* Small models (selector Z, p <= 3, at most 6 filtered variables) are filtered by a thread-per-draw kernel that keeps
- * the whole reduced state space in registers (64 draws per wavefront).  enable = 0 routes every draw through the
- * wave-per-draw kernels (used by the tests to compare the two).  Process-wide DEFAULT (per call: dsge_options); default 1. */
-DSGE_DEPRECATED int dsge_set_kalman_tiny(int enable);
-/* Selector design matrix, p <= 8: the two prediction products of a full filter step run in "NT" form on 16-byte aligned
- * rows (W stored transposed, even leading dimension, one ds_read_b128 per two k-steps, stages of four k-steps double-
- * buffered; dsge_kalman_nt.hpp): 15.2 k -> 12.6 k cycles per full step on the 18-variable bench model.  enable = 0 keeps
- * the round-1 kernel (kalman_sel_kernel); same arithmetic up to the summation order of the products (tests compare them).
- * Process-wide DEFAULT (per call: dsge_options); default 1. */
-DSGE_DEPRECATED int dsge_set_kalman_nt_products(int enable);
-/* Static-variable deflation (dsge_set_cr_deflation) as ONE launch: QR of the static columns, cycle reduction on the reduced
- * system and the back-substitution of the static rows in a single kernel, the reduced system handed over through LDS
- * (dsge_cr_fused.hpp) instead of three launches with the reduced A, B, C, D, T, R in global memory.  Taken when
- * h + 3 (n - h) + k <= 128 and (n - h) + k <= 64; otherwise, and with enable = 0, the three launches run.  Same results
- * (the arithmetic is the same code).  Process-wide DEFAULT (per call: dsge_options); default 1. */
-DSGE_DEPRECATED int dsge_set_cr_fused_deflation(int enable);
-/* Cycle reduction on systems of 49..64 variables (after the deflation, if any) runs on FOUR wavefronts per draw
- * (cr_wide_kernel, dsge_cr_wide.hpp: 16 x 16 threads with 4 x 4 register blocks, the panel factorisation on one of the
- * wavefronts) instead of one wavefront with 7 x 7 / 8 x 8 blocks that spill.  enable = 0 keeps the one-wavefront kernels
- * (same algorithm; the norms of the stopping rule are summed in a different order).  Process-wide DEFAULT (per call:
- * dsge_options); default 1. */
-DSGE_DEPRECATED int dsge_set_cr_four_waves(int enable);
-/* Fused evaluation with solver = cycle reduction: variables whose columns of A and C are both exactly zero ("static" in
- * Dynare's partition) are eliminated by a Householder QR of their columns of B before the iteration, which then runs on
- * the n - h dynamic variables (30 of 40 on the SW-shaped systems, 20 of 24 on full_nk); their rows of T and R follow by
- * back-substitution (dsge_cr_deflate.hpp).  Same solution (it is unique), (n - h)^3 instead of n^3 work per iteration.
- * h is measured once per model size (a small launch and a 4-byte read-back on the first call) and verified per draw; a
- * draw with fewer static variables is solved by the full-size kernels.  Not used when the caller asks for the iteration
- * counts or the policy residual.  enable = 0 switches it off and forgets the measured sizes.  Default on.  Process-wide DEFAULT (per call: dsge_options). */
-DSGE_DEPRECATED int dsge_set_cr_deflation(int enable);
-/* Column-compact cycle reduction on the 32-wide tile (n or n - h in 25..32): the kernel instance built for two waves per SIMD
- * (256 registers + 528 B of scratch instead of 369 registers): same arithmetic, bit-identical results, 10 % faster.
- * enable = 0 launches the one-wave instance.  Default on.  Process-wide DEFAULT (per call: dsge_options). */
-DSGE_DEPRECATED int dsge_set_cr_two_waves(int enable);
-/* Fused evaluation: the workgroups of the Kalman launch (and of the gradient path's reverse-sweep launch) are dispatched in
- * descending order of a per-draw key (a counting sort on the device).  The launch's makespan is set by its slowest draws --
- * a persistent model reaches the steady state of the covariance recursion late and keeps one wavefront busy for up to T_len
- * full steps -- so the likely slow draws start first instead of wherever their index puts them (3.29 -> 2.86 ms per 4096
- * SW-shaped draws).  mode 1 (default): key = the draw's cycle-reduction iteration count (free; both grow with the persistence
- * of the model), for the other solvers a spectral-radius estimate of T (24 power-iteration steps, persistence_key_kernel);
- * mode 2: always the latter; mode 0: index order.  Results are unaffected: every draw writes its own logp / status. */
-DSGE_DEPRECATED int dsge_set_kalman_order(int mode);
-/* dsge_solve_kalman_logp_batched (device pointers) runs batches of >= 1024 draws as n_chunks chunks alternating over two
- * library-owned streams, forked from and joined to the caller's stream by events, so that the straggler tail of one
- * chunk's Kalman launch (a draw whose covariance recursion converges late keeps one wavefront busy for up to T_len full
- * steps) overlaps the solver launch of the next chunk.  Results are identical (the kernels are per-draw).  n_chunks < 2:
- * one pass on the caller's stream (the default: on MI355X the chunks' launches did not overlap enough to pay for the
- * extra straggler tails).  Process-wide DEFAULT (per call: dsge_options). */
-DSGE_DEPRECATED int dsge_set_pipeline_chunks(int n_chunks);
-/* Experimental, OFF by default: once the covariance is frozen and the missing-data mask of the shared panel no longer
- * changes, the fast Kalman kernel hands the rest of the sample to kalman_tail_kernel, which runs the (then linear) mean
- * recursion two steps at a time as one matrix-vector product [R v_t; R v_{t+1}; a_{t+2}] = M [a_t; c_t; c_{t+1}], R'R = F^-1,
- * rows in registers.  It removes a quarter of the kernel's work but not its makespan, which is set by the draws that reach
- * the steady state late or never -- measured 3.14 vs 2.85 ms per 4096 draws with the launch's extra 0.26 ms (DESIGN.md
- * 4.3).  enable = 1 switches it on (tests compare both: same logp to 1e-12).  Process-wide DEFAULT (per call: dsge_options). */
-DSGE_DEPRECATED int dsge_set_kalman_block(int enable);
-/* gensys runs as five launches on the active window of the pencil -- structural deflation; real Hessenberg-triangular
- * reduction and complex QZ + reordering on the (N - z) x (N - z) block the deflation leaves, with H and T sharing one LDS
- * array and the accumulated right transformation kept in HBM/L2; existence/uniqueness (Jacobi SVD); post-processing --
- * 4 / 6 / 6-7 / 10 / 2 draws per CU instead of 1 at N = 52.  enable = 1
- * (default): window path unless the pencil is small (single-launch kernel <= 24 KB of LDS: RBC-sized models) or does not
- * fit; 2: window path whenever it fits; 0: single-launch kernel (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
-DSGE_DEPRECATED int dsge_set_gensys_split(int enable);
-/* Window path of gensys: implicit double-shift QZ sweeps in REAL arithmetic (Moler-Stewart) at the end of the
- * Hessenberg-triangular launch, in front of the complex single-shift iteration that reproduces zhgeqz's logic (which then only
- * splits the remaining 2 x 2 blocks).  An accelerator: every step is an orthogonal equivalence, T and eu are the same to
- * rounding (test_gensys_real_stage_matches_complex_only).  enable = 0: complex iteration only (round 1-2 behaviour).
- * Process-wide DEFAULT (per call: dsge_options.gensys_real_stage); default 1. */
-DSGE_DEPRECATED int dsge_set_gensys_real_stage(int enable);
-/* The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
- * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
- * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
- * per 4096-draw step) -- FP64 MFMA has the VALU's peak rate on gfx950, the 18-wide reduced model does not fill a
- * 16 x 16 fragment, and the accumulator + operand registers push the 256-VGPR kernel into spills (DESIGN.md 4.3).
- * enable = 1 switches it on (tests compare both).  Process-wide DEFAULT (per call: dsge_options). */
-DSGE_DEPRECATED int dsge_set_kalman_mfma(int enable);
-double dsge_get_kalman_steady_tol(void);
 /* Debug hook: device int32[batch] that later fast-path Kalman launches (and the second-order filter) fill with the first
  * time step that ran in steady-state mode (-1 = never); NULL stops recording. */
 int dsge_debug_kalman_steady_steps(int32_t* steady_at_device);
@@ -728,7 +730,7 @@ int dsge_solve_kalman_logp_grad_dense_z_batched_host(const double* A, const doub
                                                      double* d_bar, double* h_bar, double* Z_bar);
 
 /*
- * The fused entry points with per-call options (opt == NULL: the process-wide defaults); otherwise identical to the
+ * The fused entry points with per-call options (opt == NULL: the compiled-in defaults); otherwise identical to the
  * functions of the same name without the suffix.
  */
 int dsge_solve_kalman_logp_batched_opt(const dsge_options* opt, const double* A, const double* B, const double* C,

@@ -290,7 +290,7 @@ def pruned_design(Z, d, U, m):
     return Za
 
 
-def pruned_kalman_logp(T, R, sol, Sigma, Z, y, H=None, d=None, jitter=None, return_parts=False):
+def pruned_kalman_logp(T, R, sol, Sigma, Z, y, H=None, d=None, jitter=None, return_parts=False, conventions=None):
     """Gaussian quasi-likelihood of the pruned second-order system: the "standard" filter (oracle.statespace) on the reduced
     augmented state, started from its stationary mean and covariance."""
     import scipy.linalg as sla
@@ -302,12 +302,12 @@ def pruned_kalman_logp(T, R, sol, Sigma, Z, y, H=None, d=None, jitter=None, retu
     Za = pruned_design(np.asarray(Z, dtype=np.float64), d, ps["U"], ps["m"])
     P0 = sla.solve_discrete_lyapunov(ps["Az"], ps["Qz"])
     lp = kalman_filter_logp(y, ps["Az"], np.eye(ps["m"]), ps["Qz"], Za, H=H, d=d, c=ps["c"], a0=ps["mean"], P0=P0,
-                            jitter=JITTER_DEFAULT if jitter is None else jitter)
+                            jitter=JITTER_DEFAULT if jitter is None else jitter, conventions=conventions)
     return (lp, ps, P0) if return_parts else lp
 
 
 def solve_second_order_logp(A, B, C, D, hess_idx, hess_val, Sigma, Z, y, H=None, d=None, tol=1e-8, max_iter=1000,
-                            jitter=None):
+                            jitter=None, conventions=None):
     """One full second-order evaluation (BASELINE configs[4]): A,B,C,D -> T,R (cycle reduction) -> g_yy, g_yu, g_uu, g_ss
     -> pruned state space -> quasi log-likelihood.  -> dict(logp, T, R, sol)."""
     from .cycle_reduction import cycle_reduction_core
@@ -319,5 +319,5 @@ def solve_second_order_logp(A, B, C, D, hess_idx, hess_val, Sigma, Z, y, H=None,
     Rm = compute_selection_matrix(B, C, D, Tm)
     S = np.flatnonzero((A != 0).any(axis=0))
     sol = second_order_solution_reduced(B, C, Tm, Rm, hess_idx, hess_val, Sigma, S=S)
-    lp = pruned_kalman_logp(Tm, Rm, sol, Sigma, Z, y, H=H, d=d, jitter=jitter)
+    lp = pruned_kalman_logp(Tm, Rm, sol, Sigma, Z, y, H=H, d=d, jitter=jitter, conventions=conventions)
     return dict(logp=lp, T=Tm, R=Rm, sol=sol)

@@ -179,6 +179,7 @@ def solve_kalman_logp(
     missing_fill_value=MISSING_FILL,
     inv_var_order=None,
     add_solver_success_check=True,
+    conventions=None,
 ):
     """One full evaluation: A,B,C,D -> T,R -> P0 -> logp (SURVEY.md §3 A hot loop).
 
@@ -219,7 +220,7 @@ def solve_kalman_logp(
         Rm = Rm[inv_var_order]
     P0 = solve_discrete_lyapunov(Tm, Rm @ Q @ Rm.T)
     out["logp"] = kalman_filter_logp(
-        y, Tm, Rm, Q, Z, H=H, d=d, P0=P0, jitter=jitter, missing_fill_value=missing_fill_value
+        y, Tm, Rm, Q, Z, H=H, d=d, P0=P0, jitter=jitter, missing_fill_value=missing_fill_value, conventions=conventions
     )
     out.update(T=Tm, R=Rm, P0=P0)
     return out

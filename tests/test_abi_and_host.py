@@ -137,7 +137,7 @@ def test_draw_seeding_is_shard_independent():
 
 
 def test_options_struct_defaults_and_scope():
-    """dsge_options (per-call switches): init copies the process-wide defaults, unknown fields are refused, the
+    """dsge_options (per-call switches): init fills the compiled-in defaults, unknown fields are refused, the
     push/pop scope is balanced per thread -- no GPU needed."""
     import ctypes
 
@@ -163,9 +163,15 @@ def test_options_struct_defaults_and_scope():
     bad.kalman_steady_tol = 1e-14
     bad.struct_size = 8
     assert lib.dsge_options_push(ctypes.addressof(bad)) != 0
-    # the setters edit the defaults new option structs start from
-    lib.dsge_set_kalman_steady_tol(1e-12)
-    try:
-        assert _lib.make_options().kalman_steady_tol == 1e-12
-    finally:
-        lib.dsge_set_kalman_steady_tol(1e-14)
+    # ABI 8: no process-wide setters any more -- the defaults are compiled in
+    assert not any(name.startswith("dsge_set_") and name != "dsge_set_device" for name in _lib.PROTOTYPES)
+    assert not hasattr(lib, "dsge_set_kalman_steady_tol") and not hasattr(lib, "dsge_set_cr_deflation")
+    # ... and the conventions of the filter step are fields of the same struct
+    assert (o.ll_constant, o.mask_d, o.joseph, o.jitter_F, o.jitter_P) == (0, 0, 1, -1.0, -1.0)
+    o3 = _lib.make_options(_lib.filter_conventions(ll_constant="one", jitter_on_P=False, mask_d=True, joseph=False))
+    assert (o3.ll_constant, o3.mask_d, o3.joseph, o3.jitter_F, o3.jitter_P) == (2, 1, 0, -1.0, 0.0)
+    assert _lib.make_options(ll_constant="observed").ll_constant == 1
+    bad = _lib.make_options()
+    bad.ll_constant = 3
+    assert lib.dsge_options_push(ctypes.addressof(bad)) != 0
+    assert lib.dsge_forget_measured_shapes() == 0  # (host-side records only: no GPU needed)

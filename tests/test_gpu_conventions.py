@@ -1,0 +1,315 @@
+"""The third-party conventions of the "standard" filter step (pymc_extras' StandardFilter, reached from
+gEconpy/model/statespace.py:1143-1157) are RUN-TIME options of the C ABI (dsge_options.ll_constant / jitter_F / jitter_P / mask_d /
+joseph, ABI 8): for every combination ``oracle.FilterConventions`` can express, every filter kernel of the library must reproduce
+the oracle under that combination -- so that the day ``tests/golden/pymc_extras_kalman.npz`` exists, matching the reference is the
+configuration ``test_pymc_extras_pin`` names (``_lib.filter_conventions(**that)``), with zero kernel edits.
+
+Models: SW-shaped draws 0 and 752 (the nearly singular one), the RBC model; data: complete / 10 % scattered NaN / a missing
+period + fill markers; d != 0 throughout (so that ``mask_d`` matters).  A combination without the jitter on F is undefined under
+missing data in the reference itself (F is singular: the masked rows of Z and H are zero) and is checked on complete data only."""
+import itertools
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from geconpy_amd import _lib, batched
+from geconpy_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+TOTAL_RTOL = 1e-10   # total log-likelihood, relative
+STEP_TOL = 1e-10     # per-step ll_t: |hip - oracle| <= STEP_TOL * max(1, |oracle|)
+
+ALL = [dict(ll_constant=c, jitter_on_F=jf, jitter_on_P=jp, mask_d=md, joseph=js)
+       for c, jf, jp, md, js in itertools.product(("p", "observed", "one"), (True, False), (True, False), (False, True), (True, False))]
+
+
+def _id(cv):
+    return "-".join([cv["ll_constant"], "F" if cv["jitter_on_F"] else "noF", "P" if cv["jitter_on_P"] else "noP",
+                     "maskd" if cv["mask_d"] else "d", "joseph" if cv["joseph"] else "plain"])
+
+
+def _data_variants(y, rng):
+    comp = y.copy()
+    scat = y.copy()
+    scat[rng.random(scat.shape) < 0.10] = np.nan
+    scat[3, :] = np.nan  # and one step with nothing observed
+    per = y.copy()
+    per[40:60, :] = np.nan       # a missing period: every entry of twenty steps
+    per[80:120, 1] = np.nan      # one series missing for a while (constant mask: the steady-state path resumes under it)
+    per[130, 0] = oracle.MISSING_FILL
+    per[131, :] = oracle.MISSING_FILL
+    return {"complete": comp, "scattered": scat, "period": per}
+
+
+@pytest.fixture(scope="module")
+def sw_case():
+    """SW-shaped draws 0 and 752: T, R from the oracle's cycle reduction (the conventions concern the filter only)."""
+    sysm = [wl.sw_shaped_system(wl.SW_SEED0 + i) for i in (0, 752)]
+    A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    sig = np.stack([wl.sw_shaped_batch(1, first_draw=i)["sigma"][0] for i in (0, 752)])
+    om = wl.sw_shaped_observation_model()
+    T = np.stack([oracle.cycle_reduction_core(A[i], B[i], C[i], 1000, 1e-13)[0] for i in range(2)])
+    R = np.stack([oracle.compute_selection_matrix(B[i], C[i], D[i], T[i]) for i in range(2)])
+    rng = np.random.default_rng(8)
+    d = rng.normal(0, 0.01, 7)
+    return dict(A=A, B=B, C=C, D=D, T=T, R=R, q=sig ** 2, Z=om["Z"], H=om["Hdiag"], d=d, data=_data_variants(om["y"], rng))
+
+
+@pytest.fixture(scope="module")
+def rbc_case():
+    nb = 3
+    th = wl.rbc_prior_draws(nb, seed=4)
+    A, B, C, D = wl.rbc_linearized_jacobians(**th)
+    T = np.stack([oracle.cycle_reduction_core(A[i], B[i], C[i], 1000, 1e-13)[0] for i in range(nb)])
+    R = np.stack([oracle.compute_selection_matrix(B[i], C[i], D[i], T[i]) for i in range(nb)])
+    Z = np.zeros((3, 8))
+    for o, name in enumerate(("Y", "C", "L")):
+        Z[o, wl.RBC_VARIABLES.index(name)] = (1.0, 0.5, -2.0)[o]
+    rng = np.random.default_rng(9)
+    y = rng.normal(0, 0.05, (120, 3))
+    return dict(A=A, B=B, C=C, D=D, T=T, R=R, q=(th["sigma_A"] ** 2)[:, None], Z=Z, H=np.array([1e-4, 2e-4, 1e-4]),
+                d=np.array([0.01, -0.02, 0.015]), data=_data_variants(y, rng))
+
+
+def _oracle(case, i, y, cv, per_step=False):
+    return oracle.kalman_filter_logp(y, case["T"][i], case["R"][i], np.diag(case["q"][i]), case["Z"], H=np.diag(case["H"]),
+                                     d=case["d"], conventions=oracle.FilterConventions(**cv), return_per_step=per_step)
+
+
+def _variants_for(cv):
+    return ("complete", "scattered", "period") if cv["jitter_on_F"] else ("complete",)
+
+
+# the routes of dsge_kalman_logp_batched: (label, options, hints)
+SW_ROUTES = [
+    ("nt", {}, {}),                                            # kalman_nt_kernel<3, false, 24> (the headline kernel)
+    ("sel", {"kalman_nt_products": 0}, {}),                    # kalman_sel_kernel<3, true>
+    ("sel+tail", {"kalman_nt_products": 0, "kalman_block": 1}, {}),   # ... handing the steady tail to kalman_tail_kernel
+    ("general", {}, {"n_state_hint": 0, "z_selector_hint": 0}),  # no hints: kalman_sel_kernel<5, false> dense-Z fast path
+    ("steady_off", {"kalman_steady_tol": 0.0}, {}),            # the full recursion, step for step
+]
+RBC_ROUTES = [
+    ("tiny", {}, {}),                                          # kalman_tiny_kernel
+    ("nt", {"kalman_tiny": 0}, {}),                            # wave-per-draw fast path on the 8-wide tile
+    ("sel", {"kalman_tiny": 0, "kalman_nt_products": 0}, {}),
+]
+
+
+def _run_routes(case, routes, cv):
+    opts_cv = _lib.filter_conventions(**cv)
+    for name in _variants_for(cv):
+        y = case["data"][name]
+        nb = case["T"].shape[0]
+        ref = np.array([_oracle(case, i, y, cv) for i in range(nb)])
+        assert np.all(np.isfinite(ref)), (name, ref)
+        for label, opts, hints in routes:
+            logp, st = batched.kalman_logp_batched(case["T"], case["R"], case["q"], case["Z"], y, d=case["d"], Hdiag=case["H"],
+                                                   q_mode="diag_batched", options={**opts, **opts_cv}, **hints)
+            assert np.all(st == 0), (name, label, st)
+            assert_allclose(logp, ref, rtol=TOTAL_RTOL, err_msg=f"{_id(cv)} {name} route={label}")
+
+
+@pytest.mark.parametrize("cv", ALL, ids=_id)
+def test_sw_fast_kernels_follow_every_convention(sw_case, cv):
+    _run_routes(sw_case, SW_ROUTES, cv)
+
+
+@pytest.mark.parametrize("cv", ALL, ids=_id)
+def test_rbc_kernels_follow_every_convention(rbc_case, cv):
+    _run_routes(rbc_case, RBC_ROUTES, cv)
+
+
+@pytest.mark.parametrize("cv", ALL, ids=_id)
+def test_general_kernel_follows_every_convention(sw_case, cv):
+    """kalman_kernel (the last resort of the cascade: Cholesky of F, no state reduction) -- reached with p > 8 observed series, here
+    nine of them on the SW-shaped transition."""
+    rng = np.random.default_rng(21)
+    p = 9
+    Z = np.zeros((p, 40))
+    Z[np.arange(p), [0, 1, 2, 3, 4, 5, 6, 20, 30]] = 1.0
+    H = np.full(p, 1e-4)
+    d = rng.normal(0, 0.01, p)
+    y0 = rng.normal(0, 0.03, (60, p))
+    variants = _data_variants(np.vstack([y0, y0, y0])[:140], rng)
+    for name in _variants_for(cv):
+        y = variants[name]
+        logp, st = batched.kalman_logp_batched(sw_case["T"], sw_case["R"], sw_case["q"], Z, y, d=d, Hdiag=H, q_mode="diag_batched",
+                                               options=_lib.filter_conventions(**cv))
+        assert np.all(st == 0)
+        for i in range(2):
+            ref = oracle.kalman_filter_logp(y, sw_case["T"][i], sw_case["R"][i], np.diag(sw_case["q"][i]), Z, H=np.diag(H), d=d,
+                                            conventions=oracle.FilterConventions(**cv))
+            assert_allclose(logp[i], ref, rtol=TOTAL_RTOL, err_msg=f"{_id(cv)} {name}")
+
+
+@pytest.mark.parametrize("cv", ALL, ids=_id)
+def test_per_step_outputs_follow_every_convention(sw_case, rbc_case, cv):
+    """ll_t, step by step (dsge_kalman_filter_outputs_batched), and the filtered / predicted moments of the last steps."""
+    for case in (sw_case, rbc_case):
+        for name in _variants_for(cv):
+            y = case["data"][name]
+            out = batched.kalman_filter_outputs_batched(case["T"], case["R"], case["q"], case["Z"], y, d=case["d"], Hdiag=case["H"],
+                                                        q_mode="diag_batched", options=_lib.filter_conventions(**cv))
+            assert np.all(out["status"] == 0)
+            for i in range(case["T"].shape[0]):
+                tot, ll, stt = oracle.kalman_filter_logp(y, case["T"][i], case["R"][i], np.diag(case["q"][i]), case["Z"],
+                                                         H=np.diag(case["H"]), d=case["d"], return_states=True,
+                                                         conventions=oracle.FilterConventions(**cv))
+                err = np.abs(out["ll"][i] - ll) / np.maximum(1.0, np.abs(ll))
+                assert err.max() <= STEP_TOL, (_id(cv), name, i, int(err.argmax()), err.max())
+                assert_allclose(out["filtered_states"][i], stt["a_filt"], atol=1e-9 * max(1.0, np.abs(stt["a_filt"]).max()))
+                diag_f = np.einsum("tii->ti", stt["P_filt"])
+                assert_allclose(out["filtered_covs"][i], diag_f, atol=1e-10 * np.abs(diag_f).max() + 1e-18)
+
+
+@pytest.mark.parametrize("cv", ALL, ids=_id)
+def test_fused_evaluation_follows_every_convention(sw_case, cv):
+    """The fused entry point A, B, C, D -> logp (the estimation hot loop) with both solvers, through dsge_options of the call."""
+    opts = _lib.filter_conventions(**cv)
+    name = "scattered" if cv["jitter_on_F"] else "complete"
+    y = sw_case["data"][name]
+    ref = np.array([_oracle(sw_case, i, y, cv) for i in range(2)])
+    for solver in ("cycle_reduction", "gensys"):
+        out = batched.solve_kalman_logp_batched(sw_case["A"], sw_case["B"], sw_case["C"], sw_case["D"], sw_case["q"], sw_case["Z"], y,
+                                                d=sw_case["d"], Hdiag=sw_case["H"], q_mode="diag_batched", solver=solver, tol=1e-12,
+                                                max_iter=1000, options=opts)
+        assert np.all(out["status"] == 0)
+        assert_allclose(out["logp"], ref, rtol=1e-9, err_msg=f"{_id(cv)} {solver}")  # (T from the device's own solver)
+
+
+GRAD_CASES = [dict(ll_constant="one", jitter_on_F=True, jitter_on_P=False, mask_d=True, joseph=False),
+              dict(ll_constant="observed", jitter_on_F=True, jitter_on_P=True, mask_d=True, joseph=True),
+              dict(ll_constant="p", jitter_on_F=True, jitter_on_P=True, mask_d=False, joseph=False)]
+
+
+@pytest.mark.parametrize("cv", ALL, ids=_id)
+def test_gradient_kernel_logp_follows_every_convention(sw_case, cv):
+    opts = _lib.filter_conventions(**cv)
+    name = "period" if cv["jitter_on_F"] else "complete"
+    y = sw_case["data"][name][:150]
+    out = batched.solve_kalman_logp_grad_batched(sw_case["A"], sw_case["B"], sw_case["C"], sw_case["D"], sw_case["q"], sw_case["Z"], y,
+                                                 d=sw_case["d"], Hdiag=sw_case["H"], tol=1e-13, max_iter=200, options=opts)
+    assert np.all(out["status"] == 0)
+    ref = np.array([_oracle(sw_case, i, y, cv) for i in range(2)])
+    assert_allclose(out["logp"], ref, rtol=1e-9, err_msg=_id(cv))
+
+
+@pytest.mark.parametrize("cv", GRAD_CASES, ids=_id)
+def test_gradient_follows_the_conventions(rbc_case, cv):
+    """The cotangents under non-default conventions against central differences of the oracle under the same conventions
+    (d_bar of a masked entry must vanish with mask_d; the Joseph switch changes Kbar)."""
+    rng = np.random.default_rng(5)
+    c = rbc_case
+    y = c["data"]["scattered"][:60]
+    ocv = oracle.FilterConventions(**cv)
+    out = batched.solve_kalman_logp_grad_batched(c["A"], c["B"], c["C"], c["D"], c["q"], c["Z"], y, d=c["d"], Hdiag=c["H"], tol=1e-13,
+                                                 max_iter=200, options=_lib.filter_conventions(**cv))
+    assert np.all(out["status"] == 0)
+
+    def f(A, B, C, D, q, d, h):
+        return oracle.solve_kalman_logp(A, B, C, D, np.diag(q), c["Z"], y, H=np.diag(h), d=d, tol=1e-13, max_iter=200,
+                                        conventions=ocv)["logp"]
+
+    i, eps = 1, 1e-6
+    A, B, C, D, q = (c[x][i] for x in ("A", "B", "C", "D", "q"))
+    assert_allclose(out["logp"][i], f(A, B, C, D, q, c["d"], c["H"]), rtol=1e-9)
+    maskA = (A != 0).any(axis=0)[None, :] * np.ones_like(A)
+    for _ in range(2):
+        dA = rng.standard_normal(A.shape) * maskA * 0.1
+        dB, dC, dD = (rng.standard_normal(M.shape) * 0.1 for M in (B, C, D))
+        dq = rng.standard_normal(q.shape) * q * 0.3
+        dd = rng.standard_normal(3) * 0.1
+        dh = rng.standard_normal(3) * c["H"] * 0.3
+        analytic = sum((out[k_][i] * v).sum() for k_, v in (("A_bar", dA), ("B_bar", dB), ("C_bar", dC), ("D_bar", dD), ("q_bar", dq),
+                                                            ("d_bar", dd), ("h_bar", dh)))
+        fd = (f(A + eps * dA, B + eps * dB, C + eps * dC, D + eps * dD, q + eps * dq, c["d"] + eps * dd, c["H"] + eps * dh)
+              - f(A - eps * dA, B - eps * dB, C - eps * dC, D - eps * dD, q - eps * dq, c["d"] - eps * dd, c["H"] - eps * dh)) / (2 * eps)
+        assert_allclose(analytic, fd, rtol=2e-5, atol=1e-6 * max(1.0, abs(fd)))
+    # d alone: with mask_d the missing entries carry no d
+    dd = rng.standard_normal(3)
+    fd = (f(A, B, C, D, q, c["d"] + eps * dd, c["H"]) - f(A, B, C, D, q, c["d"] - eps * dd, c["H"])) / (2 * eps)
+    assert_allclose((out["d_bar"][i] * dd).sum(), fd, rtol=2e-5, atol=1e-6 * max(1.0, abs(fd)))
+
+
+SO_CASES = [dict(ll_constant="p", jitter_on_F=True, jitter_on_P=True, mask_d=False, joseph=True),
+            dict(ll_constant="one", jitter_on_F=True, jitter_on_P=False, mask_d=True, joseph=False),
+            dict(ll_constant="observed", jitter_on_F=True, jitter_on_P=True, mask_d=True, joseph=True),
+            dict(ll_constant="observed", jitter_on_F=False, jitter_on_P=False, mask_d=False, joseph=True)]
+
+
+@pytest.mark.parametrize("cv", SO_CASES, ids=_id)
+def test_second_order_filter_follows_the_conventions(cv):
+    """The pruned-state-space filter of the second-order path (BASELINE configs[4]) under non-default conventions."""
+    from oracle import second_order as so
+
+    n, ns, nl, k, obs, T_len, nb = 12, 5, 4, 3, (0, 1, 2, 7), 50, 2
+    sysm = [wl.sw_shaped_system(3100 + n + i, n=n, n_state=ns, n_lead=nl, k=k) for i in range(nb)]
+    A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    idx = wl.second_order_hessian_pattern(A[0], C[0], k, nnz_per_eq=6, seed=3100 + n)
+    val = np.random.default_rng(3199 + n).standard_normal((nb, len(idx)))
+    rng = np.random.default_rng(n)
+    q = rng.uniform(0.5e-4, 4e-4, (nb, k))
+    p = len(obs)
+    Z = np.zeros((p, n))
+    Z[np.arange(p), list(obs)] = 1.0
+    y = rng.normal(0, 0.02, (T_len, p))
+    if cv["jitter_on_F"]:
+        y[7, 0] = np.nan
+        y[20] = np.nan
+        y[30:34, 2] = oracle.MISSING_FILL
+    H = np.full(p, 1e-5)
+    d = rng.normal(0, 0.01, p)
+    out = batched.second_order_logp_batched(A, B, C, D, idx, val, q, Z, y, d=d, Hdiag=H, tol=1e-12,
+                                            options=_lib.filter_conventions(**cv))
+    assert (out["status"] == 0).all(), out["status"]
+    for i in range(nb):
+        r = so.solve_second_order_logp(A[i], B[i], C[i], D[i], idx, val[i], np.diag(q[i]), Z, y, H=np.diag(H), d=d, tol=1e-12,
+                                       conventions=oracle.FilterConventions(**cv))
+        assert abs(out["logp"][i] - r["logp"]) <= 1e-8 * abs(r["logp"]), (_id(cv), i, out["logp"][i], r["logp"])
+
+
+def test_separate_jitters_are_separate(sw_case):
+    """jitter_F and jitter_P as VALUES (not only on / off): F gets 3e-8, P+ gets 2e-9, against the oracle run with the two
+    additions written out."""
+    y = sw_case["data"]["scattered"]
+    jf, jp = 3e-8, 2e-9
+    logp, st = batched.kalman_logp_batched(sw_case["T"], sw_case["R"], sw_case["q"], sw_case["Z"], y, d=sw_case["d"], Hdiag=sw_case["H"],
+                                           q_mode="diag_batched", options={"jitter_F": jf, "jitter_P": jp})
+    assert np.all(st == 0)
+    for i in range(2):
+        ref = _two_jitter_oracle(y, sw_case["T"][i], sw_case["R"][i], np.diag(sw_case["q"][i]), sw_case["Z"], np.diag(sw_case["H"]),
+                                 sw_case["d"], jf, jp)
+        assert_allclose(logp[i], ref, rtol=TOTAL_RTOL)
+        one = oracle.kalman_filter_logp(y, sw_case["T"][i], sw_case["R"][i], np.diag(sw_case["q"][i]), sw_case["Z"],
+                                        H=np.diag(sw_case["H"]), d=sw_case["d"], jitter=jf)
+        assert abs(one - ref) > 1e-7 * abs(ref)  # (the two settings are distinguishable at this tolerance)
+
+
+def _two_jitter_oracle(y, T, R, Q, Z, H, d, jf, jp):
+    """The recursion of oracle.kalman_filter_logp (default conventions) with its two jitter additions as separate values."""
+    m, p = T.shape[0], Z.shape[0]
+    RQR = R @ Q @ R.T
+    P = oracle.solve_discrete_lyapunov(T, RQR)
+    a = np.zeros(m)
+    tot = 0.0
+    for t in range(y.shape[0]):
+        miss = np.isnan(y[t]) | (y[t] == oracle.MISSING_FILL)
+        W = np.diag((~miss).astype(float))
+        Zm, Hm, ym = W @ Z, W @ H, np.where(miss, 0.0, y[t])
+        v = ym - (d + Zm @ a)
+        PZt = P @ Zm.T
+        F = Zm @ PZt + Hm + jf * np.eye(p)
+        K = np.linalg.solve(F.T, PZt.T).T
+        IKZ = np.eye(m) - K @ Zm
+        Pf = IKZ @ P @ IKZ.T
+        KHK = K @ Hm @ K.T
+        Pf = 0.5 * (Pf + Pf.T) + 0.5 * (KHK + KHK.T) + jp * np.eye(m)
+        if not miss.all():
+            tot += -0.5 * (p * np.log(2 * np.pi) + np.log(np.linalg.det(F)) + v @ np.linalg.solve(F, v))
+        a = T @ (a + K @ v)
+        X = T @ Pf @ T.T
+        P = 0.5 * (X + X.T) + 0.5 * (RQR + RQR.T)
+    return tot

@@ -270,11 +270,8 @@ def test_gradient_with_steady_state_segments():
     h = om["Hdiag"].copy()
     kw = dict(d=d, Hdiag=h, tol=1e-13, max_iter=200)
     out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, **kw)
-    batched.set_kalman_steady_tol(0.0)
-    try:
+    with _lib.options_scope({"kalman_steady_tol": 0.0}):
         out0 = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, **kw)
-    finally:
-        batched.set_kalman_steady_tol(1e-14)
     assert np.all(out["status"] == 0) and np.all(out0["status"] == 0)
     assert_allclose(out["logp"], out0["logp"], rtol=1e-12)
     for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):

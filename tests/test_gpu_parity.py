@@ -16,9 +16,9 @@ from geconpy_amd import workloads as wl
 
 pytestmark = pytest.mark.gpu
 
-# Kernel-variant switches of a test go through dsge_options (per call / per host thread: dsge_options_push / _pop), not through
-# the deprecated process-wide dsge_set_* setters: _set_option replaces this thread's pushed record by one that carries every
-# override made so far (a test's `finally` sets its switch back to the default, so nothing leaks into the next test).
+# Kernel-variant switches of a test go through dsge_options (per call / per host thread: dsge_options_push / _pop; ABI 8 has no
+# process-wide setters): _set_option replaces this thread's pushed record by one that carries every override made so far
+# (a test's `finally` sets its switch back to the default, so nothing leaks into the next test).
 _OPTION_OVERRIDES = {}
 _OPTION_PUSHED = [False]
 
@@ -27,18 +27,25 @@ def _set_option(name, value):
     import ctypes as _ct
 
     lib = _lib.load()
-    _OPTION_OVERRIDES[name] = int(value)
+    _OPTION_OVERRIDES[name] = float(value) if name in ("kalman_steady_tol", "jitter_F", "jitter_P") else int(value)
     if _OPTION_PUSHED[0]:
         _lib.check(lib.dsge_options_pop())
         _OPTION_PUSHED[0] = False
     defaults = _lib.make_options()
     for key in [k for k, v in _OPTION_OVERRIDES.items() if getattr(defaults, k) == v]:
-        del _OPTION_OVERRIDES[key]  # back at the default: no record stays pushed (a pushed record would also shadow the defaults
-        #                             that the two remaining dsge_set_* users of this file edit)
+        del _OPTION_OVERRIDES[key]  # back at the default: no record stays pushed
     if _OPTION_OVERRIDES:
         rec = _lib.make_options(dict(_OPTION_OVERRIDES))
         _lib.check(lib.dsge_options_push(_ct.addressof(rec)))
         _OPTION_PUSHED[0] = True
+
+
+
+def _set_cr_deflation(on):
+    """cr_deflation switch + forget the measured number of static variables (what the removed dsge_set_cr_deflation did)."""
+    _set_option("cr_deflation", on)
+    _lib.check(_lib.load().dsge_forget_measured_shapes())
+
 
 T_ATOL = 1e-10
 LOGP_RTOL = 1e-9
@@ -670,15 +677,15 @@ def test_kalman_steady_state_switch_matches_full_recursion():
         return batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"],
                                                  Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
 
-    assert batched.get_kalman_steady_tol() == 1e-14
+    assert _lib.make_options().kalman_steady_tol == 1e-14
     r_ss, at = _steady_steps(run, nb)
     assert np.all(r_ss["status"] == 0)
     assert np.all(at > 0) and np.all(at < 150), at  # every draw reaches its fixed point well before T_len
-    batched.set_kalman_steady_tol(0.0)
+    _set_option("kalman_steady_tol", 0.0)
     try:
         r_full, at0 = _steady_steps(run, nb)
     finally:
-        batched.set_kalman_steady_tol(1e-14)
+        _set_option("kalman_steady_tol", 1e-14)
     assert np.all(at0 == -1)
     assert_allclose(r_ss["logp"], r_full["logp"], rtol=1e-12)
     for i in (0, 10, 63):
@@ -711,11 +718,11 @@ def test_kalman_steady_state_resumes_on_mask_change(selector):
 
 
 def test_kalman_steady_tol_validation():
-    with pytest.raises(_lib.DsgeHipError):
-        batched.set_kalman_steady_tol(-1.0)
-    with pytest.raises(_lib.DsgeHipError):
-        batched.set_kalman_steady_tol(1e-3)
-    assert batched.get_kalman_steady_tol() == 1e-14
+    for bad in (-1.0, 1e-3):
+        with pytest.raises(_lib.DsgeHipError):
+            with _lib.options_scope({"kalman_steady_tol": bad}):
+                pass
+    assert _lib.make_options().kalman_steady_tol == 1e-14
 
 
 def test_cycle_reduction_compact_equals_dense(sw_golden, ref_goldens, rbc_golden):
@@ -1585,9 +1592,9 @@ def test_cr_static_deflation_matches_full_system():
     dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:40]), eng.to_device(om["Hdiag"])
     hints = eng.structure_hints(dev["A"], dZ)
     try:
-        _lib.check(lib.dsge_set_cr_deflation(0))
+        _set_cr_deflation(0)
         lp0, st0, T0, R0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
         # the bound is measured on the first batch of a model size: give it the clean one, so that draws 9 and 300 of
         # the second call are the violators
         clean = {x: eng.to_device(b[x]) for x in "ABCD"}
@@ -1595,7 +1602,7 @@ def test_cr_static_deflation_matches_full_system():
         lp1, st1, T1, R1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
         lp2, st2, T2, R2 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
     finally:
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
     assert np.array_equal(st0, st1) and st0[5] != 0 and np.count_nonzero(st0[[0, 9, 300, 699]]) == 0
     ok = st0 == 0
     assert ok.sum() >= nb - 3
@@ -1733,10 +1740,10 @@ def test_cr_static_deflation_on_reference_goldens(ref_goldens, key):
     outs = []
     try:
         for on in (0, 1):
-            _lib.check(lib.dsge_set_cr_deflation(on))
+            _set_cr_deflation(on)
             outs.append(batched.solve_kalman_logp_batched(Ab, Bb, Cb, Db, q, Z, y, Hdiag=H, tol=1e-10, max_iter=1000))
     finally:
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
     assert np.all(outs[0]["status"] == 0) and np.all(outs[1]["status"] == 0)
     assert_allclose(outs[1]["logp"], outs[0]["logp"], rtol=LOGP_RTOL)
     for i in range(nb):
@@ -1767,12 +1774,12 @@ def test_cr_static_deflation_other_sizes(n, ns, nl):
     dq, dZ, dy, dH = eng.to_device(q), eng.to_device(Z), eng.to_device(y), eng.to_device(H)
     hints = eng.structure_hints(dev["A"], dZ)
     try:
-        _lib.check(lib.dsge_set_cr_deflation(0))
+        _set_cr_deflation(0)
         lp0, st0, T0, R0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
         lp1, st1, T1, R1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
     finally:
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
     assert np.all(st0 == 0) and np.all(st1 == 0)
     assert_allclose(T1, Tst, atol=1e-8)
     assert_allclose(T1, T0, atol=1e-9)
@@ -1804,9 +1811,9 @@ def test_cr_static_deflation_bound_corrects_itself():
     dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"][:6]), eng.to_device(om["Hdiag"])
     hints = eng.structure_hints(fewer["A"], dZ)
     try:
-        _lib.check(lib.dsge_set_cr_deflation(0))
+        _set_cr_deflation(0)
         lp0, st0, T0, R0 = _fused_policy(eng, fewer, dq, dZ, dy, dH, hints)
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
         _fused_policy(eng, clean, dq, dZ, dy, dH, hints)  # h = 10
         lp1, st1, T1, R1 = _fused_policy(eng, fewer, dq, dZ, dy, dH, hints)
         assert np.all(st0 == 0) and np.array_equal(T1, T0) and np.array_equal(lp1, lp0)  # all flagged: full-size kernels
@@ -1815,7 +1822,7 @@ def test_cr_static_deflation_bound_corrects_itself():
                                   n_state_hint=hints[0], z_selector_hint=hints[1])
         lp2, st2, T2, R2 = _fused_policy(eng, fewer, dq, dZ, dy, dH, hints)
     finally:
-        _lib.check(lib.dsge_set_cr_deflation(1))
+        _set_cr_deflation(1)
     assert np.all(st2 == 0) and not np.array_equal(T2, T0)  # h = 9 now: deflated again
     assert_allclose(T2, T0, atol=1e-10)
     assert_allclose(lp2, lp0, rtol=LOGP_RTOL)
@@ -1927,12 +1934,12 @@ def test_cr_static_deflation_fuzz():
         dq, dZ, dy, dH = eng.to_device(np.full((nb, k), 1e-4)), eng.to_device(Z), eng.to_device(y), eng.to_device(np.full(p, 1e-4))
         hints = eng.structure_hints(dev["A"], dZ)
         try:
-            _lib.check(lib.dsge_set_cr_deflation(0))
+            _set_cr_deflation(0)
             lp0, st0, T0, R0 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
-            _lib.check(lib.dsge_set_cr_deflation(1))
+            _set_cr_deflation(1)
             lp1, st1, T1, R1 = _fused_policy(eng, dev, dq, dZ, dy, dH, hints)
         finally:
-            _lib.check(lib.dsge_set_cr_deflation(1))
+            _set_cr_deflation(1)
         assert np.array_equal(st0, st1), (n, k, n_static)
         ok = st0 == 0
         assert ok.any(), (n, k, n_static)
