@@ -180,20 +180,10 @@ def test_oracle_matches_arbitrary_precision(sm_golden):
         assert abs(float(g[f"{name}_loglike"]) - float(mpg[f"{name}_loglike_mp"])) < 2e-8 * abs(float(mpg[f"{name}_loglike_mp"]))
 
 
-def test_pymc_extras_pin():
-    """The Kalman / Lyapunov conventions against the REAL third-party filter (pymc_extras' StandardFilter, the one gEconpy's
-    graph runs: statespace.py:1143-1157).  tests/golden/pymc_extras_kalman.npz is produced by
-    tests/golden/make_pymc_extras_golden.py on a machine that has pymc_extras -- the build container does not -- and until it
-    exists this test SKIPS and the filter half of the oracle stays "parity unpinned" (DESIGN.md section 2).  With the fixture:
-    every case must match ``oracle.kalman_filter_logp`` per step to 1e-10 under ``oracle.DEFAULT_CONVENTIONS``; if it does not,
-    the failure message names the combination of ``FilterConventions`` switches that does."""
+def _pin_check(path):
+    """(worst per-step error of DEFAULT_CONVENTIONS against the fixture, [matching combinations with their dsge_options])."""
     import itertools
-    import os
 
-    path = os.path.join(os.path.dirname(__file__), "golden", "pymc_extras_kalman.npz")
-    if not os.path.exists(path):
-        pytest.skip("parity unpinned: tests/golden/pymc_extras_kalman.npz does not exist (run "
-                    "tests/golden/make_pymc_extras_golden.py where pymc_extras is installed)")
     g = np.load(path)
     tags = sorted(k[: -len("_ll")] for k in g.files if k.endswith("_ll"))
     assert tags, "fixture without cases"
@@ -213,12 +203,64 @@ def test_pymc_extras_pin():
             return np.inf
 
     err = worst(oracle.DEFAULT_CONVENTIONS)
+    fits = []
     if err > 1e-10:
-        fits = []
+        from geconpy_amd import _lib  # noqa: PLC0415
+
         for llc, jf, jp, md, jo in itertools.product(("p", "observed", "one"), (True, False), (True, False), (False, True),
                                                      (True, False)):
             cv = oracle.FilterConventions(llc, jf, jp, md, jo)
             if worst(cv) <= 1e-10:
-                fits.append(repr(cv))
-        pytest.fail(f"DEFAULT_CONVENTIONS is {err:.3e} off pymc_extras ({list(g['versions'])}); matching combinations: "
-                    f"{fits or 'none -- a convention outside FilterConventions'}")
+                # ... and the library setting it maps to 1:1 (ABI 8: the conventions are run-time dsge_options fields, every
+                # filter kernel is GPU-tested under every combination: tests/test_gpu_conventions.py) -- no kernel edit
+                kw = dict(ll_constant=llc, jitter_on_F=jf, jitter_on_P=jp, mask_d=md, joseph=jo)
+                fits.append((kw, f"{cv!r}  ->  options=_lib.filter_conventions({', '.join(f'{k_}={v_!r}' for k_, v_ in kw.items())}) "
+                                 f"= dsge_options {_lib.filter_conventions(**kw)}"))
+    return err, fits, list(g["versions"]) if "versions" in g.files else []
+
+
+def test_pymc_extras_pin():
+    """The Kalman / Lyapunov conventions against the REAL third-party filter (pymc_extras' StandardFilter, the one gEconpy's
+    graph runs: statespace.py:1143-1157).  tests/golden/pymc_extras_kalman.npz is produced by
+    tests/golden/make_pymc_extras_golden.py on a machine that has pymc_extras -- the build container does not -- and until it
+    exists this test SKIPS and the filter half of the oracle stays "parity unpinned" (DESIGN.md section 2).  With the fixture:
+    every case must match ``oracle.kalman_filter_logp`` per step to 1e-10 under ``oracle.DEFAULT_CONVENTIONS``; if it does not,
+    the failure message names the combination of ``FilterConventions`` switches that does AND the ``dsge_options`` setting
+    (``_lib.filter_conventions(...)``) that makes the device kernels follow it -- a configuration, not a kernel edit."""
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "pymc_extras_kalman.npz")
+    if not os.path.exists(path):
+        pytest.skip("parity unpinned: tests/golden/pymc_extras_kalman.npz does not exist (run "
+                    "tests/golden/make_pymc_extras_golden.py where pymc_extras is installed)")
+    err, fits, versions = _pin_check(path)
+    if err > 1e-10:
+        pytest.fail(f"DEFAULT_CONVENTIONS is {err:.3e} off pymc_extras ({versions}); matching combinations: "
+                    f"{[f_[1] for f_ in fits] or 'none -- a convention outside FilterConventions'}")
+
+
+def test_pin_check_names_the_convention_and_the_abi_setting(tmp_path):
+    """Self-test of the pinning tool on a SYNTHETIC fixture in the layout make_pymc_extras_golden.py writes: per-step ll generated
+    under a non-default combination (a single ln 2pi per step, d masked) must be reported as exactly that combination together
+    with the dsge_options fields that select it on the device (ll_constant = DSGE_LL_CONST_ONE, mask_d = 1)."""
+    rng = np.random.default_rng(3)
+    m, k, p, T_len = 6, 2, 3, 40
+    T = 0.5 * rng.standard_normal((m, m)) / np.sqrt(m)
+    R = rng.standard_normal((m, k))
+    Q = np.diag(rng.uniform(0.5, 1.5, k))
+    Z = np.zeros((p, m))
+    Z[np.arange(p), [0, 2, 5]] = 1.0
+    H = np.diag(rng.uniform(0.05, 0.2, p))
+    d = rng.standard_normal(p)
+    y = rng.standard_normal((T_len, p))
+    y[4, 1] = np.nan
+    y[9] = np.nan
+    truth = dict(ll_constant="one", jitter_on_F=True, jitter_on_P=True, mask_d=True, joseph=True)
+    ll = oracle.kalman_filter_logp(y, T, R, Q, Z, H=H, d=d, return_per_step=True, conventions=oracle.FilterConventions(**truth))[1]
+    path = tmp_path / "synthetic_pin.npz"
+    np.savez(path, toy_T=T, toy_R=R, toy_Q=Q, toy_Z=Z, toy_H=H, toy_case_y=y, toy_case_d=d, toy_case_jitter=oracle.JITTER_DEFAULT,
+             toy_case_ll=ll, versions=np.array(["synthetic"]))
+    err, fits, _ = _pin_check(str(path))
+    assert err > 1e-3
+    assert [f_[0] for f_ in fits] == [truth], fits
+    assert "'ll_constant': 2" in fits[0][1] and "'mask_d': 1" in fits[0][1]
