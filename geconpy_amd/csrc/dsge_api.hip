@@ -657,6 +657,16 @@ static int pipeline_big(const double* A, const double* B, const double* C, const
   double* P0 = cv.take<double>((size_t)batch * 64 * 64);
   int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);
   int32_t* park_w = cv.take<int32_t>((size_t)batch);
+  // F depends on A and Z only: measured FIRST (one small launch, a 72-byte read-back, one stream synchronisation per call -- not
+  // per repetition), so that a model with more than 64 state + observed variables is refused before anything is enqueued and
+  // before any output of this call is touched (DSGE_ERR_TOO_LARGE: "nothing computed", include/dsge_hip.h)
+  unsigned char idx[64];
+  int u = 0, ns = 0;
+  if ((rc = big_filtered_variables(A, Z, z_batched, batch, n, p, st, idx, &u, &ns))) return rc;
+  if (u > 64)
+    return fail(DSGE_ERR_TOO_LARGE, "solve + Kalman with n > 64: " + std::to_string(u) +
+                                        " state and observed variables, the filter kernels take at most 64");
+  if (u < 1) return fail(DSGE_ERR_INVALID, "solve + Kalman with n > 64: no state and no observed variable");
   EventGuard ev[4];
   float acc_ms[3] = {0.f, 0.f, 0.f};
   if (ms_out)
@@ -676,13 +686,6 @@ static int pipeline_big(const double* A, const double* B, const double* C, const
     if (park_failures && (rc = launch_status_park(status_out, park_w, batch, 0, st))) return rc;
     if (!fuse_R && (rc = launch_selection_big(A, B, C, D, Tw, batch, n, k, Rw, resid_out, status_out, st))) return rc;
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
-    unsigned char idx[64];
-    int u = 0, ns = 0;
-    if ((rc = big_filtered_variables(A, Z, z_batched, batch, n, p, st, idx, &u, &ns))) return rc;
-    if (u > 64)
-      return fail(DSGE_ERR_TOO_LARGE, "solve + Kalman with n > 64: " + std::to_string(u) +
-                                          " state and observed variables, the filter kernels take at most 64");
-    if (u < 1) return fail(DSGE_ERR_INVALID, "solve + Kalman with n > 64: no state and no observed variable");
     if ((rc = launch_big_compress(Tw, Rw, Z, z_batched, batch, n, k, p, idx, u, T_r, R_r, Z_r, st))) return rc;
     const int ns_hint = (ns > 0 && ns < u) ? ns : 0;
     const bool q_diag = q_mode == DSGE_Q_DIAG_SHARED || q_mode == DSGE_Q_DIAG_BATCHED;

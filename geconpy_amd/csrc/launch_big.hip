@@ -10,8 +10,11 @@ long long* g_big_dbg = nullptr;  // debug: device int64[8], phase cycles of work
 namespace {
 StreamArenaPool g_big_pool;
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-// draws (one workgroup and one 300-440 KB workspace each) per launch of the solver
-constexpr int BIG_GRID_MAX = 2048;
+// draws (one workgroup and one 300-440 KB workspace each) per launch of the solver.  About one workgroup per CU is resident
+// (156 KB of LDS), so 1024 draws are four residency rounds of the chip: enough to hide a launch's straggler tail, and the
+// arena -- per (device, stream), kept for the life of the stream -- stays at 0.33 GB (n <= 80) / 0.46 GB (n <= 96) instead of twice
+// that (footprint table in INTEGRATION.md)
+constexpr int BIG_GRID_MAX = 1024;
 // Threads per draw: the elimination is a chain of short dependent phases separated by barriers, so a step's duration is set by
 // instruction latency, not by arithmetic -- more wavefronts per SIMD hide it better.  Measured cycles per pivot step at
 // n = 80 / 96 (tools/big_phases.py): 256 threads 4.5 k / 5.3 k; 640 / 512 threads (below) see DESIGN.md.

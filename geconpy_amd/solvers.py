@@ -120,9 +120,11 @@ def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=
     ``impact[:n] = R = -(C T + B)^-1 D`` (gensys.py:679-683) are what every caller reads; the lead rows are completed ON the
     stable manifold (``x_t = E_t y_{t+1}[lead] = T[lead] y_t``, so ``G_1[n:, :n] = T[lead] T``, ``impact[n:] = T[lead] R``,
     zero columns for ``x_{t-1}``) and ``C = 0`` (the model pencil has c = 0, :598).  That route keeps the ordered Schur form
-    of the active window only, so ``gev, f_mat, f_wt, y_wt, loose`` are ``None`` there, and a draw WITHOUT a unique stable
-    solution (``eu != [1, 1]``) returns ``None`` for every matrix -- the reference would still hand back the QZ quantities of
-    the failed solve; nothing downstream reads them (model.py:1696-1702 raises first)."""
+    of the active window only, so ``gev, f_mat, f_wt, y_wt, loose`` are ``None`` there.  A draw WITHOUT a unique stable
+    solution (``eu != [1, 1]``) still returns ``G_1`` and ``impact`` as arrays on BOTH routes (the reference's consumer slices
+    ``G_1[:n, :n]`` before it reads ``eu``, gensys.py:657-666) -- on this route the zero-filled T of the failed draw, not the QZ
+    quantities of the failed solve, which nothing downstream reads (model.py:1696-1702 raises first); coincident zeros
+    (``eu = [-2, -2, 0]``) give the 9-tuple of ``None`` whatever ``return_all_matrices`` says (:515-516), as ``gensys`` does."""
     g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
     try:
         return gensys(g0, g1, c, psi, pi, tol=tol, return_all_matrices=return_all_matrices)
@@ -131,13 +133,14 @@ def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=
     A3, B3, C3, D3 = (np.ascontiguousarray(x, dtype=np.float64)[None] for x in (A, B, C, D))
     out = batched.gensys_batched(A3, B3, C3, D3, tol=tol)
     eu = [int(v) for v in out["eu"][0]]
-    if not (eu[0] == 1 and eu[1] == 1):
-        if not return_all_matrices:
-            return None, eu
+    if eu[0] == -2 and eu[1] == -2:  # coincident zeros: the 9-tuple of Nones, whatever return_all_matrices says (gensys.py:515-516)
         return None, None, None, None, None, None, None, eu, None
     n, k = D3.shape[1:]
     N = g0.shape[0]
     lead = np.flatnonzero(np.abs(C3[0]).sum(axis=0) > tol)
+    # Without a unique stable solution (eu != [1, 1]) the reference still returns MATRICES (its consumer slices G_1[:n, :n] before
+    # it looks at eu: GensysWrapper.perform, gensys.py:657-666).  So does this route, for every pencil size: T and R as the
+    # window kernels wrote them for the failed draw (T zero-filled, R = -(C T + B)^-1 D of that T), never None.
     T, R = out["T"][0], out["R"][0]
     G_1 = np.zeros((N, N))
     G_1[:n, :n] = T

@@ -610,7 +610,8 @@ int dsge_kalman_filter_outputs_batched_host(const double* T, const double* R, co
  * n <= DSGE_MAX_N (64); with a cycle-reduction solver n <= DSGE_MAX_N_BIG (96): the solver then runs with one workgroup per draw
  * and the filter on the model restricted to F = {state variables} u {observed variables} -- exact, because every column of T
  * outside the state variables is zero.  F is measured on the device (the call synchronises `stream` once; the hints are not
- * used); more than 64 variables in F: DSGE_ERR_TOO_LARGE, nothing computed.
+ * used); more than 64 variables in F: DSGE_ERR_TOO_LARGE -- F is measured before the solver is launched, so nothing of the
+ * call (of the current chunk, when the batch is processed in chunks) has been computed or written.
  */
 int dsge_solve_kalman_logp_batched(const double* A, const double* B, const double* C, const double* D,
                                    const double* Q, int q_mode, const double* Z, int z_batched,

@@ -824,6 +824,27 @@ def test_numpy_gensys_wrapper_large_pencil_fallback():
     assert_allclose(impact[:n], oracle.compute_selection_matrix(B, C, D, Tg), atol=1e-9)
     G1s, eus = solvers.solve_policy_function_with_gensys(A, B, C, D, 1e-8, return_all_matrices=False)
     assert eus == eu and np.array_equal(G1s, G_1)
+    # the contract must not depend on the pencil size.  An INDETERMINATE draw of the same size (the generator's G
+    # rescaled to spectral radius 1.5: fewer than #lead unstable roots, eu[1] = 0 -- SURVEY 8c iv) still returns G_1 as an
+    # (N, N) array on this route, as the reference does (its consumer slices G_1[:n, :n] before reading eu, gensys.py:657-666)
+    Minv = np.linalg.inv(B + C @ T_star)          # M = B + C T*  (B = M - C T*), G = M^-1 C
+    G = Minv @ C
+    G2 = G * (1.5 / np.max(np.abs(np.linalg.eigvals(G))))
+    M = B + C @ T_star
+    C2 = M @ G2
+    B2 = M - C2 @ T_star
+    eu_ref = oracle.gensys_T_success(A, B2, C2, D)[2]
+    assert eu_ref[0] == 1 and eu_ref[1] == 0
+    G1f, euf = solvers.solve_policy_function_with_gensys(A, B2, C2, D, 1e-8, return_all_matrices=False)
+    assert isinstance(G1f, np.ndarray) and G1f.shape == (N, N) and list(euf[:2]) == [1, 0] and euf[2] == eu_ref[2]
+    full = solvers.solve_policy_function_with_gensys(A, B2, C2, D, 1e-8)
+    assert len(full) == 9 and full[0].shape == (N, N) and full[2].shape == (N, k) and full[7] == euf
+    assert np.all(np.isfinite(full[0])) and full[3] is None and full[8] is None
+    # coincident zeros (one equation zeroed): the 9-tuple of Nones also with return_all_matrices=False, like gensys()
+    A0, B0, C0 = A.copy(), B.copy(), C.copy()
+    A0[3] = B0[3] = C0[3] = 0.0
+    zz = solvers.solve_policy_function_with_gensys(A0, B0, C0, D, 1e-8, return_all_matrices=False)
+    assert len(zz) == 9 and zz[0] is None and zz[7][:2] == [-2, -2]
 
 
 def test_numpy_gensys_wrappers(ref_goldens, failure_golden):
