@@ -194,6 +194,11 @@ def roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_e
         "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / FP64_PEAK_TFLOPS, 5),
+        # USEFUL flops: the arithmetic of the algorithm the kernel runs on the UNPADDED reduced model (bench.py::executed_flops:
+        # u filtered variables, s state columns, the measured number of full / steady steps), over the same duration.  frac counts
+        # what the VALU executes (tile padding, replicated 8-lane groups included); useful_frac is what of the peak is algorithm
+        "useful_tflops": k["model_tflops"],
+        "useful_frac": round(k["model_tflops"] / FP64_PEAK_TFLOPS, 5),
         "flops_source": (f"{pmc_src}: rocprofv3 --pmc SQ_INSTS_VALU_{{FMA,ADD,MUL,TRANS}}_F64 x 64 lanes of the same bench "
                          f"command (tools/pmc_collect.py; committed counters, not collected in this run); duration measured in "
                          f"this run with HIP events") if counted else "analytic model bench.py::executed_flops (no counters "
@@ -209,6 +214,9 @@ def roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_e
         "structure": {"n_state": hints[0], "z_selector": hints[1], "filtered_variables": u_dim,
                       "static_variables_deflated": h_defl, **stats},
         "kernel_ms": {k_: round(v, 4) for k_, v in kms.items()},
+        "kernel_ms_source": ("a SEPARATE synchronised pass after the timed loop (dsge_profile_pipeline: each launch bracketed by HIP "
+                             "events on the launch stream, mean of --profile-reps repetitions), not the timed steps themselves: "
+                             "their sum may differ from ms_per_step by launch gaps and clock state"),
         "kernels": kern,
         "whole_eval_contract_tflops": round(flops["total"] * nloc / total_kernel_s / 1e12, 4),
         "whole_eval_model_tflops": round(sum(ex.values()) * nloc / total_kernel_s / 1e12, 4),
@@ -359,8 +367,10 @@ def spawn_ranks(n_ranks, argv, shared_gpu=False, timeout=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=800,
+                    help="timed steps (default 800: ~1.2 s of timed region at 1.5 ms per step, long enough for an outside "
+                         "observer -- rocm-smi sampling -- to see the GPU busy)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=None,
                     help="draws per GPU; default: 4096 at --gpus 1 (BASELINE configs[2]), 8192 at --gpus N > 1 (configs[3]: "
                          "65 536 draws over 8 GPUs), 1024 for --workload sw_second_order (configs[4])")
@@ -443,17 +453,24 @@ def main():
     # observation model of the realistic-structure leg (seven observed JUMP variables) -- also before the GPU is touched
     want_extras = (world == 1 and not args.no_extras and not args.from_theta and args.workload == "sw_shaped"
                    and args.solver == "cycle_reduction")
-    cpu_gensys = cpu_jumps = om_j = b80 = om80 = cpu_n80 = None
+    cpu_gensys = cpu_jumps = om_j = b80 = om80 = cpu_n80 = om_c = cpu_cons = None
     if want_extras:
         om_j = wl.sw_shaped_observation_model(observed=wl.SW_OBSERVED_JUMPS)
         shape80 = dict(n=80, n_state=36, n_lead=24, k=10, p=7, T_len=200)  # the `n80` leg: a model beyond 64 variables
         b80 = wl.sw_shaped_batch(128, **shape80)
         om80 = wl.sw_shaped_observation_model(**shape80)
+        # the `conservative` leg: observed jump variables AND 10 % of the entries of y missing at random (seeded): the mask
+        # changes at almost every step, so the filter never reaches a steady state and every step is a full covariance update
+        om_c = dict(om_j)
+        y_c = om_j["y"].copy()
+        y_c[np.random.default_rng(20261003).random(y_c.shape) < 0.10] = np.nan
+        om_c["y"] = y_c
     if want_extras and rank == 0 and args.cpu_sample > 0:
         n_x = min(hi - lo, max(64, 2 * cores))
         cpu_gensys = cpu_baseline(shard, om, n_x, cores, solver="gensys")
         cpu_jumps = cpu_baseline(shard, om_j, n_x, cores)
         cpu_n80 = cpu_baseline(b80, om80, min(128, max(16, cores)), cores)
+        cpu_cons = cpu_baseline(shard, om_c, n_x, cores, solver="gensys")
 
     so_leg = second_order_leg() if (want_extras and rank == 0) else None
 
@@ -550,6 +567,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # When the caller's --steps make the timed region shorter than a second (the driver's 20 steps are 30 ms), the same step runs
+    # on for >= 1.2 s OUTSIDE the headline timer: an outside observer (rocm-smi sampling) then sees the GPU busy, and the
+    # sustained rate corroborates `value` (same loop, same buffers; never reported as `value`).
+    sustained = None
+    if dt < 1.0:
+        n_sus = int(np.ceil(1.2 / (dt / args.steps)))
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            logp_all, stat_all = ev.step()
+        torch.cuda.synchronize()
+        barrier()
+        dt_s = time.perf_counter() - t1
+        sustained = {"value": round(global_batch * n_sus / dt_s, 2), "unit": "evals/s", "steps": n_sus,
+                     "seconds": round(dt_s, 3), "note": "the headline step repeated for >= 1.2 s after the timed region "
+                                                        "(rank-0 clock; corroboration for outside observers, not `value`)"}
+
     logp_host = logp_all.cpu().numpy()
     stat_host = stat_all.cpu().numpy()
     n_fail = int((stat_host != 0).sum())
@@ -574,7 +609,7 @@ def main():
         dt_full = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
                                                       max_iter=args.max_iter, logp=lp_full, status=stat_buf, solver=args.solver,
                                                       n_state_hint=hints[0], z_selector_hint=hints[1], options=opts_full),
-                        max(3, args.steps // 2))
+                        max(3, min(args.steps, 20) // 2))
         extras["full_recursion"] = {"value": round(nloc / dt_full, 2), "ms_per_step": round(dt_full * 1e3, 4), "unit": "evals/s",
                                     "note": "same step with kalman_steady_tol = 0 (per call): every one of the T_len filter steps "
                                             "updates the covariance, as pymc_extras' standard filter does",
@@ -586,7 +621,7 @@ def main():
         dt_g = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
                                                    max_iter=args.max_iter, logp=lp_g, status=st_g, solver="gensys",
                                                    n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g),
-                     max(3, args.steps // 2))
+                     max(3, min(args.steps, 20) // 2))
         extras["gensys"] = {"value": round(nloc / dt_g, 2), "ms_per_step": round(dt_g * 1e3, 4), "unit": "evals/s",
                             "note": "same step with solver = gensys (ordered QZ), the reference's default estimation solver "
                                     "(configure(..., solver='gensys'), statespace.py:832)",
@@ -612,7 +647,7 @@ def main():
         dt_j = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZj, dyj, Hdiag=dHj, q_mode=1, tol=args.tol,
                                                    max_iter=args.max_iter, logp=lp_j, status=st_j, solver=args.solver,
                                                    n_state_hint=hints_j[0], z_selector_hint=hints_j[1], options=opts),
-                     max(3, args.steps // 2))
+                     max(3, min(args.steps, 20) // 2))
         extras["observe_jumps"] = {"value": round(nloc / dt_j, 2), "ms_per_step": round(dt_j * 1e3, 4), "unit": "evals/s",
                                    "note": f"same step, Z selects the non-state variables {list(wl.SW_OBSERVED_JUMPS)}: 25 filtered "
                                            "variables (18 states + 7 observed jumps), the 32-wide filter tile",
@@ -623,6 +658,31 @@ def main():
             extras["observe_jumps"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle": float(rel_j.max()),
                                                  "median_rel_logp_err_vs_cpu_oracle": float(np.median(rel_j)),
                                                  "n_checked": int(len(ref_j))}
+        # CONSERVATIVE configuration -- what a reference user with configure()'s defaults and real data runs: solver = gensys (the
+        # default, statespace.py:832), observed jump variables, 10 % of the observations missing at random (mixed-frequency / ragged
+        # data: prepare_mixed_frequency_data, statespace.py:1432-1505; the mask of statespace.py:1143 then changes at almost every
+        # step) and kalman_steady_tol = 0: no structure of the data or of the recursion is exploited beyond the exact state reduction
+        dyc = eng.to_device(om_c["y"])
+        lp_c = torch.empty_like(logp_buf)
+        st_c = torch.empty_like(stat_buf)
+        opts_c = {"kalman_steady_tol": 0.0}
+        dt_c = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZj, dyc, Hdiag=dHj, q_mode=1, tol=args.tol,
+                                                   max_iter=args.max_iter, logp=lp_c, status=st_c, solver="gensys",
+                                                   n_state_hint=hints_j[0], z_selector_hint=hints_j[1], n_lead_hint=nl_g,
+                                                   options=opts_c), max(3, min(args.steps, 20) // 2))
+        extras["conservative"] = {"value": round(nloc / dt_c, 2), "ms_per_step": round(dt_c * 1e3, 4), "unit": "evals/s",
+                                  "note": "solver = gensys (the reference's default, statespace.py:832), Z selects seven JUMP variables "
+                                          "(25 filtered variables), 10 % of the entries of y missing at random (the missing-data mask "
+                                          "changes at almost every step), kalman_steady_tol = 0: every one of the T_len steps is a full "
+                                          "covariance update -- the rate of a user with configure() defaults and ragged data",
+                                  "missing_entries": int(np.isnan(om_c["y"]).sum()), "failed_draws": int((st_c != 0).sum().item())}
+        if cpu_cons is not None:
+            ref_c = cpu_cons[0]
+            rel_c = np.abs(lp_c[: len(ref_c)].cpu().numpy() - ref_c) / np.abs(ref_c)
+            extras["conservative"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle_gensys": float(rel_c.max()),
+                                                "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_c)),
+                                                "n_checked": int(len(ref_c)), "bar": 1e-8,
+                                                "cpu_oracle_evals_per_s": round(cpu_cons[1], 2)}
         # the same batch evaluated by TWO callers at once, each on its own stream (two PyMC chains sharing the GPU, or a sampler
         # that splits its particles): the library keeps its scratch per (device, stream); one sequence leaves most of the chip idle
         # while the Kalman launch waits for its never-steady draw, a second one fills that time.  Whole-GPU rate, never `value`.
@@ -637,7 +697,7 @@ def main():
                                           logp=lp2[i], status=st2[i], solver=args.solver, n_state_hint=hints[0],
                                           z_selector_hint=hints[1], options=opts)
 
-        dt_2 = timed(both, max(3, args.steps // 2))
+        dt_2 = timed(both, max(3, min(args.steps, 20) // 2))
         extras["two_streams"] = {"value": round(2 * nloc / dt_2, 2), "ms_per_round": round(dt_2 * 1e3, 4), "unit": "evals/s",
                                  "note": "two independent callers, each evaluating the same batch on its own HIP stream, whole-GPU "
                                          "rate (2 x batch per round); the headline `value` is the ONE-stream figure",
@@ -809,6 +869,7 @@ def main():
             "roofline": roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_eval, hints, u_dim, h_defl,
                                        stats),
             "failed_draws": n_fail,
+            **({"sustained": sustained} if sustained else {}),
             **extras,
         }
         if cpu is not None:
