@@ -174,7 +174,7 @@ class Options(C.Structure):
         ("ll_constant", C.c_int32),
         ("mask_d", C.c_int32),
         ("joseph", C.c_int32),
-        ("reserved0_", C.c_int32),
+        ("kalman_head_draws", C.c_int32),
         ("jitter_F", C.c_double),
         ("jitter_P", C.c_double),
         ("reserved_", C.c_int32 * 4),
@@ -205,7 +205,7 @@ def make_options(options=None, **fields):
     elif options:
         fields = {**options, **fields}
     for name, value in fields.items():
-        if name not in {f[0] for f in Options._fields_} or name in ("struct_size", "reserved_", "reserved0_"):
+        if name not in {f[0] for f in Options._fields_} or name in ("struct_size", "reserved_"):
             raise ValueError(f"unknown option {name!r}")
         if name == "ll_constant" and isinstance(value, str):
             value = LL_CONSTANT[value]

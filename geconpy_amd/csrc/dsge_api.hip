@@ -138,6 +138,7 @@ struct OptionsGuard {
     local.gensys_shape_cache = o->gensys_shape_cache;
     local.kalman_narrow = o->kalman_narrow;
     local.gensys_direct_blocks = o->gensys_direct_blocks;
+    local.kalman_head_draws = o->kalman_head_draws;
     local.ll_constant = o->ll_constant;
     local.mask_d = o->mask_d;
     local.joseph = o->joseph;
@@ -1261,12 +1262,12 @@ int dsge_debug_kalman_phases(int enable, long long* cycles_out) {
   int rc = ensure_device();
   if (rc) return rc;
   if (enable && !g_kalman_dbg) {
-    HIP_TRY(hipMalloc((void**)&g_kalman_dbg, 8 * sizeof(long long)));
-    HIP_TRY(hipMemset(g_kalman_dbg, 0, 8 * sizeof(long long)));
+    HIP_TRY(hipMalloc((void**)&g_kalman_dbg, 16 * sizeof(long long)));
+    HIP_TRY(hipMemset(g_kalman_dbg, 0, 16 * sizeof(long long)));
   }
   if (cycles_out && g_kalman_dbg) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(cycles_out, g_kalman_dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cycles_out, g_kalman_dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost));
   }
   if (!enable && g_kalman_dbg) {
     (void)hipFree(g_kalman_dbg);
@@ -2190,6 +2191,7 @@ int dsge_options_init(dsge_options* o) {
   o->gensys_shape_cache = d.gensys_shape_cache;
   o->kalman_narrow = d.kalman_narrow;
   o->gensys_direct_blocks = d.gensys_direct_blocks;
+  o->kalman_head_draws = d.kalman_head_draws;
   o->ll_constant = d.ll_constant;
   o->mask_d = d.mask_d;
   o->joseph = d.joseph;

@@ -8,6 +8,7 @@
 #include "dsge_kernels.hpp"
 #include "dsge_kalman2.hpp"
 #include "dsge_kalman_nt.hpp"
+#include "dsge_kalman_nt2.hpp"
 #include "dsge_kalman_tail.hpp"
 #include "dsge_kalman_tiny.hpp"
 
@@ -18,6 +19,27 @@ int32_t* g_kalman_steady_at = nullptr;
                        // (experimental: measured SLOWER than the VALU register blocks)
 
 namespace {
+// The stream the two-wavefront head launch runs on, next to the caller's stream (fork / join by events): one per host thread and
+// device, created on first use.  Two calls of one thread on two caller streams share it -- their heads then run one after the
+// other, which is correct (events order them) and rare.
+struct HeadStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int dev = -1;
+};
+thread_local HeadStream t_head;
+int head_stream(HeadStream** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (t_head.dev != dev) {
+    HIP_TRY(hipStreamCreateWithFlags(&t_head.s, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&t_head.fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t_head.join, hipEventDisableTiming));
+    t_head.dev = dev;
+  }
+  *out = &t_head;
+  return DSGE_SUCCESS;
+}
 // hand-off records of the fast kernel for kalman_tail_kernel: one buffer per (device, stream), grown on demand
 StreamArenaPool g_tail_pool;
 int tail_reserve(size_t bytes, hipStream_t st, void** out) { return g_tail_pool.reserve(bytes, st, out); }
@@ -165,6 +187,18 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             auto launch_nt = [&](auto sk_tag) {
               constexpr int SKV = decltype(sk_tag)::value;
               const size_t lds_q = dsge::KntSmem<BS, SKV>::bytes(s_cap);
+              if constexpr (BS <= 4) {
+                if (g_kalman_dbg && opt().kalman_head_draws != 0) {  // tools/kalman_phases.py 2: the two-wavefront kernel, stamped
+                  const size_t lds2 = dsge::Knt2Smem<BS, SKV>::bytes(s_cap);
+                  rc = set_lds(dsge::kalman_nt2_kernel<BS, SKV, true>, lds2);
+                  if (rc == DSGE_SUCCESS)
+                    hipLaunchKernelGGL((dsge::kalman_nt2_kernel<BS, SKV, true>), dim3(batch), dim3(128), lds2, st, T, RQR,
+                                       p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len,
+                                       s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, rerun, g_kalman_steady_at,
+                                       order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask, g_kalman_dbg);
+                  return;
+                }
+              }
               if (g_kalman_dbg) {  // tools/kalman_phases.py: the instance with the phase stamps
                 rc = set_lds(dsge::kalman_nt_kernel<BS, true, SKV>, lds_q);
                 if (rc == DSGE_SUCCESS)
@@ -172,13 +206,54 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                                      st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
                                      p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
                                      rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
-              } else {
+                return;
+              }
+              // Head of the dispatch order on the two-wavefront kernel (dsge_kalman_nt2.hpp), on a second stream next to the bulk:
+              // the launch ends with its slowest draws, and those run a full step in two thirds of the time there.
+              int head = 0;
+              if constexpr (BS <= 4) {
+                head = opt().kalman_head_draws;
+                if (rerun) head = 0;
+                if (head < 0 || head > batch) head = batch;
+                if (head > 0 && head < batch && !order) head = 0;  // (without an order the first indices are no slower than the rest)
+                if (head > 0 && dsge::Knt2Smem<BS, SKV>::bytes(s_cap) > LDS_LIMIT) head = 0;
+              }
+              // The HEAD runs on the caller's stream, where it starts the moment the solver ends; the BULK goes to the library's
+              // second stream (fork / join by events).  The other way round the bulk, in stream order right behind the solver, fills
+              // every CU's LDS before the cross-stream dependency of the head resolves, and the slow draws start LAST (measured).
+              HeadStream* hs = nullptr;
+              hipStream_t bulk_st = st;
+              if (head > 0 && head < batch) {
+                if ((rc = head_stream(&hs))) return;
+                if (hipEventRecord(hs->fork, st) != hipSuccess || hipStreamWaitEvent(hs->s, hs->fork, 0) != hipSuccess) {
+                  rc = fail(DSGE_ERR_HIP, "kalman head launch: fork failed");
+                  return;
+                }
+                bulk_st = hs->s;
+              }
+              if constexpr (BS <= 4) {
+                if (head > 0) {
+                  const size_t lds2 = dsge::Knt2Smem<BS, SKV>::bytes(s_cap);
+                  if ((rc = set_lds(dsge::kalman_nt2_kernel<BS, SKV>, lds2))) return;
+                  hipLaunchKernelGGL((dsge::kalman_nt2_kernel<BS, SKV>), dim3(head), dim3(128), lds2, st, T, RQR,
+                                     p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, head, m, p, T_len,
+                                     s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, rerun, g_kalman_steady_at,
+                                     order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask, nullptr);
+                }
+              }
+              rc = DSGE_SUCCESS;
+              if (head < batch) {
                 rc = set_lds(dsge::kalman_nt_kernel<BS, false, SKV>, lds_q);
                 if (rc == DSGE_SUCCESS)
-                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(batch), dim3(64), lds_q,
-                                     st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m,
-                                     p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg,
-                                     rerun, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
+                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(batch - head), dim3(64), lds_q,
+                                     bulk_st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y,
+                                     batch - head, m, p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status,
+                                     g_kalman_dbg, rerun, g_kalman_steady_at, order ? order + head : nullptr, fold ? Rsel : nullptr,
+                                     qdiag, q_batched, k_shocks, colmask);
+              }
+              if (hs) {  // join: everything later on the caller's stream waits for the bulk
+                if (hipEventRecord(hs->join, hs->s) != hipSuccess || hipStreamWaitEvent(st, hs->join, 0) != hipSuccess)
+                  rc = fail(DSGE_ERR_HIP, "kalman head launch: join failed");
               }
             };
             // (the 32-wide tile only: on the 24-wide one the 20-column instance measured 1.4 % SLOWER on the headline step --

@@ -200,7 +200,13 @@ typedef struct dsge_options {
   int32_t ll_constant;
   int32_t mask_d;
   int32_t joseph;
-  int32_t reserved0_;
+  int32_t kalman_head_draws;  /* fast filter (selector Z, p <= 8, tiles up to 32 variables): this many draws at the HEAD of the
+                                 dispatch order (dsge_options.kalman_order: the draws most likely to run many full covariance
+                                 updates) are filtered by kalman_nt2_kernel -- two wavefronts per draw, the measurement update on
+                                 one, the two prediction products of the PREDICTED covariance on the other, a rank-p correction
+                                 joins them: a full step takes two thirds of the one-wavefront kernel's time (dsge_kalman_nt2.hpp) --
+                                 on a library-owned second stream next to the bulk (fork / join by events on the caller's stream).
+                                 Same recursion, results agree to rounding (tests compare the two kernels).  0: off; -1: every draw */
   double jitter_F;
   double jitter_P;
   int32_t reserved_[4];
@@ -411,7 +417,9 @@ int dsge_debug_kalman_steady_steps(int32_t* steady_at_device);
 
 /* Debug hook: enable != 0 makes the selector-path Kalman kernel record the shader cycles draw 0 spends
  * in each of its five per-step phases, [5] the cycles spent in steady-state steps, [6] their number and
- * [7] the kernel total; cycles_out (host int64[8], may be NULL) reads them back. */
+ * [7] the kernel total; cycles_out (host int64[16], may be NULL) reads them back.  With dsge_options.kalman_head_draws != 0 the
+ * two-wavefront kernel is stamped instead: [0..7] the update wavefront (F + elimination, gain, Tc K / Tc V, wait, a', total, closing
+ * wait, full steps), [8..15] the product wavefront (W0, X0, -, wait, correction, steady segments, closing wait, full steps). */
 int dsge_debug_kalman_phases(int enable, long long* cycles_out);
 /* cr_big_kernel (65 .. 96 variables), first draw of workgroup 0; cycles_out: 16 values.  [0] block loads, [1] eliminations, [2] scatters, [3] products, [4] iterations, [5] total, [8..12] inside the eliminations (see dsge_api.hip) */
 int dsge_debug_big_phases(int enable, long long* cycles_out);

@@ -90,11 +90,14 @@ SW_ROUTES = [
     ("sel+tail", {"kalman_nt_products": 0, "kalman_block": 1}, {}),   # ... handing the steady tail to kalman_tail_kernel
     ("general", {}, {"n_state_hint": 0, "z_selector_hint": 0}),  # no hints: kalman_sel_kernel<5, false> dense-Z fast path
     ("steady_off", {"kalman_steady_tol": 0.0}, {}),            # the full recursion, step for step
+    ("nt2", {"kalman_head_draws": -1}, {}),                    # kalman_nt2_kernel<3, 24>: two wavefronts per draw
+    ("nt2_steady_off", {"kalman_head_draws": -1, "kalman_steady_tol": 0.0}, {}),
 ]
 RBC_ROUTES = [
     ("tiny", {}, {}),                                          # kalman_tiny_kernel
     ("nt", {"kalman_tiny": 0}, {}),                            # wave-per-draw fast path on the 8-wide tile
     ("sel", {"kalman_tiny": 0, "kalman_nt_products": 0}, {}),
+    ("nt2", {"kalman_tiny": 0, "kalman_head_draws": -1}, {}),  # kalman_nt2_kernel<1, 8>
 ]
 
 
