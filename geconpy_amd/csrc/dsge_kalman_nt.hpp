@@ -140,7 +140,8 @@ __device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, co
 
 // DBG = true: the instance tools/kalman_phases.py launches (phase stamps of draw 0 in `dbg`); the product instance carries
 // neither the stamps nor their registers.
-template <int BS, bool DBG = false, int SK = 8 * BS>
+// TAIL = true: the instance that hands the steady, constant-mask tail of the sample to kalman_tail_kernel (dsge_options.kalman_block)
+template <int BS, bool DBG = false, int SK = 8 * BS, bool TAIL = false>
 // (two wavefronts per SIMD up to the 24-wide tile, and on the 32-wide one for its 20-column instance -- 20 KB of LDS, eight draws
 //  per CU; with the 256-register cap it spills 332 bytes per lane, and is still faster: observe_jumps 1.96 -> 2.04 M evals/s.  The
 //  generic 32-wide instance (28 KB of LDS) measured SLOWER with the cap: 1.92 against 1.77 ms per 4096 draws at 25 states.)
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     int T_len, int s_cap, FilterConv cv, double missing_fill, double steady_tol, double* __restrict__ logp_out,
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
     const int32_t* __restrict__ order, const double* __restrict__ Rsel, const double* __restrict__ qdiag, int q_batched,
-    int k_shocks, const unsigned long long* __restrict__ colmask_in) {
+    int k_shocks, const unsigned long long* __restrict__ colmask_in, double* __restrict__ tail_rec = nullptr,
+    int32_t* __restrict__ tail_flag = nullptr, const int32_t* __restrict__ tail_from = nullptr) {
   using SM = KntSmem<BS, SK>;
   constexpr int NP = SM::NP, LDK = SM::LDK, PS = SM::PS;
   constexpr bool NARROW = SK < NP;  // rows of Tc / W' / Pc shorter than the tile: stores beyond column SK - 1 are skipped
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = DBG ? clock64() : 0;
     int steady_step = -1;
+    bool handed_off = false;
     // y_t is fetched one step ahead by an UNCONDITIONAL, branch-free load (clamped indices; lanes with r8 >= p and the value
     // past the last step are never used -- every use is guarded by `obs`): under a condition the compiler sank the load to
     // the top of the step that needs it and waited for it there (s_waitcnt vmcnt(0) right behind the load, every step)
@@ -658,6 +661,50 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       if (!steady) continue;
       // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same (register-only) ====
       if (steady_step < 0) steady_step = t + 1;
+      if constexpr (TAIL) {
+        // ---- hand-off: the covariance is frozen AND the missing-data mask no longer changes until the end of the sample
+        //      (t >= *tail_from, kalman_mask_scan_kernel): the rest is a linear recursion in the mean, which kalman_tail_kernel runs in
+        //      blocks of steps with registers of its own.  This kernel writes the record and leaves the time loop.
+        if (tail_rec && t + 2 < T_len && t >= *tail_from) {
+          const double quad_now = wave_sum_dpp(quad_sum - quad_comp);
+          double* rec = tail_rec + (size_t)draw * KT_REC;
+          for (int idx = lane; idx < NP * NP; idx += 64) {
+            const int i = idx / NP, c = idx - i * NP;
+            rec[KT_T + i * 32 + c] = (c < s && c < SK) ? Tc[i * LDK + c] : 0.0;
+          }
+          for (int idx = lane; idx < NP * 8; idx += 64) rec[KT_K + idx] = Ks[(idx >> 3) * PS + (idx & 7)];
+          if (lane < 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rec[KT_FI + lane * 8 + q] = fr[q] * inv_own;
+          }
+          if (lane < NP) rec[KT_A + lane] = (lane < m) ? av[lane] : 0.0;
+          if (lane < 8) {
+            rec[KT_ZV + lane] = (lane < p) ? zv[lane] : 0.0;
+            rec[KT_DD + lane] = (lane < p && (((omask >> lane) & 1ull) || !cv.mask_d)) ? dd[lane] : 0.0;
+            rec[KT_ZP + lane] = (lane < p) ? (double)zpos[lane] : 0.0;
+          }
+          if (lane == 0) {
+            double* sc = rec + KT_SC;
+            sc[0] = (double)m;
+            sc[1] = (double)s;
+            sc[2] = (double)t;
+            sc[3] = (double)omask;
+            sc[4] = (double)n_obs;
+            sc[5] = step_mant;
+            sc[6] = (double)step_exp;
+            sc[7] = quad_now;
+            sc[8] = 0.0;
+            sc[9] = ld_mant;
+            sc[10] = (double)ld_exp;
+            sc[11] = (double)n_ll_steps;
+            sc[12] = (double)steady_step;
+            sc[13] = (double)n_obs_entries;
+            tail_flag[draw] = 1;
+          }
+          handed_off = true;
+          break;
+        }
+      }
       {
         double trow[SK], finv_row[8], kr_ss[8];
         double av_reg = (lane < m) ? av[lane] : 0.0;
@@ -721,7 +768,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       for (int k = 0; k < 8; ++k) dbg[k] = ph[k];
     }
     const double quad_total = wave_sum_dpp(quad_sum - quad_comp);  // lanes 0..7 hold the shares, the others zero
-    if (lane == 0) {
+    if (lane == 0 && !handed_off) {
       const double logdet = log(ld_mant) + (double)ld_exp * LN2;
       const double ll = -0.5 * (cv.ll_terms(n_ll_steps, n_obs_entries, p) * LN2PI + logdet + quad_total);
       logp_out[draw] = ll;

@@ -249,4 +249,253 @@ __global__ __launch_bounds__(64) void kalman_tail_kernel(const double* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// kalman_tail4_kernel (round 5): the same tail, FOUR steps per trip, small enough in LDS to keep every draw of a 4096-draw batch
+// resident.  Inside the tail the recursion is affine with constant matrices and data known in advance:
+//     a' = L a + TK y',   v = y' - Zm a,   L = Tc - TK Zm,   TK = Tc K,   y' = ym - d,   F^-1 = U'U
+//     U v_{t+j} = U y'_{t+j} - U Zm L^j a_t - sum_{i<j} U Zm L^(j-1-i) TK y'_{t+i}          (j = 0..3, 8 entries each)
+//     a_{t+4}   = L^4 a_t + sum_j L^(3-j) TK y'_{t+j}
+// 32 + m independent affine forms of (a_t, y'_t .. y'_{t+3}): lane 32 + 8 j + o owns entry o of U v_{t+j} (its square IS its share
+// of that step's quadratic form: no exchange), lane i < m owns a_{t+4}[i].  Per four steps: ONE broadcast of a_t (2 v_readlane per
+// entry) and MC + 32 FMAs per lane -- the single-step loop of the filter kernels issues ~150 instructions per STEP on one dependent
+// chain.  Every lane builds its own coefficient row: a row vector r pushed through L up to four times, r TK collected on the way.
+// MC = tile width of the filter instance that wrote the records (compile time: the rows are register arrays).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int MC>
+__global__ __launch_bounds__(64, 2) void kalman_tail4_kernel(const double* __restrict__ rec_all, const int32_t* __restrict__ tail_flag,
+                                                              const double* __restrict__ y, int batch, int p, int T_len,
+                                                              double missing_fill, double* __restrict__ logp_out,
+                                                              int32_t* __restrict__ status, int32_t* __restrict__ steady_at,
+                                                              FilterConv cv) {
+  constexpr int LDL = MC + 2, PS = 10;
+  __shared__ __attribute__((aligned(16))) double Ls[MC * LDL];   // L
+  __shared__ __attribute__((aligned(16))) double TKs[MC * PS];   // TK
+  __shared__ __attribute__((aligned(16))) double Ksh[MC * PS];   // K (set-up only)
+  __shared__ __attribute__((aligned(16))) double FinvM[64], Us[64], ymb[64];
+  __shared__ double zv[8], dd[8], vv[8], yps[8];
+  __shared__ int zpos[8];
+  const int lane = threadIdx.x;
+  const double LN2PI = 1.8378770664093453, LN2 = 0.6931471805599453;
+  const int draw = blockIdx.x;
+  if (draw >= batch || tail_flag[draw] != 1) return;
+  const double* rec = rec_all + (size_t)draw * KT_REC;
+  const double* sc = rec + KT_SC;
+  const int m = (int)sc[0], s = (int)sc[1];
+  if (m > MC || (MC > 8 && m <= MC - 8)) return;  // another instance's draw (wave-uniform)
+  int t = (int)sc[2];
+  const unsigned long long omask = (unsigned long long)sc[3];
+  const int n_obs = (int)sc[4];
+  const double step_mant = sc[5];
+  const int step_exp = (int)sc[6];
+  double quad_sum = (lane == 0) ? sc[7] - sc[8] : 0.0, quad_comp = 0.0;  // (per-lane shares from here on; lane 0 carries the past)
+  const double ld_mant = sc[9];
+  const long long ld_exp0 = (long long)sc[10], n_ll0 = (long long)sc[11];
+  for (int idx = lane; idx < MC * 8; idx += 64) Ksh[(idx >> 3) * PS + (idx & 7)] = rec[KT_K + idx];
+  FinvM[lane] = rec[KT_FI + lane];
+  if (lane < 8) {
+    zv[lane] = rec[KT_ZV + lane];
+    dd[lane] = rec[KT_DD + lane];  // (arrives masked if the convention says so: the mask is constant over the tail)
+    zpos[lane] = (int)rec[KT_ZP + lane];
+  }
+  double av_reg = (lane < MC) ? rec[KT_A + lane] : 0.0;
+  wave_sync();
+  for (int idx = lane; idx < m * 8; idx += 64) {  // TK = Tc K[S] (rows of Tc straight from the record: used once)
+    const int i = idx >> 3, o = idx & 7;
+    double g0 = 0.0, g1 = 0.0;
+    for (int k2 = 0; k2 < s; ++k2) {
+      const double tv = rec[KT_T + i * 32 + k2];
+      if (k2 & 1) g1 = fma(tv, Ksh[k2 * PS + o], g1); else g0 = fma(tv, Ksh[k2 * PS + o], g0);
+    }
+    TKs[i * PS + o] = g0 + g1;
+  }
+  wave_sync();
+  for (int idx = lane; idx < MC * LDL; idx += 64) {  // L = Tc - TK Zm (row stride LDL; rows / columns >= m zero)
+    const int i = idx / LDL, c = idx - i * LDL;
+    double val = (i < m && c < s) ? rec[KT_T + i * 32 + c] : 0.0;
+    if (i < m)
+      for (int o = 0; o < p; ++o)
+        if (zpos[o] == c && ((omask >> o) & 1ull)) val = fma(-zv[o], TKs[i * PS + o], val);
+    Ls[idx] = (i < m && c < m) ? val : 0.0;
+  }
+  // U = upper Cholesky factor of F^-1 (block diagonal: observed block, 1 / jit_F for missing entries, 1 for the padding)
+  double rch = FinvM[lane];
+  bool chol_ok = true;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double dj = readlane_f64(rch, j * 9);
+    if (!(dj > 0.0)) chol_ok = false;
+    const double rd = 1.0 / sqrt(dj);
+    const double rowq = __shfl(rch, (j << 3) | (lane & 7), 64), rowo = __shfl(rch, (j << 3) | (lane >> 3), 64);
+    if ((lane >> 3) == j)
+      rch = rowq * rd;
+    else if ((lane >> 3) > j)
+      rch = fma(-rowo * (rd * rd), rowq, rch);
+  }
+  if ((lane & 7) < (lane >> 3)) rch = 0.0;
+  Us[lane] = rch;
+  wave_sync();
+  int n_steps = 0;  // steps of the tail processed (each contributes ln det F and, through the lanes' shares, its quadratic form)
+  if (chol_ok && n_obs > 0) {
+    const bool is_s = lane < m, is_v = lane >= 32;
+    const int vj = (lane - 32) >> 3, vo = lane & 7;
+    const int my_mults = is_s ? 4 : (is_v ? vj : 0);
+    double r[MC], dco[4][8];
+#pragma unroll
+    for (int x = 0; x < MC; ++x) r[x] = (is_s && x == lane) ? 1.0 : 0.0;
+    if (is_v) {  // r = -(U Zm)[vo, :]
+      for (int q = vo; q < p; ++q)
+        if ((omask >> q) & 1ull) {
+          const double uv = -Us[vo * 8 + q] * zv[q];
+          const int zq = zpos[q];
+#pragma unroll
+          for (int x = 0; x < MC; ++x) r[x] = (x == zq) ? r[x] + uv : r[x];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dco[i][q] = (is_v && i == vj) ? Us[vo * 8 + q] : 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      double g[8];  // g = r TK: the coefficient of y' of an earlier step (v-lanes) / of step 3 - k (state lanes)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = 0.0;
+#pragma unroll
+      for (int yy = 0; yy < MC; ++yy) {  // (unrolled: r[yy] is a register, the row of TK a wave-uniform address)
+        if (yy < m) {
+          const double2* tk2 = reinterpret_cast<const double2*>(TKs + yy * PS);
+#pragma unroll
+          for (int q2 = 0; q2 < 4; ++q2) {
+            const double2 tv = tk2[q2];
+            g[2 * q2] = fma(r[yy], tv.x, g[2 * q2]);
+            g[2 * q2 + 1] = fma(r[yy], tv.y, g[2 * q2 + 1]);
+          }
+        }
+        if ((yy & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      const int slot = is_s ? 3 - k : vj - 1 - k;  // which step's y' this coefficient multiplies
+      if (slot >= 0 && (is_s || is_v)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i == slot) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dco[i][q] = g[q];
+          }
+      }
+      if (k < my_mults) {  // r <- r L
+        double nr[MC];
+#pragma unroll
+        for (int x = 0; x < MC; ++x) nr[x] = 0.0;
+#pragma unroll
+        for (int yy = 0; yy < MC; ++yy) {
+          if (yy < m) {
+            const double2* l2 = reinterpret_cast<const double2*>(Ls + yy * LDL);
+#pragma unroll
+            for (int x2 = 0; x2 < MC / 2; ++x2) {
+              const double2 lv = l2[x2];
+              nr[2 * x2] = fma(r[yy], lv.x, nr[2 * x2]);
+              nr[2 * x2 + 1] = fma(r[yy], lv.y, nr[2 * x2 + 1]);
+            }
+          }
+          if ((yy & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // (two rows of L in flight, not all MC: the scheduler otherwise hoists every load)
+        }
+#pragma unroll
+        for (int x = 0; x < MC; ++x) r[x] = nr[x];
+      }
+    }
+    double e0 = 0.0;  // constant of the affine form: -sum dco d
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double dq = (q < p) ? dd[q] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e0 = fma(-dco[i][q], dq, e0);
+    }
+    if (!(is_s || is_v)) e0 = 0.0;
+    // ---- the block loop: steps t+1 .. t+4 per trip (the mask is constant from here on: only the count of steps decides);
+    //      the data of the next trip are in flight during the current one
+    const int bi4 = lane >> 3, bq = lane & 7;  // lanes < 32: entry bq of step bi4 of the block
+    const int bqc = (bq < p) ? bq : (p > 0 ? p - 1 : 0);
+    const bool b_obs = (lane < 32) && (bq < p) && ((omask >> bq) & 1ull);
+    double yb = (lane < 32 && t + 1 + bi4 < T_len) ? y[(size_t)(t + 1 + bi4) * p + bqc] : 0.0;
+    while (t + 4 < T_len) {
+      double* yw = ymb + ((n_steps >> 2) & 1) * 32;
+      if (lane < 32) yw[lane] = (b_obs && yb == yb) ? yb : 0.0;
+      {
+        const int tn = t + 5 + bi4;
+        yb = (lane < 32) ? y[(size_t)(tn < T_len ? tn : T_len - 1) * p + bqc] : 0.0;
+      }
+      wave_sync();
+      double o0 = e0, o1 = 0.0;
+#pragma unroll
+      for (int x = 0; x < MC; x += 2) {
+        o0 = fma(r[x], readlane_f64(av_reg, x), o0);
+        o1 = fma(r[x + 1], readlane_f64(av_reg, x + 1), o1);
+      }
+      const double2* yr = reinterpret_cast<const double2*>(yw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+          const double2 yv2 = yr[i * 4 + q2];
+          o0 = fma(dco[i][2 * q2], yv2.x, o0);
+          o1 = fma(dco[i][2 * q2 + 1], yv2.y, o1);
+        }
+      const double outv = o0 + o1;
+      if (is_v) {  // (U v)[vo] of step t + 1 + vj: its square is this lane's share of that step's quadratic form
+        const double yk = outv * outv - quad_comp;
+        const double tk = quad_sum + yk;
+        quad_comp = (tk - quad_sum) - yk;
+        quad_sum = tk;
+      }
+      av_reg = is_s ? outv : 0.0;
+      t += 4;
+      n_steps += 4;
+    }
+  }
+  // ---- whatever is left (at most three steps; everything if F^-1 lost positive definiteness to rounding, or nothing is observed):
+  //      a' = L a + TK y',  v = y' - Zm a,  v' F^-1 v, one step at a time
+  while (t + 1 < T_len) {
+    ++t;
+    const bool ob_l = (lane < p) && ((omask >> lane) & 1ull);
+    const double yt = (lane < p) ? y[(size_t)t * p + lane] : 0.0;
+    const double yp = (lane < p) ? ((ob_l && yt == yt) ? yt : 0.0) - dd[lane] : 0.0;
+    const int zp_l = (lane < p) ? zpos[lane] : 0;
+    const double a_sel = __shfl(av_reg, zp_l, 64);
+    const double v_l = (lane < p) ? yp - (ob_l ? zv[lane] * a_sel : 0.0) : 0.0;
+    wave_sync();
+    if (lane < 8) {
+      vv[lane] = v_l;
+      yps[lane] = yp;
+    }
+    wave_sync();
+    if (n_obs > 0) {
+      double part = 0.0;
+      if (lane < 8) {
+        double w = 0.0;
+        for (int q = 0; q < 8; ++q) w = fma(FinvM[lane * 8 + q], vv[q], w);
+        part = vv[lane] * w;
+      }
+      const double yk = part - quad_comp;
+      const double tk = quad_sum + yk;
+      quad_comp = (tk - quad_sum) - yk;
+      quad_sum = tk;
+      ++n_steps;
+    }
+    double acc = 0.0;  // a' = L a + TK y': row `lane` of L against the broadcast state
+    for (int c = 0; c < m; ++c) acc = fma((lane < m) ? Ls[lane * LDL + c] : 0.0, readlane_dyn_f64(av_reg, c), acc);
+    for (int q = 0; q < 8; ++q) acc = fma((lane < m) ? TKs[lane * PS + q] : 0.0, yps[q], acc);
+    av_reg = (lane < m) ? acc : 0.0;
+  }
+  const double quad_total = wave_sum_dpp(quad_sum - quad_comp);
+  if (lane == 0) {
+    const long long n_ll = n_ll0 + n_steps;
+    const long long n_entries = (long long)sc[13] + (long long)n_steps * n_obs;
+    const double logdet = log(ld_mant) + (double)ld_exp0 * LN2 + (double)n_steps * (log(step_mant) + (double)step_exp * LN2);
+    const double ll = -0.5 * (cv.ll_terms(n_ll, n_entries, p) * LN2PI + logdet + quad_total);
+    logp_out[draw] = ll;
+    if (steady_at) steady_at[draw] = (int)sc[12];
+    if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
+  }
+}
+
 }  // namespace dsge

@@ -60,7 +60,7 @@ bool kalman_folds_rqr(int m, int p, int k, int n_state_hint, int z_selector_hint
   // mirrors the dispatch below: the NT fast kernel takes every draw first (no tiny / tail / MFMA variant in front of it)
   if (!(p <= 8 && z_selector_hint && opt().kalman_nt_products) || opt().kalman_mfma || k < 1 || k > dsge::RQR_KMAX) return false;
   if (opt().kalman_tiny && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) return false;
-  if (opt().kalman_block) return false;
+  if (opt().kalman_block && !opt().kalman_nt_products) return false;  // (the selector kernel's tail instance does not form R Q R')
   const int kp = (k + 1) & ~1;
   const int lo = (n_state_hint > 0 && n_state_hint < m) ? tile_bs(n_state_hint) : tile_bs(m);
   if (lo < 1 || lo > 8) return false;
@@ -168,7 +168,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               done = true;
             }
           }
-          if (!done && tail_rec) {
+          if (!done && tail_rec && BS <= 4 && !(opt().kalman_nt_products && !g_kalman_dbg)) {
             rc = set_lds(dsge::kalman_sel_kernel<BS, true, false, true>, lds);
             if (rc == DSGE_SUCCESS) {
               hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, false, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,
@@ -184,8 +184,9 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             // round-2 fast path: NT prediction products on 16-byte aligned rows (dsge_kalman_nt.hpp)
             // instance by the state-block capacity: SK = 20 (up to 18-20 state variables: rows of the LDS matrices 22 doubles
             // long, the 32-wide tile at exactly 20 KB = eight draws per CU and two waves per SIMD) or the generic SK = NP
-            auto launch_nt = [&](auto sk_tag) {
+            auto launch_nt = [&](auto sk_tag, auto tail_tag) {
               constexpr int SKV = decltype(sk_tag)::value;
+              constexpr bool TAILV = decltype(tail_tag)::value;  // hand the steady, constant-mask tails to kalman_tail4_kernel
               const size_t lds_q = dsge::KntSmem<BS, SKV>::bytes(s_cap);
               if constexpr (BS <= 4) {
                 if (g_kalman_dbg && opt().kalman_head_draws != 0) {  // tools/kalman_phases.py 2: the two-wavefront kernel, stamped
@@ -243,13 +244,13 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
               }
               rc = DSGE_SUCCESS;
               if (head < batch) {
-                rc = set_lds(dsge::kalman_nt_kernel<BS, false, SKV>, lds_q);
+                rc = set_lds(dsge::kalman_nt_kernel<BS, false, SKV, TAILV>, lds_q);
                 if (rc == DSGE_SUCCESS)
-                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV>), dim3(batch - head), dim3(64), lds_q,
+                  hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV, TAILV>), dim3(batch - head), dim3(64), lds_q,
                                      bulk_st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y,
                                      batch - head, m, p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status,
                                      g_kalman_dbg, rerun, g_kalman_steady_at, order ? order + head : nullptr, fold ? Rsel : nullptr,
-                                     qdiag, q_batched, k_shocks, colmask);
+                                     qdiag, q_batched, k_shocks, colmask, TAILV ? tail_rec : nullptr, tail_flag, tail_from);
               }
               if (hs) {  // join: everything later on the caller's stream waits for the bulk
                 if (hipEventRecord(hs->join, hs->s) != hipSuccess || hipStreamWaitEvent(st, hs->join, 0) != hipSuccess)
@@ -262,10 +263,16 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
             constexpr int SK_NARROW = (BS == 4) ? 20 : 8 * BS;
             // (with R folded in, the kernel stages the m x k selection matrix in its W' buffer, which is narrower too)
             const bool stage_fits = !fold || (size_t)m * ((k_shocks + 1) & ~1) <= (size_t)(8 * BS) * (SK_NARROW + 2);
-            if (SK_NARROW < 8 * BS && s_cap <= SK_NARROW && opt().kalman_narrow && stage_fits)
-              launch_nt(std::integral_constant<int, SK_NARROW>{});
+            const bool narrow_i = SK_NARROW < 8 * BS && s_cap <= SK_NARROW && opt().kalman_narrow && stage_fits;
+            const bool tail_i = tail_rec != nullptr && !g_kalman_dbg && BS <= 4;  // (the record holds a tile of at most 32 variables)
+            if (narrow_i && tail_i)
+              launch_nt(std::integral_constant<int, SK_NARROW>{}, std::true_type{});
+            else if (narrow_i)
+              launch_nt(std::integral_constant<int, SK_NARROW>{}, std::false_type{});
+            else if (tail_i)
+              launch_nt(std::integral_constant<int, 8 * BS>{}, std::true_type{});
             else
-              launch_nt(std::integral_constant<int, 8 * BS>{});
+              launch_nt(std::integral_constant<int, 8 * BS>{}, std::false_type{});
             if (rc == DSGE_SUCCESS) {
               HIP_TRY(hipGetLastError());
               launched_fast = true;
@@ -304,8 +311,30 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     }
   }
   if (tail_rec) {
-    hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, st, (const double*)tail_rec,
-                       (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv);
+    // four steps per trip; one launch per tile width that can have written records (a draw's record names its dimension m: the
+    // instance MC takes the draws with MC - 8 < m <= MC, so that every draw runs with the shortest rows that hold it).
+    // kalman_block = 2: the two-step kernel of round 2 (kept for comparison)
+    if (opt().kalman_block == 2) {
+      hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, st, (const double*)tail_rec,
+                         (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv);
+    } else {
+      const int bs_lo = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint < m) ? n_state_hint : m);
+      const int bs_hi = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint + p < m) ? n_state_hint + p : m);
+#define LAUNCH_TAIL4(MCV)                                                                                                     \
+  hipLaunchKernelGGL((dsge::kalman_tail4_kernel<MCV>), dim3(batch), dim3(64), 0, st, (const double*)tail_rec,                 \
+                     (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv)
+      for (int b = bs_lo; b <= bs_hi && b <= 4; ++b) {
+        if (b <= 1)
+          LAUNCH_TAIL4(8);
+        else if (b == 2)
+          LAUNCH_TAIL4(16);
+        else if (b == 3)
+          LAUNCH_TAIL4(24);
+        else
+          LAUNCH_TAIL4(32);
+      }
+#undef LAUNCH_TAIL4
+    }
     HIP_TRY(hipGetLastError());
   }
   if (fold) {  // the general kernel's inputs for the draws the fast kernel handed on: their sym(R Q R') after all

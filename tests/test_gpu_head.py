@@ -98,3 +98,43 @@ def test_two_wavefront_kernel_small_model_and_hint_violation():
     for i in (4, 5):
         ref = oracle.kalman_filter_logp(om["y"], T[i], R[i], np.diag(b["sigma"][i] ** 2), om["Z"], H=np.diag(om["Hdiag"]))
         assert_allclose(lp[i], ref, rtol=LOGP_RTOL)
+
+
+@pytest.mark.parametrize("observed", [None, wl.SW_OBSERVED_JUMPS], ids=["states_24wide", "jumps_32wide"])
+def test_tail_hand_off_from_the_fast_kernel_four_steps_per_trip(observed):
+    """dsge_options.kalman_block = 1 with the NT fast kernel (round 5): once the covariance is frozen and the missing-data mask no
+    longer changes, kalman_nt_kernel writes a record and kalman_tail4_kernel finishes the sample four steps per trip (32 + m affine
+    forms of the state and the data, one per lane).  Same recursion: logp against the in-kernel single-step loop and the oracle;
+    a mask that changes late in the sample (the hand-off happens behind it), conventions other than the default, the head /
+    bulk split on top."""
+    nb = 96
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model(observed=observed)
+    y = om["y"].copy()
+    y[17, 2] = np.nan
+    y[60:64] = np.nan
+    y[120:, 5] = oracle.MISSING_FILL  # from here on the mask is constant: one series missing
+    d = np.random.default_rng(4).normal(0, 0.01, 7)
+
+    def run(**options):
+        return batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], y, d=d, Hdiag=om["Hdiag"],
+                                                 tol=1e-8, max_iter=1000, options=options or None)
+
+    base = run()
+    for opts in ({"kalman_block": 1}, {"kalman_block": 2, "kalman_nt_products": 0}, {"kalman_block": 1, "kalman_head_draws": -1},
+                 {"kalman_block": 1, "mask_d": 1, "ll_constant": 1}):
+        ref = run(**{k_: v for k_, v in opts.items() if k_ in ("mask_d", "ll_constant")}) if "mask_d" in opts else base
+        r = run(**opts)
+        assert np.all(r["status"] == 0), opts
+        assert_allclose(r["logp"], ref["logp"], rtol=1e-11, err_msg=str(opts))
+    for i in (0, 31):
+        o = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], np.diag(b["sigma"][i] ** 2), om["Z"], y,
+                                     H=np.diag(om["Hdiag"]), d=d, tol=1e-8, max_iter=1000)
+        assert_allclose(run(kalman_block=1)["logp"][i], o["logp"], rtol=LOGP_RTOL)
+    # complete data (the mask never changes): every steady draw hands over
+    r0 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8,
+                                           max_iter=1000)
+    r1 = batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8,
+                                           max_iter=1000, options={"kalman_block": 1})
+    assert_allclose(r1["logp"], r0["logp"], rtol=1e-11)
+    assert np.any(r1["logp"] != r0["logp"])  # (the blocked tail rounds differently: it did run)
