@@ -545,6 +545,8 @@ def main():
                                      n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=n_lead, options=opts)
 
     ev = ShardedLogpEvaluator(global_batch, local_eval, device)
+    if world > 1 and not ev.host_staged:  # the engine writes its outputs straight into the rank's slice of the gather record
+        logp_buf, stat_buf = ev.local_logp, ev.local_status
 
     def barrier():
         if world > 1:
@@ -966,6 +968,8 @@ def main_second_order(args, world, rank, local_rank):
                                      max_iter=args.max_iter, logp=logp_buf, status=stat_buf, stage_ms=stage_ms, options=options)
 
     ev = ShardedLogpEvaluator(global_batch, local_eval, device)
+    if world > 1 and not ev.host_staged:  # the engine writes its outputs straight into the rank's slice of the gather record
+        logp_buf, stat_buf = ev.local_logp, ev.local_status
     for _ in range(args.warmup):
         ev.step()
     torch.cuda.synchronize()

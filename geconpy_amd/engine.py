@@ -405,23 +405,37 @@ class ShardedLogpEvaluator:
         self._l_logp = self._l_buf[: 8 * m].view(torch.float64)
         self._l_stat = self._l_buf[8 * m : 12 * m].view(torch.int32)
         self._l_logp.fill_(float("nan"))
+        n_loc = self.hi - self.lo
+        # the rank's slice of the send record: a ``local_eval`` that writes its logp / status straight into these (device views when
+        # the group is RCCL) saves the two staging copies of every step
+        self.local_logp = self._l_logp[:n_loc]
+        self.local_status = self._l_stat[:n_loc]
+        self._even = all(hi - lo == m for lo, hi in self.bounds)
+        self._on_device = not self.host_staged
 
     def step(self):
-        """Evaluate the local shard and gather; returns (logp, status) for ALL draws."""
+        """Evaluate the local shard and gather; returns (logp, status) for ALL draws.  Per step: the local evaluation, ONE
+        ``all_gather_into_tensor`` of the packed records, and one unpacking copy per output (the gathered records interleave logp
+        and status per rank); no staging copy when ``local_eval`` wrote into ``local_logp`` / ``local_status``, no device transfer
+        when the group gathers on the device."""
         logp, status = self.local_eval(self.lo, self.hi)
-        n_loc = self.hi - self.lo
         if self.world == 1:
             return logp, status
-        self._l_logp[:n_loc].copy_(logp)
-        self._l_stat[:n_loc].copy_(status)
+        if logp.data_ptr() != self.local_logp.data_ptr():
+            self.local_logp.copy_(logp)
+        if status.data_ptr() != self.local_status.data_ptr():
+            self.local_status.copy_(status)
         self.dist.all_gather_into_tensor(self._g_buf, self._l_buf, group=self.group)
         torch = self.torch
         m = self.max_shard
         recs = self._g_buf.view(self.world, self._rec)
         g_logp = recs[:, : 8 * m].view(torch.float64)        # (world, m) strided views of the gathered records
         g_stat = recs[:, 8 * m : 12 * m].view(torch.int32)
-        if all(hi - lo == m for lo, hi in self.bounds):
-            return g_logp.reshape(-1).to(self.device), g_stat.reshape(-1).to(self.device)
-        parts_l = [g_logp[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)]
-        parts_s = [g_stat[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)]
-        return torch.cat(parts_l).to(self.device), torch.cat(parts_s).to(self.device)
+        if self._even:
+            out_l, out_s = g_logp.reshape(-1), g_stat.reshape(-1)
+        else:
+            out_l = torch.cat([g_logp[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)])
+            out_s = torch.cat([g_stat[r, : hi - lo] for r, (lo, hi) in enumerate(self.bounds)])
+        if self._on_device:
+            return out_l, out_s
+        return out_l.to(self.device), out_s.to(self.device)

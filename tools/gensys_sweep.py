@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from geconpy_amd import _lib, workloads as wl
 from geconpy_amd.batched import lead_hint
+from _opts import set_option  # (tools/_opts.py: per-thread dsge_options)
 lib = _lib.load(); dev = torch.device("cuda", 0); nb = 4096
 for n in (8, 16, 24, 32, 40, 44, 48):
     ns, nl, k = max(2, int(0.45 * n)), max(1, int(0.3 * n)), min(7, n // 2)
@@ -17,7 +18,7 @@ for n in (8, 16, 24, 32, 40, 44, 48):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
     t_auto = e0.elapsed_time(e1) / 2
-    _lib.check(lib.dsge_set_gensys_split(0))  # the single-launch kernel for comparison
+    set_option("gensys_split", 0)  # the single-launch kernel for comparison
     try:
         run(); torch.cuda.synchronize()
         e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
@@ -25,5 +26,5 @@ for n in (8, 16, 24, 32, 40, 44, 48):
     except _lib.DsgeHipError:
         t_single = float("nan")  # does not fit the 160 KB of LDS
     finally:
-        _lib.check(lib.dsge_set_gensys_split(1))
+        set_option("gensys_split", 1)
     print(f"n={n:2d} N={n + nlh:2d}: gensys {t_auto:.2f} ms per {nb} draws (single-launch kernel {t_single:.2f} ms); ok {int((st == 0).sum())}")

@@ -14,7 +14,7 @@ out = None
 for it in range(2):
     out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out)
 torch.cuda.synchronize()
-cyc = (ctypes.c_longlong * 8)()
+cyc = (ctypes.c_longlong * 16)()  # (the hook returns 16 values since ABI 8)
 _lib.check(lib.dsge_debug_kalman_phases(0, ctypes.addressof(cyc)))
 c = np.array(list(cyc), dtype=np.int64)
 nf, ns = int(c[6]), int(c[7])

@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from geconpy_amd import _lib, batched, workloads as wl
 from geconpy_amd.engine import LogpEngine
+from _opts import set_option  # (tools/_opts.py: per-thread dsge_options)
 nb = 4096
 b = wl.sw_shaped_batch(nb); om = wl.sw_shaped_observation_model()
 eng = LogpEngine(torch.device("cuda", 0)); lib = _lib.load()
-_lib.check(lib.dsge_set_pipeline_chunks(0)); _lib.check(lib.dsge_set_kalman_block(0))
+set_option("pipeline_chunks", 0); set_option("kalman_block", 0)
 dZ, dy, dH = eng.to_device(om["Z"]), eng.to_device(om["y"]), eng.to_device(om["Hdiag"])
 def timed(perm, label):
     dA, dB, dC, dD = (eng.to_device(b[x][perm]) for x in "ABCD"); dq = eng.to_device((b["sigma"] ** 2)[perm])

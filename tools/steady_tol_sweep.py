@@ -3,6 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from geconpy_amd import batched, workloads as wl
 from geconpy_amd.engine import LogpEngine
+from _opts import set_option  # (tools/_opts.py: per-thread dsge_options)
 nb = 4096
 b = wl.sw_shaped_batch(nb); om = wl.sw_shaped_observation_model()
 eng = LogpEngine(torch.device("cuda", 0))
@@ -13,7 +14,7 @@ def run():
     return eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, tol=1e-8, max_iter=1000, n_state_hint=hints[0], z_selector_hint=hints[1])
 ref = None
 for tol in (0.0, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10):
-    batched.set_kalman_steady_tol(tol)
+    set_option("kalman_steady_tol", tol)
     out = run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -23,4 +24,4 @@ for tol in (0.0, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10):
     if ref is None: ref = lp
     ok = np.isfinite(ref)
     print(f"tol {tol:g}: {e0.elapsed_time(e1)/5:.3f} ms/step, max rel diff vs tol=0: {np.max(np.abs(lp[ok]-ref[ok])/np.abs(ref[ok])):.2e}")
-batched.set_kalman_steady_tol(1e-14)
+set_option("kalman_steady_tol", 1e-14)
