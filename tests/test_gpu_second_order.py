@@ -106,6 +106,34 @@ def test_second_order_sw_shaped_draws():
         assert abs(out["logp"][i] - r["logp"]) <= LOGP_RTOL * abs(r["logp"]), (i, out["logp"][i], r["logp"])
 
 
+def test_second_order_sw_shaped_64_distinct_draws_against_fixture():
+    """the full configs[4] shape (n = 40, 18 states, 7 shocks, 7 observables, T = 200, 480 Hessian entries) on 64
+    DISTINCT draws against oracle/second_order.py through a committed fixture (tests/golden/second_order_sw64.npz, written by
+    tests/golden/make_second_order_golden.py: 3 s of CPU per draw).  logp to 1e-8 relative, g_ss to 1e-9; the same 64 draws inside
+    a 1024-draw batch (tiled; the dispatch order and the chunking are active there) come back bit-identical.
+    *** parity unpinned against the reference by construction: gEconpy raises for order != 1 (perturbation.py:97-98). ***"""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "second_order_sw64.npz"))
+    nb = int(g["n_draws"])
+    b = wl.sw_second_order_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    out = batched.second_order_logp_batched(b["A"], b["B"], b["C"], b["D"], b["hess_idx"], b["hess_val"], q, om["Z"], om["y"],
+                                            Hdiag=om["Hdiag"], tol=1e-8, return_solution=True)
+    assert (out["status"] == 0).all()
+    rel = np.abs(out["logp"] - g["logp"]) / np.abs(g["logp"])
+    assert rel.max() <= LOGP_RTOL, (int(rel.argmax()), rel.max())
+    assert_allclose(out["g_ss"], g["g_ss"], atol=1e-9 * max(1.0, np.abs(g["g_ss"]).max()))
+    rep = 16
+    t3 = lambda x: np.tile(x, (rep, 1, 1))  # noqa: E731
+    big = batched.second_order_logp_batched(t3(b["A"]), t3(b["B"]), t3(b["C"]), t3(b["D"]), b["hess_idx"], np.tile(b["hess_val"], (rep, 1)),
+                                            np.tile(q, (rep, 1)), om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8)
+    assert (big["status"] == 0).all()
+    lp = big["logp"].reshape(rep, nb)
+    assert np.array_equal(lp, np.broadcast_to(out["logp"], lp.shape))
+
+
 def test_second_order_structure_violations_are_flagged():
     """A Hessian entry list that is not sorted by equation, and a design matrix that observes a variable outside the declared
     retained set: DSGE_ST_SECOND_ORDER_UNSUPPORTED (128) and logp = -inf for every draw, never a wrong number."""
