@@ -486,10 +486,13 @@ __device__ __forceinline__ double readlane_dyn_f64(double v, int src_lane_unifor
 // kernel) a draw with a ratio of 3.3e3 at cond 9e7 came out 7e-9 off (fuzz seed 2): 1e3 there (one or two draws in a
 // hundred).  Every refinement lengthens its draw by an elimination, and the launch by that draw's tail: the 1e3 rule on the
 // 32-wide tile of the bench costs 0.1 ms of the 0.65 ms solver launch, the 1e4 rule 0.04 ms.
+// Round 5: 3e3 on the tiles of up to 40 variables.  The round-4 campaign (ten times the suite's trial counts) left ONE system in
+// 3000 at 2.7e-9 from the 40-digit T (an ill-conditioned intermediate A1 with a pivot ratio between 3e3 and 1e4) against the
+// suite's own 1e-9 bar; 3e3 takes it.  Cost on the bench: see profiles/r5/ (about three draws in a thousand more refine an iteration).
 constexpr double CR_REFINE_PIVOT_RATIO = 1e3;
 template <int BS>
 __device__ __forceinline__ constexpr double cr_refine_ratio() {
-  return BS <= 5 ? 1e4 : 1e3;
+  return BS <= 5 ? 3e3 : 1e3;
 }
 
 template <int BS>

@@ -45,9 +45,9 @@ class FilterConventions:
     (pymc_extras is not installed).  Every field is a switch, so that the day a real install produces
     tests/golden/pymc_extras_kalman.npz (tests/golden/make_pymc_extras_golden.py) a mismatch is a one-line change of
     ``DEFAULT_CONVENTIONS`` here -- tests/test_oracle_kalman.py::test_pymc_extras_pin then names the combination that matches --
-    and of the constants it maps to in the kernels ("filter conventions": the ``p ln 2pi`` term is
-    ``ll_const`` in dsge_kalman_nt.hpp / dsge_kalman2.hpp / dsge_kalman_tiny.hpp / dsge_kernels.hpp, the jitter placement the two
-    ``jit`` additions of the measurement update).
+    and a CONFIGURATION of the product: since ABI 8 the device kernels take the same switches at run time (``dsge_options.ll_constant
+    / jitter_F / jitter_P / mask_d / joseph``; ``geconpy_amd._lib.filter_conventions`` has this constructor's keyword names), and
+    tests/test_gpu_conventions.py holds every kernel to every combination of them.
 
       ll_constant     "p": p ln 2pi with p the FULL observation dimension, also under missing entries (restated default);
                       "observed": (#observed entries) ln 2pi;  "one": a single ln 2pi (older upstream ``StandardFilter.update``)
