@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void kalman_tail_kernel(const double* __restric
 // MC = tile width of the filter instance that wrote the records (compile time: the rows are register arrays).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int MC>
-__global__ __launch_bounds__(64, 2) void kalman_tail4_kernel(const double* __restrict__ rec_all, const int32_t* __restrict__ tail_flag,
+__global__ __launch_bounds__(64, 2) void kalman_tail4_kernel(const double* __restrict__ rec_all, int32_t* __restrict__ tail_flag,
                                                               const double* __restrict__ y, int batch, int p, int T_len,
                                                               double missing_fill, double* __restrict__ logp_out,
                                                               int32_t* __restrict__ status, int32_t* __restrict__ steady_at,
@@ -495,6 +495,7 @@ __global__ __launch_bounds__(64, 2) void kalman_tail4_kernel(const double* __res
     logp_out[draw] = ll;
     if (steady_at) steady_at[draw] = (int)sc[12];
     if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
+    tail_flag[draw] = 2;  // done: a later pass of the tail kernel (behind a re-run of flagged draws) leaves this draw alone
   }
 }
 

@@ -128,6 +128,34 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     }
     HIP_TRY(hipGetLastError());
   }
+  auto launch_tail = [&](hipStream_t ts) -> int {
+    // four steps per trip; one launch per tile width that can have written records (a draw's record names its dimension m: the
+    // instance MC takes the draws with MC - 8 < m <= MC, so that every draw runs with the shortest rows that hold it).
+    // kalman_block = 2: the two-step kernel of round 2 (kept for comparison)
+    if (opt().kalman_block == 2) {
+      hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, ts, (const double*)tail_rec,
+                         (int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv);
+    } else {
+      const int bs_lo = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint < m) ? n_state_hint : m);
+      const int bs_hi = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint + p < m) ? n_state_hint + p : m);
+#define LAUNCH_TAIL4(MCV)                                                                                                     \
+  hipLaunchKernelGGL((dsge::kalman_tail4_kernel<MCV>), dim3(batch), dim3(64), 0, ts, (const double*)tail_rec,                 \
+                     (int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv)
+      for (int b = bs_lo; b <= bs_hi && b <= 4; ++b) {
+        if (b <= 1)
+          LAUNCH_TAIL4(8);
+        else if (b == 2)
+          LAUNCH_TAIL4(16);
+        else if (b == 3)
+          LAUNCH_TAIL4(24);
+        else
+          LAUNCH_TAIL4(32);
+      }
+#undef LAUNCH_TAIL4
+    }
+    HIP_TRY(hipGetLastError());
+    return DSGE_SUCCESS;
+  };
   if (fast) {
     // The fast kernel filters only the variables that matter (states + observed non-states), so its
     // tile size follows that reduced dimension u, not m.  u is only known per draw on the device
@@ -252,6 +280,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                                      g_kalman_dbg, rerun, g_kalman_steady_at, order ? order + head : nullptr, fold ? Rsel : nullptr,
                                      qdiag, q_batched, k_shocks, colmask, TAILV ? tail_rec : nullptr, tail_flag, tail_from);
               }
+              if (hs && TAILV && rc == DSGE_SUCCESS) rc = launch_tail(hs->s);  // the bulk's tails next to the head, not behind it
               if (hs) {  // join: everything later on the caller's stream waits for the bulk
                 if (hipEventRecord(hs->join, hs->s) != hipSuccess || hipStreamWaitEvent(st, hs->join, 0) != hipSuccess)
                   rc = fail(DSGE_ERR_HIP, "kalman head launch: join failed");
@@ -311,31 +340,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     }
   }
   if (tail_rec) {
-    // four steps per trip; one launch per tile width that can have written records (a draw's record names its dimension m: the
-    // instance MC takes the draws with MC - 8 < m <= MC, so that every draw runs with the shortest rows that hold it).
-    // kalman_block = 2: the two-step kernel of round 2 (kept for comparison)
-    if (opt().kalman_block == 2) {
-      hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, st, (const double*)tail_rec,
-                         (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv);
-    } else {
-      const int bs_lo = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint < m) ? n_state_hint : m);
-      const int bs_hi = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint + p < m) ? n_state_hint + p : m);
-#define LAUNCH_TAIL4(MCV)                                                                                                     \
-  hipLaunchKernelGGL((dsge::kalman_tail4_kernel<MCV>), dim3(batch), dim3(64), 0, st, (const double*)tail_rec,                 \
-                     (const int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv)
-      for (int b = bs_lo; b <= bs_hi && b <= 4; ++b) {
-        if (b <= 1)
-          LAUNCH_TAIL4(8);
-        else if (b == 2)
-          LAUNCH_TAIL4(16);
-        else if (b == 3)
-          LAUNCH_TAIL4(24);
-        else
-          LAUNCH_TAIL4(32);
-      }
-#undef LAUNCH_TAIL4
-    }
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_tail(st))) return rc;
   }
   if (fold) {  // the general kernel's inputs for the draws the fast kernel handed on: their sym(R Q R') after all
     if ((rc = launch_rqr(Rsel, qdiag, q_batched, batch, m, k_shocks, status, RQR, st, 1))) return rc;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): the bench lines, rocprofv3 kernel statistics and counters that profiles/r4/ keeps.
-# Usage: bash tools/refresh_profiles_r4.sh [tag]   (then copy gpurun_out/<tag>/* into profiles/r4/)
+# Run on the GPU box (through gpurun): the bench lines, rocprofv3 kernel statistics and counters that profiles/r5/ keeps.
+# Usage: bash tools/refresh_profiles.sh [tag]   (then copy gpurun_out/<tag>/* into profiles/r5/)
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -23,8 +23,8 @@ python3 tools/pmc_collect.py "$OUT/pmc_gensys" -- --solver gensys > "$OUT/pmc_ge
 python3 tools/pmc_collect.py "$OUT/pmc_so" -- --workload sw_second_order --no-extras > "$OUT/pmc_so.txt" 2>&1 && cp "$OUT/pmc_so/pmc_counters.json" "$OUT/pmc_counters_sw_second_order.json"
 rm -rf "$OUT/pmc_default" "$OUT/pmc_gensys" "$OUT/pmc_so"
 # the roofline blocks quote flops / traffic from the counters committed under profiles/: take the lines after they are refreshed
-mkdir -p profiles/r4
-cp "$OUT/pmc_counters_sw_second_order.json" "$OUT/pmc_counters.json" "$OUT/pmc_counters_gensys.json" profiles/r4/ 2>/dev/null
+mkdir -p profiles/r5
+cp "$OUT/pmc_counters_sw_second_order.json" "$OUT/pmc_counters.json" "$OUT/pmc_counters_gensys.json" profiles/r5/ 2>/dev/null
 python3 bench.py --workload sw_second_order > "$OUT/bench_sw_second_order.json" 2> "$OUT/bench_sw_second_order.err"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
@@ -39,7 +39,10 @@ rm -rf "$OUT/kt_big"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_big" -o kt -- python3 tools/big_rate.py 80 1024 > "$OUT/kt_big.log" 2>&1
 find "$OUT/kt_big" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_big80.csv" \;
 rm -rf "$OUT/kt_big" "$OUT/kt_big.log"
-python3 tools/pipeline_chunks_rate.py gensys > "$OUT/pipeline_chunks_gensys.txt" 2>&1
+python3 tools/straggler_cut.py > "$OUT/straggler_cut.txt" 2>&1
+python3 tools/head_sweep.py > "$OUT/head_sweep.txt" 2>&1
+python3 tools/tail_ab.py > "$OUT/tail_handoff_ab.txt" 2>&1
+python3 tools/kalman_phases2.py 1 0 > "$OUT/kalman_two_wavefront_phases.txt" 2>&1; python3 tools/kalman_phases2.py 4096 0 >> "$OUT/kalman_two_wavefront_phases.txt" 2>&1
 bash tools/batch_scaling.sh "$TAG/bscale" > /dev/null 2>&1; cp "$OUT/bscale/summary.txt" "$OUT/batch_scaling.txt" 2>/dev/null; rm -rf "$OUT/bscale"
 python3 -m pytest tests -m gpu -q > "$OUT/tests_gpu.log" 2>&1
 tail -3 "$OUT/tests_gpu.log"
