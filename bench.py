@@ -101,6 +101,47 @@ def cpu_baseline(batch, om, n_sample, cores, solver="cycle_reduction"):
         dt = time.perf_counter() - t0
     return np.array(logp), n_sample / dt, dt
 
+GRAD_FD_DRAWS = (0, 1, 2, 3)
+GRAD_FD_EPS = 1e-6
+
+
+def _grad_directions(shard, i):
+    """Seeded direction of the directional-derivative check of draw i: dA respects the structural zeros of A (the contract of the
+    gradient entry point), dq is relative to q."""
+    rng = np.random.default_rng((20261003, i))
+    A = shard["A"][i]
+    maskA = (A != 0).any(axis=0)[None, :] * np.ones_like(A)
+    q = shard["sigma"][i] ** 2
+    return dict(A=rng.standard_normal(A.shape) * maskA * 0.1, B=rng.standard_normal(A.shape) * 0.1,
+                C=rng.standard_normal(A.shape) * 0.1, D=rng.standard_normal(shard["D"][i].shape) * 0.1,
+                q=rng.standard_normal(q.shape) * q * 0.3)
+
+
+def _cpu_fd_worker(args):
+    import oracle
+
+    A, B, C, D, q, Z, y, Hd = args
+    return oracle.solve_kalman_logp(A, B, C, D, np.diag(q), Z, y, H=np.diag(Hd), tol=1e-13, max_iter=1000)["logp"]
+
+
+def gradient_fd_reference(shard, om, cores):
+    """Central differences of the CPU oracle's logp along one seeded direction per draw (GRAD_FD_DRAWS): what the device gradient
+    of the `gradient` leg is checked against.  -> {draw: (f(x + eps d) - f(x - eps d)) / (2 eps)}"""
+    import multiprocessing as mp
+
+    jobs = []
+    for i in GRAD_FD_DRAWS:
+        d = _grad_directions(shard, i)
+        q = shard["sigma"][i] ** 2
+        for sgn in (1.0, -1.0):
+            e = sgn * GRAD_FD_EPS
+            jobs.append((shard["A"][i] + e * d["A"], shard["B"][i] + e * d["B"], shard["C"][i] + e * d["C"], shard["D"][i] + e * d["D"],
+                         q + e * d["q"], om["Z"], om["y"], om["Hdiag"]))
+    with mp.get_context("spawn").Pool(min(cores, len(jobs))) as pool:
+        vals = pool.map(_cpu_fd_worker, jobs)
+    return {i: (vals[2 * j] - vals[2 * j + 1]) / (2 * GRAD_FD_EPS) for j, i in enumerate(GRAD_FD_DRAWS)}
+
+
 PMC_LEGS = {  # kernels of one fused step, by leg: alternative GROUPS of rocprofv3 kernel-name substrings, first match wins
     "solver": (("cr_fused_kernel",), ("cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel"), ("cr_compact_kernel",),
                ("cr_solve_kernel",)),
@@ -453,7 +494,7 @@ def main():
     # observation model of the realistic-structure leg (seven observed JUMP variables) -- also before the GPU is touched
     want_extras = (world == 1 and not args.no_extras and not args.from_theta and args.workload == "sw_shaped"
                    and args.solver == "cycle_reduction")
-    cpu_gensys = cpu_jumps = om_j = b80 = om80 = cpu_n80 = om_c = cpu_cons = None
+    cpu_gensys = cpu_jumps = om_j = b80 = om80 = cpu_n80 = om_c = cpu_cons = grad_fd = None
     if want_extras:
         om_j = wl.sw_shaped_observation_model(observed=wl.SW_OBSERVED_JUMPS)
         shape80 = dict(n=80, n_state=36, n_lead=24, k=10, p=7, T_len=200)  # the `n80` leg: a model beyond 64 variables
@@ -471,6 +512,7 @@ def main():
         cpu_jumps = cpu_baseline(shard, om_j, n_x, cores)
         cpu_n80 = cpu_baseline(b80, om80, min(128, max(16, cores)), cores)
         cpu_cons = cpu_baseline(shard, om_c, n_x, cores, solver="gensys")
+        grad_fd = gradient_fd_reference(shard, om, cores)
 
     so_leg = second_order_leg() if (want_extras and rank == 0) else None
 
@@ -685,6 +727,35 @@ def main():
                                                 "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_c)),
                                                 "n_checked": int(len(ref_c)), "bar": 1e-8,
                                                 "cpu_oracle_evals_per_s": round(cpu_cons[1], 2)}
+        # logp + reverse-mode gradient of the same batch (what a NUTS step costs: solver pullback, reverse Kalman sweep, assembly;
+        # SURVEY 8 f2), with the directional-derivative check against central differences of the CPU oracle
+        try:
+            g_out = [None]
+
+            def grad_call():
+                g_out[0] = eng.solve_kalman_logp_grad(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, tol=args.tol, max_iter=args.max_iter,
+                                                      n_filter_hint=hints[0], out=g_out[0])
+
+            dt_gr = timed(grad_call, 3)
+            go = g_out[0]
+            extras["gradient"] = {"value": round(nloc / dt_gr, 2), "ms_per_step": round(dt_gr * 1e3, 4), "unit": "logp+gradient evals/s",
+                                  "note": "dsge_solve_kalman_logp_grad_batched on the same 4096 draws: logp and its cotangents with respect "
+                                          "to A, B, C, D, q (policy-function adjoints by Stein doubling, reverse sweep of the filter)",
+                                  "failed_draws": int((go["status"] != 0).sum().item()),
+                                  "max_rel_logp_diff_vs_headline": float((torch.abs(go["logp"] - logp_all[lo:hi]) /
+                                                                          torch.abs(go["logp"])).max().item())}
+            if grad_fd is not None:
+                errs = []
+                for i, fd in grad_fd.items():
+                    dirs = _grad_directions(shard, i)
+                    an = sum(float((go[f"{k_}_bar"][i].cpu().numpy() * dirs[k_]).sum()) for k_ in ("A", "B", "C", "D", "q"))
+                    errs.append(abs(an - fd) / max(1.0, abs(fd)))
+                extras["gradient"]["parity"] = {"max_rel_directional_derivative_err_vs_cpu_oracle_fd": float(max(errs)),
+                                                "n_checked": len(errs), "fd_eps": GRAD_FD_EPS, "bar": 2e-5,
+                                                "note": "<gradient, direction> against the central difference of the CPU oracle's logp "
+                                                        "along one seeded direction per draw (all five cotangents at once)"}
+        except Exception as exc:  # (never lose the headline line to an extra leg)
+            extras["gradient"] = {"error": repr(exc)}
         # the same batch evaluated by TWO callers at once, each on its own stream (two PyMC chains sharing the GPU, or a sampler
         # that splits its particles): the library keeps its scratch per (device, stream); one sequence leaves most of the chip idle
         # while the Kalman launch waits for its never-steady draw, a second one fills that time.  Whole-GPU rate, never `value`.

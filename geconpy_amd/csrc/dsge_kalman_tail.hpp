@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64, 2) void kalman_tail4_kernel(const double* __res
                                                               const double* __restrict__ y, int batch, int p, int T_len,
                                                               double missing_fill, double* __restrict__ logp_out,
                                                               int32_t* __restrict__ status, int32_t* __restrict__ steady_at,
-                                                              FilterConv cv) {
+                                                              FilterConv cv, int m_lo) {
   constexpr int LDL = MC + 2, PS = 10;
   __shared__ __attribute__((aligned(16))) double Ls[MC * LDL];   // L
   __shared__ __attribute__((aligned(16))) double TKs[MC * PS];   // TK
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64, 2) void kalman_tail4_kernel(const double* __res
   const double* rec = rec_all + (size_t)draw * KT_REC;
   const double* sc = rec + KT_SC;
   const int m = (int)sc[0], s = (int)sc[1];
-  if (m > MC || (MC > 8 && m <= MC - 8)) return;  // another instance's draw (wave-uniform)
+  if (m > MC || m <= m_lo) return;  // another instance's draw (wave-uniform): this one takes m_lo < m <= MC
   int t = (int)sc[2];
   const unsigned long long omask = (unsigned long long)sc[3];
   const int n_obs = (int)sc[4];

@@ -130,7 +130,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   }
   auto launch_tail = [&](hipStream_t ts) -> int {
     // four steps per trip; one launch per tile width that can have written records (a draw's record names its dimension m: the
-    // instance MC takes the draws with MC - 8 < m <= MC, so that every draw runs with the shortest rows that hold it).
+    // instance MC takes the draws with m_lo < m <= MC, so that every draw runs with the shortest rows that hold it).
     // kalman_block = 2: the two-step kernel of round 2 (kept for comparison)
     if (opt().kalman_block == 2) {
       hipLaunchKernelGGL(dsge::kalman_tail_kernel, dim3(batch), dim3(64), 0, ts, (const double*)tail_rec,
@@ -140,8 +140,9 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
       const int bs_hi = tile_bs((z_selector_hint && n_state_hint > 0 && n_state_hint + p < m) ? n_state_hint + p : m);
 #define LAUNCH_TAIL4(MCV)                                                                                                     \
   hipLaunchKernelGGL((dsge::kalman_tail4_kernel<MCV>), dim3(batch), dim3(64), 0, ts, (const double*)tail_rec,                 \
-                     (int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv)
+                     (int32_t*)tail_flag, y, batch, p, T_len, missing_fill, logp, status, g_kalman_steady_at, cv, m_lo)
       for (int b = bs_lo; b <= bs_hi && b <= 4; ++b) {
+        const int m_lo = (b == bs_lo) ? 0 : 8 * (b - 1);  // (the narrowest instance also takes the draws that are smaller than its tile)
         if (b <= 1)
           LAUNCH_TAIL4(8);
         else if (b == 2)

@@ -138,3 +138,24 @@ def test_tail_hand_off_from_the_fast_kernel_four_steps_per_trip(observed):
                                            max_iter=1000, options={"kalman_block": 1})
     assert_allclose(r1["logp"], r0["logp"], rtol=1e-11)
     assert np.any(r1["logp"] != r0["logp"])  # (the blocked tail rounds differently: it did run)
+
+
+def test_tail_hand_off_of_a_draw_smaller_than_its_tile():
+    """A draw with far fewer state variables than the hint (9 of 18: reduced dimension m = 9 inside the 24-wide tile) is handed
+    over like the others; the narrowest tail instance launched must take it (regression: instance selection by m)."""
+    nb = 8
+    b = wl.sw_shaped_batch(nb)
+    om = wl.sw_shaped_observation_model()
+    T = np.stack([oracle.cycle_reduction_core(b["A"][i], b["B"][i], b["C"][i], 1000, 1e-12)[0] for i in range(nb)])
+    R = np.stack([oracle.compute_selection_matrix(b["B"][i], b["C"][i], b["D"][i], T[i]) for i in range(nb)])
+    T[3][:, 9:18] = 0.0   # states 9..17 of draw 3 stop feeding back: 9 state columns (the observed variables 0..6 are among them)
+    T[5][:, 2:18] = 0.0   # and a draw with 2 states + 5 observed non-states
+    q = b["sigma"] ** 2
+    base, st0 = batched.kalman_logp_batched(T, R, q, om["Z"], om["y"], Hdiag=om["Hdiag"], q_mode="diag_batched", n_state_hint=18)
+    tail, st1 = batched.kalman_logp_batched(T, R, q, om["Z"], om["y"], Hdiag=om["Hdiag"], q_mode="diag_batched", n_state_hint=18,
+                                            options={"kalman_block": 1})
+    assert np.all(st0 == 0) and np.all(st1 == 0)
+    assert_allclose(tail, base, rtol=1e-11)
+    for i in (3, 5):
+        ref = oracle.kalman_filter_logp(om["y"], T[i], R[i], np.diag(q[i]), om["Z"], H=np.diag(om["Hdiag"]))
+        assert_allclose(tail[i], ref, rtol=LOGP_RTOL)
