@@ -678,6 +678,29 @@ def main():
                                           "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_g)),
                                           "n_checked": int(len(ref_g)),
                                           "cpu_oracle_gensys_evals_per_s": round(cpu_gensys[1], 2)}
+        # the same leg with dsge_options.gensys_doubling: gensys by spectral division (csrc/dsge_gensys_doubling.hpp) -- the doubling
+        # iteration computes the solvent, a per-draw certificate stands for eu = [1, 1, 0], the ordered QZ takes every draw without one
+        lp_d = torch.empty_like(logp_buf)
+        st_d = torch.empty_like(stat_buf)
+        opts_d = dict(opts or {}, gensys_doubling=1)
+        dt_d = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
+                                                   max_iter=args.max_iter, logp=lp_d, status=st_d, solver="gensys",
+                                                   n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g, options=opts_d),
+                     max(3, min(args.steps, 20) // 2))
+        extras["gensys_doubling"] = {"value": round(nloc / dt_d, 2), "ms_per_step": round(dt_d * 1e3, 4), "unit": "evals/s",
+                                     "note": "solver = gensys with dsge_options.gensys_doubling = 1 (opt-in): cycle reduction computes the "
+                                             "solvent T, the device certifies rho(T[S,S]) < 1 and rho(((B + C T)^-1 C)[L,L]) < 1 per draw "
+                                             "(= gensys's eu = [1, 1, 0]); a draw without the certificate goes to the ordered QZ. Same eu / "
+                                             "status as the QZ path on every system of tests/test_gpu_gensys_doubling.py and "
+                                             "profiles/r5/fuzz_gensys_doubling.txt",
+                                     "failed_draws": int((st_d != 0).sum().item()),
+                                     "status_equal_to_qz_path": bool(torch.equal(st_d, st_g)),
+                                     "max_rel_logp_diff_vs_qz_path": float((torch.abs(lp_d - lp_g) / torch.abs(lp_g)).max().item())}
+        if cpu_gensys is not None:
+            rel_d = np.abs(lp_d[: len(ref_g)].cpu().numpy() - ref_g) / np.abs(ref_g)
+            extras["gensys_doubling"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle_gensys": float(rel_d.max()),
+                                                   "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_d)),
+                                                   "n_checked": int(len(ref_g))}
         extras["gensys"]["roofline"] = gensys_roofline(eng, lambda: eng.solve_kalman_logp(
             dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter, logp=lp_g, status=st_g,
             solver="gensys", n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g), nloc, n, nl_g)

@@ -177,7 +177,8 @@ class Options(C.Structure):
         ("kalman_head_draws", C.c_int32),
         ("jitter_F", C.c_double),
         ("jitter_P", C.c_double),
-        ("reserved_", C.c_int32 * 4),
+        ("gensys_doubling", C.c_int32),
+        ("reserved_", C.c_int32 * 3),
     ]
 
 

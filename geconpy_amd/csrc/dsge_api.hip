@@ -139,6 +139,7 @@ struct OptionsGuard {
     local.kalman_narrow = o->kalman_narrow;
     local.gensys_direct_blocks = o->gensys_direct_blocks;
     local.kalman_head_draws = o->kalman_head_draws;
+    local.gensys_doubling = o->gensys_doubling;
     local.ll_constant = o->ll_constant;
     local.mask_d = o->mask_d;
     local.joseph = o->joseph;
@@ -424,7 +425,9 @@ int dsge_gensys_batched(const double* A, const double* B, const double* C, const
   if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "R_out requires D and 1 <= k <= n");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
-  if ((rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, T_out, eu_out, status, (hipStream_t)stream))) return rc;
+  if ((rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, T_out, eu_out, status, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                          R_out ? D : nullptr, k, R_out)))
+    return rc;
   if (R_out)  // gensys_pt: R = -(C T + B)^-1 D  (gensys.py:681); computed for every draw, as the graph does
     return launch_assemble(nullptr, B, C, D, T_out, nullptr, nullptr, 0, batch, n, k, R_out, nullptr, nullptr, nullptr,
                            nullptr, 1, 0, (hipStream_t)stream);
@@ -791,7 +794,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
       rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st, nullptr,
-                         (opt().kalman_order != 0 && batch >= 512) ? key_w : nullptr, &gensys_key);
+                         (opt().kalman_order != 0 && batch >= 512) ? key_w : nullptr, &gensys_key, D, k, Rw, n_state_hint);
     } else {
       HIP_TRY(hipMemsetAsync(status_out, 0, sizeof(int32_t) * batch, st));
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
@@ -2192,6 +2195,7 @@ int dsge_options_init(dsge_options* o) {
   o->kalman_narrow = d.kalman_narrow;
   o->gensys_direct_blocks = d.gensys_direct_blocks;
   o->kalman_head_draws = d.kalman_head_draws;
+  o->gensys_doubling = d.gensys_doubling;
   o->ll_constant = d.ll_constant;
   o->mask_d = d.mask_d;
   o->joseph = d.joseph;

@@ -169,8 +169,11 @@ int launch_grad_assemble(const double* B, const double* C, const double* T, cons
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr,
-                  int32_t* key_out = nullptr, int* key_written = nullptr);  // key_out: Kalman dispatch key from the QZ spectrum
-                                                                            // (window path only: *key_written tells)
+                  int32_t* key_out = nullptr, int* key_written = nullptr,  // key_out: Kalman dispatch key from the QZ spectrum
+                                                                           // (window path only: *key_written tells)
+                  const double* D = nullptr, int k = 0, double* R_tmp = nullptr, int n_state_hint = 0);
+// (D, k, R_tmp, n_state_hint: only for dsge_options.gensys_doubling -- with them the doubling iteration runs as the one-launch
+//  deflated cycle reduction, whose final elimination needs a right-hand side; R_tmp is scratch, [batch][n][k])
 
 int launch_gensys_pencil(const double* g0, const double* g1, const double* c, const double* psi, const double* pi, int batch,
                          int N, int k, int ell, double tol, double* G1_out, double* C_out, double* impact_out,
@@ -223,6 +226,7 @@ struct Options {
   int gensys_shape_cache = 1;  // window path: capacity record measured once per model size
   int gensys_direct_blocks = 1;  // window path: isolated 2 x 2 blocks triangularised in closed form in front of the complex iteration
   int kalman_narrow = 1;       // fast filter: the SK = 20 instance of the 32-wide tile when the state block fits
+  int gensys_doubling = 0;     // gensys by spectral division: cycle reduction + certificate, ordered QZ only for uncertified draws
   int kalman_head_draws = 0;   // fast filter: this many draws at the head of the dispatch order on the two-wavefront kernel (-1 = all)
   // conventions of the filter step (third party: pymc_extras; include/dsge_hip.h "Filter conventions")
   int ll_constant = DSGE_LL_CONST_P;

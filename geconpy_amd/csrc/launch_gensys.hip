@@ -7,6 +7,7 @@
 #include "dsge_gensys.hpp"
 #include "dsge_gensys_win.hpp"
 #include "dsge_gensys_pair.hpp"
+#include "dsge_gensys_doubling.hpp"
 
 namespace dsge_host {
 
@@ -272,11 +273,75 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
   return DSGE_SUCCESS;
 }
 
+// gensys by spectral division (dsge_gensys_doubling.hpp, dsge_options.gensys_doubling): cycle reduction for every draw, a
+// certificate of eu = [1, 1, 0] per draw, the ordered QZ (single-launch kernel, flagged draws only) for everything else.
+// *done = 0: not applicable (sizes) -- the caller runs the QZ path on the whole batch.
+static int launch_gensys_doubling(const double* A, const double* B, const double* C, const double* D, int k, double* R_tmp,
+                                  int batch, int n, double tol, int n_lead_hint, int n_state_hint, double* T_out, int32_t* eu_out,
+                                  int32_t* status, hipStream_t st, int32_t* key_out, int* key_written, int* done) {
+  *done = 0;
+  int rc;
+  int rescue_ncap = 0, rescue_lcap = 0;
+  if (gensys_caps(n, n_lead_hint, &rescue_ncap, &rescue_lcap) != DSGE_SUCCESS) return DSGE_SUCCESS;  // no QZ fall-back: not here
+  const int bs = tile_bs(n);
+  int lcap = n_lead_hint > 0 ? n_lead_hint : n;
+  if (lcap > n) lcap = n;
+  if (lcap > 32) lcap = 32;
+  int scap = (n_state_hint > 0 && n_state_hint < n) ? n_state_hint : n;
+  size_t lds = 0;
+  DISPATCH_BS(bs, 8, { lds = dsge::gd_lds_doubles<BS>(n, lcap, scap) * sizeof(double); });
+  if (lds == 0 || lds > LDS_LIMIT) return DSGE_SUCCESS;
+  void* base = nullptr;
+  if ((rc = gw_reserve(256 + ((size_t)batch * sizeof(int32_t) + 255) / 256 * 256, st, &base))) return rc;
+  int32_t* it = (int32_t*)((char*)base + 256);
+  // the doubling iteration: quadratic convergence, so the stopping tolerance only decides the LAST iteration (T is then
+  // accurate to the product of the last iterate's norms, < 1e-18)
+  const int max_iter = 50;
+  const double tol_cr = 1e-9;
+  int deflated = 0;
+  if (D && R_tmp && k >= 1) {
+    if ((rc = launch_cr_deflated(A, B, C, D, batch, n, k, max_iter, tol_cr, T_out, R_tmp, status, it, st, &deflated, nullptr))) return rc;
+  }
+  if (!deflated) {
+    if ((rc = launch_cr(A, B, C, batch, n, max_iter, tol_cr, T_out, status, it, st))) return rc;
+  }
+  rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 8, {
+    rc = set_lds(dsge::gensys_certify_kernel<BS>, lds);
+    if (rc == DSGE_SUCCESS)
+      hipLaunchKernelGGL(dsge::gensys_certify_kernel<BS>, dim3(batch), dim3(64), lds, st, B, C, (const double*)T_out, batch, n, lcap,
+                         scap, tol, eu_out, status);
+  });
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  {  // the ordered QZ for the draws without a certificate (returns at once when nothing is flagged)
+    const size_t lds_q = dsge::gensys_smem_bytes(n, rescue_ncap, rescue_lcap);
+    if ((rc = set_lds(dsge::gensys_kernel, lds_q))) return rc;
+    hipLaunchKernelGGL(dsge::gensys_kernel, dim3(rerun_grid(batch)), dim3(64), lds_q, st, A, B, C, batch, n, rescue_ncap, rescue_lcap,
+                       tol, T_out, eu_out, status, (long long*)nullptr, 1);
+    hipLaunchKernelGGL(dsge::gensys_rescue_close_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, status, eu_out);
+    HIP_TRY(hipGetLastError());
+  }
+  if (key_out) {  // Kalman dispatch key: the iteration count (grows with the persistence of the model, like the QZ-spectrum key)
+    HIP_TRY(hipMemcpyAsync(key_out, it, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (key_written) *key_written = 1;
+  }
+  *done = 1;
+  return DSGE_SUCCESS;
+}
+
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg, int32_t* key_out,
-                  int* key_written) {
+                  int* key_written, const double* D, int k, double* R_tmp, int n_state_hint) {
   if (key_written) *key_written = 0;
   int rc;
+  if (opt().gensys_doubling && !dbg) {
+    int done = 0;
+    if ((rc = launch_gensys_doubling(A, B, C, D, k, R_tmp, batch, n, tol, n_lead_hint, n_state_hint, T_out, eu_out, status, st,
+                                     key_out, key_written, &done)))
+      return rc;
+    if (done) return DSGE_SUCCESS;
+  }
   // Small pencils (<= 24 KB of LDS in the single-launch kernel, i.e. >= 6 draws per CU already) gain nothing from the
   // window path and would pay for its three launches and the shape read-back: RBC-sized models stay on one launch.
   bool small = false;

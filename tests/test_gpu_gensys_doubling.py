@@ -1,0 +1,122 @@
+"""dsge_options.gensys_doubling (csrc/dsge_gensys_doubling.hpp): gensys by spectral division -- the doubling iteration computes the
+solvent, a per-draw certificate (rho(T[S,S]) < 1 and rho(((B + C T)^-1 C)[L,L]) < 1) stands for eu = [1, 1, 0], the ordered QZ
+decides every draw without one.  Outputs must be those of the QZ path and of the reference's gensys: eu EXACT on every system
+(regular, indeterminate, explosive, coincident zeros, near-unit roots), T to the cross-solver accuracy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle
+from geconpy_amd import _lib, batched
+from geconpy_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+DBL = {"gensys_doubling": 1}
+
+
+def _stack(g, keys):
+    return tuple(np.stack([g[f"{k}_{x}"] for k in keys]) for x in "ABCD")
+
+
+@pytest.mark.parametrize("key", ["one_block", "rbc_2_block", "full_nk"])
+def test_reference_goldens(ref_goldens, key):
+    g = ref_goldens
+    A, B, C, D = (g[f"{key}_{x}"][None] for x in "ABCD")
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8, options=DBL)
+    assert list(out["eu"][0]) == [1, 1, 0] and out["success"][0]
+    assert_allclose(out["T"][0], g[f"{key}_ref_gensys_T"], atol=1e-10)
+    assert_allclose(out["R"][0], g[f"{key}_ref_gensys_R"], atol=1e-9)
+
+
+def test_failure_codes_are_the_qz_s(failure_golden):
+    """ok / non-unique / no solution / coincident zeros of tests/golden/failure_cases.npz (labelled by the reference's own core): the
+    certificate must refuse the three non-regular systems -- the non-unique one CONVERGES in cycle reduction (to the minimal solvent)
+    -- and the QZ's verdicts come back exactly; the regular one keeps the doubling iteration's T."""
+    g = failure_golden
+    names = ["ok", "nonunique", "noexist", "coincident"]
+    A, B, C, D = _stack(g, names)
+    qz = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8, options=DBL)
+    for i, name in enumerate(names):
+        assert list(out["eu"][i]) == list(g[f"{name}_ref_gensys_eu"]), name
+        assert out["success"][i] == (name == "ok")
+    assert np.array_equal(out["status"], qz["status"])
+    assert_allclose(out["T"][0], g["ok_ref_gensys_T"], atol=1e-9)
+    assert_allclose(out["T"][1:], qz["T"][1:], atol=1e-12)  # (the same kernel decided them)
+    om = wl.sw_shaped_observation_model()
+    q = np.full(7, 1e-4)
+    f = batched.solve_kalman_logp_batched(A, B, C, D, q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8, options=DBL)
+    assert np.isfinite(f["logp"][0]) and np.all(f["logp"][1:] == -np.inf)
+    ref = oracle.solve_kalman_logp(A[0], B[0], C[0], D[0], np.diag(q), om["Z"], om["y"], H=np.diag(om["Hdiag"]), solver="gensys")
+    assert_allclose(f["logp"][0], ref["logp"], rtol=1e-8)
+
+
+def test_sw_shaped_draws_fused_and_standalone():
+    """512 SW-shaped draws incl. the nearly singular draw 752 region (first_draw = 512): T and eu against the QZ path, logp of the fused
+    evaluation against the oracle's gensys; an explosive and an indeterminate draw planted in the batch."""
+    nb = 512
+    b = wl.sw_shaped_batch(nb, first_draw=512)
+    om = wl.sw_shaped_observation_model()
+    A, B, C = b["A"].copy(), b["B"].copy(), b["C"].copy()
+    A[7] *= 30.0  # explosive: no stable solution
+    M = B[11] + C[11] @ b["T_star"][11]
+    G = np.linalg.solve(M, C[11])
+    G2 = G * (1.5 / np.max(np.abs(np.linalg.eigvals(G))))  # one of the "unstable" roots becomes stable: indeterminacy
+    C[11] = M @ G2
+    B[11] = M - C[11] @ b["T_star"][11]
+    qz = batched.gensys_batched(A, B, C, b["D"], tol=1e-8)
+    out = batched.gensys_batched(A, B, C, b["D"], tol=1e-8, options=DBL)
+    assert np.array_equal(out["eu"], qz["eu"]) and np.array_equal(out["status"], qz["status"])
+    assert not out["success"][7] and not out["success"][11] and out["success"].sum() == nb - 2
+    ok = out["success"]
+    # draw 240 of this batch is draw 752 of the bench batch: cond(B + C T) = 3e8 -- two float64 algorithms agree to 1e-7 there (the
+    # reference's own cross-solver test asks 1e-8 on well-conditioned models, tests/model/test_perturbation.py:205-206)
+    dT = np.abs(out["T"] - qz["T"]).reshape(nb, -1).max(axis=1)
+    dR = np.abs(out["R"] - qz["R"]).reshape(nb, -1).max(axis=1)
+    regular = ok & (np.arange(nb) != 240)
+    assert dT[regular].max() <= 1e-9 and dR[regular].max() <= 1e-8, (int(dT[regular].argmax()), dT[regular].max())
+    assert dT[240] <= 1e-6
+    q = b["sigma"] ** 2
+    f_qz = batched.solve_kalman_logp_batched(A, B, C, b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8)
+    f = batched.solve_kalman_logp_batched(A, B, C, b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8, options=DBL)
+    assert np.array_equal(f["status"] != 0, f_qz["status"] != 0)
+    assert_allclose(f["logp"][ok], f_qz["logp"][ok], rtol=5e-9)
+    for i in (0, 240, 300):  # (240 = draw 752 of the bench batch)
+        ref = oracle.solve_kalman_logp(A[i], B[i], C[i], b["D"][i], np.diag(q[i]), om["Z"], om["y"], H=np.diag(om["Hdiag"]), solver="gensys",
+                                       tol=1e-8)
+        assert_allclose(f["logp"][i], ref["logp"], rtol=1e-8)
+
+
+def test_roots_near_the_unit_circle_go_to_the_qz():
+    """A stable root at 1 - 1e-5 and an 'unstable' one at 1 + 1e-5: gensys's counts are strict comparisons, the certificate gives up
+    within its 12 squarings (it certifies rho < 0.99983 only) and the QZ decides -- same eu as the oracle either way."""
+    n, ns, nl, k = 12, 5, 4, 3
+    sysm = []
+    for seed, (rho_s, rho_g) in enumerate([(1.0 - 1e-5, 0.5), (0.6, 1.0 / (1.0 + 1e-5)), (1.0 + 1e-5, 0.5), (0.6, 1.0 + 1e-5)]):
+        A, B, C, D, Tst = wl.sw_shaped_system(900 + seed, n=n, n_state=ns, n_lead=nl, k=k)
+        M = B + C @ Tst
+        S = Tst[:ns, :ns]
+        T2 = Tst.copy()
+        T2[:, :ns] *= rho_s / np.max(np.abs(np.linalg.eigvals(S)))
+        G = np.linalg.solve(M, C)
+        G2 = G * (rho_g / np.max(np.abs(np.linalg.eigvals(G))))
+        C2 = M @ G2
+        sysm.append((-M @ T2, M - C2 @ T2, C2, D))
+    A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8, options=DBL)
+    for i in range(4):
+        _, succ, eu = oracle.gensys_T_success(A[i], B[i], C[i], D[i], 1e-8)
+        assert list(out["eu"][i][:2]) == [int(eu[0]), int(eu[1])], (i, out["eu"][i], eu)
+        assert bool(out["success"][i]) == bool(succ)
+
+
+def test_fuzz_against_the_oracle():
+    """tools/fuzz_gensys.py (random sizes, structures, explosive draws) with the option on: eu exact, T at the suite's bar."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gensys
+
+    with _lib.options_scope(DBL):
+        assert fuzz_gensys.run(7101, 150, verbose=True) == 0

@@ -7,7 +7,7 @@ steps = []
 for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void dsge::", "")
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    if "cr_fused" in name:
+    if "cr_fused" in name or "gensys_reduce" in name:
         steps.append([])
     if steps:
         steps[-1].append((name[:40], s, e, r.get("Queue_Id", "?")))
