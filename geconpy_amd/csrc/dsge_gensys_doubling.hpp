@@ -14,7 +14,7 @@
 // iteration (it agrees with the QZ's to 1e-12: the reference's own cross-solver test, tests/model/test_perturbation.py:205-206, asks
 // 1e-8) and gets eu = [1, 1, 0].  EVERYTHING ELSE -- no convergence, no certificate within 12 squarings (a root within 2e-4 of the
 // unit circle), more lead / state columns than the hints, a column of C with 0 < sum|C_ij| <= tol (gensys drops it from the pencil,
-// gensys.py:587), a singular M -- is flagged for the ordered QZ (the rescue pass of the window path's launcher: gensys_kernel on the
+// gensys.py:587), a singular M, a solvent with entries beyond 1e6 -- is flagged for the ordered QZ (the rescue pass of the window path's launcher: gensys_kernel on the
 // flagged draws), which decides as it always did: the non-regular verdicts ([1,0,k], [0,1,0], [-2,-2,0], ...) are the QZ's alone.
 #pragma once
 #include "dsge_device.hpp"
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void gensys_certify_kernel(const double* __rest
   bool ok = (st_in == 0);
   const size_t off = (size_t)draw * n * n;
   // lead columns (gensys.py:587: sum_i |C_ij| > tol) and state columns (non-zero columns of T)
-  double csum = 0.0;
+  double csum = 0.0, tmax = 0.0;
   bool tnz = false;
   if (ok) {  // (eight rows of both matrices requested together: a loop of single loads is a round trip to memory per row)
     const int col = lane < n ? lane : n - 1;
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) void gensys_certify_kernel(const double* __rest
         if (r0 + u < n) {
           csum += fabs(cv[u]);
           tnz = tnz || (tv[u] != 0.0);
+          tmax = fmax(tmax, fabs(tv[u]));
         }
       }
     }
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(64) void gensys_certify_kernel(const double* __rest
   const unsigned long long lmask = __ballot(ok && lane < n && csum > tol);
   const unsigned long long grey = __ballot(ok && lane < n && csum > 0.0 && !(csum > tol));  // dropped by gensys, kept by the iteration
   const unsigned long long smask = __ballot(ok && lane < n && tnz);
-  const unsigned long long bad = __ballot(ok && lane < n && !(csum == csum));
+  // (a solvent with entries beyond 1e6 means a nearly rank-deficient Q2 Pi: gensys's existence test works with a tolerance there,
+  //  gensys.py:282-283 -- the QZ decides)
+  const unsigned long long bad = __ballot(ok && lane < n && (!(csum == csum) || !(tmax < 1e6)));
   const int l = __popcll(lmask), s = __popcll(smask);
   ok = ok && grey == 0ull && bad == 0ull && l <= lcap && s <= scap;
   if (ok) {
