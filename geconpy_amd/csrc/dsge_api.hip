@@ -780,6 +780,7 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     const bool fuse_R = (solver == DSGE_SOLVER_CYCLE_REDUCTION) && !resid_out && opt().cr_fused_selection && !park_failures;
     bool have_colmask = false;
     int gensys_key = 0;  // 1: the gensys launches have written the Kalman dispatch key
+    const int32_t* gensys_qz_marks = nullptr;  // gensys by spectral division: Rw already holds R of the unmarked draws
     if (is_cr) {
       int deflated = 0;
       // static variables deflated first (the iteration then runs on n - h variables); not when the caller asks for the
@@ -794,7 +795,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     } else if (solver == DSGE_SOLVER_GENSYS) {
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
       rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, Tw, eu_w, status_out, st, nullptr,
-                         (opt().kalman_order != 0 && batch >= 512) ? key_w : nullptr, &gensys_key, D, k, Rw, n_state_hint);
+                         (opt().kalman_order != 0 && batch >= 512) ? key_w : nullptr, &gensys_key, D, k, Rw, n_state_hint,
+                         &gensys_qz_marks);
     } else {
       HIP_TRY(hipMemsetAsync(status_out, 0, sizeof(int32_t) * batch, st));
       if (n_iter_out) HIP_TRY(hipMemsetAsync(n_iter_out, 0, sizeof(int32_t) * batch, st));
@@ -815,7 +817,8 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
     if (fold_rqr && fuse_R)
       rc = DSGE_SUCCESS;
     else if (fold_rqr)
-      rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, nullptr, nullptr, status_out, 1, 0, st);
+      rc = launch_assemble(A, B, C, D, Tw, nullptr, Q, q_mode, batch, n, k, Rw, resid_out, nullptr, nullptr, status_out, 1, 0, st,
+                           resid_out ? nullptr : gensys_qz_marks);
     else if (fuse_R && q_diag && k <= 16 && n <= 64)
       rc = launch_rqr(Rw, Q, q_mode == DSGE_Q_DIAG_BATCHED, batch, n, k, status_out, RQR, st);  // (RQR_KMAX = 16)
     else if (fuse_R)

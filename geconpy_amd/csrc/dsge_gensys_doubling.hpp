@@ -83,7 +83,8 @@ __device__ __forceinline__ bool gd_certify_contraction(double* buf, int d, int l
 template <int BS>
 __global__ __launch_bounds__(64) void gensys_certify_kernel(const double* __restrict__ B, const double* __restrict__ C,
                                                              const double* __restrict__ T, int batch, int n, int lcap, int scap,
-                                                             double tol, int32_t* __restrict__ eu_out, int32_t* __restrict__ status) {
+                                                             double tol, int32_t* __restrict__ eu_out, int32_t* __restrict__ status,
+                                                             int32_t* __restrict__ qz_mark) {
   constexpr int NP = 8 * BS, LDW = 2 * NP + 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int ldg = lcap | 1, lds_ = scap | 1;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(64) void gensys_certify_kernel(const double* __rest
     } else {
       status[draw] = DSGE_ST_INTERNAL_RERUN;
     }
+    if (qz_mark) qz_mark[draw] = ok ? 0 : 1;
   }
 }
 

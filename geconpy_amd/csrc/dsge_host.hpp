@@ -125,7 +125,7 @@ int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n
 int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
                     const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
-                    hipStream_t st);
+                    hipStream_t st, const int32_t* only_marked = nullptr);  // only_marked: draws with a non-zero mark (selection only)
 int launch_dense_z_augment(const double* T, const double* R, const double* Z, int z_batched, int batch, int n, int k, int p,
                            double* T_aug, double* R_aug, double* Z_aug, hipStream_t st);
 int launch_dense_z_deaugment(const double* Tbar_a, const double* Gbar_a, const double* T, const double* G_aug, const double* Z,
@@ -171,7 +171,8 @@ int launch_gensys(const double* A, const double* B, const double* C, int batch, 
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr,
                   int32_t* key_out = nullptr, int* key_written = nullptr,  // key_out: Kalman dispatch key from the QZ spectrum
                                                                            // (window path only: *key_written tells)
-                  const double* D = nullptr, int k = 0, double* R_tmp = nullptr, int n_state_hint = 0);
+                  const double* D = nullptr, int k = 0, double* R_tmp = nullptr, int n_state_hint = 0,
+                  const int32_t** qz_marks = nullptr);  // *qz_marks: [batch], non-zero = the ordered QZ solved the draw (R_tmp is not its R)
 // (D, k, R_tmp, n_state_hint: only for dsge_options.gensys_doubling -- with them the doubling iteration runs as the one-launch
 //  deflated cycle reduction, whose final elimination needs a right-hand side; R_tmp is scratch, [batch][n][k])
 

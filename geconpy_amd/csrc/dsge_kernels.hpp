@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(
     const double* __restrict__ D, const double* __restrict__ T, const double* __restrict__ R_in,
     const double* __restrict__ Q, int q_mode, int batch, int n, int k, double* __restrict__ R_out,
     double* __restrict__ resid_out, double* __restrict__ RQR_out, double* __restrict__ P0_out,
-    int32_t* __restrict__ status, int do_selection, int do_lyapunov) {
+    int32_t* __restrict__ status, int do_selection, int do_lyapunov, const int32_t* __restrict__ only_marked = nullptr) {
   constexpr int NP = AsmSmem<BS>::NP, LD = AsmSmem<BS>::LD, LDW = AsmSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // sym(R Q R') alone (the fused call): neither T nor the Gauss-Jordan scratch is touched, so the launcher allocates the
@@ -352,6 +352,9 @@ __global__ __launch_bounds__(64) void assemble_kernel(
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
     const size_t off = (size_t)draw * n * n;
     const size_t offk = (size_t)draw * n * k;
+    // only_marked: the selection alone, for the marked draws (gensys by spectral division: the draws the ordered QZ solved; the
+    // others carry R from the cycle reduction's final elimination)
+    if (only_marked && only_marked[draw] == 0) continue;
     if (do_lyapunov == 3) {
       if (status[draw] != DSGE_ST_INTERNAL_RERUN) continue;
     } else if (status && status[draw] != 0) {

@@ -9,7 +9,7 @@ namespace dsge_host {
 int launch_assemble(const double* A, const double* B, const double* C, const double* D, const double* T,
                     const double* R_in, const double* Q, int q_mode, int batch, int n, int k, double* R_out,
                     double* resid_out, double* RQR_out, double* P0_out, int32_t* status, int do_sel, int do_lyap,
-                    hipStream_t st) {
+                    hipStream_t st, const int32_t* only_marked) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 8, {
@@ -21,7 +21,7 @@ int launch_assemble(const double* A, const double* B, const double* C, const dou
                            ? sizeof(double) * dsge::AsmSmem<BS>::NP * (dsge::AsmSmem<BS>::LD + dsge::AsmSmem<BS>::LDW)
                            : dsge::AsmSmem<BS>::bytes;
     if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::assemble_kernel<BS>, dim3(do_lyap == 3 ? rerun_grid(batch) : batch), dim3(64), lds, st, A, B, C, D, T, R_in, Q, q_mode, batch, n, k, R_out, resid_out, RQR_out, P0_out, status, do_sel, do_lyap);
+      hipLaunchKernelGGL(dsge::assemble_kernel<BS>, dim3(do_lyap == 3 ? rerun_grid(batch) : batch), dim3(64), lds, st, A, B, C, D, T, R_in, Q, q_mode, batch, n, k, R_out, resid_out, RQR_out, P0_out, status, do_sel, do_lyap, only_marked);
       HIP_TRY(hipGetLastError());
     }
   });

@@ -278,8 +278,10 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
 // *done = 0: not applicable (sizes) -- the caller runs the QZ path on the whole batch.
 static int launch_gensys_doubling(const double* A, const double* B, const double* C, const double* D, int k, double* R_tmp,
                                   int batch, int n, double tol, int n_lead_hint, int n_state_hint, double* T_out, int32_t* eu_out,
-                                  int32_t* status, hipStream_t st, int32_t* key_out, int* key_written, int* done) {
+                                  int32_t* status, hipStream_t st, int32_t* key_out, int* key_written, int* done,
+                                  const int32_t** qz_marks) {
   *done = 0;
+  if (qz_marks) *qz_marks = nullptr;
   int rc;
   int rescue_ncap = 0, rescue_lcap = 0;
   if (gensys_caps(n, n_lead_hint, &rescue_ncap, &rescue_lcap) != DSGE_SUCCESS) return DSGE_SUCCESS;  // no QZ fall-back: not here
@@ -292,8 +294,10 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
   DISPATCH_BS(bs, 8, { lds = dsge::gd_lds_doubles<BS>(n, lcap, scap) * sizeof(double); });
   if (lds == 0 || lds > LDS_LIMIT) return DSGE_SUCCESS;
   void* base = nullptr;
-  if ((rc = gw_reserve(256 + ((size_t)batch * sizeof(int32_t) + 255) / 256 * 256, st, &base))) return rc;
+  const size_t ints = ((size_t)batch * sizeof(int32_t) + 255) / 256 * 256;
+  if ((rc = gw_reserve(256 + 2 * ints, st, &base))) return rc;
   int32_t* it = (int32_t*)((char*)base + 256);
+  int32_t* mark = (int32_t*)((char*)base + 256 + ints);
   // the doubling iteration: quadratic convergence, so the stopping tolerance only decides the LAST iteration (T is then
   // accurate to the product of the last iterate's norms, < 1e-18)
   const int max_iter = 50;
@@ -310,7 +314,7 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
     rc = set_lds(dsge::gensys_certify_kernel<BS>, lds);
     if (rc == DSGE_SUCCESS)
       hipLaunchKernelGGL(dsge::gensys_certify_kernel<BS>, dim3(batch), dim3(64), lds, st, B, C, (const double*)T_out, batch, n, lcap,
-                         scap, tol, eu_out, status);
+                         scap, tol, eu_out, status, mark);
   });
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -326,19 +330,21 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
     HIP_TRY(hipMemcpyAsync(key_out, it, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (key_written) *key_written = 1;
   }
+  if (qz_marks && deflated) *qz_marks = mark;  // (R_tmp holds R of the certified draws only when the fused cycle reduction ran)
   *done = 1;
   return DSGE_SUCCESS;
 }
 
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg, int32_t* key_out,
-                  int* key_written, const double* D, int k, double* R_tmp, int n_state_hint) {
+                  int* key_written, const double* D, int k, double* R_tmp, int n_state_hint, const int32_t** qz_marks) {
   if (key_written) *key_written = 0;
+  if (qz_marks) *qz_marks = nullptr;
   int rc;
   if (opt().gensys_doubling && !dbg) {
     int done = 0;
     if ((rc = launch_gensys_doubling(A, B, C, D, k, R_tmp, batch, n, tol, n_lead_hint, n_state_hint, T_out, eu_out, status, st,
-                                     key_out, key_written, &done)))
+                                     key_out, key_written, &done, qz_marks)))
       return rc;
     if (done) return DSGE_SUCCESS;
   }

@@ -67,10 +67,18 @@ def test_sw_shaped_draws_fused_and_standalone():
     G2 = G * (1.5 / np.max(np.abs(np.linalg.eigvals(G))))  # one of the "unstable" roots becomes stable: indeterminacy
     C[11] = M @ G2
     B[11] = M - C[11] @ b["T_star"][11]
+    # ... and a REGULAR draw that the certificate cannot take (a stable root at 1 - 1e-5): the QZ solves it, and the fused call must
+    # take its R from the explicit selection (the cycle reduction's R belongs to certified draws only)
+    T20 = b["T_star"][20].copy()
+    T20[:, :18] *= (1.0 - 1e-5) / np.max(np.abs(np.linalg.eigvals(T20[:18, :18])))
+    M20 = B[20] + C[20] @ b["T_star"][20]
+    A[20] = -M20 @ T20
+    B[20] = M20 - C[20] @ T20
     qz = batched.gensys_batched(A, B, C, b["D"], tol=1e-8)
     out = batched.gensys_batched(A, B, C, b["D"], tol=1e-8, options=DBL)
     assert np.array_equal(out["eu"], qz["eu"]) and np.array_equal(out["status"], qz["status"])
-    assert not out["success"][7] and not out["success"][11] and out["success"].sum() == nb - 2
+    assert not out["success"][7] and not out["success"][11] and out["success"][20] and out["success"].sum() == nb - 2
+    assert_allclose(out["T"][20], qz["T"][20], rtol=0, atol=1e-9)  # (the QZ of the rescue pass vs the QZ of the window path)
     ok = out["success"]
     # draw 240 of this batch is draw 752 of the bench batch: cond(B + C T) = 3e8 -- two float64 algorithms agree to 1e-7 there (the
     # reference's own cross-solver test asks 1e-8 on well-conditioned models, tests/model/test_perturbation.py:205-206)
@@ -84,6 +92,7 @@ def test_sw_shaped_draws_fused_and_standalone():
     f = batched.solve_kalman_logp_batched(A, B, C, b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8, options=DBL)
     assert np.array_equal(f["status"] != 0, f_qz["status"] != 0)
     assert_allclose(f["logp"][ok], f_qz["logp"][ok], rtol=5e-9)
+    assert np.isfinite(f["logp"][20]) and abs(f["logp"][20] - f_qz["logp"][20]) <= 1e-8 * abs(f_qz["logp"][20])
     for i in (0, 240, 300):  # (240 = draw 752 of the bench batch)
         ref = oracle.solve_kalman_logp(A[i], B[i], C[i], b["D"][i], np.diag(q[i]), om["Z"], om["y"], H=np.diag(om["Hdiag"]), solver="gensys",
                                        tol=1e-8)
