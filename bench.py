@@ -546,6 +546,7 @@ def main():
 
     # structure hints (verified on the device per draw; they never change results)
     hints = eng.structure_hints(dA, dZ) if not args.no_hints else (0, 0)
+    from geconpy_amd import _lib
     from geconpy_amd.batched import lead_hint
 
     n_lead = lead_hint(shard["C"], args.tol) if args.solver == "gensys" else 0
@@ -660,50 +661,50 @@ def main():
                                     "max_rel_logp_diff_vs_headline": float((torch.abs(lp_full - logp_all[lo:hi]) /
                                                                             torch.abs(lp_full)).max().item())}
         nl_g = lead_hint(shard["C"], args.tol)
-        lp_g = torch.empty_like(logp_buf)
-        st_g = torch.empty_like(stat_buf)
-        dt_g = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
-                                                   max_iter=args.max_iter, logp=lp_g, status=st_g, solver="gensys",
-                                                   n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g),
-                     max(3, min(args.steps, 20) // 2))
-        extras["gensys"] = {"value": round(nloc / dt_g, 2), "ms_per_step": round(dt_g * 1e3, 4), "unit": "evals/s",
-                            "note": "same step with solver = gensys (ordered QZ), the reference's default estimation solver "
-                                    "(configure(..., solver='gensys'), statespace.py:832)",
-                            "failed_draws": int((st_g != 0).sum().item()),
-                            "max_rel_logp_diff_vs_headline": float((torch.abs(lp_g - logp_all[lo:hi]) / torch.abs(lp_g)).max().item())}
-        if cpu_gensys is not None:  # against the ORACLE's gensys (LAPACK's ordered QZ), not against the headline
-            ref_g = cpu_gensys[0]
-            rel_g = np.abs(lp_g[: len(ref_g)].cpu().numpy() - ref_g) / np.abs(ref_g)
-            extras["gensys"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle_gensys": float(rel_g.max()),
-                                          "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_g)),
-                                          "n_checked": int(len(ref_g)),
-                                          "cpu_oracle_gensys_evals_per_s": round(cpu_gensys[1], 2)}
-        # the same leg with dsge_options.gensys_doubling: gensys by spectral division (csrc/dsge_gensys_doubling.hpp) -- the doubling
-        # iteration computes the solvent, a per-draw certificate stands for eu = [1, 1, 0], the ordered QZ takes every draw without one
-        lp_d = torch.empty_like(logp_buf)
-        st_d = torch.empty_like(stat_buf)
-        opts_d = dict(opts or {}, gensys_doubling=1)
-        dt_d = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,
-                                                   max_iter=args.max_iter, logp=lp_d, status=st_d, solver="gensys",
-                                                   n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g, options=opts_d),
-                     max(3, min(args.steps, 20) // 2))
-        extras["gensys_doubling"] = {"value": round(nloc / dt_d, 2), "ms_per_step": round(dt_d * 1e3, 4), "unit": "evals/s",
-                                     "note": "solver = gensys with dsge_options.gensys_doubling = 1 (opt-in): cycle reduction computes the "
-                                             "solvent T, the device certifies rho(T[S,S]) < 1 and rho(((B + C T)^-1 C)[L,L]) < 1 per draw "
-                                             "(= gensys's eu = [1, 1, 0]); a draw without the certificate goes to the ordered QZ. Same eu / "
-                                             "status as the QZ path on every system of tests/test_gpu_gensys_doubling.py and "
-                                             "profiles/r5/fuzz_gensys_doubling.txt",
-                                     "failed_draws": int((st_d != 0).sum().item()),
-                                     "status_equal_to_qz_path": bool(torch.equal(st_d, st_g)),
-                                     "max_rel_logp_diff_vs_qz_path": float((torch.abs(lp_d - lp_g) / torch.abs(lp_g)).max().item())}
-        if cpu_gensys is not None:
-            rel_d = np.abs(lp_d[: len(ref_g)].cpu().numpy() - ref_g) / np.abs(ref_g)
-            extras["gensys_doubling"]["parity"] = {"max_rel_logp_err_vs_cpu_oracle_gensys": float(rel_d.max()),
-                                                   "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_d)),
-                                                   "n_checked": int(len(ref_g))}
-        extras["gensys"]["roofline"] = gensys_roofline(eng, lambda: eng.solve_kalman_logp(
-            dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter, logp=lp_g, status=st_g,
-            solver="gensys", n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g), nloc, n, nl_g)
+
+        def gensys_leg(extra_opts):
+            lp_x = torch.empty_like(logp_buf)
+            st_x = torch.empty_like(stat_buf)
+            o_x = dict(opts or {}, **extra_opts) if extra_opts else opts
+            call = lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol,  # noqa: E731
+                                                 max_iter=args.max_iter, logp=lp_x, status=st_x, solver="gensys",
+                                                 n_state_hint=hints[0], z_selector_hint=hints[1], n_lead_hint=nl_g, options=o_x)
+            dt_x = timed(call, max(3, min(args.steps, 20) // 2))
+            leg = {"value": round(nloc / dt_x, 2), "ms_per_step": round(dt_x * 1e3, 4), "unit": "evals/s",
+                   "failed_draws": int((st_x != 0).sum().item()),
+                   "max_rel_logp_diff_vs_headline": float((torch.abs(lp_x - logp_all[lo:hi]) / torch.abs(lp_x)).max().item())}
+            if cpu_gensys is not None:  # against the ORACLE's gensys (LAPACK's ordered QZ), not against the headline
+                ref_g = cpu_gensys[0]
+                rel_g = np.abs(lp_x[: len(ref_g)].cpu().numpy() - ref_g) / np.abs(ref_g)
+                leg["parity"] = {"max_rel_logp_err_vs_cpu_oracle_gensys": float(rel_g.max()),
+                                 "median_rel_logp_err_vs_cpu_oracle_gensys": float(np.median(rel_g)),
+                                 "n_checked": int(len(ref_g)), "cpu_oracle_gensys_evals_per_s": round(cpu_gensys[1], 2)}
+            return leg, call, lp_x, st_x, o_x
+
+        # solver = gensys, the reference's default estimation solver (configure(..., solver='gensys'), statespace.py:832), with the
+        # library's defaults: gensys by spectral division (csrc/dsge_gensys_doubling.hpp) -- the doubling iteration computes the
+        # solvent, a per-draw certificate stands for eu = [1, 1, 0], the ordered QZ takes every draw without one
+        extras["gensys"], _call_g, lp_g, st_g, o_g = gensys_leg(None)
+        extras["gensys"]["note"] = ("same step with solver = gensys at the library's defaults (dsge_options.gensys_doubling = 1): cycle "
+                                    "reduction computes the solvent T, the device certifies rho(T[S,S]) < 1 and rho(((B + C T)^-1 C)[L,L]) "
+                                    "< 1 per draw (= gensys's eu = [1, 1, 0]); a draw without the certificate is solved by the ordered QZ. "
+                                    "Same eu / status as the QZ on every system of tests/test_gpu_gensys_doubling.py and "
+                                    "profiles/r5/fuzz_gensys_doubling.txt")
+        try:
+            with _lib.options_scope(o_g or {}):
+                ms_g = eng.profile_kernels(dA, dB, dC, dD, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=args.tol, max_iter=args.max_iter,
+                                           reps=3, n_state_hint=hints[0], z_selector_hint=hints[1], solver="gensys", n_lead_hint=nl_g)
+            extras["gensys"]["stage_ms"] = {k_: round(float(v_), 4) for k_, v_ in ms_g.items()}
+        except Exception as exc:  # (never lose the line to a diagnostic)
+            extras["gensys"]["stage_ms"] = {"error": repr(exc)}
+        # the ordered QZ for EVERY draw (dsge_options.gensys_doubling = 0): the reference's algorithm operation by operation
+        extras["gensys_qz"], _call_q, lp_q, st_q, _ = gensys_leg({"gensys_doubling": 0})
+        extras["gensys_qz"]["note"] = ("solver = gensys with dsge_options.gensys_doubling = 0: the ordered QZ of the pencil for every draw "
+                                       "(window path, six launches)")
+        extras["gensys"]["status_equal_to_qz_path"] = bool(torch.equal(st_q, st_g))
+        extras["gensys"]["max_rel_logp_diff_vs_qz_path"] = float((torch.abs(lp_q - lp_g) / torch.abs(lp_q)).max().item())
+        with _lib.options_scope({"gensys_doubling": 0}):
+            extras["gensys_qz"]["roofline"] = gensys_roofline(eng, _call_q, nloc, n, nl_g)
         # realistic observation structure: the seven observed series are JUMP variables (growth rates, inflation, hours in a
         # Smets-Wouters data set; _make_design_matrix allows any, statespace.py:260-332), so the filter runs on the 18 state
         # variables + 7 observed ones = 25 (32-wide tile) instead of the 18 of SURVEY 8(d)'s generator (24-wide tile)
@@ -732,7 +733,7 @@ def main():
         dyc = eng.to_device(om_c["y"])
         lp_c = torch.empty_like(logp_buf)
         st_c = torch.empty_like(stat_buf)
-        opts_c = {"kalman_steady_tol": 0.0}
+        opts_c = {"kalman_steady_tol": 0.0, "gensys_doubling": 0}
         dt_c = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZj, dyc, Hdiag=dHj, q_mode=1, tol=args.tol,
                                                    max_iter=args.max_iter, logp=lp_c, status=st_c, solver="gensys",
                                                    n_state_hint=hints_j[0], z_selector_hint=hints_j[1], n_lead_hint=nl_g,
@@ -743,6 +744,16 @@ def main():
                                           "changes at almost every step), kalman_steady_tol = 0: every one of the T_len steps is a full "
                                           "covariance update -- the rate of a user with configure() defaults and ragged data",
                                   "missing_entries": int(np.isnan(om_c["y"]).sum()), "failed_draws": int((st_c != 0).sum().item())}
+        extras["conservative"]["note"] += "; the ordered QZ for every draw (gensys_doubling = 0)"
+        lp_c2 = torch.empty_like(logp_buf)
+        dt_c2 = timed(lambda: eng.solve_kalman_logp(dA, dB, dC, dD, dq, dZj, dyc, Hdiag=dHj, q_mode=1, tol=args.tol,
+                                                    max_iter=args.max_iter, logp=lp_c2, status=st_c, solver="gensys",
+                                                    n_state_hint=hints_j[0], z_selector_hint=hints_j[1], n_lead_hint=nl_g,
+                                                    options={"kalman_steady_tol": 0.0}), max(3, min(args.steps, 20) // 2))
+        extras["conservative"]["with_default_gensys"] = {
+            "value": round(nloc / dt_c2, 2), "ms_per_step": round(dt_c2 * 1e3, 4),
+            "max_rel_logp_diff": float((torch.abs(lp_c2 - lp_c) / torch.abs(lp_c)).max().item()),
+            "note": "same leg with gensys at the library's default (spectral division, QZ for uncertified draws)"}
         if cpu_cons is not None:
             ref_c = cpu_cons[0]
             rel_c = np.abs(lp_c[: len(ref_c)].cpu().numpy() - ref_c) / np.abs(ref_c)

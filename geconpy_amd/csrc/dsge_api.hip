@@ -21,7 +21,16 @@ int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-const Options g_defaults{};                           // compiled-in defaults (never written)
+// Compiled-in defaults (never written after load).  One process-level override, read once when the library is loaded: the
+// environment variable DSGE_GENSYS_DOUBLING = 0 | 1 | 2 replaces the default of dsge_options.gensys_doubling (a site that wants the
+// ordered QZ for every draw everywhere without touching its callers; the test suite runs its gensys tests under both values).
+static Options defaults_from_environment() {
+  Options o{};
+  if (const char* e = std::getenv("DSGE_GENSYS_DOUBLING"))
+    if ((e[0] == '0' || e[0] == '1' || e[0] == '2') && e[1] == '\0') o.gensys_doubling = e[0] - '0';
+  return o;
+}
+const Options g_defaults = defaults_from_environment();
 thread_local const Options* t_call_options = nullptr;  // options of the call running on this thread
 }  // namespace dsge_host
 
@@ -158,6 +167,7 @@ int check_options(const dsge_options* o) {
   if (o->kalman_order < 0 || o->kalman_order > 2) return fail(DSGE_ERR_INVALID, "kalman_order must be 0, 1 or 2");
   if (o->pipeline_chunks < 0 || o->pipeline_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline_chunks must be in 0..64");
   if (o->gensys_split < 0 || o->gensys_split > 2) return fail(DSGE_ERR_INVALID, "gensys_split must be 0, 1 or 2");
+  if (o->gensys_doubling < 0 || o->gensys_doubling > 2) return fail(DSGE_ERR_INVALID, "gensys_doubling must be 0, 1 or 2");
   if (o->n_static_hint < -1 || o->n_static_hint > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "n_static_hint out of range");
   if (o->ll_constant < DSGE_LL_CONST_P || o->ll_constant > DSGE_LL_CONST_ONE)
     return fail(DSGE_ERR_INVALID, "ll_constant must be DSGE_LL_CONST_P, _OBSERVED or _ONE");

@@ -187,4 +187,30 @@ __global__ __launch_bounds__(64) void gensys_certify_kernel(const double* __rest
   }
 }
 
+// {count, the marked draws in ascending order} for the window launches' `act` (one workgroup)
+__global__ __launch_bounds__(1024) void gensys_compact_kernel(const int32_t* __restrict__ mark, int batch, int32_t* __restrict__ act) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < batch; c0 += 1024) {
+    const int i = c0 + tid;
+    const bool flag = i < batch && mark[i] != 0;
+    const unsigned long long bal = __ballot(flag);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      pre += (w < wave) ? wsum[w] : 0;
+      tot += wsum[w];
+    }
+    if (flag) act[1 + base + pre + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (tid == 0) base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) act[0] = base;
+}
+
 }  // namespace dsge

@@ -85,8 +85,9 @@ __device__ __forceinline__ GwHouse gp_house3(double x, double y, double z) {
 //   * M and X are addressed by 32-bit offsets from the (wave-uniform) workspace base.
 template <int LD>
 __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCaps cp, double* __restrict__ ws,
-                                                                 long long* __restrict__ dbg) {
+                                                                 long long* __restrict__ dbg, const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   constexpr double ULPD = 2.220446049250313e-16, SAFMIN = 2.2250738585072014e-308;
   const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
   const int rows = cp.wcap + 2;  // two zero pad rows: row k+2 of a last step and the (unused) row k+3 read at the window's edge
@@ -451,8 +452,9 @@ __global__ __launch_bounds__(64) void gensys_sweeps_pair_kernel(int batch, GwCap
 __host__ __device__ inline size_t gp_hess_smem(const GwCaps& c) { return 2 * gw_reduce2_smem(c); }
 
 __global__ __launch_bounds__(64) void gensys_hesstri_pair_kernel(int batch, GwCaps cp, double* __restrict__ ws,
-                                                                  long long* __restrict__ dbg) {
+                                                                  long long* __restrict__ dbg, const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
   const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
   const size_t per_half = (size_t)cp.wcap * ldH + (size_t)cp.wcap * ldW;

@@ -80,6 +80,14 @@ __host__ __device__ inline size_t gw_post_smem(const GwCaps& c) {
   return cplx * 16 + real * 8;
 }
 
+// act != nullptr: the launch works on the first act[0] slots of the workspace only, and slot i belongs to the caller's draw
+// act[1 + i] (gensys by spectral division: the draws without a certificate, compacted by gensys_compact_kernel)
+__device__ __forceinline__ int gw_active_count(int batch, const int32_t* act) {
+  if (!act) return batch;
+  const int na = __builtin_amdgcn_readfirstlane(act[0]);
+  return na < batch ? na : batch;
+}
+
 #define GW_STAMP(k)                                                         \
   do {                                                                     \
     if (dbg && draw == 0 && lane == 0) dbg[k] = (long long)clock64();        \
@@ -126,8 +134,10 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void gensys_reduce_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                             const double* __restrict__ C, int batch, GwCaps cp,
                                                             double tol, double* __restrict__ ws,
-                                                            long long* __restrict__ dbg, int* __restrict__ obs) {
+                                                            long long* __restrict__ dbg, int* __restrict__ obs,
+                                                            const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   // NW wavefronts per draw (round 4: 40 KB of LDS allow four draws per CU, and with one wavefront each the launch was four
   // rounds of a 230 k-cycle chain): loads and stores are spread over all threads, the lead / zero-column masks are computed by
   // every wavefront for itself, the reflectors run on hh_left_real_mw
@@ -142,8 +152,8 @@ __global__ __launch_bounds__(64 * NW) void gensys_reduce_kernel(const double* __
   const size_t total = (size_t)Ncap * ldH + (size_t)Ncap * ldW + (size_t)Ncap * ldX;
   const GwOffsets wo = gw_offsets(cp);
 
-  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    const size_t off = (size_t)draw * n * n;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {  // (draw: the slot of the workspace; act: the draw behind it)
+    const size_t off = (size_t)(act ? act[1 + draw] : draw) * n * n;
     const double* Ag = A + off;
     const double* Bg = B + off;
     const double* Cg = C + off;
@@ -562,8 +572,10 @@ __device__ __forceinline__ void gw_lartg(double f, double g, double& c, double& 
 // HBM workspace (as the complex iteration wants it): lane = row of M, the column shared by two consecutive column rotations
 // is carried in a register, the next one is prefetched a rotation ahead, each finished column is stored once.
 __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp, double* __restrict__ ws,
-                                                             long long* __restrict__ dbg, int real_stage, int m_real) {
+                                                             long long* __restrict__ dbg, int real_stage, int m_real,
+                                                             const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   const int lane = threadIdx.x;
   const int ldH = (cp.wcap + cp.lcap) | 1, ldW = cp.wcap | 1;
   double* hb = smem;                          // [H | X]: X(i, j) at column wcap + j
@@ -711,8 +723,10 @@ __global__ __launch_bounds__(64) void gensys_hesstri_kernel(int batch, GwCaps cp
 // ---- launch 2: complex single-shift QZ + reordering on the window (qz_iterate / reorder_stable_first of dsge_gensys.hpp
 // with N := w, ilo := 0; "Ztop" := the accumulated right transformation M, started from the real phase's Zr) -----------
 __global__ __launch_bounds__(64) void gensys_qzwin_kernel(int batch, GwCaps cp, double tol, double* __restrict__ ws,
-                                                           long long* __restrict__ dbg, int direct_blocks) {
+                                                           long long* __restrict__ dbg, int direct_blocks,
+                                                           const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   const int lane = threadIdx.x;
   GsLayout L;
   L.ldh = (cp.wcap + 4) | 1;
@@ -948,8 +962,9 @@ __device__ __forceinline__ double gw_sum4(int lo, int hi, F term) {
 // Needs only X2 (w x #lead), V2 and Bm on the chip (15 KB at N = 52 => 10 draws per CU): the Jacobi sweeps are a chain
 // of short dependent steps, so occupancy is what makes them cheap.
 __global__ __launch_bounds__(64) void gensys_eu_kernel(int batch, GwCaps cp, double tol, double* __restrict__ ws,
-                                                        long long* __restrict__ dbg) {
+                                                        long long* __restrict__ dbg, const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   const int lane = threadIdx.x;
   const int ldx = cp.lcap | 1;
   cx* Xc = reinterpret_cast<cx*>(smem);
@@ -1067,8 +1082,10 @@ constexpr int GW_POST_THREADS = 256;
 __global__ __launch_bounds__(GW_POST_THREADS) void gensys_post_kernel(int batch, GwCaps cp, double tol, const double* __restrict__ ws,
                                                           double* __restrict__ T_out, int32_t* __restrict__ eu_out,
                                                           int32_t* __restrict__ status, long long* __restrict__ dbg,
-                                                          int rescue, int32_t* __restrict__ key_out) {
+                                                          int rescue, int32_t* __restrict__ key_out,
+                                                          const int32_t* __restrict__ act) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  batch = gw_active_count(batch, act);
   const int lane = threadIdx.x;  // 0 .. GW_POST_THREADS-1
   const int n = cp.n;
   const int ldh = cp.wcap | 1, lds_ = cp.scap | 1;
@@ -1086,7 +1103,8 @@ __global__ __launch_bounds__(GW_POST_THREADS) void gensys_post_kernel(int batch,
 #define PT(i, j) Tc[(i)*ldh + (j)]
 #define PM(i, j) Mc[(i)*ldh + (j)]
   for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
-    const size_t off = (size_t)draw * n * n;
+    const int gdraw = act ? act[1 + draw] : draw;  // (draw: the slot of the workspace; gdraw: the caller's draw)
+    const size_t off = (size_t)gdraw * n * n;
     const double* wd = ws + (size_t)draw * wo.total;
     const int* meta = reinterpret_cast<const int*>(wd + wo.meta);
     const int eu0 = meta[GW_EU0], eu1 = meta[GW_EU1], eu2 = meta[GW_EU2];
@@ -1271,14 +1289,14 @@ __global__ __launch_bounds__(GW_POST_THREADS) void gensys_post_kernel(int batch,
         if (!(kq == kq)) kq = 0.0;
         kq = kq < 0.0 ? 0.0 : (kq > 63.0 ? 63.0 : kq);
       }
-      if (lane == 0) key_out[draw] = (int32_t)kq;
+      if (lane == 0) key_out[gdraw] = (int32_t)kq;
     }
     if (lane == 0) {
-      eu_out[3 * draw] = eu0;
-      eu_out[3 * draw + 1] = eu1;
-      eu_out[3 * draw + 2] = eu2;
+      eu_out[3 * gdraw] = eu0;
+      eu_out[3 * gdraw + 1] = eu1;
+      eu_out[3 * gdraw + 2] = eu2;
       // rescue: a rescue pass follows (the capacity record came from a cache): it takes the draws that did not fit
-      status[draw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK
+      status[gdraw] = (eu0 == 1 && eu1 == 1) ? DSGE_ST_OK
                      : ((rescue && st_extra == DSGE_ST_GENSYS_TOO_BIG) ? DSGE_ST_INTERNAL_RERUN : (DSGE_ST_NOT_CONVERGED | st_extra));
     }
   }

@@ -23,6 +23,9 @@ namespace {
 StreamArenaPool g_gw_pool;
 constexpr size_t GW_WORKSPACE_LIMIT = (size_t)1 << 30;  // draws are processed in chunks that keep the workspace below 1 GiB
 int gw_reserve(size_t bytes, hipStream_t st, void** out) { return g_gw_pool.reserve(bytes, st, out); }
+// gensys by spectral division: iteration counts, marks and the list of draws without a certificate (its own arena: the window
+// launches that solve those draws reserve -- and may re-allocate -- the one above)
+StreamArenaPool g_gd_pool;
 
 // Capacity record of the window path per (device, n, n_lead_hint): {max #lead, max window, max z, min z} of the batch it was measured on
 // (dsge_options.gensys_shape_cache).  gensys_shape_kernel measures it on the first call of a model size (a launch, a 16-byte
@@ -56,7 +59,9 @@ struct BkOut {
 };
 int launch_gensys_split(const double* A, const double* B, const double* C, int batch, int n, double tol, double* T_out,
                         int32_t* eu_out, int32_t* status, hipStream_t st, int* used, const BkOut* bk = nullptr,
-                        int n_lead_hint = 0, int32_t* key_out = nullptr) {
+                        int n_lead_hint = 0, int32_t* key_out = nullptr, const int32_t* act = nullptr) {
+  // act (device, {count, draw[0], draw[1], ...}): only those draws are solved, in workspace slots 0 .. count-1 (the launches keep
+  // their full grids -- the count is not known on the host -- and the idle workgroups return at once); without a chunk loop
   *used = 0;
   void* base = nullptr;
   int rc = gw_reserve(256, st, &base);
@@ -143,6 +148,7 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
   size_t chunk = GW_WORKSPACE_LIMIT / per_draw;
   if (chunk < 256) chunk = 256;
   if (chunk > (size_t)batch) chunk = (size_t)batch;
+  if (act && chunk < (size_t)batch) return DSGE_SUCCESS;  // (the caller falls back to its own pass)
   if ((rc = gw_reserve(256 + chunk * per_draw, st, &base))) return rc;
   double* wsp = (double*)((char*)base + 256);
   if ((rc = set_lds(dsge::gensys_reduce_kernel<2>, lds1))) return rc;
@@ -172,24 +178,24 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
     // two wavefronts per draw: the reflectors' columns in two shares (measured: 595 us per 4096 SW-shaped draws on one wavefront,
     // 499 us on two, 548 us on four -- the chain is the walk down the rows, which more column shares do not shorten)
     hipLaunchKernelGGL(dsge::gensys_reduce_kernel<2>, dim3(nb), dim3(128), lds1, st, A + c0 * nn, B + c0 * nn, C + c0 * nn, nb,
-                       cp, tol, wsp, g_gensys_win_dbg, obs_d);
+                       cp, tol, wsp, g_gensys_win_dbg, obs_d, act);
     GW_EVENT(1);
     if (pairs) {
       if (hess_pairs)
         hipLaunchKernelGGL(dsge::gensys_hesstri_pair_kernel, dim3((nb + 1) / 2), dim3(64), lds_hpair, st, nb, cp, wsp,
-                           g_gensys_win_dbg);
+                           g_gensys_win_dbg, act);
       else
-        hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0, 1);
+        hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg, 0, 1, act);
       GW_EVENT(2);
       if (dsge::gp_ld(cp) == 37)
         hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<37>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,
-                           g_gensys_win_dbg);
+                           g_gensys_win_dbg, act);
       else
         hipLaunchKernelGGL(dsge::gensys_sweeps_pair_kernel<39>, dim3((nb + 1) / 2), dim3(64), lds_pair, st, nb, cp, wsp,
-                           g_gensys_win_dbg);
+                           g_gensys_win_dbg, act);
     } else {
       hipLaunchKernelGGL(dsge::gensys_hesstri_kernel, dim3(nb), dim3(64), lds1b, st, nb, cp, wsp, g_gensys_win_dbg,
-                         opt().gensys_real_stage, 0);
+                         opt().gensys_real_stage, 0, act);
     }
     if (!pairs) GW_EVENT(2);
     GW_EVENT(3);
@@ -199,18 +205,18 @@ int launch_gensys_split(const double* A, const double* B, const double* C, int b
                        // diagonal pair and so on the order in which the roots of a block appear on the diagonal -- the
                        // iteration's order is LAPACK's, the closed form's need not be (a root of modulus 390 printed
                        // 1.2e-7 away from the golden); T, eu and the likelihood do not depend on it.
-                       (opt().gensys_real_stage && opt().gensys_direct_blocks && !bk) ? 1 : 0);
+                       (opt().gensys_real_stage && opt().gensys_direct_blocks && !bk) ? 1 : 0, act);
     GW_EVENT(4);
     if (bk)
       hipLaunchKernelGGL(dsge::gensys_bk_kernel, dim3(nb), dim3(64), 0, st, nb, cp, tol, (const double*)wsp,
                          bk->re + c0 * 2 * n, bk->im + c0 * 2 * n, bk->n_eig + c0, bk->n_forward + c0,
                          bk->n_unstable + c0, status + c0);
     else {
-      hipLaunchKernelGGL(dsge::gensys_eu_kernel, dim3(nb), dim3(64), lds_eu, st, nb, cp, tol, wsp, g_gensys_win_dbg);
+      hipLaunchKernelGGL(dsge::gensys_eu_kernel, dim3(nb), dim3(64), lds_eu, st, nb, cp, tol, wsp, g_gensys_win_dbg, act);
       GW_EVENT(5);
       hipLaunchKernelGGL(dsge::gensys_post_kernel, dim3(nb), dim3(dsge::GW_POST_THREADS), lds3, st, nb, cp, tol, (const double*)wsp,
                          T_out + c0 * nn, eu_out + 3 * c0, status + c0, g_gensys_win_dbg, cached ? 1 : 0,
-                         key_out ? key_out + c0 : nullptr);
+                         key_out ? key_out + c0 : nullptr, act);
     }
     GW_EVENT(6);
     HIP_TRY(hipGetLastError());
@@ -294,10 +300,11 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
   DISPATCH_BS(bs, 8, { lds = dsge::gd_lds_doubles<BS>(n, lcap, scap) * sizeof(double); });
   if (lds == 0 || lds > LDS_LIMIT) return DSGE_SUCCESS;
   void* base = nullptr;
-  const size_t ints = ((size_t)batch * sizeof(int32_t) + 255) / 256 * 256;
-  if ((rc = gw_reserve(256 + 2 * ints, st, &base))) return rc;
-  int32_t* it = (int32_t*)((char*)base + 256);
-  int32_t* mark = (int32_t*)((char*)base + 256 + ints);
+  const size_t ints = ((size_t)(batch + 1) * sizeof(int32_t) + 255) / 256 * 256;
+  if ((rc = g_gd_pool.reserve(3 * ints, st, &base))) return rc;
+  int32_t* it = (int32_t*)base;
+  int32_t* mark = (int32_t*)((char*)base + ints);
+  int32_t* act = (int32_t*)((char*)base + 2 * ints);  // {count, draws without a certificate in ascending order}
   // the doubling iteration: quadratic convergence, so the stopping tolerance only decides the LAST iteration (T is then
   // accurate to the product of the last iterate's norms, < 1e-18)
   const int max_iter = 50;
@@ -318,7 +325,17 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
   });
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
-  {  // the ordered QZ for the draws without a certificate (returns at once when nothing is flagged)
+  // The ordered QZ for the draws without a certificate.  Window path on the compacted list (its launches keep the grid of the
+  // whole batch -- the count stays on the device -- and the idle workgroups return at once: 0.03 ms when nothing is flagged, the QZ
+  // path's own rate when everything is); the single-launch kernel where the window path does not apply.
+  int used = 0;
+  if (opt().gensys_split && opt().gensys_doubling != 2) {
+    hipLaunchKernelGGL(dsge::gensys_compact_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)mark, batch, act);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used, nullptr, n_lead_hint, nullptr, act)))
+      return rc;
+  }
+  if (!used) {
     const size_t lds_q = dsge::gensys_smem_bytes(n, rescue_ncap, rescue_lcap);
     if ((rc = set_lds(dsge::gensys_kernel, lds_q))) return rc;
     hipLaunchKernelGGL(dsge::gensys_kernel, dim3(rerun_grid(batch)), dim3(64), lds_q, st, A, B, C, batch, n, rescue_ncap, rescue_lcap,

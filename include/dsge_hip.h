@@ -209,15 +209,17 @@ typedef struct dsge_options {
                                  Same recursion, results agree to rounding (tests compare the two kernels).  0: off; -1: every draw */
   double jitter_F;
   double jitter_P;
-  int32_t gensys_doubling;    /* 0 (default): gensys = ordered QZ of the pencil for every draw.  1: gensys by spectral division
-                                 (csrc/dsge_gensys_doubling.hpp) -- the doubling iteration (cycle reduction) computes the solvent T,
-                                 a per-draw CERTIFICATE (rho(T[S,S]) < 1 and rho(((B + C T)^-1 C)[L,L]) < 1 by norms of repeated
-                                 squares: exactly gensys's eu = [1, 1, 0]) is checked on the device, and every draw WITHOUT it --
-                                 not converged, a root within 2e-4 of the unit circle, more lead / state columns than hinted, a
-                                 column of C below tol, singular B + C T -- goes to the ordered QZ as before, which alone issues the
-                                 non-regular verdicts.  Same T (1e-12) and eu for regular draws at the cost of cycle reduction;
-                                 meant for estimation, where regular draws dominate (a batch of mostly non-regular draws is slower
-                                 than with 0: the fall-back is the single-launch kernel) */
+  int32_t gensys_doubling;    /* 1 (default): gensys by spectral division (csrc/dsge_gensys_doubling.hpp) -- the doubling iteration
+                                 (cycle reduction) computes the solvent T, a per-draw CERTIFICATE (rho(T[S,S]) < 1 and
+                                 rho(((B + C T)^-1 C)[L,L]) < 1 by norms of repeated squares: exactly gensys's eu = [1, 1, 0]) is
+                                 checked on the device, and every draw WITHOUT it -- not converged, a root within 2e-4 of the unit
+                                 circle, more lead / state columns than hinted, a column of C below tol, singular B + C T, |T| >
+                                 1e6 -- is solved by the ordered QZ (the window launches on the compacted list of those draws),
+                                 which alone issues the non-regular verdicts.  Same eu / status as 0 on every system of the test
+                                 and fuzz suites; T agrees with the QZ's to what two float64 algorithms differ by (1e-12 on
+                                 well-conditioned draws, cond(B + C T) eps in general).  0: the ordered QZ of the pencil for every
+                                 draw (the reference's algorithm, gEconpy/solvers/gensys.py:190-395, operation by operation).
+                                 2: as 1 with the single-launch QZ kernel as the fall-back (debug) */
   int32_t reserved_[3];
 } dsge_options;
 /* fills *opt with the compiled-in defaults */

@@ -14,7 +14,8 @@ from geconpy_amd import _lib, batched
 from geconpy_amd import workloads as wl
 
 pytestmark = pytest.mark.gpu
-DBL = {"gensys_doubling": 1}
+DBL = {"gensys_doubling": 1}  # (the library's default since round 5; explicit here)
+QZ = {"gensys_doubling": 0}   # the ordered QZ for every draw
 
 
 def _stack(g, keys):
@@ -38,7 +39,7 @@ def test_failure_codes_are_the_qz_s(failure_golden):
     g = failure_golden
     names = ["ok", "nonunique", "noexist", "coincident"]
     A, B, C, D = _stack(g, names)
-    qz = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    qz = batched.gensys_batched(A, B, C, D, tol=1e-8, options=QZ)
     out = batched.gensys_batched(A, B, C, D, tol=1e-8, options=DBL)
     for i, name in enumerate(names):
         assert list(out["eu"][i]) == list(g[f"{name}_ref_gensys_eu"]), name
@@ -74,7 +75,7 @@ def test_sw_shaped_draws_fused_and_standalone():
     M20 = B[20] + C[20] @ b["T_star"][20]
     A[20] = -M20 @ T20
     B[20] = M20 - C[20] @ T20
-    qz = batched.gensys_batched(A, B, C, b["D"], tol=1e-8)
+    qz = batched.gensys_batched(A, B, C, b["D"], tol=1e-8, options=QZ)
     out = batched.gensys_batched(A, B, C, b["D"], tol=1e-8, options=DBL)
     assert np.array_equal(out["eu"], qz["eu"]) and np.array_equal(out["status"], qz["status"])
     assert not out["success"][7] and not out["success"][11] and out["success"][20] and out["success"].sum() == nb - 2
@@ -88,7 +89,7 @@ def test_sw_shaped_draws_fused_and_standalone():
     assert dT[regular].max() <= 1e-9 and dR[regular].max() <= 1e-8, (int(dT[regular].argmax()), dT[regular].max())
     assert dT[240] <= 1e-6
     q = b["sigma"] ** 2
-    f_qz = batched.solve_kalman_logp_batched(A, B, C, b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8)
+    f_qz = batched.solve_kalman_logp_batched(A, B, C, b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8, options=QZ)
     f = batched.solve_kalman_logp_batched(A, B, C, b["D"], q, om["Z"], om["y"], Hdiag=om["Hdiag"], solver="gensys", tol=1e-8, options=DBL)
     assert np.array_equal(f["status"] != 0, f_qz["status"] != 0)
     assert_allclose(f["logp"][ok], f_qz["logp"][ok], rtol=5e-9)
