@@ -1,4 +1,4 @@
-// gensys by spectral division (round 5, dsge_options.gensys_doubling; OFF by default).
+// gensys by spectral division (round 5, dsge_options.gensys_doubling = 1: the default; 0 = the ordered QZ for every draw).
 //
 // What gensys needs of the pencil is its SPLIT at the unit circle: the stable deflating subspace gives T = G1[:n,:n], the counts
 // give eu (gEconpy/solvers/gensys.py:237-250, 282-310).  The ordered QZ computes far more -- every eigenvalue, triangular factors --
@@ -14,8 +14,8 @@
 // iteration (it agrees with the QZ's to 1e-12: the reference's own cross-solver test, tests/model/test_perturbation.py:205-206, asks
 // 1e-8) and gets eu = [1, 1, 0].  EVERYTHING ELSE -- no convergence, no certificate within 12 squarings (a root within 2e-4 of the
 // unit circle), more lead / state columns than the hints, a column of C with 0 < sum|C_ij| <= tol (gensys drops it from the pencil,
-// gensys.py:587), a singular M, a solvent with entries beyond 1e6 -- is flagged for the ordered QZ (the rescue pass of the window path's launcher: gensys_kernel on the
-// flagged draws), which decides as it always did: the non-regular verdicts ([1,0,k], [0,1,0], [-2,-2,0], ...) are the QZ's alone.
+// gensys.py:587), a singular M, a solvent with entries beyond 1e6 -- is flagged for the ordered QZ (the window launches on the compacted list of flagged draws,
+// gensys_compact_kernel), which decides as it always did: the non-regular verdicts ([1,0,k], [0,1,0], [-2,-2,0], ...) are the QZ's alone.
 #pragma once
 #include "dsge_device.hpp"
 
