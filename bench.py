@@ -826,6 +826,16 @@ def main():
                              "note": "SW-shaped systems scaled to n = 80 (36 states, 24 forward-looking, 10 shocks, 7 observed), "
                                      "1024 draws (128 distinct), cycle reduction: the 65..96-variable path (csrc/dsge_big.hpp)",
                              "failed_draws": int((st8 != 0).sum().item())}
+            # the same model with solver = gensys: beyond 64 variables gensys exists by spectral division only (csrc/dsge_big.hpp:
+            # gensys_certify_big_kernel -- the doubling iteration, then the certificate of eu = [1, 1, 0]; no ordered QZ at this size)
+            lp8g = torch.empty(1024, dtype=torch.float64, device=device)
+            st8g = torch.empty(1024, dtype=torch.int32, device=device)
+            dt8g = timed(lambda: eng.solve_kalman_logp(A8, B8, C8, D8, q8, Z8, y8, Hdiag=H8, q_mode=1, tol=args.tol,
+                                                       max_iter=args.max_iter, logp=lp8g, status=st8g, solver="gensys",
+                                                       z_selector_hint=1), 3)
+            extras["n80"]["gensys"] = {"value": round(1024 / dt8g, 2), "ms_per_step": round(dt8g * 1e3, 4),
+                                       "failed_draws": int((st8g != 0).sum().item()),
+                                       "max_rel_logp_diff_vs_cycle_reduction": float((torch.abs(lp8g - lp8) / torch.abs(lp8)).max().item())}
             if cpu_n80 is not None:
                 ref8 = cpu_n80[0]
                 rel8 = np.abs(lp8[: len(ref8)].cpu().numpy() - ref8) / np.abs(ref8)

@@ -429,12 +429,15 @@ int dsge_scan_cycle_reduction_batched(const double* A, const double* B, const do
 int dsge_gensys_batched(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k,
                         double tol, int n_lead_hint, double* T_out, double* R_out, int32_t* eu_out, int32_t* status,
                         void* stream) {
-  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  // 65 .. 96 variables: by spectral division only (csrc/dsge_big.hpp: gensys_certify_big_kernel; no ordered QZ at that size)
+  const bool big = big_size(n) && opt().gensys_doubling != 0;
+  int rc = check_common(batch, n, big ? DSGE_MAX_N_BIG : DSGE_MAX_N_GENSYS - 1);
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !eu_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "R_out requires D and 1 <= k <= n");
   if ((rc = ensure_device())) return rc;
   if (batch == 0) return DSGE_SUCCESS;
+  if (big) return launch_gensys_big(A, B, C, D, batch, n, k, tol, T_out, R_out, eu_out, status, nullptr, (hipStream_t)stream);
   if ((rc = launch_gensys(A, B, C, batch, n, tol, n_lead_hint, T_out, eu_out, status, (hipStream_t)stream, nullptr, nullptr, nullptr,
                           R_out ? D : nullptr, k, R_out)))
     return rc;
@@ -671,6 +674,7 @@ static int pipeline_big(const double* A, const double* B, const double* C, const
   double* P0 = cv.take<double>((size_t)batch * 64 * 64);
   int32_t* it_w = n_iter_out ? n_iter_out : cv.take<int32_t>((size_t)batch);
   int32_t* park_w = cv.take<int32_t>((size_t)batch);
+  int32_t* eu_w = cv.take<int32_t>((size_t)batch * 3);  // (gensys: the certificate's eu codes)
   // F depends on A and Z only: measured FIRST (one small launch, a 72-byte read-back, one stream synchronisation per call -- not
   // per repetition), so that a model with more than 64 state + observed variables is refused before anything is enqueued and
   // before any output of this call is touched (DSGE_ERR_TOO_LARGE: "nothing computed", include/dsge_hip.h)
@@ -694,11 +698,18 @@ static int pipeline_big(const double* A, const double* B, const double* C, const
     // (nor with the reference's default gating: a failed draw carries T = 0 on, and its R = -(C 0 + B)^-1 D comes from the
     // explicit selection, which runs after the statuses have been parked)
     const bool fuse_R = !scan && !resid_out && !park_failures;
+    if (solver == DSGE_SOLVER_GENSYS) {
+      // gensys at this size = the doubling iteration + the certificate of eu = [1, 1, 0] (gensys_certify_big_kernel), R from the
+      // certificate's elimination; a draw without the certificate is a failed draw (no ordered QZ beyond 64 variables)
+      if ((rc = launch_gensys_big(A, B, C, D, batch, n, k, tol, Tw, Rw, eu_w, status_out, it_w, st))) return rc;
+      if (resid_out && (rc = launch_selection_big(A, B, C, D, Tw, batch, n, k, nullptr, resid_out, status_out, st))) return rc;
+    } else {
     if ((rc = launch_cr_big(A, B, C, batch, n, max_iter, tol, Tw, status_out, it_w, st, scan ? 1 : 0, fuse_R ? D : nullptr, k,
                             fuse_R ? Rw : nullptr)))
       return rc;
     if (park_failures && (rc = launch_status_park(status_out, park_w, batch, 0, st))) return rc;
     if (!fuse_R && (rc = launch_selection_big(A, B, C, D, Tw, batch, n, k, Rw, resid_out, status_out, st))) return rc;
+    }
     if (ms_out) HIP_TRY(hipEventRecord(ev[1], st));
     if ((rc = launch_big_compress(Tw, Rw, Z, z_batched, batch, n, k, p, idx, u, T_r, R_r, Z_r, st))) return rc;
     const int ns_hint = (ns > 0 && ns < u) ? ns : 0;
@@ -746,7 +757,9 @@ static int pipeline(const double* A, const double* B, const double* C, const dou
   solver &= ~DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE;
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
   const bool park_failures = zero_T_on_failure && is_cr;
-  int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_BIG : DSGE_MAX_N);
+  // (gensys beyond 64 variables exists by spectral division only: dsge_options.gensys_doubling != 0)
+  const bool big_ok = is_cr || (solver == DSGE_SOLVER_GENSYS && opt().gensys_doubling != 0);
+  int rc = check_common(batch, n, big_ok ? DSGE_MAX_N_BIG : DSGE_MAX_N);
   if (rc) return rc;
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
@@ -1372,7 +1385,7 @@ int dsge_debug_gensys_window_phases(int enable, long long* cycles_out) {
 int dsge_gensys_batched_host(const double* A, const double* B, const double* C, const double* D, int batch, int n,
                              int k, double tol, int n_lead_hint, double* T_out, double* R_out, int32_t* eu_out,
                              int32_t* status) {
-  int rc = check_common(batch, n, DSGE_MAX_N_GENSYS - 1);
+  int rc = check_common(batch, n, (big_size(n) && opt().gensys_doubling != 0) ? DSGE_MAX_N_BIG : DSGE_MAX_N_GENSYS - 1);
   if (rc) return rc;
   if (!A || !B || !C || !T_out || !eu_out || !status) return fail(DSGE_ERR_INVALID, "null pointer");
   if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "R_out requires D and 1 <= k <= n");
@@ -2099,7 +2112,8 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
                                         int n_lead_hint, double* logp_out, int32_t* status_out, double* T_out,
                                         double* R_out, double* resid_out, int32_t* n_iter_out) {
   const int solver_code = solver & ~DSGE_SOLVER_FLAG_ZERO_T_ON_FAILURE;
-  int rc = check_common(batch, n, (solver_code == DSGE_SOLVER_CYCLE_REDUCTION || solver_code == DSGE_SOLVER_SCAN_CYCLE_REDUCTION)
+  int rc = check_common(batch, n, (solver_code == DSGE_SOLVER_CYCLE_REDUCTION || solver_code == DSGE_SOLVER_SCAN_CYCLE_REDUCTION ||
+                                   (solver_code == DSGE_SOLVER_GENSYS && opt().gensys_doubling != 0))
                                       ? DSGE_MAX_N_BIG
                                       : DSGE_MAX_N);
   if (rc) return rc;

@@ -708,6 +708,216 @@ __global__ __launch_bounds__(Cfg::NT) void selection_big_kernel(const double* __
   }
 }
 
+// ---- gensys for 65 .. 96 variables by spectral division (dsge_gensys_doubling.hpp has the derivation and the n <= 64 kernel):
+//      given the solvent T of the doubling iteration, M = B + C T, ONE elimination of [M | D | C] gives R = -M^-1 D and G = M^-1 C;
+//      the draw is certified -- eu = [1, 1, 0], gEconpy/solvers/gensys.py:237-250, 282-310 -- iff rho(G[L,L]) < 1 and rho(T[S,S]) < 1
+//      (L: columns of C with sum|C_ij| > tol, gensys.py:587; S: non-zero columns of T), shown by Frobenius norms of repeated squares
+//      (< 1/2 within 12 squarings).  There is NO ordered QZ at this size: a draw without the certificate -- not converged, a root
+//      within 2e-4 of the unit circle, a column of C below tol, singular M, |T| > 1e6, more than 32 lead or 64 state columns -- gets
+//      eu = [-3, -3, 0], status NOT_CONVERGED | GENSYS_TOO_BIG ("no verdict at this size") and T = R = 0: never a wrong verdict. -----
+constexpr int BIG_GD_LCAP = 32, BIG_GD_SCAP = 64, BIG_GD_SQUARINGS = 12;
+
+// rho(P) < 1 certified?  buf: 2 x d x ld doubles (P in the first half); the whole workgroup works, barriers inside, uniform result.
+template <class Cfg>
+__device__ __forceinline__ bool big_certify_contraction(double* __restrict__ buf, int d, int ld, double* __restrict__ red, int tid) {
+  if (d == 0) return true;
+  double* cur = buf;
+  double* nxt = buf + (size_t)d * ld;
+  double fro = 0.0;
+  for (int idx = tid; idx < d * d; idx += Cfg::NT) {
+    const double v = cur[(idx / d) * ld + (idx % d)];
+    fro = fma(v, v, fro);
+  }
+  fro = big_block_sum<Cfg>(fro, red, tid);
+  for (int k = 0; k <= BIG_GD_SQUARINGS; ++k) {
+    if (!(fro == fro) || !(fro < 1e300)) return false;
+    if (fro < 0.25) return true;
+    if (k == BIG_GD_SQUARINGS) break;
+    double part = 0.0;
+    for (int idx = tid; idx < d * d; idx += Cfg::NT) {
+      const int i = idx / d, j = idx - i * d;
+      double s0 = 0.0, s1 = 0.0;
+      int q = 0;
+      for (; q + 1 < d; q += 2) {
+        s0 = fma(cur[i * ld + q], cur[q * ld + j], s0);
+        s1 = fma(cur[i * ld + q + 1], cur[(q + 1) * ld + j], s1);
+      }
+      if (q < d) s0 = fma(cur[i * ld + q], cur[q * ld + j], s0);
+      const double v = s0 + s1;
+      nxt[i * ld + j] = v;
+      part = fma(v, v, part);
+    }
+    fro = big_block_sum<Cfg>(part, red, tid);  // (its barriers order the writes of nxt before the next round's reads)
+    double* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  return false;
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const double* __restrict__ B, const double* __restrict__ C,
+                                                                     const double* __restrict__ D, double* __restrict__ T,
+                                                                     int batch, int n, int k, double tol, double* __restrict__ ws,
+                                                                     double* __restrict__ R_out, int32_t* __restrict__ eu_out,
+                                                                     int32_t* __restrict__ status) {
+  constexpr int NP = Cfg::NP, TR = Cfg::TR, TC = Cfg::TC, NT = Cfg::NT;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* bufL = lds;
+  double* bufR = lds + Cfg::OFF_R;
+  double* red = lds + Cfg::OFF_RED;
+  // index maps in the column-sum partials (unused here): position of a column in L / in S (or -1), the members of S, counters
+  int* posL = reinterpret_cast<int*>(lds + Cfg::OFF_PART);
+  int* posS = posL + NP;
+  int* sidx = posS + NP;
+  int* cnt = sidx + NP;  // {#lead, #state, a column that rules the certificate out}
+  static_assert((size_t)Cfg::MT * NP * 2 >= 3 * NP + 4 && NP <= 128, "index maps fit the column-sum partials");
+  // after the elimination both panels are free: G[L,L] and its square, T[S,S] and its square
+  constexpr int LDG = BIG_GD_LCAP | 1, LDS_ = BIG_GD_SCAP | 1;
+  static_assert(2 * BIG_GD_LCAP * LDG + 2 * BIG_GD_SCAP * LDS_ <= 2 * NP * Cfg::LD, "certificate buffers fit the two panels");
+  double* Gm = lds;
+  double* Ts = lds + 2 * BIG_GD_LCAP * LDG;
+  const int tid = threadIdx.x;
+  const int ty = tid / Cfg::GX, tx = tid - ty * Cfg::GX, r0 = ty * TR, c0 = tx * TC;
+  double* W = ws + (size_t)blockIdx.x * Cfg::ws_doubles;
+  constexpr int LD = Cfg::LD, MAT = Cfg::MAT;
+  double *Cg = W, *Tg = W + MAT, *Mg = W + 2 * MAT;
+  for (int draw = blockIdx.x; draw < batch; draw += gridDim.x) {
+    const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
+    __syncthreads();
+    const bool conv = status[draw] == 0;  // (read by every thread before thread 0 writes it at the end of the draw)
+    bool ok = conv;
+    if (conv) {  // (uniform)
+      // lead and state columns; what rules the certificate out: a column gensys drops although the iteration used it
+      // (0 < sum <= tol), |T| beyond 1e6 (gensys's existence test is a tolerance there), NaN
+      if (tid == 0) cnt[2] = 0;
+      __syncthreads();
+      if (tid < NP) {
+        double csum = 0.0, tmax = 0.0;
+        bool tnz = false;
+        if (tid < n) {
+#pragma unroll 8
+          for (int r = 0; r < n; ++r) {  // (no short-circuit: the loads of eight rows are requested together)
+            const double cvv = C[off + (size_t)r * n + tid], tv = T[off + (size_t)r * n + tid];
+            csum += fabs(cvv);
+            tnz |= (tv != 0.0);
+            tmax = fmax(tmax, fabs(tv));
+          }
+        }
+        posL[tid] = (tid < n && csum > tol) ? 1 : 0;
+        posS[tid] = (tid < n && tnz) ? 1 : 0;
+        if (tid < n && ((csum > 0.0 && !(csum > tol)) || !(csum == csum) || !(tmax < 1e6))) cnt[2] = 1;
+      }
+      __syncthreads();
+      if (tid < 64) {  // flags -> positions (each lane reads and rewrites its own two entries)
+        const bool hi = tid + 64 < NP;
+        const bool l0 = posL[tid] != 0, l1 = hi && posL[hi ? tid + 64 : tid] != 0;
+        const bool s0 = posS[tid] != 0, s1 = hi && posS[hi ? tid + 64 : tid] != 0;
+        const unsigned long long ml0 = __ballot(l0), ml1 = __ballot(l1), ms0 = __ballot(s0), ms1 = __ballot(s1);
+        const unsigned long long below = (1ull << tid) - 1ull;
+        const int pl0 = __popcll(ml0 & below), pl1 = __popcll(ml0) + __popcll(ml1 & below);
+        const int ps0 = __popcll(ms0 & below), ps1 = __popcll(ms0) + __popcll(ms1 & below);
+        posL[tid] = l0 ? pl0 : -1;
+        posS[tid] = s0 ? ps0 : -1;
+        if (s0) sidx[ps0] = tid;
+        if (hi) {
+          posL[tid + 64] = l1 ? pl1 : -1;
+          posS[tid + 64] = s1 ? ps1 : -1;
+          if (s1) sidx[ps1] = tid + 64;
+        }
+        if (tid == 0) {
+          cnt[0] = __popcll(ml0) + __popcll(ml1);
+          cnt[1] = __popcll(ms0) + __popcll(ms1);
+        }
+      }
+      __syncthreads();
+      const int l = cnt[0], sN = cnt[1];
+      ok = cnt[2] == 0 && l <= BIG_GD_LCAP && sN <= BIG_GD_SCAP;
+      // M = B + C T (as selection_big_kernel)
+      for (int idx = tid; idx < MAT; idx += NT) {
+        const int r = idx / LD, c = idx - r * LD;
+        const bool in = r < n && c < n;
+        const size_t g = off + (size_t)r * n + c;
+        Cg[idx] = in ? C[g] : 0.0;
+        Tg[idx] = in ? T[g] : 0.0;
+      }
+      __syncthreads();
+      big_panel_load<Cfg>(bufL, Cg, tid);
+      big_panel_load<Cfg>(bufR, Tg, tid);
+      __syncthreads();
+      big_gemm<Cfg>(bufL, bufR, tid, BigZero(), [&](int, int, int row0, int col, big_v4f64 v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = row0 + 4 * e;
+          Mg[r * LD + col] = (r < n && col < n) ? B[off + (size_t)r * n + col] + v[e] : 0.0;
+        }
+      });
+      __syncthreads();
+      // [M | D | C] -> [. | M^-1 D | M^-1 C]
+      double t1[TR][TC], t0[TR][TC], t2[TR][TC];
+      big_tile_load<Cfg>(t1, Mg, r0, c0);
+      big_tile_load<Cfg>(t2, Cg, r0, c0);
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int jc = 0; jc < TC; ++jc) {
+          const int r = r0 + i, c = c0 + jc;
+          t0[i][jc] = (D && r < n && c < k) ? D[offk + (size_t)r * k + c] : 0.0;
+        }
+      big_eliminate<Cfg>(t1, t0, t2, n, lds, r0, c0, tid);
+      const int* pivcol = reinterpret_cast<const int*>(lds + Cfg::E_PIV);
+      int qrow[TR];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        int q = (r0 + i < n) ? pivcol[r0 + i] : 0;
+        qrow[i] = q < 0 ? 0 : (q >= n ? n - 1 : q);
+      }
+      // G[L,L] and T[S,S] into the (now free) panels
+      for (int idx = tid; idx < 2 * BIG_GD_LCAP * LDG + 2 * BIG_GD_SCAP * LDS_; idx += NT) lds[idx] = 0.0;
+      __syncthreads();
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          if (r0 + i < n) {
+            const int pr = posL[qrow[i]];
+#pragma unroll
+            for (int jc = 0; jc < TC; ++jc) {
+              const int pc = (c0 + jc < n) ? posL[c0 + jc] : -1;
+              if (pr >= 0 && pc >= 0) Gm[pr * LDG + pc] = t2[i][jc];
+            }
+          }
+        }
+        for (int idx = tid; idx < sN * sN; idx += NT) {
+          const int i = idx / sN, j = idx - i * sN;
+          Ts[i * LDS_ + j] = T[off + (size_t)sidx[i] * n + sidx[j]];
+        }
+      }
+      __syncthreads();
+      if (ok) ok = big_certify_contraction<Cfg>(Gm, l, LDG, red, tid);
+      if (ok) ok = big_certify_contraction<Cfg>(Ts, sN, LDS_, red, tid);
+      if (R_out) {
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+          if (r0 + i < n) {
+#pragma unroll
+            for (int jc = 0; jc < TC; ++jc)
+              if (c0 + jc < k) R_out[offk + (size_t)qrow[i] * k + c0 + jc] = ok ? -t0[i][jc] : 0.0;
+          }
+      }
+    } else if (R_out) {
+      for (int idx = tid; idx < n * k; idx += NT) R_out[offk + idx] = 0.0;
+    }
+    if (!ok)  // no verdict: nobody gets to use the solvent
+      for (int idx = tid; idx < n * n; idx += NT) T[off + idx] = 0.0;
+    if (tid == 0) {
+      eu_out[3 * draw] = ok ? 1 : -3;
+      eu_out[3 * draw + 1] = ok ? 1 : -3;
+      eu_out[3 * draw + 2] = 0;
+      if (!ok) status[draw] = (conv ? DSGE_ST_NOT_CONVERGED : status[draw]) | DSGE_ST_GENSYS_TOO_BIG;
+    }
+  }
+}
+
 // ---- the filtered variables of the batch: bit j of mask[0..1] = some draw has a non-zero column j in A (a state variable:
 // T = -(B + C T)^-1 A has a non-zero column exactly there) or in Z (an observed variable) -------------------------------------------
 __global__ __launch_bounds__(128) void big_mask_kernel(const double* __restrict__ A, const double* __restrict__ Z, int z_batched,

@@ -105,6 +105,8 @@ int launch_cr(const double* A, const double* B, const double* C, int batch, int 
 bool big_size(int n);
 int launch_cr_big(const double* A, const double* B, const double* C, int batch, int n, int max_iter, double tol, double* T_out,
                   int32_t* status, int32_t* n_iter, hipStream_t st, int scan_mode, const double* D, int k, double* R_out);
+int launch_gensys_big(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, double tol,
+                      double* T_out, double* R_out, int32_t* eu_out, int32_t* status, int32_t* n_iter, hipStream_t st);
 int launch_selection_big(const double* A, const double* B, const double* C, const double* D, const double* T, int batch, int n,
                          int k, double* R_out, double* resid_out, const int32_t* status, hipStream_t st);
 int big_filtered_variables(const double* A, const double* Z, int z_batched, int batch, int n, int p, hipStream_t st,

@@ -77,6 +77,33 @@ int launch_selection_big(const double* A, const double* B, const double* C, cons
   return DSGE_SUCCESS;
 }
 
+// gensys for 65 .. 96 variables (gensys_certify_big_kernel): the doubling iteration, then the certificate of eu = [1, 1, 0] with
+// R = -(B + C T)^-1 D from the same elimination.  T_out: the solvent (zeroed for draws without a verdict).
+int launch_gensys_big(const double* A, const double* B, const double* C, const double* D, int batch, int n, int k, double tol,
+                      double* T_out, double* R_out, int32_t* eu_out, int32_t* status, int32_t* n_iter, hipStream_t st) {
+  if (!big_size(n)) return fail(DSGE_ERR_INVALID, "launch_gensys_big: n out of range");
+  if (R_out && (!D || k < 1 || k > n)) return fail(DSGE_ERR_INVALID, "launch_gensys_big: R_out requires D and 1 <= k <= n");
+  int rc;
+  // (quadratic convergence: the tolerance only decides the last iteration -- as launch_gensys_doubling)
+  if ((rc = launch_cr_big(A, B, C, batch, n, 50, 1e-9, T_out, status, n_iter, st, 0, nullptr, 0, nullptr))) return rc;
+  const int grid = batch < BIG_GRID_MAX ? batch : BIG_GRID_MAX;
+  void* base = nullptr;
+#define BIG_CERT(CFG)                                                                                                          \
+  do {                                                                                                                         \
+    if ((rc = g_big_pool.reserve(al256((size_t)grid * CFG::ws_doubles * 8), st, &base))) return rc;                            \
+    if ((rc = set_lds(dsge::gensys_certify_big_kernel<CFG>, CFG::lds_bytes))) return rc;                                       \
+    hipLaunchKernelGGL(dsge::gensys_certify_big_kernel<CFG>, dim3(grid), dim3(CFG::NT), CFG::lds_bytes, st, B, C, D, T_out, batch, \
+                       n, k, tol, (double*)base, R_out, eu_out, status);                                                       \
+  } while (0)
+  if (n <= 80)
+    BIG_CERT(Cfg80);
+  else
+    BIG_CERT(Cfg96);
+#undef BIG_CERT
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
 // F = {state variables} u {observed variables} of the batch, measured on the device (one small launch and a 32-byte read-back:
 // the call synchronises the stream here).  *u_out = |F|, *ns_out = number of state variables; idx_out: the sorted members.
 int big_filtered_variables(const double* A, const double* Z, int z_batched, int batch, int n, int p, hipStream_t st,

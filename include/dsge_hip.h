@@ -331,6 +331,12 @@ int dsge_debug_cr_phases(int enable, long long* cycles_out);
  *   status: [batch] 0 iff eu[0] == 1 && eu[1] == 1 (the Op's `success`, gensys.py:663)
  *   n_lead_hint : upper bound on the number of lead columns of C (0 = unknown); sizes the
  *           on-chip pencil.  n + #lead <= DSGE_MAX_N_GENSYS.
+ * 65 <= n <= DSGE_MAX_N_BIG (96), dsge_options.gensys_doubling != 0 only: gensys by spectral division with one workgroup per draw
+ * (csrc/dsge_big.hpp: the doubling iteration, then gensys_certify_big_kernel -- one elimination of [B + C T | D | C] gives R and
+ * G = (B + C T)^-1 C; eu = {1,1,0} iff rho(T[S,S]) < 1 and rho(G[L,L]) < 1 are certified).  There is no ordered QZ at that size: a
+ * draw without the certificate (non-regular, or a root within 2e-4 of the unit circle, > 32 lead or > 64 state columns) gets
+ * eu = {-3,-3,0}, status DSGE_ST_NOT_CONVERGED | DSGE_ST_GENSYS_TOO_BIG and T = R = 0 -- a failed draw, never a wrong verdict.
+ * The fused dsge_solve_kalman_logp_batched takes solver = gensys at these sizes the same way.
  */
 int dsge_gensys_batched(const double* A, const double* B, const double* C, const double* D, int batch, int n,
                         int k, double tol, int n_lead_hint, double* T_out, double* R_out, int32_t* eu_out,

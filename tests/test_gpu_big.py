@@ -110,7 +110,7 @@ def test_big_solve_kalman_logp_vs_oracle(n, observed):
 
 def test_big_failed_draw_and_too_many_filtered_variables():
     """A failed solve inside the fused call: logp = -inf and the solver's status for that draw only.  More than 64 state and
-    observed variables: DSGE_ERR_TOO_LARGE (a return code), nothing computed.  Solvers other than cycle reduction keep n <= 64."""
+    observed variables: DSGE_ERR_TOO_LARGE (a return code), nothing computed.  The ordered QZ keeps n <= 64."""
     n = 80
     sh = SHAPES[n]
     b = wl.sw_shaped_batch(4, n=n, p=7, T_len=30, **sh)
@@ -126,9 +126,55 @@ def test_big_failed_draw_and_too_many_filtered_variables():
     with pytest.raises(_lib.DsgeTooLargeError):
         batched.solve_kalman_logp_batched(wide["A"], wide["B"], wide["C"], wide["D"], wide["sigma"] ** 2, omw["Z"], omw["y"],
                                           Hdiag=omw["Hdiag"], tol=1e-8, max_iter=1000)
+    # the ordered QZ keeps n + #lead <= 64 (gensys beyond that exists by spectral division only: test_big_gensys_*)
     with pytest.raises(_lib.DsgeHipError):
         batched.solve_kalman_logp_batched(b["A"], b["B"], b["C"], b["D"], b["sigma"] ** 2, om["Z"], om["y"], Hdiag=om["Hdiag"],
-                                          tol=1e-8, solver="gensys")
+                                          tol=1e-8, solver="gensys", options={"gensys_doubling": 0})
+    with pytest.raises(_lib.DsgeHipError):
+        batched.gensys_batched(b["A"], b["B"], b["C"], b["D"], tol=1e-8, options={"gensys_doubling": 0})
+
+
+@pytest.mark.parametrize("n", [65, 72, 80, 96])
+def test_big_gensys_by_spectral_division_vs_oracle(n):
+    """solver = gensys beyond 64 variables (the reference has no size limit and gensys is its default, statespace.py:822-839):
+    the doubling iteration + the certificate of eu = [1, 1, 0] (csrc/dsge_big.hpp: gensys_certify_big_kernel).  Regular draws:
+    T, R, eu of the oracle's gensys (LAPACK's ordered QZ of the (n + #lead)-dimensional pencil); an explosive and an indeterminate
+    draw: the oracle's gensys says eu != [1, 1], the device says 'no verdict at this size' -- a failed draw either way."""
+    sh = SHAPES[n]
+    nb = 10
+    b = wl.sw_shaped_batch(nb, n=n, p=7, T_len=30, **sh)
+    A, B, C, D = b["A"].copy(), b["B"].copy(), b["C"].copy(), b["D"]
+    A[3] *= 25.0  # explosive: no stable solvent
+    M = B[6] + C[6] @ b["T_star"][6]  # indeterminate: a root of the forward block pulled inside the unit circle
+    G = np.linalg.solve(M, C[6])
+    C[6] = M @ (G * (1.5 / np.max(np.abs(np.linalg.eigvals(G)))))
+    B[6] = M - C[6] @ b["T_star"][6]
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    for i in range(nb):
+        T_ref, succ, eu = oracle.gensys_T_success(A[i], B[i], C[i], D[i], 1e-8)
+        assert bool(out["success"][i]) == bool(succ), (i, eu, out["eu"][i], out["status"][i])
+        if succ:
+            assert list(out["eu"][i]) == [1, 1, 0]
+            assert_allclose(out["T"][i], T_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(T_ref).max()))
+            R_ref = -np.linalg.solve(C[i] @ T_ref + B[i], D[i])
+            assert_allclose(out["R"][i], R_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(R_ref).max()))
+        else:
+            assert i in (3, 6)
+            assert list(out["eu"][i]) == [-3, -3, 0] and out["status"][i] & _lib.ST_GENSYS_TOO_BIG
+            assert not out["T"][i].any() and not out["R"][i].any()
+    # the fused evaluation against the oracle's, same solver
+    om = wl.sw_shaped_observation_model(n=n, p=7, T_len=30, **sh)
+    q = b["sigma"] ** 2
+    f = batched.solve_kalman_logp_batched(A, B, C, D, q, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8, solver="gensys",
+                                          q_mode="diag_batched")
+    assert np.array_equal(f["status"] == 0, out["success"]) and np.all(f["logp"][[3, 6]] == -np.inf)
+    for i in (0, 1, 5, 9):
+        ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(q[i]), om["Z"], om["y"], H=np.diag(om["Hdiag"]), solver="gensys")
+        assert abs(f["logp"][i] - ref["logp"]) <= 1e-8 * abs(ref["logp"]), (i, f["logp"][i], ref["logp"])
+    # same T as the cycle-reduction solver's (bit for bit: the same kernel computed it)
+    T_cr = batched.cycle_reduction_batched(A, B, C, tol=1e-9, max_iter=50)[0]
+    ok = out["success"]
+    assert np.array_equal(T_cr[ok], out["T"][ok])
 
 
 def test_big_host_chunks_and_reference_default_gating():
