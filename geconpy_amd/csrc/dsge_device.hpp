@@ -497,7 +497,10 @@ __device__ __forceinline__ constexpr double cr_refine_ratio() {
 
 template <int BS>
 __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,
-                                                     int* prow, int lane, long long* ph, double& inv_min, double& inv_max) {
+                                                     int* prow, int lane, long long* ph, double& inv_min, double& inv_max,
+                                                     double* rec_L = nullptr) {
+  // rec_L (optional, nsteps x NP x BS doubles): the elimination's multipliers Lhat of every block step are kept, so that
+  // gj_replay can apply the SAME elimination to further right-hand sides (with prow, which holds the pivot rows)
   // inv_min / inv_max: smallest and largest |1 / pivot| met (wave-uniform): their ratio is a free lower estimate of the
   // condition number, which crc_iterate uses to decide on a step of iterative refinement
   constexpr int NP = 8 * BS;
@@ -563,6 +566,10 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
         if (a < bw && lane == rsel[a]) lh[a] += 1.0;
 #pragma unroll
       for (int b = 0; b < BS; ++b) Lbuf[lane * BS + b] = (lane < n) ? lh[b] : 0.0;
+      if (rec_L) {
+#pragma unroll
+        for (int b = 0; b < BS; ++b) rec_L[((size_t)kb * NP + lane) * BS + b] = (lane < n) ? lh[b] : 0.0;
+      }
     }
     // pivot rows of W (original values) -> Ybuf, one column per lane
     for (int c = lane; c < wcols; c += 64) {
@@ -612,9 +619,57 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
 
 template <int BS>
 __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, int ngroups, double* Lbuf, double* Ybuf,
-                                                     int* prow, int lane, long long* ph = nullptr) {
+                                                     int* prow, int lane, long long* ph = nullptr, double* rec_L = nullptr) {
   double lo = 1e300, hi = 0.0;
-  gauss_jordan_blocked<BS>(W, ldw, n, ngroups, Lbuf, Ybuf, prow, lane, ph, lo, hi);
+  gauss_jordan_blocked<BS>(W, ldw, n, ngroups, Lbuf, Ybuf, prow, lane, ph, lo, hi, rec_L);
+}
+
+// The elimination recorded by gauss_jordan_blocked (rec_L, prow) applied to ONE more right-hand-side column group Wg (NP columns,
+// row stride ldw): Wg <- A^-1 Wg, rows in pivot order as there.  The arithmetic is that of the trailing update above, operation
+// by operation (same multipliers, same pivot rows, same order of the FMAs): the result is bit-identical to eliminating
+// [A | Wg] again, at the cost of the rank-BS updates alone -- no pivot search, no panel, nothing on the matrix part.
+// Ybuf2: BS x NP doubles of scratch.  Syncs on entry and exit.
+template <int BS>
+__device__ __forceinline__ void gj_replay(double* Wg, int ldw, int n, const double* rec_L, const int* prow, double* Ybuf2,
+                                          int lane) {
+  constexpr int NP = 8 * BS;
+  const int lr = lane >> 3, lc = lane & 7;
+  const int nsteps = (n + BS - 1) / BS;
+  for (int kb = 0; kb < nsteps; ++kb) {
+    const int j0 = kb * BS;
+    const int bw = (n - j0 < BS) ? (n - j0) : BS;
+    wave_sync();
+    for (int c = lane; c < NP; c += 64) {
+#pragma unroll
+      for (int b = 0; b < BS; ++b) Ybuf2[b * NP + c] = (b < bw) ? Wg[prow[j0 + (b < bw ? b : 0)] * ldw + c] : 0.0;
+    }
+    wave_sync();
+    double lh[BS][BS], wb[BS][BS], yb[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) lh[i][b] = rec_L[((size_t)kb * NP + lr * BS + i) * BS + b];
+    const int c0 = lc * BS;
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) wb[i][j] = Wg[(lr * BS + i) * ldw + c0 + j];
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) yb[b][j] = Ybuf2[b * NP + c0 + j];
+#pragma unroll
+    for (int b = 0; b < BS; ++b)
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) wb[i][j] = fma(-lh[i][b], yb[b][j], wb[i][j]);
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Wg[(lr * BS + i) * ldw + c0 + j] = wb[i][j];
+  }
+  wave_sync();
 }
 
 // Restore natural row order of the right-hand-side column groups [g_first, ngroups): row j of the

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
   const int fo = lane >> 3, fq = lane & 7;
   const double LN2PI = 1.8378770664093453;
 
+  long long qh[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug (draw 0), inside FULL steps: fwd update_cov + record, fwd mean, fwd predict | rev record, rev mean side, rev products, rev panels, rev Pbar
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug (draw 0): setup+P0, fwd full, fwd steady, rev full, rev steady, tail, #full, #steady
   // (one draw per workgroup, grid = batch: no grid-stride loop for the compiler to hoist loop invariants out of and spill
   //  them around the time loops -- see kalman_nt_kernel)
@@ -518,11 +519,18 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         sg[OFF_FI + lane] = Fi[lane];
         sg[OFF_F + lane] = Fs[lane];
       }
+      long long tq = tm ? clock64() : 0;
+      if (tm) qh[0] += tq - tk0;
       if (lane == 0) sg[OFF_SRC] = (double)seg_src;
       const double quad = update_mean(yt);
       ll_acc += lam * (seg_logdet + quad);
       n_ll += (lam != 0.0);
       n_entries += __popcll(omask);
+      if (tm) {
+        const long long t_ = clock64();
+        qh[1] += t_ - tq;
+        tq = t_;
+      }
       // predict: a = T a+
       if (lane < u) {
         t1[lane] = kg_dot4(Tc + lane * LDM, 1, ap, 1, u);
@@ -559,6 +567,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
       if (lane < NP) av[lane] = (lane < u) ? t1[lane] : 0.0;
       wave_sync();
+      if (tm) qh[2] += clock64() - tq;
       if (tm) {
         const long long tk1 = clock64();
         ph[light ? 2 : 1] += tk1 - tk0;
@@ -669,6 +678,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           }
         }
         wave_sync();
+        if (tm) qh[3] += clock64() - tk0;
         cur_src = src_t;
 #pragma unroll
         for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
@@ -829,6 +839,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           tk0 = tk1;
         }
       }
+      long long tr = tm ? clock64() : 0;
       if (t == src_t) {
         // ---- covariance side, once per segment: Pb is the cotangent of the predicted covariance P_{src+1}, which the
         // steady steps after src never touched; X1 = P+ of the source step.
@@ -851,6 +862,11 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           blk_store_lds<BS>(pp, Ps, LDM, lr, lc);  // Ps now holds P+bar (P_t itself is no longer needed)
         }
         wave_sync();
+        if (tm) {
+          const long long t_ = clock64();
+          qh[5] += t_ - tr;
+          tr = t_;
+        }
         for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
           const int i = idx >> 3, o = idx & 7;
           Yp[i * PS + o] = kg_dot4(Ps + i * LDM, 1, Kp + o, PS, u);
@@ -903,6 +919,11 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           if (o < p) Ps[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], Ps[i * LDM + zpos[o]]);
         }
         wave_sync();
+        if (tm) {
+          const long long t_ = clock64();
+          qh[6] += t_ - tr;
+          tr = t_;
+        }
         {  // (register blocks: the entry-per-lane loop divided by u and read two dependent entries per trip)
           double a[BS][BS], b[BS][BS];
           blk_load_lds<BS>(a, Ps, LDM, lr, lc);
@@ -919,6 +940,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
       if (tm) {
         const long long tk1 = clock64();
+        qh[7] += tk1 - tr;
         ph[3] += tk1 - tk0;
         tk0 = tk1;
       }
@@ -981,7 +1003,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     if (tm) {
       ph[5] += clock64() - tk0;
       if (lane == 0)
-        for (int k2 = 0; k2 < 8; ++k2) dbg[k2] = ph[k2];
+        for (int k2 = 0; k2 < 8; ++k2) {
+          dbg[k2] = ph[k2];
+          dbg[8 + k2] = qh[k2];
+        }
     }
   }
 }

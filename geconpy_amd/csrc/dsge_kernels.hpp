@@ -539,6 +539,10 @@ struct AdjSmem {
   // is free: 51.8 instead of 71.5 KB at n = 40, three draws per CU instead of two
   static constexpr size_t bytes = sizeof(double) * (size_t)(NP * LDW + NP * LD);
   static_assert(NP * BS + BS * 3 * NP + NP / 2 <= NP * LD, "Gauss-Jordan scratch must fit the NP x LD matrix");
+  // the second pass (REFINE) only: the recorded elimination of its fixed-point fall-back (8 block steps x NP x BS multipliers) and
+  // the replay's pivot-row scratch (BS x NP) behind the first pass's layout -- few draws take that pass, its occupancy is free
+  static constexpr size_t refine_extra_doubles = (size_t)8 * NP * BS + (size_t)BS * NP + NP / 2 + 1;  // (+ NP ints: the pivot rows)
+  static constexpr size_t bytes_refine = bytes + sizeof(double) * refine_extra_doubles;
 };
 
 // One Stein solve on the wavefront: S = H + G S F with H = -M^-T rhs, G = -M^-T C', F = T' (see above), everything from
@@ -651,8 +655,13 @@ __device__ __forceinline__ bool adj_stein_solve(double* W, double* Tk, const dou
 // pass's S (zero when that pass failed) and returns the CORRECTION X - S in Sb and in the second column group of W.
 constexpr int ADJ_FP_MAX_SWEEPS = 200;
 constexpr double ADJ_FP_RESIDUAL = 1e-4;  // relative Stein residual of the first pass above which the second pass eliminates
+// Round 5: M' is eliminated ONCE (sweep 0, multipliers recorded: gauss_jordan_blocked's rec_L) and every later sweep replays that
+// elimination on its right-hand side (gj_replay: bit-identical to eliminating [M' | rhs] again -- the same backward-stable solve,
+// the same iterates) -- a sweep is eight rank-BS updates and two products instead of a 40-pivot elimination with its panels:
+// 97 k -> ~25 k cycles per sweep, the second pass on the batch with draw 752 1.78 -> see profiles/r5/grad_rate.txt.
+// `extra`: AdjSmem::refine_extra_doubles of LDS.
 template <int BS>
-__device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, const double* __restrict__ B,
+__device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, double* extra, const double* __restrict__ B,
                                                       const double* __restrict__ C, const double* __restrict__ T,
                                                       const double* __restrict__ T_bar, const double* __restrict__ S0, size_t off,
                                                       int n, double (&Sb)[BS][BS], int lane) {
@@ -661,6 +670,8 @@ __device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, con
   double* Lbuf = Tk;
   double* Ybuf = Lbuf + NP * BS;
   int* prow = (int*)(Ybuf + BS * 3 * NP);
+  double* rec_L = extra;                        // [8][NP][BS]
+  double* Ybuf2 = extra + (size_t)8 * NP * BS;  // [BS][NP]
   const int lr = lane >> 3, lc = lane & 7;
   wave_sync();
   lds_load_matrix(W + NP, LDW, NP, NP, S0 + off, n, n, lane);  // X_0
@@ -669,6 +680,9 @@ __device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, con
   bool ok = false;
   double best = 1e300;
   int since = 0;  // sweeps since the step last shrank by 10 % (the steps of a complex pair of modes are not monotone)
+  double Tb0[BS][BS];
+  blk_load_global<BS>(Tb0, T_bar + off, n, n, n, lr, lc);
+  int* prow2 = (int*)(Ybuf2 + BS * NP);  // the pivot rows, kept outside Tk (which C takes back from sweep 1 on)
   for (int sweep = 0; sweep < ADJ_FP_MAX_SWEEPS; ++sweep) {
     {
       double P1[BS][BS];
@@ -677,14 +691,19 @@ __device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, con
       wave_sync();
       blk_store_lds<BS>(P1, W, LDW, lr, lc);
     }
-    lds_load_matrix(Tk, LD, NP, NP, C + off, n, n, lane);  // the elimination's scratch lives here: C comes back every sweep
+    // C in Tk: sweep 0's elimination uses Tk as its scratch, so C is loaded for sweep 0 and once more for sweep 1; it stays after
+    if (sweep <= 1) lds_load_matrix(Tk, LD, NP, NP, C + off, n, n, lane);
     wave_sync();
     double Xo[BS][BS];
     blk_load_lds<BS>(Xo, W + NP, LDW, lr, lc);
-    {
-      double Rr[BS][BS], Mb[BS][BS];
-      blk_load_global<BS>(Rr, T_bar + off, n, n, n, lr, lc);
-      mm_acc_ta<BS>(Rr, Tk, LD, W, LDW, n, lr, lc);  // T_bar + C' X T'
+    double Rr[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Rr[i][j] = Tb0[i][j];
+    mm_acc_ta<BS>(Rr, Tk, LD, W, LDW, n, lr, lc);  // T_bar + C' X T'
+    if (sweep == 0) {
+      double Mb[BS][BS];
       blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
       mm_acc<BS, false>(Mb, Tk, LD, Ts, LDW, n, lr, lc);  // M = B + C T
       wave_sync();
@@ -693,9 +712,15 @@ __device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, con
 #pragma unroll
         for (int j = 0; j < BS; ++j) W[(lc * BS + j) * LDW + lr * BS + i] = Mb[i][j];  // M'
       blk_store_lds<BS>(Rr, W + NP, LDW, lr, lc);
+      gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane, nullptr, rec_L);
+      for (int idx = lane; idx < NP; idx += 64) prow2[idx] = prow[idx];  // (prow sits in Tk, which C takes back)
+      wave_sync();
+    } else {
+      wave_sync();  // (every lane has read X and P1)
+      blk_store_lds<BS>(Rr, W + NP, LDW, lr, lc);
+      gj_replay<BS>(W + NP, LDW, n, rec_L, prow2, Ybuf2, lane);
     }
-    gauss_jordan_blocked<BS>(W, LDW, n, 2, Lbuf, Ybuf, prow, lane);
-    gj_unpermute<BS>(W, LDW, n, 1, 2, prow, lane);
+    gj_unpermute<BS>(W, LDW, n, 1, 2, prow2, lane);
     double Xn[BS][BS], Df[BS][BS];
     blk_load_lds<BS>(Xn, W + NP, LDW, lr, lc);
     wave_sync();
@@ -809,7 +834,7 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
       if (rmax <= ADJ_FP_RESIDUAL * tmax)
         ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Rr, Sb, lane, gmax);  // the correction dS (also in W's second group)
       else  // the first pass broke down or is far off: no power of G can be trusted
-        ok = adj_stein_fixed_point<BS>(W, Tk, B, C, T, T_bar, A_bar, off, n, Sb, lane);
+        ok = adj_stein_fixed_point<BS>(W, Tk, smem + AdjSmem<BS>::bytes / sizeof(double), B, C, T, T_bar, A_bar, off, n, Sb, lane);
     } else {
       double Hb[BS][BS];
       blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);

@@ -45,14 +45,14 @@ int launch_adjoint(const double* B, const double* C, const double* T, const doub
   int rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 7, {
     rc = set_lds(dsge::adjoint_kernel<BS, false>, dsge::AdjSmem<BS>::bytes);
-    if (rc == DSGE_SUCCESS) rc = set_lds(dsge::adjoint_kernel<BS, true>, dsge::AdjSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) rc = set_lds(dsge::adjoint_kernel<BS, true>, dsge::AdjSmem<BS>::bytes_refine);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL((dsge::adjoint_kernel<BS, false>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
                          batch, n, Ab, Bb, Cb, status, accumulate, g_adj_refine_mode);
       HIP_TRY(hipGetLastError());
       // second pass: one step of iterative refinement for the draws whose Stein residual the first pass flagged (normally none)
       // (one workgroup per draw: a flagged draw costs a whole solve, two of them behind each other in one workgroup twice that)
-      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, true>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C,
+      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, true>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes_refine, st, B, C,
                          T, Tbar, batch, n, Ab, Bb, Cb, status, 1, 0);
       HIP_TRY(hipGetLastError());
     }

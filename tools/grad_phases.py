@@ -22,3 +22,6 @@ print(f"draw 0: {nf} full steps, {ns} steady steps")
 print({"setup+P0": int(c[0]), "forward full (per step)": int(c[1] // max(nf, 1)), "forward steady (per step)": int(c[2] // max(ns, 1)),
        "reverse full (per step)": int(c[3] // max(nf, 1)), "reverse steady (per step)": int(c[4] // max(ns, 1)), "tail (dlyap adjoint + scatter)": int(c[5])})
 print("totals", {"forward": int(c[1] + c[2]), "reverse": int(c[3] + c[4]), "kernel": int(c[:6].sum())})
+q = c[8:16]
+print("inside FULL steps (cycles per full step):", {"fwd update_cov+record": int(q[0] // max(nf, 1)), "fwd mean": int(q[1] // max(nf, 1)), "fwd predict": int(q[2] // max(nf, 1)),
+      "rev record load": int(q[3] // max(nf, 1)), "rev products": int(q[5] // max(nf, 1)), "rev panels": int(q[6] // max(nf, 1)), "rev Pbar sym + end": int(q[7] // max(nf, 1))})
