@@ -697,6 +697,20 @@ def main():
             extras["gensys"]["stage_ms"] = {k_: round(float(v_), 4) for k_, v_ in ms_g.items()}
         except Exception as exc:  # (never lose the line to a diagnostic)
             extras["gensys"]["stage_ms"] = {"error": repr(exc)}
+        # HBM bytes of one step of this leg from the committed counters of the same command (tools/refresh_profiles.sh)
+        try:
+            import glob as _glob
+            _f = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters_gensys_spectral_division.json")))
+            if _f and nloc == 4096:
+                with open(_f[-1]) as fh:
+                    _k = json.load(fh)["kernels"]
+                _per = {nm: v["hbm_bytes"] for nm, v in _k.items() if nm.startswith("dsge::") and v.get("dispatches", 0) > 1}
+                extras["gensys"]["hbm"] = {"measured_bytes_per_step": int(sum(_per.values())),
+                                           "largest": {nm: int(b_) for nm, b_ in sorted(_per.items(), key=lambda kv: -kv[1])[:4]},
+                                           "source": os.path.relpath(_f[-1], ROOT) + ": (2 x FETCH_SIZE + WRITE_SIZE) per launch of every "
+                                                     "kernel that runs once per step (committed counters, not collected in this run)"}
+        except Exception as exc:
+            extras["gensys"]["hbm"] = {"error": repr(exc)}
         # the ordered QZ for EVERY draw (dsge_options.gensys_doubling = 0): the reference's algorithm operation by operation
         extras["gensys_qz"], _call_q, lp_q, st_q, _ = gensys_leg({"gensys_doubling": 0})
         extras["gensys_qz"]["note"] = ("solver = gensys with dsge_options.gensys_doubling = 0: the ordered QZ of the pencil for every draw "
