@@ -222,3 +222,91 @@ def test_refinement_with_an_extended_residual_on_the_ill_conditioned_fixture():
     if np.finfo(np.longdouble).eps < 1e-18:  # (platforms whose longdouble is float64 have nothing to show here)
         assert np.abs(T_ext - Tx).max() <= 0.3 * e_ref
     assert np.abs(T_f64 - Tx).max() >= 0.3 * e_ref
+
+
+# ---- gensys by spectral division (round 5): the certificate's decision rule against the oracle's gensys -------------------------
+def _spectral_division_cases(seed, trials):
+    from tests.device_models.spectral_division_model import gensys_by_spectral_division
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(trials):
+        n = int(rng.integers(4, 30))
+        ns = int(rng.integers(1, max(2, n // 2)))
+        nl = int(rng.integers(1, max(2, n // 3)))
+        k = int(rng.integers(1, min(n, 5) + 1))
+        A, B, C, D, Tst = wl.sw_shaped_system(int(rng.integers(1 << 30)), n=n, n_state=ns, n_lead=nl, k=k)
+        kind = "regular"
+        u = rng.random()
+        M = B + C @ Tst
+        if u < 0.15:
+            A = A * rng.uniform(5, 40)
+            kind = "explosive"
+        elif u < 0.30:
+            G = np.linalg.solve(M, C)
+            G = G * (rng.uniform(1.05, 3.0) / np.max(np.abs(np.linalg.eigvals(G))))
+            C = M @ G
+            B = M - C @ Tst
+            kind = "indeterminate"
+        elif u < 0.45:
+            T2 = Tst.copy()
+            T2[:, :ns] *= (1.0 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-9, -3)) / np.max(np.abs(np.linalg.eigvals(T2[:ns, :ns])))
+            A = -M @ T2
+            B = M - C @ T2
+            kind = "near the unit circle"
+        elif u < 0.50:
+            C = C.copy()
+            C[:, n - 1] *= 1e-12
+            kind = "lead column below the tolerance"
+        T, cert = gensys_by_spectral_division(A, B, C, 1e-8)
+        T_ref, succ, eu = oracle.gensys_T_success(A, B, C, D, 1e-8)
+        out.append((kind, cert, bool(succ), [int(e) for e in eu], T, T_ref))
+    return out
+
+
+def test_spectral_division_certificate_never_contradicts_gensys():
+    """A certified draw is ALWAYS a draw on which the oracle's gensys says eu = [1, 1, 0], with the same T; the draws gensys
+    accepts but the certificate does not take (roots within 2e-4 of the unit circle, a lead column below the tolerance) are the
+    ones the device hands to the ordered QZ.  450 random systems, a third of them non-regular by construction."""
+    n_cert = n_succ = 0
+    kinds = {}
+    for seed in (11, 12, 13):
+        for kind, cert, succ, eu, T, T_ref in _spectral_division_cases(seed, 150):
+            kinds.setdefault(kind, [0, 0, 0])
+            kinds[kind][0] += 1
+            kinds[kind][1] += cert
+            kinds[kind][2] += succ
+            if cert:
+                assert succ and eu == [1, 1, 0], (kind, eu)
+                assert_allclose(T, T_ref, rtol=0, atol=1e-8 * max(1.0, np.abs(T_ref).max()))
+            n_cert += cert
+            n_succ += succ
+    # the certificate takes (nearly) every regular draw: that is what makes it the fast path
+    assert kinds["regular"][1] >= 0.97 * kinds["regular"][0], kinds
+    # (scaling A does not always destroy the stable solvent: a few "explosive" systems stay regular -- for gensys and for the
+    #  certificate alike, which the per-draw assertion above has checked)
+    assert kinds["indeterminate"][1] == 0 and kinds["indeterminate"][2] == 0, kinds
+    assert kinds["explosive"][1] <= kinds["explosive"][2] <= 0.2 * kinds["explosive"][0], kinds
+    assert n_cert <= n_succ
+
+
+def test_spectral_division_on_the_reference_failure_cases():
+    """tests/golden/failure_cases.npz (the reference's own solvability cases, incl. the indeterminate system on which its cycle
+    reduction CONVERGES): certified iff the reference's gensys returns eu = [1, 1, 0]."""
+    import os
+
+    from tests.device_models.spectral_division_model import certify_contraction, gensys_by_spectral_division
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "failure_cases.npz"))
+    for name in ("ok", "nonunique", "noexist", "coincident"):
+        A, B, C = g[f"{name}_A"], g[f"{name}_B"], g[f"{name}_C"]
+        T, cert = gensys_by_spectral_division(A, B, C, 1e-8)
+        eu = [int(e) for e in g[f"{name}_ref_gensys_eu"]]
+        assert cert == (eu[:2] == [1, 1]), (name, cert, eu)
+        if cert:
+            assert_allclose(T, g[f"{name}_ref_gensys_T"], atol=1e-9)
+    # the reach of the certificate: rho = 1 - 1e-3 is taken, rho = 1 - 1e-5 is not (2^-1/2^12 = 0.99983), rho > 1 never
+    assert certify_contraction(np.diag([0.999, 0.5])) and not certify_contraction(np.diag([1.0 - 1e-5, 0.5]))
+    assert not certify_contraction(np.diag([1.0 + 1e-9, 0.1])) and not certify_contraction(np.array([[np.nan]]))
+    J = np.array([[0.9, 50.0], [0.0, 0.9]])  # non-normal: the norms grow before they decay, the squares still get there
+    assert certify_contraction(J)
