@@ -376,6 +376,10 @@ int dsge_debug_kalman_steady_steps(int32_t* steady_at_device) {
   g_kalman_steady_at = steady_at_device;
   return DSGE_SUCCESS;
 }
+int dsge_debug_kalman_timeline(long long* timeline_device) {
+  g_kalman_timeline = timeline_device;
+  return DSGE_SUCCESS;
+}
 
 int dsge_device_count(void) {
   int count = 0;

@@ -202,6 +202,7 @@ extern long long* g_big_dbg;          // launch_big.hip: debug phase cycles of c
 extern long long* g_kalman_dbg;       // launch_kalman.hip: debug buffer for per-phase cycles of draw 0
 extern long long* g_gensys_win_dbg;   // launch_gensys.hip: debug phase stamps of the window kernels (device int64[32])
 extern float* g_gensys_stage_ms;      // launch_gensys.hip: debug, host float[8]: launch durations of the window path (dsge_debug_gensys_stage_ms)
+extern long long* g_kalman_timeline;  // debug: device int64 [batch][8] {start, end, HW_ID, steady step} per draw (kalman_nt_kernel)
 extern int32_t* g_kalman_steady_at;   // debug: device buffer [batch], first steady step per draw (-1 = never)
 
 // Kernel-variant switches.  They are PER CALL: the *_opt entry points carry a dsge_options, which an RAII guard installs

@@ -198,6 +198,12 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     // arrays -- then lives in scalar registers instead of being spilled around the time loop)
     const int draw = __builtin_amdgcn_readfirstlane(order ? order[bi] : bi);
     const int32_t st_in = __builtin_amdgcn_readfirstlane(status[draw]);
+    // debug (dsge_debug_kalman_timeline): the instance WITHOUT phase stamps gets a [batch][8] int64 record through `dbg` --
+    // {start, end (100 MHz wall clock), HW_ID, first steady step, start of the time loop, time of the first steady step} per draw
+    long long tl_start = 0;
+    if constexpr (!DBG) {
+      if (dbg) tl_start = (long long)wall_clock64();
+    }
     if (rerun_only) {
       if (st_in != DSGE_ST_INTERNAL_RERUN) continue;
     } else if (st_in != 0) {
@@ -413,6 +419,10 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     int n_ll_steps = 0, n_obs_entries = 0;  // steps with >= 1 observed entry, and their observed entries (FilterConv::ll_terms)
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tk_start = DBG ? clock64() : 0;
+    long long tl_loop = 0, tl_steady = 0;  // debug timeline: start of the time loop, first steady step
+    if constexpr (!DBG) {
+      if (dbg) tl_loop = (long long)wall_clock64();
+    }
     int steady_step = -1;
     bool handed_off = false;
     // y_t is fetched one step ahead by an UNCONDITIONAL, branch-free load (clamped indices; lanes with r8 >= p and the value
@@ -660,6 +670,9 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       }
       if (!steady) continue;
       // ==== steady-state steps: mean recursion only, while the missing-data mask stays the same (register-only) ====
+      if constexpr (!DBG) {
+        if (dbg && steady_step < 0) tl_steady = (long long)wall_clock64();
+      }
       if (steady_step < 0) steady_step = t + 1;
       if constexpr (TAIL) {
         // ---- hand-off: the covariance is frozen AND the missing-data mask no longer changes until the end of the sample
@@ -715,6 +728,13 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
           finv_row[q] = (lane < 8) ? fr[q] * inv_own : 0.0;  // lane r < 8 still holds row r of Finv (unscaled)
           kr_ss[q] = (lane < m) ? Ks[lane * PS + q] : 0.0;
         }
+        // (Round 5, measured and NOT used -- profiles/r5/steady_loop_ab.txt: (i) y_t staged through LDS in chunks of NP / 8 steps, so that
+        //  no step waits for the load of its successor's y -- the compiler copies the register loaded one step ahead into the
+        //  loop-carried one at the back edge behind an s_waitcnt vmcnt(0) --, and (ii) the two broadcasts of a step, v and a+, as
+        //  one ds_write + SK / 2 + 4 uniform ds_read_b128 instead of 2 (SK + 8) v_readlane_b32: 80 VALU instructions per step
+        //  instead of 156, and 0.549 us per steady step instead of 0.495 at two wavefronts per SIMD.  The step is a latency chain --
+        //  a_sel -> v -> K v -> T a+ --, not an issue-bound loop: the LDS round trips lengthen it by more than the fewer
+        //  instructions shorten it.)
         while (t + 1 < T_len) {
           const double yt_s = yt_next;
           const bool obs_s = (lane < p) && (yt_s == yt_s) && (yt_s != missing_fill);
@@ -773,6 +793,16 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       const double ll = -0.5 * (cv.ll_terms(n_ll_steps, n_obs_entries, p) * LN2PI + logdet + quad_total);
       logp_out[draw] = ll;
       if (steady_at) steady_at[draw] = steady_step;
+      if constexpr (!DBG) {
+        if (dbg) {
+          dbg[8 * (size_t)draw] = tl_start;
+          dbg[8 * (size_t)draw + 1] = (long long)wall_clock64();
+          dbg[8 * (size_t)draw + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
+          dbg[8 * (size_t)draw + 3] = steady_step;
+          dbg[8 * (size_t)draw + 4] = tl_loop;
+          dbg[8 * (size_t)draw + 5] = tl_steady;
+        }
+      }
       if (!((ll == ll) && (fabs(ll) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
     }
   }

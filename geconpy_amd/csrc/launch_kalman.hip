@@ -16,6 +16,7 @@ namespace dsge_host {
 
 long long* g_kalman_dbg = nullptr;  // debug: device buffer for per-phase cycles of draw 0
 int32_t* g_kalman_steady_at = nullptr;
+long long* g_kalman_timeline = nullptr;  // debug: device int64 [batch][8], see kalman_nt_kernel
                        // (experimental: measured SLOWER than the VALU register blocks)
 
 namespace {
@@ -278,7 +279,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, SKV, TAILV>), dim3(batch - head), dim3(64), lds_q,
                                      bulk_st, T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y,
                                      batch - head, m, p, T_len, s_cap, cv, missing_fill, opt().kalman_steady_tol, logp, status,
-                                     g_kalman_dbg, rerun, g_kalman_steady_at, order ? order + head : nullptr, fold ? Rsel : nullptr,
+                                     g_kalman_timeline, rerun, g_kalman_steady_at, order ? order + head : nullptr, fold ? Rsel : nullptr,
                                      qdiag, q_batched, k_shocks, colmask, TAILV ? tail_rec : nullptr, tail_flag, tail_from);
               }
               if (hs && TAILV && rc == DSGE_SUCCESS) rc = launch_tail(hs->s);  // the bulk's tails next to the head, not behind it

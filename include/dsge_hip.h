@@ -431,6 +431,10 @@ int dsge_bk_eigenvalues_batched_host(const double* A, const double* B, const dou
 /* Debug hook: device int32[batch] that later fast-path Kalman launches (and the second-order filter) fill with the first
  * time step that ran in steady-state mode (-1 = never); NULL stops recording. */
 int dsge_debug_kalman_steady_steps(int32_t* steady_at_device);
+/* Debug hook: timeline_device (device int64 [batch][8], or NULL to switch it off) receives {start, end -- ticks of the 100 MHz
+ * wall clock --, HW_REG_HW_ID, first steady step, start of the time loop, time of the first steady step, 0, 0} of every draw the fast selector filter kernel (kalman_nt_kernel) takes: the
+ * schedule of a launch (tools/kalman_timeline.py). */
+int dsge_debug_kalman_timeline(long long* timeline_device);
 
 /* Debug hook: enable != 0 makes the selector-path Kalman kernel record the shader cycles draw 0 spends
  * in each of its five per-step phases, [5] the cycles spent in steady-state steps, [6] their number and
