@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dsge_bk_eigenvalues_batched_host": [_dp, _dp, _dp, _i, _i, _f, _dp, _dp, _dp, _dp, _dp, _dp],
     "dsge_debug_cr_phases": [_i, _dp],
     "dsge_debug_kalman_steady_steps": [_dp],
+    "dsge_debug_kalman_timeline": [_dp],
     "dsge_debug_kalman_phases": [_i, _dp],
     "dsge_debug_big_phases": [_i, _dp],
     "dsge_debug_gensys_window_phases": [_i, _dp],

@@ -20,7 +20,6 @@ for _ in range(5):
     f()
 torch.cuda.synchronize()
 tl = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
-lib.dsge_debug_kalman_timeline.argtypes = [ctypes.c_void_p]
 _lib.check(lib.dsge_debug_kalman_timeline(tl.data_ptr()))
 f(); torch.cuda.synchronize()
 _lib.check(lib.dsge_debug_kalman_timeline(None))
