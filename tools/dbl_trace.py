@@ -1,3 +1,5 @@
+"""GPU box: a few evaluations with solver = gensys under each value of dsge_options.gensys_doubling, for rocprofv3 --kernel-trace
+(which launches run, and for how long: tools/trace_summary.py reads the trace)."""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")

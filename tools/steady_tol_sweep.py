@@ -1,3 +1,5 @@
+"""GPU box: the headline step under a range of dsge_options.kalman_steady_tol -- rate and the change of logp against the full
+recursion (kalman_steady_tol = 0)."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
