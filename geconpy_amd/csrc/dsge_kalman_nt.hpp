@@ -236,12 +236,25 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     const unsigned long long colmask = __ballot(is_state);
     unsigned long long obsmask = 0ull, used = 0ull;
     bool ok = true;
-    for (int o = 0; o < p; ++o) {
-      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
-      const unsigned long long b = __ballot(zl != 0.0);
-      if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
-      used |= b;
-      obsmask |= b;
+    // (the p <= 8 rows of Z are requested together -- clamped, unconditional loads -- and kept for the second pass below: a
+    //  load per trip, each behind its own ballot, was p round trips to L2 twice over: tools/kalman_timeline.py, prologue)
+    double zrow[8];
+    {
+      const int zl_lane = lane < m_full ? lane : m_full - 1;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) zrow[o] = Zg[(size_t)(o < p ? o : (p > 0 ? p - 1 : 0)) * m_full + zl_lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) zrow[o] = (lane < m_full && o < p) ? zrow[o] : 0.0;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      if (o < p) {
+        const unsigned long long b = __ballot(zrow[o] != 0.0);
+        if (__popcll(b) != 1 || ((used & b) != 0ull)) ok = false;
+        used |= b;
+        obsmask |= b;
+      }
     }
     const unsigned long long extra = obsmask & ~colmask;  // observed non-states
     const int s = __popcll(colmask);
@@ -256,11 +269,11 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
         my_pos = s + __popcll(extra & below);
       if (my_pos >= 0 && my_pos < NP) perm[my_pos] = lane;
     }
-    for (int o = 0; o < p; ++o) {
-      const double zl = (lane < m_full) ? Zg[(size_t)o * m_full + lane] : 0.0;
-      if (zl != 0.0) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      if (o < p && zrow[o] != 0.0) {
         zpos[o] = (my_pos >= 0 && my_pos < NP) ? my_pos : 0;
-        zv[o] = zl;
+        zv[o] = zrow[o];
       }
     }
     if (!ok) {

@@ -149,7 +149,8 @@ def test_big_gensys_by_spectral_division_vs_oracle(n):
     G = np.linalg.solve(M, C[6])
     C[6] = M @ (G * (1.5 / np.max(np.abs(np.linalg.eigvals(G)))))
     B[6] = M - C[6] @ b["T_star"][6]
-    out = batched.gensys_batched(A, B, C, D, tol=1e-8)
+    SD = {"gensys_doubling": 1}  # (the library's default; explicit, so that the test means the same under DSGE_GENSYS_DOUBLING=0)
+    out = batched.gensys_batched(A, B, C, D, tol=1e-8, options=SD)
     for i in range(nb):
         T_ref, succ, eu = oracle.gensys_T_success(A[i], B[i], C[i], D[i], 1e-8)
         assert bool(out["success"][i]) == bool(succ), (i, eu, out["eu"][i], out["status"][i])
@@ -166,7 +167,7 @@ def test_big_gensys_by_spectral_division_vs_oracle(n):
     om = wl.sw_shaped_observation_model(n=n, p=7, T_len=30, **sh)
     q = b["sigma"] ** 2
     f = batched.solve_kalman_logp_batched(A, B, C, D, q, om["Z"], om["y"], Hdiag=om["Hdiag"], tol=1e-8, solver="gensys",
-                                          q_mode="diag_batched")
+                                          q_mode="diag_batched", options=SD)
     assert np.array_equal(f["status"] == 0, out["success"]) and np.all(f["logp"][[3, 6]] == -np.inf)
     for i in (0, 1, 5, 9):
         ref = oracle.solve_kalman_logp(A[i], B[i], C[i], D[i], np.diag(q[i]), om["Z"], om["y"], H=np.diag(om["Hdiag"]), solver="gensys")

@@ -32,7 +32,7 @@ python3 tools/pmc_collect.py "$OUT/pmc_so" -- --workload sw_second_order --no-ex
 rm -rf "$OUT/pmc_default" "$OUT/pmc_gensys" "$OUT/pmc_gensys_sd" "$OUT/pmc_so"
 # the roofline blocks quote flops / traffic from the counters committed under profiles/: take the lines after they are refreshed
 mkdir -p profiles/r5
-cp "$OUT/pmc_counters_sw_second_order.json" "$OUT/pmc_counters.json" "$OUT/pmc_counters_gensys.json" profiles/r5/ 2>/dev/null
+cp "$OUT/pmc_counters_sw_second_order.json" "$OUT/pmc_counters.json" "$OUT/pmc_counters_gensys.json" "$OUT/pmc_counters_gensys_spectral_division.json" profiles/r5/ 2>/dev/null
 python3 bench.py --workload sw_second_order > "$OUT/bench_sw_second_order.json" 2> "$OUT/bench_sw_second_order.err"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
