@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from geconpy_amd import _lib, workloads as wl
 from geconpy_amd.engine import LogpEngine
+if os.environ.get("DSGE_TEST_LIB"):  # (A/B of a differently built library)
+    _lib.LIB_PATH = os.path.abspath(os.environ["DSGE_TEST_LIB"])
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 b = wl.sw_shaped_batch(min(nb, 64)); om = wl.sw_shaped_observation_model(); rep = (nb + 63) // 64
 eng = LogpEngine(0); lib = _lib.load()
