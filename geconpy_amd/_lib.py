@@ -179,7 +179,8 @@ class Options(C.Structure):
         ("jitter_F", C.c_double),
         ("jitter_P", C.c_double),
         ("gensys_doubling", C.c_int32),
-        ("reserved_", C.c_int32 * 3),
+        ("kalman_grad_split", C.c_int32),
+        ("reserved_", C.c_int32 * 2),
     ]
 
 

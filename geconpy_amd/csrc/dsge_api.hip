@@ -149,6 +149,7 @@ struct OptionsGuard {
     local.gensys_direct_blocks = o->gensys_direct_blocks;
     local.kalman_head_draws = o->kalman_head_draws;
     local.gensys_doubling = o->gensys_doubling;
+    local.kalman_grad_split = o->kalman_grad_split;
     local.ll_constant = o->ll_constant;
     local.mask_d = o->mask_d;
     local.joseph = o->joseph;
@@ -168,6 +169,7 @@ int check_options(const dsge_options* o) {
   if (o->pipeline_chunks < 0 || o->pipeline_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline_chunks must be in 0..64");
   if (o->gensys_split < 0 || o->gensys_split > 2) return fail(DSGE_ERR_INVALID, "gensys_split must be 0, 1 or 2");
   if (o->gensys_doubling < 0 || o->gensys_doubling > 2) return fail(DSGE_ERR_INVALID, "gensys_doubling must be 0, 1 or 2");
+  if (o->kalman_grad_split < 0 || o->kalman_grad_split > 1) return fail(DSGE_ERR_INVALID, "kalman_grad_split must be 0 or 1");
   if (o->n_static_hint < -1 || o->n_static_hint > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "n_static_hint out of range");
   if (o->ll_constant < DSGE_LL_CONST_P || o->ll_constant > DSGE_LL_CONST_ONE)
     return fail(DSGE_ERR_INVALID, "ll_constant must be DSGE_LL_CONST_P, _OBSERVED or _ONE");
@@ -2227,6 +2229,7 @@ int dsge_options_init(dsge_options* o) {
   o->gensys_direct_blocks = d.gensys_direct_blocks;
   o->kalman_head_draws = d.kalman_head_draws;
   o->gensys_doubling = d.gensys_doubling;
+  o->kalman_grad_split = d.kalman_grad_split;
   o->ll_constant = d.ll_constant;
   o->mask_d = d.mask_d;
   o->joseph = d.joseph;

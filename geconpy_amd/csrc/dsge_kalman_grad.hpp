@@ -33,6 +33,7 @@
 #pragma once
 #include "dsge_device.hpp"
 #include "dsge_kalman2.hpp"
+#include "dsge_kalman_rec.hpp"
 
 #include "../../include/dsge_hip.h"
 
@@ -85,20 +86,25 @@ __device__ __forceinline__ void kg_mm(double* dst, const double* A, const double
 
 __device__ __forceinline__ double yt_or_zero(double yt) { return (yt == yt) ? yt : 0.0; }
 
-template <int BS>
+// SPLIT = true (round 5): the reverse sweep ALONE -- the forward sweep ran as kalman_nt_kernel<BS, .., REC = true>
+// (dsge_kalman_nt.hpp: the logp kernel's full step at two wavefronts per SIMD instead of this kernel's at one), which wrote the
+// records (dsge_kalman_rec.hpp), logp and the status words.  rerun_only (SPLIT = false): only the draws that launch flagged
+// DSGE_ST_INTERNAL_RERUN (it could not take them) are processed, from scratch.
+template <int BS, bool SPLIT = false>
 __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ Z, int z_batched,
     const double* __restrict__ dvec, int d_batched, const double* __restrict__ Hdiag, int h_batched,
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill,
     double steady_tol, double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
-    double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order) {
+    double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order, int rerun_only) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
   // doubles stored per time step: for a FULL step the results of its covariance update -- P+ (NP x NP), K (NP x 8), F^-1,
   // F (8 x 8 each) -- so that the reverse sweep loads them instead of repeating the update; for every step a_t and the
   // index of the step whose covariance it shares.  The initial covariance P_0 sits behind the last step.
-  constexpr size_t OFF_K = (size_t)NP * NP, OFF_FI = OFF_K + (size_t)NP * 8, OFF_F = OFF_FI + 64, OFF_A = OFF_F + 64,
-                   OFF_SRC = OFF_A + NP, OFF_PREV = OFF_SRC + 1, STEP = OFF_PREV + 1;  // OFF_PREV: source of the PREVIOUS segment
+  using RC = KgRec<BS>;  // (dsge_kalman_rec.hpp: shared with the forward sweep of kalman_nt_kernel<.., REC>)
+  constexpr size_t OFF_K = RC::OFF_K, OFF_FI = RC::OFF_FI, OFF_F = RC::OFF_F, OFF_A = RC::OFF_A, OFF_SRC = RC::OFF_SRC,
+                   OFF_PREV = RC::OFF_PREV, STEP = RC::STEP;  // OFF_PREV: source of the PREVIOUS segment
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;              // transition, states-first ordering (columns >= s are zero)
   double* Ps = Tc + NP * LDM;     // predicted covariance of the current step
@@ -148,6 +154,12 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const size_t off = (size_t)draw * m_full * m_full;
     double* Tbo = Tbar_out + off;
     double* Gbo = Gbar_out + off;
+    if (rerun_only) {  // (wave-uniform)
+      if (status[draw] != DSGE_ST_INTERNAL_RERUN) continue;
+      wave_sync();
+      if (lane == 0) status[draw] = 0;
+      wave_sync();
+    }
     for (int idx = lane; idx < m_full * m_full; idx += 64) {
       Tbo[idx] = 0.0;
       Gbo[idx] = 0.0;
@@ -228,6 +240,21 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       Gs[i * LDM + j] = RQR[off + g];
     }
     wave_sync();
+    // per-draw record: T_len step records + P_0 (NP x NP) behind them -- kalman_grad_store_doubles_per_draw() on the host.
+    // (Round 1 strode by T_len * STEP only: the P_0 of draw d sat on the step-0 record of draw d + 1, a cross-workgroup
+    // race that made the cotangent of T non-repeatable for batches of ~100 draws and more.)
+    double* st = store + (size_t)draw * ((size_t)T_len * STEP + (size_t)NP * NP);
+    const int lane_kernel = lane;
+    // mask of step t -> ww; returns the ballot
+    // (y_t, and in the reverse sweep a_t and the source index, are fetched ONE STEP AHEAD: a steady step is a few hundred
+    // cycles of arithmetic, a dependent global load is a few thousand)
+    auto load_mask = [&](double yt) -> unsigned long long {
+      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
+      const unsigned long long omask = __ballot(obs);
+      if (lane < 8) ww[lane] = (lane < p && obs) ? 1.0 : 0.0;
+      return omask;
+    };
+    if constexpr (!SPLIT) {
     // ---- P0 = dlyap(Tu, G) by doubling: P <- P + A P A', A <- A A  (A in X1) ---------------------
     for (int idx = lane; idx < NP * LDM; idx += 64) {
       Ps[idx] = Gs[idx];
@@ -284,10 +311,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     }
     wave_sync();
 
-    // per-draw record: T_len step records + P_0 (NP x NP) behind them -- kalman_grad_store_doubles_per_draw() on the host.
-    // (Round 1 strode by T_len * STEP only: the P_0 of draw d sat on the step-0 record of draw d + 1, a cross-workgroup
-    // race that made the cotangent of T non-repeatable for batches of ~100 draws and more.)
-    double* st = store + (size_t)draw * ((size_t)T_len * STEP + (size_t)NP * NP);
     // ---- the measurement update, split in its data-independent and data-dependent halves --------------
     // update_cov: from Ps and the mask weights ww -> Mp, Fs, Fi, Kp, X1 = P+; returns ln det F.
     auto update_cov = [&](double* rec) -> double {
@@ -376,15 +399,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       wave_sync();
       return log(det_m) + (double)det_e * 0.6931471805599453;
     };
-    // mask of step t -> ww; returns the ballot
-    // (y_t, and in the reverse sweep a_t and the source index, are fetched ONE STEP AHEAD: a steady step is a few hundred
-    // cycles of arithmetic, a dependent global load is a few thousand)
-    auto load_mask = [&](double yt) -> unsigned long long {
-      const bool obs = (lane < p) && (yt == yt) && (yt != missing_fill);
-      const unsigned long long omask = __ballot(obs);
-      if (lane < 8) ww[lane] = (lane < p && obs) ? 1.0 : 0.0;
-      return omask;
-    };
     // update_mean: from av, y_t, ww, Kp, Fi -> vv, fiv, ap; returns v' F^-1 v.  (Fences on entry and exit.)
     auto update_mean = [&](double yt) -> double {
       wave_sync();
@@ -422,7 +436,6 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     int seg_src = -1;
     double seg_logdet = 0.0;
     double yt_next = (lane < p && T_len > 0) ? y[lane] : 0.0;
-    const int lane_kernel = lane;
     for (int t = 0; t < T_len; ++t) {
       // (lane index re-derived from an opaque copy per step: the addresses computed from it are recomputed, not hoisted in front of
       //  the time loop and kept -- or spilled -- across it; see kalman_nt_kernel / crc_iterate)
@@ -580,6 +593,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       logp_out[draw] = logp;
       if (!((logp == logp) && (fabs(logp) < 1.797e308))) status[draw] |= DSGE_ST_FILTER_NONFINITE;
     }
+    }  // (!SPLIT: the forward sweep)
 
     // ---- reverse sweep ------------------------------------------------------------------------------
     wave_sync();

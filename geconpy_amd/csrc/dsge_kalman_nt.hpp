@@ -22,6 +22,7 @@
 // build of the 32-wide tile.
 #pragma once
 #include "dsge_kalman2.hpp"
+#include "dsge_kalman_rec.hpp"
 
 namespace dsge {
 
@@ -141,7 +142,9 @@ __device__ __forceinline__ void mm_nt(double (&acc)[BS][BS], const double* A, co
 // DBG = true: the instance tools/kalman_phases.py launches (phase stamps of draw 0 in `dbg`); the product instance carries
 // neither the stamps nor their registers.
 // TAIL = true: the instance that hands the steady, constant-mask tail of the sample to kalman_tail_kernel (dsge_options.kalman_block)
-template <int BS, bool DBG = false, int SK = 8 * BS, bool TAIL = false>
+// REC = true (round 5): the forward sweep of the gradient -- every step also writes its record (dsge_kalman_rec.hpp) for the reverse
+// sweep of kalman_grad_kernel<BS, true>; the filter itself is the same code.
+template <int BS, bool DBG = false, int SK = 8 * BS, bool TAIL = false, bool REC = false>
 // (two wavefronts per SIMD up to the 24-wide tile, and on the 32-wide one for its 20-column instance -- 20 KB of LDS, eight draws
 //  per CU; with the 256-register cap it spills 332 bytes per lane, and is still faster: observe_jumps 1.96 -> 2.04 M evals/s.  The
 //  generic 32-wide instance (28 KB of LDS) measured SLOWER with the cap: 1.92 against 1.77 ms per 4096 draws at 25 states.)
@@ -153,7 +156,9 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only, int32_t* __restrict__ steady_at,
     const int32_t* __restrict__ order, const double* __restrict__ Rsel, const double* __restrict__ qdiag, int q_batched,
     int k_shocks, const unsigned long long* __restrict__ colmask_in, double* __restrict__ tail_rec = nullptr,
-    int32_t* __restrict__ tail_flag = nullptr, const int32_t* __restrict__ tail_from = nullptr) {
+    int32_t* __restrict__ tail_flag = nullptr, const int32_t* __restrict__ tail_from = nullptr,
+    double* __restrict__ rec_store = nullptr) {
+  using RC = KgRec<BS>;
   using SM = KntSmem<BS, SK>;
   constexpr int NP = SM::NP, LDK = SM::LDK, PS = SM::PS;
   constexpr bool NARROW = SK < NP;  // rows of Tc / W' / Pc shorter than the tile: stores beyond column SK - 1 are skipped
@@ -438,6 +443,15 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
     }
     int steady_step = -1;
     bool handed_off = false;
+    double* const rec_d = REC ? rec_store + (size_t)draw * RC::per_draw(T_len) : nullptr;  // this draw's record
+    int seg_src = -1;                                                                       // source step of the running segment
+    if constexpr (REC) {  // P_0 (register blocks -> row-major NP x NP behind the last step)
+      double* p0s = rec_d + (size_t)T_len * RC::STEP;
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) p0s[(lr * BS + i) * NP + lc * BS + j] = Pb[i][j];
+    }
     // y_t is fetched one step ahead by an UNCONDITIONAL, branch-free load (clamped indices; lanes with r8 >= p and the value
     // past the last step are never used -- every use is guarded by `obs`): under a condition the compiler sank the load to
     // the top of the step that needs it and waited for it there (s_waitcnt vmcnt(0) right behind the load, every step)
@@ -451,6 +465,15 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       const bool obs = (r8 < p) && (yt == yt) && (yt != missing_fill);
       const unsigned long long omask = __ballot(obs) & 0xffull;
       const int n_obs = __popcll(omask);
+      double* const sg = REC ? rec_d + (size_t)t * RC::STEP : nullptr;  // the record of this (full) step
+      if constexpr (REC) {
+        if (lane < NP) sg[RC::OFF_A + lane] = av[lane];
+        if (lane == 0) {
+          sg[RC::OFF_SRC] = (double)t;
+          sg[RC::OFF_PREV] = (double)seg_src;
+        }
+        seg_src = t;
+      }
       double2 fr2[4], pz2[BS][4];
       double pzo[BS], avi[BS];
 #pragma unroll
@@ -494,6 +517,12 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
         const double f = (c_r * tq) * wq;
         fr[q] = (q == r8) ? f + dg : f;
       }
+      if constexpr (REC) {
+        if (lane < 8) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sg[RC::OFF_F + lane * 8 + q] = fr[q];
+        }
+      }
       // ---- (c) Finv by Gauss-Jordan, one row per lane (SPD: no pivoting); the pivot row arrives through SGPRs.  The
       //      rows are left unscaled during the elimination (row j keeps its pivot: one fma per entry and lane, no
       //      per-entry select); Finv[r][:] = inv_own * fr[:] afterwards -------------------------------------------------
@@ -516,6 +545,12 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
           int e;
           step_mant *= frexp(rowj[j], &e);
           step_exp += e;
+        }
+      }
+      if constexpr (REC) {
+        if (lane < 8) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sg[RC::OFF_FI + lane * 8 + q] = fr[q] * inv_own;
         }
       }
       {
@@ -568,6 +603,9 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
         if (r8 == 0) af[i] = avi[ps] + part;
       }
       wave_sync();  // #2
+      if constexpr (REC) {
+        for (int idx = lane; idx < NP * 8; idx += 64) sg[RC::OFF_K + idx] = Ks[(idx >> 3) * PS + (idx & 7)];
+      }
       if constexpr (DBG) {
         const long long tk1 = clock64();
         ph[1] += tk1 - tk0;
@@ -603,6 +641,12 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       }
 #pragma unroll
       for (int i = 0; i < BS; ++i) Pb[i][i] += jit_d[i];
+      if constexpr (REC) {  // P+ straight from the register blocks, lane-major (BS^2 coalesced stores)
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+          for (int j = 0; j < BS; ++j) sg[(size_t)(i * BS + j) * 64 + lane] = Pb[i][j];
+      }
       if (steady_tol > 0.0) {
         double dmax = 0.0;
         if (in_state_block) {
@@ -754,6 +798,11 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
           if (__ballot(obs_s) != omask) break;
           ++t;
           yt_next = y[(size_t)((t + 1 < T_len) ? t + 1 : t) * p + r8c];
+          if constexpr (REC) {
+            double* sgs = rec_d + (size_t)t * RC::STEP;
+            if (lane < NP) sgs[RC::OFF_A + lane] = av_reg;
+            if (lane == 0) sgs[RC::OFF_SRC] = (double)seg_src;
+          }
           const double av_sel = __shfl(av_reg, v_zpos, 64);
           double v_s = 0.0;
           if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (((obs_s || !cv.mask_d) ? v_dd : 0.0) + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));

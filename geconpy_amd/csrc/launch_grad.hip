@@ -1,6 +1,7 @@
 // Launchers of the gradient kernels: Kalman reverse sweep and the reverse of the state-space assembly.
 #include "dsge_host.hpp"
 #include "dsge_kalman_grad.hpp"
+#include "dsge_kalman_nt.hpp"
 
 namespace dsge_host {
 
@@ -25,16 +26,43 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
     HIP_TRY(hipGetLastError());
     order = order_buf;
   }
+  const dsge::FilterConv cv = filter_conv(jitter);
+  const double stol = opt().kalman_steady_tol;
   DISPATCH_BS(bs, 8, {
     const size_t lds = dsge::KgSmem<BS>::bytes;
     if (lds > LDS_LIMIT) return fail(DSGE_ERR_INVALID, "gradient kernel: model too large for the 160 KB LDS");
-    rc = set_lds(dsge::kalman_grad_kernel<BS>, lds);
-    if (rc == DSGE_SUCCESS) {
-      hipLaunchKernelGGL(dsge::kalman_grad_kernel<BS>, dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
-                         Hdiag, h_batched, y, batch, m, p, T_len, filter_conv(jitter), missing_fill, opt().kalman_steady_tol, store, logp, status, Tbar,
-                         Gbar,
-                         dbar, hbar, g_kalman_dbg, order);
-      HIP_TRY(hipGetLastError());
+    // Round 5 (dsge_options.kalman_grad_split): the forward sweep is the logp kernel with record output (two wavefronts per SIMD on
+    // the tiles of up to 24 variables, its NT products, its row-per-lane update), the reverse sweep a kernel of its own; what the
+    // forward kernel cannot take (it flags DSGE_ST_INTERNAL_RERUN) goes through the one-kernel path afterwards, in the same call.
+    // Not under the phase-stamp hook (tools/grad_phases.py reads the one-kernel path's stamps).
+    const size_t lds_f = dsge::KntSmem<BS, 8 * BS>::bytes(8 * BS);
+    const bool split = opt().kalman_grad_split != 0 && !g_kalman_dbg && p <= 8 && lds_f <= LDS_LIMIT;
+    if (split) {
+      rc = set_lds(dsge::kalman_nt_kernel<BS, false, 8 * BS, false, true>, lds_f);
+      if (rc == DSGE_SUCCESS) rc = set_lds(dsge::kalman_grad_kernel<BS, true>, lds);
+      if (rc == DSGE_SUCCESS) rc = set_lds(dsge::kalman_grad_kernel<BS, false>, lds);
+      if (rc == DSGE_SUCCESS) {
+        hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, 8 * BS, false, true>), dim3(batch), dim3(64), lds_f, st, T, RQR,
+                           (const double*)nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, 8 * BS, cv,
+                           missing_fill, stol, logp, status, (long long*)nullptr, 0, (int32_t*)nullptr, order,
+                           (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr,
+                           (double*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, store);
+        hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
+                           Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar, dbar,
+                           hbar, (long long*)nullptr, order, 0);
+        hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d,
+                           d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar,
+                           dbar, hbar, (long long*)nullptr, (const int32_t*)nullptr, 1);
+        HIP_TRY(hipGetLastError());
+      }
+    } else {
+      rc = set_lds(dsge::kalman_grad_kernel<BS, false>, lds);
+      if (rc == DSGE_SUCCESS) {
+        hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
+                           Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar, dbar,
+                           hbar, g_kalman_dbg, order, 0);
+        HIP_TRY(hipGetLastError());
+      }
     }
   });
   return rc;

@@ -220,7 +220,11 @@ typedef struct dsge_options {
                                  well-conditioned draws, cond(B + C T) eps in general).  0: the ordered QZ of the pencil for every
                                  draw (the reference's algorithm, gEconpy/solvers/gensys.py:190-395, operation by operation).
                                  2: as 1 with the single-launch QZ kernel as the fall-back (debug) */
-  int32_t reserved_[3];
+  int32_t kalman_grad_split;  /* 1 (default): the logp + gradient entry points run the FORWARD filter sweep as the logp kernel itself
+                                 (kalman_nt_kernel with record output: two wavefronts per SIMD) and the reverse sweep as a kernel of
+                                 its own; draws the forward kernel cannot take fall back to the one-kernel path in the same call.
+                                 0: forward and reverse sweep in one kernel (rounds 1-4).  Same recursion, same records. */
+  int32_t reserved_[2];
 } dsge_options;
 /* fills *opt with the compiled-in defaults */
 int dsge_options_init(dsge_options* opt);
