@@ -508,3 +508,52 @@ def test_gradient_with_a_dense_design_matrix(batched_z):
     assert np.abs(den["logp"] - sel["logp"]).max() <= 1e-10 * np.abs(sel["logp"]).max()
     for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
         assert np.abs(den[key] - sel[key]).max() <= 1e-8 * np.abs(sel[key]).max(), key
+
+
+def test_gradient_split_sweeps_match_the_one_kernel_path():
+    """dsge_options.kalman_grad_split (round 5, default 1): the forward sweep runs as the logp kernel with record output
+    (kalman_nt_kernel<.., REC>), the reverse sweep as a kernel of its own.  Same recursion and the same records as the one-kernel path
+    (kalman_grad_split = 0): logp to rounding, every cotangent to 1e-10 of its scale in the median and 1e-7 at worst -- on 768 distinct SW-shaped draws (the nearly
+    singular draw 752 among them) with complete data, with scattered missing entries (the mask changes: several steady segments)
+    and with kalman_steady_tol = 0, and on RBC-sized systems (the 16-wide tile)."""
+    rng = np.random.default_rng(8)
+    om = wl.sw_shaped_observation_model()
+    b = wl.sw_shaped_batch(768)
+    q = b["sigma"] ** 2
+    y_miss = om["y"].copy()
+    y_miss[rng.random(y_miss.shape) < 0.03] = np.nan
+    y_miss[120] = np.nan
+    d = rng.normal(0, 0.01, 7)
+    cases = [("complete", om["y"], {}), ("missing", y_miss, {}), ("full recursion", om["y"][:60], {"kalman_steady_tol": 0.0})]
+    for name, y, extra in cases:
+        kw = dict(d=d, Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
+        one = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, options=dict(extra, kalman_grad_split=0), **kw)
+        two = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, options=dict(extra, kalman_grad_split=1), **kw)
+        assert np.array_equal(one["status"], two["status"]) and not one["status"].any(), name
+        assert_allclose(two["logp"], one["logp"], rtol=1e-12, err_msg=name)
+        for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
+            scale = np.abs(one[key]).reshape(len(q), -1).max(axis=1)
+            err = np.abs(two[key] - one[key]).reshape(len(q), -1).max(axis=1)
+            rel = err / np.maximum(scale, 1e-300)
+            # (the two forward sweeps sum in different orders: 1e-13 on the filter's cotangents, which the policy adjoints of an
+            #  ill-conditioned draw amplify -- 1e-8 on A_bar of draw 752, cond(B + C T) = 3e8; the typical draw sits at 1e-11)
+            assert rel.max() <= 1e-7 and np.median(rel) <= 1e-10, (name, key, float(rel.max()), int(rel.argmax()), float(np.median(rel)))
+    sysm = [wl.sw_shaped_system(9000 + i, n=12, n_state=5, n_lead=4, k=3) for i in range(64)]
+    A, B, C, D = (np.stack([s_[j] for s_ in sysm]) for j in range(4))
+    Z = np.zeros((2, 12))
+    Z[0, 1] = 1.0
+    Z[1, 7] = 1.0  # a state and a jump variable
+    y = rng.standard_normal((80, 2)) * 0.05
+    qs = np.full((64, 3), 0.01)
+    kw = dict(Hdiag=np.full(2, 1e-4), tol=1e-10, max_iter=500)
+    # (kalman_steady_tol = 0: the two forward sweeps test for the steady state on different quantities -- P+ against P -- and may
+    #  switch a step apart, which on data the model did not generate moves logp by 1e-10)
+    one = batched.solve_kalman_logp_grad_batched(A, B, C, D, qs, Z, y, options={"kalman_grad_split": 0, "kalman_steady_tol": 0.0}, **kw)
+    two = batched.solve_kalman_logp_grad_batched(A, B, C, D, qs, Z, y, options={"kalman_grad_split": 1, "kalman_steady_tol": 0.0}, **kw)
+    assert np.array_equal(one["status"], two["status"])
+    ok = one["status"] == 0
+    assert ok.sum() >= 48
+    assert_allclose(two["logp"][ok], one["logp"][ok], rtol=1e-12)
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "h_bar"):
+        scale = np.abs(one[key][ok]).max()
+        assert_allclose(two[key][ok], one[key][ok], atol=1e-9 * scale, rtol=1e-8, err_msg=key)
