@@ -86,6 +86,9 @@ __device__ __forceinline__ void kg_mm(double* dst, const double* A, const double
 
 __device__ __forceinline__ double yt_or_zero(double yt) { return (yt == yt) ? yt : 0.0; }
 
+// (Measured, round 5: capping the SPLIT instance at 256 registers for a second wavefront per SIMD -- it holds 308 -- spills 52
+// dwords into the mean-side loop: the reverse launch 3.0 -> 4.5 ms at unchanged residency; LDS, 36.6 KB, would have to shrink
+// below 27 KB as well before a second wavefront fits.)
 // SPLIT = true (round 5): the reverse sweep ALONE -- the forward sweep ran as kalman_nt_kernel<BS, .., REC = true>
 // (dsge_kalman_nt.hpp: the logp kernel's full step at two wavefronts per SIMD instead of this kernel's at one), which wrote the
 // records (dsge_kalman_rec.hpp), logp and the status words.  rerun_only (SPLIT = false): only the draws that launch flagged

@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from geconpy_amd import workloads as wl
 from geconpy_amd.engine import LogpEngine
+if os.environ.get("DSGE_TEST_LIB"):  # (A/B of a differently built library)
+    from geconpy_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ["DSGE_TEST_LIB"])
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 SOLVER = sys.argv[2] if len(sys.argv) > 2 else "cycle_reduction"  # or "gensys", the reference's default estimation solver
 nd = min(nb, 4096)  # distinct draws (a tiled small set clusters the draws that take second passes)
