@@ -8,10 +8,14 @@ namespace dsge_host {
 // tile of the reduced filter: from the hint (states + observed variables) when given, else the model size
 static int grad_tile(int u_hint, int m) { return tile_bs((u_hint > 0 && u_hint < m) ? u_hint : m); }
 
+// the per-draw record of the forward sweep (dsge_kalman_rec.hpp: KgRec<BS>::per_draw) for the tile the launch will use
 size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len) {
   const size_t np = 8 * (size_t)grad_tile(u_hint, m);
   return (size_t)T_len * (np * np + np * 8 + 128 + np + 2) + np * np;  // per step: P+, K, F^-1, F, a_t, source index, previous source; + P_0
 }
+static_assert(dsge::KgRec<3>::per_draw(200) == (size_t)200 * (24 * 24 + 24 * 8 + 128 + 24 + 2) + 24 * 24 &&
+                  dsge::KgRec<7>::per_draw(5) == (size_t)5 * (56 * 56 + 56 * 8 + 128 + 56 + 2) + 56 * 56,
+              "kalman_grad_store_doubles_per_draw and KgRec describe the same record");
 
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
                        const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
