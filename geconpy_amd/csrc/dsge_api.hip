@@ -169,7 +169,7 @@ int check_options(const dsge_options* o) {
   if (o->pipeline_chunks < 0 || o->pipeline_chunks > 64) return fail(DSGE_ERR_INVALID, "pipeline_chunks must be in 0..64");
   if (o->gensys_split < 0 || o->gensys_split > 2) return fail(DSGE_ERR_INVALID, "gensys_split must be 0, 1 or 2");
   if (o->gensys_doubling < 0 || o->gensys_doubling > 2) return fail(DSGE_ERR_INVALID, "gensys_doubling must be 0, 1 or 2");
-  if (o->kalman_grad_split < 0 || o->kalman_grad_split > 1) return fail(DSGE_ERR_INVALID, "kalman_grad_split must be 0 or 1");
+  if (o->kalman_grad_split < 0 || o->kalman_grad_split > 2) return fail(DSGE_ERR_INVALID, "kalman_grad_split must be 0, 1 or 2");
   if (o->n_static_hint < -1 || o->n_static_hint > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "n_static_hint out of range");
   if (o->ll_constant < DSGE_LL_CONST_P || o->ll_constant > DSGE_LL_CONST_ONE)
     return fail(DSGE_ERR_INVALID, "ll_constant must be DSGE_LL_CONST_P, _OBSERVED or _ONE");

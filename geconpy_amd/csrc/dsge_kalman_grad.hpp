@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill,
     double steady_tol, double* __restrict__ store, double* __restrict__ logp_out, int32_t* __restrict__ status,
     double* __restrict__ Tbar_out, double* __restrict__ Gbar_out, double* __restrict__ dbar_out,
-    double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order, int rerun_only) {
+    double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order, int rerun_only,
+    int tail_valid) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
   // doubles stored per time step: for a FULL step the results of its covariance update -- P+ (NP x NP), K (NP x 8), F^-1,
   // F (8 x 8 each) -- so that the reverse sweep loads them instead of repeating the update; for every step a_t and the
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     // per-draw record: T_len step records + P_0 (NP x NP) behind them -- kalman_grad_store_doubles_per_draw() on the host.
     // (Round 1 strode by T_len * STEP only: the P_0 of draw d sat on the step-0 record of draw d + 1, a cross-workgroup
     // race that made the cotangent of T non-repeatable for batches of ~100 draws and more.)
-    double* st = store + (size_t)draw * ((size_t)T_len * STEP + (size_t)NP * NP);
+    double* st = store + (size_t)draw * RC::per_draw(T_len);
     const int lane_kernel = lane;
     // mask of step t -> ww; returns the ballot
     // (y_t, and in the reverse sweep a_t and the source index, are fetched ONE STEP AHEAD: a steady step is a few hundred
@@ -631,13 +632,36 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
 #pragma unroll
     for (int k2 = 0; k2 < NKF; ++k2) pf_k[k2] = 0.0;
     double src_next = 0.0, av_next = 0.0, yr_next = 0.0;
+    int t_first = T_len - 1;
+    bool resumed = false;  // the steady tail's mean side came from kalman_grad_tail_kernel: this sweep starts AT its source step
+    if constexpr (SPLIT) {
+      if (tail_valid) {
+        const double* ts = st + RC::tail_state_off(T_len);
+        const int n_done = (int)ts[0];
+        if (n_done > 0) {  // (wave-uniform)
+          resumed = true;
+          t_first = T_len - 1 - n_done;
+          nlam = ts[1];
+          if (lane < NP) ab[lane] = ts[RC::TS_AB + lane];
+          if (lane < 8) db[lane] = ts[RC::TS_DB + lane];
+#pragma unroll
+          for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) TbR[i][j] = ts[RC::TS_TB + (size_t)(i * BS + j) * 64 + lane];
+#pragma unroll
+          for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = ts[RC::TS_KA + (size_t)k2 * 64 + lane];
+          Qacc = ts[RC::TS_QA + lane];
+          wave_sync();
+        }
+      }
+    }
     if (T_len > 0) {
-      const double* sg0 = st + (size_t)(T_len - 1) * STEP;
+      const double* sg0 = st + (size_t)t_first * STEP;
       src_next = sg0[OFF_SRC];
       if (lane < NP) av_next = sg0[OFF_A + lane];
-      if (lane < p) yr_next = y[(size_t)(T_len - 1) * p + lane];
+      if (lane < p) yr_next = y[(size_t)t_first * p + lane];
     }
-    for (int t = T_len - 1; t >= 0; --t) {
+    for (int t = t_first; t >= 0; --t) {
       int lane = lane_kernel;
       asm volatile("" : "+v"(lane));
       const int lr = lane >> 3, lc = lane & 7, fo = lane >> 3, fq = lane & 7;
@@ -697,10 +721,13 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         wave_sync();
         if (tm) qh[3] += clock64() - tk0;
         cur_src = src_t;
+        if (!resumed) {  // (a resumed segment arrives with the sums of its steady steps)
 #pragma unroll
-        for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
-        Qacc = 0.0;
-        nlam = 0.0;
+          for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
+          Qacc = 0.0;
+          nlam = 0.0;
+        }
+        resumed = false;
       }
       {
         // ==== the mean side of every step of the segment (its source step included) in registers: column `lane` of Tc (a+bar = T' abar), row `lane` of K (a+), rows of
@@ -860,6 +887,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       if (t == src_t) {
         // ---- covariance side, once per segment: Pb is the cotangent of the predicted covariance P_{src+1}, which the
         // steady steps after src never touched; X1 = P+ of the source step.
+        // (round 5, measured: the three products with four k-steps per stage and two stages in flight -- 8 (BS + BS) operand
+        //  registers, free at one wavefront per SIMD -- make the launch SLOWER, 2.62 -> 2.75 ms: not used)
         kg_mm<BS, false>(X2, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
         wave_sync();
         {
@@ -1025,6 +1054,236 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           dbg[8 + k2] = qh[k2];
         }
     }
+  }
+}
+
+
+// ---- the reverse MEAN side of the last steady segment, as a lean kernel of its own (round 5) ---------------------------------------
+// In the reverse sweep of kalman_grad_kernel<BS, true> half of a typical draw's time is the mean side of its steady tail -- 167 of
+// 200 steps on the SW-shaped workload, two matrix-vector products and three outer-product accumulations each -- at ONE wavefront per
+// SIMD (the kernel holds 308 registers and 36 KB of LDS for the covariance side).  That part needs none of the matrices: column
+// `lane` of T, row / column `lane` of K, rows of F^-1 in registers, a_t and y_t staged through 2.5 KB of LDS.  At the END of the
+// sample the cotangent of the state is zero, so the last segment's steady steps depend on nothing the covariance side computes:
+// this kernel runs them (t = T_len - 1 down to src + 1, src = the segment's source step) at two wavefronts per SIMD and hands
+// abar, dbar and the accumulators (Tbar, Kacc, Qacc, nlam) to the reverse sweep, which resumes AT the source step.
+// Same arithmetic as the steady_step of the reverse sweep, operation by operation.
+template <int BS>
+__global__ __launch_bounds__(64, 2) void kalman_grad_tail_kernel(
+    const double* __restrict__ T, const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
+    const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill,
+    double* __restrict__ store, const int32_t* __restrict__ status, const int32_t* __restrict__ order) {
+  using RC = KgRec<BS>;
+  constexpr int NP = 8 * BS;
+  constexpr int CH = (BS == 1) ? 4 : 8, NCA = (CH * NP + 63) / 64;
+  __shared__ double SA[CH * NP], SY[CH * 8], zv[8], dd[8];
+  __shared__ int perm[NP], zpos[8];
+  const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7, fo = lane >> 3, fq = lane & 7;
+  for (int bi = blockIdx.x; bi < batch; bi = batch) {
+    const int draw = order ? order[bi] : bi;
+    double* st = store + (size_t)draw * RC::per_draw(T_len);
+    double* ts = st + RC::tail_state_off(T_len);
+    if (lane == 0) ts[0] = 0.0;  // "nothing processed" unless the loop below runs
+    if (status[draw] != 0 || T_len < 2) continue;
+    const int src = (int)st[(size_t)(T_len - 1) * RC::STEP + RC::OFF_SRC];
+    if (src >= T_len - 1 || src < 0) continue;  // the sample ends with a full step: no steady tail
+    const size_t off = (size_t)draw * m_full * m_full;
+    // ---- reduction to U = S u O, states first (as kalman_grad_kernel) ---------------------------------------------------------
+    const double* Zg = Z + (z_batched ? (size_t)draw * p * m_full : 0);
+    bool is_state = false;
+    {
+      const double* tcol_g = T + off + (lane < m_full ? lane : 0);
+      for (int r0 = 0; r0 < m_full; r0 += 8) {
+        double tv[8];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) tv[u8] = tcol_g[(size_t)(r0 + u8 < m_full ? r0 + u8 : m_full - 1) * m_full];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) is_state |= (tv[u8] != 0.0);
+      }
+      is_state = is_state && (lane < m_full);
+    }
+    const unsigned long long colmask = __ballot(is_state);
+    unsigned long long obsmask = 0ull;
+    double zrow[8];
+    {
+      const int zl_lane = lane < m_full ? lane : m_full - 1;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) zrow[o] = Zg[(size_t)(o < p ? o : (p > 0 ? p - 1 : 0)) * m_full + zl_lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) zrow[o] = (lane < m_full && o < p) ? zrow[o] : 0.0;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < p) obsmask |= __ballot(zrow[o] != 0.0);
+    const unsigned long long extra = obsmask & ~colmask;
+    const int s = __popcll(colmask);
+    const int u = s + __popcll(extra);
+    int my_pos = -1;
+    wave_sync();
+    if (lane < m_full) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if ((colmask >> lane) & 1ull)
+        my_pos = __popcll(colmask & below);
+      else if ((extra >> lane) & 1ull)
+        my_pos = s + __popcll(extra & below);
+      if (my_pos >= 0 && my_pos < NP) perm[my_pos] = lane;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < p && zrow[o] != 0.0) {
+        zpos[o] = (my_pos >= 0 && my_pos < NP) ? my_pos : 0;
+        zv[o] = zrow[o];
+      }
+    if (lane < 8) dd[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
+    wave_sync();
+    // ---- the segment's constants in registers: column `lane` of T[U,U], row / column `lane` of K, rows of F^-1 ------------------
+    const double* rs = st + (size_t)src * RC::STEP;  // the source step's record
+    double tcol[NP], krow[8], firow[8], kcol[NP];
+    const int pl = (lane < u) ? perm[lane] : 0;
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+      const int pk = (kk < u) ? perm[kk < NP ? kk : 0] : 0;
+      tcol[kk] = T[off + (size_t)pk * m_full + pl];
+      kcol[kk] = rs[RC::OFF_K + (size_t)kk * 8 + (lane & 7)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+      tcol[kk] = (lane < u && kk < u) ? tcol[kk] : 0.0;
+      kcol[kk] = (lane < 8 && kk < u) ? kcol[kk] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      krow[q] = rs[RC::OFF_K + (size_t)(lane < NP ? lane : 0) * 8 + q];
+      firow[q] = rs[RC::OFF_FI + (size_t)(lane & 7) * 8 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      krow[q] = (lane < u) ? krow[q] : 0.0;
+      firow[q] = (lane < 8) ? firow[q] : 0.0;
+    }
+    // the mask of the segment (constant over it: the forward sweep ends a segment where the mask changes)
+    const double y_last = (lane < p) ? y[(size_t)(T_len - 1) * p + lane] : 0.0;
+    const unsigned long long omask = __ballot((lane < p) && (y_last == y_last) && (y_last != missing_fill));
+    const double lam = (omask != 0ull) ? 1.0 : 0.0;
+    const double w_l = (lane < p && ((omask >> lane) & 1ull)) ? 1.0 : 0.0;
+    const bool d_live = (w_l != 0.0 || !cv.mask_d);
+    const double v_dd = (lane < p && d_live) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
+    const int v_zpos = (lane < p) ? zpos[lane] : 0;
+    int my_o = -1;
+    for (int o = 0; o < p; ++o)
+      if (zpos[o] == lane) my_o = o;
+    const double my_wz = (my_o >= 0) ? (((omask >> my_o) & 1ull) ? 1.0 : 0.0) * zv[my_o] : 0.0;
+    const int my_os = (my_o >= 0) ? my_o : 0;
+    double ab_reg = 0.0, db_reg = 0.0, TbR[BS][BS], Kacc[BS], Qacc = 0.0, nlam = 0.0;
+    blk_zero<BS>(TbR);
+#pragma unroll
+    for (int k2 = 0; k2 < BS; ++k2) Kacc[k2] = 0.0;
+    auto steady_step = [&](const double a_in, const double y_in) __attribute__((always_inline)) {
+      const double a_sel = __shfl(a_in, v_zpos, 64);
+      const double v_s = (lane < p) ? w_l * yt_or_zero(y_in) - (v_dd + w_l * v_zv * a_sel) : 0.0;
+      double vsc[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) vsc[o] = readlane_f64(v_s, o);
+      double w0 = 0.0, w1 = 0.0, a0 = (lane < u) ? a_in : 0.0, a1 = 0.0;
+#pragma unroll
+      for (int o = 0; o < 8; o += 2) {
+        w0 = fma(firow[o], vsc[o], w0);
+        w1 = fma(firow[o + 1], vsc[o + 1], w1);
+        a0 = fma(krow[o], vsc[o], a0);
+        a1 = fma(krow[o + 1], vsc[o + 1], a1);
+      }
+      const double fiv_l = (lane < p) ? w0 + w1 : 0.0;
+      const double ap_l = a0 + a1;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < NP; kk += 2) {
+        s0 = fma(tcol[kk], readlane_f64(ab_reg, kk), s0);
+        s1 = fma(tcol[kk + 1], readlane_f64(ab_reg, kk + 1), s1);
+      }
+      const double apb_l = (lane < u) ? s0 + s1 : 0.0;
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
+        const double abi = __shfl(ab_reg, lr * BS + i, 64);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) TbR[i][j] = fma(abi, __shfl(ap_l, lc * BS + j, 64), TbR[i][j]);
+      }
+      double q0 = -lam * fiv_l, q1 = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < NP; kk += 2) {
+        q0 = fma(kcol[kk], readlane_f64(apb_l, kk), q0);
+        q1 = fma(kcol[kk + 1], readlane_f64(apb_l, kk + 1), q1);
+      }
+      const double vb_l = (lane < p) ? q0 + q1 : 0.0;
+      const double v_mine = __shfl(v_s, lane & 7, 64);
+#pragma unroll
+      for (int k2 = 0; k2 < BS; ++k2) {
+        const int i = (lane + 64 * k2) >> 3;
+        const double api = __shfl(apb_l, i & 63, 64);
+        if (i < u) Kacc[k2] = fma(api, v_mine, Kacc[k2]);
+      }
+      Qacc = fma(lam * __shfl(fiv_l, fo, 64), __shfl(fiv_l, fq, 64), Qacc);
+      nlam += lam;
+      ab_reg = apb_l - my_wz * __shfl(vb_l, my_os, 64);
+      db_reg -= d_live ? vb_l : 0.0;
+    };
+    // ---- the steps t = T_len - 1 .. src + 1, a chunk of CH of them staged through LDS at a time (see the reverse sweep) ---------
+    const int lane_a = (lane < NP) ? lane : NP - 1;
+    int t = T_len - 1;
+    double ra[NCA], ry;
+    auto chunk_load = [&](int t_hi) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k2 = 0; k2 < NCA; ++k2) {
+        const int idx = (lane + 64 * k2 < CH * NP) ? lane + 64 * k2 : CH * NP - 1;
+        const int jj = idx / NP, el = idx - jj * NP;
+        const int tt = (t_hi - jj > 0) ? t_hi - jj : 0;
+        ra[k2] = st[(size_t)tt * RC::STEP + RC::OFF_A + el];
+      }
+      const int jy = ((lane >> 3) < CH) ? (lane >> 3) : CH - 1, oy = ((lane & 7) < p) ? (lane & 7) : (p > 0 ? p - 1 : 0);
+      const int ty = (t_hi - jy > 0) ? t_hi - jy : 0;
+      ry = y[(size_t)ty * p + oy];
+    };
+    auto chunk_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k2 = 0; k2 < NCA; ++k2)
+        if (lane + 64 * k2 < CH * NP) SA[lane + 64 * k2] = ra[k2];
+      if (lane < CH * 8) SY[lane] = ry;
+    };
+    chunk_load(t);
+    chunk_store();
+    wave_sync();
+    for (;;) {
+      chunk_load(t - CH);
+      bool done = false;
+#pragma unroll 1
+      for (int j = 0; j < CH; ++j) {
+        steady_step(SA[j * NP + lane_a], SY[j * 8 + (lane & 7)]);
+        --t;
+        if (t == src) {
+          done = true;
+          break;
+        }
+      }
+      if (done) break;
+      wave_sync();
+      chunk_store();
+      wave_sync();
+    }
+    // ---- the state for the reverse sweep, which resumes at t = src -----------------------------------------------------------------
+    if (lane == 0) {
+      ts[0] = (double)(T_len - 1 - src);
+      ts[1] = nlam;
+    }
+    if (lane < NP) ts[RC::TS_AB + lane] = ab_reg;
+    if (lane < 8) ts[RC::TS_DB + lane] = db_reg;
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) ts[RC::TS_TB + (size_t)(i * BS + j) * 64 + lane] = TbR[i][j];
+#pragma unroll
+    for (int k2 = 0; k2 < BS; ++k2) ts[RC::TS_KA + (size_t)k2 * 64 + lane] = Kacc[k2];
+    ts[RC::TS_QA + lane] = Qacc;
   }
 }
 

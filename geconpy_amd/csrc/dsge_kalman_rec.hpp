@@ -14,7 +14,13 @@ struct KgRec {
   static constexpr int NP = 8 * BS;
   static constexpr size_t OFF_K = (size_t)NP * NP, OFF_FI = OFF_K + (size_t)NP * 8, OFF_F = OFF_FI + 64, OFF_A = OFF_F + 64,
                           OFF_SRC = OFF_A + NP, OFF_PREV = OFF_SRC + 1, STEP = OFF_PREV + 1;
-  __host__ __device__ static constexpr size_t per_draw(int T_len) { return (size_t)T_len * STEP + (size_t)NP * NP; }
+  // Behind P_0: the state the tail kernel (kalman_grad_tail_kernel: the reverse mean side of the LAST steady segment, run at two
+  // wavefronts per SIMD) hands to the reverse sweep -- [0] number of steps it processed (0: none), [1] nlam; abar (NP), dbar (8),
+  // then lane-major register images: Tbar (BS^2 x 64), Kacc (BS x 64), Qacc (64)
+  static constexpr size_t TS_AB = 16, TS_DB = TS_AB + NP, TS_TB = TS_DB + 8, TS_KA = TS_TB + (size_t)BS * BS * 64,
+                          TS_QA = TS_KA + (size_t)BS * 64, TAIL_STATE = TS_QA + 64;
+  __host__ __device__ static constexpr size_t tail_state_off(int T_len) { return (size_t)T_len * STEP + (size_t)NP * NP; }
+  __host__ __device__ static constexpr size_t per_draw(int T_len) { return tail_state_off(T_len) + TAIL_STATE; }
 };
 
 }  // namespace dsge

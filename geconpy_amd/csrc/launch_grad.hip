@@ -11,10 +11,12 @@ static int grad_tile(int u_hint, int m) { return tile_bs((u_hint > 0 && u_hint <
 // the per-draw record of the forward sweep (dsge_kalman_rec.hpp: KgRec<BS>::per_draw) for the tile the launch will use
 size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len) {
   const size_t np = 8 * (size_t)grad_tile(u_hint, m);
-  return (size_t)T_len * (np * np + np * 8 + 128 + np + 2) + np * np;  // per step: P+, K, F^-1, F, a_t, source index, previous source; + P_0
+  const size_t bs = np / 8;
+  // per step: P+, K, F^-1, F, a_t, source index, previous source; + P_0; + the tail kernel's state
+  return (size_t)T_len * (np * np + np * 8 + 128 + np + 2) + np * np + (16 + np + 8 + 64 * (bs * bs + bs + 1));
 }
-static_assert(dsge::KgRec<3>::per_draw(200) == (size_t)200 * (24 * 24 + 24 * 8 + 128 + 24 + 2) + 24 * 24 &&
-                  dsge::KgRec<7>::per_draw(5) == (size_t)5 * (56 * 56 + 56 * 8 + 128 + 56 + 2) + 56 * 56,
+static_assert(dsge::KgRec<3>::per_draw(200) == (size_t)200 * (24 * 24 + 24 * 8 + 128 + 24 + 2) + 24 * 24 + (16 + 24 + 8 + 64 * 13) &&
+                  dsge::KgRec<7>::per_draw(5) == (size_t)5 * (56 * 56 + 56 * 8 + 128 + 56 + 2) + 56 * 56 + (16 + 56 + 8 + 64 * 57),
               "kalman_grad_store_doubles_per_draw and KgRec describe the same record");
 
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
@@ -51,12 +53,18 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
                            missing_fill, stol, logp, status, (long long*)nullptr, 0, (int32_t*)nullptr, order,
                            (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr,
                            (double*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, store);
+        // the reverse mean side of every draw's LAST steady segment at two wavefronts per SIMD (kalman_grad_tail_kernel); the
+        // reverse sweep then starts at that segment's source step (kalman_grad_split = 2, the default; 1: without it)
+        const int with_tail = opt().kalman_grad_split >= 2;
+        if (with_tail)
+          hipLaunchKernelGGL((dsge::kalman_grad_tail_kernel<BS>), dim3(batch), dim3(64), 0, st, T, Z, z_batched, d, d_batched, y,
+                             batch, m, p, T_len, cv, missing_fill, store, (const int32_t*)status, order);
         hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
                            Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar, dbar,
-                           hbar, (long long*)nullptr, order, 0);
+                           hbar, (long long*)nullptr, order, 0, with_tail);
         hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d,
                            d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar,
-                           dbar, hbar, (long long*)nullptr, (const int32_t*)nullptr, 1);
+                           dbar, hbar, (long long*)nullptr, (const int32_t*)nullptr, 1, 0);
         HIP_TRY(hipGetLastError());
       }
     } else {
@@ -64,7 +72,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
       if (rc == DSGE_SUCCESS) {
         hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
                            Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar, dbar,
-                           hbar, g_kalman_dbg, order, 0);
+                           hbar, g_kalman_dbg, order, 0, 0);
         HIP_TRY(hipGetLastError());
       }
     }

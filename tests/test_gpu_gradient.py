@@ -528,8 +528,16 @@ def test_gradient_split_sweeps_match_the_one_kernel_path():
     for name, y, extra in cases:
         kw = dict(d=d, Hdiag=om["Hdiag"], tol=1e-8, max_iter=1000)
         one = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, options=dict(extra, kalman_grad_split=0), **kw)
-        two = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, options=dict(extra, kalman_grad_split=1), **kw)
+        two = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, options=dict(extra, kalman_grad_split=2), **kw)
+        mid = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, options=dict(extra, kalman_grad_split=1), **kw)
         assert np.array_equal(one["status"], two["status"]) and not one["status"].any(), name
+        # the tail kernel (2) runs the steps of the reverse sweep (1) it replaces operation by operation: only the ORDER in which the
+        # segment's sums meet the earlier ones differs
+        for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
+            sc = np.abs(mid[key]).reshape(len(q), -1).max(axis=1)
+            er = np.abs(two[key] - mid[key]).reshape(len(q), -1).max(axis=1) / np.maximum(sc, 1e-300)
+            assert er.max() <= 1e-7 and np.median(er) <= 1e-11, (name, key, float(er.max()), int(er.argmax()))
+        assert np.array_equal(two["logp"], mid["logp"])
         assert_allclose(two["logp"], one["logp"], rtol=1e-12, err_msg=name)
         for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar", "d_bar", "h_bar"):
             scale = np.abs(one[key]).reshape(len(q), -1).max(axis=1)
@@ -549,7 +557,7 @@ def test_gradient_split_sweeps_match_the_one_kernel_path():
     # (kalman_steady_tol = 0: the two forward sweeps test for the steady state on different quantities -- P+ against P -- and may
     #  switch a step apart, which on data the model did not generate moves logp by 1e-10)
     one = batched.solve_kalman_logp_grad_batched(A, B, C, D, qs, Z, y, options={"kalman_grad_split": 0, "kalman_steady_tol": 0.0}, **kw)
-    two = batched.solve_kalman_logp_grad_batched(A, B, C, D, qs, Z, y, options={"kalman_grad_split": 1, "kalman_steady_tol": 0.0}, **kw)
+    two = batched.solve_kalman_logp_grad_batched(A, B, C, D, qs, Z, y, options={"kalman_grad_split": 2, "kalman_steady_tol": 0.0}, **kw)
     assert np.array_equal(one["status"], two["status"])
     ok = one["status"] == 0
     assert ok.sum() >= 48
