@@ -612,6 +612,25 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     }
     wave_sync();
     int cur_src = -1;  // step whose covariance-side quantities (Mp, Fs, Fi, Kp, X1 = P+) are in LDS
+    // which observation selects this lane's variable: p dependent LDS reads -- once per draw, not once per segment (a never-steady
+    // draw has 200 segments of one step)
+    int my_o_draw = -1;
+    double my_zv_draw = 0.0;
+    for (int o = 0; o < p; ++o)
+      if (zpos[o] == lane_kernel) {
+        my_o_draw = o;
+        my_zv_draw = zv[o];
+      }
+    // likewise the draw's constants of the mean side: d, z and the selected position of observation `lane`, and column `lane` of Tc
+    // (48 registers across the whole sweep: the kernel runs one wavefront per SIMD, they are free)
+    const double dd_draw = (lane_kernel < p) ? dd[lane_kernel] : 0.0, zv_draw = (lane_kernel < p) ? zv[lane_kernel] : 0.0;
+    const int zpos_draw = (lane_kernel < p) ? zpos[lane_kernel] : 0;
+    double tcol[NP];
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) tcol[kk] = (lane_kernel < u && kk < u) ? Tc[kk * LDM + lane_kernel] : 0.0;
+    // selector entries of the observations this lane meets in the panel algebra of the covariance side: row lane >> 3, column lane & 7
+    const int zpos_f = zpos[lane_kernel >> 3], zpos_q = zpos[lane_kernel & 7];
+    const double zv_f = zv[lane_kernel >> 3], zv_q = zv[lane_kernel & 7];
     // Cotangents that the steps of one steady segment send to the quantities they SHARE (the forward sweep freezes K, F^-1
     // and ln det F of the segment's source step, so this is the exact reverse of what was executed): they are collected in
     // registers and pulled back through the covariance update once, at the source step.  A steady step therefore costs two
@@ -732,12 +751,9 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
       {
         // ==== the mean side of every step of the segment (its source step included) in registers: column `lane` of Tc (a+bar = T' abar), row `lane` of K (a+), rows of
         // F^-1 and columns of K in lanes 0..7 (F^-1 v, K' a+bar); vectors are exchanged by v_readlane / ds_bpermute, no fence.
-        double tcol[NP], krow[8], firow[8], kcol[NP];
+        double krow[8], firow[8], kcol[NP];  // (tcol: column `lane` of Tc, loaded once per draw in front of the sweep)
 #pragma unroll
-        for (int kk = 0; kk < NP; ++kk) {
-          tcol[kk] = (lane < u && kk < u) ? Tc[kk * LDM + lane] : 0.0;
-          kcol[kk] = (lane < 8 && kk < u) ? Kp[kk * PS + lane] : 0.0;
-        }
+        for (int kk = 0; kk < NP; ++kk) kcol[kk] = (lane < 8 && kk < u) ? Kp[kk * PS + lane] : 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           krow[q] = (lane < u) ? Kp[lane * PS + q] : 0.0;
@@ -745,12 +761,10 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         }
         const double w_l = (lane < p && ((omask >> lane) & 1ull)) ? 1.0 : 0.0;
         const bool d_live = (w_l != 0.0 || !cv.mask_d);  // d enters v on this entry (the mask is constant over the segment)
-        const double v_dd = (lane < p && d_live) ? dd[lane] : 0.0, v_zv = (lane < p) ? zv[lane] : 0.0;
-        const int v_zpos = (lane < p) ? zpos[lane] : 0;
-        int my_o = -1;  // the observation (if any) that selects this lane's variable
-        for (int o = 0; o < p; ++o)
-          if (zpos[o] == lane) my_o = o;
-        const double my_wz = (my_o >= 0) ? (((omask >> my_o) & 1ull) ? 1.0 : 0.0) * zv[my_o] : 0.0;
+        const double v_dd = d_live ? dd_draw : 0.0, v_zv = zv_draw;
+        const int v_zpos = zpos_draw;
+        const int my_o = my_o_draw;  // the observation (if any) that selects this lane's variable (a constant of the draw)
+        const double my_wz = (my_o >= 0) ? (((omask >> my_o) & 1ull) ? 1.0 : 0.0) * my_zv_draw : 0.0;
         const int my_os = (my_o >= 0) ? my_o : 0;
         double ab_reg = (lane < NP) ? ab[lane] : 0.0, db_reg = 0.0;
         // one steady step of the reverse sweep from the stored a_t (a_in) and y_t (y_in)
@@ -954,15 +968,17 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           Fb[lane] = sf;
         }
         wave_sync();
-        if (lane < 8 && lane < p) hb[lane] = fma(ww[lane], Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)
+        // (mask weights from the ballot, selector entries from the draw's registers: no dependent LDS reads of the 8-vectors)
+        const double w_f = ((omask >> fo) & 1ull) ? 1.0 : 0.0, w_q = ((omask >> fq) & 1ull) ? 1.0 : 0.0;
+        if (lane < 8 && lane < p) hb[lane] = fma(w_q, Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)   (lane < 8: fq = lane)
         if (fo < p && fq < p) {  // Mbar += Zm' Fbar: row zpos[fo] (distinct per fo) gets w zv Fbar[fo,:]
-          Mb[zpos[fo] * PS + fq] = fma(ww[fo] * zv[fo], Fb[lane], Mb[zpos[fo] * PS + fq]);
+          Mb[zpos_f * PS + fq] = fma(w_f * zv_f, Fb[lane], Mb[zpos_f * PS + fq]);
         }
         wave_sync();
-        // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]
+        // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]   (idx = lane + 64 k: o = idx & 7 = fq in every trip)
         for (int idx = lane; idx < u * 8; idx += 64) {
-          const int i = idx >> 3, o = idx & 7;
-          if (o < p) Ps[i * LDM + zpos[o]] = fma(ww[o] * zv[o], Mb[i * PS + o], Ps[i * LDM + zpos[o]]);
+          const int i = idx >> 3;
+          if (fq < p) Ps[i * LDM + zpos_q] = fma(w_q * zv_q, Mb[i * PS + fq], Ps[i * LDM + zpos_q]);
         }
         wave_sync();
         if (tm) {
