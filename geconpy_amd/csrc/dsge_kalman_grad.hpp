@@ -932,21 +932,31 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           Yp[i * PS + o] = kg_dot4(Ps + i * LDM, 1, Kp + o, PS, u);
         }
         wave_sync();
+        // (idx = lane + 64 k: the column o = idx & 7 = fq is the same in every trip -- column fq of F + jit I and of F^-1 are read
+        //  once, with compile-time loop bounds)
+        double fcol[8], ficol[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          fcol[q] = -2.0 * (Fs[q * 8 + fq] + ((q == fq) ? cv.jit_V : 0.0));
+          ficol[q] = Fi[q * 8 + fq];
+        }
 #pragma unroll
         for (int k2 = 0; k2 < BS; ++k2) {  // Kbar = sum_t a+bar_t v_t' - 2 Y (F + jit I)
-          const int idx = lane + 64 * k2, i = idx >> 3, o = idx & 7;
+          const int idx = lane + 64 * k2, i = idx >> 3;
           if (i < u) {
             double sk = Kacc[k2];
-            for (int q = 0; q < 8; ++q) sk = fma(-2.0 * Yp[i * PS + q], Fs[q * 8 + o] + ((q == o) ? cv.jit_V : 0.0), sk);
-            Kb[i * PS + o] = (o < p) ? sk : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sk = fma(Yp[i * PS + q], fcol[q], sk);
+            Kb[i * PS + fq] = (fq < p) ? sk : 0.0;
           }
         }
         wave_sync();
         for (int idx = lane; idx < u * 8; idx += 64) {  // Mbar = Kbar F^-1
-          const int i = idx >> 3, o = idx & 7;
+          const int i = idx >> 3;
           double sm = 0.0;
-          for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], Fi[q * 8 + o], sm);
-          Mb[i * PS + o] = (o < p) ? sm : 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], ficol[q], sm);
+          Mb[i * PS + fq] = (fq < p) ? sm : 0.0;
         }
         wave_sync();
         {  // Fbar = -1/2 (nlam F^-1 - sum_t lam_t fiv_t fiv_t') - K' Y - K' Mbar      (lane = fo*8 + fq)
