@@ -853,16 +853,17 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
         }
       });
       __syncthreads();
-      // [M | D | C] -> [. | M^-1 D | M^-1 C]
+      // [M | D | I] -> [. | M^-1 D | M^-1]   (round 6: the identity in the third operand slot -- the scale guards need the inverse;
+      //  G[L,L] = N_L C[:,L] is a small product afterwards)
       double t1[TR][TC], t0[TR][TC], t2[TR][TC];
       big_tile_load<Cfg>(t1, Mg, r0, c0);
-      big_tile_load<Cfg>(t2, Cg, r0, c0);
 #pragma unroll
       for (int i = 0; i < TR; ++i)
 #pragma unroll
         for (int jc = 0; jc < TC; ++jc) {
           const int r = r0 + i, c = c0 + jc;
           t0[i][jc] = (D && r < n && c < k) ? D[offk + (size_t)r * k + c] : 0.0;
+          t2[i][jc] = (r == c && r < n) ? 1.0 : 0.0;
         }
       big_eliminate<Cfg>(t1, t0, t2, n, lds, r0, c0, tid);
       const int* pivcol = reinterpret_cast<const int*>(lds + Cfg::E_PIV);
@@ -872,21 +873,96 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
         int q = (r0 + i < n) ? pivcol[r0 + i] : 0;
         qrow[i] = q < 0 ? 0 : (q >= n ? n - 1 : q);
       }
+      // M^-1 in natural row order over the (dead) M buffer of the workspace; the guards and G[L,L] read it from there (L2).
+      // R = -M^-1 D is written now (and zeroed below for a draw that ends without the certificate), so that no register tile
+      // lives across the guards
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+        if (r0 + i < n) {
+#pragma unroll
+          for (int jc = 0; jc < TC; ++jc) {
+            if (c0 + jc < n) Mg[qrow[i] * LD + c0 + jc] = t2[i][jc];
+            if (R_out && c0 + jc < k) R_out[offk + (size_t)qrow[i] * k + c0 + jc] = ok ? -t0[i][jc] : 0.0;
+          }
+        }
       // G[L,L] and T[S,S] into the (now free) panels
       for (int idx = tid; idx < 2 * BIG_GD_LCAP * LDG + 2 * BIG_GD_SCAP * LDS_; idx += NT) lds[idx] = 0.0;
       __syncthreads();
-      if (ok) {
-#pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          if (r0 + i < n) {
-            const int pr = posL[qrow[i]];
-#pragma unroll
-            for (int jc = 0; jc < TC; ++jc) {
-              const int pc = (c0 + jc < n) ? posL[c0 + jc] : -1;
-              if (pr >= 0 && pc >= 0) Gm[pr * LDG + pc] = t2[i][jc];
+      if (ok) {  // (uniform)
+        int gt = threadIdx.x;  // (opaque copy: nothing derived from it is hoisted across the elimination, see BIG_COORDS)
+        asm volatile("" : "+v"(gt));
+        // ---- the scale guards of dsge_gensys_doubling.hpp (derivation there): (E) existence = sigma_max(N_L) against 1 / tol, exactly
+        // the singular values of Q2 Pi; (Z) no coincident-zero pair in the stable block: ||M^-1 (I + N_L'N_L)^-1/2||_F^2 <=
+        // ||M^-1||_F^2 - |M^-1 w|^2 / (tau + |w|^2) for w = N_L'N_L v, tau = |N_L v|^2, v from the power iteration
+        double* vb = Gm + BIG_GD_LCAP * LDG;  // 128 doubles of the certificate's second buffer (unused until the squarings)
+        double* tb = vb + 128;                // 32
+        double mi2 = 0.0, nl2 = 0.0, tl2 = 0.0;
+        for (int idx = gt; idx < n * n; idx += NT) {
+          const int r = idx / n, c = idx - r * n;
+          const double v = Mg[r * LD + c];
+          mi2 = fma(v, v, mi2);
+          const int pa = posL[r], pb = posL[c];
+          if (pa >= 0) {
+            nl2 = fma(v, v, nl2);
+            const double tv = Tg[r * LD + c];
+            tl2 = fma(tv, tv, tl2);
+          }
+          if (pa >= 0 && pb >= 0) {  // G[L,L] = N_L C[:,L]
+            double g0 = 0.0, g1 = 0.0;
+            int i = 0;
+            for (; i + 1 < n; i += 2) {
+              g0 = fma(Mg[r * LD + i], Cg[i * LD + c], g0);
+              g1 = fma(Mg[r * LD + i + 1], Cg[(i + 1) * LD + c], g1);
             }
+            if (i < n) g0 = fma(Mg[r * LD + i], Cg[i * LD + c], g0);
+            Gm[pa * LDG + pb] = g0 + g1;
           }
         }
+        mi2 = big_block_sum<Cfg>(mi2, red, gt);
+        nl2 = big_block_sum<Cfg>(nl2, red, gt);
+        tl2 = big_block_sum<Cfg>(tl2, red, gt);
+        // start vector: the sum of the rows of N_L scaled by their own first... simply the row sums of N_L' N_L applied to ones:
+        // v0 = N_L' (N_L 1) (one step of the iteration from the vector of ones; three more follow)
+        double tau = 0.0, w2 = 0.0;
+        for (int it = 0; it < 4; ++it) {
+          double vj = 0.0;
+          if (it == 0) vj = (gt < n) ? 1.0 : 0.0;
+          else if (gt < n) vj = vb[gt];
+          const double nv = big_block_sum<Cfg>(vj * vj, red, gt);
+          vj = nv > 0.0 ? vj * (1.0 / sqrt(nv)) : 0.0;
+          __syncthreads();
+          if (gt < n) vb[gt] = vj;
+          __syncthreads();
+          double ta = 0.0;
+          if (gt < n && posL[gt] >= 0) {
+            for (int i = 0; i < n; ++i) ta = fma(Mg[gt * LD + i], vb[i], ta);
+            tb[posL[gt]] = ta;
+          }
+          tau = big_block_sum<Cfg>(ta * ta, red, gt);
+          __syncthreads();
+          double wj = 0.0;
+          if (gt < n)
+            for (int r = 0; r < n; ++r) {
+              const int pa = posL[r];
+              if (pa >= 0) wj = fma(Mg[r * LD + gt], tb[pa], wj);
+            }
+          w2 = big_block_sum<Cfg>(wj * wj, red, gt);
+          __syncthreads();
+          if (gt < n) vb[gt] = wj;  // (un-normalised w on exit: the bound uses w itself)
+          __syncthreads();
+        }
+        double zj = 0.0;
+        if (gt < n)
+          for (int i = 0; i < n; ++i) zj = fma(Mg[gt * LD + i], vb[i], zj);
+        const double z2 = big_block_sum<Cfg>(zj * zj, red, gt);
+        const double rs = tol > 0.0 ? tol : 2.220446049250313e-16;
+        const double m2 = 1.5625 * rs * rs;
+        const double den = tau + w2;
+        const double cut = den > 0.0 ? z2 / den : 0.0;
+        const double mw2 = fmax(mi2 - cut, 0.0) + 1e-10 * mi2;
+        ok = ((1.0 + nl2) * m2 < 1.0) && ((1.0 + tl2) * mw2 * m2 < 1.0);
+        __syncthreads();
+        for (int idx = tid; idx < 160; idx += NT) vb[idx] = 0.0;  // (the squarings' second buffer again)
         for (int idx = tid; idx < sN * sN; idx += NT) {
           const int i = idx / sN, j = idx - i * sN;
           Ts[i * LDS_ + j] = T[off + (size_t)sidx[i] * n + sidx[j]];
@@ -895,14 +971,9 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
       __syncthreads();
       if (ok) ok = big_certify_contraction<Cfg>(Gm, l, LDG, red, tid);
       if (ok) ok = big_certify_contraction<Cfg>(Ts, sN, LDS_, red, tid);
-      if (R_out) {
-#pragma unroll
-        for (int i = 0; i < TR; ++i)
-          if (r0 + i < n) {
-#pragma unroll
-            for (int jc = 0; jc < TC; ++jc)
-              if (c0 + jc < k) R_out[offk + (size_t)qrow[i] * k + c0 + jc] = ok ? -t0[i][jc] : 0.0;
-          }
+      if (R_out && !ok) {
+        __syncthreads();
+        for (int idx = tid; idx < n * k; idx += NT) R_out[offk + idx] = 0.0;
       }
     } else if (R_out) {
       for (int idx = tid; idx < n * k; idx += NT) R_out[offk + idx] = 0.0;

@@ -290,6 +290,110 @@ def test_spectral_division_certificate_never_contradicts_gensys():
     assert n_cert <= n_succ
 
 
+def _q2pi_lapack(A, B, C, D, tol=1e-8):
+    """Singular values of Q2 @ pi from LAPACK's ordered QZ of gensys_setup's pencil (gensys.py:227-235, 267-273), and the smallest
+    max(|alpha_i|, |beta_i|) over the diagonal pairs (the zxz test of :243)."""
+    import scipy.linalg as sla
+
+    from oracle.gensys_qz import gensys_setup
+
+    g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
+    _, _, alpha, beta, Qraw, _ = sla.ordqz(g0.astype(complex), g1.astype(complex), sort="ouc", output="complex")
+    aa, bb = np.abs(alpha), np.abs(beta)
+    stable = ((bb < tol) & (aa >= tol)) | ((bb >= tol) & (aa > bb))
+    nu = int(np.sum(~stable))
+    Q2 = Qraw.conj().T[len(alpha) - nu :]
+    return np.sort(sla.svd(Q2 @ pi, compute_uv=False)), float(np.maximum(aa, bb).min())
+
+
+def test_q2pi_singular_values_closed_form_vs_lapack():
+    """The identity behind the certificate's existence guard (round 6): the singular values of gensys's Q2 pi are
+    1 / sqrt(1 + sigma_i(N_L)^2), N_L = lead rows of (B + C T)^-1 -- checked against LAPACK's ordered QZ on regular systems and on
+    systems with one equation scaled by 1e-3 / 1e-6 (sigma_min follows the scale), 1e-9 relative."""
+    from tests.device_models.spectral_division_model import q2pi_singular_values
+
+    rng = np.random.default_rng(61)
+    for trial in range(24):
+        n = int(rng.integers(6, 24))
+        A, B, C, D, Tst = wl.sw_shaped_system(6100 + trial, n=n, n_state=max(1, n // 3), n_lead=max(1, n // 4), k=2)
+        e = [1.0, 1e-3, 1e-6][trial % 3]
+        r = int(rng.integers(n))
+        for X in (A, B, C, D):
+            X[r] *= e
+        s_ref, _ = _q2pi_lapack(A, B, C, D)
+        s_formula = np.sort(q2pi_singular_values(B, C, Tst))
+        assert_allclose(s_formula, s_ref, rtol=1e-7, atol=0)
+
+
+def test_scale_guards_never_certify_what_gensys_rejects():
+    """one equation multiplied by <= 1e-9 (or the whole system by ~1e-8, or one variable rescaled) leaves T untouched, so
+    the round-5 certificate said eu = [1, 1, 0] where the reference says [-2, -2, 0] / [0, ...].  With the scale guards: 0
+    contradictions in 900 such systems -- and the guards are what does it (the round-5 rule contradicts the oracle on the same list)."""
+    from tests.device_models.scale_cases import scaled_system
+    from tests.device_models.spectral_division_model import gensys_by_spectral_division
+
+    rng = np.random.default_rng(62)
+    stats = {k: [0, 0, 0, 0] for k in ("row", "global", "col", "regular")}  # n, oracle ok, certified, certified by the r5 rule
+    bad_r5 = 0
+    for trial in range(900):
+        kind = ("row", "global", "col", "regular")[trial % 4]
+        A, B, C, D, e = scaled_system(rng, kind)
+        T, cert = gensys_by_spectral_division(A, B, C, 1e-8)
+        _, cert_r5 = gensys_by_spectral_division(A, B, C, 1e-8, guards=False)
+        _, succ, eu = oracle.gensys_T_success(A, B, C, D, 1e-8)
+        regular = [int(x) for x in eu] == [1, 1, 0]
+        st = stats[kind]
+        st[0] += 1
+        st[1] += regular
+        st[2] += cert
+        st[3] += cert_r5
+        assert not cert or regular, (kind, e, eu)
+        bad_r5 += cert_r5 and not regular
+    assert bad_r5 >= 50, bad_r5  # (what the guards are for)
+    assert stats["regular"][2] == stats["regular"][0], stats  # unscaled systems: every one certified
+    # the guards are not vacuous either: most scaled systems that the reference still solves keep the fast path
+    assert stats["row"][2] >= 0.8 * stats["row"][1] and stats["global"][2] >= 0.5 * stats["global"][1], stats
+
+
+@pytest.mark.parametrize("factor", [1e-4, 1e-2, 0.3, 0.7, 0.95, 1.05, 1.3, 3.0, 1e2, 1e4])
+def test_existence_tolerance_sweep(factor):
+    """sigma_min(Q2 pi) swept through realsmall (gensys.py:276-283), tol = 1e-8 ... and two other tolerances.
+    The certificate never says [1, 1, 0] where the oracle's existence test fails, and it does take the draw once sigma_min is a
+    factor 3 clear of the tolerance (and no diagonal pair of the QZ is below it)."""
+    from tests.device_models.scale_cases import existence_sweep_system
+    from tests.device_models.spectral_division_model import gensys_by_spectral_division
+
+    for tol in (1e-8, 1e-6, 1e-10):
+        for seed in (7001, 7002, 7003):
+            A, B, C, D, e = existence_sweep_system(seed, factor * tol)
+            smin, min_pair = _q2pi_lapack(A, B, C, D, tol)
+            assert abs(smin[0] / (factor * tol) - 1.0) < 1e-3  # (the construction hit its target)
+            T, cert = gensys_by_spectral_division(A, B, C, tol)
+            _, succ, eu = oracle.gensys_T_success(A, B, C, D, tol)
+            regular = [int(x) for x in eu] == [1, 1, 0]
+            assert not cert or regular, (tol, seed, factor, eu)
+            if factor < 1.0:
+                assert not regular and not cert
+            if factor >= 3.0 and min_pair > 3.0 * tol:
+                assert regular and cert, (tol, seed, factor, eu, min_pair)
+
+
+@pytest.mark.parametrize("factor", [1e-3, 0.5, 0.999, 1.001, 2.0, 1e3])
+def test_lead_column_tolerance_sweep(factor):
+    """A lead column of C with sum|C_ij| straddling tol (gensys.py:587): below it gensys drops the column from the pencil although
+    the doubling iteration used it -- never certified; above it the column is an ordinary lead column."""
+    from tests.device_models.scale_cases import lead_column_sweep_system
+    from tests.device_models.spectral_division_model import gensys_by_spectral_division
+
+    for seed in (7101, 7102):
+        A, B, C, D = lead_column_sweep_system(seed, factor * 1e-8)
+        T, cert = gensys_by_spectral_division(A, B, C, 1e-8)
+        _, succ, eu = oracle.gensys_T_success(A, B, C, D, 1e-8)
+        assert not cert or [int(x) for x in eu] == [1, 1, 0], (seed, factor, eu)
+        if factor <= 1.0:
+            assert not cert
+
+
 def test_spectral_division_on_the_reference_failure_cases():
     """tests/golden/failure_cases.npz (the reference's own solvability cases, incl. the indeterminate system on which its cycle
     reduction CONVERGES): certified iff the reference's gensys returns eu = [1, 1, 0]."""
