@@ -48,6 +48,17 @@ class DsgeTooLargeError(DsgeHipError):
     """DSGE_ERR_TOO_LARGE: a well-formed call whose problem exceeds the entry point's on-chip capacity."""
 
 
+class DsgeNoVerdictError(DsgeHipError):
+    """``eu = [-3, -3, 0]``: gensys on a model with 65 .. 96 variables (solved by spectral division, csrc/dsge_big.hpp) whose draw
+    is NOT certified regular -- not converged, a root within 2e-4 of the unit circle, a scale the reference's absolute tolerances
+    would notice -- and there is no ordered QZ at that size to issue the reference's verdict ([1, 0, k], [0, 1, 0], [-2, -2, 0],
+    or [1, 1, 0] for a regular draw close to the unit circle).  The reference never returns -3; the batched entry points report
+    it per draw (status NOT_CONVERGED | GENSYS_TOO_BIG, T = R = 0), the single-model wrappers raise this."""
+
+
+EU_NO_VERDICT = -3  # eu[0] = eu[1] = -3: see DsgeNoVerdictError
+
+
 class GensysForward(C.Structure):
     """``dsge_gensys_forward`` of include/dsge_hip.h (addresses; 0 = not wanted)."""
 

@@ -95,7 +95,14 @@ def lead_hint(C, tol=0.0):
 
 def gensys_batched(A, B, C, D=None, tol=1e-8, n_lead_hint=None, options=None):
     """Batched ``GensysWrapper`` / ``gensys_pt`` (gEconpy/solvers/gensys.py:634-683):
-    returns dict(T, success, eu, status[, R])."""
+    returns dict(T, success, eu, status[, R]).
+
+    ``eu[i]`` is the reference's code triple -- with ONE code the reference does not have: for 65 .. 96 variables (no ordered QZ at
+    that size) a draw that the spectral-division certificate cannot prove regular comes back as ``eu = [-3, -3, 0]``
+    (``_lib.EU_NO_VERDICT``), ``success = False``, ``T = R = 0``: "no verdict at this size", never a wrong one.  It covers non-regular
+    draws (the reference would say ``[1, 0, k]``, ``[0, 1, 0]``, ...) AND regular ones with a root within 2e-4 of the unit circle
+    or a scale defect (the reference would solve them); consumers written against ``interpret_gensys_output`` should treat it as a
+    failed draw."""
     A, B, C = _check_abc(A, B, C)
     nb, n, _ = A.shape
     T = np.empty_like(A)

@@ -1,0 +1,111 @@
+// Small dense NT-form products on the FP64 matrix core's 4 x 4 x 4 instruction (round 6).
+//
+// v_mfma_f64_4x4x4f64 multiplies FOUR independent 4 x 4 x 4 blocks per issue: 256 FMAs in one instruction slot (16.4 cycles
+// back to back, 20.7 in a dependent chain; v_fma_f64: 64 FMAs per slot of 4.6 -- tools/mfma_probe/mfma4_rate.hip).  Same peak as the
+// VALU, a quarter of the instructions -- and a lone wavefront is bound by its instruction slots.  The
+// 16 x 16 x 4 instruction was measured SLOWER on the 18-wide reduced model (round 2: the fragment pads 18 -> 32); 4-wide blocks pad
+// 18 -> 20.  Operand / result layout, probed on the device with one-hot operands (tools/mfma_probe/mfma4_layout.hip):
+//     lane l:  blk = (l >> 2) & 3     A_blk[i = l & 3][k = l >> 4]     B_blk[k = l >> 4][j = l & 3]     D_blk[i = l >> 4][j = l & 3]
+//
+// mfma4_nt<KT, TA, TB, LD>:  D[r][c] = sum_k A[r][k] B[c][k]  (both operands row-major along k, even leading dimension LD,
+// 16-byte aligned rows -- the layout of the filter's Tc / W' / Pc), r < 4 TA, c < 4 TB, k < 4 KT, everything compile-time so that
+// every LDS access is one per-lane base register plus an immediate offset.
+//   * tiles: "band 0" = row tiles 0..3, one per block, column tile g in group g (A operands are the same for all TB groups: loaded
+//     once); "band 1" = the row tiles 4..TA-1 (TA <= 8), packed 4 / 2 / 1 column tiles per group.
+//   * the contraction index is PERMUTED inside the instruction so that one ds_read_b128 feeds two issues: within a pair of k-tiles
+//     (8 columns) lane group kq = l >> 4 takes k = 8 c + 2 kq (first issue) and 8 c + 2 kq + 1 (second); an odd last tile is one
+//     issue with k = 4 (KT - 1) + kq.  Two accumulators per group alternate (independent issues: 16 instead of 21 cycles each).
+//   * operands are read UNPREDICATED: rows up to 4 TA (4 TB) and columns up to 4 KT must be readable, finite, and zero where the
+//     mathematical operand ends.
+// The consumer gets every group's element through `sink(g, d)`; Mfma4Map tells which tile that is.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dsge {
+
+template <int TA, int TB>
+struct Mfma4Map {
+  static_assert(TA >= 1 && TA <= 8 && TB >= 1 && TB <= 8, "1..8 tiles per side");
+  static constexpr int G0 = TB;                                  // groups of band 0
+  static constexpr int R1 = TA > 4 ? TA - 4 : 0;                 // row tiles of band 1
+  static constexpr int RP = R1 == 0 ? 1 : (R1 == 1 ? 1 : (R1 == 2 ? 2 : 4));  // blocks per column tile in band 1
+  static constexpr int CPG = 4 / RP;                             // column tiles per group in band 1
+  static constexpr int G1 = R1 == 0 ? 0 : (TB + CPG - 1) / CPG;  // groups of band 1
+  static constexpr int NG = G0 + G1;
+  // row / column tile of this lane's block in group g (g < G0: band 0), and whether the block is a real tile
+  __device__ static __forceinline__ int ta(int g, int blk) { return g < G0 ? blk : 4 + (blk % RP); }
+  __device__ static __forceinline__ int tb(int g, int blk) { return g < G0 ? g : CPG * (g - G0) + blk / RP; }
+  __device__ static __forceinline__ bool live(int g, int blk) { return ta(g, blk) < TA && tb(g, blk) < TB; }
+};
+
+template <int KT, int TA, int TB, int LD, class Sink>
+__device__ __forceinline__ void mfma4_nt(const double* __restrict__ A, const double* __restrict__ B, int lane, Sink&& sink) {
+  using MP = Mfma4Map<TA, TB>;
+  constexpr int NPAIR = KT / 2, ODD = KT & 1, NOP = NPAIR + ODD;
+  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  // ---- band 0 ----
+  {
+    const double* ap = A + (4 * (blk < TA ? blk : 0) + i4) * LD;  // (a block beyond TA recomputes row tile 0: never stored)
+    const double* bp = B + i4 * LD;
+    double2 a2[NPAIR > 0 ? NPAIR : 1];
+    double a1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) a2[c] = *reinterpret_cast<const double2*>(ap + 8 * c + 2 * kq);
+    if (ODD) a1 = ap[4 * (KT - 1) + kq];
+    double2 b2[2][NPAIR > 0 ? NPAIR : 1];
+    double b1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) b2[0][c] = *reinterpret_cast<const double2*>(bp + 8 * c + 2 * kq);
+    if (ODD) b1[0] = bp[4 * (KT - 1) + kq];
+#pragma unroll
+    for (int g = 0; g < MP::G0; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < MP::G0) {  // operands of the next group are requested before this group's issues
+#pragma unroll
+        for (int c = 0; c < NPAIR; ++c) b2[nxt][c] = *reinterpret_cast<const double2*>(bp + (g + 1) * 4 * LD + 8 * c + 2 * kq);
+        if (ODD) b1[nxt] = bp[(g + 1) * 4 * LD + 4 * (KT - 1) + kq];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NPAIR; ++c) {
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[c].x, b2[cur][c].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[c].y, b2[cur][c].y, acc1, 0, 0, 0);
+      }
+      if (ODD) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1[cur], acc0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      sink(g, NOP > 1 ? acc0 + acc1 : acc0);
+    }
+  }
+  // ---- band 1 ----
+  if constexpr (MP::G1 > 0) {
+    const int ta1 = 4 + (blk % MP::RP), tb1 = blk / MP::RP;
+    const double* ap = A + (4 * (ta1 < TA ? ta1 : 0) + i4) * LD;
+    double2 a2[NPAIR > 0 ? NPAIR : 1];
+    double a1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) a2[c] = *reinterpret_cast<const double2*>(ap + 8 * c + 2 * kq);
+    if (ODD) a1 = ap[4 * (KT - 1) + kq];
+#pragma unroll
+    for (int g = 0; g < MP::G1; ++g) {
+      // (column tiles beyond TB: clamp to tile 0, never stored.  tb1 + CPG g < TB is lane-dependent only in the last group)
+      const int tbg = (MP::CPG * g + tb1 < TB) ? MP::CPG * g + tb1 : 0;
+      const double* bp = B + (4 * tbg + i4) * LD;
+      double2 b2[NPAIR > 0 ? NPAIR : 1];
+      double b1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NPAIR; ++c) b2[c] = *reinterpret_cast<const double2*>(bp + 8 * c + 2 * kq);
+      if (ODD) b1 = bp[4 * (KT - 1) + kq];
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NPAIR; ++c) {
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[c].x, b2[c].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[c].y, b2[c].y, acc1, 0, 0, 0);
+      }
+      if (ODD) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, acc0, 0, 0, 0);
+      sink(MP::G0 + g, NOP > 1 ? acc0 + acc1 : acc0);
+    }
+  }
+}
+
+}  // namespace dsge

@@ -54,7 +54,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
                            (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr,
                            (double*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, store);
         // the reverse mean side of every draw's LAST steady segment at two wavefronts per SIMD (kalman_grad_tail_kernel); the
-        // reverse sweep then starts at that segment's source step (kalman_grad_split = 2, the default; 1: without it)
+        // reverse sweep then starts at that segment's source step (kalman_grad_split = 2; the default is 1: without it)
         const int with_tail = opt().kalman_grad_split >= 2;
         if (with_tail)
           hipLaunchKernelGGL((dsge::kalman_grad_tail_kernel<BS>), dim3(batch), dim3(64), 0, st, T, Z, z_batched, d, d_batched, y,

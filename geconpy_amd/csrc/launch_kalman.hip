@@ -27,16 +27,32 @@ struct HeadStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   int dev = -1;
+  void release() {  // (idempotent; the owning device is made current for the destroy calls and the caller's restored)
+    if (!s && !fork && !join) return;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (dev >= 0) (void)hipSetDevice(dev);
+    if (join) (void)hipEventDestroy(join);
+    if (fork) (void)hipEventDestroy(fork);
+    if (s) (void)hipStreamDestroy(s);
+    s = nullptr;
+    fork = join = nullptr;
+    if (have_cur) (void)hipSetDevice(cur);
+  }
+  ~HeadStream() { release(); }  // thread exit: the stream and both events go with the thread
 };
 thread_local HeadStream t_head;
 int head_stream(HeadStream** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (t_head.dev != dev) {
+  if (t_head.dev != dev || !t_head.s || !t_head.fork || !t_head.join) {
+    // another device than last time, or a creation that failed half-way: drop what exists, then create all three -- a failure
+    // leaves a partially filled record behind that the next call (or the destructor) releases
+    t_head.release();
+    t_head.dev = dev;
     HIP_TRY(hipStreamCreateWithFlags(&t_head.s, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&t_head.fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&t_head.join, hipEventDisableTiming));
-    t_head.dev = dev;
   }
   *out = &t_head;
   return DSGE_SUCCESS;

@@ -176,7 +176,13 @@ int launch_cr_deflated(const double* A, const double* B, const double* C, const 
     // n_static_hint = -1: first batch of this model size measures (one small launch and a 4-byte read-back, which
     // synchronises the stream); every 256th call after that measures again and keeps the minimum, so that an
     // unrepresentative first batch corrects itself.  Callers that need a pure enqueue pass the hint.
-    const bool remeasure = g_static_hint[n] != 0 && (++g_static_calls[n] & 255) == 0;
+    // (the measurement synchronises the stream: never while the caller is capturing it into a graph -- the periodic renewal is
+    //  skipped then, and a FIRST call under capture has nothing to go by: it runs the full-size solve.  Graph capture of this
+    //  path wants n_static_hint, include/dsge_hip.h)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = (hipStreamIsCapturing(st, &cap) == hipSuccess) && cap != hipStreamCaptureStatusNone;
+    if (capturing && g_static_hint[n] == 0) return DSGE_SUCCESS;
+    const bool remeasure = !capturing && g_static_hint[n] != 0 && (++g_static_calls[n] & 255) == 0;
     if (g_static_hint[n] == 0 || remeasure) {
       if ((rc = defl_reserve(256, st, &base))) return rc;
       int32_t hmin = n;

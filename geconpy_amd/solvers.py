@@ -133,6 +133,10 @@ def solve_policy_function_with_gensys(A, B, C, D, tol=1e-8, return_all_matrices=
     A3, B3, C3, D3 = (np.ascontiguousarray(x, dtype=np.float64)[None] for x in (A, B, C, D))
     out = batched.gensys_batched(A3, B3, C3, D3, tol=tol)
     eu = [int(v) for v in out["eu"][0]]
+    if eu[0] == _lib.EU_NO_VERDICT:  # 65 .. 96 variables, draw not certified regular: no QZ at that size, and no made-up matrices
+        raise _lib.DsgeNoVerdictError(
+            "gensys on %d variables: the draw is not certified regular (eu = [-3, -3, 0]) and there is no ordered QZ beyond 64 "
+            "variables to decide it; use solver='cycle_reduction', or reduce the model" % A3.shape[1])
     if eu[0] == -2 and eu[1] == -2:  # coincident zeros: the 9-tuple of Nones, whatever return_all_matrices says (gensys.py:515-516)
         return None, None, None, None, None, None, None, eu, None
     n, k = D3.shape[1:]

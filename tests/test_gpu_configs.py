@@ -269,6 +269,10 @@ def test_bench_launches_its_own_ranks():
     assert out["roofline"]["achieved"] > 0 and out["roofline"]["peak"] > 0 and "frac" in out["roofline"]
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["kind"] == "port"
     assert out["parity"]["n_checked"] >= 8 and out["parity"]["max_rel_logp_err_vs_cpu_oracle"] <= 1e-8
+    # who took part in the gather (round 6): backend, world and one entry per rank -- here two ranks on ONE device over gloo, and the
+    # line says exactly that (on a multi-GPU node: "nccl", distinct_devices == world)
+    g = out["gather"]
+    assert g["world"] == 2 and g["backend"] == "gloo" and [e["rank"] for e in g["ranks"]] == [0, 1] and g["distinct_devices"] == 1
 
 
 def test_bench_sizes_a_multi_gpu_run_as_configs3():
