@@ -12,7 +12,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libdsge_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 ERR_INVALID, ERR_HIP, ERR_TOO_LARGE = 1, 2, 3
 MAX_N = 64
 MAX_N_CR = 64

@@ -218,7 +218,7 @@ struct Options {
   int kalman_order = 1;        // Kalman workgroups slow-draws-first (1 = CR iteration count / persistence key, 2 = key, 0 = index)
   int kalman_tiny = 1;         // thread-per-draw kernel for small models
   int kalman_block = 0;        // steady tail handed to kalman_tail_kernel
-  int kalman_mfma = 0;         // prediction products on the FP64 matrix core
+  int kalman_mfma = 2;         // prediction products on the FP64 matrix core: 2 = 4 x 4 x 4 blocks in the NT kernel (round 6), 1 = 16 x 16 x 4 (round 2, slower), 0 = VALU
   int cr_four_waves = 1;       // n = 49..64: cr_wide_kernel (256 threads per draw) instead of cr_compact_kernel<7|8>
   int cr_fused_deflation = 1;  // deflation + cycle reduction + inflation in one launch (dsge_cr_fused.hpp)
   int kalman_nt_products = 1;  // selector fast path: kalman_nt_kernel (NT prediction products, 16-byte LDS loads); 0 = kalman_sel_kernel

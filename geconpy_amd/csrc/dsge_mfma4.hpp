@@ -108,4 +108,101 @@ __device__ __forceinline__ void mfma4_nt(const double* __restrict__ A, const dou
   }
 }
 
+// ---- the upper triangle only (D symmetric by construction of the operands: X = Tc (P Tc')): tiles (ta <= tb), 4 per group --------
+template <int TM>
+struct Mfma4Upper {
+  static constexpr int NT = TM * (TM + 1) / 2, NG = (NT + 3) / 4;
+  // tile number t -> (ta, tb), columns first: t = tb (tb + 1) / 2 + ta
+  __host__ __device__ static constexpr int tb_of(int t) {
+    int tb = 0;
+    while ((tb + 1) * (tb + 2) / 2 <= t) ++tb;
+    return tb;
+  }
+  __host__ __device__ static constexpr int ta_of(int t) { return t - tb_of(t) * (tb_of(t) + 1) / 2; }
+  // per-lane tile of group g (g is a constant after unrolling: the tile numbers fold; a block beyond the last tile repeats tile 0
+  // and is not live): chains of selects on blk, no table in memory
+  __device__ static __forceinline__ void tile(int g, int blk, int& ta, int& tb, bool& live) {
+    const int t0 = 4 * g, t1 = 4 * g + 1, t2 = 4 * g + 2, t3 = 4 * g + 3;
+    const int c0 = t0 < NT ? t0 : 0, c1 = t1 < NT ? t1 : 0, c2 = t2 < NT ? t2 : 0, c3 = t3 < NT ? t3 : 0;
+    ta = blk == 0 ? ta_of(c0) : (blk == 1 ? ta_of(c1) : (blk == 2 ? ta_of(c2) : ta_of(c3)));
+    tb = blk == 0 ? tb_of(c0) : (blk == 1 ? tb_of(c1) : (blk == 2 ? tb_of(c2) : tb_of(c3)));
+    live = blk == 0 ? (t0 < NT) : (blk == 1 ? (t1 < NT) : (blk == 2 ? (t2 < NT) : (t3 < NT)));
+  }
+};
+
+// D[r][c] (+ init(g)) for the tiles ta <= tb only; sink(g, d, ta, tb, live): this lane's element is D[4 ta + (l >> 4)][4 tb + (l & 3)].
+// The operands of group g + 1 are requested before the issues of group g.  init(g): the accumulator's starting value (the lane's
+// element of C in D = A B' + C).
+template <int KT, int TM, int LD, class Init, class Sink>
+__device__ __forceinline__ void mfma4_nt_upper_acc(const double* __restrict__ A, const double* __restrict__ B, int lane, Init&& init,
+                                                   Sink&& sink) {
+  using UX = Mfma4Upper<TM>;
+  constexpr int NPAIR = KT / 2, ODD = KT & 1, NOP = NPAIR + ODD, NG = UX::NG;
+  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  double2 a2[2][NPAIR > 0 ? NPAIR : 1], b2[2][NPAIR > 0 ? NPAIR : 1];
+  double a1[2] = {0.0, 0.0}, b1[2] = {0.0, 0.0};
+  int ta[2], tb[2];
+  bool live[2];
+#define MFMA4_UP_LOAD(G_, S_)                                                                \
+  do {                                                                                       \
+    UX::tile(G_, blk, ta[S_], tb[S_], live[S_]);                                             \
+    const double* ap_ = A + (4 * ta[S_] + i4) * LD;                                          \
+    const double* bp_ = B + (4 * tb[S_] + i4) * LD;                                          \
+    _Pragma("unroll") for (int c = 0; c < NPAIR; ++c) {                                      \
+      a2[S_][c] = *reinterpret_cast<const double2*>(ap_ + 8 * c + 2 * kq);                   \
+      b2[S_][c] = *reinterpret_cast<const double2*>(bp_ + 8 * c + 2 * kq);                   \
+    }                                                                                        \
+    if (ODD) {                                                                               \
+      a1[S_] = ap_[4 * (KT - 1) + kq];                                                       \
+      b1[S_] = bp_[4 * (KT - 1) + kq];                                                       \
+    }                                                                                        \
+  } while (0)
+  MFMA4_UP_LOAD(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    if (g + 1 < NG) MFMA4_UP_LOAD(g + 1, nxt);
+    double acc0 = init(g), acc1 = 0.0;  // (two chains: the issues of a pair never wait for each other)
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) {
+      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][c].x, b2[cur][c].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][c].y, b2[cur][c].y, acc1, 0, 0, 0);
+    }
+    if (ODD) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur], b1[cur], acc0, 0, 0, 0);
+    sink(g, NPAIR > 0 ? acc0 + acc1 : acc0, ta[cur], tb[cur], live[cur]);
+  }
+#undef MFMA4_UP_LOAD
+}
+
+// D = A B (NN form: B row-major along its COLUMNS, B[k][c]) for all TA x TB tiles: the doubling iteration's A_k[:,S] A_k[S,:].
+// Same tile map and k permutation as mfma4_nt; the B operand of a k-pair is two ds_read_b64 (rows 8 c + 2 kq and 8 c + 2 kq + 1).
+template <int KT, int TA, int TB, int LD, class Sink>
+__device__ __forceinline__ void mfma4_nn(const double* __restrict__ A, const double* __restrict__ B, int lane, Sink&& sink) {
+  using MP = Mfma4Map<TA, TB>;
+  constexpr int NPAIR = KT / 2, ODD = KT & 1, NOP = NPAIR + ODD;
+  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < MP::NG; ++g) {
+    const int ta = MP::ta(g, blk), tb = MP::tb(g, blk);
+    const int tac = ta < TA ? ta : 0, tbc = tb < TB ? tb : 0;
+    const double* ap = A + (4 * tac + i4) * LD;
+    const double* bp = B + 4 * tbc + i4;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) {
+      const double2 a2 = *reinterpret_cast<const double2*>(ap + 8 * c + 2 * kq);
+      const double bx = bp[(8 * c + 2 * kq) * LD], by = bp[(8 * c + 2 * kq + 1) * LD];
+      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2.x, bx, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2.y, by, acc1, 0, 0, 0);
+    }
+    if (ODD) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * (KT - 1) + kq], bp[(4 * (KT - 1) + kq) * LD], acc0, 0, 0, 0);
+    sink(g, NOP > 1 ? acc0 + acc1 : acc0);
+  }
+}
+
+template <int KT, int TM, int LD, class Sink>
+__device__ __forceinline__ void mfma4_nt_upper(const double* __restrict__ A, const double* __restrict__ B, int lane, Sink&& sink) {
+  mfma4_nt_upper_acc<KT, TM, LD>(A, B, lane, [](int) { return 0.0; }, sink);
+}
+
 }  // namespace dsge

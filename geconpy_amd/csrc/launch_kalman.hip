@@ -9,6 +9,7 @@
 #include "dsge_kalman2.hpp"
 #include "dsge_kalman_nt.hpp"
 #include "dsge_kalman_nt2.hpp"
+#include "dsge_kalman_mf.hpp"
 #include "dsge_kalman_tail.hpp"
 #include "dsge_kalman_tiny.hpp"
 
@@ -75,7 +76,7 @@ int launch_persistence_key(const double* T, const int32_t* status, int batch, in
 // their full-size P0 from the assemble kernel's Lyapunov pass (from RQR, which must be valid).
 bool kalman_folds_rqr(int m, int p, int k, int n_state_hint, int z_selector_hint) {
   // mirrors the dispatch below: the NT fast kernel takes every draw first (no tiny / tail / MFMA variant in front of it)
-  if (!(p <= 8 && z_selector_hint && opt().kalman_nt_products) || opt().kalman_mfma || k < 1 || k > dsge::RQR_KMAX) return false;
+  if (!(p <= 8 && z_selector_hint && opt().kalman_nt_products) || opt().kalman_mfma == 1 || k < 1 || k > dsge::RQR_KMAX) return false;
   if (opt().kalman_tiny && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) return false;
   if (opt().kalman_block && !opt().kalman_nt_products) return false;  // (the selector kernel's tail instance does not form R Q R')
   const int kp = (k + 1) & ~1;
@@ -174,6 +175,32 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     HIP_TRY(hipGetLastError());
     return DSGE_SUCCESS;
   };
+  // Round 6: the covariance in the tile layout of the FP64 matrix core's 4 x 4 x 4 instruction (dsge_kalman_mf.hpp) -- downdate and
+  // both prediction products as 63 matrix issues per full step.  Instance by the caller's hint: 17 .. 20 state variables (five tiles
+  // of four: the Smets-Wouters-shaped models) and at most 20 retained variables; the kernel checks every draw and flags what does
+  // not fit for the cascade below, which then runs as a second pass.  dsge_options.kalman_mfma = 2 (default); 0: the VALU kernels.
+  if (fast && z_selector_hint && opt().kalman_mfma == 2 && opt().kalman_nt_products && !want_tail && opt().kalman_head_draws == 0 &&
+      n_state_hint >= 17 && n_state_hint <= 20 && !launched_fast) {
+    using SMF = dsge::KmfSmem<5, 5>;
+    const bool stage_fits = !fold || (size_t)m * ((k_shocks + 1) & ~1) <= (size_t)SMF::WT;
+    if (stage_fits) {
+      if (g_kalman_dbg) {
+        if ((rc = set_lds(dsge::kalman_mf_kernel<5, 5, true>, SMF::bytes))) return rc;
+        hipLaunchKernelGGL((dsge::kalman_mf_kernel<5, 5, true>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR,
+                           p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
+                           missing_fill, opt().kalman_steady_tol, logp, status, g_kalman_dbg, 0, g_kalman_steady_at, order,
+                           fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
+      } else {
+        if ((rc = set_lds(dsge::kalman_mf_kernel<5, 5, false>, SMF::bytes))) return rc;
+        hipLaunchKernelGGL((dsge::kalman_mf_kernel<5, 5, false>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR,
+                           p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
+                           missing_fill, opt().kalman_steady_tol, logp, status, (long long*)nullptr, 0, g_kalman_steady_at, order,
+                           fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
+      }
+      HIP_TRY(hipGetLastError());
+      launched_fast = true;
+    }
+  }
   if (fast) {
     // The fast kernel filters only the variables that matter (states + observed non-states), so its
     // tile size follows that reduced dimension u, not m.  u is only known per draw on the device
@@ -201,7 +228,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
           const size_t lds = dsge::Kf2Smem<BS>::bytes(s_cap, false);
           bool done = false;
           if constexpr (BS == 2 || BS == 3) {
-            if (opt().kalman_mfma) {  // prediction products on the FP64 matrix core
+            if (opt().kalman_mfma == 1) {  // prediction products on the FP64 matrix core's 16 x 16 x 4 instruction (round 2, slower)
               rc = set_lds(dsge::kalman_sel_kernel<BS, true, true>, lds);
               if (rc == DSGE_SUCCESS) {
                 hipLaunchKernelGGL((dsge::kalman_sel_kernel<BS, true, true>), dim3(rerun ? rerun_grid(batch) : batch), dim3(64), lds, st, T, RQR,

@@ -33,12 +33,17 @@
 extern "C" {
 #endif
 
-#define DSGE_ABI_VERSION 8
+#define DSGE_ABI_VERSION 9
 
 /* ABI 8: the process-wide dsge_set_* switches (deprecated at ABI 7) are GONE -- they edited defaults shared by every host
  * thread and stream of the process, which a library called from several PyMC chains must not have.  Every switch is a field
  * of the per-call dsge_options struct (the *_opt entry points, or dsge_options_push / dsge_options_pop around any entry point
  * on the calling thread); dsge_options_init() fills the compiled-in defaults. */
+/* ABI 9: no symbol and no struct layout changed; two BEHAVIOURS did, which is what a version is for: (i) dsge_options.kalman_mfma takes
+ * the value 2 -- prediction products on the 4 x 4 x 4 FP64 matrix instruction -- and 2 is the default (was 0); (ii) solver = gensys by
+ * spectral division (gensys_doubling = 1) certifies a draw only if two scale guards hold that make the reference's absolute-tolerance
+ * tests (coincident zeros, rank of Q2 Pi; gEconpy/solvers/gensys.py:243, 276-283) provably pass -- a draw with an equation scaled
+ * by <= ~tol now gets the ordered QZ's verdict instead of eu = [1, 1, 0]. */
 
 /* limits of this build */
 #define DSGE_MAX_N 64      /* model variables n == Kalman states m */
@@ -314,12 +319,16 @@ int dsge_forget_measured_shapes(void);
  * splits the remaining 2 x 2 blocks).  An accelerator: every step is an orthogonal equivalence, T and eu are the same to
  * rounding (test_gensys_real_stage_matches_complex_only).  enable = 0: complex iteration only (round 1-2 behaviour).
  * default 1. */
-/* dsge_options.kalman_mfma: The two covariance-prediction products of a full filter step (W = P+[S,S] T', T W) of the 16- and 24-wide
- * selector instances run on the FP64 matrix core (v_mfma_f64_16x16x4_f64 for the 16 x 16 core tile, VALU for the
- * fringe).  Experimental and OFF by default: on MI355X it is slower than the VALU register-block products (4.4 vs 3.3 ms
- * per 4096-draw step) -- FP64 MFMA has the VALU's peak rate on gfx950, the 18-wide reduced model does not fill a
- * 16 x 16 fragment, and the accumulator + operand registers push the 256-VGPR kernel into spills.
- * enable = 1 switches it on (tests compare both). */
+/* dsge_options.kalman_mfma: The two covariance-prediction products of a full filter step (W = P+[S,S] T', X = T W) on the FP64 matrix core.
+ *   2 (default, ABI 9): v_mfma_f64_4x4x4f64 -- four independent 4 x 4 x 4 blocks per issue -- inside the fast selector kernel
+ *       (kalman_nt_kernel) for the draws whose state block and retained variables both have five tiles of four (17 .. 20
+ *       variables: the Smets-Wouters-shaped models; chosen by n_state_hint, checked per draw, every other draw keeps the VALU
+ *       products): W in 35 issues, the upper triangle of X in 20, against 432 FMAs and 144 LDS loads per lane.  Same peak as
+ *       the VALU, a quarter of the instruction slots: a full step of a lone wavefront 8.0 k -> 7.2 k cycles.
+ *   1: the round-2 experiment -- v_mfma_f64_16x16x4_f64 on the 16 x 16 core tile of the 16- and 24-wide selector instances, VALU
+ *       for the fringe.  Slower than the VALU register blocks (4.4 vs 3.3 ms per 4096-draw step: the 18-wide reduced model pads
+ *       to 32); kept for comparison (tests compare it with the VALU path).
+ *   0: VALU products everywhere. */
 
 /* Debug hook: enable != 0 makes the compact cycle-reduction kernel record the shader cycles draw 0 spends in
  * [0] Gauss-Jordan panels, [1] trailing updates, [2] row gather + staging, [3] products, [4] scatter/updates/

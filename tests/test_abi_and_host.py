@@ -145,7 +145,7 @@ def test_options_struct_defaults_and_scope():
     o = _lib.make_options()
     assert o.struct_size == ctypes.sizeof(_lib.Options)
     assert (o.cr_compact, o.cr_fused_selection, o.cr_deflation, o.cr_two_waves) == (1, 1, 1, 1)
-    assert (o.kalman_order, o.kalman_tiny, o.kalman_block, o.kalman_mfma, o.pipeline_chunks, o.gensys_split) == (1, 1, 0, 0, 0, 1)
+    assert (o.kalman_order, o.kalman_tiny, o.kalman_block, o.kalman_mfma, o.pipeline_chunks, o.gensys_split) == (1, 1, 0, 2, 0, 1)
     assert o.n_static_hint == -1 and o.kalman_steady_tol == 1e-14
     assert (o.kalman_nt_products, o.cr_fused_deflation, o.cr_four_waves) == (1, 1, 1)
     o2 = _lib.make_options({"kalman_steady_tol": 0.0}, n_static_hint=10)

@@ -137,7 +137,7 @@ def test_scale_defects_get_the_reference_verdict(kind):
     from tests.device_models.scale_cases import scaled_system
 
     rng = np.random.default_rng({"row": 81, "global": 82, "col": 83}[kind])
-    n_bad_without_guard = 0
+    n_bad_without_guard = n_named_differently = n_total = 0
     for n in (8, 14, 20):
         systems = [scaled_system(rng, kind, n=n)[:4] for _ in range(48)]
         # (scaled_system draws n_state, n_lead, k at random: group by k for stacking)
@@ -150,13 +150,21 @@ def test_scale_defects_get_the_reference_verdict(kind):
             qz = batched.gensys_batched(A, B, C, D, tol=1e-8, options=QZ)
             for i in range(len(group)):
                 T_ref, succ, eu = oracle.gensys_T_success(A[i], B[i], C[i], D[i], 1e-8)
-                assert list(out["eu"][i]) == [int(e) for e in eu], (kind, n, i, out["eu"][i], eu, qz["eu"][i])
-                assert bool(out["success"][i]) == bool(succ)
+                # success and the verdict of the library's own ordered QZ: exact.  The oracle's eu: exact too, except that two QZs
+                # may NAME a failure differently when a diagonal pair sits at the tolerance (LAPACK: existence fails first,
+                # [0, 0, 1]; the device's pair is a hair smaller: coincident zeros, [-2, -2, 0]) -- both failures, counted below
+                assert bool(out["success"][i]) == bool(succ), (kind, n, i, out["eu"][i], eu)
+                assert list(out["eu"][i]) == list(qz["eu"][i]), (kind, n, i, out["eu"][i], qz["eu"][i])
+                if list(out["eu"][i]) != [int(e) for e in eu]:
+                    assert not succ and not out["success"][i]
+                    n_named_differently += 1
+                n_total += 1
                 if succ:  # (cond(B + C T) grows with 1 / scale, up to ~1e8 where the reference still succeeds: two float64 solvers
                     #  agree to cond x eps there)
                     assert_allclose(out["T"][i], T_ref, rtol=0, atol=1e-6 * max(1.0, np.abs(T_ref).max()))
                 n_bad_without_guard += (not succ)
     assert n_bad_without_guard >= 10  # (the family does contain systems the reference rejects)
+    assert n_named_differently <= 0.05 * n_total, (n_named_differently, n_total)
 
 
 @pytest.mark.parametrize("tol", [1e-8, 1e-6])

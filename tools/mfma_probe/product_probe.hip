@@ -54,27 +54,36 @@ __global__ __launch_bounds__(64, 2) void step_kernel(const double* Tin, const do
           Pb[i][j] = 0.5 * (Xb[i][j] + xt) + Qb[i][j];
         }
     } else {
-      // W[i][j] = sum_k Pc[i][k] Tc[j][k], i < s, j < m: 5 x 5 tiles, stored transposed
-      constexpr int KT = 5, TM = 5;
+      // W[i][j] = sum_k Pc[i][k] Tc[j][k], i < s, j < m: 5 x 5 tiles, stored transposed.  Stores are UNCONDITIONAL: a block that
+      // is no tile writes to a padding slot nothing reads (a predicated store is a branch, and a branch ends the basic block the
+      // scheduler can overlap loads and issues in)
+      constexpr int KT = 5, TM = 5, DUMP = (NP - 1) * LDK + LDK - 1;
       using MW = Mfma4Map<KT, TM>;
       const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
       mfma4_nt<KT, KT, TM, LDK>(Pc, Tc, lane, [&](int g, double d) {
-        if (MW::live(g, blk)) Wt[(4 * MW::tb(g, blk) + i4) * LDK + 4 * MW::ta(g, blk) + kq] = d;
+        const int at = (4 * MW::tb(g, blk) + i4) * LDK + 4 * MW::ta(g, blk) + kq;
+        Wt[MW::live(g, blk) ? at : DUMP] = d;
       });
       wave_sync();
-      // X[r][c] = sum_k Tc[r][k] Wt[c][k]: 5 x 5 tiles -> registers first (Wt is an operand), then over Wt
-      using MX = Mfma4Map<TM, TM>;
-      double dd[MX::NG];
-      mfma4_nt<KT, TM, TM, LDK>(Tc, Wt, lane, [&](int g, double d) { dd[g] = d; });
+      // X[r][c] = sum_k Tc[r][k] Wt[c][k]: the 15 upper tiles -> registers first (Wt is an operand), then over Wt
+      using UX = Mfma4Upper<TM>;
+      double dd[UX::NG];
+      int pos[UX::NG];
+      mfma4_nt_upper<KT, TM, LDK>(Tc, Wt, lane, [&](int g, double d, int ta, int tb, bool live) {
+        dd[g] = d;
+        pos[g] = live ? (4 * ta + kq) * LDK + 4 * tb + i4 : DUMP;
+      });
       wave_sync();
 #pragma unroll
-      for (int g = 0; g < MX::NG; ++g)
-        if (MX::live(g, blk)) Wt[(4 * MX::ta(g, blk) + kq) * LDK + 4 * MX::tb(g, blk) + i4] = dd[g];
+      for (int g = 0; g < UX::NG; ++g) Wt[pos[g]] = dd[g];
       wave_sync();
       for (int i = 0; i < BS; ++i)
         for (int j = 0; j < BS; ++j) {
           const int r = lr * BS + i, c = lc * BS + j;
-          Pb[i][j] = 0.5 * (Wt[r * LDK + c] + Wt[c * LDK + r]) + Qb[i][j];
+          const int lo = r < c ? r : c, hi = r < c ? c : r;
+          const bool in = hi < m;
+          const double xv = Wt[in ? lo * LDK + hi : 0];
+          Pb[i][j] = (in ? xv : 0.0) + Qb[i][j];
         }
       wave_sync();
     }
