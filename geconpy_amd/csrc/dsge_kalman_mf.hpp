@@ -34,7 +34,7 @@ struct KmfSmem {
   static constexpr int RP = NR / 8, PS = 10;
   static constexpr int WT = NM * LDK > NR * PS ? NM * LDK : NR * PS;  // W' buffer; the -V panel and the staged R alias it
   // doubles: Tc NM*LDK, Wt WT, Pc NS*LDK, PZt, Ks NR*PS each, av, af NR each, vv/dd/hh/zv 8 each; ints perm NR, zpos 8
-  static constexpr size_t doubles = (size_t)NM * LDK + WT + (size_t)NS * LDK + 2 * (size_t)NR * PS + 2 * NR + 2 + 32 + NR / 2 + 4;
+  static constexpr size_t doubles = (size_t)NM * LDK + WT + (size_t)NS * LDK + 2 * (size_t)NR * PS + 2 * NR + 2 + 42 + NR / 2 + 4;
   static constexpr size_t bytes = sizeof(double) * doubles;
 };
 
@@ -53,6 +53,9 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
   using UX = Mfma4Upper<TM>;
   using MW = Mfma4Map<KT, TM>;
   constexpr int NS = SM::NS, NM = SM::NM, LDK = SM::LDK, NR = SM::NR, RP = SM::RP, PS = SM::PS, NG = UX::NG;
+  // more than five groups of tiles (TM = 7: 28 upper tiles): the per-element tables of where a value is stored would push the kernel
+  // past 256 registers -- the Pc offsets are recomputed where they are used and the selector values come from an LDS table
+  constexpr bool LEAN = NG > 5;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Tc = smem;                // NM x LDK   transition, states-first ordering (columns >= s exactly zero)
   double* Wt = Tc + NM * LDK;       // WT         W' : Wt[j][k] = (P+[S,S] Tc')[k][j]
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
   double* dd = vv + 8;              // 8 obs intercept
   double* hh = dd + 8;              // 8 diag(H)
   double* zv = hh + 8;              // 8 selector values
-  int* perm = (int*)(zv + 8);       // NR: position -> original variable (states first)
+  double* zvt = zv + 8;             // 10: selector value by observation index, [8] = 0 (LEAN: the P Z' stores look their factor up)
+  int* perm = (int*)(zvt + 10);     // NR: position -> original variable (states first)
   int* zpos = perm + NR;            // 8: position of the state each observation selects
   constexpr int W_DUMP = (NM - 1) * LDK + LDK - 1;   // padding slots that nothing reads: targets of the stores of dead blocks
   constexpr int TC_DUMP = (NM - 1) * LDK + LDK - 1;
@@ -160,9 +164,12 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
     // ---- this lane's elements of the symmetric matrices: (rr[g], cc[g]) of the upper tiles, and what they feed ---------------
     int rr[NG], cc[NG];
     bool inm[NG], up[NG];    // inside the m x m matrix; on or above the diagonal (the copy that is stored / mirrored)
-    int pcw0[NG], pcw1[NG];  // where the element goes in Pc (and its mirror image), or the dump slot
-    int pzw0[NG], pzw1[NG];  // where it goes in the P Z' panel: row r at the observation selecting c, row c at the one selecting r
-    double pzv0[NG], pzv1[NG];
+    constexpr int NT_ = LEAN ? 1 : NG;
+    int pcw0_[NT_], pcw1_[NT_];  // where the element goes in Pc (and its mirror image), or the dump slot
+    int pzw0[NG], pzw1[NG];      // where it goes in the P Z' panel: row r at the observation selecting c, row c at the one selecting r
+                                 // (LEAN: shifted left by four, the observation's index into zvt -- 8 = none -- in the low bits)
+    double pzv0_[NT_], pzv1_[NT_];
+    if (lane < 9) zvt[lane] = (lane < p) ? zv[lane] : 0.0;  // selector values by observation, zvt[8] = 0
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       int ta, tb;
@@ -173,9 +180,6 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       cc[g] = c;
       inm[g] = live && r < m && c < m;
       up[g] = live && r <= c;
-      const bool in_pc = up[g] && c < NS;  // (r <= c < NS)
-      pcw0[g] = in_pc ? r * LDK + c : PC_DUMP;
-      pcw1[g] = (in_pc && r < c) ? c * LDK + r : PC_DUMP;
       int oc = -1, orr = -1;
       double zc = 0.0, zr = 0.0;
       for (int o = 0; o < p; ++o) {
@@ -188,11 +192,29 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
           zr = zv[o];
         }
       }
-      pzw0[g] = (up[g] && inm[g] && oc >= 0) ? r * PS + oc : PZ_DUMP;
-      pzw1[g] = (up[g] && inm[g] && r < c && orr >= 0) ? c * PS + orr : PZ_DUMP;
-      pzv0[g] = zc;
-      pzv1[g] = zr;
+      const bool w0 = up[g] && inm[g] && oc >= 0, w1 = up[g] && inm[g] && r < c && orr >= 0;
+      if constexpr (LEAN) {
+        pzw0[g] = ((w0 ? r * PS + oc : PZ_DUMP) << 4) | (w0 ? oc : 8);
+        pzw1[g] = ((w1 ? c * PS + orr : PZ_DUMP) << 4) | (w1 ? orr : 8);
+      } else {
+        const bool in_pc = up[g] && c < NS;  // (r <= c < NS)
+        pcw0_[g] = in_pc ? r * LDK + c : PC_DUMP;
+        pcw1_[g] = (in_pc && r < c) ? c * LDK + r : PC_DUMP;
+        pzw0[g] = w0 ? r * PS + oc : PZ_DUMP;
+        pzw1[g] = w1 ? c * PS + orr : PZ_DUMP;
+        pzv0_[g] = zc;
+        pzv1_[g] = zr;
+      }
     }
+    auto pcw0 = [&](int g) {
+      if constexpr (LEAN) return (up[g] && cc[g] < NS) ? rr[g] * LDK + cc[g] : PC_DUMP;
+      else return pcw0_[g];
+    };
+    auto pcw1 = [&](int g) {
+      if constexpr (LEAN) return (up[g] && cc[g] < NS && rr[g] < cc[g]) ? cc[g] * LDK + rr[g] : PC_DUMP;
+      else return pcw1_[g];
+    };
+    wave_sync();
 
     // ---- T -> Tc (gathered: position -> original variable), Q and P in tile layout -----------------------------------------
     auto load_T = [&]() {
@@ -244,8 +266,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
 #define KMF_STORE_PC()                        \
   do {                                        \
     _Pragma("unroll") for (int g = 0; g < NG; ++g) { \
-      Pc[pcw0[g]] = Pt[g];                    \
-      Pc[pcw1[g]] = Pt[g];                    \
+      Pc[pcw0(g)] = Pt[g];                    \
+      Pc[pcw1(g)] = Pt[g];                    \
     }                                         \
   } while (0)
     if (!P0) {
@@ -307,8 +329,13 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
 #define KMF_STORE_PZT()                                 \
   do {                                                  \
     _Pragma("unroll") for (int g = 0; g < NG; ++g) {    \
-      PZt[pzw0[g]] = pzv0[g] * Pt[g];                   \
-      PZt[pzw1[g]] = pzv1[g] * Pt[g];                   \
+      if constexpr (LEAN) {                             \
+        PZt[pzw0[g] >> 4] = zvt[pzw0[g] & 15] * Pt[g];  \
+        PZt[pzw1[g] >> 4] = zvt[pzw1[g] & 15] * Pt[g];  \
+      } else {                                          \
+        PZt[pzw0[g]] = pzv0_[g] * Pt[g];                \
+        PZt[pzw1[g]] = pzv1_[g] * Pt[g];                \
+      }                                                 \
     }                                                   \
   } while (0)
     KMF_STORE_PZT();
@@ -343,14 +370,17 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
 #pragma unroll
       for (int q2 = 0; q2 < 4; ++q2) fr2[q2] = *reinterpret_cast<const double2*>(&PZt[r_zpos * PS + 2 * q2]);
       const double a_sel = av[r_zpos];
+      auto load_panel = [&]() {
 #pragma unroll
-      for (int ps = 0; ps < RP; ++ps) {
-        const int i = g8 + 8 * ps;
+        for (int ps = 0; ps < RP; ++ps) {
+          const int i = g8 + 8 * ps;
 #pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) pz2[ps][q2] = *reinterpret_cast<const double2*>(&PZt[i * PS + 2 * q2]);
-        pzo[ps] = PZt[i * PS + r8];
-        avi[ps] = av[i];
-      }
+          for (int q2 = 0; q2 < 4; ++q2) pz2[ps][q2] = *reinterpret_cast<const double2*>(&PZt[i * PS + 2 * q2]);
+          pzo[ps] = PZt[i * PS + r8];
+          avi[ps] = av[i];
+        }
+      };
+      if constexpr (!LEAN) load_panel();  // (LEAN: requested in phase (d) -- 72 registers less across the elimination)
       __builtin_amdgcn_sched_barrier(0);
       bool steady = false;
       double pm = 0.0;  // max |P_{t|t-1}| = the largest diagonal entry (P is positive semi-definite)
@@ -426,6 +456,7 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         tk0 = tk1;
       }
       // ---- (d) K = (P Zm') Finv, V = P Zm' + jit_V K (stored negated), a+ = a + K v -----------------------------------------
+      if constexpr (LEAN) load_panel();
 #pragma unroll
       for (int ps = 0; ps < RP; ++ps) {
         const int i = g8 + 8 * ps;
@@ -461,8 +492,9 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         if (steady_tol > 0.0) {
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
-            const double old = Pc[pcw0[g]];  // (dump slot for the elements outside the state block: compared with itself below)
-            dmax = fmax(dmax, (pcw0[g] != PC_DUMP) ? fabs(Pt[g] - old) : 0.0);
+            const int at = pcw0(g);
+            const double old = Pc[at];  // (the dump slot for the elements outside the state block: not compared)
+            dmax = fmax(dmax, (at != PC_DUMP) ? fabs(Pt[g] - old) : 0.0);
           }
           steady = (t > 0) && (__ballot(!(dmax <= steady_tol * pm)) == 0ull);
         }

@@ -182,8 +182,9 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   if (fast && z_selector_hint && opt().kalman_mfma == 2 && opt().kalman_nt_products && !want_tail && opt().kalman_head_draws == 0 &&
       n_state_hint >= 17 && n_state_hint <= 20 && !launched_fast) {
     using SMF = dsge::KmfSmem<5, 5>;
-    const bool stage_fits = !fold || (size_t)m * ((k_shocks + 1) & ~1) <= (size_t)SMF::WT;
-    if (stage_fits) {
+    using SMF7 = dsge::KmfSmem<5, 7>;
+    const size_t r_doubles = fold ? (size_t)m * ((k_shocks + 1) & ~1) : 0;
+    if (r_doubles <= (size_t)SMF::WT) {
       if (g_kalman_dbg) {
         if ((rc = set_lds(dsge::kalman_mf_kernel<5, 5, true>, SMF::bytes))) return rc;
         hipLaunchKernelGGL((dsge::kalman_mf_kernel<5, 5, true>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR,
@@ -197,6 +198,17 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                            missing_fill, opt().kalman_steady_tol, logp, status, (long long*)nullptr, 0, g_kalman_steady_at, order,
                            fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
       }
+      HIP_TRY(hipGetLastError());
+      launched_fast = true;
+    }
+    // observed non-states: up to n_state_hint + p retained variables -- seven tiles hold 28 of them (the draws the five-tile
+    // instance flagged; a second pass, which returns at once when nothing is flagged)
+    if (n_state_hint + p > 20 && n_state_hint < m && r_doubles <= (size_t)SMF7::WT && !g_kalman_dbg) {
+      if ((rc = set_lds(dsge::kalman_mf_kernel<5, 7, false>, SMF7::bytes))) return rc;
+      hipLaunchKernelGGL((dsge::kalman_mf_kernel<5, 7, false>), dim3(batch), dim3(64), SMF7::bytes, st, T, RQR,
+                         p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
+                         missing_fill, opt().kalman_steady_tol, logp, status, (long long*)nullptr, launched_fast ? 1 : 0,
+                         g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
       HIP_TRY(hipGetLastError());
       launched_fast = true;
     }

@@ -77,3 +77,23 @@ def lead_column_sweep_system(seed, colsum, n=12, n_state=5, n_lead=4, k=3):
     j = n - 1
     C[:, j] *= colsum / np.abs(C[:, j]).sum()
     return A, B, C, D
+
+
+def lapack_margins(A, B, C, D, tol=1e-8):
+    """(smallest singular value of Q2 @ pi, smallest max(|alpha_i|, |beta_i|) over the diagonal pairs) of LAPACK's ordered QZ of
+    gensys_setup's pencil (gensys.py:227-235, 243, 267-283): how far the reference's two absolute-tolerance tests are from tipping.
+    Both numbers depend on the ORDER in which LAPACK leaves the eigenvalues on the diagonal (swapping two pairs changes their
+    magnitudes, not their ratios), so another QZ -- the device's -- may name a system within a factor of a few of the tolerance
+    differently; the certificate's guards (spectral_division_model.scale_guards) are order-independent bounds."""
+    import scipy.linalg as sla
+
+    from oracle.gensys_qz import gensys_setup
+
+    g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
+    _, _, alpha, beta, Qraw, _ = sla.ordqz(g0.astype(complex), g1.astype(complex), sort="ouc", output="complex")
+    aa, bb = np.abs(alpha), np.abs(beta)
+    stable = ((bb < tol) & (aa >= tol)) | ((bb >= tol) & (aa > bb))
+    nu = int(np.sum(~stable))
+    Q2 = Qraw.conj().T[len(alpha) - nu:]
+    sv = sla.svd(Q2 @ pi, compute_uv=False) if nu > 0 and pi.shape[1] > 0 else np.array([1.0])
+    return float(np.min(sv)) if sv.size else 1.0, float(np.maximum(aa, bb).min())

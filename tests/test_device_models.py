@@ -291,11 +291,11 @@ def test_spectral_division_certificate_never_contradicts_gensys():
 
 
 def _q2pi_lapack(A, B, C, D, tol=1e-8):
-    """Singular values of Q2 @ pi from LAPACK's ordered QZ of gensys_setup's pencil (gensys.py:227-235, 267-273), and the smallest
-    max(|alpha_i|, |beta_i|) over the diagonal pairs (the zxz test of :243)."""
+    """(sorted singular values of Q2 @ pi, smallest diagonal pair) from LAPACK's ordered QZ (gensys.py:227-235, 243, 267-273)."""
     import scipy.linalg as sla
 
     from oracle.gensys_qz import gensys_setup
+    from tests.device_models.scale_cases import lapack_margins
 
     g0, g1, c, psi, pi = gensys_setup(A, B, C, D, tol)
     _, _, alpha, beta, Qraw, _ = sla.ordqz(g0.astype(complex), g1.astype(complex), sort="ouc", output="complex")
@@ -303,7 +303,9 @@ def _q2pi_lapack(A, B, C, D, tol=1e-8):
     stable = ((bb < tol) & (aa >= tol)) | ((bb >= tol) & (aa > bb))
     nu = int(np.sum(~stable))
     Q2 = Qraw.conj().T[len(alpha) - nu :]
-    return np.sort(sla.svd(Q2 @ pi, compute_uv=False)), float(np.maximum(aa, bb).min())
+    sv = np.sort(sla.svd(Q2 @ pi, compute_uv=False))
+    assert abs(lapack_margins(A, B, C, D, tol)[0] - sv[0]) <= 1e-12 * max(1.0, sv[0])
+    return sv, float(np.maximum(aa, bb).min())
 
 
 def test_q2pi_singular_values_closed_form_vs_lapack():

@@ -85,11 +85,13 @@ def _variants_for(cv):
 
 # the routes of dsge_kalman_logp_batched: (label, options, hints)
 SW_ROUTES = [
-    ("nt", {}, {}),                                            # kalman_nt_kernel<3, false, 24> (the headline kernel)
+    ("mf", {}, {}),                                            # kalman_mf_kernel<5, 5> (round 6: the headline kernel, tile layout)
+    ("mf_steady_off", {"kalman_steady_tol": 0.0}, {}),         # ... the full recursion, step for step
+    ("nt", {"kalman_mfma": 0}, {}),                            # kalman_nt_kernel<3, false, 24> (the VALU products; round 2-5 default)
     ("sel", {"kalman_nt_products": 0}, {}),                    # kalman_sel_kernel<3, true>
     ("sel+tail", {"kalman_nt_products": 0, "kalman_block": 1}, {}),   # ... handing the steady tail to kalman_tail_kernel
     ("general", {}, {"n_state_hint": 0, "z_selector_hint": 0}),  # no hints: kalman_sel_kernel<5, false> dense-Z fast path
-    ("steady_off", {"kalman_steady_tol": 0.0}, {}),            # the full recursion, step for step
+    ("steady_off", {"kalman_steady_tol": 0.0, "kalman_mfma": 0}, {}),  # the full recursion, step for step
     ("nt2", {"kalman_head_draws": -1}, {}),                    # kalman_nt2_kernel<3, 24>: two wavefronts per draw
     ("nt2_steady_off", {"kalman_head_draws": -1, "kalman_steady_tol": 0.0}, {}),
 ]
