@@ -191,7 +191,7 @@ PMC_LEGS = {  # kernels of one fused step, by leg: alternative GROUPS of rocprof
     "solver": (("cr_fused_kernel",), ("cr_deflate_kernel", "cr_compact_kernel", "cr_inflate_kernel"), ("cr_compact_kernel",),
                ("cr_solve_kernel",)),
     "assemble": (("rqr_kernel",),),
-    "kalman": (("kalman_nt_kernel",), ("kalman_sel_kernel",)),
+    "kalman": (("kalman_mf_kernel",), ("kalman_nt_kernel",), ("kalman_sel_kernel",)),
 }
 
 
@@ -224,6 +224,10 @@ def load_pmc():
                 legs[leg] = {"kernels": [nm for nm, _ in chosen],
                              "fp64_flops": sum(v.get("fp64_flops", 0.0) for _, v in chosen),
                              "hbm_bytes": sum(v.get("hbm_bytes", 0.0) for _, v in chosen),
+                             "mfma_insts": sum(v.get("SQ_INSTS_VALU_MFMA_F64", 0.0) for _, v in chosen),
+                             "mfma_busy_cycles": sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for _, v in chosen),
+                             "valu_insts": sum(v.get("SQ_INSTS_VALU", 0.0) for _, v in chosen),
+                             "avg_ns": sum(v.get("avg_ns", 0.0) for _, v in chosen),
                              "lds_conflict_share": max((v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
                                                         for _, v in chosen), default=0.0)}
                 break
@@ -274,8 +278,12 @@ def roofline_block(kern, dom, kms, pmc_src, flops, ex, nloc, total_kernel_s, b_e
     return {
         "kernel": k["kernel"],
         "bound": "valu-latency",
-        "pipe": ("fp64 VALU (v_fma_f64; no MFMA issued: SQ_INSTS_VALU_MFMA_F64 = 0).  Neither HBM- nor MFMA-bound: a dependent "
-                 "chain per draw at 1-2 waves per SIMD"),
+        "pipe": (("fp64 VALU + FP64 matrix core: the downdate and both prediction products of a full filter step are v_mfma_f64_4x4x4f64 "
+                  "issues (63 per step on the SW-shaped model), the update's 7 x 7 elimination and the steady-state mean recursion are "
+                  "VALU.  Neither HBM- nor MFMA-bound: a dependent chain per draw at two waves per SIMD")
+                 if "kalman_mf_kernel" in k["kernel"] else
+                 ("fp64 VALU (v_fma_f64; no MFMA issued in this kernel).  Neither HBM- nor MFMA-bound: a dependent chain per draw at "
+                  "1-2 waves per SIMD")),
         "achieved": achieved,
         "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -991,6 +999,7 @@ def main():
         one_launch = (h_defl and nd_ + k <= 64 and
                       ((ncol_ <= 128 and (bs_n, bs_d) in {(3, 2), (3, 3), (4, 3), (4, 4), (5, 4), (6, 4), (6, 5)}) or
                        (128 < ncol_ <= 192 and (bs_n, bs_d) in {(6, 5), (7, 5), (7, 6), (8, 6)})))
+        mf_default = __import__('geconpy_amd._lib', fromlist=['make_options']).make_options().kalman_mfma == 2
         names = {"solver": ((f"dsge::cr_fused_kernel{'_occ2' if bs_d == 4 and ncol_ <= 128 else ''}<{bs_n},{bs_d}> (static-variable deflation {n} -> {nd_}: "
                              "QR of the static columns + cycle reduction + back-substitution, one launch)") if one_launch else
                             (f"dsge::cr_deflate_kernel<{bs_n}> + cr_compact_kernel<{bs_d}> + cr_inflate_kernel<{bs_d}> (static-variable "
@@ -1001,7 +1010,10 @@ def main():
                                "draws handed on to the general filter)") if folds_rqr else
                               "dsge::rqr_kernel<16>" if (args.solver == "cycle_reduction" and k <= 16)
                               else f"dsge::assemble_kernel<{(n + 7) // 8}>"),
-                 "kalman": (f"dsge::kalman_nt_kernel<{(u_dim + 7) // 8}>" if hints[1] and p <= 8
+                 "kalman": ((f"dsge::kalman_mf_kernel<5,{5 if u_dim <= 20 else 7}> (covariance in the tile layout of v_mfma_f64_4x4x4f64: downdate "
+                             f"and both prediction products on the FP64 matrix core)")
+                            if (hints[1] and p <= 8 and 17 <= hints[0] <= 20 and u_dim <= 28 and mf_default) else
+                            f"dsge::kalman_nt_kernel<{(u_dim + 7) // 8}>" if hints[1] and p <= 8
                             else f"dsge::kalman_sel_kernel<{(u_dim + 7) // 8},{'true' if hints[1] else 'false'}>")}
         kern = {}
         for key in ("solver", "assemble", "kalman"):
@@ -1018,6 +1030,13 @@ def main():
                 "counted_tflops": round(leg["fp64_flops"] / sec / 1e12, 3) if leg else None,
                 "hbm_bytes_per_launch": round(leg["hbm_bytes"]) if leg else None,
                 "lds_conflict_share": round(leg["lds_conflict_share"], 3) if leg else None,
+                # FP64 matrix-core evidence from the committed counters (north_star: "MFMA only for the F P F' products of the
+                # Kalman recursion"): wave-level MFMA instructions per launch, their share of the VALU instruction stream, and the
+                # busy share of the 1024 SIMDs' matrix pipes over the committed launch duration at 2.4 GHz
+                "mfma_insts_per_launch": round(leg["mfma_insts"]) if leg else None,
+                "mfma_share_of_valu_insts": round(leg["mfma_insts"] / leg["valu_insts"], 4) if leg and leg.get("valu_insts") else None,
+                "mfma_busy": (round(leg["mfma_busy_cycles"] / (1024 * leg["avg_ns"] * 2.4), 4)
+                              if leg and leg.get("avg_ns") else None),
             }
         dom = max(kern, key=lambda k_: kern[k_]["ms"])
         total_kernel_s = sum(kms.values()) * 1e-3

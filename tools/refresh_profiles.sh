@@ -1,8 +1,9 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): the bench lines, rocprofv3 kernel statistics and counters that profiles/r5/ keeps.
-# Usage: bash tools/refresh_profiles.sh [tag]   (then copy gpurun_out/<tag>/* into profiles/r5/)
+# Run on the GPU box (through gpurun): the bench lines, rocprofv3 kernel statistics and counters that profiles/r<N>/ keeps.
+# Usage: bash tools/refresh_profiles.sh [tag] [round dir, default r6]   (then copy gpurun_out/<tag>/* into profiles/<round dir>/)
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
+RND=${2:-r6}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -31,12 +32,14 @@ unset DSGE_GENSYS_DOUBLING
 python3 tools/pmc_collect.py "$OUT/pmc_so" -- --workload sw_second_order --no-extras > "$OUT/pmc_so.txt" 2>&1 && cp "$OUT/pmc_so/pmc_counters.json" "$OUT/pmc_counters_sw_second_order.json"
 rm -rf "$OUT/pmc_default" "$OUT/pmc_gensys" "$OUT/pmc_gensys_sd" "$OUT/pmc_so"
 # the roofline blocks quote flops / traffic from the counters committed under profiles/: take the lines after they are refreshed
-mkdir -p profiles/r5
-cp "$OUT/pmc_counters_sw_second_order.json" "$OUT/pmc_counters.json" "$OUT/pmc_counters_gensys.json" "$OUT/pmc_counters_gensys_spectral_division.json" profiles/r5/ 2>/dev/null
+mkdir -p profiles/$RND
+cp "$OUT/pmc_counters_sw_second_order.json" "$OUT/pmc_counters.json" "$OUT/pmc_counters_gensys.json" "$OUT/pmc_counters_gensys_spectral_division.json" profiles/$RND/ 2>/dev/null
 python3 bench.py --workload sw_second_order > "$OUT/bench_sw_second_order.json" 2> "$OUT/bench_sw_second_order.err"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
+# (the window kernels run on every draw only with the ordered QZ for every draw: under the default route the phase counters of draw 0 stay zero)
+DSGE_GENSYS_DOUBLING=0 python3 tools/gensys_window_phases.py > "$OUT/gensys_window_phases.txt" 2>&1
 python3 tools/kalman_phases.py > "$OUT/kalman_phases.txt" 2>&1
+python3 tools/mfma_ab.py > "$OUT/mfma_ab.txt" 2>&1
 python3 tools/two_streams.py > "$OUT/two_streams.txt" 2>&1
 python3 tools/grad_rate.py > "$OUT/grad_rate.txt" 2>&1
 python3 tools/grad_rate.py 4096 gensys >> "$OUT/grad_rate.txt" 2>&1
