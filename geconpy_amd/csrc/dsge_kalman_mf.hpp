@@ -34,7 +34,7 @@ struct KmfSmem {
   static constexpr int RP = NR / 8, PS = 10;
   static constexpr int WT = NM * LDK > NR * PS ? NM * LDK : NR * PS;  // W' buffer; the -V panel and the staged R alias it
   // doubles: Tc NM*LDK, Wt WT, Pc NS*LDK, PZt, Ks NR*PS each, av, af NR each, vv/dd/hh/zv 8 each; ints perm NR, zpos 8
-  static constexpr size_t doubles = (size_t)NM * LDK + WT + (size_t)NS * LDK + 2 * (size_t)NR * PS + 2 * NR + 2 + 42 + NR / 2 + 4;
+  static constexpr size_t doubles = (size_t)NM * LDK + WT + (size_t)NS * LDK + 2 * (size_t)NR * PS + 2 * NR + 4 + 42 + NR / 2 + 4;
   static constexpr size_t bytes = sizeof(double) * doubles;
 };
 
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
   double* Ks = PZt + NR * PS;       // NR x PS    K = P Zm' Finv
   double* av = Ks + NR * PS;        // NR + 2     predicted state (+ the dump slot of the mean's store)
   double* avd = av;
-  double* af = av + NR + 2;         // NR         filtered state
-  double* vv = af + NR;             // 8 innovation
+  double* af = av + NR + 2;         // NR + 2     filtered state (+ a dump slot)
+  double* vv = af + NR + 2;         // 8 innovation
   double* dd = vv + 8;              // 8 obs intercept
   double* hh = dd + 8;              // 8 diag(H)
   double* zv = hh + 8;              // 8 selector values
@@ -206,6 +206,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         pzv1_[g] = zr;
       }
     }
+    int rowa[NG], rowb[NG];  // operand rows of this lane's block in the three upper-tile products (computed once: mfma4_nt_upper_acc)
+    mfma4_upper_rows<TM>(lane, rowa, rowb);
     auto pcw0 = [&](int g) {
       if constexpr (LEAN) return (up[g] && cc[g] < NS) ? rr[g] * LDK + cc[g] : PC_DUMP;
       else return pcw0_[g];
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         mfma4_nn<KT, TM, KT, LDK>(Tc, Tc, lane, [&](int g, double d) { a2r[g] = d; });  // A_k[:,S] A_k[S,:]
         wave_sync();
         double dmax = 0.0, pmax = 0.0;
-        mfma4_nt_upper<KT, TM, LDK>(Tc, Wt, lane, [&](int g, double d, int, int, bool) {
+        mfma4_nt_upper_acc<KT, TM, LDK>(Tc, Wt, lane, rowa, rowb, [](int) { return 0.0; }, [&](int g, double d) {
           const double dlt = inm[g] ? d : 0.0;
           Pt[g] += dlt;
           dmax = nanmax(dmax, fabs(dlt));
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         part += dpp_move_f64<0xB1, 0xf>(part);
         part += dpp_move_f64<0x4E, 0xf>(part);
         part += dpp_move_f64<0x141, 0xf>(part);
-        if (r8 == 0) af[i] = avi[ps] + part;
+        af[(r8 == 0) ? i : NR] = avi[ps] + part;  // (entry NR: a slot for the lanes that own nothing -- no branch)
       }
       wave_sync();  // #2
       if constexpr (DBG) {
@@ -484,17 +486,27 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       // ---- (e) P+ = P + K (-V)' + jit_P I on the matrix core (C = P), then the state block -> Pc (full square) ---------------
       {
         double dmax = 0.0;
-        mfma4_nt_upper_acc<2, TM, PS>(Ks, Vs, lane, [&](int g) { return Pt[g]; },
-                                      [&](int g, double d, int, int, bool) {
+        mfma4_nt_upper_acc<2, TM, PS>(Ks, Vs, lane, rowa, rowb, [&](int g) { return Pt[g]; },
+                                      [&](int g, double d) {
                                         const double pn = inm[g] ? d + ((rr[g] == cc[g]) ? cv.jit_P : 0.0) : 0.0;
                                         Pt[g] = pn;
                                       });
         if (steady_tol > 0.0) {
+          // (the old values are read UNCONDITIONALLY and together -- volatile: under the predicate the compiler turned each read into
+          //  a branch with its own wait, four LDS round trips in a row)
+          if constexpr (!LEAN) {
+            double oldv[NG];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const int at = pcw0(g);
-            const double old = Pc[at];  // (the dump slot for the elements outside the state block: not compared)
-            dmax = fmax(dmax, (at != PC_DUMP) ? fabs(Pt[g] - old) : 0.0);
+            for (int g = 0; g < NG; ++g) oldv[g] = *reinterpret_cast<const volatile double*>(&Pc[pcw0(g)]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) dmax = fmax(dmax, (pcw0(g) != PC_DUMP) ? fabs(Pt[g] - oldv[g]) : 0.0);
+          } else {  // (seven groups: one at a time, the registers are needed elsewhere)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              const int at = pcw0(g);
+              const double old = *reinterpret_cast<const volatile double*>(&Pc[at]);
+              dmax = fmax(dmax, (at != PC_DUMP) ? fabs(Pt[g] - old) : 0.0);
+            }
           }
           steady = (t > 0) && (__ballot(!(dmax <= steady_tol * pm)) == 0ull);
         }
@@ -534,8 +546,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         ph[3] += tk1 - tk0;
         tk0 = tk1;
       }
-      mfma4_nt_upper_acc<KT, TM, LDK>(Tc, Wt, lane, [&](int g) { return Qt[g]; },
-                                      [&](int g, double d, int, int, bool) {
+      mfma4_nt_upper_acc<KT, TM, LDK>(Tc, Wt, lane, rowa, rowb, [&](int g) { return Qt[g]; },
+                                      [&](int g, double d) {
                                         // column m: the predicted mean (Q is zero there); everything else outside m x m: padding
                                         const bool is_mean = fold_a && cc[g] == m && rr[g] < m && up[g];
                                         avd[is_mean ? rr[g] : NR] = is_mean ? d : 0.0;  // (entry NR: a slot of its own for the rest)

@@ -130,24 +130,24 @@ struct Mfma4Upper {
   }
 };
 
-// D[r][c] (+ init(g)) for the tiles ta <= tb only; sink(g, d, ta, tb, live): this lane's element is D[4 ta + (l >> 4)][4 tb + (l & 3)].
-// The operands of group g + 1 are requested before the issues of group g.  init(g): the accumulator's starting value (the lane's
-// element of C in D = A B' + C).
+// D[r][c] (+ init(g)) for the tiles ta <= tb only; sink(g, d): this lane's element is D[4 ta + (l >> 4)][4 tb + (l & 3)] of the tile
+// (ta, tb) = Mfma4Upper<TM>::tile(g, blk).  The caller passes the operand rows of its block per group -- rowa[g] = 4 ta + (l & 3),
+// rowb[g] = 4 tb + (l & 3) -- computed ONCE (the select chains of tile() compile to branches: recomputed per call they cost more
+// than the issues they feed).  The operands of group g + 1 are requested before the issues of group g.  init(g): the accumulator's
+// starting value (the lane's element of C in D = A B' + C).
 template <int KT, int TM, int LD, class Init, class Sink>
-__device__ __forceinline__ void mfma4_nt_upper_acc(const double* __restrict__ A, const double* __restrict__ B, int lane, Init&& init,
-                                                   Sink&& sink) {
+__device__ __forceinline__ void mfma4_nt_upper_acc(const double* __restrict__ A, const double* __restrict__ B, int lane,
+                                                   const int (&rowa)[Mfma4Upper<TM>::NG], const int (&rowb)[Mfma4Upper<TM>::NG],
+                                                   Init&& init, Sink&& sink) {
   using UX = Mfma4Upper<TM>;
-  constexpr int NPAIR = KT / 2, ODD = KT & 1, NOP = NPAIR + ODD, NG = UX::NG;
-  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  constexpr int NPAIR = KT / 2, ODD = KT & 1, NG = UX::NG;
+  const int kq = lane >> 4;
   double2 a2[2][NPAIR > 0 ? NPAIR : 1], b2[2][NPAIR > 0 ? NPAIR : 1];
   double a1[2] = {0.0, 0.0}, b1[2] = {0.0, 0.0};
-  int ta[2], tb[2];
-  bool live[2];
 #define MFMA4_UP_LOAD(G_, S_)                                                                \
   do {                                                                                       \
-    UX::tile(G_, blk, ta[S_], tb[S_], live[S_]);                                             \
-    const double* ap_ = A + (4 * ta[S_] + i4) * LD;                                          \
-    const double* bp_ = B + (4 * tb[S_] + i4) * LD;                                          \
+    const double* ap_ = A + rowa[G_] * LD;                                                   \
+    const double* bp_ = B + rowb[G_] * LD;                                                   \
     _Pragma("unroll") for (int c = 0; c < NPAIR; ++c) {                                      \
       a2[S_][c] = *reinterpret_cast<const double2*>(ap_ + 8 * c + 2 * kq);                   \
       b2[S_][c] = *reinterpret_cast<const double2*>(bp_ + 8 * c + 2 * kq);                   \
@@ -169,9 +169,23 @@ __device__ __forceinline__ void mfma4_nt_upper_acc(const double* __restrict__ A,
       acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[cur][c].y, b2[cur][c].y, acc1, 0, 0, 0);
     }
     if (ODD) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[cur], b1[cur], acc0, 0, 0, 0);
-    sink(g, NPAIR > 0 ? acc0 + acc1 : acc0, ta[cur], tb[cur], live[cur]);
+    sink(g, NPAIR > 0 ? acc0 + acc1 : acc0);
   }
 #undef MFMA4_UP_LOAD
+}
+
+// operand rows of this lane's block for every group of the upper-tile map (see mfma4_nt_upper_acc)
+template <int TM>
+__device__ __forceinline__ void mfma4_upper_rows(int lane, int (&rowa)[Mfma4Upper<TM>::NG], int (&rowb)[Mfma4Upper<TM>::NG]) {
+  const int blk = (lane >> 2) & 3, i4 = lane & 3;
+#pragma unroll
+  for (int g = 0; g < Mfma4Upper<TM>::NG; ++g) {
+    int ta, tb;
+    bool live;
+    Mfma4Upper<TM>::tile(g, blk, ta, tb, live);
+    rowa[g] = 4 * ta + i4;
+    rowb[g] = 4 * tb + i4;
+  }
 }
 
 // D = A B (NN form: B row-major along its COLUMNS, B[k][c]) for all TA x TB tiles: the doubling iteration's A_k[:,S] A_k[S,:].
@@ -200,9 +214,19 @@ __device__ __forceinline__ void mfma4_nn(const double* __restrict__ A, const dou
   }
 }
 
+// D[r][c] for the upper tiles, no accumulator input; sink(g, d, ta, tb, live) (convenience form: computes the rows itself)
 template <int KT, int TM, int LD, class Sink>
 __device__ __forceinline__ void mfma4_nt_upper(const double* __restrict__ A, const double* __restrict__ B, int lane, Sink&& sink) {
-  mfma4_nt_upper_acc<KT, TM, LD>(A, B, lane, [](int) { return 0.0; }, sink);
+  using UX = Mfma4Upper<TM>;
+  int rowa[UX::NG], rowb[UX::NG];
+  mfma4_upper_rows<TM>(lane, rowa, rowb);
+  const int blk = (lane >> 2) & 3;
+  mfma4_nt_upper_acc<KT, TM, LD>(A, B, lane, rowa, rowb, [](int) { return 0.0; }, [&](int g, double d) {
+    int ta, tb;
+    bool live;
+    UX::tile(g, blk, ta, tb, live);
+    sink(g, d, ta, tb, live);
+  });
 }
 
 }  // namespace dsge
