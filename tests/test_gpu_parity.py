@@ -1199,10 +1199,13 @@ def test_kalman_mfma_products_match_valu():
 
 @pytest.mark.parametrize("m,k,p,ns,states_only", [(40, 7, 7, 18, True), (40, 7, 7, 18, False), (40, 7, 3, 17, False),
                                                    (30, 5, 8, 20, True), (24, 4, 2, 19, False), (28, 6, 6, 17, True),
-                                                   (40, 7, 7, 16, True), (40, 7, 7, 21, True)])
+                                                   (40, 7, 7, 16, True), (40, 7, 7, 21, True),
+                                                   # KT = 3 and 4 (9 .. 16 state variables), with and without observed non-states
+                                                   (24, 4, 3, 9, True), (24, 4, 3, 9, False), (30, 5, 4, 12, False),
+                                                   (30, 5, 6, 14, True), (36, 6, 5, 16, False), (20, 3, 8, 13, False)])
 def test_kalman_mf_kernel_matches_valu_kernels(m, k, p, ns, states_only):
-    """kalman_mf_kernel<5, 5> (round 6: the covariance in the tile layout of the 4 x 4 x 4 FP64 matrix instruction; default for 17 ..
-    20 state variables) against the VALU kernels (dsge_options.kalman_mfma = 0) and the oracle: selector values other than 1,
+    """kalman_mf_kernel<KT, TM> (round 6: the covariance in the tile layout of the 4 x 4 x 4 FP64 matrix instruction; default for 9 ..
+    20 state variables: KT = 3, 4, 5 tiles, TM = KT or KT + 2) against the VALU kernels (dsge_options.kalman_mfma = 0) and the oracle: selector values other than 1,
     d != 0, NaN and fill-marker missing data, full recursion and steady-state switch, observed non-states.  With Z on arbitrary
     variables the retained set exceeds 20 for some sizes: those draws are handed on to the VALU cascade by the kernel itself, and
     the hint sizes 16 / 21 never reach it -- the results must not care."""
