@@ -149,6 +149,12 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr,
                   const double* Rsel = nullptr, const double* qdiag = nullptr, int q_batched = 0, int k_shocks = 0,
                   const unsigned long long* colmask = nullptr);
+// launch_kalman_mf.hip: the tile-layout filter kernel (dsge_kalman_mf.hpp) in front of launch_kalman's cascade
+int launch_kalman_mf(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched, const double* d,
+                     int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
+                     dsge::FilterConv cv, double missing_fill, int n_state_hint, double* logp, int32_t* status, hipStream_t st,
+                     const int32_t* order, const double* Rsel, const double* qdiag, int q_batched, int k_shocks,
+                     const unsigned long long* colmask, int* launched, bool* covers);
 int launch_kalman_outputs(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched, const double* d,
                           int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                           double jitter, double missing_fill, double* ll, double* a_pred, double* a_filt, double* p_pred,

@@ -418,7 +418,11 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
           double rowj[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) rowj[q] = readlane_f64(fr[q], j);
-          const double inv = fast_rcp(rowj[j]);
+          // (ONE Newton step on v_rcp_f64: 2.2e-15 relative, tools/latency_probe/rcp_probe.hip -- the multipliers and the final
+          //  row scaling of a 7 x 7 inverse whose conditioning costs more digits than that; the determinant takes the pivots
+          //  themselves.  Two dependent FMAs less on the chain of every pivot)
+          double inv = __builtin_amdgcn_rcp(rowj[j]);
+          inv = inv * fma(-rowj[j], inv, 2.0);
           const bool is_j = (r8 == j);
           const double ci = is_j ? 0.0 : fr[j] * inv;
 #pragma unroll

@@ -9,7 +9,6 @@
 #include "dsge_kalman2.hpp"
 #include "dsge_kalman_nt.hpp"
 #include "dsge_kalman_nt2.hpp"
-#include "dsge_kalman_mf.hpp"
 #include "dsge_kalman_tail.hpp"
 #include "dsge_kalman_tiny.hpp"
 
@@ -175,48 +174,18 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
     HIP_TRY(hipGetLastError());
     return DSGE_SUCCESS;
   };
-  // Round 6: the covariance in the tile layout of the FP64 matrix core's 4 x 4 x 4 instruction (dsge_kalman_mf.hpp) -- downdate and
-  // both prediction products as matrix issues (63 per full step on the SW-shaped model).  Instances by the caller's hint: KT = tiles
-  // of four holding the state block (9 .. 20 state variables: KT = 3, 4, 5), TM = KT tiles for the retained variables first and,
-  // when observed non-states may add to them (n_state_hint + p beyond 4 KT), TM = KT + 2 as a second pass on the draws the first
-  // flagged.  The kernel checks every draw and flags what does not fit for the cascade below, which then runs as further passes.
-  // dsge_options.kalman_mfma = 2 (default); 0: the VALU kernels.
+  // Round 6: the covariance in the tile layout of the FP64 matrix core's 4 x 4 x 4 instruction (launch_kalman_mf.hip, dsge_kalman_mf.hpp)
+  bool mf_covers = false;  // the tile-layout instances launched cover everything the VALU cascade below could take
   if (fast && z_selector_hint && opt().kalman_mfma == 2 && opt().kalman_nt_products && !want_tail && opt().kalman_head_draws == 0 &&
       n_state_hint >= 9 && n_state_hint <= 20 && !launched_fast) {
-    const size_t r_doubles = fold ? (size_t)m * ((k_shocks + 1) & ~1) : 0;
-    auto launch_mf = [&](auto kt_tag, auto tm_tag, auto dbg_tag) -> int {
-      constexpr int KTV = decltype(kt_tag)::value, TMV = decltype(tm_tag)::value;
-      constexpr bool DBGV = decltype(dbg_tag)::value;
-      using SMF = dsge::KmfSmem<KTV, TMV>;
-      if (r_doubles > (size_t)SMF::WT) return DSGE_SUCCESS;  // the staged selection matrix does not fit this instance's W' buffer
-      int rc2;
-      if ((rc2 = set_lds(dsge::kalman_mf_kernel<KTV, TMV, DBGV>, SMF::bytes))) return rc2;
-      hipLaunchKernelGGL((dsge::kalman_mf_kernel<KTV, TMV, DBGV>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR,
-                         p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
-                         missing_fill, opt().kalman_steady_tol, logp, status, DBGV ? g_kalman_dbg : (long long*)nullptr,
-                         launched_fast ? 1 : 0, g_kalman_steady_at, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks, colmask);
-      HIP_TRY(hipGetLastError());
-      launched_fast = true;
-      return DSGE_SUCCESS;
-    };
-    using std::integral_constant;
-    const int kt = (n_state_hint + 3) / 4;
-    const bool wide = n_state_hint + p > 4 * kt && n_state_hint < m;  // observed non-states may exceed the KT x KT instance
-    if (g_kalman_dbg) {  // (tools/kalman_phases.py: the stamped instance of the SW-shaped size)
-      if (kt == 5) rc = launch_mf(integral_constant<int, 5>{}, integral_constant<int, 5>{}, std::true_type{});
-    } else if (kt == 5) {
-      rc = launch_mf(integral_constant<int, 5>{}, integral_constant<int, 5>{}, std::false_type{});
-      if (!rc && wide) rc = launch_mf(integral_constant<int, 5>{}, integral_constant<int, 7>{}, std::false_type{});
-    } else if (kt == 4) {
-      rc = launch_mf(integral_constant<int, 4>{}, integral_constant<int, 4>{}, std::false_type{});
-      if (!rc && wide) rc = launch_mf(integral_constant<int, 4>{}, integral_constant<int, 6>{}, std::false_type{});
-    } else {
-      rc = launch_mf(integral_constant<int, 3>{}, integral_constant<int, 3>{}, std::false_type{});
-      if (!rc && wide) rc = launch_mf(integral_constant<int, 3>{}, integral_constant<int, 5>{}, std::false_type{});
-    }
-    if (rc) return rc;
+    int launched = 0;
+    if ((rc = launch_kalman_mf(T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
+                               missing_fill, n_state_hint, logp, status, st, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks,
+                               colmask, &launched, &mf_covers)))
+      return rc;
+    launched_fast = launched_fast || launched > 0;
   }
-  if (fast) {
+  if (fast && !mf_covers) {
     // The fast kernel filters only the variables that matter (states + observed non-states), so its
     // tile size follows that reduced dimension u, not m.  u is only known per draw on the device
     // (n_state_hint <= u <= n_state_hint + p for a selector), so the instances are tried smallest
