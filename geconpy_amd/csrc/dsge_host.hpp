@@ -148,13 +148,14 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key = nullptr,
                   const double* Rsel = nullptr, const double* qdiag = nullptr, int q_batched = 0, int k_shocks = 0,
-                  const unsigned long long* colmask = nullptr);
+                  const unsigned long long* colmask = nullptr,
+                  int rerun_all = 0);  // 1: every launch is a second pass -- only the draws flagged DSGE_ST_INTERNAL_RERUN are filtered
 // launch_kalman_mf.hip: the tile-layout filter kernel (dsge_kalman_mf.hpp) in front of launch_kalman's cascade
 int launch_kalman_mf(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched, const double* d,
                      int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                      dsge::FilterConv cv, double missing_fill, int n_state_hint, double* logp, int32_t* status, hipStream_t st,
                      const int32_t* order, const double* Rsel, const double* qdiag, int q_batched, int k_shocks,
-                     const unsigned long long* colmask, int* launched, bool* covers);
+                     const unsigned long long* colmask, int rerun_first, int* launched, bool* covers);
 int launch_kalman_outputs(const double* T, const double* RQR, const double* P0, const double* Z, int z_batched, const double* d,
                           int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                           double jitter, double missing_fill, double* ll, double* a_pred, double* a_filt, double* p_pred,
@@ -175,12 +176,23 @@ int launch_grad_assemble(const double* B, const double* C, const double* T, cons
                          double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st,
                          const double* Rbar_in = nullptr);  // Rbar_in: pullback of R = -(C T + B)^-1 D alone (Tbar written)
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
+// gensys by spectral division with the verdict next to the filter (round 6; launch_gensys.hip::launch_gensys_doubling)
+struct GensysOverlap {
+  hipStream_t st = nullptr;       // in: the verdict's stream (a library stream of the calling thread)
+  hipEvent_t fork = nullptr;      // in: event the verdict stream waits for (recorded on the caller's stream behind the iteration)
+  int32_t* status = nullptr;      // in: [batch] status words the verdict works on
+  const int32_t* marks = nullptr; // out: [batch], non-zero = the verdict re-solved (or rejected) the draw
+  int used = 0;                   // out: 1 = the verdict was forked
+};
+int launch_gensys_overlap_merge(int batch, const int32_t* marks, const int32_t* vstatus, int32_t* status, double* logp,
+                                hipStream_t st);
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg = nullptr,
                   int32_t* key_out = nullptr, int* key_written = nullptr,  // key_out: Kalman dispatch key from the QZ spectrum
                                                                            // (window path only: *key_written tells)
                   const double* D = nullptr, int k = 0, double* R_tmp = nullptr, int n_state_hint = 0,
-                  const int32_t** qz_marks = nullptr);  // *qz_marks: [batch], non-zero = the ordered QZ solved the draw (R_tmp is not its R)
+                  const int32_t** qz_marks = nullptr,  // *qz_marks: [batch], non-zero = the ordered QZ solved the draw (R_tmp is not its R)
+                  GensysOverlap* ov = nullptr);
 // (D, k, R_tmp, n_state_hint: only for dsge_options.gensys_doubling -- with them the doubling iteration runs as the one-launch
 //  deflated cycle reduction, whose final elimination needs a right-hand side; R_tmp is scratch, [batch][n][k])
 

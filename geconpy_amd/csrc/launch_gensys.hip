@@ -282,12 +282,18 @@ int launch_gensys_bk(const double* A, const double* B, const double* C, int batc
 // gensys by spectral division (dsge_gensys_doubling.hpp, dsge_options.gensys_doubling): cycle reduction for every draw, a
 // certificate of eu = [1, 1, 0] per draw, the ordered QZ (single-launch kernel, flagged draws only) for everything else.
 // *done = 0: not applicable (sizes) -- the caller runs the QZ path on the whole batch.
+// Round 6, `ov` (optional): the VERDICT -- certificate, compaction, the ordered QZ of the draws without a certificate -- runs on a
+// second stream next to what the caller enqueues behind this call on `st` (the filter of every draw with the doubling iteration's T
+// and R): ov->st is forked from `st` behind the iteration, works on ov->status (a copy of the iteration's status words: the filter
+// reads and writes `status` meanwhile) and leaves in ov->marks which draws it re-solved.  The caller joins, merges the two status
+// arrays and re-runs the filter on the marked draws (dsge_api.hip::pipeline).
 static int launch_gensys_doubling(const double* A, const double* B, const double* C, const double* D, int k, double* R_tmp,
                                   int batch, int n, double tol, int n_lead_hint, int n_state_hint, double* T_out, int32_t* eu_out,
                                   int32_t* status, hipStream_t st, int32_t* key_out, int* key_written, int* done,
-                                  const int32_t** qz_marks) {
+                                  const int32_t** qz_marks, GensysOverlap* ov) {
   *done = 0;
   if (qz_marks) *qz_marks = nullptr;
+  if (ov) ov->used = 0;
   int rc;
   int rescue_ncap = 0, rescue_lcap = 0;
   if (gensys_caps(n, n_lead_hint, &rescue_ncap, &rescue_lcap) != DSGE_SUCCESS) return DSGE_SUCCESS;  // no QZ fall-back: not here
@@ -316,12 +322,29 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
   if (!deflated) {
     if ((rc = launch_cr(A, B, C, batch, n, max_iter, tol_cr, T_out, status, it, st))) return rc;
   }
+  // the verdict's stream and status words: the caller's own, or the fork (only behind the one-launch iteration, whose R the filter
+  // can use at once)
+  hipStream_t vst = st;
+  int32_t* vstatus = status;
+  if (ov && ov->st && ov->status && ov->fork && deflated) {
+    HIP_TRY(hipMemcpyAsync(ov->status, status, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (key_out) {  // (the filter's dispatch key is needed on the caller's stream, before the verdict)
+      HIP_TRY(hipMemcpyAsync(key_out, it, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+      if (key_written) *key_written = 1;
+    }
+    HIP_TRY(hipEventRecord(ov->fork, st));
+    HIP_TRY(hipStreamWaitEvent(ov->st, ov->fork, 0));
+    vst = ov->st;
+    vstatus = ov->status;
+    ov->used = 1;
+    ov->marks = mark;
+  }
   rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 8, {
     rc = set_lds(dsge::gensys_certify_kernel<BS>, lds);
     if (rc == DSGE_SUCCESS)
-      hipLaunchKernelGGL(dsge::gensys_certify_kernel<BS>, dim3(batch), dim3(64), lds, st, B, C, (const double*)T_out, batch, n, lcap,
-                         scap, tol, eu_out, status, mark);
+      hipLaunchKernelGGL(dsge::gensys_certify_kernel<BS>, dim3(batch), dim3(64), lds, vst, B, C, (const double*)T_out, batch, n, lcap,
+                         scap, tol, eu_out, vstatus, mark);
   });
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -330,20 +353,20 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
   // path's own rate when everything is); the single-launch kernel where the window path does not apply.
   int used = 0;
   if (opt().gensys_split && opt().gensys_doubling != 2) {
-    hipLaunchKernelGGL(dsge::gensys_compact_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)mark, batch, act);
+    hipLaunchKernelGGL(dsge::gensys_compact_kernel, dim3(1), dim3(1024), 0, vst, (const int32_t*)mark, batch, act);
     HIP_TRY(hipGetLastError());
-    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, status, st, &used, nullptr, n_lead_hint, nullptr, act)))
+    if ((rc = launch_gensys_split(A, B, C, batch, n, tol, T_out, eu_out, vstatus, vst, &used, nullptr, n_lead_hint, nullptr, act)))
       return rc;
   }
   if (!used) {
     const size_t lds_q = dsge::gensys_smem_bytes(n, rescue_ncap, rescue_lcap);
     if ((rc = set_lds(dsge::gensys_kernel, lds_q))) return rc;
-    hipLaunchKernelGGL(dsge::gensys_kernel, dim3(rerun_grid(batch)), dim3(64), lds_q, st, A, B, C, batch, n, rescue_ncap, rescue_lcap,
-                       tol, T_out, eu_out, status, (long long*)nullptr, 1);
-    hipLaunchKernelGGL(dsge::gensys_rescue_close_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, status, eu_out);
+    hipLaunchKernelGGL(dsge::gensys_kernel, dim3(rerun_grid(batch)), dim3(64), lds_q, vst, A, B, C, batch, n, rescue_ncap, rescue_lcap,
+                       tol, T_out, eu_out, vstatus, (long long*)nullptr, 1);
+    hipLaunchKernelGGL(dsge::gensys_rescue_close_kernel, dim3((batch + 255) / 256), dim3(256), 0, vst, batch, vstatus, eu_out);
     HIP_TRY(hipGetLastError());
   }
-  if (key_out) {  // Kalman dispatch key: the iteration count (grows with the persistence of the model, like the QZ-spectrum key)
+  if (key_out && vst == st) {  // Kalman dispatch key: the iteration count (grows with the persistence of the model, like the QZ-spectrum key)
     HIP_TRY(hipMemcpyAsync(key_out, it, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (key_written) *key_written = 1;
   }
@@ -354,14 +377,16 @@ static int launch_gensys_doubling(const double* A, const double* B, const double
 
 int launch_gensys(const double* A, const double* B, const double* C, int batch, int n, double tol, int n_lead_hint,
                   double* T_out, int32_t* eu_out, int32_t* status, hipStream_t st, long long* dbg, int32_t* key_out,
-                  int* key_written, const double* D, int k, double* R_tmp, int n_state_hint, const int32_t** qz_marks) {
+                  int* key_written, const double* D, int k, double* R_tmp, int n_state_hint, const int32_t** qz_marks,
+                  GensysOverlap* ov) {
   if (key_written) *key_written = 0;
   if (qz_marks) *qz_marks = nullptr;
+  if (ov) ov->used = 0;
   int rc;
   if (opt().gensys_doubling && !dbg) {
     int done = 0;
     if ((rc = launch_gensys_doubling(A, B, C, D, k, R_tmp, batch, n, tol, n_lead_hint, n_state_hint, T_out, eu_out, status, st,
-                                     key_out, key_written, &done, qz_marks)))
+                                     key_out, key_written, &done, qz_marks, opt().gensys_doubling == 1 ? ov : nullptr)))
       return rc;
     if (done) return DSGE_SUCCESS;
   }
@@ -407,6 +432,30 @@ int launch_gensys_pencil(const double* g0, const double* g1, const double* c, co
   if (fw) fo = dsge::GensysFwdOut{fw->f_mat, fw->f_wt, fw->y_wt, fw->loose, fw->n_unstable, fw->pi_raw};
   hipLaunchKernelGGL(dsge::gensys_pencil_kernel, dim3(batch), dim3(64), lds, st, g0, g1, c, psi, pi, batch, N, k, ell, tol,
                      G1_out, C_out, impact_out, gev_out, eu_out, status, fo);
+  HIP_TRY(hipGetLastError());
+  return DSGE_SUCCESS;
+}
+
+// After the overlapped verdict (launch_gensys_doubling with `ov`): the status words of the draws the verdict re-solved.  A draw the
+// ordered QZ solved is handed to the filter's second pass (DSGE_ST_INTERNAL_RERUN); a draw it rejected keeps the QZ's status and
+// gets logp = -inf (what the filter's first pass writes for a failed draw); unmarked draws keep what the first filter pass left.
+__global__ __launch_bounds__(256) void gensys_overlap_merge_kernel(int batch, const int32_t* __restrict__ marks,
+                                                                   const int32_t* __restrict__ vstatus, int32_t* __restrict__ status,
+                                                                   double* __restrict__ logp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= batch || marks[i] == 0) return;
+  const int32_t v = vstatus[i];
+  if (v == 0) {
+    status[i] = dsge::DSGE_ST_INTERNAL_RERUN;
+  } else {
+    status[i] = v;
+    logp[i] = -INFINITY;
+  }
+}
+
+int launch_gensys_overlap_merge(int batch, const int32_t* marks, const int32_t* vstatus, int32_t* status, double* logp,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(gensys_overlap_merge_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, marks, vstatus, status, logp);
   HIP_TRY(hipGetLastError());
   return DSGE_SUCCESS;
 }

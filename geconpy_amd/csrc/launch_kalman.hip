@@ -89,7 +89,7 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
                   const double* d, int d_batched, const double* Hdiag, int h_batched, const double* y, int batch,
                   int m, int p, int T_len, double jitter, double missing_fill, int n_state_hint, int z_selector_hint,
                   double* logp, int32_t* status, hipStream_t st, const int32_t* order_key, const double* Rsel,
-                  const double* qdiag, int q_batched, int k_shocks, const unsigned long long* colmask) {
+                  const double* qdiag, int q_batched, int k_shocks, const unsigned long long* colmask, int rerun_all) {
   const int bs = tile_bs(m);
   const dsge::FilterConv cv = filter_conv(jitter);  // the call's jitter + the conventions of dsge_options
   const bool fold = Rsel && qdiag && kalman_folds_rqr(m, p, k_shocks, n_state_hint, z_selector_hint);
@@ -101,10 +101,10 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   // Z (one extra product per step).  Draws that violate a hint come back flagged and are re-run by
   // the general kernel below.
   const bool fast = p <= 8;
-  bool launched_fast = false;
+  bool launched_fast = rerun_all != 0;  // (rerun_all: every launch below is a second pass on the flagged draws)
   // Small models (reduced filter of at most 6 variables, p <= 3, selector Z): one thread per draw, all in
   // registers.  Draws that do not fit are flagged and fall through to the wave-per-draw cascade below.
-  if (opt().kalman_tiny && z_selector_hint && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6) {
+  if (opt().kalman_tiny && z_selector_hint && p <= 3 && n_state_hint > 0 && n_state_hint + p <= 6 && !rerun_all) {
     const int blocks = (batch + 63) / 64;
     if (n_state_hint + p <= 4) {
       hipLaunchKernelGGL((dsge::kalman_tiny_kernel<4, 3>), dim3(blocks), dim3(64), 0, st, T, RQR, Z, z_batched, d, d_batched,
@@ -177,11 +177,11 @@ int launch_kalman(const double* T, double* RQR, double* P0, int p0_valid, const 
   // Round 6: the covariance in the tile layout of the FP64 matrix core's 4 x 4 x 4 instruction (launch_kalman_mf.hip, dsge_kalman_mf.hpp)
   bool mf_covers = false;  // the tile-layout instances launched cover everything the VALU cascade below could take
   if (fast && z_selector_hint && opt().kalman_mfma == 2 && opt().kalman_nt_products && !want_tail && opt().kalman_head_draws == 0 &&
-      n_state_hint >= 9 && n_state_hint <= 20 && !launched_fast) {
+      n_state_hint >= 9 && n_state_hint <= 20 && (!launched_fast || rerun_all)) {
     int launched = 0;
     if ((rc = launch_kalman_mf(T, RQR, p0_valid ? P0 : nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
                                missing_fill, n_state_hint, logp, status, st, order, fold ? Rsel : nullptr, qdiag, q_batched, k_shocks,
-                               colmask, &launched, &mf_covers)))
+                               colmask, rerun_all, &launched, &mf_covers)))
       return rc;
     launched_fast = launched_fast || launched > 0;
   }

@@ -12,6 +12,7 @@ namespace dsge_host {
 // 20 state variables: KT = 3, 4, 5), TM = KT tiles for the retained variables first and, when observed non-states may add to them
 // (n_state_hint + p beyond 4 KT), TM = KT + 2 as a second pass on the draws the first flagged.  The kernel checks every draw and flags
 // what does not fit (DSGE_ST_INTERNAL_RERUN) for the caller's cascade.  dsge_options.kalman_mfma = 2 (default); 0: the VALU kernels.
+//   rerun_first: 1 = the first instance, too, is a second pass (only draws flagged DSGE_ST_INTERNAL_RERUN).
 //   *launched: number of instances launched;  *covers: every instance wanted was launched.  What these instances refuse -- more state
 //   variables than the hint, a design matrix that is no selector -- the VALU fast kernels refuse too (their state-block capacity
 //   comes from the same hint, and with s <= 20, p <= 8 no draw has more than 28 retained variables): the caller then skips that
@@ -20,7 +21,7 @@ int launch_kalman_mf(const double* T, const double* RQR, const double* P0, const
                      int d_batched, const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                      dsge::FilterConv cv, double missing_fill, int n_state_hint, double* logp, int32_t* status, hipStream_t st,
                      const int32_t* order, const double* Rsel, const double* qdiag, int q_batched, int k_shocks,
-                     const unsigned long long* colmask, int* launched, bool* covers) {
+                     const unsigned long long* colmask, int rerun_first, int* launched, bool* covers) {
   *launched = 0;
   *covers = false;
   const size_t r_doubles = Rsel ? (size_t)m * ((k_shocks + 1) & ~1) : 0;
@@ -34,7 +35,7 @@ int launch_kalman_mf(const double* T, const double* RQR, const double* P0, const
     if ((rc2 = set_lds(dsge::kalman_mf_kernel<KTV, TMV, DBGV>, SMF::bytes))) return rc2;
     hipLaunchKernelGGL((dsge::kalman_mf_kernel<KTV, TMV, DBGV>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR, P0, Z, z_batched, d,
                        d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, opt().kalman_steady_tol, logp, status,
-                       DBGV ? g_kalman_dbg : (long long*)nullptr, n_mf > 0 ? 1 : 0, g_kalman_steady_at, order, Rsel, qdiag, q_batched,
+                       DBGV ? g_kalman_dbg : (long long*)nullptr, (n_mf > 0 || rerun_first) ? 1 : 0, g_kalman_steady_at, order, Rsel, qdiag, q_batched,
                        k_shocks, colmask);
     HIP_TRY(hipGetLastError());
     ++n_mf;

@@ -224,7 +224,15 @@ typedef struct dsge_options {
                                  and fuzz suites; T agrees with the QZ's to what two float64 algorithms differ by (1e-12 on
                                  well-conditioned draws, cond(B + C T) eps in general).  0: the ordered QZ of the pencil for every
                                  draw (the reference's algorithm, gEconpy/solvers/gensys.py:190-395, operation by operation).
-                                 2: as 1 with the single-launch QZ kernel as the fall-back (debug) */
+                                 2: as 1 with the single-launch QZ kernel as the fall-back (debug).
+                                 Round 6 (ABI 9): under 1 the fused evaluation (dsge_solve_kalman_logp_batched, plain form: no
+                                 residual output, diagonal Q folded into the filter, stream not being captured) runs the VERDICT --
+                                 certificate, compaction, the QZ of the draws without one -- on a library stream NEXT to the filter
+                                 of all draws, joins, and filters the draws the verdict re-solved a second time; a certified draw is
+                                 filtered once with the same inputs as in the serial order (identical logp).  3: as 1 with the
+                                 verdict on the caller's stream in front of the filter (the round-5 order; for comparison).  The
+                                 scale guards of the certificate (csrc/dsge_gensys_doubling.hpp: existence computed exactly from
+                                 (B + C T)^-1, a lower bound on the stable block's QZ diagonal) hold under 1, 2 and 3. */
   int32_t kalman_grad_split;  /* 1 (default), 2: the logp + gradient entry points run the FORWARD filter sweep as the logp kernel
                                  itself (kalman_nt_kernel with record output: two wavefronts per SIMD) and the reverse sweep as a
                                  kernel of its own; draws the forward kernel cannot take fall back to the one-kernel path in the same

@@ -16,7 +16,7 @@ ns, zs = eng.structure_hints(dev[0], dZ)
 hs = eng.static_hint(dev[0], dev[2])
 nl = lead_hint(b["C"], 1e-8)
 res = {}
-for dbl in (0, 1, 2):
+for dbl in (0, 1, 2, 3):
     lp = torch.empty(nb, dtype=torch.float64, device="cuda"); st = torch.empty(nb, dtype=torch.int32, device="cuda")
     opts = {"gensys_doubling": dbl, "n_static_hint": hs}
     f = lambda: eng.solve_kalman_logp(*dev, dq, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, logp=lp, status=st, solver="gensys",
@@ -45,7 +45,7 @@ for share in (0.02, 0.5, 1.0):
     A2[bad] *= 25.0
     dA2 = eng.to_device(A2)
     out = {}
-    for dbl in (0, 1, 2):
+    for dbl in (0, 1, 2, 3):
         lp = torch.empty(nb, dtype=torch.float64, device="cuda"); st = torch.empty(nb, dtype=torch.int32, device="cuda")
         opts = {"gensys_doubling": dbl, "n_static_hint": hs}
         f = lambda: eng.solve_kalman_logp(dA2, *dev[1:], dq, dZ, dy, Hdiag=dH, q_mode=1, tol=1e-8, max_iter=1000, logp=lp, status=st,
