@@ -34,7 +34,7 @@ struct KmfSmem {
   static constexpr int RP = NR / 8, PS = 10;
   static constexpr int WT = NM * LDK > NR * PS ? NM * LDK : NR * PS;  // W' buffer; the -V panel and the staged R alias it
   // doubles: Tc NM*LDK, Wt WT, Pc NS*LDK, PZt, Ks NR*PS each, av, af NR each, vv/dd/hh/zv 8 each; ints perm NR, zpos 8
-  static constexpr size_t doubles = (size_t)NM * LDK + WT + (size_t)NS * LDK + 2 * (size_t)NR * PS + 2 * NR + 4 + 42 + NR / 2 + 4;
+  static constexpr size_t doubles = (size_t)NM * LDK + WT + (size_t)NS * LDK + 2 * (size_t)NR * PS + 2 * NR + 4 + 44 + NR / 2 + 4;
   static constexpr size_t bytes = sizeof(double) * doubles;
 };
 
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
   double* av = Ks + NR * PS;        // NR + 2     predicted state (+ the dump slot of the mean's store)
   double* avd = av;
   double* af = av + NR + 2;         // NR + 2     filtered state (+ a dump slot)
-  double* vv = af + NR + 2;         // 8 innovation
-  double* dd = vv + 8;              // 8 obs intercept
+  double* vv = af + NR + 2;         // 8 innovation (+ 2: dump slot)
+  double* dd = vv + 10;             // 8 obs intercept
   double* hh = dd + 8;              // 8 diag(H)
   double* zv = hh + 8;              // 8 selector values
   double* zvt = zv + 8;             // 10: selector value by observation index, [8] = 0 (LEAN: the P Z' stores look their factor up)
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       const double c_r = obs ? r_zv : 0.0;
       const double v_r = (obs ? yt : 0.0) - (((obs || !cv.mask_d) ? r_dd : 0.0) + c_r * a_sel);
       const double dg = (r8 < p) ? ((obs ? r_hh : 0.0) + cv.jit_F) : 1.0;
-      if (lane < 8) vv[lane] = v_r;
+      vv[lane < 8 ? lane : 8] = v_r;  // (entry 8: a slot for the other lanes -- no branch)
       asm volatile("" ::: "memory");
       double fr[8];
 #pragma unroll
@@ -412,9 +412,12 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       // ---- (c) Finv by Gauss-Jordan, one row per lane (SPD: no pivoting); the pivot row arrives through SGPRs ----------------
       double step_mant = 1.0, inv_own = 1.0;
       int step_exp = 0;
+      // (all eight pivots, unconditionally: a row beyond p -- like the row of a missing observation -- is a row of the identity,
+      //  pivot 1, multipliers 0, mantissa 0.5 x 2^1: a no-op that costs one pivot's issue slots for p = 7 and saves the eight
+      //  branches `j < p`, which cut the chain into basic blocks the scheduler cannot overlap)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (j < p) {
+        {
           double rowj[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) rowj[q] = readlane_f64(fr[q], j);
@@ -514,7 +517,8 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
           }
           steady = (t > 0) && (__ballot(!(dmax <= steady_tol * pm)) == 0ull);
         }
-        wave_sync();  // (-V, aliased with W', and the old Pc have been read)
+        // (no fence between the reads of the old state block and its stores: same element type, and LDS executes a wavefront's
+        //  accesses in program order)
         KMF_STORE_PC();
       }
       // the filtered mean as row m of W': column m of X is then Tc a+ (rows >= m of Tc are zero: row m of W' feeds nothing else)
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         const int at = (4 * MW::tb(g, blk) + i4) * LDK + 4 * MW::ta(g, blk) + kq;
         Wt[MW::live(g, blk) ? at : W_DUMP] = d;
       });
-      if (fold_a && lane < NS) Wt[m * LDK + lane] = af_l;  // (after the W stores: LDS keeps a wavefront's program order)
+      Wt[(fold_a && lane < NS) ? m * LDK + lane : W_DUMP] = af_l;  // (after the W stores: LDS keeps a wavefront's program order)
       wave_sync();  // #4
       if constexpr (DBG) {
         const long long tk1 = clock64();
