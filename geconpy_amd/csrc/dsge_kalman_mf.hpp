@@ -20,6 +20,8 @@
 // Capacity: s <= 4 KT state variables, m <= 4 TM retained variables, p <= 8, selector Z; a draw beyond it is flagged
 // (DSGE_ST_INTERNAL_RERUN) for the next instance of the launcher's cascade, as in the other fast kernels.
 #pragma once
+#include <type_traits>
+
 #include "dsge_kalman_nt.hpp"
 #include "dsge_mfma4.hpp"
 
@@ -412,32 +414,38 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       // ---- (c) Finv by Gauss-Jordan, one row per lane (SPD: no pivoting); the pivot row arrives through SGPRs ----------------
       double step_mant = 1.0, inv_own = 1.0;
       int step_exp = 0;
-      // (all eight pivots, unconditionally: a row beyond p -- like the row of a missing observation -- is a row of the identity,
-      //  pivot 1, multipliers 0, mantissa 0.5 x 2^1: a no-op that costs one pivot's issue slots for p = 7 and saves the eight
-      //  branches `j < p`, which cut the chain into basic blocks the scheduler cannot overlap)
+      // (pivots 0..6 unconditionally, pivot 7 only when there is an eighth observation: a row beyond p -- like the row of a missing
+      //  observation -- is a row of the identity, pivot 1, multipliers 0, mantissa 0.5 x 2^1: a no-op.  Seven branches `j < p` cut the
+      //  chain into basic blocks the scheduler could not overlap; one uniform branch at the end does not)
+      auto pivot = [&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        double rowj[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        {
-          double rowj[8];
+        for (int q = 0; q < 8; ++q) rowj[q] = readlane_f64(fr[q], j);
+        // (ONE Newton step on v_rcp_f64: 2.2e-15 relative, tools/latency_probe/rcp_probe.hip -- the multipliers and the final
+        //  row scaling of a 7 x 7 inverse whose conditioning costs more digits than that; the determinant takes the pivots
+        //  themselves.  Two dependent FMAs less on the chain of every pivot)
+        double inv = __builtin_amdgcn_rcp(rowj[j]);
+        inv = inv * fma(-rowj[j], inv, 2.0);
+        const bool is_j = (r8 == j);
+        const double ci = is_j ? 0.0 : fr[j] * inv;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) rowj[q] = readlane_f64(fr[q], j);
-          // (ONE Newton step on v_rcp_f64: 2.2e-15 relative, tools/latency_probe/rcp_probe.hip -- the multipliers and the final
-          //  row scaling of a 7 x 7 inverse whose conditioning costs more digits than that; the determinant takes the pivots
-          //  themselves.  Two dependent FMAs less on the chain of every pivot)
-          double inv = __builtin_amdgcn_rcp(rowj[j]);
-          inv = inv * fma(-rowj[j], inv, 2.0);
-          const bool is_j = (r8 == j);
-          const double ci = is_j ? 0.0 : fr[j] * inv;
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (q != j) fr[q] = fma(-ci, rowj[q], fr[q]);
-          fr[j] = is_j ? 1.0 : -ci;
-          inv_own = is_j ? inv : inv_own;
-          int e;
-          step_mant *= frexp(rowj[j], &e);
-          step_exp += e;
-        }
-      }
+        for (int q = 0; q < 8; ++q)
+          if (q != j) fr[q] = fma(-ci, rowj[q], fr[q]);
+        fr[j] = is_j ? 1.0 : -ci;
+        inv_own = is_j ? inv : inv_own;
+        int e;
+        step_mant *= frexp(rowj[j], &e);
+        step_exp += e;
+      };
+      pivot(std::integral_constant<int, 0>{});
+      pivot(std::integral_constant<int, 1>{});
+      pivot(std::integral_constant<int, 2>{});
+      pivot(std::integral_constant<int, 3>{});
+      pivot(std::integral_constant<int, 4>{});
+      pivot(std::integral_constant<int, 5>{});
+      pivot(std::integral_constant<int, 6>{});
+      if (p > 7) pivot(std::integral_constant<int, 7>{});
       {
         const double2* vv2 = reinterpret_cast<const double2*>(vv);
         double w0 = 0.0, w1 = 0.0;
@@ -447,15 +455,18 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
           w0 = fma(fr[2 * q2], vq.x, w0);
           w1 = fma(fr[2 * q2 + 1], vq.y, w1);
         }
-        if (n_obs > 0) {
+        {  // (a step without any observed entry contributes nothing: selects on the wave-uniform condition instead of a branch,
+           //  which would end the basic block between the elimination and the gain)
+          const bool any = n_obs > 0;
           const double yk = ((lane < 8) ? (v_r * inv_own) * (w0 + w1) : 0.0) - quad_comp;
           const double tk = quad_sum + yk;
-          quad_comp = (tk - quad_sum) - yk;
-          quad_sum = tk;
+          quad_comp = any ? (tk - quad_sum) - yk : quad_comp;
+          quad_sum = any ? tk : quad_sum;
           int e;
-          ld_mant = frexp(ld_mant * step_mant, &e);
-          ld_exp += e + step_exp;
-          ++n_ll_steps;
+          const double lm = frexp(ld_mant * step_mant, &e);
+          ld_mant = any ? lm : ld_mant;
+          ld_exp += any ? e + step_exp : 0;
+          n_ll_steps += any ? 1 : 0;
           n_obs_entries += n_obs;
         }
       }
