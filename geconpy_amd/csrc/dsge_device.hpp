@@ -523,35 +523,45 @@ __device__ __forceinline__ void gauss_jordan_blocked(double* W, int ldw, int n, 
     int rsel[BS];
     double inv_own = 1.0;  // pivot lanes: 1 / pivot of their row (the row is scaled once, after the panel)
 #pragma unroll
-    for (int c = 0; c < BS; ++c) {
-      rsel[c] = 0;
-      if (c < bw) {
-        // pivot = largest |entry| among the unused rows, compared on the high 32 bits of the double (sign
-        // cleared; exponent + 20 mantissa bits; low 6 bits carry 63 - lane so that ties go to the first row):
-        // within 2^-14 of the true maximum, which is all partial pivoting needs, at one v_max_u32 per DPP step
-        const bool cand = (lane < n) && !((used >> lane) & 1ull);
-        unsigned key = 0u;
-        if (cand) key = (((unsigned)__double2hiint(pw[c]) & 0x7fffffffu) & ~63u) | (unsigned)(63 - lane);
-        key = wave_max_u32(key);
-        const int r = 63 - (int)(key & 63u);
-        rsel[c] = r;
-        used |= 1ull << r;
-        const bool is_r = (lane == r);
-        if (is_r) id[c] = 1.0;
-        // broadcast the pivot lane's row scaled by 1 / pivot and eliminate everywhere else.  The pivot lane itself is
-        // left alone (multiplier 0: no divergent branch) and scaled after the panel -- later columns only ever read
-        // a row through its own elimination multiplier, which is consistent with the unscaled row.
-        const double inv = fast_rcp(readlane_dyn_f64(pw[c], r));
-        inv_min = fmin(inv_min, fabs(inv));
-        inv_max = fmax(inv_max, fabs(inv));
-        const double f = is_r ? 0.0 : pw[c];
-        inv_own = is_r ? inv : inv_own;
+    for (int c = 0; c < BS; ++c) rsel[c] = 0;
+    // one pivot of the panel (column c: a compile-time constant after unrolling)
+    auto panel_pivot = [&](int c) {
+      // pivot = largest |entry| among the unused rows, compared on the high 32 bits of the double (sign
+      // cleared; exponent + 20 mantissa bits; low 6 bits carry 63 - lane so that ties go to the first row):
+      // within 2^-14 of the true maximum, which is all partial pivoting needs, at one v_max_u32 per DPP step
+      const bool cand = (lane < n) && !((used >> lane) & 1ull);
+      unsigned key = 0u;
+      if (cand) key = (((unsigned)__double2hiint(pw[c]) & 0x7fffffffu) & ~63u) | (unsigned)(63 - lane);
+      key = wave_max_u32(key);
+      const int r = 63 - (int)(key & 63u);
+      rsel[c] = r;
+      used |= 1ull << r;
+      const bool is_r = (lane == r);
+      if (is_r) id[c] = 1.0;
+      // broadcast the pivot lane's row scaled by 1 / pivot and eliminate everywhere else.  The pivot lane itself is
+      // left alone (multiplier 0: no divergent branch) and scaled after the panel -- later columns only ever read
+      // a row through its own elimination multiplier, which is consistent with the unscaled row.
+      const double inv = fast_rcp(readlane_dyn_f64(pw[c], r));
+      inv_min = fmin(inv_min, fabs(inv));
+      inv_max = fmax(inv_max, fabs(inv));
+      const double f = is_r ? 0.0 : pw[c];
+      inv_own = is_r ? inv : inv_own;
 #pragma unroll
-        for (int c2 = 0; c2 < BS; ++c2) {
-          if (c2 > c) pw[c2] = fma(-f, readlane_dyn_f64(pw[c2], r) * inv, pw[c2]);
-          if (c2 <= c) id[c2] = fma(-f, readlane_dyn_f64(id[c2], r) * inv, id[c2]);
-        }
+      for (int c2 = 0; c2 < BS; ++c2) {
+        if (c2 > c) pw[c2] = fma(-f, readlane_dyn_f64(pw[c2], r) * inv, pw[c2]);
+        if (c2 <= c) id[c2] = fma(-f, readlane_dyn_f64(id[c2], r) * inv, id[c2]);
       }
+    };
+    // (round 6) a FULL panel -- every panel but possibly the last -- runs its BS pivots without the per-column test `c < bw`: the
+    // (uniform) branches cut the chain of a panel into one basic block per pivot, which the scheduler cannot overlap; same
+    // operations in the same order, bit-identical results
+    if (bw == BS) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) panel_pivot(c);
+    } else {
+#pragma unroll
+      for (int c = 0; c < BS; ++c)
+        if (c < bw) panel_pivot(c);
     }
 #pragma unroll
     for (int c = 0; c < BS; ++c) id[c] *= inv_own;  // (pw is dead from here on)
