@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       // ---- (c) Finv by Gauss-Jordan, one row per lane (SPD: no pivoting); the pivot row arrives through SGPRs ----------------
       double step_mant = 1.0, inv_own = 1.0;
       int step_exp = 0;
-      // (pivots 0..6 unconditionally, pivot 7 only when there is an eighth observation: a row beyond p -- like the row of a missing
+      // (p >= 7: pivots 0..6 unconditionally, pivot 7 only when there is an eighth observation: a row beyond p -- like the row of a missing
       //  observation -- is a row of the identity, pivot 1, multipliers 0, mantissa 0.5 x 2^1: a no-op.  Seven branches `j < p` cut the
       //  chain into basic blocks the scheduler could not overlap; one uniform branch at the end does not)
       auto pivot = [&](auto jt) {
@@ -438,14 +438,23 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         step_mant *= frexp(rowj[j], &e);
         step_exp += e;
       };
-      pivot(std::integral_constant<int, 0>{});
-      pivot(std::integral_constant<int, 1>{});
-      pivot(std::integral_constant<int, 2>{});
-      pivot(std::integral_constant<int, 3>{});
-      pivot(std::integral_constant<int, 4>{});
-      pivot(std::integral_constant<int, 5>{});
-      pivot(std::integral_constant<int, 6>{});
-      if (p > 7) pivot(std::integral_constant<int, 7>{});
+      if (p >= 7) {
+        pivot(std::integral_constant<int, 0>{});
+        pivot(std::integral_constant<int, 1>{});
+        pivot(std::integral_constant<int, 2>{});
+        pivot(std::integral_constant<int, 3>{});
+        pivot(std::integral_constant<int, 4>{});
+        pivot(std::integral_constant<int, 5>{});
+        pivot(std::integral_constant<int, 6>{});
+        if (p > 7) pivot(std::integral_constant<int, 7>{});
+      } else {  // (few observables: the no-op pivots would cost more than the branches)
+        pivot(std::integral_constant<int, 0>{});
+        if (p > 1) pivot(std::integral_constant<int, 1>{});
+        if (p > 2) pivot(std::integral_constant<int, 2>{});
+        if (p > 3) pivot(std::integral_constant<int, 3>{});
+        if (p > 4) pivot(std::integral_constant<int, 4>{});
+        if (p > 5) pivot(std::integral_constant<int, 5>{});
+      }
       {
         const double2* vv2 = reinterpret_cast<const double2*>(vv);
         double w0 = 0.0, w1 = 0.0;
