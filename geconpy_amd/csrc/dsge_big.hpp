@@ -777,6 +777,8 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
   static_assert(2 * BIG_GD_LCAP * LDG + 2 * BIG_GD_SCAP * LDS_ <= 2 * NP * Cfg::LD, "certificate buffers fit the two panels");
   double* Gm = lds;
   double* Ts = lds + 2 * BIG_GD_LCAP * LDG;
+  double* Ml = lds + Cfg::OFF_R;  // M^-1 for the scale guards (second panel; overlaps Ts, which is filled after them)
+  static_assert(2 * BIG_GD_LCAP * LDG <= Cfg::OFF_R, "G[L,L] and its square stay clear of the inverse");
   const int tid = threadIdx.x;
   const int ty = tid / Cfg::GX, tx = tid - ty * Cfg::GX, r0 = ty * TR, c0 = tx * TC;
   double* W = ws + (size_t)blockIdx.x * Cfg::ws_doubles;
@@ -873,7 +875,10 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
         int q = (r0 + i < n) ? pivcol[r0 + i] : 0;
         qrow[i] = q < 0 ? 0 : (q >= n ? n - 1 : q);
       }
-      // M^-1 in natural row order over the (dead) M buffer of the workspace; the guards and G[L,L] read it from there (L2).
+      __syncthreads();  // (every thread is out of the elimination: its panels may be overwritten)
+      // M^-1 in natural row order into the second LDS panel (both panels are free behind the elimination; the certificate's T[S,S]
+      // buffer, which overlaps it, is filled after the guards): the guards and G[L,L] read it from there -- from the L2-resident
+      // workspace every access was a microsecond under the launch's own traffic, 60 us per draw.
       // R = -M^-1 D is written now (and zeroed below for a draw that ends without the certificate), so that no register tile
       // lives across the guards
 #pragma unroll
@@ -881,12 +886,12 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
         if (r0 + i < n) {
 #pragma unroll
           for (int jc = 0; jc < TC; ++jc) {
-            if (c0 + jc < n) Mg[qrow[i] * LD + c0 + jc] = t2[i][jc];
+            if (c0 + jc < n) Ml[qrow[i] * LD + c0 + jc] = t2[i][jc];
             if (R_out && c0 + jc < k) R_out[offk + (size_t)qrow[i] * k + c0 + jc] = ok ? -t0[i][jc] : 0.0;
           }
         }
-      // G[L,L] and T[S,S] into the (now free) panels
-      for (int idx = tid; idx < 2 * BIG_GD_LCAP * LDG + 2 * BIG_GD_SCAP * LDS_; idx += NT) lds[idx] = 0.0;
+      // G[L,L] (and, behind the guards, T[S,S]) into the first panel
+      for (int idx = tid; idx < 2 * BIG_GD_LCAP * LDG; idx += NT) lds[idx] = 0.0;
       __syncthreads();
       if (ok) {  // (uniform)
         int gt = threadIdx.x;  // (opaque copy: nothing derived from it is hoisted across the elimination, see BIG_COORDS)
@@ -897,34 +902,53 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
         double* vb = Gm + BIG_GD_LCAP * LDG;  // 128 doubles of the certificate's second buffer (unused until the squarings)
         double* tb = vb + 128;                // 32
         double mi2 = 0.0, nl2 = 0.0, tl2 = 0.0;
+        int* lrow = cnt + 4;  // the lead rows in order (the index maps' area has room: 10 NP ints against 4 NP + 4 used)
+        if (gt < n && posL[gt] >= 0) lrow[posL[gt]] = gt;
         for (int idx = gt; idx < n * n; idx += NT) {
           const int r = idx / n, c = idx - r * n;
-          const double v = Mg[r * LD + c];
+          const double v = Ml[r * LD + c];
           mi2 = fma(v, v, mi2);
-          const int pa = posL[r], pb = posL[c];
-          if (pa >= 0) {
+          if (posL[r] >= 0) {
             nl2 = fma(v, v, nl2);
             const double tv = Tg[r * LD + c];
             tl2 = fma(tv, tv, tl2);
           }
-          if (pa >= 0 && pb >= 0) {  // G[L,L] = N_L C[:,L]
-            double g0 = 0.0, g1 = 0.0;
-            int i = 0;
-            for (; i + 1 < n; i += 2) {
-              g0 = fma(Mg[r * LD + i], Cg[i * LD + c], g0);
-              g1 = fma(Mg[r * LD + i + 1], Cg[(i + 1) * LD + c], g1);
+        }
+        __syncthreads();
+        // G[L,L] = N_L C[:,L]: one element per thread, the dot product in batches of eight (16 loads of the L2-resident arrays in
+        // flight: a scalar loop under its condition was a chain of load latencies, 0.4 ms per 1024 draws at n = 80)
+        for (int idx = gt; idx < l * l; idx += NT) {
+          const int a_ = idx / l, b_ = idx - a_ * l;
+          const double* mr = Ml + lrow[a_] * LD;
+          const double* cc_ = Cg + lrow[b_];
+          double g0 = 0.0, g1 = 0.0;
+          int i = 0;
+          for (; i + 8 <= n; i += 8) {
+            double mv[8], cv8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              mv[e] = mr[i + e];
+              cv8[e] = cc_[(i + e) * LD];
             }
-            if (i < n) g0 = fma(Mg[r * LD + i], Cg[i * LD + c], g0);
-            Gm[pa * LDG + pb] = g0 + g1;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              g0 = fma(mv[e], cv8[e], g0);
+              g1 = fma(mv[e + 1], cv8[e + 1], g1);
+            }
           }
+          for (; i < n; ++i) g0 = fma(mr[i], cc_[i * LD], g0);
+          Gm[a_ * LDG + b_] = g0 + g1;
         }
         mi2 = big_block_sum<Cfg>(mi2, red, gt);
         nl2 = big_block_sum<Cfg>(nl2, red, gt);
         tl2 = big_block_sum<Cfg>(tl2, red, gt);
-        // start vector: the sum of the rows of N_L scaled by their own first... simply the row sums of N_L' N_L applied to ones:
-        // v0 = N_L' (N_L 1) (one step of the iteration from the vector of ones; three more follow)
+        // power iteration from the vector of ones (any v gives a valid bound; two steps).  The row products -- t = N_L v, z = M^-1 w --
+        // run one ROW PER WAVEFRONT with the lanes along the row (coalesced reads of the L2-resident inverse, a DPP sum per row): one
+        // thread per row walked its row alone, n cache lines one after the other, 12 times per draw (n = 80: + 0.4 ms per 1024 draws)
+        const int gw = gt >> 6, gl = gt & 63;
+        constexpr int NWV = NT / 64;
         double tau = 0.0, w2 = 0.0;
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 2; ++it) {  // (two steps: a direction that matters is ahead of the rest by orders of magnitude)
           double vj = 0.0;
           if (it == 0) vj = (gt < n) ? 1.0 : 0.0;
           else if (gt < n) vj = vb[gt];
@@ -933,28 +957,52 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
           __syncthreads();
           if (gt < n) vb[gt] = vj;
           __syncthreads();
-          double ta = 0.0;
-          if (gt < n && posL[gt] >= 0) {
-            for (int i = 0; i < n; ++i) ta = fma(Mg[gt * LD + i], vb[i], ta);
-            tb[posL[gt]] = ta;
+          double ta2 = 0.0;
+          for (int r = gw; r < n; r += NWV) {
+            const int pa = posL[r];
+            if (pa >= 0) {  // (wave-uniform)
+              double part = 0.0;
+              for (int i = gl; i < n; i += 64) part = fma(Ml[r * LD + i], vb[i], part);
+              part = wave_sum(part);
+              if (gl == 0) {
+                tb[pa] = part;
+                ta2 = fma(part, part, ta2);
+              }
+            }
           }
-          tau = big_block_sum<Cfg>(ta * ta, red, gt);
+          tau = big_block_sum<Cfg>(ta2, red, gt);
           __syncthreads();
           double wj = 0.0;
-          if (gt < n)
-            for (int r = 0; r < n; ++r) {
-              const int pa = posL[r];
-              if (pa >= 0) wj = fma(Mg[r * LD + gt], tb[pa], wj);
+          if (gt < n) {  // w = N_L' t over the list of lead rows, eight loads in flight
+            const double* mc = Ml + gt;
+            double w1 = 0.0;
+            int a_ = 0;
+            for (; a_ + 8 <= l; a_ += 8) {
+              double mv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) mv[e] = mc[lrow[a_ + e] * LD];
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                wj = fma(mv[e], tb[a_ + e], wj);
+                w1 = fma(mv[e + 1], tb[a_ + e + 1], w1);
+              }
             }
+            for (; a_ < l; ++a_) wj = fma(mc[lrow[a_] * LD], tb[a_], wj);
+            wj += w1;
+          }
           w2 = big_block_sum<Cfg>(wj * wj, red, gt);
           __syncthreads();
           if (gt < n) vb[gt] = wj;  // (un-normalised w on exit: the bound uses w itself)
           __syncthreads();
         }
         double zj = 0.0;
-        if (gt < n)
-          for (int i = 0; i < n; ++i) zj = fma(Mg[gt * LD + i], vb[i], zj);
-        const double z2 = big_block_sum<Cfg>(zj * zj, red, gt);
+        for (int r = gw; r < n; r += NWV) {
+          double part = 0.0;
+          for (int i = gl; i < n; i += 64) part = fma(Ml[r * LD + i], vb[i], part);
+          part = wave_sum(part);
+          if (gl == 0) zj = fma(part, part, zj);
+        }
+        const double z2 = big_block_sum<Cfg>(zj, red, gt);
         const double rs = tol > 0.0 ? tol : 2.220446049250313e-16;
         const double m2 = 1.5625 * rs * rs;
         const double den = tau + w2;
@@ -963,6 +1011,8 @@ __global__ __launch_bounds__(Cfg::NT) void gensys_certify_big_kernel(const doubl
         ok = ((1.0 + nl2) * m2 < 1.0) && ((1.0 + tl2) * mw2 * m2 < 1.0);
         __syncthreads();
         for (int idx = tid; idx < 160; idx += NT) vb[idx] = 0.0;  // (the squarings' second buffer again)
+        for (int idx = tid; idx < 2 * BIG_GD_SCAP * LDS_; idx += NT) Ts[idx] = 0.0;  // (over the inverse: the guards are done)
+        __syncthreads();
         for (int idx = tid; idx < sN * sN; idx += NT) {
           const int i = idx / sN, j = idx - i * sN;
           Ts[i * LDS_ + j] = T[off + (size_t)sidx[i] * n + sidx[j]];

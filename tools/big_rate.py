@@ -28,7 +28,7 @@ st = torch.empty(NB, dtype=torch.int32, device="cuda")
 
 
 def call():
-    eng.solve_kalman_logp(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, solver="cycle_reduction", z_selector_hint=1,
+    eng.solve_kalman_logp(A, B, C, D, q, Z, y, Hdiag=H, q_mode=1, tol=1e-8, max_iter=1000, solver=(sys.argv[3] if len(sys.argv) > 3 else "cycle_reduction"), z_selector_hint=1,
                           logp=lp, status=st)
 
 
