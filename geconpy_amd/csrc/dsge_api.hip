@@ -319,6 +319,7 @@ int verdict_stream(VerdictStream** out) {
 
 // Scratch of the device entry points (one arena per (device, stream), StreamArenaPool)
 StreamArenaPool g_scratch_pool;
+StreamArenaPool g_aug_big_pool;  // the gathered model of the augmented route beyond 64 states
 int scratch_reserve(hipStream_t st, size_t bytes, void** out) { return g_scratch_pool.reserve(bytes, st, out); }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1101,7 +1102,7 @@ int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, c
   const bool is_cr = solver == DSGE_SOLVER_CYCLE_REDUCTION || solver == DSGE_SOLVER_SCAN_CYCLE_REDUCTION;
   int rc = check_common(batch, n, is_cr ? DSGE_MAX_N_CR : DSGE_MAX_N);
   if (rc) return rc;
-  if (m < n || m > DSGE_MAX_N) return fail(DSGE_ERR_INVALID, "augmented state dimension m out of range (n..DSGE_MAX_N)");
+  if (m < n || m > DSGE_MAX_N_BIG) return fail(DSGE_ERR_INVALID, "augmented state dimension m out of range (n..DSGE_MAX_N_BIG)");
   if (k < 1 || k > n) return fail(DSGE_ERR_INVALID, "k out of range (1..n)");
   if (p < 1 || p > DSGE_MAX_P) return fail(DSGE_ERR_INVALID, "p out of range (1..DSGE_MAX_P)");
   if (T_len < 0 || n_links < 0) return fail(DSGE_ERR_INVALID, "T_len < 0 or n_links < 0");
@@ -1141,6 +1142,40 @@ int dsge_solve_kalman_logp_augmented_batched(const double* A, const double* B, c
                             0, st)))
     return rc;
   if ((rc = launch_augment(Tw, Rw, batch, n, k, m, inv_var_order, n_links, link_rows, link_cols, Ta, Ra, st))) return rc;
+  if (m > DSGE_MAX_N) {
+    // Round 6: 65 .. 96 augmented states (cumulator and observation-lag chains on a 40-variable model, statespace.py:598-723).
+    // The filter does not grow with m: the model restricted to F = {non-zero columns of T_aug} u {observed variables} is exact
+    // (x_t[F] depends on x_{t-1}[F] only, y_t on x_t[F] only -- the argument of the 65 .. 96-variable route, csrc/dsge_big.hpp),
+    // and the existing kernels take |F| <= 64.  F is measured on the device (one 32-byte read-back: the call synchronises its
+    // stream once); a model beyond 64 filtered variables is DSGE_ERR_TOO_LARGE -- with T_aug, R_aug, the status words and the
+    // residual of this call already written (they do not depend on the filter).
+    unsigned char idx[64];
+    int u = 0, ns = 0;
+    if ((rc = big_filtered_variables(Ta, Z, z_batched, batch, m, p, st, idx, &u, &ns))) return rc;
+    if (u > 64)
+      return fail(DSGE_ERR_TOO_LARGE, "augmented solve + Kalman with m > 64: " + std::to_string(u) +
+                                          " state (incl. chain) and observed variables, the filter kernels take at most 64");
+    if (u < 1) return fail(DSGE_ERR_INVALID, "augmented solve + Kalman with m > 64: no state and no observed variable");
+    void* b2 = nullptr;
+    const size_t uu = (size_t)batch * 64 * 64;
+    if ((rc = g_aug_big_pool.reserve(3 * align256(uu * 8) + align256((size_t)batch * 64 * k * 8) +
+                                         align256((size_t)batch * DSGE_MAX_P * 64 * 8) + 1024,
+                                     st, &b2)))
+      return rc;
+    Carver c2(b2);
+    double* T_r = c2.take<double>(uu);
+    double* RQR_r = c2.take<double>(uu);
+    double* P0_r = c2.take<double>(uu);
+    double* R_r = c2.take<double>((size_t)batch * 64 * k);
+    double* Z_r = c2.take<double>(z_batched ? (size_t)batch * p * 64 : (size_t)p * 64);
+    if ((rc = launch_big_compress(Ta, Ra, Z, z_batched, batch, m, k, p, idx, u, T_r, R_r, Z_r, st))) return rc;
+    if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, T_r, R_r, Q, q_mode, batch, u, k, nullptr, nullptr, RQR_r, P0_r,
+                              status_out, 0, 2, st)))
+      return rc;
+    const int ns_hint = (ns > 0 && ns < u) ? ns : 0;
+    return launch_kalman(T_r, RQR_r, P0_r, 0, Z_r, z_batched, d, d_batched, Hdiag, h_batched, y, batch, u, p, T_len, jitter,
+                         missing_fill, ns_hint, z_selector_hint, logp_out, status_out, st);
+  }
   if ((rc = launch_assemble(nullptr, nullptr, nullptr, nullptr, Ta, Ra, Q, q_mode, batch, m, k, nullptr, nullptr, RQR, P0,
                             status_out, 0, 2, st)))
     return rc;
@@ -1919,7 +1954,7 @@ int dsge_solve_kalman_logp_augmented_batched_host(const double* A, const double*
                                                   double* T_aug_out, double* R_aug_out, double* resid_out) {
   int rc = check_common(batch, n, DSGE_MAX_N);
   if (rc) return rc;
-  if (m < n || m > DSGE_MAX_N || k < 1 || k > n || p < 1 || p > DSGE_MAX_P || T_len < 0 || n_links < 0)
+  if (m < n || m > DSGE_MAX_N_BIG || k < 1 || k > n || p < 1 || p > DSGE_MAX_P || T_len < 0 || n_links < 0)
     return fail(DSGE_ERR_INVALID, "bad sizes");
   if (q_mode < 0 || q_mode > 3) return fail(DSGE_ERR_INVALID, "bad q_mode");
   if (!A || !B || !C || !D || !Q || !Z || !y || !logp_out || !status_out) return fail(DSGE_ERR_INVALID, "null pointer");

@@ -692,7 +692,12 @@ int dsge_solve_kalman_logp_batched_host(const double* A, const double* B, const 
  * R = R[inv] (:217-220) -> T_aug = [[T,0],[F,C]], R_aug = [R;0] (_augment_transition :598-650,
  * _append_obs_lag_block :652-694, _augment_selection :696-723) -> P0 = dlyap(T_aug, R_aug Q R_aug') (:814-815)
  * -> Kalman logp with the m-dimensional design matrix of _make_design_matrix (:260-332).
- *   m : augmented state dimension (n <= m <= DSGE_MAX_N);  Z : [p][m] or [batch][p][m]
+ *   m : augmented state dimension, n <= m <= DSGE_MAX_N_BIG (96; round 6).  Beyond 64 the filter runs on the model restricted to
+ *       F = {non-zero columns of T_aug} u {observed variables} -- exact: x_t[F] depends on x_{t-1}[F] only, y_t on x_t[F] only --,
+ *       measured on the device (the call then synchronises its stream once); |F| > 64 is DSGE_ERR_TOO_LARGE, returned with
+ *       T_aug_out, R_aug_out, resid_out and the status words of the solve already written (the exception to "nothing computed":
+ *       F is a property of the SOLVED model).  A 40-variable model with 18 states takes 46 chain states.
+ *   Z : [p][m] or [batch][p][m]
  *   inv_var_order : [n] int32 or NULL (identity)
  *   link_rows/link_cols : [n_links] int32; T_aug[link_rows[i]][link_cols[i]] = 1.0 -- the unit entries of the
  *       constant blocks F (model variable -> first slot of its cumulator / lag chain) and C (slot -> next slot);
