@@ -12,6 +12,7 @@ import oracle
 from geconpy_amd import workloads as wl
 from tests.device_models.gensys_qz_model import gensys_device_model, jacobi_svd, lartg
 from tests.device_models.kalman_model import kalman_downdate_logp
+from tests.device_models.kalman_tile_model import kalman_tile_logp, retained_variables
 
 
 def test_lartg():
@@ -114,6 +115,47 @@ def test_kalman_downdate_model_equals_joseph_oracle():
         r = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], Q, om["Z"], y, H=np.diag(om["Hdiag"]))
         lp = kalman_downdate_logp(y, r["T"], r["R"], Q, om["Z"], om["Hdiag"], np.zeros(7), r["P0"])
         assert_allclose(lp, r["logp"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("observed", [None, wl.SW_OBSERVED_JUMPS], ids=["observe_states", "observe_jumps"])
+def test_kalman_tile_model_equals_joseph_oracle(observed):
+    """kalman_mf_kernel's recursion (upper triangle only, downdate as a product, prediction through the state block, one Newton
+    step on the reciprocals, steady-state switch) against the reference's Joseph-form filter, with missing data."""
+    b = wl.sw_shaped_batch(3)
+    om = wl.sw_shaped_observation_model(observed=observed)
+    y = om["y"].copy()
+    y[5, 2] = np.nan
+    y[17, :] = np.nan
+    y[40, 0] = oracle.MISSING_FILL
+    y[150, 3] = np.nan  # (after the switch: the full update resumes for this step)
+    for i in range(3):
+        Q = np.diag(b["sigma"][i] ** 2)
+        r = oracle.solve_kalman_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], Q, om["Z"], y, H=np.diag(om["Hdiag"]))
+        RQR = r["R"] @ Q @ r["R"].T
+        perm, s = retained_variables(r["T"], om["Z"])
+        assert s < r["T"].shape[0] and len(perm) == (18 if observed is None else 25)  # (retained variables of the 40)
+        lp, at = kalman_tile_logp(y, r["T"], RQR, om["Z"], om["Hdiag"], np.zeros(7), r["P0"], return_steady_step=True)
+        assert_allclose(lp, r["logp"], rtol=1e-12)
+        assert 0 < at < y.shape[0]
+        lp_full = kalman_tile_logp(y, r["T"], RQR, om["Z"], om["Hdiag"], np.zeros(7), r["P0"], steady_tol=0.0)
+        assert_allclose(lp_full, r["logp"], rtol=1e-12)
+        assert_allclose(lp, lp_full, rtol=1e-12)
+        # the reciprocal: hardware seed + one Newton step against the correctly rounded quotient
+        lp_exact = kalman_tile_logp(y, r["T"], RQR, om["Z"], om["Hdiag"], np.zeros(7), r["P0"], seed_error=0.0)
+        assert_allclose(lp, lp_exact, rtol=1e-13)
+        # and the register-block kernels' recursion (symmetrised prediction) agrees with the mirrored upper triangle
+        lp_dd = kalman_downdate_logp(y, r["T"], r["R"], Q, om["Z"], om["Hdiag"], np.zeros(7), r["P0"])
+        assert_allclose(lp, lp_dd, rtol=1e-12)
+
+
+def test_kalman_tile_model_long_sample_stays_symmetric_positive():
+    """Carrying one triangle for 2000 steps (no symmetrisation, no Joseph form): same log-likelihood as the oracle's recursion."""
+    b = wl.sw_shaped_batch(1, first_draw=11)
+    om = wl.sw_shaped_observation_model(T_len=2000)
+    Q = np.diag(b["sigma"][0] ** 2)
+    r = oracle.solve_kalman_logp(b["A"][0], b["B"][0], b["C"][0], b["D"][0], Q, om["Z"], om["y"], H=np.diag(om["Hdiag"]))
+    lp = kalman_tile_logp(om["y"], r["T"], r["R"] @ Q @ r["R"].T, om["Z"], om["Hdiag"], np.zeros(7), r["P0"], steady_tol=0.0)
+    assert_allclose(lp, r["logp"], rtol=1e-12)
 
 
 def test_window_gensys_algebra(ref_goldens, failure_golden):
