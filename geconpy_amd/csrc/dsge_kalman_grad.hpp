@@ -34,6 +34,7 @@
 #include "dsge_device.hpp"
 #include "dsge_kalman2.hpp"
 #include "dsge_kalman_rec.hpp"
+#include "dsge_mfma4.hpp"
 
 #include "../../include/dsge_hip.h"
 
@@ -55,6 +56,10 @@ __device__ __forceinline__ double kg_dot4(const double* a, int sa, const double*
   for (; k < K; ++k) c0 = fma(a[k * sa], b[k * sb], c0);
   return (c0 + c1) + (c2 + c3);
 }
+
+#ifndef KG_MFMA_PRODUCTS
+#define KG_MFMA_PRODUCTS 1
+#endif
 
 template <int BS>
 struct KgSmem {
@@ -85,6 +90,46 @@ __device__ __forceinline__ void kg_mm(double* dst, const double* A, const double
 }
 
 __device__ __forceinline__ double yt_or_zero(double yt) { return (yt == yt) ? yt : 0.0; }
+__device__ __forceinline__ bool kg_in_u(int r, int c, int u) { return r < u && c < u; }
+
+// The three u x u products of a full reverse step on the FP64 matrix core (round 6):  X2 = Pbar T,  t2 = (Pbar T) P+  (left in
+// the Pbar buffer, which is dead from here to the end of the step),  P+bar = T' (Pbar T)  (symmetric: upper tiles, stored with
+// their mirror images).  TMU = tiles of four that cover the u retained variables; the operands stay where the kernel keeps them
+// (NP x LDM, odd LDM: mfma4_strided reads element by element).  Everything outside u x u reads as zero -- Tc, Pbar and the staged
+// P+ are zero there -- and is written as zero.  Register blocks on the 8 x 8 lane grid pad 18 variables to 24 (1.8 x the flops, and
+// the block products are bound by their LDS operand traffic: 8.4 k cycles per step for the three); tiles of four pad to 20 and the
+// symmetric product computes 15 of its 25 tiles.
+template <int BS, int TMU>
+__device__ __forceinline__ void kg_cov_products_mf(double* __restrict__ Pb, const double* __restrict__ Tc,
+                                                   const double* __restrict__ X1, double* __restrict__ X2,
+                                                   double* __restrict__ Ps, int u, int lane) {
+  constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD, DUMP = (NP - 1) * LDM + LDM - 1;  // (column LDM - 1: padding nobody reads)
+  using MP = Mfma4Map<TMU, TMU>;
+  using UX = Mfma4Upper<TMU>;
+  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  mfma4_strided<TMU, TMU, TMU, LDM, 1, LDM, 1>(Pb, Tc, lane, [&](int g, double d) {
+    const int at = (4 * MP::ta(g, blk) + kq) * LDM + 4 * MP::tb(g, blk) + i4;
+    X2[MP::live(g, blk) ? at : DUMP] = d;
+  });
+  wave_sync();
+  mfma4_strided<TMU, TMU, TMU, LDM, 1, LDM, 1>(X2, X1, lane, [&](int g, double d) {
+    const int r = 4 * MP::ta(g, blk) + kq, c = 4 * MP::tb(g, blk) + i4;
+    Pb[MP::live(g, blk) ? r * LDM + c : DUMP] = (r < u && c < u) ? d : 0.0;
+  });
+  int rowa[UX::NG], rowb[UX::NG];
+  mfma4_upper_rows<TMU>(lane, rowa, rowb);
+  mfma4_strided_upper<TMU, TMU, 1, LDM, LDM, 1>(Tc, X2, lane, rowa, rowb, [&](int g, double d) {
+    // this lane's element: row 4 ta + kq, column 4 tb + i4 (rowa / rowb carry 4 ta + i4, 4 tb + i4)
+    const int r = rowa[g] - i4 + kq, c = rowb[g];
+    int ta, tb;
+    bool live;
+    UX::tile(g, blk, ta, tb, live);
+    const bool st = live && r <= c;
+    Ps[st ? r * LDM + c : DUMP] = d;
+    Ps[st ? c * LDM + r : DUMP] = d;
+  });
+  wave_sync();
+}
 
 // (Measured, round 5: capping the SPLIT instance at 256 registers for a second wavefront per SIMD -- it holds 308 -- spills 52
 // dwords into the mean-side loop: the reverse launch 3.0 -> 4.5 ms at unchanged residency; LDS, 36.6 KB, would have to shrink
@@ -103,6 +148,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     double* __restrict__ hbar_out, long long* __restrict__ dbg, const int32_t* __restrict__ order, int rerun_only,
     int tail_valid) {
   constexpr int NP = KgSmem<BS>::NP, LDM = KgSmem<BS>::LDM, PS = KgSmem<BS>::PS;
+  constexpr bool KG_MF = KG_MFMA_PRODUCTS && BS <= 4;  // the reverse step's three products on the matrix core (kg_cov_products_mf)
   // doubles stored per time step: for a FULL step the results of its covariance update -- P+ (NP x NP), K (NP x 8), F^-1,
   // F (8 x 8 each) -- so that the reverse sweep loads them instead of repeating the update; for every step a_t and the
   // index of the step whose covariance it shares.  The initial covariance P_0 sits behind the last step.
@@ -703,7 +749,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         if (pf_src == src_t) {
 #pragma unroll
           for (int k2 = 0; k2 < NPF; ++k2)  // (lane-major record: entry (k2 / BS, k2 % BS) of this lane's block)
-            X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = pf_p[k2];
+            X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = kg_in_u(lr * BS + k2 / BS, lc * BS + k2 % BS, u) ? pf_p[k2] : 0.0;
 #pragma unroll
           for (int k2 = 0; k2 < NKF; ++k2) {
             const int idx = lane + 64 * k2;
@@ -713,7 +759,8 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           Fs[lane] = pf_f;
         } else {
 #pragma unroll
-          for (int k2 = 0; k2 < NPF; ++k2) X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = sp_[lane + 64 * k2];
+          for (int k2 = 0; k2 < NPF; ++k2)
+            X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = kg_in_u(lr * BS + k2 / BS, lc * BS + k2 % BS, u) ? sp_[lane + 64 * k2] : 0.0;
           for (int idx = lane; idx < NP * 8; idx += 64) Kp[(idx >> 3) * PS + (idx & 7)] = sp_[OFF_K + idx];
           Fi[lane] = sp_[OFF_FI + lane];
           Fs[lane] = sp_[OFF_F + lane];
@@ -903,25 +950,49 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         // steady steps after src never touched; X1 = P+ of the source step.
         // (round 5, measured: the three products with four k-steps per stage and two stages in flight -- 8 (BS + BS) operand
         //  registers, free at one wavefront per SIMD -- make the launch SLOWER, 2.62 -> 2.75 ms: not used)
-        kg_mm<BS, false>(X2, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
-        wave_sync();
-        {
-          double pb[BS][BS], t2[BS][BS], pp[BS][BS];
-          blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
-          blk_zero<BS>(t2);
-          blk_zero<BS>(pp);
-          mm_acc<BS, false>(t2, X2, LDM, X1, LDM, u, lr, lc);  // (Pbar T) P+
-          mm_acc_ta<BS>(pp, Tc, LDM, X2, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
+        if constexpr (KG_MF) {
+          {
+            double pb[BS][BS];
+            blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
 #pragma unroll
-          for (int i = 0; i < BS; ++i)
+            for (int i = 0; i < BS; ++i)
 #pragma unroll
-            for (int j = 0; j < BS; ++j) {
-              GbR[i][j] += pb[i][j];                        // Gbar += Pbar
-              TbR[i][j] = fma(2.0, t2[i][j], TbR[i][j]);    // Tbar += 2 Pbar T P+
-            }
-          blk_store_lds<BS>(pp, Ps, LDM, lr, lc);  // Ps now holds P+bar (P_t itself is no longer needed)
+              for (int j = 0; j < BS; ++j) GbR[i][j] += pb[i][j];  // Gbar += Pbar
+          }
+          wave_sync();  // (Pbar is overwritten below)
+          if (u <= 4 * (2 * BS - 1))
+            kg_cov_products_mf<BS, 2 * BS - 1>(Pb, Tc, X1, X2, Ps, u, lane);
+          else
+            kg_cov_products_mf<BS, 2 * BS>(Pb, Tc, X1, X2, Ps, u, lane);
+          {
+            double t2[BS][BS];
+            blk_load_lds<BS>(t2, Pb, LDM, lr, lc);
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+              for (int j = 0; j < BS; ++j) TbR[i][j] = fma(2.0, t2[i][j], TbR[i][j]);  // Tbar += 2 Pbar T P+
+          }
+        } else {
+          kg_mm<BS, false>(X2, Pb, Tc, u, 1.0, false, lr, lc);   // Pbar T
+          wave_sync();
+          {
+            double pb[BS][BS], t2[BS][BS], pp[BS][BS];
+            blk_load_lds<BS>(pb, Pb, LDM, lr, lc);
+            blk_zero<BS>(t2);
+            blk_zero<BS>(pp);
+            mm_acc<BS, false>(t2, X2, LDM, X1, LDM, u, lr, lc);  // (Pbar T) P+
+            mm_acc_ta<BS>(pp, Tc, LDM, X2, LDM, u, lr, lc);      // P+bar = T' (Pbar T)
+#pragma unroll
+            for (int i = 0; i < BS; ++i)
+#pragma unroll
+              for (int j = 0; j < BS; ++j) {
+                GbR[i][j] += pb[i][j];                        // Gbar += Pbar
+                TbR[i][j] = fma(2.0, t2[i][j], TbR[i][j]);    // Tbar += 2 Pbar T P+
+              }
+            blk_store_lds<BS>(pp, Ps, LDM, lr, lc);  // Ps now holds P+bar (P_t itself is no longer needed)
+          }
+          wave_sync();
         }
-        wave_sync();
         if (tm) {
           const long long t_ = clock64();
           qh[5] += t_ - tr;

@@ -229,4 +229,99 @@ __device__ __forceinline__ void mfma4_nt_upper(const double* __restrict__ A, con
   });
 }
 
+// ---- strided operands (round 6, the gradient's reverse sweep): D[r][c] = sum_k A[r ARS + k ACS] B[k BRS + c BCS] ----------------
+// Any leading dimension and either orientation of each operand (a transposed operand swaps its two strides), one ds_read_b64 per
+// operand element -- the LDS bytes per issue are those of the b128 forms above, in twice the instructions.  Same tile maps, same
+// two alternating accumulators; the B operands of the next group are requested before the issues of the current one.  Rows up to
+// 4 TA / columns up to 4 TB / contraction indices up to 4 KT are read unpredicated.
+template <int KT, int TA, int TB, int ARS, int ACS, int BRS, int BCS, class Sink>
+__device__ __forceinline__ void mfma4_strided(const double* __restrict__ A, const double* __restrict__ B, int lane, Sink&& sink) {
+  using MP = Mfma4Map<TA, TB>;
+  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  auto issue = [&](const double (&a)[KT], const double (&b)[KT]) {
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt & 1)
+        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[kt], b[kt], acc1, 0, 0, 0);
+      else
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[kt], b[kt], acc0, 0, 0, 0);
+    }
+    return KT > 1 ? acc0 + acc1 : acc0;
+  };
+  {  // ---- band 0: row tile = block, column tile = group (the A operands are the same for every group) ----
+    const double* ap = A + (4 * (blk < TA ? blk : 0) + i4) * ARS + kq * ACS;
+    const double* bp = B + kq * BRS + i4 * BCS;
+    double a[KT], b[2][KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      a[kt] = ap[4 * kt * ACS];
+      b[0][kt] = bp[4 * kt * BRS];
+    }
+#pragma unroll
+    for (int g = 0; g < MP::G0; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < MP::G0) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) b[nxt][kt] = bp[4 * kt * BRS + (g + 1) * 4 * BCS];
+      }
+      sink(g, issue(a, b[cur]));
+    }
+  }
+  if constexpr (MP::G1 > 0) {  // ---- band 1: row tiles 4 .. TA - 1 ----
+    const int ta1 = 4 + (blk % MP::RP), tb1 = blk / MP::RP;
+    const double* ap = A + (4 * (ta1 < TA ? ta1 : 0) + i4) * ARS + kq * ACS;
+    double a[KT], b[2][KT];
+    auto load_b = [&](int g, double (&bb)[KT]) {
+      const int tbg = (MP::CPG * g + tb1 < TB) ? MP::CPG * g + tb1 : 0;  // (beyond TB: tile 0, never stored)
+      const double* bp = B + kq * BRS + (4 * tbg + i4) * BCS;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) bb[kt] = bp[4 * kt * BRS];
+    };
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) a[kt] = ap[4 * kt * ACS];
+    load_b(0, b[0]);
+#pragma unroll
+    for (int g = 0; g < MP::G1; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < MP::G1) load_b(g + 1, b[nxt]);
+      sink(MP::G0 + g, issue(a, b[cur]));
+    }
+  }
+}
+
+// the upper tiles only (ta <= tb; rowa / rowb from mfma4_upper_rows): sink(g, d), d = D[4 ta + (l >> 4)][4 tb + (l & 3)]
+template <int KT, int TM, int ARS, int ACS, int BRS, int BCS, class Sink>
+__device__ __forceinline__ void mfma4_strided_upper(const double* __restrict__ A, const double* __restrict__ B, int lane,
+                                                    const int (&rowa)[Mfma4Upper<TM>::NG], const int (&rowb)[Mfma4Upper<TM>::NG],
+                                                    Sink&& sink) {
+  constexpr int NG = Mfma4Upper<TM>::NG;
+  const int kq = lane >> 4;
+  double a[2][KT], b[2][KT];
+  auto load = [&](int g, double (&aa)[KT], double (&bb)[KT]) {
+    const double* ap = A + rowa[g] * ARS + kq * ACS;
+    const double* bp = B + kq * BRS + rowb[g] * BCS;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      aa[kt] = ap[4 * kt * ACS];
+      bb[kt] = bp[4 * kt * BRS];
+    }
+  };
+  load(0, a[0], b[0]);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    if (g + 1 < NG) load(g + 1, a[nxt], b[nxt]);
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt & 1)
+        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[cur][kt], b[cur][kt], acc1, 0, 0, 0);
+      else
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[cur][kt], b[cur][kt], acc0, 0, 0, 0);
+    }
+    sink(g, KT > 1 ? acc0 + acc1 : acc0);
+  }
+}
+
 }  // namespace dsge
