@@ -667,6 +667,19 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         my_o_draw = o;
         my_zv_draw = zv[o];
       }
+    // and the observation (if any) that selects row (lane + 64 k) >> 3 of the panels (the reverse step's Mbar += Zm' Fbar)
+    int orow_draw[BS];
+    double ozv_draw[BS];
+#pragma unroll
+    for (int k2 = 0; k2 < BS; ++k2) {
+      orow_draw[k2] = -1;
+      ozv_draw[k2] = 0.0;
+      for (int o = 0; o < p; ++o)
+        if (zpos[o] == ((lane_kernel + 64 * k2) >> 3)) {
+          orow_draw[k2] = o;
+          ozv_draw[k2] = zv[o];
+        }
+    }
     // likewise the draw's constants of the mean side: d, z and the selected position of observation `lane`, and column `lane` of Tc
     // (48 registers across the whole sweep: the kernel runs one wavefront per SIMD, they are free)
     const double dd_draw = (lane_kernel < p) ? dd[lane_kernel] : 0.0, zv_draw = (lane_kernel < p) ? zv[lane_kernel] : 0.0;
@@ -998,70 +1011,152 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           qh[5] += t_ - tr;
           tr = t_;
         }
-        for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
-          const int i = idx >> 3, o = idx & 7;
-          Yp[i * PS + o] = kg_dot4(Ps + i * LDM, 1, Kp + o, PS, u);
-        }
-        wave_sync();
-        // (idx = lane + 64 k: the column o = idx & 7 = fq is the same in every trip -- column fq of F + jit I and of F^-1 are read
-        //  once, with compile-time loop bounds)
-        double fcol[8], ficol[8];
+        if constexpr (KG_MF) {
+          // ---- the panel algebra with the two contractions over the retained variables on the matrix core (round 6) ----
+          constexpr int PDUMP = (NP - 1) * PS + PS - 1;
+          const bool small = u <= 4 * (2 * BS - 1);
+          {  // Y = P+bar K
+            const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+            auto y_sink = [&](auto mp, int g, double d) {
+              using MPY = decltype(mp);
+              const int at = (4 * MPY::ta(g, blk) + kq) * PS + 4 * MPY::tb(g, blk) + i4;
+              Yp[MPY::live(g, blk) ? at : PDUMP] = d;
+            };
+            if (small)
+              mfma4_strided<2 * BS - 1, 2 * BS - 1, 2, LDM, 1, PS, 1>(Ps, Kp, lane, [&](int g, double d) { y_sink(Mfma4Map<2 * BS - 1, 2>{}, g, d); });
+            else
+              mfma4_strided<2 * BS, 2 * BS, 2, LDM, 1, PS, 1>(Ps, Kp, lane, [&](int g, double d) { y_sink(Mfma4Map<2 * BS, 2>{}, g, d); });
+          }
+          wave_sync();
+          // Kbar = sum_t a+bar_t v_t' - 2 Y (F + jit I);  Mbar = Kbar F^-1: row i of Kbar sits in the eight lanes of this lane's group
+          // (idx = lane + 64 k: i = idx >> 3, o = idx & 7 = fq) -- exchanged by shuffles, no LDS round trip;  Kb <- Y + Mbar
+          double fcol[8], ficol[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          fcol[q] = -2.0 * (Fs[q * 8 + fq] + ((q == fq) ? cv.jit_V : 0.0));
-          ficol[q] = Fi[q * 8 + fq];
-        }
+          for (int q = 0; q < 8; ++q) {
+            fcol[q] = -2.0 * (Fs[q * 8 + fq] + ((q == fq) ? cv.jit_V : 0.0));
+            ficol[q] = Fi[q * 8 + fq];
+          }
+          double yrow[BS][8];
 #pragma unroll
-        for (int k2 = 0; k2 < BS; ++k2) {  // Kbar = sum_t a+bar_t v_t' - 2 Y (F + jit I)
-          const int idx = lane + 64 * k2, i = idx >> 3;
-          if (i < u) {
+          for (int k2 = 0; k2 < BS; ++k2)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) yrow[k2][q] = Yp[((lane + 64 * k2) >> 3) * PS + q];
+#pragma unroll
+          for (int k2 = 0; k2 < BS; ++k2) {
+            const int i = (lane + 64 * k2) >> 3;
             double sk = Kacc[k2];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sk = fma(Yp[i * PS + q], fcol[q], sk);
-            Kb[i * PS + fq] = (fq < p) ? sk : 0.0;
-          }
-        }
-        wave_sync();
-        for (int idx = lane; idx < u * 8; idx += 64) {  // Mbar = Kbar F^-1
-          const int i = idx >> 3;
-          double sm = 0.0;
+            for (int q = 0; q < 8; ++q) sk = fma(yrow[k2][q], fcol[q], sk);
+            const double kb = (i < u && fq < p) ? sk : 0.0;
+            double sm0 = 0.0, sm1 = 0.0;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], ficol[q], sm);
-          Mb[i * PS + fq] = (fq < p) ? sm : 0.0;
-        }
-        wave_sync();
-        {  // Fbar = -1/2 (nlam F^-1 - sum_t lam_t fiv_t fiv_t') - K' Y - K' Mbar      (lane = fo*8 + fq)
-          double sf = 0.0;
-          if (fo < p && fq < p) {
-            // (over all NP rows with a compile-time bound: rows >= u of K are zero, of Y and Mbar zero or stale but finite;
-            // four accumulators, the 72 LDS reads requested together -- the loop over u waited for three reads per term)
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            constexpr int FB_UNROLL = BS <= 4 ? NP / 4 : 2;
-#pragma unroll FB_UNROLL
-            for (int i = 0; i < NP; i += 4) {
-              s0 = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], s0);
-              s1 = fma(-Kp[(i + 1) * PS + fo], Yp[(i + 1) * PS + fq] + Mb[(i + 1) * PS + fq], s1);
-              s2 = fma(-Kp[(i + 2) * PS + fo], Yp[(i + 2) * PS + fq] + Mb[(i + 2) * PS + fq], s2);
-              s3 = fma(-Kp[(i + 3) * PS + fo], Yp[(i + 3) * PS + fq] + Mb[(i + 3) * PS + fq], s3);
+            for (int q = 0; q < 8; q += 2) {
+              sm0 = fma(__shfl(kb, (lane & 56) + q, 64), ficol[q], sm0);
+              sm1 = fma(__shfl(kb, (lane & 56) + q + 1, 64), ficol[q + 1], sm1);
             }
-            sf = -0.5 * (nlam * Fi[lane] - Qacc) + ((s0 + s1) + (s2 + s3));
+            const double mb = (i < u && fq < p) ? sm0 + sm1 : 0.0;
+            Mb[i * PS + fq] = mb;
+            Kb[i * PS + fq] = (i < u) ? yrow[k2][fq] + mb : 0.0;
           }
+          wave_sync();
+          {  // K' (Y + Mbar), 8 x 8
+            const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+            auto f_sink = [&](int g, double d) {
+              using MPF = Mfma4Map<2, 2>;
+              const int at = (4 * MPF::ta(g, blk) + kq) * 8 + 4 * MPF::tb(g, blk) + i4;
+              *(MPF::live(g, blk) ? Ft + at : sp) = d;  // (blocks 2, 3 recompute tile 0: into the spare vector)
+            };
+            if (small)
+              mfma4_strided<2 * BS - 1, 2, 2, 1, PS, PS, 1>(Kp, Kb, lane, f_sink);
+            else
+              mfma4_strided<2 * BS, 2, 2, 1, PS, PS, 1>(Kp, Kb, lane, f_sink);
+          }
+          wave_sync();
+          // Fbar = -1/2 (nlam F^-1 - sum_t lam_t fiv_t fiv_t') - K' (Y + Mbar)      (lane = fo*8 + fq)
+          const double sf = (fo < p && fq < p) ? -0.5 * (nlam * Fi[lane] - Qacc) - Ft[lane] : 0.0;
           Fb[lane] = sf;
+          const double w_q = ((omask >> fq) & 1ull) ? 1.0 : 0.0;
+          {  // hbar += w o diag(Fbar)   (lane < 8: fq = lane)
+            const double fdiag = __shfl(sf, (lane * 9) & 63, 64);
+            if (lane < 8 && lane < p) hb[lane] = fma(w_q, fdiag, hb[lane]);
+          }
+          wave_sync();
+          // Mbar += Zm' Fbar (row zpos[o] gets w zv Fbar[o,:]) folded into  Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]
+#pragma unroll
+          for (int k2 = 0; k2 < BS; ++k2) {
+            const int i = (lane + 64 * k2) >> 3;
+            const int oi = orow_draw[k2];
+            const double wz_i = (oi >= 0 && ((omask >> (oi & 7)) & 1ull)) ? ozv_draw[k2] : 0.0;
+            const double mbv = fma(wz_i, Fb[(oi & 7) * 8 + fq], Mb[i * PS + fq]);
+            if (i < u && fq < p) Ps[i * LDM + zpos_q] = fma(w_q * zv_q, mbv, Ps[i * LDM + zpos_q]);
+          }
+          wave_sync();
+        } else {
+          for (int idx = lane; idx < u * 8; idx += 64) {  // Y = P+bar K
+            const int i = idx >> 3, o = idx & 7;
+            Yp[i * PS + o] = kg_dot4(Ps + i * LDM, 1, Kp + o, PS, u);
+          }
+          wave_sync();
+          // (idx = lane + 64 k: the column o = idx & 7 = fq is the same in every trip -- column fq of F + jit I and of F^-1 are read
+          //  once, with compile-time loop bounds)
+          double fcol[8], ficol[8];
+  #pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            fcol[q] = -2.0 * (Fs[q * 8 + fq] + ((q == fq) ? cv.jit_V : 0.0));
+            ficol[q] = Fi[q * 8 + fq];
+          }
+  #pragma unroll
+          for (int k2 = 0; k2 < BS; ++k2) {  // Kbar = sum_t a+bar_t v_t' - 2 Y (F + jit I)
+            const int idx = lane + 64 * k2, i = idx >> 3;
+            if (i < u) {
+              double sk = Kacc[k2];
+  #pragma unroll
+              for (int q = 0; q < 8; ++q) sk = fma(Yp[i * PS + q], fcol[q], sk);
+              Kb[i * PS + fq] = (fq < p) ? sk : 0.0;
+            }
+          }
+          wave_sync();
+          for (int idx = lane; idx < u * 8; idx += 64) {  // Mbar = Kbar F^-1
+            const int i = idx >> 3;
+            double sm = 0.0;
+  #pragma unroll
+            for (int q = 0; q < 8; ++q) sm = fma(Kb[i * PS + q], ficol[q], sm);
+            Mb[i * PS + fq] = (fq < p) ? sm : 0.0;
+          }
+          wave_sync();
+          {  // Fbar = -1/2 (nlam F^-1 - sum_t lam_t fiv_t fiv_t') - K' Y - K' Mbar      (lane = fo*8 + fq)
+            double sf = 0.0;
+            if (fo < p && fq < p) {
+              // (over all NP rows with a compile-time bound: rows >= u of K are zero, of Y and Mbar zero or stale but finite;
+              // four accumulators, the 72 LDS reads requested together -- the loop over u waited for three reads per term)
+              double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+              constexpr int FB_UNROLL = BS <= 4 ? NP / 4 : 2;
+  #pragma unroll FB_UNROLL
+              for (int i = 0; i < NP; i += 4) {
+                s0 = fma(-Kp[i * PS + fo], Yp[i * PS + fq] + Mb[i * PS + fq], s0);
+                s1 = fma(-Kp[(i + 1) * PS + fo], Yp[(i + 1) * PS + fq] + Mb[(i + 1) * PS + fq], s1);
+                s2 = fma(-Kp[(i + 2) * PS + fo], Yp[(i + 2) * PS + fq] + Mb[(i + 2) * PS + fq], s2);
+                s3 = fma(-Kp[(i + 3) * PS + fo], Yp[(i + 3) * PS + fq] + Mb[(i + 3) * PS + fq], s3);
+              }
+              sf = -0.5 * (nlam * Fi[lane] - Qacc) + ((s0 + s1) + (s2 + s3));
+            }
+            Fb[lane] = sf;
+          }
+          wave_sync();
+          // (mask weights from the ballot, selector entries from the draw's registers: no dependent LDS reads of the 8-vectors)
+          const double w_f = ((omask >> fo) & 1ull) ? 1.0 : 0.0, w_q = ((omask >> fq) & 1ull) ? 1.0 : 0.0;
+          if (lane < 8 && lane < p) hb[lane] = fma(w_q, Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)   (lane < 8: fq = lane)
+          if (fo < p && fq < p) {  // Mbar += Zm' Fbar: row zpos[fo] (distinct per fo) gets w zv Fbar[fo,:]
+            Mb[zpos_f * PS + fq] = fma(w_f * zv_f, Fb[lane], Mb[zpos_f * PS + fq]);
+          }
+          wave_sync();
+          // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]   (idx = lane + 64 k: o = idx & 7 = fq in every trip)
+          for (int idx = lane; idx < u * 8; idx += 64) {
+            const int i = idx >> 3;
+            if (fq < p) Ps[i * LDM + zpos_q] = fma(w_q * zv_q, Mb[i * PS + fq], Ps[i * LDM + zpos_q]);
+          }
+          wave_sync();
         }
-        wave_sync();
-        // (mask weights from the ballot, selector entries from the draw's registers: no dependent LDS reads of the 8-vectors)
-        const double w_f = ((omask >> fo) & 1ull) ? 1.0 : 0.0, w_q = ((omask >> fq) & 1ull) ? 1.0 : 0.0;
-        if (lane < 8 && lane < p) hb[lane] = fma(w_q, Fb[lane * 9], hb[lane]);  // hbar += w o diag(Fbar)   (lane < 8: fq = lane)
-        if (fo < p && fq < p) {  // Mbar += Zm' Fbar: row zpos[fo] (distinct per fo) gets w zv Fbar[fo,:]
-          Mb[zpos_f * PS + fq] = fma(w_f * zv_f, Fb[lane], Mb[zpos_f * PS + fq]);
-        }
-        wave_sync();
-        // Pbar = sym(P+bar + Mbar Zm):  column zpos[o] += w zv Mbar[:,o]   (idx = lane + 64 k: o = idx & 7 = fq in every trip)
-        for (int idx = lane; idx < u * 8; idx += 64) {
-          const int i = idx >> 3;
-          if (fq < p) Ps[i * LDM + zpos_q] = fma(w_q * zv_q, Mb[i * PS + fq], Ps[i * LDM + zpos_q]);
-        }
-        wave_sync();
         if (tm) {
           const long long t_ = clock64();
           qh[6] += t_ - tr;
