@@ -645,6 +645,222 @@ __device__ __forceinline__ bool adj_stein_solve(double* W, double* Tk, const dou
   return ok;
 }
 
+// Round 6: the same Stein equation on its COMPACT form.  C has non-zero columns only for the nl variables that appear with a
+// lead (index set L), T only for the ns state variables (index set St), so  G = -M^-T C' = -Wm V  with  Wm = M^-T E_L (n x nl),
+// V = C_L' (nl x n), and  S = H - Wm (V S) T'.  Z = V S (nl x n) solves  Z = V H + Gs Z T',  Gs = -V Wm (nl x nl), and Z T' needs
+// only the columns St of Z:  Zs = Z0s + Gs Zs Tss',  Tss = T[St, St] -- a Stein equation of size nl x ns (12 x 18 on the SW-shaped
+// systems instead of 40 x 40), solved by the same doubling on tiles of 8 BSC; then  S = H - (Wm Zs) T[:, St]'.  Per doubling
+// 4 products of <= 24^3 instead of 4 of 40^3.  And it is the BETTER conditioned iteration: the powers of the embedded G grow before
+// they decay (max |G^(2^k)| up to 1e3 on the SW-shaped draws, 1e25 in float64 on draw 752 whose B + C T has condition 3e8 --
+// which is why that form needs a refinement pass and an elimination-based fall-back), those of Gs do not (|Gs| < 1 on all of the
+// first 800 draws): against the reference's Kronecker solve (shared.py:53-71) the full form is off by up to 2e-8 before refinement,
+// the compact one by 1e-12, and 1.9e-8 on draw 752 (numpy model: tests/device_models/adjoint_compact_model.py).
+// `took` = false (and nothing else done) when L or St do not fit the compact tile; the caller then runs adj_stein_solve.
+template <int BS>
+struct AdjCompact {
+  static constexpr int BSC = BS <= 3 ? 1 : (BS - 2 > 4 ? 4 : BS - 2);
+  static constexpr int NPC = 8 * BSC, LDC = NPC + 1;
+  static constexpr bool enabled = BS >= 4;
+};
+
+template <int BS>
+__device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, const double* __restrict__ B,
+                                                        const double* __restrict__ C, const double* __restrict__ T, size_t off,
+                                                        int n, const double (&Hb)[BS][BS], double (&Sb)[BS][BS], int lane,
+                                                        double& gmax, bool& took) {
+  constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
+  constexpr int BSC = AdjCompact<BS>::BSC, NPC = AdjCompact<BS>::NPC, LDC = AdjCompact<BS>::LDC;
+  constexpr int TK_FREE = NP * LD - NPC;  // the two index lists (2 NPC ints) sit at the end of the NP x LD matrix
+  static_assert(NP * BS + BS * 3 * NP + NP / 2 <= TK_FREE && 2 * NPC * LDC <= TK_FREE && NP * LDC <= TK_FREE, "compact layout");
+  double* Ts = W + 2 * NP;
+  double* Lbuf = Tk;
+  double* Ybuf = Lbuf + NP * BS;
+  int* prow = (int*)(Ybuf + BS * 3 * NP);
+  int* Lidx = (int*)(Tk + TK_FREE);
+  int* Sidx = Lidx + NPC;
+  double* Gs = Tk;              // NPC x LDC   Gs_k
+  double* Fs = Tk + NPC * LDC;  // NPC x LDC   Tss_k
+  double* ZP = W;               // NPC x NPC in the first column group of W (row stride LDW): Zs, then Zs Tss_k'
+  const int lr = lane >> 3, lc = lane & 7;
+  wave_sync();
+  for (int idx = lane; idx < NP * LDW; idx += 64) W[idx] = 0.0;
+  wave_sync();
+  lds_load_matrix(Ts, LDW, NP, NP, T + off, n, n, lane);
+  lds_load_matrix(Tk, LD, NP, NP, C + off, n, n, lane);
+  wave_sync();
+  bool nzT = false, nzC = false;
+  if (lane < n)
+    for (int r = 0; r < n; ++r) {
+      nzT = nzT | (Ts[r * LDW + lane] != 0.0);
+      nzC = nzC | (Tk[r * LD + lane] != 0.0);
+    }
+  const unsigned long long cmT = __ballot(nzT), cmC = __ballot(nzC);
+  const int ns = __popcll(cmT), nl = __popcll(cmC);
+  took = ns >= 1 && nl >= 1 && ns <= NPC && nl <= NPC;
+  if (!took) return false;
+  {
+    double Mb[BS][BS];
+    blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
+    mm_acc<BS, false>(Mb, Tk, LD, Ts, LDW, n, lr, lc);  // M = B + C T
+    wave_sync();  // T (third column group of W) and C (Tk) are dead from here
+    if (lane < n) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if ((cmC >> lane) & 1ull) Lidx[__popcll(cmC & below)] = lane;
+      if ((cmT >> lane) & 1ull) Sidx[__popcll(cmT & below)] = lane;
+    }
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        W[(lc * BS + j) * LDW + lr * BS + i] = Mb[i][j];  // M'
+        W[(lc * BS + j) * LDW + 2 * NP + lr * BS + i] = 0.0;
+      }
+    blk_store_lds<BS>(Hb, W + NP, LDW, lr, lc);
+  }
+  wave_sync();
+  if (lane < nl) W[Lidx[lane] * LDW + 2 * NP + lane] = 1.0;  // E_L
+  gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);
+  gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
+  {
+    double Zr[BS][BS];
+    blk_zero<BS>(Zr);
+    blk_load_lds<BS>(Sb, W + NP, LDW, lr, lc);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Sb[i][j] = -Sb[i][j];
+    blk_store_lds<BS>(Sb, W + NP, LDW, lr, lc);  // H = -M^-T rhs
+    blk_store_lds<BS>(Zr, W, LDW, lr, lc);       // the first column group: zero (it takes the compact matrices)
+  }
+  // C_L (n x nl, row stride LDC) staged in the NP x LD matrix
+  lane_loop_batched<8>(n * nl, lane,
+                       [&](int idx) {
+                         const int r = idx / nl, a = idx - r * nl;
+                         return C[off + (size_t)r * n + Lidx[a]];
+                       },
+                       [&](int idx, double v) {
+                         const int r = idx / nl, a = idx - r * nl;
+                         Tk[r * LDC + a] = v;
+                       });
+  wave_sync();
+  // Gs_0 = -C_L' Wm and Zs_0 = C_L' H[:, St], one element per lane and trip (into registers: their buffers are the staged C_L's)
+  constexpr int NEL = BSC * BSC;  // NPC^2 / 64
+  double gsv[NEL], z0v[NEL];
+#pragma unroll
+  for (int e = 0; e < NEL; ++e) {
+    const int idx = lane + 64 * e, a = idx / NPC, b = idx - a * NPC;
+    const int ac = a < nl ? a : 0;
+    const double* ca = Tk + ac;
+    const double* wb = W + 2 * NP + (b < nl ? b : 0);
+    const double* hb = W + NP + Sidx[b < ns ? b : 0];
+    double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
+    int r = 0;
+    for (; r + 2 <= n; r += 2) {
+      const double c0 = ca[r * LDC], c1 = ca[(r + 1) * LDC];
+      g0 = fma(c0, wb[r * LDW], g0);
+      g1 = fma(c1, wb[(r + 1) * LDW], g1);
+      z0 = fma(c0, hb[r * LDW], z0);
+      z1 = fma(c1, hb[(r + 1) * LDW], z1);
+    }
+    if (r < n) {
+      g0 = fma(ca[r * LDC], wb[r * LDW], g0);
+      z0 = fma(ca[r * LDC], hb[r * LDW], z0);
+    }
+    gsv[e] = (a < nl && b < nl) ? -(g0 + g1) : 0.0;
+    z0v[e] = (a < nl && b < ns) ? z0 + z1 : 0.0;
+  }
+  wave_sync();
+  for (int idx = lane; idx < 2 * NPC * LDC; idx += 64) Tk[idx] = 0.0;
+  wave_sync();
+  double gm = 0.0;
+#pragma unroll
+  for (int e = 0; e < NEL; ++e) {
+    const int idx = lane + 64 * e, a = idx / NPC, b = idx - a * NPC;
+    Gs[a * LDC + b] = gsv[e];
+    ZP[a * LDW + b] = z0v[e];
+    gm = nanmax(gm, fabs(gsv[e]));
+  }
+  gmax = wave_nanmax(gm);
+  lane_loop_batched<8>(ns * ns, lane,
+                       [&](int idx) {
+                         const int i = idx / ns, j = idx - i * ns;
+                         return T[off + (size_t)Sidx[i] * n + Sidx[j]];
+                       },
+                       [&](int idx, double v) {
+                         const int i = idx / ns, j = idx - i * ns;
+                         Fs[i * LDC + j] = v;
+                       });
+  wave_sync();
+  double Zb[BSC][BSC];
+  blk_load_lds<BSC>(Zb, ZP, LDW, lr, lc);
+  bool ok = false;
+  for (int it = 0; it < LYAP_MAX_DOUBLINGS; ++it) {
+    {
+      double P1[BSC][BSC];
+      blk_zero<BSC>(P1);
+      mm_acc<BSC, true>(P1, ZP, LDW, Fs, LDC, ns, lr, lc);  // Zs Tss_k'
+      wave_sync();
+      blk_store_lds<BSC>(P1, ZP, LDW, lr, lc);
+    }
+    wave_sync();
+    double Ib[BSC][BSC], G2[BSC][BSC], T2[BSC][BSC];
+    blk_zero<BSC>(Ib);
+    blk_zero<BSC>(G2);
+    blk_zero<BSC>(T2);
+    mm_acc<BSC, false>(Ib, Gs, LDC, ZP, LDW, nl, lr, lc);  // Gs_k Zs Tss_k'
+    mm_acc<BSC, false>(G2, Gs, LDC, Gs, LDC, nl, lr, lc);  // Gs_k^2
+    mm_acc<BSC, false>(T2, Fs, LDC, Fs, LDC, ns, lr, lc);  // Tss_k^2
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < BSC; ++i)
+#pragma unroll
+      for (int j = 0; j < BSC; ++j) Zb[i][j] += Ib[i][j];
+    blk_store_lds<BSC>(Zb, ZP, LDW, lr, lc);
+    blk_store_lds<BSC>(G2, Gs, LDC, lr, lc);
+    blk_store_lds<BSC>(T2, Fs, LDC, lr, lc);
+    const double dmax = blk_maxabs<BSC>(Ib), smax = blk_maxabs<BSC>(Zb);
+    wave_sync();
+    if (!(dmax == dmax) || !(smax < 1e300)) break;
+    if (dmax <= 1e-17 * smax) {
+      ok = true;
+      break;
+    }
+    gmax = fmax(gmax, blk_maxabs<BSC>(G2));
+  }
+  // S = H - (Wm Zs) T[:, St]'
+  {
+    double Ub[BS][BS];
+    blk_zero<BS>(Ub);
+    mm_acc<BS, false>(Ub, W + 2 * NP, LDW, ZP, LDW, nl, lr, lc);  // Wm Zs (n x ns; the columns >= ns of the group are zero)
+    wave_sync();
+    blk_store_lds<BS>(Ub, W, LDW, lr, lc);
+    for (int idx = lane; idx < TK_FREE; idx += 64) Tk[idx] = 0.0;
+    wave_sync();
+    lane_loop_batched<8>(n * ns, lane,
+                         [&](int idx) {
+                           const int j = idx / ns, k = idx - j * ns;
+                           return T[off + (size_t)j * n + Sidx[k]];
+                         },
+                         [&](int idx, double v) {
+                           const int j = idx / ns, k = idx - j * ns;
+                           Tk[j * LD + k] = v;
+                         });
+    wave_sync();
+    double Db[BS][BS];
+    blk_zero<BS>(Db);
+    mm_acc<BS, true>(Db, W, LDW, Tk, LD, ns, lr, lc);  // (Wm Zs) T[:, St]'
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Sb[i][j] -= Db[i][j];
+    wave_sync();
+    blk_store_lds<BS>(Sb, W + NP, LDW, lr, lc);
+    wave_sync();
+  }
+  return ok;
+}
+
 // The fall-back of the second pass: X <- -M^-T (T_bar + C' X T') with an ELIMINATION per sweep instead of powers of an explicit
 // G = -M^-T C'.  When M = B + C T is nearly singular (SW-shaped draw 752: cond 3e8, max|G| = 2e7) G is only known to
 // cond x eps x |G| ~ 0.6 in absolute terms: its computed powers explode (true |G^16| = 1.7e5, float64 1e25) and even the plain
@@ -838,7 +1054,9 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
     } else {
       double Hb[BS][BS];
       blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);
-      ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax);
+      bool took = false;
+      if constexpr (AdjCompact<BS>::enabled) ok = adj_stein_solve_compact<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax, took);
+      if (!took) ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax);
       // (debug hook: refine_mode 1 = every draw, 2 = none).  A solve that broke down -- the computed powers of G exploded --
       // leaves zeros and goes to the second pass as well, which then takes its elimination-based fall-back
       flag = refine_mode ? refine_mode == 1 : (!ok || gmax > ADJ_REFINE_GROWTH);

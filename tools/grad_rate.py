@@ -9,6 +9,7 @@ if os.environ.get("DSGE_TEST_LIB"):  # (A/B of a differently built library)
     _lib.LIB_PATH = os.path.abspath(os.environ["DSGE_TEST_LIB"])
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 SOLVER = sys.argv[2] if len(sys.argv) > 2 else "cycle_reduction"  # or "gensys", the reference's default estimation solver
+OPTS = {"kalman_grad_split": int(sys.argv[3])} if len(sys.argv) > 3 else None  # (A/B of the reverse sweep's arrangements)
 nd = min(nb, 4096)  # distinct draws (a tiled small set clusters the draws that take second passes)
 b = wl.sw_shaped_batch(nd); om = wl.sw_shaped_observation_model(); rep = (nb + nd - 1) // nd
 eng = LogpEngine(0)
@@ -19,7 +20,7 @@ def run(A, B, C, D, q):
     for it in range(4):
         if it == 1:
             torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out, solver=SOLVER, n_lead_hint=12 if SOLVER == "gensys" else 0)
+        out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out, solver=SOLVER, n_lead_hint=12 if SOLVER == "gensys" else 0, options=OPTS)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / 3, out
 
@@ -28,11 +29,11 @@ out = None
 for it in range(4):
     if it == 1:
         torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out, solver=SOLVER, n_lead_hint=12 if SOLVER == "gensys" else 0)
+    out = eng.solve_kalman_logp_grad(A, B, C, D, q, Z, y, Hdiag=H, tol=1e-8, max_iter=1000, n_filter_hint=18, out=out, solver=SOLVER, n_lead_hint=12 if SOLVER == "gensys" else 0, options=OPTS)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 st = out["status"].cpu().numpy() if hasattr(out["status"], "cpu") else np.asarray(out["status"])
 bad = np.flatnonzero(st != 0)
-print(f"solver {SOLVER}: {nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {len(bad)}"
+print(f"solver {SOLVER}{'' if OPTS is None else ' ' + str(OPTS)}: {nb} draws: {dt*1e3:.2f} ms per logp+gradient batch = {nb/dt:.0f} gradient evals/s; failed {len(bad)}"
       + (f" (draws {bad[:8].tolist()}, status words {st[bad[:8]].tolist()})" if len(bad) else ""))
 
 # The batch holds ONE draw (752: cond(B + C T) = 3e8) whose policy adjoints need the elimination-based fixed point of the second
