@@ -11,6 +11,7 @@ from numpy.testing import assert_allclose
 import oracle
 from geconpy_amd import workloads as wl
 from tests.device_models.gensys_qz_model import gensys_device_model, jacobi_svd, lartg
+from tests.device_models.adjoint_compact_model import compact_doubling, full_doubling, kronecker_solve
 from tests.device_models.kalman_model import kalman_downdate_logp
 from tests.device_models.kalman_tile_model import kalman_tile_logp, retained_variables
 
@@ -458,3 +459,34 @@ def test_spectral_division_on_the_reference_failure_cases():
     assert not certify_contraction(np.diag([1.0 + 1e-9, 0.1])) and not certify_contraction(np.array([[np.nan]]))
     J = np.array([[0.9, 50.0], [0.0, 0.9]])  # non-normal: the norms grow before they decay, the squares still get there
     assert certify_contraction(J)
+
+
+def test_compact_adjoint_stein_equation_against_the_kronecker_solve():
+    """adj_stein_solve_compact's algebra: the nl x ns Stein equation reproduces the reference's Kronecker solve of the policy
+    adjoints (shared.py:53-71) -- to 1e-11 on ordinary SW-shaped draws and to the reference's own level on the nearly singular draw
+    752 (cond(B + C T) = 3e8), where the n x n doubling of rounds 2-5 overflows; and the powers of the compact Gs do not grow."""
+    rng = np.random.default_rng(3)
+    worst_full = 0.0
+    for first, count in ((0, 12), (752, 1)):
+        b = wl.sw_shaped_batch(count, first_draw=first)
+        for i in range(count):
+            A, B, C, D = (b[k][i] for k in "ABCD")
+            T = oracle.solve_policy_function_with_cycle_reduction(A, B, C, D, max_iter=1000, tol=1e-12)[0]
+            n = T.shape[0]
+            T_bar = rng.standard_normal((n, n))
+            T_bar[:, np.all(T == 0, axis=0)] = 0.0  # (the structurally zero columns of T carry no cotangent)
+            M = B + C @ T
+            S_ref = kronecker_solve(M, C, T, T_bar)
+            S_c, growth_c, nl, ns = compact_doubling(M, C, T, T_bar)
+            assert (nl, ns) == (wl.SW_SHAPE["n_lead"], wl.SW_SHAPE["n_state"])
+            err = np.abs(S_c - S_ref).max() / np.abs(S_ref).max()
+            assert growth_c < 1.0
+            if first == 752:
+                assert np.linalg.cond(M) > 1e8 and err < 1e-6
+                S_f, growth_f = full_doubling(M, C, T, T_bar)
+                assert not np.isfinite(S_f).all() or growth_f > 1e10  # (what the elimination-based fall-back was for)
+            else:
+                assert err < 1e-11
+                S_f, growth_f = full_doubling(M, C, T, T_bar)
+                worst_full = max(worst_full, np.abs(S_f - S_ref).max() / np.abs(S_ref).max())
+    assert worst_full < 1e-7
