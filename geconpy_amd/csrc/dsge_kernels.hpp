@@ -667,7 +667,7 @@ template <int BS>
 __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, const double* __restrict__ B,
                                                         const double* __restrict__ C, const double* __restrict__ T, size_t off,
                                                         int n, const double (&Hb)[BS][BS], double (&Sb)[BS][BS], int lane,
-                                                        double& gmax, bool& took) {
+                                                        double& gmax, bool& took, int& t_cols) {
   constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
   constexpr int BSC = AdjCompact<BS>::BSC, NPC = AdjCompact<BS>::NPC, LDC = AdjCompact<BS>::LDC;
   constexpr int TK_FREE = NP * LD - NPC;  // the two index lists (2 NPC ints) sit at the end of the NP x LD matrix
@@ -698,10 +698,16 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
   const int ns = __popcll(cmT), nl = __popcll(cmC);
   took = ns >= 1 && nl >= 1 && ns <= NPC && nl <= NPC;
   if (!took) return false;
+  t_cols = 64 - __clzll((long long)cmT);  // last non-zero column of T + 1
+#ifdef ADJ_STOP
+  if (ADJ_STOP == 1) return true;
+#endif
   {
     double Mb[BS][BS];
     blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
-    mm_acc<BS, false>(Mb, Tk, LD, Ts, LDW, n, lr, lc);  // M = B + C T
+    // M = B + C T: the contraction runs over the columns of C between its first and its last non-zero one
+    const int c_lo = __ffsll((long long)cmC) - 1, c_hi = 64 - __clzll((long long)cmC);
+    mm_acc<BS, false>(Mb, Tk + c_lo, LD, Ts + c_lo * LDW, LDW, c_hi - c_lo, lr, lc);
     wave_sync();  // T (third column group of W) and C (Tk) are dead from here
     if (lane < n) {
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -721,6 +727,9 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
   if (lane < nl) W[Lidx[lane] * LDW + 2 * NP + lane] = 1.0;  // E_L
   gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);
   gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
+#ifdef ADJ_STOP
+  if (ADJ_STOP == 2) return true;
+#endif
   {
     double Zr[BS][BS];
     blk_zero<BS>(Zr);
@@ -733,7 +742,7 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
     blk_store_lds<BS>(Sb, W + NP, LDW, lr, lc);  // H = -M^-T rhs
     blk_store_lds<BS>(Zr, W, LDW, lr, lc);       // the first column group: zero (it takes the compact matrices)
   }
-  // C_L (n x nl, row stride LDC) staged in the NP x LD matrix
+  // C_L (n x nl, row stride LDC) staged in the NP x LD matrix; H[:, St] gathered into the (zeroed) first column group
   lane_loop_batched<8>(n * nl, lane,
                        [&](int idx) {
                          const int r = idx / nl, a = idx - r * nl;
@@ -743,45 +752,41 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
                          const int r = idx / nl, a = idx - r * nl;
                          Tk[r * LDC + a] = v;
                        });
-  wave_sync();
-  // Gs_0 = -C_L' Wm and Zs_0 = C_L' H[:, St], one element per lane and trip (into registers: their buffers are the staged C_L's)
-  constexpr int NEL = BSC * BSC;  // NPC^2 / 64
-  double gsv[NEL], z0v[NEL];
-#pragma unroll
-  for (int e = 0; e < NEL; ++e) {
-    const int idx = lane + 64 * e, a = idx / NPC, b = idx - a * NPC;
-    const int ac = a < nl ? a : 0;
-    const double* ca = Tk + ac;
-    const double* wb = W + 2 * NP + (b < nl ? b : 0);
-    const double* hb = W + NP + Sidx[b < ns ? b : 0];
-    double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
-    int r = 0;
-    for (; r + 2 <= n; r += 2) {
-      const double c0 = ca[r * LDC], c1 = ca[(r + 1) * LDC];
-      g0 = fma(c0, wb[r * LDW], g0);
-      g1 = fma(c1, wb[(r + 1) * LDW], g1);
-      z0 = fma(c0, hb[r * LDW], z0);
-      z1 = fma(c1, hb[(r + 1) * LDW], z1);
-    }
-    if (r < n) {
-      g0 = fma(ca[r * LDC], wb[r * LDW], g0);
-      z0 = fma(ca[r * LDC], hb[r * LDW], z0);
-    }
-    gsv[e] = (a < nl && b < nl) ? -(g0 + g1) : 0.0;
-    z0v[e] = (a < nl && b < ns) ? z0 + z1 : 0.0;
+  for (int idx = lane; idx < NP * (LDC - nl); idx += 64) {  // (the tile reads all NPC columns: zero beyond nl)
+    const int r = idx / (LDC - nl), a = nl + idx - r * (LDC - nl);
+    Tk[r * LDC + a] = 0.0;
   }
+  wave_sync();  // (the zeros of the first column group and H in the second are in place)
+  for (int idx = lane; idx < n * ns; idx += 64) {
+    const int r = idx / ns, b = idx - r * ns;
+    W[r * LDW + b] = W[r * LDW + NP + Sidx[b]];
+  }
+  wave_sync();
+  // Gs_0 = -C_L' Wm and Zs_0 = C_L' H[:, St] on the compact tile (contraction over the n rows)
+  double Gb0[BSC][BSC];
+  double Zb[BSC][BSC];
+  blk_zero<BSC>(Gb0);
+  blk_zero<BSC>(Zb);
+  mm_acc_ta<BSC>(Gb0, Tk, LDC, W + 2 * NP, LDW, n, lr, lc);
+  mm_acc_ta<BSC>(Zb, Tk, LDC, W, LDW, n, lr, lc);
+#pragma unroll
+  for (int i = 0; i < BSC; ++i)
+#pragma unroll
+    for (int j = 0; j < BSC; ++j) {
+      const int a = lr * BSC + i, b = lc * BSC + j;
+      Gb0[i][j] = (a < nl && b < nl) ? -Gb0[i][j] : 0.0;
+      Zb[i][j] = (a < nl && b < ns) ? Zb[i][j] : 0.0;
+    }
+  gmax = blk_maxabs<BSC>(Gb0);
   wave_sync();
   for (int idx = lane; idx < 2 * NPC * LDC; idx += 64) Tk[idx] = 0.0;
-  wave_sync();
-  double gm = 0.0;
-#pragma unroll
-  for (int e = 0; e < NEL; ++e) {
-    const int idx = lane + 64 * e, a = idx / NPC, b = idx - a * NPC;
-    Gs[a * LDC + b] = gsv[e];
-    ZP[a * LDW + b] = z0v[e];
-    gm = nanmax(gm, fabs(gsv[e]));
+  for (int idx = lane; idx < n * ns; idx += 64) {  // the gathered H: back to zero (the first column group takes Zs)
+    const int r = idx / ns, b = idx - r * ns;
+    W[r * LDW + b] = 0.0;
   }
-  gmax = wave_nanmax(gm);
+  wave_sync();
+  blk_store_lds<BSC>(Gb0, Gs, LDC, lr, lc);
+  blk_store_lds<BSC>(Zb, ZP, LDW, lr, lc);
   lane_loop_batched<8>(ns * ns, lane,
                        [&](int idx) {
                          const int i = idx / ns, j = idx - i * ns;
@@ -792,8 +797,9 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
                          Fs[i * LDC + j] = v;
                        });
   wave_sync();
-  double Zb[BSC][BSC];
-  blk_load_lds<BSC>(Zb, ZP, LDW, lr, lc);
+#ifdef ADJ_STOP
+  if (ADJ_STOP == 3) return true;
+#endif
   bool ok = false;
   for (int it = 0; it < LYAP_MAX_DOUBLINGS; ++it) {
     {
@@ -828,6 +834,9 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
     }
     gmax = fmax(gmax, blk_maxabs<BSC>(G2));
   }
+#ifdef ADJ_STOP
+  if (ADJ_STOP == 4) return true;
+#endif
   // S = H - (Wm Zs) T[:, St]'
   {
     double Ub[BS][BS];
@@ -844,12 +853,12 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
                          },
                          [&](int idx, double v) {
                            const int j = idx / ns, k = idx - j * ns;
-                           Tk[j * LD + k] = v;
+                           Tk[j * LDC + k] = v;  // (row stride LDC: NP rows end below the index lists)
                          });
     wave_sync();
     double Db[BS][BS];
     blk_zero<BS>(Db);
-    mm_acc<BS, true>(Db, W, LDW, Tk, LD, ns, lr, lc);  // (Wm Zs) T[:, St]'
+    mm_acc<BS, true>(Db, W, LDW, Tk, LDC, ns, lr, lc);  // (Wm Zs) T[:, St]'
 #pragma unroll
     for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
     const size_t off = (size_t)draw * n * n;
     double Sb[BS][BS];
     bool ok = true, flag = false;
-    int st_in = 0;
+    int st_in = 0, kt_cols = 0;
     double gmax = 0.0;
     if constexpr (REFINE) {
       st_in = status[draw];
@@ -1055,7 +1064,7 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
       double Hb[BS][BS];
       blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);
       bool took = false;
-      if constexpr (AdjCompact<BS>::enabled) ok = adj_stein_solve_compact<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax, took);
+      if constexpr (AdjCompact<BS>::enabled) ok = adj_stein_solve_compact<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax, took, kt_cols);
       if (!took) ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax);
       // (debug hook: refine_mode 1 = every draw, 2 = none).  A solve that broke down -- the computed powers of G exploded --
       // leaves zeros and goes to the second pass as well, which then takes its elimination-based fall-back
@@ -1083,10 +1092,12 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
     wave_sync();
     lds_load_matrix(Ts, LDW, NP, NP, T + off, n, n, lane);  // T again, over the dead G_k
     wave_sync();
+    // (the products with T' contract over the columns of T: up to its last non-zero one when the compact solve has found it)
+    const int kt_hi = (kt_cols > 0 && kt_cols <= n) ? kt_cols : n;
     {
       double Bb[BS][BS], Cb[BS][BS];
       blk_zero<BS>(Bb);
-      mm_acc<BS, true>(Bb, W + NP, LDW, Ts, LDW, n, lr, lc);  // S T'  (second pass: dS T')
+      mm_acc<BS, true>(Bb, W + NP, LDW, Ts, LDW, kt_hi, lr, lc);  // S T'  (second pass: dS T')
       if (acc_out) {  // gradient pipeline: B_bar, C_bar already hold the cotangents that came through R
         double t0[BS][BS];
         blk_load_global<BS>(t0, B_bar + off, n, n, n, lr, lc);
@@ -1102,7 +1113,7 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
       blk_store_lds<BS>(Bb, W, LDW, lr, lc);
       wave_sync();
       blk_zero<BS>(Cb);
-      mm_acc<BS, true>(Cb, W, LDW, Ts, LDW, n, lr, lc);      // S T' T'
+      mm_acc<BS, true>(Cb, W, LDW, Ts, LDW, kt_hi, lr, lc);  // S T' T'
       if (acc_out) {
         double t0[BS][BS];
         blk_load_global<BS>(t0, C_bar + off, n, n, n, lr, lc);
