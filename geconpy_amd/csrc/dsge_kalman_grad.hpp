@@ -1543,6 +1543,26 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     if (!Rbar_in) lds_load_matrix(Ms, LD, NP, NP, Gbar + off, n, n, lane);
     lds_load_matrix(Rs, LD, NP, NP, R + offk, n, k, lane);
     wave_sync();
+    // the ranges of non-zero columns of T (states), C (variables with a lead) and Gbar (the filter's retained variables): the
+    // products below contract over them (SW-shaped: 18, 12 and 18 of 40 terms)
+    int t_hi = n, c_lo = 0, c_hi = n, g_lo = 0, g_hi = n;
+    {
+      bool nzT = false, nzC = false, nzG = false;
+      if (lane < n)
+        for (int r = 0; r < n; ++r) {
+          nzT = nzT | (Ts[r * LD + lane] != 0.0);
+          nzC = nzC | (Cs[r * LD + lane] != 0.0);
+          nzG = nzG | (Ms[r * LD + lane] != 0.0);
+        }
+      const unsigned long long cmT = __ballot(nzT), cmC = __ballot(nzC), cmG = __ballot(nzG);
+      t_hi = cmT ? 64 - __clzll((long long)cmT) : 0;
+      c_lo = cmC ? __ffsll((long long)cmC) - 1 : 0;
+      c_hi = cmC ? 64 - __clzll((long long)cmC) : 0;
+      if (!Rbar_in) {
+        g_lo = cmG ? __ffsll((long long)cmG) - 1 : 0;
+        g_hi = cmG ? 64 - __clzll((long long)cmG) : 0;
+      }
+    }
     // q_batched is the q_mode of include/dsge_hip.h: 0 / 1 = diag(q) shared / per draw, 2 / 3 = full k x k Q shared / per draw
     const bool qfull = !Rbar_in && q_batched >= 2;
     const double* qd = Rbar_in ? nullptr
@@ -1554,7 +1574,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     if (Rbar_in) {
       blk_load_global<BS>(Rbar, Rbar_in + offk, n, k, k, lr, lc);
     } else {
-    mm_acc<BS, false>(GR, Ms, LD, Rs, LD, n, lr, lc);
+    mm_acc<BS, false>(GR, Ms + g_lo, LD, Rs + g_lo * LD, LD, g_hi - g_lo, lr, lc);
     if (qfull) {
       // full shock covariance (full_covariance, statespace.py:247-251): G = R Q R', Q symmetric ->
       //   Rbar = 2 (Gbar R) Q,   Qbar = R' (Gbar R)   (k x k, symmetric because Gbar is)
@@ -1598,7 +1618,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     {
       double Mb[BS][BS];
       blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
-      mm_acc<BS, false>(Mb, Cs, LD, Ts, LD, n, lr, lc);
+      mm_acc<BS, false>(Mb, Cs + c_lo, LD, Ts + c_lo * LD, LD, c_hi - c_lo, lr, lc);
 #pragma unroll
       for (int i = 0; i < BS; ++i)
 #pragma unroll
@@ -1634,7 +1654,7 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     wave_sync();
     double Cb[BS][BS], Tb[BS][BS];
     blk_zero<BS>(Cb);
-    mm_acc<BS, true>(Cb, Ms, LD, Ts, LD, n, lr, lc);  // Mbar T'
+    mm_acc<BS, true>(Cb, Ms, LD, Ts, LD, t_hi, lr, lc);  // Mbar T'
     blk_store_global<BS>(Cb, C_bar + off, n, n, n, lr, lc);
     if (Rbar_in)
       blk_zero<BS>(Tb);
