@@ -709,6 +709,25 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     for (int k2 = 0; k2 < NPF; ++k2) pf_p[k2] = 0.0;
 #pragma unroll
     for (int k2 = 0; k2 < NKF; ++k2) pf_k[k2] = 0.0;
+    // how the forward sweep left P+ of its full steps (KgRec::TS_LAYOUT): register blocks, or -- kalman_mf_kernel<.., REC> -- the
+    // upper 4 x 4 tiles of a (2 BS - 1)-tile matrix, element g of lane l at [g 64 + l]: scattered into X1 with its mirror image
+    constexpr int TMF = 2 * BS - 1, NGF = Mfma4Upper<TMF>::NG;
+    bool rec_tiles = false;
+    int x1a[NGF], x1b[NGF];
+    if constexpr (SPLIT && KG_MF) {
+      rec_tiles = (int)st[RC::tail_state_off(T_len) + RC::TS_LAYOUT] == RC::LAYOUT_TILES + TMF;  // (wave-uniform)
+      constexpr int X1_DUMP = (NP - 1) * LDM + LDM - 1;
+#pragma unroll
+      for (int g = 0; g < NGF; ++g) {
+        int ta, tb;
+        bool live;
+        Mfma4Upper<TMF>::tile(g, (lane_kernel >> 2) & 3, ta, tb, live);
+        const int r = 4 * ta + (lane_kernel >> 4), c = 4 * tb + (lane_kernel & 3);
+        const bool in = live && r <= c && c < u;
+        x1a[g] = in ? r * LDM + c : X1_DUMP;
+        x1b[g] = in ? c * LDM + r : X1_DUMP;
+      }
+    }
     double src_next = 0.0, av_next = 0.0, yr_next = 0.0;
     int t_first = T_len - 1;
     bool resumed = false;  // the steady tail's mean side came from kalman_grad_tail_kernel: this sweep starts AT its source step
@@ -760,9 +779,19 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
         const double* sp_ = st + (size_t)src_t * STEP;  // the source step's covariance update, as the forward sweep left it
         wave_sync();
         if (pf_src == src_t) {
+          if (rec_tiles) {
+            if constexpr (SPLIT && KG_MF) {
+#pragma unroll
+              for (int g = 0; g < NGF; ++g) {
+                X1[x1a[g]] = pf_p[g];
+                X1[x1b[g]] = pf_p[g];
+              }
+            }
+          } else {
 #pragma unroll
           for (int k2 = 0; k2 < NPF; ++k2)  // (lane-major record: entry (k2 / BS, k2 % BS) of this lane's block)
             X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = kg_in_u(lr * BS + k2 / BS, lc * BS + k2 % BS, u) ? pf_p[k2] : 0.0;
+          }
 #pragma unroll
           for (int k2 = 0; k2 < NKF; ++k2) {
             const int idx = lane + 64 * k2;
@@ -771,9 +800,22 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
           Fi[lane] = pf_fi;
           Fs[lane] = pf_f;
         } else {
+          if (rec_tiles) {
+            if constexpr (SPLIT && KG_MF) {
+              double tv[NGF];
+#pragma unroll
+              for (int g = 0; g < NGF; ++g) tv[g] = sp_[lane + 64 * g];
+#pragma unroll
+              for (int g = 0; g < NGF; ++g) {
+                X1[x1a[g]] = tv[g];
+                X1[x1b[g]] = tv[g];
+              }
+            }
+          } else {
 #pragma unroll
           for (int k2 = 0; k2 < NPF; ++k2)
             X1[(lr * BS + k2 / BS) * LDM + lc * BS + k2 % BS] = kg_in_u(lr * BS + k2 / BS, lc * BS + k2 % BS, u) ? sp_[lane + 64 * k2] : 0.0;
+          }
           for (int idx = lane; idx < NP * 8; idx += 64) Kp[(idx >> 3) * PS + (idx & 7)] = sp_[OFF_K + idx];
           Fi[lane] = sp_[OFF_FI + lane];
           Fs[lane] = sp_[OFF_F + lane];

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "dsge_kalman_nt.hpp"
+#include "dsge_kalman_rec.hpp"
 #include "dsge_mfma4.hpp"
 
 namespace dsge {
@@ -43,15 +44,23 @@ struct KmfSmem {
 #ifndef KMF_WAVES
 #define KMF_WAVES 2
 #endif
-template <int KT, int TM, bool DBG>
+// REC = true (round 6): the forward sweep of the gradient -- every step also writes its record for the reverse sweep
+// (dsge_kalman_rec.hpp, KgRec<RBS>: the record of the 8 RBS-wide tile the reverse sweep runs on; 4 TM <= 8 RBS).  K, F, F^-1, a_t
+// and the segment links as kalman_nt_kernel<.., REC> writes them; P+ in the TILE layout -- element g of lane l at [g 64 + l], the
+// upper tiles straight from the registers, four coalesced stores for 18 variables instead of nine -- which the record announces in
+// its layout word (KgRec::TS_LAYOUT) and the reverse sweep scatters into its LDS square.
+template <int KT, int TM, bool DBG, bool REC = false, int RBS = (4 * TM + 7) / 8>
 __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
     const double* __restrict__ T, const double* __restrict__ RQR, const double* __restrict__ P0, const double* __restrict__ Z,
     int z_batched, const double* __restrict__ dvec, int d_batched, const double* __restrict__ Hdiag, int h_batched,
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill, double steady_tol,
     double* __restrict__ logp_out, int32_t* __restrict__ status, long long* __restrict__ dbg, int rerun_only,
     int32_t* __restrict__ steady_at, const int32_t* __restrict__ order, const double* __restrict__ Rsel,
-    const double* __restrict__ qdiag, int q_batched, int k_shocks, const unsigned long long* __restrict__ colmask_in) {
+    const double* __restrict__ qdiag, int q_batched, int k_shocks, const unsigned long long* __restrict__ colmask_in,
+    double* __restrict__ rec_store = nullptr) {
   using SM = KmfSmem<KT, TM>;
+  using RC = KgRec<RBS>;
+  static_assert(!REC || (4 * TM <= 8 * RBS && Mfma4Upper<TM>::NG * 64 <= 8 * RBS * 8 * RBS), "the record's tile holds the filter's");
   using UX = Mfma4Upper<TM>;
   using MW = Mfma4Map<KT, TM>;
   constexpr int NS = SM::NS, NM = SM::NM, LDK = SM::LDK, NR = SM::NR, RP = SM::RP, PS = SM::PS, NG = UX::NG;
@@ -325,6 +334,24 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         continue;
       }
     }
+    double* const rec_d = REC ? rec_store + (size_t)draw * RC::per_draw(T_len) : nullptr;  // this draw's record
+    int seg_src = -1;                                                                       // source step of the running segment
+    if constexpr (REC) {  // P_0, row-major NP x NP behind the last step (zero outside m x m), and the layout word
+      constexpr int RNP = 8 * RBS;
+      double* p0s = rec_d + (size_t)T_len * RC::STEP;
+      for (int idx = lane; idx < RNP * RNP; idx += 64) {
+        const int r = idx / RNP, c = idx - r * RNP;
+        if (!(r < m && c < m)) p0s[idx] = 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (up[g] && inm[g]) {
+          p0s[rr[g] * RNP + cc[g]] = Pt[g];
+          p0s[cc[g] * RNP + rr[g]] = Pt[g];
+        }
+      }
+      if (lane == 0) rec_d[RC::tail_state_off(T_len) + RC::TS_LAYOUT] = (double)(RC::LAYOUT_TILES + TM);
+    }
     if (lane < 8) {
       dd[lane] = (dvec && lane < p) ? dvec[(d_batched ? (size_t)draw * p : 0) + lane] : 0.0;
       hh[lane] = (Hdiag && lane < p) ? Hdiag[(h_batched ? (size_t)draw * p : 0) + lane] : 0.0;
@@ -369,6 +396,15 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
       const bool obs = (r8 < p) && (yt == yt) && (yt != missing_fill);
       const unsigned long long omask = __ballot(obs) & 0xffull;
       const int n_obs = __popcll(omask);
+      double* const sg = REC ? rec_d + (size_t)t * RC::STEP : nullptr;  // the record of this (full) step
+      if constexpr (REC) {
+        if (lane < 8 * RBS) sg[RC::OFF_A + lane] = (lane < NR) ? av[lane] : 0.0;
+        if (lane == 0) {
+          sg[RC::OFF_SRC] = (double)t;
+          sg[RC::OFF_PREV] = (double)seg_src;
+        }
+        seg_src = t;
+      }
       double2 fr2[4], pz2[RP][4];
       double pzo[RP], avi[RP];
 #pragma unroll
@@ -410,6 +446,12 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         const double wq = ((omask >> q) & 1ull) ? 1.0 : 0.0;  // wave-uniform
         const double f = (c_r * tq) * wq;
         fr[q] = (q == r8) ? f + dg : f;
+      }
+      if constexpr (REC) {
+        if (lane < 8) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sg[RC::OFF_F + lane * 8 + q] = fr[q];
+        }
       }
       // ---- (c) Finv by Gauss-Jordan, one row per lane (SPD: no pivoting); the pivot row arrives through SGPRs ----------------
       double step_mant = 1.0, inv_own = 1.0;
@@ -454,6 +496,12 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         if (p > 3) pivot(std::integral_constant<int, 3>{});
         if (p > 4) pivot(std::integral_constant<int, 4>{});
         if (p > 5) pivot(std::integral_constant<int, 5>{});
+      }
+      if constexpr (REC) {
+        if (lane < 8) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sg[RC::OFF_FI + lane * 8 + q] = fr[q] * inv_own;
+        }
       }
       {
         const double2* vv2 = reinterpret_cast<const double2*>(vv);
@@ -505,6 +553,9 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
         af[(r8 == 0) ? i : NR] = avi[ps] + part;  // (entry NR: a slot for the lanes that own nothing -- no branch)
       }
       wave_sync();  // #2
+      if constexpr (REC) {
+        for (int idx = lane; idx < 8 * RBS * 8; idx += 64) sg[RC::OFF_K + idx] = ((idx >> 3) < NR) ? Ks[(idx >> 3) * PS + (idx & 7)] : 0.0;
+      }
       if constexpr (DBG) {
         const long long tk1 = clock64();
         ph[1] += tk1 - tk0;
@@ -518,6 +569,10 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
                                         const double pn = inm[g] ? d + ((rr[g] == cc[g]) ? cv.jit_P : 0.0) : 0.0;
                                         Pt[g] = pn;
                                       });
+        if constexpr (REC) {  // P+ in tile layout, straight from the registers
+#pragma unroll
+          for (int g = 0; g < NG; ++g) sg[(size_t)g * 64 + lane] = Pt[g];
+        }
         if (steady_tol > 0.0) {
           // (the old values are read UNCONDITIONALLY and together -- volatile: under the predicate the compiler turned each read into
           //  a branch with its own wait, four LDS round trips in a row)
@@ -607,6 +662,11 @@ __global__ __launch_bounds__(64, KMF_WAVES) void kalman_mf_kernel(
           if (__ballot(obs_s) != omask) break;
           ++t;
           yt_next = y[(size_t)((t + 1 < T_len) ? t + 1 : t) * p + r8c];
+          if constexpr (REC) {
+            double* sgs = rec_d + (size_t)t * RC::STEP;
+            if (lane < 8 * RBS) sgs[RC::OFF_A + lane] = av_reg;
+            if (lane == 0) sgs[RC::OFF_SRC] = (double)seg_src;
+          }
           const double av_sel = __shfl(av_reg, v_zpos, 64);
           double v_s = 0.0;
           if (lane < p) v_s = (obs_s ? yt_s : 0.0) - (((obs_s || !cv.mask_d) ? v_dd : 0.0) + (obs_s ? 1.0 : 0.0) * (v_zv * av_sel));

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64, (BS == 1 ? 3 : ((BS <= KSEL_TWO_WAVES_MAX_BS ||
       for (int i = 0; i < BS; ++i)
 #pragma unroll
         for (int j = 0; j < BS; ++j) p0s[(lr * BS + i) * NP + lc * BS + j] = Pb[i][j];
+      if (lane == 0) rec_d[RC::tail_state_off(T_len) + RC::TS_LAYOUT] = 0.0;  // P+ of the full steps: lane-major register blocks
     }
     // y_t is fetched one step ahead by an UNCONDITIONAL, branch-free load (clamped indices; lanes with r8 >= p and the value
     // past the last step are never used -- every use is guarded by `obs`): under a condition the compiler sank the load to

@@ -17,6 +17,11 @@ struct KgRec {
   // Behind P_0: the state the tail kernel (kalman_grad_tail_kernel: the reverse mean side of the LAST steady segment, run at two
   // wavefronts per SIMD) hands to the reverse sweep -- [0] number of steps it processed (0: none), [1] nlam; abar (NP), dbar (8),
   // then lane-major register images: Tbar (BS^2 x 64), Kacc (BS x 64), Qacc (64)
+  // [2] (TS_LAYOUT) how the forward sweep stored P+ of its full steps: 0 = lane-major register blocks (kalman_nt_kernel<.., REC>,
+  // kalman_grad_kernel's own forward sweep), LAYOUT_TILES + TM = upper 4 x 4 tiles of a TM-tile matrix, element g of lane l at
+  // [g 64 + l] (kalman_mf_kernel<.., REC>, round 6).  Every forward sweep writes it.
+  static constexpr size_t TS_LAYOUT = 2;
+  static constexpr int LAYOUT_TILES = 100;
   static constexpr size_t TS_AB = 16, TS_DB = TS_AB + NP, TS_TB = TS_DB + 8, TS_KA = TS_TB + (size_t)BS * BS * 64,
                           TS_QA = TS_KA + (size_t)BS * 64, TAIL_STATE = TS_QA + 64;
   __host__ __device__ static constexpr size_t tail_state_off(int T_len) { return (size_t)T_len * STEP + (size_t)NP * NP; }

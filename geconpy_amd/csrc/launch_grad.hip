@@ -1,6 +1,7 @@
 // Launchers of the gradient kernels: Kalman reverse sweep and the reverse of the state-space assembly.
 #include "dsge_host.hpp"
 #include "dsge_kalman_grad.hpp"
+#include "dsge_kalman_mf.hpp"
 #include "dsge_kalman_nt.hpp"
 
 namespace dsge_host {
@@ -47,10 +48,27 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
       rc = set_lds(dsge::kalman_nt_kernel<BS, false, 8 * BS, false, true>, lds_f);
       if (rc == DSGE_SUCCESS) rc = set_lds(dsge::kalman_grad_kernel<BS, true>, lds);
       if (rc == DSGE_SUCCESS) rc = set_lds(dsge::kalman_grad_kernel<BS, false>, lds);
+      // Round 6: on the 24-wide tile the forward sweep is the tile-layout filter with record output (kalman_mf_kernel<5, 5, .., REC>:
+      // up to 20 retained variables, selector Z; P+ recorded as its upper tiles, which the reverse sweep scatters); what it cannot
+      // take it flags, and kalman_nt_kernel<.., REC> then runs as a second pass over those draws only.
+      int nt_rerun = 0;
+      if constexpr (BS == 3) {
+        using SMF = dsge::KmfSmem<5, 5>;
+        if (rc == DSGE_SUCCESS && opt().kalman_mfma == 2 && opt().kalman_nt_products && u_hint > 0 && u_hint <= 20) {
+          rc = set_lds(dsge::kalman_mf_kernel<5, 5, false, true, 3>, SMF::bytes);
+          if (rc == DSGE_SUCCESS) {
+            hipLaunchKernelGGL((dsge::kalman_mf_kernel<5, 5, false, true, 3>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR,
+                               (const double*)nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
+                               missing_fill, stol, logp, status, (long long*)nullptr, 0, (int32_t*)nullptr, order,
+                               (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr, store);
+            nt_rerun = 1;
+          }
+        }
+      }
       if (rc == DSGE_SUCCESS) {
         hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, 8 * BS, false, true>), dim3(batch), dim3(64), lds_f, st, T, RQR,
                            (const double*)nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, 8 * BS, cv,
-                           missing_fill, stol, logp, status, (long long*)nullptr, 0, (int32_t*)nullptr, order,
+                           missing_fill, stol, logp, status, (long long*)nullptr, nt_rerun, (int32_t*)nullptr, order,
                            (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr,
                            (double*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, store);
         // the reverse mean side of every draw's LAST steady segment at two wavefronts per SIMD (kalman_grad_tail_kernel); the
