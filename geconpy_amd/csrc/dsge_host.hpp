@@ -249,7 +249,7 @@ struct Options {
   int gensys_direct_blocks = 1;  // window path: isolated 2 x 2 blocks triangularised in closed form in front of the complex iteration
   int kalman_narrow = 1;       // fast filter: the SK = 20 instance of the 32-wide tile when the state block fits
   int gensys_doubling = 1;     // gensys by spectral division: cycle reduction + certificate, ordered QZ only for uncertified draws (0: QZ for all)
-  int kalman_grad_split = 1;   // gradient: forward sweep by kalman_nt_kernel<.., REC>, reverse sweep by kalman_grad_kernel<BS, true>; 2: + kalman_grad_tail_kernel
+  int kalman_grad_split = 2;   // gradient: forward sweep by a logp kernel with record output, reverse sweep by kalman_grad_kernel<BS, true>; 2: + kalman_grad_tail_kernel
   int kalman_head_draws = 0;   // fast filter: this many draws at the head of the dispatch order on the two-wavefront kernel (-1 = all)
   // conventions of the filter step (third party: pymc_extras; include/dsge_hip.h "Filter conventions")
   int ll_constant = DSGE_LL_CONST_P;

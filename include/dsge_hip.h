@@ -233,14 +233,17 @@ typedef struct dsge_options {
                                  verdict on the caller's stream in front of the filter (the round-5 order; for comparison).  The
                                  scale guards of the certificate (csrc/dsge_gensys_doubling.hpp: existence computed exactly from
                                  (B + C T)^-1, a lower bound on the stable block's QZ diagonal) hold under 1, 2 and 3. */
-  int32_t kalman_grad_split;  /* 1 (default), 2: the logp + gradient entry points run the FORWARD filter sweep as the logp kernel
-                                 itself (kalman_nt_kernel with record output: two wavefronts per SIMD) and the reverse sweep as a
-                                 kernel of its own; draws the forward kernel cannot take fall back to the one-kernel path in the same
-                                 call.  2: in addition the reverse MEAN side of every draw's last steady segment runs as a lean kernel
-                                 at two wavefronts per SIMD (kalman_grad_tail_kernel) and the reverse sweep resumes at that segment's
-                                 source step -- it takes 40 % of the reverse launch's work away, but on a batch with never-steady draws
-                                 that launch then ends with THEIR 200 full reverse steps: 3.02 -> 2.62 + 0.41 ms, no gain (off).
-                                 0: forward and reverse sweep in one kernel (rounds 1-4).  Same recursion, same records. */
+  int32_t kalman_grad_split;  /* 2 (default), 1: the logp + gradient entry points run the FORWARD filter sweep as a logp kernel
+                                 itself with record output (the tile-layout kalman_mf_kernel on the 24-wide tile since round 6,
+                                 kalman_nt_kernel otherwise: two wavefronts per SIMD) and the reverse sweep as a kernel of its own;
+                                 draws the forward kernel cannot take fall back to the one-kernel path in the same call.  2: in
+                                 addition the reverse MEAN side of every draw's last steady segment runs as a lean kernel at two
+                                 wavefronts per SIMD (kalman_grad_tail_kernel) and the reverse sweep resumes at that segment's source
+                                 step: 40 % of the reverse launch's work.  Round 5 measured no gain (that launch then ended with the
+                                 200 full reverse steps of a never-steady draw: 3.02 -> 2.62 + 0.41 ms); with the round-6 full step
+                                 (matrix-core products and panels: 19.4 k -> 13.6 k cycles) it is 2 % (5.02 -> 4.92 ms per 4096
+                                 draws) and the default.  0: forward and reverse sweep in one kernel (rounds 1-4).  Same recursion,
+                                 same records. */
   int32_t reserved_[2];
 } dsge_options;
 /* fills *opt with the compiled-in defaults */

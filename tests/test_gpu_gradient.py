@@ -511,7 +511,7 @@ def test_gradient_with_a_dense_design_matrix(batched_z):
 
 
 def test_gradient_split_sweeps_match_the_one_kernel_path():
-    """dsge_options.kalman_grad_split (round 5, default 1): the forward sweep runs as the logp kernel with record output
+    """dsge_options.kalman_grad_split (round 5; default 2 since round 6): the forward sweep runs as a logp kernel with record output
     (kalman_nt_kernel<.., REC>), the reverse sweep as a kernel of its own.  Same recursion and the same records as the one-kernel path
     (kalman_grad_split = 0): logp to rounding, every cotangent to 1e-10 of its scale in the median and 1e-7 at worst -- on 768 distinct SW-shaped draws (the nearly
     singular draw 752 among them) with complete data, with scattered missing entries (the mask changes: several steady segments)
