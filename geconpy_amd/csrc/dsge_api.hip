@@ -1278,7 +1278,7 @@ static int grad_pipeline(const double* A, const double* B, const double* C, cons
                                 stc, 0, 2, st)))
         return rc;
     }
-    const int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;
+    int32_t* gkey = (solver == DSGE_SOLVER_GENSYS) ? nullptr : it_w;  // (the gradient's forward sweep overwrites it with its step counts)
     if (opt().kalman_order == 0) {
       gkey = nullptr;
     } else if ((opt().kalman_order == 2 || solver == DSGE_SOLVER_GENSYS) && nb >= 512) {

@@ -714,7 +714,8 @@ __device__ __forceinline__ void gj_unpermute(double* W, int ldw, int n, int g_fi
 // fixed point late.  One workgroup.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void kalman_order_kernel(const int32_t* __restrict__ key, int batch,
-                                                            int32_t* __restrict__ order) {
+                                                            int32_t* __restrict__ order, int never_value = -1) {
+  // never_value >= 0: the key is a filter's first steady step (-1: never steady = never_value steps), binned by four steps
   // one histogram per wavefront (the 64 bins are hot: a single shared histogram serialises the LDS atomics of the whole
   // block), bases by a wave scan over the bins: 10 -> 4 us per 4096 draws with 1024 threads
   constexpr int NW = BLOCK / 64;
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(BLOCK) void kalman_order_kernel(const int32_t* __re
   __syncthreads();
   for (int i = tid; i < batch; i += BLOCK) {
     int kq = key[i];
+    if (never_value >= 0) kq = (kq < 0 ? never_value : kq) >> 2;
     kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
     atomicAdd(&hist[w][kq], 1);
   }
@@ -749,6 +751,7 @@ __global__ __launch_bounds__(BLOCK) void kalman_order_kernel(const int32_t* __re
   __syncthreads();
   for (int i = tid; i < batch; i += BLOCK) {
     int kq = key[i];
+    if (never_value >= 0) kq = (kq < 0 ? never_value : kq) >> 2;
     kq = kq < 0 ? 0 : (kq > 63 ? 63 : kq);
     order[atomicAdd(&base[w][kq], 1)] = i;
   }

@@ -169,7 +169,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
                        const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                        double jitter, double missing_fill, int u_hint, double* store, double* logp, int32_t* status,
                        double* Tbar, double* Gbar, double* dbar, double* hbar, hipStream_t st,
-                       const int32_t* order_key = nullptr, int32_t* order_buf = nullptr);
+                       int32_t* order_key = nullptr, int32_t* order_buf = nullptr);
 size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len);
 int launch_grad_assemble(const double* B, const double* C, const double* T, const double* R, const double* q,
                          int q_batched, const double* Gbar, int batch, int n, int k, const int32_t* status, double* Tbar,

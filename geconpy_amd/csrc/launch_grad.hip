@@ -23,7 +23,7 @@ static_assert(dsge::KgRec<3>::per_draw(200) == (size_t)200 * (24 * 24 + 24 * 8 +
 int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int z_batched, const double* d, int d_batched,
                        const double* Hdiag, int h_batched, const double* y, int batch, int m, int p, int T_len,
                        double jitter, double missing_fill, int u_hint, double* store, double* logp, int32_t* status,
-                       double* Tbar, double* Gbar, double* dbar, double* hbar, hipStream_t st, const int32_t* order_key,
+                       double* Tbar, double* Gbar, double* dbar, double* hbar, hipStream_t st, int32_t* order_key,
                        int32_t* order_buf) {
   const int bs = grad_tile(u_hint, m);
   int rc = DSGE_ERR_INVALID;
@@ -52,6 +52,10 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
       // up to 20 retained variables, selector Z; P+ recorded as its upper tiles, which the reverse sweep scatters); what it cannot
       // take it flags, and kalman_nt_kernel<.., REC> then runs as a second pass over those draws only.
       int nt_rerun = 0;
+      // the forward sweep reports every draw's first steady step into the (consumed) key buffer: the reverse launches -- whose time
+      // per draw is the number of full steps -- then start their draws in THAT order (round 6; the key of the forward launch, the
+      // solver's iteration count, is a proxy for it)
+      int32_t* const steps_key = order ? order_key : nullptr;
       if constexpr (BS == 3) {
         using SMF = dsge::KmfSmem<5, 5>;
         if (rc == DSGE_SUCCESS && opt().kalman_mfma == 2 && opt().kalman_nt_products && u_hint > 0 && u_hint <= 20) {
@@ -59,7 +63,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
           if (rc == DSGE_SUCCESS) {
             hipLaunchKernelGGL((dsge::kalman_mf_kernel<5, 5, false, true, 3>), dim3(batch), dim3(64), SMF::bytes, st, T, RQR,
                                (const double*)nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv,
-                               missing_fill, stol, logp, status, (long long*)nullptr, 0, (int32_t*)nullptr, order,
+                               missing_fill, stol, logp, status, (long long*)nullptr, 0, steps_key, order,
                                (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr, store);
             nt_rerun = 1;
           }
@@ -68,11 +72,15 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
       if (rc == DSGE_SUCCESS) {
         hipLaunchKernelGGL((dsge::kalman_nt_kernel<BS, false, 8 * BS, false, true>), dim3(batch), dim3(64), lds_f, st, T, RQR,
                            (const double*)nullptr, Z, z_batched, d, d_batched, Hdiag, h_batched, y, batch, m, p, T_len, 8 * BS, cv,
-                           missing_fill, stol, logp, status, (long long*)nullptr, nt_rerun, (int32_t*)nullptr, order,
+                           missing_fill, stol, logp, status, (long long*)nullptr, nt_rerun, steps_key, order,
                            (const double*)nullptr, (const double*)nullptr, 0, 0, (const unsigned long long*)nullptr,
                            (double*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, store);
         // the reverse mean side of every draw's LAST steady segment at two wavefronts per SIMD (kalman_grad_tail_kernel); the
         // reverse sweep then starts at that segment's source step (kalman_grad_split = 2; the default is 1: without it)
+        if (steps_key) {
+          hipLaunchKernelGGL(dsge::kalman_order_kernel<1024>, dim3(1), dim3(1024), 0, st, (const int32_t*)steps_key, batch, order_buf,
+                             T_len);
+        }
         const int with_tail = opt().kalman_grad_split >= 2;
         if (with_tail)
           hipLaunchKernelGGL((dsge::kalman_grad_tail_kernel<BS>), dim3(batch), dim3(64), 0, st, T, Z, z_batched, d, d_batched, y,
