@@ -44,6 +44,11 @@ python3 tools/two_streams.py > "$OUT/two_streams.txt" 2>&1
 python3 tools/grad_rate.py > "$OUT/grad_rate.txt" 2>&1
 python3 tools/grad_rate.py 4096 gensys >> "$OUT/grad_rate.txt" 2>&1
 python3 tools/grad_phases.py 4096 > "$OUT/grad_phases.txt" 2>&1
+python3 tools/steady_hist.py > "$OUT/steady_hist.txt" 2>&1
+rm -rf "$OUT/kt_grad"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_grad" -o kt -- python3 tools/grad_rate.py > "$OUT/kt_grad.log" 2>&1
+find "$OUT/kt_grad" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_gradient.csv" \;
+rm -rf "$OUT/kt_grad" "$OUT/kt_grad.log"
 python3 tools/gensys_doubling_rate.py > "$OUT/gensys_doubling_rate.txt" 2>&1
 # models with 65 .. 96 variables (csrc/dsge_big.hpp)
 { for N in 72 80 96; do python3 tools/big_rate.py $N 1024; done; python3 tools/big_phases.py 80; python3 tools/big_phases.py 96; } > "$OUT/big_rate.txt" 2>&1
