@@ -229,6 +229,32 @@ def test_gradient_on_the_56_wide_tile(n, ns, nl):
         _directional_check(A[i], B[i], C[i], D[i], q[i], Z, y, d, h, g, rng, n_dirs=1)
 
 
+@pytest.mark.parametrize("n,ns,nl,jumps,u", [(20, 9, 5, False, 9), (24, 14, 6, False, 14), (40, 18, 12, False, 18), (40, 22, 10, False, 22),
+                                             (40, 18, 12, True, 25), (44, 30, 8, False, 30), (48, 34, 6, False, 34)])
+def test_gradient_across_the_tiles_of_the_reverse_sweep(n, ns, nl, jumps, u):
+    """Every tile count of the reverse sweep's matrix-core products (kg_cov_products_mf: 2 BS - 1 or 2 BS tiles of four by the
+    number u of retained variables: 3, 4 | 5, 6 | 7, 8; the 40-wide tile keeps the register-block products) and both forward sweeps
+    with record output (kalman_mf_kernel for u <= 20 on the 24-wide tile, kalman_nt_kernel otherwise), against central differences of
+    the CPU oracle; the compact Stein equation of the policy adjoints at the same sizes."""
+    rng = np.random.default_rng(n + ns)
+    shape = dict(n=n, n_state=ns, n_lead=nl, k=5, p=7, T_len=40)
+    b = wl.sw_shaped_batch(2, seed0=9100 + n + ns, **shape)
+    observed = tuple(range(ns, ns + 7)) if jumps else None
+    om = wl.sw_shaped_observation_model(seed0=9100 + n + ns, observed=observed, **shape)
+    assert np.count_nonzero((b["A"][0] != 0).any(axis=0) | (om["Z"] != 0).any(axis=0)) == u
+    q = b["sigma"] ** 2
+    y = om["y"].copy()
+    y[7, 1] = np.nan
+    d = rng.normal(0, 0.01, 7)
+    h = om["Hdiag"].copy()
+    out = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], y, d=d, Hdiag=h, tol=1e-13, max_iter=200)
+    assert np.all(out["status"] == 0)
+    for i in range(2):
+        g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
+        assert_allclose(out["logp"][i], _oracle_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h), rtol=1e-9)
+        _directional_check(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h, g, rng, n_dirs=1)
+
+
 def test_gradient_failed_and_unsupported_draws():
     b = wl.sw_shaped_batch(3)
     om = wl.sw_shaped_observation_model()
