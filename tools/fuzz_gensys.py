@@ -50,6 +50,8 @@ def run(seed, trials, verbose=True):
                     print("MISMATCH", dict(n=n, ns=ns, nl=nl, k=k, draw=i), ok_d, succ, out["eu"][i], eu,
                           np.abs(out["T"][i] - Tref).max() if succ and ok_d else None, (int(bk["n_forward"][i]), n_fwd),
                           (int(bk["n_unstable"][i]), n_unst))
+                    if os.environ.get("FUZZ_GENSYS_DUMP"):
+                        np.savez(os.environ["FUZZ_GENSYS_DUMP"], A=A[i], B=B[i], C=C[i], D=D[i], T_dev=out["T"][i], T_oracle=Tref if succ else 0.0)
     if verbose:
         print("trials done, mismatches:", bad)
     return bad
