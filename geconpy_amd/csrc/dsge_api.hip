@@ -28,6 +28,9 @@ static Options defaults_from_environment() {
   Options o{};
   if (const char* e = std::getenv("DSGE_GENSYS_DOUBLING"))
     if ((e[0] >= '0' && e[0] <= '3') && e[1] == '\0') o.gensys_doubling = e[0] - '0';
+  // (A/B switch of the round-6 fused assembly + adjoint launch of the gradient pipeline; not part of dsge_options)
+  if (const char* e = std::getenv("DSGE_GRAD_FUSED_ADJOINT"))
+    if ((e[0] == '0' || e[0] == '1') && e[1] == '\0') o.grad_fused_adjoint = e[0] - '0';
   return o;
 }
 const Options g_defaults = defaults_from_environment();
@@ -1297,6 +1300,14 @@ static int grad_pipeline(const double* A, const double* B, const double* C, cons
                                         missing_fill, u_hint, store, logp_out + c0, stc, Tbar, Gbar,
                                         d_bar ? d_bar + c0 * p : nullptr, h_bar ? h_bar + c0 * p : nullptr, st, gkey, ord_w)))
       return rc;
+    // Round 6: diagonal Q, k <= 16, up to 40 variables: one launch for the reverse of the assembly AND the policy adjoints (they
+    // share the elimination of B + C T; adjoint_kernel<BS, false, true>), the two-kernel path behind it for what it flags
+    if (!qfull && k <= 16 && n <= 40 && opt().grad_fused_adjoint) {
+      if ((rc = launch_adjoint_fused(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, Tbar, nb, n, k, A_bar + c0 * n * n, B_bar + c0 * n * n,
+                                     C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * qstride, stc, st)))
+        return rc;
+      continue;
+    }
     if ((rc = launch_grad_assemble(Bc, Cc, Tw, Rw, qc, q_batched, Gbar, nb, n, k, stc, Tbar, B_bar + c0 * n * n,
                                    C_bar + c0 * n * n, D_bar + c0 * n * k, q_bar + c0 * qstride, st)))
       return rc;

@@ -135,7 +135,10 @@ int launch_dense_z_deaugment(const double* Tbar_a, const double* Gbar_a, const d
                              double* Z_bar, hipStream_t st);
 int launch_status_park(int32_t* status, int32_t* park, int batch, int restore, hipStream_t st);
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
-                   double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate = 0);
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate = 0, int only_flag = 0);
+int launch_adjoint_fused(const double* B, const double* C, const double* T, const double* R, const double* q, int q_batched,
+                         const double* Gbar, double* Tbar, int batch, int n, int k, double* Ab, double* Bb, double* Cb, double* Db,
+                         double* qb, int32_t* status, hipStream_t st);
 int launch_norms(const double* A, const double* B, const double* C, const double* D, const double* T, const double* R,
                  const int32_t* mask, int batch, int n, int k, double* det, double* sto, hipStream_t st);
 int launch_augment(const double* T, const double* R, int batch, int n, int k, int m, const int32_t* inv_var_order,
@@ -174,7 +177,7 @@ size_t kalman_grad_store_doubles_per_draw(int u_hint, int m, int T_len);
 int launch_grad_assemble(const double* B, const double* C, const double* T, const double* R, const double* q,
                          int q_batched, const double* Gbar, int batch, int n, int k, const int32_t* status, double* Tbar,
                          double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st,
-                         const double* Rbar_in = nullptr);  // Rbar_in: pullback of R = -(C T + B)^-1 D alone (Tbar written)
+                         const double* Rbar_in = nullptr, int only_flag = 0);  // Rbar_in: pullback of R = -(C T + B)^-1 D alone (Tbar written)
 int gensys_caps(int n, int n_lead_hint, int* n_cap, int* l_cap);
 // gensys by spectral division with the verdict next to the filter (round 6; launch_gensys.hip::launch_gensys_doubling)
 struct GensysOverlap {
@@ -250,6 +253,7 @@ struct Options {
   int kalman_narrow = 1;       // fast filter: the SK = 20 instance of the 32-wide tile when the state block fits
   int gensys_doubling = 1;     // gensys by spectral division: cycle reduction + certificate, ordered QZ only for uncertified draws (0: QZ for all)
   int kalman_grad_split = 2;   // gradient: forward sweep by a logp kernel with record output, reverse sweep by kalman_grad_kernel<BS, true>; 2: + kalman_grad_tail_kernel
+  int grad_fused_adjoint = 1;  // gradient pipeline: reverse of the assembly + policy adjoints in one launch (internal; DSGE_GRAD_FUSED_ADJOINT=0 switches it off)
   int kalman_head_draws = 0;   // fast filter: this many draws at the head of the dispatch order on the two-wavefront kernel (-1 = all)
   // conventions of the filter step (third party: pymc_extras; include/dsge_hip.h "Filter conventions")
   int ll_constant = DSGE_LL_CONST_P;

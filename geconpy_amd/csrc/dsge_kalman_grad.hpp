@@ -1548,7 +1548,9 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
     const double* __restrict__ R, const double* __restrict__ q, int q_batched, const double* __restrict__ Gbar,
     int batch, int n, int k, const int32_t* __restrict__ status, double* __restrict__ Tbar,
     double* __restrict__ B_bar, double* __restrict__ C_bar, double* __restrict__ D_bar, double* __restrict__ q_bar,
-    const double* __restrict__ Rbar_in = nullptr) {
+    const double* __restrict__ Rbar_in = nullptr, int only_flag = 0) {
+  // only_flag (round 6): behind the fused launch (adjoint_kernel<BS, false, true>) -- only the draws that launch flagged
+  // DSGE_ST_INTERNAL_RERUN are visited (the flag stays for the adjoint pass that follows); everything else is already done
   // Rbar_in != nullptr: the pullback of R = -(C T + B)^-1 D ALONE (pt_compute_selection_matrix, shared.py:74-75) --
   // the cotangent of R arrives directly, nothing is known about Q, and Tbar is WRITTEN (= C' Mbar) instead of accumulated.
   constexpr int NP = GaSmem<BS>::NP, LD = GaSmem<BS>::LD, LDW = GaSmem<BS>::LDW;
@@ -1564,7 +1566,9 @@ __global__ __launch_bounds__(64) void grad_assemble_kernel(
   const int lane = threadIdx.x, lr = lane >> 3, lc = lane & 7;
   for (int draw = blockIdx.x; draw < batch; draw = batch) {  // (one draw per workgroup, grid = batch)
     const size_t off = (size_t)draw * n * n, offk = (size_t)draw * n * k;
-    if (status && status[draw] != 0) {  // failed draw: zero cotangents
+    if (only_flag) {
+      if (!(status[draw] & DSGE_ST_INTERNAL_RERUN)) continue;
+    } else if (status && status[draw] != 0) {  // failed draw: zero cotangents
       double z[BS][BS];
       blk_zero<BS>(z);
       blk_store_global<BS>(z, B_bar + off, n, n, n, lr, lc);

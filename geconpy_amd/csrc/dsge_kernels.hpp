@@ -663,11 +663,25 @@ struct AdjCompact {
   static constexpr bool enabled = BS >= 4;
 };
 
+// The pullback of R = -(B + C T)^-1 D riding on the same elimination (round 6, the gradient pipeline's fused assembly + adjoint launch):
+// with Rbar the cotangent of R,  X = M^-T Rbar  gives  Dbar = -X,  Mbar = -X R'  (the cotangent of M: Bbar += Mbar, Cbar += Mbar T')
+// and a further cotangent  C' Mbar  of T -- which enters the Stein equation through  H = -M^-T (T_bar + C' Mbar) = H_f +
+// Wm (C_L' X) R'  (M^-T C' = Wm C_L'): three thin products, no second factorisation of M.  Rbar rides in the third column group
+// behind E_L (columns nl .. nl + k); X stays there until the caller has formed  Bbar = -X R' + S T',  Cbar = Bbar T'.
+template <int BS>
+struct AdjFuse {
+  const double (*Rbar)[BS];     // register block image of Rbar (n x k, columns >= k zero)
+  const double* R;              // this draw's selection matrix, n x k (global)
+  int k;
+  double* D_bar;                // this draw's output, n x k (global)
+  int x_col;                    // out: column of X inside the third group
+};
+
 template <int BS>
 __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, const double* __restrict__ B,
                                                         const double* __restrict__ C, const double* __restrict__ T, size_t off,
                                                         int n, const double (&Hb)[BS][BS], double (&Sb)[BS][BS], int lane,
-                                                        double& gmax, bool& took, int& t_cols) {
+                                                        double& gmax, bool& took, int& t_cols, AdjFuse<BS>* fz = nullptr) {
   constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
   constexpr int BSC = AdjCompact<BS>::BSC, NPC = AdjCompact<BS>::NPC, LDC = AdjCompact<BS>::LDC;
   constexpr int TK_FREE = NP * LD - NPC;  // the two index lists (2 NPC ints) sit at the end of the NP x LD matrix
@@ -697,11 +711,10 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
   const unsigned long long cmT = __ballot(nzT), cmC = __ballot(nzC);
   const int ns = __popcll(cmT), nl = __popcll(cmC);
   took = ns >= 1 && nl >= 1 && ns <= NPC && nl <= NPC;
+  const int kf = fz ? fz->k : 0, NPK = 8 * ((kf + 7) / 8);  // (fused: R and the thin products take NPK + NPC columns of group 0)
+  if (fz) took = took && kf >= 1 && nl + kf <= NP && NPK + NPC <= NP && kf <= NPC;
   if (!took) return false;
   t_cols = 64 - __clzll((long long)cmT);  // last non-zero column of T + 1
-#ifdef ADJ_STOP
-  if (ADJ_STOP == 1) return true;
-#endif
   {
     double Mb[BS][BS];
     blk_load_global<BS>(Mb, B + off, n, n, n, lr, lc);
@@ -725,11 +738,16 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
   }
   wave_sync();
   if (lane < nl) W[Lidx[lane] * LDW + 2 * NP + lane] = 1.0;  // E_L
+  if (fz) {  // Rbar behind E_L
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j)
+        if (lc * BS + j < kf) W[(lr * BS + i) * LDW + 2 * NP + nl + lc * BS + j] = fz->Rbar[i][j];
+    fz->x_col = nl;
+  }
   gauss_jordan_blocked<BS>(W, LDW, n, 3, Lbuf, Ybuf, prow, lane);
   gj_unpermute<BS>(W, LDW, n, 1, 3, prow, lane);
-#ifdef ADJ_STOP
-  if (ADJ_STOP == 2) return true;
-#endif
   {
     double Zr[BS][BS];
     blk_zero<BS>(Zr);
@@ -757,6 +775,53 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
     Tk[r * LDC + a] = 0.0;
   }
   wave_sync();  // (the zeros of the first column group and H in the second are in place)
+  if (fz) {
+    // ---- Dbar = -X;  H += Wm (C_L' X) R'  through the (zeroed) first column group: R in its columns [0, NPK), the thin factors in
+    //      [NPK, NPK + NPC) ----------------------------------------------------------------------------------------------------
+    const double* Xp = W + 2 * NP + nl;
+    for (int idx = lane; idx < n * kf; idx += 64) {
+      const int r = idx / kf, c = idx - r * kf;
+      fz->D_bar[idx] = -Xp[r * LDW + c];
+    }
+    lane_loop_batched<8>(n * kf, lane, [&](int idx) { return fz->R[idx]; },
+                         [&](int idx, double v) {
+                           const int r = idx / kf, c = idx - r * kf;
+                           W[r * LDW + c] = v;
+                         });
+    double Y1[BSC][BSC];
+    blk_zero<BSC>(Y1);
+    mm_acc_ta<BSC>(Y1, Tk, LDC, Xp, LDW, n, lr, lc);  // C_L' X  (nl x k)
+#pragma unroll
+    for (int i = 0; i < BSC; ++i)
+#pragma unroll
+      for (int j = 0; j < BSC; ++j) W[(lr * BSC + i) * LDW + NPK + lc * BSC + j] = (lr * BSC + i < nl && lc * BSC + j < kf) ? Y1[i][j] : 0.0;
+    wave_sync();
+    double Y2[BS][BS];
+    blk_zero<BS>(Y2);
+    mm_acc<BS, false>(Y2, W + 2 * NP, LDW, W + NPK, LDW, nl, lr, lc);  // Wm (C_L' X)  (n x k; columns beyond k: whatever follows)
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j)
+        if (lc * BS + j < NPC) W[(lr * BS + i) * LDW + NPK + lc * BS + j] = (lc * BS + j < kf) ? Y2[i][j] : 0.0;
+    wave_sync();
+    double Hc[BS][BS];
+    blk_zero<BS>(Hc);
+    mm_acc<BS, true>(Hc, W + NPK, LDW, W, LDW, kf, lr, lc);  // (Wm C_L' X) R'
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) Sb[i][j] += Hc[i][j];
+    wave_sync();
+    blk_store_lds<BS>(Sb, W + NP, LDW, lr, lc);
+    {
+      double Zr[BS][BS];
+      blk_zero<BS>(Zr);
+      blk_store_lds<BS>(Zr, W, LDW, lr, lc);  // the first column group back to zero
+    }
+    wave_sync();
+  }
   for (int idx = lane; idx < n * ns; idx += 64) {
     const int r = idx / ns, b = idx - r * ns;
     W[r * LDW + b] = W[r * LDW + NP + Sidx[b]];
@@ -797,9 +862,6 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
                          Fs[i * LDC + j] = v;
                        });
   wave_sync();
-#ifdef ADJ_STOP
-  if (ADJ_STOP == 3) return true;
-#endif
   bool ok = false;
   for (int it = 0; it < LYAP_MAX_DOUBLINGS; ++it) {
     {
@@ -834,9 +896,6 @@ __device__ __forceinline__ bool adj_stein_solve_compact(double* W, double* Tk, c
     }
     gmax = fmax(gmax, blk_maxabs<BSC>(G2));
   }
-#ifdef ADJ_STOP
-  if (ADJ_STOP == 4) return true;
-#endif
   // S = H - (Wm Zs) T[:, St]'
   {
     double Ub[BS][BS];
@@ -1000,13 +1059,30 @@ __device__ __forceinline__ bool adj_stein_fixed_point(double* W, double* Tk, dou
 // spills into; measuring the residual in the first pass cost it 30 % (1.05 -> 1.37 ms per 4096 draws).
 constexpr double ADJ_REFINE_GROWTH = 150.0;  // (error <~ 5e-14 x growth^2: 1e-9 at ~140; 3..6 % of the SW-shaped draws are above 100)
 
-template <int BS, bool REFINE>
+// FUSED = true (round 6; the gradient pipeline, diagonal Q): the reverse of the state-space assembly (grad_assemble_kernel's job: the
+// pullback of sym(R Q R') and of R = -(B + C T)^-1 D) rides on this kernel's elimination -- see AdjFuse -- and the launch writes all
+// of A_bar, B_bar, C_bar, D_bar, q_bar; T_bar is the filter's cotangent alone and is not written.  A draw the compact solve cannot
+// take, or whose solve asks for refinement, is left untouched and flagged DSGE_ST_INTERNAL_RERUN for the two-kernel path
+// (grad_assemble_kernel and this kernel with only_flag = 1, which visit the flagged draws only); failed draws get zero cotangents.
+struct AdjFuseArgs {
+  const double* R = nullptr;
+  const double* q = nullptr;
+  int q_batched = 0;
+  const double* Gbar = nullptr;
+  int k = 0;
+  double* D_bar = nullptr;
+  double* q_bar = nullptr;
+};
+
+template <int BS, bool REFINE, bool FUSED = false>
 __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS = 3: 258 registers without the bound)
     const double* __restrict__ B, const double* __restrict__ C,
                                                       const double* __restrict__ T, const double* __restrict__ T_bar,
                                                       int batch, int n, double* __restrict__ A_bar,
                                                       double* __restrict__ B_bar, double* __restrict__ C_bar,
-                                                      int32_t* __restrict__ status, int accumulate, int refine_mode) {
+                                                      int32_t* __restrict__ status, int accumulate, int refine_mode,
+                                                      int only_flag = 0, AdjFuseArgs fa = AdjFuseArgs()) {
+  static_assert(!(REFINE && FUSED), "the refinement pass belongs to the two-kernel path");
   constexpr int NP = AdjSmem<BS>::NP, LD = AdjSmem<BS>::LD, LDW = AdjSmem<BS>::LDW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* W = smem;             // [M' | T_bar | C'] -> [. | M^-T T_bar | M^-T C'];  later [W1 | S | G_k]
@@ -1060,7 +1136,93 @@ __global__ __launch_bounds__(64, (BS <= 3 ? 2 : 1)) void adjoint_kernel(  // (BS
         ok = adj_stein_solve<BS>(W, Tk, B, C, T, off, n, Rr, Sb, lane, gmax);  // the correction dS (also in W's second group)
       else  // the first pass broke down or is far off: no power of G can be trusted
         ok = adj_stein_fixed_point<BS>(W, Tk, smem + AdjSmem<BS>::bytes / sizeof(double), B, C, T, T_bar, A_bar, off, n, Sb, lane);
+    } else if constexpr (FUSED) {
+      const int k = fa.k;
+      const size_t offk = (size_t)draw * n * k;
+      if (status[draw] != 0) {  // failed draw: zero cotangents
+        double z[BS][BS];
+        blk_zero<BS>(z);
+        blk_store_global<BS>(z, A_bar + off, n, n, n, lr, lc);
+        blk_store_global<BS>(z, B_bar + off, n, n, n, lr, lc);
+        blk_store_global<BS>(z, C_bar + off, n, n, n, lr, lc);
+        blk_store_global<BS>(z, fa.D_bar + offk, n, k, k, lr, lc);
+        if (fa.q_bar && lane < k) fa.q_bar[(size_t)draw * k + lane] = 0.0;
+        continue;
+      }
+      // ---- GR = Gbar R;  Rbar = 2 GR diag(q);  qbar_j = sum_i R_ij GR_ij  (grad_assemble_kernel's expressions; W is free) ----
+      double Rbar[BS][BS];
+      {
+        wave_sync();
+        lds_load_matrix(W, LDW, NP, NP, fa.Gbar + off, n, n, lane);
+        lds_load_matrix(W + NP, LDW, NP, NP, fa.R + offk, n, k, lane);
+        wave_sync();
+        bool nzG = false;
+        if (lane < n)
+          for (int r = 0; r < n; ++r) nzG = nzG | (W[r * LDW + lane] != 0.0);
+        const unsigned long long cmG = __ballot(nzG);
+        const int g_lo = cmG ? __ffsll((long long)cmG) - 1 : 0, g_hi = cmG ? 64 - __clzll((long long)cmG) : 0;
+        double GR[BS][BS], Rb[BS][BS];
+        blk_zero<BS>(GR);
+        mm_acc<BS, false>(GR, W + g_lo, LDW, W + NP + g_lo * LDW, LDW, g_hi - g_lo, lr, lc);
+        blk_load_lds<BS>(Rb, W + NP, LDW, lr, lc);
+        const double* qd = fa.q + (fa.q_batched ? (size_t)draw * k : 0);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int c = lc * BS + j;
+          const double qj = (c < k) ? qd[c] : 0.0;
+          double colsum = 0.0;
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            Rbar[i][j] = 2.0 * GR[i][j] * qj;
+            colsum = fma(Rb[i][j], GR[i][j], colsum);
+          }
+          colsum += shfl_xor_f64(colsum, 8);
+          colsum += shfl_xor_f64(colsum, 16);
+          colsum += shfl_xor_f64(colsum, 32);
+          if (lr == 0 && c < k) fa.q_bar[(size_t)draw * k + c] = colsum;
+        }
+      }
+      double Hb[BS][BS];
+      blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);
+      bool took = false;
+      AdjFuse<BS> fz{Rbar, fa.R + offk, k, fa.D_bar + offk, 0};
+      if constexpr (AdjCompact<BS>::enabled) ok = adj_stein_solve_compact<BS>(W, Tk, B, C, T, off, n, Hb, Sb, lane, gmax, took, kt_cols, &fz);
+      if (!took || !ok || gmax > ADJ_REFINE_GROWTH || refine_mode == 1) {  // (wave-uniform) the two-kernel path takes this draw
+        if (lane == 0) status[draw] |= DSGE_ST_INTERNAL_RERUN;
+        continue;
+      }
+      // ---- A_bar = S;  B_bar = -X R' + S T';  C_bar = B_bar T' ------------------------------------------------------------------
+      blk_store_global<BS>(Sb, A_bar + off, n, n, n, lr, lc);
+      wave_sync();
+      lds_load_matrix(Tk, LD, NP, 8 * ((k + 7) / 8), fa.R + offk, n, k, lane);
+      wave_sync();
+      double Bb[BS][BS], Cb[BS][BS];
+      blk_zero<BS>(Bb);
+      mm_acc<BS, true>(Bb, W + 2 * NP + fz.x_col, LDW, Tk, LD, k, lr, lc);  // X R'
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) Bb[i][j] = -Bb[i][j];
+      wave_sync();  // (X has been consumed by every lane: T takes the third column group)
+      lds_load_matrix(Ts, LDW, NP, NP, T + off, n, n, lane);
+      wave_sync();
+      const int kt_f = (kt_cols > 0 && kt_cols <= n) ? kt_cols : n;
+      mm_acc<BS, true>(Bb, W + NP, LDW, Ts, LDW, kt_f, lr, lc);  // + S T'
+      blk_store_global<BS>(Bb, B_bar + off, n, n, n, lr, lc);
+      blk_store_lds<BS>(Bb, W, LDW, lr, lc);
+      wave_sync();
+      blk_zero<BS>(Cb);
+      mm_acc<BS, true>(Cb, W, LDW, Ts, LDW, kt_f, lr, lc);  // B_bar T'
+      blk_store_global<BS>(Cb, C_bar + off, n, n, n, lr, lc);
+      continue;
     } else {
+      if (BS <= 5 && only_flag) {  // (the second half of the two-kernel path behind a fused launch: the draws that launch left; the
+                                   //  fused launch is used up to 40 variables)
+        if (!(status[draw] & DSGE_ST_INTERNAL_RERUN)) continue;
+        wave_sync();
+        if (lane == 0) status[draw] &= ~DSGE_ST_INTERNAL_RERUN;
+        wave_sync();
+      }
       double Hb[BS][BS];
       blk_load_global<BS>(Hb, T_bar + off, n, n, n, lr, lc);
       bool took = false;

@@ -1,4 +1,5 @@
 // Launchers of the assembly kernels: selection matrix / residual / Lyapunov, policy adjoints, gEcon norms.
+#include <cstdlib>
 #include "dsge_host.hpp"
 #include "dsge_kernels.hpp"
 #include "dsge_acf.hpp"
@@ -39,8 +40,36 @@ int launch_rqr(const double* R, const double* q, int q_batched, int batch, int n
 
 int g_adj_refine_mode = 0;
 
+// The gradient pipeline's fused launch (adjoint_kernel<BS, false, true>: reverse of the assembly + policy adjoints on one elimination)
+// followed by the two-kernel path over the draws it flagged -- normally none: two launches that find nothing to do.
+int launch_adjoint_fused(const double* B, const double* C, const double* T, const double* R, const double* q, int q_batched,
+                         const double* Gbar, double* Tbar, int batch, int n, int k, double* Ab, double* Bb, double* Cb, double* Db,
+                         double* qb, int32_t* status, hipStream_t st) {
+  const int bs = tile_bs(n);
+  int rc = DSGE_ERR_INVALID;
+  DISPATCH_BS(bs, 7, {
+    rc = set_lds(dsge::adjoint_kernel<BS, false, true>, dsge::AdjSmem<BS>::bytes);
+    if (rc == DSGE_SUCCESS) {
+      dsge::AdjFuseArgs fa;
+      fa.R = R;
+      fa.q = q;
+      fa.q_batched = q_batched;
+      fa.Gbar = Gbar;
+      fa.k = k;
+      fa.D_bar = Db;
+      fa.q_bar = qb;
+      hipLaunchKernelGGL((dsge::adjoint_kernel<BS, false, true>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T,
+                         (const double*)Tbar, batch, n, Ab, Bb, Cb, status, 0, g_adj_refine_mode, 0, fa);
+      HIP_TRY(hipGetLastError());
+    }
+  });
+  if (rc != DSGE_SUCCESS) return rc;
+  if ((rc = launch_grad_assemble(B, C, T, R, q, q_batched, Gbar, batch, n, k, status, Tbar, Bb, Cb, Db, qb, st, nullptr, 1))) return rc;
+  return launch_adjoint(B, C, T, Tbar, batch, n, Ab, Bb, Cb, status, st, 1, 1);
+}
+
 int launch_adjoint(const double* B, const double* C, const double* T, const double* Tbar, int batch, int n, double* Ab,
-                   double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate) {
+                   double* Bb, double* Cb, int32_t* status, hipStream_t st, int accumulate, int only_flag) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 7, {
@@ -48,12 +77,12 @@ int launch_adjoint(const double* B, const double* C, const double* T, const doub
     if (rc == DSGE_SUCCESS) rc = set_lds(dsge::adjoint_kernel<BS, true>, dsge::AdjSmem<BS>::bytes_refine);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL((dsge::adjoint_kernel<BS, false>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes, st, B, C, T, Tbar,
-                         batch, n, Ab, Bb, Cb, status, accumulate, g_adj_refine_mode);
+                         batch, n, Ab, Bb, Cb, status, accumulate, g_adj_refine_mode, only_flag, dsge::AdjFuseArgs());
       HIP_TRY(hipGetLastError());
       // second pass: one step of iterative refinement for the draws whose Stein residual the first pass flagged (normally none)
       // (one workgroup per draw: a flagged draw costs a whole solve, two of them behind each other in one workgroup twice that)
       hipLaunchKernelGGL((dsge::adjoint_kernel<BS, true>), dim3(batch), dim3(64), dsge::AdjSmem<BS>::bytes_refine, st, B, C,
-                         T, Tbar, batch, n, Ab, Bb, Cb, status, 1, 0);
+                         T, Tbar, batch, n, Ab, Bb, Cb, status, 1, 0, 0, dsge::AdjFuseArgs());
       HIP_TRY(hipGetLastError());
     }
   });

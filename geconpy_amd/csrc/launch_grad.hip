@@ -108,14 +108,15 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
 
 int launch_grad_assemble(const double* B, const double* C, const double* T, const double* R, const double* q,
                          int q_batched, const double* Gbar, int batch, int n, int k, const int32_t* status, double* Tbar,
-                         double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st, const double* Rbar_in) {
+                         double* B_bar, double* C_bar, double* D_bar, double* q_bar, hipStream_t st, const double* Rbar_in,
+                         int only_flag) {
   const int bs = tile_bs(n);
   int rc = DSGE_ERR_INVALID;
   DISPATCH_BS(bs, 7, {
     rc = set_lds(dsge::grad_assemble_kernel<BS>, dsge::GaSmem<BS>::bytes);
     if (rc == DSGE_SUCCESS) {
       hipLaunchKernelGGL(dsge::grad_assemble_kernel<BS>, dim3(batch), dim3(64), dsge::GaSmem<BS>::bytes, st, B, C, T, R, q,
-                         q_batched, Gbar, batch, n, k, status, Tbar, B_bar, C_bar, D_bar, q_bar, Rbar_in);
+                         q_batched, Gbar, batch, n, k, status, Tbar, B_bar, C_bar, D_bar, q_bar, Rbar_in, only_flag);
       HIP_TRY(hipGetLastError());
     }
   });

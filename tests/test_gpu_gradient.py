@@ -230,7 +230,10 @@ def test_gradient_on_the_56_wide_tile(n, ns, nl):
 
 
 @pytest.mark.parametrize("n,ns,nl,jumps,u", [(20, 9, 5, False, 9), (24, 14, 6, False, 14), (40, 18, 12, False, 18), (40, 22, 10, False, 22),
-                                             (40, 18, 12, True, 25), (44, 30, 8, False, 30), (48, 34, 6, False, 34)])
+                                             (40, 18, 12, True, 25), (44, 30, 8, False, 30), (48, 34, 6, False, 34),
+                                             # more states than the compact Stein tile holds: the fused assembly + adjoint launch hands
+                                             # these draws to the two-kernel path (24 of 40, 16 of 32)
+                                             (40, 26, 10, False, 26), (30, 20, 6, False, 20)])
 def test_gradient_across_the_tiles_of_the_reverse_sweep(n, ns, nl, jumps, u):
     """Every tile count of the reverse sweep's matrix-core products (kg_cov_products_mf: 2 BS - 1 or 2 BS tiles of four by the
     number u of retained variables: 3, 4 | 5, 6 | 7, 8; the 40-wide tile keeps the register-block products) and both forward sweeps
@@ -253,6 +256,29 @@ def test_gradient_across_the_tiles_of_the_reverse_sweep(n, ns, nl, jumps, u):
         g = {k_: v[i] for k_, v in out.items() if k_.endswith("_bar")}
         assert_allclose(out["logp"][i], _oracle_logp(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h), rtol=1e-9)
         _directional_check(b["A"][i], b["B"][i], b["C"][i], b["D"][i], q[i], om["Z"], y, d, h, g, rng, n_dirs=1)
+
+
+def test_gradient_fused_adjoint_launch_matches_the_two_kernel_path():
+    """Round 6: the gradient pipeline's last launch is the reverse of the assembly AND the policy adjoints on one elimination of
+    B + C T (adjoint_kernel<BS, false, true>).  Forcing the refinement rule on every draw (debug mode 1) makes that launch hand every
+    draw to the two-kernel path (grad_assemble_kernel + adjoint_kernel with only_flag, then the refinement pass): same cotangents."""
+    lib = _lib.load()
+    b = wl.sw_shaped_batch(96)
+    om = wl.sw_shaped_observation_model()
+    q = b["sigma"] ** 2
+    kw = dict(Hdiag=om["Hdiag"], tol=1e-10, max_iter=1000)
+    fused = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"][:60], **kw)
+    try:
+        _lib.check(lib.dsge_debug_adjoint_refine(1))
+        two = batched.solve_kalman_logp_grad_batched(b["A"], b["B"], b["C"], b["D"], q, om["Z"], om["y"][:60], **kw)
+    finally:
+        _lib.check(lib.dsge_debug_adjoint_refine(0))
+    assert not fused["status"].any() and not two["status"].any()
+    assert np.array_equal(fused["logp"], two["logp"])
+    for key in ("A_bar", "B_bar", "C_bar", "D_bar", "q_bar"):
+        sc = np.abs(two[key]).reshape(96, -1).max(axis=1)
+        er = np.abs(fused[key] - two[key]).reshape(96, -1).max(axis=1) / np.maximum(sc, 1e-300)
+        assert er.max() <= 1e-8 and np.median(er) <= 1e-11, (key, float(er.max()), int(er.argmax()))
 
 
 def test_gradient_failed_and_unsupported_draws():
