@@ -60,6 +60,9 @@ __device__ __forceinline__ double kg_dot4(const double* a, int sa, const double*
 #ifndef KG_MFMA_PRODUCTS
 #define KG_MFMA_PRODUCTS 1
 #endif
+#ifndef KG_TAIL_WAVES
+#define KG_TAIL_WAVES 2
+#endif
 
 template <int BS>
 struct KgSmem {
@@ -1302,7 +1305,7 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
 // abar, dbar and the accumulators (Tbar, Kacc, Qacc, nlam) to the reverse sweep, which resumes AT the source step.
 // Same arithmetic as the steady_step of the reverse sweep, operation by operation.
 template <int BS>
-__global__ __launch_bounds__(64, 2) void kalman_grad_tail_kernel(
+__global__ __launch_bounds__(64, KG_TAIL_WAVES) void kalman_grad_tail_kernel(
     const double* __restrict__ T, const double* __restrict__ Z, int z_batched, const double* __restrict__ dvec, int d_batched,
     const double* __restrict__ y, int batch, int m_full, int p, int T_len, FilterConv cv, double missing_fill,
     double* __restrict__ store, const int32_t* __restrict__ status, const int32_t* __restrict__ order) {
