@@ -855,9 +855,10 @@ def main():
             go = g_out[0]
             extras["gradient"] = {"value": round(nloc / dt_gr, 2), "ms_per_step": round(dt_gr * 1e3, 4), "unit": "logp+gradient evals/s",
                                   "note": "dsge_solve_kalman_logp_grad_batched on the same 4096 draws: logp and its cotangents with respect "
-                                          "to A, B, C, D, q (policy-function adjoints by doubling on the compact nl x ns Stein equation; forward filter "
-                                          "sweep = the tile-layout logp kernel with record output, reverse sweep with its products on the "
-                                          "FP64 matrix core)",
+                                          "to A, B, C, D, q (policy-function adjoints by doubling on the compact nl x ns Stein equation, the reverse "
+                                          "of the state-space assembly on the same elimination of B + C T; forward filter sweep = the "
+                                          "tile-layout logp kernel with record output, reverse sweep with its products on the FP64 matrix "
+                                          "core)",
                                   "failed_draws": int((go["status"] != 0).sum().item()),
                                   "max_rel_logp_diff_vs_headline": float((torch.abs(go["logp"] - logp_all[lo:hi]) /
                                                                           torch.abs(go["logp"])).max().item())}

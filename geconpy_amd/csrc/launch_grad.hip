@@ -1,4 +1,5 @@
 // Launchers of the gradient kernels: Kalman reverse sweep and the reverse of the state-space assembly.
+#include <cstdlib>
 #include "dsge_host.hpp"
 #include "dsge_kalman_grad.hpp"
 #include "dsge_kalman_mf.hpp"
@@ -43,7 +44,10 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
     // forward kernel cannot take (it flags DSGE_ST_INTERNAL_RERUN) goes through the one-kernel path afterwards, in the same call.
     // Not under the phase-stamp hook (tools/grad_phases.py reads the one-kernel path's stamps).
     const size_t lds_f = dsge::KntSmem<BS, 8 * BS>::bytes(8 * BS);
-    const bool split = opt().kalman_grad_split != 0 && !g_kalman_dbg && p <= 8 && lds_f <= LDS_LIMIT;
+    // (under the phase-stamp hook the split path runs too when DSGE_DBG_SPLIT_PHASES is set: the reverse sweep's stamps of draw 0 then
+    //  come from kalman_grad_kernel<BS, true>; tools/grad_phases.py reads the one-kernel path's stamps otherwise)
+    static const bool dbg_split = std::getenv("DSGE_DBG_SPLIT_PHASES") != nullptr;
+    const bool split = opt().kalman_grad_split != 0 && (!g_kalman_dbg || dbg_split) && p <= 8 && lds_f <= LDS_LIMIT;
     if (split) {
       rc = set_lds(dsge::kalman_nt_kernel<BS, false, 8 * BS, false, true>, lds_f);
       if (rc == DSGE_SUCCESS) rc = set_lds(dsge::kalman_grad_kernel<BS, true>, lds);
@@ -87,7 +91,7 @@ int launch_kalman_grad(const double* T, const double* RQR, const double* Z, int 
                              batch, m, p, T_len, cv, missing_fill, store, (const int32_t*)status, order);
         hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, true>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d, d_batched,
                            Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar, dbar,
-                           hbar, (long long*)nullptr, order, 0, with_tail);
+                           hbar, g_kalman_dbg, order, 0, with_tail);
         hipLaunchKernelGGL((dsge::kalman_grad_kernel<BS, false>), dim3(batch), dim3(64), lds, st, T, RQR, Z, z_batched, d,
                            d_batched, Hdiag, h_batched, y, batch, m, p, T_len, cv, missing_fill, stol, store, logp, status, Tbar, Gbar,
                            dbar, hbar, (long long*)nullptr, (const int32_t*)nullptr, 1, 0);
