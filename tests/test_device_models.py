@@ -11,7 +11,8 @@ from numpy.testing import assert_allclose
 import oracle
 from geconpy_amd import workloads as wl
 from tests.device_models.gensys_qz_model import gensys_device_model, jacobi_svd, lartg
-from tests.device_models.adjoint_compact_model import compact_doubling, full_doubling, kronecker_solve
+from tests.device_models.adjoint_compact_model import (compact_doubling, full_doubling, fused_pullback, kronecker_solve,
+                                                       two_step_pullback)
 from tests.device_models.kalman_model import kalman_downdate_logp
 from tests.device_models.kalman_tile_model import kalman_tile_logp, retained_variables
 
@@ -490,3 +491,22 @@ def test_compact_adjoint_stein_equation_against_the_kronecker_solve():
                 S_f, growth_f = full_doubling(M, C, T, T_bar)
                 worst_full = max(worst_full, np.abs(S_f - S_ref).max() / np.abs(S_ref).max())
     assert worst_full < 1e-7
+
+
+def test_fused_assembly_and_adjoint_algebra():
+    """The gradient pipeline's fused launch: the pullback of R = -(B + C T)^-1 D on the elimination the policy adjoints need anyway
+    (one factorisation of B + C T instead of two) gives the cotangents of the reference's two steps."""
+    rng = np.random.default_rng(5)
+    b = wl.sw_shaped_batch(6)
+    for i in range(6):
+        A, B, C, D = (b[k][i] for k in "ABCD")
+        T = oracle.solve_policy_function_with_cycle_reduction(A, B, C, D, max_iter=1000, tol=1e-12)[0]
+        R = oracle.compute_selection_matrix(B, C, D, T)
+        n = T.shape[0]
+        T_bar = rng.standard_normal((n, n))
+        T_bar[:, np.all(T == 0, axis=0)] = 0.0
+        R_bar = rng.standard_normal(R.shape)
+        ref = two_step_pullback(B, C, T, R, R_bar, T_bar)
+        fus = fused_pullback(B, C, T, R, R_bar, T_bar)
+        for key in ref:
+            assert np.abs(fus[key] - ref[key]).max() <= 1e-10 * np.abs(ref[key]).max(), key
