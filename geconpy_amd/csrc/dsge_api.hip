@@ -130,6 +130,7 @@ struct OptionsGuard {
   const Options* prev;
   explicit OptionsGuard(const dsge_options* o) : prev(t_call_options) {
     if (!o) return;
+    local.grad_fused_adjoint = g_defaults.grad_fused_adjoint;  // (an internal switch, not in dsge_options: the process-level value)
     local.cr_compact = o->cr_compact;
     local.cr_fused_selection = o->cr_fused_selection;
     local.cr_deflation = o->cr_deflation;
