@@ -137,6 +137,48 @@ __device__ __forceinline__ void kg_cov_products_mf(double* __restrict__ Pb, cons
 // (Measured, round 5: capping the SPLIT instance at 256 registers for a second wavefront per SIMD -- it holds 308 -- spills 52
 // dwords into the mean-side loop: the reverse launch 3.0 -> 4.5 ms at unchanged residency; LDS, 36.6 KB, would have to shrink
 // below 27 KB as well before a second wavefront fits.)
+// One doubling step of  S = dlyap(A', Pbar_0)  on the matrix core (round 6):  S += A' (S A)  on the upper tiles with the mirror image,
+// A <- A A.  S in Pb (symmetric), A in X1, X2 scratch; everything outside u x u is and stays zero.  Returns max |increment|, max |S|.
+template <int BS, int TMU>
+__device__ __forceinline__ void kg_dlyap_step_mf(double* __restrict__ Pb, double* __restrict__ X1, double* __restrict__ X2, int u,
+                                                 int lane, double& dmax, double& smax) {
+  constexpr int NP = Tile<BS>::NP, LDM = Tile<BS>::LD, DUMP = (NP - 1) * LDM + LDM - 1;
+  using MP = Mfma4Map<TMU, TMU>;
+  using UX = Mfma4Upper<TMU>;
+  const int blk = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  double a2r[MP::NG];
+  mfma4_strided<TMU, TMU, TMU, LDM, 1, LDM, 1>(Pb, X1, lane, [&](int g, double d) {  // S A
+    const int at = (4 * MP::ta(g, blk) + kq) * LDM + 4 * MP::tb(g, blk) + i4;
+    X2[MP::live(g, blk) ? at : DUMP] = d;
+  });
+  mfma4_strided<TMU, TMU, TMU, LDM, 1, LDM, 1>(X1, X1, lane, [&](int g, double d) { a2r[g] = d; });  // A A
+  wave_sync();
+  int rowa[UX::NG], rowb[UX::NG];
+  mfma4_upper_rows<TMU>(lane, rowa, rowb);
+  double dm = 0.0, sm = 0.0;
+  mfma4_strided_upper<TMU, TMU, 1, LDM, LDM, 1>(X1, X2, lane, rowa, rowb, [&](int g, double d) {  // A' (S A), upper tiles
+    const int r = rowa[g] - i4 + kq, c = rowb[g];
+    int ta, tb;
+    bool live;
+    UX::tile(g, blk, ta, tb, live);
+    const bool own = live && r <= c && c < u;
+    const double nv = Pb[own ? r * LDM + c : DUMP] + d;
+    Pb[own ? r * LDM + c : DUMP] = own ? nv : 0.0;
+    Pb[own ? c * LDM + r : DUMP] = own ? nv : 0.0;
+    dm = nanmax(dm, own ? fabs(d) : 0.0);
+    sm = nanmax(sm, own ? fabs(nv) : 0.0);
+  });
+  wave_sync();
+#pragma unroll
+  for (int g = 0; g < MP::NG; ++g) {
+    const int at = (4 * MP::ta(g, blk) + kq) * LDM + 4 * MP::tb(g, blk) + i4;
+    X1[MP::live(g, blk) ? at : DUMP] = a2r[g];
+  }
+  dmax = wave_nanmax(dm);
+  smax = wave_nanmax(sm);
+  wave_sync();
+}
+
 // SPLIT = true (round 5): the reverse sweep ALONE -- the forward sweep ran as kalman_nt_kernel<BS, .., REC = true>
 // (dsge_kalman_nt.hpp: the logp kernel's full step at two wavefronts per SIMD instead of this kernel's at one), which wrote the
 // records (dsge_kalman_rec.hpp), logp and the status words.  rerun_only (SPLIT = false): only the draws that launch flagged
@@ -1233,6 +1275,15 @@ __global__ __launch_bounds__(64) void kalman_grad_kernel(
     for (int idx = lane; idx < NP * LDM; idx += 64) X1[idx] = Tc[idx];
     wave_sync();
     for (int itl = 0; itl < 64; ++itl) {
+      if constexpr (KG_MF) {
+        double dmax, smax;
+        if (u <= 4 * (2 * BS - 1))
+          kg_dlyap_step_mf<BS, 2 * BS - 1>(Pb, X1, X2, u, lane, dmax, smax);
+        else
+          kg_dlyap_step_mf<BS, 2 * BS>(Pb, X1, X2, u, lane, dmax, smax);
+        if (!(dmax == dmax) || dmax <= 1e-17 * smax || smax == 0.0) break;
+        continue;
+      }
       kg_mm<BS, false>(X2, Pb, X1, u, 1.0, false, lr, lc);  // S A
       wave_sync();
       double inc[BS][BS], a2[BS][BS];
